@@ -1,0 +1,386 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Drives the GENUINE reference (control_box_rst, compiled from /root/reference by oracle/Makefile into
+// oracle/_ref/libcorbo_ref.a) through its public C++ setters, exactly the way SURVEY.md 8(c) describes:
+//   grid + dynamics + HyperGraphOptimizationProblemEdgeBased + LevenbergMarquardtSparse
+//   -> StructuredOptimalControlProblem::compute()  (structured_optimal_control_problem.cpp:77-154)
+// It is this repo's own code (no reference source is copied); it only *calls* the reference.
+//
+// Modes
+//   ref_driver dump  scenario=<name> [N=..] [iters=..] [x0=a,b,..] [xf=a,b,..] [solves=..]
+//        -> JSON on stdout: dimensions, initial parameter vector, values and Jacobian triplets at the initial
+//           point (hot-path rows a2-a6 of SURVEY 8a), and the vertex trajectory + chi2 after k = 1..iters LM
+//           iterations (each obtained by a fresh OCP run with setIterations(k); pins row a1).
+//   ref_driver bench scenario=<name> batch=<B> [seed=..] [iters=..]
+//        -> solves B seeded instances sequentially on one core, prints JSON with solver wall time
+//           (OptimalControlProblemStatistics::solving_time, i.e. only levenberg_marquardt_sparse.cpp:44-220).
+//
+// Scenarios: unicycle (cfg 3), vdp (cfg 1), dint (cfg 2: time-optimal double integrator).
+#include <corbo-core/reference_trajectory.h>
+#include <corbo-core/time.h>
+#include <corbo-numerics/finite_differences_collocation.h>
+#include <corbo-optimal-control/functions/final_state_cost.h>
+#include <corbo-optimal-control/functions/minimum_time.h>
+#include <corbo-optimal-control/functions/quadratic_cost.h>
+#include <corbo-optimal-control/statistics.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_variable_grid.h>
+#include <corbo-optimal-control/structured_ocp/structured_optimal_control_problem.h>
+#include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_edge_based.h>
+#include <corbo-optimization/solver/levenberg_marquardt_sparse.h>
+#include <corbo-systems/benchmark/linear_benchmark_systems.h>
+#include <corbo-systems/benchmark/nonlinear_benchmark_systems.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace corbo;
+
+// Unicycle (not part of the reference; a user plug-in through SystemDynamicsInterface):
+//   xdot = u1 cos(theta), ydot = u1 sin(theta), thetadot = u2
+class UnicycleRef : public SystemDynamicsInterface
+{
+ public:
+    Ptr getInstance() const override { return std::make_shared<UnicycleRef>(); }
+    bool isContinuousTime() const override { return true; }
+    bool isLinear() const override { return false; }
+    int getInputDimension() const override { return 2; }
+    int getStateDimension() const override { return 3; }
+    void dynamics(const Eigen::Ref<const StateVector>& x, const Eigen::Ref<const ControlVector>& u, Eigen::Ref<StateVector> f) const override
+    {
+        f[0] = u[0] * std::cos(x[2]);
+        f[1] = u[0] * std::sin(x[2]);
+        f[2] = u[1];
+    }
+};
+
+struct Scenario
+{
+    std::string name;
+    int nx = 0, nu = 0, N = 0;
+    double dt = 0.1;
+    int iters  = 10;
+    int solves = 1;  // consecutive compute() calls (new_run only for the first one)
+    double w_eq = 2, w_ineq = 2, w_b = 2;
+    Eigen::VectorXd x0, xf;
+    std::string collocation = "crank_nicolson";
+};
+
+struct Built
+{
+    std::shared_ptr<FiniteDifferencesGrid> grid;
+    std::shared_ptr<HyperGraphOptimizationProblemEdgeBased> hg;
+    std::shared_ptr<LevenbergMarquardtSparse> solver;
+    std::shared_ptr<StructuredOptimalControlProblem> ocp;
+    std::shared_ptr<OptimalControlProblemStatistics> stats;
+    std::shared_ptr<StaticReference> xref;
+    std::shared_ptr<ZeroReference> uref;
+};
+
+static FiniteDifferencesCollocationInterface::Ptr makeCollocation(const std::string& n)
+{
+    if (n == "forward") return std::make_shared<ForwardDiffCollocation>();
+    if (n == "backward") return std::make_shared<BackwardDiffCollocation>();
+    if (n == "midpoint") return std::make_shared<MidpointDiffCollocation>();
+    return std::make_shared<CrankNicolsonDiffCollocation>();
+}
+
+static Built build(const Scenario& s, int iterations)
+{
+    Built b;
+    SystemDynamicsInterface::Ptr dyn;
+    b.hg     = std::make_shared<HyperGraphOptimizationProblemEdgeBased>();
+    b.solver = std::make_shared<LevenbergMarquardtSparse>();
+    b.solver->setIterations(iterations);
+    b.solver->setPenaltyWeights(s.w_eq, s.w_ineq, s.w_b);
+    b.stats = std::make_shared<OptimalControlProblemStatistics>();
+
+    if (s.name == "unicycle")
+    {
+        dyn    = std::make_shared<UnicycleRef>();
+        b.grid = std::make_shared<FiniteDifferencesGrid>();
+    }
+    else if (s.name == "vdp")
+    {
+        dyn    = std::make_shared<VanDerPolOscillator>();
+        b.grid = std::make_shared<FiniteDifferencesGrid>();
+    }
+    else if (s.name == "dint")
+    {
+        dyn       = std::make_shared<SerialIntegratorSystem>(2);
+        auto grid = std::make_shared<FiniteDifferencesVariableGrid>();
+        grid->setDtBounds(0.01, 10.0);
+        Eigen::Matrix<bool, -1, 1> fixed(2);
+        fixed.setConstant(true);
+        grid->setXfFixed(fixed);
+        b.grid = grid;
+    }
+    else
+    {
+        fprintf(stderr, "unknown scenario %s\n", s.name.c_str());
+        exit(2);
+    }
+    b.grid->setNRef(s.N);
+    b.grid->setDtRef(s.dt);
+    b.grid->setCostIntegrationRule(FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+    b.grid->setFiniteDifferencesCollocationMethod(makeCollocation(s.collocation));
+
+    b.ocp = std::make_shared<StructuredOptimalControlProblem>(b.grid, dyn, b.hg, b.solver);
+    b.ocp->setStatisticsObject(b.stats);
+
+    if (s.name == "unicycle")
+    {
+        Eigen::MatrixXd Q = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
+        Eigen::MatrixXd R = Eigen::Vector2d(0.1, 0.05).asDiagonal();
+        Eigen::MatrixXd Qf = 10.0 * Q;
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
+    }
+    else if (s.name == "vdp")
+    {
+        Eigen::MatrixXd Q = Eigen::Vector2d(1, 1).asDiagonal();
+        Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        Eigen::MatrixXd Qf = 10.0 * Q;
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
+    }
+    else if (s.name == "dint")
+    {
+        b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
+        b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
+    }
+    if (!b.ocp->initialize())
+    {
+        fprintf(stderr, "ocp initialize failed\n");
+        exit(3);
+    }
+    b.xref = std::make_shared<StaticReference>(s.xf);
+    b.uref = std::make_shared<ZeroReference>(s.nu);
+    return b;
+}
+
+static bool run(Built& b, const Scenario& s, int solves, double* solve_seconds = nullptr)
+{
+    bool ok  = true;
+    double t = 0;
+    for (int i = 0; i < solves; ++i)
+    {
+        ok = b.ocp->compute(s.x0, *b.xref, *b.uref, nullptr, Time(0), i == 0) && ok;
+        t += b.stats->solving_time.toSec();
+    }
+    if (solve_seconds) *solve_seconds = t;
+    return ok;
+}
+
+static void printVec(const char* key, const Eigen::VectorXd& v, bool comma = true)
+{
+    printf("\"%s\": [", key);
+    for (int i = 0; i < v.size(); ++i) printf("%s%.17g", i ? ", " : "", v[i]);
+    printf("]%s\n", comma ? "," : "");
+}
+
+// all vertex values in grid order  x_0 u_0 | x_1 u_1 | ... | x_f | (dt)
+static Eigen::VectorXd vertexValues(Built& b, const Scenario& s)
+{
+    auto xs = std::make_shared<TimeSeries>();
+    auto us = std::make_shared<TimeSeries>();
+    b.ocp->getTimeSeries(xs, us);
+    int n = b.grid->getN();
+    std::vector<double> out;
+    for (int k = 0; k < n - 1; ++k)
+    {
+        for (int i = 0; i < s.nx; ++i) out.push_back(xs->getValuesMatrixView()(i, k));
+        for (int i = 0; i < s.nu; ++i) out.push_back(us->getValuesMatrixView()(i, k));
+    }
+    for (int i = 0; i < s.nx; ++i) out.push_back(xs->getValuesMatrixView()(i, n - 1));
+    out.push_back(b.grid->getDt());
+    return Eigen::Map<Eigen::VectorXd>(out.data(), out.size());
+}
+
+static Scenario parse(int argc, char** argv, std::map<std::string, std::string>& kv)
+{
+    for (int i = 2; i < argc; ++i)
+    {
+        std::string a(argv[i]);
+        size_t p = a.find('=');
+        if (p == std::string::npos) continue;
+        kv[a.substr(0, p)] = a.substr(p + 1);
+    }
+    Scenario s;
+    s.name = kv.count("scenario") ? kv["scenario"] : "unicycle";
+    auto vec = [](const std::string& str) {
+        std::vector<double> v;
+        std::stringstream ss(str);
+        std::string item;
+        while (std::getline(ss, item, ',')) v.push_back(strtod(item.c_str(), nullptr));
+        return Eigen::VectorXd(Eigen::Map<Eigen::VectorXd>(v.data(), v.size()));
+    };
+    if (s.name == "unicycle")
+    {
+        s.nx = 3; s.nu = 2; s.N = 100; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 10;
+        s.x0 = Eigen::Vector3d(0, 0, 0);
+        s.xf = Eigen::Vector3d(2, 1, 0.5);
+    }
+    else if (s.name == "vdp")
+    {
+        s.nx = 2; s.nu = 1; s.N = 20; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 2;
+        s.x0 = Eigen::Vector2d(1, 0);
+        s.xf = Eigen::Vector2d(0, 0);
+    }
+    else if (s.name == "dint")
+    {
+        s.nx = 2; s.nu = 1; s.N = 50; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 100;
+        s.x0 = Eigen::Vector2d(0, 0);
+        s.xf = Eigen::Vector2d(1, 0);
+        s.solves = 5;
+    }
+    if (kv.count("N")) s.N = atoi(kv["N"].c_str());
+    if (kv.count("dt")) s.dt = atof(kv["dt"].c_str());
+    if (kv.count("iters")) s.iters = atoi(kv["iters"].c_str());
+    if (kv.count("solves")) s.solves = atoi(kv["solves"].c_str());
+    if (kv.count("w"))
+    {
+        Eigen::VectorXd w = vec(kv["w"]);
+        s.w_eq = w[0]; s.w_ineq = w[1]; s.w_b = w[2];
+    }
+    if (kv.count("x0")) s.x0 = vec(kv["x0"]);
+    if (kv.count("xf")) s.xf = vec(kv["xf"]);
+    if (kv.count("collocation")) s.collocation = kv["collocation"];
+    return s;
+}
+
+static int dump(const Scenario& s)
+{
+    printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters\": %d, \"solves\": %d,\n", s.name.c_str(), s.nx, s.nu,
+           s.N, s.dt, s.iters, s.solves);
+    printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
+    printVec("x0", s.x0);
+    printVec("xf", s.xf);
+
+    // ---- hot-path pieces at the initial point: LM with 0 iterations builds the graph, evaluates once and returns
+    {
+        Built b = build(s, 0);
+        run(b, s, 1);
+        auto& hg = *b.hg;
+        int n = hg.getParameterDimension(), lsq = hg.getLsqObjectiveDimension(), eq = hg.getEqualityDimension(), ineq = hg.getInequalityDimension(),
+            nb = hg.finiteCombinedBoundsDimension();
+        int m = lsq + eq + ineq + nb;
+        printf("\"n\": %d, \"lsq\": %d, \"eq\": %d, \"ineq\": %d, \"bounds\": %d, \"m\": %d,\n", n, lsq, eq, ineq, nb, m);
+        Eigen::VectorXd p(n), lb(n), ub(n);
+        hg.getParameterVector(p);
+        hg.getBounds(lb, ub);
+        printVec("param_init", p);
+        printVec("param_lb", lb);
+        printVec("param_ub", ub);
+        printVec("vertex_init", vertexValues(b, s));
+        // stacked residual exactly as LevenbergMarquardtSparse::computeValues (levenberg_marquardt_sparse.cpp:222-246)
+        Eigen::VectorXd values(m);
+        if (lsq) hg.computeValuesLsqObjective(values.segment(0, lsq));
+        if (eq)
+        {
+            hg.computeValuesEquality(values.segment(lsq, eq));
+            values.segment(lsq, eq) *= s.w_eq;
+        }
+        if (ineq) hg.computeValuesActiveInequality(values.segment(lsq + eq, ineq), s.w_ineq);
+        if (nb)
+        {
+            hg.computeDistanceFiniteCombinedBounds(values.segment(lsq + eq + ineq, nb));
+            values.segment(lsq + eq + ineq, nb) *= s.w_b;
+        }
+        printVec("values_init", values);
+        Eigen::SparseMatrix<double> J(m, n);
+        hg.computeCombinedSparseJacobian(J, true, true, true, true, true, s.w_eq, s.w_ineq, s.w_b, &values);
+        std::vector<int> rows, cols;
+        std::vector<double> vals;
+        for (int k = 0; k < J.outerSize(); ++k)
+            for (Eigen::SparseMatrix<double>::InnerIterator it(J, k); it; ++it)
+            {
+                rows.push_back(it.row());
+                cols.push_back(it.col());
+                vals.push_back(it.value());
+            }
+        printf("\"nnz\": %d,\n\"jac_rows\": [", (int)rows.size());
+        for (size_t i = 0; i < rows.size(); ++i) printf("%s%d", i ? ", " : "", rows[i]);
+        printf("],\n\"jac_cols\": [");
+        for (size_t i = 0; i < cols.size(); ++i) printf("%s%d", i ? ", " : "", cols[i]);
+        printf("],\n");
+        printVec("jac_vals", Eigen::Map<Eigen::VectorXd>(vals.data(), vals.size()));
+        // H = J^T J diag and rhs (levenberg_marquardt_sparse.cpp:97-100)
+        Eigen::SparseMatrix<double> H = J.transpose() * J;
+        Eigen::VectorXd rhs           = J.transpose() * -values;
+        printVec("H_diag_init", H.diagonal());
+        printVec("rhs_init", rhs);
+        printf("\"nnz_H\": %d,\n", (int)H.nonZeros());
+    }
+
+    // ---- trajectory after k LM iterations (fresh OCP each time), last solve of `solves`
+    printf("\"after_iter\": [\n");
+    for (int k = 1; k <= s.iters; ++k)
+    {
+        Built b = build(s, k);
+        bool ok = run(b, s, s.solves);
+        printf("{\"k\": %d, \"ok\": %d, \"chi2\": %.17g, ", k, ok ? 1 : 0, b.ocp->getCurrentObjectiveValue());
+        printVec("vertex", vertexValues(b, s), false);
+        printf("}%s\n", k < s.iters ? "," : "");
+    }
+    printf("]\n}\n");
+    return 0;
+}
+
+static int bench(const Scenario& s0, std::map<std::string, std::string>& kv)
+{
+    int batch         = kv.count("batch") ? atoi(kv["batch"].c_str()) : 16;
+    unsigned long seed = kv.count("seed") ? strtoul(kv["seed"].c_str(), nullptr, 10) : 20260928UL;
+    double total = 0, chi2_sum = 0;
+    auto w0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < batch; ++i)
+    {
+        Scenario s = s0;
+        std::mt19937_64 rng(seed + i);
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        if (s.name == "unicycle")
+        {
+            s.x0 = Eigen::Vector3d(U(rng), U(rng), U(rng) * M_PI / 4);
+            s.xf = Eigen::Vector3d(2 + 0.5 * U(rng), 1 + 0.5 * U(rng), 0.5 + 0.5 * U(rng));
+        }
+        Built b = build(s, s.iters);
+        double t = 0;
+        run(b, s, s.solves, &t);
+        total += t;
+        chi2_sum += b.ocp->getCurrentObjectiveValue();
+    }
+    double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    printf("{\"scenario\": \"%s\", \"batch\": %d, \"iters\": %d, \"solves\": %d, \"solve_seconds\": %.9g, \"wall_seconds\": %.9g, "
+           "\"iter_per_s\": %.9g, \"chi2_sum\": %.17g}\n",
+           s0.name.c_str(), batch, s0.iters, s0.solves, total, wall, batch * (double)s0.iters * s0.solves / total, chi2_sum);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2)
+    {
+        fprintf(stderr, "usage: ref_driver dump|bench key=value ...\n");
+        return 1;
+    }
+    std::map<std::string, std::string> kv;
+    Scenario s = parse(argc, argv, kv);
+    std::string mode(argv[1]);
+    if (mode == "dump") return dump(s);
+    if (mode == "bench") return bench(s, kv);
+    fprintf(stderr, "unknown mode\n");
+    return 1;
+}
