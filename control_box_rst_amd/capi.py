@@ -1,0 +1,117 @@
+"""ctypes mirror of include/corbo_hip.h (the C-ABI drop-in boundary) and loader of libcorbo_hip.so.
+
+The structures here are byte-for-byte the PODs of ``include/corbo_hip.h``.  ``load()`` fails loudly when the HIP
+library has not been built -- there is no CPU fallback in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_NX = 16
+MAX_NU = 8
+INF = 2e30  # CORBO_INF_DBL (reference: src/core/include/corbo-core/types.h:52)
+
+# enums (names follow include/corbo_hip.h)
+GRID_FD, GRID_FD_VARIABLE, GRID_MS = 0, 1, 2
+DEFECT_FORWARD, DEFECT_BACKWARD, DEFECT_MIDPOINT, DEFECT_CRANK_NICOLSON, DEFECT_RK4_SHOOTING = 0, 1, 2, 3, 4
+DYN_VAN_DER_POL, DYN_SERIAL_INTEGRATOR, DYN_UNICYCLE, DYN_QUADROTOR = 0, 1, 2, 3
+COST_NONE, COST_QUADRATIC_LSQ, COST_MIN_TIME_LSQ = 0, 1, 2
+INEQ_NONE, INEQ_BALL = 0, 1
+SOLVER_CONVERGED, SOLVER_EARLY_TERMINATED, SOLVER_INFEASIBLE, SOLVER_ERROR = 0, 1, 2, 3
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("grid", C.c_int32), ("defect", C.c_int32), ("dynamics", C.c_int32), ("stage_cost", C.c_int32),
+        ("final_cost", C.c_int32), ("stage_ineq", C.c_int32),
+        ("nx", C.c_int32), ("nu", C.c_int32), ("N", C.c_int32),
+        ("xf_fixed_mask", C.c_uint32),
+        ("dt_ref", C.c_double), ("dt_lb", C.c_double), ("dt_ub", C.c_double),
+        ("x_lb", C.c_double * MAX_NX), ("x_ub", C.c_double * MAX_NX),
+        ("u_lb", C.c_double * MAX_NU), ("u_ub", C.c_double * MAX_NU),
+        ("q_diag", C.c_double * MAX_NX), ("r_diag", C.c_double * MAX_NU), ("qf_diag", C.c_double * MAX_NX),
+        ("dyn_params", C.c_double * 8), ("ineq_params", C.c_double * 8),
+    ]
+
+
+class Dims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("nv", "n", "lsq", "eq", "ineq", "bounds", "m", "nnz")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class LmOpts(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("weight_eq", C.c_double), ("weight_ineq", C.c_double), ("weight_bounds", C.c_double),
+        ("adapt_factor_eq", C.c_double), ("adapt_factor_ineq", C.c_double), ("adapt_factor_bounds", C.c_double),
+        ("adapt_max_eq", C.c_double), ("adapt_max_ineq", C.c_double), ("adapt_max_bounds", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("lm_iterations", C.c_int64), ("accepted_steps", C.c_int64), ("rejected_steps", C.c_int64),
+        ("jacobian_sweeps", C.c_int64), ("residual_sweeps", C.c_int64), ("factorizations", C.c_int64),
+        ("passes", C.c_int32), ("solve_ms", C.c_float), ("sweep_ms", C.c_float), ("factor_ms", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def default_lm_opts(iterations=10, w_eq=2.0, w_ineq=2.0, w_bounds=2.0) -> LmOpts:
+    """Reference defaults (levenberg_marquardt_sparse.h:112-124)."""
+    return LmOpts(iterations, w_eq, w_ineq, w_bounds, 1.0, 1.0, 1.0, 500.0, 500.0, 500.0)
+
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcorbo_hip.so")
+_lib = None
+
+# every symbol include/corbo_hip.h declares
+EXPORTED_SYMBOLS = (
+    "corbo_hip_default_lm_opts", "corbo_hip_get_dims", "corbo_hip_get_structure", "corbo_hip_init_trajectory",
+    "corbo_hip_create", "corbo_hip_destroy", "corbo_hip_set_instance_data", "corbo_hip_solve",
+    "corbo_hip_synchronize", "corbo_hip_get_solution", "corbo_hip_get_stats", "corbo_hip_eval",
+    "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
+)
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libcorbo_hip.so (built by __graft_entry__.build()).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "control_box_rst_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    H = C.c_void_p
+    lib.corbo_hip_default_lm_opts.argtypes = [C.POINTER(LmOpts)]
+    lib.corbo_hip_default_lm_opts.restype = None
+    lib.corbo_hip_get_dims.argtypes = [C.POINTER(ProblemDesc), C.POINTER(Dims)]
+    lib.corbo_hip_get_structure.argtypes = [C.POINTER(ProblemDesc), ip, ip]
+    lib.corbo_hip_init_trajectory.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, dp]
+    lib.corbo_hip_create.argtypes = [C.POINTER(ProblemDesc), C.c_int, C.c_int, C.POINTER(H)]
+    lib.corbo_hip_destroy.argtypes = [H]
+    lib.corbo_hip_destroy.restype = None
+    lib.corbo_hip_set_instance_data.argtypes = [H, dp, dp, dp, dp]
+    lib.corbo_hip_solve.argtypes = [H, C.POINTER(LmOpts), C.c_int]
+    lib.corbo_hip_synchronize.argtypes = [H]
+    lib.corbo_hip_get_solution.argtypes = [H, dp, dp, ip]
+    lib.corbo_hip_get_stats.argtypes = [H, C.POINTER(Stats)]
+    lib.corbo_hip_eval.argtypes = [H, C.c_double, C.c_double, C.c_double, dp, dp]
+    lib.corbo_hip_device_views.argtypes = [H, C.POINTER(dp), C.POINTER(dp), C.POINTER(C.c_void_p)]
+    lib.corbo_hip_time_sweep.argtypes = [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.corbo_hip_last_error.argtypes = []
+    lib.corbo_hip_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib

@@ -1,0 +1,92 @@
+"""Descriptors and synthetic instance generators for the BASELINE.json configurations.
+
+Each builder returns the POD ``ProblemDesc`` the C-ABI consumes; it encodes exactly what the reference's C++ setters
+would configure (FiniteDifferencesGrid::setNRef/setDtRef, QuadraticFormCost(Q, R, false, true),
+QuadraticFinalStateCost(Qf, true), StructuredOptimalControlProblem::setBounds, ...).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import capi
+from .capi import INF, ProblemDesc
+
+
+def _fill(arr, values, default=0.0):
+    for i in range(len(arr)):
+        arr[i] = default
+    for i, v in enumerate(values):
+        arr[i] = float(v)
+
+
+def make_desc(*, grid, defect, dynamics, nx, nu, N, dt, stage_cost=capi.COST_QUADRATIC_LSQ, final_cost=1,
+              stage_ineq=capi.INEQ_NONE, q=(), r=(), qf=(), x_lb=(), x_ub=(), u_lb=(), u_ub=(), xf_fixed_mask=0,
+              dt_lb=0.0, dt_ub=INF, dyn_params=(), ineq_params=()) -> ProblemDesc:
+    d = ProblemDesc()
+    d.grid, d.defect, d.dynamics = grid, defect, dynamics
+    d.stage_cost, d.final_cost, d.stage_ineq = stage_cost, final_cost, stage_ineq
+    d.nx, d.nu, d.N = nx, nu, N
+    d.xf_fixed_mask = xf_fixed_mask
+    d.dt_ref, d.dt_lb, d.dt_ub = dt, dt_lb, dt_ub
+    _fill(d.x_lb, x_lb, -INF)
+    _fill(d.x_ub, x_ub, INF)
+    _fill(d.u_lb, u_lb, -INF)
+    _fill(d.u_ub, u_ub, INF)
+    _fill(d.q_diag, q)
+    _fill(d.r_diag, r)
+    _fill(d.qf_diag, qf)
+    _fill(d.dyn_params, dyn_params)
+    _fill(d.ineq_params, ineq_params)
+    return d
+
+
+# ---- cfg 3 / 4 (headline): unicycle point-to-point, FiniteDifferencesGrid N=100, Crank-Nicolson -----------------
+def unicycle_desc(N=100, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+    q = (1.0, 1.0, 0.1)
+    return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_UNICYCLE, nx=3, nu=2, N=N, dt=dt,
+                     q=q, r=(0.1, 0.05), qf=tuple(10.0 * v for v in q),
+                     x_lb=(-10.0,) * 3, x_ub=(10.0,) * 3, u_lb=(-1.0,) * 2, u_ub=(1.0,) * 2)
+
+
+UNICYCLE_WEIGHTS = (10.0, 10.0, 10.0)
+
+
+def unicycle_instances(batch: int, seed: int = 20260928, first: int = 0):
+    """x0 = (U(-1,1), U(-1,1), U(-pi/4,pi/4)), xf = (2,1,0.5)+U(-0.5,0.5)^3 with default_rng(seed + i).
+
+    ``first`` = global index of the first instance (rank offset for batch sharding)."""
+    x0 = np.empty((batch, 3))
+    xf = np.empty((batch, 3))
+    for b in range(batch):
+        rng = np.random.default_rng(seed + first + b)
+        x0[b] = (rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-math.pi / 4, math.pi / 4))
+        xf[b] = np.array([2.0, 1.0, 0.5]) + rng.uniform(-0.5, 0.5, 3)
+    return x0, xf
+
+
+# ---- cfg 1: Van-der-Pol regulator, FiniteDifferencesGrid N=20 --------------------------------------------------
+def vdp_desc(N=20, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+    return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_VAN_DER_POL, nx=2, nu=1, N=N, dt=dt,
+                     q=(1.0, 1.0), r=(0.1,), qf=(10.0, 10.0), u_lb=(-1.0,), u_ub=(1.0,), dyn_params=(1.0,))
+
+
+VDP_WEIGHTS = (2.0, 2.0, 2.0)
+
+
+# ---- cfg 2: time-optimal double integrator, FiniteDifferencesVariableGrid N=50, x_f fixed, MinimumTime(lsq) -----
+def dint_desc(N=50, dt=0.1) -> ProblemDesc:
+    return make_desc(grid=capi.GRID_FD_VARIABLE, defect=capi.DEFECT_CRANK_NICOLSON, dynamics=capi.DYN_SERIAL_INTEGRATOR,
+                     nx=2, nu=1, N=N, dt=dt, stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0,
+                     u_lb=(-1.0,), u_ub=(1.0,), xf_fixed_mask=0b11, dt_lb=0.01, dt_ub=10.0, dyn_params=(1.0,))
+
+
+DINT_WEIGHTS = (100.0, 100.0, 100.0)
+
+
+SCENARIOS = {
+    "unicycle": (unicycle_desc, UNICYCLE_WEIGHTS),
+    "vdp": (vdp_desc, VDP_WEIGHTS),
+    "dint": (dint_desc, DINT_WEIGHTS),
+}

@@ -1,0 +1,215 @@
+/*
+ * corbo_hip.h -- C-ABI of the MI355X-native NLP inner loop for control_box_rst hypergraph OCPs.
+ *
+ * This is the drop-in boundary.  Nothing like it exists in the reference: the reference's
+ * plug-in point is the C++ class corbo::NlpSolverInterface
+ *     /root/reference/src/optimization/include/corbo-optimization/solver/nlp_solver_interface.h:67-115
+ * whose solve() is called from
+ *     /root/reference/src/optimal_control/src/structured_ocp/structured_optimal_control_problem.cpp:134 .
+ * The C++ adapter in control_box_rst_amd/adapter/ implements that class on top of the functions below
+ * (binding shown in INTEGRATION.md).  Each entry point cites the reference code it replaces.
+ *
+ * Conventions: plain C, POD structs, caller owns every host buffer, the library owns device buffers and one
+ * HIP stream per handle.  Return value 0 = OK, negative = corbo_hip_status.  A handle is not thread-safe;
+ * distinct handles are independent.  All floating point is IEEE fp64 (the reference's only arithmetic type).
+ *
+ * Data layout ("vertex layout", one row per OCP instance, row stride = corbo_hip_dims.nv doubles):
+ *     [ x_0 u_0 | x_1 u_1 | ... | x_{N-2} u_{N-2} | x_f | dt (only when dt is a free parameter) ]
+ * which is the order of FullDiscretizationGridBase's vertices
+ *     /root/reference/src/optimal_control/src/structured_ocp/discretization_grids/full_discretization_grid_base.cpp:514-527 .
+ * "Parameter layout" (length n) is the same sequence with every fixed component removed (x_0, fixed x_f
+ * components, fixed dt) -- the reference's column order (vertex_set.cpp:405-418).
+ */
+#ifndef CORBO_HIP_H_
+#define CORBO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORBO_HIP_MAX_NX 16
+#define CORBO_HIP_MAX_NU 8
+#define CORBO_HIP_INF 2e30 /* CORBO_INF_DBL, /root/reference/src/core/include/corbo-core/types.h:52 */
+
+typedef enum corbo_hip_status {
+    CORBO_HIP_OK              = 0,
+    CORBO_HIP_ERR_INVALID     = -1, /* bad argument / unsupported descriptor */
+    CORBO_HIP_ERR_DEVICE      = -2, /* HIP runtime error (see corbo_hip_last_error) */
+    CORBO_HIP_ERR_UNSUPPORTED = -3, /* descriptor is valid for the reference but has no device kernel yet */
+    CORBO_HIP_ERR_STATE       = -4  /* call order violated (e.g. solve before set_instance_data) */
+} corbo_hip_status;
+
+/* SolverStatus of the reference, /root/reference/src/optimization/include/corbo-optimization/types.h:30 */
+typedef enum corbo_hip_solver_status {
+    CORBO_HIP_SOLVER_CONVERGED        = 0,
+    CORBO_HIP_SOLVER_EARLY_TERMINATED = 1,
+    CORBO_HIP_SOLVER_INFEASIBLE       = 2,
+    CORBO_HIP_SOLVER_ERROR            = 3
+} corbo_hip_solver_status;
+
+/* Discretization grid that produced the hypergraph (decides vertex set and edge creation order). */
+typedef enum corbo_hip_grid {
+    CORBO_HIP_GRID_FD          = 0, /* FiniteDifferencesGrid          (finite_differences_grid.cpp:38-154), fixed dt   */
+    CORBO_HIP_GRID_FD_VARIABLE = 1, /* FiniteDifferencesVariableGrid  (finite_differences_variable_grid.h:34-89), free dt */
+    CORBO_HIP_GRID_MS          = 2  /* MultipleShootingGrid, 1 control per interval (multiple_shooting_grid.cpp:38-197)  */
+} corbo_hip_grid;
+
+/* Dynamics-defect formula of the equality edge between (x_k, u_k, x_{k+1}, dt). */
+typedef enum corbo_hip_defect {
+    CORBO_HIP_DEFECT_FORWARD        = 0, /* finite_differences_collocation.h:126-134 */
+    CORBO_HIP_DEFECT_BACKWARD       = 1, /* :160-168 */
+    CORBO_HIP_DEFECT_MIDPOINT       = 2, /* :194-202 */
+    CORBO_HIP_DEFECT_CRANK_NICOLSON = 3, /* :228-238 (reference default, full_discretization_grid_base.h:138) */
+    CORBO_HIP_DEFECT_RK4_SHOOTING   = 4  /* multiple_shooting_edges.h:125-134 + explicit_integrators.h:280-295 */
+} corbo_hip_defect;
+
+/* System dynamics f(x,u) (SystemDynamicsInterface::dynamics, system_dynamics_interface.h:121). */
+typedef enum corbo_hip_dynamics {
+    CORBO_HIP_DYN_VAN_DER_POL       = 0, /* nonlinear_benchmark_systems.h:52-60, params[0] = a              nx=2 nu=1 */
+    CORBO_HIP_DYN_SERIAL_INTEGRATOR = 1, /* linear_benchmark_systems.h:72-83,    params[0] = time constant  nx=p nu=1 */
+    CORBO_HIP_DYN_UNICYCLE          = 2, /* user plug-in: xdot=u1 cos th, ydot=u1 sin th, thdot=u2          nx=3 nu=2 */
+    CORBO_HIP_DYN_QUADROTOR         = 3  /* user plug-in: 12-state rigid body, see DESIGN.md                nx=12 nu=4 */
+} corbo_hip_dynamics;
+
+typedef enum corbo_hip_stage_cost {
+    CORBO_HIP_COST_NONE          = 0,
+    CORBO_HIP_COST_QUADRATIC_LSQ = 1, /* QuadraticFormCost(Q,R, integral=false, lsq=true), diagonal Q,R, zero uref
+                                         (quadratic_cost.cpp:100-184) */
+    CORBO_HIP_COST_MIN_TIME_LSQ  = 2  /* MinimumTime(lsq=true) (minimum_time.h:49-78); dt edge created twice
+                                         (nlp_functions.cpp:91-107) */
+} corbo_hip_stage_cost;
+
+typedef enum corbo_hip_stage_ineq {
+    CORBO_HIP_INEQ_NONE = 0,
+    CORBO_HIP_INEQ_BALL = 1 /* c(x) = r^2 - |x[0:3]-c|^2 <= 0 : spherical keep-out, params = cx,cy,cz,r (cfg 5) */
+} corbo_hip_stage_ineq;
+
+/* Problem descriptor shared by every instance of a batch (POD). */
+typedef struct corbo_hip_problem_desc {
+    int32_t grid;          /* corbo_hip_grid */
+    int32_t defect;        /* corbo_hip_defect */
+    int32_t dynamics;      /* corbo_hip_dynamics */
+    int32_t stage_cost;    /* corbo_hip_stage_cost */
+    int32_t final_cost;    /* 0 = none, 1 = QuadraticFinalStateCost(Qf, lsq=true), diagonal (final_state_cost.cpp:72-112) */
+    int32_t stage_ineq;    /* corbo_hip_stage_ineq */
+    int32_t nx, nu, N;     /* state dim, control dim, grid points (N-1 intervals) */
+    uint32_t xf_fixed_mask; /* bit i set = component i of x_f is fixed (setXfFixed, full_discretization_grid_base.h:89-93) */
+    double dt_ref;         /* dt (fixed grids) or initial dt (free-dt grid) */
+    double dt_lb, dt_ub;   /* free-dt grid only (FiniteDifferencesVariableGrid::setDtBounds) */
+    /* Box bounds shared along the horizon (NlpFunctions::x_lb/x_ub/u_lb/u_ub, set by
+     * StructuredOptimalControlProblem::setBounds, structured_optimal_control_problem.cpp:167-176).  +-CORBO_HIP_INF =
+     * unbounded.  Their finiteness pattern fixes which bound rows exist (vector_vertex.h:174-184); per-instance
+     * values may be overridden with corbo_hip_set_instance_data but must keep that pattern. */
+    double x_lb[CORBO_HIP_MAX_NX], x_ub[CORBO_HIP_MAX_NX];
+    double u_lb[CORBO_HIP_MAX_NU], u_ub[CORBO_HIP_MAX_NU];
+    double q_diag[CORBO_HIP_MAX_NX];
+    double r_diag[CORBO_HIP_MAX_NU];
+    double qf_diag[CORBO_HIP_MAX_NX];
+    double dyn_params[8];
+    double ineq_params[8];
+} corbo_hip_problem_desc;
+
+/* Sizes derived from a descriptor (corbo_hip_get_dims). */
+typedef struct corbo_hip_dims {
+    int32_t nv;      /* doubles per instance in vertex layout */
+    int32_t n;       /* parameters (columns of J)  = getParameterDimension()            */
+    int32_t lsq;     /* getLsqObjectiveDimension()                                       */
+    int32_t eq;      /* getEqualityDimension()                                           */
+    int32_t ineq;    /* getInequalityDimension()                                         */
+    int32_t bounds;  /* finiteCombinedBoundsDimension(): one row per unfixed component with a finite lb or ub */
+    int32_t m;       /* rows of J = lsq + eq + ineq + bounds                             */
+    int32_t nnz;     /* structural non-zeros of J (hyper_graph_optimization_problem_edge_based.cpp:193-222) */
+} corbo_hip_dims;
+
+/* Levenberg-Marquardt options = LevenbergMarquardtSparse's setters
+ * (/root/reference/src/optimization/include/corbo-optimization/solver/levenberg_marquardt_sparse.h:86-124). */
+typedef struct corbo_hip_lm_opts {
+    int32_t iterations;                                       /* setIterations, default 10 */
+    double weight_eq, weight_ineq, weight_bounds;             /* setPenaltyWeights, default 2/2/2 */
+    double adapt_factor_eq, adapt_factor_ineq, adapt_factor_bounds; /* setWeightAdapation, default 1/1/1 */
+    double adapt_max_eq, adapt_max_ineq, adapt_max_bounds;    /* default 500/500/500 */
+} corbo_hip_lm_opts;
+
+typedef struct corbo_hip_stats {
+    int64_t lm_iterations;      /* sum over instances of outer iterations run (= batch * iterations) */
+    int64_t accepted_steps;
+    int64_t rejected_steps;
+    int64_t jacobian_sweeps;    /* per-instance Jacobian evaluations, summed */
+    int64_t residual_sweeps;    /* per-instance residual evaluations, summed */
+    int64_t factorizations;
+    int32_t passes;             /* device passes (kernel rounds) the batch needed */
+    float   solve_ms;           /* HIP-event time of the last corbo_hip_solve (device side) */
+    float   sweep_ms;           /* accumulated time of the edge/Jacobian sweep kernel inside it (0 if not profiled) */
+    float   factor_ms;          /* accumulated time of the assemble/factor/solve kernel (0 if not profiled) */
+} corbo_hip_stats;
+
+typedef struct corbo_hip_solver* corbo_hip_handle;
+
+/* Fill `opts` with the reference defaults (levenberg_marquardt_sparse.h:112-124). */
+void corbo_hip_default_lm_opts(corbo_hip_lm_opts* opts);
+
+/* Validate a descriptor and compute the static sizes.  Replaces the dimension bookkeeping of
+ * LevenbergMarquardtSparse::solve (levenberg_marquardt_sparse.cpp:48-80) and
+ * OptimizationEdgeSet::getDimensions / VertexSetInterface::computeVertexIndices (edge_set.cpp:198-236,
+ * vertex_set.cpp:405-418).  Needs no GPU. */
+int corbo_hip_get_dims(const corbo_hip_problem_desc* desc, corbo_hip_dims* dims);
+
+/* Static sparsity pattern of the combined Jacobian in the library's value order (length dims.nnz each).
+ * Replaces computeCombinedSparseJacobiansStructure (hyper_graph_optimization_problem_edge_based.cpp:1181-1478).
+ * Needs no GPU. */
+int corbo_hip_get_structure(const corbo_hip_problem_desc* desc, int32_t* rows, int32_t* cols);
+
+/* Initial trajectory exactly as the grid writes it into the vertices before the first solve
+ * (FullDiscretizationGridBase::initializeSequences, full_discretization_grid_base.cpp:134-179): linear
+ * interpolation x0 -> xf, u = 0, dt = dt_ref.  x0, xf: [batch][nx]; x_out: [batch][nv].  Host-only helper. */
+int corbo_hip_init_trajectory(const corbo_hip_problem_desc* desc, int batch, const double* x0, const double* xf, double* x_out);
+
+/* Create a solver for `batch` independent instances of `desc` on HIP device `device`. */
+int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out);
+void corbo_hip_destroy(corbo_hip_handle h);
+
+/* Upload per-instance data (what the grid holds in its vertices when solve() is entered):
+ *   x  [batch][nv] vertex values, lb/ub [batch][nv] bounds (+-CORBO_HIP_INF = unbounded; entries of fixed
+ *   components are ignored), xref [batch][nx] static state reference (StaticReference).
+ * lb, ub may be NULL = the descriptor's box bounds replicated along the horizon; xref may be NULL = zeros. */
+int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref);
+
+/* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
+ * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
+ * (:83-86).  Asynchronous on the handle's stream; results stay resident in HBM. */
+int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
+
+/* Block until the handle's stream is idle. */
+int corbo_hip_synchronize(corbo_hip_handle h);
+
+/* Download results (synchronises): x_out [batch][nv] last accepted iterate (what callers read from the vertices,
+ * full_discretization_grid_base.cpp:324-331,529-565), chi2_out [batch] (*obj_value), status_out [batch]
+ * (corbo_hip_solver_status).  Any pointer may be NULL. */
+int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, int32_t* status_out);
+int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats);
+
+/* Parity hook for SURVEY rows a2-a6: evaluate the stacked residual
+ * (LevenbergMarquardtSparse::computeValues, levenberg_marquardt_sparse.cpp:222-246) and, if jac_out != NULL, the
+ * combined Jacobian values (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753)
+ * at the resident x with the given weights.  values_out [batch][m], jac_out [batch][nnz] (order of
+ * corbo_hip_get_structure).  Synchronises. */
+int corbo_hip_eval(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, double* values_out, double* jac_out);
+
+/* Device-resident views for callers that already live on the GPU (torch tensors, RCCL gathers): pointers into
+ * the library's HBM buffers, valid until corbo_hip_destroy.  x: [batch][nv], chi2: [batch]. */
+int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev, void** hip_stream);
+
+/* Launch only the edge/Jacobian sweep kernel `repeat` times on the resident data and return the average
+ * per-launch time in ms measured with HIP events on the handle's stream (bench.py roofline leg). */
+int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat,
+                         float* ms_per_launch);
+
+/* Text of the last error on this thread. */
+const char* corbo_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORBO_HIP_H_ */

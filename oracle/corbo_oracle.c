@@ -1,0 +1,760 @@
+/*
+ * corbo_oracle.c -- TEST INFRASTRUCTURE ONLY (see corbo_oracle.h).
+ *
+ * Plain-C restatement of the reference's hypergraph NLP inner loop, operation by operation.  Every function cites
+ * the reference code it follows (paths relative to /root/reference/src).  It keeps the reference's data model:
+ * vertices (value storage + fixed mask + bounds), edges (attached vertices, computeValues), central-difference
+ * block Jacobians that perturb the shared vertex storage in place, the stacked residual
+ * [lsq | w_eq*eq | w_ineq*max(0,ineq) | w_b*bounds], J^T J and the Levenberg-Marquardt loop with all of its quirks.
+ * Differences to the reference that are rounding-level only (documented in DESIGN.md):
+ *   - squared norms / dot products are summed left to right (Eigen uses packet-wise partial sums);
+ *   - the linear system is solved by an envelope (skyline) Cholesky in natural order (Eigen: SimplicialLLT + AMD).
+ * Parity status: PINNED against tests/golden/ (genuine reference outputs), see tests/test_oracle_golden.py.
+ */
+#include "corbo_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* hyper-graph data model (optimization/include/corbo-optimization/hyper_graph/{vector_vertex,scalar_vertex}.h)  */
+
+typedef struct {
+    int off;        /* offset of the values in the vertex storage */
+    int dim;
+    unsigned fixed; /* bit i = component i fixed (PartiallyFixedVectorVertex, vector_vertex.h:276-446) */
+    int n_unfixed;
+    int col;        /* getVertexIdx(): first parameter index, -1 when not active (vertex_set.cpp:405-418) */
+} o_vertex;
+
+enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ };
+
+typedef struct {
+    int type;
+    int k;        /* stage index */
+    int nverts;
+    int vert[4];  /* attached vertices in the reference's order, e.g. defect: (x1,u1,x2,dt) */
+    int dim;      /* getDimension() */
+    int row;      /* global row of the first value in the stacked residual */
+    int scale;    /* 0 lsq (unscaled), 1 equality (w_eq), 2 inequality (w_ineq, active set) */
+} o_edge;
+
+typedef struct { /* one (edge, vertex) Jacobian block, values stored column-major like Eigen::MatrixXd */
+    int edge, vtx_idx;
+    int row0, col0, rows, cols;
+    int off; /* offset into the Jacobian value array */
+} o_block;
+
+struct oracle_problem {
+    corbo_hip_problem_desc d;
+    corbo_hip_dims dims;
+    int n_vertices, n_edges, n_blocks;
+    o_vertex* v;
+    o_edge* e;
+    o_block* b;
+    int first_bound_nnz;  /* offset of the bound entries in the Jacobian value array */
+    int* bound_vert_off;  /* per bound row: offset of the component in the vertex storage */
+    int* bound_col;       /* per bound row: parameter index */
+    int* param_off;       /* per parameter: offset in the vertex storage (applyIncrementNonFixed, vertex_set.cpp:357-367) */
+    double *x, *lb, *ub, *xref, *backup;
+    double sq[CORBO_HIP_MAX_NX], sr[CORBO_HIP_MAX_NU], sqf[CORBO_HIP_MAX_NX]; /* cwiseSqrt of the weights */
+    double dt_weight;
+    /* static row-wise view of J (for J^T J in Eigen's summation order) */
+    int* csr_ptr;  /* m+1 */
+    int* csr_col;  /* nnz */
+    int* csr_val;  /* nnz: index into the value array */
+    /* envelope storage of H */
+    int* env_first;  /* n: first structurally non-zero column of row i */
+    int* env_ptr;    /* n+1 */
+    int env_size;
+    /* LM work space */
+    double *values, *jac, *H, *L, *rhs, *delta, *tmp;
+    double w_eq, w_ineq, w_b; /* current penalty weights (levenberg_marquardt_sparse.h:126-128) */
+};
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* dynamics (SystemDynamicsInterface::dynamics)                                                                  */
+
+static void dynamics(const corbo_hip_problem_desc* d, const double* x, const double* u, double* f)
+{
+    switch (d->dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: { /* systems/include/corbo-systems/benchmark/nonlinear_benchmark_systems.h:52-60 */
+            double a = d->dyn_params[0];
+            f[0]     = x[1];
+            f[1]     = -a * (x[0] * x[0] - 1) * x[1] - x[0] + u[0];
+            break;
+        }
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR: { /* linear_benchmark_systems.h:72-83 */
+            int n = d->nx;
+            for (int i = 0; i < n - 1; ++i) f[i] = x[i + 1];
+            f[n - 1] = u[0] / d->dyn_params[0];
+            break;
+        }
+        case CORBO_HIP_DYN_UNICYCLE: { /* user plug-in, same formula as oracle/ref_driver.cpp */
+            f[0] = u[0] * cos(x[2]);
+            f[1] = u[0] * sin(x[2]);
+            f[2] = u[1];
+            break;
+        }
+        case CORBO_HIP_DYN_QUADROTOR: { /* user plug-in, DESIGN.md "quadrotor"; same formula as oracle/ref_driver.cpp */
+            double g = d->dyn_params[0], m = d->dyn_params[1], Ixx = d->dyn_params[2], Iyy = d->dyn_params[3], Izz = d->dyn_params[4];
+            double sphi = sin(x[6]), cphi = cos(x[6]), sth = sin(x[7]), cth = cos(x[7]), spsi = sin(x[8]), cpsi = cos(x[8]);
+            double tm = u[0] / m;
+            f[0]  = x[3];
+            f[1]  = x[4];
+            f[2]  = x[5];
+            f[3]  = (cphi * sth * cpsi + sphi * spsi) * tm;
+            f[4]  = (cphi * sth * spsi - sphi * cpsi) * tm;
+            f[5]  = cphi * cth * tm - g;
+            f[6]  = x[9] + (x[10] * sphi + x[11] * cphi) * (sth / cth);
+            f[7]  = x[10] * cphi - x[11] * sphi;
+            f[8]  = (x[10] * sphi + x[11] * cphi) / cth;
+            f[9]  = ((Iyy - Izz) * x[10] * x[11] + u[1]) / Ixx;
+            f[10] = ((Izz - Ixx) * x[9] * x[11] + u[2]) / Iyy;
+            f[11] = ((Ixx - Iyy) * x[9] * x[10] + u[3]) / Izz;
+            break;
+        }
+        default: break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* edge values                                                                                                    */
+
+static void defect_values(const oracle_problem* p, const double* x1, const double* u1, const double* x2, double dt, double* err)
+{
+    const corbo_hip_problem_desc* d = &p->d;
+    int nx = d->nx;
+    double f1[CORBO_HIP_MAX_NX], t[CORBO_HIP_MAX_NX];
+    switch (d->defect) {
+        case CORBO_HIP_DEFECT_FORWARD: /* numerics/include/corbo-numerics/finite_differences_collocation.h:126-134 */
+            dynamics(d, x1, u1, err);
+            for (int i = 0; i < nx; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+            break;
+        case CORBO_HIP_DEFECT_BACKWARD: /* :160-168 */
+            dynamics(d, x2, u1, err);
+            for (int i = 0; i < nx; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+            break;
+        case CORBO_HIP_DEFECT_MIDPOINT: /* :194-202 */
+            for (int i = 0; i < nx; ++i) t[i] = 0.5 * (x1[i] + x2[i]);
+            dynamics(d, t, u1, err);
+            for (int i = 0; i < nx; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+            break;
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: /* :228-238 */
+            dynamics(d, x1, u1, f1);
+            dynamics(d, x2, u1, err);
+            for (int i = 0; i < nx; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
+            break;
+        case CORBO_HIP_DEFECT_RK4_SHOOTING: { /* explicit_integrators.h:280-295 + integrator_interface.h:217-222 */
+            double k1[CORBO_HIP_MAX_NX], k2[CORBO_HIP_MAX_NX], k3[CORBO_HIP_MAX_NX], k4[CORBO_HIP_MAX_NX];
+            dynamics(d, x1, u1, k1);
+            for (int i = 0; i < nx; ++i) k1[i] *= dt;
+            for (int i = 0; i < nx; ++i) t[i] = x1[i] + k1[i] / 2.0;
+            dynamics(d, t, u1, k2);
+            for (int i = 0; i < nx; ++i) k2[i] *= dt;
+            for (int i = 0; i < nx; ++i) t[i] = x1[i] + k2[i] / 2.0;
+            dynamics(d, t, u1, k3);
+            for (int i = 0; i < nx; ++i) k3[i] *= dt;
+            for (int i = 0; i < nx; ++i) t[i] = x1[i] + k3[i];
+            dynamics(d, t, u1, k4);
+            for (int i = 0; i < nx; ++i) k4[i] *= dt;
+            for (int i = 0; i < nx; ++i) err[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+            for (int i = 0; i < nx; ++i) err[i] -= x2[i];
+            break;
+        }
+        default: break;
+    }
+}
+
+/* BaseEdge::computeValues of the edge classes on the path */
+static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
+{
+    const corbo_hip_problem_desc* d = &p->d;
+    const double* x = p->x;
+    switch (e->type) {
+        case E_STATE_COST: { /* optimal_control/src/functions/quadratic_cost.cpp:100-119 (lsq form, diagonal Q) */
+            const double* xk = x + p->v[e->vert[0]].off;
+            for (int i = 0; i < d->nx; ++i) out[i] = p->sq[i] * (xk[i] - p->xref[i]);
+            break;
+        }
+        case E_CONTROL_COST: { /* quadratic_cost.cpp:140-154 (lsq form, zero uref, diagonal R) */
+            const double* uk = x + p->v[e->vert[0]].off;
+            for (int i = 0; i < d->nu; ++i) out[i] = p->sr[i] * uk[i];
+            break;
+        }
+        case E_FINAL_COST: { /* optimal_control/src/functions/final_state_cost.cpp:72-92 */
+            const double* xk = x + p->v[e->vert[0]].off;
+            for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - p->xref[i]);
+            break;
+        }
+        case E_DT_COST: /* optimal_control/include/corbo-optimal-control/functions/minimum_time.h:70-78 */
+            out[0] = p->dt_weight * x[p->v[e->vert[0]].off];
+            break;
+        case E_DEFECT: { /* FDCollocationEdge / MSVariableDynamicsOnlyEdge ::computeValues */
+            const double* x1 = x + p->v[e->vert[0]].off;
+            const double* u1 = x + p->v[e->vert[1]].off;
+            const double* x2 = x + p->v[e->vert[2]].off;
+            double dt        = x[p->v[e->vert[3]].off];
+            defect_values(p, x1, u1, x2, dt, out);
+            break;
+        }
+        case E_STAGE_INEQ: { /* user StageInequalityConstraint (state term), keep-out ball: c = r^2 - |pos - c|^2 <= 0 */
+            const double* xk = x + p->v[e->vert[0]].off;
+            double dx = xk[0] - d->ineq_params[0], dy = xk[1] - d->ineq_params[1], dz = xk[2] - d->ineq_params[2];
+            out[0] = d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
+            break;
+        }
+        default: break;
+    }
+}
+
+/* BaseEdge::computeJacobian (optimization/src/hyper_graph/edge_interface.cpp:55-96): central differences, delta=1e-9,
+ * the vertex is perturbed IN PLACE and reverted by a third addition (not exact in floating point). */
+static void edge_jacobian(oracle_problem* p, const o_edge* e, int vtx_idx, double* block /* dim x n_unfixed, col-major */)
+{
+    const double delta     = 1e-9;
+    const double neg2delta = -2 * delta;
+    const double scalar    = 1.0 / (2 * delta);
+    const o_vertex* v      = &p->v[e->vert[vtx_idx]];
+    double values1[CORBO_HIP_MAX_NX], values2[CORBO_HIP_MAX_NX];
+    int col_idx = 0;
+    for (int i = 0; i < v->dim; ++i) {
+        if (v->fixed & (1u << i)) continue;
+        p->x[v->off + i] += delta;
+        edge_values(p, e, values2);
+        p->x[v->off + i] += neg2delta;
+        edge_values(p, e, values1);
+        for (int j = 0; j < e->dim; ++j) block[col_idx * e->dim + j] = scalar * (values2[j] - values1[j]);
+        p->x[v->off + i] += delta;
+        ++col_idx;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* graph construction                                                                                             */
+
+static int is_finite_bound(double lb, double ub) { return lb > -CORBO_HIP_INF || ub < CORBO_HIP_INF; } /* vector_vertex.h:174-184 */
+
+static int validate(const corbo_hip_problem_desc* d)
+{
+    if (!d) return 0;
+    if (d->nx < 1 || d->nx > CORBO_HIP_MAX_NX || d->nu < 1 || d->nu > CORBO_HIP_MAX_NU || d->N < 2) return 0;
+    if (d->grid < 0 || d->grid > CORBO_HIP_GRID_MS) return 0;
+    if (d->defect < 0 || d->defect > CORBO_HIP_DEFECT_RK4_SHOOTING) return 0;
+    if ((d->grid == CORBO_HIP_GRID_MS) != (d->defect == CORBO_HIP_DEFECT_RK4_SHOOTING)) return 0;
+    switch (d->dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: if (d->nx != 2 || d->nu != 1) return 0; break;
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d->nu != 1) return 0; break;
+        case CORBO_HIP_DYN_UNICYCLE: if (d->nx != 3 || d->nu != 2) return 0; break;
+        case CORBO_HIP_DYN_QUADROTOR: if (d->nx != 12 || d->nu != 4) return 0; break;
+        default: return 0;
+    }
+    if (d->stage_cost < 0 || d->stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return 0;
+    if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
+    if (d->stage_ineq == CORBO_HIP_INEQ_BALL && d->nx < 3) return 0;
+    if (!(d->dt_ref > 0)) return 0;
+    return 1;
+}
+
+static int dt_is_free(const corbo_hip_problem_desc* d) { return d->grid == CORBO_HIP_GRID_FD_VARIABLE; }
+
+oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
+{
+    if (!validate(desc)) return NULL;
+    oracle_problem* p = (oracle_problem*)calloc(1, sizeof(oracle_problem));
+    p->d              = *desc;
+    const corbo_hip_problem_desc* d = &p->d;
+    int nx = d->nx, nu = d->nu, N = d->N, s = nx + nu;
+    int free_dt = dt_is_free(d);
+
+    /* ---- vertices: x_0 u_0 | ... | x_{N-2} u_{N-2} | x_f | dt   (full_discretization_grid_base.cpp:134-179) */
+    p->n_vertices = 2 * (N - 1) + 2;
+    p->v          = (o_vertex*)calloc(p->n_vertices, sizeof(o_vertex));
+    int nv = (N - 1) * s + nx + 1; /* storage always holds dt (fixed dt: not part of the public vertex layout) */
+    for (int k = 0; k < N - 1; ++k) {
+        o_vertex* xv = &p->v[2 * k];
+        o_vertex* uv = &p->v[2 * k + 1];
+        xv->off = k * s;       xv->dim = nx; xv->fixed = (k == 0) ? ((1u << nx) - 1) : 0; /* x_seq.front().setFixed(true) :170 */
+        uv->off = k * s + nx;  uv->dim = nu; uv->fixed = 0;
+    }
+    o_vertex* xf = &p->v[2 * (N - 1)];
+    xf->off = (N - 1) * s; xf->dim = nx; xf->fixed = d->xf_fixed_mask & ((1u << nx) - 1);
+    o_vertex* dtv = &p->v[2 * (N - 1) + 1];
+    dtv->off = (N - 1) * s + nx; dtv->dim = 1; dtv->fixed = free_dt ? 0 : 1; /* _dt.set(.., isDtFixedIntended()) :173 */
+    /* active vertices + column indices (full_discretization_grid_base.cpp:514-527, vertex_set.cpp:405-418) */
+    int col = 0;
+    for (int i = 0; i < p->n_vertices; ++i) {
+        o_vertex* v  = &p->v[i];
+        v->n_unfixed = 0;
+        for (int c = 0; c < v->dim; ++c)
+            if (!(v->fixed & (1u << c))) v->n_unfixed++;
+        if (v->n_unfixed > 0) { v->col = col; col += v->n_unfixed; }
+        else v->col = -1;
+    }
+    int n = col;
+
+    p->x      = (double*)calloc(nv, sizeof(double));
+    p->lb     = (double*)calloc(nv, sizeof(double));
+    p->ub     = (double*)calloc(nv, sizeof(double));
+    p->backup = (double*)calloc(nv, sizeof(double));
+    p->xref   = (double*)calloc(nx, sizeof(double));
+    for (int i = 0; i < nx; ++i) { p->sq[i] = sqrt(d->q_diag[i]); p->sqf[i] = sqrt(d->qf_diag[i]); } /* quadratic_cost.cpp:59-67 */
+    for (int i = 0; i < nu; ++i) p->sr[i] = sqrt(d->r_diag[i]);
+    p->dt_weight = sqrt((double)(N - 1)); /* minimum_time.h:60 (single dt, lsq form) */
+
+    /* ---- edges in creation order (finite_differences_grid.cpp:38-154 / multiple_shooting_grid.cpp:38-197,
+     *      nlp_functions.cpp:70-132: state term, control term, dt term (twice!), ...) */
+    int max_edges = 6 * N + 8;
+    o_edge* lsq   = (o_edge*)calloc(max_edges, sizeof(o_edge));
+    o_edge* eq    = (o_edge*)calloc(max_edges, sizeof(o_edge));
+    o_edge* ineq  = (o_edge*)calloc(max_edges, sizeof(o_edge));
+    int n_lsq = 0, n_eq = 0, n_ineq = 0;
+    int dt_vertex = 2 * (N - 1) + 1;
+    for (int k = 0; k < N - 1; ++k) {
+        int xk = 2 * k, uk = 2 * k + 1, xnext = 2 * (k + 1); /* x_next = (k < n-2) ? x_seq[k+1] : xf */
+        if (d->stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) {
+            o_edge* e = &lsq[n_lsq++]; e->type = E_STATE_COST; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = nx; e->scale = 0;
+            e = &lsq[n_lsq++]; e->type = E_CONTROL_COST; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = nu; e->scale = 0;
+        }
+        else if (d->stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ && k == 0) {
+            for (int rep = 0; rep < 2; ++rep) { /* duplicated dt edge, nlp_functions.cpp:91-107 */
+                o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0;
+            }
+        }
+        if (d->stage_ineq == CORBO_HIP_INEQ_BALL) {
+            o_edge* e = &ineq[n_ineq++]; e->type = E_STAGE_INEQ; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = 1; e->scale = 2;
+        }
+        o_edge* e = &eq[n_eq++]; e->type = E_DEFECT; e->k = k; e->nverts = 4; e->dim = nx; e->scale = 1;
+        e->vert[0] = xk; e->vert[1] = uk; e->vert[2] = xnext; e->vert[3] = dt_vertex;
+    }
+    if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_cost) { /* if (!_xf.isFixed()) ... getFinalStateCostEdge */
+        o_edge* e = &lsq[n_lsq++]; e->type = E_FINAL_COST; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 0;
+    }
+    /* row indices: [lsq | eq | ineq | bounds] (edge_set.cpp:31-42, hyper_graph_optimization_problem_edge_based.cpp:1491-1493) */
+    p->n_edges = n_lsq + n_eq + n_ineq;
+    p->e       = (o_edge*)calloc(p->n_edges, sizeof(o_edge));
+    int row = 0, ne = 0;
+    for (int i = 0; i < n_lsq; ++i) { lsq[i].row = row; row += lsq[i].dim; p->e[ne++] = lsq[i]; }
+    int dim_lsq = row;
+    for (int i = 0; i < n_eq; ++i) { eq[i].row = row; row += eq[i].dim; p->e[ne++] = eq[i]; }
+    int dim_eq = row - dim_lsq;
+    for (int i = 0; i < n_ineq; ++i) { ineq[i].row = row; row += ineq[i].dim; p->e[ne++] = ineq[i]; }
+    int dim_ineq = row - dim_lsq - dim_eq;
+    free(lsq); free(eq); free(ineq);
+
+    /* default bounds from the descriptor (needed for the bound-row structure) */
+    for (int k = 0; k < N - 1; ++k) {
+        for (int i = 0; i < nx; ++i) { p->lb[k * s + i] = d->x_lb[i]; p->ub[k * s + i] = d->x_ub[i]; }
+        for (int i = 0; i < nu; ++i) { p->lb[k * s + nx + i] = d->u_lb[i]; p->ub[k * s + nx + i] = d->u_ub[i]; }
+    }
+    for (int i = 0; i < nx; ++i) { p->lb[(N - 1) * s + i] = d->x_lb[i]; p->ub[(N - 1) * s + i] = d->x_ub[i]; }
+    p->lb[(N - 1) * s + nx] = free_dt ? d->dt_lb : -CORBO_HIP_INF;
+    p->ub[(N - 1) * s + nx] = free_dt ? d->dt_ub : CORBO_HIP_INF;
+    p->x[(N - 1) * s + nx]  = d->dt_ref;
+
+    /* ---- Jacobian blocks in the reference's sweep order (…edge_based.cpp:1495-1617): edge lists in order, attached
+     *      vertices in order, skipping vertices without unfixed components */
+    int max_blocks = 4 * p->n_edges;
+    p->b           = (o_block*)calloc(max_blocks, sizeof(o_block));
+    int nnz = 0, nb = 0;
+    for (int i = 0; i < p->n_edges; ++i) {
+        const o_edge* e = &p->e[i];
+        for (int vi = 0; vi < e->nverts; ++vi) {
+            const o_vertex* v = &p->v[e->vert[vi]];
+            if (v->n_unfixed == 0) continue;
+            o_block* b = &p->b[nb++];
+            b->edge = i; b->vtx_idx = vi; b->row0 = e->row; b->col0 = v->col; b->rows = e->dim; b->cols = v->n_unfixed; b->off = nnz;
+            nnz += b->rows * b->cols;
+        }
+    }
+    p->n_blocks        = nb;
+    p->first_bound_nnz = nnz;
+    /* bound rows: one per unfixed component with a finite bound, active-vertex order (…base.cpp:291-315) */
+    p->bound_vert_off = (int*)calloc(n, sizeof(int));
+    p->bound_col      = (int*)calloc(n, sizeof(int));
+    p->param_off      = (int*)calloc(n, sizeof(int));
+    int n_bounds = 0;
+    for (int i = 0; i < p->n_vertices; ++i) {
+        const o_vertex* v = &p->v[i];
+        if (v->n_unfixed == 0) continue;
+        int free_idx = 0;
+        for (int c = 0; c < v->dim; ++c) {
+            if (v->fixed & (1u << c)) continue;
+            p->param_off[v->col + free_idx] = v->off + c;
+            if (is_finite_bound(p->lb[v->off + c], p->ub[v->off + c])) {
+                p->bound_vert_off[n_bounds] = v->off + c;
+                p->bound_col[n_bounds]      = v->col + free_idx;
+                ++n_bounds;
+            }
+            ++free_idx;
+        }
+    }
+    nnz += n_bounds;
+
+    p->dims.nv     = free_dt ? nv : nv - 1;
+    p->dims.n      = n;
+    p->dims.lsq    = dim_lsq;
+    p->dims.eq     = dim_eq;
+    p->dims.ineq   = dim_ineq;
+    p->dims.bounds = n_bounds;
+    p->dims.m      = dim_lsq + dim_eq + dim_ineq + n_bounds;
+    p->dims.nnz    = nnz;
+    int m          = p->dims.m;
+
+    /* ---- static row-wise view of J */
+    int32_t* rows = (int32_t*)calloc(nnz, sizeof(int32_t));
+    int32_t* cols = (int32_t*)calloc(nnz, sizeof(int32_t));
+    oracle_get_structure(p, rows, cols);
+    p->csr_ptr = (int*)calloc(m + 1, sizeof(int));
+    p->csr_col = (int*)calloc(nnz, sizeof(int));
+    p->csr_val = (int*)calloc(nnz, sizeof(int));
+    for (int i = 0; i < nnz; ++i) p->csr_ptr[rows[i] + 1]++;
+    for (int i = 0; i < m; ++i) p->csr_ptr[i + 1] += p->csr_ptr[i];
+    int* fill = (int*)calloc(m, sizeof(int));
+    for (int i = 0; i < nnz; ++i) {
+        int r = rows[i], pos = p->csr_ptr[r] + fill[r]++;
+        p->csr_col[pos] = cols[i];
+        p->csr_val[pos] = i;
+    }
+    for (int r = 0; r < m; ++r) /* sort every row by column (insertion sort, rows are short) */
+        for (int a = p->csr_ptr[r] + 1; a < p->csr_ptr[r + 1]; ++a) {
+            int c = p->csr_col[a], vv = p->csr_val[a], b2 = a - 1;
+            while (b2 >= p->csr_ptr[r] && p->csr_col[b2] > c) { p->csr_col[b2 + 1] = p->csr_col[b2]; p->csr_val[b2 + 1] = p->csr_val[b2]; --b2; }
+            p->csr_col[b2 + 1] = c; p->csr_val[b2 + 1] = vv;
+        }
+    free(fill); free(rows); free(cols);
+    /* ---- envelope of H = J^T J */
+    p->env_first = (int*)calloc(n, sizeof(int));
+    p->env_ptr   = (int*)calloc(n + 1, sizeof(int));
+    for (int i = 0; i < n; ++i) p->env_first[i] = i;
+    for (int r = 0; r < m; ++r) {
+        if (p->csr_ptr[r] == p->csr_ptr[r + 1]) continue;
+        int cmin = p->csr_col[p->csr_ptr[r]];
+        for (int a = p->csr_ptr[r]; a < p->csr_ptr[r + 1]; ++a)
+            if (cmin < p->env_first[p->csr_col[a]]) p->env_first[p->csr_col[a]] = cmin;
+    }
+    for (int i = 0; i < n; ++i) p->env_ptr[i + 1] = p->env_ptr[i] + (i - p->env_first[i] + 1);
+    p->env_size = p->env_ptr[n];
+
+    p->values = (double*)calloc(m, sizeof(double));
+    p->jac    = (double*)calloc(nnz, sizeof(double));
+    p->H      = (double*)calloc(p->env_size, sizeof(double));
+    p->L      = (double*)calloc(p->env_size, sizeof(double));
+    p->rhs    = (double*)calloc(n, sizeof(double));
+    p->delta  = (double*)calloc(n, sizeof(double));
+    p->tmp    = (double*)calloc(n, sizeof(double));
+    p->w_eq = p->w_ineq = p->w_b = 2; /* levenberg_marquardt_sparse.h:126-128 */
+    return p;
+}
+
+void oracle_destroy(oracle_problem* p)
+{
+    if (!p) return;
+    free(p->v); free(p->e); free(p->b); free(p->bound_vert_off); free(p->bound_col); free(p->param_off);
+    free(p->x); free(p->lb); free(p->ub); free(p->xref); free(p->backup);
+    free(p->csr_ptr); free(p->csr_col); free(p->csr_val); free(p->env_first); free(p->env_ptr);
+    free(p->values); free(p->jac); free(p->H); free(p->L); free(p->rhs); free(p->delta); free(p->tmp);
+    free(p);
+}
+
+int oracle_get_dims(const oracle_problem* p, corbo_hip_dims* dims)
+{
+    if (!p || !dims) return CORBO_HIP_ERR_INVALID;
+    *dims = p->dims;
+    return 0;
+}
+
+int oracle_get_structure(const oracle_problem* p, int32_t* rows, int32_t* cols)
+{
+    if (!p) return CORBO_HIP_ERR_INVALID;
+    for (int i = 0; i < p->n_blocks; ++i) {
+        const o_block* b = &p->b[i];
+        for (int c = 0; c < b->cols; ++c)
+            for (int r = 0; r < b->rows; ++r) {
+                rows[b->off + c * b->rows + r] = b->row0 + r;
+                cols[b->off + c * b->rows + r] = b->col0 + c;
+            }
+    }
+    int bounds_row0 = p->dims.lsq + p->dims.eq + p->dims.ineq;
+    for (int i = 0; i < p->dims.bounds; ++i) {
+        rows[p->first_bound_nnz + i] = bounds_row0 + i;
+        cols[p->first_bound_nnz + i] = p->bound_col[i];
+    }
+    return 0;
+}
+
+int oracle_init_trajectory(const corbo_hip_problem_desc* d, const double* x0, const double* xf, double* x_out)
+{
+    /* full_discretization_grid_base.cpp:134-179 (shooting_grid_base.cpp:141-214 is identical for 1 control/interval) */
+    if (!validate(d)) return CORBO_HIP_ERR_INVALID;
+    int nx = d->nx, nu = d->nu, N = d->N, s = nx + nu;
+    int num_intervals = N - 1;
+    double dir[CORBO_HIP_MAX_NX];
+    double sq = 0;
+    for (int i = 0; i < nx; ++i) { dir[i] = xf[i] - x0[i]; sq += dir[i] * dir[i]; }
+    double dist = sqrt(sq);
+    if (dist != 0)
+        for (int i = 0; i < nx; ++i) dir[i] /= dist;
+    double step = dist / num_intervals;
+    for (int k = 0; k < num_intervals; ++k) {
+        for (int i = 0; i < nx; ++i) x_out[k * s + i] = x0[i] + (double)k * step * dir[i];
+        for (int i = 0; i < nu; ++i) x_out[k * s + nx + i] = 0.0; /* uref = ZeroReference */
+    }
+    for (int i = 0; i < nx; ++i) x_out[(N - 1) * s + i] = xf[i];
+    if (dt_is_free(d)) x_out[(N - 1) * s + nx] = d->dt_ref;
+    return 0;
+}
+
+int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const double* ub, const double* xref)
+{
+    if (!p || !x) return CORBO_HIP_ERR_INVALID;
+    int nvp = p->dims.nv;
+    memcpy(p->x, x, nvp * sizeof(double));
+    if (!dt_is_free(&p->d)) p->x[nvp] = p->d.dt_ref;
+    if (lb) memcpy(p->lb, lb, nvp * sizeof(double));
+    if (ub) memcpy(p->ub, ub, nvp * sizeof(double));
+    for (int i = 0; i < p->d.nx; ++i) p->xref[i] = xref ? xref[i] : 0.0;
+    return 0;
+}
+
+int oracle_get_x(const oracle_problem* p, double* x_out)
+{
+    if (!p || !x_out) return CORBO_HIP_ERR_INVALID;
+    memcpy(x_out, p->x, p->dims.nv * sizeof(double));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* stacked residual and combined Jacobian                                                                         */
+
+/* LevenbergMarquardtSparse::computeValues (optimization/src/solver/levenberg_marquardt_sparse.cpp:222-246) on top of
+ * BaseHyperGraphOptimizationProblem::computeValues{LsqObjective,Equality,ActiveInequality},
+ * computeDistanceFiniteCombinedBounds (hyper_graph_optimization_problem_base.cpp:106-125,162-180,278-315) */
+static void compute_values(oracle_problem* p, double w_eq, double w_ineq, double w_b, double* values)
+{
+    for (int i = 0; i < p->n_edges; ++i) {
+        const o_edge* e = &p->e[i];
+        edge_values(p, e, values + e->row);
+        if (e->scale == 1)
+            for (int j = 0; j < e->dim; ++j) values[e->row + j] *= w_eq;
+        else if (e->scale == 2)
+            for (int j = 0; j < e->dim; ++j) {
+                if (values[e->row + j] < 0) values[e->row + j] = 0;
+                else values[e->row + j] *= w_ineq;
+            }
+    }
+    int row0 = p->dims.lsq + p->dims.eq + p->dims.ineq;
+    for (int i = 0; i < p->dims.bounds; ++i) {
+        int o = p->bound_vert_off[i];
+        double v;
+        if (p->x[o] < p->lb[o]) v = p->lb[o] - p->x[o];
+        else if (p->x[o] > p->ub[o]) v = p->x[o] - p->ub[o];
+        else v = 0;
+        values[row0 + i] = v * w_b;
+    }
+}
+
+/* HyperGraphOptimizationProblemEdgeBased::computeCombinedSparseJacobian
+ * (optimization/src/hyper_graph/hyper_graph_optimization_problem_edge_based.cpp:1480-1753) */
+static void compute_jacobian(oracle_problem* p, double w_eq, double w_ineq, double w_b, const double* values, double* jac)
+{
+    double block[CORBO_HIP_MAX_NX * CORBO_HIP_MAX_NX];
+    for (int i = 0; i < p->n_blocks; ++i) {
+        const o_block* b = &p->b[i];
+        const o_edge* e  = &p->e[b->edge];
+        edge_jacobian(p, e, b->vtx_idx, block);
+        for (int c = 0; c < b->cols; ++c)
+            for (int r = 0; r < b->rows; ++r) {
+                double v = block[c * b->rows + r];
+                if (e->scale == 1) v = v * w_eq;                                        /* :1552 */
+                else if (e->scale == 2) v = (values[e->row + r] > 0.0) ? v * w_ineq : 0.0; /* :1568-1610 */
+                jac[b->off + c * b->rows + r] = v;
+            }
+    }
+    for (int i = 0; i < p->dims.bounds; ++i) { /* :1721-1752 */
+        int o = p->bound_vert_off[i];
+        double v;
+        if (p->x[o] < p->lb[o]) v = -w_b;
+        else if (p->x[o] > p->ub[o]) v = w_b;
+        else v = 0.0;
+        jac[p->first_bound_nnz + i] = v;
+    }
+}
+
+int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_b, double* values, double* jac)
+{
+    if (!p || !values) return CORBO_HIP_ERR_INVALID;
+    compute_values(p, w_eq, w_ineq, w_b, values);
+    if (jac) compute_jacobian(p, w_eq, w_ineq, w_b, values, jac);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* H = J^T J, rhs = J^T (-values)  (levenberg_marquardt_sparse.cpp:97-100): each H(i,j) is accumulated over the    */
+/* rows of J in ascending order, which is the order Eigen's conservative sparse product produces.                 */
+
+static void build_hessian_rhs(oracle_problem* p)
+{
+    int n = p->dims.n, m = p->dims.m;
+    memset(p->H, 0, p->env_size * sizeof(double));
+    memset(p->rhs, 0, n * sizeof(double));
+    for (int r = 0; r < m; ++r) {
+        double nv = -p->values[r];
+        for (int a = p->csr_ptr[r]; a < p->csr_ptr[r + 1]; ++a) {
+            int ca    = p->csr_col[a];
+            double va = p->jac[p->csr_val[a]];
+            p->rhs[ca] += va * nv;
+            for (int b = p->csr_ptr[r]; b <= a; ++b) {
+                int cb = p->csr_col[b]; /* cb <= ca */
+                p->H[p->env_ptr[ca] + (cb - p->env_first[ca])] += va * p->jac[p->csr_val[b]];
+            }
+        }
+    }
+}
+
+/* envelope Cholesky H = L L^T (natural order) and solve; replaces Eigen::SimplicialLLT (:140-148). */
+static void factor_solve(oracle_problem* p)
+{
+    int n = p->dims.n;
+    const int *first = p->env_first, *ptr = p->env_ptr;
+    double* L = p->L;
+    memcpy(L, p->H, p->env_size * sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        double* Li = L + ptr[i] - first[i]; /* Li[j] = L(i,j) */
+        for (int j = first[i]; j < i; ++j) {
+            const double* Lj = L + ptr[j] - first[j];
+            int k0   = first[i] > first[j] ? first[i] : first[j];
+            double s = Li[j];
+            for (int k = k0; k < j; ++k) s -= Li[k] * Lj[k];
+            Li[j] = s / Lj[j];
+        }
+        double dsum = Li[i];
+        for (int k = first[i]; k < i; ++k) dsum -= Li[k] * Li[k];
+        Li[i] = sqrt(dsum);
+    }
+    double* y = p->delta;
+    for (int i = 0; i < n; ++i) { /* L y = rhs */
+        const double* Li = L + ptr[i] - first[i];
+        double s = p->rhs[i];
+        for (int k = first[i]; k < i; ++k) s -= Li[k] * y[k];
+        y[i] = s / Li[i];
+    }
+    for (int i = n - 1; i >= 0; --i) { /* L^T x = y (column sweep) */
+        const double* Li = L + ptr[i] - first[i];
+        y[i] /= Li[i];
+        for (int k = first[i]; k < i; ++k) y[k] -= Li[k] * y[i];
+    }
+}
+
+static double squared_norm(const double* v, int n)
+{
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += v[i] * v[i];
+    return s;
+}
+
+/* LevenbergMarquardtSparse::solve (optimization/src/solver/levenberg_marquardt_sparse.cpp:44-220) */
+int oracle_solve(oracle_problem* p, const corbo_hip_lm_opts* o, int new_run, double* chi2_out, oracle_trace_entry* trace)
+{
+    if (!p || !o) return CORBO_HIP_SOLVER_ERROR;
+    int n = p->dims.n, m = p->dims.m, nvs = p->dims.nv + (dt_is_free(&p->d) ? 0 : 1);
+    if (chi2_out) *chi2_out = -1;
+    /* adapt weights :83-86, :270-287 */
+    if (new_run) { p->w_eq = o->weight_eq; p->w_ineq = o->weight_ineq; p->w_b = o->weight_bounds; }
+    else {
+        p->w_eq *= o->adapt_factor_eq;       if (p->w_eq > o->adapt_max_eq) p->w_eq = o->adapt_max_eq;
+        p->w_ineq *= o->adapt_factor_ineq;   if (p->w_ineq > o->adapt_max_ineq) p->w_ineq = o->adapt_max_ineq;
+        p->w_b *= o->adapt_factor_bounds;    if (p->w_b > o->adapt_max_bounds) p->w_b = o->adapt_max_bounds;
+    }
+    double w_eq = p->w_eq, w_ineq = p->w_ineq, w_b = p->w_b;
+
+    compute_values(p, w_eq, w_ineq, w_b, p->values);                 /* :89 */
+    compute_jacobian(p, w_eq, w_ineq, w_b, p->values, p->jac);      /* :92 */
+    build_hessian_rhs(p);                                            /* :97-100 */
+
+    const double eps1 = 1e-5, eps2 = 1e-5, eps3 = 1e-5, eps4 = 0;
+    unsigned int v = 2;
+    double tau = 1e-5;
+    const double goodStepUpperScale = 2. / 3., goodStepLowerScale = 1. / 3.;
+
+    double rhs_inf = 0;
+    for (int i = 0; i < n; ++i) if (fabs(p->rhs[i]) > rhs_inf) rhs_inf = fabs(p->rhs[i]);
+    int stop = (rhs_inf <= eps1);                                    /* :115 */
+    double maxdiag = p->H[p->env_ptr[0] + (0 - p->env_first[0])];
+    for (int i = 0; i < n; ++i) { double dgl = p->H[p->env_ptr[i] + (i - p->env_first[i])]; if (dgl > maxdiag) maxdiag = dgl; }
+    double mu = tau * maxdiag;                                       /* :117 */
+    if (mu < 0) mu = 0;
+    double rho      = 0;
+    double chi2_old = squared_norm(p->values, m);                    /* :125 */
+    if (chi2_out) *chi2_out = chi2_old;
+
+    for (int k = 0; k < o->iterations; ++k) {                        /* :129 */
+        int inner = 0, accepted = 0;
+        double dnorm = 0;
+        do {
+            ++inner;
+            for (int i = 0; i < n; ++i) p->H[p->env_ptr[i] + (i - p->env_first[i])] += mu; /* :135-138 (never undone) */
+            factor_solve(p);                                         /* :147-148 */
+            dnorm = sqrt(squared_norm(p->delta, n));
+            if (dnorm <= eps2) { stop = 1; }                         /* :151-154 */
+            else {
+                memcpy(p->backup, p->x, nvs * sizeof(double));       /* backupParameters :158 */
+                for (int i = 0; i < n; ++i) p->x[p->param_off[i]] += p->delta[i]; /* applyIncrement :161 */
+                compute_values(p, w_eq, w_ineq, w_b, p->values);     /* :164 */
+                double chi2_new = squared_norm(p->values, m);
+                double den = 0;
+                for (int i = 0; i < n; ++i) den += p->delta[i] * (mu * p->delta[i] + p->rhs[i]);
+                rho = (chi2_old - chi2_new) / den;                   /* :169 */
+                if (rho > 0 && !isnan(chi2_new) && !isinf(chi2_new)) { /* :171 */
+                    stop = (sqrt(chi2_old) - sqrt(chi2_new) < eps4 * sqrt(chi2_old));
+                    accepted = 1;                                    /* discardBackupParameters :176 */
+                    if (!stop && k < o->iterations - 1) {            /* :178 */
+                        compute_jacobian(p, w_eq, w_ineq, w_b, p->values, p->jac);
+                        build_hessian_rhs(p);
+                        rhs_inf = 0;
+                        for (int i = 0; i < n; ++i) if (fabs(p->rhs[i]) > rhs_inf) rhs_inf = fabs(p->rhs[i]);
+                        stop = stop || (rhs_inf <= eps1);
+                        double alpha       = fmin(goodStepUpperScale, 1 - pow((2 * rho - 1), 3));
+                        double scaleFactor = fmax(goodStepLowerScale, alpha);
+                        mu *= scaleFactor;
+                        v = 2;
+                    }
+                    chi2_old = chi2_new;
+                    if (chi2_out) *chi2_out = chi2_old;
+                }
+                else {
+                    accepted = 0;
+                    memcpy(p->x, p->backup, nvs * sizeof(double));   /* restoreBackupParameters(false) :207 */
+                    mu = mu * v;                                     /* :211-212 */
+                    v  = 2 * v;
+                }
+            }
+            if (inner >= 64) break; /* guard (not in the reference, which would spin): documented in DESIGN.md */
+        } while (rho <= 0 && !stop);
+        stop = (sqrt(squared_norm(p->values, m)) <= eps3);           /* :216 */
+        if (trace) {
+            trace[k].k = k; trace[k].inner_passes = inner; trace[k].accepted = accepted; trace[k].mu = mu; trace[k].rho = rho;
+            trace[k].chi2 = chi2_old; trace[k].delta_norm = dnorm;
+        }
+    }
+    return (stop || rho <= 0) ? CORBO_HIP_SOLVER_CONVERGED : CORBO_HIP_SOLVER_EARLY_TERMINATED; /* :218 */
+}
+
+int oracle_solve_batch(const corbo_hip_problem_desc* desc, int batch, double* x, const double* xref, const corbo_hip_lm_opts* opts,
+                       double* chi2_out, int32_t* status_out)
+{
+    oracle_problem* p = oracle_create(desc);
+    if (!p) return CORBO_HIP_ERR_INVALID;
+    int nv = p->dims.nv, nx = desc->nx;
+    for (int b = 0; b < batch; ++b) {
+        oracle_set_data(p, x + (size_t)b * nv, NULL, NULL, xref ? xref + (size_t)b * nx : NULL);
+        double chi2;
+        int st = oracle_solve(p, opts, 1, &chi2, NULL);
+        oracle_get_x(p, x + (size_t)b * nv);
+        if (chi2_out) chi2_out[b] = chi2;
+        if (status_out) status_out[b] = st;
+    }
+    oracle_destroy(p);
+    return 0;
+}

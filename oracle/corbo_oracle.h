@@ -1,0 +1,63 @@
+/*
+ * corbo_oracle.h -- TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C99) of the reference's hypergraph
+ * NLP inner loop.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The product (control_box_rst_amd/) never links, imports or calls it.
+ *
+ * Parity status: PINNED -- checked against golden vectors produced by the genuine reference compiled from
+ * /root/reference (oracle/Makefile target `ref`, generator oracle/gen_golden.py, fixtures tests/golden/*.json).
+ *
+ * The descriptor PODs are shared with the product's public header (types only, no code).
+ */
+#ifndef CORBO_ORACLE_H_
+#define CORBO_ORACLE_H_
+
+#include "../include/corbo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_problem oracle_problem;
+
+/* per-outer-iteration trace of LevenbergMarquardtSparse::solve (for tests) */
+typedef struct oracle_trace_entry {
+    int32_t k;            /* outer iteration */
+    int32_t inner_passes; /* factorisations in this outer iteration */
+    int32_t accepted;     /* 1 if the last inner pass was accepted */
+    double mu;            /* damping after the iteration */
+    double rho;           /* last gain ratio */
+    double chi2;          /* accepted chi2 after the iteration */
+    double delta_norm;    /* |delta| of the last inner pass */
+} oracle_trace_entry;
+
+/* Build the hypergraph of one OCP instance (vertices + edges in the reference's creation order). NULL if invalid. */
+oracle_problem* oracle_create(const corbo_hip_problem_desc* desc);
+void oracle_destroy(oracle_problem* p);
+
+int oracle_get_dims(const oracle_problem* p, corbo_hip_dims* dims);
+/* (row, col) of every structural non-zero of the combined Jacobian, in the oracle's value order */
+int oracle_get_structure(const oracle_problem* p, int32_t* rows, int32_t* cols);
+
+/* FullDiscretizationGridBase::initializeSequences (full_discretization_grid_base.cpp:134-179) */
+int oracle_init_trajectory(const corbo_hip_problem_desc* desc, const double* x0, const double* xf, double* x_out);
+
+/* vertex values / bounds in vertex layout (nv doubles); lb/ub NULL = descriptor box bounds; xref NULL = zeros */
+int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const double* ub, const double* xref);
+int oracle_get_x(const oracle_problem* p, double* x_out);
+
+/* LevenbergMarquardtSparse::computeValues + computeCombinedSparseJacobian at the current x (jac may be NULL) */
+int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_bounds, double* values, double* jac);
+
+/* LevenbergMarquardtSparse::solve.  Returns corbo_hip_solver_status; *chi2_out = *obj_value.
+ * trace (may be NULL) must hold opts->iterations entries. */
+int oracle_solve(oracle_problem* p, const corbo_hip_lm_opts* opts, int new_run, double* chi2_out, oracle_trace_entry* trace);
+
+/* Convenience for the CPU baseline: solve `batch` instances one after another on the calling thread.
+ * x: [batch][nv] in/out, xref: [batch][nx], chi2_out: [batch], status_out: [batch]. */
+int oracle_solve_batch(const corbo_hip_problem_desc* desc, int batch, double* x, const double* xref, const corbo_hip_lm_opts* opts,
+                       double* chi2_out, int32_t* status_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

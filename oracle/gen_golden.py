@@ -1,0 +1,74 @@
+"""Generate tests/golden/*.json from the GENUINE reference -- TEST INFRASTRUCTURE ONLY.
+
+Runs here (build container) only: needs oracle/_ref/ref_driver, which oracle/Makefile compiles from the reference's
+own sources under /root/reference.  The fixtures are data (inputs + expected outputs); no reference source travels.
+
+    make -C oracle ref && python oracle/gen_golden.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from control_box_rst_amd import problems  # noqa: E402
+
+DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def run(mode, **kv):
+    args = [DRIVER, mode] + [f"{k}={v}" for k, v in kv.items()]
+    return json.loads(subprocess.check_output(args))
+
+
+def vec(v):
+    return ",".join(repr(float(a)) for a in v)
+
+
+def slim(d, keep_iters):
+    d = dict(d)
+    d["after_iter"] = [a for a in d["after_iter"] if a["k"] in keep_iters]
+    return d
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # cfg 3 (headline structure, single instance, the SURVEY 8c known-answer trace), cfg 1, cfg 2
+    for name, kv, keep in [
+        ("unicycle", dict(scenario="unicycle"), (1, 2, 5, 10)),
+        ("vdp", dict(scenario="vdp"), (1, 2, 5, 10)),
+        ("dint", dict(scenario="dint"), (1, 5, 10)),
+        # other collocation schemes on the small problem (finite_differences_collocation.h:119-241)
+        ("vdp_forward", dict(scenario="vdp", collocation="forward", iters=5), (1, 5)),
+        ("vdp_backward", dict(scenario="vdp", collocation="backward", iters=5), (1, 5)),
+        ("vdp_midpoint", dict(scenario="vdp", collocation="midpoint", iters=5), (1, 5)),
+        # a short unicycle horizon: cheap full check incl. every iterate
+        ("unicycle_n12", dict(scenario="unicycle", N=12, iters=6), (1, 2, 3, 4, 5, 6)),
+    ]:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
+
+    # 8 seeded cfg-3 instances (SURVEY 8d seeds): final trajectory + chi2 only
+    x0, xf = problems.unicycle_instances(8)
+    inst = []
+    for b in range(8):
+        d = run("dump", scenario="unicycle", x0=vec(x0[b]), xf=vec(xf[b]), iters=10)
+        last = d["after_iter"][-1]
+        assert last["k"] == 10
+        inst.append({"x0": d["x0"], "xf": d["xf"], "chi2": last["chi2"], "vertex": last["vertex"]})
+    with open(os.path.join(OUT, "unicycle_seeded8.json"), "w") as f:
+        json.dump({"scenario": "unicycle", "seed": 20260928, "iters": 10, "instances": inst}, f, separators=(",", ":"))
+    print("unicycle_seeded8", [round(i["chi2"], 6) for i in inst])
+
+
+if __name__ == "__main__":
+    main()

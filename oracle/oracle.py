@@ -1,0 +1,124 @@
+"""ctypes wrapper of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from control_box_rst_amd.capi import Dims, LmOpts, ProblemDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+class TraceEntry(C.Structure):
+    _fields_ = [("k", C.c_int32), ("inner_passes", C.c_int32), ("accepted", C.c_int32), ("mu", C.c_double),
+                ("rho", C.c_double), ("chi2", C.c_double), ("delta_norm", C.c_double)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.oracle_create.argtypes = [C.POINTER(ProblemDesc)]
+    lib.oracle_create.restype = C.c_void_p
+    lib.oracle_destroy.argtypes = [C.c_void_p]
+    lib.oracle_destroy.restype = None
+    lib.oracle_get_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
+    lib.oracle_get_structure.argtypes = [C.c_void_p, ip, ip]
+    lib.oracle_init_trajectory.argtypes = [C.POINTER(ProblemDesc), dp, dp, dp]
+    lib.oracle_set_data.argtypes = [C.c_void_p, dp, dp, dp, dp]
+    lib.oracle_get_x.argtypes = [C.c_void_p, dp]
+    lib.oracle_eval.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, dp, dp]
+    lib.oracle_solve.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.c_int, dp, C.POINTER(TraceEntry)]
+    lib.oracle_solve_batch.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, C.POINTER(LmOpts), dp, ip]
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleProblem:
+    """One OCP instance of the CPU restatement."""
+
+    def __init__(self, desc: ProblemDesc):
+        self.lib = load()
+        self.desc = desc
+        self.h = self.lib.oracle_create(C.byref(desc))
+        if not self.h:
+            raise ValueError("oracle_create: invalid descriptor")
+        d = Dims()
+        self.lib.oracle_get_dims(self.h, C.byref(d))
+        self.dims = d
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_destroy(self.h)
+            self.h = None
+
+    def structure(self):
+        rows = np.zeros(self.dims.nnz, np.int32)
+        cols = np.zeros(self.dims.nnz, np.int32)
+        self.lib.oracle_get_structure(self.h, rows.ctypes.data_as(C.POINTER(C.c_int32)), cols.ctypes.data_as(C.POINTER(C.c_int32)))
+        return rows, cols
+
+    def init_trajectory(self, x0, xf):
+        x0 = np.ascontiguousarray(x0, np.float64)
+        xf = np.ascontiguousarray(xf, np.float64)
+        out = np.zeros(self.dims.nv)
+        rc = self.lib.oracle_init_trajectory(C.byref(self.desc), _dp(x0), _dp(xf), _dp(out))
+        assert rc == 0
+        return out
+
+    def set_data(self, x, lb=None, ub=None, xref=None):
+        self._keep = [np.ascontiguousarray(a, np.float64) if a is not None else None for a in (x, lb, ub, xref)]
+        rc = self.lib.oracle_set_data(self.h, *[_dp(a) for a in self._keep])
+        assert rc == 0
+
+    def x(self):
+        out = np.zeros(self.dims.nv)
+        self.lib.oracle_get_x(self.h, _dp(out))
+        return out
+
+    def eval(self, w_eq, w_ineq, w_b, jacobian=True):
+        values = np.zeros(self.dims.m)
+        jac = np.zeros(self.dims.nnz) if jacobian else None
+        rc = self.lib.oracle_eval(self.h, w_eq, w_ineq, w_b, _dp(values), _dp(jac))
+        assert rc == 0
+        return values, jac
+
+    def solve(self, opts: LmOpts, new_run=True):
+        chi2 = C.c_double(0)
+        trace = (TraceEntry * max(1, opts.iterations))()
+        status = self.lib.oracle_solve(self.h, C.byref(opts), 1 if new_run else 0, C.byref(chi2), trace)
+        tr = [{f: getattr(trace[i], f) for f, _ in TraceEntry._fields_} for i in range(opts.iterations)]
+        return status, chi2.value, tr
+
+
+def solve_batch(desc: ProblemDesc, x: np.ndarray, xref: np.ndarray, opts: LmOpts):
+    """Sequential single-thread solve of a batch (CPU baseline leg). x: [B][nv] (copied), xref: [B][nx]."""
+    lib = load()
+    x = np.array(x, dtype=np.float64, order="C", copy=True)
+    xref = np.ascontiguousarray(xref, np.float64)
+    B = x.shape[0]
+    chi2 = np.zeros(B)
+    status = np.zeros(B, np.int32)
+    rc = lib.oracle_solve_batch(C.byref(desc), B, _dp(x), _dp(xref), C.byref(opts), _dp(chi2), status.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0
+    return x, chi2, status

@@ -1,0 +1,42 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle as O
+    O.build()
+    O.load()
+    return O
+
+
+def desc_for(g):
+    """Descriptor matching a golden fixture's header."""
+    from control_box_rst_amd import capi, problems
+    defect = {"forward": capi.DEFECT_FORWARD, "backward": capi.DEFECT_BACKWARD, "midpoint": capi.DEFECT_MIDPOINT,
+              "crank_nicolson": capi.DEFECT_CRANK_NICOLSON}[g.get("collocation", "crank_nicolson")]
+    if g["scenario"] == "unicycle":
+        return problems.unicycle_desc(N=g["N"], dt=g["dt"], defect=defect)
+    if g["scenario"] == "vdp":
+        return problems.vdp_desc(N=g["N"], dt=g["dt"], defect=defect)
+    if g["scenario"] == "dint":
+        return problems.dint_desc(N=g["N"], dt=g["dt"])
+    raise KeyError(g["scenario"])

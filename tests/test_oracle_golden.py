@@ -1,0 +1,121 @@
+"""Pins oracle/ (the CPU restatement) to golden vectors produced by the GENUINE reference (oracle/gen_golden.py).
+
+Tolerances (see DESIGN.md "numerical fidelity"):
+  * residual vector, Jacobian, diag(J^T J), rhs evaluated at the same x: BIT-EXACT (same operations, same order);
+  * trajectory after ONE LM iteration: 1e-11 (only the Cholesky elimination order differs from Eigen's AMD order);
+  * later iterations: 2e-6 -- the reference's delta=1e-9 central differences turn a 1-ulp change of x into a ~1e-7
+    relative change of J, so ANY rounding-level difference is amplified to that level from the 2nd iteration on.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import desc_for, load_golden
+from control_box_rst_amd import capi
+
+FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12"]
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_dimensions_and_structure(oracle_mod, name):
+    g = load_golden(name)
+    p = oracle_mod.OracleProblem(desc_for(g))
+    for k in ("n", "lsq", "eq", "ineq", "bounds", "m", "nnz"):
+        assert getattr(p.dims, k) == g[k], k
+    rows, cols = p.structure()
+    assert sorted(zip(rows.tolist(), cols.tolist())) == sorted(zip(g["jac_rows"], g["jac_cols"]))
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_values_and_jacobian_bit_exact(oracle_mod, name):
+    g = load_golden(name)
+    p = oracle_mod.OracleProblem(desc_for(g))
+    w = g["weights"]
+    # vertex_init = the vertex values the reference evaluated values_init / jac_vals at
+    p.set_data(np.array(g["vertex_init"])[: p.dims.nv], xref=np.array(g["xf"]))
+    values, jac = p.eval(*w)
+    assert np.array_equal(values, np.array(g["values_init"]))
+    rows, cols = p.structure()
+    Jo = sp.coo_matrix((jac, (rows, cols)), shape=(p.dims.m, p.dims.n)).tocsr()
+    Jr = sp.coo_matrix((g["jac_vals"], (g["jac_rows"], g["jac_cols"])), shape=(p.dims.m, p.dims.n)).tocsr()
+    assert abs(Jo - Jr).max() == 0.0
+    # parameter vector / bounds in parameter layout
+    lb, ub = np.array(g["param_lb"]), np.array(g["param_ub"])
+    assert lb.shape == (p.dims.n,) and ub.shape == (p.dims.n,)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_initial_trajectory(oracle_mod, name):
+    g = load_golden(name)
+    p = oracle_mod.OracleProblem(desc_for(g))
+    x = p.init_trajectory(g["x0"], g["xf"])
+    # the reference dump was taken after one in-place FD sweep (<= a few ulp of drift per component)
+    ref = np.array(g["vertex_init"])[: p.dims.nv]
+    assert np.abs(x - ref).max() <= 4e-15 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_lm_iterates(oracle_mod, name):
+    g = load_golden(name)
+    d = desc_for(g)
+    w = g["weights"]
+    for a in g["after_iter"]:
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(p.init_trajectory(g["x0"], g["xf"]), xref=np.array(g["xf"]))
+        opts = capi.default_lm_opts(a["k"], *w)
+        for s in range(g["solves"]):
+            status, chi2, _ = p.solve(opts, new_run=(s == 0))
+        ref = np.array(a["vertex"])[: p.dims.nv]
+        tol = 1e-11 if (a["k"] == 1 and g["solves"] == 1) else 2e-6
+        assert np.abs(p.x() - ref).max() <= tol, (name, a["k"])
+        assert abs(chi2 - a["chi2"]) <= max(1e-12, (1e-12 if tol < 1e-9 else 2e-6) * abs(a["chi2"])), (name, a["k"])
+        assert status in (capi.SOLVER_CONVERGED, capi.SOLVER_EARLY_TERMINATED)
+
+
+def test_known_answer_trace_cfg3(oracle_mod):
+    """SURVEY.md 8(c) in-text trace of the compiled reference (cfg 3, x0=0, xf=(2,1,0.5), 10 iterations)."""
+    g = load_golden("unicycle")
+    p = oracle_mod.OracleProblem(desc_for(g))
+    p.set_data(p.init_trajectory(g["x0"], g["xf"]), xref=np.array(g["xf"]))
+    status, chi2, tr = p.solve(capi.default_lm_opts(10, 10, 10, 10))
+    inner = [t["inner_passes"] for t in tr]
+    assert inner == [1, 2, 1, 1, 1, 1, 1, 1, 1, 1]           # one reject in outer iteration 1
+    assert abs(tr[0]["mu"] - 0.133340007262229) < 1e-13
+    assert abs(tr[0]["rho"] - 0.265229824450361) < 1e-12
+    assert abs(tr[0]["chi2"] - 537.633946130724) < 1e-9
+    assert abs(tr[1]["mu"] - 0.177786676349638) < 1e-12
+    assert tr[9]["mu"] == tr[8]["mu"]                          # quirk iii: no mu update in the last iteration
+    assert abs(chi2 - 42.5881167115454) < 1e-7
+    x = p.x()
+    assert np.allclose(x[-3:], [2.00038, 0.999306, 0.500001], atol=2e-6)
+    assert np.allclose(x[3:5], [1.02049, 1.00223], atol=1e-5)
+
+
+def test_seeded_instances(oracle_mod):
+    g = load_golden("unicycle_seeded8")
+    from control_box_rst_amd import problems
+    d = problems.unicycle_desc()
+    x0, xf = problems.unicycle_instances(8, seed=g["seed"])
+    for b, inst in enumerate(g["instances"]):
+        assert np.array_equal(x0[b], np.array(inst["x0"])) and np.array_equal(xf[b], np.array(inst["xf"]))
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(p.init_trajectory(x0[b], xf[b]), xref=xf[b])
+        status, chi2, _ = p.solve(capi.default_lm_opts(10, *problems.UNICYCLE_WEIGHTS))
+        ref = np.array(inst["vertex"])[: p.dims.nv]
+        assert np.abs(p.x() - ref).max() <= 5e-6, b
+        assert abs(chi2 - inst["chi2"]) <= 1e-6 * inst["chi2"], b
+
+
+def test_solve_batch_matches_single(oracle_mod):
+    from control_box_rst_amd import problems
+    d = problems.unicycle_desc(N=12)
+    x0, xf = problems.unicycle_instances(3)
+    p = oracle_mod.OracleProblem(d)
+    X = np.stack([p.init_trajectory(x0[b], xf[b]) for b in range(3)])
+    opts = capi.default_lm_opts(5, 10, 10, 10)
+    Xs, chi2, status = oracle_mod.solve_batch(d, X, xf, opts)
+    for b in range(3):
+        q = oracle_mod.OracleProblem(d)
+        q.set_data(X[b], xref=xf[b])
+        st, c, _ = q.solve(opts)
+        assert np.array_equal(q.x(), Xs[b]) and c == chi2[b] and st == status[b]
