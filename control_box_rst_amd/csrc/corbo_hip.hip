@@ -1,0 +1,455 @@
+// corbo_hip.hip -- implementation of the C-ABI declared in include/corbo_hip.h.
+//
+// Host side of the MI355X-native NLP inner loop: owns the device buffers of a batch of OCP instances, uploads the static
+// task tables (structure.hpp), and drives the pass loop  [factor_kernel -> sweep_kernel(LM trial)]  until every instance
+// has run its outer iterations (LevenbergMarquardtSparse::solve, levenberg_marquardt_sparse.cpp:129-217).  All per-instance
+// control flow (accept / reject / damping) lives on the device; the host only counts unfinished instances per pass.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/corbo_hip.h"
+#include "kernels.hpp"
+#include "structure.hpp"
+
+using namespace corbo_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(CORBO_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T>
+int upload(const std::vector<T>& v, T** dptr)
+{
+    *dptr = nullptr;
+    if (v.empty()) return 0;
+    HIP_TRY(hipMalloc((void**)dptr, v.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+constexpr int MAX_PASSES = 4096;
+
+}  // namespace
+
+struct corbo_hip_solver {
+    Structure S;
+    int batch  = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // static tables
+    RowTask* d_row_tasks     = nullptr;
+    ColTask* d_col_tasks     = nullptr;
+    BoundTask* d_bound_tasks = nullptr;
+    StageCols* d_stage_cols  = nullptr;
+    CompInfo* d_comp         = nullptr;
+    int32_t* d_ineq_cols     = nullptr;
+    int32_t* d_ineq_rows     = nullptr;
+    // per-instance data (HBM resident)
+    double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
+    double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
+    LmState* d_state      = nullptr;
+    double* d_chi2        = nullptr;  // [batch]
+    int32_t* d_counters   = nullptr;  // MAX_PASSES
+    int32_t* h_counter    = nullptr;  // pinned
+    int m_pad = 0, nnz_pad = 0;
+    bool have_data = false;
+    double w_eq = 2, w_ineq = 2, w_b = 2;  // current penalty weights (levenberg_marquardt_sparse.h:126-128)
+    corbo_hip_stats stats{};
+    bool profile = false;
+
+    SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
+    {
+        SweepParams p{};
+        p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.n_row_tasks = (int)S.row_tasks.size(); p.n_col_tasks = (int)S.col_tasks.size(); p.n_bound_tasks = (int)S.bound_tasks.size();
+        p.row_tasks = d_row_tasks; p.col_tasks = d_col_tasks; p.bound_tasks = d_bound_tasks;
+        std::memcpy(p.mp.dyn, S.desc.dyn_params, sizeof(p.mp.dyn));
+        std::memcpy(p.mp.ineq, S.desc.ineq_params, sizeof(p.mp.ineq));
+        std::memcpy(p.mp.sq, S.sq, sizeof(p.mp.sq));
+        std::memcpy(p.mp.sr, S.sr, sizeof(p.mp.sr));
+        std::memcpy(p.mp.sqf, S.sqf, sizeof(p.mp.sqf));
+        p.mp.dt_weight = S.dt_weight;
+        p.dt_fixed = S.desc.dt_ref;
+        p.mode = mode; p.iterations = iterations; p.w_eq = weq; p.w_ineq = wineq; p.w_b = wb;
+        p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
+        p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
+        p.st = d_state; p.active_count = counter; p.chi2 = d_chi2;
+        return p;
+    }
+    FactorParams factor_params() const
+    {
+        FactorParams p{};
+        p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.N = S.N; p.nx = S.nx; p.nu = S.nu; p.s = S.s; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.eq_row0 = S.eq_row0;
+        p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols; p.ineq_rows = d_ineq_rows;
+        p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
+        p.st = d_state; p.delta_out = nullptr;
+        return p;
+    }
+};
+
+extern "C" {
+
+void corbo_hip_default_lm_opts(corbo_hip_lm_opts* o)
+{
+    if (!o) return;
+    o->iterations = 10;
+    o->weight_eq = o->weight_ineq = o->weight_bounds = 2;
+    o->adapt_factor_eq = o->adapt_factor_ineq = o->adapt_factor_bounds = 1;
+    o->adapt_max_eq = o->adapt_max_ineq = o->adapt_max_bounds = 500;
+}
+
+int corbo_hip_get_dims(const corbo_hip_problem_desc* desc, corbo_hip_dims* dims)
+{
+    if (!desc || !dims) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    Structure S;
+    std::string err = build_structure(*desc, S);
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
+    *dims = S.dims;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_get_structure(const corbo_hip_problem_desc* desc, int32_t* rows, int32_t* cols)
+{
+    if (!desc || !rows || !cols) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    Structure S;
+    std::string err = build_structure(*desc, S);
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
+    std::memcpy(rows, S.jac_rows.data(), S.jac_rows.size() * sizeof(int32_t));
+    std::memcpy(cols, S.jac_cols.data(), S.jac_cols.size() * sizeof(int32_t));
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_init_trajectory(const corbo_hip_problem_desc* desc, int batch, const double* x0, const double* xf, double* x_out)
+{
+    if (!desc || !x0 || !xf || !x_out || batch < 0) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    std::string err = validate_desc(*desc);
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
+    init_trajectory(*desc, batch, x0, xf, x_out);
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out)
+{
+    if (!desc || !out || batch < 1) return fail(CORBO_HIP_ERR_INVALID, "null argument or batch < 1");
+    *out = nullptr;
+    auto* h = new corbo_hip_solver();
+    std::string err = build_structure(*desc, h->S);
+    if (!err.empty()) { delete h; return fail(CORBO_HIP_ERR_INVALID, err); }
+    const Structure& S = h->S;
+    {   // device kernels exist for this descriptor?
+        FactorParams fp{};
+        fp.N = S.N;
+        if (factor_lds_bytes(*desc, fp) == 0 || S.N > 256 || (desc->dynamics == CORBO_HIP_DYN_QUADROTOR)) {
+            delete h;
+            return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
+        }
+    }
+    h->batch  = batch;
+    h->device = device;
+    int ndev  = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete h; return fail(CORBO_HIP_ERR_DEVICE, "no HIP device visible"); }
+    if (device < 0 || device >= ndev) { delete h; return fail(CORBO_HIP_ERR_INVALID, "device index out of range"); }
+#define CREATE_TRY(expr)                                                                                                  \
+    do {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                           \
+        if (e_ != hipSuccess) { std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_); corbo_hip_destroy(h); \
+                                return fail(CORBO_HIP_ERR_DEVICE, m_); }                                                  \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    if (upload(S.row_tasks, &h->d_row_tasks) || upload(S.col_tasks, &h->d_col_tasks) || upload(S.bound_tasks, &h->d_bound_tasks) ||
+        upload(S.stage_cols, &h->d_stage_cols) || upload(S.comp, &h->d_comp) || upload(S.ineq_cols, &h->d_ineq_cols) ||
+        upload(S.ineq_rows, &h->d_ineq_rows)) {
+        std::string m = g_last_error;
+        corbo_hip_destroy(h);
+        return fail(CORBO_HIP_ERR_DEVICE, m);
+    }
+    h->m_pad   = (S.dims.m + 1) & ~1;
+    h->nnz_pad = (S.dims.nnz + 1) & ~1;
+    const size_t B = (size_t)batch;
+    CREATE_TRY(hipMalloc((void**)&h->d_x, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_xt, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_lb, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_ub, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_xref, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_values0, B * h->m_pad * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_values1, B * h->m_pad * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_jac, B * h->nnz_pad * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_state, B * sizeof(LmState)));
+    CREATE_TRY(hipMalloc((void**)&h->d_chi2, B * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_counters, MAX_PASSES * sizeof(int32_t)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_counter, sizeof(int32_t)));
+    CREATE_TRY(hipMemset(h->d_state, 0, B * sizeof(LmState)));
+    CREATE_TRY(hipMemset(h->d_values0, 0, B * h->m_pad * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_values1, 0, B * h->m_pad * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_jac, 0, B * h->nnz_pad * sizeof(double)));
+#undef CREATE_TRY
+    const char* prof = std::getenv("CORBO_HIP_PROFILE");
+    h->profile       = prof && prof[0] == '1';
+    *out             = h;
+    return CORBO_HIP_OK;
+}
+
+void corbo_hip_destroy(corbo_hip_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_row_tasks, h->d_col_tasks, h->d_bound_tasks, h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
+                    h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_counters};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->h_counter) (void)hipHostFree(h->h_counter);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref)
+{
+    if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const Structure& S = h->S;
+    const int nv = S.dims.nv, nvs = S.nvs, B = h->batch;
+    // repack the public vertex layout (nv per row) into the device vertex storage (nvs per row: + fixed dt + padding)
+    std::vector<double> buf((size_t)B * nvs, 0.0), blb((size_t)B * nvs, -CORBO_HIP_INF), bub((size_t)B * nvs, CORBO_HIP_INF);
+    std::vector<double> dlb(nvs, -CORBO_HIP_INF), dub(nvs, CORBO_HIP_INF);
+    for (int k = 0; k < S.N - 1; ++k) {
+        for (int i = 0; i < S.nx; ++i) { dlb[k * S.s + i] = S.desc.x_lb[i]; dub[k * S.s + i] = S.desc.x_ub[i]; }
+        for (int i = 0; i < S.nu; ++i) { dlb[k * S.s + S.nx + i] = S.desc.u_lb[i]; dub[k * S.s + S.nx + i] = S.desc.u_ub[i]; }
+    }
+    for (int i = 0; i < S.nx; ++i) { dlb[S.off_xf + i] = S.desc.x_lb[i]; dub[S.off_xf + i] = S.desc.x_ub[i]; }
+    if (S.dt_free) { dlb[S.off_dt] = S.desc.dt_lb; dub[S.off_dt] = S.desc.dt_ub; }
+    for (int b = 0; b < B; ++b) {
+        double* o = &buf[(size_t)b * nvs];
+        std::memcpy(o, x + (size_t)b * nv, nv * sizeof(double));
+        if (!S.dt_free) o[S.off_dt] = S.desc.dt_ref;
+        double* l = &blb[(size_t)b * nvs];
+        double* u = &bub[(size_t)b * nvs];
+        std::memcpy(l, dlb.data(), nvs * sizeof(double));
+        std::memcpy(u, dub.data(), nvs * sizeof(double));
+        if (lb) std::memcpy(l, lb + (size_t)b * nv, nv * sizeof(double));
+        if (ub) std::memcpy(u, ub + (size_t)b * nv, nv * sizeof(double));
+    }
+    std::vector<double> xr((size_t)B * CORBO_HIP_MAX_NX, 0.0);
+    if (xref)
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < S.nx; ++i) xr[(size_t)b * CORBO_HIP_MAX_NX + i] = xref[(size_t)b * S.nx + i];
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->d_x, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_xt, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_lb, blb.data(), blb.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_ub, bub.data(), bub.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_xref, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->have_data = true;
+    return CORBO_HIP_OK;
+}
+
+static int launch_sweep_checked(corbo_hip_handle h, const SweepParams& p)
+{
+    if (!launch_sweep(h->S.desc, p, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no sweep kernel for this dynamics/defect");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static int launch_factor_checked(corbo_hip_handle h, const FactorParams& p)
+{
+    if (!launch_factor(h->S.desc, p, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
+{
+    if (!h || !o) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called before corbo_hip_solve");
+    if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287)
+    if (new_run) { h->w_eq = o->weight_eq; h->w_ineq = o->weight_ineq; h->w_b = o->weight_bounds; }
+    else {
+        h->w_eq *= o->adapt_factor_eq;       if (h->w_eq > o->adapt_max_eq) h->w_eq = o->adapt_max_eq;
+        h->w_ineq *= o->adapt_factor_ineq;   if (h->w_ineq > o->adapt_max_ineq) h->w_ineq = o->adapt_max_ineq;
+        h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
+    }
+    h->stats = corbo_hip_stats{};
+    std::vector<hipEvent_t> evs;
+    auto stamp = [&]() {
+        if (!h->profile) return;
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, h->stream);
+        evs.push_back(e);
+    };
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, MAX_PASSES * sizeof(int32_t), h->stream));
+    stamp();
+    int rc = launch_sweep_checked(h, h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr));
+    if (rc) return rc;
+    stamp();
+    const FactorParams fp = h->factor_params();
+    int pass = 0;
+    int remaining = (o->iterations > 0) ? h->batch : 0;
+    int chunk = o->iterations;  // every instance needs at least `iterations` passes
+    while (remaining > 0 && pass < MAX_PASSES) {
+        for (int c = 0; c < chunk && pass < MAX_PASSES; ++c, ++pass) {
+            rc = launch_factor_checked(h, fp);
+            if (rc) return rc;
+            stamp();
+            rc = launch_sweep_checked(h, h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass));
+            if (rc) return rc;
+            stamp();
+        }
+        HIP_TRY(hipMemcpyAsync(h->h_counter, h->d_counters + (pass - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        remaining = *h->h_counter;
+        chunk     = 1;
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));
+    h->stats.passes = pass;
+    if (h->profile && evs.size() >= 3) {
+        // evs: [start, after init sweep, after factor, after sweep, after factor, ...]
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, evs[0], evs[1]);
+        h->stats.sweep_ms += ms;
+        for (size_t i = 2; i < evs.size(); ++i) {
+            (void)hipEventElapsedTime(&ms, evs[i - 1], evs[i]);
+            if (i % 2 == 0) h->stats.factor_ms += ms; else h->stats.sweep_ms += ms;
+        }
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (remaining > 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_synchronize(corbo_hip_handle h)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, int32_t* status_out)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const Structure& S = h->S;
+    const int B = h->batch;
+    if (x_out) {
+        std::vector<double> buf((size_t)B * S.nvs);
+        HIP_TRY(hipMemcpy(buf.data(), h->d_x, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) std::memcpy(x_out + (size_t)b * S.dims.nv, &buf[(size_t)b * S.nvs], S.dims.nv * sizeof(double));
+    }
+    if (chi2_out || status_out) {
+        std::vector<LmState> st(B);
+        HIP_TRY(hipMemcpy(st.data(), h->d_state, (size_t)B * sizeof(LmState), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            if (chi2_out) chi2_out[b] = st[b].chi2_old;
+            if (status_out) status_out[b] = st[b].status;
+        }
+    }
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
+{
+    if (!h || !stats) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<LmState> st(h->batch);
+    HIP_TRY(hipMemcpy(st.data(), h->d_state, (size_t)h->batch * sizeof(LmState), hipMemcpyDeviceToHost));
+    corbo_hip_stats s = h->stats;
+    s.lm_iterations = s.accepted_steps = s.rejected_steps = s.jacobian_sweeps = s.residual_sweeps = s.factorizations = 0;
+    for (const LmState& a : st) {
+        s.lm_iterations += a.k;
+        s.accepted_steps += a.n_accept;
+        s.rejected_steps += a.n_reject;
+        s.jacobian_sweeps += a.n_jac;
+        s.residual_sweeps += a.n_res;
+        s.factorizations += a.n_fact;
+    }
+    *stats = s;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_eval(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, double* values_out, double* jac_out)
+{
+    if (!h || !values_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = launch_sweep_checked(h, h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr));
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const Structure& S = h->S;
+    const int B = h->batch;
+    std::vector<double> buf((size_t)B * h->m_pad);
+    HIP_TRY(hipMemcpy(buf.data(), h->d_values0, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) std::memcpy(values_out + (size_t)b * S.dims.m, &buf[(size_t)b * h->m_pad], S.dims.m * sizeof(double));
+    if (jac_out) {
+        buf.resize((size_t)B * h->nnz_pad);
+        HIP_TRY(hipMemcpy(buf.data(), h->d_jac, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) std::memcpy(jac_out + (size_t)b * S.dims.nnz, &buf[(size_t)b * h->nnz_pad], S.dims.nnz * sizeof(double));
+    }
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev, void** hip_stream)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (x_dev) *x_dev = h->d_x;
+    if (chi2_dev) *chi2_dev = h->d_chi2;
+    if (hip_stream) *hip_stream = (void*)h->stream;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat, float* ms_per_launch)
+{
+    if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    HIP_TRY(hipSetDevice(h->device));
+    const SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
+    int rc = launch_sweep_checked(h, p);  // warm-up
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < repeat; ++i) {
+        rc = launch_sweep_checked(h, p);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_launch = ms / repeat;
+    return CORBO_HIP_OK;
+}
+
+const char* corbo_hip_last_error(void) { return g_last_error.c_str(); }
+
+}  // extern "C"

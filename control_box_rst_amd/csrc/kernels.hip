@@ -1,0 +1,1013 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the hypergraph NLP inner loop.
+//
+//  sweep_kernel   one workgroup per OCP instance.  Evaluates every hypergraph edge (stage cost, dynamics defect, stage
+//                 inequality, bounds) -> stacked residual, and every central-difference Jacobian column, one lane per
+//                 (edge, vertex component) column task, vertices staged in LDS, Jacobian staged in LDS and streamed to
+//                 HBM with 16-byte coalesced stores.  In LM mode it also runs the trial-step bookkeeping (rho,
+//                 accept/reject, mu update) of LevenbergMarquardtSparse::solve so the residual re-evaluation of the line
+//                 search is the same kernel (levenberg_marquardt_sparse.cpp:158-213).
+//  factor_kernel  one workgroup per OCP instance.  Assembles H = J^T J + mu I and rhs = -J^T r from the block-sparse
+//                 Jacobian (levenberg_marquardt_sparse.cpp:97-100,135-138), eliminates the per-stage controls in parallel,
+//                 factors the remaining block-tridiagonal state system by block cyclic reduction (a Cholesky
+//                 factorisation in nested-dissection order, replaces Eigen::SimplicialLLT :140-148), handles a free dt as
+//                 the last (arrowhead) pivot, back-substitutes and writes the trial iterate x + delta (:158-161).
+//
+// Both are table driven (structure.hpp); nothing here knows about edge objects.
+#include "kernels.hpp"
+
+namespace corbo_hip {
+
+namespace {
+
+constexpr int SWEEP_THREADS = 256;
+constexpr double LM_EPS1 = 1e-5, LM_EPS2 = 1e-5, LM_EPS3 = 1e-5, LM_EPS4 = 0.0, LM_TAU = 1e-5;  // levenberg_marquardt_sparse.cpp:103-110
+constexpr int LM_MAX_INNER = 64;  // guard against an endless reject loop (the reference would spin)
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// end of one outer LM iteration: levenberg_marquardt_sparse.cpp:216-218
+__device__ __forceinline__ void lm_end_outer(LmState& s, int iterations)
+{
+    s.stop  = (sqrt(s.last_sq) <= LM_EPS3) ? 1 : 0;
+    s.inner = 0;
+    s.k += 1;
+    if (s.k >= iterations) {
+        s.done   = 1;
+        s.status = (s.stop || s.rho <= 0) ? CORBO_HIP_SOLVER_CONVERGED : CORBO_HIP_SOLVER_EARLY_TERMINATED;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// edge / Jacobian sweep
+// ---------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+template <int DYN, int DEFECT>
+__global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
+{
+    using Dy          = Dynamics<DYN>;
+    constexpr int NX  = Dy::NX;
+    constexpr int NU  = Dy::NU;
+    constexpr int S   = NX + NU;
+    constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs  = smem;                     // [nvs]      vertex values of this instance
+    double* js  = smem + p.nvs;             // [nnz_pad]  Jacobian staging
+    double* red = js + p.nnz_pad;           // [8]        reduction scratch / broadcast
+    int* flags  = reinterpret_cast<int*>(red + 8);  // [4]
+
+    const int inst = blockIdx.x;
+    const int tid  = threadIdx.x;
+    const size_t xo = (size_t)inst * p.nvs;
+    LmState* st    = p.st ? p.st + inst : nullptr;
+
+    const double* xsrc = p.x + xo;
+    double* vout       = p.values0 + (size_t)inst * p.m_pad;
+    if (p.mode == 3) {
+        const int done = st->done, no_trial = st->no_trial, vbuf = st->vbuf;
+        __syncthreads();  // everybody has read the state before lane 0 may change it
+        if (done) return;
+        if (no_trial) {  // |delta| <= eps2 -> stop = true, the do-while ends without a trial step (:151-154,215)
+            if (tid == 0) {
+                LmState s = *st;
+                lm_end_outer(s, p.iterations);
+                *st = s;
+                if (p.chi2) p.chi2[inst] = s.chi2_old;
+                if (!s.done) atomicAdd(p.active_count, 1);
+            }
+            return;
+        }
+        xsrc = p.xt + xo;
+        vout = (vbuf ? p.values0 : p.values1) + (size_t)inst * p.m_pad;  // the buffer NOT paired with the resident J
+    }
+
+    // ---- stage vertex values in LDS (coalesced 16-byte loads)
+    for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+        reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
+    double xr[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
+    __syncthreads();
+
+    // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
+    double sq_acc = 0.0;
+    for (int t = tid; t < p.n_row_tasks; t += SWEEP_THREADS) {
+        const RowTask rt = p.row_tasks[t];
+        const int base   = rt.k * S;
+        switch (rt.kind) {
+            case EK_DEFECT: {
+                double e[NX];
+                defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double v   = e[i] * p.w_eq;
+                    vout[rt.row + i] = v;
+                    sq_acc += v * v;
+                }
+                break;
+            }
+            case EK_STATE_COST: {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double v   = p.mp.sq[i] * (xs[base + i] - xr[i]);
+                    vout[rt.row + i] = v;
+                    sq_acc += v * v;
+                }
+                break;
+            }
+            case EK_CONTROL_COST: {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const double v   = p.mp.sr[i] * xs[base + NX + i];
+                    vout[rt.row + i] = v;
+                    sq_acc += v * v;
+                }
+                break;
+            }
+            case EK_FINAL_COST: {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double v   = p.mp.sqf[i] * (xs[base + i] - xr[i]);
+                    vout[rt.row + i] = v;
+                    sq_acc += v * v;
+                }
+                break;
+            }
+            case EK_DT_COST: {
+                const double v = p.mp.dt_weight * xs[p.off_dt];
+                vout[rt.row]   = v;
+                sq_acc += v * v;
+                break;
+            }
+            case EK_STAGE_INEQ: {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
+                double c = ineq_ball(xs + base, p.mp.ineq);
+                c        = (c < 0) ? 0.0 : c * p.w_ineq;
+                vout[rt.row] = c;
+                sq_acc += c * c;
+                break;
+            }
+            default: break;
+        }
+    }
+    // bounds (computeDistanceFiniteCombinedBounds, hyper_graph_optimization_problem_base.cpp:291-315)
+    for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {
+        const BoundTask bt = p.bound_tasks[t];
+        const double xv = xs[bt.voff], l = p.lb[xo + bt.voff], u = p.ub[xo + bt.voff];
+        double v;
+        if (xv < l) v = l - xv;
+        else if (xv > u) v = xv - u;
+        else v = 0.0;
+        v *= p.w_b;
+        vout[bt.row] = v;
+        sq_acc += v * v;
+    }
+
+    // ---- chi2 = |values|^2 and the LM trial-step decision
+    int do_jac = (p.mode == 1 || p.mode == 2) ? 1 : 0;
+    if (p.mode >= 2) {
+        double ws = wave_sum(sq_acc);
+        if ((tid & 63) == 0) red[tid >> 6] = ws;
+        __syncthreads();
+        if (tid == 0) {
+            const double chi2 = red[0] + red[1] + red[2] + red[3];
+            LmState s;
+            if (p.mode == 2) {  // solve() prologue (:89-127)
+                s          = LmState{};
+                s.chi2_old = chi2;
+                s.last_sq  = chi2;
+                s.v        = 2;
+                s.fresh    = 1;
+                s.first    = 1;
+                s.n_res    = 1;
+                s.n_jac    = 1;
+                s.status   = CORBO_HIP_SOLVER_CONVERGED;  // iterations == 0: (stop || rho <= 0) with rho = 0
+                s.done     = (p.iterations <= 0) ? 1 : 0;
+                flags[0]   = 1;
+                flags[1]   = 0;
+            }
+            else {
+                s              = *st;
+                const double chi2_new = chi2;
+                s.last_sq      = chi2_new;
+                s.n_res += 1;
+                s.rho          = (s.chi2_old - chi2_new) / s.den;  // :169
+                int accept = 0, refresh = 0;
+                if (s.rho > 0 && !isnan(chi2_new) && !isinf(chi2_new)) {  // :171
+                    s.stop = (sqrt(s.chi2_old) - sqrt(chi2_new) < LM_EPS4 * sqrt(s.chi2_old)) ? 1 : 0;
+                    accept = 1;
+                    s.n_accept += 1;
+                    if (!s.stop && s.k < p.iterations - 1) {  // :178-199
+                        refresh            = 1;
+                        const double alpha = fmin(2. / 3., 1 - pow((2 * s.rho - 1), 3.0));
+                        const double scale = fmax(1. / 3., alpha);
+                        s.mu *= scale;
+                        s.v     = 2;
+                        s.fresh = 1;
+                        s.vbuf ^= 1;  // the residual just written pairs with the Jacobian about to be written
+                        s.n_jac += 1;
+                    }
+                    s.chi2_old = chi2_new;
+                }
+                else {  // :204-213
+                    s.n_reject += 1;
+                    s.mu = s.mu * s.v;
+                    s.v  = 2 * s.v;
+                }
+                const bool cont = (s.rho <= 0) && !s.stop;  // :215
+                if (!cont || s.inner >= LM_MAX_INNER) lm_end_outer(s, p.iterations);
+                flags[0] = refresh;
+                flags[1] = accept;
+            }
+            *st = s;
+            if (p.chi2) p.chi2[inst] = s.chi2_old;
+            if (!s.done && p.active_count) atomicAdd(p.active_count, 1);
+        }
+        __syncthreads();
+        do_jac = flags[0];
+        if (p.mode == 3 && flags[1]) {  // accepted: the trial iterate becomes the iterate (discardBackupParameters :176)
+            double* xdst = p.x + xo;
+            for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+                reinterpret_cast<double2*>(xdst)[i] = reinterpret_cast<const double2*>(xs)[i];
+        }
+    }
+    if (!do_jac) return;
+
+    // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753)
+    //      one lane per central-difference column (BaseEdge::computeJacobian, edge_interface.cpp:55-96)
+    constexpr double delta     = 1e-9;
+    constexpr double neg2delta = -2 * delta;
+    constexpr double scalar    = 1.0 / (2 * delta);
+    for (int t = tid; t < p.n_col_tasks; t += SWEEP_THREADS) {
+        const ColTask ct = p.col_tasks[t];
+        const int base   = ct.k * S;
+        if (ct.kind == EK_DEFECT) {
+            const bool is_dt = (ct.voff == p.off_dt);
+            const int idx    = is_dt ? -1 : ct.voff - base;
+            double loc[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) loc[i] = xs[base + i];
+            double dt = xs[p.off_dt];
+            double v1[NX], v2[NX];
+#pragma unroll
+            for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + delta : loc[i];  // vertex->plus(i, delta)
+            dt = is_dt ? dt + delta : dt;
+            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v2);
+#pragma unroll
+            for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + neg2delta : loc[i];  // vertex->plus(i, neg2delta)
+            dt = is_dt ? dt + neg2delta : dt;
+            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v1);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) js[ct.joff + r] = (scalar * (v2[r] - v1[r])) * p.w_eq;  // :1552
+        }
+        else if (ct.kind == EK_STATE_COST || ct.kind == EK_FINAL_COST) {
+            const int idx  = ct.voff - base;
+            const double a = xs[ct.voff] + delta, b = a + neg2delta;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                const double w  = (ct.kind == EK_STATE_COST) ? p.mp.sq[r] : p.mp.sqf[r];
+                const double x0 = xs[base + r];
+                const double e2 = w * (((r == idx) ? a : x0) - xr[r]);
+                const double e1 = w * (((r == idx) ? b : x0) - xr[r]);
+                js[ct.joff + r] = scalar * (e2 - e1);
+            }
+        }
+        else if (ct.kind == EK_CONTROL_COST) {
+            const int idx  = ct.voff - base - NX;
+            const double a = xs[ct.voff] + delta, b = a + neg2delta;
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                const double x0 = xs[base + NX + r];
+                const double e2 = p.mp.sr[r] * ((r == idx) ? a : x0);
+                const double e1 = p.mp.sr[r] * ((r == idx) ? b : x0);
+                js[ct.joff + r] = scalar * (e2 - e1);
+            }
+        }
+        else if (ct.kind == EK_DT_COST) {
+            const double a = xs[ct.voff] + delta, b = a + neg2delta;
+            js[ct.joff]    = scalar * (p.mp.dt_weight * a - p.mp.dt_weight * b);
+        }
+        else if (ct.kind == EK_STAGE_INEQ) {  // active rows only, explicit zero otherwise (:1568-1610)
+            const int idx = ct.voff - base;
+            double loc[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) loc[i] = xs[base + i];
+            const double c0 = ineq_ball(loc, p.mp.ineq);
+            const bool active = (((c0 < 0) ? 0.0 : c0 * p.w_ineq) > 0.0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) loc[i] = (i == idx) ? loc[i] + delta : loc[i];
+            const double c2 = ineq_ball(loc, p.mp.ineq);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) loc[i] = (i == idx) ? loc[i] + neg2delta : loc[i];
+            const double c1 = ineq_ball(loc, p.mp.ineq);
+            js[ct.joff]     = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
+        }
+    }
+    for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {  // :1721-1752
+        const BoundTask bt = p.bound_tasks[t];
+        const double xv = xs[bt.voff], l = p.lb[xo + bt.voff], u = p.ub[xo + bt.voff];
+        js[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
+    }
+    __syncthreads();
+    // ---- stream the Jacobian values to HBM, 16 bytes per lane, fully coalesced
+    double* jdst = p.jac + (size_t)inst * p.nnz_pad;
+    for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
+        reinterpret_cast<double2*>(jdst)[i] = reinterpret_cast<const double2*>(js)[i];
+}
+
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// assemble + factor + solve
+// ---------------------------------------------------------------------------------------------------------------------
+
+// Cholesky of a small dense SPD matrix held in registers: lower factor in M, diagonal replaced by 1/L_ii.
+template <int Nn>
+__device__ __forceinline__ void chol_inv(double (&M)[Nn][Nn])
+{
+#pragma unroll
+    for (int j = 0; j < Nn; ++j) {
+        double d = M[j][j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) d -= M[j][c] * M[j][c];
+        const double inv = 1.0 / sqrt(d);
+        M[j][j]          = inv;
+#pragma unroll
+        for (int i = j + 1; i < Nn; ++i) {
+            double v = M[i][j];
+#pragma unroll
+            for (int c = 0; c < j; ++c) v -= M[i][c] * M[j][c];
+            M[i][j] = v * inv;
+        }
+    }
+}
+// X := L^{-1} X for a column block X[Nn][Mm] (L from chol_inv)
+template <int Nn, int Mm>
+__device__ __forceinline__ void fwd_solve(const double (&L)[Nn][Nn], double (&X)[Nn][Mm])
+{
+#pragma unroll
+    for (int c = 0; c < Mm; ++c)
+#pragma unroll
+        for (int i = 0; i < Nn; ++i) {
+            double v = X[i][c];
+#pragma unroll
+            for (int j = 0; j < i; ++j) v -= L[i][j] * X[j][c];
+            X[i][c] = v * L[i][i];
+        }
+}
+template <int Nn>
+__device__ __forceinline__ void fwd_solve_vec(const double (&L)[Nn][Nn], double (&x)[Nn])
+{
+#pragma unroll
+    for (int i = 0; i < Nn; ++i) {
+        double v = x[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) v -= L[i][j] * x[j];
+        x[i] = v * L[i][i];
+    }
+}
+// x := L^{-T} x
+template <int Nn>
+__device__ __forceinline__ void bwd_solve_vec(const double (&L)[Nn][Nn], double (&x)[Nn])
+{
+#pragma unroll
+    for (int i = Nn - 1; i >= 0; --i) {
+        double v = x[i];
+#pragma unroll
+        for (int j = i + 1; j < Nn; ++j) v -= L[j][i] * x[j];
+        x[i] = v * L[i][i];
+    }
+}
+
+#define SOA(arr, e, k) (arr)[(e) * NP + (k)]
+
+template <int NX, int NU, int THREADS>
+__global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
+{
+    constexpr int S  = NX + NU;
+    constexpr int NW = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int N  = p.N;
+    const int NP = N | 1;
+    // SoA arrays, element-major: arr[e][block]
+    double* Luu = smem;                    // NU*NU
+    double* Zx  = Luu + NU * NU * NP;      // NU*NX   L_uu^{-1} H(u_k, x_k)
+    double* Zp  = Zx + NU * NX * NP;       // NU*NX   L_uu^{-1} H(u_k, x_{k+1})
+    double* yu  = Zp + NU * NX * NP;       // NU
+    double* zu  = yu + NU * NP;            // NU      (arrowhead)
+    double* Dm  = zu + NU * NP;            // NX*NX   diagonal blocks -> L_i
+    double* Cm  = Dm + NX * NX * NP;       // NX*NX   coupling H(i+h, i) -> W_b
+    double* Wm  = Cm + NX * NX * NP;       // NX*NX   neighbour partials, then W_a
+    double* gv  = Wm + NX * NX * NP;       // NX      rhs -> y -> delta x
+    double* gn  = gv + NX * NP;            // NX      neighbour partial of the rhs
+    double* bv  = gn + NX * NP;            // NX      border column (arrowhead) -> z
+    double* bn  = bv + NX * NP;            // NX
+    double* red = bn + NX * NP;            // 4*NW + 8
+
+    const int inst = blockIdx.x;
+    const int tid  = threadIdx.x;
+    LmState* st    = p.st + inst;
+    const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
+    const int stop_in = st->stop;
+    double mu = st->mu;
+    const double mu_acc_in = st->mu_acc;
+    __syncthreads();
+    if (done) return;
+
+    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
+    const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    const bool arrow  = p.dt_free != 0;
+    const int k       = tid;
+    const bool has_stage = (k < N - 1);
+    const bool has_block = (k < N);
+
+    // ---- load the local Jacobian of defect edge k: [A | B | C | d] and its residual
+    double A[NX][NX], B[NX][NU], Cc[NX][NX], dc[NX], r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        r[i] = 0; dc[i] = 0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { A[i][j] = 0; Cc[i][j] = 0; }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) B[i][j] = 0;
+    }
+    if (has_stage) {
+        const StageCols sc = p.stage_cols[k];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            const int o = sc.col[c];
+            if (o >= 0)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) A[i][c] = J[o + i];
+        }
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            const int o = sc.col[NX + c];
+            if (o >= 0)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) B[i][c] = J[o + i];
+        }
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            const int o = sc.col[S + c];
+            if (o >= 0)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Cc[i][c] = J[o + i];
+        }
+        {
+            const int o = sc.col[S + NX];
+            if (o >= 0)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dc[i] = J[o + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) r[i] = val[p.eq_row0 + k * NX + i];
+    }
+    // diagonal (single-entry) rows of this lane's components: cost rows, bound rows
+    double du_diag[NU], gu[NU], dx_diag[NX], gx[NX];
+    int xfixed[NX];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        du_diag[j] = 0; gu[j] = 0;
+        if (has_stage) {
+            const CompInfo ci = p.comp[k * S + NX + j];
+            if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; du_diag[j] += a * a; gu[j] -= a * val[ci.cost_row]; }
+            if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; du_diag[j] += a * a; gu[j] -= a * val[ci.bnd_row]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        dx_diag[i] = 0; gx[i] = 0; xfixed[i] = 1;
+        if (has_block) {
+            const CompInfo ci = p.comp[k * S + i];
+            xfixed[i]         = ci.fixed;
+            if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; dx_diag[i] += a * a; gx[i] -= a * val[ci.cost_row]; }
+            if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; dx_diag[i] += a * a; gx[i] -= a * val[ci.bnd_row]; }
+        }
+    }
+    // stage inequality row on x_k: rank-1 contribution c c^T
+    double cin[NX];
+    double rin = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) cin[i] = 0;
+    if (p.ineq_cols && has_stage) {
+        rin = val[p.ineq_rows[k]];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int o = p.ineq_cols[k * NX + i];
+            if (o >= 0) cin[i] = J[o];
+        }
+    }
+    // border (dt) scalars: this lane's share of H(dt,dt) and rhs(dt)
+    double cdt = 0, gdt = 0;
+    if (arrow) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { cdt += dc[i] * dc[i]; gdt -= dc[i] * r[i]; }
+        if (tid == 0) {
+            const CompInfo ci = p.comp[p.off_dt];
+            if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; cdt += a * a; gdt -= a * val[ci.cost_row]; }
+            if (ci.cost2_joff >= 0) { const double a = J[ci.cost2_joff]; cdt += a * a; gdt -= a * val[ci.cost2_row]; }
+            if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; cdt += a * a; gdt -= a * val[ci.bnd_row]; }
+        }
+    }
+
+    // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
+    int stop = stop_in;
+    {
+        double s_cdt = 0, s_gdt = 0;
+        if (first) {
+            // raw neighbour parts of x_{k+1}: diag(C^T C), -C^T r
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double dd = 0, gg = 0;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) { dd += Cc[q][i] * Cc[q][i]; gg -= Cc[q][i] * r[q]; }
+                if (has_stage) { SOA(Wm, i, k) = dd; SOA(gn, i, k) = gg; }
+            }
+            __syncthreads();
+            double mx_d = -1e300, mx_g = 0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j)
+                if (has_stage) {
+                    double dd = du_diag[j], gg = gu[j];
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) { dd += B[q][j] * B[q][j]; gg -= B[q][j] * r[q]; }
+                    mx_d = fmax(mx_d, dd);
+                    mx_g = fmax(mx_g, fabs(gg));
+                }
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                if (has_block && !xfixed[i]) {
+                    double dd = dx_diag[i] + cin[i] * cin[i], gg = gx[i] - cin[i] * rin;
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) { dd += A[q][i] * A[q][i]; gg -= A[q][i] * r[q]; }
+                    if (k >= 1) { dd += SOA(Wm, i, k - 1); gg += SOA(gn, i, k - 1); }
+                    mx_d = fmax(mx_d, dd);
+                    mx_g = fmax(mx_g, fabs(gg));
+                }
+            mx_d = wave_max(mx_d);
+            mx_g = wave_max(mx_g);
+            double sc_ = wave_sum(cdt), sg_ = wave_sum(gdt);
+            if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = mx_d; red[(tid >> 6) * 4 + 1] = mx_g; red[(tid >> 6) * 4 + 2] = sc_; red[(tid >> 6) * 4 + 3] = sg_; }
+            __syncthreads();
+            mx_d = red[0]; mx_g = red[1]; s_cdt = red[2]; s_gdt = red[3];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { mx_d = fmax(mx_d, red[w * 4]); mx_g = fmax(mx_g, red[w * 4 + 1]); s_cdt += red[w * 4 + 2]; s_gdt += red[w * 4 + 3]; }
+            if (arrow) { mx_d = fmax(mx_d, s_cdt); mx_g = fmax(mx_g, fabs(s_gdt)); }
+            __syncthreads();
+            stop = (mx_g <= LM_EPS1) ? 1 : 0;
+            mu   = LM_TAU * mx_d;
+            if (mu < 0) mu = 0;
+        }
+    }
+    // H_ii += mu on every inner pass, never undone on reject (:135-138 and the comment at :208)
+    const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;
+
+    // ---- phase A: eliminate the controls of stage k (they couple only to x_k and x_{k+1})
+    double Dk[NX][NX], gk[NX], bk[NX];
+    double y2 = 0, zz = 0, zy = 0;  // running sums of |y|^2, |z|^2, z.y over the pivots this lane owns
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        gk[i] = 0; bk[i] = 0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Dk[i][j] = 0;
+    }
+    if (has_stage) {
+        double Huu[NU][NU];
+#pragma unroll
+        for (int a = 0; a < NU; ++a)
+#pragma unroll
+            for (int b = 0; b < NU; ++b) {
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) v += B[q][a] * B[q][b];
+                Huu[a][b] = v;
+            }
+        double gu_[NU], bu_[NU];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+            Huu[a][a] += du_diag[a] + mu_eff;
+            double gg = gu[a], bb = 0;
+#pragma unroll
+            for (int q = 0; q < NX; ++q) { gg -= B[q][a] * r[q]; bb += B[q][a] * dc[q]; }
+            gu_[a] = gg; bu_[a] = bb;
+        }
+        chol_inv<NU>(Huu);
+        double zx[NU][NX], zp[NU][NX];
+#pragma unroll
+        for (int a = 0; a < NU; ++a)
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                double v1 = 0, v2 = 0;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) { v1 += B[q][a] * A[q][c]; v2 += B[q][a] * Cc[q][c]; }
+                zx[a][c] = v1; zp[a][c] = v2;
+            }
+        fwd_solve<NU, NX>(Huu, zx);
+        fwd_solve<NU, NX>(Huu, zp);
+        fwd_solve_vec<NU>(Huu, gu_);
+        if (arrow) fwd_solve_vec<NU>(Huu, bu_);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+            y2 += gu_[a] * gu_[a];
+            if (arrow) { zz += bu_[a] * bu_[a]; zy += bu_[a] * gu_[a]; }
+            SOA(yu, a, k) = gu_[a];
+            SOA(zu, a, k) = bu_[a];
+#pragma unroll
+            for (int b = 0; b < NU; ++b) SOA(Luu, a * NU + b, k) = Huu[a][b];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) { SOA(Zx, a * NX + c, k) = zx[a][c]; SOA(Zp, a * NX + c, k) = zp[a][c]; }
+        }
+        // Schur complement pieces
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double g1 = 0, g2 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+            for (int q = 0; q < NX; ++q) { g1 -= A[q][i] * r[q]; g2 -= Cc[q][i] * r[q]; b1 += A[q][i] * dc[q]; b2 += Cc[q][i] * dc[q]; }
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { g1 -= zx[a][i] * gu_[a]; g2 -= zp[a][i] * gu_[a]; b1 -= zx[a][i] * bu_[a]; b2 -= zp[a][i] * bu_[a]; }
+            gk[i] = g1; bk[i] = b1;
+            SOA(gn, i, k) = g2;
+            SOA(bn, i, k) = b2;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double d1 = 0, d2 = 0, cc = 0;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) { d1 += A[q][i] * A[q][j]; d2 += Cc[q][i] * Cc[q][j]; cc += Cc[q][i] * A[q][j]; }
+#pragma unroll
+                for (int a = 0; a < NU; ++a) { d1 -= zx[a][i] * zx[a][j]; d2 -= zp[a][i] * zp[a][j]; cc -= zp[a][i] * zx[a][j]; }
+                Dk[i][j] = d1;
+                SOA(Wm, i * NX + j, k) = d2;  // partial of D_{k+1}
+                SOA(Cm, i * NX + j, k) = cc;  // H'(x_{k+1}, x_k)
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: complete state block k
+    if (has_block) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double g = gk[i] + gx[i] - cin[i] * rin, b = bk[i];
+            if (k >= 1) { g += SOA(gn, i, k - 1); b += SOA(bn, i, k - 1); }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double d = Dk[i][j] + cin[i] * cin[j];
+                if (k >= 1) d += SOA(Wm, i * NX + j, k - 1);
+                if (i == j) d += dx_diag[i] + mu_eff;
+                if (xfixed[i] || xfixed[j]) d = (i == j) ? 1.0 : 0.0;
+                Dk[i][j] = d;
+            }
+            if (xfixed[i]) { g = 0; b = 0; }
+            gk[i] = g; bk[i] = b;
+        }
+    }
+    __syncthreads();  // every lane has read its neighbour partials before Wm is reused as W_a
+    if (has_block) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            SOA(gv, i, k) = gk[i];
+            SOA(bv, i, k) = bk[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) SOA(Dm, i * NX + j, k) = Dk[i][j];
+        }
+    }
+    __syncthreads();
+
+    // ---- block cyclic reduction on the state chain: at stride h eliminate the odd multiples of h
+    int hmax = 1;
+    for (int h = 1; h < N; h <<= 1) {
+        hmax = h;
+        {   // eliminate block i = h(2j+1)
+            const int i = h * (2 * tid + 1);
+            if (i < N) {
+                const int a = i - h, b = i + h;
+                double L[NX][NX], Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    y[q] = SOA(gv, q, i);
+                    z[q] = SOA(bv, q, i);
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) {
+                        L[q][c]  = SOA(Dm, q * NX + c, i);
+                        Wa[q][c] = SOA(Cm, q * NX + c, a);                         // H(i, a) = C_a
+                        Wb[q][c] = (b < N) ? SOA(Cm, c * NX + q, i) : 0.0;          // H(i, b) = C_i^T
+                    }
+                }
+                chol_inv<NX>(L);
+                fwd_solve<NX, NX>(L, Wa);
+                fwd_solve<NX, NX>(L, Wb);
+                fwd_solve_vec<NX>(L, y);
+                if (arrow) fwd_solve_vec<NX>(L, z);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    y2 += y[q] * y[q];
+                    if (arrow) { zz += z[q] * z[q]; zy += z[q] * y[q]; }
+                    SOA(gv, q, i) = y[q];
+                    SOA(bv, q, i) = z[q];
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) {
+                        SOA(Dm, q * NX + c, i) = L[q][c];
+                        SOA(Wm, q * NX + c, i) = Wa[q][c];
+                        SOA(Cm, q * NX + c, i) = Wb[q][c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {   // update surviving block a = 2h*j from its eliminated neighbours a-h (as "b side") and a+h (as "a side")
+            const int a = 2 * h * tid;
+            if (a < N) {
+                const int il = a - h, ir = a + h;
+                double D[NX][NX], g[NX], bb[NX], Cn[NX][NX];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    g[q]  = SOA(gv, q, a);
+                    bb[q] = SOA(bv, q, a);
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) { D[q][c] = SOA(Dm, q * NX + c, a); Cn[q][c] = 0; }
+                }
+                if (ir < N) {
+                    double Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        y[q] = SOA(gv, q, ir);
+                        z[q] = SOA(bv, q, ir);
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) { Wa[q][c] = SOA(Wm, q * NX + c, ir); Wb[q][c] = SOA(Cm, q * NX + c, ir); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+#pragma unroll
+                        for (int t = 0; t < NX; ++t) { g[q] -= Wa[t][q] * y[t]; bb[q] -= Wa[t][q] * z[t]; }
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) {
+                            double dd = 0, cn = 0;
+#pragma unroll
+                            for (int t = 0; t < NX; ++t) { dd += Wa[t][q] * Wa[t][c]; cn += Wb[t][q] * Wa[t][c]; }
+                            D[q][c] -= dd;
+                            Cn[q][c] = -cn;  // H'(a+2h, a) = -W_b^T W_a
+                        }
+                    }
+                }
+                if (il >= 0) {
+                    double Wb[NX][NX], y[NX], z[NX];
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        y[q] = SOA(gv, q, il);
+                        z[q] = SOA(bv, q, il);
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) Wb[q][c] = SOA(Cm, q * NX + c, il);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+#pragma unroll
+                        for (int t = 0; t < NX; ++t) { g[q] -= Wb[t][q] * y[t]; bb[q] -= Wb[t][q] * z[t]; }
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) {
+                            double dd = 0;
+#pragma unroll
+                            for (int t = 0; t < NX; ++t) dd += Wb[t][q] * Wb[t][c];
+                            D[q][c] -= dd;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    SOA(gv, q, a) = g[q];
+                    SOA(bv, q, a) = bb[q];
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) { SOA(Dm, q * NX + c, a) = D[q][c]; SOA(Cm, q * NX + c, a) = Cn[q][c]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // root block 0
+    if (tid == 0) {
+        double L[NX][NX], y[NX], z[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            y[q] = SOA(gv, q, 0);
+            z[q] = SOA(bv, q, 0);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) L[q][c] = SOA(Dm, q * NX + c, 0);
+        }
+        chol_inv<NX>(L);
+        fwd_solve_vec<NX>(L, y);
+        if (arrow) fwd_solve_vec<NX>(L, z);
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            y2 += y[q] * y[q];
+            if (arrow) { zz += z[q] * z[q]; zy += z[q] * y[q]; }
+            SOA(gv, q, 0) = y[q];
+            SOA(bv, q, 0) = z[q];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) SOA(Dm, q * NX + c, 0) = L[q][c];
+        }
+    }
+    // ---- reductions: |y|^2 (= delta^T rhs), and for the arrowhead the last pivot
+    double ddt = 0;
+    {
+        double a0 = wave_sum(y2), a1 = wave_sum(zz), a2 = wave_sum(zy), a3 = wave_sum(cdt), a4 = wave_sum(gdt);
+        __syncthreads();
+        if ((tid & 63) == 0) { double* rr = red + (tid >> 6) * 5; rr[0] = a0; rr[1] = a1; rr[2] = a2; rr[3] = a3; rr[4] = a4; }
+        __syncthreads();
+        a0 = a1 = a2 = a3 = a4 = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { a0 += red[w * 5]; a1 += red[w * 5 + 1]; a2 += red[w * 5 + 2]; a3 += red[w * 5 + 3]; a4 += red[w * 5 + 4]; }
+        y2 = a0;
+        if (arrow) {
+            const double piv = (a3 + mu_eff) - a1;   // H(dt,dt) + damping - |z|^2
+            const double ydt = (a4 - a2) / sqrt(piv);
+            y2 += ydt * ydt;
+            ddt = ydt / sqrt(piv);
+        }
+        __syncthreads();
+    }
+    if (arrow) {  // y := y - z * delta_dt  (back-substitution of the last pivot)
+        if (has_block)
+#pragma unroll
+            for (int q = 0; q < NX; ++q) SOA(gv, q, k) -= SOA(bv, q, k) * ddt;
+        if (has_stage)
+#pragma unroll
+            for (int a = 0; a < NU; ++a) SOA(yu, a, k) -= SOA(zu, a, k) * ddt;
+        __syncthreads();
+    }
+    // ---- back-substitution, root first
+    if (tid == 0) {
+        double L[NX][NX], y[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            y[q] = SOA(gv, q, 0);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) L[q][c] = SOA(Dm, q * NX + c, 0);
+        }
+        bwd_solve_vec<NX>(L, y);
+#pragma unroll
+        for (int q = 0; q < NX; ++q) SOA(gv, q, 0) = y[q];
+    }
+    __syncthreads();
+    for (int h = hmax; h >= 1; h >>= 1) {
+        const int i = h * (2 * tid + 1);
+        if (i < N) {
+            const int a = i - h, b = i + h;
+            double L[NX][NX], y[NX];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                double v = SOA(gv, q, i);
+#pragma unroll
+                for (int c = 0; c < NX; ++c) {
+                    v -= SOA(Wm, q * NX + c, i) * SOA(gv, c, a);
+                    if (b < N) v -= SOA(Cm, q * NX + c, i) * SOA(gv, c, b);
+                    L[q][c] = SOA(Dm, q * NX + c, i);
+                }
+                y[q] = v;
+            }
+            bwd_solve_vec<NX>(L, y);
+#pragma unroll
+            for (int q = 0; q < NX; ++q) SOA(gv, q, i) = y[q];
+        }
+        __syncthreads();
+    }
+    // ---- controls, trial iterate, step norms
+    double dn2 = 0;
+    double* xt = p.xt + (size_t)inst * p.nvs;
+    double* dl = p.delta_out ? p.delta_out + (size_t)inst * p.nvs : nullptr;
+    if (has_block) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const double d = xfixed[q] ? 0.0 : SOA(gv, q, k);
+            dn2 += d * d;
+            xt[k * S + q] = xin[k * S + q] + d;
+            if (dl) dl[k * S + q] = d;
+        }
+    }
+    if (has_stage) {
+        double L[NU][NU], y[NU];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+            double v = SOA(yu, a, k);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) v -= SOA(Zx, a * NX + c, k) * SOA(gv, c, k) + SOA(Zp, a * NX + c, k) * SOA(gv, c, k + 1);
+            y[a] = v;
+#pragma unroll
+            for (int b = 0; b < NU; ++b) L[a][b] = SOA(Luu, a * NU + b, k);
+        }
+        bwd_solve_vec<NU>(L, y);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+            dn2 += y[a] * y[a];
+            xt[k * S + NX + a] = xin[k * S + NX + a] + y[a];
+            if (dl) dl[k * S + NX + a] = y[a];
+        }
+    }
+    if (tid == 0) {
+        if (arrow) { dn2 += ddt * ddt; xt[p.off_dt] = xin[p.off_dt] + ddt; }
+        else xt[p.off_dt] = xin[p.off_dt];
+        if (dl) dl[p.off_dt] = arrow ? ddt : 0.0;
+        if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
+    }
+    {
+        double a0 = wave_sum(dn2);
+        if ((tid & 63) == 0) red[tid >> 6] = a0;
+        __syncthreads();
+        if (tid == 0) {
+            dn2 = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dn2 += red[w];
+            LmState s = *st;
+            s.mu      = mu;
+            s.mu_acc  = mu_eff;
+            s.first   = 0;
+            s.fresh   = 0;
+            s.stop    = stop;
+            s.n_fact += 1;
+            s.inner += 1;
+            s.dnorm = sqrt(dn2);
+            if (s.dnorm <= LM_EPS2) { s.stop = 1; s.no_trial = 1; }   // :151-154
+            else { s.no_trial = 0; s.den = mu * dn2 + y2; }           // delta^T (mu delta + rhs), delta^T rhs = |y|^2
+            *st = s;
+        }
+    }
+}
+
+#undef SOA
+
+template <int DYN, int DEFECT>
+void launch_sweep_t(const SweepParams& p, hipStream_t stream)
+{
+    hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p), stream, p);
+}
+
+template <int DYN>
+bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
+{
+    switch (defect) {
+        case CORBO_HIP_DEFECT_FORWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, stream); return true;
+        case CORBO_HIP_DEFECT_BACKWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(p, stream); return true;
+        case CORBO_HIP_DEFECT_MIDPOINT: launch_sweep_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(p, stream); return true;
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: launch_sweep_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(p, stream); return true;
+        case CORBO_HIP_DEFECT_RK4_SHOOTING: launch_sweep_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, stream); return true;
+        default: return false;
+    }
+}
+
+template <int NX, int NU>
+size_t factor_lds(int N)
+{
+    const int NP = N | 1;
+    return sizeof(double) * ((size_t)NP * (NU * NU + 2 * NU * NX + 2 * NU + 3 * NX * NX + 4 * NX) + 64);
+}
+
+template <int NX, int NU>
+bool launch_factor_t(const FactorParams& p, hipStream_t stream)
+{
+    const size_t lds = factor_lds<NX, NU>(p.N);
+    if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128>), dim3(p.batch), dim3(128), lds, stream, p);
+    else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256>), dim3(p.batch), dim3(256), lds, stream, p);
+    else return false;
+    return true;
+}
+
+}  // namespace
+
+size_t sweep_lds_bytes(const SweepParams& p) { return sizeof(double) * ((size_t)p.nvs + p.nnz_pad + 8) + 16; }
+
+size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
+{
+    if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N);
+    if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N);
+    return 0;
+}
+
+bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream)
+{
+    switch (d.dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: return launch_sweep_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, p, stream);
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
+            if (d.nx != 2) return false;
+            return launch_sweep_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, p, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return launch_sweep_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, p, stream);
+        default: return false;
+    }
+}
+
+bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream)
+{
+    if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
+    if (d.nx == 3 && d.nu == 2) return launch_factor_t<3, 2>(p, stream);
+    return false;
+}
+
+}  // namespace corbo_hip

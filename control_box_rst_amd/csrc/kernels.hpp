@@ -1,0 +1,85 @@
+// kernels.hpp -- kernel parameter blocks and launch entry points (definitions in kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "model.hpp"
+#include "structure.hpp"
+
+namespace corbo_hip {
+
+// Per-instance Levenberg-Marquardt state machine (LevenbergMarquardtSparse::solve's local variables,
+// levenberg_marquardt_sparse.cpp:103-127).  Lives in HBM, one per OCP instance; touched by one lane per pass.
+struct LmState {
+    double mu;         // damping
+    double mu_acc;     // damping accumulated on diag(H) since the last Jacobian refresh (quirk i: never undone on reject)
+    double rho;
+    double chi2_old;   // last accepted chi2 (*obj_value)
+    double last_sq;    // |values|^2 of the LAST computeValues call (accepted or not), feeds stop = |values| <= eps3
+    double den;        // delta^T (mu delta + rhs) of the pending trial step
+    double dnorm;      // |delta| of the pending trial step
+    uint32_t v;        // unsigned int v (doubles on reject, wraps like the reference's)
+    int32_t k;         // outer iteration
+    int32_t stop;
+    int32_t fresh;     // Jacobian/values refreshed since the last factorisation -> rebuild H without accumulated damping
+    int32_t first;     // first factorisation of this solve: mu = tau * max diag(H), stop = |rhs|_inf <= eps1
+    int32_t no_trial;  // |delta| <= eps2: no trial step pending
+    int32_t done;
+    int32_t status;    // corbo_hip_solver_status
+    int32_t vbuf;      // which residual buffer pairs with the resident Jacobian
+    int32_t inner;     // inner passes of the current outer iteration
+    int32_t n_accept, n_reject, n_jac, n_res, n_fact;
+    int32_t pad;
+};
+
+struct SweepParams {
+    // static structure
+    int32_t batch, nvs, m, nnz, N, s, off_dt, dt_free;
+    int32_t n_row_tasks, n_col_tasks, n_bound_tasks;
+    const RowTask* row_tasks;
+    const ColTask* col_tasks;
+    const BoundTask* bound_tasks;
+    ModelParams mp;
+    double dt_fixed;
+    // per-call
+    int32_t mode;       // 0 = residual only, 1 = residual + Jacobian, 2 = LM init, 3 = LM trial step
+    int32_t iterations; // LM: outer iteration count
+    double w_eq, w_ineq, w_b;
+    double* x;          // [batch][nvs] accepted iterate
+    const double* xt;   // [batch][nvs] trial iterate (mode 3)
+    const double* lb;   // [batch][nvs]
+    const double* ub;
+    const double* xref; // [batch][MAX_NX]
+    double* values0;    // [batch][m]   residual buffer 0
+    double* values1;    // [batch][m]   residual buffer 1 (LM only)
+    double* jac;        // [batch][nnz_pad]
+    int32_t m_pad, nnz_pad;
+    LmState* st;
+    int32_t* active_count;  // number of instances not done after this pass (mode 3)
+    double* chi2;           // [batch] dense copy of the accepted chi2 (*obj_value), written by the LM modes
+};
+
+struct FactorParams {
+    int32_t batch, nvs, m, N, nx, nu, s, off_dt, dt_free;
+    int32_t eq_row0;
+    const StageCols* stage_cols;  // N-1
+    const CompInfo* comp;         // nvs
+    const int32_t* ineq_cols;     // (N-1)*nx or null
+    const int32_t* ineq_rows;     // N-1 or null
+    const double* x;              // accepted iterate
+    double* xt;                   // trial iterate out
+    const double* values0;
+    const double* values1;
+    const double* jac;
+    int32_t m_pad, nnz_pad;
+    LmState* st;
+    double* delta_out;            // optional [batch][nvs] (debug / tests), may be null
+};
+
+// returns false if the (dynamics, defect) pair has no device instantiation
+bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
+bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
+size_t sweep_lds_bytes(const SweepParams& p);
+size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
+
+}  // namespace corbo_hip

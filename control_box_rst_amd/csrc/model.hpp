@@ -1,0 +1,120 @@
+// model.hpp -- device-side edge models: system dynamics f(x,u) and the dynamics-defect formulas.
+//
+// Everything here is evaluated with floating-point contraction OFF so that every operation is the same IEEE fp64
+// operation, in the same order, as the reference's scalar C++ (which is compiled for baseline x86-64, no FMA).  The only
+// arithmetic that can differ from the CPU is libm-vs-OCML sin/cos (<= 1-2 ulp), see DESIGN.md "numerical fidelity".
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/corbo_hip.h"
+
+namespace corbo_hip {
+
+struct ModelParams {
+    double dyn[8];
+    double ineq[8];
+    double sq[CORBO_HIP_MAX_NX];   // sqrt(Q_ii)   (QuadraticFormCost::setWeightQ, quadratic_cost.cpp:59-67)
+    double sr[CORBO_HIP_MAX_NU];   // sqrt(R_ii)
+    double sqf[CORBO_HIP_MAX_NX];  // sqrt(Qf_ii)  (final_state_cost.cpp:60-68)
+    double dt_weight;              // sqrt(N-1)    (minimum_time.h:60)
+};
+
+#pragma clang fp contract(off)
+
+// ---- SystemDynamicsInterface::dynamics -----------------------------------------------------------------------------
+template <int DYN> struct Dynamics;
+
+template <> struct Dynamics<CORBO_HIP_DYN_VAN_DER_POL> {  // nonlinear_benchmark_systems.h:52-60
+    static constexpr int NX = 2, NU = 1;
+    __device__ static __forceinline__ void eval(const double* x, const double* u, const double* prm, double* f)
+    {
+        const double a = prm[0];
+        f[0]           = x[1];
+        f[1]           = -a * (x[0] * x[0] - 1) * x[1] - x[0] + u[0];
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_SERIAL_INTEGRATOR> {  // linear_benchmark_systems.h:72-83, order 2 (double integrator)
+    static constexpr int NX = 2, NU = 1;
+    __device__ static __forceinline__ void eval(const double* x, const double* u, const double* prm, double* f)
+    {
+        f[0] = x[1];
+        f[1] = u[0] / prm[0];
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u1 cos(th), ydot = u1 sin(th), thdot = u2
+    static constexpr int NX = 3, NU = 2;
+    __device__ static __forceinline__ void eval(const double* x, const double* u, const double*, double* f)
+    {
+        double sn, cs;
+        sincos(x[2], &sn, &cs);
+        f[0] = u[0] * cs;
+        f[1] = u[0] * sn;
+        f[2] = u[1];
+    }
+};
+
+// ---- dynamics defect of the equality edge (x1, u1, x2, dt) ----------------------------------------------------------
+template <int DYN, int DEFECT>
+__device__ __forceinline__ void defect_eval(const double* x1, const double* u1, const double* x2, double dt, const double* prm, double* err)
+{
+    using D          = Dynamics<DYN>;
+    constexpr int NX = D::NX;
+    if constexpr (DEFECT == CORBO_HIP_DEFECT_FORWARD) {  // finite_differences_collocation.h:126-134
+        D::eval(x1, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+    }
+    else if constexpr (DEFECT == CORBO_HIP_DEFECT_BACKWARD) {  // :160-168
+        D::eval(x2, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+    }
+    else if constexpr (DEFECT == CORBO_HIP_DEFECT_MIDPOINT) {  // :194-202
+        double t[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) t[i] = 0.5 * (x1[i] + x2[i]);
+        D::eval(t, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+    }
+    else if constexpr (DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON) {  // :228-238
+        double f1[NX];
+        D::eval(x1, u1, prm, f1);
+        D::eval(x2, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
+    }
+    else {  // RK4 shooting: explicit_integrators.h:280-295 + integrator_interface.h:217-222
+        double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
+        D::eval(x1, u1, prm, k1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k1[i] *= dt; t[i] = x1[i] + k1[i] / 2.0; }
+        D::eval(t, u1, prm, k2);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k2[i] *= dt; t[i] = x1[i] + k2[i] / 2.0; }
+        D::eval(t, u1, prm, k3);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k3[i] *= dt; t[i] = x1[i] + k3[i]; }
+        D::eval(t, u1, prm, k4);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            k4[i] *= dt;
+            err[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+            err[i] -= x2[i];
+        }
+    }
+}
+
+// stage inequality on x_k (keep-out ball, cfg 5): c = r^2 - |pos - center|^2  (<= 0 feasible)
+__device__ __forceinline__ double ineq_ball(const double* x, const double* prm)
+{
+    double dx = x[0] - prm[0], dy = x[1] - prm[1], dz = x[2] - prm[2];
+    return prm[3] * prm[3] - (dx * dx + dy * dy + dz * dz);
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace corbo_hip

@@ -1,0 +1,213 @@
+// structure.cpp -- see structure.hpp.  Host only (no HIP).
+#include "structure.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace corbo_hip {
+
+static bool finite_bound(double lb, double ub) { return lb > -CORBO_HIP_INF || ub < CORBO_HIP_INF; }  // vector_vertex.h:174-184
+
+std::string validate_desc(const corbo_hip_problem_desc& d)
+{
+    if (d.nx < 1 || d.nx > CORBO_HIP_MAX_NX) return "nx out of range";
+    if (d.nu < 1 || d.nu > CORBO_HIP_MAX_NU) return "nu out of range";
+    if (d.N < 2) return "N must be >= 2";
+    if (d.grid < CORBO_HIP_GRID_FD || d.grid > CORBO_HIP_GRID_MS) return "unknown grid";
+    if (d.defect < CORBO_HIP_DEFECT_FORWARD || d.defect > CORBO_HIP_DEFECT_RK4_SHOOTING) return "unknown defect";
+    if ((d.grid == CORBO_HIP_GRID_MS) != (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING))
+        return "multiple-shooting grid needs the RK4 shooting defect (and only it)";
+    switch (d.dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: if (d.nx != 2 || d.nu != 1) return "van der pol: nx=2 nu=1"; break;
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d.nu != 1) return "serial integrator: nu=1"; break;
+        case CORBO_HIP_DYN_UNICYCLE: if (d.nx != 3 || d.nu != 2) return "unicycle: nx=3 nu=2"; break;
+        case CORBO_HIP_DYN_QUADROTOR: if (d.nx != 12 || d.nu != 4) return "quadrotor: nx=12 nu=4"; break;
+        default: return "unknown dynamics";
+    }
+    if (d.stage_cost < CORBO_HIP_COST_NONE || d.stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return "unknown stage cost";
+    if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
+    if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
+    if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
+    return "";
+}
+
+std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
+{
+    std::string err = validate_desc(d);
+    if (!err.empty()) return err;
+    S       = Structure();
+    S.desc  = d;
+    S.nx    = d.nx;
+    S.nu    = d.nu;
+    S.N     = d.N;
+    S.s     = d.nx + d.nu;
+    S.dt_free = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    const int nx = S.nx, nu = S.nu, N = S.N, s = S.s;
+    S.off_xf = (N - 1) * s;
+    S.off_dt = (N - 1) * s + nx;
+    const int nv_all = S.off_dt + 1;
+    S.nvs            = (nv_all + 1) & ~1;
+    for (int i = 0; i < nx; ++i) { S.sq[i] = std::sqrt(d.q_diag[i]); S.sqf[i] = std::sqrt(d.qf_diag[i]); }
+    for (int i = 0; i < nu; ++i) S.sr[i] = std::sqrt(d.r_diag[i]);
+    S.dt_weight = std::sqrt((double)(N - 1));  // minimum_time.h:60
+
+    // ---- components: fixed flags and parameter indices (full_discretization_grid_base.cpp:514-527, vertex_set.cpp:405-418)
+    S.comp.assign(S.nvs, CompInfo{1, -1, -1, -1, -1, -1, -1, -1});
+    std::vector<double> lb(S.nvs, -CORBO_HIP_INF), ub(S.nvs, CORBO_HIP_INF);
+    for (int k = 0; k < N - 1; ++k) {
+        for (int i = 0; i < nx; ++i) { S.comp[k * s + i].fixed = (k == 0); lb[k * s + i] = d.x_lb[i]; ub[k * s + i] = d.x_ub[i]; }
+        for (int i = 0; i < nu; ++i) { S.comp[k * s + nx + i].fixed = 0; lb[k * s + nx + i] = d.u_lb[i]; ub[k * s + nx + i] = d.u_ub[i]; }
+    }
+    int xf_unfixed = 0;
+    for (int i = 0; i < nx; ++i) {
+        bool fx = (d.xf_fixed_mask >> i) & 1u;
+        S.comp[S.off_xf + i].fixed = fx;
+        if (!fx) ++xf_unfixed;
+        lb[S.off_xf + i] = d.x_lb[i];
+        ub[S.off_xf + i] = d.x_ub[i];
+    }
+    S.comp[S.off_dt].fixed = S.dt_free ? 0 : 1;
+    lb[S.off_dt] = d.dt_lb;
+    ub[S.off_dt] = d.dt_ub;
+    int n = 0;
+    for (int v = 0; v < nv_all; ++v)
+        if (!S.comp[v].fixed) { S.comp[v].param = n++; S.param_voff.push_back(v); }
+
+    // ---- edges in creation order -> rows (finite_differences_grid.cpp:38-154, nlp_functions.cpp:70-132, edge_set.cpp:31-42)
+    struct E { int kind, k, dim, scale; };
+    std::vector<E> lsq, eq, ineq;
+    for (int k = 0; k < N - 1; ++k) {
+        if (d.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) {
+            lsq.push_back({EK_STATE_COST, k, nx, 0});
+            lsq.push_back({EK_CONTROL_COST, k, nu, 0});
+        }
+        else if (d.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ && k == 0) {
+            lsq.push_back({EK_DT_COST, k, 1, 0});
+            lsq.push_back({EK_DT_COST, k, 1, 0});  // duplicated edge
+        }
+        if (d.stage_ineq != CORBO_HIP_INEQ_NONE) ineq.push_back({EK_STAGE_INEQ, k, 1, 2});
+        eq.push_back({EK_DEFECT, k, nx, 1});
+    }
+    if (xf_unfixed > 0 && d.final_cost) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
+
+    int row = 0, joff = 0;
+    auto comp_of = [&](int kind, int k, int vi, int c) -> int {  // vertex-storage offset of component c of attached vertex vi
+        switch (kind) {
+            case EK_STATE_COST: case EK_STAGE_INEQ: return k * s + c;
+            case EK_CONTROL_COST: return k * s + nx + c;
+            case EK_FINAL_COST: return S.off_xf + c;
+            case EK_DT_COST: return S.off_dt;
+            default:  // defect: (x_k, u_k, x_{k+1}, dt)
+                if (vi == 0) return k * s + c;
+                if (vi == 1) return k * s + nx + c;
+                if (vi == 2) return (k + 1) * s + c;
+                return S.off_dt;
+        }
+    };
+    auto vert_dim = [&](int kind, int vi) -> int {
+        switch (kind) {
+            case EK_STATE_COST: case EK_FINAL_COST: case EK_STAGE_INEQ: return nx;
+            case EK_CONTROL_COST: return nu;
+            case EK_DT_COST: return 1;
+            default: return vi == 0 ? nx : vi == 1 ? nu : vi == 2 ? nx : 1;
+        }
+    };
+    std::vector<ColTask> heavy, light;
+    S.stage_cols.assign(N - 1, StageCols{});
+    for (auto& sc : S.stage_cols) for (int& c : sc.col) c = -1;
+    if (d.stage_ineq != CORBO_HIP_INEQ_NONE) { S.ineq_cols.assign((size_t)(N - 1) * nx, -1); S.ineq_rows.assign(N - 1, -1); }
+    int dt_cost_seen = 0;
+    auto add_list = [&](const std::vector<E>& list) {
+        for (const E& e : list) {
+            S.row_tasks.push_back({e.kind, e.k, row, e.scale});
+            if (e.kind == EK_STAGE_INEQ) S.ineq_rows[e.k] = row;
+            int nverts = (e.kind == EK_DEFECT) ? 4 : 1;
+            for (int vi = 0; vi < nverts; ++vi) {
+                int vd = vert_dim(e.kind, vi);
+                for (int c = 0; c < vd; ++c) {
+                    int voff = comp_of(e.kind, e.k, vi, c);
+                    if (S.comp[voff].fixed) continue;
+                    // one column of the block: rows e.dim, parameter = comp.param
+                    for (int r = 0; r < e.dim; ++r) { S.jac_rows.push_back(row + r); S.jac_cols.push_back(S.comp[voff].param); }
+                    ColTask t{e.kind, e.k, voff, joff};
+                    (e.kind == EK_DEFECT ? heavy : light).push_back(t);
+                    if (e.kind == EK_DEFECT) {
+                        int local = (vi == 0) ? c : (vi == 1) ? nx + c : (vi == 2) ? s + c : s + nx;
+                        S.stage_cols[e.k].col[local] = joff;
+                    }
+                    else if (e.kind == EK_STAGE_INEQ) S.ineq_cols[(size_t)e.k * nx + c] = joff;
+                    else if (e.kind == EK_DT_COST) {
+                        if (dt_cost_seen == 0) { S.comp[voff].cost_joff = joff; S.comp[voff].cost_row = row; }
+                        else { S.comp[voff].cost2_joff = joff; S.comp[voff].cost2_row = row; }
+                    }
+                    else {  // diagonal cost blocks: value of row c
+                        S.comp[voff].cost_joff = joff + c;
+                        S.comp[voff].cost_row  = row + c;
+                    }
+                    joff += e.dim;
+                }
+            }
+            if (e.kind == EK_DT_COST) ++dt_cost_seen;
+            row += e.dim;
+        }
+    };
+    add_list(lsq);
+    S.dims.lsq = row;
+    S.eq_row0  = row;
+    S.defect_joff0 = joff;
+    add_list(eq);
+    S.dims.eq   = row - S.eq_row0;
+    S.ineq_row0 = row;
+    add_list(ineq);
+    S.dims.ineq = row - S.ineq_row0;
+    S.bnd_row0  = row;
+    // bound rows (hyper_graph_optimization_problem_base.cpp:291-315)
+    for (int v = 0; v < nv_all; ++v) {
+        if (S.comp[v].fixed) continue;
+        if (!finite_bound(lb[v], ub[v])) continue;
+        S.bound_tasks.push_back({v, row, joff, 0});
+        S.comp[v].bnd_joff = joff;
+        S.comp[v].bnd_row  = row;
+        S.jac_rows.push_back(row);
+        S.jac_cols.push_back(S.comp[v].param);
+        ++row;
+        ++joff;
+    }
+    S.dims.bounds = row - S.bnd_row0;
+    S.dims.m      = row;
+    S.dims.nnz    = joff;
+    S.dims.n      = n;
+    S.dims.nv     = S.dt_free ? nv_all : nv_all - 1;
+    S.col_tasks   = heavy;
+    S.col_tasks.insert(S.col_tasks.end(), light.begin(), light.end());
+    return "";
+}
+
+void init_trajectory(const corbo_hip_problem_desc& d, int batch, const double* x0, const double* xf, double* x_out)
+{
+    // FullDiscretizationGridBase::initializeSequences (full_discretization_grid_base.cpp:134-179):
+    //   dir = xf - x0; dist = |dir|; dir /= dist; step = dist / (N-1); x_k = x0 + k*step*dir; u_k = uref(k) = 0
+    const int nx = d.nx, nu = d.nu, N = d.N, s = nx + nu;
+    const bool dt_free = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    const int nv = (N - 1) * s + nx + (dt_free ? 1 : 0);
+    for (int b = 0; b < batch; ++b) {
+        const double* a = x0 + (size_t)b * nx;
+        const double* g = xf + (size_t)b * nx;
+        double* o       = x_out + (size_t)b * nv;
+        double dir[CORBO_HIP_MAX_NX];
+        double sq = 0;
+        for (int i = 0; i < nx; ++i) { dir[i] = g[i] - a[i]; sq += dir[i] * dir[i]; }
+        double dist = std::sqrt(sq);
+        if (dist != 0)
+            for (int i = 0; i < nx; ++i) dir[i] /= dist;
+        double step = dist / (N - 1);
+        for (int k = 0; k < N - 1; ++k) {
+            for (int i = 0; i < nx; ++i) o[k * s + i] = a[i] + (double)k * step * dir[i];
+            for (int i = 0; i < nu; ++i) o[k * s + nx + i] = 0.0;
+        }
+        for (int i = 0; i < nx; ++i) o[(N - 1) * s + i] = g[i];
+        if (dt_free) o[(N - 1) * s + nx] = d.dt_ref;
+    }
+}
+
+}  // namespace corbo_hip

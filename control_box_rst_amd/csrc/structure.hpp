@@ -1,0 +1,102 @@
+// structure.hpp -- static structure of the hypergraph NLP described by a corbo_hip_problem_desc.
+//
+// Host-side, computed once per handle ("new_structure" work of the reference:
+// LevenbergMarquardtSparse::solve, levenberg_marquardt_sparse.cpp:48-80; OptimizationEdgeSet::computeEdgeIndices,
+// edge_set.cpp:31-42; VertexSetInterface::computeVertexIndices, vertex_set.cpp:405-418;
+// computeSparseJacobian*NNZ / *Structure, hyper_graph_optimization_problem_edge_based.cpp:193-322,1181-1478).
+// The device kernels are table driven: they never see edges as objects, only the flat task tables built here.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/corbo_hip.h"
+
+namespace corbo_hip {
+
+// edge kinds the device can evaluate (closed set, DESIGN.md "device-describable edges")
+enum EdgeKind : int32_t {
+    EK_STATE_COST   = 0,  // sqrt(Q) .* (x_k - xref)            quadratic_cost.cpp:100-119
+    EK_CONTROL_COST = 1,  // sqrt(R) .* u_k                     quadratic_cost.cpp:140-154
+    EK_FINAL_COST   = 2,  // sqrt(Qf) .* (x_f - xref)           final_state_cost.cpp:72-92
+    EK_DT_COST      = 3,  // sqrt(N-1) * dt                     minimum_time.h:49-78
+    EK_DEFECT       = 4,  // dynamics defect (x_k,u_k,x_{k+1},dt)
+    EK_STAGE_INEQ   = 5   // stage inequality on x_k
+};
+
+// one residual-row group = one edge's values (BaseEdge::computeValues)
+struct RowTask {
+    int32_t kind;   // EdgeKind
+    int32_t k;      // stage
+    int32_t row;    // first row in the stacked residual
+    int32_t scale;  // 0 none, 1 w_eq, 2 active inequality w_ineq
+};
+
+// one finite-difference column of one (edge, vertex) Jacobian block (BaseEdge::computeJacobian inner loop)
+struct ColTask {
+    int32_t kind;   // EdgeKind
+    int32_t k;      // stage of the edge
+    int32_t voff;   // offset of the perturbed component in the vertex storage
+    int32_t joff;   // offset of the column's first value in the Jacobian value array
+};
+
+// one bound row (computeDistanceFiniteCombinedBounds / bounds part of computeCombinedSparseJacobian)
+struct BoundTask {
+    int32_t voff;   // component in the vertex storage
+    int32_t row;    // residual row
+    int32_t joff;   // Jacobian value index (single entry)
+    int32_t pad;
+};
+
+// per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):
+// defect edge k has the dense local Jacobian [A | B | C | d] w.r.t. (x_k, u_k, x_{k+1}, dt); entry = offset of the
+// column's first value in the Jacobian value array, -1 when that component is fixed.
+struct StageCols {
+    int32_t col[CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NU + CORBO_HIP_MAX_NX + 1];
+};
+
+// per component of the vertex storage: diagonal contributions to H (cost row, bound row, inequality row)
+struct CompInfo {
+    int32_t fixed;      // 1 = not a parameter
+    int32_t param;      // parameter (column) index or -1
+    int32_t cost_joff;  // Jacobian value index of d(cost row)/d(component) (diagonal of the cost block) or -1
+    int32_t cost_row;   // residual row of that cost value or -1
+    int32_t bnd_joff;   // bound row entry or -1
+    int32_t bnd_row;
+    int32_t cost2_joff; // second cost row on the same component (duplicated dt edge, nlp_functions.cpp:91-107) or -1
+    int32_t cost2_row;
+};
+
+struct Structure {
+    corbo_hip_problem_desc desc{};
+    corbo_hip_dims dims{};
+    int nx = 0, nu = 0, N = 0, s = 0;
+    bool dt_free = false;
+    int off_xf = 0, off_dt = 0;  // vertex-storage offsets
+    int nvs = 0;                 // device vertex storage per instance (always holds dt), padded to even
+    int eq_row0 = 0, ineq_row0 = 0, bnd_row0 = 0;
+    int defect_joff0 = 0;        // first Jacobian value of the equality blocks
+    double sq[CORBO_HIP_MAX_NX]{}, sr[CORBO_HIP_MAX_NU]{}, sqf[CORBO_HIP_MAX_NX]{};
+    double dt_weight = 0;
+
+    std::vector<RowTask> row_tasks;
+    std::vector<ColTask> col_tasks;      // defect columns first (heavy), then the cheap ones
+    std::vector<BoundTask> bound_tasks;
+    std::vector<StageCols> stage_cols;   // N-1 defect edges
+    std::vector<int32_t> ineq_cols;      // (N-1)*nx: Jacobian value index of d(ineq_k)/d(x_k[i]) or -1
+    std::vector<int32_t> ineq_rows;      // N-1 residual rows (or empty)
+    std::vector<CompInfo> comp;          // nvs entries
+    std::vector<int32_t> jac_rows, jac_cols;  // structure in value order
+    std::vector<int32_t> param_voff;     // parameter -> vertex storage offset
+
+    int x_off(int k) const { return k * s; }             // k in [0, N-1]; k == N-1 is x_f
+    int u_off(int k) const { return k * s + nx; }
+};
+
+// returns "" on success, otherwise an error text
+std::string validate_desc(const corbo_hip_problem_desc& d);
+std::string build_structure(const corbo_hip_problem_desc& d, Structure& out);
+void init_trajectory(const corbo_hip_problem_desc& d, int batch, const double* x0, const double* xf, double* x_out);
+
+}  // namespace corbo_hip

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's solver plug-in for a BATCH of OCP instances, over the C-ABI (include/corbo_hip.h).
+
+Method names and semantics follow ``corbo::LevenbergMarquardtSparse`` / ``corbo::NlpSolverInterface``
+(reference: src/optimization/include/corbo-optimization/solver/levenberg_marquardt_sparse.h:68-157,
+nlp_solver_interface.h:67-115): ``setIterations``, ``setPenaltyWeights``, ``setWeightAdapation``, ``initialize``,
+``solve(new_run)``, ``clear``.  The reference's C++ adapter (control_box_rst_amd/adapter/) does the same from C++.
+This module never falls back to a CPU implementation: every call goes to libcorbo_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Dims, LmOpts, ProblemDesc, Stats
+
+
+class CorboHipError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def get_dims(desc: ProblemDesc) -> Dims:
+    lib = capi.load()
+    d = Dims()
+    rc = lib.corbo_hip_get_dims(C.byref(desc), C.byref(d))
+    if rc != 0:
+        raise CorboHipError(f"corbo_hip_get_dims: {lib.corbo_hip_last_error().decode()}")
+    return d
+
+
+def get_structure(desc: ProblemDesc):
+    lib = capi.load()
+    d = get_dims(desc)
+    rows = np.zeros(d.nnz, np.int32)
+    cols = np.zeros(d.nnz, np.int32)
+    rc = lib.corbo_hip_get_structure(C.byref(desc), _ip(rows), _ip(cols))
+    if rc != 0:
+        raise CorboHipError(f"corbo_hip_get_structure: {lib.corbo_hip_last_error().decode()}")
+    return rows, cols
+
+
+def init_trajectory(desc: ProblemDesc, x0, xf) -> np.ndarray:
+    """FullDiscretizationGridBase::initializeSequences for a batch: x0, xf [B][nx] -> [B][nv]."""
+    lib = capi.load()
+    x0 = np.ascontiguousarray(np.atleast_2d(x0), np.float64)
+    xf = np.ascontiguousarray(np.atleast_2d(xf), np.float64)
+    d = get_dims(desc)
+    out = np.zeros((x0.shape[0], d.nv))
+    rc = lib.corbo_hip_init_trajectory(C.byref(desc), x0.shape[0], _dp(x0), _dp(xf), _dp(out))
+    if rc != 0:
+        raise CorboHipError(f"corbo_hip_init_trajectory: {lib.corbo_hip_last_error().decode()}")
+    return out
+
+
+class BatchedLevenbergMarquardt:
+    """LevenbergMarquardtSparse for `batch` independent instances of one hypergraph structure, on one MI355X."""
+
+    def __init__(self, desc: ProblemDesc, batch: int, device: int = 0):
+        self.lib = capi.load()
+        self.desc = desc
+        self.batch = int(batch)
+        self.device = int(device)
+        self.opts: LmOpts = capi.default_lm_opts()
+        self.dims = get_dims(desc)
+        self._h = C.c_void_p()
+        rc = self.lib.corbo_hip_create(C.byref(desc), self.batch, self.device, C.byref(self._h))
+        self._check(rc, "corbo_hip_create")
+
+    # -- reference setters ------------------------------------------------------------------------------------------
+    def setIterations(self, iterations: int):
+        self.opts.iterations = int(iterations)
+
+    def setPenaltyWeights(self, weight_eq: float, weight_ineq: float, weight_bounds: float):
+        self.opts.weight_eq, self.opts.weight_ineq, self.opts.weight_bounds = weight_eq, weight_ineq, weight_bounds
+
+    def setWeightAdapation(self, factor_eq, factor_ineq, factor_bounds, max_eq, max_ineq, max_bounds):  # (sic) reference spelling
+        o = self.opts
+        o.adapt_factor_eq, o.adapt_factor_ineq, o.adapt_factor_bounds = factor_eq, factor_ineq, factor_bounds
+        o.adapt_max_eq, o.adapt_max_ineq, o.adapt_max_bounds = max_eq, max_ineq, max_bounds
+
+    def isLsqSolver(self) -> bool:
+        return True
+
+    def initialize(self) -> bool:
+        return bool(self._h)
+
+    def clear(self):
+        pass
+
+    # -- data ----------------------------------------------------------------------------------------------------------
+    def init_trajectory(self, x0, xf) -> np.ndarray:
+        return init_trajectory(self.desc, x0, xf)
+
+    def set_instance_data(self, x, lb=None, ub=None, xref=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (x, lb, ub, xref)]
+        assert arrs[0].shape == (self.batch, self.dims.nv), (arrs[0].shape, (self.batch, self.dims.nv))
+        if arrs[3] is not None:
+            assert arrs[3].shape == (self.batch, self.desc.nx)
+        rc = self.lib.corbo_hip_set_instance_data(self._h, *[_dp(a) for a in arrs])
+        self._check(rc, "corbo_hip_set_instance_data")
+
+    # -- the hot path ---------------------------------------------------------------------------------------------------
+    def solve(self, new_run: bool = True):
+        rc = self.lib.corbo_hip_solve(self._h, C.byref(self.opts), 1 if new_run else 0)
+        self._check(rc, "corbo_hip_solve")
+
+    def synchronize(self):
+        self._check(self.lib.corbo_hip_synchronize(self._h), "corbo_hip_synchronize")
+
+    def get_solution(self):
+        x = np.zeros((self.batch, self.dims.nv))
+        chi2 = np.zeros(self.batch)
+        status = np.zeros(self.batch, np.int32)
+        rc = self.lib.corbo_hip_get_solution(self._h, _dp(x), _dp(chi2), _ip(status))
+        self._check(rc, "corbo_hip_get_solution")
+        return x, chi2, status
+
+    def get_stats(self) -> dict:
+        s = Stats()
+        self._check(self.lib.corbo_hip_get_stats(self._h, C.byref(s)), "corbo_hip_get_stats")
+        return s.as_dict()
+
+    def eval(self, w_eq=None, w_ineq=None, w_bounds=None, jacobian=True):
+        """Residual vector [B][m] and Jacobian values [B][nnz] at the resident iterate (parity hook)."""
+        o = self.opts
+        w = (o.weight_eq if w_eq is None else w_eq, o.weight_ineq if w_ineq is None else w_ineq,
+             o.weight_bounds if w_bounds is None else w_bounds)
+        values = np.zeros((self.batch, self.dims.m))
+        jac = np.zeros((self.batch, self.dims.nnz)) if jacobian else None
+        rc = self.lib.corbo_hip_eval(self._h, *w, _dp(values), _dp(jac))
+        self._check(rc, "corbo_hip_eval")
+        return values, jac
+
+    def time_sweep(self, with_jacobian=True, repeat=20) -> float:
+        """Average duration [ms] of one edge/Jacobian sweep launch over the resident batch (HIP events)."""
+        o = self.opts
+        ms = C.c_float(0)
+        rc = self.lib.corbo_hip_time_sweep(self._h, o.weight_eq, o.weight_ineq, o.weight_bounds, 1 if with_jacobian else 0,
+                                           int(repeat), C.byref(ms))
+        self._check(rc, "corbo_hip_time_sweep")
+        return float(ms.value)
+
+    def device_views(self):
+        """(x_ptr, chi2_ptr, stream) raw device pointers into the library's HBM buffers."""
+        xp, cp, st = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.c_void_p()
+        self._check(self.lib.corbo_hip_device_views(self._h, C.byref(xp), C.byref(cp), C.byref(st)), "corbo_hip_device_views")
+        return C.cast(xp, C.c_void_p).value, C.cast(cp, C.c_void_p).value, st.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.corbo_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CorboHipError(f"{what} failed ({rc}): {self.lib.corbo_hip_last_error().decode()}")

@@ -1,0 +1,95 @@
+"""CPU-side tests of the product: the C-ABI library loads, exports every symbol include/corbo_hip.h declares, and its
+host-only entry points (dims, structure, trajectory initialisation) agree with the oracle / golden vectors.
+No compute call touches a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, desc_for, load_golden
+from control_box_rst_amd import capi, problems, solver
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    return capi.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "corbo_hip.h")).read()
+    declared = set(re.findall(r"\b(corbo_hip_[a-z_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_match_header(lib):
+    # sizes implied by include/corbo_hip.h (packing check of the ctypes mirrors)
+    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8
+    assert C.sizeof(capi.Dims) == 8 * 4
+    assert C.sizeof(capi.LmOpts) == 8 + 9 * 8
+    o = capi.LmOpts()
+    lib.corbo_hip_default_lm_opts(C.byref(o))
+    assert (o.iterations, o.weight_eq, o.adapt_factor_eq, o.adapt_max_bounds) == (10, 2.0, 1.0, 500.0)
+
+
+@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12"])
+def test_dims_and_structure_match_reference(lib, oracle_mod, name):
+    g = load_golden(name)
+    d = desc_for(g)
+    dims = solver.get_dims(d)
+    for k in ("n", "lsq", "eq", "ineq", "bounds", "m", "nnz"):
+        assert getattr(dims, k) == g[k], k
+    rows, cols = solver.get_structure(d)
+    assert sorted(zip(rows.tolist(), cols.tolist())) == sorted(zip(g["jac_rows"], g["jac_cols"]))
+    # same value order as the oracle (both follow the reference's sweep order)
+    orows, ocols = oracle_mod.OracleProblem(d).structure()
+    assert np.array_equal(rows, orows) and np.array_equal(cols, ocols)
+
+
+def test_init_trajectory_matches_oracle_bitwise(lib, oracle_mod):
+    d = problems.unicycle_desc()
+    x0, xf = problems.unicycle_instances(5)
+    X = solver.init_trajectory(d, x0, xf)
+    p = oracle_mod.OracleProblem(d)
+    for b in range(5):
+        assert np.array_equal(X[b], p.init_trajectory(x0[b], xf[b]))
+    d2 = problems.dint_desc()
+    X2 = solver.init_trajectory(d2, [[0.0, 0.0]], [[1.0, 0.0]])
+    assert np.array_equal(X2[0], oracle_mod.OracleProblem(d2).init_trajectory([0.0, 0.0], [1.0, 0.0]))
+    assert X2[0][-1] == d2.dt_ref
+
+
+def test_invalid_descriptors_are_rejected(lib):
+    d = problems.unicycle_desc()
+    d.nx = 5
+    with pytest.raises(solver.CorboHipError):
+        solver.get_dims(d)
+    d = problems.unicycle_desc()
+    d.grid = capi.GRID_MS  # MS grid needs the RK4 defect
+    with pytest.raises(solver.CorboHipError):
+        solver.get_dims(d)
+    assert b"" != lib.corbo_hip_last_error()
+
+
+def test_create_without_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(solver.CorboHipError):
+        solver.BatchedLevenbergMarquardt(problems.unicycle_desc(N=12), 2)
+
+
+def test_product_does_not_use_the_oracle():
+    """The product path must never import / link / call anything under oracle/."""
+    pkg = os.path.join(ROOT, "control_box_rst_amd")
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|liboracle|oracle_[a-z]+\s*\(|corbo_oracle\.h)")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(txt), (dirpath, f)

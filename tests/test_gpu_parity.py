@@ -1,0 +1,202 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle (same seeded inputs) and against
+the golden vectors of the genuine reference.
+
+Tolerances
+  residual vector           : 1e-12 abs x max weight (only sin/cos can differ from the CPU, by ~1 ulp of O(1) values)
+  Jacobian entries          : 1e-6 relative to max(1,|J|max)  (central differences, delta=1e-9: eps/delta ~ 1e-7 noise)
+  trajectory after k iters  : 5e-6 abs (1e-6 target / 1e-5 hard; the reference itself is only reproducible to
+                              ~1e-7..1e-6 because FD noise is a chaotic function of the last bits of x)
+  chi2                      : 2e-6 relative
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import desc_for, load_golden
+from control_box_rst_amd import capi, problems
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt, get_structure
+
+pytestmark = pytest.mark.gpu
+
+X_TOL = 5e-6
+CHI2_RTOL = 2e-6
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+
+
+GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_values_and_jacobian_vs_reference_golden(name):
+    g = load_golden(name)
+    d = desc_for(g)
+    s = BatchedLevenbergMarquardt(d, 1)
+    s.setPenaltyWeights(*g["weights"])
+    x = np.array(g["vertex_init"])[None, : s.dims.nv]
+    s.set_instance_data(x, xref=np.array(g["xf"])[None, :])
+    values, jac = s.eval()
+    assert np.abs(values[0] - np.array(g["values_init"])).max() <= 1e-12 * max(1.0, max(g["weights"]))
+    rows, cols = get_structure(d)
+    Jg = sp.coo_matrix((jac[0], (rows, cols)), shape=(s.dims.m, s.dims.n)).tocsr()
+    Jr = sp.coo_matrix((g["jac_vals"], (g["jac_rows"], g["jac_cols"])), shape=(s.dims.m, s.dims.n)).tocsr()
+    scale = max(1.0, abs(Jr).max())
+    assert abs(Jg - Jr).max() <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_lm_iterates_vs_reference_golden(name):
+    g = load_golden(name)
+    d = desc_for(g)
+    for a in g["after_iter"]:
+        s = BatchedLevenbergMarquardt(d, 1)
+        s.setIterations(a["k"])
+        s.setPenaltyWeights(*g["weights"])
+        s.set_instance_data(s.init_trajectory(g["x0"], g["xf"]), xref=np.array(g["xf"])[None, :])
+        for i in range(g["solves"]):
+            s.solve(new_run=(i == 0))
+        x, chi2, status = s.get_solution()
+        ref = np.array(a["vertex"])[: s.dims.nv]
+        assert np.abs(x[0] - ref).max() <= X_TOL, (name, a["k"], np.abs(x[0] - ref).max())
+        assert abs(chi2[0] - a["chi2"]) <= CHI2_RTOL * max(1.0, abs(a["chi2"])), (name, a["k"])
+        assert status[0] in (capi.SOLVER_CONVERGED, capi.SOLVER_EARLY_TERMINATED)
+        st = s.get_stats()
+        assert st["lm_iterations"] == a["k"]
+
+
+def test_seeded_batch_vs_reference_golden_and_oracle(oracle_mod):
+    """8 seeded cfg-3 instances solved as ONE batch: vs the genuine reference's final trajectories and vs the oracle."""
+    g = load_golden("unicycle_seeded8")
+    d = problems.unicycle_desc()
+    x0, xf = problems.unicycle_instances(8, seed=g["seed"])
+    s = BatchedLevenbergMarquardt(d, 8)
+    s.setIterations(10)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    for b, inst in enumerate(g["instances"]):
+        ref = np.array(inst["vertex"])[: s.dims.nv]
+        assert np.abs(X[b] - ref).max() <= 2 * X_TOL, b
+        assert abs(chi2[b] - inst["chi2"]) <= CHI2_RTOL * inst["chi2"], b
+    Xo, chi2o, statuso = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.abs(X - Xo).max() <= 2 * X_TOL
+    assert np.allclose(chi2, chi2o, rtol=CHI2_RTOL)
+    st = s.get_stats()
+    assert st["lm_iterations"] == 80 and st["factorizations"] >= 80
+
+
+def test_values_jacobian_vs_oracle_batch(oracle_mod):
+    """Residual/Jacobian of 32 seeded instances at their initial trajectories, per-instance vs the oracle."""
+    d = problems.unicycle_desc(N=30)
+    B = 32
+    x0, xf = problems.unicycle_instances(B, seed=7)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setPenaltyWeights(10, 10, 10)
+    X0 = s.init_trajectory(x0, xf)
+    X0[:, 4::5] += 1.5  # push some controls beyond their bounds so bound rows are active
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(10, 10, 10)
+        assert np.abs(values[b] - vo).max() <= 1e-11
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max())
+        assert np.array_equal(jac[b][-s.dims.bounds:], jo[-s.dims.bounds:])  # bound rows: exactly -w / 0 / +w
+
+
+def test_multiple_solves_warm_weights(oracle_mod):
+    """cfg 2 style: 3 consecutive solves with weight adaptation (new_run only first) vs the oracle."""
+    d = problems.dint_desc(N=20)
+    s = BatchedLevenbergMarquardt(d, 2)
+    s.setIterations(6)
+    s.setPenaltyWeights(50, 50, 50)
+    s.setWeightAdapation(1.5, 1.5, 1.5, 200, 200, 200)
+    x0 = np.array([[0.0, 0.0], [0.2, -0.1]])
+    xf = np.array([[1.0, 0.0], [1.0, 0.0]])
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    ps = []
+    for b in range(2):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        ps.append(p)
+    for i in range(3):
+        s.solve(new_run=(i == 0))
+        X, chi2, _ = s.get_solution()
+        for b in range(2):
+            st, c, _ = ps[b].solve(s.opts, new_run=(i == 0))
+            assert np.abs(X[b] - ps[b].x()).max() <= X_TOL, (i, b)
+            assert abs(chi2[b] - c) <= CHI2_RTOL * max(1.0, c)
+
+
+def test_edge_cases():
+    d = problems.unicycle_desc(N=12)
+    # iterations = 0: nothing moves, chi2 = |values|^2 of the initial point, Converged (rho = 0)
+    s = BatchedLevenbergMarquardt(d, 3)
+    s.setIterations(0)
+    s.setPenaltyWeights(10, 10, 10)
+    x0, xf = problems.unicycle_instances(3)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    assert np.array_equal(X, X0) and np.all(status == capi.SOLVER_CONVERGED)
+    values, _ = s.eval(jacobian=False)
+    assert np.allclose(chi2, (values ** 2).sum(axis=1), rtol=1e-13)
+    # start == goal: already optimal, |delta| <= eps2 path, trajectory unchanged to 1e-9
+    s2 = BatchedLevenbergMarquardt(d, 1)
+    s2.setIterations(3)
+    X1 = s2.init_trajectory([[0.3, -0.2, 0.1]], [[0.3, -0.2, 0.1]])
+    s2.set_instance_data(X1, xref=np.array([[0.3, -0.2, 0.1]]))
+    s2.solve()
+    X, chi2, status = s2.get_solution()
+    assert np.abs(X - X1).max() < 1e-9 and chi2[0] < 1e-18 and status[0] == capi.SOLVER_CONVERGED
+    # solve before data -> state error, loudly
+    s3 = BatchedLevenbergMarquardt(d, 1)
+    with pytest.raises(Exception):
+        s3.solve()
+
+
+def test_full_size_properties():
+    """BASELINE headline size (batch 1024, N=100): size-independent properties instead of a CPU comparison."""
+    d = problems.unicycle_desc()
+    B = 1024
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(10)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    v0, _ = s.eval(jacobian=False)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    st = s.get_stats()
+    assert st["lm_iterations"] == B * 10
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(chi2))
+    assert np.all(chi2 <= (v0 ** 2).sum(axis=1) + 1e-9)            # LM never accepts an uphill step
+    assert np.array_equal(X[:, :3], X0[:, :3])                       # x_0 is a fixed vertex
+    # chi2 reported == |values|^2 recomputed at the returned iterate
+    v1, _ = s.eval(jacobian=False)
+    assert np.allclose(chi2, (v1 ** 2).sum(axis=1), rtol=1e-12)
+    # batch independence: instance b of the batch == the same instance solved alone
+    for b in (0, 511, 1023):
+        s1 = BatchedLevenbergMarquardt(d, 1)
+        s1.setIterations(10)
+        s1.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+        s1.set_instance_data(X0[b:b + 1], xref=xf[b:b + 1])
+        s1.solve()
+        x1, c1, _ = s1.get_solution()
+        assert np.array_equal(x1[0], X[b]) and c1[0] == chi2[b]
+    # idempotence of the sweep: two evaluations of the same iterate are bit-identical
+    va, ja = s.eval()
+    vb, jb = s.eval()
+    assert np.array_equal(va, vb) and np.array_equal(ja, jb)
