@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- SQP(=LM outer)-iterations/s of the MI355X-native NLP inner loop on the BASELINE headline config.
+
+Workload (BASELINE.json configs[2]): unicycle point-to-point OCP, nx=3 nu=2, FiniteDifferencesGrid N=100,
+Crank-Nicolson, fp64, batch=1024 independent seeded instances PER GPU, 10 LM iterations per solve (reference default,
+no early exit).  One "step" = one corbo_hip_solve of the whole resident batch (= batch x 10 SQP iterations), preceded
+by a device-to-device re-arm of the initial trajectories (inputs are resident in HBM before the timed region starts).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iterations I]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Multi-GPU: the batch is the sharding unit (independent OCPs, no data-path collective);
+every rank solves its own `batch` instances (weak scaling), RCCL is used only for the barrier, the max-over-ranks time and
+the reduction of the solution statistics.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
+    """Reference CPU path timed on this box's host cores (rank 0, bounded sample of the same seeded workload).
+
+    kind="reference": the genuine control_box_rst LevenbergMarquardtSparse path (oracle/_ref/ref_driver, compiled from the
+    reference's own sources by oracle/Makefile in the build container; the binary travels, the sources do not).
+    The C restatement (oracle/, kind="port", static sparsity pattern) is timed next to it and reported as `port_value`.
+    """
+    from oracle import oracle as O
+    out = {}
+    # --- port: oracle/liboracle.so, 1 thread
+    p = O.OracleProblem(desc)
+    n_port = min(len(x0), 256)
+    X = np.stack([p.init_trajectory(x0[b], xf[b]) for b in range(n_port)])
+    t0 = time.perf_counter()
+    done = 0
+    for lo in range(0, n_port, 32):
+        hi = min(n_port, lo + 32)
+        O.solve_batch(desc, X[lo:hi], xf[lo:hi], opts)
+        done = hi
+        if time.perf_counter() - t0 > seconds_budget / 2:
+            break
+    t_port = time.perf_counter() - t0
+    port_value = done * opts.iterations / t_port
+    out["port_value"] = port_value
+    out["port_sample"] = f"{done} seeded instances x {opts.iterations} LM iterations, oracle/liboracle.so, 1 thread"
+    # --- genuine reference, 1 thread
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if os.path.exists(drv) and os.access(drv, os.X_OK):
+        n_ref = 64
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            np.savetxt(f, np.hstack([x0[:n_ref], xf[:n_ref]]), fmt="%.17g")
+            path = f.name
+        try:
+            r = json.loads(subprocess.check_output([drv, "bench", "scenario=unicycle", f"instances={path}", f"iters={opts.iterations}",
+                                                    f"N={desc.N}"], timeout=300))
+            out.update({"value": r["iter_per_s"], "unit": "SQP-iterations/s", "cores": 1, "kind": "reference",
+                        "sample": f"{r['batch']} seeded instances x {opts.iterations} LM iterations = {r['solve_seconds']:.2f} s of "
+                                  "LevenbergMarquardtSparse::solve (genuine reference, oracle/_ref/ref_driver), 1 thread"})
+        finally:
+            os.unlink(path)
+    if "value" not in out:
+        out.update({"value": port_value, "unit": "SQP-iterations/s", "cores": 1, "kind": "port", "sample": out["port_sample"]})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="OCP instances per GPU")
+    ap.add_argument("--iterations", type=int, default=10, help="LM outer iterations per solve")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if dist is not None:
+        dist.barrier()
+    from control_box_rst_amd import problems
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+
+    desc = problems.unicycle_desc()
+    B = args.batch
+    x0, xf = problems.unicycle_instances(B, first=rank * B)  # rank r owns global instances [r*B, (r+1)*B)
+    solver = BatchedLevenbergMarquardt(desc, B, device=local_rank)
+    solver.setIterations(args.iterations)
+    solver.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = solver.init_trajectory(x0, xf)
+    solver.set_instance_data(X0, xref=xf)  # H2D once; everything below runs on HBM-resident data
+
+    def step():
+        solver.restore_instance_data()
+        solver.solve(new_run=True)
+
+    def fence():
+        solver.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    stats = solver.get_stats()
+    X, chi2, status = solver.get_solution()
+    t_local = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    agg = torch.tensor([float(stats["lm_iterations"]), float(stats["accepted_steps"]), float(chi2.sum()),
+                        float((status <= 1).sum())], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t_local, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    t_max = float(t_local.item())
+    total_iters_per_step = float(agg[0].item())  # = world * batch * iterations
+    value = total_iters_per_step * args.steps / t_max
+
+    # ---- roofline leg: the edge/Jacobian sweep kernel, timed with HIP events on the solver's own stream
+    dims = solver.dims
+    b_sweep = 8 * (dims.nv + 2 * dims.n + dims.m + dims.nnz)  # SURVEY 8d algorithmic bytes per instance per sweep
+    sweep_ms = solver.time_sweep(with_jacobian=True, repeat=50)
+    achieved = B * b_sweep / (sweep_ms * 1e-3) / 1e9
+    peak = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
+    # per-kernel split inside one solve (separate, profiled solve: event stamping is kept out of the timed region)
+    solver.set_profiling(True)
+    step()
+    prof = solver.get_stats()
+    solver.set_profiling(False)
+
+    if rank == 0:
+        line = {
+            "metric": "SQP-iterations/sec over batch=1024 OCPs (nx=3,nu=2,N=100,fp64)",
+            "value": value,
+            "unit": "SQP-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: unicycle point-to-point nx=3 nu=2, FiniteDifferencesGrid N=100 Crank-Nicolson, "
+                                   f"batch={B} per GPU, {args.iterations} LM iterations per solve, seeds 20260928+i",
+                       "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations,
+                       "parallelism": f"batch-sharded x{world}"},
+            "batch_steps_per_s": value / (B * world),
+            "solve_stats": {"passes": stats["passes"], "lm_iterations": int(agg[0].item()), "accepted": int(agg[1].item()),
+                            "rejected_local": stats["rejected_steps"], "chi2_sum": float(agg[2].item()),
+                            "ok_instances": int(agg[3].item())},
+            "kernel_split_ms": {"solve": prof["solve_ms"], "sweep": prof["sweep_ms"], "factor": prof["factor_ms"]},
+            "roofline": {"bound": "hbm", "kernel": "sweep_kernel (residual + Jacobian, all instances)", "achieved": achieved,
+                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": None,
+                         "bytes_per_launch": B * b_sweep, "ms_per_launch": sweep_ms},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(desc, solver.opts, x0, xf)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_create", "corbo_hip_destroy", "corbo_hip_set_instance_data", "corbo_hip_solve",
     "corbo_hip_synchronize", "corbo_hip_get_solution", "corbo_hip_get_stats", "corbo_hip_eval",
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
+    "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor",
 )
 
 
@@ -104,6 +105,8 @@ def load() -> C.CDLL:
     lib.corbo_hip_destroy.argtypes = [H]
     lib.corbo_hip_destroy.restype = None
     lib.corbo_hip_set_instance_data.argtypes = [H, dp, dp, dp, dp]
+    lib.corbo_hip_restore_instance_data.argtypes = [H]
+    lib.corbo_hip_set_profiling.argtypes = [H, C.c_int]
     lib.corbo_hip_solve.argtypes = [H, C.POINTER(LmOpts), C.c_int]
     lib.corbo_hip_synchronize.argtypes = [H]
     lib.corbo_hip_get_solution.argtypes = [H, dp, dp, ip]
@@ -111,6 +114,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_eval.argtypes = [H, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.corbo_hip_device_views.argtypes = [H, C.POINTER(dp), C.POINTER(dp), C.POINTER(C.c_void_p)]
     lib.corbo_hip_time_sweep.argtypes = [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.corbo_hip_time_factor.argtypes = [H, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]
     lib.corbo_hip_last_error.argtypes = []
     lib.corbo_hip_last_error.restype = C.c_char_p
     _lib = lib

@@ -55,6 +55,7 @@ struct corbo_hip_solver {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_chk[2] = {nullptr, nullptr};
     // static tables
     RowTask* d_row_tasks     = nullptr;
     ColTask* d_col_tasks     = nullptr;
@@ -64,6 +65,7 @@ struct corbo_hip_solver {
     int32_t* d_ineq_cols     = nullptr;
     int32_t* d_ineq_rows     = nullptr;
     // per-instance data (HBM resident)
+    double *d_x0 = nullptr;  // shadow of the uploaded x (corbo_hip_restore_instance_data)
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
@@ -179,6 +181,8 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[1], hipEventDisableTiming));
     if (upload(S.row_tasks, &h->d_row_tasks) || upload(S.col_tasks, &h->d_col_tasks) || upload(S.bound_tasks, &h->d_bound_tasks) ||
         upload(S.stage_cols, &h->d_stage_cols) || upload(S.comp, &h->d_comp) || upload(S.ineq_cols, &h->d_ineq_cols) ||
         upload(S.ineq_rows, &h->d_ineq_rows)) {
@@ -191,6 +195,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     const size_t B = (size_t)batch;
     CREATE_TRY(hipMalloc((void**)&h->d_x, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xt, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_x0, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_lb, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_ub, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xref, B * CORBO_HIP_MAX_NX * sizeof(double)));
@@ -201,7 +206,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipMalloc((void**)&h->d_chi2, B * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, MAX_PASSES * sizeof(int32_t)));
-    CREATE_TRY(hipHostMalloc((void**)&h->h_counter, sizeof(int32_t)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * sizeof(int32_t)));
     CREATE_TRY(hipMemset(h->d_state, 0, B * sizeof(LmState)));
     CREATE_TRY(hipMemset(h->d_values0, 0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_values1, 0, B * h->m_pad * sizeof(double)));
@@ -219,12 +224,13 @@ void corbo_hip_destroy(corbo_hip_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_row_tasks, h->d_col_tasks, h->d_bound_tasks, h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_counters};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_counters};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev_chk) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -262,6 +268,7 @@ int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const doubl
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->d_x, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_xt, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_x0, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_lb, blb.data(), blb.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_ub, bub.data(), bub.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_xref, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -313,20 +320,35 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
     const FactorParams fp = h->factor_params();
     int pass = 0;
     int remaining = (o->iterations > 0) ? h->batch : 0;
-    int chunk = o->iterations;  // every instance needs at least `iterations` passes
-    while (remaining > 0 && pass < MAX_PASSES) {
-        for (int c = 0; c < chunk && pass < MAX_PASSES; ++c, ++pass) {
-            rc = launch_factor_checked(h, fp);
-            if (rc) return rc;
+    auto enqueue_passes = [&](int count) -> int {
+        for (int c = 0; c < count && pass < MAX_PASSES; ++c, ++pass) {
+            int r = launch_factor_checked(h, fp);
+            if (r) return r;
             stamp();
-            rc = launch_sweep_checked(h, h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass));
-            if (rc) return rc;
+            r = launch_sweep_checked(h, h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass));
+            if (r) return r;
             stamp();
         }
-        HIP_TRY(hipMemcpyAsync(h->h_counter, h->d_counters + (pass - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        remaining = *h->h_counter;
-        chunk     = 1;
+        return 0;
+    };
+    if (remaining > 0) {
+        // Every instance needs at least `iterations` passes.  After that the host reads one "unfinished instances" counter per
+        // group of passes, always with the NEXT group already enqueued, so the GPU never waits for the host; finished
+        // instances make their workgroups exit at once, so an overshooting group costs a few microseconds.
+        rc = enqueue_passes(o->iterations);
+        if (rc) return rc;
+        constexpr int GROUP = 2;
+        int slot = 0;
+        while (pass < MAX_PASSES) {
+            HIP_TRY(hipMemcpyAsync(h->h_counter + slot, h->d_counters + (pass - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipEventRecord(h->ev_chk[slot], h->stream));
+            rc = enqueue_passes(GROUP);  // speculative
+            if (rc) return rc;
+            HIP_TRY(hipEventSynchronize(h->ev_chk[slot]));
+            remaining = h->h_counter[slot];
+            slot ^= 1;
+            if (remaining == 0) break;
+        }
     }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
@@ -344,6 +366,22 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
     }
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     if (remaining > 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_restore_instance_data(corbo_hip_handle h)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_x, h->d_x0, (size_t)h->batch * h->S.nvs * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_set_profiling(corbo_hip_handle h, int enable)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    h->profile = enable != 0;
     return CORBO_HIP_OK;
 }
 
@@ -447,6 +485,43 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_per_launch = ms / repeat;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, long long* timeline8)
+{
+    if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    HIP_TRY(hipSetDevice(h->device));
+    // LM prologue (residual + Jacobian + state init), then the assemble/factor/solve kernel `repeat` times on that state
+    corbo_hip_lm_opts o;
+    corbo_hip_default_lm_opts(&o);
+    int rc = launch_sweep_checked(h, h->sweep_params(2, o.iterations, h->w_eq, h->w_ineq, h->w_b, nullptr));
+    if (rc) return rc;
+    FactorParams fp = h->factor_params();
+    rc = launch_factor_checked(h, fp);  // warm-up (also consumes the `first` pass)
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < repeat; ++i) {
+        rc = launch_factor_checked(h, fp);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_launch = ms / repeat;
+    if (timeline8) {
+        long long* d_tl = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_tl, 8 * sizeof(long long)));
+        HIP_TRY(hipMemset(d_tl, 0, 8 * sizeof(long long)));
+        fp.timeline = d_tl;
+        rc = launch_factor_checked(h, fp);
+        if (rc) { (void)hipFree(d_tl); return rc; }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(timeline8, d_tl, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d_tl);
+    }
     return CORBO_HIP_OK;
 }
 

@@ -2,8 +2,8 @@
 //
 //  sweep_kernel   one workgroup per OCP instance.  Evaluates every hypergraph edge (stage cost, dynamics defect, stage
 //                 inequality, bounds) -> stacked residual, and every central-difference Jacobian column, one lane per
-//                 (edge, vertex component) column task, vertices staged in LDS, Jacobian staged in LDS and streamed to
-//                 HBM with 16-byte coalesced stores.  In LM mode it also runs the trial-step bookkeeping (rho,
+//                 (edge, vertex component) column task, vertices and per-state dynamics caches staged in LDS, every
+//                 Jacobian column stored to HBM as soon as it is computed (stores overlap the remaining columns).  In LM mode it also runs the trial-step bookkeeping (rho,
 //                 accept/reject, mu update) of LevenbergMarquardtSparse::solve so the residual re-evaluation of the line
 //                 search is the same kernel (levenberg_marquardt_sparse.cpp:158-213).
 //  factor_kernel  one workgroup per OCP instance.  Assembles H = J^T J + mu I and rhs = -J^T r from the block-sparse
@@ -62,9 +62,12 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     constexpr int S   = NX + NU;
     constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NC  = Dy::NC;
+    constexpr bool CACHED = DefectTraits<DEFECT>::cached;
     double* xs  = smem;                     // [nvs]      vertex values of this instance
-    double* js  = smem + p.nvs;             // [nnz_pad]  Jacobian staging
-    double* red = js + p.nnz_pad;           // [8]        reduction scratch / broadcast
+    double* red = smem + p.nvs;             // [8]        reduction scratch / broadcast
+    double* js  = p.jac + (size_t)blockIdx.x * p.nnz_pad;  // Jacobian values of this instance (HBM), written column by column
+    double* cs  = red + 10;                 // [N*NC]     per-grid-state dynamics caches (prepare(x_k))
     int* flags  = reinterpret_cast<int*>(red + 8);  // [4]
 
     const int inst = blockIdx.x;
@@ -99,6 +102,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
     __syncthreads();
+    if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
+        for (int k = tid; k < p.N; k += SWEEP_THREADS) {
+            double c[NC];
+            Dy::prepare(xs + k * S, p.mp.dyn, c);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
+        }
+        __syncthreads();
+    }
 
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
     double sq_acc = 0.0;
@@ -108,7 +120,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
         switch (rt.kind) {
             case EK_DEFECT: {
                 double e[NX];
-                defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
+                if constexpr (CACHED)
+                    defect_eval_cached<DYN, DEFECT>(xs + base, cs + rt.k * NC, xs + base + NX, xs + base + S, cs + (rt.k + 1) * NC,
+                                                    xs[p.off_dt], p.mp.dyn, e);
+                else
+                    defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     const double v   = e[i] * p.w_eq;
@@ -259,14 +275,44 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
             for (int i = 0; i < W; ++i) loc[i] = xs[base + i];
             double dt = xs[p.off_dt];
             double v1[NX], v2[NX];
+            if constexpr (CACHED) {
+                double c1[NC], c2[NC];
 #pragma unroll
-            for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + delta : loc[i];  // vertex->plus(i, delta)
-            dt = is_dt ? dt + delta : dt;
-            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v2);
+                for (int i = 0; i < NC; ++i) { c1[i] = cs[ct.k * NC + i]; c2[i] = cs[(ct.k + 1) * NC + i]; }
+                const bool px1 = (idx >= 0 && idx < NX), px2 = (idx >= S);
+                const int xi   = px2 ? idx - S : idx;
+                const bool need = (px1 || px2) && ((Dy::CACHE_XMASK >> xi) & 1u);
 #pragma unroll
-            for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + neg2delta : loc[i];  // vertex->plus(i, neg2delta)
-            dt = is_dt ? dt + neg2delta : dt;
-            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v1);
+                for (int side = 0; side < 2; ++side) {
+                    const double inc = side == 0 ? delta : neg2delta;  // vertex->plus(i, delta) ; vertex->plus(i, neg2delta)
+#pragma unroll
+                    for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + inc : loc[i];
+                    dt = is_dt ? dt + inc : dt;
+                    double d1[NC], d2[NC];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) { d1[i] = c1[i]; d2[i] = c2[i]; }
+                    if (Dy::CACHE_XMASK != 0u && need) {  // only the perturbed state's cache is recomputed
+                        double xp[NX], cp[NC];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) xp[i] = px2 ? loc[S + i] : loc[i];
+                        Dy::prepare(xp, p.mp.dyn, cp);
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) { d1[i] = px2 ? c1[i] : cp[i]; d2[i] = px2 ? cp[i] : c2[i]; }
+                    }
+                    if (side == 0) defect_eval_cached<DYN, DEFECT>(loc, d1, loc + NX, loc + S, d2, dt, p.mp.dyn, v2);
+                    else defect_eval_cached<DYN, DEFECT>(loc, d1, loc + NX, loc + S, d2, dt, p.mp.dyn, v1);
+                }
+            }
+            else {
+#pragma unroll
+                for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + delta : loc[i];  // vertex->plus(i, delta)
+                dt = is_dt ? dt + delta : dt;
+                defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v2);
+#pragma unroll
+                for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + neg2delta : loc[i];  // vertex->plus(i, neg2delta)
+                dt = is_dt ? dt + neg2delta : dt;
+                defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v1);
+            }
 #pragma unroll
             for (int r = 0; r < NX; ++r) js[ct.joff + r] = (scalar * (v2[r] - v1[r])) * p.w_eq;  // :1552
         }
@@ -318,11 +364,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
         const double xv = xs[bt.voff], l = p.lb[xo + bt.voff], u = p.ub[xo + bt.voff];
         js[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
     }
-    __syncthreads();
-    // ---- stream the Jacobian values to HBM, 16 bytes per lane, fully coalesced
-    double* jdst = p.jac + (size_t)inst * p.nnz_pad;
-    for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
-        reinterpret_cast<double2*>(jdst)[i] = reinterpret_cast<const double2*>(js)[i];
 }
 
 #pragma clang fp contract(fast)
@@ -340,7 +381,7 @@ __device__ __forceinline__ void chol_inv(double (&M)[Nn][Nn])
         double d = M[j][j];
 #pragma unroll
         for (int c = 0; c < j; ++c) d -= M[j][c] * M[j][c];
-        const double inv = 1.0 / sqrt(d);
+        const double inv = rsqrt(d);  // 1/L_jj (NaN for a non-positive pivot, like an unchecked LLT: chi2 -> NaN -> step rejected)
         M[j][j]          = inv;
 #pragma unroll
         for (int i = j + 1; i < Nn; ++i) {
@@ -390,29 +431,34 @@ __device__ __forceinline__ void bwd_solve_vec(const double (&L)[Nn][Nn], double 
 }
 
 #define SOA(arr, e, k) (arr)[(e) * NP + (k)]
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower triangle, i >= j
+#define STAMP(id)                                                       \
+    do {                                                                \
+        if (p.timeline && inst == 0 && tid == 0) p.timeline[id] = clock64(); \
+    } while (0)
 
-template <int NX, int NU, int THREADS>
+template <int NX, int NU, int THREADS, bool ARROW>
 __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
+    constexpr int NT = NX * (NX + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N  = p.N;
     const int NP = N | 1;
-    // SoA arrays, element-major: arr[e][block]
-    double* Luu = smem;                    // NU*NU
+    // SoA arrays, element-major: arr[e][block].  Per state block: D/L (packed lower), W_a, W_b, rhs/y/x; per stage: the
+    // eliminated controls.  Slots of block k+1 double as the mailbox for what stage k contributes to it.
+    double* Luu = smem;                    // NU*NU   L_uu (diag inverted)
     double* Zx  = Luu + NU * NU * NP;      // NU*NX   L_uu^{-1} H(u_k, x_k)
     double* Zp  = Zx + NU * NX * NP;       // NU*NX   L_uu^{-1} H(u_k, x_{k+1})
     double* yu  = Zp + NU * NX * NP;       // NU
-    double* zu  = yu + NU * NP;            // NU      (arrowhead)
-    double* Dm  = zu + NU * NP;            // NX*NX   diagonal blocks -> L_i
-    double* Cm  = Dm + NX * NX * NP;       // NX*NX   coupling H(i+h, i) -> W_b
-    double* Wm  = Cm + NX * NX * NP;       // NX*NX   neighbour partials, then W_a
-    double* gv  = Wm + NX * NX * NP;       // NX      rhs -> y -> delta x
-    double* gn  = gv + NX * NP;            // NX      neighbour partial of the rhs
-    double* bv  = gn + NX * NP;            // NX      border column (arrowhead) -> z
-    double* bn  = bv + NX * NP;            // NX
-    double* red = bn + NX * NP;            // 4*NW + 8
+    double* Dm  = yu + NU * NP;            // NT      D_i (packed lower) -> L_i
+    double* Wam = Dm + NT * NP;            // NX*NX   W_a = L_i^{-1} H(i, i-h)   (before: mailbox for H(k, k-1))
+    double* Wbm = Wam + NX * NX * NP;      // NX*NX   W_b = L_i^{-1} H(i, i+h)
+    double* gv  = Wbm + NX * NX * NP;      // NX      rhs -> y -> delta x
+    double* red = gv + NX * NP;            // 16
+    double* zu  = red + 16;                // NU      (arrowhead only from here on)
+    double* bv  = zu + NU * NP;            // NX      border column -> z
 
     const int inst = blockIdx.x;
     const int tid  = threadIdx.x;
@@ -423,11 +469,11 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
     const double mu_acc_in = st->mu_acc;
     __syncthreads();
     if (done) return;
+    STAMP(0);
 
     const double* J   = p.jac + (size_t)inst * p.nnz_pad;
     const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
     const double* xin = p.x + (size_t)inst * p.nvs;
-    const bool arrow  = p.dt_free != 0;
     const int k       = tid;
     const bool has_stage = (k < N - 1);
     const bool has_block = (k < N);
@@ -465,7 +511,7 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 #pragma unroll
                 for (int i = 0; i < NX; ++i) Cc[i][c] = J[o + i];
         }
-        {
+        if constexpr (ARROW) {
             const int o = sc.col[S + NX];
             if (o >= 0)
 #pragma unroll
@@ -511,7 +557,7 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
     }
     // border (dt) scalars: this lane's share of H(dt,dt) and rhs(dt)
     double cdt = 0, gdt = 0;
-    if (arrow) {
+    if constexpr (ARROW) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { cdt += dc[i] * dc[i]; gdt -= dc[i] * r[i]; }
         if (tid == 0) {
@@ -521,78 +567,79 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
             if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; cdt += a * a; gdt -= a * val[ci.bnd_row]; }
         }
     }
+    STAMP(1);
 
     // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
     int stop = stop_in;
-    {
-        double s_cdt = 0, s_gdt = 0;
-        if (first) {
-            // raw neighbour parts of x_{k+1}: diag(C^T C), -C^T r
+    if (first) {
+        // raw neighbour parts of x_{k+1}: diag(C^T C), -C^T r  (scratch: the W_b / rhs slots, rewritten below)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double dd = 0, gg = 0;
+        for (int i = 0; i < NX; ++i) {
+            double dd = 0, gg = 0;
 #pragma unroll
-                for (int q = 0; q < NX; ++q) { dd += Cc[q][i] * Cc[q][i]; gg -= Cc[q][i] * r[q]; }
-                if (has_stage) { SOA(Wm, i, k) = dd; SOA(gn, i, k) = gg; }
-            }
-            __syncthreads();
-            double mx_d = -1e300, mx_g = 0;
-#pragma unroll
-            for (int j = 0; j < NU; ++j)
-                if (has_stage) {
-                    double dd = du_diag[j], gg = gu[j];
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) { dd += B[q][j] * B[q][j]; gg -= B[q][j] * r[q]; }
-                    mx_d = fmax(mx_d, dd);
-                    mx_g = fmax(mx_g, fabs(gg));
-                }
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-                if (has_block && !xfixed[i]) {
-                    double dd = dx_diag[i] + cin[i] * cin[i], gg = gx[i] - cin[i] * rin;
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) { dd += A[q][i] * A[q][i]; gg -= A[q][i] * r[q]; }
-                    if (k >= 1) { dd += SOA(Wm, i, k - 1); gg += SOA(gn, i, k - 1); }
-                    mx_d = fmax(mx_d, dd);
-                    mx_g = fmax(mx_g, fabs(gg));
-                }
-            mx_d = wave_max(mx_d);
-            mx_g = wave_max(mx_g);
-            double sc_ = wave_sum(cdt), sg_ = wave_sum(gdt);
-            if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = mx_d; red[(tid >> 6) * 4 + 1] = mx_g; red[(tid >> 6) * 4 + 2] = sc_; red[(tid >> 6) * 4 + 3] = sg_; }
-            __syncthreads();
-            mx_d = red[0]; mx_g = red[1]; s_cdt = red[2]; s_gdt = red[3];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) { mx_d = fmax(mx_d, red[w * 4]); mx_g = fmax(mx_g, red[w * 4 + 1]); s_cdt += red[w * 4 + 2]; s_gdt += red[w * 4 + 3]; }
-            if (arrow) { mx_d = fmax(mx_d, s_cdt); mx_g = fmax(mx_g, fabs(s_gdt)); }
-            __syncthreads();
-            stop = (mx_g <= LM_EPS1) ? 1 : 0;
-            mu   = LM_TAU * mx_d;
-            if (mu < 0) mu = 0;
+            for (int q = 0; q < NX; ++q) { dd += Cc[q][i] * Cc[q][i]; gg -= Cc[q][i] * r[q]; }
+            if (has_stage) { SOA(Wbm, i, k) = dd; SOA(Wbm, NX + i, k) = gg; }
         }
+        __syncthreads();
+        double mx_d = -1e300, mx_g = 0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+            if (has_stage) {
+                double dd = du_diag[j], gg = gu[j];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) { dd += B[q][j] * B[q][j]; gg -= B[q][j] * r[q]; }
+                mx_d = fmax(mx_d, dd);
+                mx_g = fmax(mx_g, fabs(gg));
+            }
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (has_block && !xfixed[i]) {
+                double dd = dx_diag[i] + cin[i] * cin[i], gg = gx[i] - cin[i] * rin;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) { dd += A[q][i] * A[q][i]; gg -= A[q][i] * r[q]; }
+                if (k >= 1) { dd += SOA(Wbm, i, k - 1); gg += SOA(Wbm, NX + i, k - 1); }
+                mx_d = fmax(mx_d, dd);
+                mx_g = fmax(mx_g, fabs(gg));
+            }
+        mx_d = wave_max(mx_d);
+        mx_g = wave_max(mx_g);
+        double sc_ = wave_sum(cdt), sg_ = wave_sum(gdt);
+        if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = mx_d; red[(tid >> 6) * 4 + 1] = mx_g; red[(tid >> 6) * 4 + 2] = sc_; red[(tid >> 6) * 4 + 3] = sg_; }
+        __syncthreads();
+        double s_cdt = 0, s_gdt = 0;
+        mx_d = red[0]; mx_g = red[1]; s_cdt = red[2]; s_gdt = red[3];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { mx_d = fmax(mx_d, red[w * 4]); mx_g = fmax(mx_g, red[w * 4 + 1]); s_cdt += red[w * 4 + 2]; s_gdt += red[w * 4 + 3]; }
+        if (ARROW) { mx_d = fmax(mx_d, s_cdt); mx_g = fmax(mx_g, fabs(s_gdt)); }
+        __syncthreads();
+        stop = (mx_g <= LM_EPS1) ? 1 : 0;
+        mu   = LM_TAU * mx_d;
+        if (mu < 0) mu = 0;
     }
     // H_ii += mu on every inner pass, never undone on reject (:135-138 and the comment at :208)
     const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;
 
-    // ---- phase A: eliminate the controls of stage k (they couple only to x_k and x_{k+1})
-    double Dk[NX][NX], gk[NX], bk[NX];
+    // ---- phase A: eliminate the controls of stage k (they couple only to x_k and x_{k+1}); Schur pieces:
+    //      own block k stays in registers, the pieces for block k+1 go to that block's slots (mailbox)
+    double Dk[NX][NX], gk[NX], bk[NX], Ck[NX][NX];  // Ck = H'(x_{k+1}, x_k)
     double y2 = 0, zz = 0, zy = 0;  // running sums of |y|^2, |z|^2, z.y over the pivots this lane owns
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         gk[i] = 0; bk[i] = 0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) Dk[i][j] = 0;
+        for (int j = 0; j < NX; ++j) { Dk[i][j] = 0; Ck[i][j] = 0; }
     }
     if (has_stage) {
         double Huu[NU][NU];
 #pragma unroll
         for (int a = 0; a < NU; ++a)
 #pragma unroll
-            for (int b = 0; b < NU; ++b) {
+            for (int b = 0; b <= a; ++b) {
                 double v = 0;
 #pragma unroll
                 for (int q = 0; q < NX; ++q) v += B[q][a] * B[q][b];
                 Huu[a][b] = v;
+                Huu[b][a] = v;
             }
         double gu_[NU], bu_[NU];
 #pragma unroll
@@ -617,19 +664,17 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
         fwd_solve<NU, NX>(Huu, zx);
         fwd_solve<NU, NX>(Huu, zp);
         fwd_solve_vec<NU>(Huu, gu_);
-        if (arrow) fwd_solve_vec<NU>(Huu, bu_);
+        if constexpr (ARROW) fwd_solve_vec<NU>(Huu, bu_);
 #pragma unroll
         for (int a = 0; a < NU; ++a) {
             y2 += gu_[a] * gu_[a];
-            if (arrow) { zz += bu_[a] * bu_[a]; zy += bu_[a] * gu_[a]; }
+            if constexpr (ARROW) { zz += bu_[a] * bu_[a]; zy += bu_[a] * gu_[a]; SOA(zu, a, k) = bu_[a]; }
             SOA(yu, a, k) = gu_[a];
-            SOA(zu, a, k) = bu_[a];
 #pragma unroll
             for (int b = 0; b < NU; ++b) SOA(Luu, a * NU + b, k) = Huu[a][b];
 #pragma unroll
             for (int c = 0; c < NX; ++c) { SOA(Zx, a * NX + c, k) = zx[a][c]; SOA(Zp, a * NX + c, k) = zp[a][c]; }
         }
-        // Schur complement pieces
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double g1 = 0, g2 = 0, b1 = 0, b2 = 0;
@@ -638,8 +683,8 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 #pragma unroll
             for (int a = 0; a < NU; ++a) { g1 -= zx[a][i] * gu_[a]; g2 -= zp[a][i] * gu_[a]; b1 -= zx[a][i] * bu_[a]; b2 -= zp[a][i] * bu_[a]; }
             gk[i] = g1; bk[i] = b1;
-            SOA(gn, i, k) = g2;
-            SOA(bn, i, k) = b2;
+            SOA(gv, i, k + 1) = g2;
+            if constexpr (ARROW) SOA(bv, i, k + 1) = b2;
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 double d1 = 0, d2 = 0, cc = 0;
@@ -648,22 +693,24 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 #pragma unroll
                 for (int a = 0; a < NU; ++a) { d1 -= zx[a][i] * zx[a][j]; d2 -= zp[a][i] * zp[a][j]; cc -= zp[a][i] * zx[a][j]; }
                 Dk[i][j] = d1;
-                SOA(Wm, i * NX + j, k) = d2;  // partial of D_{k+1}
-                SOA(Cm, i * NX + j, k) = cc;  // H'(x_{k+1}, x_k)
+                Ck[i][j] = cc;
+                if (j <= i) SOA(Dm, TRI(i, j), k + 1) = d2;   // partial of D_{k+1}
+                SOA(Wam, i * NX + j, k + 1) = cc;             // H'(x_{k+1}, x_k), consumed by block k+1 if it is odd
             }
         }
     }
     __syncthreads();
-    // ---- phase B: complete state block k
+    STAMP(2);
+    // ---- phase B + cyclic-reduction level 0: complete state block k; odd blocks are eliminated at once
     if (has_block) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double g = gk[i] + gx[i] - cin[i] * rin, b = bk[i];
-            if (k >= 1) { g += SOA(gn, i, k - 1); b += SOA(bn, i, k - 1); }
+            if (k >= 1) { g += SOA(gv, i, k); if constexpr (ARROW) b += SOA(bv, i, k); }
 #pragma unroll
-            for (int j = 0; j < NX; ++j) {
+            for (int j = 0; j <= i; ++j) {
                 double d = Dk[i][j] + cin[i] * cin[j];
-                if (k >= 1) d += SOA(Wm, i * NX + j, k - 1);
+                if (k >= 1) d += SOA(Dm, TRI(i, j), k);
                 if (i == j) d += dx_diag[i] + mu_eff;
                 if (xfixed[i] || xfixed[j]) d = (i == j) ? 1.0 : 0.0;
                 Dk[i][j] = d;
@@ -671,171 +718,156 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
             if (xfixed[i]) { g = 0; b = 0; }
             gk[i] = g; bk[i] = b;
         }
-    }
-    __syncthreads();  // every lane has read its neighbour partials before Wm is reused as W_a
-    if (has_block) {
+        if (k & 1) {  // eliminate: neighbours a = k-1, b = k+1
+            double Wa[NX][NX], Wb[NX][NX];
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) {
+                    Wa[q][c] = SOA(Wam, q * NX + c, k);            // H(k, k-1) from stage k-1
+                    Wb[q][c] = (k + 1 < N) ? Ck[c][q] : 0.0;        // H(k, k+1) = H'(x_{k+1}, x_k)^T
+                }
+            chol_inv<NX>(Dk);
+            fwd_solve<NX, NX>(Dk, Wa);
+            fwd_solve<NX, NX>(Dk, Wb);
+            fwd_solve_vec<NX>(Dk, gk);
+            if constexpr (ARROW) fwd_solve_vec<NX>(Dk, bk);
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                y2 += gk[q] * gk[q];
+                if constexpr (ARROW) { zz += bk[q] * bk[q]; zy += bk[q] * gk[q]; }
+#pragma unroll
+                for (int c = 0; c < NX; ++c) { SOA(Wam, q * NX + c, k) = Wa[q][c]; SOA(Wbm, q * NX + c, k) = Wb[q][c]; }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             SOA(gv, i, k) = gk[i];
-            SOA(bv, i, k) = bk[i];
+            if constexpr (ARROW) SOA(bv, i, k) = bk[i];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) SOA(Dm, i * NX + j, k) = Dk[i][j];
+            for (int j = 0; j <= i; ++j) SOA(Dm, TRI(i, j), k) = Dk[i][j];
         }
     }
     __syncthreads();
+    STAMP(3);
 
-    // ---- block cyclic reduction on the state chain: at stride h eliminate the odd multiples of h
-    int hmax = 1;
-    for (int h = 1; h < N; h <<= 1) {
-        hmax = h;
-        {   // eliminate block i = h(2j+1)
-            const int i = h * (2 * tid + 1);
-            if (i < N) {
-                const int a = i - h, b = i + h;
-                double L[NX][NX], Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
+    // ---- cyclic reduction, levels h = 2, 4, ...: lane t owns the active block a = h*t.  It first applies the Schur updates of
+    //      the previous level (neighbours a -+ h/2 were eliminated there); odd t then eliminates a against a -+ h, whose
+    //      couplings it forms on the fly from those same neighbours.  The first h >= N leaves block 0 alone: the root.
+    int hroot = 2;
+    for (int h = 2;; h <<= 1) {
+        const int a = h * tid;
+        if (a < N) {
+            const int hh = h >> 1;
+            const int em = a - hh, ep = a + hh;
+            double D[NX][NX], g[NX], bb[NX], Ha[NX][NX], Hb[NX][NX];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                g[q]  = SOA(gv, q, a);
+                bb[q] = ARROW ? SOA(bv, q, a) : 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) { D[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), a) : 0.0; Ha[q][c] = 0; Hb[q][c] = 0; }
+            }
+            const bool elim = (tid & 1);
+            if (em >= 0) {  // a is the b-side of em
+                double Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
-                    y[q] = SOA(gv, q, i);
-                    z[q] = SOA(bv, q, i);
+                    y[q] = SOA(gv, q, em);
+                    z[q] = ARROW ? SOA(bv, q, em) : 0.0;
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) {
-                        L[q][c]  = SOA(Dm, q * NX + c, i);
-                        Wa[q][c] = SOA(Cm, q * NX + c, a);                         // H(i, a) = C_a
-                        Wb[q][c] = (b < N) ? SOA(Cm, c * NX + q, i) : 0.0;          // H(i, b) = C_i^T
-                    }
+                    for (int c = 0; c < NX; ++c) { Wb[q][c] = SOA(Wbm, q * NX + c, em); Wa[q][c] = elim ? SOA(Wam, q * NX + c, em) : 0.0; }
                 }
-                chol_inv<NX>(L);
-                fwd_solve<NX, NX>(L, Wa);
-                fwd_solve<NX, NX>(L, Wb);
-                fwd_solve_vec<NX>(L, y);
-                if (arrow) fwd_solve_vec<NX>(L, z);
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
-                    y2 += y[q] * y[q];
-                    if (arrow) { zz += z[q] * z[q]; zy += z[q] * y[q]; }
-                    SOA(gv, q, i) = y[q];
-                    SOA(bv, q, i) = z[q];
+#pragma unroll
+                    for (int t = 0; t < NX; ++t) { g[q] -= Wb[t][q] * y[t]; if constexpr (ARROW) bb[q] -= Wb[t][q] * z[t]; }
 #pragma unroll
                     for (int c = 0; c < NX; ++c) {
-                        SOA(Dm, q * NX + c, i) = L[q][c];
-                        SOA(Wm, q * NX + c, i) = Wa[q][c];
-                        SOA(Cm, q * NX + c, i) = Wb[q][c];
+                        double dd = 0, hx = 0;
+#pragma unroll
+                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += Wb[t][q] * Wb[t][c]; hx += Wb[t][q] * Wa[t][c]; }
+                        D[q][c] -= dd;
+                        Ha[q][c] = -hx;  // H(a, a-h) = -W_b(em)^T W_a(em)
                     }
                 }
             }
-        }
-        __syncthreads();
-        {   // update surviving block a = 2h*j from its eliminated neighbours a-h (as "b side") and a+h (as "a side")
-            const int a = 2 * h * tid;
-            if (a < N) {
-                const int il = a - h, ir = a + h;
-                double D[NX][NX], g[NX], bb[NX], Cn[NX][NX];
+            if (ep < N) {  // a is the a-side of ep
+                double Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
-                    g[q]  = SOA(gv, q, a);
-                    bb[q] = SOA(bv, q, a);
+                    y[q] = SOA(gv, q, ep);
+                    z[q] = ARROW ? SOA(bv, q, ep) : 0.0;
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) { D[q][c] = SOA(Dm, q * NX + c, a); Cn[q][c] = 0; }
-                }
-                if (ir < N) {
-                    double Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-                        y[q] = SOA(gv, q, ir);
-                        z[q] = SOA(bv, q, ir);
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) { Wa[q][c] = SOA(Wm, q * NX + c, ir); Wb[q][c] = SOA(Cm, q * NX + c, ir); }
-                    }
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-#pragma unroll
-                        for (int t = 0; t < NX; ++t) { g[q] -= Wa[t][q] * y[t]; bb[q] -= Wa[t][q] * z[t]; }
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) {
-                            double dd = 0, cn = 0;
-#pragma unroll
-                            for (int t = 0; t < NX; ++t) { dd += Wa[t][q] * Wa[t][c]; cn += Wb[t][q] * Wa[t][c]; }
-                            D[q][c] -= dd;
-                            Cn[q][c] = -cn;  // H'(a+2h, a) = -W_b^T W_a
-                        }
-                    }
-                }
-                if (il >= 0) {
-                    double Wb[NX][NX], y[NX], z[NX];
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-                        y[q] = SOA(gv, q, il);
-                        z[q] = SOA(bv, q, il);
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) Wb[q][c] = SOA(Cm, q * NX + c, il);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-#pragma unroll
-                        for (int t = 0; t < NX; ++t) { g[q] -= Wb[t][q] * y[t]; bb[q] -= Wb[t][q] * z[t]; }
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) {
-                            double dd = 0;
-#pragma unroll
-                            for (int t = 0; t < NX; ++t) dd += Wb[t][q] * Wb[t][c];
-                            D[q][c] -= dd;
-                        }
-                    }
+                    for (int c = 0; c < NX; ++c) { Wa[q][c] = SOA(Wam, q * NX + c, ep); Wb[q][c] = elim ? SOA(Wbm, q * NX + c, ep) : 0.0; }
                 }
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
-                    SOA(gv, q, a) = g[q];
-                    SOA(bv, q, a) = bb[q];
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) { SOA(Dm, q * NX + c, a) = D[q][c]; SOA(Cm, q * NX + c, a) = Cn[q][c]; }
+                    for (int t = 0; t < NX; ++t) { g[q] -= Wa[t][q] * y[t]; if constexpr (ARROW) bb[q] -= Wa[t][q] * z[t]; }
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) {
+                        double dd = 0, hx = 0;
+#pragma unroll
+                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += Wa[t][q] * Wa[t][c]; hx += Wa[t][q] * Wb[t][c]; }
+                        D[q][c] -= dd;
+                        Hb[q][c] = -hx;  // H(a, a+h) = -W_a(ep)^T W_b(ep)   (zero when a+h >= N: W_b(ep) = 0)
+                    }
                 }
             }
+            const bool root = (h >= N);  // only a == 0 is active then
+            if (elim || root) {
+                chol_inv<NX>(D);
+                fwd_solve_vec<NX>(D, g);
+                if constexpr (ARROW) fwd_solve_vec<NX>(D, bb);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    y2 += g[q] * g[q];
+                    if constexpr (ARROW) { zz += bb[q] * bb[q]; zy += bb[q] * g[q]; }
+                }
+                if (!root) {
+                    fwd_solve<NX, NX>(D, Ha);
+                    fwd_solve<NX, NX>(D, Hb);
+#pragma unroll
+                    for (int q = 0; q < NX; ++q)
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) { SOA(Wam, q * NX + c, a) = Ha[q][c]; SOA(Wbm, q * NX + c, a) = Hb[q][c]; }
+                }
+                else if constexpr (!ARROW) bwd_solve_vec<NX>(D, g);  // no border: the root is back-substituted right away
+            }
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                SOA(gv, q, a) = g[q];
+                if constexpr (ARROW) SOA(bv, q, a) = bb[q];
+#pragma unroll
+                for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
+            }
         }
+        hroot = h;
+        if (h >= N) break;
         __syncthreads();
     }
-    // root block 0
-    if (tid == 0) {
-        double L[NX][NX], y[NX], z[NX];
-#pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            y[q] = SOA(gv, q, 0);
-            z[q] = SOA(bv, q, 0);
-#pragma unroll
-            for (int c = 0; c < NX; ++c) L[q][c] = SOA(Dm, q * NX + c, 0);
-        }
-        chol_inv<NX>(L);
-        fwd_solve_vec<NX>(L, y);
-        if (arrow) fwd_solve_vec<NX>(L, z);
-#pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            y2 += y[q] * y[q];
-            if (arrow) { zz += z[q] * z[q]; zy += z[q] * y[q]; }
-            SOA(gv, q, 0) = y[q];
-            SOA(bv, q, 0) = z[q];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) SOA(Dm, q * NX + c, 0) = L[q][c];
-        }
-    }
+    STAMP(4);
     // ---- reductions: |y|^2 (= delta^T rhs), and for the arrowhead the last pivot
     double ddt = 0;
     {
-        double a0 = wave_sum(y2), a1 = wave_sum(zz), a2 = wave_sum(zy), a3 = wave_sum(cdt), a4 = wave_sum(gdt);
-        __syncthreads();
+        double a0 = wave_sum(y2), a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        if constexpr (ARROW) { a1 = wave_sum(zz); a2 = wave_sum(zy); a3 = wave_sum(cdt); a4 = wave_sum(gdt); }
         if ((tid & 63) == 0) { double* rr = red + (tid >> 6) * 5; rr[0] = a0; rr[1] = a1; rr[2] = a2; rr[3] = a3; rr[4] = a4; }
         __syncthreads();
         a0 = a1 = a2 = a3 = a4 = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { a0 += red[w * 5]; a1 += red[w * 5 + 1]; a2 += red[w * 5 + 2]; a3 += red[w * 5 + 3]; a4 += red[w * 5 + 4]; }
         y2 = a0;
-        if (arrow) {
-            const double piv = (a3 + mu_eff) - a1;   // H(dt,dt) + damping - |z|^2
-            const double ydt = (a4 - a2) / sqrt(piv);
+        if constexpr (ARROW) {
+            const double piv  = (a3 + mu_eff) - a1;   // H(dt,dt) + damping - |z|^2
+            const double linv = rsqrt(piv);
+            const double ydt  = (a4 - a2) * linv;
             y2 += ydt * ydt;
-            ddt = ydt / sqrt(piv);
+            ddt = ydt * linv;
         }
-        __syncthreads();
     }
-    if (arrow) {  // y := y - z * delta_dt  (back-substitution of the last pivot)
+    if constexpr (ARROW) {  // y := y - z * delta_dt  (back-substitution of the last pivot), then the root
         if (has_block)
 #pragma unroll
             for (int q = 0; q < NX; ++q) SOA(gv, q, k) -= SOA(bv, q, k) * ddt;
@@ -843,43 +875,64 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 #pragma unroll
             for (int a = 0; a < NU; ++a) SOA(yu, a, k) -= SOA(zu, a, k) * ddt;
         __syncthreads();
-    }
-    // ---- back-substitution, root first
-    if (tid == 0) {
-        double L[NX][NX], y[NX];
-#pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            y[q] = SOA(gv, q, 0);
-#pragma unroll
-            for (int c = 0; c < NX; ++c) L[q][c] = SOA(Dm, q * NX + c, 0);
-        }
-        bwd_solve_vec<NX>(L, y);
-#pragma unroll
-        for (int q = 0; q < NX; ++q) SOA(gv, q, 0) = y[q];
-    }
-    __syncthreads();
-    for (int h = hmax; h >= 1; h >>= 1) {
-        const int i = h * (2 * tid + 1);
-        if (i < N) {
-            const int a = i - h, b = i + h;
+        if (tid == 0) {
             double L[NX][NX], y[NX];
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
-                double v = SOA(gv, q, i);
+                y[q] = SOA(gv, q, 0);
 #pragma unroll
-                for (int c = 0; c < NX; ++c) {
-                    v -= SOA(Wm, q * NX + c, i) * SOA(gv, c, a);
-                    if (b < N) v -= SOA(Cm, q * NX + c, i) * SOA(gv, c, b);
-                    L[q][c] = SOA(Dm, q * NX + c, i);
-                }
-                y[q] = v;
+                for (int c = 0; c < NX; ++c) L[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), 0) : 0.0;
             }
             bwd_solve_vec<NX>(L, y);
 #pragma unroll
-            for (int q = 0; q < NX; ++q) SOA(gv, q, i) = y[q];
+            for (int q = 0; q < NX; ++q) SOA(gv, q, 0) = y[q];
         }
         __syncthreads();
     }
+    STAMP(5);
+    // ---- back-substitution down the elimination tree; the factor data of the NEXT level is fetched before the barrier
+    {
+        int h = hroot >> 1;  // largest stride with eliminated blocks
+        double L[NX][NX], Wa[NX][NX], Wb[NX][NX], y[NX];
+        auto prefetch = [&](int hh) {
+            const int i = hh * (2 * tid + 1);
+            if (i < N) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    y[q] = SOA(gv, q, i);
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) {
+                        L[q][c]  = (c <= q) ? SOA(Dm, TRI(q, c), i) : 0.0;
+                        Wa[q][c] = SOA(Wam, q * NX + c, i);
+                        Wb[q][c] = SOA(Wbm, q * NX + c, i);
+                    }
+                }
+            }
+        };
+        prefetch(h);
+        for (; h >= 1; h >>= 1) {
+            const int i = h * (2 * tid + 1);
+            if (i < N) {
+                const int a = i - h, b = i + h;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    double v = y[q];
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) {
+                        v -= Wa[q][c] * SOA(gv, c, a);
+                        if (b < N) v -= Wb[q][c] * SOA(gv, c, b);
+                    }
+                    y[q] = v;
+                }
+                bwd_solve_vec<NX>(L, y);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) SOA(gv, q, i) = y[q];
+            }
+            if (h > 1) prefetch(h >> 1);  // touches only blocks that are still untouched by the back-substitution
+            __syncthreads();
+        }
+    }
+    STAMP(6);
     // ---- controls, trial iterate, step norms
     double dn2 = 0;
     double* xt = p.xt + (size_t)inst * p.nvs;
@@ -913,13 +966,14 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
         }
     }
     if (tid == 0) {
-        if (arrow) { dn2 += ddt * ddt; xt[p.off_dt] = xin[p.off_dt] + ddt; }
+        if (ARROW) { dn2 += ddt * ddt; xt[p.off_dt] = xin[p.off_dt] + ddt; }
         else xt[p.off_dt] = xin[p.off_dt];
-        if (dl) dl[p.off_dt] = arrow ? ddt : 0.0;
+        if (dl) dl[p.off_dt] = ARROW ? ddt : 0.0;
         if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
     }
     {
         double a0 = wave_sum(dn2);
+        __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = a0;
         __syncthreads();
         if (tid == 0) {
@@ -940,8 +994,11 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
             *st = s;
         }
     }
+    STAMP(7);
 }
 
+#undef STAMP
+#undef TRI
 #undef SOA
 
 template <int DYN, int DEFECT>
@@ -964,30 +1021,39 @@ bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
 }
 
 template <int NX, int NU>
-size_t factor_lds(int N)
+size_t factor_lds(int N, bool arrow)
 {
     const int NP = N | 1;
-    return sizeof(double) * ((size_t)NP * (NU * NU + 2 * NU * NX + 2 * NU + 3 * NX * NX + 4 * NX) + 64);
+    size_t per_block = NU * NU + 2 * NU * NX + NU + NX * (NX + 1) / 2 + 2 * NX * NX + NX;
+    if (arrow) per_block += NU + NX;
+    return sizeof(double) * ((size_t)NP * per_block + 16);
+}
+
+template <int NX, int NU, bool ARROW>
+bool launch_factor_a(const FactorParams& p, hipStream_t stream)
+{
+    const size_t lds = factor_lds<NX, NU>(p.N, ARROW);
+    if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128, ARROW>), dim3(p.batch), dim3(128), lds, stream, p);
+    else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256, ARROW>), dim3(p.batch), dim3(256), lds, stream, p);
+    else return false;
+    return true;
 }
 
 template <int NX, int NU>
 bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 {
-    const size_t lds = factor_lds<NX, NU>(p.N);
-    if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128>), dim3(p.batch), dim3(128), lds, stream, p);
-    else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256>), dim3(p.batch), dim3(256), lds, stream, p);
-    else return false;
-    return true;
+    return p.dt_free ? launch_factor_a<NX, NU, true>(p, stream) : launch_factor_a<NX, NU, false>(p, stream);
 }
 
 }  // namespace
 
-size_t sweep_lds_bytes(const SweepParams& p) { return sizeof(double) * ((size_t)p.nvs + p.nnz_pad + 8) + 16; }
+size_t sweep_lds_bytes(const SweepParams& p) { return sizeof(double) * ((size_t)p.nvs + 10 + (size_t)p.N * 2 + 2); }
 
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
 {
-    if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N);
-    if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N);
+    const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N, arrow);
+    if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
     return 0;
 }
 

@@ -74,6 +74,7 @@ struct FactorParams {
     int32_t m_pad, nnz_pad;
     LmState* st;
     double* delta_out;            // optional [batch][nvs] (debug / tests), may be null
+    long long* timeline;          // optional [8] shader-clock stamps of workgroup 0 (diagnostics), may be null
 };
 
 // returns false if the (dynamics, defect) pair has no device instantiation

@@ -23,11 +23,17 @@ struct ModelParams {
 #pragma clang fp contract(off)
 
 // ---- SystemDynamicsInterface::dynamics -----------------------------------------------------------------------------
+// Every model is split as  f(x,u) = eval(x, prepare(x), u):  prepare() holds the part that depends on the state only
+// (the transcendental functions), so a sweep evaluates it once per grid state and once per perturbed state instead of
+// once per finite-difference column.  eval(x, prepare(x), u) is, operation for operation, the reference formula, so
+// the split changes no bit of any result.  CACHE_XMASK: bit i set = prepare() reads x[i].
 template <int DYN> struct Dynamics;
 
 template <> struct Dynamics<CORBO_HIP_DYN_VAN_DER_POL> {  // nonlinear_benchmark_systems.h:52-60
-    static constexpr int NX = 2, NU = 1;
-    __device__ static __forceinline__ void eval(const double* x, const double* u, const double* prm, double* f)
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
     {
         const double a = prm[0];
         f[0]           = x[1];
@@ -36,8 +42,10 @@ template <> struct Dynamics<CORBO_HIP_DYN_VAN_DER_POL> {  // nonlinear_benchmark
 };
 
 template <> struct Dynamics<CORBO_HIP_DYN_SERIAL_INTEGRATOR> {  // linear_benchmark_systems.h:72-83, order 2 (double integrator)
-    static constexpr int NX = 2, NU = 1;
-    __device__ static __forceinline__ void eval(const double* x, const double* u, const double* prm, double* f)
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
     {
         f[0] = x[1];
         f[1] = u[0] / prm[0];
@@ -45,16 +53,56 @@ template <> struct Dynamics<CORBO_HIP_DYN_SERIAL_INTEGRATOR> {  // linear_benchm
 };
 
 template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u1 cos(th), ydot = u1 sin(th), thdot = u2
-    static constexpr int NX = 3, NU = 2;
-    __device__ static __forceinline__ void eval(const double* x, const double* u, const double*, double* f)
+    static constexpr int NX = 3, NU = 2, NC = 2;
+    static constexpr unsigned CACHE_XMASK = 0b100u;
+    __device__ static __forceinline__ void prepare(const double* x, const double*, double* c) { sincos(x[2], &c[0], &c[1]); }
+    __device__ static __forceinline__ void eval(const double*, const double* c, const double* u, const double*, double* f)
     {
-        double sn, cs;
-        sincos(x[2], &sn, &cs);
-        f[0] = u[0] * cs;
-        f[1] = u[0] * sn;
+        f[0] = u[0] * c[1];
+        f[1] = u[0] * c[0];
         f[2] = u[1];
     }
 };
+
+template <int DYN>
+__device__ __forceinline__ void dyn_full(const double* x, const double* u, const double* prm, double* f)
+{
+    double c[Dynamics<DYN>::NC];
+    Dynamics<DYN>::prepare(x, prm, c);
+    Dynamics<DYN>::eval(x, c, u, prm, f);
+}
+
+// defects whose dynamics are evaluated AT the grid states x1 / x2 can reuse per-state caches
+template <int DEFECT> struct DefectTraits {
+    static constexpr bool cached = (DEFECT == CORBO_HIP_DEFECT_FORWARD || DEFECT == CORBO_HIP_DEFECT_BACKWARD ||
+                                    DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON);
+};
+
+// defect from cached states: c1 = prepare(x1), c2 = prepare(x2)
+template <int DYN, int DEFECT>
+__device__ __forceinline__ void defect_eval_cached(const double* x1, const double* c1, const double* u1, const double* x2, const double* c2,
+                                                   double dt, const double* prm, double* err)
+{
+    using D          = Dynamics<DYN>;
+    constexpr int NX = D::NX;
+    if constexpr (DEFECT == CORBO_HIP_DEFECT_FORWARD) {  // finite_differences_collocation.h:126-134
+        D::eval(x1, c1, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+    }
+    else if constexpr (DEFECT == CORBO_HIP_DEFECT_BACKWARD) {  // :160-168
+        D::eval(x2, c2, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
+    }
+    else {  // Crank-Nicolson :228-238
+        double f1[NX];
+        D::eval(x1, c1, u1, prm, f1);
+        D::eval(x2, c2, u1, prm, err);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
+    }
+}
 
 // ---- dynamics defect of the equality edge (x1, u1, x2, dt) ----------------------------------------------------------
 template <int DYN, int DEFECT>
@@ -63,12 +111,12 @@ __device__ __forceinline__ void defect_eval(const double* x1, const double* u1, 
     using D          = Dynamics<DYN>;
     constexpr int NX = D::NX;
     if constexpr (DEFECT == CORBO_HIP_DEFECT_FORWARD) {  // finite_differences_collocation.h:126-134
-        D::eval(x1, u1, prm, err);
+        dyn_full<DYN>(x1, u1, prm, err);
 #pragma unroll
         for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
     }
     else if constexpr (DEFECT == CORBO_HIP_DEFECT_BACKWARD) {  // :160-168
-        D::eval(x2, u1, prm, err);
+        dyn_full<DYN>(x2, u1, prm, err);
 #pragma unroll
         for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
     }
@@ -76,29 +124,29 @@ __device__ __forceinline__ void defect_eval(const double* x1, const double* u1, 
         double t[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) t[i] = 0.5 * (x1[i] + x2[i]);
-        D::eval(t, u1, prm, err);
+        dyn_full<DYN>(t, u1, prm, err);
 #pragma unroll
         for (int i = 0; i < NX; ++i) err[i] -= (x2[i] - x1[i]) / dt;
     }
     else if constexpr (DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON) {  // :228-238
         double f1[NX];
-        D::eval(x1, u1, prm, f1);
-        D::eval(x2, u1, prm, err);
+        dyn_full<DYN>(x1, u1, prm, f1);
+        dyn_full<DYN>(x2, u1, prm, err);
 #pragma unroll
         for (int i = 0; i < NX; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
     }
     else {  // RK4 shooting: explicit_integrators.h:280-295 + integrator_interface.h:217-222
         double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
-        D::eval(x1, u1, prm, k1);
+        dyn_full<DYN>(x1, u1, prm, k1);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { k1[i] *= dt; t[i] = x1[i] + k1[i] / 2.0; }
-        D::eval(t, u1, prm, k2);
+        dyn_full<DYN>(t, u1, prm, k2);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { k2[i] *= dt; t[i] = x1[i] + k2[i] / 2.0; }
-        D::eval(t, u1, prm, k3);
+        dyn_full<DYN>(t, u1, prm, k3);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { k3[i] *= dt; t[i] = x1[i] + k3[i]; }
-        D::eval(t, u1, prm, k4);
+        dyn_full<DYN>(t, u1, prm, k4);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             k4[i] *= dt;

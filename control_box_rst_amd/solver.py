@@ -108,6 +108,13 @@ class BatchedLevenbergMarquardt:
         rc = self.lib.corbo_hip_set_instance_data(self._h, *[_dp(a) for a in arrs])
         self._check(rc, "corbo_hip_set_instance_data")
 
+    def restore_instance_data(self):
+        """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
+        self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")
+
+    def set_profiling(self, enable: bool):
+        self._check(self.lib.corbo_hip_set_profiling(self._h, 1 if enable else 0), "corbo_hip_set_profiling")
+
     # -- the hot path ---------------------------------------------------------------------------------------------------
     def solve(self, new_run: bool = True):
         rc = self.lib.corbo_hip_solve(self._h, C.byref(self.opts), 1 if new_run else 0)
@@ -148,6 +155,13 @@ class BatchedLevenbergMarquardt:
                                            int(repeat), C.byref(ms))
         self._check(rc, "corbo_hip_time_sweep")
         return float(ms.value)
+
+    def time_factor(self, repeat=20, timeline=False):
+        """Average duration [ms] of one assemble/factor/solve launch; optionally workgroup 0's phase stamps (shader clocks)."""
+        ms = C.c_float(0)
+        tl = (C.c_longlong * 8)() if timeline else None
+        self._check(self.lib.corbo_hip_time_factor(self._h, int(repeat), C.byref(ms), tl), "corbo_hip_time_factor")
+        return (float(ms.value), [int(v) for v in tl]) if timeline else float(ms.value)
 
     def device_views(self):
         """(x_ptr, chi2_ptr, stream) raw device pointers into the library's HBM buffers."""

@@ -176,9 +176,15 @@ void corbo_hip_destroy(corbo_hip_handle h);
  * lb, ub may be NULL = the descriptor's box bounds replicated along the horizon; xref may be NULL = zeros. */
 int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref);
 
+/* Re-arm the resident batch: copy the x uploaded by the last corbo_hip_set_instance_data back into the iterate,
+ * device to device, asynchronously on the handle's stream (what the grid does when it re-initialises its vertices for a
+ * new problem, full_discretization_grid_base.cpp:134-179).  Lets a caller re-solve the same batch without a PCIe trip. */
+int corbo_hip_restore_instance_data(corbo_hip_handle h);
+
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
- * (:83-86).  Asynchronous on the handle's stream; results stay resident in HBM. */
+ * (:83-86).  Kernels run on the handle's stream; the call returns once every instance has finished its outer iterations
+ * (the host only reads one "unfinished instances" counter per pass group); results stay resident in HBM. */
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
 
 /* Block until the handle's stream is idle. */
@@ -205,6 +211,14 @@ int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev
  * per-launch time in ms measured with HIP events on the handle's stream (bench.py roofline leg). */
 int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat,
                          float* ms_per_launch);
+
+/* Same for the assemble/factor/solve kernel: runs the LM prologue on the resident data, then launches the kernel `repeat`
+ * times.  timeline8 (may be NULL) receives 8 shader-clock stamps of workgroup 0 taken at the kernel's phase boundaries
+ * (load | assemble+control elimination | state blocks | cyclic reduction | root | back-substitution | step) -- diagnostics. */
+int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, long long* timeline8);
+
+/* Per-kernel HIP-event timing inside corbo_hip_solve (fills corbo_hip_stats.sweep_ms / factor_ms); off by default. */
+int corbo_hip_set_profiling(corbo_hip_handle h, int enable);
 
 /* Text of the last error on this thread. */
 const char* corbo_hip_last_error(void);

@@ -345,13 +345,40 @@ static int bench(const Scenario& s0, std::map<std::string, std::string>& kv)
     int batch         = kv.count("batch") ? atoi(kv["batch"].c_str()) : 16;
     unsigned long seed = kv.count("seed") ? strtoul(kv["seed"].c_str(), nullptr, 10) : 20260928UL;
     double total = 0, chi2_sum = 0;
+    // instances=<file>: one instance per line, "x0[0..nx) xf[0..nx)" (the same seeded sample the GPU run uses)
+    std::vector<std::vector<double>> inst;
+    if (kv.count("instances"))
+    {
+        FILE* f = fopen(kv["instances"].c_str(), "r");
+        if (!f)
+        {
+            fprintf(stderr, "cannot open %s\n", kv["instances"].c_str());
+            return 4;
+        }
+        std::vector<double> row(2 * s0.nx);
+        for (;;)
+        {
+            bool ok = true;
+            for (int j = 0; j < 2 * s0.nx; ++j)
+                if (fscanf(f, "%lf", &row[j]) != 1) ok = false;
+            if (!ok) break;
+            inst.push_back(row);
+        }
+        fclose(f);
+        batch = (int)inst.size();
+    }
     auto w0 = std::chrono::steady_clock::now();
     for (int i = 0; i < batch; ++i)
     {
         Scenario s = s0;
         std::mt19937_64 rng(seed + i);
         std::uniform_real_distribution<double> U(-1.0, 1.0);
-        if (s.name == "unicycle")
+        if (!inst.empty())
+        {
+            s.x0 = Eigen::Map<Eigen::VectorXd>(inst[i].data(), s.nx);
+            s.xf = Eigen::Map<Eigen::VectorXd>(inst[i].data() + s.nx, s.nx);
+        }
+        else if (s.name == "unicycle")
         {
             s.x0 = Eigen::Vector3d(U(rng), U(rng), U(rng) * M_PI / 4);
             s.xf = Eigen::Vector3d(2 + 0.5 * U(rng), 1 + 0.5 * U(rng), 0.5 + 0.5 * U(rng));
