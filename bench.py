@@ -105,12 +105,12 @@ def main():
         entry.build()
     if dist is not None:
         dist.barrier()
-    from control_box_rst_amd import problems
+    from control_box_rst_amd import problems, sharding
     from control_box_rst_amd.solver import BatchedLevenbergMarquardt
 
     desc = problems.unicycle_desc()
-    B = args.batch
-    x0, xf = problems.unicycle_instances(B, first=rank * B)  # rank r owns global instances [r*B, (r+1)*B)
+    first, B = sharding.shard_bounds(args.batch * world, world, rank)  # weak scaling: `batch` instances per GPU
+    x0, xf = problems.unicycle_instances(B, first=first)               # rank r owns global instances [first, first+B)
     solver = BatchedLevenbergMarquardt(desc, B, device=local_rank)
     solver.setIterations(args.iterations)
     solver.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
@@ -139,14 +139,9 @@ def main():
 
     stats = solver.get_stats()
     X, chi2, status = solver.get_solution()
-    t_local = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    agg = torch.tensor([float(stats["lm_iterations"]), float(stats["accepted_steps"]), float(chi2.sum()),
-                        float((status <= 1).sum())], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t_local, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    t_max = float(t_local.item())
-    total_iters_per_step = float(agg[0].item())  # = world * batch * iterations
+    t_max = sharding.reduce_max(elapsed, dist, device="cuda")                       # MAX over ranks (RCCL)
+    red = sharding.reduce_stats(stats, float(chi2.sum()), int((status <= 1).sum()), dist, device="cuda")  # SUM over ranks
+    total_iters_per_step = red["lm_iterations"]  # = world * batch * iterations
     value = total_iters_per_step * args.steps / t_max
 
     # ---- roofline leg: the edge/Jacobian sweep kernel, timed with HIP events on the solver's own stream
@@ -155,6 +150,15 @@ def main():
     sweep_ms = solver.time_sweep(with_jacobian=True, repeat=50)
     achieved = B * b_sweep / (sweep_ms * 1e-3) / 1e9
     peak = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")  # written by tools/summarize_pmc.py from a rocprofv3 --pmc run
+    if os.path.exists(pmc):
+        try:
+            j = json.load(open(pmc))
+            if j.get("batch") == B and j.get("N") == desc.N:
+                traffic, traffic_src = j["hbm_bytes_per_launch"], j["source"]
+        except Exception:
+            pass
     # per-kernel split inside one solve (separate, profiled solve: event stamping is kept out of the timed region)
     solver.set_profiling(True)
     step()
@@ -180,12 +184,13 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations,
                        "parallelism": f"batch-sharded x{world}"},
             "batch_steps_per_s": value / (B * world),
-            "solve_stats": {"passes": stats["passes"], "lm_iterations": int(agg[0].item()), "accepted": int(agg[1].item()),
-                            "rejected_local": stats["rejected_steps"], "chi2_sum": float(agg[2].item()),
-                            "ok_instances": int(agg[3].item())},
+            "solve_stats": {"passes_rank0": stats["passes"], "lm_iterations": int(red["lm_iterations"]),
+                            "accepted": int(red["accepted_steps"]), "rejected": int(red["rejected_steps"]),
+                            "factorizations": int(red["factorizations"]), "chi2_sum": red["chi2_sum"],
+                            "ok_instances": int(red["ok_instances"])},
             "kernel_split_ms": {"solve": prof["solve_ms"], "sweep": prof["sweep_ms"], "factor": prof["factor_ms"]},
             "roofline": {"bound": "hbm", "kernel": "sweep_kernel (residual + Jacobian, all instances)", "achieved": achieved,
-                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": None,
+                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": B * b_sweep, "ms_per_launch": sweep_ms},
         }
         if not args.no_cpu_baseline:

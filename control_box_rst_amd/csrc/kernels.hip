@@ -114,8 +114,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
 
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
     double sq_acc = 0.0;
+    RowTask rt_next = (tid < p.n_row_tasks) ? p.row_tasks[tid] : RowTask{};
     for (int t = tid; t < p.n_row_tasks; t += SWEEP_THREADS) {
-        const RowTask rt = p.row_tasks[t];
+        const RowTask rt = rt_next;  // the next task descriptor is fetched while this one is evaluated
+        if (t + SWEEP_THREADS < p.n_row_tasks) rt_next = p.row_tasks[t + SWEEP_THREADS];
         const int base   = rt.k * S;
         switch (rt.kind) {
             case EK_DEFECT: {
@@ -177,9 +179,16 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
         }
     }
     // bounds (computeDistanceFiniteCombinedBounds, hyper_graph_optimization_problem_base.cpp:291-315)
+    BoundTask bt_next = (tid < p.n_bound_tasks) ? p.bound_tasks[tid] : BoundTask{};
+    double l_next = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.voff] : 0.0, u_next = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.voff] : 0.0;
     for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {
-        const BoundTask bt = p.bound_tasks[t];
-        const double xv = xs[bt.voff], l = p.lb[xo + bt.voff], u = p.ub[xo + bt.voff];
+        const BoundTask bt = bt_next;
+        const double xv = xs[bt.voff], l = l_next, u = u_next;
+        if (t + SWEEP_THREADS < p.n_bound_tasks) {
+            bt_next = p.bound_tasks[t + SWEEP_THREADS];
+            l_next  = p.lb[xo + bt_next.voff];
+            u_next  = p.ub[xo + bt_next.voff];
+        }
         double v;
         if (xv < l) v = l - xv;
         else if (xv > u) v = xv - u;
@@ -264,8 +273,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     constexpr double delta     = 1e-9;
     constexpr double neg2delta = -2 * delta;
     constexpr double scalar    = 1.0 / (2 * delta);
+    ColTask ct_next = (tid < p.n_col_tasks) ? p.col_tasks[tid] : ColTask{};
     for (int t = tid; t < p.n_col_tasks; t += SWEEP_THREADS) {
-        const ColTask ct = p.col_tasks[t];
+        const ColTask ct = ct_next;
+        if (t + SWEEP_THREADS < p.n_col_tasks) ct_next = p.col_tasks[t + SWEEP_THREADS];
         const int base   = ct.k * S;
         if (ct.kind == EK_DEFECT) {
             const bool is_dt = (ct.voff == p.off_dt);
@@ -359,9 +370,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
             js[ct.joff]     = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
         }
     }
+    bt_next = (tid < p.n_bound_tasks) ? p.bound_tasks[tid] : BoundTask{};
+    l_next  = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.voff] : 0.0;
+    u_next  = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.voff] : 0.0;
     for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {  // :1721-1752
-        const BoundTask bt = p.bound_tasks[t];
-        const double xv = xs[bt.voff], l = p.lb[xo + bt.voff], u = p.ub[xo + bt.voff];
+        const BoundTask bt = bt_next;
+        const double xv = xs[bt.voff], l = l_next, u = u_next;
+        if (t + SWEEP_THREADS < p.n_bound_tasks) {
+            bt_next = p.bound_tasks[t + SWEEP_THREADS];
+            l_next  = p.lb[xo + bt_next.voff];
+            u_next  = p.ub[xo + bt_next.voff];
+        }
         js[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
     }
 }

@@ -1,0 +1,65 @@
+"""Batch sharding across the GPUs of one node.
+
+OCP instances are independent NLPs (the reference solves them one after another,
+src/tasks/src/benchmark_task_varying_initial_state.cpp:74-99), so the batch is the sharding unit: rank r owns a contiguous
+slice of the global batch and runs the whole inner loop on its own GPU.  There is NO collective on the data path; RCCL
+(torch.distributed backend "nccl") / gloo is used only for the barrier, the max-over-ranks time, the reduction of the
+solution statistics and an optional all-gather of the final trajectories.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+def shard_bounds(global_batch: int, world: int, rank: int) -> Tuple[int, int]:
+    """(first, count) of the contiguous slice owned by `rank`; remainders go to the low ranks."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(global_batch, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+STAT_KEYS = ("lm_iterations", "accepted_steps", "rejected_steps", "jacobian_sweeps", "residual_sweeps", "factorizations")
+
+
+def reduce_stats(local: Dict[str, float], chi2_sum: float, ok_instances: int, dist=None, device="cpu") -> Dict[str, float]:
+    """SUM-reduce the per-rank solver statistics (tens of bytes: one tiny all-reduce)."""
+    import torch
+    vec = torch.tensor([float(local[k]) for k in STAT_KEYS] + [float(chi2_sum), float(ok_instances)], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    out = {k: float(vec[i].item()) for i, k in enumerate(STAT_KEYS)}
+    out["chi2_sum"] = float(vec[len(STAT_KEYS)].item())
+    out["ok_instances"] = float(vec[len(STAT_KEYS) + 1].item())
+    return out
+
+
+def reduce_max(value: float, dist=None, device="cpu") -> float:
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_trajectories(x_local: np.ndarray, global_batch: int, dist=None, device="cpu") -> np.ndarray:
+    """All-gather the final trajectories [count][nv] of every rank into [global_batch][nv] (outside any timed region)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.array(x_local, copy=True)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    nv = x_local.shape[1]
+    maxc = max(shard_bounds(global_batch, world, r)[1] for r in range(world))
+    pad = torch.zeros((maxc, nv), dtype=torch.float64, device=device)
+    pad[: x_local.shape[0]] = torch.as_tensor(x_local, dtype=torch.float64, device=device)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = np.empty((global_batch, nv))
+    for r in range(world):
+        first, count = shard_bounds(global_batch, world, r)
+        out[first:first + count] = parts[r][:count].cpu().numpy()
+    return out
