@@ -1,0 +1,73 @@
+// levenberg_marquardt_sparse_hip.h -- the reference-side binding of the C-ABI (include/corbo_hip.h).
+//
+// corbo::LevenbergMarquardtSparseHip implements the reference's solver plug-in interface
+//     corbo::NlpSolverInterface   (src/optimization/include/corbo-optimization/solver/nlp_solver_interface.h:67-115)
+// with the same setters as corbo::LevenbergMarquardtSparse (levenberg_marquardt_sparse.h:86-90), so it is injected with
+//     StructuredOptimalControlProblem(grid, dynamics, hypergraph, std::make_shared<LevenbergMarquardtSparseHip>())
+// and called, unchanged, from src/optimal_control/src/structured_ocp/structured_optimal_control_problem.cpp:61,134,204.
+//
+// This file is compiled INSIDE the reference's build tree (it needs the reference's headers); it is not part of
+// libcorbo_hip.so.  There is no CPU fallback: a hypergraph the device cannot describe makes solve() return
+// SolverStatus::Error with a message on stderr.
+#ifndef CONTROL_BOX_RST_AMD_ADAPTER_LEVENBERG_MARQUARDT_SPARSE_HIP_H_
+#define CONTROL_BOX_RST_AMD_ADAPTER_LEVENBERG_MARQUARDT_SPARSE_HIP_H_
+
+#include <corbo-optimization/solver/nlp_solver_interface.h>
+
+#include <Eigen/Core>
+#include <memory>
+#include <vector>
+
+#include "corbo_hip.h"
+
+namespace corbo {
+
+class LevenbergMarquardtSparseHip : public NlpSolverInterface
+{
+ public:
+    using Ptr = std::shared_ptr<LevenbergMarquardtSparseHip>;
+
+    LevenbergMarquardtSparseHip();
+    ~LevenbergMarquardtSparseHip() override;
+
+    // ---- NlpSolverInterface
+    NlpSolverInterface::Ptr getInstance() const override { return std::make_shared<LevenbergMarquardtSparseHip>(); }
+    bool isLsqSolver() const override { return true; }
+    bool initialize(OptimizationProblemInterface* problem = nullptr) override;
+    SolverStatus solve(OptimizationProblemInterface& problem, bool new_structure, bool new_run = true, double* obj_value = nullptr) override;
+    void clear() override;
+
+    // ---- LevenbergMarquardtSparse's parameters (same names, same meaning)
+    void setIterations(int iterations) { _opts.iterations = iterations; }
+    void setPenaltyWeights(double weight_eq, double weight_ineq, double weight_bounds);
+    void setWeightAdapation(double factor_eq, double factor_ineq, double factor_bounds, double max_eq, double max_ineq, double max_bounds);
+
+    // ---- what a hypergraph does not reveal to a solver through the reference's public API: which collocation scheme, which
+    //      dynamics and which cost weights its (opaque) edges evaluate.  The caller states them once, next to the setters it
+    //      already uses to configure the OCP; dimensions, vertex values, bounds, fixed flags and dt are read from the graph
+    //      and checked against this description on every new structure.
+    void setDeviceModel(const corbo_hip_problem_desc& desc) { _desc = desc; _have_desc = true; releaseHandle(); }
+    void setStateReference(const Eigen::Ref<const Eigen::VectorXd>& xref) { _xref = xref; }
+    void setDevice(int device) { _device = device; releaseHandle(); }
+
+    const corbo_hip_stats& getStatistics() const { return _stats; }
+
+ private:
+    void releaseHandle();
+
+    corbo_hip_lm_opts _opts;
+    corbo_hip_problem_desc _desc;
+    bool _have_desc = false;
+    Eigen::VectorXd _xref;
+    int _device = 0;
+    corbo_hip_handle _handle = nullptr;
+    corbo_hip_dims _dims;
+    corbo_hip_stats _stats;
+    std::vector<double> _x, _lb, _ub;
+};
+
+FACTORY_REGISTER_NLP_SOLVER(LevenbergMarquardtSparseHip)
+
+}  // namespace corbo
+
+#endif

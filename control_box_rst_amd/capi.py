@@ -93,6 +93,12 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{_LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "control_box_rst_amd has no CPU fallback.")
+    try:
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; let it load first so that libcorbo_hip.so
+        # binds to the same runtime (two runtimes in one process do not both see the GPU).
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the C-ABI itself
+        pass
     lib = C.CDLL(_LIB_PATH)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     H = C.c_void_p
