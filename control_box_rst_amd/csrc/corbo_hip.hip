@@ -77,6 +77,7 @@ struct corbo_hip_solver {
     double w_eq = 2, w_ineq = 2, w_b = 2;  // current penalty weights (levenberg_marquardt_sparse.h:126-128)
     corbo_hip_stats stats{};
     bool profile = false;
+    bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
 
     SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
     {
@@ -214,6 +215,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
 #undef CREATE_TRY
     const char* prof = std::getenv("CORBO_HIP_PROFILE");
     h->profile       = prof && prof[0] == '1';
+    h->split_passes  = h->profile;
     *out             = h;
     return CORBO_HIP_OK;
 }
@@ -322,12 +324,19 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
     int remaining = (o->iterations > 0) ? h->batch : 0;
     auto enqueue_passes = [&](int count) -> int {
         for (int c = 0; c < count && pass < MAX_PASSES; ++c, ++pass) {
-            int r = launch_factor_checked(h, fp);
-            if (r) return r;
-            stamp();
-            r = launch_sweep_checked(h, h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass));
-            if (r) return r;
-            stamp();
+            const SweepParams sp = h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass);
+            if (h->split_passes) {  // diagnostics: the two phases as separate launches (per-kernel timing)
+                int r = launch_factor_checked(h, fp);
+                if (r) return r;
+                stamp();
+                r = launch_sweep_checked(h, sp);
+                if (r) return r;
+                stamp();
+            }
+            else {
+                if (!launch_pass(h->S.desc, fp, sp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+                HIP_TRY(hipGetLastError());
+            }
         }
         return 0;
     };
@@ -381,7 +390,8 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h)
 int corbo_hip_set_profiling(corbo_hip_handle h, int enable)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
-    h->profile = enable != 0;
+    h->profile      = enable != 0;
+    h->split_passes = enable != 0;
     return CORBO_HIP_OK;
 }
 

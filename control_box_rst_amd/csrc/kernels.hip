@@ -37,15 +37,19 @@ __device__ __forceinline__ double wave_max(double v)
 }
 
 // end of one outer LM iteration: levenberg_marquardt_sparse.cpp:216-218
-__device__ __forceinline__ void lm_end_outer(LmState& s, int iterations)
+// (works on scalars: whole-struct copies of LmState end up in scratch memory)
+__device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double rho, int k, int iterations)
 {
-    s.stop  = (sqrt(s.last_sq) <= LM_EPS3) ? 1 : 0;
-    s.inner = 0;
-    s.k += 1;
-    if (s.k >= iterations) {
-        s.done   = 1;
-        s.status = (s.stop || s.rho <= 0) ? CORBO_HIP_SOLVER_CONVERGED : CORBO_HIP_SOLVER_EARLY_TERMINATED;
+    const int stop = (sqrt(last_sq) <= LM_EPS3) ? 1 : 0;
+    st->stop  = stop;
+    st->inner = 0;
+    st->k     = k + 1;
+    if (k + 1 >= iterations) {
+        st->done   = 1;
+        st->status = (stop || rho <= 0) ? CORBO_HIP_SOLVER_CONVERGED : CORBO_HIP_SOLVER_EARLY_TERMINATED;
+        return true;
     }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -53,41 +57,37 @@ __device__ __forceinline__ void lm_end_outer(LmState& s, int iterations)
 // ---------------------------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 
-template <int DYN, int DEFECT>
-__global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
+// LDS operands: xs [nvs] vertex values of this instance, red [10] reduction scratch + 4 int flags, cs [N*NC] per-grid-state
+// dynamics caches.  FUSED: called right after factor_body in the same workgroup -- the trial iterate is already in xs and
+// the pass flags (no_trial, vbuf) are in the flag words.
+template <int DYN, int DEFECT, bool FUSED>
+__device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, double* red, double* cs, const int inst, const int tid)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
     constexpr int NU  = Dy::NU;
     constexpr int S   = NX + NU;
     constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NC  = Dy::NC;
     constexpr bool CACHED = DefectTraits<DEFECT>::cached;
-    double* xs  = smem;                     // [nvs]      vertex values of this instance
-    double* red = smem + p.nvs;             // [8]        reduction scratch / broadcast
-    double* js  = p.jac + (size_t)blockIdx.x * p.nnz_pad;  // Jacobian values of this instance (HBM), written column by column
-    double* cs  = red + 10;                 // [N*NC]     per-grid-state dynamics caches (prepare(x_k))
-    int* flags  = reinterpret_cast<int*>(red + 8);  // [4]
-
-    const int inst = blockIdx.x;
-    const int tid  = threadIdx.x;
+    double* js  = p.jac + (size_t)inst * p.nnz_pad;  // Jacobian values of this instance (HBM), written column by column
+    int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
     const size_t xo = (size_t)inst * p.nvs;
     LmState* st    = p.st ? p.st + inst : nullptr;
 
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
     if (p.mode == 3) {
-        const int done = st->done, no_trial = st->no_trial, vbuf = st->vbuf;
+        int done, no_trial, vbuf;
+        if constexpr (FUSED) { done = 0; no_trial = flags[2]; vbuf = flags[3]; }
+        else { done = st->done; no_trial = st->no_trial; vbuf = st->vbuf; }
         __syncthreads();  // everybody has read the state before lane 0 may change it
         if (done) return;
         if (no_trial) {  // |delta| <= eps2 -> stop = true, the do-while ends without a trial step (:151-154,215)
             if (tid == 0) {
-                LmState s = *st;
-                lm_end_outer(s, p.iterations);
-                *st = s;
-                if (p.chi2) p.chi2[inst] = s.chi2_old;
-                if (!s.done) atomicAdd(p.active_count, 1);
+                const bool fin = lm_end_outer(st, st->last_sq, st->rho, st->k, p.iterations);
+                if (p.chi2) p.chi2[inst] = st->chi2_old;
+                if (!fin) atomicAdd(p.active_count, 1);
             }
             return;
         }
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     }
 
     // ---- stage vertex values in LDS (coalesced 16-byte loads)
-    for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
-        reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
+    if constexpr (!FUSED)
+        for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+            reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
     double xr[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
@@ -114,10 +115,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
 
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
     double sq_acc = 0.0;
-    RowTask rt_next = (tid < p.n_row_tasks) ? p.row_tasks[tid] : RowTask{};
+    const int4* rtab = reinterpret_cast<const int4*>(p.row_tasks);   // 16-byte task descriptors, fetched one iteration ahead
+    const int4* ctab = reinterpret_cast<const int4*>(p.col_tasks);
+    const int4* btab = reinterpret_cast<const int4*>(p.bound_tasks);
+    int4 rt_next = (tid < p.n_row_tasks) ? rtab[tid] : make_int4(0, 0, 0, 0);
     for (int t = tid; t < p.n_row_tasks; t += SWEEP_THREADS) {
-        const RowTask rt = rt_next;  // the next task descriptor is fetched while this one is evaluated
-        if (t + SWEEP_THREADS < p.n_row_tasks) rt_next = p.row_tasks[t + SWEEP_THREADS];
+        const RowTask rt{rt_next.x, rt_next.y, rt_next.z, rt_next.w};
+        if (t + SWEEP_THREADS < p.n_row_tasks) rt_next = rtab[t + SWEEP_THREADS];
         const int base   = rt.k * S;
         switch (rt.kind) {
             case EK_DEFECT: {
@@ -179,15 +183,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
         }
     }
     // bounds (computeDistanceFiniteCombinedBounds, hyper_graph_optimization_problem_base.cpp:291-315)
-    BoundTask bt_next = (tid < p.n_bound_tasks) ? p.bound_tasks[tid] : BoundTask{};
-    double l_next = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.voff] : 0.0, u_next = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.voff] : 0.0;
+    int4 bt_next = (tid < p.n_bound_tasks) ? btab[tid] : make_int4(0, 0, 0, 0);
+    double l_next = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.x] : 0.0, u_next = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.x] : 0.0;
     for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {
-        const BoundTask bt = bt_next;
+        const BoundTask bt{bt_next.x, bt_next.y, bt_next.z, bt_next.w};
         const double xv = xs[bt.voff], l = l_next, u = u_next;
         if (t + SWEEP_THREADS < p.n_bound_tasks) {
-            bt_next = p.bound_tasks[t + SWEEP_THREADS];
-            l_next  = p.lb[xo + bt_next.voff];
-            u_next  = p.ub[xo + bt_next.voff];
+            bt_next = btab[t + SWEEP_THREADS];
+            l_next  = p.lb[xo + bt_next.x];
+            u_next  = p.ub[xo + bt_next.x];
         }
         double v;
         if (xv < l) v = l - xv;
@@ -206,57 +210,60 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
         __syncthreads();
         if (tid == 0) {
             const double chi2 = red[0] + red[1] + red[2] + red[3];
-            LmState s;
+            bool fin = false;
             if (p.mode == 2) {  // solve() prologue (:89-127)
-                s          = LmState{};
-                s.chi2_old = chi2;
-                s.last_sq  = chi2;
-                s.v        = 2;
-                s.fresh    = 1;
-                s.first    = 1;
-                s.n_res    = 1;
-                s.n_jac    = 1;
-                s.status   = CORBO_HIP_SOLVER_CONVERGED;  // iterations == 0: (stop || rho <= 0) with rho = 0
-                s.done     = (p.iterations <= 0) ? 1 : 0;
-                flags[0]   = 1;
-                flags[1]   = 0;
+                st->mu = 0; st->mu_acc = 0; st->rho = 0; st->chi2_old = chi2; st->last_sq = chi2; st->den = 0; st->dnorm = 0;
+                st->v = 2; st->k = 0; st->stop = 0; st->fresh = 1; st->first = 1; st->no_trial = 0;
+                st->status = CORBO_HIP_SOLVER_CONVERGED;  // iterations == 0: (stop || rho <= 0) with rho = 0
+                fin        = (p.iterations <= 0);
+                st->done   = fin ? 1 : 0;
+                st->vbuf = 0; st->inner = 0; st->n_accept = 0; st->n_reject = 0; st->n_jac = 1; st->n_res = 1; st->n_fact = 0;
+                flags[0] = 1;
+                flags[1] = 0;
+                if (p.chi2) p.chi2[inst] = chi2;
             }
             else {
-                s              = *st;
-                const double chi2_new = chi2;
-                s.last_sq      = chi2_new;
-                s.n_res += 1;
-                s.rho          = (s.chi2_old - chi2_new) / s.den;  // :169
+                const double chi2_new = chi2, chi2_old = st->chi2_old;
+                const int k = st->k;
+                double mu   = st->mu;
+                unsigned v  = st->v;
+                int stop    = st->stop;
+                st->last_sq = chi2_new;
+                st->n_res += 1;
+                const double rho = (chi2_old - chi2_new) / st->den;  // :169
+                st->rho          = rho;
                 int accept = 0, refresh = 0;
-                if (s.rho > 0 && !isnan(chi2_new) && !isinf(chi2_new)) {  // :171
-                    s.stop = (sqrt(s.chi2_old) - sqrt(chi2_new) < LM_EPS4 * sqrt(s.chi2_old)) ? 1 : 0;
+                if (rho > 0 && !isnan(chi2_new) && !isinf(chi2_new)) {  // :171
+                    stop   = (sqrt(chi2_old) - sqrt(chi2_new) < LM_EPS4 * sqrt(chi2_old)) ? 1 : 0;
                     accept = 1;
-                    s.n_accept += 1;
-                    if (!s.stop && s.k < p.iterations - 1) {  // :178-199
+                    st->n_accept += 1;
+                    if (!stop && k < p.iterations - 1) {  // :178-199
                         refresh            = 1;
-                        const double alpha = fmin(2. / 3., 1 - pow((2 * s.rho - 1), 3.0));
+                        const double alpha = fmin(2. / 3., 1 - pow((2 * rho - 1), 3.0));
                         const double scale = fmax(1. / 3., alpha);
-                        s.mu *= scale;
-                        s.v     = 2;
-                        s.fresh = 1;
-                        s.vbuf ^= 1;  // the residual just written pairs with the Jacobian about to be written
-                        s.n_jac += 1;
+                        mu *= scale;
+                        v         = 2;
+                        st->fresh = 1;
+                        st->vbuf ^= 1;  // the residual just written pairs with the Jacobian about to be written
+                        st->n_jac += 1;
                     }
-                    s.chi2_old = chi2_new;
+                    st->chi2_old = chi2_new;
+                    if (p.chi2) p.chi2[inst] = chi2_new;
                 }
                 else {  // :204-213
-                    s.n_reject += 1;
-                    s.mu = s.mu * s.v;
-                    s.v  = 2 * s.v;
+                    st->n_reject += 1;
+                    mu = mu * v;
+                    v  = 2 * v;
                 }
-                const bool cont = (s.rho <= 0) && !s.stop;  // :215
-                if (!cont || s.inner >= LM_MAX_INNER) lm_end_outer(s, p.iterations);
+                st->mu   = mu;
+                st->v    = v;
+                st->stop = stop;
+                const bool cont = (rho <= 0) && !stop;  // :215
+                if (!cont || st->inner >= LM_MAX_INNER) fin = lm_end_outer(st, chi2_new, rho, k, p.iterations);
                 flags[0] = refresh;
                 flags[1] = accept;
             }
-            *st = s;
-            if (p.chi2) p.chi2[inst] = s.chi2_old;
-            if (!s.done && p.active_count) atomicAdd(p.active_count, 1);
+            if (!fin && p.active_count) atomicAdd(p.active_count, 1);
         }
         __syncthreads();
         do_jac = flags[0];
@@ -273,10 +280,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     constexpr double delta     = 1e-9;
     constexpr double neg2delta = -2 * delta;
     constexpr double scalar    = 1.0 / (2 * delta);
-    ColTask ct_next = (tid < p.n_col_tasks) ? p.col_tasks[tid] : ColTask{};
+    int4 ct_next = (tid < p.n_col_tasks) ? ctab[tid] : make_int4(0, 0, 0, 0);
     for (int t = tid; t < p.n_col_tasks; t += SWEEP_THREADS) {
-        const ColTask ct = ct_next;
-        if (t + SWEEP_THREADS < p.n_col_tasks) ct_next = p.col_tasks[t + SWEEP_THREADS];
+        const ColTask ct{ct_next.x, ct_next.y, ct_next.z, ct_next.w};
+        if (t + SWEEP_THREADS < p.n_col_tasks) ct_next = ctab[t + SWEEP_THREADS];
         const int base   = ct.k * S;
         if (ct.kind == EK_DEFECT) {
             const bool is_dt = (ct.voff == p.off_dt);
@@ -370,19 +377,29 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
             js[ct.joff]     = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
         }
     }
-    bt_next = (tid < p.n_bound_tasks) ? p.bound_tasks[tid] : BoundTask{};
-    l_next  = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.voff] : 0.0;
-    u_next  = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.voff] : 0.0;
+    bt_next = (tid < p.n_bound_tasks) ? btab[tid] : make_int4(0, 0, 0, 0);
+    l_next  = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.x] : 0.0;
+    u_next  = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.x] : 0.0;
     for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {  // :1721-1752
-        const BoundTask bt = bt_next;
+        const BoundTask bt{bt_next.x, bt_next.y, bt_next.z, bt_next.w};
         const double xv = xs[bt.voff], l = l_next, u = u_next;
         if (t + SWEEP_THREADS < p.n_bound_tasks) {
-            bt_next = p.bound_tasks[t + SWEEP_THREADS];
-            l_next  = p.lb[xo + bt_next.voff];
-            u_next  = p.ub[xo + bt_next.voff];
+            bt_next = btab[t + SWEEP_THREADS];
+            l_next  = p.lb[xo + bt_next.x];
+            u_next  = p.ub[xo + bt_next.x];
         }
         js[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
     }
+}
+
+template <int DYN, int DEFECT>
+__global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs  = smem;
+    double* red = smem + p.nvs;
+    double* cs  = red + 10;
+    sweep_body<DYN, DEFECT, false>(p, xs, red, cs, blockIdx.x, threadIdx.x);
 }
 
 #pragma clang fp contract(fast)
@@ -456,13 +473,24 @@ __device__ __forceinline__ void bwd_solve_vec(const double (&L)[Nn][Nn], double 
         if (p.timeline && inst == 0 && tid == 0) p.timeline[id] = clock64(); \
     } while (0)
 
+// LDS carve of factor_body (doubles), shared with the fused pass kernel
+template <int NX, int NU>
+struct FactorLds {
+    static constexpr int NT = NX * (NX + 1) / 2;
+    static constexpr int RED = 24;
+    __host__ __device__ static constexpr int off_Wam(int NP) { return (NU * NU + 2 * NU * NX + NU + NT) * NP; }
+    __host__ __device__ static constexpr int off_Wbm(int NP) { return off_Wam(NP) + NX * NX * NP; }
+    __host__ __device__ static constexpr int off_red(int NP) { return off_Wbm(NP) + NX * NX * NP + NX * NP; }
+    __host__ __device__ static constexpr int total(int NP, bool arrow) { return off_red(NP) + RED + (arrow ? (NU + NX) * NP : 0); }
+};
+
+// xs_out (LDS, may be null): also receives the trial iterate; flags_out (LDS ints, may be null): [2] = no_trial, [3] = vbuf
 template <int NX, int NU, int THREADS, bool ARROW>
-__global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
+__device__ __forceinline__ void factor_body(const FactorParams& p, double* smem, const int inst, const int tid, double* xs_out, int* flags_out)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
     constexpr int NT = NX * (NX + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N  = p.N;
     const int NP = N | 1;
     // SoA arrays, element-major: arr[e][block].  Per state block: D/L (packed lower), W_a, W_b, rhs/y/x; per stage: the
@@ -475,12 +503,9 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
     double* Wam = Dm + NT * NP;            // NX*NX   W_a = L_i^{-1} H(i, i-h)   (before: mailbox for H(k, k-1))
     double* Wbm = Wam + NX * NX * NP;      // NX*NX   W_b = L_i^{-1} H(i, i+h)
     double* gv  = Wbm + NX * NX * NP;      // NX      rhs -> y -> delta x
-    double* red = gv + NX * NP;            // 16
-    double* zu  = red + 16;                // NU      (arrowhead only from here on)
+    double* red = gv + NX * NP;            // 24
+    double* zu  = red + FactorLds<NX, NU>::RED;  // NU  (arrowhead only from here on)
     double* bv  = zu + NU * NP;            // NX      border column -> z
-
-    const int inst = blockIdx.x;
-    const int tid  = threadIdx.x;
     LmState* st    = p.st + inst;
     const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
     const int stop_in = st->stop;
@@ -961,7 +986,8 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
         for (int q = 0; q < NX; ++q) {
             const double d = xfixed[q] ? 0.0 : SOA(gv, q, k);
             dn2 += d * d;
-            xt[k * S + q] = xin[k * S + q] + d;
+            const double xn = xin[k * S + q] + d;
+            if (xs_out) xs_out[k * S + q] = xn; else xt[k * S + q] = xn;
             if (dl) dl[k * S + q] = d;
         }
     }
@@ -980,15 +1006,17 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 #pragma unroll
         for (int a = 0; a < NU; ++a) {
             dn2 += y[a] * y[a];
-            xt[k * S + NX + a] = xin[k * S + NX + a] + y[a];
+            const double un = xin[k * S + NX + a] + y[a];
+            if (xs_out) xs_out[k * S + NX + a] = un; else xt[k * S + NX + a] = un;
             if (dl) dl[k * S + NX + a] = y[a];
         }
     }
     if (tid == 0) {
-        if (ARROW) { dn2 += ddt * ddt; xt[p.off_dt] = xin[p.off_dt] + ddt; }
-        else xt[p.off_dt] = xin[p.off_dt];
+        double* xo_ = xs_out ? xs_out : xt;
+        if (ARROW) { dn2 += ddt * ddt; xo_[p.off_dt] = xin[p.off_dt] + ddt; }
+        else xo_[p.off_dt] = xin[p.off_dt];
         if (dl) dl[p.off_dt] = ARROW ? ddt : 0.0;
-        if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
+        if (p.off_dt + 1 < p.nvs) { xo_[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
     }
     {
         double a0 = wave_sum(dn2);
@@ -999,21 +1027,50 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
             dn2 = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) dn2 += red[w];
-            LmState s = *st;
-            s.mu      = mu;
-            s.mu_acc  = mu_eff;
-            s.first   = 0;
-            s.fresh   = 0;
-            s.stop    = stop;
-            s.n_fact += 1;
-            s.inner += 1;
-            s.dnorm = sqrt(dn2);
-            if (s.dnorm <= LM_EPS2) { s.stop = 1; s.no_trial = 1; }   // :151-154
-            else { s.no_trial = 0; s.den = mu * dn2 + y2; }           // delta^T (mu delta + rhs), delta^T rhs = |y|^2
-            *st = s;
+            st->mu     = mu;
+            st->mu_acc = mu_eff;
+            st->first  = 0;
+            st->fresh  = 0;
+            st->n_fact += 1;
+            st->inner += 1;
+            const double dnorm = sqrt(dn2);
+            st->dnorm = dnorm;
+            int no_trial;
+            if (dnorm <= LM_EPS2) { stop = 1; no_trial = 1; }                    // :151-154
+            else { no_trial = 0; st->den = mu * dn2 + y2; }                      // delta^T (mu delta + rhs), delta^T rhs = |y|^2
+            st->stop     = stop;
+            st->no_trial = no_trial;
+            if (flags_out) { flags_out[2] = no_trial; flags_out[3] = vbuf; }
         }
     }
     STAMP(7);
+}
+
+template <int NX, int NU, int THREADS, bool ARROW>
+__global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x, threadIdx.x, nullptr, nullptr);
+}
+
+// One inner Levenberg-Marquardt pass of every unfinished instance in ONE launch: factor/solve, then the trial-step sweep in
+// the same workgroup.  The trial iterate never leaves LDS; while some workgroups are in the latency-bound factor phase others
+// are in the throughput-bound sweep phase, so the two overlap across the chip.
+template <int DYN, int DEFECT, bool ARROW>
+__global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
+{
+    using Dy = Dynamics<DYN>;
+    using FL = FactorLds<Dy::NX, Dy::NU>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    if (fp.st[inst].done) return;
+    const int NP = fp.N | 1;
+    double* xs  = smem + FL::off_Wam(NP);   // dead after the back-substitution
+    double* cs  = smem + FL::off_Wbm(NP);
+    double* red = smem + FL::off_red(NP);
+    factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
+    __syncthreads();
+    sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, inst, tid);
 }
 
 #undef STAMP
@@ -1042,10 +1099,30 @@ bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
 template <int NX, int NU>
 size_t factor_lds(int N, bool arrow)
 {
-    const int NP = N | 1;
-    size_t per_block = NU * NU + 2 * NU * NX + NU + NX * (NX + 1) / 2 + 2 * NX * NX + NX;
-    if (arrow) per_block += NU + NX;
-    return sizeof(double) * ((size_t)NP * per_block + 16);
+    return sizeof(double) * (size_t)FactorLds<NX, NU>::total(N | 1, arrow);
+}
+
+template <int DYN, int DEFECT>
+bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+{
+    using Dy = Dynamics<DYN>;
+    if (fp.N > SWEEP_THREADS) return false;
+    const size_t lds = factor_lds<Dy::NX, Dy::NU>(fp.N, fp.dt_free != 0);
+    if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true>), dim3(fp.batch), dim3(SWEEP_THREADS), lds, stream, fp, sp);
+    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false>), dim3(fp.batch), dim3(SWEEP_THREADS), lds, stream, fp, sp);
+    return true;
+}
+
+template <int DYN>
+bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+{
+    switch (defect) {
+        case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_MIDPOINT: return launch_pass_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, stream);
+        default: return false;
+    }
 }
 
 template <int NX, int NU, bool ARROW>
@@ -1084,6 +1161,18 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
             if (d.nx != 2) return false;
             return launch_sweep_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, p, stream);
         case CORBO_HIP_DYN_UNICYCLE: return launch_sweep_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, p, stream);
+        default: return false;
+    }
+}
+
+bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+{
+    switch (d.dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
+            if (d.nx != 2) return false;
+            return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, stream);
         default: return false;
     }
 }

@@ -10,7 +10,7 @@ namespace corbo_hip {
 
 // Per-instance Levenberg-Marquardt state machine (LevenbergMarquardtSparse::solve's local variables,
 // levenberg_marquardt_sparse.cpp:103-127).  Lives in HBM, one per OCP instance; touched by one lane per pass.
-struct LmState {
+struct alignas(16) LmState {
     double mu;         // damping
     double mu_acc;     // damping accumulated on diag(H) since the last Jacobian refresh (quirk i: never undone on reject)
     double rho;
@@ -29,8 +29,9 @@ struct LmState {
     int32_t vbuf;      // which residual buffer pairs with the resident Jacobian
     int32_t inner;     // inner passes of the current outer iteration
     int32_t n_accept, n_reject, n_jac, n_res, n_fact;
-    int32_t pad;
+    int32_t pad[3];  // sizeof == 128: whole-struct copies are eight aligned 16-byte moves
 };
+static_assert(sizeof(LmState) == 128, "LmState layout");
 
 struct SweepParams {
     // static structure
@@ -80,6 +81,8 @@ struct FactorParams {
 // returns false if the (dynamics, defect) pair has no device instantiation
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
+// one fused LM pass (factor + trial-step sweep in one launch)
+bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
 

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for i in 1 2 3; do python tools/profile_sweep.py 1024 50; done
+python tools/profile_sweep.py 4096 20
+rocm-smi --showclocks 2>/dev/null | head -20
