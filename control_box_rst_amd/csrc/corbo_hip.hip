@@ -77,6 +77,7 @@ struct corbo_hip_solver {
     double w_eq = 2, w_ineq = 2, w_b = 2;  // current penalty weights (levenberg_marquardt_sparse.h:126-128)
     corbo_hip_stats stats{};
     bool profile = false;
+    bool persistent = false;    // CORBO_HIP_PERSISTENT=1: whole solve in one launch (measured slower, kept for experiments)
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
 
     SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
@@ -216,6 +217,8 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     const char* prof = std::getenv("CORBO_HIP_PROFILE");
     h->profile       = prof && prof[0] == '1';
     h->split_passes  = h->profile;
+    const char* pers = std::getenv("CORBO_HIP_PERSISTENT");
+    h->persistent    = pers && pers[0] == '1';
     *out             = h;
     return CORBO_HIP_OK;
 }
@@ -334,16 +337,26 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
                 stamp();
             }
             else {
-                if (!launch_pass(h->S.desc, fp, sp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+                if (!launch_pass(h->S.desc, fp, sp, 1, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
                 HIP_TRY(hipGetLastError());
             }
         }
         return 0;
     };
-    if (remaining > 0) {
-        // Every instance needs at least `iterations` passes.  After that the host reads one "unfinished instances" counter per
-        // group of passes, always with the NEXT group already enqueued, so the GPU never waits for the host; finished
-        // instances make their workgroups exit at once, so an overshooting group costs a few microseconds.
+    if (remaining > 0 && h->persistent) {
+        // PERSISTENT variant (CORBO_HIP_PERSISTENT=1): one launch runs every instance's whole LM loop.  Measured SLOWER than
+        // one launch per pass on the headline batch (1.45 vs 1.25 ms): a workgroup stays pinned to its CU for all its passes,
+        // whereas relaunching per pass spreads the few instances still active in the tail passes over the whole chip.
+        const SweepParams sp = h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr);
+        if (!launch_pass(h->S.desc, fp, sp, MAX_PASSES, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+        HIP_TRY(hipGetLastError());
+        remaining = 0;
+    }
+    else if (remaining > 0) {
+        // One fused launch per inner pass (or, with corbo_hip_set_profiling, factor and sweep as separate launches).  Every
+        // instance needs at least `iterations` passes; after that the host reads one "unfinished instances" counter per group of
+        // passes, always with the NEXT group already enqueued, so the GPU never waits for the host; finished instances make
+        // their workgroups exit at once, so an overshooting group costs a few microseconds.
         rc = enqueue_passes(o->iterations);
         if (rc) return rc;
         constexpr int GROUP = 2;
@@ -435,7 +448,9 @@ int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
     HIP_TRY(hipMemcpy(st.data(), h->d_state, (size_t)h->batch * sizeof(LmState), hipMemcpyDeviceToHost));
     corbo_hip_stats s = h->stats;
     s.lm_iterations = s.accepted_steps = s.rejected_steps = s.jacobian_sweeps = s.residual_sweeps = s.factorizations = 0;
+    int max_fact = 0;
     for (const LmState& a : st) {
+        if (a.n_fact > max_fact) max_fact = a.n_fact;
         s.lm_iterations += a.k;
         s.accepted_steps += a.n_accept;
         s.rejected_steps += a.n_reject;
@@ -443,6 +458,7 @@ int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
         s.residual_sweeps += a.n_res;
         s.factorizations += a.n_fact;
     }
+    s.passes = max_fact;  // inner passes of the slowest instance
     *stats = s;
     return CORBO_HIP_OK;
 }

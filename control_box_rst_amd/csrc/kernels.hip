@@ -87,7 +87,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
             if (tid == 0) {
                 const bool fin = lm_end_outer(st, st->last_sq, st->rho, st->k, p.iterations);
                 if (p.chi2) p.chi2[inst] = st->chi2_old;
-                if (!fin) atomicAdd(p.active_count, 1);
+                if (!fin && p.active_count) atomicAdd(p.active_count, 1);
             }
             return;
         }
@@ -515,12 +515,21 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
     if (done) return;
     STAMP(0);
 
-    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
     const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
     const double* xin = p.x + (size_t)inst * p.nvs;
     const int k       = tid;
     const bool has_stage = (k < N - 1);
     const bool has_block = (k < N);
+    // ---- stage this instance's Jacobian values in LDS with 16-byte coalesced loads (the table-driven per-stage reads below
+    //      are 8-byte gathers with a 192-byte lane stride: from HBM/L2 they would request 16x the cache lines).  The staging
+    //      area is the whole LDS carve; it is dead before phase A writes its first array.
+    const double* J = smem;
+    {
+        const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
+        double2* dst       = reinterpret_cast<double2*>(smem);
+        for (int i = tid; i < p.nnz_pad / 2; i += THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
 
     // ---- load the local Jacobian of defect edge k: [A | B | C | d] and its residual
     double A[NX][NX], B[NX][NU], Cc[NX][NX], dc[NX], r[NX];
@@ -611,6 +620,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
             if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; cdt += a * a; gdt -= a * val[ci.bnd_row]; }
         }
     }
+    __syncthreads();  // every lane has taken its Jacobian entries out of the staging area
     STAMP(1);
 
     // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
@@ -1053,29 +1063,40 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
     factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x, threadIdx.x, nullptr, nullptr);
 }
 
-// One inner Levenberg-Marquardt pass of every unfinished instance in ONE launch: factor/solve, then the trial-step sweep in
-// the same workgroup.  The trial iterate never leaves LDS; while some workgroups are in the latency-bound factor phase others
-// are in the throughput-bound sweep phase, so the two overlap across the chip.
-template <int DYN, int DEFECT, bool ARROW>
-__global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
+// The Levenberg-Marquardt loop of one instance per workgroup: [factor/solve -> trial-step sweep] repeated in the same
+// workgroup.  The trial iterate never leaves LDS; the Jacobian written by the sweep phase is read back by the next factor
+// phase of the same workgroup (L2-resident).  max_passes = 1: one inner pass per launch (host-driven, diagnostics);
+// max_passes large: PERSISTENT -- the whole solve of the instance in one launch, no host round trips, and instances that need
+// more inner passes (rejected steps) simply run longer without holding the others back.  While some workgroups are in the
+// latency-bound factor phase others are in the throughput-bound sweep phase, so the two overlap across the chip.
+template <int DYN, int DEFECT, bool ARROW, bool PERSIST>
+__global__ __launch_bounds__(SWEEP_THREADS, PERSIST ? 3 : 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp, const int max_passes)
 {
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int inst = blockIdx.x, tid = threadIdx.x;
-    if (fp.st[inst].done) return;
     const int NP = fp.N | 1;
     double* xs  = smem + FL::off_Wam(NP);   // dead after the back-substitution
     double* cs  = smem + FL::off_Wbm(NP);
     double* red = smem + FL::off_red(NP);
-    factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
-    __syncthreads();
-    sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, inst, tid);
+    if constexpr (!PERSIST) {
+        if (fp.st[inst].done) return;
+        factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
+        __syncthreads();
+        sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, inst, tid);
+    }
+    else {
+        for (int pass = 0; pass < max_passes; ++pass) {
+            if (fp.st[inst].done) break;  // uniform: written by lane 0 before the barrier below
+            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
+            __syncthreads();
+            sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, inst, tid);
+            __threadfence_block();  // this workgroup's Jacobian / residual / state stores are visible to its next factor phase
+            __syncthreads();
+        }
+    }
 }
-
-#undef STAMP
-#undef TRI
-#undef SOA
 
 template <int DYN, int DEFECT>
 void launch_sweep_t(const SweepParams& p, hipStream_t stream)
@@ -1103,24 +1124,32 @@ size_t factor_lds(int N, bool arrow)
 }
 
 template <int DYN, int DEFECT>
-bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream)
 {
     using Dy = Dynamics<DYN>;
     if (fp.N > SWEEP_THREADS) return false;
-    const size_t lds = factor_lds<Dy::NX, Dy::NU>(fp.N, fp.dt_free != 0);
-    if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true>), dim3(fp.batch), dim3(SWEEP_THREADS), lds, stream, fp, sp);
-    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false>), dim3(fp.batch), dim3(SWEEP_THREADS), lds, stream, fp, sp);
+    size_t lds = factor_lds<Dy::NX, Dy::NU>(fp.N, fp.dt_free != 0);
+    if (lds < sizeof(double) * (size_t)fp.nnz_pad) lds = sizeof(double) * (size_t)fp.nnz_pad;  // Jacobian staging area
+    const dim3 g(fp.batch), b(SWEEP_THREADS);
+    if (max_passes > 1) {
+        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true>), g, b, lds, stream, fp, sp, max_passes);
+        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true>), g, b, lds, stream, fp, sp, max_passes);
+    }
+    else {
+        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, false>), g, b, lds, stream, fp, sp, max_passes);
+        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, false>), g, b, lds, stream, fp, sp, max_passes);
+    }
     return true;
 }
 
 template <int DYN>
-bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream)
 {
     switch (defect) {
-        case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, stream);
-        case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, stream);
-        case CORBO_HIP_DEFECT_MIDPOINT: return launch_pass_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(fp, sp, stream);
-        case CORBO_HIP_DEFECT_CRANK_NICOLSON: return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, max_passes, stream);
+        case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, max_passes, stream);
+        case CORBO_HIP_DEFECT_MIDPOINT: return launch_pass_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(fp, sp, max_passes, stream);
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, max_passes, stream);
         default: return false;
     }
 }
@@ -1128,7 +1157,8 @@ bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hi
 template <int NX, int NU, bool ARROW>
 bool launch_factor_a(const FactorParams& p, hipStream_t stream)
 {
-    const size_t lds = factor_lds<NX, NU>(p.N, ARROW);
+    size_t lds = factor_lds<NX, NU>(p.N, ARROW);
+    if (lds < sizeof(double) * (size_t)p.nnz_pad) lds = sizeof(double) * (size_t)p.nnz_pad;  // Jacobian staging area
     if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128, ARROW>), dim3(p.batch), dim3(128), lds, stream, p);
     else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256, ARROW>), dim3(p.batch), dim3(256), lds, stream, p);
     else return false;
@@ -1165,14 +1195,14 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
     }
 }
 
-bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream)
 {
     switch (d.dynamics) {
-        case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, max_passes, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
             if (d.nx != 2) return false;
-            return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, stream);
-        case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, stream);
+            return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, max_passes, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, max_passes, stream);
         default: return false;
     }
 }

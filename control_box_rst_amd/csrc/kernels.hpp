@@ -81,8 +81,8 @@ struct FactorParams {
 // returns false if the (dynamics, defect) pair has no device instantiation
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
-// one fused LM pass (factor + trial-step sweep in one launch)
-bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
+// fused LM passes (factor + trial-step sweep per workgroup); max_passes = 1: one inner pass, large: the whole solve (persistent)
+bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
 
