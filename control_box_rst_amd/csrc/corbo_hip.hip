@@ -86,6 +86,7 @@ struct corbo_hip_solver {
         p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.n_row_tasks = (int)S.row_tasks.size(); p.n_col_tasks = (int)S.col_tasks.size(); p.n_bound_tasks = (int)S.bound_tasks.size();
         p.row_tasks = d_row_tasks; p.col_tasks = d_col_tasks; p.bound_tasks = d_bound_tasks;
+        p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         std::memcpy(p.mp.dyn, S.desc.dyn_params, sizeof(p.mp.dyn));
         std::memcpy(p.mp.ineq, S.desc.ineq_params, sizeof(p.mp.ineq));
         std::memcpy(p.mp.sq, S.sq, sizeof(p.mp.sq));

@@ -58,10 +58,10 @@ __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double
 #pragma clang fp contract(off)
 
 // LDS operands: xs [nvs] vertex values of this instance, red [10] reduction scratch + 4 int flags, cs [N*NC] per-grid-state
-// dynamics caches.  FUSED: called right after factor_body in the same workgroup -- the trial iterate is already in xs and
+// dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: called right after factor_body in the same workgroup -- the trial iterate is already in xs and
 // the pass flags (no_trial, vbuf) are in the flag words.
 template <int DYN, int DEFECT, bool FUSED>
-__device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, double* red, double* cs, const int inst, const int tid)
+__device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -275,112 +275,223 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
     }
     if (!do_jac) return;
 
-    // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753)
-    //      one lane per central-difference column (BaseEdge::computeJacobian, edge_interface.cpp:55-96)
+    // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753),
+    //      central differences exactly as BaseEdge::computeJacobian (edge_interface.cpp:55-96):
+    //      x_i += delta -> v2 ; x_i += -2 delta -> v1 ; col = (1/(2 delta)) (v2 - v1), on private copies of the edge's vertices.
+    //      Values are assembled in the LDS staging area and streamed out with coalesced 16-byte stores at the end.
     constexpr double delta     = 1e-9;
     constexpr double neg2delta = -2 * delta;
     constexpr double scalar    = 1.0 / (2 * delta);
-    int4 ct_next = (tid < p.n_col_tasks) ? ctab[tid] : make_int4(0, 0, 0, 0);
-    for (int t = tid; t < p.n_col_tasks; t += SWEEP_THREADS) {
-        const ColTask ct{ct_next.x, ct_next.y, ct_next.z, ct_next.w};
-        if (t + SWEEP_THREADS < p.n_col_tasks) ct_next = ctab[t + SWEEP_THREADS];
-        const int base   = ct.k * S;
-        if (ct.kind == EK_DEFECT) {
-            const bool is_dt = (ct.voff == p.off_dt);
-            const int idx    = is_dt ? -1 : ct.voff - base;
-            double loc[W];
+    const double dt0 = xs[p.off_dt];
+    // (1) dynamics-defect blocks.  Lane = (stage k, column group g): the perturbed component is a compile-time index inside the
+    //     lane's loop, so there is no per-lane selection of what to perturb, no divergence, and for the cached defects only the
+    //     parts of the defect that depend on the perturbed component are re-evaluated (the others are bit-identical anyway).
+    {
+        constexpr int NU0 = (NU + 1) / 2;  // group 0: x_k, u_k[0,NU0) ; group 1: u_k[NU0,NU), x_{k+1}, dt
+        const int g = tid >> 7;
+        for (int k = tid & 127; k < p.N - 1; k += 128) {
+            const int base  = k * S;
+            const int* sc   = p.stage_cols[k].col;
+            double x1[NX], u1[NU], x2[NX];
 #pragma unroll
-            for (int i = 0; i < W; ++i) loc[i] = xs[base + i];
-            double dt = xs[p.off_dt];
-            double v1[NX], v2[NX];
+            for (int i = 0; i < NX; ++i) { x1[i] = xs[base + i]; x2[i] = xs[base + S + i]; }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u1[i] = xs[base + NX + i];
+            auto emit = [&](int jo, const double* e2, const double* e1) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) jst[jo + r] = (scalar * (e2[r] - e1[r])) * p.w_eq;  // :1552
+            };
             if constexpr (CACHED) {
-                double c1[NC], c2[NC];
+                using DP = DefectParts<DEFECT>;
+                double c1[NC], c2[NC], q[NX], f1[NX], f2[NX];
 #pragma unroll
-                for (int i = 0; i < NC; ++i) { c1[i] = cs[ct.k * NC + i]; c2[i] = cs[(ct.k + 1) * NC + i]; }
-                const bool px1 = (idx >= 0 && idx < NX), px2 = (idx >= S);
-                const int xi   = px2 ? idx - S : idx;
-                const bool need = (px1 || px2) && ((Dy::CACHE_XMASK >> xi) & 1u);
+                for (int i = 0; i < NC; ++i) { c1[i] = cs[k * NC + i]; c2[i] = cs[(k + 1) * NC + i]; }
 #pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const double inc = side == 0 ? delta : neg2delta;  // vertex->plus(i, delta) ; vertex->plus(i, neg2delta)
+                for (int i = 0; i < NX; ++i) q[i] = (x2[i] - x1[i]) / dt0;
+                Dy::eval(x1, c1, u1, p.mp.dyn, f1);
+                Dy::eval(x2, c2, u1, p.mp.dyn, f2);
+                if (g == 0) {
 #pragma unroll
-                    for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + inc : loc[i];
-                    dt = is_dt ? dt + inc : dt;
-                    double d1[NC], d2[NC];
+                    for (int i = 0; i < NX; ++i) {  // d/d x_k[i]: q_i and f(x1,u1) change
+                        const int jo = sc[i];
+                        if (jo < 0) continue;
+                        double e[2][NX];
+                        double xa = x1[i];
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) { d1[i] = c1[i]; d2[i] = c2[i]; }
-                    if (Dy::CACHE_XMASK != 0u && need) {  // only the perturbed state's cache is recomputed
-                        double xp[NX], cp[NC];
+                        for (int side = 0; side < 2; ++side) {
+                            xa += (side == 0) ? delta : neg2delta;
+                            double xp[NX], cp[NC], fp[NX], qp[NX];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) xp[i] = px2 ? loc[S + i] : loc[i];
-                        Dy::prepare(xp, p.mp.dyn, cp);
+                            for (int r = 0; r < NX; ++r) { xp[r] = (r == i) ? xa : x1[r]; qp[r] = q[r]; fp[r] = f1[r]; }
+                            qp[i] = (x2[i] - xa) / dt0;
+                            if constexpr (DP::uses_f1) {
+                                if ((Dy::CACHE_XMASK >> i) & 1u) Dy::prepare(xp, p.mp.dyn, cp);
+                                else {
 #pragma unroll
-                        for (int i = 0; i < NC; ++i) { d1[i] = px2 ? c1[i] : cp[i]; d2[i] = px2 ? cp[i] : c2[i]; }
+                                    for (int r = 0; r < NC; ++r) cp[r] = c1[r];
+                                }
+                                Dy::eval(xp, cp, u1, p.mp.dyn, fp);
+                            }
+                            defect_combine<NX, DEFECT>(qp, fp, f2, e[side]);
+                        }
+                        emit(jo, e[0], e[1]);
                     }
-                    if (side == 0) defect_eval_cached<DYN, DEFECT>(loc, d1, loc + NX, loc + S, d2, dt, p.mp.dyn, v2);
-                    else defect_eval_cached<DYN, DEFECT>(loc, d1, loc + NX, loc + S, d2, dt, p.mp.dyn, v1);
+                }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {  // d/d u_k[j]: both dynamics evaluations change
+                    if ((j < NU0) != (g == 0)) continue;
+                    const int jo = sc[NX + j];
+                    if (jo < 0) continue;
+                    double e[2][NX];
+                    double ua = u1[j];
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        ua += (side == 0) ? delta : neg2delta;
+                        double up[NU], g1[NX], g2[NX];
+#pragma unroll
+                        for (int r = 0; r < NU; ++r) up[r] = (r == j) ? ua : u1[r];
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) { g1[r] = f1[r]; g2[r] = f2[r]; }
+                        if constexpr (DP::uses_f1) Dy::eval(x1, c1, up, p.mp.dyn, g1);
+                        if constexpr (DP::uses_f2) Dy::eval(x2, c2, up, p.mp.dyn, g2);
+                        defect_combine<NX, DEFECT>(q, g1, g2, e[side]);
+                    }
+                    emit(jo, e[0], e[1]);
+                }
+                if (g == 1) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {  // d/d x_{k+1}[i]: q_i and f(x2,u1) change
+                        const int jo = sc[S + i];
+                        if (jo < 0) continue;
+                        double e[2][NX];
+                        double xa = x2[i];
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            xa += (side == 0) ? delta : neg2delta;
+                            double xp[NX], cp[NC], fp[NX], qp[NX];
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) { xp[r] = (r == i) ? xa : x2[r]; qp[r] = q[r]; fp[r] = f2[r]; }
+                            qp[i] = (xa - x1[i]) / dt0;
+                            if constexpr (DP::uses_f2) {
+                                if ((Dy::CACHE_XMASK >> i) & 1u) Dy::prepare(xp, p.mp.dyn, cp);
+                                else {
+#pragma unroll
+                                    for (int r = 0; r < NC; ++r) cp[r] = c2[r];
+                                }
+                                Dy::eval(xp, cp, u1, p.mp.dyn, fp);
+                            }
+                            defect_combine<NX, DEFECT>(qp, f1, fp, e[side]);
+                        }
+                        emit(jo, e[0], e[1]);
+                    }
+                    const int jo = sc[S + NX];
+                    if (jo >= 0) {  // d/d dt (free-dt grids): every q changes
+                        double e[2][NX];
+                        double da = dt0;
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            da += (side == 0) ? delta : neg2delta;
+                            double qp[NX];
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) qp[r] = (x2[r] - x1[r]) / da;
+                            defect_combine<NX, DEFECT>(qp, f1, f2, e[side]);
+                        }
+                        emit(jo, e[0], e[1]);
+                    }
                 }
             }
-            else {
+            else {  // defects that evaluate the dynamics off the grid states (midpoint, RK4 shooting): full re-evaluation per column
+                double loc[W];
 #pragma unroll
-                for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + delta : loc[i];  // vertex->plus(i, delta)
-                dt = is_dt ? dt + delta : dt;
-                defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v2);
+                for (int i = 0; i < NX; ++i) { loc[i] = x1[i]; loc[S + i] = x2[i]; }
 #pragma unroll
-                for (int i = 0; i < W; ++i) loc[i] = (i == idx) ? loc[i] + neg2delta : loc[i];  // vertex->plus(i, neg2delta)
-                dt = is_dt ? dt + neg2delta : dt;
-                defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt, p.mp.dyn, v1);
+                for (int i = 0; i < NU; ++i) loc[NX + i] = u1[i];
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    const bool mine = (c < NX + NU0) ? (g == 0) : (g == 1);
+                    const int jo    = sc[c];
+                    if (!mine || jo < 0) continue;
+                    double e[2][NX];
+                    const double keep = loc[c];
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        loc[c] += (side == 0) ? delta : neg2delta;
+                        defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt0, p.mp.dyn, e[side]);
+                    }
+                    loc[c] = keep;
+                    emit(jo, e[0], e[1]);
+                }
+                const int jo = sc[S + NX];
+                if (g == 1 && jo >= 0) {
+                    double e[2][NX];
+                    double da = dt0;
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        da += (side == 0) ? delta : neg2delta;
+                        defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, da, p.mp.dyn, e[side]);
+                    }
+                    emit(jo, e[0], e[1]);
+                }
             }
-#pragma unroll
-            for (int r = 0; r < NX; ++r) js[ct.joff + r] = (scalar * (v2[r] - v1[r])) * p.w_eq;  // :1552
-        }
-        else if (ct.kind == EK_STATE_COST || ct.kind == EK_FINAL_COST) {
-            const int idx  = ct.voff - base;
-            const double a = xs[ct.voff] + delta, b = a + neg2delta;
-#pragma unroll
-            for (int r = 0; r < NX; ++r) {
-                const double w  = (ct.kind == EK_STATE_COST) ? p.mp.sq[r] : p.mp.sqf[r];
-                const double x0 = xs[base + r];
-                const double e2 = w * (((r == idx) ? a : x0) - xr[r]);
-                const double e1 = w * (((r == idx) ? b : x0) - xr[r]);
-                js[ct.joff + r] = scalar * (e2 - e1);
-            }
-        }
-        else if (ct.kind == EK_CONTROL_COST) {
-            const int idx  = ct.voff - base - NX;
-            const double a = xs[ct.voff] + delta, b = a + neg2delta;
-#pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                const double x0 = xs[base + NX + r];
-                const double e2 = p.mp.sr[r] * ((r == idx) ? a : x0);
-                const double e1 = p.mp.sr[r] * ((r == idx) ? b : x0);
-                js[ct.joff + r] = scalar * (e2 - e1);
-            }
-        }
-        else if (ct.kind == EK_DT_COST) {
-            const double a = xs[ct.voff] + delta, b = a + neg2delta;
-            js[ct.joff]    = scalar * (p.mp.dt_weight * a - p.mp.dt_weight * b);
-        }
-        else if (ct.kind == EK_STAGE_INEQ) {  // active rows only, explicit zero otherwise (:1568-1610)
-            const int idx = ct.voff - base;
-            double loc[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) loc[i] = xs[base + i];
-            const double c0 = ineq_ball(loc, p.mp.ineq);
-            const bool active = (((c0 < 0) ? 0.0 : c0 * p.w_ineq) > 0.0);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) loc[i] = (i == idx) ? loc[i] + delta : loc[i];
-            const double c2 = ineq_ball(loc, p.mp.ineq);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) loc[i] = (i == idx) ? loc[i] + neg2delta : loc[i];
-            const double c1 = ineq_ball(loc, p.mp.ineq);
-            js[ct.joff]     = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
         }
     }
+    // (2) least-squares cost blocks: one lane per vertex component (column); each output depends on its own component only,
+    //     so a column is the diagonal entry and exact zeros elsewhere (what scalar * (e2 - e1) yields for untouched rows)
+    for (int v = tid; v <= p.off_dt; v += SWEEP_THREADS) {
+        const CompInfo ci = p.comp[v];
+        if (ci.fixed || ci.cost_joff < 0) continue;
+        const double a = xs[v] + delta, b = a + neg2delta;
+        if (v == p.off_dt) {  // duplicated MinimumTime dt edge: two 1x1 blocks (nlp_functions.cpp:91-107)
+            const double val = scalar * (p.mp.dt_weight * a - p.mp.dt_weight * b);
+            jst[ci.cost_joff] = val;
+            if (ci.cost2_joff >= 0) jst[ci.cost2_joff] = val;
+            continue;
+        }
+        int c, dim;
+        double w, ref;
+        if (v >= p.N * S - S) {  // x_f: final cost
+            c = v - (p.N - 1) * S; dim = NX; w = p.mp.sqf[c]; ref = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + c];
+        }
+        else {
+            c = v % S;
+            if (c < NX) { dim = NX; w = p.mp.sq[c]; ref = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + c]; }
+            else { c -= NX; dim = NU; w = p.mp.sr[c]; ref = 0.0; }
+        }
+        const bool is_control = (v < (p.N - 1) * S) && (v % S >= NX);
+        const double e2 = is_control ? w * a : w * (a - ref);
+        const double e1 = is_control ? w * b : w * (b - ref);
+        const int col0  = ci.cost_joff - c;
+        for (int r = 0; r < dim; ++r) jst[col0 + r] = (r == c) ? scalar * (e2 - e1) : 0.0;
+    }
+    // (3) stage inequality rows (active rows only, explicit zero otherwise, :1568-1610)
+    if constexpr (NX >= 3) {
+        if (p.ineq_cols) {
+            for (int k = tid; k < p.N - 1; k += SWEEP_THREADS) {
+                double loc[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) loc[i] = xs[k * S + i];
+                const double c0   = ineq_ball(loc, p.mp.ineq);
+                const bool active = (((c0 < 0) ? 0.0 : c0 * p.w_ineq) > 0.0);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const int jo = p.ineq_cols[k * NX + i];
+                    if (jo < 0) continue;
+                    const double keep = loc[i];
+                    loc[i] += delta;
+                    const double c2 = ineq_ball(loc, p.mp.ineq);
+                    loc[i] += neg2delta;
+                    const double c1 = ineq_ball(loc, p.mp.ineq);
+                    loc[i]  = keep;
+                    jst[jo] = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
+                }
+            }
+        }
+    }
+    // (4) bound rows: -w / 0 / +w (:1721-1752)
     bt_next = (tid < p.n_bound_tasks) ? btab[tid] : make_int4(0, 0, 0, 0);
     l_next  = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.x] : 0.0;
     u_next  = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.x] : 0.0;
-    for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {  // :1721-1752
+    for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {
         const BoundTask bt{bt_next.x, bt_next.y, bt_next.z, bt_next.w};
         const double xv = xs[bt.voff], l = l_next, u = u_next;
         if (t + SWEEP_THREADS < p.n_bound_tasks) {
@@ -388,8 +499,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
             l_next  = p.lb[xo + bt_next.x];
             u_next  = p.ub[xo + bt_next.x];
         }
-        js[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
+        jst[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
     }
+    __syncthreads();
+    // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
+    for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
+        reinterpret_cast<double2*>(js)[i] = reinterpret_cast<const double2*>(jst)[i];
 }
 
 template <int DYN, int DEFECT>
@@ -399,7 +514,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* xs  = smem;
     double* red = smem + p.nvs;
     double* cs  = red + 10;
-    sweep_body<DYN, DEFECT, false>(p, xs, red, cs, blockIdx.x, threadIdx.x);
+    double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned)
+    sweep_body<DYN, DEFECT, false>(p, xs, red, cs, jst, blockIdx.x, threadIdx.x);
 }
 
 #pragma clang fp contract(fast)
@@ -1077,21 +1193,25 @@ __global__ __launch_bounds__(SWEEP_THREADS, PERSIST ? 3 : 4) void lm_pass_kernel
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int inst = blockIdx.x, tid = threadIdx.x;
     const int NP = fp.N | 1;
-    double* xs  = smem + FL::off_Wam(NP);   // dead after the back-substitution
-    double* cs  = smem + FL::off_Wbm(NP);
+    // LDS map of the sweep phase inside the factor carve (all factor arrays are dead by then): Jacobian staging [0, nnz_pad),
+    // dynamics caches right behind it, reduction scratch = the factor phase's, trial iterate behind the factor carve.
+    const int ftot = FL::total(NP, ARROW);
     double* red = smem + FL::off_red(NP);
+    double* jst = smem;
+    double* cs  = smem + sp.nnz_pad;
+    double* xs  = smem + ((ftot > sp.nnz_pad + fp.N * Dy::NC ? ftot : sp.nnz_pad + fp.N * Dy::NC) + 1) / 2 * 2;
     if constexpr (!PERSIST) {
         if (fp.st[inst].done) return;
         factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
         __syncthreads();
-        sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, inst, tid);
+        sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, jst, inst, tid);
     }
     else {
         for (int pass = 0; pass < max_passes; ++pass) {
             if (fp.st[inst].done) break;  // uniform: written by lane 0 before the barrier below
             factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
             __syncthreads();
-            sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, inst, tid);
+            sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, jst, inst, tid);
             __threadfence_block();  // this workgroup's Jacobian / residual / state stores are visible to its next factor phase
             __syncthreads();
         }
@@ -1128,8 +1248,9 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, int max_passes
 {
     using Dy = Dynamics<DYN>;
     if (fp.N > SWEEP_THREADS) return false;
-    size_t lds = factor_lds<Dy::NX, Dy::NU>(fp.N, fp.dt_free != 0);
-    if (lds < sizeof(double) * (size_t)fp.nnz_pad) lds = sizeof(double) * (size_t)fp.nnz_pad;  // Jacobian staging area
+    size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
+    if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
+    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs);                                  // + trial iterate
     const dim3 g(fp.batch), b(SWEEP_THREADS);
     if (max_passes > 1) {
         if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true>), g, b, lds, stream, fp, sp, max_passes);
@@ -1173,7 +1294,7 @@ bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 
 }  // namespace
 
-size_t sweep_lds_bytes(const SweepParams& p) { return sizeof(double) * ((size_t)p.nvs + 10 + (size_t)p.N * 2 + 2); }
+size_t sweep_lds_bytes(const SweepParams& p) { return sizeof(double) * ((size_t)p.nvs + 10 + (size_t)p.N * 2 + 2 + p.nnz_pad); }
 
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
 {

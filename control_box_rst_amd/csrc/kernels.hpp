@@ -40,6 +40,9 @@ struct SweepParams {
     const RowTask* row_tasks;
     const ColTask* col_tasks;
     const BoundTask* bound_tasks;
+    const StageCols* stage_cols;  // N-1: Jacobian offsets of the defect columns of stage k
+    const CompInfo* comp;         // nvs: cost-block offsets per component
+    const int32_t* ineq_cols;     // (N-1)*nx or null
     ModelParams mp;
     double dt_fixed;
     // per-call

@@ -78,6 +78,23 @@ template <int DEFECT> struct DefectTraits {
                                     DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON);
 };
 
+// The cached defects are combinations of three parts: q = (x2 - x1)/dt, f1 = f(x1,u1), f2 = f(x2,u1).  A finite-difference
+// column only re-evaluates the parts that depend on the perturbed component; the others are bit-identical by construction.
+template <int DEFECT> struct DefectParts {
+    static constexpr bool uses_f1 = (DEFECT == CORBO_HIP_DEFECT_FORWARD || DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON);
+    static constexpr bool uses_f2 = (DEFECT == CORBO_HIP_DEFECT_BACKWARD || DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON);
+};
+template <int NX, int DEFECT>
+__device__ __forceinline__ void defect_combine(const double* q, const double* f1, const double* f2, double* err)
+{
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        if constexpr (DEFECT == CORBO_HIP_DEFECT_FORWARD) err[i] = f1[i] - q[i];        // err = f(x1,u1); err -= (x2-x1)/dt
+        else if constexpr (DEFECT == CORBO_HIP_DEFECT_BACKWARD) err[i] = f2[i] - q[i];  // err = f(x2,u1); err -= (x2-x1)/dt
+        else err[i] = q[i] - 0.5 * (f1[i] + f2[i]);                                     // (x2-x1)/dt - 0.5*(f1 + f2)
+    }
+}
+
 // defect from cached states: c1 = prepare(x1), c2 = prepare(x2)
 template <int DYN, int DEFECT>
 __device__ __forceinline__ void defect_eval_cached(const double* x1, const double* c1, const double* u1, const double* x2, const double* c2,
