@@ -70,6 +70,8 @@ struct corbo_hip_solver {
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
     double* d_chi2        = nullptr;  // [batch]
+    double* d_work        = nullptr;  // factor workspace (big-block kernel only)
+    size_t work_stride    = 0;
     int32_t* d_counters   = nullptr;  // MAX_PASSES
     int32_t* h_counter    = nullptr;  // pinned
     int m_pad = 0, nnz_pad = 0;
@@ -78,12 +80,13 @@ struct corbo_hip_solver {
     corbo_hip_stats stats{};
     bool profile = false;
     bool persistent = false;    // CORBO_HIP_PERSISTENT=1: whole solve in one launch (measured slower, kept for experiments)
+    bool force_split = false;   // descriptor family without a fused pass kernel
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
 
     SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
     {
         SweepParams p{};
-        p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.n_row_tasks = (int)S.row_tasks.size(); p.n_col_tasks = (int)S.col_tasks.size(); p.n_bound_tasks = (int)S.bound_tasks.size();
         p.row_tasks = d_row_tasks; p.col_tasks = d_col_tasks; p.bound_tasks = d_bound_tasks;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
@@ -108,6 +111,7 @@ struct corbo_hip_solver {
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols; p.ineq_rows = d_ineq_rows;
         p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
         p.st = d_state; p.delta_out = nullptr;
+        p.work = d_work; p.work_stride = (int64_t)work_stride;
         return p;
     }
 };
@@ -164,7 +168,8 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     {   // device kernels exist for this descriptor?
         FactorParams fp{};
         fp.N = S.N;
-        if (factor_lds_bytes(*desc, fp) == 0 || S.N > 256 || (desc->dynamics == CORBO_HIP_DYN_QUADROTOR)) {
+        const bool big = factor_work_doubles(*desc) > 0;
+        if (factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256) || S.dt_free && big) {
             delete h;
             return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
         }
@@ -207,6 +212,11 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipMalloc((void**)&h->d_jac, B * h->nnz_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_state, B * sizeof(LmState)));
     CREATE_TRY(hipMalloc((void**)&h->d_chi2, B * sizeof(double)));
+    h->work_stride = factor_work_doubles(*desc);
+    if (h->work_stride) {
+        CREATE_TRY(hipMalloc((void**)&h->d_work, B * h->work_stride * sizeof(double)));
+        h->force_split = true;  // no fused pass kernel for the big-block family: factor and sweep are separate launches
+    }
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, MAX_PASSES * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * sizeof(int32_t)));
@@ -230,7 +240,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_row_tasks, h->d_col_tasks, h->d_bound_tasks, h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_counters};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -329,7 +339,7 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
     auto enqueue_passes = [&](int count) -> int {
         for (int c = 0; c < count && pass < MAX_PASSES; ++c, ++pass) {
             const SweepParams sp = h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass);
-            if (h->split_passes) {  // diagnostics: the two phases as separate launches (per-kernel timing)
+            if (h->split_passes || h->force_split) {  // the two phases as separate launches (diagnostics / big-block family)
                 int r = launch_factor_checked(h, fp);
                 if (r) return r;
                 stamp();

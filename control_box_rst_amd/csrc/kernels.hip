@@ -70,7 +70,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
     constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
     constexpr int NC  = Dy::NC;
     constexpr bool CACHED = DefectTraits<DEFECT>::cached;
-    double* js  = p.jac + (size_t)inst * p.nnz_pad;  // Jacobian values of this instance (HBM), written column by column
+    constexpr bool STAGE  = (NX <= 6);  // small models: Jacobian assembled in LDS and streamed out; big ones: stored column by column
+    double* js  = p.jac + (size_t)inst * p.nnz_pad;  // Jacobian values of this instance (HBM)
+    if constexpr (!STAGE) jst = js;
     int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
     const size_t xo = (size_t)inst * p.nvs;
     LmState* st    = p.st ? p.st + inst : nullptr;
@@ -501,10 +503,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
         }
         jst[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
     }
-    __syncthreads();
-    // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
-    for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
-        reinterpret_cast<double2*>(js)[i] = reinterpret_cast<const double2*>(jst)[i];
+    if constexpr (STAGE) {
+        __syncthreads();
+        // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
+        for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
+            reinterpret_cast<double2*>(js)[i] = reinterpret_cast<const double2*>(jst)[i];
+    }
 }
 
 template <int DYN, int DEFECT>
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* xs  = smem;
     double* red = smem + p.nvs;
     double* cs  = red + 10;
-    double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned)
+    double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
     sweep_body<DYN, DEFECT, false>(p, xs, red, cs, jst, blockIdx.x, threadIdx.x);
 }
 
@@ -1179,6 +1183,404 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
     factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x, threadIdx.x, nullptr, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// assemble + factor + solve for LARGE stage blocks (cfg 5: quadrotor, nx = 12, nu = 4, N = 200)
+//
+// One wavefront per instance.  The block-tridiagonal system does not fit LDS (3 x 144 doubles per stage), so the stages are
+// swept sequentially (a block Cholesky in natural order): per stage the wave forms G^T G of the local defect Jacobian
+// G = [A | B | C] (12 x 28 -> 28 x 28; fp64 MFMA v_mfma_f64_16x16x4f64, a real contraction here), eliminates the controls,
+// factors the 12 x 12 state block cooperatively, pushes the Schur complement to the next stage and writes the factors to an
+// HBM workspace; a backward sweep reads them back.  Same LM bookkeeping as factor_body.
+template <int NX, int NU>
+struct BigLds {
+    static constexpr int W = 2 * NX + NU;
+    static constexpr int G = 0;                       // [NX][W]
+    static constexpr int R = G + NX * W;              // [NX]   defect residual
+    static constexpr int M = R + NX + (NX & 1);       // [W][W] G^T G
+    static constexpr int GM = M + W * W;              // [W]    -G^T r
+    static constexpr int LUU = GM + W + (W & 1);      // [NU][NU]
+    static constexpr int ZX = LUU + NU * NU;          // [NU][NX]
+    static constexpr int ZP = ZX + NU * NX;           // [NU][NX]
+    static constexpr int YU = ZP + NU * NX;           // [NU]
+    static constexpr int DC = YU + NU + (NU & 1);     // [NX][NX] current diagonal block -> L
+    static constexpr int DN = DC + NX * NX;           // [NX][NX] next diagonal block (Schur mailbox)
+    static constexpr int CX = DN + NX * NX;           // [NX][NX] coupling H'(x_{k+1}, x_k) -> Y
+    static constexpr int GC = CX + NX * NX;           // [NX] rhs of the current block -> y
+    static constexpr int GN = GC + NX;                // [NX]
+    static constexpr int XN = GN + NX;                // [NX] solution of block k+1 (backward sweep)
+    static constexpr int DIAG = XN + NX;              // [NX+NU] diagonal (single-entry row) contributions of stage k
+    static constexpr int GDIAG = DIAG + NX + NU;      // [NX+NU]
+    static constexpr int CIN = GDIAG + NX + NU;       // [NX] inequality row
+    static constexpr int FIX = CIN + NX;              // [NX] fixed flags (as doubles)
+    static constexpr int RED = FIX + NX;              // [8]
+    static constexpr int TOTAL = RED + 8;
+    // HBM workspace per stage
+    static constexpr int WS_L = 0, WS_Y = NX * NX, WS_LUU = 2 * NX * NX, WS_ZX = WS_LUU + NU * NU, WS_ZP = WS_ZX + NU * NX,
+                         WS_YV = WS_ZP + NU * NX, WS_YU = WS_YV + NX, WS_STAGE = WS_YU + NU;
+};
+
+template <int NX, int NU, bool USE_MFMA>
+__global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
+{
+    using BL         = BigLds<NX, NU>;
+    constexpr int S  = NX + NU;
+    constexpr int W  = BL::W;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Gm = sm + BL::G;   double* rv = sm + BL::R;   double* Mm = sm + BL::M;   double* gm = sm + BL::GM;
+    double* Luu = sm + BL::LUU; double* Zx = sm + BL::ZX; double* Zp = sm + BL::ZP;  double* yu = sm + BL::YU;
+    double* Dc = sm + BL::DC;  double* Dn = sm + BL::DN;  double* Cx = sm + BL::CX;  double* gc = sm + BL::GC;
+    double* gn = sm + BL::GN;  double* xn = sm + BL::XN;  double* dg = sm + BL::DIAG; double* gd = sm + BL::GDIAG;
+    double* cin = sm + BL::CIN; double* fx = sm + BL::FIX; double* red = sm + BL::RED;
+
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    LmState* st = p.st + inst;
+    const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
+    int stop = st->stop;
+    double mu = st->mu;
+    const double mu_acc_in = st->mu_acc;
+    __syncthreads();
+    if (done) return;
+    const int N = p.N;
+    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
+    const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    double* xt        = p.xt + (size_t)inst * p.nvs;
+    double* ws        = p.work + (size_t)inst * p.work_stride;
+
+    // loads the local Jacobian, residual and single-entry rows of stage k (k == N-1: only the state block's diagonal rows)
+    auto load_stage = [&](int k) {
+        const bool stage = (k < N - 1);
+        for (int e = lane; e < NX * W; e += 64) {
+            const int r = e % NX, c = e / NX;   // column-major walk: consecutive lanes read consecutive Jacobian values
+            double v = 0.0;
+            if (stage) { const int o = p.stage_cols[k].col[c]; if (o >= 0) v = J[o + r]; }
+            Gm[r * W + c] = v;
+        }
+        for (int e = lane; e < S; e += 64) {
+            double dd = 0.0, gg = 0.0;
+            const bool isx = e < NX;
+            if (isx || stage) {
+                const CompInfo ci = p.comp[k * S + e];
+                if (isx) fx[e] = ci.fixed ? 1.0 : 0.0;
+                if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; dd += a * a; gg -= a * val[ci.cost_row]; }
+                if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; dd += a * a; gg -= a * val[ci.bnd_row]; }
+            }
+            dg[e] = dd; gd[e] = gg;
+        }
+        if (lane < NX) {
+            rv[lane] = stage ? val[p.eq_row0 + k * NX + lane] : 0.0;
+            double c = 0.0;
+            if (stage && p.ineq_cols) { const int o = p.ineq_cols[k * NX + lane]; if (o >= 0) c = J[o]; }
+            cin[lane] = c;
+        }
+        if (lane == 0) red[7] = (stage && p.ineq_rows) ? val[p.ineq_rows[k]] : 0.0;
+    };
+
+    // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1
+    if (first) {
+        double mx_d = -1e300, mx_g = 0.0;
+        for (int k = 0; k < N; ++k) {
+            __syncthreads();
+            if (k > 0 && lane < NX) { gn[lane] = Dn[lane]; xn[lane] = Dn[NX + lane]; }  // previous stage's C-column parts
+            load_stage(k);
+            __syncthreads();
+            if (lane < W) {
+                double dd = 0.0, gg = 0.0;
+                for (int r = 0; r < NX; ++r) { const double a = Gm[r * W + lane]; dd += a * a; gg -= a * rv[r]; }
+                if (lane < NX) {
+                    dd += dg[lane] + cin[lane] * cin[lane]; gg += gd[lane] - cin[lane] * red[7];
+                    if (k > 0) { dd += gn[lane]; gg += xn[lane]; }
+                    if (fx[lane] == 0.0) { mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+                }
+                else if (lane < S) {
+                    if (k < N - 1) { dd += dg[lane]; gg += gd[lane]; mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+                }
+                else { Dn[lane - S] = dd; Dn[NX + lane - S] = gg; }
+            }
+        }
+        mx_d = wave_max(mx_d);
+        mx_g = wave_max(mx_g);
+        stop = (mx_g <= LM_EPS1) ? 1 : 0;
+        mu   = LM_TAU * mx_d;
+        if (mu < 0) mu = 0;
+        __syncthreads();
+    }
+    const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;
+
+    double y2 = 0.0;
+    for (int e = lane; e < NX * NX; e += 64) Dn[e] = 0.0;
+    if (lane < NX) gn[lane] = 0.0;
+    // ---- forward sweep over the stages
+    for (int k = 0; k < N; ++k) {
+        const bool stage = (k < N - 1);
+        __syncthreads();
+        for (int e = lane; e < NX * NX; e += 64) Dc[e] = Dn[e];   // Schur mailbox of the previous stage
+        if (lane < NX) gc[lane] = gn[lane];
+        load_stage(k);
+        __syncthreads();
+        if (stage) {
+            // M = G^T G  (W x NX times NX x W): fp64 matrix cores.  v_mfma_f64_16x16x4f64 layout (probed on gfx950 with
+            // tools/mfma_f64_layout.hip): A[i][k] and B[k][j] live in lane l with i|j = l % 16, k = l / 16; the result register r
+            // of lane l is D[4 r + l / 16][l % 16].  Output tiles (0,0), (1,0), (1,1) of the padded 32 x 32 product, K = NX in
+            // steps of 4; the strict upper triangle is mirrored.
+            if constexpr (USE_MFMA && W <= 32 && NX % 4 == 0) {
+                typedef double d4_t __attribute__((ext_vector_type(4)));
+                const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+                for (int tile = 0; tile < 3; ++tile) {
+                    const int ti = (tile == 0) ? 0 : 1, tj = (tile == 2) ? 1 : 0;
+                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int k0 = 0; k0 < NX; k0 += 4) {
+                        const int ia = 16 * ti + lj, ib = 16 * tj + lj;
+                        const double a = (ia < W) ? Gm[(k0 + lk) * W + ia] : 0.0;
+                        const double b = (ib < W) ? Gm[(k0 + lk) * W + ib] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + 4 * r + lk, j = 16 * tj + lj;
+                        if (i < W && j < W) {
+                            Mm[i * W + j] = acc[r];
+                            if (ti != tj) Mm[j * W + i] = acc[r];
+                        }
+                    }
+                }
+            }
+            else {
+                for (int e = lane; e < W * W; e += 64) {
+                    const int i = e / W, j = e % W;
+                    if (j > i) continue;
+                    double v = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) v += Gm[r * W + i] * Gm[r * W + j];
+                    Mm[i * W + j] = v;
+                    Mm[j * W + i] = v;
+                }
+            }
+            if (lane < W) {
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v -= Gm[r * W + lane] * rv[r];
+                gm[lane] = v;
+            }
+            __syncthreads();
+            // controls: Huu = M[uu] + diag + damping, Cholesky by one lane (NU x NU)
+            if (lane == 0) {
+                double H[NU][NU];
+#pragma unroll
+                for (int a = 0; a < NU; ++a)
+#pragma unroll
+                    for (int b = 0; b < NU; ++b) H[a][b] = Mm[(NX + a) * W + NX + b] + ((a == b) ? dg[NX + a] + mu_eff : 0.0);
+                chol_inv<NU>(H);
+#pragma unroll
+                for (int a = 0; a < NU; ++a)
+#pragma unroll
+                    for (int b = 0; b < NU; ++b) Luu[a * NU + b] = H[a][b];
+            }
+            __syncthreads();
+            // Zx = L^{-1} H(u, x_k), Zp = L^{-1} H(u, x_{k+1}), yu = L^{-1} gu : one lane per column
+            if (lane < 2 * NX + 1) {
+                double col[NU];
+#pragma unroll
+                for (int a = 0; a < NU; ++a)
+                    col[a] = (lane < NX) ? Mm[(NX + a) * W + lane] : (lane < 2 * NX) ? Mm[(NX + a) * W + S + (lane - NX)] : gm[NX + a] + gd[NX + a];
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    double v = col[a];
+#pragma unroll
+                    for (int b = 0; b < a; ++b) v -= Luu[a * NU + b] * col[b];
+                    col[a] = v * Luu[a * NU + a];
+                }
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    if (lane < NX) Zx[a * NX + lane] = col[a];
+                    else if (lane < 2 * NX) Zp[a * NX + lane - NX] = col[a];
+                    else { yu[a] = col[a]; y2 += col[a] * col[a]; }
+                }
+            }
+            __syncthreads();
+        }
+        // state block k: D_k = mailbox + M[xx] - Zx^T Zx + diag + c c^T + damping ; coupling and the mailbox for k+1
+        for (int e = lane; e < NX * NX; e += 64) {
+            const int i = e / NX, j = e % NX;
+            double d = Dc[e], cx = 0.0, dn = 0.0;
+            if (stage) {
+                d += Mm[i * W + j] + cin[i] * cin[j];
+                cx = Mm[(S + i) * W + j];
+                dn = Mm[(S + i) * W + S + j];
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    d -= Zx[a * NX + i] * Zx[a * NX + j];
+                    cx -= Zp[a * NX + i] * Zx[a * NX + j];
+                    dn -= Zp[a * NX + i] * Zp[a * NX + j];
+                }
+            }
+            if (i == j) d += dg[i] + mu_eff;
+            if (fx[i] != 0.0 || fx[j] != 0.0) d = (i == j) ? 1.0 : 0.0;
+            Dc[e] = d; Cx[e] = cx; Dn[e] = dn;
+        }
+        if (lane < NX) {
+            double g = gc[lane] + gd[lane], g2 = 0.0;
+            if (stage) {
+                g += gm[lane] - cin[lane] * red[7];
+                g2 = gm[S + lane];
+#pragma unroll
+                for (int a = 0; a < NU; ++a) { g -= Zx[a * NX + lane] * yu[a]; g2 -= Zp[a * NX + lane] * yu[a]; }
+            }
+            if (fx[lane] != 0.0) g = 0.0;
+            gc[lane] = g; gn[lane] = g2;
+        }
+        __syncthreads();
+        // Cholesky of D_k, right-looking, lanes over the trailing entries; diagonal stored inverted
+        for (int j = 0; j < NX; ++j) {
+            const double inv = rsqrt(Dc[j * NX + j]);
+            __syncthreads();
+            if (lane == 0) Dc[j * NX + j] = inv;
+            if (lane > 0 && j + lane < NX) Dc[(j + lane) * NX + j] *= inv;
+            __syncthreads();
+            const int m = NX - 1 - j;   // trailing size
+            for (int e = lane; e < m * m; e += 64) {
+                const int i = j + 1 + e / m, c = j + 1 + e % m;
+                if (c <= i) Dc[i * NX + c] -= Dc[i * NX + j] * Dc[c * NX + j];
+            }
+            __syncthreads();
+        }
+        // Y = Cx L^{-T} (one lane per row), y = L^{-1} g (lane NX)
+        if (lane < NX) {
+            double yrow[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                double v = Cx[lane * NX + c];
+#pragma unroll
+                for (int t = 0; t < c; ++t) v -= yrow[t] * Dc[c * NX + t];
+                yrow[c] = v * Dc[c * NX + c];
+            }
+#pragma unroll
+            for (int c = 0; c < NX; ++c) Cx[lane * NX + c] = yrow[c];
+        }
+        else if (lane == NX) {
+            double y[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double v = gc[i];
+#pragma unroll
+                for (int t = 0; t < i; ++t) v -= Dc[i * NX + t] * y[t];
+                y[i] = v * Dc[i * NX + i];
+                y2 += y[i] * y[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) gc[i] = y[i];
+        }
+        __syncthreads();
+        // Schur complement to the next block; factors to the HBM workspace
+        if (stage) {
+            for (int e = lane; e < NX * NX; e += 64) {
+                const int i = e / NX, j = e % NX;
+                double v = Dn[e];
+#pragma unroll
+                for (int t = 0; t < NX; ++t) v -= Cx[i * NX + t] * Cx[j * NX + t];
+                Dn[e] = v;
+            }
+            if (lane < NX) {
+                double v = gn[lane];
+#pragma unroll
+                for (int t = 0; t < NX; ++t) v -= Cx[lane * NX + t] * gc[t];
+                gn[lane] = v;
+            }
+        }
+        double* wk = ws + (size_t)k * BL::WS_STAGE;
+        for (int e = lane; e < NX * NX; e += 64) { wk[BL::WS_L + e] = Dc[e]; wk[BL::WS_Y + e] = Cx[e]; }
+        if (lane < NU * NU) wk[BL::WS_LUU + lane] = Luu[lane];
+        if (lane < NU * NX) { wk[BL::WS_ZX + lane] = Zx[lane]; wk[BL::WS_ZP + lane] = Zp[lane]; }
+        if (lane < NX) wk[BL::WS_YV + lane] = gc[lane];
+        if (lane < NU) wk[BL::WS_YU + lane] = yu[lane];
+    }
+    __syncthreads();
+    // ---- backward sweep
+    double dn2 = 0.0;
+    for (int k = N - 1; k >= 0; --k) {
+        const bool stage = (k < N - 1);
+        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+        __threadfence_block();
+        __syncthreads();
+        for (int e = lane; e < NX * NX; e += 64) { Dc[e] = wk[BL::WS_L + e]; Cx[e] = wk[BL::WS_Y + e]; }
+        if (lane < NU * NU) Luu[lane] = wk[BL::WS_LUU + lane];
+        if (lane < NU * NX) { Zx[lane] = wk[BL::WS_ZX + lane]; Zp[lane] = wk[BL::WS_ZP + lane]; }
+        if (lane < NX) gc[lane] = wk[BL::WS_YV + lane];
+        if (lane < NU) yu[lane] = wk[BL::WS_YU + lane];
+        if (lane < NX) fx[lane] = p.comp[k * S + lane].fixed ? 1.0 : 0.0;
+        __syncthreads();
+        if (lane < NX && stage) {  // t = y - Y^T x_{k+1}
+            double v = gc[lane];
+#pragma unroll
+            for (int t = 0; t < NX; ++t) v -= Cx[t * NX + lane] * xn[t];
+            gc[lane] = v;
+        }
+        __syncthreads();
+        if (lane == 0) {  // x_k = L^{-T} t
+            double x[NX];
+#pragma unroll
+            for (int i = NX - 1; i >= 0; --i) {
+                double v = gc[i];
+#pragma unroll
+                for (int t = i + 1; t < NX; ++t) v -= Dc[t * NX + i] * x[t];
+                x[i] = v * Dc[i * NX + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) gc[i] = (fx[i] != 0.0) ? 0.0 : x[i];
+        }
+        __syncthreads();
+        if (lane == 0 && stage) {  // u_k = Luu^{-T} (yu - Zx x_k - Zp x_{k+1})
+            double u[NU];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                double v = yu[a];
+#pragma unroll
+                for (int c = 0; c < NX; ++c) v -= Zx[a * NX + c] * gc[c] + Zp[a * NX + c] * xn[c];
+                u[a] = v;
+            }
+#pragma unroll
+            for (int a = NU - 1; a >= 0; --a) {
+                double v = u[a];
+#pragma unroll
+                for (int b = a + 1; b < NU; ++b) v -= Luu[b * NU + a] * u[b];
+                u[a] = v * Luu[a * NU + a];
+            }
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { dn2 += u[a] * u[a]; xt[k * S + NX + a] = xin[k * S + NX + a] + u[a]; }
+        }
+        if (lane < NX) {
+            const double d = gc[lane];
+            dn2 += d * d;
+            xt[k * S + lane] = xin[k * S + lane] + d;
+        }
+        __syncthreads();
+        if (lane < NX) xn[lane] = gc[lane];
+    }
+    if (lane == 0) {
+        xt[p.off_dt] = xin[p.off_dt];
+        if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
+    }
+    y2  = wave_sum(y2);
+    dn2 = wave_sum(dn2);
+    if (lane == 0) {
+        st->mu     = mu;
+        st->mu_acc = mu_eff;
+        st->first  = 0;
+        st->fresh  = 0;
+        st->n_fact += 1;
+        st->inner += 1;
+        const double dnorm = sqrt(dn2);
+        st->dnorm = dnorm;
+        int no_trial;
+        if (dnorm <= LM_EPS2) { stop = 1; no_trial = 1; }
+        else { no_trial = 0; st->den = mu * dn2 + y2; }
+        st->stop     = stop;
+        st->no_trial = no_trial;
+    }
+}
+
 // The Levenberg-Marquardt loop of one instance per workgroup: [factor/solve -> trial-step sweep] repeated in the same
 // workgroup.  The trial iterate never leaves LDS; the Jacobian written by the sweep phase is read back by the next factor
 // phase of the same workgroup (L2-resident).  max_passes = 1: one inner pass per launch (host-driven, diagnostics);
@@ -1294,10 +1696,21 @@ bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 
 }  // namespace
 
-size_t sweep_lds_bytes(const SweepParams& p) { return sizeof(double) * ((size_t)p.nvs + 10 + (size_t)p.N * 2 + 2 + p.nnz_pad); }
+size_t sweep_lds_bytes(const SweepParams& p)
+{
+    const size_t stage = (p.nx <= 6) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
+    return sizeof(double) * ((size_t)p.nvs + 10 + (size_t)p.N * 6 + 2 + stage);
+}
+
+size_t factor_work_doubles(const corbo_hip_problem_desc& d)
+{
+    if (d.nx == 12 && d.nu == 4) return (size_t)d.N * BigLds<12, 4>::WS_STAGE;
+    return 0;
+}
 
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
 {
+    if (d.nx == 12 && d.nu == 4) return sizeof(double) * BigLds<12, 4>::TOTAL;
     const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
     if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N, arrow);
     if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
@@ -1312,6 +1725,10 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
             if (d.nx != 2) return false;
             return launch_sweep_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, p, stream);
         case CORBO_HIP_DYN_UNICYCLE: return launch_sweep_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, p, stream);
+        case CORBO_HIP_DYN_QUADROTOR:
+            if (d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return false;
+            launch_sweep_t<CORBO_HIP_DYN_QUADROTOR, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, stream);
+            return true;
         default: return false;
     }
 }
@@ -1330,6 +1747,12 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
 
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream)
 {
+    if (d.nx == 12 && d.nu == 4) {
+        if (p.dt_free || !p.work) return false;
+        const size_t lds = sizeof(double) * (size_t)BigLds<12, 4>::TOTAL;
+        hipLaunchKernelGGL((factor_big_kernel<12, 4, true>), dim3(p.batch), dim3(64), lds, stream, p);
+        return true;
+    }
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
     if (d.nx == 3 && d.nu == 2) return launch_factor_t<3, 2>(p, stream);
     return false;

@@ -35,7 +35,7 @@ static_assert(sizeof(LmState) == 128, "LmState layout");
 
 struct SweepParams {
     // static structure
-    int32_t batch, nvs, m, nnz, N, s, off_dt, dt_free;
+    int32_t batch, nvs, m, nnz, N, s, nx, off_dt, dt_free;
     int32_t n_row_tasks, n_col_tasks, n_bound_tasks;
     const RowTask* row_tasks;
     const ColTask* col_tasks;
@@ -79,6 +79,8 @@ struct FactorParams {
     LmState* st;
     double* delta_out;            // optional [batch][nvs] (debug / tests), may be null
     long long* timeline;          // optional [8] shader-clock stamps of workgroup 0 (diagnostics), may be null
+    double* work;                 // big-block kernel only: per-instance factor workspace in HBM
+    int64_t work_stride;          // doubles per instance
 };
 
 // returns false if the (dynamics, defect) pair has no device instantiation
@@ -88,5 +90,7 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
+// doubles of HBM workspace per instance the factor kernel needs (0 for the LDS-resident small-block kernel)
+size_t factor_work_doubles(const corbo_hip_problem_desc& d);
 
 }  // namespace corbo_hip

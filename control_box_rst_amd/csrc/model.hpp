@@ -64,6 +64,35 @@ template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u
     }
 };
 
+template <> struct Dynamics<CORBO_HIP_DYN_QUADROTOR> {  // user plug-in (DESIGN.md "quadrotor"); prm = g, m, Ixx, Iyy, Izz
+    static constexpr int NX = 12, NU = 4, NC = 6;
+    static constexpr unsigned CACHE_XMASK = 0b111000000u;  // roll, pitch, yaw
+    __device__ static __forceinline__ void prepare(const double* x, const double*, double* c)
+    {
+        sincos(x[6], &c[0], &c[1]);  // sphi, cphi
+        sincos(x[7], &c[2], &c[3]);  // sth, cth
+        sincos(x[8], &c[4], &c[5]);  // spsi, cpsi
+    }
+    __device__ static __forceinline__ void eval(const double* x, const double* c, const double* u, const double* prm, double* f)
+    {
+        const double g = prm[0], m = prm[1], Ixx = prm[2], Iyy = prm[3], Izz = prm[4];
+        const double sphi = c[0], cphi = c[1], sth = c[2], cth = c[3], spsi = c[4], cpsi = c[5];
+        const double tm = u[0] / m;
+        f[0]  = x[3];
+        f[1]  = x[4];
+        f[2]  = x[5];
+        f[3]  = (cphi * sth * cpsi + sphi * spsi) * tm;
+        f[4]  = (cphi * sth * spsi - sphi * cpsi) * tm;
+        f[5]  = cphi * cth * tm - g;
+        f[6]  = x[9] + (x[10] * sphi + x[11] * cphi) * (sth / cth);
+        f[7]  = x[10] * cphi - x[11] * sphi;
+        f[8]  = (x[10] * sphi + x[11] * cphi) / cth;
+        f[9]  = ((Iyy - Izz) * x[10] * x[11] + u[1]) / Ixx;
+        f[10] = ((Izz - Ixx) * x[9] * x[11] + u[2]) / Iyy;
+        f[11] = ((Ixx - Iyy) * x[9] * x[10] + u[3]) / Izz;
+    }
+};
+
 template <int DYN>
 __device__ __forceinline__ void dyn_full(const double* x, const double* u, const double* prm, double* f)
 {

@@ -85,8 +85,36 @@ def dint_desc(N=50, dt=0.1) -> ProblemDesc:
 DINT_WEIGHTS = (100.0, 100.0, 100.0)
 
 
+# ---- cfg 5: quadrotor (nx=12, nu=4), MultipleShootingGrid + RK4, u bounds, one nonlinear stage inequality (keep-out ball) ----
+QUAD_Q = (1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05)
+QUAD_R = (0.01, 0.1, 0.1, 0.1)
+
+
+def quad_desc(N=200, dt=0.05) -> ProblemDesc:
+    return make_desc(grid=capi.GRID_MS, defect=capi.DEFECT_RK4_SHOOTING, dynamics=capi.DYN_QUADROTOR, nx=12, nu=4, N=N, dt=dt,
+                     q=QUAD_Q, r=QUAD_R, qf=tuple(10.0 * v for v in QUAD_Q),
+                     u_lb=(0.0, -1.0, -1.0, -1.0), u_ub=(20.0, 1.0, 1.0, 1.0),
+                     stage_ineq=capi.INEQ_BALL, ineq_params=(1.0, 0.5, 0.6, 0.4),
+                     dyn_params=(9.81, 1.0, 0.01, 0.01, 0.02))
+
+
+QUAD_WEIGHTS = (10.0, 10.0, 10.0)
+
+
+def quad_instances(batch: int, seed: int = 20260928, first: int = 0):
+    """x0 = hover state near the origin, xf = (2,1,1)+U(-0.3,0.3)^3 position goal, default_rng(seed + i)."""
+    x0 = np.zeros((batch, 12))
+    xf = np.zeros((batch, 12))
+    for b in range(batch):
+        rng = np.random.default_rng(seed + first + b)
+        x0[b, :3] = rng.uniform(-0.2, 0.2, 3)
+        xf[b, :3] = np.array([2.0, 1.0, 1.0]) + rng.uniform(-0.3, 0.3, 3)
+    return x0, xf
+
+
 SCENARIOS = {
     "unicycle": (unicycle_desc, UNICYCLE_WEIGHTS),
     "vdp": (vdp_desc, VDP_WEIGHTS),
     "dint": (dint_desc, DINT_WEIGHTS),
+    "quad": (quad_desc, QUAD_WEIGHTS),
 }

@@ -1,6 +1,14 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
-python tools/profile_sweep.py 1024 50
-python tools/profile_sweep.py 1 50
-python tools/profile_sweep.py 4096 20
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ['value','ms_per_step','batch_steps_per_s','kernel_split_ms','roofline']})"
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
+python - <<'PY'
+import sys,time; sys.path.insert(0,'.')
+import numpy as np
+from control_box_rst_amd import problems
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+d=problems.quad_desc(); B=512
+x0,xf=problems.quad_instances(B)
+s=BatchedLevenbergMarquardt(d,B); s.setIterations(10); s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+X0=s.init_trajectory(x0,xf); X0[:,12::16]=9.81; s.set_instance_data(X0,xref=xf)
+s.set_profiling(True); s.solve(); print('cfg5 B=512 N=200:', s.get_stats())
+print('sweep J', s.time_sweep(True,5)*1e3,'us  factor', s.time_factor(5)*1e3, 'us')
+PY

@@ -51,6 +51,8 @@ def main():
         ("vdp_midpoint", dict(scenario="vdp", collocation="midpoint", iters=5), (1, 5)),
         # a short unicycle horizon: cheap full check incl. every iterate
         ("unicycle_n12", dict(scenario="unicycle", N=12, iters=6), (1, 2, 3, 4, 5, 6)),
+        # reduced cfg 5: quadrotor, MultipleShootingGrid + RK4, u bounds, keep-out ball inequality
+        ("quad_n10", dict(scenario="quad", N=10, iters=6), (1, 2, 4, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

@@ -24,7 +24,10 @@
 #include <corbo-optimal-control/functions/quadratic_cost.h>
 #include <corbo-optimal-control/statistics.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_grid.h>
+#include <corbo-numerics/explicit_integrators.h>
+#include <corbo-optimal-control/functions/stage_functions.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_variable_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_grid.h>
 #include <corbo-optimal-control/structured_ocp/structured_optimal_control_problem.h>
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_edge_based.h>
 #include <corbo-optimization/solver/levenberg_marquardt_sparse.h>
@@ -62,6 +65,53 @@ class UnicycleRef : public SystemDynamicsInterface
     }
 };
 
+// Quadrotor (user plug-in, DESIGN.md "quadrotor"): x = [p(3) v(3) roll pitch yaw  body rates(3)], u = [thrust, torques(3)],
+// params g, m, Ixx, Iyy, Izz.  The expressions are character-for-character those of oracle/corbo_oracle.c and the device model.
+class QuadrotorRef : public SystemDynamicsInterface
+{
+ public:
+    Ptr getInstance() const override { return std::make_shared<QuadrotorRef>(); }
+    bool isContinuousTime() const override { return true; }
+    bool isLinear() const override { return false; }
+    int getInputDimension() const override { return 4; }
+    int getStateDimension() const override { return 12; }
+    void dynamics(const Eigen::Ref<const StateVector>& x, const Eigen::Ref<const ControlVector>& u, Eigen::Ref<StateVector> f) const override
+    {
+        const double g = 9.81, m = 1.0, Ixx = 0.01, Iyy = 0.01, Izz = 0.02;
+        double sphi = std::sin(x[6]), cphi = std::cos(x[6]), sth = std::sin(x[7]), cth = std::cos(x[7]), spsi = std::sin(x[8]), cpsi = std::cos(x[8]);
+        double tm = u[0] / m;
+        f[0]  = x[3];
+        f[1]  = x[4];
+        f[2]  = x[5];
+        f[3]  = (cphi * sth * cpsi + sphi * spsi) * tm;
+        f[4]  = (cphi * sth * spsi - sphi * cpsi) * tm;
+        f[5]  = cphi * cth * tm - g;
+        f[6]  = x[9] + (x[10] * sphi + x[11] * cphi) * (sth / cth);
+        f[7]  = x[10] * cphi - x[11] * sphi;
+        f[8]  = (x[10] * sphi + x[11] * cphi) / cth;
+        f[9]  = ((Iyy - Izz) * x[10] * x[11] + u[1]) / Ixx;
+        f[10] = ((Izz - Ixx) * x[9] * x[11] + u[2]) / Iyy;
+        f[11] = ((Ixx - Iyy) * x[9] * x[10] + u[3]) / Izz;
+    }
+};
+
+// keep-out ball on the position: c(x) = r^2 - |x[0:3] - center|^2 <= 0   (one nonlinear stage inequality per grid point, cfg 5)
+class BallKeepOut : public StageInequalityConstraint
+{
+ public:
+    BallKeepOut(double cx, double cy, double cz, double r) : _cx(cx), _cy(cy), _cz(cz), _r(r) {}
+    StageInequalityConstraint::Ptr getInstance() const override { return std::make_shared<BallKeepOut>(_cx, _cy, _cz, _r); }
+    int getNonIntegralStateTermDimension(int k) const override { return 1; }
+    void computeNonIntegralStateTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        double dx = x[0] - _cx, dy = x[1] - _cy, dz = x[2] - _cz;
+        cost[0]   = _r * _r - (dx * dx + dy * dy + dz * dz);
+    }
+
+ private:
+    double _cx, _cy, _cz, _r;
+};
+
 struct Scenario
 {
     std::string name;
@@ -76,7 +126,9 @@ struct Scenario
 
 struct Built
 {
-    std::shared_ptr<FiniteDifferencesGrid> grid;
+    std::shared_ptr<FullDiscretizationGridBase> grid;  // FD grids
+    std::shared_ptr<MultipleShootingGrid> ms_grid;     // multiple-shooting grid (scenario quad)
+    DiscretizationGridInterface::Ptr any_grid;
     std::shared_ptr<HyperGraphOptimizationProblemEdgeBased> hg;
     std::shared_ptr<LevenbergMarquardtSparse> solver;
     std::shared_ptr<StructuredOptimalControlProblem> ocp;
@@ -123,17 +175,30 @@ static Built build(const Scenario& s, int iterations)
         grid->setXfFixed(fixed);
         b.grid = grid;
     }
+    else if (s.name == "quad")
+    {
+        dyn       = std::make_shared<QuadrotorRef>();
+        b.ms_grid = std::make_shared<MultipleShootingGrid>();
+        b.ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        b.ms_grid->setNRef(s.N);
+        b.ms_grid->setDtRef(s.dt);
+        b.any_grid = b.ms_grid;
+    }
     else
     {
         fprintf(stderr, "unknown scenario %s\n", s.name.c_str());
         exit(2);
     }
-    b.grid->setNRef(s.N);
-    b.grid->setDtRef(s.dt);
-    b.grid->setCostIntegrationRule(FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
-    b.grid->setFiniteDifferencesCollocationMethod(makeCollocation(s.collocation));
+    if (b.grid)
+    {
+        b.grid->setNRef(s.N);
+        b.grid->setDtRef(s.dt);
+        b.grid->setCostIntegrationRule(FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        b.grid->setFiniteDifferencesCollocationMethod(makeCollocation(s.collocation));
+        b.any_grid = b.grid;
+    }
 
-    b.ocp = std::make_shared<StructuredOptimalControlProblem>(b.grid, dyn, b.hg, b.solver);
+    b.ocp = std::make_shared<StructuredOptimalControlProblem>(b.any_grid, dyn, b.hg, b.solver);
     b.ocp->setStatisticsObject(b.stats);
 
     if (s.name == "unicycle")
@@ -158,6 +223,21 @@ static Built build(const Scenario& s, int iterations)
     {
         b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
+    }
+    else if (s.name == "quad")
+    {
+        Eigen::VectorXd q(12), r(4);
+        q << 1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05;
+        r << 0.01, 0.1, 0.1, 0.1;
+        Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
+        Eigen::MatrixXd Qf = 10.0 * Q;
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        Eigen::VectorXd ulb(4), uub(4);
+        ulb << 0, -1, -1, -1;
+        uub << 20, 1, 1, 1;
+        b.ocp->setControlBounds(ulb, uub);
+        b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
     if (!b.ocp->initialize())
     {
@@ -195,7 +275,7 @@ static Eigen::VectorXd vertexValues(Built& b, const Scenario& s)
     auto xs = std::make_shared<TimeSeries>();
     auto us = std::make_shared<TimeSeries>();
     b.ocp->getTimeSeries(xs, us);
-    int n = b.grid->getN();
+    int n = b.any_grid->getN();
     std::vector<double> out;
     for (int k = 0; k < n - 1; ++k)
     {
@@ -203,7 +283,7 @@ static Eigen::VectorXd vertexValues(Built& b, const Scenario& s)
         for (int i = 0; i < s.nu; ++i) out.push_back(us->getValuesMatrixView()(i, k));
     }
     for (int i = 0; i < s.nx; ++i) out.push_back(xs->getValuesMatrixView()(i, n - 1));
-    out.push_back(b.grid->getDt());
+    out.push_back(b.any_grid->getFirstDt());
     return Eigen::Map<Eigen::VectorXd>(out.data(), out.size());
 }
 
@@ -246,6 +326,14 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         s.x0 = Eigen::Vector2d(0, 0);
         s.xf = Eigen::Vector2d(1, 0);
         s.solves = 5;
+    }
+    else if (s.name == "quad")
+    {
+        s.nx = 12; s.nu = 4; s.N = 20; s.dt = 0.05;
+        s.w_eq = s.w_ineq = s.w_b = 10;
+        s.x0 = Eigen::VectorXd::Zero(12);
+        s.xf = Eigen::VectorXd::Zero(12);
+        s.xf[0] = 2; s.xf[1] = 1; s.xf[2] = 1;
     }
     if (kv.count("N")) s.N = atoi(kv["N"].c_str());
     if (kv.count("dt")) s.dt = atof(kv["dt"].c_str());

@@ -39,4 +39,6 @@ def desc_for(g):
         return problems.vdp_desc(N=g["N"], dt=g["dt"], defect=defect)
     if g["scenario"] == "dint":
         return problems.dint_desc(N=g["N"], dt=g["dt"])
+    if g["scenario"] == "quad":
+        return problems.quad_desc(N=g["N"], dt=g["dt"])
     raise KeyError(g["scenario"])

@@ -30,7 +30,10 @@ def _built():
     g.build()
 
 
-GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12"]
+GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12", "quad_n10"]
+# reduced cfg 5 (quadrotor): nearly flat directions (yaw, torques) -- rounding-level differences move the iterate along them by
+# ~1e-4 while chi2 agrees to 1e-8 (the oracle shows the same spread against the genuine reference, tests/test_oracle_golden.py)
+X_TOL_BY = {"quad_n10": 5e-4}
 
 
 @pytest.mark.parametrize("name", GOLD)
@@ -63,7 +66,9 @@ def test_lm_iterates_vs_reference_golden(name):
             s.solve(new_run=(i == 0))
         x, chi2, status = s.get_solution()
         ref = np.array(a["vertex"])[: s.dims.nv]
-        assert np.abs(x[0] - ref).max() <= X_TOL, (name, a["k"], np.abs(x[0] - ref).max())
+        assert np.abs(x[0] - ref).max() <= X_TOL_BY.get(name, X_TOL), (name, a["k"], np.abs(x[0] - ref).max())
+        if name in X_TOL_BY:
+            assert abs(chi2[0] - a["chi2"]) <= 1e-7 * abs(a["chi2"]), (name, a["k"])
         assert abs(chi2[0] - a["chi2"]) <= CHI2_RTOL * max(1.0, abs(a["chi2"])), (name, a["k"])
         assert status[0] in (capi.SOLVER_CONVERGED, capi.SOLVER_EARLY_TERMINATED)
         st = s.get_stats()
@@ -111,6 +116,37 @@ def test_values_jacobian_vs_oracle_batch(oracle_mod):
         assert np.abs(values[b] - vo).max() <= 1e-11
         assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max())
         assert np.array_equal(jac[b][-s.dims.bounds:], jo[-s.dims.bounds:])  # bound rows: exactly -w / 0 / +w
+
+
+def test_cfg5_quadrotor_batch_vs_oracle(oracle_mod):
+    """cfg 5 family (quadrotor nx=12 nu=4, multiple shooting + RK4, u bounds, keep-out ball inequality): residual, Jacobian
+    and the LM solve of a small batch at N=40 against the oracle; the big-block factor kernel (fp64 MFMA G^T G) is on this path."""
+    d = problems.quad_desc(N=40)
+    B = 6
+    x0, xf = problems.quad_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(6)
+    s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    X0[:, 12::16] = 9.81          # hover thrust as the initial control guess
+    X0[:, 16 * 20 + 0: 16 * 20 + 3] = [1.0, 0.5, 0.6]  # put one state inside the keep-out ball: active inequality row
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*problems.QUAD_WEIGHTS)
+        assert np.abs(values[b] - vo).max() <= 1e-10 * max(1.0, np.abs(vo).max())
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max())
+        assert (vo[s.dims.lsq + s.dims.eq: s.dims.lsq + s.dims.eq + s.dims.ineq] > 0).any()  # the inequality is active somewhere
+    s.solve()
+    X, chi2, status = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.allclose(chi2, chi2o, rtol=1e-6), (chi2, chi2o)
+    assert np.abs(X - Xo).max() <= 5e-3            # flat directions, see X_TOL_BY
+    assert np.abs(X[:, :12] - X0[:, :12]).max() == 0.0  # x_0 fixed
+    st = s.get_stats()
+    assert st["lm_iterations"] == B * 6
 
 
 def test_multiple_solves_warm_weights(oracle_mod):

@@ -13,7 +13,11 @@ import scipy.sparse as sp
 from conftest import desc_for, load_golden
 from control_box_rst_amd import capi
 
-FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12"]
+FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12", "quad_n10"]
+
+# The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
+# along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
+X_TOL = {"quad_n10": 5e-4}
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -66,9 +70,11 @@ def test_lm_iterates(oracle_mod, name):
         for s in range(g["solves"]):
             status, chi2, _ = p.solve(opts, new_run=(s == 0))
         ref = np.array(a["vertex"])[: p.dims.nv]
-        tol = 1e-11 if (a["k"] == 1 and g["solves"] == 1) else 2e-6
+        tol = 1e-11 if (a["k"] == 1 and g["solves"] == 1) else X_TOL.get(name, 2e-6)
         assert np.abs(p.x() - ref).max() <= tol, (name, a["k"])
         assert abs(chi2 - a["chi2"]) <= max(1e-12, (1e-12 if tol < 1e-9 else 2e-6) * abs(a["chi2"])), (name, a["k"])
+        if name in X_TOL and a["k"] > 1:
+            assert abs(chi2 - a["chi2"]) <= 1e-8 * abs(a["chi2"]), (name, a["k"])
         assert status in (capi.SOLVER_CONVERGED, capi.SOLVER_EARLY_TERMINATED)
 
 
