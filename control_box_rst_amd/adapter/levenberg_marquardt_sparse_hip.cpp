@@ -87,12 +87,17 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     const int N = ((int)vtx.size() - 5) / 2 + 1;
     VertexInterface* xf_v = vtx[2 * (N - 1)];
     VertexInterface* dt_v = vtx[2 * (N - 1) + 1];
+    // FullDiscretizationGridBase lists all states, then all controls; ShootingGridBase (shooting_grid_base.cpp:567-581) interleaves
+    // them interval by interval: s_0, u_0, s_1, u_1, ...
+    const bool interleaved = (_desc.grid == CORBO_HIP_GRID_MS);
+    auto xv = [&](int k) { return interleaved ? vtx[2 * k] : vtx[k]; };
+    auto uv = [&](int k) { return interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; };
 
     if (new_structure || !_handle || _desc.N != N)
     {
         // describe the structure, then verify it against what the graph reports
         for (int k = 0; k < N - 1; ++k)
-            if (vtx[k]->getDimension() != nx || vtx[N - 1 + k]->getDimension() != nu)
+            if (xv(k)->getDimension() != nx || uv(k)->getDimension() != nu)
             {
                 PRINT_ERROR("LevenbergMarquardtSparseHip(): vertex dimensions do not match the device model (nx, nu).");
                 return SolverStatus::Error;
@@ -109,9 +114,9 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         }
         if (dt_free) { _desc.dt_lb = dt_v->getLowerBounds()[0]; _desc.dt_ub = dt_v->getUpperBounds()[0]; }
         // bound pattern: shared along the horizon in the reference (NlpFunctions::x_lb ...), read from x_1 / u_0 / x_f
-        VertexInterface* xb = (N > 2) ? vtx[1] : xf_v;
+        VertexInterface* xb = (N > 2) ? xv(1) : xf_v;
         for (int i = 0; i < nx; ++i) { _desc.x_lb[i] = xb->getLowerBounds()[i]; _desc.x_ub[i] = xb->getUpperBounds()[i]; }
-        for (int i = 0; i < nu; ++i) { _desc.u_lb[i] = vtx[N - 1]->getLowerBounds()[i]; _desc.u_ub[i] = vtx[N - 1]->getUpperBounds()[i]; }
+        for (int i = 0; i < nu; ++i) { _desc.u_lb[i] = uv(0)->getLowerBounds()[i]; _desc.u_ub[i] = uv(0)->getUpperBounds()[i]; }
         _desc.dt_ref = dt_v->getData()[0];
         if (corbo_hip_get_dims(&_desc, &_dims) != CORBO_HIP_OK)
         {
@@ -146,7 +151,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         std::memcpy(&_lb[off], v->getLowerBounds(), dim * sizeof(double));
         std::memcpy(&_ub[off], v->getUpperBounds(), dim * sizeof(double));
     };
-    for (int k = 0; k < N - 1; ++k) { pack(vtx[k], k * s, nx); pack(vtx[N - 1 + k], k * s + nx, nu); }
+    for (int k = 0; k < N - 1; ++k) { pack(xv(k), k * s, nx); pack(uv(k), k * s + nx, nu); }
     pack(xf_v, (N - 1) * s, nx);
     if (dt_free) pack(dt_v, (N - 1) * s + nx, 1);
 
@@ -175,7 +180,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         for (int i = 0; i < dim; ++i)
             if (!v->isFixedComponent(i)) v->setData(i, _x[off + i]);
     };
-    for (int k = 0; k < N - 1; ++k) { unpack(vtx[k], k * s, nx); unpack(vtx[N - 1 + k], k * s + nx, nu); }
+    for (int k = 0; k < N - 1; ++k) { unpack(xv(k), k * s, nx); unpack(uv(k), k * s + nx, nu); }
     unpack(xf_v, (N - 1) * s, nx);
     if (dt_free) unpack(dt_v, (N - 1) * s + nx, 1);
 

@@ -21,10 +21,11 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     g.build()
     p = subprocess.run([DEMO], capture_output=True, text=True, timeout=300)
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 2, (p.stdout, p.stderr)
+    assert len(lines) == 3, (p.stdout, p.stderr)
     for r in lines:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, r
-        # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests
-        assert r["max_abs_diff"] <= 5e-6, r
+        # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
+        # cfg 5 family (quadrotor, multiple shooting, N=30): flat directions, chi2 carries the comparison
+        assert r["max_abs_diff"] <= (5e-3 if r["scenario"] == "quad" else 5e-6), r
         assert abs(r["chi2_hip"] - r["chi2_reference"]) <= 2e-6 * max(1.0, abs(r["chi2_reference"])), r
     assert p.returncode == 0
