@@ -67,7 +67,8 @@ def default_lm_opts(iterations=10, w_eq=2.0, w_ineq=2.0, w_bounds=2.0) -> LmOpts
     return LmOpts(iterations, w_eq, w_ineq, w_bounds, 1.0, 1.0, 1.0, 500.0, 500.0, 500.0)
 
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcorbo_hip.so")
+# CORBO_HIP_LIB: A/B measurements of two builds of the same C-ABI in one GPU session (development only)
+_LIB_PATH = os.environ.get("CORBO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcorbo_hip.so")
 _lib = None
 
 # every symbol include/corbo_hip.h declares

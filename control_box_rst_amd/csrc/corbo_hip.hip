@@ -79,7 +79,6 @@ struct corbo_hip_solver {
     double w_eq = 2, w_ineq = 2, w_b = 2;  // current penalty weights (levenberg_marquardt_sparse.h:126-128)
     corbo_hip_stats stats{};
     bool profile = false;
-    bool persistent = false;    // CORBO_HIP_PERSISTENT=1: whole solve in one launch (measured slower, kept for experiments)
     bool force_split = false;   // descriptor family without a fused pass kernel
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
 
@@ -228,8 +227,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     const char* prof = std::getenv("CORBO_HIP_PROFILE");
     h->profile       = prof && prof[0] == '1';
     h->split_passes  = h->profile;
-    const char* pers = std::getenv("CORBO_HIP_PERSISTENT");
-    h->persistent    = pers && pers[0] == '1';
+
     *out             = h;
     return CORBO_HIP_OK;
 }
@@ -330,16 +328,28 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, MAX_PASSES * sizeof(int32_t), h->stream));
     stamp();
-    int rc = launch_sweep_checked(h, h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr));
-    if (rc) return rc;
-    stamp();
+    const bool split = h->split_passes || h->force_split;
     const FactorParams fp = h->factor_params();
-    int pass = 0;
+    int rc = 0;
+    int pass = 0;  // launches after the prologue
     int remaining = (o->iterations > 0) ? h->batch : 0;
+    // Launch structure.  Fused (default): every launch is [sweep phase -> factor phase] per instance; the first one runs the
+    // prologue sweep (mode 2), the following ones the trial-step sweep (mode 3); an instance that finishes in its sweep phase
+    // skips the factor phase.  Split (diagnostics / big-block family): the same phases as separate launches.
+    if (split) {
+        rc = launch_sweep_checked(h, h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr));
+        if (rc) return rc;
+        stamp();
+    }
+    else {
+        if (!launch_pass(h->S.desc, fp, h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr), h->stream))
+            return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+        HIP_TRY(hipGetLastError());
+    }
     auto enqueue_passes = [&](int count) -> int {
         for (int c = 0; c < count && pass < MAX_PASSES; ++c, ++pass) {
             const SweepParams sp = h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass);
-            if (h->split_passes || h->force_split) {  // the two phases as separate launches (diagnostics / big-block family)
+            if (split) {
                 int r = launch_factor_checked(h, fp);
                 if (r) return r;
                 stamp();
@@ -348,25 +358,15 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
                 stamp();
             }
             else {
-                if (!launch_pass(h->S.desc, fp, sp, 1, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+                if (!launch_pass(h->S.desc, fp, sp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
                 HIP_TRY(hipGetLastError());
             }
         }
         return 0;
     };
-    if (remaining > 0 && h->persistent) {
-        // PERSISTENT variant (CORBO_HIP_PERSISTENT=1): one launch runs every instance's whole LM loop.  Measured SLOWER than
-        // one launch per pass on the headline batch (1.45 vs 1.25 ms): a workgroup stays pinned to its CU for all its passes,
-        // whereas relaunching per pass spreads the few instances still active in the tail passes over the whole chip.
-        const SweepParams sp = h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr);
-        if (!launch_pass(h->S.desc, fp, sp, MAX_PASSES, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
-        HIP_TRY(hipGetLastError());
-        remaining = 0;
-    }
-    else if (remaining > 0) {
-        // One fused launch per inner pass (or, with corbo_hip_set_profiling, factor and sweep as separate launches).  Every
-        // instance needs at least `iterations` passes; after that the host reads one "unfinished instances" counter per group of
-        // passes, always with the NEXT group already enqueued, so the GPU never waits for the host; finished instances make
+    if (remaining > 0) {
+        // Every instance needs at least `iterations` passes; after that the host reads one "unfinished instances" counter per group
+        // of passes, always with the NEXT group already enqueued, so the GPU never waits for the host; finished instances make
         // their workgroups exit at once, so an overshooting group costs a few microseconds.
         rc = enqueue_passes(o->iterations);
         if (rc) return rc;
@@ -551,7 +551,7 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
     if (timeline8) {
         long long* d_tl = nullptr;
         HIP_TRY(hipMalloc((void**)&d_tl, 8 * sizeof(long long)));
-        HIP_TRY(hipMemset(d_tl, 0, 8 * sizeof(long long)));
+        HIP_TRY(hipMemsetAsync(d_tl, 0, 8 * sizeof(long long), h->stream));
         fp.timeline = d_tl;
         rc = launch_factor_checked(h, fp);
         if (rc) { (void)hipFree(d_tl); return rc; }

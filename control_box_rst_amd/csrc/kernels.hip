@@ -58,8 +58,8 @@ __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double
 #pragma clang fp contract(off)
 
 // LDS operands: xs [nvs] vertex values of this instance, red [10] reduction scratch + 4 int flags, cs [N*NC] per-grid-state
-// dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: called right after factor_body in the same workgroup -- the trial iterate is already in xs and
-// the pass flags (no_trial, vbuf) are in the flag words.
+// dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: a factor phase follows in the same workgroup and takes the Jacobian
+// straight from jst when this phase refreshed it (flag word [0]).
 template <int DYN, int DEFECT, bool FUSED>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
 {
@@ -80,9 +80,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
     if (p.mode == 3) {
-        int done, no_trial, vbuf;
-        if constexpr (FUSED) { done = 0; no_trial = flags[2]; vbuf = flags[3]; }
-        else { done = st->done; no_trial = st->no_trial; vbuf = st->vbuf; }
+        const int done = st->done, no_trial = st->no_trial, vbuf = st->vbuf;
         __syncthreads();  // everybody has read the state before lane 0 may change it
         if (done) return;
         if (no_trial) {  // |delta| <= eps2 -> stop = true, the do-while ends without a trial step (:151-154,215)
@@ -98,9 +96,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
     }
 
     // ---- stage vertex values in LDS (coalesced 16-byte loads)
-    if constexpr (!FUSED)
-        for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
-            reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
+    for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+        reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
     double xr[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
@@ -604,9 +601,10 @@ struct FactorLds {
     __host__ __device__ static constexpr int total(int NP, bool arrow) { return off_red(NP) + RED + (arrow ? (NU + NX) * NP : 0); }
 };
 
-// xs_out (LDS, may be null): also receives the trial iterate; flags_out (LDS ints, may be null): [2] = no_trial, [3] = vbuf
+// j_in_lds: the Jacobian values of this instance already sit in smem[0, nnz_pad) (left there by the sweep phase of the same
+// workgroup); otherwise they are staged from HBM first.
 template <int NX, int NU, int THREADS, bool ARROW>
-__device__ __forceinline__ void factor_body(const FactorParams& p, double* smem, const int inst, const int tid, double* xs_out, int* flags_out)
+__device__ __forceinline__ void factor_body(const FactorParams& p, double* smem, const int inst, const int tid, const bool j_in_lds)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
@@ -640,94 +638,102 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
     const int k       = tid;
     const bool has_stage = (k < N - 1);
     const bool has_block = (k < N);
-    // ---- stage this instance's Jacobian values in LDS with 16-byte coalesced loads (the table-driven per-stage reads below
-    //      are 8-byte gathers with a 192-byte lane stride: from HBM/L2 they would request 16x the cache lines).  The staging
-    //      area is the whole LDS carve; it is dead before phase A writes its first array.
-    const double* J = smem;
+    // ---- load phase, organised so that every memory latency is paid once: (1) the static tables of this lane's stage (L2), (2) the
+    //      residual entries they point to (global; all loads issued back to back, indices clamped instead of branched), (3) the
+    //      Jacobian staging (coalesced 16-byte loads into LDS unless the sweep phase left it there), (4) the per-stage Jacobian
+    //      gathers from LDS.  Absent entries (offset -1: fixed component, no cost/bound row) are loaded from index 0 and zeroed.
+    constexpr int WL = S + NX + 1;  // local columns of the defect edge: x_k, u_k, x_{k+1}, dt
+    int sco[WL];
     {
+        const int ks = has_stage ? k : 0;
+#pragma unroll
+        for (int c = 0; c < WL; ++c) { const int o = p.stage_cols[ks].col[c]; sco[c] = has_stage ? o : -1; }
+    }
+    int cj[S], cr[S], bj[S], br[S], xfixed[NX];   // cost / bound row (Jacobian offset, residual row) per component of stage k
+    {
+        const int kb = has_block ? k : 0;
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const bool ok = (e < NX) ? has_block : has_stage;
+            const CompInfo ci = p.comp[(ok ? kb : 0) * S + e];
+            cj[e] = ok ? ci.cost_joff : -1; cr[e] = ci.cost_row; bj[e] = ok ? ci.bnd_joff : -1; br[e] = ci.bnd_row;
+            if (e < NX) xfixed[e] = ok ? ci.fixed : 1;
+        }
+    }
+    int iq_row = -1, iq[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) iq[i] = -1;
+    if (p.ineq_cols && has_stage) {
+        iq_row = p.ineq_rows[k];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) iq[i] = p.ineq_cols[k * NX + i];
+    }
+    // (2) residual entries
+    double r[NX], vc[S], vb[S], rin;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r[i] = val[has_stage ? p.eq_row0 + k * NX + i : 0];
+#pragma unroll
+    for (int e = 0; e < S; ++e) { vc[e] = val[cj[e] >= 0 ? cr[e] : 0]; vb[e] = val[bj[e] >= 0 ? br[e] : 0]; }
+    rin = val[iq_row >= 0 ? iq_row : 0];
+    if (iq_row < 0) rin = 0.0;
+    if (!has_stage) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) r[i] = 0.0;
+    }
+    // (3) Jacobian staging
+    const double* J = smem;
+    if (!j_in_lds) {
         const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
         double2* dst       = reinterpret_cast<double2*>(smem);
-        for (int i = tid; i < p.nnz_pad / 2; i += THREADS) dst[i] = src[i];
-        __syncthreads();
+        const int n2       = p.nnz_pad / 2;
+        constexpr int UNR  = 8;  // loads in flight per lane (branch-free: indices are clamped, the duplicates are harmless)
+        for (int i0 = tid; i0 < n2; i0 += THREADS * UNR) {
+            double2 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) { const int i = i0 + u * THREADS; v[u] = src[i < n2 ? i : n2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) { const int i = i0 + u * THREADS; dst[i < n2 ? i : n2 - 1] = v[u]; }
+        }
     }
-
-    // ---- load the local Jacobian of defect edge k: [A | B | C | d] and its residual
-    double A[NX][NX], B[NX][NU], Cc[NX][NX], dc[NX], r[NX];
+    __syncthreads();
+    // (4) per-stage gathers from the staging area
+    double A[NX][NX], B[NX][NU], Cc[NX][NX], dc[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+        const int oa = sco[c], oc = sco[S + c];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double va = J[(oa >= 0 ? oa : 0) + i], vcc = J[(oc >= 0 ? oc : 0) + i];
+            A[i][c]  = (oa >= 0) ? va : 0.0;
+            Cc[i][c] = (oc >= 0) ? vcc : 0.0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+        const int o = sco[NX + c];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { const double v = J[(o >= 0 ? o : 0) + i]; B[i][c] = (o >= 0) ? v : 0.0; }
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        r[i] = 0; dc[i] = 0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) { A[i][j] = 0; Cc[i][j] = 0; }
-#pragma unroll
-        for (int j = 0; j < NU; ++j) B[i][j] = 0;
-    }
-    if (has_stage) {
-        const StageCols sc = p.stage_cols[k];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-            const int o = sc.col[c];
-            if (o >= 0)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) A[i][c] = J[o + i];
-        }
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            const int o = sc.col[NX + c];
-            if (o >= 0)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) B[i][c] = J[o + i];
-        }
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-            const int o = sc.col[S + c];
-            if (o >= 0)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) Cc[i][c] = J[o + i];
-        }
-        if constexpr (ARROW) {
-            const int o = sc.col[S + NX];
-            if (o >= 0)
-#pragma unroll
-                for (int i = 0; i < NX; ++i) dc[i] = J[o + i];
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) r[i] = val[p.eq_row0 + k * NX + i];
+        dc[i] = 0.0;
+        if constexpr (ARROW) { const int o = sco[S + NX]; const double v = J[(o >= 0 ? o : 0) + i]; dc[i] = (o >= 0) ? v : 0.0; }
     }
     // diagonal (single-entry) rows of this lane's components: cost rows, bound rows
     double du_diag[NU], gu[NU], dx_diag[NX], gx[NX];
-    int xfixed[NX];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-        du_diag[j] = 0; gu[j] = 0;
-        if (has_stage) {
-            const CompInfo ci = p.comp[k * S + NX + j];
-            if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; du_diag[j] += a * a; gu[j] -= a * val[ci.cost_row]; }
-            if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; du_diag[j] += a * a; gu[j] -= a * val[ci.bnd_row]; }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        dx_diag[i] = 0; gx[i] = 0; xfixed[i] = 1;
-        if (has_block) {
-            const CompInfo ci = p.comp[k * S + i];
-            xfixed[i]         = ci.fixed;
-            if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; dx_diag[i] += a * a; gx[i] -= a * val[ci.cost_row]; }
-            if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; dx_diag[i] += a * a; gx[i] -= a * val[ci.bnd_row]; }
-        }
+    for (int e = 0; e < S; ++e) {
+        double ac = J[cj[e] >= 0 ? cj[e] : 0], ab = J[bj[e] >= 0 ? bj[e] : 0];
+        if (cj[e] < 0) ac = 0.0;
+        if (bj[e] < 0) ab = 0.0;
+        const double dd = ac * ac + ab * ab, gg = -(ac * vc[e]) - ab * vb[e];
+        if (e < NX) { dx_diag[e] = dd; gx[e] = gg; }
+        else { du_diag[e - NX] = dd; gu[e - NX] = gg; }
     }
     // stage inequality row on x_k: rank-1 contribution c c^T
     double cin[NX];
-    double rin = 0;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) cin[i] = 0;
-    if (p.ineq_cols && has_stage) {
-        rin = val[p.ineq_rows[k]];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int o = p.ineq_cols[k * NX + i];
-            if (o >= 0) cin[i] = J[o];
-        }
-    }
+    for (int i = 0; i < NX; ++i) { const double v = J[iq[i] >= 0 ? iq[i] : 0]; cin[i] = (iq[i] >= 0) ? v : 0.0; }
     // border (dt) scalars: this lane's share of H(dt,dt) and rhs(dt)
     double cdt = 0, gdt = 0;
     if constexpr (ARROW) {
@@ -877,14 +883,28 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
     STAMP(2);
     // ---- phase B + cyclic-reduction level 0: complete state block k; odd blocks are eliminated at once
     if (has_block) {
+        // the mailbox of block k (written by stage k-1; block 0 has none: fetched anyway, in one batch, and discarded)
+        double mg[NX], mb[NX], mD[NX][NX], Wa[NX][NX], Wb[NX][NX];
+        const bool has_mail = (k >= 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            mg[i] = SOA(gv, i, k);
+            mb[i] = ARROW ? SOA(bv, i, k) : 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                mD[i][j] = (j <= i) ? SOA(Dm, TRI(i, j), k) : 0.0;
+                Wa[i][j] = SOA(Wam, i * NX + j, k);               // H(k, k-1) from stage k-1
+                Wb[i][j] = (k + 1 < N) ? Ck[j][i] : 0.0;           // H(k, k+1) = H'(x_{k+1}, x_k)^T
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double g = gk[i] + gx[i] - cin[i] * rin, b = bk[i];
-            if (k >= 1) { g += SOA(gv, i, k); if constexpr (ARROW) b += SOA(bv, i, k); }
+            if (has_mail) { g += mg[i]; b += mb[i]; }
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
                 double d = Dk[i][j] + cin[i] * cin[j];
-                if (k >= 1) d += SOA(Dm, TRI(i, j), k);
+                if (has_mail) d += mD[i][j];
                 if (i == j) d += dx_diag[i] + mu_eff;
                 if (xfixed[i] || xfixed[j]) d = (i == j) ? 1.0 : 0.0;
                 Dk[i][j] = d;
@@ -893,14 +913,6 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
             gk[i] = g; bk[i] = b;
         }
         if (k & 1) {  // eliminate: neighbours a = k-1, b = k+1
-            double Wa[NX][NX], Wb[NX][NX];
-#pragma unroll
-            for (int q = 0; q < NX; ++q)
-#pragma unroll
-                for (int c = 0; c < NX; ++c) {
-                    Wa[q][c] = SOA(Wam, q * NX + c, k);            // H(k, k-1) from stage k-1
-                    Wb[q][c] = (k + 1 < N) ? Ck[c][q] : 0.0;        // H(k, k+1) = H'(x_{k+1}, x_k)^T
-                }
             chol_inv<NX>(Dk);
             fwd_solve<NX, NX>(Dk, Wa);
             fwd_solve<NX, NX>(Dk, Wb);
@@ -934,56 +946,55 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
         if (a < N) {
             const int hh = h >> 1;
             const int em = a - hh, ep = a + hh;
+            const bool has_m = (em >= 0), has_p = (ep < N);
+            const int emc = has_m ? em : a, epc = has_p ? ep : a;  // clamped: every LDS operand is fetched unconditionally, in one batch
+            const bool elim = (tid & 1);
             double D[NX][NX], g[NX], bb[NX], Ha[NX][NX], Hb[NX][NX];
+            double mWa[NX][NX], mWb[NX][NX], my[NX], mz[NX];  // factor data of the left neighbour  em (a is its b-side)
+            double pWa[NX][NX], pWb[NX][NX], py[NX], pz[NX];  // factor data of the right neighbour ep (a is its a-side)
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
                 g[q]  = SOA(gv, q, a);
+                my[q] = SOA(gv, q, emc);
+                py[q] = SOA(gv, q, epc);
                 bb[q] = ARROW ? SOA(bv, q, a) : 0.0;
+                mz[q] = ARROW ? SOA(bv, q, emc) : 0.0;
+                pz[q] = ARROW ? SOA(bv, q, epc) : 0.0;
 #pragma unroll
-                for (int c = 0; c < NX; ++c) { D[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), a) : 0.0; Ha[q][c] = 0; Hb[q][c] = 0; }
-            }
-            const bool elim = (tid & 1);
-            if (em >= 0) {  // a is the b-side of em
-                double Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
-#pragma unroll
-                for (int q = 0; q < NX; ++q) {
-                    y[q] = SOA(gv, q, em);
-                    z[q] = ARROW ? SOA(bv, q, em) : 0.0;
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) { Wb[q][c] = SOA(Wbm, q * NX + c, em); Wa[q][c] = elim ? SOA(Wam, q * NX + c, em) : 0.0; }
+                for (int c = 0; c < NX; ++c) {
+                    D[q][c]   = (c <= q) ? SOA(Dm, TRI(q, c), a) : 0.0;
+                    mWb[q][c] = SOA(Wbm, q * NX + c, emc);
+                    mWa[q][c] = SOA(Wam, q * NX + c, emc);
+                    pWa[q][c] = SOA(Wam, q * NX + c, epc);
+                    pWb[q][c] = SOA(Wbm, q * NX + c, epc);
+                    Ha[q][c] = 0; Hb[q][c] = 0;
                 }
+            }
+            if (has_m) {  // a is the b-side of em
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
 #pragma unroll
-                    for (int t = 0; t < NX; ++t) { g[q] -= Wb[t][q] * y[t]; if constexpr (ARROW) bb[q] -= Wb[t][q] * z[t]; }
+                    for (int t = 0; t < NX; ++t) { g[q] -= mWb[t][q] * my[t]; if constexpr (ARROW) bb[q] -= mWb[t][q] * mz[t]; }
 #pragma unroll
                     for (int c = 0; c < NX; ++c) {
                         double dd = 0, hx = 0;
 #pragma unroll
-                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += Wb[t][q] * Wb[t][c]; hx += Wb[t][q] * Wa[t][c]; }
+                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += mWb[t][q] * mWb[t][c]; hx += mWb[t][q] * mWa[t][c]; }
                         D[q][c] -= dd;
                         Ha[q][c] = -hx;  // H(a, a-h) = -W_b(em)^T W_a(em)
                     }
                 }
             }
-            if (ep < N) {  // a is the a-side of ep
-                double Wa[NX][NX], Wb[NX][NX], y[NX], z[NX];
-#pragma unroll
-                for (int q = 0; q < NX; ++q) {
-                    y[q] = SOA(gv, q, ep);
-                    z[q] = ARROW ? SOA(bv, q, ep) : 0.0;
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) { Wa[q][c] = SOA(Wam, q * NX + c, ep); Wb[q][c] = elim ? SOA(Wbm, q * NX + c, ep) : 0.0; }
-                }
+            if (has_p) {  // a is the a-side of ep
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
 #pragma unroll
-                    for (int t = 0; t < NX; ++t) { g[q] -= Wa[t][q] * y[t]; if constexpr (ARROW) bb[q] -= Wa[t][q] * z[t]; }
+                    for (int t = 0; t < NX; ++t) { g[q] -= pWa[t][q] * py[t]; if constexpr (ARROW) bb[q] -= pWa[t][q] * pz[t]; }
 #pragma unroll
                     for (int c = 0; c < NX; ++c) {
                         double dd = 0, hx = 0;
 #pragma unroll
-                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += Wa[t][q] * Wa[t][c]; hx += Wa[t][q] * Wb[t][c]; }
+                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += pWa[t][q] * pWa[t][c]; hx += pWa[t][q] * pWb[t][c]; }
                         D[q][c] -= dd;
                         Hb[q][c] = -hx;  // H(a, a+h) = -W_a(ep)^T W_b(ep)   (zero when a+h >= N: W_b(ep) = 0)
                     }
@@ -1088,14 +1099,15 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
             const int i = h * (2 * tid + 1);
             if (i < N) {
                 const int a = i - h, b = i + h;
+                const int bc = (b < N) ? b : a;  // W_b is zero when there is no right neighbour: any finite operand will do
+                double xa[NX], xb[NX];
+#pragma unroll
+                for (int c = 0; c < NX; ++c) { xa[c] = SOA(gv, c, a); xb[c] = SOA(gv, c, bc); }
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
                     double v = y[q];
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) {
-                        v -= Wa[q][c] * SOA(gv, c, a);
-                        if (b < N) v -= Wb[q][c] * SOA(gv, c, b);
-                    }
+                    for (int c = 0; c < NX; ++c) v -= Wa[q][c] * xa[c] + Wb[q][c] * xb[c];
                     y[q] = v;
                 }
                 bwd_solve_vec<NX>(L, y);
@@ -1116,8 +1128,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
         for (int q = 0; q < NX; ++q) {
             const double d = xfixed[q] ? 0.0 : SOA(gv, q, k);
             dn2 += d * d;
-            const double xn = xin[k * S + q] + d;
-            if (xs_out) xs_out[k * S + q] = xn; else xt[k * S + q] = xn;
+            xt[k * S + q] = xin[k * S + q] + d;
             if (dl) dl[k * S + q] = d;
         }
     }
@@ -1136,17 +1147,15 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
 #pragma unroll
         for (int a = 0; a < NU; ++a) {
             dn2 += y[a] * y[a];
-            const double un = xin[k * S + NX + a] + y[a];
-            if (xs_out) xs_out[k * S + NX + a] = un; else xt[k * S + NX + a] = un;
+            xt[k * S + NX + a] = xin[k * S + NX + a] + y[a];
             if (dl) dl[k * S + NX + a] = y[a];
         }
     }
     if (tid == 0) {
-        double* xo_ = xs_out ? xs_out : xt;
-        if (ARROW) { dn2 += ddt * ddt; xo_[p.off_dt] = xin[p.off_dt] + ddt; }
-        else xo_[p.off_dt] = xin[p.off_dt];
+        if (ARROW) { dn2 += ddt * ddt; xt[p.off_dt] = xin[p.off_dt] + ddt; }
+        else xt[p.off_dt] = xin[p.off_dt];
         if (dl) dl[p.off_dt] = ARROW ? ddt : 0.0;
-        if (p.off_dt + 1 < p.nvs) { xo_[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
+        if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
     }
     {
         double a0 = wave_sum(dn2);
@@ -1170,7 +1179,6 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
             else { no_trial = 0; st->den = mu * dn2 + y2; }                      // delta^T (mu delta + rhs), delta^T rhs = |y|^2
             st->stop     = stop;
             st->no_trial = no_trial;
-            if (flags_out) { flags_out[2] = no_trial; flags_out[3] = vbuf; }
         }
     }
     STAMP(7);
@@ -1180,7 +1188,7 @@ template <int NX, int NU, int THREADS, bool ARROW>
 __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x, threadIdx.x, nullptr, nullptr);
+    factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x, threadIdx.x, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1581,43 +1589,39 @@ __global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
     }
 }
 
-// The Levenberg-Marquardt loop of one instance per workgroup: [factor/solve -> trial-step sweep] repeated in the same
-// workgroup.  The trial iterate never leaves LDS; the Jacobian written by the sweep phase is read back by the next factor
-// phase of the same workgroup (L2-resident).  max_passes = 1: one inner pass per launch (host-driven, diagnostics);
-// max_passes large: PERSISTENT -- the whole solve of the instance in one launch, no host round trips, and instances that need
-// more inner passes (rejected steps) simply run longer without holding the others back.  While some workgroups are in the
-// latency-bound factor phase others are in the throughput-bound sweep phase, so the two overlap across the chip.
-template <int DYN, int DEFECT, bool ARROW, bool PERSIST>
-__global__ __launch_bounds__(SWEEP_THREADS, PERSIST ? 3 : 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp, const int max_passes)
+// One Levenberg-Marquardt pass of every unfinished instance in ONE launch:  [sweep phase -> factor phase]  per workgroup.
+//   sweep phase  : residual at the trial iterate, accept / reject, and on an accepted step the new Jacobian (mode 3); for the
+//                  first launch of a solve the prologue instead (mode 2: residual + Jacobian at the start iterate);
+//   factor phase : assemble, factor, solve -> next trial iterate.  When the sweep phase has just refreshed the Jacobian it is
+//                  still in the LDS staging area, so accepted steps never re-read it from HBM (it is still streamed out once,
+//                  for the passes that follow a rejected step).
+// While some workgroups are in the throughput-bound sweep phase others are in the latency-bound factor phase, so the two overlap
+// across the chip.  (A persistent variant that kept iterating inside one launch was measured slower -- workgroups stay pinned to
+// their CU, the tail passes are not rebalanced over the chip -- and was removed.)
+template <int DYN, int DEFECT, bool ARROW>
+__global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int inst = blockIdx.x, tid = threadIdx.x;
     const int NP = fp.N | 1;
-    // LDS map of the sweep phase inside the factor carve (all factor arrays are dead by then): Jacobian staging [0, nnz_pad),
-    // dynamics caches right behind it, reduction scratch = the factor phase's, trial iterate behind the factor carve.
+    // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, reduction
+    // scratch = the factor phase's, vertex values behind the factor carve.
     const int ftot = FL::total(NP, ARROW);
     double* red = smem + FL::off_red(NP);
     double* jst = smem;
     double* cs  = smem + sp.nnz_pad;
     double* xs  = smem + ((ftot > sp.nnz_pad + fp.N * Dy::NC ? ftot : sp.nnz_pad + fp.N * Dy::NC) + 1) / 2 * 2;
-    if constexpr (!PERSIST) {
-        if (fp.st[inst].done) return;
-        factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
-        __syncthreads();
-        sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, jst, inst, tid);
-    }
-    else {
-        for (int pass = 0; pass < max_passes; ++pass) {
-            if (fp.st[inst].done) break;  // uniform: written by lane 0 before the barrier below
-            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, xs, reinterpret_cast<int*>(red + 8));
-            __syncthreads();
-            sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, jst, inst, tid);
-            __threadfence_block();  // this workgroup's Jacobian / residual / state stores are visible to its next factor phase
-            __syncthreads();
-        }
-    }
+    int* flags  = reinterpret_cast<int*>(red + 8);
+    if (sp.mode == 3 && fp.st[inst].done) return;
+    if (tid == 0) flags[0] = 0;
+    __syncthreads();
+    sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, jst, inst, tid);
+    __threadfence_block();  // this workgroup's residual / iterate / state stores are visible to its factor phase
+    __syncthreads();
+    if (fp.st[inst].done) return;
+    factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, flags[0] != 0);
 }
 
 template <int DYN, int DEFECT>
@@ -1646,33 +1650,27 @@ size_t factor_lds(int N, bool arrow)
 }
 
 template <int DYN, int DEFECT>
-bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream)
+bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
     using Dy = Dynamics<DYN>;
     if (fp.N > SWEEP_THREADS) return false;
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
-    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs);                                  // + trial iterate
+    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs);                                  // + vertex values
     const dim3 g(fp.batch), b(SWEEP_THREADS);
-    if (max_passes > 1) {
-        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true>), g, b, lds, stream, fp, sp, max_passes);
-        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true>), g, b, lds, stream, fp, sp, max_passes);
-    }
-    else {
-        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, false>), g, b, lds, stream, fp, sp, max_passes);
-        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, false>), g, b, lds, stream, fp, sp, max_passes);
-    }
+    if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true>), g, b, lds, stream, fp, sp);
+    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false>), g, b, lds, stream, fp, sp);
     return true;
 }
 
 template <int DYN>
-bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream)
+bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
     switch (defect) {
-        case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, max_passes, stream);
-        case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, max_passes, stream);
-        case CORBO_HIP_DEFECT_MIDPOINT: return launch_pass_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(fp, sp, max_passes, stream);
-        case CORBO_HIP_DEFECT_CRANK_NICOLSON: return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, max_passes, stream);
+        case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_MIDPOINT: return launch_pass_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, stream);
         default: return false;
     }
 }
@@ -1733,14 +1731,14 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
     }
 }
 
-bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream)
+bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
     switch (d.dynamics) {
-        case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, max_passes, stream);
+        case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
             if (d.nx != 2) return false;
-            return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, max_passes, stream);
-        case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, max_passes, stream);
+            return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, stream);
         default: return false;
     }
 }

@@ -86,8 +86,8 @@ struct FactorParams {
 // returns false if the (dynamics, defect) pair has no device instantiation
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
-// fused LM passes (factor + trial-step sweep per workgroup); max_passes = 1: one inner pass, large: the whole solve (persistent)
-bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, int max_passes, hipStream_t stream);
+// one fused LM pass: [sweep phase (sp.mode 2 = prologue, 3 = trial step) -> factor phase] per workgroup, one launch
+bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
 // doubles of HBM workspace per instance the factor kernel needs (0 for the LDS-resident small-block kernel)

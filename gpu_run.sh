@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-./oracle/_ref/dropin_demo
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python tools/ab_streams.py
