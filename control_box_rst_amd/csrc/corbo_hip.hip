@@ -54,6 +54,13 @@ struct corbo_hip_solver {
     int batch  = 0;
     int device = 0;
     hipStream_t stream = nullptr;
+    // the LM passes of a solve run as `nsub` independent sub-batches on their own streams: their kernels interleave on the chip at
+    // different phases (latency-bound factor phase of one beside the throughput-bound sweep phase of the other)
+    static constexpr int MAX_SUB = 4;
+    int nsub = 1;
+    hipStream_t sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t sub_done[MAX_SUB]    = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t sub_chk[MAX_SUB][2]  = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_chk[2] = {nullptr, nullptr};
     // static tables
@@ -188,6 +195,20 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
+    {
+        const char* e = std::getenv("CORBO_HIP_SUBBATCHES");
+        int want = e ? std::atoi(e) : (batch >= 512 ? 2 : 1);
+        if (want < 1) want = 1;
+        if (want > corbo_hip_solver::MAX_SUB) want = corbo_hip_solver::MAX_SUB;
+        if (want > batch) want = batch;
+        h->nsub = want;
+        for (int i = 0; i < h->nsub; ++i) {
+            CREATE_TRY(hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
+            CREATE_TRY(hipEventCreateWithFlags(&h->sub_done[i], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&h->sub_chk[i][0], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&h->sub_chk[i][1], hipEventDisableTiming));
+        }
+    }
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[1], hipEventDisableTiming));
     if (upload(S.row_tasks, &h->d_row_tasks) || upload(S.col_tasks, &h->d_col_tasks) || upload(S.bound_tasks, &h->d_bound_tasks) ||
@@ -217,8 +238,8 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
         h->force_split = true;  // no fused pass kernel for the big-block family: factor and sweep are separate launches
     }
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_counters, MAX_PASSES * sizeof(int32_t)));
-    CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void**)&h->d_counters, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * corbo_hip_solver::MAX_SUB * sizeof(int32_t)));
     CREATE_TRY(hipMemset(h->d_state, 0, B * sizeof(LmState)));
     CREATE_TRY(hipMemset(h->d_values0, 0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_values1, 0, B * h->m_pad * sizeof(double)));
@@ -245,6 +266,11 @@ void corbo_hip_destroy(corbo_hip_handle h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->ev_chk) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < corbo_hip_solver::MAX_SUB; ++i) {
+        if (h->sub_done[i]) (void)hipEventDestroy(h->sub_done[i]);
+        for (hipEvent_t e : h->sub_chk[i]) if (e) (void)hipEventDestroy(e);
+        if (h->sub_stream[i]) { (void)hipStreamSynchronize(h->sub_stream[i]); (void)hipStreamDestroy(h->sub_stream[i]); }
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -326,63 +352,101 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
         evs.push_back(e);
     };
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, MAX_PASSES * sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t), h->stream));
     stamp();
     const bool split = h->split_passes || h->force_split;
-    const FactorParams fp = h->factor_params();
-    int rc = 0;
-    int pass = 0;  // launches after the prologue
-    int remaining = (o->iterations > 0) ? h->batch : 0;
     // Launch structure.  Fused (default): every launch is [sweep phase -> factor phase] per instance; the first one runs the
     // prologue sweep (mode 2), the following ones the trial-step sweep (mode 3); an instance that finishes in its sweep phase
-    // skips the factor phase.  Split (diagnostics / big-block family): the same phases as separate launches.
-    if (split) {
-        rc = launch_sweep_checked(h, h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr));
-        if (rc) return rc;
-        stamp();
+    // skips the factor phase.  Split (diagnostics / big-block family): the same phases as separate launches on one stream.
+    // The batch is cut into `nsub` contiguous sub-batches, each driven on its own stream.
+    const int nsub = split ? 1 : h->nsub;
+    int pass_of[corbo_hip_solver::MAX_SUB] = {0, 0, 0, 0};
+    int left_of[corbo_hip_solver::MAX_SUB] = {0, 0, 0, 0};
+    int first_of[corbo_hip_solver::MAX_SUB], count_of[corbo_hip_solver::MAX_SUB];
+    hipStream_t st_of[corbo_hip_solver::MAX_SUB];
+    {
+        const int base = h->batch / nsub, rem = h->batch % nsub;
+        int f = 0;
+        for (int i = 0; i < nsub; ++i) {
+            count_of[i] = base + (i < rem ? 1 : 0);
+            first_of[i] = f;
+            f += count_of[i];
+            st_of[i]   = (nsub == 1) ? h->stream : h->sub_stream[i];
+            left_of[i] = (o->iterations > 0) ? count_of[i] : 0;
+        }
+        if (nsub > 1) {
+            HIP_TRY(hipEventRecord(h->ev_chk[0], h->stream));  // the sub-streams start after everything queued on the main stream
+            for (int i = 0; i < nsub; ++i) HIP_TRY(hipStreamWaitEvent(st_of[i], h->ev_chk[0], 0));
+        }
     }
-    else {
-        if (!launch_pass(h->S.desc, fp, h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr), h->stream))
-            return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
-        HIP_TRY(hipGetLastError());
-    }
-    auto enqueue_passes = [&](int count) -> int {
-        for (int c = 0; c < count && pass < MAX_PASSES; ++c, ++pass) {
-            const SweepParams sp = h->sweep_params(3, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + pass);
-            if (split) {
-                int r = launch_factor_checked(h, fp);
-                if (r) return r;
-                stamp();
-                r = launch_sweep_checked(h, sp);
-                if (r) return r;
-                stamp();
-            }
-            else {
-                if (!launch_pass(h->S.desc, fp, sp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+    int rc = 0;
+    auto launch_one = [&](int i, int mode, int32_t* counter) -> int {
+        FactorParams fp = h->factor_params();
+        SweepParams sp  = h->sweep_params(mode, o->iterations, h->w_eq, h->w_ineq, h->w_b, counter);
+        fp.batch = sp.batch = count_of[i];
+        fp.inst0 = sp.inst0 = first_of[i];
+        if (split) {
+            if (mode == 3) {
+                if (!launch_factor(h->S.desc, fp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
                 HIP_TRY(hipGetLastError());
+                stamp();
             }
+            if (!launch_sweep(h->S.desc, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no sweep kernel for this dynamics/defect");
+            HIP_TRY(hipGetLastError());
+            stamp();
+        }
+        else {
+            if (!launch_pass(h->S.desc, fp, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+            HIP_TRY(hipGetLastError());
         }
         return 0;
     };
-    if (remaining > 0) {
-        // Every instance needs at least `iterations` passes; after that the host reads one "unfinished instances" counter per group
-        // of passes, always with the NEXT group already enqueued, so the GPU never waits for the host; finished instances make
-        // their workgroups exit at once, so an overshooting group costs a few microseconds.
-        rc = enqueue_passes(o->iterations);
+    for (int i = 0; i < nsub; ++i) {  // prologue
+        rc = launch_one(i, 2, nullptr);
         if (rc) return rc;
+    }
+    auto enqueue_pass = [&](int i) -> int {
+        if (pass_of[i] >= MAX_PASSES) return 0;
+        int r = launch_one(i, 3, h->d_counters + (size_t)i * MAX_PASSES + pass_of[i]);
+        ++pass_of[i];
+        return r;
+    };
+    if (o->iterations > 0) {
+        // Every instance needs at least `iterations` passes; after that the host reads one "unfinished instances" counter per group
+        // of passes and sub-batch, always with the NEXT group already enqueued, so the GPU never waits for the host; finished
+        // instances make their workgroups exit at once, so an overshooting group costs a few microseconds.
+        for (int p_ = 0; p_ < o->iterations; ++p_)
+            for (int i = 0; i < nsub; ++i) { rc = enqueue_pass(i); if (rc) return rc; }
         constexpr int GROUP = 2;
         int slot = 0;
-        while (pass < MAX_PASSES) {
-            HIP_TRY(hipMemcpyAsync(h->h_counter + slot, h->d_counters + (pass - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipEventRecord(h->ev_chk[slot], h->stream));
-            rc = enqueue_passes(GROUP);  // speculative
-            if (rc) return rc;
-            HIP_TRY(hipEventSynchronize(h->ev_chk[slot]));
-            remaining = h->h_counter[slot];
+        bool any = true;
+        while (any) {
+            for (int i = 0; i < nsub; ++i) {
+                if (left_of[i] == 0) continue;
+                HIP_TRY(hipMemcpyAsync(h->h_counter + 2 * i + slot, h->d_counters + (size_t)i * MAX_PASSES + (pass_of[i] - 1), sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, st_of[i]));
+                HIP_TRY(hipEventRecord(h->sub_chk[i][slot], st_of[i]));
+            }
+            for (int g = 0; g < GROUP; ++g)
+                for (int i = 0; i < nsub; ++i)
+                    if (left_of[i] != 0) { rc = enqueue_pass(i); if (rc) return rc; }  // speculative
+            any = false;
+            for (int i = 0; i < nsub; ++i) {
+                if (left_of[i] == 0) continue;
+                HIP_TRY(hipEventSynchronize(h->sub_chk[i][slot]));
+                left_of[i] = h->h_counter[2 * i + slot];
+                if (left_of[i] != 0 && pass_of[i] < MAX_PASSES) any = true;
+            }
             slot ^= 1;
-            if (remaining == 0) break;
         }
     }
+    int pass = 0, remaining = 0;
+    for (int i = 0; i < nsub; ++i) { if (pass_of[i] > pass) pass = pass_of[i]; remaining += left_of[i]; }
+    if (nsub > 1)
+        for (int i = 0; i < nsub; ++i) {  // the main stream continues after every sub-batch
+            HIP_TRY(hipEventRecord(h->sub_done[i], st_of[i]));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->sub_done[i], 0));
+        }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));

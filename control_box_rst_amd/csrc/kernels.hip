@@ -516,7 +516,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* red = smem + p.nvs;
     double* cs  = red + 10;
     double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
-    sweep_body<DYN, DEFECT, false>(p, xs, red, cs, jst, blockIdx.x, threadIdx.x);
+    sweep_body<DYN, DEFECT, false>(p, xs, red, cs, jst, blockIdx.x + p.inst0, threadIdx.x);
 }
 
 #pragma clang fp contract(fast)
@@ -1188,7 +1188,7 @@ template <int NX, int NU, int THREADS, bool ARROW>
 __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x, threadIdx.x, false);
+    factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x + p.inst0, threadIdx.x, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
     double* gn = sm + BL::GN;  double* xn = sm + BL::XN;  double* dg = sm + BL::DIAG; double* gd = sm + BL::GDIAG;
     double* cin = sm + BL::CIN; double* fx = sm + BL::FIX; double* red = sm + BL::RED;
 
-    const int inst = blockIdx.x, lane = threadIdx.x;
+    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
     LmState* st = p.st + inst;
     const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
     int stop = st->stop;
@@ -1604,7 +1604,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int inst = blockIdx.x, tid = threadIdx.x;
+    const int inst = blockIdx.x + fp.inst0, tid = threadIdx.x;
     const int NP = fp.N | 1;
     // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, reduction
     // scratch = the factor phase's, vertex values behind the factor carve.

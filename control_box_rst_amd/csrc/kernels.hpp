@@ -36,6 +36,7 @@ static_assert(sizeof(LmState) == 128, "LmState layout");
 struct SweepParams {
     // static structure
     int32_t batch, nvs, m, nnz, N, s, nx, off_dt, dt_free;
+    int32_t inst0;      // first instance of this launch (sub-batch launches); grid = batch
     int32_t n_row_tasks, n_col_tasks, n_bound_tasks;
     const RowTask* row_tasks;
     const ColTask* col_tasks;
@@ -65,6 +66,7 @@ struct SweepParams {
 
 struct FactorParams {
     int32_t batch, nvs, m, N, nx, nu, s, off_dt, dt_free;
+    int32_t inst0;                // first instance of this launch (sub-batch launches); grid = batch
     int32_t eq_row0;
     const StageCols* stage_cols;  // N-1
     const CompInfo* comp;         // nvs
