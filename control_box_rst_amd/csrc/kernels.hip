@@ -940,92 +940,95 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
     // ---- cyclic reduction, levels h = 2, 4, ...: lane t owns the active block a = h*t.  It first applies the Schur updates of
     //      the previous level (neighbours a -+ h/2 were eliminated there); odd t then eliminates a against a -+ h, whose
     //      couplings it forms on the fly from those same neighbours.  The first h >= N leaves block 0 alone: the root.
+    // Two lanes share a block: lane parity 0 gathers what the left neighbour (em) contributes and forms W_a, parity 1 does the same
+    // for the right neighbour (ep) and W_b; the partial Schur updates are exchanged with one cross-lane swap, the small Cholesky is
+    // done redundantly by both.
     int hroot = 2;
     for (int h = 2;; h <<= 1) {
-        const int a = h * tid;
-        if (a < N) {
-            const int hh = h >> 1;
-            const int em = a - hh, ep = a + hh;
-            const bool has_m = (em >= 0), has_p = (ep < N);
-            const int emc = has_m ? em : a, epc = has_p ? ep : a;  // clamped: every LDS operand is fetched unconditionally, in one batch
-            const bool elim = (tid & 1);
-            double D[NX][NX], g[NX], bb[NX], Ha[NX][NX], Hb[NX][NX];
-            double mWa[NX][NX], mWb[NX][NX], my[NX], mz[NX];  // factor data of the left neighbour  em (a is its b-side)
-            double pWa[NX][NX], pWb[NX][NX], py[NX], pz[NX];  // factor data of the right neighbour ep (a is its a-side)
+        const int a    = h * (tid >> 1);
+        const int side = tid & 1;
+        const bool act = (a < N);
+        const int ac   = act ? a : 0;
+        const int hh   = h >> 1;
+        const int e    = side ? ac + hh : ac - hh;               // the neighbour this lane works on
+        const bool has = act && (side ? (e < N) : (e >= 0));
+        const int ec   = has ? e : ac;                            // clamped: every LDS operand is fetched unconditionally, in one batch
+        const bool elim = ((tid >> 1) & 1);
+        const bool root = (h >= N);                              // only a == 0 is active then
+        double D[NX][NX], g[NX], bb[NX], Wx[NX][NX], Wy[NX][NX], ny[NX], nz[NX];
 #pragma unroll
-            for (int q = 0; q < NX; ++q) {
-                g[q]  = SOA(gv, q, a);
-                my[q] = SOA(gv, q, emc);
-                py[q] = SOA(gv, q, epc);
-                bb[q] = ARROW ? SOA(bv, q, a) : 0.0;
-                mz[q] = ARROW ? SOA(bv, q, emc) : 0.0;
-                pz[q] = ARROW ? SOA(bv, q, epc) : 0.0;
+        for (int q = 0; q < NX; ++q) {
+            g[q]  = SOA(gv, q, ac);
+            ny[q] = SOA(gv, q, ec);
+            bb[q] = ARROW ? SOA(bv, q, ac) : 0.0;
+            nz[q] = ARROW ? SOA(bv, q, ec) : 0.0;
 #pragma unroll
-                for (int c = 0; c < NX; ++c) {
-                    D[q][c]   = (c <= q) ? SOA(Dm, TRI(q, c), a) : 0.0;
-                    mWb[q][c] = SOA(Wbm, q * NX + c, emc);
-                    mWa[q][c] = SOA(Wam, q * NX + c, emc);
-                    pWa[q][c] = SOA(Wam, q * NX + c, epc);
-                    pWb[q][c] = SOA(Wbm, q * NX + c, epc);
-                    Ha[q][c] = 0; Hb[q][c] = 0;
-                }
+            for (int c = 0; c < NX; ++c) {
+                D[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), ac) : 0.0;
+                // Wx: the neighbour's factor block that couples it to a; Wy: the one that couples it to a's far neighbour
+                const double wa = SOA(Wam, q * NX + c, ec), wb = SOA(Wbm, q * NX + c, ec);
+                Wx[q][c] = side ? wa : wb;   // em: a is its b-side -> W_b(em) ; ep: a is its a-side -> W_a(ep)
+                Wy[q][c] = side ? wb : wa;
             }
-            if (has_m) {  // a is the b-side of em
+        }
+        // partial Schur update from this lane's neighbour
+        double dD[NX][NX], dg[NX], db[NX], Hs[NX][NX];
 #pragma unroll
-                for (int q = 0; q < NX; ++q) {
+        for (int q = 0; q < NX; ++q) {
+            double s1 = 0, s2 = 0;
 #pragma unroll
-                    for (int t = 0; t < NX; ++t) { g[q] -= mWb[t][q] * my[t]; if constexpr (ARROW) bb[q] -= mWb[t][q] * mz[t]; }
+            for (int t = 0; t < NX; ++t) { s1 += Wx[t][q] * ny[t]; if constexpr (ARROW) s2 += Wx[t][q] * nz[t]; }
+            dg[q] = has ? s1 : 0.0;
+            db[q] = has ? s2 : 0.0;
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) {
-                        double dd = 0, hx = 0;
+            for (int c = 0; c < NX; ++c) {
+                double dd = 0, hx = 0;
 #pragma unroll
-                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += mWb[t][q] * mWb[t][c]; hx += mWb[t][q] * mWa[t][c]; }
-                        D[q][c] -= dd;
-                        Ha[q][c] = -hx;  // H(a, a-h) = -W_b(em)^T W_a(em)
-                    }
-                }
+                for (int t = 0; t < NX; ++t) { if (c <= q) dd += Wx[t][q] * Wx[t][c]; hx += Wx[t][q] * Wy[t][c]; }
+                dD[q][c] = has ? dd : 0.0;
+                Hs[q][c] = has ? -hx : 0.0;   // side 0: H(a, a-h) = -W_b(em)^T W_a(em) ; side 1: H(a, a+h) = -W_a(ep)^T W_b(ep)
             }
-            if (has_p) {  // a is the a-side of ep
+        }
+        // combine with the partner lane (same block, other neighbour)
 #pragma unroll
-                for (int q = 0; q < NX; ++q) {
+        for (int q = 0; q < NX; ++q) {
+            g[q] -= dg[q] + __shfl_xor(dg[q], 1);
+            if constexpr (ARROW) bb[q] -= db[q] + __shfl_xor(db[q], 1);
 #pragma unroll
-                    for (int t = 0; t < NX; ++t) { g[q] -= pWa[t][q] * py[t]; if constexpr (ARROW) bb[q] -= pWa[t][q] * pz[t]; }
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) {
-                        double dd = 0, hx = 0;
-#pragma unroll
-                        for (int t = 0; t < NX; ++t) { if (c <= q) dd += pWa[t][q] * pWa[t][c]; hx += pWa[t][q] * pWb[t][c]; }
-                        D[q][c] -= dd;
-                        Hb[q][c] = -hx;  // H(a, a+h) = -W_a(ep)^T W_b(ep)   (zero when a+h >= N: W_b(ep) = 0)
-                    }
-                }
-            }
-            const bool root = (h >= N);  // only a == 0 is active then
+            for (int c = 0; c <= q; ++c) D[q][c] -= dD[q][c] + __shfl_xor(dD[q][c], 1);
+        }
+        if (act) {
             if (elim || root) {
                 chol_inv<NX>(D);
                 fwd_solve_vec<NX>(D, g);
                 if constexpr (ARROW) fwd_solve_vec<NX>(D, bb);
+                if (side == 0) {
 #pragma unroll
-                for (int q = 0; q < NX; ++q) {
-                    y2 += g[q] * g[q];
-                    if constexpr (ARROW) { zz += bb[q] * bb[q]; zy += bb[q] * g[q]; }
+                    for (int q = 0; q < NX; ++q) {
+                        y2 += g[q] * g[q];
+                        if constexpr (ARROW) { zz += bb[q] * bb[q]; zy += bb[q] * g[q]; }
+                    }
                 }
                 if (!root) {
-                    fwd_solve<NX, NX>(D, Ha);
-                    fwd_solve<NX, NX>(D, Hb);
+                    fwd_solve<NX, NX>(D, Hs);
 #pragma unroll
                     for (int q = 0; q < NX; ++q)
 #pragma unroll
-                        for (int c = 0; c < NX; ++c) { SOA(Wam, q * NX + c, a) = Ha[q][c]; SOA(Wbm, q * NX + c, a) = Hb[q][c]; }
+                        for (int c = 0; c < NX; ++c) {
+                            if (side == 0) SOA(Wam, q * NX + c, a) = Hs[q][c];
+                            else SOA(Wbm, q * NX + c, a) = Hs[q][c];
+                        }
                 }
                 else if constexpr (!ARROW) bwd_solve_vec<NX>(D, g);  // no border: the root is back-substituted right away
             }
+            if (side == 0) {
 #pragma unroll
-            for (int q = 0; q < NX; ++q) {
-                SOA(gv, q, a) = g[q];
-                if constexpr (ARROW) SOA(bv, q, a) = bb[q];
+                for (int q = 0; q < NX; ++q) {
+                    SOA(gv, q, a) = g[q];
+                    if constexpr (ARROW) SOA(bv, q, a) = bb[q];
 #pragma unroll
-                for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
+                    for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
+                }
             }
         }
         hroot = h;
