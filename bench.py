@@ -58,7 +58,7 @@ def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
     # --- genuine reference, 1 thread
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(drv) and os.access(drv, os.X_OK):
-        n_ref = 64
+        n_ref = min(len(x0), 512)  # ~15 s of reference CPU work
         with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
             np.savetxt(f, np.hstack([x0[:n_ref], xf[:n_ref]]), fmt="%.17g")
             path = f.name

@@ -88,6 +88,7 @@ struct corbo_hip_solver {
     bool profile = false;
     bool force_split = false;   // descriptor family without a fused pass kernel
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
+    bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
     SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
     {
@@ -248,6 +249,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     const char* prof = std::getenv("CORBO_HIP_PROFILE");
     h->profile       = prof && prof[0] == '1';
     h->split_passes  = h->profile;
+    { const char* e = std::getenv("CORBO_HIP_LOOP"); h->loop_mode = !(e && e[0] == '0'); }
 
     *out             = h;
     return CORBO_HIP_OK;
@@ -355,11 +357,14 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t), h->stream));
     stamp();
     const bool split = h->split_passes || h->force_split;
-    // Launch structure.  Fused (default): every launch is [sweep phase -> factor phase] per instance; the first one runs the
+    // Launch structure.  Run-to-completion (default): ONE launch, every workgroup walks its instance through the prologue sweep
+    // and [factor phase -> trial sweep phase] passes until the instance has finished (the instances are independent, nothing has to
+    // meet at a grid-wide point).  Per-pass (CORBO_HIP_LOOP=0): every launch is [sweep phase -> factor phase] per instance; the first one runs the
     // prologue sweep (mode 2), the following ones the trial-step sweep (mode 3); an instance that finishes in its sweep phase
     // skips the factor phase.  Split (diagnostics / big-block family): the same phases as separate launches on one stream.
     // The batch is cut into `nsub` contiguous sub-batches, each driven on its own stream.
-    const int nsub = split ? 1 : h->nsub;
+    const bool run_to_completion = !split && h->loop_mode && o->iterations > 0;
+    const int nsub = (split || run_to_completion) ? 1 : h->nsub;
     int pass_of[corbo_hip_solver::MAX_SUB] = {0, 0, 0, 0};
     int left_of[corbo_hip_solver::MAX_SUB] = {0, 0, 0, 0};
     int first_of[corbo_hip_solver::MAX_SUB], count_of[corbo_hip_solver::MAX_SUB];
@@ -401,6 +406,25 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
         }
         return 0;
     };
+    if (run_to_completion) {
+        // one launch per sub-batch walks every instance through the prologue and all of its LM passes
+        for (int i = 0; i < nsub; ++i) {
+            FactorParams fp = h->factor_params();
+            SweepParams sp  = h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, h->d_counters + (size_t)i * MAX_PASSES);
+            fp.batch = sp.batch = count_of[i];
+            fp.inst0 = sp.inst0 = first_of[i];
+            fp.loop_passes = MAX_PASSES;
+            if (!launch_pass(h->S.desc, fp, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h->h_counter + 2 * i, h->d_counters + (size_t)i * MAX_PASSES, sizeof(int32_t), hipMemcpyDeviceToHost, st_of[i]));
+            pass_of[i] = 1;
+        }
+        for (int i = 0; i < nsub; ++i) {
+            HIP_TRY(hipStreamSynchronize(st_of[i]));
+            left_of[i] = h->h_counter[2 * i];
+        }
+    }
+    else
     for (int i = 0; i < nsub; ++i) {  // prologue
         rc = launch_one(i, 2, nullptr);
         if (rc) return rc;
@@ -411,7 +435,7 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
         ++pass_of[i];
         return r;
     };
-    if (o->iterations > 0) {
+    if (o->iterations > 0 && !run_to_completion) {
         // Every instance needs at least `iterations` passes; after that the host reads one "unfinished instances" counter per group
         // of passes and sub-batch, always with the NEXT group already enqueued, so the GPU never waits for the host; finished
         // instances make their workgroups exit at once, so an overshooting group costs a few microseconds.

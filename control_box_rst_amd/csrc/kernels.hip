@@ -61,7 +61,7 @@ __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double
 // dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: a factor phase follows in the same workgroup and takes the Jacobian
 // straight from jst when this phase refreshed it (flag word [0]).
 template <int DYN, int DEFECT, bool FUSED>
-__device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
+__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
 
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
-    if (p.mode == 3) {
+    if (mode == 3) {
         const int done = st->done, no_trial = st->no_trial, vbuf = st->vbuf;
         __syncthreads();  // everybody has read the state before lane 0 may change it
         if (done) return;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
             if (tid == 0) {
                 const bool fin = lm_end_outer(st, st->last_sq, st->rho, st->k, p.iterations);
                 if (p.chi2) p.chi2[inst] = st->chi2_old;
-                if (!fin && p.active_count) atomicAdd(p.active_count, 1);
+                if (!fin && active_count) atomicAdd(active_count, 1);
             }
             return;
         }
@@ -202,15 +202,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
     }
 
     // ---- chi2 = |values|^2 and the LM trial-step decision
-    int do_jac = (p.mode == 1 || p.mode == 2) ? 1 : 0;
-    if (p.mode >= 2) {
+    int do_jac = (mode == 1 || mode == 2) ? 1 : 0;
+    if (mode >= 2) {
         double ws = wave_sum(sq_acc);
         if ((tid & 63) == 0) red[tid >> 6] = ws;
         __syncthreads();
         if (tid == 0) {
             const double chi2 = red[0] + red[1] + red[2] + red[3];
             bool fin = false;
-            if (p.mode == 2) {  // solve() prologue (:89-127)
+            if (mode == 2) {  // solve() prologue (:89-127)
                 st->mu = 0; st->mu_acc = 0; st->rho = 0; st->chi2_old = chi2; st->last_sq = chi2; st->den = 0; st->dnorm = 0;
                 st->v = 2; st->k = 0; st->stop = 0; st->fresh = 1; st->first = 1; st->no_trial = 0;
                 st->status = CORBO_HIP_SOLVER_CONVERGED;  // iterations == 0: (stop || rho <= 0) with rho = 0
@@ -262,11 +262,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, double* xs, dou
                 flags[0] = refresh;
                 flags[1] = accept;
             }
-            if (!fin && p.active_count) atomicAdd(p.active_count, 1);
+            if (!fin && active_count) atomicAdd(active_count, 1);
         }
         __syncthreads();
         do_jac = flags[0];
-        if (p.mode == 3 && flags[1]) {  // accepted: the trial iterate becomes the iterate (discardBackupParameters :176)
+        if (mode == 3 && flags[1]) {  // accepted: the trial iterate becomes the iterate (discardBackupParameters :176)
             double* xdst = p.x + xo;
             for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
                 reinterpret_cast<double2*>(xdst)[i] = reinterpret_cast<const double2*>(xs)[i];
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* red = smem + p.nvs;
     double* cs  = red + 10;
     double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
-    sweep_body<DYN, DEFECT, false>(p, xs, red, cs, jst, blockIdx.x + p.inst0, threadIdx.x);
+    sweep_body<DYN, DEFECT, false>(p, p.mode, p.active_count, xs, red, cs, jst, blockIdx.x + p.inst0, threadIdx.x);
 }
 
 #pragma clang fp contract(fast)
@@ -1599,9 +1599,13 @@ __global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
 //                  still in the LDS staging area, so accepted steps never re-read it from HBM (it is still streamed out once,
 //                  for the passes that follow a rejected step).
 // While some workgroups are in the throughput-bound sweep phase others are in the latency-bound factor phase, so the two overlap
-// across the chip.  (A persistent variant that kept iterating inside one launch was measured slower -- workgroups stay pinned to
-// their CU, the tail passes are not rebalanced over the chip -- and was removed.)
-template <int DYN, int DEFECT, bool ARROW>
+// across the chip.
+// LOOP = run-to-completion (default of corbo_hip_solve): the workgroup repeats the pass until its instance has finished, one
+// launch per solve -- the instances are independent, so there is no grid-wide meeting point, no launch gap between passes, and
+// the slow instances of the tail run at single-instance latency (0.81 ms instead of 1.09 ms per headline solve).  The loop needs
+// two precautions against the compiler carrying state around it: the kernel arguments are re-read from the kernarg segment each
+// pass, and the library is built with -disable-machine-licm (hoisted math-library constants were spilled to scratch otherwise).
+template <int DYN, int DEFECT, bool ARROW, bool LOOP>
 __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
@@ -1617,14 +1621,46 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
     double* cs  = smem + sp.nnz_pad;
     double* xs  = smem + ((ftot > sp.nnz_pad + fp.N * Dy::NC ? ftot : sp.nnz_pad + fp.N * Dy::NC) + 1) / 2 * 2;
     int* flags  = reinterpret_cast<int*>(red + 8);
-    if (sp.mode == 3 && fp.st[inst].done) return;
-    if (tid == 0) flags[0] = 0;
-    __syncthreads();
-    sweep_body<DYN, DEFECT, true>(sp, xs, red, cs, jst, inst, tid);
-    __threadfence_block();  // this workgroup's residual / iterate / state stores are visible to its factor phase
-    __syncthreads();
-    if (fp.st[inst].done) return;
-    factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, flags[0] != 0);
+    if constexpr (!LOOP) {
+        if (sp.mode == 3 && fp.st[inst].done) return;
+        if (tid == 0) flags[0] = 0;
+        __syncthreads();
+        sweep_body<DYN, DEFECT, true>(sp, sp.mode, sp.active_count, xs, red, cs, jst, inst, tid);
+        __threadfence_block();  // this workgroup's residual / iterate / state stores are visible to its factor phase
+        __syncthreads();
+        if (fp.st[inst].done) return;
+        factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, flags[0] != 0);
+    }
+    else {
+        // run-to-completion: the instances are independent, so the workgroup walks its instance through the prologue and every LM
+        // pass without leaving the chip (no launch gaps, workgroups drift apart so that latency-bound factor phases overlap
+        // throughput-bound sweep phases of their neighbours).
+        int mode = sp.mode;
+        int inst_v = inst, tid_v = tid;
+        // the kernel arguments are re-read from the kernarg segment in every pass (scalar loads) instead of being kept live in
+        // ~200 SGPRs around the loop
+        struct Args { FactorParams f; SweepParams s; };
+        typedef const __attribute__((address_space(4))) Args* ArgsPtr;
+        ArgsPtr ka = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        const int max_passes = fp.loop_passes;
+#pragma nounroll
+        for (int pass = 0; pass <= max_passes; ++pass) {
+            asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");  // nothing derived from them is carried around the loop
+            const FactorParams& fpl = (const FactorParams&)ka->f;
+            const SweepParams& spl  = (const SweepParams&)ka->s;
+            if (tid_v == 0) flags[0] = 0;
+            __syncthreads();
+            sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, xs, red, cs, jst, inst_v, tid_v);
+            __threadfence_block();
+            __syncthreads();
+            if (fpl.st[inst_v].done) break;
+            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fpl, smem, inst_v, tid_v, flags[0] != 0);
+            __threadfence_block();
+            __syncthreads();
+            mode = 3;
+        }
+        if (tid_v == 0 && !fp.st[inst_v].done && sp.active_count) atomicAdd(sp.active_count, 1);  // pass limit hit
+    }
 }
 
 template <int DYN, int DEFECT>
@@ -1661,8 +1697,12 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
     const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs);                                  // + vertex values
     const dim3 g(fp.batch), b(SWEEP_THREADS);
-    if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true>), g, b, lds, stream, fp, sp);
-    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false>), g, b, lds, stream, fp, sp);
+    if (fp.loop_passes > 0) {
+        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true>), g, b, lds, stream, fp, sp);
+        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true>), g, b, lds, stream, fp, sp);
+    }
+    else if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, false>), g, b, lds, stream, fp, sp);
+    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, false>), g, b, lds, stream, fp, sp);
     return true;
 }
 

@@ -83,6 +83,7 @@ struct FactorParams {
     long long* timeline;          // optional [8] shader-clock stamps of workgroup 0 (diagnostics), may be null
     double* work;                 // big-block kernel only: per-instance factor workspace in HBM
     int64_t work_stride;          // doubles per instance
+    int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
 };
 
 // returns false if the (dynamics, defect) pair has no device instantiation

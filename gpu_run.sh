@@ -1,13 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python - <<PY
-import sys; sys.path.insert(0,'.')
-from control_box_rst_amd import problems
-from control_box_rst_amd.solver import BatchedLevenbergMarquardt
-d=problems.unicycle_desc()
-for B in (1,1,1024):
-    x0,xf=problems.unicycle_instances(B)
-    s=BatchedLevenbergMarquardt(d,B); s.setPenaltyWeights(10,10,10)
-    s.set_instance_data(s.init_trajectory(x0,xf), xref=xf)
-    ms, tl = s.time_factor(repeat=10, timeline=True)
-    print(f"B={B}: CR {tl[4]-tl[3]}  level h=4: loads {tl[9]-tl[8]} partial {tl[10]-tl[9]} shfl {tl[11]-tl[10]} chol(tid2) {tl[12]-tl[11]} rest {tl[13]-tl[11]} barrier {tl[14]-tl[13]} whole-level {tl[14]-tl[8]}")
-PY
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_loop.json
