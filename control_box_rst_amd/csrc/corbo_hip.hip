@@ -94,6 +94,7 @@ struct corbo_hip_solver {
     {
         SweepParams p{};
         p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
         p.n_row_tasks = (int)S.row_tasks.size(); p.n_col_tasks = (int)S.col_tasks.size(); p.n_bound_tasks = (int)S.bound_tasks.size();
         p.row_tasks = d_row_tasks; p.col_tasks = d_col_tasks; p.bound_tasks = d_bound_tasks;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
@@ -597,7 +598,14 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     HIP_TRY(hipSetDevice(h->device));
-    const SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
+    SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
+    long long* d_tl = nullptr;  // CORBO_HIP_SWEEP_TIMELINE=1: shader-clock stamps of the phases of instance 0 on stderr (diagnostics)
+    const char* tl_env = std::getenv("CORBO_HIP_SWEEP_TIMELINE");
+    if (tl_env && tl_env[0] == '1') {
+        HIP_TRY(hipMalloc((void**)&d_tl, 16 * sizeof(long long)));
+        HIP_TRY(hipMemset(d_tl, 0, 16 * sizeof(long long)));
+    }
+    p.timeline = d_tl;
     int rc = launch_sweep_checked(h, p);  // warm-up
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -610,6 +618,14 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_per_launch = ms / repeat;
+    if (d_tl) {
+        long long tl[16];
+        HIP_TRY(hipMemcpy(tl, d_tl, sizeof(tl), hipMemcpyDeviceToHost));
+        fprintf(stderr, "sweep phases of instance 0 (cycles): stage-x %lld | caches %lld | residual %lld | decision %lld | defect-J %lld | rest-J %lld | barrier %lld | stream-out %lld | total %lld\n",
+                tl[1] - tl[0], tl[2] - tl[1], tl[3] - tl[2], tl[4] - tl[3], tl[5] - tl[4], tl[6] - tl[5], tl[7] - tl[6], tl[8] - tl[7], tl[8] - tl[0]);
+        fprintf(stderr, "   residual detail: components %lld | stages %lld\n", tl[9] - tl[2], tl[3] - tl[9]);
+        (void)hipFree(d_tl);
+    }
     return CORBO_HIP_OK;
 }
 

@@ -57,6 +57,11 @@ __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double
 // ---------------------------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 
+#define SWEEP_STAMP(id)                                                     \
+    do {                                                                    \
+        if (p.timeline && inst == 0 && tid == 0) p.timeline[id] = clock64(); \
+    } while (0)
+
 // LDS operands: xs [nvs] vertex values of this instance, red [10] reduction scratch + 4 int flags, cs [N*NC] per-grid-state
 // dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: a factor phase follows in the same workgroup and takes the Jacobian
 // straight from jst when this phase refreshed it (flag word [0]).
@@ -95,6 +100,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         vout = (vbuf ? p.values0 : p.values1) + (size_t)inst * p.m_pad;  // the buffer NOT paired with the resident J
     }
 
+    SWEEP_STAMP(0);
     // ---- stage vertex values in LDS (coalesced 16-byte loads)
     for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
         reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
@@ -102,6 +108,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
     __syncthreads();
+    SWEEP_STAMP(1);
+    // per-component descriptors and bounds of the residual loop below, first two rounds of components: requested now, consumed
+    // after the dynamics caches (straight-line code: the waits are exact, nothing waits for the write acknowledgements)
+    const int4* comp4 = reinterpret_cast<const int4*>(p.comp);
+    int4 ca0 = make_int4(1, -1, -1, -1), cb0 = make_int4(-1, -1, -1, -1), ca1 = ca0, cb1 = cb0;
+    double l0 = 0.0, u0 = 0.0, l1 = 0.0, u1 = 0.0;
+    const int v0 = tid, v1 = tid + SWEEP_THREADS;
+    if (v0 <= p.off_dt) { ca0 = comp4[2 * v0]; cb0 = comp4[2 * v0 + 1]; l0 = p.lb[xo + v0]; u0 = p.ub[xo + v0]; }
+    if (v1 <= p.off_dt) { ca1 = comp4[2 * v1]; cb1 = comp4[2 * v1 + 1]; l1 = p.lb[xo + v1]; u1 = p.ub[xo + v1]; }
     if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
         for (int k = tid; k < p.N; k += SWEEP_THREADS) {
             double c[NC];
@@ -112,95 +127,104 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         __syncthreads();
     }
 
+    SWEEP_STAMP(2);
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
+    constexpr double delta     = 1e-9;
+    constexpr double neg2delta = -2 * delta;
+    constexpr double scalar    = 1.0 / (2 * delta);
     double sq_acc = 0.0;
-    const int4* rtab = reinterpret_cast<const int4*>(p.row_tasks);   // 16-byte task descriptors, fetched one iteration ahead
-    const int4* ctab = reinterpret_cast<const int4*>(p.col_tasks);
-    const int4* btab = reinterpret_cast<const int4*>(p.bound_tasks);
-    int4 rt_next = (tid < p.n_row_tasks) ? rtab[tid] : make_int4(0, 0, 0, 0);
-    for (int t = tid; t < p.n_row_tasks; t += SWEEP_THREADS) {
-        const RowTask rt{rt_next.x, rt_next.y, rt_next.z, rt_next.w};
-        if (t + SWEEP_THREADS < p.n_row_tasks) rt_next = rtab[t + SWEEP_THREADS];
-        const int base   = rt.k * S;
-        switch (rt.kind) {
-            case EK_DEFECT: {
-                double e[NX];
-                if constexpr (CACHED)
-                    defect_eval_cached<DYN, DEFECT>(xs + base, cs + rt.k * NC, xs + base + NX, xs + base + S, cs + (rt.k + 1) * NC,
-                                                    xs[p.off_dt], p.mp.dyn, e);
-                else
-                    defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
+    // (a) per vertex component: its cost row (state / control / final-state / dt cost edges are all diagonal in the component)
+    //     and its bound row (computeDistanceFiniteCombinedBounds, hyper_graph_optimization_problem_base.cpp:291-315).  The
+    //     component's entries of the Jacobian (cost block column, bound row) are functions of the same few numbers; for the models
+    //     staged in LDS they are written here as well -- ahead of the accept / reject decision, harmless, the staging area only
+    //     reaches HBM when the Jacobian is due.
+    const bool jac_with_values = STAGE && (mode != 0);
+    // role of component v: index c inside its cost edge, dimension of that edge, weight and reference (branch-free).  Edges
+    // without a reference (control cost, dt cost) use ref = 0: w * (x - 0) is w * x exactly.
+    auto comp_role = [&](int v, int& c, int& dim, double& w, double& ref) {
+        const bool is_dt  = (v == p.off_dt);
+        const bool is_fin = !is_dt && v >= (p.N - 1) * S;
+        const int cs_     = is_fin ? v - (p.N - 1) * S : v % S;
+        const bool is_u   = !is_dt && !is_fin && cs_ >= NX;
+        const int cu      = cs_ - NX;
+        double wq = 0.0, wf = 0.0, wr = 0.0, rf = 0.0;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double v   = e[i] * p.w_eq;
-                    vout[rt.row + i] = v;
-                    sq_acc += v * v;
-                }
-                break;
-            }
-            case EK_STATE_COST: {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double v   = p.mp.sq[i] * (xs[base + i] - xr[i]);
-                    vout[rt.row + i] = v;
-                    sq_acc += v * v;
-                }
-                break;
-            }
-            case EK_CONTROL_COST: {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const double v   = p.mp.sr[i] * xs[base + NX + i];
-                    vout[rt.row + i] = v;
-                    sq_acc += v * v;
-                }
-                break;
-            }
-            case EK_FINAL_COST: {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double v   = p.mp.sqf[i] * (xs[base + i] - xr[i]);
-                    vout[rt.row + i] = v;
-                    sq_acc += v * v;
-                }
-                break;
-            }
-            case EK_DT_COST: {
-                const double v = p.mp.dt_weight * xs[p.off_dt];
-                vout[rt.row]   = v;
-                sq_acc += v * v;
-                break;
-            }
-            case EK_STAGE_INEQ: {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
-                double c = ineq_ball(xs + base, p.mp.ineq);
-                c        = (c < 0) ? 0.0 : c * p.w_ineq;
-                vout[rt.row] = c;
-                sq_acc += c * c;
-                break;
-            }
-            default: break;
+        for (int i = 0; i < NX; ++i) {
+            const bool hit = (cs_ == i);
+            wq = hit ? p.mp.sq[i] : wq;
+            wf = hit ? p.mp.sqf[i] : wf;
+            rf = hit ? xr[i] : rf;
         }
-    }
-    // bounds (computeDistanceFiniteCombinedBounds, hyper_graph_optimization_problem_base.cpp:291-315)
-    int4 bt_next = (tid < p.n_bound_tasks) ? btab[tid] : make_int4(0, 0, 0, 0);
-    double l_next = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.x] : 0.0, u_next = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.x] : 0.0;
-    for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {
-        const BoundTask bt{bt_next.x, bt_next.y, bt_next.z, bt_next.w};
-        const double xv = xs[bt.voff], l = l_next, u = u_next;
-        if (t + SWEEP_THREADS < p.n_bound_tasks) {
-            bt_next = btab[t + SWEEP_THREADS];
-            l_next  = p.lb[xo + bt_next.x];
-            u_next  = p.ub[xo + bt_next.x];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) wr = (cu == i) ? p.mp.sr[i] : wr;
+        w   = is_dt ? p.mp.dt_weight : (is_fin ? wf : (is_u ? wr : wq));
+        ref = (is_dt || is_u) ? 0.0 : rf;
+        dim = is_dt ? 1 : (is_u ? NU : NX);
+        c   = is_dt ? 0 : (is_u ? cu : cs_);
+    };
+    auto comp_jac = [&](int v, const CompInfo& ci, double xv, double l, double u, int c, int dim, double w, double ref) {
+        if (!ci.fixed && ci.cost_joff >= 0) {  // central difference of the diagonal cost block (edge_interface.cpp:55-96)
+            const double a = xv + delta, b = a + neg2delta;
+            const double dv = scalar * (w * (a - ref) - w * (b - ref));
+            const int col0  = ci.cost_joff - c;
+            constexpr int DM = (NX > NU) ? NX : NU;
+#pragma unroll
+            for (int r = 0; r < DM; ++r)
+                if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;  // untouched rows: scalar * (e - e) = 0
+            if (ci.cost2_joff >= 0) jst[ci.cost2_joff] = dv;   // duplicated MinimumTime dt edge (nlp_functions.cpp:91-107)
         }
-        double v;
-        if (xv < l) v = l - xv;
-        else if (xv > u) v = xv - u;
-        else v = 0.0;
-        v *= p.w_b;
-        vout[bt.row] = v;
-        sq_acc += v * v;
+        if (ci.bnd_joff >= 0) jst[ci.bnd_joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);  // :1721-1752
+    };
+    auto comp_values = [&](int v, const int4& ca, const int4& cb, double l, double u) {
+        const CompInfo ci{ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+        const double xv = xs[v];
+        int c, dim;
+        double w, ref;
+        comp_role(v, c, dim, w, ref);
+        if (ci.cost_row >= 0) {
+            const double val = w * (xv - ref);
+            vout[ci.cost_row] = val;
+            sq_acc += val * val;
+            if (ci.cost2_row >= 0) { vout[ci.cost2_row] = val; sq_acc += val * val; }
+        }
+        if (ci.bnd_row >= 0) {
+            double val = (xv < l) ? l - xv : ((xv > u) ? xv - u : 0.0);
+            val *= p.w_b;
+            vout[ci.bnd_row] = val;
+            sq_acc += val * val;
+        }
+        if (jac_with_values) comp_jac(v, ci, xv, l, u, c, dim, w, ref);
+    };
+    if (v0 <= p.off_dt) comp_values(v0, ca0, cb0, l0, u0);
+    if (v1 <= p.off_dt) comp_values(v1, ca1, cb1, l1, u1);
+    for (int v = tid + 2 * SWEEP_THREADS; v <= p.off_dt; v += SWEEP_THREADS)  // long horizons
+        comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+    SWEEP_STAMP(9);
+    // (b) per stage: the dynamics defect (equality rows) and the stage inequality
+    for (int k = tid; k < p.N - 1; k += SWEEP_THREADS) {
+        const int base = k * S;
+        double e[NX];
+        if constexpr (CACHED)
+            defect_eval_cached<DYN, DEFECT>(xs + base, cs + k * NC, xs + base + NX, xs + base + S, cs + (k + 1) * NC, xs[p.off_dt], p.mp.dyn, e);
+        else
+            defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double val = e[i] * p.w_eq;
+            vout[p.eq_row0 + k * NX + i] = val;
+            sq_acc += val * val;
+        }
+        if constexpr (NX >= 3) {
+            if (p.ineq_cols) {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
+                double ci = ineq_ball(xs + base, p.mp.ineq);
+                ci        = (ci < 0) ? 0.0 : ci * p.w_ineq;
+                vout[p.ineq_row0 + k] = ci;
+                sq_acc += ci * ci;
+            }
+        }
     }
 
+    SWEEP_STAMP(3);
     // ---- chi2 = |values|^2 and the LM trial-step decision
     int do_jac = (mode == 1 || mode == 2) ? 1 : 0;
     if (mode >= 2) {
@@ -272,15 +296,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 reinterpret_cast<double2*>(xdst)[i] = reinterpret_cast<const double2*>(xs)[i];
         }
     }
+    SWEEP_STAMP(4);
     if (!do_jac) return;
 
     // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753),
     //      central differences exactly as BaseEdge::computeJacobian (edge_interface.cpp:55-96):
     //      x_i += delta -> v2 ; x_i += -2 delta -> v1 ; col = (1/(2 delta)) (v2 - v1), on private copies of the edge's vertices.
     //      Values are assembled in the LDS staging area and streamed out with coalesced 16-byte stores at the end.
-    constexpr double delta     = 1e-9;
-    constexpr double neg2delta = -2 * delta;
-    constexpr double scalar    = 1.0 / (2 * delta);
     const double dt0 = xs[p.off_dt];
     // (1) dynamics-defect blocks.  Lane = (stage k, column group g): the perturbed component is a compile-time index inside the
     //     lane's loop, so there is no per-lane selection of what to perturb, no divergence, and for the cached defects only the
@@ -434,33 +456,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
     }
-    // (2) least-squares cost blocks: one lane per vertex component (column); each output depends on its own component only,
-    //     so a column is the diagonal entry and exact zeros elsewhere (what scalar * (e2 - e1) yields for untouched rows)
-    for (int v = tid; v <= p.off_dt; v += SWEEP_THREADS) {
-        const CompInfo ci = p.comp[v];
-        if (ci.fixed || ci.cost_joff < 0) continue;
-        const double a = xs[v] + delta, b = a + neg2delta;
-        if (v == p.off_dt) {  // duplicated MinimumTime dt edge: two 1x1 blocks (nlp_functions.cpp:91-107)
-            const double val = scalar * (p.mp.dt_weight * a - p.mp.dt_weight * b);
-            jst[ci.cost_joff] = val;
-            if (ci.cost2_joff >= 0) jst[ci.cost2_joff] = val;
-            continue;
+    SWEEP_STAMP(5);
+    // (2) least-squares cost blocks and bound rows, per vertex component -- unless written together with the residual above
+    if (!jac_with_values) {
+        for (int v = tid; v <= p.off_dt; v += SWEEP_THREADS) {
+            const int4 ca = comp4[2 * v], cb = comp4[2 * v + 1];
+            const CompInfo ci{ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+            int c, dim;
+            double w, ref;
+            comp_role(v, c, dim, w, ref);
+            comp_jac(v, ci, xs[v], p.lb[xo + v], p.ub[xo + v], c, dim, w, ref);
         }
-        int c, dim;
-        double w, ref;
-        if (v >= p.N * S - S) {  // x_f: final cost
-            c = v - (p.N - 1) * S; dim = NX; w = p.mp.sqf[c]; ref = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + c];
-        }
-        else {
-            c = v % S;
-            if (c < NX) { dim = NX; w = p.mp.sq[c]; ref = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + c]; }
-            else { c -= NX; dim = NU; w = p.mp.sr[c]; ref = 0.0; }
-        }
-        const bool is_control = (v < (p.N - 1) * S) && (v % S >= NX);
-        const double e2 = is_control ? w * a : w * (a - ref);
-        const double e1 = is_control ? w * b : w * (b - ref);
-        const int col0  = ci.cost_joff - c;
-        for (int r = 0; r < dim; ++r) jst[col0 + r] = (r == c) ? scalar * (e2 - e1) : 0.0;
     }
     // (3) stage inequality rows (active rows only, explicit zero otherwise, :1568-1610)
     if constexpr (NX >= 3) {
@@ -486,25 +492,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
     }
-    // (4) bound rows: -w / 0 / +w (:1721-1752)
-    bt_next = (tid < p.n_bound_tasks) ? btab[tid] : make_int4(0, 0, 0, 0);
-    l_next  = (tid < p.n_bound_tasks) ? p.lb[xo + bt_next.x] : 0.0;
-    u_next  = (tid < p.n_bound_tasks) ? p.ub[xo + bt_next.x] : 0.0;
-    for (int t = tid; t < p.n_bound_tasks; t += SWEEP_THREADS) {
-        const BoundTask bt{bt_next.x, bt_next.y, bt_next.z, bt_next.w};
-        const double xv = xs[bt.voff], l = l_next, u = u_next;
-        if (t + SWEEP_THREADS < p.n_bound_tasks) {
-            bt_next = btab[t + SWEEP_THREADS];
-            l_next  = p.lb[xo + bt_next.x];
-            u_next  = p.ub[xo + bt_next.x];
-        }
-        jst[bt.joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);
-    }
+    SWEEP_STAMP(6);
     if constexpr (STAGE) {
         __syncthreads();
+    SWEEP_STAMP(7);
         // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
         for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
             reinterpret_cast<double2*>(js)[i] = reinterpret_cast<const double2*>(jst)[i];
+    SWEEP_STAMP(8);
     }
 }
 
@@ -1666,7 +1661,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
 template <int DYN, int DEFECT>
 void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 {
-    hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p), stream, p);
+    hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
 }
 
 template <int DYN>
@@ -1737,10 +1732,12 @@ bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 
 }  // namespace
 
-size_t sweep_lds_bytes(const SweepParams& p)
+size_t sweep_lds_bytes(const SweepParams& p, int nc)
 {
+    // vertex values + reduction scratch + dynamics caches + Jacobian staging; the headline family must stay below 40 KB so that
+    // four workgroups share a CU (1024 instances = one round over 256 CUs)
     const size_t stage = (p.nx <= 6) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
-    return sizeof(double) * ((size_t)p.nvs + 10 + (size_t)p.N * 6 + 2 + stage);
+    return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage);
 }
 
 size_t factor_work_doubles(const corbo_hip_problem_desc& d)

@@ -37,6 +37,7 @@ struct SweepParams {
     // static structure
     int32_t batch, nvs, m, nnz, N, s, nx, off_dt, dt_free;
     int32_t inst0;      // first instance of this launch (sub-batch launches); grid = batch
+    int32_t eq_row0, ineq_row0;  // first residual row of the defect / stage-inequality edges (one edge per stage)
     int32_t n_row_tasks, n_col_tasks, n_bound_tasks;
     const RowTask* row_tasks;
     const ColTask* col_tasks;
@@ -61,6 +62,7 @@ struct SweepParams {
     int32_t m_pad, nnz_pad;
     LmState* st;
     int32_t* active_count;  // number of instances not done after this pass (mode 3)
+    long long* timeline;    // optional [16] shader-clock stamps of instance 0 (diagnostics), may be null
     double* chi2;           // [batch] dense copy of the accepted chi2 (*obj_value), written by the LM modes
 };
 
@@ -91,7 +93,7 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
 // one fused LM pass: [sweep phase (sp.mode 2 = prologue, 3 = trial step) -> factor phase] per workgroup, one launch
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
-size_t sweep_lds_bytes(const SweepParams& p);
+size_t sweep_lds_bytes(const SweepParams& p, int nc);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
 // doubles of HBM workspace per instance the factor kernel needs (0 for the LDS-resident small-block kernel)
 size_t factor_work_doubles(const corbo_hip_problem_desc& d);

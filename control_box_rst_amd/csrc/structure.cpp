@@ -130,6 +130,8 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                 int vd = vert_dim(e.kind, vi);
                 for (int c = 0; c < vd; ++c) {
                     int voff = comp_of(e.kind, e.k, vi, c);
+                    // the cost edge of a fixed vertex still contributes its value rows (no Jacobian column)
+                    if (e.kind == EK_STATE_COST || e.kind == EK_CONTROL_COST || e.kind == EK_FINAL_COST) S.comp[voff].cost_row = row + c;
                     if (S.comp[voff].fixed) continue;
                     // one column of the block: rows e.dim, parameter = comp.param
                     for (int r = 0; r < e.dim; ++r) { S.jac_rows.push_back(row + r); S.jac_cols.push_back(S.comp[voff].param); }
