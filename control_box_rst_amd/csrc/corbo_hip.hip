@@ -415,6 +415,20 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
             fp.batch = sp.batch = count_of[i];
             fp.inst0 = sp.inst0 = first_of[i];
             fp.loop_passes = MAX_PASSES;
+            long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
+            const char* ptl_env = std::getenv("CORBO_HIP_PASS_TIMELINE");
+            if (ptl_env && i == 0) {
+                HIP_TRY(hipMalloc((void**)&d_ptl, 130 * sizeof(long long)));
+                HIP_TRY(hipMemsetAsync(d_ptl, 0, 130 * sizeof(long long), st_of[i]));
+                fp.pass_timeline      = d_ptl;
+                fp.pass_timeline_inst = std::atoi(ptl_env);
+            }
+            struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); long long tl[130];
+                if (hipMemcpy(tl, p, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess) {
+                    fprintf(stderr, "pass timeline (sweep/factor cycles):");
+                    for (int k = 0; k < 64 && tl[2 * k]; ++k) fprintf(stderr, " %lld/%lld", tl[2 * k + 1] ? tl[2 * k + 1] - tl[2 * k] : -1, (k < 63 && tl[2 * k + 2]) ? tl[2 * k + 2] - tl[2 * k + 1] : 0);
+                    fprintf(stderr, "\n"); }
+                (void)hipFree(p); } } ptl_guard{d_ptl, st_of[i]};
             if (!launch_pass(h->S.desc, fp, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h->h_counter + 2 * i, h->d_counters + (size_t)i * MAX_PASSES, sizeof(int32_t), hipMemcpyDeviceToHost, st_of[i]));

@@ -1643,11 +1643,14 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
             asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");  // nothing derived from them is carried around the loop
             const FactorParams& fpl = (const FactorParams&)ka->f;
             const SweepParams& spl  = (const SweepParams&)ka->s;
+            const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;
+            if (stamp) fpl.pass_timeline[2 * pass] = clock64();
             if (tid_v == 0) flags[0] = 0;
             __syncthreads();
             sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, xs, red, cs, jst, inst_v, tid_v);
             __threadfence_block();
             __syncthreads();
+            if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
             if (fpl.st[inst_v].done) break;
             factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fpl, smem, inst_v, tid_v, flags[0] != 0);
             __threadfence_block();

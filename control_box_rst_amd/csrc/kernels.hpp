@@ -85,6 +85,8 @@ struct FactorParams {
     long long* timeline;          // optional [8] shader-clock stamps of workgroup 0 (diagnostics), may be null
     double* work;                 // big-block kernel only: per-instance factor workspace in HBM
     int64_t work_stride;          // doubles per instance
+    long long* pass_timeline;     // optional [2 * 64 + 1] shader-clock stamps (pass start, sweep end) of one instance (diagnostics)
+    int32_t pass_timeline_inst;
     int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
 };
 

@@ -1,14 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-CORBO_HIP_SWEEP_TIMELINE=1 python - <<PY
-import sys, time; sys.path.insert(0,'.')
-from control_box_rst_amd import problems
-from control_box_rst_amd.solver import BatchedLevenbergMarquardt
-d=problems.unicycle_desc()
-for B in (1, 1024):
-    x0,xf=problems.unicycle_instances(B)
-    s=BatchedLevenbergMarquardt(d,B); s.setPenaltyWeights(10,10,10)
-    s.set_instance_data(s.init_trajectory(x0,xf), xref=xf)
-    print(B, "sweep us", s.time_sweep(True,50)*1e3, flush=True)
-PY
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
+tools/collect_profiles.sh "round 1, component-centric sweep (one prefetched descriptor per component, LDS staging, 4 workgroups / CU)"
+python bench.py 2>/dev/null | tail -1 > gpurun_out/prof/bench_line.json
