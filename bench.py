@@ -55,6 +55,22 @@ def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
     port_value = done * opts.iterations / t_port
     out["port_value"] = port_value
     out["port_sample"] = f"{done} seeded instances x {opts.iterations} LM iterations, oracle/liboracle.so, 1 thread"
+    # --- port on all host cores: one worker process per core, started together (oracle/port_worker.py)
+    cores = min(os.cpu_count() or 1, 128)
+    if cores > 1:
+        per = 1024
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "port_worker.py"), str(i * per), str(per), str(opts.iterations)],
+                                  stdout=subprocess.PIPE) for i in range(cores)]
+        res = []
+        for pr in procs:
+            so, _ = pr.communicate(timeout=300)
+            if pr.returncode == 0:
+                res.append(json.loads(so.decode().strip().splitlines()[-1]))
+        if len(res) == cores:
+            out["port_allcores_value"] = sum(r["n"] * r["iterations"] for r in res) / max(r["seconds"] for r in res)
+            out["port_allcores_sample"] = (f"{cores} worker processes x {per} seeded instances x {opts.iterations} LM iterations, "
+                                           f"oracle/liboracle.so, slowest worker {max(r['seconds'] for r in res):.2f} s")
+            out["port_allcores_cores"] = cores
     # --- genuine reference, 1 thread
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(drv) and os.access(drv, os.X_OK):

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-tools/collect_profiles.sh "round 1, component-centric sweep (one prefetched descriptor per component, LDS staging, 4 workgroups / CU)"
-python bench.py 2>/dev/null | tail -1 > gpurun_out/prof/bench_line.json
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5

@@ -98,6 +98,36 @@ def test_seeded_batch_vs_reference_golden_and_oracle(oracle_mod):
     assert st["lm_iterations"] == 80 and st["factorizations"] >= 80
 
 
+def test_accept_reject_sequence_vs_oracle(oracle_mod):
+    """SURVEY 8d parity gate "identical accept/reject sequence": for every outer-iteration count k = 1..10 the cumulative numbers
+    of inner passes (= factorisations) and of accepted steps of the device equal those of the oracle's trace, on 6
+    seeded cfg-3 instances solved as one batch (the per-k trajectories against the reference are pinned above)."""
+    d = problems.unicycle_desc()
+    B = 6
+    x0, xf = problems.unicycle_instances(B, seed=777)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    cum_inner = np.zeros((B, 10), dtype=int)
+    cum_acc = np.zeros((B, 10), dtype=int)
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        opts = s.opts
+        opts.iterations = 10
+        _, _, trace = p.solve(opts)
+        cum_inner[b] = np.cumsum([t["inner_passes"] for t in trace])
+        cum_acc[b] = np.cumsum([t["accepted"] for t in trace])
+    for k in range(1, 11):
+        s.setIterations(k)
+        s.set_instance_data(X0, xref=xf)
+        s.solve()
+        st = s.get_stats()
+        assert st["lm_iterations"] == B * k
+        assert st["factorizations"] == int(cum_inner[:, k - 1].sum()), k
+        assert st["accepted_steps"] == int(cum_acc[:, k - 1].sum()), k
+
+
 def test_values_jacobian_vs_oracle_batch(oracle_mod):
     """Residual/Jacobian of 32 seeded instances at their initial trajectories, per-instance vs the oracle."""
     d = problems.unicycle_desc(N=30)
