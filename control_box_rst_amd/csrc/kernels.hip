@@ -935,96 +935,115 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
     // ---- cyclic reduction, levels h = 2, 4, ...: lane t owns the active block a = h*t.  It first applies the Schur updates of
     //      the previous level (neighbours a -+ h/2 were eliminated there); odd t then eliminates a against a -+ h, whose
     //      couplings it forms on the fly from those same neighbours.  The first h >= N leaves block 0 alone: the root.
-    // Two lanes share a block: lane parity 0 gathers what the left neighbour (em) contributes and forms W_a, parity 1 does the same
-    // for the right neighbour (ep) and W_b; the partial Schur updates are exchanged with one cross-lane swap, the small Cholesky is
-    // done redundantly by both.
+    // Four lanes share a block (a wave64 instruction costs 4 cycles whether 1 or 64 lanes work, so the per-level instruction count
+    // is what the chain pays): every lane applies the Schur updates of both neighbours to its own copy of D (redundant, 36 FMAs, no
+    // exchange) and factors it; lane j < NX then produces column j of the new couplings W_a and W_b, lane NX the right-hand side.
+    // What differs between the lanes is only WHERE their 3-vector operand comes from / goes to (column j of W, or the rhs slot), i.e.
+    // a base pointer and a stride -- the instruction stream is the same.
     int hroot = 2;
     for (int h = 2;; h <<= 1) {
-        const int a    = h * (tid >> 1);
-        const int side = tid & 1;
-        const bool act = (a < N);
-        const int ac   = act ? a : 0;
-        const int hh   = h >> 1;
-        const int e    = side ? ac + hh : ac - hh;               // the neighbour this lane works on
-        const bool has = act && (side ? (e < N) : (e >= 0));
-        const int ec   = has ? e : ac;                            // clamped: every LDS operand is fetched unconditionally, in one batch
-        const bool elim = ((tid >> 1) & 1);
-        const bool root = (h >= N);                              // only a == 0 is active then
-        double D[NX][NX], g[NX], bb[NX], Wx[NX][NX], Wy[NX][NX], ny[NX], nz[NX];
+        const int j     = tid & 3;
+        const int hh    = h >> 1;
+        const bool root = (h >= N);                                      // only a == 0 is active then
+        static_assert(NX + 1 <= 4, "four lanes per block: NX columns + one right-hand-side lane");
+        const bool vec  = (j == NX);
+        const bool col  = (j < NX);
+        const int nblk  = (N + h - 1) / h;
+        for (int t = tid >> 2; t < nblk; t += THREADS / 4) {   // (one round whenever 4 * ceil(N / h) <= THREADS)
+        const int a      = h * t;
+        const int ac     = a;
+        const bool act   = true;
+        const bool has_m = (a - hh >= 0), has_p = (a + hh < N);
+        const int em = has_m ? a - hh : a, ep = has_p ? a + hh : a;       // clamped: absent neighbours are fetched from a and zeroed
+        const bool elim = (t & 1);
+        // operand of this lane: column j of the far coupling of each neighbour, or (lane 3) the neighbour's rhs
+        const int jc     = col ? j : 0;               // (a spare lane, NX < 3, mirrors column 0 and stores nothing)
+        const double* om = vec ? gv : Wam + jc * NP;  // em: far side is a - h  -> W_a(em)
+        const double* op = vec ? gv : Wbm + jc * NP;  // ep: far side is a + h  -> W_b(ep)
+        const int os     = vec ? NP : NX * NP;
+        double D[NX][NX], g[NX], bb[NX], Xm[NX][NX], Xp[NX][NX], ym[NX], yp[NX], zm[NX], zp[NX];
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             g[q]  = SOA(gv, q, ac);
-            ny[q] = SOA(gv, q, ec);
             bb[q] = ARROW ? SOA(bv, q, ac) : 0.0;
-            nz[q] = ARROW ? SOA(bv, q, ec) : 0.0;
+            ym[q] = om[q * os + em];
+            yp[q] = op[q * os + ep];
+            zm[q] = ARROW ? SOA(bv, q, em) : 0.0;
+            zp[q] = ARROW ? SOA(bv, q, ep) : 0.0;
 #pragma unroll
             for (int c = 0; c < NX; ++c) {
-                D[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), ac) : 0.0;
-                // Wx: the neighbour's factor block that couples it to a; Wy: the one that couples it to a's far neighbour
-                const double wa = SOA(Wam, q * NX + c, ec), wb = SOA(Wbm, q * NX + c, ec);
-                Wx[q][c] = side ? wa : wb;   // em: a is its b-side -> W_b(em) ; ep: a is its a-side -> W_a(ep)
-                Wy[q][c] = side ? wb : wa;
+                D[q][c]  = (c <= q) ? SOA(Dm, TRI(q, c), ac) : 0.0;
+                Xm[q][c] = SOA(Wbm, q * NX + c, em);   // em's coupling to a (a is its b-side)
+                Xp[q][c] = SOA(Wam, q * NX + c, ep);   // ep's coupling to a (a is its a-side)
             }
         }
-        // partial Schur update from this lane's neighbour
-        double dD[NX][NX], dg[NX], db[NX], Hs[NX][NX];
+        if (!has_m) {
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            double s1 = 0, s2 = 0;
+            for (int q = 0; q < NX; ++q)
 #pragma unroll
-            for (int t = 0; t < NX; ++t) { s1 += Wx[t][q] * ny[t]; if constexpr (ARROW) s2 += Wx[t][q] * nz[t]; }
-            dg[q] = has ? s1 : 0.0;
-            db[q] = has ? s2 : 0.0;
-#pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                double dd = 0, hx = 0;
-#pragma unroll
-                for (int t = 0; t < NX; ++t) { if (c <= q) dd += Wx[t][q] * Wx[t][c]; hx += Wx[t][q] * Wy[t][c]; }
-                dD[q][c] = has ? dd : 0.0;
-                Hs[q][c] = has ? -hx : 0.0;   // side 0: H(a, a-h) = -W_b(em)^T W_a(em) ; side 1: H(a, a+h) = -W_a(ep)^T W_b(ep)
-            }
+                for (int c = 0; c < NX; ++c) Xm[q][c] = 0.0;
         }
-        // combine with the partner lane (same block, other neighbour)
+        if (!has_p) {
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) Xp[q][c] = 0.0;
+        }
+        // Schur updates: D -= X^T X (both neighbours), v = X^T (operand)
+        double vm[NX], vp[NX], wm[NX], wp[NX];
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
-            g[q] -= dg[q] + __shfl_xor(dg[q], 1);
-            if constexpr (ARROW) bb[q] -= db[q] + __shfl_xor(db[q], 1);
+            double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
 #pragma unroll
-            for (int c = 0; c <= q; ++c) D[q][c] -= dD[q][c] + __shfl_xor(dD[q][c], 1);
+            for (int t = 0; t < NX; ++t) {
+                s1 += Xm[t][q] * ym[t];
+                s2 += Xp[t][q] * yp[t];
+                if constexpr (ARROW) { s3 += Xm[t][q] * zm[t]; s4 += Xp[t][q] * zp[t]; }
+            }
+            vm[q] = s1; vp[q] = s2; wm[q] = s3; wp[q] = s4;
+#pragma unroll
+            for (int c = 0; c <= q; ++c) {
+                double dd = 0;
+#pragma unroll
+                for (int t = 0; t < NX; ++t) dd += Xm[t][q] * Xm[t][c] + Xp[t][q] * Xp[t][c];
+                D[q][c] -= dd;
+            }
         }
         if (act) {
+            // lane 3: rhs (and border column) of block a; lanes 0..2: H(a, a-h) = -W_b(em)^T W_a(em), H(a, a+h) = -W_a(ep)^T W_b(ep)
+            double c1[NX], c2[NX];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                c1[q] = vec ? g[q] - (vm[q] + vp[q]) : -vm[q];
+                c2[q] = vec ? bb[q] - (wm[q] + wp[q]) : -vp[q];
+            }
             if (elim || root) {
                 chol_inv<NX>(D);
-                fwd_solve_vec<NX>(D, g);
-                if constexpr (ARROW) fwd_solve_vec<NX>(D, bb);
-                if (side == 0) {
+                fwd_solve_vec<NX>(D, c1);
+                if (ARROW || !vec) fwd_solve_vec<NX>(D, c2);
+                if (vec) {
 #pragma unroll
                     for (int q = 0; q < NX; ++q) {
-                        y2 += g[q] * g[q];
-                        if constexpr (ARROW) { zz += bb[q] * bb[q]; zy += bb[q] * g[q]; }
+                        y2 += c1[q] * c1[q];
+                        if constexpr (ARROW) { zz += c2[q] * c2[q]; zy += c2[q] * c1[q]; }
                     }
+                    if (root && !ARROW) bwd_solve_vec<NX>(D, c1);  // no border: the root is back-substituted right away
                 }
-                if (!root) {
-                    fwd_solve<NX, NX>(D, Hs);
-#pragma unroll
-                    for (int q = 0; q < NX; ++q)
-#pragma unroll
-                        for (int c = 0; c < NX; ++c) {
-                            if (side == 0) SOA(Wam, q * NX + c, a) = Hs[q][c];
-                            else SOA(Wbm, q * NX + c, a) = Hs[q][c];
-                        }
-                }
-                else if constexpr (!ARROW) bwd_solve_vec<NX>(D, g);  // no border: the root is back-substituted right away
             }
-            if (side == 0) {
+            if (vec) {
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
-                    SOA(gv, q, a) = g[q];
-                    if constexpr (ARROW) SOA(bv, q, a) = bb[q];
+                    SOA(gv, q, a) = c1[q];
+                    if constexpr (ARROW) SOA(bv, q, a) = c2[q];
 #pragma unroll
                     for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
                 }
             }
+            else if (col && elim && !root) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) { SOA(Wam, q * NX + j, a) = c1[q]; SOA(Wbm, q * NX + j, a) = c2[q]; }
+            }
+        }
         }
         hroot = h;
         if (h >= N) break;
