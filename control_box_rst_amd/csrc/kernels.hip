@@ -598,14 +598,16 @@ struct FactorLds {
 
 // j_in_lds: the Jacobian values of this instance already sit in smem[0, nnz_pad) (left there by the sweep phase of the same
 // workgroup); otherwise they are staged from HBM first.
-template <int NX, int NU, int THREADS, bool ARROW>
+// NPC > 0: the padded block count N | 1 as a compile-time constant (LDS element strides become immediate offsets of the DS
+// instructions instead of two VALU operations per access); 0: taken from the launch parameters.
+template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0>
 __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem, const int inst, const int tid, const bool j_in_lds)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
     constexpr int NT = NX * (NX + 1) / 2;
     const int N  = p.N;
-    const int NP = N | 1;
+    const int NP = NPC > 0 ? NPC : (N | 1);
     // SoA arrays, element-major: arr[e][block].  Per state block: D/L (packed lower), W_a, W_b, rhs/y/x; per stage: the
     // eliminated controls.  Slots of block k+1 double as the mailbox for what stage k contributes to it.
     double* Luu = smem;                    // NU*NU   L_uu (diag inverted)
@@ -1619,14 +1621,14 @@ __global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
 // the slow instances of the tail run at single-instance latency (0.81 ms instead of 1.09 ms per headline solve).  The loop needs
 // two precautions against the compiler carrying state around it: the kernel arguments are re-read from the kernarg segment each
 // pass, and the library is built with -disable-machine-licm (hoisted math-library constants were spilled to scratch otherwise).
-template <int DYN, int DEFECT, bool ARROW, bool LOOP>
+template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC>
 __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int inst = blockIdx.x + fp.inst0, tid = threadIdx.x;
-    const int NP = fp.N | 1;
+    const int NP = NPC > 0 ? NPC : (fp.N | 1);
     // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, reduction
     // scratch = the factor phase's, vertex values behind the factor carve.
     const int ftot = FL::total(NP, ARROW);
@@ -1643,7 +1645,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
         __threadfence_block();  // this workgroup's residual / iterate / state stores are visible to its factor phase
         __syncthreads();
         if (fp.st[inst].done) return;
-        factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fp, smem, inst, tid, flags[0] != 0);
+        factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fp, smem, inst, tid, flags[0] != 0);
     }
     else {
         // run-to-completion: the instances are independent, so the workgroup walks its instance through the prologue and every LM
@@ -1671,7 +1673,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
             __syncthreads();
             if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
             if (fpl.st[inst_v].done) break;
-            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW>(fpl, smem, inst_v, tid_v, flags[0] != 0);
+            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, smem, inst_v, tid_v, flags[0] != 0);
             __threadfence_block();
             __syncthreads();
             mode = 3;
@@ -1714,12 +1716,14 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
     const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs);                                  // + vertex values
     const dim3 g(fp.batch), b(SWEEP_THREADS);
+    // the run-to-completion kernel of the headline horizon (N = 100) is specialised on the LDS stride
     if (fp.loop_passes > 0) {
-        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true>), g, b, lds, stream, fp, sp);
-        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true>), g, b, lds, stream, fp, sp);
+        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0>), g, b, lds, stream, fp, sp);
+        else if ((fp.N | 1) == 101) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 101>), g, b, lds, stream, fp, sp);
+        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0>), g, b, lds, stream, fp, sp);
     }
-    else if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, false>), g, b, lds, stream, fp, sp);
-    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, false>), g, b, lds, stream, fp, sp);
+    else if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, false, 0>), g, b, lds, stream, fp, sp);
+    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, false, 0>), g, b, lds, stream, fp, sp);
     return true;
 }
 
