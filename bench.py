@@ -209,6 +209,16 @@ def main():
                          "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": B * b_sweep, "ms_per_launch": sweep_ms},
         }
+        # the solve as a whole (one run-to-completion launch): what the reference's algorithm would move through memory for the same
+        # sweeps (residual + Jacobian sweeps at B_sweep, residual-only trial sweeps at 8 (n_vert + 2n + m) bytes), against the time
+        b_val = 8 * (dims.nv + 2 * dims.n + dims.m)
+        sweeps_j, sweeps_r = red["jacobian_sweeps"], red["residual_sweeps"]
+        alg_solve = sweeps_j * b_sweep + max(0.0, sweeps_r - sweeps_j) * b_val
+        line["solve_kernel"] = {"kernel": "lm_pass_kernel (run-to-completion: prologue + all LM passes of every instance, one launch)",
+                                "bound": "latency (dependent instruction issue of one instance; DESIGN.md 3.3)",
+                                "algorithmic_bytes_per_solve": alg_solve, "achieved_GBs": alg_solve / (t_max / args.steps) / 1e9,
+                                "frac_of_hbm_peak": alg_solve / (t_max / args.steps) / 1e9 / peak,
+                                "jacobian_sweeps": int(sweeps_j), "residual_sweeps": int(sweeps_r)}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(desc, solver.opts, x0, xf)
         print(json.dumps(line), flush=True)

@@ -109,25 +109,6 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
     __syncthreads();
     SWEEP_STAMP(1);
-    // per-component descriptors and bounds of the residual loop below, first two rounds of components: requested now, consumed
-    // after the dynamics caches (straight-line code: the waits are exact, nothing waits for the write acknowledgements)
-    const int4* comp4 = reinterpret_cast<const int4*>(p.comp);
-    int4 ca0 = make_int4(1, -1, -1, -1), cb0 = make_int4(-1, -1, -1, -1), ca1 = ca0, cb1 = cb0;
-    double l0 = 0.0, u0 = 0.0, l1 = 0.0, u1 = 0.0;
-    const int v0 = tid, v1 = tid + SWEEP_THREADS;
-    if (v0 <= p.off_dt) { ca0 = comp4[2 * v0]; cb0 = comp4[2 * v0 + 1]; l0 = p.lb[xo + v0]; u0 = p.ub[xo + v0]; }
-    if (v1 <= p.off_dt) { ca1 = comp4[2 * v1]; cb1 = comp4[2 * v1 + 1]; l1 = p.lb[xo + v1]; u1 = p.ub[xo + v1]; }
-    if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
-        for (int k = tid; k < p.N; k += SWEEP_THREADS) {
-            double c[NC];
-            Dy::prepare(xs + k * S, p.mp.dyn, c);
-#pragma unroll
-            for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
-        }
-        __syncthreads();
-    }
-
-    SWEEP_STAMP(2);
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
     constexpr double delta     = 1e-9;
     constexpr double neg2delta = -2 * delta;
@@ -195,10 +176,53 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
         if (jac_with_values) comp_jac(v, ci, xv, l, u, c, dim, w, ref);
     };
-    if (v0 <= p.off_dt) comp_values(v0, ca0, cb0, l0, u0);
-    if (v1 <= p.off_dt) comp_values(v1, ca1, cb1, l1, u1);
-    for (int v = tid + 2 * SWEEP_THREADS; v <= p.off_dt; v += SWEEP_THREADS)  // long horizons
-        comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+    // Work split of the residual (horizons up to 128 stages, i.e. when half of the workgroup holds one lane per stage): waves 0-1
+    // are the stage lanes (dynamics caches, one round of components, then the defects), waves 2-3 take the other rounds of
+    // components (cost / bound rows) meanwhile -- the halves run side by side on different SIMDs.  Longer horizons: every lane does
+    // both kinds of work, in sequence.
+    const bool split   = (p.N <= SWEEP_THREADS / 2);
+    const int cstr     = split ? SWEEP_THREADS / 2 : SWEEP_THREADS;   // component stride of the lanes that do several rounds
+    const bool cworker = !split || (tid >= SWEEP_THREADS / 2);
+    // descriptors and bounds of the first two rounds of components: requested now, consumed below (straight-line code: the waits
+    // are exact, nothing waits for the write acknowledgements)
+    const int4* comp4 = reinterpret_cast<const int4*>(p.comp);
+    int4 ca0 = make_int4(1, -1, -1, -1), cb0 = make_int4(-1, -1, -1, -1), ca1 = ca0, cb1 = cb0;
+    double l0 = 0.0, u0 = 0.0, l1 = 0.0, u1 = 0.0;
+    const int vend = p.off_dt + 1;
+    const int v0 = tid, v1 = cworker ? v0 + cstr : vend, v2 = cworker ? v1 + cstr : vend;
+    if (v0 < vend) { ca0 = comp4[2 * v0]; cb0 = comp4[2 * v0 + 1]; l0 = p.lb[xo + v0]; u0 = p.ub[xo + v0]; }
+    if (v1 < vend) { ca1 = comp4[2 * v1]; cb1 = comp4[2 * v1 + 1]; l1 = p.lb[xo + v1]; u1 = p.ub[xo + v1]; }
+    if (split && cworker) {  // component lanes: rounds 0 and 1 while the stage lanes prepare their caches; round 2 requested
+        if (v0 < vend) {
+            comp_values(v0, ca0, cb0, l0, u0);
+            if (v2 < vend) { ca0 = comp4[2 * v2]; cb0 = comp4[2 * v2 + 1]; l0 = p.lb[xo + v2]; u0 = p.ub[xo + v2]; }
+        }
+        if (v1 < vend) comp_values(v1, ca1, cb1, l1, u1);
+    }
+    if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
+        for (int k = tid; k < p.N; k += SWEEP_THREADS) {
+            double c[NC];
+            Dy::prepare(xs + k * S, p.mp.dyn, c);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
+        }
+        if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);  // stage lanes: their one round of components
+        __syncthreads();
+    }
+    else if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
+
+    SWEEP_STAMP(2);
+    if (split) {
+        if (cworker) {   // round 2 is in the registers, later rounds (N > 100 or so) fetch as they go
+            if (v2 < vend) comp_values(v2, ca0, cb0, l0, u0);
+            for (int v = v2 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+        }
+    }
+    else {
+        if (v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
+        if (v1 < vend) comp_values(v1, ca1, cb1, l1, u1);
+        for (int v = v1 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+    }
     SWEEP_STAMP(9);
     // (b) per stage: the dynamics defect (equality rows) and the stage inequality
     for (int k = tid; k < p.N - 1; k += SWEEP_THREADS) {
