@@ -64,9 +64,6 @@ struct corbo_hip_solver {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_chk[2] = {nullptr, nullptr};
     // static tables
-    RowTask* d_row_tasks     = nullptr;
-    ColTask* d_col_tasks     = nullptr;
-    BoundTask* d_bound_tasks = nullptr;
     StageCols* d_stage_cols  = nullptr;
     CompInfo* d_comp         = nullptr;
     int32_t* d_ineq_cols     = nullptr;
@@ -95,8 +92,6 @@ struct corbo_hip_solver {
         SweepParams p{};
         p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
-        p.n_row_tasks = (int)S.row_tasks.size(); p.n_col_tasks = (int)S.col_tasks.size(); p.n_bound_tasks = (int)S.bound_tasks.size();
-        p.row_tasks = d_row_tasks; p.col_tasks = d_col_tasks; p.bound_tasks = d_bound_tasks;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         std::memcpy(p.mp.dyn, S.desc.dyn_params, sizeof(p.mp.dyn));
         std::memcpy(p.mp.ineq, S.desc.ineq_params, sizeof(p.mp.ineq));
@@ -213,8 +208,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     }
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[1], hipEventDisableTiming));
-    if (upload(S.row_tasks, &h->d_row_tasks) || upload(S.col_tasks, &h->d_col_tasks) || upload(S.bound_tasks, &h->d_bound_tasks) ||
-        upload(S.stage_cols, &h->d_stage_cols) || upload(S.comp, &h->d_comp) || upload(S.ineq_cols, &h->d_ineq_cols) ||
+    if (upload(S.stage_cols, &h->d_stage_cols) || upload(S.comp, &h->d_comp) || upload(S.ineq_cols, &h->d_ineq_cols) ||
         upload(S.ineq_rows, &h->d_ineq_rows)) {
         std::string m = g_last_error;
         corbo_hip_destroy(h);
@@ -261,7 +255,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_row_tasks, h->d_col_tasks, h->d_bound_tasks, h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
+    void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

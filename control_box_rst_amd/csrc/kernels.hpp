@@ -38,10 +38,6 @@ struct SweepParams {
     int32_t batch, nvs, m, nnz, N, s, nx, off_dt, dt_free;
     int32_t inst0;      // first instance of this launch (sub-batch launches); grid = batch
     int32_t eq_row0, ineq_row0;  // first residual row of the defect / stage-inequality edges (one edge per stage)
-    int32_t n_row_tasks, n_col_tasks, n_bound_tasks;
-    const RowTask* row_tasks;
-    const ColTask* col_tasks;
-    const BoundTask* bound_tasks;
     const StageCols* stage_cols;  // N-1: Jacobian offsets of the defect columns of stage k
     const CompInfo* comp;         // nvs: cost-block offsets per component
     const int32_t* ineq_cols;     // (N-1)*nx or null

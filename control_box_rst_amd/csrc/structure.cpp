@@ -112,18 +112,12 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
             default: return vi == 0 ? nx : vi == 1 ? nu : vi == 2 ? nx : 1;
         }
     };
-    // state components the device model's prepare() depends on (model.hpp Dynamics<>::CACHE_XMASK): the finite-difference
-    // columns that perturb one of them are the only ones that re-evaluate transcendental functions; they go first so that
-    // whole wavefronts either do or do not pay for them.
-    const unsigned xmask = (d.dynamics == CORBO_HIP_DYN_UNICYCLE) ? 0b100u : (d.dynamics == CORBO_HIP_DYN_QUADROTOR) ? 0b111000000u : 0u;
-    std::vector<ColTask> trig, heavy, light;
     S.stage_cols.assign(N - 1, StageCols{});
     for (auto& sc : S.stage_cols) for (int& c : sc.col) c = -1;
     if (d.stage_ineq != CORBO_HIP_INEQ_NONE) { S.ineq_cols.assign((size_t)(N - 1) * nx, -1); S.ineq_rows.assign(N - 1, -1); }
     int dt_cost_seen = 0;
     auto add_list = [&](const std::vector<E>& list) {
         for (const E& e : list) {
-            S.row_tasks.push_back({e.kind, e.k, row, e.scale});
             if (e.kind == EK_STAGE_INEQ) S.ineq_rows[e.k] = row;
             int nverts = (e.kind == EK_DEFECT) ? 4 : 1;
             for (int vi = 0; vi < nverts; ++vi) {
@@ -135,12 +129,6 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                     if (S.comp[voff].fixed) continue;
                     // one column of the block: rows e.dim, parameter = comp.param
                     for (int r = 0; r < e.dim; ++r) { S.jac_rows.push_back(row + r); S.jac_cols.push_back(S.comp[voff].param); }
-                    ColTask t{e.kind, e.k, voff, joff};
-                    if (e.kind == EK_DEFECT) {
-                        const bool is_state = (vi == 0 || vi == 2);
-                        ((is_state && ((xmask >> c) & 1u)) ? trig : heavy).push_back(t);
-                    }
-                    else light.push_back(t);
                     if (e.kind == EK_DEFECT) {
                         int local = (vi == 0) ? c : (vi == 1) ? nx + c : (vi == 2) ? s + c : s + nx;
                         S.stage_cols[e.k].col[local] = joff;
@@ -175,7 +163,6 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     for (int v = 0; v < nv_all; ++v) {
         if (S.comp[v].fixed) continue;
         if (!finite_bound(lb[v], ub[v])) continue;
-        S.bound_tasks.push_back({v, row, joff, 0});
         S.comp[v].bnd_joff = joff;
         S.comp[v].bnd_row  = row;
         S.jac_rows.push_back(row);
@@ -188,9 +175,6 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     S.dims.nnz    = joff;
     S.dims.n      = n;
     S.dims.nv     = S.dt_free ? nv_all : nv_all - 1;
-    S.col_tasks   = trig;
-    S.col_tasks.insert(S.col_tasks.end(), heavy.begin(), heavy.end());
-    S.col_tasks.insert(S.col_tasks.end(), light.begin(), light.end());
     return "";
 }
 

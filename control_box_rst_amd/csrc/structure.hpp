@@ -25,30 +25,6 @@ enum EdgeKind : int32_t {
     EK_STAGE_INEQ   = 5   // stage inequality on x_k
 };
 
-// one residual-row group = one edge's values (BaseEdge::computeValues)
-struct RowTask {
-    int32_t kind;   // EdgeKind
-    int32_t k;      // stage
-    int32_t row;    // first row in the stacked residual
-    int32_t scale;  // 0 none, 1 w_eq, 2 active inequality w_ineq
-};
-
-// one finite-difference column of one (edge, vertex) Jacobian block (BaseEdge::computeJacobian inner loop)
-struct ColTask {
-    int32_t kind;   // EdgeKind
-    int32_t k;      // stage of the edge
-    int32_t voff;   // offset of the perturbed component in the vertex storage
-    int32_t joff;   // offset of the column's first value in the Jacobian value array
-};
-
-// one bound row (computeDistanceFiniteCombinedBounds / bounds part of computeCombinedSparseJacobian)
-struct BoundTask {
-    int32_t voff;   // component in the vertex storage
-    int32_t row;    // residual row
-    int32_t joff;   // Jacobian value index (single entry)
-    int32_t pad;
-};
-
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):
 // defect edge k has the dense local Jacobian [A | B | C | d] w.r.t. (x_k, u_k, x_{k+1}, dt); entry = offset of the
 // column's first value in the Jacobian value array, -1 when that component is fixed.
@@ -80,9 +56,6 @@ struct Structure {
     double sq[CORBO_HIP_MAX_NX]{}, sr[CORBO_HIP_MAX_NU]{}, sqf[CORBO_HIP_MAX_NX]{};
     double dt_weight = 0;
 
-    std::vector<RowTask> row_tasks;
-    std::vector<ColTask> col_tasks;      // defect columns first (heavy), then the cheap ones
-    std::vector<BoundTask> bound_tasks;
     std::vector<StageCols> stage_cols;   // N-1 defect edges
     std::vector<int32_t> ineq_cols;      // (N-1)*nx: Jacobian value index of d(ineq_k)/d(x_k[i]) or -1
     std::vector<int32_t> ineq_rows;      // N-1 residual rows (or empty)
