@@ -148,6 +148,41 @@ def test_values_jacobian_vs_oracle_batch(oracle_mod):
         assert np.array_equal(jac[b][-s.dims.bounds:], jo[-s.dims.bounds:])  # bound rows: exactly -w / 0 / +w
 
 
+@pytest.mark.parametrize("scenario,N", [("unicycle", 129), ("unicycle", 160), ("unicycle", 256), ("vdp", 250), ("dint", 200),
+                                        ("unicycle", 3), ("unicycle", 64), ("unicycle", 101)])
+def test_horizon_lengths_vs_oracle(oracle_mod, scenario, N):
+    """Horizons other than the headline's: more stages than half a workgroup (the residual is not split over the waves, the
+    cyclic-reduction levels take several rounds, the LDS stride is a launch parameter), powers of two, N | 1 == 101 with N = 101,
+    the shortest grid -- residual, Jacobian and a 5-iteration solve of 3 seeded instances against the oracle."""
+    mk, w = problems.SCENARIOS[scenario]
+    d = mk(N=N)
+    B = 3
+    rng = np.random.default_rng(N)
+    if scenario == "unicycle":
+        x0, xf = problems.unicycle_instances(B, seed=4000 + N)
+    elif scenario == "vdp":
+        x0, xf = rng.uniform(-1, 1, (B, 2)), np.zeros((B, 2))
+    else:
+        x0, xf = np.zeros((B, 2)), np.tile([1.0, 0.0], (B, 1)) + rng.uniform(-0.1, 0.1, (B, 2))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(5)
+    s.setPenaltyWeights(*w)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*w)
+        assert np.abs(values[b] - vo).max() <= 1e-12 * max(w) * max(1.0, np.abs(vo).max())
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max())
+    s.solve()
+    X, chi2, status = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.abs(X - Xo).max() <= 2 * X_TOL, np.abs(X - Xo).max()
+    assert np.allclose(chi2, chi2o, rtol=CHI2_RTOL, atol=1e-12)
+
+
 def test_cfg5_quadrotor_batch_vs_oracle(oracle_mod):
     """cfg 5 family (quadrotor nx=12 nu=4, multiple shooting + RK4, u bounds, keep-out ball inequality): residual, Jacobian
     and the LM solve of a small batch at N=40 against the oracle; the big-block factor kernel (fp64 MFMA G^T G) is on this path."""
