@@ -602,6 +602,16 @@ __device__ __forceinline__ void bwd_solve_vec(const double (&L)[Nn][Nn], double 
     }
 }
 
+// value of lane SRC of the caller's quad (DPP quad_perm broadcast; all four lanes of the quad must be active)
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 #define SOA(arr, e, k) (arr)[(e) * NP + (k)]
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower triangle, i >= j
 #define STAMP(id)                                                       \
@@ -1118,46 +1128,50 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
         __syncthreads();
     }
     STAMP(5);
-    // ---- back-substitution down the elimination tree; the factor data of the NEXT level is fetched before the barrier
+    // ---- back-substitution down the elimination tree.  Four lanes per block again: lane q forms row q of
+    //      v = y - W_a x_a - W_b x_b, the three (two) numbers are broadcast inside the quad with DPP moves, every lane solves
+    //      L^T x = v and lane q stores x_q.
+    //      The factor data of the NEXT level (untouched by the back-substitution so far) is fetched before the barrier.
     {
-        int h = hroot >> 1;  // largest stride with eliminated blocks
-        double L[NX][NX], Wa[NX][NX], Wb[NX][NX], y[NX];
-        auto prefetch = [&](int hh) {
-            const int i = hh * (2 * tid + 1);
+        const int q  = tid & 3;
+        const int qc = (q < NX) ? q : NX - 1;   // spare lanes mirror the last row and store nothing
+        double L[NX][NX], wa[NX], wb[NX], yq = 0.0;
+        auto fetch = [&](int hh, int t) {
+            const int i = hh * (2 * t + 1);
             if (i < N) {
+                yq = SOA(gv, qc, i);
 #pragma unroll
-                for (int q = 0; q < NX; ++q) {
-                    y[q] = SOA(gv, q, i);
+                for (int c = 0; c < NX; ++c) {
+                    wa[c] = SOA(Wam, qc * NX + c, i);
+                    wb[c] = SOA(Wbm, qc * NX + c, i);
 #pragma unroll
-                    for (int c = 0; c < NX; ++c) {
-                        L[q][c]  = (c <= q) ? SOA(Dm, TRI(q, c), i) : 0.0;
-                        Wa[q][c] = SOA(Wam, q * NX + c, i);
-                        Wb[q][c] = SOA(Wbm, q * NX + c, i);
-                    }
+                    for (int r = 0; r < NX; ++r) L[r][c] = (c <= r) ? SOA(Dm, TRI(r, c), i) : 0.0;
                 }
             }
         };
-        prefetch(h);
+        auto finish = [&](int hh, int t) {
+            const int i = hh * (2 * t + 1);
+            const int a = i - hh, b = i + hh;
+            const int bc = (b < N) ? b : a;  // W_b is zero when there is no right neighbour: any finite operand will do
+            double v = yq;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) v -= wa[c] * SOA(gv, c, a) + wb[c] * SOA(gv, c, bc);
+            double x[NX];
+            x[0] = quad_bcast<0>(v);
+            if constexpr (NX > 1) x[1] = quad_bcast<1>(v);
+            if constexpr (NX > 2) x[2] = quad_bcast<2>(v);
+            bwd_solve_vec<NX>(L, x);
+            double xq = x[0];
+#pragma unroll
+            for (int r = 1; r < NX; ++r) xq = (q == r) ? x[r] : xq;
+            if (q < NX) SOA(gv, q, i) = xq;
+        };
+        int h = hroot >> 1;
+        fetch(h, tid >> 2);
         for (; h >= 1; h >>= 1) {
-            const int i = h * (2 * tid + 1);
-            if (i < N) {
-                const int a = i - h, b = i + h;
-                const int bc = (b < N) ? b : a;  // W_b is zero when there is no right neighbour: any finite operand will do
-                double xa[NX], xb[NX];
-#pragma unroll
-                for (int c = 0; c < NX; ++c) { xa[c] = SOA(gv, c, a); xb[c] = SOA(gv, c, bc); }
-#pragma unroll
-                for (int q = 0; q < NX; ++q) {
-                    double v = y[q];
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) v -= Wa[q][c] * xa[c] + Wb[q][c] * xb[c];
-                    y[q] = v;
-                }
-                bwd_solve_vec<NX>(L, y);
-#pragma unroll
-                for (int q = 0; q < NX; ++q) SOA(gv, q, i) = y[q];
-            }
-            if (h > 1) prefetch(h >> 1);  // touches only blocks that are still untouched by the back-substitution
+            if (h * (2 * (tid >> 2) + 1) < N) finish(h, tid >> 2);
+            for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }  // long horizons
+            if (h > 1) fetch(h >> 1, tid >> 2);
             __syncthreads();
         }
     }
