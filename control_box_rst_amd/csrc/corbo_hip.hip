@@ -412,16 +412,20 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
             long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
             const char* ptl_env = std::getenv("CORBO_HIP_PASS_TIMELINE");
             if (ptl_env && i == 0) {
-                HIP_TRY(hipMalloc((void**)&d_ptl, 130 * sizeof(long long)));
-                HIP_TRY(hipMemsetAsync(d_ptl, 0, 130 * sizeof(long long), st_of[i]));
+                HIP_TRY(hipMalloc((void**)&d_ptl, 146 * sizeof(long long)));
+                HIP_TRY(hipMemsetAsync(d_ptl, 0, 146 * sizeof(long long), st_of[i]));
                 fp.pass_timeline      = d_ptl;
+                if (fp.pass_timeline_inst == 0 || std::atoi(ptl_env) == 0) fp.timeline = d_ptl + 130;  // factor phases of instance 0 (last pass)
                 fp.pass_timeline_inst = std::atoi(ptl_env);
             }
-            struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); long long tl[130];
+            struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); long long tl[146];
                 if (hipMemcpy(tl, p, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess) {
                     fprintf(stderr, "pass timeline (sweep/factor cycles):");
                     for (int k = 0; k < 64 && tl[2 * k]; ++k) fprintf(stderr, " %lld/%lld", tl[2 * k + 1] ? tl[2 * k + 1] - tl[2 * k] : -1, (k < 63 && tl[2 * k + 2]) ? tl[2 * k + 2] - tl[2 * k + 1] : 0);
-                    fprintf(stderr, "\n"); }
+                    fprintf(stderr, "\n");
+                    const long long* f = tl + 130;
+                    if (f[7]) fprintf(stderr, "factor phases, last pass (cycles): load %lld | controls %lld | blocks + level 0 %lld | cyclic reduction %lld | root %lld | back-substitution %lld | trial iterate %lld\n",
+                                      f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5], f[7] - f[6]); }
                 (void)hipFree(p); } } ptl_guard{d_ptl, st_of[i]};
             if (!launch_pass(h->S.desc, fp, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
             HIP_TRY(hipGetLastError());

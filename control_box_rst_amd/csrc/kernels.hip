@@ -52,6 +52,18 @@ __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double
     return false;
 }
 
+// The 128-byte LM state of the instance lives in LDS while its workgroup works on it (the pass loop would otherwise pay a global
+// round trip at the start of every phase and for every read-modify-write of a counter); 8 lanes move it in / out.
+__device__ __forceinline__ void lm_state_in(LmState* sl, const LmState* sg, int tid)
+{
+    static_assert(sizeof(LmState) == 128, "LmState is moved as 8 x 16 bytes");
+    if (tid < 8) reinterpret_cast<double2*>(sl)[tid] = reinterpret_cast<const double2*>(sg)[tid];
+}
+__device__ __forceinline__ void lm_state_out(LmState* sg, const LmState* sl, int tid)
+{
+    if (tid < 8) reinterpret_cast<double2*>(sg)[tid] = reinterpret_cast<const double2*>(sl)[tid];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // edge / Jacobian sweep
 // ---------------------------------------------------------------------------------------------------------------------
@@ -66,7 +78,7 @@ __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double
 // dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: a factor phase follows in the same workgroup and takes the Jacobian
 // straight from jst when this phase refreshed it (flag word [0]).
 template <int DYN, int DEFECT, bool FUSED>
-__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
+__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -80,7 +92,6 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if constexpr (!STAGE) jst = js;
     int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
     const size_t xo = (size_t)inst * p.nvs;
-    LmState* st    = p.st ? p.st + inst : nullptr;
 
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
@@ -535,7 +546,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* red = smem + p.nvs;
     double* cs  = red + 10;
     double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
-    sweep_body<DYN, DEFECT, false>(p, p.mode, p.active_count, xs, red, cs, jst, blockIdx.x + p.inst0, threadIdx.x);
+    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 6) ? p.nnz_pad : 0));
+    const int inst = blockIdx.x + p.inst0;
+    if (p.st) { lm_state_in(sl, p.st + inst, threadIdx.x); __syncthreads(); }
+    sweep_body<DYN, DEFECT, false>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
+    if (p.st && p.mode >= 2) { __syncthreads(); lm_state_out(p.st + inst, sl, threadIdx.x); }
 }
 
 #pragma clang fp contract(fast)
@@ -635,7 +650,7 @@ struct FactorLds {
 // NPC > 0: the padded block count N | 1 as a compile-time constant (LDS element strides become immediate offsets of the DS
 // instructions instead of two VALU operations per access); 0: taken from the launch parameters.
 template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0>
-__device__ __forceinline__ void factor_body(const FactorParams& p, double* smem, const int inst, const int tid, const bool j_in_lds)
+__device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
@@ -655,7 +670,6 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
     double* red = gv + NX * NP;            // 24
     double* zu  = red + FactorLds<NX, NU>::RED;  // NU  (arrowhead only from here on)
     double* bv  = zu + NU * NP;            // NX      border column -> z
-    LmState* st    = p.st + inst;
     const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
     const int stop_in = st->stop;
     double mu = st->mu;
@@ -1128,6 +1142,11 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
         __syncthreads();
     }
     STAMP(5);
+    // the accepted iterate of this lane's stage (for x + delta below): requested now, the back-substitution hides the latency
+    double xk[S], xdt = 0.0;
+#pragma unroll
+    for (int e = 0; e < S; ++e) xk[e] = ((e < NX) ? has_block : has_stage) ? xin[k * S + e] : 0.0;
+    if (tid == 0) xdt = xin[p.off_dt];
     // ---- back-substitution down the elimination tree.  Four lanes per block again: lane q forms row q of
     //      v = y - W_a x_a - W_b x_b, the three (two) numbers are broadcast inside the quad with DPP moves, every lane solves
     //      L^T x = v and lane q stores x_q.
@@ -1185,7 +1204,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
         for (int q = 0; q < NX; ++q) {
             const double d = xfixed[q] ? 0.0 : SOA(gv, q, k);
             dn2 += d * d;
-            xt[k * S + q] = xin[k * S + q] + d;
+            xt[k * S + q] = xk[q] + d;
             if (dl) dl[k * S + q] = d;
         }
     }
@@ -1204,13 +1223,13 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, double* smem,
 #pragma unroll
         for (int a = 0; a < NU; ++a) {
             dn2 += y[a] * y[a];
-            xt[k * S + NX + a] = xin[k * S + NX + a] + y[a];
+            xt[k * S + NX + a] = xk[NX + a] + y[a];
             if (dl) dl[k * S + NX + a] = y[a];
         }
     }
     if (tid == 0) {
-        if (ARROW) { dn2 += ddt * ddt; xt[p.off_dt] = xin[p.off_dt] + ddt; }
-        else xt[p.off_dt] = xin[p.off_dt];
+        if (ARROW) { dn2 += ddt * ddt; xt[p.off_dt] = xdt + ddt; }
+        else xt[p.off_dt] = xdt;
         if (dl) dl[p.off_dt] = ARROW ? ddt : 0.0;
         if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (dl) dl[p.off_dt + 1] = 0.0; }
     }
@@ -1245,7 +1264,14 @@ template <int NX, int NU, int THREADS, bool ARROW>
 __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    factor_body<NX, NU, THREADS, ARROW>(p, smem, blockIdx.x + p.inst0, threadIdx.x, false);
+    const int inst = blockIdx.x + p.inst0;
+    const int ftot = FactorLds<NX, NU>::total(p.N | 1, ARROW);
+    LmState* sl = reinterpret_cast<LmState*>(smem + ((ftot > p.nnz_pad ? ftot : p.nnz_pad) + 1) / 2 * 2);
+    lm_state_in(sl, p.st + inst, threadIdx.x);
+    __syncthreads();
+    factor_body<NX, NU, THREADS, ARROW>(p, sl, smem, inst, threadIdx.x, false);
+    __syncthreads();
+    lm_state_out(p.st + inst, sl, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1675,15 +1701,20 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
     double* cs  = smem + sp.nnz_pad;
     double* xs  = smem + ((ftot > sp.nnz_pad + fp.N * Dy::NC ? ftot : sp.nnz_pad + fp.N * Dy::NC) + 1) / 2 * 2;
     int* flags  = reinterpret_cast<int*>(red + 8);
+    LmState* sl = reinterpret_cast<LmState*>(xs + sp.nvs);   // LM state of the instance, resident in LDS (nvs is even: 16-byte aligned)
+    lm_state_in(sl, fp.st + inst, tid);
+    if (tid == 0) flags[0] = 0;
+    __syncthreads();
     if constexpr (!LOOP) {
-        if (sp.mode == 3 && fp.st[inst].done) return;
-        if (tid == 0) flags[0] = 0;
+        if (sp.mode == 3 && sl->done) return;
+        sweep_body<DYN, DEFECT, true>(sp, sp.mode, sp.active_count, sl, xs, red, cs, jst, inst, tid);
+        __threadfence_block();  // this workgroup's residual / iterate stores are visible to its factor phase
         __syncthreads();
-        sweep_body<DYN, DEFECT, true>(sp, sp.mode, sp.active_count, xs, red, cs, jst, inst, tid);
-        __threadfence_block();  // this workgroup's residual / iterate / state stores are visible to its factor phase
-        __syncthreads();
-        if (fp.st[inst].done) return;
-        factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fp, smem, inst, tid, flags[0] != 0);
+        if (!sl->done) {
+            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fp, sl, smem, inst, tid, flags[0] != 0);
+            __syncthreads();
+        }
+        lm_state_out(fp.st + inst, sl, tid);
     }
     else {
         // run-to-completion: the instances are independent, so the workgroup walks its instance through the prologue and every LM
@@ -1704,19 +1735,22 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
             const SweepParams& spl  = (const SweepParams&)ka->s;
             const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;
             if (stamp) fpl.pass_timeline[2 * pass] = clock64();
-            if (tid_v == 0) flags[0] = 0;
-            __syncthreads();
-            sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, xs, red, cs, jst, inst_v, tid_v);
+            if (pass > 0) {
+                if (tid_v == 0) flags[0] = 0;
+                __syncthreads();
+            }
+            sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v);
             __threadfence_block();
             __syncthreads();
             if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
-            if (fpl.st[inst_v].done) break;
-            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, smem, inst_v, tid_v, flags[0] != 0);
+            if (sl->done) break;
+            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0);
             __threadfence_block();
             __syncthreads();
             mode = 3;
         }
-        if (tid_v == 0 && !fp.st[inst_v].done && sp.active_count) atomicAdd(sp.active_count, 1);  // pass limit hit
+        lm_state_out(fp.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM
+        if (tid_v == 0 && !sl->done && sp.active_count) atomicAdd(sp.active_count, 1);  // pass limit hit
     }
 }
 
@@ -1752,7 +1786,7 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     if (fp.N > SWEEP_THREADS) return false;
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
-    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs);                                  // + vertex values
+    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs) + sizeof(LmState);                // + vertex values + LM state
     const dim3 g(fp.batch), b(SWEEP_THREADS);
     // the run-to-completion kernel of the headline horizon (N = 100) is specialised on the LDS stride
     if (fp.loop_passes > 0) {
@@ -1782,6 +1816,7 @@ bool launch_factor_a(const FactorParams& p, hipStream_t stream)
 {
     size_t lds = factor_lds<NX, NU>(p.N, ARROW);
     if (lds < sizeof(double) * (size_t)p.nnz_pad) lds = sizeof(double) * (size_t)p.nnz_pad;  // Jacobian staging area
+    lds = ((lds + 15) & ~(size_t)15) + sizeof(LmState);                                      // + LM state
     if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128, ARROW>), dim3(p.batch), dim3(128), lds, stream, p);
     else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256, ARROW>), dim3(p.batch), dim3(256), lds, stream, p);
     else return false;
@@ -1801,7 +1836,7 @@ size_t sweep_lds_bytes(const SweepParams& p, int nc)
     // vertex values + reduction scratch + dynamics caches + Jacobian staging; the headline family must stay below 40 KB so that
     // four workgroups share a CU (1024 instances = one round over 256 CUs)
     const size_t stage = (p.nx <= 6) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
-    return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage);
+    return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage) + sizeof(LmState);
 }
 
 size_t factor_work_doubles(const corbo_hip_problem_desc& d)
