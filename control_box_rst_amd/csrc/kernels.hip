@@ -1277,11 +1277,16 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 // ---------------------------------------------------------------------------------------------------------------------
 // assemble + factor + solve for LARGE stage blocks (cfg 5: quadrotor, nx = 12, nu = 4, N = 200)
 //
-// One wavefront per instance.  The block-tridiagonal system does not fit LDS (3 x 144 doubles per stage), so the stages are
-// swept sequentially (a block Cholesky in natural order): per stage the wave forms G^T G of the local defect Jacobian
-// G = [A | B | C] (12 x 28 -> 28 x 28; fp64 MFMA v_mfma_f64_16x16x4f64, a real contraction here), eliminates the controls,
-// factors the 12 x 12 state block cooperatively, pushes the Schur complement to the next stage and writes the factors to an
-// HBM workspace; a backward sweep reads them back.  Same LM bookkeeping as factor_body.
+// The block-tridiagonal system does not fit LDS (3 x 144 doubles per stage), and the lane-per-block scheme does not apply to
+// 12 x 12 blocks.  Three kernels per factorisation, data handed over in an HBM workspace (BigWs, 572 doubles per stage):
+//   big_first_kernel    (first factorisation of a solve only; one wave per instance) mu = tau max diag(J^T J), stop flag;
+//   big_assemble_kernel (one wave per (stage, instance) -- everything that does not depend on the neighbours, N x batch waves):
+//                       G^T G of the local defect Jacobian G = [A | B | C] (12 x 28 -> 28 x 28; fp64 MFMA
+//                       v_mfma_f64_16x16x4f64, a real contraction here), elimination of the controls, the stage's parts of the
+//                       diagonal blocks of x_k and x_{k+1}, their coupling, the right-hand sides;
+//   big_chain_kernel    (one wave per instance) the sequential part: block Cholesky in natural order over the 12 x 12 state
+//                       blocks (Schur complement Y Y^T on the matrix cores), backward sweep, controls, trial iterate, LM state.
+// Same LM bookkeeping as factor_body.
 template <int NX, int NU>
 struct BigLds {
     static constexpr int W = 2 * NX + NU;
@@ -1306,41 +1311,33 @@ struct BigLds {
     static constexpr int RED = FIX + NX;              // [8]
     static constexpr int TOTAL = RED + 8;
     // HBM workspace per stage
-    static constexpr int WS_L = 0, WS_Y = NX * NX, WS_LUU = 2 * NX * NX, WS_ZX = WS_LUU + NU * NU, WS_ZP = WS_ZX + NU * NX,
-                         WS_YV = WS_ZP + NU * NX, WS_YU = WS_YV + NX, WS_STAGE = WS_YU + NU;
+    static constexpr int WS_L = 0;                    // [NX][NX] assemble: own parts of the diagonal block of x_k ; chain: L_k
+    static constexpr int WS_Y = WS_L + NX * NX;       // [NX][NX] assemble: coupling H'(x_{k+1}, x_k)              ; chain: Y_k
+    static constexpr int WS_DN = WS_Y + NX * NX;      // [NX][NX] this stage's contribution to the diagonal block of x_{k+1}
+    static constexpr int WS_LUU = WS_DN + NX * NX;
+    static constexpr int WS_ZX = WS_LUU + NU * NU, WS_ZP = WS_ZX + NU * NX;
+    static constexpr int WS_YV = WS_ZP + NU * NX;     // [NX] assemble: rhs part of x_k ; chain: y_k
+    static constexpr int WS_GN = WS_YV + NX;          // [NX] rhs contribution to x_{k+1}
+    static constexpr int WS_YU = WS_GN + NX;          // [NU]
+    static constexpr int WS_Y2 = WS_YU + NU;          // [1]  |y_u|^2 of the stage
+    static constexpr int WS_STAGE = (WS_Y2 + 2) & ~1;
 };
 
-template <int NX, int NU, bool USE_MFMA>
-__global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
-{
-    using BL         = BigLds<NX, NU>;
-    constexpr int S  = NX + NU;
-    constexpr int W  = BL::W;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* Gm = sm + BL::G;   double* rv = sm + BL::R;   double* Mm = sm + BL::M;   double* gm = sm + BL::GM;
-    double* Luu = sm + BL::LUU; double* Zx = sm + BL::ZX; double* Zp = sm + BL::ZP;  double* yu = sm + BL::YU;
-    double* Dc = sm + BL::DC;  double* Dn = sm + BL::DN;  double* Cx = sm + BL::CX;  double* gc = sm + BL::GC;
-    double* gn = sm + BL::GN;  double* xn = sm + BL::XN;  double* dg = sm + BL::DIAG; double* gd = sm + BL::GDIAG;
-    double* cin = sm + BL::CIN; double* fx = sm + BL::FIX; double* red = sm + BL::RED;
-
-    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
-    LmState* st = p.st + inst;
-    const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
-    int stop = st->stop;
-    double mu = st->mu;
-    const double mu_acc_in = st->mu_acc;
-    __syncthreads();
-    if (done) return;
-    const int N = p.N;
-    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
-    const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
-    const double* xin = p.x + (size_t)inst * p.nvs;
-    double* xt        = p.xt + (size_t)inst * p.nvs;
-    double* ws        = p.work + (size_t)inst * p.work_stride;
-
+// LDS pointers + the stage loader shared by the three kernels
+template <int NX, int NU>
+struct BigCtx {
+    using BL = BigLds<NX, NU>;
+    static constexpr int S = NX + NU;
+    static constexpr int W = BL::W;
+    double *Gm, *rv, *Mm, *gm, *Luu, *Zx, *Zp, *yu, *Dc, *Dn, *Cx, *gc, *gn, *xn, *dg, *gd, *cin, *fx, *red;
+    __device__ __forceinline__ explicit BigCtx(double* sm)
+        : Gm(sm + BL::G), rv(sm + BL::R), Mm(sm + BL::M), gm(sm + BL::GM), Luu(sm + BL::LUU), Zx(sm + BL::ZX), Zp(sm + BL::ZP),
+          yu(sm + BL::YU), Dc(sm + BL::DC), Dn(sm + BL::DN), Cx(sm + BL::CX), gc(sm + BL::GC), gn(sm + BL::GN), xn(sm + BL::XN),
+          dg(sm + BL::DIAG), gd(sm + BL::GDIAG), cin(sm + BL::CIN), fx(sm + BL::FIX), red(sm + BL::RED) {}
     // loads the local Jacobian, residual and single-entry rows of stage k (k == N-1: only the state block's diagonal rows)
-    auto load_stage = [&](int k) {
-        const bool stage = (k < N - 1);
+    __device__ __forceinline__ void load_stage(const FactorParams& p, const double* J, const double* val, int k, int lane) const
+    {
+        const bool stage = (k < p.N - 1);
         for (int e = lane; e < NX * W; e += 64) {
             const int r = e % NX, c = e / NX;   // column-major walk: consecutive lanes read consecutive Jacobian values
             double v = 0.0;
@@ -1365,289 +1362,411 @@ __global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
             cin[lane] = c;
         }
         if (lane == 0) red[7] = (stage && p.ineq_rows) ? val[p.ineq_rows[k]] : 0.0;
-    };
+    }
+};
 
-    // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1
-    if (first) {
-        double mx_d = -1e300, mx_g = 0.0;
-        for (int k = 0; k < N; ++k) {
-            __syncthreads();
-            if (k > 0 && lane < NX) { gn[lane] = Dn[lane]; xn[lane] = Dn[NX + lane]; }  // previous stage's C-column parts
-            load_stage(k);
-            __syncthreads();
-            if (lane < W) {
-                double dd = 0.0, gg = 0.0;
-                for (int r = 0; r < NX; ++r) { const double a = Gm[r * W + lane]; dd += a * a; gg -= a * rv[r]; }
-                if (lane < NX) {
-                    dd += dg[lane] + cin[lane] * cin[lane]; gg += gd[lane] - cin[lane] * red[7];
-                    if (k > 0) { dd += gn[lane]; gg += xn[lane]; }
-                    if (fx[lane] == 0.0) { mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+// ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118); one wave per instance
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
+{
+    using BL = BigLds<NX, NU>;
+    constexpr int S = NX + NU, W = BL::W;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const BigCtx<NX, NU> c(sm);
+    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
+    LmState* st = p.st + inst;
+    if (st->done || !st->first) return;
+    const int N = p.N;
+    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
+    const double* val = (st->vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
+    double mx_d = -1e300, mx_g = 0.0;
+    for (int k = 0; k < N; ++k) {
+        __syncthreads();
+        if (k > 0 && lane < NX) { c.gn[lane] = c.Dn[lane]; c.xn[lane] = c.Dn[NX + lane]; }  // previous stage's C-column parts
+        c.load_stage(p, J, val, k, lane);
+        __syncthreads();
+        if (lane < W) {
+            double dd = 0.0, gg = 0.0;
+            for (int r = 0; r < NX; ++r) { const double a = c.Gm[r * W + lane]; dd += a * a; gg -= a * c.rv[r]; }
+            if (lane < NX) {
+                dd += c.dg[lane] + c.cin[lane] * c.cin[lane]; gg += c.gd[lane] - c.cin[lane] * c.red[7];
+                if (k > 0) { dd += c.gn[lane]; gg += c.xn[lane]; }
+                if (c.fx[lane] == 0.0) { mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+            }
+            else if (lane < S) {
+                if (k < N - 1) { dd += c.dg[lane]; gg += c.gd[lane]; mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+            }
+            else { c.Dn[lane - S] = dd; c.Dn[NX + lane - S] = gg; }
+        }
+    }
+    mx_d = wave_max(mx_d);
+    mx_g = wave_max(mx_g);
+    if (lane == 0) {
+        double mu = LM_TAU * mx_d;
+        if (mu < 0) mu = 0;
+        st->mu   = mu;
+        st->stop = (mx_g <= LM_EPS1) ? 1 : 0;
+    }
+}
+
+// ---- per (stage, instance): everything of the factorisation that does not depend on the neighbouring stages
+template <int NX, int NU, bool USE_MFMA>
+__global__ __launch_bounds__(64) void big_assemble_kernel(const FactorParams p)
+{
+    using BL = BigLds<NX, NU>;
+    constexpr int S = NX + NU, W = BL::W;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const BigCtx<NX, NU> c(sm);
+    double *Gm = c.Gm, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *Dc = c.Dc, *Dn = c.Dn,
+           *Cx = c.Cx, *gc = c.gc, *gn = c.gn, *dg = c.dg, *gd = c.gd, *cin = c.cin, *fx = c.fx, *red = c.red;
+    const int k = blockIdx.x, inst = blockIdx.y + p.inst0, lane = threadIdx.x;
+    const LmState* st = p.st + inst;
+    if (st->done) return;
+    const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + st->mu;   // H_ii += mu on every inner pass, never undone (:135-138)
+    const int N = p.N;
+    const bool stage = (k < N - 1);
+    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
+    const double* val = (st->vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
+    double* wk        = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE;
+    c.load_stage(p, J, val, k, lane);
+    __syncthreads();
+    double y2 = 0.0;
+    if (stage) {
+        // M = G^T G  (W x NX times NX x W): fp64 matrix cores.  v_mfma_f64_16x16x4f64 layout (probed on gfx950 with
+        // tools/mfma_f64_layout.hip): A[i][k] and B[k][j] live in lane l with i|j = l % 16, k = l / 16; the result register r
+        // of lane l is D[4 r + l / 16][l % 16].  Output tiles (0,0), (1,0), (1,1) of the padded 32 x 32 product, K = NX in
+        // steps of 4; the strict upper triangle is mirrored.
+        if constexpr (USE_MFMA && W <= 32 && NX % 4 == 0) {
+            typedef double d4_t __attribute__((ext_vector_type(4)));
+            const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+            for (int tile = 0; tile < 3; ++tile) {
+                const int ti = (tile == 0) ? 0 : 1, tj = (tile == 2) ? 1 : 0;
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k0 = 0; k0 < NX; k0 += 4) {
+                    const int ia = 16 * ti + lj, ib = 16 * tj + lj;
+                    const double a = (ia < W) ? Gm[(k0 + lk) * W + ia] : 0.0;
+                    const double b = (ib < W) ? Gm[(k0 + lk) * W + ib] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
-                else if (lane < S) {
-                    if (k < N - 1) { dd += dg[lane]; gg += gd[lane]; mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + 4 * r + lk, j = 16 * tj + lj;
+                    if (i < W && j < W) {
+                        Mm[i * W + j] = acc[r];
+                        if (ti != tj) Mm[j * W + i] = acc[r];
+                    }
                 }
-                else { Dn[lane - S] = dd; Dn[NX + lane - S] = gg; }
             }
         }
-        mx_d = wave_max(mx_d);
-        mx_g = wave_max(mx_g);
-        stop = (mx_g <= LM_EPS1) ? 1 : 0;
-        mu   = LM_TAU * mx_d;
-        if (mu < 0) mu = 0;
+        else {
+            for (int e = lane; e < W * W; e += 64) {
+                const int i = e / W, j = e % W;
+                if (j > i) continue;
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v += Gm[r * W + i] * Gm[r * W + j];
+                Mm[i * W + j] = v;
+                Mm[j * W + i] = v;
+            }
+        }
+        if (lane < W) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) v -= Gm[r * W + lane] * rv[r];
+            gm[lane] = v;
+        }
+        __syncthreads();
+        // controls: Huu = M[uu] + diag + damping, Cholesky by one lane (NU x NU)
+        if (lane == 0) {
+            double H[NU][NU];
+#pragma unroll
+            for (int a = 0; a < NU; ++a)
+#pragma unroll
+                for (int b = 0; b < NU; ++b) H[a][b] = Mm[(NX + a) * W + NX + b] + ((a == b) ? dg[NX + a] + mu_eff : 0.0);
+            chol_inv<NU>(H);
+#pragma unroll
+            for (int a = 0; a < NU; ++a)
+#pragma unroll
+                for (int b = 0; b < NU; ++b) Luu[a * NU + b] = H[a][b];
+        }
+        __syncthreads();
+        // Zx = L^{-1} H(u, x_k), Zp = L^{-1} H(u, x_{k+1}), yu = L^{-1} gu : one lane per column
+        if (lane < 2 * NX + 1) {
+            double col[NU];
+#pragma unroll
+            for (int a = 0; a < NU; ++a)
+                col[a] = (lane < NX) ? Mm[(NX + a) * W + lane] : (lane < 2 * NX) ? Mm[(NX + a) * W + S + (lane - NX)] : gm[NX + a] + gd[NX + a];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                double v = col[a];
+#pragma unroll
+                for (int b = 0; b < a; ++b) v -= Luu[a * NU + b] * col[b];
+                col[a] = v * Luu[a * NU + a];
+            }
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                if (lane < NX) Zx[a * NX + lane] = col[a];
+                else if (lane < 2 * NX) Zp[a * NX + lane - NX] = col[a];
+                else { yu[a] = col[a]; y2 += col[a] * col[a]; }
+            }
+        }
         __syncthreads();
     }
-    const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;
+    // own parts of state block k: M[xx] - Zx^T Zx + diag + c c^T + damping ; the coupling ; the contribution to block k+1
+    for (int e = lane; e < NX * NX; e += 64) {
+        const int i = e / NX, j = e % NX;
+        double d = 0.0, cx = 0.0, dn = 0.0;
+        if (stage) {
+            d  = Mm[i * W + j] + cin[i] * cin[j];
+            cx = Mm[(S + i) * W + j];
+            dn = Mm[(S + i) * W + S + j];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                d -= Zx[a * NX + i] * Zx[a * NX + j];
+                cx -= Zp[a * NX + i] * Zx[a * NX + j];
+                dn -= Zp[a * NX + i] * Zp[a * NX + j];
+            }
+        }
+        if (i == j) d += dg[i] + mu_eff;
+        wk[BL::WS_L + e] = d; wk[BL::WS_Y + e] = cx; wk[BL::WS_DN + e] = dn;
+    }
+    if (lane < NX) {
+        double g = gd[lane], g2 = 0.0;
+        if (stage) {
+            g += gm[lane] - cin[lane] * red[7];
+            g2 = gm[S + lane];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { g -= Zx[a * NX + lane] * yu[a]; g2 -= Zp[a * NX + lane] * yu[a]; }
+        }
+        wk[BL::WS_YV + lane] = g; wk[BL::WS_GN + lane] = g2;
+    }
+    if (stage) {
+        if (lane < NU * NU) wk[BL::WS_LUU + lane] = Luu[lane];
+        if (lane < NU * NX) { wk[BL::WS_ZX + lane] = Zx[lane]; wk[BL::WS_ZP + lane] = Zp[lane]; }
+        if (lane < NU) wk[BL::WS_YU + lane] = yu[lane];
+    }
+    if (lane == 2 * NX) wk[BL::WS_Y2] = y2;   // (the lane that formed y_u; 0 for the last block)
+}
+
+// value of lane `src` (uniform / compile-time index) for every lane: two v_readlane_b32, the result lives in scalar registers
+__device__ __forceinline__ double lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- per instance: the sequential part.  Lane i < NX owns ROW i of the state block in registers: the 12 x 12 Cholesky, the
+//      triangular solves and the back-substitution run on register rows with v_readlane broadcasts -- no LDS round trip and no
+//      barrier per pivot; only the Schur complement Y Y^T goes through LDS (operands of the matrix-core instruction).  The
+//      assembled data of the next stage (forward) / the factors of the previous stage (backward) are in flight while the current
+//      one is worked on.
+template <int NX, int NU, bool USE_MFMA>
+__global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
+{
+    using BL = BigLds<NX, NU>;
+    constexpr int S = NX + NU;
+    static_assert(NX <= 16 && NU <= NX, "row-per-lane mapping of the chain kernel");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const BigCtx<NX, NU> c(sm);
+    double *Dn = c.Dn, *Cx = c.Cx;
+    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
+    const int row = (lane < NX) ? lane : NX - 1;   // lanes >= NX mirror the last row (their results are never stored)
+    const bool own = (lane < NX);
+    LmState* st = p.st + inst;
+    const int done = st->done;
+    int stop = st->stop;
+    const double mu = st->mu;
+    const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + mu;
+    if (done) return;
+    const int N = p.N;
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    double* xt        = p.xt + (size_t)inst * p.nvs;
+    double* ws        = p.work + (size_t)inst * p.work_stride;
 
     double y2 = 0.0;
     for (int e = lane; e < NX * NX; e += 64) Dn[e] = 0.0;
-    if (lane < NX) gn[lane] = 0.0;
+    double gn_r = 0.0;   // Schur mailbox of the right-hand side (row of this lane)
     // ---- forward sweep over the stages
+    double pd[NX], pc[NX], pn[NX], pg = 0.0, pgn = 0.0, py2 = 0.0;
+    int pfix = 0;
+    auto fetch = [&](int k) {
+        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {
+            pd[cc] = wk[BL::WS_L + row * NX + cc];
+            pc[cc] = wk[BL::WS_Y + row * NX + cc];
+            pn[cc] = wk[BL::WS_DN + row * NX + cc];
+        }
+        pg  = wk[BL::WS_YV + row];
+        pgn = wk[BL::WS_GN + row];
+        py2 = wk[BL::WS_Y2];
+        pfix = p.comp[k * S + row].fixed;
+    };
+    fetch(0);
+    __syncthreads();
     for (int k = 0; k < N; ++k) {
         const bool stage = (k < N - 1);
-        __syncthreads();
-        for (int e = lane; e < NX * NX; e += 64) Dc[e] = Dn[e];   // Schur mailbox of the previous stage
-        if (lane < NX) gc[lane] = gn[lane];
-        load_stage(k);
-        __syncthreads();
+        // state block k = own parts + Schur mailbox of the previous stage; fixed components: identity rows / columns, zero rhs
+        const unsigned long long fmask = __ballot(pfix != 0 && own);
+        const bool fixed_r = (fmask >> row) & 1ull;
+        double d[NX], cr[NX], g;
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {
+            double v = pd[cc] + Dn[row * NX + cc];
+            if (fixed_r || ((fmask >> cc) & 1ull)) v = (row == cc) ? 1.0 : 0.0;
+            d[cc]  = v;
+            cr[cc] = pc[cc];
+        }
+        g = fixed_r ? 0.0 : pg + gn_r;
+        const double gnk = pgn;
+        y2 += (lane == 0) ? py2 : 0.0;
+        __syncthreads();   // every lane has taken its mailbox row
+        if (own) {
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = pn[cc];
+        }
+        if (k + 1 < N) fetch(k + 1);
+        // Cholesky, right-looking over register rows: after step j, d[j] of lane i > j is L[i][j], of lane j it is 1 / L[j][j]
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const double inv = rsqrt(lane_bcast(d[j], j));
+            d[j] = (lane == j) ? inv : d[j] * inv;
+#pragma unroll
+            for (int cc = j + 1; cc < NX; ++cc) d[cc] -= d[j] * lane_bcast(d[j], cc);   // (rows above cc hold unused upper entries)
+        }
+        // Y = C L^{-T}: row i of Y from row i of C; y = L^{-1} g across the lanes
+        double yr[NX];
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {
+            double v = cr[cc];
+#pragma unroll
+            for (int t = 0; t < cc; ++t) v -= yr[t] * lane_bcast(d[t], cc);
+            yr[cc] = v * lane_bcast(d[cc], cc);
+        }
+        double yk = g;   // becomes y_k[row]
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const double yj = lane_bcast(yk, j) * lane_bcast(d[j], j);   // y_j = (g_j - sum_{t<j} L[j][t] y_t) / L[j][j]
+            yk = (lane == j) ? yj : ((lane > j) ? yk - d[j] * yj : yk);
+        }
+        if (own) y2 += yk * yk;
+        // Schur complement to the next block: D_{k+1} parts -= Y Y^T (matrix cores, operands through LDS), rhs -= Y y
+        double* wk = ws + (size_t)k * BL::WS_STAGE;
+        if (own) {
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) {
+                Cx[row * NX + cc] = yr[cc];
+                wk[BL::WS_L + row * NX + cc] = d[cc];
+                wk[BL::WS_Y + row * NX + cc] = yr[cc];
+            }
+            wk[BL::WS_YV + row] = yk;
+        }
         if (stage) {
-            // M = G^T G  (W x NX times NX x W): fp64 matrix cores.  v_mfma_f64_16x16x4f64 layout (probed on gfx950 with
-            // tools/mfma_f64_layout.hip): A[i][k] and B[k][j] live in lane l with i|j = l % 16, k = l / 16; the result register r
-            // of lane l is D[4 r + l / 16][l % 16].  Output tiles (0,0), (1,0), (1,1) of the padded 32 x 32 product, K = NX in
-            // steps of 4; the strict upper triangle is mirrored.
-            if constexpr (USE_MFMA && W <= 32 && NX % 4 == 0) {
+            double v = gnk;
+#pragma unroll
+            for (int t = 0; t < NX; ++t) v -= yr[t] * lane_bcast(yk, t);
+            gn_r = v;
+            __syncthreads();
+            if constexpr (USE_MFMA && NX <= 16 && NX % 4 == 0) {
                 typedef double d4_t __attribute__((ext_vector_type(4)));
                 const int lj = lane & 15, lk = lane >> 4;
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int tile = 0; tile < 3; ++tile) {
-                    const int ti = (tile == 0) ? 0 : 1, tj = (tile == 2) ? 1 : 0;
-                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < NX; k0 += 4) {   // (Y Y^T)[i][j] = sum_t Y[i][t] Y[j][t]: A[i][t] = Y[i][t], B[t][j] = Y[j][t]
+                    const double a = (lj < NX) ? Cx[lj * NX + k0 + lk] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+                }
 #pragma unroll
-                    for (int k0 = 0; k0 < NX; k0 += 4) {
-                        const int ia = 16 * ti + lj, ib = 16 * tj + lj;
-                        const double a = (ia < W) ? Gm[(k0 + lk) * W + ia] : 0.0;
-                        const double b = (ib < W) ? Gm[(k0 + lk) * W + ib] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * ti + 4 * r + lk, j = 16 * tj + lj;
-                        if (i < W && j < W) {
-                            Mm[i * W + j] = acc[r];
-                            if (ti != tj) Mm[j * W + i] = acc[r];
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * r + lk, j = lj;
+                    if (i < NX && j < NX) Dn[i * NX + j] -= acc[r];
                 }
             }
             else {
-                for (int e = lane; e < W * W; e += 64) {
-                    const int i = e / W, j = e % W;
-                    if (j > i) continue;
-                    double v = 0.0;
+                for (int e = lane; e < NX * NX; e += 64) {
+                    const int i = e / NX, j = e % NX;
+                    double v2 = Dn[e];
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) v += Gm[r * W + i] * Gm[r * W + j];
-                    Mm[i * W + j] = v;
-                    Mm[j * W + i] = v;
+                    for (int t = 0; t < NX; ++t) v2 -= Cx[i * NX + t] * Cx[j * NX + t];
+                    Dn[e] = v2;
                 }
             }
-            if (lane < W) {
-                double v = 0.0;
-#pragma unroll
-                for (int r = 0; r < NX; ++r) v -= Gm[r * W + lane] * rv[r];
-                gm[lane] = v;
-            }
-            __syncthreads();
-            // controls: Huu = M[uu] + diag + damping, Cholesky by one lane (NU x NU)
-            if (lane == 0) {
-                double H[NU][NU];
-#pragma unroll
-                for (int a = 0; a < NU; ++a)
-#pragma unroll
-                    for (int b = 0; b < NU; ++b) H[a][b] = Mm[(NX + a) * W + NX + b] + ((a == b) ? dg[NX + a] + mu_eff : 0.0);
-                chol_inv<NU>(H);
-#pragma unroll
-                for (int a = 0; a < NU; ++a)
-#pragma unroll
-                    for (int b = 0; b < NU; ++b) Luu[a * NU + b] = H[a][b];
-            }
-            __syncthreads();
-            // Zx = L^{-1} H(u, x_k), Zp = L^{-1} H(u, x_{k+1}), yu = L^{-1} gu : one lane per column
-            if (lane < 2 * NX + 1) {
-                double col[NU];
-#pragma unroll
-                for (int a = 0; a < NU; ++a)
-                    col[a] = (lane < NX) ? Mm[(NX + a) * W + lane] : (lane < 2 * NX) ? Mm[(NX + a) * W + S + (lane - NX)] : gm[NX + a] + gd[NX + a];
-#pragma unroll
-                for (int a = 0; a < NU; ++a) {
-                    double v = col[a];
-#pragma unroll
-                    for (int b = 0; b < a; ++b) v -= Luu[a * NU + b] * col[b];
-                    col[a] = v * Luu[a * NU + a];
-                }
-#pragma unroll
-                for (int a = 0; a < NU; ++a) {
-                    if (lane < NX) Zx[a * NX + lane] = col[a];
-                    else if (lane < 2 * NX) Zp[a * NX + lane - NX] = col[a];
-                    else { yu[a] = col[a]; y2 += col[a] * col[a]; }
-                }
-            }
-            __syncthreads();
-        }
-        // state block k: D_k = mailbox + M[xx] - Zx^T Zx + diag + c c^T + damping ; coupling and the mailbox for k+1
-        for (int e = lane; e < NX * NX; e += 64) {
-            const int i = e / NX, j = e % NX;
-            double d = Dc[e], cx = 0.0, dn = 0.0;
-            if (stage) {
-                d += Mm[i * W + j] + cin[i] * cin[j];
-                cx = Mm[(S + i) * W + j];
-                dn = Mm[(S + i) * W + S + j];
-#pragma unroll
-                for (int a = 0; a < NU; ++a) {
-                    d -= Zx[a * NX + i] * Zx[a * NX + j];
-                    cx -= Zp[a * NX + i] * Zx[a * NX + j];
-                    dn -= Zp[a * NX + i] * Zp[a * NX + j];
-                }
-            }
-            if (i == j) d += dg[i] + mu_eff;
-            if (fx[i] != 0.0 || fx[j] != 0.0) d = (i == j) ? 1.0 : 0.0;
-            Dc[e] = d; Cx[e] = cx; Dn[e] = dn;
-        }
-        if (lane < NX) {
-            double g = gc[lane] + gd[lane], g2 = 0.0;
-            if (stage) {
-                g += gm[lane] - cin[lane] * red[7];
-                g2 = gm[S + lane];
-#pragma unroll
-                for (int a = 0; a < NU; ++a) { g -= Zx[a * NX + lane] * yu[a]; g2 -= Zp[a * NX + lane] * yu[a]; }
-            }
-            if (fx[lane] != 0.0) g = 0.0;
-            gc[lane] = g; gn[lane] = g2;
         }
         __syncthreads();
-        // Cholesky of D_k, right-looking, lanes over the trailing entries; diagonal stored inverted
-        for (int j = 0; j < NX; ++j) {
-            const double inv = rsqrt(Dc[j * NX + j]);
-            __syncthreads();
-            if (lane == 0) Dc[j * NX + j] = inv;
-            if (lane > 0 && j + lane < NX) Dc[(j + lane) * NX + j] *= inv;
-            __syncthreads();
-            const int m = NX - 1 - j;   // trailing size
-            for (int e = lane; e < m * m; e += 64) {
-                const int i = j + 1 + e / m, c = j + 1 + e % m;
-                if (c <= i) Dc[i * NX + c] -= Dc[i * NX + j] * Dc[c * NX + j];
-            }
-            __syncthreads();
-        }
-        // Y = Cx L^{-T} (one lane per row), y = L^{-1} g (lane NX)
-        if (lane < NX) {
-            double yrow[NX];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) {
-                double v = Cx[lane * NX + c];
-#pragma unroll
-                for (int t = 0; t < c; ++t) v -= yrow[t] * Dc[c * NX + t];
-                yrow[c] = v * Dc[c * NX + c];
-            }
-#pragma unroll
-            for (int c = 0; c < NX; ++c) Cx[lane * NX + c] = yrow[c];
-        }
-        else if (lane == NX) {
-            double y[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double v = gc[i];
-#pragma unroll
-                for (int t = 0; t < i; ++t) v -= Dc[i * NX + t] * y[t];
-                y[i] = v * Dc[i * NX + i];
-                y2 += y[i] * y[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) gc[i] = y[i];
-        }
-        __syncthreads();
-        // Schur complement to the next block; factors to the HBM workspace
-        if (stage) {
-            for (int e = lane; e < NX * NX; e += 64) {
-                const int i = e / NX, j = e % NX;
-                double v = Dn[e];
-#pragma unroll
-                for (int t = 0; t < NX; ++t) v -= Cx[i * NX + t] * Cx[j * NX + t];
-                Dn[e] = v;
-            }
-            if (lane < NX) {
-                double v = gn[lane];
-#pragma unroll
-                for (int t = 0; t < NX; ++t) v -= Cx[lane * NX + t] * gc[t];
-                gn[lane] = v;
-            }
-        }
-        double* wk = ws + (size_t)k * BL::WS_STAGE;
-        for (int e = lane; e < NX * NX; e += 64) { wk[BL::WS_L + e] = Dc[e]; wk[BL::WS_Y + e] = Cx[e]; }
-        if (lane < NU * NU) wk[BL::WS_LUU + lane] = Luu[lane];
-        if (lane < NU * NX) { wk[BL::WS_ZX + lane] = Zx[lane]; wk[BL::WS_ZP + lane] = Zp[lane]; }
-        if (lane < NX) wk[BL::WS_YV + lane] = gc[lane];
-        if (lane < NU) wk[BL::WS_YU + lane] = yu[lane];
     }
+    __threadfence_block();
     __syncthreads();
-    // ---- backward sweep
-    double dn2 = 0.0;
+    // ---- backward sweep: lane i owns COLUMN i of L_k and Y_k; x_{k+1} stays in the lanes' registers
+    double dn2 = 0.0, xn_r = 0.0;
+    double bl[NX], by[NX], byv = 0.0, bzx[NX], bzp[NX], byu = 0.0, bluu[NU], bx = 0.0;
+    int bfix = 0;
+    const int urow = (lane < NU) ? lane : NU - 1;
+    auto fetch_b = [&](int k) {
+        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+        const bool stage = (k < N - 1);
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+            bl[t] = wk[BL::WS_L + t * NX + row];   // L[t][row]  (t >= row; 1 / L[row][row] at t == row)
+            by[t] = wk[BL::WS_Y + t * NX + row];   // Y[t][row]
+            bzx[t] = stage ? wk[BL::WS_ZX + urow * NX + t] : 0.0;
+            bzp[t] = stage ? wk[BL::WS_ZP + urow * NX + t] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < NU; ++b) bluu[b] = stage ? wk[BL::WS_LUU + b * NU + urow] : 1.0;   // Luu[b][urow]
+        byv  = wk[BL::WS_YV + row];
+        byu  = stage ? wk[BL::WS_YU + urow] : 0.0;
+        bfix = p.comp[k * S + row].fixed;
+        bx   = (lane < NX || (stage && lane < S)) ? xin[k * S + lane] : 0.0;
+    };
+    fetch_b(N - 1);
     for (int k = N - 1; k >= 0; --k) {
         const bool stage = (k < N - 1);
-        const double* wk = ws + (size_t)k * BL::WS_STAGE;
-        __threadfence_block();
-        __syncthreads();
-        for (int e = lane; e < NX * NX; e += 64) { Dc[e] = wk[BL::WS_L + e]; Cx[e] = wk[BL::WS_Y + e]; }
-        if (lane < NU * NU) Luu[lane] = wk[BL::WS_LUU + lane];
-        if (lane < NU * NX) { Zx[lane] = wk[BL::WS_ZX + lane]; Zp[lane] = wk[BL::WS_ZP + lane]; }
-        if (lane < NX) gc[lane] = wk[BL::WS_YV + lane];
-        if (lane < NU) yu[lane] = wk[BL::WS_YU + lane];
-        if (lane < NX) fx[lane] = p.comp[k * S + lane].fixed ? 1.0 : 0.0;
-        __syncthreads();
-        if (lane < NX && stage) {  // t = y - Y^T x_{k+1}
-            double v = gc[lane];
+        double Lc[NX], v = byv, zx[NX], zp[NX], lu[NU];
+        const double yu_r = byu, xin_r = bx;
+        const bool fixed_r = (bfix != 0);
 #pragma unroll
-            for (int t = 0; t < NX; ++t) v -= Cx[t * NX + lane] * xn[t];
-            gc[lane] = v;
+        for (int t = 0; t < NX; ++t) {
+            Lc[t] = bl[t]; zx[t] = bzx[t]; zp[t] = bzp[t];
+            if (stage) v -= by[t] * lane_bcast(xn_r, t);   // t = y - Y^T x_{k+1}
         }
-        __syncthreads();
-        if (lane == 0) {  // x_k = L^{-T} t
-            double x[NX];
 #pragma unroll
-            for (int i = NX - 1; i >= 0; --i) {
-                double v = gc[i];
+        for (int b = 0; b < NU; ++b) lu[b] = bluu[b];
+        if (k > 0) fetch_b(k - 1);
+        // x_k = L^{-T} t across the lanes
+        double xk = 0.0;
 #pragma unroll
-                for (int t = i + 1; t < NX; ++t) v -= Dc[t * NX + i] * x[t];
-                x[i] = v * Dc[i * NX + i];
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) gc[i] = (fx[i] != 0.0) ? 0.0 : x[i];
+        for (int j = NX - 1; j >= 0; --j) {
+            const double xj = lane_bcast(v * Lc[j], j);       // lane j: v_j / L[j][j]
+            if (lane == j) xk = xj;
+            v -= (lane < j) ? Lc[j] * xj : 0.0;               // lane i < j: L[j][i] x_j
         }
-        __syncthreads();
-        if (lane == 0 && stage) {  // u_k = Luu^{-T} (yu - Zx x_k - Zp x_{k+1})
-            double u[NU];
+        if (fixed_r) xk = 0.0;
+        if (!own) xk = 0.0;
+        // u_k = Luu^{-T} (yu - Zx x_k - Zp x_{k+1}) : lane a < NU owns row a of Zx, Zp and column a of Luu
+        double uk = 0.0;
+        if (stage) {
+            double w = yu_r;
 #pragma unroll
-            for (int a = 0; a < NU; ++a) {
-                double v = yu[a];
-#pragma unroll
-                for (int c = 0; c < NX; ++c) v -= Zx[a * NX + c] * gc[c] + Zp[a * NX + c] * xn[c];
-                u[a] = v;
-            }
+            for (int t = 0; t < NX; ++t) w -= zx[t] * lane_bcast(xk, t) + zp[t] * lane_bcast(xn_r, t);
 #pragma unroll
             for (int a = NU - 1; a >= 0; --a) {
-                double v = u[a];
-#pragma unroll
-                for (int b = a + 1; b < NU; ++b) v -= Luu[b * NU + a] * u[b];
-                u[a] = v * Luu[a * NU + a];
+                const double ua = lane_bcast(w * lu[a], a);   // lane a: w_a / Luu[a][a]
+                if (lane == a) uk = ua;
+                w -= (lane < a) ? lu[a] * ua : 0.0;           // lane b < a: Luu[a][b] u_a
             }
+            if (lane >= NU) uk = 0.0;
+        }
+        dn2 += xk * xk + uk * uk;
+        // trial iterate: lanes 0..NX-1 the state, lanes NX..S-1 the controls (moved there with one more broadcast round)
+        double ush = 0.0;
 #pragma unroll
-            for (int a = 0; a < NU; ++a) { dn2 += u[a] * u[a]; xt[k * S + NX + a] = xin[k * S + NX + a] + u[a]; }
-        }
-        if (lane < NX) {
-            const double d = gc[lane];
-            dn2 += d * d;
-            xt[k * S + lane] = xin[k * S + lane] + d;
-        }
-        __syncthreads();
-        if (lane < NX) xn[lane] = gc[lane];
+        for (int a = 0; a < NU; ++a) { const double ua = lane_bcast(uk, a); if (lane == NX + a) ush = ua; }
+        if (lane < NX) xt[k * S + lane] = xin_r + xk;
+        else if (lane < S && stage) xt[k * S + lane] = xin_r + ush;
+        xn_r = xk;
     }
     if (lane == 0) {
         xt[p.off_dt] = xin[p.off_dt];
@@ -1656,7 +1775,6 @@ __global__ __launch_bounds__(64) void factor_big_kernel(const FactorParams p)
     y2  = wave_sum(y2);
     dn2 = wave_sum(dn2);
     if (lane == 0) {
-        st->mu     = mu;
         st->mu_acc = mu_eff;
         st->first  = 0;
         st->fresh  = 0;
@@ -1887,7 +2005,9 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
     if (d.nx == 12 && d.nu == 4) {
         if (p.dt_free || !p.work) return false;
         const size_t lds = sizeof(double) * (size_t)BigLds<12, 4>::TOTAL;
-        hipLaunchKernelGGL((factor_big_kernel<12, 4, true>), dim3(p.batch), dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), lds, stream, p);   // returns at once unless st->first
+        hipLaunchKernelGGL((big_assemble_kernel<12, 4, true>), dim3(p.N, p.batch), dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(64), lds, stream, p);
         return true;
     }
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
