@@ -456,7 +456,73 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     }
                 }
             }
-            else {  // defects that evaluate the dynamics off the grid states (midpoint, RK4 shooting): full re-evaluation per column
+            else if constexpr (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING) {
+                // e = RK4(x_k, u_k, dt) - x_{k+1} (multiple_shooting_edges.h:125-134).  Per column the reference re-integrates; here
+                //  * an x_{k+1} column reuses the end state of the unperturbed step (same inputs, same bits) and only redoes the
+                //    subtraction,
+                //  * an (x_k, u_k) column that cannot change what prepare() sees at any Runge-Kutta stage (Dynamics<>::
+                //    RK4_CACHE_DEP_COLS) re-integrates with the caches of the unperturbed step (quadrotor: 7 of 16 columns skip
+                //    24 sin/cos evaluations each),
+                //  * the others re-integrate in full.
+                double loc[W], ck[4][NC], xe0[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { loc[i] = x1[i]; loc[S + i] = x2[i]; }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) loc[NX + i] = u1[i];
+                rk4_end_state<DYN, false>(loc, loc + NX, dt0, p.mp.dyn, ck, xe0);
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    const bool mine = (((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (g == 1);
+                    const int jo    = sc[c];
+                    if (!mine || jo < 0) continue;
+                    double e[2][NX];
+                    const double keep = loc[c];
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        loc[c] += (side == 0) ? delta : neg2delta;
+                        double xe[NX];
+                        if (((Dy::RK4_CACHE_DEP_COLS >> c) & 1u) != 0u) {   // (compile-time after unrolling)
+                            double ct[4][NC];
+                            rk4_end_state<DYN, false>(loc, loc + NX, dt0, p.mp.dyn, ct, xe);
+                        }
+                        else rk4_end_state<DYN, true>(loc, loc + NX, dt0, p.mp.dyn, ck, xe);
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) e[side][r] = xe[r] - x2[r];
+                    }
+                    loc[c] = keep;
+                    emit(jo, e[0], e[1]);
+                }
+#pragma unroll
+                for (int c = S; c < W; ++c) {
+                    const bool mine = (((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (g == 1);
+                    const int jo    = sc[c];
+                    if (!mine || jo < 0) continue;
+                    double e[2][NX];
+                    double xa = x2[c - S];
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        xa += (side == 0) ? delta : neg2delta;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) e[side][r] = xe0[r] - ((r == c - S) ? xa : x2[r]);
+                    }
+                    emit(jo, e[0], e[1]);
+                }
+                const int jo = sc[S + NX];
+                if (g == 1 && jo >= 0) {  // free dt: every stage changes
+                    double e[2][NX];
+                    double da = dt0;
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        da += (side == 0) ? delta : neg2delta;
+                        double ct[4][NC], xe[NX];
+                        rk4_end_state<DYN, false>(loc, loc + NX, da, p.mp.dyn, ct, xe);
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) e[side][r] = xe[r] - x2[r];
+                    }
+                    emit(jo, e[0], e[1]);
+                }
+            }
+            else {  // midpoint collocation evaluates the dynamics off the grid states: full re-evaluation per column
                 double loc[W];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { loc[i] = x1[i]; loc[S + i] = x2[i]; }

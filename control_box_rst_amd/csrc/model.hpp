@@ -32,6 +32,7 @@ template <int DYN> struct Dynamics;
 template <> struct Dynamics<CORBO_HIP_DYN_VAN_DER_POL> {  // nonlinear_benchmark_systems.h:52-60
     static constexpr int NX = 2, NU = 1, NC = 1;
     static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b11000u;
     __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
     __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
     {
@@ -44,6 +45,7 @@ template <> struct Dynamics<CORBO_HIP_DYN_VAN_DER_POL> {  // nonlinear_benchmark
 template <> struct Dynamics<CORBO_HIP_DYN_SERIAL_INTEGRATOR> {  // linear_benchmark_systems.h:72-83, order 2 (double integrator)
     static constexpr int NX = 2, NU = 1, NC = 1;
     static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b11000u;
     __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
     __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
     {
@@ -55,6 +57,8 @@ template <> struct Dynamics<CORBO_HIP_DYN_SERIAL_INTEGRATOR> {  // linear_benchm
 template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u1 cos(th), ydot = u1 sin(th), thdot = u2
     static constexpr int NX = 3, NU = 2, NC = 2;
     static constexpr unsigned CACHE_XMASK = 0b100u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0b10100u;      // theta, u2 (theta' = u2)
+    static constexpr unsigned RK4_GROUP1_COLS    = 0b11110000u;   // u2, x_{k+1}
     __device__ static __forceinline__ void prepare(const double* x, const double*, double* c) { sincos(x[2], &c[0], &c[1]); }
     __device__ static __forceinline__ void eval(const double*, const double* c, const double* u, const double*, double* f)
     {
@@ -67,6 +71,11 @@ template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u
 template <> struct Dynamics<CORBO_HIP_DYN_QUADROTOR> {  // user plug-in (DESIGN.md "quadrotor"); prm = g, m, Ixx, Iyy, Izz
     static constexpr int NX = 12, NU = 4, NC = 6;
     static constexpr unsigned CACHE_XMASK = 0b111000000u;  // roll, pitch, yaw
+    // the angles at the later Runge-Kutta stages depend on the angles, the body rates and (through the rates) the torques only
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0b1110111111000000u;                        // x[6..11], u[1..3]
+    // two lanes per stage: group 1 takes x[3..5], x[11], the controls and the (trivial) x_{k+1} columns -- 4 columns that
+    // re-evaluate sin/cos and 4 that do not; group 0 the other 5 + 3
+    static constexpr unsigned RK4_GROUP1_COLS = 0b1111111111111111100000111000u;
     __device__ static __forceinline__ void prepare(const double* x, const double*, double* c)
     {
         sincos(x[6], &c[0], &c[1]);  // sphi, cphi
@@ -106,6 +115,10 @@ template <int DEFECT> struct DefectTraits {
     static constexpr bool cached = (DEFECT == CORBO_HIP_DEFECT_FORWARD || DEFECT == CORBO_HIP_DEFECT_BACKWARD ||
                                     DEFECT == CORBO_HIP_DEFECT_CRANK_NICOLSON);
 };
+
+// RK4_CACHE_DEP_COLS (local columns of a defect edge: x_k | u_k): bit set = perturbing that component can change what prepare()
+// sees at SOME Runge-Kutta stage; for every other column the caches of the unperturbed evaluation are bit-identical and reused.
+// RK4_GROUP1_COLS (x_k | u_k | x_{k+1}): which of the two lanes of a stage takes the column (balances the expensive ones).
 
 // The cached defects are combinations of three parts: q = (x2 - x1)/dt, f1 = f(x1,u1), f2 = f(x2,u1).  A finite-difference
 // column only re-evaluates the parts that depend on the perturbed component; the others are bit-identical by construction.
@@ -200,6 +213,33 @@ __device__ __forceinline__ void defect_eval(const double* x1, const double* u1, 
             err[i] -= x2[i];
         }
     }
+}
+
+// End state of one explicit Runge-Kutta-4 step (explicit_integrators.h:280-295), operation for operation the sequence inside
+// defect_eval above.  REUSE = false: the per-stage caches prepare(x_stage) are computed and returned in ck; true: taken from ck.
+template <int DYN, bool REUSE>
+__device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1, double dt, const double* prm,
+                                              double (&ck)[4][Dynamics<DYN>::NC], double* xe)
+{
+    using D          = Dynamics<DYN>;
+    constexpr int NX = D::NX;
+    double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
+    if constexpr (!REUSE) D::prepare(x1, prm, ck[0]);
+    D::eval(x1, ck[0], u1, prm, k1);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { k1[i] *= dt; t[i] = x1[i] + k1[i] / 2.0; }
+    if constexpr (!REUSE) D::prepare(t, prm, ck[1]);
+    D::eval(t, ck[1], u1, prm, k2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { k2[i] *= dt; t[i] = x1[i] + k2[i] / 2.0; }
+    if constexpr (!REUSE) D::prepare(t, prm, ck[2]);
+    D::eval(t, ck[2], u1, prm, k3);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { k3[i] *= dt; t[i] = x1[i] + k3[i]; }
+    if constexpr (!REUSE) D::prepare(t, prm, ck[3]);
+    D::eval(t, ck[3], u1, prm, k4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { k4[i] *= dt; xe[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0; }
 }
 
 // stage inequality on x_k (keep-out ball, cfg 5): c = r^2 - |pos - center|^2  (<= 0 feasible)
