@@ -70,6 +70,7 @@ struct corbo_hip_solver {
     int32_t* d_ineq_rows     = nullptr;
     // per-instance data (HBM resident)
     double *d_x0 = nullptr;  // shadow of the uploaded x (corbo_hip_restore_instance_data)
+    double* d_xnew = nullptr;  // [batch][MAX_NX] measured states of corbo_hip_warm_start
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
@@ -223,6 +224,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipMalloc((void**)&h->d_lb, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_ub, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xref, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_xnew, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_values0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_values1, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_jac, B * h->nnz_pad * sizeof(double)));
@@ -256,7 +258,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters};
+                    h->d_x0, h->d_xnew, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -509,6 +511,27 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h)
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->d_x, h->d_x0, (size_t)h->batch * h->S.nvs * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
+{
+    if (!h || !x0_new) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    HIP_TRY(hipSetDevice(h->device));
+    const Structure& S = h->S;
+    std::vector<double> buf((size_t)h->batch * CORBO_HIP_MAX_NX, 0.0);
+    for (int b = 0; b < h->batch; ++b)
+        for (int i = 0; i < S.nx; ++i) buf[(size_t)b * CORBO_HIP_MAX_NX + i] = x0_new[(size_t)b * S.nx + i];
+    HIP_TRY(hipStreamSynchronize(h->stream));   // (pageable source: the copy below is synchronous anyway; keeps the order explicit)
+    HIP_TRY(hipMemcpy(h->d_xnew, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    WarmStartParams p{};
+    p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.N = S.N;
+    p.xf_fixed_mask = (int32_t)S.desc.xf_fixed_mask;
+    p.shift = (shift != 0 && !S.dt_free) ? 1 : 0;   // variable grids never shift (finite_differences_variable_grid.h:77)
+    p.x = h->d_x; p.x0new = h->d_xnew; p.xref = h->d_xref;
+    launch_warm_start(p, h->stream);
+    HIP_TRY(hipGetLastError());
     return CORBO_HIP_OK;
 }
 

@@ -622,6 +622,83 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------------------------------------------
+// moving-horizon grid update (FullDiscretizationGridBase::update, new_run branch, full_discretization_grid_base.cpp:91-108)
+// ---------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+// One workgroup per instance; the new vertex vector is assembled in LDS from the old one and written back.
+__global__ __launch_bounds__(256) void warm_start_kernel(const WarmStartParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double wsm[];
+    double* nw   = wsm;                 // [nvs] new vertex values
+    double* dist = wsm + p.nvs;         // [21]  |x0 - x_seq[i]|, i = 0..20
+    int* ish     = reinterpret_cast<int*>(dist + 22);
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    const int nx = p.nx, nu = p.nu, N = p.N, s = nx + nu;
+    double* X        = p.x + (size_t)inst * p.nvs;
+    const double* x0 = p.x0new + (size_t)inst * CORBO_HIP_MAX_NX;
+    const int lookahead = (N - 2 < 20) ? N - 2 : 20;   // min(num_interv - 1, 20), :303
+    // findNearestState (:285-317)
+    if (p.shift && tid <= lookahead) {
+        double acc = 0.0;
+        for (int c = 0; c < nx; ++c) { const double d = x0[c] - X[tid * s + c]; acc += d * d; }
+        dist[tid] = sqrt(acc);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int num_shift = 0;
+        if (p.shift && !(fabs(dist[0]) < 1e-12)) {
+            double cache = dist[0];
+            for (int i = 1; i <= lookahead; ++i) {
+                if (dist[i] < cache) { cache = dist[i]; num_shift = i; }
+                else break;
+            }
+        }
+        if (num_shift > N - 2) num_shift = 0;   // "Cannot shift if num_shift > N-2" (:236-240)
+        ish[0] = num_shift;
+    }
+    __syncthreads();
+    const int ns = ish[0];
+    // shifted copy (:247-260): x_seq[i] = x_seq[i + ns] (or x_f), u_seq[i] = u_seq[i + ns]; everything else stays
+    for (int e = tid; e < p.nvs; e += 256) {
+        double v = X[e];
+        if (ns > 0 && e < (N - 1) * s) {
+            const int i = e / s, c = e % s, idx = i + ns;
+            if (i < N - ns) {
+                if (idx == N - 1) { if (c < nx) v = X[(N - 1) * s + c]; }   // final state reached (u_seq[i] untouched)
+                else v = X[idx * s + c];
+            }
+        }
+        nw[e] = v;
+    }
+    __syncthreads();
+    // linear extrapolation of the tail (:262-282), a short sequential chain per component
+    if (ns > 0) {
+        if (tid < nx) {
+            int idx = N - ns;
+            for (int i = 0; i < ns; ++i, ++idx) {
+                const double a = nw[(idx - 2) * s + tid], b = nw[(idx - 1) * s + tid];
+                const double v = a + 2.0 * (b - a);
+                if (i == ns - 1) nw[(N - 1) * s + tid] = v;
+                else nw[idx * s + tid] = v;
+            }
+        }
+        else if (tid >= 64 && tid < 64 + nu) {
+            const int c = nx + (tid - 64);
+            int idx = N - ns;
+            for (int i = 0; i < ns; ++i, ++idx) nw[(idx - 1) * s + c] = nw[(idx - 2) * s + c];
+        }
+    }
+    __syncthreads();
+    if (tid < nx) {
+        nw[tid] = x0[tid];                                                                   // x_seq.front() = x0 (:101)
+        if ((p.xf_fixed_mask >> tid) & 1) nw[(N - 1) * s + tid] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + tid];   // :103-106
+    }
+    __syncthreads();
+    for (int e = tid; e < p.nvs; e += 256) X[e] = nw[e];
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------------------------------
 // assemble + factor + solve
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -2014,6 +2091,12 @@ bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 }
 
 }  // namespace
+
+void launch_warm_start(const WarmStartParams& p, hipStream_t stream)
+{
+    const size_t lds = sizeof(double) * ((size_t)p.nvs + 24);
+    hipLaunchKernelGGL(warm_start_kernel, dim3(p.batch), dim3(256), lds, stream, p);
+}
 
 size_t sweep_lds_bytes(const SweepParams& p, int nc)
 {

@@ -90,6 +90,14 @@ struct FactorParams {
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
 // one fused LM pass: [sweep phase (sp.mode 2 = prologue, 3 = trial step) -> factor phase] per workgroup, one launch
+struct WarmStartParams {
+    int32_t batch, nvs, nx, nu, N, xf_fixed_mask, shift;
+    double* x;            // [batch][nvs] accepted iterate, updated in place
+    const double* x0new;  // [batch][CORBO_HIP_MAX_NX]
+    const double* xref;   // [batch][CORBO_HIP_MAX_NX]
+};
+void launch_warm_start(const WarmStartParams& p, hipStream_t stream);
+
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p, int nc);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);

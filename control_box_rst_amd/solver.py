@@ -108,6 +108,13 @@ class BatchedLevenbergMarquardt:
         rc = self.lib.corbo_hip_set_instance_data(self._h, *[_dp(a) for a in arrs])
         self._check(rc, "corbo_hip_set_instance_data")
 
+    def warm_start(self, x0_new, shift: bool = True):
+        """New moving-horizon run on the resident trajectories: the grid update of FullDiscretizationGridBase::update (shifting
+        warm start when `shift`, then x_0 = x0_new) on the device.  x0_new: [batch][nx].  Follow with solve(new_run=True)."""
+        x0_new = np.ascontiguousarray(x0_new, dtype=np.float64).reshape(self.batch, self.desc.nx)
+        self._check(self.lib.corbo_hip_warm_start(self._h, x0_new.ctypes.data_as(C.POINTER(C.c_double)), 1 if shift else 0),
+                    "corbo_hip_warm_start")
+
     def restore_instance_data(self):
         """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")

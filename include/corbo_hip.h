@@ -181,6 +181,16 @@ int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const doubl
  * new problem, full_discretization_grid_base.cpp:134-179).  Lets a caller re-solve the same batch without a PCIe trip. */
 int corbo_hip_restore_instance_data(corbo_hip_handle h);
 
+/* Start of a new moving-horizon (MPC) run on the trajectories resident in HBM = the new_run branch of
+ * FullDiscretizationGridBase::update (full_discretization_grid_base.cpp:91-108), per instance, on the device:
+ *   shift != 0  (the caller's grid->setWarmStart(true); honoured by fixed-dt grids only, like
+ *               isMovingHorizonWarmStartActive, full_discretization_grid_base.h:133 / finite_differences_variable_grid.h:77):
+ *               warmStartShifting(x0) (:230-283) -- the nearest stored state within 20 samples decides the shift
+ *               (findNearestState, :285-317), states and controls move forward, the tail is extrapolated linearly;
+ *   always:     x_0 = x0_new (:101), fixed components of x_f = the state reference (:103-106).
+ * x0_new [batch][nx] (host).  Follow with corbo_hip_solve(h, opts, new_run = 1). */
+int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
+
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
  * (:83-86).  Kernels run on the handle's stream; the call returns once every instance has finished its outer iterations

@@ -518,6 +518,58 @@ int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const 
     return 0;
 }
 
+/* Start of a new moving-horizon run on the stored trajectory (FullDiscretizationGridBase::update with new_run,
+ * optimal_control/src/structured_ocp/discretization_grids/full_discretization_grid_base.cpp:91-108):
+ *   shift != 0 (grid->setWarmStart(true), fixed-dt grids only :133 / finite_differences_variable_grid.h:77):
+ *       warmStartShifting(x0) :230-283 with findNearestState :285-317;
+ *   always: x_seq.front() = x0 (:101) and the fixed goal components = xref (:103-106). */
+int oracle_warm_start(oracle_problem* p, const double* x0, int shift)
+{
+    if (!p || !x0) return CORBO_HIP_ERR_INVALID;
+    const int nx = p->d.nx, nu = p->d.nu, N = p->d.N, s = nx + nu;
+    double* X = p->x;
+#define XS(i) (X + (i) * s)            /* _x_seq[i], i <= N-2 */
+#define US(i) (X + (i) * s + nx)       /* _u_seq[i] */
+    double* xf = X + (N - 1) * s;
+    if (shift && !dt_is_free(&p->d)) {
+        /* findNearestState */
+        int num_shift = 0;
+        double first = 0;
+        for (int c = 0; c < nx; ++c) { double d = x0[c] - XS(0)[c]; first += d * d; }
+        first = sqrt(first);
+        if (!(fabs(first) < 1e-12)) {
+            int num_interv = N - 1, lookahead = num_interv - 1 < 20 ? num_interv - 1 : 20;
+            double cache = first;
+            for (int i = 1; i <= lookahead; ++i) {
+                double dist = 0;
+                for (int c = 0; c < nx; ++c) { double d = x0[c] - XS(i)[c]; dist += d * d; }
+                dist = sqrt(dist);
+                if (dist < cache) { cache = dist; num_shift = i; }
+                else break;
+            }
+        }
+        if (num_shift > 0 && num_shift <= N - 2) {
+            for (int i = 0; i < N - num_shift; ++i) {
+                int idx = i + num_shift;
+                if (idx == N - 1) memcpy(XS(i), xf, nx * sizeof(double));
+                else { memmove(XS(i), XS(idx), nx * sizeof(double)); memmove(US(i), US(idx), nu * sizeof(double)); }
+            }
+            int idx = N - num_shift;
+            for (int i = 0; i < num_shift; ++i, ++idx) {
+                double* dst = (i == num_shift - 1) ? xf : XS(idx);
+                for (int c = 0; c < nx; ++c) dst[c] = XS(idx - 2)[c] + 2.0 * (XS(idx - 1)[c] - XS(idx - 2)[c]);
+                memmove(US(idx - 1), US(idx - 2), nu * sizeof(double));
+            }
+        }
+    }
+    memcpy(XS(0), x0, nx * sizeof(double));
+    for (int c = 0; c < nx; ++c)
+        if (p->d.xf_fixed_mask & (1u << c)) xf[c] = p->xref[c];
+#undef XS
+#undef US
+    return 0;
+}
+
 int oracle_get_x(const oracle_problem* p, double* x_out)
 {
     if (!p || !x_out) return CORBO_HIP_ERR_INVALID;

@@ -43,6 +43,7 @@ int oracle_init_trajectory(const corbo_hip_problem_desc* desc, const double* x0,
 
 /* vertex values / bounds in vertex layout (nv doubles); lb/ub NULL = descriptor box bounds; xref NULL = zeros */
 int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const double* ub, const double* xref);
+int oracle_warm_start(oracle_problem* p, const double* x0, int shift);
 int oracle_get_x(const oracle_problem* p, double* x_out);
 
 /* LevenbergMarquardtSparse::computeValues + computeCombinedSparseJacobian at the current x (jac may be NULL) */

@@ -71,6 +71,21 @@ def main():
         json.dump({"scenario": "unicycle", "seed": 20260928, "iters": 10, "instances": inst}, f, separators=(",", ":"))
     print("unicycle_seeded8", [round(i["chi2"], 6) for i in inst])
 
+    # moving-horizon sequences (the grid update either side of the solve): one OCP object, new_run every step,
+    # measured state = x_1 of the previous solution + disturbance; with / without the grid's shifting warm start; iters=0 pins the
+    # warm-started initial guess itself
+    for name, kv in [
+        ("mpc_unicycle_shift_init", dict(scenario="unicycle", N=30, steps=3, iters=0, shift=1)),
+        ("mpc_unicycle_shift", dict(scenario="unicycle", N=30, steps=4, iters=5, shift=1)),
+        ("mpc_unicycle_noshift", dict(scenario="unicycle", N=30, steps=3, iters=5, shift=0)),
+        ("mpc_vdp_shift", dict(scenario="vdp", steps=4, iters=5, shift=1)),
+        ("mpc_dint", dict(scenario="dint", steps=3, iters=5, shift=1)),   # variable grid: never shifts, x_f fixed components re-set
+    ]:
+        d = run("mpc", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, [round(st["chi2"], 6) for st in d["steps"]])
+
 
 if __name__ == "__main__":
     main()

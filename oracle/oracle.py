@@ -43,6 +43,7 @@ def load():
     lib.oracle_init_trajectory.argtypes = [C.POINTER(ProblemDesc), dp, dp, dp]
     lib.oracle_set_data.argtypes = [C.c_void_p, dp, dp, dp, dp]
     lib.oracle_get_x.argtypes = [C.c_void_p, dp]
+    lib.oracle_warm_start.argtypes = [C.c_void_p, dp, C.c_int]
     lib.oracle_eval.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.oracle_solve.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.c_int, dp, C.POINTER(TraceEntry)]
     lib.oracle_solve_batch.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, C.POINTER(LmOpts), dp, ip]
@@ -102,6 +103,10 @@ class OracleProblem:
         rc = self.lib.oracle_eval(self.h, w_eq, w_ineq, w_b, _dp(values), _dp(jac))
         assert rc == 0
         return values, jac
+
+    def warm_start(self, x0, shift=True):
+        x0 = np.ascontiguousarray(x0, np.float64)
+        assert self.lib.oracle_warm_start(self.h, _dp(x0), 1 if shift else 0) == 0
 
     def solve(self, opts: LmOpts, new_run=True):
         chi2 = C.c_double(0)

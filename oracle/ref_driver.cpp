@@ -484,11 +484,44 @@ static int bench(const Scenario& s0, std::map<std::string, std::string>& kv)
     return 0;
 }
 
+// Moving-horizon sequence: `steps` calls of StructuredOptimalControlProblem::compute with new_run = true on ONE OCP object; the
+// measured state handed to step s+1 is x_1 of the solution of step s plus a deterministic disturbance.  shift=1 turns on the grid's
+// moving-horizon warm start (FullDiscretizationGridBase::setWarmStart -> warmStartShifting, full_discretization_grid_base.cpp:96,
+// 230-283); otherwise the previous solution stays in place and only x_0 is overwritten (:98-108).  Dumps x0 and the vertex values
+// after every step (iters=0: the pure warm-started initial guess).
+static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
+{
+    const int steps  = kv.count("steps") ? atoi(kv["steps"].c_str()) : 4;
+    const bool shift = kv.count("shift") ? atoi(kv["shift"].c_str()) != 0 : true;
+    const int iters0 = kv.count("iters0") ? atoi(kv["iters0"].c_str()) : 10;   // LM iterations of step 0 (builds the first trajectory)
+    Built b = build(s, iters0);
+    if (shift && b.grid) b.grid->setWarmStart(true);
+    printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters0\": %d, \"iters\": %d, \"shift\": %d,\n", s.name.c_str(),
+           s.nx, s.nu, s.N, s.dt, iters0, s.iters, shift ? 1 : 0);
+    printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
+    printVec("xf", s.xf);
+    printf("\"steps\": [\n");
+    Eigen::VectorXd x0 = s.x0;
+    for (int st = 0; st < steps; ++st)
+    {
+        if (st == 1) b.solver->setIterations(s.iters);
+        bool ok           = b.ocp->compute(x0, *b.xref, *b.uref, nullptr, Time(st * s.dt), true);
+        Eigen::VectorXd v = vertexValues(b, s);
+        printf("{\"ok\": %d, \"chi2\": %.17g, ", ok ? 1 : 0, b.ocp->getCurrentObjectiveValue());
+        printVec("x0", x0);
+        printVec("vertex", v, false);
+        printf("}%s\n", st + 1 < steps ? "," : "");
+        for (int i = 0; i < s.nx; ++i) x0[i] = v[s.nx + s.nu + i] + 0.01 * std::sin(1.0 + st + 0.5 * i);   // x_1 + disturbance
+    }
+    printf("]\n}\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2)
     {
-        fprintf(stderr, "usage: ref_driver dump|bench key=value ...\n");
+        fprintf(stderr, "usage: ref_driver dump|bench|mpc key=value ...\n");
         return 1;
     }
     std::map<std::string, std::string> kv;
@@ -496,6 +529,7 @@ int main(int argc, char** argv)
     std::string mode(argv[1]);
     if (mode == "dump") return dump(s);
     if (mode == "bench") return bench(s, kv);
+    if (mode == "mpc") return mpc(s, kv);
     fprintf(stderr, "unknown mode\n");
     return 1;
 }
