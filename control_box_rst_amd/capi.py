@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_create", "corbo_hip_destroy", "corbo_hip_set_instance_data", "corbo_hip_solve",
     "corbo_hip_synchronize", "corbo_hip_get_solution", "corbo_hip_get_stats", "corbo_hip_eval",
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
-    "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start",
+    "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
 )
 
 
@@ -114,6 +114,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_set_instance_data.argtypes = [H, dp, dp, dp, dp]
     lib.corbo_hip_restore_instance_data.argtypes = [H]
     lib.corbo_hip_warm_start.argtypes = [H, C.POINTER(C.c_double), C.c_int]
+    lib.corbo_hip_get_first_control.argtypes = [H, C.POINTER(C.c_double)]
     lib.corbo_hip_set_profiling.argtypes = [H, C.c_int]
     lib.corbo_hip_solve.argtypes = [H, C.POINTER(LmOpts), C.c_int]
     lib.corbo_hip_synchronize.argtypes = [H]

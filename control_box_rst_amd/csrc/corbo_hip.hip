@@ -71,6 +71,7 @@ struct corbo_hip_solver {
     // per-instance data (HBM resident)
     double *d_x0 = nullptr;  // shadow of the uploaded x (corbo_hip_restore_instance_data)
     double* d_xnew = nullptr;  // [batch][MAX_NX] measured states of corbo_hip_warm_start
+    double* h_xnew = nullptr;  // pinned staging of the same
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
@@ -225,6 +226,7 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipMalloc((void**)&h->d_ub, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xref, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xnew, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_xnew, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_values0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_values1, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_jac, B * h->nnz_pad * sizeof(double)));
@@ -262,6 +264,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
+    if (h->h_xnew) (void)hipHostFree(h->h_xnew);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->ev_chk) if (e) (void)hipEventDestroy(e);
@@ -520,11 +523,10 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     HIP_TRY(hipSetDevice(h->device));
     const Structure& S = h->S;
-    std::vector<double> buf((size_t)h->batch * CORBO_HIP_MAX_NX, 0.0);
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous call has been consumed
     for (int b = 0; b < h->batch; ++b)
-        for (int i = 0; i < S.nx; ++i) buf[(size_t)b * CORBO_HIP_MAX_NX + i] = x0_new[(size_t)b * S.nx + i];
-    HIP_TRY(hipStreamSynchronize(h->stream));   // (pageable source: the copy below is synchronous anyway; keeps the order explicit)
-    HIP_TRY(hipMemcpy(h->d_xnew, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < S.nx; ++i) h->h_xnew[(size_t)b * CORBO_HIP_MAX_NX + i] = x0_new[(size_t)b * S.nx + i];
+    HIP_TRY(hipMemcpyAsync(h->d_xnew, h->h_xnew, (size_t)h->batch * CORBO_HIP_MAX_NX * sizeof(double), hipMemcpyHostToDevice, h->stream));
     WarmStartParams p{};
     p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.N = S.N;
     p.xf_fixed_mask = (int32_t)S.desc.xf_fixed_mask;
@@ -532,6 +534,18 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
     p.x = h->d_x; p.x0new = h->d_xnew; p.xref = h->d_xref;
     launch_warm_start(p, h->stream);
     HIP_TRY(hipGetLastError());
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
+{
+    if (!h || !u0_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    HIP_TRY(hipSetDevice(h->device));
+    const Structure& S = h->S;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy2D(u0_out, (size_t)S.nu * sizeof(double), h->d_x + S.nx, (size_t)S.nvs * sizeof(double), (size_t)S.nu * sizeof(double),
+                        (size_t)h->batch, hipMemcpyDeviceToHost));
     return CORBO_HIP_OK;
 }
 

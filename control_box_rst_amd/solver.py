@@ -115,6 +115,12 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_warm_start(self._h, x0_new.ctypes.data_as(C.POINTER(C.c_double)), 1 if shift else 0),
                     "corbo_hip_warm_start")
 
+    def get_first_control(self) -> np.ndarray:
+        """u_0 of every instance (getFirstControlInput): [batch][nu]."""
+        u0 = np.empty((self.batch, self.desc.nu))
+        self._check(self.lib.corbo_hip_get_first_control(self._h, u0.ctypes.data_as(C.POINTER(C.c_double))), "corbo_hip_get_first_control")
+        return u0
+
     def restore_instance_data(self):
         """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")

@@ -191,6 +191,11 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h);
  * x0_new [batch][nx] (host).  Follow with corbo_hip_solve(h, opts, new_run = 1). */
 int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
 
+/* u_0 of every instance's current trajectory = FullDiscretizationGridBase::getFirstControlInput
+ * (full_discretization_grid_base.cpp:324-331), what a predictive controller applies to its plant.  u0_out [batch][nu] (host);
+ * a strided device-to-host copy of batch * nu doubles instead of the whole trajectories. */
+int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out);
+
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
  * (:83-86).  Kernels run on the handle's stream; the call returns once every instance has finished its outer iterations

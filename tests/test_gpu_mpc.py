@@ -95,6 +95,7 @@ def test_closed_loop_batch_vs_oracle(oracle_mod):
                 ps[b].warm_start(meas[b], shift=True)
         s.solve(new_run=True)
         X, chi2, _ = s.get_solution()
+        assert np.array_equal(s.get_first_control(), X[:, d.nx: d.nx + d.nu])   # getFirstControlInput
         for b in range(B):
             ps[b].solve(s.opts, new_run=True)
             assert np.abs(X[b] - ps[b].x()).max() <= 1e-5, (step, b)
