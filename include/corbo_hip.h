@@ -188,6 +188,7 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h);
  *               warmStartShifting(x0) (:230-283) -- the nearest stored state within 20 samples decides the shift
  *               (findNearestState, :285-317), states and controls move forward, the tail is extrapolated linearly;
  *   always:     x_0 = x0_new (:101), fixed components of x_f = the state reference (:103-106).
+ * ShootingGridBase (MultipleShootingGrid) does the same on its shooting intervals (shooting_grid_base.cpp:99-113, 292-388).
  * x0_new [batch][nx] (host).  Follow with corbo_hip_solve(h, opts, new_run = 1). */
 int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
 

@@ -80,6 +80,7 @@ def main():
         ("mpc_unicycle_noshift", dict(scenario="unicycle", N=30, steps=3, iters=5, shift=0)),
         ("mpc_vdp_shift", dict(scenario="vdp", steps=4, iters=5, shift=1)),
         ("mpc_dint", dict(scenario="dint", steps=3, iters=5, shift=1)),   # variable grid: never shifts, x_f fixed components re-set
+        ("mpc_quad_shift_init", dict(scenario="quad", N=10, steps=3, iters=0, iters0=4, shift=1)),   # MultipleShootingGrid (ShootingGridBase)
     ]:
         d = run("mpc", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

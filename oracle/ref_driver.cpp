@@ -496,6 +496,7 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     const int iters0 = kv.count("iters0") ? atoi(kv["iters0"].c_str()) : 10;   // LM iterations of step 0 (builds the first trajectory)
     Built b = build(s, iters0);
     if (shift && b.grid) b.grid->setWarmStart(true);
+    if (shift && b.ms_grid) b.ms_grid->setWarmStart(true);   // ShootingGridBase: the same shifting (shooting_grid_base.cpp:99-113,292-352)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters0\": %d, \"iters\": %d, \"shift\": %d,\n", s.name.c_str(),
            s.nx, s.nu, s.N, s.dt, iters0, s.iters, shift ? 1 : 0);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);

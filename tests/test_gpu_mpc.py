@@ -49,7 +49,7 @@ def test_warm_start_bit_exact_vs_oracle(oracle_mod, scenario, N):
             assert not np.array_equal(Xd[1, st:2 * st], X[1, st:2 * st])   # something did move
 
 
-@pytest.mark.parametrize("name", ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint"])
+@pytest.mark.parametrize("name", ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint", "mpc_quad_shift_init"])
 def test_sequence_vs_reference(name):
     g = load_golden(name)
     d = desc_for(g)
@@ -66,7 +66,8 @@ def test_sequence_vs_reference(name):
         s.solve(new_run=True)
         x, chi2, _ = s.get_solution()
         ref = np.array(st["vertex"])[: s.dims.nv]
-        assert np.abs(x[0] - ref).max() <= 1e-5, (name, k, np.abs(x[0] - ref).max())
+        tol = 5e-4 if "quad" in name else 1e-5   # quadrotor: nearly flat directions
+        assert np.abs(x[0] - ref).max() <= tol, (name, k, np.abs(x[0] - ref).max())
         if (g["iters0"] if k == 0 else g["iters"]) > 0:
             assert abs(chi2[0] - st["chi2"]) <= 2e-6 * abs(st["chi2"]), (name, k)
 

@@ -7,7 +7,7 @@ import pytest
 from conftest import desc_for, load_golden
 from control_box_rst_amd import capi
 
-MPC = ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint"]
+MPC = ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint", "mpc_quad_shift_init"]
 
 
 @pytest.mark.parametrize("name", MPC)
@@ -49,6 +49,7 @@ def test_sequence_vs_reference(oracle_mod, name):
             iters = g["iters"]
         status, chi2, _ = p.solve(capi.default_lm_opts(iters, *w), new_run=True)
         ref = np.array(st["vertex"])[:nv]
-        assert np.abs(p.x() - ref).max() <= 5e-6, (name, s, np.abs(p.x() - ref).max())
+        tol = 5e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
+        assert np.abs(p.x() - ref).max() <= tol, (name, s, np.abs(p.x() - ref).max())
         if iters > 0:
             assert abs(chi2 - st["chi2"]) <= 2e-6 * abs(st["chi2"]), (name, s)
