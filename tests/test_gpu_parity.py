@@ -301,3 +301,60 @@ def test_full_size_properties():
     va, ja = s.eval()
     vb, jb = s.eval()
     assert np.array_equal(va, vb) and np.array_equal(ja, jb)
+
+
+def test_cfg4_partition_invariance():
+    """cfg 4 (8192 unicycle OCPs = 8 GPUs x 1024): the batch solved in one piece on one GPU equals, bit for bit, the same batch solved
+    as the 8 shards control_box_rst_amd.sharding cuts for 8 ranks (what each GPU of a node computes) -- instances are independent."""
+    from control_box_rst_amd import sharding
+    d = problems.unicycle_desc()
+    G, per = 8, 1024
+    x0, xf = problems.unicycle_instances(G * per)
+    s = BatchedLevenbergMarquardt(d, G * per)
+    s.setIterations(10)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    assert s.get_stats()["lm_iterations"] == G * per * 10
+    sh = BatchedLevenbergMarquardt(d, per)
+    sh.setIterations(10)
+    sh.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    for r in (0, 3, 7):
+        first, count = sharding.shard_bounds(G * per, G, r)
+        assert count == per
+        xr0, xrf = problems.unicycle_instances(count, first=first)       # what rank r generates for itself
+        assert np.array_equal(xr0, x0[first:first + count])
+        sh.set_instance_data(sh.init_trajectory(xr0, xrf), xref=xrf)
+        sh.solve()
+        Xs, cs, ss = sh.get_solution()
+        assert np.array_equal(Xs, X[first:first + count]) and np.array_equal(cs, chi2[first:first + count])
+
+
+def test_full_size_properties_cfg5():
+    """BASELINE cfg 5 size (quadrotor, batch 512, N=200): size-independent properties."""
+    d = problems.quad_desc()
+    B = 512
+    x0, xf = problems.quad_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(10)
+    s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    v0, _ = s.eval(jacobian=False)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    assert s.get_stats()["lm_iterations"] == B * 10
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(chi2))
+    assert np.all(chi2 <= (v0 ** 2).sum(axis=1) + 1e-9)
+    assert np.array_equal(X[:, :12], X0[:, :12])
+    v1, _ = s.eval(jacobian=False)
+    assert np.allclose(chi2, (v1 ** 2).sum(axis=1), rtol=1e-12)
+    s1 = BatchedLevenbergMarquardt(d, 1)
+    s1.setIterations(10)
+    s1.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+    s1.set_instance_data(X0[100:101], xref=xf[100:101])
+    s1.solve()
+    x1, c1, _ = s1.get_solution()
+    assert np.array_equal(x1[0], X[100]) and c1[0] == chi2[100]
