@@ -392,6 +392,7 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
         fp.inst0 = sp.inst0 = first_of[i];
         if (split) {
             if (mode == 3) {
+                fp.first_pass = (pass_of[i] == 0) ? 1 : 0;
                 if (!launch_factor(h->S.desc, fp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
                 HIP_TRY(hipGetLastError());
                 stamp();
@@ -689,7 +690,9 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
     int rc = launch_sweep_checked(h, h->sweep_params(2, o.iterations, h->w_eq, h->w_ineq, h->w_b, nullptr));
     if (rc) return rc;
     FactorParams fp = h->factor_params();
+    fp.first_pass = 1;
     rc = launch_factor_checked(h, fp);  // warm-up (also consumes the `first` pass)
+    fp.first_pass = 0;
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < repeat; ++i) {

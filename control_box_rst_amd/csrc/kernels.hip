@@ -1508,39 +1508,68 @@ struct BigCtx {
     }
 };
 
-// ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118); one wave per instance
+// ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118), in two steps:
+//      big_diag_kernel   one wave per (stage, instance): the stage's parts of diag(J^T J) and of rhs = -J^T r, left in the
+//                        (not yet used) factor slot of the stage's workspace:  [0,NX) diag of x_k without the C-part of stage k-1,
+//                        [NX,2NX) same for rhs, [2NX,3NX) / [3NX,4NX) the C-parts this stage adds to x_{k+1}, [4NX], [4NX+1] the
+//                        maxima over the stage's controls;
+//      big_first_kernel  one wave per instance, lanes over the stages: adds the neighbouring parts, takes the maxima.
 template <int NX, int NU>
-__global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
+__global__ __launch_bounds__(64) void big_diag_kernel(const FactorParams p)
 {
     using BL = BigLds<NX, NU>;
     constexpr int S = NX + NU, W = BL::W;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BigCtx<NX, NU> c(sm);
-    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
-    LmState* st = p.st + inst;
+    const int k = blockIdx.x, inst = blockIdx.y + p.inst0, lane = threadIdx.x;
+    const LmState* st = p.st + inst;
     if (st->done || !st->first) return;
     const int N = p.N;
     const double* J   = p.jac + (size_t)inst * p.nnz_pad;
     const double* val = (st->vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
-    double mx_d = -1e300, mx_g = 0.0;
-    for (int k = 0; k < N; ++k) {
-        __syncthreads();
-        if (k > 0 && lane < NX) { c.gn[lane] = c.Dn[lane]; c.xn[lane] = c.Dn[NX + lane]; }  // previous stage's C-column parts
-        c.load_stage(p, J, val, k, lane);
-        __syncthreads();
-        if (lane < W) {
-            double dd = 0.0, gg = 0.0;
-            for (int r = 0; r < NX; ++r) { const double a = c.Gm[r * W + lane]; dd += a * a; gg -= a * c.rv[r]; }
-            if (lane < NX) {
-                dd += c.dg[lane] + c.cin[lane] * c.cin[lane]; gg += c.gd[lane] - c.cin[lane] * c.red[7];
-                if (k > 0) { dd += c.gn[lane]; gg += c.xn[lane]; }
-                if (c.fx[lane] == 0.0) { mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
-            }
-            else if (lane < S) {
-                if (k < N - 1) { dd += c.dg[lane]; gg += c.gd[lane]; mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
-            }
-            else { c.Dn[lane - S] = dd; c.Dn[NX + lane - S] = gg; }
+    double* wk        = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE + BL::WS_L;
+    c.load_stage(p, J, val, k, lane);
+    __syncthreads();
+    double mu_d = -1e300, mu_g = 0.0;
+    if (lane < W) {
+        double dd = 0.0, gg = 0.0;
+        for (int r = 0; r < NX; ++r) { const double a = c.Gm[r * W + lane]; dd += a * a; gg -= a * c.rv[r]; }
+        if (lane < NX) {
+            dd += c.dg[lane] + c.cin[lane] * c.cin[lane]; gg += c.gd[lane] - c.cin[lane] * c.red[7];
+            wk[lane] = dd; wk[NX + lane] = gg;
         }
+        else if (lane < S) {
+            if (k < N - 1) { dd += c.dg[lane]; gg += c.gd[lane]; mu_d = dd; mu_g = fabs(gg); }
+        }
+        else { wk[2 * NX + lane - S] = dd; wk[3 * NX + lane - S] = gg; }
+    }
+    mu_d = wave_max(mu_d);
+    mu_g = wave_max(mu_g);
+    if (lane == 0) { wk[4 * NX] = mu_d; wk[4 * NX + 1] = mu_g; }
+}
+
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
+{
+    using BL = BigLds<NX, NU>;
+    constexpr int S = NX + NU;
+    static_assert(4 * NX + 2 <= NX * NX, "the diag parts live in the factor slot of the stage");
+    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
+    LmState* st = p.st + inst;
+    if (st->done || !st->first) return;
+    const int N = p.N;
+    const double* ws = p.work + (size_t)inst * p.work_stride + BL::WS_L;
+    double mx_d = -1e300, mx_g = 0.0;
+    for (int k = lane; k < N; k += 64) {
+        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+        const double* wp = wk - BL::WS_STAGE;   // stage k-1 (only read for k > 0)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double dd = wk[i], gg = wk[NX + i];
+            if (k > 0) { dd += wp[2 * NX + i]; gg += wp[3 * NX + i]; }
+            if (!p.comp[k * S + i].fixed) { mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
+        }
+        if (k < N - 1) { mx_d = fmax(mx_d, wk[4 * NX]); mx_g = fmax(mx_g, wk[4 * NX + 1]); }
     }
     mx_d = wave_max(mx_d);
     mx_g = wave_max(mx_g);
@@ -2154,7 +2183,10 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
     if (d.nx == 12 && d.nu == 4) {
         if (p.dt_free || !p.work) return false;
         const size_t lds = sizeof(double) * (size_t)BigLds<12, 4>::TOTAL;
-        hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), lds, stream, p);   // returns at once unless st->first
+        if (p.first_pass) {   // (the kernels themselves also check LmState::first)
+            hipLaunchKernelGGL((big_diag_kernel<12, 4>), dim3(p.N, p.batch), dim3(64), lds, stream, p);
+            hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), 0, stream, p);
+        }
         hipLaunchKernelGGL((big_assemble_kernel<12, 4, true>), dim3(p.N, p.batch), dim3(64), lds, stream, p);
         hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(64), lds, stream, p);
         return true;
