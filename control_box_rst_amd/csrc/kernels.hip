@@ -1730,21 +1730,26 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// ---- per instance: the sequential part.  Lane i < NX owns ROW i of the state block in registers: the 12 x 12 Cholesky, the
-//      triangular solves and the back-substitution run on register rows with v_readlane broadcasts -- no LDS round trip and no
-//      barrier per pivot; only the Schur complement Y Y^T goes through LDS (operands of the matrix-core instruction).  The
-//      assembled data of the next stage (forward) / the factors of the previous stage (backward) are in flight while the current
-//      one is worked on.
+// ---- per instance: the sequential part, from both ends ("twisted" block Cholesky).  Two waves per instance: wave 0 eliminates the
+//      state blocks 0, 1, ... m-1 upwards (block k against k+1), wave 1 the blocks N-1, N-2, ... m+1 downwards (block k against
+//      k-1, the mirrored step: coupling transposed), they meet at block m = N/2, which wave 0 factors with both Schur
+//      complements; the back-substitution then runs outwards on both sides at once.  Half the sequential depth of a one-sided sweep.
+//      Inside a wave lane i < NX owns ROW i of the state block in registers: the 12 x 12 Cholesky, the triangular solves and the
+//      back-substitution run on register rows with v_readlane broadcasts -- no LDS round trip and no barrier per pivot; only the
+//      Schur complement Y Y^T goes through LDS (operands of the matrix-core instruction).  The assembled data of the next block
+//      (elimination) / the factors of the next block (back-substitution) are in flight while the current one is worked on.
 template <int NX, int NU, bool USE_MFMA>
-__global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
+__global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
 {
     using BL = BigLds<NX, NU>;
     constexpr int S = NX + NU;
     static_assert(NX <= 16 && NU <= NX, "row-per-lane mapping of the chain kernel");
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const BigCtx<NX, NU> c(sm);
-    double *Dn = c.Dn, *Cx = c.Cx;
-    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
+    const int side = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* Dn = sm + side * 2 * NX * NX;        // Schur mailbox of this wave  [NX][NX]
+    double* Cx = Dn + NX * NX;                   // Y of the current block       [NX][NX]
+    double* xch = sm + 4 * NX * NX;              // exchange between the waves: [0,NX) rhs mailbox of wave 1, [NX,2NX) x_m, [2NX..] sums
+    const int inst = blockIdx.x + p.inst0;
     const int row = (lane < NX) ? lane : NX - 1;   // lanes >= NX mirror the last row (their results are never stored)
     const bool own = (lane < NX);
     LmState* st = p.st + inst;
@@ -1754,6 +1759,8 @@ __global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
     const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + mu;
     if (done) return;
     const int N = p.N;
+    const int m = N / 2;                                   // meeting block
+    const int nsteps = (m > N - 1 - m) ? m : N - 1 - m;    // both waves run the same number of (possibly idle) steps: barriers
     const double* xin = p.x + (size_t)inst * p.nvs;
     double* xt        = p.xt + (size_t)inst * p.nvs;
     double* ws        = p.work + (size_t)inst * p.work_stride;
@@ -1761,46 +1768,32 @@ __global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
     double y2 = 0.0;
     for (int e = lane; e < NX * NX; e += 64) Dn[e] = 0.0;
     double gn_r = 0.0;   // Schur mailbox of the right-hand side (row of this lane)
-    // ---- forward sweep over the stages
+    // ---- elimination.  Block k of this wave's sequence: wave 0: k = s, wave 1: k = N-1-s.
+    //      pd: own parts of D_k (row), pc: coupling towards the block eliminated against (wave 0: row of C_k = H(k+1,k);
+    //      wave 1: row of C_{k-1}^T = H(k-1,k)), pn/pgn: the assemble-time contribution DN/GN that belongs to the NEXT block of wave
+    //      0's sequence (k+1) resp. to THIS block of wave 1's sequence (DN_{k-1} adds to D_k).
     double pd[NX], pc[NX], pn[NX], pg = 0.0, pgn = 0.0, py2 = 0.0;
     int pfix = 0;
     auto fetch = [&](int k) {
         const double* wk = ws + (size_t)k * BL::WS_STAGE;
+        const double* wc = (side == 0) ? wk : wk - BL::WS_STAGE;   // stage whose C / DN / GN this block uses (wave 1: k-1 >= m)
 #pragma unroll
         for (int cc = 0; cc < NX; ++cc) {
             pd[cc] = wk[BL::WS_L + row * NX + cc];
-            pc[cc] = wk[BL::WS_Y + row * NX + cc];
-            pn[cc] = wk[BL::WS_DN + row * NX + cc];
+            pc[cc] = (side == 0) ? wc[BL::WS_Y + row * NX + cc] : wc[BL::WS_Y + cc * NX + row];
+            pn[cc] = wc[BL::WS_DN + row * NX + cc];
         }
         pg  = wk[BL::WS_YV + row];
-        pgn = wk[BL::WS_GN + row];
+        pgn = wc[BL::WS_GN + row];
         py2 = wk[BL::WS_Y2];
         pfix = p.comp[k * S + row].fixed;
     };
-    fetch(0);
+    auto block_of = [&](int s) { return (side == 0) ? s : N - 1 - s; };
+    const int mysteps = (side == 0) ? m : N - 1 - m;
+    if (mysteps > 0) fetch(block_of(0));
     __syncthreads();
-    for (int k = 0; k < N; ++k) {
-        const bool stage = (k < N - 1);
-        // state block k = own parts + Schur mailbox of the previous stage; fixed components: identity rows / columns, zero rhs
-        const unsigned long long fmask = __ballot(pfix != 0 && own);
-        const bool fixed_r = (fmask >> row) & 1ull;
-        double d[NX], cr[NX], g;
-#pragma unroll
-        for (int cc = 0; cc < NX; ++cc) {
-            double v = pd[cc] + Dn[row * NX + cc];
-            if (fixed_r || ((fmask >> cc) & 1ull)) v = (row == cc) ? 1.0 : 0.0;
-            d[cc]  = v;
-            cr[cc] = pc[cc];
-        }
-        g = fixed_r ? 0.0 : pg + gn_r;
-        const double gnk = pgn;
-        y2 += (lane == 0) ? py2 : 0.0;
-        __syncthreads();   // every lane has taken its mailbox row
-        if (own) {
-#pragma unroll
-            for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = pn[cc];
-        }
-        if (k + 1 < N) fetch(k + 1);
+    // one elimination step on register rows; returns y_k[row]; leaves Y in yr, L in d
+    auto factor_rows = [&](double (&d)[NX], double (&cr)[NX], double g, double (&yr)[NX]) -> double {
         // Cholesky, right-looking over register rows: after step j, d[j] of lane i > j is L[i][j], of lane j it is 1 / L[j][j]
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
@@ -1810,7 +1803,6 @@ __global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
             for (int cc = j + 1; cc < NX; ++cc) d[cc] -= d[j] * lane_bcast(d[j], cc);   // (rows above cc hold unused upper entries)
         }
         // Y = C L^{-T}: row i of Y from row i of C; y = L^{-1} g across the lanes
-        double yr[NX];
 #pragma unroll
         for (int cc = 0; cc < NX; ++cc) {
             double v = cr[cc];
@@ -1818,30 +1810,65 @@ __global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
             for (int t = 0; t < cc; ++t) v -= yr[t] * lane_bcast(d[t], cc);
             yr[cc] = v * lane_bcast(d[cc], cc);
         }
-        double yk = g;   // becomes y_k[row]
+        double yk = g;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const double yj = lane_bcast(yk, j) * lane_bcast(d[j], j);   // y_j = (g_j - sum_{t<j} L[j][t] y_t) / L[j][j]
             yk = (lane == j) ? yj : ((lane > j) ? yk - d[j] * yj : yk);
         }
-        if (own) y2 += yk * yk;
-        // Schur complement to the next block: D_{k+1} parts -= Y Y^T (matrix cores, operands through LDS), rhs -= Y y
-        double* wk = ws + (size_t)k * BL::WS_STAGE;
-        if (own) {
+        return yk;
+    };
+    for (int s = 0; s < nsteps; ++s) {
+        const bool active = (s < mysteps);
+        const int k = active ? block_of(s) : 0;
+        double d[NX], cr[NX], yr[NX], g = 0.0, yk = 0.0;
+        if (active) {
+            // state block k = own parts + Schur mailbox (+ DN_{k-1} for wave 1); fixed components: identity rows / columns, zero rhs
+            const unsigned long long fmask = __ballot(pfix != 0 && own);
+            const bool fixed_r = (fmask >> row) & 1ull;
 #pragma unroll
             for (int cc = 0; cc < NX; ++cc) {
-                Cx[row * NX + cc] = yr[cc];
-                wk[BL::WS_L + row * NX + cc] = d[cc];
-                wk[BL::WS_Y + row * NX + cc] = yr[cc];
+                double v = pd[cc] + Dn[row * NX + cc];
+                if (side == 1) v += pn[cc];
+                if (fixed_r || ((fmask >> cc) & 1ull)) v = (row == cc) ? 1.0 : 0.0;
+                d[cc]  = v;
+                cr[cc] = pc[cc];
             }
-            wk[BL::WS_YV + row] = yk;
+            g = pg + gn_r;
+            if (side == 1) g += pgn;
+            if (fixed_r) g = 0.0;
+            y2 += (lane == 0) ? py2 : 0.0;
         }
-        if (stage) {
-            double v = gnk;
+        const double gnk = pgn;
+        double dnk[NX];
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) dnk[cc] = pn[cc];
+        __syncthreads();   // every lane has taken its mailbox row
+        if (active) {
+            if (own) {
+#pragma unroll
+                for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = (side == 0) ? dnk[cc] : 0.0;
+            }
+            if (s + 1 < mysteps) fetch(block_of(s + 1));
+            yk = factor_rows(d, cr, g, yr);
+            if (own) y2 += yk * yk;
+            double* wk = ws + (size_t)k * BL::WS_STAGE;
+            if (own) {
+#pragma unroll
+                for (int cc = 0; cc < NX; ++cc) {
+                    Cx[row * NX + cc] = yr[cc];
+                    wk[BL::WS_L + row * NX + cc] = d[cc];
+                    wk[BL::WS_Y + row * NX + cc] = yr[cc];
+                }
+                wk[BL::WS_YV + row] = yk;
+            }
+            double v = (side == 0) ? gnk : 0.0;
 #pragma unroll
             for (int t = 0; t < NX; ++t) v -= yr[t] * lane_bcast(yk, t);
             gn_r = v;
-            __syncthreads();
+        }
+        __syncthreads();
+        if (active) {   // Schur complement to the next block of the sequence: mailbox -= Y Y^T (matrix cores, operands through LDS)
             if constexpr (USE_MFMA && NX <= 16 && NX % 4 == 0) {
                 typedef double d4_t __attribute__((ext_vector_type(4)));
                 const int lj = lane & 15, lk = lane >> 4;
@@ -1869,44 +1896,92 @@ __global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
         }
         __syncthreads();
     }
+    // ---- the meeting block m: own parts + both mailboxes (wave 0's holds DN_{m-1} - Y Y^T, wave 1's -Y' Y'^T)
+    if (side == 1 && own) xch[row] = gn_r;
+    __syncthreads();
+    double xm_r = 0.0;
+    if (side == 0) {
+        const double* wk = ws + (size_t)m * BL::WS_STAGE;
+        const int fx = p.comp[m * S + row].fixed;
+        const unsigned long long fmask = __ballot(fx != 0 && own);
+        const bool fixed_r = (fmask >> row) & 1ull;
+        double d[NX], cr[NX], yr[NX];
+        const double* DnR = sm + 2 * NX * NX;
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {
+            double v = wk[BL::WS_L + row * NX + cc] + Dn[row * NX + cc] + DnR[row * NX + cc];
+            if (fixed_r || ((fmask >> cc) & 1ull)) v = (row == cc) ? 1.0 : 0.0;
+            d[cc] = v; cr[cc] = 0.0;
+        }
+        double g = fixed_r ? 0.0 : wk[BL::WS_YV + row] + gn_r + xch[row];
+        y2 += (lane == 0) ? wk[BL::WS_Y2] : 0.0;
+        double yk = factor_rows(d, cr, g, yr);
+        if (own) y2 += yk * yk;
+        // x_m = L^{-T} y across the lanes (row i of the register block holds L[i][.]; column access through broadcasts)
+        double v = yk, xk = 0.0;
+#pragma unroll
+        for (int j = NX - 1; j >= 0; --j) {
+            const double xj = lane_bcast(v, j) * lane_bcast(d[j], j);
+            if (lane == j) xk = xj;
+            // lane i < j subtracts L[j][i] x_j: L[j][i] lives in lane j's register d[i] -> broadcast it
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                if (i < j) { const double lji = lane_bcast(d[i], j); if (lane == i) v -= lji * xj; }
+        }
+        if (fixed_r || !own) xk = 0.0;
+        xm_r = xk;
+        if (own) {
+            double* wkm = ws + (size_t)m * BL::WS_STAGE;
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) wkm[BL::WS_L + row * NX + cc] = d[cc];
+            xch[NX + row] = xk;
+            xt[m * S + row] = xin[m * S + row] + xk;
+        }
+    }
     __threadfence_block();
     __syncthreads();
-    // ---- backward sweep: lane i owns COLUMN i of L_k and Y_k; x_{k+1} stays in the lanes' registers
-    double dn2 = 0.0, xn_r = 0.0;
-    double bl[NX], by[NX], byv = 0.0, bzx[NX], bzp[NX], byu = 0.0, bluu[NU], bx = 0.0;
+    // ---- back-substitution outwards: wave 0 blocks m-1 .. 0 (x_k from x_{k+1}), wave 1 blocks m+1 .. N-1 (x_k from x_{k-1}).
+    //      Lane i owns COLUMN i of L_k and Y_k; the neighbour's solution stays in the lanes' registers.  Controls of stage q need
+    //      x_q and x_{q+1}: wave 0 does stage k with block k, wave 1 stage k-1 with block k.
+    double dn2 = (side == 0) ? xm_r * xm_r : 0.0, xn_r = xch[NX + row];
+    if (!own) xn_r = 0.0;
+    double bl[NX], by[NX], byv = 0.0, bzx[NX], bzp[NX], byu = 0.0, bluu[NU], bx = 0.0, bxu = 0.0;
     int bfix = 0;
     const int urow = (lane < NU) ? lane : NU - 1;
     auto fetch_b = [&](int k) {
         const double* wk = ws + (size_t)k * BL::WS_STAGE;
-        const bool stage = (k < N - 1);
+        const int q = (side == 0) ? k : k - 1;                       // stage whose controls go with this block
+        const double* wq = ws + (size_t)q * BL::WS_STAGE;
 #pragma unroll
         for (int t = 0; t < NX; ++t) {
             bl[t] = wk[BL::WS_L + t * NX + row];   // L[t][row]  (t >= row; 1 / L[row][row] at t == row)
             by[t] = wk[BL::WS_Y + t * NX + row];   // Y[t][row]
-            bzx[t] = stage ? wk[BL::WS_ZX + urow * NX + t] : 0.0;
-            bzp[t] = stage ? wk[BL::WS_ZP + urow * NX + t] : 0.0;
+            bzx[t] = wq[BL::WS_ZX + urow * NX + t];
+            bzp[t] = wq[BL::WS_ZP + urow * NX + t];
         }
 #pragma unroll
-        for (int b = 0; b < NU; ++b) bluu[b] = stage ? wk[BL::WS_LUU + b * NU + urow] : 1.0;   // Luu[b][urow]
+        for (int b = 0; b < NU; ++b) bluu[b] = wq[BL::WS_LUU + b * NU + urow];   // Luu[b][urow]
         byv  = wk[BL::WS_YV + row];
-        byu  = stage ? wk[BL::WS_YU + urow] : 0.0;
+        byu  = wq[BL::WS_YU + urow];
         bfix = p.comp[k * S + row].fixed;
-        bx   = (lane < NX || (stage && lane < S)) ? xin[k * S + lane] : 0.0;
+        bx   = (lane < NX) ? xin[k * S + lane] : 0.0;
+        bxu  = (lane >= NX && lane < S) ? xin[q * S + lane] : 0.0;
     };
-    fetch_b(N - 1);
-    for (int k = N - 1; k >= 0; --k) {
-        const bool stage = (k < N - 1);
+    if (mysteps > 0) fetch_b((side == 0) ? m - 1 : m + 1);
+    for (int s = 0; s < mysteps; ++s) {
+        const int k = (side == 0) ? m - 1 - s : m + 1 + s;
+        const int q = (side == 0) ? k : k - 1;
         double Lc[NX], v = byv, zx[NX], zp[NX], lu[NU];
-        const double yu_r = byu, xin_r = bx;
+        const double yu_r = byu, xin_r = bx, xinu_r = bxu;
         const bool fixed_r = (bfix != 0);
 #pragma unroll
         for (int t = 0; t < NX; ++t) {
             Lc[t] = bl[t]; zx[t] = bzx[t]; zp[t] = bzp[t];
-            if (stage) v -= by[t] * lane_bcast(xn_r, t);   // t = y - Y^T x_{k+1}
+            v -= by[t] * lane_bcast(xn_r, t);   // t = y - Y^T x_neighbour
         }
 #pragma unroll
         for (int b = 0; b < NU; ++b) lu[b] = bluu[b];
-        if (k > 0) fetch_b(k - 1);
+        if (s + 1 < mysteps) fetch_b((side == 0) ? k - 1 : k + 1);
         // x_k = L^{-T} t across the lanes
         double xk = 0.0;
 #pragma unroll
@@ -1915,38 +1990,42 @@ __global__ __launch_bounds__(64) void big_chain_kernel(const FactorParams p)
             if (lane == j) xk = xj;
             v -= (lane < j) ? Lc[j] * xj : 0.0;               // lane i < j: L[j][i] x_j
         }
-        if (fixed_r) xk = 0.0;
-        if (!own) xk = 0.0;
-        // u_k = Luu^{-T} (yu - Zx x_k - Zp x_{k+1}) : lane a < NU owns row a of Zx, Zp and column a of Luu
-        double uk = 0.0;
-        if (stage) {
-            double w = yu_r;
+        if (fixed_r || !own) xk = 0.0;
+        // u_q = Luu^{-T} (yu - Zx x_q - Zp x_{q+1}) : lane a < NU owns row a of Zx, Zp and column a of Luu
+        //   wave 0: x_q = x_k (just computed), x_{q+1} = neighbour; wave 1: x_q = neighbour (x_{k-1}), x_{q+1} = x_k
+        double w = yu_r;
 #pragma unroll
-            for (int t = 0; t < NX; ++t) w -= zx[t] * lane_bcast(xk, t) + zp[t] * lane_bcast(xn_r, t);
-#pragma unroll
-            for (int a = NU - 1; a >= 0; --a) {
-                const double ua = lane_bcast(w * lu[a], a);   // lane a: w_a / Luu[a][a]
-                if (lane == a) uk = ua;
-                w -= (lane < a) ? lu[a] * ua : 0.0;           // lane b < a: Luu[a][b] u_a
-            }
-            if (lane >= NU) uk = 0.0;
+        for (int t = 0; t < NX; ++t) {
+            const double xa = lane_bcast(xk, t), xb = lane_bcast(xn_r, t);
+            w -= (side == 0) ? zx[t] * xa + zp[t] * xb : zx[t] * xb + zp[t] * xa;
         }
+        double uk = 0.0;
+#pragma unroll
+        for (int a = NU - 1; a >= 0; --a) {
+            const double ua = lane_bcast(w * lu[a], a);   // lane a: w_a / Luu[a][a]
+            if (lane == a) uk = ua;
+            w -= (lane < a) ? lu[a] * ua : 0.0;           // lane b < a: Luu[a][b] u_a
+        }
+        if (lane >= NU) uk = 0.0;
         dn2 += xk * xk + uk * uk;
-        // trial iterate: lanes 0..NX-1 the state, lanes NX..S-1 the controls (moved there with one more broadcast round)
         double ush = 0.0;
 #pragma unroll
         for (int a = 0; a < NU; ++a) { const double ua = lane_bcast(uk, a); if (lane == NX + a) ush = ua; }
         if (lane < NX) xt[k * S + lane] = xin_r + xk;
-        else if (lane < S && stage) xt[k * S + lane] = xin_r + ush;
+        else if (lane < S) xt[q * S + lane] = xinu_r + ush;
         xn_r = xk;
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         xt[p.off_dt] = xin[p.off_dt];
         if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
     }
     y2  = wave_sum(y2);
     dn2 = wave_sum(dn2);
-    if (lane == 0) {
+    if (lane == 0) { xch[2 * NX + 2 * side] = y2; xch[2 * NX + 2 * side + 1] = dn2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        y2  = xch[2 * NX] + xch[2 * NX + 2];
+        dn2 = xch[2 * NX + 1] + xch[2 * NX + 3];
         st->mu_acc = mu_eff;
         st->first  = 0;
         st->fresh  = 0;
@@ -2188,7 +2267,7 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
             hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), 0, stream, p);
         }
         hipLaunchKernelGGL((big_assemble_kernel<12, 4, true>), dim3(p.N, p.batch), dim3(64), lds, stream, p);
-        hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * 12 * 12 + 2 * 12 + 8), stream, p);
         return true;
     }
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
