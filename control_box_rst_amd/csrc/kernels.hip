@@ -1441,13 +1441,7 @@ struct BigLds {
     static constexpr int ZX = LUU + NU * NU;          // [NU][NX]
     static constexpr int ZP = ZX + NU * NX;           // [NU][NX]
     static constexpr int YU = ZP + NU * NX;           // [NU]
-    static constexpr int DC = YU + NU + (NU & 1);     // [NX][NX] current diagonal block -> L
-    static constexpr int DN = DC + NX * NX;           // [NX][NX] next diagonal block (Schur mailbox)
-    static constexpr int CX = DN + NX * NX;           // [NX][NX] coupling H'(x_{k+1}, x_k) -> Y
-    static constexpr int GC = CX + NX * NX;           // [NX] rhs of the current block -> y
-    static constexpr int GN = GC + NX;                // [NX]
-    static constexpr int XN = GN + NX;                // [NX] solution of block k+1 (backward sweep)
-    static constexpr int DIAG = XN + NX;              // [NX+NU] diagonal (single-entry row) contributions of stage k
+    static constexpr int DIAG = YU + NU + (NU & 1);   // [NX+NU] diagonal (single-entry row) contributions of stage k
     static constexpr int GDIAG = DIAG + NX + NU;      // [NX+NU]
     static constexpr int CIN = GDIAG + NX + NU;       // [NX] inequality row
     static constexpr int FIX = CIN + NX;              // [NX] fixed flags (as doubles)
@@ -1472,11 +1466,10 @@ struct BigCtx {
     using BL = BigLds<NX, NU>;
     static constexpr int S = NX + NU;
     static constexpr int W = BL::W;
-    double *Gm, *rv, *Mm, *gm, *Luu, *Zx, *Zp, *yu, *Dc, *Dn, *Cx, *gc, *gn, *xn, *dg, *gd, *cin, *fx, *red;
+    double *Gm, *rv, *Mm, *gm, *Luu, *Zx, *Zp, *yu, *dg, *gd, *cin, *fx, *red;
     __device__ __forceinline__ explicit BigCtx(double* sm)
         : Gm(sm + BL::G), rv(sm + BL::R), Mm(sm + BL::M), gm(sm + BL::GM), Luu(sm + BL::LUU), Zx(sm + BL::ZX), Zp(sm + BL::ZP),
-          yu(sm + BL::YU), Dc(sm + BL::DC), Dn(sm + BL::DN), Cx(sm + BL::CX), gc(sm + BL::GC), gn(sm + BL::GN), xn(sm + BL::XN),
-          dg(sm + BL::DIAG), gd(sm + BL::GDIAG), cin(sm + BL::CIN), fx(sm + BL::FIX), red(sm + BL::RED) {}
+          yu(sm + BL::YU), dg(sm + BL::DIAG), gd(sm + BL::GDIAG), cin(sm + BL::CIN), fx(sm + BL::FIX), red(sm + BL::RED) {}
     // loads the local Jacobian, residual and single-entry rows of stage k (k == N-1: only the state block's diagonal rows)
     __device__ __forceinline__ void load_stage(const FactorParams& p, const double* J, const double* val, int k, int lane) const
     {
@@ -1589,8 +1582,8 @@ __global__ __launch_bounds__(64) void big_assemble_kernel(const FactorParams p)
     constexpr int S = NX + NU, W = BL::W;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const BigCtx<NX, NU> c(sm);
-    double *Gm = c.Gm, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *Dc = c.Dc, *Dn = c.Dn,
-           *Cx = c.Cx, *gc = c.gc, *gn = c.gn, *dg = c.dg, *gd = c.gd, *cin = c.cin, *fx = c.fx, *red = c.red;
+    double *Gm = c.Gm, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *dg = c.dg, *gd = c.gd,
+           *cin = c.cin, *red = c.red;
     const int k = blockIdx.x, inst = blockIdx.y + p.inst0, lane = threadIdx.x;
     const LmState* st = p.st + inst;
     if (st->done) return;
