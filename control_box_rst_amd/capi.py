@@ -18,6 +18,7 @@ DEFECT_FORWARD, DEFECT_BACKWARD, DEFECT_MIDPOINT, DEFECT_CRANK_NICOLSON, DEFECT_
 DYN_VAN_DER_POL, DYN_SERIAL_INTEGRATOR, DYN_UNICYCLE, DYN_QUADROTOR = 0, 1, 2, 3
 COST_NONE, COST_QUADRATIC_LSQ, COST_MIN_TIME_LSQ = 0, 1, 2
 INEQ_NONE, INEQ_BALL = 0, 1
+FINAL_INEQ_NONE, FINAL_INEQ_TERMINAL_BALL = 0, 1
 SOLVER_CONVERGED, SOLVER_EARLY_TERMINATED, SOLVER_INFEASIBLE, SOLVER_ERROR = 0, 1, 2, 3
 
 
@@ -32,6 +33,7 @@ class ProblemDesc(C.Structure):
         ("u_lb", C.c_double * MAX_NU), ("u_ub", C.c_double * MAX_NU),
         ("q_diag", C.c_double * MAX_NX), ("r_diag", C.c_double * MAX_NU), ("qf_diag", C.c_double * MAX_NX),
         ("dyn_params", C.c_double * 8), ("ineq_params", C.c_double * 8),
+        ("final_ineq", C.c_int32), ("reserved0", C.c_int32), ("final_ineq_params", C.c_double * (MAX_NX + 1)),
     ]
 
 

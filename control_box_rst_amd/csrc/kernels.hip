@@ -258,6 +258,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
     }
+    // (c) the final-stage inequality on x_f (TerminalBall): one lane
+    if constexpr (NX <= 3) {
+        if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
+            double cf = terminal_ball<NX>(xs + (p.N - 1) * S, xr, p.mp.fin);
+            cf        = (cf < 0) ? 0.0 : cf * p.w_ineq;   // computeValuesActiveInequality
+            vout[p.fin_row] = cf;
+            sq_acc += cf * cf;
+        }
+    }
 
     SWEEP_STAMP(3);
     // ---- chi2 = |values|^2 and the LM trial-step decision
@@ -593,6 +602,27 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
     }
+    if constexpr (NX <= 3) {   // final-stage inequality row on x_f (same rule: active row or explicit zeros)
+        if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
+            double loc[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) loc[i] = xs[(p.N - 1) * S + i];
+            const double c0   = terminal_ball<NX>(loc, xr, p.mp.fin);
+            const bool active = (((c0 < 0) ? 0.0 : c0 * p.w_ineq) > 0.0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int jo = p.fin_joff[i];
+                if (jo < 0) continue;
+                const double keep = loc[i];
+                loc[i] += delta;
+                const double c2 = terminal_ball<NX>(loc, xr, p.mp.fin);
+                loc[i] += neg2delta;
+                const double c1 = terminal_ball<NX>(loc, xr, p.mp.fin);
+                loc[i]  = keep;
+                jst[jo] = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
+            }
+        }
+    }
     SWEEP_STAMP(6);
     if constexpr (STAGE) {
         __syncthreads();
@@ -855,6 +885,11 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         iq_row = p.ineq_rows[k];
 #pragma unroll
         for (int i = 0; i < NX; ++i) iq[i] = p.ineq_cols[k * NX + i];
+    }
+    else if (p.fin_row >= 0 && k == N - 1) {   // final-stage inequality: a row on the last state block
+        iq_row = p.fin_row;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) iq[i] = p.fin_joff[i < 4 ? i : 3];
     }
     // (2) residual entries
     double r[NX], vc[S], vb[S], rin;

@@ -41,6 +41,8 @@ struct SweepParams {
     const StageCols* stage_cols;  // N-1: Jacobian offsets of the defect columns of stage k
     const CompInfo* comp;         // nvs: cost-block offsets per component
     const int32_t* ineq_cols;     // (N-1)*nx or null
+    int32_t fin_row;              // residual row of the final-stage inequality (TerminalBall) or -1
+    int32_t fin_joff[4];          // its Jacobian entries on x_f (small-block families: nx <= 3), -1 = fixed component
     ModelParams mp;
     double dt_fixed;
     // per-call
@@ -70,6 +72,8 @@ struct FactorParams {
     const CompInfo* comp;         // nvs
     const int32_t* ineq_cols;     // (N-1)*nx or null
     const int32_t* ineq_rows;     // N-1 or null
+    int32_t fin_row;              // final-stage inequality on the last block (see SweepParams)
+    int32_t fin_joff[4];
     const double* x;              // accepted iterate
     double* xt;                   // trial iterate out
     const double* values0;

@@ -18,6 +18,7 @@ struct ModelParams {
     double sr[CORBO_HIP_MAX_NU];   // sqrt(R_ii)
     double sqf[CORBO_HIP_MAX_NX];  // sqrt(Qf_ii)  (final_state_cost.cpp:60-68)
     double dt_weight;              // sqrt(N-1)    (minimum_time.h:60)
+    double fin[CORBO_HIP_MAX_NX + 1];  // final-stage inequality: S_11 .. S_nn, gamma (TerminalBall)
 };
 
 #pragma clang fp contract(off)
@@ -240,6 +241,17 @@ __device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1
     D::eval(t, ck[3], u1, prm, k4);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { k4[i] *= dt; xe[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0; }
+}
+
+// final-stage inequality TerminalBall, diagonal S, non-zero reference (final_state_constraints.cpp:72-76):
+//   xd = x - xref;  c = xd^T * S_diag * xd - gamma   (row vector times diagonal, then the inner product)
+template <int NX>
+__device__ __forceinline__ double terminal_ball(const double* x, const double* xref, const double* prm)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { const double xd = x[i] - xref[i]; acc += (xd * prm[i]) * xd; }
+    return acc - prm[NX];
 }
 
 // stage inequality on x_k (keep-out ball, cfg 5): c = r^2 - |pos - center|^2  (<= 0 feasible)

@@ -27,6 +27,8 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.stage_cost < CORBO_HIP_COST_NONE || d.stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return "unknown stage cost";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
+    if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
+    if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 3) return "terminal ball: families with nx <= 3 only";
     if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
     return "";
 }
@@ -89,13 +91,14 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         eq.push_back({EK_DEFECT, k, nx, 1});
     }
     if (xf_unfixed > 0 && d.final_cost) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
+    if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) ineq.push_back({EK_FINAL_INEQ, N - 1, 1, 2});  // finite_differences_grid.cpp:135-143
 
     int row = 0, joff = 0;
     auto comp_of = [&](int kind, int k, int vi, int c) -> int {  // vertex-storage offset of component c of attached vertex vi
         switch (kind) {
             case EK_STATE_COST: case EK_STAGE_INEQ: return k * s + c;
             case EK_CONTROL_COST: return k * s + nx + c;
-            case EK_FINAL_COST: return S.off_xf + c;
+            case EK_FINAL_COST: case EK_FINAL_INEQ: return S.off_xf + c;
             case EK_DT_COST: return S.off_dt;
             default:  // defect: (x_k, u_k, x_{k+1}, dt)
                 if (vi == 0) return k * s + c;
@@ -106,7 +109,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     };
     auto vert_dim = [&](int kind, int vi) -> int {
         switch (kind) {
-            case EK_STATE_COST: case EK_FINAL_COST: case EK_STAGE_INEQ: return nx;
+            case EK_STATE_COST: case EK_FINAL_COST: case EK_STAGE_INEQ: case EK_FINAL_INEQ: return nx;
             case EK_CONTROL_COST: return nu;
             case EK_DT_COST: return 1;
             default: return vi == 0 ? nx : vi == 1 ? nu : vi == 2 ? nx : 1;
@@ -116,9 +119,12 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     for (auto& sc : S.stage_cols) for (int& c : sc.col) c = -1;
     if (d.stage_ineq != CORBO_HIP_INEQ_NONE) { S.ineq_cols.assign((size_t)(N - 1) * nx, -1); S.ineq_rows.assign(N - 1, -1); }
     int dt_cost_seen = 0;
+    S.fin_row = -1;
+    for (int& f : S.fin_joff) f = -1;
     auto add_list = [&](const std::vector<E>& list) {
         for (const E& e : list) {
             if (e.kind == EK_STAGE_INEQ) S.ineq_rows[e.k] = row;
+            if (e.kind == EK_FINAL_INEQ) S.fin_row = row;
             int nverts = (e.kind == EK_DEFECT) ? 4 : 1;
             for (int vi = 0; vi < nverts; ++vi) {
                 int vd = vert_dim(e.kind, vi);
@@ -134,6 +140,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                         S.stage_cols[e.k].col[local] = joff;
                     }
                     else if (e.kind == EK_STAGE_INEQ) S.ineq_cols[(size_t)e.k * nx + c] = joff;
+                    else if (e.kind == EK_FINAL_INEQ) S.fin_joff[c] = joff;
                     else if (e.kind == EK_DT_COST) {
                         if (dt_cost_seen == 0) { S.comp[voff].cost_joff = joff; S.comp[voff].cost_row = row; }
                         else { S.comp[voff].cost2_joff = joff; S.comp[voff].cost2_row = row; }

@@ -22,7 +22,8 @@ enum EdgeKind : int32_t {
     EK_FINAL_COST   = 2,  // sqrt(Qf) .* (x_f - xref)           final_state_cost.cpp:72-92
     EK_DT_COST      = 3,  // sqrt(N-1) * dt                     minimum_time.h:49-78
     EK_DEFECT       = 4,  // dynamics defect (x_k,u_k,x_{k+1},dt)
-    EK_STAGE_INEQ   = 5   // stage inequality on x_k
+    EK_STAGE_INEQ   = 5,  // stage inequality on x_k
+    EK_FINAL_INEQ   = 6   // final-stage inequality on x_f (TerminalBall)
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):
@@ -59,6 +60,8 @@ struct Structure {
     std::vector<StageCols> stage_cols;   // N-1 defect edges
     std::vector<int32_t> ineq_cols;      // (N-1)*nx: Jacobian value index of d(ineq_k)/d(x_k[i]) or -1
     std::vector<int32_t> ineq_rows;      // N-1 residual rows (or empty)
+    int fin_row = -1;                    // residual row of the final-stage inequality or -1
+    int fin_joff[CORBO_HIP_MAX_NX];      // Jacobian value index of d(final ineq)/d(x_f[i]) or -1
     std::vector<CompInfo> comp;          // nvs entries
     std::vector<int32_t> jac_rows, jac_cols;  // structure in value order
     std::vector<int32_t> param_voff;     // parameter -> vertex storage offset

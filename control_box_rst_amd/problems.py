@@ -23,7 +23,7 @@ def _fill(arr, values, default=0.0):
 
 def make_desc(*, grid, defect, dynamics, nx, nu, N, dt, stage_cost=capi.COST_QUADRATIC_LSQ, final_cost=1,
               stage_ineq=capi.INEQ_NONE, q=(), r=(), qf=(), x_lb=(), x_ub=(), u_lb=(), u_ub=(), xf_fixed_mask=0,
-              dt_lb=0.0, dt_ub=INF, dyn_params=(), ineq_params=()) -> ProblemDesc:
+              dt_lb=0.0, dt_ub=INF, dyn_params=(), ineq_params=(), final_ineq=capi.FINAL_INEQ_NONE, final_ineq_params=()) -> ProblemDesc:
     d = ProblemDesc()
     d.grid, d.defect, d.dynamics = grid, defect, dynamics
     d.stage_cost, d.final_cost, d.stage_ineq = stage_cost, final_cost, stage_ineq
@@ -39,15 +39,21 @@ def make_desc(*, grid, defect, dynamics, nx, nu, N, dt, stage_cost=capi.COST_QUA
     _fill(d.qf_diag, qf)
     _fill(d.dyn_params, dyn_params)
     _fill(d.ineq_params, ineq_params)
+    d.final_ineq = final_ineq
+    _fill(d.final_ineq_params, final_ineq_params)
     return d
 
 
 # ---- cfg 3 / 4 (headline): unicycle point-to-point, FiniteDifferencesGrid N=100, Crank-Nicolson -----------------
-def unicycle_desc(N=100, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+def unicycle_desc(N=100, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, terminal_ball=None) -> ProblemDesc:
+    """terminal_ball = (S_diag, gamma): TerminalBall final-stage constraint (x_f - xref)^T S (x_f - xref) <= gamma."""
     q = (1.0, 1.0, 0.1)
+    extra = {}
+    if terminal_ball is not None:
+        extra = dict(final_ineq=capi.FINAL_INEQ_TERMINAL_BALL, final_ineq_params=tuple(terminal_ball[0]) + (terminal_ball[1],))
     return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_UNICYCLE, nx=3, nu=2, N=N, dt=dt,
                      q=q, r=(0.1, 0.05), qf=tuple(10.0 * v for v in q),
-                     x_lb=(-10.0,) * 3, x_ub=(10.0,) * 3, u_lb=(-1.0,) * 2, u_ub=(1.0,) * 2)
+                     x_lb=(-10.0,) * 3, x_ub=(10.0,) * 3, u_lb=(-1.0,) * 2, u_ub=(1.0,) * 2, **extra)
 
 
 UNICYCLE_WEIGHTS = (10.0, 10.0, 10.0)
@@ -67,9 +73,12 @@ def unicycle_instances(batch: int, seed: int = 20260928, first: int = 0):
 
 
 # ---- cfg 1: Van-der-Pol regulator, FiniteDifferencesGrid N=20 --------------------------------------------------
-def vdp_desc(N=20, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+def vdp_desc(N=20, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, terminal_ball=None) -> ProblemDesc:
+    extra = {}
+    if terminal_ball is not None:
+        extra = dict(final_ineq=capi.FINAL_INEQ_TERMINAL_BALL, final_ineq_params=tuple(terminal_ball[0]) + (terminal_ball[1],))
     return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_VAN_DER_POL, nx=2, nu=1, N=N, dt=dt,
-                     q=(1.0, 1.0), r=(0.1,), qf=(10.0, 10.0), u_lb=(-1.0,), u_ub=(1.0,), dyn_params=(1.0,))
+                     q=(1.0, 1.0), r=(0.1,), qf=(10.0, 10.0), u_lb=(-1.0,), u_ub=(1.0,), dyn_params=(1.0,), **extra)
 
 
 VDP_WEIGHTS = (2.0, 2.0, 2.0)

@@ -86,6 +86,14 @@ typedef enum corbo_hip_stage_ineq {
     CORBO_HIP_INEQ_BALL = 1 /* c(x) = r^2 - |x[0:3]-c|^2 <= 0 : spherical keep-out, params = cx,cy,cz,r (cfg 5) */
 } corbo_hip_stage_ineq;
 
+typedef enum corbo_hip_final_ineq {
+    CORBO_HIP_FINAL_INEQ_NONE = 0,
+    /* TerminalBall, diagonal S (optimal_control/include/corbo-optimal-control/functions/final_state_constraints.h:38-96,
+     * src/functions/final_state_constraints.cpp:60-80): c(x_f) = (x_f - xref)^T S (x_f - xref) - gamma <= 0, one inequality row
+     * on x_f, created after the stage inequalities (finite_differences_grid.cpp:135-143).  params = S_11 .. S_nn, gamma. */
+    CORBO_HIP_FINAL_INEQ_TERMINAL_BALL = 1
+} corbo_hip_final_ineq;
+
 /* Problem descriptor shared by every instance of a batch (POD). */
 typedef struct corbo_hip_problem_desc {
     int32_t grid;          /* corbo_hip_grid */
@@ -109,6 +117,9 @@ typedef struct corbo_hip_problem_desc {
     double qf_diag[CORBO_HIP_MAX_NX];
     double dyn_params[8];
     double ineq_params[8];
+    int32_t final_ineq;    /* enum corbo_hip_final_ineq; families with nx <= 3 only */
+    int32_t reserved0;
+    double final_ineq_params[CORBO_HIP_MAX_NX + 1];
 } corbo_hip_problem_desc;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */

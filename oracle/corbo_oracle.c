@@ -28,7 +28,7 @@ typedef struct {
     int col;        /* getVertexIdx(): first parameter index, -1 when not active (vertex_set.cpp:405-418) */
 } o_vertex;
 
-enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ };
+enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ };
 
 typedef struct {
     int type;
@@ -205,6 +205,14 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             out[0] = d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
             break;
         }
+        case E_FINAL_INEQ: { /* TerminalBall, diagonal mode, non-zero reference (final_state_constraints.cpp:72-76):
+                              * xd = x_k - xref; cost = xd^T * S_diag * xd - gamma  (row vector times diagonal, then the inner product) */
+            const double* xk = x + p->v[e->vert[0]].off;
+            double acc = 0.0;
+            for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - p->xref[i]; acc += (xd * d->final_ineq_params[i]) * xd; }
+            out[0] = acc - d->final_ineq_params[d->nx];
+            break;
+        }
         default: break;
     }
 }
@@ -330,6 +338,9 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_cost) { /* if (!_xf.isFixed()) ... getFinalStateCostEdge */
         o_edge* e = &lsq[n_lsq++]; e->type = E_FINAL_COST; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 0;
+    }
+    if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_ineq == CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) { /* getFinalStateConstraintEdge :136-143 */
+        o_edge* e = &ineq[n_ineq++]; e->type = E_FINAL_INEQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = 1; e->scale = 2;
     }
     /* row indices: [lsq | eq | ineq | bounds] (edge_set.cpp:31-42, hyper_graph_optimization_problem_edge_based.cpp:1491-1493) */
     p->n_edges = n_lsq + n_eq + n_ineq;

@@ -7,6 +7,7 @@
 // Built here (needs the reference's headers), runs on the GPU box (tests/test_gpu_dropin.py).
 #include <corbo-core/reference_trajectory.h>
 #include <corbo-core/time.h>
+#include <corbo-optimal-control/functions/final_state_constraints.h>
 #include <corbo-optimal-control/functions/final_state_cost.h>
 #include <corbo-optimal-control/functions/minimum_time.h>
 #include <corbo-optimal-control/functions/quadratic_cost.h>
@@ -125,7 +126,8 @@ static Run run(const std::string& scenario, bool hip, int N)
     double w;
     Eigen::VectorXd x0, xf;
     int solves = 1;
-    if (scenario == "unicycle")
+    const bool tball = (scenario == "unicycle_tball");   // cfg 3 structure, short horizon, TerminalBall final-stage constraint
+    if (scenario == "unicycle" || tball)
     {
         dyn  = std::make_shared<UnicycleRef>();
         grid = std::make_shared<FiniteDifferencesGrid>();
@@ -137,6 +139,11 @@ static Run run(const std::string& scenario, bool hip, int N)
         const double q[3] = {1, 1, 0.1}, rr[2] = {0.1, 0.05};
         for (int i = 0; i < 3; ++i) { d.q_diag[i] = q[i]; d.qf_diag[i] = 10.0 * q[i]; }
         for (int i = 0; i < 2; ++i) d.r_diag[i] = rr[i];
+        if (tball)
+        {
+            d.final_ineq = CORBO_HIP_FINAL_INEQ_TERMINAL_BALL;
+            d.final_ineq_params[0] = 1.0; d.final_ineq_params[1] = 1.0; d.final_ineq_params[2] = 0.1; d.final_ineq_params[3] = 0.05;  // S, gamma
+        }
     }
     else if (scenario == "quad")
     {
@@ -204,7 +211,7 @@ static Run run(const std::string& scenario, bool hip, int N)
         any_grid = ms_grid;
     }
     StructuredOptimalControlProblem ocp(any_grid, dyn, hg, solver);
-    if (scenario == "unicycle")
+    if (scenario == "unicycle" || tball)
     {
         Eigen::MatrixXd Q  = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
         Eigen::MatrixXd R  = Eigen::Vector2d(0.1, 0.05).asDiagonal();
@@ -212,6 +219,11 @@ static Run run(const std::string& scenario, bool hip, int N)
         ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         ocp.setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
+        if (tball)
+        {
+            Eigen::MatrixXd Sm = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
+            ocp.setFinalStageConstraint(std::make_shared<TerminalBall>(Sm, 0.05));
+        }
     }
     else if (scenario == "quad")
     {
@@ -244,7 +256,7 @@ static Run run(const std::string& scenario, bool hip, int N)
 int main(int argc, char** argv)
 {
     int rc = 0;
-    for (const char* sc : {"unicycle", "dint", "quad"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball"})
     {
         const int N = std::string(sc) == "unicycle" ? 100 : std::string(sc) == "dint" ? 50 : 30;
         Run a = run(sc, false, N);

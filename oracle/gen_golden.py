@@ -53,6 +53,10 @@ def main():
         ("unicycle_n12", dict(scenario="unicycle", N=12, iters=6), (1, 2, 3, 4, 5, 6)),
         # reduced cfg 5: quadrotor, MultipleShootingGrid + RK4, u bounds, keep-out ball inequality
         ("quad_n10", dict(scenario="quad", N=10, iters=6), (1, 2, 4, 6)),
+        # TerminalBall final-stage inequality (final_state_constraints.h:38-96): violated on the short horizon (active row), and on
+        # the small problem with a radius that lets it switch between active and inactive
+        ("unicycle_n12_tball", dict(scenario="unicycle", N=12, iters=6, tball=1e-4, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
+        ("vdp_tball", dict(scenario="vdp", iters=6, tball=0.02, tball_s="1,2"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

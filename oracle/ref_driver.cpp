@@ -19,6 +19,7 @@
 #include <corbo-core/reference_trajectory.h>
 #include <corbo-core/time.h>
 #include <corbo-numerics/finite_differences_collocation.h>
+#include <corbo-optimal-control/functions/final_state_constraints.h>
 #include <corbo-optimal-control/functions/final_state_cost.h>
 #include <corbo-optimal-control/functions/minimum_time.h>
 #include <corbo-optimal-control/functions/quadratic_cost.h>
@@ -122,6 +123,8 @@ struct Scenario
     double w_eq = 2, w_ineq = 2, w_b = 2;
     Eigen::VectorXd x0, xf;
     std::string collocation = "crank_nicolson";
+    double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
+    Eigen::VectorXd tball_s;    // empty = no terminal ball
 };
 
 struct Built
@@ -239,6 +242,11 @@ static Built build(const Scenario& s, int iterations)
         b.ocp->setControlBounds(ulb, uub);
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
+    if (s.tball_s.size() > 0)
+    {
+        Eigen::MatrixXd Sm = s.tball_s.asDiagonal();
+        b.ocp->setFinalStageConstraint(std::make_shared<TerminalBall>(Sm, s.tball_gamma));
+    }
     if (!b.ocp->initialize())
     {
         fprintf(stderr, "ocp initialize failed\n");
@@ -347,6 +355,11 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("x0")) s.x0 = vec(kv["x0"]);
     if (kv.count("xf")) s.xf = vec(kv["xf"]);
     if (kv.count("collocation")) s.collocation = kv["collocation"];
+    if (kv.count("tball"))
+    {
+        s.tball_gamma = atof(kv["tball"].c_str());
+        s.tball_s     = kv.count("tball_s") ? vec(kv["tball_s"]) : Eigen::VectorXd::Ones(s.nx);
+    }
     return s;
 }
 
@@ -357,6 +370,11 @@ static int dump(const Scenario& s)
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     printVec("x0", s.x0);
     printVec("xf", s.xf);
+    if (s.tball_s.size() > 0)
+    {
+        printf("\"tball_gamma\": %.17g, ", s.tball_gamma);
+        printVec("tball_s", s.tball_s);
+    }
 
     // ---- hot-path pieces at the initial point: LM with 0 iterations builds the graph, evaluates once and returns
     {

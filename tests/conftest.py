@@ -33,10 +33,11 @@ def desc_for(g):
     from control_box_rst_amd import capi, problems
     defect = {"forward": capi.DEFECT_FORWARD, "backward": capi.DEFECT_BACKWARD, "midpoint": capi.DEFECT_MIDPOINT,
               "crank_nicolson": capi.DEFECT_CRANK_NICOLSON}[g.get("collocation", "crank_nicolson")]
+    tball = (g["tball_s"], g["tball_gamma"]) if "tball_s" in g else None
     if g["scenario"] == "unicycle":
-        return problems.unicycle_desc(N=g["N"], dt=g["dt"], defect=defect)
+        return problems.unicycle_desc(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
     if g["scenario"] == "vdp":
-        return problems.vdp_desc(N=g["N"], dt=g["dt"], defect=defect)
+        return problems.vdp_desc(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
     if g["scenario"] == "dint":
         return problems.dint_desc(N=g["N"], dt=g["dt"])
     if g["scenario"] == "quad":

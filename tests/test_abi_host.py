@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header(lib):
     # sizes implied by include/corbo_hip.h (packing check of the ctypes mirrors)
-    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8
+    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8
     assert C.sizeof(capi.Dims) == 8 * 4
     assert C.sizeof(capi.LmOpts) == 8 + 9 * 8
     o = capi.LmOpts()
@@ -37,7 +37,7 @@ def test_struct_sizes_match_header(lib):
     assert (o.iterations, o.weight_eq, o.adapt_factor_eq, o.adapt_max_bounds) == (10, 2.0, 1.0, 500.0)
 
 
-@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12", "quad_n10"])
+@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12", "quad_n10", "unicycle_n12_tball", "vdp_tball"])
 def test_dims_and_structure_match_reference(lib, oracle_mod, name):
     g = load_golden(name)
     d = desc_for(g)

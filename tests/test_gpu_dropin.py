@@ -21,7 +21,7 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     g.build()
     p = subprocess.run([DEMO], capture_output=True, text=True, timeout=300)
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 3, (p.stdout, p.stderr)
+    assert len(lines) == 4, (p.stdout, p.stderr)   # cfg 3, cfg 2, reduced cfg 5, cfg 3 structure + TerminalBall
     for r in lines:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, r
         # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
