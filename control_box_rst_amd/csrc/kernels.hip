@@ -2204,6 +2204,7 @@ bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hi
         case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, stream);
         case CORBO_HIP_DEFECT_MIDPOINT: return launch_pass_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(fp, sp, stream);
         case CORBO_HIP_DEFECT_CRANK_NICOLSON: return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, stream);
+        case CORBO_HIP_DEFECT_RK4_SHOOTING: return launch_pass_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(fp, sp, stream);
         default: return false;
     }
 }

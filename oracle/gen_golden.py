@@ -57,6 +57,9 @@ def main():
         # the small problem with a radius that lets it switch between active and inactive
         ("unicycle_n12_tball", dict(scenario="unicycle", N=12, iters=6, tball=1e-4, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
         ("vdp_tball", dict(scenario="vdp", iters=6, tball=0.02, tball_s="1,2"), (1, 2, 3, 4, 5, 6)),
+        # MultipleShootingGrid + explicit RK4 on the small models (multiple_shooting_grid.cpp:38-197, explicit_integrators.h:280-295)
+        ("vdp_ms_rk4", dict(scenario="vdp", grid="ms", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("unicycle_n12_ms_rk4", dict(scenario="unicycle", grid="ms", N=12, iters=6), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

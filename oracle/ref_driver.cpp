@@ -123,6 +123,7 @@ struct Scenario
     double w_eq = 2, w_ineq = 2, w_b = 2;
     Eigen::VectorXd x0, xf;
     std::string collocation = "crank_nicolson";
+    bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
 };
@@ -158,15 +159,22 @@ static Built build(const Scenario& s, int iterations)
     b.solver->setPenaltyWeights(s.w_eq, s.w_ineq, s.w_b);
     b.stats = std::make_shared<OptimalControlProblemStatistics>();
 
+    auto make_ms = [&]() {
+        b.ms_grid = std::make_shared<MultipleShootingGrid>();
+        b.ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        b.ms_grid->setNRef(s.N);
+        b.ms_grid->setDtRef(s.dt);
+        b.any_grid = b.ms_grid;
+    };
     if (s.name == "unicycle")
     {
-        dyn    = std::make_shared<UnicycleRef>();
-        b.grid = std::make_shared<FiniteDifferencesGrid>();
+        dyn = std::make_shared<UnicycleRef>();
+        if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
     else if (s.name == "vdp")
     {
-        dyn    = std::make_shared<VanDerPolOscillator>();
-        b.grid = std::make_shared<FiniteDifferencesGrid>();
+        dyn = std::make_shared<VanDerPolOscillator>();
+        if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
     else if (s.name == "dint")
     {
@@ -355,6 +363,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("x0")) s.x0 = vec(kv["x0"]);
     if (kv.count("xf")) s.xf = vec(kv["xf"]);
     if (kv.count("collocation")) s.collocation = kv["collocation"];
+    if (kv.count("grid")) s.ms = (kv["grid"] == "ms");
     if (kv.count("tball"))
     {
         s.tball_gamma = atof(kv["tball"].c_str());
@@ -368,6 +377,7 @@ static int dump(const Scenario& s)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters\": %d, \"solves\": %d,\n", s.name.c_str(), s.nx, s.nu,
            s.N, s.dt, s.iters, s.solves);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
+    if (s.ms) printf("\"grid\": \"ms\",\n");
     printVec("x0", s.x0);
     printVec("xf", s.xf);
     if (s.tball_s.size() > 0)

@@ -34,10 +34,12 @@ def desc_for(g):
     defect = {"forward": capi.DEFECT_FORWARD, "backward": capi.DEFECT_BACKWARD, "midpoint": capi.DEFECT_MIDPOINT,
               "crank_nicolson": capi.DEFECT_CRANK_NICOLSON}[g.get("collocation", "crank_nicolson")]
     tball = (g["tball_s"], g["tball_gamma"]) if "tball_s" in g else None
-    if g["scenario"] == "unicycle":
-        return problems.unicycle_desc(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
-    if g["scenario"] == "vdp":
-        return problems.vdp_desc(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
+    if g["scenario"] in ("unicycle", "vdp"):
+        mk = problems.unicycle_desc if g["scenario"] == "unicycle" else problems.vdp_desc
+        d = mk(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
+        if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
+            d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+        return d
     if g["scenario"] == "dint":
         return problems.dint_desc(N=g["N"], dt=g["dt"])
     if g["scenario"] == "quad":
