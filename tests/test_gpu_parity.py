@@ -359,3 +359,35 @@ def test_full_size_properties_cfg5():
     s1.solve()
     x1, c1, _ = s1.get_solution()
     assert np.array_equal(x1[0], X[100]) and c1[0] == chi2[100]
+
+
+def test_small_family_with_stage_inequality_vs_oracle(oracle_mod):
+    """The stage inequality (keep-out ball in the first three state components) on a small-block family: the fused kernel's stage-
+    inequality rows (rank-1 terms on the 3x3 blocks), here together with a TerminalBall -- residual, Jacobian, 6-iteration solve."""
+    d = problems.unicycle_desc(N=24, terminal_ball=((1.0, 1.0, 0.1), 0.02))
+    d.stage_ineq = capi.INEQ_BALL
+    for i, v in enumerate((1.0, 0.5, 0.25, 0.35)):
+        d.ineq_params[i] = v
+    B = 4
+    x0, xf = problems.unicycle_instances(B, seed=5)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(6)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    assert s.dims.ineq == 23 + 1
+    n_active = 0
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*problems.UNICYCLE_WEIGHTS)
+        assert np.abs(values[b] - vo).max() <= 1e-11
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max())
+        n_active += int((vo[s.dims.lsq + s.dims.eq: s.dims.lsq + s.dims.eq + s.dims.ineq] > 0).sum())
+    assert n_active > 0   # the straight-line start runs through the ball
+    s.solve()
+    X, chi2, _ = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.abs(X - Xo).max() <= 2 * X_TOL, np.abs(X - Xo).max()
+    assert np.allclose(chi2, chi2o, rtol=CHI2_RTOL)
