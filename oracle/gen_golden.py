@@ -60,6 +60,8 @@ def main():
         # MultipleShootingGrid + explicit RK4 on the small models (multiple_shooting_grid.cpp:38-197, explicit_integrators.h:280-295)
         ("vdp_ms_rk4", dict(scenario="vdp", grid="ms", iters=6), (1, 2, 3, 4, 5, 6)),
         ("unicycle_n12_ms_rk4", dict(scenario="unicycle", grid="ms", N=12, iters=6), (1, 2, 3, 4, 5, 6)),
+        # stage inequality (keep-out ball in the first three state components) on the small-block family, with a terminal ball
+        ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

@@ -123,6 +123,7 @@ struct Scenario
     double w_eq = 2, w_ineq = 2, w_b = 2;
     Eigen::VectorXd x0, xf;
     std::string collocation = "crank_nicolson";
+    Eigen::VectorXd ball;       // ball=cx,cy,cz,r: BallKeepOut stage inequality on the first three state components (unicycle)
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
@@ -250,6 +251,8 @@ static Built build(const Scenario& s, int iterations)
         b.ocp->setControlBounds(ulb, uub);
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
+    if (s.ball.size() == 4 && s.name != "quad")
+        b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
     if (s.tball_s.size() > 0)
     {
         Eigen::MatrixXd Sm = s.tball_s.asDiagonal();
@@ -364,6 +367,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("xf")) s.xf = vec(kv["xf"]);
     if (kv.count("collocation")) s.collocation = kv["collocation"];
     if (kv.count("grid")) s.ms = (kv["grid"] == "ms");
+    if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("tball"))
     {
         s.tball_gamma = atof(kv["tball"].c_str());
@@ -378,6 +382,7 @@ static int dump(const Scenario& s)
            s.N, s.dt, s.iters, s.solves);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (s.ball.size() == 4) printVec("ball", s.ball);
     printVec("x0", s.x0);
     printVec("xf", s.xf);
     if (s.tball_s.size() > 0)

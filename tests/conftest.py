@@ -39,6 +39,10 @@ def desc_for(g):
         d = mk(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
         if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
             d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+        if "ball" in g:             # BallKeepOut stage inequality
+            d.stage_ineq = capi.INEQ_BALL
+            for i, v in enumerate(g["ball"]):
+                d.ineq_params[i] = v
         return d
     if g["scenario"] == "dint":
         return problems.dint_desc(N=g["N"], dt=g["dt"])
