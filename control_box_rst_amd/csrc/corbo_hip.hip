@@ -249,6 +249,15 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipMemset(h->d_values0, 0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_values1, 0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_jac, 0, B * h->nnz_pad * sizeof(double)));
+    // nothing the kernels may read depends on what the allocator handed out
+    CREATE_TRY(hipMemset(h->d_x, 0, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_xt, 0, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_x0, 0, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_lb, 0, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_ub, 0, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_xref, 0, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_xnew, 0, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    if (h->d_work) CREATE_TRY(hipMemset(h->d_work, 0, B * h->work_stride * sizeof(double)));
 #undef CREATE_TRY
     const char* prof = std::getenv("CORBO_HIP_PROFILE");
     h->profile       = prof && prof[0] == '1';
