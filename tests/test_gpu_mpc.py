@@ -75,12 +75,13 @@ def test_sequence_vs_reference(name):
 def test_closed_loop_batch_vs_oracle(oracle_mod):
     """Four MPC steps of 6 seeded unicycle instances on the device (trajectories never leave HBM).  Every step is checked against
     the oracle started from the device's previous trajectories (single-step comparison: rounding-level differences -- device
-    sin/cos vs the host's libm variant -- are amplified by every LM solve and would compound over the steps otherwise)."""
+    sin/cos vs the host's libm variant -- are amplified by every LM solve and would compound over the steps otherwise; the
+    disturbance is large enough that the accept / reject decisions of each solve are not noise-driven)."""
     d = problems.unicycle_desc(N=40)
     B = 6
     x0, xf = problems.unicycle_instances(B, seed=31)
     s = BatchedLevenbergMarquardt(d, B)
-    s.setIterations(5)
+    s.setIterations(4)
     s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
     X = s.init_trajectory(x0, xf)
     s.set_instance_data(X, xref=xf)
@@ -88,7 +89,7 @@ def test_closed_loop_batch_vs_oracle(oracle_mod):
     for step in range(4):
         Xprev = X
         if step > 0:
-            meas = X[:, st: st + d.nx] + 0.01 * np.sin(step + np.arange(d.nx))[None, :]
+            meas = X[:, st: st + d.nx] + 0.05 * np.sin(step + np.arange(d.nx))[None, :]
             s.warm_start(meas, shift=True)
         s.solve(new_run=True)
         X, chi2, _ = s.get_solution()
