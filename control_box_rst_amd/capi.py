@@ -33,7 +33,7 @@ class ProblemDesc(C.Structure):
         ("u_lb", C.c_double * MAX_NU), ("u_ub", C.c_double * MAX_NU),
         ("q_diag", C.c_double * MAX_NX), ("r_diag", C.c_double * MAX_NU), ("qf_diag", C.c_double * MAX_NX),
         ("dyn_params", C.c_double * 8), ("ineq_params", C.c_double * 8),
-        ("final_ineq", C.c_int32), ("reserved0", C.c_int32), ("final_ineq_params", C.c_double * (MAX_NX + 1)),
+        ("final_ineq", C.c_int32), ("final_eq", C.c_int32), ("final_ineq_params", C.c_double * (MAX_NX + 1)),
     ]
 
 

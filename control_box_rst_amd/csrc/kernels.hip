@@ -133,7 +133,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     const bool jac_with_values = STAGE && (mode != 0);
     // role of component v: index c inside its cost edge, dimension of that edge, weight and reference (branch-free).  Edges
     // without a reference (control cost, dt cost) use ref = 0: w * (x - 0) is w * x exactly.
-    auto comp_role = [&](int v, int& c, int& dim, double& w, double& ref) {
+    auto comp_role = [&](int v, int& c, int& dim, double& w, double& ref, bool& fin) {
         const bool is_dt  = (v == p.off_dt);
         const bool is_fin = !is_dt && v >= (p.N - 1) * S;
         const int cs_     = is_fin ? v - (p.N - 1) * S : v % S;
@@ -153,8 +153,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         ref = (is_dt || is_u) ? 0.0 : rf;
         dim = is_dt ? 1 : (is_u ? NU : NX);
         c   = is_dt ? 0 : (is_u ? cu : cs_);
+        fin = is_fin;
     };
-    auto comp_jac = [&](int v, const CompInfo& ci, double xv, double l, double u, int c, int dim, double w, double ref) {
+    auto comp_jac = [&](int v, const CompInfo& ci, double xv, double l, double u, int c, int dim, double w, double ref, bool fin) {
         if (!ci.fixed && ci.cost_joff >= 0) {  // central difference of the diagonal cost block (edge_interface.cpp:55-96)
             const double a = xv + delta, b = a + neg2delta;
             const double dv = scalar * (w * (a - ref) - w * (b - ref));
@@ -163,7 +164,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
             for (int r = 0; r < DM; ++r)
                 if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;  // untouched rows: scalar * (e - e) = 0
-            if (ci.cost2_joff >= 0) jst[ci.cost2_joff] = dv;   // duplicated MinimumTime dt edge (nlp_functions.cpp:91-107)
+            if (!fin && ci.cost2_joff >= 0) jst[ci.cost2_joff] = dv;   // duplicated MinimumTime dt edge (nlp_functions.cpp:91-107)
+        }
+        if (fin && !ci.fixed && ci.cost2_joff >= 0) {   // TerminalEqualityConstraint x_f - xref: diagonal block, scaled by w_eq (:1552)
+            const double a = xv + delta, b = a + neg2delta;
+            const double dv = (scalar * ((a - ref) - (b - ref))) * p.w_eq;
+            const int col0  = ci.cost2_joff - c;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) jst[col0 + r] = (r == c) ? dv : 0.0;
         }
         if (ci.bnd_joff >= 0) jst[ci.bnd_joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);  // :1721-1752
     };
@@ -172,12 +180,18 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         const double xv = xs[v];
         int c, dim;
         double w, ref;
-        comp_role(v, c, dim, w, ref);
+        bool fin;
+        comp_role(v, c, dim, w, ref, fin);
         if (ci.cost_row >= 0) {
             const double val = w * (xv - ref);
             vout[ci.cost_row] = val;
             sq_acc += val * val;
-            if (ci.cost2_row >= 0) { vout[ci.cost2_row] = val; sq_acc += val * val; }
+            if (!fin && ci.cost2_row >= 0) { vout[ci.cost2_row] = val; sq_acc += val * val; }
+        }
+        if (fin && ci.cost2_row >= 0) {   // TerminalEqualityConstraint row (equality section: times w_eq)
+            const double val = (xv - ref) * p.w_eq;
+            vout[ci.cost2_row] = val;
+            sq_acc += val * val;
         }
         if (ci.bnd_row >= 0) {
             double val = (xv < l) ? l - xv : ((xv > u) ? xv - u : 0.0);
@@ -185,7 +199,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             vout[ci.bnd_row] = val;
             sq_acc += val * val;
         }
-        if (jac_with_values) comp_jac(v, ci, xv, l, u, c, dim, w, ref);
+        if (jac_with_values) comp_jac(v, ci, xv, l, u, c, dim, w, ref, fin);
     };
     // Work split of the residual (horizons up to 128 stages, i.e. when half of the workgroup holds one lane per stage): waves 0-1
     // are the stage lanes (dynamics caches, one round of components, then the defects), waves 2-3 take the other rounds of
@@ -574,8 +588,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             const CompInfo ci{ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
             int c, dim;
             double w, ref;
-            comp_role(v, c, dim, w, ref);
-            comp_jac(v, ci, xs[v], p.lb[xo + v], p.ub[xo + v], c, dim, w, ref);
+            bool fin;
+            comp_role(v, c, dim, w, ref, fin);
+            comp_jac(v, ci, xs[v], p.lb[xo + v], p.ub[xo + v], c, dim, w, ref, fin);
         }
     }
     // (3) stage inequality rows (active rows only, explicit zero otherwise, :1568-1610)
@@ -952,6 +967,13 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const double dd = ac * ac + ab * ab, gg = -(ac * vc[e]) - ab * vb[e];
         if (e < NX) { dx_diag[e] = dd; gx[e] = gg; }
         else { du_diag[e - NX] = dd; gu[e - NX] = gg; }
+    }
+    if (has_block && !has_stage) {   // the last block: rows of a TerminalEqualityConstraint on x_f (second diagonal row of a component)
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const CompInfo ci = p.comp[k * S + e];
+            if (!ci.fixed && ci.cost2_joff >= 0) { const double a = J[ci.cost2_joff]; dx_diag[e] += a * a; gx[e] -= a * val[ci.cost2_row]; }
+        }
     }
     // stage inequality row on x_k: rank-1 contribution c c^T
     double cin[NX];

@@ -29,6 +29,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
     if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
     if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 3) return "terminal ball: families with nx <= 3 only";
+    if (d.final_eq != 0 && d.final_eq != 1) return "final_eq must be 0 or 1";
+    if (d.final_eq && d.nx > 3) return "terminal equality constraint: families with nx <= 3 only";
+    if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
     if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
     return "";
 }
@@ -90,6 +93,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         if (d.stage_ineq != CORBO_HIP_INEQ_NONE) ineq.push_back({EK_STAGE_INEQ, k, 1, 2});
         eq.push_back({EK_DEFECT, k, nx, 1});
     }
+    if (xf_unfixed > 0 && d.final_eq) eq.push_back({EK_FINAL_EQ, N - 1, nx, 1});   // finite_differences_grid.cpp:135-141
     if (xf_unfixed > 0 && d.final_cost) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
     if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) ineq.push_back({EK_FINAL_INEQ, N - 1, 1, 2});  // finite_differences_grid.cpp:135-143
 
@@ -98,7 +102,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         switch (kind) {
             case EK_STATE_COST: case EK_STAGE_INEQ: return k * s + c;
             case EK_CONTROL_COST: return k * s + nx + c;
-            case EK_FINAL_COST: case EK_FINAL_INEQ: return S.off_xf + c;
+            case EK_FINAL_COST: case EK_FINAL_INEQ: case EK_FINAL_EQ: return S.off_xf + c;
             case EK_DT_COST: return S.off_dt;
             default:  // defect: (x_k, u_k, x_{k+1}, dt)
                 if (vi == 0) return k * s + c;
@@ -109,7 +113,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     };
     auto vert_dim = [&](int kind, int vi) -> int {
         switch (kind) {
-            case EK_STATE_COST: case EK_FINAL_COST: case EK_STAGE_INEQ: case EK_FINAL_INEQ: return nx;
+            case EK_STATE_COST: case EK_FINAL_COST: case EK_STAGE_INEQ: case EK_FINAL_INEQ: case EK_FINAL_EQ: return nx;
             case EK_CONTROL_COST: return nu;
             case EK_DT_COST: return 1;
             default: return vi == 0 ? nx : vi == 1 ? nu : vi == 2 ? nx : 1;
@@ -132,6 +136,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                     int voff = comp_of(e.kind, e.k, vi, c);
                     // the cost edge of a fixed vertex still contributes its value rows (no Jacobian column)
                     if (e.kind == EK_STATE_COST || e.kind == EK_CONTROL_COST || e.kind == EK_FINAL_COST) S.comp[voff].cost_row = row + c;
+                    if (e.kind == EK_FINAL_EQ) S.comp[voff].cost2_row = row + c;   // second diagonal row of an x_f component
                     if (S.comp[voff].fixed) continue;
                     // one column of the block: rows e.dim, parameter = comp.param
                     for (int r = 0; r < e.dim; ++r) { S.jac_rows.push_back(row + r); S.jac_cols.push_back(S.comp[voff].param); }
@@ -141,6 +146,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                     }
                     else if (e.kind == EK_STAGE_INEQ) S.ineq_cols[(size_t)e.k * nx + c] = joff;
                     else if (e.kind == EK_FINAL_INEQ) S.fin_joff[c] = joff;
+                    else if (e.kind == EK_FINAL_EQ) S.comp[voff].cost2_joff = joff + c;
                     else if (e.kind == EK_DT_COST) {
                         if (dt_cost_seen == 0) { S.comp[voff].cost_joff = joff; S.comp[voff].cost_row = row; }
                         else { S.comp[voff].cost2_joff = joff; S.comp[voff].cost2_row = row; }

@@ -23,7 +23,8 @@ enum EdgeKind : int32_t {
     EK_DT_COST      = 3,  // sqrt(N-1) * dt                     minimum_time.h:49-78
     EK_DEFECT       = 4,  // dynamics defect (x_k,u_k,x_{k+1},dt)
     EK_STAGE_INEQ   = 5,  // stage inequality on x_k
-    EK_FINAL_INEQ   = 6   // final-stage inequality on x_f (TerminalBall)
+    EK_FINAL_INEQ   = 6,  // final-stage inequality on x_f (TerminalBall)
+    EK_FINAL_EQ     = 7   // final-stage equality x_f - xref (TerminalEqualityConstraint)
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):

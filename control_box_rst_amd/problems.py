@@ -23,7 +23,7 @@ def _fill(arr, values, default=0.0):
 
 def make_desc(*, grid, defect, dynamics, nx, nu, N, dt, stage_cost=capi.COST_QUADRATIC_LSQ, final_cost=1,
               stage_ineq=capi.INEQ_NONE, q=(), r=(), qf=(), x_lb=(), x_ub=(), u_lb=(), u_ub=(), xf_fixed_mask=0,
-              dt_lb=0.0, dt_ub=INF, dyn_params=(), ineq_params=(), final_ineq=capi.FINAL_INEQ_NONE, final_ineq_params=()) -> ProblemDesc:
+              dt_lb=0.0, dt_ub=INF, dyn_params=(), ineq_params=(), final_ineq=capi.FINAL_INEQ_NONE, final_ineq_params=(), final_eq=0) -> ProblemDesc:
     d = ProblemDesc()
     d.grid, d.defect, d.dynamics = grid, defect, dynamics
     d.stage_cost, d.final_cost, d.stage_ineq = stage_cost, final_cost, stage_ineq
@@ -40,6 +40,7 @@ def make_desc(*, grid, defect, dynamics, nx, nu, N, dt, stage_cost=capi.COST_QUA
     _fill(d.dyn_params, dyn_params)
     _fill(d.ineq_params, ineq_params)
     d.final_ineq = final_ineq
+    d.final_eq = final_eq
     _fill(d.final_ineq_params, final_ineq_params)
     return d
 

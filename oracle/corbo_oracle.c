@@ -28,7 +28,7 @@ typedef struct {
     int col;        /* getVertexIdx(): first parameter index, -1 when not active (vertex_set.cpp:405-418) */
 } o_vertex;
 
-enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ };
+enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ, E_FINAL_EQ };
 
 typedef struct {
     int type;
@@ -205,6 +205,11 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             out[0] = d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
             break;
         }
+        case E_FINAL_EQ: { /* TerminalEqualityConstraint::computeNonIntegralStateTerm (final_state_constraints.h:149-154): x_k - xref */
+            const double* xk = x + p->v[e->vert[0]].off;
+            for (int i = 0; i < d->nx; ++i) out[i] = xk[i] - p->xref[i];
+            break;
+        }
         case E_FINAL_INEQ: { /* TerminalBall, diagonal mode, non-zero reference (final_state_constraints.cpp:72-76):
                               * xd = x_k - xref; cost = xd^T * S_diag * xd - gamma  (row vector times diagonal, then the inner product) */
             const double* xk = x + p->v[e->vert[0]].off;
@@ -338,6 +343,9 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_cost) { /* if (!_xf.isFixed()) ... getFinalStateCostEdge */
         o_edge* e = &lsq[n_lsq++]; e->type = E_FINAL_COST; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 0;
+    }
+    if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_eq) { /* getFinalStateConstraintEdge, isEqualityConstraint() :136-141 */
+        o_edge* e = &eq[n_eq++]; e->type = E_FINAL_EQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 1;
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_ineq == CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) { /* getFinalStateConstraintEdge :136-143 */
         o_edge* e = &ineq[n_ineq++]; e->type = E_FINAL_INEQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = 1; e->scale = 2;

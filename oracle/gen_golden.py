@@ -61,6 +61,9 @@ def main():
         ("vdp_ms_rk4", dict(scenario="vdp", grid="ms", iters=6), (1, 2, 3, 4, 5, 6)),
         ("unicycle_n12_ms_rk4", dict(scenario="unicycle", grid="ms", N=12, iters=6), (1, 2, 3, 4, 5, 6)),
         # stage inequality (keep-out ball in the first three state components) on the small-block family, with a terminal ball
+        # TerminalEqualityConstraint x_f = xref (final_state_constraints.h:130-160): nx more equality rows on x_f
+        ("unicycle_n12_teq", dict(scenario="unicycle", N=12, iters=6, teq=1), (1, 2, 3, 4, 5, 6)),
+        ("vdp_teq", dict(scenario="vdp", iters=6, teq=1), (1, 2, 3, 4, 5, 6)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)

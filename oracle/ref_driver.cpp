@@ -124,6 +124,7 @@ struct Scenario
     Eigen::VectorXd x0, xf;
     std::string collocation = "crank_nicolson";
     Eigen::VectorXd ball;       // ball=cx,cy,cz,r: BallKeepOut stage inequality on the first three state components (unicycle)
+    bool teq = false;           // teq=1: TerminalEqualityConstraint(xf) final-stage constraint
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
@@ -253,6 +254,7 @@ static Built build(const Scenario& s, int iterations)
     }
     if (s.ball.size() == 4 && s.name != "quad")
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
+    if (s.teq) b.ocp->setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(s.xf));
     if (s.tball_s.size() > 0)
     {
         Eigen::MatrixXd Sm = s.tball_s.asDiagonal();
@@ -368,6 +370,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("collocation")) s.collocation = kv["collocation"];
     if (kv.count("grid")) s.ms = (kv["grid"] == "ms");
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
+    if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
     if (kv.count("tball"))
     {
         s.tball_gamma = atof(kv["tball"].c_str());
@@ -383,6 +386,7 @@ static int dump(const Scenario& s)
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.ms) printf("\"grid\": \"ms\",\n");
     if (s.ball.size() == 4) printVec("ball", s.ball);
+    if (s.teq) printf("\"teq\": 1,\n");
     printVec("x0", s.x0);
     printVec("xf", s.xf);
     if (s.tball_s.size() > 0)

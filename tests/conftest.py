@@ -39,6 +39,8 @@ def desc_for(g):
         d = mk(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
         if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
             d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+        if g.get("teq"):            # TerminalEqualityConstraint(xf)
+            d.final_eq = 1
         if "ball" in g:             # BallKeepOut stage inequality
             d.stage_ineq = capi.INEQ_BALL
             for i, v in enumerate(g["ball"]):
