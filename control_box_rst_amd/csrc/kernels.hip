@@ -1227,17 +1227,23 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
                 Xp[q][c] = SOA(Wam, q * NX + c, ep);   // ep's coupling to a (a is its a-side)
             }
         }
+        // absent neighbour: BOTH factors of every product are zeroed -- the clamped loads may have fetched never-written LDS
+        // (whatever an earlier kernel left there, possibly NaN bit patterns; 0 x NaN would poison the block)
         if (!has_m) {
 #pragma unroll
-            for (int q = 0; q < NX; ++q)
+            for (int q = 0; q < NX; ++q) {
+                ym[q] = 0.0; zm[q] = 0.0;
 #pragma unroll
                 for (int c = 0; c < NX; ++c) Xm[q][c] = 0.0;
+            }
         }
         if (!has_p) {
 #pragma unroll
-            for (int q = 0; q < NX; ++q)
+            for (int q = 0; q < NX; ++q) {
+                yp[q] = 0.0; zp[q] = 0.0;
 #pragma unroll
                 for (int c = 0; c < NX; ++c) Xp[q][c] = 0.0;
+            }
         }
         // Schur updates: D -= X^T X (both neighbours), v = X^T (operand)
         double vm[NX], vp[NX], wm[NX], wp[NX];
@@ -2112,15 +2118,16 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int inst = blockIdx.x + fp.inst0, tid = threadIdx.x;
     const int NP = NPC > 0 ? NPC : (fp.N | 1);
-    // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, reduction
-    // scratch = the factor phase's, vertex values behind the factor carve.
+    // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, vertex values
+    // behind the factor carve, then the LM state and the sweep phase's reduction scratch + flags.  (The scratch must not live inside
+    // the factor carve: a Jacobian with many bound and inequality entries is longer than the carve's prefix in front of it.)
     const int ftot = FL::total(NP, ARROW);
-    double* red = smem + FL::off_red(NP);
     double* jst = smem;
     double* cs  = smem + sp.nnz_pad;
     double* xs  = smem + ((ftot > sp.nnz_pad + fp.N * Dy::NC ? ftot : sp.nnz_pad + fp.N * Dy::NC) + 1) / 2 * 2;
-    int* flags  = reinterpret_cast<int*>(red + 8);
     LmState* sl = reinterpret_cast<LmState*>(xs + sp.nvs);   // LM state of the instance, resident in LDS (nvs is even: 16-byte aligned)
+    double* red = reinterpret_cast<double*>(sl + 1);         // [12]
+    int* flags  = reinterpret_cast<int*>(red + 8);
     lm_state_in(sl, fp.st + inst, tid);
     if (tid == 0) flags[0] = 0;
     __syncthreads();
@@ -2205,7 +2212,7 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     if (fp.N > SWEEP_THREADS) return false;
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
-    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs) + sizeof(LmState);                // + vertex values + LM state
+    const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs + 12) + sizeof(LmState);           // + vertex values + LM state + scratch
     const dim3 g(fp.batch), b(SWEEP_THREADS);
     // the run-to-completion kernel of the headline horizon (N = 100) is specialised on the LDS stride
     if (fp.loop_passes > 0) {

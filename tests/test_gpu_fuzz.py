@@ -1,0 +1,103 @@
+"""GPU fuzz test (-m gpu): seeded random descriptors of the small-block families (horizon, defect formula, grid kind, bound
+patterns with unbounded components, partially fixed x_f, cost terms on / off, stage inequality, final-stage constraints, weights)
+-- structure, residual, Jacobian and a short LM solve of the device against the oracle."""
+import numpy as np
+import pytest
+
+from control_box_rst_amd import capi, problems
+from control_box_rst_amd.capi import INF
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt, get_structure
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+
+
+def random_desc(rng):
+    fam = rng.choice(["vdp", "unicycle", "dint"])
+    N = int(rng.integers(3, 70))
+    dt = float(rng.uniform(0.05, 0.2))
+    if fam == "dint":
+        d = problems.dint_desc(N=N, dt=dt)
+        d.xf_fixed_mask = int(rng.choice([0b11, 0b01, 0b10, 0b00]))
+        if d.xf_fixed_mask != 0b11 and rng.random() < 0.5:   # a final cost on the unfixed components
+            d.final_cost = 1
+            for i in range(2):
+                d.qf_diag[i] = float(rng.uniform(0.5, 5.0))
+        nx, nu = 2, 1
+    else:
+        mk = problems.vdp_desc if fam == "vdp" else problems.unicycle_desc
+        d = mk(N=N, dt=dt)
+        nx, nu = d.nx, d.nu
+        if rng.random() < 0.3:
+            d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+        else:
+            d.defect = int(rng.choice([capi.DEFECT_FORWARD, capi.DEFECT_BACKWARD, capi.DEFECT_MIDPOINT, capi.DEFECT_CRANK_NICOLSON]))
+        d.xf_fixed_mask = int(rng.integers(0, 2 ** nx)) if rng.random() < 0.3 else 0
+        all_fixed = d.xf_fixed_mask == 2 ** nx - 1
+        d.final_cost = 0 if all_fixed else int(rng.random() < 0.8)
+        r = rng.random()
+        if not all_fixed and r < 0.25:
+            d.final_ineq = capi.FINAL_INEQ_TERMINAL_BALL
+            for i in range(nx):
+                d.final_ineq_params[i] = float(rng.uniform(0.1, 2.0))
+            d.final_ineq_params[nx] = float(rng.uniform(1e-4, 0.5))
+        elif not all_fixed and r < 0.45:
+            d.final_eq = 1
+        if fam == "unicycle" and rng.random() < 0.3:
+            d.stage_ineq = capi.INEQ_BALL
+            for i, v in enumerate((1.0, 0.5, 0.2, float(rng.uniform(0.1, 0.5)))):
+                d.ineq_params[i] = v
+        for i in range(nx):
+            d.q_diag[i] = float(rng.uniform(0.0, 2.0))
+        for i in range(nu):
+            d.r_diag[i] = float(rng.uniform(0.01, 1.0))
+    # bound patterns: every component independently unbounded / one-sided / two-sided
+    for arr_lb, arr_ub, n, lo, hi in ((d.x_lb, d.x_ub, nx, -3.0, 3.0), (d.u_lb, d.u_ub, nu, -1.0, 1.0)):
+        for i in range(n):
+            k = rng.integers(0, 4)
+            arr_lb[i] = -INF if k in (0, 2) else lo * float(rng.uniform(0.3, 1.0))
+            arr_ub[i] = INF if k in (0, 1) else hi * float(rng.uniform(0.3, 1.0))
+    return fam, d
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_descriptor_vs_oracle(oracle_mod, seed):
+    rng = np.random.default_rng(1000 + seed)
+    fam, d = random_desc(rng)
+    B = 3
+    w = tuple(float(v) for v in rng.uniform(1.0, 50.0, 3))
+    x0 = rng.uniform(-1, 1, (B, d.nx))
+    xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2])[: d.nx] if fam != "dint" else np.array([1.0, 0.0]))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(3)
+    s.setPenaltyWeights(*w)
+    X0 = s.init_trajectory(x0, xf)
+    X0 = X0 + 0.05 * rng.normal(size=X0.shape)          # off the straight line: bounds / inequalities get active
+    X0[:, : d.nx] = x0
+    if d.grid == capi.GRID_FD_VARIABLE:
+        X0[:, -1] = d.dt_ref
+    s.set_instance_data(X0, xref=xf)
+    po = oracle_mod.OracleProblem(d)
+    rows, cols = get_structure(d)
+    ro, co = po.structure()
+    assert np.array_equal(rows, ro) and np.array_equal(cols, co), (seed, fam)
+    assert s.dims.as_dict() == po.dims.as_dict()
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*w)
+        assert np.abs(values[b] - vo).max() <= 1e-11 * max(1.0, np.abs(vo).max()), (seed, fam, b)
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max()), (seed, fam, b)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    Xo, chi2o, so = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.abs(X - Xo).max() <= 1e-5 * max(1.0, np.abs(Xo).max()), (seed, fam, np.abs(X - Xo).max())
+    assert np.allclose(chi2, chi2o, rtol=1e-5, atol=1e-10), (seed, fam)
