@@ -67,7 +67,7 @@ def random_desc(rng):
     return fam, d
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(160))
 def test_random_descriptor_vs_oracle(oracle_mod, seed):
     rng = np.random.default_rng(1000 + seed)
     fam, d = random_desc(rng)
@@ -101,3 +101,45 @@ def test_random_descriptor_vs_oracle(oracle_mod, seed):
     Xo, chi2o, so = oracle_mod.solve_batch(d, X0, xf, s.opts)
     assert np.abs(X - Xo).max() <= 1e-5 * max(1.0, np.abs(Xo).max()), (seed, fam, np.abs(X - Xo).max())
     assert np.allclose(chi2, chi2o, rtol=1e-5, atol=1e-10), (seed, fam)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
+    """Big-block family (quadrotor, multiple shooting + RK4): random horizon, bound patterns, keep-out ball on / off, weights."""
+    rng = np.random.default_rng(5000 + seed)
+    N = int(rng.integers(4, 36))
+    d = problems.quad_desc(N=N, dt=float(rng.uniform(0.03, 0.08)))
+    if rng.random() < 0.4:
+        d.stage_ineq = capi.INEQ_NONE
+    for i in range(12):
+        k = rng.integers(0, 4)
+        d.x_lb[i] = -INF if k in (0, 1, 2) else -4.0
+        d.x_ub[i] = INF if k in (0, 1) else 4.0
+    for i in range(4):
+        d.u_lb[i] = -INF if rng.random() < 0.3 else (0.0 if i == 0 else -1.0)
+        d.u_ub[i] = INF if rng.random() < 0.3 else (20.0 if i == 0 else 1.0)
+    B = 2
+    w = tuple(float(v) for v in rng.uniform(2.0, 30.0, 3))
+    x0, xf = problems.quad_instances(B, seed=int(rng.integers(0, 10 ** 6)))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(3)
+    s.setPenaltyWeights(*w)
+    X0 = s.init_trajectory(x0, xf)
+    X0[:, 12:] += 0.02 * rng.normal(size=X0[:, 12:].shape)
+    s.set_instance_data(X0, xref=xf)
+    po = oracle_mod.OracleProblem(d)
+    rows, cols = get_structure(d)
+    ro, co = po.structure()
+    assert np.array_equal(rows, ro) and np.array_equal(cols, co)
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*w)
+        assert np.abs(values[b] - vo).max() <= 1e-10 * max(1.0, np.abs(vo).max()), (seed, b)
+        assert np.abs(jac[b] - jo).max() <= 2e-6 * max(1.0, np.abs(jo).max()), (seed, b)
+    s.solve()
+    X, chi2, _ = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.allclose(chi2, chi2o, rtol=1e-6), (seed, chi2, chi2o)
+    assert np.abs(X - Xo).max() <= 5e-4, (seed, np.abs(X - Xo).max())
