@@ -19,9 +19,9 @@ def _built():
     g.build()
 
 
-def random_desc(rng):
+def random_desc(rng, long_horizon=False):
     fam = rng.choice(["vdp", "unicycle", "dint"])
-    N = int(rng.integers(3, 70))
+    N = int(rng.integers(100, 257)) if long_horizon else int(rng.integers(3, 70))
     dt = float(rng.uniform(0.05, 0.2))
     if fam == "dint":
         d = problems.dint_desc(N=N, dt=dt)
@@ -67,10 +67,10 @@ def random_desc(rng):
     return fam, d
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", list(range(160)) + list(range(10000, 10024)))
 def test_random_descriptor_vs_oracle(oracle_mod, seed):
     rng = np.random.default_rng(1000 + seed)
-    fam, d = random_desc(rng)
+    fam, d = random_desc(rng, long_horizon=(seed >= 10000))   # the last 24: horizons of 100 .. 256 stages
     B = 3
     w = tuple(float(v) for v in rng.uniform(1.0, 50.0, 3))
     x0 = rng.uniform(-1, 1, (B, d.nx))
