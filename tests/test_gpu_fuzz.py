@@ -143,3 +143,65 @@ def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
     Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
     assert np.allclose(chi2, chi2o, rtol=1e-6), (seed, chi2, chi2o)
     assert np.abs(X - Xo).max() <= 5e-4, (seed, np.abs(X - Xo).max())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_per_instance_bounds_and_weight_adaptation_vs_oracle(oracle_mod, seed):
+    """Per-instance bound VALUES (the finiteness pattern of the descriptor is kept, corbo_hip_set_instance_data) and a second solve
+    with adapted penalty weights (new_run = false: weights times factor, clamped; levenberg_marquardt_sparse.cpp:83-86,270-287)."""
+    rng = np.random.default_rng(7000 + seed)
+    d = problems.unicycle_desc(N=int(rng.integers(5, 50)))
+    B = 3
+    x0, xf = problems.unicycle_instances(B, seed=int(rng.integers(0, 10 ** 6)))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(3)
+    s.setPenaltyWeights(*(float(v) for v in rng.uniform(2.0, 20.0, 3)))
+    s.setWeightAdapation(*(float(v) for v in rng.uniform(1.0, 3.0, 3)), 25.0, 25.0, 25.0)
+    X0 = s.init_trajectory(x0, xf) + 0.03 * rng.normal(size=(B, s.dims.nv))
+    X0[:, :3] = x0
+    nv = s.dims.nv
+    lb = np.tile(np.concatenate([np.tile([-10.0] * 3 + [-1.0] * 2, d.N - 1), [-10.0] * 3]), (B, 1))[:, :nv]
+    ub = -lb
+    lb *= rng.uniform(0.2, 1.0, lb.shape)      # per-instance, per-component bound values
+    ub *= rng.uniform(0.2, 1.0, ub.shape)
+    s.set_instance_data(X0, lb=lb, ub=ub, xref=xf)
+    ps = []
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], lb=lb[b], ub=ub[b], xref=xf[b])
+        ps.append(p)
+    for k in range(2):
+        s.solve(new_run=(k == 0))
+        X, chi2, _ = s.get_solution()
+        for b in range(B):
+            _, c2, _ = ps[b].solve(s.opts, new_run=(k == 0))
+            assert np.abs(X[b] - ps[b].x()).max() <= 1e-5, (seed, k, b, np.abs(X[b] - ps[b].x()).max())
+            assert abs(chi2[b] - c2) <= 1e-5 * max(1.0, abs(c2)), (seed, k, b)
+
+
+def test_independent_handles_interleaved():
+    """Handles are independent (own buffers, own stream): two batches solved through two handles whose calls interleave give the
+    results of the same batches solved one after the other; creating and destroying handles in between does not disturb them."""
+    d1, d2 = problems.unicycle_desc(N=60), problems.vdp_desc(N=33)
+    xa0, xaf = problems.unicycle_instances(70, seed=1)
+    rng = np.random.default_rng(2)
+    xb0, xbf = rng.uniform(-1, 1, (40, 2)), np.zeros((40, 2))
+
+    def fresh(d, B, w, x0, xf):
+        s = BatchedLevenbergMarquardt(d, B)
+        s.setIterations(6)
+        s.setPenaltyWeights(*w)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        return s
+
+    ref1 = fresh(d1, 70, problems.UNICYCLE_WEIGHTS, xa0, xaf); ref1.solve(); R1 = ref1.get_solution()
+    ref2 = fresh(d2, 40, problems.VDP_WEIGHTS, xb0, xbf); ref2.solve(); R2 = ref2.get_solution()
+    del ref1, ref2
+    s1 = fresh(d1, 70, problems.UNICYCLE_WEIGHTS, xa0, xaf)
+    s2 = fresh(d2, 40, problems.VDP_WEIGHTS, xb0, xbf)
+    for _ in range(3):
+        s1.restore_instance_data(); s2.restore_instance_data()
+        s1.solve(); tmp = fresh(d2, 5, problems.VDP_WEIGHTS, xb0[:5], xbf[:5]); s2.solve(); tmp.solve(); del tmp
+        A, B_ = s1.get_solution(), s2.get_solution()
+        assert np.array_equal(A[0], R1[0]) and np.array_equal(A[1], R1[1])
+        assert np.array_equal(B_[0], R2[0]) and np.array_equal(B_[1], R2[1])
