@@ -205,3 +205,32 @@ def test_independent_handles_interleaved():
         A, B_ = s1.get_solution(), s2.get_solution()
         assert np.array_equal(A[0], R1[0]) and np.array_equal(A[1], R1[1])
         assert np.array_equal(B_[0], R2[0]) and np.array_equal(B_[1], R2[1])
+
+
+def test_nan_instance_is_contained(oracle_mod):
+    """An instance whose start trajectory holds a NaN: chi2 is NaN, rho is NaN, `rho <= 0` is false, the inner loops end at once
+    (levenberg_marquardt_sparse.cpp:169-215) -- same status as the oracle, no hang, and its batch neighbours are not affected."""
+    d = problems.unicycle_desc(N=30)
+    B = 5
+    x0, xf = problems.unicycle_instances(B, seed=9)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(10)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    Xbad = X0.copy()
+    Xbad[2, 40] = np.nan
+    s.set_instance_data(Xbad, xref=xf)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    p = oracle_mod.OracleProblem(d)
+    p.set_data(Xbad[2], xref=xf[2])
+    so, c2, _ = p.solve(s.opts)
+    assert status[2] == so and np.isnan(chi2[2]) == np.isnan(c2)
+    good = [0, 1, 3, 4]
+    s2 = BatchedLevenbergMarquardt(d, 4)
+    s2.setIterations(10)
+    s2.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    s2.set_instance_data(X0[good], xref=xf[good])
+    s2.solve()
+    X2, chi22, st2 = s2.get_solution()
+    assert np.array_equal(X[good], X2) and np.array_equal(chi2[good], chi22) and np.array_equal(status[good], st2)
