@@ -64,6 +64,11 @@ def main():
         # TerminalEqualityConstraint x_f = xref (final_state_constraints.h:130-160): nx more equality rows on x_f
         ("unicycle_n12_teq", dict(scenario="unicycle", N=12, iters=6, teq=1), (1, 2, 3, 4, 5, 6)),
         ("vdp_teq", dict(scenario="vdp", iters=6, teq=1), (1, 2, 3, 4, 5, 6)),
+        # bound patterns with unbounded and one-sided components (finite <=> lb > -2e30 || ub < 2e30, vector_vertex.h:174-184) and a
+        # partially fixed goal state (PartiallyFixedVectorVertex, setXfFixed)
+        ("unicycle_n12_patterns", dict(scenario="unicycle", N=12, iters=5, xlb="-inf,-1.5,-inf", xub="1.2,inf,inf", ulb="-0.8,-inf", uub="inf,0.6",
+                                       xf_fixed=5), (1, 2, 3, 4, 5)),
+        ("vdp_patterns", dict(scenario="vdp", iters=5, xlb="-0.5,-inf", xub="inf,inf", ulb="-inf", uub="0.7", xf_fixed=2, final_cost=0), (1, 2, 3, 4, 5)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)

@@ -124,6 +124,9 @@ struct Scenario
     Eigen::VectorXd x0, xf;
     std::string collocation = "crank_nicolson";
     Eigen::VectorXd ball;       // ball=cx,cy,cz,r: BallKeepOut stage inequality on the first three state components (unicycle)
+    Eigen::VectorXd xlb, xub, ulb, uub;   // xlb=/xub=/ulb=/uub= comma lists ("inf" = unbounded): replace the scenario's box bounds
+    int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
+    int final_cost = -1;        // final_cost=0: no final-state cost
     bool teq = false;           // teq=1: TerminalEqualityConstraint(xf) final-stage constraint
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
@@ -208,6 +211,12 @@ static Built build(const Scenario& s, int iterations)
         b.grid->setDtRef(s.dt);
         b.grid->setCostIntegrationRule(FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         b.grid->setFiniteDifferencesCollocationMethod(makeCollocation(s.collocation));
+        if (s.xf_fixed >= 0)
+        {
+            Eigen::Matrix<bool, -1, 1> fixed(s.nx);
+            for (int i = 0; i < s.nx; ++i) fixed[i] = (s.xf_fixed >> i) & 1;
+            b.grid->setXfFixed(fixed);
+        }
         b.any_grid = b.grid;
     }
 
@@ -252,6 +261,15 @@ static Built build(const Scenario& s, int iterations)
         b.ocp->setControlBounds(ulb, uub);
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
+    if (s.xlb.size() > 0 || s.ulb.size() > 0)
+    {
+        Eigen::VectorXd xl = s.xlb.size() ? s.xlb : Eigen::VectorXd::Constant(s.nx, -CORBO_INF_DBL);
+        Eigen::VectorXd xu = s.xub.size() ? s.xub : Eigen::VectorXd::Constant(s.nx, CORBO_INF_DBL);
+        Eigen::VectorXd ul = s.ulb.size() ? s.ulb : Eigen::VectorXd::Constant(s.nu, -CORBO_INF_DBL);
+        Eigen::VectorXd uu = s.uub.size() ? s.uub : Eigen::VectorXd::Constant(s.nu, CORBO_INF_DBL);
+        b.ocp->setBounds(xl, xu, ul, uu);
+    }
+    if (s.final_cost == 0) b.ocp->setFinalStageCost({});
     if (s.ball.size() == 4 && s.name != "quad")
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
     if (s.teq) b.ocp->setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(s.xf));
@@ -369,6 +387,19 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("xf")) s.xf = vec(kv["xf"]);
     if (kv.count("collocation")) s.collocation = kv["collocation"];
     if (kv.count("grid")) s.ms = (kv["grid"] == "ms");
+    auto bvec = [&](const std::string& str) {   // like vec(), "inf" / "-inf" = +-CORBO_INF_DBL
+        std::vector<double> v;
+        std::stringstream ss(str);
+        std::string item;
+        while (std::getline(ss, item, ',')) v.push_back(item == "inf" ? CORBO_INF_DBL : item == "-inf" ? -CORBO_INF_DBL : strtod(item.c_str(), nullptr));
+        return Eigen::VectorXd(Eigen::Map<Eigen::VectorXd>(v.data(), v.size()));
+    };
+    if (kv.count("xlb")) s.xlb = bvec(kv["xlb"]);
+    if (kv.count("xub")) s.xub = bvec(kv["xub"]);
+    if (kv.count("ulb")) s.ulb = bvec(kv["ulb"]);
+    if (kv.count("uub")) s.uub = bvec(kv["uub"]);
+    if (kv.count("xf_fixed")) s.xf_fixed = atoi(kv["xf_fixed"].c_str());
+    if (kv.count("final_cost")) s.final_cost = atoi(kv["final_cost"].c_str());
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
     if (kv.count("tball"))
@@ -387,6 +418,12 @@ static int dump(const Scenario& s)
     if (s.ms) printf("\"grid\": \"ms\",\n");
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.teq) printf("\"teq\": 1,\n");
+    if (s.xlb.size()) printVec("xlb", s.xlb);
+    if (s.xub.size()) printVec("xub", s.xub);
+    if (s.ulb.size()) printVec("ulb", s.ulb);
+    if (s.uub.size()) printVec("uub", s.uub);
+    if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
+    if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
     printVec("x0", s.x0);
     printVec("xf", s.xf);
     if (s.tball_s.size() > 0)

@@ -39,6 +39,17 @@ def desc_for(g):
         d = mk(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
         if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
             d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+        for key, arr in (("xlb", d.x_lb), ("xub", d.x_ub), ("ulb", d.u_lb), ("uub", d.u_ub)):
+            if key in g or (("xlb" in g or "ulb" in g) and key in ("xlb", "xub", "ulb", "uub")):
+                vals = g.get(key)
+                n = d.nx if key[0] == "x" else d.nu
+                for i in range(n):   # setBounds replaces all four vectors: the ones not given are unbounded
+                    v = vals[i] if vals is not None else (-2e30 if key.endswith("lb") else 2e30)
+                    arr[i] = -capi.INF if v <= -2e30 else (capi.INF if v >= 2e30 else v)
+        if "xf_fixed" in g:
+            d.xf_fixed_mask = g["xf_fixed"]
+        if "final_cost" in g:
+            d.final_cost = g["final_cost"]
         if g.get("teq"):            # TerminalEqualityConstraint(xf)
             d.final_eq = 1
         if "ball" in g:             # BallKeepOut stage inequality
