@@ -169,6 +169,12 @@ static Built build(const Scenario& s, int iterations)
         b.ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
         b.ms_grid->setNRef(s.N);
         b.ms_grid->setDtRef(s.dt);
+        if (s.xf_fixed >= 0)
+        {
+            Eigen::Matrix<bool, -1, 1> fixed(s.nx);
+            for (int i = 0; i < s.nx; ++i) fixed[i] = (s.xf_fixed >> i) & 1;
+            b.ms_grid->setXfFixed(fixed);
+        }
         b.any_grid = b.ms_grid;
     };
     if (s.name == "unicycle")

@@ -1,0 +1,95 @@
+"""CPU test: the oracle against the genuine reference RUN HERE on random configurations (oracle/_ref/ref_driver, the binary that
+`make -C oracle ref` compiles from the reference's own sources; it travels with the repository snapshot, the sources do not).
+Skipped where the binary is absent.  Complements the committed golden vectors: dimensions and sparsity pattern, residual and
+Jacobian bit for bit (the oracle reproduces the reference's in-place finite-difference drift), iterates to the usual tolerance."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, desc_for
+from control_box_rst_amd import capi
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+pytestmark = pytest.mark.skipif(not (os.path.exists(DRIVER) and os.access(DRIVER, os.X_OK)), reason="oracle/_ref/ref_driver not built")
+
+
+def _fmt(v):
+    return ",".join("inf" if x >= 2e30 else "-inf" if x <= -2e30 else repr(float(x)) for x in v)
+
+
+def random_case(rng):
+    sc = str(rng.choice(["unicycle", "vdp", "dint"]))
+    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1)}[sc]
+    kv = dict(scenario=sc, N=int(rng.integers(4, 36)), iters=3, w=_fmt(rng.uniform(1.0, 40.0, 3)),
+              x0=_fmt(rng.uniform(-1, 1, nx)))
+    if sc == "dint":
+        kv["xf"] = _fmt([float(rng.uniform(0.5, 1.5)), 0.0])
+        kv["solves"] = int(rng.integers(1, 3))
+        return kv
+    kv["xf"] = _fmt(rng.uniform(-1, 1, nx) + np.array([1.5, 0.5, 0.2])[:nx])
+    if rng.random() < 0.3:
+        kv["grid"] = "ms"
+    else:
+        kv["collocation"] = str(rng.choice(["forward", "backward", "midpoint", "crank_nicolson"]))
+    if rng.random() < 0.6:   # bound patterns (setBounds replaces all four vectors)
+        def side(n, lo, hi):
+            lb, ub = [], []
+            for _ in range(n):
+                k = rng.integers(0, 4)
+                lb.append(-2e30 if k in (0, 2) else lo * rng.uniform(0.3, 1.0))
+                ub.append(2e30 if k in (0, 1) else hi * rng.uniform(0.3, 1.0))
+            return lb, ub
+        xl, xu = side(nx, -3.0, 3.0)
+        ul, uu = side(nu, -1.0, 1.0)
+        kv.update(xlb=_fmt(xl), xub=_fmt(xu), ulb=_fmt(ul), uub=_fmt(uu))
+    mask = int(rng.integers(0, 2 ** nx)) if rng.random() < 0.3 else 0
+    if mask:
+        kv["xf_fixed"] = mask
+    all_fixed = mask == 2 ** nx - 1
+    if not all_fixed and rng.random() < 0.2:
+        kv["final_cost"] = 0
+    r = rng.random()
+    if not all_fixed and "grid" not in kv:
+        if r < 0.25:
+            kv.update(tball=repr(float(rng.uniform(1e-4, 0.5))), tball_s=_fmt(rng.uniform(0.1, 2.0, nx)))
+        elif r < 0.45:
+            kv["teq"] = 1
+    if sc == "unicycle" and rng.random() < 0.3:
+        kv["ball"] = _fmt([1.0, 0.5, 0.2, float(rng.uniform(0.1, 0.5))])
+    return kv
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_oracle_vs_live_reference(oracle_mod, seed):
+    rng = np.random.default_rng(424200 + seed)
+    kv = random_case(rng)
+    out = subprocess.check_output([DRIVER, "dump"] + [f"{k}={v}" for k, v in kv.items()], timeout=120)
+    g = json.loads(out)
+    d = desc_for(g)
+    p = oracle_mod.OracleProblem(d)
+    for k in ("n", "lsq", "eq", "ineq", "bounds", "m", "nnz"):
+        assert getattr(p.dims, k) == g[k], (kv, k)
+    rows, cols = p.structure()
+    assert sorted(zip(rows.tolist(), cols.tolist())) == sorted(zip(g["jac_rows"], g["jac_cols"])), kv
+    w = g["weights"]
+    p.set_data(np.array(g["vertex_init"])[: p.dims.nv], xref=np.array(g["xf"]))
+    values, jac = p.eval(*w)
+    assert np.array_equal(values, np.array(g["values_init"])), kv
+    Jo = sp.coo_matrix((jac, (rows, cols)), shape=(p.dims.m, p.dims.n)).tocsr()
+    Jr = sp.coo_matrix((g["jac_vals"], (g["jac_rows"], g["jac_cols"])), shape=(p.dims.m, p.dims.n)).tocsr()
+    assert abs(Jo - Jr).max() == 0.0, kv
+    for a in g["after_iter"]:
+        q = oracle_mod.OracleProblem(d)
+        q.set_data(q.init_trajectory(g["x0"], g["xf"]), xref=np.array(g["xf"]))
+        opts = capi.default_lm_opts(a["k"], *w)
+        for s in range(g["solves"]):
+            status, chi2, _ = q.solve(opts, new_run=(s == 0))
+        ref = np.array(a["vertex"])[: q.dims.nv]
+        # random, sometimes poorly conditioned cases: the finite-difference noise (1e-7 relative in J) is amplified a little more
+        # than on the fixtures; values and Jacobian above are exact
+        assert np.abs(q.x() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (kv, a["k"], np.abs(q.x() - ref).max())
+        assert abs(chi2 - a["chi2"]) <= 5e-6 * max(1.0, abs(a["chi2"])), (kv, a["k"])
