@@ -2284,6 +2284,7 @@ size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
     const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
     if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N, arrow);
     if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
+    if (d.nx == 3 && d.nu == 1) return factor_lds<3, 1>(p.N, arrow);
     return 0;
 }
 
@@ -2292,6 +2293,7 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: return launch_sweep_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, p, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
+            if (d.nx == 3) return launch_sweep_d<DYN_SERIAL_INTEGRATOR3>(d.defect, p, stream);
             if (d.nx != 2) return false;
             return launch_sweep_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, p, stream);
         case CORBO_HIP_DYN_UNICYCLE: return launch_sweep_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, p, stream);
@@ -2308,6 +2310,7 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
+            if (d.nx == 3) return launch_pass_d<DYN_SERIAL_INTEGRATOR3>(d.defect, fp, sp, stream);
             if (d.nx != 2) return false;
             return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, stream);
@@ -2330,6 +2333,7 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
     }
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
     if (d.nx == 3 && d.nu == 2) return launch_factor_t<3, 2>(p, stream);
+    if (d.nx == 3 && d.nu == 1) return launch_factor_t<3, 1>(p, stream);
     return false;
 }
 

@@ -55,6 +55,21 @@ template <> struct Dynamics<CORBO_HIP_DYN_SERIAL_INTEGRATOR> {  // linear_benchm
     }
 };
 
+// the same system of order 3 (public id CORBO_HIP_DYN_SERIAL_INTEGRATOR with nx = 3; internal template id)
+constexpr int DYN_SERIAL_INTEGRATOR3 = 100;
+template <> struct Dynamics<DYN_SERIAL_INTEGRATOR3> {
+    static constexpr int NX = 3, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b1110000u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
+    {
+        f[0] = x[1];
+        f[1] = x[2];
+        f[2] = u[0] / prm[0];
+    }
+};
+
 template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u1 cos(th), ydot = u1 sin(th), thdot = u2
     static constexpr int NX = 3, NU = 2, NC = 2;
     static constexpr unsigned CACHE_XMASK = 0b100u;

@@ -95,6 +95,20 @@ def dint_desc(N=50, dt=0.1) -> ProblemDesc:
 DINT_WEIGHTS = (100.0, 100.0, 100.0)
 
 
+# ---- SerialIntegratorSystem of order 3 (reference built-in, linear_benchmark_systems.h:50-118): fixed grid + quadratic cost, or time-optimal
+def int3_desc(N=30, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, time_optimal=False) -> ProblemDesc:
+    if time_optimal:
+        return make_desc(grid=capi.GRID_FD_VARIABLE, defect=capi.DEFECT_CRANK_NICOLSON, dynamics=capi.DYN_SERIAL_INTEGRATOR, nx=3, nu=1, N=N,
+                         dt=dt, stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0, u_lb=(-1.0,), u_ub=(1.0,), xf_fixed_mask=0b111,
+                         dt_lb=0.01, dt_ub=10.0, dyn_params=(1.0,))
+    q = (1.0, 0.5, 0.1)
+    return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_SERIAL_INTEGRATOR, nx=3, nu=1, N=N, dt=dt,
+                     q=q, r=(0.1,), qf=tuple(10.0 * v for v in q), u_lb=(-1.0,), u_ub=(1.0,), dyn_params=(1.0,))
+
+
+INT3_WEIGHTS = (10.0, 10.0, 10.0)
+
+
 # ---- cfg 5: quadrotor (nx=12, nu=4), MultipleShootingGrid + RK4, u bounds, one nonlinear stage inequality (keep-out ball) ----
 QUAD_Q = (1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05)
 QUAD_R = (0.01, 0.1, 0.1, 0.1)
@@ -126,5 +140,6 @@ SCENARIOS = {
     "unicycle": (unicycle_desc, UNICYCLE_WEIGHTS),
     "vdp": (vdp_desc, VDP_WEIGHTS),
     "dint": (dint_desc, DINT_WEIGHTS),
+    "int3": (int3_desc, INT3_WEIGHTS),
     "quad": (quad_desc, QUAD_WEIGHTS),
 }

@@ -69,6 +69,10 @@ def main():
         ("unicycle_n12_patterns", dict(scenario="unicycle", N=12, iters=5, xlb="-inf,-1.5,-inf", xub="1.2,inf,inf", ulb="-0.8,-inf", uub="inf,0.6",
                                        xf_fixed=5), (1, 2, 3, 4, 5)),
         ("vdp_patterns", dict(scenario="vdp", iters=5, xlb="-0.5,-inf", xub="inf,inf", ulb="-inf", uub="0.7", xf_fixed=2, final_cost=0), (1, 2, 3, 4, 5)),
+        # SerialIntegratorSystem of order 3 (nx = 3, nu = 1): fixed grid, multiple shooting, and time-optimal with the free dt
+        ("int3", dict(scenario="int3", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("int3_ms_rk4", dict(scenario="int3", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
+        ("int3_time_optimal", dict(scenario="int3", vargrid=1, N=25, iters=8, w="100,100,100", solves=3), (1, 4, 8)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)

@@ -127,6 +127,7 @@ struct Scenario
     Eigen::VectorXd xlb, xub, ulb, uub;   // xlb=/xub=/ulb=/uub= comma lists ("inf" = unbounded): replace the scenario's box bounds
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
+    bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
     bool teq = false;           // teq=1: TerminalEqualityConstraint(xf) final-stage constraint
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
@@ -187,6 +188,21 @@ static Built build(const Scenario& s, int iterations)
         dyn = std::make_shared<VanDerPolOscillator>();
         if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
+    else if (s.name == "int3")
+    {
+        dyn = std::make_shared<SerialIntegratorSystem>(3);
+        if (s.vargrid)
+        {
+            auto grid = std::make_shared<FiniteDifferencesVariableGrid>();
+            grid->setDtBounds(0.01, 10.0);
+            Eigen::Matrix<bool, -1, 1> fixed(3);
+            fixed.setConstant(true);
+            grid->setXfFixed(fixed);
+            b.grid = grid;
+        }
+        else if (s.ms) make_ms();
+        else b.grid = std::make_shared<FiniteDifferencesGrid>();
+    }
     else if (s.name == "dint")
     {
         dyn       = std::make_shared<SerialIntegratorSystem>(2);
@@ -245,6 +261,19 @@ static Built build(const Scenario& s, int iterations)
         Eigen::MatrixXd Qf = 10.0 * Q;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
+    }
+    else if (s.name == "int3")
+    {
+        if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
+        else
+        {
+            Eigen::MatrixXd Q = Eigen::Vector3d(1, 0.5, 0.1).asDiagonal();
+            Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+            Eigen::MatrixXd Qf = 10.0 * Q;
+            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        }
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else if (s.name == "dint")
@@ -372,6 +401,13 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         s.xf = Eigen::Vector2d(1, 0);
         s.solves = 5;
     }
+    else if (s.name == "int3")   // SerialIntegratorSystem(3): fixed grid + quadratic cost, or (vargrid=1) time-optimal like cfg 2
+    {
+        s.nx = 3; s.nu = 1; s.N = 30; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 10;
+        s.x0 = Eigen::Vector3d(0, 0, 0);
+        s.xf = Eigen::Vector3d(1, 0, 0);
+    }
     else if (s.name == "quad")
     {
         s.nx = 12; s.nu = 4; s.N = 20; s.dt = 0.05;
@@ -408,6 +444,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("final_cost")) s.final_cost = atoi(kv["final_cost"].c_str());
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
+    if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
     if (kv.count("tball"))
     {
         s.tball_gamma = atof(kv["tball"].c_str());
@@ -424,6 +461,7 @@ static int dump(const Scenario& s)
     if (s.ms) printf("\"grid\": \"ms\",\n");
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.teq) printf("\"teq\": 1,\n");
+    if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (s.xlb.size()) printVec("xlb", s.xlb);
     if (s.xub.size()) printVec("xub", s.xub);
     if (s.ulb.size()) printVec("ulb", s.ulb);

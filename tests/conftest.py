@@ -33,32 +33,38 @@ def desc_for(g):
     from control_box_rst_amd import capi, problems
     defect = {"forward": capi.DEFECT_FORWARD, "backward": capi.DEFECT_BACKWARD, "midpoint": capi.DEFECT_MIDPOINT,
               "crank_nicolson": capi.DEFECT_CRANK_NICOLSON}[g.get("collocation", "crank_nicolson")]
-    tball = (g["tball_s"], g["tball_gamma"]) if "tball_s" in g else None
-    if g["scenario"] in ("unicycle", "vdp"):
-        mk = problems.unicycle_desc if g["scenario"] == "unicycle" else problems.vdp_desc
-        d = mk(N=g["N"], dt=g["dt"], defect=defect, terminal_ball=tball)
-        if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
-            d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
-        for key, arr in (("xlb", d.x_lb), ("xub", d.x_ub), ("ulb", d.u_lb), ("uub", d.u_ub)):
-            if key in g or (("xlb" in g or "ulb" in g) and key in ("xlb", "xub", "ulb", "uub")):
-                vals = g.get(key)
-                n = d.nx if key[0] == "x" else d.nu
-                for i in range(n):   # setBounds replaces all four vectors: the ones not given are unbounded
-                    v = vals[i] if vals is not None else (-2e30 if key.endswith("lb") else 2e30)
-                    arr[i] = -capi.INF if v <= -2e30 else (capi.INF if v >= 2e30 else v)
-        if "xf_fixed" in g:
-            d.xf_fixed_mask = g["xf_fixed"]
-        if "final_cost" in g:
-            d.final_cost = g["final_cost"]
-        if g.get("teq"):            # TerminalEqualityConstraint(xf)
-            d.final_eq = 1
-        if "ball" in g:             # BallKeepOut stage inequality
-            d.stage_ineq = capi.INEQ_BALL
-            for i, v in enumerate(g["ball"]):
-                d.ineq_params[i] = v
-        return d
-    if g["scenario"] == "dint":
+    sc = g["scenario"]
+    if sc == "dint":
         return problems.dint_desc(N=g["N"], dt=g["dt"])
-    if g["scenario"] == "quad":
+    if sc == "quad":
         return problems.quad_desc(N=g["N"], dt=g["dt"])
-    raise KeyError(g["scenario"])
+    if sc == "int3":
+        d = problems.int3_desc(N=g["N"], dt=g["dt"], defect=defect, time_optimal=bool(g.get("vargrid")))
+    elif sc in ("unicycle", "vdp"):
+        d = (problems.unicycle_desc if sc == "unicycle" else problems.vdp_desc)(N=g["N"], dt=g["dt"], defect=defect)
+    else:
+        raise KeyError(sc)
+    # options of oracle/ref_driver.cpp recorded in the fixture header
+    if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
+        d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+    if "xlb" in g or "ulb" in g:   # setBounds replaces all four vectors: the ones not given are unbounded
+        for key, arr, n in (("xlb", d.x_lb, d.nx), ("xub", d.x_ub, d.nx), ("ulb", d.u_lb, d.nu), ("uub", d.u_ub, d.nu)):
+            vals = g.get(key)
+            for i in range(n):
+                v = vals[i] if vals is not None else (-2e30 if key.endswith("lb") else 2e30)
+                arr[i] = -capi.INF if v <= -2e30 else (capi.INF if v >= 2e30 else v)
+    if "xf_fixed" in g:
+        d.xf_fixed_mask = g["xf_fixed"]
+    if "final_cost" in g:
+        d.final_cost = g["final_cost"]
+    if "tball_s" in g:          # TerminalBall(S, gamma)
+        d.final_ineq = capi.FINAL_INEQ_TERMINAL_BALL
+        for i, v in enumerate(list(g["tball_s"]) + [g["tball_gamma"]]):
+            d.final_ineq_params[i] = v
+    if g.get("teq"):            # TerminalEqualityConstraint(xf)
+        d.final_eq = 1
+    if "ball" in g:             # BallKeepOut stage inequality
+        d.stage_ineq = capi.INEQ_BALL
+        for i, v in enumerate(g["ball"]):
+            d.ineq_params[i] = v
+    return d

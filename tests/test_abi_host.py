@@ -37,7 +37,7 @@ def test_struct_sizes_match_header(lib):
     assert (o.iterations, o.weight_eq, o.adapt_factor_eq, o.adapt_max_bounds) == (10, 2.0, 1.0, 500.0)
 
 
-@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12", "quad_n10", "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns"])
+@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12", "quad_n10", "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal"])
 def test_dims_and_structure_match_reference(lib, oracle_mod, name):
     g = load_golden(name)
     d = desc_for(g)

@@ -20,19 +20,20 @@ def _built():
 
 
 def random_desc(rng, long_horizon=False):
-    fam = rng.choice(["vdp", "unicycle", "dint"])
+    fam = rng.choice(["vdp", "unicycle", "dint", "int3", "int3t"])
     N = int(rng.integers(100, 257)) if long_horizon else int(rng.integers(3, 70))
     dt = float(rng.uniform(0.05, 0.2))
-    if fam == "dint":
-        d = problems.dint_desc(N=N, dt=dt)
-        d.xf_fixed_mask = int(rng.choice([0b11, 0b01, 0b10, 0b00]))
-        if d.xf_fixed_mask != 0b11 and rng.random() < 0.5:   # a final cost on the unfixed components
+    if fam in ("dint", "int3t"):   # time-optimal, free dt (arrowhead)
+        d = problems.dint_desc(N=N, dt=dt) if fam == "dint" else problems.int3_desc(N=N, dt=dt, time_optimal=True)
+        nx, nu = d.nx, 1
+        full = 2 ** nx - 1
+        d.xf_fixed_mask = int(rng.choice([full, full, 1, full - 1, 0]))
+        if d.xf_fixed_mask != full and rng.random() < 0.5:   # a final cost on the unfixed components
             d.final_cost = 1
-            for i in range(2):
+            for i in range(nx):
                 d.qf_diag[i] = float(rng.uniform(0.5, 5.0))
-        nx, nu = 2, 1
     else:
-        mk = problems.vdp_desc if fam == "vdp" else problems.unicycle_desc
+        mk = {"vdp": problems.vdp_desc, "unicycle": problems.unicycle_desc, "int3": problems.int3_desc}[fam]
         d = mk(N=N, dt=dt)
         nx, nu = d.nx, d.nu
         if rng.random() < 0.3:
@@ -74,7 +75,7 @@ def test_random_descriptor_vs_oracle(oracle_mod, seed):
     B = 3
     w = tuple(float(v) for v in rng.uniform(1.0, 50.0, 3))
     x0 = rng.uniform(-1, 1, (B, d.nx))
-    xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2])[: d.nx] if fam != "dint" else np.array([1.0, 0.0]))
+    xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2])[: d.nx] if fam not in ("dint", "int3t") else np.array([1.0, 0.0, 0.0])[: d.nx])
     s = BatchedLevenbergMarquardt(d, B)
     s.setIterations(3)
     s.setPenaltyWeights(*w)

@@ -22,13 +22,16 @@ def _fmt(v):
 
 
 def random_case(rng):
-    sc = str(rng.choice(["unicycle", "vdp", "dint"]))
-    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1)}[sc]
+    sc = str(rng.choice(["unicycle", "vdp", "dint", "int3"]))
+    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1), "int3": (3, 1)}[sc]
     kv = dict(scenario=sc, N=int(rng.integers(4, 36)), iters=3, w=_fmt(rng.uniform(1.0, 40.0, 3)),
               x0=_fmt(rng.uniform(-1, 1, nx)))
     if sc == "dint":
         kv["xf"] = _fmt([float(rng.uniform(0.5, 1.5)), 0.0])
         kv["solves"] = int(rng.integers(1, 3))
+        return kv
+    if sc == "int3" and rng.random() < 0.3:   # time-optimal on the variable grid
+        kv.update(vargrid=1, xf=_fmt([float(rng.uniform(0.5, 1.5)), 0.0, 0.0]), solves=int(rng.integers(1, 3)))
         return kv
     kv["xf"] = _fmt(rng.uniform(-1, 1, nx) + np.array([1.5, 0.5, 0.2])[:nx])
     if rng.random() < 0.3:
