@@ -18,7 +18,8 @@ def _built():
     g.build()
 
 
-@pytest.mark.parametrize("scenario,N", [("unicycle", 100), ("unicycle", 30), ("vdp", 20), ("dint", 50), ("quad", 24), ("unicycle", 4)])
+@pytest.mark.parametrize("scenario,N", [("unicycle", 100), ("unicycle", 30), ("vdp", 20), ("dint", 50), ("quad", 24), ("unicycle", 4),
+                                        ("int3", 17), ("vdp", 3), ("unicycle", 256), ("quad", 5)])
 def test_warm_start_bit_exact_vs_oracle(oracle_mod, scenario, N):
     """Random resident trajectories; the measured state of instance b is stored state (b mod 5) plus a small offset, so shifts of
     0 .. 4 samples (and the `same start` early exit) all occur in one batch; with and without shifting."""
