@@ -108,13 +108,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    # tests/test_gpu_bench_ranks.py runs the N > 1 path on a 1-GPU box: every rank on GPU 0, gloo instead of RCCL (RCCL refuses two
+    # ranks on one device).  Never set by the driver: one rank per GPU over RCCL is the product configuration.
+    shared_gpu = os.environ.get("CORBO_BENCH_TEST_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
+    red_dev = "cpu" if shared_gpu else "cuda"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -158,8 +167,8 @@ def main():
 
     stats = solver.get_stats()
     X, chi2, status = solver.get_solution()
-    t_max = sharding.reduce_max(elapsed, dist, device="cuda")                       # MAX over ranks (RCCL)
-    red = sharding.reduce_stats(stats, float(chi2.sum()), int((status <= 1).sum()), dist, device="cuda")  # SUM over ranks
+    t_max = sharding.reduce_max(elapsed, dist, device=red_dev)                       # MAX over ranks (RCCL)
+    red = sharding.reduce_stats(stats, float(chi2.sum()), int((status <= 1).sum()), dist, device=red_dev)  # SUM over ranks
     total_iters_per_step = red["lm_iterations"]  # = world * batch * iterations
     value = total_iters_per_step * args.steps / t_max
 
