@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -46,6 +48,36 @@ int upload(const std::vector<T>& v, T** dptr)
 }
 
 constexpr int MAX_PASSES = 4096;
+
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it (the library shares the
+// process with the caller's own HIP / PyTorch code).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = hipSetDevice(device);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE_OF(h)                      \
+    DeviceGuard device_guard_((h)->device);  \
+    HIP_TRY(device_guard_.err)
+
+// No C++ exception crosses the C boundary (host-side staging buffers are std::vector).
+#define ABI_CATCH                                                                                       \
+    catch (const std::bad_alloc&) { return fail(CORBO_HIP_ERR_DEVICE, "host allocation failed"); }      \
+    catch (const std::exception& e) { return fail(CORBO_HIP_ERR_DEVICE, std::string("exception: ") + e.what()); } \
+    catch (...) { return fail(CORBO_HIP_ERR_DEVICE, "unknown exception"); }
+
+// per-phase events of a profiled solve: destroyed on every exit path
+struct EventList {
+    std::vector<hipEvent_t> v;
+    ~EventList() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
+};
 
 }  // namespace
 
@@ -138,7 +170,7 @@ void corbo_hip_default_lm_opts(corbo_hip_lm_opts* o)
 }
 
 int corbo_hip_get_dims(const corbo_hip_problem_desc* desc, corbo_hip_dims* dims)
-{
+try {
     if (!desc || !dims) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     Structure S;
     std::string err = build_structure(*desc, S);
@@ -146,9 +178,10 @@ int corbo_hip_get_dims(const corbo_hip_problem_desc* desc, corbo_hip_dims* dims)
     *dims = S.dims;
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 int corbo_hip_get_structure(const corbo_hip_problem_desc* desc, int32_t* rows, int32_t* cols)
-{
+try {
     if (!desc || !rows || !cols) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     Structure S;
     std::string err = build_structure(*desc, S);
@@ -157,45 +190,56 @@ int corbo_hip_get_structure(const corbo_hip_problem_desc* desc, int32_t* rows, i
     std::memcpy(cols, S.jac_cols.data(), S.jac_cols.size() * sizeof(int32_t));
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 int corbo_hip_init_trajectory(const corbo_hip_problem_desc* desc, int batch, const double* x0, const double* xf, double* x_out)
-{
+try {
     if (!desc || !x0 || !xf || !x_out || batch < 0) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     std::string err = validate_desc(*desc);
     if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
     init_trajectory(*desc, batch, x0, xf, x_out);
     return CORBO_HIP_OK;
 }
+ABI_CATCH
+
+static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out);
 
 int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out)
-{
+try {
     if (!desc || !out || batch < 1) return fail(CORBO_HIP_ERR_INVALID, "null argument or batch < 1");
     *out = nullptr;
-    auto* h = new corbo_hip_solver();
+    return create_impl(desc, batch, device, out);
+}
+ABI_CATCH
+
+static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out)
+{
+    // owns the half-built handle until it is handed to the caller (exceptions and early returns free everything created so far)
+    struct Owner { corbo_hip_solver* p; ~Owner() { if (p) corbo_hip_destroy(p); } } owner{new corbo_hip_solver()};
+    corbo_hip_solver* h = owner.p;
     std::string err = build_structure(*desc, h->S);
-    if (!err.empty()) { delete h; return fail(CORBO_HIP_ERR_INVALID, err); }
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
     const Structure& S = h->S;
     {   // device kernels exist for this descriptor?
         FactorParams fp{};
         fp.N = S.N;
         const bool big = factor_work_doubles(*desc) > 0;
-        if (factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256) || S.dt_free && big) {
-            delete h;
+        if (factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256) || (S.dt_free && big)) {
             return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
         }
     }
     h->batch  = batch;
     h->device = device;
     int ndev  = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete h; return fail(CORBO_HIP_ERR_DEVICE, "no HIP device visible"); }
-    if (device < 0 || device >= ndev) { delete h; return fail(CORBO_HIP_ERR_INVALID, "device index out of range"); }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CORBO_HIP_ERR_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(CORBO_HIP_ERR_INVALID, "device index out of range");
 #define CREATE_TRY(expr)                                                                                                  \
     do {                                                                                                                  \
         hipError_t e_ = (expr);                                                                                           \
-        if (e_ != hipSuccess) { std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_); corbo_hip_destroy(h); \
-                                return fail(CORBO_HIP_ERR_DEVICE, m_); }                                                  \
+        if (e_ != hipSuccess) return fail(CORBO_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
-    CREATE_TRY(hipSetDevice(device));
+    DeviceGuard device_guard(device);
+    CREATE_TRY(device_guard.err);
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
@@ -216,11 +260,8 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[1], hipEventDisableTiming));
     if (upload(S.stage_cols, &h->d_stage_cols) || upload(S.comp, &h->d_comp) || upload(S.ineq_cols, &h->d_ineq_cols) ||
-        upload(S.ineq_rows, &h->d_ineq_rows)) {
-        std::string m = g_last_error;
-        corbo_hip_destroy(h);
-        return fail(CORBO_HIP_ERR_DEVICE, m);
-    }
+        upload(S.ineq_rows, &h->d_ineq_rows))
+        return CORBO_HIP_ERR_DEVICE;  // message set by upload()
     h->m_pad   = (S.dims.m + 1) & ~1;
     h->nnz_pad = (S.dims.nnz + 1) & ~1;
     const size_t B = (size_t)batch;
@@ -264,14 +305,15 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
     h->split_passes  = h->profile;
     { const char* e = std::getenv("CORBO_HIP_LOOP"); h->loop_mode = !(e && e[0] == '0'); }
 
-    *out             = h;
+    owner.p = nullptr;
+    *out    = h;
     return CORBO_HIP_OK;
 }
 
 void corbo_hip_destroy(corbo_hip_handle h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_xnew, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters};
@@ -292,9 +334,9 @@ void corbo_hip_destroy(corbo_hip_handle h)
 }
 
 int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref)
-{
+try {
     if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     const Structure& S = h->S;
     const int nv = S.dims.nv, nvs = S.nvs, B = h->batch;
     // repack the public vertex layout (nv per row) into the device vertex storage (nvs per row: + fixed dt + padding)
@@ -331,6 +373,7 @@ int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const doubl
     h->have_data = true;
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 static int launch_sweep_checked(corbo_hip_handle h, const SweepParams& p)
 {
@@ -346,11 +389,11 @@ static int launch_factor_checked(corbo_hip_handle h, const FactorParams& p)
 }
 
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
-{
+try {
     if (!h || !o) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called before corbo_hip_solve");
     if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287)
     if (new_run) { h->w_eq = o->weight_eq; h->w_ineq = o->weight_ineq; h->w_b = o->weight_bounds; }
     else {
@@ -359,11 +402,12 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
         h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
     }
     h->stats = corbo_hip_stats{};
-    std::vector<hipEvent_t> evs;
+    EventList ev_list;
+    std::vector<hipEvent_t>& evs = ev_list.v;
     auto stamp = [&]() {
         if (!h->profile) return;
         hipEvent_t e;
-        (void)hipEventCreate(&e);
+        if (hipEventCreate(&e) != hipSuccess) return;
         (void)hipEventRecord(e, h->stream);
         evs.push_back(e);
     };
@@ -518,16 +562,16 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
             if (i % 2 == 0) h->stats.factor_ms += ms; else h->stats.sweep_ms += ms;
         }
     }
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     if (remaining > 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 int corbo_hip_restore_instance_data(corbo_hip_handle h)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     HIP_TRY(hipMemcpyAsync(h->d_x, h->d_x0, (size_t)h->batch * h->S.nvs * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return CORBO_HIP_OK;
 }
@@ -536,7 +580,7 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
 {
     if (!h || !x0_new) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     const Structure& S = h->S;
     HIP_TRY(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous call has been consumed
     for (int b = 0; b < h->batch; ++b)
@@ -556,7 +600,7 @@ int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
 {
     if (!h || !u0_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     const Structure& S = h->S;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy2D(u0_out, (size_t)S.nu * sizeof(double), h->d_x + S.nx, (size_t)S.nvs * sizeof(double), (size_t)S.nu * sizeof(double),
@@ -575,15 +619,15 @@ int corbo_hip_set_profiling(corbo_hip_handle h, int enable)
 int corbo_hip_synchronize(corbo_hip_handle h)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CORBO_HIP_OK;
 }
 
 int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, int32_t* status_out)
-{
+try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     const Structure& S = h->S;
     const int B = h->batch;
@@ -602,11 +646,12 @@ int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, 
     }
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
-{
+try {
     if (!h || !stats) return fail(CORBO_HIP_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::vector<LmState> st(h->batch);
     HIP_TRY(hipMemcpy(st.data(), h->d_state, (size_t)h->batch * sizeof(LmState), hipMemcpyDeviceToHost));
@@ -626,12 +671,13 @@ int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
     *stats = s;
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 int corbo_hip_eval(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, double* values_out, double* jac_out)
-{
+try {
     if (!h || !values_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     int rc = launch_sweep_checked(h, h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr));
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -647,6 +693,7 @@ int corbo_hip_eval(corbo_hip_handle h, double w_eq, double w_ineq, double w_boun
     }
     return CORBO_HIP_OK;
 }
+ABI_CATCH
 
 int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev, void** hip_stream)
 {
@@ -661,7 +708,7 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
 {
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     long long* d_tl = nullptr;  // CORBO_HIP_SWEEP_TIMELINE=1: shader-clock stamps of the phases of instance 0 on stderr (diagnostics)
     const char* tl_env = std::getenv("CORBO_HIP_SWEEP_TIMELINE");
@@ -697,7 +744,7 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
 {
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE_OF(h);
     // LM prologue (residual + Jacobian + state init), then the assemble/factor/solve kernel `repeat` times on that state
     corbo_hip_lm_opts o;
     corbo_hip_default_lm_opts(&o);
