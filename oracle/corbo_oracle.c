@@ -71,6 +71,7 @@ struct oracle_problem {
     /* LM work space */
     double *values, *jac, *H, *L, *rhs, *delta, *tmp;
     double w_eq, w_ineq, w_b; /* current penalty weights (levenberg_marquardt_sparse.h:126-128) */
+    oracle_generic_fun gen;   /* != NULL: a callback problem (oracle_create_generic) instead of a hypergraph */
 };
 
 /* ------------------------------------------------------------------------------------------------------------ */
@@ -272,6 +273,56 @@ static int validate(const corbo_hip_problem_desc* d)
 
 static int dt_is_free(const corbo_hip_problem_desc* d) { return d->grid == CORBO_HIP_GRID_FD_VARIABLE; }
 
+/* static row-wise view of J, envelope of H = J^T J and the LM work space (needs dims and the structure) */
+static void finish_linear_algebra_setup(oracle_problem* p)
+{
+    int n = p->dims.n, m = p->dims.m, nnz = p->dims.nnz;
+    /* ---- static row-wise view of J */
+    int32_t* rows = (int32_t*)calloc(nnz, sizeof(int32_t));
+    int32_t* cols = (int32_t*)calloc(nnz, sizeof(int32_t));
+    oracle_get_structure(p, rows, cols);
+    p->csr_ptr = (int*)calloc(m + 1, sizeof(int));
+    p->csr_col = (int*)calloc(nnz, sizeof(int));
+    p->csr_val = (int*)calloc(nnz, sizeof(int));
+    for (int i = 0; i < nnz; ++i) p->csr_ptr[rows[i] + 1]++;
+    for (int i = 0; i < m; ++i) p->csr_ptr[i + 1] += p->csr_ptr[i];
+    int* fill = (int*)calloc((size_t)(m > 0 ? m : 1), sizeof(int));
+    for (int i = 0; i < nnz; ++i) {
+        int r = rows[i], pos = p->csr_ptr[r] + fill[r]++;
+        p->csr_col[pos] = cols[i];
+        p->csr_val[pos] = i;
+    }
+    for (int r = 0; r < m; ++r) /* sort every row by column (insertion sort, rows are short) */
+        for (int a = p->csr_ptr[r] + 1; a < p->csr_ptr[r + 1]; ++a) {
+            int c = p->csr_col[a], vv = p->csr_val[a], b2 = a - 1;
+            while (b2 >= p->csr_ptr[r] && p->csr_col[b2] > c) { p->csr_col[b2 + 1] = p->csr_col[b2]; p->csr_val[b2 + 1] = p->csr_val[b2]; --b2; }
+            p->csr_col[b2 + 1] = c; p->csr_val[b2 + 1] = vv;
+        }
+    free(fill); free(rows); free(cols);
+    /* ---- envelope of H = J^T J */
+    p->env_first = (int*)calloc(n, sizeof(int));
+    p->env_ptr   = (int*)calloc(n + 1, sizeof(int));
+    for (int i = 0; i < n; ++i) p->env_first[i] = i;
+    for (int r = 0; r < m; ++r) {
+        if (p->csr_ptr[r] == p->csr_ptr[r + 1]) continue;
+        int cmin = p->csr_col[p->csr_ptr[r]];
+        for (int a = p->csr_ptr[r]; a < p->csr_ptr[r + 1]; ++a)
+            if (cmin < p->env_first[p->csr_col[a]]) p->env_first[p->csr_col[a]] = cmin;
+    }
+    for (int i = 0; i < n; ++i) p->env_ptr[i + 1] = p->env_ptr[i] + (i - p->env_first[i] + 1);
+    p->env_size = p->env_ptr[n];
+
+    p->values = (double*)calloc(m, sizeof(double));
+    p->jac    = (double*)calloc(nnz, sizeof(double));
+    p->H      = (double*)calloc(p->env_size, sizeof(double));
+    p->L      = (double*)calloc(p->env_size, sizeof(double));
+    p->rhs    = (double*)calloc(n, sizeof(double));
+    p->delta  = (double*)calloc(n, sizeof(double));
+    p->tmp    = (double*)calloc(n, sizeof(double));
+    p->w_eq = p->w_ineq = p->w_b = 2; /* levenberg_marquardt_sparse.h:126-128 */
+}
+
+
 oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
 {
     if (!validate(desc)) return NULL;
@@ -419,51 +470,47 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     p->dims.bounds = n_bounds;
     p->dims.m      = dim_lsq + dim_eq + dim_ineq + n_bounds;
     p->dims.nnz    = nnz;
-    int m          = p->dims.m;
+    finish_linear_algebra_setup(p);
+    return p;
+}
 
-    /* ---- static row-wise view of J */
-    int32_t* rows = (int32_t*)calloc(nnz, sizeof(int32_t));
-    int32_t* cols = (int32_t*)calloc(nnz, sizeof(int32_t));
-    oracle_get_structure(p, rows, cols);
-    p->csr_ptr = (int*)calloc(m + 1, sizeof(int));
-    p->csr_col = (int*)calloc(nnz, sizeof(int));
-    p->csr_val = (int*)calloc(nnz, sizeof(int));
-    for (int i = 0; i < nnz; ++i) p->csr_ptr[rows[i] + 1]++;
-    for (int i = 0; i < m; ++i) p->csr_ptr[i + 1] += p->csr_ptr[i];
-    int* fill = (int*)calloc(m, sizeof(int));
-    for (int i = 0; i < nnz; ++i) {
-        int r = rows[i], pos = p->csr_ptr[r] + fill[r]++;
-        p->csr_col[pos] = cols[i];
-        p->csr_val[pos] = i;
-    }
-    for (int r = 0; r < m; ++r) /* sort every row by column (insertion sort, rows are short) */
-        for (int a = p->csr_ptr[r] + 1; a < p->csr_ptr[r + 1]; ++a) {
-            int c = p->csr_col[a], vv = p->csr_val[a], b2 = a - 1;
-            while (b2 >= p->csr_ptr[r] && p->csr_col[b2] > c) { p->csr_col[b2 + 1] = p->csr_col[b2]; p->csr_val[b2 + 1] = p->csr_val[b2]; --b2; }
-            p->csr_col[b2 + 1] = c; p->csr_val[b2 + 1] = vv;
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Callback problem: SimpleOptimizationProblemWithCallbacks (optimization/include/corbo-optimization/             */
+/* simple_optimization_problem.h:203-310) with the interface's default, dense central-difference Jacobians.      */
+/* It exists so that the SAME oracle_solve() that runs the OCPs can be pinned against the known-answer cases of   */
+/* the reference's own solver test (optimization/test/test_levenberg_marquardt_sparse.cpp:71-371), which are      */
+/* small non-OCP problems.  Jacobian value order: dense rows [lsq | eq | ineq] row-major, then one entry per bound. */
+
+oracle_problem* oracle_create_generic(int n, int dim_lsq, int dim_eq, int dim_ineq, const double* lb, const double* ub, oracle_generic_fun f)
+{
+    if (n < 1 || dim_lsq < 0 || dim_eq < 0 || dim_ineq < 0 || !f) return NULL;
+    oracle_problem* p = (oracle_problem*)calloc(1, sizeof(oracle_problem));
+    p->gen = f;
+    p->x      = (double*)calloc(n + 1, sizeof(double));
+    p->backup = (double*)calloc(n + 1, sizeof(double));
+    p->lb     = (double*)calloc(n + 1, sizeof(double));
+    p->ub     = (double*)calloc(n + 1, sizeof(double));
+    p->xref   = (double*)calloc(CORBO_HIP_MAX_NX, sizeof(double));
+    p->param_off      = (int*)calloc(n, sizeof(int));
+    p->bound_vert_off = (int*)calloc(n, sizeof(int));
+    p->bound_col      = (int*)calloc(n, sizeof(int));
+    int n_bounds = 0;
+    for (int i = 0; i < n; ++i) {
+        p->lb[i] = lb ? lb[i] : -CORBO_HIP_INF;
+        p->ub[i] = ub ? ub[i] : CORBO_HIP_INF;
+        p->param_off[i] = i;
+        if (is_finite_bound(p->lb[i], p->ub[i])) { /* optimization_problem_interface.cpp:566-592 */
+            p->bound_vert_off[n_bounds] = i;
+            p->bound_col[n_bounds]      = i;
+            ++n_bounds;
         }
-    free(fill); free(rows); free(cols);
-    /* ---- envelope of H = J^T J */
-    p->env_first = (int*)calloc(n, sizeof(int));
-    p->env_ptr   = (int*)calloc(n + 1, sizeof(int));
-    for (int i = 0; i < n; ++i) p->env_first[i] = i;
-    for (int r = 0; r < m; ++r) {
-        if (p->csr_ptr[r] == p->csr_ptr[r + 1]) continue;
-        int cmin = p->csr_col[p->csr_ptr[r]];
-        for (int a = p->csr_ptr[r]; a < p->csr_ptr[r + 1]; ++a)
-            if (cmin < p->env_first[p->csr_col[a]]) p->env_first[p->csr_col[a]] = cmin;
     }
-    for (int i = 0; i < n; ++i) p->env_ptr[i + 1] = p->env_ptr[i] + (i - p->env_first[i] + 1);
-    p->env_size = p->env_ptr[n];
-
-    p->values = (double*)calloc(m, sizeof(double));
-    p->jac    = (double*)calloc(nnz, sizeof(double));
-    p->H      = (double*)calloc(p->env_size, sizeof(double));
-    p->L      = (double*)calloc(p->env_size, sizeof(double));
-    p->rhs    = (double*)calloc(n, sizeof(double));
-    p->delta  = (double*)calloc(n, sizeof(double));
-    p->tmp    = (double*)calloc(n, sizeof(double));
-    p->w_eq = p->w_ineq = p->w_b = 2; /* levenberg_marquardt_sparse.h:126-128 */
+    int dense_rows = dim_lsq + dim_eq + dim_ineq;
+    p->dims.nv = n; p->dims.n = n; p->dims.lsq = dim_lsq; p->dims.eq = dim_eq; p->dims.ineq = dim_ineq; p->dims.bounds = n_bounds;
+    p->dims.m   = dense_rows + n_bounds;
+    p->dims.nnz = dense_rows * n + n_bounds;
+    p->first_bound_nnz = dense_rows * n;
+    finish_linear_algebra_setup(p);
     return p;
 }
 
@@ -487,6 +534,9 @@ int oracle_get_dims(const oracle_problem* p, corbo_hip_dims* dims)
 int oracle_get_structure(const oracle_problem* p, int32_t* rows, int32_t* cols)
 {
     if (!p) return CORBO_HIP_ERR_INVALID;
+    if (p->gen)
+        for (int r = 0; r < p->dims.lsq + p->dims.eq + p->dims.ineq; ++r)
+            for (int c = 0; c < p->dims.n; ++c) { rows[r * p->dims.n + c] = r; cols[r * p->dims.n + c] = c; }
     for (int i = 0; i < p->n_blocks; ++i) {
         const o_block* b = &p->b[i];
         for (int c = 0; c < b->cols; ++c)
@@ -604,6 +654,12 @@ int oracle_get_x(const oracle_problem* p, double* x_out)
  * computeDistanceFiniteCombinedBounds (hyper_graph_optimization_problem_base.cpp:106-125,162-180,278-315) */
 static void compute_values(oracle_problem* p, double w_eq, double w_ineq, double w_b, double* values)
 {
+    if (p->gen) { /* computeValuesLsqObjective / Equality / ActiveInequality of the callback problem (:222-246) */
+        int l = p->dims.lsq, q = p->dims.eq, g = p->dims.ineq;
+        p->gen(p->x, values, values + l, values + l + q);
+        for (int j = 0; j < q; ++j) values[l + j] *= w_eq;
+        for (int j = 0; j < g; ++j) values[l + q + j] = (values[l + q + j] < 0) ? 0 : w_ineq * values[l + q + j]; /* optimization_problem_interface.cpp:118-130 */
+    }
     for (int i = 0; i < p->n_edges; ++i) {
         const o_edge* e = &p->e[i];
         edge_values(p, e, values + e->row);
@@ -628,9 +684,42 @@ static void compute_values(oracle_problem* p, double w_eq, double w_ineq, double
 
 /* HyperGraphOptimizationProblemEdgeBased::computeCombinedSparseJacobian
  * (optimization/src/hyper_graph/hyper_graph_optimization_problem_edge_based.cpp:1480-1753) */
+/* OptimizationProblemInterface::computeCombinedSparseJacobian, default implementation (optimization_problem_interface.cpp:702-810):
+ * one CentralDifferences::jacobian pass (numerics/include/corbo-numerics/finite_differences.hpp:167-188: x_i += d, f1, x_i -= 2d, f0,
+ * col = (1/2d)(f1 - f0), x_i += d; d = 1e-9) per non-empty part -- lsq (:217-233), equalities, ACTIVE inequalities (max(0,c) is what gets
+ * differentiated, :439-456) -- each scaled by its weight on insertion. */
+static void generic_jacobian(oracle_problem* p, double w_eq, double w_ineq, double* jac)
+{
+    const double delta = 1e-9, ddelta = 2 * delta, scalar = 1.0 / ddelta;
+    int n = p->dims.n, l = p->dims.lsq, q = p->dims.eq, g = p->dims.ineq, rows = l + q + g;
+    double* f1 = (double*)calloc(2 * rows + 2, sizeof(double));
+    double* f0 = f1 + rows + 1;
+    int row0[3] = {0, l, l + q}, dim[3] = {l, q, g};
+    for (int part = 0; part < 3; ++part) {
+        if (dim[part] < 1) continue;
+        for (int i = 0; i < n; ++i) {
+            p->x[i] += delta;
+            p->gen(p->x, f1, f1 + l, f1 + l + q);
+            p->x[i] += -ddelta;
+            p->gen(p->x, f0, f0 + l, f0 + l + q);
+            for (int r = row0[part]; r < row0[part] + dim[part]; ++r) {
+                double a = f1[r], b = f0[r];
+                if (part == 2) { a = a < 0 ? 0 : a; b = b < 0 ? 0 : b; }
+                double v = scalar * (a - b);
+                if (part == 1) v = v * w_eq;
+                if (part == 2) v = v * w_ineq;
+                jac[r * n + i] = v;
+            }
+            p->x[i] += delta;
+        }
+    }
+    free(f1);
+}
+
 static void compute_jacobian(oracle_problem* p, double w_eq, double w_ineq, double w_b, const double* values, double* jac)
 {
     double block[CORBO_HIP_MAX_NX * CORBO_HIP_MAX_NX];
+    if (p->gen) generic_jacobian(p, w_eq, w_ineq, jac);
     for (int i = 0; i < p->n_blocks; ++i) {
         const o_block* b = &p->b[i];
         const o_edge* e  = &p->e[b->edge];

@@ -46,6 +46,12 @@ int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const 
 int oracle_warm_start(oracle_problem* p, const double* x0, int shift);
 int oracle_get_x(const oracle_problem* p, double* x_out);
 
+/* Callback problem (SimpleOptimizationProblemWithCallbacks): n parameters, f fills the lsq / equality / inequality value vectors at x
+ * (any of them may have dimension 0).  lb / ub NULL = unbounded.  Runs through the same oracle_solve() as the OCPs; used to pin the LM
+ * loop against the known-answer cases of the reference's own solver test.  set_data / get_x / eval / solve work as for an OCP (nv = n). */
+typedef void (*oracle_generic_fun)(const double* x, double* lsq, double* eq, double* ineq);
+oracle_problem* oracle_create_generic(int n, int dim_lsq, int dim_eq, int dim_ineq, const double* lb, const double* ub, oracle_generic_fun f);
+
 /* LevenbergMarquardtSparse::computeValues + computeCombinedSparseJacobian at the current x (jac may be NULL) */
 int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_bounds, double* values, double* jac);
 

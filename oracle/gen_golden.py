@@ -80,6 +80,14 @@ def main():
             json.dump(d, f, separators=(",", ":"))
         print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
 
+    # known-answer cases of the reference's own LM solver test (test_levenberg_marquardt_sparse.cpp:71-371), re-run against the compiled
+    # reference: pins LevenbergMarquardtSparse::solve on problems that are not OCPs
+    d = json.loads(subprocess.check_output([DRIVER, "kat"]))
+    d["first_iteration"] = json.loads(subprocess.check_output([DRIVER, "kat", "cap=1"]))["cases"]   # every phase capped at ONE LM iteration
+    with open(os.path.join(OUT, "lm_known_answers.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+    print("lm_known_answers", [(c["name"], [round(v, 9) for v in c["phases"][-1]["x_final"]]) for c in d["cases"]])
+
     # 8 seeded cfg-3 instances (SURVEY 8d seeds): final trajectory + chi2 only
     x0, xf = problems.unicycle_instances(8)
     inst = []

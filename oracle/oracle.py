@@ -47,8 +47,13 @@ def load():
     lib.oracle_eval.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.oracle_solve.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.c_int, dp, C.POINTER(TraceEntry)]
     lib.oracle_solve_batch.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, C.POINTER(LmOpts), dp, ip]
+    lib.oracle_create_generic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, GENERIC_FUN]
+    lib.oracle_create_generic.restype = C.c_void_p
     _lib = lib
     return lib
+
+
+GENERIC_FUN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 def _dp(a):
@@ -114,6 +119,41 @@ class OracleProblem:
         status = self.lib.oracle_solve(self.h, C.byref(opts), 1 if new_run else 0, C.byref(chi2), trace)
         tr = [{f: getattr(trace[i], f) for f, _ in TraceEntry._fields_} for i in range(opts.iterations)]
         return status, chi2.value, tr
+
+
+class GenericProblem(OracleProblem):
+    """A callback problem (the reference's SimpleOptimizationProblemWithCallbacks) run through the SAME oracle_solve as the OCPs.
+
+    lsq / eq / ineq: Python callables x -> sequence of values (or None); their dimensions are given explicitly like in the
+    reference's setObjectiveFunction(fun, dim, lsq_form=true) / setEqualityConstraint(fun, dim) / setInequalityConstraint(fun, dim)."""
+
+    def __init__(self, n, lsq=None, dim_lsq=0, eq=None, dim_eq=0, ineq=None, dim_ineq=0, lb=None, ub=None):
+        self.lib = load()
+        self.desc = None
+
+        def cb(xp, lp, ep, ip):
+            x = np.ctypeslib.as_array(xp, shape=(n,))
+            for fun, dim, out in ((lsq, dim_lsq, lp), (eq, dim_eq, ep), (ineq, dim_ineq, ip)):
+                if fun is not None and dim > 0:
+                    v = fun(x)
+                    for j in range(dim):
+                        out[j] = v[j]
+
+        self._cb = GENERIC_FUN(cb)  # keep the trampoline alive as long as the problem
+        lb = None if lb is None else np.ascontiguousarray(lb, np.float64)
+        ub = None if ub is None else np.ascontiguousarray(ub, np.float64)
+        self.h = self.lib.oracle_create_generic(n, dim_lsq, dim_eq, dim_ineq, _dp(lb), _dp(ub), self._cb)
+        if not self.h:
+            raise ValueError("oracle_create_generic: invalid arguments")
+        d = Dims()
+        self.lib.oracle_get_dims(self.h, C.byref(d))
+        self.dims = d
+
+    def init_trajectory(self, x0, xf):
+        raise NotImplementedError("not an OCP")
+
+    def warm_start(self, x0, shift=True):
+        raise NotImplementedError("not an OCP")
 
 
 def solve_batch(desc: ProblemDesc, x: np.ndarray, xref: np.ndarray, opts: LmOpts):

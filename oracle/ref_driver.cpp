@@ -15,6 +15,9 @@
 //        -> solves B seeded instances sequentially on one core, prints JSON with solver wall time
 //           (OptimalControlProblemStatistics::solving_time, i.e. only levenberg_marquardt_sparse.cpp:44-220).
 //
+//   ref_driver kat
+//        -> the known-answer cases of the reference's own LM solver test re-run on non-OCP problems (see kat() below).
+//
 // Scenarios: unicycle (cfg 3), vdp (cfg 1), dint (cfg 2: time-optimal double integrator).
 #include <corbo-core/reference_trajectory.h>
 #include <corbo-core/time.h>
@@ -31,6 +34,7 @@
 #include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_grid.h>
 #include <corbo-optimal-control/structured_ocp/structured_optimal_control_problem.h>
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_edge_based.h>
+#include <corbo-optimization/simple_optimization_problem.h>
 #include <corbo-optimization/solver/levenberg_marquardt_sparse.h>
 #include <corbo-systems/benchmark/linear_benchmark_systems.h>
 #include <corbo-systems/benchmark/nonlinear_benchmark_systems.h>
@@ -636,16 +640,150 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// kat: the known-answer cases of the reference's own solver test (optimization/test/test_levenberg_marquardt_sparse.cpp:71-371;
+// written against an older class name, `StandardOptimizationProblemWithCallbacks` = today's SimpleOptimizationProblemWithCallbacks)
+// re-run against the compiled reference.  The problem definitions below are this file's own restatement of what those tests set
+// up (same functions, starts, bounds, weights, iteration counts, call order -- including the tests' "setParameterValue(0, ..)
+// twice" slip); the output pins LevenbergMarquardtSparse::solve on problems that are not OCPs.
+static int g_kat_iter_cap = 0;   // kat cap=K: every phase runs at most K LM iterations (to compare iterate by iterate)
+
+struct KatPhase
+{
+    std::vector<std::pair<int, double>> set_values;  // setParameterValue calls before the phase
+    double w[3]     = {2, 2, 2};                     // levenberg_marquardt_sparse.h:126-128 defaults
+    double adapt[6] = {1, 1, 1, 500, 500, 500};
+    int iterations  = 100;                           // the fixture's SetUp
+    int solves      = 1;                             // new_run only for the first
+    bool set_weights = false, set_adapt = false, initialize = true;
+};
+
+static void katRun(const char* name, const char* fun, int n, int lsq, int eq, int ineq, const Eigen::VectorXd& x_start, const Eigen::VectorXd& lb,
+                   const Eigen::VectorXd& ub, std::function<void(const Eigen::VectorXd&, Eigen::Ref<Eigen::VectorXd>)> f_obj,
+                   std::function<void(const Eigen::VectorXd&, Eigen::Ref<Eigen::VectorXd>)> f_eq,
+                   std::function<void(const Eigen::VectorXd&, Eigen::Ref<Eigen::VectorXd>)> f_ineq, const std::vector<KatPhase>& phases, bool last)
+{
+    SimpleOptimizationProblemWithCallbacks optim;
+    LevenbergMarquardtSparse solver;
+    solver.setIterations(100);
+    optim.resizeParameterVector(n);
+    if (x_start.size() == n) optim.setX(x_start);
+    for (int i = 0; i < n; ++i)
+    {
+        if (lb.size() == n) optim.setLowerBound(i, lb[i]);
+        if (ub.size() == n) optim.setUpperBound(i, ub[i]);
+    }
+    optim.setObjectiveFunction(f_obj, lsq, true);
+    if (eq) optim.setEqualityConstraint(f_eq, eq);
+    if (ineq) optim.setInequalityConstraint(f_ineq, ineq);
+    printf("{\"name\": \"%s\", \"fun\": \"%s\", \"n\": %d, \"lsq\": %d, \"eq\": %d, \"ineq\": %d,\n", name, fun, n, lsq, eq, ineq);
+    Eigen::VectorXd lbv(n), ubv(n);
+    for (int i = 0; i < n; ++i) { lbv[i] = optim.getLowerBound(i); ubv[i] = optim.getUpperBound(i); }
+    printVec("lb", lbv);
+    printVec("ub", ubv);
+    printf("\"phases\": [\n");
+    for (size_t ph = 0; ph < phases.size(); ++ph)
+    {
+        const KatPhase& P = phases[ph];
+        for (auto& sv : P.set_values) optim.setParameterValue(sv.first, sv.second);
+        if (P.set_weights) solver.setPenaltyWeights(P.w[0], P.w[1], P.w[2]);
+        if (P.set_adapt) solver.setWeightAdapation(P.adapt[0], P.adapt[1], P.adapt[2], P.adapt[3], P.adapt[4], P.adapt[5]);
+        const int iters = (g_kat_iter_cap > 0 && g_kat_iter_cap < P.iterations) ? g_kat_iter_cap : P.iterations;
+        solver.setIterations(iters);
+        if (P.initialize) solver.initialize(&optim);
+        printf("{");
+        printVec("x_init", optim.getX());
+        SolverStatus st = SolverStatus::Error;
+        double obj      = -1;
+        for (int i = 0; i < P.solves; ++i) st = solver.solve(optim, true, i == 0, &obj);
+        printf("\"weights\": [%.17g, %.17g, %.17g], \"adapt\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"iterations\": %d, \"solves\": %d,\n", P.w[0],
+               P.w[1], P.w[2], P.adapt[0], P.adapt[1], P.adapt[2], P.adapt[3], P.adapt[4], P.adapt[5], iters, P.solves);
+        printf("\"status\": %d, \"chi2\": %.17g, ", (int)st, obj);
+        printVec("x_final", optim.getX(), false);
+        printf("}%s\n", ph + 1 < phases.size() ? "," : "");
+    }
+    printf("]}%s\n", last ? "" : ",");
+}
+
+static int kat()
+{
+    using V  = Eigen::VectorXd;
+    using R  = Eigen::Ref<Eigen::VectorXd>;
+    V none;
+    auto shift1  = [](const V& x, R v) { v[0] = x[0] - 2; };
+    auto affine3 = [](const V& x, R v) { v[0] = x[0] - 5; v[1] = x[1] + 3; v[2] = x[2]; };
+    auto rosen   = [](const V& x, R v) { v[0] = std::sqrt(100) * (x[1] - x[0] * x[0]); v[1] = 1 - x[0]; };
+    auto eq3     = [](const V& x, R v) { v[0] = x[0] - 3; };
+    auto ineq3   = [](const V& x, R v) { v[0] = -x[0] + 3; };
+    auto betts   = [](const V& x, R v) { v[0] = std::sqrt(0.01) * x[0]; v[1] = x[1]; };
+    auto bettsc  = [](const V& x, R v) { v[0] = x[1] - 10.0 * x[0] + 10.0; };
+    KatPhase def;
+    KatPhase w100;
+    w100.set_weights = true;
+    w100.w[0] = w100.w[1] = w100.w[2] = 100;
+    printf("{\"source\": \"optimization/test/test_levenberg_marquardt_sparse.cpp:71-371 re-run against the compiled reference\",\n\"cases\": [\n");
+    katRun("solve_unconstr_1", "shift1", 1, 1, 0, 0, V::Ones(1), none, none, shift1, nullptr, nullptr, {def}, false);
+    katRun("solve_unconstr_2", "affine3", 3, 3, 0, 0, V::Ones(3), none, none, affine3, nullptr, nullptr, {def}, false);
+    katRun("solve_rosenbrock_unconstr", "rosenbrock", 2, 2, 0, 0, V::Ones(2), none, none, rosen, nullptr, nullptr, {def}, false);
+    {   // the classic start (SURVEY 8c quotes its result)
+        V x(2);
+        x << -1.2, 1;
+        katRun("rosenbrock_classic_start", "rosenbrock", 2, 2, 0, 0, x, none, none, rosen, nullptr, nullptr, {def}, false);
+    }
+    katRun("solve_eqconstr_1", "shift1_eq3", 1, 1, 1, 0, V::Ones(1), none, none, shift1, eq3, nullptr, {w100}, false);
+    katRun("solve_ineqconstr_1", "shift1_ineq3", 1, 1, 0, 1, V::Ones(1), none, none, shift1, nullptr, ineq3, {w100}, false);
+    {
+        V lb(1);
+        lb[0] = 5;
+        katRun("solve_lower_bounds", "shift1", 1, 1, 0, 0, V::Ones(1), lb, none, shift1, nullptr, nullptr, {w100}, false);
+        V ub(1);
+        ub[0] = -1;
+        katRun("solve_upper_bounds", "shift1", 1, 1, 0, 0, V::Ones(1), none, ub, shift1, nullptr, nullptr, {w100}, false);
+    }
+    {
+        V lb(2), ub(2);
+        lb << 2, -50;
+        ub << 50, 50;
+        KatPhase a;   // "feasible start": no initialize() call in the test, default weights
+        a.set_values = {{0, 5.0}, {0, -5.0}};
+        a.initialize = false;
+        KatPhase b;   // "infeasible start"
+        b.set_values  = {{0, -1.0}, {0, -1.0}};
+        b.set_weights = true;
+        b.w[0] = 1; b.w[1] = 10; b.w[2] = 10;
+        b.iterations = 5000;
+        katRun("solve_betts_fun_constr", "betts", 2, 2, 0, 1, none, lb, ub, betts, nullptr, bettsc, {a, b}, false);
+        KatPhase c;
+        c.set_values  = {{0, 5.0}, {0, -5.0}};
+        c.set_weights = true;
+        c.set_adapt   = true;
+        c.adapt[0] = c.adapt[1] = c.adapt[2] = 5;
+        c.iterations = 5;
+        c.solves     = 5;
+        KatPhase d = c;
+        d.set_values = {{0, -1.0}, {0, -1.0}};
+        d.initialize = false;
+        katRun("solve_betts_fun_constr_weight_adapt", "betts", 2, 2, 0, 1, none, lb, ub, betts, nullptr, bettsc, {c, d}, true);
+    }
+    printf("]}\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2)
     {
-        fprintf(stderr, "usage: ref_driver dump|bench|mpc key=value ...\n");
+        fprintf(stderr, "usage: ref_driver dump|bench|mpc|kat key=value ...\n");
         return 1;
+    }
+    std::string mode(argv[1]);
+    if (mode == "kat")
+    {
+        if (argc > 2 && std::string(argv[2]).rfind("cap=", 0) == 0) g_kat_iter_cap = std::atoi(argv[2] + 4);
+        return kat();
     }
     std::map<std::string, std::string> kv;
     Scenario s = parse(argc, argv, kv);
-    std::string mode(argv[1]);
     if (mode == "dump") return dump(s);
     if (mode == "bench") return bench(s, kv);
     if (mode == "mpc") return mpc(s, kv);
