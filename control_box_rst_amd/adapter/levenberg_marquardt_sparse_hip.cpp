@@ -5,6 +5,7 @@
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_base.h>
 #include <corbo-optimization/hyper_graph/vertex_interface.h>
 
+#include <cmath>
 #include <cstring>
 
 namespace corbo {
@@ -65,6 +66,48 @@ void LevenbergMarquardtSparseHip::clear()
     std::memset(&_stats, 0, sizeof(_stats));
 }
 
+// Stacked residual [lsq | w_eq eq | w_ineq max(0, c) | w_b bound distance] of the graph's own edges (the reference's
+// LevenbergMarquardtSparse::computeValues, levenberg_marquardt_sparse.cpp:222-246) against the device's at the uploaded vertex values.
+bool LevenbergMarquardtSparseHip::modelMatchesGraph(OptimizationProblemInterface& problem)
+{
+    const double w_eq = _opts.weight_eq, w_ineq = _opts.weight_ineq, w_b = _opts.weight_bounds;
+    Eigen::VectorXd host(_dims.m), dev(_dims.m);
+    int idx = 0;
+    if (_dims.lsq > 0) problem.computeValuesLsqObjective(host.segment(idx, _dims.lsq));
+    idx += _dims.lsq;
+    if (_dims.eq > 0)
+    {
+        problem.computeValuesEquality(host.segment(idx, _dims.eq));
+        host.segment(idx, _dims.eq) *= w_eq;
+    }
+    idx += _dims.eq;
+    if (_dims.ineq > 0) problem.computeValuesActiveInequality(host.segment(idx, _dims.ineq), w_ineq);
+    idx += _dims.ineq;
+    if (_dims.bounds > 0)
+    {
+        problem.computeDistanceFiniteCombinedBounds(host.segment(idx, _dims.bounds));
+        host.segment(idx, _dims.bounds) *= w_b;
+    }
+    if (corbo_hip_eval(_handle, w_eq, w_ineq, w_b, dev.data(), nullptr) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
+    }
+    for (int i = 0; i < _dims.m; ++i)
+    {
+        const double tol = 1e-9 * (1.0 + std::abs(host[i]));
+        if (!(std::abs(host[i] - dev[i]) <= tol))
+        {
+            const char* part = i < _dims.lsq ? "lsq objective" : i < _dims.lsq + _dims.eq ? "equality" : i < _dims.lsq + _dims.eq + _dims.ineq ? "inequality" : "bounds";
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): the device model does not describe this hypergraph: residual row "
+                        << i << " (" << part << ") is " << host[i] << " on the graph's edges and " << dev[i]
+                        << " on the device; refusing to solve (no CPU fallback).");
+            return false;
+        }
+    }
+    return true;
+}
+
 SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& problem, bool new_structure, bool new_run, double* obj_value)
 {
     if (obj_value) *obj_value = -1;
@@ -93,8 +136,10 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     auto xv = [&](int k) { return interleaved ? vtx[2 * k] : vtx[k]; };
     auto uv = [&](int k) { return interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; };
 
+    bool verify_now = false;
     if (new_structure || !_handle || _desc.N != N)
     {
+        verify_now = _verify;
         // describe the structure, then verify it against what the graph reports
         for (int k = 0; k < N - 1; ++k)
             if (xv(k)->getDimension() != nx || uv(k)->getDimension() != nu)
@@ -159,8 +204,17 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     if (_xref.size() == nx)
         for (int i = 0; i < nx; ++i) xref[i] = _xref[i];
 
-    if (corbo_hip_set_instance_data(_handle, _x.data(), _lb.data(), _ub.data(), xref.data()) != CORBO_HIP_OK ||
-        corbo_hip_solve(_handle, &_opts, new_run ? 1 : 0) != CORBO_HIP_OK)
+    if (corbo_hip_set_instance_data(_handle, _x.data(), _lb.data(), _ub.data(), xref.data()) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return SolverStatus::Error;
+    }
+    if (verify_now && !modelMatchesGraph(problem))
+    {
+        releaseHandle();   // the next call re-checks
+        return SolverStatus::Error;
+    }
+    if (corbo_hip_solve(_handle, &_opts, new_run ? 1 : 0) != CORBO_HIP_OK)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
         return SolverStatus::Error;

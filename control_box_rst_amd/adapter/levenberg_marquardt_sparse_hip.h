@@ -49,15 +49,22 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     void setDeviceModel(const corbo_hip_problem_desc& desc) { _desc = desc; _have_desc = true; releaseHandle(); }
     void setStateReference(const Eigen::Ref<const Eigen::VectorXd>& xref) { _xref = xref; }
     void setDevice(int device) { _device = device; releaseHandle(); }
+    // On every new structure the stacked residual of the graph's own edges (evaluated on the host through the reference's
+    // computeValues* methods) is compared with the device's residual at the same vertex values; a device model that does not describe
+    // what the graph's edges compute (other dynamics, weights, collocation scheme, constraint) is refused instead of silently solving
+    // a different problem.  On by default; costs one host residual evaluation and one device sweep per structure change.
+    void setVerifyModel(bool verify) { _verify = verify; }
 
     const corbo_hip_stats& getStatistics() const { return _stats; }
 
  private:
     void releaseHandle();
+    bool modelMatchesGraph(OptimizationProblemInterface& problem);
 
     corbo_hip_lm_opts _opts;
     corbo_hip_problem_desc _desc;
     bool _have_desc = false;
+    bool _verify    = true;
     Eigen::VectorXd _xref;
     int _device = 0;
     corbo_hip_handle _handle = nullptr;

@@ -111,8 +111,11 @@ static Eigen::VectorXd trajectory(StructuredOptimalControlProblem& ocp, Discreti
 }
 
 // scenario "unicycle": cfg 3 single instance; "dint": cfg 2 (free dt, 5 consecutive solves, new_run only first)
-static Run run(const std::string& scenario, bool hip, int N)
+static Run run(const std::string& scenario_in, bool hip, int N)
 {
+    // "<scenario>_mismatch": the OCP of <scenario>, but the device model handed to the HIP solver states another state weight
+    const bool mismatch        = scenario_in.size() > 9 && scenario_in.compare(scenario_in.size() - 9, 9, "_mismatch") == 0;
+    const std::string scenario = mismatch ? scenario_in.substr(0, scenario_in.size() - 9) : scenario_in;
     Run r;
     SystemDynamicsInterface::Ptr dyn;
     std::shared_ptr<FiniteDifferencesGrid> grid;
@@ -180,6 +183,7 @@ static Run run(const std::string& scenario, bool hip, int N)
     }
     const double dt = (scenario == "quad") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
+    if (mismatch) d.q_diag[1] = 2.0 * d.q_diag[1];
     if (hip)
     {
         auto s = std::make_shared<LevenbergMarquardtSparseHip>();
@@ -265,6 +269,11 @@ int main(int argc, char** argv)
         printf("{\"scenario\": \"%s\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n", sc,
                a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
         if (!(diff < (std::string(sc) == "quad" ? 5e-3 : 1e-5))) rc = 1;
+    }
+    {   // a device model that does not describe the graph must be refused (SolverStatus::Error -> compute() fails), not solved
+        Run c = run("unicycle_mismatch", true, 30);
+        printf("{\"scenario\": \"unicycle_mismatch\", \"ok_hip\": %d}\n", c.ok ? 1 : 0);
+        if (c.ok) rc = 1;
     }
     return rc;
 }

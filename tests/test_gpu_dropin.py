@@ -21,7 +21,12 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     g.build()
     p = subprocess.run([DEMO], capture_output=True, text=True, timeout=300)
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 4, (p.stdout, p.stderr)   # cfg 3, cfg 2, reduced cfg 5, cfg 3 structure + TerminalBall
+    assert len(lines) == 5, (p.stdout, p.stderr)   # cfg 3, cfg 2, reduced cfg 5, cfg 3 structure + TerminalBall, mismatching model
+    refused = lines.pop()
+    # the adapter compares the graph's own residual with the device's on every new structure: a device model with another
+    # state weight than the OCP's QuadraticFormCost is refused (SolverStatus::Error), never silently solved
+    assert refused["scenario"] == "unicycle_mismatch" and refused["ok_hip"] == 0, refused
+    assert "does not describe this hypergraph" in p.stdout + p.stderr
     for r in lines:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, r
         # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
