@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="OCP instances per GPU")
     ap.add_argument("--iterations", type=int, default=10, help="LM outer iterations per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup", type=int, default=0, help="untimed sweep launches before the warm-up steps")
     args = ap.parse_args()
 
     import torch
@@ -153,9 +154,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # bring the GPU out of its idle power state before anything is timed (a solve is < 1 ms; after host-side set-up the first
-    # kernels otherwise run at idle clocks -- measured: 26 ms instead of 0.7 ms per solve): ~50 ms of untimed sweep launches
-    solver.time_sweep(with_jacobian=True, repeat=3000)
+    # optional untimed sweep launches before the warm-up steps (diagnostics; A/B-measured: no effect on the timed region.  The 26 ms
+    # solves once seen after host-side set-up were the runtime releasing the pages of a pageable upload -- the boundary now stages
+    # through pinned memory)
+    if args.spinup > 0:
+        solver.time_sweep(with_jacobian=True, repeat=args.spinup)
     for _ in range(args.warmup):
         step()
     fence()
@@ -187,6 +190,15 @@ def main():
                 traffic, traffic_src = j["hbm_bytes_per_launch"], j["source"]
         except Exception:
             pass
+    # the boundary takes HOST buffers: one-shot rate including the upload of trajectories / bounds / references over PCIe, the solve
+    # and the download of trajectories, chi2 and status (never `value`; a moving-horizon caller keeps the trajectories resident and
+    # uploads only the measured states, corbo_hip_warm_start)
+    t_h = time.perf_counter()
+    for _ in range(5):
+        solver.set_instance_data(X0, xref=xf)
+        solver.solve(new_run=True)
+        solver.get_solution()
+    host_ms = (time.perf_counter() - t_h) / 5 * 1e3
     # per-kernel split inside one solve (separate, profiled solve: event stamping is kept out of the timed region)
     solver.set_profiling(True)
     step()
@@ -231,6 +243,8 @@ def main():
                                 "algorithmic_bytes_per_solve": alg_solve, "achieved_GBs": alg_solve / (t_max / args.steps) / 1e9,
                                 "frac_of_hbm_peak": alg_solve / (t_max / args.steps) / 1e9 / peak,
                                 "jacobian_sweeps": int(sweeps_j), "residual_sweeps": int(sweeps_r)}
+        line["host_inclusive"] = {"ms_per_step": host_ms, "value_rank0": stats["lm_iterations"] / (host_ms * 1e-3),
+                                  "what": "set_instance_data (H2D of x, bounds, xref from pageable host memory) + solve + get_solution (D2H), rank 0"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(desc, solver.opts, x0, xf)
         print(json.dumps(line), flush=True)

@@ -2176,7 +2176,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
             mode = 3;
         }
         lm_state_out(fp.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM
-        if (tid_v == 0 && !sl->done && sp.active_count) atomicAdd(sp.active_count, 1);  // pass limit hit
+        if (tid_v == 0 && !sl->done && fp.unfinished_flag) *(volatile int32_t*)fp.unfinished_flag = 1;  // pass limit hit
     }
 }
 
@@ -2257,6 +2257,35 @@ bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 }
 
 }  // namespace
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const double* __restrict__ row_a, const double* __restrict__ row_b,
+                                                             double* __restrict__ dst_a, double* __restrict__ dst_b, int nvs)
+{
+    const size_t base = (size_t)blockIdx.x * nvs;
+    for (int i = threadIdx.x; i < nvs; i += 256) {
+        dst_a[base + i] = row_a[i];
+        dst_b[base + i] = row_b[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_first_control_kernel(const double* __restrict__ x, double* __restrict__ out, int nvs, int nx, int nu,
+                                                                   int batch)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= batch * nu) return;
+    const int b = t / nu, i = t - b * nu;
+    out[t] = x[(size_t)b * nvs + nx + i];
+}
+
+void launch_gather_first_control(const double* x, double* out, int nvs, int nx, int nu, int batch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gather_first_control_kernel, dim3((batch * nu + 255) / 256), dim3(256), 0, stream, x, out, nvs, nx, nu, batch);
+}
+
+void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst_a, double* dst_b, int nvs, int batch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(batch), dim3(256), 0, stream, row_a, row_b, dst_a, dst_b, nvs);
+}
 
 void launch_warm_start(const WarmStartParams& p, hipStream_t stream)
 {

@@ -89,6 +89,7 @@ struct FactorParams {
     int32_t pass_timeline_inst;
     int32_t first_pass;           // big-block family: this may be the first factorisation of a solve (launches the mu / stop kernels)
     int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
+    int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 
 // returns false if the (dynamics, defect) pair has no device instantiation
@@ -102,6 +103,10 @@ struct WarmStartParams {
     const double* xref;   // [batch][CORBO_HIP_MAX_NX]
 };
 void launch_warm_start(const WarmStartParams& p, hipStream_t stream);
+// out[b][0..nu) = x[b][nx .. nx+nu)  (u_0 of every instance, packed; `out` may be device-visible pinned host memory)
+void launch_gather_first_control(const double* x, double* out, int nvs, int nx, int nu, int batch, hipStream_t stream);
+// dst_a[b][:] = row_a, dst_b[b][:] = row_b for b < batch (the descriptor's bound pattern repeated for every instance)
+void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst_a, double* dst_b, int nvs, int batch, hipStream_t stream);
 
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p, int nc);

@@ -391,3 +391,24 @@ def test_small_family_with_stage_inequality_vs_oracle(oracle_mod):
     Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
     assert np.abs(X - Xo).max() <= 2 * X_TOL, np.abs(X - Xo).max()
     assert np.allclose(chi2, chi2o, rtol=CHI2_RTOL)
+
+
+def test_pass_limit_is_reported_not_swallowed(monkeypatch):
+    """An instance still unfinished when the run-to-completion kernel's pass limit is reached raises a flag in pinned host memory;
+    corbo_hip_solve turns it into an error (the limit is 4096 passes; CORBO_HIP_PASS_LIMIT lowers it for this test)."""
+    from control_box_rst_amd import problems
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    d = problems.unicycle_desc(N=20)
+    x0, xf = problems.unicycle_instances(4)
+    s = BatchedLevenbergMarquardt(d, 4)
+    s.setIterations(10)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    monkeypatch.setenv("CORBO_HIP_PASS_LIMIT", "3")     # 10 outer iterations need at least 10 passes
+    with pytest.raises(Exception, match="pass limit"):
+        s.solve(new_run=True)
+    monkeypatch.delenv("CORBO_HIP_PASS_LIMIT")
+    s.restore_instance_data()
+    s.solve(new_run=True)                                # the handle stays usable
+    _, _, status = s.get_solution()
+    assert (status <= 1).all()

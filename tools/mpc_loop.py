@@ -51,5 +51,5 @@ for k in range(STEPS):
 wall = time.perf_counter() - t_all
 dist1 = np.linalg.norm(x[:, :2] - xf[:, :2], axis=1).mean()
 print(f"batch={B} N={d.N} iterations={ITERS}: {STEPS / wall:.1f} closed-loop steps/s of the whole batch = {B * STEPS / wall / 1e3:.1f} k plant-steps/s "
-      f"(per step: u_0 read-back {t_u / STEPS * 1e3:.3f} ms, warm start {t_ws / STEPS * 1e3:.3f} ms, solve {t_solve / STEPS * 1e3:.3f} ms, "
+      f"(per step: u_0 read-back {t_u / STEPS * 1e3:.3f} ms, warm start {t_ws / STEPS * 1e3:.3f} ms, solve {t_solve / STEPS * 1e3:.3f} ms (last one on the device: {s.get_stats()['solve_ms']:.3f} ms), "
       f"host plant + loop {(wall - t_u - t_ws - t_solve) / STEPS * 1e3:.3f} ms); mean distance to goal {dist0:.3f} -> {dist1:.3f}")
