@@ -1191,14 +1191,14 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     // What differs between the lanes is only WHERE their 3-vector operand comes from / goes to (column j of W, or the rhs slot), i.e.
     // a base pointer and a stride -- the instruction stream is the same.
     int hroot = 2;
-    for (int h = 2;; h <<= 1) {
+    for (int h = 2, lg = 1;; h <<= 1, ++lg) {   // h = 2^lg
         const int j     = tid & 3;
         const int hh    = h >> 1;
         const bool root = (h >= N);                                      // only a == 0 is active then
         static_assert(NX + 1 <= 4, "four lanes per block: NX columns + one right-hand-side lane");
         const bool vec  = (j == NX);
         const bool col  = (j < NX);
-        const int nblk  = (N + h - 1) / h;
+        const int nblk  = (N + h - 1) >> lg;
         for (int t = tid >> 2; t < nblk; t += THREADS / 4) {   // (one round whenever 4 * ceil(N / h) <= THREADS)
         const int a      = h * t;
         const int ac     = a;
