@@ -178,14 +178,18 @@ int corbo_hip_get_structure(const corbo_hip_problem_desc* desc, int32_t* rows, i
  * interpolation x0 -> xf, u = 0, dt = dt_ref.  x0, xf: [batch][nx]; x_out: [batch][nv].  Host-only helper. */
 int corbo_hip_init_trajectory(const corbo_hip_problem_desc* desc, int batch, const double* x0, const double* xf, double* x_out);
 
-/* Create a solver for `batch` independent instances of `desc` on HIP device `device`. */
+/* Create a solver for `batch` independent instances of `desc` on HIP device `device`.  Every entry point below runs on that device
+ * and restores the caller's current device before it returns.  No C++ exception leaves the library.  A handle is not thread-safe;
+ * different handles (also on the same device) are independent. */
 int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out);
 void corbo_hip_destroy(corbo_hip_handle h);
 
 /* Upload per-instance data (what the grid holds in its vertices when solve() is entered):
  *   x  [batch][nv] vertex values, lb/ub [batch][nv] bounds (+-CORBO_HIP_INF = unbounded; entries of fixed
  *   components are ignored), xref [batch][nx] static state reference (StaticReference).
- * lb, ub may be NULL = the descriptor's box bounds replicated along the horizon; xref may be NULL = zeros. */
+ * lb, ub may be NULL = the descriptor's box bounds replicated along the horizon (filled in on the device); xref may be NULL = zeros.
+ * The caller's arrays are plain host memory and are free again when the call returns: they are repacked into a pinned staging
+ * buffer owned by the handle and copied on the handle's stream. */
 int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref);
 
 /* Re-arm the resident batch: copy the x uploaded by the last corbo_hip_set_instance_data back into the iterate,
@@ -201,18 +205,20 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h);
  *               (findNearestState, :285-317), states and controls move forward, the tail is extrapolated linearly;
  *   always:     x_0 = x0_new (:101), fixed components of x_f = the state reference (:103-106).
  * ShootingGridBase (MultipleShootingGrid) does the same on its shooting intervals (shooting_grid_base.cpp:99-113, 292-388).
- * x0_new [batch][nx] (host).  Follow with corbo_hip_solve(h, opts, new_run = 1). */
+ * x0_new [batch][nx] (host; copied into pinned memory that the kernel reads directly, free again on return).  Asynchronous on the
+ * handle's stream.  Follow with corbo_hip_solve(h, opts, new_run = 1). */
 int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
 
 /* u_0 of every instance's current trajectory = FullDiscretizationGridBase::getFirstControlInput
  * (full_discretization_grid_base.cpp:324-331), what a predictive controller applies to its plant.  u0_out [batch][nu] (host);
- * a strided device-to-host copy of batch * nu doubles instead of the whole trajectories. */
+ * batch * nu doubles, packed by a small kernel into pinned host memory, instead of the whole trajectories.  Synchronises. */
 int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out);
 
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
- * (:83-86).  Kernels run on the handle's stream; the call returns once every instance has finished its outer iterations
- * (the host only reads one "unfinished instances" counter per pass group); results stay resident in HBM. */
+ * (:83-86).  One run-to-completion launch on the handle's stream; the call returns once every instance has finished its outer
+ * iterations; results stay resident in HBM.  CORBO_HIP_ERR_DEVICE "pass limit reached" if an instance is still unfinished after
+ * 4096 LM passes (never seen; the reference would loop). */
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
 
 /* Block until the handle's stream is idle. */
