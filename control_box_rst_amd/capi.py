@@ -69,6 +69,8 @@ def default_lm_opts(iterations=10, w_eq=2.0, w_ineq=2.0, w_bounds=2.0) -> LmOpts
     return LmOpts(iterations, w_eq, w_ineq, w_bounds, 1.0, 1.0, 1.0, 500.0, 500.0, 500.0)
 
 
+INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1   # corbo_hip_integrator
+
 # CORBO_HIP_LIB: A/B measurements of two builds of the same C-ABI in one GPU session (development only)
 _LIB_PATH = os.environ.get("CORBO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcorbo_hip.so")
 _lib = None
@@ -80,6 +82,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_synchronize", "corbo_hip_get_solution", "corbo_hip_get_stats", "corbo_hip_eval",
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
     "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
+    "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_warm_start_from_plant",
 )
 
 
@@ -117,6 +120,10 @@ def load() -> C.CDLL:
     lib.corbo_hip_restore_instance_data.argtypes = [H]
     lib.corbo_hip_warm_start.argtypes = [H, C.POINTER(C.c_double), C.c_int]
     lib.corbo_hip_get_first_control.argtypes = [H, C.POINTER(C.c_double)]
+    lib.corbo_hip_plant_set_state.argtypes = [H, dp]
+    lib.corbo_hip_plant_step.argtypes = [H, C.c_int, C.c_double, dp]
+    lib.corbo_hip_plant_get_state.argtypes = [H, dp]
+    lib.corbo_hip_warm_start_from_plant.argtypes = [H, C.c_int]
     lib.corbo_hip_set_profiling.argtypes = [H, C.c_int]
     lib.corbo_hip_solve.argtypes = [H, C.POINTER(LmOpts), C.c_int]
     lib.corbo_hip_synchronize.argtypes = [H]

@@ -109,6 +109,9 @@ struct corbo_hip_solver {
     double* h_stage      = nullptr;
     double* d_bound_rows = nullptr;  // [2][nvs] the descriptor's bound pattern of one instance (lower row, upper row)
     std::vector<double> bound_rows;  // host copy of the same
+    double* d_xplant = nullptr;      // [batch][MAX_NX] plant states of the closed loop (corbo_hip_plant_*)
+    double* h_dist   = nullptr;      // pinned, device-visible [batch][MAX_NX]: state disturbance of corbo_hip_plant_step
+    bool have_plant  = false;
     LmState* h_state = nullptr;      // pinned [batch] read-back of the per-instance LM state (get_solution / get_stats)
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
@@ -278,8 +281,11 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMalloc((void**)&h->d_ub, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xref, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_xnew, B * CORBO_HIP_MAX_NX * sizeof(double)));
-    CREATE_TRY(hipHostMalloc((void**)&h->h_stage, B * S.nvs * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_stage, B * (size_t)(S.nvs > CORBO_HIP_MAX_NX ? S.nvs : CORBO_HIP_MAX_NX) * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_state, B * sizeof(LmState)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_dist, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_xplant, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_xplant, 0, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_bound_rows, 2 * (size_t)S.nvs * sizeof(double)));
     {   // bound pattern of one instance (descriptor boxes along the horizon, x_f, free dt)
         std::vector<double>& rows = h->bound_rows;
@@ -336,13 +342,14 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows, h->d_xplant};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     if (h->h_xnew) (void)hipHostFree(h->h_xnew);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_dist) (void)hipHostFree(h->h_dist);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->ev_chk) if (e) (void)hipEventDestroy(e);
@@ -611,6 +618,19 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h)
     return CORBO_HIP_OK;
 }
 
+static int warm_start_from(corbo_hip_handle h, const double* x0_dev_visible, int shift)
+{
+    const Structure& S = h->S;
+    WarmStartParams p{};
+    p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.N = S.N;
+    p.xf_fixed_mask = (int32_t)S.desc.xf_fixed_mask;
+    p.shift = (shift != 0 && !S.dt_free) ? 1 : 0;   // variable grids never shift (finite_differences_variable_grid.h:77)
+    p.x = h->d_x; p.x0new = x0_dev_visible; p.xref = h->d_xref;
+    launch_warm_start(p, h->stream);
+    HIP_TRY(hipGetLastError());
+    return CORBO_HIP_OK;
+}
+
 int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
 {
     if (!h || !x0_new) return fail(CORBO_HIP_ERR_INVALID, "null argument");
@@ -621,13 +641,65 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
     for (int b = 0; b < h->batch; ++b)
         for (int i = 0; i < S.nx; ++i) h->h_xnew[(size_t)b * CORBO_HIP_MAX_NX + i] = x0_new[(size_t)b * S.nx + i];
     // the kernel reads the measured states straight from the pinned (device-visible) buffer: no copy engine in the control loop
-    WarmStartParams p{};
-    p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.N = S.N;
-    p.xf_fixed_mask = (int32_t)S.desc.xf_fixed_mask;
-    p.shift = (shift != 0 && !S.dt_free) ? 1 : 0;   // variable grids never shift (finite_differences_variable_grid.h:77)
-    p.x = h->d_x; p.x0new = h->h_xnew; p.xref = h->d_xref;
-    launch_warm_start(p, h->stream);
+    return warm_start_from(h, h->h_xnew, shift);
+}
+
+int corbo_hip_warm_start_from_plant(corbo_hip_handle h, int shift)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
+    ON_DEVICE_OF(h);
+    return warm_start_from(h, h->d_xplant, shift);
+}
+
+int corbo_hip_plant_set_state(corbo_hip_handle h, const double* x)
+{
+    if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    ON_DEVICE_OF(h);
+    const Structure& S = h->S;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->batch; ++b)
+        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) h->h_dist[(size_t)b * CORBO_HIP_MAX_NX + i] = (i < S.nx) ? x[(size_t)b * S.nx + i] : 0.0;
+    HIP_TRY(hipMemcpyAsync(h->d_xplant, h->h_dist, (size_t)h->batch * CORBO_HIP_MAX_NX * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_plant = true;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const double* disturbance)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (integrator != CORBO_HIP_INTEGRATOR_EULER && integrator != CORBO_HIP_INTEGRATOR_RK4) return fail(CORBO_HIP_ERR_INVALID, "unknown integrator");
+    if (!(dt > 0)) return fail(CORBO_HIP_ERR_INVALID, "dt must be positive");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
+    ON_DEVICE_OF(h);
+    const Structure& S = h->S;
+    if (disturbance) {
+        HIP_TRY(hipStreamSynchronize(h->stream));   // the previous step has consumed the pinned buffer
+        for (int b = 0; b < h->batch; ++b)
+            for (int i = 0; i < S.nx; ++i) h->h_dist[(size_t)b * CORBO_HIP_MAX_NX + i] = disturbance[(size_t)b * S.nx + i];
+    }
+    PlantParams p{};
+    p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.integrator = integrator; p.dt = dt;
+    std::memcpy(p.dyn, S.desc.dyn_params, sizeof(p.dyn));
+    p.x = h->d_x; p.xplant = h->d_xplant; p.disturbance = disturbance ? h->h_dist : nullptr;
+    if (!launch_plant_step(S.desc, p, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no plant kernel for this dynamics");
     HIP_TRY(hipGetLastError());
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out)
+{
+    if (!h || !x_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
+    ON_DEVICE_OF(h);
+    const Structure& S = h->S;
+    HIP_TRY(hipMemcpyAsync(h->h_stage, h->d_xplant, (size_t)h->batch * CORBO_HIP_MAX_NX * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->batch; ++b)
+        for (int i = 0; i < S.nx; ++i) x_out[(size_t)b * S.nx + i] = h->h_stage[(size_t)b * CORBO_HIP_MAX_NX + i];
     return CORBO_HIP_OK;
 }
 

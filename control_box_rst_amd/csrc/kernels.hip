@@ -2268,6 +2268,60 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const double* __res
     }
 }
 
+#pragma clang fp contract(off)
+// SimulatedPlant::control without dead time: x+ = integrator.solveIVP(x, u_0, dt) (explicit Euler, explicit_integrators.h:66-72:
+// f * dt + x; Runge-Kutta 4, :280-295), then the state disturbance.  Operation for operation the host formulas: bit-identical.
+template <int DYN>
+__global__ __launch_bounds__(256) void plant_step_kernel(const PlantParams p)
+{
+    using D = Dynamics<DYN>;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= p.batch) return;
+    double x1[D::NX], u[D::NU], xe[D::NX];
+    double* xp = p.xplant + (size_t)b * CORBO_HIP_MAX_NX;
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) x1[i] = xp[i];
+#pragma unroll
+    for (int i = 0; i < D::NU; ++i) u[i] = p.x[(size_t)b * p.nvs + D::NX + i];
+    if (p.integrator == CORBO_HIP_INTEGRATOR_RK4) {
+        double ck[4][D::NC];
+        rk4_end_state<DYN, false>(x1, u, p.dt, p.dyn, ck, xe);
+    }
+    else {
+        dyn_full<DYN>(x1, u, p.dyn, xe);
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) { xe[i] *= p.dt; xe[i] += x1[i]; }
+    }
+    if (p.disturbance) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) xe[i] = xe[i] + p.disturbance[(size_t)b * CORBO_HIP_MAX_NX + i];
+    }
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) xp[i] = xe[i];
+}
+#pragma clang fp contract(fast)
+
+template <int DYN>
+static void launch_plant_step_t(const PlantParams& p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(plant_step_kernel<DYN>, dim3((p.batch + 255) / 256), dim3(256), 0, stream, p);
+}
+
+bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hipStream_t stream)
+{
+    switch (d.dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: launch_plant_step_t<CORBO_HIP_DYN_VAN_DER_POL>(p, stream); return true;
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
+            if (d.nx == 3) { launch_plant_step_t<DYN_SERIAL_INTEGRATOR3>(p, stream); return true; }
+            if (d.nx != 2) return false;
+            launch_plant_step_t<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(p, stream);
+            return true;
+        case CORBO_HIP_DYN_UNICYCLE: launch_plant_step_t<CORBO_HIP_DYN_UNICYCLE>(p, stream); return true;
+        case CORBO_HIP_DYN_QUADROTOR: launch_plant_step_t<CORBO_HIP_DYN_QUADROTOR>(p, stream); return true;
+        default: return false;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_first_control_kernel(const double* __restrict__ x, double* __restrict__ out, int nvs, int nx, int nu,
                                                                    int batch)
 {

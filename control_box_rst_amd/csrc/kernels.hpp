@@ -103,6 +103,16 @@ struct WarmStartParams {
     const double* xref;   // [batch][CORBO_HIP_MAX_NX]
 };
 void launch_warm_start(const WarmStartParams& p, hipStream_t stream);
+// the plant side of a closed loop (SimulatedPlant::control, plants/src/simulated_plant.cpp:97-160, no dead time): one thread per instance
+struct PlantParams {
+    int32_t batch, nvs, nx, nu, integrator;   // integrator: corbo_hip_integrator
+    double dt;
+    double dyn[8];
+    const double* x;            // [batch][nvs] resident trajectories: u_0 = x[b][nx .. nx+nu)
+    double* xplant;             // [batch][CORBO_HIP_MAX_NX] plant states, updated in place
+    const double* disturbance;  // [batch][CORBO_HIP_MAX_NX] added to the new state (may be pinned host memory), or null
+};
+bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hipStream_t stream);
 // out[b][0..nu) = x[b][nx .. nx+nu)  (u_0 of every instance, packed; `out` may be device-visible pinned host memory)
 void launch_gather_first_control(const double* x, double* out, int nvs, int nx, int nu, int batch, hipStream_t stream);
 // dst_a[b][:] = row_a, dst_b[b][:] = row_b for b < batch (the descriptor's bound pattern repeated for every instance)

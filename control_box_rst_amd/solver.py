@@ -121,6 +121,28 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_get_first_control(self._h, u0.ctypes.data_as(C.POINTER(C.c_double))), "corbo_hip_get_first_control")
         return u0
 
+    # ---- the plant side of a closed loop, on the device (SimulatedPlant with the descriptor's dynamics, full-state output)
+    def plant_set_state(self, x):
+        """SimulatedPlant::setInitialState: x [batch][nx]."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.desc.nx)
+        self._check(self.lib.corbo_hip_plant_set_state(self._h, x.ctypes.data_as(C.POINTER(C.c_double))), "corbo_hip_plant_set_state")
+
+    def plant_step(self, dt=None, integrator=capi.INTEGRATOR_RK4, disturbance=None):
+        """SimulatedPlant::control: hold u_0 of every resident trajectory over dt, integrate, add the state disturbance [batch][nx]."""
+        dt = float(self.desc.dt_ref if dt is None else dt)
+        d = None if disturbance is None else np.ascontiguousarray(disturbance, dtype=np.float64).reshape(self.batch, self.desc.nx)
+        self._check(self.lib.corbo_hip_plant_step(self._h, int(integrator), dt, None if d is None else d.ctypes.data_as(C.POINTER(C.c_double))),
+                    "corbo_hip_plant_step")
+
+    def plant_get_state(self) -> np.ndarray:
+        x = np.empty((self.batch, self.desc.nx))
+        self._check(self.lib.corbo_hip_plant_get_state(self._h, x.ctypes.data_as(C.POINTER(C.c_double))), "corbo_hip_plant_get_state")
+        return x
+
+    def warm_start_from_plant(self, shift: bool = True):
+        """warm_start with the device-resident plant states as the measured states."""
+        self._check(self.lib.corbo_hip_warm_start_from_plant(self._h, 1 if shift else 0), "corbo_hip_warm_start_from_plant")
+
     def restore_instance_data(self):
         """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")

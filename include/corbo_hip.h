@@ -214,6 +214,27 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
  * batch * nu doubles, packed by a small kernel into pinned host memory, instead of the whole trajectories.  Synchronises. */
 int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out);
 
+/* ---- The plant side of a closed loop, on the device -----------------------------------------------------------
+ * One plant per instance whose model is the descriptor's dynamics: the reference's SimulatedPlant(dynamics) with a full-state output
+ * (plants/src/simulated_plant.cpp).  With these four entries a batch of predictive controllers runs
+ *     corbo_hip_plant_step -> corbo_hip_warm_start_from_plant -> corbo_hip_solve
+ * (= per step of task_closed_loop_control.cpp:153-235: plant.output, controller.step, plant.control) without any state or control
+ * crossing PCIe. */
+typedef enum corbo_hip_integrator {
+    CORBO_HIP_INTEGRATOR_EULER = 0, /* IntegratorExplicitEuler (SimulatedPlant's default), explicit_integrators.h:66-72 */
+    CORBO_HIP_INTEGRATOR_RK4   = 1  /* IntegratorExplicitRungeKutta4, explicit_integrators.h:280-295 */
+} corbo_hip_integrator;
+/* SimulatedPlant::setInitialState + reset: x [batch][nx] (host). */
+int corbo_hip_plant_set_state(corbo_hip_handle h, const double* x);
+/* SimulatedPlant::control(u_sequence, ., dt, t) without dead time (simulated_plant.cpp:97-160): the first control of each instance's
+ * resident trajectory is held over dt, x_plant <- integrator.solveIVP(x_plant, u_0, dt), then the state disturbance: `disturbance`
+ * [batch][nx] (host, may be NULL) is ADDED to the new state (what a DisturbanceInterface object does to it, :141).  Asynchronous. */
+int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const double* disturbance);
+/* SimulatedPlant::output with FullStateSystemOutput: x_out [batch][nx] (host).  Synchronises. */
+int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out);
+/* corbo_hip_warm_start with x0_new = the device-resident plant states (the measured state a controller is handed). */
+int corbo_hip_warm_start_from_plant(corbo_hip_handle h, int shift);
+
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
  * (:83-86).  One run-to-completion launch on the handle's stream; the call returns once every instance has finished its outer

@@ -639,6 +639,38 @@ int oracle_warm_start(oracle_problem* p, const double* x0, int shift)
     return 0;
 }
 
+int oracle_plant_step(const oracle_problem* p, int integrator, double dt, const double* disturbance, double* x_plant)
+{
+    if (!p || !x_plant || p->gen) return CORBO_HIP_ERR_INVALID;
+    const corbo_hip_problem_desc* d = &p->d;
+    const int nx = d->nx;
+    const double* u = p->x + nx; /* first control of the sequence (simulated_plant.cpp:111) */
+    double x2[CORBO_HIP_MAX_NX];
+    if (integrator == CORBO_HIP_INTEGRATOR_RK4) { /* explicit_integrators.h:280-295 */
+        double k1[CORBO_HIP_MAX_NX], k2[CORBO_HIP_MAX_NX], k3[CORBO_HIP_MAX_NX], k4[CORBO_HIP_MAX_NX], t[CORBO_HIP_MAX_NX];
+        dynamics(d, x_plant, u, k1);
+        for (int i = 0; i < nx; ++i) k1[i] *= dt;
+        for (int i = 0; i < nx; ++i) t[i] = x_plant[i] + k1[i] / 2.0;
+        dynamics(d, t, u, k2);
+        for (int i = 0; i < nx; ++i) k2[i] *= dt;
+        for (int i = 0; i < nx; ++i) t[i] = x_plant[i] + k2[i] / 2.0;
+        dynamics(d, t, u, k3);
+        for (int i = 0; i < nx; ++i) k3[i] *= dt;
+        for (int i = 0; i < nx; ++i) t[i] = x_plant[i] + k3[i];
+        dynamics(d, t, u, k4);
+        for (int i = 0; i < nx; ++i) k4[i] *= dt;
+        for (int i = 0; i < nx; ++i) x2[i] = x_plant[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+    }
+    else if (integrator == CORBO_HIP_INTEGRATOR_EULER) { /* explicit_integrators.h:66-72 */
+        dynamics(d, x_plant, u, x2);
+        for (int i = 0; i < nx; ++i) x2[i] *= dt;
+        for (int i = 0; i < nx; ++i) x2[i] += x_plant[i];
+    }
+    else return CORBO_HIP_ERR_INVALID;
+    for (int i = 0; i < nx; ++i) x_plant[i] = disturbance ? x2[i] + disturbance[i] : x2[i]; /* state disturbance, :141 */
+    return 0;
+}
+
 int oracle_get_x(const oracle_problem* p, double* x_out)
 {
     if (!p || !x_out) return CORBO_HIP_ERR_INVALID;

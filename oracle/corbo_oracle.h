@@ -45,6 +45,9 @@ int oracle_init_trajectory(const corbo_hip_problem_desc* desc, const double* x0,
 int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const double* ub, const double* xref);
 int oracle_warm_start(oracle_problem* p, const double* x0, int shift);
 int oracle_get_x(const oracle_problem* p, double* x_out);
+/* SimulatedPlant::control without dead time (plants/src/simulated_plant.cpp:97-160): x_plant <- integrator.solveIVP(x_plant, u_0 of
+ * the stored trajectory, dt), then x_plant += disturbance (may be NULL).  integrator: corbo_hip_integrator.  x_plant: nx doubles, in/out. */
+int oracle_plant_step(const oracle_problem* p, int integrator, double dt, const double* disturbance, double* x_plant);
 
 /* Callback problem (SimpleOptimizationProblemWithCallbacks): n parameters, f fills the lsq / equality / inequality value vectors at x
  * (any of them may have dimension 0).  lb / ub NULL = unbounded.  Runs through the same oracle_solve() as the OCPs; used to pin the LM

@@ -116,6 +116,20 @@ def main():
             json.dump(d, f, separators=(",", ":"))
         print(name, [round(st["chi2"], 6) for st in d["steps"]])
 
+    # closed loops with the reference's own SimulatedPlant: plant.output -> compute(new_run) -> plant.control, the
+    # plant integrating the OCP's dynamics with explicit Euler (its default) or RK4, plus a deterministic state disturbance
+    for name, kv in [
+        ("loop_unicycle_rk4", dict(scenario="unicycle", N=30, steps=5, iters=5, shift=1, integrator="rk4")),
+        ("loop_unicycle_euler_noshift", dict(scenario="unicycle", N=20, steps=4, iters=5, shift=0, integrator="euler")),
+        ("loop_vdp_euler", dict(scenario="vdp", steps=5, iters=5, shift=1, integrator="euler")),
+        ("loop_int3_rk4", dict(scenario="int3", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
+        ("loop_quad_rk4", dict(scenario="quad", N=10, steps=3, iters=4, shift=1, integrator="rk4", disturbance=0.002)),
+    ]:
+        d = run("loop", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, [round(st["chi2"], 6) for st in d["steps"]])
+
 
 if __name__ == "__main__":
     main()

@@ -44,6 +44,7 @@ def load():
     lib.oracle_set_data.argtypes = [C.c_void_p, dp, dp, dp, dp]
     lib.oracle_get_x.argtypes = [C.c_void_p, dp]
     lib.oracle_warm_start.argtypes = [C.c_void_p, dp, C.c_int]
+    lib.oracle_plant_step.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp]
     lib.oracle_eval.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.oracle_solve.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.c_int, dp, C.POINTER(TraceEntry)]
     lib.oracle_solve_batch.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, C.POINTER(LmOpts), dp, ip]
@@ -112,6 +113,13 @@ class OracleProblem:
     def warm_start(self, x0, shift=True):
         x0 = np.ascontiguousarray(x0, np.float64)
         assert self.lib.oracle_warm_start(self.h, _dp(x0), 1 if shift else 0) == 0
+
+    def plant_step(self, x_plant, integrator, dt, disturbance=None):
+        """SimulatedPlant::control on the stored trajectory's first control; returns the new plant state."""
+        x = np.array(x_plant, np.float64)
+        dist = None if disturbance is None else np.ascontiguousarray(disturbance, np.float64)
+        assert self.lib.oracle_plant_step(self.h, int(integrator), float(dt), _dp(dist), _dp(x)) == 0
+        return x
 
     def solve(self, opts: LmOpts, new_run=True):
         chi2 = C.c_double(0)

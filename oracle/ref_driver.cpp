@@ -15,6 +15,8 @@
 //        -> solves B seeded instances sequentially on one core, prints JSON with solver wall time
 //           (OptimalControlProblemStatistics::solving_time, i.e. only levenberg_marquardt_sparse.cpp:44-220).
 //
+//   ref_driver loop  scenario=<name> [steps=..] [iters=..] [shift=0|1] [integrator=euler|rk4] [disturbance=amp]
+//        -> closed loop with the reference's SimulatedPlant (see loop() below).
 //   ref_driver kat
 //        -> the known-answer cases of the reference's own LM solver test re-run on non-OCP problems (see kat() below).
 //
@@ -35,6 +37,9 @@
 #include <corbo-optimal-control/structured_ocp/structured_optimal_control_problem.h>
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_edge_based.h>
 #include <corbo-optimization/simple_optimization_problem.h>
+#include <corbo-plants/disturbance_interface.h>
+#include <corbo-plants/simulated_plant.h>
+#include <corbo-systems/output_function_interface.h>
 #include <corbo-optimization/solver/levenberg_marquardt_sparse.h>
 #include <corbo-systems/benchmark/linear_benchmark_systems.h>
 #include <corbo-systems/benchmark/nonlinear_benchmark_systems.h>
@@ -149,6 +154,7 @@ struct Built
     std::shared_ptr<OptimalControlProblemStatistics> stats;
     std::shared_ptr<StaticReference> xref;
     std::shared_ptr<ZeroReference> uref;
+    SystemDynamicsInterface::Ptr dyn;
 };
 
 static FiniteDifferencesCollocationInterface::Ptr makeCollocation(const std::string& n)
@@ -246,6 +252,7 @@ static Built build(const Scenario& s, int iterations)
         b.any_grid = b.grid;
     }
 
+    b.dyn = dyn;
     b.ocp = std::make_shared<StructuredOptimalControlProblem>(b.any_grid, dyn, b.hg, b.solver);
     b.ocp->setStatisticsObject(b.stats);
 
@@ -641,6 +648,86 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// loop: closed loop of the OCP with the reference's own plant, the step either side of the solve:
+//   y = SimulatedPlant::output (full state)  ->  StructuredOptimalControlProblem::compute(y, ..., new_run = true)
+//   ->  SimulatedPlant::control(u_sequence, x_sequence, dt, t)   (plants/src/simulated_plant.cpp:97-160: the first control of the
+//       sequence is held over dt and integrated with the plant's integrator; then the state disturbance is applied)
+// i.e. what task_closed_loop_control.cpp:153-235 does per step with a PredictiveController.  plant = the OCP's own dynamics,
+// integrator=euler|rk4 (SimulatedPlant's default is explicit Euler), a deterministic state disturbance (an object of this file
+// behind the reference's DisturbanceInterface).  Dumps per step the measured state, chi2, the vertex values after the solve and
+// the plant state after control().
+class DeterministicStateDisturbance : public DisturbanceInterface
+{
+ public:
+    explicit DeterministicStateDisturbance(double dt = 0.1, double amplitude = 0.0) : _dt(dt), _amp(amplitude) {}
+    Ptr getInstance() const override { return std::make_shared<DeterministicStateDisturbance>(); }
+    void disturb(const Time& t, const Eigen::Ref<const Eigen::VectorXd>& values, Eigen::Ref<Eigen::VectorXd> disturbed_values) override
+    {
+        const int step = (int)std::lround(t.toSec() / _dt);
+        last.resize(values.size());
+        for (int i = 0; i < values.size(); ++i)
+        {
+            last[i]             = _amp * std::sin(1.0 + step + 0.5 * i);
+            disturbed_values[i] = values[i] + last[i];
+        }
+    }
+    Eigen::VectorXd last;   // what the last call added (recorded in the fixture: a checker need not share this host's libm)
+    void reset() override {}
+
+ private:
+    double _dt, _amp;
+};
+
+static int loop(const Scenario& s, std::map<std::string, std::string>& kv)
+{
+    const int steps         = kv.count("steps") ? atoi(kv["steps"].c_str()) : 5;
+    const bool shift        = kv.count("shift") ? atoi(kv["shift"].c_str()) != 0 : true;
+    const std::string integ = kv.count("integrator") ? kv["integrator"] : "rk4";
+    const double amp        = kv.count("disturbance") ? atof(kv["disturbance"].c_str()) : 0.01;
+    Built b = build(s, s.iters);
+    if (shift && b.grid) b.grid->setWarmStart(true);
+    if (shift && b.ms_grid) b.ms_grid->setWarmStart(true);
+    SimulatedPlant plant(b.dyn, std::make_shared<FullStateSystemOutput>());
+    if (integ == "rk4") plant.setIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());   // else: the default explicit Euler
+    auto disturbance = std::make_shared<DeterministicStateDisturbance>(s.dt, amp);
+    plant.setStateDisturbance(disturbance);
+    plant.setInitialState(s.x0);
+    plant.reset();
+    printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters\": %d, \"shift\": %d, \"integrator\": \"%s\", \"disturbance\": %.17g,\n",
+           s.name.c_str(), s.nx, s.nu, s.N, s.dt, s.iters, shift ? 1 : 0, integ.c_str(), amp);
+    printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
+    printVec("xf", s.xf);
+    printf("\"steps\": [\n");
+    for (int st = 0; st < steps; ++st)
+    {
+        const Time t(st * s.dt);
+        Eigen::VectorXd y(s.nx);
+        plant.output(y, t);
+        bool ok           = b.ocp->compute(y, *b.xref, *b.uref, nullptr, t, true);
+        Eigen::VectorXd v = vertexValues(b, s);
+        auto xs = std::make_shared<TimeSeries>();
+        auto us = std::make_shared<TimeSeries>();
+        b.ocp->getTimeSeries(xs, us);
+        ok = plant.control(us, xs, Duration(s.dt), t) && ok;
+        Eigen::VectorXd after(s.nx);
+        plant.output(after, t);
+        printf("{\"ok\": %d, \"chi2\": %.17g, ", ok ? 1 : 0, b.ocp->getCurrentObjectiveValue());
+        printVec("x0", y);
+        printVec("vertex", v);
+        {   // the interval the plant really integrates over: its time-stamped control buffer hands out (t + dt) - t, rounded
+            // (systems/src/time_value_buffer.cpp:68-73), e.g. 0.10000000000000003 at t = 0.2
+            const double ts = t.toSec();
+            printf("\"plant_dt\": %.17g, ", (ts + Duration(s.dt).toSec()) - ts);
+        }
+        printVec("disturbance", disturbance->last);
+        printVec("plant_after", after, false);
+        printf("}%s\n", st + 1 < steps ? "," : "");
+    }
+    printf("]\n}\n");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // kat: the known-answer cases of the reference's own solver test (optimization/test/test_levenberg_marquardt_sparse.cpp:71-371;
 // written against an older class name, `StandardOptimizationProblemWithCallbacks` = today's SimpleOptimizationProblemWithCallbacks)
 // re-run against the compiled reference.  The problem definitions below are this file's own restatement of what those tests set
@@ -773,7 +860,7 @@ int main(int argc, char** argv)
 {
     if (argc < 2)
     {
-        fprintf(stderr, "usage: ref_driver dump|bench|mpc|kat key=value ...\n");
+        fprintf(stderr, "usage: ref_driver dump|bench|mpc|loop|kat key=value ...\n");
         return 1;
     }
     std::string mode(argv[1]);
@@ -787,6 +874,7 @@ int main(int argc, char** argv)
     if (mode == "dump") return dump(s);
     if (mode == "bench") return bench(s, kv);
     if (mode == "mpc") return mpc(s, kv);
+    if (mode == "loop") return loop(s, kv);
     fprintf(stderr, "unknown mode\n");
     return 1;
 }

@@ -1,0 +1,126 @@
+"""GPU tests (-m gpu) of the plant side of the closed loop on the device: corbo_hip_plant_* and
+corbo_hip_warm_start_from_plant through the C-ABI, against the oracle's restatement of SimulatedPlant::control and against closed
+loops of the genuine reference with its own SimulatedPlant (tests/golden/loop_*.json)."""
+import numpy as np
+import pytest
+
+from conftest import desc_for, load_golden
+from control_box_rst_amd import capi, problems
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
+
+pytestmark = pytest.mark.gpu
+
+LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4"]
+
+
+def integrator_of(g):
+    return capi.INTEGRATOR_RK4 if g["integrator"] == "rk4" else capi.INTEGRATOR_EULER
+
+
+@pytest.mark.parametrize("scenario,N", [("vdp", 20), ("int3", 20), ("unicycle", 30), ("quad", 10)])
+@pytest.mark.parametrize("integrator", [capi.INTEGRATOR_EULER, capi.INTEGRATOR_RK4])
+def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
+    """Per instance: x+ = integrator(x, u_0 of the resident trajectory, dt) + disturbance, same operations as the oracle -- bit for
+    bit for the polynomial dynamics, to the last ulps of the device's sin / cos otherwise."""
+    d = problems.SCENARIOS[scenario][0](N=N)
+    B = 6
+    rng = np.random.default_rng(7)
+    p = oracle_mod.OracleProblem(d)
+    nv, nx = p.dims.nv, d.nx
+    X = rng.normal(scale=0.4, size=(B, nv))
+    if d.grid == capi.GRID_FD_VARIABLE:
+        X[:, -1] = 0.1
+    xp = rng.normal(scale=0.5, size=(B, nx))
+    dist = 1e-3 * rng.normal(size=(B, nx))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.set_instance_data(X)
+    s.plant_set_state(xp)
+    assert np.array_equal(s.plant_get_state(), xp)
+    dt = 0.07
+    for rep, dd in enumerate((dist, None)):
+        s.plant_step(dt=dt, integrator=integrator, disturbance=dd)
+        got = s.plant_get_state()
+        for b in range(B):
+            p.set_data(X[b])
+            xp[b] = p.plant_step(xp[b], integrator, dt, None if dd is None else dd[b])
+        if scenario in ("vdp", "int3"):
+            assert np.array_equal(got, xp), (scenario, rep)
+        else:
+            assert np.abs(got - xp).max() <= 1e-14 * max(1.0, np.abs(xp).max()), (scenario, rep)
+            xp = got.copy()   # continue from the device's states: one step at a time is compared
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_closed_loop_vs_reference(name):
+    """plant.output -> grid update -> solve -> plant.control entirely on the device, every step against the genuine reference."""
+    g = load_golden(name)
+    d = desc_for(g)
+    B = 3
+    xf = np.tile(np.array(g["xf"]), (B, 1))
+    x0 = np.tile(np.array(g["steps"][0]["x0"]), (B, 1))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(g["iters"])
+    s.setPenaltyWeights(*g["weights"])
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    s.plant_set_state(x0)
+    nv = s.dims.nv
+    tol = 5e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
+    for k, st in enumerate(g["steps"]):
+        if k > 0:
+            s.warm_start_from_plant(shift=bool(g["shift"]))
+        s.solve(new_run=True)
+        X, chi2, status = s.get_solution()
+        ref = np.array(st["vertex"])[:nv]
+        for b in range(B):
+            assert np.abs(X[b] - ref).max() <= tol, (name, k, b, np.abs(X[b] - ref).max())
+            assert abs(chi2[b] - st["chi2"]) <= 2e-6 * abs(st["chi2"]), (name, k, b)
+        s.plant_step(dt=st["plant_dt"], integrator=integrator_of(g), disturbance=np.tile(np.array(st["disturbance"]), (B, 1)))
+        xp = s.plant_get_state()
+        assert np.abs(xp - np.array(st["plant_after"])).max() <= tol, (name, k)
+        assert np.array_equal(xp[0], xp[1]) and np.array_equal(xp[0], xp[2])   # identical instances stay identical
+
+
+def test_device_plant_loop_equals_host_driven_loop():
+    """warm_start_from_plant(device states) and warm_start(the same states read back to the host) give bit-identical loops."""
+    d = problems.unicycle_desc(N=30)
+    B = 16
+    x0, xf = problems.unicycle_instances(B)
+    a = BatchedLevenbergMarquardt(d, B)
+    b = BatchedLevenbergMarquardt(d, B)
+    rng = np.random.default_rng(3)
+    for s in (a, b):
+        s.setIterations(5)
+        s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.solve(new_run=True)
+    a.plant_set_state(x0)
+    for k in range(4):
+        dist = 1e-2 * rng.normal(size=(B, d.nx))
+        a.plant_step(integrator=capi.INTEGRATOR_RK4, disturbance=dist)
+        x = a.plant_get_state()
+        a.warm_start_from_plant(shift=True)
+        b.warm_start(x, shift=True)
+        a.solve(new_run=True)
+        b.solve(new_run=True)
+        Xa, ca, _ = a.get_solution()
+        Xb, cb, _ = b.get_solution()
+        assert np.array_equal(Xa, Xb) and np.array_equal(ca, cb), k
+        # keep b's u_0 = a's: b has no plant of its own
+    assert np.linalg.norm(x[:, :2] - xf[:, :2], axis=1).mean() < np.linalg.norm(x0[:, :2] - xf[:, :2], axis=1).mean()
+
+
+def test_plant_calls_need_a_plant_state():
+    d = problems.vdp_desc()
+    s = BatchedLevenbergMarquardt(d, 2)
+    x0 = np.array([[1.0, 0.0], [0.5, 0.1]])
+    s.set_instance_data(s.init_trajectory(x0, np.zeros((2, 2))))
+    for call in (lambda: s.plant_step(), lambda: s.plant_get_state(), lambda: s.warm_start_from_plant()):
+        with pytest.raises(CorboHipError, match="plant_set_state"):
+            call()
+    s.plant_set_state(x0)
+    with pytest.raises(CorboHipError, match="integrator"):
+        s.plant_step(integrator=7)
+    with pytest.raises(CorboHipError, match="dt"):
+        s.plant_step(dt=-1.0)
+    s.plant_step()
+    assert np.isfinite(s.plant_get_state()).all()

@@ -2,7 +2,9 @@
     corbo_hip_warm_start (shifting warm start + new measured state: batch x nx doubles up)  ->  corbo_hip_solve(new_run)
     ->  corbo_hip_get_first_control (batch x nu doubles down)  ->  plant step on the host (RK4 of the unicycle over dt + disturbance).
 The trajectories never leave HBM.
-    python tools/mpc_loop.py [batch] [steps] [iterations]"""
+With "device" as 4th argument the plants live on the device too (corbo_hip_plant_step -> corbo_hip_warm_start_from_plant -> solve):
+per step only the disturbance goes up (or nothing).
+    python tools/mpc_loop.py [batch] [steps] [iterations] [host|device]"""
 import os
 import sys
 import time
@@ -25,6 +27,7 @@ def plant(x, u, dt):
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+PLANT = sys.argv[4] if len(sys.argv) > 4 else "host"
 d = problems.unicycle_desc()
 x0, xf = problems.unicycle_instances(B)
 s = BatchedLevenbergMarquardt(d, B)
@@ -36,6 +39,28 @@ x = x0.copy()
 rng = np.random.default_rng(1)
 t_ws = t_solve = t_u = 0.0
 dist0 = np.linalg.norm(x[:, :2] - xf[:, :2], axis=1).mean()
+if PLANT == "device":
+    from control_box_rst_amd import capi  # noqa: E402
+    s.plant_set_state(x0)
+    t_p = t_ws = t_solve = 0.0
+    t_all = time.perf_counter()
+    for k in range(STEPS):
+        t0 = time.perf_counter()
+        s.plant_step(integrator=capi.INTEGRATOR_RK4, disturbance=1e-3 * rng.normal(size=x.shape))
+        t1 = time.perf_counter()
+        s.warm_start_from_plant(shift=True)
+        t2 = time.perf_counter()
+        s.solve(new_run=True)
+        t3 = time.perf_counter()
+        t_p += t1 - t0; t_ws += t2 - t1; t_solve += t3 - t2
+    wall = time.perf_counter() - t_all
+    x = s.plant_get_state()
+    dist1 = np.linalg.norm(x[:, :2] - xf[:, :2], axis=1).mean()
+    print(f"batch={B} N={d.N} iterations={ITERS}, plants on the device: {STEPS / wall:.1f} closed-loop steps/s of the whole batch = "
+          f"{B * STEPS / wall / 1e3:.1f} k plant-steps/s (per step: plant step incl. drawing the disturbance {t_p / STEPS * 1e3:.3f} ms, warm start "
+          f"{t_ws / STEPS * 1e3:.3f} ms, solve {t_solve / STEPS * 1e3:.3f} ms (last one on the device: {s.get_stats()['solve_ms']:.3f} ms)); "
+          f"mean distance to goal {dist0:.3f} -> {dist1:.3f}")
+    sys.exit(0)
 t_all = time.perf_counter()
 for k in range(STEPS):
     t0 = time.perf_counter()
