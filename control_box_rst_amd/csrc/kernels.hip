@@ -1201,8 +1201,6 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const int nblk  = (N + h - 1) >> lg;
         for (int t = tid >> 2; t < nblk; t += THREADS / 4) {   // (one round whenever 4 * ceil(N / h) <= THREADS)
         const int a      = h * t;
-        const int ac     = a;
-        const bool act   = true;
         const bool has_m = (a - hh >= 0), has_p = (a + hh < N);
         const int em = has_m ? a - hh : a, ep = has_p ? a + hh : a;       // clamped: absent neighbours are fetched from a and zeroed
         const bool elim = (t & 1);
@@ -1214,15 +1212,15 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         double D[NX][NX], g[NX], bb[NX], Xm[NX][NX], Xp[NX][NX], ym[NX], yp[NX], zm[NX], zp[NX];
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
-            g[q]  = SOA(gv, q, ac);
-            bb[q] = ARROW ? SOA(bv, q, ac) : 0.0;
+            g[q]  = SOA(gv, q, a);
+            bb[q] = ARROW ? SOA(bv, q, a) : 0.0;
             ym[q] = om[q * os + em];
             yp[q] = op[q * os + ep];
             zm[q] = ARROW ? SOA(bv, q, em) : 0.0;
             zp[q] = ARROW ? SOA(bv, q, ep) : 0.0;
 #pragma unroll
             for (int c = 0; c < NX; ++c) {
-                D[q][c]  = (c <= q) ? SOA(Dm, TRI(q, c), ac) : 0.0;
+                D[q][c]  = (c <= q) ? SOA(Dm, TRI(q, c), a) : 0.0;
                 Xm[q][c] = SOA(Wbm, q * NX + c, em);   // em's coupling to a (a is its b-side)
                 Xp[q][c] = SOA(Wam, q * NX + c, ep);   // ep's coupling to a (a is its a-side)
             }
@@ -1265,40 +1263,38 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
                 D[q][c] -= dd;
             }
         }
-        if (act) {
-            // lane 3: rhs (and border column) of block a; lanes 0..2: H(a, a-h) = -W_b(em)^T W_a(em), H(a, a+h) = -W_a(ep)^T W_b(ep)
-            double c1[NX], c2[NX];
+        // lane 3: rhs (and border column) of block a; lanes 0..2: H(a, a-h) = -W_b(em)^T W_a(em), H(a, a+h) = -W_a(ep)^T W_b(ep)
+        double c1[NX], c2[NX];
 #pragma unroll
-            for (int q = 0; q < NX; ++q) {
-                c1[q] = vec ? g[q] - (vm[q] + vp[q]) : -vm[q];
-                c2[q] = vec ? bb[q] - (wm[q] + wp[q]) : -vp[q];
-            }
-            if (elim || root) {
-                chol_inv<NX>(D);
-                fwd_solve_vec<NX>(D, c1);
-                if (ARROW || !vec) fwd_solve_vec<NX>(D, c2);
-                if (vec) {
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-                        y2 += c1[q] * c1[q];
-                        if constexpr (ARROW) { zz += c2[q] * c2[q]; zy += c2[q] * c1[q]; }
-                    }
-                    if (root && !ARROW) bwd_solve_vec<NX>(D, c1);  // no border: the root is back-substituted right away
-                }
-            }
+        for (int q = 0; q < NX; ++q) {
+            c1[q] = vec ? g[q] - (vm[q] + vp[q]) : -vm[q];
+            c2[q] = vec ? bb[q] - (wm[q] + wp[q]) : -vp[q];
+        }
+        if (elim || root) {
+            chol_inv<NX>(D);
+            fwd_solve_vec<NX>(D, c1);
+            if (ARROW || !vec) fwd_solve_vec<NX>(D, c2);
             if (vec) {
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
-                    SOA(gv, q, a) = c1[q];
-                    if constexpr (ARROW) SOA(bv, q, a) = c2[q];
-#pragma unroll
-                    for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
+                    y2 += c1[q] * c1[q];
+                    if constexpr (ARROW) { zz += c2[q] * c2[q]; zy += c2[q] * c1[q]; }
                 }
+                if (root && !ARROW) bwd_solve_vec<NX>(D, c1);  // no border: the root is back-substituted right away
             }
-            else if (col && elim && !root) {
+        }
+        if (vec) {
 #pragma unroll
-                for (int q = 0; q < NX; ++q) { SOA(Wam, q * NX + j, a) = c1[q]; SOA(Wbm, q * NX + j, a) = c2[q]; }
+            for (int q = 0; q < NX; ++q) {
+                SOA(gv, q, a) = c1[q];
+                if constexpr (ARROW) SOA(bv, q, a) = c2[q];
+#pragma unroll
+                for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
             }
+        }
+        else if (col && elim && !root) {
+#pragma unroll
+            for (int q = 0; q < NX; ++q) { SOA(Wam, q * NX + j, a) = c1[q]; SOA(Wbm, q * NX + j, a) = c2[q]; }
         }
         }
         hroot = h;
