@@ -83,6 +83,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
     "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
     "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_warm_start_from_plant",
+    "corbo_hip_closed_loop",
 )
 
 
@@ -124,6 +125,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_plant_step.argtypes = [H, C.c_int, C.c_double, dp]
     lib.corbo_hip_plant_get_state.argtypes = [H, dp]
     lib.corbo_hip_warm_start_from_plant.argtypes = [H, C.c_int]
+    lib.corbo_hip_closed_loop.argtypes = [H, C.POINTER(LmOpts), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp]
     lib.corbo_hip_set_profiling.argtypes = [H, C.c_int]
     lib.corbo_hip_solve.argtypes = [H, C.POINTER(LmOpts), C.c_int]
     lib.corbo_hip_synchronize.argtypes = [H]

@@ -112,6 +112,9 @@ struct corbo_hip_solver {
     double* d_xplant = nullptr;      // [batch][MAX_NX] plant states of the closed loop (corbo_hip_plant_*)
     double* h_dist   = nullptr;      // pinned, device-visible [batch][MAX_NX]: state disturbance of corbo_hip_plant_step
     bool have_plant  = false;
+    // grow-only scratch of corbo_hip_closed_loop: pinned staging (disturbances up, logs down) and the device-side logs
+    double* h_loop = nullptr; size_t h_loop_doubles = 0;
+    double* d_loop = nullptr; size_t d_loop_doubles = 0;
     LmState* h_state = nullptr;      // pinned [batch] read-back of the per-instance LM state (get_solution / get_stats)
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
@@ -342,7 +345,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows, h->d_xplant};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows, h->d_xplant, h->d_loop};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -350,6 +353,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_dist) (void)hipHostFree(h->h_dist);
+    if (h->h_loop) (void)hipHostFree(h->h_loop);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->ev_chk) if (e) (void)hipEventDestroy(e);
@@ -702,6 +706,91 @@ int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out)
         for (int i = 0; i < S.nx; ++i) x_out[(size_t)b * S.nx + i] = h->h_stage[(size_t)b * CORBO_HIP_MAX_NX + i];
     return CORBO_HIP_OK;
 }
+
+int corbo_hip_closed_loop(corbo_hip_handle h, const corbo_hip_lm_opts* o, int steps, int ocp_iterations, int integrator, double dt, int shift,
+                          const double* disturbance, double* states_out, double* controls_out)
+try {
+    if (!h || !o || steps < 0 || ocp_iterations < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (integrator != CORBO_HIP_INTEGRATOR_EULER && integrator != CORBO_HIP_INTEGRATOR_RK4) return fail(CORBO_HIP_ERR_INVALID, "unknown integrator");
+    if (!(dt > 0)) return fail(CORBO_HIP_ERR_INVALID, "dt must be positive");
+    if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
+    if (steps == 0) return CORBO_HIP_OK;
+    ON_DEVICE_OF(h);
+    const Structure& S = h->S;
+    const size_t B = (size_t)h->batch, NXm = CORBO_HIP_MAX_NX;
+    const size_t dist_doubles = disturbance ? (size_t)steps * B * NXm : 0;
+    const size_t logx = states_out ? (size_t)steps * B * S.nx : 0, logu = controls_out ? (size_t)steps * B * S.nu : 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t need_h = dist_doubles > logx + logu ? dist_doubles : logx + logu;
+    if (need_h > h->h_loop_doubles) {
+        if (h->h_loop) (void)hipHostFree(h->h_loop);
+        h->h_loop = nullptr; h->h_loop_doubles = 0;
+        HIP_TRY(hipHostMalloc((void**)&h->h_loop, need_h * sizeof(double)));
+        h->h_loop_doubles = need_h;
+    }
+    if (logx + logu > h->d_loop_doubles) {
+        if (h->d_loop) (void)hipFree(h->d_loop);
+        h->d_loop = nullptr; h->d_loop_doubles = 0;
+        HIP_TRY(hipMalloc((void**)&h->d_loop, (logx + logu) * sizeof(double)));
+        h->d_loop_doubles = logx + logu;
+    }
+    if (disturbance)
+        for (size_t r = 0; r < (size_t)steps * B; ++r)
+            for (size_t i = 0; i < NXm; ++i) h->h_loop[r * NXm + i] = (i < (size_t)S.nx) ? disturbance[r * S.nx + i] : 0.0;
+    double* d_logx = logx ? h->d_loop : nullptr;
+    double* d_logu = logu ? h->d_loop + logx : nullptr;
+
+    const bool split = h->split_passes || h->force_split;
+    const bool rtc   = !split && h->loop_mode && o->iterations > 0;   // run-to-completion solve kernel: the whole loop is asynchronous
+    int limit = MAX_PASSES;
+    if (const char* lim = std::getenv("CORBO_HIP_PASS_LIMIT"))
+        if (std::atoi(lim) > 0 && std::atoi(lim) < MAX_PASSES) limit = std::atoi(lim);
+    h->h_counter[0] = 0;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int s = 0; s < steps; ++s) {
+        PlantParams pp{};
+        pp.batch = h->batch; pp.nvs = S.nvs; pp.nx = S.nx; pp.nu = S.nu; pp.integrator = integrator; pp.dt = dt;
+        std::memcpy(pp.dyn, S.desc.dyn_params, sizeof(pp.dyn));
+        pp.x = h->d_x; pp.xplant = h->d_xplant;
+        pp.disturbance = disturbance ? h->h_loop + (size_t)s * B * NXm : nullptr;   // read by the kernel from pinned host memory
+        pp.log_x = d_logx ? d_logx + (size_t)s * B * S.nx : nullptr;
+        pp.log_u = d_logu ? d_logu + (size_t)s * B * S.nu : nullptr;
+        if (!launch_plant_step(S.desc, pp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no plant kernel for this dynamics");
+        HIP_TRY(hipGetLastError());
+        if (int rc = warm_start_from(h, h->d_xplant, shift)) return rc;
+        for (int it = 0; it < ocp_iterations; ++it) {
+            const int new_run = (it == 0) ? 1 : 0;
+            if (!rtc) {
+                if (int rc = corbo_hip_solve(h, o, new_run)) return rc;
+                continue;
+            }
+            // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287) -- host-side state only
+            if (new_run) { h->w_eq = o->weight_eq; h->w_ineq = o->weight_ineq; h->w_b = o->weight_bounds; }
+            else {
+                h->w_eq *= o->adapt_factor_eq;       if (h->w_eq > o->adapt_max_eq) h->w_eq = o->adapt_max_eq;
+                h->w_ineq *= o->adapt_factor_ineq;   if (h->w_ineq > o->adapt_max_ineq) h->w_ineq = o->adapt_max_ineq;
+                h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
+            }
+            FactorParams fp = h->factor_params();
+            SweepParams sp  = h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr);
+            fp.loop_passes     = limit;
+            fp.unfinished_flag = h->h_counter;   // any step's unfinished instance raises it
+            if (!launch_pass(S.desc, fp, sp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    if (logx + logu) HIP_TRY(hipMemcpyAsync(h->h_loop, h->d_loop, (logx + logu) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));   // the whole loop
+    if (logx) std::memcpy(states_out, h->h_loop, logx * sizeof(double));
+    if (logu) std::memcpy(controls_out, h->h_loop + logx, logu * sizeof(double));
+    if (rtc && h->h_counter[0] != 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
 
 int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
 {

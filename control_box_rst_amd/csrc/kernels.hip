@@ -2294,6 +2294,14 @@ __global__ __launch_bounds__(256) void plant_step_kernel(const PlantParams p)
     }
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) xp[i] = xe[i];
+    if (p.log_x) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) p.log_x[(size_t)b * D::NX + i] = xe[i];
+    }
+    if (p.log_u) {
+#pragma unroll
+        for (int i = 0; i < D::NU; ++i) p.log_u[(size_t)b * D::NU + i] = u[i];
+    }
 }
 #pragma clang fp contract(fast)
 

@@ -111,6 +111,8 @@ struct PlantParams {
     const double* x;            // [batch][nvs] resident trajectories: u_0 = x[b][nx .. nx+nu)
     double* xplant;             // [batch][CORBO_HIP_MAX_NX] plant states, updated in place
     const double* disturbance;  // [batch][CORBO_HIP_MAX_NX] added to the new state (may be pinned host memory), or null
+    double* log_x;              // [batch][nx] packed: the new plant states (closed-loop log of this step), or null
+    double* log_u;              // [batch][nu] packed: the controls that were applied, or null
 };
 bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hipStream_t stream);
 // out[b][0..nu) = x[b][nx .. nx+nu)  (u_0 of every instance, packed; `out` may be device-visible pinned host memory)

@@ -143,6 +143,19 @@ class BatchedLevenbergMarquardt:
         """warm_start with the device-resident plant states as the measured states."""
         self._check(self.lib.corbo_hip_warm_start_from_plant(self._h, 1 if shift else 0), "corbo_hip_warm_start_from_plant")
 
+    def closed_loop(self, steps, dt=None, integrator=capi.INTEGRATOR_RK4, shift=True, disturbance=None, ocp_iterations=1, log=True):
+        """`steps` x [plant_step -> warm_start_from_plant -> solve(new_run) (+ ocp_iterations - 1 solves without new_run)] in one
+        call (one synchronisation).  disturbance: [steps][batch][nx] or None.  Returns (states [steps][batch][nx], controls
+        [steps][batch][nu]) when `log`, else None."""
+        dt = float(self.desc.dt_ref if dt is None else dt)
+        d = None if disturbance is None else np.ascontiguousarray(disturbance, dtype=np.float64).reshape(steps, self.batch, self.desc.nx)
+        xs = np.empty((steps, self.batch, self.desc.nx)) if log else None
+        us = np.empty((steps, self.batch, self.desc.nu)) if log else None
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        self._check(self.lib.corbo_hip_closed_loop(self._h, C.byref(self.opts), int(steps), int(ocp_iterations), int(integrator), dt,
+                                                   1 if shift else 0, ptr(d), ptr(xs), ptr(us)), "corbo_hip_closed_loop")
+        return (xs, us) if log else None
+
     def restore_instance_data(self):
         """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")

@@ -235,6 +235,18 @@ int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out);
 /* corbo_hip_warm_start with x0_new = the device-resident plant states (the measured state a controller is handed). */
 int corbo_hip_warm_start_from_plant(corbo_hip_handle h, int shift);
 
+/* A batch of predictive controllers with simulated plants: `steps` control steps without returning to the host in between, i.e.
+ * steps x [plant.control; controller.step] of task_closed_loop_control.cpp:153-235 with PredictiveController::step
+ * (controllers/src/predictive_controller.cpp:46-80: `ocp_iterations` solves per step, new_run only for the first) per instance:
+ *     for s in 0 .. steps-1:   corbo_hip_plant_step(integrator, dt, disturbance[s]);   corbo_hip_warm_start_from_plant(shift);
+ *                              corbo_hip_solve(new_run = 1);   (ocp_iterations - 1) x corbo_hip_solve(new_run = 0)
+ * For the families with a run-to-completion solve kernel everything is enqueued on the handle's stream and synchronised once at
+ * the end (3 launches per step); the others run the same sequence step by step.  Needs resident, solved trajectories and a plant
+ * state.  disturbance [steps][batch][nx] (host) or NULL.  states_out [steps][batch][nx], controls_out [steps][batch][nu] (host, may
+ * be NULL): the plant state after each step and the control that was applied during it. */
+int corbo_hip_closed_loop(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int steps, int ocp_iterations, int integrator, double dt, int shift,
+                          const double* disturbance, double* states_out, double* controls_out);
+
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
  * (:83-86).  One run-to-completion launch on the handle's stream; the call returns once every instance has finished its outer

@@ -124,3 +124,49 @@ def test_plant_calls_need_a_plant_state():
         s.plant_step(dt=-1.0)
     s.plant_step()
     assert np.isfinite(s.plant_get_state()).all()
+
+
+@pytest.mark.parametrize("scenario,N,B,ocp_iterations", [("unicycle", 30, 16, 1), ("unicycle", 20, 5, 2), ("vdp", 20, 4, 1), ("dint", 20, 3, 1), ("quad", 10, 3, 1)])
+def test_closed_loop_call_equals_stepwise_sequence(scenario, N, B, ocp_iterations):
+    """corbo_hip_closed_loop (everything enqueued, one synchronisation; the quadrotor family runs it step by step inside) is
+    bit-identical to the same sequence driven through the single-step entry points; its logs are the states / applied controls."""
+    desc_fn, weights = problems.SCENARIOS[scenario]
+    d = desc_fn(N=N)
+    rng = np.random.default_rng(11)
+    nx, nu = d.nx, d.nu
+    x0 = rng.normal(scale=0.3, size=(B, nx))
+    xf = np.zeros((B, nx))
+    if scenario == "unicycle":
+        x0, xf = problems.unicycle_instances(B)
+    elif scenario == "dint":
+        xf = np.tile(np.array([1.0, 0.0]), (B, 1))
+    elif scenario == "quad":
+        xf[:, :3] = [2.0, 1.0, 1.0]
+    steps = 4
+    dist = 1e-3 * rng.normal(size=(steps, B, nx))
+    dt = d.dt_ref
+    a = BatchedLevenbergMarquardt(d, B)
+    b = BatchedLevenbergMarquardt(d, B)
+    for s in (a, b):
+        s.setIterations(4)
+        s.setPenaltyWeights(*weights)
+        if ocp_iterations > 1:
+            s.setWeightAdapation(2.0, 2.0, 2.0, 500.0, 500.0, 500.0)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.solve(new_run=True)
+        s.plant_set_state(x0)
+    xs, us = a.closed_loop(steps, dt=dt, integrator=capi.INTEGRATOR_RK4, shift=True, disturbance=dist, ocp_iterations=ocp_iterations)
+    for k in range(steps):
+        u_applied = b.get_first_control()
+        b.plant_step(dt=dt, integrator=capi.INTEGRATOR_RK4, disturbance=dist[k])
+        assert np.array_equal(us[k], u_applied), k
+        assert np.array_equal(xs[k], b.plant_get_state()), k
+        b.warm_start_from_plant(shift=True)
+        for it in range(ocp_iterations):
+            b.solve(new_run=(it == 0))
+    Xa, ca, sa = a.get_solution()
+    Xb, cb, sb = b.get_solution()
+    assert np.array_equal(Xa, Xb) and np.array_equal(ca, cb) and np.array_equal(sa, sb)
+    assert np.array_equal(a.plant_get_state(), b.plant_get_state())
+    assert a.closed_loop(2, dt=dt, log=False) is None          # without logs and without disturbance
+    assert np.isfinite(a.plant_get_state()).all()

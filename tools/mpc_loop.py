@@ -4,7 +4,8 @@
 The trajectories never leave HBM.
 With "device" as 4th argument the plants live on the device too (corbo_hip_plant_step -> corbo_hip_warm_start_from_plant -> solve):
 per step only the disturbance goes up (or nothing).
-    python tools/mpc_loop.py [batch] [steps] [iterations] [host|device]"""
+"call": the same loop as one corbo_hip_closed_loop call (everything enqueued, one synchronisation at the end).
+    python tools/mpc_loop.py [batch] [steps] [iterations] [host|device|call]"""
 import os
 import sys
 import time
@@ -39,6 +40,19 @@ x = x0.copy()
 rng = np.random.default_rng(1)
 t_ws = t_solve = t_u = 0.0
 dist0 = np.linalg.norm(x[:, :2] - xf[:, :2], axis=1).mean()
+if PLANT == "call":
+    from control_box_rst_amd import capi  # noqa: E402
+    s.plant_set_state(x0)
+    noise = 1e-3 * rng.normal(size=(STEPS,) + x.shape)
+    s.closed_loop(2, integrator=capi.INTEGRATOR_RK4, disturbance=noise[:2], log=False)   # warm-up (scratch buffers)
+    t_all = time.perf_counter()
+    xs, us = s.closed_loop(STEPS, integrator=capi.INTEGRATOR_RK4, disturbance=noise)
+    wall = time.perf_counter() - t_all
+    dist1 = np.linalg.norm(xs[-1][:, :2] - xf[:, :2], axis=1).mean()
+    print(f"batch={B} N={d.N} iterations={ITERS}, one corbo_hip_closed_loop call of {STEPS} steps: {STEPS / wall:.1f} closed-loop steps/s of the whole "
+          f"batch = {B * STEPS / wall / 1e3:.1f} k plant-steps/s ({wall / STEPS * 1e3:.3f} ms per step, on the device {s.get_stats()['solve_ms'] / STEPS:.3f} ms); "
+          f"mean distance to goal {dist0:.3f} -> {dist1:.3f}")
+    sys.exit(0)
 if PLANT == "device":
     from control_box_rst_amd import capi  # noqa: E402
     s.plant_set_state(x0)
