@@ -78,7 +78,7 @@ __device__ __forceinline__ void lm_state_out(LmState* sg, const LmState* sl, int
 // dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: a factor phase follows in the same workgroup and takes the Jacobian
 // straight from jst when this phase refreshed it (flag word [0]).
 template <int DYN, int DEFECT, bool FUSED>
-__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid)
+__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -112,9 +112,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
 
     SWEEP_STAMP(0);
-    // ---- stage vertex values in LDS (coalesced 16-byte loads)
-    for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
-        reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
+    // ---- stage vertex values in LDS (coalesced 16-byte loads), unless the factor phase of the same launch left its trial iterate
+    //      there (run-to-completion kernel)
+    if (!xs_ready)
+        for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+            reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
     double xr[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
@@ -838,7 +840,7 @@ struct FactorLds {
 // NPC > 0: the padded block count N | 1 as a compile-time constant (LDS element strides become immediate offsets of the DS
 // instructions instead of two VALU operations per access); 0: taken from the launch parameters.
 template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0>
-__device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds)
+__device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
@@ -1399,7 +1401,9 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     STAMP(6);
     // ---- controls, trial iterate, step norms
     double dn2 = 0;
-    double* xt = p.xt + (size_t)inst * p.nvs;
+    // the trial iterate goes to HBM for the sweep kernel / phase of the NEXT launch, or -- run-to-completion kernel -- straight into
+    // the LDS array the sweep phase of this launch evaluates it from
+    double* xt = xt_lds ? xt_lds : p.xt + (size_t)inst * p.nvs;
     double* dl = p.delta_out ? p.delta_out + (size_t)inst * p.nvs : nullptr;
     if (has_block) {
 #pragma unroll
@@ -2161,12 +2165,12 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
                 if (tid_v == 0) flags[0] = 0;
                 __syncthreads();
             }
-            sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v);
+            sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);
             __threadfence_block();
             __syncthreads();
             if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
             if (sl->done) break;
-            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0);
+            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, xs);
             __threadfence_block();
             __syncthreads();
             mode = 3;
