@@ -235,3 +235,48 @@ def test_nan_instance_is_contained(oracle_mod):
     s2.solve()
     X2, chi22, st2 = s2.get_solution()
     assert np.array_equal(X[good], X2) and np.array_equal(chi2[good], chi22) and np.array_equal(status[good], st2)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_closed_loop_call_vs_stepwise_and_oracle_plant(oracle_mod, seed):
+    """Closed loops on random descriptors: the one-call harness is bit-identical to the step-by-step entry points, and every plant
+    step agrees with the oracle's SimulatedPlant restatement on the controls that were applied."""
+    rng = np.random.default_rng(7000 + seed)
+    fam, d = random_desc(rng)
+    B = 3
+    w = tuple(float(v) for v in rng.uniform(1.0, 50.0, 3))
+    x0 = rng.uniform(-1, 1, (B, d.nx))
+    xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2])[: d.nx] if fam not in ("dint", "int3t") else np.array([1.0, 0.0, 0.0])[: d.nx])
+    integrator = int(rng.integers(0, 2))
+    steps, ocp_iterations = 3, int(rng.integers(1, 3))
+    dt = float(d.dt_ref * rng.uniform(0.5, 1.0))
+    dist = 1e-3 * rng.normal(size=(steps, B, d.nx))
+    shift = bool(rng.integers(0, 2))
+    a = BatchedLevenbergMarquardt(d, B)
+    b = BatchedLevenbergMarquardt(d, B)
+    for s in (a, b):
+        s.setIterations(3)
+        s.setPenaltyWeights(*w)
+        s.setWeightAdapation(1.5, 2.0, 1.2, 80.0, 90.0, 70.0)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.solve(new_run=True)
+        s.plant_set_state(x0)
+    xs, us = a.closed_loop(steps, dt=dt, integrator=integrator, shift=shift, disturbance=dist, ocp_iterations=ocp_iterations)
+    p = oracle_mod.OracleProblem(d)
+    xp = x0.copy()
+    for k in range(steps):
+        Xb, _, _ = b.get_solution()
+        b.plant_step(dt=dt, integrator=integrator, disturbance=dist[k])
+        assert np.array_equal(xs[k], b.plant_get_state()), (seed, fam, k)
+        assert np.array_equal(us[k], Xb[:, d.nx : d.nx + d.nu]), (seed, fam, k)
+        for i in range(B):   # oracle plant on the device's trajectory and previous plant state
+            p.set_data(Xb[i], xref=xf[i])
+            ref = p.plant_step(xp[i], integrator, dt, dist[k][i])
+            assert np.abs(xs[k][i] - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max()), (seed, fam, k, i)
+        xp = xs[k].copy()
+        b.warm_start_from_plant(shift=shift)
+        for it in range(ocp_iterations):
+            b.solve(new_run=(it == 0))
+    Xa, ca, sa = a.get_solution()
+    Xb, cb, sb = b.get_solution()
+    assert np.array_equal(Xa, Xb) and np.array_equal(ca, cb) and np.array_equal(sa, sb), (seed, fam)
