@@ -668,6 +668,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
 
 #pragma clang fp contract(fast)
 
+#ifndef CORBO_HIP_DYN_TU
 // ---------------------------------------------------------------------------------------------------------------------
 // moving-horizon grid update (FullDiscretizationGridBase::update, new_run branch, full_discretization_grid_base.cpp:91-108)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -744,6 +745,7 @@ __global__ __launch_bounds__(256) void warm_start_kernel(const WarmStartParams p
     for (int e = tid; e < p.nvs; e += 256) X[e] = nw[e];
 }
 #pragma clang fp contract(fast)
+#endif  // !CORBO_HIP_DYN_TU
 
 // ---------------------------------------------------------------------------------------------------------------------
 // assemble + factor + solve
@@ -2258,16 +2260,6 @@ bool launch_factor_t(const FactorParams& p, hipStream_t stream)
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void broadcast_rows_kernel(const double* __restrict__ row_a, const double* __restrict__ row_b,
-                                                             double* __restrict__ dst_a, double* __restrict__ dst_b, int nvs)
-{
-    const size_t base = (size_t)blockIdx.x * nvs;
-    for (int i = threadIdx.x; i < nvs; i += 256) {
-        dst_a[base + i] = row_a[i];
-        dst_b[base + i] = row_b[i];
-    }
-}
-
 #pragma clang fp contract(off)
 // SimulatedPlant::control without dead time: x+ = integrator.solveIVP(x, u_0, dt) (explicit Euler, explicit_integrators.h:66-72:
 // f * dt + x; Runge-Kutta 4, :280-295), then the state disturbance.  Operation for operation the host formulas: bit-identical.
@@ -2315,17 +2307,71 @@ static void launch_plant_step_t(const PlantParams& p, hipStream_t stream)
     hipLaunchKernelGGL(plant_step_kernel<DYN>, dim3((p.batch + 255) / 256), dim3(256), 0, stream, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Translation units.  This file is compiled once as the MAIN unit (CORBO_HIP_DYN_TU undefined): the kernels that do not depend on
+// the dynamics model (factor / big-block / warm start / helpers) and the dispatch; and once PER DYNAMICS MODEL with
+//   -DCORBO_HIP_DYN_TU=<template id> -DCORBO_HIP_DYN_TU_NAME=<suffix> [-DCORBO_HIP_DYN_TU_BIG]
+// : the sweep, fused-pass and plant kernels of that model behind three plain entry functions.  The models compile in parallel
+// (__graft_entry__.build()); a new model costs one more unit, not a longer critical path.
+// ---------------------------------------------------------------------------------------------------------------------
+#define CORBO_HIP_DYN_ENTRIES(NAME)                                                                              \
+    bool sweep_entry_##NAME(int defect, const SweepParams& p, hipStream_t stream);                               \
+    bool pass_entry_##NAME(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);       \
+    void plant_entry_##NAME(const PlantParams& p, hipStream_t stream);
+CORBO_HIP_DYN_ENTRIES(vdp)
+CORBO_HIP_DYN_ENTRIES(integ2)
+CORBO_HIP_DYN_ENTRIES(integ3)
+CORBO_HIP_DYN_ENTRIES(unicycle)
+CORBO_HIP_DYN_ENTRIES(quadrotor)
+
+#ifdef CORBO_HIP_DYN_TU
+#define CORBO_HIP_CAT2(a, b) a##b
+#define CORBO_HIP_CAT(a, b) CORBO_HIP_CAT2(a, b)
+bool CORBO_HIP_CAT(sweep_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const SweepParams& p, hipStream_t stream)
+{
+#ifdef CORBO_HIP_DYN_TU_BIG   // big-block family: multiple shooting with RK4 only
+    if (defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return false;
+    launch_sweep_t<CORBO_HIP_DYN_TU, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, stream);
+    return true;
+#else
+    return launch_sweep_d<CORBO_HIP_DYN_TU>(defect, p, stream);
+#endif
+}
+bool CORBO_HIP_CAT(pass_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+{
+#ifdef CORBO_HIP_DYN_TU_BIG   // no fused pass kernel for the big-block family
+    (void)defect; (void)fp; (void)sp; (void)stream;
+    return false;
+#else
+    return launch_pass_d<CORBO_HIP_DYN_TU>(defect, fp, sp, stream);
+#endif
+}
+void CORBO_HIP_CAT(plant_entry_, CORBO_HIP_DYN_TU_NAME)(const PlantParams& p, hipStream_t stream) { launch_plant_step_t<CORBO_HIP_DYN_TU>(p, stream); }
+#endif  // CORBO_HIP_DYN_TU
+
+#ifndef CORBO_HIP_DYN_TU
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const double* __restrict__ row_a, const double* __restrict__ row_b,
+                                                             double* __restrict__ dst_a, double* __restrict__ dst_b, int nvs)
+{
+    const size_t base = (size_t)blockIdx.x * nvs;
+    for (int i = threadIdx.x; i < nvs; i += 256) {
+        dst_a[base + i] = row_a[i];
+        dst_b[base + i] = row_b[i];
+    }
+}
+
 bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hipStream_t stream)
 {
     switch (d.dynamics) {
-        case CORBO_HIP_DYN_VAN_DER_POL: launch_plant_step_t<CORBO_HIP_DYN_VAN_DER_POL>(p, stream); return true;
+        case CORBO_HIP_DYN_VAN_DER_POL: plant_entry_vdp(p, stream); return true;
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
-            if (d.nx == 3) { launch_plant_step_t<DYN_SERIAL_INTEGRATOR3>(p, stream); return true; }
+            if (d.nx == 3) { plant_entry_integ3(p, stream); return true; }
             if (d.nx != 2) return false;
-            launch_plant_step_t<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(p, stream);
+            plant_entry_integ2(p, stream);
             return true;
-        case CORBO_HIP_DYN_UNICYCLE: launch_plant_step_t<CORBO_HIP_DYN_UNICYCLE>(p, stream); return true;
-        case CORBO_HIP_DYN_QUADROTOR: launch_plant_step_t<CORBO_HIP_DYN_QUADROTOR>(p, stream); return true;
+        case CORBO_HIP_DYN_UNICYCLE: plant_entry_unicycle(p, stream); return true;
+        case CORBO_HIP_DYN_QUADROTOR: plant_entry_quadrotor(p, stream); return true;
         default: return false;
     }
 }
@@ -2382,16 +2428,13 @@ size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream)
 {
     switch (d.dynamics) {
-        case CORBO_HIP_DYN_VAN_DER_POL: return launch_sweep_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, p, stream);
+        case CORBO_HIP_DYN_VAN_DER_POL: return sweep_entry_vdp(d.defect, p, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
-            if (d.nx == 3) return launch_sweep_d<DYN_SERIAL_INTEGRATOR3>(d.defect, p, stream);
+            if (d.nx == 3) return sweep_entry_integ3(d.defect, p, stream);
             if (d.nx != 2) return false;
-            return launch_sweep_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, p, stream);
-        case CORBO_HIP_DYN_UNICYCLE: return launch_sweep_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, p, stream);
-        case CORBO_HIP_DYN_QUADROTOR:
-            if (d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return false;
-            launch_sweep_t<CORBO_HIP_DYN_QUADROTOR, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, stream);
-            return true;
+            return sweep_entry_integ2(d.defect, p, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return sweep_entry_unicycle(d.defect, p, stream);
+        case CORBO_HIP_DYN_QUADROTOR: return sweep_entry_quadrotor(d.defect, p, stream);
         default: return false;
     }
 }
@@ -2399,12 +2442,12 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
     switch (d.dynamics) {
-        case CORBO_HIP_DYN_VAN_DER_POL: return launch_pass_d<CORBO_HIP_DYN_VAN_DER_POL>(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_VAN_DER_POL: return pass_entry_vdp(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
-            if (d.nx == 3) return launch_pass_d<DYN_SERIAL_INTEGRATOR3>(d.defect, fp, sp, stream);
+            if (d.nx == 3) return pass_entry_integ3(d.defect, fp, sp, stream);
             if (d.nx != 2) return false;
-            return launch_pass_d<CORBO_HIP_DYN_SERIAL_INTEGRATOR>(d.defect, fp, sp, stream);
-        case CORBO_HIP_DYN_UNICYCLE: return launch_pass_d<CORBO_HIP_DYN_UNICYCLE>(d.defect, fp, sp, stream);
+            return pass_entry_integ2(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return pass_entry_unicycle(d.defect, fp, sp, stream);
         default: return false;
     }
 }
@@ -2427,5 +2470,7 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
     if (d.nx == 3 && d.nu == 1) return launch_factor_t<3, 1>(p, stream);
     return false;
 }
+
+#endif  // !CORBO_HIP_DYN_TU
 
 }  // namespace corbo_hip
