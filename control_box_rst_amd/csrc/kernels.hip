@@ -2324,6 +2324,12 @@ CORBO_HIP_DYN_ENTRIES(integ2)
 CORBO_HIP_DYN_ENTRIES(integ3)
 CORBO_HIP_DYN_ENTRIES(unicycle)
 CORBO_HIP_DYN_ENTRIES(quadrotor)
+CORBO_HIP_DYN_ENTRIES(duffing)
+CORBO_HIP_DYN_ENTRIES(rocket)
+CORBO_HIP_DYN_ENTRIES(pendulum)
+CORBO_HIP_DYN_ENTRIES(mpendulum)
+CORBO_HIP_DYN_ENTRIES(toy)
+CORBO_HIP_DYN_ENTRIES(artstein)
 
 #ifdef CORBO_HIP_DYN_TU
 #define CORBO_HIP_CAT2(a, b) a##b
@@ -2372,6 +2378,12 @@ bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hi
             return true;
         case CORBO_HIP_DYN_UNICYCLE: plant_entry_unicycle(p, stream); return true;
         case CORBO_HIP_DYN_QUADROTOR: plant_entry_quadrotor(p, stream); return true;
+        case CORBO_HIP_DYN_DUFFING: plant_entry_duffing(p, stream); return true;
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: plant_entry_rocket(p, stream); return true;
+        case CORBO_HIP_DYN_SIMPLE_PENDULUM: plant_entry_pendulum(p, stream); return true;
+        case CORBO_HIP_DYN_MASSLESS_PENDULUM: plant_entry_mpendulum(p, stream); return true;
+        case CORBO_HIP_DYN_TOY_EXAMPLE: plant_entry_toy(p, stream); return true;
+        case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: plant_entry_artstein(p, stream); return true;
         default: return false;
     }
 }
@@ -2435,6 +2447,12 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
             return sweep_entry_integ2(d.defect, p, stream);
         case CORBO_HIP_DYN_UNICYCLE: return sweep_entry_unicycle(d.defect, p, stream);
         case CORBO_HIP_DYN_QUADROTOR: return sweep_entry_quadrotor(d.defect, p, stream);
+        case CORBO_HIP_DYN_DUFFING: return sweep_entry_duffing(d.defect, p, stream);
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: return sweep_entry_rocket(d.defect, p, stream);
+        case CORBO_HIP_DYN_SIMPLE_PENDULUM: return sweep_entry_pendulum(d.defect, p, stream);
+        case CORBO_HIP_DYN_MASSLESS_PENDULUM: return sweep_entry_mpendulum(d.defect, p, stream);
+        case CORBO_HIP_DYN_TOY_EXAMPLE: return sweep_entry_toy(d.defect, p, stream);
+        case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return sweep_entry_artstein(d.defect, p, stream);
         default: return false;
     }
 }
@@ -2448,6 +2466,12 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
             if (d.nx != 2) return false;
             return pass_entry_integ2(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_UNICYCLE: return pass_entry_unicycle(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_DUFFING: return pass_entry_duffing(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: return pass_entry_rocket(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_SIMPLE_PENDULUM: return pass_entry_pendulum(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_MASSLESS_PENDULUM: return pass_entry_mpendulum(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_TOY_EXAMPLE: return pass_entry_toy(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return pass_entry_artstein(d.defect, fp, sp, stream);
         default: return false;
     }
 }

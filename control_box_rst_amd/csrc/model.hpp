@@ -70,6 +70,83 @@ template <> struct Dynamics<DYN_SERIAL_INTEGRATOR3> {
     }
 };
 
+// ---- the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), each formula in the reference's
+//      operation order (C++ evaluates a - b - c + d and a * b * c left to right)
+template <> struct Dynamics<CORBO_HIP_DYN_DUFFING> {  // :108-115, prm = damping, spring_alpha, spring_beta
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b11000u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
+    {
+        f[0] = x[1];
+        f[1] = -prm[0] * x[1] - prm[1] * x[0] - prm[2] * x[0] * x[0] * x[0] + u[0];
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_FREE_SPACE_ROCKET> {  // :174-183
+    static constexpr int NX = 3, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b1110000u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double*, double* f)
+    {
+        f[0] = x[1];
+        f[1] = (u[0] - 0.02 * x[1] * x[1]) / x[2];
+        f[2] = -0.01 * u[0] * u[0];
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_SIMPLE_PENDULUM> {  // :207-215, prm = m, l, g, rho
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0b01u;                                   // sin(phi)
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0b00111u, RK4_GROUP1_COLS = 0b11100u;   // phi at the later stages depends on phi, phidot, u
+    __device__ static __forceinline__ void prepare(const double* x, const double*, double* c) { c[0] = sin(x[0]); }
+    __device__ static __forceinline__ void eval(const double* x, const double* c, const double* u, const double* prm, double* f)
+    {
+        const double m = prm[0], l = prm[1], g = prm[2], rho = prm[3];
+        f[0] = x[1];
+        f[1] = u[0] - rho / (m * l * l) * x[1] - g / l * c[0];
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_MASSLESS_PENDULUM> {  // :281-289, prm[0] = omega0
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0b01u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0b00111u, RK4_GROUP1_COLS = 0b11100u;
+    __device__ static __forceinline__ void prepare(const double* x, const double*, double* c) { c[0] = sin(x[0]); }
+    __device__ static __forceinline__ void eval(const double* x, const double* c, const double* u, const double* prm, double* f)
+    {
+        f[0] = x[1];
+        f[1] = u[0] - prm[0] * c[0];
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_TOY_EXAMPLE> {  // :426-436, prm[0] = mu
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b11000u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
+    {
+        const double mu = prm[0];
+        f[0] = x[1] + u[0] * (mu + (1.0 - mu) * x[0]);
+        f[1] = x[0] + u[0] * (mu - 4.0 * (1.0 - mu) * x[1]);
+    }
+};
+
+template <> struct Dynamics<CORBO_HIP_DYN_ARTSTEINS_CIRCLE> {  // :483-491
+    static constexpr int NX = 2, NU = 1, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u, RK4_GROUP1_COLS = 0b11000u;
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double*, double* f)
+    {
+        f[0] = (x[0] * x[0] - x[1] * x[1]) * u[0];
+        f[1] = 2 * x[0] * x[1] * u[0];
+    }
+};
+
 template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u1 cos(th), ydot = u1 sin(th), thdot = u2
     static constexpr int NX = 3, NU = 2, NC = 2;
     static constexpr unsigned CACHE_XMASK = 0b100u;

@@ -109,6 +109,26 @@ def int3_desc(N=30, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, time_optimal=Fals
 INT3_WEIGHTS = (10.0, 10.0, 10.0)
 
 
+# ---- the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), their default parameters; the cost / bound
+#      set-up of oracle/ref_driver.cpp's scenarios of the same names
+BENCHMARK_SYSTEMS = {   # name: (dynamics id, nx, default parameters)
+    "duffing": (capi.DYN_DUFFING, 2, (1.0, 1.0, 1.0)),              # damping, spring_alpha, spring_beta
+    "rocket": (capi.DYN_FREE_SPACE_ROCKET, 3, ()),
+    "pendulum": (capi.DYN_SIMPLE_PENDULUM, 2, (0.205, 0.34, 9.81, 0.0)),   # mass, length, gravitation, friction
+    "mpendulum": (capi.DYN_MASSLESS_PENDULUM, 2, (1.0,)),           # omega0
+    "toy": (capi.DYN_TOY_EXAMPLE, 2, (0.5,)),                       # mu
+    "artstein": (capi.DYN_ARTSTEINS_CIRCLE, 2, ()),
+}
+BENCHMARK_WEIGHTS = (5.0, 5.0, 5.0)
+
+
+def benchmark_desc(name, N=24, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+    dyn, nx, prm = BENCHMARK_SYSTEMS[name]
+    q = (1.0, 0.5, 0.2)[:nx]
+    return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=dyn, nx=nx, nu=1, N=N, dt=dt, q=q, r=(0.1,), qf=tuple(10.0 * v for v in q),
+                     u_lb=(-1.5,), u_ub=(1.5,), dyn_params=prm)
+
+
 # ---- cfg 5: quadrotor (nx=12, nu=4), MultipleShootingGrid + RK4, u bounds, one nonlinear stage inequality (keep-out ball) ----
 QUAD_Q = (1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05)
 QUAD_R = (0.01, 0.1, 0.1, 0.1)
@@ -143,3 +163,5 @@ SCENARIOS = {
     "int3": (int3_desc, INT3_WEIGHTS),
     "quad": (quad_desc, QUAD_WEIGHTS),
 }
+for _name in BENCHMARK_SYSTEMS:
+    SCENARIOS[_name] = ((lambda n: (lambda **kw: benchmark_desc(n, **kw)))(_name), BENCHMARK_WEIGHTS)

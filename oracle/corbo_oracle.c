@@ -116,6 +116,38 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
             f[11] = ((Ixx - Iyy) * x[9] * x[10] + u[3]) / Izz;
             break;
         }
+        /* the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h) */
+        case CORBO_HIP_DYN_DUFFING: { /* :108-115 */
+            double damping = d->dyn_params[0], alpha = d->dyn_params[1], beta = d->dyn_params[2];
+            f[0] = x[1];
+            f[1] = -damping * x[1] - alpha * x[0] - beta * x[0] * x[0] * x[0] + u[0];
+            break;
+        }
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: /* :174-183 */
+            f[0] = x[1];
+            f[1] = (u[0] - 0.02 * x[1] * x[1]) / x[2];
+            f[2] = -0.01 * u[0] * u[0];
+            break;
+        case CORBO_HIP_DYN_SIMPLE_PENDULUM: { /* :207-215 */
+            double m = d->dyn_params[0], l = d->dyn_params[1], g = d->dyn_params[2], rho = d->dyn_params[3];
+            f[0] = x[1];
+            f[1] = u[0] - rho / (m * l * l) * x[1] - g / l * sin(x[0]);
+            break;
+        }
+        case CORBO_HIP_DYN_MASSLESS_PENDULUM: /* :281-289 */
+            f[0] = x[1];
+            f[1] = u[0] - d->dyn_params[0] * sin(x[0]);
+            break;
+        case CORBO_HIP_DYN_TOY_EXAMPLE: { /* :426-436 */
+            double mu = d->dyn_params[0];
+            f[0] = x[1] + u[0] * (mu + (1.0 - mu) * x[0]);
+            f[1] = x[0] + u[0] * (mu - 4.0 * (1.0 - mu) * x[1]);
+            break;
+        }
+        case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: /* :483-491 */
+            f[0] = (x[0] * x[0] - x[1] * x[1]) * u[0];
+            f[1] = 2 * x[0] * x[1] * u[0];
+            break;
         default: break;
     }
 }
@@ -262,6 +294,12 @@ static int validate(const corbo_hip_problem_desc* d)
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_UNICYCLE: if (d->nx != 3 || d->nu != 2) return 0; break;
         case CORBO_HIP_DYN_QUADROTOR: if (d->nx != 12 || d->nu != 4) return 0; break;
+        case CORBO_HIP_DYN_DUFFING:
+        case CORBO_HIP_DYN_SIMPLE_PENDULUM:
+        case CORBO_HIP_DYN_MASSLESS_PENDULUM:
+        case CORBO_HIP_DYN_TOY_EXAMPLE:
+        case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: if (d->nx != 2 || d->nu != 1) return 0; break;
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: if (d->nx != 3 || d->nu != 1) return 0; break;
         default: return 0;
     }
     if (d->stage_cost < 0 || d->stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return 0;

@@ -73,6 +73,21 @@ def main():
         ("int3", dict(scenario="int3", iters=6), (1, 2, 3, 4, 5, 6)),
         ("int3_ms_rk4", dict(scenario="int3", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
         ("int3_time_optimal", dict(scenario="int3", vargrid=1, N=25, iters=8, w="100,100,100", solves=3), (1, 4, 8)),
+        # the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h): Crank-Nicolson on the fixed grid, one
+        # other scheme each, and multiple shooting with RK4 for the two with sin()
+        ("duffing", dict(scenario="duffing", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("rocket", dict(scenario="rocket", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("pendulum", dict(scenario="pendulum", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("mpendulum", dict(scenario="mpendulum", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("toy", dict(scenario="toy", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("artstein", dict(scenario="artstein", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("duffing_midpoint", dict(scenario="duffing", collocation="midpoint", N=12, iters=4), (1, 2, 3, 4)),
+        ("rocket_forward", dict(scenario="rocket", collocation="forward", N=12, iters=4), (1, 2, 3, 4)),
+        ("toy_backward", dict(scenario="toy", collocation="backward", N=12, iters=4), (1, 2, 3, 4)),
+        ("pendulum_ms_rk4", dict(scenario="pendulum", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
+        ("mpendulum_ms_rk4", dict(scenario="mpendulum", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
+        ("rocket_ms_rk4", dict(scenario="rocket", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
+        ("artstein_ms_rk4", dict(scenario="artstein", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
@@ -123,6 +138,8 @@ def main():
         ("loop_unicycle_euler_noshift", dict(scenario="unicycle", N=20, steps=4, iters=5, shift=0, integrator="euler")),
         ("loop_vdp_euler", dict(scenario="vdp", steps=5, iters=5, shift=1, integrator="euler")),
         ("loop_int3_rk4", dict(scenario="int3", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
+        ("loop_pendulum_rk4", dict(scenario="pendulum", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
+        ("loop_duffing_euler", dict(scenario="duffing", steps=4, iters=5, shift=1, integrator="euler", disturbance=0.002)),
         ("loop_quad_rk4", dict(scenario="quad", N=10, steps=3, iters=4, shift=1, integrator="rk4", disturbance=0.002)),
     ]:
         d = run("loop", **kv)

@@ -143,6 +143,9 @@ struct Scenario
     Eigen::VectorXd tball_s;    // empty = no terminal ball
 };
 
+// the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket
+static bool isZoo(const std::string& n) { return n == "duffing" || n == "rocket" || n == "pendulum" || n == "mpendulum" || n == "toy" || n == "artstein"; }
+
 struct Built
 {
     std::shared_ptr<FullDiscretizationGridBase> grid;  // FD grids
@@ -196,6 +199,16 @@ static Built build(const Scenario& s, int iterations)
     else if (s.name == "vdp")
     {
         dyn = std::make_shared<VanDerPolOscillator>();
+        if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
+    }
+    else if (isZoo(s.name))
+    {
+        if (s.name == "duffing") dyn = std::make_shared<DuffingOscillator>();
+        else if (s.name == "rocket") dyn = std::make_shared<FreeSpaceRocket>();
+        else if (s.name == "pendulum") dyn = std::make_shared<SimplePendulum>();
+        else if (s.name == "mpendulum") dyn = std::make_shared<MasslessPendulum>();
+        else if (s.name == "toy") dyn = std::make_shared<ToyExample>();
+        else dyn = std::make_shared<ArtsteinsCircle>();
         if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
     else if (s.name == "int3")
@@ -273,6 +286,18 @@ static Built build(const Scenario& s, int iterations)
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
+    }
+    else if (isZoo(s.name))   // Q = diag(1, 0.5[, 0.2]), R = 0.1, Qf = 10 Q, |u| <= 1.5
+    {
+        Eigen::VectorXd q(s.nx);
+        const double qv[3] = {1.0, 0.5, 0.2};
+        for (int i = 0; i < s.nx; ++i) q[i] = qv[i];
+        Eigen::MatrixXd Q = q.asDiagonal();
+        Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        Eigen::MatrixXd Qf = 10.0 * Q;
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1.5), Eigen::VectorXd::Constant(1, 1.5));
     }
     else if (s.name == "int3")
     {
@@ -403,6 +428,15 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         s.w_eq = s.w_ineq = s.w_b = 2;
         s.x0 = Eigen::Vector2d(1, 0);
         s.xf = Eigen::Vector2d(0, 0);
+    }
+    else if (isZoo(s.name))
+    {
+        s.nx = (s.name == "rocket") ? 3 : 2; s.nu = 1; s.N = 24; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 5;
+        if (s.name == "rocket") { s.x0 = Eigen::Vector3d(0, 0, 1); s.xf = Eigen::Vector3d(0.6, 0, 0.98); }   // position, speed, mass
+        else if (s.name == "pendulum" || s.name == "mpendulum") { s.x0 = Eigen::Vector2d(0.8, 0); s.xf = Eigen::Vector2d(0, 0); }
+        else if (s.name == "artstein") { s.x0 = Eigen::Vector2d(0.6, 0.4); s.xf = Eigen::Vector2d(0.1, 0); }
+        else { s.x0 = Eigen::Vector2d(0.8, -0.2); s.xf = Eigen::Vector2d(0, 0); }
     }
     else if (s.name == "dint")
     {

@@ -10,14 +10,15 @@ from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
 
 pytestmark = pytest.mark.gpu
 
-LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4"]
+LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler"]
 
 
 def integrator_of(g):
     return capi.INTEGRATOR_RK4 if g["integrator"] == "rk4" else capi.INTEGRATOR_EULER
 
 
-@pytest.mark.parametrize("scenario,N", [("vdp", 20), ("int3", 20), ("unicycle", 30), ("quad", 10)])
+@pytest.mark.parametrize("scenario,N", [("vdp", 20), ("int3", 20), ("unicycle", 30), ("quad", 10), ("duffing", 12), ("rocket", 12), ("pendulum", 12),
+                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12)])
 @pytest.mark.parametrize("integrator", [capi.INTEGRATOR_EULER, capi.INTEGRATOR_RK4])
 def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
     """Per instance: x+ = integrator(x, u_0 of the resident trajectory, dt) + disturbance, same operations as the oracle -- bit for
@@ -43,7 +44,7 @@ def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
         for b in range(B):
             p.set_data(X[b])
             xp[b] = p.plant_step(xp[b], integrator, dt, None if dd is None else dd[b])
-        if scenario in ("vdp", "int3"):
+        if scenario in ("vdp", "int3", "duffing", "rocket", "toy", "artstein"):
             assert np.array_equal(got, xp), (scenario, rep)
         else:
             assert np.abs(got - xp).max() <= 1e-14 * max(1.0, np.abs(xp).max()), (scenario, rep)

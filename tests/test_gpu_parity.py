@@ -31,10 +31,17 @@ def _built():
 
 
 GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12", "quad_n10",
-        "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal"]
+        "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal",
+        # the reference's other benchmark systems with nx <= 3
+        "duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein", "duffing_midpoint", "rocket_forward", "toy_backward", "pendulum_ms_rk4", "mpendulum_ms_rk4", "rocket_ms_rk4", "artstein_ms_rk4"]
 # reduced cfg 5 (quadrotor): nearly flat directions (yaw, torques) -- rounding-level differences move the iterate along them by
 # ~1e-4 while chi2 agrees to 1e-8 (the oracle shows the same spread against the genuine reference, tests/test_oracle_golden.py)
-X_TOL_BY = {"quad_n10": 5e-4}
+X_TOL_BY = {"quad_n10": 5e-4,
+            # SimplePendulum with the reference's default length: g / l = 29 multiplies sin(phi) in the dynamics, so the last-ulp difference
+            # between the device's sin and the host libm's (1e-16 / (2 delta) = 5e-8 in a finite-difference column) is amplified 29-fold
+            # per Runge-Kutta stage; the first, large step (chi2 3069 -> 266) then differs by 9e-6
+            "pendulum_ms_rk4": 5e-5}
+CHI2_RTOL_BY = {"pendulum_ms_rk4": 2e-5}   # same fixture, same reason (5e-6 after the first iteration)
 
 
 @pytest.mark.parametrize("name", GOLD)
@@ -68,9 +75,9 @@ def test_lm_iterates_vs_reference_golden(name):
         x, chi2, status = s.get_solution()
         ref = np.array(a["vertex"])[: s.dims.nv]
         assert np.abs(x[0] - ref).max() <= X_TOL_BY.get(name, X_TOL), (name, a["k"], np.abs(x[0] - ref).max())
-        if name in X_TOL_BY:
+        if name == "quad_n10":   # flat directions: chi2 carries the comparison
             assert abs(chi2[0] - a["chi2"]) <= 1e-7 * abs(a["chi2"]), (name, a["k"])
-        assert abs(chi2[0] - a["chi2"]) <= CHI2_RTOL * max(1.0, abs(a["chi2"])), (name, a["k"])
+        assert abs(chi2[0] - a["chi2"]) <= CHI2_RTOL_BY.get(name, CHI2_RTOL) * max(1.0, abs(a["chi2"])), (name, a["k"])
         assert status[0] in (capi.SOLVER_CONVERGED, capi.SOLVER_EARLY_TERMINATED)
         st = s.get_stats()
         assert st["lm_iterations"] == a["k"]
