@@ -21,11 +21,17 @@ def _fmt(v):
     return ",".join("inf" if x >= 2e30 else "-inf" if x <= -2e30 else repr(float(x)) for x in v)
 
 
-def random_case(rng):
-    sc = str(rng.choice(["unicycle", "vdp", "dint", "int3"]))
-    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1), "int3": (3, 1)}[sc]
-    kv = dict(scenario=sc, N=int(rng.integers(4, 36)), iters=3, w=_fmt(rng.uniform(1.0, 40.0, 3)),
-              x0=_fmt(rng.uniform(-1, 1, nx)))
+ZOO = ["duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein"]   # the reference's other benchmark systems with nx <= 3
+
+
+def random_case(rng, zoo=False):
+    sc = str(rng.choice(ZOO if zoo else ["unicycle", "vdp", "dint", "int3"]))
+    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1), "int3": (3, 1), "rocket": (3, 1)}.get(sc, (2, 1))
+    kv = dict(scenario=sc, N=int(rng.integers(4, 36)), iters=3, w=_fmt(rng.uniform(1.0, 40.0, 3)))
+    x0 = rng.uniform(-1, 1, nx)
+    if sc == "rocket":
+        x0[2] = rng.uniform(0.9, 1.1)   # the mass is a divisor
+    kv["x0"] = _fmt(x0)
     if sc == "dint":
         kv["xf"] = _fmt([float(rng.uniform(0.5, 1.5)), 0.0])
         kv["solves"] = int(rng.integers(1, 3))
@@ -33,7 +39,10 @@ def random_case(rng):
     if sc == "int3" and rng.random() < 0.3:   # time-optimal on the variable grid
         kv.update(vargrid=1, xf=_fmt([float(rng.uniform(0.5, 1.5)), 0.0, 0.0]), solves=int(rng.integers(1, 3)))
         return kv
-    kv["xf"] = _fmt(rng.uniform(-1, 1, nx) + np.array([1.5, 0.5, 0.2])[:nx])
+    xf = rng.uniform(-1, 1, nx) + np.array([1.5, 0.5, 0.2])[:nx]
+    if sc == "rocket":
+        xf[2] = rng.uniform(0.8, 1.0)
+    kv["xf"] = _fmt(xf)
     if rng.random() < 0.3:
         kv["grid"] = "ms"
     else:
@@ -47,6 +56,8 @@ def random_case(rng):
                 ub.append(2e30 if k in (0, 1) else hi * rng.uniform(0.3, 1.0))
             return lb, ub
         xl, xu = side(nx, -3.0, 3.0)
+        if sc == "rocket":
+            xl[2], xu[2] = 0.5, 2e30   # keeps the mass positive along the iterations
         ul, uu = side(nu, -1.0, 1.0)
         kv.update(xlb=_fmt(xl), xub=_fmt(xu), ulb=_fmt(ul), uub=_fmt(uu))
     mask = int(rng.integers(0, 2 ** nx)) if rng.random() < 0.3 else 0
@@ -66,10 +77,10 @@ def random_case(rng):
     return kv
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", list(range(120)) + list(range(5000, 5060)))
 def test_oracle_vs_live_reference(oracle_mod, seed):
     rng = np.random.default_rng(424200 + seed)
-    kv = random_case(rng)
+    kv = random_case(rng, zoo=(seed >= 5000))   # the last 60: the reference's other benchmark systems
     out = subprocess.check_output([DRIVER, "dump"] + [f"{k}={v}" for k, v in kv.items()], timeout=120)
     g = json.loads(out)
     d = desc_for(g)
