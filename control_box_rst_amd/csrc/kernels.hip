@@ -928,7 +928,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
         double2* dst       = reinterpret_cast<double2*>(smem);
         const int n2       = p.nnz_pad / 2;
-        constexpr int UNR  = 8;  // loads in flight per lane (branch-free: indices are clamped, the duplicates are harmless)
+        constexpr int UNR  = 4;  // loads in flight per lane (8 costs 3 % of a solve at the 128-VGPR budget) (branch-free: indices are clamped, the duplicates are harmless)
         for (int i0 = tid; i0 < n2; i0 += THREADS * UNR) {
             double2 v[UNR];
 #pragma unroll
