@@ -1356,7 +1356,8 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     // ---- back-substitution down the elimination tree.  Four lanes per block again: lane q forms row q of
     //      v = y - W_a x_a - W_b x_b, the three (two) numbers are broadcast inside the quad with DPP moves, every lane solves
     //      L^T x = v and lane q stores x_q.
-    //      The factor data of the NEXT level (untouched by the back-substitution so far) is fetched before the barrier.
+    //      (Fetching the factor data of the next level ahead of the barrier was tried: its 26 registers cost more than the LDS
+    //      latency it hides, at the 128-VGPR budget.)
     {
         const int q  = tid & 3;
         const int qc = (q < NX) ? q : NX - 1;   // spare lanes mirror the last row and store nothing
@@ -1396,8 +1397,8 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (; h >= 1; h >>= 1) {
             if (h * (2 * (tid >> 2) + 1) < N) finish(h, tid >> 2);
             for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }  // long horizons
-            if (h > 1) fetch(h >> 1, tid >> 2);
             __syncthreads();
+            if (h > 1) fetch(h >> 1, tid >> 2);
         }
     }
     STAMP(6);
