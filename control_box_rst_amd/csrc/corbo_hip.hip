@@ -428,19 +428,22 @@ static int launch_factor_checked(corbo_hip_handle h, const FactorParams& p)
     return 0;
 }
 
+// penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287)
+static void update_penalty_weights(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
+{
+    if (new_run) { h->w_eq = o->weight_eq; h->w_ineq = o->weight_ineq; h->w_b = o->weight_bounds; return; }
+    h->w_eq *= o->adapt_factor_eq;       if (h->w_eq > o->adapt_max_eq) h->w_eq = o->adapt_max_eq;
+    h->w_ineq *= o->adapt_factor_ineq;   if (h->w_ineq > o->adapt_max_ineq) h->w_ineq = o->adapt_max_ineq;
+    h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
+}
+
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
 try {
     if (!h || !o) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called before corbo_hip_solve");
     if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
     ON_DEVICE_OF(h);
-    // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287)
-    if (new_run) { h->w_eq = o->weight_eq; h->w_ineq = o->weight_ineq; h->w_b = o->weight_bounds; }
-    else {
-        h->w_eq *= o->adapt_factor_eq;       if (h->w_eq > o->adapt_max_eq) h->w_eq = o->adapt_max_eq;
-        h->w_ineq *= o->adapt_factor_ineq;   if (h->w_ineq > o->adapt_max_ineq) h->w_ineq = o->adapt_max_ineq;
-        h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
-    }
+    update_penalty_weights(h, o, new_run);
     h->stats = corbo_hip_stats{};
     EventList ev_list;
     std::vector<hipEvent_t>& evs = ev_list.v;
@@ -766,13 +769,7 @@ try {
                 if (int rc = corbo_hip_solve(h, o, new_run)) return rc;
                 continue;
             }
-            // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287) -- host-side state only
-            if (new_run) { h->w_eq = o->weight_eq; h->w_ineq = o->weight_ineq; h->w_b = o->weight_bounds; }
-            else {
-                h->w_eq *= o->adapt_factor_eq;       if (h->w_eq > o->adapt_max_eq) h->w_eq = o->adapt_max_eq;
-                h->w_ineq *= o->adapt_factor_ineq;   if (h->w_ineq > o->adapt_max_ineq) h->w_ineq = o->adapt_max_ineq;
-                h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
-            }
+            update_penalty_weights(h, o, new_run);   // host-side state only
             FactorParams fp = h->factor_params();
             SweepParams sp  = h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr);
             fp.loop_passes     = limit;
