@@ -1199,8 +1199,11 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const int j     = tid & 3;
         const int hh    = h >> 1;
         const bool root = (h >= N);                                      // only a == 0 is active then
-        static_assert(NX + 1 <= 4, "four lanes per block: NX columns + one right-hand-side lane");
-        const bool vec  = (j == NX);
+        static_assert(NX <= 4, "four lanes per block: NX columns (+ one right-hand-side lane when NX <= 3)");
+        // NX = 4 leaves no spare lane for the right-hand side: every lane carries it as a SECOND operand (redundantly, same
+        // instruction stream) and lane 0 stores it.
+        constexpr bool RHS2 = (NX == 4);
+        const bool vec  = !RHS2 && (j == NX);
         const bool col  = (j < NX);
         const int nblk  = (N + h - 1) >> lg;
         for (int t = tid >> 2; t < nblk; t += THREADS / 4) {   // (one round whenever 4 * ceil(N / h) <= THREADS)
@@ -1214,12 +1217,15 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const double* op = vec ? gv : Wbm + jc * NP;  // ep: far side is a + h  -> W_b(ep)
         const int os     = vec ? NP : NX * NP;
         double D[NX][NX], g[NX], bb[NX], Xm[NX][NX], Xp[NX][NX], ym[NX], yp[NX], zm[NX], zp[NX];
+        double ymr[NX], ypr[NX];   // RHS2: the neighbours' right-hand sides
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             g[q]  = SOA(gv, q, a);
             bb[q] = ARROW ? SOA(bv, q, a) : 0.0;
             ym[q] = om[q * os + em];
             yp[q] = op[q * os + ep];
+            ymr[q] = RHS2 ? SOA(gv, q, em) : 0.0;
+            ypr[q] = RHS2 ? SOA(gv, q, ep) : 0.0;
             zm[q] = ARROW ? SOA(bv, q, em) : 0.0;
             zp[q] = ARROW ? SOA(bv, q, ep) : 0.0;
 #pragma unroll
@@ -1234,7 +1240,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         if (!has_m) {
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
-                ym[q] = 0.0; zm[q] = 0.0;
+                ym[q] = 0.0; zm[q] = 0.0; ymr[q] = 0.0;
 #pragma unroll
                 for (int c = 0; c < NX; ++c) Xm[q][c] = 0.0;
             }
@@ -1242,23 +1248,24 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         if (!has_p) {
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
-                yp[q] = 0.0; zp[q] = 0.0;
+                yp[q] = 0.0; zp[q] = 0.0; ypr[q] = 0.0;
 #pragma unroll
                 for (int c = 0; c < NX; ++c) Xp[q][c] = 0.0;
             }
         }
         // Schur updates: D -= X^T X (both neighbours), v = X^T (operand)
-        double vm[NX], vp[NX], wm[NX], wp[NX];
+        double vm[NX], vp[NX], wm[NX], wp[NX], vr[NX];
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
-            double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+            double s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
 #pragma unroll
             for (int t = 0; t < NX; ++t) {
                 s1 += Xm[t][q] * ym[t];
                 s2 += Xp[t][q] * yp[t];
                 if constexpr (ARROW) { s3 += Xm[t][q] * zm[t]; s4 += Xp[t][q] * zp[t]; }
+                if constexpr (RHS2) s5 += Xm[t][q] * ymr[t] + Xp[t][q] * ypr[t];
             }
-            vm[q] = s1; vp[q] = s2; wm[q] = s3; wp[q] = s4;
+            vm[q] = s1; vp[q] = s2; wm[q] = s3; wp[q] = s4; vr[q] = s5;
 #pragma unroll
             for (int c = 0; c <= q; ++c) {
                 double dd = 0;
@@ -1268,16 +1275,30 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             }
         }
         // lane 3: rhs (and border column) of block a; lanes 0..2: H(a, a-h) = -W_b(em)^T W_a(em), H(a, a+h) = -W_a(ep)^T W_b(ep)
-        double c1[NX], c2[NX];
+        double c1[NX], c2[NX], r1[NX], r2[NX];
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             c1[q] = vec ? g[q] - (vm[q] + vp[q]) : -vm[q];
             c2[q] = vec ? bb[q] - (wm[q] + wp[q]) : -vp[q];
+            r1[q] = RHS2 ? g[q] - vr[q] : 0.0;
+            r2[q] = (RHS2 && ARROW) ? bb[q] - (wm[q] + wp[q]) : 0.0;
         }
         if (elim || root) {
             chol_inv<NX>(D);
             fwd_solve_vec<NX>(D, c1);
             if (ARROW || !vec) fwd_solve_vec<NX>(D, c2);
+            if constexpr (RHS2) {
+                fwd_solve_vec<NX>(D, r1);
+                if constexpr (ARROW) fwd_solve_vec<NX>(D, r2);
+                if (j == 0) {
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        y2 += r1[q] * r1[q];
+                        if constexpr (ARROW) { zz += r2[q] * r2[q]; zy += r2[q] * r1[q]; }
+                    }
+                }
+                if (root && !ARROW) bwd_solve_vec<NX>(D, r1);
+            }
             if (vec) {
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
@@ -1299,6 +1320,17 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         else if (col && elim && !root) {
 #pragma unroll
             for (int q = 0; q < NX; ++q) { SOA(Wam, q * NX + j, a) = c1[q]; SOA(Wbm, q * NX + j, a) = c2[q]; }
+        }
+        if constexpr (RHS2) {
+            if (j == 0) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    SOA(gv, q, a) = r1[q];
+                    if constexpr (ARROW) SOA(bv, q, a) = r2[q];
+#pragma unroll
+                    for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
+                }
+            }
         }
         }
         hroot = h;
@@ -1386,6 +1418,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             x[0] = quad_bcast<0>(v);
             if constexpr (NX > 1) x[1] = quad_bcast<1>(v);
             if constexpr (NX > 2) x[2] = quad_bcast<2>(v);
+            if constexpr (NX > 3) x[3] = quad_bcast<3>(v);
             bwd_solve_vec<NX>(L, x);
             double xq = x[0];
 #pragma unroll
@@ -2331,6 +2364,7 @@ CORBO_HIP_DYN_ENTRIES(pendulum)
 CORBO_HIP_DYN_ENTRIES(mpendulum)
 CORBO_HIP_DYN_ENTRIES(toy)
 CORBO_HIP_DYN_ENTRIES(artstein)
+CORBO_HIP_DYN_ENTRIES(cartpole)
 
 #ifdef CORBO_HIP_DYN_TU
 #define CORBO_HIP_CAT2(a, b) a##b
@@ -2385,6 +2419,7 @@ bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hi
         case CORBO_HIP_DYN_MASSLESS_PENDULUM: plant_entry_mpendulum(p, stream); return true;
         case CORBO_HIP_DYN_TOY_EXAMPLE: plant_entry_toy(p, stream); return true;
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: plant_entry_artstein(p, stream); return true;
+        case CORBO_HIP_DYN_CART_POLE: plant_entry_cartpole(p, stream); return true;
         default: return false;
     }
 }
@@ -2435,6 +2470,7 @@ size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
     if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N, arrow);
     if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
     if (d.nx == 3 && d.nu == 1) return factor_lds<3, 1>(p.N, arrow);
+    if (d.nx == 4 && d.nu == 1) return factor_lds<4, 1>(p.N, arrow);
     return 0;
 }
 
@@ -2454,6 +2490,7 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
         case CORBO_HIP_DYN_MASSLESS_PENDULUM: return sweep_entry_mpendulum(d.defect, p, stream);
         case CORBO_HIP_DYN_TOY_EXAMPLE: return sweep_entry_toy(d.defect, p, stream);
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return sweep_entry_artstein(d.defect, p, stream);
+        case CORBO_HIP_DYN_CART_POLE: return sweep_entry_cartpole(d.defect, p, stream);
         default: return false;
     }
 }
@@ -2473,6 +2510,7 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
         case CORBO_HIP_DYN_MASSLESS_PENDULUM: return pass_entry_mpendulum(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_TOY_EXAMPLE: return pass_entry_toy(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return pass_entry_artstein(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_CART_POLE: return pass_entry_cartpole(d.defect, fp, sp, stream);
         default: return false;
     }
 }
@@ -2493,6 +2531,7 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
     if (d.nx == 3 && d.nu == 2) return launch_factor_t<3, 2>(p, stream);
     if (d.nx == 3 && d.nu == 1) return launch_factor_t<3, 1>(p, stream);
+    if (d.nx == 4 && d.nu == 1) return launch_factor_t<4, 1>(p, stream);
     return false;
 }
 

@@ -147,6 +147,26 @@ template <> struct Dynamics<CORBO_HIP_DYN_ARTSTEINS_CIRCLE> {  // :483-491
     }
 };
 
+template <> struct Dynamics<CORBO_HIP_DYN_CART_POLE> {  // :337-355; state [x phi xdot phidot]; the reference's fixed parameters
+    static constexpr int NX = 4, NU = 1, NC = 2;
+    static constexpr unsigned CACHE_XMASK = 0b0010u;                 // sin(phi), cos(phi)
+    // phi at the later Runge-Kutta stages depends on phi, phidot and (through phidot') u; never on x or xdot
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0b000011010u;
+    static constexpr unsigned RK4_GROUP1_COLS    = 0b111111000u;    // phidot, u, x_{k+1}
+    __device__ static __forceinline__ void prepare(const double* x, const double*, double* c) { sincos(x[1], &c[0], &c[1]); }
+    __device__ static __forceinline__ void eval(const double* x, const double* c, const double* u, const double*, double* f)
+    {
+        const double mc = 1.0, mp = 0.3, l = 0.5, g = 9.81;
+        const double s = c[0], co = c[1];
+        const double sin_phi_phidot_sq = s * x[3] * x[3];
+        const double denum             = mc + mp * (1 - co * co);    // std::pow(cos, 2) = cos * cos exactly
+        f[0] = x[2];
+        f[1] = x[3];
+        f[2] = (l * mp * sin_phi_phidot_sq + u[0] + mp * g * co * s) / denum;
+        f[3] = -(l * mp * co * sin_phi_phidot_sq + u[0] * co + (mp + mc) * g * s) / (l * denum);
+    }
+};
+
 template <> struct Dynamics<CORBO_HIP_DYN_UNICYCLE> {  // user plug-in: xdot = u1 cos(th), ydot = u1 sin(th), thdot = u2
     static constexpr int NX = 3, NU = 2, NC = 2;
     static constexpr unsigned CACHE_XMASK = 0b100u;

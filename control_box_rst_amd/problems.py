@@ -118,13 +118,14 @@ BENCHMARK_SYSTEMS = {   # name: (dynamics id, nx, default parameters)
     "mpendulum": (capi.DYN_MASSLESS_PENDULUM, 2, (1.0,)),           # omega0
     "toy": (capi.DYN_TOY_EXAMPLE, 2, (0.5,)),                       # mu
     "artstein": (capi.DYN_ARTSTEINS_CIRCLE, 2, ()),
+    "cartpole": (capi.DYN_CART_POLE, 4, ()),                        # state [x phi xdot phidot], fixed parameters
 }
 BENCHMARK_WEIGHTS = (5.0, 5.0, 5.0)
 
 
 def benchmark_desc(name, N=24, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
     dyn, nx, prm = BENCHMARK_SYSTEMS[name]
-    q = (1.0, 0.5, 0.2)[:nx]
+    q = (1.0, 0.5, 0.2, 0.1)[:nx]
     return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=dyn, nx=nx, nu=1, N=N, dt=dt, q=q, r=(0.1,), qf=tuple(10.0 * v for v in q),
                      u_lb=(-1.5,), u_ub=(1.5,), dyn_params=prm)
 

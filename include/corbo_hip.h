@@ -71,13 +71,14 @@ typedef enum corbo_hip_dynamics {
     CORBO_HIP_DYN_SERIAL_INTEGRATOR = 1, /* linear_benchmark_systems.h:72-83,    params[0] = time constant  nx=p nu=1 */
     CORBO_HIP_DYN_UNICYCLE          = 2, /* user plug-in: xdot=u1 cos th, ydot=u1 sin th, thdot=u2          nx=3 nu=2 */
     CORBO_HIP_DYN_QUADROTOR         = 3, /* user plug-in: 12-state rigid body, see DESIGN.md                nx=12 nu=4 */
-    /* the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), parameters in the order of their setters */
+    /* the reference's other benchmark systems (nonlinear_benchmark_systems.h), parameters in the order of their setters */
     CORBO_HIP_DYN_DUFFING           = 4, /* DuffingOscillator :88-148,  params = damping, spring_alpha, spring_beta  nx=2 nu=1 */
     CORBO_HIP_DYN_FREE_SPACE_ROCKET = 5, /* FreeSpaceRocket :154-184    (no parameters)                              nx=3 nu=1 */
     CORBO_HIP_DYN_SIMPLE_PENDULUM   = 6, /* SimplePendulum :187-258,    params = mass, length, gravitation, friction  nx=2 nu=1 */
     CORBO_HIP_DYN_MASSLESS_PENDULUM = 7, /* MasslessPendulum :261-314,  params[0] = omega0                            nx=2 nu=1 */
     CORBO_HIP_DYN_TOY_EXAMPLE       = 8, /* ToyExample :406-460,        params[0] = mu                                nx=2 nu=1 */
-    CORBO_HIP_DYN_ARTSTEINS_CIRCLE  = 9  /* ArtsteinsCircle :463-509    (no parameters)                              nx=2 nu=1 */
+    CORBO_HIP_DYN_ARTSTEINS_CIRCLE  = 9, /* ArtsteinsCircle :463-509    (no parameters)                              nx=2 nu=1 */
+    CORBO_HIP_DYN_CART_POLE         = 10 /* CartPole :317-390           (fixed parameters), state [x phi xdot phidot] nx=4 nu=1 */
 } corbo_hip_dynamics;
 
 typedef enum corbo_hip_stage_cost {

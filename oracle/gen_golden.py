@@ -88,6 +88,12 @@ def main():
         ("mpendulum_ms_rk4", dict(scenario="mpendulum", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
         ("rocket_ms_rk4", dict(scenario="rocket", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
         ("artstein_ms_rk4", dict(scenario="artstein", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
+        # CartPole (nx = 4): fixed grid, another scheme, multiple shooting, bound patterns with a partially fixed goal
+        ("cartpole", dict(scenario="cartpole", iters=6), (1, 2, 3, 4, 5, 6)),
+        ("cartpole_midpoint", dict(scenario="cartpole", collocation="midpoint", N=12, iters=4), (1, 2, 3, 4)),
+        ("cartpole_ms_rk4", dict(scenario="cartpole", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
+        ("cartpole_patterns", dict(scenario="cartpole", N=14, iters=4, xlb="-0.3,-inf,-inf,-1.0", xub="0.4,inf,0.8,inf", ulb="-2.0", uub="inf",
+                                   xf_fixed=5), (1, 2, 3, 4)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
@@ -140,6 +146,7 @@ def main():
         ("loop_int3_rk4", dict(scenario="int3", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
         ("loop_pendulum_rk4", dict(scenario="pendulum", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
         ("loop_duffing_euler", dict(scenario="duffing", steps=4, iters=5, shift=1, integrator="euler", disturbance=0.002)),
+        ("loop_cartpole_rk4", dict(scenario="cartpole", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
         ("loop_quad_rk4", dict(scenario="quad", N=10, steps=3, iters=4, shift=1, integrator="rk4", disturbance=0.002)),
     ]:
         d = run("loop", **kv)

@@ -143,8 +143,8 @@ struct Scenario
     Eigen::VectorXd tball_s;    // empty = no terminal ball
 };
 
-// the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket
-static bool isZoo(const std::string& n) { return n == "duffing" || n == "rocket" || n == "pendulum" || n == "mpendulum" || n == "toy" || n == "artstein"; }
+// the reference's other benchmark systems (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket (3) and the cart-pole (4)
+static bool isZoo(const std::string& n) { return n == "duffing" || n == "rocket" || n == "pendulum" || n == "mpendulum" || n == "toy" || n == "artstein" || n == "cartpole"; }
 
 struct Built
 {
@@ -208,6 +208,7 @@ static Built build(const Scenario& s, int iterations)
         else if (s.name == "pendulum") dyn = std::make_shared<SimplePendulum>();
         else if (s.name == "mpendulum") dyn = std::make_shared<MasslessPendulum>();
         else if (s.name == "toy") dyn = std::make_shared<ToyExample>();
+        else if (s.name == "cartpole") dyn = std::make_shared<CartPole>();
         else dyn = std::make_shared<ArtsteinsCircle>();
         if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
@@ -290,7 +291,7 @@ static Built build(const Scenario& s, int iterations)
     else if (isZoo(s.name))   // Q = diag(1, 0.5[, 0.2]), R = 0.1, Qf = 10 Q, |u| <= 1.5
     {
         Eigen::VectorXd q(s.nx);
-        const double qv[3] = {1.0, 0.5, 0.2};
+        const double qv[4] = {1.0, 0.5, 0.2, 0.1};
         for (int i = 0; i < s.nx; ++i) q[i] = qv[i];
         Eigen::MatrixXd Q = q.asDiagonal();
         Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
@@ -431,9 +432,10 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     }
     else if (isZoo(s.name))
     {
-        s.nx = (s.name == "rocket") ? 3 : 2; s.nu = 1; s.N = 24; s.dt = 0.1;
+        s.nx = (s.name == "rocket") ? 3 : (s.name == "cartpole") ? 4 : 2; s.nu = 1; s.N = 24; s.dt = 0.1;
         s.w_eq = s.w_ineq = s.w_b = 5;
         if (s.name == "rocket") { s.x0 = Eigen::Vector3d(0, 0, 1); s.xf = Eigen::Vector3d(0.6, 0, 0.98); }   // position, speed, mass
+        else if (s.name == "cartpole") { s.x0 = Eigen::Vector4d(0, 0.4, 0, 0); s.xf = Eigen::Vector4d(0.5, 0, 0, 0); }   // [x phi xdot phidot]
         else if (s.name == "pendulum" || s.name == "mpendulum") { s.x0 = Eigen::Vector2d(0.8, 0); s.xf = Eigen::Vector2d(0, 0); }
         else if (s.name == "artstein") { s.x0 = Eigen::Vector2d(0.6, 0.4); s.xf = Eigen::Vector2d(0.1, 0); }
         else { s.x0 = Eigen::Vector2d(0.8, -0.2); s.xf = Eigen::Vector2d(0, 0); }

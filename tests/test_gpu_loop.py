@@ -10,7 +10,7 @@ from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
 
 pytestmark = pytest.mark.gpu
 
-LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler"]
+LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4"]
 
 
 def integrator_of(g):
@@ -18,7 +18,7 @@ def integrator_of(g):
 
 
 @pytest.mark.parametrize("scenario,N", [("vdp", 20), ("int3", 20), ("unicycle", 30), ("quad", 10), ("duffing", 12), ("rocket", 12), ("pendulum", 12),
-                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12)])
+                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12), ("cartpole", 12)])
 @pytest.mark.parametrize("integrator", [capi.INTEGRATOR_EULER, capi.INTEGRATOR_RK4])
 def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
     """Per instance: x+ = integrator(x, u_0 of the resident trajectory, dt) + disturbance, same operations as the oracle -- bit for

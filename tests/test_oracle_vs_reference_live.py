@@ -21,12 +21,12 @@ def _fmt(v):
     return ",".join("inf" if x >= 2e30 else "-inf" if x <= -2e30 else repr(float(x)) for x in v)
 
 
-ZOO = ["duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein"]   # the reference's other benchmark systems with nx <= 3
+ZOO = ["duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein", "cartpole"]   # the reference's other benchmark systems with nx <= 3
 
 
 def random_case(rng, zoo=False):
     sc = str(rng.choice(ZOO if zoo else ["unicycle", "vdp", "dint", "int3"]))
-    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1), "int3": (3, 1), "rocket": (3, 1)}.get(sc, (2, 1))
+    nx, nu = {"unicycle": (3, 2), "vdp": (2, 1), "dint": (2, 1), "int3": (3, 1), "rocket": (3, 1), "cartpole": (4, 1)}.get(sc, (2, 1))
     kv = dict(scenario=sc, N=int(rng.integers(4, 36)), iters=3, w=_fmt(rng.uniform(1.0, 40.0, 3)))
     x0 = rng.uniform(-1, 1, nx)
     if sc == "rocket":
@@ -39,7 +39,7 @@ def random_case(rng, zoo=False):
     if sc == "int3" and rng.random() < 0.3:   # time-optimal on the variable grid
         kv.update(vargrid=1, xf=_fmt([float(rng.uniform(0.5, 1.5)), 0.0, 0.0]), solves=int(rng.integers(1, 3)))
         return kv
-    xf = rng.uniform(-1, 1, nx) + np.array([1.5, 0.5, 0.2])[:nx]
+    xf = rng.uniform(-1, 1, nx) + np.array([1.5, 0.5, 0.2, 0.0])[:nx]
     if sc == "rocket":
         xf[2] = rng.uniform(0.8, 1.0)
     kv["xf"] = _fmt(xf)
@@ -67,7 +67,7 @@ def random_case(rng, zoo=False):
     if not all_fixed and rng.random() < 0.2:
         kv["final_cost"] = 0
     r = rng.random()
-    if not all_fixed and "grid" not in kv:
+    if not all_fixed and "grid" not in kv and nx <= 3:   # final-stage constraints: oracle and device support nx <= 3
         if r < 0.25:
             kv.update(tball=repr(float(rng.uniform(1e-4, 0.5))), tball_s=_fmt(rng.uniform(0.1, 2.0, nx)))
         elif r < 0.45:
