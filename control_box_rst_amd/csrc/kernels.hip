@@ -275,7 +275,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
     // (c) the final-stage inequality on x_f (TerminalBall): one lane
-    if constexpr (NX <= 3) {
+    if constexpr (NX <= 4) {
         if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
             double cf = terminal_ball<NX>(xs + (p.N - 1) * S, xr, p.mp.fin);
             cf        = (cf < 0) ? 0.0 : cf * p.w_ineq;   // computeValuesActiveInequality
@@ -619,7 +619,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
     }
-    if constexpr (NX <= 3) {   // final-stage inequality row on x_f (same rule: active row or explicit zeros)
+    if constexpr (NX <= 4) {   // final-stage inequality row on x_f (same rule: active row or explicit zeros)
         if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
             double loc[NX];
 #pragma unroll

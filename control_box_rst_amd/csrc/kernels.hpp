@@ -42,7 +42,7 @@ struct SweepParams {
     const CompInfo* comp;         // nvs: cost-block offsets per component
     const int32_t* ineq_cols;     // (N-1)*nx or null
     int32_t fin_row;              // residual row of the final-stage inequality (TerminalBall) or -1
-    int32_t fin_joff[4];          // its Jacobian entries on x_f (small-block families: nx <= 3), -1 = fixed component
+    int32_t fin_joff[4];          // its Jacobian entries on x_f (small-block families: nx <= 4), -1 = fixed component
     ModelParams mp;
     double dt_fixed;
     // per-call

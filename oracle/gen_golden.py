@@ -94,6 +94,8 @@ def main():
         ("cartpole_ms_rk4", dict(scenario="cartpole", grid="ms", N=16, iters=5), (1, 2, 3, 4, 5)),
         ("cartpole_patterns", dict(scenario="cartpole", N=14, iters=4, xlb="-0.3,-inf,-inf,-1.0", xub="0.4,inf,0.8,inf", ulb="-2.0", uub="inf",
                                    xf_fixed=5), (1, 2, 3, 4)),
+        ("cartpole_tball", dict(scenario="cartpole", N=14, iters=5, tball=0.01, tball_s="1,2,0.5,0.5"), (1, 2, 3, 4, 5)),
+        ("cartpole_teq", dict(scenario="cartpole", N=14, iters=5, teq=1), (1, 2, 3, 4, 5)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)

@@ -54,7 +54,7 @@ def random_desc(rng, long_horizon=False):
         d.xf_fixed_mask = int(rng.integers(0, 2 ** nx)) if rng.random() < 0.3 else 0
         all_fixed = d.xf_fixed_mask == 2 ** nx - 1
         d.final_cost = 0 if all_fixed else int(rng.random() < 0.8)
-        r = rng.random() if nx <= 3 else 1.0   # final-stage constraints: families with nx <= 3
+        r = rng.random()
         if not all_fixed and r < 0.25:
             d.final_ineq = capi.FINAL_INEQ_TERMINAL_BALL
             for i in range(nx):

@@ -67,7 +67,7 @@ def random_case(rng, zoo=False):
     if not all_fixed and rng.random() < 0.2:
         kv["final_cost"] = 0
     r = rng.random()
-    if not all_fixed and "grid" not in kv and nx <= 3:   # final-stage constraints: oracle and device support nx <= 3
+    if not all_fixed and "grid" not in kv:
         if r < 0.25:
             kv.update(tball=repr(float(rng.uniform(1e-4, 0.5))), tball_s=_fmt(rng.uniform(0.1, 2.0, nx)))
         elif r < 0.45:
