@@ -406,6 +406,7 @@ def test_pass_limit_is_reported_not_swallowed(monkeypatch):
     corbo_hip_solve turns it into an error (the limit is 4096 passes; CORBO_HIP_PASS_LIMIT lowers it for this test)."""
     from control_box_rst_amd import problems
     from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    monkeypatch.delenv("CORBO_HIP_LOOP", raising=False)   # (the limit belongs to the run-to-completion kernel, the default mode)
     d = problems.unicycle_desc(N=20)
     x0, xf = problems.unicycle_instances(4)
     s = BatchedLevenbergMarquardt(d, 4)
