@@ -16,7 +16,7 @@ INF = 2e30  # CORBO_INF_DBL (reference: src/core/include/corbo-core/types.h:52)
 GRID_FD, GRID_FD_VARIABLE, GRID_MS = 0, 1, 2
 DEFECT_FORWARD, DEFECT_BACKWARD, DEFECT_MIDPOINT, DEFECT_CRANK_NICOLSON, DEFECT_RK4_SHOOTING = 0, 1, 2, 3, 4
 DYN_VAN_DER_POL, DYN_SERIAL_INTEGRATOR, DYN_UNICYCLE, DYN_QUADROTOR = 0, 1, 2, 3
-# the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h)
+# the reference's other benchmark systems (nonlinear_benchmark_systems.h)
 DYN_DUFFING, DYN_FREE_SPACE_ROCKET, DYN_SIMPLE_PENDULUM, DYN_MASSLESS_PENDULUM, DYN_TOY_EXAMPLE, DYN_ARTSTEINS_CIRCLE = 4, 5, 6, 7, 8, 9
 DYN_CART_POLE = 10
 COST_NONE, COST_QUADRATIC_LSQ, COST_MIN_TIME_LSQ = 0, 1, 2

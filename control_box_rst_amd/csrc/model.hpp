@@ -70,7 +70,7 @@ template <> struct Dynamics<DYN_SERIAL_INTEGRATOR3> {
     }
 };
 
-// ---- the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), each formula in the reference's
+// ---- the reference's other benchmark systems (nonlinear_benchmark_systems.h), each formula in the reference's
 //      operation order (C++ evaluates a - b - c + d and a * b * c left to right)
 template <> struct Dynamics<CORBO_HIP_DYN_DUFFING> {  // :108-115, prm = damping, spring_alpha, spring_beta
     static constexpr int NX = 2, NU = 1, NC = 1;

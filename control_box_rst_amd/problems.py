@@ -109,7 +109,7 @@ def int3_desc(N=30, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, time_optimal=Fals
 INT3_WEIGHTS = (10.0, 10.0, 10.0)
 
 
-# ---- the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h), their default parameters; the cost / bound
+# ---- the reference's other benchmark systems (nonlinear_benchmark_systems.h), their default parameters; the cost / bound
 #      set-up of oracle/ref_driver.cpp's scenarios of the same names
 BENCHMARK_SYSTEMS = {   # name: (dynamics id, nx, default parameters)
     "duffing": (capi.DYN_DUFFING, 2, (1.0, 1.0, 1.0)),              # damping, spring_alpha, spring_beta

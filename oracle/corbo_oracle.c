@@ -116,7 +116,7 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
             f[11] = ((Ixx - Iyy) * x[9] * x[10] + u[3]) / Izz;
             break;
         }
-        /* the reference's other benchmark systems with nx <= 3 (nonlinear_benchmark_systems.h) */
+        /* the reference's other benchmark systems (nonlinear_benchmark_systems.h) */
         case CORBO_HIP_DYN_DUFFING: { /* :108-115 */
             double damping = d->dyn_params[0], alpha = d->dyn_params[1], beta = d->dyn_params[2];
             f[0] = x[1];
