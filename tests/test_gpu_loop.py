@@ -171,3 +171,38 @@ def test_closed_loop_call_equals_stepwise_sequence(scenario, N, B, ocp_iteration
     assert np.array_equal(a.plant_get_state(), b.plant_get_state())
     assert a.closed_loop(2, dt=dt, log=False) is None          # without logs and without disturbance
     assert np.isfinite(a.plant_get_state()).all()
+
+
+def test_long_closed_loop_and_handle_churn_leave_nothing_behind():
+    """2000 control steps in one call stay finite and on target; creating and destroying handles (with plants, logs and per-instance
+    bounds) in a loop returns all device memory."""
+    import torch
+    d = problems.unicycle_desc(N=30)
+    B = 64
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(4)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    s.solve(new_run=True)
+    s.plant_set_state(x0)
+    s.closed_loop(2000, integrator=capi.INTEGRATOR_RK4, log=False)
+    x = s.plant_get_state()
+    assert np.isfinite(x).all() and np.linalg.norm(x[:, :2] - xf[:, :2], axis=1).max() < 0.15   # a unicycle parks near, not on, the goal
+    _, _, status = s.get_solution()
+    assert (status <= 1).all()
+    del s
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(60):
+        h = BatchedLevenbergMarquardt(d, B)
+        X0 = h.init_trajectory(x0, xf)
+        h.set_instance_data(X0, lb=np.full_like(X0, -5.0), ub=np.full_like(X0, 5.0), xref=xf)
+        h.setIterations(2)
+        h.solve(new_run=True)
+        h.plant_set_state(x0)
+        h.closed_loop(3, disturbance=np.zeros((3, B, 3)))
+        del h
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - free0) <= 8 << 20, (free0, free1)   # allocator granularity, not a per-handle leak
