@@ -2365,6 +2365,8 @@ CORBO_HIP_DYN_ENTRIES(mpendulum)
 CORBO_HIP_DYN_ENTRIES(toy)
 CORBO_HIP_DYN_ENTRIES(artstein)
 CORBO_HIP_DYN_ENTRIES(cartpole)
+CORBO_HIP_DYN_ENTRIES(par2)
+CORBO_HIP_DYN_ENTRIES(par3)
 
 #ifdef CORBO_HIP_DYN_TU
 #define CORBO_HIP_CAT2(a, b) a##b
@@ -2420,6 +2422,9 @@ bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hi
         case CORBO_HIP_DYN_TOY_EXAMPLE: plant_entry_toy(p, stream); return true;
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: plant_entry_artstein(p, stream); return true;
         case CORBO_HIP_DYN_CART_POLE: plant_entry_cartpole(p, stream); return true;
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR:
+            if (d.nx == 2) plant_entry_par2(p, stream); else plant_entry_par3(p, stream);
+            return true;
         default: return false;
     }
 }
@@ -2471,6 +2476,8 @@ size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
     if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
     if (d.nx == 3 && d.nu == 1) return factor_lds<3, 1>(p.N, arrow);
     if (d.nx == 4 && d.nu == 1) return factor_lds<4, 1>(p.N, arrow);
+    if (d.nx == 2 && d.nu == 2) return factor_lds<2, 2>(p.N, arrow);
+    if (d.nx == 3 && d.nu == 3) return factor_lds<3, 3>(p.N, arrow);
     return 0;
 }
 
@@ -2491,6 +2498,7 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
         case CORBO_HIP_DYN_TOY_EXAMPLE: return sweep_entry_toy(d.defect, p, stream);
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return sweep_entry_artstein(d.defect, p, stream);
         case CORBO_HIP_DYN_CART_POLE: return sweep_entry_cartpole(d.defect, p, stream);
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: return d.nx == 2 ? sweep_entry_par2(d.defect, p, stream) : sweep_entry_par3(d.defect, p, stream);
         default: return false;
     }
 }
@@ -2511,6 +2519,7 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
         case CORBO_HIP_DYN_TOY_EXAMPLE: return pass_entry_toy(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return pass_entry_artstein(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_CART_POLE: return pass_entry_cartpole(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: return d.nx == 2 ? pass_entry_par2(d.defect, fp, sp, stream) : pass_entry_par3(d.defect, fp, sp, stream);
         default: return false;
     }
 }
@@ -2532,6 +2541,8 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
     if (d.nx == 3 && d.nu == 2) return launch_factor_t<3, 2>(p, stream);
     if (d.nx == 3 && d.nu == 1) return launch_factor_t<3, 1>(p, stream);
     if (d.nx == 4 && d.nu == 1) return launch_factor_t<4, 1>(p, stream);
+    if (d.nx == 2 && d.nu == 2) return launch_factor_t<2, 2>(p, stream);
+    if (d.nx == 3 && d.nu == 3) return launch_factor_t<3, 3>(p, stream);
     return false;
 }
 

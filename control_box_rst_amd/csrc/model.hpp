@@ -147,6 +147,24 @@ template <> struct Dynamics<CORBO_HIP_DYN_ARTSTEINS_CIRCLE> {  // :483-491
     }
 };
 
+// ParallelIntegratorSystem of dimension 2 / 3 (linear_benchmark_systems.h:142-148: f = T u; public id CORBO_HIP_DYN_PARALLEL_INTEGRATOR
+// with nx = nu = p; internal template ids)
+constexpr int DYN_PARALLEL_INTEGRATOR2 = 101, DYN_PARALLEL_INTEGRATOR3 = 102;
+template <int P> struct ParallelIntegratorDynamics {
+    static constexpr int NX = P, NU = P, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u;
+    static constexpr unsigned RK4_GROUP1_COLS = (P == 2) ? 0b111000u : 0b111100000u;   // the last control and x_{k+1}
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double*, const double*, const double* u, const double* prm, double* f)
+    {
+#pragma unroll
+        for (int i = 0; i < P; ++i) f[i] = prm[0] * u[i];
+    }
+};
+template <> struct Dynamics<DYN_PARALLEL_INTEGRATOR2> : ParallelIntegratorDynamics<2> {};
+template <> struct Dynamics<DYN_PARALLEL_INTEGRATOR3> : ParallelIntegratorDynamics<3> {};
+
 template <> struct Dynamics<CORBO_HIP_DYN_CART_POLE> {  // :337-355; state [x phi xdot phidot]; the reference's fixed parameters
     static constexpr int NX = 4, NU = 1, NC = 2;
     static constexpr unsigned CACHE_XMASK = 0b0010u;                 // sin(phi), cos(phi)

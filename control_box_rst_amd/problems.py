@@ -123,6 +123,14 @@ BENCHMARK_SYSTEMS = {   # name: (dynamics id, nx, default parameters)
 BENCHMARK_WEIGHTS = (5.0, 5.0, 5.0)
 
 
+def parallel_integrator_desc(p=2, N=24, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+    """ParallelIntegratorSystem of dimension p (linear_benchmark_systems.h:120-183), time constant 1; set-up of oracle/ref_driver.cpp's par2 / par3."""
+    q = (1.0, 0.5, 0.2)[:p]
+    r = (0.1, 0.2, 0.05)[:p]
+    return make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_PARALLEL_INTEGRATOR, nx=p, nu=p, N=N, dt=dt, q=q, r=r,
+                     qf=tuple(10.0 * v for v in q), u_lb=(-1.5,) * p, u_ub=(1.5,) * p, dyn_params=(1.0,))
+
+
 def benchmark_desc(name, N=24, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
     dyn, nx, prm = BENCHMARK_SYSTEMS[name]
     q = (1.0, 0.5, 0.2, 0.1)[:nx]
@@ -164,5 +172,7 @@ SCENARIOS = {
     "int3": (int3_desc, INT3_WEIGHTS),
     "quad": (quad_desc, QUAD_WEIGHTS),
 }
+SCENARIOS["par2"] = (lambda **kw: parallel_integrator_desc(2, **kw), BENCHMARK_WEIGHTS)
+SCENARIOS["par3"] = (lambda **kw: parallel_integrator_desc(3, **kw), BENCHMARK_WEIGHTS)
 for _name in BENCHMARK_SYSTEMS:
     SCENARIOS[_name] = ((lambda n: (lambda **kw: benchmark_desc(n, **kw)))(_name), BENCHMARK_WEIGHTS)

@@ -78,7 +78,8 @@ typedef enum corbo_hip_dynamics {
     CORBO_HIP_DYN_MASSLESS_PENDULUM = 7, /* MasslessPendulum :261-314,  params[0] = omega0                            nx=2 nu=1 */
     CORBO_HIP_DYN_TOY_EXAMPLE       = 8, /* ToyExample :406-460,        params[0] = mu                                nx=2 nu=1 */
     CORBO_HIP_DYN_ARTSTEINS_CIRCLE  = 9, /* ArtsteinsCircle :463-509    (no parameters)                              nx=2 nu=1 */
-    CORBO_HIP_DYN_CART_POLE         = 10 /* CartPole :317-390           (fixed parameters), state [x phi xdot phidot] nx=4 nu=1 */
+    CORBO_HIP_DYN_CART_POLE         = 10, /* CartPole :317-390          (fixed parameters), state [x phi xdot phidot] nx=4 nu=1 */
+    CORBO_HIP_DYN_PARALLEL_INTEGRATOR = 11 /* linear_benchmark_systems.h:120-183, f = T u, params[0] = T       nx=nu=2|3 */
 } corbo_hip_dynamics;
 
 typedef enum corbo_hip_stage_cost {

@@ -148,6 +148,9 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
             f[0] = (x[0] * x[0] - x[1] * x[1]) * u[0];
             f[1] = 2 * x[0] * x[1] * u[0];
             break;
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: /* linear_benchmark_systems.h:142-148 */
+            for (int i = 0; i < d->nx; ++i) f[i] = d->dyn_params[0] * u[i];
+            break;
         case CORBO_HIP_DYN_CART_POLE: { /* :337-355, state [x phi xdot phidot], the reference's fixed parameters */
             const double mc = 1.0, mp = 0.3, l = 0.5, g = 9.81;
             double sin_phi_phidot_sq = sin(x[1]) * x[3] * x[3];
@@ -311,6 +314,7 @@ static int validate(const corbo_hip_problem_desc* d)
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: if (d->nx != 2 || d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_FREE_SPACE_ROCKET: if (d->nx != 3 || d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_CART_POLE: if (d->nx != 4 || d->nu != 1) return 0; break;
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: if (d->nx != d->nu || d->nx < 2 || d->nx > 3) return 0; break;
         default: return 0;
     }
     if (d->stage_cost < 0 || d->stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return 0;

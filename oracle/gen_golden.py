@@ -96,6 +96,11 @@ def main():
                                    xf_fixed=5), (1, 2, 3, 4)),
         ("cartpole_tball", dict(scenario="cartpole", N=14, iters=5, tball=0.01, tball_s="1,2,0.5,0.5"), (1, 2, 3, 4, 5)),
         ("cartpole_teq", dict(scenario="cartpole", N=14, iters=5, teq=1), (1, 2, 3, 4, 5)),
+        # ParallelIntegratorSystem of dimension 2 / 3 (nx = nu): the families with as many controls as states
+        ("par2", dict(scenario="par2", iters=5), (1, 2, 3, 4, 5)),
+        ("par3", dict(scenario="par3", iters=5), (1, 2, 3, 4, 5)),
+        ("par2_ms_rk4", dict(scenario="par2", grid="ms", N=12, iters=4), (1, 2, 3, 4)),
+        ("par3_forward", dict(scenario="par3", collocation="forward", N=12, iters=4, xf_fixed=5), (1, 2, 3, 4)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)

@@ -201,6 +201,13 @@ static Built build(const Scenario& s, int iterations)
         dyn = std::make_shared<VanDerPolOscillator>();
         if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
+    else if (s.name == "par2" || s.name == "par3")   // ParallelIntegratorSystem(p), time constant 1
+    {
+        auto sys = std::make_shared<ParallelIntegratorSystem>();
+        sys->setDimension(s.nx);
+        dyn = sys;
+        if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
+    }
     else if (isZoo(s.name))
     {
         if (s.name == "duffing") dyn = std::make_shared<DuffingOscillator>();
@@ -287,6 +294,16 @@ static Built build(const Scenario& s, int iterations)
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
+    }
+    else if (s.name == "par2" || s.name == "par3")   // Q = diag(1, 0.5[, 0.2]), R = diag(0.1, 0.2[, 0.05]), Qf = 10 Q, |u_i| <= 1.5
+    {
+        Eigen::VectorXd q(s.nx), r(s.nx);
+        const double qv[3] = {1.0, 0.5, 0.2}, rv[3] = {0.1, 0.2, 0.05};
+        for (int i = 0; i < s.nx; ++i) { q[i] = qv[i]; r[i] = rv[i]; }
+        Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal(), Qf = 10.0 * Q;
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setControlBounds(Eigen::VectorXd::Constant(s.nx, -1.5), Eigen::VectorXd::Constant(s.nx, 1.5));
     }
     else if (isZoo(s.name))   // Q = diag(1, 0.5[, 0.2]), R = 0.1, Qf = 10 Q, |u| <= 1.5
     {
@@ -429,6 +446,13 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         s.w_eq = s.w_ineq = s.w_b = 2;
         s.x0 = Eigen::Vector2d(1, 0);
         s.xf = Eigen::Vector2d(0, 0);
+    }
+    else if (s.name == "par2" || s.name == "par3")
+    {
+        s.nx = s.nu = (s.name == "par2") ? 2 : 3; s.N = 24; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 5;
+        s.x0 = Eigen::VectorXd::Zero(s.nx);
+        s.xf = (s.nx == 2) ? Eigen::VectorXd(Eigen::Vector2d(1.0, -0.5)) : Eigen::VectorXd(Eigen::Vector3d(1.0, -0.5, 0.3));
     }
     else if (isZoo(s.name))
     {

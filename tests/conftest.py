@@ -40,6 +40,8 @@ def desc_for(g):
         return problems.quad_desc(N=g["N"], dt=g["dt"])
     if sc == "int3":
         d = problems.int3_desc(N=g["N"], dt=g["dt"], defect=defect, time_optimal=bool(g.get("vargrid")))
+    elif sc in ("par2", "par3"):
+        d = problems.parallel_integrator_desc(int(sc[-1]), N=g["N"], dt=g["dt"], defect=defect)
     elif sc in problems.BENCHMARK_SYSTEMS:
         d = problems.benchmark_desc(sc, N=g["N"], dt=g["dt"], defect=defect)
     elif sc in ("unicycle", "vdp"):

@@ -18,7 +18,7 @@ def integrator_of(g):
 
 
 @pytest.mark.parametrize("scenario,N", [("vdp", 20), ("int3", 20), ("unicycle", 30), ("quad", 10), ("duffing", 12), ("rocket", 12), ("pendulum", 12),
-                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12), ("cartpole", 12)])
+                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12), ("cartpole", 12), ("par2", 12), ("par3", 12)])
 @pytest.mark.parametrize("integrator", [capi.INTEGRATOR_EULER, capi.INTEGRATOR_RK4])
 def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
     """Per instance: x+ = integrator(x, u_0 of the resident trajectory, dt) + disturbance, same operations as the oracle -- bit for
@@ -44,7 +44,7 @@ def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
         for b in range(B):
             p.set_data(X[b])
             xp[b] = p.plant_step(xp[b], integrator, dt, None if dd is None else dd[b])
-        if scenario in ("vdp", "int3", "duffing", "rocket", "toy", "artstein"):
+        if scenario in ("vdp", "int3", "duffing", "rocket", "toy", "artstein", "par2", "par3"):
             assert np.array_equal(got, xp), (scenario, rep)
         else:
             assert np.abs(got - xp).max() <= 1e-14 * max(1.0, np.abs(xp).max()), (scenario, rep)

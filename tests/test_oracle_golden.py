@@ -17,7 +17,8 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal",
         # the reference's other benchmark systems with nx <= 3
         "duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein", "duffing_midpoint", "rocket_forward", "toy_backward", "pendulum_ms_rk4", "mpendulum_ms_rk4", "rocket_ms_rk4", "artstein_ms_rk4",
-        "cartpole", "cartpole_midpoint", "cartpole_ms_rk4", "cartpole_patterns", "cartpole_tball", "cartpole_teq"]
+        "cartpole", "cartpole_midpoint", "cartpole_ms_rk4", "cartpole_patterns", "cartpole_tball", "cartpole_teq",
+        "par2", "par3", "par2_ms_rk4", "par3_forward"]
 
 # The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
 # along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
