@@ -645,8 +645,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         __syncthreads();
     SWEEP_STAMP(7);
         // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
-        for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS)
-            reinterpret_cast<double2*>(js)[i] = reinterpret_cast<const double2*>(jst)[i];
+        // (stand-alone kernel: streaming stores -- the consumer is a later launch and 1024 Jacobians do not fit the L2 anyway, +7 % on the
+        //  sweep; fused kernel: normal stores -- the pass after a rejected step reads its Jacobian back from the L2, streaming costs 3 %)
+        for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS) {
+            const double2 v = reinterpret_cast<const double2*>(jst)[i];
+            if constexpr (FUSED) reinterpret_cast<double2*>(js)[i] = v;
+            else {
+                __builtin_nontemporal_store(v.x, &js[2 * i]);
+                __builtin_nontemporal_store(v.y, &js[2 * i + 1]);
+            }
+        }
     SWEEP_STAMP(8);
     }
 }
