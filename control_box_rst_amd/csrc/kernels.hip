@@ -135,6 +135,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     const bool jac_with_values = STAGE && (mode != 0);
     // role of component v: index c inside its cost edge, dimension of that edge, weight and reference (branch-free).  Edges
     // without a reference (control cost, dt cost) use ref = 0: w * (x - 0) is w * x exactly.
+    // residual entries: streaming stores in the stand-alone kernel (consumed by a later launch), normal ones in the fused kernel
+    auto put_value = [&](int row, double val) {
+        if constexpr (FUSED) vout[row] = val;
+        else __builtin_nontemporal_store(val, &vout[row]);
+    };
     auto comp_role = [&](int v, int& c, int& dim, double& w, double& ref, bool& fin) {
         const bool is_dt  = (v == p.off_dt);
         const bool is_fin = !is_dt && v >= (p.N - 1) * S;
@@ -186,19 +191,19 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         comp_role(v, c, dim, w, ref, fin);
         if (ci.cost_row >= 0) {
             const double val = w * (xv - ref);
-            vout[ci.cost_row] = val;
+            put_value(ci.cost_row, val);
             sq_acc += val * val;
-            if (!fin && ci.cost2_row >= 0) { vout[ci.cost2_row] = val; sq_acc += val * val; }
+            if (!fin && ci.cost2_row >= 0) { put_value(ci.cost2_row, val); sq_acc += val * val; }
         }
         if (fin && ci.cost2_row >= 0) {   // TerminalEqualityConstraint row (equality section: times w_eq)
             const double val = (xv - ref) * p.w_eq;
-            vout[ci.cost2_row] = val;
+            put_value(ci.cost2_row, val);
             sq_acc += val * val;
         }
         if (ci.bnd_row >= 0) {
             double val = (xv < l) ? l - xv : ((xv > u) ? xv - u : 0.0);
             val *= p.w_b;
-            vout[ci.bnd_row] = val;
+            put_value(ci.bnd_row, val);
             sq_acc += val * val;
         }
         if (jac_with_values) comp_jac(v, ci, xv, l, u, c, dim, w, ref, fin);
@@ -262,14 +267,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double val = e[i] * p.w_eq;
-            vout[p.eq_row0 + k * NX + i] = val;
+            put_value(p.eq_row0 + k * NX + i, val);
             sq_acc += val * val;
         }
         if constexpr (NX >= 3) {
             if (p.ineq_cols) {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
                 double ci = ineq_ball(xs + base, p.mp.ineq);
                 ci        = (ci < 0) ? 0.0 : ci * p.w_ineq;
-                vout[p.ineq_row0 + k] = ci;
+                put_value(p.ineq_row0 + k, ci);
                 sq_acc += ci * ci;
             }
         }
@@ -279,7 +284,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
             double cf = terminal_ball<NX>(xs + (p.N - 1) * S, xr, p.mp.fin);
             cf        = (cf < 0) ? 0.0 : cf * p.w_ineq;   // computeValuesActiveInequality
-            vout[p.fin_row] = cf;
+            put_value(p.fin_row, cf);
             sq_acc += cf * cf;
         }
     }
