@@ -18,7 +18,7 @@ DEFECT_FORWARD, DEFECT_BACKWARD, DEFECT_MIDPOINT, DEFECT_CRANK_NICOLSON, DEFECT_
 DYN_VAN_DER_POL, DYN_SERIAL_INTEGRATOR, DYN_UNICYCLE, DYN_QUADROTOR = 0, 1, 2, 3
 # the reference's other benchmark systems (nonlinear_benchmark_systems.h)
 DYN_DUFFING, DYN_FREE_SPACE_ROCKET, DYN_SIMPLE_PENDULUM, DYN_MASSLESS_PENDULUM, DYN_TOY_EXAMPLE, DYN_ARTSTEINS_CIRCLE = 4, 5, 6, 7, 8, 9
-DYN_CART_POLE, DYN_PARALLEL_INTEGRATOR = 10, 11
+DYN_CART_POLE, DYN_PARALLEL_INTEGRATOR, DYN_LINEAR_STATE_SPACE = 10, 11, 12
 COST_NONE, COST_QUADRATIC_LSQ, COST_MIN_TIME_LSQ = 0, 1, 2
 INEQ_NONE, INEQ_BALL = 0, 1
 FINAL_INEQ_NONE, FINAL_INEQ_TERMINAL_BALL = 0, 1
@@ -37,6 +37,7 @@ class ProblemDesc(C.Structure):
         ("q_diag", C.c_double * MAX_NX), ("r_diag", C.c_double * MAX_NU), ("qf_diag", C.c_double * MAX_NX),
         ("dyn_params", C.c_double * 8), ("ineq_params", C.c_double * 8),
         ("final_ineq", C.c_int32), ("final_eq", C.c_int32), ("final_ineq_params", C.c_double * (MAX_NX + 1)),
+        ("lin_a", C.c_double * 16), ("lin_b", C.c_double * 12),
     ]
 
 

@@ -6,6 +6,7 @@
 // control flow (accept / reject / damping) lives on the device; the host only counts unfinished instances per pass.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -109,6 +110,7 @@ struct corbo_hip_solver {
     double* h_stage      = nullptr;
     double* d_bound_rows = nullptr;  // [2][nvs] the descriptor's bound pattern of one instance (lower row, upper row)
     std::vector<double> bound_rows;  // host copy of the same
+    double* d_lin    = nullptr;      // [A | B] of a LinearStateSpaceModel (row-major), else null
     double* d_xplant = nullptr;      // [batch][MAX_NX] plant states of the closed loop (corbo_hip_plant_*)
     double* h_dist   = nullptr;      // pinned, device-visible [batch][MAX_NX]: state disturbance of corbo_hip_plant_step
     bool have_plant  = false;
@@ -133,13 +135,23 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
+    // the 8 model parameters as the kernels see them: the descriptor's, except for the linear state-space model, whose first slot
+    // carries the device address of its [A | B] table as a bit pattern (model.hpp, LinearDynamics)
+    void fill_dyn(double (&dyn)[8]) const
+    {
+        std::memcpy(dyn, S.desc.dyn_params, sizeof(dyn));
+        if (S.desc.dynamics == CORBO_HIP_DYN_LINEAR_STATE_SPACE) {
+            const long long bits = (long long)reinterpret_cast<uintptr_t>(d_lin);
+            std::memcpy(&dyn[0], &bits, sizeof(double));
+        }
+    }
     SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
     {
         SweepParams p{};
         p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
-        std::memcpy(p.mp.dyn, S.desc.dyn_params, sizeof(p.mp.dyn));
+        fill_dyn(p.mp.dyn);
         std::memcpy(p.mp.ineq, S.desc.ineq_params, sizeof(p.mp.ineq));
         std::memcpy(p.mp.sq, S.sq, sizeof(p.mp.sq));
         std::memcpy(p.mp.sr, S.sr, sizeof(p.mp.sr));
@@ -287,6 +299,13 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipHostMalloc((void**)&h->h_stage, B * (size_t)(S.nvs > CORBO_HIP_MAX_NX ? S.nvs : CORBO_HIP_MAX_NX) * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_state, B * sizeof(LmState)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_dist, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    if (S.desc.dynamics == CORBO_HIP_DYN_LINEAR_STATE_SPACE) {
+        std::vector<double> ab((size_t)S.nx * S.nx + (size_t)S.nx * S.nu);
+        for (int i = 0; i < S.nx * S.nx; ++i) ab[i] = S.desc.lin_a[i];
+        for (int i = 0; i < S.nx * S.nu; ++i) ab[(size_t)S.nx * S.nx + i] = S.desc.lin_b[i];
+        CREATE_TRY(hipMalloc((void**)&h->d_lin, ab.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(h->d_lin, ab.data(), ab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipMalloc((void**)&h->d_xplant, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_xplant, 0, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_bound_rows, 2 * (size_t)S.nvs * sizeof(double)));
@@ -345,7 +364,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows, h->d_xplant, h->d_loop};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -690,7 +709,7 @@ int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const do
     }
     PlantParams p{};
     p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.integrator = integrator; p.dt = dt;
-    std::memcpy(p.dyn, S.desc.dyn_params, sizeof(p.dyn));
+    h->fill_dyn(p.dyn);
     p.x = h->d_x; p.xplant = h->d_xplant; p.disturbance = disturbance ? h->h_dist : nullptr;
     if (!launch_plant_step(S.desc, p, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no plant kernel for this dynamics");
     HIP_TRY(hipGetLastError());
@@ -755,7 +774,7 @@ try {
     for (int s = 0; s < steps; ++s) {
         PlantParams pp{};
         pp.batch = h->batch; pp.nvs = S.nvs; pp.nx = S.nx; pp.nu = S.nu; pp.integrator = integrator; pp.dt = dt;
-        std::memcpy(pp.dyn, S.desc.dyn_params, sizeof(pp.dyn));
+        h->fill_dyn(pp.dyn);
         pp.x = h->d_x; pp.xplant = h->d_xplant;
         pp.disturbance = disturbance ? h->h_loop + (size_t)s * B * NXm : nullptr;   // read by the kernel from pinned host memory
         pp.log_x = d_logx ? d_logx + (size_t)s * B * S.nx : nullptr;

@@ -2380,6 +2380,12 @@ CORBO_HIP_DYN_ENTRIES(artstein)
 CORBO_HIP_DYN_ENTRIES(cartpole)
 CORBO_HIP_DYN_ENTRIES(par2)
 CORBO_HIP_DYN_ENTRIES(par3)
+CORBO_HIP_DYN_ENTRIES(lin21)
+CORBO_HIP_DYN_ENTRIES(lin22)
+CORBO_HIP_DYN_ENTRIES(lin31)
+CORBO_HIP_DYN_ENTRIES(lin32)
+CORBO_HIP_DYN_ENTRIES(lin33)
+CORBO_HIP_DYN_ENTRIES(lin41)
 
 #ifdef CORBO_HIP_DYN_TU
 #define CORBO_HIP_CAT2(a, b) a##b
@@ -2438,6 +2444,14 @@ bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hi
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR:
             if (d.nx == 2) plant_entry_par2(p, stream); else plant_entry_par3(p, stream);
             return true;
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE:
+            if (d.nx == 2 && d.nu == 1) { plant_entry_lin21(p, stream); return true; }
+            if (d.nx == 2 && d.nu == 2) { plant_entry_lin22(p, stream); return true; }
+            if (d.nx == 3 && d.nu == 1) { plant_entry_lin31(p, stream); return true; }
+            if (d.nx == 3 && d.nu == 2) { plant_entry_lin32(p, stream); return true; }
+            if (d.nx == 3 && d.nu == 3) { plant_entry_lin33(p, stream); return true; }
+            if (d.nx == 4 && d.nu == 1) { plant_entry_lin41(p, stream); return true; }
+            return false;
         default: return false;
     }
 }
@@ -2512,6 +2526,14 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return sweep_entry_artstein(d.defect, p, stream);
         case CORBO_HIP_DYN_CART_POLE: return sweep_entry_cartpole(d.defect, p, stream);
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: return d.nx == 2 ? sweep_entry_par2(d.defect, p, stream) : sweep_entry_par3(d.defect, p, stream);
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE:
+            if (d.nx == 2 && d.nu == 1) return sweep_entry_lin21(d.defect, p, stream);
+            if (d.nx == 2 && d.nu == 2) return sweep_entry_lin22(d.defect, p, stream);
+            if (d.nx == 3 && d.nu == 1) return sweep_entry_lin31(d.defect, p, stream);
+            if (d.nx == 3 && d.nu == 2) return sweep_entry_lin32(d.defect, p, stream);
+            if (d.nx == 3 && d.nu == 3) return sweep_entry_lin33(d.defect, p, stream);
+            if (d.nx == 4 && d.nu == 1) return sweep_entry_lin41(d.defect, p, stream);
+            return false;
         default: return false;
     }
 }
@@ -2533,6 +2555,14 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return pass_entry_artstein(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_CART_POLE: return pass_entry_cartpole(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: return d.nx == 2 ? pass_entry_par2(d.defect, fp, sp, stream) : pass_entry_par3(d.defect, fp, sp, stream);
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE:
+            if (d.nx == 2 && d.nu == 1) return pass_entry_lin21(d.defect, fp, sp, stream);
+            if (d.nx == 2 && d.nu == 2) return pass_entry_lin22(d.defect, fp, sp, stream);
+            if (d.nx == 3 && d.nu == 1) return pass_entry_lin31(d.defect, fp, sp, stream);
+            if (d.nx == 3 && d.nu == 2) return pass_entry_lin32(d.defect, fp, sp, stream);
+            if (d.nx == 3 && d.nu == 3) return pass_entry_lin33(d.defect, fp, sp, stream);
+            if (d.nx == 4 && d.nu == 1) return pass_entry_lin41(d.defect, fp, sp, stream);
+            return false;
         default: return false;
     }
 }

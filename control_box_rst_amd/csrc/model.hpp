@@ -165,6 +165,47 @@ template <int P> struct ParallelIntegratorDynamics {
 template <> struct Dynamics<DYN_PARALLEL_INTEGRATOR2> : ParallelIntegratorDynamics<2> {};
 template <> struct Dynamics<DYN_PARALLEL_INTEGRATOR3> : ParallelIntegratorDynamics<3> {};
 
+// LinearStateSpaceModel (linear_benchmark_systems.h:206-213: f = A x + B u; public id CORBO_HIP_DYN_LINEAR_STATE_SPACE, one internal
+// template id per (nx, nu) family).  Eigen evaluates `f = A * x + B * u` as ONE running sum per row -- f_i = 0, += A_i0 x_0, += A_i1 x_1,
+// ..., += B_i0 u_0, ... (dst = A x; dst += B u, column-major gemv accumulating column by column; a full block of FOUR columns is added
+// pairwise, (c0 + c1) + (c2 + c3) -- measured against the compiled reference) -- restated here.  The matrices do not
+// fit the 8 model parameters: prm[0] carries, as a bit pattern, the device address of the row-major table [A | B] (set by the host
+// side of the C-ABI; uniform, so the entries arrive through scalar loads).
+constexpr int dyn_linear_id(int nx, int nu) { return 200 + 10 * nx + nu; }
+template <int NXv, int NUv> struct LinearDynamics {
+    static constexpr int NX = NXv, NU = NUv, NC = 1;
+    static constexpr unsigned CACHE_XMASK = 0u;
+    static constexpr unsigned RK4_CACHE_DEP_COLS = 0u;
+    // group 1: the last ceil(NU / 2) controls' worth of columns and x_{k+1} (the same split as the models of equal shape above)
+    static constexpr unsigned RK4_GROUP1_COLS = (((1u << (2 * NXv + NUv)) - 1u) >> (NXv + (NUv + 1) / 2)) << (NXv + (NUv + 1) / 2);
+    __device__ static __forceinline__ void prepare(const double*, const double*, double* c) { c[0] = 0.0; }
+    __device__ static __forceinline__ void eval(const double* x, const double*, const double* u, const double* prm, double* f)
+    {
+        const double* ab = reinterpret_cast<const double*>(__double_as_longlong(prm[0]));
+#pragma unroll
+        for (int i = 0; i < NXv; ++i) {
+            double acc = 0.0;
+            if constexpr (NXv == 4) {   // a full block of four columns: Eigen's gemv kernel adds it pairwise
+                const double* a = ab + i * 4;
+                acc = (a[0] * x[0] + a[1] * x[1]) + (a[2] * x[2] + a[3] * x[3]);
+            }
+            else {
+#pragma unroll
+                for (int j = 0; j < NXv; ++j) acc += ab[i * NXv + j] * x[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NUv; ++j) acc += ab[NXv * NXv + i * NUv + j] * u[j];
+            f[i] = acc;
+        }
+    }
+};
+template <> struct Dynamics<dyn_linear_id(2, 1)> : LinearDynamics<2, 1> {};
+template <> struct Dynamics<dyn_linear_id(2, 2)> : LinearDynamics<2, 2> {};
+template <> struct Dynamics<dyn_linear_id(3, 1)> : LinearDynamics<3, 1> {};
+template <> struct Dynamics<dyn_linear_id(3, 2)> : LinearDynamics<3, 2> {};
+template <> struct Dynamics<dyn_linear_id(3, 3)> : LinearDynamics<3, 3> {};
+template <> struct Dynamics<dyn_linear_id(4, 1)> : LinearDynamics<4, 1> {};
+
 template <> struct Dynamics<CORBO_HIP_DYN_CART_POLE> {  // :337-355; state [x phi xdot phidot]; the reference's fixed parameters
     static constexpr int NX = 4, NU = 1, NC = 2;
     static constexpr unsigned CACHE_XMASK = 0b0010u;                 // sin(phi), cos(phi)

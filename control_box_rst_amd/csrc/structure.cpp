@@ -29,6 +29,10 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: if (d.nx != 2 || d.nu != 1) return "this benchmark system has nx=2 nu=1"; break;
         case CORBO_HIP_DYN_FREE_SPACE_ROCKET: if (d.nx != 3 || d.nu != 1) return "free-space rocket: nx=3 nu=1"; break;
         case CORBO_HIP_DYN_CART_POLE: if (d.nx != 4 || d.nu != 1) return "cart-pole: nx=4 nu=1"; break;
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE:
+            if (!((d.nx == 2 && (d.nu == 1 || d.nu == 2)) || (d.nx == 3 && d.nu >= 1 && d.nu <= 3) || (d.nx == 4 && d.nu == 1)))
+                return "linear state-space model: (nx, nu) in {(2,1), (2,2), (3,1), (3,2), (3,3), (4,1)}";
+            break;
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: if (d.nx != d.nu || d.nx < 2 || d.nx > 3) return "parallel integrators: nx=nu=2 or 3"; break;
         default: return "unknown dynamics";
     }

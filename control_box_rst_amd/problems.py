@@ -123,6 +123,22 @@ BENCHMARK_SYSTEMS = {   # name: (dynamics id, nx, default parameters)
 BENCHMARK_WEIGHTS = (5.0, 5.0, 5.0)
 
 
+def linear_desc(A, B, N=24, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
+    """LinearStateSpaceModel f = A x + B u (linear_benchmark_systems.h:186-262); cost / bound set-up of oracle/ref_driver.cpp's `lin`."""
+    A, B = np.atleast_2d(np.asarray(A, float)), np.atleast_2d(np.asarray(B, float))
+    nx, nu = B.shape
+    assert A.shape == (nx, nx)
+    q = (1.0, 0.5, 0.2, 0.1)[:nx]
+    r = (0.1, 0.2, 0.05)[:nu]
+    d = make_desc(grid=capi.GRID_FD, defect=defect, dynamics=capi.DYN_LINEAR_STATE_SPACE, nx=nx, nu=nu, N=N, dt=dt, q=q, r=r,
+                  qf=tuple(10.0 * v for v in q), u_lb=(-1.5,) * nu, u_ub=(1.5,) * nu)
+    for i, v in enumerate(A.reshape(-1)):
+        d.lin_a[i] = v
+    for i, v in enumerate(B.reshape(-1)):
+        d.lin_b[i] = v
+    return d
+
+
 def parallel_integrator_desc(p=2, N=24, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON) -> ProblemDesc:
     """ParallelIntegratorSystem of dimension p (linear_benchmark_systems.h:120-183), time constant 1; set-up of oracle/ref_driver.cpp's par2 / par3."""
     q = (1.0, 0.5, 0.2)[:p]

@@ -79,7 +79,9 @@ typedef enum corbo_hip_dynamics {
     CORBO_HIP_DYN_TOY_EXAMPLE       = 8, /* ToyExample :406-460,        params[0] = mu                                nx=2 nu=1 */
     CORBO_HIP_DYN_ARTSTEINS_CIRCLE  = 9, /* ArtsteinsCircle :463-509    (no parameters)                              nx=2 nu=1 */
     CORBO_HIP_DYN_CART_POLE         = 10, /* CartPole :317-390          (fixed parameters), state [x phi xdot phidot] nx=4 nu=1 */
-    CORBO_HIP_DYN_PARALLEL_INTEGRATOR = 11 /* linear_benchmark_systems.h:120-183, f = T u, params[0] = T       nx=nu=2|3 */
+    CORBO_HIP_DYN_PARALLEL_INTEGRATOR = 11, /* linear_benchmark_systems.h:120-183, f = T u, params[0] = T      nx=nu=2|3 */
+    CORBO_HIP_DYN_LINEAR_STATE_SPACE  = 12  /* LinearStateSpaceModel :186-262, f = A x + B u, matrices in lin_a / lin_b;
+                                             * (nx, nu) in {(2,1), (2,2), (3,1), (3,2), (3,3), (4,1)} */
 } corbo_hip_dynamics;
 
 typedef enum corbo_hip_stage_cost {
@@ -130,6 +132,9 @@ typedef struct corbo_hip_problem_desc {
     int32_t final_eq;      /* 1 = TerminalEqualityConstraint(xref) (final_state_constraints.h:130-160): nx equality rows x_f - xref after the
                             * defect rows (finite_differences_grid.cpp:135-141), xref = the instance's state reference; nx <= 4 only */
     double final_ineq_params[CORBO_HIP_MAX_NX + 1];
+    /* CORBO_HIP_DYN_LINEAR_STATE_SPACE (LinearStateSpaceModel::setParameters(A, B)): row-major A[i * nx + j], B[i * nu + j] */
+    double lin_a[16];
+    double lin_b[12];
 } corbo_hip_problem_desc;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */

@@ -148,6 +148,20 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
             f[0] = (x[0] * x[0] - x[1] * x[1]) * u[0];
             f[1] = 2 * x[0] * x[1] * u[0];
             break;
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE: /* linear_benchmark_systems.h:206-213: f = A x + B u, evaluated by Eigen as one running sum
+                                                * per row (dst = A x; dst += B u; column-major gemv, column by column) */
+            for (int i = 0; i < d->nx; ++i) {
+                double acc = 0.0;
+                if (d->nx == 4) { /* a full block of four columns: Eigen's gemv kernel adds it pairwise (GeneralMatrixVector.h) */
+                    const double* a = d->lin_a + i * 4;
+                    acc = (a[0] * x[0] + a[1] * x[1]) + (a[2] * x[2] + a[3] * x[3]);
+                }
+                else
+                    for (int j = 0; j < d->nx; ++j) acc += d->lin_a[i * d->nx + j] * x[j];
+                for (int j = 0; j < d->nu; ++j) acc += d->lin_b[i * d->nu + j] * u[j];
+                f[i] = acc;
+            }
+            break;
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: /* linear_benchmark_systems.h:142-148 */
             for (int i = 0; i < d->nx; ++i) f[i] = d->dyn_params[0] * u[i];
             break;
@@ -315,6 +329,9 @@ static int validate(const corbo_hip_problem_desc* d)
         case CORBO_HIP_DYN_FREE_SPACE_ROCKET: if (d->nx != 3 || d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_CART_POLE: if (d->nx != 4 || d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: if (d->nx != d->nu || d->nx < 2 || d->nx > 3) return 0; break;
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE:
+            if (!((d->nx == 2 && (d->nu == 1 || d->nu == 2)) || (d->nx == 3 && d->nu >= 1 && d->nu <= 3) || (d->nx == 4 && d->nu == 1))) return 0;
+            break;
         default: return 0;
     }
     if (d->stage_cost < 0 || d->stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return 0;

@@ -101,6 +101,13 @@ def main():
         ("par3", dict(scenario="par3", iters=5), (1, 2, 3, 4, 5)),
         ("par2_ms_rk4", dict(scenario="par2", grid="ms", N=12, iters=4), (1, 2, 3, 4)),
         ("par3_forward", dict(scenario="par3", collocation="forward", N=12, iters=4, xf_fixed=5), (1, 2, 3, 4)),
+        # LinearStateSpaceModel f = A x + B u, one fixture per (nx, nu) block family (matrices drawn once, rounded to 3 digits)
+        ("lin21", dict(scenario='lin', nx=2, nu=1, lin_a='-1.045,-0.366,0.595,-0.14700000000000002', lin_b='-0.218,-0.334', iters=4), (1, 2, 3, 4)),
+        ("lin22", dict(scenario='lin', nx=2, nu=2, lin_a='-0.303,-0.627,0.346,0.384', lin_b='-0.504,0.898,0.334,-0.808', iters=4, collocation='midpoint'), (1, 2, 3, 4)),
+        ("lin31", dict(scenario='lin', nx=3, nu=1, lin_a='-0.616,0.773,0.395,-0.347,-0.03199999999999997,-0.56,-0.837,-0.68,-0.8200000000000001', lin_b='-0.07,-0.467,0.632', iters=4, grid='ms', N=14), (1, 2, 3, 4)),
+        ("lin32", dict(scenario='lin', nx=3, nu=2, lin_a='-1.113,-0.741,-0.817,0.197,0.20899999999999996,0.203,0.864,0.45,0.22099999999999997', lin_b='0.859,0.092,0.875,-0.01,-0.452,-0.096', iters=4), (1, 2, 3, 4)),
+        ("lin33", dict(scenario='lin', nx=3, nu=3, lin_a='-0.16999999999999998,-0.338,0.807,-0.486,-0.8200000000000001,-0.482,-0.289,-0.99,-0.243', lin_b='-0.435,-0.864,0.234,-0.647,-0.391,-0.118,-0.7,-0.564,-0.051', iters=4, collocation='forward', N=14), (1, 2, 3, 4)),
+        ("lin41", dict(scenario='lin', nx=4, nu=1, lin_a='-0.547,-0.49,-0.405,-0.442,-0.479,-0.534,-0.576,-0.009,-0.507,0.677,-1.1400000000000001,0.724,-0.643,0.501,0.222,-1.0819999999999999', lin_b='0.52,-0.501,-0.829,0.236', iters=4, N=16), (1, 2, 3, 4)),
         ("unicycle_n24_ball", dict(scenario="unicycle", N=24, iters=6, ball="1,0.5,0.25,0.35", tball=0.02, tball_s="1,1,0.1"), (1, 2, 3, 4, 5, 6)),
     ]:
         d = slim(run("dump", **kv), keep)
@@ -154,6 +161,7 @@ def main():
         ("loop_pendulum_rk4", dict(scenario="pendulum", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
         ("loop_duffing_euler", dict(scenario="duffing", steps=4, iters=5, shift=1, integrator="euler", disturbance=0.002)),
         ("loop_cartpole_rk4", dict(scenario="cartpole", steps=4, iters=5, shift=1, integrator="rk4", disturbance=0.002)),
+        ("loop_lin32_rk4", dict(scenario='lin', nx=3, nu=2, lin_a='-1.113,-0.741,-0.817,0.197,0.20899999999999996,0.203,0.864,0.45,0.22099999999999997', lin_b='0.859,0.092,0.875,-0.01,-0.452,-0.096', iters=4, steps=4, shift=1, integrator='rk4', disturbance=0.002)),
         ("loop_quad_rk4", dict(scenario="quad", N=10, steps=3, iters=4, shift=1, integrator="rk4", disturbance=0.002)),
     ]:
         d = run("loop", **kv)

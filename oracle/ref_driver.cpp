@@ -141,6 +141,7 @@ struct Scenario
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
+    Eigen::VectorXd lin_a, lin_b;   // scenario lin: LinearStateSpaceModel matrices, row-major (lin_a= / lin_b= with nx= / nu=)
 };
 
 // the reference's other benchmark systems (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket (3) and the cart-pole (4)
@@ -199,6 +200,19 @@ static Built build(const Scenario& s, int iterations)
     else if (s.name == "vdp")
     {
         dyn = std::make_shared<VanDerPolOscillator>();
+        if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
+    }
+    else if (s.name == "lin")   // LinearStateSpaceModel(A, B)
+    {
+        Eigen::MatrixXd A(s.nx, s.nx), B(s.nx, s.nu);
+        for (int i = 0; i < s.nx; ++i)
+        {
+            for (int j = 0; j < s.nx; ++j) A(i, j) = s.lin_a[i * s.nx + j];
+            for (int j = 0; j < s.nu; ++j) B(i, j) = s.lin_b[i * s.nu + j];
+        }
+        auto sys = std::make_shared<LinearStateSpaceModel>();
+        sys->setParameters(A, B);
+        dyn = sys;
         if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
     else if (s.name == "par2" || s.name == "par3")   // ParallelIntegratorSystem(p), time constant 1
@@ -295,15 +309,16 @@ static Built build(const Scenario& s, int iterations)
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
-    else if (s.name == "par2" || s.name == "par3")   // Q = diag(1, 0.5[, 0.2]), R = diag(0.1, 0.2[, 0.05]), Qf = 10 Q, |u_i| <= 1.5
+    else if (s.name == "par2" || s.name == "par3" || s.name == "lin")   // Q = diag(1, 0.5, 0.2, 0.1), R = diag(0.1, 0.2, 0.05), Qf = 10 Q, |u_i| <= 1.5
     {
-        Eigen::VectorXd q(s.nx), r(s.nx);
-        const double qv[3] = {1.0, 0.5, 0.2}, rv[3] = {0.1, 0.2, 0.05};
-        for (int i = 0; i < s.nx; ++i) { q[i] = qv[i]; r[i] = rv[i]; }
+        Eigen::VectorXd q(s.nx), r(s.nu);
+        const double qv[4] = {1.0, 0.5, 0.2, 0.1}, rv[3] = {0.1, 0.2, 0.05};
+        for (int i = 0; i < s.nx; ++i) q[i] = qv[i];
+        for (int i = 0; i < s.nu; ++i) r[i] = rv[i];
         Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal(), Qf = 10.0 * Q;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
-        b.ocp->setControlBounds(Eigen::VectorXd::Constant(s.nx, -1.5), Eigen::VectorXd::Constant(s.nx, 1.5));
+        b.ocp->setControlBounds(Eigen::VectorXd::Constant(s.nu, -1.5), Eigen::VectorXd::Constant(s.nu, 1.5));
     }
     else if (isZoo(s.name))   // Q = diag(1, 0.5[, 0.2]), R = 0.1, Qf = 10 Q, |u| <= 1.5
     {
@@ -447,6 +462,18 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         s.x0 = Eigen::Vector2d(1, 0);
         s.xf = Eigen::Vector2d(0, 0);
     }
+    else if (s.name == "lin")
+    {
+        s.nx = kv.count("nx") ? atoi(kv["nx"].c_str()) : 2;
+        s.nu = kv.count("nu") ? atoi(kv["nu"].c_str()) : 1;
+        s.N = 24; s.dt = 0.1;
+        s.w_eq = s.w_ineq = s.w_b = 5;
+        s.x0 = Eigen::VectorXd::Zero(s.nx);
+        s.xf = Eigen::VectorXd::Constant(s.nx, 0.5);
+        s.lin_a = vec(kv["lin_a"]);
+        s.lin_b = vec(kv["lin_b"]);
+        if (s.lin_a.size() != s.nx * s.nx || s.lin_b.size() != s.nx * s.nu) { fprintf(stderr, "lin: lin_a / lin_b sizes\n"); exit(1); }
+    }
     else if (s.name == "par2" || s.name == "par3")
     {
         s.nx = s.nu = (s.name == "par2") ? 2 : 3; s.N = 24; s.dt = 0.1;
@@ -530,6 +557,7 @@ static int dump(const Scenario& s)
            s.N, s.dt, s.iters, s.solves);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.vargrid) printf("\"vargrid\": 1,\n");
@@ -689,6 +717,7 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters0\": %d, \"iters\": %d, \"shift\": %d,\n", s.name.c_str(),
            s.nx, s.nu, s.N, s.dt, iters0, s.iters, shift ? 1 : 0);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
+    if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);
     printf("\"steps\": [\n");
     Eigen::VectorXd x0 = s.x0;
@@ -756,6 +785,7 @@ static int loop(const Scenario& s, std::map<std::string, std::string>& kv)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters\": %d, \"shift\": %d, \"integrator\": \"%s\", \"disturbance\": %.17g,\n",
            s.name.c_str(), s.nx, s.nu, s.N, s.dt, s.iters, shift ? 1 : 0, integ.c_str(), amp);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
+    if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);
     printf("\"steps\": [\n");
     for (int st = 0; st < steps; ++st)

@@ -40,6 +40,10 @@ def desc_for(g):
         return problems.quad_desc(N=g["N"], dt=g["dt"])
     if sc == "int3":
         d = problems.int3_desc(N=g["N"], dt=g["dt"], defect=defect, time_optimal=bool(g.get("vargrid")))
+    elif sc == "lin":
+        import numpy as np
+        d = problems.linear_desc(np.array(g["lin_a"]).reshape(g["nx"], g["nx"]), np.array(g["lin_b"]).reshape(g["nx"], g["nu"]),
+                                 N=g["N"], dt=g["dt"], defect=defect)
     elif sc in ("par2", "par3"):
         d = problems.parallel_integrator_desc(int(sc[-1]), N=g["N"], dt=g["dt"], defect=defect)
     elif sc in problems.BENCHMARK_SYSTEMS:

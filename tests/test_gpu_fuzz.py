@@ -23,7 +23,7 @@ ZOO = sorted(problems.BENCHMARK_SYSTEMS)   # the reference's other benchmark sys
 
 
 def random_desc(rng, long_horizon=False):
-    fam = rng.choice(["vdp", "unicycle", "dint", "int3", "int3t", "par2", "par3"] + ZOO)
+    fam = rng.choice(["vdp", "unicycle", "dint", "int3", "int3t", "par2", "par3", "lin"] + ZOO)
     N = int(rng.integers(100, 257)) if long_horizon else int(rng.integers(3, 70))
     dt = float(rng.uniform(0.05, 0.2))
     if fam in ("dint", "int3t"):   # time-optimal, free dt (arrowhead)
@@ -36,7 +36,10 @@ def random_desc(rng, long_horizon=False):
             for i in range(nx):
                 d.qf_diag[i] = float(rng.uniform(0.5, 5.0))
     else:
-        if fam in ("par2", "par3"):
+        if fam == "lin":   # LinearStateSpaceModel with random matrices, every (nx, nu) block family
+            nxl, nul = [(2, 1), (2, 2), (3, 1), (3, 2), (3, 3), (4, 1)][int(rng.integers(0, 6))]
+            d = problems.linear_desc(rng.uniform(-1, 1, (nxl, nxl)) - 0.3 * np.eye(nxl), rng.uniform(-1, 1, (nxl, nul)), N=N, dt=dt)
+        elif fam in ("par2", "par3"):
             d = problems.parallel_integrator_desc(int(fam[-1]), N=N, dt=dt)
             d.dyn_params[0] = float(rng.uniform(0.5, 2.0))
         elif fam in ZOO:

@@ -10,7 +10,7 @@ from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
 
 pytestmark = pytest.mark.gpu
 
-LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4"]
+LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4", "loop_lin32_rk4"]
 
 
 def integrator_of(g):
@@ -18,12 +18,17 @@ def integrator_of(g):
 
 
 @pytest.mark.parametrize("scenario,N", [("vdp", 20), ("int3", 20), ("unicycle", 30), ("quad", 10), ("duffing", 12), ("rocket", 12), ("pendulum", 12),
-                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12), ("cartpole", 12), ("par2", 12), ("par3", 12)])
+                                        ("mpendulum", 12), ("toy", 12), ("artstein", 12), ("cartpole", 12), ("par2", 12), ("par3", 12), ("lin32", 12), ("lin41", 12)])
 @pytest.mark.parametrize("integrator", [capi.INTEGRATOR_EULER, capi.INTEGRATOR_RK4])
 def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
     """Per instance: x+ = integrator(x, u_0 of the resident trajectory, dt) + disturbance, same operations as the oracle -- bit for
     bit for the polynomial dynamics, to the last ulps of the device's sin / cos otherwise."""
-    d = problems.SCENARIOS[scenario][0](N=N)
+    if scenario.startswith("lin"):
+        nxl, nul = int(scenario[3]), int(scenario[4])
+        r0 = np.random.default_rng(5)
+        d = problems.linear_desc(r0.uniform(-1, 1, (nxl, nxl)), r0.uniform(-1, 1, (nxl, nul)), N=N)
+    else:
+        d = problems.SCENARIOS[scenario][0](N=N)
     B = 6
     rng = np.random.default_rng(7)
     p = oracle_mod.OracleProblem(d)
@@ -44,7 +49,7 @@ def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
         for b in range(B):
             p.set_data(X[b])
             xp[b] = p.plant_step(xp[b], integrator, dt, None if dd is None else dd[b])
-        if scenario in ("vdp", "int3", "duffing", "rocket", "toy", "artstein", "par2", "par3"):
+        if scenario in ("vdp", "int3", "duffing", "rocket", "toy", "artstein", "par2", "par3", "lin32", "lin41"):
             assert np.array_equal(got, xp), (scenario, rep)
         else:
             assert np.abs(got - xp).max() <= 1e-14 * max(1.0, np.abs(xp).max()), (scenario, rep)
