@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- SQP(=LM outer)-iterations/s of the MI355X-native NLP inner loop on the BASELINE headline config.
+"""bench.py -- SQP(=LM outer)-iterations/s of the MI355X-native NLP inner loop on the BASELINE configurations.
 
-Workload (BASELINE.json configs[2]): unicycle point-to-point OCP, nx=3 nu=2, FiniteDifferencesGrid N=100,
-Crank-Nicolson, fp64, batch=1024 independent seeded instances PER GPU, 10 LM iterations per solve (reference default,
-no early exit).  One "step" = one corbo_hip_solve of the whole resident batch (= batch x 10 SQP iterations), preceded
-by a device-to-device re-arm of the initial trajectories (inputs are resident in HBM before the timed region starts).
+Default workload (BASELINE.json configs[2], SURVEY.md 8d, the one the metric is quoted on): unicycle point-to-point OCP, nx=3 nu=2,
+FiniteDifferencesGrid N=100, Crank-Nicolson, fp64, batch=1024 independent seeded instances PER GPU, 10 LM iterations per solve
+(reference default, no early exit).  One "step" = device-to-device re-arm of the initial trajectories (inputs are resident in HBM
+before the timed region starts) + one corbo_hip_solve of the whole resident batch (= batch x 10 SQP iterations) + the results
+(trajectories, chi2, status) copied into host-visible pinned memory ("to last result resident on host-visible memory").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iterations I]
+    python bench.py [--config 1|2|3|5] [--gpus N] [--steps K] [--warmup W] [--batch B] [--iterations I]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+--config selects another BASELINE.json configuration (parity-test cases; their lines are diagnostics, the driver's line is config 3):
+  1  Van-der-Pol, FiniteDifferencesGrid N=20, batch 1           (configs[0]: plumbing; single-OCP latency through the boundary)
+  2  double integrator, time-optimal, variable grid N=50, batch 1, 5 solves per step (configs[1]: single-OCP latency)
+  5  quadrotor nx=12 nu=4, multiple shooting N=200 + RK4, batch 512 (configs[4]: big-block family, fp64 MFMA factorisation)
+
 Rank 0 prints ONE JSON line.  Multi-GPU: the batch is the sharding unit (independent OCPs, no data-path collective);
-every rank solves its own `batch` instances (weak scaling), RCCL is used only for the barrier, the max-over-ranks time and
-the reduction of the solution statistics.
+every rank solves its own `batch` instances (weak scaling), RCCL is used only for the barrier, the max-over-ranks time, the
+per-rank times and the reduction of the solution statistics.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
 import subprocess
@@ -29,8 +37,49 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBS = 8000.0      # MI355X HBM3E (MI355X_MICROARCH.md)
+PEAK_F64_MFMA_TFLOPS = 78.6  # gfx950 dense fp64 matrix peak
 
-def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
+
+def workload(cfg: int, batch: int, first: int = 0):
+    """(name, descriptor, weights, x0, xf, solves per step, ref_driver scenario, default batch) of a BASELINE configuration."""
+    from control_box_rst_amd import problems
+    if cfg == 3:
+        d = problems.unicycle_desc()
+        x0, xf = problems.unicycle_instances(batch, first=first)
+        return dict(name="configs[2]: unicycle point-to-point nx=3 nu=2, FiniteDifferencesGrid N=100 Crank-Nicolson", desc=d,
+                    weights=problems.UNICYCLE_WEIGHTS, x0=x0, xf=xf, solves=1, scenario="unicycle")
+    if cfg == 5:
+        d = problems.quad_desc()
+        x0, xf = problems.quad_instances(batch, first=first)
+        return dict(name="configs[4]: quadrotor nx=12 nu=4, MultipleShootingGrid N=200 RK4, u box + keep-out ball per stage", desc=d,
+                    weights=problems.QUAD_WEIGHTS, x0=x0, xf=xf, solves=1, scenario="quad")
+    if cfg == 2:
+        d = problems.dint_desc()
+        rng = np.random.default_rng(20260928 + first)
+        x0 = np.zeros((batch, 2))
+        xf = np.tile([1.0, 0.0], (batch, 1))
+        if batch > 1:
+            x0[1:] = rng.uniform(-0.1, 0.1, (batch - 1, 2))
+        return dict(name="configs[1]: double integrator time-optimal, FiniteDifferencesVariableGrid N=50, x_f fixed, MinimumTime", desc=d,
+                    weights=problems.DINT_WEIGHTS, x0=x0, xf=xf, solves=5, scenario="dint")
+    if cfg == 1:
+        d = problems.vdp_desc()
+        rng = np.random.default_rng(20260928 + first)
+        x0 = np.tile([1.0, 0.0], (batch, 1))
+        if batch > 1:
+            x0[1:] += rng.uniform(-0.5, 0.5, (batch - 1, 2))
+        return dict(name="configs[0]: Van-der-Pol regulator, FiniteDifferencesGrid N=20", desc=d, weights=problems.VDP_WEIGHTS, x0=x0,
+                    xf=np.zeros((batch, 2)), solves=1, scenario="vdp")
+    raise SystemExit(f"unknown --config {cfg}")
+
+
+DEFAULT_BATCH = {1: 1, 2: 1, 3: 1024, 5: 512}
+REF_SAMPLE = {1: 2000, 2: 400, 3: 512, 5: 1}       # instances of the genuine reference's bounded sample (10-30 s of CPU work)
+PORT_SAMPLE = {1: 4000, 2: 1000, 3: 256, 5: 64}
+
+
+def cpu_baseline(cfg, w, opts, seconds_budget=20.0):
     """Reference CPU path timed on this box's host cores (rank 0, bounded sample of the same seeded workload).
 
     kind="reference": the genuine control_box_rst LevenbergMarquardtSparse path (oracle/_ref/ref_driver, compiled from the
@@ -38,26 +87,42 @@ def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
     The C restatement (oracle/, kind="port", static sparsity pattern) is timed next to it and reported as `port_value`.
     """
     from oracle import oracle as O
+    desc, solves = w["desc"], w["solves"]
+    x0, xf = w["x0"], w["xf"]
+    if len(x0) < max(REF_SAMPLE[cfg], PORT_SAMPLE[cfg]):   # batch-1 configurations: the sample is more instances of the same family
+        big = workload(cfg, max(REF_SAMPLE[cfg], PORT_SAMPLE[cfg]))
+        x0, xf = big["x0"], big["xf"]
     out = {}
     # --- port: oracle/liboracle.so, 1 thread
     p = O.OracleProblem(desc)
-    n_port = min(len(x0), 256)
+    n_port = min(len(x0), PORT_SAMPLE[cfg])
     X = np.stack([p.init_trajectory(x0[b], xf[b]) for b in range(n_port)])
     t0 = time.perf_counter()
     done = 0
-    for lo in range(0, n_port, 32):
-        hi = min(n_port, lo + 32)
-        O.solve_batch(desc, X[lo:hi], xf[lo:hi], opts)
-        done = hi
-        if time.perf_counter() - t0 > seconds_budget / 2:
-            break
+    chunk = max(1, n_port // 8)
+    if solves == 1:
+        for lo in range(0, n_port, chunk):
+            hi = min(n_port, lo + chunk)
+            O.solve_batch(desc, X[lo:hi], xf[lo:hi], opts)
+            done = hi
+            if time.perf_counter() - t0 > seconds_budget / 2:
+                break
+    else:
+        for b in range(n_port):
+            q = O.OracleProblem(desc)
+            q.set_data(X[b], xref=xf[b])
+            for i in range(solves):
+                q.solve(opts, new_run=(i == 0))
+            done = b + 1
+            if time.perf_counter() - t0 > seconds_budget / 2:
+                break
     t_port = time.perf_counter() - t0
-    port_value = done * opts.iterations / t_port
+    port_value = done * opts.iterations * solves / t_port
     out["port_value"] = port_value
-    out["port_sample"] = f"{done} seeded instances x {opts.iterations} LM iterations, oracle/liboracle.so, 1 thread"
-    # --- port on all host cores: one worker process per core, started together (oracle/port_worker.py)
+    out["port_sample"] = f"{done} seeded instances x {solves} solve(s) x {opts.iterations} LM iterations, oracle/liboracle.so, 1 thread"
+    # --- port on all host cores: one worker process per core, started together (oracle/port_worker.py; headline config only)
     cores = min(os.cpu_count() or 1, 128)
-    if cores > 1:
+    if cfg == 3 and cores > 1:
         per = 1024
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "port_worker.py"), str(i * per), str(per), str(opts.iterations)],
                                   stdout=subprocess.PIPE) for i in range(cores)]
@@ -74,16 +139,17 @@ def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
     # --- genuine reference, 1 thread
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(drv) and os.access(drv, os.X_OK):
-        n_ref = min(len(x0), 512)  # ~15 s of reference CPU work
+        n_ref = min(len(x0), REF_SAMPLE[cfg])
         with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
             np.savetxt(f, np.hstack([x0[:n_ref], xf[:n_ref]]), fmt="%.17g")
             path = f.name
         try:
-            r = json.loads(subprocess.check_output([drv, "bench", "scenario=unicycle", f"instances={path}", f"iters={opts.iterations}",
-                                                    f"N={desc.N}"], timeout=300))
+            r = json.loads(subprocess.check_output([drv, "bench", f"scenario={w['scenario']}", f"instances={path}", f"iters={opts.iterations}",
+                                                    f"solves={solves}", f"N={desc.N}"], timeout=600))
             out.update({"value": r["iter_per_s"], "unit": "SQP-iterations/s", "cores": 1, "kind": "reference",
-                        "sample": f"{r['batch']} seeded instances x {opts.iterations} LM iterations = {r['solve_seconds']:.2f} s of "
-                                  "LevenbergMarquardtSparse::solve (genuine reference, oracle/_ref/ref_driver), 1 thread"})
+                        "sample": f"{r['batch']} seeded instance(s) x {solves} solve(s) x {opts.iterations} LM iterations = {r['solve_seconds']:.2f} s of "
+                                  "LevenbergMarquardtSparse::solve (genuine reference, oracle/_ref/ref_driver), 1 thread",
+                        "ms_per_ocp": 1e3 * r["solve_seconds"] / r["batch"]})
         finally:
             os.unlink(path)
     if "value" not in out:
@@ -91,16 +157,46 @@ def cpu_baseline(desc, opts, x0, xf, seconds_budget=20.0):
     return out
 
 
+def profile_kernel_avg_ns(pattern, kernel_substr):
+    """Average duration [ns] of a kernel in the committed rocprofv3 --kernel-trace --stats summary (profiles/), or None."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            for r in csv.DictReader(open(path)):
+                if kernel_substr in r.get("Name", ""):
+                    return float(r["AverageNs"]), int(r["Calls"]), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None
+
+
+def load_profile_json(name, batch, N):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            j = json.load(open(path))
+            if j.get("batch") == batch and j.get("N") == N:
+                return j
+        except Exception:
+            pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="OCP instances per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=(1, 2, 3, 5))
+    ap.add_argument("--batch", type=int, default=None, help="OCP instances per GPU")
     ap.add_argument("--iterations", type=int, default=10, help="LM outer iterations per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spinup", type=int, default=0, help="untimed sweep launches before the warm-up steps")
+    ap.add_argument("--no-sink", action="store_true", help="results via D2H copies after the solve instead of the kernel-written pinned sink")
+    ap.add_argument("--solve-only", action="store_true", help="profiling: only warm-up + timed steps (no roofline / host legs)")
     args = ap.parse_args()
+    cfg = args.config
+    batch = args.batch if args.batch is not None else DEFAULT_BATCH[cfg]
+    steps = args.steps if args.steps is not None else {1: 300, 2: 200, 3: 100, 5: 20}[cfg]
+    warmup = args.warmup if args.warmup is not None else {1: 20, 2: 20, 3: 10, 5: 3}[cfg]
 
     import torch
 
@@ -131,21 +227,27 @@ def main():
         entry.build()
     if dist is not None:
         dist.barrier()
-    from control_box_rst_amd import problems, sharding
+    from control_box_rst_amd import sharding
     from control_box_rst_amd.solver import BatchedLevenbergMarquardt
 
-    desc = problems.unicycle_desc()
-    first, B = sharding.shard_bounds(args.batch * world, world, rank)  # weak scaling: `batch` instances per GPU
-    x0, xf = problems.unicycle_instances(B, first=first)               # rank r owns global instances [first, first+B)
+    first, B = sharding.shard_bounds(batch * world, world, rank)  # weak scaling: `batch` instances per GPU
+    w = workload(cfg, B, first=first)                             # rank r owns global instances [first, first+B)
+    desc, x0, xf, solves = w["desc"], w["x0"], w["xf"], w["solves"]
     solver = BatchedLevenbergMarquardt(desc, B, device=local_rank)
     solver.setIterations(args.iterations)
-    solver.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    solver.setPenaltyWeights(*w["weights"])
     X0 = solver.init_trajectory(x0, xf)
     solver.set_instance_data(X0, xref=xf)  # H2D once; everything below runs on HBM-resident data
 
-    def step():
+    use_sink = not args.no_sink
+    solver.set_result_sink(use_sink)   # the solve kernel writes each finished instance's results into pinned host memory itself
+
+    def step(fetch=True):
         solver.restore_instance_data()
-        solver.solve(new_run=True)
+        for i in range(solves):
+            solver.solve(new_run=(i == 0))
+        if fetch:
+            return solver.fetch_solution()   # trajectories, chi2, status -> pinned host memory (inside the timed region)
 
     def fence():
         solver.synchronize()
@@ -154,99 +256,146 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # optional untimed sweep launches before the warm-up steps (diagnostics; A/B-measured: no effect on the timed region.  The 26 ms
-    # solves once seen after host-side set-up were the runtime releasing the pages of a pageable upload -- the boundary now stages
-    # through pinned memory)
-    if args.spinup > 0:
-        solver.time_sweep(with_jacobian=True, repeat=args.spinup)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
+    solver.get_timing(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    solve_ms_sum, n_solves = solver.get_timing(reset=True)
 
-    stats = solver.get_stats()
+    stats = solver.get_stats()                    # statistics of the LAST solve of a step
     X, chi2, status = solver.get_solution()
     t_max = sharding.reduce_max(elapsed, dist, device=red_dev)                       # MAX over ranks (RCCL)
+    t_ranks = sharding.gather_scalars(elapsed, dist, device=red_dev)                 # every rank's own time (straggler visibility)
     red = sharding.reduce_stats(stats, float(chi2.sum()), int((status <= 1).sum()), dist, device=red_dev)  # SUM over ranks
-    total_iters_per_step = red["lm_iterations"]  # = world * batch * iterations
-    value = total_iters_per_step * args.steps / t_max
+    total_iters_per_step = red["lm_iterations"] * solves  # = world * batch * iterations * solves
+    value = total_iters_per_step * steps / t_max
 
-    # ---- roofline leg: the edge/Jacobian sweep kernel, timed with HIP events on the solver's own stream
+    line = {
+        "metric": "SQP-iterations/sec over batch=1024 OCPs (nx=3,nu=2,N=100,fp64)",
+        "value": value,
+        "unit": "SQP-iterations/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * t_max / steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{w['name']}, batch={B} per GPU, {solves} solve(s) x {args.iterations} LM iterations per step, seeds 20260928+i",
+                   "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations, "solves_per_step": solves,
+                   "parallelism": f"batch-sharded x{world}"},
+        "timed_region": "re-arm (D2D) + corbo_hip_solve + trajectories/chi2/status resident in pinned host memory ("
+                        + ("written by the solve kernel as each instance finishes, corbo_hip_set_result_sink" if use_sink else "two D2H copies behind the solve")
+                        + ", views from corbo_hip_fetch_solution); wall clock, barrier + synchronize on both sides, MAX over ranks",
+        "batch_steps_per_s": value / (B * world),
+        "ms_per_step_ranks": [1e3 * t / steps for t in t_ranks],
+        "solve_stats": {"passes_rank0": stats["passes"], "lm_iterations": int(red["lm_iterations"]),
+                        "accepted": int(red["accepted_steps"]), "rejected": int(red["rejected_steps"]),
+                        "factorizations": int(red["factorizations"]), "chi2_sum": red["chi2_sum"],
+                        "ok_instances": int(red["ok_instances"])},
+    }
+    if args.solve_only:
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- the same steps with the results left in HBM (what a device-resident caller -- the closed loop, an RCCL gather -- sees)
+    solver.set_result_sink(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(fetch=False)
+    fence()
+    t_res = sharding.reduce_max(time.perf_counter() - t0, dist, device=red_dev)
+    line["results_left_in_hbm"] = {"ms_per_step": 1e3 * t_res / steps, "value": total_iters_per_step * steps / t_res}
+
+    # ---- roofline of the kernel that dominates the timed region
     dims = solver.dims
-    b_sweep = 8 * (dims.nv + 2 * dims.n + dims.m + dims.nnz)  # SURVEY 8d algorithmic bytes per instance per sweep
-    sweep_ms = solver.time_sweep(with_jacobian=True, repeat=50)
-    achieved = B * b_sweep / (sweep_ms * 1e-3) / 1e9
-    peak = 8000.0  # GB/s, MI355X HBM3E (MI355X_MICROARCH.md)
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "sweep_pmc_latest.json")  # written by tools/summarize_pmc.py from a rocprofv3 --pmc run
-    if os.path.exists(pmc):
-        try:
-            j = json.load(open(pmc))
-            if j.get("batch") == B and j.get("N") == desc.N:
-                traffic, traffic_src = j["hbm_bytes_per_launch"], j["source"]
-        except Exception:
-            pass
-    # the boundary takes HOST buffers: one-shot rate including the upload of trajectories / bounds / references over PCIe, the solve
-    # and the download of trajectories, chi2 and status (never `value`; a moving-horizon caller keeps the trajectories resident and
-    # uploads only the measured states, corbo_hip_warm_start)
-    t_h = time.perf_counter()
-    for _ in range(5):
-        solver.set_instance_data(X0, xref=xf)
-        solver.solve(new_run=True)
-        solver.get_solution()
-    host_ms = (time.perf_counter() - t_h) / 5 * 1e3
+    b_sweep = 8 * (dims.nv + 2 * dims.n + dims.m + dims.nnz)  # SURVEY 8d algorithmic bytes per instance per residual + Jacobian sweep
+    b_val = 8 * (dims.nv + 2 * dims.n + dims.m)               # residual-only (trial step) sweep
+    sweeps_j, sweeps_r = stats["jacobian_sweeps"], stats["residual_sweeps"]   # this rank, one solve
+    alg_solve = sweeps_j * b_sweep + max(0, sweeps_r - sweeps_j) * b_val
+    launch_ms = solve_ms_sum / max(1, n_solves)               # HIP events on the handle's stream, every solve of the timed region
+    if cfg != 5:
+        # run-to-completion families: ONE launch per solve (lm_pass_kernel); its bytes = what the reference's algorithm moves for the
+        # same sweeps: sweeps_j x (read vertices + bounds, write residual + Jacobian) + trial sweeps x (read vertices + bounds, write residual)
+        achieved = alg_solve / (launch_ms * 1e-3) / 1e9
+        pmc = load_profile_json("r02_solve_pmc.json", B, desc.N)
+        prof = profile_kernel_avg_ns("r02_bench_kernel_stats.csv", "lm_pass_kernel")
+        line["roofline"] = {"bound": "hbm", "kernel": "lm_pass_kernel (run-to-completion: prologue sweep + every LM pass of every instance, one launch per solve)",
+                            "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                            "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
+                            "bytes_per_launch": alg_solve, "ms_per_launch": launch_ms, "launches_timed": n_solves,
+                            "jacobian_sweeps": int(sweeps_j), "residual_sweeps": int(sweeps_r),
+                            "timing": "HIP events on the handle's stream around every launch of the timed region (corbo_hip_get_timing)",
+                            "profile_avg_ms": prof[0] * 1e-6 if prof else None, "profile": prof[2] if prof else None,
+                            "frac_from_profile": (alg_solve / (prof[0] * 1e-9) / 1e9 / PEAK_HBM_GBS) if (prof and B == 1024 and cfg == 3) else None,
+                            "note": "a latency chain per instance (DESIGN.md 3.3), priced against HBM because its algorithmic work is the sweep traffic"}
+    # ---- the stand-alone edge/Jacobian sweep (north star: ">= 40 % of the HBM roofline on the Jacobian sweep")
+    each = solver.time_sweep_each(with_jacobian=True, repeat=50)        # one event pair per launch (what a kernel trace reports)
+    b2b_ms = solver.time_sweep(with_jacobian=True, repeat=50)            # back-to-back launches, one event pair around all of them
+    sweep_ms = float(np.mean(each))
+    prof = profile_kernel_avg_ns("r02_sweep_kernel_stats.csv", "sweep_kernel")
+    spmc = load_profile_json("sweep_pmc_latest.json", B, desc.N)
+    rs = {"bound": "hbm", "kernel": "sweep_kernel (residual + Jacobian of every instance, stand-alone launch)",
+          "achieved": B * b_sweep / (sweep_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+          "frac": B * b_sweep / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+          "traffic": spmc["hbm_bytes_per_launch"] if spmc else None, "traffic_source": spmc["source"] if spmc else None,
+          "bytes_per_launch": B * b_sweep, "ms_per_launch": sweep_ms, "ms_per_launch_min": float(each.min()), "ms_per_launch_max": float(each.max()),
+          "timing": "50 launches, each bracketed by its own HIP event pair on the handle's stream (corbo_hip_time_sweep_each)",
+          "back_to_back": {"ms_per_launch": b2b_ms, "frac": B * b_sweep / (b2b_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                           "what": "50 launches between ONE event pair: the next launch's ramp-up overlaps the previous one's store drain"},
+          "profile_avg_ms": prof[0] * 1e-6 if prof else None, "profile": prof[2] if prof else None}
+    if cfg == 5:
+        line["roofline"] = rs
+    else:
+        line["roofline_sweep"] = rs
     # per-kernel split inside one solve (separate, profiled solve: event stamping is kept out of the timed region)
     solver.set_profiling(True)
-    step()
-    prof = solver.get_stats()
+    step(fetch=False)
+    prof_stats = solver.get_stats()
     solver.set_profiling(False)
-
+    line["kernel_split_ms"] = {"solve": prof_stats["solve_ms"], "sweep": prof_stats["sweep_ms"], "factor": prof_stats["factor_ms"],
+                               "what": "one solve with the phases as separate launches (per-pass mode), HIP events between them"}
+    if cfg == 5:
+        # block factorisation on the fp64 matrix cores: SURVEY 8d algorithmic flops per instance per factorisation
+        s_blk, nb = desc.nx + desc.nu, desc.N - 1
+        flops_fact = (7.0 / 3.0) * s_blk ** 3 * nb + 8.0 * s_blk ** 2 * nb + 2.0 * desc.nx * (2 * desc.nx + desc.nu) ** 2 * nb
+        n_fact = stats["factorizations"]
+        mf = load_profile_json("r02_cfg5_mfma.json", B, desc.N)
+        line["factorization"] = {"bound": "mfma", "algorithmic_flops_per_instance": flops_fact, "factorizations_per_solve": int(n_fact),
+                                 "factor_ms_per_solve": prof_stats["factor_ms"],
+                                 "achieved_TFLOPs": (n_fact * flops_fact / (prof_stats["factor_ms"] * 1e-3) / 1e12) if prof_stats["factor_ms"] > 0 else None,
+                                 "peak_TFLOPs": PEAK_F64_MFMA_TFLOPS, "mfma_counters": mf}
+    # the boundary takes HOST buffers: one-shot rate including the upload of trajectories / references over PCIe, the solve(s)
+    # and the download of trajectories, chi2 and status into the caller's arrays (never `value`)
+    fence()
+    n_h = 5 if B >= 64 else 50
+    t_h = time.perf_counter()
+    for _ in range(n_h):
+        solver.set_instance_data(X0, xref=xf)
+        for i in range(solves):
+            solver.solve(new_run=(i == 0))
+        solver.get_solution()
+    host_ms = (time.perf_counter() - t_h) / n_h * 1e3
+    line["host_inclusive"] = {"ms_per_step": host_ms, "value_rank0": B * args.iterations * solves / (host_ms * 1e-3),
+                              "what": "set_instance_data (H2D of x, xref from pageable host memory) + solve(s) + get_solution (D2H into caller arrays), rank 0"}
     if rank == 0:
-        line = {
-            "metric": "SQP-iterations/sec over batch=1024 OCPs (nx=3,nu=2,N=100,fp64)",
-            "value": value,
-            "unit": "SQP-iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * t_max / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "configs[2]: unicycle point-to-point nx=3 nu=2, FiniteDifferencesGrid N=100 Crank-Nicolson, "
-                                   f"batch={B} per GPU, {args.iterations} LM iterations per solve, seeds 20260928+i",
-                       "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations,
-                       "parallelism": f"batch-sharded x{world}"},
-            "batch_steps_per_s": value / (B * world),
-            "solve_stats": {"passes_rank0": stats["passes"], "lm_iterations": int(red["lm_iterations"]),
-                            "accepted": int(red["accepted_steps"]), "rejected": int(red["rejected_steps"]),
-                            "factorizations": int(red["factorizations"]), "chi2_sum": red["chi2_sum"],
-                            "ok_instances": int(red["ok_instances"])},
-            "kernel_split_ms": {"solve": prof["solve_ms"], "sweep": prof["sweep_ms"], "factor": prof["factor_ms"]},
-            "roofline": {"bound": "hbm", "kernel": "sweep_kernel (residual + Jacobian, all instances)", "achieved": achieved,
-                         "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": B * b_sweep, "ms_per_launch": sweep_ms},
-        }
-        # the solve as a whole (one run-to-completion launch): what the reference's algorithm would move through memory for the same
-        # sweeps (residual + Jacobian sweeps at B_sweep, residual-only trial sweeps at 8 (n_vert + 2n + m) bytes), against the time
-        b_val = 8 * (dims.nv + 2 * dims.n + dims.m)
-        sweeps_j, sweeps_r = red["jacobian_sweeps"], red["residual_sweeps"]
-        alg_solve = sweeps_j * b_sweep + max(0.0, sweeps_r - sweeps_j) * b_val
-        line["solve_kernel"] = {"kernel": "lm_pass_kernel (run-to-completion: prologue + all LM passes of every instance, one launch)",
-                                "bound": "latency (dependent instruction issue of one instance; DESIGN.md 3.3)",
-                                "algorithmic_bytes_per_solve": alg_solve, "achieved_GBs": alg_solve / (t_max / args.steps) / 1e9,
-                                "frac_of_hbm_peak": alg_solve / (t_max / args.steps) / 1e9 / peak,
-                                "jacobian_sweeps": int(sweeps_j), "residual_sweeps": int(sweeps_r)}
-        line["host_inclusive"] = {"ms_per_step": host_ms, "value_rank0": stats["lm_iterations"] / (host_ms * 1e-3),
-                                  "what": "set_instance_data (H2D of x, bounds, xref from pageable host memory) + solve + get_solution (D2H), rank 0"}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(desc, solver.opts, x0, xf)
+            cb = cpu_baseline(cfg, w, solver.opts)
+            line["cpu_baseline"] = cb
+            if "ms_per_ocp" in cb:
+                line["cpu_baseline"]["gpu_ms_per_ocp_batch1_equivalent"] = host_ms if B == 1 else None
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -118,6 +118,9 @@ struct corbo_hip_solver {
     double* h_loop = nullptr; size_t h_loop_doubles = 0;
     double* d_loop = nullptr; size_t d_loop_doubles = 0;
     LmState* h_state = nullptr;      // pinned [batch] read-back of the per-instance LM state (get_solution / get_stats)
+    double* h_chi2   = nullptr;      // pinned [batch] chi2 + [batch] status (int32) of corbo_hip_fetch_solution
+    double solve_ms_sum = 0.0;       // HIP-event time of every corbo_hip_solve since the last reset (corbo_hip_get_timing)
+    int64_t solve_count = 0;
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
@@ -133,6 +136,8 @@ struct corbo_hip_solver {
     bool profile = false;
     bool force_split = false;   // descriptor family without a fused pass kernel
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
+    bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
+    bool sink_valid  = false;   // ... and the last solve did so
     bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
     // the 8 model parameters as the kernels see them: the descriptor's, except for the linear state-space model, whose first slot
@@ -298,6 +303,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipHostMalloc((void**)&h->h_xnew, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_stage, B * (size_t)(S.nvs > CORBO_HIP_MAX_NX ? S.nvs : CORBO_HIP_MAX_NX) * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_state, B * sizeof(LmState)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_chi2, B * (sizeof(double) + sizeof(int32_t))));
     CREATE_TRY(hipHostMalloc((void**)&h->h_dist, B * CORBO_HIP_MAX_NX * sizeof(double)));
     if (S.desc.dynamics == CORBO_HIP_DYN_LINEAR_STATE_SPACE) {
         std::vector<double> ab((size_t)S.nx * S.nx + (size_t)S.nx * S.nu);
@@ -371,6 +377,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     if (h->h_xnew) (void)hipHostFree(h->h_xnew);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_chi2) (void)hipHostFree(h->h_chi2);
     if (h->h_dist) (void)hipHostFree(h->h_dist);
     if (h->h_loop) (void)hipHostFree(h->h_loop);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -389,6 +396,7 @@ int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const doubl
 try {
     if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     const int nv = S.dims.nv, nvs = S.nvs, B = h->batch;
     // Repack the public vertex layout (nv per row) into the device vertex storage (nvs per row: + fixed dt + padding) through the
@@ -464,6 +472,7 @@ try {
     ON_DEVICE_OF(h);
     update_penalty_weights(h, o, new_run);
     h->stats = corbo_hip_stats{};
+    h->sink_valid = false;
     EventList ev_list;
     std::vector<hipEvent_t>& evs = ev_list.v;
     auto stamp = [&]() {
@@ -536,6 +545,8 @@ try {
             fp.batch = sp.batch = count_of[i];
             fp.inst0 = sp.inst0 = first_of[i];
             fp.loop_passes = MAX_PASSES;
+            if (h->result_sink) { fp.x_host = h->h_stage; fp.st_host = h->h_state; }
+            if (const char* wr = std::getenv("CORBO_HIP_WAVE_ROT")) fp.wave_rot = std::atoi(wr);
             if (const char* lim = std::getenv("CORBO_HIP_PASS_LIMIT"))   // tests: provoke the "pass limit reached" error path
                 if (std::atoi(lim) > 0 && std::atoi(lim) < MAX_PASSES) fp.loop_passes = std::atoi(lim);
             // an instance that runs into the pass limit raises a flag in pinned, device-visible host memory: no memset, no read-back
@@ -615,6 +626,8 @@ try {
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));
+    h->solve_ms_sum += h->stats.solve_ms;
+    h->solve_count += 1;
     if (run_to_completion) {
         remaining = 0;
         for (int i = 0; i < nsub; ++i) remaining += h->h_counter[2 * i];
@@ -631,15 +644,25 @@ try {
         }
     }
     if (remaining > 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    h->sink_valid = run_to_completion && h->result_sink;
     return CORBO_HIP_OK;
 }
 ABI_CATCH
+
+int corbo_hip_set_result_sink(corbo_hip_handle h, int enable)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    h->result_sink = enable != 0;
+    h->sink_valid  = false;
+    return CORBO_HIP_OK;
+}
 
 int corbo_hip_restore_instance_data(corbo_hip_handle h)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     HIP_TRY(hipMemcpyAsync(h->d_x, h->d_x0, (size_t)h->batch * h->S.nvs * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return CORBO_HIP_OK;
 }
@@ -662,6 +685,7 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
     if (!h || !x0_new) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     HIP_TRY(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous call has been consumed
     for (int b = 0; b < h->batch; ++b)
@@ -676,6 +700,7 @@ int corbo_hip_warm_start_from_plant(corbo_hip_handle h, int shift)
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     return warm_start_from(h, h->d_xplant, shift);
 }
 
@@ -683,6 +708,7 @@ int corbo_hip_plant_set_state(corbo_hip_handle h, const double* x)
 {
     if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int b = 0; b < h->batch; ++b)
@@ -721,6 +747,7 @@ int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out)
     if (!h || !x_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     HIP_TRY(hipMemcpyAsync(h->h_stage, h->d_xplant, (size_t)h->batch * CORBO_HIP_MAX_NX * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -740,6 +767,7 @@ try {
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     if (steps == 0) return CORBO_HIP_OK;
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     const size_t B = (size_t)h->batch, NXm = CORBO_HIP_MAX_NX;
     const size_t dist_doubles = disturbance ? (size_t)steps * B * NXm : 0;
@@ -813,6 +841,7 @@ int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
     if (!h || !u0_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     // a small kernel packs u_0 of every instance straight into the pinned (device-visible) staging buffer: no copy engine in the
     // loop of a predictive controller (waking the idle DMA engine for 16 KB cost ~0.1 ms per step)
@@ -843,6 +872,7 @@ int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, 
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     HIP_TRY(hipStreamSynchronize(h->stream));
     const Structure& S = h->S;
     const int B = h->batch;
@@ -864,10 +894,46 @@ try {
 }
 ABI_CATCH
 
+int corbo_hip_fetch_solution(corbo_hip_handle h, const double** x_pinned, int32_t* x_row_stride, const double** chi2_pinned,
+                             const int32_t** status_pinned)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    const Structure& S = h->S;
+    const int B = h->batch;
+    if (!h->sink_valid) {
+        // both copies are queued behind the solve on the handle's stream; one synchronisation
+        if (x_pinned) HIP_TRY(hipMemcpyAsync(h->h_stage, h->d_x, (size_t)B * S.nvs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (chi2_pinned || status_pinned)
+            HIP_TRY(hipMemcpyAsync(h->h_state, h->d_state, (size_t)B * sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }   // else: the solve kernel has written both itself and corbo_hip_solve has waited for it
+    if (chi2_pinned || status_pinned) {
+        int32_t* hs = reinterpret_cast<int32_t*>(h->h_chi2 + B);
+        for (int b = 0; b < B; ++b) { h->h_chi2[b] = h->h_state[b].chi2_old; hs[b] = h->h_state[b].status; }
+        if (chi2_pinned) *chi2_pinned = h->h_chi2;
+        if (status_pinned) *status_pinned = hs;
+    }
+    if (x_pinned) *x_pinned = h->h_stage;
+    if (x_row_stride) *x_row_stride = S.nvs;
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solves, int reset)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (solve_ms_sum) *solve_ms_sum = h->solve_ms_sum;
+    if (solves) *solves = h->solve_count;
+    if (reset) { h->solve_ms_sum = 0.0; h->solve_count = 0; }
+    return CORBO_HIP_OK;
+}
+
 int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
 try {
     if (!h || !stats) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyAsync(h->h_state, h->d_state, (size_t)h->batch * sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -895,6 +961,7 @@ try {
     if (!h || !values_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    h->sink_valid = false;   // the pinned result views are stale from here on
     int rc = launch_sweep_checked(h, h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr));
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -956,6 +1023,29 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     }
     return CORBO_HIP_OK;
 }
+
+int corbo_hip_time_sweep_each(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat, float* ms_each)
+try {
+    if (!h || !ms_each || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    ON_DEVICE_OF(h);
+    const SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
+    EventList evs;
+    evs.v.reserve((size_t)repeat + 1);
+    int rc = launch_sweep_checked(h, p);  // warm-up
+    if (rc) return rc;
+    for (int i = 0; i <= repeat; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        evs.v.push_back(e);
+        HIP_TRY(hipEventRecord(e, h->stream));
+        if (i < repeat) { rc = launch_sweep_checked(h, p); if (rc) return rc; }
+    }
+    HIP_TRY(hipEventSynchronize(evs.v.back()));
+    for (int i = 0; i < repeat; ++i) HIP_TRY(hipEventElapsedTime(&ms_each[i], evs.v[i], evs.v[i + 1]));
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
 
 int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, long long* timeline8)
 {

@@ -2165,7 +2165,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int inst = blockIdx.x + fp.inst0, tid = threadIdx.x;
+    const int inst = blockIdx.x + fp.inst0;
+    const int rot  = fp.wave_rot == 1 ? (blockIdx.x & 3) : (fp.wave_rot == 2 ? ((blockIdx.x >> 8) & 3) : (fp.wave_rot == 3 ? ((blockIdx.x >> 3) & 3) : 0));
+    const int tid  = (threadIdx.x + 64 * rot) & (SWEEP_THREADS - 1);
     const int NP = NPC > 0 ? NPC : (fp.N | 1);
     // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, vertex values
     // behind the factor carve, then the LM state and the sweep phase's reduction scratch + flags.  (The scratch must not live inside
@@ -2225,6 +2227,14 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
             mode = 3;
         }
         lm_state_out(fp.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM
+        if (fp.x_host) {
+            // result sink: the finished instance's accepted iterate and LM state go straight to host-visible memory (posted PCIe
+            // writes, overlapped with the instances that are still iterating) -- no copy-engine pass after the launch
+            const double2* src = reinterpret_cast<const double2*>(fp.x + (size_t)inst_v * fp.nvs);
+            double2* dst       = reinterpret_cast<double2*>(fp.x_host + (size_t)inst_v * fp.nvs);
+            for (int i = tid_v; i < fp.nvs / 2; i += SWEEP_THREADS) dst[i] = src[i];
+            lm_state_out(fp.st_host + inst_v, sl, tid_v);
+        }
         if (tid_v == 0 && !sl->done && fp.unfinished_flag) *(volatile int32_t*)fp.unfinished_flag = 1;  // pass limit hit
     }
 }

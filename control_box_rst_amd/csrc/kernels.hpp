@@ -89,6 +89,9 @@ struct FactorParams {
     int32_t pass_timeline_inst;
     int32_t first_pass;           // big-block family: this may be the first factorisation of a solve (launches the mu / stop kernels)
     int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
+    double* x_host;               // run-to-completion kernel: optional result sink in pinned, device-visible HOST memory [batch][nvs]: every
+    LmState* st_host;             //   workgroup writes its instance's accepted iterate and LM state there as soon as the instance has finished
+    int32_t wave_rot;             // fused pass kernel: which hardware wave plays logical wave 0 (see lm_pass_kernel)
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 

@@ -46,6 +46,17 @@ def reduce_max(value: float, dist=None, device="cpu") -> float:
     return float(t.item())
 
 
+def gather_scalars(value: float, dist=None, device="cpu"):
+    """Every rank's value, in rank order (one tiny all-gather): makes a straggler GPU visible in the one bench line."""
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def gather_trajectories(x_local: np.ndarray, global_batch: int, dist=None, device="cpu") -> np.ndarray:
     """All-gather the final trajectories [count][nv] of every rank into [global_batch][nv] (outside any timed region)."""
     import torch

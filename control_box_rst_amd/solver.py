@@ -179,6 +179,25 @@ class BatchedLevenbergMarquardt:
         self._check(rc, "corbo_hip_get_solution")
         return x, chi2, status
 
+    def fetch_solution(self):
+        """Results in host-visible (pinned) memory owned by the handle: zero-copy numpy views (x [batch][nv], chi2, status), valid
+        until the next call that stages data through the handle."""
+        xp, cp, sp = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.POINTER(C.c_int32)()
+        stride = C.c_int32(0)
+        self._check(self.lib.corbo_hip_fetch_solution(self._h, C.byref(xp), C.byref(stride), C.byref(cp), C.byref(sp)), "corbo_hip_fetch_solution")
+        x = np.ctypeslib.as_array(xp, shape=(self.batch, stride.value))[:, : self.dims.nv]
+        return x, np.ctypeslib.as_array(cp, shape=(self.batch,)), np.ctypeslib.as_array(sp, shape=(self.batch,))
+
+    def set_result_sink(self, enable: bool):
+        """Let the solve kernel write the results into the handle's pinned host memory itself (see corbo_hip_set_result_sink)."""
+        self._check(self.lib.corbo_hip_set_result_sink(self._h, 1 if enable else 0), "corbo_hip_set_result_sink")
+
+    def get_timing(self, reset=False):
+        """(sum of the HIP-event times [ms] of the solves since the last reset, number of solves)."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._check(self.lib.corbo_hip_get_timing(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "corbo_hip_get_timing")
+        return float(ms.value), int(n.value)
+
     def get_stats(self) -> dict:
         s = Stats()
         self._check(self.lib.corbo_hip_get_stats(self._h, C.byref(s)), "corbo_hip_get_stats")
@@ -203,6 +222,14 @@ class BatchedLevenbergMarquardt:
                                            int(repeat), C.byref(ms))
         self._check(rc, "corbo_hip_time_sweep")
         return float(ms.value)
+
+    def time_sweep_each(self, with_jacobian=True, repeat=50) -> np.ndarray:
+        """Duration [ms] of each of `repeat` sweep launches, every launch bracketed by its own HIP events."""
+        o = self.opts
+        ms = (C.c_float * int(repeat))()
+        self._check(self.lib.corbo_hip_time_sweep_each(self._h, o.weight_eq, o.weight_ineq, o.weight_bounds, 1 if with_jacobian else 0,
+                                                       int(repeat), ms), "corbo_hip_time_sweep_each")
+        return np.array(ms[:], dtype=np.float64)
 
     def time_factor(self, repeat=20, timeline=False):
         """Average duration [ms] of one assemble/factor/solve launch; optionally workgroup 0's phase stamps (shader clocks)."""

@@ -277,6 +277,24 @@ int corbo_hip_synchronize(corbo_hip_handle h);
 int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, int32_t* status_out);
 int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats);
 
+/* Results into HOST-VISIBLE (pinned) memory owned by the handle, without the repacking copy of corbo_hip_get_solution: the
+ * accepted iterates [batch][*x_row_stride] (the first dims.nv doubles of a row are the vertex layout; the rest is the library's
+ * padding), chi2 [batch], status [batch].  Asynchronous copies behind the solve on the handle's stream, one synchronisation.  The
+ * views stay valid until the next call that stages data through the handle (set_instance_data, get_solution, fetch_solution,
+ * plant_get_state).  This is "last result resident on host-visible memory" of SURVEY.md 8d.  Any pointer may be NULL. */
+int corbo_hip_fetch_solution(corbo_hip_handle h, const double** x_pinned, int32_t* x_row_stride, const double** chi2_pinned,
+                             const int32_t** status_pinned);
+
+/* Result sink: with enable != 0 the run-to-completion solve kernel writes every instance's accepted iterate and LM state into the
+ * handle's pinned host memory itself, as soon as that instance has finished (posted PCIe writes, overlapped with the instances still
+ * iterating); corbo_hip_fetch_solution after such a solve returns the views without any copy.  Off by default (a moving-horizon
+ * caller keeps its results on the device).  Families without a run-to-completion kernel ignore it (fetch_solution copies). */
+int corbo_hip_set_result_sink(corbo_hip_handle h, int enable);
+
+/* Accumulated HIP-event time [ms] (handle's stream, first launch to last kernel end) and number of corbo_hip_solve calls since the
+ * last reset: the average launch duration of the run-to-completion solve kernel, measured live (bench.py roofline object). */
+int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solves, int reset);
+
 /* Parity hook for SURVEY rows a2-a6: evaluate the stacked residual
  * (LevenbergMarquardtSparse::computeValues, levenberg_marquardt_sparse.cpp:222-246) and, if jac_out != NULL, the
  * combined Jacobian values (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753)
@@ -292,6 +310,11 @@ int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev
  * per-launch time in ms measured with HIP events on the handle's stream (bench.py roofline leg). */
 int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat,
                          float* ms_per_launch);
+
+/* The same launches, each bracketed by its own pair of HIP events on the handle's stream (the launches do not overlap): ms_each
+ * [repeat] = the duration of every single launch, the quantity a rocprofv3 kernel trace reports per dispatch. */
+int corbo_hip_time_sweep_each(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat,
+                              float* ms_each);
 
 /* Same for the assemble/factor/solve kernel: runs the LM prologue on the resident data, then launches the kernel `repeat`
  * times.  timeline8 (may be NULL) receives 8 shader-clock stamps of workgroup 0 taken at the kernel's phase boundaries

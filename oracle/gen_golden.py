@@ -38,8 +38,64 @@ def slim(d, keep_iters):
     return d
 
 
+def final_of(kv):
+    d = run("dump", **kv)
+    last = d["after_iter"][-1]
+    return np.array(last["vertex"]), last["chi2"]
+
+
+def ulp_runs(scenario, x0, xf, n_perturb, **kv):
+    """Reference result for (x0, xf) and for x0 with component k moved by ONE ulp, k < n_perturb: the reference's own reproducibility
+    under a rounding-level change of its input (central differences with delta = 1e-9 amplify the last bits)."""
+    base, chi2 = final_of(dict(scenario=scenario, x0=vec(x0), xf=vec(xf), **kv))
+    pert = []
+    for k in range(n_perturb):
+        x1 = np.array(x0, dtype=float)
+        x1[k] = np.nextafter(x1[k], 10.0)
+        pert.append(final_of(dict(scenario=scenario, x0=vec(x1), xf=vec(xf), **kv))[0])
+    return base, chi2, pert
+
+
+def _uni_job(args):
+    b, x0, xf = args
+    base, chi2, pert = ulp_runs("unicycle", x0, xf, 3, iters=10)
+    return b, base, chi2, max(float(np.abs(p - base)[3:].max()) for p in pert)
+
+
+def fullsize():
+    """Full-size parity fixtures: the reference's result for EVERY instance of the headline batch, and the
+    reference's own one-ulp reproducibility per instance (binary .npz: 1024 x 498 doubles)."""
+    from concurrent.futures import ProcessPoolExecutor
+    B = 1024
+    x0, xf = problems.unicycle_instances(B)
+    vertex, chi2, spread = None, np.zeros(B), np.zeros(B)
+    with ProcessPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        for b, base, c, s in ex.map(_uni_job, [(b, x0[b], xf[b]) for b in range(B)], chunksize=8):
+            if vertex is None:
+                vertex = np.zeros((B, len(base)))
+            vertex[b], chi2[b], spread[b] = base, c, s
+    np.savez_compressed(os.path.join(OUT, "unicycle_seeded1024.npz"), seed=20260928, iters=10, vertex=vertex, chi2=chi2, ulp_spread=spread)
+    print("unicycle_seeded1024: spread median %.2e p99 %.2e max %.2e (instance %d), n(spread > 3e-6) = %d" % (
+        np.median(spread), np.quantile(spread, 0.99), spread.max(), spread.argmax(), int((spread > 3e-6).sum())))
+    # cfg 5 family: 6 seeded instances at N = 40 (base + 2 one-ulp perturbations each) and instance 0 at the full N = 200
+    nq = 6
+    x0, xf = problems.quad_instances(nq)
+    inst = []
+    for b in range(nq):
+        base, c, pert = ulp_runs("quad", x0[b], xf[b], 2, N=40, iters=10)
+        inst.append({"x0": list(x0[b]), "xf": list(xf[b]), "chi2": c, "vertex": list(base), "vertex_ulp": [list(p) for p in pert]})
+        print("quad N=40 instance", b, "ulp spread", [float(np.abs(p - base)[12:].max()) for p in pert])
+    with open(os.path.join(OUT, "quad_n40_seeded_ulp.json"), "w") as f:
+        json.dump({"scenario": "quad", "N": 40, "dt": 0.05, "iters": 10, "seed": 20260928, "weights": [10, 10, 10], "instances": inst}, f, separators=(",", ":"))
+    base, c, pert = ulp_runs("quad", x0[0], xf[0], 1, N=200, iters=10)
+    print("quad N=200 instance 0 ulp spread", float(np.abs(pert[0] - base)[12:].max()))
+    np.savez_compressed(os.path.join(OUT, "quad_n200_seeded_ulp.npz"), seed=20260928, iters=10, x0=x0[0], xf=xf[0], chi2=c, vertex=base, vertex_ulp=pert[0])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        return fullsize()
     # cfg 3 (headline structure, single instance, the SURVEY 8c known-answer trace), cfg 1, cfg 2
     for name, kv, keep in [
         ("unicycle", dict(scenario="unicycle"), (1, 2, 5, 10)),

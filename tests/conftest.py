@@ -76,3 +76,23 @@ def desc_for(g):
         for i, v in enumerate(g["ball"]):
             d.ineq_params[i] = v
     return d
+
+
+def load_npz(name):
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+SOFT_EIGENVALUE = 0.2   # eigen-directions of J^T J with lambda <= this are "soft" (cfg 5: thrust / rate / torque cost weights 0.01 .. 0.1)
+
+
+def stiff_part(J, dp, lam=SOFT_EIGENVALUE):
+    """Split a parameter-space difference dp by the eigen-directions of H = J^T J: returns (component of dp in the directions with
+    eigenvalue > lam, |J dp|^2).  Differences confined to the soft directions change chi2 by ~lam |dp|^2: they are what the
+    reference's own finite-difference noise (delta = 1e-9) leaves undetermined -- see tests/golden/quad_n40_seeded_ulp.json."""
+    import numpy as np
+    H = (J.T @ J).toarray()
+    w, V = np.linalg.eigh(H)
+    c = V.T @ dp
+    stiff = V[:, w > lam] @ c[w > lam]
+    return stiff, float(np.linalg.norm(J @ dp) ** 2)

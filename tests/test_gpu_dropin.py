@@ -31,6 +31,6 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, r
         # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
         # cfg 5 family (quadrotor, multiple shooting, N=30): flat directions, chi2 carries the comparison
-        assert r["max_abs_diff"] <= (5e-3 if r["scenario"] == "quad" else 5e-6), r
+        assert r["max_abs_diff"] <= (3e-4 if r["scenario"] == "quad" else 5e-6), r
         assert abs(r["chi2_hip"] - r["chi2_reference"]) <= 2e-6 * max(1.0, abs(r["chi2_reference"])), r
     assert p.returncode == 0

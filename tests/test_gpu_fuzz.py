@@ -164,7 +164,7 @@ def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
     X, chi2, _ = s.get_solution()
     Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
     assert np.allclose(chi2, chi2o, rtol=1e-6), (seed, chi2, chi2o)
-    assert np.abs(X - Xo).max() <= 5e-4, (seed, np.abs(X - Xo).max())
+    assert np.abs(X - Xo).max() <= 3e-4, (seed, np.abs(X - Xo).max())
 
 
 @pytest.mark.parametrize("seed", range(16))

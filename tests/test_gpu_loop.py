@@ -70,7 +70,7 @@ def test_closed_loop_vs_reference(name):
     s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
     s.plant_set_state(x0)
     nv = s.dims.nv
-    tol = 5e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
+    tol = 3e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
     for k, st in enumerate(g["steps"]):
         if k > 0:
             s.warm_start_from_plant(shift=bool(g["shift"]))

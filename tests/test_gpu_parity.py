@@ -37,9 +37,10 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "cartpole", "cartpole_midpoint", "cartpole_ms_rk4", "cartpole_patterns", "cartpole_tball", "cartpole_teq",
         "par2", "par3", "par2_ms_rk4", "par3_forward",
         "lin21", "lin22", "lin31", "lin32", "lin33", "lin41"]
-# reduced cfg 5 (quadrotor): nearly flat directions (yaw, torques) -- rounding-level differences move the iterate along them by
-# ~1e-4 while chi2 agrees to 1e-8 (the oracle shows the same spread against the genuine reference, tests/test_oracle_golden.py)
-X_TOL_BY = {"quad_n10": 5e-4,
+# reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
+# with x0 one ulp apart differs by 5e-5 .. 1.1e-4 there while chi2 agrees to 1e-9 (tests/test_oracle_fullsize.py demonstrates it on the
+# reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility
+X_TOL_BY = {"quad_n10": 3e-4,
             # SimplePendulum with the reference's default length: g / l = 29 multiplies sin(phi) in the dynamics, so the last-ulp difference
             # between the device's sin and the host libm's (1e-16 / (2 delta) = 5e-8 in a finite-difference column) is amplified 29-fold
             # per Runge-Kutta stage; the first, large step (chi2 3069 -> 266) then differs by 9e-6
@@ -219,7 +220,7 @@ def test_cfg5_quadrotor_batch_vs_oracle(oracle_mod):
     X, chi2, status = s.get_solution()
     Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
     assert np.allclose(chi2, chi2o, rtol=1e-6), (chi2, chi2o)
-    assert np.abs(X - Xo).max() <= 5e-3            # flat directions, see X_TOL_BY
+    assert np.abs(X - Xo).max() <= 3e-4            # soft directions, see X_TOL_BY
     assert np.abs(X[:, :12] - X0[:, :12]).max() == 0.0  # x_0 fixed
     st = s.get_stats()
     assert st["lm_iterations"] == B * 6

@@ -23,7 +23,7 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
 
 # The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
 # along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
-X_TOL = {"quad_n10": 5e-4,
+X_TOL = {"quad_n10": 3e-4,
          "cartpole_teq": 5e-6}   # 3.0e-6 at the fifth iteration (FD-noise level, different elimination order than Eigen's)
 
 

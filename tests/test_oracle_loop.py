@@ -48,7 +48,7 @@ def test_closed_loop_vs_reference(oracle_mod, name):
     nv = p.dims.nv
     xf = np.array(g["xf"])
     x = np.array(g["steps"][0]["x0"])
-    tol = 5e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
+    tol = 3e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
     for k, st in enumerate(g["steps"]):
         if k == 0:
             p.set_data(p.init_trajectory(x, xf), xref=xf)    # first compute(): the grid initialises its sequences

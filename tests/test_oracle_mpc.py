@@ -49,7 +49,7 @@ def test_sequence_vs_reference(oracle_mod, name):
             iters = g["iters"]
         status, chi2, _ = p.solve(capi.default_lm_opts(iters, *w), new_run=True)
         ref = np.array(st["vertex"])[:nv]
-        tol = 5e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
+        tol = 3e-4 if "quad" in name else 5e-6   # quadrotor: nearly flat directions, see tests/test_oracle_golden.py
         assert np.abs(p.x() - ref).max() <= tol, (name, s, np.abs(p.x() - ref).max())
         if iters > 0:
             assert abs(chi2 - st["chi2"]) <= 2e-6 * abs(st["chi2"]), (name, s)

@@ -47,8 +47,9 @@ def _worker(rank, world, port, global_batch, tmp):
         local["lm_iterations"] = count * opts.iterations
         red = sharding.reduce_stats(local, float(chi2.sum()), int((status <= 1).sum()), dist)
         tmax = sharding.reduce_max(1.0 + rank, dist)
+        tall = sharding.gather_scalars(1.0 + rank, dist)
         allx = sharding.gather_trajectories(X, global_batch, dist)
-        np.savez(os.path.join(tmp, f"r{rank}.npz"), allx=allx, tmax=tmax, iters=red["lm_iterations"], chi2=red["chi2_sum"], ok=red["ok_instances"])
+        np.savez(os.path.join(tmp, f"r{rank}.npz"), allx=allx, tmax=tmax, tall=np.array(tall), iters=red["lm_iterations"], chi2=red["chi2_sum"], ok=red["ok_instances"])
     finally:
         dist.destroy_process_group()
 
@@ -68,5 +69,6 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle_mod):
         z = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(z["allx"], X)                # gathered global result == single-process result, bit for bit
         assert z["tmax"] == 2.0                            # MAX over ranks
+        assert np.array_equal(z["tall"], [1.0, 2.0])       # every rank's own value, in rank order
         assert z["iters"] == G * opts.iterations and z["ok"] == G
         assert abs(z["chi2"] - chi2.sum()) < 1e-9
