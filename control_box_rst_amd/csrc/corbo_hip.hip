@@ -127,6 +127,8 @@ struct corbo_hip_solver {
     double* d_chi2        = nullptr;  // [batch]
     double* d_work        = nullptr;  // factor workspace (big-block kernel only)
     size_t work_stride    = 0;
+    int num_cus = 0;                  // compute units of the handle's device
+    int32_t* d_queue      = nullptr;  // ticket counter of the run-to-completion kernel's instance queue (batches beyond 4 workgroups per CU)
     int32_t* d_counters   = nullptr;  // MAX_PASSES
     int32_t* h_counter    = nullptr;  // pinned
     int m_pad = 0, nnz_pad = 0;
@@ -339,6 +341,12 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         h->force_split = true;  // no fused pass kernel for the big-block family: factor and sweep are separate launches
     }
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
+    {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, device));
+        h->num_cus = prop.multiProcessorCount;
+    }
+    CREATE_TRY(hipMalloc((void**)&h->d_queue, sizeof(int32_t)));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * corbo_hip_solver::MAX_SUB * sizeof(int32_t)));
     CREATE_TRY(hipMemset(h->d_state, 0, B * sizeof(LmState)));
@@ -370,7 +378,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -546,7 +554,10 @@ try {
             fp.inst0 = sp.inst0 = first_of[i];
             fp.loop_passes = MAX_PASSES;
             if (h->result_sink) { fp.x_host = h->h_stage; fp.st_host = h->h_state; }
-            if (const char* wr = std::getenv("CORBO_HIP_WAVE_ROT")) fp.wave_rot = std::atoi(wr);
+            if (count_of[i] > 4 * h->num_cus) {   // more instances than resident workgroups: instance queue
+                HIP_TRY(hipMemsetAsync(h->d_queue, 0, sizeof(int32_t), st_of[i]));
+                fp.queue = h->d_queue; fp.queue_grid = h->num_cus;
+            }
             if (const char* lim = std::getenv("CORBO_HIP_PASS_LIMIT"))   // tests: provoke the "pass limit reached" error path
                 if (std::atoi(lim) > 0 && std::atoi(lim) < MAX_PASSES) fp.loop_passes = std::atoi(lim);
             // an instance that runs into the pass limit raises a flag in pinned, device-visible host memory: no memset, no read-back
@@ -821,6 +832,10 @@ try {
             SweepParams sp  = h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr);
             fp.loop_passes     = limit;
             fp.unfinished_flag = h->h_counter;   // any step's unfinished instance raises it
+            if (h->batch > 4 * h->num_cus) {
+                HIP_TRY(hipMemsetAsync(h->d_queue, 0, sizeof(int32_t), h->stream));
+                fp.queue = h->d_queue; fp.queue_grid = h->num_cus;
+            }
             if (!launch_pass(S.desc, fp, sp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
             HIP_TRY(hipGetLastError());
         }

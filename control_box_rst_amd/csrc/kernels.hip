@@ -2159,15 +2159,14 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
 // the slow instances of the tail run at single-instance latency (0.81 ms instead of 1.09 ms per headline solve).  The loop needs
 // two precautions against the compiler carrying state around it: the kernel arguments are re-read from the kernarg segment each
 // pass, and the library is built with -disable-machine-licm (hoisted math-library constants were spilled to scratch otherwise).
-template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC>
+template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, bool QUEUE = false>
 __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int inst = blockIdx.x + fp.inst0;
-    const int rot  = fp.wave_rot == 1 ? (blockIdx.x & 3) : (fp.wave_rot == 2 ? ((blockIdx.x >> 8) & 3) : (fp.wave_rot == 3 ? ((blockIdx.x >> 3) & 3) : 0));
-    const int tid  = (threadIdx.x + 64 * rot) & (SWEEP_THREADS - 1);
+    const int tid = threadIdx.x;
+    int inst      = blockIdx.x + fp.inst0;
     const int NP = NPC > 0 ? NPC : (fp.N | 1);
     // LDS map: Jacobian staging [0, nnz_pad) (= where the factor phase expects it), dynamics caches right behind it, vertex values
     // behind the factor carve, then the LM state and the sweep phase's reduction scratch + flags.  (The scratch must not live inside
@@ -2179,10 +2178,10 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
     LmState* sl = reinterpret_cast<LmState*>(xs + sp.nvs);   // LM state of the instance, resident in LDS (nvs is even: 16-byte aligned)
     double* red = reinterpret_cast<double*>(sl + 1);         // [12]
     int* flags  = reinterpret_cast<int*>(red + 8);
-    lm_state_in(sl, fp.st + inst, tid);
-    if (tid == 0) flags[0] = 0;
-    __syncthreads();
     if constexpr (!LOOP) {
+        lm_state_in(sl, fp.st + inst, tid);
+        if (tid == 0) flags[0] = 0;
+        __syncthreads();
         if (sp.mode == 3 && sl->done) return;
         sweep_body<DYN, DEFECT, true>(sp, sp.mode, sp.active_count, sl, xs, red, cs, jst, inst, tid);
         __threadfence_block();  // this workgroup's residual / iterate stores are visible to its factor phase
@@ -2197,45 +2196,71 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
         // run-to-completion: the instances are independent, so the workgroup walks its instance through the prologue and every LM
         // pass without leaving the chip (no launch gaps, workgroups drift apart so that latency-bound factor phases overlap
         // throughput-bound sweep phases of their neighbours).
-        int mode = sp.mode;
-        int inst_v = inst, tid_v = tid;
+        // Batches larger than what the chip holds at once (4 workgroups per CU): the launch has as many workgroups as fit, and every
+        // workgroup pulls instance after instance from a ticket counter -- a finished instance's slot is refilled at once instead of
+        // idling until the slowest instance of its round is through (instances need 10 .. 23+ passes).
         // the kernel arguments are re-read from the kernarg segment in every pass (scalar loads) instead of being kept live in
         // ~200 SGPRs around the loop
         struct Args { FactorParams f; SweepParams s; };
         typedef const __attribute__((address_space(4))) Args* ArgsPtr;
         ArgsPtr ka = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        const int max_passes = fp.loop_passes;
+        int tid_v = tid;
 #pragma nounroll
-        for (int pass = 0; pass <= max_passes; ++pass) {
-            asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");  // nothing derived from them is carried around the loop
-            const FactorParams& fpl = (const FactorParams&)ka->f;
-            const SweepParams& spl  = (const SweepParams&)ka->s;
-            const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;
-            if (stamp) fpl.pass_timeline[2 * pass] = clock64();
-            if (pass > 0) {
-                if (tid_v == 0) flags[0] = 0;
+        for (;;) {
+            if constexpr (QUEUE) {
+                asm volatile("" : "+v"(tid_v), "+s"(ka) : : "memory");   // (as in the pass loop: nothing is carried around this loop either)
+                const FactorParams& fq = (const FactorParams&)ka->f;
+                __syncthreads();   // the previous instance's last readers of flags[] are through
+                if (tid_v == 0) flags[2] = atomicAdd(fq.queue, 1);
                 __syncthreads();
+                const int ticket = __builtin_amdgcn_readfirstlane(flags[2]);   // (uniform: into a scalar register)
+                if (ticket >= fq.batch) break;
+                inst = ticket + fq.inst0;
             }
-            sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);
-            __threadfence_block();
+            int inst_v = inst;
+            {
+                const FactorParams& fq = (const FactorParams&)ka->f;
+                lm_state_in(sl, fq.st + inst_v, tid_v);
+            }
+            if (tid_v == 0) flags[0] = 0;
             __syncthreads();
-            if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
-            if (sl->done) break;
-            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, xs);
-            __threadfence_block();
-            __syncthreads();
-            mode = 3;
+            int mode = ((const SweepParams&)ka->s).mode;
+            const int max_passes = ((const FactorParams&)ka->f).loop_passes;
+#pragma nounroll
+            for (int pass = 0; pass <= max_passes; ++pass) {
+                asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");  // nothing derived from them is carried around the loop
+                const FactorParams& fpl = (const FactorParams&)ka->f;
+                const SweepParams& spl  = (const SweepParams&)ka->s;
+                const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;
+                if (stamp) fpl.pass_timeline[2 * pass] = clock64();
+                if (pass > 0) {
+                    if (tid_v == 0) flags[0] = 0;
+                    __syncthreads();
+                }
+                sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);
+                __threadfence_block();
+                __syncthreads();
+                if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
+                if (sl->done) break;
+                factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, xs);
+                __threadfence_block();
+                __syncthreads();
+                mode = 3;
+            }
+            asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");
+            const FactorParams& fe = (const FactorParams&)ka->f;
+            lm_state_out(fe.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM
+            if (fe.x_host) {
+                // result sink: the finished instance's accepted iterate and LM state go straight to host-visible memory (posted PCIe
+                // writes, overlapped with the instances that are still iterating) -- no copy-engine pass after the launch
+                const double2* src = reinterpret_cast<const double2*>(fe.x + (size_t)inst_v * fe.nvs);
+                double2* dst       = reinterpret_cast<double2*>(fe.x_host + (size_t)inst_v * fe.nvs);
+                for (int i = tid_v; i < fe.nvs / 2; i += SWEEP_THREADS) dst[i] = src[i];
+                lm_state_out(fe.st_host + inst_v, sl, tid_v);
+            }
+            if (tid_v == 0 && !sl->done && fe.unfinished_flag) *(volatile int32_t*)fe.unfinished_flag = 1;  // pass limit hit
+            if constexpr (!QUEUE) break;
         }
-        lm_state_out(fp.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM
-        if (fp.x_host) {
-            // result sink: the finished instance's accepted iterate and LM state go straight to host-visible memory (posted PCIe
-            // writes, overlapped with the instances that are still iterating) -- no copy-engine pass after the launch
-            const double2* src = reinterpret_cast<const double2*>(fp.x + (size_t)inst_v * fp.nvs);
-            double2* dst       = reinterpret_cast<double2*>(fp.x_host + (size_t)inst_v * fp.nvs);
-            for (int i = tid_v; i < fp.nvs / 2; i += SWEEP_THREADS) dst[i] = src[i];
-            lm_state_out(fp.st_host + inst_v, sl, tid_v);
-        }
-        if (tid_v == 0 && !sl->done && fp.unfinished_flag) *(volatile int32_t*)fp.unfinished_flag = 1;  // pass limit hit
     }
 }
 
@@ -2248,6 +2273,11 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 template <int DYN>
 bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
 {
+#ifdef CORBO_HIP_DEV_FAST   // development builds: only the headline defect formula is instantiated (compile time)
+    if (defect != CORBO_HIP_DEFECT_CRANK_NICOLSON) return false;
+    launch_sweep_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(p, stream);
+    return true;
+#else
     switch (defect) {
         case CORBO_HIP_DEFECT_FORWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, stream); return true;
         case CORBO_HIP_DEFECT_BACKWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(p, stream); return true;
@@ -2256,6 +2286,7 @@ bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
         case CORBO_HIP_DEFECT_RK4_SHOOTING: launch_sweep_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, stream); return true;
         default: return false;
     }
+#endif
 }
 
 template <int NX, int NU>
@@ -2272,9 +2303,23 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
     const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs + 12) + sizeof(LmState);           // + vertex values + LM state + scratch
-    const dim3 g(fp.batch), b(SWEEP_THREADS);
+    // queue mode: as many workgroups as the chip holds at once (register budget: 4 of these workgroups per CU; LDS: 160 KB per CU)
+    int grid = fp.batch;
+    if (fp.queue) {
+        int per_cu = (int)((size_t)160 * 1024 / lds);
+        if (per_cu > 4) per_cu = 4;
+        if (per_cu < 1) per_cu = 1;
+        grid = fp.queue_grid * per_cu;   // queue_grid = compute units of the device
+        if (grid > fp.batch) grid = fp.batch;
+    }
+    const dim3 g(grid), b(SWEEP_THREADS);
     // the run-to-completion kernel of the headline horizon (N = 100) is specialised on the LDS stride
-    if (fp.loop_passes > 0) {
+    if (fp.loop_passes > 0 && fp.queue) {
+        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0, true>), g, b, lds, stream, fp, sp);
+        else if ((fp.N | 1) == 101) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 101, true>), g, b, lds, stream, fp, sp);
+        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0, true>), g, b, lds, stream, fp, sp);
+    }
+    else if (fp.loop_passes > 0) {
         if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0>), g, b, lds, stream, fp, sp);
         else if ((fp.N | 1) == 101) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 101>), g, b, lds, stream, fp, sp);
         else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0>), g, b, lds, stream, fp, sp);
@@ -2287,6 +2332,10 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
 template <int DYN>
 bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
+#ifdef CORBO_HIP_DEV_FAST
+    if (defect != CORBO_HIP_DEFECT_CRANK_NICOLSON) return false;
+    return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, stream);
+#else
     switch (defect) {
         case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, stream);
         case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, stream);
@@ -2295,6 +2344,7 @@ bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hi
         case CORBO_HIP_DEFECT_RK4_SHOOTING: return launch_pass_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(fp, sp, stream);
         default: return false;
     }
+#endif
 }
 
 template <int NX, int NU, bool ARROW>

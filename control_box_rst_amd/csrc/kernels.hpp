@@ -91,7 +91,9 @@ struct FactorParams {
     int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
     double* x_host;               // run-to-completion kernel: optional result sink in pinned, device-visible HOST memory [batch][nvs]: every
     LmState* st_host;             //   workgroup writes its instance's accepted iterate and LM state there as soon as the instance has finished
-    int32_t wave_rot;             // fused pass kernel: which hardware wave plays logical wave 0 (see lm_pass_kernel)
+    int32_t queue_grid;           // workgroups of a launch in queue mode
+    int32_t* queue;               // run-to-completion kernel, batch > resident workgroups: ticket counter (zeroed before the launch); every
+                                  //   workgroup pulls instance after instance from it.  null = workgroup b solves instance inst0 + b
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 

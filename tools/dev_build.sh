@@ -1,0 +1,14 @@
+#!/bin/bash
+# development aid: compile ONLY the unicycle unit of kernels.hip (headline defect formula) with extra flags and link it with the
+# other objects of the last full build into csrc/libcorbo_hip_dev.so (A/B against the product library with CORBO_HIP_LIB=...)
+#   tools/dev_build.sh [name] [extra hipcc flags...]      -> control_box_rst_amd/csrc/libcorbo_hip_<name>.so + /tmp/<name>.s
+set -e
+cd "$(dirname "$0")/../control_box_rst_amd/csrc"
+name=${1:-dev}; shift || true
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-function -mllvm -disable-machine-licm"
+/opt/rocm/bin/hipcc $FLAGS -DCORBO_HIP_DEV_FAST -DCORBO_HIP_DYN_TU=CORBO_HIP_DYN_UNICYCLE -DCORBO_HIP_DYN_TU_NAME=unicycle "$@" \
+    -c kernels.hip -o /tmp/kernels_unicycle_$name.o -Rpass-analysis=kernel-resource-usage 2> /tmp/$name.remarks || { tail -30 /tmp/$name.remarks; exit 1; }
+grep -A9 "lm_pass_kernelILi2ELi3ELb0ELb1ELi101" /tmp/$name.remarks | grep -E "VGPRs|Scratch|SGPRs" | sed 's/.*remark: //' | tr '\n' ' '; echo
+objs=$(ls _obj/*.o | grep -v kernels_unicycle.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libcorbo_hip_$name.so $objs /tmp/kernels_unicycle_$name.o
+echo "built libcorbo_hip_$name.so"
