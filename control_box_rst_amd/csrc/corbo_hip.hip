@@ -126,6 +126,7 @@ struct corbo_hip_solver {
     LmState* d_state      = nullptr;
     double* d_chi2        = nullptr;  // [batch]
     double* d_work        = nullptr;  // factor workspace (big-block kernel only)
+    double* d_xe0         = nullptr;  // big-block family: [2][batch][N][nx] end states of the unperturbed Runge-Kutta steps (SweepParams::xe0)
     size_t work_stride    = 0;
     int num_cus = 0;                  // compute units of the handle's device
     int32_t* d_queue      = nullptr;  // ticket counter of the run-to-completion kernel's instance queue (batches beyond 4 workgroups per CU)
@@ -156,6 +157,7 @@ struct corbo_hip_solver {
     {
         SweepParams p{};
         p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.batch_total = batch; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2) ? 1 : 0;
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         fill_dyn(p.mp.dyn);
@@ -338,6 +340,8 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
         CREATE_TRY(hipMalloc((void**)&h->d_work, B * h->work_stride * sizeof(double)));
+        CREATE_TRY(hipMalloc((void**)&h->d_xe0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
+        CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
         h->force_split = true;  // no fused pass kernel for the big-block family: factor and sweep are separate launches
     }
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
@@ -378,7 +382,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -458,7 +462,8 @@ static int launch_sweep_checked(corbo_hip_handle h, const SweepParams& p)
 }
 static int launch_factor_checked(corbo_hip_handle h, const FactorParams& p)
 {
-    if (!launch_factor(h->S.desc, p, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
+    const SweepParams sp = h->sweep_params(3, 0, h->w_eq, h->w_ineq, h->w_b, nullptr);
+    if (!launch_factor(h->S.desc, p, h->stream, &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -531,7 +536,7 @@ try {
         if (split) {
             if (mode == 3) {
                 fp.first_pass = (pass_of[i] == 0) ? 1 : 0;
-                if (!launch_factor(h->S.desc, fp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
+                if (!launch_factor(h->S.desc, fp, st_of[i], &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
                 HIP_TRY(hipGetLastError());
                 stamp();
             }
@@ -977,8 +982,17 @@ try {
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
-    int rc = launch_sweep_checked(h, h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr));
+    const SweepParams spe = h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
+    int rc = launch_sweep_checked(h, spe);
     if (rc) return rc;
+    if (jac_out && h->d_xe0) {
+        // big-block family: what an LM pass differentiates is the stage kernel's Jacobian (never stored during a solve); the parity hook
+        // returns THAT one -- every value is overwritten (an entry the stage kernel does not produce would come back as NaN)
+        HIP_TRY(hipMemsetAsync(h->d_jac, 0xFF, (size_t)h->batch * h->nnz_pad * sizeof(double), h->stream));
+        if (!launch_stage_jacobian_dump(h->S.desc, h->factor_params(), spe, h->d_jac, h->stream))
+            return fail(CORBO_HIP_ERR_UNSUPPORTED, "no stage kernel for this dynamics");
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     const Structure& S = h->S;
     const int B = h->batch;

@@ -23,6 +23,20 @@ constexpr int SWEEP_THREADS = 256;
 constexpr double LM_EPS1 = 1e-5, LM_EPS2 = 1e-5, LM_EPS3 = 1e-5, LM_EPS4 = 0.0, LM_TAU = 1e-5;  // levenberg_marquardt_sparse.cpp:103-110
 constexpr int LM_MAX_INNER = 64;  // guard against an endless reject loop (the reference would spin)
 
+// Workgroup barrier for hand-overs through LDS only.  __syncthreads() is a workgroup-scope release/acquire fence + s_barrier: the
+// fence waits for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)), i.e. also for the write acknowledgements of
+// global stores that nobody in the workgroup is going to read (gfx9 counts stores in vmcnt) -- an HBM / L2 round trip at every
+// barrier that follows a store.  Where the data that crosses the barrier lives in LDS, waiting for the wave's LDS operations is
+// enough.  (-DCORBO_HIP_FULL_BARRIERS: the conservative barrier everywhere, for A/B measurements.)
+__device__ __forceinline__ void lds_barrier()
+{
+#ifdef CORBO_HIP_FULL_BARRIERS
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -95,9 +109,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
+    int vsel           = 0;   // which half of the two-buffer arrays (values0 / values1, xe0) this evaluation writes
     if (mode == 3) {
         const int done = st->done, no_trial = st->no_trial, vbuf = st->vbuf;
-        __syncthreads();  // everybody has read the state before lane 0 may change it
+        lds_barrier();  // everybody has read the state before lane 0 may change it
         if (done) return;
         if (no_trial) {  // |delta| <= eps2 -> stop = true, the do-while ends without a trial step (:151-154,215)
             if (tid == 0) {
@@ -109,6 +124,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
         xsrc = p.xt + xo;
         vout = (vbuf ? p.values0 : p.values1) + (size_t)inst * p.m_pad;  // the buffer NOT paired with the resident J
+        vsel = vbuf ? 0 : 1;
     }
 
     SWEEP_STAMP(0);
@@ -120,7 +136,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     double xr[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
-    __syncthreads();
+    lds_barrier();
     SWEEP_STAMP(1);
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
     constexpr double delta     = 1e-9;
@@ -239,7 +255,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
         }
         if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);  // stage lanes: their one round of components
-        __syncthreads();
+        lds_barrier();
     }
     else if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
 
@@ -262,6 +278,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         double e[NX];
         if constexpr (CACHED)
             defect_eval_cached<DYN, DEFECT>(xs + base, cs + k * NC, xs + base + NX, xs + base + S, cs + (k + 1) * NC, xs[p.off_dt], p.mp.dyn, e);
+        else if constexpr (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING && !STAGE) {
+            // same operations as defect_eval (end state of the step, then the subtraction); the end state is kept for the stage kernel
+            double ck[4][NC], xe[NX];
+            rk4_end_state<DYN, false>(xs + base, xs + base + NX, xs[p.off_dt], p.mp.dyn, ck, xe);
+            double* xeo = p.xe0 ? p.xe0 + (((size_t)vsel * p.batch_total + inst) * p.N + k) * NX : nullptr;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                e[i] = xe[i] - xs[base + S + i];
+                if (xeo) xeo[i] = xe[i];
+            }
+        }
         else
             defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
 #pragma unroll
@@ -295,7 +322,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if (mode >= 2) {
         double ws = wave_sum(sq_acc);
         if ((tid & 63) == 0) red[tid >> 6] = ws;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             const double chi2 = red[0] + red[1] + red[2] + red[3];
             bool fin = false;
@@ -353,7 +380,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
             if (!fin && active_count) atomicAdd(active_count, 1);
         }
-        __syncthreads();
+        lds_barrier();
         do_jac = flags[0];
         if (mode == 3 && flags[1]) {  // accepted: the trial iterate becomes the iterate (discardBackupParameters :176)
             double* xdst = p.x + xo;
@@ -362,7 +389,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
     SWEEP_STAMP(4);
-    if (!do_jac) return;
+    if (!do_jac || (p.skip_jac && mode >= 2)) return;
 
     // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753),
     //      central differences exactly as BaseEdge::computeJacobian (edge_interface.cpp:55-96):
@@ -647,7 +674,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
     SWEEP_STAMP(6);
     if constexpr (STAGE) {
-        __syncthreads();
+        lds_barrier();
     SWEEP_STAMP(7);
         // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
         // (stand-alone kernel: streaming stores -- the consumer is a later launch and 1024 Jacobians do not fit the L2 anyway, +7 % on the
@@ -879,7 +906,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     const int stop_in = st->stop;
     double mu = st->mu;
     const double mu_acc_in = st->mu_acc;
-    __syncthreads();
+    lds_barrier();
     if (done) return;
     STAMP(0);
 
@@ -950,7 +977,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int u = 0; u < UNR; ++u) { const int i = i0 + u * THREADS; dst[i < n2 ? i : n2 - 1] = v[u]; }
         }
     }
-    __syncthreads();
+    lds_barrier();
     // (4) per-stage gathers from the staging area
     double A[NX][NX], B[NX][NU], Cc[NX][NX], dc[NX];
 #pragma unroll
@@ -1008,7 +1035,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; cdt += a * a; gdt -= a * val[ci.bnd_row]; }
         }
     }
-    __syncthreads();  // every lane has taken its Jacobian entries out of the staging area
+    lds_barrier();  // every lane has taken its Jacobian entries out of the staging area
     STAMP(1);
 
     // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
@@ -1022,7 +1049,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int q = 0; q < NX; ++q) { dd += Cc[q][i] * Cc[q][i]; gg -= Cc[q][i] * r[q]; }
             if (has_stage) { SOA(Wbm, i, k) = dd; SOA(Wbm, NX + i, k) = gg; }
         }
-        __syncthreads();
+        lds_barrier();
         double mx_d = -1e300, mx_g = 0;
 #pragma unroll
         for (int j = 0; j < NU; ++j)
@@ -1047,13 +1074,13 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         mx_g = wave_max(mx_g);
         double sc_ = wave_sum(cdt), sg_ = wave_sum(gdt);
         if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = mx_d; red[(tid >> 6) * 4 + 1] = mx_g; red[(tid >> 6) * 4 + 2] = sc_; red[(tid >> 6) * 4 + 3] = sg_; }
-        __syncthreads();
+        lds_barrier();
         double s_cdt = 0, s_gdt = 0;
         mx_d = red[0]; mx_g = red[1]; s_cdt = red[2]; s_gdt = red[3];
 #pragma unroll
         for (int w = 1; w < NW; ++w) { mx_d = fmax(mx_d, red[w * 4]); mx_g = fmax(mx_g, red[w * 4 + 1]); s_cdt += red[w * 4 + 2]; s_gdt += red[w * 4 + 3]; }
         if (ARROW) { mx_d = fmax(mx_d, s_cdt); mx_g = fmax(mx_g, fabs(s_gdt)); }
-        __syncthreads();
+        lds_barrier();
         stop = (mx_g <= LM_EPS1) ? 1 : 0;
         mu   = LM_TAU * mx_d;
         if (mu < 0) mu = 0;
@@ -1141,7 +1168,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(2);
     // ---- phase B + cyclic-reduction level 0: complete state block k; odd blocks are eliminated at once
     if (has_block) {
@@ -1196,7 +1223,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int j = 0; j <= i; ++j) SOA(Dm, TRI(i, j), k) = Dk[i][j];
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
 
     // ---- cyclic reduction, levels h = 2, 4, ...: lane t owns the active block a = h*t.  It first applies the Schur updates of
@@ -1348,7 +1375,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         }
         hroot = h;
         if (h >= N) break;
-        __syncthreads();
+        lds_barrier();
     }
     STAMP(4);
     // ---- reductions: |y|^2 (= delta^T rhs), and for the arrowhead the last pivot
@@ -1357,7 +1384,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         double a0 = wave_sum(y2), a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         if constexpr (ARROW) { a1 = wave_sum(zz); a2 = wave_sum(zy); a3 = wave_sum(cdt); a4 = wave_sum(gdt); }
         if ((tid & 63) == 0) { double* rr = red + (tid >> 6) * 5; rr[0] = a0; rr[1] = a1; rr[2] = a2; rr[3] = a3; rr[4] = a4; }
-        __syncthreads();
+        lds_barrier();
         a0 = a1 = a2 = a3 = a4 = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { a0 += red[w * 5]; a1 += red[w * 5 + 1]; a2 += red[w * 5 + 2]; a3 += red[w * 5 + 3]; a4 += red[w * 5 + 4]; }
@@ -1377,7 +1404,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         if (has_stage)
 #pragma unroll
             for (int a = 0; a < NU; ++a) SOA(yu, a, k) -= SOA(zu, a, k) * ddt;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             double L[NX][NX], y[NX];
 #pragma unroll
@@ -1390,7 +1417,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 #pragma unroll
             for (int q = 0; q < NX; ++q) SOA(gv, q, 0) = y[q];
         }
-        __syncthreads();
+        lds_barrier();
     }
     STAMP(5);
     // the accepted iterate of this lane's stage (for x + delta below): requested now, the back-substitution hides the latency
@@ -1443,7 +1470,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (; h >= 1; h >>= 1) {
             if (h * (2 * (tid >> 2) + 1) < N) finish(h, tid >> 2);
             for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }  // long horizons
-            __syncthreads();
+            lds_barrier();
             if (h > 1) fetch(h >> 1, tid >> 2);
         }
     }
@@ -1490,9 +1517,9 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     }
     {
         double a0 = wave_sum(dn2);
-        __syncthreads();
+        lds_barrier();
         if ((tid & 63) == 0) red[tid >> 6] = a0;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             dn2 = 0;
 #pragma unroll
@@ -1582,59 +1609,19 @@ struct BigCtx {
     __device__ __forceinline__ explicit BigCtx(double* sm)
         : Gm(sm + BL::G), rv(sm + BL::R), Mm(sm + BL::M), gm(sm + BL::GM), Luu(sm + BL::LUU), Zx(sm + BL::ZX), Zp(sm + BL::ZP),
           yu(sm + BL::YU), dg(sm + BL::DIAG), gd(sm + BL::GDIAG), cin(sm + BL::CIN), fx(sm + BL::FIX), red(sm + BL::RED) {}
-    // loads the local Jacobian, residual and single-entry rows of stage k (k == N-1: only the state block's diagonal rows)
-    __device__ __forceinline__ void load_stage(const FactorParams& p, const double* J, const double* val, int k, int lane) const
-    {
-        const bool stage = (k < p.N - 1);
-        for (int e = lane; e < NX * W; e += 64) {
-            const int r = e % NX, c = e / NX;   // column-major walk: consecutive lanes read consecutive Jacobian values
-            double v = 0.0;
-            if (stage) { const int o = p.stage_cols[k].col[c]; if (o >= 0) v = J[o + r]; }
-            Gm[r * W + c] = v;
-        }
-        for (int e = lane; e < S; e += 64) {
-            double dd = 0.0, gg = 0.0;
-            const bool isx = e < NX;
-            if (isx || stage) {
-                const CompInfo ci = p.comp[k * S + e];
-                if (isx) fx[e] = ci.fixed ? 1.0 : 0.0;
-                if (ci.cost_joff >= 0) { const double a = J[ci.cost_joff]; dd += a * a; gg -= a * val[ci.cost_row]; }
-                if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; dd += a * a; gg -= a * val[ci.bnd_row]; }
-            }
-            dg[e] = dd; gd[e] = gg;
-        }
-        if (lane < NX) {
-            rv[lane] = stage ? val[p.eq_row0 + k * NX + lane] : 0.0;
-            double c = 0.0;
-            if (stage && p.ineq_cols) { const int o = p.ineq_cols[k * NX + lane]; if (o >= 0) c = J[o]; }
-            cin[lane] = c;
-        }
-        if (lane == 0) red[7] = (stage && p.ineq_rows) ? val[p.ineq_rows[k]] : 0.0;
-    }
 };
 
 // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118), in two steps:
-//      big_diag_kernel   one wave per (stage, instance): the stage's parts of diag(J^T J) and of rhs = -J^T r, left in the
+//      big_diag_stage    (stage kernel, diag pass) per (stage, instance): the stage's parts of diag(J^T J) and of rhs = -J^T r, left in the
 //                        (not yet used) factor slot of the stage's workspace:  [0,NX) diag of x_k without the C-part of stage k-1,
 //                        [NX,2NX) same for rhs, [2NX,3NX) / [3NX,4NX) the C-parts this stage adds to x_{k+1}, [4NX], [4NX+1] the
 //                        maxima over the stage's controls;
 //      big_first_kernel  one wave per instance, lanes over the stages: adds the neighbouring parts, takes the maxima.
 template <int NX, int NU>
-__global__ __launch_bounds__(64) void big_diag_kernel(const FactorParams p)
+__device__ __forceinline__ void big_diag_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk)
 {
     using BL = BigLds<NX, NU>;
     constexpr int S = NX + NU, W = BL::W;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const BigCtx<NX, NU> c(sm);
-    const int k = blockIdx.x, inst = blockIdx.y + p.inst0, lane = threadIdx.x;
-    const LmState* st = p.st + inst;
-    if (st->done || !st->first) return;
-    const int N = p.N;
-    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
-    const double* val = (st->vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
-    double* wk        = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE + BL::WS_L;
-    c.load_stage(p, J, val, k, lane);
-    __syncthreads();
     double mu_d = -1e300, mu_g = 0.0;
     if (lane < W) {
         double dd = 0.0, gg = 0.0;
@@ -1686,27 +1673,17 @@ __global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
     }
 }
 
-// ---- per (stage, instance): everything of the factorisation that does not depend on the neighbouring stages
+// ---- per (stage, instance): everything of the factorisation that does not depend on the neighbouring stages.  The local Jacobian
+//      G = [A | B | C], the defect residual and the single-entry rows of the stage's components are in the LDS context c (written by
+//      the stage kernel straight from the finite differences: the Jacobian of this family never exists in HBM).
 template <int NX, int NU, bool USE_MFMA>
-__global__ __launch_bounds__(64) void big_assemble_kernel(const FactorParams p)
+__device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk, const double mu_eff)
 {
     using BL = BigLds<NX, NU>;
     constexpr int S = NX + NU, W = BL::W;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const BigCtx<NX, NU> c(sm);
     double *Gm = c.Gm, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *dg = c.dg, *gd = c.gd,
            *cin = c.cin, *red = c.red;
-    const int k = blockIdx.x, inst = blockIdx.y + p.inst0, lane = threadIdx.x;
-    const LmState* st = p.st + inst;
-    if (st->done) return;
-    const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + st->mu;   // H_ii += mu on every inner pass, never undone (:135-138)
-    const int N = p.N;
     const bool stage = (k < N - 1);
-    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
-    const double* val = (st->vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
-    double* wk        = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE;
-    c.load_stage(p, J, val, k, lane);
-    __syncthreads();
     double y2 = 0.0;
     if (stage) {
         // M = G^T G  (W x NX times NX x W): fp64 matrix cores.  v_mfma_f64_16x16x4f64 layout (probed on gfx950 with
@@ -1827,6 +1804,175 @@ __global__ __launch_bounds__(64) void big_assemble_kernel(const FactorParams p)
     if (lane == 2 * NX) wk[BL::WS_Y2] = y2;   // (the lane that formed y_u; 0 for the last block)
 }
 
+// ---- the stage kernel of the big-block family: ONE wave per PAIR of shooting intervals (k, k+1) of one instance.
+//      Phase 1 (edges): the finite-difference Jacobian of the two defect edges, one lane per (interval, column, side) -- 2 x 16 x 2 =
+//      64 Runge-Kutta integrations side by side, each with its own perturbed copy of (x_k, u_k), exactly BaseEdge::computeJacobian
+//      (edge_interface.cpp:55-96: x_i += delta -> v2, x_i += -2 delta -> v1, (1 / (2 delta)) (v2 - v1)); the two sides of a column meet
+//      through a lane swap.  The x_{k+1} columns need no integration: e = RK4(x_k, u_k) - x_{k+1} with the end state of the UNPERTURBED
+//      step, which the residual sweep has kept (SweepParams::xe0).  Cost rows, bound rows and the stage inequality of the intervals'
+//      components are evaluated by the first lanes of each half (same formulas, same operation order as sweep_body: bit-identical).
+//      Phase 2 (assemble): big_diag_stage (first factorisation of a solve: diag(J^T J), rhs) or big_assemble_stage, interval by
+//      interval on the whole wave.  The Jacobian lives in LDS for the length of this kernel and nowhere else; a rejected step is
+//      re-assembled from the (unchanged) accepted iterate with the larger damping -- same bits, no Jacobian traffic at all.
+//      jac_dump (parity hook, corbo_hip_eval): the Jacobian values this kernel works with, written in the public value order.
+#pragma clang fp contract(off)
+template <int DYN>
+__device__ __forceinline__ void big_stage_edges(const FactorParams& p, const SweepParams& sp, const BigCtx<Dynamics<DYN>::NX, Dynamics<DYN>::NU>& c,
+                                                const int k, const int l32, const int inst, const int vsel, double* jac_dump)
+{
+    using Dy = Dynamics<DYN>;
+    constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, W = 2 * NX + NU, NC = Dy::NC;
+    constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
+    const int N      = p.N;
+    const bool stage = (k < N - 1), block = (k < N);
+    const int kk     = stage ? k : 0;   // (clamped: absent intervals load interval 0 and write zeros)
+    const size_t xo  = (size_t)inst * sp.nvs;
+    const double* X  = sp.x + xo;
+    const double dt0 = X[sp.off_dt];
+    const int* sc    = p.stage_cols[kk].col;
+    // ---- (x_k, u_k) columns: lane = (column, side)
+    {
+        double loc[S], x2[NX], ck[4][NC], xe[NX];
+#pragma unroll
+        for (int i = 0; i < S; ++i) loc[i] = X[kk * S + i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x2[i] = X[kk * S + S + i];
+        const int col    = l32 >> 1;
+        const bool minus = (l32 & 1) != 0;
+        double pert = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) pert = (i == col) ? loc[i] : pert;
+        pert += delta;
+        if (minus) pert += neg2delta;
+#pragma unroll
+        for (int i = 0; i < S; ++i) loc[i] = (i == col) ? pert : loc[i];
+        rk4_end_state<DYN, false>(loc, loc + NX, dt0, sp.mp.dyn, ck, xe);
+        int jo = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) jo = (i == col) ? sc[i] : jo;
+        const bool present = stage && jo >= 0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const double ev = xe[r] - x2[r];
+            const double eo = __shfl_xor(ev, 1);   // the other side of the same column
+            const double cv = (scalar * (ev - eo)) * sp.w_eq;   // (plus lanes: v2 - v1; hyper_graph_optimization_problem_edge_based.cpp:1552)
+            if (!minus) {
+                c.Gm[r * W + col] = present ? cv : 0.0;
+                if (jac_dump && present) jac_dump[jo + r] = cv;
+            }
+        }
+    }
+    // ---- x_{k+1} columns (diagonal: only e_i depends on x_{k+1,i}), defect residual, stage inequality: lane i < NX
+    if (l32 < NX) {
+        const int i      = l32;
+        const double xei = sp.xe0[(((size_t)vsel * sp.batch_total + inst) * sp.N + kk) * NX + i];
+        const double x2i = X[kk * S + S + i];
+        const double a = x2i + delta, b = a + neg2delta;
+        const double cd = (scalar * ((xei - a) - (xei - b))) * sp.w_eq;
+        const int jo    = sc[S + i];
+        const bool present = stage && jo >= 0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const double v = (present && r == i) ? cd : 0.0;   // rows r != i: scalar * (e_r - e_r) = 0
+            c.Gm[r * W + S + i] = v;
+            if (jac_dump && present) jac_dump[jo + r] = v;
+        }
+        c.rv[i] = stage ? (xei - x2i) * sp.w_eq : 0.0;
+        double cinv = 0.0, rin = 0.0;
+        if (stage && p.ineq_cols) {   // computeValuesActiveInequality + its active-row Jacobian (sweep_body (b), (3))
+            double q[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) q[t] = X[kk * S + t];
+            const double c0 = ineq_ball(q, sp.mp.ineq);
+            rin             = (c0 < 0) ? 0.0 : c0 * sp.w_ineq;
+            const bool active = rin > 0.0;
+            double q2[3], q1[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { const double up = q[t] + delta; q2[t] = (t == i) ? up : q[t]; q1[t] = (t == i) ? up + neg2delta : q[t]; }
+            const double c2 = ineq_ball(q2, sp.mp.ineq), c1 = ineq_ball(q1, sp.mp.ineq);
+            const int jq = p.ineq_cols[kk * NX + i];
+            cinv = (jq >= 0 && active) ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
+            if (jac_dump && jq >= 0) jac_dump[jq] = active ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
+        }
+        c.cin[i] = cinv;
+        if (i == 0) c.red[7] = rin;
+    }
+    // ---- single-entry rows of the interval's components (cost row, bound row): lane e < S  (sweep_body comp_values / comp_jac)
+    if (l32 < S) {
+        const int e    = l32;
+        const bool isx = e < NX;
+        double dd = 0.0, gg = 0.0;
+        if (block && (isx || stage)) {
+            const int v       = k * S + e;
+            const CompInfo ci = p.comp[v];
+            if (isx) c.fx[e] = ci.fixed ? 1.0 : 0.0;
+            const double xv = X[v];
+            const bool fin  = (k == N - 1);
+            double w = 0.0, ref = 0.0;
+#pragma unroll
+            for (int t = 0; t < NX; ++t)
+                if (isx && e == t) { w = fin ? sp.mp.sqf[t] : sp.mp.sq[t]; ref = sp.xref[(size_t)inst * CORBO_HIP_MAX_NX + t]; }
+#pragma unroll
+            for (int t = 0; t < NU; ++t)
+                if (!isx && e - NX == t) w = sp.mp.sr[t];
+            if (!ci.fixed && ci.cost_joff >= 0) {
+                const double a = xv + delta, b = a + neg2delta;
+                const double dv  = scalar * (w * (a - ref) - w * (b - ref));
+                const double val = w * (xv - ref);
+                dd += dv * dv;
+                gg -= dv * val;
+                if (jac_dump) {   // the cost block column incl. its explicit zeros
+                    const int cdim = isx ? NX : NU, cc = isx ? e : e - NX;
+                    for (int r = 0; r < cdim; ++r) jac_dump[ci.cost_joff - cc + r] = (r == cc) ? dv : 0.0;
+                }
+            }
+            if (ci.bnd_joff >= 0) {
+                const double l = sp.lb[xo + v], u = sp.ub[xo + v];
+                const double ab = (xv < l) ? -sp.w_b : ((xv > u) ? sp.w_b : 0.0);
+                double vb = (xv < l) ? l - xv : ((xv > u) ? xv - u : 0.0);
+                vb *= sp.w_b;
+                dd += ab * ab;
+                gg -= ab * vb;
+                if (jac_dump) jac_dump[ci.bnd_joff] = ab;
+            }
+        }
+        c.dg[e] = dd;
+        c.gd[e] = gg;
+    }
+}
+#pragma clang fp contract(fast)
+
+template <int DYN, bool USE_MFMA>
+__global__ __launch_bounds__(64) void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
+{
+    using Dy = Dynamics<DYN>;
+    constexpr int NX = Dy::NX, NU = Dy::NU;
+    using BL = BigLds<NX, NU>;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int pair = blockIdx.x, inst = blockIdx.y + p.inst0, lane = threadIdx.x;
+    const LmState* st = p.st + inst;
+    int vsel = 0;
+    double mu_eff = 0.0;
+    if (!jac_dump) {
+        if (st->done) return;
+        if (diag_only && !st->first) return;
+        vsel   = st->vbuf;
+        mu_eff = (st->fresh ? 0.0 : st->mu_acc) + st->mu;   // H_ii += mu on every inner pass, never undone (:135-138)
+    }
+    const BigCtx<NX, NU> c0(sm), c1(sm + BL::TOTAL);
+    const int half = lane >> 5;
+    big_stage_edges<DYN>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
+    __syncthreads();
+    if (jac_dump) return;
+    for (int h = 0; h < 2; ++h) {
+        const int k = 2 * pair + h;
+        if (k >= p.N) break;
+        double* wk = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE;
+        if (diag_only) big_diag_stage<NX, NU>(h ? c1 : c0, p.N, k, lane, wk + BL::WS_L);
+        else big_assemble_stage<NX, NU, USE_MFMA>(h ? c1 : c0, p.N, k, lane, wk, mu_eff);
+    }
+}
+
 // value of lane `src` (uniform / compile-time index) for every lane: two v_readlane_b32, the result lives in scalar registers
 __device__ __forceinline__ double lane_bcast(double v, int src)
 {
@@ -1896,7 +2042,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
     auto block_of = [&](int s) { return (side == 0) ? s : N - 1 - s; };
     const int mysteps = (side == 0) ? m : N - 1 - m;
     if (mysteps > 0) fetch(block_of(0));
-    __syncthreads();
+    lds_barrier();
     // one elimination step on register rows; returns y_k[row]; leaves Y in yr, L in d
     auto factor_rows = [&](double (&d)[NX], double (&cr)[NX], double g, double (&yr)[NX]) -> double {
         // Cholesky, right-looking over register rows: after step j, d[j] of lane i > j is L[i][j], of lane j it is 1 / L[j][j]
@@ -1948,7 +2094,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
         double dnk[NX];
 #pragma unroll
         for (int cc = 0; cc < NX; ++cc) dnk[cc] = pn[cc];
-        __syncthreads();   // every lane has taken its mailbox row
+        lds_barrier();   // every lane has taken its mailbox row
         if (active) {
             if (own) {
 #pragma unroll
@@ -1972,7 +2118,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
             for (int t = 0; t < NX; ++t) v -= yr[t] * lane_bcast(yk, t);
             gn_r = v;
         }
-        __syncthreads();
+        lds_barrier();
         if (active) {   // Schur complement to the next block of the sequence: mailbox -= Y Y^T (matrix cores, operands through LDS)
             if constexpr (USE_MFMA && NX <= 16 && NX % 4 == 0) {
                 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -1999,11 +2145,11 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // ---- the meeting block m: own parts + both mailboxes (wave 0's holds DN_{m-1} - Y Y^T, wave 1's -Y' Y'^T)
     if (side == 1 && own) xch[row] = gn_r;
-    __syncthreads();
+    lds_barrier();
     double xm_r = 0.0;
     if (side == 0) {
         const double* wk = ws + (size_t)m * BL::WS_STAGE;
@@ -2127,7 +2273,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
     y2  = wave_sum(y2);
     dn2 = wave_sum(dn2);
     if (lane == 0) { xch[2 * NX + 2 * side] = y2; xch[2 * NX + 2 * side + 1] = dn2; }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         y2  = xch[2 * NX] + xch[2 * NX + 2];
         dn2 = xch[2 * NX + 1] + xch[2 * NX + 3];
@@ -2447,6 +2593,8 @@ CORBO_HIP_DYN_ENTRIES(lin32)
 CORBO_HIP_DYN_ENTRIES(lin33)
 CORBO_HIP_DYN_ENTRIES(lin41)
 
+bool stage_entry_quadrotor(const FactorParams& fp, const SweepParams& sp, int diag_only, double* jac_dump, hipStream_t stream);
+
 #ifdef CORBO_HIP_DYN_TU
 #define CORBO_HIP_CAT2(a, b) a##b
 #define CORBO_HIP_CAT(a, b) CORBO_HIP_CAT2(a, b)
@@ -2470,6 +2618,16 @@ bool CORBO_HIP_CAT(pass_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const FactorP
 #endif
 }
 void CORBO_HIP_CAT(plant_entry_, CORBO_HIP_DYN_TU_NAME)(const PlantParams& p, hipStream_t stream) { launch_plant_step_t<CORBO_HIP_DYN_TU>(p, stream); }
+#ifdef CORBO_HIP_DYN_TU_BIG
+bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, const SweepParams& sp, int diag_only, double* jac_dump, hipStream_t stream)
+{
+    using Dy = Dynamics<CORBO_HIP_DYN_TU>;
+    if (!sp.xe0 || (!fp.work && !jac_dump)) return false;
+    const size_t lds = sizeof(double) * 2 * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
+    hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), dim3((fp.N + 1) / 2, fp.batch), dim3(64), lds, stream, fp, sp, diag_only, jac_dump);
+    return true;
+}
+#endif
 #endif  // CORBO_HIP_DYN_TU
 
 #ifndef CORBO_HIP_DYN_TU
@@ -2598,6 +2756,12 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
     }
 }
 
+bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, double* jac_out, hipStream_t stream)
+{
+    if (d.dynamics != CORBO_HIP_DYN_QUADROTOR) return false;
+    return stage_entry_quadrotor(fp, sp, 0, jac_out, stream);
+}
+
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
     switch (d.dynamics) {
@@ -2627,16 +2791,15 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
     }
 }
 
-bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream)
+bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream, const SweepParams* sp)
 {
     if (d.nx == 12 && d.nu == 4) {
-        if (p.dt_free || !p.work) return false;
-        const size_t lds = sizeof(double) * (size_t)BigLds<12, 4>::TOTAL;
+        if (p.dt_free || !p.work || !sp || d.dynamics != CORBO_HIP_DYN_QUADROTOR) return false;
         if (p.first_pass) {   // (the kernels themselves also check LmState::first)
-            hipLaunchKernelGGL((big_diag_kernel<12, 4>), dim3(p.N, p.batch), dim3(64), lds, stream, p);
+            if (!stage_entry_quadrotor(p, *sp, 1, nullptr, stream)) return false;
             hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), 0, stream, p);
         }
-        hipLaunchKernelGGL((big_assemble_kernel<12, 4, true>), dim3(p.N, p.batch), dim3(64), lds, stream, p);
+        if (!stage_entry_quadrotor(p, *sp, 0, nullptr, stream)) return false;
         hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * 12 * 12 + 2 * 12 + 8), stream, p);
         return true;
     }

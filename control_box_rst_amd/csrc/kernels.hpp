@@ -37,6 +37,7 @@ struct SweepParams {
     // static structure
     int32_t batch, nvs, m, nnz, N, s, nx, off_dt, dt_free;
     int32_t inst0;      // first instance of this launch (sub-batch launches); grid = batch
+    int32_t batch_total;  // instances of the handle (stride of the per-handle two-buffer arrays)
     int32_t eq_row0, ineq_row0;  // first residual row of the defect / stage-inequality edges (one edge per stage)
     const StageCols* stage_cols;  // N-1: Jacobian offsets of the defect columns of stage k
     const CompInfo* comp;         // nvs: cost-block offsets per component
@@ -62,6 +63,12 @@ struct SweepParams {
     int32_t* active_count;  // number of instances not done after this pass (mode 3)
     long long* timeline;    // optional [16] shader-clock stamps of instance 0 (diagnostics), may be null
     double* chi2;           // [batch] dense copy of the accepted chi2 (*obj_value), written by the LM modes
+    // big-block family (multiple shooting with RK4, nx > 6): the Jacobian of an LM pass is never stored.  The residual sweep keeps
+    // the end state of the unperturbed Runge-Kutta step of every shooting interval, [2][batch][N][nx] (the half paired with the
+    // accepted iterate / the trial half, like values0 / values1), and the stage kernel (big_stage_kernel) differentiates and
+    // assembles from the accepted iterate on the fly.
+    double* xe0;            // or null
+    int32_t skip_jac;       // LM modes: leave the Jacobian to the stage kernel
 };
 
 struct FactorParams {
@@ -99,7 +106,9 @@ struct FactorParams {
 
 // returns false if the (dynamics, defect) pair has no device instantiation
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
-bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream);
+// sp: the sweep parameters of the same pass (big-block family: the stage kernel evaluates the edges itself); may be null for the
+// LDS-resident small-block families
+bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream, const SweepParams* sp = nullptr);
 // one fused LM pass: [sweep phase (sp.mode 2 = prologue, 3 = trial step) -> factor phase] per workgroup, one launch
 struct WarmStartParams {
     int32_t batch, nvs, nx, nu, N, xf_fixed_mask, shift;
@@ -125,6 +134,10 @@ void launch_gather_first_control(const double* x, double* out, int nvs, int nx, 
 // dst_a[b][:] = row_a, dst_b[b][:] = row_b for b < batch (the descriptor's bound pattern repeated for every instance)
 void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst_a, double* dst_b, int nvs, int batch, hipStream_t stream);
 
+// big-block family, parity hook: the Jacobian values the stage kernel differentiates (defect blocks, cost / bound / inequality rows of
+// every interval) at the accepted iterate, written into jac_out [batch][nnz_pad] in the public value order; needs a residual sweep
+// (mode 0 / 1 with sp.xe0) of the same iterate before it
+bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, double* jac_out, hipStream_t stream);
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p, int nc);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
