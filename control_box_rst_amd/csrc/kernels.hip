@@ -1943,7 +1943,11 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 #pragma clang fp contract(fast)
 
 template <int DYN, bool USE_MFMA>
-__global__ __launch_bounds__(64) void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
+__global__ __launch_bounds__(64)
+#ifdef CORBO_HIP_STAGE_WAVES
+__attribute__((amdgpu_waves_per_eu(CORBO_HIP_STAGE_WAVES, CORBO_HIP_STAGE_WAVES)))
+#endif
+void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
 {
     using Dy = Dynamics<DYN>;
     constexpr int NX = Dy::NX, NU = Dy::NU;
@@ -2016,6 +2020,11 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
     double* xt        = p.xt + (size_t)inst * p.nvs;
     double* ws        = p.work + (size_t)inst * p.work_stride;
 
+    // diagnostics (p.timeline): cycles of wave 0 per part of a step, summed over the steps
+    const bool tl_on = p.timeline && blockIdx.x == 0 && threadIdx.x == 0;
+    long long tl_acc[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;
+#define CHAIN_STAMP(slot) do { if (p.timeline) { const long long now_ = clock64(); tl_acc[slot] += now_ - tl_t; tl_t = now_; } } while (0)
+    if (p.timeline) tl_t = clock64();
     double y2 = 0.0;
     for (int e = lane; e < NX * NX; e += 64) Dn[e] = 0.0;
     double gn_r = 0.0;   // Schur mailbox of the right-hand side (row of this lane)
@@ -2041,7 +2050,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
     };
     auto block_of = [&](int s) { return (side == 0) ? s : N - 1 - s; };
     const int mysteps = (side == 0) ? m : N - 1 - m;
-    if (mysteps > 0) fetch(block_of(0));
+    fetch(block_of(0));   // (mysteps >= 1 for every horizon this kernel is launched with; block 0 / N-1 always exist)
     lds_barrier();
     // one elimination step on register rows; returns y_k[row]; leaves Y in yr, L in d
     auto factor_rows = [&](double (&d)[NX], double (&cr)[NX], double g, double (&yr)[NX]) -> double {
@@ -2094,14 +2103,16 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
         double dnk[NX];
 #pragma unroll
         for (int cc = 0; cc < NX; ++cc) dnk[cc] = pn[cc];
+        CHAIN_STAMP(0);   // waited for the block's data, combined it
         lds_barrier();   // every lane has taken its mailbox row
+        fetch(block_of((s + 1 < mysteps) ? s + 1 : ((mysteps > 0) ? mysteps - 1 : 0)));   // unconditional (see the back-substitution)
         if (active) {
             if (own) {
 #pragma unroll
                 for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = (side == 0) ? dnk[cc] : 0.0;
             }
-            if (s + 1 < mysteps) fetch(block_of(s + 1));
             yk = factor_rows(d, cr, g, yr);
+            CHAIN_STAMP(1);   // Cholesky + triangular solves on register rows
             if (own) y2 += yk * yk;
             double* wk = ws + (size_t)k * BL::WS_STAGE;
             if (own) {
@@ -2118,6 +2129,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
             for (int t = 0; t < NX; ++t) v -= yr[t] * lane_bcast(yk, t);
             gn_r = v;
         }
+        CHAIN_STAMP(2);   // stores + right-hand-side update
         lds_barrier();
         if (active) {   // Schur complement to the next block of the sequence: mailbox -= Y Y^T (matrix cores, operands through LDS)
             if constexpr (USE_MFMA && NX <= 16 && NX % 4 == 0) {
@@ -2146,6 +2158,7 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
             }
         }
         lds_barrier();
+        CHAIN_STAMP(3);   // Schur complement (matrix cores) + barriers
     }
     // ---- the meeting block m: own parts + both mailboxes (wave 0's holds DN_{m-1} - Y Y^T, wave 1's -Y' Y'^T)
     if (side == 1 && own) xch[row] = gn_r;
@@ -2196,43 +2209,50 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
     //      x_q and x_{q+1}: wave 0 does stage k with block k, wave 1 stage k-1 with block k.
     double dn2 = (side == 0) ? xm_r * xm_r : 0.0, xn_r = xch[NX + row];
     if (!own) xn_r = 0.0;
-    double bl[NX], by[NX], byv = 0.0, bzx[NX], bzp[NX], byu = 0.0, bluu[NU], bx = 0.0, bxu = 0.0;
-    int bfix = 0;
+    // The factor data of a block is requested TWO steps ahead (two register buffers, the loop is unrolled by two): one step of
+    // arithmetic (~1.5k cycles) does not cover an HBM round trip, and with one step of lookahead the wave sat in s_waitcnt for more
+    // than half of this loop.
+    struct BackBuf { double bl[NX], by[NX], bzx[NX], bzp[NX], bluu[NU], byv, byu, bx, bxu; int bfix; };
+    BackBuf b0{}, b1{};
     const int urow = (lane < NU) ? lane : NU - 1;
-    auto fetch_b = [&](int k) {
+    auto blk_of = [&](int s) { return (side == 0) ? m - 1 - s : m + 1 + s; };
+    auto fetch_b = [&](BackBuf& bb, int k) {
         const double* wk = ws + (size_t)k * BL::WS_STAGE;
         const int q = (side == 0) ? k : k - 1;                       // stage whose controls go with this block
         const double* wq = ws + (size_t)q * BL::WS_STAGE;
 #pragma unroll
         for (int t = 0; t < NX; ++t) {
-            bl[t] = wk[BL::WS_L + t * NX + row];   // L[t][row]  (t >= row; 1 / L[row][row] at t == row)
-            by[t] = wk[BL::WS_Y + t * NX + row];   // Y[t][row]
-            bzx[t] = wq[BL::WS_ZX + urow * NX + t];
-            bzp[t] = wq[BL::WS_ZP + urow * NX + t];
+            bb.bl[t] = wk[BL::WS_L + t * NX + row];   // L[t][row]  (t >= row; 1 / L[row][row] at t == row)
+            bb.by[t] = wk[BL::WS_Y + t * NX + row];   // Y[t][row]
+            bb.bzx[t] = wq[BL::WS_ZX + urow * NX + t];
+            bb.bzp[t] = wq[BL::WS_ZP + urow * NX + t];
         }
 #pragma unroll
-        for (int b = 0; b < NU; ++b) bluu[b] = wq[BL::WS_LUU + b * NU + urow];   // Luu[b][urow]
-        byv  = wk[BL::WS_YV + row];
-        byu  = wq[BL::WS_YU + urow];
-        bfix = p.comp[k * S + row].fixed;
-        bx   = (lane < NX) ? xin[k * S + lane] : 0.0;
-        bxu  = (lane >= NX && lane < S) ? xin[q * S + lane] : 0.0;
+        for (int b = 0; b < NU; ++b) bb.bluu[b] = wq[BL::WS_LUU + b * NU + urow];   // Luu[b][urow]
+        bb.byv  = wk[BL::WS_YV + row];
+        bb.byu  = wq[BL::WS_YU + urow];
+        bb.bfix = p.comp[k * S + row].fixed;
+        bb.bx   = (lane < NX) ? xin[k * S + lane] : 0.0;
+        bb.bxu  = (lane >= NX && lane < S) ? xin[q * S + lane] : 0.0;
     };
-    if (mysteps > 0) fetch_b((side == 0) ? m - 1 : m + 1);
-    for (int s = 0; s < mysteps; ++s) {
-        const int k = (side == 0) ? m - 1 - s : m + 1 + s;
+    // (The prefetch is UNCONDITIONAL -- clamped block index -- and a step beyond the end is computed and discarded: loads issued on
+    // one side of a branch only make the compiler fall back to s_waitcnt vmcnt(0) at the next use, which serialises the prefetch.)
+    const int last_s = (mysteps > 0) ? mysteps - 1 : 0;
+    auto back_step = [&](BackBuf& bb, int s) {
+        const bool valid = (s < mysteps);
+        const int k = blk_of(valid ? s : last_s);
         const int q = (side == 0) ? k : k - 1;
-        double Lc[NX], v = byv, zx[NX], zp[NX], lu[NU];
-        const double yu_r = byu, xin_r = bx, xinu_r = bxu;
-        const bool fixed_r = (bfix != 0);
+        double Lc[NX], v = bb.byv, zx[NX], zp[NX], lu[NU];
+        const double yu_r = bb.byu, xin_r = bb.bx, xinu_r = bb.bxu;
+        const bool fixed_r = (bb.bfix != 0);
 #pragma unroll
         for (int t = 0; t < NX; ++t) {
-            Lc[t] = bl[t]; zx[t] = bzx[t]; zp[t] = bzp[t];
-            v -= by[t] * lane_bcast(xn_r, t);   // t = y - Y^T x_neighbour
+            Lc[t] = bb.bl[t]; zx[t] = bb.bzx[t]; zp[t] = bb.bzp[t];
+            v -= bb.by[t] * lane_bcast(xn_r, t);   // t = y - Y^T x_neighbour
         }
 #pragma unroll
-        for (int b = 0; b < NU; ++b) lu[b] = bluu[b];
-        if (s + 1 < mysteps) fetch_b((side == 0) ? k - 1 : k + 1);
+        for (int b = 0; b < NU; ++b) lu[b] = bb.bluu[b];
+        fetch_b(bb, blk_of((s + 2 < mysteps) ? s + 2 : last_s));
         // x_k = L^{-T} t across the lanes
         double xk = 0.0;
 #pragma unroll
@@ -2258,14 +2278,24 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
             w -= (lane < a) ? lu[a] * ua : 0.0;           // lane b < a: Luu[a][b] u_a
         }
         if (lane >= NU) uk = 0.0;
-        dn2 += xk * xk + uk * uk;
+        dn2 += valid ? xk * xk + uk * uk : 0.0;
         double ush = 0.0;
 #pragma unroll
         for (int a = 0; a < NU; ++a) { const double ua = lane_bcast(uk, a); if (lane == NX + a) ush = ua; }
-        if (lane < NX) xt[k * S + lane] = xin_r + xk;
-        else if (lane < S) xt[q * S + lane] = xinu_r + ush;
-        xn_r = xk;
+        if (valid && lane < NX) xt[k * S + lane] = xin_r + xk;
+        else if (valid && lane < S) xt[q * S + lane] = xinu_r + ush;
+        xn_r = valid ? xk : xn_r;
+    };
+    fetch_b(b0, blk_of(0 < mysteps ? 0 : last_s));
+    fetch_b(b1, blk_of(1 < mysteps ? 1 : last_s));
+    CHAIN_STAMP(4);   // meeting block
+    for (int s = 0; s < mysteps; s += 2) {
+        back_step(b0, s);
+        back_step(b1, s + 1);
     }
+    CHAIN_STAMP(5);   // back-substitution
+    if (tl_on)
+        for (int i = 0; i < 6; ++i) p.timeline[i] = tl_acc[i];
     if (threadIdx.x == 0) {
         xt[p.off_dt] = xin[p.off_dt];
         if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
