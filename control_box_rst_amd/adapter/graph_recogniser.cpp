@@ -1,0 +1,576 @@
+// graph_recogniser.cpp -- see the header.  Compiled against the reference's headers (inside the reference's build tree).
+#include "graph_recogniser.h"
+
+#include <corbo-numerics/explicit_integrators.h>
+#include <corbo-numerics/finite_differences_collocation.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_variable_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_grid.h>
+#include <corbo-optimal-control/structured_ocp/edges/finite_differences_collocation_edges.h>
+#include <corbo-optimal-control/structured_ocp/edges/multiple_shooting_edges.h>
+#include <corbo-optimization/hyper_graph/scalar_vertex.h>
+#include <corbo-optimization/hyper_graph/vector_vertex.h>
+#include <corbo-systems/benchmark/linear_benchmark_systems.h>
+#include <corbo-systems/benchmark/nonlinear_benchmark_systems.h>
+
+#include <cmath>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+namespace corbo {
+namespace {
+
+// ---- private data members of reference classes that have no getter, reached without touching the reference's headers: the usual
+//      access rules do not apply to the arguments of an explicit instantiation ([temp.spec]/6), and the instantiation publishes the
+//      pointer-to-member through a static initialiser.
+template <class Tag>
+struct MemberOf
+{
+    static typename Tag::type ptr;
+};
+template <class Tag>
+typename Tag::type MemberOf<Tag>::ptr;
+template <class Tag, typename Tag::type P>
+struct Publish
+{
+    struct Filler
+    {
+        Filler() { MemberOf<Tag>::ptr = P; }
+    };
+    static Filler filler;
+};
+template <class Tag, typename Tag::type P>
+typename Publish<Tag, P>::Filler Publish<Tag, P>::filler;
+
+#define CORBO_HIP_PRIVATE_MEMBER(TAG, CLASS, MEMBER_TYPE, MEMBER) \
+    struct TAG { using type = MEMBER_TYPE CLASS::*; };           \
+    template struct Publish<TAG, &CLASS::MEMBER>;
+
+CORBO_HIP_PRIVATE_MEMBER(FdEdgeDynamics, FDCollocationEdge, SystemDynamicsInterface::Ptr, _dynamics)
+CORBO_HIP_PRIVATE_MEMBER(FdEdgeScheme, FDCollocationEdge, FiniteDifferencesCollocationInterface::Ptr, _fd_eval)
+CORBO_HIP_PRIVATE_MEMBER(MsEdgeDynamics, MSVariableDynamicsOnlyEdge, SystemDynamicsInterface::Ptr, _dynamics)
+CORBO_HIP_PRIVATE_MEMBER(MsEdgeIntegrator, MSVariableDynamicsOnlyEdge, NumericalIntegratorExplicitInterface::Ptr, _integrator)
+CORBO_HIP_PRIVATE_MEMBER(DuffingDamping, DuffingOscillator, double, _damping)
+CORBO_HIP_PRIVATE_MEMBER(DuffingAlpha, DuffingOscillator, double, _spring_alpha)
+CORBO_HIP_PRIVATE_MEMBER(DuffingBeta, DuffingOscillator, double, _spring_beta)
+CORBO_HIP_PRIVATE_MEMBER(PendulumM, SimplePendulum, double, _m)
+CORBO_HIP_PRIVATE_MEMBER(PendulumL, SimplePendulum, double, _l)
+CORBO_HIP_PRIVATE_MEMBER(PendulumG, SimplePendulum, double, _g)
+CORBO_HIP_PRIVATE_MEMBER(PendulumRho, SimplePendulum, double, _rho)
+CORBO_HIP_PRIVATE_MEMBER(MasslessOmega, MasslessPendulum, double, _omega0)
+CORBO_HIP_PRIVATE_MEMBER(ToyMu, ToyExample, double, _mu)
+CORBO_HIP_PRIVATE_MEMBER(CartMc, CartPole, double, _mc)
+CORBO_HIP_PRIVATE_MEMBER(CartMp, CartPole, double, _mp)
+CORBO_HIP_PRIVATE_MEMBER(CartL, CartPole, double, _l)
+CORBO_HIP_PRIVATE_MEMBER(CartG, CartPole, double, _g)
+
+template <class Tag, class Obj>
+auto& member(Obj& o)
+{
+    return o.*(MemberOf<Tag>::ptr);
+}
+
+bool fail(std::string* reason, const std::string& why)
+{
+    if (reason) *reason = why;
+    return false;
+}
+
+// temporarily changed vertex values: restored on scope exit (the graph is exactly as it was found when the recogniser returns)
+struct VertexGuard
+{
+    VertexInterface* v;
+    std::vector<double> keep;
+    explicit VertexGuard(VertexInterface* vtx) : v(vtx), keep(vtx->getData(), vtx->getData() + vtx->getDimension()) {}
+    ~VertexGuard() { std::memcpy(v->getDataRaw(), keep.data(), keep.size() * sizeof(double)); }
+};
+
+Eigen::VectorXd evalEdge(BaseEdge& e)
+{
+    Eigen::VectorXd v(e.getDimension());
+    e.computeValues(v);
+    return v;
+}
+
+// A row of a least-squares term  r_i = w_i (x_i - ref_i)  (diagonal weights, quadratic_cost.cpp:116-118, final_state_cost.cpp:76-92)
+// identified EXACTLY through the edge's own evaluation: ref_i is the x_i at which the row is exactly zero (x - ref rounds to zero only
+// for x == ref), and w_i = r_i / d at x_i = ref_i + d with d a power of two for which (ref_i + d) - ref_i == d holds in floating point
+// (then w d is a pure exponent shift).  Off-diagonal responses must vanish.  false: not a diagonal affine term.
+bool identifyDiagonalAffine(BaseEdge& e, VertexInterface* v, Eigen::VectorXd* w, Eigen::VectorXd* ref)
+{
+    const int n = v->getDimension();
+    if (e.getDimension() != n) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    w->resize(n);
+    ref->resize(n);
+    for (int i = 0; i < n; ++i)
+    {
+        const double x0 = x[i];
+        const Eigen::VectorXd r0 = evalEdge(e);
+        x[i] = x0 + 1.0;
+        const Eigen::VectorXd r1 = evalEdge(e);
+        for (int j = 0; j < n; ++j)
+            if (j != i && r1[j] != r0[j]) return false;   // coupled components: not diagonal
+        double wi = r1[i] - r0[i];
+        if (wi == 0.0 || !std::isfinite(wi))
+        {   // zero weight: the row is identically zero, any reference will do
+            x[i] = x0 + 1024.0;
+            if (evalEdge(e)[i] != 0.0 || r0[i] != 0.0) return false;
+            (*w)[i] = 0.0; (*ref)[i] = 0.0;
+            x[i] = x0;
+            continue;
+        }
+        // root of the row: zero itself (terms without a reference), else Newton on an exactly linear function lands within an ulp or
+        // two; then walk to the exact zero
+        double xr = x0 - r0[i] / wi;
+        bool found = false;
+        x[i] = 0.0;
+        if (evalEdge(e)[i] == 0.0) { xr = 0.0; found = true; }
+        for (int it = 0; it < 8 && !found; ++it)
+        {
+            x[i] = xr;
+            const double r = evalEdge(e)[i];
+            if (r == 0.0) { found = true; break; }
+            const double step = r / wi;
+            double xn = xr - step;
+            if (xn == xr) xn = std::nextafter(xr, (step > 0) ? -INFINITY : INFINITY);
+            xr = xn;
+        }
+        if (!found) return false;
+        (*ref)[i] = xr;
+        // exact weight
+        double d = std::ldexp(1.0, std::max(-20, std::min(20, (xr == 0.0) ? 0 : std::ilogb(xr))));
+        bool ok = false;
+        for (int t = 0; t < 40 && !ok; ++t, d *= 2.0)
+        {
+            volatile double xp = xr + d;
+            if ((double)xp - xr == d)
+            {
+                x[i] = xp;
+                (*w)[i] = evalEdge(e)[i] / d;
+                ok = true;
+            }
+        }
+        if (!ok) return false;
+        // the model reproduces the edge at the original point bit for bit
+        x[i] = x0;
+        if (evalEdge(e)[i] != (*w)[i] * (x0 - (*ref)[i])) return false;
+    }
+    return true;
+}
+
+bool sameVector(const Eigen::VectorXd& a, const Eigen::VectorXd& b)
+{
+    return a.size() == b.size() && (a.array() == b.array()).all();
+}
+
+// ---- dynamics object -> device dynamics id + parameters
+bool describeDynamics(SystemDynamicsInterface& dyn, corbo_hip_problem_desc& d, std::string* reason)
+{
+    const int nx = dyn.getStateDimension(), nu = dyn.getInputDimension();
+    for (double& p : d.dyn_params) p = 0.0;
+    if (auto* s = dynamic_cast<VanDerPolOscillator*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_VAN_DER_POL; d.dyn_params[0] = s->getDampingCoefficient(); return true; }
+    if (auto* s = dynamic_cast<SerialIntegratorSystem*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_SERIAL_INTEGRATOR; d.dyn_params[0] = s->getTimeConstant(); return true; }
+    if (auto* s = dynamic_cast<ParallelIntegratorSystem*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_PARALLEL_INTEGRATOR; d.dyn_params[0] = s->getTimeConstant(); return true; }
+    if (auto* s = dynamic_cast<DuffingOscillator*>(&dyn))
+    {
+        d.dynamics = CORBO_HIP_DYN_DUFFING;
+        d.dyn_params[0] = member<DuffingDamping>(*s); d.dyn_params[1] = member<DuffingAlpha>(*s); d.dyn_params[2] = member<DuffingBeta>(*s);
+        return true;
+    }
+    if (dynamic_cast<FreeSpaceRocket*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_FREE_SPACE_ROCKET; return true; }
+    if (auto* s = dynamic_cast<SimplePendulum*>(&dyn))
+    {
+        d.dynamics = CORBO_HIP_DYN_SIMPLE_PENDULUM;
+        d.dyn_params[0] = member<PendulumM>(*s); d.dyn_params[1] = member<PendulumL>(*s); d.dyn_params[2] = member<PendulumG>(*s);
+        d.dyn_params[3] = member<PendulumRho>(*s);
+        return true;
+    }
+    if (auto* s = dynamic_cast<MasslessPendulum*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_MASSLESS_PENDULUM; d.dyn_params[0] = member<MasslessOmega>(*s); return true; }
+    if (auto* s = dynamic_cast<ToyExample*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_TOY_EXAMPLE; d.dyn_params[0] = member<ToyMu>(*s); return true; }
+    if (dynamic_cast<ArtsteinsCircle*>(&dyn)) { d.dynamics = CORBO_HIP_DYN_ARTSTEINS_CIRCLE; return true; }
+    if (auto* s = dynamic_cast<CartPole*>(&dyn))
+    {
+        if (member<CartMc>(*s) != 1.0 || member<CartMp>(*s) != 0.3 || member<CartL>(*s) != 0.5 || member<CartG>(*s) != 9.81)
+            return fail(reason, "CartPole with non-default parameters (the device model has the reference's defaults built in)");
+        d.dynamics = CORBO_HIP_DYN_CART_POLE;
+        return true;
+    }
+    Eigen::VectorXd x = Eigen::VectorXd::Zero(nx), u = Eigen::VectorXd::Zero(nu), f(nx);
+    if (dynamic_cast<LinearStateSpaceModel*>(&dyn))
+    {   // f = A x + B u is exact on unit vectors (every other term of a row sum is an exact zero)
+        if (nx * nx > 16 || nx * nu > 12) return fail(reason, "LinearStateSpaceModel too large for the device table");
+        d.dynamics = CORBO_HIP_DYN_LINEAR_STATE_SPACE;
+        for (int j = 0; j < nx; ++j)
+        {
+            x.setZero(); x[j] = 1.0;
+            dyn.dynamics(x, u, f);
+            for (int i = 0; i < nx; ++i) d.lin_a[i * nx + j] = f[i];
+        }
+        x.setZero();
+        for (int j = 0; j < nu; ++j)
+        {
+            u.setZero(); u[j] = 1.0;
+            dyn.dynamics(x, u, f);
+            for (int i = 0; i < nx; ++i) d.lin_b[i * nu + j] = f[i];
+        }
+        return true;
+    }
+    // user systems: matched against the device library's plug-in models by evaluating them (corbo_hip_eval_dynamics runs the device's
+    // formula on the GPU) at deterministic probe points; sin / cos may differ from the host's by an ulp
+    struct Candidate { int id; int nx, nu; double prm[5]; const char* name; };
+    const Candidate cands[] = {{CORBO_HIP_DYN_UNICYCLE, 3, 2, {0, 0, 0, 0, 0}, "unicycle"},
+                               {CORBO_HIP_DYN_QUADROTOR, 12, 4, {9.81, 1.0, 0.01, 0.01, 0.02}, "quadrotor (g = 9.81, m = 1, I = 0.01 / 0.01 / 0.02)"}};
+    for (const Candidate& c : cands)
+    {
+        if (c.nx != nx || c.nu != nu) continue;
+        corbo_hip_problem_desc t = d;
+        t.dynamics = c.id; t.nx = nx; t.nu = nu;
+        for (int i = 0; i < 5; ++i) t.dyn_params[i] = c.prm[i];
+        const int P = 6;
+        std::vector<double> xs(P * nx), us(P * nu), fd(P * nx);
+        for (int p = 0; p < P; ++p)
+        {
+            for (int i = 0; i < nx; ++i) xs[p * nx + i] = 0.37 * std::sin(1.0 + 1.7 * i + 0.9 * p) + 0.05 * p;
+            for (int i = 0; i < nu; ++i) us[p * nu + i] = 0.8 * std::cos(0.3 + 2.1 * i + 1.3 * p) + ((c.id == CORBO_HIP_DYN_QUADROTOR && i == 0) ? 9.0 : 0.0);
+        }
+        if (corbo_hip_eval_dynamics(&t, P, xs.data(), us.data(), fd.data()) != CORBO_HIP_OK) continue;
+        bool same = true;
+        for (int p = 0; p < P && same; ++p)
+        {
+            dyn.dynamics(Eigen::Map<Eigen::VectorXd>(&xs[p * nx], nx), Eigen::Map<Eigen::VectorXd>(&us[p * nu], nu), f);
+            for (int i = 0; i < nx; ++i)
+                if (!(std::abs(f[i] - fd[p * nx + i]) <= 1e-14 * (1.0 + std::abs(f[i])))) same = false;
+        }
+        if (same)
+        {
+            d.dynamics = c.id;
+            for (int i = 0; i < 5; ++i) d.dyn_params[i] = c.prm[i];
+            return true;
+        }
+    }
+    return fail(reason, "system dynamics class is neither one of the reference's benchmark systems nor one of the device library's plug-in models "
+                        "(setDeviceModel() states a model explicitly)");
+}
+
+// keep-out ball  c(x) = r^2 - |x[0:3] - centre|^2  (stage inequality of cfg 5), identified from evaluations and verified at probes
+bool identifyBall(BaseEdge& e, VertexInterface* v, double* prm /*cx, cy, cz, r*/)
+{
+    const int n = v->getDimension();
+    if (e.getDimension() != 1 || n < 3) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    const double c0 = evalEdge(e)[0];
+    double ctr[3];
+    for (int i = 0; i < 3; ++i)
+    {   // c(e_i) - c(-e_i) = 4 centre_i   (exact for moderate centres)
+        x[i] = 1.0;  const double cp = evalEdge(e)[0];
+        x[i] = -1.0; const double cm = evalEdge(e)[0];
+        x[i] = 0.0;
+        ctr[i] = (cp - cm) / 4.0;
+    }
+    for (int i = 0; i < 3; ++i) x[i] = ctr[i];
+    const double r2 = evalEdge(e)[0];   // value at the centre
+    if (!(r2 > 0)) return false;
+    prm[0] = ctr[0]; prm[1] = ctr[1]; prm[2] = ctr[2]; prm[3] = std::sqrt(r2);
+    // verify: the device formula (model.hpp ineq_ball) at probe points, components >= 3 do not matter
+    (void)c0;
+    for (int p = 0; p < 4; ++p)
+    {
+        for (int i = 0; i < n; ++i) x[i] = 0.3 * std::sin(0.7 + 1.3 * i + 2.1 * p);
+        const double dx = x[0] - prm[0], dy = x[1] - prm[1], dz = x[2] - prm[2];
+        const double mine = prm[3] * prm[3] - (dx * dx + dy * dy + dz * dz);
+        if (!(std::abs(evalEdge(e)[0] - mine) <= 1e-13 * (1.0 + std::abs(mine)))) return false;
+    }
+    return true;
+}
+
+// TerminalBall, diagonal S:  c(x_f) = (x_f - ref)^T S (x_f - ref) - gamma   (final_state_constraints.cpp:60-80)
+bool identifyTerminalBall(BaseEdge& e, VertexInterface* v, const Eigen::VectorXd& ref, double* prm /*S_11..S_nn, gamma*/)
+{
+    const int n = v->getDimension();
+    if (e.getDimension() != 1 || ref.size() != n) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    for (int i = 0; i < n; ++i) x[i] = ref[i];
+    const double gamma = -evalEdge(e)[0];   // 0 - gamma, exact
+    for (int i = 0; i < n; ++i)
+    {
+        double d = 1024.0;
+        volatile double xp = ref[i] + d;
+        if ((double)xp - ref[i] != d) return false;
+        x[i] = xp;
+        const double s_est = (evalEdge(e)[0] + gamma) / (d * d);
+        // candidates around the estimate: the one that reproduces the edge at several distances wins
+        double best = s_est;
+        int best_hits = -1;
+        for (int c = -2; c <= 2; ++c)
+        {
+            double s = s_est;
+            for (int t = 0; t < std::abs(c); ++t) s = std::nextafter(s, (c > 0) ? INFINITY : -INFINITY);
+            int hits = 0;
+            for (double dd : {1.0, 2.0, 0.5, 1024.0})
+            {
+                volatile double xq = ref[i] + dd;
+                if ((double)xq - ref[i] != dd) continue;
+                x[i] = xq;
+                if (evalEdge(e)[0] == (dd * s) * dd - gamma) ++hits;
+            }
+            if (hits > best_hits) { best_hits = hits; best = s; }
+        }
+        prm[i] = best;
+        x[i]   = ref[i];
+    }
+    prm[n] = gamma;
+    for (int p = 0; p < 3; ++p)
+    {   // cross terms must vanish: verify the diagonal model away from the axes
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i)
+        {
+            x[i] = ref[i] + 0.25 * std::sin(0.4 + 1.1 * i + 1.9 * p);
+            const double xd = x[i] - ref[i];
+            acc += (xd * prm[i]) * xd;
+        }
+        const double mine = acc - gamma;
+        if (!(std::abs(evalEdge(e)[0] - mine) <= 1e-13 * (1.0 + std::abs(mine)))) return false;
+    }
+    return true;
+}
+
+struct GridView
+{
+    int kind = -1;   // corbo_hip_grid
+    int N = 0, nx = 0, nu = 0;
+    std::vector<VertexInterface*> xs, us;   // x_0 .. x_{N-2}, u_0 .. u_{N-2}
+    VertexInterface* xf = nullptr;
+    VertexInterface* dt = nullptr;
+};
+
+bool viewGrid(BaseHyperGraphOptimizationProblem& hg, GridView* g, std::string* reason)
+{
+    if (!hg.getGraph().hasVertexSet()) return fail(reason, "the hypergraph has no vertex set");
+    VertexSetInterface* vs = hg.getGraph().getVertexSetRaw();
+    if (dynamic_cast<FiniteDifferencesVariableGrid*>(vs)) g->kind = CORBO_HIP_GRID_FD_VARIABLE;
+    else if (dynamic_cast<FiniteDifferencesGrid*>(vs)) g->kind = CORBO_HIP_GRID_FD;
+    else if (dynamic_cast<MultipleShootingGrid*>(vs)) g->kind = CORBO_HIP_GRID_MS;
+    else return fail(reason, "vertex set is not a FiniteDifferencesGrid, FiniteDifferencesVariableGrid or MultipleShootingGrid");
+    std::vector<VertexInterface*> vtx;
+    vs->getVertices(vtx);
+    // x_0..x_{N-2}, u_0..u_{N-2}, x_f, dt, (u_prev, u_ref, u_prev_dt)  (full_discretization_grid_base.cpp:499-512); ShootingGridBase
+    // interleaves states and controls (shooting_grid_base.cpp:567-581)
+    if ((int)vtx.size() < 7 || ((int)vtx.size() - 5) % 2 != 0) return fail(reason, "unexpected vertex list of the grid");
+    g->N = ((int)vtx.size() - 5) / 2 + 1;
+    const bool interleaved = (g->kind == CORBO_HIP_GRID_MS);
+    for (int k = 0; k < g->N - 1; ++k)
+    {
+        g->xs.push_back(interleaved ? vtx[2 * k] : vtx[k]);
+        g->us.push_back(interleaved ? vtx[2 * k + 1] : vtx[g->N - 1 + k]);
+    }
+    g->xf = vtx[2 * (g->N - 1)];
+    g->dt = vtx[2 * (g->N - 1) + 1];
+    g->nx = g->xf->getDimension();
+    g->nu = g->us[0]->getDimension();
+    if (g->nx > CORBO_HIP_MAX_NX || g->nu > CORBO_HIP_MAX_NU) return fail(reason, "state / control dimension beyond the device limits");
+    for (int k = 0; k < g->N - 1; ++k)
+        if (g->xs[k]->getDimension() != g->nx || g->us[k]->getDimension() != g->nu) return fail(reason, "vertex dimensions vary along the horizon");
+    if (g->dt->getDimension() != 1) return fail(reason, "dt vertex is not scalar");
+    return true;
+}
+
+int indexOf(const std::vector<VertexInterface*>& list, const VertexInterface* v)
+{
+    for (size_t i = 0; i < list.size(); ++i)
+        if (list[i] == v) return (int)i;
+    return -1;
+}
+
+}  // namespace
+
+bool readStateReferenceForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::VectorXd* xref)
+{
+    GridView g;
+    std::string why;
+    if (!viewGrid(hg, &g, &why) || g.nx != nx) return false;
+    for (const BaseEdge::Ptr& e : hg.getGraph().getEdgeSetRaw()->getLsqObjectiveEdges())
+    {
+        if (e->getNumVertices() != 1 || e->getDimension() != nx) continue;
+        VertexInterface* v = e->getVertexRaw(0);
+        if (v != g.xf && indexOf(g.xs, v) < 0) continue;
+        Eigen::VectorXd w, ref;
+        if (!identifyDiagonalAffine(*e, v, &w, &ref)) return false;
+        if ((w.array() == 0.0).any()) continue;   // a zero weight hides the reference of that component: try another edge
+        *xref = ref;
+        return true;
+    }
+    return false;
+}
+
+bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason)
+{
+    GridView g;
+    if (!viewGrid(hg, &g, reason)) return false;
+    corbo_hip_problem_desc& d = model->desc;
+    std::memset(&d, 0, sizeof(d));
+    d.grid = g.kind; d.nx = g.nx; d.nu = g.nu; d.N = g.N;
+    const OptimizationEdgeSet* es = hg.getGraph().getEdgeSetRaw();
+    if (!es->getObjectiveEdges().empty()) return fail(reason, "objective edges that are not in least-squares form");
+    if (!es->getMixedEdges().empty()) return fail(reason, "mixed edges (single-control shooting intervals, integral terms)");
+
+    // ---- equality edges: one defect edge per interval, in order; then optionally the terminal equality constraint
+    const std::vector<BaseEdge::Ptr>& eqs = es->getEqualityEdges();
+    if ((int)eqs.size() < g.N - 1) return fail(reason, "fewer equality edges than grid intervals");
+    SystemDynamicsInterface* dyn = nullptr;
+    for (int k = 0; k < g.N - 1; ++k)
+    {
+        BaseEdge* e = eqs[k].get();
+        VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
+        if (e->getNumVertices() != 4 || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] || e->getVertexRaw(2) != x2 || e->getVertexRaw(3) != g.dt)
+            return fail(reason, "equality edge " + std::to_string(k) + " is not a dynamics defect on (x_k, u_k, x_{k+1}, dt)");
+        SystemDynamicsInterface* dk = nullptr;
+        int defect = -1;
+        if (auto* fd = dynamic_cast<FDCollocationEdge*>(e))
+        {
+            dk = member<FdEdgeDynamics>(*fd).get();
+            FiniteDifferencesCollocationInterface* sch = member<FdEdgeScheme>(*fd).get();
+            if (dynamic_cast<ForwardDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_FORWARD;
+            else if (dynamic_cast<BackwardDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_BACKWARD;
+            else if (dynamic_cast<MidpointDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_MIDPOINT;
+            else if (dynamic_cast<CrankNicolsonDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_CRANK_NICOLSON;
+            else return fail(reason, "unknown finite-differences collocation scheme");
+        }
+        else if (auto* ms = dynamic_cast<MSVariableDynamicsOnlyEdge*>(e))
+        {
+            dk = member<MsEdgeDynamics>(*ms).get();
+            if (!dynamic_cast<IntegratorExplicitRungeKutta4*>(member<MsEdgeIntegrator>(*ms).get()))
+                return fail(reason, "shooting integrator other than IntegratorExplicitRungeKutta4");
+            defect = CORBO_HIP_DEFECT_RK4_SHOOTING;
+        }
+        else return fail(reason, "equality edge " + std::to_string(k) + " is neither an FDCollocationEdge nor an MSVariableDynamicsOnlyEdge");
+        if (k == 0) { dyn = dk; d.defect = defect; }
+        else if (dk != dyn || defect != d.defect) return fail(reason, "dynamics object / defect formula varies along the horizon");
+    }
+    if (!dyn) return fail(reason, "no dynamics object");
+    if (dyn->getStateDimension() != g.nx || dyn->getInputDimension() != g.nu) return fail(reason, "dynamics dimensions do not match the vertices");
+
+    // ---- least-squares objective edges, in the grid's creation order (nlp_functions.cpp:70-132, finite_differences_grid.cpp:38-154)
+    Eigen::VectorXd sq, sr, sqf, xref_state, xref_final;
+    int n_state = 0, n_ctrl = 0, n_final = 0, n_dt = 0;
+    double dt_weight = 0.0;
+    for (const BaseEdge::Ptr& ep : es->getLsqObjectiveEdges())
+    {
+        BaseEdge* e = ep.get();
+        if (e->getNumVertices() != 1) return fail(reason, "least-squares edge on more than one vertex (control deviation / integral term)");
+        VertexInterface* v = e->getVertexRaw(0);
+        Eigen::VectorXd w, ref;
+        if (v == g.dt)
+        {   // MinimumTime(lsq): weight * dt, created twice (nlp_functions.cpp:91-107)
+            if (e->getDimension() != 1) return fail(reason, "dt cost term of dimension > 1");
+            if (!identifyDiagonalAffine(*e, v, &w, &ref) || ref[0] != 0.0) return fail(reason, "dt cost term is not weight * dt");
+            if (n_dt > 0 && w[0] != dt_weight) return fail(reason, "dt cost terms with different weights");
+            dt_weight = w[0];
+            ++n_dt;
+            continue;
+        }
+        if (!identifyDiagonalAffine(*e, v, &w, &ref))
+            return fail(reason, "a least-squares term is not of the form sqrt(W_diag) (v - ref) (non-diagonal weight matrix?)");
+        if (v == g.xf)
+        {
+            if (n_final++ > 0) return fail(reason, "more than one least-squares term on x_f");
+            sqf = w; xref_final = ref;
+        }
+        else if (indexOf(g.xs, v) >= 0)
+        {
+            if (n_state++ == 0) { sq = w; xref_state = ref; }
+            else if (!sameVector(w, sq) || !sameVector(ref, xref_state)) return fail(reason, "state cost weights / reference vary along the horizon (time-varying reference trajectory)");
+        }
+        else if (indexOf(g.us, v) >= 0)
+        {
+            if ((ref.array() != 0.0).any()) return fail(reason, "non-zero control reference");
+            if (n_ctrl++ == 0) sr = w;
+            else if (!sameVector(w, sr)) return fail(reason, "control cost weights vary along the horizon");
+        }
+        else return fail(reason, "least-squares term on an unexpected vertex");
+    }
+    if (n_dt > 0)
+    {
+        if (n_dt != 2 || n_state || n_ctrl) return fail(reason, "minimum-time cost combined with other stage costs");
+        if (dt_weight != std::sqrt((double)(g.N - 1))) return fail(reason, "minimum-time weight is not sqrt(N - 1)");
+        d.stage_cost = CORBO_HIP_COST_MIN_TIME_LSQ;
+    }
+    else if (n_state || n_ctrl)
+    {
+        if (n_state != g.N - 1 || n_ctrl != g.N - 1) return fail(reason, "quadratic stage cost without a state or without a control term on every interval");
+        d.stage_cost = CORBO_HIP_COST_QUADRATIC_LSQ;
+        for (int i = 0; i < g.nx; ++i) d.q_diag[i] = sq[i] * sq[i];
+        for (int i = 0; i < g.nu; ++i) d.r_diag[i] = sr[i] * sr[i];
+    }
+    else d.stage_cost = CORBO_HIP_COST_NONE;
+    d.final_cost = n_final ? 1 : 0;
+    if (n_final)
+        for (int i = 0; i < g.nx; ++i) d.qf_diag[i] = sqf[i] * sqf[i];
+    // one static reference for every term
+    model->xref = Eigen::VectorXd::Zero(g.nx);
+    if (n_state) model->xref = xref_state;
+    if (n_final)
+    {
+        if (n_state)
+        {
+            for (int i = 0; i < g.nx; ++i)
+                if (sq[i] != 0.0 && sqf[i] != 0.0 && xref_state[i] != xref_final[i]) return fail(reason, "stage and final cost use different state references");
+            for (int i = 0; i < g.nx; ++i)
+                if (sq[i] == 0.0) model->xref[i] = xref_final[i];
+        }
+        else model->xref = xref_final;
+    }
+    // The device takes the weights as Q / R / Qf diagonals and forms sqrt() itself (structure.cpp): the round trip sqrt(w * w) == w
+    // must hold for the identified sqrt-weights, otherwise the residual rows would differ in the last bit
+    for (int i = 0; i < g.nx; ++i)
+        if ((n_state && std::sqrt(d.q_diag[i]) != sq[i]) || (n_final && std::sqrt(d.qf_diag[i]) != sqf[i])) return fail(reason, "state weight does not survive the square / square-root round trip");
+    for (int i = 0; i < g.nu; ++i)
+        if (n_ctrl && std::sqrt(d.r_diag[i]) != sr[i]) return fail(reason, "control weight does not survive the square / square-root round trip");
+
+    // ---- terminal equality constraint: x_f - xref (final_state_constraints.h:130-160)
+    if ((int)eqs.size() == g.N)
+    {
+        BaseEdge* e = eqs[g.N - 1].get();
+        Eigen::VectorXd w, ref;
+        if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf || !identifyDiagonalAffine(*e, g.xf, &w, &ref) || (w.array() != 1.0).any())
+            return fail(reason, "extra equality edge is not a TerminalEqualityConstraint x_f - xref");
+        if ((n_state || n_final) && !sameVector(ref, model->xref)) return fail(reason, "terminal equality constraint uses a different reference");
+        model->xref = ref;
+        d.final_eq = 1;
+    }
+    else if ((int)eqs.size() > g.N) return fail(reason, "unexpected additional equality edges");
+
+    // ---- inequality edges: one stage inequality per interval on x_k (keep-out ball), then optionally the TerminalBall on x_f
+    const std::vector<BaseEdge::Ptr>& ins = es->getInequalityEdges();
+    size_t at = 0;
+    if (ins.size() >= (size_t)(g.N - 1) && ins[0]->getNumVertices() == 1 && ins[0]->getVertexRaw(0) == g.xs[0])
+    {
+        double prm[4], prm_k[4];
+        for (int k = 0; k < g.N - 1; ++k)
+        {
+            BaseEdge* e = ins[k].get();
+            if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xs[k] || !identifyBall(*e, g.xs[k], (k == 0) ? prm : prm_k))
+                return fail(reason, "stage inequality " + std::to_string(k) + " is not a keep-out ball on the first three state components");
+            if (k > 0 && std::memcmp(prm, prm_k, sizeof(prm)) != 0) return fail(reason, "stage inequality varies along the horizon");
+        }
+        d.stage_ineq = CORBO_HIP_INEQ_BALL;
+        for (int i = 0; i < 4; ++i) d.ineq_params[i] = prm[i];
+        at = g.N - 1;
+    }
+    if (at < ins.size())
+    {
+        BaseEdge* e = ins[at].get();
+        if (at + 1 != ins.size() || e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf || !identifyTerminalBall(*e, g.xf, model->xref, d.final_ineq_params))
+            return fail(reason, "inequality edge that is neither the per-interval keep-out ball nor a TerminalBall (diagonal S) on x_f around the cost reference");
+        d.final_ineq = CORBO_HIP_FINAL_INEQ_TERMINAL_BALL;
+    }
+    // ---- the dynamics object last (user systems are matched on the device)
+    return describeDynamics(*dyn, d, reason);
+}
+
+}  // namespace corbo

@@ -1,0 +1,45 @@
+// graph_recogniser.h -- hypergraph -> device descriptor ("graph -> descriptor recogniser").
+//
+// The reference hands a solver nothing but the hypergraph (corbo::NlpSolverInterface::solve, nlp_solver_interface.h:105): vertices
+// with values / bounds / fixed flags and opaque edge objects.  This unit works out, from that graph alone, which of the
+// device-describable problems it is:
+//   * the vertex set IS the grid object (DiscretizationGridInterface derives from VertexSetInterface): RTTI gives the grid kind
+//     (FiniteDifferencesGrid, FiniteDifferencesVariableGrid, MultipleShootingGrid);
+//   * the equality edges are FDCollocationEdge / MSVariableDynamicsOnlyEdge objects (RTTI); the dynamics object, the collocation
+//     scheme and the integrator they hold are read out of them (the reference keeps them private and has no getters: they are
+//     reached through pointers-to-member published by explicit template instantiations, [temp.spec]/6 -- no reference header is
+//     modified); the benchmark systems of the reference are mapped to the device's dynamics ids with their parameters, user systems
+//     are matched by evaluating them (unicycle, quadrotor);
+//   * cost / constraint edges are generic adapters around StageFunction members (generic_edge.h:294-498): their weights and
+//     references are IDENTIFIED through the edges' own public computeValues() on temporarily modified vertex values -- the weight
+//     vectors and references come out bit-exact (evaluation points are chosen so that every product is a power-of-two scaling).
+// Anything else (non-diagonal weights, time-varying references, integral cost edges, other edge types) is refused with a reason:
+// the adapter has no CPU fallback.
+#ifndef CONTROL_BOX_RST_AMD_ADAPTER_GRAPH_RECOGNISER_H_
+#define CONTROL_BOX_RST_AMD_ADAPTER_GRAPH_RECOGNISER_H_
+
+#include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_base.h>
+
+#include <Eigen/Core>
+#include <string>
+
+#include "corbo_hip.h"
+
+namespace corbo {
+
+struct HipRecognisedModel
+{
+    corbo_hip_problem_desc desc;   // everything but N, bounds, xf_fixed_mask, dt_ref / dt bounds (the adapter reads those from the vertices)
+    Eigen::VectorXd xref;          // static state reference all cost / constraint terms agree on
+};
+
+// false: *reason says what the device cannot describe
+bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason);
+
+// the state reference alone (cheap: a few evaluations of one cost edge); used on every solve to follow a reference that changed
+// between runs without a structure change.  false if the graph has no state-dependent least-squares term.
+bool readStateReferenceForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::VectorXd* xref);
+
+}  // namespace corbo
+
+#endif

@@ -1,10 +1,13 @@
 // levenberg_marquardt_sparse_hip.cpp -- see the header.  Compiled against the reference's headers.
 #include "levenberg_marquardt_sparse_hip.h"
 
+#include "graph_recogniser.h"
+
 #include <corbo-core/console.h>
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_base.h>
 #include <corbo-optimization/hyper_graph/vertex_interface.h>
 
+#include <Eigen/Sparse>
 #include <cmath>
 #include <cstring>
 
@@ -52,11 +55,6 @@ bool LevenbergMarquardtSparseHip::initialize(OptimizationProblemInterface* probl
         PRINT_ERROR("LevenbergMarquardtSparseHip(): cannot handle non-least-squares objectives or LS objectives in non-LS form.");
         return false;
     }
-    if (!_have_desc)
-    {
-        PRINT_ERROR("LevenbergMarquardtSparseHip(): setDeviceModel() must be called before initialize().");
-        return false;
-    }
     return true;
 }
 
@@ -66,12 +64,14 @@ void LevenbergMarquardtSparseHip::clear()
     std::memset(&_stats, 0, sizeof(_stats));
 }
 
-// Stacked residual [lsq | w_eq eq | w_ineq max(0, c) | w_b bound distance] of the graph's own edges (the reference's
-// LevenbergMarquardtSparse::computeValues, levenberg_marquardt_sparse.cpp:222-246) against the device's at the uploaded vertex values.
-bool LevenbergMarquardtSparseHip::modelMatchesGraph(OptimizationProblemInterface& problem)
+// Stacked residual [lsq | w_eq eq | w_ineq max(0, c) | w_b bound distance] and combined sparse Jacobian of the graph's own edges (the
+// reference's LevenbergMarquardtSparse::computeValues, levenberg_marquardt_sparse.cpp:222-246, and
+// computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753) against the device's at the uploaded
+// vertex values.
+bool LevenbergMarquardtSparseHip::modelMatchesGraph(OptimizationProblemInterface& problem, bool perturbed)
 {
-    const double w_eq = _opts.weight_eq, w_ineq = _opts.weight_ineq, w_b = _opts.weight_bounds;
-    Eigen::VectorXd host(_dims.m), dev(_dims.m);
+    const double w_eq = _w_eq, w_ineq = _w_ineq, w_b = _w_b;
+    Eigen::VectorXd host(_dims.m), dev(_dims.m), devj(_dims.nnz);
     int idx = 0;
     if (_dims.lsq > 0) problem.computeValuesLsqObjective(host.segment(idx, _dims.lsq));
     idx += _dims.lsq;
@@ -88,11 +88,12 @@ bool LevenbergMarquardtSparseHip::modelMatchesGraph(OptimizationProblemInterface
         problem.computeDistanceFiniteCombinedBounds(host.segment(idx, _dims.bounds));
         host.segment(idx, _dims.bounds) *= w_b;
     }
-    if (corbo_hip_eval(_handle, w_eq, w_ineq, w_b, dev.data(), nullptr) != CORBO_HIP_OK)
+    if (corbo_hip_eval(_handle, w_eq, w_ineq, w_b, dev.data(), devj.data()) != CORBO_HIP_OK)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
         return false;
     }
+    const char* where = perturbed ? "at the perturbed probe point" : "at the current vertex values";
     for (int i = 0; i < _dims.m; ++i)
     {
         const double tol = 1e-9 * (1.0 + std::abs(host[i]));
@@ -100,10 +101,62 @@ bool LevenbergMarquardtSparseHip::modelMatchesGraph(OptimizationProblemInterface
         {
             const char* part = i < _dims.lsq ? "lsq objective" : i < _dims.lsq + _dims.eq ? "equality" : i < _dims.lsq + _dims.eq + _dims.ineq ? "inequality" : "bounds";
             PRINT_ERROR("LevenbergMarquardtSparseHip(): the device model does not describe this hypergraph: residual row "
-                        << i << " (" << part << ") is " << host[i] << " on the graph's edges and " << dev[i]
-                        << " on the device; refusing to solve (no CPU fallback).");
+                        << i << " (" << part << ") is " << host[i] << " on the graph's edges and " << dev[i] << " on the device " << where
+                        << "; refusing to solve (no CPU fallback).");
             return false;
         }
+    }
+    // combined sparse Jacobian: same (row, column) pattern, values to the finite-difference noise level (delta = 1e-9: ~1e-7 relative)
+    std::vector<int32_t> rows(_dims.nnz), cols(_dims.nnz);
+    if (corbo_hip_get_structure(&_desc, rows.data(), cols.data()) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
+    }
+    Eigen::SparseMatrix<double> Jh(_dims.m, _dims.n);
+    Jh.reserve(_dims.nnz);
+    problem.computeCombinedSparseJacobian(Jh, true, true, true, true, true, w_eq, w_ineq, w_b, &host);
+    double jmax = 1.0;
+    for (int k = 0; k < Jh.outerSize(); ++k)
+        for (Eigen::SparseMatrix<double>::InnerIterator it(Jh, k); it; ++it) jmax = std::max(jmax, std::abs(it.value()));
+    if ((int)Jh.nonZeros() != _dims.nnz)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): the graph's combined Jacobian has " << Jh.nonZeros() << " structural non-zeros, the device model " << _dims.nnz
+                                                                                       << "; refusing to solve.");
+        return false;
+    }
+    for (int k = 0; k < _dims.nnz; ++k)
+    {
+        const double jh = Jh.coeff(rows[k], cols[k]);
+        if (!(std::abs(jh - devj[k]) <= 2e-6 * jmax))
+        {
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): the device model does not describe this hypergraph: Jacobian entry (" << rows[k] << ", " << cols[k] << ") is "
+                        << jh << " on the graph's edges and " << devj[k] << " on the device " << where << "; refusing to solve (no CPU fallback).");
+            return false;
+        }
+    }
+    return true;
+}
+
+bool LevenbergMarquardtSparseHip::uploadVertices(const std::vector<VertexInterface*>& xs, const std::vector<VertexInterface*>& us, VertexInterface* xf,
+                                                 VertexInterface* dt)
+{
+    const int nx = _desc.nx, nu = _desc.nu, s = nx + nu, N = _desc.N;
+    auto pack = [&](VertexInterface* v, int off, int dim) {
+        std::memcpy(&_x[off], v->getData(), dim * sizeof(double));
+        std::memcpy(&_lb[off], v->getLowerBounds(), dim * sizeof(double));
+        std::memcpy(&_ub[off], v->getUpperBounds(), dim * sizeof(double));
+    };
+    for (int k = 0; k < N - 1; ++k) { pack(xs[k], k * s, nx); pack(us[k], k * s + nx, nu); }
+    pack(xf, (N - 1) * s, nx);
+    if (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE) pack(dt, (N - 1) * s + nx, 1);
+    std::vector<double> xref(nx, 0.0);
+    if (_xref.size() == nx)
+        for (int i = 0; i < nx; ++i) xref[i] = _xref[i];
+    if (corbo_hip_set_instance_data(_handle, _x.data(), _lb.data(), _ub.data(), xref.data()) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
     }
     return true;
 }
@@ -117,12 +170,20 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         PRINT_ERROR("LevenbergMarquardtSparseHip(): the problem is not a hypergraph optimization problem.");
         return SolverStatus::Error;
     }
+    // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287).  Kept here, not in the device
+    // handle: the reference's _weight_* survive a structure change, the handle does not.
+    if (new_run) { _w_eq = _opts.weight_eq; _w_ineq = _opts.weight_ineq; _w_b = _opts.weight_bounds; }
+    else
+    {
+        _w_eq *= _opts.adapt_factor_eq;       if (_w_eq > _opts.adapt_max_eq) _w_eq = _opts.adapt_max_eq;
+        _w_ineq *= _opts.adapt_factor_ineq;   if (_w_ineq > _opts.adapt_max_ineq) _w_ineq = _opts.adapt_max_ineq;
+        _w_b *= _opts.adapt_factor_bounds;    if (_w_b > _opts.adapt_max_bounds) _w_b = _opts.adapt_max_bounds;
+    }
     // vertices in the grid's order: x_0..x_{N-2}, u_0..u_{N-2}, x_f, dt, (u_prev, u_ref, u_prev_dt)
     // (FullDiscretizationGridBase::getVertices, full_discretization_grid_base.cpp:499-512)
     std::vector<VertexInterface*> vtx;
     hg->getGraph().getVertexSetRaw()->getVertices(vtx);
-    const int nx = _desc.nx, nu = _desc.nu, s = nx + nu;
-    if ((int)vtx.size() < 4 || ((int)vtx.size() - 5) % 2 != 0)
+    if ((int)vtx.size() < 7 || ((int)vtx.size() - 5) % 2 != 0)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): unexpected vertex set (not a full-discretization / shooting grid with 1 control per interval).");
         return SolverStatus::Error;
@@ -130,19 +191,40 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     const int N = ((int)vtx.size() - 5) / 2 + 1;
     VertexInterface* xf_v = vtx[2 * (N - 1)];
     VertexInterface* dt_v = vtx[2 * (N - 1) + 1];
+
+    // a fixed dt that changed without a structure change (setDtRef between runs) is a new problem for the device
+    const bool dt_changed = _handle && _desc.grid != CORBO_HIP_GRID_FD_VARIABLE && dt_v->getData()[0] != _desc.dt_ref;
+    bool verify_now = false;
+    if (new_structure || !_handle || _desc.N != N || dt_changed)
+    {
+        verify_now = _verify;
+        if (!_have_desc || _recognised)
+        {   // derive the device model from the graph
+            HipRecognisedModel m;
+            std::string why;
+            if (!recogniseHyperGraphForHip(*hg, &m, &why))
+            {
+                PRINT_ERROR("LevenbergMarquardtSparseHip(): this hypergraph has no device description: " << why << "; refusing to solve (no CPU fallback).");
+                return SolverStatus::Error;
+            }
+            _desc       = m.desc;
+            _xref       = m.xref;
+            _have_desc  = true;
+            _recognised = true;
+        }
+    }
+    const int nx = _desc.nx, nu = _desc.nu, s = nx + nu;
     // FullDiscretizationGridBase lists all states, then all controls; ShootingGridBase (shooting_grid_base.cpp:567-581) interleaves
     // them interval by interval: s_0, u_0, s_1, u_1, ...
     const bool interleaved = (_desc.grid == CORBO_HIP_GRID_MS);
-    auto xv = [&](int k) { return interleaved ? vtx[2 * k] : vtx[k]; };
-    auto uv = [&](int k) { return interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; };
+    std::vector<VertexInterface*> xs(N - 1), us(N - 1);
+    for (int k = 0; k < N - 1; ++k) { xs[k] = interleaved ? vtx[2 * k] : vtx[k]; us[k] = interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; }
 
-    bool verify_now = false;
-    if (new_structure || !_handle || _desc.N != N)
+    if (new_structure || !_handle || _desc.N != N || dt_changed)
     {
-        verify_now = _verify;
         // describe the structure, then verify it against what the graph reports
         for (int k = 0; k < N - 1; ++k)
-            if (xv(k)->getDimension() != nx || uv(k)->getDimension() != nu)
+            if (xs[k]->getDimension() != nx || us[k]->getDimension() != nu)
             {
                 PRINT_ERROR("LevenbergMarquardtSparseHip(): vertex dimensions do not match the device model (nx, nu).");
                 return SolverStatus::Error;
@@ -159,9 +241,9 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         }
         if (dt_free) { _desc.dt_lb = dt_v->getLowerBounds()[0]; _desc.dt_ub = dt_v->getUpperBounds()[0]; }
         // bound pattern: shared along the horizon in the reference (NlpFunctions::x_lb ...), read from x_1 / u_0 / x_f
-        VertexInterface* xb = (N > 2) ? xv(1) : xf_v;
+        VertexInterface* xb = (N > 2) ? xs[1] : xf_v;
         for (int i = 0; i < nx; ++i) { _desc.x_lb[i] = xb->getLowerBounds()[i]; _desc.x_ub[i] = xb->getUpperBounds()[i]; }
-        for (int i = 0; i < nu; ++i) { _desc.u_lb[i] = uv(0)->getLowerBounds()[i]; _desc.u_ub[i] = uv(0)->getUpperBounds()[i]; }
+        for (int i = 0; i < nu; ++i) { _desc.u_lb[i] = us[0]->getLowerBounds()[i]; _desc.u_ub[i] = us[0]->getUpperBounds()[i]; }
         _desc.dt_ref = dt_v->getData()[0];
         if (corbo_hip_get_dims(&_desc, &_dims) != CORBO_HIP_OK)
         {
@@ -188,33 +270,40 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         _lb.assign(_dims.nv, 0.0);
         _ub.assign(_dims.nv, 0.0);
     }
+    else if (_recognised)
+    {   // same structure, possibly a new reference (new_run with another xref): re-read it from the cost edges
+        Eigen::VectorXd xr;
+        if (readStateReferenceForHip(*hg, nx, &xr)) _xref = xr;
+    }
     const bool dt_free = (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE);
 
+    if (verify_now)
+    {
+        // (1) at the current vertex values, (2) at a deterministically perturbed point: every unfixed component moved by a fixed
+        // non-zero pattern through the problem's own increment operator, then restored
+        if (!uploadVertices(xs, us, xf_v, dt_v) || !modelMatchesGraph(problem, false))
+        {
+            releaseHandle();   // the next call re-checks
+            return SolverStatus::Error;
+        }
+        Eigen::VectorXd inc(_dims.n);
+        for (int i = 0; i < _dims.n; ++i) inc[i] = ((i & 1) ? -1.0 : 1.0) * 0.01 * (1.0 + (i % 7) / 7.0);
+        problem.backupParameters();
+        problem.applyIncrement(inc);
+        const bool ok = uploadVertices(xs, us, xf_v, dt_v) && modelMatchesGraph(problem, true);
+        problem.restoreBackupParameters(false);
+        if (!ok)
+        {
+            releaseHandle();
+            return SolverStatus::Error;
+        }
+    }
     // ---- gather vertex values and bounds into the C-ABI's vertex layout
-    auto pack = [&](VertexInterface* v, int off, int dim) {
-        std::memcpy(&_x[off], v->getData(), dim * sizeof(double));
-        std::memcpy(&_lb[off], v->getLowerBounds(), dim * sizeof(double));
-        std::memcpy(&_ub[off], v->getUpperBounds(), dim * sizeof(double));
-    };
-    for (int k = 0; k < N - 1; ++k) { pack(xv(k), k * s, nx); pack(uv(k), k * s + nx, nu); }
-    pack(xf_v, (N - 1) * s, nx);
-    if (dt_free) pack(dt_v, (N - 1) * s + nx, 1);
+    if (!uploadVertices(xs, us, xf_v, dt_v)) return SolverStatus::Error;
 
-    std::vector<double> xref(nx, 0.0);
-    if (_xref.size() == nx)
-        for (int i = 0; i < nx; ++i) xref[i] = _xref[i];
-
-    if (corbo_hip_set_instance_data(_handle, _x.data(), _lb.data(), _ub.data(), xref.data()) != CORBO_HIP_OK)
-    {
-        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
-        return SolverStatus::Error;
-    }
-    if (verify_now && !modelMatchesGraph(problem))
-    {
-        releaseHandle();   // the next call re-checks
-        return SolverStatus::Error;
-    }
-    if (corbo_hip_solve(_handle, &_opts, new_run ? 1 : 0) != CORBO_HIP_OK)
+    corbo_hip_lm_opts o = _opts;   // the weights of THIS solve, stated explicitly (new_run = 1 makes the library take them as they are)
+    o.weight_eq = _w_eq; o.weight_ineq = _w_ineq; o.weight_bounds = _w_b;
+    if (corbo_hip_solve(_handle, &o, 1) != CORBO_HIP_OK)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
         return SolverStatus::Error;
@@ -234,7 +323,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         for (int i = 0; i < dim; ++i)
             if (!v->isFixedComponent(i)) v->setData(i, _x[off + i]);
     };
-    for (int k = 0; k < N - 1; ++k) { unpack(xv(k), k * s, nx); unpack(uv(k), k * s + nx, nu); }
+    for (int k = 0; k < N - 1; ++k) { unpack(xs[k], k * s, nx); unpack(us[k], k * s + nx, nu); }
     unpack(xf_v, (N - 1) * s, nx);
     if (dt_free) unpack(dt_v, (N - 1) * s + nx, 1);
 

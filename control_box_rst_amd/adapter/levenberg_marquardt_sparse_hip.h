@@ -12,6 +12,7 @@
 #ifndef CONTROL_BOX_RST_AMD_ADAPTER_LEVENBERG_MARQUARDT_SPARSE_HIP_H_
 #define CONTROL_BOX_RST_AMD_ADAPTER_LEVENBERG_MARQUARDT_SPARSE_HIP_H_
 
+#include <corbo-optimization/hyper_graph/vertex_interface.h>
 #include <corbo-optimization/solver/nlp_solver_interface.h>
 
 #include <Eigen/Core>
@@ -42,24 +43,30 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     void setPenaltyWeights(double weight_eq, double weight_ineq, double weight_bounds);
     void setWeightAdapation(double factor_eq, double factor_ineq, double factor_bounds, double max_eq, double max_ineq, double max_bounds);
 
-    // ---- what a hypergraph does not reveal to a solver through the reference's public API: which collocation scheme, which
-    //      dynamics and which cost weights its (opaque) edges evaluate.  The caller states them once, next to the setters it
-    //      already uses to configure the OCP; dimensions, vertex values, bounds, fixed flags and dt are read from the graph
-    //      and checked against this description on every new structure.
+    // ---- By default NOTHING else has to be called: on every new structure the device model (grid kind, collocation scheme /
+    //      integrator, dynamics and its parameters, cost weights, reference, constraints) is derived from the hypergraph itself
+    //      (graph_recogniser.h), dimensions / vertex values / bounds / fixed flags / dt are read from the vertices, and the state
+    //      reference is re-read from the cost edges on every solve.  A graph the device cannot describe makes solve() return
+    //      SolverStatus::Error with the reason on stderr.
+    //      setDeviceModel() is the override for system dynamics the recogniser cannot know (user classes other than the device
+    //      library's plug-in models): the caller states the model; setStateReference() then states the reference.
     void setDeviceModel(const corbo_hip_problem_desc& desc) { _desc = desc; _have_desc = true; releaseHandle(); }
     void setStateReference(const Eigen::Ref<const Eigen::VectorXd>& xref) { _xref = xref; }
     void setDevice(int device) { _device = device; releaseHandle(); }
-    // On every new structure the stacked residual of the graph's own edges (evaluated on the host through the reference's
-    // computeValues* methods) is compared with the device's residual at the same vertex values; a device model that does not describe
-    // what the graph's edges compute (other dynamics, weights, collocation scheme, constraint) is refused instead of silently solving
-    // a different problem.  On by default; costs one host residual evaluation and one device sweep per structure change.
+    // On every new structure the device model -- recognised or stated -- is checked against the graph's own edges (evaluated on the
+    // host through the reference's computeValues* / computeCombinedSparseJacobian methods): stacked residual AND combined sparse
+    // Jacobian, at the current vertex values and at a deterministically perturbed point (every unfixed component moved, controls
+    // included -- at the reference's initial guess u = 0 and x_f = xref many descriptor errors are invisible).  A model that does not
+    // describe what the graph's edges compute is refused instead of silently solving a different problem.  On by default; costs two
+    // host evaluations and two device sweeps per structure change.
     void setVerifyModel(bool verify) { _verify = verify; }
 
     const corbo_hip_stats& getStatistics() const { return _stats; }
 
  private:
     void releaseHandle();
-    bool modelMatchesGraph(OptimizationProblemInterface& problem);
+    bool modelMatchesGraph(OptimizationProblemInterface& problem, bool perturbed);
+    bool uploadVertices(const std::vector<VertexInterface*>& xs, const std::vector<VertexInterface*>& us, VertexInterface* xf, VertexInterface* dt);
 
     corbo_hip_lm_opts _opts;
     corbo_hip_problem_desc _desc;
@@ -71,6 +78,8 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     corbo_hip_dims _dims;
     corbo_hip_stats _stats;
     std::vector<double> _x, _lb, _ub;
+    bool _recognised = false;               // _desc comes from the recogniser (not from setDeviceModel)
+    double _w_eq = 2, _w_ineq = 2, _w_b = 2;  // current (adapted) penalty weights: survive a structure change like the reference's _weight_*
 };
 
 FACTORY_REGISTER_NLP_SOLVER(LevenbergMarquardtSparseHip)

@@ -1116,6 +1116,49 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
     return CORBO_HIP_OK;
 }
 
+int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const double* x, const double* u, double* f)
+try {
+    if (!desc || !x || !u || !f || n < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    const int nx = desc->nx, nu = desc->nu;
+    if (nx < 1 || nx > CORBO_HIP_MAX_NX || nu < 1 || nu > CORBO_HIP_MAX_NU) return fail(CORBO_HIP_ERR_INVALID, "nx / nu out of range");
+    // the plant kernel with the "no integrator" mode: state in [n][MAX_NX], control at offset nx of a row of nx + nu doubles
+    struct Buffers {
+        double *xp = nullptr, *xu = nullptr, *lin = nullptr;
+        ~Buffers() { if (xp) (void)hipFree(xp); if (xu) (void)hipFree(xu); if (lin) (void)hipFree(lin); }
+    } b;
+    const int row = nx + nu;
+    std::vector<double> hxp((size_t)n * CORBO_HIP_MAX_NX, 0.0), hxu((size_t)n * row, 0.0);
+    for (int p = 0; p < n; ++p) {
+        for (int i = 0; i < nx; ++i) hxp[(size_t)p * CORBO_HIP_MAX_NX + i] = x[(size_t)p * nx + i];
+        for (int i = 0; i < nu; ++i) hxu[(size_t)p * row + nx + i] = u[(size_t)p * nu + i];
+    }
+    HIP_TRY(hipMalloc((void**)&b.xp, hxp.size() * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&b.xu, hxu.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(b.xp, hxp.data(), hxp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b.xu, hxu.data(), hxu.size() * sizeof(double), hipMemcpyHostToDevice));
+    PlantParams p{};
+    p.batch = n; p.nvs = row; p.nx = nx; p.nu = nu; p.integrator = 2 /* none: f itself */; p.dt = 1.0;
+    std::memcpy(p.dyn, desc->dyn_params, sizeof(p.dyn));
+    if (desc->dynamics == CORBO_HIP_DYN_LINEAR_STATE_SPACE) {
+        std::vector<double> ab((size_t)nx * nx + (size_t)nx * nu);
+        for (int i = 0; i < nx * nx; ++i) ab[i] = desc->lin_a[i];
+        for (int i = 0; i < nx * nu; ++i) ab[(size_t)nx * nx + i] = desc->lin_b[i];
+        HIP_TRY(hipMalloc((void**)&b.lin, ab.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(b.lin, ab.data(), ab.size() * sizeof(double), hipMemcpyHostToDevice));
+        const long long bits = (long long)reinterpret_cast<uintptr_t>(b.lin);
+        std::memcpy(&p.dyn[0], &bits, sizeof(double));
+    }
+    p.x = b.xu; p.xplant = b.xp;
+    if (!launch_plant_step(*desc, p, nullptr)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device model for this dynamics id / (nx, nu)");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hxp.data(), b.xp, hxp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int q = 0; q < n; ++q)
+        for (int i = 0; i < nx; ++i) f[(size_t)q * nx + i] = hxp[(size_t)q * CORBO_HIP_MAX_NX + i];
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
 const char* corbo_hip_last_error(void) { return g_last_error.c_str(); }
 
 }  // extern "C"

@@ -2564,8 +2564,10 @@ __global__ __launch_bounds__(256) void plant_step_kernel(const PlantParams p)
     }
     else {
         dyn_full<DYN>(x1, u, p.dyn, xe);
+        if (p.integrator == CORBO_HIP_INTEGRATOR_EULER) {
 #pragma unroll
-        for (int i = 0; i < D::NX; ++i) { xe[i] *= p.dt; xe[i] += x1[i]; }
+            for (int i = 0; i < D::NX; ++i) { xe[i] *= p.dt; xe[i] += x1[i]; }
+        }   // else (internal, corbo_hip_eval_dynamics): the right-hand side f(x, u) itself
     }
     if (p.disturbance) {
 #pragma unroll

@@ -324,6 +324,12 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
 /* Per-kernel HIP-event timing inside corbo_hip_solve (fills corbo_hip_stats.sweep_ms / factor_ms); off by default. */
 int corbo_hip_set_profiling(corbo_hip_handle h, int enable);
 
+/* f(x, u) of the descriptor's dynamics (SystemDynamicsInterface::dynamics, system_dynamics_interface.h:121) as the DEVICE evaluates
+ * it, for n points: x [n][nx], u [n][nu] -> f [n][nx] (host arrays).  Only dynamics, nx, nu, dyn_params (and lin_a / lin_b) of
+ * the descriptor are read.  Runs on the current HIP device.  Lets a caller check that a dynamics object it holds is the model a
+ * descriptor names (the adapter's recogniser matches user systems against the library's plug-in models with it). */
+int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const double* x, const double* u, double* f);
+
 /* Text of the last error on this thread. */
 const char* corbo_hip_last_error(void);
 

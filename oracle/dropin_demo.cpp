@@ -28,6 +28,9 @@
 #include <memory>
 #include <string>
 
+#include <vector>
+
+#include "../control_box_rst_amd/adapter/graph_recogniser.h"
 #include "../control_box_rst_amd/adapter/levenberg_marquardt_sparse_hip.h"
 
 using namespace corbo;
@@ -110,62 +113,121 @@ static Eigen::VectorXd trajectory(StructuredOptimalControlProblem& ocp, Discreti
     return out;
 }
 
-// scenario "unicycle": cfg 3 single instance; "dint": cfg 2 (free dt, 5 consecutive solves, new_run only first)
-static Run run(const std::string& scenario_in, bool hip, int N)
+// What the recogniser derived from a graph, as one JSON object (describe mode; compared with control_box_rst_amd/problems.py's
+// descriptors by tests/test_adapter_recogniser.py)
+static void printDesc(const char* scenario, bool ok, const std::string& why, const HipRecognisedModel& m)
 {
-    // "<scenario>_mismatch": the OCP of <scenario>, but the device model handed to the HIP solver states another state weight
-    const bool mismatch        = scenario_in.size() > 9 && scenario_in.compare(scenario_in.size() - 9, 9, "_mismatch") == 0;
-    const std::string scenario = mismatch ? scenario_in.substr(0, scenario_in.size() - 9) : scenario_in;
+    const corbo_hip_problem_desc& d = m.desc;
+    printf("{\"scenario\": \"%s\", \"recognised\": %d, \"reason\": \"%s\"", scenario, ok ? 1 : 0, why.c_str());
+    if (ok)
+    {
+        printf(", \"grid\": %d, \"defect\": %d, \"dynamics\": %d, \"stage_cost\": %d, \"final_cost\": %d, \"stage_ineq\": %d, \"final_ineq\": %d, \"final_eq\": %d, \"nx\": %d, \"nu\": %d, \"N\": %d",
+               d.grid, d.defect, d.dynamics, d.stage_cost, d.final_cost, d.stage_ineq, d.final_ineq, d.final_eq, d.nx, d.nu, d.N);
+        auto arr = [](const char* name, const double* v, int n) {
+            printf(", \"%s\": [", name);
+            for (int i = 0; i < n; ++i) printf("%s%.17g", i ? ", " : "", v[i]);
+            printf("]");
+        };
+        arr("q_diag", d.q_diag, d.nx); arr("r_diag", d.r_diag, d.nu); arr("qf_diag", d.qf_diag, d.nx); arr("dyn_params", d.dyn_params, 8);
+        arr("ineq_params", d.ineq_params, 4); arr("final_ineq_params", d.final_ineq_params, d.nx + 1); arr("xref", m.xref.data(), (int)m.xref.size());
+        arr("lin_a", d.lin_a, d.nx * d.nx <= 16 ? d.nx * d.nx : 0); arr("lin_b", d.lin_b, d.nx * d.nu <= 12 ? d.nx * d.nu : 0);
+    }
+    printf("}\n");
+}
+
+// describe mode: a solver that only runs the recogniser on the graph it is handed (no device needed for the reference's own classes)
+class RecogniseOnly : public NlpSolverInterface
+{
+ public:
+    NlpSolverInterface::Ptr getInstance() const override { return std::make_shared<RecogniseOnly>(); }
+    bool isLsqSolver() const override { return true; }
+    bool initialize(OptimizationProblemInterface* = nullptr) override { return true; }
+    SolverStatus solve(OptimizationProblemInterface& problem, bool, bool, double* obj_value) override
+    {
+        if (obj_value) *obj_value = 0;
+        auto* hg = dynamic_cast<BaseHyperGraphOptimizationProblem*>(&problem);
+        ok = hg && recogniseHyperGraphForHip(*hg, &model, &why);
+        // the graph must be left exactly as it was found
+        return SolverStatus::Converged;
+    }
+    void clear() override {}
+    bool ok = false;
+    std::string why;
+    HipRecognisedModel model;
+};
+
+enum class Mode { Reference, HipAuto, HipStated, HipStatedWrong, Describe };
+
+// scenarios: "unicycle" cfg 3 single instance; "dint" cfg 2 (free dt, 5 consecutive solves, new_run only first); "quad" reduced cfg 5;
+// "vdp" cfg 1; "unicycle_tball" TerminalBall; "duffing" / "pendulum" / "lin32": reference benchmark classes with NON-default parameters
+// (their private members are what the recogniser has to get right); "unicycle_fullq": a non-diagonal Q (must be refused)
+static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* describe_out = nullptr)
+{
     Run r;
     SystemDynamicsInterface::Ptr dyn;
     std::shared_ptr<FiniteDifferencesGrid> grid;
     std::shared_ptr<MultipleShootingGrid> ms_grid;
     auto hg = std::make_shared<HyperGraphOptimizationProblemEdgeBased>();
     NlpSolverInterface::Ptr solver;
-    corbo_hip_problem_desc d;
+    corbo_hip_problem_desc d;   // only for the stated-model modes
     std::memset(&d, 0, sizeof(d));
     for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) { d.x_lb[i] = -CORBO_HIP_INF; d.x_ub[i] = CORBO_HIP_INF; }
     for (int i = 0; i < CORBO_HIP_MAX_NU; ++i) { d.u_lb[i] = -CORBO_HIP_INF; d.u_ub[i] = CORBO_HIP_INF; }
-    double w;
+    double w = 10;
     Eigen::VectorXd x0, xf;
-    int solves = 1;
-    const bool tball = (scenario == "unicycle_tball");   // cfg 3 structure, short horizon, TerminalBall final-stage constraint
-    if (scenario == "unicycle" || tball)
+    int solves = 1, nu = 1;
+    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq");
+    const bool uni = (scenario == "unicycle" || tball || fullq);
+    if (uni)
     {
         dyn  = std::make_shared<UnicycleRef>();
         grid = std::make_shared<FiniteDifferencesGrid>();
-        w    = 10;
         x0   = Eigen::Vector3d(0, 0, 0);
         xf   = Eigen::Vector3d(2, 1, 0.5);
+        nu   = 2;
         d.grid = CORBO_HIP_GRID_FD; d.defect = CORBO_HIP_DEFECT_CRANK_NICOLSON; d.dynamics = CORBO_HIP_DYN_UNICYCLE;
         d.stage_cost = CORBO_HIP_COST_QUADRATIC_LSQ; d.final_cost = 1; d.nx = 3; d.nu = 2;
         const double q[3] = {1, 1, 0.1}, rr[2] = {0.1, 0.05};
         for (int i = 0; i < 3; ++i) { d.q_diag[i] = q[i]; d.qf_diag[i] = 10.0 * q[i]; }
         for (int i = 0; i < 2; ++i) d.r_diag[i] = rr[i];
-        if (tball)
-        {
-            d.final_ineq = CORBO_HIP_FINAL_INEQ_TERMINAL_BALL;
-            d.final_ineq_params[0] = 1.0; d.final_ineq_params[1] = 1.0; d.final_ineq_params[2] = 0.1; d.final_ineq_params[3] = 0.05;  // S, gamma
-        }
     }
     else if (scenario == "quad")
     {
         dyn     = std::make_shared<QuadrotorRef>();
         ms_grid = std::make_shared<MultipleShootingGrid>();
         ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
-        w  = 10;
         x0 = Eigen::VectorXd::Zero(12);
         xf = Eigen::VectorXd::Zero(12);
         xf[0] = 2; xf[1] = 1; xf[2] = 1;
-        d.grid = CORBO_HIP_GRID_MS; d.defect = CORBO_HIP_DEFECT_RK4_SHOOTING; d.dynamics = CORBO_HIP_DYN_QUADROTOR;
-        d.stage_cost = CORBO_HIP_COST_QUADRATIC_LSQ; d.final_cost = 1; d.nx = 12; d.nu = 4; d.stage_ineq = CORBO_HIP_INEQ_BALL;
-        const double q[12] = {1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05}, rr[4] = {0.01, 0.1, 0.1, 0.1};
-        for (int i = 0; i < 12; ++i) { d.q_diag[i] = q[i]; d.qf_diag[i] = 10.0 * q[i]; }
-        for (int i = 0; i < 4; ++i) d.r_diag[i] = rr[i];
-        d.ineq_params[0] = 1.0; d.ineq_params[1] = 0.5; d.ineq_params[2] = 0.6; d.ineq_params[3] = 0.4;
-        d.dyn_params[0] = 9.81; d.dyn_params[1] = 1.0; d.dyn_params[2] = 0.01; d.dyn_params[3] = 0.01; d.dyn_params[4] = 0.02;
+        nu = 4;
     }
-    else
+    else if (scenario == "vdp" || scenario == "duffing" || scenario == "pendulum")
+    {
+        if (scenario == "vdp") { auto s = std::make_shared<VanDerPolOscillator>(); s->setDampingCoefficient(1.3); dyn = s; }
+        else if (scenario == "duffing") { auto s = std::make_shared<DuffingOscillator>(); s->setParameters(0.7, 1.1, 0.9); dyn = s; }
+        else { auto s = std::make_shared<SimplePendulum>(); s->setParameters(0.3, 0.5, 9.81, 0.02); dyn = s; }
+        grid = std::make_shared<FiniteDifferencesGrid>();
+        if (scenario == "duffing") grid->setFiniteDifferencesCollocationMethod(std::make_shared<MidpointDiffCollocation>());
+        w  = 5;
+        x0 = Eigen::Vector2d(1, 0);
+        xf = Eigen::Vector2d(0.2, -0.1);
+    }
+    else if (scenario == "lin32")
+    {
+        auto s = std::make_shared<LinearStateSpaceModel>();
+        Eigen::MatrixXd A(3, 3), B(3, 2);
+        A << -1.113, -0.741, -0.817, 0.197, 0.209, 0.203, 0.864, 0.45, 0.221;
+        B << 0.859, 0.092, 0.875, -0.01, -0.452, -0.096;
+        s->setParameters(A, B);
+        dyn     = s;
+        ms_grid = std::make_shared<MultipleShootingGrid>();
+        ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        w  = 5;
+        x0 = Eigen::Vector3d(0.5, -0.2, 0.1);
+        xf = Eigen::Vector3d(0.1, 0.2, -0.3);
+        nu = 2;
+    }
+    else   // dint
     {
         dyn       = std::make_shared<SerialIntegratorSystem>(2);
         auto vg   = std::make_shared<FiniteDifferencesVariableGrid>();
@@ -178,26 +240,32 @@ static Run run(const std::string& scenario_in, bool hip, int N)
         x0     = Eigen::Vector2d(0, 0);
         xf     = Eigen::Vector2d(1, 0);
         solves = 5;
-        d.grid = CORBO_HIP_GRID_FD_VARIABLE; d.defect = CORBO_HIP_DEFECT_CRANK_NICOLSON; d.dynamics = CORBO_HIP_DYN_SERIAL_INTEGRATOR;
-        d.stage_cost = CORBO_HIP_COST_MIN_TIME_LSQ; d.final_cost = 0; d.nx = 2; d.nu = 1; d.dyn_params[0] = 1.0;
     }
     const double dt = (scenario == "quad") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
-    if (mismatch) d.q_diag[1] = 2.0 * d.q_diag[1];
-    if (hip)
-    {
-        auto s = std::make_shared<LevenbergMarquardtSparseHip>();
-        s->setIterations(10);
-        s->setPenaltyWeights(w, w, w);
-        s->setDeviceModel(d);
-        s->setStateReference(xf);
-        solver = s;
-    }
-    else
+    if (mode == Mode::HipStatedWrong) d.r_diag[1] = 2.0 * d.r_diag[1];   // invisible at the reference's initial guess (u = 0)
+    if (mode == Mode::Reference)
     {
         auto s = std::make_shared<LevenbergMarquardtSparse>();
         s->setIterations(10);
         s->setPenaltyWeights(w, w, w);
+        solver = s;
+    }
+    else if (mode == Mode::Describe)
+    {
+        solver = std::make_shared<RecogniseOnly>();
+    }
+    else
+    {
+        // the reference solver's own two setters -- and, in the automatic mode, NOTHING else
+        auto s = std::make_shared<LevenbergMarquardtSparseHip>();
+        s->setIterations(10);
+        s->setPenaltyWeights(w, w, w);
+        if (mode != Mode::HipAuto)
+        {
+            s->setDeviceModel(d);
+            s->setStateReference(xf);
+        }
         solver = s;
     }
     DiscretizationGridInterface::Ptr any_grid;
@@ -215,11 +283,12 @@ static Run run(const std::string& scenario_in, bool hip, int N)
         any_grid = ms_grid;
     }
     StructuredOptimalControlProblem ocp(any_grid, dyn, hg, solver);
-    if (scenario == "unicycle" || tball)
+    if (uni)
     {
         Eigen::MatrixXd Q  = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
+        if (fullq) { Q(0, 1) = 0.2; Q(1, 0) = 0.2; }
         Eigen::MatrixXd R  = Eigen::Vector2d(0.1, 0.05).asDiagonal();
-        Eigen::MatrixXd Qf = 10.0 * Q;
+        Eigen::MatrixXd Qf = 10.0 * Eigen::MatrixXd(Eigen::Vector3d(1, 1, 0.1).asDiagonal());
         ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         ocp.setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
@@ -242,37 +311,78 @@ static Run run(const std::string& scenario_in, bool hip, int N)
         ocp.setControlBounds(ulb, uub);
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
-    else
+    else if (scenario == "dint")
     {
         ocp.setStageCost(std::make_shared<MinimumTime>(true));
         ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
+    else
+    {
+        const int nx = (int)x0.size();
+        Eigen::VectorXd q = Eigen::VectorXd::LinSpaced(nx, 1.0, 0.3), rr = Eigen::VectorXd::LinSpaced(nu, 0.1, 0.2);
+        Eigen::MatrixXd Q = q.asDiagonal(), R = rr.asDiagonal(), Qf = 7.0 * Q;
+        ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        ocp.setControlBounds(Eigen::VectorXd::Constant(nu, -1.5), Eigen::VectorXd::Constant(nu, 1.5));
+        if (scenario == "pendulum") ocp.setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(xf));
+    }
     if (!ocp.initialize()) return r;
     StaticReference xref(xf);
-    ZeroReference uref(d.nu);
+    ZeroReference uref(nu);
     r.ok = true;
     for (int i = 0; i < solves; ++i) r.ok = ocp.compute(x0, xref, uref, nullptr, Time(0), i == 0) && r.ok;
     r.traj = trajectory(ocp, *any_grid);
     r.chi2 = ocp.getCurrentObjectiveValue();
+    if (describe_out) *describe_out = *std::static_pointer_cast<RecogniseOnly>(solver);
     return r;
 }
+
+static int horizon(const std::string& sc) { return sc == "unicycle" ? 100 : sc == "dint" ? 50 : sc == "vdp" ? 20 : 30; }
 
 int main(int argc, char** argv)
 {
     int rc = 0;
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball"})
-    {
-        const int N = std::string(sc) == "unicycle" ? 100 : std::string(sc) == "dint" ? 50 : 30;
-        Run a = run(sc, false, N);
-        Run b = run(sc, true, N);
-        double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
-        printf("{\"scenario\": \"%s\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n", sc,
-               a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
-        if (!(diff < (std::string(sc) == "quad" ? 5e-3 : 1e-5))) rc = 1;
+    if (argc > 1 && std::string(argv[1]) == "describe")
+    {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
+        std::vector<std::string> list;
+        for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq"};
+        for (const std::string& sc : list)
+        {
+            RecogniseOnly rec;
+            Run a = run(sc, Mode::Describe, horizon(sc), &rec);
+            printDesc(sc.c_str(), a.ok && rec.ok, rec.why, rec.model);
+        }
+        return 0;
     }
-    {   // a device model that does not describe the graph must be refused (SolverStatus::Error -> compute() fails), not solved
-        Run c = run("unicycle_mismatch", true, 30);
+    // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32"})
+    {
+        const int N = horizon(sc);
+        Run a = run(sc, Mode::Reference, N);
+        Run b = run(sc, Mode::HipAuto, N);
+        double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
+        printf("{\"scenario\": \"%s\", \"mode\": \"recognised\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
+               sc, a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
+        if (!(diff < (std::string(sc) == "quad" ? 3e-4 : 1e-5))) rc = 1;
+    }
+    {   // the override: a stated device model
+        Run a = run("unicycle", Mode::Reference, 30);
+        Run b = run("unicycle", Mode::HipStated, 30);
+        double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
+        printf("{\"scenario\": \"unicycle\", \"mode\": \"stated\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
+               a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
+        if (!(diff < 1e-5)) rc = 1;
+    }
+    {   // a stated model that does not describe the graph must be refused (SolverStatus::Error -> compute() fails), not solved: the
+        // control weight is wrong, which no residual row shows at the reference's initial guess u = 0 -- the perturbed probe does
+        Run c = run("unicycle", Mode::HipStatedWrong, 30);
         printf("{\"scenario\": \"unicycle_mismatch\", \"ok_hip\": %d}\n", c.ok ? 1 : 0);
+        if (c.ok) rc = 1;
+    }
+    {   // a graph the device cannot describe (non-diagonal Q) must be refused by the recogniser
+        Run c = run("unicycle_fullq", Mode::HipAuto, 30);
+        printf("{\"scenario\": \"unicycle_fullq\", \"ok_hip\": %d}\n", c.ok ? 1 : 0);
         if (c.ok) rc = 1;
     }
     return rc;

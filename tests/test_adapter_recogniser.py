@@ -1,0 +1,59 @@
+"""The adapter's graph -> descriptor recogniser (control_box_rst_amd/adapter/graph_recogniser.cpp) on hypergraphs built by the GENUINE
+reference (oracle/_ref/dropin_demo describe: StructuredOptimalControlProblem + the reference's grids, dynamics and cost classes, a
+solver stub that only runs the recogniser).  CPU only: the reference's own classes need no device.  Skipped when the binary has not been
+built (needs /root/reference at build time; it travels to the GPU box)."""
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from control_box_rst_amd import capi
+
+DEMO = os.path.join(ROOT, "oracle", "_ref", "dropin_demo")
+pytestmark = pytest.mark.skipif(not os.path.exists(DEMO), reason="oracle/_ref/dropin_demo not built (needs /root/reference at build time)")
+
+
+@pytest.fixture(scope="module")
+def described():
+    p = subprocess.run([DEMO, "describe"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    return {r["scenario"]: r for r in (json.loads(l) for l in p.stdout.splitlines() if l.startswith("{"))}
+
+
+def _sqrt_equal(q, expected):
+    """The recogniser recovers sqrt(Q_ii) exactly; the descriptor stores its square: compare what the device will use."""
+    return all(math.sqrt(a) == math.sqrt(b) for a, b in zip(q, expected))
+
+
+def test_reference_benchmark_classes_with_private_parameters(described):
+    nx2 = list(np.linspace(1.0, 0.3, 2))
+    v = described["vdp"]
+    assert v["recognised"] == 1 and (v["grid"], v["defect"], v["dynamics"]) == (capi.GRID_FD, capi.DEFECT_CRANK_NICOLSON, capi.DYN_VAN_DER_POL)
+    assert v["dyn_params"][0] == 1.3 and v["N"] == 20 and (v["stage_cost"], v["final_cost"]) == (capi.COST_QUADRATIC_LSQ, 1)
+    assert _sqrt_equal(v["q_diag"], nx2) and _sqrt_equal(v["r_diag"], [0.2])   # (Eigen::LinSpaced of size 1 is its upper end) and _sqrt_equal(v["qf_diag"], [7.0 * a for a in nx2])
+    assert v["xref"] == [0.2, -0.1]                      # the StaticReference the OCP was given, read out of the cost edges bit for bit
+    d = described["duffing"]                             # private members _damping / _spring_alpha / _spring_beta; midpoint collocation
+    assert d["recognised"] == 1 and d["dynamics"] == capi.DYN_DUFFING and d["defect"] == capi.DEFECT_MIDPOINT
+    assert d["dyn_params"][:3] == [0.7, 1.1, 0.9]
+    pd = described["pendulum"]                           # + TerminalEqualityConstraint
+    assert pd["recognised"] == 1 and pd["dynamics"] == capi.DYN_SIMPLE_PENDULUM and pd["final_eq"] == 1
+    assert pd["dyn_params"][:4] == [0.3, 0.5, 9.81, 0.02]
+
+
+def test_time_optimal_variable_grid_and_shooting_grid(described):
+    t = described["dint"]                                # cfg 2: FiniteDifferencesVariableGrid, MinimumTime(lsq) with its duplicated dt edge
+    assert t["recognised"] == 1 and t["grid"] == capi.GRID_FD_VARIABLE and t["stage_cost"] == capi.COST_MIN_TIME_LSQ and t["final_cost"] == 0
+    assert t["dynamics"] == capi.DYN_SERIAL_INTEGRATOR and t["dyn_params"][0] == 1.0 and t["N"] == 50
+    l = described["lin32"]                               # LinearStateSpaceModel on the MultipleShootingGrid with RK4
+    assert l["recognised"] == 1 and (l["grid"], l["defect"], l["dynamics"]) == (capi.GRID_MS, capi.DEFECT_RK4_SHOOTING, capi.DYN_LINEAR_STATE_SPACE)
+    assert l["lin_a"] == [-1.113, -0.741, -0.817, 0.197, 0.209, 0.203, 0.864, 0.45, 0.221]
+    assert l["lin_b"] == [0.859, 0.092, 0.875, -0.01, -0.452, -0.096]
+
+
+def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):
+    f = described["unicycle_fullq"]
+    assert f["recognised"] == 0 and "non-diagonal" in f["reason"]

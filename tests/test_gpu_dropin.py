@@ -1,7 +1,9 @@
 """Drop-in test (-m gpu): the genuine reference's StructuredOptimalControlProblem, driven with the HIP solver injected
 through corbo::NlpSolverInterface (control_box_rst_amd/adapter + libcorbo_hip.so), against the same OCP solved by the
-reference's own LevenbergMarquardtSparse.  The binary oracle/_ref/dropin_demo is built in the build container by
-`make -C oracle ref` (it needs the reference's headers); it is skipped when it has not travelled."""
+reference's own LevenbergMarquardtSparse.  The HIP solver is configured with the reference solver's own setters ONLY
+(setIterations, setPenaltyWeights): the device model is derived from the hypergraph (adapter/graph_recogniser.cpp).
+The binary oracle/_ref/dropin_demo is built in the build container by `make -C oracle ref` (it needs the reference's
+headers); it is skipped when it has not travelled."""
 import json
 import os
 import subprocess
@@ -19,18 +21,23 @@ DEMO = os.path.join(ROOT, "oracle", "_ref", "dropin_demo")
 def test_reference_ocp_with_hip_solver_matches_reference_solver():
     import __graft_entry__ as g
     g.build()
-    p = subprocess.run([DEMO], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([DEMO], capture_output=True, text=True, timeout=600)
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 5, (p.stdout, p.stderr)   # cfg 3, cfg 2, reduced cfg 5, cfg 3 structure + TerminalBall, mismatching model
-    refused = lines.pop()
-    # the adapter compares the graph's own residual with the device's on every new structure: a device model with another
-    # state weight than the OCP's QuadraticFormCost is refused (SolverStatus::Error), never silently solved
-    assert refused["scenario"] == "unicycle_mismatch" and refused["ok_hip"] == 0, refused
-    assert "does not describe this hypergraph" in p.stdout + p.stderr
-    for r in lines:
-        assert r["ok_reference"] == 1 and r["ok_hip"] == 1, r
+    solved = [r for r in lines if "max_abs_diff" in r]
+    refused = {r["scenario"]: r for r in lines if "max_abs_diff" not in r}
+    # cfg 3, cfg 2, reduced cfg 5, TerminalBall, cfg 1 (a = 1.3), Duffing (midpoint, private parameters), pendulum (+ terminal equality),
+    # linear state-space model on the shooting grid -- all recognised from the graph; then the stated-model override
+    assert [r["scenario"] for r in solved] == ["unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle"], (p.stdout, p.stderr)
+    assert [r["mode"] for r in solved] == ["recognised"] * 8 + ["stated"]
+    for r in solved:
+        assert r["ok_reference"] == 1 and r["ok_hip"] == 1, (r, p.stderr[-2000:])
         # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
-        # cfg 5 family (quadrotor, multiple shooting, N=30): flat directions, chi2 carries the comparison
+        # cfg 5 family (quadrotor, multiple shooting, N=30): soft directions, chi2 carries the comparison (tests/test_oracle_fullsize.py)
         assert r["max_abs_diff"] <= (3e-4 if r["scenario"] == "quad" else 5e-6), r
         assert abs(r["chi2_hip"] - r["chi2_reference"]) <= 2e-6 * max(1.0, abs(r["chi2_reference"])), r
+    # a stated model with a wrong CONTROL weight -- invisible in the residual at the reference's initial guess u = 0 -- is refused by the
+    # perturbed probe (residual + Jacobian); a graph with a non-diagonal Q is refused by the recogniser.  Never silently solved.
+    assert refused["unicycle_mismatch"]["ok_hip"] == 0 and refused["unicycle_fullq"]["ok_hip"] == 0, refused
+    assert "does not describe this hypergraph" in p.stdout + p.stderr
+    assert "has no device description" in p.stdout + p.stderr
     assert p.returncode == 0
