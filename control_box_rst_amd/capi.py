@@ -61,7 +61,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("lm_iterations", C.c_int64), ("accepted_steps", C.c_int64), ("rejected_steps", C.c_int64),
         ("jacobian_sweeps", C.c_int64), ("residual_sweeps", C.c_int64), ("factorizations", C.c_int64),
-        ("passes", C.c_int32), ("solve_ms", C.c_float), ("sweep_ms", C.c_float), ("factor_ms", C.c_float),
+        ("passes", C.c_int32), ("solve_ms", C.c_float), ("sweep_ms", C.c_float), ("factor_ms", C.c_float), ("inner_loop_cuts", C.c_int32),
     ]
 
     def as_dict(self):
@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
     "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
     "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_warm_start_from_plant",
-    "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics",
+    "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option",
 )
 
 
@@ -138,9 +138,13 @@ def load() -> C.CDLL:
     lib.corbo_hip_eval.argtypes = [H, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.corbo_hip_device_views.argtypes = [H, C.POINTER(dp), C.POINTER(dp), C.POINTER(C.c_void_p)]
     lib.corbo_hip_time_sweep.argtypes = [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    if not hasattr(lib, "corbo_hip_set_option"):   # an older build of the C-ABI loaded through CORBO_HIP_LIB (A/B measurements)
+        _lib = lib
+        return lib
     lib.corbo_hip_time_sweep_each.argtypes = [H, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.corbo_hip_fetch_solution.argtypes = [H, C.POINTER(dp), C.POINTER(C.c_int32), C.POINTER(dp), C.POINTER(ip)]
     lib.corbo_hip_set_result_sink.argtypes = [H, C.c_int]
+    lib.corbo_hip_set_option.argtypes = [H, C.c_char_p, C.c_int]
     lib.corbo_hip_eval_dynamics.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, dp]
     lib.corbo_hip_get_timing.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.corbo_hip_time_factor.argtypes = [H, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]

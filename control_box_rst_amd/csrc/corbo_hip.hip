@@ -141,6 +141,9 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
+    int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
+    int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
+    bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")
     bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
     // the 8 model parameters as the kernels see them: the descriptor's, except for the linear state-space model, whose first slot
@@ -257,7 +260,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         FactorParams fp{};
         fp.N = S.N;
         const bool big = factor_work_doubles(*desc) > 0;
-        if (factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256) || (S.dt_free && big)) {
+        if (!device_kernels_exist(*desc) || factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256) || (S.dt_free && big)) {
             return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
         }
     }
@@ -277,8 +280,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     {
-        const char* e = std::getenv("CORBO_HIP_SUBBATCHES");
-        int want = e ? std::atoi(e) : (batch >= 512 ? 2 : 1);
+        int want = (batch >= 512 ? 2 : 1);
         if (want < 1) want = 1;
         if (want > corbo_hip_solver::MAX_SUB) want = corbo_hip_solver::MAX_SUB;
         if (want > batch) want = batch;
@@ -365,11 +367,11 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMemset(h->d_ub, 0, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_xref, 0, B * CORBO_HIP_MAX_NX * sizeof(double)));
     if (h->d_work) CREATE_TRY(hipMemset(h->d_work, 0, B * h->work_stride * sizeof(double)));
+    // hipMemset of device memory is asynchronous with respect to the host and runs on the NULL stream; the handle's streams are
+    // non-blocking, i.e. NOT ordered behind it.  Without this wait a memset that is still queued (several processes sharing the GPU)
+    // wiped data uploaded by the first corbo_hip_set_instance_data (found by tools/stress_eval.py: four concurrent processes).
+    CREATE_TRY(hipDeviceSynchronize());
 #undef CREATE_TRY
-    const char* prof = std::getenv("CORBO_HIP_PROFILE");
-    h->profile       = prof && prof[0] == '1';
-    h->split_passes  = h->profile;
-    { const char* e = std::getenv("CORBO_HIP_LOOP"); h->loop_mode = !(e && e[0] == '0'); }
 
     owner.p = nullptr;
     *out    = h;
@@ -430,6 +432,17 @@ try {
     if (lb || ub) {
         // entries beyond nv (fixed dt, padding) keep the pattern's "unbounded": stage the pattern row, then the caller's values
         const std::vector<double>& rows = h->bound_rows;
+        // the bound ROWS are static (one per unfixed component with a finite descriptor bound): a per-instance bound must not turn an
+        // unbounded component into a bounded one -- it would silently not be enforced -- nor the other way round
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < nv; ++i) {
+                if (S.comp[i].fixed) continue;
+                const double l = lb ? lb[(size_t)b * nv + i] : rows[i], u = ub ? ub[(size_t)b * nv + i] : rows[(size_t)nvs + i];
+                const bool finite = (l > -CORBO_HIP_INF) || (u < CORBO_HIP_INF);   // vector_vertex.h:174-184
+                if (finite != (S.comp[i].bnd_row >= 0))
+                    return fail(CORBO_HIP_ERR_INVALID, "per-instance bounds change the descriptor's finiteness pattern (instance " + std::to_string(b) +
+                                                           ", component " + std::to_string(i) + "): bound rows are static");
+            }
         HIP_TRY(hipStreamSynchronize(h->stream));
         for (int which = 0; which < 2; ++which) {
             const double* src = which == 0 ? lb : ub;
@@ -564,20 +577,19 @@ try {
                 HIP_TRY(hipMemsetAsync(h->d_queue, 0, sizeof(int32_t), st_of[i]));
                 fp.queue = h->d_queue; fp.queue_grid = h->num_cus;
             }
-            if (const char* lim = std::getenv("CORBO_HIP_PASS_LIMIT"))   // tests: provoke the "pass limit reached" error path
-                if (std::atoi(lim) > 0 && std::atoi(lim) < MAX_PASSES) fp.loop_passes = std::atoi(lim);
+            if (h->pass_limit > 0 && h->pass_limit < MAX_PASSES) fp.loop_passes = h->pass_limit;   // (tests: provoke the "pass limit reached" error path)
             // an instance that runs into the pass limit raises a flag in pinned, device-visible host memory: no memset, no read-back
             // copy and no second synchronisation around the one launch of a solve
             h->h_counter[2 * i] = 0;
             fp.unfinished_flag  = h->h_counter + 2 * i;
             long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
-            const char* ptl_env = std::getenv("CORBO_HIP_PASS_TIMELINE");
-            if (ptl_env && i == 0) {
+            const bool ptl_on = h->pass_timeline_inst >= 0;
+            if (ptl_on && i == 0) {
                 HIP_TRY(hipMalloc((void**)&d_ptl, 146 * sizeof(long long)));
                 HIP_TRY(hipMemsetAsync(d_ptl, 0, 146 * sizeof(long long), st_of[i]));
                 fp.pass_timeline      = d_ptl;
-                if (fp.pass_timeline_inst == 0 || std::atoi(ptl_env) == 0) fp.timeline = d_ptl + 130;  // factor phases of instance 0 (last pass)
-                fp.pass_timeline_inst = std::atoi(ptl_env);
+                if (h->pass_timeline_inst == 0) fp.timeline = d_ptl + 130;  // factor phases of instance 0 (last pass)
+                fp.pass_timeline_inst = h->pass_timeline_inst;
             }
             struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); long long tl[146];
                 if (hipMemcpy(tl, p, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -811,10 +823,9 @@ try {
 
     const bool split = h->split_passes || h->force_split;
     const bool rtc   = !split && h->loop_mode && o->iterations > 0;   // run-to-completion solve kernel: the whole loop is asynchronous
-    int limit = MAX_PASSES;
-    if (const char* lim = std::getenv("CORBO_HIP_PASS_LIMIT"))
-        if (std::atoi(lim) > 0 && std::atoi(lim) < MAX_PASSES) limit = std::atoi(lim);
+    const int limit = (h->pass_limit > 0 && h->pass_limit < MAX_PASSES) ? h->pass_limit : MAX_PASSES;
     h->h_counter[0] = 0;
+    float nested_ms = 0.0f;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int s = 0; s < steps; ++s) {
         PlantParams pp{};
@@ -831,6 +842,7 @@ try {
             const int new_run = (it == 0) ? 1 : 0;
             if (!rtc) {
                 if (int rc = corbo_hip_solve(h, o, new_run)) return rc;
+                nested_ms += h->stats.solve_ms;   // (each nested solve re-records ev0 / ev1: the loop's time is the sum)
                 continue;
             }
             update_penalty_weights(h, o, new_run);   // host-side state only
@@ -849,7 +861,8 @@ try {
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     if (logx + logu) HIP_TRY(hipMemcpyAsync(h->h_loop, h->d_loop, (logx + logu) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));   // the whole loop
+    if (rtc) HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));   // the whole loop
+    else h->stats.solve_ms = nested_ms;                                          // (sum of the solves; plant / grid-update kernels are microseconds)
     if (logx) std::memcpy(states_out, h->h_loop, logx * sizeof(double));
     if (logu) std::memcpy(controls_out, h->h_loop + logx, logu * sizeof(double));
     if (rtc && h->h_counter[0] != 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
@@ -870,6 +883,18 @@ int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::memcpy(u0_out, h->h_stage, (size_t)h->batch * S.nu * sizeof(double));
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
+{
+    if (!h || !name) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    const std::string n(name);
+    if (n == "pass_limit") h->pass_limit = value;
+    else if (n == "run_to_completion") h->loop_mode = value != 0;
+    else if (n == "pass_timeline") h->pass_timeline_inst = value;
+    else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
+    else return fail(CORBO_HIP_ERR_INVALID, "unknown option: " + n);
     return CORBO_HIP_OK;
 }
 
@@ -960,6 +985,7 @@ try {
     HIP_TRY(hipStreamSynchronize(h->stream));
     corbo_hip_stats s = h->stats;
     s.lm_iterations = s.accepted_steps = s.rejected_steps = s.jacobian_sweeps = s.residual_sweeps = s.factorizations = 0;
+    s.inner_loop_cuts = 0;
     int max_fact = 0;
     for (int b = 0; b < h->batch; ++b) {
         const LmState& a = h->h_state[b];
@@ -970,6 +996,7 @@ try {
         s.jacobian_sweeps += a.n_jac;
         s.residual_sweeps += a.n_res;
         s.factorizations += a.n_fact;
+        s.inner_loop_cuts += a.pad[0];
     }
     s.passes = max_fact;  // inner passes of the slowest instance
     *stats = s;
@@ -1025,8 +1052,7 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     ON_DEVICE_OF(h);
     SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     long long* d_tl = nullptr;  // CORBO_HIP_SWEEP_TIMELINE=1: shader-clock stamps of the phases of instance 0 on stderr (diagnostics)
-    const char* tl_env = std::getenv("CORBO_HIP_SWEEP_TIMELINE");
-    if (tl_env && tl_env[0] == '1') {
+    if (h->sweep_timeline) {
         HIP_TRY(hipMalloc((void**)&d_tl, 16 * sizeof(long long)));
         HIP_TRY(hipMemset(d_tl, 0, 16 * sizeof(long long)));
     }

@@ -332,7 +332,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 st->status = CORBO_HIP_SOLVER_CONVERGED;  // iterations == 0: (stop || rho <= 0) with rho = 0
                 fin        = (p.iterations <= 0);
                 st->done   = fin ? 1 : 0;
-                st->vbuf = 0; st->inner = 0; st->n_accept = 0; st->n_reject = 0; st->n_jac = 1; st->n_res = 1; st->n_fact = 0;
+                st->vbuf = 0; st->inner = 0; st->n_accept = 0; st->n_reject = 0; st->n_jac = 1; st->n_res = 1; st->n_fact = 0; st->pad[0] = 0;
                 flags[0] = 1;
                 flags[1] = 0;
                 if (p.chi2) p.chi2[inst] = chi2;
@@ -374,7 +374,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 st->v    = v;
                 st->stop = stop;
                 const bool cont = (rho <= 0) && !stop;  // :215
-                if (!cont || st->inner >= LM_MAX_INNER) fin = lm_end_outer(st, chi2_new, rho, k, p.iterations);
+                if (cont && st->inner >= LM_MAX_INNER) {
+                    // guarded deviation from the reference (which would keep rejecting and multiplying the damping): the instance stops
+                    // at its last accepted iterate and says so -- status ERROR, counted in corbo_hip_stats.inner_loop_cuts
+                    st->done = 1; st->status = CORBO_HIP_SOLVER_ERROR; st->pad[0] = 1;
+                    fin = true;
+                }
+                else if (!cont) fin = lm_end_outer(st, chi2_new, rho, k, p.iterations);
                 flags[0] = refresh;
                 flags[1] = accept;
             }
@@ -2756,6 +2762,28 @@ size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
     if (d.nx == 2 && d.nu == 2) return factor_lds<2, 2>(p.N, arrow);
     if (d.nx == 3 && d.nu == 3) return factor_lds<3, 3>(p.N, arrow);
     return 0;
+}
+
+// Host-only mirror of the launch_sweep / launch_pass / launch_factor dispatch below: is there a device kernel set for this
+// (dynamics, nx, nu, defect, grid)?  corbo_hip_create refuses a descriptor at once instead of failing in the first solve.
+bool device_kernels_exist(const corbo_hip_problem_desc& d)
+{
+    const bool known_defect = d.defect >= CORBO_HIP_DEFECT_FORWARD && d.defect <= CORBO_HIP_DEFECT_RK4_SHOOTING;
+    if (!known_defect) return false;
+    auto is = [&](int nx, int nu) { return d.nx == nx && d.nu == nu; };
+    switch (d.dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: case CORBO_HIP_DYN_DUFFING: case CORBO_HIP_DYN_SIMPLE_PENDULUM: case CORBO_HIP_DYN_MASSLESS_PENDULUM:
+        case CORBO_HIP_DYN_TOY_EXAMPLE: case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return is(2, 1);
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: return is(3, 1);
+        case CORBO_HIP_DYN_CART_POLE: return is(4, 1);
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR: return is(2, 1) || is(3, 1);
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: return is(2, 2) || is(3, 3);
+        case CORBO_HIP_DYN_UNICYCLE: return is(3, 2);
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE: return is(2, 1) || is(2, 2) || is(3, 1) || is(3, 2) || is(3, 3) || is(4, 1);
+        case CORBO_HIP_DYN_QUADROTOR:   // big-block family: multiple shooting with RK4, fixed dt
+            return is(12, 4) && d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_MS;
+        default: return false;
+    }
 }
 
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream)

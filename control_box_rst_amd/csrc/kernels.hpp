@@ -138,6 +138,7 @@ void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst
 // every interval) at the accepted iterate, written into jac_out [batch][nnz_pad] in the public value order; needs a residual sweep
 // (mode 0 / 1 with sp.xe0) of the same iterate before it
 bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, double* jac_out, hipStream_t stream);
+bool device_kernels_exist(const corbo_hip_problem_desc& d);   // host-only mirror of the dispatch (corbo_hip_create's gate)
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p, int nc);
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);

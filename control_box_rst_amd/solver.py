@@ -103,6 +103,8 @@ class BatchedLevenbergMarquardt:
     def set_instance_data(self, x, lb=None, ub=None, xref=None):
         arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (x, lb, ub, xref)]
         assert arrs[0].shape == (self.batch, self.dims.nv), (arrs[0].shape, (self.batch, self.dims.nv))
+        for a in arrs[1:3]:
+            assert a is None or a.shape == (self.batch, self.dims.nv), (a.shape, (self.batch, self.dims.nv))
         if arrs[3] is not None:
             assert arrs[3].shape == (self.batch, self.desc.nx)
         rc = self.lib.corbo_hip_set_instance_data(self._h, *[_dp(a) for a in arrs])
@@ -159,6 +161,10 @@ class BatchedLevenbergMarquardt:
     def restore_instance_data(self):
         """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")
+
+    def set_option(self, name: str, value: int):
+        """Diagnostics / test hooks of the handle (corbo_hip_set_option): pass_limit, run_to_completion, pass_timeline, sweep_timeline."""
+        self._check(self.lib.corbo_hip_set_option(self._h, name.encode(), int(value)), "corbo_hip_set_option")
 
     def set_profiling(self, enable: bool):
         self._check(self.lib.corbo_hip_set_profiling(self._h, 1 if enable else 0), "corbo_hip_set_profiling")

@@ -169,6 +169,7 @@ typedef struct corbo_hip_stats {
     float   solve_ms;           /* HIP-event time of the last corbo_hip_solve (device side) */
     float   sweep_ms;           /* accumulated time of the edge/Jacobian sweep kernel inside it (0 if not profiled) */
     float   factor_ms;          /* accumulated time of the assemble/factor/solve kernel (0 if not profiled) */
+    int32_t inner_loop_cuts;    /* instances whose inner loop was cut after 64 consecutive rejections (status ERROR); 0 in every test */
 } corbo_hip_stats;
 
 typedef struct corbo_hip_solver* corbo_hip_handle;
@@ -265,7 +266,9 @@ int corbo_hip_closed_loop(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
  * (:83-86).  One run-to-completion launch on the handle's stream; the call returns once every instance has finished its outer
  * iterations; results stay resident in HBM.  CORBO_HIP_ERR_DEVICE "pass limit reached" if an instance is still unfinished after
- * 4096 LM passes (never seen; the reference would loop). */
+ * 4096 LM passes (never seen; the reference would loop).  One deviation from the reference is guarded, not silent: an inner loop
+ * that rejects 64 trial steps in a row is cut (the reference would keep multiplying the damping); such an instance finishes with
+ * status CORBO_HIP_SOLVER_ERROR and is counted in corbo_hip_stats.inner_loop_cuts. */
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
 
 /* Block until the handle's stream is idle. */
@@ -329,6 +332,13 @@ int corbo_hip_set_profiling(corbo_hip_handle h, int enable);
  * the descriptor are read.  Runs on the current HIP device.  Lets a caller check that a dynamics object it holds is the model a
  * descriptor names (the adapter's recogniser matches user systems against the library's plug-in models with it). */
 int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const double* x, const double* u, double* f);
+
+/* Diagnostics and test hooks of a handle (nothing here is read from the environment):
+ *   "pass_limit"        value > 0: the run-to-completion kernel gives up after `value` LM passes per instance instead of 4096
+ *   "run_to_completion" 0: one launch per LM pass (the host counts unfinished instances) instead of one launch per solve
+ *   "pass_timeline"     value >= 0: corbo_hip_solve prints the per-pass shader-clock stamps of instance `value` on stderr; -1: off
+ *   "sweep_timeline"    1: corbo_hip_time_sweep prints the phase stamps of instance 0 on stderr */
+int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value);
 
 /* Text of the last error on this thread. */
 const char* corbo_hip_last_error(void);

@@ -404,23 +404,56 @@ def test_small_family_with_stage_inequality_vs_oracle(oracle_mod):
     assert np.allclose(chi2, chi2o, rtol=CHI2_RTOL)
 
 
-def test_pass_limit_is_reported_not_swallowed(monkeypatch):
+def test_pass_limit_is_reported_not_swallowed():
     """An instance still unfinished when the run-to-completion kernel's pass limit is reached raises a flag in pinned host memory;
-    corbo_hip_solve turns it into an error (the limit is 4096 passes; CORBO_HIP_PASS_LIMIT lowers it for this test)."""
-    from control_box_rst_amd import problems
-    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
-    monkeypatch.delenv("CORBO_HIP_LOOP", raising=False)   # (the limit belongs to the run-to-completion kernel, the default mode)
+    corbo_hip_solve turns it into an error (the limit is 4096 passes; corbo_hip_set_option("pass_limit") lowers it for this test)."""
     d = problems.unicycle_desc(N=20)
     x0, xf = problems.unicycle_instances(4)
     s = BatchedLevenbergMarquardt(d, 4)
     s.setIterations(10)
     s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
     s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
-    monkeypatch.setenv("CORBO_HIP_PASS_LIMIT", "3")     # 10 outer iterations need at least 10 passes
+    s.set_option("pass_limit", 3)     # 10 outer iterations need at least 10 passes
     with pytest.raises(Exception, match="pass limit"):
         s.solve(new_run=True)
-    monkeypatch.delenv("CORBO_HIP_PASS_LIMIT")
+    s.set_option("pass_limit", 0)
     s.restore_instance_data()
     s.solve(new_run=True)                                # the handle stays usable
     _, _, status = s.get_solution()
     assert (status <= 1).all()
+    assert s.get_stats()["inner_loop_cuts"] == 0
+
+
+def test_per_pass_mode_equals_run_to_completion():
+    """corbo_hip_set_option("run_to_completion", 0): one launch per LM pass, the host counting unfinished instances -- bit-identical results."""
+    d = problems.unicycle_desc(N=40)
+    x0, xf = problems.unicycle_instances(16, seed=99)
+    res = []
+    for rtc in (1, 0):
+        s = BatchedLevenbergMarquardt(d, 16)
+        s.set_option("run_to_completion", rtc)
+        s.setIterations(8)
+        s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.solve()
+        res.append(s.get_solution())
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_per_instance_bounds_must_keep_the_descriptors_finiteness_pattern():
+    """bound rows are static; a finite per-instance bound on a component the descriptor leaves unbounded (or the reverse) is an
+    error at upload, not a silently unenforced bound."""
+    d = problems.vdp_desc(N=10)          # u bounded, x unbounded
+    s = BatchedLevenbergMarquardt(d, 2)
+    X0 = s.init_trajectory([[1.0, 0.0], [0.5, 0.1]], [[0.0, 0.0], [0.0, 0.0]])
+    lb = np.full((2, s.dims.nv), -capi.INF)
+    ub = np.full((2, s.dims.nv), capi.INF)
+    lb[:, 2::3], ub[:, 2::3] = -1.0, 1.0             # the descriptor's own pattern: fine
+    s.set_instance_data(X0, lb=lb, ub=ub)
+    ub[1, 3] = 0.7                                   # a state component of instance 1 gets a bound the structure has no row for
+    with pytest.raises(Exception, match="finiteness pattern"):
+        s.set_instance_data(X0, lb=lb, ub=ub)
+    ub[1, 3] = capi.INF
+    lb[0, 2], ub[0, 2] = -capi.INF, capi.INF          # ... and a bounded control loses its bounds
+    with pytest.raises(Exception, match="finiteness pattern"):
+        s.set_instance_data(X0, lb=lb, ub=ub)
