@@ -84,7 +84,8 @@ struct EventList {
 
 struct corbo_hip_solver {
     Structure S;
-    int batch  = 0;
+    int batch  = 0;    // capacity: instances the device buffers hold
+    int active = 0;    // instances [0, active) take part in solve / warm start / statistics (corbo_hip_set_active; default = batch)
     int device = 0;
     hipStream_t stream = nullptr;
     // the LM passes of a solve run as `nsub` independent sub-batches on their own streams: their kernels interleave on the chip at
@@ -159,7 +160,7 @@ struct corbo_hip_solver {
     SweepParams sweep_params(int mode, int iterations, double weq, double wineq, double wb, int32_t* counter) const
     {
         SweepParams p{};
-        p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.batch = active; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.batch_total = batch; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2) ? 1 : 0;
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
@@ -182,7 +183,7 @@ struct corbo_hip_solver {
     FactorParams factor_params() const
     {
         FactorParams p{};
-        p.batch = batch; p.nvs = S.nvs; p.m = S.dims.m; p.N = S.N; p.nx = S.nx; p.nu = S.nu; p.s = S.s; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
+        p.batch = active; p.nvs = S.nvs; p.m = S.dims.m; p.N = S.N; p.nx = S.nx; p.nu = S.nu; p.s = S.s; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.eq_row0 = S.eq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols; p.ineq_rows = d_ineq_rows;
         p.fin_row = S.fin_row;
@@ -265,6 +266,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         }
     }
     h->batch  = batch;
+    h->active = batch;
     h->device = device;
     int ndev  = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CORBO_HIP_ERR_DEVICE, "no HIP device visible");
@@ -499,6 +501,7 @@ try {
     update_penalty_weights(h, o, new_run);
     h->stats = corbo_hip_stats{};
     h->sink_valid = false;
+    if (h->active == 0) return CORBO_HIP_OK;   // an empty bucket of an adaptive-grid batch
     EventList ev_list;
     std::vector<hipEvent_t>& evs = ev_list.v;
     auto stamp = [&]() {
@@ -527,7 +530,7 @@ try {
     int first_of[corbo_hip_solver::MAX_SUB], count_of[corbo_hip_solver::MAX_SUB];
     hipStream_t st_of[corbo_hip_solver::MAX_SUB];
     {
-        const int base = h->batch / nsub, rem = h->batch % nsub;
+        const int base = h->active / nsub, rem = h->active % nsub;
         int f = 0;
         for (int i = 0; i < nsub; ++i) {
             count_of[i] = base + (i < rem ? 1 : 0);
@@ -700,10 +703,11 @@ static int warm_start_from(corbo_hip_handle h, const double* x0_dev_visible, int
 {
     const Structure& S = h->S;
     WarmStartParams p{};
-    p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.N = S.N;
+    p.batch = h->active; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.N = S.N;
     p.xf_fixed_mask = (int32_t)S.desc.xf_fixed_mask;
     p.shift = (shift != 0 && !S.dt_free) ? 1 : 0;   // variable grids never shift (finite_differences_variable_grid.h:77)
     p.x = h->d_x; p.x0new = x0_dev_visible; p.xref = h->d_xref;
+    if (p.batch == 0) return CORBO_HIP_OK;
     launch_warm_start(p, h->stream);
     HIP_TRY(hipGetLastError());
     return CORBO_HIP_OK;
@@ -886,6 +890,65 @@ int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
     return CORBO_HIP_OK;
 }
 
+int corbo_hip_prepare_slots(corbo_hip_handle h, int active)
+{
+    if (!h || active < 0 || active > h->batch) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    ON_DEVICE_OF(h);
+    h->sink_valid = false;
+    const Structure& S = h->S;
+    if (!h->have_data) {   // never uploaded: zero iterates (create cleared them), the descriptor's bound pattern in every slot
+        launch_broadcast_rows(h->d_bound_rows, h->d_bound_rows + S.nvs, h->d_lb, h->d_ub, S.nvs, h->batch, h->stream);
+        HIP_TRY(hipGetLastError());
+        h->have_data = true;
+    }
+    h->active = active;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_get_dt(corbo_hip_handle h, double* dt_out)
+{
+    if (!h || !dt_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "no instance data");
+    ON_DEVICE_OF(h);
+    h->sink_valid = false;
+    if (h->active == 0) return CORBO_HIP_OK;
+    launch_gather_dt(h->d_x, h->h_stage, h->S.nvs, h->S.off_dt, h->active, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(dt_out, h->h_stage, (size_t)h->active * sizeof(double));
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_resample_into(corbo_hip_handle src, corbo_hip_handle dst, int count, const int32_t* src_index, const int32_t* dst_index)
+try {
+    if (!src || !dst || count < 0 || (count > 0 && (!src_index || !dst_index))) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (count == 0) return CORBO_HIP_OK;
+    const Structure &A = src->S, &B = dst->S;
+    if (!A.dt_free || !B.dt_free) return fail(CORBO_HIP_ERR_INVALID, "resampling needs free-dt grids on both sides");
+    if (A.nx != B.nx || A.nu != B.nu || src->device != dst->device) return fail(CORBO_HIP_ERR_INVALID, "handles do not belong to the same problem family / device");
+    if (!src->have_data || !dst->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data / corbo_hip_prepare_slots must be called on both handles first");
+    for (int q = 0; q < count; ++q)
+        if (src_index[q] < 0 || src_index[q] >= src->batch || dst_index[q] < 0 || dst_index[q] >= dst->batch) return fail(CORBO_HIP_ERR_INVALID, "instance index out of range");
+    ON_DEVICE_OF(dst);
+    src->sink_valid = dst->sink_valid = false;
+    // the index lists travel through the destination handle's pinned counter scratch when they fit, else through a temporary
+    struct Tmp { int32_t* p = nullptr; ~Tmp() { if (p) (void)hipHostFree(p); } } tmp;
+    HIP_TRY(hipHostMalloc((void**)&tmp.p, 2 * (size_t)count * sizeof(int32_t)));
+    std::memcpy(tmp.p, src_index, (size_t)count * sizeof(int32_t));
+    std::memcpy(tmp.p + count, dst_index, (size_t)count * sizeof(int32_t));
+    HIP_TRY(hipStreamSynchronize(src->stream));   // the source trajectories are final
+    ResampleParams p{};
+    p.pairs = count; p.nx = A.nx; p.nu = A.nu;
+    p.n_src = A.N; p.nvs_src = A.nvs; p.n_dst = B.N; p.nvs_dst = B.nvs;
+    p.x_src = src->d_x; p.x_dst = dst->d_x; p.xref_src = src->d_xref; p.xref_dst = dst->d_xref;
+    p.src_index = tmp.p; p.dst_index = tmp.p + count;
+    launch_resample(p, dst->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
 int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
 {
     if (!h || !name) return fail(CORBO_HIP_ERR_INVALID, "null argument");
@@ -987,7 +1050,7 @@ try {
     s.lm_iterations = s.accepted_steps = s.rejected_steps = s.jacobian_sweeps = s.residual_sweeps = s.factorizations = 0;
     s.inner_loop_cuts = 0;
     int max_fact = 0;
-    for (int b = 0; b < h->batch; ++b) {
+    for (int b = 0; b < h->active; ++b) {
         const LmState& a = h->h_state[b];
         if (a.n_fact > max_fact) max_fact = a.n_fact;
         s.lm_iterations += a.k;

@@ -790,6 +790,49 @@ __global__ __launch_bounds__(256) void warm_start_kernel(const WarmStartParams p
     __syncthreads();
     for (int e = tid; e < p.nvs; e += 256) X[e] = nw[e];
 }
+// resampleTrajectory: one workgroup per (source instance, destination instance) pair.  The old trajectory is staged in LDS (the
+// destination may be another row of the SAME array: compaction moves), every interior grid point of the new trajectory is one lane:
+// idx_old = the first old sample not before t_new (the reference's running while-loop, :428-432, is monotone, so each lane finds it
+// on its own), linear interpolation of the state, held control (:440-447), same operation order -> bit-identical to the oracle.
+__global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double old[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int nx = p.nx, nu = p.nu, s = nx + nu, n = p.n_src, n_new = p.n_dst;
+    const double* X = p.x_src + (size_t)p.src_index[q] * p.nvs_src;
+    double* Y       = p.x_dst + (size_t)p.dst_index[q] * p.nvs_dst;
+    for (int e = tid; e < p.nvs_src; e += 256) old[e] = X[e];
+    double xr = 0.0;
+    if (tid < CORBO_HIP_MAX_NX) xr = p.xref_src[(size_t)p.src_index[q] * CORBO_HIP_MAX_NX + tid];
+    __syncthreads();
+    if (tid < CORBO_HIP_MAX_NX) p.xref_dst[(size_t)p.dst_index[q] * CORBO_HIP_MAX_NX + tid] = xr;
+    const double* xf    = old + (n - 1) * s;
+    const double dt_old = old[(n - 1) * s + nx];
+    if (n == n_new) {   // :400
+        for (int e = tid; e < p.nvs_dst; e += 256) Y[e] = old[e];
+        return;
+    }
+    const double dt_new = dt_old * (double)(n - 1) / (double)(n_new - 1);
+    for (int e = tid; e < s; e += 256) Y[e] = old[e];                         // start sample untouched
+    for (int e = tid; e < nx; e += 256) Y[(n_new - 1) * s + e] = xf[e];       // x_f copied
+    if (tid == 0) {
+        Y[(n_new - 1) * s + nx] = dt_new;
+        for (int e = (n_new - 1) * s + nx + 1; e < p.nvs_dst; ++e) Y[e] = 0.0;
+    }
+    for (int idx_new = 1 + tid; idx_new < n_new - 1; idx_new += 256) {
+        const double t_new = dt_new * (double)idx_new;
+        int idx_old = 1;
+        while (t_new > (double)idx_old * dt_old && idx_old < n) ++idx_old;
+        const double t_old_p1 = (double)idx_old * dt_old;
+        const double* x_prev  = old + (idx_old - 1) * s;
+        const double* x_cur   = (idx_old < n - 1) ? old + idx_old * s : xf;
+        const double f        = (t_new - (t_old_p1 - dt_old)) / dt_old;
+        double* yn            = Y + idx_new * s;
+        for (int c = 0; c < nx; ++c) yn[c] = x_prev[c] + f * (x_cur[c] - x_prev[c]);
+        const double* u_prev = old + ((idx_old - 1 < n - 1) ? idx_old - 1 : n - 2) * s + nx;
+        for (int c = 0; c < nu; ++c) yn[nx + c] = u_prev[c];
+    }
+}
 #pragma clang fp contract(fast)
 #endif  // !CORBO_HIP_DYN_TU
 
@@ -2729,6 +2772,22 @@ void launch_gather_first_control(const double* x, double* out, int nvs, int nx, 
 void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst_a, double* dst_b, int nvs, int batch, hipStream_t stream)
 {
     hipLaunchKernelGGL(broadcast_rows_kernel, dim3(batch), dim3(256), 0, stream, row_a, row_b, dst_a, dst_b, nvs);
+}
+
+void launch_resample(const ResampleParams& p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(resample_kernel, dim3(p.pairs), dim3(256), sizeof(double) * (size_t)p.nvs_src, stream, p);
+}
+
+__global__ __launch_bounds__(256) void gather_dt_kernel(const double* __restrict__ x, double* __restrict__ out, int nvs, int off_dt, int batch)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < batch) out[b] = x[(size_t)b * nvs + off_dt];
+}
+
+void launch_gather_dt(const double* x, double* out, int nvs, int off_dt, int batch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gather_dt_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, x, out, nvs, off_dt, batch);
 }
 
 void launch_warm_start(const WarmStartParams& p, hipStream_t stream)

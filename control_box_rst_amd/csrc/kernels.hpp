@@ -117,6 +117,21 @@ struct WarmStartParams {
     const double* xref;   // [batch][CORBO_HIP_MAX_NX]
 };
 void launch_warm_start(const WarmStartParams& p, hipStream_t stream);
+// FullDiscretizationGridBase::resampleTrajectory (full_discretization_grid_base.cpp:397-474) between two batches of free-dt grids with
+// N_src / N_dst grid points: pair q takes instance src_index[q] of the source arrays to instance dst_index[q] of the destination arrays
+struct ResampleParams {
+    int32_t pairs, nx, nu;
+    int32_t n_src, nvs_src, n_dst, nvs_dst;
+    const double* x_src;      // [.][nvs_src]
+    double* x_dst;            // [.][nvs_dst]
+    const double* xref_src;   // [.][CORBO_HIP_MAX_NX]
+    double* xref_dst;
+    const int32_t* src_index; // [pairs] (device-visible)
+    const int32_t* dst_index;
+};
+void launch_resample(const ResampleParams& p, hipStream_t stream);
+// dt_out[b] = x[b][off_dt]  (packed; dt_out may be device-visible pinned host memory)
+void launch_gather_dt(const double* x, double* out, int nvs, int off_dt, int batch, hipStream_t stream);
 // the plant side of a closed loop (SimulatedPlant::control, plants/src/simulated_plant.cpp:97-160, no dead time): one thread per instance
 struct PlantParams {
     int32_t batch, nvs, nx, nu, integrator;   // integrator: corbo_hip_integrator

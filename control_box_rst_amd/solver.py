@@ -162,6 +162,23 @@ class BatchedLevenbergMarquardt:
         """Device-side re-arm of the batch with the last uploaded x (no PCIe traffic)."""
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")
 
+    # -- adaptive time-optimal grids: one handle per N, instances move between them (see adaptive_grid.py) ------------------------
+    def prepare_slots(self, active: int):
+        """Use the first `active` slots (and give a never-uploaded handle the descriptor's bound pattern)."""
+        self._check(self.lib.corbo_hip_prepare_slots(self._h, int(active)), "corbo_hip_prepare_slots")
+
+    def get_dt(self, active: int) -> np.ndarray:
+        out = np.zeros(max(1, int(active)))
+        self._check(self.lib.corbo_hip_get_dt(self._h, _dp(out)), "corbo_hip_get_dt")
+        return out[:active]
+
+    def resample_into(self, dst: "BatchedLevenbergMarquardt", src_index, dst_index):
+        """resampleTrajectory of this handle's instances src_index into slots dst_index of `dst` (its N may differ; same N = move)."""
+        si = np.ascontiguousarray(src_index, np.int32)
+        di = np.ascontiguousarray(dst_index, np.int32)
+        assert si.shape == di.shape and si.ndim == 1
+        self._check(self.lib.corbo_hip_resample_into(self._h, dst._h, len(si), _ip(si), _ip(di)), "corbo_hip_resample_into")
+
     def set_option(self, name: str, value: int):
         """Diagnostics / test hooks of the handle (corbo_hip_set_option): pass_limit, run_to_completion, pass_timeline, sweep_timeline."""
         self._check(self.lib.corbo_hip_set_option(self._h, name.encode(), int(value)), "corbo_hip_set_option")

@@ -224,6 +224,23 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h);
  * handle's stream.  Follow with corbo_hip_solve(h, opts, new_run = 1). */
 int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
 
+/* ---- Time-optimal grids whose resolution adapts per instance (FiniteDifferencesVariableGrid::adaptGrid*, finite_differences_variable_grid.cpp:
+ * 66-163): N differs from instance to instance, a handle has ONE N -- a caller keeps one handle per N (a "bucket") and moves an
+ * instance whose N changes into the bucket of its new N with a resampled trajectory, all on the device
+ * (control_box_rst_amd/adaptive_grid.py is that caller).
+ *   corbo_hip_prepare_slots  a handle that is only ever filled by corbo_hip_resample_into: the descriptor's bound pattern in every
+ *                            slot, zero iterates; and / or sets how many of the handle's slots are in use: instances [0, active) take
+ *                            part in corbo_hip_solve / corbo_hip_warm_start / corbo_hip_get_stats (default after create: all).
+ *   corbo_hip_get_dt         dt of the active instances (what adaptGridTimeBased* decides on), dt_out [active].  Synchronises.
+ *   corbo_hip_resample_into  FullDiscretizationGridBase::resampleTrajectory(N_dst) (full_discretization_grid_base.cpp:397-474) of
+ *                            instance src_index[q] of `src` into slot dst_index[q] of `dst`, q < count: start sample and x_f kept, interior
+ *                            states interpolated linearly in time, controls held, dt_new = dt_old (N_src - 1) / (N_dst - 1); the state
+ *                            reference travels along.  N_src == N_dst is a plain move (src and dst may be the same handle: compaction).
+ *                            Bit-identical to the oracle's restatement, which is pinned bit for bit to sequences of the reference. */
+int corbo_hip_prepare_slots(corbo_hip_handle h, int active);
+int corbo_hip_get_dt(corbo_hip_handle h, double* dt_out);
+int corbo_hip_resample_into(corbo_hip_handle src, corbo_hip_handle dst, int count, const int32_t* src_index, const int32_t* dst_index);
+
 /* u_0 of every instance's current trajectory = FullDiscretizationGridBase::getFirstControlInput
  * (full_discretization_grid_base.cpp:324-331), what a predictive controller applies to its plant.  u0_out [batch][nu] (host);
  * batch * nu doubles, packed by a small kernel into pinned host memory, instead of the whole trajectories.  Synchronises. */

@@ -709,6 +709,59 @@ int oracle_warm_start(oracle_problem* p, const double* x0, int shift)
     return 0;
 }
 
+/* FullDiscretizationGridBase::resampleTrajectory(n_new), full_discretization_grid_base.cpp:397-474, on the vertex layout of a
+ * free-dt grid: x_old = [x_0 u_0 | ... | x_{n-2} u_{n-2} | x_f | dt] (n grid points) -> x_new with n_new grid points.  The start
+ * sample and x_f are not touched; interior states are interpolated linearly in time between the old samples, controls are held
+ * (:433-447); dt_new = dt_old (n - 1) / (n_new - 1) (:421).  n_new == n: unchanged (:400). */
+int oracle_resample_trajectory(int nx, int nu, int n, const double* x_old, int n_new, double* x_new)
+{
+    if (!x_old || !x_new || n < 2 || n_new < 2) return CORBO_HIP_ERR_INVALID;
+    const int s = nx + nu;
+    const double* xf = x_old + (n - 1) * s;
+    const double dt_old = x_old[(n - 1) * s + nx];
+    if (n == n_new) { memcpy(x_new, x_old, ((size_t)(n - 1) * s + nx + 1) * sizeof(double)); return 0; }
+    const double dt_new = dt_old * (double)(n - 1) / (double)(n_new - 1);
+    memcpy(x_new, x_old, s * sizeof(double));                          /* x_0, u_0 stay */
+    int idx_old = 1;
+    for (int idx_new = 1; idx_new < n_new - 1; ++idx_new) {
+        const double t_new = dt_new * (double)idx_new;
+        while (t_new > (double)idx_old * dt_old && idx_old < n) ++idx_old;
+        const double t_old_p1 = (double)idx_old * dt_old;
+        const double* x_prev = x_old + (idx_old - 1) * s;
+        const double* x_cur  = (idx_old < n - 1) ? x_old + idx_old * s : xf;
+        const double f = (t_new - (t_old_p1 - dt_old)) / dt_old;
+        double* xn = x_new + idx_new * s;
+        for (int c = 0; c < nx; ++c) xn[c] = x_prev[c] + f * (x_cur[c] - x_prev[c]);
+        /* the old control sample idx_old - 1; the time series holds the last control once more behind the horizon (:548-560) */
+        const double* u_prev = x_old + ((idx_old - 1 < n - 1) ? idx_old - 1 : n - 2) * s + nx;
+        for (int c = 0; c < nu; ++c) xn[nx + c] = u_prev[c];
+    }
+    memcpy(x_new + (n_new - 1) * s, xf, nx * sizeof(double));
+    x_new[(n_new - 1) * s + nx] = dt_new;
+    return 0;
+}
+
+/* FiniteDifferencesVariableGrid::adaptGridTimeBasedSingleStep / ...AggressiveEstimate / ...SimpleShrinkingHorizon
+ * (finite_differences_variable_grid.cpp:101-163): the number of grid points after the adaptation (== n: no change).
+ * strategy: 1 = single step, 2 = aggressive estimate, 3 = simple shrinking horizon. */
+int oracle_adapt_grid_n(int strategy, int n, double dt, double dt_ref, double hyst, int n_min, int n_max)
+{
+    if (strategy == 1) {
+        if (dt > dt_ref * (1.0 + hyst) && n < n_max) return n + 1;
+        if (dt < dt_ref * (1.0 - hyst) && n > n_min) return n - 1;
+        return n;
+    }
+    if (strategy == 2) {
+        if (dt >= dt_ref * (1.0 - hyst) && dt <= dt_ref * (1.0 + hyst)) return n;
+        int new_n = (int)round((double)n * (dt / dt_ref));
+        if (new_n > n_max) new_n = n_max;
+        else if (new_n < n_min) new_n = n_min;
+        return new_n;
+    }
+    if (strategy == 3) return (n > n_min) ? n - 1 : n;
+    return n;
+}
+
 int oracle_plant_step(const oracle_problem* p, int integrator, double dt, const double* disturbance, double* x_plant)
 {
     if (!p || !x_plant || p->gen) return CORBO_HIP_ERR_INVALID;

@@ -47,6 +47,10 @@ int oracle_warm_start(oracle_problem* p, const double* x0, int shift);
 int oracle_get_x(const oracle_problem* p, double* x_out);
 /* SimulatedPlant::control without dead time (plants/src/simulated_plant.cpp:97-160): x_plant <- integrator.solveIVP(x_plant, u_0 of
  * the stored trajectory, dt), then x_plant += disturbance (may be NULL).  integrator: corbo_hip_integrator.  x_plant: nx doubles, in/out. */
+/* resampleTrajectory (full_discretization_grid_base.cpp:397-474) on the vertex layout of a free-dt grid; the grid-adaptation rules of
+ * FiniteDifferencesVariableGrid (finite_differences_variable_grid.cpp:101-163) */
+int oracle_resample_trajectory(int nx, int nu, int n, const double* x_old, int n_new, double* x_new);
+int oracle_adapt_grid_n(int strategy, int n, double dt, double dt_ref, double hyst, int n_min, int n_max);
 int oracle_plant_step(const oracle_problem* p, int integrator, double dt, const double* disturbance, double* x_plant);
 
 /* Callback problem (SimpleOptimizationProblemWithCallbacks): n parameters, f fills the lsq / equality / inequality value vectors at x

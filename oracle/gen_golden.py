@@ -92,10 +92,32 @@ def fullsize():
     np.savez_compressed(os.path.join(OUT, "quad_n200_seeded_ulp.npz"), seed=20260928, iters=10, x0=x0[0], xf=xf[0], chi2=c, vertex=base, vertex_ulp=pert[0])
 
 
+def adapt():
+    """Time-optimal grid adaptation (SURVEY 8f rank 2 remainder): moving-horizon sequences on the FiniteDifferencesVariableGrid with
+    TimeBasedSingleStep / TimeBasedAggressiveEstimate / SimpleShrinkingHorizon (finite_differences_variable_grid.cpp:101-163), K
+    compute() calls per step like PredictiveController::step.  iters=0 after step 0: the dumps show the pure grid update (chains of
+    resampleTrajectory, full_discretization_grid_base.cpp:397-474); iters=5: the controller as it runs."""
+    base = dict(scenario="dint", steps=5, iters0=10, shift=0, ocp_iters=3)
+    for name, kv in [
+        ("mpc_dint_adapt_single_grow_init", dict(iters=0, adapt="single", nmax=80, hyst=0.02, dt=0.06)),
+        ("mpc_dint_adapt_single_shrink_init", dict(iters=0, adapt="single", nmax=80, hyst=0.1)),
+        ("mpc_dint_adapt_aggressive_init", dict(iters=0, adapt="aggressive", nmax=70, hyst=0.05, dt=0.09, adapt_first=1)),
+        ("mpc_dint_adapt_shrink_init", dict(iters=0, adapt="shrink", nmin=44)),
+        ("mpc_dint_adapt_single", dict(iters=5, adapt="single", nmax=80, hyst=0.1, steps=6)),
+        ("mpc_dint_adapt_aggressive", dict(iters=5, adapt="aggressive", nmax=80, hyst=0.1, steps=4)),
+    ]:
+        d = run("mpc", **{**base, **kv})
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, [st["n_seq"] for st in d["steps"]])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         return fullsize()
+    if len(sys.argv) > 1 and sys.argv[1] == "adapt":
+        return adapt()
     # cfg 3 (headline structure, single instance, the SURVEY 8c known-answer trace), cfg 1, cfg 2
     for name, kv, keep in [
         ("unicycle", dict(scenario="unicycle"), (1, 2, 5, 10)),
@@ -206,6 +228,7 @@ def main():
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))
         print(name, [round(st["chi2"], 6) for st in d["steps"]])
+    adapt()
 
     # closed loops with the reference's own SimulatedPlant: plant.output -> compute(new_run) -> plant.control, the
     # plant integrating the OCP's dynamics with explicit Euler (its default) or RK4, plus a deterministic state disturbance

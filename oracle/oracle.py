@@ -48,6 +48,8 @@ def load():
     lib.oracle_eval.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.oracle_solve.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.c_int, dp, C.POINTER(TraceEntry)]
     lib.oracle_solve_batch.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, C.POINTER(LmOpts), dp, ip]
+    lib.oracle_resample_trajectory.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]
+    lib.oracle_adapt_grid_n.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     lib.oracle_create_generic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, GENERIC_FUN]
     lib.oracle_create_generic.restype = C.c_void_p
     _lib = lib
@@ -162,6 +164,25 @@ class GenericProblem(OracleProblem):
 
     def warm_start(self, x0, shift=True):
         raise NotImplementedError("not an OCP")
+
+
+def resample_trajectory(nx: int, nu: int, x_old: np.ndarray, n_new: int) -> np.ndarray:
+    """resampleTrajectory on the vertex layout of a free-dt grid: [x_0 u_0 | ... | x_f | dt] with n points -> n_new points."""
+    lib = load()
+    x_old = np.ascontiguousarray(x_old, np.float64)
+    s = nx + nu
+    n = (len(x_old) - nx - 1) // s + 1
+    assert (n - 1) * s + nx + 1 == len(x_old), (len(x_old), n)
+    out = np.zeros((n_new - 1) * s + nx + 1)
+    assert lib.oracle_resample_trajectory(nx, nu, n, _dp(x_old), n_new, _dp(out)) == 0
+    return out
+
+
+ADAPT_SINGLE_STEP, ADAPT_AGGRESSIVE, ADAPT_SHRINK = 1, 2, 3
+
+
+def adapt_grid_n(strategy: int, n: int, dt: float, dt_ref: float, hyst: float, n_min: int, n_max: int) -> int:
+    return load().oracle_adapt_grid_n(strategy, n, dt, dt_ref, hyst, n_min, n_max)
 
 
 def solve_batch(desc: ProblemDesc, x: np.ndarray, xref: np.ndarray, opts: LmOpts):

@@ -142,6 +142,12 @@ struct Scenario
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
     Eigen::VectorXd lin_a, lin_b;   // scenario lin: LinearStateSpaceModel matrices, row-major (lin_a= / lin_b= with nx= / nu=)
+    // adapt=single|aggressive|shrink (variable grids): FiniteDifferencesVariableGrid::setGridAdaptTimeBased* / SimpleShrinkingHorizon
+    // (finite_differences_variable_grid.cpp:44-66) with nmax= / nmin= / hyst= / adapt_first=
+    std::string adapt;
+    int n_max = 1000, n_min = 2;
+    double hyst = 0.1;
+    bool adapt_first = false;
 };
 
 // the reference's other benchmark systems (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket (3) and the cart-pole (4)
@@ -271,6 +277,20 @@ static Built build(const Scenario& s, int iterations)
     {
         fprintf(stderr, "unknown scenario %s\n", s.name.c_str());
         exit(2);
+    }
+    if (!s.adapt.empty())
+    {
+        auto vg = std::dynamic_pointer_cast<FiniteDifferencesVariableGrid>(b.grid);
+        if (!vg)
+        {
+            fprintf(stderr, "adapt= needs a FiniteDifferencesVariableGrid scenario\n");
+            exit(2);
+        }
+        vg->setNmin(s.n_min);
+        if (s.adapt == "single") vg->setGridAdaptTimeBasedSingleStep(s.n_max, s.hyst, s.adapt_first);
+        else if (s.adapt == "aggressive") vg->setGridAdaptTimeBasedAggressiveEstimate(s.n_max, s.hyst, s.adapt_first);
+        else if (s.adapt == "shrink") vg->setGridAdaptSimpleShrinkingHorizon(s.adapt_first);
+        else { fprintf(stderr, "unknown adapt=%s\n", s.adapt.c_str()); exit(2); }
     }
     if (b.grid)
     {
@@ -543,6 +563,11 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
+    if (kv.count("adapt")) s.adapt = kv["adapt"];
+    if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
+    if (kv.count("nmin")) s.n_min = atoi(kv["nmin"].c_str());
+    if (kv.count("hyst")) s.hyst = strtod(kv["hyst"].c_str(), nullptr);
+    if (kv.count("adapt_first")) s.adapt_first = atoi(kv["adapt_first"].c_str()) != 0;
     if (kv.count("tball"))
     {
         s.tball_gamma = atof(kv["tball"].c_str());
@@ -711,11 +736,16 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     const int steps  = kv.count("steps") ? atoi(kv["steps"].c_str()) : 4;
     const bool shift = kv.count("shift") ? atoi(kv["shift"].c_str()) != 0 : true;
     const int iters0 = kv.count("iters0") ? atoi(kv["iters0"].c_str()) : 10;   // LM iterations of step 0 (builds the first trajectory)
+    // ocp_iters=K: K compute() calls per step like PredictiveController::step (predictive_controller.cpp:46-80), new_run only for the
+    // first -- the calls in which a variable grid adapts its resolution (adaptGrid skips new runs unless adapt_first)
+    const int ocp_iters = kv.count("ocp_iters") ? atoi(kv["ocp_iters"].c_str()) : 1;
     Built b = build(s, iters0);
     if (shift && b.grid) b.grid->setWarmStart(true);
     if (shift && b.ms_grid) b.ms_grid->setWarmStart(true);   // ShootingGridBase: the same shifting (shooting_grid_base.cpp:99-113,292-352)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters0\": %d, \"iters\": %d, \"shift\": %d,\n", s.name.c_str(),
            s.nx, s.nu, s.N, s.dt, iters0, s.iters, shift ? 1 : 0);
+    printf("\"ocp_iters\": %d, \"adapt\": \"%s\", \"nmax\": %d, \"nmin\": %d, \"hyst\": %.17g, \"adapt_first\": %d,\n", ocp_iters, s.adapt.c_str(), s.n_max, s.n_min,
+           s.hyst, s.adapt_first ? 1 : 0);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);
@@ -724,9 +754,17 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     for (int st = 0; st < steps; ++st)
     {
         if (st == 1) b.solver->setIterations(s.iters);
-        bool ok           = b.ocp->compute(x0, *b.xref, *b.uref, nullptr, Time(st * s.dt), true);
+        bool ok = true;
+        std::vector<int> n_seq;
+        for (int it = 0; it < ocp_iters; ++it)
+        {
+            ok = b.ocp->compute(x0, *b.xref, *b.uref, nullptr, Time(st * s.dt), it == 0) && ok;
+            n_seq.push_back(b.any_grid->getN());
+        }
         Eigen::VectorXd v = vertexValues(b, s);
-        printf("{\"ok\": %d, \"chi2\": %.17g, ", ok ? 1 : 0, b.ocp->getCurrentObjectiveValue());
+        printf("{\"ok\": %d, \"chi2\": %.17g, \"n\": %d, \"n_seq\": [", ok ? 1 : 0, b.ocp->getCurrentObjectiveValue(), b.any_grid->getN());
+        for (size_t i = 0; i < n_seq.size(); ++i) printf("%s%d", i ? ", " : "", n_seq[i]);
+        printf("], ");
         printVec("x0", x0);
         printVec("vertex", v, false);
         printf("}%s\n", st + 1 < steps ? "," : "");
