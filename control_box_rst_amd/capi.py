@@ -88,6 +88,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
     "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_warm_start_from_plant",
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
+    "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
 )
 
 
@@ -145,6 +146,9 @@ def load() -> C.CDLL:
     lib.corbo_hip_fetch_solution.argtypes = [H, C.POINTER(dp), C.POINTER(C.c_int32), C.POINTER(dp), C.POINTER(ip)]
     lib.corbo_hip_set_result_sink.argtypes = [H, C.c_int]
     lib.corbo_hip_set_option.argtypes = [H, C.c_char_p, C.c_int]
+    lib.corbo_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.corbo_hip_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.corbo_hip_device_row_stride.argtypes = [H, C.POINTER(C.c_int32)]
     lib.corbo_hip_prepare_slots.argtypes = [H, C.c_int]
     lib.corbo_hip_get_dt.argtypes = [H, dp]
     lib.corbo_hip_resample_into.argtypes = [H, H, C.c_int, ip, ip]

@@ -890,6 +890,24 @@ int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
     return CORBO_HIP_OK;
 }
 
+int corbo_hip_device_count(int* count)
+{
+    if (!count) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_shard_bounds(int global_batch, int world, int rank, int* first, int* count)
+{
+    if (!first || !count || world < 1 || rank < 0 || rank >= world || global_batch < 0) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    const int base = global_batch / world, rem = global_batch % world;
+    *count = base + (rank < rem ? 1 : 0);
+    *first = rank * base + (rank < rem ? rank : rem);
+    return CORBO_HIP_OK;
+}
+
 int corbo_hip_prepare_slots(corbo_hip_handle h, int active)
 {
     if (!h || active < 0 || active > h->batch) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
@@ -1105,6 +1123,13 @@ int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev
     if (x_dev) *x_dev = h->d_x;
     if (chi2_dev) *chi2_dev = h->d_chi2;
     if (hip_stream) *hip_stream = (void*)h->stream;
+    return CORBO_HIP_OK;
+}
+
+int corbo_hip_device_row_stride(corbo_hip_handle h, int32_t* row_stride)
+{
+    if (!h || !row_stride) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    *row_stride = h->S.nvs;
     return CORBO_HIP_OK;
 }
 

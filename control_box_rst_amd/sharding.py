@@ -74,3 +74,33 @@ def gather_trajectories(x_local: np.ndarray, global_batch: int, dist=None, devic
         first, count = shard_bounds(global_batch, world, r)
         out[first:first + count] = parts[r][:count].cpu().numpy()
     return out
+
+
+def gather_trajectories_device(solver, global_batch: int, dist=None):
+    """All-gather of the final trajectories straight from device memory: every rank contributes its handle's resident iterate array (a
+    torch view of the library's HBM buffer, BatchedLevenbergMarquardt.device_tensor) to ONE collective (RCCL all_gather_into_tensor over
+    xGMI under backend "nccl"); no host round trip.  Uneven shards are padded to the largest one.  Returns a CUDA tensor
+    [global_batch][nv] on every rank."""
+    import torch
+    solver.synchronize()
+    view = solver.device_tensor()                      # [count][row_stride], aliases the handle's buffer
+    nv = solver.dims.nv
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return view[:, :nv].clone()
+    world = dist.get_world_size()
+    maxc = max(shard_bounds(global_batch, world, r)[1] for r in range(world))
+    send = view
+    if view.shape[0] != maxc:
+        send = torch.zeros((maxc, view.shape[1]), dtype=view.dtype, device=view.device)
+        send[: view.shape[0]] = view
+    recv = torch.empty((world * maxc, view.shape[1]), dtype=view.dtype, device=view.device)
+    try:
+        dist.all_gather_into_tensor(recv, send.contiguous())
+    except (RuntimeError, NotImplementedError):   # (backends without the flat variant, e.g. gloo in the shared-GPU test)
+        parts = list(recv.view(world, maxc, view.shape[1]).unbind(0))
+        dist.all_gather(parts, send.contiguous())
+    out = torch.empty((global_batch, nv), dtype=view.dtype, device=view.device)
+    for r in range(world):
+        first, count = shard_bounds(global_batch, world, r)
+        out[first:first + count] = recv[r * maxc: r * maxc + count, :nv]
+    return out

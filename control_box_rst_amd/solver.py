@@ -267,6 +267,21 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_device_views(self._h, C.byref(xp), C.byref(cp), C.byref(st)), "corbo_hip_device_views")
         return C.cast(xp, C.c_void_p).value, C.cast(cp, C.c_void_p).value, st.value
 
+    def device_tensor(self):
+        """The resident iterates as a torch CUDA tensor [batch][row_stride] (float64) that ALIASES the library's HBM buffer (no copy):
+        what an RCCL collective or any torch op reads.  Columns [0, dims.nv) are the vertex layout.  Synchronise with the handle's
+        stream (self.synchronize()) before reading."""
+        import torch
+        xp, _, _ = self.device_views()
+        stride = C.c_int32(0)
+        self._check(self.lib.corbo_hip_device_row_stride(self._h, C.byref(stride)), "corbo_hip_device_row_stride")
+
+        class _View:   # __cuda_array_interface__ holder; keeps the solver alive as long as the tensor
+            def __init__(s, owner):
+                s.owner = owner
+                s.__cuda_array_interface__ = {"shape": (owner.batch, stride.value), "typestr": "<f8", "data": (xp, False), "version": 2}
+        return torch.as_tensor(_View(self), device=torch.device("cuda", self.device))
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self.lib.corbo_hip_destroy(self._h)

@@ -322,9 +322,20 @@ int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solv
  * corbo_hip_get_structure).  Synchronises. */
 int corbo_hip_eval(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, double* values_out, double* jac_out);
 
+/* ---- Several GPUs of one node: the batch is the sharding unit -- independent OCP instances, no collective on the data
+ * path.  A caller (one process per GPU, or one thread per handle) creates one handle per device on its slice:
+ *     corbo_hip_device_count(&n);  corbo_hip_shard_bounds(global_batch, world, rank, &first, &count);  corbo_hip_create(desc, count, rank % n, &h);
+ * Results of all ranks are collected straight from device memory: corbo_hip_device_views gives the [batch][row_stride] iterate array and the
+ * handle's stream for an RCCL all-gather (control_box_rst_amd/sharding.py gather_trajectories_device does it through torch.distributed). */
+int corbo_hip_device_count(int* count);
+/* Contiguous slice of `rank` out of `world` (remainders go to the low ranks) -- the same rule as control_box_rst_amd.sharding.shard_bounds. */
+int corbo_hip_shard_bounds(int global_batch, int world, int rank, int* first, int* count);
+
 /* Device-resident views for callers that already live on the GPU (torch tensors, RCCL gathers): pointers into
  * the library's HBM buffers, valid until corbo_hip_destroy.  x: [batch][nv], chi2: [batch]. */
 int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev, void** hip_stream);
+/* Row stride (doubles) of the x view: dims.nv values + the library's padding (a fixed dt lives there too). */
+int corbo_hip_device_row_stride(corbo_hip_handle h, int32_t* row_stride);
 
 /* Launch only the edge/Jacobian sweep kernel `repeat` times on the resident data and return the average
  * per-launch time in ms measured with HIP events on the handle's stream (bench.py roofline leg). */

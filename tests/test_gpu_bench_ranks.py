@@ -44,6 +44,8 @@ def test_two_ranks_line_and_whole_job_totals():
         assert j["config"]["global_batch"] == 128
         assert abs(j["value"] - j["solve_stats"]["lm_iterations"] * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) <= 1e-6 * j["value"]
         assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+        assert len(j["ms_per_step_ranks"]) == n                              # every rank's own time: a straggler GPU is visible in the line
+        assert j["gather"]["matches_host_copy"] is True and j["gather"]["bytes"] == 128 * 498 * 8   # device-side all-gather of the trajectories
     # rank r owns global instances [64 r, 64 r + 64): the union is the single-rank batch, so the totals agree exactly
     # (integers) / to rounding of the summation order (chi2)
     for k in ("lm_iterations", "accepted", "rejected", "factorizations", "ok_instances"):
