@@ -142,6 +142,7 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
+    int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, 1 = first formulation of the chain kernel
     int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
     int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
     bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")
@@ -191,6 +192,7 @@ struct corbo_hip_solver {
         p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
+        p.chain_variant = chain_variant;
         return p;
     }
 };
@@ -975,6 +977,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "run_to_completion") h->loop_mode = value != 0;
     else if (n == "pass_timeline") h->pass_timeline_inst = value;
     else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
+    else if (n == "chain_variant") h->chain_variant = value;
     else return fail(CORBO_HIP_ERR_INVALID, "unknown option: " + n);
     return CORBO_HIP_OK;
 }

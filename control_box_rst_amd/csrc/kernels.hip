@@ -2371,6 +2371,286 @@ __global__ __launch_bounds__(128) void big_chain_kernel(const FactorParams p)
     }
 }
 
+// ---- per instance: the sequential part, second formulation ("stacked" twisted block Cholesky with explicit back-substitution
+//      operators).  Same two waves from both ends as big_chain_kernel, but
+//      * ONE right-looking Cholesky pass over register rows factors the block AND produces everything that depends on its factor: the
+//        wave holds the stacked matrix  [ D_k ; C ; g^T ; I ]  (lanes 0..NX-1: rows of the state block, 16..16+NX-1: rows of the
+//        coupling to the next block of the sequence, lane 28: the right-hand side as a row, 32..32+NX-1: rows of the identity); the column
+//        operations of the factorisation turn it into  [ L ; Y = C L^{-T} ; y^T = g^T L^{-T} ; W = L^{-T} ]  -- the rows are independent,
+//        so the extra rows ride in lanes that were idle (the separate triangular solves of big_chain_kernel: 350 instructions per step);
+//      * the back-substitution  x_k = L^{-T} (y - Y^T x_next)  is prepared as  x_k = a_k - G_k x_next  with  a_k = W y  (one more dot
+//        product per lane in the same loop that forms Y y for the right-hand-side mailbox and |y|^2) and  G_k = W Y^T  (three
+//        matrix-core instructions next to the three of the Schur complement Y Y^T).  A back-substitution step is then ONE 12 x 12
+//        matrix-vector product on data that was prefetched steps ahead -- 13 doubles per lane instead of 57 -- with no triangular
+//        solve in the dependent chain (big_chain_kernel: 6 k cycles per step, here a few hundred);
+//      * the controls and the trial iterate are not part of the chain at all: the state increments are collected in LDS and a
+//        stage-parallel epilogue (all lanes of both waves) forms  u_q = L_uu^{-T} (y_u - Z_x dx_q - Z_p dx_{q+1}),  x + delta,  |delta|^2;
+//      * each wave owns its LDS areas, so the elimination loop has NO workgroup barrier (the waves meet twice: at the middle block
+//        and before the epilogue).
+//      W = L^{-T} is formed explicitly (condition of a damped 12 x 12 block: <= 1e5; the step changes at the 1e-11 level, five orders
+//      below the finite-difference noise of the Jacobian).
+template <int NX, int NU>
+struct Chain2Lds {
+    static constexpr int DN = 0;                     // [NX][NX] Schur mailbox of the wave
+    static constexpr int GN = DN + NX * NX;          // [16]     right-hand-side mailbox
+    static constexpr int YL = GN + 16;               // [16][NX] Y rows (rows >= NX stay zero: matrix-core operand padding)
+    static constexpr int WL = YL + 16 * NX;          // [16][NX] W rows
+    static constexpr int PER_WAVE = WL + 16 * NX;
+    __host__ __device__ static constexpr int total(int N) { return 2 * PER_WAVE + N * NX + 16; }   // + state increments + sums
+};
+
+template <int NX, int NU>
+__global__ __launch_bounds__(128) void big_chain2_kernel(const FactorParams p)
+{
+    using BL = BigLds<NX, NU>;
+    using CL = Chain2Lds<NX, NU>;
+    constexpr int S = NX + NU;
+    static_assert(NX <= 12 && NX % 4 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, identity rows 32..");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int side = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* wsm = sm + side * CL::PER_WAVE;
+    double *Dn = wsm + CL::DN, *gnl = wsm + CL::GN, *Yl = wsm + CL::YL, *Wl = wsm + CL::WL;
+    double* dxs = sm + 2 * CL::PER_WAVE;             // [N][NX] delta x of every block
+    const int inst = blockIdx.x + p.inst0;
+    LmState* st = p.st + inst;
+    const int done = st->done;
+    int stop = st->stop;
+    const double mu = st->mu;
+    const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + mu;
+    if (done) return;
+    const int N = p.N;
+    double* sums = dxs + N * NX;                     // [8] reductions across the waves
+    const int m = N / 2;                             // meeting block
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    double* xt        = p.xt + (size_t)inst * p.nvs;
+    double* ws        = p.work + (size_t)inst * p.work_stride;
+    // lane roles
+    const bool isD = lane < NX, isC = lane >= 16 && lane < 16 + NX, isG = lane == 28, isI = lane >= 32 && lane < 32 + NX;
+    const int row = isD ? lane : (isC ? lane - 16 : (isI ? lane - 32 : 0));
+    for (int e = lane; e < CL::PER_WAVE; e += 64) wsm[e] = 0.0;   // mailboxes empty, operand padding zero
+    const int mysteps = (side == 0) ? m : N - 1 - m;
+    auto block_of = [&](int s) { return (side == 0) ? s : N - 1 - s; };
+    // ---- prefetch of a block's assembled data.  BRANCH-FREE: every lane loads NX + NX + 3 values through per-lane offsets that encode
+    //      its role (lanes without a role read the block's first words and ignore them) -- loads inside divergent branches made the
+    //      compiler put an s_waitcnt vmcnt(0) behind every one of them (measured: 12 k cycles per step instead of 2.5 k).
+    //      pm: D rows: own parts of D_k | C rows: coupling (wave 1: transposed) | rhs row: own rhs.   pe: D rows: DN of the stage that
+    //      feeds this block (wave 0: into the mailbox of the next block; wave 1: added to this block) | rhs row: GN likewise.
+    const int back = (side == 0) ? 0 : BL::WS_STAGE;   // wave 1 takes coupling / DN / GN from stage k-1
+    int off_a = 0, str_a = 1, off_b = 0, off_g = 0;
+    if (isD) { off_a = BL::WS_L + row * NX; off_b = BL::WS_DN + row * NX - back; }
+    if (isC) { off_a = (side == 0) ? BL::WS_Y + row * NX : BL::WS_Y + row - back; str_a = (side == 0) ? 1 : NX; off_g = BL::WS_GN + row - back; }
+    if (isG) { off_a = BL::WS_YV; off_b = BL::WS_GN - back; }
+    // (lanes without a role and wave 1's dummy offsets never go below the instance's workspace: wave 1 starts at block N-1 >= 1)
+    double pm[NX], pe[NX], pgn = 0.0, py2 = 0.0;
+    int pfix = 0;
+    auto fetch = [&](int k) {
+        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) { pm[cc] = wk[off_a + cc * str_a]; pe[cc] = wk[off_b + cc]; }
+        pgn  = wk[off_g];
+        py2  = wk[BL::WS_Y2];
+        pfix = p.comp[k * S + row].fixed;
+    };
+    // the stacked right-looking pass (see the head comment); returns this lane's dot product with y
+    auto stacked_pass = [&](double (&mrow)[NX]) -> double {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const double inv = rsqrt(lane_bcast(mrow[j], j));
+            mrow[j] = (lane == j) ? inv : mrow[j] * inv;
+#pragma unroll
+            for (int cc = j + 1; cc < NX; ++cc) mrow[cc] -= mrow[j] * lane_bcast(mrow[j], cc);   // (the pivot lanes' upper entries are unused)
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < NX; ++t) acc += mrow[t] * lane_bcast(mrow[t], 28);
+        return acc;
+    };
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int lj = lane & 15, lk = lane >> 4;
+    double y2 = 0.0;
+    long long tl_acc[6] = {0, 0, 0, 0, 0, 0}, tl_t = 0;   // diagnostics (p.timeline): cycles of wave 0 per part, summed over the steps
+#define CHAIN2_STAMP(slot) do { if (p.timeline) { const long long now_ = clock64(); tl_acc[slot] += now_ - tl_t; tl_t = now_; } } while (0)
+    if (p.timeline) tl_t = clock64();
+    fetch(block_of(0));
+    // ---- elimination (no workgroup barrier: the LDS areas belong to the wave)
+    for (int s = 0; s < mysteps; ++s) {
+        const int k = block_of(s);
+        const unsigned long long fmask = __ballot(pfix != 0 && isD);
+        const bool fixed_r = (fmask >> row) & 1ull;
+        double mrow[NX];
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {   // (selects, no branches)
+            const bool fixed_c = (fmask >> cc) & 1ull;
+            const double unit  = (row == cc) ? 1.0 : 0.0;
+            const double mail  = isD ? Dn[row * NX + cc] : gnl[cc];
+            const double sum   = pm[cc] + mail + ((side == 1) ? pe[cc] : 0.0);
+            double v = 0.0;
+            v = isC ? pm[cc] : v;
+            v = isI ? unit : v;
+            v = isD ? ((fixed_r || fixed_c) ? unit : sum) : v;
+            v = isG ? (fixed_c ? 0.0 : sum) : v;
+            mrow[cc] = v;
+        }
+        if (isD) {   // the mailbox of the next block starts from this stage's contribution (wave 0) / empty (wave 1)
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = (side == 0) ? pe[cc] : 0.0;
+        }
+        const double gn_base = (side == 0) ? pgn : 0.0;
+        y2 += (lane == 0) ? py2 : 0.0;
+        CHAIN2_STAMP(0);   // waited for the block's data, combined it
+        fetch(block_of((s + 1 < mysteps) ? s + 1 : s));
+        const double acc = stacked_pass(mrow);
+        CHAIN2_STAMP(1);   // stacked Cholesky pass + dot products
+        if (isG) y2 += acc;                               // |y|^2
+        if (isC) gnl[row] = gn_base - acc;                // rhs mailbox: GN - Y y
+        double* wk = ws + (size_t)k * BL::WS_STAGE;
+        if (isI) wk[BL::WS_YV + row] = acc;               // a_k = W y
+        if (isC || isI) {
+            double* dst = (isC ? Yl : Wl) + row * NX;
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
+        }
+        // matrix cores: S = Y Y^T -> mailbox, G = W Y^T -> workspace (operand (i, k) of lane l: i = l % 16, k = k0 + l / 16)
+        d4_t accS = {0.0, 0.0, 0.0, 0.0}, accG = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < NX; k0 += 4) {
+            const double yv = Yl[lj * NX + k0 + lk];
+            const double wv = Wl[lj * NX + k0 + lk];
+            accS = __builtin_amdgcn_mfma_f64_16x16x4f64(yv, yv, accS, 0, 0, 0);
+            accG = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, yv, accG, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * r + lk, j = lj;
+            if (i < NX && j < NX) {
+                Dn[i * NX + j] -= accS[r];
+                wk[BL::WS_L + i * NX + j] = accG[r];      // G_k
+            }
+        }
+        CHAIN2_STAMP(2);   // LDS hand-over, matrix cores, stores
+    }
+    // ---- the meeting block m (wave 0): own parts + both mailboxes
+    __syncthreads();
+    if (side == 0) {
+        const double* wk = ws + (size_t)m * BL::WS_STAGE;
+        const int fx = isD ? p.comp[m * S + row].fixed : 0;
+        const unsigned long long fmask = __ballot(fx != 0);
+        const bool fixed_r = (fmask >> row) & 1ull;
+        const double* Dn1 = sm + CL::PER_WAVE + CL::DN;
+        const double* gn1 = sm + CL::PER_WAVE + CL::GN;
+        double mrow[NX];
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {
+            double v = 0.0;
+            if (isD) {
+                v = wk[BL::WS_L + row * NX + cc] + Dn[row * NX + cc] + Dn1[row * NX + cc];
+                if (fixed_r || ((fmask >> cc) & 1ull)) v = (row == cc) ? 1.0 : 0.0;
+            }
+            else if (isG) {
+                v = wk[BL::WS_YV + cc] + gnl[cc] + gn1[cc];
+                if ((fmask >> cc) & 1ull) v = 0.0;
+            }
+            else if (isI) v = (row == cc) ? 1.0 : 0.0;
+            mrow[cc] = v;
+        }
+        y2 += (lane == 0) ? wk[BL::WS_Y2] : 0.0;
+        const double acc = stacked_pass(mrow);
+        if (isG) y2 += acc;
+        if (isI) dxs[m * NX + row] = acc;                 // x_m = W y
+    }
+    __syncthreads();
+    CHAIN2_STAMP(3);   // meeting block
+    // ---- back-substitution outwards: x_k = a_k - G_k x_neighbour, lane r < NX owns component r; data two steps ahead
+    {
+        struct BackBuf { double g[NX], a; };
+        BackBuf b0{}, b1{};
+        auto blk_of = [&](int s) { return (side == 0) ? m - 1 - s : m + 1 + s; };
+        const int last_s = (mysteps > 0) ? mysteps - 1 : 0;
+        const int rr = isD ? lane : 0;
+        auto fetch_b = [&](BackBuf& bb, int s) {
+            const double* wk = ws + (size_t)blk_of(s < mysteps ? s : last_s) * BL::WS_STAGE;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) bb.g[i] = wk[BL::WS_L + rr * NX + i];
+            bb.a = wk[BL::WS_YV + rr];
+        };
+        double xn = isD ? dxs[m * NX + lane] : 0.0;
+        auto back_step = [&](BackBuf& bb, int s) {
+            const bool valid = (s < mysteps);
+            double v = bb.a;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v -= bb.g[i] * lane_bcast(xn, i);
+            fetch_b(bb, s + 2);
+            if (valid && isD) dxs[blk_of(s) * NX + lane] = v;
+            xn = valid ? v : xn;
+        };
+        if (mysteps > 0) {
+            fetch_b(b0, 0);
+            fetch_b(b1, 1);
+            for (int s = 0; s < mysteps; s += 2) {
+                back_step(b0, s);
+                back_step(b1, s + 1);
+            }
+        }
+    }
+    __syncthreads();
+    CHAIN2_STAMP(4);   // back-substitution
+    // ---- epilogue, stage-parallel over both waves: trial iterate of the states, controls, step norm
+    double dn2 = 0.0;
+    for (int e = threadIdx.x; e < N * NX; e += 128) {
+        const int k = e / NX, r = e - k * NX;
+        const double d = p.comp[k * S + r].fixed ? 0.0 : dxs[e];
+        dn2 += d * d;
+        xt[k * S + r] = xin[k * S + r] + d;
+    }
+    for (int q = threadIdx.x; q < N - 1; q += 128) {
+        const double* wq = ws + (size_t)q * BL::WS_STAGE;
+        double w[NU];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+            double v = wq[BL::WS_YU + a];
+#pragma unroll
+            for (int t = 0; t < NX; ++t) v -= wq[BL::WS_ZX + a * NX + t] * dxs[q * NX + t] + wq[BL::WS_ZP + a * NX + t] * dxs[(q + 1) * NX + t];
+            w[a] = v;
+        }
+#pragma unroll
+        for (int a = NU - 1; a >= 0; --a) {   // u = L_uu^{-T} w (diagonal stored inverted)
+            double v = w[a];
+#pragma unroll
+            for (int b = a + 1; b < NU; ++b) v -= wq[BL::WS_LUU + b * NU + a] * w[b];
+            w[a] = v * wq[BL::WS_LUU + a * NU + a];
+            dn2 += w[a] * w[a];
+            xt[q * S + NX + a] = xin[q * S + NX + a] + w[a];
+        }
+    }
+    if (threadIdx.x == 0) {
+        xt[p.off_dt] = xin[p.off_dt];
+        if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
+    }
+    CHAIN2_STAMP(5);   // epilogue
+    if (p.timeline && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) p.timeline[i] = tl_acc[i];
+    y2  = wave_sum(y2);
+    dn2 = wave_sum(dn2);
+    if (lane == 0) { sums[2 * side] = y2; sums[2 * side + 1] = dn2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        y2  = sums[0] + sums[2];
+        dn2 = sums[1] + sums[3];
+        st->mu_acc = mu_eff;
+        st->first  = 0;
+        st->fresh  = 0;
+        st->n_fact += 1;
+        st->inner += 1;
+        const double dnorm = sqrt(dn2);
+        st->dnorm = dnorm;
+        int no_trial;
+        if (dnorm <= LM_EPS2) { stop = 1; no_trial = 1; }
+        else { no_trial = 0; st->den = mu * dn2 + y2; }
+        st->stop     = stop;
+        st->no_trial = no_trial;
+    }
+}
+
 // One Levenberg-Marquardt pass of every unfinished instance in ONE launch:  [sweep phase -> factor phase]  per workgroup.
 //   sweep phase  : residual at the trial iterate, accept / reject, and on an accepted step the new Jacobian (mode 3); for the
 //                  first launch of a solve the prologue instead (mode 2: residual + Jacobian at the start iterate);
@@ -2919,7 +3199,12 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
             hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), 0, stream, p);
         }
         if (!stage_entry_quadrotor(p, *sp, 0, nullptr, stream)) return false;
-        hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * 12 * 12 + 2 * 12 + 8), stream, p);
+        if (p.chain_variant == 1)   // (diagnostics: the first formulation)
+            hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * 12 * 12 + 2 * 12 + 8), stream, p);
+        else {
+            const size_t lds2 = sizeof(double) * (size_t)Chain2Lds<12, 4>::total(p.N);
+            hipLaunchKernelGGL((big_chain2_kernel<12, 4>), dim3(p.batch), dim3(128), lds2, stream, p);
+        }
         return true;
     }
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);

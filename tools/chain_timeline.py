@@ -11,5 +11,5 @@ s = BatchedLevenbergMarquardt(d, B)
 s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
 s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
 ms, tl = s.time_factor(repeat=5, timeline=True)
-names = ["wait+combine", "factor_rows", "stores+rhs", "schur+barriers", "meeting block", "back-substitution"]
+names = ["wait+combine", "stacked pass", "lds+mfma+stores", "meeting block", "back-substitution", "epilogue"]
 print(f"factor launch group: {ms:.3f} ms;  chain kernel, wave 0 of instance 0 (cycles): " + " | ".join(f"{n} {v}" for n, v in zip(names, tl[:6])), " total", sum(tl[:6]))
