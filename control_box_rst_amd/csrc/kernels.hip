@@ -1620,21 +1620,27 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 // Same LM bookkeeping as factor_body.
 template <int NX, int NU>
 struct BigLds {
-    static constexpr int W = 2 * NX + NU;
-    static constexpr int G = 0;                       // [NX][W]
-    static constexpr int R = G + NX * W;              // [NX]   defect residual
-    static constexpr int M = R + NX + (NX & 1);       // [W][W] G^T G
-    static constexpr int GM = M + W * W;              // [W]    -G^T r
-    static constexpr int LUU = GM + W + (W & 1);      // [NU][NU]
-    static constexpr int ZX = LUU + NU * NU;          // [NU][NX]
-    static constexpr int ZP = ZX + NU * NX;           // [NU][NX]
-    static constexpr int YU = ZP + NU * NX;           // [NU]
-    static constexpr int DIAG = YU + NU + (NU & 1);   // [NX+NU] diagonal (single-entry row) contributions of stage k
-    static constexpr int GDIAG = DIAG + NX + NU;      // [NX+NU]
-    static constexpr int CIN = GDIAG + NX + NU;       // [NX] inequality row
-    static constexpr int FIX = CIN + NX;              // [NX] fixed flags (as doubles)
-    static constexpr int RED = FIX + NX;              // [8]
-    static constexpr int TOTAL = RED + 8;
+    // LDS of the stage kernel.  The x_{k+1} block C of the local defect Jacobian [A | B | C] is DIAGONAL (only e_i depends on
+    // x_{k+1,i}), so C lives as NX numbers and G^T G is the S x S product [A B]^T [A B] plus row / column scalings.
+    // per interval (two per wave):
+    static constexpr int G = 0;                        // [NX][S]  [A | B]
+    static constexpr int CD = G + NX * (NX + NU);      // [NX]     diagonal of C
+    static constexpr int R = CD + NX;                  // [NX]     defect residual
+    static constexpr int DIAG = R + NX;                // [NX+NU]  diagonal (single-entry row) contributions of the interval's components
+    static constexpr int GDIAG = DIAG + NX + NU;       // [NX+NU]
+    static constexpr int CIN = GDIAG + NX + NU;        // [NX]     inequality row
+    static constexpr int FIX = CIN + NX;               // [NX]     fixed flags (as doubles)
+    static constexpr int RED = FIX + NX;               // [8]
+    static constexpr int HALF = (RED + 8 + 1) & ~1;
+    // shared by the two assemble turns of a wave:
+    static constexpr int M = 0;                        // [S][S]   [A B]^T [A B]
+    static constexpr int GM = M + (NX + NU) * (NX + NU);   // [S] -[A B]^T r
+    static constexpr int LUU = GM + NX + NU;           // [NU][NU]
+    static constexpr int ZX = LUU + NU * NU;           // [NU][NX]
+    static constexpr int ZP = ZX + NU * NX;            // [NU][NX]
+    static constexpr int YU = ZP + NU * NX;            // [NU]
+    static constexpr int SHARED = (YU + NU + 1) & ~1;
+    static constexpr int TOTAL = 2 * HALF + SHARED;    // doubles per wave (7.4 KB for nx = 12, nu = 4: the register budget, not LDS, bounds the occupancy)
     // HBM workspace per stage
     static constexpr int WS_L = 0;                    // [NX][NX] assemble: own parts of the diagonal block of x_k ; chain: L_k
     static constexpr int WS_Y = WS_L + NX * NX;       // [NX][NX] assemble: coupling H'(x_{k+1}, x_k)              ; chain: Y_k
@@ -1648,16 +1654,15 @@ struct BigLds {
     static constexpr int WS_STAGE = (WS_Y2 + 2) & ~1;
 };
 
-// LDS pointers + the stage loader shared by the three kernels
+// LDS pointers of one interval of the stage kernel (half = its per-interval area, shared = the wave's assemble scratch)
 template <int NX, int NU>
 struct BigCtx {
     using BL = BigLds<NX, NU>;
     static constexpr int S = NX + NU;
-    static constexpr int W = BL::W;
-    double *Gm, *rv, *Mm, *gm, *Luu, *Zx, *Zp, *yu, *dg, *gd, *cin, *fx, *red;
-    __device__ __forceinline__ explicit BigCtx(double* sm)
-        : Gm(sm + BL::G), rv(sm + BL::R), Mm(sm + BL::M), gm(sm + BL::GM), Luu(sm + BL::LUU), Zx(sm + BL::ZX), Zp(sm + BL::ZP),
-          yu(sm + BL::YU), dg(sm + BL::DIAG), gd(sm + BL::GDIAG), cin(sm + BL::CIN), fx(sm + BL::FIX), red(sm + BL::RED) {}
+    double *Gm, *cd, *rv, *dg, *gd, *cin, *fx, *red, *Mm, *gm, *Luu, *Zx, *Zp, *yu;
+    __device__ __forceinline__ BigCtx(double* half, double* shared)
+        : Gm(half + BL::G), cd(half + BL::CD), rv(half + BL::R), dg(half + BL::DIAG), gd(half + BL::GDIAG), cin(half + BL::CIN), fx(half + BL::FIX),
+          red(half + BL::RED), Mm(shared + BL::M), gm(shared + BL::GM), Luu(shared + BL::LUU), Zx(shared + BL::ZX), Zp(shared + BL::ZP), yu(shared + BL::YU) {}
 };
 
 // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118), in two steps:
@@ -1669,12 +1674,14 @@ struct BigCtx {
 template <int NX, int NU>
 __device__ __forceinline__ void big_diag_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk)
 {
-    using BL = BigLds<NX, NU>;
-    constexpr int S = NX + NU, W = BL::W;
+    constexpr int S = NX + NU, W = 2 * NX + NU;
     double mu_d = -1e300, mu_g = 0.0;
     if (lane < W) {
         double dd = 0.0, gg = 0.0;
-        for (int r = 0; r < NX; ++r) { const double a = c.Gm[r * W + lane]; dd += a * a; gg -= a * c.rv[r]; }
+        if (lane < S) {
+            for (int r = 0; r < NX; ++r) { const double a = c.Gm[r * S + lane]; dd += a * a; gg -= a * c.rv[r]; }
+        }
+        else { const double a = c.cd[lane - S]; dd = a * a; gg = -(a * c.rv[lane - S]); }   // column i of the diagonal block C
         if (lane < NX) {
             dd += c.dg[lane] + c.cin[lane] * c.cin[lane]; gg += c.gd[lane] - c.cin[lane] * c.red[7];
             wk[lane] = dd; wk[NX + lane] = gg;
@@ -1729,55 +1736,43 @@ template <int NX, int NU, bool USE_MFMA>
 __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk, const double mu_eff)
 {
     using BL = BigLds<NX, NU>;
-    constexpr int S = NX + NU, W = BL::W;
-    double *Gm = c.Gm, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *dg = c.dg, *gd = c.gd,
+    constexpr int S = NX + NU;
+    double *Gm = c.Gm, *cd = c.cd, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *dg = c.dg, *gd = c.gd,
            *cin = c.cin, *red = c.red;
     const bool stage = (k < N - 1);
     double y2 = 0.0;
     if (stage) {
-        // M = G^T G  (W x NX times NX x W): fp64 matrix cores.  v_mfma_f64_16x16x4f64 layout (probed on gfx950 with
-        // tools/mfma_f64_layout.hip): A[i][k] and B[k][j] live in lane l with i|j = l % 16, k = l / 16; the result register r
-        // of lane l is D[4 r + l / 16][l % 16].  Output tiles (0,0), (1,0), (1,1) of the padded 32 x 32 product, K = NX in
-        // steps of 4; the strict upper triangle is mirrored.
-        if constexpr (USE_MFMA && W <= 32 && NX % 4 == 0) {
+        // M = [A B]^T [A B]  (S x NX times NX x S): fp64 matrix cores, one 16 x 16 tile, K = NX in steps of 4.  v_mfma_f64_16x16x4f64
+        // layout (probed on gfx950 with tools/mfma_f64_layout.hip): A[i][k] and B[k][j] live in lane l with i|j = l % 16, k = l / 16;
+        // the result register r of lane l is D[4 r + l / 16][l % 16].
+        if constexpr (USE_MFMA && S <= 16 && NX % 4 == 0) {
             typedef double d4_t __attribute__((ext_vector_type(4)));
             const int lj = lane & 15, lk = lane >> 4;
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int tile = 0; tile < 3; ++tile) {
-                const int ti = (tile == 0) ? 0 : 1, tj = (tile == 2) ? 1 : 0;
-                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < NX; k0 += 4) {
+                const double a = (lj < S) ? Gm[(k0 + lk) * S + lj] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+            }
 #pragma unroll
-                for (int k0 = 0; k0 < NX; k0 += 4) {
-                    const int ia = 16 * ti + lj, ib = 16 * tj + lj;
-                    const double a = (ia < W) ? Gm[(k0 + lk) * W + ia] : 0.0;
-                    const double b = (ib < W) ? Gm[(k0 + lk) * W + ib] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * ti + 4 * r + lk, j = 16 * tj + lj;
-                    if (i < W && j < W) {
-                        Mm[i * W + j] = acc[r];
-                        if (ti != tj) Mm[j * W + i] = acc[r];
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * r + lk, j = lj;
+                if (i < S && j < S) Mm[i * S + j] = acc[r];
             }
         }
         else {
-            for (int e = lane; e < W * W; e += 64) {
-                const int i = e / W, j = e % W;
-                if (j > i) continue;
+            for (int e = lane; e < S * S; e += 64) {
+                const int i = e / S, j = e % S;
                 double v = 0.0;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) v += Gm[r * W + i] * Gm[r * W + j];
-                Mm[i * W + j] = v;
-                Mm[j * W + i] = v;
+                for (int r = 0; r < NX; ++r) v += Gm[r * S + i] * Gm[r * S + j];
+                Mm[i * S + j] = v;
             }
         }
-        if (lane < W) {
+        if (lane < S) {
             double v = 0.0;
 #pragma unroll
-            for (int r = 0; r < NX; ++r) v -= Gm[r * W + lane] * rv[r];
+            for (int r = 0; r < NX; ++r) v -= Gm[r * S + lane] * rv[r];
             gm[lane] = v;
         }
         __syncthreads();
@@ -1787,7 +1782,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
 #pragma unroll
             for (int a = 0; a < NU; ++a)
 #pragma unroll
-                for (int b = 0; b < NU; ++b) H[a][b] = Mm[(NX + a) * W + NX + b] + ((a == b) ? dg[NX + a] + mu_eff : 0.0);
+                for (int b = 0; b < NU; ++b) H[a][b] = Mm[(NX + a) * S + NX + b] + ((a == b) ? dg[NX + a] + mu_eff : 0.0);
             chol_inv<NU>(H);
 #pragma unroll
             for (int a = 0; a < NU; ++a)
@@ -1795,12 +1790,12 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
                 for (int b = 0; b < NU; ++b) Luu[a * NU + b] = H[a][b];
         }
         __syncthreads();
-        // Zx = L^{-1} H(u, x_k), Zp = L^{-1} H(u, x_{k+1}), yu = L^{-1} gu : one lane per column
+        // Zx = L^{-1} H(u, x_k), Zp = L^{-1} H(u, x_{k+1}) = L^{-1} B^T C (column j of B^T scaled by c_j), yu = L^{-1} gu: one lane per column
         if (lane < 2 * NX + 1) {
             double col[NU];
 #pragma unroll
             for (int a = 0; a < NU; ++a)
-                col[a] = (lane < NX) ? Mm[(NX + a) * W + lane] : (lane < 2 * NX) ? Mm[(NX + a) * W + S + (lane - NX)] : gm[NX + a] + gd[NX + a];
+                col[a] = (lane < NX) ? Mm[(NX + a) * S + lane] : (lane < 2 * NX) ? Gm[(lane - NX) * S + NX + a] * cd[lane - NX] : gm[NX + a] + gd[NX + a];
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 double v = col[a];
@@ -1817,14 +1812,15 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         }
         __syncthreads();
     }
-    // own parts of state block k: M[xx] - Zx^T Zx + diag + c c^T + damping ; the coupling ; the contribution to block k+1
+    // own parts of state block k: M[xx] - Zx^T Zx + diag + c c^T + damping ; the coupling C^T A - Zp^T Zx (row i of A scaled by c_i) ;
+    // the contribution to block k+1: C^T C - Zp^T Zp
     for (int e = lane; e < NX * NX; e += 64) {
         const int i = e / NX, j = e % NX;
         double d = 0.0, cx = 0.0, dn = 0.0;
         if (stage) {
-            d  = Mm[i * W + j] + cin[i] * cin[j];
-            cx = Mm[(S + i) * W + j];
-            dn = Mm[(S + i) * W + S + j];
+            d  = Mm[i * S + j] + cin[i] * cin[j];
+            cx = cd[i] * Gm[i * S + j];
+            dn = (i == j) ? cd[i] * cd[i] : 0.0;
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 d -= Zx[a * NX + i] * Zx[a * NX + j];
@@ -1839,7 +1835,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         double g = gd[lane], g2 = 0.0;
         if (stage) {
             g += gm[lane] - cin[lane] * red[7];
-            g2 = gm[S + lane];
+            g2 = -(cd[lane] * rv[lane]);
 #pragma unroll
             for (int a = 0; a < NU; ++a) { g -= Zx[a * NX + lane] * yu[a]; g2 -= Zp[a * NX + lane] * yu[a]; }
         }
@@ -1851,6 +1847,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         if (lane < NU) wk[BL::WS_YU + lane] = yu[lane];
     }
     if (lane == 2 * NX) wk[BL::WS_Y2] = y2;   // (the lane that formed y_u; 0 for the last block)
+    __syncthreads();   // the shared scratch is free for the wave's second interval
 }
 
 // ---- the stage kernel of the big-block family: ONE wave per PAIR of shooting intervals (k, k+1) of one instance.
@@ -1870,7 +1867,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
                                                 const int k, const int l32, const int inst, const int vsel, double* jac_dump)
 {
     using Dy = Dynamics<DYN>;
-    constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, W = 2 * NX + NU, NC = Dy::NC;
+    constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, NC = Dy::NC;
     constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
     const int N      = p.N;
     const bool stage = (k < N - 1), block = (k < N);
@@ -1881,11 +1878,9 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
     const int* sc    = p.stage_cols[kk].col;
     // ---- (x_k, u_k) columns: lane = (column, side)
     {
-        double loc[S], x2[NX], ck[4][NC], xe[NX];
+        double loc[S], ck[4][NC], xe[NX];
 #pragma unroll
         for (int i = 0; i < S; ++i) loc[i] = X[kk * S + i];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x2[i] = X[kk * S + S + i];
         const int col    = l32 >> 1;
         const bool minus = (l32 & 1) != 0;
         double pert = 0.0;
@@ -1902,11 +1897,11 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         const bool present = stage && jo >= 0;
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-            const double ev = xe[r] - x2[r];
+            const double ev = xe[r] - X[kk * S + S + r];   // (x_{k+1} is read here, not kept in registers across the integration)
             const double eo = __shfl_xor(ev, 1);   // the other side of the same column
             const double cv = (scalar * (ev - eo)) * sp.w_eq;   // (plus lanes: v2 - v1; hyper_graph_optimization_problem_edge_based.cpp:1552)
             if (!minus) {
-                c.Gm[r * W + col] = present ? cv : 0.0;
+                c.Gm[r * S + col] = present ? cv : 0.0;
                 if (jac_dump && present) jac_dump[jo + r] = cv;
             }
         }
@@ -1920,11 +1915,10 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         const double cd = (scalar * ((xei - a) - (xei - b))) * sp.w_eq;
         const int jo    = sc[S + i];
         const bool present = stage && jo >= 0;
+        c.cd[i] = present ? cd : 0.0;
+        if (jac_dump && present) {
 #pragma unroll
-        for (int r = 0; r < NX; ++r) {
-            const double v = (present && r == i) ? cd : 0.0;   // rows r != i: scalar * (e_r - e_r) = 0
-            c.Gm[r * W + S + i] = v;
-            if (jac_dump && present) jac_dump[jo + r] = v;
+            for (int r = 0; r < NX; ++r) jac_dump[jo + r] = (r == i) ? cd : 0.0;   // rows r != i: scalar * (e_r - e_r) = 0
         }
         c.rv[i] = stage ? (xei - x2i) * sp.w_eq : 0.0;
         double cinv = 0.0, rin = 0.0;
@@ -1993,9 +1987,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 
 template <int DYN, bool USE_MFMA>
 __global__ __launch_bounds__(64)
-#ifdef CORBO_HIP_STAGE_WAVES
-__attribute__((amdgpu_waves_per_eu(CORBO_HIP_STAGE_WAVES, CORBO_HIP_STAGE_WAVES)))
-#endif
+__attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 registers: three waves per SIMD (170 without the cap, i.e. two; a cap of four spills 270 bytes and loses)
 void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
 {
     using Dy = Dynamics<DYN>;
@@ -2012,7 +2004,7 @@ void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag
         vsel   = st->vbuf;
         mu_eff = (st->fresh ? 0.0 : st->mu_acc) + st->mu;   // H_ii += mu on every inner pass, never undone (:135-138)
     }
-    const BigCtx<NX, NU> c0(sm), c1(sm + BL::TOTAL);
+    const BigCtx<NX, NU> c0(sm, sm + 2 * BL::HALF), c1(sm + BL::HALF, sm + 2 * BL::HALF);
     const int half = lane >> 5;
     big_stage_edges<DYN>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
     __syncthreads();
@@ -2984,7 +2976,7 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
 {
     using Dy = Dynamics<CORBO_HIP_DYN_TU>;
     if (!sp.xe0 || (!fp.work && !jac_dump)) return false;
-    const size_t lds = sizeof(double) * 2 * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
+    const size_t lds = sizeof(double) * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
     hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), dim3((fp.N + 1) / 2, fp.batch), dim3(64), lds, stream, fp, sp, diag_only, jac_dump);
     return true;
 }

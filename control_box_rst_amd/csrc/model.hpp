@@ -395,23 +395,25 @@ __device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1
 {
     using D          = Dynamics<DYN>;
     constexpr int NX = D::NX;
-    double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
+    // The weighted sum ((k1 + 2 k2) + 2 k3) + k4 is formed left to right AS the stages complete -- the reference's association, the same
+    // bits -- so that only one stage vector is live at a time (the four of the textbook form cost the stage kernel 50 registers).
+    double k[NX], sum[NX], t[NX];
     if constexpr (!REUSE) D::prepare(x1, prm, ck[0]);
-    D::eval(x1, ck[0], u1, prm, k1);
+    D::eval(x1, ck[0], u1, prm, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { k1[i] *= dt; t[i] = x1[i] + k1[i] / 2.0; }
+    for (int i = 0; i < NX; ++i) { k[i] *= dt; sum[i] = k[i]; t[i] = x1[i] + k[i] / 2.0; }
     if constexpr (!REUSE) D::prepare(t, prm, ck[1]);
-    D::eval(t, ck[1], u1, prm, k2);
+    D::eval(t, ck[1], u1, prm, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { k2[i] *= dt; t[i] = x1[i] + k2[i] / 2.0; }
+    for (int i = 0; i < NX; ++i) { k[i] *= dt; sum[i] = sum[i] + 2.0 * k[i]; t[i] = x1[i] + k[i] / 2.0; }
     if constexpr (!REUSE) D::prepare(t, prm, ck[2]);
-    D::eval(t, ck[2], u1, prm, k3);
+    D::eval(t, ck[2], u1, prm, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { k3[i] *= dt; t[i] = x1[i] + k3[i]; }
+    for (int i = 0; i < NX; ++i) { k[i] *= dt; sum[i] = sum[i] + 2.0 * k[i]; t[i] = x1[i] + k[i]; }
     if constexpr (!REUSE) D::prepare(t, prm, ck[3]);
-    D::eval(t, ck[3], u1, prm, k4);
+    D::eval(t, ck[3], u1, prm, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { k4[i] *= dt; xe[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0; }
+    for (int i = 0; i < NX; ++i) { k[i] *= dt; xe[i] = x1[i] + (sum[i] + k[i]) / 6.0; }
 }
 
 // final-stage inequality TerminalBall, diagonal S, non-zero reference (final_state_constraints.cpp:72-76):
