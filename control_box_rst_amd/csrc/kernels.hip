@@ -2392,18 +2392,24 @@ struct Chain2Lds {
 };
 
 template <int NX, int NU>
-__global__ __launch_bounds__(128) void big_chain2_kernel(const FactorParams p)
+__global__ __launch_bounds__(256) void big_chain2_kernel(const FactorParams p)
 {
     using BL = BigLds<NX, NU>;
     using CL = Chain2Lds<NX, NU>;
     constexpr int S = NX + NU;
     static_assert(NX <= 12 && NX % 4 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, identity rows 32..");
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int side = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) double sm_all[];
+    // one workgroup = TWO instances x two waves: its four waves land on the four SIMDs of a compute unit, one each.  (Workgroups of two
+    // waves were placed two to a SIMD pair: at 512 instances half of the SIMDs idled while the others were shared -- 461 us per launch
+    // against 369 us; rocprofv3 kernel trace over the batch size, DESIGN.md.)
+    const int pair = threadIdx.x >> 7, tid = threadIdx.x & 127;
+    const int side = tid >> 6, lane = tid & 63;
+    if (2 * (int)blockIdx.x + pair >= p.batch) return;   // odd batch: the last workgroup holds one instance (ended waves do not hold barriers)
+    double* sm  = sm_all + (size_t)pair * CL::total(p.N);
     double* wsm = sm + side * CL::PER_WAVE;
     double *Dn = wsm + CL::DN, *gnl = wsm + CL::GN, *Yl = wsm + CL::YL, *Wl = wsm + CL::WL;
     double* dxs = sm + 2 * CL::PER_WAVE;             // [N][NX] delta x of every block
-    const int inst = blockIdx.x + p.inst0;
+    const int inst = 2 * blockIdx.x + pair + p.inst0;
     LmState* st = p.st + inst;
     const int done = st->done;
     int stop = st->stop;
@@ -2444,13 +2450,30 @@ __global__ __launch_bounds__(128) void big_chain2_kernel(const FactorParams p)
         pfix = p.comp[k * S + row].fixed;
     };
     // the stacked right-looking pass (see the head comment); returns this lane's dot product with y
+    // Look-ahead order: column j+1 is updated first, then the reciprocal square root of its pivot (v_rsq_f64 + the math library's
+    // Newton step, written out: five dependent instructions) is interleaved with the remaining column updates of step j -- a wave that
+    // has its SIMD to itself has nobody else to hide that chain behind.  Same operations as rsqrt(): bit-identical results.
     auto stacked_pass = [&](double (&mrow)[NX]) -> double {
+        double inv = rsqrt(lane_bcast(mrow[0], 0));
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const double inv = rsqrt(lane_bcast(mrow[j], j));
             mrow[j] = (lane == j) ? inv : mrow[j] * inv;
+            if (j + 1 < NX) {
+                mrow[j + 1] -= mrow[j] * lane_bcast(mrow[j], j + 1);
+                const double d = lane_bcast(mrow[j + 1], j + 1);
+                double y = 0.0, t = 0.0, e = 0.0, u = 0.0, w = 0.0, r = 0.0;
+                const int REM = NX - (j + 2);   // (compile-time after unrolling)
 #pragma unroll
-            for (int cc = j + 1; cc < NX; ++cc) mrow[cc] -= mrow[j] * lane_bcast(mrow[j], cc);   // (the pivot lanes' upper entries are unused)
+                for (int q = 0; q < NX; ++q) {
+                    if (q == 0) y = __builtin_amdgcn_rsq(d);
+                    if (q == 1) t = y * (-d);
+                    if (q == 2) e = __builtin_fma(t, y, 1.0);
+                    if (q == 3) { u = y * e; w = __builtin_fma(e, 0.375, 0.5); }
+                    if (q == 4) r = __builtin_fma(u, w, y);
+                    if (q == 5) inv = __builtin_amdgcn_class(y, 0x180) ? r : y;   // (+normal | +denormal: refined; else rsq's own inf / nan / 0)
+                    if (q < REM) mrow[j + 2 + q] -= mrow[j] * lane_bcast(mrow[j], j + 2 + q);   // (the pivot lanes' upper entries are unused)
+                }
+            }
         }
         double acc = 0.0;
 #pragma unroll
@@ -2588,13 +2611,13 @@ __global__ __launch_bounds__(128) void big_chain2_kernel(const FactorParams p)
     CHAIN2_STAMP(4);   // back-substitution
     // ---- epilogue, stage-parallel over both waves: trial iterate of the states, controls, step norm
     double dn2 = 0.0;
-    for (int e = threadIdx.x; e < N * NX; e += 128) {
+    for (int e = tid; e < N * NX; e += 128) {
         const int k = e / NX, r = e - k * NX;
         const double d = p.comp[k * S + r].fixed ? 0.0 : dxs[e];
         dn2 += d * d;
         xt[k * S + r] = xin[k * S + r] + d;
     }
-    for (int q = threadIdx.x; q < N - 1; q += 128) {
+    for (int q = tid; q < N - 1; q += 128) {
         const double* wq = ws + (size_t)q * BL::WS_STAGE;
         double w[NU];
 #pragma unroll
@@ -2614,7 +2637,7 @@ __global__ __launch_bounds__(128) void big_chain2_kernel(const FactorParams p)
             xt[q * S + NX + a] = xin[q * S + NX + a] + w[a];
         }
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         xt[p.off_dt] = xin[p.off_dt];
         if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
     }
@@ -2625,7 +2648,7 @@ __global__ __launch_bounds__(128) void big_chain2_kernel(const FactorParams p)
     dn2 = wave_sum(dn2);
     if (lane == 0) { sums[2 * side] = y2; sums[2 * side + 1] = dn2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         y2  = sums[0] + sums[2];
         dn2 = sums[1] + sums[3];
         st->mu_acc = mu_eff;
@@ -3194,8 +3217,8 @@ bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipSt
         if (p.chain_variant == 1)   // (diagnostics: the first formulation)
             hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * 12 * 12 + 2 * 12 + 8), stream, p);
         else {
-            const size_t lds2 = sizeof(double) * (size_t)Chain2Lds<12, 4>::total(p.N);
-            hipLaunchKernelGGL((big_chain2_kernel<12, 4>), dim3(p.batch), dim3(128), lds2, stream, p);
+            const size_t lds2 = 2 * sizeof(double) * (size_t)Chain2Lds<12, 4>::total(p.N);   // two instances per workgroup
+            hipLaunchKernelGGL((big_chain2_kernel<12, 4>), dim3((p.batch + 1) / 2), dim3(256), lds2, stream, p);
         }
         return true;
     }
