@@ -906,6 +906,201 @@ int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_b, doubl
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* Operators of the exact-Hessian path: what IpoptWrapper::eval_h asks the hypergraph for       */
+/* (nlp_solver_ipopt_wrapper.cpp:249-271) and the two-side-bounded linear form of the QP interface.               */
+
+#define O_MAX_BLOCK (CORBO_HIP_MAX_NX * CORBO_HIP_MAX_NX)
+
+/* BaseEdge::computeHessian / computeHessianInc with a precomputed Jacobian block (edge_interface.cpp:151-255): forward differences
+ * (HESSIAN_DELTA = 1e-2, :32) of the central-difference Jacobian of vertex i with respect to the components of vertex j, the vertex
+ * perturbed in place and reverted by a second addition.  block: n_i x n_j, column-major.  inc = 0: the first row assigns. */
+static void edge_hessian(oracle_problem* p, const o_edge* e, int vi, int vj, const double* jac_i, double* block, const double* mult, double weight, int inc)
+{
+    const double delta = 1e-2;
+    double scalar      = 1.0 / delta;
+    if (weight != 1.0) scalar *= weight;
+    const o_vertex* a = &p->v[e->vert[vi]];
+    const o_vertex* b = &p->v[e->vert[vj]];
+    double jac2[O_MAX_BLOCK];
+    int cj = 0;
+    for (int j = 0; j < b->dim; ++j) {
+        if (b->fixed & (1u << j)) continue;
+        p->x[b->off + j] += delta;
+        edge_jacobian(p, e, vi, jac2);
+        for (int r = 0; r < e->dim; ++r) {
+            const double f = mult ? scalar * mult[r] : scalar;
+            for (int c = 0; c < a->n_unfixed; ++c) {
+                const double t = f * (jac2[c * e->dim + r] - jac_i[c * e->dim + r]);
+                if (r == 0 && !inc) block[cj * a->n_unfixed + c] = t;
+                else block[cj * a->n_unfixed + c] += t;
+            }
+        }
+        p->x[b->off + j] += -delta;
+        ++cj;
+    }
+}
+
+/* which category of computeSparseHessians* an edge belongs to: 0 objective (lsq), 1 equalities, 2 inequalities */
+static int hessian_walk(oracle_problem* p, int lower, int with_values, double mult_obj, const double* mult_eq, const double* mult_ineq,
+                        int32_t* rows[3], int32_t* cols[3], double* vals[3], int nnz[3])
+{
+    nnz[0] = nnz[1] = nnz[2] = 0;
+    const int row_eq0 = p->dims.lsq, row_ineq0 = p->dims.lsq + p->dims.eq;
+    for (int ei = 0; ei < p->n_edges; ++ei) {
+        const o_edge* e = &p->e[ei];
+        const int cat   = e->scale;
+        const double* mult = (cat == 1) ? (mult_eq ? mult_eq + (e->row - row_eq0) : NULL) : (cat == 2) ? (mult_ineq ? mult_ineq + (e->row - row_ineq0) : NULL) : NULL;
+        for (int vi = 0; vi < e->nverts; ++vi) {
+            const o_vertex* a = &p->v[e->vert[vi]];
+            if (a->n_unfixed == 0) continue;
+            double jac1[O_MAX_BLOCK], jac2[O_MAX_BLOCK], blk[O_MAX_BLOCK];
+            if (with_values) edge_jacobian(p, e, vi, jac1);
+            const int vend = lower ? vi + 1 : e->nverts;
+            for (int vj = 0; vj < vend; ++vj) {
+                const o_vertex* b = &p->v[e->vert[vj]];
+                if (b->n_unfixed == 0) continue;
+                const int diag_lower = lower && (e->vert[vi] == e->vert[vj]);
+                const int ni = a->n_unfixed, nj = b->n_unfixed;
+                int at = nnz[cat];
+                if (with_values) {
+                    if (cat == 0) { /* lsq objective edge: 2 * multiplier * J_i^T J_j (the Gauss-Newton block, :3566-3606) */
+                        edge_jacobian(p, e, vj, jac2);
+                        for (int c = 0; c < nj; ++c)
+                            for (int r = 0; r < ni; ++r) {
+                                double acc = 0.0;
+                                /* Eigen: small products (rows + cols + depth < 20, EIGEN_GEMM_TO_COEFFBASED_THRESHOLD) are coefficient-based with
+                                 * (2 m J_i^T) as the left factor -- every term scaled first; larger ones go through the GEMM kernel, which
+                                 * applies the factor to the finished sum.  (The cost Jacobians are diagonal: one non-zero term per sum.) */
+                                if (ni + nj + e->dim < 20) {
+                                    for (int q = 0; q < e->dim; ++q) acc += ((2.0 * mult_obj) * jac1[r * e->dim + q]) * jac2[c * e->dim + q];
+                                    blk[c * ni + r] = acc;
+                                }
+                                else {
+                                    for (int q = 0; q < e->dim; ++q) acc += jac1[r * e->dim + q] * jac2[c * e->dim + q];
+                                    blk[c * ni + r] = (2.0 * mult_obj) * acc;
+                                }
+                            }
+                    }
+                    else {
+                        for (int q = 0; q < ni * nj; ++q) blk[q] = 0.0;
+                        edge_hessian(p, e, vi, vj, jac1, blk, mult, 1.0, diag_lower ? 0 : 1);
+                    }
+                }
+                if (diag_lower) { /* lower triangle, row by row (:3537-3546) */
+                    for (int i = 0; i < ni; ++i)
+                        for (int j = 0; j <= i; ++j, ++at) {
+                            if (rows[cat]) { rows[cat][at] = a->col + i; cols[cat][at] = b->col + j; }
+                            if (with_values) vals[cat][at] = 0.0 + blk[j * ni + i];
+                        }
+                }
+                else { /* values: the block column-major (Eigen::Map<MatrixXd> on the value array, :3550-3552); the structure lists the
+                        * same entries ROW-major (:2993-3003) -- the reference's own mismatch for off-diagonal vertex pairs, kept */
+                    for (int i = 0; i < ni; ++i)
+                        for (int j = 0; j < nj; ++j)
+                            if (rows[cat]) { rows[cat][at + i * nj + j] = a->col + i; cols[cat][at + i * nj + j] = b->col + j; }
+                    if (with_values)
+                        for (int q = 0; q < ni * nj; ++q) vals[cat][at + q] = 0.0 + blk[q];
+                    at += ni * nj;
+                }
+                nnz[cat] = at;
+            }
+        }
+    }
+    return 0;
+}
+
+int oracle_get_param_offsets(const oracle_problem* p, int32_t* off_out)
+{
+    if (!p || p->gen || !off_out) return CORBO_HIP_ERR_INVALID;
+    for (int i = 0; i < p->dims.n; ++i) off_out[i] = p->param_off[i];
+    return 0;
+}
+
+int oracle_hessian_nnz(oracle_problem* p, int lower_part_only, int32_t nnz_out[3])
+{
+    if (!p || p->gen) return CORBO_HIP_ERR_INVALID;
+    int32_t* none[3] = {NULL, NULL, NULL};
+    double* nov[3]   = {NULL, NULL, NULL};
+    int nnz[3];
+    hessian_walk(p, lower_part_only, 0, 1.0, NULL, NULL, none, none, nov, nnz);
+    for (int i = 0; i < 3; ++i) nnz_out[i] = nnz[i];
+    return 0;
+}
+
+int oracle_hessian_structure(oracle_problem* p, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq, int32_t* cols_eq,
+                             int32_t* rows_ineq, int32_t* cols_ineq)
+{
+    if (!p || p->gen) return CORBO_HIP_ERR_INVALID;
+    int32_t* rows[3] = {rows_obj, rows_eq, rows_ineq};
+    int32_t* cols[3] = {cols_obj, cols_eq, cols_ineq};
+    double* nov[3]   = {NULL, NULL, NULL};
+    int nnz[3];
+    return hessian_walk(p, lower_part_only, 0, 1.0, NULL, NULL, rows, cols, nov, nnz);
+}
+
+/* computeSparseHessiansValues (hyper_graph_optimization_problem_edge_based.cpp:3491-3760) at the current x */
+int oracle_hessian_values(oracle_problem* p, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq,
+                          double* vals_obj, double* vals_eq, double* vals_ineq)
+{
+    if (!p || p->gen) return CORBO_HIP_ERR_INVALID;
+    int32_t* none[3] = {NULL, NULL, NULL};
+    double* vals[3]  = {vals_obj, vals_eq, vals_ineq};
+    int nnz[3];
+    return hessian_walk(p, lower_part_only, 1, mult_obj, mult_eq, mult_ineq, none, none, vals, nnz);
+}
+
+/* computeSparseJacobianTwoSideBoundedLinearForm{NNZ,Structure,Values} with include_finite_bounds = true (:4762-4968) and
+ * computeBoundsForTwoSideBoundedLinearForm (optimization_problem_interface.cpp:1141-1183; ubA of a bound row is x - ub there, kept).
+ * rows / cols / vals may be NULL (nnz query); lbA / ubA: eq + ineq + bounds entries. */
+int oracle_linear_form(oracle_problem* p, int32_t* nnz_out, int32_t* rows, int32_t* cols, double* vals, double* lbA, double* ubA)
+{
+    if (!p || p->gen) return CORBO_HIP_ERR_INVALID;
+    const int row_eq0 = p->dims.lsq;
+    int at = 0;
+    double blk[O_MAX_BLOCK];
+    for (int ei = 0; ei < p->n_edges; ++ei) {
+        const o_edge* e = &p->e[ei];
+        if (e->scale == 0) continue;
+        for (int vi = 0; vi < e->nverts; ++vi) {
+            const o_vertex* a = &p->v[e->vert[vi]];
+            if (a->n_unfixed == 0) continue;
+            if (vals) edge_jacobian(p, e, vi, blk);
+            for (int c = 0; c < a->n_unfixed; ++c)
+                for (int r = 0; r < e->dim; ++r, ++at) {
+                    if (rows) { rows[at] = e->row - row_eq0 + r; cols[at] = a->col + c; }
+                    if (vals) vals[at] = blk[c * e->dim + r];
+                }
+        }
+    }
+    const int rowb0 = p->dims.eq + p->dims.ineq;
+    for (int i = 0; i < p->dims.bounds; ++i, ++at) {
+        if (rows) { rows[at] = rowb0 + i; cols[at] = p->bound_col[i]; }
+        if (vals) vals[at] = 1.0;
+    }
+    if (nnz_out) *nnz_out = at;
+    if (lbA && ubA) {
+        double* tmp = (double*)calloc(p->dims.m + 1, sizeof(double));
+        for (int ei = 0; ei < p->n_edges; ++ei) {
+            const o_edge* e = &p->e[ei];
+            if (e->scale == 0) continue;
+            edge_values(p, e, tmp);
+            for (int r = 0; r < e->dim; ++r) {
+                const int row = e->row - row_eq0 + r;
+                if (e->scale == 1) { lbA[row] = tmp[r] * -1; ubA[row] = lbA[row]; }
+                else { lbA[row] = -CORBO_HIP_INF; ubA[row] = tmp[r] * -1; }
+            }
+        }
+        free(tmp);
+        for (int i = 0; i < p->dims.bounds; ++i) {
+            const int o = p->bound_vert_off[i];
+            lbA[rowb0 + i] = p->lb[o] - p->x[o];
+            ubA[rowb0 + i] = p->x[o] - p->ub[o];
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
 /* H = J^T J, rhs = J^T (-values)  (levenberg_marquardt_sparse.cpp:97-100): each H(i,j) is accumulated over the    */
 /* rows of J in ascending order, which is the order Eigen's conservative sparse product produces.                 */
 

@@ -62,6 +62,20 @@ oracle_problem* oracle_create_generic(int n, int dim_lsq, int dim_eq, int dim_in
 /* LevenbergMarquardtSparse::computeValues + computeCombinedSparseJacobian at the current x (jac may be NULL) */
 int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_bounds, double* values, double* jac);
 
+/* Operators of the exact-Hessian path at the current x.  Three triplet lists -- objective, equalities, inequalities -- exactly as
+ * computeSparseHessians{NNZ,Structure,Values} (hyper_graph_optimization_problem_edge_based.cpp:2087-3760) produce them, entry order
+ * included; lower_part_only as IpoptWrapper::eval_h passes it (true).  Multipliers: one per equality / inequality row (NULL = 1). */
+/* offset in the vertex layout of every optimisation parameter (n entries) */
+int oracle_get_param_offsets(const oracle_problem* p, int32_t* off_out);
+int oracle_hessian_nnz(oracle_problem* p, int lower_part_only, int32_t nnz_out[3]);
+int oracle_hessian_structure(oracle_problem* p, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq, int32_t* cols_eq,
+                             int32_t* rows_ineq, int32_t* cols_ineq);
+int oracle_hessian_values(oracle_problem* p, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq,
+                          double* vals_obj, double* vals_eq, double* vals_ineq);
+/* lbA <= A dx <= ubA: computeSparseJacobianTwoSideBoundedLinearForm* with the finite bounds (:4762-4968) and
+ * computeBoundsForTwoSideBoundedLinearForm (optimization_problem_interface.cpp:1141-1183).  Any output may be NULL. */
+int oracle_linear_form(oracle_problem* p, int32_t* nnz_out, int32_t* rows, int32_t* cols, double* vals, double* lbA, double* ubA);
+
 /* LevenbergMarquardtSparse::solve.  Returns corbo_hip_solver_status; *chi2_out = *obj_value.
  * trace (may be NULL) must hold opts->iterations entries. */
 int oracle_solve(oracle_problem* p, const corbo_hip_lm_opts* opts, int new_run, double* chi2_out, oracle_trace_entry* trace);

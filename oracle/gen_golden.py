@@ -112,8 +112,35 @@ def adapt():
         print(name, [st["n_seq"] for st in d["steps"]])
 
 
+def hess():
+    """Operators of the exact-Hessian path at a generic point: computeSparseHessians{Structure,Values} (full and
+    lower part, seeded multipliers) and the two-side-bounded linear form with its bounds, from the genuine reference
+    (ref_driver hess).  Small horizons: the operators are per edge, the structure repeats."""
+    for name, kv in [
+        ("hess_vdp", dict(scenario="vdp")),
+        ("hess_vdp_forward", dict(scenario="vdp", collocation="forward", N=10)),
+        ("hess_vdp_backward", dict(scenario="vdp", collocation="backward", N=10)),
+        ("hess_vdp_midpoint", dict(scenario="vdp", collocation="midpoint", N=10)),
+        ("hess_vdp_teq", dict(scenario="vdp", N=10, teq=1)),
+        ("hess_dint", dict(scenario="dint", N=20)),
+        ("hess_int3_time_optimal", dict(scenario="int3", vargrid=1, N=12)),
+        ("hess_unicycle_n16", dict(scenario="unicycle", N=16)),
+        ("hess_unicycle_xf_fixed", dict(scenario="unicycle", N=10, xf_fixed=3)),
+        ("hess_unicycle_n24_ball", dict(scenario="unicycle", N=24, ball="2,1.2,0.3,0.6", tball=0.02, tball_s="1,1,0.1")),
+        ("hess_pendulum_ms_rk4", dict(scenario="pendulum", grid="ms", N=8)),
+        ("hess_cartpole", dict(scenario="cartpole", N=8)),
+        ("hess_quad_n4", dict(scenario="quad", N=4)),
+    ]:
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], len(d["heq_vals_full"]), len(d["hineq_vals_full"]), os.path.getsize(os.path.join(OUT, f"{name}.json")))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "hess":
+        return hess()
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         return fullsize()
     if len(sys.argv) > 1 and sys.argv[1] == "adapt":

@@ -50,6 +50,12 @@ def load():
     lib.oracle_solve_batch.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, C.POINTER(LmOpts), dp, ip]
     lib.oracle_resample_trajectory.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]
     lib.oracle_adapt_grid_n.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+    i3 = C.POINTER(C.c_int32)
+    lib.oracle_get_param_offsets.argtypes = [C.c_void_p, i3]
+    lib.oracle_hessian_nnz.argtypes = [C.c_void_p, C.c_int, i3]
+    lib.oracle_hessian_structure.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, ip, ip]
+    lib.oracle_hessian_values.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, dp, dp, dp]
+    lib.oracle_linear_form.argtypes = [C.c_void_p, i3, ip, ip, dp, dp, dp]
     lib.oracle_create_generic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, GENERIC_FUN]
     lib.oracle_create_generic.restype = C.c_void_p
     _lib = lib
@@ -112,6 +118,36 @@ class OracleProblem:
         assert rc == 0
         return values, jac
 
+    def param_offsets(self):
+        out = np.zeros(self.dims.n, np.int32)
+        assert self.lib.oracle_get_param_offsets(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        return out
+
+    def hessians(self, lower, mult_obj=1.0, mult_eq=None, mult_ineq=None):
+        """computeSparseHessians{Structure,Values}: three (rows, cols, values) triplet lists -- objective, equalities, inequalities."""
+        nnz = (C.c_int32 * 3)()
+        assert self.lib.oracle_hessian_nnz(self.h, int(lower), nnz) == 0
+        rows = [np.zeros(max(1, n), np.int32) for n in nnz]
+        cols = [np.zeros(max(1, n), np.int32) for n in nnz]
+        vals = [np.zeros(max(1, n)) for n in nnz]
+        ipp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        assert self.lib.oracle_hessian_structure(self.h, int(lower), ipp(rows[0]), ipp(cols[0]), ipp(rows[1]), ipp(cols[1]), ipp(rows[2]), ipp(cols[2])) == 0
+        me = None if mult_eq is None else np.ascontiguousarray(mult_eq, np.float64)
+        mi = None if mult_ineq is None or len(mult_ineq) == 0 else np.ascontiguousarray(mult_ineq, np.float64)
+        assert self.lib.oracle_hessian_values(self.h, int(lower), float(mult_obj), _dp(me), _dp(mi), _dp(vals[0]), _dp(vals[1]), _dp(vals[2])) == 0
+        return [(rows[i][:nnz[i]], cols[i][:nnz[i]], vals[i][:nnz[i]]) for i in range(3)]
+
+    def linear_form(self):
+        """computeSparseJacobianTwoSideBoundedLinearForm* (with the finite bounds) and its bounds: rows, cols, values, lbA, ubA."""
+        nnz = C.c_int32(0)
+        assert self.lib.oracle_linear_form(self.h, C.byref(nnz), None, None, None, None, None) == 0
+        rows, cols, vals = np.zeros(nnz.value, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nnz.value)
+        ma = self.dims.eq + self.dims.ineq + self.dims.bounds
+        lbA, ubA = np.zeros(ma), np.zeros(ma)
+        ipp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        assert self.lib.oracle_linear_form(self.h, C.byref(nnz), ipp(rows), ipp(cols), _dp(vals), _dp(lbA), _dp(ubA)) == 0
+        return rows, cols, vals, lbA, ubA
+
     def warm_start(self, x0, shift=True):
         x0 = np.ascontiguousarray(x0, np.float64)
         assert self.lib.oracle_warm_start(self.h, _dp(x0), 1 if shift else 0) == 0
@@ -161,6 +197,36 @@ class GenericProblem(OracleProblem):
 
     def init_trajectory(self, x0, xf):
         raise NotImplementedError("not an OCP")
+
+    def param_offsets(self):
+        out = np.zeros(self.dims.n, np.int32)
+        assert self.lib.oracle_get_param_offsets(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        return out
+
+    def hessians(self, lower, mult_obj=1.0, mult_eq=None, mult_ineq=None):
+        """computeSparseHessians{Structure,Values}: three (rows, cols, values) triplet lists -- objective, equalities, inequalities."""
+        nnz = (C.c_int32 * 3)()
+        assert self.lib.oracle_hessian_nnz(self.h, int(lower), nnz) == 0
+        rows = [np.zeros(max(1, n), np.int32) for n in nnz]
+        cols = [np.zeros(max(1, n), np.int32) for n in nnz]
+        vals = [np.zeros(max(1, n)) for n in nnz]
+        ipp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        assert self.lib.oracle_hessian_structure(self.h, int(lower), ipp(rows[0]), ipp(cols[0]), ipp(rows[1]), ipp(cols[1]), ipp(rows[2]), ipp(cols[2])) == 0
+        me = None if mult_eq is None else np.ascontiguousarray(mult_eq, np.float64)
+        mi = None if mult_ineq is None or len(mult_ineq) == 0 else np.ascontiguousarray(mult_ineq, np.float64)
+        assert self.lib.oracle_hessian_values(self.h, int(lower), float(mult_obj), _dp(me), _dp(mi), _dp(vals[0]), _dp(vals[1]), _dp(vals[2])) == 0
+        return [(rows[i][:nnz[i]], cols[i][:nnz[i]], vals[i][:nnz[i]]) for i in range(3)]
+
+    def linear_form(self):
+        """computeSparseJacobianTwoSideBoundedLinearForm* (with the finite bounds) and its bounds: rows, cols, values, lbA, ubA."""
+        nnz = C.c_int32(0)
+        assert self.lib.oracle_linear_form(self.h, C.byref(nnz), None, None, None, None, None) == 0
+        rows, cols, vals = np.zeros(nnz.value, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nnz.value)
+        ma = self.dims.eq + self.dims.ineq + self.dims.bounds
+        lbA, ubA = np.zeros(ma), np.zeros(ma)
+        ipp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        assert self.lib.oracle_linear_form(self.h, C.byref(nnz), ipp(rows), ipp(cols), _dp(vals), _dp(lbA), _dp(ubA)) == 0
+        return rows, cols, vals, lbA, ubA
 
     def warm_start(self, x0, shift=True):
         raise NotImplementedError("not an OCP")

@@ -861,6 +861,87 @@ static int loop(const Scenario& s, std::map<std::string, std::string>& kv)
 // re-run against the compiled reference.  The problem definitions below are this file's own restatement of what those tests set
 // up (same functions, starts, bounds, weights, iteration counts, call order -- including the tests' "setParameterValue(0, ..)
 // twice" slip); the output pins LevenbergMarquardtSparse::solve on problems that are not OCPs.
+
+static void printIVec(const char* key, const Eigen::VectorXi& v, bool comma = true)
+{
+    printf("\"%s\": [", key);
+    for (int i = 0; i < v.size(); ++i) printf("%s%d", i ? ", " : "", v[i]);
+    printf("]%s\n", comma ? "," : "");
+}
+
+// hess: the operators of the exact-Hessian path at a generic point of the scenario's hypergraph -- what
+// IpoptWrapper::eval_h hands to the interior-point solver (nlp_solver_ipopt_wrapper.cpp:249-271, lower_part_only = true) and the
+// two-side-bounded linear form lbA <= A x <= ubA of the QP interface (hyper_graph_optimization_problem_edge_based.cpp:4762-4968).
+static int hess(const Scenario& s)
+{
+    Built b = build(s, 0);
+    run(b, s, 1);   // 0 iterations: graph built, evaluated once
+    auto& hg = *b.hg;
+    const int n = hg.getParameterDimension(), eq = hg.getEqualityDimension(), ineq = hg.getInequalityDimension();
+    Eigen::VectorXd inc(n);
+    for (int i = 0; i < n; ++i) inc[i] = 0.05 * std::sin(1.3 * i + 0.4);
+    hg.applyIncrement(inc);   // away from the structured initial guess (u = 0, straight line)
+    printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g,\n", s.name.c_str(), s.nx, s.nu, s.N, s.dt);
+    printf("\"collocation\": \"%s\",\n", s.collocation.c_str());
+    if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (s.ball.size() == 4) printVec("ball", s.ball);
+    if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
+    if (s.teq) printf("\"teq\": 1,\n");
+    if (s.vargrid) printf("\"vargrid\": 1,\n");
+    if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
+    if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
+    if (s.xlb.size()) printVec("xlb", s.xlb);
+    if (s.xub.size()) printVec("xub", s.xub);
+    if (s.ulb.size()) printVec("ulb", s.ulb);
+    if (s.uub.size()) printVec("uub", s.uub);
+    printVec("x0", s.x0);
+    printVec("xf", s.xf);
+    if (s.tball_s.size() > 0)
+    {
+        printf("\"tball_gamma\": %.17g, ", s.tball_gamma);
+        printVec("tball_s", s.tball_s);
+    }
+    printf("\"n\": %d, \"eq\": %d, \"ineq\": %d, \"bounds\": %d,\n", n, eq, ineq, hg.finiteCombinedBoundsDimension());
+    printVec("vertex_point", vertexValues(b, s));
+    Eigen::VectorXd meq(eq), mineq(ineq);
+    for (int i = 0; i < eq; ++i) meq[i] = 0.5 + 0.25 * std::cos(0.7 * i);
+    for (int i = 0; i < ineq; ++i) mineq[i] = 0.3 + 0.125 * (i % 5);
+    const double mobj = 1.5;
+    printf("\"mult_obj\": %.17g,\n", mobj);
+    printVec("mult_eq", meq);
+    printVec("mult_ineq", mineq);
+    for (int lower = 0; lower < 2; ++lower)
+    {
+        int no = 0, ne = 0, ni = 0;
+        hg.computeSparseHessiansNNZ(no, ne, ni, lower != 0);
+        Eigen::VectorXi io(no), jo(no), ie(ne), je(ne), ii(ni), ji(ni);
+        hg.computeSparseHessiansStructure(io, jo, ie, je, ii, ji, lower != 0);
+        Eigen::VectorXd vo(no), ve(ne), vi(ni);
+        hg.computeSparseHessiansValues(vo, ve, vi, mobj, meq.data(), ineq ? mineq.data() : nullptr, lower != 0);
+        const char* tag = lower ? "lower" : "full";
+        char key[64];
+        auto K = [&](const char* base) { snprintf(key, sizeof(key), "%s_%s", base, tag); return key; };
+        printIVec(K("hobj_rows"), io); printIVec(K("hobj_cols"), jo); printVec(K("hobj_vals"), vo);
+        printIVec(K("heq_rows"), ie);  printIVec(K("heq_cols"), je);  printVec(K("heq_vals"), ve);
+        printIVec(K("hineq_rows"), ii); printIVec(K("hineq_cols"), ji); printVec(K("hineq_vals"), vi);
+    }
+    {   // linear form
+        const int nnz = hg.computeSparseJacobianTwoSideBoundedLinearFormNNZ(true);
+        Eigen::VectorXi ir(nnz), jc(nnz);
+        Eigen::VectorXd va(nnz);
+        hg.computeSparseJacobianTwoSideBoundedLinearFormStructure(ir, jc, true);
+        hg.computeSparseJacobianTwoSideBoundedLinearFormValues(va, true);
+        const int ma = eq + ineq + hg.finiteCombinedBoundsDimension();
+        Eigen::VectorXd lbA(ma), ubA(ma);
+        hg.computeBoundsForTwoSideBoundedLinearForm(lbA, ubA, true);
+        printIVec("lin_rows", ir); printIVec("lin_cols", jc); printVec("lin_vals", va);
+        printVec("lin_lbA", lbA); printVec("lin_ubA", ubA);
+    }
+    printVec("vertex_after", vertexValues(b, s), false);   // (the in-place perturbations of the finite differences leave the point a few ulps off)
+    printf("}\n");
+    return 0;
+}
+
 static int g_kat_iter_cap = 0;   // kat cap=K: every phase runs at most K LM iterations (to compare iterate by iterate)
 
 struct KatPhase
@@ -988,7 +1069,7 @@ int main(int argc, char** argv)
 {
     if (argc < 2)
     {
-        fprintf(stderr, "usage: ref_driver dump|bench|mpc|loop|kat key=value ...\n");
+        fprintf(stderr, "usage: ref_driver dump|bench|mpc|loop|hess|kat key=value ...\n");
         return 1;
     }
     std::string mode(argv[1]);
@@ -1003,6 +1084,7 @@ int main(int argc, char** argv)
     if (mode == "bench") return bench(s, kv);
     if (mode == "mpc") return mpc(s, kv);
     if (mode == "loop") return loop(s, kv);
+    if (mode == "hess") return hess(s);
     fprintf(stderr, "unknown mode\n");
     return 1;
 }
