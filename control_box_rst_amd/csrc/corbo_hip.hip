@@ -1120,6 +1120,146 @@ try {
 }
 ABI_CATCH
 
+// ---- operators of the exact-Hessian path ----------------------------------------------------------------------
+namespace {
+struct DevBuf {   // scratch device buffer of one call
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    double* d() const { return static_cast<double*>(p); }
+    int32_t* i() const { return static_cast<int32_t*>(p); }
+};
+}  // namespace
+
+int corbo_hip_hessian_nnz(corbo_hip_handle h, int lower_part_only, int32_t* nnz_out)
+try {
+    if (!h || !nnz_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    HessianStructure H;
+    build_hessian_structure(h->S, lower_part_only != 0, H);
+    for (int c = 0; c < 3; ++c) nnz_out[c] = H.nnz[c];
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_hessian_structure(corbo_hip_handle h, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq, int32_t* cols_eq,
+                                int32_t* rows_ineq, int32_t* cols_ineq)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    HessianStructure H;
+    build_hessian_structure(h->S, lower_part_only != 0, H);
+    int32_t* rows[3] = {rows_obj, rows_eq, rows_ineq};
+    int32_t* cols[3] = {cols_obj, cols_eq, cols_ineq};
+    for (int c = 0; c < 3; ++c) {
+        if (H.nnz[c] > 0 && (!rows[c] || !cols[c])) return fail(CORBO_HIP_ERR_INVALID, "null structure array for a non-empty list");
+        if (H.nnz[c] > 0) { std::memcpy(rows[c], H.rows[c].data(), H.nnz[c] * sizeof(int32_t)); std::memcpy(cols[c], H.cols[c].data(), H.nnz[c] * sizeof(int32_t)); }
+    }
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+static int hessian_common(corbo_hip_handle h, HessianStructure& H, bool lower, HessParams& hp, DevBuf& d_so, DevBuf& d_lo)
+{
+    if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    if (h->S.nx > 6) return fail(CORBO_HIP_ERR_UNSUPPORTED, "the Hessian / linear-form operators exist for the small-block families (nx <= 6) only");
+    build_hessian_structure(h->S, lower, H);
+    HIP_TRY(d_so.alloc(H.stage_off.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(d_so.p, H.stage_off.data(), H.stage_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(d_lo.alloc(H.lin_off.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(d_lo.p, H.lin_off.data(), H.lin_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    hp = HessParams{};
+    hp.lower = lower ? 1 : 0;
+    hp.eq_dim = h->S.dims.eq; hp.ineq_dim = h->S.dims.ineq;
+    hp.stage_off = d_so.i(); hp.lin_off = d_lo.i();
+    for (int c = 0; c < 3; ++c) hp.nnz[c] = H.nnz[c];
+    hp.lin_nnz = H.lin_nnz; hp.lin_bounds0 = H.lin_bounds0; hp.bnd_row0 = h->S.bnd_row0; hp.n_bounds = h->S.dims.bounds;
+    hp.stage_cost = h->S.desc.stage_cost; hp.stage_ineq = h->S.desc.stage_ineq;
+    return 0;
+}
+
+int corbo_hip_eval_hessians(corbo_hip_handle h, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq, double* vals_obj,
+                            double* vals_eq, double* vals_ineq)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    HessianStructure H;
+    HessParams hp;
+    DevBuf d_so, d_lo, d_me, d_mi, d_v[3];
+    int rc = hessian_common(h, H, lower_part_only != 0, hp, d_so, d_lo);
+    if (rc) return rc;
+    const size_t B = (size_t)h->active;
+    double* out[3] = {vals_obj, vals_eq, vals_ineq};
+    for (int c = 0; c < 3; ++c) {
+        if (H.nnz[c] > 0 && !out[c]) return fail(CORBO_HIP_ERR_INVALID, "null value array for a non-empty list");
+        HIP_TRY(d_v[c].alloc(B * H.nnz[c] * sizeof(double)));
+        hp.vals[c] = d_v[c].d();
+    }
+    if (mult_eq && hp.eq_dim > 0) {
+        HIP_TRY(d_me.alloc(B * hp.eq_dim * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_me.p, mult_eq, B * hp.eq_dim * sizeof(double), hipMemcpyHostToDevice));
+        hp.mult_eq = d_me.d();
+    }
+    if (mult_ineq && hp.ineq_dim > 0) {
+        HIP_TRY(d_mi.alloc(B * hp.ineq_dim * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_mi.p, mult_ineq, B * hp.ineq_dim * sizeof(double), hipMemcpyHostToDevice));
+        hp.mult_ineq = d_mi.d();
+    }
+    hp.mode = 0;
+    hp.mult_obj = mult_obj;
+    const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int c = 0; c < 3; ++c)
+        if (H.nnz[c] > 0) HIP_TRY(hipMemcpy(out[c], d_v[c].p, B * H.nnz[c] * sizeof(double), hipMemcpyDeviceToHost));
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_linear_form_structure(corbo_hip_handle h, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    HessianStructure H;
+    build_hessian_structure(h->S, false, H);
+    if (nnz_out) *nnz_out = H.lin_nnz;
+    if (n_rows_out) *n_rows_out = h->S.dims.eq + h->S.dims.ineq + h->S.dims.bounds;
+    if (rows && cols && H.lin_nnz > 0) {
+        std::memcpy(rows, H.lin_rows.data(), H.lin_nnz * sizeof(int32_t));
+        std::memcpy(cols, H.lin_cols.data(), H.lin_nnz * sizeof(int32_t));
+    }
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_eval_linear_form(corbo_hip_handle h, double* vals, double* lbA, double* ubA)
+try {
+    if (!h || !vals || !lbA || !ubA) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    ON_DEVICE_OF(h);
+    HessianStructure H;
+    HessParams hp;
+    DevBuf d_so, d_lo, d_v, d_l, d_u;
+    int rc = hessian_common(h, H, false, hp, d_so, d_lo);
+    if (rc) return rc;
+    const size_t B = (size_t)h->active, rows = (size_t)(hp.eq_dim + hp.ineq_dim + hp.n_bounds);
+    HIP_TRY(d_v.alloc(B * H.lin_nnz * sizeof(double)));
+    HIP_TRY(d_l.alloc(B * rows * sizeof(double)));
+    HIP_TRY(d_u.alloc(B * rows * sizeof(double)));
+    hp.mode = 1;
+    hp.lin_vals = d_v.d(); hp.lbA = d_l.d(); hp.ubA = d_u.d();
+    const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (H.lin_nnz > 0) HIP_TRY(hipMemcpy(vals, d_v.p, B * H.lin_nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (rows > 0) {
+        HIP_TRY(hipMemcpy(lbA, d_l.p, B * rows * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ubA, d_u.p, B * rows * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
 int corbo_hip_device_views(corbo_hip_handle h, double** x_dev, double** chi2_dev, void** hip_stream)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");

@@ -2809,6 +2809,251 @@ bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact-Hessian path: computeSparseHessiansValues (hyper_graph_optimization_problem_edge_based.cpp:3491-3760)
+// and the two-side-bounded linear form (:4904-4968, optimization_problem_interface.cpp:1141-1183) on the device.
+// One lane per (instance, stage): the lane owns private copies of the vertices of its stage's edges -- x_k, u_k, x_{k+1}, dt -- and
+// runs, edge by edge, the reference's own sequence on them: the central-difference Jacobian block of vertex i (BaseEdge::computeJacobian,
+// edge_interface.cpp:55-96, delta = 1e-9, perturbed in place and reverted by a third addition), then for every component of vertex j a
+// forward step of HESSIAN_DELTA = 1e-2 (:32), the Jacobian block again, and  (1 / delta) * multiplier_r * (J2 - J1)  summed over the
+// edge's rows r (computeHessian / computeHessianInc, :151-255).  Least-squares cost edges contribute the Gauss-Newton block
+// 2 m J_i^T J_j (:3566-3606).  Value layout and entry order: build_hessian_structure.  The only thing a lane cannot reproduce is the
+// drift the reference's in-place perturbations leave in vertices SHARED with edges evaluated earlier (x_{k+1} of stage k is x_k of
+// stage k+1): a few ulps of the point, i.e. 1e-7 in a Jacobian entry and 1e-5 in a Hessian entry -- the size of the difference
+// between two consecutive calls of the reference itself (tests/test_gpu_hessian.py).
+// ---------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+template <int DYN, int DEFECT>
+struct HessEdge {
+    using Dy = Dynamics<DYN>;
+    static constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, W = S + NX + 1;
+    static constexpr int MAXD = (NX > NU) ? NX : NU;
+    // BaseEdge::computeValues of the edge kinds on the path, on the lane's private vertex copies (xl: x_k | u_k | x_{k+1} | dt)
+    __device__ static void values(int kind, const double* xl, const double* xr, const ModelParams& mp, double* out)
+    {
+        switch (kind) {
+            case EK_STATE_COST:
+                for (int i = 0; i < NX; ++i) out[i] = mp.sq[i] * (xl[i] - xr[i]);
+                break;
+            case EK_CONTROL_COST:
+                for (int i = 0; i < NU; ++i) out[i] = mp.sr[i] * xl[NX + i];
+                break;
+            case EK_FINAL_COST:
+                for (int i = 0; i < NX; ++i) out[i] = mp.sqf[i] * (xl[i] - xr[i]);
+                break;
+            case EK_DT_COST: out[0] = mp.dt_weight * xl[W - 1]; break;
+            case EK_DEFECT: defect_eval<DYN, DEFECT>(xl, xl + NX, xl + S, xl[W - 1], mp.dyn, out); break;
+            case EK_STAGE_INEQ:
+                if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
+                break;
+            case EK_FINAL_EQ:
+                for (int i = 0; i < NX; ++i) out[i] = xl[i] - xr[i];
+                break;
+            case EK_FINAL_INEQ: out[0] = terminal_ball<NX>(xl, xr, mp.fin); break;
+            default: break;
+        }
+    }
+    __device__ static int edge_dim(int kind) { return kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ) ? 1 : NX; }
+    __device__ static int n_verts(int kind) { return kind == EK_DEFECT ? 4 : 1; }
+    __device__ static int vert_off(int kind, int vi) { return kind == EK_DEFECT ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : kind == EK_CONTROL_COST ? NX : kind == EK_DT_COST ? W - 1 : 0; }
+    __device__ static int vert_dim(int kind, int vi)
+    {
+        if (kind == EK_DEFECT) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? NX : 1;
+        return kind == EK_CONTROL_COST ? NU : kind == EK_DT_COST ? 1 : NX;   // every other edge hangs on one state vertex
+    }
+    __device__ static int unfixed(unsigned fm, int off, int dim) { int n = 0; for (int i = 0; i < dim; ++i) n += ((fm >> (off + i)) & 1u) ? 0 : 1; return n; }
+    // BaseEdge::computeJacobian (edge_interface.cpp:55-96): block [dim x n_unfixed], column-major
+    __device__ static void jacobian(int kind, int vi, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double* blk)
+    {
+        constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
+        const int off = vert_off(kind, vi), dim = vert_dim(kind, vi), ed = edge_dim(kind);
+        double v1[MAXD], v2[MAXD];
+        int col = 0;
+        for (int i = 0; i < dim; ++i) {
+            if ((fm >> (off + i)) & 1u) continue;
+            xl[off + i] += delta;
+            values(kind, xl, xr, mp, v2);
+            xl[off + i] += neg2delta;
+            values(kind, xl, xr, mp, v1);
+            for (int r = 0; r < ed; ++r) blk[col * ed + r] = scalar * (v2[r] - v1[r]);
+            xl[off + i] += delta;
+            ++col;
+        }
+    }
+    // all blocks of one edge, in the order of the reference's walk; returns the number of values written
+    __device__ static int hessian_blocks(int kind, int cat, bool lower, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double mult_obj,
+                                         const double* mult, double* out)
+    {
+        constexpr double hdelta = 1e-2;
+        const int ed = edge_dim(kind), nv = n_verts(kind);
+        double jac1[MAXD * MAXD], jac2[MAXD * MAXD], blk[MAXD * MAXD];
+        int at = 0;
+        for (int vi = 0; vi < nv; ++vi) {
+            const int oi = vert_off(kind, vi), di = vert_dim(kind, vi), ni = unfixed(fm, oi, di);
+            if (ni == 0) continue;
+            jacobian(kind, vi, fm, xl, xr, mp, jac1);
+            const int vend = lower ? vi + 1 : nv;
+            for (int vj = 0; vj < vend; ++vj) {
+                const int oj = vert_off(kind, vj), dj = vert_dim(kind, vj), nj = unfixed(fm, oj, dj);
+                if (nj == 0) continue;
+                const bool diag_lower = lower && vi == vj;
+                if (cat == 0) {   // least-squares objective edge: (2 m J_i)^T J_j, coefficient-based product (every term scaled first)
+                    jacobian(kind, vj, fm, xl, xr, mp, jac2);
+                    for (int c = 0; c < nj; ++c)
+                        for (int r = 0; r < ni; ++r) {
+                            double acc = 0.0;
+                            for (int q = 0; q < ed; ++q) acc += ((2.0 * mult_obj) * jac1[r * ed + q]) * jac2[c * ed + q];
+                            blk[c * ni + r] = acc;
+                        }
+                }
+                else {
+                    const double scalar = 1.0 / hdelta;
+                    for (int q = 0; q < ni * nj; ++q) blk[q] = 0.0;
+                    int cj = 0;
+                    for (int j = 0; j < dj; ++j) {
+                        if ((fm >> (oj + j)) & 1u) continue;
+                        xl[oj + j] += hdelta;
+                        jacobian(kind, vi, fm, xl, xr, mp, jac2);
+                        for (int r = 0; r < ed; ++r) {
+                            const double f = mult ? scalar * mult[r] : scalar;
+                            for (int c = 0; c < ni; ++c) {
+                                const double t = f * (jac2[c * ed + r] - jac1[c * ed + r]);
+                                if (r == 0 && diag_lower) blk[cj * ni + c] = t;
+                                else blk[cj * ni + c] += t;
+                            }
+                        }
+                        xl[oj + j] += -hdelta;
+                        ++cj;
+                    }
+                }
+                if (diag_lower) {
+                    for (int i = 0; i < ni; ++i)
+                        for (int j = 0; j <= i; ++j) out[at++] = 0.0 + blk[j * ni + i];
+                }
+                else {
+                    for (int q = 0; q < ni * nj; ++q) out[at + q] = 0.0 + blk[q];
+                    at += ni * nj;
+                }
+            }
+        }
+        return at;
+    }
+    // the unweighted Jacobian blocks of a constraint edge in the order of computeSparseJacobianTwoSideBoundedLinearFormValues (:4904-4968)
+    __device__ static void linear_blocks(int kind, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double* out)
+    {
+        const int ed = edge_dim(kind), nv = n_verts(kind);
+        double blk[MAXD * MAXD];
+        int at = 0;
+        for (int vi = 0; vi < nv; ++vi) {
+            const int ni = unfixed(fm, vert_off(kind, vi), vert_dim(kind, vi));
+            if (ni == 0) continue;
+            jacobian(kind, vi, fm, xl, xr, mp, blk);
+            for (int q = 0; q < ni * ed; ++q) out[at + q] = blk[q];
+            at += ni * ed;
+        }
+    }
+};
+
+template <int DYN, int DEFECT>
+__global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const HessParams hp)
+{
+    using HE = HessEdge<DYN, DEFECT>;
+    constexpr int NX = HE::NX, NU = HE::NU, S = HE::S, W = HE::W;
+    const int k = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y, inst = b + p.inst0;
+    if (k >= p.N) return;
+    const bool final_stage = (k == p.N - 1);
+    const double* xg = p.x + (size_t)inst * p.nvs;
+    double xl[W], xr[NX];
+    unsigned fm = 0;
+    for (int i = 0; i < W - 1; ++i) {
+        const int v = k * S + i;
+        const bool in = final_stage ? (i < NX) : true;
+        xl[i] = in ? xg[v] : 0.0;
+        if (!in || p.comp[v].fixed) fm |= 1u << i;
+    }
+    xl[W - 1] = p.dt_free ? xg[p.off_dt] : p.dt_fixed;
+    if (!p.dt_free) fm |= 1u << (W - 1);
+    for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
+    const int32_t* so = hp.stage_off + (size_t)k * 6;
+    if (hp.mode == 0) {
+        double* vo = hp.vals[0] + (size_t)b * hp.nnz[0];
+        double* ve = hp.vals[1] + (size_t)b * hp.nnz[1];
+        double* vi = hp.vals[2] + (size_t)b * hp.nnz[2];
+        const double* me = (hp.mult_eq && so[4] >= 0) ? hp.mult_eq + (size_t)b * hp.eq_dim + so[4] : nullptr;
+        const double* mi = (hp.mult_ineq && so[5] >= 0) ? hp.mult_ineq + (size_t)b * hp.ineq_dim + so[5] : nullptr;
+        const bool lower = hp.lower != 0;
+        // the reference walks the three lists one after the other: objective edges first, ...
+        if (so[0] >= 0) {
+            if (final_stage) HE::hessian_blocks(EK_FINAL_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0]);
+            else if (hp.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ) {
+                const int n1 = HE::hessian_blocks(EK_DT_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0]);
+                HE::hessian_blocks(EK_DT_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0] + n1);
+            }
+            else HE::hessian_blocks(EK_STATE_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0]);
+        }
+        if (so[1] >= 0) HE::hessian_blocks(EK_CONTROL_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[1]);
+        // ... then the equality edges, then the inequality edges
+        if (so[2] >= 0) HE::hessian_blocks(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, lower, fm, xl, xr, p.mp, 1.0, me, ve + so[2]);
+        if (so[3] >= 0) HE::hessian_blocks(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, lower, fm, xl, xr, p.mp, 1.0, mi, vi + so[3]);
+    }
+    else {
+        const int32_t* lo = hp.lin_off + (size_t)k * 2;
+        const int rows = hp.eq_dim + hp.ineq_dim + hp.n_bounds;
+        double* lv = hp.lin_vals + (size_t)b * hp.lin_nnz;
+        double* lb = hp.lbA + (size_t)b * rows;
+        double* ub = hp.ubA + (size_t)b * rows;
+        double c[NX];
+        if (lo[0] >= 0) {   // computeBoundsForTwoSideBoundedLinearForm: lbA = ubA = -c_eq
+            const int kind = final_stage ? EK_FINAL_EQ : EK_DEFECT;
+            HE::values(kind, xl, xr, p.mp, c);
+            for (int r = 0; r < NX; ++r) { lb[so[4] + r] = c[r] * -1; ub[so[4] + r] = c[r] * -1; }
+            HE::linear_blocks(kind, fm, xl, xr, p.mp, lv + lo[0]);
+        }
+        if (lo[1] >= 0) {   // (-inf, -c_ineq]
+            const int kind = final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ;
+            HE::values(kind, xl, xr, p.mp, c);
+            lb[hp.eq_dim + so[5]] = -CORBO_HIP_INF;
+            ub[hp.eq_dim + so[5]] = c[0] * -1;
+            HE::linear_blocks(kind, fm, xl, xr, p.mp, lv + lo[1]);
+        }
+        // finite bounds of this stage's components (and of dt, with the final stage): identity rows; lbA = lb - x, ubA = x - ub (sic, :1177-1178)
+        const int ncomp = final_stage ? NX + 1 : S;
+        for (int i = 0; i < ncomp; ++i) {
+            const int v = (final_stage && i == NX) ? p.off_dt : k * S + i;
+            const int br = p.comp[v].bnd_row;
+            if (br < 0) continue;
+            const int idx = br - hp.bnd_row0;
+            const double xv = xg[v];
+            lv[hp.lin_bounds0 + idx] = 1.0;
+            lb[hp.eq_dim + hp.ineq_dim + idx] = p.lb[(size_t)inst * p.nvs + v] - xv;
+            ub[hp.eq_dim + hp.ineq_dim + idx] = xv - p.ub[(size_t)inst * p.nvs + v];
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
+template <int DYN, int DEFECT>
+void launch_hessian_t(const SweepParams& p, const HessParams& hp, hipStream_t stream)
+{
+    hipLaunchKernelGGL((hessian_kernel<DYN, DEFECT>), dim3((p.N + 63) / 64, p.batch), dim3(64), 0, stream, p, hp);
+}
+
+template <int DYN>
+bool launch_hessian_d(int defect, const SweepParams& p, const HessParams& hp, hipStream_t stream)
+{
+    if constexpr (Dynamics<DYN>::NX > 6) return false;   // the big-block family has no Hessian kernel yet
+    else {
+        switch (defect) {
+            case CORBO_HIP_DEFECT_FORWARD: launch_hessian_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, hp, stream); return true;
+            case CORBO_HIP_DEFECT_BACKWARD: launch_hessian_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(p, hp, stream); return true;
+            case CORBO_HIP_DEFECT_MIDPOINT: launch_hessian_t<DYN, CORBO_HIP_DEFECT_MIDPOINT>(p, hp, stream); return true;
+            case CORBO_HIP_DEFECT_CRANK_NICOLSON: launch_hessian_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(p, hp, stream); return true;
+            case CORBO_HIP_DEFECT_RK4_SHOOTING: launch_hessian_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, hp, stream); return true;
+            default: return false;
+        }
+    }
+}
+
 template <int NX, int NU>
 size_t factor_lds(int N, bool arrow)
 {
@@ -2947,7 +3192,8 @@ static void launch_plant_step_t(const PlantParams& p, hipStream_t stream)
 #define CORBO_HIP_DYN_ENTRIES(NAME)                                                                              \
     bool sweep_entry_##NAME(int defect, const SweepParams& p, hipStream_t stream);                               \
     bool pass_entry_##NAME(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);       \
-    void plant_entry_##NAME(const PlantParams& p, hipStream_t stream);
+    void plant_entry_##NAME(const PlantParams& p, hipStream_t stream);                                           \
+    bool hessian_entry_##NAME(int defect, const SweepParams& p, const HessParams& hp, hipStream_t stream);
 CORBO_HIP_DYN_ENTRIES(vdp)
 CORBO_HIP_DYN_ENTRIES(integ2)
 CORBO_HIP_DYN_ENTRIES(integ3)
@@ -2994,6 +3240,10 @@ bool CORBO_HIP_CAT(pass_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const FactorP
 #endif
 }
 void CORBO_HIP_CAT(plant_entry_, CORBO_HIP_DYN_TU_NAME)(const PlantParams& p, hipStream_t stream) { launch_plant_step_t<CORBO_HIP_DYN_TU>(p, stream); }
+bool CORBO_HIP_CAT(hessian_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const SweepParams& p, const HessParams& hp, hipStream_t stream)
+{
+    return launch_hessian_d<CORBO_HIP_DYN_TU>(defect, p, hp, stream);
+}
 #ifdef CORBO_HIP_DYN_TU_BIG
 bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, const SweepParams& sp, int diag_only, double* jac_dump, hipStream_t stream)
 {
@@ -3165,6 +3415,36 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
             if (d.nx == 3 && d.nu == 2) return sweep_entry_lin32(d.defect, p, stream);
             if (d.nx == 3 && d.nu == 3) return sweep_entry_lin33(d.defect, p, stream);
             if (d.nx == 4 && d.nu == 1) return sweep_entry_lin41(d.defect, p, stream);
+            return false;
+        default: return false;
+    }
+}
+
+bool launch_hessian(const corbo_hip_problem_desc& d, const SweepParams& p, const HessParams& hp, hipStream_t stream)
+{
+    switch (d.dynamics) {
+        case CORBO_HIP_DYN_VAN_DER_POL: return hessian_entry_vdp(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
+            if (d.nx == 3) return hessian_entry_integ3(d.defect, p, hp, stream);
+            if (d.nx != 2) return false;
+            return hessian_entry_integ2(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_UNICYCLE: return hessian_entry_unicycle(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_QUADROTOR: return hessian_entry_quadrotor(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_DUFFING: return hessian_entry_duffing(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_FREE_SPACE_ROCKET: return hessian_entry_rocket(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_SIMPLE_PENDULUM: return hessian_entry_pendulum(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_MASSLESS_PENDULUM: return hessian_entry_mpendulum(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_TOY_EXAMPLE: return hessian_entry_toy(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return hessian_entry_artstein(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_CART_POLE: return hessian_entry_cartpole(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: return d.nx == 2 ? hessian_entry_par2(d.defect, p, hp, stream) : hessian_entry_par3(d.defect, p, hp, stream);
+        case CORBO_HIP_DYN_LINEAR_STATE_SPACE:
+            if (d.nx == 2 && d.nu == 1) return hessian_entry_lin21(d.defect, p, hp, stream);
+            if (d.nx == 2 && d.nu == 2) return hessian_entry_lin22(d.defect, p, hp, stream);
+            if (d.nx == 3 && d.nu == 1) return hessian_entry_lin31(d.defect, p, hp, stream);
+            if (d.nx == 3 && d.nu == 2) return hessian_entry_lin32(d.defect, p, hp, stream);
+            if (d.nx == 3 && d.nu == 3) return hessian_entry_lin33(d.defect, p, hp, stream);
+            if (d.nx == 4 && d.nu == 1) return hessian_entry_lin41(d.defect, p, hp, stream);
             return false;
         default: return false;
     }

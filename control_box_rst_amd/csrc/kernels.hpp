@@ -105,6 +105,27 @@ struct FactorParams {
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 
+// Operators of the exact-Hessian path, evaluated at the accepted iterate of every instance (hessian_kernel):
+// mode 0: the value lists of computeSparseHessiansValues (objective / equalities / inequalities); mode 1: the two-side-bounded linear
+// form (values, lbA, ubA).  Structure: build_hessian_structure (structure.hpp).
+struct HessParams {
+    int32_t mode, lower;
+    double mult_obj;
+    const double* mult_eq;      // [batch][eq_dim] or null (= 1)
+    const double* mult_ineq;    // [batch][ineq_dim] or null
+    int32_t eq_dim, ineq_dim;
+    const int32_t* stage_off;   // [N][6] (HessianStructure::stage_off)
+    double* vals[3];            // [batch][nnz[c]]
+    int32_t nnz[3];
+    const int32_t* lin_off;     // [N][2]
+    double* lin_vals;           // [batch][lin_nnz]
+    double* lbA;                // [batch][eq_dim + ineq_dim + bounds]
+    double* ubA;
+    int32_t lin_nnz, lin_bounds0, bnd_row0, n_bounds;
+    int32_t stage_cost, stage_ineq;   // corbo_hip_cost / corbo_hip_ineq of the descriptor
+};
+bool launch_hessian(const corbo_hip_problem_desc& d, const SweepParams& sp, const HessParams& hp, hipStream_t stream);
+
 // returns false if the (dynamics, defect) pair has no device instantiation
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream);
 // sp: the sweep parameters of the same pass (big-block family: the stage kernel evaluates the edges itself); may be null for the

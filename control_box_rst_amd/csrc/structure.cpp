@@ -231,3 +231,118 @@ void init_trajectory(const corbo_hip_problem_desc& d, int batch, const double* x
 }
 
 }  // namespace corbo_hip
+
+namespace corbo_hip {
+
+// The walk of computeSparseHessians{NNZ,Structure} (hyper_graph_optimization_problem_edge_based.cpp:2087-2348, 2869-3050, 3172-3353):
+// per edge, vertex pairs (i, j) in attachment order, j <= i for the lower part; a diagonal pair of the lower part lists its lower
+// triangle row by row, every other pair its full block ROW-major (while the values are written column-major, :3550-3552 -- the
+// reference's own mismatch for rectangular off-diagonal pairs, reproduced so that the lists line up with the reference's entry by entry).
+void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H)
+{
+    H = HessianStructure();
+    const corbo_hip_problem_desc& d = S.desc;
+    const int nx = S.nx, nu = S.nu, N = S.N, s = S.s;
+    H.stage_off.assign((size_t)N * 6, -1);
+    H.lin_off.assign((size_t)N * 2, -1);
+    struct V { int voff, dim; };
+    auto unfixed = [&](const V& v) { int n = 0; for (int i = 0; i < v.dim; ++i) n += S.comp[v.voff + i].fixed ? 0 : 1; return n; };
+    auto col_of  = [&](const V& v) { for (int i = 0; i < v.dim; ++i) if (!S.comp[v.voff + i].fixed) return S.comp[v.voff + i].param; return -1; };
+    auto walk = [&](int cat, const V* verts, int nverts) {
+        for (int vi = 0; vi < nverts; ++vi) {
+            const int ni = unfixed(verts[vi]);
+            if (ni == 0) continue;
+            const int vend = lower ? vi + 1 : nverts;
+            for (int vj = 0; vj < vend; ++vj) {
+                const int nj = unfixed(verts[vj]);
+                if (nj == 0) continue;
+                const int ci = col_of(verts[vi]), cj = col_of(verts[vj]);
+                if (lower && vi == vj) {
+                    for (int i = 0; i < ni; ++i)
+                        for (int j = 0; j <= i; ++j) { H.rows[cat].push_back(ci + i); H.cols[cat].push_back(cj + j); }
+                }
+                else
+                    for (int i = 0; i < ni; ++i)
+                        for (int j = 0; j < nj; ++j) { H.rows[cat].push_back(ci + i); H.cols[cat].push_back(cj + j); }
+            }
+        }
+    };
+    auto lin_walk = [&](const V* verts, int nverts, int dim, int row0) {
+        for (int vi = 0; vi < nverts; ++vi) {
+            const V& v = verts[vi];
+            for (int i = 0; i < v.dim; ++i) {
+                if (S.comp[v.voff + i].fixed) continue;
+                for (int r = 0; r < dim; ++r) { H.lin_rows.push_back(row0 + r); H.lin_cols.push_back(S.comp[v.voff + i].param); }
+            }
+        }
+    };
+    int xf_unfixed = 0;
+    for (int i = 0; i < nx; ++i) xf_unfixed += S.comp[S.off_xf + i].fixed ? 0 : 1;
+    const V xf{S.off_xf, nx}, dtv{S.off_dt, 1};
+    // objective (least-squares edges) and the per-stage offsets
+    for (int k = 0; k < N - 1; ++k) {
+        const V xk{k * s, nx}, uk{k * s + nx, nu};
+        if (d.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) {
+            H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size();
+            walk(0, &xk, 1);
+            H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size();
+            walk(0, &uk, 1);
+        }
+        else if (d.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ && k == 0) {
+            H.stage_off[0] = (int32_t)H.rows[0].size();
+            walk(0, &dtv, 1);
+            walk(0, &dtv, 1);   // duplicated edge (nlp_functions.cpp:91-107)
+        }
+    }
+    if (xf_unfixed > 0 && d.final_cost) { H.stage_off[(size_t)(N - 1) * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xf, 1); }
+    // equalities
+    int eq_row = 0;
+    for (int k = 0; k < N - 1; ++k) {
+        const V verts[4] = {{k * s, nx}, {k * s + nx, nu}, {(k + 1) * s, nx}, dtv};
+        H.stage_off[(size_t)k * 6 + 2] = (int32_t)H.rows[1].size();
+        H.stage_off[(size_t)k * 6 + 4] = eq_row;
+        walk(1, verts, 4);
+        H.lin_off[(size_t)k * 2 + 0] = (int32_t)H.lin_rows.size();
+        lin_walk(verts, 4, nx, eq_row);
+        eq_row += nx;
+    }
+    if (xf_unfixed > 0 && d.final_eq) {
+        H.stage_off[(size_t)(N - 1) * 6 + 2] = (int32_t)H.rows[1].size();
+        H.stage_off[(size_t)(N - 1) * 6 + 4] = eq_row;
+        walk(1, &xf, 1);
+        H.lin_off[(size_t)(N - 1) * 2 + 0] = (int32_t)H.lin_rows.size();
+        lin_walk(&xf, 1, nx, eq_row);
+        eq_row += nx;
+    }
+    // inequalities
+    int ineq_row = 0;
+    for (int k = 0; k < N - 1; ++k) {
+        if (d.stage_ineq == CORBO_HIP_INEQ_NONE) break;
+        const V xk{k * s, nx};
+        H.stage_off[(size_t)k * 6 + 3] = (int32_t)H.rows[2].size();
+        H.stage_off[(size_t)k * 6 + 5] = ineq_row;
+        walk(2, &xk, 1);
+        H.lin_off[(size_t)k * 2 + 1] = (int32_t)H.lin_rows.size();
+        lin_walk(&xk, 1, 1, eq_row + ineq_row);
+        ineq_row += 1;
+    }
+    if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) {
+        H.stage_off[(size_t)(N - 1) * 6 + 3] = (int32_t)H.rows[2].size();
+        H.stage_off[(size_t)(N - 1) * 6 + 5] = ineq_row;
+        walk(2, &xf, 1);
+        H.lin_off[(size_t)(N - 1) * 2 + 1] = (int32_t)H.lin_rows.size();
+        lin_walk(&xf, 1, 1, eq_row + ineq_row);
+        ineq_row += 1;
+    }
+    for (int c = 0; c < 3; ++c) H.nnz[c] = (int32_t)H.rows[c].size();
+    // finite bounds: identity rows in parameter order
+    H.lin_bounds0 = (int32_t)H.lin_rows.size();
+    for (int v = 0; v <= S.off_dt; ++v) {
+        if (S.comp[v].bnd_row < 0) continue;
+        H.lin_rows.push_back(eq_row + ineq_row + (S.comp[v].bnd_row - S.bnd_row0));
+        H.lin_cols.push_back(S.comp[v].param);
+    }
+    H.lin_nnz = (int32_t)H.lin_rows.size();
+}
+
+}  // namespace corbo_hip

@@ -1,0 +1,108 @@
+"""Exact-Hessian path, -m gpu: corbo_hip_hessian_structure / corbo_hip_eval_hessians /
+corbo_hip_eval_linear_form through the C-ABI against the genuine reference's outputs (tests/golden/hess_*.json) and against the oracle.
+
+Structure: identical entry by entry.  Values: a lane reproduces the reference's finite-difference sequence on private copies of its
+stage's vertices, so it cannot see the few-ulp drift the reference's IN-PLACE perturbations leave in vertices shared with edges
+evaluated earlier.  A few ulps of the point are 1e-7 in a central-difference Jacobian entry (delta = 1e-9) and, through the forward
+step of 1e-2, 1e-5 in a Hessian entry.  The tolerance is therefore the reference's own reproducibility: the difference between two
+CONSECUTIVE evaluations of the same operator by the reference (second one from the drifted point), measured here with the
+bit-exact oracle and asserted to be of the same size as the device's deviation."""
+import numpy as np
+import pytest
+
+from conftest import desc_for, load_golden
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
+from control_box_rst_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+HESS = ["hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
+        "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole"]
+KEYS = ("hobj", "heq", "hineq")
+REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below
+
+
+def device_at_point(g, B=3):
+    d = desc_for(g)
+    s = BatchedLevenbergMarquardt(d, B)
+    nv = s.dims.nv
+    X = np.tile(np.array(g["vertex_point"])[:nv], (B, 1))
+    s.set_instance_data(X, xref=np.tile(np.array(g["xf"]), (B, 1)))
+    return d, s
+
+
+@pytest.mark.parametrize("name", HESS)
+def test_hessians_vs_reference(oracle_mod, name):
+    g = load_golden(name)
+    d, s = device_at_point(g)
+    B = s.batch
+    # the reference's own reproducibility: the oracle (bit-exact with the fixture) evaluated twice in a row
+    p = oracle_mod.OracleProblem(d)
+    p.set_data(np.array(g["vertex_point"])[:p.dims.nv], xref=np.array(g["xf"]))
+    first = p.hessians(1, g["mult_obj"], g["mult_eq"], g["mult_ineq"])
+    second = p.hessians(1, g["mult_obj"], g["mult_eq"], g["mult_ineq"])
+    own_spread = max([np.abs(a[2] - b[2]).max() / max(1.0, np.abs(a[2]).max()) for a, b in zip(first, second) if len(a[2])] + [0.0])
+    assert own_spread <= REL
+    for lower, tag in ((0, "full"), (1, "lower")):
+        st = s.hessian_structure(bool(lower))
+        vals = s.eval_hessians(bool(lower), g["mult_obj"], np.array(g["mult_eq"]), np.array(g["mult_ineq"]) if g["mult_ineq"] else None)
+        for c, key in enumerate(KEYS):
+            gr, gc, gv = np.array(g[f"{key}_rows_{tag}"], np.int32), np.array(g[f"{key}_cols_{tag}"], np.int32), np.array(g[f"{key}_vals_{tag}"])
+            assert np.array_equal(st[c][0], gr) and np.array_equal(st[c][1], gc), (name, tag, key)
+            assert vals[c].shape == (B, len(gv))
+            if len(gv) == 0:
+                continue
+            for b in range(B):
+                err = np.abs(vals[c][b] - gv).max() / max(1.0, np.abs(gv).max())
+                assert err <= REL, (name, tag, key, b, err, own_spread)
+            assert np.array_equal(vals[c][0], vals[c][1]) and np.array_equal(vals[c][0], vals[c][2])   # identical instances, identical bits
+    if name in ("hess_vdp", "hess_dint"):   # polynomial dynamics, objective list: the Gauss-Newton blocks do not feel the drift -- bit-exact
+        assert np.array_equal(s.eval_hessians(False, g["mult_obj"], np.array(g["mult_eq"]))[0][0], np.array(g["hobj_vals_full"]))
+
+
+@pytest.mark.parametrize("name", HESS)
+def test_linear_form_vs_reference(name):
+    g = load_golden(name)
+    d, s = device_at_point(g)
+    rows, cols, vals, lbA, ubA = s.linear_form()
+    assert np.array_equal(rows, np.array(g["lin_rows"], np.int32)) and np.array_equal(cols, np.array(g["lin_cols"], np.int32))
+    gv, gl, gu = np.array(g["lin_vals"]), np.array(g["lin_lbA"]), np.array(g["lin_ubA"])
+    for b in range(s.batch):
+        # Jacobian blocks: central differences at a point a few ulps away from the reference's drifted one
+        assert np.abs(vals[b] - gv).max() <= 2e-6 * max(1.0, np.abs(gv).max()), (name, b)
+        fin = np.isfinite(gl)
+        assert np.array_equal(np.isfinite(lbA[b]), fin) and np.all(lbA[b][~fin] < -1e29)
+        assert np.abs(lbA[b][fin] - gl[fin]).max() <= 1e-12 * max(1.0, np.abs(gl[fin]).max()), (name, b)
+        fu = np.abs(gu) < 1e29
+        assert np.abs(ubA[b][fu] - gu[fu]).max() <= 1e-12 * max(1.0, np.abs(gu[fu]).max()), (name, b)
+        assert np.all(np.abs(ubA[b][~fu]) > 1e29)
+
+
+def test_hessians_batch_vs_oracle(oracle_mod):
+    """Different instances, per-instance multipliers: every instance against the oracle at its own point."""
+    d = problems.unicycle_desc(N=20)
+    B = 8
+    rng = np.random.default_rng(5)
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    X = s.init_trajectory(x0, xf) + 0.05 * rng.normal(size=(B, s.dims.nv))
+    X[:, :d.nx] = x0
+    s.set_instance_data(X, xref=xf)
+    me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
+    vals = s.eval_hessians(True, 0.8, me, None)
+    p = oracle_mod.OracleProblem(d)
+    for b in range(B):
+        p.set_data(X[b], xref=xf[b])
+        ref = p.hessians(1, 0.8, me[b], None)
+        for c in range(3):
+            if len(ref[c][2]):
+                assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (b, c)
+
+
+def test_hessians_refused_for_the_big_block_family():
+    d = problems.quad_desc(N=6)
+    s = BatchedLevenbergMarquardt(d, 2)
+    x0, xf = problems.quad_instances(2)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    with pytest.raises(CorboHipError, match="small-block"):
+        s.eval_hessians()
