@@ -161,23 +161,14 @@ bool LevenbergMarquardtSparseHip::uploadVertices(const std::vector<VertexInterfa
     return true;
 }
 
-SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& problem, bool new_structure, bool new_run, double* obj_value)
+// Everything between "here is a hypergraph" and "its vertex values are on the device": recognise (new structure), describe, verify, upload.
+bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, bool new_structure)
 {
-    if (obj_value) *obj_value = -1;
     auto* hg = dynamic_cast<BaseHyperGraphOptimizationProblem*>(&problem);
     if (!hg || !hg->getGraph().hasVertexSet())
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): the problem is not a hypergraph optimization problem.");
-        return SolverStatus::Error;
-    }
-    // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287).  Kept here, not in the device
-    // handle: the reference's _weight_* survive a structure change, the handle does not.
-    if (new_run) { _w_eq = _opts.weight_eq; _w_ineq = _opts.weight_ineq; _w_b = _opts.weight_bounds; }
-    else
-    {
-        _w_eq *= _opts.adapt_factor_eq;       if (_w_eq > _opts.adapt_max_eq) _w_eq = _opts.adapt_max_eq;
-        _w_ineq *= _opts.adapt_factor_ineq;   if (_w_ineq > _opts.adapt_max_ineq) _w_ineq = _opts.adapt_max_ineq;
-        _w_b *= _opts.adapt_factor_bounds;    if (_w_b > _opts.adapt_max_bounds) _w_b = _opts.adapt_max_bounds;
+        return false;
     }
     // vertices in the grid's order: x_0..x_{N-2}, u_0..u_{N-2}, x_f, dt, (u_prev, u_ref, u_prev_dt)
     // (FullDiscretizationGridBase::getVertices, full_discretization_grid_base.cpp:499-512)
@@ -186,7 +177,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     if ((int)vtx.size() < 7 || ((int)vtx.size() - 5) % 2 != 0)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): unexpected vertex set (not a full-discretization / shooting grid with 1 control per interval).");
-        return SolverStatus::Error;
+        return false;
     }
     const int N = ((int)vtx.size() - 5) / 2 + 1;
     VertexInterface* xf_v = vtx[2 * (N - 1)];
@@ -205,7 +196,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
             if (!recogniseHyperGraphForHip(*hg, &m, &why))
             {
                 PRINT_ERROR("LevenbergMarquardtSparseHip(): this hypergraph has no device description: " << why << "; refusing to solve (no CPU fallback).");
-                return SolverStatus::Error;
+                return false;
             }
             _desc       = m.desc;
             _xref       = m.xref;
@@ -217,7 +208,8 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     // FullDiscretizationGridBase lists all states, then all controls; ShootingGridBase (shooting_grid_base.cpp:567-581) interleaves
     // them interval by interval: s_0, u_0, s_1, u_1, ...
     const bool interleaved = (_desc.grid == CORBO_HIP_GRID_MS);
-    std::vector<VertexInterface*> xs(N - 1), us(N - 1);
+    std::vector<VertexInterface*>& xs = _xs; std::vector<VertexInterface*>& us = _us;
+    xs.assign(N - 1, nullptr); us.assign(N - 1, nullptr);
     for (int k = 0; k < N - 1; ++k) { xs[k] = interleaved ? vtx[2 * k] : vtx[k]; us[k] = interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; }
 
     if (new_structure || !_handle || _desc.N != N || dt_changed)
@@ -227,7 +219,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
             if (xs[k]->getDimension() != nx || us[k]->getDimension() != nu)
             {
                 PRINT_ERROR("LevenbergMarquardtSparseHip(): vertex dimensions do not match the device model (nx, nu).");
-                return SolverStatus::Error;
+                return false;
             }
         _desc.N             = N;
         _desc.xf_fixed_mask = 0;
@@ -237,7 +229,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         if (dt_free != (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE))
         {
             PRINT_ERROR("LevenbergMarquardtSparseHip(): dt fixed/free does not match the device model's grid kind.");
-            return SolverStatus::Error;
+            return false;
         }
         if (dt_free) { _desc.dt_lb = dt_v->getLowerBounds()[0]; _desc.dt_ub = dt_v->getUpperBounds()[0]; }
         // bound pattern: shared along the horizon in the reference (NlpFunctions::x_lb ...), read from x_1 / u_0 / x_f
@@ -248,7 +240,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         if (corbo_hip_get_dims(&_desc, &_dims) != CORBO_HIP_OK)
         {
             PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
-            return SolverStatus::Error;
+            return false;
         }
         if (_dims.n != problem.getParameterDimension() || _dims.lsq != problem.getLsqObjectiveDimension() ||
             _dims.eq != problem.getEqualityDimension() || _dims.ineq != problem.getInequalityDimension() ||
@@ -257,14 +249,14 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
             PRINT_ERROR("LevenbergMarquardtSparseHip(): hypergraph dimensions (n=" << problem.getParameterDimension() << ", lsq="
                                                                                   << problem.getLsqObjectiveDimension() << ", eq=" << problem.getEqualityDimension()
                                                                                   << ") do not match the device model; refusing to solve (no CPU fallback).");
-            return SolverStatus::Error;
+            return false;
         }
         releaseHandle();
         if (corbo_hip_create(&_desc, 1, _device, &_handle) != CORBO_HIP_OK)
         {
             PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
             _handle = nullptr;
-            return SolverStatus::Error;
+            return false;
         }
         _x.assign(_dims.nv, 0.0);
         _lb.assign(_dims.nv, 0.0);
@@ -284,7 +276,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         if (!uploadVertices(xs, us, xf_v, dt_v) || !modelMatchesGraph(problem, false))
         {
             releaseHandle();   // the next call re-checks
-            return SolverStatus::Error;
+            return false;
         }
         Eigen::VectorXd inc(_dims.n);
         for (int i = 0; i < _dims.n; ++i) inc[i] = ((i & 1) ? -1.0 : 1.0) * 0.01 * (1.0 + (i % 7) / 7.0);
@@ -295,11 +287,29 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         if (!ok)
         {
             releaseHandle();
-            return SolverStatus::Error;
+            return false;
         }
     }
     // ---- gather vertex values and bounds into the C-ABI's vertex layout
-    if (!uploadVertices(xs, us, xf_v, dt_v)) return SolverStatus::Error;
+    if (!uploadVertices(xs, us, xf_v, dt_v)) return false;
+    _xf_v = xf_v; _dt_v = dt_v;
+    return true;
+
+}
+
+SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& problem, bool new_structure, bool new_run, double* obj_value)
+{
+    if (obj_value) *obj_value = -1;
+    // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287).  Kept here, not in the device
+    // handle: the reference's _weight_* survive a structure change, the handle does not.
+    if (new_run) { _w_eq = _opts.weight_eq; _w_ineq = _opts.weight_ineq; _w_b = _opts.weight_bounds; }
+    else
+    {
+        _w_eq *= _opts.adapt_factor_eq;       if (_w_eq > _opts.adapt_max_eq) _w_eq = _opts.adapt_max_eq;
+        _w_ineq *= _opts.adapt_factor_ineq;   if (_w_ineq > _opts.adapt_max_ineq) _w_ineq = _opts.adapt_max_ineq;
+        _w_b *= _opts.adapt_factor_bounds;    if (_w_b > _opts.adapt_max_bounds) _w_b = _opts.adapt_max_bounds;
+    }
+    if (!attach(problem, new_structure)) return SolverStatus::Error;
 
     corbo_hip_lm_opts o = _opts;   // the weights of THIS solve, stated explicitly (new_run = 1 makes the library take them as they are)
     o.weight_eq = _w_eq; o.weight_ineq = _w_ineq; o.weight_bounds = _w_b;
@@ -323,9 +333,10 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         for (int i = 0; i < dim; ++i)
             if (!v->isFixedComponent(i)) v->setData(i, _x[off + i]);
     };
-    for (int k = 0; k < N - 1; ++k) { unpack(xs[k], k * s, nx); unpack(us[k], k * s + nx, nu); }
-    unpack(xf_v, (N - 1) * s, nx);
-    if (dt_free) unpack(dt_v, (N - 1) * s + nx, 1);
+    const int nx = _desc.nx, nu = _desc.nu, s = nx + nu, N = _desc.N;
+    for (int k = 0; k < N - 1; ++k) { unpack(_xs[k], k * s, nx); unpack(_us[k], k * s + nx, nu); }
+    unpack(_xf_v, (N - 1) * s, nx);
+    if (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE) unpack(_dt_v, (N - 1) * s + nx, 1);
 
     if (obj_value) *obj_value = chi2;
     switch (status)
@@ -335,6 +346,49 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         case CORBO_HIP_SOLVER_INFEASIBLE: return SolverStatus::Infeasible;
         default: return SolverStatus::Error;
     }
+}
+
+
+// ---- operators of the exact-Hessian path (what an interior-point / SQP solver asks the problem for), evaluated on the device for the
+//      hypergraph's current vertex values; signatures of OptimizationProblemInterface::computeSparseHessians{NNZ,Structure,Values}
+//      (optimization_problem_interface.h) with the problem as the first argument
+bool LevenbergMarquardtSparseHip::computeSparseHessiansNNZ(OptimizationProblemInterface& problem, int& nnz_obj, int& nnz_eq, int& nnz_ineq, bool lower_part_only)
+{
+    if (!attach(problem, _handle == nullptr)) return false;
+    int32_t nnz[3];
+    if (corbo_hip_hessian_nnz(_handle, lower_part_only ? 1 : 0, nnz) != CORBO_HIP_OK) { PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error()); return false; }
+    nnz_obj = nnz[0]; nnz_eq = nnz[1]; nnz_ineq = nnz[2];
+    return true;
+}
+
+bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXi> i_row_obj,
+                                                                 Eigen::Ref<Eigen::VectorXi> j_col_obj, Eigen::Ref<Eigen::VectorXi> i_row_eq,
+                                                                 Eigen::Ref<Eigen::VectorXi> j_col_eq, Eigen::Ref<Eigen::VectorXi> i_row_ineq,
+                                                                 Eigen::Ref<Eigen::VectorXi> j_col_ineq, bool lower_part_only)
+{
+    if (!attach(problem, _handle == nullptr)) return false;
+    static_assert(sizeof(int) == sizeof(int32_t), "Eigen::VectorXi is handed to the C-ABI as int32_t");
+    if (corbo_hip_hessian_structure(_handle, lower_part_only ? 1 : 0, i_row_obj.data(), j_col_obj.data(), i_row_eq.data(), j_col_eq.data(), i_row_ineq.data(),
+                                    j_col_ineq.data()) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool LevenbergMarquardtSparseHip::computeSparseHessiansValues(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> values_obj,
+                                                              Eigen::Ref<Eigen::VectorXd> values_eq, Eigen::Ref<Eigen::VectorXd> values_ineq, double multiplier_obj,
+                                                              const double* multipliers_eq, const double* multipliers_ineq, bool lower_part_only)
+{
+    if (!attach(problem, _handle == nullptr)) return false;   // uploads the current vertex values
+    if (corbo_hip_eval_hessians(_handle, lower_part_only ? 1 : 0, multiplier_obj, multipliers_eq, multipliers_ineq, values_obj.data(), values_eq.data(),
+                                values_ineq.data()) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
+    }
+    return true;
 }
 
 }  // namespace corbo

@@ -63,8 +63,20 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
 
     const corbo_hip_stats& getStatistics() const { return _stats; }
 
+    // ---- Operators of the exact-Hessian path, on the device, for the same hypergraph (recognised / verified like in solve()):
+    //      OptimizationProblemInterface::computeSparseHessians{NNZ,Structure,Values} as IpoptWrapper::eval_h calls them
+    //      (nlp_solver_ipopt_wrapper.cpp:249-271), entry order of the reference's lists.  false = refused (reason on stderr).
+    bool computeSparseHessiansNNZ(OptimizationProblemInterface& problem, int& nnz_obj, int& nnz_eq, int& nnz_ineq, bool lower_part_only = false);
+    bool computeSparseHessiansStructure(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXi> i_row_obj, Eigen::Ref<Eigen::VectorXi> j_col_obj,
+                                        Eigen::Ref<Eigen::VectorXi> i_row_eq, Eigen::Ref<Eigen::VectorXi> j_col_eq, Eigen::Ref<Eigen::VectorXi> i_row_ineq,
+                                        Eigen::Ref<Eigen::VectorXi> j_col_ineq, bool lower_part_only = false);
+    bool computeSparseHessiansValues(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> values_obj, Eigen::Ref<Eigen::VectorXd> values_eq,
+                                     Eigen::Ref<Eigen::VectorXd> values_ineq, double multiplier_obj = 1.0, const double* multipliers_eq = nullptr,
+                                     const double* multipliers_ineq = nullptr, bool lower_part_only = false);
+
  private:
     void releaseHandle();
+    bool attach(OptimizationProblemInterface& problem, bool new_structure);
     bool modelMatchesGraph(OptimizationProblemInterface& problem, bool perturbed);
     bool uploadVertices(const std::vector<VertexInterface*>& xs, const std::vector<VertexInterface*>& us, VertexInterface* xf, VertexInterface* dt);
 
@@ -78,6 +90,9 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     corbo_hip_dims _dims;
     corbo_hip_stats _stats;
     std::vector<double> _x, _lb, _ub;
+    std::vector<VertexInterface*> _xs, _us;   // the grid's vertices of the attached structure (valid during a call)
+    VertexInterface* _xf_v = nullptr;
+    VertexInterface* _dt_v = nullptr;
     bool _recognised = false;               // _desc comes from the recogniser (not from setDeviceModel)
     double _w_eq = 2, _w_ineq = 2, _w_b = 2;  // current (adapted) penalty weights: survive a structure change like the reference's _weight_*
 };

@@ -100,6 +100,10 @@ struct Run
     Eigen::VectorXd traj;
     double chi2 = 0;
     bool ok     = false;
+    // Mode::Hessian: the exact-Hessian operators of the graph, device against the graph's own methods
+    bool hess_ok = false, hess_struct = false;
+    int hess_nnz[3] = {0, 0, 0};
+    double hess_rel = 1e300;
 };
 
 static Eigen::VectorXd trajectory(StructuredOptimalControlProblem& ocp, DiscretizationGridInterface& grid)
@@ -156,7 +160,7 @@ class RecogniseOnly : public NlpSolverInterface
     HipRecognisedModel model;
 };
 
-enum class Mode { Reference, HipAuto, HipStated, HipStatedWrong, Describe };
+enum class Mode { Reference, HipAuto, HipStated, HipStatedWrong, Describe, Hessian };
 
 // scenarios: "unicycle" cfg 3 single instance; "dint" cfg 2 (free dt, 5 consecutive solves, new_run only first); "quad" reduced cfg 5;
 // "vdp" cfg 1; "unicycle_tball" TerminalBall; "duffing" / "pendulum" / "lin32": reference benchmark classes with NON-default parameters
@@ -261,7 +265,8 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         auto s = std::make_shared<LevenbergMarquardtSparseHip>();
         s->setIterations(10);
         s->setPenaltyWeights(w, w, w);
-        if (mode != Mode::HipAuto)
+        if (mode == Mode::Hessian) s->setIterations(1);
+        if (mode != Mode::HipAuto && mode != Mode::Hessian)
         {
             s->setDeviceModel(d);
             s->setStateReference(xf);
@@ -334,6 +339,42 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     r.traj = trajectory(ocp, *any_grid);
     r.chi2 = ocp.getCurrentObjectiveValue();
     if (describe_out) *describe_out = *std::static_pointer_cast<RecogniseOnly>(solver);
+    if (mode == Mode::Hessian && r.ok)
+    {
+        // computeSparseHessians{NNZ,Structure,Values} as IpoptWrapper::eval_h calls them (lower part, per-row multipliers), at a generic
+        // point: the device first (it only reads the vertices), then the graph's own methods (their in-place finite differences leave
+        // the point a few ulps off)
+        auto hip = std::static_pointer_cast<LevenbergMarquardtSparseHip>(solver);
+        const int n = hg->getParameterDimension(), eq = hg->getEqualityDimension(), ineq = hg->getInequalityDimension();
+        Eigen::VectorXd inc(n), meq(eq), mineq(ineq);
+        for (int i = 0; i < n; ++i) inc[i] = 0.03 * std::sin(0.9 * i + 0.2);
+        for (int i = 0; i < eq; ++i) meq[i] = 0.4 + 0.3 * std::cos(0.5 * i);
+        for (int i = 0; i < ineq; ++i) mineq[i] = 0.2 + 0.1 * (i % 4);
+        hg->applyIncrement(inc);
+        const double mobj = 1.25;
+        int dn[3] = {0, 0, 0}, rn[3] = {0, 0, 0};
+        r.hess_ok = hip->computeSparseHessiansNNZ(*hg, dn[0], dn[1], dn[2], true);
+        hg->computeSparseHessiansNNZ(rn[0], rn[1], rn[2], true);
+        r.hess_struct = r.hess_ok && dn[0] == rn[0] && dn[1] == rn[1] && dn[2] == rn[2];
+        for (int c = 0; c < 3; ++c) r.hess_nnz[c] = rn[c];
+        if (r.hess_struct)
+        {
+            Eigen::VectorXi di[3], dj[3], ri[3], rj[3];
+            Eigen::VectorXd dv[3], rv[3];
+            for (int c = 0; c < 3; ++c) { di[c].resize(rn[c]); dj[c].resize(rn[c]); ri[c].resize(rn[c]); rj[c].resize(rn[c]); dv[c].resize(rn[c]); rv[c].resize(rn[c]); }
+            r.hess_ok = hip->computeSparseHessiansStructure(*hg, di[0], dj[0], di[1], dj[1], di[2], dj[2], true) &&
+                        hip->computeSparseHessiansValues(*hg, dv[0], dv[1], dv[2], mobj, meq.data(), ineq ? mineq.data() : nullptr, true);
+            hg->computeSparseHessiansStructure(ri[0], rj[0], ri[1], rj[1], ri[2], rj[2], true);
+            hg->computeSparseHessiansValues(rv[0], rv[1], rv[2], mobj, meq.data(), ineq ? mineq.data() : nullptr, true);
+            r.hess_rel = 0;
+            for (int c = 0; c < 3; ++c)
+            {
+                if (rn[c] == 0) continue;
+                if (di[c] != ri[c] || dj[c] != rj[c]) r.hess_struct = false;
+                r.hess_rel = std::max(r.hess_rel, (dv[c] - rv[c]).cwiseAbs().maxCoeff() / std::max(1.0, rv[c].cwiseAbs().maxCoeff()));
+            }
+        }
+    }
     return r;
 }
 
@@ -365,6 +406,14 @@ int main(int argc, char** argv)
         printf("{\"scenario\": \"%s\", \"mode\": \"recognised\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
                sc, a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : 1e-5))) rc = 1;
+    }
+    // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32"})
+    {
+        Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
+        printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,
+               (h.ok && h.hess_ok) ? 1 : 0, h.hess_struct ? 1 : 0, h.hess_nnz[0], h.hess_nnz[1], h.hess_nnz[2], h.hess_rel);
+        if (!(h.ok && h.hess_ok && h.hess_struct && h.hess_rel <= 2e-4)) rc = 1;
     }
     {   // the override: a stated device model
         Run a = run("unicycle", Mode::Reference, 30);
