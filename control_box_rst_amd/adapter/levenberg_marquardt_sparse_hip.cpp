@@ -356,7 +356,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansNNZ(OptimizationProblemIn
 {
     if (!attach(problem, _handle == nullptr)) return false;
     int32_t nnz[3];
-    if (corbo_hip_hessian_nnz(_handle, lower_part_only ? 1 : 0, nnz) != CORBO_HIP_OK) { PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error()); return false; }
+    if (corbo_hip_hessian_nnz(&_desc, lower_part_only ? 1 : 0, nnz) != CORBO_HIP_OK) { PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error()); return false; }
     nnz_obj = nnz[0]; nnz_eq = nnz[1]; nnz_ineq = nnz[2];
     return true;
 }
@@ -368,7 +368,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationPro
 {
     if (!attach(problem, _handle == nullptr)) return false;
     static_assert(sizeof(int) == sizeof(int32_t), "Eigen::VectorXi is handed to the C-ABI as int32_t");
-    if (corbo_hip_hessian_structure(_handle, lower_part_only ? 1 : 0, i_row_obj.data(), j_col_obj.data(), i_row_eq.data(), j_col_eq.data(), i_row_ineq.data(),
+    if (corbo_hip_hessian_structure(&_desc, lower_part_only ? 1 : 0, i_row_obj.data(), j_col_obj.data(), i_row_eq.data(), j_col_eq.data(), i_row_ineq.data(),
                                     j_col_ineq.data()) != CORBO_HIP_OK)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());

@@ -156,10 +156,10 @@ def load() -> C.CDLL:
     lib.corbo_hip_eval_dynamics.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, dp]
     lib.corbo_hip_get_timing.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     lib.corbo_hip_time_factor.argtypes = [H, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]
-    lib.corbo_hip_hessian_nnz.argtypes = [H, C.c_int, ip]
-    lib.corbo_hip_hessian_structure.argtypes = [H, C.c_int, ip, ip, ip, ip, ip, ip]
+    lib.corbo_hip_hessian_nnz.argtypes = [C.POINTER(ProblemDesc), C.c_int, ip]
+    lib.corbo_hip_hessian_structure.argtypes = [C.POINTER(ProblemDesc), C.c_int, ip, ip, ip, ip, ip, ip]
     lib.corbo_hip_eval_hessians.argtypes = [H, C.c_int, C.c_double, dp, dp, dp, dp, dp]
-    lib.corbo_hip_linear_form_structure.argtypes = [H, ip, ip, ip, ip]
+    lib.corbo_hip_linear_form_structure.argtypes = [C.POINTER(ProblemDesc), ip, ip, ip, ip]
     lib.corbo_hip_eval_linear_form.argtypes = [H, dp, dp, dp]
     lib.corbo_hip_last_error.argtypes = []
     lib.corbo_hip_last_error.restype = C.c_char_p

@@ -1131,22 +1131,28 @@ struct DevBuf {   // scratch device buffer of one call
 };
 }  // namespace
 
-int corbo_hip_hessian_nnz(corbo_hip_handle h, int lower_part_only, int32_t* nnz_out)
+int corbo_hip_hessian_nnz(const corbo_hip_problem_desc* desc, int lower_part_only, int32_t* nnz_out)
 try {
-    if (!h || !nnz_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (!desc || !nnz_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    Structure S;
+    std::string err = build_structure(*desc, S);
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
     HessianStructure H;
-    build_hessian_structure(h->S, lower_part_only != 0, H);
+    build_hessian_structure(S, lower_part_only != 0, H);
     for (int c = 0; c < 3; ++c) nnz_out[c] = H.nnz[c];
     return CORBO_HIP_OK;
 }
 ABI_CATCH
 
-int corbo_hip_hessian_structure(corbo_hip_handle h, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq, int32_t* cols_eq,
-                                int32_t* rows_ineq, int32_t* cols_ineq)
+int corbo_hip_hessian_structure(const corbo_hip_problem_desc* desc, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq,
+                                int32_t* cols_eq, int32_t* rows_ineq, int32_t* cols_ineq)
 try {
-    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (!desc) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    Structure S;
+    std::string err = build_structure(*desc, S);
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
     HessianStructure H;
-    build_hessian_structure(h->S, lower_part_only != 0, H);
+    build_hessian_structure(S, lower_part_only != 0, H);
     int32_t* rows[3] = {rows_obj, rows_eq, rows_ineq};
     int32_t* cols[3] = {cols_obj, cols_eq, cols_ineq};
     for (int c = 0; c < 3; ++c) {
@@ -1160,7 +1166,6 @@ ABI_CATCH
 static int hessian_common(corbo_hip_handle h, HessianStructure& H, bool lower, HessParams& hp, DevBuf& d_so, DevBuf& d_lo)
 {
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    if (h->S.nx > 6) return fail(CORBO_HIP_ERR_UNSUPPORTED, "the Hessian / linear-form operators exist for the small-block families (nx <= 6) only");
     build_hessian_structure(h->S, lower, H);
     HIP_TRY(d_so.alloc(H.stage_off.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(d_so.p, H.stage_off.data(), H.stage_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1216,13 +1221,16 @@ try {
 }
 ABI_CATCH
 
-int corbo_hip_linear_form_structure(corbo_hip_handle h, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols)
+int corbo_hip_linear_form_structure(const corbo_hip_problem_desc* desc, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols)
 try {
-    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (!desc) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    Structure S;
+    std::string err = build_structure(*desc, S);
+    if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
     HessianStructure H;
-    build_hessian_structure(h->S, false, H);
+    build_hessian_structure(S, false, H);
     if (nnz_out) *nnz_out = H.lin_nnz;
-    if (n_rows_out) *n_rows_out = h->S.dims.eq + h->S.dims.ineq + h->S.dims.bounds;
+    if (n_rows_out) *n_rows_out = S.dims.eq + S.dims.ineq + S.dims.bounds;
     if (rows && cols && H.lin_nnz > 0) {
         std::memcpy(rows, H.lin_rows.data(), H.lin_nnz * sizeof(int32_t));
         std::memcpy(cols, H.lin_cols.data(), H.lin_nnz * sizeof(int32_t));

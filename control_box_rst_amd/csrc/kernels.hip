@@ -2897,12 +2897,16 @@ struct HessEdge {
                 const int oj = vert_off(kind, vj), dj = vert_dim(kind, vj), nj = unfixed(fm, oj, dj);
                 if (nj == 0) continue;
                 const bool diag_lower = lower && vi == vj;
-                if (cat == 0) {   // least-squares objective edge: (2 m J_i)^T J_j, coefficient-based product (every term scaled first)
+                if (cat == 0) {   // least-squares objective edge: 2 m J_i^T J_j.  Eigen evaluates small products (rows + cols + depth < 20)
+                    // coefficient-based with (2 m J_i^T) as the left factor -- every term scaled first -- and larger ones through its GEMM
+                    // kernel, which scales the finished sum (the 12 x 12 state-cost block of the quadrotor)
                     jacobian(kind, vj, fm, xl, xr, mp, jac2);
+                    const bool small = ni + nj + ed < 20;
                     for (int c = 0; c < nj; ++c)
                         for (int r = 0; r < ni; ++r) {
                             double acc = 0.0;
-                            for (int q = 0; q < ed; ++q) acc += ((2.0 * mult_obj) * jac1[r * ed + q]) * jac2[c * ed + q];
+                            if (small) for (int q = 0; q < ed; ++q) acc += ((2.0 * mult_obj) * jac1[r * ed + q]) * jac2[c * ed + q];
+                            else { for (int q = 0; q < ed; ++q) acc += jac1[r * ed + q] * jac2[c * ed + q]; acc = (2.0 * mult_obj) * acc; }
                             blk[c * ni + r] = acc;
                         }
                 }
@@ -2982,19 +2986,27 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         const double* me = (hp.mult_eq && so[4] >= 0) ? hp.mult_eq + (size_t)b * hp.eq_dim + so[4] : nullptr;
         const double* mi = (hp.mult_ineq && so[5] >= 0) ? hp.mult_ineq + (size_t)b * hp.ineq_dim + so[5] : nullptr;
         const bool lower = hp.lower != 0;
-        // the reference walks the three lists one after the other: objective edges first, ...
+        // The stage's edges in the order of the reference's walk (the three lists one after the other: objective edges first, then the
+        // equality edges, then the inequality edges) -- ONE call site in a loop.  (With four inlined call sites the 12-state instantiation
+        // never finished on the hardware -- > 120 s for one interval; the compiler had merged the copies into an exec-mask dispatch loop.)
+        int kinds[5], cats[5], n_edges = 0;
+        double* outs[5];
+        const double* mults[5];
+        auto add = [&](int kind, int cat, double* out, const double* mult) { kinds[n_edges] = kind; cats[n_edges] = cat; outs[n_edges] = out; mults[n_edges] = mult; ++n_edges; };
         if (so[0] >= 0) {
-            if (final_stage) HE::hessian_blocks(EK_FINAL_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0]);
-            else if (hp.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ) {
-                const int n1 = HE::hessian_blocks(EK_DT_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0]);
-                HE::hessian_blocks(EK_DT_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0] + n1);
-            }
-            else HE::hessian_blocks(EK_STATE_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[0]);
+            if (final_stage) add(EK_FINAL_COST, 0, vo + so[0], nullptr);
+            else if (hp.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ) { add(EK_DT_COST, 0, vo + so[0], nullptr); add(EK_DT_COST, 0, nullptr, nullptr); }
+            else add(EK_STATE_COST, 0, vo + so[0], nullptr);
         }
-        if (so[1] >= 0) HE::hessian_blocks(EK_CONTROL_COST, 0, lower, fm, xl, xr, p.mp, hp.mult_obj, nullptr, vo + so[1]);
-        // ... then the equality edges, then the inequality edges
-        if (so[2] >= 0) HE::hessian_blocks(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, lower, fm, xl, xr, p.mp, 1.0, me, ve + so[2]);
-        if (so[3] >= 0) HE::hessian_blocks(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, lower, fm, xl, xr, p.mp, 1.0, mi, vi + so[3]);
+        if (so[1] >= 0) add(EK_CONTROL_COST, 0, vo + so[1], nullptr);
+        if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
+        if (so[3] >= 0) add(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, vi + so[3], mi);
+        double* next = nullptr;
+        for (int e = 0; e < n_edges; ++e) {
+            double* out = outs[e] ? outs[e] : next;   // (the duplicated dt edge follows the first one)
+            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, p.mp, hp.mult_obj, mults[e], out);
+            next = out + n;
+        }
     }
     else {
         const int32_t* lo = hp.lin_off + (size_t)k * 2;
@@ -3041,7 +3053,11 @@ void launch_hessian_t(const SweepParams& p, const HessParams& hp, hipStream_t st
 template <int DYN>
 bool launch_hessian_d(int defect, const SweepParams& p, const HessParams& hp, hipStream_t stream)
 {
-    if constexpr (Dynamics<DYN>::NX > 6) return false;   // the big-block family has no Hessian kernel yet
+    if constexpr (Dynamics<DYN>::NX > 6) {   // big-block family: multiple shooting with RK4 only
+        if (defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return false;
+        launch_hessian_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, hp, stream);
+        return true;
+    }
     else {
         switch (defect) {
             case CORBO_HIP_DEFECT_FORWARD: launch_hessian_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, hp, stream); return true;

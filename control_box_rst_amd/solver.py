@@ -240,10 +240,10 @@ class BatchedLevenbergMarquardt:
     def hessian_structure(self, lower_part_only=True):
         """Three (rows, cols) pairs -- objective, equalities, inequalities -- of computeSparseHessiansStructure, in the reference's order."""
         nnz = np.zeros(3, np.int32)
-        self._check(self.lib.corbo_hip_hessian_nnz(self._h, int(lower_part_only), _ip(nnz)), "corbo_hip_hessian_nnz")
+        self._check(self.lib.corbo_hip_hessian_nnz(C.byref(self.desc), int(lower_part_only), _ip(nnz)), "corbo_hip_hessian_nnz")
         rows = [np.zeros(max(1, n), np.int32) for n in nnz]
         cols = [np.zeros(max(1, n), np.int32) for n in nnz]
-        rc = self.lib.corbo_hip_hessian_structure(self._h, int(lower_part_only), _ip(rows[0]), _ip(cols[0]), _ip(rows[1]), _ip(cols[1]), _ip(rows[2]), _ip(cols[2]))
+        rc = self.lib.corbo_hip_hessian_structure(C.byref(self.desc), int(lower_part_only), _ip(rows[0]), _ip(cols[0]), _ip(rows[1]), _ip(cols[1]), _ip(rows[2]), _ip(cols[2]))
         self._check(rc, "corbo_hip_hessian_structure")
         return [(rows[c][:nnz[c]], cols[c][:nnz[c]]) for c in range(3)]
 
@@ -251,7 +251,7 @@ class BatchedLevenbergMarquardt:
         """computeSparseHessiansValues at the resident iterates: value arrays [B][nnz] of the objective / equality / inequality lists.
         mult_eq [B][eq], mult_ineq [B][ineq] (None = ones)."""
         nnz = np.zeros(3, np.int32)
-        self._check(self.lib.corbo_hip_hessian_nnz(self._h, int(lower_part_only), _ip(nnz)), "corbo_hip_hessian_nnz")
+        self._check(self.lib.corbo_hip_hessian_nnz(C.byref(self.desc), int(lower_part_only), _ip(nnz)), "corbo_hip_hessian_nnz")
         vals = [np.zeros((self.batch, max(1, int(n)))) for n in nnz]
         me = None if mult_eq is None else np.ascontiguousarray(np.broadcast_to(mult_eq, (self.batch, self.dims.eq)), np.float64)
         mi = None if mult_ineq is None or self.dims.ineq == 0 else np.ascontiguousarray(np.broadcast_to(mult_ineq, (self.batch, self.dims.ineq)), np.float64)
@@ -265,9 +265,9 @@ class BatchedLevenbergMarquardt:
     def linear_form(self):
         """lbA <= A dx <= ubA of the QP interface at the resident iterates: rows, cols (structure), vals [B][nnz], lbA, ubA [B][rows]."""
         nnz, nrows = C.c_int32(0), C.c_int32(0)
-        self._check(self.lib.corbo_hip_linear_form_structure(self._h, C.byref(nnz), C.byref(nrows), None, None), "corbo_hip_linear_form_structure")
+        self._check(self.lib.corbo_hip_linear_form_structure(C.byref(self.desc), C.byref(nnz), C.byref(nrows), None, None), "corbo_hip_linear_form_structure")
         rows, cols = np.zeros(nnz.value, np.int32), np.zeros(nnz.value, np.int32)
-        self._check(self.lib.corbo_hip_linear_form_structure(self._h, C.byref(nnz), C.byref(nrows), _ip(rows), _ip(cols)), "corbo_hip_linear_form_structure")
+        self._check(self.lib.corbo_hip_linear_form_structure(C.byref(self.desc), C.byref(nnz), C.byref(nrows), _ip(rows), _ip(cols)), "corbo_hip_linear_form_structure")
         vals = np.zeros((self.batch, nnz.value))
         lbA, ubA = np.zeros((self.batch, nrows.value)), np.zeros((self.batch, nrows.value))
         self._check(self.lib.corbo_hip_eval_linear_form(self._h, _dp(vals), _dp(lbA), _dp(ubA)), "corbo_hip_eval_linear_form")

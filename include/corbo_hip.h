@@ -342,17 +342,18 @@ int corbo_hip_shard_bounds(int global_batch, int world, int rank, int* first, in
  * Three triplet lists -- objective (least-squares edges: 2 m J^T J blocks), equalities, inequalities (forward differences,
  * HESSIAN_DELTA = 1e-2, of the central-difference edge Jacobians, weighted by the multipliers) -- in the reference's entry order.
  * Entry order quirk kept from the reference: a rectangular off-diagonal vertex pair is LISTED row-major but FILLED column-major
- * (:2993-3003 against :3550-3552).  Small-block families (nx <= 6); CORBO_HIP_ERR_UNSUPPORTED otherwise.  Host arrays in and out. */
-int corbo_hip_hessian_nnz(corbo_hip_handle h, int lower_part_only, int32_t* nnz_out /* [3]: objective, equalities, inequalities */);
-int corbo_hip_hessian_structure(corbo_hip_handle h, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq, int32_t* cols_eq,
-                                int32_t* rows_ineq, int32_t* cols_ineq);
+ * (:2993-3003 against :3550-3552).  The structure entries are host-only functions of the descriptor (like corbo_hip_get_structure); the
+ * eval entries take and return host arrays. */
+int corbo_hip_hessian_nnz(const corbo_hip_problem_desc* desc, int lower_part_only, int32_t* nnz_out /* [3]: objective, equalities, inequalities */);
+int corbo_hip_hessian_structure(const corbo_hip_problem_desc* desc, int lower_part_only, int32_t* rows_obj, int32_t* cols_obj, int32_t* rows_eq,
+                                int32_t* cols_eq, int32_t* rows_ineq, int32_t* cols_ineq);
 /* mult_eq [batch][dims.eq], mult_ineq [batch][dims.ineq] (NULL = all ones, as the reference treats a null pointer);
  * vals_* [batch][nnz of the list] */
 int corbo_hip_eval_hessians(corbo_hip_handle h, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq, double* vals_obj,
                             double* vals_eq, double* vals_ineq);
 /* lbA <= A dx <= ubA with the finite bounds as identity rows: structure (rows / cols may be NULL for the size query), then
  * vals [batch][nnz], lbA / ubA [batch][n_rows].  (ubA of a bound row is x - ub, as the reference computes it.) */
-int corbo_hip_linear_form_structure(corbo_hip_handle h, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols);
+int corbo_hip_linear_form_structure(const corbo_hip_problem_desc* desc, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols);
 int corbo_hip_eval_linear_form(corbo_hip_handle h, double* vals, double* lbA, double* ubA);
 
 /* Device-resident views for callers that already live on the GPU (torch tensors, RCCL gathers): pointers into

@@ -110,3 +110,33 @@ def test_create_refuses_descriptors_without_device_kernels_before_touching_the_d
     q = problems.quad_desc(N=10)
     q.grid, q.defect = capi.GRID_FD, capi.DEFECT_CRANK_NICOLSON
     assert lib.corbo_hip_create(C.byref(q), 1, 0, C.byref(h)) == -3 and not h.value
+
+
+@pytest.mark.parametrize("name", ["hess_vdp", "hess_vdp_forward", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal", "hess_unicycle_n16",
+                                  "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4"])
+def test_hessian_and_linear_form_structure_vs_reference(name):
+    """corbo_hip_hessian_{nnz,structure} / corbo_hip_linear_form_structure are host-only functions of the descriptor: the three triplet
+    lists of computeSparseHessiansStructure (full and lower part) and the linear form's, entry by entry as the genuine reference
+    lists them (tests/golden/hess_*.json)."""
+    import ctypes as C
+    from conftest import desc_for, load_golden
+    g = load_golden(name)
+    d = desc_for(g)
+    lib = capi.load()
+    ipp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    for lower, tag in ((0, "full"), (1, "lower")):
+        nnz = np.zeros(3, np.int32)
+        assert lib.corbo_hip_hessian_nnz(C.byref(d), lower, ipp(nnz)) == 0
+        rows = [np.zeros(max(1, n), np.int32) for n in nnz]
+        cols = [np.zeros(max(1, n), np.int32) for n in nnz]
+        assert lib.corbo_hip_hessian_structure(C.byref(d), lower, ipp(rows[0]), ipp(cols[0]), ipp(rows[1]), ipp(cols[1]), ipp(rows[2]), ipp(cols[2])) == 0
+        for c, key in enumerate(("hobj", "heq", "hineq")):
+            assert nnz[c] == len(g[f"{key}_rows_{tag}"]), (name, tag, key)
+            assert np.array_equal(rows[c][:nnz[c]], np.array(g[f"{key}_rows_{tag}"], np.int32)), (name, tag, key)
+            assert np.array_equal(cols[c][:nnz[c]], np.array(g[f"{key}_cols_{tag}"], np.int32)), (name, tag, key)
+    n, m = C.c_int32(0), C.c_int32(0)
+    assert lib.corbo_hip_linear_form_structure(C.byref(d), C.byref(n), C.byref(m), None, None) == 0
+    assert n.value == len(g["lin_rows"]) and m.value == len(g["lin_lbA"])
+    r, c = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+    assert lib.corbo_hip_linear_form_structure(C.byref(d), C.byref(n), C.byref(m), ipp(r), ipp(c)) == 0
+    assert np.array_equal(r, np.array(g["lin_rows"], np.int32)) and np.array_equal(c, np.array(g["lin_cols"], np.int32))

@@ -11,13 +11,13 @@ import numpy as np
 import pytest
 
 from conftest import desc_for, load_golden
-from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt
 from control_box_rst_amd import problems
 
 pytestmark = pytest.mark.gpu
 
 HESS = ["hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
-        "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole"]
+        "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4"]
 KEYS = ("hobj", "heq", "hineq")
 REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below
 
@@ -99,10 +99,32 @@ def test_hessians_batch_vs_oracle(oracle_mod):
                 assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (b, c)
 
 
-def test_hessians_refused_for_the_big_block_family():
-    d = problems.quad_desc(N=6)
-    s = BatchedLevenbergMarquardt(d, 2)
-    x0, xf = problems.quad_instances(2)
-    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
-    with pytest.raises(CorboHipError, match="small-block"):
-        s.eval_hessians()
+def test_hessians_big_block_family_vs_oracle(oracle_mod):
+    """Quadrotor (nx = 12, multiple shooting + RK4, control bounds, keep-out ball): the same kernel, 12 x 12 blocks."""
+    d = problems.quad_desc(N=8)
+    B = 3
+    rng = np.random.default_rng(9)
+    x0, xf = problems.quad_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    X = s.init_trajectory(x0, xf) + 0.02 * rng.normal(size=(B, s.dims.nv))
+    X[:, :d.nx] = x0
+    s.set_instance_data(X, xref=xf)
+    me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
+    mi = rng.uniform(0.1, 0.5, (B, s.dims.ineq))
+    vals = s.eval_hessians(True, 1.3, me, mi)
+    st = s.hessian_structure(True)
+    rows, cols, lv, lbA, ubA = s.linear_form()
+    p = oracle_mod.OracleProblem(d)
+    for b in range(B):
+        p.set_data(X[b], xref=xf[b])
+        ref = p.hessians(1, 1.3, me[b], mi[b])
+        for c in range(3):
+            assert np.array_equal(st[c][0], ref[c][0]) and np.array_equal(st[c][1], ref[c][1])
+            if len(ref[c][2]):
+                assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (b, c)
+        p.set_data(X[b], xref=xf[b])
+        r2, c2, v2, l2, u2 = p.linear_form()
+        assert np.array_equal(rows, r2) and np.array_equal(cols, c2)
+        assert np.abs(lv[b] - v2).max() <= 2e-6 * max(1.0, np.abs(v2).max())
+        fin = np.isfinite(l2) & (np.abs(l2) < 1e29)
+        assert np.abs(lbA[b][fin] - l2[fin]).max() <= 1e-12 * max(1.0, np.abs(l2[fin]).max())
