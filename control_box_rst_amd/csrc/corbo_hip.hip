@@ -123,6 +123,8 @@ struct corbo_hip_solver {
     double solve_ms_sum = 0.0;       // HIP-event time of every corbo_hip_solve since the last reset (corbo_hip_get_timing)
     int64_t solve_count = 0;
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
+    double* d_refvec = nullptr;   // per-component references [batch][nvs] (corbo_hip_set_references), allocated on first use
+    bool refvec_on   = false;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
     double* d_chi2        = nullptr;  // [batch]
@@ -177,6 +179,7 @@ struct corbo_hip_solver {
         p.dt_fixed = S.desc.dt_ref;
         p.mode = mode; p.iterations = iterations; p.w_eq = weq; p.w_ineq = wineq; p.w_b = wb;
         p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
+        p.refvec = refvec_on ? d_refvec : nullptr;
         p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
         p.st = d_state; p.active_count = counter; p.chi2 = d_chi2;
         return p;
@@ -388,7 +391,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_refvec};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -690,6 +693,30 @@ int corbo_hip_set_result_sink(corbo_hip_handle h, int enable)
     h->sink_valid  = false;
     return CORBO_HIP_OK;
 }
+
+int corbo_hip_set_references(corbo_hip_handle h, const double* ref)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    h->sink_valid = false;
+    if (!ref) { h->refvec_on = false; return CORBO_HIP_OK; }   // back to the static state reference of corbo_hip_set_instance_data
+    const Structure& S = h->S;
+    const size_t B = (size_t)h->active, nv = (size_t)S.dims.nv, nvs = (size_t)S.nvs;
+    if (!h->d_refvec) HIP_TRY(hipMalloc((void**)&h->d_refvec, (size_t)h->batch * nvs * sizeof(double)));
+    std::vector<double> st(B * nvs, 0.0);
+    for (size_t b = 0; b < B; ++b) {
+        std::memcpy(&st[b * nvs], ref + b * nv, nv * sizeof(double));
+        for (int k = 0; k < S.N - 1; ++k)
+            for (int i = 0; i < S.nu; ++i)
+                if (ref[b * nv + (size_t)k * S.s + S.nx + i] != 0.0)
+                    return fail(CORBO_HIP_ERR_INVALID, "corbo_hip_set_references: non-zero control reference (the reference's least-squares control term is not defined for one, quadratic_cost.cpp:160-163)");
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_refvec, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->refvec_on = true;
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
 
 int corbo_hip_restore_instance_data(corbo_hip_handle h)
 {

@@ -135,7 +135,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
     double xr[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
+    for (int i = 0; i < NX; ++i) xr[i] = p.refvec ? p.refvec[xo + (size_t)(p.N - 1) * S + i] : p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
     lds_barrier();
     SWEEP_STAMP(1);
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
@@ -174,6 +174,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         for (int i = 0; i < NU; ++i) wr = (cu == i) ? p.mp.sr[i] : wr;
         w   = is_dt ? p.mp.dt_weight : (is_fin ? wf : (is_u ? wr : wq));
         ref = (is_dt || is_u) ? 0.0 : rf;
+        // time-varying state references (ReferenceTrajectoryInterface::getReferenceCached(k), quadratic_cost.cpp:100-119): one per component.
+        // (Controls keep the zero reference: the reference's least-squares control term with a non-zero uref is not a function of the
+        // control vector -- quadratic_cost.cpp:160-163 assigns the scalar ud^T R^(1/2) ud to the nu-vector.)
+        if (p.refvec && !is_dt && !is_u) ref = p.refvec[xo + v];
         dim = is_dt ? 1 : (is_u ? NU : NX);
         c   = is_dt ? 0 : (is_u ? cu : cs_);
         fin = is_fin;
@@ -1958,6 +1962,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 #pragma unroll
             for (int t = 0; t < NU; ++t)
                 if (!isx && e - NX == t) w = sp.mp.sr[t];
+            if (sp.refvec && isx) ref = sp.refvec[xo + v];   // time-varying state references
             if (!ci.fixed && ci.cost_joff >= 0) {
                 const double a = xv + delta, b = a + neg2delta;
                 const double dv  = scalar * (w * (a - ref) - w * (b - ref));
@@ -2977,7 +2982,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
     }
     xl[W - 1] = p.dt_free ? xg[p.off_dt] : p.dt_fixed;
     if (!p.dt_free) fm |= 1u << (W - 1);
-    for (int i = 0; i < NX; ++i) xr[i] = p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
+    for (int i = 0; i < NX; ++i) xr[i] = p.refvec ? p.refvec[(size_t)inst * p.nvs + k * S + i] : p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
     const int32_t* so = hp.stage_off + (size_t)k * 6;
     if (hp.mode == 0) {
         double* vo = hp.vals[0] + (size_t)b * hp.nnz[0];

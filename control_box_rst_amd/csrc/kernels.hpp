@@ -55,6 +55,8 @@ struct SweepParams {
     const double* lb;   // [batch][nvs]
     const double* ub;
     const double* xref; // [batch][MAX_NX]
+    const double* refvec;  // or null: per-component state references in the vertex layout [batch][nvs] (time-varying reference,
+                           // corbo_hip_set_references): the cost row of state component v is w * (x_v - refvec[v]); final-stage terms use the x_f entries
     double* values0;    // [batch][m]   residual buffer 0
     double* values1;    // [batch][m]   residual buffer 1 (LM only)
     double* jac;        // [batch][nnz_pad]

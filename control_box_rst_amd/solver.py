@@ -237,6 +237,21 @@ class BatchedLevenbergMarquardt:
         self._check(rc, "corbo_hip_eval")
         return values, jac
 
+    def set_references(self, xref_traj=None):
+        """Time-varying state reference: xref_traj [B][N][nx] (grid point k; the last one serves the final-stage terms).  Without an
+        argument: back to the static reference of set_instance_data."""
+        if xref_traj is None:
+            self._check(self.lib.corbo_hip_set_references(self._h, None), "corbo_hip_set_references")
+            return
+        d, B = self.desc, self.batch
+        nx, N, S = d.nx, d.N, d.nx + d.nu
+        ref = np.zeros((B, self.dims.nv))
+        xr = np.broadcast_to(np.asarray(xref_traj, np.float64), (B, N, nx))
+        for k in range(N):
+            ref[:, k * S:k * S + nx] = xr[:, k]
+        ref = np.ascontiguousarray(ref)
+        self._check(self.lib.corbo_hip_set_references(self._h, _dp(ref)), "corbo_hip_set_references")
+
     def hessian_structure(self, lower_part_only=True):
         """Three (rows, cols) pairs -- objective, equalities, inequalities -- of computeSparseHessiansStructure, in the reference's order."""
         nnz = np.zeros(3, np.int32)

@@ -207,6 +207,18 @@ void corbo_hip_destroy(corbo_hip_handle h);
  * buffer owned by the handle and copied on the handle's stream. */
 int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref);
 
+
+/* Time-varying state reference (what ReferenceTrajectoryInterface::getReferenceCached(k) hands the cost and final-stage terms,
+ * optimal_control/src/functions/quadratic_cost.cpp:100-119, final_state_cost.cpp:72-92, final_state_constraints.cpp:60-80): one
+ * reference per vertex component, in the vertex layout of corbo_hip_set_instance_data -- ref [batch][nv]: the entries of x_k are the
+ * state reference at grid point k, those of x_f the reference of the final-stage terms (final cost, TerminalBall,
+ * TerminalEqualityConstraint); the dt entry is ignored.  The cost row of a state component is w * (x - ref).  The control entries
+ * must be zero (CORBO_HIP_ERR_INVALID otherwise): the reference's least-squares control term with a non-zero control reference
+ * assigns the scalar ud^T R^(1/2) ud to the nu-vector (quadratic_cost.cpp:160-163) -- there is nothing well-defined to reproduce.
+ * Stays in force until the next call; NULL returns to the static reference of corbo_hip_set_instance_data.  The moving-horizon shift
+ * does not move references: a caller that advances time uploads the references of the new grid. */
+int corbo_hip_set_references(corbo_hip_handle h, const double* ref);
+
 /* Re-arm the resident batch: copy the x uploaded by the last corbo_hip_set_instance_data back into the iterate,
  * device to device, asynchronously on the handle's stream (what the grid does when it re-initialises its vertices for a
  * new problem, full_discretization_grid_base.cpp:134-179).  Lets a caller re-solve the same batch without a PCIe trip. */

@@ -58,6 +58,7 @@ struct oracle_problem {
     int* bound_col;       /* per bound row: parameter index */
     int* param_off;       /* per parameter: offset in the vertex storage (applyIncrementNonFixed, vertex_set.cpp:357-367) */
     double *x, *lb, *ub, *xref, *backup;
+    double* refvec; /* NULL, or one reference per vertex component (time-varying references, oracle_set_references) */
     double sq[CORBO_HIP_MAX_NX], sr[CORBO_HIP_MAX_NU], sqf[CORBO_HIP_MAX_NX]; /* cwiseSqrt of the weights */
     double dt_weight;
     /* static row-wise view of J (for J^T J in Eigen's summation order) */
@@ -235,17 +236,20 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
     switch (e->type) {
         case E_STATE_COST: { /* optimal_control/src/functions/quadratic_cost.cpp:100-119 (lsq form, diagonal Q) */
             const double* xk = x + p->v[e->vert[0]].off;
-            for (int i = 0; i < d->nx; ++i) out[i] = p->sq[i] * (xk[i] - p->xref[i]);
+            const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref; /* getReferenceCached(k) */
+            for (int i = 0; i < d->nx; ++i) out[i] = p->sq[i] * (xk[i] - rk[i]);
             break;
         }
-        case E_CONTROL_COST: { /* quadratic_cost.cpp:140-154 (lsq form, zero uref, diagonal R) */
+        case E_CONTROL_COST: { /* quadratic_cost.cpp:140-154 (lsq form, zero uref, diagonal R).  A non-zero uref is not restated: the
+                                * reference assigns the scalar ud^T R^(1/2) ud to the nu-vector there (:160-163) */
             const double* uk = x + p->v[e->vert[0]].off;
             for (int i = 0; i < d->nu; ++i) out[i] = p->sr[i] * uk[i];
             break;
         }
         case E_FINAL_COST: { /* optimal_control/src/functions/final_state_cost.cpp:72-92 */
             const double* xk = x + p->v[e->vert[0]].off;
-            for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - p->xref[i]);
+            const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
+            for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - rk[i]);
             break;
         }
         case E_DT_COST: /* optimal_control/include/corbo-optimal-control/functions/minimum_time.h:70-78 */
@@ -267,14 +271,16 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
         }
         case E_FINAL_EQ: { /* TerminalEqualityConstraint::computeNonIntegralStateTerm (final_state_constraints.h:149-154): x_k - xref */
             const double* xk = x + p->v[e->vert[0]].off;
-            for (int i = 0; i < d->nx; ++i) out[i] = xk[i] - p->xref[i];
+            const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
+            for (int i = 0; i < d->nx; ++i) out[i] = xk[i] - rk[i];
             break;
         }
         case E_FINAL_INEQ: { /* TerminalBall, diagonal mode, non-zero reference (final_state_constraints.cpp:72-76):
                               * xd = x_k - xref; cost = xd^T * S_diag * xd - gamma  (row vector times diagonal, then the inner product) */
             const double* xk = x + p->v[e->vert[0]].off;
+            const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
             double acc = 0.0;
-            for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - p->xref[i]; acc += (xd * d->final_ineq_params[i]) * xd; }
+            for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->final_ineq_params[i]) * xd; }
             out[0] = acc - d->final_ineq_params[d->nx];
             break;
         }
@@ -588,7 +594,7 @@ void oracle_destroy(oracle_problem* p)
 {
     if (!p) return;
     free(p->v); free(p->e); free(p->b); free(p->bound_vert_off); free(p->bound_col); free(p->param_off);
-    free(p->x); free(p->lb); free(p->ub); free(p->xref); free(p->backup);
+    free(p->x); free(p->lb); free(p->ub); free(p->xref); free(p->backup); free(p->refvec);
     free(p->csr_ptr); free(p->csr_col); free(p->csr_val); free(p->env_first); free(p->env_ptr);
     free(p->values); free(p->jac); free(p->H); free(p->L); free(p->rhs); free(p->delta); free(p->tmp);
     free(p);
@@ -662,6 +668,19 @@ int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const 
  *   shift != 0 (grid->setWarmStart(true), fixed-dt grids only :133 / finite_differences_variable_grid.h:77):
  *       warmStartShifting(x0) :230-283 with findNearestState :285-317;
  *   always: x_seq.front() = x0 (:101) and the fixed goal components = xref (:103-106). */
+/* one reference per vertex component (vertex layout, nv doubles); NULL = back to the static state reference */
+int oracle_set_references(oracle_problem* p, const double* ref)
+{
+    if (!p || p->gen) return CORBO_HIP_ERR_INVALID;
+    free(p->refvec);
+    p->refvec = NULL;
+    if (ref) {
+        p->refvec = (double*)calloc(p->dims.nv + 2, sizeof(double));
+        memcpy(p->refvec, ref, p->dims.nv * sizeof(double));
+    }
+    return 0;
+}
+
 int oracle_warm_start(oracle_problem* p, const double* x0, int shift)
 {
     if (!p || !x0) return CORBO_HIP_ERR_INVALID;

@@ -43,6 +43,9 @@ int oracle_init_trajectory(const corbo_hip_problem_desc* desc, const double* x0,
 
 /* vertex values / bounds in vertex layout (nv doubles); lb/ub NULL = descriptor box bounds; xref NULL = zeros */
 int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const double* ub, const double* xref);
+/* time-varying state reference: one per vertex component (state reference at grid point k in the x_k entries, the final-stage terms
+ * use the x_f entries; control / dt entries are not read); NULL = the static reference of oracle_set_data */
+int oracle_set_references(oracle_problem* p, const double* ref);
 int oracle_warm_start(oracle_problem* p, const double* x0, int shift);
 int oracle_get_x(const oracle_problem* p, double* x_out);
 /* SimulatedPlant::control without dead time (plants/src/simulated_plant.cpp:97-160): x_plant <- integrator.solveIVP(x_plant, u_0 of

@@ -137,10 +137,36 @@ def hess():
         print(name, d["n"], len(d["heq_vals_full"]), len(d["hineq_vals_full"]), os.path.getsize(os.path.join(OUT, f"{name}.json")))
 
 
+def tvref():
+    """Time-varying state reference (DiscreteTimeReferenceTrajectory, one sample per grid point): what getReferenceCached(k) hands the cost
+    / final-stage terms is recorded in the fixture ("ref_vertex", vertex layout).  (No control reference: the reference's least-squares
+    control term with a non-zero uref writes one element of the nu-vector and leaves the rest uninitialised, quadratic_cost.cpp:160-163 --
+    ref_driver's uref= option shows it.)"""
+    for name, kv, keep in [
+        ("unicycle_n12_tvref", dict(scenario="unicycle", N=12, iters=6, xref_traj=1), (1, 2, 3, 4, 5, 6)),
+        ("vdp_tvref", dict(scenario="vdp", iters=6, xref_traj=1), (1, 2, 3, 6)),
+        ("unicycle_n12_tball_tvref", dict(scenario="unicycle", N=12, iters=6, xref_traj=1, tball=1e-4, tball_s="1,1,0.1"), (1, 2, 3, 6)),
+        ("vdp_teq_tvref", dict(scenario="vdp", N=12, iters=5, xref_traj=1, teq=1), (1, 2, 5)),
+        ("pendulum_ms_rk4_tvref", dict(scenario="pendulum", grid="ms", N=12, iters=5, xref_traj=1), (1, 2, 5)),
+        ("quad_n10_tvref", dict(scenario="quad", N=10, iters=4, xref_traj=1), (1, 2, 4)),
+    ]:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], d["m"], [a["chi2"] for a in d["after_iter"]][-1])
+    for name, kv in [("hess_unicycle_tvref", dict(scenario="unicycle", N=12, xref_traj=1))]:
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "hess":
         return hess()
+    if len(sys.argv) > 1 and sys.argv[1] == "tvref":
+        return tvref()
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         return fullsize()
     if len(sys.argv) > 1 and sys.argv[1] == "adapt":

@@ -51,6 +51,7 @@ def load():
     lib.oracle_resample_trajectory.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]
     lib.oracle_adapt_grid_n.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     i3 = C.POINTER(C.c_int32)
+    lib.oracle_set_references.argtypes = [C.c_void_p, dp]
     lib.oracle_get_param_offsets.argtypes = [C.c_void_p, i3]
     lib.oracle_hessian_nnz.argtypes = [C.c_void_p, C.c_int, i3]
     lib.oracle_hessian_structure.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, ip, ip]
@@ -117,6 +118,11 @@ class OracleProblem:
         rc = self.lib.oracle_eval(self.h, w_eq, w_ineq, w_b, _dp(values), _dp(jac))
         assert rc == 0
         return values, jac
+
+    def set_references(self, ref):
+        """ref: one reference per vertex component (nv) or None (static reference again)."""
+        r = None if ref is None else np.ascontiguousarray(ref, np.float64)
+        assert self.lib.oracle_set_references(self.h, _dp(r)) == 0
 
     def param_offsets(self):
         out = np.zeros(self.dims.n, np.int32)
@@ -197,6 +203,11 @@ class GenericProblem(OracleProblem):
 
     def init_trajectory(self, x0, xf):
         raise NotImplementedError("not an OCP")
+
+    def set_references(self, ref):
+        """ref: one reference per vertex component (nv) or None (static reference again)."""
+        r = None if ref is None else np.ascontiguousarray(ref, np.float64)
+        assert self.lib.oracle_set_references(self.h, _dp(r)) == 0
 
     def param_offsets(self):
         out = np.zeros(self.dims.n, np.int32)

@@ -148,6 +148,10 @@ struct Scenario
     int n_max = 1000, n_min = 2;
     double hyst = 0.1;
     bool adapt_first = false;
+    // xref_traj=1: a time-varying state reference (DiscreteTimeReferenceTrajectory, one sample per grid point, zero-order hold) that ends in
+    // xf; uref=<csv>: a static non-zero control reference (StaticReference) instead of ZeroReference
+    bool xref_traj = false;
+    Eigen::VectorXd uref;
 };
 
 // the reference's other benchmark systems (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket (3) and the cart-pole (4)
@@ -162,8 +166,8 @@ struct Built
     std::shared_ptr<LevenbergMarquardtSparse> solver;
     std::shared_ptr<StructuredOptimalControlProblem> ocp;
     std::shared_ptr<OptimalControlProblemStatistics> stats;
-    std::shared_ptr<StaticReference> xref;
-    std::shared_ptr<ZeroReference> uref;
+    ReferenceTrajectoryInterface::Ptr xref;
+    ReferenceTrajectoryInterface::Ptr uref;
     SystemDynamicsInterface::Ptr dyn;
 };
 
@@ -407,8 +411,23 @@ static Built build(const Scenario& s, int iterations)
         fprintf(stderr, "ocp initialize failed\n");
         exit(3);
     }
-    b.xref = std::make_shared<StaticReference>(s.xf);
-    b.uref = std::make_shared<ZeroReference>(s.nu);
+    if (s.xref_traj)
+    {
+        auto ts = std::make_shared<TimeSeries>();
+        ts->setValueDimension(s.nx);
+        for (int k = 0; k < s.N; ++k)
+        {
+            Eigen::VectorXd r = s.xf;
+            const double fade = double(s.N - 1 - k) / double(s.N - 1);   // the last sample is xf itself
+            for (int i = 0; i < s.nx; ++i) r[i] += 0.3 * fade * std::sin(0.37 * k + 1.1 * i);
+            ts->add(k * s.dt, r);
+        }
+        b.xref = std::make_shared<DiscreteTimeReferenceTrajectory>(ts, TimeSeries::Interpolation::ZeroOrderHold);
+    }
+    else
+        b.xref = std::make_shared<StaticReference>(s.xf);
+    if (s.uref.size() == s.nu) b.uref = std::make_shared<StaticReference>(s.uref);
+    else b.uref = std::make_shared<ZeroReference>(s.nu);
     return b;
 }
 
@@ -448,6 +467,27 @@ static Eigen::VectorXd vertexValues(Built& b, const Scenario& s)
     for (int i = 0; i < s.nx; ++i) out.push_back(xs->getValuesMatrixView()(i, n - 1));
     out.push_back(b.any_grid->getFirstDt());
     return Eigen::Map<Eigen::VectorXd>(out.data(), out.size());
+}
+
+
+// the references the cost terms actually used (ReferenceTrajectoryInterface::getReferenceCached(k) after the grid's precompute):
+// "ref_vertex" in the vertex layout x_0 u_0 | x_1 u_1 | ... | x_f | (dt -> 0)
+static void printReferences(Built& b, const Scenario& s)
+{
+    if (!s.xref_traj && s.uref.size() == 0) return;
+    const int n = b.any_grid->getN();
+    std::vector<double> out;
+    for (int k = 0; k < n - 1; ++k)
+    {
+        const auto& xr = b.xref->getReferenceCached(k);
+        for (int i = 0; i < s.nx; ++i) out.push_back(xr[i]);
+        const auto& ur = b.uref->getReferenceCached(k);
+        for (int i = 0; i < s.nu; ++i) out.push_back(ur[i]);
+    }
+    const auto& xr = b.xref->getReferenceCached(n - 1);
+    for (int i = 0; i < s.nx; ++i) out.push_back(xr[i]);
+    out.push_back(0.0);
+    printVec("ref_vertex", Eigen::Map<Eigen::VectorXd>(out.data(), out.size()));
 }
 
 static Scenario parse(int argc, char** argv, std::map<std::string, std::string>& kv)
@@ -562,6 +602,8 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("final_cost")) s.final_cost = atoi(kv["final_cost"].c_str());
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
+    if (kv.count("xref_traj")) s.xref_traj = atoi(kv["xref_traj"].c_str()) != 0;
+    if (kv.count("uref")) s.uref = vec(kv["uref"]);
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
@@ -616,6 +658,7 @@ static int dump(const Scenario& s)
         printVec("param_lb", lb);
         printVec("param_ub", ub);
         printVec("vertex_init", vertexValues(b, s));
+        printReferences(b, s);
         // stacked residual exactly as LevenbergMarquardtSparse::computeValues (levenberg_marquardt_sparse.cpp:222-246)
         Eigen::VectorXd values(m);
         if (lsq) hg.computeValuesLsqObjective(values.segment(0, lsq));
@@ -903,6 +946,7 @@ static int hess(const Scenario& s)
     }
     printf("\"n\": %d, \"eq\": %d, \"ineq\": %d, \"bounds\": %d,\n", n, eq, ineq, hg.finiteCombinedBoundsDimension());
     printVec("vertex_point", vertexValues(b, s));
+    printReferences(b, s);
     Eigen::VectorXd meq(eq), mineq(ineq);
     for (int i = 0; i < eq; ++i) meq[i] = 0.5 + 0.25 * std::cos(0.7 * i);
     for (int i = 0; i < ineq; ++i) mineq[i] = 0.3 + 0.125 * (i % 5);
