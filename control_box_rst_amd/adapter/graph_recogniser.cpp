@@ -408,6 +408,26 @@ bool readStateReferenceForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eig
     return false;
 }
 
+bool readStateReferenceTrajectoryForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::MatrixXd* traj)
+{
+    GridView g;
+    std::string why;
+    if (!viewGrid(hg, &g, &why) || g.nx != nx || traj->rows() != g.N || traj->cols() != nx) return false;
+    int seen = 0;
+    for (const BaseEdge::Ptr& e : hg.getGraph().getEdgeSetRaw()->getLsqObjectiveEdges())
+    {
+        if (e->getNumVertices() != 1 || e->getDimension() != nx) continue;
+        VertexInterface* v = e->getVertexRaw(0);
+        const int k = (v == g.xf) ? g.N - 1 : indexOf(g.xs, v);
+        if (k < 0) continue;
+        Eigen::VectorXd w, ref;
+        if (!identifyDiagonalAffine(*e, v, &w, &ref)) return false;
+        traj->row(k) = ref.transpose();
+        ++seen;
+    }
+    return seen >= g.N - 1;   // (without a final cost term row N-1 keeps what the caller put there)
+}
+
 bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason)
 {
     GridView g;
@@ -457,6 +477,8 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
 
     // ---- least-squares objective edges, in the grid's creation order (nlp_functions.cpp:70-132, finite_differences_grid.cpp:38-154)
     Eigen::VectorXd sq, sr, sqf, xref_state, xref_final;
+    std::vector<Eigen::VectorXd> stage_refs(g.N - 1);   // reference of the state cost term of every interval (getReferenceCached(k))
+    bool refs_vary = false;
     int n_state = 0, n_ctrl = 0, n_final = 0, n_dt = 0;
     double dt_weight = 0.0;
     for (const BaseEdge::Ptr& ep : es->getLsqObjectiveEdges())
@@ -483,8 +505,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         }
         else if (indexOf(g.xs, v) >= 0)
         {
+            stage_refs[indexOf(g.xs, v)] = ref;
             if (n_state++ == 0) { sq = w; xref_state = ref; }
-            else if (!sameVector(w, sq) || !sameVector(ref, xref_state)) return fail(reason, "state cost weights / reference vary along the horizon (time-varying reference trajectory)");
+            else if (!sameVector(w, sq)) return fail(reason, "state cost weights vary along the horizon");
+            else if (!sameVector(ref, xref_state)) refs_vary = true;   // a time-varying reference trajectory
         }
         else if (indexOf(g.us, v) >= 0)
         {
@@ -511,10 +535,18 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     d.final_cost = n_final ? 1 : 0;
     if (n_final)
         for (int i = 0; i < g.nx; ++i) d.qf_diag[i] = sqf[i] * sqf[i];
-    // one static reference for every term
+    // one static reference for every term -- or one per grid point (time-varying ReferenceTrajectoryInterface): then the final-stage terms
+    // have their own (the reference at the last grid point) and model->xref is that one
+    model->xref_traj.resize(0, 0);
     model->xref = Eigen::VectorXd::Zero(g.nx);
     if (n_state) model->xref = xref_state;
-    if (n_final)
+    if (refs_vary)
+    {
+        if ((sq.array() == 0.0).any()) return fail(reason, "time-varying state reference with a zero state weight (the reference of that component cannot be identified)");
+        if (n_final) model->xref = xref_final;
+        else model->xref = stage_refs[g.N - 2];
+    }
+    else if (n_final)
     {
         if (n_state)
         {
@@ -539,7 +571,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         Eigen::VectorXd w, ref;
         if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf || !identifyDiagonalAffine(*e, g.xf, &w, &ref) || (w.array() != 1.0).any())
             return fail(reason, "extra equality edge is not a TerminalEqualityConstraint x_f - xref");
-        if ((n_state || n_final) && !sameVector(ref, model->xref)) return fail(reason, "terminal equality constraint uses a different reference");
+        if ((n_final || (n_state && !refs_vary)) && !sameVector(ref, model->xref)) return fail(reason, "terminal equality constraint uses a different reference");
         model->xref = ref;
         d.final_eq = 1;
     }
@@ -568,6 +600,12 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         if (at + 1 != ins.size() || e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf || !identifyTerminalBall(*e, g.xf, model->xref, d.final_ineq_params))
             return fail(reason, "inequality edge that is neither the per-interval keep-out ball nor a TerminalBall (diagonal S) on x_f around the cost reference");
         d.final_ineq = CORBO_HIP_FINAL_INEQ_TERMINAL_BALL;
+    }
+    if (refs_vary)
+    {   // rows 0 .. N-2: the stage references, row N-1: the reference of the final-stage terms
+        model->xref_traj.resize(g.N, g.nx);
+        for (int k = 0; k < g.N - 1; ++k) model->xref_traj.row(k) = stage_refs[k].transpose();
+        model->xref_traj.row(g.N - 1) = model->xref.transpose();
     }
     // ---- the dynamics object last (user systems are matched on the device)
     return describeDynamics(*dyn, d, reason);

@@ -13,7 +13,7 @@
 //   * cost / constraint edges are generic adapters around StageFunction members (generic_edge.h:294-498): their weights and
 //     references are IDENTIFIED through the edges' own public computeValues() on temporarily modified vertex values -- the weight
 //     vectors and references come out bit-exact (evaluation points are chosen so that every product is a power-of-two scaling).
-// Anything else (non-diagonal weights, time-varying references, integral cost edges, other edge types) is refused with a reason:
+// Anything else (non-diagonal weights, control references, integral cost edges, other edge types) is refused with a reason:
 // the adapter has no CPU fallback.
 #ifndef CONTROL_BOX_RST_AMD_ADAPTER_GRAPH_RECOGNISER_H_
 #define CONTROL_BOX_RST_AMD_ADAPTER_GRAPH_RECOGNISER_H_
@@ -30,7 +30,8 @@ namespace corbo {
 struct HipRecognisedModel
 {
     corbo_hip_problem_desc desc;   // everything but N, bounds, xf_fixed_mask, dt_ref / dt bounds (the adapter reads those from the vertices)
-    Eigen::VectorXd xref;          // static state reference all cost / constraint terms agree on
+    Eigen::VectorXd xref;          // static state reference all cost / constraint terms agree on (time-varying: of the final-stage terms)
+    Eigen::MatrixXd xref_traj;     // empty, or [N][nx]: the state reference of every grid point (time-varying ReferenceTrajectoryInterface)
 };
 
 // false: *reason says what the device cannot describe
@@ -39,6 +40,9 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
 // the state reference alone (cheap: a few evaluations of one cost edge); used on every solve to follow a reference that changed
 // between runs without a structure change.  false if the graph has no state-dependent least-squares term.
 bool readStateReferenceForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::VectorXd* xref);
+// the same for a time-varying reference: row k of traj ([N][nx], sized by the caller) = reference of the state cost term of grid point k
+// (row N-1: of the final cost term, left untouched if the graph has none)
+bool readStateReferenceTrajectoryForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::MatrixXd* traj);
 
 }  // namespace corbo
 

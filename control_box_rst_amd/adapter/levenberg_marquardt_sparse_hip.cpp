@@ -158,6 +158,20 @@ bool LevenbergMarquardtSparseHip::uploadVertices(const std::vector<VertexInterfa
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
         return false;
     }
+    // time-varying state reference: one reference per vertex component (corbo_hip_set_references), else the static one above
+    const double* refs = nullptr;
+    if (_xref_traj.rows() == N && _xref_traj.cols() == nx)
+    {
+        _ref.assign(_x.size(), 0.0);
+        for (int k = 0; k < N; ++k)
+            for (int i = 0; i < nx; ++i) _ref[k * s + i] = _xref_traj(k, i);
+        refs = _ref.data();
+    }
+    if (corbo_hip_set_references(_handle, refs) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
+    }
     return true;
 }
 
@@ -200,6 +214,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
             }
             _desc       = m.desc;
             _xref       = m.xref;
+            _xref_traj  = m.xref_traj;
             _have_desc  = true;
             _recognised = true;
         }
@@ -264,8 +279,18 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     }
     else if (_recognised)
     {   // same structure, possibly a new reference (new_run with another xref): re-read it from the cost edges
+        // (every grid point's: a static reference may have become a time-varying one)
+        Eigen::MatrixXd tr(N, nx);
+        tr.row(N - 1) = _xref.transpose();
         Eigen::VectorXd xr;
-        if (readStateReferenceForHip(*hg, nx, &xr)) _xref = xr;
+        if (readStateReferenceTrajectoryForHip(*hg, nx, &tr))
+        {
+            bool vary = false;
+            for (int k = 1; k < N - 1 && !vary; ++k) vary = (tr.row(k) != tr.row(0));
+            if (vary) { _xref_traj = tr; _xref = tr.row(N - 1).transpose(); }
+            else { _xref_traj.resize(0, 0); if (readStateReferenceForHip(*hg, nx, &xr)) _xref = xr; }
+        }
+        else if (readStateReferenceForHip(*hg, nx, &xr)) { _xref_traj.resize(0, 0); _xref = xr; }
     }
     const bool dt_free = (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE);
 

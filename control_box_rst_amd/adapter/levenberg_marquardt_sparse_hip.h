@@ -50,7 +50,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     //      SolverStatus::Error with the reason on stderr.
     //      setDeviceModel() is the override for system dynamics the recogniser cannot know (user classes other than the device
     //      library's plug-in models): the caller states the model; setStateReference() then states the reference.
-    void setDeviceModel(const corbo_hip_problem_desc& desc) { _desc = desc; _have_desc = true; releaseHandle(); }
+    void setDeviceModel(const corbo_hip_problem_desc& desc) { _desc = desc; _have_desc = true; _xref_traj.resize(0, 0); releaseHandle(); }
     void setStateReference(const Eigen::Ref<const Eigen::VectorXd>& xref) { _xref = xref; }
     void setDevice(int device) { _device = device; releaseHandle(); }
     // On every new structure the device model -- recognised or stated -- is checked against the graph's own edges (evaluated on the
@@ -85,6 +85,8 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     bool _have_desc = false;
     bool _verify    = true;
     Eigen::VectorXd _xref;
+    Eigen::MatrixXd _xref_traj;   // recognised time-varying state reference [N][nx] (empty: static)
+    std::vector<double> _ref;
     int _device = 0;
     corbo_hip_handle _handle = nullptr;
     corbo_hip_dims _dims;
