@@ -169,6 +169,20 @@ def profile_kernel_avg_ns(pattern, kernel_substr):
     return None
 
 
+def profile_kernel_max_ns(csv_name, kernels):
+    """Sum over `kernels` of the longest launch (MaxNs = a launch with every instance active) in a committed rocprofv3 kernel-stats CSV."""
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if not os.path.exists(path):
+        return None
+    tot = 0.0
+    for k in kernels:
+        rows = [r for r in csv.DictReader(open(path)) if k in r["Name"]]
+        if not rows:
+            return None
+        tot += max(float(r["MaxNs"]) for r in rows)
+    return tot, "profiles/" + csv_name
+
+
 def load_profile_json(name, batch, N):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -366,10 +380,26 @@ def main():
           "back_to_back": {"ms_per_launch": b2b_ms, "frac": B * b_sweep / (b2b_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                            "what": "50 launches between ONE event pair: the next launch's ramp-up overlaps the previous one's store drain"},
           "profile_avg_ms": prof[0] * 1e-6 if prof else None, "profile": prof[2] if prof else None}
+    line["roofline_sweep"] = rs
     if cfg == 5:
-        line["roofline"] = rs
-    else:
-        line["roofline_sweep"] = rs
+        # big-block family: an LM pass is sweep (residual) -> big_stage_kernel -> big_chain2_kernel; the last two are 81 % of the GPU time
+        # of a solve (profiles/r02_cfg5_kernel_stats.csv).  One factorisation of EVERY instance (stage + chain launch), HIP events
+        # around 5 back-to-back pairs (corbo_hip_time_factor).  Algorithmic bytes per shooting interval: stage kernel
+        # reads x_k u_k, the stored RK4 end state, the bounds (60 doubles) and writes the 572-double stage record; the chain kernel
+        # reads the record, writes G_k and a_k (156), reads them back in the back-substitution and moves the iterate (32): 1548 doubles
+        rs["note"] = "parity hook of this family (residual + Jacobian in HBM); its LM passes launch the residual-only sweep and the stage kernel instead"
+        nxq, nuq = desc.nx, desc.nu
+        rec = 3 * nxq * nxq + nuq * nuq + 2 * nuq * nxq + 2 * nxq + nuq + 2
+        per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
+        f_ms = solver.time_factor(repeat=5)
+        alg_pair = per_stage * desc.N * B
+        pc = profile_kernel_max_ns("r02_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
+        line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance: FD Jacobian + assemble, then the block chain)",
+                            "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                            "traffic": None, "bytes_per_launch": alg_pair, "bytes_per_interval": per_stage, "ms_per_launch": f_ms,
+                            "timing": "HIP events around 5 back-to-back (stage, chain) launch pairs over all instances (corbo_hip_time_factor)",
+                            "profile_full_launch_ms": pc[0] * 1e-6 if pc else None, "profile": pc[1] if pc else None,
+                            "note": "the stage kernel is fp64-VALU-bound (RK4 finite differences), the chain a latency chain of 12 x 12 pivots; matrix-core view in `factorization`"}
     # per-kernel split inside one solve (separate, profiled solve: event stamping is kept out of the timed region)
     solver.set_profiling(True)
     step(fetch=False)
