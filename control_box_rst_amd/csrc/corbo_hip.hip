@@ -175,7 +175,7 @@ struct corbo_hip_solver {
         p.mp.dt_weight = S.dt_weight;
         std::memcpy(p.mp.fin, S.desc.final_ineq_params, sizeof(p.mp.fin));
         p.fin_row = S.fin_row;
-        for (int i = 0; i < 4; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
+        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
         p.dt_fixed = S.desc.dt_ref;
         p.mode = mode; p.iterations = iterations; p.w_eq = weq; p.w_ineq = wineq; p.w_b = wb;
         p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
@@ -191,7 +191,7 @@ struct corbo_hip_solver {
         p.eq_row0 = S.eq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols; p.ineq_rows = d_ineq_rows;
         p.fin_row = S.fin_row;
-        for (int i = 0; i < 4; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
+        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
         p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;

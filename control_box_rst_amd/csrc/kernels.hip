@@ -311,7 +311,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
     // (c) the final-stage inequality on x_f (TerminalBall): one lane
-    if constexpr (NX <= 4) {
+    {
         if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
             double cf = terminal_ball<NX>(xs + (p.N - 1) * S, xr, p.mp.fin);
             cf        = (cf < 0) ? 0.0 : cf * p.w_ineq;   // computeValuesActiveInequality
@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     else if (p.fin_row >= 0 && k == N - 1) {   // final-stage inequality: a row on the last state block
         iq_row = p.fin_row;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) iq[i] = p.fin_joff[i < 4 ? i : 3];
+        for (int i = 0; i < NX; ++i) iq[i] = p.fin_joff[i];
     }
     // (2) residual entries
     double r[NX], vc[S], vb[S], rin;
@@ -1820,9 +1820,9 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
     // the contribution to block k+1: C^T C - Zp^T Zp
     for (int e = lane; e < NX * NX; e += 64) {
         const int i = e / NX, j = e % NX;
-        double d = 0.0, cx = 0.0, dn = 0.0;
+        double d = cin[i] * cin[j], cx = 0.0, dn = 0.0;   // (the inequality row of the block: keep-out ball, or the TerminalBall on x_f)
         if (stage) {
-            d  = Mm[i * S + j] + cin[i] * cin[j];
+            d  = Mm[i * S + j] + d;
             cx = cd[i] * Gm[i * S + j];
             dn = (i == j) ? cd[i] * cd[i] : 0.0;
 #pragma unroll
@@ -1837,6 +1837,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
     }
     if (lane < NX) {
         double g = gd[lane], g2 = 0.0;
+        if (!stage) g += -(cin[lane] * red[7]);
         if (stage) {
             g += gm[lane] - cin[lane] * red[7];
             g2 = -(cd[lane] * rv[lane]);
@@ -1941,6 +1942,30 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
             cinv = (jq >= 0 && active) ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
             if (jac_dump && jq >= 0) jac_dump[jq] = active ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
         }
+        if (!stage && block && sp.fin_row >= 0) {   // final block: TerminalBall on x_f (sweep_body (c) + its active-row Jacobian), same slot
+            double loc[NX], xrf[NX];
+#pragma unroll
+            for (int t = 0; t < NX; ++t) {
+                loc[t] = X[(size_t)(N - 1) * S + t];
+                xrf[t] = sp.refvec ? sp.refvec[xo + (size_t)(N - 1) * S + t] : sp.xref[(size_t)inst * CORBO_HIP_MAX_NX + t];
+            }
+            const double c0 = terminal_ball<NX>(loc, xrf, sp.mp.fin);
+            rin             = (c0 < 0) ? 0.0 : c0 * sp.w_ineq;
+            const bool active = rin > 0.0;
+            double keep = 0.0;
+#pragma unroll
+            for (int t = 0; t < NX; ++t) keep = (t == i) ? loc[t] : keep;
+            const double up = keep + delta, dn = up + neg2delta;
+#pragma unroll
+            for (int t = 0; t < NX; ++t) loc[t] = (t == i) ? up : loc[t];
+            const double c2 = terminal_ball<NX>(loc, xrf, sp.mp.fin);
+#pragma unroll
+            for (int t = 0; t < NX; ++t) loc[t] = (t == i) ? dn : loc[t];
+            const double c1 = terminal_ball<NX>(loc, xrf, sp.mp.fin);
+            const int jq = p.fin_joff[i];
+            cinv = (jq >= 0 && active) ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
+            if (jac_dump && jq >= 0) jac_dump[jq] = active ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
+        }
         c.cin[i] = cinv;
         if (i == 0) c.red[7] = rin;
     }
@@ -1973,6 +1998,15 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
                     const int cdim = isx ? NX : NU, cc = isx ? e : e - NX;
                     for (int r = 0; r < cdim; ++r) jac_dump[ci.cost_joff - cc + r] = (r == cc) ? dv : 0.0;
                 }
+            }
+            if (fin && isx && !ci.fixed && ci.cost2_joff >= 0) {   // TerminalEqualityConstraint x_f - xref: a second diagonal row, times w_eq
+                const double a = xv + delta, b = a + neg2delta;
+                const double dv  = (scalar * ((a - ref) - (b - ref))) * sp.w_eq;
+                const double val = (xv - ref) * sp.w_eq;
+                dd += dv * dv;
+                gg -= dv * val;
+                if (jac_dump)
+                    for (int r = 0; r < NX; ++r) jac_dump[ci.cost2_joff - e + r] = (r == e) ? dv : 0.0;
             }
             if (ci.bnd_joff >= 0) {
                 const double l = sp.lb[xo + v], u = sp.ub[xo + v];

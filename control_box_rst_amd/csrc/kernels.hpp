@@ -43,7 +43,7 @@ struct SweepParams {
     const CompInfo* comp;         // nvs: cost-block offsets per component
     const int32_t* ineq_cols;     // (N-1)*nx or null
     int32_t fin_row;              // residual row of the final-stage inequality (TerminalBall) or -1
-    int32_t fin_joff[4];          // its Jacobian entries on x_f (small-block families: nx <= 4), -1 = fixed component
+    int32_t fin_joff[CORBO_HIP_MAX_NX];   // its Jacobian entries on x_f, -1 = fixed component
     ModelParams mp;
     double dt_fixed;
     // per-call
@@ -82,7 +82,7 @@ struct FactorParams {
     const int32_t* ineq_cols;     // (N-1)*nx or null
     const int32_t* ineq_rows;     // N-1 or null
     int32_t fin_row;              // final-stage inequality on the last block (see SweepParams)
-    int32_t fin_joff[4];
+    int32_t fin_joff[CORBO_HIP_MAX_NX];
     const double* x;              // accepted iterate
     double* xt;                   // trial iterate out
     const double* values0;

@@ -40,9 +40,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
     if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
-    if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 4) return "terminal ball: families with nx <= 4 only";
+    if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 4 && d.nx != 12) return "terminal ball: families with nx <= 4, and the 12-state big-block family";
     if (d.final_eq != 0 && d.final_eq != 1) return "final_eq must be 0 or 1";
-    if (d.final_eq && d.nx > 4) return "terminal equality constraint: families with nx <= 4 only";
+    if (d.final_eq && d.nx > 4 && d.nx != 12) return "terminal equality constraint: families with nx <= 4, and the 12-state big-block family";
     if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
     if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
     return "";

@@ -161,8 +161,23 @@ def tvref():
         print(name, d["n"])
 
 
+def bigterm():
+    """Final-stage constraints on the 12-state quadrotor (big-block family): TerminalBall (violated: active row) and the terminal equality."""
+    for name, kv, keep in [
+        ("quad_n10_tball", dict(scenario="quad", N=10, iters=5, tball=0.05, tball_s="1,1,1,0.2,0.2,0.2,0.5,0.5,0.5,0.1,0.1,0.1"), (1, 2, 3, 5)),
+        ("quad_n10_tball_loose", dict(scenario="quad", N=10, iters=5, tball=4.0, tball_s="1,1,1,0.2,0.2,0.2,0.5,0.5,0.5,0.1,0.1,0.1"), (1, 2, 5)),
+        ("quad_n10_teq", dict(scenario="quad", N=10, iters=5, teq=1), (1, 2, 3, 5)),
+    ]:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], d["m"], d["ineq"], d["eq"], [a["chi2"] for a in d["after_iter"]])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "bigterm":
+        return bigterm()
     if len(sys.argv) > 1 and sys.argv[1] == "hess":
         return hess()
     if len(sys.argv) > 1 and sys.argv[1] == "tvref":

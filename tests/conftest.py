@@ -55,8 +55,8 @@ def desc_for(g):
     if sc == "dint":
         return problems.dint_desc(N=g["N"], dt=g["dt"])
     if sc == "quad":
-        return problems.quad_desc(N=g["N"], dt=g["dt"])
-    if sc == "int3":
+        d = problems.quad_desc(N=g["N"], dt=g["dt"])
+    elif sc == "int3":
         d = problems.int3_desc(N=g["N"], dt=g["dt"], defect=defect, time_optimal=bool(g.get("vargrid")))
     elif sc == "lin":
         import numpy as np

@@ -127,7 +127,8 @@ def test_random_descriptor_vs_oracle(oracle_mod, seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
-    """Big-block family (quadrotor, multiple shooting + RK4): random horizon, bound patterns, keep-out ball on / off, weights."""
+    """Big-block family (quadrotor, multiple shooting + RK4): random horizon, bound patterns, keep-out ball on / off, final-stage
+    constraint (TerminalBall / terminal equality / none), weights."""
     rng = np.random.default_rng(5000 + seed)
     N = int(rng.integers(4, 36))
     d = problems.quad_desc(N=N, dt=float(rng.uniform(0.03, 0.08)))
@@ -143,6 +144,16 @@ def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
     B = 2
     w = tuple(float(v) for v in rng.uniform(2.0, 30.0, 3))
     x0, xf = problems.quad_instances(B, seed=int(rng.integers(0, 10 ** 6)))
+    # final-stage constraint on x_f (own generator: the cases above keep their draws): TerminalBall, terminal equality or none
+    rf = np.random.default_rng(9000 + seed)
+    kind = int(rf.integers(0, 3))
+    if kind == 1:
+        d.final_ineq = capi.FINAL_INEQ_TERMINAL_BALL
+        for i in range(12):
+            d.final_ineq_params[i] = float(rf.uniform(0.1, 2.0))
+        d.final_ineq_params[12] = float(rf.uniform(1e-4, 0.05))
+    elif kind == 2:
+        d.final_eq = 1
     s = BatchedLevenbergMarquardt(d, B)
     s.setIterations(3)
     s.setPenaltyWeights(*w)
