@@ -130,7 +130,7 @@ typedef struct corbo_hip_problem_desc {
     double ineq_params[8];
     int32_t final_ineq;    /* enum corbo_hip_final_ineq; families with nx <= 4 and the 12-state big-block family */
     int32_t final_eq;      /* 1 = TerminalEqualityConstraint(xref) (final_state_constraints.h:130-160): nx equality rows x_f - xref after the
-                            * defect rows (finite_differences_grid.cpp:135-141), xref = the instance's state reference; nx <= 4 only */
+                            * defect rows (finite_differences_grid.cpp:135-141), xref = the instance's state reference; nx <= 4 or 12 */
     double final_ineq_params[CORBO_HIP_MAX_NX + 1];
     /* CORBO_HIP_DYN_LINEAR_STATE_SPACE (LinearStateSpaceModel::setParameters(A, B)): row-major A[i * nx + j], B[i * nu + j] */
     double lin_a[16];
