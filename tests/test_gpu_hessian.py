@@ -128,3 +128,52 @@ def test_hessians_big_block_family_vs_oracle(oracle_mod):
         assert np.abs(lv[b] - v2).max() <= 2e-6 * max(1.0, np.abs(v2).max())
         fin = np.isfinite(l2) & (np.abs(l2) < 1e29)
         assert np.abs(lbA[b][fin] - l2[fin]).max() <= 1e-12 * max(1.0, np.abs(l2[fin]).max())
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
+    """The random descriptors of tests/test_gpu_fuzz.py (every small-block family, grid kind, defect formula, bound pattern, partially
+    fixed x_f, cost terms on / off, stage inequality, final-stage constraints): structure of the three lists and of the linear form
+    identical to the oracle's, values within the reference's own consecutive-call spread, per-instance multipliers."""
+    from test_gpu_fuzz import random_desc
+    from control_box_rst_amd import capi
+    rng = np.random.default_rng(31000 + seed)
+    fam, d = random_desc(rng)
+    B = 2
+    x0 = rng.uniform(-1, 1, (B, d.nx))
+    xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2, 0.0])[: d.nx] if fam not in ("dint", "int3t") else np.array([1.0, 0.0, 0.0])[: d.nx])
+    if fam == "rocket":
+        x0[:, 2] = rng.uniform(0.9, 1.1, B)
+        xf[:, 2] = rng.uniform(0.8, 1.0, B)
+    s = BatchedLevenbergMarquardt(d, B)
+    X0 = s.init_trajectory(x0, xf) + 0.05 * rng.normal(size=(B, s.dims.nv))
+    X0[:, : d.nx] = x0
+    if d.grid == capi.GRID_FD_VARIABLE:
+        X0[:, -1] = d.dt_ref
+    s.set_instance_data(X0, xref=xf)
+    lower = bool(seed % 2)
+    me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
+    mi = rng.uniform(0.1, 0.6, (B, max(1, s.dims.ineq)))[:, : s.dims.ineq]
+    mobj = float(rng.uniform(0.5, 2.0))
+    st = s.hessian_structure(lower)
+    vals = s.eval_hessians(lower, mobj, me, mi if s.dims.ineq else None)
+    rows, cols, lv, lbA, ubA = s.linear_form()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        ref = p.hessians(int(lower), mobj, me[b], mi[b] if s.dims.ineq else None)
+        for c in range(3):
+            assert np.array_equal(st[c][0], ref[c][0]) and np.array_equal(st[c][1], ref[c][1]), (seed, fam, c)
+            if len(ref[c][2]):
+                assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (seed, fam, b, c)
+        p.set_data(X0[b], xref=xf[b])
+        r2, c2, v2, l2, u2 = p.linear_form()
+        assert np.array_equal(rows, r2) and np.array_equal(cols, c2), (seed, fam)
+        assert np.abs(lv[b] - v2).max() <= 2e-6 * max(1.0, np.abs(v2).max()), (seed, fam, b)
+        fin = np.abs(l2) < 1e29
+        assert np.array_equal(np.abs(lbA[b]) < 1e29, fin)
+        if fin.any():
+            assert np.abs(lbA[b][fin] - l2[fin]).max() <= 1e-11 * max(1.0, np.abs(l2[fin]).max()), (seed, fam, b)
+        fu = np.abs(u2) < 1e29
+        if fu.any():
+            assert np.abs(ubA[b][fu] - u2[fu]).max() <= 1e-11 * max(1.0, np.abs(u2[fu]).max()), (seed, fam, b)
