@@ -458,3 +458,27 @@ def test_per_instance_bounds_must_keep_the_descriptors_finiteness_pattern():
     lb[0, 2], ub[0, 2] = -capi.INF, capi.INF          # ... and a bounded control loses its bounds
     with pytest.raises(Exception, match="finiteness pattern"):
         s.set_instance_data(X0, lb=lb, ub=ub)
+
+
+def test_device_sincos():
+    """The device's sin / cos (what the dynamics models call) against the host libm, through corbo_hip_eval_dynamics on the unicycle
+    (f = (u1 cos th, u1 sin th, u2), u1 = 1): within one unit in the last place of 1.0 in absolute terms everywhere, bit-equal for most
+    arguments -- the "<= 1-2 ulp where sin / cos enter" of DESIGN.md 4, measured."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    th = np.concatenate([rng.uniform(-100, 100, 20000), rng.uniform(-1e4, 1e4, 5000), np.arange(-50, 50) * np.pi / 2 + rng.uniform(-1e-9, 1e-9, 100),
+                         rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, 1e5 - 1.0, 1e5 + 1.0, 3e7, -2.5e9, 1e300]])
+    n = len(th)
+    d = problems.unicycle_desc(N=5)
+    x = np.zeros((n, 3)); x[:, 2] = th
+    u = np.zeros((n, 2)); u[:, 0] = 1.0
+    f = np.zeros((n, 3))
+    lib = capi.load()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.corbo_hip_eval_dynamics(C.byref(d), n, dp(x), dp(u), dp(f)) == 0
+    c_ref, s_ref = np.cos(th), np.sin(th)
+    assert np.abs(f[:, 0] - c_ref).max() <= 2.3e-16 and np.abs(f[:, 1] - s_ref).max() <= 2.3e-16
+    assert (f[:, 0] == c_ref).mean() > 0.9 and (f[:, 1] == s_ref).mean() > 0.9
+    x[:, 2] = np.nan
+    assert lib.corbo_hip_eval_dynamics(C.byref(d), n, dp(x), dp(u), dp(f)) == 0
+    assert np.isnan(f[:, 0]).all() and np.isnan(f[:, 1]).all()
