@@ -402,6 +402,18 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationPro
     return true;
 }
 
+bool LevenbergMarquardtSparseHip::computeGradientObjective(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> gradient, double* obj_value)
+{
+    if (!attach(problem, _handle == nullptr)) return false;
+    if (gradient.size() != _dims.n) { PRINT_ERROR("LevenbergMarquardtSparseHip(): gradient vector of the wrong size."); return false; }
+    if (corbo_hip_eval_objective_gradient(_handle, gradient.data(), obj_value) != CORBO_HIP_OK)
+    {
+        PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
 bool LevenbergMarquardtSparseHip::computeSparseHessiansValues(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> values_obj,
                                                               Eigen::Ref<Eigen::VectorXd> values_eq, Eigen::Ref<Eigen::VectorXd> values_ineq, double multiplier_obj,
                                                               const double* multipliers_eq, const double* multipliers_ineq, bool lower_part_only)

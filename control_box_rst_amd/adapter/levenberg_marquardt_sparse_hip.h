@@ -70,6 +70,8 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     bool computeSparseHessiansStructure(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXi> i_row_obj, Eigen::Ref<Eigen::VectorXi> j_col_obj,
                                         Eigen::Ref<Eigen::VectorXi> i_row_eq, Eigen::Ref<Eigen::VectorXi> j_col_eq, Eigen::Ref<Eigen::VectorXi> i_row_ineq,
                                         Eigen::Ref<Eigen::VectorXi> j_col_ineq, bool lower_part_only = false);
+    // eval_grad_f / eval_f: OptimizationProblemInterface::computeGradientObjective (+ computeValueObjective into *obj_value if given)
+    bool computeGradientObjective(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> gradient, double* obj_value = nullptr);
     bool computeSparseHessiansValues(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> values_obj, Eigen::Ref<Eigen::VectorXd> values_eq,
                                      Eigen::Ref<Eigen::VectorXd> values_ineq, double multiplier_obj = 1.0, const double* multipliers_eq = nullptr,
                                      const double* multipliers_ineq = nullptr, bool lower_part_only = false);

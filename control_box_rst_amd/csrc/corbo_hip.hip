@@ -1248,6 +1248,39 @@ try {
 }
 ABI_CATCH
 
+int corbo_hip_eval_objective_gradient(corbo_hip_handle h, double* grad, double* obj)
+try {
+    if (!h || !grad) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    ON_DEVICE_OF(h);
+    HessianStructure H;
+    HessParams hp;
+    DevBuf d_so, d_lo, d_g, d_o;
+    int rc = hessian_common(h, H, false, hp, d_so, d_lo);
+    if (rc) return rc;
+    const size_t B = (size_t)h->active, n = (size_t)h->S.dims.n, N = (size_t)h->S.N;
+    HIP_TRY(d_g.alloc(B * n * sizeof(double)));
+    HIP_TRY(d_o.alloc(B * N * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(d_g.p, 0, B * n * sizeof(double), h->stream));
+    hp.mode = 2;
+    hp.grad = d_g.d(); hp.obj_part = d_o.d(); hp.n_params = (int32_t)n;
+    const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
+    if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(grad, d_g.p, B * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (obj) {
+        std::vector<double> part(B * N);
+        HIP_TRY(hipMemcpy(part.data(), d_o.p, B * N * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < B; ++b) {   // in edge order: stages 0 .. N-2, then the final cost
+            double v = 0.0;
+            for (size_t k = 0; k < N; ++k) v += part[b * N + k];
+            obj[b] = v;
+        }
+    }
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
 int corbo_hip_linear_form_structure(const corbo_hip_problem_desc* desc, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols)
 try {
     if (!desc) return fail(CORBO_HIP_ERR_INVALID, "null argument");

@@ -3047,6 +3047,36 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
             next = out + n;
         }
     }
+    else if (hp.mode == 2) {
+        // computeGradientObjective: per least-squares edge the Jacobian block, then the values, gradient += (2 values^T) J; the stage's
+        // share of computeValueObjective.  Every component belongs to exactly one lane: no atomics.
+        double* gr = hp.grad + (size_t)b * hp.n_params;
+        int kinds[3], n_edges = 0;
+        if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = EK_FINAL_COST; }
+        else if (hp.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ) { if (k == 0) { kinds[n_edges++] = EK_DT_COST; kinds[n_edges++] = EK_DT_COST; } }
+        else if (hp.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) { kinds[n_edges++] = EK_STATE_COST; kinds[n_edges++] = EK_CONTROL_COST; }
+        double obj = 0.0;
+        for (int e = 0; e < n_edges; ++e) {
+            const int kind = kinds[e], ed = HE::edge_dim(kind), off = HE::vert_off(kind, 0), dim = HE::vert_dim(kind, 0);
+            double blk[HE::MAXD * HE::MAXD], vals[HE::MAXD];
+            const int nu_ = HE::unfixed(fm, off, dim);
+            if (nu_ > 0) HE::jacobian(kind, 0, fm, xl, xr, p.mp, blk);
+            HE::values(kind, xl, xr, p.mp, vals);
+            int col = 0;
+            for (int i = 0; i < dim; ++i) {
+                if ((fm >> (off + i)) & 1u) continue;
+                double acc = 0.0;
+                for (int r = 0; r < ed; ++r) acc += (2.0 * vals[r]) * blk[col * ed + r];
+                const int v = (kind == EK_DT_COST) ? p.off_dt : k * S + off + i;
+                gr[p.comp[v].param] += acc;
+                ++col;
+            }
+            double sq = 0.0;
+            for (int r = 0; r < ed; ++r) sq += vals[r] * vals[r];
+            obj += sq;
+        }
+        hp.obj_part[(size_t)b * p.N + k] = obj;
+    }
     else {
         const int32_t* lo = hp.lin_off + (size_t)k * 2;
         const int rows = hp.eq_dim + hp.ineq_dim + hp.n_bounds;

@@ -109,7 +109,7 @@ struct FactorParams {
 
 // Operators of the exact-Hessian path, evaluated at the accepted iterate of every instance (hessian_kernel):
 // mode 0: the value lists of computeSparseHessiansValues (objective / equalities / inequalities); mode 1: the two-side-bounded linear
-// form (values, lbA, ubA).  Structure: build_hessian_structure (structure.hpp).
+// form (values, lbA, ubA); mode 2: gradient and value of the objective.  Structure: build_hessian_structure (structure.hpp).
 struct HessParams {
     int32_t mode, lower;
     double mult_obj;
@@ -125,6 +125,10 @@ struct HessParams {
     double* ubA;
     int32_t lin_nnz, lin_bounds0, bnd_row0, n_bounds;
     int32_t stage_cost, stage_ineq;   // corbo_hip_cost / corbo_hip_ineq of the descriptor
+    // mode 2: gradient of the least-squares objective, computeGradientObjective (hyper_graph_optimization_problem_edge_based.cpp:31-102)
+    double* grad;               // [batch][n], zeroed by the caller (every parameter is written by the one lane that owns its component)
+    double* obj_part;           // [batch][N]: the stage's share of computeValueObjective (sum of the squared norms of its cost edges)
+    int32_t n_params;
 };
 bool launch_hessian(const corbo_hip_problem_desc& d, const SweepParams& sp, const HessParams& hp, hipStream_t stream);
 

@@ -277,6 +277,12 @@ class BatchedLevenbergMarquardt:
         self._check(rc, "corbo_hip_eval_hessians")
         return vals
 
+    def objective_gradient(self):
+        """computeGradientObjective [B][n] and computeValueObjective [B] at the resident iterates (eval_grad_f / eval_f of an interior-point solver)."""
+        grad, obj = np.zeros((self.batch, self.dims.n)), np.zeros(self.batch)
+        self._check(self.lib.corbo_hip_eval_objective_gradient(self._h, _dp(grad), _dp(obj)), "corbo_hip_eval_objective_gradient")
+        return grad, obj
+
     def linear_form(self):
         """lbA <= A dx <= ubA of the QP interface at the resident iterates: rows, cols (structure), vals [B][nnz], lbA, ubA [B][rows]."""
         nnz, nrows = C.c_int32(0), C.c_int32(0)

@@ -363,6 +363,12 @@ int corbo_hip_hessian_structure(const corbo_hip_problem_desc* desc, int lower_pa
  * vals_* [batch][nnz of the list] */
 int corbo_hip_eval_hessians(corbo_hip_handle h, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq, double* vals_obj,
                             double* vals_eq, double* vals_ineq);
+/* The first-order callbacks of the same interface (IpoptWrapper::eval_grad_f / eval_f, nlp_solver_ipopt_wrapper.cpp:128-169):
+ * computeGradientObjective (hyper_graph_optimization_problem_edge_based.cpp:31-102) -> grad [batch][n], and computeValueObjective
+ * (hyper_graph_optimization_problem_base.cpp:127-161) -> obj [batch] (may be NULL).  eval_g / eval_jac_g are covered by
+ * corbo_hip_eval_linear_form: the constraint values are -lbA (equalities) and -ubA (inequalities), the Jacobian list of
+ * computeCombinedSparseJacobiansValues(false, true, true) is the linear form's value list without the bound rows, same order. */
+int corbo_hip_eval_objective_gradient(corbo_hip_handle h, double* grad, double* obj);
 /* lbA <= A dx <= ubA with the finite bounds as identity rows: structure (rows / cols may be NULL for the size query), then
  * vals [batch][nnz], lbA / ubA [batch][n_rows].  (ubA of a bound row is x - ub, as the reference computes it.) */
 int corbo_hip_linear_form_structure(const corbo_hip_problem_desc* desc, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols);

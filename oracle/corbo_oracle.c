@@ -929,6 +929,7 @@ int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_b, doubl
 /* (nlp_solver_ipopt_wrapper.cpp:249-271) and the two-side-bounded linear form of the QP interface.               */
 
 #define O_MAX_BLOCK (CORBO_HIP_MAX_NX * CORBO_HIP_MAX_NX)
+static double squared_norm(const double* v, int n);
 
 /* BaseEdge::computeHessian / computeHessianInc with a precomputed Jacobian block (edge_interface.cpp:151-255): forward differences
  * (HESSIAN_DELTA = 1e-2, :32) of the central-difference Jacobian of vertex i with respect to the components of vertex j, the vertex
@@ -1115,6 +1116,44 @@ int oracle_linear_form(oracle_problem* p, int32_t* nnz_out, int32_t* rows, int32
             lbA[rowb0 + i] = p->lb[o] - p->x[o];
             ubA[rowb0 + i] = p->x[o] - p->ub[o];
         }
+    }
+    return 0;
+}
+
+/* The first-order callbacks of IpoptWrapper (nlp_solver_ipopt_wrapper.cpp:128-230) at the current x: computeGradientObjective
+ * (hyper_graph_optimization_problem_edge_based.cpp:31-102: per least-squares edge the central-difference Jacobian block, THEN the
+ * edge values -- at the point the in-place differences left -- and gradient += (2 values^T) J), then computeValueObjective
+ * (hyper_graph_optimization_problem_base.cpp:127-161: sum of the edges' squared norms).  eval_g / eval_jac_g are the constraint values
+ * and the unweighted constraint Jacobian: oracle_linear_form (lbA = -c_eq, ubA = -c_ineq, the value list without the bound rows). */
+int oracle_objective_gradient(oracle_problem* p, double* grad, double* obj_out)
+{
+    if (!p || p->gen || !grad) return CORBO_HIP_ERR_INVALID;
+    for (int i = 0; i < p->dims.n; ++i) grad[i] = 0.0;
+    double blk[O_MAX_BLOCK], vals[CORBO_HIP_MAX_NX];
+    for (int ei = 0; ei < p->n_edges; ++ei) {
+        const o_edge* e = &p->e[ei];
+        if (e->scale != 0) continue;
+        for (int vi = 0; vi < e->nverts; ++vi) {
+            const o_vertex* a = &p->v[e->vert[vi]];
+            if (a->n_unfixed == 0) continue;
+            edge_jacobian(p, e, vi, blk);
+            edge_values(p, e, vals);
+            for (int c = 0; c < a->n_unfixed; ++c) {
+                double acc = 0.0;
+                for (int r = 0; r < e->dim; ++r) acc += (2.0 * vals[r]) * blk[c * e->dim + r];
+                grad[a->col + c] += acc;
+            }
+        }
+    }
+    if (obj_out) {
+        double value = 0.0;
+        for (int ei = 0; ei < p->n_edges; ++ei) {
+            const o_edge* e = &p->e[ei];
+            if (e->scale != 0) continue;
+            edge_values(p, e, vals);
+            value += squared_norm(vals, e->dim);
+        }
+        *obj_out = value;
     }
     return 0;
 }

@@ -77,6 +77,8 @@ int oracle_hessian_values(oracle_problem* p, int lower_part_only, double mult_ob
                           double* vals_obj, double* vals_eq, double* vals_ineq);
 /* lbA <= A dx <= ubA: computeSparseJacobianTwoSideBoundedLinearForm* with the finite bounds (:4762-4968) and
  * computeBoundsForTwoSideBoundedLinearForm (optimization_problem_interface.cpp:1141-1183).  Any output may be NULL. */
+/* eval_grad_f / eval_f of the interior-point interface: computeGradientObjective (n entries) and computeValueObjective */
+int oracle_objective_gradient(oracle_problem* p, double* grad, double* obj_out);
 int oracle_linear_form(oracle_problem* p, int32_t* nnz_out, int32_t* rows, int32_t* cols, double* vals, double* lbA, double* ubA);
 
 /* LevenbergMarquardtSparse::solve.  Returns corbo_hip_solver_status; *chi2_out = *obj_value.

@@ -379,6 +379,15 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
             hg->computeSparseHessiansStructure(ri[0], rj[0], ri[1], rj[1], ri[2], rj[2], true);
             hg->computeSparseHessiansValues(rv[0], rv[1], rv[2], mobj, meq.data(), ineq ? mineq.data() : nullptr, true);
             r.hess_rel = 0;
+            {   // eval_grad_f / eval_f next to the graph's own computeGradientObjective / computeValueObjective
+                Eigen::VectorXd gd(n), gr(n);
+                double od = 0;
+                r.hess_ok = r.hess_ok && hip->computeGradientObjective(*hg, gd, &od);
+                hg->computeGradientObjective(gr);
+                const double orf = hg->computeValueObjective();
+                r.hess_rel = std::max(r.hess_rel, (gd - gr).cwiseAbs().maxCoeff() / std::max(1.0, gr.cwiseAbs().maxCoeff()));
+                r.hess_rel = std::max(r.hess_rel, std::abs(od - orf) / std::max(1.0, std::abs(orf)));
+            }
             for (int c = 0; c < 3; ++c)
             {
                 if (rn[c] == 0) continue;

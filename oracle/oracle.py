@@ -57,6 +57,7 @@ def load():
     lib.oracle_hessian_structure.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, ip, ip]
     lib.oracle_hessian_values.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, dp, dp, dp]
     lib.oracle_linear_form.argtypes = [C.c_void_p, i3, ip, ip, dp, dp, dp]
+    lib.oracle_objective_gradient.argtypes = [C.c_void_p, dp, dp]
     lib.oracle_create_generic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, GENERIC_FUN]
     lib.oracle_create_generic.restype = C.c_void_p
     _lib = lib
@@ -142,6 +143,13 @@ class OracleProblem:
         mi = None if mult_ineq is None or len(mult_ineq) == 0 else np.ascontiguousarray(mult_ineq, np.float64)
         assert self.lib.oracle_hessian_values(self.h, int(lower), float(mult_obj), _dp(me), _dp(mi), _dp(vals[0]), _dp(vals[1]), _dp(vals[2])) == 0
         return [(rows[i][:nnz[i]], cols[i][:nnz[i]], vals[i][:nnz[i]]) for i in range(3)]
+
+    def objective_gradient(self):
+        """computeGradientObjective (n) and computeValueObjective at the current x."""
+        g = np.zeros(self.dims.n)
+        obj = C.c_double(0)
+        assert self.lib.oracle_objective_gradient(self.h, _dp(g), C.byref(obj)) == 0
+        return g, obj.value
 
     def linear_form(self):
         """computeSparseJacobianTwoSideBoundedLinearForm* (with the finite bounds) and its bounds: rows, cols, values, lbA, ubA."""

@@ -981,6 +981,22 @@ static int hess(const Scenario& s)
         printIVec("lin_rows", ir); printIVec("lin_cols", jc); printVec("lin_vals", va);
         printVec("lin_lbA", lbA); printVec("lin_ubA", ubA);
     }
+    {   // the other callbacks of IpoptWrapper (nlp_solver_ipopt_wrapper.cpp:128-230): eval_f, eval_grad_f, eval_g, eval_jac_g
+        Eigen::VectorXd grad(n);
+        hg.computeGradientObjective(grad);
+        printVec("grad_obj", grad);
+        printf("\"obj_value\": %.17g,\n", hg.computeValueObjective());
+        Eigen::VectorXd g(eq + ineq);
+        if (eq) hg.computeValuesEquality(g.head(eq));
+        if (ineq) hg.computeValuesInequality(g.tail(ineq));
+        printVec("g_values", g);
+        const int nj = hg.computeCombinedSparseJacobiansNNZ(false, true, true);
+        Eigen::VectorXi ir(nj), jc(nj);
+        Eigen::VectorXd vj(nj);
+        hg.computeCombinedSparseJacobiansStructure(ir, jc, false, true, true);
+        hg.computeCombinedSparseJacobiansValues(vj, false, true, true);
+        printIVec("jacg_rows", ir); printIVec("jacg_cols", jc); printVec("jacg_vals", vj);
+    }
     printVec("vertex_after", vertexValues(b, s), false);   // (the in-place perturbations of the finite differences leave the point a few ulps off)
     printf("}\n");
     return 0;

@@ -67,6 +67,15 @@ def test_linear_form_vs_reference(name):
     rows, cols, vals, lbA, ubA = s.linear_form()
     assert np.array_equal(rows, np.array(g["lin_rows"], np.int32)) and np.array_equal(cols, np.array(g["lin_cols"], np.int32))
     gv, gl, gu = np.array(g["lin_vals"]), np.array(g["lin_lbA"]), np.array(g["lin_ubA"])
+    # eval_grad_f / eval_f of the interior-point interface (computeGradientObjective, computeValueObjective)
+    grad, obj = s.objective_gradient()
+    gg = np.array(g["grad_obj"])
+    for b in range(s.batch):
+        assert np.abs(grad[b] - gg).max() <= 1e-6 * max(1.0, np.abs(gg).max()), (name, b)   # 2 v J: J's finite-difference noise (1e-7) times v
+        assert abs(obj[b] - g["obj_value"]) <= 1e-13 * max(1.0, abs(g["obj_value"])), (name, b)
+    # eval_g: the constraint values are -lbA / -ubA; eval_jac_g: the value list without the bound rows
+    gcon, eq = np.array(g["g_values"]), s.dims.eq
+    assert np.abs(-lbA[0][:eq] - gcon[:eq]).max() <= 1e-12 * max(1.0, np.abs(gcon).max())
     for b in range(s.batch):
         # Jacobian blocks: central differences at a point a few ulps away from the reference's drifted one
         assert np.abs(vals[b] - gv).max() <= 2e-6 * max(1.0, np.abs(gv).max()), (name, b)
@@ -158,6 +167,7 @@ def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
     st = s.hessian_structure(lower)
     vals = s.eval_hessians(lower, mobj, me, mi if s.dims.ineq else None)
     rows, cols, lv, lbA, ubA = s.linear_form()
+    grad, obj = s.objective_gradient()
     for b in range(B):
         p = oracle_mod.OracleProblem(d)
         p.set_data(X0[b], xref=xf[b])
@@ -166,6 +176,10 @@ def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
             assert np.array_equal(st[c][0], ref[c][0]) and np.array_equal(st[c][1], ref[c][1]), (seed, fam, c)
             if len(ref[c][2]):
                 assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (seed, fam, b, c)
+        p.set_data(X0[b], xref=xf[b])
+        go, oo = p.objective_gradient()
+        assert np.abs(grad[b] - go).max() <= 1e-6 * max(1.0, np.abs(go).max()), (seed, fam, b)
+        assert abs(obj[b] - oo) <= 1e-12 * max(1.0, abs(oo)), (seed, fam, b)
         p.set_data(X0[b], xref=xf[b])
         r2, c2, v2, l2, u2 = p.linear_form()
         assert np.array_equal(rows, r2) and np.array_equal(cols, c2), (seed, fam)

@@ -36,6 +36,21 @@ def test_hessian_triplets_and_linear_form_bit_exact(oracle_mod, name):
     assert np.array_equal(r, g["lin_rows"]) and np.array_equal(c, g["lin_cols"])
     assert np.array_equal(v, np.array(g["lin_vals"]))
     assert np.array_equal(lbA, np.array(g["lin_lbA"])) and np.array_equal(ubA, np.array(g["lin_ubA"]))
+    # the first-order callbacks of IpoptWrapper: eval_grad_f / eval_f (computeGradientObjective, computeValueObjective) ...
+    grad, obj = p.objective_gradient()
+    assert np.array_equal(grad, np.array(g["grad_obj"])), np.abs(grad - np.array(g["grad_obj"])).max()
+    assert abs(obj - g["obj_value"]) <= 4e-16 * abs(g["obj_value"])   # (Eigen's squaredNorm sums in packets)
+    # ... eval_g / eval_jac_g = the linear form: constraint values are -lbA (equalities) / -ubA (inequalities), the Jacobian list is the
+    # linear form's without the bound rows, same entry order
+    r2, c2, v2, l2, u2 = p.linear_form()
+    eq, ineq = p.dims.eq, p.dims.ineq
+    gv = np.array(g["g_values"])
+    # (values: the oracle evaluates them behind the Jacobian blocks of the same call, the fixture before -- a few ulps of drift apart)
+    assert np.abs(-l2[:eq] - gv[:eq]).max() <= 1e-14 * max(1.0, np.abs(gv).max())
+    if ineq:
+        assert np.abs(-u2[eq:eq + ineq] - gv[eq:]).max() <= 1e-14 * max(1.0, np.abs(gv).max())
+    nj = len(g["jacg_vals"])
+    assert np.array_equal(r2[:nj], g["jacg_rows"]) and np.array_equal(c2[:nj], g["jacg_cols"]) and np.array_equal(v2[:nj], np.array(g["jacg_vals"]))
     assert np.array_equal(p.x(), np.array(g["vertex_after"])[:p.dims.nv])   # the drift of the in-place perturbations, reproduced
 
 
