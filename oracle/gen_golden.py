@@ -154,6 +154,15 @@ def tvref():
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))
         print(name, d["n"], d["m"], [a["chi2"] for a in d["after_iter"]][-1])
+    # tracking closed loops: the reference trajectory is sampled at t + k dt, so every control step sees a shifted window of it
+    for name, kv in [
+        ("loop_unicycle_tvref", dict(scenario="unicycle", N=20, steps=6, iters=5, shift=1, integrator="rk4", xref_traj=1)),
+        ("loop_vdp_tvref", dict(scenario="vdp", steps=5, iters=5, shift=1, integrator="euler", xref_traj=1)),
+    ]:
+        d = run("loop", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, [round(st["chi2"], 6) for st in d["steps"]])
     for name, kv in [("hess_unicycle_tvref", dict(scenario="unicycle", N=12, xref_traj=1))]:
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

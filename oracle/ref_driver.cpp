@@ -884,6 +884,7 @@ static int loop(const Scenario& s, std::map<std::string, std::string>& kv)
         plant.output(after, t);
         printf("{\"ok\": %d, \"chi2\": %.17g, ", ok ? 1 : 0, b.ocp->getCurrentObjectiveValue());
         printVec("x0", y);
+        printReferences(b, s);   // (time-varying reference: what getReferenceCached handed out at this control step)
         printVec("vertex", v);
         {   // the interval the plant really integrates over: its time-stamped control buffer hands out (t + dt) - t, rounded
             // (systems/src/time_value_buffer.cpp:68-73), e.g. 0.10000000000000003 at t = 0.2

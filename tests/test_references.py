@@ -149,3 +149,42 @@ def test_device_references_per_instance_and_hessians(oracle_mod):
     for c, key in enumerate(("hobj", "heq")):
         gv = np.array(g[f"{key}_vals_lower"])
         assert np.abs(vals[c][1] - gv).max() <= 2e-4 * max(1.0, np.abs(gv).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["loop_unicycle_tvref", "loop_vdp_tvref"])
+def test_tracking_closed_loop_vs_reference(name):
+    """Tracking MPC: the reference's closed loop (SimulatedPlant, warm start with shifting) with a DiscreteTimeReferenceTrajectory sampled
+    at t + k dt -- every control step sees a shifted window of it.  On the device: plant step, warm start from the plant, the step's
+    references (corbo_hip_set_references), solve; every step against the genuine reference."""
+    import ctypes as C
+    from control_box_rst_amd import capi as cp
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    g = load_golden(name)
+    d = desc_for(g)
+    B = 2
+    s = BatchedLevenbergMarquardt(d, B)
+    nv, nx = s.dims.nv, d.nx
+    s.setIterations(g["iters"])
+    s.setPenaltyWeights(*g["weights"])
+    xf = np.tile(np.array(g["xf"]), (B, 1))
+    x0 = np.tile(np.array(g["steps"][0]["x0"]), (B, 1))
+    # cold start of the reference with a time-varying reference: x_k = xref_k, u = 0, x_0 = the measured state
+    X = np.tile(np.array(g["steps"][0]["ref_vertex"])[:nv], (B, 1))
+    X[:, :nx] = x0
+    s.set_instance_data(X, xref=xf)
+    s.plant_set_state(x0)
+    integ = cp.INTEGRATOR_RK4 if g["integrator"] == "rk4" else cp.INTEGRATOR_EULER
+    for k, st in enumerate(g["steps"]):
+        if k > 0:
+            s.warm_start_from_plant(shift=bool(g["shift"]))
+        ref = np.ascontiguousarray(np.tile(np.array(st["ref_vertex"])[:nv], (B, 1)))
+        assert s.lib.corbo_hip_set_references(s._h, ref.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        s.solve(new_run=True)
+        Xs, chi2, status = s.get_solution()
+        want = np.array(st["vertex"])[:nv]
+        for b in range(B):
+            assert np.abs(Xs[b] - want).max() <= 3e-5, (name, k, b, np.abs(Xs[b] - want).max())
+            assert abs(chi2[b] - st["chi2"]) <= 2e-6 * abs(st["chi2"]), (name, k, b)
+        s.plant_step(dt=st["plant_dt"], integrator=integ, disturbance=np.tile(np.array(st["disturbance"]), (B, 1)))
+        assert np.abs(s.plant_get_state() - np.array(st["plant_after"])).max() <= 3e-5, (name, k)
