@@ -125,6 +125,8 @@ struct corbo_hip_solver {
     double *d_x = nullptr, *d_xt = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_xref = nullptr;
     double* d_refvec = nullptr;   // per-component references [batch][nvs] (corbo_hip_set_references), allocated on first use
     bool refvec_on   = false;
+    double* d_reftraj = nullptr;  // resident reference trajectory [batch][ref_T][nx] (corbo_hip_set_reference_trajectory)
+    int ref_T = 0, ref_step = 0;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
     LmState* d_state      = nullptr;
     double* d_chi2        = nullptr;  // [batch]
@@ -391,7 +393,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_refvec};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_refvec, h->d_reftraj};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -699,6 +701,7 @@ try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
     h->sink_valid = false;
+    h->ref_T = 0;   // (an explicit set of references ends the stepping of a resident reference trajectory)
     if (!ref) { h->refvec_on = false; return CORBO_HIP_OK; }   // back to the static state reference of corbo_hip_set_instance_data
     const Structure& S = h->S;
     const size_t B = (size_t)h->active, nv = (size_t)S.dims.nv, nvs = (size_t)S.nvs;
@@ -712,6 +715,34 @@ try {
                     return fail(CORBO_HIP_ERR_INVALID, "corbo_hip_set_references: non-zero control reference (the reference's least-squares control term is not defined for one, quadratic_cost.cpp:160-163)");
     }
     HIP_TRY(hipMemcpyAsync(h->d_refvec, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->refvec_on = true;
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_set_reference_trajectory(corbo_hip_handle h, const double* traj, int T, int step)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    h->sink_valid = false;
+    const Structure& S = h->S;
+    if (!traj) {   // back to the static reference
+        if (h->d_reftraj) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->d_reftraj); h->d_reftraj = nullptr; }
+        h->ref_T = 0; h->ref_step = 0; h->refvec_on = false;
+        return CORBO_HIP_OK;
+    }
+    if (T < 1 || step < 0) return fail(CORBO_HIP_ERR_INVALID, "corbo_hip_set_reference_trajectory: T >= 1 and step >= 0");
+    const size_t B = (size_t)h->batch, bytes = B * (size_t)T * S.nx * sizeof(double);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_reftraj) { (void)hipFree(h->d_reftraj); h->d_reftraj = nullptr; }
+    HIP_TRY(hipMalloc((void**)&h->d_reftraj, bytes));
+    HIP_TRY(hipMemcpy(h->d_reftraj, traj, bytes, hipMemcpyHostToDevice));
+    if (!h->d_refvec) HIP_TRY(hipMalloc((void**)&h->d_refvec, B * (size_t)S.nvs * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->d_refvec, 0, B * (size_t)S.nvs * sizeof(double), h->stream));   // control / dt entries: zero
+    h->ref_T = T; h->ref_step = step;
+    launch_reference_window(h->d_reftraj, h->d_refvec, h->batch, T, S.N, S.nx, S.s, S.nvs, step, h->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->refvec_on = true;
     return CORBO_HIP_OK;
@@ -871,6 +902,11 @@ try {
         if (!launch_plant_step(S.desc, pp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no plant kernel for this dynamics");
         HIP_TRY(hipGetLastError());
         if (int rc = warm_start_from(h, h->d_xplant, shift)) return rc;
+        if (h->d_reftraj && h->ref_T > 0) {   // tracking: the next control step sees the reference trajectory one sample further on
+            ++h->ref_step;
+            launch_reference_window(h->d_reftraj, h->d_refvec, h->batch, h->ref_T, S.N, S.nx, S.s, S.nvs, h->ref_step, h->stream);
+            HIP_TRY(hipGetLastError());
+        }
         for (int it = 0; it < ocp_iterations; ++it) {
             const int new_run = (it == 0) ? 1 : 0;
             if (!rtc) {

@@ -3342,6 +3342,21 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
 #endif  // CORBO_HIP_DYN_TU
 
 #ifndef CORBO_HIP_DYN_TU
+__global__ __launch_bounds__(256) void reference_window_kernel(const double* __restrict__ traj, double* __restrict__ refvec, int batch, int T, int N, int nx,
+                                                               int s, int nvs, int step)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= batch * N * nx) return;
+    const int b = t / (N * nx), r = t - b * (N * nx), k = r / nx, i = r - k * nx;
+    const int smp = (step + k < T - 1) ? step + k : T - 1;
+    refvec[(size_t)b * nvs + (size_t)k * s + i] = traj[((size_t)b * T + smp) * nx + i];
+}
+
+void launch_reference_window(const double* traj, double* refvec, int batch, int T, int N, int nx, int s, int nvs, int step, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reference_window_kernel, dim3((batch * N * nx + 255) / 256), dim3(256), 0, stream, traj, refvec, batch, T, N, nx, s, nvs, step);
+}
+
 __global__ __launch_bounds__(256) void broadcast_rows_kernel(const double* __restrict__ row_a, const double* __restrict__ row_b,
                                                              double* __restrict__ dst_a, double* __restrict__ dst_b, int nvs)
 {

@@ -158,6 +158,9 @@ struct ResampleParams {
     const int32_t* dst_index;
 };
 void launch_resample(const ResampleParams& p, hipStream_t stream);
+// refvec[b][x_k entries] = traj[b][min(step + k, T - 1)] for k = 0 .. N-1 (the window of a resident reference trajectory that control step
+// `step` sees: DiscreteTimeReferenceTrajectory sampled at t + k dt, the last sample held beyond its end); other entries are left alone
+void launch_reference_window(const double* traj, double* refvec, int batch, int T, int N, int nx, int s, int nvs, int step, hipStream_t stream);
 // dt_out[b] = x[b][off_dt]  (packed; dt_out may be device-visible pinned host memory)
 void launch_gather_dt(const double* x, double* out, int nvs, int off_dt, int batch, hipStream_t stream);
 // the plant side of a closed loop (SimulatedPlant::control, plants/src/simulated_plant.cpp:97-160, no dead time): one thread per instance

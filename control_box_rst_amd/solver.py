@@ -252,6 +252,16 @@ class BatchedLevenbergMarquardt:
         ref = np.ascontiguousarray(ref)
         self._check(self.lib.corbo_hip_set_references(self._h, _dp(ref)), "corbo_hip_set_references")
 
+    def set_reference_trajectory(self, traj=None, step=0):
+        """Resident tracking reference: traj [B][T][nx] sampled at the grid's dt; control step `step` sees samples step .. step+N-1 and
+        closed_loop() advances the window by one sample per control step.  None: static reference again."""
+        if traj is None:
+            self._check(self.lib.corbo_hip_set_reference_trajectory(self._h, None, 0, 0), "corbo_hip_set_reference_trajectory")
+            return
+        tr = np.ascontiguousarray(np.broadcast_to(np.asarray(traj, np.float64), (self.batch,) + np.asarray(traj).shape[-2:]))
+        assert tr.shape[2] == self.desc.nx
+        self._check(self.lib.corbo_hip_set_reference_trajectory(self._h, _dp(tr), int(tr.shape[1]), int(step)), "corbo_hip_set_reference_trajectory")
+
     def hessian_structure(self, lower_part_only=True):
         """Three (rows, cols) pairs -- objective, equalities, inequalities -- of computeSparseHessiansStructure, in the reference's order."""
         nnz = np.zeros(3, np.int32)

@@ -218,6 +218,12 @@ int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const doubl
  * Stays in force until the next call; NULL returns to the static reference of corbo_hip_set_instance_data.  The moving-horizon shift
  * does not move references: a caller that advances time uploads the references of the new grid. */
 int corbo_hip_set_references(corbo_hip_handle h, const double* ref);
+/* The same for a whole tracking run, resident on the device: traj [batch][T][nx] = the state reference sampled at the grid's dt
+ * (DiscreteTimeReferenceTrajectory with one sample per dt, zero-order hold; the last sample is held beyond the end,
+ * core/include/corbo-core/reference_trajectory.h:383-400).  Control step `step` sees samples step .. step + N - 1; the call sets the
+ * window of `step`, and every control step of corbo_hip_closed_loop moves it one sample on before its solve (what sampling at
+ * t + k dt does in PredictiveController::step).  NULL ends it (static reference again). */
+int corbo_hip_set_reference_trajectory(corbo_hip_handle h, const double* traj, int T, int step);
 
 /* Re-arm the resident batch: copy the x uploaded by the last corbo_hip_set_instance_data back into the iterate,
  * device to device, asynchronously on the handle's stream (what the grid does when it re-initialises its vertices for a

@@ -188,3 +188,58 @@ def test_tracking_closed_loop_vs_reference(name):
             assert abs(chi2[b] - st["chi2"]) <= 2e-6 * abs(st["chi2"]), (name, k, b)
         s.plant_step(dt=st["plant_dt"], integrator=integ, disturbance=np.tile(np.array(st["disturbance"]), (B, 1)))
         assert np.abs(s.plant_get_state() - np.array(st["plant_after"])).max() <= 3e-5, (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["loop_unicycle_tvref", "loop_vdp_tvref"])
+def test_resident_tracking_loop_vs_reference(name):
+    """The same tracking loops with everything resident: corbo_hip_set_reference_trajectory + ONE corbo_hip_closed_loop call (plant step,
+    warm start, reference window one sample on, solve -- per control step, no host in between) against the genuine reference, and
+    bit-identical to the loop driven step by step with corbo_hip_set_references."""
+    import ctypes as C
+    from control_box_rst_amd import capi as cp
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    g = load_golden(name)
+    d = desc_for(g)
+    B, steps = 2, len(g["steps"])
+    nx, S = d.nx, d.nx + d.nu
+    integ = cp.INTEGRATOR_RK4 if g["integrator"] == "rk4" else cp.INTEGRATOR_EULER
+    r0 = np.array(g["steps"][0]["ref_vertex"])
+    traj = np.array([r0[k * S:k * S + nx] for k in range(d.N)])   # one sample per grid point; the reference holds the last one beyond
+    dist = np.array([np.tile(np.array(st["disturbance"]), (B, 1)) for st in g["steps"][:-1]])
+
+    def fresh():
+        s = BatchedLevenbergMarquardt(d, B)
+        s.setIterations(g["iters"])
+        s.setPenaltyWeights(*g["weights"])
+        X = np.tile(r0[:s.dims.nv], (B, 1))
+        X[:, :nx] = g["steps"][0]["x0"]
+        s.set_instance_data(X, xref=np.tile(np.array(g["xf"]), (B, 1)))
+        s.plant_set_state(np.tile(np.array(g["steps"][0]["x0"]), (B, 1)))
+        return s
+
+    a = fresh()
+    a.set_reference_trajectory(traj, step=0)
+    a.solve(new_run=True)
+    xs, us = a.closed_loop(steps - 1, dt=g["dt"], integrator=integ, shift=bool(g["shift"]), disturbance=dist)
+    Xa, ca, _ = a.get_solution()
+    nv = a.dims.nv
+    for k in range(steps - 1):
+        assert np.abs(xs[k] - np.array(g["steps"][k]["plant_after"])).max() <= 3e-5, (name, k)
+    assert np.abs(Xa[0] - np.array(g["steps"][-1]["vertex"])[:nv]).max() <= 3e-5
+    assert abs(ca[0] - g["steps"][-1]["chi2"]) <= 2e-6 * abs(g["steps"][-1]["chi2"])
+    # step by step with explicit references
+    b = fresh()
+    for k in range(steps):
+        if k > 0:
+            b.plant_step(dt=g["dt"], integrator=integ, disturbance=dist[k - 1])
+            b.warm_start_from_plant(shift=bool(g["shift"]))
+        win = traj[[min(k + j, d.N - 1) for j in range(d.N)]]
+        b.set_references(np.tile(win, (B, 1, 1)))
+        b.solve(new_run=True)
+    Xb, cb, _ = b.get_solution()
+    assert np.array_equal(Xa, Xb) and np.array_equal(ca, cb)
+    a.set_reference_trajectory(None)
+    a.set_instance_data(Xa, xref=np.tile(np.array(g["xf"]), (B, 1)))
+    a.solve(new_run=True)   # (static reference again: still solves)
+    assert np.isfinite(a.get_solution()[1]).all()
