@@ -3232,12 +3232,15 @@ __global__ __launch_bounds__(256) void plant_step_kernel(const PlantParams p)
     for (int i = 0; i < D::NX; ++i) x1[i] = xp[i];
 #pragma unroll
     for (int i = 0; i < D::NU; ++i) u[i] = p.x[(size_t)b * p.nvs + D::NX + i];
+    double prm[8];   // model parameters of THIS plant
+#pragma unroll
+    for (int i = 0; i < 8; ++i) prm[i] = p.dyn_inst ? p.dyn_inst[(size_t)b * 8 + i] : p.dyn[i];
     if (p.integrator == CORBO_HIP_INTEGRATOR_RK4) {
         double ck[4][D::NC];
-        rk4_end_state<DYN, false>(x1, u, p.dt, p.dyn, ck, xe);
+        rk4_end_state<DYN, false>(x1, u, p.dt, prm, ck, xe);
     }
     else {
-        dyn_full<DYN>(x1, u, p.dyn, xe);
+        dyn_full<DYN>(x1, u, prm, xe);
         if (p.integrator == CORBO_HIP_INTEGRATOR_EULER) {
 #pragma unroll
             for (int i = 0; i < D::NX; ++i) { xe[i] *= p.dt; xe[i] += x1[i]; }

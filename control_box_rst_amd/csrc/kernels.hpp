@@ -168,6 +168,8 @@ struct PlantParams {
     int32_t batch, nvs, nx, nu, integrator;   // integrator: corbo_hip_integrator
     double dt;
     double dyn[8];
+    const double* dyn_inst;     // or null: the plant's OWN model parameters per instance [batch][8] (a plant that differs from the controller's
+                                // model: SimulatedPlant takes its own dynamics object, plants/src/simulated_plant.cpp)
     const double* x;            // [batch][nvs] resident trajectories: u_0 = x[b][nx .. nx+nu)
     double* xplant;             // [batch][CORBO_HIP_MAX_NX] plant states, updated in place
     const double* disturbance;  // [batch][CORBO_HIP_MAX_NX] added to the new state (may be pinned host memory), or null

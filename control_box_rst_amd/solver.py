@@ -136,6 +136,14 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_plant_step(self._h, int(integrator), dt, None if d is None else d.ctypes.data_as(C.POINTER(C.c_double))),
                     "corbo_hip_plant_step")
 
+    def plant_set_params(self, params=None):
+        """The plants' own model parameters [B][8] (a plant that differs from the controller's model); None = the controller's again."""
+        if params is None:
+            self._check(self.lib.corbo_hip_plant_set_params(self._h, None), "corbo_hip_plant_set_params")
+            return
+        pr = np.ascontiguousarray(np.broadcast_to(np.asarray(params, np.float64), (self.batch, 8)))
+        self._check(self.lib.corbo_hip_plant_set_params(self._h, _dp(pr)), "corbo_hip_plant_set_params")
+
     def plant_get_state(self) -> np.ndarray:
         x = np.empty((self.batch, self.desc.nx))
         self._check(self.lib.corbo_hip_plant_get_state(self._h, x.ctypes.data_as(C.POINTER(C.c_double))), "corbo_hip_plant_get_state")

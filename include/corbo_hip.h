@@ -280,6 +280,11 @@ int corbo_hip_plant_set_state(corbo_hip_handle h, const double* x);
  * resident trajectory is held over dt, x_plant <- integrator.solveIVP(x_plant, u_0, dt), then the state disturbance: `disturbance`
  * [batch][nx] (host, may be NULL) is ADDED to the new state (what a DisturbanceInterface object does to it, :141).  Asynchronous. */
 int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const double* disturbance);
+/* A plant that differs from the controller's model: SimulatedPlant takes its OWN SystemDynamicsInterface object
+ * (plants/include/corbo-plants/simulated_plant.h), e.g. the same system class with other parameters.  params [batch][8]: the model
+ * parameters (order of the descriptor's dyn_params) of every instance's plant; NULL = the controller's again.  The controller keeps
+ * the descriptor's parameters.  Not for CORBO_HIP_DYN_LINEAR_STATE_SPACE. */
+int corbo_hip_plant_set_params(corbo_hip_handle h, const double* params);
 /* SimulatedPlant::output with FullStateSystemOutput: x_out [batch][nx] (host).  Synchronises. */
 int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out);
 /* corbo_hip_warm_start with x0_new = the device-resident plant states (the measured state a controller is handed). */

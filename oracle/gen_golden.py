@@ -158,6 +158,8 @@ def tvref():
     for name, kv in [
         ("loop_unicycle_tvref", dict(scenario="unicycle", N=20, steps=6, iters=5, shift=1, integrator="rk4", xref_traj=1)),
         ("loop_vdp_tvref", dict(scenario="vdp", steps=5, iters=5, shift=1, integrator="euler", xref_traj=1)),
+        # a plant that is NOT the controller's model: Van der Pol with damping 1.8 (the OCP keeps the default 1)
+        ("loop_vdp_plant_mismatch", dict(scenario="vdp", steps=6, iters=5, shift=1, integrator="rk4", plant_a=1.8)),
     ]:
         d = run("loop", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

@@ -792,6 +792,7 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);
+    if (kv.count("plant_a")) printf("\"plant_a\": %.17g,\n", atof(kv["plant_a"].c_str()));
     printf("\"steps\": [\n");
     Eigen::VectorXd x0 = s.x0;
     for (int st = 0; st < steps; ++st)
@@ -857,7 +858,15 @@ static int loop(const Scenario& s, std::map<std::string, std::string>& kv)
     Built b = build(s, s.iters);
     if (shift && b.grid) b.grid->setWarmStart(true);
     if (shift && b.ms_grid) b.ms_grid->setWarmStart(true);
-    SimulatedPlant plant(b.dyn, std::make_shared<FullStateSystemOutput>());
+    // plant_a=<a>: the plant is a Van der Pol oscillator with ANOTHER damping coefficient than the controller's model
+    SystemDynamicsInterface::Ptr plant_dyn = b.dyn;
+    if (kv.count("plant_a"))
+    {
+        auto pd = std::make_shared<VanDerPolOscillator>();
+        pd->setDampingCoefficient(atof(kv["plant_a"].c_str()));
+        plant_dyn = pd;
+    }
+    SimulatedPlant plant(plant_dyn, std::make_shared<FullStateSystemOutput>());
     if (integ == "rk4") plant.setIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());   // else: the default explicit Euler
     auto disturbance = std::make_shared<DeterministicStateDisturbance>(s.dt, amp);
     plant.setStateDisturbance(disturbance);
@@ -868,6 +877,7 @@ static int loop(const Scenario& s, std::map<std::string, std::string>& kv)
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);
+    if (kv.count("plant_a")) printf("\"plant_a\": %.17g,\n", atof(kv["plant_a"].c_str()));
     printf("\"steps\": [\n");
     for (int st = 0; st < steps; ++st)
     {

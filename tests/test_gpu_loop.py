@@ -211,3 +211,54 @@ def test_long_closed_loop_and_handle_churn_leave_nothing_behind():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert abs(free1 - free0) <= 8 << 20, (free0, free1)   # allocator granularity, not a per-handle leak
+
+
+def test_plant_that_differs_from_the_controllers_model():
+    """corbo_hip_plant_set_params: per-instance model parameters of the PLANT (SimulatedPlant takes its own dynamics object).  Instance 0
+    runs the Van der Pol plant with damping 1.8 against the controller's 1.0 -- every step against the genuine reference's closed loop with
+    that plant (tests/golden/loop_vdp_plant_mismatch.json); instance 1 keeps the nominal plant and follows the nominal loop's first step;
+    one corbo_hip_closed_loop call gives the same as the steps one by one."""
+    g = load_golden("loop_vdp_plant_mismatch")
+    d = desc_for(g)
+    B = 2
+    xf = np.tile(np.array(g["xf"]), (B, 1))
+    x0 = np.tile(np.array(g["steps"][0]["x0"]), (B, 1))
+    prm = np.zeros((B, 8))
+    prm[:] = [d.dyn_params[i] for i in range(8)]
+    prm[0, 0] = g["plant_a"]
+    dist = np.array([np.tile(np.array(st["disturbance"]), (B, 1)) for st in g["steps"]])
+
+    def fresh():
+        s = BatchedLevenbergMarquardt(d, B)
+        s.setIterations(g["iters"])
+        s.setPenaltyWeights(*g["weights"])
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.plant_set_state(x0)
+        s.plant_set_params(prm)
+        return s
+
+    s = fresh()
+    nv = s.dims.nv
+    for k, st in enumerate(g["steps"]):
+        if k > 0:
+            s.warm_start_from_plant(shift=bool(g["shift"]))
+        s.solve(new_run=True)
+        X, chi2, _ = s.get_solution()
+        assert np.abs(X[0] - np.array(st["vertex"])[:nv]).max() <= 5e-6, k
+        assert abs(chi2[0] - st["chi2"]) <= 2e-6 * abs(st["chi2"]), k
+        s.plant_step(dt=st["plant_dt"], integrator=integrator_of(g), disturbance=dist[k])
+        xp = s.plant_get_state()
+        assert np.abs(xp[0] - np.array(st["plant_after"])).max() <= 5e-6, k
+        if k == 0:
+            assert np.abs(xp[1] - xp[0]).max() > 1e-5   # the nominal plant goes elsewhere (x2 starts at 0: the damping term is small)
+    a = fresh()
+    a.solve(new_run=True)
+    a.closed_loop(len(g["steps"]) - 1, dt=g["dt"], integrator=integrator_of(g), shift=bool(g["shift"]), disturbance=dist[:-1], log=False)
+    Xa, ca, _ = a.get_solution()
+    assert np.abs(Xa[0] - np.array(g["steps"][-1]["vertex"])[:nv]).max() <= 5e-6
+    a.plant_set_params(None)
+    a.plant_step(dt=g["dt"], integrator=integrator_of(g))
+    assert np.isfinite(a.plant_get_state()).all()
+    lin = BatchedLevenbergMarquardt(problems.linear_desc(np.eye(2) * -0.1, np.ones((2, 1)), N=6), 2)
+    with pytest.raises(CorboHipError, match="linear state-space"):
+        lin.plant_set_params(np.zeros((2, 8)))
