@@ -6,6 +6,7 @@
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_grid.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/edges/finite_differences_collocation_edges.h>
 #include <corbo-optimal-control/structured_ocp/edges/multiple_shooting_edges.h>
 #include <corbo-optimization/hyper_graph/scalar_vertex.h>
@@ -355,15 +356,16 @@ bool viewGrid(BaseHyperGraphOptimizationProblem& hg, GridView* g, std::string* r
     VertexSetInterface* vs = hg.getGraph().getVertexSetRaw();
     if (dynamic_cast<FiniteDifferencesVariableGrid*>(vs)) g->kind = CORBO_HIP_GRID_FD_VARIABLE;
     else if (dynamic_cast<FiniteDifferencesGrid*>(vs)) g->kind = CORBO_HIP_GRID_FD;
+    else if (dynamic_cast<MultipleShootingVariableGrid*>(vs)) g->kind = CORBO_HIP_GRID_MS_VARIABLE;
     else if (dynamic_cast<MultipleShootingGrid*>(vs)) g->kind = CORBO_HIP_GRID_MS;
-    else return fail(reason, "vertex set is not a FiniteDifferencesGrid, FiniteDifferencesVariableGrid or MultipleShootingGrid");
+    else return fail(reason, "vertex set is not a FiniteDifferencesGrid, FiniteDifferencesVariableGrid, MultipleShootingGrid or MultipleShootingVariableGrid");
     std::vector<VertexInterface*> vtx;
     vs->getVertices(vtx);
     // x_0..x_{N-2}, u_0..u_{N-2}, x_f, dt, (u_prev, u_ref, u_prev_dt)  (full_discretization_grid_base.cpp:499-512); ShootingGridBase
     // interleaves states and controls (shooting_grid_base.cpp:567-581)
     if ((int)vtx.size() < 7 || ((int)vtx.size() - 5) % 2 != 0) return fail(reason, "unexpected vertex list of the grid");
     g->N = ((int)vtx.size() - 5) / 2 + 1;
-    const bool interleaved = (g->kind == CORBO_HIP_GRID_MS);
+    const bool interleaved = (g->kind == CORBO_HIP_GRID_MS || g->kind == CORBO_HIP_GRID_MS_VARIABLE);
     for (int k = 0; k < g->N - 1; ++k)
     {
         g->xs.push_back(interleaved ? vtx[2 * k] : vtx[k]);

@@ -149,7 +149,7 @@ bool LevenbergMarquardtSparseHip::uploadVertices(const std::vector<VertexInterfa
     };
     for (int k = 0; k < N - 1; ++k) { pack(xs[k], k * s, nx); pack(us[k], k * s + nx, nu); }
     pack(xf, (N - 1) * s, nx);
-    if (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE) pack(dt, (N - 1) * s + nx, 1);
+    if ((_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE)) pack(dt, (N - 1) * s + nx, 1);
     std::vector<double> xref(nx, 0.0);
     if (_xref.size() == nx)
         for (int i = 0; i < nx; ++i) xref[i] = _xref[i];
@@ -198,7 +198,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     VertexInterface* dt_v = vtx[2 * (N - 1) + 1];
 
     // a fixed dt that changed without a structure change (setDtRef between runs) is a new problem for the device
-    const bool dt_changed = _handle && _desc.grid != CORBO_HIP_GRID_FD_VARIABLE && dt_v->getData()[0] != _desc.dt_ref;
+    const bool dt_changed = _handle && !(_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE) && dt_v->getData()[0] != _desc.dt_ref;
     bool verify_now = false;
     if (new_structure || !_handle || _desc.N != N || dt_changed)
     {
@@ -222,7 +222,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     const int nx = _desc.nx, nu = _desc.nu, s = nx + nu;
     // FullDiscretizationGridBase lists all states, then all controls; ShootingGridBase (shooting_grid_base.cpp:567-581) interleaves
     // them interval by interval: s_0, u_0, s_1, u_1, ...
-    const bool interleaved = (_desc.grid == CORBO_HIP_GRID_MS);
+    const bool interleaved = (_desc.grid == CORBO_HIP_GRID_MS || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE);
     std::vector<VertexInterface*>& xs = _xs; std::vector<VertexInterface*>& us = _us;
     xs.assign(N - 1, nullptr); us.assign(N - 1, nullptr);
     for (int k = 0; k < N - 1; ++k) { xs[k] = interleaved ? vtx[2 * k] : vtx[k]; us[k] = interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; }
@@ -241,7 +241,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
         for (int i = 0; i < nx; ++i)
             if (xf_v->isFixedComponent(i)) _desc.xf_fixed_mask |= (1u << i);
         const bool dt_free = !dt_v->isFixedComponent(0);
-        if (dt_free != (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE))
+        if (dt_free != ((_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE)))
         {
             PRINT_ERROR("LevenbergMarquardtSparseHip(): dt fixed/free does not match the device model's grid kind.");
             return false;
@@ -292,7 +292,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
         }
         else if (readStateReferenceForHip(*hg, nx, &xr)) { _xref_traj.resize(0, 0); _xref = xr; }
     }
-    const bool dt_free = (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    const bool dt_free = ((_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE));
 
     if (verify_now)
     {
@@ -361,7 +361,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     const int nx = _desc.nx, nu = _desc.nu, s = nx + nu, N = _desc.N;
     for (int k = 0; k < N - 1; ++k) { unpack(_xs[k], k * s, nx); unpack(_us[k], k * s + nx, nu); }
     unpack(_xf_v, (N - 1) * s, nx);
-    if (_desc.grid == CORBO_HIP_GRID_FD_VARIABLE) unpack(_dt_v, (N - 1) * s + nx, 1);
+    if ((_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE)) unpack(_dt_v, (N - 1) * s + nx, 1);
 
     if (obj_value) *obj_value = chi2;
     switch (status)

@@ -13,7 +13,7 @@ MAX_NU = 8
 INF = 2e30  # CORBO_INF_DBL (reference: src/core/include/corbo-core/types.h:52)
 
 # enums (names follow include/corbo_hip.h)
-GRID_FD, GRID_FD_VARIABLE, GRID_MS = 0, 1, 2
+GRID_FD, GRID_FD_VARIABLE, GRID_MS, GRID_MS_VARIABLE = 0, 1, 2, 3
 DEFECT_FORWARD, DEFECT_BACKWARD, DEFECT_MIDPOINT, DEFECT_CRANK_NICOLSON, DEFECT_RK4_SHOOTING = 0, 1, 2, 3, 4
 DYN_VAN_DER_POL, DYN_SERIAL_INTEGRATOR, DYN_UNICYCLE, DYN_QUADROTOR = 0, 1, 2, 3
 # the reference's other benchmark systems (nonlinear_benchmark_systems.h)

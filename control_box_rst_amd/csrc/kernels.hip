@@ -3461,7 +3461,7 @@ size_t factor_work_doubles(const corbo_hip_problem_desc& d)
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
 {
     if (d.nx == 12 && d.nu == 4) return sizeof(double) * BigLds<12, 4>::TOTAL;
-    const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE || d.grid == CORBO_HIP_GRID_MS_VARIABLE);
     if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N, arrow);
     if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
     if (d.nx == 3 && d.nu == 1) return factor_lds<3, 1>(p.N, arrow);

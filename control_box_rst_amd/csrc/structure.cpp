@@ -13,9 +13,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.nx < 1 || d.nx > CORBO_HIP_MAX_NX) return "nx out of range";
     if (d.nu < 1 || d.nu > CORBO_HIP_MAX_NU) return "nu out of range";
     if (d.N < 2) return "N must be >= 2";
-    if (d.grid < CORBO_HIP_GRID_FD || d.grid > CORBO_HIP_GRID_MS) return "unknown grid";
+    if (d.grid < CORBO_HIP_GRID_FD || d.grid > CORBO_HIP_GRID_MS_VARIABLE) return "unknown grid";
     if (d.defect < CORBO_HIP_DEFECT_FORWARD || d.defect > CORBO_HIP_DEFECT_RK4_SHOOTING) return "unknown defect";
-    if ((d.grid == CORBO_HIP_GRID_MS) != (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING))
+    if ((d.grid == CORBO_HIP_GRID_MS || d.grid == CORBO_HIP_GRID_MS_VARIABLE) != (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING))
         return "multiple-shooting grid needs the RK4 shooting defect (and only it)";
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: if (d.nx != 2 || d.nu != 1) return "van der pol: nx=2 nu=1"; break;
@@ -58,7 +58,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     S.nu    = d.nu;
     S.N     = d.N;
     S.s     = d.nx + d.nu;
-    S.dt_free = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    S.dt_free = (d.grid == CORBO_HIP_GRID_FD_VARIABLE || d.grid == CORBO_HIP_GRID_MS_VARIABLE);
     const int nx = S.nx, nu = S.nu, N = S.N, s = S.s;
     S.off_xf = (N - 1) * s;
     S.off_dt = (N - 1) * s + nx;
@@ -208,7 +208,7 @@ void init_trajectory(const corbo_hip_problem_desc& d, int batch, const double* x
     // FullDiscretizationGridBase::initializeSequences (full_discretization_grid_base.cpp:134-179):
     //   dir = xf - x0; dist = |dir|; dir /= dist; step = dist / (N-1); x_k = x0 + k*step*dir; u_k = uref(k) = 0
     const int nx = d.nx, nu = d.nu, N = d.N, s = nx + nu;
-    const bool dt_free = (d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+    const bool dt_free = (d.grid == CORBO_HIP_GRID_FD_VARIABLE || d.grid == CORBO_HIP_GRID_MS_VARIABLE);
     const int nv = (N - 1) * s + nx + (dt_free ? 1 : 0);
     for (int b = 0; b < batch; ++b) {
         const double* a = x0 + (size_t)b * nx;

@@ -53,7 +53,8 @@ typedef enum corbo_hip_solver_status {
 typedef enum corbo_hip_grid {
     CORBO_HIP_GRID_FD          = 0, /* FiniteDifferencesGrid          (finite_differences_grid.cpp:38-154), fixed dt   */
     CORBO_HIP_GRID_FD_VARIABLE = 1, /* FiniteDifferencesVariableGrid  (finite_differences_variable_grid.h:34-89), free dt */
-    CORBO_HIP_GRID_MS          = 2  /* MultipleShootingGrid, 1 control per interval (multiple_shooting_grid.cpp:38-197)  */
+    CORBO_HIP_GRID_MS          = 2, /* MultipleShootingGrid, 1 control per interval (multiple_shooting_grid.cpp:38-197)  */
+    CORBO_HIP_GRID_MS_VARIABLE = 3  /* MultipleShootingVariableGrid (multiple_shooting_variable_grid.h:34-90): the same with a free dt */
 } corbo_hip_grid;
 
 /* Dynamics-defect formula of the equality edge between (x_k, u_k, x_{k+1}, dt). */

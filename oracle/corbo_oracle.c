@@ -319,9 +319,9 @@ static int validate(const corbo_hip_problem_desc* d)
 {
     if (!d) return 0;
     if (d->nx < 1 || d->nx > CORBO_HIP_MAX_NX || d->nu < 1 || d->nu > CORBO_HIP_MAX_NU || d->N < 2) return 0;
-    if (d->grid < 0 || d->grid > CORBO_HIP_GRID_MS) return 0;
+    if (d->grid < 0 || d->grid > CORBO_HIP_GRID_MS_VARIABLE) return 0;
     if (d->defect < 0 || d->defect > CORBO_HIP_DEFECT_RK4_SHOOTING) return 0;
-    if ((d->grid == CORBO_HIP_GRID_MS) != (d->defect == CORBO_HIP_DEFECT_RK4_SHOOTING)) return 0;
+    if ((d->grid == CORBO_HIP_GRID_MS || d->grid == CORBO_HIP_GRID_MS_VARIABLE) != (d->defect == CORBO_HIP_DEFECT_RK4_SHOOTING)) return 0;
     switch (d->dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: if (d->nx != 2 || d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d->nu != 1) return 0; break;
@@ -347,7 +347,7 @@ static int validate(const corbo_hip_problem_desc* d)
     return 1;
 }
 
-static int dt_is_free(const corbo_hip_problem_desc* d) { return d->grid == CORBO_HIP_GRID_FD_VARIABLE; }
+static int dt_is_free(const corbo_hip_problem_desc* d) { return d->grid == CORBO_HIP_GRID_FD_VARIABLE || d->grid == CORBO_HIP_GRID_MS_VARIABLE; }
 
 /* static row-wise view of J, envelope of H = J^T J and the LM work space (needs dims and the structure) */
 static void finish_linear_algebra_setup(oracle_problem* p)

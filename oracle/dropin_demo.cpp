@@ -16,6 +16,7 @@
 #include <corbo-optimal-control/functions/stage_functions.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/structured_optimal_control_problem.h>
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_edge_based.h>
 #include <corbo-optimization/solver/levenberg_marquardt_sparse.h>
@@ -231,6 +232,21 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         xf = Eigen::Vector3d(0.1, 0.2, -0.3);
         nu = 2;
     }
+    else if (scenario == "dint_ms")   // cfg 2 on the shooting grid: MultipleShootingVariableGrid (free dt), RK4
+    {
+        dyn     = std::make_shared<SerialIntegratorSystem>(2);
+        auto vg = std::make_shared<MultipleShootingVariableGrid>();
+        vg->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        vg->setDtBounds(0.01, 10.0);
+        Eigen::Matrix<bool, -1, 1> fixed(2);
+        fixed.setConstant(true);
+        vg->setXfFixed(fixed);
+        ms_grid = vg;
+        w       = 100;
+        x0      = Eigen::Vector2d(0, 0);
+        xf      = Eigen::Vector2d(1, 0);
+        solves  = 5;
+    }
     else   // dint
     {
         dyn       = std::make_shared<SerialIntegratorSystem>(2);
@@ -316,7 +332,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setControlBounds(ulb, uub);
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
-    else if (scenario == "dint")
+    else if (scenario == "dint" || scenario == "dint_ms")
     {
         ocp.setStageCost(std::make_shared<MinimumTime>(true));
         ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
@@ -418,7 +434,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -429,7 +445,7 @@ int main(int argc, char** argv)
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

@@ -172,6 +172,23 @@ def tvref():
         print(name, d["n"])
 
 
+def msvar():
+    """Time-optimal OCPs on the shooting grid: MultipleShootingVariableGrid (free dt, RK4, x_f fixed, MinimumTime) -- single solves, a
+    moving-horizon sequence and the exact-Hessian operators."""
+    for name, kv, keep in [
+        ("int3_ms_time_optimal", dict(scenario="int3", vargrid=1, grid="ms", N=16, iters=8), (1, 2, 3, 5, 8)),
+        ("int3_ms_time_optimal_n40", dict(scenario="int3", vargrid=1, grid="ms", N=40, iters=6), (1, 3, 6)),
+    ]:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], d["m"], [a["chi2"] for a in d["after_iter"]])
+    d = run("hess", scenario="int3", vargrid=1, grid="ms", N=10)
+    with open(os.path.join(OUT, "hess_int3_ms_time_optimal.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+    print("hess_int3_ms_time_optimal", d["n"])
+
+
 def bigterm():
     """Final-stage constraints on the 12-state quadrotor (big-block family): TerminalBall (violated: active row) and the terminal equality."""
     for name, kv, keep in [
@@ -187,6 +204,8 @@ def bigterm():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "msvar":
+        return msvar()
     if len(sys.argv) > 1 and sys.argv[1] == "bigterm":
         return bigterm()
     if len(sys.argv) > 1 and sys.argv[1] == "hess":

@@ -34,6 +34,7 @@
 #include <corbo-optimal-control/functions/stage_functions.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_grid.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/structured_optimal_control_problem.h>
 #include <corbo-optimization/hyper_graph/hyper_graph_optimization_problem_edge_based.h>
 #include <corbo-optimization/simple_optimization_problem.h>
@@ -246,7 +247,20 @@ static Built build(const Scenario& s, int iterations)
     else if (s.name == "int3")
     {
         dyn = std::make_shared<SerialIntegratorSystem>(3);
-        if (s.vargrid)
+        if (s.vargrid && s.ms)
+        {   // time-optimal on the shooting grid: MultipleShootingVariableGrid (free dt), RK4, x_f fixed
+            auto grid = std::make_shared<MultipleShootingVariableGrid>();
+            grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+            grid->setNRef(s.N);
+            grid->setDtRef(s.dt);
+            grid->setDtBounds(0.01, 10.0);
+            Eigen::Matrix<bool, -1, 1> fixed(3);
+            fixed.setConstant(true);
+            grid->setXfFixed(fixed);
+            b.ms_grid  = grid;
+            b.any_grid = grid;
+        }
+        else if (s.vargrid)
         {
             auto grid = std::make_shared<FiniteDifferencesVariableGrid>();
             grid->setDtBounds(0.01, 10.0);

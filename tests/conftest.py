@@ -71,8 +71,8 @@ def desc_for(g):
     else:
         raise KeyError(sc)
     # options of oracle/ref_driver.cpp recorded in the fixture header
-    if g.get("grid") == "ms":   # MultipleShootingGrid + RK4
-        d.grid, d.defect = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING
+    if g.get("grid") == "ms":   # MultipleShootingGrid (vargrid: MultipleShootingVariableGrid, free dt) + RK4
+        d.grid, d.defect = (capi.GRID_MS_VARIABLE if g.get("vargrid") else capi.GRID_MS), capi.DEFECT_RK4_SHOOTING
     if "xlb" in g or "ulb" in g:   # setBounds replaces all four vectors: the ones not given are unbounded
         for key, arr, n in (("xlb", d.x_lb, d.nx), ("xub", d.x_ub, d.nx), ("ulb", d.u_lb, d.nu), ("uub", d.u_ub, d.nu)):
             vals = g.get(key)

@@ -28,6 +28,8 @@ def random_desc(rng, long_horizon=False):
     dt = float(rng.uniform(0.05, 0.2))
     if fam in ("dint", "int3t"):   # time-optimal, free dt (arrowhead)
         d = problems.dint_desc(N=N, dt=dt) if fam == "dint" else problems.int3_desc(N=N, dt=dt, time_optimal=True)
+        if N % 3 == 0:   # (no extra draw: the other cases keep theirs) the same on the shooting grid, MultipleShootingVariableGrid + RK4
+            d.grid, d.defect = capi.GRID_MS_VARIABLE, capi.DEFECT_RK4_SHOOTING
         nx, nu = d.nx, 1
         full = 2 ** nx - 1
         d.xf_fixed_mask = int(rng.choice([full, full, 1, full - 1, 0]))
@@ -102,7 +104,7 @@ def test_random_descriptor_vs_oracle(oracle_mod, seed):
     X0 = s.init_trajectory(x0, xf)
     X0 = X0 + 0.05 * rng.normal(size=X0.shape)          # off the straight line: bounds / inequalities get active
     X0[:, : d.nx] = x0
-    if d.grid == capi.GRID_FD_VARIABLE:
+    if d.grid in (capi.GRID_FD_VARIABLE, capi.GRID_MS_VARIABLE):
         X0[:, -1] = d.dt_ref
     s.set_instance_data(X0, xref=xf)
     po = oracle_mod.OracleProblem(d)
@@ -122,7 +124,10 @@ def test_random_descriptor_vs_oracle(oracle_mod, seed):
     Xo, chi2o, so = oracle_mod.solve_batch(d, X0, xf, s.opts)
     # (random, partly stiff problems a few iterations away from a wild start: the FD noise of J is amplified more than on the fixtures)
     assert np.abs(X - Xo).max() <= 3e-5 * max(1.0, np.abs(Xo).max()), (seed, fam, np.abs(X - Xo).max())
-    assert np.allclose(chi2, chi2o, rtol=5e-5, atol=1e-10), (seed, fam)   # far from convergence chi2 ~ 1e5 amplifies the FD noise of J
+    # far from convergence chi2 ~ 1e5 amplifies the FD noise of J.  Free dt through RK4 (MultipleShootingVariableGrid) amplifies it more:
+    # the oracle's own chi2 moves by 1.8e-4 (relative) when seed 154's start is perturbed by 1e-12, its iterate by 2e-5
+    rtol = 5e-4 if d.grid == capi.GRID_MS_VARIABLE else 5e-5
+    assert np.allclose(chi2, chi2o, rtol=rtol, atol=1e-10), (seed, fam)
 
 
 @pytest.mark.parametrize("seed", range(12))

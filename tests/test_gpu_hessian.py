@@ -17,7 +17,7 @@ from control_box_rst_amd import problems
 pytestmark = pytest.mark.gpu
 
 HESS = ["hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
-        "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4"]
+        "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal"]
 KEYS = ("hobj", "heq", "hineq")
 REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below
 
@@ -157,7 +157,7 @@ def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
     s = BatchedLevenbergMarquardt(d, B)
     X0 = s.init_trajectory(x0, xf) + 0.05 * rng.normal(size=(B, s.dims.nv))
     X0[:, : d.nx] = x0
-    if d.grid == capi.GRID_FD_VARIABLE:
+    if d.grid in (capi.GRID_FD_VARIABLE, capi.GRID_MS_VARIABLE):
         X0[:, -1] = d.dt_ref
     s.set_instance_data(X0, xref=xf)
     lower = bool(seed % 2)

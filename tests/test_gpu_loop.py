@@ -34,7 +34,7 @@ def test_plant_step_vs_oracle(oracle_mod, scenario, N, integrator):
     p = oracle_mod.OracleProblem(d)
     nv, nx = p.dims.nv, d.nx
     X = rng.normal(scale=0.4, size=(B, nv))
-    if d.grid == capi.GRID_FD_VARIABLE:
+    if d.grid in (capi.GRID_FD_VARIABLE, capi.GRID_MS_VARIABLE):
         X[:, -1] = 0.1
     xp = rng.normal(scale=0.5, size=(B, nx))
     dist = 1e-3 * rng.normal(size=(B, nx))
