@@ -3,7 +3,9 @@
 Reference behaviour mirrored (per instance): ``PredictiveController::step`` (controllers/src/predictive_controller.cpp:46-80: K
 ``compute()`` calls per control step, ``new_run`` only for the first) on a ``FiniteDifferencesVariableGrid`` with
 ``setGridAdaptTimeBasedSingleStep`` / ``...AggressiveEstimate`` / ``...SimpleShrinkingHorizon``
-(finite_differences_variable_grid.cpp:44-163).  Every ``compute()`` starts with the grid update
+(finite_differences_variable_grid.cpp:44-163), or on a ``MultipleShootingVariableGrid`` with its setters of the same names
+(multiple_shooting_variable_grid.cpp:42-152; same rules except the aggressive estimate, which rounds dt / dt_ref before it multiplies;
+ShootingGridBase::resampleTrajectory, shooting_grid_base.cpp:473-547, is the full-discretisation resampling on the same vertex layout).  Every ``compute()`` starts with the grid update
 (full_discretization_grid_base.cpp:38-131): adaptGrid -- unless it is a new run without ``adapt_first_iter``, or the very first run --
 then, on a new run, x_0 = measured state and fixed goal components = reference; then the solver.
 
@@ -20,10 +22,11 @@ from typing import Callable, Dict, List
 
 import numpy as np
 
-from .capi import ProblemDesc
+from .capi import GRID_MS_VARIABLE, ProblemDesc
 from .solver import BatchedLevenbergMarquardt
 
 NO_ADAPT, SINGLE_STEP, AGGRESSIVE, SHRINK = 0, 1, 2, 3
+AGGRESSIVE_SHOOTING = 4   # what AGGRESSIVE means on a MultipleShootingVariableGrid (picked by AdaptiveGridBatch from the descriptor's grid kind)
 
 
 def adapt_grid_n(strategy: int, n: int, dt: float, dt_ref: float, hyst: float, n_min: int, n_max: int) -> int:
@@ -42,6 +45,12 @@ def adapt_grid_n(strategy: int, n: int, dt: float, dt_ref: float, hyst: float, n
         return min(max(new_n, n_min), n_max)
     if strategy == SHRINK:
         return n - 1 if n > n_min else n
+    if strategy == AGGRESSIVE_SHOOTING:   # multiple_shooting_variable_grid.cpp:115-141: n * (int)round(dt / dt_ref) -- the ratio is rounded first
+        if dt_ref * (1.0 - hyst) <= dt <= dt_ref * (1.0 + hyst):
+            return n
+        v = dt / dt_ref
+        new_n = n * (int(math.floor(v + 0.5)) if v >= 0 else -int(math.floor(-v + 0.5)))
+        return min(max(new_n, n_min), n_max)
     return n
 
 
@@ -53,7 +62,10 @@ class AdaptiveGridBatch:
         self.make_desc, self.batch, self.n_ref = make_desc, int(batch), int(n_ref)
         self.strategy, self.n_min, self.n_max, self.hyst, self.adapt_first = strategy, n_min, n_max, hyst, adapt_first_iter
         self.device = device
-        self.dt_ref = float(make_desc(n_ref).dt_ref)
+        d_ref = make_desc(n_ref)
+        self.dt_ref = float(d_ref.dt_ref)
+        if self.strategy == AGGRESSIVE and d_ref.grid == GRID_MS_VARIABLE:
+            self.strategy = AGGRESSIVE_SHOOTING
         self.iterations = 10
         self.weights = (2.0, 2.0, 2.0)
         self.adaptation = (1.0, 1.0, 1.0, 500.0, 500.0, 500.0)

@@ -86,8 +86,10 @@ VDP_WEIGHTS = (2.0, 2.0, 2.0)
 
 
 # ---- cfg 2: time-optimal double integrator, FiniteDifferencesVariableGrid N=50, x_f fixed, MinimumTime(lsq) -----
-def dint_desc(N=50, dt=0.1) -> ProblemDesc:
-    return make_desc(grid=capi.GRID_FD_VARIABLE, defect=capi.DEFECT_CRANK_NICOLSON, dynamics=capi.DYN_SERIAL_INTEGRATOR,
+def dint_desc(N=50, dt=0.1, shooting=False) -> ProblemDesc:
+    """shooting=True: the same problem on a MultipleShootingVariableGrid with RK4 defects."""
+    grid, defect = (capi.GRID_MS_VARIABLE, capi.DEFECT_RK4_SHOOTING) if shooting else (capi.GRID_FD_VARIABLE, capi.DEFECT_CRANK_NICOLSON)
+    return make_desc(grid=grid, defect=defect, dynamics=capi.DYN_SERIAL_INTEGRATOR,
                      nx=2, nu=1, N=N, dt=dt, stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0,
                      u_lb=(-1.0,), u_ub=(1.0,), xf_fixed_mask=0b11, dt_lb=0.01, dt_ub=10.0, dyn_params=(1.0,))
 
@@ -96,9 +98,10 @@ DINT_WEIGHTS = (100.0, 100.0, 100.0)
 
 
 # ---- SerialIntegratorSystem of order 3 (reference built-in, linear_benchmark_systems.h:50-118): fixed grid + quadratic cost, or time-optimal
-def int3_desc(N=30, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, time_optimal=False) -> ProblemDesc:
+def int3_desc(N=30, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, time_optimal=False, shooting=False) -> ProblemDesc:
     if time_optimal:
-        return make_desc(grid=capi.GRID_FD_VARIABLE, defect=capi.DEFECT_CRANK_NICOLSON, dynamics=capi.DYN_SERIAL_INTEGRATOR, nx=3, nu=1, N=N,
+        grid, defect = (capi.GRID_MS_VARIABLE, capi.DEFECT_RK4_SHOOTING) if shooting else (capi.GRID_FD_VARIABLE, capi.DEFECT_CRANK_NICOLSON)
+        return make_desc(grid=grid, defect=defect, dynamics=capi.DYN_SERIAL_INTEGRATOR, nx=3, nu=1, N=N,
                          dt=dt, stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0, u_lb=(-1.0,), u_ub=(1.0,), xf_fixed_mask=0b111,
                          dt_lb=0.01, dt_ub=10.0, dyn_params=(1.0,))
     q = (1.0, 0.5, 0.1)

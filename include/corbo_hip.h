@@ -255,7 +255,9 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift);
  *                            instance src_index[q] of `src` into slot dst_index[q] of `dst`, q < count: start sample and x_f kept, interior
  *                            states interpolated linearly in time, controls held, dt_new = dt_old (N_src - 1) / (N_dst - 1); the state
  *                            reference travels along.  N_src == N_dst is a plain move (src and dst may be the same handle: compaction).
- *                            Bit-identical to the oracle's restatement, which is pinned bit for bit to sequences of the reference. */
+ *                            Bit-identical to the oracle's restatement, which is pinned bit for bit to sequences of the reference.
+ *                            CORBO_HIP_GRID_MS_VARIABLE handles: ShootingGridBase::resampleTrajectory (shooting_grid_base.cpp:473-547),
+ *                            the same operation on the same vertex layout. */
 int corbo_hip_prepare_slots(corbo_hip_handle h, int active);
 int corbo_hip_get_dt(corbo_hip_handle h, double* dt_out);
 int corbo_hip_resample_into(corbo_hip_handle src, corbo_hip_handle dst, int count, const int32_t* src_index, const int32_t* dst_index);

@@ -762,7 +762,8 @@ int oracle_resample_trajectory(int nx, int nu, int n, const double* x_old, int n
 
 /* FiniteDifferencesVariableGrid::adaptGridTimeBasedSingleStep / ...AggressiveEstimate / ...SimpleShrinkingHorizon
  * (finite_differences_variable_grid.cpp:101-163): the number of grid points after the adaptation (== n: no change).
- * strategy: 1 = single step, 2 = aggressive estimate, 3 = simple shrinking horizon. */
+ * strategy: 1 = single step, 2 = aggressive estimate, 3 = simple shrinking horizon, 4 = aggressive estimate of the shooting grid
+ * (MultipleShootingVariableGrid; its single-step and shrinking rules are 1 and 3: multiple_shooting_variable_grid.cpp:93-152). */
 int oracle_adapt_grid_n(int strategy, int n, double dt, double dt_ref, double hyst, int n_min, int n_max)
 {
     if (strategy == 1) {
@@ -778,6 +779,14 @@ int oracle_adapt_grid_n(int strategy, int n, double dt, double dt_ref, double hy
         return new_n;
     }
     if (strategy == 3) return (n > n_min) ? n - 1 : n;
+    if (strategy == 4) { /* MultipleShootingVariableGrid::adaptGridTimeBasedAggressiveEstimate (multiple_shooting_variable_grid.cpp:115-141):
+                          * the RATIO is rounded to an integer first -- dt < dt_ref / 2 collapses the grid to n_min */
+        if (dt >= dt_ref * (1.0 - hyst) && dt <= dt_ref * (1.0 + hyst)) return n;
+        int new_n = n * (int)round(dt / dt_ref);
+        if (new_n > n_max) new_n = n_max;
+        else if (new_n < n_min) new_n = n_min;
+        return new_n;
+    }
     return n;
 }
 

@@ -105,6 +105,16 @@ def adapt():
         ("mpc_dint_adapt_shrink_init", dict(iters=0, adapt="shrink", nmin=44)),
         ("mpc_dint_adapt_single", dict(iters=5, adapt="single", nmax=80, hyst=0.1, steps=6)),
         ("mpc_dint_adapt_aggressive", dict(iters=5, adapt="aggressive", nmax=80, hyst=0.1, steps=4)),
+        # the same on the MultipleShootingVariableGrid (multiple_shooting_variable_grid.cpp:58-152 -> ShootingGridBase::resampleTrajectory,
+        # shooting_grid_base.cpp:473-547)
+        ("mpc_dint_ms_adapt_single_init", dict(grid="ms", iters=0, adapt="single", nmax=80, hyst=0.02, dt=0.06)),
+        ("mpc_dint_ms_adapt_shrink_init", dict(grid="ms", iters=0, adapt="shrink", nmin=44)),
+        # (4 + 2 LM iterations per compute(): with 10 + 5 at penalty weight 100 the iterates sit next to the bang-bang solution, where the
+        # restatement's own result moves by 1e-4 under a 1e-13 perturbation of its start -- nothing to pin a tolerance on)
+        ("mpc_dint_ms_adapt_single", dict(grid="ms", iters0=4, iters=2, adapt="single", nmax=80, hyst=0.1, steps=6)),
+        ("mpc_dint_ms_adapt_aggressive", dict(grid="ms", iters0=4, iters=2, adapt="aggressive", dt=0.03, N=30, nmax=70, nmin=20, hyst=0.1, steps=4)),
+        # n * (int)round(dt / dt_ref) with dt < dt_ref / 2: the grid collapses to n_min (multiple_shooting_variable_grid.cpp:127-133)
+        ("mpc_dint_ms_adapt_aggressive_collapse", dict(grid="ms", iters0=4, iters=2, adapt="aggressive", dt=0.2, N=60, nmax=90, nmin=12, hyst=0.1, steps=4)),
     ]:
         d = run("mpc", **{**base, **kv})
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

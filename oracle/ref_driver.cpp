@@ -274,13 +274,27 @@ static Built build(const Scenario& s, int iterations)
     }
     else if (s.name == "dint")
     {
-        dyn       = std::make_shared<SerialIntegratorSystem>(2);
-        auto grid = std::make_shared<FiniteDifferencesVariableGrid>();
-        grid->setDtBounds(0.01, 10.0);
+        dyn = std::make_shared<SerialIntegratorSystem>(2);
         Eigen::Matrix<bool, -1, 1> fixed(2);
         fixed.setConstant(true);
-        grid->setXfFixed(fixed);
-        b.grid = grid;
+        if (s.ms)
+        {   // cfg 2 on the shooting grid: MultipleShootingVariableGrid (free dt), RK4
+            auto grid = std::make_shared<MultipleShootingVariableGrid>();
+            grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+            grid->setNRef(s.N);
+            grid->setDtRef(s.dt);
+            grid->setDtBounds(0.01, 10.0);
+            grid->setXfFixed(fixed);
+            b.ms_grid  = grid;
+            b.any_grid = grid;
+        }
+        else
+        {
+            auto grid = std::make_shared<FiniteDifferencesVariableGrid>();
+            grid->setDtBounds(0.01, 10.0);
+            grid->setXfFixed(fixed);
+            b.grid = grid;
+        }
     }
     else if (s.name == "quad")
     {
@@ -299,16 +313,29 @@ static Built build(const Scenario& s, int iterations)
     if (!s.adapt.empty())
     {
         auto vg = std::dynamic_pointer_cast<FiniteDifferencesVariableGrid>(b.grid);
-        if (!vg)
+        auto mg = std::dynamic_pointer_cast<MultipleShootingVariableGrid>(b.ms_grid);
+        if (!vg && !mg)
         {
-            fprintf(stderr, "adapt= needs a FiniteDifferencesVariableGrid scenario\n");
+            fprintf(stderr, "adapt= needs a FiniteDifferencesVariableGrid / MultipleShootingVariableGrid scenario\n");
             exit(2);
         }
-        vg->setNmin(s.n_min);
-        if (s.adapt == "single") vg->setGridAdaptTimeBasedSingleStep(s.n_max, s.hyst, s.adapt_first);
-        else if (s.adapt == "aggressive") vg->setGridAdaptTimeBasedAggressiveEstimate(s.n_max, s.hyst, s.adapt_first);
-        else if (s.adapt == "shrink") vg->setGridAdaptSimpleShrinkingHorizon(s.adapt_first);
-        else { fprintf(stderr, "unknown adapt=%s\n", s.adapt.c_str()); exit(2); }
+        if (mg)
+        {   // (multiple_shooting_variable_grid.h:52-56: no adapt_first_iter argument, the member stays false)
+            if (s.adapt_first) { fprintf(stderr, "adapt_first=1: not settable on a MultipleShootingVariableGrid\n"); exit(2); }
+            mg->setNmin(s.n_min);
+            if (s.adapt == "single") mg->setGridAdaptTimeBasedSingleStep(s.n_max, s.hyst);
+            else if (s.adapt == "aggressive") mg->setGridAdaptTimeBasedAggressiveEstimate(s.n_max, s.hyst);
+            else if (s.adapt == "shrink") mg->setGridAdaptSimpleShrinkingHorizon();
+            else { fprintf(stderr, "unknown adapt=%s\n", s.adapt.c_str()); exit(2); }
+        }
+        else
+        {
+            vg->setNmin(s.n_min);
+            if (s.adapt == "single") vg->setGridAdaptTimeBasedSingleStep(s.n_max, s.hyst, s.adapt_first);
+            else if (s.adapt == "aggressive") vg->setGridAdaptTimeBasedAggressiveEstimate(s.n_max, s.hyst, s.adapt_first);
+            else if (s.adapt == "shrink") vg->setGridAdaptSimpleShrinkingHorizon(s.adapt_first);
+            else { fprintf(stderr, "unknown adapt=%s\n", s.adapt.c_str()); exit(2); }
+        }
     }
     if (b.grid)
     {
@@ -798,11 +825,14 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     const int ocp_iters = kv.count("ocp_iters") ? atoi(kv["ocp_iters"].c_str()) : 1;
     Built b = build(s, iters0);
     if (shift && b.grid) b.grid->setWarmStart(true);
-    if (shift && b.ms_grid) b.ms_grid->setWarmStart(true);   // ShootingGridBase: the same shifting (shooting_grid_base.cpp:99-113,292-352)
+    // ShootingGridBase: the same shifting (shooting_grid_base.cpp:99-113,292-352).  Without warm start a shooting grid re-initialises its
+    // sequences in every update (:85-96) -- an adapting grid keeps them (the variable grid never shifts: isMovingHorizonWarmStartActive() false)
+    if ((shift || !s.adapt.empty()) && b.ms_grid) b.ms_grid->setWarmStart(true);
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g, \"iters0\": %d, \"iters\": %d, \"shift\": %d,\n", s.name.c_str(),
            s.nx, s.nu, s.N, s.dt, iters0, s.iters, shift ? 1 : 0);
     printf("\"ocp_iters\": %d, \"adapt\": \"%s\", \"nmax\": %d, \"nmin\": %d, \"hyst\": %.17g, \"adapt_first\": %d,\n", ocp_iters, s.adapt.c_str(), s.n_max, s.n_min,
            s.hyst, s.adapt_first ? 1 : 0);
+    if (s.ms) printf("\"grid\": \"ms\",\n");
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);

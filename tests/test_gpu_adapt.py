@@ -1,6 +1,6 @@
 """GPU tests (-m gpu) of the time-optimal grid adaptation on the device: corbo_hip_resample_into against the oracle's restatement of
 resampleTrajectory (bit for bit), and the bucketed batch of adaptive controllers (control_box_rst_amd/adaptive_grid.py) against
-moving-horizon sequences of the genuine reference (tests/golden/mpc_dint_adapt_*.json)."""
+moving-horizon sequences of the genuine reference (tests/golden/mpc_dint_adapt_*.json; mpc_dint_ms_adapt_*: the MultipleShootingVariableGrid)."""
 import numpy as np
 import pytest
 
@@ -20,12 +20,13 @@ def _built():
     g.build()
 
 
+@pytest.mark.parametrize("shooting", [False, True], ids=["fd", "ms"])   # ms: ShootingGridBase::resampleTrajectory (shooting_grid_base.cpp:473-547)
 @pytest.mark.parametrize("n_dst", [19, 21, 33, 12, 20, 2, 150])
-def test_resample_into_vs_oracle_bit_exact(oracle_mod, n_dst):
+def test_resample_into_vs_oracle_bit_exact(oracle_mod, n_dst, shooting):
     n_src, B = 20, 5
     rng = np.random.default_rng(n_dst)
-    src = BatchedLevenbergMarquardt(problems.dint_desc(N=n_src), B)
-    dst = BatchedLevenbergMarquardt(problems.dint_desc(N=n_dst), B)
+    src = BatchedLevenbergMarquardt(problems.dint_desc(N=n_src, shooting=shooting), B)
+    dst = BatchedLevenbergMarquardt(problems.dint_desc(N=n_dst, shooting=shooting), B)
     X = rng.normal(size=(B, src.dims.nv))
     X[:, -1] = rng.uniform(0.03, 0.3, B)       # dt
     xref = rng.normal(size=(B, 2))
@@ -42,10 +43,12 @@ def test_resample_into_vs_oracle_bit_exact(oracle_mod, n_dst):
         assert np.array_equal(Z[1], X[4]) and np.array_equal(Z[0], X[0])
 
 
-@pytest.mark.parametrize("name", ["mpc_dint_adapt_single", "mpc_dint_adapt_aggressive"])
+@pytest.mark.parametrize("name", ["mpc_dint_adapt_single", "mpc_dint_adapt_aggressive", "mpc_dint_ms_adapt_single", "mpc_dint_ms_adapt_aggressive",
+                                  "mpc_dint_ms_adapt_aggressive_collapse"])
 def test_adaptive_controller_on_the_device_vs_reference(name):
     g = load_golden(name)
-    ctl = adaptive_grid.AdaptiveGridBatch(lambda n: problems.dint_desc(N=n, dt=g["dt"]), 1, g["N"], strategy=STRATEGY[g["adapt"]], n_min=g["nmin"],
+    shooting = g.get("grid") == "ms"   # MultipleShootingVariableGrid: AdaptiveGridBatch picks its aggressive rule from the descriptor
+    ctl = adaptive_grid.AdaptiveGridBatch(lambda n: problems.dint_desc(N=n, dt=g["dt"], shooting=shooting), 1, g["N"], strategy=STRATEGY[g["adapt"]], n_min=g["nmin"],
                                           n_max=g["nmax"], hyst=g["hyst"], adapt_first_iter=bool(g["adapt_first"]))
     ctl.setPenaltyWeights(*g["weights"])
     ctl.initialize([g["steps"][0]["x0"]], [g["xf"]])
@@ -62,7 +65,8 @@ def test_adaptive_controller_on_the_device_vs_reference(name):
     ctl.close()
 
 
-def test_batch_of_adaptive_controllers_equals_the_instances_run_alone():
+@pytest.mark.parametrize("shooting", [False, True], ids=["fd", "ms"])
+def test_batch_of_adaptive_controllers_equals_the_instances_run_alone(shooting):
     """16 double-integrator controllers with different distances to the goal: their grids end up with different N (several buckets, instances
     moving between them, holes being closed).  Every instance's trajectory is bit-identical to the same instance run as a batch of one."""
     B, steps, K = 16, 5, 3
@@ -73,7 +77,8 @@ def test_batch_of_adaptive_controllers_equals_the_instances_run_alone():
     dist = rng.normal(scale=0.005, size=(steps, B, 2))
 
     def run(ids):
-        ctl = adaptive_grid.AdaptiveGridBatch(lambda n: problems.dint_desc(N=n), len(ids), 30, strategy=adaptive_grid.SINGLE_STEP, n_min=5, n_max=60, hyst=0.05)
+        ctl = adaptive_grid.AdaptiveGridBatch(lambda n: problems.dint_desc(N=n, shooting=shooting), len(ids), 30, strategy=adaptive_grid.SINGLE_STEP, n_min=5, n_max=60,
+                                              hyst=0.05)
         ctl.setPenaltyWeights(*problems.DINT_WEIGHTS)
         ctl.setIterations(6)
         ctl.initialize(x0[ids], xf[ids])
