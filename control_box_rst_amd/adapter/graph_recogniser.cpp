@@ -520,20 +520,23 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         }
         else return fail(reason, "least-squares term on an unexpected vertex");
     }
+    // the stage cost is identified by the TERMS it created (nlp_functions.cpp:70-107), not by its class: QuadraticFormCost = state + control,
+    // MinimumTime = dt (twice), MinTimeQuadratic = all three (hybrid_cost.h:189-303) -- a user's own StageCost with the same terms maps as
+    // well.  (QuadraticStateCost / QuadraticControlCost / MinTimeQuadraticStates / ...Controls with a diagonal weight create no
+    // least-squares term at all -- quadratic_state_cost.cpp:33-62 leaves _Q empty -- and arrive here as what is left of them.)
     if (n_dt > 0)
     {
-        if (n_dt != 2 || n_state || n_ctrl) return fail(reason, "minimum-time cost combined with other stage costs");
+        if (n_dt != 2) return fail(reason, "minimum-time term that was not created twice at k = 0 (a grid with one dt per interval?)");
         if (dt_weight != std::sqrt((double)(g.N - 1))) return fail(reason, "minimum-time weight is not sqrt(N - 1)");
-        d.stage_cost = CORBO_HIP_COST_MIN_TIME_LSQ;
     }
-    else if (n_state || n_ctrl)
+    if ((n_state != 0) != (n_ctrl != 0)) return fail(reason, "quadratic stage cost with a state term but no control term, or the other way round (non-diagonal weights?)");
+    if (n_state && (n_state != g.N - 1 || n_ctrl != g.N - 1)) return fail(reason, "quadratic cost terms on some intervals only (MinTimeQuadratic with only_last_n?)");
+    d.stage_cost = n_dt ? (n_state ? CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ : CORBO_HIP_COST_MIN_TIME_LSQ) : (n_state ? CORBO_HIP_COST_QUADRATIC_LSQ : CORBO_HIP_COST_NONE);
+    if (n_state)
     {
-        if (n_state != g.N - 1 || n_ctrl != g.N - 1) return fail(reason, "quadratic stage cost without a state or without a control term on every interval");
-        d.stage_cost = CORBO_HIP_COST_QUADRATIC_LSQ;
         for (int i = 0; i < g.nx; ++i) d.q_diag[i] = sq[i] * sq[i];
         for (int i = 0; i < g.nu; ++i) d.r_diag[i] = sr[i] * sr[i];
     }
-    else d.stage_cost = CORBO_HIP_COST_NONE;
     d.final_cost = n_final ? 1 : 0;
     if (n_final)
         for (int i = 0; i < g.nx; ++i) d.qf_diag[i] = sqf[i] * sqf[i];

@@ -3028,16 +3028,13 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         // The stage's edges in the order of the reference's walk (the three lists one after the other: objective edges first, then the
         // equality edges, then the inequality edges) -- ONE call site in a loop.  (With four inlined call sites the 12-state instantiation
         // never finished on the hardware -- > 120 s for one interval; the compiler had merged the copies into an exec-mask dispatch loop.)
-        int kinds[5], cats[5], n_edges = 0;
-        double* outs[5];
-        const double* mults[5];
+        int kinds[6], cats[6], n_edges = 0;
+        double* outs[6];
+        const double* mults[6];
         auto add = [&](int kind, int cat, double* out, const double* mult) { kinds[n_edges] = kind; cats[n_edges] = cat; outs[n_edges] = out; mults[n_edges] = mult; ++n_edges; };
-        if (so[0] >= 0) {
-            if (final_stage) add(EK_FINAL_COST, 0, vo + so[0], nullptr);
-            else if (hp.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ) { add(EK_DT_COST, 0, vo + so[0], nullptr); add(EK_DT_COST, 0, nullptr, nullptr); }
-            else add(EK_STATE_COST, 0, vo + so[0], nullptr);
-        }
+        if (so[0] >= 0) add(final_stage ? EK_FINAL_COST : EK_STATE_COST, 0, vo + so[0], nullptr);
         if (so[1] >= 0) add(EK_CONTROL_COST, 0, vo + so[1], nullptr);
+        if (k == 0 && hp.dt_cost_off >= 0) { add(EK_DT_COST, 0, vo + hp.dt_cost_off, nullptr); add(EK_DT_COST, 0, nullptr, nullptr); }
         if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
         if (so[3] >= 0) add(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, vi + so[3], mi);
         double* next = nullptr;
@@ -3051,10 +3048,14 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         // computeGradientObjective: per least-squares edge the Jacobian block, then the values, gradient += (2 values^T) J; the stage's
         // share of computeValueObjective.  Every component belongs to exactly one lane: no atomics.
         double* gr = hp.grad + (size_t)b * hp.n_params;
-        int kinds[3], n_edges = 0;
+        int kinds[4], n_edges = 0;
+        const int terms = CORBO_HIP_COST_TERMS(hp.stage_cost);
         if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = EK_FINAL_COST; }
-        else if (hp.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ) { if (k == 0) { kinds[n_edges++] = EK_DT_COST; kinds[n_edges++] = EK_DT_COST; } }
-        else if (hp.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) { kinds[n_edges++] = EK_STATE_COST; kinds[n_edges++] = EK_CONTROL_COST; }
+        else {
+            if (terms & 1) kinds[n_edges++] = EK_STATE_COST;
+            if (terms & 2) kinds[n_edges++] = EK_CONTROL_COST;
+            if ((terms & 4) && k == 0) { kinds[n_edges++] = EK_DT_COST; kinds[n_edges++] = EK_DT_COST; }
+        }
         double obj = 0.0;
         for (int e = 0; e < n_edges; ++e) {
             const int kind = kinds[e], ed = HE::edge_dim(kind), off = HE::vert_off(kind, 0), dim = HE::vert_dim(kind, 0);

@@ -36,7 +36,10 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         case CORBO_HIP_DYN_PARALLEL_INTEGRATOR: if (d.nx != d.nu || d.nx < 2 || d.nx > 3) return "parallel integrators: nx=nu=2 or 3"; break;
         default: return "unknown dynamics";
     }
-    if (d.stage_cost < CORBO_HIP_COST_NONE || d.stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ) return "unknown stage cost";
+    if (d.stage_cost < CORBO_HIP_COST_NONE || d.stage_cost > CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "unknown stage cost";
+    if (d.stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ && (CORBO_HIP_COST_TERMS(d.stage_cost) & 4) && d.grid != CORBO_HIP_GRID_FD_VARIABLE &&
+        d.grid != CORBO_HIP_GRID_MS_VARIABLE)
+        return "a stage cost with a minimum-time term needs a grid with a free dt";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
     if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
@@ -94,11 +97,10 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     struct E { int kind, k, dim, scale; };
     std::vector<E> lsq, eq, ineq;
     for (int k = 0; k < N - 1; ++k) {
-        if (d.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) {
-            lsq.push_back({EK_STATE_COST, k, nx, 0});
-            lsq.push_back({EK_CONTROL_COST, k, nu, 0});
-        }
-        else if (d.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ && k == 0) {
+        const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);   // nlp_functions.cpp:70-107: state term, control term, dt term twice
+        if (terms & 1) lsq.push_back({EK_STATE_COST, k, nx, 0});
+        if (terms & 2) lsq.push_back({EK_CONTROL_COST, k, nu, 0});
+        if ((terms & 4) && k == 0) {   // MinimumTime on a single-dt grid: k = 0 only (minimum_time.h:49)
             lsq.push_back({EK_DT_COST, k, 1, 0});
             lsq.push_back({EK_DT_COST, k, 1, 0});  // duplicated edge
         }
@@ -282,14 +284,11 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
     // objective (least-squares edges) and the per-stage offsets
     for (int k = 0; k < N - 1; ++k) {
         const V xk{k * s, nx}, uk{k * s + nx, nu};
-        if (d.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ) {
-            H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size();
-            walk(0, &xk, 1);
-            H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size();
-            walk(0, &uk, 1);
-        }
-        else if (d.stage_cost == CORBO_HIP_COST_MIN_TIME_LSQ && k == 0) {
-            H.stage_off[0] = (int32_t)H.rows[0].size();
+        const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);
+        if (terms & 1) { H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xk, 1); }
+        if (terms & 2) { H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size(); walk(0, &uk, 1); }
+        if ((terms & 4) && k == 0) {
+            H.dt_cost_off = (int32_t)H.rows[0].size();
             walk(0, &dtv, 1);
             walk(0, &dtv, 1);   // duplicated edge (nlp_functions.cpp:91-107)
         }

@@ -78,10 +78,11 @@ struct HessianStructure {
     int32_t nnz[3] = {0, 0, 0};
     std::vector<int32_t> rows[3], cols[3];
     // per stage k (N entries, k = N-1 = final stage), six numbers: first value of the stage's edges in the lists, -1 = no such edge:
-    //   [0] objective: state cost (or the two dt cost edges at k = 0; final stage: final cost)   [1] objective: control cost
+    //   [0] objective: state cost (final stage: final cost)   [1] objective: control cost
     //   [2] equalities: defect edge (final stage: terminal equality)   [3] inequalities: stage inequality (final stage: terminal inequality)
     //   [4] first equality row of [2]   [5] first inequality row of [3]   (multiplier / linear-form row indices)
     std::vector<int32_t> stage_off;
+    int32_t dt_cost_off = -1;       // objective: first value of the two dt cost edges (they follow stage 0's state / control terms), -1 = none
     int32_t lin_nnz = 0, lin_bounds0 = 0;
     std::vector<int32_t> lin_rows, lin_cols;
     std::vector<int32_t> lin_off;   // [N][2]: first linear-form value of the stage's equality edge / inequality edge, -1 = none

@@ -97,6 +97,18 @@ def dint_desc(N=50, dt=0.1, shooting=False) -> ProblemDesc:
 DINT_WEIGHTS = (100.0, 100.0, 100.0)
 
 
+def min_time_quadratic(d: ProblemDesc, q, r) -> ProblemDesc:
+    """Turn a time-optimal descriptor (free dt, MinimumTime) into the reference's MinTimeQuadratic(Q, R, integral=False, lsq=True)
+    (hybrid_cost.h:189-303): the quadratic form's state and control terms next to the minimum-time term."""
+    assert d.grid in (capi.GRID_FD_VARIABLE, capi.GRID_MS_VARIABLE)
+    d.stage_cost = capi.COST_MIN_TIME_QUADRATIC_LSQ
+    for i, v in enumerate(q):
+        d.q_diag[i] = v
+    for i, v in enumerate(r):
+        d.r_diag[i] = v
+    return d
+
+
 # ---- SerialIntegratorSystem of order 3 (reference built-in, linear_benchmark_systems.h:50-118): fixed grid + quadratic cost, or time-optimal
 def int3_desc(N=30, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, time_optimal=False, shooting=False) -> ProblemDesc:
     if time_optimal:

@@ -89,9 +89,18 @@ typedef enum corbo_hip_stage_cost {
     CORBO_HIP_COST_NONE          = 0,
     CORBO_HIP_COST_QUADRATIC_LSQ = 1, /* QuadraticFormCost(Q,R, integral=false, lsq=true), diagonal Q,R, zero uref
                                          (quadratic_cost.cpp:100-184) */
-    CORBO_HIP_COST_MIN_TIME_LSQ  = 2  /* MinimumTime(lsq=true) (minimum_time.h:49-78); dt edge created twice
+    CORBO_HIP_COST_MIN_TIME_LSQ  = 2, /* MinimumTime(lsq=true) (minimum_time.h:49-78); dt edge created twice
                                          (nlp_functions.cpp:91-107) */
+    CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ = 3 /* MinTimeQuadratic(Q,R, integral=false, lsq=true), only_last_n = 0 (hybrid_cost.h:189-303): the
+                                         terms of both, per interval in the edge order of nlp_functions.cpp:70-107 (state term, control
+                                         term, at k = 0 the dt term twice); free-dt grids.  (QuadraticStateCost / QuadraticControlCost and
+                                         the hybrids built on them, MinTimeQuadraticStates / ...Controls, create NO least-squares term for a
+                                         diagonal weight: their diagonal setWeight overload leaves _Q / _R empty and the term dimension is
+                                         _Q.rows() -- quadratic_state_cost.cpp:33-62, quadratic_state_cost.h:50; such graphs are what is
+                                         left of them, COST_NONE resp. COST_MIN_TIME_LSQ, and the adapter's recogniser maps them so.) */
 } corbo_hip_stage_cost;
+/* which terms a stage cost has: bit 0 state term, bit 1 control term, bit 2 dt term (free-dt grids only) */
+#define CORBO_HIP_COST_TERMS(c) ((c) == 1 ? 3 : (c) == 2 ? 4 : (c) == 3 ? 7 : 0)
 
 typedef enum corbo_hip_stage_ineq {
     CORBO_HIP_INEQ_NONE = 0,

@@ -9,6 +9,7 @@
 #include <corbo-core/time.h>
 #include <corbo-optimal-control/functions/final_state_constraints.h>
 #include <corbo-optimal-control/functions/final_state_cost.h>
+#include <corbo-optimal-control/functions/hybrid_cost.h>
 #include <corbo-optimal-control/functions/minimum_time.h>
 #include <corbo-optimal-control/functions/quadratic_cost.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_grid.h>
@@ -259,7 +260,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         w      = 100;
         x0     = Eigen::Vector2d(0, 0);
         xf     = Eigen::Vector2d(1, 0);
-        solves = 5;
+        solves = (scenario == "dint_mtq") ? 2 : 5;
     }
     const double dt = (scenario == "quad") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
@@ -331,6 +332,14 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         ocp.setControlBounds(ulb, uub);
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
+    }
+    else if (scenario == "dint_mtq" || scenario == "dint_mtqs")
+    {   // hybrid costs (hybrid_cost.h): minimum time + quadratic form; "..s": MinTimeQuadraticStates, whose QuadraticStateCost creates no
+        // least-squares term for a diagonal Q (quadratic_state_cost.cpp:33-62) -- the graph is MinimumTime's
+        Eigen::MatrixXd Q = Eigen::Vector2d(1.0, 0.5).asDiagonal(), R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        if (scenario == "dint_mtq") ocp.setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, true));
+        else ocp.setStageCost(std::make_shared<MinTimeQuadraticStates>(Q, false, true));
+        ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else if (scenario == "dint" || scenario == "dint_ms")
     {
@@ -415,7 +424,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     return r;
 }
 
-static int horizon(const std::string& sc) { return sc == "unicycle" ? 100 : sc == "dint" ? 50 : sc == "vdp" ? 20 : 30; }
+static int horizon(const std::string& sc) { return sc == "unicycle" ? 100 : sc == "dint" ? 50 : sc == "vdp" ? 20 : sc == "dint_mtq" ? 40 : 30; }
 
 int main(int argc, char** argv)
 {
@@ -424,7 +433,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -434,7 +443,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -445,7 +454,7 @@ int main(int argc, char** argv)
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

@@ -199,6 +199,25 @@ def msvar():
     print("hess_int3_ms_time_optimal", d["n"])
 
 
+def mtq():
+    """MinTimeQuadratic (hybrid_cost.h:189-303: minimum time + quadratic form, least-squares form) on the free-dt grids: single solves and
+    the exact-Hessian operators."""
+    for name, kv, keep in [
+        ("dint_mtq", dict(scenario="dint", cost="mtq", iters=6, solves=2), (1, 2, 3, 6)),   # (cfg 2 runs 5 solves: 40 iterations at weight 100 amplify the FD noise to 3e-5)
+        ("int3_mtq_n20", dict(scenario="int3", vargrid=1, cost="mtq", N=20, iters=6), (1, 2, 3, 6)),
+        ("int3_ms_mtq", dict(scenario="int3", vargrid=1, grid="ms", cost="mtq", N=16, iters=6), (1, 2, 3, 6)),
+    ]:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], d["m"], [a["chi2"] for a in d["after_iter"]])
+    for name, kv in [("hess_dint_mtq", dict(scenario="dint", cost="mtq", N=12)), ("hess_int3_ms_mtq", dict(scenario="int3", vargrid=1, grid="ms", cost="mtq", N=8))]:
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"])
+
+
 def bigterm():
     """Final-stage constraints on the 12-state quadrotor (big-block family): TerminalBall (violated: active row) and the terminal equality."""
     for name, kv, keep in [
@@ -226,6 +245,8 @@ def main():
         return fullsize()
     if len(sys.argv) > 1 and sys.argv[1] == "adapt":
         return adapt()
+    if len(sys.argv) > 1 and sys.argv[1] == "mtq":
+        return mtq()
     # cfg 3 (headline structure, single instance, the SURVEY 8c known-answer trace), cfg 1, cfg 2
     for name, kv, keep in [
         ("unicycle", dict(scenario="unicycle"), (1, 2, 5, 10)),

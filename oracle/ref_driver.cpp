@@ -26,7 +26,10 @@
 #include <corbo-numerics/finite_differences_collocation.h>
 #include <corbo-optimal-control/functions/final_state_constraints.h>
 #include <corbo-optimal-control/functions/final_state_cost.h>
+#include <corbo-optimal-control/functions/hybrid_cost.h>
 #include <corbo-optimal-control/functions/minimum_time.h>
+#include <corbo-optimal-control/functions/quadratic_control_cost.h>
+#include <corbo-optimal-control/functions/quadratic_state_cost.h>
 #include <corbo-optimal-control/functions/quadratic_cost.h>
 #include <corbo-optimal-control/statistics.h>
 #include <corbo-optimal-control/structured_ocp/discretization_grids/finite_differences_grid.h>
@@ -135,6 +138,9 @@ struct Scenario
     std::string collocation = "crank_nicolson";
     Eigen::VectorXd ball;       // ball=cx,cy,cz,r: BallKeepOut stage inequality on the first three state components (unicycle)
     Eigen::VectorXd xlb, xub, ulb, uub;   // xlb=/xub=/ulb=/uub= comma lists ("inf" = unbounded): replace the scenario's box bounds
+    // cost=mtq|qstate|qctrl|mtqs|mtqc: replace the scenario's stage cost by MinTimeQuadratic / QuadraticStateCost / QuadraticControlCost /
+    // MinTimeQuadraticStates / MinTimeQuadraticControls (lsq form), Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
+    std::string cost;
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
     bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
@@ -438,6 +444,20 @@ static Built build(const Scenario& s, int iterations)
         Eigen::VectorXd uu = s.uub.size() ? s.uub : Eigen::VectorXd::Constant(s.nu, CORBO_INF_DBL);
         b.ocp->setBounds(xl, xu, ul, uu);
     }
+    if (!s.cost.empty())
+    {
+        Eigen::VectorXd q(s.nx), r(s.nu);
+        const double qv[4] = {1.0, 0.5, 0.2, 0.1}, rv[3] = {0.1, 0.2, 0.05};
+        for (int i = 0; i < s.nx; ++i) q[i] = qv[i % 4];
+        for (int i = 0; i < s.nu; ++i) r[i] = rv[i % 3];
+        Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
+        if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, true));
+        else if (s.cost == "qstate") b.ocp->setStageCost(std::make_shared<QuadraticStateCost>(Q, false, true));
+        else if (s.cost == "qctrl") b.ocp->setStageCost(std::make_shared<QuadraticControlCost>(R, false, true));
+        else if (s.cost == "mtqs") b.ocp->setStageCost(std::make_shared<MinTimeQuadraticStates>(Q, false, true));
+        else if (s.cost == "mtqc") b.ocp->setStageCost(std::make_shared<MinTimeQuadraticControls>(R, false, true));
+        else { fprintf(stderr, "unknown cost=%s\n", s.cost.c_str()); exit(2); }
+    }
     if (s.final_cost == 0) b.ocp->setFinalStageCost({});
     if (s.ball.size() == 4 && s.name != "quad")
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
@@ -646,6 +666,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("xref_traj")) s.xref_traj = atoi(kv["xref_traj"].c_str()) != 0;
     if (kv.count("uref")) s.uref = vec(kv["uref"]);
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
+    if (kv.count("cost")) s.cost = kv["cost"];
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
     if (kv.count("nmin")) s.n_min = atoi(kv["nmin"].c_str());
@@ -669,6 +690,7 @@ static int dump(const Scenario& s)
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.vargrid) printf("\"vargrid\": 1,\n");
+    if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.xlb.size()) printVec("xlb", s.xlb);
     if (s.xub.size()) printVec("xub", s.xub);
     if (s.ulb.size()) printVec("ulb", s.ulb);
@@ -986,6 +1008,7 @@ static int hess(const Scenario& s)
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.vargrid) printf("\"vargrid\": 1,\n");
+    if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
     if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
     if (s.xlb.size()) printVec("xlb", s.xlb);

@@ -52,8 +52,14 @@ def desc_for(g):
     defect = {"forward": capi.DEFECT_FORWARD, "backward": capi.DEFECT_BACKWARD, "midpoint": capi.DEFECT_MIDPOINT,
               "crank_nicolson": capi.DEFECT_CRANK_NICOLSON}[g.get("collocation", "crank_nicolson")]
     sc = g["scenario"]
+    def cost_option(d):   # cost=mtq of oracle/ref_driver.cpp: MinTimeQuadratic, Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
+        if g.get("cost") == "mtq":
+            problems.min_time_quadratic(d, (1.0, 0.5, 0.2, 0.1)[: d.nx], (0.1, 0.2, 0.05)[: d.nu])
+        else:
+            assert "cost" not in g, g["cost"]
+        return d
     if sc == "dint":
-        return problems.dint_desc(N=g["N"], dt=g["dt"])
+        return cost_option(problems.dint_desc(N=g["N"], dt=g["dt"], shooting=(g.get("grid") == "ms")))
     if sc == "quad":
         d = problems.quad_desc(N=g["N"], dt=g["dt"])
     elif sc == "int3":
@@ -89,6 +95,7 @@ def desc_for(g):
             d.final_ineq_params[i] = v
     if g.get("teq"):            # TerminalEqualityConstraint(xf)
         d.final_eq = 1
+    cost_option(d)
     if "ball" in g:             # BallKeepOut stage inequality
         d.stage_ineq = capi.INEQ_BALL
         for i, v in enumerate(g["ball"]):

@@ -48,6 +48,13 @@ def test_time_optimal_variable_grid_and_shooting_grid(described):
     t = described["dint"]                                # cfg 2: FiniteDifferencesVariableGrid, MinimumTime(lsq) with its duplicated dt edge
     assert t["recognised"] == 1 and t["grid"] == capi.GRID_FD_VARIABLE and t["stage_cost"] == capi.COST_MIN_TIME_LSQ and t["final_cost"] == 0
     assert t["dynamics"] == capi.DYN_SERIAL_INTEGRATOR and t["dyn_params"][0] == 1.0 and t["N"] == 50
+    m = described["dint_ms"]                             # the same on the MultipleShootingVariableGrid (told apart from the fixed shooting grid by RTTI)
+    assert m["recognised"] == 1 and (m["grid"], m["defect"], m["stage_cost"]) == (capi.GRID_MS_VARIABLE, capi.DEFECT_RK4_SHOOTING, capi.COST_MIN_TIME_LSQ)
+    h = described["dint_mtq"]                            # MinTimeQuadratic: state, control and minimum-time terms (hybrid_cost.h:189-303)
+    assert h["recognised"] == 1 and h["grid"] == capi.GRID_FD_VARIABLE and h["stage_cost"] == capi.COST_MIN_TIME_QUADRATIC_LSQ
+    assert _sqrt_equal(h["q_diag"], [1.0, 0.5]) and _sqrt_equal(h["r_diag"], [0.1]) and h["final_cost"] == 0
+    hs = described["dint_mtqs"]                          # MinTimeQuadraticStates with a diagonal Q: the reference creates no state term
+    assert hs["recognised"] == 1 and hs["stage_cost"] == capi.COST_MIN_TIME_LSQ   # (quadratic_state_cost.cpp:33-62) -- the graph is MinimumTime's
     l = described["lin32"]                               # LinearStateSpaceModel on the MultipleShootingGrid with RK4
     assert l["recognised"] == 1 and (l["grid"], l["defect"], l["dynamics"]) == (capi.GRID_MS, capi.DEFECT_RK4_SHOOTING, capi.DYN_LINEAR_STATE_SPACE)
     assert l["lin_a"] == [-1.113, -0.741, -0.817, 0.197, 0.209, 0.203, 0.864, 0.45, 0.221]

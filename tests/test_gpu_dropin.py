@@ -29,8 +29,8 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # cfg 3, cfg 2, reduced cfg 5, TerminalBall, cfg 1 (a = 1.3), Duffing (midpoint, private parameters), pendulum (+ terminal equality),
     # linear state-space model on the shooting grid -- all recognised from the graph; then the stated-model override
     # ... and a time-varying state reference (DiscreteTimeReferenceTrajectory): one reference per cost edge, corbo_hip_set_references
-    assert [r["scenario"] for r in solved] == ["unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "unicycle"], (p.stdout, p.stderr)
-    assert [r["mode"] for r in solved] == ["recognised"] * 10 + ["stated"]   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid)
+    assert [r["scenario"] for r in solved] == ["unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle"], (p.stdout, p.stderr)
+    assert [r["mode"] for r in solved] == ["recognised"] * 11 + ["stated"]   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic)
     for r in solved:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, (r, p.stderr[-2000:])
         # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
@@ -40,7 +40,7 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # the operators of the exact-Hessian path through the adapter (LevenbergMarquardtSparseHip::computeSparseHessians*), at a generic point
     # of the same graphs, against the graph's own computeSparseHessians{NNZ,Structure,Values}: identical lists, values within the
     # reference's own consecutive-call spread (tests/test_gpu_hessian.py)
-    assert [r["scenario"] for r in hessian] == ["unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms"], p.stdout
+    assert [r["scenario"] for r in hessian] == ["unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq"], p.stdout
     for r in hessian:
         assert r["ok_hip"] == 1 and r["structure_equal"] == 1 and r["nnz"][1] > 0 and r["max_rel_diff"] <= 2e-4, r
     # a stated model with a wrong CONTROL weight -- invisible in the residual at the reference's initial guess u = 0 -- is refused by the

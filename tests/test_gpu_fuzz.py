@@ -30,6 +30,8 @@ def random_desc(rng, long_horizon=False):
         d = problems.dint_desc(N=N, dt=dt) if fam == "dint" else problems.int3_desc(N=N, dt=dt, time_optimal=True)
         if N % 3 == 0:   # (no extra draw: the other cases keep theirs) the same on the shooting grid, MultipleShootingVariableGrid + RK4
             d.grid, d.defect = capi.GRID_MS_VARIABLE, capi.DEFECT_RK4_SHOOTING
+        if N % 4 == 1:   # MinTimeQuadratic: the quadratic form's terms next to the minimum-time term (fixed weights: no extra draw)
+            problems.min_time_quadratic(d, (1.0, 0.5, 0.2)[: d.nx], (0.1,))
         nx, nu = d.nx, 1
         full = 2 ** nx - 1
         d.xf_fixed_mask = int(rng.choice([full, full, 1, full - 1, 0]))
