@@ -182,8 +182,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     double w = 10;
     Eigen::VectorXd x0, xf;
     int solves = 1, nu = 1;
+    const bool tballc = (scenario == "unicycle_tballc");   // TerminalBallInheritFromCost: S = the final cost's Qf
     const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref");
-    const bool uni = (scenario == "unicycle" || tball || fullq || tvref);
+    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref);
     if (uni)
     {
         dyn  = std::make_shared<UnicycleRef>();
@@ -319,6 +320,12 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
             Eigen::MatrixXd Sm = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
             ocp.setFinalStageConstraint(std::make_shared<TerminalBall>(Sm, 0.05));
         }
+        if (tballc)
+        {   // (final_state_constraints.h:98-127: gamma is a public member of the derived class, S arrives in update() from the final cost)
+            auto c    = std::make_shared<TerminalBallInheritFromCost>();
+            c->_gamma = 0.4;
+            ocp.setFinalStageConstraint(c);
+        }
     }
     else if (scenario == "quad")
     {
@@ -424,7 +431,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     return r;
 }
 
-static int horizon(const std::string& sc) { return sc == "unicycle" ? 100 : sc == "dint" ? 50 : sc == "vdp" ? 20 : sc == "dint_mtq" ? 40 : 30; }
+static int horizon(const std::string& sc) { return sc == "unicycle" ? 100 : sc == "unicycle_tballc" ? 24 : sc == "dint" ? 50 : sc == "vdp" ? 20 : sc == "dint_mtq" ? 40 : 30; }
 
 int main(int argc, char** argv)
 {
@@ -443,7 +450,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
