@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_synchronize", "corbo_hip_get_solution", "corbo_hip_get_stats", "corbo_hip_eval",
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
     "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
-    "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_plant_set_params", "corbo_hip_warm_start_from_plant",
+    "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_plant_set_params", "corbo_hip_set_instance_params", "corbo_hip_warm_start_from_plant",
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
     "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_plant_step.argtypes = [H, C.c_int, C.c_double, dp]
     lib.corbo_hip_plant_get_state.argtypes = [H, dp]
     lib.corbo_hip_plant_set_params.argtypes = [H, dp]
+    lib.corbo_hip_set_instance_params.argtypes = [H, dp]
     lib.corbo_hip_warm_start_from_plant.argtypes = [H, C.c_int]
     lib.corbo_hip_closed_loop.argtypes = [H, C.POINTER(LmOpts), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp]
     lib.corbo_hip_set_profiling.argtypes = [H, C.c_int]

@@ -126,6 +126,7 @@ struct corbo_hip_solver {
     double* d_refvec = nullptr;   // per-component references [batch][nvs] (corbo_hip_set_references), allocated on first use
     bool refvec_on   = false;
     double* d_plant_prm = nullptr;   // per-instance plant model parameters [batch][8] (corbo_hip_plant_set_params) or null
+    double* d_dyn_inst  = nullptr;   // per-instance parameters of the controller's dynamics [batch][8] (corbo_hip_set_instance_params) or null
     double* d_reftraj = nullptr;  // resident reference trajectory [batch][ref_T][nx] (corbo_hip_set_reference_trajectory)
     int ref_T = 0, ref_step = 0;
     double *d_values0 = nullptr, *d_values1 = nullptr, *d_jac = nullptr;
@@ -183,6 +184,7 @@ struct corbo_hip_solver {
         p.mode = mode; p.iterations = iterations; p.w_eq = weq; p.w_ineq = wineq; p.w_b = wb;
         p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
         p.refvec = refvec_on ? d_refvec : nullptr;
+        p.dyn_inst = d_dyn_inst;
         p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
         p.st = d_state; p.active_count = counter; p.chi2 = d_chi2;
         return p;
@@ -394,7 +396,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_refvec, h->d_reftraj, h->d_plant_prm};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -831,7 +833,7 @@ int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const do
     p.batch = h->batch; p.nvs = S.nvs; p.nx = S.nx; p.nu = S.nu; p.integrator = integrator; p.dt = dt;
     h->fill_dyn(p.dyn);
     p.x = h->d_x; p.xplant = h->d_xplant; p.disturbance = disturbance ? h->h_dist : nullptr;
-    p.dyn_inst = h->d_plant_prm;
+    p.dyn_inst = h->d_plant_prm ? h->d_plant_prm : h->d_dyn_inst;   // the plant's own parameters, else the controller's (per instance or the descriptor's)
     if (!launch_plant_step(S.desc, p, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no plant kernel for this dynamics");
     HIP_TRY(hipGetLastError());
     return CORBO_HIP_OK;
@@ -851,6 +853,27 @@ try {
     const size_t bytes = (size_t)h->batch * 8 * sizeof(double);
     if (!h->d_plant_prm) HIP_TRY(hipMalloc((void**)&h->d_plant_prm, bytes));
     HIP_TRY(hipMemcpy(h->d_plant_prm, params, bytes, hipMemcpyHostToDevice));
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_set_instance_params(corbo_hip_handle h, const double* params)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->sink_valid = false;
+    if (!params) {   // every instance uses the descriptor's parameters again
+        if (h->d_dyn_inst) { (void)hipFree(h->d_dyn_inst); h->d_dyn_inst = nullptr; }
+        return CORBO_HIP_OK;
+    }
+    if (h->S.desc.dynamics == CORBO_HIP_DYN_LINEAR_STATE_SPACE)
+        return fail(CORBO_HIP_ERR_UNSUPPORTED, "corbo_hip_set_instance_params: the linear state-space model keeps its matrices per handle");
+    for (size_t i = 0; i < (size_t)h->batch * 8; ++i)
+        if (!std::isfinite(params[i])) return fail(CORBO_HIP_ERR_INVALID, "corbo_hip_set_instance_params: non-finite parameter");
+    const size_t bytes = (size_t)h->batch * 8 * sizeof(double);
+    if (!h->d_dyn_inst) HIP_TRY(hipMalloc((void**)&h->d_dyn_inst, bytes));
+    HIP_TRY(hipMemcpy(h->d_dyn_inst, params, bytes, hipMemcpyHostToDevice));
     return CORBO_HIP_OK;
 }
 ABI_CATCH
@@ -915,7 +938,7 @@ try {
         PlantParams pp{};
         pp.batch = h->batch; pp.nvs = S.nvs; pp.nx = S.nx; pp.nu = S.nu; pp.integrator = integrator; pp.dt = dt;
         h->fill_dyn(pp.dyn);
-        pp.x = h->d_x; pp.xplant = h->d_xplant; pp.dyn_inst = h->d_plant_prm;
+        pp.x = h->d_x; pp.xplant = h->d_xplant; pp.dyn_inst = h->d_plant_prm ? h->d_plant_prm : h->d_dyn_inst;
         pp.disturbance = disturbance ? h->h_loop + (size_t)s * B * NXm : nullptr;   // read by the kernel from pinned host memory
         pp.log_x = d_logx ? d_logx + (size_t)s * B * S.nx : nullptr;
         pp.log_u = d_logu ? d_logu + (size_t)s * B * S.nu : nullptr;

@@ -52,6 +52,21 @@ __device__ __forceinline__ double wave_max(double v)
 
 // end of one outer LM iteration: levenberg_marquardt_sparse.cpp:216-218
 // (works on scalars: whole-struct copies of LmState end up in scratch memory)
+// A value every lane of the wave loads from the same address: kept in scalar registers like a kernel argument.
+__device__ __forceinline__ double uniform_load(const double* q)
+{
+    const double v = *q;
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// The 8 parameters of the dynamics for one instance: the descriptor's (kernel argument) or the instance's own
+// (corbo_hip_set_instance_params; the instance is uniform over the workgroup / wave in every kernel that evaluates dynamics).
+#define CORBO_HIP_DYN_OF(dynl, P, INST)                                                                \
+    double dynl[8];                                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) dynl[i_] = (P).mp.dyn[i_];                         \
+    if ((P).dyn_inst) {                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) dynl[i_] = uniform_load((P).dyn_inst + (size_t)(INST) * 8 + i_); \
+    }
+
 __device__ __forceinline__ bool lm_end_outer(LmState* st, double last_sq, double rho, int k, int iterations)
 {
     const int stop = (sqrt(last_sq) <= LM_EPS3) ? 1 : 0;
@@ -106,6 +121,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if constexpr (!STAGE) jst = js;
     int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
     const size_t xo = (size_t)inst * p.nvs;
+    CORBO_HIP_DYN_OF(dynl, p, inst)
 
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
@@ -254,7 +270,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
         for (int k = tid; k < p.N; k += SWEEP_THREADS) {
             double c[NC];
-            Dy::prepare(xs + k * S, p.mp.dyn, c);
+            Dy::prepare(xs + k * S, dynl, c);
 #pragma unroll
             for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
         }
@@ -281,11 +297,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         const int base = k * S;
         double e[NX];
         if constexpr (CACHED)
-            defect_eval_cached<DYN, DEFECT>(xs + base, cs + k * NC, xs + base + NX, xs + base + S, cs + (k + 1) * NC, xs[p.off_dt], p.mp.dyn, e);
+            defect_eval_cached<DYN, DEFECT>(xs + base, cs + k * NC, xs + base + NX, xs + base + S, cs + (k + 1) * NC, xs[p.off_dt], dynl, e);
         else if constexpr (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING && !STAGE) {
             // same operations as defect_eval (end state of the step, then the subtraction); the end state is kept for the stage kernel
             double ck[4][NC], xe[NX];
-            rk4_end_state<DYN, false>(xs + base, xs + base + NX, xs[p.off_dt], p.mp.dyn, ck, xe);
+            rk4_end_state<DYN, false>(xs + base, xs + base + NX, xs[p.off_dt], dynl, ck, xe);
             double* xeo = p.xe0 ? p.xe0 + (((size_t)vsel * p.batch_total + inst) * p.N + k) * NX : nullptr;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
@@ -294,7 +310,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
         else
-            defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], p.mp.dyn, e);
+            defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], dynl, e);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double val = e[i] * p.w_eq;
@@ -431,8 +447,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 for (int i = 0; i < NC; ++i) { c1[i] = cs[k * NC + i]; c2[i] = cs[(k + 1) * NC + i]; }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) q[i] = (x2[i] - x1[i]) / dt0;
-                Dy::eval(x1, c1, u1, p.mp.dyn, f1);
-                Dy::eval(x2, c2, u1, p.mp.dyn, f2);
+                Dy::eval(x1, c1, u1, dynl, f1);
+                Dy::eval(x2, c2, u1, dynl, f2);
                 if (g == 0) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {  // d/d x_k[i]: q_i and f(x1,u1) change
@@ -448,12 +464,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                             for (int r = 0; r < NX; ++r) { xp[r] = (r == i) ? xa : x1[r]; qp[r] = q[r]; fp[r] = f1[r]; }
                             qp[i] = (x2[i] - xa) / dt0;
                             if constexpr (DP::uses_f1) {
-                                if ((Dy::CACHE_XMASK >> i) & 1u) Dy::prepare(xp, p.mp.dyn, cp);
+                                if ((Dy::CACHE_XMASK >> i) & 1u) Dy::prepare(xp, dynl, cp);
                                 else {
 #pragma unroll
                                     for (int r = 0; r < NC; ++r) cp[r] = c1[r];
                                 }
-                                Dy::eval(xp, cp, u1, p.mp.dyn, fp);
+                                Dy::eval(xp, cp, u1, dynl, fp);
                             }
                             defect_combine<NX, DEFECT>(qp, fp, f2, e[side]);
                         }
@@ -475,8 +491,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                         for (int r = 0; r < NU; ++r) up[r] = (r == j) ? ua : u1[r];
 #pragma unroll
                         for (int r = 0; r < NX; ++r) { g1[r] = f1[r]; g2[r] = f2[r]; }
-                        if constexpr (DP::uses_f1) Dy::eval(x1, c1, up, p.mp.dyn, g1);
-                        if constexpr (DP::uses_f2) Dy::eval(x2, c2, up, p.mp.dyn, g2);
+                        if constexpr (DP::uses_f1) Dy::eval(x1, c1, up, dynl, g1);
+                        if constexpr (DP::uses_f2) Dy::eval(x2, c2, up, dynl, g2);
                         defect_combine<NX, DEFECT>(q, g1, g2, e[side]);
                     }
                     emit(jo, e[0], e[1]);
@@ -496,12 +512,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                             for (int r = 0; r < NX; ++r) { xp[r] = (r == i) ? xa : x2[r]; qp[r] = q[r]; fp[r] = f2[r]; }
                             qp[i] = (xa - x1[i]) / dt0;
                             if constexpr (DP::uses_f2) {
-                                if ((Dy::CACHE_XMASK >> i) & 1u) Dy::prepare(xp, p.mp.dyn, cp);
+                                if ((Dy::CACHE_XMASK >> i) & 1u) Dy::prepare(xp, dynl, cp);
                                 else {
 #pragma unroll
                                     for (int r = 0; r < NC; ++r) cp[r] = c2[r];
                                 }
-                                Dy::eval(xp, cp, u1, p.mp.dyn, fp);
+                                Dy::eval(xp, cp, u1, dynl, fp);
                             }
                             defect_combine<NX, DEFECT>(qp, f1, fp, e[side]);
                         }
@@ -536,7 +552,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 for (int i = 0; i < NX; ++i) { loc[i] = x1[i]; loc[S + i] = x2[i]; }
 #pragma unroll
                 for (int i = 0; i < NU; ++i) loc[NX + i] = u1[i];
-                rk4_end_state<DYN, false>(loc, loc + NX, dt0, p.mp.dyn, ck, xe0);
+                rk4_end_state<DYN, false>(loc, loc + NX, dt0, dynl, ck, xe0);
 #pragma unroll
                 for (int c = 0; c < S; ++c) {
                     const bool mine = (((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (g == 1);
@@ -550,9 +566,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                         double xe[NX];
                         if (((Dy::RK4_CACHE_DEP_COLS >> c) & 1u) != 0u) {   // (compile-time after unrolling)
                             double ct[4][NC];
-                            rk4_end_state<DYN, false>(loc, loc + NX, dt0, p.mp.dyn, ct, xe);
+                            rk4_end_state<DYN, false>(loc, loc + NX, dt0, dynl, ct, xe);
                         }
-                        else rk4_end_state<DYN, true>(loc, loc + NX, dt0, p.mp.dyn, ck, xe);
+                        else rk4_end_state<DYN, true>(loc, loc + NX, dt0, dynl, ck, xe);
 #pragma unroll
                         for (int r = 0; r < NX; ++r) e[side][r] = xe[r] - x2[r];
                     }
@@ -582,7 +598,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     for (int side = 0; side < 2; ++side) {
                         da += (side == 0) ? delta : neg2delta;
                         double ct[4][NC], xe[NX];
-                        rk4_end_state<DYN, false>(loc, loc + NX, da, p.mp.dyn, ct, xe);
+                        rk4_end_state<DYN, false>(loc, loc + NX, da, dynl, ct, xe);
 #pragma unroll
                         for (int r = 0; r < NX; ++r) e[side][r] = xe[r] - x2[r];
                     }
@@ -605,7 +621,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
                     for (int side = 0; side < 2; ++side) {
                         loc[c] += (side == 0) ? delta : neg2delta;
-                        defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt0, p.mp.dyn, e[side]);
+                        defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt0, dynl, e[side]);
                     }
                     loc[c] = keep;
                     emit(jo, e[0], e[1]);
@@ -617,7 +633,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
                     for (int side = 0; side < 2; ++side) {
                         da += (side == 0) ? delta : neg2delta;
-                        defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, da, p.mp.dyn, e[side]);
+                        defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, da, dynl, e[side]);
                     }
                     emit(jo, e[0], e[1]);
                 }
@@ -1895,7 +1911,8 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         if (minus) pert += neg2delta;
 #pragma unroll
         for (int i = 0; i < S; ++i) loc[i] = (i == col) ? pert : loc[i];
-        rk4_end_state<DYN, false>(loc, loc + NX, dt0, sp.mp.dyn, ck, xe);
+        CORBO_HIP_DYN_OF(dynl, sp, inst)
+        rk4_end_state<DYN, false>(loc, loc + NX, dt0, dynl, ck, xe);
         int jo = 0;
 #pragma unroll
         for (int i = 0; i < S; ++i) jo = (i == col) ? sc[i] : jo;
@@ -3018,6 +3035,9 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
     if (!p.dt_free) fm |= 1u << (W - 1);
     for (int i = 0; i < NX; ++i) xr[i] = p.refvec ? p.refvec[(size_t)inst * p.nvs + k * S + i] : p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
     const int32_t* so = hp.stage_off + (size_t)k * 6;
+    ModelParams mpl = p.mp;   // the instance's own parameters of the dynamics (corbo_hip_set_instance_params)
+    if (p.dyn_inst)
+        for (int i = 0; i < 8; ++i) mpl.dyn[i] = p.dyn_inst[(size_t)inst * 8 + i];
     if (hp.mode == 0) {
         double* vo = hp.vals[0] + (size_t)b * hp.nnz[0];
         double* ve = hp.vals[1] + (size_t)b * hp.nnz[1];
@@ -3040,7 +3060,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         double* next = nullptr;
         for (int e = 0; e < n_edges; ++e) {
             double* out = outs[e] ? outs[e] : next;   // (the duplicated dt edge follows the first one)
-            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, p.mp, hp.mult_obj, mults[e], out);
+            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out);
             next = out + n;
         }
     }
@@ -3061,8 +3081,8 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
             const int kind = kinds[e], ed = HE::edge_dim(kind), off = HE::vert_off(kind, 0), dim = HE::vert_dim(kind, 0);
             double blk[HE::MAXD * HE::MAXD], vals[HE::MAXD];
             const int nu_ = HE::unfixed(fm, off, dim);
-            if (nu_ > 0) HE::jacobian(kind, 0, fm, xl, xr, p.mp, blk);
-            HE::values(kind, xl, xr, p.mp, vals);
+            if (nu_ > 0) HE::jacobian(kind, 0, fm, xl, xr, mpl, blk);
+            HE::values(kind, xl, xr, mpl, vals);
             int col = 0;
             for (int i = 0; i < dim; ++i) {
                 if ((fm >> (off + i)) & 1u) continue;
@@ -3087,16 +3107,16 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         double c[NX];
         if (lo[0] >= 0) {   // computeBoundsForTwoSideBoundedLinearForm: lbA = ubA = -c_eq
             const int kind = final_stage ? EK_FINAL_EQ : EK_DEFECT;
-            HE::values(kind, xl, xr, p.mp, c);
+            HE::values(kind, xl, xr, mpl, c);
             for (int r = 0; r < NX; ++r) { lb[so[4] + r] = c[r] * -1; ub[so[4] + r] = c[r] * -1; }
-            HE::linear_blocks(kind, fm, xl, xr, p.mp, lv + lo[0]);
+            HE::linear_blocks(kind, fm, xl, xr, mpl, lv + lo[0]);
         }
         if (lo[1] >= 0) {   // (-inf, -c_ineq]
             const int kind = final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ;
-            HE::values(kind, xl, xr, p.mp, c);
+            HE::values(kind, xl, xr, mpl, c);
             lb[hp.eq_dim + so[5]] = -CORBO_HIP_INF;
             ub[hp.eq_dim + so[5]] = c[0] * -1;
-            HE::linear_blocks(kind, fm, xl, xr, p.mp, lv + lo[1]);
+            HE::linear_blocks(kind, fm, xl, xr, mpl, lv + lo[1]);
         }
         // finite bounds of this stage's components (and of dt, with the final stage): identity rows; lbA = lb - x, ubA = x - ub (sic, :1177-1178)
         const int ncomp = final_stage ? NX + 1 : S;

@@ -56,6 +56,7 @@ struct SweepParams {
     const double* ub;
     const double* xref; // [batch][MAX_NX]
     const double* refvec;  // or null: per-component state references in the vertex layout [batch][nvs] (time-varying reference,
+    const double* dyn_inst;      // [batch_total][8] per-instance parameters of the dynamics (corbo_hip_set_instance_params) or null: mp.dyn for all
                            // corbo_hip_set_references): the cost row of state component v is w * (x_v - refvec[v]); final-stage terms use the x_f entries
     double* values0;    // [batch][m]   residual buffer 0
     double* values1;    // [batch][m]   residual buffer 1 (LM only)

@@ -144,6 +144,15 @@ class BatchedLevenbergMarquardt:
         pr = np.ascontiguousarray(np.broadcast_to(np.asarray(params, np.float64), (self.batch, 8)))
         self._check(self.lib.corbo_hip_plant_set_params(self._h, _dp(pr)), "corbo_hip_plant_set_params")
 
+    def set_instance_params(self, params=None):
+        """Per-instance parameters [B][8] of the controller's dynamics (order of the descriptor's dyn_params); None = the descriptor's again."""
+        if params is None:
+            self._check(self.lib.corbo_hip_set_instance_params(self._h, None), "corbo_hip_set_instance_params")
+            return
+        pr = np.ascontiguousarray(np.asarray(params, np.float64))
+        assert pr.shape == (self.batch, 8), pr.shape
+        self._check(self.lib.corbo_hip_set_instance_params(self._h, _dp(pr)), "corbo_hip_set_instance_params")
+
     def plant_get_state(self) -> np.ndarray:
         x = np.empty((self.batch, self.desc.nx))
         self._check(self.lib.corbo_hip_plant_get_state(self._h, x.ctypes.data_as(C.POINTER(C.c_double))), "corbo_hip_plant_get_state")

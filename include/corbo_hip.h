@@ -297,6 +297,13 @@ int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const do
  * parameters (order of the descriptor's dyn_params) of every instance's plant; NULL = the controller's again.  The controller keeps
  * the descriptor's parameters.  Not for CORBO_HIP_DYN_LINEAR_STATE_SPACE. */
 int corbo_hip_plant_set_params(corbo_hip_handle h, const double* params);
+/* Per-instance parameters of the CONTROLLER's dynamics (the `params` argument of SURVEY 8b's set_instance_data sketch): a batch of
+ * controllers for plants of one class that differ in their parameters -- in the reference one SystemDynamicsInterface object each
+ * (e.g. VanDerPolOscillator::setParameters(a), nonlinear_benchmark_systems.h) handed to its own StructuredOptimalControlProblem.
+ * params [batch][8] in the order of the descriptor's dyn_params; NULL = the descriptor's for every instance again.  Used by every
+ * kernel that evaluates the dynamics (LM solve, corbo_hip_eval, the Hessian-path operators, and the simulated plants unless
+ * corbo_hip_plant_set_params gave them their own).  Not for CORBO_HIP_DYN_LINEAR_STATE_SPACE.  Synchronises. */
+int corbo_hip_set_instance_params(corbo_hip_handle h, const double* params);
 /* SimulatedPlant::output with FullStateSystemOutput: x_out [batch][nx] (host).  Synchronises. */
 int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out);
 /* corbo_hip_warm_start with x0_new = the device-resident plant states (the measured state a controller is handed). */
