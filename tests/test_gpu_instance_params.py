@@ -151,3 +151,25 @@ def test_refusals():
     bad[1, 0] = np.nan
     with pytest.raises(CorboHipError):
         t.set_instance_params(bad)
+
+
+def test_large_batch_through_the_instance_queue(oracle_mod):
+    """More instances than resident workgroups: persistent workgroups pull instance after instance -- each with its own parameters."""
+    d = problems.vdp_desc(N=20)
+    B = 4500
+    rng = np.random.default_rng(21)
+    prm = np.zeros((B, 8))
+    prm[:, 0] = rng.uniform(0.5, 1.8, B)
+    x0 = rng.uniform(-1, 1, (B, 2))
+    xf = np.zeros((B, 2))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(5)
+    s.setPenaltyWeights(*problems.VDP_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    s.set_instance_params(prm)
+    s.solve()
+    X, chi2, _ = s.get_solution()
+    for b in (0, 1, 1023, 1024, 2047, 3000, B - 1):
+        Xo, co, _ = oracle_mod.solve_batch(_with_params(d, prm[b]), X0[b : b + 1], xf[b : b + 1], s.opts)
+        assert np.abs(X[b] - Xo[0]).max() <= 1e-5 and abs(chi2[b] - co[0]) <= 2e-6 * abs(co[0]), b
