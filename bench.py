@@ -394,9 +394,11 @@ def main():
         f_ms = solver.time_factor(repeat=5)
         alg_pair = per_stage * desc.N * B
         pc = profile_kernel_max_ns("r02_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
+        qpmc = load_profile_json("r02_cfg5_pmc.json", B, desc.N)
         line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance: FD Jacobian + assemble, then the block chain)",
                             "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                            "traffic": None, "bytes_per_launch": alg_pair, "bytes_per_interval": per_stage, "ms_per_launch": f_ms,
+                            "traffic": qpmc["hbm_bytes_per_launch"] if qpmc else None, "traffic_source": qpmc["source"] if qpmc else None,
+                            "bytes_per_launch": alg_pair, "bytes_per_interval": per_stage, "ms_per_launch": f_ms,
                             "timing": "HIP events around 5 back-to-back (stage, chain) launch pairs over all instances (corbo_hip_time_factor)",
                             "profile_full_launch_ms": pc[0] * 1e-6 if pc else None, "profile": pc[1] if pc else None,
                             "note": "the stage kernel is fp64-VALU-bound (RK4 finite differences), the chain a latency chain of 12 x 12 pivots; matrix-core view in `factorization`"}

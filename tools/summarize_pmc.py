@@ -7,6 +7,7 @@ uncalibrated there: recorded raw).
     python tools/summarize_pmc.py sweep <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/sweep_pmc_latest.json
     python tools/summarize_pmc.py solve <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/r02_solve_pmc.json
     python tools/summarize_pmc.py mfma  <counters.csv> <batch> <N> <tag>               -> profiles/r02_cfg5_mfma.json
+    python tools/summarize_pmc.py cfg5  <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/r02_cfg5_pmc.json
     python tools/summarize_pmc.py sq    <counters.csv> [<counters2.csv>] <batch> <N> <tag> -> profiles/r02_solve_sq.json
 """
 import collections
@@ -51,6 +52,28 @@ def traffic(kind, fetch_csv, write_csv, batch, N, tag):
     print(json.dumps(out))
 
 
+def cfg5_traffic(fetch_csv, write_csv, batch, N, tag):
+    """HBM-side traffic of the two kernels of a cfg-5 factorisation, per full launch (the tail passes' small launches dropped)."""
+    out = {"batch": batch, "N": N, "tag": tag, "kernels": {}}
+    tot_raw = tot = 0.0
+    for kernel in ("big_stage_kernel", "big_chain2_kernel"):
+        f = per_dispatch(fetch_csv, kernel)["FETCH_SIZE"]
+        w = per_dispatch(write_csv, kernel)["WRITE_SIZE"]
+        f = [v for v in f if v > 0.5 * max(f)]
+        w = [v for v in w if v > 0.5 * max(w)]
+        fa, wa = mean(f), mean(w)
+        out["kernels"][kernel] = {"dispatches_averaged": [len(f), len(w)], "FETCH_SIZE_KiB_per_launch_raw": fa, "WRITE_SIZE_KiB_per_launch_raw": wa,
+                                  "hbm_bytes_per_launch_raw": (fa + wa) * 1024.0, "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+        tot_raw += (fa + wa) * 1024.0
+        tot += (2.0 * fa + wa) * 1024.0
+    out["kernel"] = "big_stage_kernel + big_chain2_kernel"
+    out["hbm_bytes_per_launch_raw"], out["hbm_bytes_per_launch"] = tot_raw, tot
+    out["source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {tag}; per-dispatch means over the full launches of each kernel, summed over "
+                     "the pair; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction, WRITE_SIZE raw")
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_cfg5_pmc.json"), "w"), indent=1)
+    print(json.dumps(out))
+
+
 def mfma(path, batch, N, tag):
     """fp64 matrix-core counters of the cfg-5 kernels that use them."""
     out = {"batch": batch, "N": N, "tag": tag, "kernels": {}}
@@ -91,6 +114,8 @@ if __name__ == "__main__":
     kind = sys.argv[1]
     if kind in ("sweep", "solve"):
         traffic(kind, sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
+    elif kind == "cfg5":
+        cfg5_traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
     elif kind == "mfma":
         mfma(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
     elif kind == "sq":
