@@ -482,6 +482,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     std::vector<Eigen::VectorXd> stage_refs(g.N - 1);   // reference of the state cost term of every interval (getReferenceCached(k))
     bool refs_vary = false;
     int n_state = 0, n_ctrl = 0, n_final = 0, n_dt = 0;
+    int k_first_state = g.N, k_first_ctrl = g.N;   // first interval that carries a state / control term (MinTimeQuadratic::only_last_n)
     double dt_weight = 0.0;
     for (const BaseEdge::Ptr& ep : es->getLsqObjectiveEdges())
     {
@@ -508,6 +509,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         else if (indexOf(g.xs, v) >= 0)
         {
             stage_refs[indexOf(g.xs, v)] = ref;
+            k_first_state = std::min(k_first_state, indexOf(g.xs, v));
             if (n_state++ == 0) { sq = w; xref_state = ref; }
             else if (!sameVector(w, sq)) return fail(reason, "state cost weights vary along the horizon");
             else if (!sameVector(ref, xref_state)) refs_vary = true;   // a time-varying reference trajectory
@@ -515,6 +517,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         else if (indexOf(g.us, v) >= 0)
         {
             if ((ref.array() != 0.0).any()) return fail(reason, "non-zero control reference");
+            k_first_ctrl = std::min(k_first_ctrl, indexOf(g.us, v));
             if (n_ctrl++ == 0) sr = w;
             else if (!sameVector(w, sr)) return fail(reason, "control cost weights vary along the horizon");
         }
@@ -530,7 +533,13 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         if (dt_weight != std::sqrt((double)(g.N - 1))) return fail(reason, "minimum-time weight is not sqrt(N - 1)");
     }
     if ((n_state != 0) != (n_ctrl != 0)) return fail(reason, "quadratic stage cost with a state term but no control term, or the other way round (non-diagonal weights?)");
-    if (n_state && (n_state != g.N - 1 || n_ctrl != g.N - 1)) return fail(reason, "quadratic cost terms on some intervals only (MinTimeQuadratic with only_last_n?)");
+    if (n_state)
+    {   // on every interval -- or, next to a minimum-time term, on the last intervals only (MinTimeQuadratic::only_last_n, hybrid_cost.h:224-237)
+        const int k0 = k_first_state;
+        if (k_first_ctrl != k0 || n_state != g.N - 1 - k0 || n_ctrl != g.N - 1 - k0) return fail(reason, "quadratic cost terms on a set of intervals that is not a tail of the horizon");
+        if (k0 != 0 && !n_dt) return fail(reason, "quadratic cost terms on the last intervals only, without a minimum-time term");
+        d.quad_first_interval = k0;
+    }
     d.stage_cost = n_dt ? (n_state ? CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ : CORBO_HIP_COST_MIN_TIME_LSQ) : (n_state ? CORBO_HIP_COST_QUADRATIC_LSQ : CORBO_HIP_COST_NONE);
     if (n_state)
     {

@@ -3072,8 +3072,8 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         const int terms = CORBO_HIP_COST_TERMS(hp.stage_cost);
         if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = EK_FINAL_COST; }
         else {
-            if (terms & 1) kinds[n_edges++] = EK_STATE_COST;
-            if (terms & 2) kinds[n_edges++] = EK_CONTROL_COST;
+            if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = EK_STATE_COST;
+            if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = EK_CONTROL_COST;
             if ((terms & 4) && k == 0) { kinds[n_edges++] = EK_DT_COST; kinds[n_edges++] = EK_DT_COST; }
         }
         double obj = 0.0;

@@ -40,6 +40,8 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ && (CORBO_HIP_COST_TERMS(d.stage_cost) & 4) && d.grid != CORBO_HIP_GRID_FD_VARIABLE &&
         d.grid != CORBO_HIP_GRID_MS_VARIABLE)
         return "a stage cost with a minimum-time term needs a grid with a free dt";
+    if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
+    if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
     if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
@@ -98,8 +100,9 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     std::vector<E> lsq, eq, ineq;
     for (int k = 0; k < N - 1; ++k) {
         const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);   // nlp_functions.cpp:70-107: state term, control term, dt term twice
-        if (terms & 1) lsq.push_back({EK_STATE_COST, k, nx, 0});
-        if (terms & 2) lsq.push_back({EK_CONTROL_COST, k, nu, 0});
+        const bool quad = (k >= d.quad_first_interval);   // MinTimeQuadratic::only_last_n (hybrid_cost.h:224-237)
+        if ((terms & 1) && quad) lsq.push_back({EK_STATE_COST, k, nx, 0});
+        if ((terms & 2) && quad) lsq.push_back({EK_CONTROL_COST, k, nu, 0});
         if ((terms & 4) && k == 0) {   // MinimumTime on a single-dt grid: k = 0 only (minimum_time.h:49)
             lsq.push_back({EK_DT_COST, k, 1, 0});
             lsq.push_back({EK_DT_COST, k, 1, 0});  // duplicated edge
@@ -285,8 +288,9 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
     for (int k = 0; k < N - 1; ++k) {
         const V xk{k * s, nx}, uk{k * s + nx, nu};
         const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);
-        if (terms & 1) { H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xk, 1); }
-        if (terms & 2) { H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size(); walk(0, &uk, 1); }
+        const bool quad = (k >= d.quad_first_interval);
+        if ((terms & 1) && quad) { H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xk, 1); }
+        if ((terms & 2) && quad) { H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size(); walk(0, &uk, 1); }
         if ((terms & 4) && k == 0) {
             H.dt_cost_off = (int32_t)H.rows[0].size();
             walk(0, &dtv, 1);

@@ -97,11 +97,13 @@ def dint_desc(N=50, dt=0.1, shooting=False) -> ProblemDesc:
 DINT_WEIGHTS = (100.0, 100.0, 100.0)
 
 
-def min_time_quadratic(d: ProblemDesc, q, r) -> ProblemDesc:
+def min_time_quadratic(d: ProblemDesc, q, r, only_last_n=0) -> ProblemDesc:
     """Turn a time-optimal descriptor (free dt, MinimumTime) into the reference's MinTimeQuadratic(Q, R, integral=False, lsq=True)
-    (hybrid_cost.h:189-303): the quadratic form's state and control terms next to the minimum-time term."""
+    (hybrid_cost.h:189-303): the quadratic form's state and control terms next to the minimum-time term; only_last_n > 0: on the
+    last intervals only (the class's option of that name)."""
     assert d.grid in (capi.GRID_FD_VARIABLE, capi.GRID_MS_VARIABLE)
     d.stage_cost = capi.COST_MIN_TIME_QUADRATIC_LSQ
+    d.quad_first_interval = max(d.N - only_last_n, 0) if only_last_n > 0 else 0   # _quad_k_min of hybrid_cost.h:224-237
     for i, v in enumerate(q):
         d.q_diag[i] = v
     for i, v in enumerate(r):

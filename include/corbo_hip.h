@@ -145,6 +145,10 @@ typedef struct corbo_hip_problem_desc {
     /* CORBO_HIP_DYN_LINEAR_STATE_SPACE (LinearStateSpaceModel::setParameters(A, B)): row-major A[i * nx + j], B[i * nu + j] */
     double lin_a[16];
     double lin_b[12];
+    /* CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ only: first interval that carries the quadratic form's terms -- MinTimeQuadratic's
+     * only_last_n option, _quad_k_min = max(N - only_last_n, 0) (hybrid_cost.h:224-237); 0 = every interval */
+    int32_t quad_first_interval;
+    int32_t reserved0;
 } corbo_hip_problem_desc;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */

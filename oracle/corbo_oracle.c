@@ -344,6 +344,8 @@ static int validate(const corbo_hip_problem_desc* d)
     if (d->stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ && (CORBO_HIP_COST_TERMS(d->stage_cost) & 4) && d->grid != CORBO_HIP_GRID_FD_VARIABLE &&
         d->grid != CORBO_HIP_GRID_MS_VARIABLE)
         return 0;
+    if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
+    if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
     if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
     if (d->stage_ineq == CORBO_HIP_INEQ_BALL && d->nx < 3) return 0;
     if (!(d->dt_ref > 0)) return 0;
@@ -458,10 +460,11 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         int xk = 2 * k, uk = 2 * k + 1, xnext = 2 * (k + 1); /* x_next = (k < n-2) ? x_seq[k+1] : xf */
         /* MinTimeQuadratic (hybrid_cost.h:189-303) has all three terms, in this order */
         const int terms = CORBO_HIP_COST_TERMS(d->stage_cost);
-        if (terms & 1) {
+        const int quad = (k >= d->quad_first_interval); /* MinTimeQuadratic::only_last_n, hybrid_cost.h:224-237 */
+        if ((terms & 1) && quad) {
             o_edge* e = &lsq[n_lsq++]; e->type = E_STATE_COST; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = nx; e->scale = 0;
         }
-        if (terms & 2) {
+        if ((terms & 2) && quad) {
             o_edge* e = &lsq[n_lsq++]; e->type = E_CONTROL_COST; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = nu; e->scale = 0;
         }
         if ((terms & 4) && k == 0) {

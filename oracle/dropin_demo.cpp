@@ -127,8 +127,8 @@ static void printDesc(const char* scenario, bool ok, const std::string& why, con
     printf("{\"scenario\": \"%s\", \"recognised\": %d, \"reason\": \"%s\"", scenario, ok ? 1 : 0, why.c_str());
     if (ok)
     {
-        printf(", \"grid\": %d, \"defect\": %d, \"dynamics\": %d, \"stage_cost\": %d, \"final_cost\": %d, \"stage_ineq\": %d, \"final_ineq\": %d, \"final_eq\": %d, \"nx\": %d, \"nu\": %d, \"N\": %d",
-               d.grid, d.defect, d.dynamics, d.stage_cost, d.final_cost, d.stage_ineq, d.final_ineq, d.final_eq, d.nx, d.nu, d.N);
+        printf(", \"grid\": %d, \"defect\": %d, \"dynamics\": %d, \"stage_cost\": %d, \"final_cost\": %d, \"stage_ineq\": %d, \"final_ineq\": %d, \"final_eq\": %d, \"quad_first_interval\": %d, \"nx\": %d, \"nu\": %d, \"N\": %d",
+               d.grid, d.defect, d.dynamics, d.stage_cost, d.final_cost, d.stage_ineq, d.final_ineq, d.final_eq, d.quad_first_interval, d.nx, d.nu, d.N);
         auto arr = [](const char* name, const double* v, int n) {
             printf(", \"%s\": [", name);
             for (int i = 0; i < n; ++i) printf("%s%.17g", i ? ", " : "", v[i]);
@@ -261,7 +261,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         w      = 100;
         x0     = Eigen::Vector2d(0, 0);
         xf     = Eigen::Vector2d(1, 0);
-        solves = (scenario == "dint_mtq") ? 2 : 5;
+        solves = (scenario == "dint_mtq" || scenario == "dint_mtq8") ? 2 : 5;
     }
     const double dt = (scenario == "quad") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
@@ -339,6 +339,16 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         ocp.setControlBounds(ulb, uub);
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
+    }
+    else if (scenario == "dint_mtq8")
+    {   // MinTimeQuadratic with only_last_n = 8 (no setter outside fromMessage, hybrid_cost.h:300: a subclass reaches the protected member)
+        struct LastN : public MinTimeQuadratic
+        {
+            LastN(const Eigen::MatrixXd& Q, const Eigen::MatrixXd& R, int n) : MinTimeQuadratic(Q, R, false, true) { _only_last_n = n; }
+        };
+        Eigen::MatrixXd Q = Eigen::Vector2d(1.0, 0.5).asDiagonal(), R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        ocp.setStageCost(std::make_shared<LastN>(Q, R, 8));
+        ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else if (scenario == "dint_mtq" || scenario == "dint_mtqs")
     {   // hybrid costs (hybrid_cost.h): minimum time + quadratic form; "..s": MinTimeQuadraticStates, whose QuadraticStateCost creates no
@@ -440,7 +450,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -450,7 +460,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);

@@ -206,12 +206,14 @@ def mtq():
         ("dint_mtq", dict(scenario="dint", cost="mtq", iters=6, solves=2), (1, 2, 3, 6)),   # (cfg 2 runs 5 solves: 40 iterations at weight 100 amplify the FD noise to 3e-5)
         ("int3_mtq_n20", dict(scenario="int3", vargrid=1, cost="mtq", N=20, iters=6), (1, 2, 3, 6)),
         ("int3_ms_mtq", dict(scenario="int3", vargrid=1, grid="ms", cost="mtq", N=16, iters=6), (1, 2, 3, 6)),
+        ("int3_mtq_last6", dict(scenario="int3", vargrid=1, cost="mtq", last_n=6, N=20, iters=6), (1, 2, 3, 6)),   # only_last_n: quadratic terms near the goal only
     ]:
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))
         print(name, d["n"], d["m"], [a["chi2"] for a in d["after_iter"]])
-    for name, kv in [("hess_dint_mtq", dict(scenario="dint", cost="mtq", N=12)), ("hess_int3_ms_mtq", dict(scenario="int3", vargrid=1, grid="ms", cost="mtq", N=8))]:
+    for name, kv in [("hess_dint_mtq", dict(scenario="dint", cost="mtq", N=12)), ("hess_int3_ms_mtq", dict(scenario="int3", vargrid=1, grid="ms", cost="mtq", N=8)),
+                     ("hess_dint_mtq_last5", dict(scenario="dint", cost="mtq", last_n=5, N=12))]:
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))

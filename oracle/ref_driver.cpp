@@ -126,6 +126,12 @@ class BallKeepOut : public StageInequalityConstraint
     double _cx, _cy, _cz, _r;
 };
 
+// MinTimeQuadratic::_only_last_n has no setter outside fromMessage (hybrid_cost.h:300): reach the protected member through a subclass
+struct MinTimeQuadraticLastN : public MinTimeQuadratic
+{
+    MinTimeQuadraticLastN(const Eigen::MatrixXd& Q, const Eigen::MatrixXd& R, int last_n) : MinTimeQuadratic(Q, R, false, true) { _only_last_n = last_n; }
+};
+
 struct Scenario
 {
     std::string name;
@@ -141,6 +147,7 @@ struct Scenario
     // cost=mtq|qstate|qctrl|mtqs|mtqc: replace the scenario's stage cost by MinTimeQuadratic / QuadraticStateCost / QuadraticControlCost /
     // MinTimeQuadraticStates / MinTimeQuadraticControls (lsq form), Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
     std::string cost;
+    int last_n = 0;             // last_n=<n> with cost=mtq: MinTimeQuadratic's only_last_n
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
     bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
@@ -451,7 +458,8 @@ static Built build(const Scenario& s, int iterations)
         for (int i = 0; i < s.nx; ++i) q[i] = qv[i % 4];
         for (int i = 0; i < s.nu; ++i) r[i] = rv[i % 3];
         Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
-        if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, true));
+        if (s.cost == "mtq" && s.last_n > 0) b.ocp->setStageCost(std::make_shared<MinTimeQuadraticLastN>(Q, R, s.last_n));
+        else if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, true));
         else if (s.cost == "qstate") b.ocp->setStageCost(std::make_shared<QuadraticStateCost>(Q, false, true));
         else if (s.cost == "qctrl") b.ocp->setStageCost(std::make_shared<QuadraticControlCost>(R, false, true));
         else if (s.cost == "mtqs") b.ocp->setStageCost(std::make_shared<MinTimeQuadraticStates>(Q, false, true));
@@ -667,6 +675,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("uref")) s.uref = vec(kv["uref"]);
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
     if (kv.count("cost")) s.cost = kv["cost"];
+    if (kv.count("last_n")) s.last_n = atoi(kv["last_n"].c_str());
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
     if (kv.count("nmin")) s.n_min = atoi(kv["nmin"].c_str());
@@ -691,6 +700,7 @@ static int dump(const Scenario& s)
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
+    if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
     if (s.xlb.size()) printVec("xlb", s.xlb);
     if (s.xub.size()) printVec("xub", s.xub);
     if (s.ulb.size()) printVec("ulb", s.ulb);
@@ -1009,6 +1019,7 @@ static int hess(const Scenario& s)
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
+    if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
     if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
     if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
     if (s.xlb.size()) printVec("xlb", s.xlb);

@@ -54,7 +54,7 @@ def desc_for(g):
     sc = g["scenario"]
     def cost_option(d):   # cost=mtq of oracle/ref_driver.cpp: MinTimeQuadratic, Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
         if g.get("cost") == "mtq":
-            problems.min_time_quadratic(d, (1.0, 0.5, 0.2, 0.1)[: d.nx], (0.1, 0.2, 0.05)[: d.nu])
+            problems.min_time_quadratic(d, (1.0, 0.5, 0.2, 0.1)[: d.nx], (0.1, 0.2, 0.05)[: d.nu], only_last_n=g.get("last_n", 0))
         else:
             assert "cost" not in g, g["cost"]
         return d

@@ -53,6 +53,9 @@ def test_time_optimal_variable_grid_and_shooting_grid(described):
     h = described["dint_mtq"]                            # MinTimeQuadratic: state, control and minimum-time terms (hybrid_cost.h:189-303)
     assert h["recognised"] == 1 and h["grid"] == capi.GRID_FD_VARIABLE and h["stage_cost"] == capi.COST_MIN_TIME_QUADRATIC_LSQ
     assert _sqrt_equal(h["q_diag"], [1.0, 0.5]) and _sqrt_equal(h["r_diag"], [0.1]) and h["final_cost"] == 0
+    h8 = described["dint_mtq8"]                          # only_last_n = 8: the quadratic terms on the last intervals only
+    assert h8["recognised"] == 1 and h8["stage_cost"] == capi.COST_MIN_TIME_QUADRATIC_LSQ and h8["quad_first_interval"] == h8["N"] - 8
+    assert h["quad_first_interval"] == 0
     hs = described["dint_mtqs"]                          # MinTimeQuadraticStates with a diagonal Q: the reference creates no state term
     assert hs["recognised"] == 1 and hs["stage_cost"] == capi.COST_MIN_TIME_LSQ   # (quadratic_state_cost.cpp:33-62) -- the graph is MinimumTime's
     l = described["lin32"]                               # LinearStateSpaceModel on the MultipleShootingGrid with RK4

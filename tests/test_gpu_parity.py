@@ -33,7 +33,7 @@ def _built():
 GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint", "unicycle_n12", "quad_n10",
         "quad_n10_tball", "quad_n10_tball_loose", "quad_n10_teq",   # final-stage constraints on the 12-state big-block family
         "int3_ms_time_optimal", "int3_ms_time_optimal_n40",          # MultipleShootingVariableGrid: free dt on the shooting grid
-        "dint_mtq", "int3_mtq_n20", "int3_ms_mtq",                   # MinTimeQuadratic: minimum time + quadratic form (hybrid_cost.h:189-303)
+        "dint_mtq", "int3_mtq_n20", "int3_ms_mtq", "int3_mtq_last6",                   # MinTimeQuadratic: minimum time + quadratic form (hybrid_cost.h:189-303)
         "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal",
         # the reference's other benchmark systems with nx <= 3
         "duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein", "duffing_midpoint", "rocket_forward", "toy_backward", "pendulum_ms_rk4", "mpendulum_ms_rk4", "rocket_ms_rk4", "artstein_ms_rk4",
