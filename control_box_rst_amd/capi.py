@@ -92,6 +92,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
     "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
+    "corbo_hip_sizeof",
 )
 
 
@@ -115,6 +116,11 @@ def load() -> C.CDLL:
     except Exception:  # torch is optional for the C-ABI itself
         pass
     lib = C.CDLL(_LIB_PATH)
+    lib.corbo_hip_sizeof.argtypes, lib.corbo_hip_sizeof.restype = [C.c_int], C.c_size_t
+    for which, mirror in ((0, ProblemDesc), (1, Dims), (2, LmOpts), (3, Stats)):
+        if lib.corbo_hip_sizeof(which) != C.sizeof(mirror):
+            raise RuntimeError(f"{_LIB_PATH} was built from another include/corbo_hip.h: sizeof({mirror.__name__}) = {C.sizeof(mirror)} here, "
+                               f"{lib.corbo_hip_sizeof(which)} in the library -- rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     H = C.c_void_p
     lib.corbo_hip_default_lm_opts.argtypes = [C.POINTER(LmOpts)]

@@ -1566,4 +1566,15 @@ ABI_CATCH
 
 const char* corbo_hip_last_error(void) { return g_last_error.c_str(); }
 
+size_t corbo_hip_sizeof(int which)
+{
+    switch (which) {
+        case 0: return sizeof(corbo_hip_problem_desc);
+        case 1: return sizeof(corbo_hip_dims);
+        case 2: return sizeof(corbo_hip_lm_opts);
+        case 3: return sizeof(corbo_hip_stats);
+        default: return 0;
+    }
+}
+
 }  // extern "C"

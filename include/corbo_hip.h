@@ -23,6 +23,7 @@
 #ifndef CORBO_HIP_H_
 #define CORBO_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -447,6 +448,11 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value);
 
 /* Text of the last error on this thread. */
 const char* corbo_hip_last_error(void);
+
+/* Layout check for bindings that mirror the PODs above by hand (ctypes, cgo, JNI ...): sizeof of what THIS library was compiled with --
+ * which = 0: corbo_hip_problem_desc, 1: corbo_hip_dims, 2: corbo_hip_lm_opts, 3: corbo_hip_stats; anything else: 0.  A binding compares
+ * it with its own mirror when it loads the library and refuses on a mismatch (control_box_rst_amd/capi.py does). */
+size_t corbo_hip_sizeof(int which);
 
 #ifdef __cplusplus
 }

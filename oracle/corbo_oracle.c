@@ -774,6 +774,8 @@ int oracle_resample_trajectory(int nx, int nu, int n, const double* x_old, int n
  * (finite_differences_variable_grid.cpp:101-163): the number of grid points after the adaptation (== n: no change).
  * strategy: 1 = single step, 2 = aggressive estimate, 3 = simple shrinking horizon, 4 = aggressive estimate of the shooting grid
  * (MultipleShootingVariableGrid; its single-step and shrinking rules are 1 and 3: multiple_shooting_variable_grid.cpp:93-152). */
+int oracle_sizeof_problem_desc(void) { return (int)sizeof(corbo_hip_problem_desc); }
+
 int oracle_adapt_grid_n(int strategy, int n, double dt, double dt_ref, double hyst, int n_min, int n_max)
 {
     if (strategy == 1) {

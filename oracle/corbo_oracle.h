@@ -54,6 +54,8 @@ int oracle_get_x(const oracle_problem* p, double* x_out);
  * FiniteDifferencesVariableGrid (finite_differences_variable_grid.cpp:101-163) */
 int oracle_resample_trajectory(int nx, int nu, int n, const double* x_old, int n_new, double* x_new);
 int oracle_adapt_grid_n(int strategy, int n, double dt, double dt_ref, double hyst, int n_min, int n_max);
+/* sizeof(corbo_hip_problem_desc) this checker was compiled with (oracle.py rebuilds a stale liboracle.so on a mismatch) */
+int oracle_sizeof_problem_desc(void);
 int oracle_plant_step(const oracle_problem* p, int integrator, double dt, const double* disturbance, double* x_plant);
 
 /* Callback problem (SimpleOptimizationProblemWithCallbacks): n parameters, f fills the lsq / equality / inequality value vectors at x

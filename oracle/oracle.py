@@ -33,6 +33,10 @@ def load():
     if not os.path.exists(_LIB):
         build()
     lib = C.CDLL(_LIB)
+    if not hasattr(lib, "oracle_sizeof_problem_desc") or lib.oracle_sizeof_problem_desc() != C.sizeof(ProblemDesc):
+        build()   # compiled from another include/corbo_hip.h: a stale checker would read the descriptor with the wrong layout
+        lib = C.CDLL(_LIB)
+        assert lib.oracle_sizeof_problem_desc() == C.sizeof(ProblemDesc)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     lib.oracle_create.argtypes = [C.POINTER(ProblemDesc)]
     lib.oracle_create.restype = C.c_void_p
