@@ -219,6 +219,20 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         x0 = Eigen::Vector2d(1, 0);
         xf = Eigen::Vector2d(0.2, -0.1);
     }
+    else if (scenario == "rocket" || scenario == "mpendulum" || scenario == "toy" || scenario == "artstein" || scenario == "cartpole" || scenario == "par2")
+    {   // the rest of the reference's benchmark classes (nonlinear_benchmark_systems.h, linear_benchmark_systems.h), non-default
+        // parameters where the class has a setter
+        if (scenario == "rocket") { dyn = std::make_shared<FreeSpaceRocket>(); x0 = Eigen::Vector3d(0, 0, 1.0); xf = Eigen::Vector3d(0.6, 0.1, 0.9); }
+        else if (scenario == "mpendulum") { auto s = std::make_shared<MasslessPendulum>(); s->setParameter(1.4); dyn = s; x0 = Eigen::Vector2d(0.8, 0); xf = Eigen::Vector2d(0.1, 0); }
+        else if (scenario == "toy") { auto s = std::make_shared<ToyExample>(); s->setParameters(0.35); dyn = s; x0 = Eigen::Vector2d(0.4, -0.3); xf = Eigen::Vector2d(0, 0.1); }
+        else if (scenario == "artstein") { dyn = std::make_shared<ArtsteinsCircle>(); x0 = Eigen::Vector2d(0.5, 0.4); xf = Eigen::Vector2d(0.1, -0.1); }
+        else if (scenario == "cartpole") { dyn = std::make_shared<CartPole>(); x0 = Eigen::Vector4d(0, 0.2, 0, 0); xf = Eigen::Vector4d(0.3, 0, 0, 0); }
+        else { auto s = std::make_shared<ParallelIntegratorSystem>(2); s->setTimeConstant(0.8); dyn = s; x0 = Eigen::Vector2d(0.5, -0.4); xf = Eigen::Vector2d(-0.1, 0.2); nu = 2; }
+        grid = std::make_shared<FiniteDifferencesGrid>();
+        if (scenario == "toy") grid->setFiniteDifferencesCollocationMethod(std::make_shared<ForwardDiffCollocation>());
+        if (scenario == "artstein") grid->setFiniteDifferencesCollocationMethod(std::make_shared<BackwardDiffCollocation>());
+        w = 5;
+    }
     else if (scenario == "lin32")
     {
         auto s = std::make_shared<LinearStateSpaceModel>();
@@ -450,7 +464,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -460,7 +474,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);

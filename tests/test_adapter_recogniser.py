@@ -64,6 +64,20 @@ def test_time_optimal_variable_grid_and_shooting_grid(described):
     assert l["lin_b"] == [0.859, 0.092, 0.875, -0.01, -0.452, -0.096]
 
 
+def test_the_rest_of_the_reference_benchmark_classes(described):
+    """Every system class of nonlinear_benchmark_systems.h / linear_benchmark_systems.h is recognised by RTTI, with the parameters its
+    setters were given (private members where the class has no getter) and the collocation scheme of its grid."""
+    want = {"rocket": (capi.DYN_FREE_SPACE_ROCKET, capi.DEFECT_CRANK_NICOLSON, None), "mpendulum": (capi.DYN_MASSLESS_PENDULUM, capi.DEFECT_CRANK_NICOLSON, 1.4),
+            "toy": (capi.DYN_TOY_EXAMPLE, capi.DEFECT_FORWARD, 0.35), "artstein": (capi.DYN_ARTSTEINS_CIRCLE, capi.DEFECT_BACKWARD, None),
+            "cartpole": (capi.DYN_CART_POLE, capi.DEFECT_CRANK_NICOLSON, None), "par2": (capi.DYN_PARALLEL_INTEGRATOR, capi.DEFECT_CRANK_NICOLSON, 0.8)}
+    for name, (dyn, defect, p0) in want.items():
+        r = described[name]
+        assert r["recognised"] == 1 and r["dynamics"] == dyn and r["defect"] == defect and r["grid"] == capi.GRID_FD, name
+        if p0 is not None:
+            assert r["dyn_params"][0] == p0, name
+    assert (described["cartpole"]["nx"], described["par2"]["nu"]) == (4, 2)
+
+
 def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):
     f = described["unicycle_fullq"]
     assert f["recognised"] == 0 and "non-diagonal" in f["reason"]
