@@ -506,6 +506,7 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
 try {
     if (!h || !o) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called before corbo_hip_solve");
+    if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
     ON_DEVICE_OF(h);
     update_penalty_weights(h, o, new_run);
@@ -896,6 +897,7 @@ int corbo_hip_closed_loop(corbo_hip_handle h, const corbo_hip_lm_opts* o, int st
                           const double* disturbance, double* states_out, double* controls_out)
 try {
     if (!h || !o || steps < 0 || ocp_iterations < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (integrator != CORBO_HIP_INTEGRATOR_EULER && integrator != CORBO_HIP_INTEGRATOR_RK4) return fail(CORBO_HIP_ERR_INVALID, "unknown integrator");
     if (!(dt > 0)) return fail(CORBO_HIP_ERR_INVALID, "dt must be positive");
     if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
@@ -1197,6 +1199,7 @@ ABI_CATCH
 int corbo_hip_eval(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, double* values_out, double* jac_out)
 try {
     if (!h || !values_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
@@ -1284,7 +1287,7 @@ static int hessian_common(corbo_hip_handle h, HessianStructure& H, bool lower, H
     for (int c = 0; c < 3; ++c) hp.nnz[c] = H.nnz[c];
     hp.lin_nnz = H.lin_nnz; hp.lin_bounds0 = H.lin_bounds0; hp.bnd_row0 = h->S.bnd_row0; hp.n_bounds = h->S.dims.bounds;
     hp.stage_cost = h->S.desc.stage_cost; hp.stage_ineq = h->S.desc.stage_ineq;
-    hp.dt_cost_off = H.dt_cost_off; hp.quad_first_interval = h->S.desc.quad_first_interval;
+    hp.dt_cost_off = H.dt_cost_off; hp.quad_first_interval = h->S.desc.quad_first_interval; hp.cost_nonlsq = h->S.desc.cost_nonlsq;
     return 0;
 }
 
@@ -1429,6 +1432,7 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     long long* d_tl = nullptr;  // CORBO_HIP_SWEEP_TIMELINE=1: shader-clock stamps of the phases of instance 0 on stderr (diagnostics)
     if (h->sweep_timeline) {
@@ -1462,6 +1466,7 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
 int corbo_hip_time_sweep_each(corbo_hip_handle h, double w_eq, double w_ineq, double w_bounds, int with_jacobian, int repeat, float* ms_each)
 try {
     if (!h || !ms_each || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
     const SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
@@ -1487,6 +1492,7 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     // LM prologue (residual + Jacobian + state init), then the assemble/factor/solve kernel `repeat` times on that state
     corbo_hip_lm_opts o;
     corbo_hip_default_lm_opts(&o);

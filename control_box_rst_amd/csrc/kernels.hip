@@ -2898,6 +2898,11 @@ struct HessEdge {
                 for (int i = 0; i < NX; ++i) out[i] = mp.sqf[i] * (xl[i] - xr[i]);
                 break;
             case EK_DT_COST: out[0] = mp.dt_weight * xl[W - 1]; break;
+            // plain objective edges, lsq_form = false (quadratic_cost.cpp:133-138,165-170, final_state_cost.cpp:102-108): xd^T * W_diag * xd, the
+            // expression of TerminalBall; mp.sq / sr / sqf hold the weights themselves for such a descriptor
+            case EK_STATE_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sq[i]) * xd; } out[0] = acc; break; }
+            case EK_CONTROL_QCOST: { double acc = 0.0; for (int i = 0; i < NU; ++i) acc += (xl[NX + i] * mp.sr[i]) * xl[NX + i]; out[0] = acc; break; }
+            case EK_FINAL_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sqf[i]) * xd; } out[0] = acc; break; }
             case EK_DEFECT: defect_eval<DYN, DEFECT>(xl, xl + NX, xl + S, xl[W - 1], mp.dyn, out); break;
             case EK_STAGE_INEQ:
                 if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
@@ -2909,13 +2914,13 @@ struct HessEdge {
             default: break;
         }
     }
-    __device__ static int edge_dim(int kind) { return kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ) ? 1 : NX; }
+    __device__ static int edge_dim(int kind) { return kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
     __device__ static int n_verts(int kind) { return kind == EK_DEFECT ? 4 : 1; }
-    __device__ static int vert_off(int kind, int vi) { return kind == EK_DEFECT ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : kind == EK_CONTROL_COST ? NX : kind == EK_DT_COST ? W - 1 : 0; }
+    __device__ static int vert_off(int kind, int vi) { return kind == EK_DEFECT ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : kind == EK_DT_COST ? W - 1 : 0; }
     __device__ static int vert_dim(int kind, int vi)
     {
         if (kind == EK_DEFECT) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? NX : 1;
-        return kind == EK_CONTROL_COST ? NU : kind == EK_DT_COST ? 1 : NX;   // every other edge hangs on one state vertex
+        return (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NU : kind == EK_DT_COST ? 1 : NX;   // every other edge hangs on one state vertex
     }
     __device__ static int unfixed(unsigned fm, int off, int dim) { int n = 0; for (int i = 0; i < dim; ++i) n += ((fm >> (off + i)) & 1u) ? 0 : 1; return n; }
     // BaseEdge::computeJacobian (edge_interface.cpp:55-96): block [dim x n_unfixed], column-major
@@ -2966,8 +2971,10 @@ struct HessEdge {
                             blk[c * ni + r] = acc;
                         }
                 }
-                else {
-                    const double scalar = 1.0 / hdelta;
+                else {   // BaseEdge::computeHessian[Inc] (edge_interface.cpp:151-255); cat 3: a plain objective edge, weighted with the objective
+                    // multiplier instead of row multipliers (…edge_based.cpp:2363-2410)
+                    double scalar = 1.0 / hdelta;
+                    if (cat == 3 && mult_obj != 1.0) scalar *= mult_obj;
                     for (int q = 0; q < ni * nj; ++q) blk[q] = 0.0;
                     int cj = 0;
                     for (int j = 0; j < dj; ++j) {
@@ -3052,8 +3059,9 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         double* outs[6];
         const double* mults[6];
         auto add = [&](int kind, int cat, double* out, const double* mult) { kinds[n_edges] = kind; cats[n_edges] = cat; outs[n_edges] = out; mults[n_edges] = mult; ++n_edges; };
-        if (so[0] >= 0) add(final_stage ? EK_FINAL_COST : EK_STATE_COST, 0, vo + so[0], nullptr);
-        if (so[1] >= 0) add(EK_CONTROL_COST, 0, vo + so[1], nullptr);
+        const bool nl = hp.cost_nonlsq != 0;   // plain objective edges: category 3 (same output list)
+        if (so[0] >= 0) add(final_stage ? (nl ? EK_FINAL_QCOST : EK_FINAL_COST) : (nl ? EK_STATE_QCOST : EK_STATE_COST), nl ? 3 : 0, vo + so[0], nullptr);
+        if (so[1] >= 0) add(nl ? EK_CONTROL_QCOST : EK_CONTROL_COST, nl ? 3 : 0, vo + so[1], nullptr);
         if (k == 0 && hp.dt_cost_off >= 0) { add(EK_DT_COST, 0, vo + hp.dt_cost_off, nullptr); add(EK_DT_COST, 0, nullptr, nullptr); }
         if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
         if (so[3] >= 0) add(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, vi + so[3], mi);
@@ -3070,10 +3078,11 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         double* gr = hp.grad + (size_t)b * hp.n_params;
         int kinds[4], n_edges = 0;
         const int terms = CORBO_HIP_COST_TERMS(hp.stage_cost);
-        if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = EK_FINAL_COST; }
+        const bool nl = hp.cost_nonlsq != 0;
+        if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = nl ? EK_FINAL_QCOST : EK_FINAL_COST; }
         else {
-            if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = EK_STATE_COST;
-            if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = EK_CONTROL_COST;
+            if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_STATE_QCOST : EK_STATE_COST;
+            if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_CONTROL_QCOST : EK_CONTROL_COST;
             if ((terms & 4) && k == 0) { kinds[n_edges++] = EK_DT_COST; kinds[n_edges++] = EK_DT_COST; }
         }
         double obj = 0.0;
@@ -3082,6 +3091,19 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
             double blk[HE::MAXD * HE::MAXD], vals[HE::MAXD];
             const int nu_ = HE::unfixed(fm, off, dim);
             if (nu_ > 0) HE::jacobian(kind, 0, fm, xl, xr, mpl, blk);
+            if (kind >= EK_STATE_QCOST) {   // plain objective edge: gradient += the Jacobian's column sums, value += the sum of the values
+                int col = 0;                // (…edge_based.cpp:43-56, hyper_graph_optimization_problem_base.cpp:136-141); no values before the sum
+                for (int i = 0; i < dim; ++i) {
+                    if ((fm >> (off + i)) & 1u) continue;
+                    double acc = 0.0;
+                    for (int r = 0; r < ed; ++r) acc += blk[col * ed + r];
+                    gr[p.comp[k * S + off + i].param] += acc;
+                    ++col;
+                }
+                HE::values(kind, xl, xr, mpl, vals);
+                for (int r = 0; r < ed; ++r) obj += vals[r];
+                continue;
+            }
             HE::values(kind, xl, xr, mpl, vals);
             int col = 0;
             for (int i = 0; i < dim; ++i) {

@@ -128,6 +128,7 @@ struct HessParams {
     int32_t stage_cost, stage_ineq;   // corbo_hip_cost / corbo_hip_ineq of the descriptor
     int32_t dt_cost_off;              // HessianStructure::dt_cost_off
     int32_t quad_first_interval;      // descriptor field (MinTimeQuadratic::only_last_n)
+    int32_t cost_nonlsq;              // descriptor field: the cost edges are plain objective edges (scalar terms)
     // mode 2: gradient of the least-squares objective, computeGradientObjective (hyper_graph_optimization_problem_edge_based.cpp:31-102)
     double* grad;               // [batch][n], zeroed by the caller (every parameter is written by the one lane that owns its component)
     double* obj_part;           // [batch][N]: the stage's share of computeValueObjective (sum of the squared norms of its cost edges)

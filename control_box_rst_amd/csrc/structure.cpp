@@ -40,6 +40,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ && (CORBO_HIP_COST_TERMS(d.stage_cost) & 4) && d.grid != CORBO_HIP_GRID_FD_VARIABLE &&
         d.grid != CORBO_HIP_GRID_MS_VARIABLE)
         return "a stage cost with a minimum-time term needs a grid with a free dt";
+    if (d.cost_nonlsq != 0 && d.cost_nonlsq != 1) return "cost_nonlsq must be 0 or 1";
+    if (d.cost_nonlsq && d.stage_cost != CORBO_HIP_COST_NONE && d.stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ)
+        return "cost_nonlsq: quadratic stage cost (or none) only";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
     if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
@@ -71,6 +74,10 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     S.nvs            = (nv_all + 1) & ~1;
     for (int i = 0; i < nx; ++i) { S.sq[i] = std::sqrt(d.q_diag[i]); S.sqf[i] = std::sqrt(d.qf_diag[i]); }
     for (int i = 0; i < nu; ++i) S.sr[i] = std::sqrt(d.r_diag[i]);
+    if (d.cost_nonlsq) {   // plain objective edges x^T Q x: the kernels of the Hessian path get the weights themselves in these slots
+        for (int i = 0; i < nx; ++i) { S.sq[i] = d.q_diag[i]; S.sqf[i] = d.qf_diag[i]; }
+        for (int i = 0; i < nu; ++i) S.sr[i] = d.r_diag[i];
+    }
     S.dt_weight = std::sqrt((double)(N - 1));  // minimum_time.h:60
 
     // ---- components: fixed flags and parameter indices (full_discretization_grid_base.cpp:514-527, vertex_set.cpp:405-418)
@@ -100,7 +107,8 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     std::vector<E> lsq, eq, ineq;
     for (int k = 0; k < N - 1; ++k) {
         const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);   // nlp_functions.cpp:70-107: state term, control term, dt term twice
-        const bool quad = (k >= d.quad_first_interval);   // MinTimeQuadratic::only_last_n (hybrid_cost.h:224-237)
+        // (cost_nonlsq: plain objective edges are no rows of the LM residual -- getLsqObjectiveDimension() == 0; the LM entries refuse such a handle)
+        const bool quad = (k >= d.quad_first_interval) && !d.cost_nonlsq;   // MinTimeQuadratic::only_last_n (hybrid_cost.h:224-237)
         if ((terms & 1) && quad) lsq.push_back({EK_STATE_COST, k, nx, 0});
         if ((terms & 2) && quad) lsq.push_back({EK_CONTROL_COST, k, nu, 0});
         if ((terms & 4) && k == 0) {   // MinimumTime on a single-dt grid: k = 0 only (minimum_time.h:49)
@@ -111,7 +119,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         eq.push_back({EK_DEFECT, k, nx, 1});
     }
     if (xf_unfixed > 0 && d.final_eq) eq.push_back({EK_FINAL_EQ, N - 1, nx, 1});   // finite_differences_grid.cpp:135-141
-    if (xf_unfixed > 0 && d.final_cost) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
+    if (xf_unfixed > 0 && d.final_cost && !d.cost_nonlsq) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
     if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) ineq.push_back({EK_FINAL_INEQ, N - 1, 1, 2});  // finite_differences_grid.cpp:135-143
 
     int row = 0, joff = 0;

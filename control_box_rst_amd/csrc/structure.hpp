@@ -24,7 +24,12 @@ enum EdgeKind : int32_t {
     EK_DEFECT       = 4,  // dynamics defect (x_k,u_k,x_{k+1},dt)
     EK_STAGE_INEQ   = 5,  // stage inequality on x_k
     EK_FINAL_INEQ   = 6,  // final-stage inequality on x_f (TerminalBall)
-    EK_FINAL_EQ     = 7   // final-stage equality x_f - xref (TerminalEqualityConstraint)
+    EK_FINAL_EQ     = 7,  // final-stage equality x_f - xref (TerminalEqualityConstraint)
+    // plain objective edges (cost_nonlsq: QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false), one scalar term each;
+    // Hessian-path operators only
+    EK_STATE_QCOST   = 8,
+    EK_CONTROL_QCOST = 9,
+    EK_FINAL_QCOST   = 10
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):

@@ -149,7 +149,13 @@ typedef struct corbo_hip_problem_desc {
     /* CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ only: first interval that carries the quadratic form's terms -- MinTimeQuadratic's
      * only_last_n option, _quad_k_min = max(N - only_last_n, 0) (hybrid_cost.h:224-237); 0 = every interval */
     int32_t quad_first_interval;
-    int32_t reserved0;
+    /* 1: the quadratic stage cost and the final cost are NOT in least-squares form -- QuadraticFormCost(Q, R, false, lsq_form = false),
+     * QuadraticFinalStateCost(Qf, false): one scalar term xd^T Q xd / u^T R u / xd^T Qf xd per edge (quadratic_cost.cpp:133-138,165-170,
+     * final_state_cost.cpp:102-108), filed as plain objective edges (edge_set.h:118-125).  What the reference's IPOPT / QP callers use.
+     * Such a problem is not a least-squares problem: corbo_hip_solve / corbo_hip_eval refuse it like LevenbergMarquardtSparse::solve does
+     * (levenberg_marquardt_sparse.cpp:48-55); the operators of the exact-Hessian path work on it (objective edges: finite-difference Hessians
+     * weighted with the objective multiplier, gradient = Jacobian rows, value = sum).  stage_cost NONE or QUADRATIC_LSQ only. */
+    int32_t cost_nonlsq;
 } corbo_hip_problem_desc;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */

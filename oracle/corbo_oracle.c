@@ -38,6 +38,7 @@ typedef struct {
     int dim;      /* getDimension() */
     int row;      /* global row of the first value in the stacked residual */
     int scale;    /* 0 lsq (unscaled), 1 equality (w_eq), 2 inequality (w_ineq, active set) */
+    int nonlsq;   /* objective edge that is NOT in least-squares form (scalar term; Hessian-path operators only: row = -1, no LM rows) */
 } o_edge;
 
 typedef struct { /* one (edge, vertex) Jacobian block, values stored column-major like Eigen::MatrixXd */
@@ -50,6 +51,7 @@ struct oracle_problem {
     corbo_hip_problem_desc d;
     corbo_hip_dims dims;
     int n_vertices, n_edges, n_blocks;
+    int has_nonlsq; /* objective edges that are not in least-squares form: LevenbergMarquardtSparse refuses the problem (:48-55), so do the LM entries here */
     o_vertex* v;
     o_edge* e;
     o_block* b;
@@ -237,18 +239,36 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
         case E_STATE_COST: { /* optimal_control/src/functions/quadratic_cost.cpp:100-119 (lsq form, diagonal Q) */
             const double* xk = x + p->v[e->vert[0]].off;
             const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref; /* getReferenceCached(k) */
+            if (e->nonlsq) { /* lsq_form = false, diagonal mode: xd^T * Q_diag * xd (quadratic_cost.cpp:133-138; the expression of TerminalBall) */
+                double acc = 0.0;
+                for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->q_diag[i]) * xd; }
+                out[0] = acc;
+                break;
+            }
             for (int i = 0; i < d->nx; ++i) out[i] = p->sq[i] * (xk[i] - rk[i]);
             break;
         }
         case E_CONTROL_COST: { /* quadratic_cost.cpp:140-154 (lsq form, zero uref, diagonal R).  A non-zero uref is not restated: the
                                 * reference assigns the scalar ud^T R^(1/2) ud to the nu-vector there (:160-163) */
             const double* uk = x + p->v[e->vert[0]].off;
+            if (e->nonlsq) { /* u_k^T * R_diag * u_k (quadratic_cost.cpp:165-170) */
+                double acc = 0.0;
+                for (int i = 0; i < d->nu; ++i) acc += (uk[i] * d->r_diag[i]) * uk[i];
+                out[0] = acc;
+                break;
+            }
             for (int i = 0; i < d->nu; ++i) out[i] = p->sr[i] * uk[i];
             break;
         }
         case E_FINAL_COST: { /* optimal_control/src/functions/final_state_cost.cpp:72-92 */
             const double* xk = x + p->v[e->vert[0]].off;
             const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
+            if (e->nonlsq) { /* xd^T * Qf_diag * xd (final_state_cost.cpp:102-108) */
+                double acc = 0.0;
+                for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->qf_diag[i]) * xd; }
+                out[0] = acc;
+                break;
+            }
             for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - rk[i]);
             break;
         }
@@ -344,6 +364,8 @@ static int validate(const corbo_hip_problem_desc* d)
     if (d->stage_cost > CORBO_HIP_COST_MIN_TIME_LSQ && (CORBO_HIP_COST_TERMS(d->stage_cost) & 4) && d->grid != CORBO_HIP_GRID_FD_VARIABLE &&
         d->grid != CORBO_HIP_GRID_MS_VARIABLE)
         return 0;
+    if (d->cost_nonlsq != 0 && d->cost_nonlsq != 1) return 0;
+    if (d->cost_nonlsq && d->stage_cost != CORBO_HIP_COST_NONE && d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ) return 0;
     if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
     if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
     if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
@@ -461,11 +483,12 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         /* MinTimeQuadratic (hybrid_cost.h:189-303) has all three terms, in this order */
         const int terms = CORBO_HIP_COST_TERMS(d->stage_cost);
         const int quad = (k >= d->quad_first_interval); /* MinTimeQuadratic::only_last_n, hybrid_cost.h:224-237 */
+        const int nl = d->cost_nonlsq; /* QuadraticFormCost(.., lsq_form = false): one scalar term each (quadratic_cost.h: dimension 1) */
         if ((terms & 1) && quad) {
-            o_edge* e = &lsq[n_lsq++]; e->type = E_STATE_COST; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = nx; e->scale = 0;
+            o_edge* e = &lsq[n_lsq++]; e->type = E_STATE_COST; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = nl ? 1 : nx; e->scale = 0; e->nonlsq = nl;
         }
         if ((terms & 2) && quad) {
-            o_edge* e = &lsq[n_lsq++]; e->type = E_CONTROL_COST; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = nu; e->scale = 0;
+            o_edge* e = &lsq[n_lsq++]; e->type = E_CONTROL_COST; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = nl ? 1 : nu; e->scale = 0; e->nonlsq = nl;
         }
         if ((terms & 4) && k == 0) {
             for (int rep = 0; rep < 2; ++rep) { /* duplicated dt edge, nlp_functions.cpp:91-107 */
@@ -479,7 +502,8 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         e->vert[0] = xk; e->vert[1] = uk; e->vert[2] = xnext; e->vert[3] = dt_vertex;
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_cost) { /* if (!_xf.isFixed()) ... getFinalStateCostEdge */
-        o_edge* e = &lsq[n_lsq++]; e->type = E_FINAL_COST; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 0;
+        o_edge* e = &lsq[n_lsq++]; e->type = E_FINAL_COST; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = d->cost_nonlsq ? 1 : nx; e->scale = 0;
+        e->nonlsq = d->cost_nonlsq;
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_eq) { /* getFinalStateConstraintEdge, isEqualityConstraint() :136-141 */
         o_edge* e = &eq[n_eq++]; e->type = E_FINAL_EQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 1;
@@ -491,7 +515,11 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     p->n_edges = n_lsq + n_eq + n_ineq;
     p->e       = (o_edge*)calloc(p->n_edges, sizeof(o_edge));
     int row = 0, ne = 0;
-    for (int i = 0; i < n_lsq; ++i) { lsq[i].row = row; row += lsq[i].dim; p->e[ne++] = lsq[i]; }
+    for (int i = 0; i < n_lsq; ++i) {
+        if (lsq[i].nonlsq) { lsq[i].row = -1; p->has_nonlsq = 1; }   /* not a row of the LM residual (getLsqObjectiveDimension() == 0) */
+        else { lsq[i].row = row; row += lsq[i].dim; }
+        p->e[ne++] = lsq[i];
+    }
     int dim_lsq = row;
     for (int i = 0; i < n_eq; ++i) { eq[i].row = row; row += eq[i].dim; p->e[ne++] = eq[i]; }
     int dim_eq = row - dim_lsq;
@@ -516,6 +544,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     int nnz = 0, nb = 0;
     for (int i = 0; i < p->n_edges; ++i) {
         const o_edge* e = &p->e[i];
+        if (e->nonlsq) continue;
         for (int vi = 0; vi < e->nverts; ++vi) {
             const o_vertex* v = &p->v[e->vert[vi]];
             if (v->n_unfixed == 0) continue;
@@ -940,6 +969,7 @@ static void compute_jacobian(oracle_problem* p, double w_eq, double w_ineq, doub
 int oracle_eval(oracle_problem* p, double w_eq, double w_ineq, double w_b, double* values, double* jac)
 {
     if (!p || !values) return CORBO_HIP_ERR_INVALID;
+    if (p->has_nonlsq) return CORBO_HIP_ERR_UNSUPPORTED;
     compute_values(p, w_eq, w_ineq, w_b, values);
     if (jac) compute_jacobian(p, w_eq, w_ineq, w_b, values, jac);
     return 0;
@@ -1004,7 +1034,11 @@ static int hessian_walk(oracle_problem* p, int lower, int with_values, double mu
                 const int ni = a->n_unfixed, nj = b->n_unfixed;
                 int at = nnz[cat];
                 if (with_values) {
-                    if (cat == 0) { /* lsq objective edge: 2 * multiplier * J_i^T J_j (the Gauss-Newton block, :3566-3606) */
+                    if (cat == 0 && e->nonlsq) { /* plain objective edge: BaseEdge::computeHessian[Inc] with weight = multiplier, no row multipliers (:2363-2410) */
+                        for (int q = 0; q < ni * nj; ++q) blk[q] = 0.0;
+                        edge_hessian(p, e, vi, vj, jac1, blk, NULL, mult_obj, diag_lower ? 0 : 1);
+                    }
+                    else if (cat == 0) { /* lsq objective edge: 2 * multiplier * J_i^T J_j (the Gauss-Newton block, :3566-3606) */
                         edge_jacobian(p, e, vj, jac2);
                         for (int c = 0; c < nj; ++c)
                             for (int r = 0; r < ni; ++r) {
@@ -1158,6 +1192,14 @@ int oracle_objective_gradient(oracle_problem* p, double* grad, double* obj_out)
             const o_vertex* a = &p->v[e->vert[vi]];
             if (a->n_unfixed == 0) continue;
             edge_jacobian(p, e, vi, blk);
+            if (e->nonlsq) { /* block_jacobian.colwise().sum() (:43-56); dimension 1: the entry itself */
+                for (int c = 0; c < a->n_unfixed; ++c) {
+                    double acc = 0.0;
+                    for (int r = 0; r < e->dim; ++r) acc += blk[c * e->dim + r];
+                    grad[a->col + c] += acc;
+                }
+                continue;
+            }
             edge_values(p, e, vals);
             for (int c = 0; c < a->n_unfixed; ++c) {
                 double acc = 0.0;
@@ -1172,7 +1214,8 @@ int oracle_objective_gradient(oracle_problem* p, double* grad, double* obj_out)
             const o_edge* e = &p->e[ei];
             if (e->scale != 0) continue;
             edge_values(p, e, vals);
-            value += squared_norm(vals, e->dim);
+            if (e->nonlsq) { for (int r = 0; r < e->dim; ++r) value += vals[r]; }   /* computeSumOfValues() */
+            else value += squared_norm(vals, e->dim);
         }
         *obj_out = value;
     }
@@ -1247,6 +1290,7 @@ static double squared_norm(const double* v, int n)
 int oracle_solve(oracle_problem* p, const corbo_hip_lm_opts* o, int new_run, double* chi2_out, oracle_trace_entry* trace)
 {
     if (!p || !o) return CORBO_HIP_SOLVER_ERROR;
+    if (p->has_nonlsq) return CORBO_HIP_SOLVER_ERROR; /* isLeastSquaresProblem() false: SolverStatus::Error (levenberg_marquardt_sparse.cpp:48-55) */
     int n = p->dims.n, m = p->dims.m, nvs = p->dims.nv + (dt_is_free(&p->d) ? 0 : 1);
     if (chi2_out) *chi2_out = -1;
     /* adapt weights :83-86, :270-287 */

@@ -220,6 +220,20 @@ def mtq():
         print(name, d["n"])
 
 
+def nonlsq():
+    """The exact-Hessian path on costs that are NOT in least-squares form (QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false:
+    plain objective edges, what the reference's IPOPT / QP callers use) -- SURVEY 8f rank 4's own case."""
+    for name, kv in [
+        ("hess_vdp_nonlsq", dict(scenario="vdp", N=10, lsq=0)),
+        ("hess_unicycle_nonlsq", dict(scenario="unicycle", N=12, lsq=0)),
+        ("hess_unicycle_nonlsq_tball", dict(scenario="unicycle", N=10, lsq=0, xf_fixed=4, tball=0.02, tball_s="1,1,0.1")),
+    ]:
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], len(d["hobj_vals_full"]))
+
+
 def bigterm():
     """Final-stage constraints on the 12-state quadrotor (big-block family): TerminalBall (violated: active row) and the terminal equality."""
     for name, kv, keep in [
@@ -249,6 +263,8 @@ def main():
         return adapt()
     if len(sys.argv) > 1 and sys.argv[1] == "mtq":
         return mtq()
+    if len(sys.argv) > 1 and sys.argv[1] == "nonlsq":
+        return nonlsq()
     # cfg 3 (headline structure, single instance, the SURVEY 8c known-answer trace), cfg 1, cfg 2
     for name, kv, keep in [
         ("unicycle", dict(scenario="unicycle"), (1, 2, 5, 10)),

@@ -148,6 +148,7 @@ struct Scenario
     // MinTimeQuadraticStates / MinTimeQuadraticControls (lsq form), Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
     std::string cost;
     int last_n = 0;             // last_n=<n> with cost=mtq: MinTimeQuadratic's only_last_n
+    bool nonlsq = false;        // lsq=0 (unicycle, vdp; hess mode): QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false -- scalar terms
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
     bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
@@ -374,8 +375,8 @@ static Built build(const Scenario& s, int iterations)
         Eigen::MatrixXd Q = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
         Eigen::MatrixXd R = Eigen::Vector2d(0.1, 0.05).asDiagonal();
         Eigen::MatrixXd Qf = 10.0 * Q;
-        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, !s.nonlsq));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         b.ocp->setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
     }
     else if (s.name == "vdp")
@@ -383,8 +384,8 @@ static Built build(const Scenario& s, int iterations)
         Eigen::MatrixXd Q = Eigen::Vector2d(1, 1).asDiagonal();
         Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
         Eigen::MatrixXd Qf = 10.0 * Q;
-        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, !s.nonlsq));
+        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else if (s.name == "par2" || s.name == "par3" || s.name == "lin")   // Q = diag(1, 0.5, 0.2, 0.1), R = diag(0.1, 0.2, 0.05), Qf = 10 Q, |u_i| <= 1.5
@@ -676,6 +677,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
     if (kv.count("cost")) s.cost = kv["cost"];
     if (kv.count("last_n")) s.last_n = atoi(kv["last_n"].c_str());
+    if (kv.count("lsq")) s.nonlsq = atoi(kv["lsq"].c_str()) == 0;
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
     if (kv.count("nmin")) s.n_min = atoi(kv["nmin"].c_str());
@@ -701,6 +703,7 @@ static int dump(const Scenario& s)
     if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
+    if (s.nonlsq) printf("\"lsq\": 0,\n");
     if (s.xlb.size()) printVec("xlb", s.xlb);
     if (s.xub.size()) printVec("xub", s.xub);
     if (s.ulb.size()) printVec("ulb", s.ulb);
@@ -1020,6 +1023,7 @@ static int hess(const Scenario& s)
     if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
+    if (s.nonlsq) printf("\"lsq\": 0,\n");
     if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
     if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
     if (s.xlb.size()) printVec("xlb", s.xlb);

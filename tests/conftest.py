@@ -96,6 +96,8 @@ def desc_for(g):
     if g.get("teq"):            # TerminalEqualityConstraint(xf)
         d.final_eq = 1
     cost_option(d)
+    if g.get("lsq") == 0:       # QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false (Hessian-path fixtures)
+        d.cost_nonlsq = 1
     if "ball" in g:             # BallKeepOut stage inequality
         d.stage_ineq = capi.INEQ_BALL
         for i, v in enumerate(g["ball"]):

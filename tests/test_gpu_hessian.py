@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 HESS = ["hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
         "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal",
-        "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5"]
+        "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5",
+        "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball"]   # *_nonlsq: plain (non-least-squares) objective edges
 KEYS = ("hobj", "heq", "hineq")
 REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below
 
@@ -192,3 +193,18 @@ def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
         fu = np.abs(u2) < 1e29
         if fu.any():
             assert np.abs(ubA[b][fu] - u2[fu]).max() <= 1e-11 * max(1.0, np.abs(u2[fu]).max()), (seed, fam, b)
+
+
+def test_a_problem_with_plain_objective_edges_is_refused_by_the_lm_entries():
+    """cost_nonlsq: not a least-squares problem -- LevenbergMarquardtSparse::solve returns Error for it (levenberg_marquardt_sparse.cpp:48-55),
+    corbo_hip_solve / corbo_hip_eval say so; the Hessian-path operators are what such a handle is for."""
+    from control_box_rst_amd.solver import CorboHipError
+    g = load_golden("hess_vdp_nonlsq")
+    d, s = device_at_point(g, B=2)
+    assert d.cost_nonlsq == 1 and s.dims.lsq == 0
+    with pytest.raises(CorboHipError, match="least-squares"):
+        s.solve()
+    with pytest.raises(CorboHipError, match="least-squares"):
+        s.eval()
+    grad, obj = s.objective_gradient()
+    assert np.isfinite(grad).all() and abs(obj[0] - g["obj_value"]) <= 1e-12 * abs(g["obj_value"])
