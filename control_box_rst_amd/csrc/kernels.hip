@@ -2897,7 +2897,7 @@ struct HessEdge {
             case EK_FINAL_COST:
                 for (int i = 0; i < NX; ++i) out[i] = mp.sqf[i] * (xl[i] - xr[i]);
                 break;
-            case EK_DT_COST: out[0] = mp.dt_weight * xl[W - 1]; break;
+            case EK_DT_COST: case EK_DT_QCOST: out[0] = mp.dt_weight * xl[W - 1]; break;   // (plain form: dt_weight = N - 1)
             // plain objective edges, lsq_form = false (quadratic_cost.cpp:133-138,165-170, final_state_cost.cpp:102-108): xd^T * W_diag * xd, the
             // expression of TerminalBall; mp.sq / sr / sqf hold the weights themselves for such a descriptor
             case EK_STATE_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sq[i]) * xd; } out[0] = acc; break; }
@@ -2916,11 +2916,11 @@ struct HessEdge {
     }
     __device__ static int edge_dim(int kind) { return kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
     __device__ static int n_verts(int kind) { return kind == EK_DEFECT ? 4 : 1; }
-    __device__ static int vert_off(int kind, int vi) { return kind == EK_DEFECT ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : kind == EK_DT_COST ? W - 1 : 0; }
+    __device__ static int vert_off(int kind, int vi) { return kind == EK_DEFECT ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
     __device__ static int vert_dim(int kind, int vi)
     {
         if (kind == EK_DEFECT) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? NX : 1;
-        return (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NU : kind == EK_DT_COST ? 1 : NX;   // every other edge hangs on one state vertex
+        return (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NU : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? 1 : NX;   // every other edge hangs on one state vertex
     }
     __device__ static int unfixed(unsigned fm, int off, int dim) { int n = 0; for (int i = 0; i < dim; ++i) n += ((fm >> (off + i)) & 1u) ? 0 : 1; return n; }
     // BaseEdge::computeJacobian (edge_interface.cpp:55-96): block [dim x n_unfixed], column-major
@@ -3062,7 +3062,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         const bool nl = hp.cost_nonlsq != 0;   // plain objective edges: category 3 (same output list)
         if (so[0] >= 0) add(final_stage ? (nl ? EK_FINAL_QCOST : EK_FINAL_COST) : (nl ? EK_STATE_QCOST : EK_STATE_COST), nl ? 3 : 0, vo + so[0], nullptr);
         if (so[1] >= 0) add(nl ? EK_CONTROL_QCOST : EK_CONTROL_COST, nl ? 3 : 0, vo + so[1], nullptr);
-        if (k == 0 && hp.dt_cost_off >= 0) { add(EK_DT_COST, 0, vo + hp.dt_cost_off, nullptr); add(EK_DT_COST, 0, nullptr, nullptr); }
+        if (k == 0 && hp.dt_cost_off >= 0) { add(nl ? EK_DT_QCOST : EK_DT_COST, nl ? 3 : 0, vo + hp.dt_cost_off, nullptr); add(nl ? EK_DT_QCOST : EK_DT_COST, nl ? 3 : 0, nullptr, nullptr); }
         if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
         if (so[3] >= 0) add(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, vi + so[3], mi);
         double* next = nullptr;
@@ -3083,7 +3083,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         else {
             if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_STATE_QCOST : EK_STATE_COST;
             if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_CONTROL_QCOST : EK_CONTROL_COST;
-            if ((terms & 4) && k == 0) { kinds[n_edges++] = EK_DT_COST; kinds[n_edges++] = EK_DT_COST; }
+            if ((terms & 4) && k == 0) { kinds[n_edges++] = nl ? EK_DT_QCOST : EK_DT_COST; kinds[n_edges++] = nl ? EK_DT_QCOST : EK_DT_COST; }
         }
         double obj = 0.0;
         for (int e = 0; e < n_edges; ++e) {
@@ -3097,7 +3097,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
                     if ((fm >> (off + i)) & 1u) continue;
                     double acc = 0.0;
                     for (int r = 0; r < ed; ++r) acc += blk[col * ed + r];
-                    gr[p.comp[k * S + off + i].param] += acc;
+                    gr[p.comp[kind == EK_DT_QCOST ? p.off_dt : k * S + off + i].param] += acc;
                     ++col;
                 }
                 HE::values(kind, xl, xr, mpl, vals);

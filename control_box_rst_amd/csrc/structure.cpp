@@ -41,8 +41,6 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         d.grid != CORBO_HIP_GRID_MS_VARIABLE)
         return "a stage cost with a minimum-time term needs a grid with a free dt";
     if (d.cost_nonlsq != 0 && d.cost_nonlsq != 1) return "cost_nonlsq must be 0 or 1";
-    if (d.cost_nonlsq && d.stage_cost != CORBO_HIP_COST_NONE && d.stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ)
-        return "cost_nonlsq: quadratic stage cost (or none) only";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
     if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
@@ -78,7 +76,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         for (int i = 0; i < nx; ++i) { S.sq[i] = d.q_diag[i]; S.sqf[i] = d.qf_diag[i]; }
         for (int i = 0; i < nu; ++i) S.sr[i] = d.r_diag[i];
     }
-    S.dt_weight = std::sqrt((double)(N - 1));  // minimum_time.h:60
+    S.dt_weight = d.cost_nonlsq ? (double)(N - 1) : std::sqrt((double)(N - 1));  // minimum_time.h:60: sqrt(n - 1) in lsq form, n - 1 otherwise
 
     // ---- components: fixed flags and parameter indices (full_discretization_grid_base.cpp:514-527, vertex_set.cpp:405-418)
     S.comp.assign(S.nvs, CompInfo{1, -1, -1, -1, -1, -1, -1, -1});
@@ -111,7 +109,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         const bool quad = (k >= d.quad_first_interval) && !d.cost_nonlsq;   // MinTimeQuadratic::only_last_n (hybrid_cost.h:224-237)
         if ((terms & 1) && quad) lsq.push_back({EK_STATE_COST, k, nx, 0});
         if ((terms & 2) && quad) lsq.push_back({EK_CONTROL_COST, k, nu, 0});
-        if ((terms & 4) && k == 0) {   // MinimumTime on a single-dt grid: k = 0 only (minimum_time.h:49)
+        if ((terms & 4) && k == 0 && !d.cost_nonlsq) {   // MinimumTime on a single-dt grid: k = 0 only (minimum_time.h:49)
             lsq.push_back({EK_DT_COST, k, 1, 0});
             lsq.push_back({EK_DT_COST, k, 1, 0});  // duplicated edge
         }

@@ -29,7 +29,8 @@ enum EdgeKind : int32_t {
     // Hessian-path operators only
     EK_STATE_QCOST   = 8,
     EK_CONTROL_QCOST = 9,
-    EK_FINAL_QCOST   = 10
+    EK_FINAL_QCOST   = 10,
+    EK_DT_QCOST      = 11   // MinimumTime(lsq_form = false): (N - 1) dt (minimum_time.h:60), not flagged linear
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):

@@ -154,7 +154,8 @@ typedef struct corbo_hip_problem_desc {
      * final_state_cost.cpp:102-108), filed as plain objective edges (edge_set.h:118-125).  What the reference's IPOPT / QP callers use.
      * Such a problem is not a least-squares problem: corbo_hip_solve / corbo_hip_eval refuse it like LevenbergMarquardtSparse::solve does
      * (levenberg_marquardt_sparse.cpp:48-55); the operators of the exact-Hessian path work on it (objective edges: finite-difference Hessians
-     * weighted with the objective multiplier, gradient = Jacobian rows, value = sum).  stage_cost NONE or QUADRATIC_LSQ only. */
+     * weighted with the objective multiplier, gradient = Jacobian rows, value = sum).  Every stage cost kind: MinimumTime(false) is
+     * (N - 1) dt (minimum_time.h:60), not flagged linear (stage_functions.h:73) -- its Hessian entries are finite differences too. */
     int32_t cost_nonlsq;
 } corbo_hip_problem_desc;
 

@@ -365,7 +365,6 @@ static int validate(const corbo_hip_problem_desc* d)
         d->grid != CORBO_HIP_GRID_MS_VARIABLE)
         return 0;
     if (d->cost_nonlsq != 0 && d->cost_nonlsq != 1) return 0;
-    if (d->cost_nonlsq && d->stage_cost != CORBO_HIP_COST_NONE && d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ) return 0;
     if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
     if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
     if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
@@ -468,7 +467,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     p->xref   = (double*)calloc(nx, sizeof(double));
     for (int i = 0; i < nx; ++i) { p->sq[i] = sqrt(d->q_diag[i]); p->sqf[i] = sqrt(d->qf_diag[i]); } /* quadratic_cost.cpp:59-67 */
     for (int i = 0; i < nu; ++i) p->sr[i] = sqrt(d->r_diag[i]);
-    p->dt_weight = sqrt((double)(N - 1)); /* minimum_time.h:60 (single dt, lsq form) */
+    p->dt_weight = d->cost_nonlsq ? (double)(N - 1) : sqrt((double)(N - 1)); /* minimum_time.h:60 (single dt): sqrt(n - 1) in lsq form, n - 1 otherwise */
 
     /* ---- edges in creation order (finite_differences_grid.cpp:38-154 / multiple_shooting_grid.cpp:38-197,
      *      nlp_functions.cpp:70-132: state term, control term, dt term (twice!), ...) */
@@ -492,7 +491,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         }
         if ((terms & 4) && k == 0) {
             for (int rep = 0; rep < 2; ++rep) { /* duplicated dt edge, nlp_functions.cpp:91-107 */
-                o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0;
+                o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0; e->nonlsq = d->cost_nonlsq;
             }
         }
         if (d->stage_ineq == CORBO_HIP_INEQ_BALL) {

@@ -227,6 +227,11 @@ def nonlsq():
         ("hess_vdp_nonlsq", dict(scenario="vdp", N=10, lsq=0)),
         ("hess_unicycle_nonlsq", dict(scenario="unicycle", N=12, lsq=0)),
         ("hess_unicycle_nonlsq_tball", dict(scenario="unicycle", N=10, lsq=0, xf_fixed=4, tball=0.02, tball_s="1,1,0.1")),
+        # MinimumTime(lsq_form = false): (n - 1) dt, created twice, NOT flagged linear (stage_functions.h:73) -- finite-difference Hessians of a
+        # linear term; MinTimeQuadratic(.., lsq_form = false): all three terms plain
+        ("hess_dint_nonlsq", dict(scenario="dint", N=12, lsq=0)),
+        ("hess_dint_mtq_nonlsq", dict(scenario="dint", N=10, cost="mtq", lsq=0)),
+        ("hess_int3_ms_nonlsq", dict(scenario="int3", vargrid=1, grid="ms", N=8, lsq=0)),
     ]:
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

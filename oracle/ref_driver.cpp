@@ -148,7 +148,7 @@ struct Scenario
     // MinTimeQuadraticStates / MinTimeQuadraticControls (lsq form), Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
     std::string cost;
     int last_n = 0;             // last_n=<n> with cost=mtq: MinTimeQuadratic's only_last_n
-    bool nonlsq = false;        // lsq=0 (unicycle, vdp; hess mode): QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false -- scalar terms
+    bool nonlsq = false;        // lsq=0 (unicycle, vdp, dint, int3 vargrid, cost=mtq; hess mode): QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false -- scalar terms
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
     bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
@@ -413,7 +413,7 @@ static Built build(const Scenario& s, int iterations)
     }
     else if (s.name == "int3")
     {
-        if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
+        if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(!s.nonlsq));
         else
         {
             Eigen::MatrixXd Q = Eigen::Vector3d(1, 0.5, 0.1).asDiagonal();
@@ -426,7 +426,7 @@ static Built build(const Scenario& s, int iterations)
     }
     else if (s.name == "dint")
     {
-        b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
+        b.ocp->setStageCost(std::make_shared<MinimumTime>(!s.nonlsq));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else if (s.name == "quad")
@@ -460,7 +460,7 @@ static Built build(const Scenario& s, int iterations)
         for (int i = 0; i < s.nu; ++i) r[i] = rv[i % 3];
         Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
         if (s.cost == "mtq" && s.last_n > 0) b.ocp->setStageCost(std::make_shared<MinTimeQuadraticLastN>(Q, R, s.last_n));
-        else if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, true));
+        else if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, !s.nonlsq));
         else if (s.cost == "qstate") b.ocp->setStageCost(std::make_shared<QuadraticStateCost>(Q, false, true));
         else if (s.cost == "qctrl") b.ocp->setStageCost(std::make_shared<QuadraticControlCost>(R, false, true));
         else if (s.cost == "mtqs") b.ocp->setStageCost(std::make_shared<MinTimeQuadraticStates>(Q, false, true));

@@ -57,6 +57,8 @@ def desc_for(g):
             problems.min_time_quadratic(d, (1.0, 0.5, 0.2, 0.1)[: d.nx], (0.1, 0.2, 0.05)[: d.nu], only_last_n=g.get("last_n", 0))
         else:
             assert "cost" not in g, g["cost"]
+        if g.get("lsq") == 0:   # lsq_form = false for every cost term (Hessian-path fixtures): plain objective edges
+            d.cost_nonlsq = 1
         return d
     if sc == "dint":
         return cost_option(problems.dint_desc(N=g["N"], dt=g["dt"], shooting=(g.get("grid") == "ms")))
@@ -96,8 +98,6 @@ def desc_for(g):
     if g.get("teq"):            # TerminalEqualityConstraint(xf)
         d.final_eq = 1
     cost_option(d)
-    if g.get("lsq") == 0:       # QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false (Hessian-path fixtures)
-        d.cost_nonlsq = 1
     if "ball" in g:             # BallKeepOut stage inequality
         d.stage_ineq = capi.INEQ_BALL
         for i, v in enumerate(g["ball"]):

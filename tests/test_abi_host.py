@@ -115,7 +115,7 @@ def test_create_refuses_descriptors_without_device_kernels_before_touching_the_d
 @pytest.mark.parametrize("name", ["hess_vdp", "hess_vdp_forward", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal", "hess_unicycle_n16",
                                   "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal",
                                   "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5",
-                                  "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball"])
+                                  "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq"])
 def test_hessian_and_linear_form_structure_vs_reference(name):
     """corbo_hip_hessian_{nnz,structure} / corbo_hip_linear_form_structure are host-only functions of the descriptor: the three triplet
     lists of computeSparseHessiansStructure (full and lower part) and the linear form's, entry by entry as the genuine reference
