@@ -2903,6 +2903,24 @@ struct HessEdge {
             case EK_STATE_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sq[i]) * xd; } out[0] = acc; break; }
             case EK_CONTROL_QCOST: { double acc = 0.0; for (int i = 0; i < NU; ++i) acc += (xl[NX + i] * mp.sr[i]) * xl[NX + i]; out[0] = acc; break; }
             case EK_FINAL_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sqf[i]) * xd; } out[0] = acc; break; }
+            // QuadraticFormCost::computeIntegralStateControlTerm (quadratic_cost.cpp:186-230): cost = 0; cost += xd^T Q xd; cost += u^T R u, at
+            // (x_k, u_k) and -- trapezoidal rule -- at (x_{k+1}, u_k), both against reference k; 0.5 dt (c1 + c2) resp. c1 *= dt
+            case EK_INTEGRAL_TRAP: case EK_INTEGRAL_LEFT: {
+                double c[2] = {0.0, 0.0};
+                for (int end = 0; end < (kind == EK_INTEGRAL_TRAP ? 2 : 1); ++end) {
+                    const double* xe = end ? xl + S : xl;
+                    double cost = 0.0, acc = 0.0;
+                    for (int i = 0; i < NX; ++i) { const double xd = xe[i] - xr[i]; acc += (xd * mp.sq[i]) * xd; }
+                    cost += acc;
+                    acc = 0.0;
+                    for (int i = 0; i < NU; ++i) acc += (xl[NX + i] * mp.sr[i]) * xl[NX + i];
+                    cost += acc;
+                    c[end] = cost;
+                }
+                if (kind == EK_INTEGRAL_TRAP) out[0] = 0.5 * xl[W - 1] * (c[0] + c[1]);
+                else { out[0] = c[0]; out[0] *= xl[W - 1]; }
+                break;
+            }
             case EK_DEFECT: defect_eval<DYN, DEFECT>(xl, xl + NX, xl + S, xl[W - 1], mp.dyn, out); break;
             case EK_STAGE_INEQ:
                 if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
@@ -2915,11 +2933,12 @@ struct HessEdge {
         }
     }
     __device__ static int edge_dim(int kind) { return kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
-    __device__ static int n_verts(int kind) { return kind == EK_DEFECT ? 4 : 1; }
-    __device__ static int vert_off(int kind, int vi) { return kind == EK_DEFECT ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
+    __device__ static int n_verts(int kind) { return (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? 4 : kind == EK_INTEGRAL_LEFT ? 3 : 1; }
+    __device__ static int vert_off(int kind, int vi) { return kind == EK_INTEGRAL_LEFT ? (vi == 0 ? 0 : vi == 1 ? NX : W - 1) : (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
     __device__ static int vert_dim(int kind, int vi)
     {
-        if (kind == EK_DEFECT) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? NX : 1;
+        if (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? NX : 1;
+        if (kind == EK_INTEGRAL_LEFT) return vi == 0 ? NX : vi == 1 ? NU : 1;
         return (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NU : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? 1 : NX;   // every other edge hangs on one state vertex
     }
     __device__ static int unfixed(unsigned fm, int off, int dim) { int n = 0; for (int i = 0; i < dim; ++i) n += ((fm >> (off + i)) & 1u) ? 0 : 1; return n; }
@@ -3060,7 +3079,8 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         const double* mults[6];
         auto add = [&](int kind, int cat, double* out, const double* mult) { kinds[n_edges] = kind; cats[n_edges] = cat; outs[n_edges] = out; mults[n_edges] = mult; ++n_edges; };
         const bool nl = hp.cost_nonlsq != 0;   // plain objective edges: category 3 (same output list)
-        if (so[0] >= 0) add(final_stage ? (nl ? EK_FINAL_QCOST : EK_FINAL_COST) : (nl ? EK_STATE_QCOST : EK_STATE_COST), nl ? 3 : 0, vo + so[0], nullptr);
+        const int stage_kind = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : hp.cost_integral == 2 ? EK_INTEGRAL_LEFT : (nl ? EK_STATE_QCOST : EK_STATE_COST);
+        if (so[0] >= 0) add(final_stage ? (nl ? EK_FINAL_QCOST : EK_FINAL_COST) : stage_kind, nl ? 3 : 0, vo + so[0], nullptr);
         if (so[1] >= 0) add(nl ? EK_CONTROL_QCOST : EK_CONTROL_COST, nl ? 3 : 0, vo + so[1], nullptr);
         if (k == 0 && hp.dt_cost_off >= 0) { add(nl ? EK_DT_QCOST : EK_DT_COST, nl ? 3 : 0, vo + hp.dt_cost_off, nullptr); add(nl ? EK_DT_QCOST : EK_DT_COST, nl ? 3 : 0, nullptr, nullptr); }
         if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
@@ -3081,8 +3101,11 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         const bool nl = hp.cost_nonlsq != 0;
         if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = nl ? EK_FINAL_QCOST : EK_FINAL_COST; }
         else {
-            if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_STATE_QCOST : EK_STATE_COST;
-            if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_CONTROL_QCOST : EK_CONTROL_COST;
+            if (hp.cost_integral) kinds[n_edges++] = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : EK_INTEGRAL_LEFT;
+            else {
+                if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_STATE_QCOST : EK_STATE_COST;
+                if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_CONTROL_QCOST : EK_CONTROL_COST;
+            }
             if ((terms & 4) && k == 0) { kinds[n_edges++] = nl ? EK_DT_QCOST : EK_DT_COST; kinds[n_edges++] = nl ? EK_DT_QCOST : EK_DT_COST; }
         }
         double obj = 0.0;
@@ -3090,20 +3113,29 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
             const int kind = kinds[e], ed = HE::edge_dim(kind), off = HE::vert_off(kind, 0), dim = HE::vert_dim(kind, 0);
             double blk[HE::MAXD * HE::MAXD], vals[HE::MAXD];
             const int nu_ = HE::unfixed(fm, off, dim);
-            if (nu_ > 0) HE::jacobian(kind, 0, fm, xl, xr, mpl, blk);
-            if (kind >= EK_STATE_QCOST) {   // plain objective edge: gradient += the Jacobian's column sums, value += the sum of the values
-                int col = 0;                // (…edge_based.cpp:43-56, hyper_graph_optimization_problem_base.cpp:136-141); no values before the sum
-                for (int i = 0; i < dim; ++i) {
-                    if ((fm >> (off + i)) & 1u) continue;
-                    double acc = 0.0;
-                    for (int r = 0; r < ed; ++r) acc += blk[col * ed + r];
-                    gr[p.comp[kind == EK_DT_QCOST ? p.off_dt : k * S + off + i].param] += acc;
-                    ++col;
+            if (kind >= EK_STATE_QCOST) {   // plain objective edge: gradient += the Jacobian's column sums per attached vertex, value += the sum of
+                // the values (…edge_based.cpp:43-56, hyper_graph_optimization_problem_base.cpp:136-141).  An integral cost edge reaches into
+                // x_{k+1}, whose other contribution comes from the next lane: atomic adds (two terms per component: either order gives the same sum)
+                for (int vi = 0; vi < HE::n_verts(kind); ++vi) {
+                    const int vo_ = HE::vert_off(kind, vi), vd_ = HE::vert_dim(kind, vi);
+                    if (HE::unfixed(fm, vo_, vd_) == 0) continue;
+                    HE::jacobian(kind, vi, fm, xl, xr, mpl, blk);
+                    int col = 0;
+                    for (int i = 0; i < vd_; ++i) {
+                        if ((fm >> (vo_ + i)) & 1u) continue;
+                        double acc = 0.0;
+                        for (int r = 0; r < ed; ++r) acc += blk[col * ed + r];
+                        const int L = vo_ + i;   // local slot -> vertex-storage offset: x_k u_k | x_{k+1} | dt
+                        const int v = (L == HE::W - 1) ? p.off_dt : (L < S ? k * S + L : (k + 1) * S + (L - S));
+                        atomicAdd(&gr[p.comp[v].param], acc);
+                        ++col;
+                    }
                 }
                 HE::values(kind, xl, xr, mpl, vals);
                 for (int r = 0; r < ed; ++r) obj += vals[r];
                 continue;
             }
+            if (nu_ > 0) HE::jacobian(kind, 0, fm, xl, xr, mpl, blk);
             HE::values(kind, xl, xr, mpl, vals);
             int col = 0;
             for (int i = 0; i < dim; ++i) {

@@ -41,6 +41,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         d.grid != CORBO_HIP_GRID_MS_VARIABLE)
         return "a stage cost with a minimum-time term needs a grid with a free dt";
     if (d.cost_nonlsq != 0 && d.cost_nonlsq != 1) return "cost_nonlsq must be 0 or 1";
+    if (d.cost_integral < 0 || d.cost_integral > 2) return "cost_integral must be 0, 1 (trapezoidal rule) or 2 (left sum)";
+    if (d.cost_integral && (!d.cost_nonlsq || d.stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || d.grid != CORBO_HIP_GRID_FD))
+        return "cost_integral: quadratic stage cost with cost_nonlsq = 1 on the FiniteDifferencesGrid";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
     if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
@@ -294,7 +297,12 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
     for (int k = 0; k < N - 1; ++k) {
         const V xk{k * s, nx}, uk{k * s + nx, nu};
         const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);
-        const bool quad = (k >= d.quad_first_interval);
+        const bool quad = (k >= d.quad_first_interval) && !d.cost_integral;
+        if (d.cost_integral) {   // one integral cost edge per interval instead of the per-vertex terms (finite_differences_grid.cpp:62-77)
+            const V trap[4] = {xk, uk, {(k + 1) * s, nx}, dtv}, left[3] = {xk, uk, dtv};
+            H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size();
+            if (d.cost_integral == 1) walk(0, trap, 4); else walk(0, left, 3);
+        }
         if ((terms & 1) && quad) { H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xk, 1); }
         if ((terms & 2) && quad) { H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size(); walk(0, &uk, 1); }
         if ((terms & 4) && k == 0) {

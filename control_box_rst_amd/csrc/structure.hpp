@@ -30,7 +30,10 @@ enum EdgeKind : int32_t {
     EK_STATE_QCOST   = 8,
     EK_CONTROL_QCOST = 9,
     EK_FINAL_QCOST   = 10,
-    EK_DT_QCOST      = 11   // MinimumTime(lsq_form = false): (N - 1) dt (minimum_time.h:60), not flagged linear
+    EK_DT_QCOST      = 11,  // MinimumTime(lsq_form = false): (N - 1) dt (minimum_time.h:60), not flagged linear
+    // QuadraticFormCost in integral form: one objective edge per interval (finite_differences_collocation_edges.h:98-152, 323-368)
+    EK_INTEGRAL_TRAP = 12,  // TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt)
+    EK_INTEGRAL_LEFT = 13   // LeftSumCostEdge on (x_k, u_k, dt)
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):

@@ -157,6 +157,13 @@ typedef struct corbo_hip_problem_desc {
      * weighted with the objective multiplier, gradient = Jacobian rows, value = sum).  Every stage cost kind: MinimumTime(false) is
      * (N - 1) dt (minimum_time.h:60), not flagged linear (stage_functions.h:73) -- its Hessian entries are finite differences too. */
     int32_t cost_nonlsq;
+    /* QuadraticFormCost(Q, R, integral_form = true) on a FiniteDifferencesGrid: instead of the per-vertex terms ONE objective edge per
+     * interval that integrates c(x, u) = (x - xref)^T Q (x - xref) + u^T R u over it (finite_differences_grid.cpp:62-77) --
+     * 1: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt), 0.5 dt (c(x_k, u_k) + c(x_{k+1}, u_k));  2: LeftSumCostEdge on (x_k, u_k, dt),
+     * dt c(x_k, u_k) (finite_differences_collocation_edges.h:98-152, 323-368; FullDiscretizationGridBase::CostIntegrationRule).  Plain objective
+     * edges: needs cost_nonlsq = 1 (the final cost is then QuadraticFinalStateCost(Qf, false)); Hessian-path operators only. */
+    int32_t cost_integral;
+    int32_t reserved0;
 } corbo_hip_problem_desc;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */

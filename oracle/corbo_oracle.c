@@ -28,7 +28,7 @@ typedef struct {
     int col;        /* getVertexIdx(): first parameter index, -1 when not active (vertex_set.cpp:405-418) */
 } o_vertex;
 
-enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ, E_FINAL_EQ };
+enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ, E_FINAL_EQ, E_INTEGRAL_COST };
 
 typedef struct {
     int type;
@@ -272,6 +272,29 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - rk[i]);
             break;
         }
+        case E_INTEGRAL_COST: { /* TrapezoidalIntegralCostEdge (x1, u1, x2, dt) / LeftSumCostEdge (x1, u1, dt)
+                                 * (finite_differences_collocation_edges.h:98-152, 323-368) over QuadraticFormCost::computeIntegralStateControlTerm
+                                 * (quadratic_cost.cpp:186-230): cost = 0; cost += xd^T Q_diag xd; cost += u^T R_diag u; both ends use reference k */
+            const double* x1 = x + p->v[e->vert[0]].off;
+            const double* u1 = x + p->v[e->vert[1]].off;
+            const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
+            const int trap   = (e->nverts == 4);
+            const double dt  = x[p->v[e->vert[trap ? 3 : 2]].off];
+            double c[2];
+            for (int end = 0; end < (trap ? 2 : 1); ++end) {
+                const double* xe = end ? x + p->v[e->vert[2]].off : x1;
+                double cost = 0.0, acc = 0.0;
+                for (int i = 0; i < d->nx; ++i) { double xd = xe[i] - rk[i]; acc += (xd * d->q_diag[i]) * xd; }
+                cost += acc;
+                acc = 0.0;
+                for (int i = 0; i < d->nu; ++i) acc += (u1[i] * d->r_diag[i]) * u1[i];
+                cost += acc;
+                c[end] = cost;
+            }
+            if (trap) out[0] = 0.5 * dt * (c[0] + c[1]);
+            else { out[0] = c[0]; out[0] *= dt; }
+            break;
+        }
         case E_DT_COST: /* optimal_control/include/corbo-optimal-control/functions/minimum_time.h:70-78 */
             out[0] = p->dt_weight * x[p->v[e->vert[0]].off];
             break;
@@ -365,6 +388,8 @@ static int validate(const corbo_hip_problem_desc* d)
         d->grid != CORBO_HIP_GRID_MS_VARIABLE)
         return 0;
     if (d->cost_nonlsq != 0 && d->cost_nonlsq != 1) return 0;
+    if (d->cost_integral < 0 || d->cost_integral > 2) return 0;
+    if (d->cost_integral && (!d->cost_nonlsq || d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || d->grid != CORBO_HIP_GRID_FD)) return 0;
     if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
     if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
     if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
@@ -483,10 +508,17 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         const int terms = CORBO_HIP_COST_TERMS(d->stage_cost);
         const int quad = (k >= d->quad_first_interval); /* MinTimeQuadratic::only_last_n, hybrid_cost.h:224-237 */
         const int nl = d->cost_nonlsq; /* QuadraticFormCost(.., lsq_form = false): one scalar term each (quadratic_cost.h: dimension 1) */
-        if ((terms & 1) && quad) {
+        if (d->cost_integral) { /* QuadraticFormCost(Q, R, integral_form = true): no non-integral terms; one integral cost edge per interval
+                                 * (finite_differences_grid.cpp:62-77), 1 = TrapezoidalRule, 2 = LeftSum */
+            o_edge* e = &lsq[n_lsq++]; e->type = E_INTEGRAL_COST; e->k = k; e->dim = 1; e->scale = 0; e->nonlsq = 1;
+            e->vert[0] = xk; e->vert[1] = uk;
+            if (d->cost_integral == 1) { e->nverts = 4; e->vert[2] = xnext; e->vert[3] = dt_vertex; }
+            else { e->nverts = 3; e->vert[2] = dt_vertex; }
+        }
+        else if ((terms & 1) && quad) {
             o_edge* e = &lsq[n_lsq++]; e->type = E_STATE_COST; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = nl ? 1 : nx; e->scale = 0; e->nonlsq = nl;
         }
-        if ((terms & 2) && quad) {
+        if (!d->cost_integral && (terms & 2) && quad) {
             o_edge* e = &lsq[n_lsq++]; e->type = E_CONTROL_COST; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = nl ? 1 : nu; e->scale = 0; e->nonlsq = nl;
         }
         if ((terms & 4) && k == 0) {

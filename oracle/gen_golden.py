@@ -232,6 +232,10 @@ def nonlsq():
         ("hess_dint_nonlsq", dict(scenario="dint", N=12, lsq=0)),
         ("hess_dint_mtq_nonlsq", dict(scenario="dint", N=10, cost="mtq", lsq=0)),
         ("hess_int3_ms_nonlsq", dict(scenario="int3", vargrid=1, grid="ms", N=8, lsq=0)),
+        # QuadraticFormCost in integral form: TrapezoidalIntegralCostEdge / LeftSumCostEdge (finite_differences_collocation_edges.h:98-152, 323-368)
+        ("hess_vdp_integral_trap", dict(scenario="vdp", N=10, lsq=0, integral="trap")),
+        ("hess_unicycle_integral_trap", dict(scenario="unicycle", N=10, lsq=0, integral="trap", xf_fixed=2)),
+        ("hess_unicycle_integral_left", dict(scenario="unicycle", N=10, lsq=0, integral="left")),
     ]:
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:

@@ -148,6 +148,7 @@ struct Scenario
     // MinTimeQuadraticStates / MinTimeQuadraticControls (lsq form), Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
     std::string cost;
     int last_n = 0;             // last_n=<n> with cost=mtq: MinTimeQuadratic's only_last_n
+    std::string integral;       // integral=trap|left (unicycle, vdp; with lsq=0): QuadraticFormCost in integral form, the grid's cost integration rule
     bool nonlsq = false;        // lsq=0 (unicycle, vdp, dint, int3 vargrid, cost=mtq; hess mode): QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false -- scalar terms
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
@@ -355,7 +356,7 @@ static Built build(const Scenario& s, int iterations)
     {
         b.grid->setNRef(s.N);
         b.grid->setDtRef(s.dt);
-        b.grid->setCostIntegrationRule(FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        b.grid->setCostIntegrationRule(s.integral == "trap" ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         b.grid->setFiniteDifferencesCollocationMethod(makeCollocation(s.collocation));
         if (s.xf_fixed >= 0)
         {
@@ -375,7 +376,7 @@ static Built build(const Scenario& s, int iterations)
         Eigen::MatrixXd Q = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
         Eigen::MatrixXd R = Eigen::Vector2d(0.1, 0.05).asDiagonal();
         Eigen::MatrixXd Qf = 10.0 * Q;
-        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, !s.nonlsq));
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         b.ocp->setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
     }
@@ -384,7 +385,7 @@ static Built build(const Scenario& s, int iterations)
         Eigen::MatrixXd Q = Eigen::Vector2d(1, 1).asDiagonal();
         Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
         Eigen::MatrixXd Qf = 10.0 * Q;
-        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, !s.nonlsq));
+        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
@@ -678,6 +679,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("cost")) s.cost = kv["cost"];
     if (kv.count("last_n")) s.last_n = atoi(kv["last_n"].c_str());
     if (kv.count("lsq")) s.nonlsq = atoi(kv["lsq"].c_str()) == 0;
+    if (kv.count("integral")) s.integral = kv["integral"];
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
     if (kv.count("nmin")) s.n_min = atoi(kv["nmin"].c_str());
@@ -704,6 +706,7 @@ static int dump(const Scenario& s)
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
     if (s.nonlsq) printf("\"lsq\": 0,\n");
+    if (!s.integral.empty()) printf("\"integral\": \"%s\",\n", s.integral.c_str());
     if (s.xlb.size()) printVec("xlb", s.xlb);
     if (s.xub.size()) printVec("xub", s.xub);
     if (s.ulb.size()) printVec("ulb", s.ulb);
@@ -1024,6 +1027,7 @@ static int hess(const Scenario& s)
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
     if (s.nonlsq) printf("\"lsq\": 0,\n");
+    if (!s.integral.empty()) printf("\"integral\": \"%s\",\n", s.integral.c_str());
     if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
     if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
     if (s.xlb.size()) printVec("xlb", s.xlb);

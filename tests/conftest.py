@@ -59,6 +59,8 @@ def desc_for(g):
             assert "cost" not in g, g["cost"]
         if g.get("lsq") == 0:   # lsq_form = false for every cost term (Hessian-path fixtures): plain objective edges
             d.cost_nonlsq = 1
+        if "integral" in g:     # QuadraticFormCost in integral form + the grid's cost integration rule
+            d.cost_integral = {"trap": 1, "left": 2}[g["integral"]]
         return d
     if sc == "dint":
         return cost_option(problems.dint_desc(N=g["N"], dt=g["dt"], shooting=(g.get("grid") == "ms")))

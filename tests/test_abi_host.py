@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header(lib):
     # sizes implied by include/corbo_hip.h (packing check of the ctypes mirrors)
-    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8 + 28 * 8 + 2 * 4
+    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8 + 28 * 8 + 4 * 4
     assert C.sizeof(capi.Dims) == 8 * 4
     assert C.sizeof(capi.LmOpts) == 8 + 9 * 8
     o = capi.LmOpts()
@@ -115,7 +115,8 @@ def test_create_refuses_descriptors_without_device_kernels_before_touching_the_d
 @pytest.mark.parametrize("name", ["hess_vdp", "hess_vdp_forward", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal", "hess_unicycle_n16",
                                   "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal",
                                   "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5",
-                                  "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq"])
+                                  "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq",
+                                  "hess_vdp_integral_trap", "hess_unicycle_integral_trap", "hess_unicycle_integral_left"])
 def test_hessian_and_linear_form_structure_vs_reference(name):
     """corbo_hip_hessian_{nnz,structure} / corbo_hip_linear_form_structure are host-only functions of the descriptor: the three triplet
     lists of computeSparseHessiansStructure (full and lower part) and the linear form's, entry by entry as the genuine reference

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 HESS = ["hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
         "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal",
         "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5",
-        "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq"]   # *_nonlsq: plain (non-least-squares) objective edges
+        "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq",
+        "hess_vdp_integral_trap", "hess_unicycle_integral_trap", "hess_unicycle_integral_left"]   # integral-form cost: one objective edge per interval   # *_nonlsq: plain (non-least-squares) objective edges
 KEYS = ("hobj", "heq", "hineq")
 REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below
 
@@ -151,7 +152,9 @@ def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
     rng = np.random.default_rng(31000 + seed)
     fam, d = random_desc(rng)
     if seed % 3 == 0:
-        d.cost_nonlsq = 1   # the same terms as plain objective edges (lsq_form = false): what the Hessian path is for
+        d.cost_nonlsq = 1
+        if d.grid == capi.GRID_FD and d.stage_cost == capi.COST_QUADRATIC_LSQ and seed % 2 == 0:
+            d.cost_integral = 1 + (seed // 6) % 2   # QuadraticFormCost in integral form: trapezoidal / left-sum cost edge per interval   # the same terms as plain objective edges (lsq_form = false): what the Hessian path is for
     B = 2
     x0 = rng.uniform(-1, 1, (B, d.nx))
     xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2, 0.0])[: d.nx] if fam not in ("dint", "int3t") else np.array([1.0, 0.0, 0.0])[: d.nx])
