@@ -74,6 +74,27 @@ def test_invalid_descriptors_are_rejected(lib):
     with pytest.raises(solver.CorboHipError):
         solver.get_dims(d)
     assert b"" != lib.corbo_hip_last_error()
+    # the cost-form fields: an integral cost is a plain objective edge on the FiniteDifferencesGrid; only_last_n belongs to MinTimeQuadratic;
+    # a minimum-time term needs a free dt
+    for edit in (lambda d: setattr(d, "cost_integral", 1), lambda d: setattr(d, "cost_integral", 3), lambda d: setattr(d, "cost_nonlsq", 2),
+                 lambda d: setattr(d, "quad_first_interval", 5), lambda d: setattr(d, "stage_cost", capi.COST_MIN_TIME_QUADRATIC_LSQ)):
+        d = problems.unicycle_desc()
+        edit(d)
+        with pytest.raises(solver.CorboHipError):
+            solver.get_dims(d)
+    d = problems.unicycle_desc()
+    d.cost_nonlsq, d.cost_integral = 1, 2
+    assert solver.get_dims(d).lsq == 0   # plain objective edges are no rows of the LM residual
+
+
+def test_the_oracle_refuses_what_the_reference_solver_refuses(oracle_mod):
+    """LevenbergMarquardtSparse::solve returns Error for a problem with plain objective edges (levenberg_marquardt_sparse.cpp:48-55)."""
+    d = problems.vdp_desc(N=8)
+    d.cost_nonlsq = 1
+    p = oracle_mod.OracleProblem(d)
+    p.set_data(p.init_trajectory([1.0, 0.0], [0.0, 0.0]), xref=np.zeros(2))
+    assert p.dims.lsq == 0
+    assert oracle_mod.load().oracle_solve(p.h, C.byref(capi.default_lm_opts(2, 2.0, 2.0, 2.0)), 1, None, None) == capi.SOLVER_ERROR
 
 
 def test_create_without_gpu_fails_loudly(lib):
