@@ -97,6 +97,16 @@ def dint_desc(N=50, dt=0.1, shooting=False) -> ProblemDesc:
 DINT_WEIGHTS = (100.0, 100.0, 100.0)
 
 
+def hessian_path_cost_form(d: ProblemDesc, integral: str = "") -> ProblemDesc:
+    """The cost forms of the reference's IPOPT / QP callers (Hessian-path operators only; corbo_hip_solve refuses such a handle like
+    LevenbergMarquardtSparse does): every cost term with lsq_form = False -- scalar terms x^T Q x, plain objective edges -- and, with
+    integral = "trapezoidal" | "left_sum", QuadraticFormCost(integral_form = True): one TrapezoidalIntegralCostEdge / LeftSumCostEdge per
+    interval of a FiniteDifferencesGrid instead of the per-vertex terms."""
+    d.cost_nonlsq = 1
+    d.cost_integral = {"": 0, "trapezoidal": 1, "left_sum": 2}[integral]
+    return d
+
+
 def min_time_quadratic(d: ProblemDesc, q, r, only_last_n=0) -> ProblemDesc:
     """Turn a time-optimal descriptor (free dt, MinimumTime) into the reference's MinTimeQuadratic(Q, R, integral=False, lsq=True)
     (hybrid_cost.h:189-303): the quadratic form's state and control terms next to the minimum-time term; only_last_n > 0: on the

@@ -16,7 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for label, nonlsq, integral in (("least-squares cost", 0, 0), ("plain quadratic cost (lsq_form = false)", 1, 0), ("integral cost, trapezoidal rule", 1, 1)):
     d = problems.unicycle_desc()
-    d.cost_nonlsq, d.cost_integral = nonlsq, integral
+    if nonlsq:
+        problems.hessian_path_cost_form(d, "trapezoidal" if integral else "")
     x0, xf = problems.unicycle_instances(B)
     s = BatchedLevenbergMarquardt(d, B)
     rng = np.random.default_rng(0)
