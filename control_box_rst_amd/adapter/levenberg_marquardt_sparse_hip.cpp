@@ -70,6 +70,41 @@ void LevenbergMarquardtSparseHip::clear()
 // vertex values.
 bool LevenbergMarquardtSparseHip::modelMatchesGraph(OptimizationProblemInterface& problem, bool perturbed)
 {
+    const char* where0 = perturbed ? "at the perturbed probe point" : "at the current vertex values";
+    if (_desc.cost_nonlsq)
+    {   // a stated model for the exact-Hessian path (plain / integral objective edges: no least-squares residual to compare, and
+        // corbo_hip_eval refuses the handle like LevenbergMarquardtSparse refuses the problem): objective value and gradient, the
+        // constraint values through the linear form's bounds (lbA = -c_eq, ubA = -c_ineq)
+        const int n = _dims.n, rows = _dims.eq + _dims.ineq + _dims.bounds;
+        Eigen::VectorXd gd(n), gh(n), ceq(_dims.eq), cineq(_dims.ineq), lbA(rows), ubA(rows);
+        double od = 0;
+        int32_t lnnz = 0, lrows = 0;
+        if (corbo_hip_eval_objective_gradient(_handle, gd.data(), &od) != CORBO_HIP_OK || corbo_hip_linear_form_structure(&_desc, &lnnz, &lrows, nullptr, nullptr) != CORBO_HIP_OK)
+        {
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
+            return false;
+        }
+        Eigen::VectorXd lvals(lnnz);
+        if (lrows != rows || corbo_hip_eval_linear_form(_handle, lvals.data(), lbA.data(), ubA.data()) != CORBO_HIP_OK)
+        {
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): linear form of the device model: " << corbo_hip_last_error());
+            return false;
+        }
+        const double oh = problem.computeValueObjective();
+        problem.computeGradientObjective(gh);
+        if (_dims.eq > 0) problem.computeValuesEquality(ceq);
+        if (_dims.ineq > 0) problem.computeValuesInequality(cineq);
+        bool ok = std::abs(oh - od) <= 1e-9 * (1.0 + std::abs(oh));
+        const double gmax = std::max(1.0, gh.cwiseAbs().maxCoeff());
+        for (int i = 0; i < n && ok; ++i) ok = std::abs(gh[i] - gd[i]) <= 2e-6 * gmax;
+        for (int i = 0; i < _dims.eq && ok; ++i) ok = std::abs(ceq[i] + lbA[i]) <= 1e-9 * (1.0 + std::abs(ceq[i]));
+        for (int i = 0; i < _dims.ineq && ok; ++i) ok = std::abs(cineq[i] + ubA[_dims.eq + i]) <= 1e-9 * (1.0 + std::abs(cineq[i]));
+        if (!ok)
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): the stated device model does not describe this hypergraph (objective value " << oh << " on the graph's edges, " << od
+                                                                                                                                    << " on the device, or its gradient / constraint values differ) "
+                                                                                                                                    << where0 << "; refusing (no CPU fallback).");
+        return ok;
+    }
     const double w_eq = _w_eq, w_ineq = _w_ineq, w_b = _w_b;
     Eigen::VectorXd host(_dims.m), dev(_dims.m), devj(_dims.nnz);
     int idx = 0;

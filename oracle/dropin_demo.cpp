@@ -183,8 +183,12 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     Eigen::VectorXd x0, xf;
     int solves = 1, nu = 1;
     const bool tballc = (scenario == "unicycle_tballc");   // TerminalBallInheritFromCost: S = the final cost's Qf
+    // the cost forms of the reference's IPOPT / QP callers (Hessian mode only; the device model is STATED: the recogniser derives
+    // least-squares-form graphs): lsq_form = false, and QuadraticFormCost in integral form with the trapezoidal rule / the left sum
+    const bool plain = (scenario == "unicycle_plain"), itrap = (scenario == "unicycle_itrap"), ileft = (scenario == "unicycle_ileft");
+    const bool hpath = plain || itrap || ileft;
     const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref");
-    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref);
+    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || hpath);
     if (uni)
     {
         dyn  = std::make_shared<UnicycleRef>();
@@ -298,8 +302,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         s->setIterations(10);
         s->setPenaltyWeights(w, w, w);
         if (mode == Mode::Hessian) s->setIterations(1);
-        if (mode != Mode::HipAuto && mode != Mode::Hessian)
+        if ((mode != Mode::HipAuto && mode != Mode::Hessian) || hpath)
         {
+            if (hpath) { d.cost_nonlsq = 1; d.cost_integral = itrap ? 1 : ileft ? 2 : 0; }
             s->setDeviceModel(d);
             s->setStateReference(xf);
         }
@@ -310,7 +315,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     {
         grid->setNRef(N);
         grid->setDtRef(dt);
-        grid->setCostIntegrationRule(FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        grid->setCostIntegrationRule(itrap ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         any_grid = grid;
     }
     else
@@ -326,8 +331,8 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         if (fullq) { Q(0, 1) = 0.2; Q(1, 0) = 0.2; }
         Eigen::MatrixXd R  = Eigen::Vector2d(0.1, 0.05).asDiagonal();
         Eigen::MatrixXd Qf = 10.0 * Eigen::MatrixXd(Eigen::Vector3d(1, 1, 0.1).asDiagonal());
-        ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-        ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, itrap || ileft, !hpath));
+        ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
         if (tball)
         {
@@ -407,6 +412,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     r.traj = trajectory(ocp, *any_grid);
     r.chi2 = ocp.getCurrentObjectiveValue();
     if (describe_out) *describe_out = *std::static_pointer_cast<RecogniseOnly>(solver);
+    if (mode == Mode::Hessian && hpath) r.ok = true;   // compute() returned false: neither solver takes a problem that is not least squares; the graph is built
     if (mode == Mode::Hessian && r.ok)
     {
         // computeSparseHessians{NNZ,Structure,Values} as IpoptWrapper::eval_h calls them (lower part, per-row multipliers), at a generic
@@ -485,7 +491,7 @@ int main(int argc, char** argv)
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,
