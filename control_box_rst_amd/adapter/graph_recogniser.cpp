@@ -15,6 +15,7 @@
 #include <corbo-systems/benchmark/nonlinear_benchmark_systems.h>
 
 #include <cmath>
+#include <memory>
 #include <cstring>
 #include <sstream>
 #include <vector>
@@ -289,6 +290,72 @@ bool identifyBall(BaseEdge& e, VertexInterface* v, double* prm /*cx, cy, cz, r*/
     return true;
 }
 
+// A scalar term  scale * sum_i q_i (x_i - ref_i)^2  (a cost in plain, non-least-squares form: quadratic_cost.cpp:133-138; the integrand of the
+// integral cost edges, finite_differences_collocation_edges.h:98-152, 323-368), diagonal and non-negative, evaluated through the edge itself.
+// `twins`: vertices that receive the same values (x_k and x_{k+1} of a trapezoidal edge: 0.5 dt (c + c) = dt c exactly).  The reference is
+// the point where the term is EXACTLY zero (three-point estimate, then a walk over neighbouring floating-point numbers); the weights from
+// x_i = ref_i + d with d a power of two ((d q_i) d is a pure exponent shift; divided by `scale`, which costs an ulp unless scale == 1).
+bool identifyDiagonalQuadratic(BaseEdge& e, const std::vector<VertexInterface*>& twins, double scale, Eigen::VectorXd* q, Eigen::VectorXd* ref)
+{
+    if (e.getDimension() != 1 || twins.empty() || !(scale > 0.0)) return false;
+    const int n = twins[0]->getDimension();
+    std::vector<std::unique_ptr<VertexGuard>> guards;
+    for (VertexInterface* v : twins)
+    {
+        if (v->getDimension() != n) return false;
+        guards.emplace_back(new VertexGuard(v));
+    }
+    Eigen::VectorXd x = Eigen::VectorXd::Zero(n);
+    auto f = [&]() {
+        for (VertexInterface* v : twins) std::memcpy(v->getDataRaw(), x.data(), n * sizeof(double));
+        return evalEdge(e)[0];
+    };
+    q->setZero(n);
+    ref->setZero(n);
+    const double f0 = f();
+    std::vector<bool> active(n, false);
+    for (int i = 0; i < n; ++i)
+    {
+        x[i] = 1.0;  const double fp = f();
+        x[i] = -1.0; const double fm = f();
+        x[i] = 0.0;
+        const double qi = 0.5 * (fp + fm - 2.0 * f0);
+        if (!std::isfinite(qi) || qi < 0.0) return false;
+        if (qi == 0.0) { if (fp != f0 || fm != f0) return false; continue; }   // no weight on this component: any reference will do
+        active[i] = true;
+        (*ref)[i] = (fm - fp) / (4.0 * qi);
+    }
+    for (int i = 0; i < n; ++i) x[i] = active[i] ? (*ref)[i] : 0.0;
+    double fx = f();
+    for (int sweep = 0; sweep < 4 && fx != 0.0; ++sweep)
+        for (int i = 0; i < n; ++i)
+        {
+            if (!active[i]) continue;
+            for (int dir = -1; dir <= 1; dir += 2)
+                for (int it = 0; it < 256; ++it)
+                {
+                    const double keep = x[i];
+                    x[i] = std::nextafter(keep, dir > 0 ? INFINITY : -INFINITY);
+                    const double ft = f();
+                    if (ft < fx) fx = ft;
+                    else { x[i] = keep; break; }
+                }
+        }
+    if (f() != 0.0) return false;   // not a sum of squares around one point
+    *ref = x;
+    for (int i = 0; i < n; ++i)
+    {
+        if (!active[i]) { (*ref)[i] = 0.0; continue; }
+        const double r = x[i];
+        const double d = std::ldexp(1.0, std::max(-20, std::min(20, (r == 0.0) ? 0 : std::ilogb(r))));
+        x[i] = r + d;
+        if (x[i] - r != d) { x[i] = r; return false; }
+        (*q)[i] = f() / (d * d) / scale;
+        x[i] = r;
+    }
+    return true;
+}
+
 // TerminalBall, diagonal S:  c(x_f) = (x_f - ref)^T S (x_f - ref) - gamma   (final_state_constraints.cpp:60-80)
 bool identifyTerminalBall(BaseEdge& e, VertexInterface* v, const Eigen::VectorXd& ref, double* prm /*S_11..S_nn, gamma*/)
 {
@@ -438,7 +505,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     std::memset(&d, 0, sizeof(d));
     d.grid = g.kind; d.nx = g.nx; d.nu = g.nu; d.N = g.N;
     const OptimizationEdgeSet* es = hg.getGraph().getEdgeSetRaw();
-    if (!es->getObjectiveEdges().empty()) return fail(reason, "objective edges that are not in least-squares form");
+    // plain objective edges (costs with lsq_form = false, integral-form costs): the IPOPT-style configuration.  Not a least-squares problem --
+    // solve() will refuse it like the reference's solver -- but the Hessian-path operators work on it; identified below
+    const bool plain_costs = !es->getObjectiveEdges().empty();
+    if (plain_costs && !es->getLsqObjectiveEdges().empty()) return fail(reason, "cost terms in least-squares form and in plain form in one graph");
     if (!es->getMixedEdges().empty()) return fail(reason, "mixed edges (single-control shooting intervals, integral terms)");
 
     // ---- equality edges: one defect edge per interval, in order; then optionally the terminal equality constraint
@@ -577,6 +647,77 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         if ((n_state && std::sqrt(d.q_diag[i]) != sq[i]) || (n_final && std::sqrt(d.qf_diag[i]) != sqf[i])) return fail(reason, "state weight does not survive the square / square-root round trip");
     for (int i = 0; i < g.nu; ++i)
         if (n_ctrl && std::sqrt(d.r_diag[i]) != sr[i]) return fail(reason, "control weight does not survive the square / square-root round trip");
+
+    if (plain_costs)
+    {   // per interval: a state term and a control term (QuadraticFormCost(.., lsq_form = false)), or ONE integral cost edge
+        // (integral_form = true: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt) / LeftSumCostEdge on (x_k, u_k, dt)); then the final cost
+        Eigen::VectorXd q, r, qf, ref, rf, uz;
+        int ns = 0, nc = 0, nf = 0, ni = 0, integral = 0;
+        const double dtv = g.dt->getData()[0];
+        for (const BaseEdge::Ptr& ep : es->getObjectiveEdges())
+        {
+            BaseEdge* e = ep.get();
+            Eigen::VectorXd w, rr;
+            const bool trap = dynamic_cast<TrapezoidalIntegralCostEdge*>(e) != nullptr, left = dynamic_cast<LeftSumCostEdge*>(e) != nullptr;
+            if (trap || left)
+            {
+                if (g.kind != CORBO_HIP_GRID_FD) return fail(reason, "integral cost edges on a grid other than the FiniteDifferencesGrid");
+                const int k = indexOf(g.xs, e->getVertexRaw(0));
+                VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
+                if (k < 0 || e->getVertexRaw(1) != g.us[k] || (trap && (e->getVertexRaw(2) != x2 || e->getVertexRaw(3) != g.dt)) || (left && e->getVertexRaw(2) != g.dt))
+                    return fail(reason, "integral cost edge on unexpected vertices");
+                if (integral && integral != (trap ? 1 : 2)) return fail(reason, "trapezoidal and left-sum cost edges in one graph");
+                integral = trap ? 1 : 2;
+                VertexGuard gu(g.us[k]);
+                std::memset(g.us[k]->getDataRaw(), 0, g.nu * sizeof(double));   // the control part of the integrand is (u r) u: exactly zero at u = 0
+                std::vector<VertexInterface*> tw = {g.xs[k]};
+                if (trap) tw.push_back(x2);
+                if (!identifyDiagonalQuadratic(*e, tw, dtv, &w, &rr)) return fail(reason, "integral cost edge whose integrand is not a diagonal quadratic form in the state");
+                Eigen::VectorXd wu, ru;
+                {   // the control part, with the states at their reference (state part exactly zero)
+                    std::vector<std::unique_ptr<VertexGuard>> gs;
+                    for (VertexInterface* v : tw) { gs.emplace_back(new VertexGuard(v)); std::memcpy(v->getDataRaw(), rr.data(), g.nx * sizeof(double)); }
+                    if (!identifyDiagonalQuadratic(*e, {g.us[k]}, trap ? dtv : dtv, &wu, &ru) || (ru.array() != 0.0).any())
+                        return fail(reason, "integral cost edge whose integrand is not a diagonal quadratic form in the control (zero reference)");
+                }
+                if (ni++ == 0) { q = w; ref = rr; r = wu; }
+                else if ((w - q).cwiseAbs().maxCoeff() > 1e-12 * (1.0 + q.cwiseAbs().maxCoeff()) || !sameVector(rr, ref)) return fail(reason, "integral cost varies along the horizon");
+                continue;
+            }
+            if (e->getNumVertices() != 1) return fail(reason, "plain objective edge on more than one vertex that is not an integral cost edge");
+            VertexInterface* v = e->getVertexRaw(0);
+            if (v == g.dt) return fail(reason, "minimum-time term in plain form: state the device model (setDeviceModel, cost_nonlsq)");
+            if (!identifyDiagonalQuadratic(*e, {v}, 1.0, &w, &rr)) return fail(reason, "plain objective edge that is not a diagonal quadratic form around one reference");
+            if (v == g.xf) { if (nf++ > 0) return fail(reason, "more than one plain term on x_f"); qf = w; rf = rr; }
+            else if (indexOf(g.xs, v) >= 0)
+            {
+                if (ns++ == 0) { q = w; ref = rr; }
+                else if (!sameVector(w, q) || !sameVector(rr, ref)) return fail(reason, "plain state cost varies along the horizon (time-varying references: least-squares form only)");
+            }
+            else if (indexOf(g.us, v) >= 0)
+            {
+                if ((rr.array() != 0.0).any()) return fail(reason, "non-zero control reference");
+                if (nc++ == 0) r = w;
+                else if (!sameVector(w, r)) return fail(reason, "plain control cost varies along the horizon");
+            }
+            else return fail(reason, "plain objective edge on an unexpected vertex");
+        }
+        if (integral ? (ni != g.N - 1 || ns || nc) : (ns != g.N - 1 || nc != g.N - 1)) return fail(reason, "plain cost terms that are not one state and one control term (or one integral edge) per interval");
+        d.cost_nonlsq = 1;
+        d.cost_integral = integral;
+        d.stage_cost = CORBO_HIP_COST_QUADRATIC_LSQ;
+        for (int i = 0; i < g.nx; ++i) d.q_diag[i] = q[i];
+        for (int i = 0; i < g.nu; ++i) d.r_diag[i] = r[i];
+        d.final_cost = nf ? 1 : 0;
+        if (nf) for (int i = 0; i < g.nx; ++i) d.qf_diag[i] = qf[i];
+        model->xref = ref;
+        if (nf)
+            for (int i = 0; i < g.nx; ++i)
+            {
+                if (q[i] != 0.0 && qf[i] != 0.0 && ref[i] != rf[i]) return fail(reason, "stage and final cost use different state references");
+                if (q[i] == 0.0) model->xref[i] = rf[i];
+            }
+    }
 
     // ---- terminal equality constraint: x_f - xref (final_state_constraints.h:130-160)
     if ((int)eqs.size() == g.N)

@@ -127,8 +127,8 @@ static void printDesc(const char* scenario, bool ok, const std::string& why, con
     printf("{\"scenario\": \"%s\", \"recognised\": %d, \"reason\": \"%s\"", scenario, ok ? 1 : 0, why.c_str());
     if (ok)
     {
-        printf(", \"grid\": %d, \"defect\": %d, \"dynamics\": %d, \"stage_cost\": %d, \"final_cost\": %d, \"stage_ineq\": %d, \"final_ineq\": %d, \"final_eq\": %d, \"quad_first_interval\": %d, \"nx\": %d, \"nu\": %d, \"N\": %d",
-               d.grid, d.defect, d.dynamics, d.stage_cost, d.final_cost, d.stage_ineq, d.final_ineq, d.final_eq, d.quad_first_interval, d.nx, d.nu, d.N);
+        printf(", \"grid\": %d, \"defect\": %d, \"dynamics\": %d, \"stage_cost\": %d, \"final_cost\": %d, \"stage_ineq\": %d, \"final_ineq\": %d, \"final_eq\": %d, \"quad_first_interval\": %d, \"cost_nonlsq\": %d, \"cost_integral\": %d, \"nx\": %d, \"nu\": %d, \"N\": %d",
+               d.grid, d.defect, d.dynamics, d.stage_cost, d.final_cost, d.stage_ineq, d.final_ineq, d.final_eq, d.quad_first_interval, d.cost_nonlsq, d.cost_integral, d.nx, d.nu, d.N);
         auto arr = [](const char* name, const double* v, int n) {
             printf(", \"%s\": [", name);
             for (int i = 0; i < n; ++i) printf("%s%.17g", i ? ", " : "", v[i]);
@@ -185,10 +185,14 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     const bool tballc = (scenario == "unicycle_tballc");   // TerminalBallInheritFromCost: S = the final cost's Qf
     // the cost forms of the reference's IPOPT / QP callers (Hessian mode only; the device model is STATED: the recogniser derives
     // least-squares-form graphs): lsq_form = false, and QuadraticFormCost in integral form with the trapezoidal rule / the left sum
-    const bool plain = (scenario == "unicycle_plain"), itrap = (scenario == "unicycle_itrap"), ileft = (scenario == "unicycle_ileft");
+    // ("…_stated": the same with the device model stated through setDeviceModel instead of derived by the recogniser; "vdp_…": on the
+    // reference's own VanDerPolOscillator, recognisable without a device)
+    const bool stated = (scenario == "unicycle_plain_stated");
+    const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap"),
+               ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
     const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref");
-    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || hpath);
+    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
     {
         dyn  = std::make_shared<UnicycleRef>();
@@ -212,9 +216,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         xf[0] = 2; xf[1] = 1; xf[2] = 1;
         nu = 4;
     }
-    else if (scenario == "vdp" || scenario == "duffing" || scenario == "pendulum")
+    else if (scenario == "vdp" || scenario == "duffing" || scenario == "pendulum" || scenario == "vdp_plain" || scenario == "vdp_itrap")
     {
-        if (scenario == "vdp") { auto s = std::make_shared<VanDerPolOscillator>(); s->setDampingCoefficient(1.3); dyn = s; }
+        if (scenario.compare(0, 3, "vdp") == 0) { auto s = std::make_shared<VanDerPolOscillator>(); s->setDampingCoefficient(1.3); dyn = s; }
         else if (scenario == "duffing") { auto s = std::make_shared<DuffingOscillator>(); s->setParameters(0.7, 1.1, 0.9); dyn = s; }
         else { auto s = std::make_shared<SimplePendulum>(); s->setParameters(0.3, 0.5, 9.81, 0.02); dyn = s; }
         grid = std::make_shared<FiniteDifferencesGrid>();
@@ -302,9 +306,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         s->setIterations(10);
         s->setPenaltyWeights(w, w, w);
         if (mode == Mode::Hessian) s->setIterations(1);
-        if ((mode != Mode::HipAuto && mode != Mode::Hessian) || hpath)
+        if ((mode != Mode::HipAuto && mode != Mode::Hessian) || stated)
         {
-            if (hpath) { d.cost_nonlsq = 1; d.cost_integral = itrap ? 1 : ileft ? 2 : 0; }
+            if (stated) { d.cost_nonlsq = 1; d.cost_integral = 0; }
             s->setDeviceModel(d);
             s->setStateReference(xf);
         }
@@ -387,8 +391,8 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         const int nx = (int)x0.size();
         Eigen::VectorXd q = Eigen::VectorXd::LinSpaced(nx, 1.0, 0.3), rr = Eigen::VectorXd::LinSpaced(nu, 0.1, 0.2);
         Eigen::MatrixXd Q = q.asDiagonal(), R = rr.asDiagonal(), Qf = 7.0 * Q;
-        ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-        ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, itrap || ileft, !hpath));
+        ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setControlBounds(Eigen::VectorXd::Constant(nu, -1.5), Eigen::VectorXd::Constant(nu, 1.5));
         if (scenario == "pendulum") ocp.setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(xf));
     }
@@ -470,7 +474,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -491,7 +495,7 @@ int main(int argc, char** argv)
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

@@ -78,6 +78,18 @@ def test_the_rest_of_the_reference_benchmark_classes(described):
     assert (described["cartpole"]["nx"], described["par2"]["nu"]) == (4, 2)
 
 
+def test_plain_and_integral_cost_forms_are_recognised(described):
+    """The IPOPT-style configuration: QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false are plain objective edges, the
+    integral form one TrapezoidalIntegralCostEdge per interval.  Weights and reference are identified through the edges themselves: the
+    reference as the point where the term is exactly zero, plain weights exactly, integrand weights to an ulp (they come divided by dt)."""
+    p = described["vdp_plain"]
+    assert p["recognised"] == 1 and (p["cost_nonlsq"], p["cost_integral"], p["stage_cost"], p["final_cost"]) == (1, 0, capi.COST_QUADRATIC_LSQ, 1)
+    assert p["q_diag"] == [1.0, 0.3] and p["r_diag"] == [0.2] and p["qf_diag"] == [7.0, 7.0 * 0.3] and p["xref"] == [0.2, -0.1]
+    t = described["vdp_itrap"]
+    assert t["recognised"] == 1 and (t["cost_nonlsq"], t["cost_integral"]) == (1, 1) and t["xref"] == [0.2, -0.1]
+    assert np.allclose(t["q_diag"], [1.0, 0.3], rtol=4e-16, atol=0) and np.allclose(t["r_diag"], [0.2], rtol=4e-16, atol=0) and t["qf_diag"] == [7.0, 7.0 * 0.3]
+
+
 def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):
     f = described["unicycle_fullq"]
     assert f["recognised"] == 0 and "non-diagonal" in f["reason"]
