@@ -652,7 +652,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     {   // per interval: a state term and a control term (QuadraticFormCost(.., lsq_form = false)), or ONE integral cost edge
         // (integral_form = true: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt) / LeftSumCostEdge on (x_k, u_k, dt)); then the final cost
         Eigen::VectorXd q, r, qf, ref, rf, uz;
-        int ns = 0, nc = 0, nf = 0, ni = 0, integral = 0;
+        int ns = 0, nc = 0, nf = 0, ni = 0, ndt = 0, integral = 0;
         const double dtv = g.dt->getData()[0];
         for (const BaseEdge::Ptr& ep : es->getObjectiveEdges())
         {
@@ -686,7 +686,17 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             }
             if (e->getNumVertices() != 1) return fail(reason, "plain objective edge on more than one vertex that is not an integral cost edge");
             VertexInterface* v = e->getVertexRaw(0);
-            if (v == g.dt) return fail(reason, "minimum-time term in plain form: state the device model (setDeviceModel, cost_nonlsq)");
+            if (v == g.dt)
+            {   // MinimumTime(lsq_form = false): (N - 1) dt (minimum_time.h:60), created twice (nlp_functions.cpp:91-107)
+                VertexGuard gd(g.dt);
+                double* t = g.dt->getDataRaw();
+                t[0] = 0.0; const double a0 = evalEdge(*e)[0];
+                t[0] = 1.0; const double a1 = evalEdge(*e)[0];
+                t[0] = 2.0; const double a2 = evalEdge(*e)[0];
+                if (e->getDimension() != 1 || a0 != 0.0 || a1 != (double)(g.N - 1) || a2 != 2.0 * a1) return fail(reason, "plain dt term that is not (N - 1) dt");
+                ++ndt;
+                continue;
+            }
             if (!identifyDiagonalQuadratic(*e, {v}, 1.0, &w, &rr)) return fail(reason, "plain objective edge that is not a diagonal quadratic form around one reference");
             if (v == g.xf) { if (nf++ > 0) return fail(reason, "more than one plain term on x_f"); qf = w; rf = rr; }
             else if (indexOf(g.xs, v) >= 0)
@@ -702,10 +712,14 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             }
             else return fail(reason, "plain objective edge on an unexpected vertex");
         }
-        if (integral ? (ni != g.N - 1 || ns || nc) : (ns != g.N - 1 || nc != g.N - 1)) return fail(reason, "plain cost terms that are not one state and one control term (or one integral edge) per interval");
+        const bool quad = integral || ns || nc;
+        if (quad && (integral ? (ni != g.N - 1 || ns || nc) : (ns != g.N - 1 || nc != g.N - 1)))
+            return fail(reason, "plain cost terms that are not one state and one control term (or one integral edge) per interval");
+        if (ndt != 0 && (ndt != 2 || integral)) return fail(reason, "plain minimum-time term that was not created twice at k = 0, or next to an integral cost");
         d.cost_nonlsq = 1;
         d.cost_integral = integral;
-        d.stage_cost = CORBO_HIP_COST_QUADRATIC_LSQ;
+        d.stage_cost = ndt ? (quad ? CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ : CORBO_HIP_COST_MIN_TIME_LSQ) : (quad ? CORBO_HIP_COST_QUADRATIC_LSQ : CORBO_HIP_COST_NONE);
+        if (!quad) { q = Eigen::VectorXd::Zero(g.nx); r = Eigen::VectorXd::Zero(g.nu); ref = nf ? rf : Eigen::VectorXd::Zero(g.nx); }
         for (int i = 0; i < g.nx; ++i) d.q_diag[i] = q[i];
         for (int i = 0; i < g.nu; ++i) d.r_diag[i] = r[i];
         d.final_cost = nf ? 1 : 0;

@@ -381,9 +381,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         else ocp.setStageCost(std::make_shared<MinTimeQuadraticStates>(Q, false, true));
         ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
-    else if (scenario == "dint" || scenario == "dint_ms")
+    else if (scenario == "dint" || scenario == "dint_ms" || scenario == "dint_plain")
     {
-        ocp.setStageCost(std::make_shared<MinimumTime>(true));
+        ocp.setStageCost(std::make_shared<MinimumTime>(scenario != "dint_plain"));   // dint_plain: (N - 1) dt as a plain objective edge (Hessian mode)
         ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else
@@ -416,7 +416,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     r.traj = trajectory(ocp, *any_grid);
     r.chi2 = ocp.getCurrentObjectiveValue();
     if (describe_out) *describe_out = *std::static_pointer_cast<RecogniseOnly>(solver);
-    if (mode == Mode::Hessian && hpath) r.ok = true;   // compute() returned false: neither solver takes a problem that is not least squares; the graph is built
+    if (mode == Mode::Hessian && (hpath || scenario == "dint_plain")) r.ok = true;   // compute() returned false: neither solver takes a problem that is not least squares; the graph is built
     if (mode == Mode::Hessian && r.ok)
     {
         // computeSparseHessians{NNZ,Structure,Values} as IpoptWrapper::eval_h calls them (lower part, per-row multipliers), at a generic
@@ -474,7 +474,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -495,7 +495,7 @@ int main(int argc, char** argv)
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

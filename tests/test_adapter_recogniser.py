@@ -85,6 +85,8 @@ def test_plain_and_integral_cost_forms_are_recognised(described):
     p = described["vdp_plain"]
     assert p["recognised"] == 1 and (p["cost_nonlsq"], p["cost_integral"], p["stage_cost"], p["final_cost"]) == (1, 0, capi.COST_QUADRATIC_LSQ, 1)
     assert p["q_diag"] == [1.0, 0.3] and p["r_diag"] == [0.2] and p["qf_diag"] == [7.0, 7.0 * 0.3] and p["xref"] == [0.2, -0.1]
+    m = described["dint_plain"]                          # MinimumTime(lsq_form = false): (N - 1) dt, created twice
+    assert m["recognised"] == 1 and (m["cost_nonlsq"], m["stage_cost"], m["grid"]) == (1, capi.COST_MIN_TIME_LSQ, capi.GRID_FD_VARIABLE)
     t = described["vdp_itrap"]
     assert t["recognised"] == 1 and (t["cost_nonlsq"], t["cost_integral"]) == (1, 1) and t["xref"] == [0.2, -0.1]
     assert np.allclose(t["q_diag"], [1.0, 0.3], rtol=4e-16, atol=0) and np.allclose(t["r_diag"], [0.2], rtol=4e-16, atol=0) and t["qf_diag"] == [7.0, 7.0 * 0.3]

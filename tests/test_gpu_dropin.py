@@ -44,7 +44,7 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # reference's own consecutive-call spread (tests/test_gpu_hessian.py)
     assert [r["scenario"] for r in hessian] == ["unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy",
                                                "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft",
-                                               "unicycle_plain_stated", "vdp_plain", "vdp_itrap"], p.stdout   # (the last six: graphs with plain / integral
+                                               "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"], p.stdout   # (the last seven: graphs with plain / integral
     # objective edges, the IPOPT-style cost forms -- recognised, one of them with a stated model)
     for r in hessian:
         assert r["ok_hip"] == 1 and r["structure_equal"] == 1 and r["nnz"][1] > 0 and r["max_rel_diff"] <= 2e-4, r
