@@ -152,6 +152,8 @@ struct corbo_hip_solver {
     int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
     int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
     bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")
+    int stagger = 0;               // corbo_hip_set_option("stagger")
+    int lag_priority = 1;          // corbo_hip_set_option("lag_priority")
     bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
     // the 8 model parameters as the kernels see them: the descriptor's, except for the linear state-space model, whose first slot
@@ -364,7 +366,8 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
         h->num_cus = prop.multiProcessorCount;
     }
-    CREATE_TRY(hipMalloc((void**)&h->d_queue, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void**)&h->d_queue, (size_t)(16 + 2048 * 16) * sizeof(int32_t)));   // [0] ticket counter, [16..] per-CU progress table
+    CREATE_TRY(hipMemset(h->d_queue, 0, (size_t)(16 + 2048 * 16) * sizeof(int32_t)));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * corbo_hip_solver::MAX_SUB * sizeof(int32_t)));
     CREATE_TRY(hipMemset(h->d_state, 0, B * sizeof(LmState)));
@@ -586,6 +589,8 @@ try {
             fp.batch = sp.batch = count_of[i];
             fp.inst0 = sp.inst0 = first_of[i];
             fp.loop_passes = MAX_PASSES;
+            fp.stagger = h->stagger;
+            if (h->lag_priority && !(count_of[i] > 4 * h->num_cus)) fp.cu_table = h->d_queue + 16;
             if (h->result_sink) { fp.x_host = h->h_stage; fp.st_host = h->h_state; }
             if (count_of[i] > 4 * h->num_cus) {   // more instances than resident workgroups: instance queue
                 HIP_TRY(hipMemsetAsync(h->d_queue, 0, sizeof(int32_t), st_of[i]));
@@ -610,6 +615,7 @@ try {
                     fprintf(stderr, "pass timeline (sweep/factor cycles):");
                     for (int k = 0; k < 64 && tl[2 * k]; ++k) fprintf(stderr, " %lld/%lld", tl[2 * k + 1] ? tl[2 * k + 1] - tl[2 * k] : -1, (k < 63 && tl[2 * k + 2]) ? tl[2 * k + 2] - tl[2 * k + 1] : 0);
                     fprintf(stderr, "\n");
+                    if (tl[65] || tl[66]) { fprintf(stderr, "issue priority per pass (+10*slot):"); for (int k = 1; k < 32 && tl[2 * k]; ++k) fprintf(stderr, " %lld", tl[64 + k]); fprintf(stderr, "\n"); }
                     const long long* f = tl + 130;
                     if (f[7]) fprintf(stderr, "factor phases, last pass (cycles): load %lld | controls %lld | blocks + level 0 %lld | cyclic reduction %lld | root %lld | back-substitution %lld | trial iterate %lld\n",
                                       f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5], f[7] - f[6]); }
@@ -1086,6 +1092,8 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "pass_timeline") h->pass_timeline_inst = value;
     else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
     else if (n == "chain_variant") h->chain_variant = value;
+    else if (n == "stagger") h->stagger = value;
+    else if (n == "lag_priority") h->lag_priority = value;
     else return fail(CORBO_HIP_ERR_INVALID, "unknown option: " + n);
     return CORBO_HIP_OK;
 }

@@ -2735,6 +2735,17 @@ __global__ __launch_bounds__(256) void big_chain2_kernel(const FactorParams p)
 // the slow instances of the tail run at single-instance latency (0.81 ms instead of 1.09 ms per headline solve).  The loop needs
 // two precautions against the compiler carrying state around it: the kernel arguments are re-read from the kernarg segment each
 // pass, and the library is built with -disable-machine-licm (hoisted math-library constants were spilled to scratch otherwise).
+// row of this wave's CU in the per-CU progress table: [0] workgroups present, [1..8] their outer iteration + 1 (0 = empty slot)
+__device__ __forceinline__ int32_t* cu_row_of(int32_t* table)
+{
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // HW_ID (gfx9): cu_id[11:8] sh_id[12] se_id[15:13]
+    const unsigned idx = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);
+    return table + (size_t)idx * 16;
+}
+
 template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, bool QUEUE = false>
 __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
@@ -2781,6 +2792,18 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
         typedef const __attribute__((address_space(4))) Args* ArgsPtr;
         ArgsPtr ka = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
         int tid_v = tid;
+        if (fp.stagger == -1 || (fp.cu_table && fp.batch <= 1024)) {   // before the first table-based priority: by dispatch generation, youngest first (age favours the oldest)
+            switch (blockIdx.x >> 8) {
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+            }
+        }
+        if (fp.stagger > 0) {   // diagnostics: phase-shift the workgroups that share a CU
+            const long long t0 = clock64(), d = (long long)(blockIdx.x >> 8) * fp.stagger;
+            while (clock64() - t0 < d) __builtin_amdgcn_s_sleep(16);
+        }
 #pragma nounroll
         for (;;) {
             if constexpr (QUEUE) {
@@ -2798,7 +2821,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
                 const FactorParams& fq = (const FactorParams&)ka->f;
                 lm_state_in(sl, fq.st + inst_v, tid_v);
             }
-            if (tid_v == 0) flags[0] = 0;
+            if (tid_v == 0) { flags[0] = 0; flags[3] = -1; }
             __syncthreads();
             int mode = ((const SweepParams&)ka->s).mode;
             const int max_passes = ((const FactorParams&)ka->f).loop_passes;
@@ -2812,12 +2835,43 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
                 if (pass > 0) {
                     if (tid_v == 0) flags[0] = 0;
                     __syncthreads();
+                    if (fpl.cu_table) {
+                        if (stamp && pass < 32) fpl.pass_timeline[64 + pass] = flags[2] + 10 * flags[3];   // (diagnostics: valid for < 32 passes)
+                        switch (__builtin_amdgcn_readfirstlane(flags[2])) {
+                            case 3: __builtin_amdgcn_s_setprio(3); break;
+                            case 2: __builtin_amdgcn_s_setprio(2); break;
+                            case 1: __builtin_amdgcn_s_setprio(1); break;
+                            default: __builtin_amdgcn_s_setprio(0); break;
+                        }
+                    }
                 }
                 sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);
                 __threadfence_block();
                 __syncthreads();
                 if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
                 if (sl->done) break;
+                if (fpl.cu_table) {
+                    // lag-based issue priority: the SIMD arbiter prefers older waves, so the workgroups dispatched last to a CU run every
+                    // pass ~40 % slower than the first ones while the CU is full -- and the launch ends with the slowest chain.  Every
+                    // workgroup publishes its outer iteration in a per-CU row; the one that is furthest behind gets the highest user
+                    // priority (s_setprio beats age).  A spare lane of wave 2 does the bookkeeping during the factor phase, the waves pick
+                    // the new priority up at the start of the next pass.
+                    if (tid_v == 128) {
+                        int32_t* row = cu_row_of(fpl.cu_table);
+                        int slot = flags[3];
+                        if (slot < 0) { slot = atomicAdd(row, 1) & 7; flags[3] = slot; }
+                        const int myk = sl->k;
+                        __hip_atomic_store(row + 1 + slot, myk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int rank = 0;
+                        const int rot = (slot > 3 || __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) ? 7 : 3;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int kq = __hip_atomic_load(row + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;   // -1: empty slot
+                            if (q != slot && kq >= 0 && (kq < myk || (kq == myk && ((pass - q) & rot) < ((pass - slot) & rot)))) ++rank;   // ties: rotating order (the arbiter's own tie-break is age)
+                        }
+                        flags[2] = rank > 3 ? 0 : 3 - rank;
+                    }
+                }
                 factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, xs);
                 __threadfence_block();
                 __syncthreads();
@@ -2825,6 +2879,11 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
             }
             asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");
             const FactorParams& fe = (const FactorParams&)ka->f;
+            if (fe.cu_table && tid_v == 128 && flags[3] >= 0) {   // leave the CU's progress row (the table is all zeros again when the launch retires)
+                int32_t* row = cu_row_of(fe.cu_table);
+                __hip_atomic_store(row + 1 + flags[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicSub(row, 1);
+            }
             lm_state_out(fe.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM
             if (fe.x_host) {
                 // result sink: the finished instance's accepted iterate and LM state go straight to host-visible memory (posted PCIe
