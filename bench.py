@@ -195,6 +195,73 @@ def load_profile_json(name, batch, N):
     return None
 
 
+def secondary_leg(cfg, iterations, device):
+    """One BASELINE configuration other than the headline, measured in the same process (rank 0 of a 1-GPU run): ms per step,
+    SQP-iterations/s, the chi2 sum of the timed workload next to the genuine reference's (tests/golden/bench_secondary.json,
+    oracle/gen_golden.py secondary) and the roofline fraction of its dominant kernel(s).  No CPU baseline in this leg."""
+    import torch
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    B = DEFAULT_BATCH[cfg]
+    w = workload(cfg, B)
+    desc, solves = w["desc"], w["solves"]
+    solver = BatchedLevenbergMarquardt(desc, B, device=device)
+    solver.setIterations(iterations)
+    solver.setPenaltyWeights(*w["weights"])
+    X0 = solver.init_trajectory(w["x0"], w["xf"])
+    solver.set_instance_data(X0, xref=w["xf"])
+    solver.set_result_sink(True)
+    steps, warmup = {1: 200, 2: 100, 5: 10}[cfg], {1: 20, 2: 10, 5: 2}[cfg]
+
+    def step():
+        solver.restore_instance_data()
+        for i in range(solves):
+            solver.solve(new_run=(i == 0))
+        return solver.fetch_solution()
+
+    for _ in range(warmup):
+        step()
+    solver.synchronize(); torch.cuda.synchronize()
+    solver.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    solver.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    solve_ms_sum, n_solves = solver.get_timing(reset=True)
+    stats = solver.get_stats()
+    _, chi2, status = solver.get_solution()
+    iters_per_step = B * iterations * solves
+    out = {"workload": f"{w['name']}, batch={B}, {solves} solve(s) x {iterations} LM iterations per step", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "value": iters_per_step * steps / dt, "unit": "SQP-iterations/s",
+           "chi2_sum": float(chi2.sum()), "ok_instances": int((status <= 1).sum()), "ms_per_solve_launch": solve_ms_sum / max(1, n_solves)}
+    gpath = os.path.join(ROOT, "tests", "golden", "bench_secondary.json")
+    if os.path.exists(gpath) and iterations == 10:
+        g = json.load(open(gpath)).get(f"cfg{cfg}")
+        if g and g["batch"] == B and g["N"] == desc.N:
+            out["chi2_sum_reference"] = g["chi2_sum"]
+            out["chi2_sum_rel_diff"] = abs(out["chi2_sum"] - g["chi2_sum"]) / abs(g["chi2_sum"])
+    dims = solver.dims
+    if cfg != 5:
+        b_sweep = 8 * (dims.nv + 2 * dims.n + dims.m + dims.nnz)
+        b_val = 8 * (dims.nv + 2 * dims.n + dims.m)
+        alg = stats["jacobian_sweeps"] * b_sweep + max(0, stats["residual_sweeps"] - stats["jacobian_sweeps"]) * b_val
+        ms = out["ms_per_solve_launch"]
+        out["roofline"] = {"bound": "hbm", "kernel": "lm_pass_kernel", "bytes_per_launch": alg, "ms_per_launch": ms,
+                           "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                           "note": "one OCP = one workgroup: a single-instance latency chain, not a bandwidth figure"}
+    else:
+        nxq, nuq = desc.nx, desc.nu
+        rec = 3 * nxq * nxq + nuq * nuq + 2 * nuq * nxq + 2 * nxq + nuq + 2
+        per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
+        f_ms = solver.time_factor(repeat=5)
+        alg = per_stage * desc.N * B
+        out["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance)", "bytes_per_launch": alg,
+                           "ms_per_launch": f_ms, "achieved": alg / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": alg / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    del solver
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +272,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=10, help="LM outer iterations per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sink", action="store_true", help="results via D2H copies after the solve instead of the kernel-written pinned sink")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the legs over BASELINE configs 1, 2, 5 in the default (config 3, 1 GPU) line")
     ap.add_argument("--solve-only", action="store_true", help="profiling: only warm-up + timed steps (no roofline / host legs)")
     args = ap.parse_args()
     cfg = args.config
@@ -432,6 +500,14 @@ def main():
     host_ms = (time.perf_counter() - t_h) / n_h * 1e3
     line["host_inclusive"] = {"ms_per_step": host_ms, "value_rank0": B * args.iterations * solves / (host_ms * 1e-3),
                               "what": "set_instance_data (H2D of x, xref from pageable host memory) + solve(s) + get_solution (D2H into caller arrays), rank 0"}
+    if rank == 0 and world == 1 and cfg == 3 and not args.no_secondary:
+        # every other BASELINE configuration, driver-visible in the same line (a few hundred ms of GPU time each)
+        line["secondary"] = {}
+        for c2 in (1, 2, 5):
+            try:
+                line["secondary"][f"config{c2}"] = secondary_leg(c2, args.iterations, local_rank)
+            except Exception as e:   # a failing leg must not take the headline line with it
+                line["secondary"][f"config{c2}"] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, w, solver.opts)

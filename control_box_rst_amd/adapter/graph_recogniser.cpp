@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <memory>
+#include <algorithm>
 #include <cstring>
 #include <sstream>
 #include <vector>
@@ -161,6 +162,105 @@ bool identifyDiagonalAffine(BaseEdge& e, VertexInterface* v, Eigen::VectorXd* w,
         if (evalEdge(e)[i] != (*w)[i] * (x0 - (*ref)[i])) return false;
     }
     return true;
+}
+
+// U * xd the way the reference evaluates `cost.noalias() = _Q_sqrt * xd` (Eigen's column-major gemv into a zeroed destination: one running
+// sum per row over the columns, a full block of four columns added pairwise) -- what the device and the oracle restate
+Eigen::VectorXd upperTimes(const Eigen::MatrixXd& U, const Eigen::VectorXd& xd)
+{
+    const int n = (int)U.rows();
+    Eigen::VectorXd out(n);
+    for (int i = 0; i < n; ++i)
+    {
+        if (n == 4) { out[i] = 0.0 + ((U(i, 0) * xd[0] + U(i, 1) * xd[1]) + (U(i, 2) * xd[2] + U(i, 3) * xd[3])); continue; }
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += U(i, j) * xd[j];
+        out[i] = acc;
+    }
+    return out;
+}
+
+// A least-squares term with a NON-DIAGONAL weight,  r = U (x - ref)  with U the upper Cholesky factor the reference keeps
+// (quadratic_cost.cpp:36-55, 116-118; final_state_cost.cpp:38-58, 88-90), identified EXACTLY through the edge's own evaluation: the
+// references bottom-up (with x_j = ref_j for j > i row i is U_ii (x_i - ref_i) plus exact zeros: its root is ref_i), then column j of U
+// from x = ref + d e_j with d a power of two for which (ref_j + d) - ref_j == d.  false: not such a term (lower-triangular responses,
+// a singular diagonal, or the model does not reproduce the edge at the original point bit for bit).
+bool identifyUpperAffine(BaseEdge& e, VertexInterface* v, Eigen::MatrixXd* U, Eigen::VectorXd* ref)
+{
+    const int n = v->getDimension();
+    if (e.getDimension() != n || n > 4) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    const std::vector<double> x0(x, x + n);
+    const Eigen::VectorXd r0 = evalEdge(e);
+    for (int j = 0; j < n; ++j)
+    {   // structure: x_j moves rows 0 .. j only
+        x[j] = x0[j] + 1.0;
+        const Eigen::VectorXd r1 = evalEdge(e);
+        x[j] = x0[j];
+        for (int i = j + 1; i < n; ++i)
+            if (r1[i] != r0[i]) return false;
+        if (r1[j] == r0[j] || !std::isfinite(r1[j])) return false;   // a Cholesky factor has a positive diagonal
+    }
+    ref->resize(n);
+    for (int i = n - 1; i >= 0; --i)
+    {
+        x[i] = x0[i];
+        const double a0 = evalEdge(e)[i];
+        x[i] = x0[i] + 1.0;
+        const double wi = evalEdge(e)[i] - a0;
+        double xr = x0[i] - a0 / wi;
+        bool found = false;
+        x[i] = 0.0;   // terms without a reference (controls): the root is zero itself
+        if (evalEdge(e)[i] == 0.0) { xr = 0.0; found = true; }
+        for (int it = 0; it < 8 && !found; ++it)
+        {
+            x[i] = xr;
+            const double r = evalEdge(e)[i];
+            if (r == 0.0) { found = true; break; }
+            const double step = r / wi;
+            double xn = xr - step;
+            if (xn == xr) xn = std::nextafter(xr, (step > 0) ? -INFINITY : INFINITY);
+            xr = xn;
+        }
+        if (!found) return false;
+        (*ref)[i] = xr;
+        x[i]      = xr;   // rows above see an exact zero difference from here on
+    }
+    *U = Eigen::MatrixXd::Zero(n, n);
+    for (int j = 0; j < n; ++j)
+    {
+        const double xr = (*ref)[j];
+        double d = std::ldexp(1.0, std::max(-20, std::min(20, (xr == 0.0) ? 0 : std::ilogb(xr))));
+        bool ok = false;
+        for (int t = 0; t < 40 && !ok; ++t, d *= 2.0)
+        {
+            volatile double xp = xr + d;
+            if ((double)xp - xr == d)
+            {
+                x[j] = xp;
+                const Eigen::VectorXd r = evalEdge(e);
+                for (int i = 0; i <= j; ++i) (*U)(i, j) = r[i] / d;
+                for (int i = j + 1; i < n; ++i)
+                    if (r[i] != 0.0) return false;
+                ok = true;
+            }
+        }
+        x[j] = xr;
+        if (!ok) return false;
+    }
+    // the model reproduces the edge at the original point bit for bit
+    Eigen::VectorXd xd(n);
+    for (int i = 0; i < n; ++i) { x[i] = x0[i]; xd[i] = x0[i] - (*ref)[i]; }
+    const Eigen::VectorXd r = evalEdge(e), m = upperTimes(*U, xd);
+    for (int i = 0; i < n; ++i)
+        if (r[i] != m[i]) return false;
+    return true;
+}
+
+bool sameMatrix(const Eigen::MatrixXd& a, const Eigen::MatrixXd& b)
+{
+    return a.rows() == b.rows() && a.cols() == b.cols() && (a.array() == b.array()).all();
 }
 
 bool sameVector(const Eigen::VectorXd& a, const Eigen::VectorXd& b)
@@ -549,6 +649,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
 
     // ---- least-squares objective edges, in the grid's creation order (nlp_functions.cpp:70-132, finite_differences_grid.cpp:38-154)
     Eigen::VectorXd sq, sr, sqf, xref_state, xref_final;
+    Eigen::MatrixXd Uq, Ur, Uqf;   // upper Cholesky factors of non-diagonal weights (empty: diagonal)
     std::vector<Eigen::VectorXd> stage_refs(g.N - 1);   // reference of the state cost term of every interval (getReferenceCached(k))
     bool refs_vary = false;
     int n_state = 0, n_ctrl = 0, n_final = 0, n_dt = 0;
@@ -569,27 +670,33 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             ++n_dt;
             continue;
         }
+        Eigen::MatrixXd Ud;   // non-empty: the term has a non-diagonal weight, r = U (v - ref)
         if (!identifyDiagonalAffine(*e, v, &w, &ref))
-            return fail(reason, "a least-squares term is not of the form sqrt(W_diag) (v - ref) (non-diagonal weight matrix?)");
+        {
+            if (g.nx > 4 || g.nu > 4 || !identifyUpperAffine(*e, v, &Ud, &ref))
+                return fail(reason, "a least-squares term is neither sqrt(W_diag) (v - ref) nor U (v - ref) with an upper Cholesky factor U (nx <= 4; with a ZERO "
+                                    "reference the reference's non-diagonal branch assigns a scalar to the vector, quadratic_cost.cpp:108-111 -- nothing to reproduce)");
+            w = Ud.diagonal();
+        }
         if (v == g.xf)
         {
             if (n_final++ > 0) return fail(reason, "more than one least-squares term on x_f");
-            sqf = w; xref_final = ref;
+            sqf = w; xref_final = ref; Uqf = Ud;
         }
         else if (indexOf(g.xs, v) >= 0)
         {
             stage_refs[indexOf(g.xs, v)] = ref;
             k_first_state = std::min(k_first_state, indexOf(g.xs, v));
-            if (n_state++ == 0) { sq = w; xref_state = ref; }
-            else if (!sameVector(w, sq)) return fail(reason, "state cost weights vary along the horizon");
+            if (n_state++ == 0) { sq = w; xref_state = ref; Uq = Ud; }
+            else if (!sameVector(w, sq) || !sameMatrix(Ud, Uq)) return fail(reason, "state cost weights vary along the horizon");
             else if (!sameVector(ref, xref_state)) refs_vary = true;   // a time-varying reference trajectory
         }
         else if (indexOf(g.us, v) >= 0)
         {
             if ((ref.array() != 0.0).any()) return fail(reason, "non-zero control reference");
             k_first_ctrl = std::min(k_first_ctrl, indexOf(g.us, v));
-            if (n_ctrl++ == 0) sr = w;
-            else if (!sameVector(w, sr)) return fail(reason, "control cost weights vary along the horizon");
+            if (n_ctrl++ == 0) { sr = w; Ur = Ud; }
+            else if (!sameVector(w, sr) || !sameMatrix(Ud, Ur)) return fail(reason, "control cost weights vary along the horizon");
         }
         else return fail(reason, "least-squares term on an unexpected vertex");
     }
@@ -644,9 +751,15 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     // The device takes the weights as Q / R / Qf diagonals and forms sqrt() itself (structure.cpp): the round trip sqrt(w * w) == w
     // must hold for the identified sqrt-weights, otherwise the residual rows would differ in the last bit
     for (int i = 0; i < g.nx; ++i)
-        if ((n_state && std::sqrt(d.q_diag[i]) != sq[i]) || (n_final && std::sqrt(d.qf_diag[i]) != sqf[i])) return fail(reason, "state weight does not survive the square / square-root round trip");
+        if ((n_state && !Uq.size() && std::sqrt(d.q_diag[i]) != sq[i]) || (n_final && !Uqf.size() && std::sqrt(d.qf_diag[i]) != sqf[i]))
+            return fail(reason, "state weight does not survive the square / square-root round trip");
     for (int i = 0; i < g.nu; ++i)
-        if (n_ctrl && std::sqrt(d.r_diag[i]) != sr[i]) return fail(reason, "control weight does not survive the square / square-root round trip");
+        if (n_ctrl && !Ur.size() && std::sqrt(d.r_diag[i]) != sr[i]) return fail(reason, "control weight does not survive the square / square-root round trip");
+    // non-diagonal weights travel as the factors themselves (corbo_hip_problem_desc::weights_dense)
+    if (Uq.size()) { d.weights_dense |= 1; for (int i = 0; i < g.nx; ++i) for (int j = 0; j < g.nx; ++j) d.q_sqrt[i * g.nx + j] = Uq(i, j); }
+    if (Ur.size()) { d.weights_dense |= 2; for (int i = 0; i < g.nu; ++i) for (int j = 0; j < g.nu; ++j) d.r_sqrt[i * g.nu + j] = Ur(i, j); }
+    if (Uqf.size()) { d.weights_dense |= 4; for (int i = 0; i < g.nx; ++i) for (int j = 0; j < g.nx; ++j) d.qf_sqrt[i * g.nx + j] = Uqf(i, j); }
+    if (d.weights_dense && plain_costs) return fail(reason, "non-diagonal weights next to plain objective edges");
 
     if (plain_costs)
     {   // per interval: a state term and a control term (QuadraticFormCost(.., lsq_form = false)), or ONE integral cost edge
@@ -773,7 +886,9 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     if (refs_vary)
     {   // rows 0 .. N-2: the stage references, row N-1: the reference of the final-stage terms
         model->xref_traj.resize(g.N, g.nx);
-        for (int k = 0; k < g.N - 1; ++k) model->xref_traj.row(k) = stage_refs[k].transpose();
+        // (MinTimeQuadratic::only_last_n: the intervals before quad_first_interval carry no state term and no reference -- their rows are never
+        //  read by a cost row; they get the first identified one)
+        for (int k = 0; k < g.N - 1; ++k) model->xref_traj.row(k) = stage_refs[std::max(k, (int)d.quad_first_interval)].transpose();
         model->xref_traj.row(g.N - 1) = model->xref.transpose();
     }
     // ---- the dynamics object last (user systems are matched on the device)

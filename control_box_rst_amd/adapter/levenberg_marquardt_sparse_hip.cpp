@@ -211,7 +211,7 @@ bool LevenbergMarquardtSparseHip::uploadVertices(const std::vector<VertexInterfa
 }
 
 // Everything between "here is a hypergraph" and "its vertex values are on the device": recognise (new structure), describe, verify, upload.
-bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, bool new_structure)
+bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, bool new_structure, bool new_run)
 {
     auto* hg = dynamic_cast<BaseHyperGraphOptimizationProblem*>(&problem);
     if (!hg || !hg->getGraph().hasVertexSet())
@@ -235,6 +235,29 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     // a fixed dt that changed without a structure change (setDtRef between runs) is a new problem for the device
     const bool dt_changed = _handle && !(_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE) && dt_v->getData()[0] != _desc.dt_ref;
     bool verify_now = false;
+    // Same structure, new run: the reference's cost / constraint objects may have been given another reference, other weights or other
+    // parameters WITHOUT a structure change (QuadraticFormCost::update returns false, setpoints move between runs).  The model
+    // is derived again from the graph and compared with the resident one: only-the-references-moved keeps the handle, anything else
+    // rebuilds it like a new structure.  (_tracking = false: the caller vouches that nothing but the vertex values changes, like setDeviceModel.)
+    bool model_changed = false;
+    if (!(new_structure || !_handle || _desc.N != N || dt_changed) && _recognised && new_run && _tracking)
+    {
+        HipRecognisedModel m;
+        std::string why;
+        if (!recogniseHyperGraphForHip(*hg, &m, &why))
+        {
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): this hypergraph has no device description any more: " << why << "; refusing to solve (no CPU fallback).");
+            return false;
+        }
+        corbo_hip_problem_desc cmp = m.desc;   // the fields the adapter reads from the vertices are not the recogniser's
+        cmp.N = _desc.N; cmp.xf_fixed_mask = _desc.xf_fixed_mask; cmp.dt_ref = _desc.dt_ref; cmp.dt_lb = _desc.dt_lb; cmp.dt_ub = _desc.dt_ub;
+        std::memcpy(cmp.x_lb, _desc.x_lb, sizeof(cmp.x_lb)); std::memcpy(cmp.x_ub, _desc.x_ub, sizeof(cmp.x_ub));
+        std::memcpy(cmp.u_lb, _desc.u_lb, sizeof(cmp.u_lb)); std::memcpy(cmp.u_ub, _desc.u_ub, sizeof(cmp.u_ub));
+        model_changed = std::memcmp(&cmp, &_desc, sizeof(cmp)) != 0;
+        if (model_changed) _desc = m.desc;
+        _xref      = m.xref;
+        _xref_traj = m.xref_traj;
+    }
     if (new_structure || !_handle || _desc.N != N || dt_changed)
     {
         verify_now = _verify;
@@ -262,7 +285,8 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     xs.assign(N - 1, nullptr); us.assign(N - 1, nullptr);
     for (int k = 0; k < N - 1; ++k) { xs[k] = interleaved ? vtx[2 * k] : vtx[k]; us[k] = interleaved ? vtx[2 * k + 1] : vtx[N - 1 + k]; }
 
-    if (new_structure || !_handle || _desc.N != N || dt_changed)
+    if (model_changed) verify_now = _verify;
+    if (new_structure || !_handle || _desc.N != N || dt_changed || model_changed)
     {
         // describe the structure, then verify it against what the graph reports
         for (int k = 0; k < N - 1; ++k)
@@ -312,21 +336,6 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
         _lb.assign(_dims.nv, 0.0);
         _ub.assign(_dims.nv, 0.0);
     }
-    else if (_recognised)
-    {   // same structure, possibly a new reference (new_run with another xref): re-read it from the cost edges
-        // (every grid point's: a static reference may have become a time-varying one)
-        Eigen::MatrixXd tr(N, nx);
-        tr.row(N - 1) = _xref.transpose();
-        Eigen::VectorXd xr;
-        if (readStateReferenceTrajectoryForHip(*hg, nx, &tr))
-        {
-            bool vary = false;
-            for (int k = 1; k < N - 1 && !vary; ++k) vary = (tr.row(k) != tr.row(0));
-            if (vary) { _xref_traj = tr; _xref = tr.row(N - 1).transpose(); }
-            else { _xref_traj.resize(0, 0); if (readStateReferenceForHip(*hg, nx, &xr)) _xref = xr; }
-        }
-        else if (readStateReferenceForHip(*hg, nx, &xr)) { _xref_traj.resize(0, 0); _xref = xr; }
-    }
     const bool dt_free = ((_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE));
 
     if (verify_now)
@@ -369,7 +378,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
         _w_ineq *= _opts.adapt_factor_ineq;   if (_w_ineq > _opts.adapt_max_ineq) _w_ineq = _opts.adapt_max_ineq;
         _w_b *= _opts.adapt_factor_bounds;    if (_w_b > _opts.adapt_max_bounds) _w_b = _opts.adapt_max_bounds;
     }
-    if (!attach(problem, new_structure)) return SolverStatus::Error;
+    if (!attach(problem, new_structure, new_run)) return SolverStatus::Error;
 
     corbo_hip_lm_opts o = _opts;   // the weights of THIS solve, stated explicitly (new_run = 1 makes the library take them as they are)
     o.weight_eq = _w_eq; o.weight_ineq = _w_ineq; o.weight_bounds = _w_b;
@@ -414,7 +423,7 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
 //      (optimization_problem_interface.h) with the problem as the first argument
 bool LevenbergMarquardtSparseHip::computeSparseHessiansNNZ(OptimizationProblemInterface& problem, int& nnz_obj, int& nnz_eq, int& nnz_ineq, bool lower_part_only)
 {
-    if (!attach(problem, _handle == nullptr)) return false;
+    if (!attach(problem, _handle == nullptr, true)) return false;
     int32_t nnz[3];
     if (corbo_hip_hessian_nnz(&_desc, lower_part_only ? 1 : 0, nnz) != CORBO_HIP_OK) { PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error()); return false; }
     nnz_obj = nnz[0]; nnz_eq = nnz[1]; nnz_ineq = nnz[2];
@@ -426,7 +435,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationPro
                                                                  Eigen::Ref<Eigen::VectorXi> j_col_eq, Eigen::Ref<Eigen::VectorXi> i_row_ineq,
                                                                  Eigen::Ref<Eigen::VectorXi> j_col_ineq, bool lower_part_only)
 {
-    if (!attach(problem, _handle == nullptr)) return false;
+    if (!attach(problem, _handle == nullptr, true)) return false;
     static_assert(sizeof(int) == sizeof(int32_t), "Eigen::VectorXi is handed to the C-ABI as int32_t");
     if (corbo_hip_hessian_structure(&_desc, lower_part_only ? 1 : 0, i_row_obj.data(), j_col_obj.data(), i_row_eq.data(), j_col_eq.data(), i_row_ineq.data(),
                                     j_col_ineq.data()) != CORBO_HIP_OK)
@@ -439,7 +448,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationPro
 
 bool LevenbergMarquardtSparseHip::computeGradientObjective(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> gradient, double* obj_value)
 {
-    if (!attach(problem, _handle == nullptr)) return false;
+    if (!attach(problem, _handle == nullptr, true)) return false;
     if (gradient.size() != _dims.n) { PRINT_ERROR("LevenbergMarquardtSparseHip(): gradient vector of the wrong size."); return false; }
     if (corbo_hip_eval_objective_gradient(_handle, gradient.data(), obj_value) != CORBO_HIP_OK)
     {
@@ -453,7 +462,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansValues(OptimizationProble
                                                               Eigen::Ref<Eigen::VectorXd> values_eq, Eigen::Ref<Eigen::VectorXd> values_ineq, double multiplier_obj,
                                                               const double* multipliers_eq, const double* multipliers_ineq, bool lower_part_only)
 {
-    if (!attach(problem, _handle == nullptr)) return false;   // uploads the current vertex values
+    if (!attach(problem, _handle == nullptr, true)) return false;   // uploads the current vertex values
     if (corbo_hip_eval_hessians(_handle, lower_part_only ? 1 : 0, multiplier_obj, multipliers_eq, multipliers_ineq, values_obj.data(), values_eq.data(),
                                 values_ineq.data()) != CORBO_HIP_OK)
     {

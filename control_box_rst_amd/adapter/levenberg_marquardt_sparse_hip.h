@@ -45,8 +45,8 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
 
     // ---- By default NOTHING else has to be called: on every new structure the device model (grid kind, collocation scheme /
     //      integrator, dynamics and its parameters, cost weights, reference, constraints) is derived from the hypergraph itself
-    //      (graph_recogniser.h), dimensions / vertex values / bounds / fixed flags / dt are read from the vertices, and the state
-    //      reference is re-read from the cost edges on every solve.  A graph the device cannot describe makes solve() return
+    //      (graph_recogniser.h), dimensions / vertex values / bounds / fixed flags / dt are read from the vertices, and on every new run
+    //      the model (references, weights, parameters) is derived again and compared with the resident one (setTrackModel).  A graph the device cannot describe makes solve() return
     //      SolverStatus::Error with the reason on stderr.
     //      setDeviceModel() is the override for system dynamics the recogniser cannot know (user classes other than the device
     //      library's plug-in models): the caller states the model; setStateReference() then states the reference.
@@ -60,6 +60,11 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     // describe what the graph's edges compute is refused instead of silently solving a different problem.  On by default; costs two
     // host evaluations and two device sweeps per structure change.
     void setVerifyModel(bool verify) { _verify = verify; }
+    // On every new RUN with an unchanged structure the model is derived from the graph again and compared with the resident one: a
+    // reference, weight or parameter that changed without a structure change (QuadraticFormCost::update returns false) is followed --
+    // moved references keep the device handle, anything else rebuilds (and re-verifies) it.  On by default; costs one pass of the
+    // recogniser over the edges per run.  Off: the caller vouches that only the vertex values change between runs.
+    void setTrackModel(bool track) { _tracking = track; }
 
     const corbo_hip_stats& getStatistics() const { return _stats; }
 
@@ -78,7 +83,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
 
  private:
     void releaseHandle();
-    bool attach(OptimizationProblemInterface& problem, bool new_structure);
+    bool attach(OptimizationProblemInterface& problem, bool new_structure, bool new_run);
     bool modelMatchesGraph(OptimizationProblemInterface& problem, bool perturbed);
     bool uploadVertices(const std::vector<VertexInterface*>& xs, const std::vector<VertexInterface*>& us, VertexInterface* xf, VertexInterface* dt);
 
@@ -86,6 +91,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     corbo_hip_problem_desc _desc;
     bool _have_desc = false;
     bool _verify    = true;
+    bool _tracking  = true;
     Eigen::VectorXd _xref;
     Eigen::MatrixXd _xref_traj;   // recognised time-varying state reference [N][nx] (empty: static)
     std::vector<double> _ref;

@@ -128,6 +128,11 @@ class AdaptiveGridBatch:
                 n_new = adapt_grid_n(self.strategy, n, float(dt), self.dt_ref, self.hyst, self.n_min, self.n_max)
                 if n_new != n:
                     plan.setdefault(n, []).append((slot, n_new))
+        # every destination bucket exists (and its descriptor is accepted by the device) BEFORE anything moves: a refused horizon
+        # must not leave the bookkeeping half way through a plan
+        for moves in plan.values():
+            for _, n_new in moves:
+                self._bucket(n_new)
         for n, moves in plan.items():
             src, ids = self.buckets[n], self.ids[n]
             by_dst: Dict[int, List[int]] = {}

@@ -112,6 +112,7 @@ struct corbo_hip_solver {
     double* d_bound_rows = nullptr;  // [2][nvs] the descriptor's bound pattern of one instance (lower row, upper row)
     std::vector<double> bound_rows;  // host copy of the same
     double* d_lin    = nullptr;      // [A | B] of a LinearStateSpaceModel (row-major), else null
+    double* d_wdense = nullptr;      // [q_sqrt | r_sqrt | qf_sqrt] (16 doubles each) of a descriptor with non-diagonal weights, else null
     double* d_xplant = nullptr;      // [batch][MAX_NX] plant states of the closed loop (corbo_hip_plant_*)
     double* h_dist   = nullptr;      // pinned, device-visible [batch][MAX_NX]: state disturbance of corbo_hip_plant_step
     bool have_plant  = false;
@@ -180,6 +181,7 @@ struct corbo_hip_solver {
         std::memcpy(p.mp.sqf, S.sqf, sizeof(p.mp.sqf));
         p.mp.dt_weight = S.dt_weight;
         std::memcpy(p.mp.fin, S.desc.final_ineq_params, sizeof(p.mp.fin));
+        p.mp.wdense = d_wdense; p.mp.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         p.fin_row = S.fin_row;
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
         p.dt_fixed = S.desc.dt_ref;
@@ -203,6 +205,7 @@ struct corbo_hip_solver {
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
         p.chain_variant = chain_variant;
+        p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         return p;
     }
 };
@@ -332,6 +335,12 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         CREATE_TRY(hipMalloc((void**)&h->d_lin, ab.size() * sizeof(double)));
         CREATE_TRY(hipMemcpy(h->d_lin, ab.data(), ab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (S.desc.weights_dense) {
+        double wd[48];
+        std::memcpy(wd, S.desc.q_sqrt, 16 * sizeof(double)); std::memcpy(wd + 16, S.desc.r_sqrt, 16 * sizeof(double)); std::memcpy(wd + 32, S.desc.qf_sqrt, 16 * sizeof(double));
+        CREATE_TRY(hipMalloc((void**)&h->d_wdense, sizeof(wd)));
+        CREATE_TRY(hipMemcpy(h->d_wdense, wd, sizeof(wd), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipMalloc((void**)&h->d_xplant, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_xplant, 0, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_bound_rows, 2 * (size_t)S.nvs * sizeof(double)));
@@ -360,6 +369,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
         h->force_split = true;  // no fused pass kernel for the big-block family: factor and sweep are separate launches
     }
+    if (S.desc.weights_dense) h->force_split = true;   // non-diagonal weights: the DENSE instantiations exist for the stand-alone kernels only (kernels.hip, sweep_body)
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
     {
         hipDeviceProp_t prop;
@@ -399,7 +409,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -1065,9 +1075,10 @@ try {
         if (src_index[q] < 0 || src_index[q] >= src->batch || dst_index[q] < 0 || dst_index[q] >= dst->batch) return fail(CORBO_HIP_ERR_INVALID, "instance index out of range");
     ON_DEVICE_OF(dst);
     src->sink_valid = dst->sink_valid = false;
-    // the index lists travel through the destination handle's pinned counter scratch when they fit, else through a temporary
-    struct Tmp { int32_t* p = nullptr; ~Tmp() { if (p) (void)hipHostFree(p); } } tmp;
-    HIP_TRY(hipHostMalloc((void**)&tmp.p, 2 * (size_t)count * sizeof(int32_t)));
+    // the index lists travel through the destination handle's pinned staging buffer (batch x nvs doubles: 2 x count ints always fit; the
+    // result views it may have held were invalidated above) -- no allocation on this path
+    HIP_TRY(hipStreamSynchronize(dst->stream));   // nothing in flight reads the staging buffer
+    struct { int32_t* p; } tmp{reinterpret_cast<int32_t*>(dst->h_stage)};
     std::memcpy(tmp.p, src_index, (size_t)count * sizeof(int32_t));
     std::memcpy(tmp.p + count, dst_index, (size_t)count * sizeof(int32_t));
     HIP_TRY(hipStreamSynchronize(src->stream));   // the source trajectories are final

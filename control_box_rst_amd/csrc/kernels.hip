@@ -103,10 +103,35 @@ __device__ __forceinline__ void lm_state_out(LmState* sg, const LmState* sl, int
         if (p.timeline && inst == 0 && tid == 0) p.timeline[id] = clock64(); \
     } while (0)
 
+// Row c of  U (x - ref)  for a vertex with a NON-DIAGONAL weight (quadratic_cost.cpp:116-118, 148-150, final_state_cost.cpp:88-90:
+// `cost.noalias() = _Q_sqrt * xd` with xd = x_k - xref(k), U = the upper Cholesky factor kept by setWeightQ / setWeightR / setWeightQf).
+// Eigen evaluates the dynamic-size product as a column-major gemv into a zeroed destination: one running sum per row over the columns,
+// a full block of FOUR columns added pairwise (the order LinearDynamics restates for f = A x + B u, measured against the compiled
+// reference).  U: row-major [dim][dim] with its explicit zeros below the diagonal -- they take part in the sum like in the reference.
+// xd: the vertex's differences x_j - ref_j (ref = 0 for controls), xd[c] possibly replaced by a perturbed value (finite differences).
+template <int DM>
+__device__ __forceinline__ double dense_weight_row(const double* U, int c, int dim, const double (&xd)[DM])
+{
+    double u[DM];
+#pragma unroll
+    for (int j = 0; j < DM; ++j) u[j] = (j < dim) ? U[c * dim + j] : 0.0;
+    if (dim == 4) {
+        if constexpr (DM >= 4) return 0.0 + ((u[0] * xd[0] + u[1] * xd[1]) + (u[2] * xd[2] + u[3] * xd[3]));
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < DM; ++j)
+        if (j < dim) acc += u[j] * xd[j];
+    return acc;
+}
+
 // LDS operands: xs [nvs] vertex values of this instance, red [10] reduction scratch + 4 int flags, cs [N*NC] per-grid-state
 // dynamics caches, jst [nnz_pad] Jacobian staging.  FUSED: a factor phase follows in the same workgroup and takes the Jacobian
 // straight from jst when this phase refreshed it (flag word [0]).
-template <int DYN, int DEFECT, bool FUSED>
+// DENSE: the descriptor has non-diagonal weights (corbo_hip_problem_desc::weights_dense).  A compile-time switch, instantiated for the
+// stand-alone kernels only (such handles run the phases as separate launches): inside the fused run-to-completion kernel even the
+// never-taken branches cost the headline path a third of its speed (register allocation: 44 -> 82 spilled VGPRs, measured).
+template <int DYN, int DEFECT, bool FUSED, bool DENSE = false>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false)
 {
     using Dy          = Dynamics<DYN>;
@@ -172,6 +197,21 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         if constexpr (FUSED) vout[row] = val;
         else __builtin_nontemporal_store(val, &vout[row]);
     };
+    constexpr int DM = (NX > NU) ? NX : NU;
+    const int wdm = (DENSE && p.mp.wdense) ? p.mp.wdense_mask : 0;   // non-diagonal weights: bit 0 Q, bit 1 R, bit 2 Qf (uniform; 0 for every diagonal problem)
+    // differences x_j - ref_j of the whole vertex that component v (index c, class cls: 0 state, 1 control, 2 final state) belongs to
+    auto vertex_diffs = [&](int v, int c, int dim, int cls, double (&xd)[DM]) {
+#pragma unroll
+        for (int j = 0; j < DM; ++j) {
+            double rj = 0.0;
+            if (cls != 1) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) rj = (j == i) ? xr[i] : rj;
+                if (p.refvec && j < dim) rj = p.refvec[xo + v - c + j];
+            }
+            xd[j] = (j < dim) ? xs[v - c + j] - rj : 0.0;
+        }
+    };
     auto comp_role = [&](int v, int& c, int& dim, double& w, double& ref, bool& fin) {
         const bool is_dt  = (v == p.off_dt);
         const bool is_fin = !is_dt && v >= (p.N - 1) * S;
@@ -199,11 +239,36 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         fin = is_fin;
     };
     auto comp_jac = [&](int v, const CompInfo& ci, double xv, double l, double u, int c, int dim, double w, double ref, bool fin) {
-        if (!ci.fixed && ci.cost_joff >= 0) {  // central difference of the diagonal cost block (edge_interface.cpp:55-96)
+        const int cls = (v == p.off_dt) ? 3 : (fin ? 2 : (v % S >= NX ? 1 : 0));
+        if (DENSE && wdm && cls < 3 && ((wdm >> cls) & 1)) {
+            // dense weight: column c of the (upper-triangular) block U, every row by central differences of the edge's own value
+            if (!ci.fixed && ci.cost_joff >= 0) {
+                const double* U = p.mp.wdense + 16 * cls;
+                double xd[DM];
+                vertex_diffs(v, c, dim, cls, xd);
+                double refc = 0.0;   // the component's own reference (the perturbed difference is (x_c +- delta) - ref_c)
+                if (cls != 1) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) refc = (c == i) ? xr[i] : refc;
+                    if (p.refvec) refc = p.refvec[xo + v];
+                }
+                const double a = xv + delta, b = a + neg2delta;
+                const int col0 = ci.cost_joff - c;
+#pragma unroll
+                for (int r = 0; r < DM; ++r) {
+                    if (r < dim) {
+                        double x2[DM], x1[DM];
+#pragma unroll
+                        for (int j = 0; j < DM; ++j) { x2[j] = (j == c) ? a - refc : xd[j]; x1[j] = (j == c) ? b - refc : xd[j]; }
+                        jst[col0 + r] = scalar * (dense_weight_row<DM>(U, r, dim, x2) - dense_weight_row<DM>(U, r, dim, x1));
+                    }
+                }
+            }
+        }
+        else if (!ci.fixed && ci.cost_joff >= 0) {  // central difference of the diagonal cost block (edge_interface.cpp:55-96)
             const double a = xv + delta, b = a + neg2delta;
             const double dv = scalar * (w * (a - ref) - w * (b - ref));
             const int col0  = ci.cost_joff - c;
-            constexpr int DM = (NX > NU) ? NX : NU;
 #pragma unroll
             for (int r = 0; r < DM; ++r)
                 if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;  // untouched rows: scalar * (e - e) = 0
@@ -226,7 +291,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         bool fin;
         comp_role(v, c, dim, w, ref, fin);
         if (ci.cost_row >= 0) {
-            const double val = w * (xv - ref);
+            double val = w * (xv - ref);
+            if (DENSE && wdm) {
+                const int cls = (v == p.off_dt) ? 3 : (fin ? 2 : (v % S >= NX ? 1 : 0));
+                if (cls < 3 && ((wdm >> cls) & 1)) {
+                    double xd[DM];
+                    vertex_diffs(v, c, dim, cls, xd);
+                    val = dense_weight_row<DM>(p.mp.wdense + 16 * cls, c, dim, xd);
+                }
+            }
             put_value(ci.cost_row, val);
             sq_acc += val * val;
             if (!fin && ci.cost2_row >= 0) { put_value(ci.cost2_row, val); sq_acc += val * val; }
@@ -717,7 +790,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
 }
 
-template <int DYN, int DEFECT>
+template <int DYN, int DEFECT, bool DENSE = false>
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -728,7 +801,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 6) ? p.nnz_pad : 0));
     const int inst = blockIdx.x + p.inst0;
     if (p.st) { lm_state_in(sl, p.st + inst, threadIdx.x); __syncthreads(); }
-    sweep_body<DYN, DEFECT, false>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
+    sweep_body<DYN, DEFECT, false, DENSE>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
     if (p.st && p.mode >= 2) { __syncthreads(); lm_state_out(p.st + inst, sl, threadIdx.x); }
 }
 
@@ -946,11 +1019,81 @@ struct FactorLds {
     __host__ __device__ static constexpr int total(int NP, bool arrow) { return off_red(NP) + RED + (arrow ? (NU + NX) * NP : 0); }
 };
 
+// Non-diagonal weights (corbo_hip_problem_desc::weights_dense): the cost edge of a vertex is a dense block C (the finite-difference
+// Jacobian of U (x - ref), upper triangular up to rounding) instead of single-entry rows.  Its share of H = J^T J and rhs = -J^T r for
+// stage k's state vertex (Q, or Qf on the last block) and control vertex (R):  out = [C^T C packed lower (NT) | -C^T v (NX) | the same for
+// the controls (NUT, NU)], zeros for a vertex whose weight is diagonal (those go through the single-entry path) or that has no cost edge.
+// Deliberately NOT inlined and handed a private array: the diagonal problems (every BASELINE configuration) pay one uniform branch and
+// no registers for it.
+template <int NX, int NU>
+__device__ __noinline__ void dense_cost_terms(const StageCols*, const CompInfo* comp, int wdense_mask, int N, const double* J, const double* val, int k, double* out)
+{
+    constexpr int S = NX + NU, NT = NX * (NX + 1) / 2, NUT = NU * (NU + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < NT + NX + NUT + NU; ++i) out[i] = 0.0;
+    if (k >= N) return;
+    {   // state vertex of block k
+        const int cls = (k == N - 1) ? 2 : 0;
+        if (((wdense_mask >> cls) & 1) && comp[k * S].cost_row >= 0) {
+            double C[NX][NX], v[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                const CompInfo ci = comp[k * S + c];
+                v[c] = val[ci.cost_row];
+                const bool have = !ci.fixed && ci.cost_joff >= 0;
+                const int col0  = have ? ci.cost_joff - c : 0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) { const double a = J[col0 + r]; C[r][c] = have ? a : 0.0; }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double g = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) g -= C[r][i] * v[r];
+                out[NT + i] = g;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double d = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) d += C[r][i] * C[r][j];
+                    out[i * (i + 1) / 2 + j] = d;
+                }
+            }
+        }
+    }
+    if (k < N - 1 && ((wdense_mask >> 1) & 1) && comp[k * S + NX].cost_row >= 0) {   // control vertex of stage k
+        double C[NU][NU], v[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            const CompInfo ci = comp[k * S + NX + c];
+            v[c] = val[ci.cost_row];
+            const bool have = !ci.fixed && ci.cost_joff >= 0;
+            const int col0  = have ? ci.cost_joff - c : 0;
+#pragma unroll
+            for (int r = 0; r < NU; ++r) { const double a = J[col0 + r]; C[r][c] = have ? a : 0.0; }
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            double g = 0.0;
+#pragma unroll
+            for (int r = 0; r < NU; ++r) g -= C[r][i] * v[r];
+            out[NT + NX + NUT + i] = g;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double d = 0.0;
+#pragma unroll
+                for (int r = 0; r < NU; ++r) d += C[r][i] * C[r][j];
+                out[NT + NX + i * (i + 1) / 2 + j] = d;
+            }
+        }
+    }
+}
+
 // j_in_lds: the Jacobian values of this instance already sit in smem[0, nnz_pad) (left there by the sweep phase of the same
 // workgroup); otherwise they are staged from HBM first.
 // NPC > 0: the padded block count N | 1 as a compile-time constant (LDS element strides become immediate offsets of the DS
 // instructions instead of two VALU operations per access); 0: taken from the launch parameters.
-template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0>
+template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false>
 __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr)
 {
     constexpr int S  = NX + NU;
@@ -1071,16 +1214,23 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         if constexpr (ARROW) { const int o = sco[S + NX]; const double v = J[(o >= 0 ? o : 0) + i]; dc[i] = (o >= 0) ? v : 0.0; }
     }
     // diagonal (single-entry) rows of this lane's components: cost rows, bound rows
+    // (a vertex with a NON-DIAGONAL weight has a dense cost block instead: its share comes from dense_cost_terms below)
+    const int wdm = DENSE ? p.wdense_mask : 0;
+    const bool wd_x = DENSE && wdm && ((wdm >> ((k == N - 1) ? 2 : 0)) & 1), wd_u = DENSE && wdm && ((wdm >> 1) & 1);
     double du_diag[NU], gu[NU], dx_diag[NX], gx[NX];
 #pragma unroll
     for (int e = 0; e < S; ++e) {
         double ac = J[cj[e] >= 0 ? cj[e] : 0], ab = J[bj[e] >= 0 ? bj[e] : 0];
-        if (cj[e] < 0) ac = 0.0;
+        if (cj[e] < 0 || ((e < NX) ? wd_x : wd_u)) ac = 0.0;
         if (bj[e] < 0) ab = 0.0;
         const double dd = ac * ac + ab * ab, gg = -(ac * vc[e]) - ab * vb[e];
         if (e < NX) { dx_diag[e] = dd; gx[e] = gg; }
         else { du_diag[e - NX] = dd; gu[e - NX] = gg; }
     }
+    // non-diagonal weights: the dense cost blocks' shares, computed out of line into a private array (see dense_cost_terms)
+    constexpr int NUT = NU * (NU + 1) / 2;
+    double dq[NT + NX + NUT + NU];
+    if constexpr (DENSE) { if (wdm) dense_cost_terms<NX, NU>(p.stage_cols, p.comp, wdm, N, J, val, k, dq); }
     if (has_block && !has_stage) {   // the last block: rows of a TerminalEqualityConstraint on x_f (second diagonal row of a component)
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
@@ -1124,6 +1274,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (int j = 0; j < NU; ++j)
             if (has_stage) {
                 double dd = du_diag[j], gg = gu[j];
+                if constexpr (DENSE) { if (wd_u) { dd += dq[NT + NX + TRI(j, j)]; gg += dq[NT + NX + NUT + j]; } }
 #pragma unroll
                 for (int q = 0; q < NX; ++q) { dd += B[q][j] * B[q][j]; gg -= B[q][j] * r[q]; }
                 mx_d = fmax(mx_d, dd);
@@ -1133,6 +1284,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (int i = 0; i < NX; ++i)
             if (has_block && !xfixed[i]) {
                 double dd = dx_diag[i] + cin[i] * cin[i], gg = gx[i] - cin[i] * rin;
+                if constexpr (DENSE) { if (wd_x) { dd += dq[TRI(i, i)]; gg += dq[NT + i]; } }
 #pragma unroll
                 for (int q = 0; q < NX; ++q) { dd += A[q][i] * A[q][i]; gg -= A[q][i] * r[q]; }
                 if (k >= 1) { dd += SOA(Wbm, i, k - 1); gg += SOA(Wbm, NX + i, k - 1); }
@@ -1184,6 +1336,11 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (int a = 0; a < NU; ++a) {
             Huu[a][a] += du_diag[a] + mu_eff;
             double gg = gu[a], bb = 0;
+            if constexpr (DENSE) if (wd_u) {
+                gg += dq[NT + NX + NUT + a];
+#pragma unroll
+                for (int b = 0; b <= a; ++b) { Huu[a][b] += dq[NT + NX + TRI(a, b)]; if (b < a) Huu[b][a] += dq[NT + NX + TRI(a, b)]; }
+            }
 #pragma unroll
             for (int q = 0; q < NX; ++q) { gg -= B[q][a] * r[q]; bb += B[q][a] * dc[q]; }
             gu_[a] = gg; bu_[a] = bb;
@@ -1259,11 +1416,13 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (int i = 0; i < NX; ++i) {
             double g = gk[i] + gx[i] - cin[i] * rin, b = bk[i];
             if (has_mail) { g += mg[i]; b += mb[i]; }
+            if constexpr (DENSE) { if (wd_x) g += dq[NT + i]; }
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
                 double d = Dk[i][j] + cin[i] * cin[j];
                 if (has_mail) d += mD[i][j];
                 if (i == j) d += dx_diag[i] + mu_eff;
+                if constexpr (DENSE) { if (wd_x) d += dq[TRI(i, j)]; }
                 if (xfixed[i] || xfixed[j]) d = (i == j) ? 1.0 : 0.0;
                 Dk[i][j] = d;
             }
@@ -1611,7 +1770,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     STAMP(7);
 }
 
-template <int NX, int NU, int THREADS, bool ARROW>
+template <int NX, int NU, int THREADS, bool ARROW, bool DENSE = false>
 __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1620,7 +1779,7 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
     LmState* sl = reinterpret_cast<LmState*>(smem + ((ftot > p.nnz_pad ? ftot : p.nnz_pad) + 1) / 2 * 2);
     lm_state_in(sl, p.st + inst, threadIdx.x);
     __syncthreads();
-    factor_body<NX, NU, THREADS, ARROW>(p, sl, smem, inst, threadIdx.x, false);
+    factor_body<NX, NU, THREADS, ARROW, 0, DENSE>(p, sl, smem, inst, threadIdx.x, false);
     __syncthreads();
     lm_state_out(p.st + inst, sl, threadIdx.x);
 }
@@ -2902,6 +3061,12 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorP
 template <int DYN, int DEFECT>
 void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 {
+    if constexpr (Dynamics<DYN>::NX <= 4) {
+        if (p.mp.wdense) {   // non-diagonal weights: the DENSE instantiation
+            hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
 }
 
@@ -2947,14 +3112,25 @@ struct HessEdge {
     __device__ static void values(int kind, const double* xl, const double* xr, const ModelParams& mp, double* out)
     {
         switch (kind) {
-            case EK_STATE_COST:
-                for (int i = 0; i < NX; ++i) out[i] = mp.sq[i] * (xl[i] - xr[i]);
+            case EK_STATE_COST: case EK_FINAL_COST: {
+                const int cls = (kind == EK_FINAL_COST) ? 2 : 0;
+                if (mp.wdense && ((mp.wdense_mask >> cls) & 1)) {   // non-diagonal weight: U (x - ref), Eigen's gemv order (dense_weight_row)
+                    double xd[MAXD];
+                    for (int i = 0; i < MAXD; ++i) xd[i] = (i < NX) ? xl[i] - xr[i] : 0.0;
+                    for (int i = 0; i < NX; ++i) out[i] = dense_weight_row<MAXD>(mp.wdense + 16 * cls, i, NX, xd);
+                }
+                else
+                    for (int i = 0; i < NX; ++i) out[i] = (cls ? mp.sqf[i] : mp.sq[i]) * (xl[i] - xr[i]);
                 break;
+            }
             case EK_CONTROL_COST:
-                for (int i = 0; i < NU; ++i) out[i] = mp.sr[i] * xl[NX + i];
-                break;
-            case EK_FINAL_COST:
-                for (int i = 0; i < NX; ++i) out[i] = mp.sqf[i] * (xl[i] - xr[i]);
+                if (mp.wdense && (mp.wdense_mask & 2)) {
+                    double ud[MAXD];
+                    for (int i = 0; i < MAXD; ++i) ud[i] = (i < NU) ? xl[NX + i] : 0.0;
+                    for (int i = 0; i < NU; ++i) out[i] = dense_weight_row<MAXD>(mp.wdense + 16, i, NU, ud);
+                }
+                else
+                    for (int i = 0; i < NU; ++i) out[i] = mp.sr[i] * xl[NX + i];
                 break;
             case EK_DT_COST: case EK_DT_QCOST: out[0] = mp.dt_weight * xl[W - 1]; break;   // (plain form: dt_weight = N - 1)
             // plain objective edges, lsq_form = false (quadratic_cost.cpp:133-138,165-170, final_state_cost.cpp:102-108): xd^T * W_diag * xd, the
@@ -3284,6 +3460,7 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
 {
     using Dy = Dynamics<DYN>;
     if (fp.N > SWEEP_THREADS) return false;
+    if (fp.wdense_mask) return false;   // non-diagonal weights: separate launches only (see sweep_body)
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
     const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs + 12) + sizeof(LmState);           // + vertex values + LM state + scratch
@@ -3337,6 +3514,12 @@ bool launch_factor_a(const FactorParams& p, hipStream_t stream)
     size_t lds = factor_lds<NX, NU>(p.N, ARROW);
     if (lds < sizeof(double) * (size_t)p.nnz_pad) lds = sizeof(double) * (size_t)p.nnz_pad;  // Jacobian staging area
     lds = ((lds + 15) & ~(size_t)15) + sizeof(LmState);                                      // + LM state
+    if (p.wdense_mask) {   // non-diagonal weights: the DENSE instantiation
+        if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128, ARROW, true>), dim3(p.batch), dim3(128), lds, stream, p);
+        else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256, ARROW, true>), dim3(p.batch), dim3(256), lds, stream, p);
+        else return false;
+        return true;
+    }
     if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128, ARROW>), dim3(p.batch), dim3(128), lds, stream, p);
     else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256, ARROW>), dim3(p.batch), dim3(256), lds, stream, p);
     else return false;

@@ -19,6 +19,8 @@ struct ModelParams {
     double sqf[CORBO_HIP_MAX_NX];  // sqrt(Qf_ii)  (final_state_cost.cpp:60-68)
     double dt_weight;              // sqrt(N-1)    (minimum_time.h:60)
     double fin[CORBO_HIP_MAX_NX + 1];  // final-stage inequality: S_11 .. S_nn, gamma (TerminalBall)
+    const double* wdense;          // or null: non-diagonal weights, [Uq 16 | Ur 16 | Uqf 16] row-major upper Cholesky factors (corbo_hip_problem_desc::q_sqrt ...)
+    int32_t wdense_mask;           // bit 0 Q, bit 1 R, bit 2 Qf are dense (sq / sr / sqf of that class are then unused)
 };
 
 #pragma clang fp contract(off)

@@ -53,6 +53,20 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.final_eq != 0 && d.final_eq != 1) return "final_eq must be 0 or 1";
     if (d.final_eq && d.nx > 4 && d.nx != 12) return "terminal equality constraint: families with nx <= 4, and the 12-state big-block family";
     if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
+    if (d.weights_dense < 0 || d.weights_dense > 7) return "weights_dense: bits 0..2";
+    if (d.weights_dense) {
+        if (d.nx > 4 || d.nu > 4) return "non-diagonal weights: families with nx <= 4";
+        if (d.cost_nonlsq) return "non-diagonal weights: least-squares form only (cost_nonlsq = 0)";
+        if ((d.weights_dense & 3) && !(CORBO_HIP_COST_TERMS(d.stage_cost) & 3)) return "weights_dense bits 0 / 1 without a quadratic stage cost";
+        if ((d.weights_dense & 4) && !d.final_cost) return "weights_dense bit 2 without a final cost";
+        for (int i = 0; i < d.nx; ++i)
+            for (int j = 0; j < i; ++j)
+                if (((d.weights_dense & 1) && d.q_sqrt[i * d.nx + j] != 0.0) || ((d.weights_dense & 4) && d.qf_sqrt[i * d.nx + j] != 0.0))
+                    return "q_sqrt / qf_sqrt must be upper triangular (Eigen::LLT<.., Upper>::matrixU())";
+        for (int i = 0; i < d.nu; ++i)
+            for (int j = 0; j < i; ++j)
+                if ((d.weights_dense & 2) && d.r_sqrt[i * d.nu + j] != 0.0) return "r_sqrt must be upper triangular";
+    }
     if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
     return "";
 }

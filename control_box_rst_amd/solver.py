@@ -185,7 +185,7 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_prepare_slots(self._h, int(active)), "corbo_hip_prepare_slots")
 
     def get_dt(self, active: int) -> np.ndarray:
-        out = np.zeros(max(1, int(active)))
+        out = np.zeros(self.batch)   # the library writes one value per ACTIVE slot of the handle (<= batch), whatever the caller expects
         self._check(self.lib.corbo_hip_get_dt(self._h, _dp(out)), "corbo_hip_get_dt")
         return out[:active]
 

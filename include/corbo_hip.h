@@ -163,7 +163,17 @@ typedef struct corbo_hip_problem_desc {
      * dt c(x_k, u_k) (finite_differences_collocation_edges.h:98-152, 323-368; FullDiscretizationGridBase::CostIntegrationRule).  Plain objective
      * edges: needs cost_nonlsq = 1 (the final cost is then QuadraticFinalStateCost(Qf, false)); Hessian-path operators only. */
     int32_t cost_integral;
-    int32_t reserved0;
+    /* Non-diagonal weights (QuadraticFormCost::setWeightQ / setWeightR with a full matrix, quadratic_cost.cpp:36-55, 77-95;
+     * QuadraticFinalStateCost::setWeightQf, final_state_cost.cpp:36-58; QuadraticFinalStateCostRiccati, final_state_cost.h:103, whose Qf is
+     * always dense): the reference keeps the UPPER Cholesky factor U (Q = U^T U, Eigen::LLT<.., Upper>::matrixU()) and the least-squares
+     * term is U (x - xref) / U u (quadratic_cost.cpp:116-118, 148-150; final_state_cost.cpp:88-90) -- a dense product in Eigen's gemv
+     * order, its Jacobian block a dense (upper-triangular) nx x nx block.  Bit 0: q_sqrt is used instead of q_diag, bit 1: r_sqrt instead of
+     * r_diag, bit 2: qf_sqrt instead of qf_diag.  Row-major [i * nx + j] (r_sqrt: [i * nu + j]), entries below the diagonal zero.  Families
+     * with nx <= 4 on the Levenberg-Marquardt path and the Hessian-path operators in least-squares form (cost_nonlsq = 0). */
+    int32_t weights_dense;
+    double q_sqrt[16];
+    double r_sqrt[16];
+    double qf_sqrt[16];
 } corbo_hip_problem_desc;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */

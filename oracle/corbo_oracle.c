@@ -231,6 +231,21 @@ static void defect_values(const oracle_problem* p, const double* x1, const doubl
 }
 
 /* BaseEdge::computeValues of the edge classes on the path */
+/* U * xd for a NON-DIAGONAL weight: `cost.noalias() = _Q_sqrt * xd` (quadratic_cost.cpp:116-118, 148-150; final_state_cost.cpp:88-90) with U the
+ * upper Cholesky factor kept by setWeightQ / setWeightR / setWeightQf (quadratic_cost.cpp:36-55, final_state_cost.cpp:38-58).  Eigen evaluates the
+ * dynamic-size product as a column-major gemv into a zeroed destination: one running sum per row over the columns, a full block of FOUR columns
+ * added pairwise (the order the linear state-space model's A x + B u is restated in; pinned bit for bit by the *_fullq fixtures). */
+static void dense_weight_times(const double* U, int n, const double* xd, double* out)
+{
+    for (int i = 0; i < n; ++i) {
+        const double* u = U + i * n;
+        if (n == 4) { out[i] = 0.0 + ((u[0] * xd[0] + u[1] * xd[1]) + (u[2] * xd[2] + u[3] * xd[3])); continue; }
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += u[j] * xd[j];
+        out[i] = acc;
+    }
+}
+
 static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
 {
     const corbo_hip_problem_desc* d = &p->d;
@@ -245,6 +260,12 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
                 out[0] = acc;
                 break;
             }
+            if (d->weights_dense & 1) { /* non-diagonal Q: xd = x_k - xref(k); cost = Q_sqrt * xd */
+                double xd[CORBO_HIP_MAX_NX];
+                for (int i = 0; i < d->nx; ++i) xd[i] = xk[i] - rk[i];
+                dense_weight_times(d->q_sqrt, d->nx, xd, out);
+                break;
+            }
             for (int i = 0; i < d->nx; ++i) out[i] = p->sq[i] * (xk[i] - rk[i]);
             break;
         }
@@ -257,6 +278,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
                 out[0] = acc;
                 break;
             }
+            if (d->weights_dense & 2) { dense_weight_times(d->r_sqrt, d->nu, uk, out); break; } /* R_sqrt * u_k (quadratic_cost.cpp:148-150) */
             for (int i = 0; i < d->nu; ++i) out[i] = p->sr[i] * uk[i];
             break;
         }
@@ -267,6 +289,12 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
                 double acc = 0.0;
                 for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->qf_diag[i]) * xd; }
                 out[0] = acc;
+                break;
+            }
+            if (d->weights_dense & 4) { /* Qf_sqrt * xd (final_state_cost.cpp:88-90) */
+                double xd[CORBO_HIP_MAX_NX];
+                for (int i = 0; i < d->nx; ++i) xd[i] = xk[i] - rk[i];
+                dense_weight_times(d->qf_sqrt, d->nx, xd, out);
                 break;
             }
             for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - rk[i]);

@@ -166,7 +166,7 @@ enum class Mode { Reference, HipAuto, HipStated, HipStatedWrong, Describe, Hessi
 
 // scenarios: "unicycle" cfg 3 single instance; "dint" cfg 2 (free dt, 5 consecutive solves, new_run only first); "quad" reduced cfg 5;
 // "vdp" cfg 1; "unicycle_tball" TerminalBall; "duffing" / "pendulum" / "lin32": reference benchmark classes with NON-default parameters
-// (their private members are what the recogniser has to get right); "unicycle_fullq": a non-diagonal Q (must be refused)
+// (their private members are what the recogniser has to get right); "unicycle_fullq": non-diagonal Q, R, Qf (dense cost blocks); "unicycle_uref": a non-zero control reference (must be refused)
 static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* describe_out = nullptr)
 {
     Run r;
@@ -191,8 +191,8 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap"),
                ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
-    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref");
-    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || (hpath && scenario.compare(0, 3, "vdp") != 0));
+    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref"), urefnz = (scenario == "unicycle_uref");
+    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || urefnz || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
     {
         dyn  = std::make_shared<UnicycleRef>();
@@ -332,9 +332,14 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     if (uni)
     {
         Eigen::MatrixXd Q  = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
-        if (fullq) { Q(0, 1) = 0.2; Q(1, 0) = 0.2; }
         Eigen::MatrixXd R  = Eigen::Vector2d(0.1, 0.05).asDiagonal();
         Eigen::MatrixXd Qf = 10.0 * Eigen::MatrixXd(Eigen::Vector3d(1, 1, 0.1).asDiagonal());
+        if (fullq)
+        {   // non-diagonal Q, R and Qf: upper Cholesky factors, dense cost blocks (quadratic_cost.cpp:36-55; an LQR-style terminal weight)
+            Q(0, 1) = Q(1, 0) = 0.2; Q(1, 2) = Q(2, 1) = -0.05;
+            R(0, 1) = R(1, 0) = 0.02;
+            Qf(0, 1) = Qf(1, 0) = 3.0; Qf(0, 2) = Qf(2, 0) = 0.4;
+        }
         ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, itrap || ileft, !hpath));
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
@@ -410,7 +415,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     }
     DiscreteTimeReferenceTrajectory xref_tv(ts, TimeSeries::Interpolation::ZeroOrderHold);
     ReferenceTrajectoryInterface& xref = tvref ? static_cast<ReferenceTrajectoryInterface&>(xref_tv) : static_cast<ReferenceTrajectoryInterface&>(xref_static);
-    ZeroReference uref(nu);
+    ZeroReference uref_zero(nu);
+    StaticReference uref_nz(Eigen::VectorXd::Constant(nu, 0.1));
+    ReferenceTrajectoryInterface& uref = urefnz ? static_cast<ReferenceTrajectoryInterface&>(uref_nz) : static_cast<ReferenceTrajectoryInterface&>(uref_zero);
     r.ok = true;
     for (int i = 0; i < solves; ++i) r.ok = ocp.compute(x0, xref, uref, nullptr, Time(0), i == 0) && r.ok;
     r.traj = trajectory(ocp, *any_grid);
@@ -474,7 +481,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "unicycle_uref", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -484,7 +491,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -495,7 +502,7 @@ int main(int argc, char** argv)
         if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,
@@ -516,9 +523,10 @@ int main(int argc, char** argv)
         printf("{\"scenario\": \"unicycle_mismatch\", \"ok_hip\": %d}\n", c.ok ? 1 : 0);
         if (c.ok) rc = 1;
     }
-    {   // a graph the device cannot describe (non-diagonal Q) must be refused by the recogniser
-        Run c = run("unicycle_fullq", Mode::HipAuto, 30);
-        printf("{\"scenario\": \"unicycle_fullq\", \"ok_hip\": %d}\n", c.ok ? 1 : 0);
+    {   // a graph the device cannot describe (a non-zero control reference: the reference's least-squares control term is then a scalar
+        // assigned to the nu-vector, quadratic_cost.cpp:160-163) must be refused by the recogniser
+        Run c = run("unicycle_uref", Mode::HipAuto, 30);
+        printf("{\"scenario\": \"unicycle_uref\", \"ok_hip\": %d}\n", c.ok ? 1 : 0);
         if (c.ok) rc = 1;
     }
     return rc;

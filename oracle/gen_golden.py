@@ -256,8 +256,78 @@ def bigterm():
         print(name, d["n"], d["m"], d["ineq"], d["eq"], [a["chi2"] for a in d["after_iter"]])
 
 
+
+def _bench_chunk(args):
+    scenario, x0, xf, kv = args
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        np.savetxt(f, np.hstack([x0, xf]), fmt="%.17g")
+        path = f.name
+    try:
+        r = json.loads(subprocess.check_output([DRIVER, "bench", f"scenario={scenario}", f"instances={path}"] + [f"{k}={v}" for k, v in kv.items()]))
+    finally:
+        os.unlink(path)
+    return r["chi2_sum"]
+
+
+def secondary():
+    """chi2 sums of the genuine reference over the workloads of bench.py's `secondary` legs (BASELINE configs 1, 2, 5 at their full
+    sizes): cfg 1 Van-der-Pol batch 1, cfg 2 double integrator batch 1 x 5 warm-started solves, cfg 5 the 512 seeded
+    quadrotor instances at N = 200 (one reference process per instance, 8.8 s each)."""
+    from concurrent.futures import ProcessPoolExecutor
+    import bench
+    out = {}
+    for cfg, scen in ((1, "vdp"), (2, "dint")):
+        w = bench.workload(cfg, 1)
+        out[f"cfg{cfg}"] = {"batch": 1, "iters": 10, "solves": w["solves"], "N": int(w["desc"].N),
+                            "chi2_sum": _bench_chunk((scen, w["x0"], w["xf"], dict(iters=10, solves=w["solves"], N=w["desc"].N)))}
+        print(cfg, out[f"cfg{cfg}"])
+    B = 512
+    w = bench.workload(5, B)
+    jobs = [("quad", w["x0"][b:b + 1], w["xf"][b:b + 1], dict(iters=10, solves=1, N=w["desc"].N)) for b in range(B)]
+    with ProcessPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        chi2 = list(ex.map(_bench_chunk, jobs, chunksize=4))
+    out["cfg5"] = {"batch": B, "iters": 10, "solves": 1, "N": int(w["desc"].N), "chi2_sum": float(np.sum(chi2)), "chi2": [float(c) for c in chi2]}
+    print(5, out["cfg5"]["chi2_sum"])
+    with open(os.path.join(OUT, "bench_secondary.json"), "w") as f:
+        json.dump({"source": "oracle/_ref/ref_driver bench (genuine reference), seeds 20260928+i, weights as bench.workload", **out}, f, separators=(",", ":"))
+
+
+
+FULLQ = [
+    # NON-DIAGONAL Q / R / Qf (fullq = 1 of ref_driver: off-diagonal entries 0.25 sqrt(w_i w_j)): the dense branch of QuadraticFormCost::setWeightQ /
+    # setWeightR and QuadraticFinalStateCost::setWeightQf -- upper Cholesky factors, dense cost blocks (VERDICT r2 item 5)
+    ("unicycle_n12_fullq", dict(scenario="unicycle", N=12, iters=6, fullq=1), (1, 2, 3, 4, 5, 6)),
+    # (a ZERO state reference takes another branch of the reference, quadratic_cost.cpp:108-111: `cost.noalias() = x_k.transpose() * _Q_sqrt * x_k`, a
+    #  scalar assigned to the nx-vector -- rows beyond the first are uninitialised memory; nothing to pin, like the non-zero control reference)
+    ("vdp_fullq", dict(scenario="vdp", iters=6, fullq=1, xf="0.4,0.1"), (1, 2, 3, 4, 5, 6)),
+    ("unicycle_n12_fullq_patterns", dict(scenario="unicycle", N=12, iters=5, fullq=1, xlb="-inf,-1.5,-inf", xub="1.2,inf,inf", ulb="-0.8,-inf", uub="inf,0.6", xf_fixed=5), (1, 2, 3, 4, 5)),
+    ("unicycle_n12_fullq_ms", dict(scenario="unicycle", grid="ms", N=12, iters=6, fullq=1), (1, 2, 3, 4, 5, 6)),
+    ("cartpole_fullq", dict(scenario="cartpole", N=14, iters=5, fullq=1), (1, 2, 3, 4, 5)),            # nx = 4: Eigen's four-column gemv block
+    ("par3_fullq", dict(scenario="par3", iters=5, fullq=1), (1, 2, 3, 4, 5)),                          # nu = 3: dense R
+    ("lin33_fullq", dict(scenario='lin', nx=3, nu=3, lin_a='-0.16999999999999998,-0.338,0.807,-0.486,-0.8200000000000001,-0.482,-0.289,-0.99,-0.243', lin_b='-0.435,-0.864,0.234,-0.647,-0.391,-0.118,-0.7,-0.564,-0.051', iters=4, collocation='forward', N=14, fullq=1), (1, 2, 3, 4)),
+    ("unicycle_n12_fullq_tvref", dict(scenario="unicycle", N=12, iters=5, fullq=1, xref_traj=1), (1, 2, 3, 4, 5)),
+]
+
+
+def fullq():
+    for name, kv, keep in FULLQ:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
+    d = run("hess", scenario="unicycle", N=10, fullq=1)
+    with open(os.path.join(OUT, "hess_unicycle_fullq.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+    print("hess_unicycle_fullq")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullq":
+        return fullq()
+    if len(sys.argv) > 1 and sys.argv[1] == "secondary":
+        return secondary()
     if len(sys.argv) > 1 and sys.argv[1] == "msvar":
         return msvar()
     if len(sys.argv) > 1 and sys.argv[1] == "bigterm":

@@ -149,6 +149,9 @@ struct Scenario
     std::string cost;
     int last_n = 0;             // last_n=<n> with cost=mtq: MinTimeQuadratic's only_last_n
     std::string integral;       // integral=trap|left (unicycle, vdp; with lsq=0): QuadraticFormCost in integral form, the grid's cost integration rule
+    mutable Eigen::MatrixXd Qfull, Rfull, Qffull;   // what fullq = 1 configured (filled by build(); dump prints their factors)
+    bool fullq = false;         // fullq=1 (unicycle, vdp, par2 / par3 / lin, the zoo): NON-DIAGONAL Q, R, Qf = 10 Q (off-diagonal entries 0.25 sqrt(w_i w_j)): the dense
+                                // branch of QuadraticFormCost::setWeightQ / setWeightR and QuadraticFinalStateCost::setWeightQf (upper Cholesky factors)
     bool nonlsq = false;        // lsq=0 (unicycle, vdp, dint, int3 vargrid, cost=mtq; hess mode): QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false -- scalar terms
     int xf_fixed = -1;          // xf_fixed=<bit mask>: partially fixed goal state (setXfFixed), unicycle / vdp
     int final_cost = -1;        // final_cost=0: no final-state cost
@@ -193,6 +196,16 @@ static FiniteDifferencesCollocationInterface::Ptr makeCollocation(const std::str
     if (n == "backward") return std::make_shared<BackwardDiffCollocation>();
     if (n == "midpoint") return std::make_shared<MidpointDiffCollocation>();
     return std::make_shared<CrankNicolsonDiffCollocation>();
+}
+
+// fullq = 1: the weight with off-diagonal entries 0.25 sqrt(w_i w_j) (symmetric positive definite for these sizes)
+static Eigen::MatrixXd fullWeight(const Eigen::MatrixXd& D)
+{
+    Eigen::MatrixXd W = D;
+    for (int i = 0; i < W.rows(); ++i)
+        for (int j = 0; j < W.cols(); ++j)
+            if (i != j) W(i, j) = 0.25 * std::sqrt(D(i, i) * D(j, j));
+    return W;
 }
 
 static Built build(const Scenario& s, int iterations)
@@ -375,7 +388,9 @@ static Built build(const Scenario& s, int iterations)
     {
         Eigen::MatrixXd Q = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
         Eigen::MatrixXd R = Eigen::Vector2d(0.1, 0.05).asDiagonal();
+        if (s.fullq) { Q = fullWeight(Q); R = fullWeight(R); }
         Eigen::MatrixXd Qf = 10.0 * Q;
+        s.Qfull = Q; s.Rfull = R; s.Qffull = Qf;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         b.ocp->setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
@@ -384,7 +399,9 @@ static Built build(const Scenario& s, int iterations)
     {
         Eigen::MatrixXd Q = Eigen::Vector2d(1, 1).asDiagonal();
         Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        if (s.fullq) Q = fullWeight(Q);
         Eigen::MatrixXd Qf = 10.0 * Q;
+        s.Qfull = Q; s.Rfull = R; s.Qffull = Qf;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
@@ -395,7 +412,10 @@ static Built build(const Scenario& s, int iterations)
         const double qv[4] = {1.0, 0.5, 0.2, 0.1}, rv[3] = {0.1, 0.2, 0.05};
         for (int i = 0; i < s.nx; ++i) q[i] = qv[i];
         for (int i = 0; i < s.nu; ++i) r[i] = rv[i];
-        Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal(), Qf = 10.0 * Q;
+        Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
+        if (s.fullq) { Q = fullWeight(Q); R = fullWeight(R); }
+        Eigen::MatrixXd Qf = 10.0 * Q;
+        s.Qfull = Q; s.Rfull = R; s.Qffull = Qf;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(s.nu, -1.5), Eigen::VectorXd::Constant(s.nu, 1.5));
@@ -407,7 +427,9 @@ static Built build(const Scenario& s, int iterations)
         for (int i = 0; i < s.nx; ++i) q[i] = qv[i];
         Eigen::MatrixXd Q = q.asDiagonal();
         Eigen::MatrixXd R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        if (s.fullq) Q = fullWeight(Q);
         Eigen::MatrixXd Qf = 10.0 * Q;
+        s.Qfull = Q; s.Rfull = R; s.Qffull = Qf;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         b.ocp->setControlBounds(Eigen::VectorXd::Constant(1, -1.5), Eigen::VectorXd::Constant(1, 1.5));
@@ -679,6 +701,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("cost")) s.cost = kv["cost"];
     if (kv.count("last_n")) s.last_n = atoi(kv["last_n"].c_str());
     if (kv.count("lsq")) s.nonlsq = atoi(kv["lsq"].c_str()) == 0;
+    if (kv.count("fullq")) s.fullq = atoi(kv["fullq"].c_str()) != 0;
     if (kv.count("integral")) s.integral = kv["integral"];
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
@@ -691,6 +714,17 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         s.tball_s     = kv.count("tball_s") ? vec(kv["tball_s"]) : Eigen::VectorXd::Ones(s.nx);
     }
     return s;
+}
+
+// the upper Cholesky factor exactly as QuadraticFormCost::setWeightQ keeps it (quadratic_cost.cpp:52-54), row-major
+static void printFactor(const char* name, const Eigen::MatrixXd& W)
+{
+    Eigen::LLT<Eigen::MatrixXd, Eigen::Upper> chol(W);
+    const Eigen::MatrixXd U = chol.matrixU();
+    printf("\"%s\": [", name);
+    for (int i = 0; i < U.rows(); ++i)
+        for (int j = 0; j < U.cols(); ++j) printf("%s%.17g", (i + j) ? ", " : "", U(i, j));
+    printf("],\n");
 }
 
 static int dump(const Scenario& s)
@@ -738,6 +772,13 @@ static int dump(const Scenario& s)
         printVec("param_ub", ub);
         printVec("vertex_init", vertexValues(b, s));
         printReferences(b, s);
+        if (s.fullq)
+        {
+            printf("\"fullq\": 1,\n");
+            printFactor("q_sqrt", s.Qfull);
+            if (s.nu > 1) printFactor("r_sqrt", s.Rfull);
+            printFactor("qf_sqrt", s.Qffull);
+        }
         // stacked residual exactly as LevenbergMarquardtSparse::computeValues (levenberg_marquardt_sparse.cpp:222-246)
         Eigen::VectorXd values(m);
         if (lsq) hg.computeValuesLsqObjective(values.segment(0, lsq));
@@ -1044,6 +1085,13 @@ static int hess(const Scenario& s)
     printf("\"n\": %d, \"eq\": %d, \"ineq\": %d, \"bounds\": %d,\n", n, eq, ineq, hg.finiteCombinedBoundsDimension());
     printVec("vertex_point", vertexValues(b, s));
     printReferences(b, s);
+    if (s.fullq)
+    {
+        printf("\"fullq\": 1,\n");
+        printFactor("q_sqrt", s.Qfull);
+        if (s.nu > 1) printFactor("r_sqrt", s.Rfull);
+        printFactor("qf_sqrt", s.Qffull);
+    }
     Eigen::VectorXd meq(eq), mineq(ineq);
     for (int i = 0; i < eq; ++i) meq[i] = 0.5 + 0.25 * std::cos(0.7 * i);
     for (int i = 0; i < ineq; ++i) mineq[i] = 0.3 + 0.125 * (i % 5);

@@ -100,6 +100,12 @@ def desc_for(g):
     if g.get("teq"):            # TerminalEqualityConstraint(xf)
         d.final_eq = 1
     cost_option(d)
+    if g.get("fullq"):          # non-diagonal weights: the reference's upper Cholesky factors as the fixture records them
+        nx, nu = d.nx, d.nu
+        d.weights_dense = 5 | (2 if "r_sqrt" in g else 0)
+        for i, v in enumerate(g["q_sqrt"]): d.q_sqrt[i] = v
+        for i, v in enumerate(g["qf_sqrt"]): d.qf_sqrt[i] = v
+        for i, v in enumerate(g.get("r_sqrt", [])): d.r_sqrt[i] = v
     if "ball" in g:             # BallKeepOut stage inequality
         d.stage_ineq = capi.INEQ_BALL
         for i, v in enumerate(g["ball"]):

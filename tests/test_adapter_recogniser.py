@@ -93,5 +93,9 @@ def test_plain_and_integral_cost_forms_are_recognised(described):
 
 
 def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):
+    # (unicycle_fullq -- non-diagonal Q, R, Qf -- is described since round 3: its weights are identified as upper Cholesky factors and the
+    #  describe mode, which runs without a device, stops at the user dynamics class that is fingerprinted ON the device)
     f = described["unicycle_fullq"]
-    assert f["recognised"] == 0 and "non-diagonal" in f["reason"]
+    assert f["recognised"] == 0 and "system dynamics class" in f["reason"]
+    u = described["unicycle_uref"]
+    assert u["recognised"] == 0 and "least-squares term" in u["reason"]

@@ -30,8 +30,8 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # linear state-space model on the shooting grid -- all recognised from the graph; then the stated-model override
     # ... and a time-varying state reference (DiscreteTimeReferenceTrajectory): one reference per cost edge, corbo_hip_set_references
     assert [r["scenario"] for r in solved] == ["unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum",
-                                              "toy", "artstein", "cartpole", "par2", "unicycle"], (p.stdout, p.stderr)
-    assert [r["mode"] for r in solved] == ["recognised"] * 19 + ["stated"]   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
+                                              "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "unicycle"], (p.stdout, p.stderr)
+    assert [r["mode"] for r in solved] == ["recognised"] * 20 + ["stated"]   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
     # unicycle_tballc: TerminalBallInheritFromCost; dint_mtq8: MinTimeQuadratic with only_last_n)
     for r in solved:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, (r, p.stderr[-2000:])
@@ -43,14 +43,15 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # of the same graphs, against the graph's own computeSparseHessians{NNZ,Structure,Values}: identical lists, values within the
     # reference's own consecutive-call spread (tests/test_gpu_hessian.py)
     assert [r["scenario"] for r in hessian] == ["unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy",
-                                               "cartpole", "par2", "unicycle_plain", "unicycle_itrap", "unicycle_ileft",
+                                               "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft",
                                                "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"], p.stdout   # (the last seven: graphs with plain / integral
     # objective edges, the IPOPT-style cost forms -- recognised, one of them with a stated model)
     for r in hessian:
         assert r["ok_hip"] == 1 and r["structure_equal"] == 1 and r["nnz"][1] > 0 and r["max_rel_diff"] <= 2e-4, r
     # a stated model with a wrong CONTROL weight -- invisible in the residual at the reference's initial guess u = 0 -- is refused by the
-    # perturbed probe (residual + Jacobian); a graph with a non-diagonal Q is refused by the recogniser.  Never silently solved.
-    assert refused["unicycle_mismatch"]["ok_hip"] == 0 and refused["unicycle_fullq"]["ok_hip"] == 0, refused
+    # perturbed probe (residual + Jacobian); a graph with a non-zero control reference is refused by the recogniser.  Never silently solved.
+    # (unicycle_fullq -- non-diagonal Q, R, Qf -- was refused until round 3: it is solved above now)
+    assert refused["unicycle_mismatch"]["ok_hip"] == 0 and refused["unicycle_uref"]["ok_hip"] == 0, refused
     assert "does not describe this hypergraph" in p.stdout + p.stderr
     assert "has no device description" in p.stdout + p.stderr
     assert p.returncode == 0

@@ -39,7 +39,9 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein", "duffing_midpoint", "rocket_forward", "toy_backward", "pendulum_ms_rk4", "mpendulum_ms_rk4", "rocket_ms_rk4", "artstein_ms_rk4",
         "cartpole", "cartpole_midpoint", "cartpole_ms_rk4", "cartpole_patterns", "cartpole_tball", "cartpole_teq",
         "par2", "par3", "par2_ms_rk4", "par3_forward",
-        "lin21", "lin22", "lin31", "lin32", "lin33", "lin41"]
+        "lin21", "lin22", "lin31", "lin32", "lin33", "lin41",
+        # NON-DIAGONAL Q / R / Qf (dense cost blocks; these handles run the phases as separate launches)
+        "unicycle_n12_fullq", "vdp_fullq", "unicycle_n12_fullq_patterns", "unicycle_n12_fullq_ms", "cartpole_fullq", "par3_fullq", "lin33_fullq"]
 # reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
 # with x0 one ulp apart differs by 5e-5 .. 1.1e-4 there while chi2 agrees to 1e-9 (tests/test_oracle_fullsize.py demonstrates it on the
 # reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility

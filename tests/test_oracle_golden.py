@@ -22,7 +22,9 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "duffing", "rocket", "pendulum", "mpendulum", "toy", "artstein", "duffing_midpoint", "rocket_forward", "toy_backward", "pendulum_ms_rk4", "mpendulum_ms_rk4", "rocket_ms_rk4", "artstein_ms_rk4",
         "cartpole", "cartpole_midpoint", "cartpole_ms_rk4", "cartpole_patterns", "cartpole_tball", "cartpole_teq",
         "par2", "par3", "par2_ms_rk4", "par3_forward",
-        "lin21", "lin22", "lin31", "lin32", "lin33", "lin41"]
+        "lin21", "lin22", "lin31", "lin32", "lin33", "lin41",
+        # NON-DIAGONAL Q / R / Qf: upper Cholesky factors, dense cost blocks (quadratic_cost.cpp:36-55, 100-184)
+        "unicycle_n12_fullq", "vdp_fullq", "unicycle_n12_fullq_patterns", "unicycle_n12_fullq_ms", "cartpole_fullq", "par3_fullq", "lin33_fullq"]
 
 # The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
 # along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.

@@ -13,11 +13,12 @@ import scipy.sparse as sp
 from conftest import desc_for, load_golden
 from control_box_rst_amd import capi
 
-TVREF = ["unicycle_n12_tvref", "vdp_tvref", "unicycle_n12_tball_tvref", "vdp_teq_tvref", "pendulum_ms_rk4_tvref", "quad_n10_tvref"]
+TVREF = ["unicycle_n12_tvref", "vdp_tvref", "unicycle_n12_tball_tvref", "vdp_teq_tvref", "pendulum_ms_rk4_tvref", "quad_n10_tvref",
+         "unicycle_n12_fullq_tvref"]   # non-diagonal weights against a time-varying reference
 # unicycle_n12_tvref: the start (x_k = xref_k, u = 0) is far from feasible -- chi2 3080 -> 2158 -> 55 in the first steps -- and the k = 1
 # iterate agrees to 1e-12; from there the finite-difference noise amplifies the few-ulp difference of the
 # start (the fixture's vertex_init carries the drift of one in-place sweep) to 1e-5 at k = 6 with chi2 equal to 2e-8 relative
-X_TOL = {"quad_n10_tvref": 3e-4, "pendulum_ms_rk4_tvref": 5e-5, "unicycle_n12_tvref": 3e-5, "unicycle_n12_tball_tvref": 3e-5}
+X_TOL = {"quad_n10_tvref": 3e-4, "pendulum_ms_rk4_tvref": 5e-5, "unicycle_n12_tvref": 3e-5, "unicycle_n12_tball_tvref": 3e-5, "unicycle_n12_fullq_tvref": 3e-5}
 CHI2_RTOL = {"pendulum_ms_rk4_tvref": 2e-5}
 
 

@@ -1,3 +1,1 @@
-export CORBO_HIP_LIB=$PWD/control_box_rst_amd/csrc/libcorbo_hip_dev.so
-python tools/opt_probe.py lag_priority=0 lag_priority=1 lag_priority=0 lag_priority=1 2>&1 | grep -v amdgpu.ids
-for i in 900; do OPTS=lag_priority=1 python tools/pass_timeline.py $i 1024 2>&1 | grep "pass timeline\|priority"; done
+timeout 1500 python -m pytest tests/test_gpu_dropin.py tests/test_adapter_recogniser.py -m gpu -q -x 2>&1 | tail -6
