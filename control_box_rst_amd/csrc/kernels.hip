@@ -20,6 +20,8 @@ namespace corbo_hip {
 namespace {
 
 constexpr int SWEEP_THREADS = 256;
+constexpr int LONG_HORIZON = 256;   // grid points beyond which the small-block families switch to the long-horizon kernels (up to LONG_HORIZON_MAX)
+constexpr int LONG_HORIZON_MAX = 1024;
 constexpr double LM_EPS1 = 1e-5, LM_EPS2 = 1e-5, LM_EPS3 = 1e-5, LM_EPS4 = 0.0, LM_TAU = 1e-5;  // levenberg_marquardt_sparse.cpp:103-110
 constexpr int LM_MAX_INNER = 64;  // guard against an endless reject loop (the reference would spin)
 
@@ -131,7 +133,10 @@ __device__ __forceinline__ double dense_weight_row(const double* U, int c, int d
 // DENSE: the descriptor has non-diagonal weights (corbo_hip_problem_desc::weights_dense).  A compile-time switch, instantiated for the
 // stand-alone kernels only (such handles run the phases as separate launches): inside the fused run-to-completion kernel even the
 // never-taken branches cost the headline path a third of its speed (register allocation: 44 -> 82 spilled VGPRs, measured).
-template <int DYN, int DEFECT, bool FUSED, bool DENSE = false>
+// LONG: horizons beyond 256 grid points (up to 1024; FiniteDifferencesVariableGrid's default n_max is 1000,
+// finite_differences_variable_grid.h:82): the Jacobian of such an instance does not fit the LDS staging area, its entries go straight
+// to HBM like the big-block family's (STAGE = false).  Stand-alone kernels only.
+template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false)
 {
     using Dy          = Dynamics<DYN>;
@@ -141,7 +146,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
     constexpr int NC  = Dy::NC;
     constexpr bool CACHED = DefectTraits<DEFECT>::cached;
-    constexpr bool STAGE  = (NX <= 6);  // small models: Jacobian assembled in LDS and streamed out; big ones: stored column by column
+    constexpr bool STAGE  = (NX <= 6) && !LONG;  // small models: Jacobian assembled in LDS and streamed out; big ones / long horizons: stored column by column
     double* js  = p.jac + (size_t)inst * p.nnz_pad;  // Jacobian values of this instance (HBM)
     if constexpr (!STAGE) jst = js;
     int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
@@ -790,7 +795,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
 }
 
-template <int DYN, int DEFECT, bool DENSE = false>
+template <int DYN, int DEFECT, bool DENSE = false, bool LONG = false>
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -798,10 +803,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* red = smem + p.nvs;
     double* cs  = red + 10;
     double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
-    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 6) ? p.nnz_pad : 0));
+    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 6 && !LONG) ? p.nnz_pad : 0));
     const int inst = blockIdx.x + p.inst0;
     if (p.st) { lm_state_in(sl, p.st + inst, threadIdx.x); __syncthreads(); }
-    sweep_body<DYN, DEFECT, false, DENSE>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
+    sweep_body<DYN, DEFECT, false, DENSE, LONG>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
     if (p.st && p.mode >= 2) { __syncthreads(); lm_state_out(p.st + inst, sl, threadIdx.x); }
 }
 
@@ -1093,7 +1098,10 @@ __device__ __noinline__ void dense_cost_terms(const StageCols*, const CompInfo* 
 // workgroup); otherwise they are staged from HBM first.
 // NPC > 0: the padded block count N | 1 as a compile-time constant (LDS element strides become immediate offsets of the DS
 // instructions instead of two VALU operations per access); 0: taken from the launch parameters.
-template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false>
+// GWS: the factor workspace (`smem`) is a per-instance array in HBM instead of LDS, and the Jacobian is read from HBM in place -- the
+// long-horizon variant (256 < N <= 1024, one lane per stage in a 1024-thread workgroup; 45 N doubles do not fit 160 KB of LDS then).
+// Same code, the barriers become full workgroup barriers (global memory crosses them).
+template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false>
 __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr)
 {
     constexpr int S  = NX + NU;
@@ -1101,6 +1109,11 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     constexpr int NT = NX * (NX + 1) / 2;
     const int N  = p.N;
     const int NP = NPC > 0 ? NPC : (N | 1);
+    auto fb_barrier = [] {
+        if constexpr (GWS) __syncthreads();   // workspace in HBM: the stores of every wave are visible behind the barrier
+        else lds_barrier();
+    };
+    constexpr int REDN = GWS ? 8 * (THREADS / 64) : FactorLds<NX, NU>::RED;   // reduction scratch: 5 doubles per wave
     // SoA arrays, element-major: arr[e][block].  Per state block: D/L (packed lower), W_a, W_b, rhs/y/x; per stage: the
     // eliminated controls.  Slots of block k+1 double as the mailbox for what stage k contributes to it.
     double* Luu = smem;                    // NU*NU   L_uu (diag inverted)
@@ -1112,13 +1125,13 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     double* Wbm = Wam + NX * NX * NP;      // NX*NX   W_b = L_i^{-1} H(i, i+h)
     double* gv  = Wbm + NX * NX * NP;      // NX      rhs -> y -> delta x
     double* red = gv + NX * NP;            // 24
-    double* zu  = red + FactorLds<NX, NU>::RED;  // NU  (arrowhead only from here on)
+    double* zu  = red + REDN;  // NU  (arrowhead only from here on)
     double* bv  = zu + NU * NP;            // NX      border column -> z
     const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
     const int stop_in = st->stop;
     double mu = st->mu;
     const double mu_acc_in = st->mu_acc;
-    lds_barrier();
+    fb_barrier();
     if (done) return;
     STAMP(0);
 
@@ -1175,8 +1188,8 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (int i = 0; i < NX; ++i) r[i] = 0.0;
     }
     // (3) Jacobian staging
-    const double* J = smem;
-    if (!j_in_lds) {
+    const double* J = GWS ? p.jac + (size_t)inst * p.nnz_pad : smem;
+    if (!GWS && !j_in_lds) {
         const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
         double2* dst       = reinterpret_cast<double2*>(smem);
         const int n2       = p.nnz_pad / 2;
@@ -1189,7 +1202,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int u = 0; u < UNR; ++u) { const int i = i0 + u * THREADS; dst[i < n2 ? i : n2 - 1] = v[u]; }
         }
     }
-    lds_barrier();
+    fb_barrier();
     // (4) per-stage gathers from the staging area
     double A[NX][NX], B[NX][NU], Cc[NX][NX], dc[NX];
 #pragma unroll
@@ -1254,7 +1267,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; cdt += a * a; gdt -= a * val[ci.bnd_row]; }
         }
     }
-    lds_barrier();  // every lane has taken its Jacobian entries out of the staging area
+    fb_barrier();  // every lane has taken its Jacobian entries out of the staging area
     STAMP(1);
 
     // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
@@ -1268,7 +1281,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int q = 0; q < NX; ++q) { dd += Cc[q][i] * Cc[q][i]; gg -= Cc[q][i] * r[q]; }
             if (has_stage) { SOA(Wbm, i, k) = dd; SOA(Wbm, NX + i, k) = gg; }
         }
-        lds_barrier();
+        fb_barrier();
         double mx_d = -1e300, mx_g = 0;
 #pragma unroll
         for (int j = 0; j < NU; ++j)
@@ -1295,13 +1308,13 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         mx_g = wave_max(mx_g);
         double sc_ = wave_sum(cdt), sg_ = wave_sum(gdt);
         if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = mx_d; red[(tid >> 6) * 4 + 1] = mx_g; red[(tid >> 6) * 4 + 2] = sc_; red[(tid >> 6) * 4 + 3] = sg_; }
-        lds_barrier();
+        fb_barrier();
         double s_cdt = 0, s_gdt = 0;
         mx_d = red[0]; mx_g = red[1]; s_cdt = red[2]; s_gdt = red[3];
 #pragma unroll
         for (int w = 1; w < NW; ++w) { mx_d = fmax(mx_d, red[w * 4]); mx_g = fmax(mx_g, red[w * 4 + 1]); s_cdt += red[w * 4 + 2]; s_gdt += red[w * 4 + 3]; }
         if (ARROW) { mx_d = fmax(mx_d, s_cdt); mx_g = fmax(mx_g, fabs(s_gdt)); }
-        lds_barrier();
+        fb_barrier();
         stop = (mx_g <= LM_EPS1) ? 1 : 0;
         mu   = LM_TAU * mx_d;
         if (mu < 0) mu = 0;
@@ -1394,7 +1407,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             }
         }
     }
-    lds_barrier();
+    fb_barrier();
     STAMP(2);
     // ---- phase B + cyclic-reduction level 0: complete state block k; odd blocks are eliminated at once
     if (has_block) {
@@ -1451,7 +1464,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int j = 0; j <= i; ++j) SOA(Dm, TRI(i, j), k) = Dk[i][j];
         }
     }
-    lds_barrier();
+    fb_barrier();
     STAMP(3);
 
     // ---- cyclic reduction, levels h = 2, 4, ...: lane t owns the active block a = h*t.  It first applies the Schur updates of
@@ -1603,7 +1616,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         }
         hroot = h;
         if (h >= N) break;
-        lds_barrier();
+        fb_barrier();
     }
     STAMP(4);
     // ---- reductions: |y|^2 (= delta^T rhs), and for the arrowhead the last pivot
@@ -1612,7 +1625,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         double a0 = wave_sum(y2), a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         if constexpr (ARROW) { a1 = wave_sum(zz); a2 = wave_sum(zy); a3 = wave_sum(cdt); a4 = wave_sum(gdt); }
         if ((tid & 63) == 0) { double* rr = red + (tid >> 6) * 5; rr[0] = a0; rr[1] = a1; rr[2] = a2; rr[3] = a3; rr[4] = a4; }
-        lds_barrier();
+        fb_barrier();
         a0 = a1 = a2 = a3 = a4 = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { a0 += red[w * 5]; a1 += red[w * 5 + 1]; a2 += red[w * 5 + 2]; a3 += red[w * 5 + 3]; a4 += red[w * 5 + 4]; }
@@ -1632,7 +1645,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         if (has_stage)
 #pragma unroll
             for (int a = 0; a < NU; ++a) SOA(yu, a, k) -= SOA(zu, a, k) * ddt;
-        lds_barrier();
+        fb_barrier();
         if (tid == 0) {
             double L[NX][NX], y[NX];
 #pragma unroll
@@ -1645,7 +1658,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 #pragma unroll
             for (int q = 0; q < NX; ++q) SOA(gv, q, 0) = y[q];
         }
-        lds_barrier();
+        fb_barrier();
     }
     STAMP(5);
     // the accepted iterate of this lane's stage (for x + delta below): requested now, the back-substitution hides the latency
@@ -1698,7 +1711,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (; h >= 1; h >>= 1) {
             if (h * (2 * (tid >> 2) + 1) < N) finish(h, tid >> 2);
             for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }  // long horizons
-            lds_barrier();
+            fb_barrier();
             if (h > 1) fetch(h >> 1, tid >> 2);
         }
     }
@@ -1745,9 +1758,9 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     }
     {
         double a0 = wave_sum(dn2);
-        lds_barrier();
+        fb_barrier();
         if ((tid & 63) == 0) red[tid >> 6] = a0;
-        lds_barrier();
+        fb_barrier();
         if (tid == 0) {
             dn2 = 0;
 #pragma unroll
@@ -1768,6 +1781,24 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         }
     }
     STAMP(7);
+}
+
+// long horizons: the same phases with the workspace in HBM (FactorParams::work), one lane per stage in a 1024-thread workgroup
+template <int NX, int NU, bool ARROW>
+__global__ __launch_bounds__(1024) void factor_long_kernel(const FactorParams p)
+{
+    __shared__ __attribute__((aligned(16))) LmState sl_;
+    const int inst = blockIdx.x + p.inst0;
+    lm_state_in(&sl_, p.st + inst, threadIdx.x);
+    __syncthreads();
+    factor_body<NX, NU, 1024, ARROW, 0, false, true>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
+    __syncthreads();
+    lm_state_out(p.st + inst, &sl_, threadIdx.x);
+}
+template <int NX, int NU>
+__host__ __device__ constexpr size_t factor_long_work_doubles(int N, bool arrow)
+{
+    return (size_t)FactorLds<NX, NU>::off_red(N | 1) + 8 * 16 + (arrow ? (size_t)(NU + NX) * (N | 1) : 0) + 2;
 }
 
 template <int NX, int NU, int THREADS, bool ARROW, bool DENSE = false>
@@ -3062,6 +3093,10 @@ template <int DYN, int DEFECT>
 void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 {
     if constexpr (Dynamics<DYN>::NX <= 4) {
+        if (p.N > LONG_HORIZON) {   // long horizon: Jacobian straight to HBM (non-diagonal weights are refused for those at create time)
+            hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+            return;
+        }
         if (p.mp.wdense) {   // non-diagonal weights: the DENSE instantiation
             hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
@@ -3514,6 +3549,11 @@ bool launch_factor_a(const FactorParams& p, hipStream_t stream)
     size_t lds = factor_lds<NX, NU>(p.N, ARROW);
     if (lds < sizeof(double) * (size_t)p.nnz_pad) lds = sizeof(double) * (size_t)p.nnz_pad;  // Jacobian staging area
     lds = ((lds + 15) & ~(size_t)15) + sizeof(LmState);                                      // + LM state
+    if (p.N > LONG_HORIZON) {   // long horizon: workspace in HBM
+        if (p.N > LONG_HORIZON_MAX || p.wdense_mask || !p.work) return false;
+        hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW>), dim3(p.batch), dim3(1024), 0, stream, p);
+        return true;
+    }
     if (p.wdense_mask) {   // non-diagonal weights: the DENSE instantiation
         if (p.N <= 128) hipLaunchKernelGGL((factor_kernel<NX, NU, 128, ARROW, true>), dim3(p.batch), dim3(128), lds, stream, p);
         else if (p.N <= 256) hipLaunchKernelGGL((factor_kernel<NX, NU, 256, ARROW, true>), dim3(p.batch), dim3(256), lds, stream, p);
@@ -3765,13 +3805,22 @@ size_t sweep_lds_bytes(const SweepParams& p, int nc)
 {
     // vertex values + reduction scratch + dynamics caches + Jacobian staging; the headline family must stay below 40 KB so that
     // four workgroups share a CU (1024 instances = one round over 256 CUs)
-    const size_t stage = (p.nx <= 6) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
+    const size_t stage = (p.nx <= 6 && p.N <= LONG_HORIZON) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
     return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage) + sizeof(LmState);
 }
 
 size_t factor_work_doubles(const corbo_hip_problem_desc& d)
 {
     if (d.nx == 12 && d.nu == 4) return (size_t)d.N * BigLds<12, 4>::WS_STAGE;
+    if (d.N > LONG_HORIZON && d.N <= LONG_HORIZON_MAX) {   // small-block families, long horizon: the factor carve lives in HBM
+        const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE || d.grid == CORBO_HIP_GRID_MS_VARIABLE);
+        if (d.nx == 2 && d.nu == 1) return factor_long_work_doubles<2, 1>(d.N, arrow);
+        if (d.nx == 3 && d.nu == 2) return factor_long_work_doubles<3, 2>(d.N, arrow);
+        if (d.nx == 3 && d.nu == 1) return factor_long_work_doubles<3, 1>(d.N, arrow);
+        if (d.nx == 4 && d.nu == 1) return factor_long_work_doubles<4, 1>(d.N, arrow);
+        if (d.nx == 2 && d.nu == 2) return factor_long_work_doubles<2, 2>(d.N, arrow);
+        if (d.nx == 3 && d.nu == 3) return factor_long_work_doubles<3, 3>(d.N, arrow);
+    }
     return 0;
 }
 

@@ -105,6 +105,9 @@ def adapt():
         ("mpc_dint_adapt_shrink_init", dict(iters=0, adapt="shrink", nmin=44)),
         ("mpc_dint_adapt_single", dict(iters=5, adapt="single", nmax=80, hyst=0.1, steps=6)),
         ("mpc_dint_adapt_aggressive", dict(iters=5, adapt="aggressive", nmax=80, hyst=0.1, steps=4)),
+        # grids that grow past 256 points (the LDS-resident kernels' limit: beyond it the long-horizon kernels take over): one jump, and point by point
+        ("mpc_dint_adapt_cross256_aggressive", dict(iters0=6, iters=3, adapt="aggressive", N=250, dt=0.007, nmax=300, hyst=0.05, steps=3)),
+        ("mpc_dint_adapt_cross256_single", dict(iters0=6, iters=3, adapt="single", N=255, dt=0.007, nmax=300, hyst=0.05, steps=2)),
         # the same on the MultipleShootingVariableGrid (multiple_shooting_variable_grid.cpp:58-152 -> ShootingGridBase::resampleTrajectory,
         # shooting_grid_base.cpp:473-547)
         ("mpc_dint_ms_adapt_single_init", dict(grid="ms", iters=0, adapt="single", nmax=80, hyst=0.02, dt=0.06)),

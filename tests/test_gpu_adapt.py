@@ -43,7 +43,8 @@ def test_resample_into_vs_oracle_bit_exact(oracle_mod, n_dst, shooting):
         assert np.array_equal(Z[1], X[4]) and np.array_equal(Z[0], X[0])
 
 
-@pytest.mark.parametrize("name", ["mpc_dint_adapt_single", "mpc_dint_adapt_aggressive", "mpc_dint_ms_adapt_single", "mpc_dint_ms_adapt_aggressive",
+@pytest.mark.parametrize("name", ["mpc_dint_adapt_cross256_aggressive", "mpc_dint_adapt_cross256_single",   # the grid grows past 256 points: long-horizon kernels
+                                  "mpc_dint_adapt_single", "mpc_dint_adapt_aggressive", "mpc_dint_ms_adapt_single", "mpc_dint_ms_adapt_aggressive",
                                   "mpc_dint_ms_adapt_aggressive_collapse"])
 def test_adaptive_controller_on_the_device_vs_reference(name):
     g = load_golden(name)

@@ -165,7 +165,8 @@ def test_values_jacobian_vs_oracle_batch(oracle_mod):
         assert np.array_equal(jac[b][-s.dims.bounds:], jo[-s.dims.bounds:])  # bound rows: exactly -w / 0 / +w
 
 
-@pytest.mark.parametrize("scenario,N", [("unicycle", 129), ("unicycle", 160), ("unicycle", 256), ("vdp", 250), ("dint", 200),
+@pytest.mark.parametrize("scenario,N", [("unicycle", 300), ("unicycle", 512), ("unicycle", 1000), ("dint", 400), ("vdp", 1024),   # long-horizon kernels (N > 256)
+                                        ("unicycle", 129), ("unicycle", 160), ("unicycle", 256), ("vdp", 250), ("dint", 200),
                                         ("unicycle", 3), ("unicycle", 64), ("unicycle", 101)])
 def test_horizon_lengths_vs_oracle(oracle_mod, scenario, N):
     """Horizons other than the headline's: more stages than half a workgroup (the residual is not split over the waves, the

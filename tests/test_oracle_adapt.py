@@ -12,7 +12,7 @@ STRATEGY = {"single": 1, "aggressive": 2, "shrink": 3}
 # *_ms_*: the same on the MultipleShootingVariableGrid (multiple_shooting_variable_grid.cpp:58-152, shooting_grid_base.cpp:473-547)
 INIT = ["mpc_dint_adapt_single_grow_init", "mpc_dint_adapt_single_shrink_init", "mpc_dint_adapt_aggressive_init", "mpc_dint_adapt_shrink_init",
         "mpc_dint_ms_adapt_single_init", "mpc_dint_ms_adapt_shrink_init"]
-FULL = ["mpc_dint_adapt_single", "mpc_dint_adapt_aggressive", "mpc_dint_ms_adapt_single", "mpc_dint_ms_adapt_aggressive",
+FULL = ["mpc_dint_adapt_cross256_aggressive", "mpc_dint_adapt_cross256_single", "mpc_dint_adapt_single", "mpc_dint_adapt_aggressive", "mpc_dint_ms_adapt_single", "mpc_dint_ms_adapt_aggressive",
         "mpc_dint_ms_adapt_aggressive_collapse"]
 
 
