@@ -141,6 +141,9 @@ struct corbo_hip_solver {
     int32_t* d_counters   = nullptr;  // MAX_PASSES
     int32_t* h_counter    = nullptr;  // pinned
     int m_pad = 0, nnz_pad = 0;
+    std::vector<int32_t> jmap;        // public Jacobian value index -> device-internal index (see corbo_hip_create)
+    int nnz_int = 0;                  // values of the device-internal layout (pads included)
+    int32_t fin_joff_dev[CORBO_HIP_MAX_NX];
     bool have_data = false;
     double w_eq = 2, w_ineq = 2, w_b = 2;  // current penalty weights (levenberg_marquardt_sparse.h:126-128)
     corbo_hip_stats stats{};
@@ -183,7 +186,7 @@ struct corbo_hip_solver {
         std::memcpy(p.mp.fin, S.desc.final_ineq_params, sizeof(p.mp.fin));
         p.mp.wdense = d_wdense; p.mp.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         p.fin_row = S.fin_row;
-        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
+        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
         p.dt_fixed = S.desc.dt_ref;
         p.mode = mode; p.iterations = iterations; p.w_eq = weq; p.w_ineq = wineq; p.w_b = wb;
         p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
@@ -200,7 +203,7 @@ struct corbo_hip_solver {
         p.eq_row0 = S.eq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols; p.ineq_rows = d_ineq_rows;
         p.fin_row = S.fin_row;
-        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = (i < S.nx) ? S.fin_joff[i] : -1;
+        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
         p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
@@ -313,11 +316,35 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     }
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_chk[1], hipEventDisableTiming));
-    if (upload(S.stage_cols, &h->d_stage_cols) || upload(S.comp, &h->d_comp) || upload(S.ineq_cols, &h->d_ineq_cols) ||
-        upload(S.ineq_rows, &h->d_ineq_rows))
-        return CORBO_HIP_ERR_DEVICE;  // message set by upload()
+    // Device-internal Jacobian value layout (small-block families): the public value order (corbo_hip_get_structure) with ONE pad double in
+    // front of every defect edge's block.  The blocks of consecutive stages are then 25 / 19 / ... doubles apart instead of 24 / 18 / ...: a
+    // stride of 24 doubles maps the 32 lanes of an LDS access (one lane per stage) onto 4 bank groups -- 8-way conflicts on every gather of
+    // the factor phase and every scatter of the sweep phase (SQ_LDS_BANK_CONFLICT: 31 % of the solve kernel's LDS cycles) -- an odd stride
+    // spreads them over all banks.  Only the offset tables change; corbo_hip_eval maps the values back to the public order.
+    {
+        const bool pad_layout = (S.nx <= 6);
+        const int nnz = S.dims.nnz;
+        h->jmap.resize(nnz);
+        for (int i = 0; i < nnz; ++i) {
+            const int row = S.jac_rows[i];
+            int pad = 0;
+            if (pad_layout && row >= S.eq_row0) { pad = (row - S.eq_row0) / S.nx + 1; if (pad > S.N) pad = S.N; }
+            h->jmap[i] = i + pad;
+        }
+        auto mp = [&](int o) { return o < 0 ? o : h->jmap[o]; };
+        std::vector<StageCols> sc = S.stage_cols;
+        for (auto& c : sc) for (int& o : c.col) o = mp(o);
+        std::vector<CompInfo> ci = S.comp;
+        for (auto& c : ci) { c.cost_joff = mp(c.cost_joff); c.bnd_joff = mp(c.bnd_joff); c.cost2_joff = mp(c.cost2_joff); }
+        std::vector<int32_t> ic = S.ineq_cols;
+        for (int32_t& o : ic) o = mp(o);
+        for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) h->fin_joff_dev[i] = (i < S.nx) ? mp(S.fin_joff[i]) : -1;
+        h->nnz_int = nnz ? h->jmap[nnz - 1] + 1 : 0;
+        if (upload(sc, &h->d_stage_cols) || upload(ci, &h->d_comp) || upload(ic, &h->d_ineq_cols) || upload(S.ineq_rows, &h->d_ineq_rows))
+            return CORBO_HIP_ERR_DEVICE;  // message set by upload()
+    }
     h->m_pad   = (S.dims.m + 1) & ~1;
-    h->nnz_pad = (S.dims.nnz + 1) & ~1;
+    h->nnz_pad = (h->nnz_int + 1) & ~1;
     const size_t B = (size_t)batch;
     CREATE_TRY(hipMalloc((void**)&h->d_x, B * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xt, B * S.nvs * sizeof(double)));
@@ -1250,7 +1277,11 @@ try {
     if (jac_out) {
         buf.resize((size_t)B * h->nnz_pad);
         HIP_TRY(hipMemcpy(buf.data(), h->d_jac, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; ++b) std::memcpy(jac_out + (size_t)b * S.dims.nnz, &buf[(size_t)b * h->nnz_pad], S.dims.nnz * sizeof(double));
+        for (int b = 0; b < B; ++b) {   // device-internal layout -> public value order
+            const double* src = &buf[(size_t)b * h->nnz_pad];
+            double* dst       = jac_out + (size_t)b * S.dims.nnz;
+            for (int i = 0; i < S.dims.nnz; ++i) dst[i] = src[h->jmap[i]];
+        }
     }
     return CORBO_HIP_OK;
 }

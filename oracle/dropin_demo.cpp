@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -102,6 +103,7 @@ struct Run
     Eigen::VectorXd traj;
     double chi2 = 0;
     bool ok     = false;
+    double us_per_compute = 0;   // timing mode (g_timing_repeats > 0): wall time of one more compute(new_run = true), averaged
     // Mode::Hessian: the exact-Hessian operators of the graph, device against the graph's own methods
     bool hess_ok = false, hess_struct = false;
     int hess_nnz[3] = {0, 0, 0};
@@ -163,6 +165,8 @@ class RecogniseOnly : public NlpSolverInterface
 };
 
 enum class Mode { Reference, HipAuto, HipStated, HipStatedWrong, Describe, Hessian };
+static int g_timing_repeats = 0;    // "timing" mode: this many extra compute(new_run = true) calls per run, timed
+static bool g_track_model = true;   // LevenbergMarquardtSparseHip::setTrackModel for those runs
 
 // scenarios: "unicycle" cfg 3 single instance; "dint" cfg 2 (free dt, 5 consecutive solves, new_run only first); "quad" reduced cfg 5;
 // "vdp" cfg 1; "unicycle_tball" TerminalBall; "duffing" / "pendulum" / "lin32": reference benchmark classes with NON-default parameters
@@ -420,6 +424,15 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     ReferenceTrajectoryInterface& uref = urefnz ? static_cast<ReferenceTrajectoryInterface&>(uref_nz) : static_cast<ReferenceTrajectoryInterface&>(uref_zero);
     r.ok = true;
     for (int i = 0; i < solves; ++i) r.ok = ocp.compute(x0, xref, uref, nullptr, Time(0), i == 0) && r.ok;
+    if (g_timing_repeats > 0 && r.ok)
+    {   // the controller's steady state: the same structure, a new run per control step (StructuredOptimalControlProblem::compute,
+        // structured_optimal_control_problem.cpp:77-154: grid update, solve, statistics)
+        if (auto hip = std::dynamic_pointer_cast<LevenbergMarquardtSparseHip>(solver)) hip->setTrackModel(g_track_model);
+        for (int i = 0; i < 20; ++i) ocp.compute(x0, xref, uref, nullptr, Time(0), true);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < g_timing_repeats; ++i) r.ok = ocp.compute(x0, xref, uref, nullptr, Time(0), true) && r.ok;
+        r.us_per_compute = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / g_timing_repeats;
+    }
     r.traj = trajectory(ocp, *any_grid);
     r.chi2 = ocp.getCurrentObjectiveValue();
     if (describe_out) *describe_out = *std::static_pointer_cast<RecogniseOnly>(solver);
@@ -487,6 +500,26 @@ int main(int argc, char** argv)
             RecogniseOnly rec;
             Run a = run(sc, Mode::Describe, horizon(sc), &rec);
             printDesc(sc.c_str(), a.ok && rec.ok, rec.why, rec.model);
+        }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "timing")
+    {   // single-OCP latency through the drop-in boundary: one compute() per control step, reference solver next to the
+        // HIP solver (model tracking on = the default: the recogniser runs once per new run; off = the caller vouches for the model)
+        std::vector<std::string> list;
+        for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
+        if (list.empty()) list = {"vdp", "dint", "unicycle"};
+        g_timing_repeats = 200;
+        for (const std::string& sc : list)
+        {
+            const int N = horizon(sc);
+            Run a = run(sc, Mode::Reference, N);
+            g_track_model = true;
+            Run b = run(sc, Mode::HipAuto, N);
+            g_track_model = false;
+            Run c = run(sc, Mode::HipAuto, N);
+            printf("{\"scenario\": \"%s\", \"mode\": \"timing\", \"N\": %d, \"us_per_compute_reference\": %.1f, \"us_per_compute_hip\": %.1f, \"us_per_compute_hip_untracked\": %.1f, "
+                   "\"ok\": %d}\n", sc.c_str(), N, a.us_per_compute, b.us_per_compute, c.us_per_compute, (a.ok && b.ok && c.ok) ? 1 : 0);
         }
         return 0;
     }

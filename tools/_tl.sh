@@ -1,2 +1,2 @@
-for w in 5 100 5 300; do python bench.py --steps 20 --warmup $w --no-cpu-baseline --solve-only 2>/dev/null | tail -1 | python -c "
-import json,sys; j=json.loads(sys.stdin.read()); print('warmup $w ms_per_step', j['ms_per_step'], j['value'])"; done
+python tools/opt_probe.py lag_priority=1 lag_priority=1 2>&1 | grep -v amdgpu.ids
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q -x -n 4 2>&1 | tail -5
