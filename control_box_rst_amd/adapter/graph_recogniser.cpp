@@ -636,8 +636,15 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         else if (auto* ms = dynamic_cast<MSVariableDynamicsOnlyEdge*>(e))
         {
             dk = member<MsEdgeDynamics>(*ms).get();
-            if (!dynamic_cast<IntegratorExplicitRungeKutta4*>(member<MsEdgeIntegrator>(*ms).get()))
-                return fail(reason, "shooting integrator other than IntegratorExplicitRungeKutta4");
+            NumericalIntegratorExplicitInterface* in = member<MsEdgeIntegrator>(*ms).get();
+            int integ = -1;
+            if (dynamic_cast<IntegratorExplicitRungeKutta4*>(in)) integ = 0;
+            else if (dynamic_cast<IntegratorExplicitEuler*>(in)) integ = 1;
+            else if (dynamic_cast<IntegratorExplicitRungeKutta2*>(in)) integ = 2;
+            else if (dynamic_cast<IntegratorExplicitRungeKutta3*>(in)) integ = 3;
+            else return fail(reason, "shooting integrator other than IntegratorExplicitEuler / RungeKutta2 / RungeKutta3 / RungeKutta4");
+            if (k > 0 && integ != d.shooting_integrator) return fail(reason, "shooting integrator varies along the horizon");
+            d.shooting_integrator = integ;
             defect = CORBO_HIP_DEFECT_RK4_SHOOTING;
         }
         else return fail(reason, "equality edge " + std::to_string(k) + " is neither an FDCollocationEdge nor an MSVariableDynamicsOnlyEdge");

@@ -165,6 +165,7 @@ struct corbo_hip_solver {
     void fill_dyn(double (&dyn)[8]) const
     {
         std::memcpy(dyn, S.desc.dyn_params, sizeof(dyn));
+        dyn[7] = (double)S.desc.shooting_integrator;   // slot 7: the shooting grids' integrator (model.hpp, rk4_end_state)
         if (S.desc.dynamics == CORBO_HIP_DYN_LINEAR_STATE_SPACE) {
             const long long bits = (long long)reinterpret_cast<uintptr_t>(d_lin);
             std::memcpy(&dyn[0], &bits, sizeof(double));
@@ -923,7 +924,9 @@ try {
         if (!std::isfinite(params[i])) return fail(CORBO_HIP_ERR_INVALID, "corbo_hip_set_instance_params: non-finite parameter");
     const size_t bytes = (size_t)h->batch * 8 * sizeof(double);
     if (!h->d_dyn_inst) HIP_TRY(hipMalloc((void**)&h->d_dyn_inst, bytes));
-    HIP_TRY(hipMemcpy(h->d_dyn_inst, params, bytes, hipMemcpyHostToDevice));
+    std::vector<double> prm(params, params + (size_t)h->batch * 8);
+    for (int b = 0; b < h->batch; ++b) prm[(size_t)b * 8 + 7] = (double)h->S.desc.shooting_integrator;   // slot 7 is the library's (fill_dyn)
+    HIP_TRY(hipMemcpy(h->d_dyn_inst, prm.data(), bytes, hipMemcpyHostToDevice));
     return CORBO_HIP_OK;
 }
 ABI_CATCH

@@ -3592,6 +3592,7 @@ __global__ __launch_bounds__(256) void plant_step_kernel(const PlantParams p)
     double prm[8];   // model parameters of THIS plant
 #pragma unroll
     for (int i = 0; i < 8; ++i) prm[i] = p.dyn_inst ? p.dyn_inst[(size_t)b * 8 + i] : p.dyn[i];
+    prm[7] = 0.0;   // (slot 7 selects the shooting grids' integrator for the defect edges; the plant's own integrator is p.integrator)
     if (p.integrator == CORBO_HIP_INTEGRATOR_RK4) {
         double ck[4][D::NC];
         rk4_end_state<DYN, false>(x1, u, p.dt, prm, ck, xe);

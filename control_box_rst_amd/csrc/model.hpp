@@ -337,6 +337,9 @@ __device__ __forceinline__ void defect_eval_cached(const double* x1, const doubl
     }
 }
 
+template <int DYN, bool REUSE>
+__device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1, double dt, const double* prm, double (&ck)[4][Dynamics<DYN>::NC], double* xe);
+
 // ---- dynamics defect of the equality edge (x1, u1, x2, dt) ----------------------------------------------------------
 template <int DYN, int DEFECT>
 __device__ __forceinline__ void defect_eval(const double* x1, const double* u1, const double* x2, double dt, const double* prm, double* err)
@@ -368,24 +371,11 @@ __device__ __forceinline__ void defect_eval(const double* x1, const double* u1, 
 #pragma unroll
         for (int i = 0; i < NX; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
     }
-    else {  // RK4 shooting: explicit_integrators.h:280-295 + integrator_interface.h:217-222
-        double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
-        dyn_full<DYN>(x1, u1, prm, k1);
+    else {  // shooting: x_{k+1}(integrator) - x2  (explicit_integrators.h + integrator_interface.h:217-222); the step itself: rk4_end_state below
+        double ck[4][D::NC], xe[NX];
+        rk4_end_state<DYN, false>(x1, u1, dt, prm, ck, xe);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { k1[i] *= dt; t[i] = x1[i] + k1[i] / 2.0; }
-        dyn_full<DYN>(t, u1, prm, k2);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { k2[i] *= dt; t[i] = x1[i] + k2[i] / 2.0; }
-        dyn_full<DYN>(t, u1, prm, k3);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { k3[i] *= dt; t[i] = x1[i] + k3[i]; }
-        dyn_full<DYN>(t, u1, prm, k4);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            k4[i] *= dt;
-            err[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
-            err[i] -= x2[i];
-        }
+        for (int i = 0; i < NX; ++i) { err[i] = xe[i]; err[i] -= x2[i]; }
     }
 }
 
@@ -402,6 +392,40 @@ __device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1
     double k[NX], sum[NX], t[NX];
     if constexpr (!REUSE) D::prepare(x1, prm, ck[0]);
     D::eval(x1, ck[0], u1, prm, k);
+    // the other explicit integrators of the shooting grids (corbo_hip_problem_desc::shooting_integrator, carried in prm[7]; uniform branch)
+    const int integ = (int)prm[7];
+    if (integ != 0) {
+        if (integ == 1) {   // IntegratorExplicitEuler (explicit_integrators.h:66-72): x2 = f; x2 *= dt; x2 += x1
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xe[i] = k[i] * dt + x1[i];
+            return;
+        }
+        double k1[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k[i] *= dt; k1[i] = k[i]; }
+        if (integ == 2) {   // IntegratorExplicitRungeKutta2 (:127-138): k2 = dt f(x1 + k1); x2 = x1 + (k1 + k2) / 2
+#pragma unroll
+            for (int i = 0; i < NX; ++i) t[i] = x1[i] + k1[i];
+            if constexpr (!REUSE) D::prepare(t, prm, ck[1]);
+            D::eval(t, ck[1], u1, prm, k);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { k[i] *= dt; xe[i] = x1[i] + (k1[i] + k[i]) / 2.0; }
+            return;
+        }
+        // IntegratorExplicitRungeKutta3 (:200-213): k2 = dt f(x1 + k1 / 2); k3 = dt f(x1 - k1 + 2 k2); x2 = x1 + (k1 + 4 k2 + k3) / 6
+        double k2[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) t[i] = x1[i] + (k1[i] / 2.0);
+        if constexpr (!REUSE) D::prepare(t, prm, ck[1]);
+        D::eval(t, ck[1], u1, prm, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k[i] *= dt; k2[i] = k[i]; t[i] = (x1[i] - k1[i]) + 2.0 * k2[i]; }
+        if constexpr (!REUSE) D::prepare(t, prm, ck[2]);
+        D::eval(t, ck[2], u1, prm, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { k[i] *= dt; xe[i] = x1[i] + ((k1[i] + 4.0 * k2[i]) + k[i]) / 6.0; }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { k[i] *= dt; sum[i] = k[i]; t[i] = x1[i] + k[i] / 2.0; }
     if constexpr (!REUSE) D::prepare(t, prm, ck[1]);

@@ -53,6 +53,8 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.final_eq != 0 && d.final_eq != 1) return "final_eq must be 0 or 1";
     if (d.final_eq && d.nx > 4 && d.nx != 12) return "terminal equality constraint: families with nx <= 4, and the 12-state big-block family";
     if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
+    if (d.shooting_integrator < 0 || d.shooting_integrator > 3) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3)";
+    if (d.shooting_integrator != 0 && d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return "shooting_integrator: shooting grids only";
     if (d.weights_dense < 0 || d.weights_dense > 7) return "weights_dense: bits 0..2";
     if (d.weights_dense) {
         if (d.nx > 4 || d.nu > 4) return "non-diagonal weights: families with nx <= 4";

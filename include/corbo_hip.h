@@ -171,6 +171,11 @@ typedef struct corbo_hip_problem_desc {
      * r_diag, bit 2: qf_sqrt instead of qf_diag.  Row-major [i * nx + j] (r_sqrt: [i * nu + j]), entries below the diagonal zero.  Families
      * with nx <= 4 on the Levenberg-Marquardt path and the Hessian-path operators in least-squares form (cost_nonlsq = 0). */
     int32_t weights_dense;
+    /* Integrator of the shooting grids' defect edges (MultipleShootingGrid::setNumericalIntegrator; explicit_integrators.h):
+     * 0 = IntegratorExplicitRungeKutta4 (:244-295, what the reference's examples use), 1 = IntegratorExplicitEuler (:47-72),
+     * 2 = IntegratorExplicitRungeKutta2 (:97-138), 3 = IntegratorExplicitRungeKutta3 (:167-213).  (Orders 5 - 7: not built.)
+     * Travels to the kernels in slot 7 of the dynamics parameters (no model uses more than 5). */
+    int32_t shooting_integrator;
     double q_sqrt[16];
     double r_sqrt[16];
     double qf_sqrt[16];

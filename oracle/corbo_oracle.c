@@ -211,6 +211,36 @@ static void defect_values(const oracle_problem* p, const double* x1, const doubl
             break;
         case CORBO_HIP_DEFECT_RK4_SHOOTING: { /* explicit_integrators.h:280-295 + integrator_interface.h:217-222 */
             double k1[CORBO_HIP_MAX_NX], k2[CORBO_HIP_MAX_NX], k3[CORBO_HIP_MAX_NX], k4[CORBO_HIP_MAX_NX];
+            if (d->shooting_integrator == 1) { /* IntegratorExplicitEuler (:66-72): x2 = f; x2 *= dt; x2 += x1 */
+                dynamics(d, x1, u1, err);
+                for (int i = 0; i < nx; ++i) err[i] *= dt;
+                for (int i = 0; i < nx; ++i) err[i] += x1[i];
+                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
+                break;
+            }
+            if (d->shooting_integrator == 2) { /* IntegratorExplicitRungeKutta2 (:127-138) */
+                dynamics(d, x1, u1, k1);
+                for (int i = 0; i < nx; ++i) k1[i] *= dt;
+                for (int i = 0; i < nx; ++i) t[i] = x1[i] + k1[i];
+                dynamics(d, t, u1, k2);
+                for (int i = 0; i < nx; ++i) k2[i] *= dt;
+                for (int i = 0; i < nx; ++i) err[i] = x1[i] + (k1[i] + k2[i]) / 2.0;
+                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
+                break;
+            }
+            if (d->shooting_integrator == 3) { /* IntegratorExplicitRungeKutta3 (:200-213) */
+                dynamics(d, x1, u1, k1);
+                for (int i = 0; i < nx; ++i) k1[i] *= dt;
+                for (int i = 0; i < nx; ++i) t[i] = x1[i] + (k1[i] / 2.0);
+                dynamics(d, t, u1, k2);
+                for (int i = 0; i < nx; ++i) k2[i] *= dt;
+                for (int i = 0; i < nx; ++i) t[i] = x1[i] - k1[i] + 2.0 * k2[i];
+                dynamics(d, t, u1, k3);
+                for (int i = 0; i < nx; ++i) k3[i] *= dt;
+                for (int i = 0; i < nx; ++i) err[i] = x1[i] + (k1[i] + 4.0 * k2[i] + k3[i]) / 6.0;
+                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
+                break;
+            }
             dynamics(d, x1, u1, k1);
             for (int i = 0; i < nx; ++i) k1[i] *= dt;
             for (int i = 0; i < nx; ++i) t[i] = x1[i] + k1[i] / 2.0;

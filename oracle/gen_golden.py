@@ -325,8 +325,31 @@ def fullq():
     print("hess_unicycle_fullq")
 
 
+
+MSINT = [
+    # the shooting grids' other explicit integrators (explicit_integrators.h:47-213): Euler, Runge-Kutta 2 / 3 instead of Runge-Kutta 4
+    ("vdp_ms_euler", dict(scenario="vdp", grid="ms", iters=6, ms_integrator="euler"), (1, 2, 3, 4, 5, 6)),
+    ("unicycle_n12_ms_rk2", dict(scenario="unicycle", grid="ms", N=12, iters=6, ms_integrator="rk2"), (1, 2, 3, 4, 5, 6)),
+    ("pendulum_ms_rk3", dict(scenario="pendulum", grid="ms", N=16, iters=5, ms_integrator="rk3"), (1, 2, 3, 4, 5)),
+    ("cartpole_ms_rk2", dict(scenario="cartpole", grid="ms", N=16, iters=5, ms_integrator="rk2"), (1, 2, 3, 4, 5)),
+    ("int3_ms_time_optimal_rk2", dict(scenario="int3", grid="ms", vargrid=1, N=25, iters=8, w="100,100,100", ms_integrator="rk2"), (1, 4, 8)),
+    ("quad_n10_rk3", dict(scenario="quad", N=10, iters=6, ms_integrator="rk3"), (1, 2, 4, 6)),
+    ("quad_n10_euler", dict(scenario="quad", N=10, iters=6, ms_integrator="euler"), (1, 2, 4, 6)),
+]
+
+
+def msint():
+    for name, kv, keep in MSINT:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "msint":
+        return msint()
     if len(sys.argv) > 1 and sys.argv[1] == "fullq":
         return fullq()
     if len(sys.argv) > 1 and sys.argv[1] == "secondary":

@@ -150,6 +150,7 @@ struct Scenario
     int last_n = 0;             // last_n=<n> with cost=mtq: MinTimeQuadratic's only_last_n
     std::string integral;       // integral=trap|left (unicycle, vdp; with lsq=0): QuadraticFormCost in integral form, the grid's cost integration rule
     mutable Eigen::MatrixXd Qfull, Rfull, Qffull;   // what fullq = 1 configured (filled by build(); dump prints their factors)
+    std::string ms_integrator;  // ms_integrator=euler|rk2|rk3 (shooting grids): IntegratorExplicitEuler / RungeKutta2 / RungeKutta3 instead of RungeKutta4
     bool fullq = false;         // fullq=1 (unicycle, vdp, par2 / par3 / lin, the zoo): NON-DIAGONAL Q, R, Qf = 10 Q (off-diagonal entries 0.25 sqrt(w_i w_j)): the dense
                                 // branch of QuadraticFormCost::setWeightQ / setWeightR and QuadraticFinalStateCost::setWeightQf (upper Cholesky factors)
     bool nonlsq = false;        // lsq=0 (unicycle, vdp, dint, int3 vargrid, cost=mtq; hess mode): QuadraticFormCost / QuadraticFinalStateCost with lsq_form = false -- scalar terms
@@ -208,6 +209,14 @@ static Eigen::MatrixXd fullWeight(const Eigen::MatrixXd& D)
     return W;
 }
 
+static NumericalIntegratorExplicitInterface::Ptr shootingIntegrator(const Scenario& s)
+{
+    if (s.ms_integrator == "euler") return std::make_shared<IntegratorExplicitEuler>();
+    if (s.ms_integrator == "rk2") return std::make_shared<IntegratorExplicitRungeKutta2>();
+    if (s.ms_integrator == "rk3") return std::make_shared<IntegratorExplicitRungeKutta3>();
+    return std::make_shared<IntegratorExplicitRungeKutta4>();
+}
+
 static Built build(const Scenario& s, int iterations)
 {
     Built b;
@@ -220,7 +229,7 @@ static Built build(const Scenario& s, int iterations)
 
     auto make_ms = [&]() {
         b.ms_grid = std::make_shared<MultipleShootingGrid>();
-        b.ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        b.ms_grid->setNumericalIntegrator(shootingIntegrator(s));
         b.ms_grid->setNRef(s.N);
         b.ms_grid->setDtRef(s.dt);
         if (s.xf_fixed >= 0)
@@ -278,7 +287,7 @@ static Built build(const Scenario& s, int iterations)
         if (s.vargrid && s.ms)
         {   // time-optimal on the shooting grid: MultipleShootingVariableGrid (free dt), RK4, x_f fixed
             auto grid = std::make_shared<MultipleShootingVariableGrid>();
-            grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+            grid->setNumericalIntegrator(shootingIntegrator(s));
             grid->setNRef(s.N);
             grid->setDtRef(s.dt);
             grid->setDtBounds(0.01, 10.0);
@@ -308,7 +317,7 @@ static Built build(const Scenario& s, int iterations)
         if (s.ms)
         {   // cfg 2 on the shooting grid: MultipleShootingVariableGrid (free dt), RK4
             auto grid = std::make_shared<MultipleShootingVariableGrid>();
-            grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+            grid->setNumericalIntegrator(shootingIntegrator(s));
             grid->setNRef(s.N);
             grid->setDtRef(s.dt);
             grid->setDtBounds(0.01, 10.0);
@@ -328,7 +337,7 @@ static Built build(const Scenario& s, int iterations)
     {
         dyn       = std::make_shared<QuadrotorRef>();
         b.ms_grid = std::make_shared<MultipleShootingGrid>();
-        b.ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        b.ms_grid->setNumericalIntegrator(shootingIntegrator(s));
         b.ms_grid->setNRef(s.N);
         b.ms_grid->setDtRef(s.dt);
         b.any_grid = b.ms_grid;
@@ -702,6 +711,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("last_n")) s.last_n = atoi(kv["last_n"].c_str());
     if (kv.count("lsq")) s.nonlsq = atoi(kv["lsq"].c_str()) == 0;
     if (kv.count("fullq")) s.fullq = atoi(kv["fullq"].c_str()) != 0;
+    if (kv.count("ms_integrator")) s.ms_integrator = kv["ms_integrator"];
     if (kv.count("integral")) s.integral = kv["integral"];
     if (kv.count("adapt")) s.adapt = kv["adapt"];
     if (kv.count("nmax")) s.n_max = atoi(kv["nmax"].c_str());
@@ -733,6 +743,7 @@ static int dump(const Scenario& s)
            s.N, s.dt, s.iters, s.solves);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.teq) printf("\"teq\": 1,\n");

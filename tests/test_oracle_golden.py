@@ -24,11 +24,13 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "par2", "par3", "par2_ms_rk4", "par3_forward",
         "lin21", "lin22", "lin31", "lin32", "lin33", "lin41",
         # NON-DIAGONAL Q / R / Qf: upper Cholesky factors, dense cost blocks (quadratic_cost.cpp:36-55, 100-184)
-        "unicycle_n12_fullq", "vdp_fullq", "unicycle_n12_fullq_patterns", "unicycle_n12_fullq_ms", "cartpole_fullq", "par3_fullq", "lin33_fullq"]
+        "unicycle_n12_fullq", "vdp_fullq", "unicycle_n12_fullq_patterns", "unicycle_n12_fullq_ms", "cartpole_fullq", "par3_fullq", "lin33_fullq",
+        # the shooting grids' other integrators: explicit Euler, Runge-Kutta 2 / 3 (explicit_integrators.h:47-213)
+        "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler"]
 
 # The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
 # along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
-X_TOL = {"quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4,
+X_TOL = {"quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
          "cartpole_teq": 5e-6}   # 3.0e-6 at the fifth iteration (FD-noise level, different elimination order than Eigen's)
 
 
