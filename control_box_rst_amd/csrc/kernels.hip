@@ -2936,8 +2936,11 @@ __device__ __forceinline__ int32_t* cu_row_of(int32_t* table)
     return table + (size_t)idx * 16;
 }
 
+#ifndef CORBO_HIP_PASS_WAVES
+#define CORBO_HIP_PASS_WAVES 4   // waves per SIMD the fused kernel is compiled for: 4 = 128 VGPRs (44 spilled), four workgroups per CU.  -DCORBO_HIP_PASS_WAVES=3:
+#endif                           // 168 VGPRs, no spills, three workgroups per CU (diagnostics: attribution of the scratch traffic, profiles/r03_spill_attribution.json)
 template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, bool QUEUE = false>
-__global__ __launch_bounds__(SWEEP_THREADS, 4) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
+__global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
