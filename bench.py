@@ -424,8 +424,8 @@ def main():
         # run-to-completion families: ONE launch per solve (lm_pass_kernel); its bytes = what the reference's algorithm moves for the
         # same sweeps: sweeps_j x (read vertices + bounds, write residual + Jacobian) + trial sweeps x (read vertices + bounds, write residual)
         achieved = alg_solve / (launch_ms * 1e-3) / 1e9
-        pmc = load_profile_json("r02_solve_pmc.json", B, desc.N)
-        prof = profile_kernel_avg_ns("r02_bench_kernel_stats.csv", "lm_pass_kernel")
+        pmc = load_profile_json("r03_solve_pmc.json", B, desc.N)
+        prof = profile_kernel_avg_ns("r03_bench_kernel_stats.csv", "lm_pass_kernel")
         line["roofline"] = {"bound": "hbm", "kernel": "lm_pass_kernel (run-to-completion: prologue sweep + every LM pass of every instance, one launch per solve)",
                             "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                             "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
@@ -439,7 +439,7 @@ def main():
     each = solver.time_sweep_each(with_jacobian=True, repeat=50)        # one event pair per launch (what a kernel trace reports)
     b2b_ms = solver.time_sweep(with_jacobian=True, repeat=50)            # back-to-back launches, one event pair around all of them
     sweep_ms = float(np.mean(each))
-    prof = profile_kernel_avg_ns("r02_sweep_kernel_stats.csv", "sweep_kernel")
+    prof = profile_kernel_avg_ns("r03_sweep_kernel_stats.csv", "sweep_kernel")
     spmc = load_profile_json("sweep_pmc_latest.json", B, desc.N)
     rs = {"bound": "hbm", "kernel": "sweep_kernel (residual + Jacobian of every instance, stand-alone launch)",
           "achieved": B * b_sweep / (sweep_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -453,7 +453,7 @@ def main():
     line["roofline_sweep"] = rs
     if cfg == 5:
         # big-block family: an LM pass is sweep (residual) -> big_stage_kernel -> big_chain2_kernel; the last two are 81 % of the GPU time
-        # of a solve (profiles/r02_cfg5_kernel_stats.csv).  One factorisation of EVERY instance (stage + chain launch), HIP events
+        # of a solve (profiles/r03_cfg5_kernel_stats.csv).  One factorisation of EVERY instance (stage + chain launch), HIP events
         # around 5 back-to-back pairs (corbo_hip_time_factor).  Algorithmic bytes per shooting interval: stage kernel
         # reads x_k u_k, the stored RK4 end state, the bounds (60 doubles) and writes the 572-double stage record; the chain kernel
         # reads the record, writes G_k and a_k (156), reads them back in the back-substitution and moves the iterate (32): 1548 doubles
@@ -463,8 +463,8 @@ def main():
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
         alg_pair = per_stage * desc.N * B
-        pc = profile_kernel_max_ns("r02_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
-        qpmc = load_profile_json("r02_cfg5_pmc.json", B, desc.N)
+        pc = profile_kernel_max_ns("r03_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
+        qpmc = load_profile_json("r03_cfg5_pmc.json", B, desc.N)
         line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance: FD Jacobian + assemble, then the block chain)",
                             "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                             "traffic": qpmc["hbm_bytes_per_launch"] if qpmc else None, "traffic_source": qpmc["source"] if qpmc else None,
@@ -484,7 +484,7 @@ def main():
         s_blk, nb = desc.nx + desc.nu, desc.N - 1
         flops_fact = (7.0 / 3.0) * s_blk ** 3 * nb + 8.0 * s_blk ** 2 * nb + 2.0 * desc.nx * (2 * desc.nx + desc.nu) ** 2 * nb
         n_fact = stats["factorizations"]
-        mf = load_profile_json("r02_cfg5_mfma.json", B, desc.N)
+        mf = load_profile_json("r03_cfg5_mfma.json", B, desc.N)
         line["factorization"] = {"bound": "mfma", "algorithmic_flops_per_instance": flops_fact, "factorizations_per_solve": int(n_fact),
                                  "factor_ms_per_solve": prof_stats["factor_ms"],
                                  "achieved_TFLOPs": (n_fact * flops_fact / (prof_stats["factor_ms"] * 1e-3) / 1e12) if prof_stats["factor_ms"] > 0 else None,
