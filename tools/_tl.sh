@@ -1,1 +1,2 @@
-timeout 1500 python -m pytest tests/test_gpu_dropin.py -m gpu -q -x 2>&1 | tail -5
+timeout 2400 python -m pytest tests -m gpu -q -x -n 4 2>&1 | tail -8
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
