@@ -324,7 +324,14 @@ bool describeDynamics(SystemDynamicsInterface& dyn, corbo_hip_problem_desc& d, s
     // formula on the GPU) at deterministic probe points; sin / cos may differ from the host's by an ulp
     struct Candidate { int id; int nx, nu; double prm[5]; const char* name; };
     const Candidate cands[] = {{CORBO_HIP_DYN_UNICYCLE, 3, 2, {0, 0, 0, 0, 0}, "unicycle"},
-                               {CORBO_HIP_DYN_QUADROTOR, 12, 4, {9.81, 1.0, 0.01, 0.01, 0.02}, "quadrotor (g = 9.81, m = 1, I = 0.01 / 0.01 / 0.02)"}};
+                               {CORBO_HIP_DYN_QUADROTOR, 12, 4, {9.81, 1.0, 0.01, 0.01, 0.02}, "quadrotor (g = 9.81, m = 1, I = 0.01 / 0.01 / 0.02)"},
+// the user models dropped into csrc/models/ (registry generated by the build), each with the parameter values its header states
+#if __has_include("../csrc/models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) {CORBO_HIP_DYN_USER + SLOT, NX_, NU_, {P0, P1, P2, P3, 0}, "user model " #NAME},
+#include "../csrc/models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
+    };
     for (const Candidate& c : cands)
     {
         if (c.nx != nx || c.nu != nu) continue;
@@ -336,7 +343,7 @@ bool describeDynamics(SystemDynamicsInterface& dyn, corbo_hip_problem_desc& d, s
         for (int p = 0; p < P; ++p)
         {
             for (int i = 0; i < nx; ++i) xs[p * nx + i] = 0.37 * std::sin(1.0 + 1.7 * i + 0.9 * p) + 0.05 * p;
-            for (int i = 0; i < nu; ++i) us[p * nu + i] = 0.8 * std::cos(0.3 + 2.1 * i + 1.3 * p) + ((c.id == CORBO_HIP_DYN_QUADROTOR && i == 0) ? 9.0 : 0.0);
+            for (int i = 0; i < nu; ++i) us[p * nu + i] = 0.8 * std::cos(0.3 + 2.1 * i + 1.3 * p) + ((c.id == CORBO_HIP_DYN_QUADROTOR && i == 0) ? 9.0 : 0.0);   // (|u| < 0.8: inside tan()'s first branch for a steering angle)
         }
         if (corbo_hip_eval_dynamics(&t, P, xs.data(), us.data(), fd.data()) != CORBO_HIP_OK) continue;
         bool same = true;

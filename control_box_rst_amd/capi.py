@@ -19,6 +19,7 @@ DYN_VAN_DER_POL, DYN_SERIAL_INTEGRATOR, DYN_UNICYCLE, DYN_QUADROTOR = 0, 1, 2, 3
 # the reference's other benchmark systems (nonlinear_benchmark_systems.h)
 DYN_DUFFING, DYN_FREE_SPACE_ROCKET, DYN_SIMPLE_PENDULUM, DYN_MASSLESS_PENDULUM, DYN_TOY_EXAMPLE, DYN_ARTSTEINS_CIRCLE = 4, 5, 6, 7, 8, 9
 DYN_CART_POLE, DYN_PARALLEL_INTEGRATOR, DYN_LINEAR_STATE_SPACE = 10, 11, 12
+DYN_USER = 1000   # + slot: user models dropped into csrc/models/ (slot 0: the kinematic-car example)
 COST_NONE, COST_QUADRATIC_LSQ, COST_MIN_TIME_LSQ = 0, 1, 2
 COST_MIN_TIME_QUADRATIC_LSQ = 3   # MinTimeQuadratic(Q, R, integral=False, lsq=True): state, control and minimum-time terms
 INEQ_NONE, INEQ_BALL = 0, 1

@@ -3664,6 +3664,13 @@ CORBO_HIP_DYN_ENTRIES(lin32)
 CORBO_HIP_DYN_ENTRIES(lin33)
 CORBO_HIP_DYN_ENTRIES(lin41)
 
+// user models (csrc/models/*.hpp, registry generated by the build): one set of entries each
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) CORBO_HIP_DYN_ENTRIES(user_##NAME)
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
+
 bool stage_entry_quadrotor(const FactorParams& fp, const SweepParams& sp, int diag_only, double* jac_dump, hipStream_t stream);
 
 #ifdef CORBO_HIP_DYN_TU
@@ -3733,6 +3740,11 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const double* __res
 
 bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hipStream_t stream)
 {
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) { plant_entry_user_##NAME(p, stream); return true; }
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: plant_entry_vdp(p, stream); return true;
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
@@ -3870,6 +3882,11 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d)
     const bool known_defect = d.defect >= CORBO_HIP_DEFECT_FORWARD && d.defect <= CORBO_HIP_DEFECT_RK4_SHOOTING;
     if (!known_defect) return false;
     auto is = [&](int nx, int nu) { return d.nx == nx && d.nu == nu; };
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return is(NX_, NU_);
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: case CORBO_HIP_DYN_DUFFING: case CORBO_HIP_DYN_SIMPLE_PENDULUM: case CORBO_HIP_DYN_MASSLESS_PENDULUM:
         case CORBO_HIP_DYN_TOY_EXAMPLE: case CORBO_HIP_DYN_ARTSTEINS_CIRCLE: return is(2, 1);
@@ -3887,6 +3904,11 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d)
 
 bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStream_t stream)
 {
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return sweep_entry_user_##NAME(d.defect, p, stream);
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: return sweep_entry_vdp(d.defect, p, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
@@ -3917,6 +3939,11 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
 
 bool launch_hessian(const corbo_hip_problem_desc& d, const SweepParams& p, const HessParams& hp, hipStream_t stream)
 {
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return hessian_entry_user_##NAME(d.defect, p, hp, stream);
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: return hessian_entry_vdp(d.defect, p, hp, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:
@@ -3953,6 +3980,11 @@ bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorPar
 
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return pass_entry_user_##NAME(d.defect, fp, sp, stream);
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: return pass_entry_vdp(d.defect, fp, sp, stream);
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR:

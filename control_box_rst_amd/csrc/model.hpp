@@ -460,6 +460,11 @@ __device__ __forceinline__ double ineq_ball(const double* x, const double* prm)
     return prm[3] * prm[3] - (dx * dx + dy * dy + dz * dz);
 }
 
+// ---- user models dropped into csrc/models/ (generated include list: __graft_entry__.build(); see models/README.md)
+#if __has_include("models/_includes.inc")
+#include "models/_includes.inc"
+#endif
+
 #pragma clang fp contract(fast)
 
 }  // namespace corbo_hip

@@ -17,6 +17,14 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.defect < CORBO_HIP_DEFECT_FORWARD || d.defect > CORBO_HIP_DEFECT_RK4_SHOOTING) return "unknown defect";
     if ((d.grid == CORBO_HIP_GRID_MS || d.grid == CORBO_HIP_GRID_MS_VARIABLE) != (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING))
         return "multiple-shooting grid needs the RK4 shooting defect (and only it)";
+    bool user_model = false;
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) \
+    if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) { if (d.nx != NX_ || d.nu != NU_) return "user model " #NAME ": wrong nx / nu"; user_model = true; }
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
+    if (!user_model)
     switch (d.dynamics) {
         case CORBO_HIP_DYN_VAN_DER_POL: if (d.nx != 2 || d.nu != 1) return "van der pol: nx=2 nu=1"; break;
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d.nu != 1) return "serial integrator: nu=1"; break;

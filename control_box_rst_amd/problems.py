@@ -60,6 +60,14 @@ def unicycle_desc(N=100, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, terminal_bal
 UNICYCLE_WEIGHTS = (10.0, 10.0, 10.0)
 
 
+def kinematic_car_desc(N=100, dt=0.1, defect=capi.DEFECT_CRANK_NICOLSON, wheelbase=2.5) -> ProblemDesc:
+    """The user-model example csrc/models/kinematic_car.hpp (public dynamics id DYN_USER + 0) inside the unicycle's OCP (same cost and bounds)."""
+    d = unicycle_desc(N=N, dt=dt, defect=defect)
+    d.dynamics = capi.DYN_USER + 0
+    d.dyn_params[0] = wheelbase
+    return d
+
+
 def unicycle_instances(batch: int, seed: int = 20260928, first: int = 0):
     """x0 = (U(-1,1), U(-1,1), U(-pi/4,pi/4)), xf = (2,1,0.5)+U(-0.5,0.5)^3 with default_rng(seed + i).
 

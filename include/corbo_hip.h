@@ -85,6 +85,10 @@ typedef enum corbo_hip_dynamics {
     CORBO_HIP_DYN_LINEAR_STATE_SPACE  = 12  /* LinearStateSpaceModel :186-262, f = A x + B u, matrices in lin_a / lin_b;
                                              * (nx, nu) in {(2,1), (2,2), (3,1), (3,2), (3,3), (4,1)} */
 } corbo_hip_dynamics;
+/* User dynamics models: a `Dynamics<>` specialisation dropped into control_box_rst_amd/csrc/models/ (README.md there) is registered by
+ * the build under the id CORBO_HIP_DYN_USER + slot, slot = 0 .. 15 -- the device-side counterpart of a user's own
+ * corbo::SystemDynamicsInterface subclass (system_dynamics_interface.h:66-121).  Shipped example: slot 0 = kinematic car (nx = 3, nu = 2). */
+#define CORBO_HIP_DYN_USER 1000
 
 typedef enum corbo_hip_stage_cost {
     CORBO_HIP_COST_NONE          = 0,

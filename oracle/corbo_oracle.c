@@ -95,6 +95,12 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
             f[n - 1] = u[0] / d->dyn_params[0];
             break;
         }
+        case CORBO_HIP_DYN_USER + 0: { /* user model csrc/models/kinematic_car.hpp = class KinematicCarRef of oracle/ref_driver.cpp (scenario kcar) */
+            f[0] = u[0] * cos(x[2]);
+            f[1] = u[0] * sin(x[2]);
+            f[2] = u[0] / d->dyn_params[0] * tan(u[1]);
+            break;
+        }
         case CORBO_HIP_DYN_UNICYCLE: { /* user plug-in, same formula as oracle/ref_driver.cpp */
             f[0] = u[0] * cos(x[2]);
             f[1] = u[0] * sin(x[2]);
@@ -427,6 +433,7 @@ static int validate(const corbo_hip_problem_desc* d)
         case CORBO_HIP_DYN_VAN_DER_POL: if (d->nx != 2 || d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_UNICYCLE: if (d->nx != 3 || d->nu != 2) return 0; break;
+        case CORBO_HIP_DYN_USER + 0: if (d->nx != 3 || d->nu != 2) return 0; break; /* kinematic car (csrc/models/kinematic_car.hpp) */
         case CORBO_HIP_DYN_QUADROTOR: if (d->nx != 12 || d->nu != 4) return 0; break;
         case CORBO_HIP_DYN_DUFFING:
         case CORBO_HIP_DYN_SIMPLE_PENDULUM:

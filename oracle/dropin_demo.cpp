@@ -54,6 +54,22 @@ class UnicycleRef : public SystemDynamicsInterface
     }
 };
 
+class KinematicCarRef : public SystemDynamicsInterface  // a USER class: its device counterpart is csrc/models/kinematic_car.hpp (same expressions)
+{
+ public:
+    Ptr getInstance() const override { return std::make_shared<KinematicCarRef>(); }
+    bool isContinuousTime() const override { return true; }
+    bool isLinear() const override { return false; }
+    int getInputDimension() const override { return 2; }
+    int getStateDimension() const override { return 3; }
+    void dynamics(const Eigen::Ref<const StateVector>& x, const Eigen::Ref<const ControlVector>& u, Eigen::Ref<StateVector> f) const override
+    {
+        f[0] = u[0] * std::cos(x[2]);
+        f[1] = u[0] * std::sin(x[2]);
+        f[2] = u[0] / 2.5 * std::tan(u[1]);
+    }
+};
+
 class QuadrotorRef : public SystemDynamicsInterface  // same expressions as oracle/ref_driver.cpp
 {
  public:
@@ -195,11 +211,12 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap"),
                ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
-    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref"), urefnz = (scenario == "unicycle_uref");
-    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || urefnz || (hpath && scenario.compare(0, 3, "vdp") != 0));
+    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
+    const bool uni = (scenario == "unicycle" || tball || tballc || fullq || tvref || urefnz || kcar || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
     {
-        dyn  = std::make_shared<UnicycleRef>();
+        if (kcar) dyn = std::make_shared<KinematicCarRef>();   // a user dynamics class: fingerprinted against the models of csrc/models/
+        else dyn = std::make_shared<UnicycleRef>();
         grid = std::make_shared<FiniteDifferencesGrid>();
         x0   = Eigen::Vector3d(0, 0, 0);
         xf   = Eigen::Vector3d(2, 1, 0.5);
@@ -525,7 +542,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);

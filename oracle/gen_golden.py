@@ -346,8 +346,30 @@ def msint():
         print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
 
 
+
+USERMODEL = [
+    # a USER dynamics model (control_box_rst_amd/csrc/models/kinematic_car.hpp <-> class KinematicCarRef of ref_driver.cpp): fixed grid, another scheme, shooting
+    ("kcar_n16", dict(scenario="kcar", N=16, iters=6), (1, 2, 3, 4, 5, 6)),
+    ("kcar_midpoint", dict(scenario="kcar", N=12, iters=4, collocation="midpoint"), (1, 2, 3, 4)),
+    ("kcar_ms_rk4", dict(scenario="kcar", grid="ms", N=12, iters=5), (1, 2, 3, 4, 5)),
+]
+
+
+def usermodel():
+    for name, kv, keep in USERMODEL:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
+    d = run("hess", scenario="kcar", N=10)
+    with open(os.path.join(OUT, "hess_kcar.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "usermodel":
+        return usermodel()
     if len(sys.argv) > 1 and sys.argv[1] == "msint":
         return msint()
     if len(sys.argv) > 1 and sys.argv[1] == "fullq":

@@ -79,6 +79,26 @@ class UnicycleRef : public SystemDynamicsInterface
     }
 };
 
+// Kinematic car (the user-model example of control_box_rst_amd/csrc/models/kinematic_car.hpp): state (x, y, theta), controls (v, delta),
+// wheelbase L.  The expressions are character-for-character those of the device model and of oracle/corbo_oracle.c.
+class KinematicCarRef : public SystemDynamicsInterface
+{
+ public:
+    explicit KinematicCarRef(double wheelbase = 2.5) : L(wheelbase) {}
+    Ptr getInstance() const override { return std::make_shared<KinematicCarRef>(); }
+    bool isContinuousTime() const override { return true; }
+    bool isLinear() const override { return false; }
+    int getInputDimension() const override { return 2; }
+    int getStateDimension() const override { return 3; }
+    void dynamics(const Eigen::Ref<const StateVector>& x, const Eigen::Ref<const ControlVector>& u, Eigen::Ref<StateVector> f) const override
+    {
+        f[0] = u[0] * std::cos(x[2]);
+        f[1] = u[0] * std::sin(x[2]);
+        f[2] = u[0] / L * std::tan(u[1]);
+    }
+    double L;
+};
+
 // Quadrotor (user plug-in, DESIGN.md "quadrotor"): x = [p(3) v(3) roll pitch yaw  body rates(3)], u = [thrust, torques(3)],
 // params g, m, Ixx, Iyy, Izz.  The expressions are character-for-character those of oracle/corbo_oracle.c and the device model.
 class QuadrotorRef : public SystemDynamicsInterface
@@ -240,9 +260,10 @@ static Built build(const Scenario& s, int iterations)
         }
         b.any_grid = b.ms_grid;
     };
-    if (s.name == "unicycle")
+    if (s.name == "unicycle" || s.name == "kcar")   // kcar: the same OCP around the kinematic-car user model (wheelbase 2.5)
     {
-        dyn = std::make_shared<UnicycleRef>();
+        if (s.name == "kcar") dyn = std::make_shared<KinematicCarRef>(2.5);
+        else dyn = std::make_shared<UnicycleRef>();
         if (s.ms) make_ms(); else b.grid = std::make_shared<FiniteDifferencesGrid>();
     }
     else if (s.name == "vdp")
@@ -393,7 +414,7 @@ static Built build(const Scenario& s, int iterations)
     b.ocp = std::make_shared<StructuredOptimalControlProblem>(b.any_grid, dyn, b.hg, b.solver);
     b.ocp->setStatisticsObject(b.stats);
 
-    if (s.name == "unicycle")
+    if (s.name == "unicycle" || s.name == "kcar")
     {
         Eigen::MatrixXd Q = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
         Eigen::MatrixXd R = Eigen::Vector2d(0.1, 0.05).asDiagonal();
@@ -610,7 +631,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
         while (std::getline(ss, item, ',')) v.push_back(strtod(item.c_str(), nullptr));
         return Eigen::VectorXd(Eigen::Map<Eigen::VectorXd>(v.data(), v.size()));
     };
-    if (s.name == "unicycle")
+    if (s.name == "unicycle" || s.name == "kcar")
     {
         s.nx = 3; s.nu = 2; s.N = 100; s.dt = 0.1;
         s.w_eq = s.w_ineq = s.w_b = 10;

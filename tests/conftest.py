@@ -76,6 +76,8 @@ def desc_for(g):
         d = problems.parallel_integrator_desc(int(sc[-1]), N=g["N"], dt=g["dt"], defect=defect)
     elif sc in problems.BENCHMARK_SYSTEMS:
         d = problems.benchmark_desc(sc, N=g["N"], dt=g["dt"], defect=defect)
+    elif sc == "kcar":   # the user-model example (csrc/models/kinematic_car.hpp) in the unicycle's OCP
+        d = problems.kinematic_car_desc(N=g["N"], dt=g["dt"], defect=defect)
     elif sc in ("unicycle", "vdp"):
         d = (problems.unicycle_desc if sc == "unicycle" else problems.vdp_desc)(N=g["N"], dt=g["dt"], defect=defect)
     else:

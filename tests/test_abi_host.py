@@ -164,3 +164,23 @@ def test_hessian_and_linear_form_structure_vs_reference(name):
     r, c = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
     assert lib.corbo_hip_linear_form_structure(C.byref(d), C.byref(n), C.byref(m), ipp(r), ipp(c)) == 0
     assert np.array_equal(r, np.array(g["lin_rows"], np.int32)) and np.array_equal(c, np.array(g["lin_cols"], np.int32))
+
+
+def test_user_model_directory_is_registered(lib):
+    """csrc/models/*.hpp (user dynamics models): the build registers every header under CORBO_HIP_DYN_USER + slot; the shipped example is the
+    kinematic car in slot 0 -- accepted with its own shape, refused with another, and an empty slot is an unknown dynamics id."""
+    import __graft_entry__ as g
+    from control_box_rst_amd import problems
+    models = g.user_models()
+    assert ("kinematic_car", 0, 3, 2) in [(m[0], m[1], m[2], m[3]) for m in models]
+    reg = open(os.path.join(ROOT, "control_box_rst_amd", "csrc", "models", "_registry.inc")).read()
+    for name, slot, nx, nu, prm, _ in models:
+        assert f"CORBO_HIP_USER_MODEL({name}, {slot}, {nx}, {nu}," in reg
+    d = problems.kinematic_car_desc(N=12)
+    dims = capi.Dims()
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) == 0 and dims.n == 55
+    d.nu = 1
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0
+    d = problems.kinematic_car_desc(N=12)
+    d.dynamics = capi.DYN_USER + 9
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0
