@@ -94,7 +94,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_plant_set_state", "corbo_hip_plant_step", "corbo_hip_plant_get_state", "corbo_hip_plant_set_params", "corbo_hip_set_instance_params", "corbo_hip_warm_start_from_plant",
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
-    "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
+    "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_eval_hessians_views", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
     "corbo_hip_sizeof",
 )
 
@@ -174,6 +174,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_hessian_nnz.argtypes = [C.POINTER(ProblemDesc), C.c_int, ip]
     lib.corbo_hip_hessian_structure.argtypes = [C.POINTER(ProblemDesc), C.c_int, ip, ip, ip, ip, ip, ip]
     lib.corbo_hip_eval_hessians.argtypes = [H, C.c_int, C.c_double, dp, dp, dp, dp, dp]
+    lib.corbo_hip_eval_hessians_views.argtypes = [H, C.c_int, C.c_double, dp, dp, C.c_int, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]
     lib.corbo_hip_linear_form_structure.argtypes = [C.POINTER(ProblemDesc), ip, ip, ip, ip]
     lib.corbo_hip_eval_linear_form.argtypes = [H, dp, dp, dp]
     lib.corbo_hip_eval_objective_gradient.argtypes = [H, dp, dp]

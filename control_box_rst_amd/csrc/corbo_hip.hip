@@ -141,6 +141,23 @@ struct corbo_hip_solver {
     int32_t* d_counters   = nullptr;  // MAX_PASSES
     int32_t* h_counter    = nullptr;  // pinned
     int m_pad = 0, nnz_pad = 0;
+    // Hessian-path operators: the structure of a (handle, lower) pair is built once, scratch buffers only grow (an interior-point
+    // loop calls these once per iteration)
+    struct GrowBuf {
+        void* p = nullptr; size_t cap = 0; bool host = false;
+        hipError_t need(size_t bytes) {
+            if (bytes <= cap && p) return hipSuccess;
+            if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
+            hipError_t e = host ? hipHostMalloc(&p, bytes ? bytes : 8) : hipMalloc(&p, bytes ? bytes : 8);
+            if (e == hipSuccess) cap = bytes ? bytes : 8;
+            return e;
+        }
+        void release() { if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
+        double* d() const { return static_cast<double*>(p); }
+    };
+    struct HessCache { bool valid = false; HessianStructure H; GrowBuf d_so, d_lo; } hess_cache[2];
+    GrowBuf hb_vals[3], hb_me, hb_mi, hb_lin, hb_lb, hb_ub, hb_grad, hb_obj;   // device
+    GrowBuf hb_pin{nullptr, 0, true};                                          // pinned host staging (multipliers up, results down)
     std::vector<int32_t> jmap;        // public Jacobian value index -> device-internal index (see corbo_hip_create)
     int nnz_int = 0;                  // values of the device-internal layout (pads included)
     int32_t fin_joff_dev[CORBO_HIP_MAX_NX];
@@ -444,6 +461,9 @@ void corbo_hip_destroy(corbo_hip_handle h)
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
+    for (auto& b : h->hb_vals) b.release();
+    h->hb_me.release(); h->hb_mi.release(); h->hb_lin.release(); h->hb_lb.release(); h->hb_ub.release(); h->hb_grad.release(); h->hb_obj.release(); h->hb_pin.release();
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     if (h->h_xnew) (void)hipHostFree(h->h_xnew);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -1333,22 +1353,80 @@ try {
 }
 ABI_CATCH
 
-static int hessian_common(corbo_hip_handle h, HessianStructure& H, bool lower, HessParams& hp, DevBuf& d_so, DevBuf& d_lo)
+static int hessian_common(corbo_hip_handle h, const HessianStructure*& Hout, bool lower, HessParams& hp)
 {
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    build_hessian_structure(h->S, lower, H);
-    HIP_TRY(d_so.alloc(H.stage_off.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(d_so.p, H.stage_off.data(), H.stage_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(d_lo.alloc(H.lin_off.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(d_lo.p, H.lin_off.data(), H.lin_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    auto& c = h->hess_cache[lower ? 1 : 0];
+    if (!c.valid) {   // once per (handle, lower): the walk over the edges and its two device tables
+        build_hessian_structure(h->S, lower, c.H);
+        HIP_TRY(c.d_so.need(c.H.stage_off.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(c.d_so.p, c.H.stage_off.data(), c.H.stage_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c.d_lo.need(c.H.lin_off.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(c.d_lo.p, c.H.lin_off.data(), c.H.lin_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        c.valid = true;
+    }
+    const HessianStructure& H = c.H;
+    Hout = &H;
     hp = HessParams{};
     hp.lower = lower ? 1 : 0;
     hp.eq_dim = h->S.dims.eq; hp.ineq_dim = h->S.dims.ineq;
-    hp.stage_off = d_so.i(); hp.lin_off = d_lo.i();
-    for (int c = 0; c < 3; ++c) hp.nnz[c] = H.nnz[c];
+    hp.stage_off = static_cast<const int32_t*>(c.d_so.p); hp.lin_off = static_cast<const int32_t*>(c.d_lo.p);
+    for (int q = 0; q < 3; ++q) hp.nnz[q] = H.nnz[q];
     hp.lin_nnz = H.lin_nnz; hp.lin_bounds0 = H.lin_bounds0; hp.bnd_row0 = h->S.bnd_row0; hp.n_bounds = h->S.dims.bounds;
     hp.stage_cost = h->S.desc.stage_cost; hp.stage_ineq = h->S.desc.stage_ineq;
     hp.dt_cost_off = H.dt_cost_off; hp.quad_first_interval = h->S.desc.quad_first_interval; hp.cost_nonlsq = h->S.desc.cost_nonlsq; hp.cost_integral = h->S.desc.cost_integral;
+    return 0;
+}
+
+// device -> pinned host: a copy kernel for what a kernel moves faster than a copy engine wakes up (<= 8 MB), the copy engine above
+static int copy_to_pinned(corbo_hip_handle h, const double* src_dev, double* dst_pin, size_t doubles)
+{
+    if (doubles * sizeof(double) <= ((size_t)8 << 20)) { launch_copy_rows(src_dev, dst_pin, nullptr, doubles, h->stream); HIP_TRY(hipGetLastError()); }
+    else HIP_TRY(hipMemcpyAsync(dst_pin, src_dev, doubles * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+// multipliers of the caller (pageable host memory) -> device, through the pinned staging buffer and a copy kernel (no copy engine)
+static int upload_through_pin(corbo_hip_handle h, const double* src, size_t doubles, corbo_hip_solver::GrowBuf& dev)
+{
+    const size_t even = (doubles + 1) & ~(size_t)1;
+    HIP_TRY(dev.need(even * sizeof(double)));
+    HIP_TRY(h->hb_pin.need(even * sizeof(double)));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the staging buffer is free
+    std::memcpy(h->hb_pin.p, src, doubles * sizeof(double));
+    launch_copy_rows(h->hb_pin.d(), dev.d(), nullptr, even, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// the three value lists on the device (hb_vals); `where`: 0 = leave them there, 1 = also into the pinned buffer [obj | eq | ineq]
+static int eval_hessians_device(corbo_hip_handle h, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq, const HessianStructure*& H,
+                                size_t off[4], bool to_pinned)
+{
+    HessParams hp;
+    int rc = hessian_common(h, H, lower_part_only != 0, hp);
+    if (rc) return rc;
+    const size_t B = (size_t)h->active;
+    off[0] = 0;
+    for (int c = 0; c < 3; ++c) {
+        const size_t n = (B * H->nnz[c] + 1) & ~(size_t)1;
+        HIP_TRY(h->hb_vals[c].need(n * sizeof(double)));
+        hp.vals[c] = h->hb_vals[c].d();
+        off[c + 1] = off[c] + n;
+    }
+    if (mult_eq && hp.eq_dim > 0) { rc = upload_through_pin(h, mult_eq, B * hp.eq_dim, h->hb_me); if (rc) return rc; hp.mult_eq = h->hb_me.d(); }
+    if (mult_ineq && hp.ineq_dim > 0) { rc = upload_through_pin(h, mult_ineq, B * hp.ineq_dim, h->hb_mi); if (rc) return rc; hp.mult_ineq = h->hb_mi.d(); }
+    hp.mode = 0;
+    hp.mult_obj = mult_obj;
+    const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
+    if (to_pinned) HIP_TRY(h->hb_pin.need(off[3] * sizeof(double)));
+    if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
+    HIP_TRY(hipGetLastError());
+    if (to_pinned)
+        for (int c = 0; c < 3; ++c)
+            if (H->nnz[c] > 0) { rc = copy_to_pinned(h, h->hb_vals[c].d(), h->hb_pin.d() + off[c], off[c + 1] - off[c]); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -1357,37 +1435,43 @@ int corbo_hip_eval_hessians(corbo_hip_handle h, int lower_part_only, double mult
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
-    HessianStructure H;
-    HessParams hp;
-    DevBuf d_so, d_lo, d_me, d_mi, d_v[3];
-    int rc = hessian_common(h, H, lower_part_only != 0, hp, d_so, d_lo);
-    if (rc) return rc;
-    const size_t B = (size_t)h->active;
+    const HessianStructure* H = nullptr;
+    size_t off[4];
     double* out[3] = {vals_obj, vals_eq, vals_ineq};
+    {
+        HessParams probe;
+        int rc0 = hessian_common(h, H, lower_part_only != 0, probe);
+        if (rc0) return rc0;
+        for (int c = 0; c < 3; ++c)
+            if (H->nnz[c] > 0 && !out[c]) return fail(CORBO_HIP_ERR_INVALID, "null value array for a non-empty list");
+    }
+    const size_t B = (size_t)h->active;
+    // small results travel through the pinned buffer (copy kernel, no copy engine); large ones (the 36 MB of a 1024-instance batch) go
+    // straight into the caller's arrays -- a second pass over them on the host would cost more than the engine's wake-up
+    const bool small = B * ((size_t)H->nnz[0] + H->nnz[1] + H->nnz[2]) * sizeof(double) <= ((size_t)8 << 20);
+    int rc = eval_hessians_device(h, lower_part_only, mult_obj, mult_eq, mult_ineq, H, off, small);
+    if (rc) return rc;
     for (int c = 0; c < 3; ++c) {
-        if (H.nnz[c] > 0 && !out[c]) return fail(CORBO_HIP_ERR_INVALID, "null value array for a non-empty list");
-        HIP_TRY(d_v[c].alloc(B * H.nnz[c] * sizeof(double)));
-        hp.vals[c] = d_v[c].d();
+        if (H->nnz[c] == 0) continue;
+        if (small) std::memcpy(out[c], h->hb_pin.d() + off[c], B * H->nnz[c] * sizeof(double));
+        else HIP_TRY(hipMemcpy(out[c], h->hb_vals[c].p, B * H->nnz[c] * sizeof(double), hipMemcpyDeviceToHost));
     }
-    if (mult_eq && hp.eq_dim > 0) {
-        HIP_TRY(d_me.alloc(B * hp.eq_dim * sizeof(double)));
-        HIP_TRY(hipMemcpy(d_me.p, mult_eq, B * hp.eq_dim * sizeof(double), hipMemcpyHostToDevice));
-        hp.mult_eq = d_me.d();
-    }
-    if (mult_ineq && hp.ineq_dim > 0) {
-        HIP_TRY(d_mi.alloc(B * hp.ineq_dim * sizeof(double)));
-        HIP_TRY(hipMemcpy(d_mi.p, mult_ineq, B * hp.ineq_dim * sizeof(double), hipMemcpyHostToDevice));
-        hp.mult_ineq = d_mi.d();
-    }
-    hp.mode = 0;
-    hp.mult_obj = mult_obj;
-    const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
+
+int corbo_hip_eval_hessians_views(corbo_hip_handle h, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq, int device_views,
+                                  const double** vals_obj, const double** vals_eq, const double** vals_ineq)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    const HessianStructure* H = nullptr;
+    size_t off[4];
+    int rc = eval_hessians_device(h, lower_part_only, mult_obj, mult_eq, mult_ineq, H, off, device_views == 0);
+    if (rc) return rc;
+    const double** out[3] = {vals_obj, vals_eq, vals_ineq};
     for (int c = 0; c < 3; ++c)
-        if (H.nnz[c] > 0) HIP_TRY(hipMemcpy(out[c], d_v[c].p, B * H.nnz[c] * sizeof(double), hipMemcpyDeviceToHost));
+        if (out[c]) *out[c] = (H->nnz[c] == 0) ? nullptr : (device_views ? h->hb_vals[c].d() : h->hb_pin.d() + off[c]);
     return CORBO_HIP_OK;
 }
 ABI_CATCH
@@ -1396,25 +1480,28 @@ int corbo_hip_eval_objective_gradient(corbo_hip_handle h, double* grad, double* 
 try {
     if (!h || !grad) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
-    HessianStructure H;
+    const HessianStructure* H = nullptr;
     HessParams hp;
-    DevBuf d_so, d_lo, d_g, d_o;
-    int rc = hessian_common(h, H, false, hp, d_so, d_lo);
+    int rc = hessian_common(h, H, false, hp);
     if (rc) return rc;
     const size_t B = (size_t)h->active, n = (size_t)h->S.dims.n, N = (size_t)h->S.N;
-    HIP_TRY(d_g.alloc(B * n * sizeof(double)));
-    HIP_TRY(d_o.alloc(B * N * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(d_g.p, 0, B * n * sizeof(double), h->stream));
+    const size_t ng = (B * n + 1) & ~(size_t)1, no = (B * N + 1) & ~(size_t)1;
+    HIP_TRY(h->hb_grad.need(ng * sizeof(double)));
+    HIP_TRY(h->hb_obj.need(no * sizeof(double)));
+    HIP_TRY(h->hb_pin.need((ng + no) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->hb_grad.p, 0, ng * sizeof(double), h->stream));
     hp.mode = 2;
-    hp.grad = d_g.d(); hp.obj_part = d_o.d(); hp.n_params = (int32_t)n;
+    hp.grad = h->hb_grad.d(); hp.obj_part = h->hb_obj.d(); hp.n_params = (int32_t)n;
     const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
     if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
     HIP_TRY(hipGetLastError());
+    launch_copy_rows(h->hb_grad.d(), h->hb_pin.d(), nullptr, ng, h->stream);
+    if (obj) launch_copy_rows(h->hb_obj.d(), h->hb_pin.d() + ng, nullptr, no, h->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(grad, d_g.p, B * n * sizeof(double), hipMemcpyDeviceToHost));
+    std::memcpy(grad, h->hb_pin.p, B * n * sizeof(double));
     if (obj) {
-        std::vector<double> part(B * N);
-        HIP_TRY(hipMemcpy(part.data(), d_o.p, B * N * sizeof(double), hipMemcpyDeviceToHost));
+        const double* part = h->hb_pin.d() + ng;
         for (size_t b = 0; b < B; ++b) {   // in edge order: stages 0 .. N-2, then the final cost
             double v = 0.0;
             for (size_t k = 0; k < N; ++k) v += part[b * N + k];
@@ -1447,26 +1534,43 @@ int corbo_hip_eval_linear_form(corbo_hip_handle h, double* vals, double* lbA, do
 try {
     if (!h || !vals || !lbA || !ubA) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
-    HessianStructure H;
+    const HessianStructure* H = nullptr;
     HessParams hp;
-    DevBuf d_so, d_lo, d_v, d_l, d_u;
-    int rc = hessian_common(h, H, false, hp, d_so, d_lo);
+    int rc = hessian_common(h, H, false, hp);
     if (rc) return rc;
     const size_t B = (size_t)h->active, rows = (size_t)(hp.eq_dim + hp.ineq_dim + hp.n_bounds);
-    HIP_TRY(d_v.alloc(B * H.lin_nnz * sizeof(double)));
-    HIP_TRY(d_l.alloc(B * rows * sizeof(double)));
-    HIP_TRY(d_u.alloc(B * rows * sizeof(double)));
+    const size_t nv = (B * H->lin_nnz + 1) & ~(size_t)1, nr = (B * rows + 1) & ~(size_t)1;
+    HIP_TRY(h->hb_lin.need(nv * sizeof(double)));
+    HIP_TRY(h->hb_lb.need(nr * sizeof(double)));
+    HIP_TRY(h->hb_ub.need(nr * sizeof(double)));
+    HIP_TRY(h->hb_pin.need((nv + 2 * nr) * sizeof(double)));
     hp.mode = 1;
-    hp.lin_vals = d_v.d(); hp.lbA = d_l.d(); hp.ubA = d_u.d();
+    hp.lin_vals = h->hb_lin.d(); hp.lbA = h->hb_lb.d(); hp.ubA = h->hb_ub.d();
     const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
-    HIP_TRY(hipStreamSynchronize(h->stream));
     if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");
     HIP_TRY(hipGetLastError());
+    const bool small = (nv + 2 * nr) * sizeof(double) <= ((size_t)8 << 20);   // (see corbo_hip_eval_hessians)
+    if (small) {
+        if (H->lin_nnz > 0) { rc = copy_to_pinned(h, h->hb_lin.d(), h->hb_pin.d(), nv); if (rc) return rc; }
+        if (rows > 0) {
+            rc = copy_to_pinned(h, h->hb_lb.d(), h->hb_pin.d() + nv, nr); if (rc) return rc;
+            rc = copy_to_pinned(h, h->hb_ub.d(), h->hb_pin.d() + nv + nr, nr); if (rc) return rc;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (H.lin_nnz > 0) HIP_TRY(hipMemcpy(vals, d_v.p, B * H.lin_nnz * sizeof(double), hipMemcpyDeviceToHost));
-    if (rows > 0) {
-        HIP_TRY(hipMemcpy(lbA, d_l.p, B * rows * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ubA, d_u.p, B * rows * sizeof(double), hipMemcpyDeviceToHost));
+    if (small) {
+        if (H->lin_nnz > 0) std::memcpy(vals, h->hb_pin.p, B * H->lin_nnz * sizeof(double));
+        if (rows > 0) {
+            std::memcpy(lbA, h->hb_pin.d() + nv, B * rows * sizeof(double));
+            std::memcpy(ubA, h->hb_pin.d() + nv + nr, B * rows * sizeof(double));
+        }
+    }
+    else {
+        if (H->lin_nnz > 0) HIP_TRY(hipMemcpy(vals, h->hb_lin.p, B * H->lin_nnz * sizeof(double), hipMemcpyDeviceToHost));
+        if (rows > 0) {
+            HIP_TRY(hipMemcpy(lbA, h->hb_lb.p, B * rows * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ubA, h->hb_ub.p, B * rows * sizeof(double), hipMemcpyDeviceToHost));
+        }
     }
     return CORBO_HIP_OK;
 }

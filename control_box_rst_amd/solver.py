@@ -296,6 +296,20 @@ class BatchedLevenbergMarquardt:
         self._check(rc, "corbo_hip_hessian_structure")
         return [(rows[c][:nnz[c]], cols[c][:nnz[c]]) for c in range(3)]
 
+    def eval_hessians_views(self, lower_part_only=True, mult_obj=1.0, mult_eq=None, mult_ineq=None, device=False):
+        """The same three value lists without the copy into caller arrays: numpy views of the handle's pinned buffer ([B][nnz] each, valid until
+        the next Hessian-path call), or -- device=True -- the raw device addresses (ints) of the lists in HBM."""
+        nnz = np.zeros(3, np.int32)
+        self._check(self.lib.corbo_hip_hessian_nnz(C.byref(self.desc), int(lower_part_only), _ip(nnz)), "corbo_hip_hessian_nnz")
+        me = None if mult_eq is None else np.ascontiguousarray(np.broadcast_to(mult_eq, (self.batch, self.dims.eq)), np.float64)
+        mi = None if mult_ineq is None or self.dims.ineq == 0 else np.ascontiguousarray(np.broadcast_to(mult_ineq, (self.batch, self.dims.ineq)), np.float64)
+        ptr = [C.POINTER(C.c_double)() for _ in range(3)]
+        self._check(self.lib.corbo_hip_eval_hessians_views(self._h, int(lower_part_only), float(mult_obj), _dp(me), _dp(mi), 1 if device else 0,
+                                                           C.byref(ptr[0]), C.byref(ptr[1]), C.byref(ptr[2])), "corbo_hip_eval_hessians_views")
+        if device:
+            return [C.cast(q, C.c_void_p).value for q in ptr]
+        return [np.ctypeslib.as_array(ptr[c], shape=(self.batch, int(nnz[c]))) if nnz[c] else np.zeros((self.batch, 0)) for c in range(3)]
+
     def eval_hessians(self, lower_part_only=True, mult_obj=1.0, mult_eq=None, mult_ineq=None):
         """computeSparseHessiansValues at the resident iterates: value arrays [B][nnz] of the objective / equality / inequality lists.
         mult_eq [B][eq], mult_ineq [B][ineq] (None = ones)."""

@@ -439,6 +439,12 @@ int corbo_hip_eval_hessians(corbo_hip_handle h, int lower_part_only, double mult
 int corbo_hip_eval_objective_gradient(corbo_hip_handle h, double* grad, double* obj);
 /* lbA <= A dx <= ubA with the finite bounds as identity rows: structure (rows / cols may be NULL for the size query), then
  * vals [batch][nnz], lbA / ubA [batch][n_rows].  (ubA of a bound row is x - ub, as the reference computes it.) */
+/* The same lists WITHOUT the copy into caller arrays (a batch of 1024 cfg-3 instances returns 36 MB: the copy, not the kernel, is what a
+ * call costs): device_views = 0 -> views into pinned host memory owned by the handle (one PCIe transfer by a copy kernel), device_views = 1 ->
+ * pointers into the handle's HBM buffers (no transfer at all: a solver that lives on the GPU).  [batch][nnz] each, valid until the next
+ * Hessian-path call on the handle; a NULL view pointer skips that list, an empty list yields NULL. */
+int corbo_hip_eval_hessians_views(corbo_hip_handle h, int lower_part_only, double mult_obj, const double* mult_eq, const double* mult_ineq, int device_views,
+                                  const double** vals_obj, const double** vals_eq, const double** vals_ineq);
 int corbo_hip_linear_form_structure(const corbo_hip_problem_desc* desc, int32_t* nnz_out, int32_t* n_rows_out, int32_t* rows, int32_t* cols);
 int corbo_hip_eval_linear_form(corbo_hip_handle h, double* vals, double* lbA, double* ubA);
 

@@ -213,3 +213,27 @@ def test_a_problem_with_plain_objective_edges_is_refused_by_the_lm_entries():
         s.eval()
     grad, obj = s.objective_gradient()
     assert np.isfinite(grad).all() and abs(obj[0] - g["obj_value"]) <= 1e-12 * abs(g["obj_value"])
+
+
+def test_hessian_views_equal_the_copied_lists():
+    """corbo_hip_eval_hessians_views (pinned-host views, no copy into caller arrays) returns the same numbers as corbo_hip_eval_hessians."""
+    from control_box_rst_amd import problems
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    d = problems.unicycle_desc(N=24)
+    B = 7
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    rng = np.random.default_rng(5)
+    X = s.init_trajectory(x0, xf) + 0.02 * rng.normal(size=(B, s.dims.nv))
+    X[:, : d.nx] = x0
+    s.set_instance_data(X, xref=xf)
+    me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
+    for lower in (True, False):
+        a = s.eval_hessians(lower, 1.3, me, None)
+        v = [np.array(q) for q in s.eval_hessians_views(lower, 1.3, me, None)]
+        for c in range(3):
+            assert a[c].shape[1] == 0 or np.array_equal(a[c], v[c]), (lower, c)
+        # twice in a row: the cached structure and the grown buffers are reused
+        a2 = s.eval_hessians(lower, 1.3, me, None)
+        for c in range(3):
+            assert np.array_equal(a[c], a2[c])

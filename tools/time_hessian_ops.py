@@ -27,7 +27,9 @@ for label, nonlsq, integral in (("least-squares cost", 0, 0), ("plain quadratic 
     me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
     st = s.hessian_structure(True)
     out = {}
-    for name, fn in (("eval_hessians", lambda: s.eval_hessians(True, 1.0, me, None)), ("objective_gradient", s.objective_gradient), ("linear_form", s.linear_form)):
+    for name, fn in (("eval_hessians", lambda: s.eval_hessians(True, 1.0, me, None)), ("eval_hessians_views(pinned)", lambda: s.eval_hessians_views(True, 1.0, me, None)),
+                     ("eval_hessians_views(device, resident multipliers)", lambda: s.eval_hessians_views(True, 1.0, None, None, device=True)),
+                     ("objective_gradient", s.objective_gradient), ("linear_form", s.linear_form)):
         fn()
         t0 = time.perf_counter()
         for _ in range(R):
