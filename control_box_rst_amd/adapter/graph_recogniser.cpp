@@ -258,6 +258,61 @@ bool identifyUpperAffine(BaseEdge& e, VertexInterface* v, Eigen::MatrixXd* U, Ei
     return true;
 }
 
+// TerminalPartialEqualityConstraint (final_state_constraints.h:198-300): rows  x_i - ref_i  for the ACTIVE components of the vertex only, in
+// component order.  Identified through the edge itself: component i is active iff moving it changes a row -- which must be the next row --;
+// its reference is that row's exact root, its weight must be exactly 1.  *mask: bit i = active; ref: the active components' references.
+bool identifyPartialIdentity(BaseEdge& e, VertexInterface* v, unsigned* mask, Eigen::VectorXd* ref)
+{
+    const int n = v->getDimension(), m = e.getDimension();
+    if (m < 1 || m > n) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    *mask = 0;
+    *ref  = Eigen::VectorXd::Zero(n);
+    int next_row = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        const double x0 = x[i];
+        const Eigen::VectorXd r0 = evalEdge(e);
+        x[i] = x0 + 1.0;
+        const Eigen::VectorXd r1 = evalEdge(e);
+        int hit = -1, hits = 0;
+        for (int r = 0; r < m; ++r)
+            if (r1[r] != r0[r]) { hit = r; ++hits; }
+        if (hits == 0) { x[i] = x0; continue; }   // inactive component
+        if (hits != 1 || hit != next_row) return false;
+        // root of the row (Newton on an exactly linear function, then a walk to the exact zero), and the unit weight
+        const double wi = r1[hit] - r0[hit];
+        double xr = x0 - r0[hit] / wi;
+        bool found = false;
+        x[i] = 0.0;
+        if (evalEdge(e)[hit] == 0.0) { xr = 0.0; found = true; }
+        for (int it = 0; it < 8 && !found; ++it)
+        {
+            x[i] = xr;
+            const double r = evalEdge(e)[hit];
+            if (r == 0.0) { found = true; break; }
+            double xn = xr - r / wi;
+            if (xn == xr) xn = std::nextafter(xr, (r / wi > 0) ? -INFINITY : INFINITY);
+            xr = xn;
+        }
+        if (!found) return false;
+        double d = std::ldexp(1.0, std::max(-20, std::min(20, (xr == 0.0) ? 0 : std::ilogb(xr))));
+        bool ok = false;
+        for (int t = 0; t < 40 && !ok; ++t, d *= 2.0)
+        {
+            volatile double xp = xr + d;
+            if ((double)xp - xr == d) { x[i] = xp; ok = (evalEdge(e)[hit] == d); break; }
+        }
+        x[i] = x0;
+        if (!ok) return false;
+        (*ref)[i] = xr;
+        *mask |= 1u << i;
+        ++next_row;
+    }
+    return next_row == m;
+}
+
 bool sameMatrix(const Eigen::MatrixXd& a, const Eigen::MatrixXd& b)
 {
     return a.rows() == b.rows() && a.cols() == b.cols() && (a.array() == b.array()).all();
@@ -865,11 +920,28 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     {
         BaseEdge* e = eqs[g.N - 1].get();
         Eigen::VectorXd w, ref;
-        if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf || !identifyDiagonalAffine(*e, g.xf, &w, &ref) || (w.array() != 1.0).any())
+        if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf) return fail(reason, "extra equality edge is not on x_f");
+        if (e->getDimension() < g.nx)
+        {   // TerminalPartialEqualityConstraint: rows for a subset of the components
+            unsigned mask = 0;
+            if (g.nx > 4 || !identifyPartialIdentity(*e, g.xf, &mask, &ref)) return fail(reason, "extra equality edge is not a TerminalPartialEqualityConstraint (x_f - xref)_active");
+            for (int i = 0; i < g.nx; ++i)
+                if ((mask >> i) & 1u)
+                {
+                    if ((n_final || (n_state && !refs_vary)) && ref[i] != model->xref[i]) return fail(reason, "partial terminal equality constraint uses a different reference");
+                    model->xref[i] = ref[i];
+                }
+            d.final_eq = 1;
+            d.final_eq_mask = mask;
+        }
+        else
+        {
+        if (!identifyDiagonalAffine(*e, g.xf, &w, &ref) || (w.array() != 1.0).any())
             return fail(reason, "extra equality edge is not a TerminalEqualityConstraint x_f - xref");
         if ((n_final || (n_state && !refs_vary)) && !sameVector(ref, model->xref)) return fail(reason, "terminal equality constraint uses a different reference");
         model->xref = ref;
         d.final_eq = 1;
+        }
     }
     else if ((int)eqs.size() > g.N) return fail(reason, "unexpected additional equality edges");
 

@@ -41,7 +41,7 @@ class ProblemDesc(C.Structure):
         ("final_ineq", C.c_int32), ("final_eq", C.c_int32), ("final_ineq_params", C.c_double * (MAX_NX + 1)),
         ("lin_a", C.c_double * 16), ("lin_b", C.c_double * 12),
         ("quad_first_interval", C.c_int32), ("cost_nonlsq", C.c_int32),
-        ("cost_integral", C.c_int32), ("weights_dense", C.c_int32), ("shooting_integrator", C.c_int32), ("_pad0", C.c_int32),
+        ("cost_integral", C.c_int32), ("weights_dense", C.c_int32), ("shooting_integrator", C.c_int32), ("final_eq_mask", C.c_uint32),
         ("q_sqrt", C.c_double * 16), ("r_sqrt", C.c_double * 16), ("qf_sqrt", C.c_double * 16),
     ]
 

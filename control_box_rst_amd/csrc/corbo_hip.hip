@@ -202,6 +202,7 @@ struct corbo_hip_solver {
         std::memcpy(p.mp.sqf, S.sqf, sizeof(p.mp.sqf));
         p.mp.dt_weight = S.dt_weight;
         std::memcpy(p.mp.fin, S.desc.final_ineq_params, sizeof(p.mp.fin));
+        p.fin_eq_row0 = S.fin_eq_row0; p.fin_eq_dim = S.fin_eq_dim;
         p.mp.wdense = d_wdense; p.mp.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         p.fin_row = S.fin_row;
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
@@ -1324,6 +1325,7 @@ struct DevBuf {   // scratch device buffer of one call
 int corbo_hip_hessian_nnz(const corbo_hip_problem_desc* desc, int lower_part_only, int32_t* nnz_out)
 try {
     if (!desc || !nnz_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    if (desc->final_eq_mask) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with a partial terminal equality constraint: not built");
     Structure S;
     std::string err = build_structure(*desc, S);
     if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
@@ -1356,6 +1358,7 @@ ABI_CATCH
 static int hessian_common(corbo_hip_handle h, const HessianStructure*& Hout, bool lower, HessParams& hp)
 {
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
+    if (h->S.desc.final_eq_mask) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with a partial terminal equality constraint: not built");
     auto& c = h->hess_cache[lower ? 1 : 0];
     if (!c.valid) {   // once per (handle, lower): the walk over the edges and its two device tables
         build_hessian_structure(h->S, lower, c.H);

@@ -279,12 +279,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;  // untouched rows: scalar * (e - e) = 0
             if (!fin && ci.cost2_joff >= 0) jst[ci.cost2_joff] = dv;   // duplicated MinimumTime dt edge (nlp_functions.cpp:91-107)
         }
-        if (fin && !ci.fixed && ci.cost2_joff >= 0) {   // TerminalEqualityConstraint x_f - xref: diagonal block, scaled by w_eq (:1552)
+        if (fin && !ci.fixed && ci.cost2_joff >= 0) {   // Terminal[Partial]EqualityConstraint x_f - xref: one row per (active) component, scaled by w_eq (:1552)
             const double a = xv + delta, b = a + neg2delta;
             const double dv = (scalar * ((a - ref) - (b - ref))) * p.w_eq;
-            const int col0  = ci.cost2_joff - c;
+            // the component's row inside the edge (TerminalPartialEqualityConstraint: active components only; an inactive one has no row and
+            // its column is explicit zeros -- cost2_joff is then the column's start)
+            const int idx  = (ci.cost2_row >= 0) ? ci.cost2_row - p.fin_eq_row0 : -1;
+            const int col0 = ci.cost2_joff - (idx >= 0 ? idx : 0);
 #pragma unroll
-            for (int r = 0; r < NX; ++r) jst[col0 + r] = (r == c) ? dv : 0.0;
+            for (int r = 0; r < NX; ++r)
+                if (r < p.fin_eq_dim) jst[col0 + r] = (r == idx) ? dv : 0.0;
         }
         if (ci.bnd_joff >= 0) jst[ci.bnd_joff] = (xv < l) ? -p.w_b : ((xv > u) ? p.w_b : 0.0);  // :1721-1752
     };
@@ -1248,7 +1252,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
             const CompInfo ci = p.comp[k * S + e];
-            if (!ci.fixed && ci.cost2_joff >= 0) { const double a = J[ci.cost2_joff]; dx_diag[e] += a * a; gx[e] -= a * val[ci.cost2_row]; }
+            if (!ci.fixed && ci.cost2_joff >= 0 && ci.cost2_row >= 0) { const double a = J[ci.cost2_joff]; dx_diag[e] += a * a; gx[e] -= a * val[ci.cost2_row]; }
         }
     }
     // stage inequality row on x_k: rank-1 contribution c c^T

@@ -44,6 +44,7 @@ struct SweepParams {
     const int32_t* ineq_cols;     // (N-1)*nx or null
     int32_t fin_row;              // residual row of the final-stage inequality (TerminalBall) or -1
     int32_t fin_joff[CORBO_HIP_MAX_NX];   // its Jacobian entries on x_f, -1 = fixed component
+    int32_t fin_eq_row0, fin_eq_dim;      // final-stage equality (TerminalEqualityConstraint: nx rows; partial: one per active component): first row, rows
     ModelParams mp;
     double dt_fixed;
     // per-call

@@ -61,6 +61,12 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.final_eq != 0 && d.final_eq != 1) return "final_eq must be 0 or 1";
     if (d.final_eq && d.nx > 4 && d.nx != 12) return "terminal equality constraint: families with nx <= 4, and the 12-state big-block family";
     if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
+    if (d.final_eq_mask) {
+        if (!d.final_eq) return "final_eq_mask without final_eq";
+        if (d.nx > 4) return "partial terminal equality constraint: families with nx <= 4";
+        if (d.final_eq_mask >> d.nx) return "final_eq_mask has bits beyond nx";
+        if (d.cost_nonlsq) return "partial terminal equality constraint: Levenberg-Marquardt path only";
+    }
     if (d.shooting_integrator < 0 || d.shooting_integrator > 3) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3)";
     if (d.shooting_integrator != 0 && d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return "shooting_integrator: shooting grids only";
     if (d.weights_dense < 0 || d.weights_dense > 7) return "weights_dense: bits 0..2";
@@ -143,7 +149,11 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         if (d.stage_ineq != CORBO_HIP_INEQ_NONE) ineq.push_back({EK_STAGE_INEQ, k, 1, 2});
         eq.push_back({EK_DEFECT, k, nx, 1});
     }
-    if (xf_unfixed > 0 && d.final_eq) eq.push_back({EK_FINAL_EQ, N - 1, nx, 1});   // finite_differences_grid.cpp:135-141
+    // TerminalEqualityConstraint: nx rows; TerminalPartialEqualityConstraint: one row per active component (final_state_constraints.h:219)
+    const uint32_t feq_mask = d.final_eq_mask ? d.final_eq_mask : ((1u << nx) - 1u);
+    int feq_dim = 0;
+    for (int i = 0; i < nx; ++i) feq_dim += (feq_mask >> i) & 1u;
+    if (xf_unfixed > 0 && d.final_eq) eq.push_back({EK_FINAL_EQ, N - 1, feq_dim, 1});   // finite_differences_grid.cpp:135-141
     if (xf_unfixed > 0 && d.final_cost && !d.cost_nonlsq) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
     if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) ineq.push_back({EK_FINAL_INEQ, N - 1, 1, 2});  // finite_differences_grid.cpp:135-143
 
@@ -174,6 +184,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     if (d.stage_ineq != CORBO_HIP_INEQ_NONE) { S.ineq_cols.assign((size_t)(N - 1) * nx, -1); S.ineq_rows.assign(N - 1, -1); }
     int dt_cost_seen = 0;
     S.fin_row = -1;
+    S.fin_eq_dim = (xf_unfixed > 0 && d.final_eq) ? feq_dim : 0;
     for (int& f : S.fin_joff) f = -1;
     auto add_list = [&](const std::vector<E>& list) {
         for (const E& e : list) {
@@ -186,7 +197,11 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                     int voff = comp_of(e.kind, e.k, vi, c);
                     // the cost edge of a fixed vertex still contributes its value rows (no Jacobian column)
                     if (e.kind == EK_STATE_COST || e.kind == EK_CONTROL_COST || e.kind == EK_FINAL_COST) S.comp[voff].cost_row = row + c;
-                    if (e.kind == EK_FINAL_EQ) S.comp[voff].cost2_row = row + c;   // second diagonal row of an x_f component
+                    // second row of an x_f component: row idx = active components before it; an inactive component has no row
+                    int feq_idx = 0;
+                    for (int q = 0; q < c; ++q) feq_idx += (feq_mask >> q) & 1u;
+                    const bool feq_active = (feq_mask >> c) & 1u;
+                    if (e.kind == EK_FINAL_EQ) { S.comp[voff].cost2_row = feq_active ? row + feq_idx : -1; if (c == 0) S.fin_eq_row0 = row; }
                     if (S.comp[voff].fixed) continue;
                     // one column of the block: rows e.dim, parameter = comp.param
                     for (int r = 0; r < e.dim; ++r) { S.jac_rows.push_back(row + r); S.jac_cols.push_back(S.comp[voff].param); }
@@ -196,7 +211,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                     }
                     else if (e.kind == EK_STAGE_INEQ) S.ineq_cols[(size_t)e.k * nx + c] = joff;
                     else if (e.kind == EK_FINAL_INEQ) S.fin_joff[c] = joff;
-                    else if (e.kind == EK_FINAL_EQ) S.comp[voff].cost2_joff = joff + c;
+                    else if (e.kind == EK_FINAL_EQ) S.comp[voff].cost2_joff = joff + (feq_active ? feq_idx : 0);   // active: the entry of its row; inactive (no row): the column's start (explicit zeros)
                     else if (e.kind == EK_DT_COST) {
                         if (dt_cost_seen == 0) { S.comp[voff].cost_joff = joff; S.comp[voff].cost_row = row; }
                         else { S.comp[voff].cost2_joff = joff; S.comp[voff].cost2_row = row; }

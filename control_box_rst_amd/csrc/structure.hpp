@@ -71,6 +71,7 @@ struct Structure {
     std::vector<int32_t> ineq_cols;      // (N-1)*nx: Jacobian value index of d(ineq_k)/d(x_k[i]) or -1
     std::vector<int32_t> ineq_rows;      // N-1 residual rows (or empty)
     int fin_row = -1;                    // residual row of the final-stage inequality or -1
+    int fin_eq_row0 = -1, fin_eq_dim = 0; // first row / number of rows of the final-stage equality (TerminalEqualityConstraint: nx, partial: active components)
     int fin_joff[CORBO_HIP_MAX_NX];      // Jacobian value index of d(final ineq)/d(x_f[i]) or -1
     std::vector<CompInfo> comp;          // nvs entries
     std::vector<int32_t> jac_rows, jac_cols;  // structure in value order

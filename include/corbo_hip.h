@@ -180,6 +180,10 @@ typedef struct corbo_hip_problem_desc {
      * 2 = IntegratorExplicitRungeKutta2 (:97-138), 3 = IntegratorExplicitRungeKutta3 (:167-213).  (Orders 5 - 7: not built.)
      * Travels to the kernels in slot 7 of the dynamics parameters (no model uses more than 5). */
     int32_t shooting_integrator;
+    /* TerminalPartialEqualityConstraint (final_state_constraints.h:198-300): with final_eq = 1 and a non-zero mask the equality rows exist for the
+     * components whose bit is set only -- row idx = the number of active components before it, x_f[i] - xref[i]; 0 = every component
+     * (TerminalEqualityConstraint).  Levenberg-Marquardt path of the families with nx <= 4. */
+    uint32_t final_eq_mask;
     double q_sqrt[16];
     double r_sqrt[16];
     double qf_sqrt[16];

@@ -379,6 +379,12 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
         case E_FINAL_EQ: { /* TerminalEqualityConstraint::computeNonIntegralStateTerm (final_state_constraints.h:149-154): x_k - xref */
             const double* xk = x + p->v[e->vert[0]].off;
             const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
+            if (d->final_eq_mask) { /* TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): the active components only, in order */
+                int idx = 0;
+                for (int i = 0; i < d->nx; ++i)
+                    if ((d->final_eq_mask >> i) & 1u) out[idx++] = xk[i] - rk[i];
+                break;
+            }
             for (int i = 0; i < d->nx; ++i) out[i] = xk[i] - rk[i];
             break;
         }
@@ -603,6 +609,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_eq) { /* getFinalStateConstraintEdge, isEqualityConstraint() :136-141 */
         o_edge* e = &eq[n_eq++]; e->type = E_FINAL_EQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = nx; e->scale = 1;
+        if (d->final_eq_mask) { e->dim = 0; for (int i = 0; i < nx; ++i) e->dim += (d->final_eq_mask >> i) & 1u; } /* getNonIntegralStateTermDimension = _num_active */
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_ineq == CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) { /* getFinalStateConstraintEdge :136-143 */
         o_edge* e = &ineq[n_ineq++]; e->type = E_FINAL_INEQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = 1; e->scale = 2;

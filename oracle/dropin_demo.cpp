@@ -153,6 +153,7 @@ static void printDesc(const char* scenario, bool ok, const std::string& why, con
             printf("]");
         };
         arr("q_diag", d.q_diag, d.nx); arr("r_diag", d.r_diag, d.nu); arr("qf_diag", d.qf_diag, d.nx); arr("dyn_params", d.dyn_params, 8);
+        printf(", \"final_eq_mask\": %u, \"shooting_integrator\": %d, \"weights_dense\": %d", d.final_eq_mask, d.shooting_integrator, d.weights_dense);
         arr("ineq_params", d.ineq_params, 4); arr("final_ineq_params", d.final_ineq_params, d.nx + 1); arr("xref", m.xref.data(), (int)m.xref.size());
         arr("lin_a", d.lin_a, d.nx * d.nx <= 16 ? d.nx * d.nx : 0); arr("lin_b", d.lin_b, d.nx * d.nu <= 12 ? d.nx * d.nu : 0);
     }
@@ -422,6 +423,14 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setControlBounds(Eigen::VectorXd::Constant(nu, -1.5), Eigen::VectorXd::Constant(nu, 1.5));
         if (scenario == "pendulum") ocp.setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(xf));
+        if (scenario == "mpendulum")
+        {   // TerminalPartialEqualityConstraint: the angle pinned, the angular velocity free
+            Eigen::Matrix<bool, -1, 1> active(2);
+            active << true, false;
+            auto c = std::make_shared<TerminalPartialEqualityConstraint>();
+            c->setXRef(xf, active);
+            ocp.setFinalStageConstraint(c);
+        }
     }
     if (!ocp.initialize()) return r;
     StaticReference xref_static(xf);

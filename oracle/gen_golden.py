@@ -355,6 +355,23 @@ USERMODEL = [
 ]
 
 
+PTEQ = [
+    # TerminalPartialEqualityConstraint (final_state_constraints.h:198-300): equality rows on a subset of the components of x_f
+    ("unicycle_n12_pteq", dict(scenario="unicycle", N=12, iters=6, teq=1, teq_mask=5), (1, 2, 3, 4, 5, 6)),
+    ("vdp_pteq", dict(scenario="vdp", iters=6, teq=1, teq_mask=2), (1, 2, 3, 4, 5, 6)),
+    ("cartpole_pteq", dict(scenario="cartpole", N=14, iters=5, teq=1, teq_mask=9), (1, 2, 3, 4, 5)),
+    ("unicycle_n12_ms_pteq", dict(scenario="unicycle", grid="ms", N=12, iters=5, teq=1, teq_mask=3, xf_fixed=4), (1, 2, 3, 4, 5)),
+]
+
+
+def pteq():
+    for name, kv, keep in PTEQ:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
+
+
 def usermodel():
     for name, kv, keep in USERMODEL:
         d = slim(run("dump", **kv), keep)
@@ -368,6 +385,8 @@ def usermodel():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "pteq":
+        return pteq()
     if len(sys.argv) > 1 and sys.argv[1] == "usermodel":
         return usermodel()
     if len(sys.argv) > 1 and sys.argv[1] == "msint":

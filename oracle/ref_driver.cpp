@@ -178,6 +178,7 @@ struct Scenario
     int final_cost = -1;        // final_cost=0: no final-state cost
     bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
     bool teq = false;           // teq=1: TerminalEqualityConstraint(xf) final-stage constraint
+    int teq_mask = 0;           // teq_mask=m (with teq=1): TerminalPartialEqualityConstraint, component i active iff bit i of m
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
@@ -523,7 +524,15 @@ static Built build(const Scenario& s, int iterations)
     if (s.final_cost == 0) b.ocp->setFinalStageCost({});
     if (s.ball.size() == 4 && s.name != "quad")
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
-    if (s.teq) b.ocp->setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(s.xf));
+    if (s.teq && s.teq_mask)
+    {
+        Eigen::Matrix<bool, -1, 1> active(s.nx);
+        for (int i = 0; i < s.nx; ++i) active[i] = (s.teq_mask >> i) & 1;
+        auto c = std::make_shared<TerminalPartialEqualityConstraint>();
+        c->setXRef(s.xf, active);
+        b.ocp->setFinalStageConstraint(c);
+    }
+    else if (s.teq) b.ocp->setFinalStageConstraint(std::make_shared<TerminalEqualityConstraint>(s.xf));
     if (s.tball_s.size() > 0)
     {
         Eigen::MatrixXd Sm = s.tball_s.asDiagonal();
@@ -725,6 +734,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("final_cost")) s.final_cost = atoi(kv["final_cost"].c_str());
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
+    if (kv.count("teq_mask")) s.teq_mask = atoi(kv["teq_mask"].c_str());
     if (kv.count("xref_traj")) s.xref_traj = atoi(kv["xref_traj"].c_str()) != 0;
     if (kv.count("uref")) s.uref = vec(kv["uref"]);
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
@@ -768,6 +778,7 @@ static int dump(const Scenario& s)
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.teq) printf("\"teq\": 1,\n");
+    if (s.teq && s.teq_mask) printf("\"teq_mask\": %d,\n", s.teq_mask);
     if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);
@@ -1096,6 +1107,7 @@ static int hess(const Scenario& s)
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.teq) printf("\"teq\": 1,\n");
+    if (s.teq && s.teq_mask) printf("\"teq_mask\": %d,\n", s.teq_mask);
     if (s.vargrid) printf("\"vargrid\": 1,\n");
     if (!s.cost.empty()) printf("\"cost\": \"%s\",\n", s.cost.c_str());
     if (s.last_n > 0) printf("\"last_n\": %d,\n", s.last_n);

@@ -101,8 +101,9 @@ def desc_for(g):
         d.final_ineq = capi.FINAL_INEQ_TERMINAL_BALL
         for i, v in enumerate(list(g["tball_s"]) + [g["tball_gamma"]]):
             d.final_ineq_params[i] = v
-    if g.get("teq"):            # TerminalEqualityConstraint(xf)
+    if g.get("teq"):            # TerminalEqualityConstraint(xf); teq_mask: TerminalPartialEqualityConstraint (active components)
         d.final_eq = 1
+        d.final_eq_mask = g.get("teq_mask", 0)
     cost_option(d)
     if g.get("fullq"):          # non-diagonal weights: the reference's upper Cholesky factors as the fixture records them
         nx, nu = d.nx, d.nu

@@ -76,6 +76,8 @@ def test_the_rest_of_the_reference_benchmark_classes(described):
         if p0 is not None:
             assert r["dyn_params"][0] == p0, name
     assert (described["cartpole"]["nx"], described["par2"]["nu"]) == (4, 2)
+    # the massless pendulum carries a TerminalPartialEqualityConstraint on its angle only
+    assert (described["mpendulum"]["final_eq"], described["mpendulum"]["final_eq_mask"]) == (1, 1)
 
 
 def test_plain_and_integral_cost_forms_are_recognised(described):

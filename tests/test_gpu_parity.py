@@ -45,7 +45,9 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         # the shooting grids' other integrators: explicit Euler, Runge-Kutta 2 / 3 (explicit_integrators.h:47-213)
         "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler",
         # a user dynamics model dropped into csrc/models/ (kinematic car)
-        "kcar_n16", "kcar_midpoint", "kcar_ms_rk4"]
+        "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
+        # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
+        "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 # reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
 # with x0 one ulp apart differs by 5e-5 .. 1.1e-4 there while chi2 agrees to 1e-9 (tests/test_oracle_fullsize.py demonstrates it on the
 # reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility

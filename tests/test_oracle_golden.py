@@ -28,7 +28,9 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         # the shooting grids' other integrators: explicit Euler, Runge-Kutta 2 / 3 (explicit_integrators.h:47-213)
         "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler",
         # a user dynamics model dropped into csrc/models/ (kinematic car)
-        "kcar_n16", "kcar_midpoint", "kcar_ms_rk4"]
+        "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
+        # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
+        "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 
 # The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
 # along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
