@@ -297,7 +297,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     {   // device kernels exist for this descriptor?
         FactorParams fp{};
         fp.N = S.N;
-        const bool big = (desc->nx == 12 && desc->nu == 4);   // big-block family (workspace + stage kernels)
+        const bool big = big_family_dims(desc->nx, desc->nu);   // big-block family (workspace + stage kernels)
         // small-block families: N <= 256 LDS-resident, 256 < N <= 1024 the long-horizon kernels (factor workspace in HBM; kernels.hip, factor_body GWS)
         if (!device_kernels_exist(*desc) || factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256 && factor_work_doubles(*desc) == 0) || (S.dt_free && big)) {
             return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
@@ -413,7 +413,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
         CREATE_TRY(hipMalloc((void**)&h->d_work, B * h->work_stride * sizeof(double)));
-        if (S.nx == 12 && S.nu == 4) {
+        if (big_family_dims(S.nx, S.nu)) {
             CREATE_TRY(hipMalloc((void**)&h->d_xe0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
             CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
         }

@@ -146,7 +146,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
     constexpr int NC  = Dy::NC;
     constexpr bool CACHED = DefectTraits<DEFECT>::cached;
-    constexpr bool STAGE  = (NX <= 6) && !LONG;  // small models: Jacobian assembled in LDS and streamed out; big ones / long horizons: stored column by column
+    constexpr bool STAGE  = (NX <= 4) && !LONG;  // small models: Jacobian assembled in LDS and streamed out; big ones / long horizons: stored column by column
     double* js  = p.jac + (size_t)inst * p.nnz_pad;  // Jacobian values of this instance (HBM)
     if constexpr (!STAGE) jst = js;
     int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* red = smem + p.nvs;
     double* cs  = red + 10;
     double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
-    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 6 && !LONG) ? p.nnz_pad : 0));
+    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 4 && !LONG) ? p.nnz_pad : 0));
     const int inst = blockIdx.x + p.inst0;
     if (p.st) { lm_state_in(sl, p.st + inst, threadIdx.x); __syncthreads(); }
     sweep_body<DYN, DEFECT, false, DENSE, LONG>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
@@ -1832,6 +1832,14 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 //   big_chain_kernel    (one wave per instance) the sequential part: block Cholesky in natural order over the 12 x 12 state
 //                       blocks (Schur complement Y Y^T on the matrix cores), backward sweep, controls, trial iterate, LM state.
 // Same LM bookkeeping as factor_body.
+// the two sizes of BigLds the host needs for a descriptor's (nx, nu) (checked against the structure in every unit that uses it)
+constexpr int big_ws_stage(int nx, int nu) { return (3 * nx * nx + nu * nu + 2 * nu * nx + 2 * nx + nu + 2) & ~1; }
+constexpr int big_lds_total(int nx, int nu)
+{
+    const int half = (4 * nx + 2 * (nx + nu) + nx * (nx + nu) + 8 + 1) & ~1, s = nx + nu;
+    return 2 * half + ((s * s + s + nu * nu + 2 * nu * nx + nu + 1) & ~1);
+}
+
 template <int NX, int NU>
 struct BigLds {
     // LDS of the stage kernel.  The x_{k+1} block C of the local defect Jacobian [A | B | C] is DIAGONAL (only e_i depends on
@@ -1866,6 +1874,7 @@ struct BigLds {
     static constexpr int WS_YU = WS_GN + NX;          // [NU]
     static constexpr int WS_Y2 = WS_YU + NU;          // [1]  |y_u|^2 of the stage
     static constexpr int WS_STAGE = (WS_Y2 + 2) & ~1;
+    static_assert(WS_STAGE == big_ws_stage(NX, NU) && TOTAL == big_lds_total(NX, NU), "host-side mirrors of the sizes");
 };
 
 // LDS pointers of one interval of the stage kernel (half = its per-interval area, shared = the wave's assemble scratch)
@@ -2110,13 +2119,13 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         int jo = 0;
 #pragma unroll
         for (int i = 0; i < S; ++i) jo = (i == col) ? sc[i] : jo;
-        const bool present = stage && jo >= 0;
+        const bool present = stage && col < S && jo >= 0;   // (models with fewer than 16 columns: the lanes beyond them integrate the unperturbed step and write nothing)
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
             const double ev = xe[r] - X[kk * S + S + r];   // (x_{k+1} is read here, not kept in registers across the integration)
             const double eo = __shfl_xor(ev, 1);   // the other side of the same column
             const double cv = (scalar * (ev - eo)) * sp.w_eq;   // (plus lanes: v2 - v1; hyper_graph_optimization_problem_edge_based.cpp:1552)
-            if (!minus) {
+            if (!minus && col < S) {
                 c.Gm[r * S + col] = present ? cv : 0.0;
                 if (jac_dump && present) jac_dump[jo + r] = cv;
             }
@@ -3675,7 +3684,16 @@ CORBO_HIP_DYN_ENTRIES(lin41)
 #undef CORBO_HIP_USER_MODEL
 #endif
 
-bool stage_entry_quadrotor(const FactorParams& fp, const SweepParams& sp, int diag_only, double* jac_dump, hipStream_t stream);
+// big-block family (5 <= nx <= 12; quadrotor and the user models of that size): stage kernel (Jacobian dump / assemble) and the factorisation
+#define CORBO_HIP_BIG_ENTRIES(NAME)                                                                                                       \
+    bool stage_entry_##NAME(const FactorParams& fp, const SweepParams& sp, int diag_only, double* jac_dump, hipStream_t stream);          \
+    bool factor_entry_##NAME(const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
+CORBO_HIP_BIG_ENTRIES(quadrotor)
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) CORBO_HIP_BIG_ENTRIES(user_##NAME)
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
 
 #ifdef CORBO_HIP_DYN_TU
 #define CORBO_HIP_CAT2(a, b) a##b
@@ -3713,6 +3731,34 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
     hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), dim3((fp.N + 1) / 2, fp.batch), dim3(64), lds, stream, fp, sp, diag_only, jac_dump);
     return true;
 }
+// one factorisation of the big-block family: (first factorisation of a solve: diag pass + mu / stop) stage kernel, then the chain.  The
+// stacked chain kernel (big_chain2_kernel) is laid out for state blocks of 4, 8 or 12 rows; other sizes take the first formulation
+// (big_chain_kernel, without the matrix-core tiles).
+bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, const SweepParams& sp, hipStream_t stream)
+{
+    using Dy = Dynamics<CORBO_HIP_DYN_TU>;
+    constexpr int NX = Dy::NX, NU = Dy::NU;
+    static_assert(big_family_dims(NX, NU), "big-block family: 5 <= nx <= 12, nu <= 4, nx + nu <= 16");
+    if (p.dt_free || !p.work) return false;
+    if (p.first_pass) {   // (the kernels themselves also check LmState::first)
+        if (!CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(p, sp, 1, nullptr, stream)) return false;
+        hipLaunchKernelGGL((big_first_kernel<NX, NU>), dim3(p.batch), dim3(64), 0, stream, p);
+    }
+    if (!CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(p, sp, 0, nullptr, stream)) return false;
+    if constexpr (NX % 4 == 0) {
+        if (p.chain_variant == 1)   // (diagnostics: the first formulation)
+            hipLaunchKernelGGL((big_chain_kernel<NX, NU, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);
+        else {
+            const size_t lds2 = 2 * sizeof(double) * (size_t)Chain2Lds<NX, NU>::total(p.N);   // two instances per workgroup
+            hipLaunchKernelGGL((big_chain2_kernel<NX, NU>), dim3((p.batch + 1) / 2), dim3(256), lds2, stream, p);
+        }
+    }
+    else hipLaunchKernelGGL((big_chain_kernel<NX, NU, false>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);
+    return true;
+}
+#else   // small-block family: the dispatch tables name these entries for every user model
+bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams&, const SweepParams&, int, double*, hipStream_t) { return false; }
+bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams&, const SweepParams&, hipStream_t) { return false; }
 #endif
 #endif  // CORBO_HIP_DYN_TU
 
@@ -3847,13 +3893,13 @@ size_t sweep_lds_bytes(const SweepParams& p, int nc)
 {
     // vertex values + reduction scratch + dynamics caches + Jacobian staging; the headline family must stay below 40 KB so that
     // four workgroups share a CU (1024 instances = one round over 256 CUs)
-    const size_t stage = (p.nx <= 6 && p.N <= LONG_HORIZON) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
+    const size_t stage = (p.nx <= 4 && p.N <= LONG_HORIZON) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
     return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage) + sizeof(LmState);
 }
 
 size_t factor_work_doubles(const corbo_hip_problem_desc& d)
 {
-    if (d.nx == 12 && d.nu == 4) return (size_t)d.N * BigLds<12, 4>::WS_STAGE;
+    if (big_family_dims(d.nx, d.nu)) return (size_t)d.N * big_ws_stage(d.nx, d.nu);
     if (d.N > LONG_HORIZON && d.N <= LONG_HORIZON_MAX) {   // small-block families, long horizon: the factor carve lives in HBM
         const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE || d.grid == CORBO_HIP_GRID_MS_VARIABLE);
         if (d.nx == 2 && d.nu == 1) return factor_long_work_doubles<2, 1>(d.N, arrow);
@@ -3868,7 +3914,7 @@ size_t factor_work_doubles(const corbo_hip_problem_desc& d)
 
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p)
 {
-    if (d.nx == 12 && d.nu == 4) return sizeof(double) * BigLds<12, 4>::TOTAL;
+    if (big_family_dims(d.nx, d.nu)) return sizeof(double) * big_lds_total(d.nx, d.nu);
     const bool arrow = (d.grid == CORBO_HIP_GRID_FD_VARIABLE || d.grid == CORBO_HIP_GRID_MS_VARIABLE);
     if (d.nx == 2 && d.nu == 1) return factor_lds<2, 1>(p.N, arrow);
     if (d.nx == 3 && d.nu == 2) return factor_lds<3, 2>(p.N, arrow);
@@ -3887,7 +3933,9 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d)
     if (!known_defect) return false;
     auto is = [&](int nx, int nu) { return d.nx == nx && d.nu == nu; };
 #if __has_include("models/_registry.inc")
-#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return is(NX_, NU_);
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) \
+    if (d.dynamics == CORBO_HIP_DYN_USER + SLOT)                     \
+        return is(NX_, NU_) && (NX_ <= 4 || (big_family_dims(NX_, NU_) && d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_MS));   // (big-block family: as the quadrotor)
 #include "models/_registry.inc"
 #undef CORBO_HIP_USER_MODEL
 #endif
@@ -3978,8 +4026,14 @@ bool launch_hessian(const corbo_hip_problem_desc& d, const SweepParams& p, const
 
 bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, double* jac_out, hipStream_t stream)
 {
-    if (d.dynamics != CORBO_HIP_DYN_QUADROTOR) return false;
-    return stage_entry_quadrotor(fp, sp, 0, jac_out, stream);
+    if (!big_family_dims(d.nx, d.nu)) return false;
+    if (d.dynamics == CORBO_HIP_DYN_QUADROTOR) return stage_entry_quadrotor(fp, sp, 0, jac_out, stream);
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return stage_entry_user_##NAME(fp, sp, 0, jac_out, stream);
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
+    return false;
 }
 
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
@@ -4018,20 +4072,15 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
 
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream, const SweepParams* sp)
 {
-    if (d.nx == 12 && d.nu == 4) {
-        if (p.dt_free || !p.work || !sp || d.dynamics != CORBO_HIP_DYN_QUADROTOR) return false;
-        if (p.first_pass) {   // (the kernels themselves also check LmState::first)
-            if (!stage_entry_quadrotor(p, *sp, 1, nullptr, stream)) return false;
-            hipLaunchKernelGGL((big_first_kernel<12, 4>), dim3(p.batch), dim3(64), 0, stream, p);
-        }
-        if (!stage_entry_quadrotor(p, *sp, 0, nullptr, stream)) return false;
-        if (p.chain_variant == 1)   // (diagnostics: the first formulation)
-            hipLaunchKernelGGL((big_chain_kernel<12, 4, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * 12 * 12 + 2 * 12 + 8), stream, p);
-        else {
-            const size_t lds2 = 2 * sizeof(double) * (size_t)Chain2Lds<12, 4>::total(p.N);   // two instances per workgroup
-            hipLaunchKernelGGL((big_chain2_kernel<12, 4>), dim3((p.batch + 1) / 2), dim3(256), lds2, stream, p);
-        }
-        return true;
+    if (big_family_dims(d.nx, d.nu)) {   // big-block family: the model's own unit
+        if (!sp) return false;
+        if (d.dynamics == CORBO_HIP_DYN_QUADROTOR) return factor_entry_quadrotor(p, *sp, stream);
+#if __has_include("models/_registry.inc")
+#define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) return factor_entry_user_##NAME(p, *sp, stream);
+#include "models/_registry.inc"
+#undef CORBO_HIP_USER_MODEL
+#endif
+        return false;
     }
     if (d.nx == 2 && d.nu == 1) return launch_factor_t<2, 1>(p, stream);
     if (d.nx == 3 && d.nu == 2) return launch_factor_t<3, 2>(p, stream);

@@ -20,7 +20,11 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     bool user_model = false;
 #if __has_include("models/_registry.inc")
 #define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) \
-    if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) { if (d.nx != NX_ || d.nu != NU_) return "user model " #NAME ": wrong nx / nu"; user_model = true; }
+    if (d.dynamics == CORBO_HIP_DYN_USER + SLOT) {                                                                                              \
+        if (d.nx != NX_ || d.nu != NU_) return "user model " #NAME ": wrong nx / nu";                                                           \
+        if (NX_ > 4 && !big_family_dims(NX_, NU_)) return "user model " #NAME ": nx <= 4 (small-block families: nu <= 3) or the big-block family (5 <= nx <= 12, nu <= 4, nx + nu <= 16)"; \
+        user_model = true;                                                                                                                       \
+    }
 #include "models/_registry.inc"
 #undef CORBO_HIP_USER_MODEL
 #endif
@@ -57,9 +61,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
     if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
-    if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 4 && d.nx != 12) return "terminal ball: families with nx <= 4, and the 12-state big-block family";
+    if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 4 && !big_family_dims(d.nx, d.nu)) return "terminal ball: families with nx <= 4, and the big-block family";
     if (d.final_eq != 0 && d.final_eq != 1) return "final_eq must be 0 or 1";
-    if (d.final_eq && d.nx > 4 && d.nx != 12) return "terminal equality constraint: families with nx <= 4, and the 12-state big-block family";
+    if (d.final_eq && d.nx > 4 && !big_family_dims(d.nx, d.nu)) return "terminal equality constraint: families with nx <= 4, and the big-block family";
     if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
     if (d.final_eq_mask) {
         if (!d.final_eq) return "final_eq_mask without final_eq";

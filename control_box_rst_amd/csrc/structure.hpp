@@ -15,6 +15,12 @@
 
 namespace corbo_hip {
 
+// Big-block family (kernels.hip, BigLds: stage kernels + chain kernel, factor workspace in HBM; multiple shooting with RK4, fixed dt):
+// the dimensions it is built for -- one lane per (column, side) of an interval's finite differences (nx + nu <= 16), the diag pass parks
+// 4 nx + 2 numbers in the nx x nx factor slot (nx >= 5), the controls are eliminated by one lane (nu <= 4).  The quadrotor (12, 4) and
+// every user model (csrc/models/) of that size.
+constexpr bool big_family_dims(int nx, int nu) { return nx >= 5 && nx <= 12 && nu >= 1 && nu <= 4 && nu <= nx && nx + nu <= 16; }
+
 // edge kinds the device can evaluate (closed set, DESIGN.md "device-describable edges")
 enum EdgeKind : int32_t {
     EK_STATE_COST   = 0,  // sqrt(Q) .* (x_k - xref)            quadratic_cost.cpp:100-119

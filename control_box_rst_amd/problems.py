@@ -205,6 +205,17 @@ def quad_desc(N=200, dt=0.05) -> ProblemDesc:
 QUAD_WEIGHTS = (10.0, 10.0, 10.0)
 
 
+def planar_quadrotor_desc(N=50, dt=0.05) -> ProblemDesc:
+    """The big-block user-model example csrc/models/planar_quadrotor.hpp (public dynamics id DYN_USER + 1; nx = 6, nu = 2): multiple shooting with
+    RK4, thrust bounds, keep-out ball on (x, z, theta) -- scenario pquad of oracle/ref_driver.cpp."""
+    q = (1.0, 1.0, 0.5, 0.1, 0.1, 0.05)
+    return make_desc(grid=capi.GRID_MS, defect=capi.DEFECT_RK4_SHOOTING, dynamics=capi.DYN_USER + 1, nx=6, nu=2, N=N, dt=dt,
+                     q=q, r=(0.02, 0.02), qf=tuple(10.0 * v for v in q),
+                     u_lb=(0.0, 0.0), u_ub=(12.0, 12.0),
+                     stage_ineq=capi.INEQ_BALL, ineq_params=(1.0, 0.5, 0.0, 0.3),
+                     dyn_params=(1.0, 0.05, 0.25, 9.81))
+
+
 def quad_instances(batch: int, seed: int = 20260928, first: int = 0):
     """x0 = hover state near the origin, xf = (2,1,1)+U(-0.3,0.3)^3 position goal, default_rng(seed + i)."""
     x0 = np.zeros((batch, 12))
@@ -222,6 +233,7 @@ SCENARIOS = {
     "dint": (dint_desc, DINT_WEIGHTS),
     "int3": (int3_desc, INT3_WEIGHTS),
     "quad": (quad_desc, QUAD_WEIGHTS),
+    "pquad": (planar_quadrotor_desc, QUAD_WEIGHTS),
 }
 SCENARIOS["par2"] = (lambda **kw: parallel_integrator_desc(2, **kw), BENCHMARK_WEIGHTS)
 SCENARIOS["par3"] = (lambda **kw: parallel_integrator_desc(3, **kw), BENCHMARK_WEIGHTS)

@@ -101,6 +101,17 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
             f[2] = u[0] / d->dyn_params[0] * tan(u[1]);
             break;
         }
+        case CORBO_HIP_DYN_USER + 1: { /* user model csrc/models/planar_quadrotor.hpp = class PlanarQuadrotorRef of oracle/ref_driver.cpp (scenario pquad) */
+            double m = d->dyn_params[0], I = d->dyn_params[1], l = d->dyn_params[2], g = d->dyn_params[3];
+            double T = u[0] + u[1];
+            f[0] = x[3];
+            f[1] = x[4];
+            f[2] = x[5];
+            f[3] = -(T * sin(x[2])) / m;
+            f[4] = (T * cos(x[2])) / m - g;
+            f[5] = (u[0] - u[1]) * l / I;
+            break;
+        }
         case CORBO_HIP_DYN_UNICYCLE: { /* user plug-in, same formula as oracle/ref_driver.cpp */
             f[0] = u[0] * cos(x[2]);
             f[1] = u[0] * sin(x[2]);
@@ -440,6 +451,7 @@ static int validate(const corbo_hip_problem_desc* d)
         case CORBO_HIP_DYN_SERIAL_INTEGRATOR: if (d->nu != 1) return 0; break;
         case CORBO_HIP_DYN_UNICYCLE: if (d->nx != 3 || d->nu != 2) return 0; break;
         case CORBO_HIP_DYN_USER + 0: if (d->nx != 3 || d->nu != 2) return 0; break; /* kinematic car (csrc/models/kinematic_car.hpp) */
+        case CORBO_HIP_DYN_USER + 1: if (d->nx != 6 || d->nu != 2) return 0; break; /* planar quadrotor (csrc/models/planar_quadrotor.hpp) */
         case CORBO_HIP_DYN_QUADROTOR: if (d->nx != 12 || d->nu != 4) return 0; break;
         case CORBO_HIP_DYN_DUFFING:
         case CORBO_HIP_DYN_SIMPLE_PENDULUM:

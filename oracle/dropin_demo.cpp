@@ -70,6 +70,27 @@ class KinematicCarRef : public SystemDynamicsInterface  // a USER class: its dev
     }
 };
 
+class PlanarQuadrotorRef : public SystemDynamicsInterface  // a USER class of the big-block family (nx = 6): device counterpart csrc/models/planar_quadrotor.hpp
+{
+ public:
+    Ptr getInstance() const override { return std::make_shared<PlanarQuadrotorRef>(); }
+    bool isContinuousTime() const override { return true; }
+    bool isLinear() const override { return false; }
+    int getInputDimension() const override { return 2; }
+    int getStateDimension() const override { return 6; }
+    void dynamics(const Eigen::Ref<const StateVector>& x, const Eigen::Ref<const ControlVector>& u, Eigen::Ref<StateVector> f) const override
+    {
+        const double m = 1.0, I = 0.05, l = 0.25, g = 9.81;
+        const double T = u[0] + u[1];
+        f[0] = x[3];
+        f[1] = x[4];
+        f[2] = x[5];
+        f[3] = -(T * std::sin(x[2])) / m;
+        f[4] = (T * std::cos(x[2])) / m - g;
+        f[5] = (u[0] - u[1]) * l / I;
+    }
+};
+
 class QuadrotorRef : public SystemDynamicsInterface  // same expressions as oracle/ref_driver.cpp
 {
  public:
@@ -238,6 +259,16 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         xf[0] = 2; xf[1] = 1; xf[2] = 1;
         nu = 4;
     }
+    else if (scenario == "pquad")
+    {   // a user dynamics class with six states: matched against the models of csrc/models/, solved by the big-block family
+        dyn     = std::make_shared<PlanarQuadrotorRef>();
+        ms_grid = std::make_shared<MultipleShootingGrid>();
+        ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
+        x0 = Eigen::VectorXd::Zero(6);
+        xf = Eigen::VectorXd::Zero(6);
+        xf[0] = 2; xf[1] = 1;
+        nu = 2;
+    }
     else if (scenario == "vdp" || scenario == "duffing" || scenario == "pendulum" || scenario == "vdp_plain" || scenario == "vdp_itrap")
     {
         if (scenario.compare(0, 3, "vdp") == 0) { auto s = std::make_shared<VanDerPolOscillator>(); s->setDampingCoefficient(1.3); dyn = s; }
@@ -308,7 +339,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         xf     = Eigen::Vector2d(1, 0);
         solves = (scenario == "dint_mtq" || scenario == "dint_mtq8") ? 2 : 5;
     }
-    const double dt = (scenario == "quad") ? 0.05 : 0.1;
+    const double dt = (scenario == "quad" || scenario == "pquad") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
     if (mode == Mode::HipStatedWrong) d.r_diag[1] = 2.0 * d.r_diag[1];   // invisible at the reference's initial guess (u = 0)
     if (mode == Mode::Reference)
@@ -390,6 +421,17 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         ocp.setControlBounds(ulb, uub);
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
+    }
+    else if (scenario == "pquad")
+    {
+        Eigen::VectorXd q(6), rr(2);
+        q << 1, 1, 0.5, 0.1, 0.1, 0.05;
+        rr << 0.02, 0.02;
+        Eigen::MatrixXd Q = q.asDiagonal(), R = rr.asDiagonal(), Qf = 10.0 * Q;
+        ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+        ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        ocp.setControlBounds(Eigen::Vector2d(0, 0), Eigen::Vector2d(12, 12));
+        ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.0, 0.3));
     }
     else if (scenario == "dint_mtq8")
     {   // MinTimeQuadratic with only_last_n = 8 (no setter outside fromMessage, hybrid_cost.h:300: a subclass reaches the protected member)
@@ -551,7 +593,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -559,7 +601,7 @@ int main(int argc, char** argv)
         double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
         printf("{\"scenario\": \"%s\", \"mode\": \"recognised\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
                sc, a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
-        if (!(diff < (std::string(sc) == "quad" ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
+        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "pquad") ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
     for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"})

@@ -372,6 +372,34 @@ def pteq():
         print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
 
 
+BIGMODEL = [
+    # a USER dynamics model of the big-block family (csrc/models/planar_quadrotor.hpp <-> class PlanarQuadrotorRef of ref_driver.cpp; nx = 6, nu = 2):
+    # multiple shooting + RK4, thrust bounds, keep-out ball; final-stage constraints; another integrator
+    ("pquad_n10", dict(scenario="pquad", N=10, iters=6), (1, 2, 3, 4, 5, 6)),
+    ("pquad_n24", dict(scenario="pquad", N=24, iters=8), (1, 2, 4, 8)),
+    ("pquad_n10_teq", dict(scenario="pquad", N=10, iters=5, teq=1), (1, 2, 3, 5)),
+    ("pquad_n10_tball", dict(scenario="pquad", N=10, iters=5, tball=0.05, tball_s="1,1,0.5,0.2,0.2,0.1"), (1, 2, 3, 5)),
+    ("pquad_n10_rk3", dict(scenario="pquad", N=10, iters=6, ms_integrator="rk3"), (1, 2, 4, 6)),
+]
+
+
+def bigmodel():
+    for name, kv, keep in BIGMODEL:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", [a["chi2"] for a in d["after_iter"]])
+    d = run("hess", scenario="pquad", N=5)
+    with open(os.path.join(OUT, "hess_pquad_n5.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+    for name, mode, kv in [("mpc_pquad_shift_init", "mpc", dict(scenario="pquad", N=10, steps=3, iters=0, iters0=4, shift=1)),
+                           ("loop_pquad_rk4", "loop", dict(scenario="pquad", N=10, steps=3, iters=4, shift=1, integrator="rk4", disturbance=0.002))]:
+        d = run(mode, **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, [round(st["chi2"], 6) for st in d["steps"]])
+
+
 def usermodel():
     for name, kv, keep in USERMODEL:
         d = slim(run("dump", **kv), keep)
@@ -389,6 +417,8 @@ def main():
         return pteq()
     if len(sys.argv) > 1 and sys.argv[1] == "usermodel":
         return usermodel()
+    if len(sys.argv) > 1 and sys.argv[1] == "bigmodel":
+        return bigmodel()
     if len(sys.argv) > 1 and sys.argv[1] == "msint":
         return msint()
     if len(sys.argv) > 1 and sys.argv[1] == "fullq":

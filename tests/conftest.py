@@ -66,6 +66,8 @@ def desc_for(g):
         return cost_option(problems.dint_desc(N=g["N"], dt=g["dt"], shooting=(g.get("grid") == "ms")))
     if sc == "quad":
         d = problems.quad_desc(N=g["N"], dt=g["dt"])
+    elif sc == "pquad":   # the big-block user-model example (csrc/models/planar_quadrotor.hpp)
+        d = problems.planar_quadrotor_desc(N=g["N"], dt=g["dt"])
     elif sc == "int3":
         d = problems.int3_desc(N=g["N"], dt=g["dt"], defect=defect, time_optimal=bool(g.get("vargrid")))
     elif sc == "lin":

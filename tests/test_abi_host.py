@@ -184,3 +184,9 @@ def test_user_model_directory_is_registered(lib):
     d = problems.kinematic_car_desc(N=12)
     d.dynamics = capi.DYN_USER + 9
     assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0
+    # a model of the big-block family (5 <= nx <= 12): the planar quadrotor in slot 1
+    assert ("planar_quadrotor", 1, 6, 2) in [(m[0], m[1], m[2], m[3]) for m in models]
+    d = problems.planar_quadrotor_desc(N=10)
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) == 0 and (dims.n, dims.m) == (72, 159)   # = the reference's own count (tests/golden/pquad_n10.json)
+    d.nx = 5
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0

@@ -10,7 +10,7 @@ from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
 
 pytestmark = pytest.mark.gpu
 
-LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4", "loop_lin32_rk4"]
+LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pquad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4", "loop_lin32_rk4"]
 
 
 def integrator_of(g):

@@ -50,7 +50,7 @@ def test_warm_start_bit_exact_vs_oracle(oracle_mod, scenario, N):
             assert not np.array_equal(Xd[1, st:2 * st], X[1, st:2 * st])   # something did move
 
 
-@pytest.mark.parametrize("name", ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint", "mpc_quad_shift_init"])
+@pytest.mark.parametrize("name", ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint", "mpc_quad_shift_init", "mpc_pquad_shift_init"])
 def test_sequence_vs_reference(name):
     g = load_golden(name)
     d = desc_for(g)

@@ -46,12 +46,15 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler",
         # a user dynamics model dropped into csrc/models/ (kinematic car)
         "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
+        # a user dynamics model of the big-block family dropped into csrc/models/ (planar quadrotor, nx = 6, nu = 2)
+        "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 # reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
 # with x0 one ulp apart differs by 5e-5 .. 1.1e-4 there while chi2 agrees to 1e-9 (tests/test_oracle_fullsize.py demonstrates it on the
 # reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility
-X_TOL_BY = {"quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
+X_TOL_BY = {"pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,   # (planar quadrotor: same kind of soft directions, see tests/test_oracle_golden.py)
+            "quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
             # SimplePendulum with the reference's default length: g / l = 29 multiplies sin(phi) in the dynamics, so the last-ulp difference
             # between the device's sin and the host libm's (1e-16 / (2 delta) = 5e-8 in a finite-difference column) is amplified 29-fold
             # per Runge-Kutta stage; the first, large step (chi2 3069 -> 266) then differs by 9e-6
@@ -236,6 +239,40 @@ def test_cfg5_quadrotor_batch_vs_oracle(oracle_mod):
     assert np.abs(X[:, :12] - X0[:, :12]).max() == 0.0  # x_0 fixed
     st = s.get_stats()
     assert st["lm_iterations"] == B * 6
+
+
+@pytest.mark.parametrize("N,B", [(50, 33), (129, 5)])
+def test_big_block_user_model_batch_vs_oracle(oracle_mod, N, B):
+    """The big-block family generalised to user models with 5 <= nx <= 12 (csrc/models/planar_quadrotor.hpp: nx = 6, nu = 2; multiple shooting +
+    RK4, thrust bounds, keep-out ball): residual, Jacobian and the LM solve of a seeded batch against the oracle, odd batch (the chain kernels
+    pair instances) and odd / longer horizons (the two waves of the chain kernel meet in the middle block)."""
+    d = problems.planar_quadrotor_desc(N=N)
+    rng = np.random.default_rng(20260929)
+    x0 = np.zeros((B, 6)); xf = np.zeros((B, 6))
+    x0[:, :2] = rng.uniform(-0.2, 0.2, (B, 2))
+    xf[:, :2] = np.array([2.0, 1.0]) + rng.uniform(-0.3, 0.3, (B, 2))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(6)
+    s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+    X0 = s.init_trajectory(x0, xf)
+    X0[:, 6::8] = 4.905; X0[:, 7::8] = 4.905          # hover thrusts as the initial control guess
+    X0[:, 8 * (N // 2): 8 * (N // 2) + 3] = [1.0, 0.5, 0.0]  # one state inside the keep-out ball: active inequality row
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    for b in range(min(B, 4)):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*problems.QUAD_WEIGHTS)
+        assert np.abs(values[b] - vo).max() <= 1e-10 * max(1.0, np.abs(vo).max())
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max())
+        assert (vo[s.dims.lsq + s.dims.eq: s.dims.lsq + s.dims.eq + s.dims.ineq] > 0).any()
+    s.solve()
+    X, chi2, status = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.allclose(chi2, chi2o, rtol=1e-6), (chi2, chi2o)
+    assert np.abs(X - Xo).max() <= 3e-4            # soft directions, see X_TOL_BY
+    assert np.abs(X[:, :6] - X0[:, :6]).max() == 0.0  # x_0 fixed
+    assert s.get_stats()["lm_iterations"] == B * 6
 
 
 def test_multiple_solves_warm_weights(oracle_mod):

@@ -29,12 +29,17 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler",
         # a user dynamics model dropped into csrc/models/ (kinematic car)
         "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
+        # a user dynamics model of the big-block family dropped into csrc/models/ (planar quadrotor, nx = 6, nu = 2)
+        "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 
 # The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
 # along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
 X_TOL = {"quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
+         # the planar quadrotor (user model, big-block family) has the same kind of soft directions (thrusts, cost weight 0.02): the first
+         # iteration agrees to 3e-13, later ones to 3e-5 .. 1e-4 while chi2 agrees to 1e-7 .. 1e-10
+         "pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,
          "cartpole_teq": 5e-6}   # 3.0e-6 at the fifth iteration (FD-noise level, different elimination order than Eigen's)
 
 

@@ -12,7 +12,7 @@ import pytest
 from conftest import desc_for, load_golden
 from control_box_rst_amd import capi
 
-LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4", "loop_lin32_rk4"]
+LOOPS = ["loop_unicycle_rk4", "loop_unicycle_euler_noshift", "loop_vdp_euler", "loop_int3_rk4", "loop_quad_rk4", "loop_pquad_rk4", "loop_pendulum_rk4", "loop_duffing_euler", "loop_cartpole_rk4", "loop_lin32_rk4"]
 POLYNOMIAL = {"loop_vdp_euler", "loop_int3_rk4", "loop_duffing_euler", "loop_lin32_rk4"}   # dynamics without sin / cos: nothing depends on the host's libm
 
 

@@ -7,7 +7,7 @@ import pytest
 from conftest import desc_for, load_golden
 from control_box_rst_amd import capi
 
-MPC = ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint", "mpc_quad_shift_init"]
+MPC = ["mpc_unicycle_shift_init", "mpc_unicycle_shift", "mpc_unicycle_noshift", "mpc_vdp_shift", "mpc_dint", "mpc_quad_shift_init", "mpc_pquad_shift_init"]
 
 
 @pytest.mark.parametrize("name", MPC)
