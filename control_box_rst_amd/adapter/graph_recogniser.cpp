@@ -704,7 +704,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             else if (dynamic_cast<IntegratorExplicitEuler*>(in)) integ = 1;
             else if (dynamic_cast<IntegratorExplicitRungeKutta2*>(in)) integ = 2;
             else if (dynamic_cast<IntegratorExplicitRungeKutta3*>(in)) integ = 3;
-            else return fail(reason, "shooting integrator other than IntegratorExplicitEuler / RungeKutta2 / RungeKutta3 / RungeKutta4");
+            else if (dynamic_cast<IntegratorExplicitRungeKutta5*>(in)) integ = 5;
+            else if (dynamic_cast<IntegratorExplicitRungeKutta6*>(in)) integ = 6;
+            else if (dynamic_cast<IntegratorExplicitRungeKutta7*>(in)) integ = 7;
+            else return fail(reason, "shooting integrator other than IntegratorExplicitEuler / RungeKutta2 ... RungeKutta7");
             if (k > 0 && integ != d.shooting_integrator) return fail(reason, "shooting integrator varies along the horizon");
             d.shooting_integrator = integ;
             defect = CORBO_HIP_DEFECT_RK4_SHOOTING;

@@ -419,6 +419,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         }
         h->force_split = true;  // no fused pass kernel for the big-block family / the long horizons: factor and sweep are separate launches
     }
+    if (S.desc.shooting_integrator >= 5) h->force_split = true;   // Runge-Kutta 5 - 7: a defect formula of the stand-alone kernels only (model.hpp, DEFECT_SHOOTING_HIGH)
     if (S.desc.weights_dense) h->force_split = true;   // non-diagonal weights: the DENSE instantiations exist for the stand-alone kernels only (kernels.hip, sweep_body)
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
     {

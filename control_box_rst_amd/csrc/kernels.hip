@@ -3129,6 +3129,10 @@ bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
     launch_sweep_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(p, stream);
     return true;
 #else
+    if (defect == CORBO_HIP_DEFECT_RK4_SHOOTING && (int)p.mp.dyn[7] >= 5) {   // Runge-Kutta 5 / 6 / 7: a defect formula of its own (model.hpp)
+        if constexpr (Dynamics<DYN>::NX <= 4) { launch_sweep_t<DYN, DEFECT_SHOOTING_HIGH>(p, stream); return true; }
+        else return false;
+    }
     switch (defect) {
         case CORBO_HIP_DEFECT_FORWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, stream); return true;
         case CORBO_HIP_DEFECT_BACKWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(p, stream); return true;
@@ -3489,6 +3493,10 @@ bool launch_hessian_d(int defect, const SweepParams& p, const HessParams& hp, hi
         return true;
     }
     else {
+        if (defect == CORBO_HIP_DEFECT_RK4_SHOOTING && (int)p.mp.dyn[7] >= 5) {
+            if constexpr (Dynamics<DYN>::NX <= 4) { launch_hessian_t<DYN, DEFECT_SHOOTING_HIGH>(p, hp, stream); return true; }
+            else return false;
+        }
         switch (defect) {
             case CORBO_HIP_DEFECT_FORWARD: launch_hessian_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, hp, stream); return true;
             case CORBO_HIP_DEFECT_BACKWARD: launch_hessian_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(p, hp, stream); return true;
@@ -3548,6 +3556,7 @@ bool launch_pass_d(int defect, const FactorParams& fp, const SweepParams& sp, hi
     if (defect != CORBO_HIP_DEFECT_CRANK_NICOLSON) return false;
     return launch_pass_t<DYN, CORBO_HIP_DEFECT_CRANK_NICOLSON>(fp, sp, stream);
 #else
+    if (defect == CORBO_HIP_DEFECT_RK4_SHOOTING && (int)sp.mp.dyn[7] >= 5) return false;   // Runge-Kutta 5 / 6 / 7: separate launches only
     switch (defect) {
         case CORBO_HIP_DEFECT_FORWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_FORWARD>(fp, sp, stream);
         case CORBO_HIP_DEFECT_BACKWARD: return launch_pass_t<DYN, CORBO_HIP_DEFECT_BACKWARD>(fp, sp, stream);

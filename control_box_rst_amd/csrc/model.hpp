@@ -337,6 +337,67 @@ __device__ __forceinline__ void defect_eval_cached(const double* x1, const doubl
     }
 }
 
+// IntegratorExplicitRungeKutta5 / 6 / 7 on the shooting grids (explicit_integrators.h:371-394, :479-503, :600-628; shooting_integrator = 5, 6, 7):
+// 6 / 8 / 11 stages k_s = dt f(x1 + combination of the earlier ones), every combination written with the reference's association (Eigen
+// evaluates the expression coefficient-wise, left to right).  A rarely used option with up to eleven live stage vectors: it is NOT a
+// branch of rk4_end_state (that would raise the register peak of every kernel that integrates with Runge-Kutta 4; an out-of-line call
+// halved their occupancy just the same) but a defect formula of its own, DEFECT_SHOOTING_HIGH, instantiated for the stand-alone sweep
+// and Hessian kernels of the small-block families only (such handles run the phases as separate launches).
+constexpr int DEFECT_SHOOTING_HIGH = CORBO_HIP_DEFECT_RK4_SHOOTING + 1;   // internal: RK4_SHOOTING with shooting_integrator >= 5
+template <int DYN>
+__device__ __forceinline__ void rk_high_order_end_state(const double* x1, const double* u1, double dt, const double* prm, int order, double* xe)
+{
+    using D          = Dynamics<DYN>;
+    constexpr int NX = D::NX;
+    double k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], k7[NX], k8[NX], t[NX];
+#define RK_STAGE(K, EXPR)                                          \
+    {                                                              \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) t[i] = EXPR; \
+        dyn_full<DYN>(t, u1, prm, K);                              \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) K[i] *= dt; \
+    }
+    RK_STAGE(k1, x1[i])
+    if (order == 5) {
+        const double s6 = 2.449489742783178;   // std::sqrt(6.0), correctly rounded (0x1.3988e1409212ep+1)
+        RK_STAGE(k2, x1[i] + 4.0 * k1[i] / 11.0)
+        RK_STAGE(k3, x1[i] + (9.0 * k1[i] + 11.0 * k2[i]) / 50.0)
+        RK_STAGE(k4, x1[i] + (-11.0 * k2[i] + 15.0 * k3[i]) / 4.0)
+        RK_STAGE(k5, x1[i] + ((81.0 + 9.0 * s6) * k1[i] + (255.0 - 55.0 * s6) * k3[i] + (24.0 - 14.0 * s6) * k4[i]) / 600.0)
+        RK_STAGE(k6, x1[i] + ((81.0 - 9.0 * s6) * k1[i] + (255.0 + 55.0 * s6) * k3[i] + (24.0 + 14.0 * s6) * k4[i]) / 600.0)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xe[i] = x1[i] + (4.0 * k1[i] + (16.0 + s6) * k5[i] + (16.0 - s6) * k6[i]) / 36.0;
+    }
+    else if (order == 6) {
+        RK_STAGE(k2, x1[i] + 2.0 * k1[i] / 33.0)
+        RK_STAGE(k3, x1[i] + 4.0 * k2[i] / 33.0)
+        RK_STAGE(k4, x1[i] + (k1[i] + 3.0 * k3[i]) / 22.0)
+        RK_STAGE(k5, x1[i] + (43.0 * k1[i] - 165.0 * k3[i] + 144.0 * k4[i]) / 64.0)
+        RK_STAGE(k6, x1[i] + (-4053483.0 * k1[i] + 16334703.0 * k3[i] - 12787632.0 * k4[i] + 1057536.0 * k5[i]) / 826686.0)
+        RK_STAGE(k7, x1[i] + (169364139.0 * k1[i] - 663893307.0 * k3[i] + 558275718.0 * k4[i] - 29964480.0 * k5[i] + 35395542.0 * k6[i]) / 80707214.0)
+        RK_STAGE(k8, x1[i] + (-733.0 * k1[i] + 3102.0 * k3[i]) / 176.0 - (335763.0 * k4[i] / 23296.0) + (216.0 * k5[i] / 77.0) - (4617.0 * k6[i] / 2816.0) + (7203.0 * k7[i] / 9152.0))
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xe[i] = x1[i] + (336336.0 * k1[i] + 1771561.0 * k4[i] + 1916928.0 * k5[i] + 597051.0 * k6[i] + 1411788.0 * k7[i] + 256256.0 * k8[i]) / 6289920.0;
+    }
+    else {
+        double k9[NX], k10[NX], k11[NX];
+        RK_STAGE(k2, x1[i] + 2.0 * k1[i] / 27.0)
+        RK_STAGE(k3, x1[i] + (k1[i] + 3.0 * k2[i]) / 36.0)
+        RK_STAGE(k4, x1[i] + (k1[i] + 3.0 * k3[i]) / 24.0)
+        RK_STAGE(k5, x1[i] + (80.0 * k1[i] - 300.0 * k3[i] + 300.0 * k4[i]) / 192.0)
+        RK_STAGE(k6, x1[i] + (k1[i] + 5.0 * k4[i] + 4.0 * k5[i]) / 20.0)
+        RK_STAGE(k7, x1[i] + (-25.0 * k1[i] + 125.0 * k4[i] - 260.0 * k5[i] + 250.0 * k6[i]) / 108.0)
+        RK_STAGE(k8, x1[i] + (93.0 * k1[i] + 244.0 * k5[i] - 200.0 * k6[i] + 13.0 * k7[i]) / 900.0)
+        RK_STAGE(k9, x1[i] + (12.0 * k1[i] - 53.0 * k4[i]) / 6.0 + (1408.0 * k5[i] - 1070.0 * k6[i] + 67.0 * k7[i] + 270.0 * k8[i]) / 90.0)
+        RK_STAGE(k10, x1[i] + (-12285.0 * k1[i] + 3105.0 * k4[i] - 105408.0 * k5[i] + 83970.0 * k6[i] - 4617.0 * k7[i] + 41310.0 * k8[i] - 1215.0 * k9[i]) / 14580.0)
+        RK_STAGE(k11, x1[i] + (2383.0 * k1[i] - 8525.0 * k4[i] + 17984.0 * k5[i] - 15050.0 * k6[i] + 2133.0 * k7[i] + 2250.0 * k8[i] + 1125.0 * k9[i] + 1800.0 * k10[i]) / 4100.0)
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xe[i] = x1[i] + (41.0 * k1[i] + 272.0 * k6[i] + 216.0 * k7[i] + 216.0 * k8[i] + 27.0 * k9[i] + 27.0 * k10[i] + 41.0 * k11[i]) / 840.0;
+    }
+#undef RK_STAGE
+}
+
 template <int DYN, bool REUSE>
 __device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1, double dt, const double* prm, double (&ck)[4][Dynamics<DYN>::NC], double* xe);
 
@@ -370,6 +431,12 @@ __device__ __forceinline__ void defect_eval(const double* x1, const double* u1, 
         dyn_full<DYN>(x2, u1, prm, err);
 #pragma unroll
         for (int i = 0; i < NX; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
+    }
+    else if constexpr (DEFECT == DEFECT_SHOOTING_HIGH) {   // shooting with Runge-Kutta 5 / 6 / 7
+        double xe[NX];
+        rk_high_order_end_state<DYN>(x1, u1, dt, prm, (int)prm[7], xe);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { err[i] = xe[i]; err[i] -= x2[i]; }
     }
     else {  // shooting: x_{k+1}(integrator) - x2  (explicit_integrators.h + integrator_interface.h:217-222); the step itself: rk4_end_state below
         double ck[4][D::NC], xe[NX];

@@ -71,7 +71,8 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         if (d.final_eq_mask >> d.nx) return "final_eq_mask has bits beyond nx";
         if (d.cost_nonlsq) return "partial terminal equality constraint: Levenberg-Marquardt path only";
     }
-    if (d.shooting_integrator < 0 || d.shooting_integrator > 3) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3)";
+    if (d.shooting_integrator < 0 || d.shooting_integrator > 7 || d.shooting_integrator == 4) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3), 5 / 6 / 7 (RK5 / RK6 / RK7)";
+    if (d.shooting_integrator >= 5 && d.nx > 4) return "shooting_integrator 5 .. 7 (Runge-Kutta 5 - 7): families with nx <= 4";
     if (d.shooting_integrator != 0 && d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return "shooting_integrator: shooting grids only";
     if (d.weights_dense < 0 || d.weights_dense > 7) return "weights_dense: bits 0..2";
     if (d.weights_dense) {

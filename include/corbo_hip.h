@@ -177,7 +177,8 @@ typedef struct corbo_hip_problem_desc {
     int32_t weights_dense;
     /* Integrator of the shooting grids' defect edges (MultipleShootingGrid::setNumericalIntegrator; explicit_integrators.h):
      * 0 = IntegratorExplicitRungeKutta4 (:244-295, what the reference's examples use), 1 = IntegratorExplicitEuler (:47-72),
-     * 2 = IntegratorExplicitRungeKutta2 (:97-138), 3 = IntegratorExplicitRungeKutta3 (:167-213).  (Orders 5 - 7: not built.)
+     * 2 = IntegratorExplicitRungeKutta2 (:97-138), 3 = IntegratorExplicitRungeKutta3 (:167-213), 5 / 6 / 7 = IntegratorExplicitRungeKutta5 / 6 / 7
+     * (:327-394, :429-503, :541-628; families with nx <= 4).
      * Travels to the kernels in slot 7 of the dynamics parameters (no model uses more than 5). */
     int32_t shooting_integrator;
     /* TerminalPartialEqualityConstraint (final_state_constraints.h:198-300): with final_eq = 1 and a non-zero mask the equality rows exist for the

@@ -228,6 +228,54 @@ static void defect_values(const oracle_problem* p, const double* x1, const doubl
             break;
         case CORBO_HIP_DEFECT_RK4_SHOOTING: { /* explicit_integrators.h:280-295 + integrator_interface.h:217-222 */
             double k1[CORBO_HIP_MAX_NX], k2[CORBO_HIP_MAX_NX], k3[CORBO_HIP_MAX_NX], k4[CORBO_HIP_MAX_NX];
+            if (d->shooting_integrator >= 5) { /* IntegratorExplicitRungeKutta5 / 6 / 7 (:371-394, :479-503, :600-628), coefficient-wise like Eigen, left to right */
+                double K[11][CORBO_HIP_MAX_NX];
+                double *q1 = K[0], *q2 = K[1], *q3 = K[2], *q4 = K[3], *q5 = K[4], *q6 = K[5], *q7 = K[6], *q8 = K[7], *q9 = K[8], *q10 = K[9], *q11 = K[10];
+#define RK_STAGE(Q, EXPR)                                   \
+    {                                                       \
+        for (int i = 0; i < nx; ++i) t[i] = EXPR;           \
+        dynamics(d, t, u1, Q);                              \
+        for (int i = 0; i < nx; ++i) Q[i] *= dt;            \
+    }
+                RK_STAGE(q1, x1[i])
+                if (d->shooting_integrator == 5) {
+                    const double s6 = sqrt(6.0);
+                    RK_STAGE(q2, x1[i] + 4.0 * q1[i] / 11.0)
+                    RK_STAGE(q3, x1[i] + (9.0 * q1[i] + 11.0 * q2[i]) / 50.0)
+                    RK_STAGE(q4, x1[i] + (-11.0 * q2[i] + 15.0 * q3[i]) / 4.0)
+                    RK_STAGE(q5, x1[i] + ((81.0 + 9.0 * s6) * q1[i] + (255.0 - 55.0 * s6) * q3[i] + (24.0 - 14.0 * s6) * q4[i]) / 600.0)
+                    RK_STAGE(q6, x1[i] + ((81.0 - 9.0 * s6) * q1[i] + (255.0 + 55.0 * s6) * q3[i] + (24.0 + 14.0 * s6) * q4[i]) / 600.0)
+                    for (int i = 0; i < nx; ++i) err[i] = x1[i] + (4.0 * q1[i] + (16.0 + s6) * q5[i] + (16.0 - s6) * q6[i]) / 36.0;
+                }
+                else if (d->shooting_integrator == 6) {
+                    RK_STAGE(q2, x1[i] + 2.0 * q1[i] / 33.0)
+                    RK_STAGE(q3, x1[i] + 4.0 * q2[i] / 33.0)
+                    RK_STAGE(q4, x1[i] + (q1[i] + 3.0 * q3[i]) / 22.0)
+                    RK_STAGE(q5, x1[i] + (43.0 * q1[i] - 165.0 * q3[i] + 144.0 * q4[i]) / 64.0)
+                    RK_STAGE(q6, x1[i] + (-4053483.0 * q1[i] + 16334703.0 * q3[i] - 12787632.0 * q4[i] + 1057536.0 * q5[i]) / 826686.0)
+                    RK_STAGE(q7, x1[i] + (169364139.0 * q1[i] - 663893307.0 * q3[i] + 558275718.0 * q4[i] - 29964480.0 * q5[i] + 35395542.0 * q6[i]) / 80707214.0)
+                    RK_STAGE(q8, x1[i] + (-733.0 * q1[i] + 3102.0 * q3[i]) / 176.0 - (335763.0 * q4[i] / 23296.0) + (216.0 * q5[i] / 77.0) - (4617.0 * q6[i] / 2816.0) + (7203.0 * q7[i] / 9152.0))
+                    for (int i = 0; i < nx; ++i)
+                        err[i] = x1[i] + (336336.0 * q1[i] + 1771561.0 * q4[i] + 1916928.0 * q5[i] + 597051.0 * q6[i] + 1411788.0 * q7[i] + 256256.0 * q8[i]) / 6289920.0;
+                }
+                else {
+                    RK_STAGE(q2, x1[i] + 2.0 * q1[i] / 27.0)
+                    RK_STAGE(q3, x1[i] + (q1[i] + 3.0 * q2[i]) / 36.0)
+                    RK_STAGE(q4, x1[i] + (q1[i] + 3.0 * q3[i]) / 24.0)
+                    RK_STAGE(q5, x1[i] + (80.0 * q1[i] - 300.0 * q3[i] + 300.0 * q4[i]) / 192.0)
+                    RK_STAGE(q6, x1[i] + (q1[i] + 5.0 * q4[i] + 4.0 * q5[i]) / 20.0)
+                    RK_STAGE(q7, x1[i] + (-25.0 * q1[i] + 125.0 * q4[i] - 260.0 * q5[i] + 250.0 * q6[i]) / 108.0)
+                    RK_STAGE(q8, x1[i] + (93.0 * q1[i] + 244.0 * q5[i] - 200.0 * q6[i] + 13.0 * q7[i]) / 900.0)
+                    RK_STAGE(q9, x1[i] + (12.0 * q1[i] - 53.0 * q4[i]) / 6.0 + (1408.0 * q5[i] - 1070.0 * q6[i] + 67.0 * q7[i] + 270.0 * q8[i]) / 90.0)
+                    RK_STAGE(q10, x1[i] + (-12285.0 * q1[i] + 3105.0 * q4[i] - 105408.0 * q5[i] + 83970.0 * q6[i] - 4617.0 * q7[i] + 41310.0 * q8[i] - 1215.0 * q9[i]) / 14580.0)
+                    RK_STAGE(q11, x1[i] + (2383.0 * q1[i] - 8525.0 * q4[i] + 17984.0 * q5[i] - 15050.0 * q6[i] + 2133.0 * q7[i] + 2250.0 * q8[i] + 1125.0 * q9[i] + 1800.0 * q10[i]) / 4100.0)
+                    for (int i = 0; i < nx; ++i)
+                        err[i] = x1[i] + (41.0 * q1[i] + 272.0 * q6[i] + 216.0 * q7[i] + 216.0 * q8[i] + 27.0 * q9[i] + 27.0 * q10[i] + 41.0 * q11[i]) / 840.0;
+                }
+#undef RK_STAGE
+                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
+                break;
+            }
             if (d->shooting_integrator == 1) { /* IntegratorExplicitEuler (:66-72): x2 = f; x2 *= dt; x2 += x1 */
                 dynamics(d, x1, u1, err);
                 for (int i = 0; i < nx; ++i) err[i] *= dt;

@@ -294,7 +294,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         if (scenario == "artstein") grid->setFiniteDifferencesCollocationMethod(std::make_shared<BackwardDiffCollocation>());
         w = 5;
     }
-    else if (scenario == "lin32" || scenario == "lin32_rk3")
+    else if (scenario == "lin32" || scenario == "lin32_rk3" || scenario == "lin32_rk7")
     {
         auto s = std::make_shared<LinearStateSpaceModel>();
         Eigen::MatrixXd A(3, 3), B(3, 2);
@@ -304,6 +304,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         dyn     = s;
         ms_grid = std::make_shared<MultipleShootingGrid>();
         if (scenario == "lin32_rk3") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta3>());   // another explicit integrator on the shooting grid
+        else if (scenario == "lin32_rk7") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta7>());   // (eleven stages)
         else ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
         w  = 5;
         x0 = Eigen::Vector3d(0.5, -0.2, 0.1);
@@ -593,7 +594,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);

@@ -335,15 +335,28 @@ MSINT = [
     ("int3_ms_time_optimal_rk2", dict(scenario="int3", grid="ms", vargrid=1, N=25, iters=8, w="100,100,100", ms_integrator="rk2"), (1, 4, 8)),
     ("quad_n10_rk3", dict(scenario="quad", N=10, iters=6, ms_integrator="rk3"), (1, 2, 4, 6)),
     ("quad_n10_euler", dict(scenario="quad", N=10, iters=6, ms_integrator="euler"), (1, 2, 4, 6)),
+    # Runge-Kutta 5 / 6 / 7 (explicit_integrators.h:327-628: six / eight / eleven stages), families with nx <= 4
+    ("vdp_ms_rk5", dict(scenario="vdp", grid="ms", iters=6, ms_integrator="rk5"), (1, 2, 3, 4, 5, 6)),
+    ("unicycle_n12_ms_rk6", dict(scenario="unicycle", grid="ms", N=12, iters=6, ms_integrator="rk6"), (1, 2, 3, 4, 5, 6)),
+    ("cartpole_ms_rk7", dict(scenario="cartpole", grid="ms", N=16, iters=5, ms_integrator="rk7"), (1, 2, 3, 4, 5)),
+    ("pendulum_ms_rk5", dict(scenario="pendulum", grid="ms", N=16, iters=5, ms_integrator="rk5"), (1, 2, 3, 4, 5)),
+    ("int3_ms_time_optimal_rk7", dict(scenario="int3", grid="ms", vargrid=1, N=25, iters=8, w="100,100,100", ms_integrator="rk7"), (1, 4, 8)),
+    ("par3_ms_rk6", dict(scenario="par3", grid="ms", iters=5, ms_integrator="rk6"), (1, 2, 3, 4, 5)),
 ]
 
 
 def msint():
+    only = sys.argv[2] if len(sys.argv) > 2 else ""   # e.g. `gen_golden.py msint rk` regenerates the Runge-Kutta 5 - 7 fixtures only
     for name, kv, keep in MSINT:
+        if only and only not in name:
+            continue
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))
         print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", d["after_iter"][-1]["chi2"])
+    d = run("hess", scenario="pendulum", grid="ms", N=8, ms_integrator="rk5")   # the Hessian-path operators with a six-stage integrator in the defect edges
+    with open(os.path.join(OUT, "hess_pendulum_ms_rk5.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
 
 
 

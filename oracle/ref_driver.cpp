@@ -258,6 +258,9 @@ static NumericalIntegratorExplicitInterface::Ptr shootingIntegrator(const Scenar
     if (s.ms_integrator == "euler") return std::make_shared<IntegratorExplicitEuler>();
     if (s.ms_integrator == "rk2") return std::make_shared<IntegratorExplicitRungeKutta2>();
     if (s.ms_integrator == "rk3") return std::make_shared<IntegratorExplicitRungeKutta3>();
+    if (s.ms_integrator == "rk5") return std::make_shared<IntegratorExplicitRungeKutta5>();
+    if (s.ms_integrator == "rk6") return std::make_shared<IntegratorExplicitRungeKutta6>();
+    if (s.ms_integrator == "rk7") return std::make_shared<IntegratorExplicitRungeKutta7>();
     return std::make_shared<IntegratorExplicitRungeKutta4>();
 }
 
@@ -999,6 +1002,7 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     printf("\"ocp_iters\": %d, \"adapt\": \"%s\", \"nmax\": %d, \"nmin\": %d, \"hyst\": %.17g, \"adapt_first\": %d,\n", ocp_iters, s.adapt.c_str(), s.n_max, s.n_min,
            s.hyst, s.adapt_first ? 1 : 0);
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     printVec("xf", s.xf);
@@ -1148,6 +1152,7 @@ static int hess(const Scenario& s)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g,\n", s.name.c_str(), s.nx, s.nu, s.N, s.dt);
     printf("\"collocation\": \"%s\",\n", s.collocation.c_str());
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.teq) printf("\"teq\": 1,\n");

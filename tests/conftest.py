@@ -88,7 +88,7 @@ def desc_for(g):
     if g.get("grid") == "ms":   # MultipleShootingGrid (vargrid: MultipleShootingVariableGrid, free dt) + RK4
         d.grid, d.defect = (capi.GRID_MS_VARIABLE if g.get("vargrid") else capi.GRID_MS), capi.DEFECT_RK4_SHOOTING
     if "ms_integrator" in g:    # IntegratorExplicitEuler / RungeKutta2 / RungeKutta3 on the shooting grid
-        d.shooting_integrator = {"euler": 1, "rk2": 2, "rk3": 3}[g["ms_integrator"]]
+        d.shooting_integrator = {"euler": 1, "rk2": 2, "rk3": 3, "rk5": 5, "rk6": 6, "rk7": 7}[g["ms_integrator"]]
     if "xlb" in g or "ulb" in g:   # setBounds replaces all four vectors: the ones not given are unbounded
         for key, arr, n in (("xlb", d.x_lb, d.nx), ("xub", d.x_ub, d.nx), ("ulb", d.u_lb, d.nu), ("uub", d.u_ub, d.nu)):
             vals = g.get(key)

@@ -44,6 +44,8 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "unicycle_n12_fullq", "vdp_fullq", "unicycle_n12_fullq_patterns", "unicycle_n12_fullq_ms", "cartpole_fullq", "par3_fullq", "lin33_fullq",
         # the shooting grids' other integrators: explicit Euler, Runge-Kutta 2 / 3 (explicit_integrators.h:47-213)
         "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler",
+        # Runge-Kutta 5 / 6 / 7 on the shooting grids (explicit_integrators.h:327-628)
+        "vdp_ms_rk5", "pendulum_ms_rk5", "unicycle_n12_ms_rk6", "par3_ms_rk6", "cartpole_ms_rk7", "int3_ms_time_optimal_rk7",
         # a user dynamics model dropped into csrc/models/ (kinematic car)
         "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
         # a user dynamics model of the big-block family dropped into csrc/models/ (planar quadrotor, nx = 6, nu = 2)
