@@ -227,6 +227,7 @@ struct corbo_hip_solver {
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
         p.chain_variant = chain_variant;
+        p.defect = S.desc.defect;
         p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         return p;
     }

@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 constexpr int big_ws_stage(int nx, int nu) { return (3 * nx * nx + nu * nu + 2 * nu * nx + 2 * nx + nu + 2) & ~1; }
 constexpr int big_lds_total(int nx, int nu)
 {
-    const int half = (4 * nx + 2 * (nx + nu) + nx * (nx + nu) + 8 + 1) & ~1, s = nx + nu;
+    const int half = (4 * nx + 2 * (nx + nu) + nx * (nx + nu) + 8 + nx * nx + 1) & ~1, s = nx + nu;
     return 2 * half + ((s * s + s + nu * nu + 2 * nu * nx + nu + 1) & ~1);
 }
 
@@ -1853,7 +1853,8 @@ struct BigLds {
     static constexpr int CIN = GDIAG + NX + NU;        // [NX]     inequality row
     static constexpr int FIX = CIN + NX;               // [NX]     fixed flags (as doubles)
     static constexpr int RED = FIX + NX;               // [8]
-    static constexpr int HALF = (RED + 8 + 1) & ~1;
+    static constexpr int CM = RED + 8;                 // [NX][NX] the x_{k+1} block C when it is dense (collocation defects; shooting: diagonal, CD)
+    static constexpr int HALF = (CM + NX * NX + 1) & ~1;
     // shared by the two assemble turns of a wave:
     static constexpr int M = 0;                        // [S][S]   [A B]^T [A B]
     static constexpr int GM = M + (NX + NU) * (NX + NU);   // [S] -[A B]^T r
@@ -1882,10 +1883,10 @@ template <int NX, int NU>
 struct BigCtx {
     using BL = BigLds<NX, NU>;
     static constexpr int S = NX + NU;
-    double *Gm, *cd, *rv, *dg, *gd, *cin, *fx, *red, *Mm, *gm, *Luu, *Zx, *Zp, *yu;
+    double *Gm, *cd, *rv, *dg, *gd, *cin, *fx, *red, *cm, *Mm, *gm, *Luu, *Zx, *Zp, *yu;
     __device__ __forceinline__ BigCtx(double* half, double* shared)
         : Gm(half + BL::G), cd(half + BL::CD), rv(half + BL::R), dg(half + BL::DIAG), gd(half + BL::GDIAG), cin(half + BL::CIN), fx(half + BL::FIX),
-          red(half + BL::RED), Mm(shared + BL::M), gm(shared + BL::GM), Luu(shared + BL::LUU), Zx(shared + BL::ZX), Zp(shared + BL::ZP), yu(shared + BL::YU) {}
+          red(half + BL::RED), cm(half + BL::CM), Mm(shared + BL::M), gm(shared + BL::GM), Luu(shared + BL::LUU), Zx(shared + BL::ZX), Zp(shared + BL::ZP), yu(shared + BL::YU) {}
 };
 
 // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118), in two steps:
@@ -1894,7 +1895,7 @@ struct BigCtx {
 //                        [NX,2NX) same for rhs, [2NX,3NX) / [3NX,4NX) the C-parts this stage adds to x_{k+1}, [4NX], [4NX+1] the
 //                        maxima over the stage's controls;
 //      big_first_kernel  one wave per instance, lanes over the stages: adds the neighbouring parts, takes the maxima.
-template <int NX, int NU>
+template <int NX, int NU, bool DENSEC = false>
 __device__ __forceinline__ void big_diag_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk)
 {
     constexpr int S = NX + NU, W = 2 * NX + NU;
@@ -1903,6 +1904,9 @@ __device__ __forceinline__ void big_diag_stage(const BigCtx<NX, NU>& c, const in
         double dd = 0.0, gg = 0.0;
         if (lane < S) {
             for (int r = 0; r < NX; ++r) { const double a = c.Gm[r * S + lane]; dd += a * a; gg -= a * c.rv[r]; }
+        }
+        else if constexpr (DENSEC) {   // column i of the dense block C (collocation defects)
+            for (int r = 0; r < NX; ++r) { const double a = c.cm[r * NX + lane - S]; dd += a * a; gg -= a * c.rv[r]; }
         }
         else { const double a = c.cd[lane - S]; dd = a * a; gg = -(a * c.rv[lane - S]); }   // column i of the diagonal block C
         if (lane < NX) {
@@ -1955,11 +1959,12 @@ __global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
 // ---- per (stage, instance): everything of the factorisation that does not depend on the neighbouring stages.  The local Jacobian
 //      G = [A | B | C], the defect residual and the single-entry rows of the stage's components are in the LDS context c (written by
 //      the stage kernel straight from the finite differences: the Jacobian of this family never exists in HBM).
-template <int NX, int NU, bool USE_MFMA>
+template <int NX, int NU, bool USE_MFMA, bool DENSEC = false>
 __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk, const double mu_eff)
 {
     using BL = BigLds<NX, NU>;
     constexpr int S = NX + NU;
+    const double* cm = c.cm;   // (DENSEC) the x_{k+1} block, [NX][NX]
     double *Gm = c.Gm, *cd = c.cd, *rv = c.rv, *Mm = c.Mm, *gm = c.gm, *Luu = c.Luu, *Zx = c.Zx, *Zp = c.Zp, *yu = c.yu, *dg = c.dg, *gd = c.gd,
            *cin = c.cin, *red = c.red;
     const bool stage = (k < N - 1);
@@ -2017,8 +2022,16 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         if (lane < 2 * NX + 1) {
             double col[NU];
 #pragma unroll
-            for (int a = 0; a < NU; ++a)
+            for (int a = 0; a < NU; ++a) {
+                if constexpr (DENSEC) {   // B^T C, column lane - NX
+                    double bc = 0.0;
+                    if (lane >= NX && lane < 2 * NX)
+                        for (int r = 0; r < NX; ++r) bc += Gm[r * S + NX + a] * cm[r * NX + lane - NX];
+                    col[a] = (lane < NX) ? Mm[(NX + a) * S + lane] : (lane < 2 * NX) ? bc : gm[NX + a] + gd[NX + a];
+                }
+                else
                 col[a] = (lane < NX) ? Mm[(NX + a) * S + lane] : (lane < 2 * NX) ? Gm[(lane - NX) * S + NX + a] * cd[lane - NX] : gm[NX + a] + gd[NX + a];
+            }
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 double v = col[a];
@@ -2042,8 +2055,13 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         double d = cin[i] * cin[j], cx = 0.0, dn = 0.0;   // (the inequality row of the block: keep-out ball, or the TerminalBall on x_f)
         if (stage) {
             d  = Mm[i * S + j] + d;
-            cx = cd[i] * Gm[i * S + j];
-            dn = (i == j) ? cd[i] * cd[i] : 0.0;
+            if constexpr (DENSEC) {   // C^T A and C^T C
+                for (int r = 0; r < NX; ++r) { cx += cm[r * NX + i] * Gm[r * S + j]; dn += cm[r * NX + i] * cm[r * NX + j]; }
+            }
+            else {
+                cx = cd[i] * Gm[i * S + j];
+                dn = (i == j) ? cd[i] * cd[i] : 0.0;
+            }
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 d -= Zx[a * NX + i] * Zx[a * NX + j];
@@ -2059,7 +2077,8 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         if (!stage) g += -(cin[lane] * red[7]);
         if (stage) {
             g += gm[lane] - cin[lane] * red[7];
-            g2 = -(cd[lane] * rv[lane]);
+            if constexpr (DENSEC) { for (int r = 0; r < NX; ++r) g2 -= cm[r * NX + lane] * rv[r]; }
+            else g2 = -(cd[lane] * rv[lane]);
 #pragma unroll
             for (int a = 0; a < NU; ++a) { g -= Zx[a * NX + lane] * yu[a]; g2 -= Zp[a * NX + lane] * yu[a]; }
         }
@@ -2086,12 +2105,13 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
 //      re-assembled from the (unchanged) accepted iterate with the larger damping -- same bits, no Jacobian traffic at all.
 //      jac_dump (parity hook, corbo_hip_eval): the Jacobian values this kernel works with, written in the public value order.
 #pragma clang fp contract(off)
-template <int DYN>
+template <int DYN, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING>
 __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const SweepParams& sp, const BigCtx<Dynamics<DYN>::NX, Dynamics<DYN>::NU>& c,
                                                 const int k, const int l32, const int inst, const int vsel, double* jac_dump)
 {
     using Dy = Dynamics<DYN>;
     constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, NC = Dy::NC;
+    constexpr bool SHOOT = (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING);
     constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
     const int N      = p.N;
     const bool stage = (k < N - 1), block = (k < N);
@@ -2100,8 +2120,48 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
     const double* X  = sp.x + xo;
     const double dt0 = X[sp.off_dt];
     const int* sc    = p.stage_cols[kk].col;
+    if constexpr (!SHOOT) {
+        // ---- collocation defects (FDCollocationEdge, finite_differences_collocation_edges.h:43-80): every one of the 2 nx + nu columns
+        //      (x_k | u_k | x_{k+1}) is a pair of evaluations of the defect formula (the x_{k+1} block is dense: LDS area cm), 16 columns
+        //      per round of the interval's 32 lanes; the round behind the last column evaluates the unperturbed defect (the residual the
+        //      assembly needs: same inputs and operations as the sweep's, same bits)
+        constexpr int W = 2 * NX + NU;
+        double base[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) base[i] = X[kk * S + i];
+        CORBO_HIP_DYN_OF(dynl, sp, inst)
+        const bool minus = (l32 & 1) != 0;
+#pragma unroll 1
+        for (int c0 = 0; c0 <= W; c0 += 16) {
+            const int col = c0 + (l32 >> 1);
+            double loc[W], e[NX];
+            double pert = 0.0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) { loc[i] = base[i]; pert = (i == col) ? base[i] : pert; }
+            pert += delta;
+            if (minus) pert += neg2delta;
+#pragma unroll
+            for (int i = 0; i < W; ++i) loc[i] = (i == col) ? pert : loc[i];
+            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt0, dynl, e);
+            int jo = -1;
+#pragma unroll
+            for (int i = 0; i < W; ++i) jo = (i == col) ? sc[i] : jo;
+            const bool present = stage && col < W && jo >= 0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                const double eo = __shfl_xor(e[r], 1);   // the other side of the same column
+                const double cv = (scalar * (e[r] - eo)) * sp.w_eq;
+                if (!minus && col < W) {
+                    if (col < S) c.Gm[r * S + col] = present ? cv : 0.0;
+                    else c.cm[r * NX + col - S] = present ? cv : 0.0;
+                    if (jac_dump && present) jac_dump[jo + r] = cv;
+                }
+                if (col == W && !minus) c.rv[r] = stage ? e[r] * sp.w_eq : 0.0;
+            }
+        }
+    }
     // ---- (x_k, u_k) columns: lane = (column, side)
-    {
+    if constexpr (SHOOT) {
         double loc[S], ck[4][NC], xe[NX];
 #pragma unroll
         for (int i = 0; i < S; ++i) loc[i] = X[kk * S + i];
@@ -2134,6 +2194,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
     // ---- x_{k+1} columns (diagonal: only e_i depends on x_{k+1,i}), defect residual, stage inequality: lane i < NX
     if (l32 < NX) {
         const int i      = l32;
+        if constexpr (SHOOT) {
         const double xei = sp.xe0[(((size_t)vsel * sp.batch_total + inst) * sp.N + kk) * NX + i];
         const double x2i = X[kk * S + S + i];
         const double a = x2i + delta, b = a + neg2delta;
@@ -2146,6 +2207,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
             for (int r = 0; r < NX; ++r) jac_dump[jo + r] = (r == i) ? cd : 0.0;   // rows r != i: scalar * (e_r - e_r) = 0
         }
         c.rv[i] = stage ? (xei - x2i) * sp.w_eq : 0.0;
+        }
         double cinv = 0.0, rin = 0.0;
         if (stage && p.ineq_cols) {   // computeValuesActiveInequality + its active-row Jacobian (sweep_body (b), (3))
             double q[3];
@@ -2244,11 +2306,12 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 }
 #pragma clang fp contract(fast)
 
-template <int DYN, bool USE_MFMA>
+template <int DYN, bool USE_MFMA, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 registers: three waves per SIMD (170 without the cap, i.e. two; a cap of four spills 270 bytes and loses)
 void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
 {
+    constexpr bool DENSEC = (DEFECT != CORBO_HIP_DEFECT_RK4_SHOOTING);   // collocation: the x_{k+1} block of the local Jacobian is dense
     using Dy = Dynamics<DYN>;
     constexpr int NX = Dy::NX, NU = Dy::NU;
     using BL = BigLds<NX, NU>;
@@ -2265,15 +2328,15 @@ void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag
     }
     const BigCtx<NX, NU> c0(sm, sm + 2 * BL::HALF), c1(sm + BL::HALF, sm + 2 * BL::HALF);
     const int half = lane >> 5;
-    big_stage_edges<DYN>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
+    big_stage_edges<DYN, DEFECT>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
     __syncthreads();
     if (jac_dump) return;
     for (int h = 0; h < 2; ++h) {
         const int k = 2 * pair + h;
         if (k >= p.N) break;
         double* wk = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE;
-        if (diag_only) big_diag_stage<NX, NU>(h ? c1 : c0, p.N, k, lane, wk + BL::WS_L);
-        else big_assemble_stage<NX, NU, USE_MFMA>(h ? c1 : c0, p.N, k, lane, wk, mu_eff);
+        if (diag_only) big_diag_stage<NX, NU, DENSEC>(h ? c1 : c0, p.N, k, lane, wk + BL::WS_L);
+        else big_assemble_stage<NX, NU, USE_MFMA, DENSEC>(h ? c1 : c0, p.N, k, lane, wk, mu_eff);
     }
 }
 
@@ -3487,12 +3550,7 @@ void launch_hessian_t(const SweepParams& p, const HessParams& hp, hipStream_t st
 template <int DYN>
 bool launch_hessian_d(int defect, const SweepParams& p, const HessParams& hp, hipStream_t stream)
 {
-    if constexpr (Dynamics<DYN>::NX > 6) {   // big-block family: multiple shooting with RK4 only
-        if (defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return false;
-        launch_hessian_t<DYN, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, hp, stream);
-        return true;
-    }
-    else {
+    {
         if (defect == CORBO_HIP_DEFECT_RK4_SHOOTING && (int)p.mp.dyn[7] >= 5) {
             if constexpr (Dynamics<DYN>::NX <= 4) { launch_hessian_t<DYN, DEFECT_SHOOTING_HIGH>(p, hp, stream); return true; }
             else return false;
@@ -3709,13 +3767,7 @@ CORBO_HIP_BIG_ENTRIES(quadrotor)
 #define CORBO_HIP_CAT(a, b) CORBO_HIP_CAT2(a, b)
 bool CORBO_HIP_CAT(sweep_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const SweepParams& p, hipStream_t stream)
 {
-#ifdef CORBO_HIP_DYN_TU_BIG   // big-block family: multiple shooting with RK4 only
-    if (defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return false;
-    launch_sweep_t<CORBO_HIP_DYN_TU, CORBO_HIP_DEFECT_RK4_SHOOTING>(p, stream);
-    return true;
-#else
-    return launch_sweep_d<CORBO_HIP_DYN_TU>(defect, p, stream);
-#endif
+    return launch_sweep_d<CORBO_HIP_DYN_TU>(defect, p, stream);   // (big-block family: shooting with its integrators, and the four collocation formulas)
 }
 bool CORBO_HIP_CAT(pass_entry_, CORBO_HIP_DYN_TU_NAME)(int defect, const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
 {
@@ -3737,8 +3789,15 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
     using Dy = Dynamics<CORBO_HIP_DYN_TU>;
     if (!sp.xe0 || (!fp.work && !jac_dump)) return false;
     const size_t lds = sizeof(double) * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
-    hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), dim3((fp.N + 1) / 2, fp.batch), dim3(64), lds, stream, fp, sp, diag_only, jac_dump);
-    return true;
+    const dim3 g((fp.N + 1) / 2, fp.batch), b(64);
+    switch (fp.defect) {   // shooting (Runge-Kutta 4 / 3 / 2, Euler), or a collocation formula on the FiniteDifferencesGrid
+        case CORBO_HIP_DEFECT_RK4_SHOOTING: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+        case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+        case CORBO_HIP_DEFECT_BACKWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_BACKWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+        case CORBO_HIP_DEFECT_MIDPOINT: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_MIDPOINT>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_CRANK_NICOLSON>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+        default: return false;
+    }
 }
 // one factorisation of the big-block family: (first factorisation of a solve: diag pass + mu / stop) stage kernel, then the chain.  The
 // stacked chain kernel (big_chain2_kernel) is laid out for state blocks of 4, 8 or 12 rows; other sizes take the first formulation
@@ -3941,10 +4000,12 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d)
     const bool known_defect = d.defect >= CORBO_HIP_DEFECT_FORWARD && d.defect <= CORBO_HIP_DEFECT_RK4_SHOOTING;
     if (!known_defect) return false;
     auto is = [&](int nx, int nu) { return d.nx == nx && d.nu == nu; };
+    // big-block family: the grids with a fixed dt -- MultipleShootingGrid (explicit integrators) or FiniteDifferencesGrid (collocation formulas)
+    const bool big_grid = (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_MS) || (d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_FD);
 #if __has_include("models/_registry.inc")
 #define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) \
     if (d.dynamics == CORBO_HIP_DYN_USER + SLOT)                     \
-        return is(NX_, NU_) && (NX_ <= 4 || (big_family_dims(NX_, NU_) && d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_MS));   // (big-block family: as the quadrotor)
+        return is(NX_, NU_) && (NX_ <= 4 || (big_family_dims(NX_, NU_) && big_grid));   // (big-block family: as the quadrotor)
 #include "models/_registry.inc"
 #undef CORBO_HIP_USER_MODEL
 #endif
@@ -3958,7 +4019,7 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d)
         case CORBO_HIP_DYN_UNICYCLE: return is(3, 2);
         case CORBO_HIP_DYN_LINEAR_STATE_SPACE: return is(2, 1) || is(2, 2) || is(3, 1) || is(3, 2) || is(3, 3) || is(4, 1);
         case CORBO_HIP_DYN_QUADROTOR:   // big-block family: multiple shooting with RK4, fixed dt
-            return is(12, 4) && d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_MS;
+            return is(12, 4) && big_grid;
         default: return false;
     }
 }

@@ -109,6 +109,7 @@ struct FactorParams {
     int32_t wdense_mask;          // non-diagonal weights (SweepParams::wdense_mask): the cost blocks of those vertices are dense
     int32_t* cu_table;            // run-to-completion kernel: per-CU progress table for the lag-based issue priority (see lm_pass_kernel), or null
     int32_t stagger;              // run-to-completion kernel (diagnostics): workgroup b waits (b / 256) * stagger shader cycles before it starts
+    int32_t defect;               // corbo_hip_problem_desc::defect (big-block family: which stage kernel)
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 

@@ -393,18 +393,34 @@ BIGMODEL = [
     ("pquad_n10_teq", dict(scenario="pquad", N=10, iters=5, teq=1), (1, 2, 3, 5)),
     ("pquad_n10_tball", dict(scenario="pquad", N=10, iters=5, tball=0.05, tball_s="1,1,0.5,0.2,0.2,0.1"), (1, 2, 3, 5)),
     ("pquad_n10_rk3", dict(scenario="pquad", N=10, iters=6, ms_integrator="rk3"), (1, 2, 4, 6)),
+    # the big-block family on the FiniteDifferencesGrid: the four collocation formulas (dense x_{k+1} block in the stage kernel)
+    ("pquad_fd_n10", dict(scenario="pquad", grid="fd", N=10, iters=6), (1, 2, 3, 4, 5, 6)),
+    ("pquad_fd_n24", dict(scenario="pquad", grid="fd", N=24, iters=8), (1, 2, 4, 8)),
+    ("pquad_fd_n10_forward", dict(scenario="pquad", grid="fd", N=10, iters=5, collocation="forward"), (1, 2, 3, 5)),
+    ("pquad_fd_n10_backward", dict(scenario="pquad", grid="fd", N=10, iters=5, collocation="backward"), (1, 2, 3, 5)),
+    ("pquad_fd_n10_midpoint", dict(scenario="pquad", grid="fd", N=10, iters=5, collocation="midpoint"), (1, 2, 3, 5)),
+    ("pquad_fd_n10_teq", dict(scenario="pquad", grid="fd", N=10, iters=5, teq=1), (1, 2, 3, 5)),
+    ("quad_fd_n10", dict(scenario="quad", grid="fd", N=10, iters=6), (1, 2, 4, 6)),
 ]
 
 
 def bigmodel():
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
     for name, kv, keep in BIGMODEL:
+        if only and only not in name:
+            continue
         d = slim(run("dump", **kv), keep)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))
         print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", [a["chi2"] for a in d["after_iter"]])
-    d = run("hess", scenario="pquad", N=5)
-    with open(os.path.join(OUT, "hess_pquad_n5.json"), "w") as f:
-        json.dump(d, f, separators=(",", ":"))
+    for name, kv in (("hess_pquad_n5", dict(scenario="pquad", N=5)), ("hess_pquad_fd_n5", dict(scenario="pquad", grid="fd", N=5))):
+        if only and only not in name:
+            continue
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+    if only:
+        return
     for name, mode, kv in [("mpc_pquad_shift_init", "mpc", dict(scenario="pquad", N=10, steps=3, iters=0, iters0=4, shift=1)),
                            ("loop_pquad_rk4", "loop", dict(scenario="pquad", N=10, steps=3, iters=4, shift=1, integrator="rk4", disturbance=0.002))]:
         d = run(mode, **kv)

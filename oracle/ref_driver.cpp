@@ -202,6 +202,7 @@ struct Scenario
     bool vargrid = false;       // vargrid=1 (int3): FiniteDifferencesVariableGrid, x_f fixed, MinimumTime(lsq)
     bool teq = false;           // teq=1: TerminalEqualityConstraint(xf) final-stage constraint
     int teq_mask = 0;           // teq_mask=m (with teq=1): TerminalPartialEqualityConstraint, component i active iff bit i of m
+    bool fd = false;            // grid=fd (scenarios quad / pquad, whose default is the shooting grid): FiniteDifferencesGrid + collocation
     bool ms = false;            // grid=ms: MultipleShootingGrid + RK4 instead of the finite-differences grid (vdp, unicycle)
     double tball_gamma = 0;     // tball=<gamma>: TerminalBall(S, gamma) final-stage constraint, S = tball_s (diagonal)
     Eigen::VectorXd tball_s;    // empty = no terminal ball
@@ -385,11 +386,15 @@ static Built build(const Scenario& s, int iterations)
     {
         dyn = std::make_shared<QuadrotorRef>();
         if (s.name == "pquad") dyn = std::make_shared<PlanarQuadrotorRef>();
-        b.ms_grid = std::make_shared<MultipleShootingGrid>();
-        b.ms_grid->setNumericalIntegrator(shootingIntegrator(s));
-        b.ms_grid->setNRef(s.N);
-        b.ms_grid->setDtRef(s.dt);
-        b.any_grid = b.ms_grid;
+        if (s.fd) b.grid = std::make_shared<FiniteDifferencesGrid>();   // grid=fd: the same OCP on the collocation grid
+        else
+        {
+            b.ms_grid = std::make_shared<MultipleShootingGrid>();
+            b.ms_grid->setNumericalIntegrator(shootingIntegrator(s));
+            b.ms_grid->setNRef(s.N);
+            b.ms_grid->setDtRef(s.dt);
+            b.any_grid = b.ms_grid;
+        }
     }
     else
     {
@@ -765,7 +770,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("x0")) s.x0 = vec(kv["x0"]);
     if (kv.count("xf")) s.xf = vec(kv["xf"]);
     if (kv.count("collocation")) s.collocation = kv["collocation"];
-    if (kv.count("grid")) s.ms = (kv["grid"] == "ms");
+    if (kv.count("grid")) { s.ms = (kv["grid"] == "ms"); s.fd = (kv["grid"] == "fd"); }
     auto bvec = [&](const std::string& str) {   // like vec(), "inf" / "-inf" = +-CORBO_INF_DBL
         std::vector<double> v;
         std::stringstream ss(str);
@@ -821,6 +826,7 @@ static int dump(const Scenario& s)
            s.N, s.dt, s.iters, s.solves);
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (s.fd) printf("\"grid\": \"fd\",\n");
     if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.ball.size() == 4) printVec("ball", s.ball);
@@ -1002,6 +1008,7 @@ static int mpc(const Scenario& s, std::map<std::string, std::string>& kv)
     printf("\"ocp_iters\": %d, \"adapt\": \"%s\", \"nmax\": %d, \"nmin\": %d, \"hyst\": %.17g, \"adapt_first\": %d,\n", ocp_iters, s.adapt.c_str(), s.n_max, s.n_min,
            s.hyst, s.adapt_first ? 1 : 0);
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (s.fd) printf("\"grid\": \"fd\",\n");
     if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     printf("\"collocation\": \"%s\", \"weights\": [%.17g, %.17g, %.17g],\n", s.collocation.c_str(), s.w_eq, s.w_ineq, s.w_b);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
@@ -1152,6 +1159,7 @@ static int hess(const Scenario& s)
     printf("{\n\"scenario\": \"%s\", \"nx\": %d, \"nu\": %d, \"N\": %d, \"dt\": %.17g,\n", s.name.c_str(), s.nx, s.nu, s.N, s.dt);
     printf("\"collocation\": \"%s\",\n", s.collocation.c_str());
     if (s.ms) printf("\"grid\": \"ms\",\n");
+    if (s.fd) printf("\"grid\": \"fd\",\n");
     if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }

@@ -85,6 +85,8 @@ def desc_for(g):
     else:
         raise KeyError(sc)
     # options of oracle/ref_driver.cpp recorded in the fixture header
+    if g.get("grid") == "fd":   # scenarios whose default is the shooting grid (quad, pquad) on the FiniteDifferencesGrid
+        d.grid, d.defect = capi.GRID_FD, defect
     if g.get("grid") == "ms":   # MultipleShootingGrid (vargrid: MultipleShootingVariableGrid, free dt) + RK4
         d.grid, d.defect = (capi.GRID_MS_VARIABLE if g.get("vargrid") else capi.GRID_MS), capi.DEFECT_RK4_SHOOTING
     if "ms_integrator" in g:    # IntegratorExplicitEuler / RungeKutta2 / RungeKutta3 on the shooting grid

@@ -117,8 +117,8 @@ def test_product_does_not_use_the_oracle():
 
 
 def test_create_refuses_descriptors_without_device_kernels_before_touching_the_device():
-    """a descriptor that validates but has no sweep / pass kernel (serial integrator of order 4; quadrotor on a collocation
-    grid) is refused by corbo_hip_create itself (CORBO_HIP_ERR_UNSUPPORTED), not by the first solve.  The gate runs before any HIP call,
+    """a descriptor that validates but has no sweep / pass kernel (serial integrator of order 4; quadrotor on a grid
+    with a free dt) is refused by corbo_hip_create itself (CORBO_HIP_ERR_UNSUPPORTED), not by the first solve.  The gate runs before any HIP call,
     so it is testable without a GPU."""
     import ctypes as C
     lib = capi.load()
@@ -128,8 +128,10 @@ def test_create_refuses_descriptors_without_device_kernels_before_touching_the_d
         d.q_diag[i], d.qf_diag[i] = 1.0, 1.0
     h = C.c_void_p()
     assert lib.corbo_hip_create(C.byref(d), 1, 0, C.byref(h)) == -3 and not h.value
-    q = problems.quad_desc(N=10)
-    q.grid, q.defect = capi.GRID_FD, capi.DEFECT_CRANK_NICOLSON
+    q = problems.quad_desc(N=10)   # (the big-block family has the fixed-dt grids only: shooting and -- since round 3 -- collocation)
+    q.grid = capi.GRID_MS_VARIABLE
+    assert lib.corbo_hip_create(C.byref(q), 1, 0, C.byref(h)) == -3 and not h.value
+    q.grid, q.defect = capi.GRID_FD_VARIABLE, capi.DEFECT_CRANK_NICOLSON
     assert lib.corbo_hip_create(C.byref(q), 1, 0, C.byref(h)) == -3 and not h.value
 
 

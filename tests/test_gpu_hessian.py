@@ -16,7 +16,7 @@ from control_box_rst_amd import problems
 
 pytestmark = pytest.mark.gpu
 
-HESS = ["hess_kcar", "hess_pquad_n5", "hess_unicycle_fullq", "hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
+HESS = ["hess_kcar", "hess_pquad_n5", "hess_pquad_fd_n5", "hess_unicycle_fullq", "hess_vdp", "hess_vdp_forward", "hess_vdp_backward", "hess_vdp_midpoint", "hess_vdp_teq", "hess_dint", "hess_int3_time_optimal",
         "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_pendulum_ms_rk5", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal",
         "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5",
         "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq",

@@ -50,12 +50,15 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
         # a user dynamics model of the big-block family dropped into csrc/models/ (planar quadrotor, nx = 6, nu = 2)
         "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
+        # ... and the same family on the FiniteDifferencesGrid (the four collocation formulas), incl. the 12-state quadrotor
+        "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 # reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
 # with x0 one ulp apart differs by 5e-5 .. 1.1e-4 there while chi2 agrees to 1e-9 (tests/test_oracle_fullsize.py demonstrates it on the
 # reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility
-X_TOL_BY = {"pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,   # (planar quadrotor: same kind of soft directions, see tests/test_oracle_golden.py)
+X_TOL_BY = {"pquad_fd_n10": 2e-5, "pquad_fd_n24": 2e-5, "pquad_fd_n10_forward": 2e-5, "pquad_fd_n10_backward": 2e-5, "pquad_fd_n10_midpoint": 2e-5, "pquad_fd_n10_teq": 2e-5, "quad_fd_n10": 2e-5,   # (the same models on the collocation grid: tests/test_oracle_golden.py)
+            "pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,   # (planar quadrotor: same kind of soft directions, see tests/test_oracle_golden.py)
             "quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
             # SimplePendulum with the reference's default length: g / l = 29 multiplies sin(phi) in the dynamics, so the last-ulp difference
             # between the device's sin and the host libm's (1e-16 / (2 delta) = 5e-8 in a finite-difference column) is amplified 29-fold
@@ -243,12 +246,14 @@ def test_cfg5_quadrotor_batch_vs_oracle(oracle_mod):
     assert st["lm_iterations"] == B * 6
 
 
-@pytest.mark.parametrize("N,B", [(50, 33), (129, 5)])
-def test_big_block_user_model_batch_vs_oracle(oracle_mod, N, B):
+@pytest.mark.parametrize("N,B,defect", [(50, 33, None), (129, 5, None), (40, 9, capi.DEFECT_CRANK_NICOLSON), (33, 4, capi.DEFECT_MIDPOINT), (24, 3, capi.DEFECT_BACKWARD)])
+def test_big_block_user_model_batch_vs_oracle(oracle_mod, N, B, defect):
     """The big-block family generalised to user models with 5 <= nx <= 12 (csrc/models/planar_quadrotor.hpp: nx = 6, nu = 2; multiple shooting +
     RK4, thrust bounds, keep-out ball): residual, Jacobian and the LM solve of a seeded batch against the oracle, odd batch (the chain kernels
     pair instances) and odd / longer horizons (the two waves of the chain kernel meet in the middle block)."""
     d = problems.planar_quadrotor_desc(N=N)
+    if defect is not None:   # the same OCP on the FiniteDifferencesGrid: collocation defects, dense x_{k+1} blocks in the stage kernel
+        d.grid, d.defect = capi.GRID_FD, defect
     rng = np.random.default_rng(20260929)
     x0 = np.zeros((B, 6)); xf = np.zeros((B, 6))
     x0[:, :2] = rng.uniform(-0.2, 0.2, (B, 2))
