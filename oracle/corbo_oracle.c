@@ -28,7 +28,8 @@ typedef struct {
     int col;        /* getVertexIdx(): first parameter index, -1 when not active (vertex_set.cpp:405-418) */
 } o_vertex;
 
-enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ, E_FINAL_EQ, E_INTEGRAL_COST };
+enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ, E_FINAL_EQ, E_INTEGRAL_COST,
+       E_MS_MIXED_OBJ, E_MS_MIXED_EQ }; /* the objective part and the equality part of one MultipleShootingEdgeSingleControl (a BaseMixedEdge) */
 
 typedef struct {
     int type;
@@ -39,6 +40,7 @@ typedef struct {
     int row;      /* global row of the first value in the stacked residual */
     int scale;    /* 0 lsq (unscaled), 1 equality (w_eq), 2 inequality (w_ineq, active set) */
     int nonlsq;   /* objective edge that is NOT in least-squares form (scalar term; Hessian-path operators only: row = -1, no LM rows) */
+    int partner;  /* E_MS_MIXED_OBJ: index of the E_MS_MIXED_EQ part of the same mixed edge (and vice versa); else -1 */
 } o_edge;
 
 typedef struct { /* one (edge, vertex) Jacobian block, values stored column-major like Eigen::MatrixXd */
@@ -202,6 +204,126 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
 /* ------------------------------------------------------------------------------------------------------------ */
 /* edge values                                                                                                    */
 
+/* QuadraticFormCost::computeIntegralStateControlTerm (quadratic_cost.cpp:186-230), diagonal weights: cost = 0; cost += xd^T Q xd; cost += u^T R u */
+static void integral_cost_term(const oracle_problem* p, const double* rk, const double* x, const double* u, double* cost_out)
+{
+    const corbo_hip_problem_desc* d = &p->d;
+    double cost = 0.0, acc = 0.0;
+    for (int i = 0; i < d->nx; ++i) { double xd = x[i] - rk[i]; acc += (xd * d->q_diag[i]) * xd; }
+    cost += acc;
+    acc = 0.0;
+    for (int i = 0; i < d->nu; ++i) acc += (u[i] * d->r_diag[i]) * u[i];
+    cost += acc;
+    cost_out[0] = cost;
+}
+
+/* One step of the shooting grids' explicit integrator (MultipleShootingGrid::setNumericalIntegrator): the end state x(t + dt).
+ * aug = 0: solveIVP(x1, u1, dt, system, x2) on the system dynamics (MSVariableDynamicsOnlyEdge, multiple_shooting_edges.h:125-134);
+ * aug = 1: solveIVP(current, dt, integrand, values) of MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:214-229, 251-281) on
+ *          current = [cost; x] (n = nx + 1): integrand = [c(x, u) against reference k; f(x, u)] -- both overloads of every integrator are the
+ *          same expressions (explicit_integrators.h). */
+static void shooting_end_state(const oracle_problem* p, int aug, const double* rk, const double* x1, const double* u1, double dt, double* err)
+{
+    const corbo_hip_problem_desc* d = &p->d;
+    const int n = aug ? d->nx + 1 : d->nx;
+    double t[CORBO_HIP_MAX_NX + 1];
+#define SHOOT_RHS(X, U, F)                                                                                   \
+    do {                                                                                                     \
+        if (aug) { dynamics(d, (X) + 1, (U), (F) + 1); integral_cost_term(p, rk, (X) + 1, (U), (F)); }       \
+        else dynamics(d, (X), (U), (F));                                                                     \
+    } while (0)
+        {
+            double k1[CORBO_HIP_MAX_NX + 1], k2[CORBO_HIP_MAX_NX + 1], k3[CORBO_HIP_MAX_NX + 1], k4[CORBO_HIP_MAX_NX + 1];
+            if (d->shooting_integrator >= 5) { /* IntegratorExplicitRungeKutta5 / 6 / 7 (:371-394, :479-503, :600-628), coefficient-wise like Eigen, left to right */
+                double K[11][CORBO_HIP_MAX_NX + 1];
+                double *q1 = K[0], *q2 = K[1], *q3 = K[2], *q4 = K[3], *q5 = K[4], *q6 = K[5], *q7 = K[6], *q8 = K[7], *q9 = K[8], *q10 = K[9], *q11 = K[10];
+#define RK_STAGE(Q, EXPR)                                   \
+    {                                                       \
+        for (int i = 0; i < n; ++i) t[i] = EXPR;           \
+        SHOOT_RHS(t, u1, Q);                              \
+        for (int i = 0; i < n; ++i) Q[i] *= dt;            \
+    }
+                RK_STAGE(q1, x1[i])
+                if (d->shooting_integrator == 5) {
+                    const double s6 = sqrt(6.0);
+                    RK_STAGE(q2, x1[i] + 4.0 * q1[i] / 11.0)
+                    RK_STAGE(q3, x1[i] + (9.0 * q1[i] + 11.0 * q2[i]) / 50.0)
+                    RK_STAGE(q4, x1[i] + (-11.0 * q2[i] + 15.0 * q3[i]) / 4.0)
+                    RK_STAGE(q5, x1[i] + ((81.0 + 9.0 * s6) * q1[i] + (255.0 - 55.0 * s6) * q3[i] + (24.0 - 14.0 * s6) * q4[i]) / 600.0)
+                    RK_STAGE(q6, x1[i] + ((81.0 - 9.0 * s6) * q1[i] + (255.0 + 55.0 * s6) * q3[i] + (24.0 + 14.0 * s6) * q4[i]) / 600.0)
+                    for (int i = 0; i < n; ++i) err[i] = x1[i] + (4.0 * q1[i] + (16.0 + s6) * q5[i] + (16.0 - s6) * q6[i]) / 36.0;
+                }
+                else if (d->shooting_integrator == 6) {
+                    RK_STAGE(q2, x1[i] + 2.0 * q1[i] / 33.0)
+                    RK_STAGE(q3, x1[i] + 4.0 * q2[i] / 33.0)
+                    RK_STAGE(q4, x1[i] + (q1[i] + 3.0 * q3[i]) / 22.0)
+                    RK_STAGE(q5, x1[i] + (43.0 * q1[i] - 165.0 * q3[i] + 144.0 * q4[i]) / 64.0)
+                    RK_STAGE(q6, x1[i] + (-4053483.0 * q1[i] + 16334703.0 * q3[i] - 12787632.0 * q4[i] + 1057536.0 * q5[i]) / 826686.0)
+                    RK_STAGE(q7, x1[i] + (169364139.0 * q1[i] - 663893307.0 * q3[i] + 558275718.0 * q4[i] - 29964480.0 * q5[i] + 35395542.0 * q6[i]) / 80707214.0)
+                    RK_STAGE(q8, x1[i] + (-733.0 * q1[i] + 3102.0 * q3[i]) / 176.0 - (335763.0 * q4[i] / 23296.0) + (216.0 * q5[i] / 77.0) - (4617.0 * q6[i] / 2816.0) + (7203.0 * q7[i] / 9152.0))
+                    for (int i = 0; i < n; ++i)
+                        err[i] = x1[i] + (336336.0 * q1[i] + 1771561.0 * q4[i] + 1916928.0 * q5[i] + 597051.0 * q6[i] + 1411788.0 * q7[i] + 256256.0 * q8[i]) / 6289920.0;
+                }
+                else {
+                    RK_STAGE(q2, x1[i] + 2.0 * q1[i] / 27.0)
+                    RK_STAGE(q3, x1[i] + (q1[i] + 3.0 * q2[i]) / 36.0)
+                    RK_STAGE(q4, x1[i] + (q1[i] + 3.0 * q3[i]) / 24.0)
+                    RK_STAGE(q5, x1[i] + (80.0 * q1[i] - 300.0 * q3[i] + 300.0 * q4[i]) / 192.0)
+                    RK_STAGE(q6, x1[i] + (q1[i] + 5.0 * q4[i] + 4.0 * q5[i]) / 20.0)
+                    RK_STAGE(q7, x1[i] + (-25.0 * q1[i] + 125.0 * q4[i] - 260.0 * q5[i] + 250.0 * q6[i]) / 108.0)
+                    RK_STAGE(q8, x1[i] + (93.0 * q1[i] + 244.0 * q5[i] - 200.0 * q6[i] + 13.0 * q7[i]) / 900.0)
+                    RK_STAGE(q9, x1[i] + (12.0 * q1[i] - 53.0 * q4[i]) / 6.0 + (1408.0 * q5[i] - 1070.0 * q6[i] + 67.0 * q7[i] + 270.0 * q8[i]) / 90.0)
+                    RK_STAGE(q10, x1[i] + (-12285.0 * q1[i] + 3105.0 * q4[i] - 105408.0 * q5[i] + 83970.0 * q6[i] - 4617.0 * q7[i] + 41310.0 * q8[i] - 1215.0 * q9[i]) / 14580.0)
+                    RK_STAGE(q11, x1[i] + (2383.0 * q1[i] - 8525.0 * q4[i] + 17984.0 * q5[i] - 15050.0 * q6[i] + 2133.0 * q7[i] + 2250.0 * q8[i] + 1125.0 * q9[i] + 1800.0 * q10[i]) / 4100.0)
+                    for (int i = 0; i < n; ++i)
+                        err[i] = x1[i] + (41.0 * q1[i] + 272.0 * q6[i] + 216.0 * q7[i] + 216.0 * q8[i] + 27.0 * q9[i] + 27.0 * q10[i] + 41.0 * q11[i]) / 840.0;
+                }
+#undef RK_STAGE
+                return;
+            }
+            if (d->shooting_integrator == 1) { /* IntegratorExplicitEuler (:66-72): x2 = f; x2 *= dt; x2 += x1 */
+                SHOOT_RHS(x1, u1, err);
+                for (int i = 0; i < n; ++i) err[i] *= dt;
+                for (int i = 0; i < n; ++i) err[i] += x1[i];
+                return;
+            }
+            if (d->shooting_integrator == 2) { /* IntegratorExplicitRungeKutta2 (:127-138) */
+                SHOOT_RHS(x1, u1, k1);
+                for (int i = 0; i < n; ++i) k1[i] *= dt;
+                for (int i = 0; i < n; ++i) t[i] = x1[i] + k1[i];
+                SHOOT_RHS(t, u1, k2);
+                for (int i = 0; i < n; ++i) k2[i] *= dt;
+                for (int i = 0; i < n; ++i) err[i] = x1[i] + (k1[i] + k2[i]) / 2.0;
+                return;
+            }
+            if (d->shooting_integrator == 3) { /* IntegratorExplicitRungeKutta3 (:200-213) */
+                SHOOT_RHS(x1, u1, k1);
+                for (int i = 0; i < n; ++i) k1[i] *= dt;
+                for (int i = 0; i < n; ++i) t[i] = x1[i] + (k1[i] / 2.0);
+                SHOOT_RHS(t, u1, k2);
+                for (int i = 0; i < n; ++i) k2[i] *= dt;
+                for (int i = 0; i < n; ++i) t[i] = x1[i] - k1[i] + 2.0 * k2[i];
+                SHOOT_RHS(t, u1, k3);
+                for (int i = 0; i < n; ++i) k3[i] *= dt;
+                for (int i = 0; i < n; ++i) err[i] = x1[i] + (k1[i] + 4.0 * k2[i] + k3[i]) / 6.0;
+                return;
+            }
+            SHOOT_RHS(x1, u1, k1);
+            for (int i = 0; i < n; ++i) k1[i] *= dt;
+            for (int i = 0; i < n; ++i) t[i] = x1[i] + k1[i] / 2.0;
+            SHOOT_RHS(t, u1, k2);
+            for (int i = 0; i < n; ++i) k2[i] *= dt;
+            for (int i = 0; i < n; ++i) t[i] = x1[i] + k2[i] / 2.0;
+            SHOOT_RHS(t, u1, k3);
+            for (int i = 0; i < n; ++i) k3[i] *= dt;
+            for (int i = 0; i < n; ++i) t[i] = x1[i] + k3[i];
+            SHOOT_RHS(t, u1, k4);
+            for (int i = 0; i < n; ++i) k4[i] *= dt;
+            for (int i = 0; i < n; ++i) err[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+        }
+#undef SHOOT_RHS
+}
+
 static void defect_values(const oracle_problem* p, const double* x1, const double* u1, const double* x2, double dt, double* err)
 {
     const corbo_hip_problem_desc* d = &p->d;
@@ -226,101 +348,10 @@ static void defect_values(const oracle_problem* p, const double* x1, const doubl
             dynamics(d, x2, u1, err);
             for (int i = 0; i < nx; ++i) err[i] = (x2[i] - x1[i]) / dt - 0.5 * (f1[i] + err[i]);
             break;
-        case CORBO_HIP_DEFECT_RK4_SHOOTING: { /* explicit_integrators.h:280-295 + integrator_interface.h:217-222 */
-            double k1[CORBO_HIP_MAX_NX], k2[CORBO_HIP_MAX_NX], k3[CORBO_HIP_MAX_NX], k4[CORBO_HIP_MAX_NX];
-            if (d->shooting_integrator >= 5) { /* IntegratorExplicitRungeKutta5 / 6 / 7 (:371-394, :479-503, :600-628), coefficient-wise like Eigen, left to right */
-                double K[11][CORBO_HIP_MAX_NX];
-                double *q1 = K[0], *q2 = K[1], *q3 = K[2], *q4 = K[3], *q5 = K[4], *q6 = K[5], *q7 = K[6], *q8 = K[7], *q9 = K[8], *q10 = K[9], *q11 = K[10];
-#define RK_STAGE(Q, EXPR)                                   \
-    {                                                       \
-        for (int i = 0; i < nx; ++i) t[i] = EXPR;           \
-        dynamics(d, t, u1, Q);                              \
-        for (int i = 0; i < nx; ++i) Q[i] *= dt;            \
-    }
-                RK_STAGE(q1, x1[i])
-                if (d->shooting_integrator == 5) {
-                    const double s6 = sqrt(6.0);
-                    RK_STAGE(q2, x1[i] + 4.0 * q1[i] / 11.0)
-                    RK_STAGE(q3, x1[i] + (9.0 * q1[i] + 11.0 * q2[i]) / 50.0)
-                    RK_STAGE(q4, x1[i] + (-11.0 * q2[i] + 15.0 * q3[i]) / 4.0)
-                    RK_STAGE(q5, x1[i] + ((81.0 + 9.0 * s6) * q1[i] + (255.0 - 55.0 * s6) * q3[i] + (24.0 - 14.0 * s6) * q4[i]) / 600.0)
-                    RK_STAGE(q6, x1[i] + ((81.0 - 9.0 * s6) * q1[i] + (255.0 + 55.0 * s6) * q3[i] + (24.0 + 14.0 * s6) * q4[i]) / 600.0)
-                    for (int i = 0; i < nx; ++i) err[i] = x1[i] + (4.0 * q1[i] + (16.0 + s6) * q5[i] + (16.0 - s6) * q6[i]) / 36.0;
-                }
-                else if (d->shooting_integrator == 6) {
-                    RK_STAGE(q2, x1[i] + 2.0 * q1[i] / 33.0)
-                    RK_STAGE(q3, x1[i] + 4.0 * q2[i] / 33.0)
-                    RK_STAGE(q4, x1[i] + (q1[i] + 3.0 * q3[i]) / 22.0)
-                    RK_STAGE(q5, x1[i] + (43.0 * q1[i] - 165.0 * q3[i] + 144.0 * q4[i]) / 64.0)
-                    RK_STAGE(q6, x1[i] + (-4053483.0 * q1[i] + 16334703.0 * q3[i] - 12787632.0 * q4[i] + 1057536.0 * q5[i]) / 826686.0)
-                    RK_STAGE(q7, x1[i] + (169364139.0 * q1[i] - 663893307.0 * q3[i] + 558275718.0 * q4[i] - 29964480.0 * q5[i] + 35395542.0 * q6[i]) / 80707214.0)
-                    RK_STAGE(q8, x1[i] + (-733.0 * q1[i] + 3102.0 * q3[i]) / 176.0 - (335763.0 * q4[i] / 23296.0) + (216.0 * q5[i] / 77.0) - (4617.0 * q6[i] / 2816.0) + (7203.0 * q7[i] / 9152.0))
-                    for (int i = 0; i < nx; ++i)
-                        err[i] = x1[i] + (336336.0 * q1[i] + 1771561.0 * q4[i] + 1916928.0 * q5[i] + 597051.0 * q6[i] + 1411788.0 * q7[i] + 256256.0 * q8[i]) / 6289920.0;
-                }
-                else {
-                    RK_STAGE(q2, x1[i] + 2.0 * q1[i] / 27.0)
-                    RK_STAGE(q3, x1[i] + (q1[i] + 3.0 * q2[i]) / 36.0)
-                    RK_STAGE(q4, x1[i] + (q1[i] + 3.0 * q3[i]) / 24.0)
-                    RK_STAGE(q5, x1[i] + (80.0 * q1[i] - 300.0 * q3[i] + 300.0 * q4[i]) / 192.0)
-                    RK_STAGE(q6, x1[i] + (q1[i] + 5.0 * q4[i] + 4.0 * q5[i]) / 20.0)
-                    RK_STAGE(q7, x1[i] + (-25.0 * q1[i] + 125.0 * q4[i] - 260.0 * q5[i] + 250.0 * q6[i]) / 108.0)
-                    RK_STAGE(q8, x1[i] + (93.0 * q1[i] + 244.0 * q5[i] - 200.0 * q6[i] + 13.0 * q7[i]) / 900.0)
-                    RK_STAGE(q9, x1[i] + (12.0 * q1[i] - 53.0 * q4[i]) / 6.0 + (1408.0 * q5[i] - 1070.0 * q6[i] + 67.0 * q7[i] + 270.0 * q8[i]) / 90.0)
-                    RK_STAGE(q10, x1[i] + (-12285.0 * q1[i] + 3105.0 * q4[i] - 105408.0 * q5[i] + 83970.0 * q6[i] - 4617.0 * q7[i] + 41310.0 * q8[i] - 1215.0 * q9[i]) / 14580.0)
-                    RK_STAGE(q11, x1[i] + (2383.0 * q1[i] - 8525.0 * q4[i] + 17984.0 * q5[i] - 15050.0 * q6[i] + 2133.0 * q7[i] + 2250.0 * q8[i] + 1125.0 * q9[i] + 1800.0 * q10[i]) / 4100.0)
-                    for (int i = 0; i < nx; ++i)
-                        err[i] = x1[i] + (41.0 * q1[i] + 272.0 * q6[i] + 216.0 * q7[i] + 216.0 * q8[i] + 27.0 * q9[i] + 27.0 * q10[i] + 41.0 * q11[i]) / 840.0;
-                }
-#undef RK_STAGE
-                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
-                break;
-            }
-            if (d->shooting_integrator == 1) { /* IntegratorExplicitEuler (:66-72): x2 = f; x2 *= dt; x2 += x1 */
-                dynamics(d, x1, u1, err);
-                for (int i = 0; i < nx; ++i) err[i] *= dt;
-                for (int i = 0; i < nx; ++i) err[i] += x1[i];
-                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
-                break;
-            }
-            if (d->shooting_integrator == 2) { /* IntegratorExplicitRungeKutta2 (:127-138) */
-                dynamics(d, x1, u1, k1);
-                for (int i = 0; i < nx; ++i) k1[i] *= dt;
-                for (int i = 0; i < nx; ++i) t[i] = x1[i] + k1[i];
-                dynamics(d, t, u1, k2);
-                for (int i = 0; i < nx; ++i) k2[i] *= dt;
-                for (int i = 0; i < nx; ++i) err[i] = x1[i] + (k1[i] + k2[i]) / 2.0;
-                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
-                break;
-            }
-            if (d->shooting_integrator == 3) { /* IntegratorExplicitRungeKutta3 (:200-213) */
-                dynamics(d, x1, u1, k1);
-                for (int i = 0; i < nx; ++i) k1[i] *= dt;
-                for (int i = 0; i < nx; ++i) t[i] = x1[i] + (k1[i] / 2.0);
-                dynamics(d, t, u1, k2);
-                for (int i = 0; i < nx; ++i) k2[i] *= dt;
-                for (int i = 0; i < nx; ++i) t[i] = x1[i] - k1[i] + 2.0 * k2[i];
-                dynamics(d, t, u1, k3);
-                for (int i = 0; i < nx; ++i) k3[i] *= dt;
-                for (int i = 0; i < nx; ++i) err[i] = x1[i] + (k1[i] + 4.0 * k2[i] + k3[i]) / 6.0;
-                for (int i = 0; i < nx; ++i) err[i] -= x2[i];
-                break;
-            }
-            dynamics(d, x1, u1, k1);
-            for (int i = 0; i < nx; ++i) k1[i] *= dt;
-            for (int i = 0; i < nx; ++i) t[i] = x1[i] + k1[i] / 2.0;
-            dynamics(d, t, u1, k2);
-            for (int i = 0; i < nx; ++i) k2[i] *= dt;
-            for (int i = 0; i < nx; ++i) t[i] = x1[i] + k2[i] / 2.0;
-            dynamics(d, t, u1, k3);
-            for (int i = 0; i < nx; ++i) k3[i] *= dt;
-            for (int i = 0; i < nx; ++i) t[i] = x1[i] + k3[i];
-            dynamics(d, t, u1, k4);
-            for (int i = 0; i < nx; ++i) k4[i] *= dt;
-            for (int i = 0; i < nx; ++i) err[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+        case CORBO_HIP_DEFECT_RK4_SHOOTING: /* explicit_integrators.h:280-295 + integrator_interface.h:217-222 */
+            shooting_end_state(p, 0, NULL, x1, u1, dt, err);
             for (int i = 0; i < nx; ++i) err[i] -= x2[i];
             break;
-        }
         default: break;
     }
 }
@@ -416,6 +447,24 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             }
             if (trap) out[0] = 0.5 * dt * (c[0] + c[1]);
             else { out[0] = c[0]; out[0] *= dt; }
+            break;
+        }
+        case E_MS_MIXED_OBJ: case E_MS_MIXED_EQ: { /* MultipleShootingEdgeSingleControl (x_k, u_k, dt, x_{k+1}), multiple_shooting_edges.h:151-303:
+                                                   * precompute() integrates current = [0; x_k] with the grid's integrator over dt, integrand
+                                                   * [c(x, u_k) against reference k; f(x, u_k)] (:214-229, :251-281); objective value = values[0]
+                                                   * (:230-233), equality values = values[1 .. nx] - x_{k+1} (:234-242) */
+            const double* x1 = x + p->v[e->vert[0]].off;
+            const double* u1 = x + p->v[e->vert[1]].off;
+            const double dt  = x[p->v[e->vert[2]].off];
+            const double* x2 = x + p->v[e->vert[3]].off;
+            const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
+            double cur[CORBO_HIP_MAX_NX + 1], val[CORBO_HIP_MAX_NX + 1];
+            cur[0] = 0;
+            for (int i = 0; i < d->nx; ++i) cur[1 + i] = x1[i];
+            shooting_end_state(p, 1, rk, cur, u1, dt, val);
+            if (e->type == E_MS_MIXED_OBJ) out[0] = val[0];
+            else
+                for (int i = 0; i < d->nx; ++i) out[i] = val[1 + i] - x2[i];
             break;
         }
         case E_DT_COST: /* optimal_control/include/corbo-optimal-control/functions/minimum_time.h:70-78 */
@@ -520,7 +569,8 @@ static int validate(const corbo_hip_problem_desc* d)
         return 0;
     if (d->cost_nonlsq != 0 && d->cost_nonlsq != 1) return 0;
     if (d->cost_integral < 0 || d->cost_integral > 2) return 0;
-    if (d->cost_integral && (!d->cost_nonlsq || d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || d->grid != CORBO_HIP_GRID_FD)) return 0;
+    if (d->cost_integral && (!d->cost_nonlsq || d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || (d->grid != CORBO_HIP_GRID_FD && d->grid != CORBO_HIP_GRID_MS))) return 0;
+    if (d->cost_integral && d->grid == CORBO_HIP_GRID_MS && (d->stage_ineq || (d->weights_dense & 3))) return 0; /* MultipleShootingEdgeSingleControl: diagonal Q / R, no stage inequality */
     if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
     if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
     if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
@@ -631,7 +681,8 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     o_edge* lsq   = (o_edge*)calloc(max_edges, sizeof(o_edge));
     o_edge* eq    = (o_edge*)calloc(max_edges, sizeof(o_edge));
     o_edge* ineq  = (o_edge*)calloc(max_edges, sizeof(o_edge));
-    int n_lsq = 0, n_eq = 0, n_ineq = 0;
+    o_edge* mix   = (o_edge*)calloc(max_edges, sizeof(o_edge)); /* getMixedEdgesRef(): (objective part, equality part) pairs */
+    int n_lsq = 0, n_eq = 0, n_ineq = 0, n_mix = 0;
     int dt_vertex = 2 * (N - 1) + 1;
     for (int k = 0; k < N - 1; ++k) {
         int xk = 2 * k, uk = 2 * k + 1, xnext = 2 * (k + 1); /* x_next = (k < n-2) ? x_seq[k+1] : xf */
@@ -639,6 +690,13 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         const int terms = CORBO_HIP_COST_TERMS(d->stage_cost);
         const int quad = (k >= d->quad_first_interval); /* MinTimeQuadratic::only_last_n, hybrid_cost.h:224-237 */
         const int nl = d->cost_nonlsq; /* QuadraticFormCost(.., lsq_form = false): one scalar term each (quadratic_cost.h: dimension 1) */
+        if (d->cost_integral && d->grid == CORBO_HIP_GRID_MS) { /* multiple_shooting_grid.cpp:70-77: hasIntegralTerms(k) -> ONE mixed edge per interval instead of
+                                                                 * the dynamics-only edge, on (s_k, u_k, dt, s_{k+1}); filed in the mixed list (last in every walk) */
+            o_edge* eo = &mix[n_mix++]; eo->type = E_MS_MIXED_OBJ; eo->k = k; eo->dim = 1; eo->scale = 0; eo->nonlsq = 1; eo->nverts = 4;
+            eo->vert[0] = xk; eo->vert[1] = uk; eo->vert[2] = dt_vertex; eo->vert[3] = xnext;
+            o_edge* ee = &mix[n_mix++]; *ee = *eo; ee->type = E_MS_MIXED_EQ; ee->dim = nx; ee->scale = 1; ee->nonlsq = 0;
+            continue;
+        }
         if (d->cost_integral) { /* QuadraticFormCost(Q, R, integral_form = true): no non-integral terms; one integral cost edge per interval
                                  * (finite_differences_grid.cpp:62-77), 1 = TrapezoidalRule, 2 = LeftSum */
             o_edge* e = &lsq[n_lsq++]; e->type = E_INTEGRAL_COST; e->k = k; e->dim = 1; e->scale = 0; e->nonlsq = 1;
@@ -675,7 +733,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         o_edge* e = &ineq[n_ineq++]; e->type = E_FINAL_INEQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = 1; e->scale = 2;
     }
     /* row indices: [lsq | eq | ineq | bounds] (edge_set.cpp:31-42, hyper_graph_optimization_problem_edge_based.cpp:1491-1493) */
-    p->n_edges = n_lsq + n_eq + n_ineq;
+    p->n_edges = n_lsq + n_eq + n_ineq + n_mix;
     p->e       = (o_edge*)calloc(p->n_edges, sizeof(o_edge));
     int row = 0, ne = 0;
     for (int i = 0; i < n_lsq; ++i) {
@@ -685,10 +743,19 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     }
     int dim_lsq = row;
     for (int i = 0; i < n_eq; ++i) { eq[i].row = row; row += eq[i].dim; p->e[ne++] = eq[i]; }
+    /* equality indices run on through the mixed edges (edge_set.cpp:31-42: computeEdgeIndices(_mixed, ..) continues idx_eq) */
+    for (int i = 0; i < n_mix; ++i)
+        if (mix[i].type == E_MS_MIXED_EQ) { mix[i].row = row; row += mix[i].dim; }
     int dim_eq = row - dim_lsq;
     for (int i = 0; i < n_ineq; ++i) { ineq[i].row = row; row += ineq[i].dim; p->e[ne++] = ineq[i]; }
     int dim_ineq = row - dim_lsq - dim_eq;
-    free(lsq); free(eq); free(ineq);
+    for (int i = 0; i < ne; ++i) p->e[i].partner = -1;
+    for (int i = 0; i < n_mix; ++i) { /* stored behind every other edge: mixed edges are the last loop of every function of the reference */
+        if (mix[i].type == E_MS_MIXED_OBJ) { mix[i].row = -1; mix[i].partner = ne + 1; p->has_nonlsq = 1; }
+        else mix[i].partner = ne - 1;
+        p->e[ne++] = mix[i];
+    }
+    free(lsq); free(eq); free(ineq); free(mix);
 
     /* default bounds from the descriptor (needed for the bound-row structure) */
     for (int k = 0; k < N - 1; ++k) {
@@ -1174,6 +1241,52 @@ static void edge_hessian(oracle_problem* p, const o_edge* e, int vi, int vj, con
     }
 }
 
+/* one vertex-pair block of a Hessian list: entries behind position `at`, returns the new position */
+static int hess_emit(const o_vertex* a, const o_vertex* b, int diag_lower, int with_values, const double* blk, int32_t* rows, int32_t* cols, double* vals, int at)
+{
+    const int ni = a->n_unfixed, nj = b->n_unfixed;
+    if (diag_lower) { /* lower triangle, row by row (:3537-3546) */
+        for (int i = 0; i < ni; ++i)
+            for (int j = 0; j <= i; ++j, ++at) {
+                if (rows) { rows[at] = a->col + i; cols[at] = b->col + j; }
+                if (with_values) vals[at] = 0.0 + blk[j * ni + i];
+            }
+    }
+    else { /* values: the block column-major (Eigen::Map<MatrixXd> on the value array, :3550-3552); the structure lists the
+            * same entries ROW-major (:2993-3003) -- the reference's own mismatch for off-diagonal vertex pairs, kept */
+        for (int i = 0; i < ni; ++i)
+            for (int j = 0; j < nj; ++j)
+                if (rows) { rows[at + i * nj + j] = a->col + i; cols[at + i * nj + j] = b->col + j; }
+        if (with_values)
+            for (int q = 0; q < ni * nj; ++q) vals[at + q] = 0.0 + blk[q];
+        at += ni * nj;
+    }
+    return at;
+}
+
+/* BaseMixedEdge::computeJacobians (edge_interface.cpp:394-465) of a MultipleShootingEdgeSingleControl: ONE in-place perturbation cycle per
+ * component serves the objective block (1 x n_unfixed) and the equality block (nx x n_unfixed). */
+static void mixed_jacobians(oracle_problem* p, const o_edge* eo, const o_edge* ee, int vtx_idx, double* jac_obj, double* jac_eq)
+{
+    const double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
+    const o_vertex* v = &p->v[eo->vert[vtx_idx]];
+    double o1[1], o2[1], q1[CORBO_HIP_MAX_NX], q2[CORBO_HIP_MAX_NX];
+    int col_idx = 0;
+    for (int i = 0; i < v->dim; ++i) {
+        if (v->fixed & (1u << i)) continue;
+        p->x[v->off + i] += delta;
+        edge_values(p, eo, o2);
+        edge_values(p, ee, q2);
+        p->x[v->off + i] += neg2delta;
+        edge_values(p, eo, o1);
+        edge_values(p, ee, q1);
+        jac_obj[col_idx] = scalar * (o2[0] - o1[0]);
+        for (int j = 0; j < ee->dim; ++j) jac_eq[col_idx * ee->dim + j] = scalar * (q2[j] - q1[j]);
+        p->x[v->off + i] += delta;
+        ++col_idx;
+    }
+}
+
 /* which category of computeSparseHessians* an edge belongs to: 0 objective (lsq), 1 equalities, 2 inequalities */
 static int hessian_walk(oracle_problem* p, int lower, int with_values, double mult_obj, const double* mult_eq, const double* mult_ineq,
                         int32_t* rows[3], int32_t* cols[3], double* vals[3], int nnz[3])
@@ -1182,6 +1295,37 @@ static int hessian_walk(oracle_problem* p, int lower, int with_values, double mu
     const int row_eq0 = p->dims.lsq, row_ineq0 = p->dims.lsq + p->dims.eq;
     for (int ei = 0; ei < p->n_edges; ++ei) {
         const o_edge* e = &p->e[ei];
+        if (e->type == E_MS_MIXED_EQ) continue; /* walked together with its objective part */
+        if (e->type == E_MS_MIXED_OBJ) {
+            /* a mixed edge with a plain objective part and an equality part, no inequality part: the last branch of the mixed loop
+             * (:3941-3988) -- computeJacobians once per vertex i, then per vertex j computeObjectiveHessian[Inc](.., nullptr, multiplier_obj)
+             * and computeEqualityHessian[Inc](.., mult_eq_part); both lists advance by the same blocks */
+            const o_edge* q   = &p->e[e->partner];
+            const double* meq = mult_eq ? mult_eq + (q->row - row_eq0) : NULL;
+            for (int vi = 0; vi < e->nverts; ++vi) {
+                const o_vertex* a = &p->v[e->vert[vi]];
+                if (a->n_unfixed == 0) continue;
+                double jo[O_MAX_BLOCK], je[O_MAX_BLOCK], blk[O_MAX_BLOCK];
+                if (with_values) mixed_jacobians(p, e, q, vi, jo, je);
+                const int vend = lower ? vi + 1 : e->nverts;
+                for (int vj = 0; vj < vend; ++vj) {
+                    const o_vertex* b = &p->v[e->vert[vj]];
+                    if (b->n_unfixed == 0) continue;
+                    const int diag_lower = lower && (e->vert[vi] == e->vert[vj]);
+                    if (with_values) {
+                        for (int z = 0; z < a->n_unfixed * b->n_unfixed; ++z) blk[z] = 0.0;
+                        edge_hessian(p, e, vi, vj, jo, blk, NULL, mult_obj, diag_lower ? 0 : 1);
+                    }
+                    nnz[0] = hess_emit(a, b, diag_lower, with_values, blk, rows[0], cols[0], vals[0], nnz[0]);
+                    if (with_values) {
+                        for (int z = 0; z < a->n_unfixed * b->n_unfixed; ++z) blk[z] = 0.0;
+                        edge_hessian(p, q, vi, vj, je, blk, meq, 1.0, diag_lower ? 0 : 1);
+                    }
+                    nnz[1] = hess_emit(a, b, diag_lower, with_values, blk, rows[1], cols[1], vals[1], nnz[1]);
+                }
+            }
+            continue;
+        }
         const int cat   = e->scale;
         const double* mult = (cat == 1) ? (mult_eq ? mult_eq + (e->row - row_eq0) : NULL) : (cat == 2) ? (mult_ineq ? mult_ineq + (e->row - row_ineq0) : NULL) : NULL;
         for (int vi = 0; vi < e->nverts; ++vi) {
@@ -1224,23 +1368,7 @@ static int hessian_walk(oracle_problem* p, int lower, int with_values, double mu
                         edge_hessian(p, e, vi, vj, jac1, blk, mult, 1.0, diag_lower ? 0 : 1);
                     }
                 }
-                if (diag_lower) { /* lower triangle, row by row (:3537-3546) */
-                    for (int i = 0; i < ni; ++i)
-                        for (int j = 0; j <= i; ++j, ++at) {
-                            if (rows[cat]) { rows[cat][at] = a->col + i; cols[cat][at] = b->col + j; }
-                            if (with_values) vals[cat][at] = 0.0 + blk[j * ni + i];
-                        }
-                }
-                else { /* values: the block column-major (Eigen::Map<MatrixXd> on the value array, :3550-3552); the structure lists the
-                        * same entries ROW-major (:2993-3003) -- the reference's own mismatch for off-diagonal vertex pairs, kept */
-                    for (int i = 0; i < ni; ++i)
-                        for (int j = 0; j < nj; ++j)
-                            if (rows[cat]) { rows[cat][at + i * nj + j] = a->col + i; cols[cat][at + i * nj + j] = b->col + j; }
-                    if (with_values)
-                        for (int q = 0; q < ni * nj; ++q) vals[cat][at + q] = 0.0 + blk[q];
-                    at += ni * nj;
-                }
-                nnz[cat] = at;
+                nnz[cat] = hess_emit(a, b, diag_lower, with_values, blk, rows[cat], cols[cat], vals[cat], at);
             }
         }
     }

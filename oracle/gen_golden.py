@@ -246,6 +246,24 @@ def nonlsq():
         print(name, d["n"], len(d["hobj_vals_full"]))
 
 
+def msmixed():
+    """MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:151-303): what a MultipleShootingGrid creates instead of the dynamics-only edge
+    when the stage cost has integral terms (multiple_shooting_grid.cpp:70-77) -- QuadraticFormCost(Q, R, integral_form = true): ONE mixed edge
+    per interval (objective part: the cost integrated along the shooting step by the grid's integrator; equality part: the defect).
+    Hessian-path operators only (a mixed edge with a plain objective part is refused by LevenbergMarquardtSparse)."""
+    for name, kv in [
+        ("hess_unicycle_ms_integral", dict(scenario="unicycle", grid="ms", N=8, lsq=0, integral="trap")),
+        ("hess_unicycle_ms_integral_xf_fixed", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="left", xf_fixed=5)),
+        ("hess_vdp_ms_integral_euler", dict(scenario="vdp", grid="ms", N=10, lsq=0, integral="trap", ms_integrator="euler")),
+        ("hess_vdp_ms_integral_rk3", dict(scenario="vdp", grid="ms", N=8, lsq=0, integral="trap", ms_integrator="rk3")),
+        ("hess_unicycle_ms_integral_rk5", dict(scenario="unicycle", grid="ms", N=5, lsq=0, integral="trap", ms_integrator="rk5")),
+    ]:
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], len(d["hobj_vals_full"]), len(d["heq_vals_full"]))
+
+
 def bigterm():
     """Final-stage constraints on the 12-state quadrotor (big-block family): TerminalBall (violated: active row) and the terminal equality."""
     for name, kv, keep in [
@@ -470,6 +488,8 @@ def main():
         return mtq()
     if len(sys.argv) > 1 and sys.argv[1] == "nonlsq":
         return nonlsq()
+    if len(sys.argv) > 1 and sys.argv[1] == "msmixed":
+        return msmixed()
     # cfg 3 (headline structure, single instance, the SURVEY 8c known-answer trace), cfg 1, cfg 2
     for name, kv, keep in [
         ("unicycle", dict(scenario="unicycle"), (1, 2, 5, 10)),
