@@ -9,6 +9,7 @@
 #include <corbo-optimal-control/structured_ocp/discretization_grids/multiple_shooting_variable_grid.h>
 #include <corbo-optimal-control/structured_ocp/edges/finite_differences_collocation_edges.h>
 #include <corbo-optimal-control/structured_ocp/edges/multiple_shooting_edges.h>
+#include <corbo-optimization/hyper_graph/generic_edge.h>
 #include <corbo-optimization/hyper_graph/scalar_vertex.h>
 #include <corbo-optimization/hyper_graph/vector_vertex.h>
 #include <corbo-systems/benchmark/linear_benchmark_systems.h>
@@ -54,6 +55,9 @@ CORBO_HIP_PRIVATE_MEMBER(FdEdgeDynamics, FDCollocationEdge, SystemDynamicsInterf
 CORBO_HIP_PRIVATE_MEMBER(FdEdgeScheme, FDCollocationEdge, FiniteDifferencesCollocationInterface::Ptr, _fd_eval)
 CORBO_HIP_PRIVATE_MEMBER(MsEdgeDynamics, MSVariableDynamicsOnlyEdge, SystemDynamicsInterface::Ptr, _dynamics)
 CORBO_HIP_PRIVATE_MEMBER(MsEdgeIntegrator, MSVariableDynamicsOnlyEdge, NumericalIntegratorExplicitInterface::Ptr, _integrator)
+CORBO_HIP_PRIVATE_MEMBER(MixedEdgeDynamics, MultipleShootingEdgeSingleControl, SystemDynamicsInterface::Ptr, _dynamics)
+CORBO_HIP_PRIVATE_MEMBER(MixedEdgeIntegrator, MultipleShootingEdgeSingleControl, NumericalIntegratorExplicitInterface::Ptr, _integrator)
+CORBO_HIP_PRIVATE_MEMBER(MixedEdgeStageCost, MultipleShootingEdgeSingleControl, StageCost::ConstPtr, _stage_cost)
 CORBO_HIP_PRIVATE_MEMBER(DuffingDamping, DuffingOscillator, double, _damping)
 CORBO_HIP_PRIVATE_MEMBER(DuffingAlpha, DuffingOscillator, double, _spring_alpha)
 CORBO_HIP_PRIVATE_MEMBER(DuffingBeta, DuffingOscillator, double, _spring_beta)
@@ -671,13 +675,51 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     // solve() will refuse it like the reference's solver -- but the Hessian-path operators work on it; identified below
     const bool plain_costs = !es->getObjectiveEdges().empty();
     if (plain_costs && !es->getLsqObjectiveEdges().empty()) return fail(reason, "cost terms in least-squares form and in plain form in one graph");
-    if (!es->getMixedEdges().empty()) return fail(reason, "mixed edges (single-control shooting intervals, integral terms)");
+    // mixed edges: a MultipleShootingGrid whose stage cost has integral terms files ONE MultipleShootingEdgeSingleControl per interval INSTEAD of
+    // the dynamics-only edge (multiple_shooting_grid.cpp:70-77): objective part = the cost integrated along the shooting step, equality part = the defect
+    const std::vector<BaseMixedEdge::Ptr>& mixed = es->getMixedEdges();
+    const bool ms_mixed = !mixed.empty();
+    auto integratorId = [](NumericalIntegratorExplicitInterface* in) {
+        if (dynamic_cast<IntegratorExplicitRungeKutta4*>(in)) return 0;
+        if (dynamic_cast<IntegratorExplicitEuler*>(in)) return 1;
+        if (dynamic_cast<IntegratorExplicitRungeKutta2*>(in)) return 2;
+        if (dynamic_cast<IntegratorExplicitRungeKutta3*>(in)) return 3;
+        if (dynamic_cast<IntegratorExplicitRungeKutta5*>(in)) return 5;
+        if (dynamic_cast<IntegratorExplicitRungeKutta6*>(in)) return 6;
+        if (dynamic_cast<IntegratorExplicitRungeKutta7*>(in)) return 7;
+        return -1;
+    };
 
     // ---- equality edges: one defect edge per interval, in order; then optionally the terminal equality constraint
     const std::vector<BaseEdge::Ptr>& eqs = es->getEqualityEdges();
-    if ((int)eqs.size() < g.N - 1) return fail(reason, "fewer equality edges than grid intervals");
+    const int n_defect_eq = ms_mixed ? 0 : g.N - 1;   // (mixed edges carry the defects themselves)
+    if ((int)eqs.size() < n_defect_eq) return fail(reason, "fewer equality edges than grid intervals");
     SystemDynamicsInterface* dyn = nullptr;
-    for (int k = 0; k < g.N - 1; ++k)
+    const StageCost* mixed_cost = nullptr;
+    if (ms_mixed)
+    {
+        if (g.kind != CORBO_HIP_GRID_MS) return fail(reason, "mixed edges on a grid other than the MultipleShootingGrid with a fixed dt");
+        if ((int)mixed.size() != g.N - 1) return fail(reason, "mixed edges: not one per interval");
+        if (!es->getLsqObjectiveEdges().empty()) return fail(reason, "mixed edges next to least-squares cost terms");
+        for (int k = 0; k < g.N - 1; ++k)
+        {
+            auto* me = dynamic_cast<MultipleShootingEdgeSingleControl*>(mixed[k].get());
+            VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
+            if (!me) return fail(reason, "mixed edge " + std::to_string(k) + " is not a MultipleShootingEdgeSingleControl");
+            if (me->getNumVertices() != 4 || me->getVertexRaw(0) != g.xs[k] || me->getVertexRaw(1) != g.us[k] || me->getVertexRaw(2) != g.dt || me->getVertexRaw(3) != x2)
+                return fail(reason, "mixed edge " + std::to_string(k) + " is not on (x_k, u_k, dt, x_{k+1})");
+            if (me->getObjectiveDimension() != 1 || me->getEqualityDimension() != g.nx || me->getInequalityDimension() != 0)
+                return fail(reason, "mixed edge with integral equality / inequality terms");
+            SystemDynamicsInterface* dk = member<MixedEdgeDynamics>(*me).get();
+            const int integ = integratorId(member<MixedEdgeIntegrator>(*me).get());
+            const StageCost* ck = member<MixedEdgeStageCost>(*me).get();
+            if (integ < 0) return fail(reason, "shooting integrator other than IntegratorExplicitEuler / RungeKutta2 ... RungeKutta7");
+            if (k == 0) { dyn = dk; mixed_cost = ck; d.shooting_integrator = integ; d.defect = CORBO_HIP_DEFECT_RK4_SHOOTING; }
+            else if (dk != dyn || ck != mixed_cost || integ != d.shooting_integrator) return fail(reason, "dynamics / stage cost / integrator of the mixed edges vary along the horizon");
+        }
+        if (!mixed_cost) return fail(reason, "mixed edges without a stage cost");
+    }
+    for (int k = 0; k < n_defect_eq; ++k)
     {
         BaseEdge* e = eqs[k].get();
         VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
@@ -698,16 +740,8 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         else if (auto* ms = dynamic_cast<MSVariableDynamicsOnlyEdge*>(e))
         {
             dk = member<MsEdgeDynamics>(*ms).get();
-            NumericalIntegratorExplicitInterface* in = member<MsEdgeIntegrator>(*ms).get();
-            int integ = -1;
-            if (dynamic_cast<IntegratorExplicitRungeKutta4*>(in)) integ = 0;
-            else if (dynamic_cast<IntegratorExplicitEuler*>(in)) integ = 1;
-            else if (dynamic_cast<IntegratorExplicitRungeKutta2*>(in)) integ = 2;
-            else if (dynamic_cast<IntegratorExplicitRungeKutta3*>(in)) integ = 3;
-            else if (dynamic_cast<IntegratorExplicitRungeKutta5*>(in)) integ = 5;
-            else if (dynamic_cast<IntegratorExplicitRungeKutta6*>(in)) integ = 6;
-            else if (dynamic_cast<IntegratorExplicitRungeKutta7*>(in)) integ = 7;
-            else return fail(reason, "shooting integrator other than IntegratorExplicitEuler / RungeKutta2 ... RungeKutta7");
+            const int integ = integratorId(member<MsEdgeIntegrator>(*ms).get());
+            if (integ < 0) return fail(reason, "shooting integrator other than IntegratorExplicitEuler / RungeKutta2 ... RungeKutta7");
             if (k > 0 && integ != d.shooting_integrator) return fail(reason, "shooting integrator varies along the horizon");
             d.shooting_integrator = integ;
             defect = CORBO_HIP_DEFECT_RK4_SHOOTING;
@@ -833,12 +867,45 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     if (Uqf.size()) { d.weights_dense |= 4; for (int i = 0; i < g.nx; ++i) for (int j = 0; j < g.nx; ++j) d.qf_sqrt[i * g.nx + j] = Uqf(i, j); }
     if (d.weights_dense && plain_costs) return fail(reason, "non-diagonal weights next to plain objective edges");
 
-    if (plain_costs)
+    if (plain_costs || ms_mixed)
     {   // per interval: a state term and a control term (QuadraticFormCost(.., lsq_form = false)), or ONE integral cost edge
         // (integral_form = true: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt) / LeftSumCostEdge on (x_k, u_k, dt)); then the final cost
         Eigen::VectorXd q, r, qf, ref, rf, uz;
         int ns = 0, nc = 0, nf = 0, ni = 0, ndt = 0, integral = 0;
         const double dtv = g.dt->getData()[0];
+        if (ms_mixed)
+        {   // the integrand c(x, u) of the mixed edges' objective part, probed through the stage cost's own computeIntegralStateControlTerm
+            // (what MultipleShootingEdgeSingleControl::configureIntegrand calls, multiple_shooting_edges.h:251-263) on x_k / u_k of an interval:
+            // a diagonal quadratic form around one state reference and a zero control reference, the same on the first and the last interval
+            for (int k : {0, g.N - 2})
+            {
+                const StageCost* sc = mixed_cost;
+                EdgeGenericScalarFun<VectorVertex, VectorVertex> probe(
+                    [sc, k](const EdgeGenericScalarFun<VectorVertex, VectorVertex>::VertexContainer& vs) {
+                        Eigen::VectorXd c(1);
+                        c[0] = 0.0;
+                        sc->computeIntegralStateControlTerm(k, static_cast<const VectorVertex*>(vs[0])->values(), static_cast<const VectorVertex*>(vs[1])->values(), c);
+                        return c[0];
+                    },
+                    false, *static_cast<VectorVertex*>(g.xs[k]), *static_cast<VectorVertex*>(g.us[k]));
+                Eigen::VectorXd w, rr, wu, ru;
+                {
+                    VertexGuard gu(g.us[k]);
+                    std::memset(g.us[k]->getDataRaw(), 0, g.nu * sizeof(double));
+                    if (!identifyDiagonalQuadratic(probe, {g.xs[k]}, 1.0, &w, &rr)) return fail(reason, "mixed edges: the integrand is not a diagonal quadratic form in the state");
+                }
+                {
+                    VertexGuard gx(g.xs[k]);
+                    std::memcpy(g.xs[k]->getDataRaw(), rr.data(), g.nx * sizeof(double));
+                    if (!identifyDiagonalQuadratic(probe, {g.us[k]}, 1.0, &wu, &ru) || (ru.array() != 0.0).any())
+                        return fail(reason, "mixed edges: the integrand is not a diagonal quadratic form in the control (zero reference)");
+                }
+                if (k == 0) { q = w; ref = rr; r = wu; }
+                else if (!sameVector(w, q) || !sameVector(rr, ref) || !sameVector(wu, r)) return fail(reason, "mixed edges: the integrand varies along the horizon");
+            }
+            integral = 1;
+            ni = g.N - 1;
+        }
         for (const BaseEdge::Ptr& ep : es->getObjectiveEdges())
         {
             BaseEdge* e = ep.get();
@@ -919,9 +986,9 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     }
 
     // ---- terminal equality constraint: x_f - xref (final_state_constraints.h:130-160)
-    if ((int)eqs.size() == g.N)
+    if ((int)eqs.size() == n_defect_eq + 1)
     {
-        BaseEdge* e = eqs[g.N - 1].get();
+        BaseEdge* e = eqs[n_defect_eq].get();
         Eigen::VectorXd w, ref;
         if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf) return fail(reason, "extra equality edge is not on x_f");
         if (e->getDimension() < g.nx)
@@ -946,7 +1013,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         d.final_eq = 1;
         }
     }
-    else if ((int)eqs.size() > g.N) return fail(reason, "unexpected additional equality edges");
+    else if ((int)eqs.size() > n_defect_eq + 1) return fail(reason, "unexpected additional equality edges");
 
     // ---- inequality edges: one stage inequality per interval on x_k (keep-out ball), then optionally the TerminalBall on x_f
     const std::vector<BaseEdge::Ptr>& ins = es->getInequalityEdges();

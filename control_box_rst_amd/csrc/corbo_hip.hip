@@ -1380,6 +1380,7 @@ static int hessian_common(corbo_hip_handle h, const HessianStructure*& Hout, boo
     hp.lin_nnz = H.lin_nnz; hp.lin_bounds0 = H.lin_bounds0; hp.bnd_row0 = h->S.bnd_row0; hp.n_bounds = h->S.dims.bounds;
     hp.stage_cost = h->S.desc.stage_cost; hp.stage_ineq = h->S.desc.stage_ineq;
     hp.dt_cost_off = H.dt_cost_off; hp.quad_first_interval = h->S.desc.quad_first_interval; hp.cost_nonlsq = h->S.desc.cost_nonlsq; hp.cost_integral = h->S.desc.cost_integral;
+    hp.ms_mixed = (h->S.desc.cost_integral && h->S.desc.grid == CORBO_HIP_GRID_MS) ? 1 : 0;
     return 0;
 }
 

@@ -3226,6 +3226,95 @@ struct HessEdge {
     using Dy = Dynamics<DYN>;
     static constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, W = S + NX + 1;
     static constexpr int MAXD = (NX > NU) ? NX : NU;
+    static constexpr int MAXE = MAXD + 1;   // rows of the widest edge: the joint view of a mixed edge (1 objective value + NX equality values)
+    static constexpr bool MIXED_OK = (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING || DEFECT == DEFECT_SHOOTING_HIGH) && NX <= 4;
+    // precompute() of MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:214-229, 251-281): the grid's integrator on current = [cost; x]
+    // with the integrand [c(x, u_k) against reference k; f(x, u_k)], c = QuadraticFormCost::computeIntegralStateControlTerm (quadratic_cost.cpp:
+    // 186-230, diagonal weights in mp.sq / mp.sr).  The solveIVP overload for a generic integrand has the expressions of the one for the system
+    // dynamics (explicit_integrators.h), so the state part is the defect edge's own integration.
+    __device__ static void aug_rhs(const double* X, const double* u, const double* xr, const ModelParams& mp, double* F)
+    {
+        dyn_full<DYN>(X + 1, u, mp.dyn, F + 1);
+        double cost = 0.0, acc = 0.0;
+        for (int i = 0; i < NX; ++i) { const double xd = X[1 + i] - xr[i]; acc += (xd * mp.sq[i]) * xd; }
+        cost += acc;
+        acc = 0.0;
+        for (int i = 0; i < NU; ++i) acc += (u[i] * mp.sr[i]) * u[i];
+        cost += acc;
+        F[0] = cost;
+    }
+    __device__ static void aug_end_state(const double* x1, const double* u1, double dt, const double* xr, const ModelParams& mp, double* xe)
+    {
+        constexpr int n = NX + 1;
+        const int order = (int)mp.dyn[7];
+        double t[n];
+#define AUG_STAGE(K, EXPR)                               \
+    {                                                    \
+        for (int i = 0; i < n; ++i) t[i] = EXPR;         \
+        aug_rhs(t, u1, xr, mp, K);                       \
+        for (int i = 0; i < n; ++i) K[i] *= dt;          \
+    }
+        if constexpr (DEFECT == DEFECT_SHOOTING_HIGH) {   // Runge-Kutta 5 / 6 / 7 (explicit_integrators.h:371-394, 479-503, 600-628)
+            double k1[n], k2[n], k3[n], k4[n], k5[n], k6[n], k7[n], k8[n];
+            AUG_STAGE(k1, x1[i])
+            if (order == 5) {
+                const double s6 = 2.449489742783178;
+                AUG_STAGE(k2, x1[i] + 4.0 * k1[i] / 11.0)
+                AUG_STAGE(k3, x1[i] + (9.0 * k1[i] + 11.0 * k2[i]) / 50.0)
+                AUG_STAGE(k4, x1[i] + (-11.0 * k2[i] + 15.0 * k3[i]) / 4.0)
+                AUG_STAGE(k5, x1[i] + ((81.0 + 9.0 * s6) * k1[i] + (255.0 - 55.0 * s6) * k3[i] + (24.0 - 14.0 * s6) * k4[i]) / 600.0)
+                AUG_STAGE(k6, x1[i] + ((81.0 - 9.0 * s6) * k1[i] + (255.0 + 55.0 * s6) * k3[i] + (24.0 + 14.0 * s6) * k4[i]) / 600.0)
+                for (int i = 0; i < n; ++i) xe[i] = x1[i] + (4.0 * k1[i] + (16.0 + s6) * k5[i] + (16.0 - s6) * k6[i]) / 36.0;
+            }
+            else if (order == 6) {
+                AUG_STAGE(k2, x1[i] + 2.0 * k1[i] / 33.0)
+                AUG_STAGE(k3, x1[i] + 4.0 * k2[i] / 33.0)
+                AUG_STAGE(k4, x1[i] + (k1[i] + 3.0 * k3[i]) / 22.0)
+                AUG_STAGE(k5, x1[i] + (43.0 * k1[i] - 165.0 * k3[i] + 144.0 * k4[i]) / 64.0)
+                AUG_STAGE(k6, x1[i] + (-4053483.0 * k1[i] + 16334703.0 * k3[i] - 12787632.0 * k4[i] + 1057536.0 * k5[i]) / 826686.0)
+                AUG_STAGE(k7, x1[i] + (169364139.0 * k1[i] - 663893307.0 * k3[i] + 558275718.0 * k4[i] - 29964480.0 * k5[i] + 35395542.0 * k6[i]) / 80707214.0)
+                AUG_STAGE(k8, x1[i] + (-733.0 * k1[i] + 3102.0 * k3[i]) / 176.0 - (335763.0 * k4[i] / 23296.0) + (216.0 * k5[i] / 77.0) - (4617.0 * k6[i] / 2816.0) + (7203.0 * k7[i] / 9152.0))
+                for (int i = 0; i < n; ++i)
+                    xe[i] = x1[i] + (336336.0 * k1[i] + 1771561.0 * k4[i] + 1916928.0 * k5[i] + 597051.0 * k6[i] + 1411788.0 * k7[i] + 256256.0 * k8[i]) / 6289920.0;
+            }
+            else {
+                double k9[n], k10[n], k11[n];
+                AUG_STAGE(k2, x1[i] + 2.0 * k1[i] / 27.0)
+                AUG_STAGE(k3, x1[i] + (k1[i] + 3.0 * k2[i]) / 36.0)
+                AUG_STAGE(k4, x1[i] + (k1[i] + 3.0 * k3[i]) / 24.0)
+                AUG_STAGE(k5, x1[i] + (80.0 * k1[i] - 300.0 * k3[i] + 300.0 * k4[i]) / 192.0)
+                AUG_STAGE(k6, x1[i] + (k1[i] + 5.0 * k4[i] + 4.0 * k5[i]) / 20.0)
+                AUG_STAGE(k7, x1[i] + (-25.0 * k1[i] + 125.0 * k4[i] - 260.0 * k5[i] + 250.0 * k6[i]) / 108.0)
+                AUG_STAGE(k8, x1[i] + (93.0 * k1[i] + 244.0 * k5[i] - 200.0 * k6[i] + 13.0 * k7[i]) / 900.0)
+                AUG_STAGE(k9, x1[i] + (12.0 * k1[i] - 53.0 * k4[i]) / 6.0 + (1408.0 * k5[i] - 1070.0 * k6[i] + 67.0 * k7[i] + 270.0 * k8[i]) / 90.0)
+                AUG_STAGE(k10, x1[i] + (-12285.0 * k1[i] + 3105.0 * k4[i] - 105408.0 * k5[i] + 83970.0 * k6[i] - 4617.0 * k7[i] + 41310.0 * k8[i] - 1215.0 * k9[i]) / 14580.0)
+                AUG_STAGE(k11, x1[i] + (2383.0 * k1[i] - 8525.0 * k4[i] + 17984.0 * k5[i] - 15050.0 * k6[i] + 2133.0 * k7[i] + 2250.0 * k8[i] + 1125.0 * k9[i] + 1800.0 * k10[i]) / 4100.0)
+                for (int i = 0; i < n; ++i)
+                    xe[i] = x1[i] + (41.0 * k1[i] + 272.0 * k6[i] + 216.0 * k7[i] + 216.0 * k8[i] + 27.0 * k9[i] + 27.0 * k10[i] + 41.0 * k11[i]) / 840.0;
+            }
+        }
+        else {   // Euler (:66-72), Runge-Kutta 2 (:127-138), 3 (:200-213), 4 (:280-295)
+            double k1[n], k2[n], k3[n], k4[n];
+            AUG_STAGE(k1, x1[i])
+            if (order == 1) { for (int i = 0; i < n; ++i) xe[i] = k1[i] + x1[i]; }
+            else if (order == 2) {
+                AUG_STAGE(k2, x1[i] + k1[i])
+                for (int i = 0; i < n; ++i) xe[i] = x1[i] + (k1[i] + k2[i]) / 2.0;
+            }
+            else if (order == 3) {
+                AUG_STAGE(k2, x1[i] + (k1[i] / 2.0))
+                AUG_STAGE(k3, x1[i] - k1[i] + 2.0 * k2[i])
+                for (int i = 0; i < n; ++i) xe[i] = x1[i] + (k1[i] + 4.0 * k2[i] + k3[i]) / 6.0;
+            }
+            else {
+                AUG_STAGE(k2, x1[i] + k1[i] / 2.0)
+                AUG_STAGE(k3, x1[i] + k2[i] / 2.0)
+                AUG_STAGE(k4, x1[i] + k3[i])
+                for (int i = 0; i < n; ++i) xe[i] = x1[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+            }
+        }
+#undef AUG_STAGE
+    }
     // BaseEdge::computeValues of the edge kinds on the path, on the lane's private vertex copies (xl: x_k | u_k | x_{k+1} | dt)
     __device__ static void values(int kind, const double* xl, const double* xr, const ModelParams& mp, double* out)
     {
@@ -3275,6 +3364,20 @@ struct HessEdge {
                 break;
             }
             case EK_DEFECT: defect_eval<DYN, DEFECT>(xl, xl + NX, xl + S, xl[W - 1], mp.dyn, out); break;
+            // MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:214-242): objective value = values[0], equality values = values[1 .. nx] - x_{k+1}
+            // EK_MIXED_JOINT: both parts, [objective value; equality values] -- what BaseMixedEdge::computeJacobians differentiates in ONE perturbation cycle
+            case EK_MIXED_OBJ: case EK_MIXED_EQ: case EK_MIXED_JOINT:
+                if constexpr (MIXED_OK) {
+                    double cur[NX + 1], val[NX + 1];
+                    cur[0] = 0;
+                    for (int i = 0; i < NX; ++i) cur[1 + i] = xl[i];
+                    aug_end_state(cur, xl + NX, xl[W - 1], xr, mp, val);
+                    if (kind != EK_MIXED_EQ) out[0] = val[0];
+                    const int o = (kind == EK_MIXED_JOINT) ? 1 : 0;
+                    if (kind != EK_MIXED_OBJ)
+                        for (int i = 0; i < NX; ++i) out[o + i] = val[1 + i] - xl[S + i];
+                }
+                break;
             case EK_STAGE_INEQ:
                 if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
                 break;
@@ -3285,13 +3388,14 @@ struct HessEdge {
             default: break;
         }
     }
-    __device__ static int edge_dim(int kind) { return kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
-    __device__ static int n_verts(int kind) { return (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? 4 : kind == EK_INTEGRAL_LEFT ? 3 : 1; }
-    __device__ static int vert_off(int kind, int vi) { return kind == EK_INTEGRAL_LEFT ? (vi == 0 ? 0 : vi == 1 ? NX : W - 1) : (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
+    __device__ static int edge_dim(int kind) { return kind == EK_MIXED_JOINT ? NX + 1 : kind == EK_MIXED_EQ ? NX : kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
+    __device__ static int n_verts(int kind) { return (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP || kind >= EK_MIXED_OBJ) ? 4 : kind == EK_INTEGRAL_LEFT ? 3 : 1; }
+    __device__ static int vert_off(int kind, int vi) { return (kind >= EK_MIXED_OBJ) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? W - 1 : S) : kind == EK_INTEGRAL_LEFT ? (vi == 0 ? 0 : vi == 1 ? NX : W - 1) : (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
     __device__ static int vert_dim(int kind, int vi)
     {
         if (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? NX : 1;
         if (kind == EK_INTEGRAL_LEFT) return vi == 0 ? NX : vi == 1 ? NU : 1;
+        if (kind >= EK_MIXED_OBJ) return vi == 0 ? NX : vi == 1 ? NU : vi == 2 ? 1 : NX;   // (x_k, u_k, dt, x_{k+1})
         return (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NU : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? 1 : NX;   // every other edge hangs on one state vertex
     }
     __device__ static int unfixed(unsigned fm, int off, int dim) { int n = 0; for (int i = 0; i < dim; ++i) n += ((fm >> (off + i)) & 1u) ? 0 : 1; return n; }
@@ -3300,7 +3404,7 @@ struct HessEdge {
     {
         constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
         const int off = vert_off(kind, vi), dim = vert_dim(kind, vi), ed = edge_dim(kind);
-        double v1[MAXD], v2[MAXD];
+        double v1[MAXE], v2[MAXE];
         int col = 0;
         for (int i = 0; i < dim; ++i) {
             if ((fm >> (off + i)) & 1u) continue;
@@ -3313,13 +3417,19 @@ struct HessEdge {
             ++col;
         }
     }
-    // all blocks of one edge, in the order of the reference's walk; returns the number of values written
+    // all blocks of one edge, in the order of the reference's walk; returns the number of values written (per list).
+    // cat 0: least-squares objective edge; 1 / 2: equality / inequality edge; 3: plain objective edge; 4: a MIXED edge with a plain objective part
+    // and an equality part (kind EK_MIXED_JOINT; the last branch of the mixed loop, :3941-3988): BaseMixedEdge::computeJacobians once per vertex i
+    // (ONE perturbation cycle for both parts, edge_interface.cpp:394-465), then per vertex j computeObjectiveHessian[Inc](.., nullptr, multiplier_obj)
+    // into `out` and computeEqualityHessian[Inc](.., mult_eq_part) into `out2` (edge_interface.cpp:525-634) -- both lists advance by the same
+    // blocks; the Jacobian at the perturbed point is the joint one again (the other part's rows are not read: same perturbation cycle, same values).
     __device__ static int hessian_blocks(int kind, int cat, bool lower, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double mult_obj,
-                                         const double* mult, double* out)
+                                         const double* mult, double* out, double* out2)
     {
         constexpr double hdelta = 1e-2;
         const int ed = edge_dim(kind), nv = n_verts(kind);
-        double jac1[MAXD * MAXD], jac2[MAXD * MAXD], blk[MAXD * MAXD];
+        const int nparts = (cat == 4) ? 2 : 1;
+        double jac1[MAXE * MAXD], jac2[MAXE * MAXD], blk[MAXD * MAXD];
         int at = 0;
         for (int vi = 0; vi < nv; ++vi) {
             const int oi = vert_off(kind, vi), di = vert_dim(kind, vi), ni = unfixed(fm, oi, di);
@@ -3330,49 +3440,54 @@ struct HessEdge {
                 const int oj = vert_off(kind, vj), dj = vert_dim(kind, vj), nj = unfixed(fm, oj, dj);
                 if (nj == 0) continue;
                 const bool diag_lower = lower && vi == vj;
-                if (cat == 0) {   // least-squares objective edge: 2 m J_i^T J_j.  Eigen evaluates small products (rows + cols + depth < 20)
-                    // coefficient-based with (2 m J_i^T) as the left factor -- every term scaled first -- and larger ones through its GEMM
-                    // kernel, which scales the finished sum (the 12 x 12 state-cost block of the quadrotor)
-                    jacobian(kind, vj, fm, xl, xr, mp, jac2);
-                    const bool small = ni + nj + ed < 20;
-                    for (int c = 0; c < nj; ++c)
-                        for (int r = 0; r < ni; ++r) {
-                            double acc = 0.0;
-                            if (small) for (int q = 0; q < ed; ++q) acc += ((2.0 * mult_obj) * jac1[r * ed + q]) * jac2[c * ed + q];
-                            else { for (int q = 0; q < ed; ++q) acc += jac1[r * ed + q] * jac2[c * ed + q]; acc = (2.0 * mult_obj) * acc; }
-                            blk[c * ni + r] = acc;
-                        }
-                }
-                else {   // BaseEdge::computeHessian[Inc] (edge_interface.cpp:151-255); cat 3: a plain objective edge, weighted with the objective
-                    // multiplier instead of row multipliers (…edge_based.cpp:2363-2410)
-                    double scalar = 1.0 / hdelta;
-                    if (cat == 3 && mult_obj != 1.0) scalar *= mult_obj;
-                    for (int q = 0; q < ni * nj; ++q) blk[q] = 0.0;
-                    int cj = 0;
-                    for (int j = 0; j < dj; ++j) {
-                        if ((fm >> (oj + j)) & 1u) continue;
-                        xl[oj + j] += hdelta;
-                        jacobian(kind, vi, fm, xl, xr, mp, jac2);
-                        for (int r = 0; r < ed; ++r) {
-                            const double f = mult ? scalar * mult[r] : scalar;
-                            for (int c = 0; c < ni; ++c) {
-                                const double t = f * (jac2[c * ed + r] - jac1[c * ed + r]);
-                                if (r == 0 && diag_lower) blk[cj * ni + c] = t;
-                                else blk[cj * ni + c] += t;
+                for (int part = 0; part < nparts; ++part) {
+                    if (cat == 0) {   // least-squares objective edge: 2 m J_i^T J_j.  Eigen evaluates small products (rows + cols + depth < 20)
+                        // coefficient-based with (2 m J_i^T) as the left factor -- every term scaled first -- and larger ones through its GEMM
+                        // kernel, which scales the finished sum (the 12 x 12 state-cost block of the quadrotor)
+                        jacobian(kind, vj, fm, xl, xr, mp, jac2);
+                        const bool small = ni + nj + ed < 20;
+                        for (int c = 0; c < nj; ++c)
+                            for (int r = 0; r < ni; ++r) {
+                                double acc = 0.0;
+                                if (small) for (int q = 0; q < ed; ++q) acc += ((2.0 * mult_obj) * jac1[r * ed + q]) * jac2[c * ed + q];
+                                else { for (int q = 0; q < ed; ++q) acc += jac1[r * ed + q] * jac2[c * ed + q]; acc = (2.0 * mult_obj) * acc; }
+                                blk[c * ni + r] = acc;
                             }
-                        }
-                        xl[oj + j] += -hdelta;
-                        ++cj;
                     }
+                    else {   // BaseEdge::computeHessian[Inc] (edge_interface.cpp:151-255); cat 3: a plain objective edge, weighted with the objective
+                        // multiplier instead of row multipliers (…edge_based.cpp:2363-2410); cat 4: rows [0, 1) like cat 3, rows [1, ed) like cat 1
+                        const int r0 = (cat == 4 && part == 1) ? 1 : 0, r1 = (cat == 4 && part == 0) ? 1 : ed;
+                        const double* pm = (cat == 4 && part == 0) ? nullptr : mult;
+                        double scalar = 1.0 / hdelta;
+                        if ((cat == 3 || (cat == 4 && part == 0)) && mult_obj != 1.0) scalar *= mult_obj;
+                        for (int q = 0; q < ni * nj; ++q) blk[q] = 0.0;
+                        int cj = 0;
+                        for (int j = 0; j < dj; ++j) {
+                            if ((fm >> (oj + j)) & 1u) continue;
+                            xl[oj + j] += hdelta;
+                            jacobian(kind, vi, fm, xl, xr, mp, jac2);
+                            for (int r = r0; r < r1; ++r) {
+                                const double f = pm ? scalar * pm[r - r0] : scalar;
+                                for (int c = 0; c < ni; ++c) {
+                                    const double t = f * (jac2[c * ed + r] - jac1[c * ed + r]);
+                                    if (r == r0 && diag_lower) blk[cj * ni + c] = t;
+                                    else blk[cj * ni + c] += t;
+                                }
+                            }
+                            xl[oj + j] += -hdelta;
+                            ++cj;
+                        }
+                    }
+                    double* o = (part ? out2 : out) + at;
+                    if (diag_lower) {
+                        int w = 0;
+                        for (int i = 0; i < ni; ++i)
+                            for (int j = 0; j <= i; ++j) o[w++] = 0.0 + blk[j * ni + i];
+                    }
+                    else
+                        for (int q = 0; q < ni * nj; ++q) o[q] = 0.0 + blk[q];
                 }
-                if (diag_lower) {
-                    for (int i = 0; i < ni; ++i)
-                        for (int j = 0; j <= i; ++j) out[at++] = 0.0 + blk[j * ni + i];
-                }
-                else {
-                    for (int q = 0; q < ni * nj; ++q) out[at + q] = 0.0 + blk[q];
-                    at += ni * nj;
-                }
+                at += diag_lower ? ni * (ni + 1) / 2 : ni * nj;
             }
         }
         return at;
@@ -3429,19 +3544,23 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         // never finished on the hardware -- > 120 s for one interval; the compiler had merged the copies into an exec-mask dispatch loop.)
         int kinds[6], cats[6], n_edges = 0;
         double* outs[6];
+        double* outs2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (mixed edge: its second list)
         const double* mults[6];
         auto add = [&](int kind, int cat, double* out, const double* mult) { kinds[n_edges] = kind; cats[n_edges] = cat; outs[n_edges] = out; mults[n_edges] = mult; ++n_edges; };
         const bool nl = hp.cost_nonlsq != 0;   // plain objective edges: category 3 (same output list)
         const int stage_kind = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : hp.cost_integral == 2 ? EK_INTEGRAL_LEFT : (nl ? EK_STATE_QCOST : EK_STATE_COST);
+        if (hp.ms_mixed && !final_stage) { add(EK_MIXED_JOINT, 4, vo + so[0], me); outs2[0] = ve + so[2]; }   // shooting grid + integral-form cost: the interval's only edge is the mixed one
+        else {
         if (so[0] >= 0) add(final_stage ? (nl ? EK_FINAL_QCOST : EK_FINAL_COST) : stage_kind, nl ? 3 : 0, vo + so[0], nullptr);
         if (so[1] >= 0) add(nl ? EK_CONTROL_QCOST : EK_CONTROL_COST, nl ? 3 : 0, vo + so[1], nullptr);
         if (k == 0 && hp.dt_cost_off >= 0) { add(nl ? EK_DT_QCOST : EK_DT_COST, nl ? 3 : 0, vo + hp.dt_cost_off, nullptr); add(nl ? EK_DT_QCOST : EK_DT_COST, nl ? 3 : 0, nullptr, nullptr); }
         if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
         if (so[3] >= 0) add(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, vi + so[3], mi);
+        }
         double* next = nullptr;
         for (int e = 0; e < n_edges; ++e) {
             double* out = outs[e] ? outs[e] : next;   // (the duplicated dt edge follows the first one)
-            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out);
+            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out, outs2[e]);
             next = out + n;
         }
     }
@@ -3454,7 +3573,8 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         const bool nl = hp.cost_nonlsq != 0;
         if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = nl ? EK_FINAL_QCOST : EK_FINAL_COST; }
         else {
-            if (hp.cost_integral) kinds[n_edges++] = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : EK_INTEGRAL_LEFT;
+            if (hp.ms_mixed) kinds[n_edges++] = EK_MIXED_OBJ;   // computeObjectiveJacobian per vertex, column sums (:75-101)
+            else if (hp.cost_integral) kinds[n_edges++] = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : EK_INTEGRAL_LEFT;
             else {
                 if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_STATE_QCOST : EK_STATE_COST;
                 if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_CONTROL_QCOST : EK_CONTROL_COST;
@@ -3513,7 +3633,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         double* ub = hp.ubA + (size_t)b * rows;
         double c[NX];
         if (lo[0] >= 0) {   // computeBoundsForTwoSideBoundedLinearForm: lbA = ubA = -c_eq
-            const int kind = final_stage ? EK_FINAL_EQ : EK_DEFECT;
+            const int kind = final_stage ? EK_FINAL_EQ : (hp.ms_mixed ? EK_MIXED_EQ : EK_DEFECT);   // (mixed edge: computeConstraintJacobians, :4944-4960)
             HE::values(kind, xl, xr, mpl, c);
             for (int r = 0; r < NX; ++r) { lb[so[4] + r] = c[r] * -1; ub[so[4] + r] = c[r] * -1; }
             HE::linear_blocks(kind, fm, xl, xr, mpl, lv + lo[0]);

@@ -135,6 +135,7 @@ struct HessParams {
     int32_t quad_first_interval;      // descriptor field (MinTimeQuadratic::only_last_n)
     int32_t cost_nonlsq;              // descriptor field: the cost edges are plain objective edges (scalar terms)
     int32_t cost_integral;            // descriptor field: 1 / 2 = one trapezoidal / left-sum integral cost edge per interval
+    int32_t ms_mixed;                 // cost_integral on a MultipleShootingGrid: one MultipleShootingEdgeSingleControl (mixed edge) per interval
     // mode 2: gradient of the least-squares objective, computeGradientObjective (hyper_graph_optimization_problem_edge_based.cpp:31-102)
     double* grad;               // [batch][n], zeroed by the caller (every parameter is written by the one lane that owns its component)
     double* obj_part;           // [batch][N]: the stage's share of computeValueObjective (sum of the squared norms of its cost edges)

@@ -54,8 +54,10 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         return "a stage cost with a minimum-time term needs a grid with a free dt";
     if (d.cost_nonlsq != 0 && d.cost_nonlsq != 1) return "cost_nonlsq must be 0 or 1";
     if (d.cost_integral < 0 || d.cost_integral > 2) return "cost_integral must be 0, 1 (trapezoidal rule) or 2 (left sum)";
-    if (d.cost_integral && (!d.cost_nonlsq || d.stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || d.grid != CORBO_HIP_GRID_FD))
-        return "cost_integral: quadratic stage cost with cost_nonlsq = 1 on the FiniteDifferencesGrid";
+    if (d.cost_integral && (!d.cost_nonlsq || d.stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || (d.grid != CORBO_HIP_GRID_FD && d.grid != CORBO_HIP_GRID_MS)))
+        return "cost_integral: quadratic stage cost with cost_nonlsq = 1 on the FiniteDifferencesGrid or the MultipleShootingGrid";
+    if (d.cost_integral && d.grid == CORBO_HIP_GRID_MS && (d.stage_ineq || (d.weights_dense & 3) || d.nx > 4))
+        return "cost_integral on the MultipleShootingGrid (MultipleShootingEdgeSingleControl): diagonal Q / R, no stage inequality, nx <= 4";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
     if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
@@ -337,6 +339,53 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
     int xf_unfixed = 0;
     for (int i = 0; i < nx; ++i) xf_unfixed += S.comp[S.off_xf + i].fixed ? 0 : 1;
     const V xf{S.off_xf, nx}, dtv{S.off_dt, 1};
+    if (d.cost_integral && d.grid == CORBO_HIP_GRID_MS) {
+        // MultipleShootingGrid + integral-form cost: one MIXED edge per interval on (x_k, u_k, dt, x_{k+1}) (multiple_shooting_grid.cpp:70-77).
+        // Mixed edges are the last loop of every function of the reference: their objective / equality blocks follow the final cost /
+        // the terminal equality in the Hessian lists (per vertex pair one block in each list, :3721-3990), their equality rows follow the
+        // terminal equality's (edge_set.cpp:31-42), their linear-form blocks follow the inequality edges' (:4944-4960).
+        if (xf_unfixed > 0 && d.final_cost) { H.stage_off[(size_t)(N - 1) * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xf, 1); }
+        int eq_row = 0, ineq_row = 0;
+        if (xf_unfixed > 0 && d.final_eq) {
+            H.stage_off[(size_t)(N - 1) * 6 + 2] = (int32_t)H.rows[1].size();
+            H.stage_off[(size_t)(N - 1) * 6 + 4] = eq_row;
+            walk(1, &xf, 1);
+            H.lin_off[(size_t)(N - 1) * 2 + 0] = (int32_t)H.lin_rows.size();
+            lin_walk(&xf, 1, nx, eq_row);
+            eq_row += nx;
+        }
+        const int eq_mixed0 = eq_row, eq_total = eq_row + (N - 1) * nx;
+        for (int k = 0; k < N - 1; ++k) {
+            const V verts[4] = {{k * s, nx}, {k * s + nx, nu}, dtv, {(k + 1) * s, nx}};
+            H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size();
+            walk(0, verts, 4);
+            H.stage_off[(size_t)k * 6 + 2] = (int32_t)H.rows[1].size();
+            H.stage_off[(size_t)k * 6 + 4] = eq_mixed0 + k * nx;
+            walk(1, verts, 4);
+        }
+        if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) {
+            H.stage_off[(size_t)(N - 1) * 6 + 3] = (int32_t)H.rows[2].size();
+            H.stage_off[(size_t)(N - 1) * 6 + 5] = ineq_row;
+            walk(2, &xf, 1);
+            H.lin_off[(size_t)(N - 1) * 2 + 1] = (int32_t)H.lin_rows.size();
+            lin_walk(&xf, 1, 1, eq_total + ineq_row);
+            ineq_row += 1;
+        }
+        for (int k = 0; k < N - 1; ++k) {
+            const V verts[4] = {{k * s, nx}, {k * s + nx, nu}, dtv, {(k + 1) * s, nx}};
+            H.lin_off[(size_t)k * 2 + 0] = (int32_t)H.lin_rows.size();
+            lin_walk(verts, 4, nx, eq_mixed0 + k * nx);
+        }
+        for (int c = 0; c < 3; ++c) H.nnz[c] = (int32_t)H.rows[c].size();
+        H.lin_bounds0 = (int32_t)H.lin_rows.size();
+        for (int v = 0; v <= S.off_dt; ++v) {
+            if (S.comp[v].bnd_row < 0) continue;
+            H.lin_rows.push_back(eq_total + ineq_row + (S.comp[v].bnd_row - S.bnd_row0));
+            H.lin_cols.push_back(S.comp[v].param);
+        }
+        H.lin_nnz = (int32_t)H.lin_rows.size();
+        return;
+    }
     // objective (least-squares edges) and the per-stage offsets
     for (int k = 0; k < N - 1; ++k) {
         const V xk{k * s, nx}, uk{k * s + nx, nu};

@@ -39,7 +39,12 @@ enum EdgeKind : int32_t {
     EK_DT_QCOST      = 11,  // MinimumTime(lsq_form = false): (N - 1) dt (minimum_time.h:60), not flagged linear
     // QuadraticFormCost in integral form: one objective edge per interval (finite_differences_collocation_edges.h:98-152, 323-368)
     EK_INTEGRAL_TRAP = 12,  // TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt)
-    EK_INTEGRAL_LEFT = 13   // LeftSumCostEdge on (x_k, u_k, dt)
+    EK_INTEGRAL_LEFT = 13,  // LeftSumCostEdge on (x_k, u_k, dt)
+    // MultipleShootingEdgeSingleControl on (x_k, u_k, dt, x_{k+1}) (multiple_shooting_edges.h:151-303): a mixed edge -- what a MultipleShootingGrid
+    // creates instead of the dynamics-only edge when the stage cost has integral terms (multiple_shooting_grid.cpp:70-77)
+    EK_MIXED_OBJ = 14,      // objective part: the cost integrated along the shooting step (1 value)
+    EK_MIXED_EQ  = 15,      // equality part: the defect (nx values)
+    EK_MIXED_JOINT = 16     // both parts as one value vector [objective; equalities] (the Jacobian of the Hessian walk: one perturbation cycle for both)
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):
@@ -97,6 +102,7 @@ struct HessianStructure {
     //   [0] objective: state cost (final stage: final cost)   [1] objective: control cost
     //   [2] equalities: defect edge (final stage: terminal equality)   [3] inequalities: stage inequality (final stage: terminal inequality)
     //   [4] first equality row of [2]   [5] first inequality row of [3]   (multiplier / linear-form row indices)
+    // shooting grid with an integral-form cost (mixed edges): [0] / [2] of an interval = first value of the mixed edge's objective / equality blocks
     std::vector<int32_t> stage_off;
     int32_t dt_cost_off = -1;       // objective: first value of the two dt cost edges (they follow stage 0's state / control terms), -1 = none
     int32_t lin_nnz = 0, lin_bounds0 = 0;

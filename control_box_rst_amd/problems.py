@@ -109,7 +109,9 @@ def hessian_path_cost_form(d: ProblemDesc, integral: str = "") -> ProblemDesc:
     """The cost forms of the reference's IPOPT / QP callers (Hessian-path operators only; corbo_hip_solve refuses such a handle like
     LevenbergMarquardtSparse does): every cost term with lsq_form = False -- scalar terms x^T Q x, plain objective edges -- and, with
     integral = "trapezoidal" | "left_sum", QuadraticFormCost(integral_form = True): one TrapezoidalIntegralCostEdge / LeftSumCostEdge per
-    interval of a FiniteDifferencesGrid instead of the per-vertex terms."""
+    interval of a FiniteDifferencesGrid instead of the per-vertex terms.  On a MultipleShootingGrid (set d.grid / d.defect afterwards) either
+    value stands for the same thing: ONE MultipleShootingEdgeSingleControl per interval -- a mixed edge that integrates the cost along the
+    shooting step with the grid's integrator and carries the defect as its equality part (multiple_shooting_grid.cpp:70-77)."""
     d.cost_nonlsq = 1
     d.cost_integral = {"": 0, "trapezoidal": 1, "left_sum": 2}[integral]
     return d

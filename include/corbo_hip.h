@@ -165,7 +165,12 @@ typedef struct corbo_hip_problem_desc {
      * interval that integrates c(x, u) = (x - xref)^T Q (x - xref) + u^T R u over it (finite_differences_grid.cpp:62-77) --
      * 1: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt), 0.5 dt (c(x_k, u_k) + c(x_{k+1}, u_k));  2: LeftSumCostEdge on (x_k, u_k, dt),
      * dt c(x_k, u_k) (finite_differences_collocation_edges.h:98-152, 323-368; FullDiscretizationGridBase::CostIntegrationRule).  Plain objective
-     * edges: needs cost_nonlsq = 1 (the final cost is then QuadraticFinalStateCost(Qf, false)); Hessian-path operators only. */
+     * edges: needs cost_nonlsq = 1 (the final cost is then QuadraticFinalStateCost(Qf, false)); Hessian-path operators only.
+     * On a MultipleShootingGrid (CORBO_HIP_GRID_MS; either value): the grid creates ONE MultipleShootingEdgeSingleControl per interval INSTEAD of
+     * the dynamics-only edge (multiple_shooting_grid.cpp:70-77; multiple_shooting_edges.h:151-303) -- a mixed edge on (x_k, u_k, dt, x_{k+1}) whose
+     * objective part is the cost integrated along the shooting step by the grid's integrator (augmented state [cost; x], :214-229, :251-281) and
+     * whose equality part is the defect.  Its blocks are the last ones of the Hessian lists, its equality rows follow the terminal equality's.
+     * Diagonal Q / R, no stage inequality, nx <= 4. */
     int32_t cost_integral;
     /* Non-diagonal weights (QuadraticFormCost::setWeightQ / setWeightR with a full matrix, quadratic_cost.cpp:36-55, 77-95;
      * QuadraticFinalStateCost::setWeightQf, final_state_cost.cpp:36-58; QuadraticFinalStateCostRiccati, final_state_cost.h:103, whose Qf is

@@ -230,7 +230,10 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     // ("…_stated": the same with the device model stated through setDeviceModel instead of derived by the recogniser; "vdp_…": on the
     // reference's own VanDerPolOscillator, recognisable without a device)
     const bool stated = (scenario == "unicycle_plain_stated");
-    const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap"),
+    // "..._msint": the integral-form cost on a MultipleShootingGrid -- the grid files one MultipleShootingEdgeSingleControl (a MIXED edge: the cost
+    // integrated along the shooting step + the defect) per interval instead of the dynamics-only edge (multiple_shooting_grid.cpp:70-77)
+    const bool msint = (scenario == "unicycle_msint" || scenario == "vdp_msint");
+    const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap" || msint),
                ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
     const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
@@ -274,7 +277,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         xf[0] = 2; xf[1] = 1;
         nu = 2;
     }
-    else if (scenario == "vdp" || scenario == "duffing" || scenario == "pendulum" || scenario == "vdp_plain" || scenario == "vdp_itrap")
+    else if (scenario == "vdp" || scenario == "duffing" || scenario == "pendulum" || scenario == "vdp_plain" || scenario == "vdp_itrap" || scenario == "vdp_msint")
     {
         if (scenario.compare(0, 3, "vdp") == 0) { auto s = std::make_shared<VanDerPolOscillator>(); s->setDampingCoefficient(1.3); dyn = s; }
         else if (scenario == "duffing") { auto s = std::make_shared<DuffingOscillator>(); s->setParameters(0.7, 1.1, 0.9); dyn = s; }
@@ -344,6 +347,13 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         x0     = Eigen::Vector2d(0, 0);
         xf     = Eigen::Vector2d(1, 0);
         solves = (scenario == "dint_mtq" || scenario == "dint_mtq8") ? 2 : 5;
+    }
+    if (msint)
+    {   // the same OCP on the shooting grid (unicycle: Runge-Kutta 4, Van der Pol: Runge-Kutta 3)
+        grid.reset();
+        ms_grid = std::make_shared<MultipleShootingGrid>();
+        if (scenario == "vdp_msint") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta3>());
+        else ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
     }
     const double dt = (scenario == "quad" || scenario == "pquad" || scenario == "pquad_fd") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
@@ -569,7 +579,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "unicycle_uref", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "unicycle_uref", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain", "vdp_msint"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -610,7 +620,7 @@ int main(int argc, char** argv)
         if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd") ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

@@ -92,6 +92,11 @@ def test_plain_and_integral_cost_forms_are_recognised(described):
     t = described["vdp_itrap"]
     assert t["recognised"] == 1 and (t["cost_nonlsq"], t["cost_integral"]) == (1, 1) and t["xref"] == [0.2, -0.1]
     assert np.allclose(t["q_diag"], [1.0, 0.3], rtol=4e-16, atol=0) and np.allclose(t["r_diag"], [0.2], rtol=4e-16, atol=0) and t["qf_diag"] == [7.0, 7.0 * 0.3]
+    # the same cost on a MultipleShootingGrid (Runge-Kutta 3): one MultipleShootingEdgeSingleControl -- a MIXED edge -- per interval; dynamics, integrator
+    # and stage cost come from the edge's private members, the integrand's weights (exactly: no dt in between) from the stage cost's own integrand
+    ms = described["vdp_msint"]
+    assert ms["recognised"] == 1 and (ms["grid"], ms["defect"], ms["cost_nonlsq"], ms["cost_integral"], ms["final_cost"]) == (capi.GRID_MS, capi.DEFECT_RK4_SHOOTING, 1, 1, 1)
+    assert ms["q_diag"] == [1.0, 0.3] and ms["r_diag"] == [0.2] and ms["qf_diag"] == [7.0, 7.0 * 0.3] and ms["xref"] == [0.2, -0.1] and ms["shooting_integrator"] == 3
 
 
 def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):

@@ -20,7 +20,9 @@ HESS = ["hess_kcar", "hess_pquad_n5", "hess_pquad_fd_n5", "hess_unicycle_fullq",
         "hess_unicycle_n16", "hess_unicycle_xf_fixed", "hess_unicycle_n24_ball", "hess_pendulum_ms_rk4", "hess_pendulum_ms_rk5", "hess_cartpole", "hess_quad_n4", "hess_int3_ms_time_optimal",
         "hess_dint_mtq", "hess_int3_ms_mtq", "hess_dint_mtq_last5",
         "hess_vdp_nonlsq", "hess_unicycle_nonlsq", "hess_unicycle_nonlsq_tball", "hess_dint_nonlsq", "hess_dint_mtq_nonlsq", "hess_int3_ms_nonlsq",
-        "hess_vdp_integral_trap", "hess_unicycle_integral_trap", "hess_unicycle_integral_left"]   # integral-form cost: one objective edge per interval   # *_nonlsq: plain (non-least-squares) objective edges
+        "hess_vdp_integral_trap", "hess_unicycle_integral_trap", "hess_unicycle_integral_left",
+        # MultipleShootingEdgeSingleControl: shooting grid + integral-form cost -> one mixed edge (integrated cost + defect) per interval
+        "hess_unicycle_ms_integral", "hess_unicycle_ms_integral_xf_fixed", "hess_vdp_ms_integral_euler", "hess_vdp_ms_integral_rk3", "hess_unicycle_ms_integral_rk5"]   # integral-form cost: one objective edge per interval   # *_nonlsq: plain (non-least-squares) objective edges
 KEYS = ("hobj", "heq", "hineq")
 REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below
 
@@ -109,6 +111,49 @@ def test_hessians_batch_vs_oracle(oracle_mod):
         for c in range(3):
             if len(ref[c][2]):
                 assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (b, c)
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 2, 3, 5, 6, 7])
+def test_mixed_edges_batch_vs_oracle(oracle_mod, integrator):
+    """MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:151-303): different instances, per-instance multipliers, every shooting
+    integrator -- Hessian lists, linear form, gradient and objective value of every instance against the oracle at its own point."""
+    from control_box_rst_amd import capi
+    d = problems.hessian_path_cost_form(problems.unicycle_desc(N=14), integral="trapezoidal")
+    d.grid, d.defect, d.shooting_integrator = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING, integrator
+    B = 6
+    rng = np.random.default_rng(40 + integrator)
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    X = s.init_trajectory(x0, xf) + 0.05 * rng.normal(size=(B, s.dims.nv))
+    X[:, :d.nx] = x0
+    s.set_instance_data(X, xref=xf)
+    me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
+    p = oracle_mod.OracleProblem(d)
+    for lower in (True, False):
+        st = s.hessian_structure(lower)
+        vals = s.eval_hessians(lower, 0.8, me, None)
+        for b in range(B):
+            p.set_data(X[b], xref=xf[b])
+            ref = p.hessians(1 if lower else 0, 0.8, me[b], None)
+            for c in range(3):
+                assert np.array_equal(st[c][0], ref[c][0]) and np.array_equal(st[c][1], ref[c][1])
+                if len(ref[c][2]):
+                    assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (b, c)
+    rows, cols, vals, lbA, ubA = s.linear_form()
+    grad, obj = s.objective_gradient()
+    for b in range(B):
+        p.set_data(X[b], xref=xf[b])
+        r, c, v, l, u = p.linear_form()
+        assert np.array_equal(rows, r) and np.array_equal(cols, c)
+        assert np.abs(vals[b] - v).max() <= 2e-6 * max(1.0, np.abs(v).max())
+        fin = np.abs(l) < 1e29
+        assert np.abs(lbA[b][fin] - l[fin]).max() <= 1e-12 * max(1.0, np.abs(l[fin]).max())
+        p.set_data(X[b], xref=xf[b])
+        go, oo = p.objective_gradient()
+        assert np.abs(grad[b] - go).max() <= 1e-6 * max(1.0, np.abs(go).max())
+        assert abs(obj[b] - oo) <= 1e-13 * max(1.0, abs(oo))
+    with pytest.raises(Exception):   # a mixed edge with a plain objective part is no least-squares problem: refused like LevenbergMarquardtSparse::solve does
+        s.solve(new_run=True)
 
 
 def test_hessians_big_block_family_vs_oracle(oracle_mod):
