@@ -332,6 +332,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
             _handle = nullptr;
             return false;
         }
+        corbo_hip_set_result_sink(_handle, 1);   // one OCP per solve() whose result goes back into the vertices: let the solve kernel deliver it
         _x.assign(_dims.nv, 0.0);
         _lb.assign(_dims.nv, 0.0);
         _ub.assign(_dims.nv, 0.0);
@@ -389,11 +390,21 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
     }
     double chi2    = -1;
     int32_t status = CORBO_HIP_SOLVER_ERROR;
-    if (corbo_hip_get_solution(_handle, _x.data(), &chi2, &status) != CORBO_HIP_OK)
+    // the solve kernel has written the accepted iterate and the LM state into the handle's pinned host memory itself (result sink, enabled at
+    // create): views, no copy kernel and no second synchronisation on the per-solve path (families without a run-to-completion kernel: the
+    // library copies behind the solve)
+    const double* xp    = nullptr;
+    const double* chi2p = nullptr;
+    const int32_t* stp  = nullptr;
+    int32_t stride      = 0;
+    if (corbo_hip_fetch_solution(_handle, &xp, &stride, &chi2p, &stp) != CORBO_HIP_OK || !xp || !chi2p || !stp)
     {
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
         return SolverStatus::Error;
     }
+    std::memcpy(_x.data(), xp, sizeof(double) * (size_t)_dims.nv);
+    chi2   = chi2p[0];
+    status = stp[0];
     corbo_hip_get_stats(_handle, &_stats);
 
     // ---- scatter the last accepted iterate back into the vertices (what callers read after solve(),

@@ -109,6 +109,7 @@ struct corbo_hip_solver {
     // copies of this size make the runtime pin and unpin the caller's (or a temporary's) pages on the fly; releasing those pages
     // afterwards stalls the queue for ~20 ms (measured: first solve after an upload 25 ms instead of 0.76 ms).
     double* h_stage      = nullptr;
+    double* h_stage_b[2] = {nullptr, nullptr};   // pinned staging of per-instance lower / upper bounds (allocated on first use)
     double* d_bound_rows = nullptr;  // [2][nvs] the descriptor's bound pattern of one instance (lower row, upper row)
     std::vector<double> bound_rows;  // host copy of the same
     double* d_lin    = nullptr;      // [A | B] of a LinearStateSpaceModel (row-major), else null
@@ -232,6 +233,7 @@ struct corbo_hip_solver {
         return p;
     }
 };
+
 
 extern "C" {
 
@@ -470,6 +472,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     if (h->h_xnew) (void)hipHostFree(h->h_xnew);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    for (int w = 0; w < 2; ++w) if (h->h_stage_b[w]) (void)hipHostFree(h->h_stage_b[w]);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_chi2) (void)hipHostFree(h->h_chi2);
     if (h->h_dist) (void)hipHostFree(h->h_dist);
@@ -523,18 +526,21 @@ try {
                     return fail(CORBO_HIP_ERR_INVALID, "per-instance bounds change the descriptor's finiteness pattern (instance " + std::to_string(b) +
                                                            ", component " + std::to_string(i) + "): bound rows are static");
             }
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        // each array through its own pinned staging buffer and a copy kernel behind the pattern broadcast on the handle's stream: no copy
+        // engine (a hipMemcpyAsync wakes one: 0.1 - 0.3 ms before the next kernel may start) and no synchronisation in between -- this is
+        // the per-solve path of the drop-in adapter (one OCP, bounds re-read from the vertices on every solve)
         for (int which = 0; which < 2; ++which) {
             const double* src = which == 0 ? lb : ub;
             if (!src) continue;
-            double* st = h->h_stage;
+            if (!h->h_stage_b[which]) HIP_TRY(hipHostMalloc((void**)&h->h_stage_b[which], all_bytes));
+            double* st = h->h_stage_b[which];
             for (int b = 0; b < B; ++b) {
                 double* o = st + (size_t)b * nvs;
                 std::memcpy(o, rows.data() + (size_t)which * nvs, row_bytes);
                 std::memcpy(o, src + (size_t)b * nv, nv * sizeof(double));
             }
-            HIP_TRY(hipMemcpyAsync(which == 0 ? h->d_lb : h->d_ub, st, all_bytes, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            launch_copy_rows(st, which == 0 ? h->d_lb : h->d_ub, nullptr, all_bytes / sizeof(double), h->stream);
+            HIP_TRY(hipGetLastError());
         }
     }
     for (int b = 0; b < B; ++b)
@@ -542,7 +548,8 @@ try {
             h->h_xnew[(size_t)b * CORBO_HIP_MAX_NX + i] = (xref && i < S.nx) ? xref[(size_t)b * S.nx + i] : 0.0;
     launch_copy_rows(h->h_xnew, h->d_xref, nullptr, (size_t)B * CORBO_HIP_MAX_NX, h->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));   // the staging buffers are the caller's again
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the staging buffers are the caller's again (deferring this wait to the solve that follows was
+                                                // measured: no gain -- waiting on a stream that is about to drain costs next to nothing)
     h->have_data = true;
     return CORBO_HIP_OK;
 }
