@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <algorithm>
 #include <cstring>
 #include <sstream>
@@ -391,6 +392,10 @@ bool describeDynamics(SystemDynamicsInterface& dyn, corbo_hip_problem_desc& d, s
 #undef CORBO_HIP_USER_MODEL
 #endif
     };
+    // the device's answers at the probe points do not change while the process lives: ONE device evaluation per candidate and process, kept here
+    // (the adapter's model tracking walks through this function once per new run -- a kernel launch and a synchronisation each time otherwise)
+    static std::mutex cache_mutex;
+    static std::vector<std::vector<double>> device_values(sizeof(cands) / sizeof(cands[0]));
     for (const Candidate& c : cands)
     {
         if (c.nx != nx || c.nu != nu) continue;
@@ -404,7 +409,16 @@ bool describeDynamics(SystemDynamicsInterface& dyn, corbo_hip_problem_desc& d, s
             for (int i = 0; i < nx; ++i) xs[p * nx + i] = 0.37 * std::sin(1.0 + 1.7 * i + 0.9 * p) + 0.05 * p;
             for (int i = 0; i < nu; ++i) us[p * nu + i] = 0.8 * std::cos(0.3 + 2.1 * i + 1.3 * p) + ((c.id == CORBO_HIP_DYN_QUADROTOR && i == 0) ? 9.0 : 0.0);   // (|u| < 0.8: inside tan()'s first branch for a steering angle)
         }
-        if (corbo_hip_eval_dynamics(&t, P, xs.data(), us.data(), fd.data()) != CORBO_HIP_OK) continue;
+        {
+            std::lock_guard<std::mutex> lock(cache_mutex);
+            std::vector<double>& kept = device_values[&c - cands];
+            if (kept.empty())
+            {
+                if (corbo_hip_eval_dynamics(&t, P, xs.data(), us.data(), fd.data()) != CORBO_HIP_OK) continue;
+                kept = fd;
+            }
+            else fd = kept;
+        }
         bool same = true;
         for (int p = 0; p < P && same; ++p)
         {
@@ -458,6 +472,37 @@ bool identifyBall(BaseEdge& e, VertexInterface* v, double* prm /*cx, cy, cz, r*/
 
 // A scalar term  scale * sum_i q_i (x_i - ref_i)^2  (a cost in plain, non-least-squares form: quadratic_cost.cpp:133-138; the integrand of the
 // integral cost edges, finite_differences_collocation_edges.h:98-152, 323-368), diagonal and non-negative, evaluated through the edge itself.
+// The same term checked against a KNOWN model (the resident device model of the previous run): n + 1 evaluations instead of ~ 7 n.  The edge must
+// reproduce  w_i (x_i - ref_i)  bit for bit at the current point and at x_i + 1 for every component (two points fix an affine row), off-diagonal
+// responses must vanish, rows with a zero weight must be identically zero.  false: identify from scratch.
+bool verifyDiagonalAffine(BaseEdge& e, VertexInterface* v, const Eigen::VectorXd& wh, const Eigen::VectorXd& rh, Eigen::VectorXd* w, Eigen::VectorXd* ref)
+{
+    const int n = v->getDimension();
+    if (e.getDimension() != n || wh.size() != n || rh.size() != n) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    const Eigen::VectorXd r0 = evalEdge(e);
+    for (int i = 0; i < n; ++i)
+        if (r0[i] != ((wh[i] == 0.0) ? 0.0 : wh[i] * (x[i] - rh[i]))) return false;
+    for (int i = 0; i < n; ++i)
+    {
+        const double x0 = x[i];
+        volatile double xp = x0 + 1.0;
+        x[i] = xp;
+        const Eigen::VectorXd r1 = evalEdge(e);
+        x[i] = x0;
+        for (int j = 0; j < n; ++j)
+            if (j != i && r1[j] != r0[j]) return false;
+        if (r1[i] != ((wh[i] == 0.0) ? 0.0 : wh[i] * ((double)xp - rh[i]))) return false;
+        if (wh[i] != 0.0 && r1[i] == r0[i]) return false;
+    }
+    *w = wh;
+    *ref = rh;
+    for (int i = 0; i < n; ++i)
+        if (wh[i] == 0.0) (*ref)[i] = 0.0;   // (what the identification reports for a row without a weight)
+    return true;
+}
+
 // `twins`: vertices that receive the same values (x_k and x_{k+1} of a trapezoidal edge: 0.5 dt (c + c) = dt c exactly).  The reference is
 // the point where the term is EXACTLY zero (three-point estimate, then a walk over neighbouring floating-point numbers); the weights from
 // x_i = ref_i + d with d a power of two ((d q_i) d is a pure exponent shift; divided by `scale`, which costs an ulp unless scale == 1).
@@ -663,7 +708,7 @@ bool readStateReferenceTrajectoryForHip(BaseHyperGraphOptimizationProblem& hg, i
     return seen >= g.N - 1;   // (without a final cost term row N-1 keeps what the caller put there)
 }
 
-bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason)
+bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason, const HipRecognisedModel* hint)
 {
     GridView g;
     if (!viewGrid(hg, &g, reason)) return false;
@@ -777,7 +822,35 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             continue;
         }
         Eigen::MatrixXd Ud;   // non-empty: the term has a non-diagonal weight, r = U (v - ref)
-        if (!identifyDiagonalAffine(*e, v, &w, &ref))
+        // a resident model of the same graph (the adapter's model tracking, one call per new run): check the term against it first -- n + 1
+        // evaluations of the edge instead of the full identification; any surprise falls through to the identification from scratch
+        bool hinted = false;
+        if (hint && !hint->desc.weights_dense && !hint->desc.cost_nonlsq && hint->desc.nx == g.nx && hint->desc.nu == g.nu)
+        {
+            const bool traj = hint->xref_traj.rows() == g.N && hint->xref_traj.cols() == g.nx;
+            Eigen::VectorXd wh, rh;
+            const int ks = indexOf(g.xs, v);
+            if (v == g.xf && hint->desc.final_cost && hint->xref.size() == g.nx)
+            {
+                wh.resize(g.nx);
+                for (int i = 0; i < g.nx; ++i) wh[i] = std::sqrt(hint->desc.qf_diag[i]);
+                rh = traj ? Eigen::VectorXd(hint->xref_traj.row(g.N - 1).transpose()) : hint->xref;
+            }
+            else if (ks >= 0 && (CORBO_HIP_COST_TERMS(hint->desc.stage_cost) & 1) && hint->xref.size() == g.nx)
+            {
+                wh.resize(g.nx);
+                for (int i = 0; i < g.nx; ++i) wh[i] = std::sqrt(hint->desc.q_diag[i]);
+                rh = traj ? Eigen::VectorXd(hint->xref_traj.row(ks).transpose()) : hint->xref;
+            }
+            else if (indexOf(g.us, v) >= 0 && (CORBO_HIP_COST_TERMS(hint->desc.stage_cost) & 2))
+            {
+                wh.resize(g.nu);
+                for (int i = 0; i < g.nu; ++i) wh[i] = std::sqrt(hint->desc.r_diag[i]);
+                rh = Eigen::VectorXd::Zero(g.nu);
+            }
+            hinted = wh.size() > 0 && verifyDiagonalAffine(*e, v, wh, rh, &w, &ref);
+        }
+        if (!hinted && !identifyDiagonalAffine(*e, v, &w, &ref))
         {
             if (g.nx > 4 || g.nu > 4 || !identifyUpperAffine(*e, v, &Ud, &ref))
                 return fail(reason, "a least-squares term is neither sqrt(W_diag) (v - ref) nor U (v - ref) with an upper Cholesky factor U (nx <= 4; with a ZERO "

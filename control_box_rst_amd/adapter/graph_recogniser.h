@@ -35,7 +35,9 @@ struct HipRecognisedModel
 };
 
 // false: *reason says what the device cannot describe
-bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason);
+// hint: the model a previous call derived from the same graph (the adapter's model tracking, once per new run) -- cost terms are CHECKED against it
+// (n + 1 edge evaluations each) before they are identified from scratch (~ 7 n); the result is the same model either way
+bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecognisedModel* model, std::string* reason, const HipRecognisedModel* hint = nullptr);
 
 // the state reference alone (cheap: a few evaluations of one cost edge); used on every solve to follow a reference that changed
 // between runs without a structure change.  false if the graph has no state-dependent least-squares term.

@@ -242,9 +242,10 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     bool model_changed = false;
     if (!(new_structure || !_handle || _desc.N != N || dt_changed) && _recognised && new_run && _tracking)
     {
-        HipRecognisedModel m;
+        HipRecognisedModel m, resident;
+        resident.desc = _desc; resident.xref = _xref; resident.xref_traj = _xref_traj;   // checked term by term first (graph_recogniser.h)
         std::string why;
-        if (!recogniseHyperGraphForHip(*hg, &m, &why))
+        if (!recogniseHyperGraphForHip(*hg, &m, &why, &resident))
         {
             PRINT_ERROR("LevenbergMarquardtSparseHip(): this hypergraph has no device description any more: " << why << "; refusing to solve (no CPU fallback).");
             return false;

@@ -506,12 +506,8 @@ try {
         for (int i = nv; i < nvs; ++i) o[i] = 0.0;
         if (!S.dt_free) o[S.off_dt] = S.desc.dt_ref;   // a fixed dt lives in the vertex storage too
     }
-    // iterate, trial iterate and re-arm copy: ONE kernel that reads the pinned staging buffer (device-visible host memory) -- no copy engine
-    launch_copy_rows(h->h_stage, h->d_x, h->d_xt, all_bytes / sizeof(double), h->stream, h->d_x0);
-    HIP_TRY(hipGetLastError());
     // bounds: the descriptor's pattern for every instance, overwritten by the caller's per-instance arrays where given
-    launch_broadcast_rows(h->d_bound_rows, h->d_bound_rows + nvs, h->d_lb, h->d_ub, nvs, B, h->stream);
-    HIP_TRY(hipGetLastError());
+    const double* b_src[2] = {nullptr, nullptr};
     if (lb || ub) {
         // entries beyond nv (fixed dt, padding) keep the pattern's "unbounded": stage the pattern row, then the caller's values
         const std::vector<double>& rows = h->bound_rows;
@@ -526,9 +522,9 @@ try {
                     return fail(CORBO_HIP_ERR_INVALID, "per-instance bounds change the descriptor's finiteness pattern (instance " + std::to_string(b) +
                                                            ", component " + std::to_string(i) + "): bound rows are static");
             }
-        // each array through its own pinned staging buffer and a copy kernel behind the pattern broadcast on the handle's stream: no copy
-        // engine (a hipMemcpyAsync wakes one: 0.1 - 0.3 ms before the next kernel may start) and no synchronisation in between -- this is
-        // the per-solve path of the drop-in adapter (one OCP, bounds re-read from the vertices on every solve)
+        // each array through its own pinned staging buffer: no copy engine (a hipMemcpyAsync wakes one: 0.1 - 0.3 ms before the next kernel
+        // may start) and no synchronisation in between -- this is the per-solve path of the drop-in adapter (one OCP, bounds re-read from the
+        // vertices on every solve)
         for (int which = 0; which < 2; ++which) {
             const double* src = which == 0 ? lb : ub;
             if (!src) continue;
@@ -539,14 +535,22 @@ try {
                 std::memcpy(o, rows.data() + (size_t)which * nvs, row_bytes);
                 std::memcpy(o, src + (size_t)b * nv, nv * sizeof(double));
             }
-            launch_copy_rows(st, which == 0 ? h->d_lb : h->d_ub, nullptr, all_bytes / sizeof(double), h->stream);
-            HIP_TRY(hipGetLastError());
+            b_src[which] = st;
         }
     }
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i)
             h->h_xnew[(size_t)b * CORBO_HIP_MAX_NX + i] = (xref && i < S.nx) ? xref[(size_t)b * S.nx + i] : 0.0;
-    launch_copy_rows(h->h_xnew, h->d_xref, nullptr, (size_t)B * CORBO_HIP_MAX_NX, h->stream);
+    // ONE kernel reads the pinned staging buffers (device-visible host memory): iterate -> accepted / trial / re-arm copies, the bounds (staged
+    // arrays or the pattern rows), the state references
+    UploadParams up{};
+    up.x = reinterpret_cast<const double2*>(h->h_stage); up.dx = reinterpret_cast<double2*>(h->d_x); up.dxt = reinterpret_cast<double2*>(h->d_xt);
+    up.dx0 = reinterpret_cast<double2*>(h->d_x0); up.n2 = all_bytes / sizeof(double2);
+    up.lb_src = reinterpret_cast<const double2*>(b_src[0]); up.ub_src = reinterpret_cast<const double2*>(b_src[1]);
+    up.row_lb = reinterpret_cast<const double2*>(h->d_bound_rows); up.row_ub = reinterpret_cast<const double2*>(h->d_bound_rows + nvs);
+    up.dlb = reinterpret_cast<double2*>(h->d_lb); up.dub = reinterpret_cast<double2*>(h->d_ub); up.nvs2 = (size_t)nvs / 2;
+    up.xref = reinterpret_cast<const double2*>(h->h_xnew); up.dxref = reinterpret_cast<double2*>(h->d_xref); up.nref2 = (size_t)B * CORBO_HIP_MAX_NX / 2;
+    launch_upload_instance(up, h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));   // the staging buffers are the caller's again (deferring this wait to the solve that follows was
                                                 // measured: no gain -- waiting on a stream that is about to drain costs next to nothing)

@@ -3424,7 +3424,7 @@ struct HessEdge {
     // into `out` and computeEqualityHessian[Inc](.., mult_eq_part) into `out2` (edge_interface.cpp:525-634) -- both lists advance by the same
     // blocks; the Jacobian at the perturbed point is the joint one again (the other part's rows are not read: same perturbation cycle, same values).
     __device__ static int hessian_blocks(int kind, int cat, bool lower, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double mult_obj,
-                                         const double* mult, double* out, double* out2)
+                                         const double* mult, double* out, double* out2, double* out3)
     {
         constexpr double hdelta = 1e-2;
         const int ed = edge_dim(kind), nv = n_verts(kind);
@@ -3487,6 +3487,8 @@ struct HessEdge {
                     else
                         for (int q = 0; q < ni * nj; ++q) o[q] = 0.0 + blk[q];
                 }
+                if (out3)   // (mixed edge in a problem that has inequalities: its blocks exist in the inequality list as well -- the reference never writes them)
+                    for (int q = 0; q < (diag_lower ? ni * (ni + 1) / 2 : ni * nj); ++q) out3[at + q] = 0.0;
                 at += diag_lower ? ni * (ni + 1) / 2 : ni * nj;
             }
         }
@@ -3545,11 +3547,12 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         int kinds[6], cats[6], n_edges = 0;
         double* outs[6];
         double* outs2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (mixed edge: its second list)
+        double* outs3[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (mixed edge: its zero blocks in the inequality list)
         const double* mults[6];
         auto add = [&](int kind, int cat, double* out, const double* mult) { kinds[n_edges] = kind; cats[n_edges] = cat; outs[n_edges] = out; mults[n_edges] = mult; ++n_edges; };
         const bool nl = hp.cost_nonlsq != 0;   // plain objective edges: category 3 (same output list)
         const int stage_kind = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : hp.cost_integral == 2 ? EK_INTEGRAL_LEFT : (nl ? EK_STATE_QCOST : EK_STATE_COST);
-        if (hp.ms_mixed && !final_stage) { add(EK_MIXED_JOINT, 4, vo + so[0], me); outs2[0] = ve + so[2]; }   // shooting grid + integral-form cost: the interval's only edge is the mixed one
+        if (hp.ms_mixed && !final_stage) { add(EK_MIXED_JOINT, 4, vo + so[0], me); outs2[0] = ve + so[2]; if (so[3] >= 0) outs3[0] = vi + so[3]; }   // shooting grid + integral-form cost: the interval's only edge is the mixed one
         else {
         if (so[0] >= 0) add(final_stage ? (nl ? EK_FINAL_QCOST : EK_FINAL_COST) : stage_kind, nl ? 3 : 0, vo + so[0], nullptr);
         if (so[1] >= 0) add(nl ? EK_CONTROL_QCOST : EK_CONTROL_COST, nl ? 3 : 0, vo + so[1], nullptr);
@@ -3560,7 +3563,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         double* next = nullptr;
         for (int e = 0; e < n_edges; ++e) {
             double* out = outs[e] ? outs[e] : next;   // (the duplicated dt edge follows the first one)
-            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out, outs2[e]);
+            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out, outs2[e], outs3[e]);
             next = out + n;
         }
     }
@@ -4053,6 +4056,30 @@ void launch_copy_rows(const double* src, double* dst, double* dst2, size_t doubl
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst),
                        reinterpret_cast<double2*>(dst2), reinterpret_cast<double2*>(dst3), n2);
+}
+
+// The whole upload of corbo_hip_set_instance_data as ONE launch (the per-solve path of the drop-in adapter: five small launches back to back
+// cost ~5 us each on an otherwise idle stream): iterate -> accepted / trial / re-arm copies, bounds from the per-instance staging arrays or
+// from the descriptor's pattern rows, state references.  All sources are device-visible (pinned host memory or device arrays).
+__global__ __launch_bounds__(256) void upload_instance_kernel(const UploadParams p)
+{
+    const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < p.n2; i += stride) {
+        const double2 v = p.x[i];
+        p.dx[i] = v;
+        p.dxt[i] = v;
+        if (p.dx0) p.dx0[i] = v;
+        p.dlb[i] = p.lb_src ? p.lb_src[i] : p.row_lb[i % p.nvs2];
+        p.dub[i] = p.ub_src ? p.ub_src[i] : p.row_ub[i % p.nvs2];
+    }
+    for (size_t i = t0; i < p.nref2; i += stride) p.dxref[i] = p.xref[i];
+}
+void launch_upload_instance(const UploadParams& p, hipStream_t stream)
+{
+    size_t blocks = (p.n2 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(upload_instance_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
 }
 
 void launch_resample(const ResampleParams& p, hipStream_t stream)

@@ -195,6 +195,14 @@ bool launch_plant_step(const corbo_hip_problem_desc& d, const PlantParams& p, hi
 void launch_gather_first_control(const double* x, double* out, int nvs, int nx, int nu, int batch, hipStream_t stream);
 // dst_a[b][:] = row_a, dst_b[b][:] = row_b for b < batch (the descriptor's bound pattern repeated for every instance)
 void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst_a, double* dst_b, int nvs, int batch, hipStream_t stream);
+// corbo_hip_set_instance_data as one launch (see upload_instance_kernel); double2 element counts, nvs is even
+struct UploadParams {
+    const double2* x; double2 *dx, *dxt, *dx0; size_t n2;
+    const double2 *lb_src, *ub_src;   // per-instance bound arrays in pinned staging, or null: the pattern rows
+    const double2 *row_lb, *row_ub; double2 *dlb, *dub; size_t nvs2;
+    const double2* xref; double2* dxref; size_t nref2;
+};
+void launch_upload_instance(const UploadParams& p, hipStream_t stream);
 
 // big-block family, parity hook: the Jacobian values the stage kernel differentiates (defect blocks, cost / bound / inequality rows of
 // every interval) at the accepted iterate, written into jac_out [batch][nnz_pad] in the public value order; needs a residual sweep

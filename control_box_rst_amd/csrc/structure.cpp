@@ -370,6 +370,13 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
             H.lin_off[(size_t)(N - 1) * 2 + 1] = (int32_t)H.lin_rows.size();
             lin_walk(&xf, 1, 1, eq_total + ineq_row);
             ineq_row += 1;
+            // the reference's quirk: the inequality list's mixed loop tests the PROBLEM's getInequalityDimension(), not the edge's (:3216, :3421) --
+            // as soon as the problem has any inequality every mixed edge gets the same blocks in the inequality list too (never written: zeros)
+            for (int k = 0; k < N - 1; ++k) {
+                const V verts[4] = {{k * s, nx}, {k * s + nx, nu}, dtv, {(k + 1) * s, nx}};
+                H.stage_off[(size_t)k * 6 + 3] = (int32_t)H.rows[2].size();
+                walk(2, verts, 4);
+            }
         }
         for (int k = 0; k < N - 1; ++k) {
             const V verts[4] = {{k * s, nx}, {k * s + nx, nu}, dtv, {(k + 1) * s, nx}};

@@ -1322,6 +1322,13 @@ static int hessian_walk(oracle_problem* p, int lower, int with_values, double mu
                         edge_hessian(p, q, vi, vj, je, blk, meq, 1.0, diag_lower ? 0 : 1);
                     }
                     nnz[1] = hess_emit(a, b, diag_lower, with_values, blk, rows[1], cols[1], vals[1], nnz[1]);
+                    /* the reference's quirk: the inequality list's mixed loop tests the PROBLEM's getInequalityDimension(), not the edge's
+                     * (:3216, :3421) -- as soon as the problem has any inequality, every mixed edge gets the same blocks in the inequality list too;
+                     * this branch of the values function never writes them (:3941-3988): zeros */
+                    if (p->dims.ineq > 0) {
+                        if (with_values) for (int z = 0; z < a->n_unfixed * b->n_unfixed; ++z) blk[z] = 0.0;
+                        nnz[2] = hess_emit(a, b, diag_lower, with_values, blk, rows[2], cols[2], vals[2], nnz[2]);
+                    }
                 }
             }
             continue;

@@ -257,6 +257,9 @@ def msmixed():
         ("hess_vdp_ms_integral_euler", dict(scenario="vdp", grid="ms", N=10, lsq=0, integral="trap", ms_integrator="euler")),
         ("hess_vdp_ms_integral_rk3", dict(scenario="vdp", grid="ms", N=8, lsq=0, integral="trap", ms_integrator="rk3")),
         ("hess_unicycle_ms_integral_rk5", dict(scenario="unicycle", grid="ms", N=5, lsq=0, integral="trap", ms_integrator="rk5")),
+        # with a terminal equality / a TerminalBall: regular equality and inequality edges come BEFORE the mixed edges in every list and in the row order
+        ("hess_unicycle_ms_integral_teq", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", teq=1, ms_integrator="rk2")),
+        ("hess_unicycle_ms_integral_tball", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", tball=0.02, tball_s="1,1,0.1")),
     ]:
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
