@@ -114,6 +114,46 @@ def test_hessians_batch_vs_oracle(oracle_mod):
                 assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (b, c)
 
 
+@pytest.mark.parametrize("variant", ["xf_fixed", "teq", "tball", "vdp"])
+def test_mixed_edges_structure_variants_vs_oracle(oracle_mod, variant):
+    """The mixed edges next to what else a graph can carry: fixed x_f components (fewer columns in the last edge's blocks), a terminal equality
+    (its rows and blocks come BEFORE the mixed edges'), a TerminalBall (the reference then lists every mixed edge's blocks in the inequality list
+    too, as zeros) -- structure entry for entry, values within the operators' tolerance, per instance against the oracle."""
+    from control_box_rst_amd import capi
+    d = problems.hessian_path_cost_form(problems.vdp_desc(N=9) if variant == "vdp" else problems.unicycle_desc(N=9, terminal_ball=(((1.0, 1.0, 0.1), 0.02) if variant == "tball" else None)), integral="trapezoidal")
+    d.grid, d.defect, d.shooting_integrator = capi.GRID_MS, capi.DEFECT_RK4_SHOOTING, 2
+    if variant == "xf_fixed": d.xf_fixed_mask = 6
+    if variant == "teq": d.final_eq = 1
+    B = 4
+    rng = np.random.default_rng(77)
+    s = BatchedLevenbergMarquardt(d, B)
+    x0 = rng.uniform(-0.5, 0.5, (B, d.nx))
+    xf = rng.uniform(-0.5, 0.5, (B, d.nx))
+    X = s.init_trajectory(x0, xf) + 0.05 * rng.normal(size=(B, s.dims.nv))
+    X[:, :d.nx] = x0
+    s.set_instance_data(X, xref=xf)
+    me = rng.uniform(0.2, 1.0, (B, s.dims.eq))
+    mi = rng.uniform(0.2, 1.0, (B, s.dims.ineq)) if s.dims.ineq else None
+    p = oracle_mod.OracleProblem(d)
+    assert (p.dims.n, p.dims.eq, p.dims.ineq, p.dims.bounds) == (s.dims.n, s.dims.eq, s.dims.ineq, s.dims.bounds)
+    for lower in (True, False):
+        st = s.hessian_structure(lower)
+        vals = s.eval_hessians(lower, 1.3, me, mi)
+        for b in range(B):
+            p.set_data(X[b], xref=xf[b])
+            ref = p.hessians(1 if lower else 0, 1.3, me[b], None if mi is None else mi[b])
+            for c in range(3):
+                assert np.array_equal(st[c][0], ref[c][0]) and np.array_equal(st[c][1], ref[c][1]), (variant, lower, c)
+                if len(ref[c][2]):
+                    assert np.abs(vals[c][b] - ref[c][2]).max() <= REL * max(1.0, np.abs(ref[c][2]).max()), (variant, b, c)
+    rows, cols, vals, lbA, ubA = s.linear_form()
+    for b in range(B):
+        p.set_data(X[b], xref=xf[b])
+        r, c, v, l, u = p.linear_form()
+        assert np.array_equal(rows, r) and np.array_equal(cols, c)
+        assert np.abs(vals[b] - v).max() <= 2e-6 * max(1.0, np.abs(v).max())
+
+
 @pytest.mark.parametrize("integrator", [0, 1, 2, 3, 5, 6, 7])
 def test_mixed_edges_batch_vs_oracle(oracle_mod, integrator):
     """MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:151-303): different instances, per-instance multipliers, every shooting
