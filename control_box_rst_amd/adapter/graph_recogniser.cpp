@@ -945,6 +945,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         // (integral_form = true: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt) / LeftSumCostEdge on (x_k, u_k, dt)); then the final cost
         Eigen::VectorXd q, r, qf, ref, rf, uz;
         int ns = 0, nc = 0, nf = 0, ni = 0, ndt = 0, integral = 0;
+        int k_first_integral = ms_mixed ? 0 : g.N;   // first interval with an integral cost edge (MinTimeQuadratic::only_last_n in integral form)
         const double dtv = g.dt->getData()[0];
         if (ms_mixed)
         {   // the integrand c(x, u) of the mixed edges' objective part, probed through the stage cost's own computeIntegralStateControlTerm
@@ -986,8 +987,9 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             const bool trap = dynamic_cast<TrapezoidalIntegralCostEdge*>(e) != nullptr, left = dynamic_cast<LeftSumCostEdge*>(e) != nullptr;
             if (trap || left)
             {
-                if (g.kind != CORBO_HIP_GRID_FD) return fail(reason, "integral cost edges on a grid other than the FiniteDifferencesGrid");
+                if (g.kind != CORBO_HIP_GRID_FD && g.kind != CORBO_HIP_GRID_FD_VARIABLE) return fail(reason, "integral cost edges on a grid other than the FiniteDifferencesGrid / FiniteDifferencesVariableGrid");
                 const int k = indexOf(g.xs, e->getVertexRaw(0));
+                if (k >= 0 && k < k_first_integral) k_first_integral = k;
                 VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
                 if (k < 0 || e->getVertexRaw(1) != g.us[k] || (trap && (e->getVertexRaw(2) != x2 || e->getVertexRaw(3) != g.dt)) || (left && e->getVertexRaw(2) != g.dt))
                     return fail(reason, "integral cost edge on unexpected vertices");
@@ -1038,9 +1040,14 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             else return fail(reason, "plain objective edge on an unexpected vertex");
         }
         const bool quad = integral || ns || nc;
-        if (quad && (integral ? (ni != g.N - 1 || ns || nc) : (ns != g.N - 1 || nc != g.N - 1)))
-            return fail(reason, "plain cost terms that are not one state and one control term (or one integral edge) per interval");
-        if (ndt != 0 && (ndt != 2 || integral)) return fail(reason, "plain minimum-time term that was not created twice at k = 0, or next to an integral cost");
+        if (quad && (integral ? (ni != g.N - 1 - k_first_integral || ns || nc) : (ns != g.N - 1 || nc != g.N - 1)))
+            return fail(reason, "plain cost terms that are not one state and one control term (or one integral edge) per interval -- or, integral edges, per interval of a tail of the horizon");
+        if (ndt != 0 && ndt != 2) return fail(reason, "plain minimum-time term that was not created twice at k = 0");
+        // integral edges next to the dt terms: MinTimeQuadratic(integral_form = true), also with only_last_n (hybrid_cost.h:209); without dt terms
+        // they are QuadraticFormCost's, on every interval of a fixed-dt grid
+        if (integral && !ms_mixed && ((ndt == 2) != (g.kind == CORBO_HIP_GRID_FD_VARIABLE) || (k_first_integral != 0 && !ndt)))
+            return fail(reason, "integral cost edges: QuadraticFormCost on a fixed-dt grid or MinTimeQuadratic on the FiniteDifferencesVariableGrid");
+        if (integral && !ms_mixed) d.quad_first_interval = k_first_integral;
         d.cost_nonlsq = 1;
         d.cost_integral = integral;
         d.stage_cost = ndt ? (quad ? CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ : CORBO_HIP_COST_MIN_TIME_LSQ) : (quad ? CORBO_HIP_COST_QUADRATIC_LSQ : CORBO_HIP_COST_NONE);

@@ -3577,7 +3577,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         if (final_stage) { if (so[0] >= 0) kinds[n_edges++] = nl ? EK_FINAL_QCOST : EK_FINAL_COST; }
         else {
             if (hp.ms_mixed) kinds[n_edges++] = EK_MIXED_OBJ;   // computeObjectiveJacobian per vertex, column sums (:75-101)
-            else if (hp.cost_integral) kinds[n_edges++] = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : EK_INTEGRAL_LEFT;
+            else if (hp.cost_integral) { if (k >= hp.quad_first_interval) kinds[n_edges++] = hp.cost_integral == 1 ? EK_INTEGRAL_TRAP : EK_INTEGRAL_LEFT; }
             else {
                 if ((terms & 1) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_STATE_QCOST : EK_STATE_COST;
                 if ((terms & 2) && k >= hp.quad_first_interval) kinds[n_edges++] = nl ? EK_CONTROL_QCOST : EK_CONTROL_COST;

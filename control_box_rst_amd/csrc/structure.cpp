@@ -54,8 +54,13 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         return "a stage cost with a minimum-time term needs a grid with a free dt";
     if (d.cost_nonlsq != 0 && d.cost_nonlsq != 1) return "cost_nonlsq must be 0 or 1";
     if (d.cost_integral < 0 || d.cost_integral > 2) return "cost_integral must be 0, 1 (trapezoidal rule) or 2 (left sum)";
-    if (d.cost_integral && (!d.cost_nonlsq || d.stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || (d.grid != CORBO_HIP_GRID_FD && d.grid != CORBO_HIP_GRID_MS)))
-        return "cost_integral: quadratic stage cost with cost_nonlsq = 1 on the FiniteDifferencesGrid or the MultipleShootingGrid";
+    {   // QuadraticFormCost(integral_form = true) on the FiniteDifferencesGrid / the MultipleShootingGrid; MinTimeQuadratic(integral_form = true) -- its
+        // quadratic part integrated, next to its dt terms (hybrid_cost.h:189-303) -- on the FiniteDifferencesVariableGrid
+        const bool quad_ok = d.stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ && (d.grid == CORBO_HIP_GRID_FD || d.grid == CORBO_HIP_GRID_MS);
+        const bool mtq_ok  = d.stage_cost == CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ && d.grid == CORBO_HIP_GRID_FD_VARIABLE;
+        if (d.cost_integral && (!d.cost_nonlsq || !(quad_ok || mtq_ok)))
+            return "cost_integral: with cost_nonlsq = 1, a quadratic stage cost on the FiniteDifferencesGrid / the MultipleShootingGrid or MinTimeQuadratic on the FiniteDifferencesVariableGrid";
+    }
     if (d.cost_integral && d.grid == CORBO_HIP_GRID_MS && (d.stage_ineq || (d.weights_dense & 3) || d.nx > 4))
         return "cost_integral on the MultipleShootingGrid (MultipleShootingEdgeSingleControl): diagonal Q / R, no stage inequality, nx <= 4";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
@@ -398,14 +403,20 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
         const V xk{k * s, nx}, uk{k * s + nx, nu};
         const int terms = CORBO_HIP_COST_TERMS(d.stage_cost);
         const bool quad = (k >= d.quad_first_interval) && !d.cost_integral;
-        if (d.cost_integral) {   // one integral cost edge per interval instead of the per-vertex terms (finite_differences_grid.cpp:62-77)
+        if (d.cost_integral && (terms & 4) && k == 0) {   // MinTimeQuadratic in integral form: an interval's non-integral terms (the dt term, twice) are
+            H.dt_cost_off = (int32_t)H.rows[0].size();   // filed BEFORE its integral edge (finite_differences_grid.cpp:58-77)
+            walk(0, &dtv, 1);
+            walk(0, &dtv, 1);
+        }
+        if (d.cost_integral && k >= d.quad_first_interval) {   // one integral cost edge per interval instead of the per-vertex terms (finite_differences_grid.cpp:62-77;
+            // MinTimeQuadratic::only_last_n: hasIntegralTerms(k) = k >= _quad_k_min, hybrid_cost.h:209)
             const V trap[4] = {xk, uk, {(k + 1) * s, nx}, dtv}, left[3] = {xk, uk, dtv};
             H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size();
             if (d.cost_integral == 1) walk(0, trap, 4); else walk(0, left, 3);
         }
         if ((terms & 1) && quad) { H.stage_off[(size_t)k * 6 + 0] = (int32_t)H.rows[0].size(); walk(0, &xk, 1); }
         if ((terms & 2) && quad) { H.stage_off[(size_t)k * 6 + 1] = (int32_t)H.rows[0].size(); walk(0, &uk, 1); }
-        if ((terms & 4) && k == 0) {
+        if (!d.cost_integral && (terms & 4) && k == 0) {
             H.dt_cost_off = (int32_t)H.rows[0].size();
             walk(0, &dtv, 1);
             walk(0, &dtv, 1);   // duplicated edge (nlp_functions.cpp:91-107)

@@ -166,6 +166,9 @@ typedef struct corbo_hip_problem_desc {
      * 1: TrapezoidalIntegralCostEdge on (x_k, u_k, x_{k+1}, dt), 0.5 dt (c(x_k, u_k) + c(x_{k+1}, u_k));  2: LeftSumCostEdge on (x_k, u_k, dt),
      * dt c(x_k, u_k) (finite_differences_collocation_edges.h:98-152, 323-368; FullDiscretizationGridBase::CostIntegrationRule).  Plain objective
      * edges: needs cost_nonlsq = 1 (the final cost is then QuadraticFinalStateCost(Qf, false)); Hessian-path operators only.
+     * With CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ on the FiniteDifferencesVariableGrid: MinTimeQuadratic(Q, R, integral_form = true, lsq_form = false)
+     * (hybrid_cost.h:189-303) -- its quadratic part in integral form (integral edges on the intervals k >= quad_first_interval), its dt term (plain,
+     * created twice at k = 0) filed BEFORE interval 0's integral edge (finite_differences_grid.cpp:58-77).
      * On a MultipleShootingGrid (CORBO_HIP_GRID_MS; either value): the grid creates ONE MultipleShootingEdgeSingleControl per interval INSTEAD of
      * the dynamics-only edge (multiple_shooting_grid.cpp:70-77; multiple_shooting_edges.h:151-303) -- a mixed edge on (x_k, u_k, dt, x_{k+1}) whose
      * objective part is the cost integrated along the shooting step by the grid's integrator (augmented state [cost; x], :214-229, :251-281) and

@@ -569,7 +569,12 @@ static int validate(const corbo_hip_problem_desc* d)
         return 0;
     if (d->cost_nonlsq != 0 && d->cost_nonlsq != 1) return 0;
     if (d->cost_integral < 0 || d->cost_integral > 2) return 0;
-    if (d->cost_integral && (!d->cost_nonlsq || d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ || (d->grid != CORBO_HIP_GRID_FD && d->grid != CORBO_HIP_GRID_MS))) return 0;
+    /* integral-form quadratic cost: QuadraticFormCost on a FiniteDifferencesGrid / FiniteDifferencesVariableGrid / MultipleShootingGrid, MinTimeQuadratic
+     * (quadratic part in integral form next to its dt terms, hybrid_cost.h:189-303) on the FiniteDifferencesVariableGrid */
+    if (d->cost_integral && (!d->cost_nonlsq || (d->stage_cost != CORBO_HIP_COST_QUADRATIC_LSQ && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) ||
+                             d->grid == CORBO_HIP_GRID_MS_VARIABLE)) return 0;
+    if (d->cost_integral && d->stage_cost == CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ && d->grid != CORBO_HIP_GRID_FD_VARIABLE) return 0;
+    if (d->cost_integral && d->stage_cost == CORBO_HIP_COST_QUADRATIC_LSQ && d->grid == CORBO_HIP_GRID_FD_VARIABLE) return 0; /* (no fixture of the reference pins it) */
     if (d->cost_integral && d->grid == CORBO_HIP_GRID_MS && (d->stage_ineq || (d->weights_dense & 3))) return 0; /* MultipleShootingEdgeSingleControl: diagonal Q / R, no stage inequality */
     if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
     if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
@@ -697,7 +702,14 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
             o_edge* ee = &mix[n_mix++]; *ee = *eo; ee->type = E_MS_MIXED_EQ; ee->dim = nx; ee->scale = 1; ee->nonlsq = 0;
             continue;
         }
-        if (d->cost_integral) { /* QuadraticFormCost(Q, R, integral_form = true): no non-integral terms; one integral cost edge per interval
+        if (d->cost_integral && (terms & 4) && k == 0) { /* MinTimeQuadratic in integral form: the NON-integral terms of an interval (its dt term, twice)
+                                                          * are filed before the interval's integral edge (finite_differences_grid.cpp:58-77) */
+            for (int rep = 0; rep < 2; ++rep) {
+                o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0; e->nonlsq = d->cost_nonlsq;
+            }
+        }
+        if (d->cost_integral && !quad) { /* MinTimeQuadratic::only_last_n: hasIntegralTerms(k) = k >= _quad_k_min (hybrid_cost.h:209) */ }
+        else if (d->cost_integral) { /* QuadraticFormCost(Q, R, integral_form = true): no non-integral terms; one integral cost edge per interval
                                  * (finite_differences_grid.cpp:62-77), 1 = TrapezoidalRule, 2 = LeftSum */
             o_edge* e = &lsq[n_lsq++]; e->type = E_INTEGRAL_COST; e->k = k; e->dim = 1; e->scale = 0; e->nonlsq = 1;
             e->vert[0] = xk; e->vert[1] = uk;
@@ -710,7 +722,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         if (!d->cost_integral && (terms & 2) && quad) {
             o_edge* e = &lsq[n_lsq++]; e->type = E_CONTROL_COST; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = nl ? 1 : nu; e->scale = 0; e->nonlsq = nl;
         }
-        if ((terms & 4) && k == 0) {
+        if (!d->cost_integral && (terms & 4) && k == 0) {
             for (int rep = 0; rep < 2; ++rep) { /* duplicated dt edge, nlp_functions.cpp:91-107 */
                 o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0; e->nonlsq = d->cost_nonlsq;
             }

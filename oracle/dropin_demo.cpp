@@ -233,6 +233,9 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     // "..._msint": the integral-form cost on a MultipleShootingGrid -- the grid files one MultipleShootingEdgeSingleControl (a MIXED edge: the cost
     // integrated along the shooting step + the defect) per interval instead of the dynamics-only edge (multiple_shooting_grid.cpp:70-77)
     const bool msint = (scenario == "unicycle_msint" || scenario == "vdp_msint");
+    // MinTimeQuadratic(integral_form = true, lsq_form = false) on the FiniteDifferencesVariableGrid: its dt terms (plain, twice) precede interval 0's
+    // integral edge; "..8_ileft": with only_last_n = 8 and the left sum
+    const bool mtq_int = (scenario == "dint_mtq_itrap" || scenario == "dint_mtq8_ileft");
     const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap" || msint),
                ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
@@ -390,7 +393,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     {
         grid->setNRef(N);
         grid->setDtRef(dt);
-        grid->setCostIntegrationRule(itrap ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        grid->setCostIntegrationRule((itrap || scenario == "dint_mtq_itrap") ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         any_grid = grid;
     }
     else
@@ -449,6 +452,17 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         ocp.setControlBounds(Eigen::Vector2d(0, 0), Eigen::Vector2d(12, 12));
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.0, 0.3));
+    }
+    else if (mtq_int)
+    {
+        struct LastN : public MinTimeQuadratic
+        {
+            LastN(const Eigen::MatrixXd& Q, const Eigen::MatrixXd& R, int n) : MinTimeQuadratic(Q, R, true, false) { _only_last_n = n; }
+        };
+        Eigen::MatrixXd Q = Eigen::Vector2d(1.0, 0.5).asDiagonal(), R = Eigen::MatrixXd::Constant(1, 1, 0.1);
+        if (scenario == "dint_mtq8_ileft") ocp.setStageCost(std::make_shared<LastN>(Q, R, 8));
+        else ocp.setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, true, false));
+        ocp.setControlBounds(Eigen::VectorXd::Constant(1, -1), Eigen::VectorXd::Constant(1, 1));
     }
     else if (scenario == "dint_mtq8")
     {   // MinTimeQuadratic with only_last_n = 8 (no setter outside fromMessage, hybrid_cost.h:300: a subclass reaches the protected member)
@@ -526,7 +540,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     r.traj = trajectory(ocp, *any_grid);
     r.chi2 = ocp.getCurrentObjectiveValue();
     if (describe_out) *describe_out = *std::static_pointer_cast<RecogniseOnly>(solver);
-    if (mode == Mode::Hessian && (hpath || scenario == "dint_plain")) r.ok = true;   // compute() returned false: neither solver takes a problem that is not least squares; the graph is built
+    if (mode == Mode::Hessian && (hpath || mtq_int || scenario == "dint_plain")) r.ok = true;   // compute() returned false: neither solver takes a problem that is not least squares; the graph is built
     if (mode == Mode::Hessian && r.ok)
     {
         // computeSparseHessians{NNZ,Structure,Values} as IpoptWrapper::eval_h calls them (lower part, per-row multipliers), at a generic
@@ -584,7 +598,7 @@ int main(int argc, char** argv)
     {   // recogniser only (no solve): scenarios given on the command line, default = the ones that need no device
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
-        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "unicycle_uref", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain", "vdp_msint"};
+        if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "unicycle_uref", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft"};
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
@@ -625,7 +639,7 @@ int main(int argc, char** argv)
         if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd") ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

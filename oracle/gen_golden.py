@@ -257,6 +257,10 @@ def msmixed():
         ("hess_vdp_ms_integral_euler", dict(scenario="vdp", grid="ms", N=10, lsq=0, integral="trap", ms_integrator="euler")),
         ("hess_vdp_ms_integral_rk3", dict(scenario="vdp", grid="ms", N=8, lsq=0, integral="trap", ms_integrator="rk3")),
         ("hess_unicycle_ms_integral_rk5", dict(scenario="unicycle", grid="ms", N=5, lsq=0, integral="trap", ms_integrator="rk5")),
+        # MinTimeQuadratic(integral_form = true, lsq_form = false) on the FiniteDifferencesVariableGrid: the dt terms (plain, twice) are filed before
+        # interval 0's integral edge; with only_last_n the integral edges exist on the last intervals only (hybrid_cost.h:209)
+        ("hess_dint_mtq_integral_trap", dict(scenario="dint", cost="mtq", N=8, lsq=0, integral="trap")),
+        ("hess_dint_mtq_integral_left_last4", dict(scenario="dint", cost="mtq", N=10, lsq=0, integral="left", last_n=4)),
         # with a terminal equality / a TerminalBall: regular equality and inequality edges come BEFORE the mixed edges in every list and in the row order
         ("hess_unicycle_ms_integral_teq", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", teq=1, ms_integrator="rk2")),
         ("hess_unicycle_ms_integral_tball", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", tball=0.02, tball_s="1,1,0.1")),

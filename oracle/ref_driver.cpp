@@ -172,7 +172,7 @@ class BallKeepOut : public StageInequalityConstraint
 // MinTimeQuadratic::_only_last_n has no setter outside fromMessage (hybrid_cost.h:300): reach the protected member through a subclass
 struct MinTimeQuadraticLastN : public MinTimeQuadratic
 {
-    MinTimeQuadraticLastN(const Eigen::MatrixXd& Q, const Eigen::MatrixXd& R, int last_n) : MinTimeQuadratic(Q, R, false, true) { _only_last_n = last_n; }
+    MinTimeQuadraticLastN(const Eigen::MatrixXd& Q, const Eigen::MatrixXd& R, int last_n, bool integral_form = false, bool lsq_form = true) : MinTimeQuadratic(Q, R, integral_form, lsq_form) { _only_last_n = last_n; }
 };
 
 struct Scenario
@@ -557,8 +557,8 @@ static Built build(const Scenario& s, int iterations)
         for (int i = 0; i < s.nx; ++i) q[i] = qv[i % 4];
         for (int i = 0; i < s.nu; ++i) r[i] = rv[i % 3];
         Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
-        if (s.cost == "mtq" && s.last_n > 0) b.ocp->setStageCost(std::make_shared<MinTimeQuadraticLastN>(Q, R, s.last_n));
-        else if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, false, !s.nonlsq));
+        if (s.cost == "mtq" && s.last_n > 0) b.ocp->setStageCost(std::make_shared<MinTimeQuadraticLastN>(Q, R, s.last_n, !s.integral.empty(), !s.nonlsq));
+        else if (s.cost == "mtq") b.ocp->setStageCost(std::make_shared<MinTimeQuadratic>(Q, R, !s.integral.empty(), !s.nonlsq));
         else if (s.cost == "qstate") b.ocp->setStageCost(std::make_shared<QuadraticStateCost>(Q, false, true));
         else if (s.cost == "qctrl") b.ocp->setStageCost(std::make_shared<QuadraticControlCost>(R, false, true));
         else if (s.cost == "mtqs") b.ocp->setStageCost(std::make_shared<MinTimeQuadraticStates>(Q, false, true));

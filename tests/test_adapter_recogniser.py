@@ -97,6 +97,13 @@ def test_plain_and_integral_cost_forms_are_recognised(described):
     ms = described["vdp_msint"]
     assert ms["recognised"] == 1 and (ms["grid"], ms["defect"], ms["cost_nonlsq"], ms["cost_integral"], ms["final_cost"]) == (capi.GRID_MS, capi.DEFECT_RK4_SHOOTING, 1, 1, 1)
     assert ms["q_diag"] == [1.0, 0.3] and ms["r_diag"] == [0.2] and ms["qf_diag"] == [7.0, 7.0 * 0.3] and ms["xref"] == [0.2, -0.1] and ms["shooting_integrator"] == 3
+    # MinTimeQuadratic in integral form on the FiniteDifferencesVariableGrid: plain dt terms (twice) + one integral edge per interval -- with
+    # only_last_n = 8 on the intervals k >= N - 8 only (hybrid_cost.h:209, 224-237)
+    mi = described["dint_mtq_itrap"]
+    assert mi["recognised"] == 1 and (mi["grid"], mi["stage_cost"], mi["cost_nonlsq"], mi["cost_integral"], mi["quad_first_interval"]) == (capi.GRID_FD_VARIABLE, capi.COST_MIN_TIME_QUADRATIC_LSQ, 1, 1, 0)
+    ml = described["dint_mtq8_ileft"]
+    assert ml["recognised"] == 1 and (ml["stage_cost"], ml["cost_integral"], ml["quad_first_interval"], ml["N"]) == (capi.COST_MIN_TIME_QUADRATIC_LSQ, 2, 22, 30)
+    assert np.allclose(mi["q_diag"], [1.0, 0.5], rtol=4e-16, atol=0) and np.allclose(ml["r_diag"], [0.1], rtol=4e-16, atol=0)
 
 
 def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):
