@@ -1,0 +1,33 @@
+"""Extended randomized parity campaign on a GPU box: the bodies of tests/test_gpu_fuzz.py over seeds the suite does not run.
+    python tools/fuzz_campaign.py [first_seed] [count]      -> failing seeds with their assertion text (nothing = all passed)
+"""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import test_gpu_fuzz as F   # noqa: E402
+from oracle import oracle as O   # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+O.build()
+O.load()
+bad = []
+for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range(first, first + count)),
+                        ("quadrotor", F.test_random_quadrotor_descriptor_vs_oracle, range(first, first + count // 10)),
+                        ("bounds+weights", F.test_per_instance_bounds_and_weight_adaptation_vs_oracle, range(first, first + count // 5)),
+                        ("closed loop", F.test_random_closed_loop_call_vs_stepwise_and_oracle_plant, range(first, first + count // 5))):
+    n_bad = 0
+    for seed in seeds:
+        try:
+            fn(O, seed)
+        except Exception as e:   # noqa: BLE001
+            n_bad += 1
+            bad.append((name, seed, type(e).__name__, str(e)[:300]))
+    print(f"{name}: {len(seeds)} seeds, {n_bad} failed", flush=True)
+for b in bad:
+    print("FAILED", b)
