@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import test_gpu_fuzz as F   # noqa: E402
+import test_gpu_hessian as H   # noqa: E402
 from oracle import oracle as O   # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -20,7 +21,8 @@ bad = []
 for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range(first, first + count)),
                         ("quadrotor", F.test_random_quadrotor_descriptor_vs_oracle, range(first, first + count // 10)),
                         ("bounds+weights", F.test_per_instance_bounds_and_weight_adaptation_vs_oracle, range(first, first + count // 5)),
-                        ("closed loop", F.test_random_closed_loop_call_vs_stepwise_and_oracle_plant, range(first, first + count // 5))):
+                        ("closed loop", F.test_random_closed_loop_call_vs_stepwise_and_oracle_plant, range(first, first + count // 5)),
+                        ("hessian operators", H.test_random_descriptor_hessians_vs_oracle, range(first, first + count))):
     n_bad = 0
     for seed in seeds:
         try:
