@@ -537,6 +537,20 @@ bool identifyDiagonalQuadratic(BaseEdge& e, const std::vector<VertexInterface*>&
         (*ref)[i] = (fm - fp) / (4.0 * qi);
     }
     for (int i = 0; i < n; ++i) x[i] = active[i] ? (*ref)[i] : 0.0;
+    // The estimates above come from values of size sum_j q_j ref_j^2: a component with a small weight next to others with large ones is off
+    // by hundreds of ulps (q = 0.1 beside q = 1 and references of size 2: ~1e-13).  Refine around the estimate, where the OTHER terms are
+    // (nearly) zero and every value is of size q h^2: the correction (f(r - h) - f(r + h)) / (4 q h) is then good to a fraction of an ulp.
+    for (int round = 0; round < 2; ++round)
+        for (int i = 0; i < n; ++i)
+        {
+            if (!active[i]) continue;
+            const double r = x[i], h = std::ldexp(1.0, -10) * std::max(1.0, std::abs(r));
+            const double fc = f();
+            x[i] = r + h; const double fp = f();
+            x[i] = r - h; const double fm = f();
+            const double qi = 0.5 * (fp + fm - 2.0 * fc) / (h * h);
+            x[i] = (qi > 0.0 && std::isfinite(qi)) ? r + (fm - fp) / (4.0 * qi * h) : r;
+        }
     double fx = f();
     for (int sweep = 0; sweep < 4 && fx != 0.0; ++sweep)
         for (int i = 0; i < n; ++i)
@@ -558,9 +572,19 @@ bool identifyDiagonalQuadratic(BaseEdge& e, const std::vector<VertexInterface*>&
     {
         if (!active[i]) { (*ref)[i] = 0.0; continue; }
         const double r = x[i];
-        const double d = std::ldexp(1.0, std::max(-20, std::min(20, (r == 0.0) ? 0 : std::ilogb(r))));
-        x[i] = r + d;
-        if (x[i] - r != d) { x[i] = r; return false; }
+        // a power of two d with (r + d) - r == d in floating point: r + d must not need a bit more than r has (an arbitrary reference -- a sample
+        // of a time-varying trajectory -- plus 2^ilogb(r) crosses into the next binade and loses its last bit half of the time): start well below
+        // r's own exponent and take the first d that survives the round trip
+        double d = std::ldexp(1.0, std::max(-20, std::min(20, (r == 0.0) ? 0 : std::ilogb(r))) - ((r == 0.0) ? 0 : 12));
+        bool ok = false;
+        for (int t = 0; t < 24 && !ok; ++t, d *= 0.5)
+        {
+            volatile double xp = r + d;
+            ok = ((double)xp - r == d);
+            if (ok) x[i] = xp;
+        }
+        if (!ok) { x[i] = r; return false; }
+        d = x[i] - r;
         (*q)[i] = f() / (d * d) / scale;
         x[i] = r;
     }
@@ -951,7 +975,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         {   // the integrand c(x, u) of the mixed edges' objective part, probed through the stage cost's own computeIntegralStateControlTerm
             // (what MultipleShootingEdgeSingleControl::configureIntegrand calls, multiple_shooting_edges.h:251-263) on x_k / u_k of an interval:
             // a diagonal quadratic form around one state reference and a zero control reference, the same on the first and the last interval
-            for (int k : {0, g.N - 2})
+            for (int k = 0; k < g.N - 1; ++k)
             {
                 const StageCost* sc = mixed_cost;
                 EdgeGenericScalarFun<VectorVertex, VectorVertex> probe(
@@ -974,8 +998,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
                     if (!identifyDiagonalQuadratic(probe, {g.us[k]}, 1.0, &wu, &ru) || (ru.array() != 0.0).any())
                         return fail(reason, "mixed edges: the integrand is not a diagonal quadratic form in the control (zero reference)");
                 }
+                stage_refs[k] = rr;
                 if (k == 0) { q = w; ref = rr; r = wu; }
-                else if (!sameVector(w, q) || !sameVector(rr, ref) || !sameVector(wu, r)) return fail(reason, "mixed edges: the integrand varies along the horizon");
+                else if (!sameVector(w, q) || !sameVector(wu, r)) return fail(reason, "mixed edges: the integrand's weights vary along the horizon");
+                else if (!sameVector(rr, ref)) refs_vary = true;   // a time-varying reference trajectory: interval k integrates against reference k
             }
             integral = 1;
             ni = g.N - 1;
@@ -1007,8 +1033,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
                     if (!identifyDiagonalQuadratic(*e, {g.us[k]}, trap ? dtv : dtv, &wu, &ru) || (ru.array() != 0.0).any())
                         return fail(reason, "integral cost edge whose integrand is not a diagonal quadratic form in the control (zero reference)");
                 }
+                stage_refs[k] = rr;
                 if (ni++ == 0) { q = w; ref = rr; r = wu; }
-                else if ((w - q).cwiseAbs().maxCoeff() > 1e-12 * (1.0 + q.cwiseAbs().maxCoeff()) || !sameVector(rr, ref)) return fail(reason, "integral cost varies along the horizon");
+                else if ((w - q).cwiseAbs().maxCoeff() > 1e-12 * (1.0 + q.cwiseAbs().maxCoeff())) return fail(reason, "integral cost weights vary along the horizon");
+                else if (!sameVector(rr, ref)) refs_vary = true;   // time-varying reference: both ends of interval k use reference k
                 continue;
             }
             if (e->getNumVertices() != 1) return fail(reason, "plain objective edge on more than one vertex that is not an integral cost edge");
@@ -1028,8 +1056,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             if (v == g.xf) { if (nf++ > 0) return fail(reason, "more than one plain term on x_f"); qf = w; rf = rr; }
             else if (indexOf(g.xs, v) >= 0)
             {
+                stage_refs[indexOf(g.xs, v)] = rr;
                 if (ns++ == 0) { q = w; ref = rr; }
-                else if (!sameVector(w, q) || !sameVector(rr, ref)) return fail(reason, "plain state cost varies along the horizon (time-varying references: least-squares form only)");
+                else if (!sameVector(w, q)) return fail(reason, "plain state cost weights vary along the horizon");
+                else if (!sameVector(rr, ref)) refs_vary = true;   // a time-varying reference trajectory
             }
             else if (indexOf(g.us, v) >= 0)
             {
@@ -1057,7 +1087,12 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         d.final_cost = nf ? 1 : 0;
         if (nf) for (int i = 0; i < g.nx; ++i) d.qf_diag[i] = qf[i];
         model->xref = ref;
-        if (nf)
+        if (refs_vary)
+        {   // one reference per grid point: model->xref is the final-stage terms' (the last sample)
+            if ((q.array() == 0.0).any()) return fail(reason, "time-varying state reference with a zero state weight (the reference of that component cannot be identified)");
+            model->xref = nf ? rf : stage_refs[g.N - 2];
+        }
+        else if (nf)
             for (int i = 0; i < g.nx; ++i)
             {
                 if (q[i] != 0.0 && qf[i] != 0.0 && ref[i] != rf[i]) return fail(reason, "stage and final cost use different state references");

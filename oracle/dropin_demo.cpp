@@ -232,14 +232,14 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     const bool stated = (scenario == "unicycle_plain_stated");
     // "..._msint": the integral-form cost on a MultipleShootingGrid -- the grid files one MultipleShootingEdgeSingleControl (a MIXED edge: the cost
     // integrated along the shooting step + the defect) per interval instead of the dynamics-only edge (multiple_shooting_grid.cpp:70-77)
-    const bool msint = (scenario == "unicycle_msint" || scenario == "vdp_msint");
+    const bool msint = (scenario == "unicycle_msint" || scenario == "vdp_msint" || scenario == "unicycle_msint_tvref");
     // MinTimeQuadratic(integral_form = true, lsq_form = false) on the FiniteDifferencesVariableGrid: its dt terms (plain, twice) precede interval 0's
     // integral edge; "..8_ileft": with only_last_n = 8 and the left sum
     const bool mtq_int = (scenario == "dint_mtq_itrap" || scenario == "dint_mtq8_ileft");
-    const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap" || msint),
+    const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain" || scenario == "unicycle_plain_tvref"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap" || msint),
                ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
-    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
+    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref" || scenario == "unicycle_plain_tvref" || scenario == "unicycle_msint_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
     const bool moved = (scenario == "unicycle_moved");   // the setpoint moves between two runs WITHOUT a structure change (model tracking)
     const bool uni = (scenario == "unicycle" || moved || tball || tballc || fullq || tvref || urefnz || kcar || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
@@ -639,7 +639,7 @@ int main(int argc, char** argv)
         if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd") ? 3e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
-    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft"})
+    for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft", "unicycle_plain_tvref", "unicycle_msint_tvref"})
     {
         Run h = run(sc, Mode::Hessian, std::min(horizon(sc), 40));
         printf("{\"scenario\": \"%s\", \"mode\": \"hessian\", \"ok_hip\": %d, \"structure_equal\": %d, \"nnz\": [%d, %d, %d], \"max_rel_diff\": %.6e}\n", sc,

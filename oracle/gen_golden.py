@@ -178,7 +178,12 @@ def tvref():
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))
         print(name, [round(st["chi2"], 6) for st in d["steps"]])
-    for name, kv in [("hess_unicycle_tvref", dict(scenario="unicycle", N=12, xref_traj=1))]:
+    for name, kv in [("hess_unicycle_tvref", dict(scenario="unicycle", N=12, xref_traj=1)),
+                     # the cost forms of the Hessian path against a time-varying reference: plain terms, integral edges (both ends of an interval use
+                     # reference k), the shooting grid's mixed edges (the integrand along the step uses reference k)
+                     ("hess_unicycle_tvref_nonlsq", dict(scenario="unicycle", N=8, xref_traj=1, lsq=0)),
+                     ("hess_unicycle_tvref_integral_trap", dict(scenario="unicycle", N=8, xref_traj=1, lsq=0, integral="trap")),
+                     ("hess_unicycle_tvref_ms_integral", dict(scenario="unicycle", grid="ms", N=7, xref_traj=1, lsq=0, integral="trap"))]:
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))

@@ -44,7 +44,7 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # reference's own consecutive-call spread (tests/test_gpu_hessian.py)
     assert [r["scenario"] for r in hessian] == ["unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy",
                                                "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft",
-                                               "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft"], p.stdout   # (the last nine: graphs with plain /
+                                               "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft", "unicycle_plain_tvref", "unicycle_msint_tvref"], p.stdout   # (the last nine: graphs with plain /
     # integral objective edges, the IPOPT-style cost forms -- recognised, one of them with a stated model; ..._msint: the shooting grid's MIXED edges,
     # MultipleShootingEdgeSingleControl)
     for r in hessian:

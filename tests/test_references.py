@@ -55,8 +55,13 @@ def test_oracle_values_jacobian_and_iterates(oracle_mod, name):
         assert abs(chi2 - a["chi2"]) <= CHI2_RTOL.get(name, 2e-6) * max(1.0, abs(a["chi2"])), (name, a["k"])
 
 
-def test_oracle_hessians_with_references(oracle_mod):
-    g = load_golden("hess_unicycle_tvref")
+HESS_TVREF = ["hess_unicycle_tvref", "hess_unicycle_tvref_nonlsq", "hess_unicycle_tvref_integral_trap", "hess_unicycle_tvref_ms_integral"]   # least-squares terms,
+# plain terms, integral cost edges, the shooting grid's mixed edges -- each against one reference per grid point
+
+
+@pytest.mark.parametrize("name", HESS_TVREF)
+def test_oracle_hessians_with_references(oracle_mod, name):
+    g = load_golden(name)
     d = desc_for(g)
     p = oracle_mod.OracleProblem(d)
     p.set_data(np.array(g["vertex_point"])[:p.dims.nv], xref=np.array(g["xf"]))
@@ -67,6 +72,8 @@ def test_oracle_hessians_with_references(oracle_mod):
             assert np.array_equal(v, np.array(g[f"{key}_vals_{tag}"])), (tag, key)
     r, c, v, lbA, ubA = p.linear_form()
     assert np.array_equal(v, np.array(g["lin_vals"])) and np.array_equal(lbA, np.array(g["lin_lbA"]))
+    grad, obj = p.objective_gradient()
+    assert np.array_equal(grad, np.array(g["grad_obj"])) and abs(obj - g["obj_value"]) <= 4e-16 * abs(g["obj_value"])
 
 
 @pytest.mark.gpu
@@ -139,17 +146,23 @@ def test_device_references_per_instance_and_hessians(oracle_mod):
     bad[0, d.nx] = 0.1   # a control reference
     import ctypes as C
     assert s.lib.corbo_hip_set_references(s._h, bad.ctypes.data_as(C.POINTER(C.c_double))) < 0
-    g = load_golden("hess_unicycle_tvref")
-    dg = desc_for(g)
-    h = BatchedLevenbergMarquardt(dg, 2)
-    nv = h.dims.nv
-    h.set_instance_data(np.tile(np.array(g["vertex_point"])[:nv], (2, 1)), xref=np.tile(np.array(g["xf"]), (2, 1)))
-    refv = np.ascontiguousarray(np.tile(np.array(g["ref_vertex"])[:nv], (2, 1)))
-    assert h.lib.corbo_hip_set_references(h._h, refv.ctypes.data_as(C.POINTER(C.c_double))) == 0
-    vals = h.eval_hessians(True, g["mult_obj"], np.array(g["mult_eq"]), None)
-    for c, key in enumerate(("hobj", "heq")):
-        gv = np.array(g[f"{key}_vals_lower"])
-        assert np.abs(vals[c][1] - gv).max() <= 2e-4 * max(1.0, np.abs(gv).max())
+    for name in HESS_TVREF:
+        g = load_golden(name)
+        dg = desc_for(g)
+        h = BatchedLevenbergMarquardt(dg, 2)
+        nv = h.dims.nv
+        h.set_instance_data(np.tile(np.array(g["vertex_point"])[:nv], (2, 1)), xref=np.tile(np.array(g["xf"]), (2, 1)))
+        refv = np.ascontiguousarray(np.tile(np.array(g["ref_vertex"])[:nv], (2, 1)))
+        assert h.lib.corbo_hip_set_references(h._h, refv.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        vals = h.eval_hessians(True, g["mult_obj"], np.array(g["mult_eq"]), None)
+        for c, key in enumerate(("hobj", "heq")):
+            gv = np.array(g[f"{key}_vals_lower"])
+            assert vals[c].shape[1] == len(gv), (name, key)
+            assert np.abs(vals[c][1] - gv).max() <= 2e-4 * max(1.0, np.abs(gv).max()), (name, key)
+        grad, obj = h.objective_gradient()
+        gg = np.array(g["grad_obj"])
+        assert np.abs(grad[1] - gg).max() <= 1e-6 * max(1.0, np.abs(gg).max()), name
+        assert abs(obj[1] - g["obj_value"]) <= 1e-13 * max(1.0, abs(g["obj_value"])), name
 
 
 @pytest.mark.gpu
