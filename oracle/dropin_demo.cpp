@@ -26,9 +26,11 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <random>
 #include <string>
 
 #include <vector>
@@ -203,6 +205,8 @@ class RecogniseOnly : public NlpSolverInterface
 };
 
 enum class Mode { Reference, HipAuto, HipStated, HipStatedWrong, Describe, Hessian };
+static long g_fuzz_seed = -1;       // describe mode, DROPIN_FUZZ=<seed>: the generic scenarios' weights, goal and damping drawn at random (arbitrary doubles instead
+static std::vector<double> g_drawn;  // of the round numbers of the scenarios) -- what was drawn, for the test to compare the identified model with
 static int g_timing_repeats = 0;    // "timing" mode: this many extra compute(new_run = true) calls per run, timed
 static bool g_track_model = true;   // LevenbergMarquardtSparseHip::setTrackModel for those runs
 
@@ -291,6 +295,15 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         w  = 5;
         x0 = Eigen::Vector2d(1, 0);
         xf = Eigen::Vector2d(0.2, -0.1);
+        if (g_fuzz_seed >= 0 && scenario.compare(0, 3, "vdp") == 0)
+        {
+            std::mt19937_64 gen((unsigned long long)g_fuzz_seed * 7919ULL + 17ULL);
+            std::uniform_real_distribution<double> u(-2.0, 2.0), a(0.2, 3.0);
+            xf = Eigen::Vector2d(u(gen), u(gen));
+            const double damping = a(gen);
+            std::static_pointer_cast<VanDerPolOscillator>(dyn)->setDampingCoefficient(damping);
+            g_drawn = {xf[0], xf[1], damping};
+        }
     }
     else if (scenario == "rocket" || scenario == "mpendulum" || scenario == "toy" || scenario == "artstein" || scenario == "cartpole" || scenario == "par2")
     {   // the rest of the reference's benchmark classes (nonlinear_benchmark_systems.h, linear_benchmark_systems.h), non-default
@@ -491,7 +504,18 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     {
         const int nx = (int)x0.size();
         Eigen::VectorXd q = Eigen::VectorXd::LinSpaced(nx, 1.0, 0.3), rr = Eigen::VectorXd::LinSpaced(nu, 0.1, 0.2);
-        Eigen::MatrixXd Q = q.asDiagonal(), R = rr.asDiagonal(), Qf = 7.0 * Q;
+        Eigen::VectorXd qfv = 7.0 * q;
+        if (g_fuzz_seed >= 0 && scenario.compare(0, 3, "vdp") == 0)
+        {
+            std::mt19937_64 gen((unsigned long long)g_fuzz_seed * 104729ULL + 5ULL);
+            std::uniform_real_distribution<double> lw(-2.0, 1.0);   // weights over three decades
+            for (int i = 0; i < nx; ++i) { q[i] = std::pow(10.0, lw(gen)); qfv[i] = std::pow(10.0, lw(gen) + 0.5); }
+            for (int i = 0; i < nu; ++i) rr[i] = std::pow(10.0, lw(gen) - 0.5);
+            for (int i = 0; i < nx; ++i) g_drawn.push_back(q[i]);
+            for (int i = 0; i < nu; ++i) g_drawn.push_back(rr[i]);
+            for (int i = 0; i < nx; ++i) g_drawn.push_back(qfv[i]);
+        }
+        Eigen::MatrixXd Q = q.asDiagonal(), R = rr.asDiagonal(), Qf = qfv.asDiagonal();
         ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, itrap || ileft, !hpath));
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setControlBounds(Eigen::VectorXd::Constant(nu, -1.5), Eigen::VectorXd::Constant(nu, 1.5));
@@ -599,10 +623,18 @@ int main(int argc, char** argv)
         std::vector<std::string> list;
         for (int i = 2; i < argc; ++i) list.push_back(argv[i]);
         if (list.empty()) list = {"vdp", "dint", "duffing", "pendulum", "lin32", "unicycle_fullq", "unicycle_uref", "dint_ms", "dint_mtq", "dint_mtqs", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "vdp_plain", "vdp_itrap", "dint_plain", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft"};
+        if (const char* fz = std::getenv("DROPIN_FUZZ")) g_fuzz_seed = std::atol(fz);
         for (const std::string& sc : list)
         {
             RecogniseOnly rec;
+            g_drawn.clear();
             Run a = run(sc, Mode::Describe, horizon(sc), &rec);
+            if (g_fuzz_seed >= 0)
+            {   // what was drawn: xf (2), damping, q (2), r (1), qf (2) -- %.17g round-trips a double
+                printf("{\"drawn\": [");
+                for (size_t i = 0; i < g_drawn.size(); ++i) printf("%s%.17g", i ? ", " : "", g_drawn[i]);
+                printf("]}\n");
+            }
             printDesc(sc.c_str(), a.ok && rec.ok, rec.why, rec.model);
         }
         return 0;

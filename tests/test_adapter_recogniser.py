@@ -113,3 +113,27 @@ def test_what_the_device_cannot_describe_is_refused_with_a_reason(described):
     assert f["recognised"] == 0 and "system dynamics class" in f["reason"]
     u = described["unicycle_uref"]
     assert u["recognised"] == 0 and "least-squares term" in u["reason"]
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_arbitrary_weights_references_and_parameters_are_identified(seed):
+    """DROPIN_FUZZ=<seed>: the Van-der-Pol scenarios with weights over three decades, a goal and a damping coefficient drawn at random -- arbitrary
+    doubles instead of the scenarios' round numbers (which hid two weaknesses of the plain-term identification until a time-varying reference
+    met them).  Least-squares form, plain terms, integral cost edges, the shooting grid's mixed edges: the reference and the damping come out
+    bit for bit, plain weights exactly, least-squares weights as the device will take their root, integrand weights to an ulp (they arrive
+    multiplied by dt).  (2 400 further cases run clean: DESIGN.md 3.6.)"""
+    p = subprocess.run([DEMO, "describe", "vdp", "vdp_plain", "vdp_itrap", "vdp_msint"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, DROPIN_FUZZ=str(seed)))
+    assert p.returncode == 0, p.stderr
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 8
+    for drawn, r in zip(lines[0::2], lines[1::2]):
+        xf, damping, q, rr, qf = drawn["drawn"][0:2], drawn["drawn"][2], drawn["drawn"][3:5], drawn["drawn"][5:6], drawn["drawn"][6:8]
+        assert r["recognised"] == 1, r
+        assert r["xref"] == xf and r["dyn_params"][0] == damping, (r["scenario"], seed)
+        if r["cost_nonlsq"] == 0:
+            assert _sqrt_equal(r["q_diag"], q) and _sqrt_equal(r["r_diag"], rr) and _sqrt_equal(r["qf_diag"], qf), (r["scenario"], seed)
+        else:
+            rtol = 4e-16 if (r["cost_integral"] and r["grid"] == capi.GRID_FD) else 0.0   # (mixed edges: probed through the stage cost itself, no dt in between)
+            assert np.allclose(r["q_diag"], q, rtol=rtol, atol=0) and np.allclose(r["r_diag"], rr, rtol=rtol, atol=0), (r["scenario"], seed)
+            assert r["qf_diag"] == qf, (r["scenario"], seed)
