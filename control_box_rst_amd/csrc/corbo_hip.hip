@@ -176,6 +176,7 @@ struct corbo_hip_solver {
     bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")
     int stagger = 0;               // corbo_hip_set_option("stagger")
     int lag_priority = 1;          // corbo_hip_set_option("lag_priority")
+    int ff_converged = 1;          // corbo_hip_set_option("ff_converged"): 0 = compute the outer iterations that follow a converged step (A/B, tests)
     bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
     // the 8 model parameters as the kernels see them: the descriptor's, except for the linear state-space model, whose first slot
@@ -208,6 +209,7 @@ struct corbo_hip_solver {
         p.fin_row = S.fin_row;
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
         p.dt_fixed = S.desc.dt_ref;
+        p.ff_converged = ff_converged;
         p.mode = mode; p.iterations = iterations; p.w_eq = weq; p.w_ineq = wineq; p.w_b = wb;
         p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
         p.refvec = refvec_on ? d_refvec : nullptr;
@@ -1175,6 +1177,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "chain_variant") h->chain_variant = value;
     else if (n == "stagger") h->stagger = value;
     else if (n == "lag_priority") h->lag_priority = value;
+    else if (n == "ff_converged") h->ff_converged = value;
     else return fail(CORBO_HIP_ERR_INVALID, "unknown option: " + n);
     return CORBO_HIP_OK;
 }

@@ -162,7 +162,20 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         if (done) return;
         if (no_trial) {  // |delta| <= eps2 -> stop = true, the do-while ends without a trial step (:151-154,215)
             if (tid == 0) {
-                const bool fin = lm_end_outer(st, st->last_sq, st->rho, st->k, p.iterations);
+                // The reference's outer loop does not look at `stop` (:129): every remaining iteration adds mu to the diagonal of the SAME H again
+                // (:135-138 -- mu itself, the right-hand side, the iterate and the values are untouched on this branch), factorises, solves and finds
+                // |delta| <= eps2 again: for a positive definite H the norm of (H + s I)^-1 rhs only shrinks as s grows.  None of those
+                // iterations changes anything the caller sees -- iterate, chi2, values, rho, status -- so they are COUNTED here, not computed
+                // (one factorisation each), once the step is below eps2 by a factor of two (rounding cannot lift a later one above eps2 then).
+                // A warm-started moving-horizon solve spends most of its iterations on this branch.
+                int k = st->k;
+                if (p.ff_converged && st->dnorm <= 0.5 * LM_EPS2 && k + 1 < p.iterations) {
+                    const int rest = p.iterations - 1 - k;
+                    st->n_fact += rest;
+                    st->mu_acc += rest * st->mu;
+                    k += rest;
+                }
+                const bool fin = lm_end_outer(st, st->last_sq, st->rho, k, p.iterations);
                 if (p.chi2) p.chi2[inst] = st->chi2_old;
                 if (!fin && active_count) atomicAdd(active_count, 1);
             }

@@ -50,6 +50,7 @@ struct SweepParams {
     // per-call
     int32_t mode;       // 0 = residual only, 1 = residual + Jacobian, 2 = LM init, 3 = LM trial step
     int32_t iterations; // LM: outer iteration count
+    int32_t ff_converged;   // 1 (default): count the outer iterations that follow a step of norm <= eps2 / 2 instead of computing them (sweep_body, mode 3)
     double w_eq, w_ineq, w_b;
     double* x;          // [batch][nvs] accepted iterate
     const double* xt;   // [batch][nvs] trial iterate (mode 3)

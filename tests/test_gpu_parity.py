@@ -537,3 +537,35 @@ def test_device_sincos():
     x[:, 2] = np.nan
     assert lib.corbo_hip_eval_dynamics(C.byref(d), n, dp(x), dp(u), dp(f)) == 0
     assert np.isnan(f[:, 0]).all() and np.isnan(f[:, 1]).all()
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_counted_converged_iterations_change_nothing(cfg):
+    """Once a step has |delta| <= eps2 / 2 the remaining outer iterations of the reference's loop (which never looks at `stop`,
+    levenberg_marquardt_sparse.cpp:129) re-factorise the same H with more damping and find a smaller step still: the device counts them instead
+    of computing them (sweep_body, option ff_converged).  Iterate, chi2, status and every counter are bit-identical with the option off --
+    on cold starts and on a warm-started sequence of solves (where most iterations are of that kind)."""
+    import bench
+    B = {1: 4, 2: 3, 3: 16}[cfg]
+    w = bench.workload(cfg, B)
+    out = []
+    for ff in (1, 0):
+        s = BatchedLevenbergMarquardt(w["desc"], B)
+        s.set_option("ff_converged", ff)
+        s.setIterations(10)
+        s.setPenaltyWeights(*w["weights"])
+        s.set_instance_data(s.init_trajectory(w["x0"], w["xf"]), xref=w["xf"])
+        seq = []
+        for run in range(4):   # the later solves start from the previous solution: converged after a step or two
+            s.solve(new_run=(run == 0))
+            X, chi2, status = s.get_solution()
+            st = s.get_stats()
+            seq.append((X.copy(), chi2.copy(), status.copy(), {k: st[k] for k in ("lm_iterations", "accepted_steps", "rejected_steps", "jacobian_sweeps", "residual_sweeps", "factorizations", "passes")}))
+        out.append(seq)
+    for a, b in zip(*out):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3] == b[3], (a[3], b[3])
+    # (and something was actually counted: the last solve of the sequence needs fewer accepted steps than iterations)
+    # (cfg 2, time-optimal with a free dt far from its optimum, still accepts a step in every iteration of its fourth solve: nothing to count there)
+    if cfg != 2:
+        assert out[0][-1][3]["accepted_steps"] < 10 * B
