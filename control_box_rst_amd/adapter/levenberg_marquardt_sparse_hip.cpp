@@ -333,7 +333,8 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
             _handle = nullptr;
             return false;
         }
-        corbo_hip_set_result_sink(_handle, 1);   // one OCP per solve() whose result goes back into the vertices: let the solve kernel deliver it
+        corbo_hip_set_result_sink(_handle, 1);
+        corbo_hip_set_option(_handle, "solve_timing", 0);   // no HIP timing events around the one launch of a solve: 10 - 13 us of a batch-1 solve   // one OCP per solve() whose result goes back into the vertices: let the solve kernel deliver it
         _x.assign(_dims.nv, 0.0);
         _lb.assign(_dims.nv, 0.0);
         _ub.assign(_dims.nv, 0.0);

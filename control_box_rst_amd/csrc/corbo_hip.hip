@@ -176,6 +176,8 @@ struct corbo_hip_solver {
     bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")
     int stagger = 0;               // corbo_hip_set_option("stagger")
     int lag_priority = 1;          // corbo_hip_set_option("lag_priority")
+    int solve_timing = 1;          // corbo_hip_set_option("solve_timing"): 0 = no HIP events around the launches of a solve (stats.solve_ms stays 0): two
+                                   // event records and an event wait cost a batch-1 solve 10 - 13 us, a plain stream synchronisation the rest
     int ff_converged = 1;          // corbo_hip_set_option("ff_converged"): 0 = compute the outer iterations that follow a converged step (A/B, tests)
     bool loop_mode = true;      // run-to-completion pass kernel: one launch per solve (CORBO_HIP_LOOP=0: one launch per LM pass)
 
@@ -606,7 +608,7 @@ try {
     };
     const bool split = h->split_passes || h->force_split;
     const bool run_to_completion = !split && h->loop_mode && o->iterations > 0;
-    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    if (h->solve_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (!run_to_completion)   // per-pass "unfinished instances" counters (the run-to-completion kernel reports through pinned host memory)
         HIP_TRY(hipMemsetAsync(h->d_counters, 0, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t), h->stream));
     stamp();
@@ -751,9 +753,12 @@ try {
             HIP_TRY(hipEventRecord(h->sub_done[i], st_of[i]));
             HIP_TRY(hipStreamWaitEvent(h->stream, h->sub_done[i], 0));
         }
-    HIP_TRY(hipEventRecord(h->ev1, h->stream));
-    HIP_TRY(hipEventSynchronize(h->ev1));
-    HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));
+    if (h->solve_timing) {
+        HIP_TRY(hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(hipEventSynchronize(h->ev1));
+        HIP_TRY(hipEventElapsedTime(&h->stats.solve_ms, h->ev0, h->ev1));
+    }
+    else HIP_TRY(hipStreamSynchronize(h->stream));
     h->solve_ms_sum += h->stats.solve_ms;
     h->solve_count += 1;
     if (run_to_completion) {
@@ -1178,6 +1183,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "stagger") h->stagger = value;
     else if (n == "lag_priority") h->lag_priority = value;
     else if (n == "ff_converged") h->ff_converged = value;
+    else if (n == "solve_timing") h->solve_timing = value;
     else return fail(CORBO_HIP_ERR_INVALID, "unknown option: " + n);
     return CORBO_HIP_OK;
 }

@@ -495,7 +495,11 @@ int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const dou
  *   "pass_limit"        value > 0: the run-to-completion kernel gives up after `value` LM passes per instance instead of 4096
  *   "run_to_completion" 0: one launch per LM pass (the host counts unfinished instances) instead of one launch per solve
  *   "pass_timeline"     value >= 0: corbo_hip_solve prints the per-pass shader-clock stamps of instance `value` on stderr; -1: off
- *   "sweep_timeline"    1: corbo_hip_time_sweep prints the phase stamps of instance 0 on stderr */
+ *   "sweep_timeline"    1: corbo_hip_time_sweep prints the phase stamps of instance 0 on stderr
+ *   "solve_timing"      0: corbo_hip_solve records no HIP timing events around its launches (corbo_hip_stats::solve_ms and corbo_hip_get_timing stay 0):
+ *                       7 - 13 us less per call, what a caller that solves ONE problem per call wants (the drop-in adapter sets it)
+ *   "ff_converged"      0: compute the outer iterations that follow a converged step instead of counting them (A/B and tests)
+ *   "lag_priority"      0: no lag-based issue priority in the run-to-completion kernel */
 int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value);
 
 /* Text of the last error on this thread. */
