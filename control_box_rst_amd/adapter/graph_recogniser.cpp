@@ -475,13 +475,15 @@ bool identifyBall(BaseEdge& e, VertexInterface* v, double* prm /*cx, cy, cz, r*/
 // The same term checked against a KNOWN model (the resident device model of the previous run): n + 1 evaluations instead of ~ 7 n.  The edge must
 // reproduce  w_i (x_i - ref_i)  bit for bit at the current point and at x_i + 1 for every component (two points fix an affine row), off-diagonal
 // responses must vanish, rows with a zero weight must be identically zero.  false: identify from scratch.
-bool verifyDiagonalAffine(BaseEdge& e, VertexInterface* v, const Eigen::VectorXd& wh, const Eigen::VectorXd& rh, Eigen::VectorXd* w, Eigen::VectorXd* ref)
+bool verifyDiagonalAffine(BaseEdge& e, VertexInterface* v, const double* wh, const double* rh, Eigen::VectorXd* w, Eigen::VectorXd* ref)
 {
     const int n = v->getDimension();
-    if (e.getDimension() != n || wh.size() != n || rh.size() != n) return false;
+    if (e.getDimension() != n || n > CORBO_HIP_MAX_NX) return false;
     VertexGuard guard(v);
     double* x = v->getDataRaw();
-    const Eigen::VectorXd r0 = evalEdge(e);
+    double b0[CORBO_HIP_MAX_NX], b1[CORBO_HIP_MAX_NX];   // (no heap on this path: it runs once per cost edge and control step)
+    Eigen::Map<Eigen::VectorXd> r0(b0, n), r1(b1, n);
+    e.computeValues(r0);
     for (int i = 0; i < n; ++i)
         if (r0[i] != ((wh[i] == 0.0) ? 0.0 : wh[i] * (x[i] - rh[i]))) return false;
     for (int i = 0; i < n; ++i)
@@ -489,17 +491,16 @@ bool verifyDiagonalAffine(BaseEdge& e, VertexInterface* v, const Eigen::VectorXd
         const double x0 = x[i];
         volatile double xp = x0 + 1.0;
         x[i] = xp;
-        const Eigen::VectorXd r1 = evalEdge(e);
+        e.computeValues(r1);
         x[i] = x0;
         for (int j = 0; j < n; ++j)
             if (j != i && r1[j] != r0[j]) return false;
         if (r1[i] != ((wh[i] == 0.0) ? 0.0 : wh[i] * ((double)xp - rh[i]))) return false;
         if (wh[i] != 0.0 && r1[i] == r0[i]) return false;
     }
-    *w = wh;
-    *ref = rh;
-    for (int i = 0; i < n; ++i)
-        if (wh[i] == 0.0) (*ref)[i] = 0.0;   // (what the identification reports for a row without a weight)
+    w->resize(n);
+    ref->resize(n);
+    for (int i = 0; i < n; ++i) { (*w)[i] = wh[i]; (*ref)[i] = (wh[i] == 0.0) ? 0.0 : rh[i]; }   // (a row without a weight reports reference 0, like the identification)
     return true;
 }
 
@@ -830,12 +831,12 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     int n_state = 0, n_ctrl = 0, n_final = 0, n_dt = 0;
     int k_first_state = g.N, k_first_ctrl = g.N;   // first interval that carries a state / control term (MinTimeQuadratic::only_last_n)
     double dt_weight = 0.0;
+    Eigen::VectorXd w, ref;   // (outside the loop: no allocation per edge once they have their size)
     for (const BaseEdge::Ptr& ep : es->getLsqObjectiveEdges())
     {
         BaseEdge* e = ep.get();
         if (e->getNumVertices() != 1) return fail(reason, "least-squares edge on more than one vertex (control deviation / integral term)");
         VertexInterface* v = e->getVertexRaw(0);
-        Eigen::VectorXd w, ref;
         if (v == g.dt)
         {   // MinimumTime(lsq): weight * dt, created twice (nlp_functions.cpp:91-107)
             if (e->getDimension() != 1) return fail(reason, "dt cost term of dimension > 1");
@@ -852,27 +853,25 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         if (hint && !hint->desc.weights_dense && !hint->desc.cost_nonlsq && hint->desc.nx == g.nx && hint->desc.nu == g.nu)
         {
             const bool traj = hint->xref_traj.rows() == g.N && hint->xref_traj.cols() == g.nx;
-            Eigen::VectorXd wh, rh;
+            double wh[CORBO_HIP_MAX_NX], rh[CORBO_HIP_MAX_NX];
+            int nh = 0;
             const int ks = indexOf(g.xs, v);
             if (v == g.xf && hint->desc.final_cost && hint->xref.size() == g.nx)
             {
-                wh.resize(g.nx);
-                for (int i = 0; i < g.nx; ++i) wh[i] = std::sqrt(hint->desc.qf_diag[i]);
-                rh = traj ? Eigen::VectorXd(hint->xref_traj.row(g.N - 1).transpose()) : hint->xref;
+                nh = g.nx;
+                for (int i = 0; i < g.nx; ++i) { wh[i] = std::sqrt(hint->desc.qf_diag[i]); rh[i] = traj ? hint->xref_traj(g.N - 1, i) : hint->xref[i]; }
             }
             else if (ks >= 0 && (CORBO_HIP_COST_TERMS(hint->desc.stage_cost) & 1) && hint->xref.size() == g.nx)
             {
-                wh.resize(g.nx);
-                for (int i = 0; i < g.nx; ++i) wh[i] = std::sqrt(hint->desc.q_diag[i]);
-                rh = traj ? Eigen::VectorXd(hint->xref_traj.row(ks).transpose()) : hint->xref;
+                nh = g.nx;
+                for (int i = 0; i < g.nx; ++i) { wh[i] = std::sqrt(hint->desc.q_diag[i]); rh[i] = traj ? hint->xref_traj(ks, i) : hint->xref[i]; }
             }
             else if (indexOf(g.us, v) >= 0 && (CORBO_HIP_COST_TERMS(hint->desc.stage_cost) & 2))
             {
-                wh.resize(g.nu);
-                for (int i = 0; i < g.nu; ++i) wh[i] = std::sqrt(hint->desc.r_diag[i]);
-                rh = Eigen::VectorXd::Zero(g.nu);
+                nh = g.nu;
+                for (int i = 0; i < g.nu; ++i) { wh[i] = std::sqrt(hint->desc.r_diag[i]); rh[i] = 0.0; }
             }
-            hinted = wh.size() > 0 && verifyDiagonalAffine(*e, v, wh, rh, &w, &ref);
+            hinted = nh > 0 && nh == v->getDimension() && verifyDiagonalAffine(*e, v, wh, rh, &w, &ref);
         }
         if (!hinted && !identifyDiagonalAffine(*e, v, &w, &ref))
         {
