@@ -347,3 +347,38 @@ def test_random_closed_loop_call_vs_stepwise_and_oracle_plant(oracle_mod, seed):
     Xa, ca, sa = a.get_solution()
     Xb, cb, sb = b.get_solution()
     assert np.array_equal(Xa, Xb) and np.array_equal(ca, cb) and np.array_equal(sa, sb), (seed, fam)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_counted_converged_iterations_random_descriptors(seed):
+    """Option ff_converged (the outer iterations that follow a step with |delta| <= eps2 / 2 are counted, not computed -- DESIGN.md 3.3) on the random
+    descriptors: ten iterations, then two warm-started solves; iterate, chi2, status and every counter bit-identical with the option off."""
+    rng = np.random.default_rng(77000 + seed)
+    fam, d = random_desc(rng)
+    B = 3
+    w = tuple(float(v) for v in rng.uniform(1.0, 50.0, 3))
+    x0 = rng.uniform(-1, 1, (B, d.nx))
+    xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2, 0.0])[: d.nx] if fam not in ("dint", "int3t") else np.array([1.0, 0.0, 0.0])[: d.nx])
+    if fam == "rocket":
+        x0[:, 2] = rng.uniform(0.9, 1.1, B)
+        xf[:, 2] = rng.uniform(0.8, 1.0, B)
+    res = []
+    for ff in (1, 0):
+        s = BatchedLevenbergMarquardt(d, B)
+        s.set_option("ff_converged", ff)
+        s.setIterations(10)
+        s.setPenaltyWeights(*w)
+        X0 = s.init_trajectory(x0, xf)
+        if d.grid in (capi.GRID_FD_VARIABLE, capi.GRID_MS_VARIABLE):
+            X0[:, -1] = d.dt_ref
+        s.set_instance_data(X0, xref=xf)
+        seq = []
+        for run in range(3):
+            s.solve(new_run=True)
+            X, chi2, status = s.get_solution()
+            st = s.get_stats()
+            seq.append((X.copy(), chi2.copy(), status.copy(), tuple(st[k] for k in ("lm_iterations", "accepted_steps", "rejected_steps", "jacobian_sweeps", "residual_sweeps", "factorizations", "passes"))))
+        res.append(seq)
+    for a, b in zip(*res):
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2]), (seed, fam)
+        assert a[3] == b[3], (seed, fam, a[3], b[3])
