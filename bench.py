@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E (MI355X_MICROARCH.md)
 PEAK_F64_MFMA_TFLOPS = 78.6  # gfx950 dense fp64 matrix peak
+PROFILE_ROUND = "r04"         # prefix of the committed rocprofv3 summaries under profiles/ the line cross-checks itself against
 
 
 def workload(cfg: int, batch: int, first: int = 0):
@@ -195,6 +196,17 @@ def load_profile_json(name, batch, N):
     return None
 
 
+def counted_per_step(solver, solves):
+    """Outer iterations of ONE step (re-arm + `solves` solves) that the device counted instead of executing (corbo_hip_stats.counted_iterations,
+    option ff_converged): an untimed extra step with the statistics read after every solve."""
+    solver.restore_instance_data()
+    tot = 0
+    for i in range(solves):
+        solver.solve(new_run=(i == 0))
+        tot += int(solver.get_stats()["counted_iterations"])
+    return tot
+
+
 def secondary_leg(cfg, iterations, device):
     """One BASELINE configuration other than the headline, measured in the same process (rank 0 of a 1-GPU run): ms per step,
     SQP-iterations/s, the chi2 sum of the timed workload next to the genuine reference's (tests/golden/bench_secondary.json,
@@ -231,8 +243,11 @@ def secondary_leg(cfg, iterations, device):
     stats = solver.get_stats()
     _, chi2, status = solver.get_solution()
     iters_per_step = B * iterations * solves
+    counted = counted_per_step(solver, solves)
     out = {"workload": f"{w['name']}, batch={B}, {solves} solve(s) x {iterations} LM iterations per step", "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * dt / steps, "value": iters_per_step * steps / dt, "unit": "SQP-iterations/s",
+           "counted_iterations": counted, "value_computed": (iters_per_step - counted) * steps / dt,
+           "counted_note": "outer iterations after a converged step (|delta| <= eps2/2) are counted, not executed (corbo_hip_stats.counted_iterations); value_computed = executed iterations / s",
            "chi2_sum": float(chi2.sum()), "ok_instances": int((status <= 1).sum()), "ms_per_solve_launch": solve_ms_sum / max(1, n_solves)}
     gpath = os.path.join(ROOT, "tests", "golden", "bench_secondary.json")
     if os.path.exists(gpath) and iterations == 10:
@@ -367,6 +382,8 @@ def main():
     red = sharding.reduce_stats(stats, float(chi2.sum()), int((status <= 1).sum()), dist, device=red_dev)  # SUM over ranks
     total_iters_per_step = red["lm_iterations"] * solves  # = world * batch * iterations * solves
     value = total_iters_per_step * steps / t_max
+    counted_step = sharding.reduce_stats({k: (counted_per_step(solver, solves) if k == "counted_iterations" else 0) for k in sharding.STAT_KEYS},
+                                         0.0, 0, dist, device=red_dev)["counted_iterations"]   # per step, all ranks (untimed extra step)
 
     line = {
         "metric": "SQP-iterations/sec over batch=1024 OCPs (nx=3,nu=2,N=100,fp64)",
@@ -388,11 +405,14 @@ def main():
                         + ("written by the solve kernel as each instance finishes, corbo_hip_set_result_sink" if use_sink else "two D2H copies behind the solve")
                         + ", views from corbo_hip_fetch_solution); wall clock, barrier + synchronize on both sides, MAX over ranks",
         "preheat": {"ms": args.preheat_ms, "untimed_steps": preheat_steps, "what": "untimed steps before the warm-up steps: steady-state clocks and warm pages (a cold process measures 0.74 - 0.77 ms per step over its first 25 steps, 0.68 ms afterwards)"},
+        "counted_iterations": int(counted_step),
+        "value_computed": (total_iters_per_step - counted_step) * steps / t_max,
+        "counted_note": "outer iterations after a converged step (|delta| <= eps2/2) are counted, not executed (corbo_hip_stats.counted_iterations); value_computed = executed iterations / s",
         "batch_steps_per_s": value / (B * world),
         "ms_per_step_ranks": [1e3 * t / steps for t in t_ranks],
         "solve_stats": {"passes_rank0": stats["passes"], "lm_iterations": int(red["lm_iterations"]),
                         "accepted": int(red["accepted_steps"]), "rejected": int(red["rejected_steps"]),
-                        "factorizations": int(red["factorizations"]), "chi2_sum": red["chi2_sum"],
+                        "factorizations": int(red["factorizations"]), "counted_iterations": int(red["counted_iterations"]), "chi2_sum": red["chi2_sum"],
                         "ok_instances": int(red["ok_instances"])},
     }
     # ---- outside the timed region: the trajectories of ALL ranks collected straight from device memory (one RCCL all-gather on the
@@ -434,8 +454,8 @@ def main():
         # run-to-completion families: ONE launch per solve (lm_pass_kernel); its bytes = what the reference's algorithm moves for the
         # same sweeps: sweeps_j x (read vertices + bounds, write residual + Jacobian) + trial sweeps x (read vertices + bounds, write residual)
         achieved = alg_solve / (launch_ms * 1e-3) / 1e9
-        pmc = load_profile_json("r03_solve_pmc.json", B, desc.N)
-        prof = profile_kernel_avg_ns("r03_bench_kernel_stats.csv", "lm_pass_kernel")
+        pmc = load_profile_json(PROFILE_ROUND + "_solve_pmc.json", B, desc.N)
+        prof = profile_kernel_avg_ns(PROFILE_ROUND + "_bench_kernel_stats.csv", "lm_pass_kernel")
         line["roofline"] = {"bound": "hbm", "kernel": "lm_pass_kernel (run-to-completion: prologue sweep + every LM pass of every instance, one launch per solve)",
                             "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                             "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
@@ -449,7 +469,7 @@ def main():
     each = solver.time_sweep_each(with_jacobian=True, repeat=50)        # one event pair per launch (what a kernel trace reports)
     b2b_ms = solver.time_sweep(with_jacobian=True, repeat=50)            # back-to-back launches, one event pair around all of them
     sweep_ms = float(np.mean(each))
-    prof = profile_kernel_avg_ns("r03_sweep_kernel_stats.csv", "sweep_kernel")
+    prof = profile_kernel_avg_ns(PROFILE_ROUND + "_sweep_kernel_stats.csv", "sweep_kernel")
     spmc = load_profile_json("sweep_pmc_latest.json", B, desc.N)
     rs = {"bound": "hbm", "kernel": "sweep_kernel (residual + Jacobian of every instance, stand-alone launch)",
           "achieved": B * b_sweep / (sweep_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -473,8 +493,8 @@ def main():
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
         alg_pair = per_stage * desc.N * B
-        pc = profile_kernel_max_ns("r03_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
-        qpmc = load_profile_json("r03_cfg5_pmc.json", B, desc.N)
+        pc = profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
+        qpmc = load_profile_json(PROFILE_ROUND + "_cfg5_pmc.json", B, desc.N)
         line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance: FD Jacobian + assemble, then the block chain)",
                             "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                             "traffic": qpmc["hbm_bytes_per_launch"] if qpmc else None, "traffic_source": qpmc["source"] if qpmc else None,
@@ -493,8 +513,8 @@ def main():
         # block factorisation on the fp64 matrix cores: SURVEY 8d algorithmic flops per instance per factorisation
         s_blk, nb = desc.nx + desc.nu, desc.N - 1
         flops_fact = (7.0 / 3.0) * s_blk ** 3 * nb + 8.0 * s_blk ** 2 * nb + 2.0 * desc.nx * (2 * desc.nx + desc.nu) ** 2 * nb
-        n_fact = stats["factorizations"]
-        mf = load_profile_json("r03_cfg5_mfma.json", B, desc.N)
+        n_fact = stats["factorizations"] - stats["counted_iterations"]   # executed factorisations only
+        mf = load_profile_json(PROFILE_ROUND + "_cfg5_mfma.json", B, desc.N)
         line["factorization"] = {"bound": "mfma", "algorithmic_flops_per_instance": flops_fact, "factorizations_per_solve": int(n_fact),
                                  "factor_ms_per_solve": prof_stats["factor_ms"],
                                  "achieved_TFLOPs": (n_fact * flops_fact / (prof_stats["factor_ms"] * 1e-3) / 1e12) if prof_stats["factor_ms"] > 0 else None,

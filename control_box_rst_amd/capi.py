@@ -67,6 +67,7 @@ class Stats(C.Structure):
         ("lm_iterations", C.c_int64), ("accepted_steps", C.c_int64), ("rejected_steps", C.c_int64),
         ("jacobian_sweeps", C.c_int64), ("residual_sweeps", C.c_int64), ("factorizations", C.c_int64),
         ("passes", C.c_int32), ("solve_ms", C.c_float), ("sweep_ms", C.c_float), ("factor_ms", C.c_float), ("inner_loop_cuts", C.c_int32),
+        ("counted_iterations", C.c_int64),
     ]
 
     def as_dict(self):

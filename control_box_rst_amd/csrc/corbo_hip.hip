@@ -82,6 +82,7 @@ struct EventList {
 
 }  // namespace
 
+static constexpr int PTL_LEN = 150 + 18 * 64;   // pass timeline buffer (diagnostics): stamps + per-pass phase log
 struct corbo_hip_solver {
     Structure S;
     int batch  = 0;    // capacity: instances the device buffers hold
@@ -175,6 +176,7 @@ struct corbo_hip_solver {
     int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
     bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")
     int stagger = 0;               // corbo_hip_set_option("stagger")
+    int pass_threads = 0;          // corbo_hip_set_option("pass_threads"): 0 = the default workgroup size of the run-to-completion kernel
     int lag_priority = 1;          // corbo_hip_set_option("lag_priority")
     int solve_timing = 1;          // corbo_hip_set_option("solve_timing"): 0 = no HIP events around the launches of a solve (stats.solve_ms stays 0): two
                                    // event records and an event wait cost a batch-1 solve 10 - 13 us, a plain stream synchronisation the rest
@@ -348,7 +350,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     // the factor phase and every scatter of the sweep phase (SQ_LDS_BANK_CONFLICT: 31 % of the solve kernel's LDS cycles) -- an odd stride
     // spreads them over all banks.  Only the offset tables change; corbo_hip_eval maps the values back to the public order.
     {
-        const bool pad_layout = (S.nx <= 6);
+        const bool pad_layout = jacobian_staged_in_lds(S.nx, S.N);   // the same predicate as STAGE in sweep_body: only the LDS staging area has bank conflicts to avoid
         const int nnz = S.dims.nnz;
         h->jmap.resize(nnz);
         for (int i = 0; i < nnz; ++i) {
@@ -645,6 +647,7 @@ try {
         SweepParams sp  = h->sweep_params(mode, o->iterations, h->w_eq, h->w_ineq, h->w_b, counter);
         fp.batch = sp.batch = count_of[i];
         fp.inst0 = sp.inst0 = first_of[i];
+        fp.pass_threads = h->pass_threads;
         if (split) {
             if (mode == 3) {
                 fp.first_pass = (pass_of[i] == 0) ? 1 : 0;
@@ -671,6 +674,7 @@ try {
             fp.inst0 = sp.inst0 = first_of[i];
             fp.loop_passes = MAX_PASSES;
             fp.stagger = h->stagger;
+            fp.pass_threads = h->pass_threads;
             if (h->lag_priority && !(count_of[i] > 4 * h->num_cus)) fp.cu_table = h->d_queue + 16;
             if (h->result_sink) { fp.x_host = h->h_stage; fp.st_host = h->h_state; }
             if (count_of[i] > 4 * h->num_cus) {   // more instances than resident workgroups: instance queue
@@ -685,14 +689,27 @@ try {
             long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
             const bool ptl_on = h->pass_timeline_inst >= 0;
             if (ptl_on && i == 0) {
-                HIP_TRY(hipMalloc((void**)&d_ptl, 146 * sizeof(long long)));
-                HIP_TRY(hipMemsetAsync(d_ptl, 0, 146 * sizeof(long long), st_of[i]));
+                HIP_TRY(hipMalloc((void**)&d_ptl, PTL_LEN * sizeof(long long)));
+                HIP_TRY(hipMemsetAsync(d_ptl, 0, PTL_LEN * sizeof(long long), st_of[i]));
                 fp.pass_timeline      = d_ptl;
-                if (h->pass_timeline_inst == 0) fp.timeline = d_ptl + 130;  // factor phases of instance 0 (last pass)
+                fp.timeline = d_ptl + 130;  // factor phases of that instance [130,138), sweep phases [138,148); copied into the per-pass log [150 + 18 pass, ...)
+                sp.timeline = d_ptl + 138;
+                fp.timeline_inst = sp.timeline_inst = h->pass_timeline_inst;
                 fp.pass_timeline_inst = h->pass_timeline_inst;
             }
-            struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); long long tl[146];
+            struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); static long long tl[PTL_LEN];
                 if (hipMemcpy(tl, p, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess) {
+                    // per-pass phase log: factor stamps F0..F7 (start, loaded, first-mu, controls, blocks, cyclic reduction, root/arrow, back-substitution, trial iterate)
+                    // and sweep stamps S0..S9 of the sweep phase that STARTED the pass
+                    for (int k = 0; k < 64 && tl[2 * k]; ++k) {
+                        const long long* f = tl + 150 + 18 * k; const long long* w = f + 8;
+                        if (!f[0] && !w[0]) continue;
+                        fprintf(stderr, "pass %2d sweep:", k);
+                        if (w[0]) { const int ids[] = {1, 2, 9, 3, 4, 5, 6, 7, 8}; long long prev = w[0]; for (int q : ids) { if (w[q]) { fprintf(stderr, " s%d+%lld", q, w[q] - prev); prev = w[q]; } } }
+                        fprintf(stderr, " | factor:");
+                        if (f[0]) { long long prev = f[0]; for (int q = 1; q < 8; ++q) if (f[q]) { fprintf(stderr, " f%d+%lld", q, f[q] - prev); prev = f[q]; } fprintf(stderr, " | sweep-end->factor-start %lld, pass-start->sweep-start %lld", f[0] - tl[2 * k + 1], w[0] ? w[0] - tl[2 * k] : -1); }
+                        fprintf(stderr, "\n");
+                    }
                     fprintf(stderr, "pass timeline (sweep/factor cycles):");
                     for (int k = 0; k < 64 && tl[2 * k]; ++k) fprintf(stderr, " %lld/%lld", tl[2 * k + 1] ? tl[2 * k + 1] - tl[2 * k] : -1, (k < 63 && tl[2 * k + 2]) ? tl[2 * k + 2] - tl[2 * k + 1] : 0);
                     fprintf(stderr, "\n");
@@ -1144,6 +1161,9 @@ int corbo_hip_resample_into(corbo_hip_handle src, corbo_hip_handle dst, int coun
 try {
     if (!src || !dst || count < 0 || (count > 0 && (!src_index || !dst_index))) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (count == 0) return CORBO_HIP_OK;
+    // every destination slot is written at most once: more pairs than slots means duplicates, and the two index lists are staged in a
+    // buffer of dst->batch rows
+    if (count > dst->batch) return fail(CORBO_HIP_ERR_INVALID, "more index pairs than destination slots");
     const Structure &A = src->S, &B = dst->S;
     if (!A.dt_free || !B.dt_free) return fail(CORBO_HIP_ERR_INVALID, "resampling needs free-dt grids on both sides");
     if (A.nx != B.nx || A.nu != B.nu || src->device != dst->device) return fail(CORBO_HIP_ERR_INVALID, "handles do not belong to the same problem family / device");
@@ -1181,6 +1201,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
     else if (n == "chain_variant") h->chain_variant = value;
     else if (n == "stagger") h->stagger = value;
+    else if (n == "pass_threads") h->pass_threads = value;
     else if (n == "lag_priority") h->lag_priority = value;
     else if (n == "ff_converged") h->ff_converged = value;
     else if (n == "solve_timing") h->solve_timing = value;
@@ -1278,6 +1299,7 @@ try {
     corbo_hip_stats s = h->stats;
     s.lm_iterations = s.accepted_steps = s.rejected_steps = s.jacobian_sweeps = s.residual_sweeps = s.factorizations = 0;
     s.inner_loop_cuts = 0;
+    s.counted_iterations = 0;
     int max_fact = 0;
     for (int b = 0; b < h->active; ++b) {
         const LmState& a = h->h_state[b];
@@ -1289,6 +1311,7 @@ try {
         s.residual_sweeps += a.n_res;
         s.factorizations += a.n_fact;
         s.inner_loop_cuts += a.pad[0];
+        s.counted_iterations += a.pad[1];
     }
     s.passes = max_fact;  // inner passes of the slowest instance
     *stats = s;

@@ -39,17 +39,35 @@ __device__ __forceinline__ void lds_barrier()
 #endif
 }
 
-__device__ __forceinline__ double wave_sum(double v)
+// Wave-wide reductions without the LDS crossbar: __shfl_xor on a double is two ds_bpermute_b32 per step, six dependent LDS round trips per
+// reduction (>= 800 cycles on an idle CU, and the LDS pipeline is the resource the four workgroups of a CU share) -- three of them sat on the
+// critical path of every LM pass.  Four DPP steps give every lane the sum of its row of 16, four v_readlane pairs combine the rows.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane)   // (uniform: lives in scalar registers)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v)   // all 64 lanes active; every lane gets the total
+{
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror (the other quad pair of the 8: holds that pair's sum in every lane)
+    v += dpp_move<0x140>(v);   // row_mirror (the other half of the row)
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x140>(v));
+    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // end of one outer LM iteration: levenberg_marquardt_sparse.cpp:216-218
@@ -102,7 +120,7 @@ __device__ __forceinline__ void lm_state_out(LmState* sg, const LmState* sl, int
 
 #define SWEEP_STAMP(id)                                                     \
     do {                                                                    \
-        if (p.timeline && inst == 0 && tid == 0) p.timeline[id] = clock64(); \
+        if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); \
     } while (0)
 
 // Row c of  U (x - ref)  for a vertex with a NON-DIAGONAL weight (quadratic_cost.cpp:116-118, 148-150, final_state_cost.cpp:88-90:
@@ -136,7 +154,7 @@ __device__ __forceinline__ double dense_weight_row(const double* U, int c, int d
 // LONG: horizons beyond 256 grid points (up to 1024; FiniteDifferencesVariableGrid's default n_max is 1000,
 // finite_differences_variable_grid.h:82): the Jacobian of such an instance does not fit the LDS staging area, its entries go straight
 // to HBM like the big-block family's (STAGE = false).  Stand-alone kernels only.
-template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false>
+template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false)
 {
     using Dy          = Dynamics<DYN>;
@@ -146,7 +164,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     constexpr int W   = S + NX;  // local vertex values of a defect edge: x1 u1 x2
     constexpr int NC  = Dy::NC;
     constexpr bool CACHED = DefectTraits<DEFECT>::cached;
-    constexpr bool STAGE  = (NX <= 4) && !LONG;  // small models: Jacobian assembled in LDS and streamed out; big ones / long horizons: stored column by column
+    constexpr bool STAGE  = (NX <= 4) && !LONG;  // (= jacobian_staged_in_lds(nx, N): LONG is N > 256) small models: Jacobian assembled in LDS and streamed out; big ones / long horizons: stored column by column
     double* js  = p.jac + (size_t)inst * p.nnz_pad;  // Jacobian values of this instance (HBM)
     if constexpr (!STAGE) jst = js;
     int* flags  = reinterpret_cast<int*>(red + 8);   // [4]
@@ -169,9 +187,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 // (one factorisation each), once the step is below eps2 by a factor of two (rounding cannot lift a later one above eps2 then).
                 // A warm-started moving-horizon solve spends most of its iterations on this branch.
                 int k = st->k;
-                if (p.ff_converged && st->dnorm <= 0.5 * LM_EPS2 && k + 1 < p.iterations) {
+                // (mu > 0: the argument needs H + s I positive definite with s growing; an all-zero Jacobian gives mu = 0 and is computed)
+                if (p.ff_converged && st->mu > 0 && st->dnorm <= 0.5 * LM_EPS2 && k + 1 < p.iterations) {
                     const int rest = p.iterations - 1 - k;
                     st->n_fact += rest;
+                    st->pad[1] += rest;   // corbo_hip_stats.counted_iterations: these iterations / factorisations were not executed
                     st->mu_acc += rest * st->mu;
                     k += rest;
                 }
@@ -190,7 +210,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     // ---- stage vertex values in LDS (coalesced 16-byte loads), unless the factor phase of the same launch left its trial iterate
     //      there (run-to-completion kernel)
     if (!xs_ready)
-        for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+        for (int i = tid; i < p.nvs / 2; i += THREADS)
             reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
     double xr[NX];
 #pragma unroll
@@ -339,56 +359,176 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
         if (jac_with_values) comp_jac(v, ci, xv, l, u, c, dim, w, ref, fin);
     };
-    // Work split of the residual (horizons up to 128 stages, i.e. when half of the workgroup holds one lane per stage): waves 0-1
-    // are the stage lanes (dynamics caches, one round of components, then the defects), waves 2-3 take the other rounds of
-    // components (cost / bound rows) meanwhile -- the halves run side by side on different SIMDs.  Longer horizons: every lane does
-    // both kinds of work, in sequence.
-    const bool split   = (p.N <= SWEEP_THREADS / 2);
-    const int cstr     = split ? SWEEP_THREADS / 2 : SWEEP_THREADS;   // component stride of the lanes that do several rounds
-    const bool cworker = !split || (tid >= SWEEP_THREADS / 2);
-    // descriptors and bounds of the first two rounds of components: requested now, consumed below (straight-line code: the waits
-    // are exact, nothing waits for the write acknowledgements)
     const int4* comp4 = reinterpret_cast<const int4*>(p.comp);
-    int4 ca0 = make_int4(1, -1, -1, -1), cb0 = make_int4(-1, -1, -1, -1), ca1 = ca0, cb1 = cb0;
-    double l0 = 0.0, u0 = 0.0, l1 = 0.0, u1 = 0.0;
-    const int vend = p.off_dt + 1;
-    const int v0 = tid, v1 = cworker ? v0 + cstr : vend, v2 = cworker ? v1 + cstr : vend;
-    if (v0 < vend) { ca0 = comp4[2 * v0]; cb0 = comp4[2 * v0 + 1]; l0 = p.lb[xo + v0]; u0 = p.ub[xo + v0]; }
-    if (v1 < vend) { ca1 = comp4[2 * v1]; cb1 = comp4[2 * v1 + 1]; l1 = p.lb[xo + v1]; u1 = p.ub[xo + v1]; }
-    if (split && cworker) {  // component lanes: rounds 0 and 1 while the stage lanes prepare their caches; round 2 requested
-        if (v0 < vend) {
-            comp_values(v0, ca0, cb0, l0, u0);
-            if (v2 < vend) { ca0 = comp4[2 * v2]; cb0 = comp4[2 * v2 + 1]; l0 = p.lb[xo + v2]; u0 = p.ub[xo + v2]; }
-        }
-        if (v1 < vend) comp_values(v1, ca1, cb1, l1, u1);
-    }
-    if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
-        for (int k = tid; k < p.N; k += SWEEP_THREADS) {
-            double c[NC];
-            Dy::prepare(xs + k * S, dynl, c);
+    // Two-wave shape of the run-to-completion kernel: STAGE-CENTRIC component pass.  Lane k owns the components of block k (x_k, u_k; the last
+    // block: x_f) and one lane the dt component, the component's role (weight, reference, index inside its cost edge) is a compile-time
+    // property of its slot -- no per-component selection -- and the pass is ordered  loads -> arithmetic -> stores: the component rounds
+    // of the other shapes interleave global stores (residual rows) with global loads (the next round's descriptors), and on gfx9 a wait for
+    // a load issued behind stores waits for the stores' acknowledgements as well (one memory round trip per round: 7.4 k cycles for the
+    // four rounds of the headline instance, measured with the phase stamps).
+    constexpr bool SC = (THREADS <= 128) && !DENSE && !LONG;
+    if constexpr (SC) {
+        // regular slots: lane k < N - 1, slot e of block k (e < NX: state component e, else control component e - NX);
+        // special slots: lane N + j -- j < NX the component j of x_f (final cost / terminal equality), j = NX the dt component
+        const int kb     = tid;
+        const bool reg   = (kb < p.N - 1);
+        const int js     = kb - p.N;
+        const bool spec  = (js >= 0 && js <= NX);
+        const int vspec  = (js < NX) ? (p.N - 1) * S + js : p.off_dt;
+        int4 cA[S], cB[S];
+        double lo[S], up[S], rv[NX];
 #pragma unroll
-            for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
+        for (int e = 0; e < S; ++e) {   // (clamped, branch-free: an absent slot fetches component 0 and is ignored; slot 0 of a special lane: its component)
+            const int vc = reg ? kb * S + e : ((spec && e == 0) ? vspec : 0);
+            cA[e] = comp4[2 * vc]; cB[e] = comp4[2 * vc + 1]; lo[e] = p.lb[xo + vc]; up[e] = p.ub[xo + vc];
         }
-        if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);  // stage lanes: their one round of components
-        lds_barrier();
-    }
-    else if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
-
-    SWEEP_STAMP(2);
-    if (split) {
-        if (cworker) {   // round 2 is in the registers, later rounds (N > 100 or so) fetch as they go
-            if (v2 < vend) comp_values(v2, ca0, cb0, l0, u0);
-            for (int v = v2 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+#pragma unroll
+        for (int e = 0; e < NX; ++e) rv[e] = xr[e];
+        double rspec = 0.0;
+        if (p.refvec) {
+#pragma unroll
+            for (int e = 0; e < NX; ++e) rv[e] = p.refvec[xo + (reg ? kb * S + e : 0)];
+            rspec = p.refvec[xo + ((spec && js < NX) ? vspec : 0)];
         }
+        if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
+            for (int k = tid; k < p.N; k += THREADS) {
+                double c[NC];
+                Dy::prepare(xs + k * S, dynl, c);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
+            }
+        }
+        SWEEP_STAMP(2);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            constexpr double zero = 0.0;
+            const bool is_u   = (e >= NX);
+            const double w    = is_u ? p.mp.sr[is_u ? e - NX : 0] : p.mp.sq[is_u ? 0 : e];   // (compile-time slot: scalar operands)
+            const double ref  = is_u ? zero : rv[is_u ? 0 : e];
+            const int c       = is_u ? e - NX : e;
+            const int dim     = is_u ? NU : NX;
+            const double xv   = xs[reg ? kb * S + e : 0];
+            const int fixed = cA[e].x, cost_joff = cA[e].z, cost_row = cA[e].w, bnd_joff = cB[e].x, bnd_row = cB[e].y;
+            const double val  = w * (xv - ref);
+            // (branch-free forms of the bound row -- lo <= up: at most one of the two distances is positive -- and of its Jacobian entry below)
+            const double bval = fmax(fmax(lo[e] - xv, xv - up[e]), 0.0) * p.w_b;
+            const bool pc = reg && cost_row >= 0, pb = reg && bnd_row >= 0;
+            if (pc) put_value(cost_row, val);
+            if (pb) put_value(bnd_row, bval);
+            sq_acc += (pc ? val * val : 0.0) + (pb ? bval * bval : 0.0);
+            if (jac_with_values) {
+                const double a = xv + delta, b = a + neg2delta;
+                const double dv = scalar * (w * (a - ref) - w * (b - ref));   // central difference of the diagonal cost block (edge_interface.cpp:55-96)
+                if (reg && !fixed && cost_joff >= 0) {
+                    const int col0 = cost_joff - c;
+#pragma unroll
+                    for (int r = 0; r < DM; ++r)
+                        if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;   // untouched rows: scalar * (e - e) = 0
+                }
+                if (reg && bnd_joff >= 0) jst[bnd_joff] = (((xv > up[e]) ? 1.0 : 0.0) - ((xv < lo[e]) ? 1.0 : 0.0)) * p.w_b;  // -w_b / 0 / +w_b, :1721-1752
+            }
+        }
+        if (spec) {   // the x_f components and dt: every row kind a component can carry (second rows: terminal equality, duplicated dt edge)
+            const bool fin = (js < NX);
+            double wf = p.mp.dt_weight, reff = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                wf   = (js == i) ? p.mp.sqf[i] : wf;
+                reff = (js == i) ? xr[i] : reff;
+            }
+            if (p.refvec && fin) reff = rspec;
+            const CompInfo ci{cA[0].x, cA[0].y, cA[0].z, cA[0].w, cB[0].x, cB[0].y, cB[0].z, cB[0].w};
+            const double xv = xs[vspec];
+            if (ci.cost_row >= 0) {
+                const double val = wf * (xv - reff);
+                put_value(ci.cost_row, val);
+                sq_acc += val * val;
+                if (!fin && ci.cost2_row >= 0) { put_value(ci.cost2_row, val); sq_acc += val * val; }
+            }
+            if (fin && ci.cost2_row >= 0) {   // TerminalEqualityConstraint row (equality section: times w_eq)
+                const double val = (xv - reff) * p.w_eq;
+                put_value(ci.cost2_row, val);
+                sq_acc += val * val;
+            }
+            if (ci.bnd_row >= 0) {
+                double val = (xv < lo[0]) ? lo[0] - xv : ((xv > up[0]) ? xv - up[0] : 0.0);
+                val *= p.w_b;
+                put_value(ci.bnd_row, val);
+                sq_acc += val * val;
+            }
+            if (jac_with_values) comp_jac(vspec, ci, xv, lo[0], up[0], fin ? js : 0, fin ? NX : 1, wf, reff, fin);
+        }
+        if constexpr (CACHED) lds_barrier();
     }
     else {
-        if (v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
-        if (v1 < vend) comp_values(v1, ca1, cb1, l1, u1);
-        for (int v = v1 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+        // Work split of the residual (horizons up to 128 stages, i.e. when half of the workgroup holds one lane per stage): waves 0-1
+        // are the stage lanes (dynamics caches, one round of components, then the defects), waves 2-3 take the other rounds of
+        // components (cost / bound rows) meanwhile -- the halves run side by side on different SIMDs.  Longer horizons: every lane does
+        // both kinds of work, in sequence.
+        // (THREADS = 192, the three-wave shape of the run-to-completion kernel: waves 0-1 stage lanes, wave 2 the component rounds)
+        constexpr int SLANES = (THREADS == 192) ? 128 : THREADS / 2;   // stage lanes of the split
+        const bool split   = (THREADS > 128) && (p.N <= SLANES);
+        const int cstr     = split ? THREADS - SLANES : THREADS;   // component stride of the lanes that do several rounds
+        const bool cworker = !split || (tid >= SLANES);
+        // descriptors and bounds of the first two rounds of components: requested now, consumed below (straight-line code: the waits
+        // are exact, nothing waits for the write acknowledgements)
+        int4 ca0 = make_int4(1, -1, -1, -1), cb0 = make_int4(-1, -1, -1, -1), ca1 = ca0, cb1 = cb0;
+        double l0 = 0.0, u0 = 0.0, l1 = 0.0, u1 = 0.0;
+        const int vend = p.off_dt + 1;
+        const int v0 = tid, v1 = cworker ? v0 + cstr : vend, v2 = cworker ? v1 + cstr : vend;
+        if (v0 < vend) { ca0 = comp4[2 * v0]; cb0 = comp4[2 * v0 + 1]; l0 = p.lb[xo + v0]; u0 = p.ub[xo + v0]; }
+        if (v1 < vend) { ca1 = comp4[2 * v1]; cb1 = comp4[2 * v1 + 1]; l1 = p.lb[xo + v1]; u1 = p.ub[xo + v1]; }
+        // two-wave shape (256 VGPRs): every lane does four rounds of components one after the other -- all four requested up front (a round that
+        // fetches as it goes pays a memory round trip: 7.5 k cycles for the four rounds of the headline instance, measured)
+        constexpr bool PF4 = (THREADS <= 128);
+        int4 ca2 = ca0, cb2 = cb0, ca3 = ca0, cb3 = cb0;
+        double l2 = 0.0, u2 = 0.0, l3 = 0.0, u3 = 0.0;
+        const int w2 = v1 + cstr, w3 = w2 + cstr;
+        if constexpr (PF4) {
+            if (w2 < vend) { ca2 = comp4[2 * w2]; cb2 = comp4[2 * w2 + 1]; l2 = p.lb[xo + w2]; u2 = p.ub[xo + w2]; }
+            if (w3 < vend) { ca3 = comp4[2 * w3]; cb3 = comp4[2 * w3 + 1]; l3 = p.lb[xo + w3]; u3 = p.ub[xo + w3]; }
+        }
+        if (split && cworker) {  // component lanes: rounds 0 and 1 while the stage lanes prepare their caches; round 2 requested
+            if (v0 < vend) {
+                comp_values(v0, ca0, cb0, l0, u0);
+                if (v2 < vend) { ca0 = comp4[2 * v2]; cb0 = comp4[2 * v2 + 1]; l0 = p.lb[xo + v2]; u0 = p.ub[xo + v2]; }
+            }
+            if (v1 < vend) comp_values(v1, ca1, cb1, l1, u1);
+        }
+        if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
+            for (int k = tid; k < p.N; k += THREADS) {
+                double c[NC];
+                Dy::prepare(xs + k * S, dynl, c);
+    #pragma unroll
+                for (int i = 0; i < NC; ++i) cs[k * NC + i] = c[i];
+            }
+            if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);  // stage lanes: their one round of components
+            lds_barrier();
+        }
+        else if (split && !cworker && v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
+
+        SWEEP_STAMP(2);
+        if (split) {
+            if (cworker) {   // round 2 is in the registers, later rounds (N > 100 or so) fetch as they go
+                if (v2 < vend) comp_values(v2, ca0, cb0, l0, u0);
+                for (int v = v2 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+            }
+        }
+        else {
+            if (v0 < vend) comp_values(v0, ca0, cb0, l0, u0);
+            if (v1 < vend) comp_values(v1, ca1, cb1, l1, u1);
+            if constexpr (PF4) {
+                if (w2 < vend) comp_values(w2, ca2, cb2, l2, u2);
+                if (w3 < vend) comp_values(w3, ca3, cb3, l3, u3);
+                for (int v = w3 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+            }
+            else
+                for (int v = v1 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+        }
     }
     SWEEP_STAMP(9);
     // (b) per stage: the dynamics defect (equality rows) and the stage inequality
-    for (int k = tid; k < p.N - 1; k += SWEEP_THREADS) {
+    for (int k = tid; k < p.N - 1; k += THREADS) {
         const int base = k * S;
         double e[NX];
         if constexpr (CACHED)
@@ -423,7 +563,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
     // (c) the final-stage inequality on x_f (TerminalBall): one lane
     {
-        if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
+        if (p.fin_row >= 0 && tid == THREADS - 1) {
             double cf = terminal_ball<NX>(xs + (p.N - 1) * S, xr, p.mp.fin);
             cf        = (cf < 0) ? 0.0 : cf * p.w_ineq;   // computeValuesActiveInequality
             put_value(p.fin_row, cf);
@@ -439,7 +579,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         if ((tid & 63) == 0) red[tid >> 6] = ws;
         lds_barrier();
         if (tid == 0) {
-            const double chi2 = red[0] + red[1] + red[2] + red[3];
+            double chi2 = red[0] + red[1];
+            if constexpr (THREADS >= 192) chi2 += red[2];
+            if constexpr (THREADS >= 256) chi2 += red[3];
             bool fin = false;
             if (mode == 2) {  // solve() prologue (:89-127)
                 st->mu = 0; st->mu_acc = 0; st->rho = 0; st->chi2_old = chi2; st->last_sq = chi2; st->den = 0; st->dnorm = 0;
@@ -447,7 +589,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 st->status = CORBO_HIP_SOLVER_CONVERGED;  // iterations == 0: (stop || rho <= 0) with rho = 0
                 fin        = (p.iterations <= 0);
                 st->done   = fin ? 1 : 0;
-                st->vbuf = 0; st->inner = 0; st->n_accept = 0; st->n_reject = 0; st->n_jac = 1; st->n_res = 1; st->n_fact = 0; st->pad[0] = 0;
+                st->vbuf = 0; st->inner = 0; st->n_accept = 0; st->n_reject = 0; st->n_jac = 1; st->n_res = 1; st->n_fact = 0; st->pad[0] = 0; st->pad[1] = 0;
                 flags[0] = 1;
                 flags[1] = 0;
                 if (p.chi2) p.chi2[inst] = chi2;
@@ -469,7 +611,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     st->n_accept += 1;
                     if (!stop && k < p.iterations - 1) {  // :178-199
                         refresh            = 1;
-                        const double alpha = fmin(2. / 3., 1 - pow((2 * rho - 1), 3.0));
+                        // (2 rho - 1)^3 (:195, std::pow(., 3)): the cube with the rounding error of the square carried along (fma) -- within
+                        // half an ulp of the exact cube like the math library's pow, a dozen instructions instead of its few hundred on the
+                        // one lane every other lane of the workgroup waits for
+                        const double t_ = 2 * rho - 1, t2_ = t_ * t_;
+                        const double cube = __builtin_fma(t2_, t_, __builtin_fma(t_, t_, -t2_) * t_);
+                        const double alpha = fmin(2. / 3., 1 - cube);
                         const double scale = fmax(1. / 3., alpha);
                         mu *= scale;
                         v         = 2;
@@ -505,7 +652,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         do_jac = flags[0];
         if (mode == 3 && flags[1]) {  // accepted: the trial iterate becomes the iterate (discardBackupParameters :176)
             double* xdst = p.x + xo;
-            for (int i = tid; i < p.nvs / 2; i += SWEEP_THREADS)
+            for (int i = tid; i < p.nvs / 2; i += THREADS)
                 reinterpret_cast<double2*>(xdst)[i] = reinterpret_cast<const double2*>(xs)[i];
         }
     }
@@ -522,8 +669,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     //     parts of the defect that depend on the perturbed component are re-evaluated (the others are bit-identical anyway).
     {
         constexpr int NU0 = (NU + 1) / 2;  // group 0: x_k, u_k[0,NU0) ; group 1: u_k[NU0,NU), x_{k+1}, dt
-        const int g = tid >> 7;
-        for (int k = tid & 127; k < p.N - 1; k += 128) {
+        // Column sets of a lane (wave-uniform): bit 0 the x_k columns, bit 1 u_k[0,NU0), bit 2 u_k[NU0,NU), bit 3 x_{k+1} and dt.
+        //   256 threads: two lanes per stage (groups 0 / 1 = bits 0|1 / 2|3);  128 threads: one lane per stage, every column;
+        //   192 threads: wave 0 the x_k columns, wave 1 the u_k columns, wave 2 x_{k+1} / dt, 64 stages per round.
+        constexpr int JL = (THREADS == 256) ? 128 : (THREADS == 192 ? 64 : THREADS);   // lanes (= stages per round) of a column group
+        const int jw = tid / JL;
+        const unsigned cset = (THREADS == 256) ? (jw == 0 ? 0x3u : 0xCu) : (THREADS == 192 ? (jw == 0 ? 0x1u : (jw == 1 ? 0x6u : 0x8u)) : 0xFu);
+        const bool cs_x1 = cset & 1u, cs_u0 = cset & 2u, cs_u1 = cset & 4u, cs_x2 = cset & 8u;
+        for (int k = tid % JL; k < p.N - 1; k += JL) {
             const int base  = k * S;
             const int* sc   = p.stage_cols[k].col;
             double x1[NX], u1[NU], x2[NX];
@@ -544,7 +697,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 for (int i = 0; i < NX; ++i) q[i] = (x2[i] - x1[i]) / dt0;
                 Dy::eval(x1, c1, u1, dynl, f1);
                 Dy::eval(x2, c2, u1, dynl, f2);
-                if (g == 0) {
+                if (cs_x1) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {  // d/d x_k[i]: q_i and f(x1,u1) change
                         const int jo = sc[i];
@@ -573,7 +726,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 }
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {  // d/d u_k[j]: both dynamics evaluations change
-                    if ((j < NU0) != (g == 0)) continue;
+                    if (!((j < NU0) ? cs_u0 : cs_u1)) continue;
                     const int jo = sc[NX + j];
                     if (jo < 0) continue;
                     double e[2][NX];
@@ -592,7 +745,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     }
                     emit(jo, e[0], e[1]);
                 }
-                if (g == 1) {
+                if (cs_x2) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {  // d/d x_{k+1}[i]: q_i and f(x2,u1) change
                         const int jo = sc[S + i];
@@ -650,7 +803,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 rk4_end_state<DYN, false>(loc, loc + NX, dt0, dynl, ck, xe0);
 #pragma unroll
                 for (int c = 0; c < S; ++c) {
-                    const bool mine = (((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (g == 1);
+                    const bool mine = (THREADS == 256) ? ((((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (jw == 1)) : ((c < NX) ? cs_x1 : ((c - NX < NU0) ? cs_u0 : cs_u1));
                     const int jo    = sc[c];
                     if (!mine || jo < 0) continue;
                     double e[2][NX];
@@ -672,7 +825,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 }
 #pragma unroll
                 for (int c = S; c < W; ++c) {
-                    const bool mine = (((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (g == 1);
+                    const bool mine = (THREADS == 256) ? ((((Dy::RK4_GROUP1_COLS >> c) & 1u) != 0u) == (jw == 1)) : cs_x2;
                     const int jo    = sc[c];
                     if (!mine || jo < 0) continue;
                     double e[2][NX];
@@ -686,7 +839,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     emit(jo, e[0], e[1]);
                 }
                 const int jo = sc[S + NX];
-                if (g == 1 && jo >= 0) {  // free dt: every stage changes
+                if (cs_x2 && jo >= 0) {  // free dt: every stage changes
                     double e[2][NX];
                     double da = dt0;
 #pragma unroll
@@ -708,7 +861,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 for (int i = 0; i < NU; ++i) loc[NX + i] = u1[i];
 #pragma unroll
                 for (int c = 0; c < W; ++c) {
-                    const bool mine = (c < NX + NU0) ? (g == 0) : (g == 1);
+                    const bool mine = (c < NX) ? cs_x1 : ((c < NX + NU0) ? cs_u0 : ((c < S) ? cs_u1 : cs_x2));
                     const int jo    = sc[c];
                     if (!mine || jo < 0) continue;
                     double e[2][NX];
@@ -722,7 +875,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     emit(jo, e[0], e[1]);
                 }
                 const int jo = sc[S + NX];
-                if (g == 1 && jo >= 0) {
+                if (cs_x2 && jo >= 0) {
                     double e[2][NX];
                     double da = dt0;
 #pragma unroll
@@ -738,7 +891,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     SWEEP_STAMP(5);
     // (2) least-squares cost blocks and bound rows, per vertex component -- unless written together with the residual above
     if (!jac_with_values) {
-        for (int v = tid; v <= p.off_dt; v += SWEEP_THREADS) {
+        for (int v = tid; v <= p.off_dt; v += THREADS) {
             const int4 ca = comp4[2 * v], cb = comp4[2 * v + 1];
             const CompInfo ci{ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
             int c, dim;
@@ -751,7 +904,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     // (3) stage inequality rows (active rows only, explicit zero otherwise, :1568-1610)
     if constexpr (NX >= 3) {
         if (p.ineq_cols) {
-            for (int k = tid; k < p.N - 1; k += SWEEP_THREADS) {
+            for (int k = tid; k < p.N - 1; k += THREADS) {
                 double loc[NX];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) loc[i] = xs[k * S + i];
@@ -773,7 +926,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
     if constexpr (NX <= 4) {   // final-stage inequality row on x_f (same rule: active row or explicit zeros)
-        if (p.fin_row >= 0 && tid == SWEEP_THREADS - 1) {
+        if (p.fin_row >= 0 && tid == THREADS - 1) {
             double loc[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) loc[i] = xs[(p.N - 1) * S + i];
@@ -800,7 +953,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
         // (stand-alone kernel: streaming stores -- the consumer is a later launch and 1024 Jacobians do not fit the L2 anyway, +7 % on the
         //  sweep; fused kernel: normal stores -- the pass after a rejected step reads its Jacobian back from the L2, streaming costs 3 %)
-        for (int i = tid; i < p.nnz_pad / 2; i += SWEEP_THREADS) {
+        for (int i = tid; i < p.nnz_pad / 2; i += THREADS) {
             const double2 v = reinterpret_cast<const double2*>(jst)[i];
             if constexpr (FUSED) reinterpret_cast<double2*>(js)[i] = v;
             else {
@@ -1027,7 +1180,7 @@ __device__ __forceinline__ double quad_bcast(double v)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower triangle, i >= j
 #define STAMP(id)                                                       \
     do {                                                                \
-        if (p.timeline && inst == 0 && tid == 0) p.timeline[id] = clock64(); \
+        if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); \
     } while (0)
 
 // LDS carve of factor_body (doubles), shared with the fused pass kernel
@@ -1210,7 +1363,9 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
         double2* dst       = reinterpret_cast<double2*>(smem);
         const int n2       = p.nnz_pad / 2;
-        constexpr int UNR  = 4;  // loads in flight per lane (8 costs 3 % of a solve at the 128-VGPR budget) (branch-free: indices are clamped, the duplicates are harmless)
+        // loads in flight per lane (8 costs 3 % of a solve at the 128-VGPR budget) (branch-free: indices are clamped, the duplicates are harmless);
+        // the two-wave shape of the run-to-completion kernel has the registers for the whole headline Jacobian in ONE round trip (17 x 128 x 16 bytes)
+        constexpr int UNR  = 4;   // (17 -- the whole headline Jacobian in one round trip of the two-wave shape -- was measured: 5.2 k -> 7.2 k cycles alone, 14 k+ under load)
         for (int i0 = tid; i0 < n2; i0 += THREADS * UNR) {
             double2 v[UNR];
 #pragma unroll
@@ -1348,6 +1503,19 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         gk[i] = 0; bk[i] = 0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) { Dk[i][j] = 0; Ck[i][j] = 0; }
+    }
+    // Register-rich shapes of the run-to-completion kernel (two / three waves per workgroup, headline stride): the pad slot N of the SoA arrays
+    // (NP = N | 1, N even) is a ZERO neighbour -- the cyclic-reduction levels fetch absent neighbours from it instead of zeroing 30 registers
+    // per side with selects (measured at the 128-VGPR budget of the four-wave shape: -7 % in the levels, +15 % in the stage phases through
+    // register allocation; the rich shapes have the registers).  A spare lane clears it while the stage lanes eliminate their controls.
+    constexpr bool ZSLOT = (THREADS < 256) && (NPC > 0) && !ARROW && !GWS;
+    if constexpr (ZSLOT) {
+        if (k == N && N < NP) {
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) { SOA(Wam, i, N) = 0.0; SOA(Wbm, i, N) = 0.0; }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) SOA(gv, i, N) = 0.0;
+        }
     }
     if (has_stage) {
         double Huu[NU][NU];
@@ -1507,7 +1675,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         for (int t = tid >> 2; t < nblk; t += THREADS / 4) {   // (one round whenever 4 * ceil(N / h) <= THREADS)
         const int a      = h * t;
         const bool has_m = (a - hh >= 0), has_p = (a + hh < N);
-        const int em = has_m ? a - hh : a, ep = has_p ? a + hh : a;       // clamped: absent neighbours are fetched from a and zeroed
+        const int em = has_m ? a - hh : (ZSLOT ? N : a), ep = has_p ? a + hh : (ZSLOT ? N : a);       // clamped: absent neighbours are fetched from a and zeroed (ZSLOT: from the zero slot)
         const bool elim = (t & 1);
         // operand of this lane: column j of the far coupling of each neighbour, or (lane 3) the neighbour's rhs
         const int jc     = col ? j : 0;               // (a spare lane, NX < 3, mirrors column 0 and stores nothing)
@@ -1535,7 +1703,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         }
         // absent neighbour: BOTH factors of every product are zeroed -- the clamped loads may have fetched never-written LDS
         // (whatever an earlier kernel left there, possibly NaN bit patterns; 0 x NaN would poison the block)
-        if (!has_m) {
+        if (!ZSLOT && !has_m) {
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
                 ym[q] = 0.0; zm[q] = 0.0; ymr[q] = 0.0;
@@ -1543,7 +1711,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
                 for (int c = 0; c < NX; ++c) Xm[q][c] = 0.0;
             }
         }
-        if (!has_p) {
+        if (!ZSLOT && !has_p) {
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
                 yp[q] = 0.0; zp[q] = 0.0; ypr[q] = 0.0;
@@ -1725,11 +1893,44 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         };
         int h = hroot >> 1;
         fetch(h, tid >> 2);
-        for (; h >= 1; h >>= 1) {
+        constexpr bool PREFETCH = false && (THREADS < 256) && (NPC > 0) && !GWS;   // measured in the two-wave shape: back-substitution 5.9 k -> 7.0 k cycles -- off   // register-rich shapes: the factor data of the NEXT level (final since the
+        for (; h >= 1; h >>= 1) {                                         // forward sweep) is requested ahead of this level's arithmetic and barrier
+            if constexpr (PREFETCH) {
+                double L0[NX][NX], wa0[NX], wb0[NX];
+                const double yq0 = yq;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) {
+                    wa0[c] = wa[c]; wb0[c] = wb[c];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) L0[r][c] = L[r][c];
+                }
+                if (h > 1) fetch(h >> 1, tid >> 2);   // into L / wa / wb / yq; this level works on the copies
+                if (h * (2 * (tid >> 2) + 1) < N) {
+                    const int t = tid >> 2, i = h * (2 * t + 1), a = i - h, b = i + h, bc = (b < N) ? b : a;
+                    double v = yq0;
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) v -= wa0[c] * SOA(gv, c, a) + wb0[c] * SOA(gv, c, bc);
+                    double x[NX];
+                    x[0] = quad_bcast<0>(v);
+                    if constexpr (NX > 1) x[1] = quad_bcast<1>(v);
+                    if constexpr (NX > 2) x[2] = quad_bcast<2>(v);
+                    if constexpr (NX > 3) x[3] = quad_bcast<3>(v);
+                    bwd_solve_vec<NX>(L0, x);
+                    double xq = x[0];
+#pragma unroll
+                    for (int r = 1; r < NX; ++r) xq = (q == r) ? x[r] : xq;
+                    if (q < NX) SOA(gv, q, i) = xq;
+                }
+                // more blocks than quads: only at h = 1 (N / 4 <= THREADS / 4 blocks at h = 2), where nothing was prefetched
+                for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }
+                fb_barrier();
+            }
+            else {
             if (h * (2 * (tid >> 2) + 1) < N) finish(h, tid >> 2);
             for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }  // long horizons
             fb_barrier();
             if (h > 1) fetch(h >> 1, tid >> 2);
+            }
         }
     }
     STAMP(6);
@@ -3028,9 +3229,12 @@ __device__ __forceinline__ int32_t* cu_row_of(int32_t* table)
 #ifndef CORBO_HIP_PASS_WAVES
 #define CORBO_HIP_PASS_WAVES 4   // waves per SIMD the fused kernel is compiled for: 4 = 128 VGPRs (44 spilled), four workgroups per CU.  -DCORBO_HIP_PASS_WAVES=3:
 #endif                           // 168 VGPRs, no spills, three workgroups per CU (diagnostics: attribution of the scratch traffic, profiles/r03_spill_attribution.json)
-template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, bool QUEUE = false>
-__global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
+// THREADS: 256 (four waves, 128 VGPRs at four workgroups per CU), 192 (three waves: 168 VGPRs at the same four workgroups per CU, i.e. the
+// same 1024 resident instances without the register spills of the 128-VGPR build -- VERDICT r3 item 1a) or 128 (two waves, 256 VGPRs).
+template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, int THREADS = SWEEP_THREADS>
+__global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS_WAVES : THREADS / 64)) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
+    constexpr int BK_LANE = (THREADS > 128) ? 128 : THREADS - 1;   // the lane that keeps the CU's progress row (a spare lane of wave 2 / the last lane)
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -3052,11 +3256,11 @@ __global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_k
         if (tid == 0) flags[0] = 0;
         __syncthreads();
         if (sp.mode == 3 && sl->done) return;
-        sweep_body<DYN, DEFECT, true>(sp, sp.mode, sp.active_count, sl, xs, red, cs, jst, inst, tid);
+        sweep_body<DYN, DEFECT, true, false, false, THREADS>(sp, sp.mode, sp.active_count, sl, xs, red, cs, jst, inst, tid);
         __threadfence_block();  // this workgroup's residual / iterate stores are visible to its factor phase
         __syncthreads();
         if (!sl->done) {
-            factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fp, sl, smem, inst, tid, flags[0] != 0);
+            factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC>(fp, sl, smem, inst, tid, flags[0] != 0);
             __syncthreads();
         }
         lm_state_out(fp.st + inst, sl, tid);
@@ -3088,7 +3292,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_k
         }
 #pragma nounroll
         for (;;) {
-            if constexpr (QUEUE) {
+            // (queue mode is a launch parameter, not an instantiation: one uniform branch per instance; the library carries half as many kernels)
+            const bool queue_mode = ((const FactorParams&)ka->f).queue != nullptr;
+            if (queue_mode) {
                 asm volatile("" : "+v"(tid_v), "+s"(ka) : : "memory");   // (as in the pass loop: nothing is carried around this loop either)
                 const FactorParams& fq = (const FactorParams&)ka->f;
                 __syncthreads();   // the previous instance's last readers of flags[] are through
@@ -3115,8 +3321,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_k
                 const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;
                 if (stamp) fpl.pass_timeline[2 * pass] = clock64();
                 if (pass > 0) {
+                    // (no barrier: lane 0 itself is the next writer of flags[0] -- the sweep phase's decision -- and every reader sits behind that
+                    //  phase's barriers; the previous pass's readers are through, the pass ended with a workgroup barrier)
                     if (tid_v == 0) flags[0] = 0;
-                    __syncthreads();
                     if (fpl.cu_table) {
                         if (stamp && pass < 32) fpl.pass_timeline[64 + pass] = flags[2] + 10 * flags[3];   // (diagnostics: valid for < 32 passes)
                         switch (__builtin_amdgcn_readfirstlane(flags[2])) {
@@ -3127,41 +3334,56 @@ __global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_k
                         }
                     }
                 }
-                sweep_body<DYN, DEFECT, true>(spl, mode, nullptr, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);
+                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);   // (active_count: per-pass launches only)
                 __threadfence_block();
                 __syncthreads();
                 if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
                 if (sl->done) break;
-                if (fpl.cu_table) {
-                    // lag-based issue priority: the SIMD arbiter prefers older waves, so the workgroups dispatched last to a CU run every
-                    // pass ~40 % slower than the first ones while the CU is full -- and the launch ends with the slowest chain.  Every
-                    // workgroup publishes its outer iteration in a per-CU row; the one that is furthest behind gets the highest user
-                    // priority (s_setprio beats age).  A spare lane of wave 2 does the bookkeeping during the factor phase, the waves pick
-                    // the new priority up at the start of the next pass.
-                    if (tid_v == 128) {
-                        int32_t* row = cu_row_of(fpl.cu_table);
-                        int slot = flags[3];
-                        if (slot < 0) { slot = atomicAdd(row, 1) & 7; flags[3] = slot; }
-                        const int myk = sl->k;
-                        __hip_atomic_store(row + 1 + slot, myk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        int rank = 0;
-                        const int rot = (slot > 3 || __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) ? 7 : 3;
+                // lag-based issue priority: the SIMD arbiter prefers older waves, so the workgroups dispatched last to a CU run every
+                // pass ~40 % slower than the first ones while the CU is full -- and the launch ends with the slowest chain.  Every
+                // workgroup publishes its outer iteration in a per-CU row; the one that is furthest behind gets the highest user
+                // priority (s_setprio beats age).  One lane does the bookkeeping: it publishes and REQUESTS the row before the factor phase
+                // and ranks the workgroup after it -- the memory round trip rides under the factor phase instead of holding every wave
+                // of the workgroup at the phase's first barrier (measured: 2 k of the 4.3 k cycles between the two phases).
+                // (four-wave shape: ranked at once -- eleven more live registers across the factor phase cost 26 more spills at its 128-VGPR budget)
+                constexpr bool BK_DEFER = THREADS < SWEEP_THREADS;
+                int bk_slot = -1, bk_k = 0, bk_cnt = 0, bk_row[8];
+                auto bk_rank = [&] {
+                    int rank = 0;
+                    const int rot = (bk_slot > 3 || bk_cnt > 4) ? 7 : 3;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int kq = __hip_atomic_load(row + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;   // -1: empty slot
-                            if (q != slot && kq >= 0 && (kq < myk || (kq == myk && ((pass - q) & rot) < ((pass - slot) & rot)))) ++rank;   // ties: rotating order (the arbiter's own tie-break is age)
-                        }
-                        flags[2] = rank > 3 ? 0 : 3 - rank;
+                    for (int q = 0; q < 8; ++q) {
+                        const int kq = bk_row[q] - 1;   // -1: empty slot
+                        if (q != bk_slot && kq >= 0 && (kq < bk_k || (kq == bk_k && ((pass - q) & rot) < ((pass - bk_slot) & rot)))) ++rank;   // ties: rotating order (the arbiter's own tie-break is age)
                     }
+                    flags[2] = rank > 3 ? 0 : 3 - rank;
+                };
+                if (fpl.cu_table && tid_v == BK_LANE) {
+                    int32_t* row = cu_row_of(fpl.cu_table);
+                    bk_slot = flags[3];
+                    if (bk_slot < 0) { bk_slot = atomicAdd(row, 1) & 7; flags[3] = bk_slot; }
+                    bk_k = sl->k;
+                    __hip_atomic_store(row + 1 + bk_slot, bk_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bk_cnt = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bk_row[q] = __hip_atomic_load(row + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (!BK_DEFER) bk_rank();
                 }
-                factor_body<Dy::NX, Dy::NU, SWEEP_THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, xs);
+                // (loop_passes = 0: ONE pass per launch -- the per-pass mode of corbo_hip_solve and the profiling mode; the trial iterate then
+                //  goes to HBM for the next launch instead of staying in the LDS array the next sweep phase evaluates it from)
+                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, max_passes > 0 ? xs : nullptr);
+                if constexpr (BK_DEFER) { if (bk_slot >= 0) bk_rank(); }
                 __threadfence_block();
                 __syncthreads();
+                if (stamp && fpl.timeline) {   // diagnostics: the phase stamps of this pass (factor [0,8), sweep [8,18)) into the per-pass log
+                    long long* lg = fpl.pass_timeline + 150 + 18 * pass;
+                    for (int q = 0; q < 18; ++q) { lg[q] = fpl.timeline[q]; fpl.timeline[q] = 0; }
+                }
                 mode = 3;
             }
             asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");
             const FactorParams& fe = (const FactorParams&)ka->f;
-            if (fe.cu_table && tid_v == 128 && flags[3] >= 0) {   // leave the CU's progress row (the table is all zeros again when the launch retires)
+            if (fe.cu_table && tid_v == BK_LANE && flags[3] >= 0) {   // leave the CU's progress row (the table is all zeros again when the launch retires)
                 int32_t* row = cu_row_of(fe.cu_table);
                 __hip_atomic_store(row + 1 + flags[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicSub(row, 1);
@@ -3172,11 +3394,12 @@ __global__ __launch_bounds__(SWEEP_THREADS, CORBO_HIP_PASS_WAVES) void lm_pass_k
                 // writes, overlapped with the instances that are still iterating) -- no copy-engine pass after the launch
                 const double2* src = reinterpret_cast<const double2*>(fe.x + (size_t)inst_v * fe.nvs);
                 double2* dst       = reinterpret_cast<double2*>(fe.x_host + (size_t)inst_v * fe.nvs);
-                for (int i = tid_v; i < fe.nvs / 2; i += SWEEP_THREADS) dst[i] = src[i];
+                for (int i = tid_v; i < fe.nvs / 2; i += THREADS) dst[i] = src[i];
                 lm_state_out(fe.st_host + inst_v, sl, tid_v);
             }
             if (tid_v == 0 && !sl->done && fe.unfinished_flag) *(volatile int32_t*)fe.unfinished_flag = 1;  // pass limit hit
-            if constexpr (!QUEUE) break;
+            asm volatile("" : "+s"(ka) : : "memory");
+            if (((const FactorParams&)ka->f).queue == nullptr) break;
         }
     }
 }
@@ -3726,20 +3949,25 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
         grid = fp.queue_grid * per_cu;   // queue_grid = compute units of the device
         if (grid > fp.batch) grid = fp.batch;
     }
-    const dim3 g(grid), b(SWEEP_THREADS);
-    // the run-to-completion kernel of the headline horizon (N = 100) is specialised on the LDS stride
-    if (fp.loop_passes > 0 && fp.queue) {
-        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0, true>), g, b, lds, stream, fp, sp);
-        else if ((fp.N | 1) == 101) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 101, true>), g, b, lds, stream, fp, sp);
-        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0, true>), g, b, lds, stream, fp, sp);
+    // Workgroup shape of the run-to-completion kernel: TWO waves (128 threads, 256 VGPRs at the same four workgroups per CU) whenever every
+    // block and the special component lanes fit (N + NX + 1 <= 128) -- fewer waves per SIMD, no register spills, the stage-centric component
+    // pass, the zero neighbour slot (0.66 -> 0.55 ms per headline solve); four waves for longer horizons.  Handle option
+    // "pass_threads" (256 / 128) forces a shape (A/B measurements).
+    const bool two_ok = fp.N + Dy::NX + 1 <= 128;
+    const bool two    = two_ok && fp.pass_threads != 256;
+    {
+        if (two) {
+            const dim3 b(128);
+            if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0, 128>), dim3(grid), b, lds, stream, fp, sp);
+            else if (fp.N == 100) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 101, 128>), dim3(grid), b, lds, stream, fp, sp);   // the headline horizon: LDS strides as immediates, zero neighbour slot
+            else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0, 128>), dim3(grid), b, lds, stream, fp, sp);
+        }
+        else {
+            const dim3 b(SWEEP_THREADS);
+            if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0>), dim3(grid), b, lds, stream, fp, sp);
+            else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0>), dim3(grid), b, lds, stream, fp, sp);
+        }
     }
-    else if (fp.loop_passes > 0) {
-        if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0>), g, b, lds, stream, fp, sp);
-        else if ((fp.N | 1) == 101) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 101>), g, b, lds, stream, fp, sp);
-        else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0>), g, b, lds, stream, fp, sp);
-    }
-    else if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, false, 0>), g, b, lds, stream, fp, sp);
-    else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, false, 0>), g, b, lds, stream, fp, sp);
     return true;
 }
 
@@ -4121,7 +4349,8 @@ size_t sweep_lds_bytes(const SweepParams& p, int nc)
 {
     // vertex values + reduction scratch + dynamics caches + Jacobian staging; the headline family must stay below 40 KB so that
     // four workgroups share a CU (1024 instances = one round over 256 CUs)
-    const size_t stage = (p.nx <= 4 && p.N <= LONG_HORIZON) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
+    static_assert(LONG_HORIZON == 256, "jacobian_staged_in_lds");
+    const size_t stage = jacobian_staged_in_lds(p.nx, p.N) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
     return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage) + sizeof(LmState);
 }
 

@@ -66,7 +66,8 @@ struct SweepParams {
     int32_t m_pad, nnz_pad;
     LmState* st;
     int32_t* active_count;  // number of instances not done after this pass (mode 3)
-    long long* timeline;    // optional [16] shader-clock stamps of instance 0 (diagnostics), may be null
+    long long* timeline;    // optional [16] shader-clock stamps of instance `timeline_inst` (diagnostics), may be null
+    int32_t timeline_inst;
     double* chi2;           // [batch] dense copy of the accepted chi2 (*obj_value), written by the LM modes
     // big-block family (multiple shooting with RK4, nx > 6): the Jacobian of an LM pass is never stored.  The residual sweep keeps
     // the end state of the unperturbed Runge-Kutta step of every shooting interval, [2][batch][N][nx] (the half paired with the
@@ -94,7 +95,8 @@ struct FactorParams {
     int32_t m_pad, nnz_pad;
     LmState* st;
     double* delta_out;            // optional [batch][nvs] (debug / tests), may be null
-    long long* timeline;          // optional [8] shader-clock stamps of workgroup 0 (diagnostics), may be null
+    long long* timeline;          // optional [8] shader-clock stamps of instance `timeline_inst` (diagnostics), may be null
+    int32_t timeline_inst;
     double* work;                 // big-block kernel only: per-instance factor workspace in HBM
     int64_t work_stride;          // doubles per instance
     long long* pass_timeline;     // optional [2 * 64 + 1] shader-clock stamps (pass start, sweep end) of one instance (diagnostics)
@@ -111,6 +113,7 @@ struct FactorParams {
     int32_t* cu_table;            // run-to-completion kernel: per-CU progress table for the lag-based issue priority (see lm_pass_kernel), or null
     int32_t stagger;              // run-to-completion kernel (diagnostics): workgroup b waits (b / 256) * stagger shader cycles before it starts
     int32_t defect;               // corbo_hip_problem_desc::defect (big-block family: which stage kernel)
+    int32_t pass_threads;         // run-to-completion kernel: workgroup size 256 (default) / 192 / 128 (option "pass_threads"; headline shape only)
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 
@@ -212,6 +215,9 @@ bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorPar
 bool device_kernels_exist(const corbo_hip_problem_desc& d);   // host-only mirror of the dispatch (corbo_hip_create's gate)
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepParams& p, int nc);
+// Small-block families with horizons up to 256 grid points assemble the Jacobian values in an LDS staging area (STAGE in sweep_body); the
+// device-internal value layout carries one pad double per defect block for exactly those (corbo_hip_create).
+constexpr bool jacobian_staged_in_lds(int nx, int N) { return nx <= 4 && N <= 256; }
 size_t factor_lds_bytes(const corbo_hip_problem_desc& d, const FactorParams& p);
 // doubles of HBM workspace per instance the factor kernel needs (0 for the LDS-resident small-block kernel)
 size_t factor_work_doubles(const corbo_hip_problem_desc& d);

@@ -23,7 +23,7 @@ def shard_bounds(global_batch: int, world: int, rank: int) -> Tuple[int, int]:
     return first, count
 
 
-STAT_KEYS = ("lm_iterations", "accepted_steps", "rejected_steps", "jacobian_sweeps", "residual_sweeps", "factorizations")
+STAT_KEYS = ("lm_iterations", "accepted_steps", "rejected_steps", "jacobian_sweeps", "residual_sweeps", "factorizations", "counted_iterations")
 
 
 def reduce_stats(local: Dict[str, float], chi2_sum: float, ok_instances: int, dist=None, device="cpu") -> Dict[str, float]:

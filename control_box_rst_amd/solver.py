@@ -183,6 +183,7 @@ class BatchedLevenbergMarquardt:
     def prepare_slots(self, active: int):
         """Use the first `active` slots (and give a never-uploaded handle the descriptor's bound pattern)."""
         self._check(self.lib.corbo_hip_prepare_slots(self._h, int(active)), "corbo_hip_prepare_slots")
+        self._active = int(active)
 
     def get_dt(self, active: int) -> np.ndarray:
         out = np.zeros(self.batch)   # the library writes one value per ACTIVE slot of the handle (<= batch), whatever the caller expects
@@ -308,7 +309,8 @@ class BatchedLevenbergMarquardt:
                                                            C.byref(ptr[0]), C.byref(ptr[1]), C.byref(ptr[2])), "corbo_hip_eval_hessians_views")
         if device:
             return [C.cast(q, C.c_void_p).value for q in ptr]
-        return [np.ctypeslib.as_array(ptr[c], shape=(self.batch, int(nnz[c]))) if nnz[c] else np.zeros((self.batch, 0)) for c in range(3)]
+        rows = getattr(self, "_active", self.batch)   # the library sizes and fills the lists for the handle's ACTIVE instances only
+        return [np.ctypeslib.as_array(ptr[c], shape=(rows, int(nnz[c]))) if nnz[c] else np.zeros((rows, 0)) for c in range(3)]
 
     def eval_hessians(self, lower_part_only=True, mult_obj=1.0, mult_eq=None, mult_ineq=None):
         """computeSparseHessiansValues at the resident iterates: value arrays [B][nnz] of the objective / equality / inequality lists.

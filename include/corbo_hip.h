@@ -231,6 +231,10 @@ typedef struct corbo_hip_stats {
     float   sweep_ms;           /* accumulated time of the edge/Jacobian sweep kernel inside it (0 if not profiled) */
     float   factor_ms;          /* accumulated time of the assemble/factor/solve kernel (0 if not profiled) */
     int32_t inner_loop_cuts;    /* instances whose inner loop was cut after 64 consecutive rejections (status ERROR); 0 in every test */
+    int64_t counted_iterations; /* of lm_iterations (and of factorizations, one each): outer iterations that followed a converged step
+                                 * (|delta| <= eps2 / 2) and were COUNTED, not executed (option "ff_converged", default on; the reference
+                                 * executes them and changes nothing a caller sees, levenberg_marquardt_sparse.cpp:129-154).  Rates of
+                                 * executed work: lm_iterations - counted_iterations, factorizations - counted_iterations. */
 } corbo_hip_stats;
 
 typedef struct corbo_hip_solver* corbo_hip_handle;

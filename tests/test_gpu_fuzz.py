@@ -89,6 +89,21 @@ def random_desc(rng, long_horizon=False):
     return fam, d
 
 
+# ---- escalation bookkeeping (VERDICT r3 "weak" 1): a comparison that misses its base tolerance may pass on the oracle's own one-ulp spread, but
+#      (a) the widened tolerance is capped ABSOLUTELY at WIDEN_CAP x the base tolerance -- a device error larger than that fails whatever the
+#          spread says, (b) every such case is recorded (test name, seed, stage, deviation, spread) and written to gpurun_out/fuzz_escalations.json,
+#      (c) test_fuzz_escalation_budget (last in this file) fails if more seeds of the suite escalate than the committed budget allows -- a
+#          one-decision bug in the device shows up as a growing count long before it breaks a widened tolerance.
+WIDEN_CAP = 10.0
+ESCALATIONS = []   # dicts: test, seed, stage (1: six-trial spread, 2: 48-trial spread), ex, ec, sx, sc
+ESCALATION_BUDGET = {1: 4, 2: 1}   # seeds of THIS suite (184 + 12 descriptors) that may take stage 1 / stage 2; measured on MI355X boxes: see DESIGN.md 4
+
+
+def widened(base, factor, spread, scale=1.0):
+    """max(base, factor x spread), never beyond WIDEN_CAP x base."""
+    return min(max(base, factor * spread * scale), WIDEN_CAP * base)
+
+
 def oracle_own_spread(oracle_mod, d, X0, xf, opts, first_free, trials=6):
     """What the reference algorithm itself leaves undetermined on this problem: the oracle (bit-exact restatement) solved again from starts that
     differ by ONE ULP in the free components -- the finite-difference noise of J (1-ulp -> 1e-7 in an entry) is amplified through the iterations,
@@ -151,14 +166,16 @@ def test_random_descriptor_vs_oracle(oracle_mod, seed):
         # over 600 more seeds: 4 such cases, all on the MultipleShootingVariableGrid, device deviation 0.7 - 1.8e-4 against an own spread of 0.4 - 1.3e-4)
         ec = np.abs(chi2 - chi2o).max() / max(1e-10, np.abs(chi2o).max())
         sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, d.nx)
-        if not (ex <= max(3e-5, 8.0 * sx) and ec <= max(rtol, 8.0 * sc)):
+        ESCALATIONS.append(dict(test="descriptor", seed=seed, fam=str(fam), stage=1, ex=float(ex), ec=float(ec), sx=sx, sc=sc))
+        if not (ex <= widened(3e-5, 8.0, sx) and ec <= widened(rtol, 8.0, sc)):
             # the spread is heavy-tailed: a one-ulp change of the start can flip a discrete decision of the algorithm (a step accepted or rejected, a
             # bound row switched on) and the result JUMPS -- seed 23091 of the campaign: 57 of 60 one-ulp starts within 3e-6 of each other, three
             # 4.55e-5 away, which is where the device landed (4.55e-5).  Six trials do not see that; look again with 48, then the device must
             # lie within twice the largest jump the oracle itself makes
             sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, d.nx, trials=48)
-            assert ex <= max(3e-5, 2.0 * sx), (seed, fam, ex, sx)
-            assert ec <= max(rtol, 2.0 * sc), (seed, fam, ec, sc)
+            ESCALATIONS[-1].update(stage=2, sx=sx, sc=sc)
+            assert ex <= widened(3e-5, 2.0, sx), (seed, fam, ex, sx)
+            assert ec <= widened(rtol, 2.0, sc), (seed, fam, ec, sc)
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -214,10 +231,14 @@ def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
         # (tools/fuzz_campaign.py over 60 more seeds: 5 cases with chi2 1.3e-6 .. 3.6e-5 apart against an own spread of 1e-6 .. 1.4e-5)
         ec, ex = np.abs(chi2 - chi2o).max() / np.abs(chi2o).max(), np.abs(X - Xo).max()
         sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, 12)
-        if not (ec <= max(1e-6, 8.0 * sc) and ex <= max(3e-4, 8.0 * sx * max(1.0, np.abs(Xo).max()))):
+        xs_ = max(1.0, np.abs(Xo).max())
+        ESCALATIONS.append(dict(test="quadrotor", seed=seed, stage=1, ex=float(ex), ec=float(ec), sx=sx, sc=sc))
+        # (chi2 base 1e-6: the cap is 1e-5 x WIDEN_CAP / 10 -- the campaign's largest own spread on this family is 1.4e-5, so chi2 is capped at 1e-4)
+        if not (ec <= min(max(1e-6, 8.0 * sc), 1e-4) and ex <= widened(3e-4, 8.0, sx, xs_)):
             sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, 12, trials=48)   # (heavy tail: see test_random_descriptor_vs_oracle)
-            assert ec <= max(1e-6, 2.0 * sc), (seed, chi2, chi2o, sc)
-            assert ex <= max(3e-4, 2.0 * sx * max(1.0, np.abs(Xo).max())), (seed, ex, sx)
+            ESCALATIONS[-1].update(stage=2, sx=sx, sc=sc)
+            assert ec <= min(max(1e-6, 2.0 * sc), 1e-4), (seed, chi2, chi2o, sc)
+            assert ex <= widened(3e-4, 2.0, sx, xs_), (seed, ex, sx)
 
 
 @pytest.mark.parametrize("seed", range(16))
@@ -392,3 +413,21 @@ def test_counted_converged_iterations_random_descriptors(seed):
     for a, b in zip(*res):
         assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2]), (seed, fam)
         assert a[3] == b[3], (seed, fam, a[3], b[3])
+
+
+def test_fuzz_escalation_budget():
+    """Runs last in this file: how many of the suite's random descriptors needed the oracle's own spread to pass (see ESCALATIONS above).  The
+    record goes to gpurun_out/fuzz_escalations.json; more escalations than the committed budget is a failure even if every widened tolerance held.
+    (Under pytest-xdist every worker checks the seeds it ran.)"""
+    import json
+    import os
+    from conftest import ROOT
+    n1 = sum(1 for e in ESCALATIONS if e["stage"] >= 1)
+    n2 = sum(1 for e in ESCALATIONS if e["stage"] >= 2)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fuzz_escalations.json"), "w") as f:
+            json.dump({"stage1_or_more": n1, "stage2": n2, "budget": ESCALATION_BUDGET, "widen_cap": WIDEN_CAP, "cases": ESCALATIONS}, f, indent=1)
+    print(f"fuzz escalations: {n1} seed(s) beyond the base tolerance, {n2} needed the 48-trial spread; budget {ESCALATION_BUDGET}")
+    assert n1 <= ESCALATION_BUDGET[1], ESCALATIONS
+    assert n2 <= ESCALATION_BUDGET[2], ESCALATIONS

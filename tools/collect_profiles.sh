@@ -5,7 +5,8 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
-TAG="${1:-round 3}"
+RND=${CORBO_PROFILE_ROUND:-r04}
+TAG="${1:-round ${RND#r0}}"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; timeout 900 rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || echo "rocprofv3 $name failed ($?)"; }
@@ -28,21 +29,21 @@ run qfetch --pmc FETCH_SIZE -d "$OUT/qfetch" -o q --output-format csv -- python 
 run qwrite --pmc WRITE_SIZE -d "$OUT/qwrite" -o q --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3
 cd "$ROOT"
 P=$ROOT/profiles
-for n in bench sweep cfg5 loop; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/r03_${n}_kernel_stats.csv"; done
+for n in bench sweep cfg5 loop; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done
 python tools/summarize_pmc.py sweep "$(first sfetch '*counter_collection.csv')" "$(first swrite '*counter_collection.csv')" 1024 100 "$TAG, tools/profile_sweep.py 1024 10" | cut -c1-300
 python tools/summarize_pmc.py solve "$(first lfetch '*counter_collection.csv')" "$(first lwrite '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 10 --warmup 2" | cut -c1-300
 python tools/summarize_pmc.py sq "$(first sq1 '*counter_collection.csv')" "$(first sq2 '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 5 --warmup 1" | cut -c1-600
 python tools/summarize_pmc.py cfg5 "$(first qfetch '*counter_collection.csv')" "$(first qwrite '*counter_collection.csv')" 512 200 "$TAG, tools/profile_cfg5.py 512 3" | cut -c1-900
 python tools/summarize_pmc.py mfma "$(first mfma '*counter_collection.csv')" 512 200 "$TAG, tools/profile_cfg5.py 512 3" | cut -c1-900
-cp "$(first sfetch '*counter_collection.csv')" "$P/r03_sweep_pmc_fetch_counter_collection.csv"; cp "$(first swrite '*counter_collection.csv')" "$P/r03_sweep_pmc_write_counter_collection.csv"
+cp "$(first sfetch '*counter_collection.csv')" "$P/${RND}_sweep_pmc_fetch_counter_collection.csv"; cp "$(first swrite '*counter_collection.csv')" "$P/${RND}_sweep_pmc_write_counter_collection.csv"
 # ---- the bench lines of the same build on the same box (the profile-derived fields now resolve against the files above)
-python bench.py > "$P/r03_bench_line.json" 2> "$OUT/benchline3.err"
-python bench.py --config 5 > "$P/r03_bench_line_cfg5.json" 2> "$OUT/benchline5.err"
-python bench.py --config 2 > "$P/r03_bench_line_cfg2.json" 2> "$OUT/benchline2.err"
-python bench.py --config 1 > "$P/r03_bench_line_cfg1.json" 2> "$OUT/benchline1.err"
-mkdir -p "$OUT/profiles"; cp "$P"/r03_* "$P"/sweep_pmc_latest.json "$OUT/profiles/"
-head -3 "$P/r03_bench_kernel_stats.csv" | cut -c1-200; head -3 "$P/r03_sweep_kernel_stats.csv" | cut -c1-200; head -5 "$P/r03_cfg5_kernel_stats.csv" | cut -c1-200
+python bench.py > "$P/${RND}_bench_line.json" 2> "$OUT/benchline3.err"
+python bench.py --config 5 > "$P/${RND}_bench_line_cfg5.json" 2> "$OUT/benchline5.err"
+python bench.py --config 2 > "$P/${RND}_bench_line_cfg2.json" 2> "$OUT/benchline2.err"
+python bench.py --config 1 > "$P/${RND}_bench_line_cfg1.json" 2> "$OUT/benchline1.err"
+mkdir -p "$OUT/profiles"; cp "$P"/${RND}_* "$P"/sweep_pmc_latest.json "$OUT/profiles/"
+head -3 "$P/${RND}_bench_kernel_stats.csv" | cut -c1-200; head -3 "$P/${RND}_sweep_kernel_stats.csv" | cut -c1-200; head -5 "$P/${RND}_cfg5_kernel_stats.csv" | cut -c1-200
 for c in "" _cfg5 _cfg2 _cfg1; do python -c "
 import json,sys
-j=json.loads(open('$P/r03_bench_line$c.json').read().strip().splitlines()[-1])
+j=json.loads(open('$P/${RND}_bench_line$c.json').read().strip().splitlines()[-1])
 print('$c', j['value'], j['ms_per_step'], j.get('roofline',{}).get('frac'), j.get('cpu_baseline',{}).get('value'))"; done

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../control_box_rst_amd/csrc"
 name=${1:-dev}; shift || true
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-function -mllvm -disable-machine-licm"
+FLAGS="--offload-arch=gfx950 --offload-compress -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-function -mllvm -disable-machine-licm"
 /opt/rocm/bin/hipcc $FLAGS -DCORBO_HIP_DEV_FAST -DCORBO_HIP_DYN_TU=CORBO_HIP_DYN_UNICYCLE -DCORBO_HIP_DYN_TU_NAME=unicycle "$@" \
     -c kernels.hip -o /tmp/kernels_unicycle_$name.o -Rpass-analysis=kernel-resource-usage 2> /tmp/$name.remarks || { tail -30 /tmp/$name.remarks; exit 1; }
 grep -A9 "lm_pass_kernelILi2ELi3ELb0ELb1ELi101" /tmp/$name.remarks | grep -E "VGPRs|Scratch|SGPRs" | sed 's/.*remark: //' | tr '\n' ' '; echo
@@ -15,5 +15,5 @@ if [ -n "$MAIN" ]; then   # MAIN=1: also the main unit (model-independent kernel
     /opt/rocm/bin/hipcc $FLAGS -DCORBO_HIP_DYN_TU=CORBO_HIP_DYN_QUADROTOR -DCORBO_HIP_DYN_TU_NAME=quadrotor -DCORBO_HIP_DYN_TU_BIG "$@" -c kernels.hip -o /tmp/kernels_quad_$name.o
     objs=$(echo "$objs" | tr ' ' '\n' | grep -v "_obj/kernels.o" | grep -v "_obj/kernels_quadrotor.o"); objs="$objs /tmp/kernels_main_$name.o /tmp/kernels_quad_$name.o"
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libcorbo_hip_$name.so $objs /tmp/kernels_unicycle_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 --offload-compress -shared -fPIC -o libcorbo_hip_$name.so $objs /tmp/kernels_unicycle_$name.o
 echo "built libcorbo_hip_$name.so"

@@ -34,3 +34,7 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
     print(f"{name}: {len(seeds)} seeds, {n_bad} failed", flush=True)
 for b in bad:
     print("FAILED", b)
+esc = F.ESCALATIONS
+print(f"escalations: {sum(1 for e in esc if e['stage'] >= 1)} beyond the base tolerance, {sum(1 for e in esc if e['stage'] >= 2)} needed the 48-trial spread")
+for e in esc:
+    print("ESCALATED", e)

@@ -5,10 +5,10 @@ under-reports wide coalesced streaming reads by exactly 2x; both the raw and the
 uncalibrated there: recorded raw).
 
     python tools/summarize_pmc.py sweep <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/sweep_pmc_latest.json
-    python tools/summarize_pmc.py solve <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/r03_solve_pmc.json
-    python tools/summarize_pmc.py mfma  <counters.csv> <batch> <N> <tag>               -> profiles/r03_cfg5_mfma.json
-    python tools/summarize_pmc.py cfg5  <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/r03_cfg5_pmc.json
-    python tools/summarize_pmc.py sq    <counters.csv> [<counters2.csv>] <batch> <N> <tag> -> profiles/r03_solve_sq.json
+    python tools/summarize_pmc.py solve <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/<round>_solve_pmc.json
+    python tools/summarize_pmc.py mfma  <counters.csv> <batch> <N> <tag>               -> profiles/<round>_cfg5_mfma.json
+    python tools/summarize_pmc.py cfg5  <fetch.csv> <write.csv> <batch> <N> <tag>      -> profiles/<round>_cfg5_pmc.json
+    python tools/summarize_pmc.py sq    <counters.csv> [<counters2.csv>] <batch> <N> <tag> -> profiles/<round>_solve_sq.json
 """
 import collections
 import csv
@@ -17,6 +17,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = os.environ.get("CORBO_PROFILE_ROUND", "r04")   # file-name prefix of the round's summaries (<round> above)
 
 
 def per_dispatch(path, kernel_substr):
@@ -47,7 +48,7 @@ def traffic(kind, fetch_csv, write_csv, batch, N, tag):
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {tag}; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 "
                   "correction, WRITE_SIZE raw",
     }
-    name = "sweep_pmc_latest.json" if kind == "sweep" else "r03_solve_pmc.json"
+    name = "sweep_pmc_latest.json" if kind == "sweep" else RND + "_solve_pmc.json"
     json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     print(json.dumps(out))
 
@@ -70,7 +71,7 @@ def cfg5_traffic(fetch_csv, write_csv, batch, N, tag):
     out["hbm_bytes_per_launch_raw"], out["hbm_bytes_per_launch"] = tot_raw, tot
     out["source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {tag}; per-dispatch means over the full launches of each kernel, summed over "
                      "the pair; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction, WRITE_SIZE raw")
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_cfg5_pmc.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "" + RND + "_cfg5_pmc.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
@@ -89,7 +90,7 @@ def mfma(path, batch, N, tag):
             d["mfma_busy_fraction_of_sq_busy"] = mbusy / busy
         out["kernels"][kernel] = d
     out["source"] = f"rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU, {tag}; per-dispatch means over the full launches"
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_cfg5_mfma.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "" + RND + "_cfg5_mfma.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
@@ -106,7 +107,7 @@ def sq(paths, batch, N, tag):
             if c.get(k) is not None:
                 out.setdefault("fraction_of_wave_cycles", {})[k] = c[k] / c["SQ_WAVE_CYCLES"]
     out["source"] = f"rocprofv3 --pmc (two SQ passes), {tag}; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_solve_sq.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "" + RND + "_solve_sq.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
