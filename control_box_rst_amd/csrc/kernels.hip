@@ -118,6 +118,30 @@ __device__ __forceinline__ void lm_state_out(LmState* sg, const LmState* sl, int
 // ---------------------------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 
+// Two-wave shape of the run-to-completion kernel: what lane k's factor phase needs from the residual paired with the resident Jacobian -- the
+// single-entry rows of block k's components (values + Jacobian entries) and defect k's residual -- stays in lane k's REGISTERS from the sweep
+// phase that evaluated it (the stage-centric component pass and the defect loop run in the same lane) until the next accepted step replaces it:
+// the same rule as the flip of the two residual buffers in HBM (LmState::vbuf), without the round trip through them.
+template <int NX, int NU>
+struct StageKeep {
+    double vc[NX + NU], ac[NX + NU], vb[NX + NU], ab[NX + NU], r[NX];
+};
+
+// The single-entry rows of ONE vertex component exactly as the edges define them (contraction off: the same IEEE operations wherever this
+// is evaluated): cost value w (x - ref) with its central-difference Jacobian entry (edge_interface.cpp:55-96, delta = 1e-9), distance to the
+// box bounds times w_b (hyper_graph_optimization_problem_base.cpp:291-315) with its entry -w_b / 0 / +w_b (:1721-1752).  The two-wave shape of
+// the run-to-completion kernel evaluates these rows where they are consumed -- chi2 in the sweep phase, H and rhs in the factor phase -- and
+// never moves them through memory.
+__device__ __forceinline__ void diagonal_rows(double xv, double w, double ref, double lo, double up, double w_b, double& val, double& dv, double& bval, double& bent)
+{
+    constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
+    val = w * (xv - ref);
+    const double a = xv + delta, b = a + neg2delta;
+    dv   = scalar * (w * (a - ref) - w * (b - ref));
+    bval = fmax(fmax(lo - xv, xv - up), 0.0) * w_b;   // (lo <= up: at most one of the two distances is positive)
+    bent = (((xv > up) ? 1.0 : 0.0) - ((xv < lo) ? 1.0 : 0.0)) * w_b;
+}
+
 #define SWEEP_STAMP(id)                                                     \
     do {                                                                    \
         if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); \
@@ -155,7 +179,8 @@ __device__ __forceinline__ double dense_weight_row(const double* U, int c, int d
 // finite_differences_variable_grid.h:82): the Jacobian of such an instance does not fit the LDS staging area, its entries go straight
 // to HBM like the big-block family's (STAGE = false).  Stand-alone kernels only.
 template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS>
-__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false)
+__device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false,
+                                           StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -367,10 +392,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     // a load issued behind stores waits for the stores' acknowledgements as well (one memory round trip per round: 7.4 k cycles for the
     // four rounds of the headline instance, measured with the phase stamps).
     constexpr bool SC = (THREADS <= 128) && !DENSE && !LONG;
+    constexpr bool LEAN = SC && FUSED;   // the diagonal rows of the stage blocks' components are not stored: they reach the factor phase in registers
+    StageKeep<NX, NU> kt;                // (LEAN) this evaluation's rows; they become *keep when the step is accepted and the Jacobian refreshed
     if constexpr (SC) {
         // regular slots: lane k < N - 1, slot e of block k (e < NX: state component e, else control component e - NX);
         // special slots: lane N + j -- j < NX the component j of x_f (final cost / terminal equality), j = NX the dt component
         const int kb     = tid;
+        const bool isfin = (kb == p.N - 1);
         const bool reg   = (kb < p.N - 1);
         const int js     = kb - p.N;
         const bool spec  = (js >= 0 && js <= NX);
@@ -379,7 +407,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         double lo[S], up[S], rv[NX];
 #pragma unroll
         for (int e = 0; e < S; ++e) {   // (clamped, branch-free: an absent slot fetches component 0 and is ignored; slot 0 of a special lane: its component)
-            const int vc = reg ? kb * S + e : ((spec && e == 0) ? vspec : 0);
+            const bool on = reg || (isfin && e < NX);   // (the last block: x_f, no controls)
+            const int vc = on ? kb * S + e : ((spec && e == 0) ? vspec : 0);
             cA[e] = comp4[2 * vc]; cB[e] = comp4[2 * vc + 1]; lo[e] = p.lb[xo + vc]; up[e] = p.ub[xo + vc];
         }
 #pragma unroll
@@ -387,7 +416,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         double rspec = 0.0;
         if (p.refvec) {
 #pragma unroll
-            for (int e = 0; e < NX; ++e) rv[e] = p.refvec[xo + (reg ? kb * S + e : 0)];
+            for (int e = 0; e < NX; ++e) rv[e] = p.refvec[xo + ((reg || isfin) ? kb * S + e : 0)];
             rspec = p.refvec[xo + ((spec && js < NX) ? vspec : 0)];
         }
         if constexpr (CACHED) {  // state-only part of the dynamics, once per grid state
@@ -403,30 +432,32 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         for (int e = 0; e < S; ++e) {
             constexpr double zero = 0.0;
             const bool is_u   = (e >= NX);
-            const double w    = is_u ? p.mp.sr[is_u ? e - NX : 0] : p.mp.sq[is_u ? 0 : e];   // (compile-time slot: scalar operands)
+            const bool on     = reg || (isfin && !is_u);
+            const double w    = is_u ? p.mp.sr[is_u ? e - NX : 0] : (isfin ? p.mp.sqf[is_u ? 0 : e] : p.mp.sq[is_u ? 0 : e]);   // (compile-time slot: scalar operands)
             const double ref  = is_u ? zero : rv[is_u ? 0 : e];
             const int c       = is_u ? e - NX : e;
             const int dim     = is_u ? NU : NX;
-            const double xv   = xs[reg ? kb * S + e : 0];
+            const double xv   = xs[on ? kb * S + e : 0];
             const int fixed = cA[e].x, cost_joff = cA[e].z, cost_row = cA[e].w, bnd_joff = cB[e].x, bnd_row = cB[e].y;
-            const double val  = w * (xv - ref);
-            // (branch-free forms of the bound row -- lo <= up: at most one of the two distances is positive -- and of its Jacobian entry below)
-            const double bval = fmax(fmax(lo[e] - xv, xv - up[e]), 0.0) * p.w_b;
-            const bool pc = reg && cost_row >= 0, pb = reg && bnd_row >= 0;
-            if (pc) put_value(cost_row, val);
-            if (pb) put_value(bnd_row, bval);
+            double val, dv, bval, bent;
+            diagonal_rows(xv, w, ref, lo[e], up[e], p.w_b, val, dv, bval, bent);
+            const bool pc = on && cost_row >= 0, pb = on && bnd_row >= 0;
             sq_acc += (pc ? val * val : 0.0) + (pb ? bval * bval : 0.0);
-            if (jac_with_values) {
-                const double a = xv + delta, b = a + neg2delta;
-                const double dv = scalar * (w * (a - ref) - w * (b - ref));   // central difference of the diagonal cost block (edge_interface.cpp:55-96)
-                if (reg && !fixed && cost_joff >= 0) {
-                    const int col0 = cost_joff - c;
+            if constexpr (LEAN) { kt.vc[e] = val; kt.ac[e] = dv; kt.vb[e] = bval; kt.ab[e] = bent; }   // handed to the factor phase in registers (below)
+            else {
+                if (pc) put_value(cost_row, val);
+                if (pb) put_value(bnd_row, bval);
+                if (jac_with_values) {
+                    if (on && !fixed && cost_joff >= 0) {
+                        const int col0 = cost_joff - c;
 #pragma unroll
-                    for (int r = 0; r < DM; ++r)
-                        if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;   // untouched rows: scalar * (e - e) = 0
+                        for (int r = 0; r < DM; ++r)
+                            if (r < dim) jst[col0 + r] = (r == c) ? dv : 0.0;   // untouched rows: scalar * (e - e) = 0
+                    }
+                    if (on && bnd_joff >= 0) jst[bnd_joff] = bent;
                 }
-                if (reg && bnd_joff >= 0) jst[bnd_joff] = (((xv > up[e]) ? 1.0 : 0.0) - ((xv < lo[e]) ? 1.0 : 0.0)) * p.w_b;  // -w_b / 0 / +w_b, :1721-1752
             }
+            (void)fixed; (void)cost_joff; (void)bnd_joff; (void)c; (void)dim;
         }
         if (spec) {   // the x_f components and dt: every row kind a component can carry (second rows: terminal equality, duplicated dt edge)
             const bool fin = (js < NX);
@@ -439,18 +470,18 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             if (p.refvec && fin) reff = rspec;
             const CompInfo ci{cA[0].x, cA[0].y, cA[0].z, cA[0].w, cB[0].x, cB[0].y, cB[0].z, cB[0].w};
             const double xv = xs[vspec];
-            if (ci.cost_row >= 0) {
+            if (!fin && ci.cost_row >= 0) {   // (the x_f components' cost and bound rows: the regular slots of lane N - 1)
                 const double val = wf * (xv - reff);
                 put_value(ci.cost_row, val);
                 sq_acc += val * val;
-                if (!fin && ci.cost2_row >= 0) { put_value(ci.cost2_row, val); sq_acc += val * val; }
+                if (ci.cost2_row >= 0) { put_value(ci.cost2_row, val); sq_acc += val * val; }
             }
             if (fin && ci.cost2_row >= 0) {   // TerminalEqualityConstraint row (equality section: times w_eq)
                 const double val = (xv - reff) * p.w_eq;
                 put_value(ci.cost2_row, val);
                 sq_acc += val * val;
             }
-            if (ci.bnd_row >= 0) {
+            if (!fin && ci.bnd_row >= 0) {
                 double val = (xv < lo[0]) ? lo[0] - xv : ((xv > up[0]) ? xv - up[0] : 0.0);
                 val *= p.w_b;
                 put_value(ci.bnd_row, val);
@@ -549,8 +580,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double val = e[i] * p.w_eq;
-            put_value(p.eq_row0 + k * NX + i, val);
+            put_value(p.eq_row0 + k * NX + i, val);   // (LEAN: still stored -- the one-pass-per-launch mode picks the rows up from HBM in the next launch)
             sq_acc += val * val;
+            if constexpr (LEAN) kt.r[i] = val;
         }
         if constexpr (NX >= 3) {
             if (p.ineq_cols) {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
@@ -657,6 +689,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
     SWEEP_STAMP(4);
+    if constexpr (LEAN) {
+        if (keep && do_jac) *keep = kt;   // the residual just evaluated pairs with the Jacobian about to be written (like LmState::vbuf ^= 1)
+    }
     if (!do_jac || (p.skip_jac && mode >= 2)) return;
 
     // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753),
@@ -1271,8 +1306,13 @@ __device__ __noinline__ void dense_cost_terms(const StageCols*, const CompInfo* 
 // GWS: the factor workspace (`smem`) is a per-instance array in HBM instead of LDS, and the Jacobian is read from HBM in place -- the
 // long-horizon variant (256 < N <= 1024, one lane per stage in a 1024-thread workgroup; 45 N doubles do not fit 160 KB of LDS then).
 // Same code, the barriers become full workgroup barriers (global memory crosses them).
-template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false>
-__device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr)
+// RECOMP (two-wave shape of the run-to-completion kernel; `sq` = the launch's sweep parameters): the single-entry rows of the lane's components
+// -- cost and bound values and their Jacobian entries -- are re-evaluated from the accepted iterate (diagonal_rows, the very function the sweep
+// phase sums chi2 with) instead of being fetched: the sweep phase does not store them, and the load phase loses its dependent round trip
+// (table entry -> residual row).
+template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false, bool RECOMP = false>
+__device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr, const SweepParams* const sq = nullptr,
+                                            const StageKeep<NX, NU>* const keep = nullptr, const bool keep_valid = false)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
@@ -1347,10 +1387,37 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     }
     // (2) residual entries
     double r[NX], vc[S], vb[S], rin;
+    double acr[S], abr[S];   // RECOMP: the Jacobian entries of the same rows
+    double xk[S];            // the accepted iterate of this lane's stage (RECOMP: needed here; otherwise requested before the back-substitution)
 #pragma unroll
-    for (int i = 0; i < NX; ++i) r[i] = val[has_stage ? p.eq_row0 + k * NX + i : 0];
+    for (int i = 0; i < NX; ++i) r[i] = (RECOMP && keep_valid) ? keep->r[i] : val[has_stage ? p.eq_row0 + k * NX + i : 0];
+    if (RECOMP && keep_valid) {   // the rows lane k's own sweep phase evaluated (run to completion: always; one pass per launch: after an accepted step)
 #pragma unroll
-    for (int e = 0; e < S; ++e) { vc[e] = val[cj[e] >= 0 ? cr[e] : 0]; vb[e] = val[bj[e] >= 0 ? br[e] : 0]; }
+        for (int e = 0; e < S; ++e) { vc[e] = keep->vc[e]; acr[e] = keep->ac[e]; vb[e] = keep->vb[e]; abr[e] = keep->ab[e]; }
+    }
+    else if constexpr (RECOMP) {
+        const SweepParams& q = *sq;
+        const size_t xo = (size_t)inst * p.nvs;
+        double lo[S], up[S], rf[NX];
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const int v = ((e < NX) ? has_block : has_stage) ? k * S + e : 0;
+            xk[e] = xin[v]; lo[e] = q.lb[xo + v]; up[e] = q.ub[xo + v];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rf[i] = q.refvec ? q.refvec[xo + (has_block ? k * S + i : 0)] : q.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
+        const bool lastb = (k == N - 1);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const bool is_u = (e >= NX);
+            const double w  = is_u ? q.mp.sr[is_u ? e - NX : 0] : (lastb ? q.mp.sqf[is_u ? 0 : e] : q.mp.sq[is_u ? 0 : e]);
+            diagonal_rows(xk[e], w, is_u ? 0.0 : rf[is_u ? 0 : e], lo[e], up[e], q.w_b, vc[e], acr[e], vb[e], abr[e]);
+        }
+    }
+    else {
+#pragma unroll
+        for (int e = 0; e < S; ++e) { vc[e] = val[cj[e] >= 0 ? cr[e] : 0]; vb[e] = val[bj[e] >= 0 ? br[e] : 0]; }
+    }
     rin = val[iq_row >= 0 ? iq_row : 0];
     if (iq_row < 0) rin = 0.0;
     if (!has_stage) {
@@ -1365,7 +1432,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const int n2       = p.nnz_pad / 2;
         // loads in flight per lane (8 costs 3 % of a solve at the 128-VGPR budget) (branch-free: indices are clamped, the duplicates are harmless);
         // the two-wave shape of the run-to-completion kernel has the registers for the whole headline Jacobian in ONE round trip (17 x 128 x 16 bytes)
-        constexpr int UNR  = 4;   // (17 -- the whole headline Jacobian in one round trip of the two-wave shape -- was measured: 5.2 k -> 7.2 k cycles alone, 14 k+ under load)
+        constexpr int UNR  = (THREADS <= 128) ? 8 : 4;   // (17 -- the whole headline Jacobian in one round trip of the two-wave shape -- was measured: 5.2 k -> 7.2 k cycles alone, 14 k+ under load)
         for (int i0 = tid; i0 < n2; i0 += THREADS * UNR) {
             double2 v[UNR];
 #pragma unroll
@@ -1405,7 +1472,9 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     double du_diag[NU], gu[NU], dx_diag[NX], gx[NX];
 #pragma unroll
     for (int e = 0; e < S; ++e) {
-        double ac = J[cj[e] >= 0 ? cj[e] : 0], ab = J[bj[e] >= 0 ? bj[e] : 0];
+        double ac, ab;
+        if constexpr (RECOMP) { ac = acr[e]; ab = abr[e]; }
+        else { ac = J[cj[e] >= 0 ? cj[e] : 0]; ab = J[bj[e] >= 0 ? bj[e] : 0]; }
         if (cj[e] < 0 || ((e < NX) ? wd_x : wd_u)) ac = 0.0;
         if (bj[e] < 0) ab = 0.0;
         const double dd = ac * ac + ab * ab, gg = -(ac * vc[e]) - ab * vb[e];
@@ -1847,9 +1916,11 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     }
     STAMP(5);
     // the accepted iterate of this lane's stage (for x + delta below): requested now, the back-substitution hides the latency
-    double xk[S], xdt = 0.0;
+    double xdt = 0.0;
+    if (!RECOMP || keep_valid) {
 #pragma unroll
-    for (int e = 0; e < S; ++e) xk[e] = ((e < NX) ? has_block : has_stage) ? xin[k * S + e] : 0.0;
+        for (int e = 0; e < S; ++e) xk[e] = ((e < NX) ? has_block : has_stage) ? xin[k * S + e] : 0.0;
+    }
     if (tid == 0) xdt = xin[p.off_dt];
     // ---- back-substitution down the elimination tree.  Four lanes per block again: lane q forms row q of
     //      v = y - W_a x_a - W_b x_b, the three (two) numbers are broadcast inside the quad with DPP moves, every lane solves
@@ -3313,6 +3384,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
             __syncthreads();
             int mode = ((const SweepParams&)ka->s).mode;
             const int max_passes = ((const FactorParams&)ka->f).loop_passes;
+            StageKeep<Dy::NX, Dy::NU> keep;   // (two-wave shape) the residual rows paired with the resident Jacobian, in registers across the passes
 #pragma nounroll
             for (int pass = 0; pass <= max_passes; ++pass) {
                 asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");  // nothing derived from them is carried around the loop
@@ -3334,7 +3406,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                         }
                     }
                 }
-                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);   // (active_count: per-pass launches only)
+                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep);   // (active_count: per-pass launches only)
                 __threadfence_block();
                 __syncthreads();
                 if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
@@ -3371,7 +3443,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 }
                 // (loop_passes = 0: ONE pass per launch -- the per-pass mode of corbo_hip_solve and the profiling mode; the trial iterate then
                 //  goes to HBM for the next launch instead of staying in the LDS array the next sweep phase evaluates it from)
-                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, max_passes > 0 ? xs : nullptr);
+                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, false, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || flags[0] != 0);
                 if constexpr (BK_DEFER) { if (bk_slot >= 0) bk_rank(); }
                 __threadfence_block();
                 __syncthreads();
