@@ -24,6 +24,9 @@ COST_NONE, COST_QUADRATIC_LSQ, COST_MIN_TIME_LSQ = 0, 1, 2
 COST_MIN_TIME_QUADRATIC_LSQ = 3   # MinTimeQuadratic(Q, R, integral=False, lsq=True): state, control and minimum-time terms
 INEQ_NONE, INEQ_BALL = 0, 1
 FINAL_INEQ_NONE, FINAL_INEQ_TERMINAL_BALL = 0, 1
+RULE_TRAPEZOIDAL, RULE_LEFT_SUM = 1, 2         # constraint_integration (corbo_hip.h)
+STAGE_EQ_NONE, STAGE_EQ_LINEAR = 0, 1
+CTRL_DEV_NONE, CTRL_DEV_RATE = 0, 1
 SOLVER_CONVERGED, SOLVER_EARLY_TERMINATED, SOLVER_INFEASIBLE, SOLVER_ERROR = 0, 1, 2, 3
 
 
@@ -43,6 +46,8 @@ class ProblemDesc(C.Structure):
         ("quad_first_interval", C.c_int32), ("cost_nonlsq", C.c_int32),
         ("cost_integral", C.c_int32), ("weights_dense", C.c_int32), ("shooting_integrator", C.c_int32), ("final_eq_mask", C.c_uint32),
         ("q_sqrt", C.c_double * 16), ("r_sqrt", C.c_double * 16), ("qf_sqrt", C.c_double * 16),
+        ("constraint_integration", C.c_int32), ("stage_ineq_integral", C.c_int32), ("stage_eq", C.c_int32), ("ctrl_dev", C.c_int32),
+        ("stage_eq_params", C.c_double * (MAX_NX + MAX_NU + 1)), ("ctrl_dev_params", C.c_double * MAX_NU),
     ]
 
 
@@ -96,7 +101,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
     "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_eval_hessians_views", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
-    "corbo_hip_sizeof",
+    "corbo_hip_sizeof", "corbo_hip_set_previous_control",
 )
 
 

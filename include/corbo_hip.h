@@ -196,7 +196,38 @@ typedef struct corbo_hip_problem_desc {
     double q_sqrt[16];
     double r_sqrt[16];
     double qf_sqrt[16];
+    /* ---- Integral-form constraints and the control-deviation term (FiniteDifferencesGrid / FiniteDifferencesVariableGrid,
+     * families with nx <= 4, horizons up to 256 grid points).  The reference creates these edges from USER stage functions only (no stock
+     * class has such terms); the device knows the plug-in functions named here.
+     * constraint_integration: the grid's integration rule for them (FullDiscretizationGridBase::CostIntegrationRule; the same member that
+     *   integrates an integral cost): 1 = TrapezoidalRule, 2 = LeftSum (finite_differences_grid.cpp:80-125); required with stage_ineq_integral / stage_eq.
+     * stage_ineq_integral = 1: stage_ineq is the stage inequalities' INTEGRAL state-control term c(x, u) (getIntegralStateControlTermDimension = 1)
+     *   instead of their non-integral state term: one TrapezoidalIntegralInequalityEdge on (x_k, u_k, x_{k+1}, dt), 0.5 dt (c(x_k, u_k) + c(x_{k+1}, u_k)),
+     *   or one LeftSumInequalityEdge on (x_k, u_k, dt), c(x_k, u_k) dt, per interval (finite_differences_collocation_edges.h:271-321, 412-459).
+     * stage_eq: corbo_hip_stage_eq, the stage equalities' integral state-control term e(x, u) (one row).  TrapezoidalRule: the row is APPENDED to the
+     *   interval's dynamics edge (TrapezoidalIntegralEqualityDynamicsEdge, :149-216: dimension nx + 1); LeftSum: a LeftSumEqualityEdge on (x_k, u_k, dt)
+     *   in front of the dynamics edge (:368-410).
+     * ctrl_dev: corbo_hip_ctrl_dev, the stage inequalities' control-deviation term (getNonIntegralControlDeviationTermDimension = nu): one
+     *   TernaryVectorScalarVertexEdge per interval on (u_k, u_{k-1}, dt) -- k = 0: on (u_0, the previously applied control, its age), both fixed,
+     *   corbo_hip_set_previous_control -- and one behind the final-stage edges on (u_ref = 0, u_{N-2}, dt) (nlp_functions.cpp:117-131, 152-186,
+     *   finite_differences_grid.cpp:145-153).  It couples the controls of neighbouring intervals.
+     * Handles with any of these run the LM pass as separate launches with the band factorisation (band_factor_kernel), not the fused kernels. */
+    int32_t constraint_integration;
+    int32_t stage_ineq_integral;
+    int32_t stage_eq;
+    int32_t ctrl_dev;
+    double stage_eq_params[CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NU + 1];   /* CORBO_HIP_STAGE_EQ_LINEAR: a_1 .. a_nx, b_1 .. b_nu, c */
+    double ctrl_dev_params[CORBO_HIP_MAX_NU];                          /* CORBO_HIP_CTRL_DEV_RATE: r_max per control */
 } corbo_hip_problem_desc;
+
+typedef enum corbo_hip_stage_eq {
+    CORBO_HIP_STAGE_EQ_NONE   = 0,
+    CORBO_HIP_STAGE_EQ_LINEAR = 1   /* e(x, u) = a^T x + b^T u - c (summed left to right: the x terms, then the u terms, then - c) */
+} corbo_hip_stage_eq;
+typedef enum corbo_hip_ctrl_dev {
+    CORBO_HIP_CTRL_DEV_NONE = 0,
+    CORBO_HIP_CTRL_DEV_RATE = 1     /* row i: ((u_k[i] - u_prev[i]) / dt_prev)^2 - r_max[i]^2 <= 0 (an input-rate limit) */
+} corbo_hip_ctrl_dev;
 
 /* Sizes derived from a descriptor (corbo_hip_get_dims). */
 typedef struct corbo_hip_dims {
@@ -271,6 +302,12 @@ void corbo_hip_destroy(corbo_hip_handle h);
  * The caller's arrays are plain host memory and are free again when the call returns: they are repacked into a pinned staging
  * buffer owned by the handle and copied on the handle's stream. */
 int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const double* lb, const double* ub, const double* xref);
+
+/* The previously applied control and its age, per instance (StructuredOptimalControlProblem::setPreviousControlInput,
+ * structured_optimal_control_problem.h:73-79; the fixed vertices _u_prev / _u_prev_dt of the grid, full_discretization_grid_base.cpp:66-70): what the
+ * control-deviation edge of interval 0 sees (corbo_hip_problem_desc::ctrl_dev).  u_prev [batch][nu], dt_prev [batch]; NULL = zeros resp. the
+ * descriptor's dt_ref (the reference's defaults, structured_optimal_control_problem.cpp:67-71). */
+int corbo_hip_set_previous_control(corbo_hip_handle h, const double* u_prev, const double* dt_prev);
 
 
 /* Time-varying state reference (what ReferenceTrajectoryInterface::getReferenceCached(k) hands the cost and final-stage terms,

@@ -29,7 +29,10 @@ typedef struct {
 } o_vertex;
 
 enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_INEQ, E_FINAL_INEQ, E_FINAL_EQ, E_INTEGRAL_COST,
-       E_MS_MIXED_OBJ, E_MS_MIXED_EQ }; /* the objective part and the equality part of one MultipleShootingEdgeSingleControl (a BaseMixedEdge) */
+       E_MS_MIXED_OBJ, E_MS_MIXED_EQ, /* the objective part and the equality part of one MultipleShootingEdgeSingleControl (a BaseMixedEdge) */
+       E_INT_INEQ,     /* TrapezoidalIntegralInequalityEdge (x1, u1, x2, dt) / LeftSumInequalityEdge (x1, u1, dt) */
+       E_INT_EQ_LEFT,  /* LeftSumEqualityEdge (x1, u1, dt); the trapezoidal rule appends its row to the dynamics edge instead (E_DEFECT with dim = nx + 1) */
+       E_CTRL_DEV };   /* TernaryVectorScalarVertexEdge<computeNonIntegralControlDeviationTerm> (u_k, u_prev, dt_prev) */
 
 typedef struct {
     int type;
@@ -372,6 +375,20 @@ static void dense_weight_times(const double* U, int n, const double* xd, double*
     }
 }
 
+/* the plug-in stage functions (user classes in the reference; oracle/ref_driver.cpp UserStageInequalities / LinearIntegralEquality) */
+static double stage_ineq_value(const corbo_hip_problem_desc* d, const double* xk) /* keep-out ball: r^2 - |pos - c|^2 */
+{
+    double dx = xk[0] - d->ineq_params[0], dy = xk[1] - d->ineq_params[1], dz = xk[2] - d->ineq_params[2];
+    return d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
+}
+static double stage_eq_value(const corbo_hip_problem_desc* d, const double* xk, const double* uk) /* a^T x + b^T u - c, summed left to right */
+{
+    double acc = 0.0;
+    for (int i = 0; i < d->nx; ++i) acc += d->stage_eq_params[i] * xk[i];
+    for (int i = 0; i < d->nu; ++i) acc += d->stage_eq_params[d->nx + i] * uk[i];
+    return acc - d->stage_eq_params[d->nx + d->nu];
+}
+
 static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
 {
     const corbo_hip_problem_desc* d = &p->d;
@@ -476,12 +493,40 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             const double* x2 = x + p->v[e->vert[2]].off;
             double dt        = x[p->v[e->vert[3]].off];
             defect_values(p, x1, u1, x2, dt, out);
+            if (e->dim > d->nx) { /* TrapezoidalIntegralEqualityDynamicsEdge (:149-216): values.tail = 0.5 * dt * (e(x1, u1) + e(x2, u1)) */
+                const double e1 = stage_eq_value(d, x1, u1), e2 = stage_eq_value(d, x2, u1);
+                out[d->nx] = 0.5 * dt * (e1 + e2);
+            }
             break;
         }
         case E_STAGE_INEQ: { /* user StageInequalityConstraint (state term), keep-out ball: c = r^2 - |pos - c|^2 <= 0 */
             const double* xk = x + p->v[e->vert[0]].off;
             double dx = xk[0] - d->ineq_params[0], dy = xk[1] - d->ineq_params[1], dz = xk[2] - d->ineq_params[2];
             out[0] = d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
+            break;
+        }
+        case E_INT_INEQ: { /* finite_differences_collocation_edges.h:271-321 (0.5 * dt * (c1 + c2), both ends with u1) / :412-459 (c1, then *= dt) */
+            const double* x1 = x + p->v[e->vert[0]].off;
+            const int trap   = (e->nverts == 4);
+            const double dt  = x[p->v[e->vert[trap ? 3 : 2]].off];
+            const double c1  = stage_ineq_value(d, x1);
+            if (trap) { const double c2 = stage_ineq_value(d, x + p->v[e->vert[2]].off); out[0] = 0.5 * dt * (c1 + c2); }
+            else { out[0] = c1; out[0] *= dt; }
+            break;
+        }
+        case E_INT_EQ_LEFT: { /* LeftSumEqualityEdge::computeValues (:368-410): e(x1, u1), then *= dt */
+            out[0] = stage_eq_value(d, x + p->v[e->vert[0]].off, x + p->v[e->vert[1]].off);
+            out[0] *= x[p->v[e->vert[2]].off];
+            break;
+        }
+        case E_CTRL_DEV: { /* user computeNonIntegralControlDeviationTerm(k, u_k, u_prev, dt_prev): ((u_k - u_prev) / dt_prev)^2 - r_max^2 per control */
+            const double* uk = x + p->v[e->vert[0]].off;
+            const double* up = x + p->v[e->vert[1]].off;
+            const double dtp = x[p->v[e->vert[2]].off];
+            for (int i = 0; i < d->nu; ++i) {
+                const double dd = (uk[i] - up[i]) / dtp;
+                out[i] = dd * dd - d->ctrl_dev_params[i] * d->ctrl_dev_params[i];
+            }
             break;
         }
         case E_FINAL_EQ: { /* TerminalEqualityConstraint::computeNonIntegralStateTerm (final_state_constraints.h:149-154): x_k - xref */
@@ -584,6 +629,18 @@ static int validate(const corbo_hip_problem_desc* d)
     return 1;
 }
 
+/* integral-form constraints / control-deviation term: FiniteDifferencesGrid and FiniteDifferencesVariableGrid, least-squares problems */
+static int validate_extra(const corbo_hip_problem_desc* d)
+{
+    const int any = d->stage_ineq_integral || d->stage_eq || d->ctrl_dev;
+    if (d->constraint_integration < 0 || d->constraint_integration > 2) return 0;
+    if (d->stage_ineq_integral && (d->stage_ineq != CORBO_HIP_INEQ_BALL || !d->constraint_integration)) return 0;
+    if (d->stage_eq && (d->stage_eq != CORBO_HIP_STAGE_EQ_LINEAR || !d->constraint_integration)) return 0;
+    if (d->ctrl_dev && d->ctrl_dev != CORBO_HIP_CTRL_DEV_RATE) return 0;
+    if (any && (d->grid == CORBO_HIP_GRID_MS || d->grid == CORBO_HIP_GRID_MS_VARIABLE || d->cost_nonlsq || d->cost_integral || d->N < 3)) return 0;
+    return 1;
+}
+
 static int dt_is_free(const corbo_hip_problem_desc* d) { return d->grid == CORBO_HIP_GRID_FD_VARIABLE || d->grid == CORBO_HIP_GRID_MS_VARIABLE; }
 
 /* static row-wise view of J, envelope of H = J^T J and the LM work space (needs dims and the structure) */
@@ -638,7 +695,7 @@ static void finish_linear_algebra_setup(oracle_problem* p)
 
 oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
 {
-    if (!validate(desc)) return NULL;
+    if (!validate(desc) || !validate_extra(desc)) return NULL;
     oracle_problem* p = (oracle_problem*)calloc(1, sizeof(oracle_problem));
     p->d              = *desc;
     const corbo_hip_problem_desc* d = &p->d;
@@ -646,9 +703,15 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     int free_dt = dt_is_free(d);
 
     /* ---- vertices: x_0 u_0 | ... | x_{N-2} u_{N-2} | x_f | dt   (full_discretization_grid_base.cpp:134-179) */
-    p->n_vertices = 2 * (N - 1) + 2;
+    /* + the grid's always-fixed vertices _u_prev, _u_ref, _u_prev_dt (full_discretization_grid_base.cpp:509-511), stored behind dt */
+    p->n_vertices = 2 * (N - 1) + 2 + 3;
     p->v          = (o_vertex*)calloc(p->n_vertices, sizeof(o_vertex));
     int nv = (N - 1) * s + nx + 1; /* storage always holds dt (fixed dt: not part of the public vertex layout) */
+    const int v_uprev = 2 * (N - 1) + 2, v_uref = v_uprev + 1, v_uprev_dt = v_uprev + 2;
+    p->v[v_uprev].off = nv;             p->v[v_uprev].dim = nu;  p->v[v_uprev].fixed = (1u << nu) - 1;
+    p->v[v_uref].off = nv + nu;         p->v[v_uref].dim = nu;   p->v[v_uref].fixed = (1u << nu) - 1;
+    p->v[v_uprev_dt].off = nv + 2 * nu; p->v[v_uprev_dt].dim = 1; p->v[v_uprev_dt].fixed = 1;
+    const int nv_store = nv + 2 * nu + 1;
     for (int k = 0; k < N - 1; ++k) {
         o_vertex* xv = &p->v[2 * k];
         o_vertex* uv = &p->v[2 * k + 1];
@@ -671,10 +734,11 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     }
     int n = col;
 
-    p->x      = (double*)calloc(nv, sizeof(double));
-    p->lb     = (double*)calloc(nv, sizeof(double));
-    p->ub     = (double*)calloc(nv, sizeof(double));
-    p->backup = (double*)calloc(nv, sizeof(double));
+    p->x      = (double*)calloc(nv_store, sizeof(double));
+    p->lb     = (double*)calloc(nv_store, sizeof(double));
+    p->ub     = (double*)calloc(nv_store, sizeof(double));
+    p->backup = (double*)calloc(nv_store, sizeof(double));
+    p->x[nv + 2 * nu] = d->dt_ref; /* _u_prev = 0, _u_prev_dt = grid->getInitialDt() (structured_optimal_control_problem.cpp:67-71); _u_ref = uref = 0 */
     p->xref   = (double*)calloc(nx, sizeof(double));
     for (int i = 0; i < nx; ++i) { p->sq[i] = sqrt(d->q_diag[i]); p->sqf[i] = sqrt(d->qf_diag[i]); } /* quadratic_cost.cpp:59-67 */
     for (int i = 0; i < nu; ++i) p->sr[i] = sqrt(d->r_diag[i]);
@@ -727,11 +791,27 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
                 o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0; e->nonlsq = d->cost_nonlsq;
             }
         }
-        if (d->stage_ineq == CORBO_HIP_INEQ_BALL) {
+        if (d->stage_ineq == CORBO_HIP_INEQ_BALL && !d->stage_ineq_integral) {
             o_edge* e = &ineq[n_ineq++]; e->type = E_STAGE_INEQ; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = 1; e->scale = 2;
+        }
+        if (d->ctrl_dev) { /* nlp_functions.cpp:117-123 (behind the state term of the same stage function): (u_k, u_prev, dt_prev);
+                            * finite_differences_grid.cpp:51-53: u_prev = k > 0 ? u_seq[k-1] : _u_prev, dt_prev = k > 0 ? _dt : _u_prev_dt */
+            o_edge* e = &ineq[n_ineq++]; e->type = E_CTRL_DEV; e->k = k; e->nverts = 3; e->dim = nu; e->scale = 2;
+            e->vert[0] = uk; e->vert[1] = (k > 0) ? 2 * (k - 1) + 1 : v_uprev; e->vert[2] = (k > 0) ? dt_vertex : v_uprev_dt;
+        }
+        if (d->stage_eq && d->constraint_integration == 2) { /* finite_differences_grid.cpp:89-98: LeftSumEqualityEdge, then the system dynamics edge */
+            o_edge* e = &eq[n_eq++]; e->type = E_INT_EQ_LEFT; e->k = k; e->nverts = 3; e->dim = 1; e->scale = 1;
+            e->vert[0] = xk; e->vert[1] = uk; e->vert[2] = dt_vertex;
         }
         o_edge* e = &eq[n_eq++]; e->type = E_DEFECT; e->k = k; e->nverts = 4; e->dim = nx; e->scale = 1;
         e->vert[0] = xk; e->vert[1] = uk; e->vert[2] = xnext; e->vert[3] = dt_vertex;
+        if (d->stage_eq && d->constraint_integration == 1) e->dim = nx + 1; /* :82-88: TrapezoidalIntegralEqualityDynamicsEdge */
+        if (d->stage_ineq == CORBO_HIP_INEQ_BALL && d->stage_ineq_integral) { /* :107-122 */
+            o_edge* ei = &ineq[n_ineq++]; ei->type = E_INT_INEQ; ei->k = k; ei->dim = 1; ei->scale = 2;
+            ei->vert[0] = xk; ei->vert[1] = uk;
+            if (d->constraint_integration == 1) { ei->nverts = 4; ei->vert[2] = xnext; ei->vert[3] = dt_vertex; }
+            else { ei->nverts = 3; ei->vert[2] = dt_vertex; }
+        }
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_cost) { /* if (!_xf.isFixed()) ... getFinalStateCostEdge */
         o_edge* e = &lsq[n_lsq++]; e->type = E_FINAL_COST; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = d->cost_nonlsq ? 1 : nx; e->scale = 0;
@@ -743,6 +823,11 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
     }
     if (p->v[2 * (N - 1)].n_unfixed > 0 && d->final_ineq == CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) { /* getFinalStateConstraintEdge :136-143 */
         o_edge* e = &ineq[n_ineq++]; e->type = E_FINAL_INEQ; e->k = N - 1; e->nverts = 1; e->vert[0] = 2 * (N - 1); e->dim = 1; e->scale = 2;
+    }
+    if (d->ctrl_dev) { /* finite_differences_grid.cpp:145-153, nlp_functions.cpp:152-186: the control-deviation edge of the last control, index n,
+                        * on (u_ref, u_seq.back(), dt) -- after the final-stage edges */
+        o_edge* e = &ineq[n_ineq++]; e->type = E_CTRL_DEV; e->k = N; e->nverts = 3; e->dim = nu; e->scale = 2;
+        e->vert[0] = v_uref; e->vert[1] = 2 * (N - 2) + 1; e->vert[2] = dt_vertex;
     }
     /* row indices: [lsq | eq | ineq | bounds] (edge_set.cpp:31-42, hyper_graph_optimization_problem_edge_based.cpp:1491-1493) */
     p->n_edges = n_lsq + n_eq + n_ineq + n_mix;
@@ -941,6 +1026,17 @@ int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const 
     if (lb) memcpy(p->lb, lb, nvp * sizeof(double));
     if (ub) memcpy(p->ub, ub, nvp * sizeof(double));
     for (int i = 0; i < p->d.nx; ++i) p->xref[i] = xref ? xref[i] : 0.0;
+    return 0;
+}
+
+/* StructuredOptimalControlProblem::setPreviousControlInput (structured_optimal_control_problem.h:73-79): the values of the fixed vertices
+ * _u_prev / _u_prev_dt; NULL / <= 0 = the defaults (zeros, dt_ref) */
+int oracle_set_previous_control(oracle_problem* p, const double* u_prev, double dt_prev)
+{
+    if (!p || p->gen) return CORBO_HIP_ERR_INVALID;
+    const int nvs = (p->d.N - 1) * (p->d.nx + p->d.nu) + p->d.nx + 1;
+    for (int i = 0; i < p->d.nu; ++i) p->x[nvs + i] = u_prev ? u_prev[i] : 0.0;
+    p->x[nvs + 2 * p->d.nu] = dt_prev > 0 ? dt_prev : p->d.dt_ref;
     return 0;
 }
 

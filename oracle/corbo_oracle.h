@@ -43,6 +43,8 @@ int oracle_init_trajectory(const corbo_hip_problem_desc* desc, const double* x0,
 
 /* vertex values / bounds in vertex layout (nv doubles); lb/ub NULL = descriptor box bounds; xref NULL = zeros */
 int oracle_set_data(oracle_problem* p, const double* x, const double* lb, const double* ub, const double* xref);
+/* the previously applied control and its age (setPreviousControlInput): the fixed vertices the control-deviation edge of interval 0 sees */
+int oracle_set_previous_control(oracle_problem* p, const double* u_prev, double dt_prev);
 /* time-varying state reference: one per vertex component (state reference at grid point k in the x_k entries, the final-stage terms
  * use the x_f entries; control / dt entries are not read); NULL = the static reference of oracle_set_data */
 int oracle_set_references(oracle_problem* p, const double* ref);

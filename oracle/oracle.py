@@ -47,6 +47,7 @@ def load():
     lib.oracle_init_trajectory.argtypes = [C.POINTER(ProblemDesc), dp, dp, dp]
     lib.oracle_set_data.argtypes = [C.c_void_p, dp, dp, dp, dp]
     lib.oracle_get_x.argtypes = [C.c_void_p, dp]
+    lib.oracle_set_previous_control.argtypes = [C.c_void_p, dp, C.c_double]
     lib.oracle_warm_start.argtypes = [C.c_void_p, dp, C.c_int]
     lib.oracle_plant_step.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp]
     lib.oracle_eval.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, dp, dp]
@@ -111,6 +112,11 @@ class OracleProblem:
         self._keep = [np.ascontiguousarray(a, np.float64) if a is not None else None for a in (x, lb, ub, xref)]
         rc = self.lib.oracle_set_data(self.h, *[_dp(a) for a in self._keep])
         assert rc == 0
+
+    def set_previous_control(self, u_prev=None, dt_prev=0.0):
+        """setPreviousControlInput: the fixed vertices the control-deviation edge of interval 0 sees (None / 0 = zeros, dt_ref)."""
+        self._keep_up = None if u_prev is None else np.ascontiguousarray(u_prev, np.float64)
+        assert self.lib.oracle_set_previous_control(self.h, _dp(self._keep_up), float(dt_prev)) == 0
 
     def x(self):
         out = np.zeros(self.dims.nv)

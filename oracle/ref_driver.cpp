@@ -169,6 +169,64 @@ class BallKeepOut : public StageInequalityConstraint
     double _cx, _cy, _cz, _r;
 };
 
+// A user's stage inequalities as ONE object (the OCP holds a single StageInequalityConstraint): the keep-out ball either as the non-integral
+// state term (= BallKeepOut) or as the INTEGRAL state-control term (the grid then creates TrapezoidalIntegralInequalityEdge / LeftSumInequalityEdge,
+// finite_differences_grid.cpp:107-122), and an input-rate limit ((u_k - u_prev) / dt_prev)^2 - r_max^2 <= 0 per control as the
+// control-deviation term (TernaryVectorScalarVertexEdge on (u_k, u_{k-1}, dt), nlp_functions.cpp:117-131, 152-186).
+class UserStageInequalities : public StageInequalityConstraint
+{
+ public:
+    Eigen::VectorXd ball;        // cx, cy, cz, r or empty
+    bool ball_integral = false;
+    Eigen::VectorXd rate;        // r_max per control, or empty
+    StageInequalityConstraint::Ptr getInstance() const override { return std::make_shared<UserStageInequalities>(*this); }
+    int getNonIntegralStateTermDimension(int k) const override { return (ball.size() == 4 && !ball_integral) ? 1 : 0; }
+    void computeNonIntegralStateTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, Eigen::Ref<Eigen::VectorXd> cost) const override { cost[0] = ballValue(x); }
+    int getIntegralStateControlTermDimension(int k) const override { return (ball.size() == 4 && ball_integral) ? 1 : 0; }
+    void computeIntegralStateControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, const Eigen::Ref<const Eigen::VectorXd>& u,
+                                         Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        cost[0] = ballValue(x);
+    }
+    int getNonIntegralControlDeviationTermDimension(int k) const override { return (int)rate.size(); }
+    void computeNonIntegralControlDeviationTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& u_k, const Eigen::Ref<const Eigen::VectorXd>& u_prev,
+                                                double dt_prev, Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        for (int i = 0; i < rate.size(); ++i)
+        {
+            const double d = (u_k[i] - u_prev[i]) / dt_prev;
+            cost[i]        = d * d - rate[i] * rate[i];
+        }
+    }
+
+ private:
+    double ballValue(const Eigen::Ref<const Eigen::VectorXd>& x) const
+    {
+        double dx = x[0] - ball[0], dy = x[1] - ball[1], dz = x[2] - ball[2];
+        return ball[3] * ball[3] - (dx * dx + dy * dy + dz * dz);
+    }
+};
+
+// A user's stage equality in INTEGRAL form: a^T x + b^T u - c (one row; e.g. a path constraint that has to hold on average over every interval).  The
+// grid integrates it with its cost integration rule: appended to the dynamics edge (TrapezoidalIntegralEqualityDynamicsEdge) or as a
+// LeftSumEqualityEdge in front of it (finite_differences_grid.cpp:80-106).
+class LinearIntegralEquality : public StageEqualityConstraint
+{
+ public:
+    Eigen::VectorXd a, b;
+    double c = 0;
+    StageEqualityConstraint::Ptr getInstance() const override { return std::make_shared<LinearIntegralEquality>(*this); }
+    int getIntegralStateControlTermDimension(int k) const override { return 1; }
+    void computeIntegralStateControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, const Eigen::Ref<const Eigen::VectorXd>& u,
+                                         Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        double acc = 0.0;
+        for (int i = 0; i < a.size(); ++i) acc += a[i] * x[i];
+        for (int i = 0; i < b.size(); ++i) acc += b[i] * u[i];
+        cost[0] = acc - c;
+    }
+};
+
 // MinTimeQuadratic::_only_last_n has no setter outside fromMessage (hybrid_cost.h:300): reach the protected member through a subclass
 struct MinTimeQuadraticLastN : public MinTimeQuadratic
 {
@@ -186,6 +244,13 @@ struct Scenario
     Eigen::VectorXd x0, xf;
     std::string collocation = "crank_nicolson";
     Eigen::VectorXd ball;       // ball=cx,cy,cz,r: BallKeepOut stage inequality on the first three state components (unicycle)
+    // integral-form constraints and the control-deviation term (user stage functions above; FiniteDifferencesGrid / ...VariableGrid):
+    std::string crule;          // crule=trap|left: the grid's integration rule for the integral constraint edges (setCostIntegrationRule)
+    bool ball_integral = false; // ball_int=1 (with ball=): the ball as the INTEGRAL state-control term of the stage inequalities
+    Eigen::VectorXd eq_lin;     // eq_lin=a_1..a_nx,b_1..b_nu,c: LinearIntegralEquality
+    Eigen::VectorXd rate;       // rate=r_1..r_nu: input-rate limit as the control-deviation term of the stage inequalities
+    Eigen::VectorXd u_prev;     // u_prev=... (with rate=): the previously applied control (setPreviousControlInput), default zero
+    double u_prev_dt = 0;       // u_prev_dt=<dt>: its age (default: the grid's dt)
     Eigen::VectorXd xlb, xub, ulb, uub;   // xlb=/xub=/ulb=/uub= comma lists ("inf" = unbounded): replace the scenario's box bounds
     // cost=mtq|qstate|qctrl|mtqs|mtqc: replace the scenario's stage cost by MinTimeQuadratic / QuadraticStateCost / QuadraticControlCost /
     // MinTimeQuadraticStates / MinTimeQuadraticControls (lsq form), Q = diag(1, 0.5, 0.2, 0.1)[:nx], R = diag(0.1, 0.2, 0.05)[:nu]
@@ -432,7 +497,7 @@ static Built build(const Scenario& s, int iterations)
     {
         b.grid->setNRef(s.N);
         b.grid->setDtRef(s.dt);
-        b.grid->setCostIntegrationRule(s.integral == "trap" ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        b.grid->setCostIntegrationRule((s.integral == "trap" || s.crule == "trap") ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         b.grid->setFiniteDifferencesCollocationMethod(makeCollocation(s.collocation));
         if (s.xf_fixed >= 0)
         {
@@ -566,8 +631,23 @@ static Built build(const Scenario& s, int iterations)
         else { fprintf(stderr, "unknown cost=%s\n", s.cost.c_str()); exit(2); }
     }
     if (s.final_cost == 0) b.ocp->setFinalStageCost({});
-    if (s.ball.size() == 4 && s.name != "quad" && s.name != "pquad")
+    if (s.ball.size() == 4 && s.name != "quad" && s.name != "pquad" && !s.ball_integral && s.rate.size() == 0)
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
+    else if (s.ball_integral || s.rate.size() > 0)
+    {
+        auto c = std::make_shared<UserStageInequalities>();
+        c->ball = s.ball; c->ball_integral = s.ball_integral; c->rate = s.rate;
+        b.ocp->setStageInequalityConstraint(c);
+    }
+    if (s.eq_lin.size() > 0)
+    {
+        if (s.eq_lin.size() != s.nx + s.nu + 1) { fprintf(stderr, "eq_lin needs nx + nu + 1 numbers\n"); exit(2); }
+        auto c = std::make_shared<LinearIntegralEquality>();
+        c->a = s.eq_lin.head(s.nx); c->b = s.eq_lin.segment(s.nx, s.nu); c->c = s.eq_lin[s.nx + s.nu];
+        b.ocp->setStageEqualityConstraint(c);
+    }
+    if (s.u_prev.size() > 0 || s.u_prev_dt > 0)
+        b.ocp->setPreviousControlInput(s.u_prev.size() > 0 ? s.u_prev : Eigen::VectorXd(Eigen::VectorXd::Zero(s.nu)), s.u_prev_dt > 0 ? s.u_prev_dt : s.dt);
     if (s.teq && s.teq_mask)
     {
         Eigen::Matrix<bool, -1, 1> active(s.nx);
@@ -785,6 +865,12 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("xf_fixed")) s.xf_fixed = atoi(kv["xf_fixed"].c_str());
     if (kv.count("final_cost")) s.final_cost = atoi(kv["final_cost"].c_str());
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
+    if (kv.count("crule")) s.crule = kv["crule"];
+    if (kv.count("ball_int")) s.ball_integral = atoi(kv["ball_int"].c_str()) != 0;
+    if (kv.count("eq_lin")) s.eq_lin = vec(kv["eq_lin"]);
+    if (kv.count("rate")) s.rate = vec(kv["rate"]);
+    if (kv.count("u_prev")) s.u_prev = vec(kv["u_prev"]);
+    if (kv.count("u_prev_dt")) s.u_prev_dt = atof(kv["u_prev_dt"].c_str());
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
     if (kv.count("teq_mask")) s.teq_mask = atoi(kv["teq_mask"].c_str());
     if (kv.count("xref_traj")) s.xref_traj = atoi(kv["xref_traj"].c_str()) != 0;
@@ -830,6 +916,12 @@ static int dump(const Scenario& s)
     if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
     if (s.ball.size() == 4) printVec("ball", s.ball);
+    if (!s.crule.empty()) printf("\"crule\": \"%s\",\n", s.crule.c_str());
+    if (s.ball_integral) printf("\"ball_int\": 1,\n");
+    if (s.eq_lin.size()) printVec("eq_lin", s.eq_lin);
+    if (s.rate.size()) printVec("rate", s.rate);
+    if (s.u_prev.size()) printVec("u_prev", s.u_prev);
+    if (s.u_prev_dt > 0) printf("\"u_prev_dt\": %.17g,\n", s.u_prev_dt);
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.teq && s.teq_mask) printf("\"teq_mask\": %d,\n", s.teq_mask);
     if (s.vargrid) printf("\"vargrid\": 1,\n");

@@ -119,6 +119,18 @@ def desc_for(g):
         d.stage_ineq = capi.INEQ_BALL
         for i, v in enumerate(g["ball"]):
             d.ineq_params[i] = v
+    if "crule" in g:            # the grid's integration rule for integral-form constraint edges (user stage functions of oracle/ref_driver.cpp)
+        d.constraint_integration = {"trap": capi.RULE_TRAPEZOIDAL, "left": capi.RULE_LEFT_SUM}[g["crule"]]
+    if g.get("ball_int"):       # the ball as the stage inequalities' INTEGRAL state-control term
+        d.stage_ineq_integral = 1
+    if "eq_lin" in g:           # LinearIntegralEquality a^T x + b^T u - c
+        d.stage_eq = capi.STAGE_EQ_LINEAR
+        for i, v in enumerate(g["eq_lin"]):
+            d.stage_eq_params[i] = v
+    if "rate" in g:             # input-rate limit as the control-deviation term of the stage inequalities
+        d.ctrl_dev = capi.CTRL_DEV_RATE
+        for i, v in enumerate(g["rate"]):
+            d.ctrl_dev_params[i] = v
     return d
 
 
