@@ -141,6 +141,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_destroy.argtypes = [H]
     lib.corbo_hip_destroy.restype = None
     lib.corbo_hip_set_instance_data.argtypes = [H, dp, dp, dp, dp]
+    lib.corbo_hip_set_previous_control.argtypes = [H, dp, dp]
     lib.corbo_hip_restore_instance_data.argtypes = [H]
     lib.corbo_hip_warm_start.argtypes = [H, C.POINTER(C.c_double), C.c_int]
     lib.corbo_hip_get_first_control.argtypes = [H, C.POINTER(C.c_double)]

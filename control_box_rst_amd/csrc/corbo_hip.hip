@@ -13,6 +13,9 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <climits>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "../../include/corbo_hip.h"
@@ -168,6 +171,12 @@ struct corbo_hip_solver {
     corbo_hip_stats stats{};
     bool profile = false;
     bool force_split = false;   // descriptor family without a fused pass kernel
+    // integral-form constraint edges / control-deviation edges (Structure::xedges): the sweep's edge table, the plug-in functions' parameters, the
+    // previously applied control per instance, and the tables of the band factorisation (kernels.hpp BandParams)
+    XEdge* d_xedges = nullptr;
+    double *d_xparams = nullptr, *d_uprev = nullptr, *d_band_work = nullptr;
+    int32_t *d_band_target = nullptr, *d_band_ptr = nullptr, *d_band_pairs = nullptr, *d_band_rptr = nullptr, *d_band_rent = nullptr, *d_band_voff = nullptr;
+    BandParams band{};
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
@@ -209,6 +218,8 @@ struct corbo_hip_solver {
         p.mp.dt_weight = S.dt_weight;
         std::memcpy(p.mp.fin, S.desc.final_ineq_params, sizeof(p.mp.fin));
         p.fin_eq_row0 = S.fin_eq_row0; p.fin_eq_dim = S.fin_eq_dim;
+        p.xedges = d_xedges; p.n_xedges = (int32_t)S.xedges.size(); p.eq_stride = S.eq_stride; p.eq_defect_off = S.eq_defect_off;
+        p.xparams = d_xparams; p.uprev = d_uprev;
         p.mp.wdense = d_wdense; p.mp.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         p.fin_row = S.fin_row;
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
@@ -350,7 +361,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     // the factor phase and every scatter of the sweep phase (SQ_LDS_BANK_CONFLICT: 31 % of the solve kernel's LDS cycles) -- an odd stride
     // spreads them over all banks.  Only the offset tables change; corbo_hip_eval maps the values back to the public order.
     {
-        const bool pad_layout = jacobian_staged_in_lds(S.nx, S.N);   // the same predicate as STAGE in sweep_body: only the LDS staging area has bank conflicts to avoid
+        const bool pad_layout = jacobian_staged_in_lds(S.nx, S.N) && !S.has_extra();   // (extra edges: rows per interval are not nx -- public order kept)   // the same predicate as STAGE in sweep_body: only the LDS staging area has bank conflicts to avoid
         const int nnz = S.dims.nnz;
         h->jmap.resize(nnz);
         for (int i = 0; i < nnz; ++i) {
@@ -428,6 +439,64 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         }
         h->force_split = true;  // no fused pass kernel for the big-block family / the long horizons: factor and sweep are separate launches
     }
+    if (S.has_extra()) {
+        // ---- the sweep's extra-edge table, the plug-in parameters, the previous control (zeros, dt_ref: structured_optimal_control_problem.cpp:67-71)
+        h->force_split = true;   // separate launches: sweep_kernel<..., XE> + band_factor_kernel
+        std::vector<XEdge> xe = S.xedges;   // (Jacobian offsets: the device-internal layout is the public order for these handles)
+        CREATE_TRY(hipMalloc((void**)&h->d_xedges, xe.size() * sizeof(XEdge)));
+        CREATE_TRY(hipMemcpy(h->d_xedges, xe.data(), xe.size() * sizeof(XEdge), hipMemcpyHostToDevice));
+        std::vector<double> xp(CORBO_HIP_MAX_NX + 2 * CORBO_HIP_MAX_NU + 2, 0.0);
+        for (int i = 0; i < S.nx + S.nu + 1; ++i) xp[i] = S.desc.stage_eq_params[i];
+        for (int i = 0; i < S.nu; ++i) xp[S.nx + S.nu + 1 + i] = S.desc.ctrl_dev_params[i];
+        CREATE_TRY(hipMalloc((void**)&h->d_xparams, xp.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(h->d_xparams, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> up(B * (CORBO_HIP_MAX_NU + 1), 0.0);
+        for (size_t b = 0; b < B; ++b) up[b * (CORBO_HIP_MAX_NU + 1) + CORBO_HIP_MAX_NU] = S.desc.dt_ref;
+        CREATE_TRY(hipMalloc((void**)&h->d_uprev, up.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(h->d_uprev, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice));
+        // ---- band factorisation tables: H = J^T J entry by entry as sums of products of Jacobian values (natural parameter order; a free dt
+        //      -- the last parameter -- as a border)
+        const int n = S.dims.n, nb = S.dt_free ? n - 1 : n, m = S.dims.m, nnz = S.dims.nnz;
+        std::vector<std::vector<std::pair<int, int>>> rows(m);   // per residual row: (column, Jacobian value index)
+        for (int i = 0; i < nnz; ++i) rows[S.jac_rows[i]].push_back({S.jac_cols[i], h->jmap[i]});
+        int bw = 0;
+        std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> ent;   // (r, c <= r) -> products
+        std::vector<std::vector<std::pair<int, int>>> rl(n);                   // per column: (Jacobian value index, residual row)
+        for (int r = 0; r < m; ++r)
+            for (const auto& a : rows[r]) {
+                rl[a.first].push_back({a.second, r});
+                for (const auto& b : rows[r]) {
+                    if (b.first > a.first) continue;
+                    ent[{a.first, b.first}].push_back({a.second, b.second});
+                    if (a.first < nb && a.first - b.first > bw) bw = a.first - b.first;
+                }
+            }
+        std::vector<int32_t> tgt, ptr{0}, pairs, rptr{0}, rent;
+        for (const auto& kv : ent) {
+            const int r = kv.first.first, c = kv.first.second;
+            tgt.push_back(r < nb ? r * (bw + 1) + bw - (r - c) : (c < nb ? -1 - c : INT32_MIN));
+            for (const auto& pr : kv.second) { pairs.push_back(pr.first); pairs.push_back(pr.second); }
+            ptr.push_back((int32_t)(pairs.size() / 2));
+        }
+        for (int c = 0; c < n; ++c) {
+            for (const auto& pr : rl[c]) { rent.push_back(pr.first); rent.push_back(pr.second); }
+            rptr.push_back((int32_t)(rent.size() / 2));
+        }
+        if (upload(tgt, &h->d_band_target) || upload(ptr, &h->d_band_ptr) || upload(pairs, &h->d_band_pairs) || upload(rptr, &h->d_band_rptr) ||
+            upload(rent, &h->d_band_rent) || upload(S.param_voff, &h->d_band_voff))
+            return CORBO_HIP_ERR_DEVICE;
+        BandParams& bp = h->band;
+        bp.n = n; bp.nb = nb; bp.bw = bw; bp.n_ent = (int32_t)tgt.size();
+        bp.ent_target = h->d_band_target; bp.ent_ptr = h->d_band_ptr; bp.ent_pairs = h->d_band_pairs; bp.rhs_ptr = h->d_band_rptr; bp.rhs_ent = h->d_band_rent;
+        bp.param_voff = h->d_band_voff;
+        bp.work_stride = (int64_t)band_work_doubles(nb, bw);
+        bp.use_lds = (bp.work_stride * sizeof(double) <= 60 * 1024) ? 1 : 0;
+        if (!bp.use_lds) {
+            CREATE_TRY(hipMalloc((void**)&h->d_band_work, B * (size_t)bp.work_stride * sizeof(double)));
+            CREATE_TRY(hipMemset(h->d_band_work, 0, B * (size_t)bp.work_stride * sizeof(double)));
+        }
+        bp.work = h->d_band_work;
+    }
     if (S.desc.shooting_integrator >= 5) h->force_split = true;   // Runge-Kutta 5 - 7: a defect formula of the stand-alone kernels only (model.hpp, DEFECT_SHOOTING_HIGH)
     if (S.desc.weights_dense) h->force_split = true;   // non-diagonal weights: the DENSE instantiations exist for the stand-alone kernels only (kernels.hip, sweep_body)
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
@@ -469,7 +538,8 @@ void corbo_hip_destroy(corbo_hip_handle h)
     DeviceGuard device_guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
-                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst};
+                    h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
+                    h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
@@ -574,7 +644,8 @@ static int launch_sweep_checked(corbo_hip_handle h, const SweepParams& p)
 static int launch_factor_checked(corbo_hip_handle h, const FactorParams& p)
 {
     const SweepParams sp = h->sweep_params(3, 0, h->w_eq, h->w_ineq, h->w_b, nullptr);
-    if (!launch_factor(h->S.desc, p, h->stream, &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
+    if (h->band.n > 0) launch_band_factor(p, h->band, h->stream);
+    else if (!launch_factor(h->S.desc, p, h->stream, &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -587,6 +658,25 @@ static void update_penalty_weights(corbo_hip_handle h, const corbo_hip_lm_opts* 
     h->w_ineq *= o->adapt_factor_ineq;   if (h->w_ineq > o->adapt_max_ineq) h->w_ineq = o->adapt_max_ineq;
     h->w_b *= o->adapt_factor_bounds;    if (h->w_b > o->adapt_max_bounds) h->w_b = o->adapt_max_bounds;
 }
+
+int corbo_hip_set_previous_control(corbo_hip_handle h, const double* u_prev, const double* dt_prev)
+try {
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (!h->d_uprev) return CORBO_HIP_OK;   // no edge of this handle looks at the previous control
+    ON_DEVICE_OF(h);
+    const Structure& S = h->S;
+    std::vector<double> up((size_t)h->batch * (CORBO_HIP_MAX_NU + 1), 0.0);
+    for (int b = 0; b < h->batch; ++b) {
+        for (int i = 0; i < S.nu; ++i) up[(size_t)b * (CORBO_HIP_MAX_NU + 1) + i] = (u_prev && b < h->active) ? u_prev[(size_t)b * S.nu + i] : 0.0;
+        const double dtp = (dt_prev && b < h->active) ? dt_prev[b] : S.desc.dt_ref;
+        if (!(dtp > 0)) return fail(CORBO_HIP_ERR_INVALID, "corbo_hip_set_previous_control: dt_prev must be > 0");
+        up[(size_t)b * (CORBO_HIP_MAX_NU + 1) + CORBO_HIP_MAX_NU] = dtp;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->d_uprev, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice));
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
 
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
 try {
@@ -651,7 +741,8 @@ try {
         if (split) {
             if (mode == 3) {
                 fp.first_pass = (pass_of[i] == 0) ? 1 : 0;
-                if (!launch_factor(h->S.desc, fp, st_of[i], &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
+                if (h->band.n > 0) launch_band_factor(fp, h->band, st_of[i]);   // integral-form constraint edges / control-deviation edges: the band factorisation
+                else if (!launch_factor(h->S.desc, fp, st_of[i], &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
                 HIP_TRY(hipGetLastError());
                 stamp();
             }
@@ -1371,6 +1462,7 @@ int corbo_hip_hessian_nnz(const corbo_hip_problem_desc* desc, int lower_part_onl
 try {
     if (!desc || !nnz_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (desc->final_eq_mask) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with a partial terminal equality constraint: not built");
+    if (desc->stage_ineq_integral || desc->stage_eq || desc->ctrl_dev) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with integral-form constraints / a control-deviation term: not built");
     Structure S;
     std::string err = build_structure(*desc, S);
     if (!err.empty()) return fail(CORBO_HIP_ERR_INVALID, err);
@@ -1404,6 +1496,7 @@ static int hessian_common(corbo_hip_handle h, const HessianStructure*& Hout, boo
 {
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     if (h->S.desc.final_eq_mask) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with a partial terminal equality constraint: not built");
+    if (h->S.has_extra()) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with integral-form constraints / a control-deviation term: not built");
     auto& c = h->hess_cache[lower ? 1 : 0];
     if (!c.valid) {   // once per (handle, lower): the walk over the edges and its two device tables
         build_hessian_structure(h->S, lower, c.H);

@@ -178,7 +178,47 @@ __device__ __forceinline__ double dense_weight_row(const double* U, int c, int d
 // LONG: horizons beyond 256 grid points (up to 1024; FiniteDifferencesVariableGrid's default n_max is 1000,
 // finite_differences_variable_grid.h:82): the Jacobian of such an instance does not fit the LDS staging area, its entries go straight
 // to HBM like the big-block family's (STAGE = false).  Stand-alone kernels only.
-template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS>
+// Values of one extra edge (structure.hpp XEdge: integral-form constraint edges, control-deviation edges) on private copies of its vertices,
+// in the reference's operation order (finite_differences_collocation_edges.h:149-459: 0.5 * dt * (c1 + c2) resp. c1, then *= dt; the plug-in
+// stage functions as oracle/ref_driver.cpp states them).  loc[vi][c]: component c of attached vertex vi.
+template <int NX, int NU>
+__device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc)[4][4], const double* xp, const double* ineqp, double (&out)[4])
+{
+    auto lin = [&](const double (&x)[4], const double (&u)[4]) {   // a^T x + b^T u - c, summed left to right
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc += xp[i] * x[i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) acc += xp[NX + i] * u[i];
+        return acc - xp[NX + NU];
+    };
+    auto ball = [&](const double (&x)[4]) {
+        if constexpr (NX >= 3) { const double v[3] = {x[0], x[1], x[2]}; return ineq_ball(v, ineqp); }
+        else return 0.0;
+    };
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    switch (xe.kind) {
+        case EK_XI_INEQ: {
+            const double c1 = ball(loc[0]);
+            if (xe.nverts == 4) { const double c2 = ball(loc[2]); out[0] = 0.5 * loc[3][0] * (c1 + c2); }
+            else { out[0] = c1; out[0] *= loc[2][0]; }
+            break;
+        }
+        case EK_XI_EQ_LEFT: out[0] = lin(loc[0], loc[1]); out[0] *= loc[2][0]; break;
+        case EK_XI_EQ_ROW: { const double e1 = lin(loc[0], loc[1]), e2 = lin(loc[2], loc[1]); out[0] = 0.5 * loc[3][0] * (e1 + e2); break; }
+        default:   // EK_CTRL_DEV: ((u_k - u_prev) / dt_prev)^2 - r_max^2 per control
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const double dd = (loc[0][i] - loc[1][i]) / loc[2][0];
+                out[i] = dd * dd - xp[NX + NU + 1 + i] * xp[NX + NU + 1 + i];
+            }
+            break;
+    }
+}
+
+// XE: the descriptor has integral-form constraint edges / control-deviation edges (SweepParams::xedges): one lane per such edge evaluates it
+// generically (values before the chi2 reduction, central-difference blocks with the other Jacobian entries).  Stand-alone kernels only.
+template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS, bool XE = false>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false,
                                            StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr)
 {
@@ -580,7 +620,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double val = e[i] * p.w_eq;
-            put_value(p.eq_row0 + k * NX + i, val);   // (LEAN: still stored -- the one-pass-per-launch mode picks the rows up from HBM in the next launch)
+            put_value(p.eq_row0 + (XE ? k * p.eq_stride + p.eq_defect_off : k * NX) + i, val);   // (LEAN: still stored -- the one-pass-per-launch mode picks the rows up from HBM in the next launch)
             sq_acc += val * val;
             if constexpr (LEAN) kt.r[i] = val;
         }
@@ -603,6 +643,38 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
 
+    // (d) integral-form constraint edges, control-deviation edges: one lane per edge
+    auto xe_load = [&](const XEdge& xe, double (&loc)[4][4]) {
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = 0.0;
+                if (vi < xe.nverts && c < xe.vdim[vi]) {
+                    const int vo = xe.voff[vi];
+                    if (vo >= 0) v = xs[vo + c];
+                    else if (vo == -1) v = p.uprev[(size_t)inst * (CORBO_HIP_MAX_NU + 1) + c];            // _u_prev
+                    else if (vo == -3) v = p.uprev[(size_t)inst * (CORBO_HIP_MAX_NU + 1) + CORBO_HIP_MAX_NU];   // _u_prev_dt
+                    // (-2: _u_ref = the zero control reference)
+                }
+                loc[vi][c] = v;
+            }
+    };
+    if constexpr (XE) {
+        for (int i = tid; i < p.n_xedges; i += THREADS) {
+            const XEdge xe = p.xedges[i];
+            double loc[4][4], out[4];
+            xe_load(xe, loc);
+            xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, out);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < xe.dim) {
+                    const double val = (xe.scale == 1) ? out[j] * p.w_eq : ((out[j] < 0) ? 0.0 : out[j] * p.w_ineq);   // computeValuesActiveInequality
+                    put_value(xe.row + j, val);
+                    sq_acc += val * val;
+                }
+        }
+    }
     SWEEP_STAMP(3);
     // ---- chi2 = |values|^2 and the LM trial-step decision
     int do_jac = (mode == 1 || mode == 2) ? 1 : 0;
@@ -981,6 +1053,40 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             }
         }
     }
+    // (4) extra edges: central differences of every unfixed component of every attached vertex (BaseEdge::computeJacobian, edge_interface.cpp:55-96);
+    //     equality rows times w_eq (:1552), inequality rows times w_ineq where active, explicit zeros otherwise (:1568-1610)
+    if constexpr (XE) {
+        for (int i = tid; i < p.n_xedges; i += THREADS) {
+            const XEdge xe = p.xedges[i];
+            double loc[4][4], f0[4];
+            xe_load(xe, loc);
+            xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, f0);
+#pragma unroll
+            for (int vi = 0; vi < 4; ++vi) {
+                if (vi >= xe.nverts || xe.joff[vi] < 0) continue;
+                int col = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= xe.vdim[vi] || ((xe.fixed[vi] >> c) & 1u)) continue;
+                    const double keep = loc[vi][c];
+                    double v2[4], v1[4];
+                    loc[vi][c] += delta;
+                    xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, v2);
+                    loc[vi][c] += neg2delta;
+                    xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, v1);
+                    loc[vi][c] = keep;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < xe.dim) {
+                            const double dj = scalar * (v2[j] - v1[j]);
+                            const bool active = (((f0[j] < 0) ? 0.0 : f0[j] * p.w_ineq) > 0.0);
+                            jst[xe.joff[vi] + col * xe.edim + xe.rie + j] = (xe.scale == 1) ? dj * p.w_eq : (active ? dj * p.w_ineq : 0.0);
+                        }
+                    ++col;
+                }
+            }
+        }
+    }
     SWEEP_STAMP(6);
     if constexpr (STAGE) {
         lds_barrier();
@@ -1000,7 +1106,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
 }
 
-template <int DYN, int DEFECT, bool DENSE = false, bool LONG = false>
+template <int DYN, int DEFECT, bool DENSE = false, bool LONG = false, bool XE = false>
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1011,7 +1117,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 4 && !LONG) ? p.nnz_pad : 0));
     const int inst = blockIdx.x + p.inst0;
     if (p.st) { lm_state_in(sl, p.st + inst, threadIdx.x); __syncthreads(); }
-    sweep_body<DYN, DEFECT, false, DENSE, LONG>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
+    sweep_body<DYN, DEFECT, false, DENSE, LONG, SWEEP_THREADS, XE>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
     if (p.st && p.mode >= 2) { __syncthreads(); lm_state_out(p.st + inst, sl, threadIdx.x); }
 }
 
@@ -3484,6 +3590,12 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
             hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
         }
+        if constexpr (DEFECT != CORBO_HIP_DEFECT_RK4_SHOOTING && DEFECT != DEFECT_SHOOTING_HIGH) {
+            if (p.n_xedges > 0) {   // integral-form constraint edges / control-deviation edges: the XE instantiation (finite-differences grids)
+                hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+                return;
+            }
+        }
         if (p.mp.wdense) {   // non-diagonal weights: the DENSE instantiation
             hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
@@ -4599,6 +4711,159 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
             return false;
         default: return false;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Band factorisation: assemble H = J^T J + mu I and rhs = -J^T r from the stored Jacobian values through static product lists, Cholesky in
+// band storage (natural parameter order), solve, trial iterate -- levenberg_marquardt_sparse.cpp:97-100, 135-161 for ANY sparsity of J whose
+// normal matrix is banded (plus a free dt as a border).  One wave per instance: every elimination step updates the bw (bw + 1) / 2 trailing
+// entries with one lane each; the steps are sequential (n of them), so this is the slow, general path -- the stage-parallel kernels cover
+// the structures that matter for throughput.  Replaces Eigen::SimplicialLLT (:140-148) like factor_body does: ordering differences are
+// rounding-level.
+// ---------------------------------------------------------------------------------------------------------------------
+size_t band_work_doubles(int nb, int bw) { return (size_t)nb * (bw + 1) + 3 * (size_t)nb + 8; }
+
+__global__ __launch_bounds__(64) void band_factor_kernel(const FactorParams p, const BandParams bp)
+{
+    extern __shared__ __attribute__((aligned(16))) double band_smem[];
+    __shared__ __attribute__((aligned(16))) LmState sl_;
+    const int inst = blockIdx.x + p.inst0, tid = threadIdx.x;
+    LmState* st = &sl_;
+    lm_state_in(st, p.st + inst, tid);
+    __syncthreads();
+    if (st->done) return;
+    const int n = bp.n, nb = bp.nb, bw = bp.bw, W = bw + 1;
+    const bool arrow = (nb < n);
+    double* Hb = bp.use_lds ? band_smem : bp.work + (size_t)inst * bp.work_stride;   // [nb][W]: column r - bw + d of row r at d; d = bw is the diagonal
+    double* g  = Hb + (size_t)nb * W;   // rhs -> y -> delta
+    double* z  = g + nb;                // border column (free dt) -> L^-1 border
+    double* sc = z + nb;                // scratch: [0] corner, [1] rhs of dt
+    const int vbuf = st->vbuf, fresh = st->fresh, first = st->first;
+    int stop = st->stop;
+    double mu = st->mu;
+    const double mu_acc_in = st->mu_acc;
+    const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
+    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
+    // ---- assemble
+    for (int i = tid; i < nb * W; i += 64) Hb[i] = 0.0;
+    for (int i = tid; i < nb; i += 64) z[i] = 0.0;
+    if (tid == 0) { sc[0] = 0.0; sc[1] = 0.0; }
+    __syncthreads();
+    for (int e = tid; e < bp.n_ent; e += 64) {
+        double acc = 0.0;
+        for (int q = bp.ent_ptr[e]; q < bp.ent_ptr[e + 1]; ++q) acc += J[bp.ent_pairs[2 * q]] * J[bp.ent_pairs[2 * q + 1]];
+        const int t = bp.ent_target[e];
+        if (t >= 0) Hb[t] = acc;
+        else if (t == INT32_MIN) sc[0] = acc;
+        else z[-1 - t] = acc;
+    }
+    for (int c = tid; c < n; c += 64) {
+        double acc = 0.0;
+        for (int q = bp.rhs_ptr[c]; q < bp.rhs_ptr[c + 1]; ++q) acc -= J[bp.rhs_ent[2 * q]] * val[bp.rhs_ent[2 * q + 1]];
+        if (c < nb) g[c] = acc; else sc[1] = acc;
+    }
+    __syncthreads();
+    if (first) {   // mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
+        double mx_d = -1e300, mx_g = 0.0;
+        for (int c = tid; c < nb; c += 64) { mx_d = fmax(mx_d, Hb[(size_t)c * W + bw]); mx_g = fmax(mx_g, fabs(g[c])); }
+        mx_d = wave_max(mx_d); mx_g = wave_max(mx_g);
+        if (arrow) { mx_d = fmax(mx_d, sc[0]); mx_g = fmax(mx_g, fabs(sc[1])); }
+        stop = (mx_g <= LM_EPS1) ? 1 : 0;
+        mu   = LM_TAU * mx_d;
+        if (mu < 0) mu = 0;
+    }
+    const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;   // H_ii += mu on every inner pass, never undone on reject (:135-138)
+    for (int c = tid; c < nb; c += 64) Hb[(size_t)c * W + bw] += mu_eff;
+    __syncthreads();
+    // ---- band Cholesky (in place, lower), forward substitution of rhs and border fused into the elimination
+    double y2 = 0.0, zz = 0.0, zy = 0.0;
+    for (int j = 0; j < nb; ++j) {
+        const double l = sqrt(Hb[(size_t)j * W + bw]);
+        const double inv = 1.0 / l;
+        const int cnt = (nb - 1 - j < bw) ? nb - 1 - j : bw;   // rows below the pivot inside the band
+        __syncthreads();
+        // column j: L(i, j) = H(i, j) / l, i = j + 1 .. j + cnt  (lane t -> i = j + 1 + t)
+        if (tid < cnt) { const int i = j + 1 + tid; Hb[(size_t)i * W + bw - (i - j)] *= inv; }
+        if (tid == 62) g[j] *= inv;                // y_j
+        if (tid == 63 && arrow) z[j] *= inv;       // (L^-1 border)_j
+        if (tid == 0) Hb[(size_t)j * W + bw] = l;
+        __syncthreads();
+        // trailing update: H(i, c) -= L(i, j) L(c, j), j < c <= i <= j + cnt; rhs / border: g_i -= L(i, j) y_j
+        for (int q = tid; q < cnt * (cnt + 1) / 2; q += 64) {
+            int a = 0, rem = q;
+            while (rem > a) { rem -= a + 1; ++a; }   // q -> (a, rem), rem <= a: i = j + 1 + a, c = j + 1 + rem
+            const int i = j + 1 + a, c = j + 1 + rem;
+            Hb[(size_t)i * W + bw - (i - c)] -= Hb[(size_t)i * W + bw - (i - j)] * Hb[(size_t)c * W + bw - (c - j)];
+        }
+        if (tid < cnt) {
+            const int i = j + 1 + tid;
+            const double lij = Hb[(size_t)i * W + bw - (i - j)];
+            g[i] -= lij * g[j];
+            if (arrow) z[i] -= lij * z[j];
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < nb; c += 64) { y2 += g[c] * g[c]; if (arrow) { zz += z[c] * z[c]; zy += z[c] * g[c]; } }
+    y2 = wave_sum(y2);
+    double ddt = 0.0;
+    if (arrow) {   // the last pivot: H(dt, dt) + damping - |z|^2
+        zz = wave_sum(zz); zy = wave_sum(zy);
+        const double piv  = (sc[0] + mu_eff) - zz;
+        const double linv = 1.0 / sqrt(piv);
+        const double ydt  = (sc[1] - zy) * linv;
+        y2 += ydt * ydt;
+        ddt = ydt * linv;
+        for (int c = tid; c < nb; c += 64) g[c] -= z[c] * ddt;
+    }
+    __syncthreads();
+    // ---- back-substitution L^T delta = y
+    for (int j = nb - 1; j >= 0; --j) {
+        const int cnt = (nb - 1 - j < bw) ? nb - 1 - j : bw;
+        double part = (tid < cnt) ? Hb[(size_t)(j + 1 + tid) * W + bw - (1 + tid)] * g[j + 1 + tid] : 0.0;
+        part = wave_sum(part);
+        __syncthreads();
+        if (tid == 0) g[j] = (g[j] - part) / Hb[(size_t)j * W + bw];
+        __syncthreads();
+    }
+    // ---- trial iterate x + delta (applyIncrementNonFixed, vertex_set.cpp:357-367), step norms
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    double* xt        = p.xt + (size_t)inst * p.nvs;
+    double* dl        = p.delta_out ? p.delta_out + (size_t)inst * p.nvs : nullptr;
+    for (int v = tid; v < p.nvs; v += 64) { xt[v] = xin[v]; if (dl) dl[v] = 0.0; }
+    __syncthreads();
+    double dn2 = 0.0;
+    for (int c = tid; c < n; c += 64) {
+        const double d = (c < nb) ? g[c] : ddt;
+        const int v    = bp.param_voff[c];
+        xt[v] = xin[v] + d;
+        if (dl) dl[v] = d;
+        dn2 += d * d;
+    }
+    dn2 = wave_sum(dn2);
+    if (tid == 0) {
+        st->mu     = mu;
+        st->mu_acc = mu_eff;
+        st->first  = 0;
+        st->fresh  = 0;
+        st->n_fact += 1;
+        st->inner += 1;
+        const double dnorm = sqrt(dn2);
+        st->dnorm = dnorm;
+        int no_trial;
+        if (dnorm <= LM_EPS2) { stop = 1; no_trial = 1; }                    // :151-154
+        else { no_trial = 0; st->den = mu * dn2 + y2; }                      // delta^T (mu delta + rhs), delta^T rhs = |y|^2
+        st->stop     = stop;
+        st->no_trial = no_trial;
+    }
+    __syncthreads();
+    lm_state_out(p.st + inst, st, tid);
+}
+
+bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream)
+{
+    const size_t lds = bp.use_lds ? sizeof(double) * band_work_doubles(bp.nb, bp.bw) : 0;
+    hipLaunchKernelGGL(band_factor_kernel, dim3(fp.batch), dim3(64), lds, stream, fp, bp);
+    return true;
 }
 
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream, const SweepParams* sp)

@@ -48,6 +48,12 @@ struct SweepParams {
     ModelParams mp;
     double dt_fixed;
     // per-call
+    // integral-form constraint edges / control-deviation edges (structure.hpp XEdge; sweep_body<..., XE>), or n_xedges = 0
+    const XEdge* xedges;
+    int32_t n_xedges;
+    int32_t eq_stride, eq_defect_off;   // equality rows per interval and the defect's row inside them (nx, 0 without integral equality rows)
+    const double* xparams;              // [stage_eq: a (nx), b (nu), c | ctrl_dev: r_max (nu)]
+    const double* uprev;                // [batch_total][CORBO_HIP_MAX_NU + 1]: previously applied control, its age (corbo_hip_set_previous_control)
     int32_t mode;       // 0 = residual only, 1 = residual + Jacobian, 2 = LM init, 3 = LM trial step
     int32_t iterations; // LM: outer iteration count
     int32_t ff_converged;   // 1 (default): count the outer iterations that follow a step of norm <= eps2 / 2 instead of computing them (sweep_body, mode 3)
@@ -115,6 +121,26 @@ struct FactorParams {
     int32_t defect;               // corbo_hip_problem_desc::defect (big-block family: which stage kernel)
     int32_t pass_threads;         // run-to-completion kernel: workgroup size 256 (default) / 192 / 128 (option "pass_threads"; headline shape only)
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
+};
+
+// Band factorisation (band_factor_kernel): the generic assemble / factor / solve step for structures the stage-parallel kernels do not
+// cover -- integral-form constraint edges, control-deviation edges (they couple the controls of neighbouring intervals).  H = J^T J is
+// assembled from static product lists into band storage (natural parameter order: half-bandwidth of a few stage widths), a free dt -- the last
+// parameter, a dense row of H -- is carried as a border column.  Tables built once per handle (corbo_hip_create).
+struct BandParams {
+    int32_t n;            // parameters (columns of J)
+    int32_t nb;           // parameters inside the band (n, or n - 1 with a free dt)
+    int32_t bw;           // half-bandwidth: H(r, c) is structurally zero for r - c > bw (r, c < nb)
+    int32_t n_ent;        // entries of the lower part of H that are assembled: band entries, border entries, the corner
+    const int32_t* ent_target;  // [n_ent] r * (bw + 1) + (bw - (r - c)) for a band entry; -1 - c for the border entry (n - 1, c); INT32_MIN for the corner
+    const int32_t* ent_ptr;     // [n_ent + 1] into ent_pairs
+    const int32_t* ent_pairs;   // [2 * pairs] Jacobian value indices (a, b): H entry = sum J[a] * J[b]
+    const int32_t* rhs_ptr;     // [n + 1] into rhs_ent
+    const int32_t* rhs_ent;     // [2 * entries] (Jacobian value index, residual row): rhs_c = - sum J[a] * values[row]
+    const int32_t* param_voff;  // [n] parameter -> vertex storage offset
+    double* work;               // [batch][work_stride] band + vectors (HBM), used when the LDS does not hold them
+    int64_t work_stride;
+    int32_t use_lds;
 };
 
 // Operators of the exact-Hessian path, evaluated at the accepted iterate of every instance (hessian_kernel):
@@ -214,6 +240,8 @@ void launch_upload_instance(const UploadParams& p, hipStream_t stream);
 bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, double* jac_out, hipStream_t stream);
 bool device_kernels_exist(const corbo_hip_problem_desc& d);   // host-only mirror of the dispatch (corbo_hip_create's gate)
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
+bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream);
+size_t band_work_doubles(int nb, int bw);
 size_t sweep_lds_bytes(const SweepParams& p, int nc);
 // Small-block families with horizons up to 256 grid points assemble the Jacobian values in an LDS staging area (STAGE in sweep_body); the
 // device-internal value layout carries one pad double per defect block for exactly those (corbo_hip_create).

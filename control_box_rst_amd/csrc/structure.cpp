@@ -96,6 +96,22 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
                 if ((d.weights_dense & 2) && d.r_sqrt[i * d.nu + j] != 0.0) return "r_sqrt must be upper triangular";
     }
     if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
+    {   // integral-form constraints / control-deviation term (user stage functions of the reference)
+        const bool any = d.stage_ineq_integral || d.stage_eq || d.ctrl_dev;
+        if (d.constraint_integration < 0 || d.constraint_integration > 2) return "constraint_integration: 0, 1 (trapezoidal rule) or 2 (left sum)";
+        if (d.stage_ineq_integral != 0 && d.stage_ineq_integral != 1) return "stage_ineq_integral must be 0 or 1";
+        if (d.stage_ineq_integral && (d.stage_ineq == CORBO_HIP_INEQ_NONE || !d.constraint_integration)) return "stage_ineq_integral needs a stage inequality and a constraint_integration rule";
+        if (d.stage_eq != CORBO_HIP_STAGE_EQ_NONE && d.stage_eq != CORBO_HIP_STAGE_EQ_LINEAR) return "unknown stage equality";
+        if (d.stage_eq && !d.constraint_integration) return "stage_eq (integral form) needs a constraint_integration rule";
+        if (d.ctrl_dev != CORBO_HIP_CTRL_DEV_NONE && d.ctrl_dev != CORBO_HIP_CTRL_DEV_RATE) return "unknown control-deviation term";
+        if (any) {
+            if (d.grid != CORBO_HIP_GRID_FD && d.grid != CORBO_HIP_GRID_FD_VARIABLE) return "integral-form constraints / control-deviation term: FiniteDifferencesGrid and FiniteDifferencesVariableGrid";
+            if (d.cost_nonlsq || d.cost_integral) return "integral-form constraints / control-deviation term: Levenberg-Marquardt path (least-squares costs) only";
+            if (d.nx > 4) return "integral-form constraints / control-deviation term: families with nx <= 4";
+            if (d.N < 3 || d.N > 256) return "integral-form constraints / control-deviation term: 3 <= N <= 256";
+            if (d.weights_dense) return "integral-form constraints / control-deviation term: diagonal weights";
+        }
+    }
     return "";
 }
 
@@ -158,9 +174,16 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
             lsq.push_back({EK_DT_COST, k, 1, 0});
             lsq.push_back({EK_DT_COST, k, 1, 0});  // duplicated edge
         }
-        if (d.stage_ineq != CORBO_HIP_INEQ_NONE) ineq.push_back({EK_STAGE_INEQ, k, 1, 2});
-        eq.push_back({EK_DEFECT, k, nx, 1});
+        // (creation order inside an interval, finite_differences_grid.cpp:49-125: the non-integral terms of the stage functions -- inequalities: state
+        //  term, then control-deviation term, nlp_functions.cpp:70-131 --, then the integral equality / dynamics edges, then the integral inequality)
+        if (d.stage_ineq != CORBO_HIP_INEQ_NONE && !d.stage_ineq_integral) ineq.push_back({EK_STAGE_INEQ, k, 1, 2});
+        if (d.ctrl_dev) ineq.push_back({EK_CTRL_DEV, k, nu, 2});
+        if (d.stage_eq && d.constraint_integration == 2) eq.push_back({EK_XI_EQ_LEFT, k, 1, 1});
+        eq.push_back({EK_DEFECT, k, (d.stage_eq && d.constraint_integration == 1) ? nx + 1 : nx, 1});
+        if (d.stage_ineq != CORBO_HIP_INEQ_NONE && d.stage_ineq_integral) ineq.push_back({EK_XI_INEQ, k, 1, 2});
     }
+    S.eq_stride     = nx + (d.stage_eq ? 1 : 0);
+    S.eq_defect_off = (d.stage_eq && d.constraint_integration == 2) ? 1 : 0;
     // TerminalEqualityConstraint: nx rows; TerminalPartialEqualityConstraint: one row per active component (final_state_constraints.h:219)
     const uint32_t feq_mask = d.final_eq_mask ? d.final_eq_mask : ((1u << nx) - 1u);
     int feq_dim = 0;
@@ -168,6 +191,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     if (xf_unfixed > 0 && d.final_eq) eq.push_back({EK_FINAL_EQ, N - 1, feq_dim, 1});   // finite_differences_grid.cpp:135-141
     if (xf_unfixed > 0 && d.final_cost && !d.cost_nonlsq) lsq.push_back({EK_FINAL_COST, N - 1, nx, 0});
     if (xf_unfixed > 0 && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) ineq.push_back({EK_FINAL_INEQ, N - 1, 1, 2});  // finite_differences_grid.cpp:135-143
+    if (d.ctrl_dev) ineq.push_back({EK_CTRL_DEV, N, nu, 2});   // the last control against u_ref, index n (finite_differences_grid.cpp:145-153)
 
     int row = 0, joff = 0;
     auto comp_of = [&](int kind, int k, int vi, int c) -> int {  // vertex-storage offset of component c of attached vertex vi
@@ -193,13 +217,68 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     };
     S.stage_cols.assign(N - 1, StageCols{});
     for (auto& sc : S.stage_cols) for (int& c : sc.col) c = -1;
-    if (d.stage_ineq != CORBO_HIP_INEQ_NONE) { S.ineq_cols.assign((size_t)(N - 1) * nx, -1); S.ineq_rows.assign(N - 1, -1); }
+    if (d.stage_ineq != CORBO_HIP_INEQ_NONE && !d.stage_ineq_integral) { S.ineq_cols.assign((size_t)(N - 1) * nx, -1); S.ineq_rows.assign(N - 1, -1); }
     int dt_cost_seen = 0;
     S.fin_row = -1;
     S.fin_eq_dim = (xf_unfixed > 0 && d.final_eq) ? feq_dim : 0;
     for (int& f : S.fin_joff) f = -1;
+    // attached vertices of the extra edge kinds: (storage offset, dimension); offsets < 0 = the grid's always-fixed vertices (XEdge)
+    struct XV { int voff, dim; };
+    auto extra_verts = [&](const E& e, XV (&v)[4]) -> int {
+        const int k = e.k;
+        switch (e.kind) {
+            case EK_XI_INEQ:
+                v[0] = {k * s, nx}; v[1] = {k * s + nx, nu};
+                if (d.constraint_integration == 1) { v[2] = {(k + 1) * s, nx}; v[3] = {S.off_dt, 1}; return 4; }
+                v[2] = {S.off_dt, 1}; return 3;
+            case EK_XI_EQ_LEFT: v[0] = {k * s, nx}; v[1] = {k * s + nx, nu}; v[2] = {S.off_dt, 1}; return 3;
+            case EK_CTRL_DEV:   // (u_k, u_prev, dt_prev): finite_differences_grid.cpp:51-53; the last one on (u_ref, u_{N-2}, dt), :149
+                if (k == N) { v[0] = {-2, nu}; v[1] = {(N - 2) * s + nx, nu}; v[2] = {S.off_dt, 1}; return 3; }
+                v[0] = {k * s + nx, nu};
+                if (k == 0) { v[1] = {-1, nu}; v[2] = {-3, 1}; }
+                else { v[1] = {(k - 1) * s + nx, nu}; v[2] = {S.off_dt, 1}; }
+                return 3;
+            default:            // the dynamics edge (its appended integral row)
+                v[0] = {k * s, nx}; v[1] = {k * s + nx, nu}; v[2] = {(k + 1) * s, nx}; v[3] = {S.off_dt, 1}; return 4;
+        }
+    };
+    auto add_extra = [&](const E& e) {   // one edge of the kinds EK_XI_INEQ / EK_XI_EQ_LEFT / EK_CTRL_DEV: structure entries + its XEdge
+        XEdge x{};
+        XV v[4];
+        x.kind = e.kind; x.k = e.k; x.row = row; x.dim = e.dim; x.edim = e.dim; x.rie = 0; x.scale = e.scale;
+        x.nverts = extra_verts(e, v);
+        for (int vi = 0; vi < x.nverts; ++vi) {
+            x.voff[vi] = v[vi].voff; x.vdim[vi] = v[vi].dim; x.joff[vi] = -1; x.fixed[vi] = 0;
+            for (int c = 0; c < v[vi].dim; ++c) {
+                const bool fx = v[vi].voff < 0 || S.comp[v[vi].voff + c].fixed;
+                if (fx) { x.fixed[vi] |= 1u << c; continue; }
+                if (x.joff[vi] < 0) x.joff[vi] = joff;
+                for (int r = 0; r < e.dim; ++r) { S.jac_rows.push_back(row + r); S.jac_cols.push_back(S.comp[v[vi].voff + c].param); }
+                joff += e.dim;
+            }
+        }
+        S.xedges.push_back(x);
+        row += e.dim;
+    };
     auto add_list = [&](const std::vector<E>& list) {
         for (const E& e : list) {
+            if (e.kind == EK_XI_INEQ || e.kind == EK_XI_EQ_LEFT || e.kind == EK_CTRL_DEV) { add_extra(e); continue; }
+            if (e.kind == EK_DEFECT && e.dim > nx) {   // TrapezoidalIntegralEqualityDynamicsEdge: the appended row as an XEdge over the dynamics edge's blocks
+                XEdge x{};
+                XV v[4];
+                x.kind = EK_XI_EQ_ROW; x.k = e.k; x.row = row + nx; x.dim = 1; x.edim = e.dim; x.rie = nx; x.scale = 1;
+                x.nverts = extra_verts(e, v);
+                int jo = joff;
+                for (int vi = 0; vi < x.nverts; ++vi) {
+                    x.voff[vi] = v[vi].voff; x.vdim[vi] = v[vi].dim; x.joff[vi] = -1; x.fixed[vi] = 0;
+                    for (int c = 0; c < v[vi].dim; ++c) {
+                        if (S.comp[v[vi].voff + c].fixed) { x.fixed[vi] |= 1u << c; continue; }
+                        if (x.joff[vi] < 0) x.joff[vi] = jo;
+                        jo += e.dim;
+                    }
+                }
+                S.xedges.push_back(x);
+            }
             if (e.kind == EK_STAGE_INEQ) S.ineq_rows[e.k] = row;
             if (e.kind == EK_FINAL_INEQ) S.fin_row = row;
             int nverts = (e.kind == EK_DEFECT) ? 4 : 1;

@@ -44,7 +44,22 @@ enum EdgeKind : int32_t {
     // creates instead of the dynamics-only edge when the stage cost has integral terms (multiple_shooting_grid.cpp:70-77)
     EK_MIXED_OBJ = 14,      // objective part: the cost integrated along the shooting step (1 value)
     EK_MIXED_EQ  = 15,      // equality part: the defect (nx values)
-    EK_MIXED_JOINT = 16     // both parts as one value vector [objective; equalities] (the Jacobian of the Hessian walk: one perturbation cycle for both)
+    EK_MIXED_JOINT = 16,    // both parts as one value vector [objective; equalities] (the Jacobian of the Hessian walk: one perturbation cycle for both)
+    // integral-form constraints and the control-deviation term (user stage functions; corbo_hip_problem_desc::constraint_integration ...)
+    EK_XI_INEQ    = 17,     // TrapezoidalIntegralInequalityEdge (x_k, u_k, x_{k+1}, dt) / LeftSumInequalityEdge (x_k, u_k, dt)
+    EK_XI_EQ_LEFT = 18,     // LeftSumEqualityEdge (x_k, u_k, dt)
+    EK_XI_EQ_ROW  = 19,     // the integral row the trapezoidal rule appends to the dynamics edge (TrapezoidalIntegralEqualityDynamicsEdge: dimension nx + 1)
+    EK_CTRL_DEV   = 20      // TernaryVectorScalarVertexEdge<computeNonIntegralControlDeviationTerm> (u_k, u_prev, dt_prev)
+};
+
+// One "extra" edge (the kinds above), evaluated by a lane of the sweep kernel's generic loop (sweep_body, XE): attached vertices with their storage
+// offsets (voff < 0: the grid's always-fixed vertices -- -1 _u_prev, -2 _u_ref, -3 _u_prev_dt, full_discretization_grid_base.cpp:509-511), the
+// residual row of its first value and, per vertex, the Jacobian value offset of its block (columns of the unfixed components only, column stride
+// = the EDGE's dimension `edim`, this entry's first row inside the edge = `rie`).
+struct XEdge {
+    int32_t kind, k, row, dim, edim, rie, nverts, scale;
+    int32_t voff[4], vdim[4], joff[4];
+    uint32_t fixed[4];
 };
 
 // per-stage view of the Jacobian for the assembly of H = J^T J (levenberg_marquardt_sparse.cpp:97-100):
@@ -87,6 +102,10 @@ struct Structure {
     std::vector<CompInfo> comp;          // nvs entries
     std::vector<int32_t> jac_rows, jac_cols;  // structure in value order
     std::vector<int32_t> param_voff;     // parameter -> vertex storage offset
+    std::vector<XEdge> xedges;           // integral-form constraint edges / control-deviation edges (empty for every other descriptor)
+    int eq_stride = 0;                   // residual rows per interval in the equality section (nx; nx + 1 with an integral equality row)
+    int eq_defect_off = 0;               // row of the dynamics defect inside the interval's equality rows (1 behind a LeftSumEqualityEdge)
+    bool has_extra() const { return !xedges.empty(); }
 
     int x_off(int k) const { return k * s; }             // k in [0, N-1]; k == N-1 is x_f
     int u_off(int k) const { return k * s + nx; }

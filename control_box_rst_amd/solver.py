@@ -180,6 +180,13 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_restore_instance_data(self._h), "corbo_hip_restore_instance_data")
 
     # -- adaptive time-optimal grids: one handle per N, instances move between them (see adaptive_grid.py) ------------------------
+    def set_previous_control(self, u_prev=None, dt_prev=None):
+        """The previously applied control [B][nu] and its age [B] (StructuredOptimalControlProblem::setPreviousControlInput): what the
+        control-deviation edge of interval 0 sees (descriptor field ctrl_dev).  None = zeros resp. the grid's dt."""
+        up = None if u_prev is None else np.ascontiguousarray(np.broadcast_to(np.asarray(u_prev, np.float64), (self.batch, self.desc.nu)))
+        dp_ = None if dt_prev is None else np.ascontiguousarray(np.broadcast_to(np.asarray(dt_prev, np.float64), (self.batch,)))
+        self._check(self.lib.corbo_hip_set_previous_control(self._h, _dp(up), _dp(dp_)), "corbo_hip_set_previous_control")
+
     def prepare_slots(self, active: int):
         """Use the first `active` slots (and give a never-uploaded handle the descriptor's bound pattern)."""
         self._check(self.lib.corbo_hip_prepare_slots(self._h, int(active)), "corbo_hip_prepare_slots")

@@ -459,6 +459,36 @@ def bigmodel():
         print(name, [round(st["chi2"], 6) for st in d["steps"]])
 
 
+# Integral-form constraint edges and the control-deviation term: user stage functions of ref_driver
+# (UserStageInequalities: the keep-out ball as INTEGRAL state-control term, an input-rate limit as control-deviation term; LinearIntegralEquality),
+# both integration rules of the grid (crule), fixed- and free-dt finite-differences grids.
+XE = [
+    ("xe_unicycle_ballint_trap", dict(scenario="unicycle", N=12, iters=6, crule="trap", ball="1.0,0.5,0.2,0.3", ball_int=1), (1, 2, 3, 4, 6)),
+    ("xe_unicycle_ballint_left", dict(scenario="unicycle", N=12, iters=6, crule="left", ball="1.0,0.5,0.2,0.3", ball_int=1), (1, 2, 3, 4, 6)),
+    ("xe_unicycle_eqlin_trap", dict(scenario="unicycle", N=12, iters=6, crule="trap", eq_lin="0.3,-0.2,0.1,0.05,0.02,0.1"), (1, 2, 3, 4, 6)),
+    ("xe_unicycle_eqlin_left", dict(scenario="unicycle", N=12, iters=6, crule="left", eq_lin="0.3,-0.2,0.1,0.05,0.02,0.1"), (1, 2, 3, 4, 6)),
+    ("xe_unicycle_rate", dict(scenario="unicycle", N=12, iters=6, rate="0.8,0.5", u_prev="0.2,-0.1", u_prev_dt=0.07), (1, 2, 3, 4, 6)),
+    ("xe_unicycle_rate_default_prev", dict(scenario="unicycle", N=10, iters=4, rate="0.6,0.4"), (1, 2, 4)),
+    ("xe_unicycle_all_n40", dict(scenario="unicycle", N=40, iters=8, crule="trap", ball="1.0,0.5,0.2,0.3", ball_int=1, eq_lin="0.3,-0.2,0.1,0.05,0.02,0.1",
+                                 rate="0.9,0.6", u_prev="0.1,0.1"), (1, 2, 4, 8)),
+    ("xe_unicycle_all_left_n100", dict(scenario="unicycle", N=100, iters=5, crule="left", ball="1.0,0.5,0.2,0.3", ball_int=1, eq_lin="0.3,-0.2,0.1,0.05,0.02,0.1",
+                                       rate="0.9,0.6"), (1, 2, 5)),
+    ("xe_vdp_eqlin_rate", dict(scenario="vdp", N=20, iters=6, crule="trap", eq_lin="0.3,-0.2,0.05,0.1", rate="0.7"), (1, 2, 3, 6)),
+    ("xe_int3_vargrid_left", dict(scenario="int3", N=20, iters=5, vargrid=1, xf="1.0,0.0,0.0", crule="left", eq_lin="0.01,0.02,0.0,0.05,0.0", rate="3.0"), (1, 2, 3, 5)),
+    ("xe_int3_vargrid_trap", dict(scenario="int3", N=20, iters=5, vargrid=1, xf="1.0,0.0,0.0", crule="trap", eq_lin="0.01,0.02,0.0,0.05,0.0"), (1, 2, 3, 5)),
+    ("xe_rocket_rate_eq", dict(scenario="rocket", N=16, iters=5, crule="trap", eq_lin="0.1,0.0,0.05,0.02,0.0", rate="0.5"), (1, 2, 3, 5)),
+    ("xe_par3_rate_eq", dict(scenario="par3", N=14, iters=5, crule="left", eq_lin="0.1,0.0,0.05,0.02,0.0,0.01,0.0", rate="0.8,0.6,0.9"), (1, 2, 3, 5)),
+]
+
+
+def xe():
+    for name, kv, keep in XE:
+        d = slim(run("dump", **kv), keep)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, {k: d[k] for k in ("n", "m", "nnz")}, "chi2", [round(a["chi2"], 6) for a in d["after_iter"]])
+
+
 def usermodel():
     for name, kv, keep in USERMODEL:
         d = slim(run("dump", **kv), keep)
@@ -474,6 +504,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "pteq":
         return pteq()
+    if len(sys.argv) > 1 and sys.argv[1] == "xe":
+        return xe()
     if len(sys.argv) > 1 and sys.argv[1] == "usermodel":
         return usermodel()
     if len(sys.argv) > 1 and sys.argv[1] == "bigmodel":

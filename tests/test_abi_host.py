@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header(lib):
     # sizes implied by include/corbo_hip.h (packing check of the ctypes mirrors)
-    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8 + 28 * 8 + 4 * 4 + 2 * 4 + 3 * 16 * 8   # (+ shooting_integrator, final_eq_mask, q_sqrt, r_sqrt, qf_sqrt)
+    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8 + 28 * 8 + 4 * 4 + 2 * 4 + 3 * 16 * 8 + 4 * 4 + (25 + 8) * 8   # (+ shooting_integrator, final_eq_mask, q_sqrt, r_sqrt, qf_sqrt; + the integral-constraint / control-deviation fields)
     assert C.sizeof(capi.Dims) == 8 * 4
     assert C.sizeof(capi.LmOpts) == 8 + 9 * 8
     o = capi.LmOpts()

@@ -21,7 +21,7 @@ def _built():
 
 
 @pytest.mark.parametrize("world,batch,N", [(1, 96, 40), (2, 96, 40), (3, 100, 24), (2, 2048, 100),
-                                           (2, 8192, 100)]   # the last: cfg 4 at full size (8192 unicycle OCPs), two slices of 4096 through the instance queue)
+                                           (2, 8192, 100)])   # the last: cfg 4 at full size (8192 unicycle OCPs), two slices of 4096 through the instance queue
 def test_slices_match_single_handle(world, batch, N):
     p = subprocess.run([EXE, str(world), str(batch), str(N)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout, p.stderr)
