@@ -54,6 +54,8 @@ typename Publish<Tag, P>::Filler Publish<Tag, P>::filler;
 
 CORBO_HIP_PRIVATE_MEMBER(FdEdgeDynamics, FDCollocationEdge, SystemDynamicsInterface::Ptr, _dynamics)
 CORBO_HIP_PRIVATE_MEMBER(FdEdgeScheme, FDCollocationEdge, FiniteDifferencesCollocationInterface::Ptr, _fd_eval)
+CORBO_HIP_PRIVATE_MEMBER(TrapEqEdgeDynamics, TrapezoidalIntegralEqualityDynamicsEdge, SystemDynamicsInterface::Ptr, _dynamics)
+CORBO_HIP_PRIVATE_MEMBER(TrapEqEdgeScheme, TrapezoidalIntegralEqualityDynamicsEdge, FiniteDifferencesCollocationInterface::Ptr, _fd_eval)
 CORBO_HIP_PRIVATE_MEMBER(MsEdgeDynamics, MSVariableDynamicsOnlyEdge, SystemDynamicsInterface::Ptr, _dynamics)
 CORBO_HIP_PRIVATE_MEMBER(MsEdgeIntegrator, MSVariableDynamicsOnlyEdge, NumericalIntegratorExplicitInterface::Ptr, _integrator)
 CORBO_HIP_PRIVATE_MEMBER(MixedEdgeDynamics, MultipleShootingEdgeSingleControl, SystemDynamicsInterface::Ptr, _dynamics)
@@ -437,6 +439,129 @@ bool describeDynamics(SystemDynamicsInterface& dyn, corbo_hip_problem_desc& d, s
                         "(setDeviceModel() states a model explicitly)");
 }
 
+// ---- integral-form constraint edges and control-deviation edges (user stage functions): the integrand / term is probed THROUGH the edge.
+// An integral edge evaluates 0.5 dt (f(x1, u) + f(x2, u)) resp. f(x1, u) dt (finite_differences_collocation_edges.h:149-459): with dt = 1 and
+// x1 = x2 both are f(x, u) exactly (f + f and the halving are exact).  `row`: the value row of the integrand inside the edge.
+struct IntegrandProbe
+{
+    BaseEdge& e;
+    std::vector<VertexInterface*> xv;   // the state vertices of the edge (one or two), all set to the probe point
+    VertexInterface* u;
+    VertexInterface* dt;
+    int row;
+    std::vector<VertexGuard> guards;
+    IntegrandProbe(BaseEdge& edge, std::vector<VertexInterface*> xs_, VertexInterface* u_, VertexInterface* dt_, int row_) : e(edge), xv(std::move(xs_)), u(u_), dt(dt_), row(row_)
+    {
+        guards.reserve(xv.size() + 2);
+        for (VertexInterface* v : xv) guards.emplace_back(v);
+        guards.emplace_back(u);
+        guards.emplace_back(dt);
+        dt->getDataRaw()[0] = 1.0;
+    }
+    double operator()(const double* x, const double* uu)
+    {
+        for (VertexInterface* v : xv) std::memcpy(v->getDataRaw(), x, v->getDimension() * sizeof(double));
+        std::memcpy(u->getDataRaw(), uu, u->getDimension() * sizeof(double));
+        return evalEdge(e)[row];
+    }
+};
+
+// LinearIntegralEquality-like integrand  a^T x + b^T u - c: prm = a (nx), b (nu), c.  `known`: check against these parameters only (later intervals).
+bool identifyLinearIntegrand(IntegrandProbe& f, int nx, int nu, double* prm, bool known)
+{
+    std::vector<double> x(nx, 0.0), u(nu, 0.0);
+    auto mine = [&](const double* p) {
+        double acc = 0.0;
+        for (int i = 0; i < nx; ++i) acc += p[i] * x[i];
+        for (int i = 0; i < nu; ++i) acc += p[nx + i] * u[i];
+        return acc - p[nx + nu];
+    };
+    if (!known)
+    {
+        const double c = -f(x.data(), u.data());   // f(0, 0) = 0 - c exactly
+        for (int i = 0; i < nx; ++i) { x[i] = 1.0; prm[i] = f(x.data(), u.data()) + c; x[i] = 0.0; }
+        for (int i = 0; i < nu; ++i) { u[i] = 1.0; prm[nx + i] = f(x.data(), u.data()) + c; u[i] = 0.0; }
+        prm[nx + nu] = c;
+    }
+    for (int p = 0; p < (known ? 1 : 4); ++p)
+    {   // the device formula (kernels.hip xedge_values) at probe points
+        for (int i = 0; i < nx; ++i) x[i] = 0.4 * std::sin(0.3 + 1.1 * i + 1.7 * p);
+        for (int i = 0; i < nu; ++i) u[i] = 0.5 * std::cos(0.9 + 0.7 * i + 2.3 * p);
+        const double m = mine(prm);
+        if (!(std::abs(f(x.data(), u.data()) - m) <= 1e-13 * (1.0 + std::abs(m)))) return false;
+    }
+    return true;
+}
+
+// keep-out ball as an integrand (independent of u): prm = cx, cy, cz, r
+bool identifyBallIntegrand(IntegrandProbe& f, int nx, int nu, double* prm, bool known)
+{
+    if (nx < 3) return false;
+    std::vector<double> x(nx, 0.0), u(nu, 0.0);
+    if (!known)
+    {
+        double ctr[3];
+        for (int i = 0; i < 3; ++i)
+        {
+            x[i] = 1.0;  const double cp = f(x.data(), u.data());
+            x[i] = -1.0; const double cm = f(x.data(), u.data());
+            x[i] = 0.0;
+            ctr[i] = (cp - cm) / 4.0;
+        }
+        for (int i = 0; i < 3; ++i) x[i] = ctr[i];
+        const double r2 = f(x.data(), u.data());
+        if (!(r2 > 0)) return false;
+        prm[0] = ctr[0]; prm[1] = ctr[1]; prm[2] = ctr[2]; prm[3] = std::sqrt(r2);
+    }
+    for (int p = 0; p < (known ? 1 : 4); ++p)
+    {
+        for (int i = 0; i < nx; ++i) x[i] = 0.3 * std::sin(0.7 + 1.3 * i + 2.1 * p);
+        for (int i = 0; i < nu; ++i) u[i] = 0.5 * std::cos(0.2 + 0.9 * i + 1.3 * p);
+        const double dx = x[0] - prm[0], dy = x[1] - prm[1], dz = x[2] - prm[2];
+        const double m = prm[3] * prm[3] - (dx * dx + dy * dy + dz * dz);
+        const double v0 = f(x.data(), u.data());
+        if (!(std::abs(v0 - m) <= 1e-13 * (1.0 + std::abs(m)))) return false;
+        for (int i = 0; i < nu; ++i) u[i] += 1.0;   // must not depend on the control
+        if (f(x.data(), u.data()) != v0) return false;
+    }
+    return true;
+}
+
+// the control-deviation edge type the grids create (nlp_functions.cpp:117-131, 152-186)
+using ControlDeviationEdge = TernaryVectorScalarVertexEdge<StageFunction, &StageFunction::computeNonIntegralControlDeviationTerm>;
+
+// input-rate limit  ((u_k - u_prev) / dt_prev)^2 - r_max^2  per control: prm = r_max (nu)
+bool identifyRateLimit(BaseEdge& e, VertexInterface* uk, VertexInterface* up, VertexInterface* dtp, int nu, double* prm, bool known)
+{
+    if (e.getDimension() != nu) return false;
+    VertexGuard g0(uk), g1(up), g2(dtp);
+    double *a = uk->getDataRaw(), *b = up->getDataRaw(), *t = dtp->getDataRaw();
+    if (!known)
+    {
+        for (int i = 0; i < nu; ++i) { a[i] = 0.0; b[i] = 0.0; }
+        t[0] = 1.0;
+        const Eigen::VectorXd v = evalEdge(e);   // - r_max^2
+        for (int i = 0; i < nu; ++i)
+        {
+            if (!(v[i] < 0)) return false;
+            prm[i] = std::sqrt(-v[i]);
+        }
+    }
+    for (int p = 0; p < (known ? 1 : 3); ++p)
+    {
+        for (int i = 0; i < nu; ++i) { a[i] = 0.6 * std::sin(0.4 + 1.9 * i + 1.1 * p); b[i] = 0.5 * std::cos(1.2 + 0.8 * i + 2.9 * p); }
+        t[0] = 0.05 + 0.07 * (p + 1);
+        const Eigen::VectorXd v = evalEdge(e);
+        for (int i = 0; i < nu; ++i)
+        {
+            const double dd = (a[i] - b[i]) / t[0];
+            const double m  = dd * dd - prm[i] * prm[i];
+            if (!(std::abs(v[i] - m) <= 1e-13 * (1.0 + std::abs(m)))) return false;
+        }
+    }
+    return true;
+}
+
 // keep-out ball  c(x) = r^2 - |x[0:3] - centre|^2  (stage inequality of cfg 5), identified from evaluations and verified at probes
 bool identifyBall(BaseEdge& e, VertexInterface* v, double* prm /*cx, cy, cz, r*/)
 {
@@ -713,6 +838,19 @@ bool readStateReferenceForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eig
     return false;
 }
 
+bool readPreviousControlForHip(BaseHyperGraphOptimizationProblem& hg, int nu, Eigen::VectorXd* u_prev, double* dt_prev)
+{
+    for (const BaseEdge::Ptr& e : hg.getGraph().getEdgeSetRaw()->getInequalityEdges())
+    {
+        if (!dynamic_cast<ControlDeviationEdge*>(e.get()) || e->getNumVertices() != 3) continue;
+        if (e->getVertexRaw(1)->getDimension() != nu || !e->getVertexRaw(1)->isFixed()) return false;   // the first one is interval 0's: (u_0, _u_prev, _u_prev_dt)
+        *u_prev  = Eigen::Map<const Eigen::VectorXd>(e->getVertexRaw(1)->getData(), nu);
+        *dt_prev = e->getVertexRaw(2)->getData()[0];
+        return true;
+    }
+    return false;
+}
+
 bool readStateReferenceTrajectoryForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::MatrixXd* traj)
 {
     GridView g;
@@ -762,8 +900,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
 
     // ---- equality edges: one defect edge per interval, in order; then optionally the terminal equality constraint
     const std::vector<BaseEdge::Ptr>& eqs = es->getEqualityEdges();
-    const int n_defect_eq = ms_mixed ? 0 : g.N - 1;   // (mixed edges carry the defects themselves)
+    int n_defect_eq = ms_mixed ? 0 : g.N - 1;   // (mixed edges carry the defects themselves); + the LeftSumEqualityEdges found below
     if ((int)eqs.size() < n_defect_eq) return fail(reason, "fewer equality edges than grid intervals");
+    int integral_rule = 0;   // 1 / 2: trapezoidal / left-sum integral constraint edges were found (the grid's one integration rule)
+    auto set_rule = [&](int r) { if (integral_rule && integral_rule != r) return false; integral_rule = r; return true; };
     SystemDynamicsInterface* dyn = nullptr;
     const StageCost* mixed_cost = nullptr;
     if (ms_mixed)
@@ -789,10 +929,24 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         }
         if (!mixed_cost) return fail(reason, "mixed edges without a stage cost");
     }
-    for (int k = 0; k < n_defect_eq; ++k)
+    const int n_intervals_eq = n_defect_eq;
+    for (int k = 0, qi = 0; k < n_intervals_eq; ++k, ++qi)
     {
-        BaseEdge* e = eqs[k].get();
+        if (qi >= (int)eqs.size()) return fail(reason, "fewer equality edges than grid intervals");
+        BaseEdge* e = eqs[qi].get();
         VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
+        if (dynamic_cast<LeftSumEqualityEdge*>(e))
+        {   // integral stage equality, left sum: its own edge on (x_k, u_k, dt) in front of the dynamics edge (finite_differences_grid.cpp:89-98)
+            if (e->getNumVertices() != 3 || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] || e->getVertexRaw(2) != g.dt || e->getDimension() != 1 || g.nx > 4)
+                return fail(reason, "LeftSumEqualityEdge " + std::to_string(k) + ": not a one-row integrand on (x_k, u_k, dt) of a family with nx <= 4");
+            IntegrandProbe f(*e, {g.xs[k]}, g.us[k], g.dt, 0);
+            if (!set_rule(2) || !identifyLinearIntegrand(f, g.nx, g.nu, d.stage_eq_params, k > 0))
+                return fail(reason, "integral stage equality " + std::to_string(k) + " is not a^T x + b^T u - c (the device's plug-in), or varies along the horizon");
+            d.stage_eq = CORBO_HIP_STAGE_EQ_LINEAR;
+            ++qi; ++n_defect_eq;
+            if (qi >= (int)eqs.size()) return fail(reason, "LeftSumEqualityEdge without a dynamics edge behind it");
+            e = eqs[qi].get();
+        }
         if (e->getNumVertices() != 4 || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] || e->getVertexRaw(2) != x2 || e->getVertexRaw(3) != g.dt)
             return fail(reason, "equality edge " + std::to_string(k) + " is not a dynamics defect on (x_k, u_k, x_{k+1}, dt)");
         SystemDynamicsInterface* dk = nullptr;
@@ -806,6 +960,21 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             else if (dynamic_cast<MidpointDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_MIDPOINT;
             else if (dynamic_cast<CrankNicolsonDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_CRANK_NICOLSON;
             else return fail(reason, "unknown finite-differences collocation scheme");
+        }
+        else if (auto* tq = dynamic_cast<TrapezoidalIntegralEqualityDynamicsEdge*>(e))
+        {   // dynamics + the trapezoidal integral of the stage equalities in one edge (finite_differences_grid.cpp:82-88)
+            dk = member<TrapEqEdgeDynamics>(*tq).get();
+            FiniteDifferencesCollocationInterface* sch = member<TrapEqEdgeScheme>(*tq).get();
+            if (dynamic_cast<ForwardDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_FORWARD;
+            else if (dynamic_cast<BackwardDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_BACKWARD;
+            else if (dynamic_cast<MidpointDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_MIDPOINT;
+            else if (dynamic_cast<CrankNicolsonDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_CRANK_NICOLSON;
+            else return fail(reason, "unknown finite-differences collocation scheme");
+            if (e->getDimension() != g.nx + 1 || g.nx > 4) return fail(reason, "TrapezoidalIntegralEqualityDynamicsEdge: one integrand row, families with nx <= 4");
+            IntegrandProbe f(*e, {g.xs[k], x2}, g.us[k], g.dt, g.nx);
+            if (!set_rule(1) || !identifyLinearIntegrand(f, g.nx, g.nu, d.stage_eq_params, k > 0))
+                return fail(reason, "integral stage equality " + std::to_string(k) + " is not a^T x + b^T u - c (the device's plug-in), or varies along the horizon");
+            d.stage_eq = CORBO_HIP_STAGE_EQ_LINEAR;
         }
         else if (auto* ms = dynamic_cast<MSVariableDynamicsOnlyEdge*>(e))
         {
@@ -1129,30 +1298,84 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     }
     else if ((int)eqs.size() > n_defect_eq + 1) return fail(reason, "unexpected additional equality edges");
 
-    // ---- inequality edges: one stage inequality per interval on x_k (keep-out ball), then optionally the TerminalBall on x_f
+    // ---- inequality edges, in the grid's creation order (finite_differences_grid.cpp:49-153): per interval the stage inequality on x_k (keep-out
+    //      ball), the control-deviation edge (input-rate limit), the integral inequality edge (the ball as integrand); then the TerminalBall on x_f;
+    //      then the control-deviation edge of the last control against u_ref
     const std::vector<BaseEdge::Ptr>& ins = es->getInequalityEdges();
     size_t at = 0;
-    if (ins.size() >= (size_t)(g.N - 1) && ins[0]->getNumVertices() == 1 && ins[0]->getVertexRaw(0) == g.xs[0])
     {
-        double prm[4], prm_k[4];
+        double prm_k[4];
+        int n_ball = 0, n_dev = 0, n_int = 0;
         for (int k = 0; k < g.N - 1; ++k)
         {
-            BaseEdge* e = ins[k].get();
-            if (e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xs[k] || !identifyBall(*e, g.xs[k], (k == 0) ? prm : prm_k))
-                return fail(reason, "stage inequality " + std::to_string(k) + " is not a keep-out ball on the first three state components");
-            if (k > 0 && std::memcmp(prm, prm_k, sizeof(prm)) != 0) return fail(reason, "stage inequality varies along the horizon");
+            VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
+            if (at < ins.size() && ins[at]->getNumVertices() == 1 && ins[at]->getVertexRaw(0) == g.xs[k])
+            {
+                BaseEdge* e = ins[at].get();
+                if (!identifyBall(*e, g.xs[k], (n_ball == 0) ? d.ineq_params : prm_k))
+                    return fail(reason, "stage inequality " + std::to_string(k) + " is not a keep-out ball on the first three state components");
+                if (n_ball > 0 && std::memcmp(d.ineq_params, prm_k, sizeof(prm_k)) != 0) return fail(reason, "stage inequality varies along the horizon");
+                ++n_ball; ++at;
+            }
+            if (at < ins.size() && dynamic_cast<ControlDeviationEdge*>(ins[at].get()))
+            {
+                BaseEdge* e = ins[at].get();
+                if (e->getNumVertices() != 3 || e->getVertexRaw(0) != g.us[k] || (k > 0 && (e->getVertexRaw(1) != g.us[k - 1] || e->getVertexRaw(2) != g.dt)) ||
+                    (k == 0 && (!e->getVertexRaw(1)->isFixed() || !e->getVertexRaw(2)->isFixed())) || g.nx > 4)
+                    return fail(reason, "control-deviation edge " + std::to_string(k) + " is not on (u_k, u_{k-1}, dt) resp. (u_0, previous control, its age)");
+                if (!identifyRateLimit(*e, e->getVertexRaw(0), e->getVertexRaw(1), e->getVertexRaw(2), g.nu, d.ctrl_dev_params, n_dev > 0))
+                    return fail(reason, "control-deviation term " + std::to_string(k) + " is not the input-rate limit ((u_k - u_prev) / dt)^2 - r_max^2 (the device's plug-in), or varies along the horizon");
+                if (k == 0)
+                {   // the previously applied control and its age: the values of the two fixed vertices
+                    model->u_prev = Eigen::Map<const Eigen::VectorXd>(e->getVertexRaw(1)->getData(), g.nu);
+                    model->u_prev_dt = e->getVertexRaw(2)->getData()[0];
+                }
+                ++n_dev; ++at;
+            }
+            if (at < ins.size() && (dynamic_cast<TrapezoidalIntegralInequalityEdge*>(ins[at].get()) || dynamic_cast<LeftSumInequalityEdge*>(ins[at].get())))
+            {
+                BaseEdge* e = ins[at].get();
+                const bool trap = dynamic_cast<TrapezoidalIntegralInequalityEdge*>(e) != nullptr;
+                if (e->getDimension() != 1 || e->getNumVertices() != (trap ? 4 : 3) || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] ||
+                    e->getVertexRaw(trap ? 3 : 2) != g.dt || (trap && e->getVertexRaw(2) != x2) || g.nx > 4)
+                    return fail(reason, "integral inequality edge " + std::to_string(k) + ": not a one-row integrand on (x_k, u_k[, x_{k+1}], dt) of a family with nx <= 4");
+                IntegrandProbe f(*e, trap ? std::vector<VertexInterface*>{g.xs[k], x2} : std::vector<VertexInterface*>{g.xs[k]}, g.us[k], g.dt, 0);
+                if (!set_rule(trap ? 1 : 2) || !identifyBallIntegrand(f, g.nx, g.nu, d.ineq_params, n_int > 0))
+                    return fail(reason, "integral stage inequality " + std::to_string(k) + " is not the keep-out ball on the first three state components, or varies along the horizon");
+                ++n_int; ++at;
+            }
         }
-        d.stage_ineq = CORBO_HIP_INEQ_BALL;
-        for (int i = 0; i < 4; ++i) d.ineq_params[i] = prm[i];
-        at = g.N - 1;
+        if ((n_ball && n_ball != g.N - 1) || (n_dev && n_dev != g.N - 1) || (n_int && n_int != g.N - 1) || (n_ball && n_int))
+            return fail(reason, "stage inequality terms that are not created on every interval (or both a non-integral and an integral state term)");
+        if (n_ball || n_int) d.stage_ineq = CORBO_HIP_INEQ_BALL;
+        d.stage_ineq_integral = n_int ? 1 : 0;
+        d.ctrl_dev = n_dev ? CORBO_HIP_CTRL_DEV_RATE : CORBO_HIP_CTRL_DEV_NONE;
     }
-    if (at < ins.size())
+    if (at < ins.size() && ins[at]->getNumVertices() == 1 && ins[at]->getVertexRaw(0) == g.xf)
     {
         BaseEdge* e = ins[at].get();
-        if (at + 1 != ins.size() || e->getNumVertices() != 1 || e->getVertexRaw(0) != g.xf || !identifyTerminalBall(*e, g.xf, model->xref, d.final_ineq_params))
-            return fail(reason, "inequality edge that is neither the per-interval keep-out ball nor a TerminalBall (diagonal S) on x_f around the cost reference");
+        if (!identifyTerminalBall(*e, g.xf, model->xref, d.final_ineq_params))
+            return fail(reason, "inequality edge on x_f that is not a TerminalBall (diagonal S) around the cost reference");
         d.final_ineq = CORBO_HIP_FINAL_INEQ_TERMINAL_BALL;
+        ++at;
     }
+    if (d.ctrl_dev)
+    {   // finite_differences_grid.cpp:145-153: (u_ref, u_{N-2}, dt); u_ref = the control reference of the last interval, zero on this path
+        BaseEdge* e = (at < ins.size()) ? ins[at].get() : nullptr;
+        if (!e || !dynamic_cast<ControlDeviationEdge*>(e) || e->getNumVertices() != 3 || !e->getVertexRaw(0)->isFixed() || e->getVertexRaw(1) != g.us[g.N - 2] || e->getVertexRaw(2) != g.dt)
+            return fail(reason, "control-deviation term without its final edge on (u_ref, u_{N-2}, dt)");
+        for (int i = 0; i < g.nu; ++i)
+            if (e->getVertexRaw(0)->getData()[i] != 0.0) return fail(reason, "control-deviation term with a non-zero control reference");
+        double prm_f[CORBO_HIP_MAX_NU];
+        std::memcpy(prm_f, d.ctrl_dev_params, sizeof(prm_f));
+        if (!identifyRateLimit(*e, e->getVertexRaw(0), e->getVertexRaw(1), e->getVertexRaw(2), g.nu, prm_f, true))
+            return fail(reason, "final control-deviation edge is not the input-rate limit of the intervals");
+        ++at;
+    }
+    if (at != ins.size()) return fail(reason, "inequality edges the device cannot describe (kinds: keep-out ball on x_k or as integrand, input-rate limit, TerminalBall)");
+    d.constraint_integration = integral_rule;
+    if ((d.stage_eq || d.stage_ineq_integral || d.ctrl_dev) && (g.kind != CORBO_HIP_GRID_FD && g.kind != CORBO_HIP_GRID_FD_VARIABLE))
+        return fail(reason, "integral-form constraints / control-deviation term on a grid other than the finite-differences grids");
     if (refs_vary)
     {   // rows 0 .. N-2: the stage references, row N-1: the reference of the final-stage terms
         model->xref_traj.resize(g.N, g.nx);

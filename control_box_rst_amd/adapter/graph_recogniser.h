@@ -32,6 +32,8 @@ struct HipRecognisedModel
     corbo_hip_problem_desc desc;   // everything but N, bounds, xf_fixed_mask, dt_ref / dt bounds (the adapter reads those from the vertices)
     Eigen::VectorXd xref;          // static state reference all cost / constraint terms agree on (time-varying: of the final-stage terms)
     Eigen::MatrixXd xref_traj;     // empty, or [N][nx]: the state reference of every grid point (time-varying ReferenceTrajectoryInterface)
+    Eigen::VectorXd u_prev;        // control-deviation term (desc.ctrl_dev): the previously applied control and its age, the values of the grid's fixed
+    double u_prev_dt = 0.0;        //   vertices _u_prev / _u_prev_dt as the edge of interval 0 sees them (empty / 0: no such term)
 };
 
 // false: *reason says what the device cannot describe
@@ -45,6 +47,8 @@ bool readStateReferenceForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eig
 // the same for a time-varying reference: row k of traj ([N][nx], sized by the caller) = reference of the state cost term of grid point k
 // (row N-1: of the final cost term, left untouched if the graph has none)
 bool readStateReferenceTrajectoryForHip(BaseHyperGraphOptimizationProblem& hg, int nx, Eigen::MatrixXd* traj);
+// the previously applied control and its age as the graph's first control-deviation edge holds them (cheap; read on every solve); false: no such edge
+bool readPreviousControlForHip(BaseHyperGraphOptimizationProblem& hg, int nu, Eigen::VectorXd* u_prev, double* dt_prev);
 
 }  // namespace corbo
 

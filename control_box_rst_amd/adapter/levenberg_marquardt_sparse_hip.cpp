@@ -207,6 +207,15 @@ bool LevenbergMarquardtSparseHip::uploadVertices(const std::vector<VertexInterfa
         PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error());
         return false;
     }
+    if (_desc.ctrl_dev && _uprev_v && _uprev_dt_v)
+    {   // what setPreviousControlInput left in the grid's fixed vertices (structured_optimal_control_problem.cpp:119, full_discretization_grid_base.cpp:66-70)
+        const double dtp = _uprev_dt_v->getData()[0];
+        if (_uprev_v->getDimension() != nu || corbo_hip_set_previous_control(_handle, _uprev_v->getData(), &dtp) != CORBO_HIP_OK)
+        {
+            PRINT_ERROR("LevenbergMarquardtSparseHip(): previous control: " << corbo_hip_last_error());
+            return false;
+        }
+    }
     return true;
 }
 
@@ -231,6 +240,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
     const int N = ((int)vtx.size() - 5) / 2 + 1;
     VertexInterface* xf_v = vtx[2 * (N - 1)];
     VertexInterface* dt_v = vtx[2 * (N - 1) + 1];
+    _uprev_v = vtx[2 * (N - 1) + 2]; _uprev_dt_v = vtx[2 * (N - 1) + 4];   // the grid's fixed vertices _u_prev / _u_prev_dt (control-deviation edge of interval 0)
 
     // a fixed dt that changed without a structure change (setDtRef between runs) is a new problem for the device
     const bool dt_changed = _handle && !(_desc.grid == CORBO_HIP_GRID_FD_VARIABLE || _desc.grid == CORBO_HIP_GRID_MS_VARIABLE) && dt_v->getData()[0] != _desc.dt_ref;

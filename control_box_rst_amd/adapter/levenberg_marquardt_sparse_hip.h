@@ -102,6 +102,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     std::vector<double> _x, _lb, _ub;
     std::vector<VertexInterface*> _xs, _us;   // the grid's vertices of the attached structure (valid during a call)
     VertexInterface* _xf_v = nullptr;
+    VertexInterface *_uprev_v = nullptr, *_uprev_dt_v = nullptr;   // the grid's fixed vertices _u_prev / _u_prev_dt (control-deviation term)
     VertexInterface* _dt_v = nullptr;
     bool _recognised = false;               // _desc comes from the recogniser (not from setDeviceModel)
     double _w_eq = 2, _w_ineq = 2, _w_b = 2;  // current (adapted) penalty weights: survive a structure change like the reference's _weight_*

@@ -137,6 +137,48 @@ class BallKeepOut : public StageInequalityConstraint
     double _cx, _cy, _cz, _r;
 };
 
+// A user's stage inequalities / equalities with INTEGRAL terms and a control-deviation term (what oracle/ref_driver.cpp's goldens are made with): the
+// keep-out ball as the integral state-control term, an input-rate limit per control as the control-deviation term, a linear integral equality.
+class UserStageInequalities : public StageInequalityConstraint
+{
+ public:
+    Eigen::VectorXd ball, rate;   // cx, cy, cz, r (integral term) / r_max per control (control-deviation term); empty = absent
+    StageInequalityConstraint::Ptr getInstance() const override { return std::make_shared<UserStageInequalities>(*this); }
+    int getIntegralStateControlTermDimension(int k) const override { return ball.size() == 4 ? 1 : 0; }
+    void computeIntegralStateControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, const Eigen::Ref<const Eigen::VectorXd>& u,
+                                         Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        double dx = x[0] - ball[0], dy = x[1] - ball[1], dz = x[2] - ball[2];
+        cost[0]   = ball[3] * ball[3] - (dx * dx + dy * dy + dz * dz);
+    }
+    int getNonIntegralControlDeviationTermDimension(int k) const override { return (int)rate.size(); }
+    void computeNonIntegralControlDeviationTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& u_k, const Eigen::Ref<const Eigen::VectorXd>& u_prev,
+                                                double dt_prev, Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        for (int i = 0; i < rate.size(); ++i)
+        {
+            const double d = (u_k[i] - u_prev[i]) / dt_prev;
+            cost[i]        = d * d - rate[i] * rate[i];
+        }
+    }
+};
+class LinearIntegralEquality : public StageEqualityConstraint
+{
+ public:
+    Eigen::VectorXd a, b;
+    double c = 0;
+    StageEqualityConstraint::Ptr getInstance() const override { return std::make_shared<LinearIntegralEquality>(*this); }
+    int getIntegralStateControlTermDimension(int k) const override { return 1; }
+    void computeIntegralStateControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, const Eigen::Ref<const Eigen::VectorXd>& u,
+                                         Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        double acc = 0.0;
+        for (int i = 0; i < a.size(); ++i) acc += a[i] * x[i];
+        for (int i = 0; i < b.size(); ++i) acc += b[i] * u[i];
+        cost[0] = acc - c;
+    }
+};
+
 struct Run
 {
     Eigen::VectorXd traj;
@@ -245,7 +287,11 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     const bool hpath = plain || itrap || ileft;
     const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref" || scenario == "unicycle_plain_tvref" || scenario == "unicycle_msint_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
     const bool moved = (scenario == "unicycle_moved");   // the setpoint moves between two runs WITHOUT a structure change (model tracking)
-    const bool uni = (scenario == "unicycle" || moved || tball || tballc || fullq || tvref || urefnz || kcar || (hpath && scenario.compare(0, 3, "vdp") != 0));
+    // integral-form constraints / control-deviation term (user stage functions above): the ball as integrand (trapezoidal rule), a linear integral
+    // equality (left sum), an input-rate limit with a previously applied control, and all three together
+    const bool xe_ball = (scenario == "unicycle_xe_ball" || scenario == "unicycle_xe_all"), xe_eq = (scenario == "unicycle_xe_eq" || scenario == "unicycle_xe_all"),
+               xe_rate = (scenario == "unicycle_xe_rate" || scenario == "unicycle_xe_all"), xe = xe_ball || xe_eq || xe_rate;
+    const bool uni = (scenario == "unicycle" || xe || moved || tball || tballc || fullq || tvref || urefnz || kcar || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
     {
         if (kcar) dyn = std::make_shared<KinematicCarRef>();   // a user dynamics class: fingerprinted against the models of csrc/models/
@@ -406,7 +452,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     {
         grid->setNRef(N);
         grid->setDtRef(dt);
-        grid->setCostIntegrationRule((itrap || scenario == "dint_mtq_itrap") ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        grid->setCostIntegrationRule((itrap || scenario == "dint_mtq_itrap" || scenario == "unicycle_xe_ball" || scenario == "unicycle_xe_all") ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         any_grid = grid;
     }
     else
@@ -430,6 +476,20 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, itrap || ileft, !hpath));
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
+        if (xe_ball || xe_rate)
+        {
+            auto c = std::make_shared<UserStageInequalities>();
+            if (xe_ball) { c->ball.resize(4); c->ball << 1.0, 0.5, 0.2, 0.3; }
+            if (xe_rate) { c->rate.resize(2); c->rate << 0.9, 0.6; }
+            ocp.setStageInequalityConstraint(c);
+            if (xe_rate) ocp.setPreviousControlInput(Eigen::Vector2d(0.2, -0.1), 0.07);
+        }
+        if (xe_eq)
+        {
+            auto c = std::make_shared<LinearIntegralEquality>();
+            c->a = Eigen::Vector3d(0.3, -0.2, 0.1); c->b = Eigen::Vector2d(0.05, 0.02); c->c = 0.1;
+            ocp.setStageEqualityConstraint(c);
+        }
         if (tball)
         {
             Eigen::MatrixXd Sm = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
@@ -660,7 +720,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);

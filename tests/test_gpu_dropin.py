@@ -30,8 +30,10 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
     # linear state-space model on the shooting grid -- all recognised from the graph; then the stated-model override
     # ... and a time-varying state reference (DiscreteTimeReferenceTrajectory): one reference per cost edge, corbo_hip_set_references
     assert [r["scenario"] for r in solved] == ["unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum",
-                                              "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle"], (p.stdout, p.stderr)
-    assert [r["mode"] for r in solved] == ["recognised"] * 26 + ["stated"]   # (unicycle_moved: the setpoint moves between two runs without a structure change -- model tracking)   # (kcar, pquad: user dynamics classes matched against csrc/models/kinematic_car.hpp / planar_quadrotor.hpp -- the latter one of the big-block family)   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
+                                              "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved",
+                                              # integral-form constraints / control-deviation term: user stage functions recognised through the edges' own evaluation
+                                              "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "unicycle"], (p.stdout, p.stderr)
+    assert [r["mode"] for r in solved] == ["recognised"] * 30 + ["stated"]   # (unicycle_moved: the setpoint moves between two runs without a structure change -- model tracking)   # (kcar, pquad: user dynamics classes matched against csrc/models/kinematic_car.hpp / planar_quadrotor.hpp -- the latter one of the big-block family)   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
     # unicycle_tballc: TerminalBallInheritFromCost; dint_mtq8: MinTimeQuadratic with only_last_n)
     for r in solved:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, (r, p.stderr[-2000:])
