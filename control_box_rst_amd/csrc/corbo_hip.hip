@@ -180,7 +180,7 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
-    int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, 1 = first formulation of the chain kernel
+    int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, see FactorParams::chain_variant
     int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
     int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
     bool sweep_timeline = false;   // corbo_hip_set_option("sweep_timeline")

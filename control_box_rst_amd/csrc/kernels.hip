@@ -3379,6 +3379,437 @@ __global__ __launch_bounds__(256) void big_chain2_kernel(const FactorParams p)
     }
 }
 
+// ---- per instance: the sequential part, third formulation ("partitioned" stacked block Cholesky).  The twisted elimination of
+//      big_chain2_kernel has a dependent depth of N / 2 block steps per instance (cfg 5: 100 steps of ~5.8 k cycles = the 0.29 ms a
+//      single instance needs per LM pass, whatever the batch).  Here the chain is cut by NSEG - 1 SEPARATOR blocks s_j = j N / NSEG into
+//      NSEG segments, every segment is eliminated from both of its ends by a pair of waves (2 NSEG waves per instance, N / (2 NSEG)
+//      steps each), the separators are solved as a small reduced chain, and the back-substitution runs outwards in every segment at once:
+//      * a wave that starts next to a separator carries the fill that its eliminations create towards that separator (the "spike"
+//        T_k = H[sep, k], one more 12 x 12 block) along the segment: the stacked matrix of a step is  [ D_k ; C ; S ; g^T ; I ]  with the
+//        rows of the spike in lanes that were idle in big_chain2_kernel (D rows: lanes 0.., C: 16.., g: 28, S: 32.., I: 48..), the same
+//        right-looking pass turns it into  [ L ; Y = C L^-T ; Z = S L^-T ; y^T ; W = L^-T ];
+//      * per step five products on the matrix cores instead of two:  Y Y^T (next diagonal block),  Z Y^T (the next block's spike),
+//        Z Z^T (accumulated for the separator),  G = W Y^T and Gs = W Z^T (back-substitution:  x_k = a_k - G_k x_next - Gs_k x_sep);
+//      * the meeting block of a segment is the same step with "next" = the segment's other separator: its Y Z^T is the coupling of the
+//        two separators in the reduced chain;
+//      * reduced chain (NSEG - 1 blocks, one wave), then x_meeting, then both waves of every segment outwards.
+//      Same numbers as a Cholesky factorisation in the order [segment interiors, outside in | meeting blocks | separators]: the step
+//      differs from big_chain2_kernel's at rounding level (1e-13 relative), like that one's from Eigen's AMD order.
+template <int NX, int NU, int NSEG>
+struct Chain3Lds {
+    static constexpr int NN = NX * NX;
+    static constexpr int DN = 0;                     // [NX][NX] Schur mailbox: -Y Y^T (+ the stage's contribution) for the next block of the sequence
+    static constexpr int TM = DN + NN;               // [NX][NX] spike mailbox: rows of the separator, columns of the next block
+    static constexpr int DS = TM + NN;               // [NX][NX] what this wave adds to the diagonal block of its separator
+    static constexpr int YL = DS + NN;               // [NX][NX] Y rows   (matrix-core operands)
+    static constexpr int ZL = YL + NN;               // [NX][NX] Z rows
+    static constexpr int WL = ZL + NN;               // [NX][NX] W rows
+    static constexpr int GN = WL + NN;               // [16] right-hand-side mailbox
+    static constexpr int GS = GN + 16;               // [16] what this wave adds to the right-hand side of its separator
+    static constexpr int PER_WAVE = GS + 16;
+    // shared: couplings of neighbouring separators, the reduced chain's scratch, state increments, sums
+    static constexpr int RC = 2 * NSEG * PER_WAVE;   // [NSEG][NX][NX] -Z Y^T of segment j's meeting block (rows: left separator, columns: right separator)
+    static constexpr int SEPD = RC + NSEG * NN;      // [NSEG][NX][NX] own parts of the separators' diagonal blocks (staged by wave 1 while the meeting blocks run)
+    static constexpr int SEPG = SEPD + NSEG * NN;    // [NSEG][16]     own right-hand sides, [12] = |y_u|^2 of the stage, [13] = fixed mask (as a double)
+    static constexpr int GR = SEPG + NSEG * 16;      // [NSEG][NX][NX] reduced chain: back-substitution operators
+    static constexpr int AR = GR + NSEG * NN;        // [NSEG][16]
+    static constexpr int DR = AR + NSEG * 16;        // [NX][NX] reduced chain: Schur mailbox
+    static constexpr int GRM = DR + NN;              // [16]
+    static constexpr int DXS = GRM + 16;
+    __host__ __device__ static constexpr int total(int N) { return DXS + N * NX + 4 * NSEG + 8; }   // + state increments + sums
+};
+
+template <int NX, int NU, int NSEG>
+__global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorParams p)
+{
+    using BL = BigLds<NX, NU>;
+    using CL = Chain3Lds<NX, NU, NSEG>;
+    constexpr int S = NX + NU, NN = NX * NX, NW = 2 * NSEG, THREADS = 128 * NSEG;
+    static_assert(NX <= 12 && NX % 4 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, spike rows 32.., identity rows 48..");
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int seg = wave >> 1, side = wave & 1;
+    const int inst = blockIdx.x + p.inst0;
+    LmState* st = p.st + inst;
+    if (st->done) return;
+    int stop = st->stop;
+    const double mu = st->mu;
+    const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + mu;
+    const int N = p.N;
+    double* wsm = sm + wave * CL::PER_WAVE;
+    double *Dn = wsm + CL::DN, *Tm = wsm + CL::TM, *Ds = wsm + CL::DS, *Yl = wsm + CL::YL, *Zl = wsm + CL::ZL, *Wl = wsm + CL::WL, *gnl = wsm + CL::GN, *gs = wsm + CL::GS;
+    double* dxs  = sm + CL::DXS;                     // [N][NX] delta x of every block
+    double* sums = dxs + N * NX;                     // [2 NW + ..] reductions across the waves
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    double* xt        = p.xt + (size_t)inst * p.nvs;
+    double* ws        = p.work + (size_t)inst * p.work_stride;
+    // ---- the wave's part of the chain: segment [a, b] between the separators a - 1 and b + 1, meeting block m
+    auto sep_of = [&](int j) { return (int)(((long long)j * N) / NSEG); };   // j = 1 .. NSEG - 1
+    const int a = (seg == 0) ? 0 : sep_of(seg) + 1;
+    const int b = (seg == NSEG - 1) ? N - 1 : sep_of(seg + 1) - 1;
+    const int m = a + (b - a + 1) / 2;
+    const int mysteps = (side == 0) ? m - a : b - m;
+    const bool spike  = (side == 0) ? (seg > 0) : (seg < NSEG - 1);   // (wave-uniform) there is a separator behind the wave's first block
+    auto block_of = [&](int s) { return (side == 0) ? a + s : b - s; };
+    // lane roles
+    const bool isD = lane < NX, isC = lane >= 16 && lane < 16 + NX, isG = lane == 28, isS = lane >= 32 && lane < 32 + NX, isI = lane >= 48 && lane < 48 + NX;
+    const int row = isD ? lane : (isC ? lane - 16 : (isS ? lane - 32 : (isI ? lane - 48 : 0)));
+    // ---- mailboxes: empty, except next to a separator (the separator's stage contributes to the first block of an upward wave; the
+    //      direct coupling of the first block to the separator is the spike the wave starts with)
+    for (int e = lane; e < CL::PER_WAVE; e += 64) wsm[e] = 0.0;
+    if (spike) {
+        if (side == 0) {
+            const double* wq = ws + (size_t)(a - 1) * BL::WS_STAGE;   // the separator's own stage record
+            for (int e = lane; e < NN; e += 64) {
+                const int r = e / NX, c = e - r * NX;
+                Dn[e] = wq[BL::WS_DN + e];
+                Tm[e] = wq[BL::WS_Y + c * NX + r];                    // H[sep, a] = H[a, sep]^T
+            }
+            if (lane < NX) gnl[lane] = wq[BL::WS_GN + lane];
+        }
+        else {
+            const double* wq = ws + (size_t)b * BL::WS_STAGE;         // stage b: couples block b to the separator b + 1
+            for (int e = lane; e < NN; e += 64) {
+                Tm[e] = wq[BL::WS_Y + e];                             // H[sep, b]
+                Ds[e] = wq[BL::WS_DN + e];
+            }
+            if (lane < NX) gs[lane] = wq[BL::WS_GN + lane];
+        }
+    }
+    // ---- prefetch of a block's assembled data, branch-free (see big_chain2_kernel)
+    const int back = (side == 0) ? 0 : BL::WS_STAGE;   // downward waves take coupling / DN / GN from stage k-1
+    int off_a = 0, str_a = 1, off_b = 0, off_g = 0;
+    if (isD) { off_a = BL::WS_L + row * NX; off_b = BL::WS_DN + row * NX - back; }
+    if (isC) { off_a = (side == 0) ? BL::WS_Y + row * NX : BL::WS_Y + row - back; str_a = (side == 0) ? 1 : NX; off_g = BL::WS_GN + row - back; }
+    if (isG) { off_a = BL::WS_YV; off_b = BL::WS_GN - back; }
+    double pm[NX], pe[NX], pgn = 0.0, py2 = 0.0;
+    int pfix = 0;
+    auto fetch = [&](int k) {
+        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) { pm[cc] = wk[off_a + cc * str_a]; pe[cc] = wk[off_b + cc]; }
+        pgn  = wk[off_g];
+        py2  = wk[BL::WS_Y2];
+        pfix = p.comp[k * S + row].fixed;
+    };
+    auto stacked_pass = [&](double (&mrow)[NX]) -> double {   // (big_chain2_kernel: look-ahead order, v_rsq_f64 + the library's Newton step)
+        double inv = rsqrt(lane_bcast(mrow[0], 0));
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            mrow[j] = (lane == j) ? inv : mrow[j] * inv;
+            if (j + 1 < NX) {
+                mrow[j + 1] -= mrow[j] * lane_bcast(mrow[j], j + 1);
+                const double d = lane_bcast(mrow[j + 1], j + 1);
+                double y = 0.0, t = 0.0, e = 0.0, u = 0.0, w = 0.0, r = 0.0;
+                const int REM = NX - (j + 2);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    if (q == 0) y = __builtin_amdgcn_rsq(d);
+                    if (q == 1) t = y * (-d);
+                    if (q == 2) e = __builtin_fma(t, y, 1.0);
+                    if (q == 3) { u = y * e; w = __builtin_fma(e, 0.375, 0.5); }
+                    if (q == 4) r = __builtin_fma(u, w, y);
+                    if (q == 5) inv = __builtin_amdgcn_class(y, 0x180) ? r : y;
+                    if (q < REM) mrow[j + 2 + q] -= mrow[j] * lane_bcast(mrow[j], j + 2 + q);
+                }
+            }
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < NX; ++t) acc += mrow[t] * lane_bcast(mrow[t], 28);
+        return acc;
+    };
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int lj = lane & 15, lk = lane >> 4, ljc = (lj < NX) ? lj : 0;
+    const bool ljin = lj < NX;
+    // the five products of a step: Y Y^T -> dS (-=), Z Y^T -> dT (= -), Z Z^T -> dZ (-=), W Y^T -> gG, W Z^T -> gH (operands: the wave's Yl / Zl / Wl)
+    auto products = [&](double* dS, double* dT, double* dZ, double* gG, double* gH, const bool with_spike) {
+        d4_t accS = {0.0, 0.0, 0.0, 0.0}, accG = accS, accT = accS, accZ = accS, accH = accS;
+#pragma unroll
+        for (int k0 = 0; k0 < NX; k0 += 4) {
+            double yv = Yl[ljc * NX + k0 + lk], wv = Wl[ljc * NX + k0 + lk];
+            yv = ljin ? yv : 0.0; wv = ljin ? wv : 0.0;
+            accS = __builtin_amdgcn_mfma_f64_16x16x4f64(yv, yv, accS, 0, 0, 0);
+            accG = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, yv, accG, 0, 0, 0);
+            if (with_spike) {
+                double zv = Zl[ljc * NX + k0 + lk];
+                zv = ljin ? zv : 0.0;
+                accT = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, yv, accT, 0, 0, 0);
+                accZ = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, zv, accZ, 0, 0, 0);
+                accH = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, zv, accH, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * r + lk, j = lj;
+            if (i < NX && j < NX) {
+                const int e = i * NX + j;
+                dS[e] -= accS[r];
+                gG[e] = accG[r];
+                if (with_spike) { dT[e] = -accT[r]; dZ[e] -= accZ[r]; }
+                gH[e] = with_spike ? accH[r] : 0.0;
+            }
+        }
+    };
+    double y2 = 0.0;
+    fetch(block_of(0));
+    // ---- elimination of the wave's blocks (no workgroup barrier: the LDS areas belong to the wave)
+    for (int s = 0; s < mysteps; ++s) {
+        const int k = block_of(s);
+        const unsigned long long fmask = __ballot(pfix != 0 && isD);
+        const bool fixed_r = (fmask >> row) & 1ull;
+        double mrow[NX];
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {   // (selects, no branches)
+            const bool fixed_c = (fmask >> cc) & 1ull;
+            const double unit  = (row == cc) ? 1.0 : 0.0;
+            const double mail  = isD ? Dn[row * NX + cc] : (isS ? Tm[row * NX + cc] : gnl[cc]);
+            const double sum   = pm[cc] + mail + ((side == 1) ? pe[cc] : 0.0);
+            double v = 0.0;
+            v = isC ? pm[cc] : v;
+            v = isS ? mail : v;
+            v = isI ? unit : v;
+            v = isD ? ((fixed_r || fixed_c) ? unit : sum) : v;
+            v = isG ? (fixed_c ? 0.0 : sum) : v;
+            mrow[cc] = v;
+        }
+        if (isD) {   // the mailbox of the next block starts from this stage's contribution (upward) / empty (downward)
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = (side == 0) ? pe[cc] : 0.0;
+        }
+        const double gn_base = (side == 0) ? pgn : 0.0;
+        y2 += (lane == 0) ? py2 : 0.0;
+        // next block of the wave; behind the last one: the segment's meeting block (its own parts: the upward wave takes it after the barrier)
+        fetch((s + 1 < mysteps) ? block_of(s + 1) : m);
+        const double acc = stacked_pass(mrow);
+        if (isG) y2 += acc;                               // |y|^2
+        if (isC) gnl[row] = gn_base - acc;                // rhs mailbox: GN - Y y
+        if (isS) gs[row] -= acc;                          // the separator's right-hand side: - Z y
+        double* wk = ws + (size_t)k * BL::WS_STAGE;
+        if (isI) wk[BL::WS_YV + row] = acc;               // a_k = W y
+        if (isC || isS || isI) {
+            double* dst = (isC ? Yl : (isS ? Zl : Wl)) + row * NX;
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
+        }
+        products(Dn, Tm, Ds, wk + BL::WS_L, wk + BL::WS_DN, spike);
+    }
+    if (mysteps == 0 && side == 0) fetch(m);   // (a segment of one or two blocks)
+    // wave 1 stages the separators' own parts for the reduced chain (its loop is over; the meeting blocks do not touch these areas)
+    if (wave == 1) {
+        for (int j = 1; j < NSEG; ++j) {
+            const int sj = sep_of(j);
+            const double* wq = ws + (size_t)sj * BL::WS_STAGE;
+            for (int e = lane; e < NN; e += 64) sm[CL::SEPD + j * NN + e] = wq[BL::WS_L + e];
+            if (lane < NX) sm[CL::SEPG + j * 16 + lane] = wq[BL::WS_YV + lane];
+            const unsigned long long fm = __ballot(lane < NX && p.comp[sj * S + (lane < NX ? lane : 0)].fixed != 0);
+            if (lane == 0) { sm[CL::SEPG + j * 16 + 12] = wq[BL::WS_Y2]; sm[CL::SEPG + j * 16 + 13] = (double)(unsigned)fm; }
+        }
+    }
+    __syncthreads();
+    // ---- the meeting block of every segment (upward wave): own parts + both mailboxes, "next" = the right separator, spike = the left one
+    if (side == 0) {
+        double* wo = wsm + CL::PER_WAVE;                  // the downward wave's areas
+        const double *Dn1 = wo + CL::DN, *gn1 = wo + CL::GN, *Tm1 = wo + CL::TM;
+        double *Ds1 = wo + CL::DS, *gs1 = wo + CL::GS;
+        const unsigned long long fmask = __ballot(pfix != 0 && isD);
+        const bool fixed_r = (fmask >> row) & 1ull;
+        double mrow[NX];
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) {
+            const bool fixed_c = (fmask >> cc) & 1ull;
+            const double unit  = (row == cc) ? 1.0 : 0.0;
+            double v = 0.0;
+            if (isD) v = (fixed_r || fixed_c) ? unit : pm[cc] + Dn[row * NX + cc] + Dn1[row * NX + cc];
+            else if (isC) v = Tm1[row * NX + cc];
+            else if (isS) v = Tm[row * NX + cc];
+            else if (isG) v = fixed_c ? 0.0 : pm[cc] + gnl[cc] + gn1[cc];
+            else if (isI) v = unit;
+            mrow[cc] = v;
+        }
+        y2 += (lane == 0) ? py2 : 0.0;
+        const double acc = stacked_pass(mrow);
+        if (isG) y2 += acc;
+        if (isC) gs1[row] -= acc;                         // right separator: - Y y
+        if (isS) gs[row] -= acc;                          // left separator:  - Z y
+        double* wk = ws + (size_t)m * BL::WS_STAGE;
+        if (isI) wk[BL::WS_YV + row] = acc;
+        if (isC || isS || isI) {
+            double* dst = (isC ? Yl : (isS ? Zl : Wl)) + row * NX;
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
+        }
+        products(Ds1, sm + CL::RC + seg * NN, Ds, wk + BL::WS_L, wk + BL::WS_DN, true);
+    }
+    __syncthreads();
+    // ---- reduced chain over the separators (wave 1): D_j = own + what the two neighbouring waves collected, coupling to the next
+    //      separator = (segment j's  -Z Y^T)^T, plain twisted-free elimination (NSEG - 1 blocks), then its back-substitution
+    if (wave == 1) {
+        double* Dr = sm + CL::DR;
+        double* gr = sm + CL::GRM;
+        for (int e = lane; e < NN + 16; e += 64) Dr[e] = 0.0;   // (DR and GRM are adjacent)
+        for (int j = 1; j < NSEG; ++j) {
+            const double* DsL = sm + (2 * (j - 1) + 1) * CL::PER_WAVE + CL::DS;   // downward wave of the segment on the left
+            const double* DsR = sm + (2 * j) * CL::PER_WAVE + CL::DS;             // upward wave of the segment on the right
+            const double* gsL = sm + (2 * (j - 1) + 1) * CL::PER_WAVE + CL::GS;
+            const double* gsR = sm + (2 * j) * CL::PER_WAVE + CL::GS;
+            const double* own = sm + CL::SEPD + j * NN;
+            const double* og  = sm + CL::SEPG + j * 16;
+            const double* rc  = sm + CL::RC + j * NN;     // segment j lies between separator j and j + 1
+            const unsigned long long fmask = (unsigned long long)(unsigned)og[13];
+            const bool fixed_r = (fmask >> row) & 1ull;
+            const bool last = (j == NSEG - 1);
+            double mrow[NX];
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) {
+                const bool fixed_c = (fmask >> cc) & 1ull;
+                const double unit  = (row == cc) ? 1.0 : 0.0;
+                double v = 0.0;
+                if (isD) v = (fixed_r || fixed_c) ? unit : own[row * NX + cc] + DsL[row * NX + cc] + DsR[row * NX + cc] + Dr[row * NX + cc];
+                else if (isC) v = last ? 0.0 : rc[cc * NX + row];   // H[sep j+1, sep j]
+                else if (isG) v = fixed_c ? 0.0 : og[cc] + gsL[cc] + gsR[cc] + gr[cc];
+                else if (isI) v = unit;
+                mrow[cc] = v;
+            }
+            y2 += (lane == 0) ? og[12] : 0.0;
+            const double acc = stacked_pass(mrow);
+            if (isG) y2 += acc;
+            if (last) {
+                if (isI) dxs[sep_of(j) * NX + row] = acc;   // x = W y
+            }
+            else {
+                if (isC) gr[row] = -acc;
+                if (isI) sm[CL::AR + j * 16 + row] = acc;
+                if (isC || isI) {
+                    double* dst = (isC ? Yl : Wl) + row * NX;
+#pragma unroll
+                    for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
+                }
+                if (isD) {
+#pragma unroll
+                    for (int cc = 0; cc < NX; ++cc) Dr[row * NX + cc] = 0.0;
+                }
+                products(Dr, nullptr, nullptr, sm + CL::GR + j * NN, Zl, false);   // (gH: scratch)
+            }
+        }
+        for (int j = NSEG - 2; j >= 1; --j) {
+            const double xn = isD ? dxs[sep_of(j + 1) * NX + lane] : 0.0;
+            double v = isD ? sm[CL::AR + j * 16 + lane] : 0.0;
+            const double* g = sm + CL::GR + j * NN + (isD ? lane : 0) * NX;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v -= g[i] * lane_bcast(xn, i);
+            if (isD) dxs[sep_of(j) * NX + lane] = v;
+        }
+    }
+    __syncthreads();
+    // ---- back-substitution.  Meeting block (upward wave):  x_m = a_m - G_m x_right - Gs_m x_left
+    const int rr = isD ? lane : (isC ? lane - 16 : 0);
+    const int off_back = isC ? BL::WS_DN + rr * NX : BL::WS_L + rr * NX;   // D lanes: rows of G_k, C lanes: rows of Gs_k
+    if (side == 0) {
+        const double* wk = ws + (size_t)m * BL::WS_STAGE;
+        double g[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) g[i] = wk[off_back + i];
+        const double am = wk[BL::WS_YV + rr];
+        const double xr = (isD && seg < NSEG - 1) ? dxs[(b + 1) * NX + lane] : 0.0;
+        const double xl = (isD && seg > 0) ? dxs[(a - 1) * NX + lane] : 0.0;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) v += g[i] * (isC ? lane_bcast(xl, i) : lane_bcast(xr, i));
+        const double vs = __shfl(v, (lane + 16) & 63);   // D lane r: the spike part computed by lane 16 + r
+        if (isD) dxs[m * NX + lane] = am - v - vs;
+    }
+    __syncthreads();
+    // ---- outwards in every segment: x_k = a_k - G_k x_neighbour - Gs_k x_sep, data two steps ahead
+    {
+        struct BackBuf { double g[NX], a; };
+        BackBuf b0{}, b1{};
+        auto blk_of = [&](int s) { return (side == 0) ? m - 1 - s : m + 1 + s; };
+        const int last_s = (mysteps > 0) ? mysteps - 1 : 0;
+        auto fetch_b = [&](BackBuf& bb, int s) {
+            const double* wk = ws + (size_t)blk_of(s < mysteps ? s : last_s) * BL::WS_STAGE;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) bb.g[i] = wk[off_back + i];
+            bb.a = wk[BL::WS_YV + rr];
+        };
+        const double xsep = (isD && spike) ? dxs[((side == 0) ? a - 1 : b + 1) * NX + lane] : 0.0;
+        double xn = isD ? dxs[m * NX + lane] : 0.0;
+        auto back_step = [&](BackBuf& bb, int s) {
+            const bool valid = (s < mysteps);
+            double t = 0.0;   // C lanes: (Gs_k x_sep)[row] -- does not depend on the neighbour's solution
+#pragma unroll
+            for (int i = 0; i < NX; ++i) t += bb.g[i] * lane_bcast(xsep, i);
+            double v = bb.a - __shfl(t, (lane + 16) & 63);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v -= bb.g[i] * lane_bcast(xn, i);
+            fetch_b(bb, s + 2);
+            if (valid && isD) dxs[blk_of(s) * NX + lane] = v;
+            xn = valid ? v : xn;
+        };
+        if (mysteps > 0) {
+            fetch_b(b0, 0);
+            fetch_b(b1, 1);
+            for (int s = 0; s < mysteps; s += 2) {
+                back_step(b0, s);
+                back_step(b1, s + 1);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- epilogue, stage-parallel over all waves: trial iterate of the states, controls, step norm (big_chain2_kernel)
+    double dn2 = 0.0;
+    for (int e = tid; e < N * NX; e += THREADS) {
+        const int k = e / NX, r = e - k * NX;
+        const double d = p.comp[k * S + r].fixed ? 0.0 : dxs[e];
+        dn2 += d * d;
+        xt[k * S + r] = xin[k * S + r] + d;
+    }
+    for (int q = tid; q < N - 1; q += THREADS) {
+        const double* wq = ws + (size_t)q * BL::WS_STAGE;
+        double w[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            double v = wq[BL::WS_YU + c];
+#pragma unroll
+            for (int t = 0; t < NX; ++t) v -= wq[BL::WS_ZX + c * NX + t] * dxs[q * NX + t] + wq[BL::WS_ZP + c * NX + t] * dxs[(q + 1) * NX + t];
+            w[c] = v;
+        }
+#pragma unroll
+        for (int c = NU - 1; c >= 0; --c) {   // u = L_uu^{-T} w (diagonal stored inverted)
+            double v = w[c];
+#pragma unroll
+            for (int d = c + 1; d < NU; ++d) v -= wq[BL::WS_LUU + d * NU + c] * w[d];
+            w[c] = v * wq[BL::WS_LUU + c * NU + c];
+            dn2 += w[c] * w[c];
+            xt[q * S + NX + c] = xin[q * S + NX + c] + w[c];
+        }
+    }
+    if (tid == 0) {
+        xt[p.off_dt] = xin[p.off_dt];
+        if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
+    }
+    y2  = wave_sum(y2);
+    dn2 = wave_sum(dn2);
+    if (lane == 0) { sums[2 * wave] = y2; sums[2 * wave + 1] = dn2; }
+    __syncthreads();
+    if (tid == 0) {
+        y2 = 0.0; dn2 = 0.0;
+        for (int w = 0; w < NW; ++w) { y2 += sums[2 * w]; dn2 += sums[2 * w + 1]; }
+        st->mu_acc = mu_eff;
+        st->first  = 0;
+        st->fresh  = 0;
+        st->n_fact += 1;
+        st->inner += 1;
+        const double dnorm = sqrt(dn2);
+        st->dnorm = dnorm;
+        int no_trial;
+        if (dnorm <= LM_EPS2) { stop = 1; no_trial = 1; }
+        else { no_trial = 0; st->den = mu * dn2 + y2; }
+        st->stop     = stop;
+        st->no_trial = no_trial;
+    }
+}
+
 // One Levenberg-Marquardt pass of every unfinished instance in ONE launch:  [sweep phase -> factor phase]  per workgroup.
 //   sweep phase  : residual at the trial iterate, accept / reject, and on an accepted step the new Jacobian (mode 3); for the
 //                  first launch of a solve the prologue instead (mode 2: residual + Jacobian at the start iterate);
@@ -4365,8 +4796,28 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
         if (p.chain_variant == 1)   // (diagnostics: the first formulation)
             hipLaunchKernelGGL((big_chain_kernel<NX, NU, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);
         else {
-            const size_t lds2 = 2 * sizeof(double) * (size_t)Chain2Lds<NX, NU>::total(p.N);   // two instances per workgroup
-            hipLaunchKernelGGL((big_chain2_kernel<NX, NU>), dim3((p.batch + 1) / 2), dim3(256), lds2, stream, p);
+            // partitioned chain (big_chain3_kernel): NSEG segments = 2 NSEG waves per instance.  chain_variant 0 = automatic (horizons of 64 grid points
+            // and more: four segments), 2 = the twisted chain (big_chain2_kernel) whatever the horizon, 3 / 4 / 5 / 6 = 4 / 2 / 8 / 1 segments (tests, A/B)
+            int nseg = 0;
+            if (p.chain_variant == 0 && p.N >= 64) nseg = 4;
+            if (p.chain_variant == 3) nseg = 4;
+            if (p.chain_variant == 4) nseg = 2;
+            if (p.chain_variant == 5) nseg = 8;
+            if (p.chain_variant == 6) nseg = 1;
+            if (nseg > 0 && p.N < 4 * nseg) nseg = 0;   // (every segment needs a block of its own next to its separators)
+            auto launch3 = [&](auto kernel, int nseg_, size_t lds3) {
+                static bool attr_set[9] = {};
+                if (!attr_set[nseg_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[nseg_] = true; }
+                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(128 * nseg_), lds3, stream, p);
+            };
+            if (nseg == 4) launch3(big_chain3_kernel<NX, NU, 4>, 4, sizeof(double) * (size_t)Chain3Lds<NX, NU, 4>::total(p.N));
+            else if (nseg == 2) launch3(big_chain3_kernel<NX, NU, 2>, 2, sizeof(double) * (size_t)Chain3Lds<NX, NU, 2>::total(p.N));
+            else if (nseg == 8) launch3(big_chain3_kernel<NX, NU, 8>, 8, sizeof(double) * (size_t)Chain3Lds<NX, NU, 8>::total(p.N));
+            else if (nseg == 1) launch3(big_chain3_kernel<NX, NU, 1>, 1, sizeof(double) * (size_t)Chain3Lds<NX, NU, 1>::total(p.N));
+            else {
+                const size_t lds2 = 2 * sizeof(double) * (size_t)Chain2Lds<NX, NU>::total(p.N);   // two instances per workgroup
+                hipLaunchKernelGGL((big_chain2_kernel<NX, NU>), dim3((p.batch + 1) / 2), dim3(256), lds2, stream, p);
+            }
         }
     }
     else hipLaunchKernelGGL((big_chain_kernel<NX, NU, false>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);

@@ -107,7 +107,7 @@ struct FactorParams {
     int64_t work_stride;          // doubles per instance
     long long* pass_timeline;     // optional [2 * 64 + 1] shader-clock stamps (pass start, sweep end) of one instance (diagnostics)
     int32_t pass_timeline_inst;
-    int32_t chain_variant;        // big-block family: 0 = stacked chain kernel (big_chain2_kernel), 1 = the first formulation (diagnostics)
+    int32_t chain_variant;        // big-block family: 0 = automatic (N >= 64: partitioned chain big_chain3_kernel, four segments; else the twisted chain big_chain2_kernel), 1 = the first formulation, 2 = twisted, 3 / 4 / 6 = 4 / 2 / 1 segments
     int32_t first_pass;           // big-block family: this may be the first factorisation of a solve (launches the mu / stop kernels)
     int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
     double* x_host;               // run-to-completion kernel: optional result sink in pinned, device-visible HOST memory [batch][nvs]: every
