@@ -3407,20 +3407,21 @@ struct Chain3Lds {
     static constexpr int GN = WL + NN;               // [16] right-hand-side mailbox
     static constexpr int GS = GN + 16;               // [16] what this wave adds to the right-hand side of its separator
     static constexpr int PER_WAVE = GS + 16;
-    // shared: couplings of neighbouring separators, the reduced chain's scratch, state increments, sums
-    static constexpr int RC = 2 * NSEG * PER_WAVE;   // [NSEG][NX][NX] -Z Y^T of segment j's meeting block (rows: left separator, columns: right separator)
-    static constexpr int SEPD = RC + NSEG * NN;      // [NSEG][NX][NX] own parts of the separators' diagonal blocks (staged by wave 1 while the meeting blocks run)
-    static constexpr int SEPG = SEPD + NSEG * NN;    // [NSEG][16]     own right-hand sides, [12] = |y_u|^2 of the stage, [13] = fixed mask (as a double)
-    static constexpr int GR = SEPG + NSEG * 16;      // [NSEG][NX][NX] reduced chain: back-substitution operators
-    static constexpr int AR = GR + NSEG * NN;        // [NSEG][16]
-    static constexpr int DR = AR + NSEG * 16;        // [NX][NX] reduced chain: Schur mailbox
-    static constexpr int GRM = DR + NN;              // [16]
-    static constexpr int DXS = GRM + 16;
-    __host__ __device__ static constexpr int total(int N) { return DXS + N * NX + 4 * NSEG + 8; }   // + state increments + sums
+    // Nothing else is shared but the state increments: what the phases after the elimination need lives in wave areas that are dead by then --
+    //   the separator behind a downward wave is staged by that wave in its own YL (own parts of the diagonal block) and ZL ([0,12) right-hand side,
+    //   [12] |y_u|^2 of the stage, [13] fixed mask), the coupling of a segment's two separators (-Z Y^T of its meeting block; rows: left
+    //   separator) replaces the upward wave's spike mailbox TM, and the reduced chain (wave 1) works with wave 0's YL / WL as operands, wave 0's ZL /
+    //   GN as its Schur / right-hand-side mailbox and keeps separator j's back-substitution operator / vector in ZL / GN of the upward wave 2 j.
+    static constexpr int IDM = 2 * NSEG * PER_WAVE;  // [NX][NX] identity: the I rows of the stacked matrix read their start values like the other rows read their mailboxes
+    static constexpr int DXS = IDM + NN;
+    __host__ __device__ static constexpr int total(int N) { return DXS + N * NX + 4 * NSEG + 8; }   // + state increments + sums (NSEG = 4, N = 200: 76.7 KB, two workgroups per CU)
 };
 
 template <int NX, int NU, int NSEG>
-__global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorParams p)
+__global__ __launch_bounds__(128 * NSEG)
+__attribute__((amdgpu_waves_per_eu(2, 2)))   // 216 registers: two waves per SIMD (four segments: one workgroup per CU; two: two).  A 128-register build
+                                             // (two 8-wave workgroups per CU) spills 290 - 340 bytes per lane into the dependent chain: 0.73 -> 0.88 ms per factor launch group at cfg 5, measured
+void big_chain3_kernel(const FactorParams p)
 {
     using BL = BigLds<NX, NU>;
     using CL = Chain3Lds<NX, NU, NSEG>;
@@ -3476,6 +3477,14 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
             if (lane < NX) gs[lane] = wq[BL::WS_GN + lane];
         }
     }
+    if (wave == 0)
+        for (int e = lane; e < NN; e += 64) sm[CL::IDM + e] = (e / NX == e % NX) ? 1.0 : 0.0;
+    // how a lane forms its row of the stacked matrix from what it prefetched (pm, pe) and its mailbox: coefficients instead of selects
+    //   D: pm + mailbox (+ pe downward) | C: pm | S: mailbox | g: pm + mailbox (+ pe downward) | I: "mailbox" = a row of the identity
+    const double cpm   = (isD || isC || isG) ? 1.0 : 0.0;
+    const double cmail = (isD || isS || isG || isI) ? 1.0 : 0.0;
+    const double cpe   = (side == 1 && (isD || isG)) ? 1.0 : 0.0;
+    const double2* mailp = reinterpret_cast<const double2*>(isD ? Dn + row * NX : (isS ? Tm + row * NX : (isI ? sm + CL::IDM + row * NX : gnl)));
     // ---- prefetch of a block's assembled data, branch-free (see big_chain2_kernel)
     const int back = (side == 0) ? 0 : BL::WS_STAGE;   // downward waves take coupling / DN / GN from stage k-1
     int off_a = 0, str_a = 1, off_b = 0, off_g = 0;
@@ -3484,19 +3493,27 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
     if (isG) { off_a = BL::WS_YV; off_b = BL::WS_GN - back; }
     double pm[NX], pe[NX], pgn = 0.0, py2 = 0.0;
     int pfix = 0;
+    // (per-lane pointers and a per-lane byte stride, advanced load by load: indexing wk[off + cc * stride] cost 130 address instructions per block)
+    const double* const pa0 = ws + off_a;
+    const double* const pb0 = ws + off_b;
+    const double* const pg0 = ws + off_g;
+    const ptrdiff_t sa = str_a;
+    const int32_t* const fx0 = &p.comp[row].fixed;
     auto fetch = [&](int k) {
-        const double* wk = ws + (size_t)k * BL::WS_STAGE;
+        const size_t ko = (size_t)k * BL::WS_STAGE;
+        const double* pa = pa0 + ko;
+        const double* pb = pb0 + ko;
 #pragma unroll
-        for (int cc = 0; cc < NX; ++cc) { pm[cc] = wk[off_a + cc * str_a]; pe[cc] = wk[off_b + cc]; }
-        pgn  = wk[off_g];
-        py2  = wk[BL::WS_Y2];
-        pfix = p.comp[k * S + row].fixed;
+        for (int cc = 0; cc < NX; ++cc) { pm[cc] = *pa; pa += sa; pe[cc] = pb[cc]; }
+        pgn  = pg0[ko];
+        py2  = ws[ko + BL::WS_Y2];
+        pfix = fx0[(size_t)k * S * (sizeof(CompInfo) / sizeof(int32_t))];
     };
     auto stacked_pass = [&](double (&mrow)[NX]) -> double {   // (big_chain2_kernel: look-ahead order, v_rsq_f64 + the library's Newton step)
         double inv = rsqrt(lane_bcast(mrow[0], 0));
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            mrow[j] = (lane == j) ? inv : mrow[j] * inv;
+            mrow[j] *= inv;   // (the pivot lane keeps sqrt(d) instead of its reciprocal: a D row's entries at and right of its pivot are never read again)
             if (j + 1 < NX) {
                 mrow[j + 1] -= mrow[j] * lane_bcast(mrow[j], j + 1);
                 const double d = lane_bcast(mrow[j + 1], j + 1);
@@ -3523,16 +3540,17 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
     const int lj = lane & 15, lk = lane >> 4, ljc = (lj < NX) ? lj : 0;
     const bool ljin = lj < NX;
     // the five products of a step: Y Y^T -> dS (-=), Z Y^T -> dT (= -), Z Z^T -> dZ (-=), W Y^T -> gG, W Z^T -> gH (operands: the wave's Yl / Zl / Wl)
-    auto products = [&](double* dS, double* dT, double* dZ, double* gG, double* gH, const bool with_spike) {
-        d4_t accS = {0.0, 0.0, 0.0, 0.0}, accG = accS, accT = accS, accZ = accS, accH = accS;
+    // (Z Z^T is not stored step by step: the wave's accumulator accZ collects it over all of its steps and reaches the separator's area once, at the end)
+    auto products = [&](const double* yop, const double* zop, const double* wop, double* dS, double* dT, d4_t& accZ, double* gG, double* gH, const bool with_spike) {
+        d4_t accS = {0.0, 0.0, 0.0, 0.0}, accG = accS, accT = accS, accH = accS;
 #pragma unroll
         for (int k0 = 0; k0 < NX; k0 += 4) {
-            double yv = Yl[ljc * NX + k0 + lk], wv = Wl[ljc * NX + k0 + lk];
+            double yv = yop[ljc * NX + k0 + lk], wv = wop[ljc * NX + k0 + lk];
             yv = ljin ? yv : 0.0; wv = ljin ? wv : 0.0;
             accS = __builtin_amdgcn_mfma_f64_16x16x4f64(yv, yv, accS, 0, 0, 0);
             accG = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, yv, accG, 0, 0, 0);
             if (with_spike) {
-                double zv = Zl[ljc * NX + k0 + lk];
+                double zv = zop[ljc * NX + k0 + lk];
                 zv = ljin ? zv : 0.0;
                 accT = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, yv, accT, 0, 0, 0);
                 accZ = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, zv, accZ, 0, 0, 0);
@@ -3546,36 +3564,43 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
                 const int e = i * NX + j;
                 dS[e] -= accS[r];
                 gG[e] = accG[r];
-                if (with_spike) { dT[e] = -accT[r]; dZ[e] -= accZ[r]; }
+                if (with_spike) dT[e] = -accT[r];
                 gH[e] = with_spike ? accH[r] : 0.0;
             }
         }
     };
-    double y2 = 0.0;
+    double y2 = 0.0, zy = 0.0;            // zy: S lanes, (Z y)[row] summed over the wave's steps
+    d4_t accZ = {0.0, 0.0, 0.0, 0.0};
     fetch(block_of(0));
+    __syncthreads();   // the identity rows are in place
     // ---- elimination of the wave's blocks (no workgroup barrier: the LDS areas belong to the wave)
     for (int s = 0; s < mysteps; ++s) {
         const int k = block_of(s);
         const unsigned long long fmask = __ballot(pfix != 0 && isD);
-        const bool fixed_r = (fmask >> row) & 1ull;
         double mrow[NX];
 #pragma unroll
-        for (int cc = 0; cc < NX; ++cc) {   // (selects, no branches)
-            const bool fixed_c = (fmask >> cc) & 1ull;
-            const double unit  = (row == cc) ? 1.0 : 0.0;
-            const double mail  = isD ? Dn[row * NX + cc] : (isS ? Tm[row * NX + cc] : gnl[cc]);
-            const double sum   = pm[cc] + mail + ((side == 1) ? pe[cc] : 0.0);
-            double v = 0.0;
-            v = isC ? pm[cc] : v;
-            v = isS ? mail : v;
-            v = isI ? unit : v;
-            v = isD ? ((fixed_r || fixed_c) ? unit : sum) : v;
-            v = isG ? (fixed_c ? 0.0 : sum) : v;
-            mrow[cc] = v;
+        for (int c2 = 0; c2 < NX / 2; ++c2) {   // (pm + mailbox) + pe, the operation order of big_chain2_kernel; the products by 0 / 1 are exact
+            const double2 mail = mailp[c2];
+            mrow[2 * c2]     = __builtin_fma(cpe, pe[2 * c2], __builtin_fma(cpm, pm[2 * c2], cmail * mail.x));
+            mrow[2 * c2 + 1] = __builtin_fma(cpe, pe[2 * c2 + 1], __builtin_fma(cpm, pm[2 * c2 + 1], cmail * mail.y));
+        }
+        if (fmask) {   // (wave-uniform; block 0 and a terminal equality) fixed components: unit row and column in D, no right-hand side
+            asm volatile("" ::: "memory");   // (a real branch: if-converted, these selects ran for every block)
+            const bool fixed_r = (fmask >> row) & 1ull;
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) {
+                const bool fixed_c = (fmask >> cc) & 1ull;
+                const double unit  = (row == cc) ? 1.0 : 0.0;
+                double v = mrow[cc];
+                v = (isD && (fixed_r || fixed_c)) ? unit : v;
+                v = (isG && fixed_c) ? 0.0 : v;
+                mrow[cc] = v;
+            }
         }
         if (isD) {   // the mailbox of the next block starts from this stage's contribution (upward) / empty (downward)
+            double2* dn2 = reinterpret_cast<double2*>(Dn + row * NX);
 #pragma unroll
-            for (int cc = 0; cc < NX; ++cc) Dn[row * NX + cc] = (side == 0) ? pe[cc] : 0.0;
+            for (int c2 = 0; c2 < NX / 2; ++c2) dn2[c2] = (side == 0) ? double2{pe[2 * c2], pe[2 * c2 + 1]} : double2{0.0, 0.0};
         }
         const double gn_base = (side == 0) ? pgn : 0.0;
         y2 += (lane == 0) ? py2 : 0.0;
@@ -3584,27 +3609,35 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
         const double acc = stacked_pass(mrow);
         if (isG) y2 += acc;                               // |y|^2
         if (isC) gnl[row] = gn_base - acc;                // rhs mailbox: GN - Y y
-        if (isS) gs[row] -= acc;                          // the separator's right-hand side: - Z y
+        zy += acc;                                        // (S lanes) the separator's right-hand side collects - Z y
         double* wk = ws + (size_t)k * BL::WS_STAGE;
         if (isI) wk[BL::WS_YV + row] = acc;               // a_k = W y
         if (isC || isS || isI) {
-            double* dst = (isC ? Yl : (isS ? Zl : Wl)) + row * NX;
+            double2* dst = reinterpret_cast<double2*>((isC ? Yl : (isS ? Zl : Wl)) + row * NX);
 #pragma unroll
-            for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
+            for (int c2 = 0; c2 < NX / 2; ++c2) dst[c2] = double2{mrow[2 * c2], mrow[2 * c2 + 1]};
         }
-        products(Dn, Tm, Ds, wk + BL::WS_L, wk + BL::WS_DN, spike);
+        products(Yl, Zl, Wl, Dn, Tm, accZ, wk + BL::WS_L, wk + BL::WS_DN, spike);
     }
-    if (mysteps == 0 && side == 0) fetch(m);   // (a segment of one or two blocks)
-    // wave 1 stages the separators' own parts for the reduced chain (its loop is over; the meeting blocks do not touch these areas)
-    if (wave == 1) {
-        for (int j = 1; j < NSEG; ++j) {
-            const int sj = sep_of(j);
-            const double* wq = ws + (size_t)sj * BL::WS_STAGE;
-            for (int e = lane; e < NN; e += 64) sm[CL::SEPD + j * NN + e] = wq[BL::WS_L + e];
-            if (lane < NX) sm[CL::SEPG + j * 16 + lane] = wq[BL::WS_YV + lane];
-            const unsigned long long fm = __ballot(lane < NX && p.comp[sj * S + (lane < NX ? lane : 0)].fixed != 0);
-            if (lane == 0) { sm[CL::SEPG + j * 16 + 12] = wq[BL::WS_Y2]; sm[CL::SEPG + j * 16 + 13] = (double)(unsigned)fm; }
+    auto flush_sep = [&]() {   // what the wave collected for its separator
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * r + lk, j = lj;
+            if (i < NX && j < NX) Ds[i * NX + j] -= accZ[r];
         }
+        if (isS) gs[row] -= zy;
+    };
+    if (side == 1) flush_sep();
+    if (mysteps == 0 && side == 0) fetch(m);   // (a segment of one or two blocks)
+    // a downward wave stages the separator behind its first block for the reduced chain (its loop is over: its operand areas are dead, and
+    // the meeting blocks do not touch them)
+    if (side == 1 && spike) {
+        const int sj = b + 1;
+        const double* wq = ws + (size_t)sj * BL::WS_STAGE;
+        for (int e = lane; e < NN; e += 64) Yl[e] = wq[BL::WS_L + e];
+        if (lane < NX) Zl[lane] = wq[BL::WS_YV + lane];
+        const unsigned long long fm = __ballot(lane < NX && p.comp[sj * S + (lane < NX ? lane : 0)].fixed != 0);
+        if (lane == 0) { Zl[12] = wq[BL::WS_Y2]; Zl[13] = (double)(unsigned)fm; }
     }
     __syncthreads();
     // ---- the meeting block of every segment (upward wave): own parts + both mailboxes, "next" = the right separator, spike = the left one
@@ -3631,7 +3664,7 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
         const double acc = stacked_pass(mrow);
         if (isG) y2 += acc;
         if (isC) gs1[row] -= acc;                         // right separator: - Y y
-        if (isS) gs[row] -= acc;                          // left separator:  - Z y
+        zy += acc;                                        // left separator:  - Z y
         double* wk = ws + (size_t)m * BL::WS_STAGE;
         if (isI) wk[BL::WS_YV + row] = acc;
         if (isC || isS || isI) {
@@ -3639,23 +3672,26 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
 #pragma unroll
             for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
         }
-        products(Ds1, sm + CL::RC + seg * NN, Ds, wk + BL::WS_L, wk + BL::WS_DN, true);
+        products(Yl, Zl, Wl, Ds1, Tm, accZ, wk + BL::WS_L, wk + BL::WS_DN, true);   // (the spike mailbox has been read: it takes the separators' coupling)
+        flush_sep();
     }
     __syncthreads();
     // ---- reduced chain over the separators (wave 1): D_j = own + what the two neighbouring waves collected, coupling to the next
     //      separator = (segment j's  -Z Y^T)^T, plain twisted-free elimination (NSEG - 1 blocks), then its back-substitution
     if (wave == 1) {
-        double* Dr = sm + CL::DR;
-        double* gr = sm + CL::GRM;
-        for (int e = lane; e < NN + 16; e += 64) Dr[e] = 0.0;   // (DR and GRM are adjacent)
+        double* w0 = sm;                                  // wave 0's areas (its meeting block is done)
+        double *Dr = w0 + CL::ZL, *gr = w0 + CL::GN, *yop = w0 + CL::YL, *wop = w0 + CL::WL;
+        auto area = [&](int w) { return sm + w * CL::PER_WAVE; };
+        for (int e = lane; e < NN; e += 64) Dr[e] = 0.0;
+        if (lane < 16) gr[lane] = 0.0;
         for (int j = 1; j < NSEG; ++j) {
-            const double* DsL = sm + (2 * (j - 1) + 1) * CL::PER_WAVE + CL::DS;   // downward wave of the segment on the left
-            const double* DsR = sm + (2 * j) * CL::PER_WAVE + CL::DS;             // upward wave of the segment on the right
-            const double* gsL = sm + (2 * (j - 1) + 1) * CL::PER_WAVE + CL::GS;
-            const double* gsR = sm + (2 * j) * CL::PER_WAVE + CL::GS;
-            const double* own = sm + CL::SEPD + j * NN;
-            const double* og  = sm + CL::SEPG + j * 16;
-            const double* rc  = sm + CL::RC + j * NN;     // segment j lies between separator j and j + 1
+            const double* DsL = area(2 * j - 1) + CL::DS;   // downward wave of the segment on the left
+            const double* DsR = area(2 * j) + CL::DS;       // upward wave of the segment on the right
+            const double* gsL = area(2 * j - 1) + CL::GS;
+            const double* gsR = area(2 * j) + CL::GS;
+            const double* own = area(2 * j - 1) + CL::YL;   // staged by the downward wave on the left
+            const double* og  = area(2 * j - 1) + CL::ZL;
+            const double* rc  = area(2 * j) + CL::TM;       // segment j lies between separator j and j + 1
             const unsigned long long fmask = (unsigned long long)(unsigned)og[13];
             const bool fixed_r = (fmask >> row) & 1ull;
             const bool last = (j == NSEG - 1);
@@ -3678,10 +3714,12 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
                 if (isI) dxs[sep_of(j) * NX + row] = acc;   // x = W y
             }
             else {
+                double* GRj = area(2 * j) + CL::ZL;         // (upward wave 2 j: dead since its meeting block)
+                double* ARj = area(2 * j) + CL::GN;
                 if (isC) gr[row] = -acc;
-                if (isI) sm[CL::AR + j * 16 + row] = acc;
+                if (isI) ARj[row] = acc;
                 if (isC || isI) {
-                    double* dst = (isC ? Yl : Wl) + row * NX;
+                    double* dst = (isC ? yop : wop) + row * NX;
 #pragma unroll
                     for (int cc = 0; cc < NX; ++cc) dst[cc] = mrow[cc];
                 }
@@ -3689,13 +3727,13 @@ __global__ __launch_bounds__(128 * NSEG) void big_chain3_kernel(const FactorPara
 #pragma unroll
                     for (int cc = 0; cc < NX; ++cc) Dr[row * NX + cc] = 0.0;
                 }
-                products(Dr, nullptr, nullptr, sm + CL::GR + j * NN, Zl, false);   // (gH: scratch)
+                products(yop, yop, wop, Dr, nullptr, accZ, GRj, w0 + CL::DN, false);   // (gH: scratch)
             }
         }
         for (int j = NSEG - 2; j >= 1; --j) {
             const double xn = isD ? dxs[sep_of(j + 1) * NX + lane] : 0.0;
-            double v = isD ? sm[CL::AR + j * 16 + lane] : 0.0;
-            const double* g = sm + CL::GR + j * NN + (isD ? lane : 0) * NX;
+            double v = isD ? (area(2 * j) + CL::GN)[lane] : 0.0;
+            const double* g = area(2 * j) + CL::ZL + (isD ? lane : 0) * NX;
 #pragma unroll
             for (int i = 0; i < NX; ++i) v -= g[i] * lane_bcast(xn, i);
             if (isD) dxs[sep_of(j) * NX + lane] = v;

@@ -1,5 +1,5 @@
 """cfg 5 (quadrotor, multiple shooting + RK4, N = 200, batch 512): a few solves -- the command rocprofv3 --kernel-trace --stats wraps.
-    python tools/profile_cfg5.py [batch] [solves]"""
+    python tools/profile_cfg5.py [batch] [solves] [chain_variant]"""
 import os
 import sys
 import time
@@ -15,6 +15,8 @@ d = problems.quad_desc()
 x0, xf = problems.quad_instances(B)
 s = BatchedLevenbergMarquardt(d, B)
 s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+if len(sys.argv) > 3:
+    s.set_option("chain_variant", int(sys.argv[3]))
 s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
 s.restore_instance_data(); s.solve(new_run=True); s.synchronize()
 t0 = time.perf_counter()
