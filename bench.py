@@ -270,10 +270,49 @@ def secondary_leg(cfg, iterations, device):
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
         alg = per_stage * desc.N * B
-        out["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance)", "bytes_per_launch": alg,
+        out["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain3_kernel (one factorisation of every instance)", "bytes_per_launch": alg,
                            "ms_per_launch": f_ms, "achieved": alg / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": alg / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
     del solver
+    return out
+
+
+def hessian_leg(desc, B, x0, xf, device):
+    """Operators of the exact-Hessian path on the headline structure: corbo_hip_eval_hessians (lower part, values left in HBM) for the
+    bench batch and for ONE OCP (what the drop-in adapter's Hessian-path entry points run).  Wall time per call around a device-resident call +
+    synchronize; algorithmic bytes = read vertices + equality multipliers, write the three value lists."""
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    out = {"bound": "hbm", "kernel": "hessian_kernel (mode 0: Hessian values of every stage's edges, forward differences of central-difference Jacobians)",
+           "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+    prof = profile_kernel_avg_ns(PROFILE_ROUND + "_hessian_kernel_stats.csv", "hessian_kernel")
+    for tag, b in (("batch", B), ("single", 1)):
+        s = BatchedLevenbergMarquardt(desc, b, device=device)
+        rng = np.random.default_rng(0)
+        X = s.init_trajectory(x0[:b], xf[:b]) + 0.02 * rng.normal(size=(b, s.dims.nv))
+        X[:, : desc.nx] = x0[:b]
+        s.set_instance_data(X, xref=xf[:b])
+        me = rng.uniform(0.2, 1.0, (b, s.dims.eq))
+        st = s.hessian_structure(True)
+        nnz = [len(st[c][0]) for c in range(3)]
+        s.eval_hessians(True, 1.0, me, None)   # multipliers resident from here on
+        n = 30 if b > 1 else 200
+        s.eval_hessians_views(True, 1.0, None, None, device=True)
+        s.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s.eval_hessians_views(True, 1.0, None, None, device=True)
+        s.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        alg = 8 * b * (s.dims.nv + s.dims.eq + sum(nnz))
+        out[tag] = {"instances": b, "nnz_obj_eq_ineq": nnz, "ms_per_call": ms, "bytes_per_call": alg, "achieved": alg / (ms * 1e-3) / 1e9,
+                    "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        del s
+    out["achieved"], out["frac"] = out["batch"]["achieved"], out["batch"]["frac"]
+    out["profile_avg_ms"] = prof[0] * 1e-6 if prof else None
+    out["profile"] = prof[2] if prof else None
+    out["timing"] = "wall clock around device-resident calls (values left in HBM), synchronize on both sides"
+    out["note"] = ("fp64-compute-bound, not a bandwidth kernel: ~100 central-difference edge evaluations per stage (2 dynamics evaluations each); the fraction is quoted "
+                   "for completeness.  One OCP: the stage's blocks are spread over ~15 waves per 64 stages (HessParams::split = 2), a batch that fills the chip walks them per lane")
     return out
 
 
@@ -487,7 +526,7 @@ def main():
           "profile_avg_ms": prof[0] * 1e-6 if prof else None, "profile": prof[2] if prof else None}
     line["roofline_sweep"] = rs
     if cfg == 5:
-        # big-block family: an LM pass is sweep (residual) -> big_stage_kernel -> big_chain2_kernel; the last two are 81 % of the GPU time
+        # big-block family: an LM pass is sweep (residual) -> big_stage_kernel -> big_chain3_kernel (N >= 64; shorter horizons: big_chain2_kernel); the last two are 80 % of the GPU time
         # of a solve (profiles/r03_cfg5_kernel_stats.csv).  One factorisation of EVERY instance (stage + chain launch), HIP events
         # around 5 back-to-back pairs (corbo_hip_time_factor).  Algorithmic bytes per shooting interval: stage kernel
         # reads x_k u_k, the stored RK4 end state, the bounds (60 doubles) and writes the 572-double stage record; the chain kernel
@@ -498,9 +537,9 @@ def main():
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
         alg_pair = per_stage * desc.N * B
-        pc = profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain2_kernel"))
+        pc = profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain3_kernel" if desc.N >= 64 else "big_chain2_kernel"))
         qpmc = load_profile_json(PROFILE_ROUND + "_cfg5_pmc.json", B, desc.N)
-        line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain2_kernel (one factorisation of every instance: FD Jacobian + assemble, then the block chain)",
+        line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain3_kernel (one factorisation of every instance: FD Jacobian + assemble, then the partitioned block chain)",
                             "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                             "traffic": qpmc["hbm_bytes_per_launch"] if qpmc else None, "traffic_source": qpmc["source"] if qpmc else None,
                             "bytes_per_launch": alg_pair, "bytes_per_interval": per_stage, "ms_per_launch": f_ms,
@@ -538,6 +577,10 @@ def main():
     line["host_inclusive"] = {"ms_per_step": host_ms, "value_rank0": B * args.iterations * solves / (host_ms * 1e-3),
                               "what": "set_instance_data (H2D of x, xref from pageable host memory) + solve(s) + get_solution (D2H into caller arrays), rank 0"}
     if rank == 0 and world == 1 and cfg == 3 and not args.no_secondary:
+        try:
+            line["roofline_hessian"] = hessian_leg(desc, B, x0, xf, local_rank)
+        except Exception as e:
+            line["roofline_hessian"] = {"error": repr(e)}
         # every other BASELINE configuration, driver-visible in the same line (a few hundred ms of GPU time each)
         line["secondary"] = {}
         for c2 in (1, 2, 5):

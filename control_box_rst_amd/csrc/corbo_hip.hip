@@ -180,6 +180,7 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
+    int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
     int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, see FactorParams::chain_variant
     int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
     int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
@@ -1291,6 +1292,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "pass_timeline") h->pass_timeline_inst = value;
     else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
     else if (n == "chain_variant") h->chain_variant = value;
+    else if (n == "hess_split") h->hess_split = value;
     else if (n == "stagger") h->stagger = value;
     else if (n == "pass_threads") h->pass_threads = value;
     else if (n == "lag_priority") h->lag_priority = value;
@@ -1561,6 +1563,10 @@ static int eval_hessians_device(corbo_hip_handle h, int lower_part_only, double 
     if (mult_ineq && hp.ineq_dim > 0) { rc = upload_through_pin(h, mult_ineq, B * hp.ineq_dim, h->hb_mi); if (rc) return rc; hp.mult_ineq = h->hb_mi.d(); }
     hp.mode = 0;
     hp.mult_obj = mult_obj;
+    {   // how the blocks of a stage are spread over waves (hessian_kernel): few instances -> by block, a batch that fills the chip anyway -> not at all
+        const long waves = (long)((h->S.N + 63) / 64) * h->active;
+        hp.split = h->hess_split >= 0 ? h->hess_split : (waves > 768 ? 0 : (waves > 256 ? 1 : 2));   // (measured, unicycle N = 100: one OCP 171 -> 86 -> 43 us with split 0 / 1 / 2, 32 OCPs 173 / 89 / 66, 1024 OCPs 284 / 380 / 838)
+    }
     const SweepParams sp = h->sweep_params(0, 0, 1.0, 1.0, 1.0, nullptr);
     if (to_pinned) HIP_TRY(h->hb_pin.need(off[3] * sizeof(double)));
     if (!launch_hessian(h->S.desc, sp, hp, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no Hessian kernel for this dynamics/defect");

@@ -4313,7 +4313,7 @@ struct HessEdge {
     // into `out` and computeEqualityHessian[Inc](.., mult_eq_part) into `out2` (edge_interface.cpp:525-634) -- both lists advance by the same
     // blocks; the Jacobian at the perturbed point is the joint one again (the other part's rows are not read: same perturbation cycle, same values).
     __device__ static int hessian_blocks(int kind, int cat, bool lower, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double mult_obj,
-                                         const double* mult, double* out, double* out2, double* out3)
+                                         const double* mult, double* out, double* out2, double* out3, int vi_only = -1, int vj_only = -1)
     {
         constexpr double hdelta = 1e-2;
         const int ed = edge_dim(kind), nv = n_verts(kind);
@@ -4323,12 +4323,14 @@ struct HessEdge {
         for (int vi = 0; vi < nv; ++vi) {
             const int oi = vert_off(kind, vi), di = vert_dim(kind, vi), ni = unfixed(fm, oi, di);
             if (ni == 0) continue;
-            jacobian(kind, vi, fm, xl, xr, mp, jac1);
             const int vend = lower ? vi + 1 : nv;
+            const bool mine = (vi_only < 0 || vi == vi_only);   // (the kernel splits an edge's blocks over waves: by row vertex, or by block)
+            if (mine) jacobian(kind, vi, fm, xl, xr, mp, jac1);
             for (int vj = 0; vj < vend; ++vj) {
                 const int oj = vert_off(kind, vj), dj = vert_dim(kind, vj), nj = unfixed(fm, oj, dj);
                 if (nj == 0) continue;
                 const bool diag_lower = lower && vi == vj;
+                if (!mine || (vj_only >= 0 && vj != vj_only)) { at += diag_lower ? ni * (ni + 1) / 2 : ni * nj; continue; }
                 for (int part = 0; part < nparts; ++part) {
                     if (cat == 0) {   // least-squares objective edge: 2 m J_i^T J_j.  Eigen evaluates small products (rows + cols + depth < 20)
                         // coefficient-based with (2 m J_i^T) as the left factor -- every term scaled first -- and larger ones through its GEMM
@@ -4449,10 +4451,20 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         if (so[2] >= 0) add(final_stage ? EK_FINAL_EQ : EK_DEFECT, 1, ve + so[2], me);
         if (so[3] >= 0) add(final_stage ? EK_FINAL_INEQ : EK_STAGE_INEQ, 2, vi + so[3], mi);
         }
+        // Work split (HessParams::split, uniform per wave: blockIdx.z): 0 = this lane walks all edges of its stage (round 3: two waves per
+        // instance at N = 100 and a dependent chain of 35 k instructions per lane, whatever the batch); 1 = one wave per (edge, row vertex i):
+        // the base Jacobian J_i once, then its blocks (i, j); 2 = one wave per block (i, j) (J_i recomputed per block: + 30 % evaluations, a
+        // quarter of the depth).  The lanes of a wave are 64 stages of the SAME edge and vertex: no divergence.  The host picks by batch size.
+        const int gz = blockIdx.z;
+        const int ge = hp.split ? gz / (hp.split == 2 ? 16 : 4) : -1, gvi = hp.split ? (hp.split == 2 ? (gz / 4) % 4 : gz % 4) : -1, gvj = (hp.split == 2) ? gz % 4 : -1;
         double* next = nullptr;
         for (int e = 0; e < n_edges; ++e) {
             double* out = outs[e] ? outs[e] : next;   // (the duplicated dt edge follows the first one)
-            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out, outs2[e], outs3[e]);
+            if (ge >= 0 && e != ge) {   // another wave's edge: only the second dt edge needs to know where the first one ends (one 1 x 1 block)
+                next = out + (((fm >> (W - 1)) & 1u) ? 0 : 1);
+                continue;
+            }
+            const int n = HE::hessian_blocks(kinds[e], cats[e], lower, fm, xl, xr, mpl, hp.mult_obj, mults[e], out, outs2[e], outs3[e], gvi, gvj);
             next = out + n;
         }
     }
@@ -4556,7 +4568,8 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
 template <int DYN, int DEFECT>
 void launch_hessian_t(const SweepParams& p, const HessParams& hp, hipStream_t stream)
 {
-    hipLaunchKernelGGL((hessian_kernel<DYN, DEFECT>), dim3((p.N + 63) / 64, p.batch), dim3(64), 0, stream, p, hp);
+    const int gz = (hp.mode == 0 && hp.split) ? 6 * (hp.split == 2 ? 16 : 4) : 1;   // Hessian values: waves per (edge, row vertex [, column vertex]) -- at most 6 edges per stage, 4 vertices per edge
+    hipLaunchKernelGGL((hessian_kernel<DYN, DEFECT>), dim3((p.N + 63) / 64, p.batch, gz), dim3(64), 0, stream, p, hp);
 }
 
 template <int DYN>

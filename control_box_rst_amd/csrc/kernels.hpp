@@ -148,6 +148,7 @@ struct BandParams {
 // form (values, lbA, ubA); mode 2: gradient and value of the objective.  Structure: build_hessian_structure (structure.hpp).
 struct HessParams {
     int32_t mode, lower;
+    int32_t split;              // mode 0: 0 = one lane walks all edges of its stage, 1 = one wave per (edge, row vertex), 2 = per block (hessian_kernel); chosen from the batch size
     double mult_obj;
     const double* mult_eq;      // [batch][eq_dim] or null (= 1)
     const double* mult_ineq;    // [batch][ineq_dim] or null

@@ -24,12 +24,14 @@ run lwrite --pmc WRITE_SIZE -d "$OUT/lwrite" -o q --output-format csv -- python 
 # ---- issue / wait counters of the solve kernel, fp64 matrix-core counters of the cfg-5 kernels
 run sq1 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d "$OUT/sq1" -o q --output-format csv -- python "$ROOT/bench.py" --solve-only --steps 5 --warmup 1
 run sq2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -d "$OUT/sq2" -o q --output-format csv -- python "$ROOT/bench.py" --solve-only --steps 5 --warmup 1
+run hess   --kernel-trace --stats -d "$OUT/hess" -o hess --output-format csv -- python "$ROOT/tools/hessian_split_ab.py" 1024 0
+run hess1  --kernel-trace --stats -d "$OUT/hess1" -o hess1 --output-format csv -- python "$ROOT/tools/hessian_split_ab.py" 1 2
 run mfma --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d "$OUT/mfma" -o q --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3
 run qfetch --pmc FETCH_SIZE -d "$OUT/qfetch" -o q --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3
 run qwrite --pmc WRITE_SIZE -d "$OUT/qwrite" -o q --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3
 cd "$ROOT"
 P=$ROOT/profiles
-for n in bench sweep cfg5 loop; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done
+for n in bench sweep cfg5 loop hess hess1; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done; [ -f "$P/${RND}_hess_kernel_stats.csv" ] && mv "$P/${RND}_hess_kernel_stats.csv" "$P/${RND}_hessian_kernel_stats.csv"; [ -f "$P/${RND}_hess1_kernel_stats.csv" ] && mv "$P/${RND}_hess1_kernel_stats.csv" "$P/${RND}_hessian_single_kernel_stats.csv"
 python tools/summarize_pmc.py sweep "$(first sfetch '*counter_collection.csv')" "$(first swrite '*counter_collection.csv')" 1024 100 "$TAG, tools/profile_sweep.py 1024 10" | cut -c1-300
 python tools/summarize_pmc.py solve "$(first lfetch '*counter_collection.csv')" "$(first lwrite '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 10 --warmup 2" | cut -c1-300
 python tools/summarize_pmc.py sq "$(first sq1 '*counter_collection.csv')" "$(first sq2 '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 5 --warmup 1" | cut -c1-600

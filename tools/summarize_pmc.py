@@ -57,7 +57,7 @@ def cfg5_traffic(fetch_csv, write_csv, batch, N, tag):
     """HBM-side traffic of the two kernels of a cfg-5 factorisation, per full launch (the tail passes' small launches dropped)."""
     out = {"batch": batch, "N": N, "tag": tag, "kernels": {}}
     tot_raw = tot = 0.0
-    for kernel in ("big_stage_kernel", "big_chain2_kernel"):
+    for kernel in ("big_stage_kernel", "big_chain3_kernel"):
         f = per_dispatch(fetch_csv, kernel)["FETCH_SIZE"]
         w = per_dispatch(write_csv, kernel)["WRITE_SIZE"]
         f = [v for v in f if v > 0.5 * max(f)]
@@ -67,7 +67,7 @@ def cfg5_traffic(fetch_csv, write_csv, batch, N, tag):
                                   "hbm_bytes_per_launch_raw": (fa + wa) * 1024.0, "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
         tot_raw += (fa + wa) * 1024.0
         tot += (2.0 * fa + wa) * 1024.0
-    out["kernel"] = "big_stage_kernel + big_chain2_kernel"
+    out["kernel"] = "big_stage_kernel + big_chain3_kernel"
     out["hbm_bytes_per_launch_raw"], out["hbm_bytes_per_launch"] = tot_raw, tot
     out["source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {tag}; per-dispatch means over the full launches of each kernel, summed over "
                      "the pair; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction, WRITE_SIZE raw")
@@ -78,7 +78,7 @@ def cfg5_traffic(fetch_csv, write_csv, batch, N, tag):
 def mfma(path, batch, N, tag):
     """fp64 matrix-core counters of the cfg-5 kernels that use them."""
     out = {"batch": batch, "N": N, "tag": tag, "kernels": {}}
-    for kernel in ("big_stage_kernel", "big_chain2_kernel"):
+    for kernel in ("big_stage_kernel", "big_chain3_kernel"):
         acc = per_dispatch(path, kernel)
         if not acc:
             continue
