@@ -208,7 +208,7 @@ struct corbo_hip_solver {
     {
         SweepParams p{};
         p.batch = active; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
-        p.batch_total = batch; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2) ? 1 : 0;
+        p.batch_total = batch; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2 && band.n == 0) ? 1 : 0;   // (band route: the factorisation reads the stored Jacobian)
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         fill_dyn(p.mp.dyn);
@@ -320,7 +320,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         fp.N = S.N;
         const bool big = big_family_dims(desc->nx, desc->nu);   // big-block family (workspace + stage kernels)
         // small-block families: N <= 256 LDS-resident, 256 < N <= 1024 the long-horizon kernels (factor workspace in HBM; kernels.hip, factor_body GWS)
-        if (!device_kernels_exist(*desc) || factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256 && factor_work_doubles(*desc) == 0) || (S.dt_free && big)) {
+        if (!device_kernels_exist(*desc) || factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256 && factor_work_doubles(*desc) == 0)) {
             return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
         }
         if (!big && S.N > 256 && desc->weights_dense) return fail(CORBO_HIP_ERR_UNSUPPORTED, "non-diagonal weights on a horizon beyond 256 grid points: not built");
@@ -440,9 +440,13 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         }
         h->force_split = true;  // no fused pass kernel for the big-block family / the long horizons: factor and sweep are separate launches
     }
+    // The band factorisation (band_factor_kernel: H = J^T J from the stored Jacobian through static product lists, natural parameter order, a free dt
+    // as a border) takes the structures the stage-parallel kernels do not cover: integral-form constraint edges / control-deviation edges, and a FREE dt
+    // with state blocks of 5 .. 12 rows (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid around a big-block model: the stage and chain
+    // kernels of that family carry no border column) -- the general, slower path: one wave per instance, n sequential pivots.
+    const bool band_route = S.has_extra() || (S.dt_free && big_family_dims(S.nx, S.nu));
     if (S.has_extra()) {
         // ---- the sweep's extra-edge table, the plug-in parameters, the previous control (zeros, dt_ref: structured_optimal_control_problem.cpp:67-71)
-        h->force_split = true;   // separate launches: sweep_kernel<..., XE> + band_factor_kernel
         std::vector<XEdge> xe = S.xedges;   // (Jacobian offsets: the device-internal layout is the public order for these handles)
         CREATE_TRY(hipMalloc((void**)&h->d_xedges, xe.size() * sizeof(XEdge)));
         CREATE_TRY(hipMemcpy(h->d_xedges, xe.data(), xe.size() * sizeof(XEdge), hipMemcpyHostToDevice));
@@ -455,6 +459,9 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         for (size_t b = 0; b < B; ++b) up[b * (CORBO_HIP_MAX_NU + 1) + CORBO_HIP_MAX_NU] = S.desc.dt_ref;
         CREATE_TRY(hipMalloc((void**)&h->d_uprev, up.size() * sizeof(double)));
         CREATE_TRY(hipMemcpy(h->d_uprev, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (band_route) {
+        h->force_split = true;   // separate launches: sweep_kernel (residual + Jacobian in HBM) + band_factor_kernel
         // ---- band factorisation tables: H = J^T J entry by entry as sums of products of Jacobian values (natural parameter order; a free dt
         //      -- the last parameter -- as a border)
         const int n = S.dims.n, nb = S.dt_free ? n - 1 : n, m = S.dims.m, nnz = S.dims.nnz;
@@ -1422,7 +1429,7 @@ try {
     const SweepParams spe = h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     int rc = launch_sweep_checked(h, spe);
     if (rc) return rc;
-    if (jac_out && h->d_xe0) {
+    if (jac_out && h->d_xe0 && h->band.n == 0) {   // (band route: the sweep's stored Jacobian IS what the factorisation reads)
         // big-block family: what an LM pass differentiates is the stage kernel's Jacobian (never stored during a solve); the parity hook
         // returns THAT one -- every value is overwritten (an entry the stage kernel does not produce would come back as NaN)
         HIP_TRY(hipMemsetAsync(h->d_jac, 0xFF, (size_t)h->batch * h->nnz_pad * sizeof(double), h->stream));

@@ -5075,8 +5075,10 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d)
     const bool known_defect = d.defect >= CORBO_HIP_DEFECT_FORWARD && d.defect <= CORBO_HIP_DEFECT_RK4_SHOOTING;
     if (!known_defect) return false;
     auto is = [&](int nx, int nu) { return d.nx == nx && d.nu == nu; };
-    // big-block family: the grids with a fixed dt -- MultipleShootingGrid (explicit integrators) or FiniteDifferencesGrid (collocation formulas)
-    const bool big_grid = (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_MS) || (d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING && d.grid == CORBO_HIP_GRID_FD);
+    // big-block family: the shooting grids (explicit integrators) or the collocation grids (the four formulas); with a fixed dt the stage / chain
+    // kernels, with a free dt (...VariableGrid) the sweep kernel's stored Jacobian and the band factorisation (corbo_hip_create, band_route)
+    const bool big_grid = (d.defect == CORBO_HIP_DEFECT_RK4_SHOOTING && (d.grid == CORBO_HIP_GRID_MS || d.grid == CORBO_HIP_GRID_MS_VARIABLE)) ||
+                          (d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING && (d.grid == CORBO_HIP_GRID_FD || d.grid == CORBO_HIP_GRID_FD_VARIABLE));
 #if __has_include("models/_registry.inc")
 #define CORBO_HIP_USER_MODEL(NAME, SLOT, NX_, NU_, P0, P1, P2, P3) \
     if (d.dynamics == CORBO_HIP_DYN_USER + SLOT)                     \

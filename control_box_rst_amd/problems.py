@@ -196,7 +196,12 @@ QUAD_Q = (1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05)
 QUAD_R = (0.01, 0.1, 0.1, 0.1)
 
 
-def quad_desc(N=200, dt=0.05) -> ProblemDesc:
+def quad_desc(N=200, dt=0.05, time_optimal=False) -> ProblemDesc:
+    if time_optimal:   # vargrid=1 of oracle/ref_driver.cpp: MultipleShootingVariableGrid, free dt, x_f fixed, MinimumTime
+        return make_desc(grid=capi.GRID_MS_VARIABLE, defect=capi.DEFECT_RK4_SHOOTING, dynamics=capi.DYN_QUADROTOR, nx=12, nu=4, N=N, dt=dt,
+                         stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0, u_lb=(0.0, -1.0, -1.0, -1.0), u_ub=(20.0, 1.0, 1.0, 1.0),
+                         xf_fixed_mask=0xFFF, dt_lb=0.01, dt_ub=10.0, stage_ineq=capi.INEQ_BALL, ineq_params=(1.0, 0.5, 0.6, 0.4),
+                         dyn_params=(9.81, 1.0, 0.01, 0.01, 0.02))
     return make_desc(grid=capi.GRID_MS, defect=capi.DEFECT_RK4_SHOOTING, dynamics=capi.DYN_QUADROTOR, nx=12, nu=4, N=N, dt=dt,
                      q=QUAD_Q, r=QUAD_R, qf=tuple(10.0 * v for v in QUAD_Q),
                      u_lb=(0.0, -1.0, -1.0, -1.0), u_ub=(20.0, 1.0, 1.0, 1.0),
@@ -207,10 +212,16 @@ def quad_desc(N=200, dt=0.05) -> ProblemDesc:
 QUAD_WEIGHTS = (10.0, 10.0, 10.0)
 
 
-def planar_quadrotor_desc(N=50, dt=0.05) -> ProblemDesc:
+def planar_quadrotor_desc(N=50, dt=0.05, time_optimal=False, shooting=True) -> ProblemDesc:
     """The big-block user-model example csrc/models/planar_quadrotor.hpp (public dynamics id DYN_USER + 1; nx = 6, nu = 2): multiple shooting with
-    RK4, thrust bounds, keep-out ball on (x, z, theta) -- scenario pquad of oracle/ref_driver.cpp."""
+    RK4, thrust bounds, keep-out ball on (x, z, theta) -- scenario pquad of oracle/ref_driver.cpp.  time_optimal (vargrid=1 there): free dt on the
+    MultipleShootingVariableGrid (shooting) / FiniteDifferencesVariableGrid, x_f fixed, MinimumTime cost."""
     q = (1.0, 1.0, 0.5, 0.1, 0.1, 0.05)
+    if time_optimal:
+        grid, defect = (capi.GRID_MS_VARIABLE, capi.DEFECT_RK4_SHOOTING) if shooting else (capi.GRID_FD_VARIABLE, capi.DEFECT_CRANK_NICOLSON)
+        return make_desc(grid=grid, defect=defect, dynamics=capi.DYN_USER + 1, nx=6, nu=2, N=N, dt=dt, stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0,
+                         u_lb=(0.0, 0.0), u_ub=(12.0, 12.0), xf_fixed_mask=0b111111, dt_lb=0.01, dt_ub=10.0,
+                         stage_ineq=capi.INEQ_BALL, ineq_params=(1.0, 0.5, 0.0, 0.3), dyn_params=(1.0, 0.05, 0.25, 9.81))
     return make_desc(grid=capi.GRID_MS, defect=capi.DEFECT_RK4_SHOOTING, dynamics=capi.DYN_USER + 1, nx=6, nu=2, N=N, dt=dt,
                      q=q, r=(0.02, 0.02), qf=tuple(10.0 * v for v in q),
                      u_lb=(0.0, 0.0), u_ub=(12.0, 12.0),

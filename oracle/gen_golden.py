@@ -431,6 +431,11 @@ BIGMODEL = [
     ("pquad_fd_n10_midpoint", dict(scenario="pquad", grid="fd", N=10, iters=5, collocation="midpoint"), (1, 2, 3, 5)),
     ("pquad_fd_n10_teq", dict(scenario="pquad", grid="fd", N=10, iters=5, teq=1), (1, 2, 3, 5)),
     ("quad_fd_n10", dict(scenario="quad", grid="fd", N=10, iters=6), (1, 2, 4, 6)),
+    # a FREE dt around the big-block models (time-optimal transfer to a fixed x_f, MinimumTime): MultipleShootingVariableGrid / FiniteDifferencesVariableGrid
+    ("pquad_topt_n10", dict(scenario="pquad", vargrid=1, N=10, iters=6, w="100,100,100"), (1, 2, 3, 6)),
+    ("pquad_topt_n30", dict(scenario="pquad", vargrid=1, N=30, iters=8, w="100,100,100"), (1, 4, 8)),
+    ("pquad_fd_topt_n12", dict(scenario="pquad", grid="fd", vargrid=1, N=12, iters=6, w="100,100,100"), (1, 2, 3, 6)),
+    ("quad_topt_n8", dict(scenario="quad", vargrid=1, N=8, iters=5, w="100,100,100"), (1, 2, 5)),
 ]
 
 

@@ -451,7 +451,30 @@ static Built build(const Scenario& s, int iterations)
     {
         dyn = std::make_shared<QuadrotorRef>();
         if (s.name == "pquad") dyn = std::make_shared<PlanarQuadrotorRef>();
-        if (s.fd) b.grid = std::make_shared<FiniteDifferencesGrid>();   // grid=fd: the same OCP on the collocation grid
+        if (s.vargrid)
+        {   // vargrid=1: time-optimal transfer to a fixed x_f with a free dt (MultipleShootingVariableGrid, or FiniteDifferencesVariableGrid with grid=fd)
+            Eigen::Matrix<bool, -1, 1> fixed(s.name == "pquad" ? 6 : 12);
+            fixed.setConstant(true);
+            if (s.fd)
+            {
+                auto grid = std::make_shared<FiniteDifferencesVariableGrid>();
+                grid->setDtBounds(0.01, 10.0);
+                grid->setXfFixed(fixed);
+                b.grid = grid;
+            }
+            else
+            {
+                auto grid = std::make_shared<MultipleShootingVariableGrid>();
+                grid->setNumericalIntegrator(shootingIntegrator(s));
+                grid->setNRef(s.N);
+                grid->setDtRef(s.dt);
+                grid->setDtBounds(0.01, 10.0);
+                grid->setXfFixed(fixed);
+                b.ms_grid  = grid;
+                b.any_grid = grid;
+            }
+        }
+        else if (s.fd) b.grid = std::make_shared<FiniteDifferencesGrid>();   // grid=fd: the same OCP on the collocation grid
         else
         {
             b.ms_grid = std::make_shared<MultipleShootingGrid>();
@@ -587,8 +610,12 @@ static Built build(const Scenario& s, int iterations)
         r << 0.02, 0.02;
         Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
         Eigen::MatrixXd Qf = 10.0 * Q;
-        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
+        else
+        {
+            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        }
         b.ocp->setControlBounds(Eigen::Vector2d(0, 0), Eigen::Vector2d(12, 12));
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.0, 0.3));
     }
@@ -599,8 +626,12 @@ static Built build(const Scenario& s, int iterations)
         r << 0.01, 0.1, 0.1, 0.1;
         Eigen::MatrixXd Q = q.asDiagonal(), R = r.asDiagonal();
         Eigen::MatrixXd Qf = 10.0 * Q;
-        b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-        b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
+        else
+        {
+            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
+            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        }
         Eigen::VectorXd ulb(4), uub(4);
         ulb << 0, -1, -1, -1;
         uub << 20, 1, 1, 1;

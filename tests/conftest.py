@@ -65,9 +65,9 @@ def desc_for(g):
     if sc == "dint":
         return cost_option(problems.dint_desc(N=g["N"], dt=g["dt"], shooting=(g.get("grid") == "ms")))
     if sc == "quad":
-        d = problems.quad_desc(N=g["N"], dt=g["dt"])
+        d = problems.quad_desc(N=g["N"], dt=g["dt"], time_optimal=bool(g.get("vargrid")))
     elif sc == "pquad":   # the big-block user-model example (csrc/models/planar_quadrotor.hpp)
-        d = problems.planar_quadrotor_desc(N=g["N"], dt=g["dt"])
+        d = problems.planar_quadrotor_desc(N=g["N"], dt=g["dt"], time_optimal=bool(g.get("vargrid")), shooting=(g.get("grid") != "fd"))
     elif sc == "int3":
         d = problems.int3_desc(N=g["N"], dt=g["dt"], defect=defect, time_optimal=bool(g.get("vargrid")))
     elif sc == "lin":
@@ -85,8 +85,8 @@ def desc_for(g):
     else:
         raise KeyError(sc)
     # options of oracle/ref_driver.cpp recorded in the fixture header
-    if g.get("grid") == "fd":   # scenarios whose default is the shooting grid (quad, pquad) on the FiniteDifferencesGrid
-        d.grid, d.defect = capi.GRID_FD, defect
+    if g.get("grid") == "fd":   # scenarios whose default is the shooting grid (quad, pquad) on the FiniteDifferencesGrid (vargrid: ...VariableGrid)
+        d.grid, d.defect = (capi.GRID_FD_VARIABLE if g.get("vargrid") else capi.GRID_FD), defect
     if g.get("grid") == "ms":   # MultipleShootingGrid (vargrid: MultipleShootingVariableGrid, free dt) + RK4
         d.grid, d.defect = (capi.GRID_MS_VARIABLE if g.get("vargrid") else capi.GRID_MS), capi.DEFECT_RK4_SHOOTING
     if "ms_integrator" in g:    # IntegratorExplicitEuler / RungeKutta2 / RungeKutta3 on the shooting grid

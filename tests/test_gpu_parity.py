@@ -52,6 +52,8 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
         # ... and the same family on the FiniteDifferencesGrid (the four collocation formulas), incl. the 12-state quadrotor
         "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
+        # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation takes these
+        "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 # reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
@@ -59,6 +61,7 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
 # reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility
 X_TOL_BY = {"pquad_fd_n10": 2e-5, "pquad_fd_n24": 2e-5, "pquad_fd_n10_forward": 2e-5, "pquad_fd_n10_backward": 2e-5, "pquad_fd_n10_midpoint": 2e-5, "pquad_fd_n10_teq": 2e-5, "quad_fd_n10": 2e-5,   # (the same models on the collocation grid: tests/test_oracle_golden.py)
             "pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,   # (planar quadrotor: same kind of soft directions, see tests/test_oracle_golden.py)
+            "pquad_topt_n10": 3e-4, "pquad_topt_n30": 3e-4, "pquad_fd_topt_n12": 2e-5, "quad_topt_n8": 3e-4,   # (free dt around the same models)
             "quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
             # SimplePendulum with the reference's default length: g / l = 29 multiplies sin(phi) in the dynamics, so the last-ulp difference
             # between the device's sin and the host libm's (1e-16 / (2 delta) = 5e-8 in a finite-difference column) is amplified 29-fold

@@ -35,6 +35,8 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
         # ... and the same family on the FiniteDifferencesGrid (the four collocation formulas), incl. the 12-state quadrotor
         "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
+        # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation on the device
+        "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
 
@@ -46,6 +48,8 @@ X_TOL = {"quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4,
          "pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,
          # the same models on the collocation grid are stiffer in those directions: 3e-7 .. 4e-6 (chi2 to 1e-7)
          "pquad_fd_n10": 1e-5, "pquad_fd_n24": 1e-5, "pquad_fd_n10_forward": 1e-5, "pquad_fd_n10_backward": 1e-5, "pquad_fd_n10_midpoint": 1e-5, "pquad_fd_n10_teq": 1e-5, "quad_fd_n10": 1e-5,
+         # ... and with a free dt: the same soft directions (1e-5 at the later iterations, chi2 to 1e-9)
+         "pquad_topt_n10": 3e-4, "pquad_topt_n30": 3e-4, "pquad_fd_topt_n12": 1e-5, "quad_topt_n8": 3e-4,
          "cartpole_teq": 5e-6}   # 3.0e-6 at the fifth iteration (FD-noise level, different elimination order than Eigen's)
 
 
