@@ -4116,7 +4116,9 @@ struct HessEdge {
     static constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, W = S + NX + 1;
     static constexpr int MAXD = (NX > NU) ? NX : NU;
     static constexpr int MAXE = MAXD + 1;   // rows of the widest edge: the joint view of a mixed edge (1 objective value + NX equality values)
-    static constexpr bool MIXED_OK = (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING || DEFECT == DEFECT_SHOOTING_HIGH) && NX <= 4;
+    // (round 4: state blocks up to 8 rows -- the planar quadrotor; the 12-state instantiation compiles but does not finish on the hardware: > 100 s for a
+    // 4-interval problem, the same pathology as the four-call-site version of round 3 -- structure.cpp refuses it)
+    static constexpr bool MIXED_OK = (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING || DEFECT == DEFECT_SHOOTING_HIGH) && NX <= 8;
     // precompute() of MultipleShootingEdgeSingleControl (multiple_shooting_edges.h:214-229, 251-281): the grid's integrator on current = [cost; x]
     // with the integrand [c(x, u_k) against reference k; f(x, u_k)], c = QuadraticFormCost::computeIntegralStateControlTerm (quadratic_cost.cpp:
     // 186-230, diagonal weights in mp.sq / mp.sr).  The solveIVP overload for a generic integrand has the expressions of the one for the system
@@ -4125,10 +4127,9 @@ struct HessEdge {
     {
         dyn_full<DYN>(X + 1, u, mp.dyn, F + 1);
         double cost = 0.0, acc = 0.0;
-        for (int i = 0; i < NX; ++i) { const double xd = X[1 + i] - xr[i]; acc += (xd * mp.sq[i]) * xd; }
+        { double t[NX]; for (int i = 0; i < NX; ++i) { const double xd = X[1 + i] - xr[i]; t[i] = (xd * mp.sq[i]) * xd; } acc = eigen_sum<NX>(t); }   // (Eigen's reduction order: model.hpp)
         cost += acc;
-        acc = 0.0;
-        for (int i = 0; i < NU; ++i) acc += (u[i] * mp.sr[i]) * u[i];
+        { double t[NU]; for (int i = 0; i < NU; ++i) t[i] = (u[i] * mp.sr[i]) * u[i]; acc = eigen_sum<NU>(t); }
         cost += acc;
         F[0] = cost;
     }
@@ -4231,9 +4232,9 @@ struct HessEdge {
             case EK_DT_COST: case EK_DT_QCOST: out[0] = mp.dt_weight * xl[W - 1]; break;   // (plain form: dt_weight = N - 1)
             // plain objective edges, lsq_form = false (quadratic_cost.cpp:133-138,165-170, final_state_cost.cpp:102-108): xd^T * W_diag * xd, the
             // expression of TerminalBall; mp.sq / sr / sqf hold the weights themselves for such a descriptor
-            case EK_STATE_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sq[i]) * xd; } out[0] = acc; break; }
-            case EK_CONTROL_QCOST: { double acc = 0.0; for (int i = 0; i < NU; ++i) acc += (xl[NX + i] * mp.sr[i]) * xl[NX + i]; out[0] = acc; break; }
-            case EK_FINAL_QCOST: { double acc = 0.0; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; acc += (xd * mp.sqf[i]) * xd; } out[0] = acc; break; }
+            case EK_STATE_QCOST: { double t[NX]; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; t[i] = (xd * mp.sq[i]) * xd; } out[0] = 0.0 + eigen_sum<NX>(t); break; }
+            case EK_CONTROL_QCOST: { double t[NU]; for (int i = 0; i < NU; ++i) t[i] = (xl[NX + i] * mp.sr[i]) * xl[NX + i]; out[0] = 0.0 + eigen_sum<NU>(t); break; }
+            case EK_FINAL_QCOST: { double t[NX]; for (int i = 0; i < NX; ++i) { const double xd = xl[i] - xr[i]; t[i] = (xd * mp.sqf[i]) * xd; } out[0] = 0.0 + eigen_sum<NX>(t); break; }
             // QuadraticFormCost::computeIntegralStateControlTerm (quadratic_cost.cpp:186-230): cost = 0; cost += xd^T Q xd; cost += u^T R u, at
             // (x_k, u_k) and -- trapezoidal rule -- at (x_{k+1}, u_k), both against reference k; 0.5 dt (c1 + c2) resp. c1 *= dt
             case EK_INTEGRAL_TRAP: case EK_INTEGRAL_LEFT: {
@@ -4241,10 +4242,9 @@ struct HessEdge {
                 for (int end = 0; end < (kind == EK_INTEGRAL_TRAP ? 2 : 1); ++end) {
                     const double* xe = end ? xl + S : xl;
                     double cost = 0.0, acc = 0.0;
-                    for (int i = 0; i < NX; ++i) { const double xd = xe[i] - xr[i]; acc += (xd * mp.sq[i]) * xd; }
+                    { double t[NX]; for (int i = 0; i < NX; ++i) { const double xd = xe[i] - xr[i]; t[i] = (xd * mp.sq[i]) * xd; } acc = eigen_sum<NX>(t); }
                     cost += acc;
-                    acc = 0.0;
-                    for (int i = 0; i < NU; ++i) acc += (xl[NX + i] * mp.sr[i]) * xl[NX + i];
+                    { double t[NU]; for (int i = 0; i < NU; ++i) t[i] = (xl[NX + i] * mp.sr[i]) * xl[NX + i]; acc = eigen_sum<NU>(t); }
                     cost += acc;
                     c[end] = cost;
                 }

@@ -511,13 +511,37 @@ __device__ __forceinline__ void rk4_end_state(const double* x1, const double* u1
 
 // final-stage inequality TerminalBall, diagonal S, non-zero reference (final_state_constraints.cpp:72-76):
 //   xd = x - xref;  c = xd^T * S_diag * xd - gamma   (row vector times diagonal, then the inner product)
+// Sum of the n terms of a quadratic form x^T W_diag x in the order of the reference's arithmetic: Eigen's vectorised reduction of the inner product
+// (Redux.h, LinearVectorizedTraversal: packets of two doubles on the reference's baseline x86-64 build, two packet accumulators) -- lane sums
+// (t0 + t2 [+ t4 ..]) and (t1 + t3 [+ t5 ..]), added, then an odd last term.  Up to three terms the plain left-to-right sum; from four on the
+// rounding differs (oracle/corbo_oracle.c eigen_sum, pinned bit for bit by the nx = 6 / 12 fixtures of the Hessian path).
+template <int N>
+__host__ __device__ __forceinline__ double eigen_sum(const double (&t)[N])
+{
+    constexpr int AS2 = (N / 4) * 4, AS1 = (N / 2) * 2;
+    if constexpr (N == 1) return t[0];
+    else {
+        double a0 = t[0], a1 = t[1];
+        if constexpr (AS1 > 2) {
+            double b0 = t[2], b1 = t[3];
+#pragma unroll
+            for (int i = 4; i < AS2; i += 4) { a0 += t[i]; a1 += t[i + 1]; b0 += t[i + 2]; b1 += t[i + 3]; }
+            a0 += b0; a1 += b1;
+            if constexpr (AS1 > AS2) { a0 += t[AS2]; a1 += t[AS2 + 1]; }
+        }
+        double res = a0 + a1;
+        if constexpr (N > AS1) res += t[N - 1];
+        return res;
+    }
+}
+
 template <int NX>
 __device__ __forceinline__ double terminal_ball(const double* x, const double* xref, const double* prm)
 {
-    double acc = 0.0;
+    double t[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { const double xd = x[i] - xref[i]; acc += (xd * prm[i]) * xd; }
-    return acc - prm[NX];
+    for (int i = 0; i < NX; ++i) { const double xd = x[i] - xref[i]; t[i] = (xd * prm[i]) * xd; }
+    return eigen_sum<NX>(t) - prm[NX];
 }
 
 // stage inequality on x_k (keep-out ball, cfg 5): c = r^2 - |pos - center|^2  (<= 0 feasible)

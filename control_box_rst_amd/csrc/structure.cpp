@@ -61,8 +61,8 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         if (d.cost_integral && (!d.cost_nonlsq || !(quad_ok || mtq_ok)))
             return "cost_integral: with cost_nonlsq = 1, a quadratic stage cost on the FiniteDifferencesGrid / the MultipleShootingGrid or MinTimeQuadratic on the FiniteDifferencesVariableGrid";
     }
-    if (d.cost_integral && d.grid == CORBO_HIP_GRID_MS && (d.stage_ineq || (d.weights_dense & 3) || d.nx > 4))
-        return "cost_integral on the MultipleShootingGrid (MultipleShootingEdgeSingleControl): diagonal Q / R, no stage inequality, nx <= 4";
+    if (d.cost_integral && d.grid == CORBO_HIP_GRID_MS && (d.stage_ineq || (d.weights_dense & 3) || d.nx > 8))
+        return "cost_integral on the MultipleShootingGrid (MultipleShootingEdgeSingleControl): diagonal Q / R, no stage inequality, nx <= 8";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
     if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
     if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";

@@ -207,15 +207,37 @@ static void dynamics(const corbo_hip_problem_desc* d, const double* x, const dou
 /* ------------------------------------------------------------------------------------------------------------ */
 /* edge values                                                                                                    */
 
+/* sum of the n terms of a quadratic form  x^T W_diag x  in the order the reference's arithmetic takes: the inner product is Eigen's
+ * (lhs.transpose().cwiseProduct(rhs)).sum() (GeneralProduct, InnerProduct), a vectorised reduction with packets of two doubles (the
+ * reference is compiled for baseline x86-64: SSE2) and two packet accumulators -- src/extern/eigen3/Eigen/src/Core/Redux.h,
+ * redux_impl<Func, Derived, LinearVectorizedTraversal, NoUnrolling>: ((t0 + t4 + ..) + (t2 + t6 + ..)) lane by lane, a leftover packet, the two
+ * lanes added, then the odd element.  Up to three terms this is the plain left-to-right sum; from four terms on the rounding differs. */
+static double eigen_sum(const double* t, int n)
+{
+    const int as2 = (n / 4) * 4, as1 = (n / 2) * 2;
+    if (n <= 0) return 0.0;
+    if (!as1) return t[0];
+    double a0 = t[0], a1 = t[1];
+    if (as1 > 2) {
+        double b0 = t[2], b1 = t[3];
+        for (int i = 4; i < as2; i += 4) { a0 += t[i]; a1 += t[i + 1]; b0 += t[i + 2]; b1 += t[i + 3]; }
+        a0 += b0; a1 += b1;
+        if (as1 > as2) { a0 += t[as2]; a1 += t[as2 + 1]; }
+    }
+    double res = a0 + a1;
+    for (int i = as1; i < n; ++i) res += t[i];
+    return res;
+}
+
 /* QuadraticFormCost::computeIntegralStateControlTerm (quadratic_cost.cpp:186-230), diagonal weights: cost = 0; cost += xd^T Q xd; cost += u^T R u */
 static void integral_cost_term(const oracle_problem* p, const double* rk, const double* x, const double* u, double* cost_out)
 {
     const corbo_hip_problem_desc* d = &p->d;
     double cost = 0.0, acc = 0.0;
-    for (int i = 0; i < d->nx; ++i) { double xd = x[i] - rk[i]; acc += (xd * d->q_diag[i]) * xd; }
+    { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nx; ++i) { double xd = x[i] - rk[i]; t_[i] = (xd * d->q_diag[i]) * xd; } acc += eigen_sum(t_, d->nx); }
     cost += acc;
     acc = 0.0;
-    for (int i = 0; i < d->nu; ++i) acc += (u[i] * d->r_diag[i]) * u[i];
+    { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nu; ++i) t_[i] = (u[i] * d->r_diag[i]) * u[i]; acc += eigen_sum(t_, d->nu); }
     cost += acc;
     cost_out[0] = cost;
 }
@@ -399,7 +421,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref; /* getReferenceCached(k) */
             if (e->nonlsq) { /* lsq_form = false, diagonal mode: xd^T * Q_diag * xd (quadratic_cost.cpp:133-138; the expression of TerminalBall) */
                 double acc = 0.0;
-                for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->q_diag[i]) * xd; }
+                { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; t_[i] = (xd * d->q_diag[i]) * xd; } acc += eigen_sum(t_, d->nx); }
                 out[0] = acc;
                 break;
             }
@@ -417,7 +439,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             const double* uk = x + p->v[e->vert[0]].off;
             if (e->nonlsq) { /* u_k^T * R_diag * u_k (quadratic_cost.cpp:165-170) */
                 double acc = 0.0;
-                for (int i = 0; i < d->nu; ++i) acc += (uk[i] * d->r_diag[i]) * uk[i];
+                { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nu; ++i) t_[i] = (uk[i] * d->r_diag[i]) * uk[i]; acc += eigen_sum(t_, d->nu); }
                 out[0] = acc;
                 break;
             }
@@ -430,7 +452,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
             if (e->nonlsq) { /* xd^T * Qf_diag * xd (final_state_cost.cpp:102-108) */
                 double acc = 0.0;
-                for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->qf_diag[i]) * xd; }
+                { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; t_[i] = (xd * d->qf_diag[i]) * xd; } acc += eigen_sum(t_, d->nx); }
                 out[0] = acc;
                 break;
             }
@@ -455,10 +477,10 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             for (int end = 0; end < (trap ? 2 : 1); ++end) {
                 const double* xe = end ? x + p->v[e->vert[2]].off : x1;
                 double cost = 0.0, acc = 0.0;
-                for (int i = 0; i < d->nx; ++i) { double xd = xe[i] - rk[i]; acc += (xd * d->q_diag[i]) * xd; }
+                { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nx; ++i) { double xd = xe[i] - rk[i]; t_[i] = (xd * d->q_diag[i]) * xd; } acc += eigen_sum(t_, d->nx); }
                 cost += acc;
                 acc = 0.0;
-                for (int i = 0; i < d->nu; ++i) acc += (u1[i] * d->r_diag[i]) * u1[i];
+                { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nu; ++i) t_[i] = (u1[i] * d->r_diag[i]) * u1[i]; acc += eigen_sum(t_, d->nu); }
                 cost += acc;
                 c[end] = cost;
             }
@@ -546,7 +568,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             const double* xk = x + p->v[e->vert[0]].off;
             const double* rk = p->refvec ? p->refvec + p->v[e->vert[0]].off : p->xref;
             double acc = 0.0;
-            for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; acc += (xd * d->final_ineq_params[i]) * xd; }
+            { double t_[CORBO_HIP_MAX_NX]; for (int i = 0; i < d->nx; ++i) { double xd = xk[i] - rk[i]; t_[i] = (xd * d->final_ineq_params[i]) * xd; } acc += eigen_sum(t_, d->nx); }
             out[0] = acc - d->final_ineq_params[d->nx];
             break;
         }

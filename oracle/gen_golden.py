@@ -269,7 +269,13 @@ def msmixed():
         # with a terminal equality / a TerminalBall: regular equality and inequality edges come BEFORE the mixed edges in every list and in the row order
         ("hess_unicycle_ms_integral_teq", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", teq=1, ms_integrator="rk2")),
         ("hess_unicycle_ms_integral_tball", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", tball=0.02, tball_s="1,1,0.1")),
+        # the mixed edge around the big-block models (their scenarios' default grid is the shooting grid; noball: the mixed edge's device form has no stage inequality)
+        ("hess_pquad_ms_integral", dict(scenario="pquad", N=5, lsq=0, integral="trap", noball=1)),
+        ("hess_pquad_ms_integral_rk3", dict(scenario="pquad", N=4, lsq=0, integral="left", noball=1, ms_integrator="rk3")),
+        ("hess_quad_ms_integral", dict(scenario="quad", N=4, lsq=0, integral="trap", noball=1)),
     ]:
+        if len(sys.argv) > 2 and sys.argv[2] not in name:
+            continue
         d = run("hess", **kv)
         with open(os.path.join(OUT, f"{name}.json"), "w") as f:
             json.dump(d, f, separators=(",", ":"))

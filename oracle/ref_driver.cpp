@@ -246,6 +246,7 @@ struct Scenario
     Eigen::VectorXd ball;       // ball=cx,cy,cz,r: BallKeepOut stage inequality on the first three state components (unicycle)
     // integral-form constraints and the control-deviation term (user stage functions above; FiniteDifferencesGrid / ...VariableGrid):
     std::string crule;          // crule=trap|left: the grid's integration rule for the integral constraint edges (setCostIntegrationRule)
+    bool noball = false;        // noball=1 (pquad): without the keep-out ball the scenario carries by default
     bool ball_integral = false; // ball_int=1 (with ball=): the ball as the INTEGRAL state-control term of the stage inequalities
     Eigen::VectorXd eq_lin;     // eq_lin=a_1..a_nx,b_1..b_nu,c: LinearIntegralEquality
     Eigen::VectorXd rate;       // rate=r_1..r_nu: input-rate limit as the control-deviation term of the stage inequalities
@@ -612,12 +613,12 @@ static Built build(const Scenario& s, int iterations)
         Eigen::MatrixXd Qf = 10.0 * Q;
         if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
         else
-        {
-            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+        {   // (lsq=0 integral=..: the cost forms of the Hessian path -- on the shooting grid the intervals' edges become MultipleShootingEdgeSingleControl)
+            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
+            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         }
         b.ocp->setControlBounds(Eigen::Vector2d(0, 0), Eigen::Vector2d(12, 12));
-        b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.0, 0.3));
+        if (!s.noball) b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.0, 0.3));
     }
     else if (s.name == "quad")
     {
@@ -629,14 +630,14 @@ static Built build(const Scenario& s, int iterations)
         if (s.vargrid) b.ocp->setStageCost(std::make_shared<MinimumTime>(true));
         else
         {
-            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, false, true));
-            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
+            b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
+            b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
         }
         Eigen::VectorXd ulb(4), uub(4);
         ulb << 0, -1, -1, -1;
         uub << 20, 1, 1, 1;
         b.ocp->setControlBounds(ulb, uub);
-        b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
+        if (!s.noball) b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
     if (s.xlb.size() > 0 || s.ulb.size() > 0)
     {
@@ -898,6 +899,7 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("ball")) s.ball = vec(kv["ball"]);
     if (kv.count("crule")) s.crule = kv["crule"];
     if (kv.count("ball_int")) s.ball_integral = atoi(kv["ball_int"].c_str()) != 0;
+    if (kv.count("noball")) s.noball = atoi(kv["noball"].c_str()) != 0;
     if (kv.count("eq_lin")) s.eq_lin = vec(kv["eq_lin"]);
     if (kv.count("rate")) s.rate = vec(kv["rate"]);
     if (kv.count("u_prev")) s.u_prev = vec(kv["u_prev"]);
@@ -953,6 +955,7 @@ static int dump(const Scenario& s)
     if (s.rate.size()) printVec("rate", s.rate);
     if (s.u_prev.size()) printVec("u_prev", s.u_prev);
     if (s.u_prev_dt > 0) printf("\"u_prev_dt\": %.17g,\n", s.u_prev_dt);
+    if (s.noball) printf("\"noball\": 1,\n");
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.teq && s.teq_mask) printf("\"teq_mask\": %d,\n", s.teq_mask);
     if (s.vargrid) printf("\"vargrid\": 1,\n");
@@ -1286,6 +1289,7 @@ static int hess(const Scenario& s)
     if (!s.ms_integrator.empty()) printf("\"ms_integrator\": \"%s\",\n", s.ms_integrator.c_str());
     if (s.ball.size() == 4) printVec("ball", s.ball);
     if (s.lin_a.size()) { printVec("lin_a", s.lin_a); printVec("lin_b", s.lin_b); }
+    if (s.noball) printf("\"noball\": 1,\n");
     if (s.teq) printf("\"teq\": 1,\n");
     if (s.teq && s.teq_mask) printf("\"teq_mask\": %d,\n", s.teq_mask);
     if (s.vargrid) printf("\"vargrid\": 1,\n");

@@ -115,6 +115,8 @@ def desc_for(g):
         for i, v in enumerate(g["q_sqrt"]): d.q_sqrt[i] = v
         for i, v in enumerate(g["qf_sqrt"]): d.qf_sqrt[i] = v
         for i, v in enumerate(g.get("r_sqrt", [])): d.r_sqrt[i] = v
+    if g.get("noball"):         # quad / pquad without the keep-out ball their scenarios carry by default
+        d.stage_ineq = capi.INEQ_NONE
     if "ball" in g:             # BallKeepOut stage inequality
         d.stage_ineq = capi.INEQ_BALL
         for i, v in enumerate(g["ball"]):

@@ -17,6 +17,7 @@ HESS = ["hess_kcar", "hess_pquad_n5", "hess_pquad_fd_n5", "hess_unicycle_fullq",
         # MultipleShootingEdgeSingleControl (a mixed edge: integrated cost + defect, multiple_shooting_edges.h:151-303) -- shooting grid + integral-form cost
         "hess_unicycle_ms_integral", "hess_unicycle_ms_integral_xf_fixed", "hess_vdp_ms_integral_euler", "hess_vdp_ms_integral_rk3", "hess_unicycle_ms_integral_rk5",
         "hess_unicycle_ms_integral_teq", "hess_unicycle_ms_integral_tball",
+        "hess_pquad_ms_integral", "hess_pquad_ms_integral_rk3", "hess_quad_ms_integral",   # the mixed edge around the big-block models (nx = 6, 12)
         "hess_dint_mtq_integral_trap", "hess_dint_mtq_integral_left_last4"]   # MinTimeQuadratic in integral form (free dt)   # integral-form cost: one objective edge per interval   # *_nonlsq: plain (non-least-squares) objective edges
 KEYS = ("hobj", "heq", "hineq")
 
