@@ -60,6 +60,7 @@ bool LevenbergMarquardtSparseHip::initialize(OptimizationProblemInterface* probl
 
 void LevenbergMarquardtSparseHip::clear()
 {
+    _hess_run_tracked = false;
     releaseHandle();
     std::memset(&_stats, 0, sizeof(_stats));
 }
@@ -382,6 +383,7 @@ bool LevenbergMarquardtSparseHip::attach(OptimizationProblemInterface& problem, 
 SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& problem, bool new_structure, bool new_run, double* obj_value)
 {
     if (obj_value) *obj_value = -1;
+    _hess_run_tracked = false;   // (a Hessian-path call after this solve tracks the model again)
     // penalty weights: resetWeights / adaptWeights (levenberg_marquardt_sparse.cpp:83-86, 270-287).  Kept here, not in the device
     // handle: the reference's _weight_* survive a structure change, the handle does not.
     if (new_run) { _w_eq = _opts.weight_eq; _w_ineq = _opts.weight_ineq; _w_b = _opts.weight_bounds; }
@@ -444,9 +446,19 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
 // ---- operators of the exact-Hessian path (what an interior-point / SQP solver asks the problem for), evaluated on the device for the
 //      hypergraph's current vertex values; signatures of OptimizationProblemInterface::computeSparseHessians{NNZ,Structure,Values}
 //      (optimization_problem_interface.h) with the problem as the first argument
+// attach for the Hessian-path entry points: the vertex values are uploaded on every call, the model tracking (one recogniser pass over all cost edges)
+// runs once per outer run (newHessianRun(), solve(), clear() start the next one)
+bool LevenbergMarquardtSparseHip::attachHessianPath(OptimizationProblemInterface& problem)
+{
+    const bool first = !_hess_run_tracked || _handle == nullptr;
+    if (!attach(problem, _handle == nullptr, first)) return false;
+    _hess_run_tracked = true;
+    return true;
+}
+
 bool LevenbergMarquardtSparseHip::computeSparseHessiansNNZ(OptimizationProblemInterface& problem, int& nnz_obj, int& nnz_eq, int& nnz_ineq, bool lower_part_only)
 {
-    if (!attach(problem, _handle == nullptr, true)) return false;
+    if (!attachHessianPath(problem)) return false;
     int32_t nnz[3];
     if (corbo_hip_hessian_nnz(&_desc, lower_part_only ? 1 : 0, nnz) != CORBO_HIP_OK) { PRINT_ERROR("LevenbergMarquardtSparseHip(): " << corbo_hip_last_error()); return false; }
     nnz_obj = nnz[0]; nnz_eq = nnz[1]; nnz_ineq = nnz[2];
@@ -458,7 +470,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationPro
                                                                  Eigen::Ref<Eigen::VectorXi> j_col_eq, Eigen::Ref<Eigen::VectorXi> i_row_ineq,
                                                                  Eigen::Ref<Eigen::VectorXi> j_col_ineq, bool lower_part_only)
 {
-    if (!attach(problem, _handle == nullptr, true)) return false;
+    if (!attachHessianPath(problem)) return false;
     static_assert(sizeof(int) == sizeof(int32_t), "Eigen::VectorXi is handed to the C-ABI as int32_t");
     if (corbo_hip_hessian_structure(&_desc, lower_part_only ? 1 : 0, i_row_obj.data(), j_col_obj.data(), i_row_eq.data(), j_col_eq.data(), i_row_ineq.data(),
                                     j_col_ineq.data()) != CORBO_HIP_OK)
@@ -471,7 +483,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansStructure(OptimizationPro
 
 bool LevenbergMarquardtSparseHip::computeGradientObjective(OptimizationProblemInterface& problem, Eigen::Ref<Eigen::VectorXd> gradient, double* obj_value)
 {
-    if (!attach(problem, _handle == nullptr, true)) return false;
+    if (!attachHessianPath(problem)) return false;
     if (gradient.size() != _dims.n) { PRINT_ERROR("LevenbergMarquardtSparseHip(): gradient vector of the wrong size."); return false; }
     if (corbo_hip_eval_objective_gradient(_handle, gradient.data(), obj_value) != CORBO_HIP_OK)
     {
@@ -485,7 +497,7 @@ bool LevenbergMarquardtSparseHip::computeSparseHessiansValues(OptimizationProble
                                                               Eigen::Ref<Eigen::VectorXd> values_eq, Eigen::Ref<Eigen::VectorXd> values_ineq, double multiplier_obj,
                                                               const double* multipliers_eq, const double* multipliers_ineq, bool lower_part_only)
 {
-    if (!attach(problem, _handle == nullptr, true)) return false;   // uploads the current vertex values
+    if (!attachHessianPath(problem)) return false;   // uploads the current vertex values
     if (corbo_hip_eval_hessians(_handle, lower_part_only ? 1 : 0, multiplier_obj, multipliers_eq, multipliers_ineq, values_obj.data(), values_eq.data(),
                                 values_ineq.data()) != CORBO_HIP_OK)
     {

@@ -65,6 +65,10 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     // moved references keep the device handle, anything else rebuilds (and re-verifies) it.  On by default; costs one pass of the
     // recogniser over the edges per run.  Off: the caller vouches that only the vertex values change between runs.
     void setTrackModel(bool track) { _tracking = track; }
+    // Hessian-path entry points (computeGradientObjective, computeSparseHessians*): the model is tracked -- derived again from the graph and compared
+    // with the resident one -- by the FIRST such call of an outer run, not by every call of an interior-point iteration.  A run ends
+    // with the next solve() / clear(), or explicitly:
+    void newHessianRun() { _hess_run_tracked = false; }
 
     const corbo_hip_stats& getStatistics() const { return _stats; }
 
@@ -84,6 +88,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
  private:
     void releaseHandle();
     bool attach(OptimizationProblemInterface& problem, bool new_structure, bool new_run);
+    bool attachHessianPath(OptimizationProblemInterface& problem);
     bool modelMatchesGraph(OptimizationProblemInterface& problem, bool perturbed);
     bool uploadVertices(const std::vector<VertexInterface*>& xs, const std::vector<VertexInterface*>& us, VertexInterface* xf, VertexInterface* dt);
 
@@ -92,6 +97,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     bool _have_desc = false;
     bool _verify    = true;
     bool _tracking  = true;
+    bool _hess_run_tracked = false;
     Eigen::VectorXd _xref;
     Eigen::MatrixXd _xref_traj;   // recognised time-varying state reference [N][nx] (empty: static)
     std::vector<double> _ref;
