@@ -3417,22 +3417,18 @@ struct Chain3Lds {
     __host__ __device__ static constexpr int total(int N) { return DXS + N * NX + 4 * NSEG + 8; }   // + state increments + sums (NSEG = 4, N = 200: 76.7 KB, two workgroups per CU)
 };
 
+// (the body: `st` = the instance's LM state in LDS, `sm` = the chain's LDS area, `xs` = optional LDS copy of the trial iterate.  A residual sweep fused
+// behind the chain in the same launch -- sweep_body on that copy, 8 waves -- was built and measured: cfg 5 9.09 -> 9.36 ms, one OCP 1.83 -> 1.96 ms: the
+// sweep then runs at the chain's occupancy, one workgroup per CU, and its dependent descriptor loads are no longer hidden by co-resident workgroups; removed)
 template <int NX, int NU, int NSEG>
-__global__ __launch_bounds__(128 * NSEG)
-__attribute__((amdgpu_waves_per_eu(2, 2)))   // 216 registers: two waves per SIMD (four segments: one workgroup per CU; two: two).  A 128-register build
-                                             // (two 8-wave workgroups per CU) spills 290 - 340 bytes per lane into the dependent chain: 0.73 -> 0.88 ms per factor launch group at cfg 5, measured
-void big_chain3_kernel(const FactorParams p)
+__device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* const st, double* const sm, const int inst, double* const xs)
 {
     using BL = BigLds<NX, NU>;
     using CL = Chain3Lds<NX, NU, NSEG>;
     constexpr int S = NX + NU, NN = NX * NX, NW = 2 * NSEG, THREADS = 128 * NSEG;
     static_assert(NX <= 12 && NX % 4 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, spike rows 32.., identity rows 48..");
-    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int seg = wave >> 1, side = wave & 1;
-    const int inst = blockIdx.x + p.inst0;
-    LmState* st = p.st + inst;
-    if (st->done) return;
     int stop = st->stop;
     const double mu = st->mu;
     const double mu_eff = (st->fresh ? 0.0 : st->mu_acc) + mu;
@@ -3800,7 +3796,9 @@ void big_chain3_kernel(const FactorParams p)
         const int k = e / NX, r = e - k * NX;
         const double d = p.comp[k * S + r].fixed ? 0.0 : dxs[e];
         dn2 += d * d;
-        xt[k * S + r] = xin[k * S + r] + d;
+        const double v = xin[k * S + r] + d;
+        xt[k * S + r] = v;
+        if (xs) xs[k * S + r] = v;
     }
     for (int q = tid; q < N - 1; q += THREADS) {
         const double* wq = ws + (size_t)q * BL::WS_STAGE;
@@ -3819,12 +3817,15 @@ void big_chain3_kernel(const FactorParams p)
             for (int d = c + 1; d < NU; ++d) v -= wq[BL::WS_LUU + d * NU + c] * w[d];
             w[c] = v * wq[BL::WS_LUU + c * NU + c];
             dn2 += w[c] * w[c];
-            xt[q * S + NX + c] = xin[q * S + NX + c] + w[c];
+            const double un = xin[q * S + NX + c] + w[c];
+            xt[q * S + NX + c] = un;
+            if (xs) xs[q * S + NX + c] = un;
         }
     }
     if (tid == 0) {
         xt[p.off_dt] = xin[p.off_dt];
-        if (p.off_dt + 1 < p.nvs) xt[p.off_dt + 1] = 0.0;
+        if (xs) xs[p.off_dt] = xin[p.off_dt];
+        if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (xs) xs[p.off_dt + 1] = 0.0; }
     }
     y2  = wave_sum(y2);
     dn2 = wave_sum(dn2);
@@ -3846,6 +3847,23 @@ void big_chain3_kernel(const FactorParams p)
         st->stop     = stop;
         st->no_trial = no_trial;
     }
+}
+
+template <int NX, int NU, int NSEG>
+__global__ __launch_bounds__(128 * NSEG)
+__attribute__((amdgpu_waves_per_eu(2, 2)))   // 196 registers: two waves per SIMD (four segments: one workgroup per CU; two: two).  A 128-register build
+                                             // (two 8-wave workgroups per CU) spills 290 - 340 bytes per lane into the dependent chain: 0.73 -> 0.88 ms per factor launch group at cfg 5, measured
+void big_chain3_kernel(const FactorParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm3[];
+    LmState* sl = reinterpret_cast<LmState*>(sm3 + ((Chain3Lds<NX, NU, NSEG>::total(p.N) + 1) & ~1));
+    const int inst = blockIdx.x + p.inst0;
+    lm_state_in(sl, p.st + inst, threadIdx.x);
+    __syncthreads();
+    if (sl->done) return;
+    big_chain3_body<NX, NU, NSEG>(p, sl, sm3, inst, nullptr);
+    __syncthreads();
+    lm_state_out(p.st + inst, sl, threadIdx.x);
 }
 
 // One Levenberg-Marquardt pass of every unfinished instance in ONE launch:  [sweep phase -> factor phase]  per workgroup.
@@ -4859,7 +4877,7 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
             auto launch3 = [&](auto kernel, int nseg_, size_t lds3) {
                 static bool attr_set[9] = {};
                 if (!attr_set[nseg_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[nseg_] = true; }
-                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(128 * nseg_), lds3, stream, p);
+                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(128 * nseg_), ((lds3 + 15) & ~(size_t)15) + sizeof(LmState), stream, p);
             };
             if (nseg == 4) launch3(big_chain3_kernel<NX, NU, 4>, 4, sizeof(double) * (size_t)Chain3Lds<NX, NU, 4>::total(p.N));
             else if (nseg == 2) launch3(big_chain3_kernel<NX, NU, 2>, 2, sizeof(double) * (size_t)Chain3Lds<NX, NU, 2>::total(p.N));
