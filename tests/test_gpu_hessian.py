@@ -333,3 +333,25 @@ def test_hessian_views_equal_the_copied_lists():
         a2 = s.eval_hessians(lower, 1.3, me, None)
         for c in range(3):
             assert np.array_equal(a[c], a2[c])
+
+
+@pytest.mark.parametrize("name", ["hess_unicycle_n24_ball", "hess_pquad_n5", "hess_unicycle_ms_integral", "hess_dint_mtq"])
+def test_hessian_work_splits_agree(name):
+    """hessian_kernel spreads a stage's blocks over waves by batch size (HessParams::split: per stage / per (edge, row vertex) / per block; option
+    hess_split): the three splits evaluate the same finite-difference nest from the pristine point of their part of the walk instead of the one the
+    earlier parts left a few ulps away (the in-place perturbations' drift): the lists agree within the operators' tolerance, 1e-6 typically."""
+    g = load_golden(name)
+    d, s = device_at_point(g, B=5)
+    me = np.array(g["mult_eq"]); mi = np.array(g["mult_ineq"]) if g["mult_ineq"] else None
+    ref = None
+    for split in (0, 1, 2):
+        s.set_option("hess_split", split)
+        for lower in (False, True):
+            vals = s.eval_hessians(lower, g["mult_obj"], me, mi)
+            if split == 0:
+                ref = ref or {}
+                ref[lower] = vals
+            else:
+                for a, b in zip(vals, ref[lower]):
+                    if a.size:
+                        assert np.abs(a - b).max() <= REL * max(1.0, np.abs(b).max()), (name, split, lower)
