@@ -180,6 +180,11 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
+    // reject-streak speculation of the big-block family (kernels.hpp SpecParams): spare instance rows behind the batch in the per-instance arrays
+    static constexpr int SPEC_GROUPS = 8, SPEC_SLOTS = 4;
+    int spare = 0;              // SPEC_GROUPS * SPEC_SLOTS for a big-block handle on the stage / chain path, else 0
+    int reject_speculation = 1; // corbo_hip_set_option("reject_speculation"): 0 = every rejected step is a pass of its own (A/B, tests)
+    int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
     int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, see FactorParams::chain_variant
     int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
@@ -208,7 +213,7 @@ struct corbo_hip_solver {
     {
         SweepParams p{};
         p.batch = active; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
-        p.batch_total = batch; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2 && band.n == 0) ? 1 : 0;   // (band route: the factorisation reads the stored Jacobian)
+        p.batch_total = batch + spare; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2 && band.n == 0) ? 1 : 0;   // (band route: the factorisation reads the stored Jacobian)
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         fill_dyn(p.mp.dyn);
@@ -386,12 +391,15 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     h->m_pad   = (S.dims.m + 1) & ~1;
     h->nnz_pad = (h->nnz_int + 1) & ~1;
     const size_t B = (size_t)batch;
-    CREATE_TRY(hipMalloc((void**)&h->d_x, B * S.nvs * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_xt, B * S.nvs * sizeof(double)));
+    // big-block family on the stage / chain path: spare rows behind the batch for the candidates of the reject-streak speculation
+    h->spare = (big_family_dims(S.nx, S.nu) && !(S.dt_free) && !S.has_extra()) ? corbo_hip_solver::SPEC_GROUPS * corbo_hip_solver::SPEC_SLOTS : 0;
+    const size_t BT = B + (size_t)h->spare;
+    CREATE_TRY(hipMalloc((void**)&h->d_x, BT * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_xt, BT * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_x0, B * S.nvs * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_lb, B * S.nvs * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_ub, B * S.nvs * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_xref, B * CORBO_HIP_MAX_NX * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_lb, BT * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_ub, BT * S.nvs * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_xref, BT * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_xnew, B * CORBO_HIP_MAX_NX * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_stage, B * (size_t)(S.nvs > CORBO_HIP_MAX_NX ? S.nvs : CORBO_HIP_MAX_NX) * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_state, B * sizeof(LmState)));
@@ -426,17 +434,23 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         if (S.dt_free) { dlb[S.off_dt] = S.desc.dt_lb; dub[S.off_dt] = S.desc.dt_ub; }
         CREATE_TRY(hipMemcpy(h->d_bound_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    CREATE_TRY(hipMalloc((void**)&h->d_values0, B * h->m_pad * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_values1, B * h->m_pad * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_values0, BT * h->m_pad * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_values1, BT * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_jac, B * h->nnz_pad * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->d_state, B * sizeof(LmState)));
-    CREATE_TRY(hipMalloc((void**)&h->d_chi2, B * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->d_state, BT * sizeof(LmState)));
+    CREATE_TRY(hipMalloc((void**)&h->d_chi2, BT * sizeof(double)));
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
-        CREATE_TRY(hipMalloc((void**)&h->d_work, B * h->work_stride * sizeof(double)));
+        CREATE_TRY(hipMalloc((void**)&h->d_work, BT * h->work_stride * sizeof(double)));
         if (big_family_dims(S.nx, S.nu)) {
-            CREATE_TRY(hipMalloc((void**)&h->d_xe0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
-            CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * B * (size_t)S.N * S.nx * sizeof(double)));
+            CREATE_TRY(hipMalloc((void**)&h->d_xe0, 2 * BT * (size_t)S.N * S.nx * sizeof(double)));
+            CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * BT * (size_t)S.N * S.nx * sizeof(double)));
+        }
+        if (h->spare) {
+            CREATE_TRY(hipMalloc((void**)&h->d_spec_parent, corbo_hip_solver::SPEC_GROUPS * sizeof(int32_t)));
+            CREATE_TRY(hipMalloc((void**)&h->d_spec_seen, corbo_hip_solver::SPEC_GROUPS * sizeof(int32_t)));
+            CREATE_TRY(hipMalloc((void**)&h->d_spec_slotrej, (size_t)h->spare * sizeof(int32_t)));
+            CREATE_TRY(hipMalloc((void**)&h->d_spec_prev, B * sizeof(int32_t)));
         }
         h->force_split = true;  // no fused pass kernel for the big-block family / the long horizons: factor and sweep are separate launches
     }
@@ -517,7 +531,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMemset(h->d_queue, 0, (size_t)(16 + 2048 * 16) * sizeof(int32_t)));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counter, 2 * corbo_hip_solver::MAX_SUB * sizeof(int32_t)));
-    CREATE_TRY(hipMemset(h->d_state, 0, B * sizeof(LmState)));
+    CREATE_TRY(hipMemset(h->d_state, 0, (B + (size_t)h->spare) * sizeof(LmState)));
     CREATE_TRY(hipMemset(h->d_values0, 0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_values1, 0, B * h->m_pad * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_jac, 0, B * h->nnz_pad * sizeof(double)));
@@ -547,7 +561,8 @@ void corbo_hip_destroy(corbo_hip_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
-                    h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff};
+                    h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
@@ -740,10 +755,27 @@ try {
         }
     }
     int rc = 0;
+    // reject-streak speculation (big-block family, stage / chain path; kernels.hpp SpecParams): the candidates live in the spare rows right behind
+    // the batch, so the launches of a pass simply cover batch + spare rows -- possible when every row of the handle is in use and no per-instance table
+    // (references per component, model parameters per instance) would have to follow the candidates
+    // ... and when a pass is long against the one small launch per pass the bookkeeping costs (7 us: below 128 instances it is 4 - 7 % of a solve
+    // and the laggers of a small batch hold back little); option reject_speculation: 0 = off, 1 = this rule, 2 = always, every streak (tests)
+    const bool spec = split && h->spare > 0 && h->reject_speculation && (h->batch >= 128 || h->reject_speculation == 2) && h->band.n == 0 &&
+                      h->active == h->batch && !h->refvec_on && !h->d_dyn_inst && !h->profile && o->iterations > 0;
+    auto spec_params = [&](int mode, int32_t* counter) {
+        SpecParams q{};
+        q.mode = mode; q.batch = h->batch; q.groups = corbo_hip_solver::SPEC_GROUPS; q.spec = corbo_hip_solver::SPEC_SLOTS;
+        q.nvs = h->S.nvs; q.m_pad = h->m_pad; q.xe_row = h->S.N * h->S.nx; q.batch_total = h->batch + h->spare;
+        q.x = h->d_x; q.lb = h->d_lb; q.ub = h->d_ub; q.xref = h->d_xref; q.values0 = h->d_values0; q.values1 = h->d_values1; q.xe0 = h->d_xe0; q.chi2 = h->d_chi2;
+        q.st = h->d_state; q.parent_of = h->d_spec_parent; q.rej_seen = h->d_spec_seen; q.slot_rej = h->d_spec_slotrej; q.prev_reject = h->d_spec_prev;
+        q.counter = counter;
+        q.max_parents = (h->reject_speculation == 2) ? corbo_hip_solver::SPEC_GROUPS : 3;
+        return q;
+    };
     auto launch_one = [&](int i, int mode, int32_t* counter) -> int {
         FactorParams fp = h->factor_params();
         SweepParams sp  = h->sweep_params(mode, o->iterations, h->w_eq, h->w_ineq, h->w_b, counter);
-        fp.batch = sp.batch = count_of[i];
+        fp.batch = sp.batch = count_of[i] + ((spec && mode == 3) ? h->spare : 0);
         fp.inst0 = sp.inst0 = first_of[i];
         fp.pass_threads = h->pass_threads;
         if (split) {
@@ -756,6 +788,10 @@ try {
             }
             if (!launch_sweep(h->S.desc, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no sweep kernel for this dynamics/defect");
             HIP_TRY(hipGetLastError());
+            if (spec) {   // after the prologue: every slot free; after a pass: candidates merged, the next ones started
+                launch_big_spec(spec_params(mode == 3 ? 0 : 1, counter), st_of[i]);
+                HIP_TRY(hipGetLastError());
+            }
             stamp();
         }
         else {
@@ -1300,6 +1336,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
     else if (n == "chain_variant") h->chain_variant = value;
     else if (n == "hess_split") h->hess_split = value;
+    else if (n == "reject_speculation") h->reject_speculation = value;
     else if (n == "stagger") h->stagger = value;
     else if (n == "pass_threads") h->pass_threads = value;
     else if (n == "lag_priority") h->lag_priority = value;

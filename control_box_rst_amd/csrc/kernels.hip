@@ -5243,6 +5243,141 @@ bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const 
 // the structures that matter for throughput.  Replaces Eigen::SimplicialLLT (:140-148) like factor_body does: ordering differences are
 // rounding-level.
 // ---------------------------------------------------------------------------------------------------------------------
+// ---- reject-streak speculation (SpecParams, kernels.hpp): one workgroup, after every pass's sweep
+__global__ __launch_bounds__(1024) void big_spec_kernel(const SpecParams p)
+{
+    constexpr int MAXG = 16;
+    __shared__ int a_parent[MAXG];   // the instance that takes over the state of its group's slot a_take (this pass), or -1
+    __shared__ int a_take[MAXG];
+    __shared__ int a_fill[MAXG];     // 1 = fill the group's slots from its parent (new group, or a streak that outlasted its candidates)
+    __shared__ int n_new, new_list[MAXG];
+    const int tid = threadIdx.x, G = p.groups < MAXG ? p.groups : MAXG, SP = p.spec;
+    const int slot0 = p.batch;
+    if (p.mode == 1) {   // start of a solve
+        for (int g = tid; g < G; g += 1024) { p.parent_of[g] = -1; p.rej_seen[g] = 0; }
+        for (int i = tid; i < p.batch; i += 1024) p.prev_reject[i] = 0;
+        for (int q = tid; q < G * SP; q += 1024) { p.st[slot0 + q].done = 1; p.slot_rej[q] = 0; }
+        return;
+    }
+    if (tid < MAXG) { a_parent[tid] = -1; a_take[tid] = 0; a_fill[tid] = 0; }
+    if (tid == 0) n_new = 0;
+    __syncthreads();
+    // ---- A: groups in use -- what did the parent and its candidates do in this pass?
+    if (tid < G && p.parent_of[tid] >= 0) {
+        const int g = tid, P = p.parent_of[g];
+        int uncount = 0;   // slots the sweep counted as unfinished
+        for (int c = 0; c < SP; ++c) uncount += p.st[slot0 + g * SP + c].done ? 0 : 1;
+        const bool parent_rejected = !p.st[P].done && p.st[P].n_reject > p.rej_seen[g];
+        if (!parent_rejected) p.parent_of[g] = -1;   // its own pass ended the streak (or the solve): the candidates are void
+        else {
+            int take = SP - 1;
+            bool goes_on = true;
+            for (int c = 0; c < SP; ++c) {
+                const LmState& sc = p.st[slot0 + g * SP + c];
+                const bool rejected = !sc.done && sc.n_reject > p.slot_rej[g * SP + c];
+                if (!rejected) { take = c; goes_on = false; break; }
+            }
+            a_parent[g] = P;
+            a_take[g]   = take;
+            if (goes_on) a_fill[g] = 1;   // every candidate rejected: the parent takes the last one's state, the next dampings are tried
+            else p.parent_of[g] = -1;
+        }
+        if (p.counter && uncount) atomicSub(p.counter, uncount);
+    }
+    __syncthreads();
+    // ---- B: instances whose step was rejected in this pass and that have no group yet
+    for (int i = tid; i < p.batch; i += 1024) {
+        const int nr = p.st[i].n_reject;
+        const bool rejected_now = !p.st[i].done && nr > p.prev_reject[i];
+        p.prev_reject[i] = nr;
+        if (!rejected_now) continue;
+        bool has_group = false;
+        for (int g = 0; g < G; ++g) has_group = has_group || (p.parent_of[g] == i) || (a_parent[g] == i);
+        if (!has_group) { const int q = atomicAdd(&n_new, 1); if (q < MAXG) new_list[q] = i; }
+    }
+    __syncthreads();
+    if (tid == 0) {   // C: free groups for them (a group that hands a state over in this pass is busy until the copy is done: next pass)
+        // Speculation pays when rejections are RARE (a few laggers hold the whole batch back): every candidate is a full instance of work in the
+        // next pass.  With many instances rejecting at once the slowest one is not helped and the candidates only add work (64 quadrotor OCPs at N = 40,
+        // 83 rejections: 1.69 -> 2.12 ms when every rejecting instance got candidates) -- at most max_parents streaks are followed at a time.
+        const int SPEC_MAX_PARENTS = p.max_parents;   // (3 by default; tests lift it)
+        int busy = 0;
+        for (int g = 0; g < G; ++g) busy += (p.parent_of[g] >= 0 || a_parent[g] >= 0) ? 1 : 0;
+        int nn = n_new < MAXG ? n_new : MAXG;
+        if (busy + nn > SPEC_MAX_PARENTS) nn = 0;
+        int g = 0;
+        for (int q = 0; q < nn; ++q) {
+            while (g < G && (p.parent_of[g] >= 0 || a_parent[g] >= 0)) ++g;
+            if (g >= G) break;
+            p.parent_of[g] = new_list[q];
+            a_fill[g] = 1;
+            ++g;
+        }
+    }
+    __syncthreads();
+    auto copy_row = [&](double* base, size_t row_len, int dst, int src) {
+        const double* s_ = base + (size_t)src * row_len;
+        double* d_       = base + (size_t)dst * row_len;
+        for (size_t i = tid; i < row_len; i += 1024) d_[i] = s_[i];
+    };
+    // ---- D: take over a candidate's state (iterate, end states of both buffers, residual buffers, chi2, LM state)
+    for (int g = 0; g < G; ++g) {
+        const int P = a_parent[g];
+        if (P < 0) continue;
+        const int src = slot0 + g * SP + a_take[g];
+        // (the residual buffers are scratch of the sweep for this family -- the stage kernel recomputes what it needs -- and are not moved; of the
+        // two end-state buffers the one paired with the candidate's accepted iterate is what the next stage kernel reads: both halves are 2 x N nx doubles)
+        copy_row(p.x, p.nvs, P, src);
+        copy_row(p.xe0, p.xe_row, P, src);
+        copy_row(p.xe0, p.xe_row, p.batch_total + P, p.batch_total + src);
+        copy_row(reinterpret_cast<double*>(p.st), sizeof(LmState) / sizeof(double), P, src);
+        if (tid == 0) p.chi2[P] = p.chi2[src];
+    }
+    __syncthreads();
+    // ---- E: fill slots: copies of the parent with the LM state it would have after 1, 2, ... more rejected steps
+    for (int g = 0; g < G; ++g) {
+        if (!a_fill[g]) continue;
+        const int P = p.parent_of[g];
+        const LmState s0 = p.st[P];
+        const bool ok = !s0.done && (s0.inner + SP + 2 < LM_MAX_INNER) && !s0.no_trial;   // (near the inner-loop guard: no speculation)
+        __syncthreads();
+        if (!ok) { if (tid == 0) p.parent_of[g] = -1; continue; }
+        for (int c = 0; c < SP; ++c) {
+            const int dst = slot0 + g * SP + c;
+            copy_row(p.x, p.nvs, dst, P);
+            copy_row(p.lb, p.nvs, dst, P);
+            copy_row(p.ub, p.nvs, dst, P);
+            copy_row(p.xref, CORBO_HIP_MAX_NX, dst, P);
+            copy_row(p.xe0, p.xe_row, dst, P);
+            copy_row(p.xe0, p.xe_row, p.batch_total + dst, p.batch_total + P);
+            if (tid == c) {
+                LmState sc = s0;
+                for (int r = 0; r <= c; ++r) {   // one more rejected pass: the chain's bookkeeping, then the sweep's reject branch (:204-213)
+                    sc.mu_acc = (sc.fresh ? 0.0 : sc.mu_acc) + sc.mu;
+                    sc.fresh  = 0;
+                    sc.n_fact += 1; sc.inner += 1;
+                    sc.n_res += 1;  sc.n_reject += 1;
+                    sc.mu = sc.mu * sc.v;
+                    sc.v  = 2 * sc.v;
+                }
+                p.st[dst] = sc;
+                p.slot_rej[g * SP + c] = sc.n_reject;
+            }
+        }
+        if (tid == 0) p.rej_seen[g] = s0.n_reject;
+    }
+    __syncthreads();
+    // ---- slots of free groups do nothing in the next pass
+    for (int q = tid; q < G * SP; q += 1024)
+        if (p.parent_of[q / SP] < 0) p.st[slot0 + q].done = 1;
+}
+
+bool launch_big_spec(const SpecParams& p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(big_spec_kernel, dim3(1), dim3(1024), 0, stream, p);
+    return true;
+}
+
 size_t band_work_doubles(int nb, int bw) { return (size_t)nb * (bw + 1) + 3 * (size_t)nb + 8; }
 
 __global__ __launch_bounds__(64) void band_factor_kernel(const FactorParams p, const BandParams bp)

@@ -123,6 +123,30 @@ struct FactorParams {
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
 };
 
+// Reject-streak speculation of the big-block family (big_spec_kernel; VERDICT r3 item 2 a).  An instance whose trial step was rejected re-factorises the
+// SAME Jacobian with the damping mu v, then mu v 2v, ... (levenberg_marquardt_sparse.cpp:204-215) until a step is accepted: every one of those passes is a
+// full launch group for one or two instances (cfg 5: two streaks of five and four rejections = 5 of the 15 passes of the solve).  The dampings of a streak
+// are known in advance, so the next SPEC of them are tried in the same pass as the instance's own: SPEC spare instance slots per rejecting instance
+// (rows behind the batch in every per-instance array) start from copies of its accepted iterate with the LM state it WOULD have after 1, 2, ... more
+// rejections; after the pass's sweep this kernel walks the candidates in order, the first one that did not reject is what the instance itself would have
+// reached that many passes later and is copied back (iterate, end states, residual buffers, LM state -- counters included), the others are dropped.  Same
+// arithmetic on the same numbers: bit-identical results.
+struct SpecParams {
+    int32_t mode;            // 0 = after a pass's sweep: merge + spawn; 1 = start of a solve: every slot free
+    int32_t batch;           // real instances (rows [0, batch)); slots are rows [batch, batch + groups * spec)
+    int32_t groups, spec;    // slot groups (one rejecting instance each), slots per group
+    int32_t nvs, m_pad, xe_row, batch_total;   // row lengths: vertex storage, residual buffer, N * nx end states; rows of the two-buffer end-state array
+    double *x, *lb, *ub, *xref, *values0, *values1, *xe0, *chi2;
+    LmState* st;
+    int32_t* parent_of;      // [groups] instance of the group or -1
+    int32_t* rej_seen;       // [groups] the parent's n_reject when its slots were filled
+    int32_t* slot_rej;       // [groups * spec] a slot's n_reject when it was filled
+    int32_t* prev_reject;    // [batch] n_reject of every instance at the last visit
+    int32_t* counter;        // the pass's "unfinished instances" counter (slots that the sweep counted are taken out again) or null
+    int32_t max_parents;     // streaks followed at a time (speculation pays when rejections are rare: see big_spec_kernel)
+};
+bool launch_big_spec(const SpecParams& p, hipStream_t stream);
+
 // Band factorisation (band_factor_kernel): the generic assemble / factor / solve step for structures the stage-parallel kernels do not
 // cover -- integral-form constraint edges, control-deviation edges (they couple the controls of neighbouring intervals).  H = J^T J is
 // assembled from static product lists into band storage (natural parameter order: half-bandwidth of a few stage widths), a free dt -- the last

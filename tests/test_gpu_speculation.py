@@ -1,0 +1,60 @@
+"""Reject-streak speculation of the big-block family (-m gpu; kernels.hpp SpecParams, option reject_speculation: 0 off, 1 automatic, 2 always and for
+every streak): the damping candidates of a rejecting instance tried in one pass are the instance's own next passes -- same arithmetic on the same
+numbers -- so iterates, chi2, status and every counter of corbo_hip_stats must be IDENTICAL to the run without it."""
+import numpy as np
+import pytest
+
+from control_box_rst_amd import problems
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+
+pytestmark = pytest.mark.gpu
+KEYS = ("lm_iterations", "accepted_steps", "rejected_steps", "factorizations", "residual_sweeps", "jacobian_sweeps", "passes", "inner_loop_cuts")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+
+
+def _run(d, weights, x0, xf, spec, iters=10, chain=0):
+    s = BatchedLevenbergMarquardt(d, len(x0))
+    s.setIterations(iters)
+    s.setPenaltyWeights(*weights)
+    s.set_option("reject_speculation", spec)
+    s.set_option("chain_variant", chain)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    st = s.get_stats()
+    s.restore_instance_data(); s.solve()          # a second solve on the same handle: the slots start free again
+    X2, chi22, status2 = s.get_solution()
+    assert np.array_equal(X, X2) and np.array_equal(chi2, chi22) and np.array_equal(status, status2)
+    return X, chi2, status, st
+
+
+@pytest.mark.parametrize("B,N,weights,first", [(64, 40, problems.QUAD_WEIGHTS, 0),      # 83 rejected steps over the batch: every group busy, streaks outlast their candidates
+                                              (24, 24, (100.0, 100.0, 100.0), 100),   # stiffer penalties: other streak lengths
+                                              (40, 64, problems.QUAD_WEIGHTS, 7)])     # the partitioned chain (N >= 64)
+def test_forced_speculation_is_bit_identical(B, N, weights, first):
+    d = problems.quad_desc(N=N)
+    x0, xf = problems.quad_instances(B, first=first)
+    ref = _run(d, weights, x0, xf, 0)
+    assert ref[3]["rejected_steps"] > 0, "the scenario is meant to reject steps"
+    got = _run(d, weights, x0, xf, 2)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    for k in KEYS:
+        assert got[3][k] == ref[3][k], k
+
+
+def test_cfg5_full_batch_identical_with_and_without():
+    d = problems.quad_desc()
+    x0, xf = problems.quad_instances(512)
+    ref = _run(d, problems.QUAD_WEIGHTS, x0, xf, 0)
+    got = _run(d, problems.QUAD_WEIGHTS, x0, xf, 1)
+    assert ref[3]["rejected_steps"] == 9 and ref[3]["passes"] == 15       # two streaks (five and four rejected steps): the 5 tail passes of the solve
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    for k in KEYS:
+        assert got[3][k] == ref[3][k], k
