@@ -184,6 +184,8 @@ struct corbo_hip_solver {
     static constexpr int SPEC_GROUPS = 8, SPEC_SLOTS = 4;
     int spare = 0;              // SPEC_GROUPS * SPEC_SLOTS for a big-block handle on the stage / chain path, else 0
     int reject_speculation = 1; // corbo_hip_set_option("reject_speculation"): 0 = every rejected step is a pass of its own (A/B, tests)
+    double* d_stage_cache = nullptr;   // big-block family: the stage waves' local Jacobians between the two passes of a solve's first factorisation (FactorParams::stage_cache)
+    size_t stage_cache_stride = 0;
     int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
     int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, see FactorParams::chain_variant
@@ -251,6 +253,7 @@ struct corbo_hip_solver {
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
         p.chain_variant = chain_variant;
+        p.stage_cache = d_stage_cache; p.stage_cache_stride = (int64_t)stage_cache_stride;
         p.defect = S.desc.defect;
         p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         return p;
@@ -446,6 +449,12 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
             CREATE_TRY(hipMalloc((void**)&h->d_xe0, 2 * BT * (size_t)S.N * S.nx * sizeof(double)));
             CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * BT * (size_t)S.N * S.nx * sizeof(double)));
         }
+        if (big_family_dims(S.nx, S.nu)) {
+            h->stage_cache_stride = big_stage_cache_doubles(*desc, S.N);
+            const size_t bytes = BT * h->stage_cache_stride * sizeof(double);
+            if (bytes > ((size_t)2 << 30)) h->stage_cache_stride = 0;   // (beyond 2 GB the first factorisation integrates twice, as before)
+            else CREATE_TRY(hipMalloc((void**)&h->d_stage_cache, bytes));
+        }
         if (h->spare) {
             CREATE_TRY(hipMalloc((void**)&h->d_spec_parent, corbo_hip_solver::SPEC_GROUPS * sizeof(int32_t)));
             CREATE_TRY(hipMalloc((void**)&h->d_spec_seen, corbo_hip_solver::SPEC_GROUPS * sizeof(int32_t)));
@@ -562,7 +571,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
                     h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
-                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev};
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_stage_cache};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }

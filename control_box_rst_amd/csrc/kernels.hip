@@ -2267,6 +2267,7 @@ struct BigLds {
     static constexpr int WS_Y2 = WS_YU + NU;          // [1]  |y_u|^2 of the stage
     static constexpr int WS_STAGE = (WS_Y2 + 2) & ~1;
     static_assert(WS_STAGE == big_ws_stage(NX, NU) && TOTAL == big_lds_total(NX, NU), "host-side mirrors of the sizes");
+    static_assert(HALF == ((4 * NX + 2 * (NX + NU) + NX * (NX + NU) + 8 + NX * NX + 1) & ~1), "big_stage_cache_doubles mirrors HALF");
 };
 
 // LDS pointers of one interval of the stage kernel (half = its per-interval area, shared = the wave's assemble scratch)
@@ -2719,9 +2720,21 @@ void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag
     }
     const BigCtx<NX, NU> c0(sm, sm + 2 * BL::HALF), c1(sm + BL::HALF, sm + 2 * BL::HALF);
     const int half = lane >> 5;
+    // The first factorisation of a solve needs every stage's diag(J^T J) before any block can be damped (mu = tau max diag, :117): two passes of this
+    // kernel.  The diag pass leaves the wave's LDS context -- the finite-difference Jacobians of its two intervals, 6.8 KB -- in HBM and the assembly
+    // pass reads it back instead of integrating the 64 perturbed Runge-Kutta steps a second time (same numbers: bit-identical).
+    double2* const cache = (p.stage_cache && !jac_dump && p.first_pass)
+                               ? reinterpret_cast<double2*>(p.stage_cache + (size_t)inst * p.stage_cache_stride + (size_t)pair * 2 * BL::HALF) : nullptr;
+    const bool cached = cache && !diag_only && st->first;
+    if (cached) {
+        for (int i = lane; i < BL::HALF; i += 64) reinterpret_cast<double2*>(sm)[i] = cache[i];
+    }
+    else
     big_stage_edges<DYN, DEFECT>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
     __syncthreads();
     if (jac_dump) return;
+    if (cache && diag_only)
+        for (int i = lane; i < BL::HALF; i += 64) cache[i] = reinterpret_cast<const double2*>(sm)[i];
     for (int h = 0; h < 2; ++h) {
         const int k = 2 * pair + h;
         if (k >= p.N) break;
@@ -5521,6 +5534,13 @@ bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_
     const size_t lds = bp.use_lds ? sizeof(double) * band_work_doubles(bp.nb, bp.bw) : 0;
     hipLaunchKernelGGL(band_factor_kernel, dim3(fp.batch), dim3(64), lds, stream, fp, bp);
     return true;
+}
+
+size_t big_stage_cache_doubles(const corbo_hip_problem_desc& d, int N)
+{
+    if (!big_family_dims(d.nx, d.nu)) return 0;
+    const int half = (4 * d.nx + 2 * (d.nx + d.nu) + d.nx * (d.nx + d.nu) + 8 + d.nx * d.nx + 1) & ~1;   // BigLds::HALF (checked there)
+    return (size_t)((N + 1) / 2) * 2 * (size_t)half;
 }
 
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream, const SweepParams* sp)

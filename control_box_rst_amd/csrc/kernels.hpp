@@ -109,6 +109,9 @@ struct FactorParams {
     int32_t pass_timeline_inst;
     int32_t chain_variant;        // big-block family: 0 = automatic (N >= 64: partitioned chain big_chain3_kernel, four segments; else the twisted chain big_chain2_kernel), 1 = the first formulation, 2 = twisted, 3 / 4 / 6 = 4 / 2 / 1 segments
     int32_t first_pass;           // big-block family: this may be the first factorisation of a solve (launches the mu / stop kernels)
+    double* stage_cache;          // big-block family: [batch][pairs][2 x BigLds::HALF] the stage waves' local Jacobians of a solve's FIRST factorisation, written by its
+                                  //   diag pass (mu = tau max diag(J^T J) needs all of them before any block can be damped) and read back by its assembly pass, or null
+    int64_t stage_cache_stride;   // doubles per instance
     int32_t loop_passes;          // fused pass kernel: > 0 = run-to-completion, at most this many LM passes inside one launch
     double* x_host;               // run-to-completion kernel: optional result sink in pinned, device-visible HOST memory [batch][nvs]: every
     LmState* st_host;             //   workgroup writes its instance's accepted iterate and LM state there as soon as the instance has finished
@@ -203,6 +206,7 @@ bool launch_sweep(const corbo_hip_problem_desc& d, const SweepParams& p, hipStre
 // sp: the sweep parameters of the same pass (big-block family: the stage kernel evaluates the edges itself); may be null for the
 // LDS-resident small-block families
 bool launch_factor(const corbo_hip_problem_desc& d, const FactorParams& p, hipStream_t stream, const SweepParams* sp = nullptr);
+size_t big_stage_cache_doubles(const corbo_hip_problem_desc& d, int N);   // per instance (0: not a big-block descriptor)
 // one fused LM pass: [sweep phase (sp.mode 2 = prologue, 3 = trial step) -> factor phase] per workgroup, one launch
 struct WarmStartParams {
     int32_t batch, nvs, nx, nu, N, xf_fixed_mask, shift;
