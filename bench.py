@@ -537,7 +537,10 @@ def main():
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
         alg_pair = per_stage * desc.N * B
-        pc = profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain3_kernel" if desc.N >= 64 else "big_chain2_kernel"))
+        # (the longest launches of a solve WITH the reject-streak speculation carry 32 candidate instances more than the batch -- a third round of the chain
+        # kernel; the cross-check of a full launch over exactly `batch` instances reads the trace taken without it: tools/profile_cfg5.py .. nospec)
+        pc = (profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_nospec_kernel_stats.csv", ("big_stage_kernel", "big_chain3_kernel" if desc.N >= 64 else "big_chain2_kernel"))
+              or profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_kernel_stats.csv", ("big_stage_kernel", "big_chain3_kernel" if desc.N >= 64 else "big_chain2_kernel")))
         qpmc = load_profile_json(PROFILE_ROUND + "_cfg5_pmc.json", B, desc.N)
         line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain3_kernel (one factorisation of every instance: FD Jacobian + assemble, then the partitioned block chain)",
                             "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

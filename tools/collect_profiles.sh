@@ -15,6 +15,7 @@ first() { find "$OUT/$1" -name "$2" | head -1; }
 run bench  --kernel-trace --stats -d "$OUT/bench" -o bench --output-format csv -- python "$ROOT/bench.py" --no-cpu-baseline --no-secondary
 run sweep  --kernel-trace --stats -d "$OUT/sweep" -o sweep --output-format csv -- python "$ROOT/tools/profile_sweep.py" 1024 50
 run cfg5   --kernel-trace --stats -d "$OUT/cfg5" -o cfg5 --output-format csv -- python "$ROOT/bench.py" --config 5 --no-cpu-baseline
+run cfg5ns --kernel-trace --stats -d "$OUT/cfg5ns" -o cfg5ns --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3 0 nospec
 run loop   --kernel-trace --stats -d "$OUT/loop" -o loop --output-format csv -- python "$ROOT/tools/mpc_loop.py" 1024 100 10 call
 # ---- HBM traffic counters (separate passes): the stand-alone sweep, and the run-to-completion solve kernel
 run sfetch --pmc FETCH_SIZE -d "$OUT/sfetch" -o q --output-format csv -- python "$ROOT/tools/profile_sweep.py" 1024 10
@@ -31,7 +32,7 @@ run qfetch --pmc FETCH_SIZE -d "$OUT/qfetch" -o q --output-format csv -- python 
 run qwrite --pmc WRITE_SIZE -d "$OUT/qwrite" -o q --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3
 cd "$ROOT"
 P=$ROOT/profiles
-for n in bench sweep cfg5 loop hess hess1; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done; [ -f "$P/${RND}_hess_kernel_stats.csv" ] && mv "$P/${RND}_hess_kernel_stats.csv" "$P/${RND}_hessian_kernel_stats.csv"; [ -f "$P/${RND}_hess1_kernel_stats.csv" ] && mv "$P/${RND}_hess1_kernel_stats.csv" "$P/${RND}_hessian_single_kernel_stats.csv"
+for n in bench sweep cfg5 cfg5ns loop hess hess1; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done; [ -f "$P/${RND}_hess_kernel_stats.csv" ] && mv "$P/${RND}_hess_kernel_stats.csv" "$P/${RND}_hessian_kernel_stats.csv"; [ -f "$P/${RND}_hess1_kernel_stats.csv" ] && mv "$P/${RND}_hess1_kernel_stats.csv" "$P/${RND}_hessian_single_kernel_stats.csv"; [ -f "$P/${RND}_cfg5ns_kernel_stats.csv" ] && mv "$P/${RND}_cfg5ns_kernel_stats.csv" "$P/${RND}_cfg5_nospec_kernel_stats.csv"
 python tools/summarize_pmc.py sweep "$(first sfetch '*counter_collection.csv')" "$(first swrite '*counter_collection.csv')" 1024 100 "$TAG, tools/profile_sweep.py 1024 10" | cut -c1-300
 python tools/summarize_pmc.py solve "$(first lfetch '*counter_collection.csv')" "$(first lwrite '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 10 --warmup 2" | cut -c1-300
 python tools/summarize_pmc.py sq "$(first sq1 '*counter_collection.csv')" "$(first sq2 '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 5 --warmup 1" | cut -c1-600

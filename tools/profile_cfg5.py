@@ -1,5 +1,5 @@
 """cfg 5 (quadrotor, multiple shooting + RK4, N = 200, batch 512): a few solves -- the command rocprofv3 --kernel-trace --stats wraps.
-    python tools/profile_cfg5.py [batch] [solves] [chain_variant]"""
+    python tools/profile_cfg5.py [batch] [solves] [chain_variant] [nospec]      (nospec: without the reject-streak speculation -- every launch has exactly `batch` workgroups / instance rows)"""
 import os
 import sys
 import time
@@ -17,6 +17,8 @@ s = BatchedLevenbergMarquardt(d, B)
 s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
 if len(sys.argv) > 3:
     s.set_option("chain_variant", int(sys.argv[3]))
+if len(sys.argv) > 4 and sys.argv[4] == "nospec":
+    s.set_option("reject_speculation", 0)
 s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
 s.restore_instance_data(); s.solve(new_run=True); s.synchronize()
 t0 = time.perf_counter()
