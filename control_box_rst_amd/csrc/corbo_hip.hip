@@ -502,6 +502,9 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
                     if (a.first < nb && a.first - b.first > bw) bw = a.first - b.first;
                 }
             }
+        // every position of the band gets a list (an empty one for a structural zero inside the band): the assembly kernel writes all of it, no zero fill
+        for (int r = 0; r < nb; ++r)
+            for (int c = (r - bw > 0 ? r - bw : 0); c <= r; ++c) ent[{r, c}];
         std::vector<int32_t> tgt, ptr{0}, pairs, rptr{0}, rent;
         for (const auto& kv : ent) {
             const int r = kv.first.first, c = kv.first.second;
@@ -521,11 +524,9 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         bp.ent_target = h->d_band_target; bp.ent_ptr = h->d_band_ptr; bp.ent_pairs = h->d_band_pairs; bp.rhs_ptr = h->d_band_rptr; bp.rhs_ent = h->d_band_rent;
         bp.param_voff = h->d_band_voff;
         bp.work_stride = (int64_t)band_work_doubles(nb, bw);
-        bp.use_lds = (bp.work_stride * sizeof(double) <= 60 * 1024) ? 1 : 0;
-        if (!bp.use_lds) {
-            CREATE_TRY(hipMalloc((void**)&h->d_band_work, B * (size_t)bp.work_stride * sizeof(double)));
-            CREATE_TRY(hipMemset(h->d_band_work, 0, B * (size_t)bp.work_stride * sizeof(double)));
-        }
+        bp.use_lds = 0;   // (the band lives in HBM, its sliding window and the vectors in LDS: band_factor_kernel)
+        CREATE_TRY(hipMalloc((void**)&h->d_band_work, B * (size_t)bp.work_stride * sizeof(double)));
+        CREATE_TRY(hipMemset(h->d_band_work, 0, B * (size_t)bp.work_stride * sizeof(double)));
         bp.work = h->d_band_work;
     }
     if (S.desc.shooting_integrator >= 5) h->force_split = true;   // Runge-Kutta 5 - 7: a defect formula of the stand-alone kernels only (model.hpp, DEFECT_SHOOTING_HIGH)
@@ -676,7 +677,7 @@ static int launch_sweep_checked(corbo_hip_handle h, const SweepParams& p)
 static int launch_factor_checked(corbo_hip_handle h, const FactorParams& p)
 {
     const SweepParams sp = h->sweep_params(3, 0, h->w_eq, h->w_ineq, h->w_b, nullptr);
-    if (h->band.n > 0) launch_band_factor(p, h->band, h->stream);
+    if (h->band.n > 0) { if (!launch_band_factor(p, h->band, h->stream)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "band factorisation: half-bandwidth beyond 63 or more than 160 KB of LDS"); }
     else if (!launch_factor(h->S.desc, p, h->stream, &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
     HIP_TRY(hipGetLastError());
     return 0;
@@ -790,7 +791,7 @@ try {
         if (split) {
             if (mode == 3) {
                 fp.first_pass = (pass_of[i] == 0) ? 1 : 0;
-                if (h->band.n > 0) launch_band_factor(fp, h->band, st_of[i]);   // integral-form constraint edges / control-deviation edges: the band factorisation
+                if (h->band.n > 0) { if (!launch_band_factor(fp, h->band, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "band factorisation: half-bandwidth beyond 63 or more than 160 KB of LDS"); }   // integral-form constraint edges / control-deviation edges / a free dt around a big-block model
                 else if (!launch_factor(h->S.desc, fp, st_of[i], &sp)) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no factor kernel for this nx/nu/N");
                 HIP_TRY(hipGetLastError());
                 stamp();

@@ -5391,118 +5391,202 @@ bool launch_big_spec(const SpecParams& p, hipStream_t stream)
     return true;
 }
 
-size_t band_work_doubles(int nb, int bw) { return (size_t)nb * (bw + 1) + 3 * (size_t)nb + 8; }
+size_t band_work_doubles(int nb, int bw) { return (size_t)nb * (bw + 1) + 2 * (size_t)nb + 8; }   // the band, then rhs [nb], border [nb], corner, rhs of dt
+static size_t band_lds_doubles(int nb, int bw) { return (size_t)(bw + 1) * (bw + 1) + 2 * (size_t)nb + 32; }   // window, rhs, border, scratch [corner, rhs of dt, per-wave partial results]
 
-__global__ __launch_bounds__(64) void band_factor_kernel(const FactorParams p, const BandParams bp)
+// ---- assembly of H = J^T J and rhs = -J^T r from the static product lists, spread over the chip: grid (chunks, instances).  (Inside the factor kernel
+//      -- four waves per instance -- it was a third of the launch: every product is an index load and two dependent value loads.)  Every position of
+//      the band has a list (possibly empty): no zero fill.
+__global__ __launch_bounds__(256) void band_assemble_kernel(const FactorParams p, const BandParams bp)
+{
+    const int inst = blockIdx.y + p.inst0, tid = threadIdx.x, chunk = blockIdx.x, nchunk = gridDim.x;
+    const LmState* st = p.st + inst;
+    if (st->done) return;
+    const int n = bp.n, nb = bp.nb, W = bp.bw + 1;
+    double* Hb = bp.work + (size_t)inst * bp.work_stride;
+    double* gz = Hb + (size_t)nb * W;                         // rhs [nb], border [nb], corner, rhs of dt
+    const double* val = (st->vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
+    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
+    // (the product lists are walked four products at a time: eight independent Jacobian loads in flight -- the sums keep their order)
+    const int2* pairs2 = reinterpret_cast<const int2*>(bp.ent_pairs);
+    for (int e = chunk * 256 + tid; e < bp.n_ent; e += nchunk * 256) {
+        double acc = 0.0;
+        int q = bp.ent_ptr[e];
+        const int qe = bp.ent_ptr[e + 1];
+        for (; q + 4 <= qe; q += 4) {
+            const int2 i0 = pairs2[q], i1 = pairs2[q + 1], i2 = pairs2[q + 2], i3 = pairs2[q + 3];
+            const double a0 = J[i0.x], b0 = J[i0.y], a1 = J[i1.x], b1 = J[i1.y], a2 = J[i2.x], b2 = J[i2.y], a3 = J[i3.x], b3 = J[i3.y];
+            acc += a0 * b0; acc += a1 * b1; acc += a2 * b2; acc += a3 * b3;
+        }
+        for (; q < qe; ++q) { const int2 i0 = pairs2[q]; acc += J[i0.x] * J[i0.y]; }
+        const int t = bp.ent_target[e];
+        if (t >= 0) Hb[t] = acc;
+        else if (t == INT32_MIN) gz[2 * nb] = acc;
+        else gz[nb + (-1 - t)] = acc;
+    }
+    const int2* rent2 = reinterpret_cast<const int2*>(bp.rhs_ent);
+    for (int c = chunk * 256 + tid; c < n; c += nchunk * 256) {
+        double acc = 0.0;
+        int q = bp.rhs_ptr[c];
+        const int qe = bp.rhs_ptr[c + 1];
+        for (; q + 4 <= qe; q += 4) {
+            const int2 i0 = rent2[q], i1 = rent2[q + 1], i2 = rent2[q + 2], i3 = rent2[q + 3];
+            const double a0 = J[i0.x], b0 = val[i0.y], a1 = J[i1.x], b1 = val[i1.y], a2 = J[i2.x], b2 = val[i2.y], a3 = J[i3.x], b3 = val[i3.y];
+            acc -= a0 * b0; acc -= a1 * b1; acc -= a2 * b2; acc -= a3 * b3;
+        }
+        for (; q < qe; ++q) { const int2 i0 = rent2[q]; acc -= J[i0.x] * val[i0.y]; }
+        if (c < nb) gz[c] = acc; else gz[2 * nb + 1] = acc;
+    }
+}
+
+// (round 4) Four waves per instance and a SLIDING WINDOW: pivot j only touches rows j .. j + bw of the band, so those bw + 1 rows live in LDS (a ring of
+// row slots, (bw + 1)^2 doubles) while the band itself stays in HBM -- a finished row is written out once, the row that enters the window is requested one
+// pivot ahead.  Right-hand side and border column stay in LDS for the whole factorisation; the back-substitution walks the rows of L from the last one
+// (x_i = y_i / L_ii, then y_c -= L_ic x_i for the row's band: contiguous rows, requested two ahead) instead of gathering columns.  Before: one wave,
+// every pivot three dependent trips to wherever the band was (the 12-state quadrotor with a free dt at N = 100: 13 ms per factorisation).
+__global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, const BandParams bp)
 {
     extern __shared__ __attribute__((aligned(16))) double band_smem[];
     __shared__ __attribute__((aligned(16))) LmState sl_;
-    const int inst = blockIdx.x + p.inst0, tid = threadIdx.x;
+    constexpr int T = 512, NWV = T / 64;   // (eight waves: the trailing update of a pivot -- up to 63 * 64 / 2 entries -- in two rounds)
+    const int inst = blockIdx.x + p.inst0, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     LmState* st = &sl_;
     lm_state_in(st, p.st + inst, tid);
     __syncthreads();
     if (st->done) return;
     const int n = bp.n, nb = bp.nb, bw = bp.bw, W = bw + 1;
     const bool arrow = (nb < n);
-    double* Hb = bp.use_lds ? band_smem : bp.work + (size_t)inst * bp.work_stride;   // [nb][W]: column r - bw + d of row r at d; d = bw is the diagonal
-    double* g  = Hb + (size_t)nb * W;   // rhs -> y -> delta
-    double* z  = g + nb;                // border column (free dt) -> L^-1 border
-    double* sc = z + nb;                // scratch: [0] corner, [1] rhs of dt
-    const int vbuf = st->vbuf, fresh = st->fresh, first = st->first;
+    double* Hb  = bp.work + (size_t)inst * bp.work_stride;   // [nb][W]: column r - bw + d of row r at d; d = bw is the diagonal
+    const double* gz = Hb + (size_t)nb * W;                   // what band_assemble_kernel left: rhs, border, corner, rhs of dt
+    double* win = band_smem;                                  // [W][W] ring of row slots: row i lives in slot i % W
+    double* g   = win + (size_t)W * W;                        // rhs -> y -> delta
+    double* z   = g + nb;                                     // border column (free dt) -> L^-1 border
+    double* sc  = z + nb;                                     // scratch: [0] corner, [1] rhs of dt, [2..] reductions
+    const int fresh = st->fresh, first = st->first;
     int stop = st->stop;
     double mu = st->mu;
     const double mu_acc_in = st->mu_acc;
-    const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
-    const double* J   = p.jac + (size_t)inst * p.nnz_pad;
-    // ---- assemble
-    for (int i = tid; i < nb * W; i += 64) Hb[i] = 0.0;
-    for (int i = tid; i < nb; i += 64) z[i] = 0.0;
-    if (tid == 0) { sc[0] = 0.0; sc[1] = 0.0; }
-    __syncthreads();
-    for (int e = tid; e < bp.n_ent; e += 64) {
-        double acc = 0.0;
-        for (int q = bp.ent_ptr[e]; q < bp.ent_ptr[e + 1]; ++q) acc += J[bp.ent_pairs[2 * q]] * J[bp.ent_pairs[2 * q + 1]];
-        const int t = bp.ent_target[e];
-        if (t >= 0) Hb[t] = acc;
-        else if (t == INT32_MIN) sc[0] = acc;
-        else z[-1 - t] = acc;
-    }
-    for (int c = tid; c < n; c += 64) {
-        double acc = 0.0;
-        for (int q = bp.rhs_ptr[c]; q < bp.rhs_ptr[c + 1]; ++q) acc -= J[bp.rhs_ent[2 * q]] * val[bp.rhs_ent[2 * q + 1]];
-        if (c < nb) g[c] = acc; else sc[1] = acc;
-    }
+#define BAND_STAMP(i) do { if (p.timeline && blockIdx.x == 0 && tid == 0) p.timeline[i] = clock64(); } while (0)
+    BAND_STAMP(0);
+    // ---- right-hand side and border into LDS
+    for (int i = tid; i < nb; i += T) { g[i] = gz[i]; z[i] = arrow ? gz[nb + i] : 0.0; }
+    if (tid == 0) { sc[0] = arrow ? gz[2 * nb] : 0.0; sc[1] = arrow ? gz[2 * nb + 1] : 0.0; }
     __syncthreads();
     if (first) {   // mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
         double mx_d = -1e300, mx_g = 0.0;
-        for (int c = tid; c < nb; c += 64) { mx_d = fmax(mx_d, Hb[(size_t)c * W + bw]); mx_g = fmax(mx_g, fabs(g[c])); }
+        for (int c = tid; c < nb; c += T) { mx_d = fmax(mx_d, Hb[(size_t)c * W + bw]); mx_g = fmax(mx_g, fabs(g[c])); }
         mx_d = wave_max(mx_d); mx_g = wave_max(mx_g);
+        if (lane == 0) { sc[2 + 2 * wave] = mx_d; sc[3 + 2 * wave] = mx_g; }
+        __syncthreads();
+        mx_d = sc[2]; mx_g = sc[3];
+        for (int w = 1; w < NWV; ++w) { mx_d = fmax(mx_d, sc[2 + 2 * w]); mx_g = fmax(mx_g, sc[3 + 2 * w]); }
         if (arrow) { mx_d = fmax(mx_d, sc[0]); mx_g = fmax(mx_g, fabs(sc[1])); }
         stop = (mx_g <= LM_EPS1) ? 1 : 0;
         mu   = LM_TAU * mx_d;
         if (mu < 0) mu = 0;
+        __syncthreads();
     }
     const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;   // H_ii += mu on every inner pass, never undone on reject (:135-138)
-    for (int c = tid; c < nb; c += 64) Hb[(size_t)c * W + bw] += mu_eff;
+    BAND_STAMP(1);   // assembled
+    // ---- the window: rows 0 .. bw (with the damping on their diagonals), the next row requested
+    for (int i = tid; i < W * W; i += T) {
+        const int r = i / W, d = i - r * W;
+        double v = (r < nb) ? Hb[(size_t)r * W + d] : 0.0;
+        if (d == bw) v += mu_eff;
+        win[i] = v;
+    }
+    const bool loader = (wave == 3) && lane < W;   // wave 3: lane d carries entry d of the row that enters next
+    int rnext = W;                                  // (rows 0 .. bw are in)
+    double pre = 0.0;
+    if (loader && rnext < nb) { pre = Hb[(size_t)rnext * W + lane]; if (lane == bw) pre += mu_eff; }
     __syncthreads();
-    // ---- band Cholesky (in place, lower), forward substitution of rhs and border fused into the elimination
-    double y2 = 0.0, zz = 0.0, zy = 0.0;
+    BAND_STAMP(2);   // window loaded
+    // ---- band Cholesky (lower), forward substitution of rhs and border fused into the elimination.  LDS-only barriers: a full __syncthreads() waits for the
+    //      wave's global operations too -- the write-out of row j and the request of the entering row would cost a memory round trip per pivot each
     for (int j = 0; j < nb; ++j) {
-        const double l = sqrt(Hb[(size_t)j * W + bw]);
-        const double inv = 1.0 / l;
         const int cnt = (nb - 1 - j < bw) ? nb - 1 - j : bw;   // rows below the pivot inside the band
-        __syncthreads();
-        // column j: L(i, j) = H(i, j) / l, i = j + 1 .. j + cnt  (lane t -> i = j + 1 + t)
-        if (tid < cnt) { const int i = j + 1 + tid; Hb[(size_t)i * W + bw - (i - j)] *= inv; }
-        if (tid == 62) g[j] *= inv;                // y_j
-        if (tid == 63 && arrow) z[j] *= inv;       // (L^-1 border)_j
-        if (tid == 0) Hb[(size_t)j * W + bw] = l;
-        __syncthreads();
+        double* rowj = win + (size_t)(j % W) * W;
+        const double dj  = rowj[bw];
+        const double inv = rsqrt(dj);              // (v_rsq_f64 + one Newton step: half the dependent instructions of sqrt and a division)
+        const double l   = dj * inv;
+        if (wave == 2 && lane < W) Hb[(size_t)j * W + lane] = (lane == bw) ? l : rowj[lane];   // row j is final: L(j, j - bw .. j)
+        // column j: L(i, j) = H(i, j) / l, i = j + 1 .. j + cnt   (row j itself is only read in this phase: no barrier before it)
+        if (tid < cnt) { const int i = j + 1 + tid; win[(size_t)(i % W) * W + bw - (i - j)] *= inv; }
+        if (tid == 64) g[j] *= inv;                // y_j
+        if (tid == 65 && arrow) z[j] *= inv;       // (L^-1 border)_j
+        lds_barrier();   // (what crosses it lives in LDS: the row written out and the row requested stay in flight)
         // trailing update: H(i, c) -= L(i, j) L(c, j), j < c <= i <= j + cnt; rhs / border: g_i -= L(i, j) y_j
-        for (int q = tid; q < cnt * (cnt + 1) / 2; q += 64) {
-            int a = 0, rem = q;
-            while (rem > a) { rem -= a + 1; ++a; }   // q -> (a, rem), rem <= a: i = j + 1 + a, c = j + 1 + rem
+        const int ntri = cnt * (cnt + 1) / 2;
+        for (int q = tid; q < ntri; q += T) {
+            int a = (int)((__builtin_sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);   // q = a (a + 1) / 2 + rem, rem <= a (single-precision estimate, corrected below)
+            while (a * (a + 1) / 2 > q) --a;
+            while ((a + 1) * (a + 2) / 2 <= q) ++a;
+            const int rem = q - a * (a + 1) / 2;
             const int i = j + 1 + a, c = j + 1 + rem;
-            Hb[(size_t)i * W + bw - (i - c)] -= Hb[(size_t)i * W + bw - (i - j)] * Hb[(size_t)c * W + bw - (c - j)];
+            double* ri = win + (size_t)(i % W) * W;
+            ri[bw - (i - c)] -= ri[bw - (i - j)] * win[(size_t)(c % W) * W + bw - (c - j)];
         }
-        if (tid < cnt) {
-            const int i = j + 1 + tid;
-            const double lij = Hb[(size_t)i * W + bw - (i - j)];
+        if (tid >= 128 && tid < 128 + cnt) {
+            const int i = j + 1 + (tid - 128);
+            const double lij = win[(size_t)(i % W) * W + bw - (i - j)];
             g[i] -= lij * g[j];
             if (arrow) z[i] -= lij * z[j];
         }
-        __syncthreads();
+        // the row that enters for the next pivot takes the slot of row j (its entries were written out above), the one behind it is requested
+        if (loader) {
+            if (rnext < nb) rowj[lane] = pre;
+            ++rnext;
+            if (rnext < nb) { pre = Hb[(size_t)rnext * W + lane]; if (lane == bw) pre += mu_eff; }
+        }
+        lds_barrier();   // (what crosses it lives in LDS: the row written out and the row requested stay in flight)
     }
-    for (int c = tid; c < nb; c += 64) { y2 += g[c] * g[c]; if (arrow) { zz += z[c] * z[c]; zy += z[c] * g[c]; } }
-    y2 = wave_sum(y2);
+    __syncthreads();
+    BAND_STAMP(3);   // factorised
+    double y2 = 0.0, zz = 0.0, zy = 0.0;
+    for (int c = tid; c < nb; c += T) { y2 += g[c] * g[c]; if (arrow) { zz += z[c] * z[c]; zy += z[c] * g[c]; } }
+    y2 = wave_sum(y2); zz = wave_sum(zz); zy = wave_sum(zy);
+    if (lane == 0) { sc[2 + 3 * wave] = y2; sc[3 + 3 * wave] = zz; sc[4 + 3 * wave] = zy; }
+    __syncthreads();
+    y2 = 0.0; zz = 0.0; zy = 0.0;
+    for (int w = 0; w < NWV; ++w) { y2 += sc[2 + 3 * w]; zz += sc[3 + 3 * w]; zy += sc[4 + 3 * w]; }
     double ddt = 0.0;
     if (arrow) {   // the last pivot: H(dt, dt) + damping - |z|^2
-        zz = wave_sum(zz); zy = wave_sum(zy);
         const double piv  = (sc[0] + mu_eff) - zz;
         const double linv = 1.0 / sqrt(piv);
         const double ydt  = (sc[1] - zy) * linv;
         y2 += ydt * ydt;
         ddt = ydt * linv;
-        for (int c = tid; c < nb; c += 64) g[c] -= z[c] * ddt;
+        for (int c = tid; c < nb; c += T) g[c] -= z[c] * ddt;
     }
     __syncthreads();
-    // ---- back-substitution L^T delta = y
-    for (int j = nb - 1; j >= 0; --j) {
-        const int cnt = (nb - 1 - j < bw) ? nb - 1 - j : bw;
-        double part = (tid < cnt) ? Hb[(size_t)(j + 1 + tid) * W + bw - (1 + tid)] * g[j + 1 + tid] : 0.0;
-        part = wave_sum(part);
-        __syncthreads();
-        if (tid == 0) g[j] = (g[j] - part) / Hb[(size_t)j * W + bw];
-        __syncthreads();
+    // ---- back-substitution L^T delta = y, row by row from the last one (wave 0; rows of L from HBM, two ahead)
+    if (wave == 0) {
+        __threadfence_block();
+        const bool on = lane < W;
+        double r0 = 0.0, r1 = 0.0;
+        if (on && nb >= 1) r0 = Hb[(size_t)(nb - 1) * W + lane];
+        if (on && nb >= 2) r1 = Hb[(size_t)(nb - 2) * W + lane];
+        for (int i = nb - 1; i >= 0; --i) {
+            const double row = r0;
+            r0 = r1;
+            if (on && i >= 2) r1 = Hb[(size_t)(i - 2) * W + lane];
+            const double gi  = g[i];
+            const double xi  = gi / lane_bcast(row, bw);       // x_i = y_i / L(i, i)   (every lane the same number)
+            const int c = i - bw + lane;                        // lane d < bw: column c of row i
+            if (lane < bw && c >= 0) g[c] -= row * xi;
+            if (lane == bw) g[i] = xi;
+        }
     }
+    __syncthreads();
+    BAND_STAMP(4);   // back-substituted
     // ---- trial iterate x + delta (applyIncrementNonFixed, vertex_set.cpp:357-367), step norms
     const double* xin = p.x + (size_t)inst * p.nvs;
     double* xt        = p.xt + (size_t)inst * p.nvs;
     double* dl        = p.delta_out ? p.delta_out + (size_t)inst * p.nvs : nullptr;
-    for (int v = tid; v < p.nvs; v += 64) { xt[v] = xin[v]; if (dl) dl[v] = 0.0; }
+    for (int v = tid; v < p.nvs; v += T) { xt[v] = xin[v]; if (dl) dl[v] = 0.0; }
     __syncthreads();
     double dn2 = 0.0;
-    for (int c = tid; c < n; c += 64) {
+    for (int c = tid; c < n; c += T) {
         const double d = (c < nb) ? g[c] : ddt;
         const int v    = bp.param_voff[c];
         xt[v] = xin[v] + d;
@@ -5510,7 +5594,11 @@ __global__ __launch_bounds__(64) void band_factor_kernel(const FactorParams p, c
         dn2 += d * d;
     }
     dn2 = wave_sum(dn2);
+    if (lane == 0) sc[2 + wave] = dn2;
+    __syncthreads();
     if (tid == 0) {
+        dn2 = 0.0;
+        for (int w = 0; w < NWV; ++w) dn2 += sc[2 + w];
         st->mu     = mu;
         st->mu_acc = mu_eff;
         st->first  = 0;
@@ -5525,14 +5613,26 @@ __global__ __launch_bounds__(64) void band_factor_kernel(const FactorParams p, c
         st->stop     = stop;
         st->no_trial = no_trial;
     }
+    BAND_STAMP(5);
+#undef BAND_STAMP
     __syncthreads();
     lm_state_out(p.st + inst, st, tid);
 }
 
 bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream)
 {
-    const size_t lds = bp.use_lds ? sizeof(double) * band_work_doubles(bp.nb, bp.bw) : 0;
-    hipLaunchKernelGGL(band_factor_kernel, dim3(fp.batch), dim3(64), lds, stream, fp, bp);
+    const size_t lds = sizeof(double) * (band_lds_doubles(bp.nb, bp.bw) + 8);   // window + rhs + border + scratch (a horizon of 256 twelve-state intervals: 85 KB)
+    static bool attr_set = false;
+    constexpr size_t LDS_MAX = 160 * 1024 - 256;   // (the kernel also has 128 bytes of static LDS: the LM state)
+    if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError(); attr_set = true; }
+    if (lds > LDS_MAX || !bp.work || bp.bw + 1 > 64) return false;   // (one wave writes a finished row out / walks a row in the back-substitution: half-bandwidth <= 63)
+    {
+        int chunks = (bp.n_ent + 2047) / 2048;   // (eight list entries per thread)
+        if (chunks > 64) chunks = 64;
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(band_assemble_kernel, dim3(chunks, fp.batch), dim3(256), 0, stream, fp, bp);
+    }
+    hipLaunchKernelGGL(band_factor_kernel, dim3(fp.batch), dim3(512), lds, stream, fp, bp);
     return true;
 }
 

@@ -1,0 +1,23 @@
+"""Band factorisation path (free dt around a big-block model, integral-form constraints): time per solve (diagnostics).  python tools/band_time.py"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from control_box_rst_amd import problems
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+for name, d, B in (("pquad time-optimal N=30", problems.planar_quadrotor_desc(N=30, time_optimal=True), 1), ("pquad time-optimal N=30", problems.planar_quadrotor_desc(N=30, time_optimal=True), 256),
+                   ("quad time-optimal N=100", problems.quad_desc(N=100, time_optimal=True), 1), ("quad time-optimal N=100", problems.quad_desc(N=100, time_optimal=True), 64)):
+    nx = d.nx
+    x0 = np.zeros((B, nx)); xf = np.zeros((B, nx)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
+    s = BatchedLevenbergMarquardt(d, B); s.setPenaltyWeights(100.0, 100.0, 100.0)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf); s.solve(new_run=True); s.synchronize()
+    x, chi2, status = s.get_solution()
+    t0 = time.perf_counter()
+    for _ in range(3): s.restore_instance_data(); s.solve(new_run=True)
+    s.synchronize(); ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(f"{name}: batch {B}: {ms:.2f} ms per 10-iteration solve, chi2[0] {chi2[0]:.10g}, passes {s.get_stats()['passes']}", flush=True)
+    if B == 1:
+        s.restore_instance_data()
+        ms_f, tl = s.time_factor(repeat=3, timeline=True)
+        names = ["load rhs", "window", "factorise", "back-substitute", "trial iterate"]
+        print(f"   band_factor_kernel {ms_f:.3f} ms per launch; phases (cycles): " + " | ".join(f"{nm} {tl[i + 1] - tl[i]}" for i, nm in enumerate(names)), flush=True)
