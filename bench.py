@@ -327,6 +327,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sink", action="store_true", help="results via D2H copies after the solve instead of the kernel-written pinned sink")
     ap.add_argument("--preheat-ms", type=float, default=300.0, help="untimed steps for this long before the warm-up steps (clock ramp, cold pages); 0 = none")
+    ap.add_argument("--sync-steps", action="store_true", help="the host waits for every solve of the timed region (rounds 1-3) instead of enqueueing the steps back to back")
     ap.add_argument("--no-secondary", action="store_true", help="skip the legs over BASELINE configs 1, 2, 5 in the default (config 3, 1 GPU) line")
     ap.add_argument("--solve-only", action="store_true", help="profiling: only warm-up + timed steps (no roofline / host legs)")
     args = ap.parse_args()
@@ -388,6 +389,19 @@ def main():
         if fetch:
             return solver.fetch_solution()   # trajectories, chi2, status -> pinned host memory (inside the timed region)
 
+    # The timed steps are ENQUEUED back to back (corbo_hip_solve_async: the solve without the wait): the host side of step k + 1 -- re-arm, launch --
+    # overlaps the kernel of step k, as a caller that streams batch after batch through a handle would run it.  Every step does the same work as the
+    # synchronous one (re-arm + every LM pass + the results written into pinned host memory by the kernel); the closing fence waits for all of them.
+    # Handles whose passes are driven from the host (cfg 5) solve synchronously inside solve_async.  --sync-steps: the per-step wait of rounds 1-3.
+    pipelined = use_sink and not args.sync_steps
+
+    def step_timed():
+        if not pipelined:
+            return step()
+        solver.restore_instance_data()
+        for i in range(solves):
+            solver.solve_async(new_run=(i == 0))
+
     def fence():
         solver.synchronize()
         torch.cuda.synchronize()
@@ -409,10 +423,22 @@ def main():
     solver.get_timing(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        step_timed()
     fence()
+    if pipelined:
+        solver.fetch_solution()                   # (views of the pinned result buffers the last step's kernel filled)
     elapsed = time.perf_counter() - t0
     solve_ms_sum, n_solves = solver.get_timing(reset=True)
+    # the same K steps with the host waiting for every solve (how rounds 1-3 timed the step): reported next to `value`, never in its place
+    sync_ms_per_step = None
+    if pipelined:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        sync_ms_per_step = 1e3 * sharding.reduce_max(time.perf_counter() - t1, dist, device=red_dev) / steps
+        solver.get_timing(reset=True)
 
     stats = solver.get_stats()                    # statistics of the LAST solve of a step
     X, chi2, status = solver.get_solution()
@@ -440,9 +466,15 @@ def main():
         "config": {"workload": f"{w['name']}, batch={B} per GPU, {solves} solve(s) x {args.iterations} LM iterations per step, seeds 20260928+i",
                    "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations, "solves_per_step": solves,
                    "parallelism": f"batch-sharded x{world}"},
-        "timed_region": "re-arm (D2D) + corbo_hip_solve + trajectories/chi2/status resident in pinned host memory ("
-                        + ("written by the solve kernel as each instance finishes, corbo_hip_set_result_sink" if use_sink else "two D2H copies behind the solve")
-                        + ", views from corbo_hip_fetch_solution); wall clock, barrier + synchronize on both sides, MAX over ranks",
+        "timed_region": ("re-arm (D2D) + corbo_hip_solve_async per step, the K steps enqueued back to back (the host side of a step overlaps the previous step's kernel), "
+                         "every step's trajectories/chi2/status written into pinned host memory by the solve kernel as each instance finishes (corbo_hip_set_result_sink); "
+                         "wall clock, barrier + synchronize on both sides, MAX over ranks" if pipelined else
+                         "re-arm (D2D) + corbo_hip_solve + trajectories/chi2/status resident in pinned host memory ("
+                         + ("written by the solve kernel as each instance finishes, corbo_hip_set_result_sink" if use_sink else "two D2H copies behind the solve")
+                         + ", views from corbo_hip_fetch_solution); wall clock, barrier + synchronize on both sides, MAX over ranks"),
+        "synchronous_steps": ({"ms_per_step": sync_ms_per_step, "value": total_iters_per_step / (sync_ms_per_step * 1e-3),
+                               "what": "the same K steps with the host waiting for every solve before it re-arms the next one (corbo_hip_solve; the timed region of rounds 1-3)"}
+                              if sync_ms_per_step else None),
         "preheat": {"ms": args.preheat_ms, "untimed_steps": preheat_steps, "what": "untimed steps before the warm-up steps: steady-state clocks and warm pages (a cold process measures 0.74 - 0.77 ms per step over its first 25 steps, 0.68 ms afterwards)"},
         "counted_iterations": int(counted_step),
         "value_computed": (total_iters_per_step - counted_step) * steps / t_max,

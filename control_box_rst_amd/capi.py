@@ -93,7 +93,7 @@ _lib = None
 # every symbol include/corbo_hip.h declares
 EXPORTED_SYMBOLS = (
     "corbo_hip_default_lm_opts", "corbo_hip_get_dims", "corbo_hip_get_structure", "corbo_hip_init_trajectory",
-    "corbo_hip_create", "corbo_hip_destroy", "corbo_hip_set_instance_data", "corbo_hip_solve",
+    "corbo_hip_create", "corbo_hip_destroy", "corbo_hip_set_instance_data", "corbo_hip_solve", "corbo_hip_solve_async",
     "corbo_hip_synchronize", "corbo_hip_get_solution", "corbo_hip_get_stats", "corbo_hip_eval",
     "corbo_hip_device_views", "corbo_hip_time_sweep", "corbo_hip_last_error",
     "corbo_hip_restore_instance_data", "corbo_hip_set_profiling", "corbo_hip_time_factor", "corbo_hip_warm_start", "corbo_hip_get_first_control",
@@ -154,6 +154,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_closed_loop.argtypes = [H, C.POINTER(LmOpts), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp]
     lib.corbo_hip_set_profiling.argtypes = [H, C.c_int]
     lib.corbo_hip_solve.argtypes = [H, C.POINTER(LmOpts), C.c_int]
+    lib.corbo_hip_solve_async.argtypes = [H, C.POINTER(LmOpts), C.c_int]
     lib.corbo_hip_synchronize.argtypes = [H]
     lib.corbo_hip_get_solution.argtypes = [H, dp, dp, ip]
     lib.corbo_hip_get_stats.argtypes = [H, C.POINTER(Stats)]

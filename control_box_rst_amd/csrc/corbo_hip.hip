@@ -145,6 +145,9 @@ struct corbo_hip_solver {
     int32_t* d_queue      = nullptr;  // ticket counter of the run-to-completion kernel's instance queue (batches beyond 4 workgroups per CU)
     int32_t* d_counters   = nullptr;  // MAX_PASSES
     int32_t* h_counter    = nullptr;  // pinned
+    // corbo_hip_solve_async: solves enqueued and not yet waited for (their timing event pairs; the pass-limit flag alternates between two pinned slots)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> async_events, event_pool;
+    int async_pending = 0;
     int m_pad = 0, nnz_pad = 0;
     // Hessian-path operators: the structure of a (handle, lower) pair is built once, scratch buffers only grow (an interior-point
     // loop calls these once per iteration)
@@ -578,6 +581,8 @@ void corbo_hip_destroy(corbo_hip_handle h)
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
     for (auto& b : h->hb_vals) b.release();
     h->hb_me.release(); h->hb_mi.release(); h->hb_lin.release(); h->hb_lb.release(); h->hb_ub.release(); h->hb_grad.release(); h->hb_obj.release(); h->hb_pin.release();
+    for (auto* list : {&h->async_events, &h->event_pool})
+        for (auto& pr : *list) { if (pr.first) (void)hipEventDestroy(pr.first); if (pr.second) (void)hipEventDestroy(pr.second); }
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     if (h->h_xnew) (void)hipHostFree(h->h_xnew);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -711,8 +716,46 @@ try {
 }
 ABI_CATCH
 
+// what a synchronous solve does behind its last launch, for the solves of corbo_hip_solve_async that are still in flight: wait, add their HIP-event times
+// to the handle's timing, check the pass-limit flags
+static int finish_async(corbo_hip_handle h)
+{
+    if (h->async_pending == 0) return CORBO_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& pr : h->async_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { h->solve_ms_sum += ms; h->stats.solve_ms = ms; }
+        h->event_pool.push_back(pr);
+    }
+    h->async_events.clear();
+    h->async_pending = 0;
+    const bool unfinished = h->h_counter[0] != 0 || h->h_counter[1] != 0;
+    h->h_counter[0] = h->h_counter[1] = 0;
+    if (unfinished) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    h->sink_valid = h->result_sink;
+    return CORBO_HIP_OK;
+}
+
+static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run, bool async);
+
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
 try {
+    if (h) { const int rc = finish_async(h); if (rc) return rc; }
+    return solve_impl(h, o, new_run, false);
+}
+ABI_CATCH
+
+// The same solve without the wait: everything is enqueued on the handle's stream and the call returns -- the host side of the next solve (its re-arm,
+// its launch) overlaps this one's kernel.  Run-to-completion handles only (one launch per solve); other handles solve synchronously.  Results, statistics
+// and the pass-limit check become available with the next corbo_hip_synchronize / corbo_hip_solve / corbo_hip_get_* call.
+int corbo_hip_solve_async(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run)
+try {
+    return solve_impl(h, o, new_run, true);
+}
+ABI_CATCH
+
+static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run, bool async)
+{
     if (!h || !o) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called before corbo_hip_solve");
     if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
@@ -733,7 +776,14 @@ try {
     };
     const bool split = h->split_passes || h->force_split;
     const bool run_to_completion = !split && h->loop_mode && o->iterations > 0;
-    if (h->solve_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    if (async && !run_to_completion) { const int rc0 = finish_async(h); if (rc0) return rc0; async = false; }   // (host-driven passes: synchronous)
+    std::pair<hipEvent_t, hipEvent_t> aev{nullptr, nullptr};
+    if (async && h->solve_timing) {
+        if (!h->event_pool.empty()) { aev = h->event_pool.back(); h->event_pool.pop_back(); }
+        else { HIP_TRY(hipEventCreate(&aev.first)); HIP_TRY(hipEventCreate(&aev.second)); }
+        HIP_TRY(hipEventRecord(aev.first, h->stream));
+    }
+    else if (h->solve_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (!run_to_completion)   // per-pass "unfinished instances" counters (the run-to-completion kernel reports through pinned host memory)
         HIP_TRY(hipMemsetAsync(h->d_counters, 0, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t), h->stream));
     stamp();
@@ -829,8 +879,10 @@ try {
             if (h->pass_limit > 0 && h->pass_limit < MAX_PASSES) fp.loop_passes = h->pass_limit;   // (tests: provoke the "pass limit reached" error path)
             // an instance that runs into the pass limit raises a flag in pinned, device-visible host memory: no memset, no read-back
             // copy and no second synchronisation around the one launch of a solve
-            h->h_counter[2 * i] = 0;
-            fp.unfinished_flag  = h->h_counter + 2 * i;
+            // (asynchronous solves alternate between two flag slots: the flag of the solve still in flight is not cleared under it)
+            const int flag_slot = async ? (h->async_pending & 1) : 0;
+            if (!async || h->async_pending < 2) h->h_counter[2 * i + flag_slot] = 0;
+            fp.unfinished_flag  = h->h_counter + 2 * i + flag_slot;
             long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
             const bool ptl_on = h->pass_timeline_inst >= 0;
             if (ptl_on && i == 0) {
@@ -915,6 +967,13 @@ try {
             HIP_TRY(hipEventRecord(h->sub_done[i], st_of[i]));
             HIP_TRY(hipStreamWaitEvent(h->stream, h->sub_done[i], 0));
         }
+    if (async) {   // no wait: finish_async does the rest
+        if (aev.first) { HIP_TRY(hipEventRecord(aev.second, h->stream)); h->async_events.push_back(aev); }
+        h->async_pending += 1;
+        h->solve_count += 1;
+        h->stats.passes = 1;
+        return CORBO_HIP_OK;
+    }
     if (h->solve_timing) {
         HIP_TRY(hipEventRecord(h->ev1, h->stream));
         HIP_TRY(hipEventSynchronize(h->ev1));
@@ -942,7 +1001,6 @@ try {
     h->sink_valid = run_to_completion && h->result_sink;
     return CORBO_HIP_OK;
 }
-ABI_CATCH
 
 int corbo_hip_set_result_sink(corbo_hip_handle h, int enable)
 {
@@ -1368,6 +1426,7 @@ int corbo_hip_synchronize(corbo_hip_handle h)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    { const int rc = finish_async(h); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return CORBO_HIP_OK;
 }
@@ -1376,6 +1435,7 @@ int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, 
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    { const int rc_a = finish_async(h); if (rc_a) return rc_a; }
     h->sink_valid = false;   // the pinned result views are stale from here on
     HIP_TRY(hipStreamSynchronize(h->stream));
     const Structure& S = h->S;
@@ -1404,6 +1464,7 @@ int corbo_hip_fetch_solution(corbo_hip_handle h, const double** x_pinned, int32_
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    { const int rc_a = finish_async(h); if (rc_a) return rc_a; }
     const Structure& S = h->S;
     const int B = h->batch;
     if (!h->sink_valid) {
@@ -1429,6 +1490,7 @@ ABI_CATCH
 int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solves, int reset)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    { ON_DEVICE_OF(h); const int rc = finish_async(h); if (rc) return rc; }
     if (solve_ms_sum) *solve_ms_sum = h->solve_ms_sum;
     if (solves) *solves = h->solve_count;
     if (reset) { h->solve_ms_sum = 0.0; h->solve_count = 0; }
@@ -1439,6 +1501,7 @@ int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
 try {
     if (!h || !stats) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    { const int rc_a = finish_async(h); if (rc_a) return rc_a; }
     h->sink_valid = false;   // the pinned result views are stale from here on
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyAsync(h->h_state, h->d_state, (size_t)h->batch * sizeof(LmState), hipMemcpyDeviceToHost, h->stream));

@@ -216,6 +216,12 @@ class BatchedLevenbergMarquardt:
         rc = self.lib.corbo_hip_solve(self._h, C.byref(self.opts), 1 if new_run else 0)
         self._check(rc, "corbo_hip_solve")
 
+    def solve_async(self, new_run: bool = True):
+        """corbo_hip_solve_async: enqueue the solve and return (run-to-completion handles; others solve synchronously).  Results / timing / errors of
+        the enqueued solves with the next synchronize() / solve() / get_*() / fetch_solution()."""
+        rc = self.lib.corbo_hip_solve_async(self._h, C.byref(self.opts), 1 if new_run else 0)
+        self._check(rc, "corbo_hip_solve_async")
+
     def synchronize(self):
         self._check(self.lib.corbo_hip_synchronize(self._h), "corbo_hip_synchronize")
 

@@ -421,6 +421,13 @@ int corbo_hip_closed_loop(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int
  * that rejects 64 trial steps in a row is cut (the reference would keep multiplying the damping); such an instance finishes with
  * status CORBO_HIP_SOLVER_ERROR and is counted in corbo_hip_stats.inner_loop_cuts. */
 int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
+/* The same solve WITHOUT the wait (round 4): everything is enqueued on the handle's stream and the call returns, so the host side of the next solve --
+ * re-arm / warm start, the launch -- overlaps this one's kernel (the reference has no counterpart: LevenbergMarquardtSparse::solve is a blocking call;
+ * a caller that streams batch after batch through one handle uses this).  Handles that solve in one launch (run to completion: the small-block families
+ * up to 256 grid points); every other handle solves synchronously like corbo_hip_solve.  Results, statistics, the HIP-event times of corbo_hip_get_timing
+ * and the pass-limit check of the enqueued solves become available with the next corbo_hip_synchronize / corbo_hip_solve / corbo_hip_get_* /
+ * corbo_hip_fetch_solution call (an error of an enqueued solve is reported there). */
+int corbo_hip_solve_async(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
 
 /* Block until the handle's stream is idle. */
 int corbo_hip_synchronize(corbo_hip_handle h);

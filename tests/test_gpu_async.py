@@ -1,0 +1,82 @@
+"""corbo_hip_solve_async (-m gpu): the solve without the wait.  Enqueued back to back on one handle the solves give what the synchronous calls give;
+timing and the pass-limit check of the enqueued solves arrive with the next synchronising call; handles whose passes are driven from the host solve
+synchronously inside the same entry point."""
+import numpy as np
+import pytest
+
+from control_box_rst_amd import problems
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt, CorboHipError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+
+
+def _solver(B=48, N=40):
+    d = problems.unicycle_desc(N=N)
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    return s
+
+
+@pytest.mark.parametrize("sink", [False, True])
+def test_enqueued_solves_match_synchronous_ones(sink):
+    s = _solver()
+    s.set_result_sink(sink)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    st = s.get_stats()
+    s.get_timing(reset=True)
+    for _ in range(5):                       # five steps enqueued back to back, one wait
+        s.restore_instance_data()
+        s.solve_async()
+    s.synchronize()
+    ms, n = s.get_timing(reset=True)
+    assert n == 5 and ms > 0                 # every enqueued solve was timed by its own HIP event pair
+    Xv, cv, sv = s.fetch_solution()
+    X2, chi22, status2 = s.get_solution()
+    assert np.array_equal(X, X2) and np.array_equal(chi2, chi22) and np.array_equal(status, status2)
+    assert np.array_equal(np.asarray(cv), chi2)
+    st2 = s.get_stats()
+    for k in ("lm_iterations", "accepted_steps", "rejected_steps", "factorizations"):
+        assert st[k] == st2[k], k
+    s.restore_instance_data()
+    s.solve_async()                          # a synchronous call behind an enqueued one waits for it first
+    s.restore_instance_data()
+    s.solve()
+    X3, _, _ = s.get_solution()
+    assert np.array_equal(X, X3)
+
+
+def test_pass_limit_of_an_enqueued_solve_is_reported_by_the_next_wait():
+    s = _solver()
+    s.set_option("pass_limit", 3)
+    s.solve_async()                          # returns at once: nothing has been checked yet
+    with pytest.raises(CorboHipError, match="pass limit"):
+        s.synchronize()
+    s.set_option("pass_limit", 0)
+    s.restore_instance_data()
+    s.solve()                                # the handle is usable again
+    assert (s.get_solution()[2] <= 1).all()
+
+
+def test_host_driven_handles_solve_synchronously():
+    d = problems.quad_desc(N=24)
+    x0, xf = problems.quad_instances(4)
+    s = BatchedLevenbergMarquardt(d, 4)
+    s.setPenaltyWeights(*problems.QUAD_WEIGHTS)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    s.solve()
+    X, chi2, _ = s.get_solution()
+    s.restore_instance_data()
+    s.solve_async()                          # big-block family: passes driven from the host -> a plain solve
+    X2, chi22, _ = s.get_solution()
+    assert np.array_equal(X, X2) and np.array_equal(chi2, chi22)
