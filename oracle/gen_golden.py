@@ -511,8 +511,76 @@ def usermodel():
         json.dump(d, f, separators=(",", ":"))
 
 
+FUZZ_SEEDS = (23091,)   # tests/test_gpu_fuzz.py::test_random_descriptor_vs_oracle seeds whose device result needed the 48-trial spread (stage 2)
+
+
+def fuzzseed():
+    """Randomized-start cases of the fuzz suite pinned to the reference: the seed's descriptor, weights and noisy start re-drawn exactly as
+    tests/test_gpu_fuzz.py draws them, handed to the reference through ref_driver's start= (its parameter vector) -- every instance of the seed."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as F
+    from control_box_rst_amd import capi
+    from control_box_rst_amd.solver import init_trajectory
+    for seed in FUZZ_SEEDS:
+        rng = np.random.default_rng(1000 + seed)
+        fam, d = F.random_desc(rng, long_horizon=(seed >= 10000))
+        assert fam == "unicycle" and d.grid == capi.GRID_MS and d.xf_fixed_mask == 0, "fuzzseed: only what ref_driver's start= covers"
+        B = 3
+        w = tuple(float(v) for v in rng.uniform(1.0, 50.0, 3))
+        x0 = rng.uniform(-1, 1, (B, d.nx))
+        xf = rng.uniform(-1, 1, (B, d.nx)) + np.array([1.5, 0.5, 0.2, 0.0])[: d.nx]
+        X0 = init_trajectory(d, x0, xf)
+        X0 = X0 + 0.05 * rng.normal(size=X0.shape)
+        X0[:, : d.nx] = x0
+        inf = lambda v: ("inf" if v > 0 else "-inf") if abs(v) >= 1e30 else repr(float(v))   # noqa: E731
+        for b in range(B):
+            with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+                f.write(" ".join(repr(float(v)) for v in X0[b, d.nx:]))   # active parameters: everything behind the fixed x_0
+            kv = dict(scenario="unicycle", grid="ms", N=d.N, dt=repr(float(d.dt_ref)), iters=3, w=vec(w), x0=vec(x0[b]), xf=vec(xf[b]),
+                      qdiag=vec(list(d.q_diag)[:3]), rdiag=vec(list(d.r_diag)[:2]), qfdiag=vec(list(d.qf_diag)[:3]), final_cost=int(d.final_cost),
+                      xlb=",".join(inf(v) for v in list(d.x_lb)[:3]), xub=",".join(inf(v) for v in list(d.x_ub)[:3]),
+                      ulb=",".join(inf(v) for v in list(d.u_lb)[:2]), uub=",".join(inf(v) for v in list(d.u_ub)[:2]), start=f.name)
+            if d.stage_ineq == capi.INEQ_BALL:
+                kv["ball"] = vec(list(d.ineq_params)[:4])
+            else:
+                kv["noball"] = 1
+            if d.final_ineq == capi.FINAL_INEQ_TERMINAL_BALL:
+                kv["tball"] = repr(float(d.final_ineq_params[3]))
+                kv["tball_s"] = vec(list(d.final_ineq_params)[:3])
+            if d.final_eq:
+                kv["teq"] = 1
+            g = slim(run("dump", **kv), (1, 2, 3))
+            os.unlink(f.name)
+            g["fuzz_seed"], g["fuzz_instance"] = seed, b
+            # the reference's own reproducibility on this case: the same solve from starts ONE ulp away (one component each, spread over the
+            # horizon) -- how far its third iterate moves, per perturbed start (heavy-tailed: most starts stay close, a few jump)
+            base, base_chi2 = np.array(g["after_iter"][-1]["vertex"]), g["after_iter"][-1]["chi2"]
+            n_act = X0.shape[1] - d.nx
+            ulp_dx, ulp_dchi2 = [], []
+            for j in range(64):
+                xs = X0[b, d.nx:].copy()
+                c = (j * 97) % n_act
+                xs[c] = np.nextafter(xs[c], 10.0)
+                with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f2:
+                    f2.write(" ".join(repr(float(v)) for v in xs))
+                last = run("dump", **dict(kv, start=f2.name))["after_iter"][-1]
+                os.unlink(f2.name)
+                ulp_dx.append(float(np.abs(np.array(last["vertex"]) - base).max()))
+                ulp_dchi2.append(float(abs(last["chi2"] - base_chi2) / abs(base_chi2)))
+            g["ulp_dx"], g["ulp_dchi2"] = ulp_dx, ulp_dchi2
+            assert np.array_equal(np.array(g["vertex_init"])[: X0.shape[1]], X0[b]), "the reference did not start where the fuzz test starts"
+            name = f"fuzz_{seed}_b{b}"
+            with open(os.path.join(OUT, f"{name}.json"), "w") as fo:
+                json.dump(g, fo, separators=(",", ":"))
+            print(name, {k: g[k] for k in ("n", "m", "nnz")}, "chi2", [a["chi2"] for a in g["after_iter"]],
+                  "own one-ulp spread: x median %.2e max %.2e, chi2 max %.2e" % (np.median(ulp_dx), max(ulp_dx), max(ulp_dchi2)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "fuzzseed":
+        return fuzzseed()
     if len(sys.argv) > 1 and sys.argv[1] == "pteq":
         return pteq()
     if len(sys.argv) > 1 and sys.argv[1] == "xe":

@@ -283,6 +283,10 @@ struct Scenario
     // xf; uref=<csv>: a static non-zero control reference (StaticReference) instead of ZeroReference
     bool xref_traj = false;
     Eigen::VectorXd uref;
+    // qdiag= / rdiag= / qfdiag= (unicycle): diagonal weights instead of the scenario's; start=<file>: the parameter vector (the hypergraph's
+    // active parameters, in its order) the solve starts from instead of the grid's straight-line initial guess -- see startFrom() below
+    Eigen::VectorXd qdiag, rdiag, qfdiag;
+    std::string start;
 };
 
 // the reference's other benchmark systems (nonlinear_benchmark_systems.h), default parameters: nx = 2 except the rocket (3) and the cart-pole (4)
@@ -540,8 +544,11 @@ static Built build(const Scenario& s, int iterations)
     {
         Eigen::MatrixXd Q = Eigen::Vector3d(1, 1, 0.1).asDiagonal();
         Eigen::MatrixXd R = Eigen::Vector2d(0.1, 0.05).asDiagonal();
+        if (s.qdiag.size() == 3) Q = s.qdiag.asDiagonal();
+        if (s.rdiag.size() == 2) R = s.rdiag.asDiagonal();
         if (s.fullq) { Q = fullWeight(Q); R = fullWeight(R); }
         Eigen::MatrixXd Qf = 10.0 * Q;
+        if (s.qfdiag.size() == 3) Qf = s.qfdiag.asDiagonal();
         s.Qfull = Q; s.Rfull = R; s.Qffull = Qf;
         b.ocp->setStageCost(std::make_shared<QuadraticFormCost>(Q, R, !s.integral.empty(), !s.nonlsq));
         b.ocp->setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !s.nonlsq));
@@ -732,6 +739,37 @@ static bool run(Built& b, const Scenario& s, int solves, double* solve_seconds =
     return ok;
 }
 
+// start=<file>: the OCP as it stands after a 0-iteration compute() (graph built, straight-line guess in the vertices), its active parameters
+// overwritten with the file's values (OptimizationProblemInterface::setParameterVector); the LM iterations then run in a second compute()
+// with new_run = false, which keeps the vertices (full_discretization_grid_base.cpp:83-108; the shooting grids need their warm-start flag for that, shooting_grid_base.cpp:85).
+// Pins randomized-start cases (tests/test_gpu_fuzz.py seeds) to the reference itself.
+static Built buildStarted(const Scenario& s, int iterations, bool* ok = nullptr)
+{
+    Built b = build(s, s.start.empty() ? iterations : 0);
+    bool r  = b.ocp->compute(s.x0, *b.xref, *b.uref, nullptr, Time(0), true);
+    if (!s.start.empty())
+    {
+        const int n = b.hg->getParameterDimension();
+        Eigen::VectorXd p(n);
+        FILE* f = fopen(s.start.c_str(), "r");
+        if (!f) { fprintf(stderr, "cannot open %s\n", s.start.c_str()); exit(4); }
+        for (int i = 0; i < n; ++i)
+            if (fscanf(f, "%lf", &p[i]) != 1) { fprintf(stderr, "start: %d values expected\n", n); exit(4); }
+        fclose(f);
+        b.hg->setParameterVector(p);
+        b.any_grid->setModified(true);   // the solver analyses the sparsity pattern inside its first iteration only (levenberg_marquardt_sparse.cpp:121): the 0-iteration
+                                         // solve left that undone, so the second compute() has to see a new structure (edges re-created, vertices kept)
+        if (b.ms_grid) b.ms_grid->setWarmStart(true);   // (shooting_grid_base.cpp:85-96: without it every update() re-initialises the sequences)
+        if (iterations > 0)
+        {
+            b.solver->setIterations(iterations);
+            r = b.ocp->compute(s.x0, *b.xref, *b.uref, nullptr, Time(0), false);
+        }
+    }
+    if (ok) *ok = r;
+    return b;
+}
+
 static void printVec(const char* key, const Eigen::VectorXd& v, bool comma = true)
 {
     printf("\"%s\": [", key);
@@ -908,6 +946,10 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("teq_mask")) s.teq_mask = atoi(kv["teq_mask"].c_str());
     if (kv.count("xref_traj")) s.xref_traj = atoi(kv["xref_traj"].c_str()) != 0;
     if (kv.count("uref")) s.uref = vec(kv["uref"]);
+    if (kv.count("qdiag")) s.qdiag = vec(kv["qdiag"]);
+    if (kv.count("rdiag")) s.rdiag = vec(kv["rdiag"]);
+    if (kv.count("qfdiag")) s.qfdiag = vec(kv["qfdiag"]);
+    if (kv.count("start")) s.start = kv["start"];
     if (kv.count("vargrid")) s.vargrid = atoi(kv["vargrid"].c_str()) != 0;
     if (kv.count("cost")) s.cost = kv["cost"];
     if (kv.count("last_n")) s.last_n = atoi(kv["last_n"].c_str());
@@ -967,6 +1009,10 @@ static int dump(const Scenario& s)
     if (s.xub.size()) printVec("xub", s.xub);
     if (s.ulb.size()) printVec("ulb", s.ulb);
     if (s.uub.size()) printVec("uub", s.uub);
+    if (s.qdiag.size()) printVec("qdiag", s.qdiag);
+    if (s.rdiag.size()) printVec("rdiag", s.rdiag);
+    if (s.qfdiag.size()) printVec("qfdiag", s.qfdiag);
+    if (!s.start.empty()) printf("\"start\": 1,\n");
     if (s.xf_fixed >= 0) printf("\"xf_fixed\": %d,\n", s.xf_fixed);
     if (s.final_cost >= 0) printf("\"final_cost\": %d,\n", s.final_cost);
     printVec("x0", s.x0);
@@ -979,8 +1025,7 @@ static int dump(const Scenario& s)
 
     // ---- hot-path pieces at the initial point: LM with 0 iterations builds the graph, evaluates once and returns
     {
-        Built b = build(s, 0);
-        run(b, s, 1);
+        Built b = buildStarted(s, 0);
         auto& hg = *b.hg;
         int n = hg.getParameterDimension(), lsq = hg.getLsqObjectiveDimension(), eq = hg.getEqualityDimension(), ineq = hg.getInequalityDimension(),
             nb = hg.finiteCombinedBoundsDimension();
@@ -1045,8 +1090,9 @@ static int dump(const Scenario& s)
     printf("\"after_iter\": [\n");
     for (int k = 1; k <= s.iters; ++k)
     {
-        Built b = build(s, k);
-        bool ok = run(b, s, s.solves);
+        bool ok = true;
+        Built b = s.start.empty() ? build(s, k) : buildStarted(s, k, &ok);
+        if (s.start.empty()) ok = run(b, s, s.solves);
         printf("{\"k\": %d, \"ok\": %d, \"chi2\": %.17g, ", k, ok ? 1 : 0, b.ocp->getCurrentObjectiveValue());
         printVec("vertex", vertexValues(b, s), false);
         printf("}%s\n", k < s.iters ? "," : "");

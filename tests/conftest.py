@@ -115,6 +115,9 @@ def desc_for(g):
         for i, v in enumerate(g["q_sqrt"]): d.q_sqrt[i] = v
         for i, v in enumerate(g["qf_sqrt"]): d.qf_sqrt[i] = v
         for i, v in enumerate(g.get("r_sqrt", [])): d.r_sqrt[i] = v
+    for key, arr in (("qdiag", "q_diag"), ("rdiag", "r_diag"), ("qfdiag", "qf_diag")):   # diagonal weights other than the scenario's (fuzz_* fixtures)
+        for i, v in enumerate(g.get(key, [])):
+            getattr(d, arr)[i] = v
     if g.get("noball"):         # quad / pquad without the keep-out ball their scenarios carry by default
         d.stage_ineq = capi.INEQ_NONE
     if "ball" in g:             # BallKeepOut stage inequality

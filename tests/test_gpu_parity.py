@@ -55,7 +55,9 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation takes these
         "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
-        "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq"]
+        "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq",
+        # seed 23091 of the randomized suite (tests/test_gpu_fuzz.py), every instance, solved by the REFERENCE from the same noisy start
+        "fuzz_23091_b0", "fuzz_23091_b1", "fuzz_23091_b2"]
 # reduced cfg 5 (quadrotor): soft directions (thrust / rate / torque components, cost weights 0.01 .. 0.1) -- the reference run twice
 # with x0 one ulp apart differs by 5e-5 .. 1.1e-4 there while chi2 agrees to 1e-9 (tests/test_oracle_fullsize.py demonstrates it on the
 # reference itself; tests/test_gpu_fullsize.py bounds the stiff part by 1e-6): 3 x that reproducibility
@@ -95,15 +97,22 @@ def test_lm_iterates_vs_reference_golden(name):
         s = BatchedLevenbergMarquardt(d, 1)
         s.setIterations(a["k"])
         s.setPenaltyWeights(*g["weights"])
-        s.set_instance_data(s.init_trajectory(g["x0"], g["xf"]), xref=np.array(g["xf"])[None, :])
+        start = np.array(g["vertex_init"])[None, : s.dims.nv] if g.get("start") else s.init_trajectory(g["x0"], g["xf"])   # (fuzz_* fixtures: a given start)
+        s.set_instance_data(start, xref=np.array(g["xf"])[None, :])
         for i in range(g["solves"]):
             s.solve(new_run=(i == 0))
         x, chi2, status = s.get_solution()
         ref = np.array(a["vertex"])[: s.dims.nv]
-        assert np.abs(x[0] - ref).max() <= X_TOL_BY.get(name, X_TOL), (name, a["k"], np.abs(x[0] - ref).max())
+        xtol, ctol = X_TOL_BY.get(name, X_TOL), CHI2_RTOL_BY.get(name, CHI2_RTOL)
+        if "ulp_dx" in g and a is g["after_iter"][-1]:
+            # fuzz_* fixtures carry the REFERENCE's own reproducibility at its last iterate: 64 runs of the reference from starts one ulp away
+            # (oracle/gen_golden.py fuzzseed).  fuzz_23091_b2: median 4e-8, but one of the 64 lands 5.888e-5 away (chi2 2.0e-4) -- the third
+            # iteration takes chi2 from 5292 to 469 and has two outcomes at rounding level; the device takes that other one (5.888e-5, chi2 2.04e-4).
+            xtol, ctol = max(xtol, 1.5 * max(g["ulp_dx"])), max(ctol, 1.5 * max(g["ulp_dchi2"]))
+        assert np.abs(x[0] - ref).max() <= xtol, (name, a["k"], np.abs(x[0] - ref).max())
         if name == "quad_n10":   # flat directions: chi2 carries the comparison
             assert abs(chi2[0] - a["chi2"]) <= 1e-7 * abs(a["chi2"]), (name, a["k"])
-        assert abs(chi2[0] - a["chi2"]) <= CHI2_RTOL_BY.get(name, CHI2_RTOL) * max(1.0, abs(a["chi2"])), (name, a["k"])
+        assert abs(chi2[0] - a["chi2"]) <= ctol * max(1.0, abs(a["chi2"])), (name, a["k"])
         assert status[0] in (capi.SOLVER_CONVERGED, capi.SOLVER_EARLY_TERMINATED)
         st = s.get_stats()
         assert st["lm_iterations"] == a["k"]
