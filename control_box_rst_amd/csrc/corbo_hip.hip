@@ -232,6 +232,7 @@ struct corbo_hip_solver {
         p.xedges = d_xedges; p.n_xedges = (int32_t)S.xedges.size(); p.eq_stride = S.eq_stride; p.eq_defect_off = S.eq_defect_off;
         p.xparams = d_xparams; p.uprev = d_uprev;
         p.mp.wdense = d_wdense; p.mp.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
+        p.mp.fin_eq_mask = S.desc.final_eq ? (int32_t)S.desc.final_eq_mask : 0;
         p.fin_row = S.fin_row;
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
         p.dt_fixed = S.desc.dt_ref;
@@ -334,7 +335,6 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         if (!device_kernels_exist(*desc) || factor_lds_bytes(*desc, fp) == 0 || (!big && S.N > 256 && factor_work_doubles(*desc) == 0)) {
             return fail(CORBO_HIP_ERR_UNSUPPORTED, "no device kernel for this (nx, nu, N, dynamics) yet");
         }
-        if (!big && S.N > 256 && desc->weights_dense) return fail(CORBO_HIP_ERR_UNSUPPORTED, "non-diagonal weights on a horizon beyond 256 grid points: not built");
     }
     h->batch  = batch;
     h->active = batch;
@@ -1580,7 +1580,6 @@ struct DevBuf {   // scratch device buffer of one call
 int corbo_hip_hessian_nnz(const corbo_hip_problem_desc* desc, int lower_part_only, int32_t* nnz_out)
 try {
     if (!desc || !nnz_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
-    if (desc->final_eq_mask) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with a partial terminal equality constraint: not built");
     if (desc->stage_ineq_integral || desc->stage_eq || desc->ctrl_dev) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with integral-form constraints / a control-deviation term: not built");
     Structure S;
     std::string err = build_structure(*desc, S);
@@ -1614,7 +1613,6 @@ ABI_CATCH
 static int hessian_common(corbo_hip_handle h, const HessianStructure*& Hout, bool lower, HessParams& hp)
 {
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
-    if (h->S.desc.final_eq_mask) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with a partial terminal equality constraint: not built");
     if (h->S.has_extra()) return fail(CORBO_HIP_ERR_UNSUPPORTED, "Hessian-path operators with integral-form constraints / a control-deviation term: not built");
     auto& c = h->hess_cache[lower ? 1 : 0];
     if (!c.valid) {   // once per (handle, lower): the walk over the edges and its two device tables

@@ -142,6 +142,7 @@ __device__ __forceinline__ void diagonal_rows(double xv, double w, double ref, d
     bent = (((xv > up) ? 1.0 : 0.0) - ((xv < lo) ? 1.0 : 0.0)) * w_b;
 }
 
+constexpr int SWEEP_ROLE_TABLE = 2 * CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NU;   // doubles: [sq | sr] [sqf] [xref], see sweep_body
 #define SWEEP_STAMP(id)                                                     \
     do {                                                                    \
         if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); \
@@ -153,12 +154,18 @@ __device__ __forceinline__ void diagonal_rows(double xv, double w, double ref, d
 // a full block of FOUR columns added pairwise (the order LinearDynamics restates for f = A x + B u, measured against the compiled
 // reference).  U: row-major [dim][dim] with its explicit zeros below the diagonal -- they take part in the sum like in the reference.
 // xd: the vertex's differences x_j - ref_j (ref = 0 for controls), xd[c] possibly replaced by a perturbed value (finite differences).
+// THREE columns into a destination that starts on an odd row of the solver's residual vector (8 bytes past a 16-byte boundary): the kernel skips
+// column 0 to line its packets up, runs columns 1, 2 and adds column 0 last (GeneralMatrixVector.h, skipColumns; alignmentStep = 1 for an odd
+// leading dimension) -- `odd`; finite-difference temporaries start aligned.  Pinned bit for bit by unicycle_n300_fullq (150 odd stages).
 template <int DM>
-__device__ __forceinline__ double dense_weight_row(const double* U, int c, int dim, const double (&xd)[DM])
+__device__ __forceinline__ double dense_weight_row(const double* U, int c, int dim, const double (&xd)[DM], bool odd = false)
 {
     double u[DM];
 #pragma unroll
     for (int j = 0; j < DM; ++j) u[j] = (j < dim) ? U[c * dim + j] : 0.0;
+    if (dim == 3 && odd) {
+        if constexpr (DM >= 3) return ((0.0 + u[1] * xd[1]) + u[2] * xd[2]) + u[0] * xd[0];
+    }
     if (dim == 4) {
         if constexpr (DM >= 4) return 0.0 + ((u[0] * xd[0] + u[1] * xd[1]) + (u[2] * xd[2] + u[3] * xd[3]));
     }
@@ -218,7 +225,7 @@ __device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc
 
 // XE: the descriptor has integral-form constraint edges / control-deviation edges (SweepParams::xedges): one lane per such edge evaluates it
 // generically (values before the chi2 reduction, central-difference blocks with the other Jacobian entries).  Stand-alone kernels only.
-template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS, bool XE = false>
+template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS, bool XE = false, bool NOJAC = false>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false,
                                            StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr)
 {
@@ -280,6 +287,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     double xr[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xr[i] = p.refvec ? p.refvec[xo + (size_t)(p.N - 1) * S + i] : p.xref[(size_t)inst * CORBO_HIP_MAX_NX + i];
+    // big models (stand-alone kernel): weight and reference of a component by its slot, in LDS in front of the LM state.  Selecting them out of the
+    // kernel arguments costs a compare / select chain over NX entries per component, and the 40 scalars it runs over do not fit the scalar
+    // register file next to everything else (the compiler parked them in vector-register lanes: 719 v_readlane in the component phase of the
+    // quadrotor's kernel, 600 instructions per component -- measured: 33 k of the 52 k cycles of a residual evaluation)
+    constexpr bool ROLE_TAB = (NX > 4) && !FUSED;
+    double* const role = reinterpret_cast<double*>(st) - SWEEP_ROLE_TABLE;   // [0, S): sqrt(Q_ii) | sqrt(R_jj); [S, S + NX): sqrt(Qf_ii); [S + NX, S + 2 NX): xref
+    if constexpr (ROLE_TAB) {
+        if (tid < S) role[tid] = (tid < NX) ? p.mp.sq[tid < NX ? tid : 0] : p.mp.sr[tid < NX ? 0 : tid - NX];
+        if (tid < NX) { role[S + tid] = p.mp.sqf[tid]; role[S + NX + tid] = p.refvec ? p.refvec[xo + (size_t)(p.N - 1) * S + tid] : p.xref[(size_t)inst * CORBO_HIP_MAX_NX + tid]; }
+    }
     lds_barrier();
     SWEEP_STAMP(1);
     // ---- stacked residual (LevenbergMarquardtSparse::computeValues, :222-246)
@@ -297,7 +314,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     // without a reference (control cost, dt cost) use ref = 0: w * (x - 0) is w * x exactly.
     // residual entries: streaming stores in the stand-alone kernel (consumed by a later launch), normal ones in the fused kernel
     auto put_value = [&](int row, double val) {
-        if constexpr (FUSED) vout[row] = val;
+        if constexpr (FUSED || NX > 4) vout[row] = val;
         else __builtin_nontemporal_store(val, &vout[row]);
     };
     constexpr int DM = (NX > NU) ? NX : NU;
@@ -322,6 +339,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         const bool is_u   = !is_dt && !is_fin && cs_ >= NX;
         const int cu      = cs_ - NX;
         double wq = 0.0, wf = 0.0, wr = 0.0, rf = 0.0;
+        if constexpr (ROLE_TAB) {   // (the same numbers, read by slot)
+            const int sl_ = is_dt ? 0 : cs_, sx_ = (is_dt || is_u) ? 0 : cs_;
+            wq = wr = role[sl_];
+            wf = role[S + sx_];
+            rf = role[S + NX + sx_];
+        }
+        else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const bool hit = (cs_ == i);
@@ -331,6 +355,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) wr = (cu == i) ? p.mp.sr[i] : wr;
+        }
         w   = is_dt ? p.mp.dt_weight : (is_fin ? wf : (is_u ? wr : wq));
         ref = (is_dt || is_u) ? 0.0 : rf;
         // time-varying state references (ReferenceTrajectoryInterface::getReferenceCached(k), quadratic_cost.cpp:100-119): one per component.
@@ -404,7 +429,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 if (cls < 3 && ((wdm >> cls) & 1)) {
                     double xd[DM];
                     vertex_diffs(v, c, dim, cls, xd);
-                    val = dense_weight_row<DM>(p.mp.wdense + 16 * cls, c, dim, xd);
+                    val = dense_weight_row<DM>(p.mp.wdense + 16 * cls, c, dim, xd, ((ci.cost_row - c) & 1) != 0);   // (the edge's first row)
                 }
             }
             put_value(ci.cost_row, val);
@@ -593,8 +618,24 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 if (w3 < vend) comp_values(w3, ca3, cb3, l3, u3);
                 for (int v = w3 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
             }
-            else
-                for (int v = v1 + cstr; v < vend; v += cstr) comp_values(v, comp4[2 * v], comp4[2 * v + 1], p.lb[xo + v], p.ub[xo + v]);
+            else {
+                // later rounds four at a time: all descriptors and bounds of the four requested first, then the arithmetic and the stores -- a round
+                // that fetches as it goes waits for the previous round's store acknowledgements with its loads (one memory round trip per round:
+                // 2.3 k cycles each, 11 such rounds on the 12-state quadrotor with N = 200, measured with the phase stamps)
+                for (int v = v1 + cstr; v < vend; v += 4 * cstr) {
+                    int4 qa[4], qb[4];
+                    double ql[4], qu[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int vr = v + r * cstr;
+                        const int vc = (vr < vend) ? vr : v;   // (clamped: an absent round re-reads the first one and is skipped below)
+                        qa[r] = comp4[2 * vc]; qb[r] = comp4[2 * vc + 1]; ql[r] = p.lb[xo + vc]; qu[r] = p.ub[xo + vc];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (v + r * cstr < vend) comp_values(v + r * cstr, qa[r], qb[r], ql[r], qu[r]);
+                }
+            }
         }
     }
     SWEEP_STAMP(9);
@@ -765,6 +806,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         if (keep && do_jac) *keep = kt;   // the residual just evaluated pairs with the Jacobian about to be written (like LmState::vbuf ^= 1)
     }
     if (!do_jac || (p.skip_jac && mode >= 2)) return;
+    if constexpr (NOJAC) return;   // residual-only instantiation (big-block family inside the LM loop: the Jacobian is big_stage_kernel's): no Jacobian code, a quarter of the registers
 
     // ---- combined sparse Jacobian (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753),
     //      central differences exactly as BaseEdge::computeJacobian (edge_interface.cpp:55-96):
@@ -1106,7 +1148,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
 }
 
-template <int DYN, int DEFECT, bool DENSE = false, bool LONG = false, bool XE = false>
+template <int DYN, int DEFECT, bool DENSE = false, bool LONG = false, bool XE = false, bool NOJAC = false>
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1114,10 +1156,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(const SweepParams 
     double* red = smem + p.nvs;
     double* cs  = red + 10;
     double* jst = cs + ((p.N * Dynamics<DYN>::NC + 1) & ~1);  // Jacobian staging (16-byte aligned; unused by big models)
-    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 4 && !LONG) ? p.nnz_pad : 0));
+    LmState* sl = reinterpret_cast<LmState*>(jst + ((p.nx <= 4 && !LONG) ? p.nnz_pad : 0) + (Dynamics<DYN>::NX > 4 ? SWEEP_ROLE_TABLE : 0));   // (big models: the role table in front of it)
     const int inst = blockIdx.x + p.inst0;
     if (p.st) { lm_state_in(sl, p.st + inst, threadIdx.x); __syncthreads(); }
-    sweep_body<DYN, DEFECT, false, DENSE, LONG, SWEEP_THREADS, XE>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
+    sweep_body<DYN, DEFECT, false, DENSE, LONG, SWEEP_THREADS, XE, NOJAC>(p, p.mode, p.active_count, sl, xs, red, cs, jst, inst, threadIdx.x);
     if (p.st && p.mode >= 2) { __syncthreads(); lm_state_out(p.st + inst, sl, threadIdx.x); }
 }
 
@@ -2179,14 +2221,14 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 }
 
 // long horizons: the same phases with the workspace in HBM (FactorParams::work), one lane per stage in a 1024-thread workgroup
-template <int NX, int NU, bool ARROW>
+template <int NX, int NU, bool ARROW, bool DENSE = false>
 __global__ __launch_bounds__(1024) void factor_long_kernel(const FactorParams p)
 {
     __shared__ __attribute__((aligned(16))) LmState sl_;
     const int inst = blockIdx.x + p.inst0;
     lm_state_in(&sl_, p.st + inst, threadIdx.x);
     __syncthreads();
-    factor_body<NX, NU, 1024, ARROW, 0, false, true>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
+    factor_body<NX, NU, 1024, ARROW, 0, DENSE, true>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
     __syncthreads();
     lm_state_out(p.st + inst, &sl_, threadIdx.x);
 }
@@ -4086,8 +4128,9 @@ template <int DYN, int DEFECT>
 void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 {
     if constexpr (Dynamics<DYN>::NX <= 4) {
-        if (p.N > LONG_HORIZON) {   // long horizon: Jacobian straight to HBM (non-diagonal weights are refused for those at create time)
-            hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+        if (p.N > LONG_HORIZON) {   // long horizon: Jacobian straight to HBM
+            if (p.mp.wdense) hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+            else hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
         }
         if constexpr (DEFECT != CORBO_HIP_DEFECT_RK4_SHOOTING && DEFECT != DEFECT_SHOOTING_HIGH) {
@@ -4098,6 +4141,12 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
         }
         if (p.mp.wdense) {   // non-diagonal weights: the DENSE instantiation
             hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+            return;
+        }
+    }
+    if constexpr (Dynamics<DYN>::NX > 4) {
+        if (p.mode == 0 || (p.skip_jac && p.mode >= 2)) {   // no Jacobian due in this launch, whatever the decision: the residual-only instantiation
+            hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
         }
     }
@@ -4302,13 +4351,19 @@ struct HessEdge {
                 if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
                 break;
             case EK_FINAL_EQ:
-                for (int i = 0; i < NX; ++i) out[i] = xl[i] - xr[i];
+                if (NX <= 4 && mp.fin_eq_mask) {   // (the descriptor gate admits it for nx <= 4, structure.cpp) TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): the active components only, in order
+                    int idx = 0;
+                    for (int i = 0; i < NX; ++i)
+                        if ((mp.fin_eq_mask >> i) & 1) out[idx++] = xl[i] - xr[i];
+                }
+                else
+                    for (int i = 0; i < NX; ++i) out[i] = xl[i] - xr[i];
                 break;
             case EK_FINAL_INEQ: out[0] = terminal_ball<NX>(xl, xr, mp.fin); break;
             default: break;
         }
     }
-    __device__ static int edge_dim(int kind) { return kind == EK_MIXED_JOINT ? NX + 1 : kind == EK_MIXED_EQ ? NX : kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
+    __device__ static int edge_dim(int kind, const ModelParams& mp) { return (NX <= 4 && kind == EK_FINAL_EQ && mp.fin_eq_mask) ? __popc((unsigned)mp.fin_eq_mask) : kind == EK_MIXED_JOINT ? NX + 1 : kind == EK_MIXED_EQ ? NX : kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
     __device__ static int n_verts(int kind) { return (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP || kind >= EK_MIXED_OBJ) ? 4 : kind == EK_INTEGRAL_LEFT ? 3 : 1; }
     __device__ static int vert_off(int kind, int vi) { return (kind >= EK_MIXED_OBJ) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? W - 1 : S) : kind == EK_INTEGRAL_LEFT ? (vi == 0 ? 0 : vi == 1 ? NX : W - 1) : (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
     __device__ static int vert_dim(int kind, int vi)
@@ -4323,7 +4378,7 @@ struct HessEdge {
     __device__ static void jacobian(int kind, int vi, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double* blk)
     {
         constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
-        const int off = vert_off(kind, vi), dim = vert_dim(kind, vi), ed = edge_dim(kind);
+        const int off = vert_off(kind, vi), dim = vert_dim(kind, vi), ed = edge_dim(kind, mp);
         double v1[MAXE], v2[MAXE];
         int col = 0;
         for (int i = 0; i < dim; ++i) {
@@ -4347,7 +4402,7 @@ struct HessEdge {
                                          const double* mult, double* out, double* out2, double* out3, int vi_only = -1, int vj_only = -1)
     {
         constexpr double hdelta = 1e-2;
-        const int ed = edge_dim(kind), nv = n_verts(kind);
+        const int ed = edge_dim(kind, mp), nv = n_verts(kind);
         const int nparts = (cat == 4) ? 2 : 1;
         double jac1[MAXE * MAXD], jac2[MAXE * MAXD], blk[MAXD * MAXD];
         int at = 0;
@@ -4419,7 +4474,7 @@ struct HessEdge {
     // the unweighted Jacobian blocks of a constraint edge in the order of computeSparseJacobianTwoSideBoundedLinearFormValues (:4904-4968)
     __device__ static void linear_blocks(int kind, unsigned fm, double* xl, const double* xr, const ModelParams& mp, double* out)
     {
-        const int ed = edge_dim(kind), nv = n_verts(kind);
+        const int ed = edge_dim(kind, mp), nv = n_verts(kind);
         double blk[MAXD * MAXD];
         int at = 0;
         for (int vi = 0; vi < nv; ++vi) {
@@ -4518,7 +4573,7 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         }
         double obj = 0.0;
         for (int e = 0; e < n_edges; ++e) {
-            const int kind = kinds[e], ed = HE::edge_dim(kind), off = HE::vert_off(kind, 0), dim = HE::vert_dim(kind, 0);
+            const int kind = kinds[e], ed = HE::edge_dim(kind, mpl), off = HE::vert_off(kind, 0), dim = HE::vert_dim(kind, 0);
             double blk[HE::MAXD * HE::MAXD], vals[HE::MAXD];
             const int nu_ = HE::unfixed(fm, off, dim);
             if (kind >= EK_STATE_QCOST) {   // plain objective edge: gradient += the Jacobian's column sums per attached vertex, value += the sum of
@@ -4570,7 +4625,9 @@ __global__ __launch_bounds__(64) void hessian_kernel(const SweepParams p, const 
         if (lo[0] >= 0) {   // computeBoundsForTwoSideBoundedLinearForm: lbA = ubA = -c_eq
             const int kind = final_stage ? EK_FINAL_EQ : (hp.ms_mixed ? EK_MIXED_EQ : EK_DEFECT);   // (mixed edge: computeConstraintJacobians, :4944-4960)
             HE::values(kind, xl, xr, mpl, c);
-            for (int r = 0; r < NX; ++r) { lb[so[4] + r] = c[r] * -1; ub[so[4] + r] = c[r] * -1; }
+            const int ed = HE::edge_dim(kind, mpl);
+            for (int r = 0; r < NX; ++r)
+                if (r < ed) { lb[so[4] + r] = c[r] * -1; ub[so[4] + r] = c[r] * -1; }
             HE::linear_blocks(kind, fm, xl, xr, mpl, lv + lo[0]);
         }
         if (lo[1] >= 0) {   // (-inf, -c_ineq]
@@ -4694,8 +4751,9 @@ bool launch_factor_a(const FactorParams& p, hipStream_t stream)
     if (lds < sizeof(double) * (size_t)p.nnz_pad) lds = sizeof(double) * (size_t)p.nnz_pad;  // Jacobian staging area
     lds = ((lds + 15) & ~(size_t)15) + sizeof(LmState);                                      // + LM state
     if (p.N > LONG_HORIZON) {   // long horizon: workspace in HBM
-        if (p.N > LONG_HORIZON_MAX || p.wdense_mask || !p.work) return false;
-        hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW>), dim3(p.batch), dim3(1024), 0, stream, p);
+        if (p.N > LONG_HORIZON_MAX || !p.work) return false;
+        if (p.wdense_mask) hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW, true>), dim3(p.batch), dim3(1024), 0, stream, p);   // non-diagonal weights
+        else hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW>), dim3(p.batch), dim3(1024), 0, stream, p);
         return true;
     }
     if (p.wdense_mask) {   // non-diagonal weights: the DENSE instantiation
@@ -4999,17 +5057,27 @@ void launch_broadcast_rows(const double* row_a, const double* row_b, double* dst
 // re-arm + solve of one OCP 0.44 ms per step with the copy engine, 0.13 ms with this kernel)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const double2* __restrict__ src, double2* __restrict__ dst, double2* __restrict__ dst2, double2* __restrict__ dst3, size_t n2)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
-        const double2 v = src[i];
-        dst[i] = v;
-        if (dst2) dst2[i] = v;
-        if (dst3) dst3[i] = v;
+    // four elements per lane and round, all four requested before the first store (one element per round left the copy latency-bound:
+    // cfg 5's re-arm, 14 MB into two destinations, 72 us = 0.58 TB/s)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += 4 * stride) {
+        double2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const size_t j = i + r * stride; v[r] = src[j < n2 ? j : i]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t j = i + r * stride;
+            if (j >= n2) break;
+            dst[j] = v[r];
+            if (dst2) dst2[j] = v[r];
+            if (dst3) dst3[j] = v[r];
+        }
     }
 }
 void launch_copy_rows(const double* src, double* dst, double* dst2, size_t doubles, hipStream_t stream, double* dst3)
 {
     const size_t n2 = doubles / 2;   // (row strides are even: 16-byte elements)
-    size_t blocks = (n2 + 255) / 256;
+    size_t blocks = (n2 + 1023) / 1024;   // (four elements per lane)
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst),
@@ -5068,7 +5136,8 @@ size_t sweep_lds_bytes(const SweepParams& p, int nc)
     // four workgroups share a CU (1024 instances = one round over 256 CUs)
     static_assert(LONG_HORIZON == 256, "jacobian_staged_in_lds");
     const size_t stage = jacobian_staged_in_lds(p.nx, p.N) ? (size_t)p.nnz_pad : 0;  // see STAGE in sweep_body
-    return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage) + sizeof(LmState);
+    const size_t role_table = (p.nx > 4) ? SWEEP_ROLE_TABLE : 0;   // big models: weights / reference by slot (sweep_body, comp_role), in front of the LM state
+    return sizeof(double) * ((size_t)p.nvs + 10 + (((size_t)p.N * nc + 1) & ~(size_t)1) + stage + role_table) + sizeof(LmState);
 }
 
 size_t factor_work_doubles(const corbo_hip_problem_desc& d)

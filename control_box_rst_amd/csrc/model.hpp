@@ -21,6 +21,7 @@ struct ModelParams {
     double fin[CORBO_HIP_MAX_NX + 1];  // final-stage inequality: S_11 .. S_nn, gamma (TerminalBall)
     const double* wdense;          // or null: non-diagonal weights, [Uq 16 | Ur 16 | Uqf 16] row-major upper Cholesky factors (corbo_hip_problem_desc::q_sqrt ...)
     int32_t wdense_mask;           // bit 0 Q, bit 1 R, bit 2 Qf are dense (sq / sr / sqf of that class are then unused)
+    int32_t fin_eq_mask;           // TerminalPartialEqualityConstraint: the active components (0 = all of them); read by the Hessian-path edges
 };
 
 #pragma clang fp contract(off)

@@ -76,7 +76,6 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         if (!d.final_eq) return "final_eq_mask without final_eq";
         if (d.nx > 4) return "partial terminal equality constraint: families with nx <= 4";
         if (d.final_eq_mask >> d.nx) return "final_eq_mask has bits beyond nx";
-        if (d.cost_nonlsq) return "partial terminal equality constraint: Levenberg-Marquardt path only";
     }
     if (d.shooting_integrator < 0 || d.shooting_integrator > 7 || d.shooting_integrator == 4) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3), 5 / 6 / 7 (RK5 / RK6 / RK7)";
     if (d.shooting_integrator >= 5 && d.nx > 4) return "shooting_integrator 5 .. 7 (Runge-Kutta 5 - 7): families with nx <= 4";
@@ -435,8 +434,8 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
             H.stage_off[(size_t)(N - 1) * 6 + 4] = eq_row;
             walk(1, &xf, 1);
             H.lin_off[(size_t)(N - 1) * 2 + 0] = (int32_t)H.lin_rows.size();
-            lin_walk(&xf, 1, nx, eq_row);
-            eq_row += nx;
+            lin_walk(&xf, 1, S.fin_eq_dim, eq_row);   // (TerminalPartialEqualityConstraint: its active components' rows)
+            eq_row += S.fin_eq_dim;
         }
         const int eq_mixed0 = eq_row, eq_total = eq_row + (N - 1) * nx;
         for (int k = 0; k < N - 1; ++k) {
@@ -518,8 +517,8 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
         H.stage_off[(size_t)(N - 1) * 6 + 4] = eq_row;
         walk(1, &xf, 1);
         H.lin_off[(size_t)(N - 1) * 2 + 0] = (int32_t)H.lin_rows.size();
-        lin_walk(&xf, 1, nx, eq_row);
-        eq_row += nx;
+        lin_walk(&xf, 1, S.fin_eq_dim, eq_row);
+        eq_row += S.fin_eq_dim;
     }
     // inequalities
     int ineq_row = 0;

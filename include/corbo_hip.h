@@ -191,7 +191,7 @@ typedef struct corbo_hip_problem_desc {
     int32_t shooting_integrator;
     /* TerminalPartialEqualityConstraint (final_state_constraints.h:198-300): with final_eq = 1 and a non-zero mask the equality rows exist for the
      * components whose bit is set only -- row idx = the number of active components before it, x_f[i] - xref[i]; 0 = every component
-     * (TerminalEqualityConstraint).  Levenberg-Marquardt path of the families with nx <= 4. */
+     * (TerminalEqualityConstraint).  Families with nx <= 4, both the Levenberg-Marquardt path and the Hessian-path operators. */
     uint32_t final_eq_mask;
     double q_sqrt[16];
     double r_sqrt[16];

@@ -386,10 +386,15 @@ static void defect_values(const oracle_problem* p, const double* x1, const doubl
  * upper Cholesky factor kept by setWeightQ / setWeightR / setWeightQf (quadratic_cost.cpp:36-55, final_state_cost.cpp:38-58).  Eigen evaluates the
  * dynamic-size product as a column-major gemv into a zeroed destination: one running sum per row over the columns, a full block of FOUR columns
  * added pairwise (the order the linear state-space model's A x + B u is restated in; pinned bit for bit by the *_fullq fixtures). */
-static void dense_weight_times(const double* U, int n, const double* xd, double* out)
+/* ... and with THREE columns the kernel's column order depends on where the destination lies: for a destination that starts 8 bytes past a
+ * 16-byte boundary (an odd row of the solver's residual vector) it skips the first column to line the packets up, runs columns 1, 2 and adds
+ * column 0 last (Eigen/src/Core/products/GeneralMatrixVector.h: skipColumns, with alignmentStep = 1 for an odd leading dimension); pinned bit
+ * for bit by unicycle_n300_fullq (150 odd stages).  `odd` = that case; temporaries (finite differences, Hessian path) start aligned. */
+static void dense_weight_times(const double* U, int n, const double* xd, double* out, int odd)
 {
     for (int i = 0; i < n; ++i) {
         const double* u = U + i * n;
+        if (n == 3 && odd) { out[i] = ((0.0 + u[1] * xd[1]) + u[2] * xd[2]) + u[0] * xd[0]; continue; }
         if (n == 4) { out[i] = 0.0 + ((u[0] * xd[0] + u[1] * xd[1]) + (u[2] * xd[2] + u[3] * xd[3])); continue; }
         double acc = 0.0;
         for (int j = 0; j < n; ++j) acc += u[j] * xd[j];
@@ -411,7 +416,10 @@ static double stage_eq_value(const corbo_hip_problem_desc* d, const double* xk, 
     return acc - d->stage_eq_params[d->nx + d->nu];
 }
 
-static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
+static void edge_values_at(const oracle_problem* p, const o_edge* e, double* out, int odd);
+static void edge_values(const oracle_problem* p, const o_edge* e, double* out) { edge_values_at(p, e, out, 0); }
+/* odd: `out` is an odd row of the solver's residual vector (see dense_weight_times) */
+static void edge_values_at(const oracle_problem* p, const o_edge* e, double* out, int odd)
 {
     const corbo_hip_problem_desc* d = &p->d;
     const double* x = p->x;
@@ -428,7 +436,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             if (d->weights_dense & 1) { /* non-diagonal Q: xd = x_k - xref(k); cost = Q_sqrt * xd */
                 double xd[CORBO_HIP_MAX_NX];
                 for (int i = 0; i < d->nx; ++i) xd[i] = xk[i] - rk[i];
-                dense_weight_times(d->q_sqrt, d->nx, xd, out);
+                dense_weight_times(d->q_sqrt, d->nx, xd, out, odd);
                 break;
             }
             for (int i = 0; i < d->nx; ++i) out[i] = p->sq[i] * (xk[i] - rk[i]);
@@ -443,7 +451,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
                 out[0] = acc;
                 break;
             }
-            if (d->weights_dense & 2) { dense_weight_times(d->r_sqrt, d->nu, uk, out); break; } /* R_sqrt * u_k (quadratic_cost.cpp:148-150) */
+            if (d->weights_dense & 2) { dense_weight_times(d->r_sqrt, d->nu, uk, out, odd); break; } /* R_sqrt * u_k (quadratic_cost.cpp:148-150) */
             for (int i = 0; i < d->nu; ++i) out[i] = p->sr[i] * uk[i];
             break;
         }
@@ -459,7 +467,7 @@ static void edge_values(const oracle_problem* p, const o_edge* e, double* out)
             if (d->weights_dense & 4) { /* Qf_sqrt * xd (final_state_cost.cpp:88-90) */
                 double xd[CORBO_HIP_MAX_NX];
                 for (int i = 0; i < d->nx; ++i) xd[i] = xk[i] - rk[i];
-                dense_weight_times(d->qf_sqrt, d->nx, xd, out);
+                dense_weight_times(d->qf_sqrt, d->nx, xd, out, odd);
                 break;
             }
             for (int i = 0; i < d->nx; ++i) out[i] = p->sqf[i] * (xk[i] - rk[i]);
@@ -1246,7 +1254,7 @@ static void compute_values(oracle_problem* p, double w_eq, double w_ineq, double
     }
     for (int i = 0; i < p->n_edges; ++i) {
         const o_edge* e = &p->e[i];
-        edge_values(p, e, values + e->row);
+        edge_values_at(p, e, values + e->row, e->row & 1);
         if (e->scale == 1)
             for (int j = 0; j < e->dim; ++j) values[e->row + j] *= w_eq;
         else if (e->scale == 2)

@@ -345,6 +345,9 @@ FULLQ = [
     ("cartpole_fullq", dict(scenario="cartpole", N=14, iters=5, fullq=1), (1, 2, 3, 4, 5)),            # nx = 4: Eigen's four-column gemv block
     ("par3_fullq", dict(scenario="par3", iters=5, fullq=1), (1, 2, 3, 4, 5)),                          # nu = 3: dense R
     ("lin33_fullq", dict(scenario='lin', nx=3, nu=3, lin_a='-0.16999999999999998,-0.338,0.807,-0.486,-0.8200000000000001,-0.482,-0.289,-0.99,-0.243', lin_b='-0.435,-0.864,0.234,-0.647,-0.391,-0.118,-0.7,-0.564,-0.051', iters=4, collocation='forward', N=14, fullq=1), (1, 2, 3, 4)),
+    # ... on horizons beyond 256 grid points (the long-horizon kernels' DENSE instantiation: Jacobian and factor workspace in HBM)
+    ("unicycle_n300_fullq", dict(scenario="unicycle", N=300, iters=3, fullq=1), (1, 3)),
+    ("vdp_n400_fullq_ms", dict(scenario="vdp", grid="ms", N=400, iters=3, fullq=1, xf="0.4,0.1"), (1, 3)),
     ("unicycle_n12_fullq_tvref", dict(scenario="unicycle", N=12, iters=5, fullq=1, xref_traj=1), (1, 2, 3, 4, 5)),
 ]
 
@@ -511,6 +514,22 @@ def usermodel():
         json.dump(d, f, separators=(",", ":"))
 
 
+def hesspteq():
+    """Hessian-path operators with a TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): equality rows, multipliers and
+    linear-form rows for the active components of x_f only."""
+    for name, kv in [
+        ("hess_unicycle_pteq", dict(scenario="unicycle", N=10, teq=1, teq_mask=5)),
+        ("hess_cartpole_pteq", dict(scenario="cartpole", N=8, teq=1, teq_mask=6)),
+        ("hess_unicycle_ms_pteq", dict(scenario="unicycle", grid="ms", N=8, teq=1, teq_mask=3)),
+        ("hess_unicycle_ms_integral_pteq", dict(scenario="unicycle", grid="ms", N=6, lsq=0, integral="trap", teq=1, teq_mask=6)),
+        ("hess_pquad_pteq", dict(scenario="pquad", N=5, teq=1, teq_mask=0b100101)),
+    ]:
+        d = run("hess", **kv)
+        with open(os.path.join(OUT, f"{name}.json"), "w") as f:
+            json.dump(d, f, separators=(",", ":"))
+        print(name, d["n"], d.get("eq"), len(d["heq_vals_full"]), os.path.getsize(os.path.join(OUT, f"{name}.json")))
+
+
 FUZZ_SEEDS = (23091,)   # tests/test_gpu_fuzz.py::test_random_descriptor_vs_oracle seeds whose device result needed the 48-trial spread (stage 2)
 
 
@@ -581,6 +600,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "fuzzseed":
         return fuzzseed()
+    if len(sys.argv) > 1 and sys.argv[1] == "hesspteq":
+        return hesspteq()
     if len(sys.argv) > 1 and sys.argv[1] == "pteq":
         return pteq()
     if len(sys.argv) > 1 and sys.argv[1] == "xe":

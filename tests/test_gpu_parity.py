@@ -42,6 +42,7 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "lin21", "lin22", "lin31", "lin32", "lin33", "lin41",
         # NON-DIAGONAL Q / R / Qf (dense cost blocks; these handles run the phases as separate launches)
         "unicycle_n12_fullq", "vdp_fullq", "unicycle_n12_fullq_patterns", "unicycle_n12_fullq_ms", "cartpole_fullq", "par3_fullq", "lin33_fullq",
+        "unicycle_n300_fullq", "vdp_n400_fullq_ms",   # ... beyond 256 grid points (long-horizon kernels, DENSE instantiation)
         # the shooting grids' other integrators: explicit Euler, Runge-Kutta 2 / 3 (explicit_integrators.h:47-213)
         "vdp_ms_euler", "unicycle_n12_ms_rk2", "pendulum_ms_rk3", "cartpole_ms_rk2", "int3_ms_time_optimal_rk2", "quad_n10_rk3", "quad_n10_euler",
         # Runge-Kutta 5 / 6 / 7 on the shooting grids (explicit_integrators.h:327-628)

@@ -18,6 +18,8 @@ HESS = ["hess_kcar", "hess_pquad_n5", "hess_pquad_fd_n5", "hess_unicycle_fullq",
         "hess_unicycle_ms_integral", "hess_unicycle_ms_integral_xf_fixed", "hess_vdp_ms_integral_euler", "hess_vdp_ms_integral_rk3", "hess_unicycle_ms_integral_rk5",
         "hess_unicycle_ms_integral_teq", "hess_unicycle_ms_integral_tball",
         "hess_pquad_ms_integral", "hess_pquad_ms_integral_rk3", "hess_quad_ms_integral",   # the mixed edge around the big-block models (nx = 6, 12)
+        # TerminalPartialEqualityConstraint on the Hessian path: rows / multipliers for the active components of x_f only
+        "hess_unicycle_pteq", "hess_cartpole_pteq", "hess_unicycle_ms_pteq", "hess_unicycle_ms_integral_pteq", "hess_pquad_pteq",
         "hess_dint_mtq_integral_trap", "hess_dint_mtq_integral_left_last4"]   # MinTimeQuadratic in integral form (free dt)   # integral-form cost: one objective edge per interval   # *_nonlsq: plain (non-least-squares) objective edges
 KEYS = ("hobj", "heq", "hineq")
 
