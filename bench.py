@@ -392,7 +392,8 @@ def main():
     # The timed steps are ENQUEUED back to back (corbo_hip_solve_async: the solve without the wait): the host side of step k + 1 -- re-arm, launch --
     # overlaps the kernel of step k, as a caller that streams batch after batch through a handle would run it.  Every step does the same work as the
     # synchronous one (re-arm + every LM pass + the results written into pinned host memory by the kernel); the closing fence waits for all of them.
-    # Handles whose passes are driven from the host (cfg 5) solve synchronously inside solve_async.  --sync-steps: the per-step wait of rounds 1-3.
+    # Handles whose passes are driven from the host (cfg 5) solve synchronously inside solve_async and deliver each step's results with a copy on a
+    # second stream (device-side snapshot first), which overlaps the next step's kernels.  --sync-steps: the per-step wait of rounds 1-3.
     pipelined = use_sink and not args.sync_steps
 
     def step_timed():
@@ -467,7 +468,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations, "solves_per_step": solves,
                    "parallelism": f"batch-sharded x{world}"},
         "timed_region": ("re-arm (D2D) + corbo_hip_solve_async per step, the K steps enqueued back to back (the host side of a step overlaps the previous step's kernel), "
-                         "every step's trajectories/chi2/status written into pinned host memory by the solve kernel as each instance finishes (corbo_hip_set_result_sink); "
+                         "every step's trajectories/chi2/status written into pinned host memory (corbo_hip_set_result_sink): by the solve kernel as each instance finishes, or -- "
+                         "handles whose passes are launched from the host, cfg 5 -- by a copy on a second stream behind a device-side snapshot, overlapping the next step; "
                          "wall clock, barrier + synchronize on both sides, MAX over ranks" if pipelined else
                          "re-arm (D2D) + corbo_hip_solve + trajectories/chi2/status resident in pinned host memory ("
                          + ("written by the solve kernel as each instance finishes, corbo_hip_set_result_sink" if use_sink else "two D2H copies behind the solve")

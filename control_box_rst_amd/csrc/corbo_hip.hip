@@ -183,6 +183,15 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
+    // handles whose passes are launched from the host (big-block family, band route, ...): the results are delivered by a copy instead -- a
+    // device-to-device snapshot behind the last pass (10 us), then snapshot -> pinned host memory on a stream of its own, off the critical path of
+    // the next solve (13 MB over PCIe for cfg 5: 0.24 ms); corbo_hip_synchronize / corbo_hip_fetch_solution / corbo_hip_get_* wait for it
+    double* d_snap = nullptr;            // [batch][nvs] iterates | [batch] LmState
+    double* h_sink = nullptr;            // the same layout in pinned host memory (its own buffer: h_stage / h_state stay the staging areas of the other calls)
+    bool sink_delivered = false;         // the valid results are in h_sink (else: h_stage / h_state, written by the run-to-completion kernel)
+    hipStream_t sink_stream = nullptr;
+    hipEvent_t ev_snap = nullptr, ev_sink = nullptr;
+    bool sink_pending = false;
     // reject-streak speculation of the big-block family (kernels.hpp SpecParams): spare instance rows behind the batch in the per-instance arrays
     static constexpr int SPEC_GROUPS = 8, SPEC_SLOTS = 4;
     int spare = 0;              // SPEC_GROUPS * SPEC_SLOTS for a big-block handle on the stage / chain path, else 0
@@ -599,6 +608,11 @@ void corbo_hip_destroy(corbo_hip_handle h)
         for (hipEvent_t e : h->sub_chk[i]) if (e) (void)hipEventDestroy(e);
         if (h->sub_stream[i]) { (void)hipStreamSynchronize(h->sub_stream[i]); (void)hipStreamDestroy(h->sub_stream[i]); }
     }
+    if (h->sink_stream) { (void)hipStreamSynchronize(h->sink_stream); (void)hipStreamDestroy(h->sink_stream); }
+    if (h->ev_snap) (void)hipEventDestroy(h->ev_snap);
+    if (h->ev_sink) (void)hipEventDestroy(h->ev_sink);
+    if (h->d_snap) (void)hipFree(h->d_snap);
+    if (h->h_sink) (void)hipHostFree(h->h_sink);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -718,6 +732,40 @@ ABI_CATCH
 
 // what a synchronous solve does behind its last launch, for the solves of corbo_hip_solve_async that are still in flight: wait, add their HIP-event times
 // to the handle's timing, check the pass-limit flags
+// the delivery of a host-driven handle's results (snapshot -> pinned host memory on sink_stream) has landed
+static int wait_sink(corbo_hip_handle h)
+{
+    if (!h->sink_pending) return CORBO_HIP_OK;
+    HIP_TRY(hipEventSynchronize(h->ev_sink));
+    h->sink_pending = false;
+    return CORBO_HIP_OK;
+}
+
+// enqueue that delivery behind everything on the handle's stream
+static int deliver_results(corbo_hip_handle h)
+{
+    const size_t xd = (size_t)h->batch * h->S.nvs, sd = (size_t)h->batch * sizeof(LmState) / sizeof(double);
+    if (!h->d_snap) {
+        HIP_TRY(hipMalloc((void**)&h->d_snap, (xd + sd) * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void**)&h->h_sink, (xd + sd) * sizeof(double)));
+        HIP_TRY(hipStreamCreateWithFlags(&h->sink_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_sink, hipEventDisableTiming));
+    }
+    if (h->sink_pending) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_sink, 0));   // the previous delivery has finished reading the snapshot
+    launch_copy_rows(h->d_x, h->d_snap, nullptr, xd, h->stream);
+    launch_copy_rows(reinterpret_cast<const double*>(h->d_state), h->d_snap + xd, nullptr, sd, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_snap, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->sink_stream, h->ev_snap, 0));
+    // (a copy ENGINE, not a copy kernel: a kernel's posted writes over PCIe fill the write path of the whole chip -- measured: the next step's 7 us re-arm
+    //  copy, started while such a kernel ran on the other stream, ended with it 164 us later, and everything queued behind it waited)
+    HIP_TRY(hipMemcpyAsync(h->h_sink, h->d_snap, (xd + sd) * sizeof(double), hipMemcpyDeviceToHost, h->sink_stream));
+    HIP_TRY(hipEventRecord(h->ev_sink, h->sink_stream));
+    h->sink_pending = true;
+    return CORBO_HIP_OK;
+}
+
 static int finish_async(corbo_hip_handle h)
 {
     if (h->async_pending == 0) return CORBO_HIP_OK;
@@ -733,6 +781,7 @@ static int finish_async(corbo_hip_handle h)
     h->h_counter[0] = h->h_counter[1] = 0;
     if (unfinished) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
     h->sink_valid = h->result_sink;
+    h->sink_delivered = false;
     return CORBO_HIP_OK;
 }
 
@@ -777,6 +826,8 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     const bool split = h->split_passes || h->force_split;
     const bool run_to_completion = !split && h->loop_mode && o->iterations > 0;
     if (async && !run_to_completion) { const int rc0 = finish_async(h); if (rc0) return rc0; async = false; }   // (host-driven passes: synchronous)
+    // (measured and not kept: asynchronous run-to-completion solves delivering through the copy engine as well -- the kernel alone is 7.5 us shorter
+    //  without its own stores into pinned host memory, but the cross-stream waits and the engine's traffic cost more: 0.543 -> 0.753 ms per step)
     std::pair<hipEvent_t, hipEvent_t> aev{nullptr, nullptr};
     if (async && h->solve_timing) {
         if (!h->event_pool.empty()) { aev = h->event_pool.back(); h->event_pool.pop_back(); }
@@ -785,7 +836,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     }
     else if (h->solve_timing) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (!run_to_completion)   // per-pass "unfinished instances" counters (the run-to-completion kernel reports through pinned host memory)
-        HIP_TRY(hipMemsetAsync(h->d_counters, 0, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES * sizeof(int32_t), h->stream));
+    { launch_zero_ints(h->d_counters, (size_t)corbo_hip_solver::MAX_SUB * MAX_PASSES, h->stream); HIP_TRY(hipGetLastError()); }
     stamp();
     // Launch structure.  Run-to-completion (default): ONE launch, every workgroup walks its instance through the prologue sweep
     // and [factor phase -> trial sweep phase] passes until the instance has finished (the instances are independent, nothing has to
@@ -937,7 +988,9 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
         // instances make their workgroups exit at once, so an overshooting group costs a few microseconds.
         for (int p_ = 0; p_ < o->iterations; ++p_)
             for (int i = 0; i < nsub; ++i) { rc = enqueue_pass(i); if (rc) return rc; }
-        constexpr int GROUP = 2;
+        // (big-block family: a pass is 0.2 - 0.8 ms, the read-back 30 us -- ONE pass ahead keeps the GPU busy just as well, and a batch that is
+        //  through leaves one overshooting pass behind instead of three: 28 us each at cfg 5's size, the launches of four grids that exit at once)
+        const int GROUP = big_family_dims(h->S.desc.nx, h->S.desc.nu) ? 1 : 2;
         int slot = 0;
         bool any = true;
         while (any) {
@@ -998,7 +1051,9 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
         }
     }
     if (remaining > 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
-    h->sink_valid = run_to_completion && h->result_sink;
+    h->sink_valid     = h->result_sink && (run_to_completion || h->active == h->batch);
+    h->sink_delivered = h->sink_valid && !run_to_completion;
+    if (h->sink_delivered) { const int rc = deliver_results(h); if (rc) return rc; }   // (host-driven passes: delivered by a copy)
     return CORBO_HIP_OK;
 }
 
@@ -1428,7 +1483,7 @@ int corbo_hip_synchronize(corbo_hip_handle h)
     ON_DEVICE_OF(h);
     { const int rc = finish_async(h); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return CORBO_HIP_OK;
+    return wait_sink(h);
 }
 
 int corbo_hip_get_solution(corbo_hip_handle h, double* x_out, double* chi2_out, int32_t* status_out)
@@ -1474,14 +1529,17 @@ try {
             launch_copy_rows(reinterpret_cast<const double*>(h->d_state), reinterpret_cast<double*>(h->h_state), nullptr, (size_t)B * sizeof(LmState) / sizeof(double), h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
-    }   // else: the solve kernel has written both itself and corbo_hip_solve has waited for it
+    }   // else: the solve kernel has written both itself and corbo_hip_solve has waited for it -- or (host-driven passes) the delivery behind the solve has
+    const bool delivered = h->sink_valid && h->sink_delivered;
+    if (delivered) { const int rc_s = wait_sink(h); if (rc_s) return rc_s; }
+    const LmState* hstate = delivered ? reinterpret_cast<const LmState*>(h->h_sink + (size_t)B * S.nvs) : h->h_state;
     if (chi2_pinned || status_pinned) {
         int32_t* hs = reinterpret_cast<int32_t*>(h->h_chi2 + B);
-        for (int b = 0; b < B; ++b) { h->h_chi2[b] = h->h_state[b].chi2_old; hs[b] = h->h_state[b].status; }
+        for (int b = 0; b < B; ++b) { h->h_chi2[b] = hstate[b].chi2_old; hs[b] = hstate[b].status; }
         if (chi2_pinned) *chi2_pinned = h->h_chi2;
         if (status_pinned) *status_pinned = hs;
     }
-    if (x_pinned) *x_pinned = h->h_stage;
+    if (x_pinned) *x_pinned = delivered ? h->h_sink : h->h_stage;
     if (x_row_stride) *x_row_stride = S.nvs;
     return CORBO_HIP_OK;
 }

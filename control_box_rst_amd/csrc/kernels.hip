@@ -5074,6 +5074,19 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const double2* __restric
         }
     }
 }
+// n 32-bit zeros as a plain kernel on the caller's stream (hipMemsetAsync was seen to hold the stream back until a copy kernel on ANOTHER
+// stream of the handle had finished: the result delivery of the host-driven handles, corbo_hip.hip deliver_results)
+__global__ __launch_bounds__(256) void zero_ints_kernel(int32_t* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = 0;
+}
+void launch_zero_ints(int32_t* dst, size_t n, hipStream_t stream)
+{
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_ints_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, n);
+}
 void launch_copy_rows(const double* src, double* dst, double* dst2, size_t doubles, hipStream_t stream, double* dst3)
 {
     const size_t n2 = doubles / 2;   // (row strides are even: 16-byte elements)

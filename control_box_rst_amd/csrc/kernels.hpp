@@ -231,6 +231,7 @@ void launch_resample(const ResampleParams& p, hipStream_t stream);
 // dst (and dst2, may be null) = src, `doubles` values (even), as a kernel on `stream` (no copy engine: see kernels.hip)
 // (src may be pinned, device-visible HOST memory: the upload of a staged array is then the same kernel, no DMA engine either)
 void launch_copy_rows(const double* src, double* dst, double* dst2, size_t doubles, hipStream_t stream, double* dst3 = nullptr);
+void launch_zero_ints(int32_t* dst, size_t n, hipStream_t stream);
 // refvec[b][x_k entries] = traj[b][min(step + k, T - 1)] for k = 0 .. N-1 (the window of a resident reference trajectory that control step
 // `step` sees: DiscreteTimeReferenceTrajectory sampled at t + k dt, the last sample held beyond its end); other entries are left alone
 void launch_reference_window(const double* traj, double* refvec, int batch, int T, int N, int nx, int s, int nvs, int step, hipStream_t stream);
