@@ -3907,7 +3907,8 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
 template <int NX, int NU, int NSEG>
 __global__ __launch_bounds__(128 * NSEG)
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 196 registers: two waves per SIMD (four segments: one workgroup per CU; two: two).  A 128-register build
-                                             // (two 8-wave workgroups per CU) spills 290 - 340 bytes per lane into the dependent chain: 0.73 -> 0.88 ms per factor launch group at cfg 5, measured
+                                             // (two 8-wave workgroups per CU) spills 290 - 340 bytes per lane into the dependent chain: 0.73 -> 0.88 ms per factor launch group at cfg 5, measured;
+                                             // six segments (12 waves at 168 registers, 68 bytes of scratch): 0.698 -> 0.723 ms per group, one OCP 0.149 -> 0.158 -- measured, not kept
 void big_chain3_kernel(const FactorParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double sm3[];
@@ -4352,9 +4353,17 @@ struct HessEdge {
                 break;
             case EK_FINAL_EQ:
                 if (NX <= 4 && mp.fin_eq_mask) {   // (the descriptor gate admits it for nx <= 4, structure.cpp) TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): the active components only, in order
+                    // (static indices only: a running output index puts the lane's arrays into scratch memory -- measured on this kernel: 448 -> 1408 bytes
+                    //  per lane, 273 -> 458 us for 1024 OCPs)
                     int idx = 0;
-                    for (int i = 0; i < NX; ++i)
-                        if ((mp.fin_eq_mask >> i) & 1) out[idx++] = xl[i] - xr[i];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        const bool a = ((mp.fin_eq_mask >> i) & 1) != 0;
+                        const double v = xl[i] - xr[i];
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) out[r] = (a && idx == r) ? v : out[r];
+                        idx += a ? 1 : 0;
+                    }
                 }
                 else
                     for (int i = 0; i < NX; ++i) out[i] = xl[i] - xr[i];
