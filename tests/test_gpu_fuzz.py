@@ -431,3 +431,57 @@ def test_fuzz_escalation_budget():
     print(f"fuzz escalations: {n1} seed(s) beyond the base tolerance, {n2} needed the 48-trial spread; budget {ESCALATION_BUDGET}")
     assert n1 <= ESCALATION_BUDGET[1], ESCALATIONS
     assert n2 <= ESCALATION_BUDGET[2], ESCALATIONS
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_dense_weights_vs_oracle(oracle_mod, seed):
+    """NON-DIAGONAL Q / R / Qf (random symmetric positive definite matrices, handed over as upper Cholesky factors) on random small-block
+    descriptors -- short horizons and, every other seed, horizons beyond 256 grid points (the long-horizon kernels' DENSE instantiation):
+    residual, Jacobian and a 3-iteration solve against the oracle (which the *_fullq fixtures pin to the reference, incl. Eigen's
+    alignment-dependent column order for three-column weights on odd residual rows)."""
+    rng = np.random.default_rng(61000 + seed)
+    while True:
+        fam, d = random_desc(rng, long_horizon=False)
+        if fam not in ("dint", "int3t") and d.grid in (capi.GRID_FD, capi.GRID_MS):
+            break
+    if seed % 2:
+        d.N = int(rng.integers(257, 330))
+
+    def factor(n):
+        a = rng.uniform(-1, 1, (n, n))
+        return np.linalg.cholesky(a.T @ a + 0.5 * np.eye(n)).T   # upper factor U, U^T U = the weight
+
+    nx, nu = d.nx, d.nu
+    d.weights_dense = 1 | (2 if nu > 1 else 0) | (4 if d.final_cost else 0)
+    for dst, U in ((d.q_sqrt, factor(nx)), (d.r_sqrt, factor(nu)), (d.qf_sqrt, factor(nx))):
+        for i, v in enumerate(U.ravel()):
+            dst[i] = float(v)
+    B = 2
+    w = tuple(float(v) for v in rng.uniform(1.0, 30.0, 3))
+    x0 = rng.uniform(-1, 1, (B, nx))
+    xf = rng.uniform(-1, 1, (B, nx)) + np.array([1.5, 0.5, 0.2, 0.0])[:nx]
+    if fam == "rocket":
+        x0[:, 2] = rng.uniform(0.9, 1.1, B)
+        xf[:, 2] = rng.uniform(0.8, 1.0, B)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(3)
+    s.setPenaltyWeights(*w)
+    X0 = s.init_trajectory(x0, xf) + 0.02 * rng.normal(size=(B, s.dims.nv))
+    X0[:, :nx] = x0
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*w)
+        assert np.abs(values[b] - vo).max() <= 1e-11 * max(1.0, np.abs(vo).max()), (seed, fam, b)
+        assert np.abs(jac[b] - jo).max() <= 1e-6 * max(1.0, np.abs(jo).max()), (seed, fam, b)
+    s.solve()
+    X, chi2, _ = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    ex = np.abs(X - Xo).max() / max(1.0, np.abs(Xo).max())
+    if ex > 3e-5 or not np.allclose(chi2, chi2o, rtol=5e-5, atol=1e-10):   # (same gate as the diagonal-weight descriptors above)
+        ec = np.abs(chi2 - chi2o).max() / max(1e-10, np.abs(chi2o).max())
+        sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, nx)
+        ESCALATIONS.append(dict(test="dense weights", seed=seed, fam=str(fam), stage=1, ex=float(ex), ec=float(ec), sx=sx, sc=sc))
+        assert ex <= widened(3e-5, 8.0, sx) and ec <= widened(5e-5, 8.0, sc), (seed, fam, ex, ec, sx, sc)

@@ -249,6 +249,30 @@ def test_random_descriptor_hessians_vs_oracle(oracle_mod, seed):
             d.cost_integral = 1                     # the same on the shooting grid: one MultipleShootingEdgeSingleControl (mixed edge) per interval
         elif d.grid == capi.GRID_FD_VARIABLE and d.stage_cost == capi.COST_MIN_TIME_QUADRATIC_LSQ and seed % 2 == 0:
             d.cost_integral = 1 + (seed // 6) % 2   # MinTimeQuadratic in integral form: plain dt terms + integral edges (only_last_n as drawn)
+    _check_hessian_operators(oracle_mod, d, fam, rng, seed)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_descriptor_hessians_partial_terminal_equality(oracle_mod, seed):
+    """The same operators with a TerminalPartialEqualityConstraint on a random subset of the components of x_f (equality rows, multipliers and
+    linear-form rows for the active components only): random descriptors of the fixed-dt families, own generator for the mask."""
+    from test_gpu_fuzz import random_desc
+    from control_box_rst_amd import capi
+    rng = np.random.default_rng(47000 + seed)
+    while True:
+        fam, d = random_desc(rng)
+        if fam not in ("dint", "int3t") and d.xf_fixed_mask != 2 ** d.nx - 1:
+            break
+    d.final_ineq = capi.FINAL_INEQ_NONE
+    d.final_eq = 1
+    d.final_eq_mask = int(rng.integers(1, 2 ** d.nx))
+    if seed % 3 == 0:
+        d.cost_nonlsq = 1
+    _check_hessian_operators(oracle_mod, d, fam, rng, seed)
+
+
+def _check_hessian_operators(oracle_mod, d, fam, rng, seed):
+    from control_box_rst_amd import capi
     B = 2
     x0 = rng.uniform(-1, 1, (B, d.nx))
     xf = rng.uniform(-1, 1, (B, d.nx)) + (np.array([1.5, 0.5, 0.2, 0.0])[: d.nx] if fam not in ("dint", "int3t") else np.array([1.0, 0.0, 0.0])[: d.nx])
