@@ -1051,8 +1051,11 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
         }
     }
     if (remaining > 0) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
-    h->sink_valid     = h->result_sink && (run_to_completion || h->active == h->batch);
-    h->sink_delivered = h->sink_valid && !run_to_completion;
+    // (host-driven passes: a large batch is delivered by the copy engine on the second stream; a small one -- the drop-in adapter's single OCP -- is
+    //  fetched by the copy kernels of corbo_hip_fetch_solution as before: a copy engine takes 0.1 - 0.3 ms to wake up, more than such a solve)
+    const bool deliver = !run_to_completion && h->result_sink && h->active == h->batch && (size_t)h->batch * h->S.nvs * sizeof(double) >= ((size_t)1 << 20);
+    h->sink_valid     = h->result_sink && (run_to_completion || deliver);
+    h->sink_delivered = deliver;
     if (h->sink_delivered) { const int rc = deliver_results(h); if (rc) return rc; }   // (host-driven passes: delivered by a copy)
     return CORBO_HIP_OK;
 }

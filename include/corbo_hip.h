@@ -450,9 +450,9 @@ int corbo_hip_fetch_solution(corbo_hip_handle h, const double** x_pinned, int32_
  * handle's pinned host memory itself, as soon as that instance has finished (posted PCIe writes, overlapped with the instances still
  * iterating); corbo_hip_fetch_solution after such a solve returns the views without any copy.  Off by default (a moving-horizon
  * caller keeps its results on the device).  Handles without a run-to-completion kernel (big-block family, band route: passes launched
- * from the host) deliver the same with a copy instead: a device-side snapshot behind the last pass, then the copy engine moves it into
+ * from the host) deliver the same with a copy instead when the batch's results are 1 MB or more: a device-side snapshot behind the last pass, then the copy engine moves it into
  * pinned memory on a second stream, overlapping whatever the caller enqueues next; corbo_hip_fetch_solution / corbo_hip_synchronize
- * wait for it. */
+ * wait for it (smaller batches: corbo_hip_fetch_solution copies, as without the sink). */
 int corbo_hip_set_result_sink(corbo_hip_handle h, int enable);
 
 /* Accumulated HIP-event time [ms] (handle's stream, first launch to last kernel end) and number of corbo_hip_solve calls since the

@@ -21,7 +21,7 @@ def _solver(B, N):
     return s, X0, xf
 
 
-@pytest.mark.parametrize("B,N", [(3, 12), (130, 64)])   # (130 instances: reject-streak speculation on, partitioned chain)
+@pytest.mark.parametrize("B,N", [(3, 12), (160, 64)])   # (3 OCPs: below 1 MB of results, fetched by the copy kernels as before; 160: delivered by the copy engine, reject-streak speculation on, partitioned chain)
 def test_delivered_results_equal_get_solution(B, N):
     s, X0, xf = _solver(B, N)
     s.solve()

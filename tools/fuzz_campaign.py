@@ -23,7 +23,9 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
                         ("bounds+weights", F.test_per_instance_bounds_and_weight_adaptation_vs_oracle, range(first, first + count // 5)),
                         ("closed loop", F.test_random_closed_loop_call_vs_stepwise_and_oracle_plant, range(first, first + count // 5)),
                         ("hessian operators", H.test_random_descriptor_hessians_vs_oracle, range(first, first + count)),
-                        ("counted iterations on / off", lambda o, seed: F.test_counted_converged_iterations_random_descriptors(seed), range(first, first + count // 3))):
+                        ("counted iterations on / off", lambda o, seed: F.test_counted_converged_iterations_random_descriptors(seed), range(first, first + count // 3)),
+                        ("dense weights (incl. long horizons)", F.test_random_dense_weights_vs_oracle, range(first, first + count // 2)),
+                        ("hessian operators, partial terminal equality", H.test_random_descriptor_hessians_partial_terminal_equality, range(first, first + count // 2))):
     n_bad = 0
     for seed in seeds:
         try:
