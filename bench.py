@@ -399,9 +399,8 @@ def main():
     def step_timed():
         if not pipelined:
             return step()
-        solver.restore_instance_data()
         for i in range(solves):
-            solver.solve_async(new_run=(i == 0))
+            solver.solve_async(new_run=(i == 0), rearm=(i == 0))   # (rearm: the re-arm of the step inside the solve -- new_run = 2 of the C-ABI)
 
     def fence():
         solver.synchronize()
@@ -467,7 +466,7 @@ def main():
         "config": {"workload": f"{w['name']}, batch={B} per GPU, {solves} solve(s) x {args.iterations} LM iterations per step, seeds 20260928+i",
                    "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iterations, "solves_per_step": solves,
                    "parallelism": f"batch-sharded x{world}"},
-        "timed_region": ("re-arm (D2D) + corbo_hip_solve_async per step, the K steps enqueued back to back (the host side of a step overlaps the previous step's kernel), "
+        "timed_region": ("corbo_hip_solve_async(new_run = 2: re-arm from the uploaded start, done by the solve kernel itself; handles with host-launched passes copy first) per step, the K steps enqueued back to back (the host side of a step overlaps the previous step's kernel), "
                          "every step's trajectories/chi2/status written into pinned host memory (corbo_hip_set_result_sink): by the solve kernel as each instance finishes, or -- "
                          "handles whose passes are launched from the host, cfg 5 -- by a copy on a second stream behind a device-side snapshot, overlapping the next step; "
                          "wall clock, barrier + synchronize on both sides, MAX over ranks" if pipelined else

@@ -810,6 +810,10 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (o->iterations < 0 || o->iterations > MAX_PASSES / 8) return fail(CORBO_HIP_ERR_INVALID, "iterations out of range");
     ON_DEVICE_OF(h);
+    // new_run = 2: a new run from the iterates of the last corbo_hip_set_instance_data -- corbo_hip_restore_instance_data + new_run = 1 in one call; the
+    // run-to-completion kernel reads its start from the shadow copy itself (no copy launch in front of it), other handles copy first
+    const bool rearm = (new_run == 2);
+    new_run = new_run ? 1 : 0;
     update_penalty_weights(h, o, new_run);
     h->stats = corbo_hip_stats{};
     h->sink_valid = false;
@@ -825,6 +829,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     };
     const bool split = h->split_passes || h->force_split;
     const bool run_to_completion = !split && h->loop_mode && o->iterations > 0;
+    if (rearm && !run_to_completion) { launch_copy_rows(h->d_x0, h->d_x, nullptr, (size_t)h->batch * h->S.nvs, h->stream); HIP_TRY(hipGetLastError()); }
     if (async && !run_to_completion) { const int rc0 = finish_async(h); if (rc0) return rc0; async = false; }   // (host-driven passes: synchronous)
     // (measured and not kept: asynchronous run-to-completion solves delivering through the copy engine as well -- the kernel alone is 7.5 us shorter
     //  without its own stores into pinned host memory, but the cross-stream waits and the engine's traffic cost more: 0.543 -> 0.753 ms per step)
@@ -916,6 +921,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
         for (int i = 0; i < nsub; ++i) {
             FactorParams fp = h->factor_params();
             SweepParams sp  = h->sweep_params(2, o->iterations, h->w_eq, h->w_ineq, h->w_b, nullptr);
+            if (rearm) sp.x_init = h->d_x0;
             fp.batch = sp.batch = count_of[i];
             fp.inst0 = sp.inst0 = first_of[i];
             fp.loop_passes = MAX_PASSES;

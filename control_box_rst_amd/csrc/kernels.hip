@@ -281,6 +281,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     SWEEP_STAMP(0);
     // ---- stage vertex values in LDS (coalesced 16-byte loads), unless the factor phase of the same launch left its trial iterate
     //      there (run-to-completion kernel)
+    if constexpr (FUSED) {
+        if (mode == 2 && p.x_init) {   // re-armed solve: the start is the shadow copy of the uploaded iterates, which becomes the accepted iterate here
+            const double2* x0s = reinterpret_cast<const double2*>(p.x_init + xo);
+            double2* xacc      = reinterpret_cast<double2*>(p.x + xo);
+            for (int i = tid; i < p.nvs / 2; i += THREADS) { const double2 v = x0s[i]; reinterpret_cast<double2*>(xs)[i] = v; xacc[i] = v; }
+        }
+        else if (!xs_ready)
+            for (int i = tid; i < p.nvs / 2; i += THREADS)
+                reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];
+    }
+    else
     if (!xs_ready)
         for (int i = tid; i < p.nvs / 2; i += THREADS)
             reinterpret_cast<double2*>(xs)[i] = reinterpret_cast<const double2*>(xsrc)[i];

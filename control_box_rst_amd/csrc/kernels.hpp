@@ -81,6 +81,8 @@ struct SweepParams {
     // assembles from the accepted iterate on the fly.
     double* xe0;            // or null
     int32_t skip_jac;       // LM modes: leave the Jacobian to the stage kernel
+    const double* x_init;   // or null: (run-to-completion kernel, prologue) start from these iterates and make them the accepted ones -- the re-arm copy of
+                            // corbo_hip_restore_instance_data done by the solve kernel itself (corbo_hip_solve[_async] with new_run = 2)
 };
 
 struct FactorParams {

@@ -212,14 +212,16 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_set_profiling(self._h, 1 if enable else 0), "corbo_hip_set_profiling")
 
     # -- the hot path ---------------------------------------------------------------------------------------------------
-    def solve(self, new_run: bool = True):
-        rc = self.lib.corbo_hip_solve(self._h, C.byref(self.opts), 1 if new_run else 0)
+    def solve(self, new_run: bool = True, rearm: bool = False):
+        """rearm: a new run from the iterates of the last set_instance_data (restore_instance_data() + solve(new_run=True) in one call, new_run = 2 of the
+        C-ABI: the run-to-completion kernel reads its start from the shadow copy itself)."""
+        rc = self.lib.corbo_hip_solve(self._h, C.byref(self.opts), 2 if rearm else (1 if new_run else 0))
         self._check(rc, "corbo_hip_solve")
 
-    def solve_async(self, new_run: bool = True):
+    def solve_async(self, new_run: bool = True, rearm: bool = False):
         """corbo_hip_solve_async: enqueue the solve and return (run-to-completion handles; others solve synchronously).  Results / timing / errors of
-        the enqueued solves with the next synchronize() / solve() / get_*() / fetch_solution()."""
-        rc = self.lib.corbo_hip_solve_async(self._h, C.byref(self.opts), 1 if new_run else 0)
+        the enqueued solves with the next synchronize() / solve() / get_*() / fetch_solution().  rearm: see solve()."""
+        rc = self.lib.corbo_hip_solve_async(self._h, C.byref(self.opts), 2 if rearm else (1 if new_run else 0))
         self._check(rc, "corbo_hip_solve_async")
 
     def synchronize(self):

@@ -415,7 +415,8 @@ int corbo_hip_closed_loop(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int
 
 /* The NLP inner loop for the whole batch = LevenbergMarquardtSparse::solve
  * (levenberg_marquardt_sparse.cpp:44-220) per instance.  new_run: reset (1) or adapt (0) the penalty weights
- * (:83-86).  One run-to-completion launch on the handle's stream; the call returns once every instance has finished its outer
+ * (:83-86); 2 = 1 with the iterates of the last corbo_hip_set_instance_data as the start (corbo_hip_restore_instance_data and new_run = 1
+ * in one call: the run-to-completion kernel reads its start from the shadow copy itself, other handles copy first).  One run-to-completion launch on the handle's stream; the call returns once every instance has finished its outer
  * iterations; results stay resident in HBM.  CORBO_HIP_ERR_DEVICE "pass limit reached" if an instance is still unfinished after
  * 4096 LM passes (never seen; the reference would loop).  One deviation from the reference is guarded, not silent: an inner loop
  * that rejects 64 trial steps in a row is cut (the reference would keep multiplying the damping); such an instance finishes with

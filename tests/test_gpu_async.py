@@ -80,3 +80,34 @@ def test_host_driven_handles_solve_synchronously():
     s.solve_async()                          # big-block family: passes driven from the host -> a plain solve
     X2, chi22, _ = s.get_solution()
     assert np.array_equal(X, X2) and np.array_equal(chi2, chi22)
+
+
+@pytest.mark.parametrize("cfg", [3, 5])
+def test_rearmed_solve_equals_restore_then_solve(cfg):
+    """new_run = 2 (solve(rearm=True)): restore_instance_data() + solve(new_run=True) in one call -- the run-to-completion kernel reads its start from the
+    shadow copy itself (cfg 3), handles with host-launched passes copy first (cfg 5, reduced).  Bit-identical results and statistics, also back to back."""
+    import bench
+    B = 64 if cfg == 3 else 6
+    w = bench.workload(cfg, B)
+    d = w["desc"]
+    if cfg == 5:
+        from control_box_rst_amd import problems
+        d = problems.quad_desc(N=24)
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(6)
+    s.setPenaltyWeights(*w["weights"])
+    s.set_instance_data(s.init_trajectory(w["x0"], w["xf"]), xref=w["xf"])
+    s.solve()
+    ref = [a.copy() for a in s.get_solution()]
+    ref_stats = {k: v for k, v in s.get_stats().items() if not k.endswith("_ms")}
+    for rep in range(2):
+        s.solve(rearm=True)            # (the iterate is the previous solution at this point: the start must come from the shadow copy)
+        got = s.get_solution()
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), rep
+        assert {k: v for k, v in s.get_stats().items() if not k.endswith("_ms")} == ref_stats
+    s.set_result_sink(True)
+    for _ in range(3):
+        s.solve_async(rearm=True)
+    s.synchronize()
+    X, chi2, status = s.fetch_solution()
+    assert np.array_equal(np.asarray(X), ref[0]) and np.array_equal(chi2, ref[1]) and np.array_equal(status, ref[2])
