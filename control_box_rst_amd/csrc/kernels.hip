@@ -5597,7 +5597,10 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
         if (d == bw) v += mu_eff;
         win[i] = v;
     }
-    const bool loader = (wave == 3) && lane < W;   // wave 3: lane d carries entry d of the row that enters next
+    // wave 7: lane d carries entry d of the row that enters next.  (The LAST wave: with the quadrotor's half-bandwidth of 27 the trailing update is 378 entries,
+    //  waves 6 and 7 have none of it -- the wait for the requested row rides under the other waves' update.  Per-wave clock sums, cycles per pivot, with the
+    //  loader on wave 3 and the right-hand-side updates on wave 2: update phase 875 / 875 / 1160 / 1630 / 1030 / 1030 / 210 / 210 -- everybody waited for wave 3.)
+    const bool loader = (wave == 7) && lane < W;
     int rnext = W;                                  // (rows 0 .. bw are in)
     double pre = 0.0;
     if (loader && rnext < nb) { pre = Hb[(size_t)rnext * W + lane]; if (lane == bw) pre += mu_eff; }
@@ -5628,8 +5631,8 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
             double* ri = win + (size_t)(i % W) * W;
             ri[bw - (i - c)] -= ri[bw - (i - j)] * win[(size_t)(c % W) * W + bw - (c - j)];
         }
-        if (tid >= 128 && tid < 128 + cnt) {
-            const int i = j + 1 + (tid - 128);
+        if (tid >= 384 && tid < 384 + cnt) {   // (wave 6, see above)
+            const int i = j + 1 + (tid - 384);
             const double lij = win[(size_t)(i % W) * W + bw - (i - j)];
             g[i] -= lij * g[j];
             if (arrow) z[i] -= lij * z[j];
