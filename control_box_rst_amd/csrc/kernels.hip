@@ -5597,29 +5597,30 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
         if (d == bw) v += mu_eff;
         win[i] = v;
     }
-    // wave 7: lane d carries entry d of the row that enters next.  (The LAST wave: with the quadrotor's half-bandwidth of 27 the trailing update is 378 entries,
-    //  waves 6 and 7 have none of it -- the wait for the requested row rides under the other waves' update.  Per-wave clock sums, cycles per pivot, with the
-    //  loader on wave 3 and the right-hand-side updates on wave 2: update phase 875 / 875 / 1160 / 1630 / 1030 / 1030 / 210 / 210 -- everybody waited for wave 3.)
+    // wave 7: lane d writes entry d of the finished row out and carries entry d of the row that enters next.  (The LAST wave: with the quadrotor's
+    //  half-bandwidth of 27 the trailing update is 378 entries, waves 6 and 7 have none of it -- the wait for the requested row rides under the other
+    //  waves' update.  Per-wave clock sums, cycles per pivot, with the loader on wave 3 and the right-hand-side updates on wave 2: update phase
+    //  875 / 875 / 1160 / 1630 / 1030 / 1030 / 210 / 210 -- everybody waited for wave 3.)
     const bool loader = (wave == 7) && lane < W;
     int rnext = W;                                  // (rows 0 .. bw are in)
     double pre = 0.0;
     if (loader && rnext < nb) { pre = Hb[(size_t)rnext * W + lane]; if (lane == bw) pre += mu_eff; }
+    double* dpiv = sc + 30;                         // the next pivot's diagonal, double-buffered (the pivot row's slot is recycled inside the phase)
+    if (tid == 0) dpiv[0] = win[bw];
     __syncthreads();
     BAND_STAMP(2);   // window loaded
-    // ---- band Cholesky (lower), forward substitution of rhs and border fused into the elimination.  LDS-only barriers: a full __syncthreads() waits for the
-    //      wave's global operations too -- the write-out of row j and the request of the entering row would cost a memory round trip per pivot each
+    // ---- band Cholesky (lower), forward substitution of rhs and border fused into the elimination.  ONE LDS-only barrier per pivot: column j is used
+    //      unscaled inside phase j (every product scales its two factors itself: the same numbers as scaling first), its entries are scaled in place
+    //      during phase j + 1 (wave 6), when nobody reads them any more; the pivot row is written out and its slot refilled by wave 7, and the next
+    //      pivot's diagonal travels through a two-slot side buffer.  (LDS-only barriers: a full __syncthreads() waits for the wave's global operations
+    //      too -- the write-out of row j and the request of the entering row would cost a memory round trip per pivot each.)
+    double inv_prev = 1.0;
     for (int j = 0; j < nb; ++j) {
         const int cnt = (nb - 1 - j < bw) ? nb - 1 - j : bw;   // rows below the pivot inside the band
         double* rowj = win + (size_t)(j % W) * W;
-        const double dj  = rowj[bw];
+        const double dj  = dpiv[j & 1];
         const double inv = rsqrt(dj);              // (v_rsq_f64 + one Newton step: half the dependent instructions of sqrt and a division)
         const double l   = dj * inv;
-        if (wave == 2 && lane < W) Hb[(size_t)j * W + lane] = (lane == bw) ? l : rowj[lane];   // row j is final: L(j, j - bw .. j)
-        // column j: L(i, j) = H(i, j) / l, i = j + 1 .. j + cnt   (row j itself is only read in this phase: no barrier before it)
-        if (tid < cnt) { const int i = j + 1 + tid; win[(size_t)(i % W) * W + bw - (i - j)] *= inv; }
-        if (tid == 64) g[j] *= inv;                // y_j
-        if (tid == 65 && arrow) z[j] *= inv;       // (L^-1 border)_j
-        lds_barrier();   // (what crosses it lives in LDS: the row written out and the row requested stay in flight)
         // trailing update: H(i, c) -= L(i, j) L(c, j), j < c <= i <= j + cnt; rhs / border: g_i -= L(i, j) y_j
         const int ntri = cnt * (cnt + 1) / 2;
         for (int q = tid; q < ntri; q += T) {
@@ -5629,22 +5630,39 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
             const int rem = q - a * (a + 1) / 2;
             const int i = j + 1 + a, c = j + 1 + rem;
             double* ri = win + (size_t)(i % W) * W;
-            ri[bw - (i - c)] -= ri[bw - (i - j)] * win[(size_t)(c % W) * W + bw - (c - j)];
+            const double lij = ri[bw - (i - j)] * inv, lcj = win[(size_t)(c % W) * W + bw - (c - j)] * inv;
+            const double v = ri[bw - (i - c)] - lij * lcj;
+            ri[bw - (i - c)] = v;
+            if (q == 0) dpiv[(j + 1) & 1] = v;     // (i = c = j + 1: the next pivot's diagonal)
         }
-        if (tid >= 384 && tid < 384 + cnt) {   // (wave 6, see above)
-            const int i = j + 1 + (tid - 384);
-            const double lij = win[(size_t)(i % W) * W + bw - (i - j)];
-            g[i] -= lij * g[j];
-            if (arrow) z[i] -= lij * z[j];
+        if (wave == 6) {
+            if (lane < cnt) {   // rhs / border updates of the rows below the pivot
+                const int i = j + 1 + lane;
+                const double lij = win[(size_t)(i % W) * W + bw - (i - j)] * inv;
+                g[i] -= lij * (g[j] * inv);
+                if (arrow) z[i] -= lij * (z[j] * inv);
+            }
+            // column j - 1, rows j + 1 .. : scaled in place now (phase j - 1 used it unscaled; row j's entry leaves with the row, see the loader)
+            if (j > 0 && lane < bw) {
+                const int i = j + 1 + lane;
+                if (i < nb && i - (j - 1) <= bw) win[(size_t)(i % W) * W + bw - (i - (j - 1))] *= inv_prev;
+            }
+            if (lane == 63 && j > 0) { g[j - 1] *= inv_prev; if (arrow) z[j - 1] *= inv_prev; }   // y_{j-1}, (L^-1 border)_{j-1}
         }
-        // the row that enters for the next pivot takes the slot of row j (its entries were written out above), the one behind it is requested
         if (loader) {
+            // row j is final: L(j, j - bw .. j) goes out (its entry in column j - 1 scaled on the way), the row that enters for the next pivot takes its
+            // slot, the one behind it is requested
+            const double old = rowj[lane];
+            Hb[(size_t)j * W + lane] = (lane == bw) ? l : ((lane == bw - 1) ? old * inv_prev : old);
             if (rnext < nb) rowj[lane] = pre;
             ++rnext;
             if (rnext < nb) { pre = Hb[(size_t)rnext * W + lane]; if (lane == bw) pre += mu_eff; }
         }
+        inv_prev = inv;
         lds_barrier();   // (what crosses it lives in LDS: the row written out and the row requested stay in flight)
     }
+    if (tid == 64 && nb > 0) g[nb - 1] *= inv_prev;
+    if (tid == 65 && arrow && nb > 0) z[nb - 1] *= inv_prev;
     __syncthreads();
     BAND_STAMP(3);   // factorised
     double y2 = 0.0, zz = 0.0, zy = 0.0;
