@@ -446,11 +446,11 @@ SolverStatus LevenbergMarquardtSparseHip::solve(OptimizationProblemInterface& pr
 // ---- operators of the exact-Hessian path (what an interior-point / SQP solver asks the problem for), evaluated on the device for the
 //      hypergraph's current vertex values; signatures of OptimizationProblemInterface::computeSparseHessians{NNZ,Structure,Values}
 //      (optimization_problem_interface.h) with the problem as the first argument
-// attach for the Hessian-path entry points: the vertex values are uploaded on every call, the model tracking (one recogniser pass over all cost edges)
-// runs once per outer run (newHessianRun(), solve(), clear() start the next one)
+// attach for the Hessian-path entry points: the vertex values are uploaded on every call; the model tracking (one recogniser pass over all cost edges)
+// runs on every call too unless setHessianTrackOncePerRun(true) limits it to the first call of an outer run (newHessianRun(), solve(), clear() start the next one)
 bool LevenbergMarquardtSparseHip::attachHessianPath(OptimizationProblemInterface& problem)
 {
-    const bool first = !_hess_run_tracked || _handle == nullptr;
+    const bool first = !_hess_track_once || !_hess_run_tracked || _handle == nullptr;
     if (!attach(problem, _handle == nullptr, first)) return false;
     _hess_run_tracked = true;
     return true;

@@ -65,9 +65,12 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     // moved references keep the device handle, anything else rebuilds (and re-verifies) it.  On by default; costs one pass of the
     // recogniser over the edges per run.  Off: the caller vouches that only the vertex values change between runs.
     void setTrackModel(bool track) { _tracking = track; }
-    // Hessian-path entry points (computeGradientObjective, computeSparseHessians*): the model is tracked -- derived again from the graph and compared
-    // with the resident one -- by the FIRST such call of an outer run, not by every call of an interior-point iteration.  A run ends
-    // with the next solve() / clear(), or explicitly:
+    // Hessian-path entry points (computeGradientObjective, computeSparseHessians*): by default EVERY call tracks the model -- derived again from the
+    // graph and compared with the resident one -- like the reference, which always evaluates the live cost objects (a setpoint or weight that moves
+    // between two calls of an external interior-point / SQP loop is followed).  setHessianTrackOncePerRun(true) relaxes this to the FIRST
+    // such call of an outer run (one recogniser pass per run instead of one per call); the caller then ends a run with the next solve() / clear(),
+    // or explicitly with newHessianRun() whenever references, weights or parameters may have changed.
+    void setHessianTrackOncePerRun(bool once) { _hess_track_once = once; }
     void newHessianRun() { _hess_run_tracked = false; }
 
     const corbo_hip_stats& getStatistics() const { return _stats; }
@@ -98,6 +101,7 @@ class LevenbergMarquardtSparseHip : public NlpSolverInterface
     bool _verify    = true;
     bool _tracking  = true;
     bool _hess_run_tracked = false;
+    bool _hess_track_once  = false;
     Eigen::VectorXd _xref;
     Eigen::MatrixXd _xref_traj;   // recognised time-varying state reference [N][nx] (empty: static)
     std::vector<double> _ref;

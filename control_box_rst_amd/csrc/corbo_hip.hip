@@ -67,6 +67,14 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
+// Pending corbo_hip_solve_async launches are drained before any entry point touches iterates, flags, pinned result views or the shared
+// h_counter slots (a mutator between solve_async and fetch_solution must not leave the sink "valid" with stale rows).
+
+#define DRAIN_ASYNC(h)                                   \
+    do {                                                 \
+        const int rc_drain_ = finish_async(h);           \
+        if (rc_drain_) return rc_drain_;                 \
+    } while (0)
 #define ON_DEVICE_OF(h)                      \
     DeviceGuard device_guard_((h)->device);  \
     HIP_TRY(device_guard_.err)
@@ -84,6 +92,8 @@ struct EventList {
 };
 
 }  // namespace
+
+static int finish_async(corbo_hip_handle h);   // (DRAIN_ASYNC)
 
 static constexpr int PTL_LEN = 150 + 18 * 64;   // pass timeline buffer (diagnostics): stamps + per-pass phase log
 struct corbo_hip_solver {
@@ -183,6 +193,7 @@ struct corbo_hip_solver {
     bool split_passes = false;  // profiling: factor and sweep phases of a pass as two launches
     bool result_sink = false;   // corbo_hip_set_result_sink: the run-to-completion kernel writes results into pinned host memory itself
     bool sink_valid  = false;   // ... and the last solve did so
+    bool sink_invalidated = false;   // an enqueued re-arm (corbo_hip_restore_instance_data) came after the last enqueued solve: draining must not re-validate the views
     // handles whose passes are launched from the host (big-block family, band route, ...): the results are delivered by a copy instead -- a
     // device-to-device snapshot behind the last pass (10 us), then snapshot -> pinned host memory on a stream of its own, off the critical path of
     // the next solve (13 MB over PCIe for cfg 5: 0.24 ms); corbo_hip_synchronize / corbo_hip_fetch_solution / corbo_hip_get_* wait for it
@@ -454,14 +465,16 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMalloc((void**)&h->d_jac, B * h->nnz_pad * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_state, BT * sizeof(LmState)));
     CREATE_TRY(hipMalloc((void**)&h->d_chi2, BT * sizeof(double)));
+    // (the band route -- decided below -- reads the sweep's stored Jacobian: it needs neither the stage / chain workspace nor the first factorisation's cache)
+    const bool band_route_early = S.has_extra() || (S.dt_free && big_family_dims(S.nx, S.nu));
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
-        CREATE_TRY(hipMalloc((void**)&h->d_work, BT * h->work_stride * sizeof(double)));
+        if (!band_route_early || !big_family_dims(S.nx, S.nu)) CREATE_TRY(hipMalloc((void**)&h->d_work, BT * h->work_stride * sizeof(double)));
         if (big_family_dims(S.nx, S.nu)) {
             CREATE_TRY(hipMalloc((void**)&h->d_xe0, 2 * BT * (size_t)S.N * S.nx * sizeof(double)));
             CREATE_TRY(hipMemset(h->d_xe0, 0, 2 * BT * (size_t)S.N * S.nx * sizeof(double)));
         }
-        if (big_family_dims(S.nx, S.nu)) {
+        if (big_family_dims(S.nx, S.nu) && !band_route_early) {
             h->stage_cache_stride = big_stage_cache_doubles(*desc, S.N);
             const size_t bytes = BT * h->stage_cache_stride * sizeof(double);
             if (bytes > ((size_t)2 << 30)) h->stage_cache_stride = 0;   // (beyond 2 GB the first factorisation integrates twice, as before)
@@ -532,6 +545,10 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
             upload(rent, &h->d_band_rent) || upload(S.param_voff, &h->d_band_voff))
             return CORBO_HIP_ERR_DEVICE;
         BandParams& bp = h->band;
+        if (!band_route_supported(nb, bw)) {   // refused here, not at the first solve (include/corbo_hip.h: unsupported descriptors fail at create)
+            g_last_error = "band factorisation: half-bandwidth " + std::to_string(bw) + " beyond 63, or window + vectors of " + std::to_string(nb) + " parameters beyond 160 KB of LDS";
+            return CORBO_HIP_ERR_UNSUPPORTED;
+        }
         bp.n = n; bp.nb = nb; bp.bw = bw; bp.n_ent = (int32_t)tgt.size();
         bp.ent_target = h->d_band_target; bp.ent_ptr = h->d_band_ptr; bp.ent_pairs = h->d_band_pairs; bp.rhs_ptr = h->d_band_rptr; bp.rhs_ent = h->d_band_rent;
         bp.param_voff = h->d_band_voff;
@@ -621,6 +638,7 @@ int corbo_hip_set_instance_data(corbo_hip_handle h, const double* x, const doubl
 try {
     if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     const int nv = S.dims.nv, nvs = S.nvs, B = h->batch;
@@ -716,6 +734,7 @@ try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     if (!h->d_uprev) return CORBO_HIP_OK;   // no edge of this handle looks at the previous control
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const Structure& S = h->S;
     std::vector<double> up((size_t)h->batch * (CORBO_HIP_MAX_NU + 1), 0.0);
     for (int b = 0; b < h->batch; ++b) {
@@ -780,7 +799,7 @@ static int finish_async(corbo_hip_handle h)
     const bool unfinished = h->h_counter[0] != 0 || h->h_counter[1] != 0;
     h->h_counter[0] = h->h_counter[1] = 0;
     if (unfinished) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
-    h->sink_valid = h->result_sink;
+    h->sink_valid = h->result_sink && !h->sink_invalidated;
     h->sink_delivered = false;
     return CORBO_HIP_OK;
 }
@@ -817,6 +836,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     update_penalty_weights(h, o, new_run);
     h->stats = corbo_hip_stats{};
     h->sink_valid = false;
+    h->sink_invalidated = false;   // (this solve's results are the newest thing the sink will hold)
     if (h->active == 0) return CORBO_HIP_OK;   // an empty bucket of an adaptive-grid batch
     EventList ev_list;
     std::vector<hipEvent_t>& evs = ev_list.v;
@@ -1069,6 +1089,8 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
 int corbo_hip_set_result_sink(corbo_hip_handle h, int enable)
 {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->result_sink = enable != 0;
     h->sink_valid  = false;
     return CORBO_HIP_OK;
@@ -1078,6 +1100,7 @@ int corbo_hip_set_references(corbo_hip_handle h, const double* ref)
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;
     h->ref_T = 0;   // (an explicit set of references ends the stepping of a resident reference trajectory)
     if (!ref) { h->refvec_on = false; return CORBO_HIP_OK; }   // back to the static state reference of corbo_hip_set_instance_data
@@ -1103,6 +1126,7 @@ int corbo_hip_set_reference_trajectory(corbo_hip_handle h, const double* traj, i
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;
     const Structure& S = h->S;
     if (!traj) {   // back to the static reference
@@ -1132,7 +1156,10 @@ int corbo_hip_restore_instance_data(corbo_hip_handle h)
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    // (no drain: the copy is ordered behind the enqueued solves on the handle's stream, so re-arm + solve_async pipelines; the pinned views of those
+    //  solves must not come back as "valid" when they are drained -- the device iterates are the re-armed ones by then)
     h->sink_valid = false;   // the pinned result views are stale from here on
+    h->sink_invalidated = true;
     launch_copy_rows(h->d_x0, h->d_x, nullptr, (size_t)h->batch * h->S.nvs, h->stream);
     HIP_TRY(hipGetLastError());
     return CORBO_HIP_OK;
@@ -1157,6 +1184,7 @@ int corbo_hip_warm_start(corbo_hip_handle h, const double* x0_new, int shift)
     if (!h || !x0_new) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     HIP_TRY(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous call has been consumed
@@ -1172,6 +1200,7 @@ int corbo_hip_warm_start_from_plant(corbo_hip_handle h, int shift)
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     return warm_start_from(h, h->d_xplant, shift);
 }
@@ -1180,6 +1209,7 @@ int corbo_hip_plant_set_state(corbo_hip_handle h, const double* x)
 {
     if (!h || !x) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1199,6 +1229,7 @@ int corbo_hip_plant_step(corbo_hip_handle h, int integrator, double dt, const do
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const Structure& S = h->S;
     if (disturbance) {
         HIP_TRY(hipStreamSynchronize(h->stream));   // the previous step has consumed the pinned buffer
@@ -1219,6 +1250,7 @@ int corbo_hip_plant_set_params(corbo_hip_handle h, const double* params)
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (!params) {   // the plants use the controller's model again
         if (h->d_plant_prm) { (void)hipFree(h->d_plant_prm); h->d_plant_prm = nullptr; }
@@ -1237,6 +1269,7 @@ int corbo_hip_set_instance_params(corbo_hip_handle h, const double* params)
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sink_valid = false;
     if (!params) {   // every instance uses the descriptor's parameters again
@@ -1261,6 +1294,7 @@ int corbo_hip_plant_get_state(corbo_hip_handle h, double* x_out)
     if (!h || !x_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     HIP_TRY(hipMemcpyAsync(h->h_stage, h->d_xplant, (size_t)h->batch * CORBO_HIP_MAX_NX * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1282,6 +1316,7 @@ try {
     if (!h->have_plant) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_plant_set_state must be called first");
     if (steps == 0) return CORBO_HIP_OK;
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     const size_t B = (size_t)h->batch, NXm = CORBO_HIP_MAX_NX;
@@ -1366,6 +1401,7 @@ int corbo_hip_get_first_control(corbo_hip_handle h, double* u0_out)
     if (!h || !u0_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const Structure& S = h->S;
     // a small kernel packs u_0 of every instance straight into the pinned (device-visible) staging buffer: no copy engine in the
@@ -1399,6 +1435,7 @@ int corbo_hip_prepare_slots(corbo_hip_handle h, int active)
 {
     if (!h || active < 0 || active > h->batch) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;
     const Structure& S = h->S;
     if (!h->have_data) {   // never uploaded: zero iterates (create cleared them), the descriptor's bound pattern in every slot
@@ -1415,6 +1452,7 @@ int corbo_hip_get_dt(corbo_hip_handle h, double* dt_out)
     if (!h || !dt_out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "no instance data");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;
     if (h->active == 0) return CORBO_HIP_OK;
     launch_gather_dt(h->d_x, h->h_stage, h->S.nvs, h->S.off_dt, h->active, h->stream);
@@ -1438,6 +1476,8 @@ try {
     for (int q = 0; q < count; ++q)
         if (src_index[q] < 0 || src_index[q] >= src->batch || dst_index[q] < 0 || dst_index[q] >= dst->batch) return fail(CORBO_HIP_ERR_INVALID, "instance index out of range");
     ON_DEVICE_OF(dst);
+    DRAIN_ASYNC(src);
+    DRAIN_ASYNC(dst);
     src->sink_valid = dst->sink_valid = false;
     // the index lists travel through the destination handle's pinned staging buffer (batch x nvs doubles: 2 x count ints always fit; the
     // result views it may have held were invalidated above) -- no allocation on this path
@@ -1602,6 +1642,7 @@ try {
     if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
     const SweepParams spe = h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     int rc = launch_sweep_checked(h, spe);
@@ -1765,6 +1806,7 @@ int corbo_hip_eval_hessians(corbo_hip_handle h, int lower_part_only, double mult
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const HessianStructure* H = nullptr;
     size_t off[4];
     double* out[3] = {vals_obj, vals_eq, vals_ineq};
@@ -1795,6 +1837,7 @@ int corbo_hip_eval_hessians_views(corbo_hip_handle h, int lower_part_only, doubl
 try {
     if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const HessianStructure* H = nullptr;
     size_t off[4];
     int rc = eval_hessians_device(h, lower_part_only, mult_obj, mult_eq, mult_ineq, H, off, device_views == 0);
@@ -1810,6 +1853,7 @@ int corbo_hip_eval_objective_gradient(corbo_hip_handle h, double* grad, double* 
 try {
     if (!h || !grad) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const HessianStructure* H = nullptr;
     HessParams hp;
     int rc = hessian_common(h, H, false, hp);
@@ -1864,6 +1908,7 @@ int corbo_hip_eval_linear_form(corbo_hip_handle h, double* vals, double* lbA, do
 try {
     if (!h || !vals || !lbA || !ubA) return fail(CORBO_HIP_ERR_INVALID, "null argument");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const HessianStructure* H = nullptr;
     HessParams hp;
     int rc = hessian_common(h, H, false, hp);
@@ -1927,6 +1972,7 @@ int corbo_hip_time_sweep(corbo_hip_handle h, double w_eq, double w_ineq, double 
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     long long* d_tl = nullptr;  // CORBO_HIP_SWEEP_TIMELINE=1: shader-clock stamps of the phases of instance 0 on stderr (diagnostics)
@@ -1964,6 +2010,7 @@ try {
     if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     const SweepParams p = h->sweep_params(with_jacobian ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     EventList evs;
     evs.v.reserve((size_t)repeat + 1);
@@ -1987,6 +2034,7 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
     if (!h || !ms_per_launch || repeat < 1) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
     if (!h->have_data) return fail(CORBO_HIP_ERR_STATE, "corbo_hip_set_instance_data must be called first");
     ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
     if (h->S.desc.cost_nonlsq) return fail(CORBO_HIP_ERR_UNSUPPORTED, "not a least-squares problem (cost_nonlsq): LevenbergMarquardtSparse::solve refuses it too (levenberg_marquardt_sparse.cpp:48-55); the Hessian-path operators work on it");
     // LM prologue (residual + Jacobian + state init), then the assemble/factor/solve kernel `repeat` times on that state
     corbo_hip_lm_opts o;

@@ -5742,13 +5742,18 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
     lm_state_out(p.st + inst, st, tid);
 }
 
+static constexpr size_t BAND_LDS_MAX = 160 * 1024 - 256;   // (the kernel also has 128 bytes of static LDS: the LM state)
+// what band_factor_kernel can take: one wave writes a finished row out / walks a row in the back-substitution (half-bandwidth <= 63), and the sliding
+// window + right-hand side + border live in LDS.  corbo_hip_create asks, so that an unsupported descriptor is refused THERE (include/corbo_hip.h).
+bool band_route_supported(int nb, int bw) { return bw + 1 <= 64 && sizeof(double) * (band_lds_doubles(nb, bw) + 8) <= BAND_LDS_MAX; }
+
 bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream)
 {
     const size_t lds = sizeof(double) * (band_lds_doubles(bp.nb, bp.bw) + 8);   // window + rhs + border + scratch (a horizon of 256 twelve-state intervals: 85 KB)
     static bool attr_set = false;
-    constexpr size_t LDS_MAX = 160 * 1024 - 256;   // (the kernel also has 128 bytes of static LDS: the LM state)
+    constexpr size_t LDS_MAX = BAND_LDS_MAX;
     if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError(); attr_set = true; }
-    if (lds > LDS_MAX || !bp.work || bp.bw + 1 > 64) return false;   // (one wave writes a finished row out / walks a row in the back-substitution: half-bandwidth <= 63)
+    if (!bp.work || !band_route_supported(bp.nb, bp.bw)) return false;
     {
         int chunks = (bp.n_ent + 2047) / 2048;   // (eight list entries per thread)
         if (chunks > 64) chunks = 64;

@@ -274,6 +274,7 @@ bool device_kernels_exist(const corbo_hip_problem_desc& d);   // host-only mirro
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream);
 size_t band_work_doubles(int nb, int bw);
+bool band_route_supported(int nb, int bw);   // half-bandwidth <= 63 and the sliding window + vectors within the LDS of a CU
 size_t sweep_lds_bytes(const SweepParams& p, int nc);
 // Small-block families with horizons up to 256 grid points assemble the Jacobian values in an LDS staging area (STAGE in sweep_body); the
 // device-internal value layout carries one pad double per defect block for exactly those (corbo_hip_create).

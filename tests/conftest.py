@@ -157,3 +157,40 @@ def stiff_part(J, dp, lam=SOFT_EIGENVALUE):
     c = V.T @ dp
     stiff = V[:, w > lam] @ c[w > lam]
     return stiff, float(np.linalg.norm(J @ dp) ** 2)
+
+
+# ---- tolerance ledger (tests/tolerances.json, generated by `python oracle/gen_golden.py tolerances` from the genuine reference):
+#      fixture -> tolerance of the device result against the fixture + the reference's own one-ulp reproducibility on that fixture
+with open(os.path.join(ROOT, "tests", "tolerances.json")) as _f:
+    LEDGER = json.load(_f)
+
+
+def ledger_rule_violations(ledger=None):
+    """Entries whose tolerance is wider than the rule allows: beyond the hard gate a tolerance must be covered by 4 x the recorded spread."""
+    L = ledger or LEDGER
+    bad = []
+    for name, e in L["fixtures"].items():
+        if e["x_tol"] > max(L["hard_x"], 4.0 * e["ref_spread_x"]) * (1 + 1e-12) and e["x_tol"] > max(L["hard_x"], _round_up(4.0 * e["ref_spread_x"])):
+            bad.append((name, "x_tol", e["x_tol"], e["ref_spread_x"]))
+        if e["chi2_rtol"] > max(L["hard_chi2"], _round_up(4.0 * e["ref_spread_chi2"])):
+            bad.append((name, "chi2_rtol", e["chi2_rtol"], e["ref_spread_chi2"]))
+    return bad
+
+
+def _round_up(v):
+    """one significant digit, upwards (how the generator rounds 4 x spread)"""
+    import math
+    if v <= 0:
+        return 0.0
+    e = 10.0 ** math.floor(math.log10(v))
+    return math.ceil(v / e - 1e-9) * e
+
+
+def ledger_tolerances(name):
+    """(x_tol, chi2_rtol) of a fixture; the defaults for fixtures the ledger does not list.  Fails when the entry breaks the ledger's rule."""
+    e = LEDGER["fixtures"].get(name)
+    if e is None:
+        return LEDGER["default_x_tol"], LEDGER["default_chi2_rtol"]
+    bad = [b for b in ledger_rule_violations() if b[0] == name]
+    assert not bad, f"tests/tolerances.json: tolerance wider than max(hard gate, 4 x the reference's own spread): {bad}"
+    return e["x_tol"], e["chi2_rtol"]

@@ -111,3 +111,24 @@ def test_rearmed_solve_equals_restore_then_solve(cfg):
     s.synchronize()
     X, chi2, status = s.fetch_solution()
     assert np.array_equal(np.asarray(X), ref[0]) and np.array_equal(chi2, ref[1]) and np.array_equal(status, ref[2])
+
+
+@pytest.mark.parametrize("mutator", ["warm_start", "set_instance_data", "restore"])
+def test_mutator_behind_an_enqueued_solve_does_not_leave_stale_sink_views(mutator):
+    """solve_async(); <mutator>; fetch_solution() must hand out what the synchronous sequence hands out (the device iterates AFTER the
+    mutator), not the pinned rows the enqueued solve wrote before it."""
+    def run(async_):
+        s = _solver()
+        s.set_result_sink(True)
+        (s.solve_async if async_ else s.solve)()
+        if mutator == "warm_start":
+            x0, _ = problems.unicycle_instances(48, seed=7)
+            s.warm_start(x0, shift=False)
+        elif mutator == "set_instance_data":
+            x0, xf = problems.unicycle_instances(48, seed=11)
+            s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        else:
+            s.restore_instance_data()
+        Xv, _, _ = s.fetch_solution()
+        return np.array(Xv, copy=True)
+    assert np.array_equal(run(True), run(False))
