@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E (MI355X_MICROARCH.md)
 PEAK_F64_MFMA_TFLOPS = 78.6  # gfx950 dense fp64 matrix peak
-PROFILE_ROUND = "r04"         # prefix of the committed rocprofv3 summaries under profiles/ the line cross-checks itself against
+PROFILE_ROUND = "r05"         # prefix of the committed rocprofv3 summaries under profiles/ the line cross-checks itself against
 
 
 def workload(cfg: int, batch: int, first: int = 0):
@@ -245,9 +245,9 @@ def secondary_leg(cfg, iterations, device):
     iters_per_step = B * iterations * solves
     counted = counted_per_step(solver, solves)
     out = {"workload": f"{w['name']}, batch={B}, {solves} solve(s) x {iterations} LM iterations per step", "steps": steps, "warmup": warmup,
-           "ms_per_step": 1e3 * dt / steps, "value": iters_per_step * steps / dt, "unit": "SQP-iterations/s",
-           "counted_iterations": counted, "value_computed": (iters_per_step - counted) * steps / dt,
-           "counted_note": "outer iterations after a converged step (|delta| <= eps2/2) are counted, not executed (corbo_hip_stats.counted_iterations); value_computed = executed iterations / s",
+           "ms_per_step": 1e3 * dt / steps, "value": (iters_per_step - counted) * steps / dt, "unit": "SQP-iterations/s",
+           "counted_iterations": counted, "value_computed": (iters_per_step - counted) * steps / dt, "value_incl_counted": iters_per_step * steps / dt,
+           "counted_note": "`value` = EXECUTED outer iterations / s; outer iterations after a converged step (|delta| <= eps2/2) are counted, not executed (corbo_hip_stats.counted_iterations) -- value_incl_counted adds them (what the reference's loop count would credit)",
            "chi2_sum": float(chi2.sum()), "ok_instances": int((status <= 1).sum()), "ms_per_solve_launch": solve_ms_sum / max(1, n_solves)}
     gpath = os.path.join(ROOT, "tests", "golden", "bench_secondary.json")
     if os.path.exists(gpath) and iterations == 10:
@@ -275,6 +275,87 @@ def secondary_leg(cfg, iterations, device):
                            "frac": alg / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
     del solver
     return out
+
+
+def batch8192_leg(iterations, device, value_1024):
+    """BASELINE cfg 4's whole batch (8192 unicycle OCPs) on ONE GPU through the instance queue of the run-to-completion kernel: CUs x 4 persistent workgroups
+    pull instance after instance, so a finished instance's slot is refilled at once.  Throughput beyond the latency-bound headline point."""
+    import torch
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    B = 8192
+    w = workload(3, B)
+    solver = BatchedLevenbergMarquardt(w["desc"], B, device=device)
+    solver.setIterations(iterations)
+    solver.setPenaltyWeights(*w["weights"])
+    solver.set_instance_data(solver.init_trajectory(w["x0"], w["xf"]), xref=w["xf"])
+    solver.set_result_sink(True)
+    steps, warmup = 20, 3
+    for _ in range(warmup):
+        solver.solve(rearm=True)
+    solver.synchronize(); torch.cuda.synchronize()
+    solver.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.solve_async(rearm=True)
+    solver.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_sum, n = solver.get_timing(reset=True)
+    st = solver.get_stats()
+    _, chi2, status = solver.get_solution()
+    passes = st["factorizations"] - st["counted_iterations"]
+    # slot utilisation from the in-kernel phase totals (one more solve with the option on): busy cycles of all instances / (slots x kernel cycles)
+    util = None
+    try:
+        solver.set_option("phase_cycles", 1)
+        solver.solve(rearm=True)
+        ms_pc = solver.get_stats()["solve_ms"]
+        pc = solver.get_phase_cycles()
+        solver.set_option("phase_cycles", 0)
+        import torch as _t
+        slots = 4 * _t.cuda.get_device_properties(device).multi_processor_count
+        busy = float(pc[:, 0:3].sum())
+        util = {"busy_cycles_sum": busy, "slots": slots, "kernel_ms": ms_pc,
+                "mean_cycles_per_pass": busy / max(1, int(pc[:, 5].sum())),
+                "what": "sum over instances of the cycles between an instance's first and last phase, per resident workgroup slot; divide by slots x kernel cycles for the slot utilisation (shader clock ~ 2.4 GHz): "
+                        "busy / (slots x kernel_ms x 2.4e6)", "slot_utilisation_at_2p4GHz": busy / (slots * ms_pc * 2.4e6)}
+    except Exception as e:   # (an older library without the option)
+        util = {"error": repr(e)}
+    value = B * iterations * steps / dt
+    del solver
+    return {"workload": "BASELINE cfg 4's batch on one GPU: unicycle nx=3 nu=2 N=100 CN, batch=8192, instance queue (persistent workgroups)", "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps, "ms_per_solve_launch": ms_sum / max(1, n), "value": value, "unit": "SQP-iterations/s",
+            "vs_batch1024": value / value_1024 if value_1024 else None, "executed_passes_per_solve": int(passes),
+            "chi2_sum": float(chi2.sum()), "ok_instances": int((status <= 1).sum()), "slot_occupancy": util}
+
+
+def sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms):
+    """The sweep PHASE of the kernel the timed region runs: per-instance phase totals accumulated by lm_pass_kernel itself
+    (corbo_hip_get_phase_cycles; one extra solve with the option on, outside the timed region).  `achieved` = algorithmic bytes of every Jacobian sweep of the
+    solve / the time those sweep phases would take if all resident workgroups ran nothing else: sum of the phases' cycles / resident workgroups / shader clock
+    -- the in-kernel counterpart of `roofline_sweep` (the stand-alone kernel).  The shader clock is taken from the kernel itself: the slowest instance's phase
+    cycles add up to (almost) the launch's duration."""
+    solver.set_option("phase_cycles", 1)
+    solver.solve(rearm=True)
+    ms = solver.get_stats()["solve_ms"]
+    pc = solver.get_phase_cycles().astype(np.float64)
+    solver.set_option("phase_cycles", 0)
+    tot = pc[:, 0:3].sum(axis=1)
+    clk_ghz = tot.max() / (ms * 1e6)                      # cycles of the slowest instance / kernel time [ns] (lower bound of the clock: launch ramp excluded)
+    n_j, n_r, n_f = pc[:, 3].sum(), pc[:, 4].sum(), pc[:, 5].sum()
+    cyc_j, cyc_r, cyc_f = pc[:, 0].sum(), pc[:, 1].sum(), pc[:, 2].sum()
+    t_j = cyc_j / B / (clk_ghz * 1e9)                     # seconds: the Jacobian sweep phases of one solve, all B workgroups side by side
+    t_r = cyc_r / B / (clk_ghz * 1e9)
+    ach_j = n_j * b_sweep / t_j / 1e9
+    ach_all = (n_j * b_sweep + n_r * b_val) / (t_j + t_r) / 1e9
+    return {"bound": "hbm", "kernel": "lm_pass_kernel, sweep phases only (residual + Jacobian of accepted steps and of the prologue)",
+            "achieved": ach_j, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_j / PEAK_HBM_GBS,
+            "achieved_all_sweeps": ach_all, "frac_all_sweeps": ach_all / PEAK_HBM_GBS,
+            "bytes_per_jacobian_sweep": b_sweep, "jacobian_sweeps": int(n_j), "residual_sweeps": int(n_r), "factor_phases": int(n_f),
+            "mean_cycles": {"jacobian_sweep_phase": cyc_j / max(1, n_j), "residual_sweep_phase": cyc_r / max(1, n_r), "factor_phase": cyc_f / max(1, n_f)},
+            "share_of_workgroup_time": {"jacobian_sweeps": cyc_j / tot.sum(), "residual_sweeps": cyc_r / tot.sum(), "factor": cyc_f / tot.sum()},
+            "slowest_instance_cycles": float(tot.max()), "mean_instance_cycles": float(tot.mean()), "shader_clock_ghz_estimate": clk_ghz, "kernel_ms": ms,
+            "note": "algorithmic bytes of SURVEY 8d over the time the sweep phases occupy their workgroups; inside the fused kernel most of these bytes never leave the chip "
+                    "(the Jacobian goes from the sweep phase to the factor phase through LDS), the HBM-side traffic of the whole launch is `roofline.traffic`"}
 
 
 def hessian_leg(desc, B, x0, xf, device):
@@ -542,6 +623,10 @@ def main():
                             "profile_avg_ms": prof[0] * 1e-6 if prof else None, "profile": prof[2] if prof else None,
                             "frac_from_profile": (alg_solve / (prof[0] * 1e-9) / 1e9 / PEAK_HBM_GBS) if (prof and B == 1024 and cfg == 3) else None,
                             "note": "a latency chain per instance (DESIGN.md 3.3), priced against HBM because its algorithmic work is the sweep traffic"}
+        try:
+            line["roofline_sweep_phase"] = sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms)
+        except Exception as e:
+            line["roofline_sweep_phase"] = {"error": repr(e)}
     # ---- the stand-alone edge/Jacobian sweep (north star: ">= 40 % of the HBM roofline on the Jacobian sweep")
     each = solver.time_sweep_each(with_jacobian=True, repeat=50)        # one event pair per launch (what a kernel trace reports)
     b2b_ms = solver.time_sweep(with_jacobian=True, repeat=50)            # back-to-back launches, one event pair around all of them
@@ -612,6 +697,7 @@ def main():
     host_ms = (time.perf_counter() - t_h) / n_h * 1e3
     line["host_inclusive"] = {"ms_per_step": host_ms, "value_rank0": B * args.iterations * solves / (host_ms * 1e-3),
                               "what": "set_instance_data (H2D of x, xref from pageable host memory) + solve(s) + get_solution (D2H into caller arrays), rank 0"}
+    lm_opts = solver.opts
     if rank == 0 and world == 1 and cfg == 3 and not args.no_secondary:
         try:
             line["roofline_hessian"] = hessian_leg(desc, B, x0, xf, local_rank)
@@ -624,9 +710,15 @@ def main():
                 line["secondary"][f"config{c2}"] = secondary_leg(c2, args.iterations, local_rank)
             except Exception as e:   # a failing leg must not take the headline line with it
                 line["secondary"][f"config{c2}"] = {"error": repr(e)}
+        try:
+            lm_opts = solver.opts
+            del solver
+            line["secondary"]["batch8192"] = batch8192_leg(args.iterations, local_rank, value if B == 1024 else None)
+        except Exception as e:
+            line["secondary"]["batch8192"] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, w, solver.opts)
+            cb = cpu_baseline(cfg, w, lm_opts)
             line["cpu_baseline"] = cb
             if "ms_per_ocp" in cb:
                 line["cpu_baseline"]["gpu_ms_per_ocp_batch1_equivalent"] = host_ms if B == 1 else None

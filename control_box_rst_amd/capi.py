@@ -101,7 +101,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
     "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_eval_hessians_views", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
-    "corbo_hip_sizeof", "corbo_hip_set_previous_control",
+    "corbo_hip_sizeof", "corbo_hip_set_previous_control", "corbo_hip_get_phase_cycles",
 )
 
 
@@ -176,6 +176,7 @@ def load() -> C.CDLL:
     lib.corbo_hip_resample_into.argtypes = [H, H, C.c_int, ip, ip]
     lib.corbo_hip_eval_dynamics.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, dp]
     lib.corbo_hip_get_timing.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    lib.corbo_hip_get_phase_cycles.argtypes = [H, C.POINTER(C.c_int64)]
     lib.corbo_hip_time_factor.argtypes = [H, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]
     lib.corbo_hip_set_references.argtypes = [H, dp]
     lib.corbo_hip_set_reference_trajectory.argtypes = [H, dp, C.c_int, C.c_int]

@@ -159,6 +159,7 @@ struct corbo_hip_solver {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> async_events, event_pool;
     int async_pending = 0;
     int m_pad = 0, nnz_pad = 0;
+    int jlean_lo2 = 0, jlean_hi2 = 0;   // kernels.hpp SweepParams::jlean_*
     // Hessian-path operators: the structure of a (handle, lower) pair is built once, scratch buffers only grow (an interior-point
     // loop calls these once per iteration)
     struct GrowBuf {
@@ -218,6 +219,9 @@ struct corbo_hip_solver {
     int stagger = 0;               // corbo_hip_set_option("stagger")
     int pass_threads = 0;          // corbo_hip_set_option("pass_threads"): 0 = the default workgroup size of the run-to-completion kernel
     int lag_priority = 1;          // corbo_hip_set_option("lag_priority")
+    bool phase_cycles = false;     // corbo_hip_set_option("phase_cycles"): per-instance phase totals (FactorParams::phase_cycles)
+    long long* d_phase = nullptr;  // [batch][8]
+    bool raw_stamps = false;       // corbo_hip_set_option("raw_stamps"): the per-pass stamp log as raw offsets (development builds)
     int solve_timing = 1;          // corbo_hip_set_option("solve_timing"): 0 = no HIP events around the launches of a solve (stats.solve_ms stays 0): two
                                    // event records and an event wait cost a batch-1 solve 10 - 13 us, a plain stream synchronisation the rest
     int ff_converged = 1;          // corbo_hip_set_option("ff_converged"): 0 = compute the outer iterations that follow a converged step (A/B, tests)
@@ -261,7 +265,7 @@ struct corbo_hip_solver {
         p.x = d_x; p.xt = d_xt; p.lb = d_lb; p.ub = d_ub; p.xref = d_xref;
         p.refvec = refvec_on ? d_refvec : nullptr;
         p.dyn_inst = d_dyn_inst;
-        p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
+        p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad; p.jlean_lo2 = jlean_lo2; p.jlean_hi2 = jlean_hi2;
         p.st = d_state; p.active_count = counter; p.chi2 = d_chi2;
         return p;
     }
@@ -273,7 +277,7 @@ struct corbo_hip_solver {
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols; p.ineq_rows = d_ineq_rows;
         p.fin_row = S.fin_row;
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) p.fin_joff[i] = fin_joff_dev[i];
-        p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad;
+        p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad; p.jlean_lo2 = jlean_lo2; p.jlean_hi2 = jlean_hi2;
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
         p.chain_variant = chain_variant;
@@ -411,6 +415,18 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         for (int32_t& o : ic) o = mp(o);
         for (int i = 0; i < CORBO_HIP_MAX_NX; ++i) h->fin_joff_dev[i] = (i < S.nx) ? mp(S.fin_joff[i]) : -1;
         h->nnz_int = nnz ? h->jmap[nnz - 1] + 1 : 0;
+        {   // the part of the Jacobian the factor phase reads from the staging area / HBM in the two-wave run-to-completion shape (kernels.hpp, jlean_*):
+            // defect blocks (nx rows per column), inequality entries, the final-stage rows and whatever the dt component carries -- not the cost blocks
+            // and bound rows of the stage components
+            int lo = INT32_MAX, hi = -1;
+            auto take = [&](int o, int len) { if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o + len); } };
+            for (const auto& c : sc) for (int o : c.col) take(o, S.nx);
+            for (int32_t o : ic) take(o, 1);
+            for (int i = 0; i < S.nx; ++i) take(h->fin_joff_dev[i], 1);
+            for (int i = 0; i < S.nx; ++i) take(ci[(size_t)(S.N - 1) * S.s + i].cost2_joff, S.nx);   // (terminal equality: a column of up to nx rows)
+            { const CompInfo& d = ci[S.off_dt]; take(d.cost_joff, 1); take(d.cost2_joff, 1); take(d.bnd_joff, 1); }
+            if (hi > lo) { h->jlean_lo2 = lo / 2; h->jlean_hi2 = (hi + 1) / 2; }
+        }
         if (upload(sc, &h->d_stage_cols) || upload(ci, &h->d_comp) || upload(ic, &h->d_ineq_cols) || upload(S.ineq_rows, &h->d_ineq_rows))
             return CORBO_HIP_ERR_DEVICE;  // message set by upload()
     }
@@ -601,7 +617,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
                     h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
-                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_stage_cache};
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_stage_cache, h->d_phase};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
@@ -960,6 +976,11 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
             const int flag_slot = async ? (h->async_pending & 1) : 0;
             if (!async || h->async_pending < 2) h->h_counter[2 * i + flag_slot] = 0;
             fp.unfinished_flag  = h->h_counter + 2 * i + flag_slot;
+            if (h->phase_cycles) {
+                if (!h->d_phase) HIP_TRY(hipMalloc((void**)&h->d_phase, (size_t)h->batch * 8 * sizeof(long long)));
+                if (i == 0) HIP_TRY(hipMemsetAsync(h->d_phase, 0, (size_t)h->batch * 8 * sizeof(long long), st_of[i]));
+                fp.phase_cycles = h->d_phase;
+            }
             long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
             const bool ptl_on = h->pass_timeline_inst >= 0;
             if (ptl_on && i == 0) {
@@ -971,13 +992,20 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
                 fp.timeline_inst = sp.timeline_inst = h->pass_timeline_inst;
                 fp.pass_timeline_inst = h->pass_timeline_inst;
             }
-            struct PtlGuard { long long* p; hipStream_t s; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); static long long tl[PTL_LEN];
+            struct PtlGuard { long long* p; hipStream_t s; bool raw; ~PtlGuard() { if (!p) return; (void)hipStreamSynchronize(s); static long long tl[PTL_LEN];
                 if (hipMemcpy(tl, p, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess) {
                     // per-pass phase log: factor stamps F0..F7 (start, loaded, first-mu, controls, blocks, cyclic reduction, root/arrow, back-substitution, trial iterate)
                     // and sweep stamps S0..S9 of the sweep phase that STARTED the pass
                     for (int k = 0; k < 64 && tl[2 * k]; ++k) {
                         const long long* f = tl + 150 + 18 * k; const long long* w = f + 8;
                         if (!f[0] && !w[0]) continue;
+                        if (raw) {   // (option raw_stamps: development builds that re-purpose the stamp slots, e.g. one stamp per cyclic-reduction level)
+                            fprintf(stderr, "pass %2d raw:", k);
+                            const long long base = f[0] ? f[0] : w[0];
+                            for (int q = 0; q < 18; ++q) fprintf(stderr, " %lld", f[q] ? f[q] - base : -1);
+                            fprintf(stderr, "\n");
+                            continue;
+                        }
                         fprintf(stderr, "pass %2d sweep:", k);
                         if (w[0]) { const int ids[] = {1, 2, 9, 3, 4, 5, 6, 7, 8}; long long prev = w[0]; for (int q : ids) { if (w[q]) { fprintf(stderr, " s%d+%lld", q, w[q] - prev); prev = w[q]; } } }
                         fprintf(stderr, " | factor:");
@@ -991,7 +1019,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
                     const long long* f = tl + 130;
                     if (f[7]) fprintf(stderr, "factor phases, last pass (cycles): load %lld | controls %lld | blocks + level 0 %lld | cyclic reduction %lld | root %lld | back-substitution %lld | trial iterate %lld\n",
                                       f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], f[5] - f[4], f[6] - f[5], f[7] - f[6]); }
-                (void)hipFree(p); } } ptl_guard{d_ptl, st_of[i]};
+                (void)hipFree(p); } } ptl_guard{d_ptl, st_of[i], h->raw_stamps};
             if (!launch_pass(h->S.desc, fp, sp, st_of[i])) return fail(CORBO_HIP_ERR_UNSUPPORTED, "no fused pass kernel for this descriptor");
             HIP_TRY(hipGetLastError());
             pass_of[i] = 1;
@@ -1512,6 +1540,8 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "stagger") h->stagger = value;
     else if (n == "pass_threads") h->pass_threads = value;
     else if (n == "lag_priority") h->lag_priority = value;
+    else if (n == "raw_stamps") h->raw_stamps = value != 0;
+    else if (n == "phase_cycles") h->phase_cycles = value != 0;
     else if (n == "ff_converged") h->ff_converged = value;
     else if (n == "solve_timing") h->solve_timing = value;
     else return fail(CORBO_HIP_ERR_INVALID, "unknown option: " + n);
@@ -1593,6 +1623,18 @@ try {
     return CORBO_HIP_OK;
 }
 ABI_CATCH
+
+int corbo_hip_get_phase_cycles(corbo_hip_handle h, int64_t* out)
+{
+    if (!h || !out) return fail(CORBO_HIP_ERR_INVALID, "null argument");
+    ON_DEVICE_OF(h);
+    DRAIN_ASYNC(h);
+    if (!h->d_phase) return fail(CORBO_HIP_ERR_STATE, "no phase totals: set option \"phase_cycles\" and solve (run-to-completion handles)");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    static_assert(sizeof(long long) == sizeof(int64_t), "phase totals are 64-bit");
+    HIP_TRY(hipMemcpy(out, h->d_phase, (size_t)h->batch * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return CORBO_HIP_OK;
+}
 
 int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solves, int reset)
 {

@@ -143,10 +143,14 @@ __device__ __forceinline__ void diagonal_rows(double xv, double w, double ref, d
 }
 
 constexpr int SWEEP_ROLE_TABLE = 2 * CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NU;   // doubles: [sq | sr] [sqf] [xref], see sweep_body
+#ifdef CORBO_HIP_LEVEL_STAMPS
+#define SWEEP_STAMP(id) do { } while (0)
+#else
 #define SWEEP_STAMP(id)                                                     \
     do {                                                                    \
         if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); \
     } while (0)
+#endif
 
 // Row c of  U (x - ref)  for a vertex with a NON-DIAGONAL weight (quadratic_cost.cpp:116-118, 148-150, final_state_cost.cpp:88-90:
 // `cost.noalias() = _Q_sqrt * xd` with xd = x_k - xref(k), U = the upper Cholesky factor kept by setWeightQ / setWeightR / setWeightQf).
@@ -227,7 +231,7 @@ __device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc
 // generically (values before the chi2 reduction, central-difference blocks with the other Jacobian entries).  Stand-alone kernels only.
 template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS, bool XE = false, bool NOJAC = false>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false,
-                                           StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr)
+                                           StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr, const bool in_loop = false)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -672,7 +676,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double val = e[i] * p.w_eq;
-            put_value(p.eq_row0 + (XE ? k * p.eq_stride + p.eq_defect_off : k * NX) + i, val);   // (LEAN: still stored -- the one-pass-per-launch mode picks the rows up from HBM in the next launch)
+            // (LEAN: the factor phase takes the rows from registers, StageKeep; stored all the same when the next factor phase is another LAUNCH.  Inside the
+            //  run-to-completion loop nobody reads them -- and on gfx9 the first load the factor phase waits for would wait for these stores'
+            //  acknowledgements too, a memory round trip on the critical path of every pass)
+            if (!(LEAN && in_loop)) put_value(p.eq_row0 + (XE ? k * p.eq_stride + p.eq_defect_off : k * NX) + i, val);
             sq_acc += val * val;
             if constexpr (LEAN) kt.r[i] = val;
         }
@@ -1144,10 +1151,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if constexpr (STAGE) {
         lds_barrier();
     SWEEP_STAMP(7);
+        // (run-to-completion loop, two-wave shape: the factor phase of this pass streams the range out behind its own loads -- stream_jacobian_range --
+        //  so that nothing on the pass's critical path waits for the write acknowledgements)
+        if (LEAN && in_loop) return;
         // ---- stream the Jacobian values to HBM: 16 bytes per lane, fully coalesced
         // (stand-alone kernel: streaming stores -- the consumer is a later launch and 1024 Jacobians do not fit the L2 anyway, +7 % on the
         //  sweep; fused kernel: normal stores -- the pass after a rejected step reads its Jacobian back from the L2, streaming costs 3 %)
-        for (int i = tid; i < p.nnz_pad / 2; i += THREADS) {
+        // (two-wave run-to-completion shape: only the range the factor phase of a later pass re-reads -- SweepParams::jlean_*; the cost blocks and bound
+        //  rows of the stage components are not even assembled in the staging area there, they travel in registers)
+        const int so_lo = (LEAN && p.jlean_hi2 > 0) ? p.jlean_lo2 : 0, so_hi = (LEAN && p.jlean_hi2 > 0) ? p.jlean_hi2 : p.nnz_pad / 2;
+        for (int i = so_lo + tid; i < so_hi; i += THREADS) {
             const double2 v = reinterpret_cast<const double2*>(jst)[i];
             if constexpr (FUSED) reinterpret_cast<double2*>(js)[i] = v;
             else {
@@ -1157,6 +1170,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     SWEEP_STAMP(8);
     }
+}
+
+// the lean range of the staged Jacobian (SweepParams::jlean_*) from LDS to HBM, for the passes that follow a rejected step
+template <int THREADS>
+__device__ __forceinline__ void stream_jacobian_range(const SweepParams& p, const double* jst, const int inst, const int tid)
+{
+    double* js = p.jac + (size_t)inst * p.nnz_pad;
+    const int lo = (p.jlean_hi2 > 0) ? p.jlean_lo2 : 0, hi = (p.jlean_hi2 > 0) ? p.jlean_hi2 : p.nnz_pad / 2;
+    for (int i = lo + tid; i < hi; i += THREADS) reinterpret_cast<double2*>(js)[i] = reinterpret_cast<const double2*>(jst)[i];
 }
 
 template <int DYN, int DEFECT, bool DENSE = false, bool LONG = false, bool XE = false, bool NOJAC = false>
@@ -1370,12 +1392,48 @@ __device__ __forceinline__ double quad_bcast(double v)
     return __hiloint2double(hi, lo);
 }
 
+#ifndef CORBO_HIP_TWISTED_TOP
+#define CORBO_HIP_TWISTED_TOP 1      // (0: cyclic reduction up to the root, for A/B)
+#endif
+#ifndef CORBO_HIP_SOLO_LAST_LEVEL
+#define CORBO_HIP_SOLO_LAST_LEVEL 1  // (0: the last back-substitution level in two rounds of quads, for A/B)
+#endif
+#ifndef CORBO_HIP_COMPACT_LEVELS
+#define CORBO_HIP_COMPACT_LEVELS 1   // (0: the two-round h = 2 level of round 4, for A/B)
+#endif
 #define SOA(arr, e, k) (arr)[(e) * NP + (k)]
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower triangle, i >= j
 #define STAMP(id)                                                       \
     do {                                                                \
         if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); \
     } while (0)
+
+// twisted top of the block-tridiagonal elimination (factor_body): the level h (a power of two >= 4) at which at most eight and at least three blocks are left
+__host__ __device__ constexpr int twist_level(int N)
+{
+    for (int h = 4; h < N; h <<= 1) {
+        const int nb = (N + h - 1) / h;
+        if (nb <= 8) return nb >= 3 ? h : 0;
+    }
+    return 0;
+}
+// value of lane 0 of the caller's lane PAIR (0,1), (2,3), ...: DPP quad_perm [0,0,2,2]
+__device__ __forceinline__ double pair_bcast0(double v)
+{
+    constexpr int ctrl = 0 | (0 << 2) | (2 << 4) | (2 << 6);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// ... and of lane 1 of the pair: quad_perm [1,1,3,3]
+__device__ __forceinline__ double pair_bcast1(double v)
+{
+    constexpr int ctrl = 1 | (1 << 2) | (3 << 4) | (3 << 6);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 
 // LDS carve of factor_body (doubles), shared with the fused pass kernel
 template <int NX, int NU>
@@ -1469,9 +1527,13 @@ __device__ __noinline__ void dense_cost_terms(const StageCols*, const CompInfo* 
 // -- cost and bound values and their Jacobian entries -- are re-evaluated from the accepted iterate (diagonal_rows, the very function the sweep
 // phase sums chi2 with) instead of being fetched: the sweep phase does not store them, and the load phase loses its dependent round trip
 // (table entry -> residual row).
-template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false, bool RECOMP = false>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// after_gather: called once every lane holds its Jacobian entries and before the staging area is released -- the run-to-completion kernel streams the
+// freshly evaluated Jacobian out there and does its per-CU bookkeeping: memory operations that nothing in the factor phase waits for, issued BEHIND the
+// phase's own loads (gfx9 returns vector-memory operations in order: a load's wait includes every store and every slow load issued before it).
+template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false, bool RECOMP = false, class Hook = NoHook>
 __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr, const SweepParams* const sq = nullptr,
-                                            const StageKeep<NX, NU>* const keep = nullptr, const bool keep_valid = false)
+                                            const StageKeep<NX, NU>* const keep = nullptr, const bool keep_valid = false, Hook&& after_gather = Hook{})
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
@@ -1585,14 +1647,17 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     }
     // (3) Jacobian staging
     const double* J = GWS ? p.jac + (size_t)inst * p.nnz_pad : smem;
+    // (measured and not kept: after a rejected step lane k gathering its stage's defect block straight from HBM / L2 instead of staging the range in LDS
+    //  first -- the load phase 4.7 k -> 3.9 k cycles, but one pointer for two address spaces makes every access of J a flat access: the solve 0.471 -> 0.478 ms)
     if (!GWS && !j_in_lds) {
         const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
         double2* dst       = reinterpret_cast<double2*>(smem);
-        const int n2       = p.nnz_pad / 2;
+        const int lo2      = (RECOMP && p.jlean_hi2 > 0) ? p.jlean_lo2 : 0;                  // (RECOMP: the range the sweep phase streamed out, FactorParams::jlean_*)
+        const int n2       = (RECOMP && p.jlean_hi2 > 0) ? p.jlean_hi2 : p.nnz_pad / 2;
         // loads in flight per lane (8 costs 3 % of a solve at the 128-VGPR budget) (branch-free: indices are clamped, the duplicates are harmless);
         // the two-wave shape of the run-to-completion kernel has the registers for the whole headline Jacobian in ONE round trip (17 x 128 x 16 bytes)
         constexpr int UNR  = (THREADS <= 128) ? 8 : 4;   // (17 -- the whole headline Jacobian in one round trip of the two-wave shape -- was measured: 5.2 k -> 7.2 k cycles alone, 14 k+ under load)
-        for (int i0 = tid; i0 < n2; i0 += THREADS * UNR) {
+        for (int i0 = lo2 + tid; i0 < n2; i0 += THREADS * UNR) {
             double2 v[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) { const int i = i0 + u * THREADS; v[u] = src[i < n2 ? i : n2 - 1]; }
@@ -1667,6 +1732,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             if (ci.bnd_joff >= 0) { const double a = J[ci.bnd_joff]; cdt += a * a; gdt -= a * val[ci.bnd_row]; }
         }
     }
+    after_gather();
     fb_barrier();  // every lane has taken its Jacobian entries out of the staging area
     STAMP(1);
 
@@ -1888,19 +1954,39 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     // exchange) and factors it; lane j < NX then produces column j of the new couplings W_a and W_b, lane NX the right-hand side.
     // What differs between the lanes is only WHERE their 3-vector operand comes from / goes to (column j of W, or the rhs slot), i.e.
     // a base pointer and a stride -- the instruction stream is the same.
-    int hroot = 2;
-    for (int h = 2, lg = 1;; h <<= 1, ++lg) {   // h = 2^lg
-        const int j     = tid & 3;
+    // One level as a generic lambda: instantiated for the regular lane mapping (the loop below; everything that depends on the lane's role is
+    // loop-invariant there) and, two-wave shape only, once more for the COMPACT mapping of the first level (peeled: with the choice inside the loop the
+    // role-dependent pointers became loop-variant and every OTHER level paid 150 - 270 cycles for it -- measured with one stamp per level).
+    auto cr_level = [&](const int h, const int lg, auto compact_tag, auto top_tag) {
+        constexpr bool COMPACT = decltype(compact_tag)::value;
+        constexpr bool TOP     = decltype(top_tag)::value;   // assembly of the top system only (twisted top, below): no block is eliminated at this level
         const int hh    = h >> 1;
         const bool root = (h >= N);                                      // only a == 0 is active then
         static_assert(NX <= 4, "four lanes per block: NX columns (+ one right-hand-side lane when NX <= 3)");
         // NX = 4 leaves no spare lane for the right-hand side: every lane carries it as a SECOND operand (redundantly, same
         // instruction stream) and lane 0 stores it.
         constexpr bool RHS2 = (NX == 4);
+        const int nblk  = (N + h - 1) >> lg;
+        // Lane -> (block t, role j).  Regular: four lanes per block, THREADS / 4 blocks per round.  COMPACT (two-wave shape; a level with more blocks than
+        // quads -- h = 2: 50 blocks, 32 quads -- would take two rounds): only the blocks that are ELIMINATED at this level (odd t) need the column lanes; a
+        // block that is merely updated (even t) needs its right-hand-side lane alone.  Four lanes per odd block + one per even block make it ONE round.
+        // Quads and single lanes are dealt to the two waves half and half: the blocks of a level are 2 doubles apart in the SoA arrays (16 distinct
+        // bank groups), so a wave that held all the single lanes would serialise its LDS reads four-fold (measured: +1.5 k cycles per pass).
+        int j = tid & 3, t_first = tid >> 2, t_step = THREADS / 4;
+        if constexpr (COMPACT) {
+            const int n_el = nblk >> 1, n_ne = nblk - n_el;
+            const int nq0 = (n_el + 1) >> 1, ns0 = n_ne >> 1;   // wave 0's quads / single lanes
+            const int w = tid >> 6, l = tid & 63;
+            const int nq = w ? n_el - nq0 : nq0, ns = w ? n_ne - ns0 : ns0;
+            const int qb = w ? nq0 : 0, sb = w ? ns0 : 0;
+            t_step = nblk;
+            if (l < 4 * nq) t_first = 2 * (qb + (l >> 2)) + 1;
+            else if (l < 4 * nq + ns) { t_first = 2 * (sb + l - 4 * nq); j = RHS2 ? 0 : NX; }
+            else t_first = nblk;
+        }
         const bool vec  = !RHS2 && (j == NX);
         const bool col  = (j < NX);
-        const int nblk  = (N + h - 1) >> lg;
-        for (int t = tid >> 2; t < nblk; t += THREADS / 4) {   // (one round whenever 4 * ceil(N / h) <= THREADS)
+        for (int t = t_first; t < nblk; t += t_step) {   // (one round whenever 4 * ceil(N / h) <= THREADS, or compact)
         const int a      = h * t;
         const bool has_m = (a - hh >= 0), has_p = (a + hh < N);
         const int em = has_m ? a - hh : (ZSLOT ? N : a), ep = has_p ? a + hh : (ZSLOT ? N : a);       // clamped: absent neighbours are fetched from a and zeroed (ZSLOT: from the zero slot)
@@ -1977,7 +2063,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             r1[q] = RHS2 ? g[q] - vr[q] : 0.0;
             r2[q] = (RHS2 && ARROW) ? bb[q] - (wm[q] + wp[q]) : 0.0;
         }
-        if (elim || root) {
+        if (!TOP && (elim || root)) {
             chol_inv<NX>(D);
             fwd_solve_vec<NX>(D, c1);
             if (ARROW || !vec) fwd_solve_vec<NX>(D, c2);
@@ -2011,7 +2097,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
                 for (int c = 0; c <= q; ++c) SOA(Dm, TRI(q, c), a) = D[q][c];
             }
         }
-        else if (col && elim && !root) {
+        else if (col && (TOP || (elim && !root))) {   // (TOP: the raw couplings H(a, a -+ h) of every top block, for the chains)
 #pragma unroll
             for (int q = 0; q < NX; ++q) { SOA(Wam, q * NX + j, a) = c1[q]; SOA(Wbm, q * NX + j, a) = c2[q]; }
         }
@@ -2027,7 +2113,168 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             }
         }
         }
+    };
+    int hroot = 2, h_first = 2, lg_first = 1;
+    if constexpr (CORBO_HIP_COMPACT_LEVELS && THREADS == 128 && !GWS) {
+        const int nblk2 = (N + 1) >> 1, n_el = nblk2 >> 1, n_ne = nblk2 - n_el, nq0 = (n_el + 1) >> 1, ns0 = n_ne >> 1;
+        if (4 * nblk2 > THREADS && 4 * nq0 + ns0 <= 64 && 4 * (n_el - nq0) + (n_ne - ns0) <= 64) {   // (more blocks than quads at h = 2: N > 64, so h = 2 is not the root level)
+            cr_level(2, 1, std::true_type{}, std::false_type{});
+#ifdef CORBO_HIP_LEVEL_STAMPS
+            STAMP(8 + 1);
+#endif
+            fb_barrier();
+            h_first = 4; lg_first = 2;
+        }
+    }
+    // TWISTED TOP (two-wave shape, headline stride).  Once at most eight blocks are left (N = 100: the seven blocks 0, 16, ..., 96 at h = 16) the remaining
+    // block-tridiagonal system is not reduced by three or four more levels -- each a barrier, 33 LDS loads per lane, two-sided Schur updates, a 3 x 3
+    // Cholesky and the stores, ~ 2 k cycles whatever the number of blocks -- but ASSEMBLED once (one level without eliminations: updated diagonal blocks,
+    // right-hand sides and the raw couplings between neighbouring top blocks) and eliminated by two lanes from both ends towards the middle block
+    // (block Thomas steps: one-sided update, the running block stays in registers, no barrier, the next block's loads ride under the Cholesky), then
+    // back-substituted outwards by the same two lanes.  Sequential depth: ceil(nb / 2) steps instead of log2(nb) + 1 levels, but a step is less than
+    // half a level.  Same matrix, another elimination order for its last few blocks: rounding-level differences (like the partitioned chain of the
+    // big-block family); |y|^2 sums the same quantity g^T H^-1 g.
+    // (the running blocks, the factors and the couplings of the chains stay in REGISTERS: the step count is a compile-time constant of the headline
+    //  stride -- N is NPC - 1 or NPC --, the loops are unrolled, nothing but the solution of the top blocks goes back to LDS)
+    constexpr int TW_HS = twist_level(NPC), TW_NB = TW_HS ? (NPC + TW_HS - 1) / TW_HS : 0;
+    constexpr bool TWIST = CORBO_HIP_TWISTED_TOP && THREADS == 128 && NPC > 0 && !ARROW && !GWS && !DENSE && NX <= 3 && TW_HS > 0 &&
+                           (NPC - 1 + TW_HS - 1) / TW_HS == TW_NB;   // (the same block count for N = NPC - 1 and N = NPC)
+    const int hs = TWIST ? TW_HS : 0;   // the level at which the top system is assembled (0: never)
+    for (int h = h_first, lg = lg_first;; h <<= 1, ++lg) {   // h = 2^lg
+        if constexpr (TWIST) {
+            if (h == hs) {
+                cr_level(h, lg, std::false_type{}, std::true_type{});
+                fb_barrier();
+#ifdef CORBO_HIP_LEVEL_STAMPS
+                STAMP(13);
+#endif
+                if (tid < 2) {   // lane 0: blocks 0 .. m - 1 upwards, then the middle block m; lane 1: blocks nb - 1 .. m + 1 downwards
+                    constexpr int nb = TW_NB, m = nb >> 1, NSMAX = m;   // (m >= nb - 1 - m)
+                    const bool up = (tid == 0);
+                    const int nsteps = up ? m : nb - 1 - m;
+                    const int di = up ? 1 : -1;
+                    const double* const Wf = up ? Wbm : Wam;   // raw coupling towards the next block in this lane's direction, H(a, a +- hs)
+                    const int i0 = up ? 0 : nb - 1;
+                    double D[NX][NX], g[NX];
+                    double Ls[NSMAX][NX][NX], Ys[NSMAX][NX][NX], ys[NSMAX][NX];   // per eliminated block: L (diagonal inverted), Y = L^-1 H, y = L^-1 g
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        g[q] = SOA(gv, q, hs * i0);
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) D[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), hs * i0) : 0.0;
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < NSMAX; ++s_) {
+                        if (s_ < nsteps) {
+                            const int a = hs * (i0 + s_ * di), an = a + hs * di;
+                            double Dn[NX][NX], gn[NX];
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) {
+                                gn[q] = SOA(gv, q, an);
+#pragma unroll
+                                for (int c = 0; c < NX; ++c) { Ys[s_][q][c] = SOA(Wf, q * NX + c, a); Dn[q][c] = (c <= q) ? SOA(Dm, TRI(q, c), an) : 0.0; }
+                            }
+                            chol_inv<NX>(D);
+                            fwd_solve<NX, NX>(D, Ys[s_]);
+                            fwd_solve_vec<NX>(D, g);
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) {
+                                y2 += g[q] * g[q];
+                                ys[s_][q] = g[q];
+#pragma unroll
+                                for (int c = 0; c < NX; ++c) Ls[s_][q][c] = D[q][c];
+                            }
+#pragma unroll
+                            for (int c1_ = 0; c1_ < NX; ++c1_) {
+                                double sv = 0;
+#pragma unroll
+                                for (int q = 0; q < NX; ++q) sv += Ys[s_][q][c1_] * g[q];
+                                gn[c1_] -= sv;
+#pragma unroll
+                                for (int c2_ = 0; c2_ <= c1_; ++c2_) {
+                                    double sd = 0;
+#pragma unroll
+                                    for (int q = 0; q < NX; ++q) sd += Ys[s_][q][c1_] * Ys[s_][q][c2_];
+                                    Dn[c1_][c2_] -= sd;
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) {
+                                g[q] = gn[q];
+#pragma unroll
+                                for (int c = 0; c < NX; ++c) D[q][c] = Dn[q][c];
+                            }
+                        }
+                    }
+#ifdef CORBO_HIP_LEVEL_STAMPS
+                    asm volatile("" :: "v"(D[0][0]), "v"(g[0]));
+                    STAMP(14);
+#endif
+                    // the middle block: both lanes hold their one-sided version  D_m - U_side, g_m - v_side;  lane 0 combines them with the assembled block
+                    // (lane 1's version reaches lane 0 through DPP moves inside the pair: no LDS round trip)
+                    const int am = hs * m;
+                    double xn[NX];
+                    {
+                        double Do[NX][NX], go[NX];
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            go[q] = pair_bcast1(g[q]);
+#pragma unroll
+                            for (int c = 0; c <= q; ++c) Do[q][c] = pair_bcast1(D[q][c]);
+                        }
+                        if (up) {
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) {
+                                g[q] += go[q] - SOA(gv, q, am);
+#pragma unroll
+                                for (int c = 0; c <= q; ++c) D[q][c] += Do[q][c] - SOA(Dm, TRI(q, c), am);
+                            }
+                            chol_inv<NX>(D);
+                            fwd_solve_vec<NX>(D, g);
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) y2 += g[q] * g[q];
+                            bwd_solve_vec<NX>(D, g);
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) SOA(gv, q, am) = g[q];
+                        }
+                    }
+                    // x_m to the other chain's lane: a quad-local broadcast from lane 0 (both lanes of the pair are active)
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) xn[q] = pair_bcast0(g[q]);
+#ifdef CORBO_HIP_LEVEL_STAMPS
+                    STAMP(15);
+#endif
+                    // back-substitution outwards from the middle:  x_i = L_i^-T (y_i - Y_i x_next), everything in registers
+#pragma unroll
+                    for (int s_ = NSMAX - 1; s_ >= 0; --s_) {
+                        if (s_ < nsteps) {
+                            const int a = hs * (i0 + s_ * di);
+                            double v[NX];
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) {
+                                double t_ = ys[s_][q];
+#pragma unroll
+                                for (int c = 0; c < NX; ++c) t_ -= Ys[s_][q][c] * xn[c];
+                                v[q] = t_;
+                            }
+                            bwd_solve_vec<NX>(Ls[s_], v);
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) { SOA(gv, q, a) = v[q]; xn[q] = v[q]; }
+                        }
+                    }
+                }
+                hroot = hs;
+#ifdef CORBO_HIP_LEVEL_STAMPS
+                STAMP(8 + lg);
+#endif
+                break;
+            }
+        }
+        cr_level(h, lg, std::false_type{}, std::false_type{});
         hroot = h;
+#ifdef CORBO_HIP_LEVEL_STAMPS
+        STAMP(8 + lg);
+#endif
         if (h >= N) break;
         fb_barrier();
     }
@@ -2121,6 +2368,28 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
             for (int r = 1; r < NX; ++r) xq = (q == r) ? x[r] : xq;
             if (q < NX) SOA(gv, q, i) = xq;
         };
+        // SOLO last level (two-wave shape): the level h = 1 has N / 2 blocks -- more than the workgroup has quads (50 against 32 at N = 100), two rounds of
+        // the quad scheme.  One lane per block instead: every row of  v = y - W_a x_a - W_b x_b  and the triangular solve in the same lane (no exchange,
+        // three times the multiply-adds of a quad lane, but ONE round); the factor data of the block -- final since the forward sweep -- is requested
+        // before the levels above run, their barriers hide the latency.  The blocks are dealt to the two waves half and half (LDS bank groups, see the
+        // compact level of the forward sweep).
+        constexpr bool SOLO_OK = CORBO_HIP_SOLO_LAST_LEVEL && (THREADS == 128) && (NPC > 0) && !GWS && !ARROW;
+        const int nb1 = N >> 1, nb1h = (nb1 + 1) >> 1;                       // blocks 1, 3, ..; wave 0's share
+        const bool solo = SOLO_OK && (4 * nb1 > THREADS) && nb1h <= 64 && hroot > 2;
+        const int tsolo = (tid < 64) ? tid : nb1h + (tid - 64);
+        const bool solo_on = solo && ((tid < 64) ? (tid < nb1h) : (tsolo < nb1));
+        double sL[NX][NX], sWa[NX][NX], sWb[NX][NX], sy[NX];
+        if constexpr (SOLO_OK) {
+            if (solo_on) {
+                const int i = 2 * tsolo + 1;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    sy[r] = SOA(gv, r, i);
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) { sWa[r][c] = SOA(Wam, r * NX + c, i); sWb[r][c] = SOA(Wbm, r * NX + c, i); sL[r][c] = (c <= r) ? SOA(Dm, TRI(r, c), i) : 0.0; }
+                }
+            }
+        }
         int h = hroot >> 1;
         fetch(h, tid >> 2);
         constexpr bool PREFETCH = false && (THREADS < 256) && (NPC > 0) && !GWS;   // measured in the two-wave shape: back-substitution 5.9 k -> 7.0 k cycles -- off   // register-rich shapes: the factor data of the NEXT level (final since the
@@ -2156,10 +2425,30 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
                 fb_barrier();
             }
             else {
+            if constexpr (SOLO_OK) {
+                if (h == 1 && solo) {
+                    if (solo_on) {
+                        const int i = 2 * tsolo + 1, a = i - 1, b = i + 1, bc = (b < N) ? b : a;
+                        double v[NX];
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) {
+                            double t_ = sy[r];
+#pragma unroll
+                            for (int c = 0; c < NX; ++c) t_ -= sWa[r][c] * SOA(gv, c, a) + sWb[r][c] * SOA(gv, c, bc);
+                            v[r] = t_;
+                        }
+                        bwd_solve_vec<NX>(sL, v);
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) SOA(gv, r, i) = v[r];
+                    }
+                    fb_barrier();
+                    break;
+                }
+            }
             if (h * (2 * (tid >> 2) + 1) < N) finish(h, tid >> 2);
             for (int t = (tid >> 2) + THREADS / 4; h * (2 * t + 1) < N; t += THREADS / 4) { fetch(h, t); finish(h, t); }  // long horizons
             fb_barrier();
-            if (h > 1) fetch(h >> 1, tid >> 2);
+            if (h > 1 && !(SOLO_OK && solo && h == 2)) fetch(h >> 1, tid >> 2);
             }
         }
     }
@@ -3946,7 +4235,7 @@ void big_chain3_kernel(const FactorParams p)
 // the slow instances of the tail run at single-instance latency (0.81 ms instead of 1.09 ms per headline solve).  The loop needs
 // two precautions against the compiler carrying state around it: the kernel arguments are re-read from the kernarg segment each
 // pass, and the library is built with -disable-machine-licm (hoisted math-library constants were spilled to scratch otherwise).
-// row of this wave's CU in the per-CU progress table: [0] workgroups present, [1..8] their outer iteration + 1 (0 = empty slot)
+// row of this wave's CU in the per-CU progress table (16 ints): [0] workgroups present, [2..3] = eight BYTES, their outer iteration + 1 (0 = empty slot)
 __device__ __forceinline__ int32_t* cu_row_of(int32_t* table)
 {
     unsigned hw, xcc;
@@ -4052,6 +4341,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 const SweepParams& spl  = (const SweepParams&)ka->s;
                 const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;
                 if (stamp) fpl.pass_timeline[2 * pass] = clock64();
+                const bool pcyc = fpl.phase_cycles && tid_v == 0;   // (diagnostics: per-instance phase totals, corbo_hip_get_phase_cycles)
+                long long pc_t0 = 0;
+                if (pcyc) pc_t0 = clock64();
                 if (pass > 0) {
                     // (no barrier: lane 0 itself is the next writer of flags[0] -- the sweep phase's decision -- and every reader sits behind that
                     //  phase's barriers; the previous pass's readers are through, the pass ended with a workgroup barrier)
@@ -4066,10 +4358,18 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                         }
                     }
                 }
-                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep);   // (active_count: per-pass launches only)
+                constexpr bool TWOW = (THREADS <= 128);   // two-wave shape: Jacobian stream-out and bookkeeping ride inside the factor phase (factor_body, after_gather)
+                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep, TWOW && max_passes > 0);   // (active_count: per-pass launches only)
                 __threadfence_block();
                 __syncthreads();
                 if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
+                if (pcyc) {
+                    const long long t1 = clock64();
+                    long long* row = fpl.phase_cycles + (size_t)inst_v * 8;
+                    const int w = flags[0] != 0 ? 0 : 1;
+                    row[w] += t1 - pc_t0; row[3 + w] += 1;
+                    pc_t0 = t1;
+                }
                 if (sl->done) break;
                 // lag-based issue priority: the SIMD arbiter prefers older waves, so the workgroups dispatched last to a CU run every
                 // pass ~40 % slower than the first ones while the CU is full -- and the launch ends with the slowest chain.  Every
@@ -4079,34 +4379,49 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 // of the workgroup at the phase's first barrier (measured: 2 k of the 4.3 k cycles between the two phases).
                 // (four-wave shape: ranked at once -- eleven more live registers across the factor phase cost 26 more spills at its 128-VGPR budget)
                 constexpr bool BK_DEFER = THREADS < SWEEP_THREADS;
-                int bk_slot = -1, bk_k = 0, bk_cnt = 0, bk_row[8];
+                int bk_slot = -1, bk_k = 0;
+                unsigned long long bk_word = 0;
                 auto bk_rank = [&] {
-                    int rank = 0;
+                    int rank = 0, bk_cnt = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bk_cnt += ((bk_word >> (8 * q)) & 0xFFull) ? 1 : 0;
                     const int rot = (bk_slot > 3 || bk_cnt > 4) ? 7 : 3;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int kq = bk_row[q] - 1;   // -1: empty slot
+                        const int kq = (int)((bk_word >> (8 * q)) & 0xFFull) - 1;   // -1: empty slot
                         if (q != bk_slot && kq >= 0 && (kq < bk_k || (kq == bk_k && ((pass - q) & rot) < ((pass - bk_slot) & rot)))) ++rank;   // ties: rotating order (the arbiter's own tie-break is age)
                     }
                     flags[2] = rank > 3 ? 0 : 3 - rank;
                 };
-                if (fpl.cu_table && tid_v == BK_LANE) {
-                    int32_t* row = cu_row_of(fpl.cu_table);
-                    bk_slot = flags[3];
-                    if (bk_slot < 0) { bk_slot = atomicAdd(row, 1) & 7; flags[3] = bk_slot; }
-                    bk_k = sl->k;
-                    __hip_atomic_store(row + 1 + bk_slot, bk_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bk_cnt = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) bk_row[q] = __hip_atomic_load(row + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if constexpr (!BK_DEFER) bk_rank();
-                }
+                auto bk_publish = [&] {
+                    // (measured and not kept: the bookkeeping in every other pass only -- 0.463 ms either way)
+                    if (fpl.cu_table && tid_v == BK_LANE) {
+                        int32_t* row = cu_row_of(fpl.cu_table);
+                        bk_slot = flags[3];
+                        if (bk_slot < 0) { bk_slot = atomicAdd(row, 1) & 7; flags[3] = bk_slot; }
+                        bk_k = sl->k;
+                        // the eight slots of the row are BYTES of one 64-bit word (outer iteration + 1 <= 255; 0 = empty): one byte store and one 8-byte load per
+                        // pass instead of one store and nine loads -- every one of them a trip to the L2 that the lane's later loads queue up behind
+                        __hip_atomic_store(reinterpret_cast<unsigned char*>(row + 2) + bk_slot, (unsigned char)((bk_k + 1) & 0xFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bk_word = __hip_atomic_load(reinterpret_cast<unsigned long long*>(row + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (!BK_DEFER) bk_rank();
+                    }
+                };
+                if constexpr (!TWOW) bk_publish();
+                const bool j_fresh = flags[0] != 0;
+                auto hook = [&] {   // (two-wave shape: behind the factor phase's own loads)
+                    if constexpr (TWOW) {
+                        if (max_passes > 0 && j_fresh) stream_jacobian_range<THREADS>(spl, jst, inst_v, tid_v);
+                        bk_publish();
+                    }
+                };
                 // (loop_passes = 0: ONE pass per launch -- the per-pass mode of corbo_hip_solve and the profiling mode; the trial iterate then
                 //  goes to HBM for the next launch instead of staying in the LDS array the next sweep phase evaluates it from)
-                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, false, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, flags[0] != 0, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || flags[0] != 0);
+                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, false, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook);
                 if constexpr (BK_DEFER) { if (bk_slot >= 0) bk_rank(); }
                 __threadfence_block();
                 __syncthreads();
+                if (pcyc) { long long* row = fpl.phase_cycles + (size_t)inst_v * 8; row[2] += clock64() - pc_t0; row[5] += 1; }
                 if (stamp && fpl.timeline) {   // diagnostics: the phase stamps of this pass (factor [0,8), sweep [8,18)) into the per-pass log
                     long long* lg = fpl.pass_timeline + 150 + 18 * pass;
                     for (int q = 0; q < 18; ++q) { lg[q] = fpl.timeline[q]; fpl.timeline[q] = 0; }
@@ -4117,7 +4432,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
             const FactorParams& fe = (const FactorParams&)ka->f;
             if (fe.cu_table && tid_v == BK_LANE && flags[3] >= 0) {   // leave the CU's progress row (the table is all zeros again when the launch retires)
                 int32_t* row = cu_row_of(fe.cu_table);
-                __hip_atomic_store(row + 1 + flags[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned char*>(row + 2) + flags[3], (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicSub(row, 1);
             }
             lm_state_out(fe.st + inst_v, sl, tid_v);   // the host reads status and counters from HBM

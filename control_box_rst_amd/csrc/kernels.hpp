@@ -70,6 +70,8 @@ struct SweepParams {
     double* values1;    // [batch][m]   residual buffer 1 (LM only)
     double* jac;        // [batch][nnz_pad]
     int32_t m_pad, nnz_pad;
+    int32_t jlean_lo2, jlean_hi2;   // [lo, hi) in double2 units: the part of the Jacobian the two-wave run-to-completion shape moves between its phases (defect / inequality / special
+                                    // blocks; the cost blocks and bound rows of the stage components travel in registers, StageKeep); 0, 0: everything
     LmState* st;
     int32_t* active_count;  // number of instances not done after this pass (mode 3)
     long long* timeline;    // optional [16] shader-clock stamps of instance `timeline_inst` (diagnostics), may be null
@@ -101,9 +103,13 @@ struct FactorParams {
     const double* values1;
     const double* jac;
     int32_t m_pad, nnz_pad;
+    int32_t jlean_lo2, jlean_hi2;   // [lo, hi) in double2 units: the part of the Jacobian the two-wave run-to-completion shape moves between its phases (defect / inequality / special
+                                    // blocks; the cost blocks and bound rows of the stage components travel in registers, StageKeep); 0, 0: everything
     LmState* st;
     double* delta_out;            // optional [batch][nvs] (debug / tests), may be null
     long long* timeline;          // optional [8] shader-clock stamps of instance `timeline_inst` (diagnostics), may be null
+    long long* phase_cycles;      // optional [batch][8] (diagnostics, run-to-completion kernel): shader-clock cycles every instance's workgroup spent in sweep phases that
+                                  // end with a Jacobian [0] / residual-only sweep phases [1] / factor phases [2], and their counts [3], [4], [5]; may be null
     int32_t timeline_inst;
     double* work;                 // big-block kernel only: per-instance factor workspace in HBM
     int64_t work_stride;          // doubles per instance

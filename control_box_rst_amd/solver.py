@@ -255,6 +255,12 @@ class BatchedLevenbergMarquardt:
         """Let the solve kernel write the results into the handle's pinned host memory itself (see corbo_hip_set_result_sink)."""
         self._check(self.lib.corbo_hip_set_result_sink(self._h, 1 if enable else 0), "corbo_hip_set_result_sink")
 
+    def get_phase_cycles(self) -> np.ndarray:
+        """Per-instance phase totals of the last run-to-completion solve (option "phase_cycles"): [batch][8] int64, see corbo_hip_get_phase_cycles."""
+        out = np.zeros((self.batch, 8), np.int64)
+        self._check(self.lib.corbo_hip_get_phase_cycles(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))), "corbo_hip_get_phase_cycles")
+        return out
+
     def get_timing(self, reset=False):
         """(sum of the HIP-event times [ms] of the solves since the last reset, number of solves)."""
         ms, n = C.c_double(0), C.c_int64(0)

@@ -460,6 +460,14 @@ int corbo_hip_set_result_sink(corbo_hip_handle h, int enable);
  * last reset: the average launch duration of the run-to-completion solve kernel, measured live (bench.py roofline object). */
 int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solves, int reset);
 
+/* Measurement hook (bench.py `roofline_sweep_phase`, profiles/rNN_pass_phases.json): with corbo_hip_set_option(h, "phase_cycles", 1) the
+ * run-to-completion solve kernel adds up, per instance, the shader-clock cycles its workgroup spends in the phases of an LM pass -- the hot path of
+ * LevenbergMarquardtSparse::solve (levenberg_marquardt_sparse.cpp:129-215) split where the reference splits it: residual + Jacobian sweeps
+ * (computeValues + computeCombinedSparseJacobian, :97-100, :178-199), residual-only sweeps of rejected trial steps (:160-169), factor phases
+ * (H + mu I, SimplicialLLT, solve: :135-158).  out [batch][8] of the LAST solve: cycles [0] Jacobian sweep phases, [1] residual-only sweep phases,
+ * [2] factor phases; counts [3], [4], [5]; [6], [7] unused.  Two clock reads per phase: the solve is ~ 1 % slower with the option on. */
+int corbo_hip_get_phase_cycles(corbo_hip_handle h, int64_t* out);
+
 /* Parity hook for SURVEY rows a2-a6: evaluate the stacked residual
  * (LevenbergMarquardtSparse::computeValues, levenberg_marquardt_sparse.cpp:222-246) and, if jac_out != NULL, the
  * combined Jacobian values (computeCombinedSparseJacobian, hyper_graph_optimization_problem_edge_based.cpp:1480-1753)
@@ -551,7 +559,9 @@ int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const dou
  *   "solve_timing"      0: corbo_hip_solve records no HIP timing events around its launches (corbo_hip_stats::solve_ms and corbo_hip_get_timing stay 0):
  *                       7 - 13 us less per call, what a caller that solves ONE problem per call wants (the drop-in adapter sets it)
  *   "ff_converged"      0: compute the outer iterations that follow a converged step instead of counting them (A/B and tests)
- *   "lag_priority"      0: no lag-based issue priority in the run-to-completion kernel */
+ *   "lag_priority"      0: no lag-based issue priority in the run-to-completion kernel
+ *   "phase_cycles"      1: per-instance phase totals of the run-to-completion kernel (corbo_hip_get_phase_cycles)
+ *   "raw_stamps"        1: "pass_timeline" prints raw stamp offsets (development builds that re-purpose the stamp slots) */
 int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value);
 
 /* Text of the last error on this thread. */

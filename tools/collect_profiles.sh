@@ -5,7 +5,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
-RND=${CORBO_PROFILE_ROUND:-r04}
+RND=${CORBO_PROFILE_ROUND:-r05}
 TAG="${1:-round ${RND#r0}}"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

@@ -22,5 +22,9 @@ for cfg in sys.argv[1:] or [""]:
         s.solve(new_run=True)
         ts.append(s.get_stats()["solve_ms"])
     X, chi2, st = s.get_solution()
-    if ref is None: ref = X.copy()
+    if ref is None:
+        ref = X.copy()
+        if os.environ.get("SAVE_X"): np.save(os.environ["SAVE_X"], X)
+        if os.environ.get("CMP_X") and os.path.exists(os.environ["CMP_X"]):
+            R = np.load(os.environ["CMP_X"]); print("   vs", os.environ["CMP_X"], ": identical", bool(np.array_equal(X, R)), "max |dx|", float(np.abs(X - R).max()), "stats", {k: s.get_stats()[k] for k in ("accepted_steps", "rejected_steps", "factorizations")})
     print(f"{cfg:30s} solve_ms min {min(ts[2:]):.4f} median {sorted(ts[2:])[len(ts[2:]) // 2]:.4f}  chi2_sum {chi2.sum():.6f}  identical_to_first {bool(np.array_equal(X, ref))}")

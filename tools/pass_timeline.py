@@ -13,6 +13,7 @@ s.setIterations(10)
 s.setPenaltyWeights(*w["weights"])
 X0 = s.init_trajectory(w["x0"], w["xf"])
 for rep in range(3):
+    if os.environ.get("RAW"): s.set_option("raw_stamps", 1)
     for kv in [c for c in os.environ.get("OPTS","").split(",") if c]: s.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     s.set_instance_data(X0, xref=w["xf"])
     if rep == 2:
