@@ -280,7 +280,12 @@ struct corbo_hip_solver {
         p.x = d_x; p.xt = d_xt; p.values0 = d_values0; p.values1 = d_values1; p.jac = d_jac; p.m_pad = m_pad; p.nnz_pad = nnz_pad; p.jlean_lo2 = jlean_lo2; p.jlean_hi2 = jlean_hi2;
         p.st = d_state; p.delta_out = nullptr;
         p.work = d_work; p.work_stride = (int64_t)work_stride;
-        p.chain_variant = chain_variant;
+        // big-block family, automatic choice of the partitioned chain: four segments (8 waves per instance: one workgroup fills a CU) while every instance of the
+        // handle gets a CU of its own in ONE round; two segments (4 waves, two workgroups per CU) for larger batches -- 512 instances are then one round
+        // instead of two rounds of single-instance latency (cfg 5: 8.33 -> 8.06 ms per solve; a single OCP: 1.76 against 2.03 ms, hence not always).
+        // By the HANDLE's batch, not the launch's active count: every pass of a handle factorises the same way (the segment count changes the
+        // elimination order, i.e. the iterates at rounding level -- tests/test_gpu_chain_variants.py).
+        p.chain_variant = (chain_variant == 0 && big_family_dims(S.nx, S.nu) && S.N >= 64 && num_cus > 0 && batch > num_cus) ? 4 : chain_variant;
         p.stage_cache = d_stage_cache; p.stage_cache_stride = (int64_t)stage_cache_stride;
         p.defect = S.desc.defect;
         p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
