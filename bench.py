@@ -341,6 +341,49 @@ def batch8192_leg(iterations, device, value_1024):
             "chi2_sum": float(chi2.sum()), "ok_instances": int((status <= 1).sum()), "slot_occupancy": util}
 
 
+def band_leg(device):
+    """The band factorisation (free dt around a big-block model; integral-form constraint edges / control-deviation edges): the general, slower path
+    (a measurement row).  Time-optimal 12-state quadrotor on the MultipleShootingVariableGrid, N = 100 (n = 1613 parameters, dt as border)."""
+    import torch
+    from control_box_rst_amd import problems
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt, get_dims, get_structure
+    out = {}
+    for B in (1, 64):
+        d = problems.quad_desc(N=100, time_optimal=True)
+        x0 = np.zeros((B, d.nx)); xf = np.zeros((B, d.nx)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
+        s = BatchedLevenbergMarquardt(d, B, device=device)
+        s.setPenaltyWeights(100.0, 100.0, 100.0)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.solve(new_run=True); s.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.restore_instance_data(); s.solve(new_run=True)
+        s.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        st = s.get_stats()
+        s.restore_instance_data()
+        f_ms = s.time_factor(repeat=3)
+        rows, cols = get_structure(d)
+        dims = get_dims(d)
+        n = dims.n
+        # half-bandwidth of H = J^T J in natural parameter order without the border (dt = the last parameter)
+        import scipy.sparse as sp
+        J = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(dims.m, n)).tocsr()[:, : n - 1]
+        H = (J.T @ J).tocoo()
+        bw = int(np.abs(H.row - H.col).max())
+        flops = float(n - 1) * (bw * bw + 3 * bw + 1) + 4.0 * (n - 1) * bw   # banded Cholesky + the two triangular solves (multiply-adds counted as 2)
+        out[f"batch{B}"] = {"ms_per_solve": ms, "passes": int(st["passes"]), "factorizations": int(st["factorizations"]),
+                            "band_assemble_plus_factor_ms_per_launch": f_ms, "parameters": n, "half_bandwidth": bw,
+                            "us_per_pivot": 1e3 * f_ms / (n - 1), "cycles_per_pivot_at_2p4GHz": 2.4e6 * f_ms / (n - 1),
+                            "flops_per_factorization_per_instance": flops,
+                            "achieved_GFLOPs": B * flops / (f_ms * 1e-3) / 1e9, "frac_of_fp64_vector_peak": B * flops / (f_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        del s
+    out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass"
+    out["bound"] = "latency: n sequential pivots per instance (one barrier each, eight waves on a sliding LDS window); the flop rate is quoted for completeness"
+    return out
+
+
 def sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms):
     """The sweep PHASE of the kernel the timed region runs: per-instance phase totals accumulated by lm_pass_kernel itself
     (corbo_hip_get_phase_cycles; one extra solve with the option on, outside the timed region).  `achieved` = algorithmic bytes of every Jacobian sweep of the
@@ -723,6 +766,10 @@ def main():
                 line["secondary"][f"config{c2}"] = secondary_leg(c2, args.iterations, local_rank)
             except Exception as e:   # a failing leg must not take the headline line with it
                 line["secondary"][f"config{c2}"] = {"error": repr(e)}
+        try:
+            line["secondary"]["band_path"] = band_leg(local_rank)
+        except Exception as e:
+            line["secondary"]["band_path"] = {"error": repr(e)}
         try:
             lm_opts = solver.opts
             del solver

@@ -937,7 +937,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
         if (dynamic_cast<LeftSumEqualityEdge*>(e))
         {   // integral stage equality, left sum: its own edge on (x_k, u_k, dt) in front of the dynamics edge (finite_differences_grid.cpp:89-98)
-            if (e->getNumVertices() != 3 || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] || e->getVertexRaw(2) != g.dt || e->getDimension() != 1 || g.nx > 4)
+            if (e->getNumVertices() != 3 || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] || e->getVertexRaw(2) != g.dt || e->getDimension() != 1)
                 return fail(reason, "LeftSumEqualityEdge " + std::to_string(k) + ": not a one-row integrand on (x_k, u_k, dt) of a family with nx <= 4");
             IntegrandProbe f(*e, {g.xs[k]}, g.us[k], g.dt, 0);
             if (!set_rule(2) || !identifyLinearIntegrand(f, g.nx, g.nu, d.stage_eq_params, k > 0))
@@ -970,7 +970,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             else if (dynamic_cast<MidpointDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_MIDPOINT;
             else if (dynamic_cast<CrankNicolsonDiffCollocation*>(sch)) defect = CORBO_HIP_DEFECT_CRANK_NICOLSON;
             else return fail(reason, "unknown finite-differences collocation scheme");
-            if (e->getDimension() != g.nx + 1 || g.nx > 4) return fail(reason, "TrapezoidalIntegralEqualityDynamicsEdge: one integrand row, families with nx <= 4");
+            if (e->getDimension() != g.nx + 1) return fail(reason, "TrapezoidalIntegralEqualityDynamicsEdge: one integrand row");
             IntegrandProbe f(*e, {g.xs[k], x2}, g.us[k], g.dt, g.nx);
             if (!set_rule(1) || !identifyLinearIntegrand(f, g.nx, g.nu, d.stage_eq_params, k > 0))
                 return fail(reason, "integral stage equality " + std::to_string(k) + " is not a^T x + b^T u - c (the device's plug-in), or varies along the horizon");
@@ -1277,7 +1277,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
         if (e->getDimension() < g.nx)
         {   // TerminalPartialEqualityConstraint: rows for a subset of the components
             unsigned mask = 0;
-            if (g.nx > 4 || !identifyPartialIdentity(*e, g.xf, &mask, &ref)) return fail(reason, "extra equality edge is not a TerminalPartialEqualityConstraint (x_f - xref)_active");
+            if ((g.nx > 4 && !(g.nx <= 12 && g.nu <= 4 && g.nx + g.nu <= 16)) || !identifyPartialIdentity(*e, g.xf, &mask, &ref)) return fail(reason, "extra equality edge is not a TerminalPartialEqualityConstraint (x_f - xref)_active");
             for (int i = 0; i < g.nx; ++i)
                 if ((mask >> i) & 1u)
                 {
@@ -1321,7 +1321,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             {
                 BaseEdge* e = ins[at].get();
                 if (e->getNumVertices() != 3 || e->getVertexRaw(0) != g.us[k] || (k > 0 && (e->getVertexRaw(1) != g.us[k - 1] || e->getVertexRaw(2) != g.dt)) ||
-                    (k == 0 && (!e->getVertexRaw(1)->isFixed() || !e->getVertexRaw(2)->isFixed())) || g.nx > 4)
+                    (k == 0 && (!e->getVertexRaw(1)->isFixed() || !e->getVertexRaw(2)->isFixed())))
                     return fail(reason, "control-deviation edge " + std::to_string(k) + " is not on (u_k, u_{k-1}, dt) resp. (u_0, previous control, its age)");
                 if (!identifyRateLimit(*e, e->getVertexRaw(0), e->getVertexRaw(1), e->getVertexRaw(2), g.nu, d.ctrl_dev_params, n_dev > 0))
                     return fail(reason, "control-deviation term " + std::to_string(k) + " is not the input-rate limit ((u_k - u_prev) / dt)^2 - r_max^2 (the device's plug-in), or varies along the horizon");
@@ -1337,8 +1337,8 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
                 BaseEdge* e = ins[at].get();
                 const bool trap = dynamic_cast<TrapezoidalIntegralInequalityEdge*>(e) != nullptr;
                 if (e->getDimension() != 1 || e->getNumVertices() != (trap ? 4 : 3) || e->getVertexRaw(0) != g.xs[k] || e->getVertexRaw(1) != g.us[k] ||
-                    e->getVertexRaw(trap ? 3 : 2) != g.dt || (trap && e->getVertexRaw(2) != x2) || g.nx > 4)
-                    return fail(reason, "integral inequality edge " + std::to_string(k) + ": not a one-row integrand on (x_k, u_k[, x_{k+1}], dt) of a family with nx <= 4");
+                    e->getVertexRaw(trap ? 3 : 2) != g.dt || (trap && e->getVertexRaw(2) != x2))
+                    return fail(reason, "integral inequality edge " + std::to_string(k) + ": not a one-row integrand on (x_k, u_k[, x_{k+1}], dt)");
                 IntegrandProbe f(*e, trap ? std::vector<VertexInterface*>{g.xs[k], x2} : std::vector<VertexInterface*>{g.xs[k]}, g.us[k], g.dt, 0);
                 if (!set_rule(trap ? 1 : 2) || !identifyBallIntegrand(f, g.nx, g.nu, d.ineq_params, n_int > 0))
                     return fail(reason, "integral stage inequality " + std::to_string(k) + " is not the keep-out ball on the first three state components, or varies along the horizon");

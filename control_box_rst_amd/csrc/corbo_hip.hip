@@ -244,6 +244,7 @@ struct corbo_hip_solver {
         p.batch = active; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.batch_total = batch + spare; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2 && band.n == 0) ? 1 : 0;   // (band route: the factorisation reads the stored Jacobian)
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
+        p.ineq_stride = 1 + ((S.desc.ctrl_dev && S.desc.stage_ineq != CORBO_HIP_INEQ_NONE && !S.desc.stage_ineq_integral) ? S.nu : 0);   // (creation order per interval: state term, control-deviation term)
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         fill_dyn(p.mp.dyn);
         std::memcpy(p.mp.ineq, S.desc.ineq_params, sizeof(p.mp.ineq));
@@ -1694,7 +1695,8 @@ try {
     const SweepParams spe = h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     int rc = launch_sweep_checked(h, spe);
     if (rc) return rc;
-    if (jac_out && h->d_xe0 && h->band.n == 0) {   // (band route: the sweep's stored Jacobian IS what the factorisation reads)
+    // (a partial terminal equality: the stage kernel's dump writes the full constraint's block -- kernels.hip, big_stage_edges --, the sweep kernel's Jacobian is returned)
+    if (jac_out && h->d_xe0 && h->band.n == 0 && !h->S.desc.final_eq_mask) {   // (band route: the sweep's stored Jacobian IS what the factorisation reads)
         // big-block family: what an LM pass differentiates is the stage kernel's Jacobian (never stored during a solve); the parity hook
         // returns THAT one -- every value is overwritten (an entry the stage kernel does not produce would come back as NaN)
         HIP_TRY(hipMemsetAsync(h->d_jac, 0xFF, (size_t)h->batch * h->nnz_pad * sizeof(double), h->stream));

@@ -193,9 +193,10 @@ __device__ __forceinline__ double dense_weight_row(const double* U, int c, int d
 // in the reference's operation order (finite_differences_collocation_edges.h:149-459: 0.5 * dt * (c1 + c2) resp. c1, then *= dt; the plug-in
 // stage functions as oracle/ref_driver.cpp states them).  loc[vi][c]: component c of attached vertex vi.
 template <int NX, int NU>
-__device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc)[4][4], const double* xp, const double* ineqp, double (&out)[4])
+__device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc)[4][(NX > NU ? NX : NU)], const double* xp, const double* ineqp, double (&out)[4])
 {
-    auto lin = [&](const double (&x)[4], const double (&u)[4]) {   // a^T x + b^T u - c, summed left to right
+    constexpr int MC = (NX > NU) ? NX : NU;   // components of the widest attached vertex
+    auto lin = [&](const double (&x)[MC], const double (&u)[MC]) {   // a^T x + b^T u - c, summed left to right
         double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) acc += xp[i] * x[i];
@@ -203,7 +204,7 @@ __device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc
         for (int i = 0; i < NU; ++i) acc += xp[NX + i] * u[i];
         return acc - xp[NX + NU];
     };
-    auto ball = [&](const double (&x)[4]) {
+    auto ball = [&](const double (&x)[MC]) {
         if constexpr (NX >= 3) { const double v[3] = {x[0], x[1], x[2]}; return ineq_ball(v, ineqp); }
         else return 0.0;
     };
@@ -687,7 +688,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             if (p.ineq_cols) {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
                 double ci = ineq_ball(xs + base, p.mp.ineq);
                 ci        = (ci < 0) ? 0.0 : ci * p.w_ineq;
-                put_value(p.ineq_row0 + k, ci);
+                put_value(p.ineq_row0 + k * p.ineq_stride, ci);
                 sq_acc += ci * ci;
             }
         }
@@ -703,11 +704,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     }
 
     // (d) integral-form constraint edges, control-deviation edges: one lane per edge
-    auto xe_load = [&](const XEdge& xe, double (&loc)[4][4]) {
+    constexpr int XMC = (NX > NU) ? NX : NU;   // components of the widest vertex an extra edge attaches
+    auto xe_load = [&](const XEdge& xe, double (&loc)[4][XMC]) {
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < XMC; ++c) {
                 double v = 0.0;
                 if (vi < xe.nverts && c < xe.vdim[vi]) {
                     const int vo = xe.voff[vi];
@@ -722,7 +724,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if constexpr (XE) {
         for (int i = tid; i < p.n_xedges; i += THREADS) {
             const XEdge xe = p.xedges[i];
-            double loc[4][4], out[4];
+            double loc[4][XMC], out[4];
             xe_load(xe, loc);
             xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, out);
 #pragma unroll
@@ -1118,7 +1120,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     if constexpr (XE) {
         for (int i = tid; i < p.n_xedges; i += THREADS) {
             const XEdge xe = p.xedges[i];
-            double loc[4][4], f0[4];
+            double loc[4][XMC], f0[4];
             xe_load(xe, loc);
             xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, f0);
 #pragma unroll
@@ -1126,7 +1128,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 if (vi >= xe.nverts || xe.joff[vi] < 0) continue;
                 int col = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < XMC; ++c) {
                     if (c >= xe.vdim[vi] || ((xe.fixed[vi] >> c) & 1u)) continue;
                     const double keep = loc[vi][c];
                     double v2[4], v1[4];
@@ -3015,12 +3017,14 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
                     for (int r = 0; r < cdim; ++r) jac_dump[ci.cost_joff - cc + r] = (r == cc) ? dv : 0.0;
                 }
             }
-            if (fin && isx && !ci.fixed && ci.cost2_joff >= 0) {   // TerminalEqualityConstraint x_f - xref: a second diagonal row, times w_eq
+            if (fin && isx && !ci.fixed && ci.cost2_joff >= 0) {   // Terminal[Partial]EqualityConstraint x_f - xref: a second diagonal row, times w_eq
                 const double a = xv + delta, b = a + neg2delta;
                 const double dv  = (scalar * ((a - ref) - (b - ref))) * sp.w_eq;
                 const double val = (xv - ref) * sp.w_eq;
-                dd += dv * dv;
-                gg -= dv * val;
+                // (TerminalPartialEqualityConstraint, final_state_constraints.h:219-252: a row for the ACTIVE components only; an inactive component has no
+                //  row -- cost2_row < 0.  The Jacobian dump below writes the FULL constraint's nx x nx block: corbo_hip_eval takes the Jacobian of a handle
+                //  with a partial mask from the sweep kernel instead, corbo_hip.hip)
+                if (ci.cost2_row >= 0) { dd += dv * dv; gg -= dv * val; }
                 if (jac_dump)
                     for (int r = 0; r < NX; ++r) jac_dump[ci.cost2_joff - e + r] = (r == e) ? dv : 0.0;
             }
@@ -4456,12 +4460,18 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 {
     if constexpr (Dynamics<DYN>::NX <= 4) {
         if (p.N > LONG_HORIZON) {   // long horizon: Jacobian straight to HBM
+            if constexpr (DEFECT != DEFECT_SHOOTING_HIGH) {
+                if (p.n_xedges > 0) {   // ... with integral-form constraint edges / control-deviation edges
+                    hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+                    return;
+                }
+            }
             if (p.mp.wdense) hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             else hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
         }
-        if constexpr (DEFECT != CORBO_HIP_DEFECT_RK4_SHOOTING && DEFECT != DEFECT_SHOOTING_HIGH) {
-            if (p.n_xedges > 0) {   // integral-form constraint edges / control-deviation edges: the XE instantiation (finite-differences grids)
+        if constexpr (DEFECT != DEFECT_SHOOTING_HIGH) {
+            if (p.n_xedges > 0) {   // integral-form constraint edges (finite-differences grids) / control-deviation edges (every grid): the XE instantiation
                 hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
                 return;
             }
@@ -4472,6 +4482,10 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
         }
     }
     if constexpr (Dynamics<DYN>::NX > 4) {
+        if (p.n_xedges > 0) {   // big-block family with extra edges (the band factorisation reads the stored Jacobian): the XE instantiation
+            hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+            return;
+        }
         if (p.mode == 0 || (p.skip_jac && p.mode >= 2)) {   // no Jacobian due in this launch, whatever the decision: the residual-only instantiation
             hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
             return;
@@ -4678,7 +4692,7 @@ struct HessEdge {
                 if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
                 break;
             case EK_FINAL_EQ:
-                if (NX <= 4 && mp.fin_eq_mask) {   // (the descriptor gate admits it for nx <= 4, structure.cpp) TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): the active components only, in order
+                if (mp.fin_eq_mask) {   // TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): the active components only, in order
                     // (static indices only: a running output index puts the lane's arrays into scratch memory -- measured on this kernel: 448 -> 1408 bytes
                     //  per lane, 273 -> 458 us for 1024 OCPs)
                     int idx = 0;
@@ -4698,7 +4712,7 @@ struct HessEdge {
             default: break;
         }
     }
-    __device__ static int edge_dim(int kind, const ModelParams& mp) { return (NX <= 4 && kind == EK_FINAL_EQ && mp.fin_eq_mask) ? __popc((unsigned)mp.fin_eq_mask) : kind == EK_MIXED_JOINT ? NX + 1 : kind == EK_MIXED_EQ ? NX : kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
+    __device__ static int edge_dim(int kind, const ModelParams& mp) { return (kind == EK_FINAL_EQ && mp.fin_eq_mask) ? __popc((unsigned)mp.fin_eq_mask) : kind == EK_MIXED_JOINT ? NX + 1 : kind == EK_MIXED_EQ ? NX : kind == EK_CONTROL_COST ? NU : (kind == EK_DT_COST || kind == EK_STAGE_INEQ || kind == EK_FINAL_INEQ || kind >= EK_STATE_QCOST) ? 1 : NX; }
     __device__ static int n_verts(int kind) { return (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP || kind >= EK_MIXED_OBJ) ? 4 : kind == EK_INTEGRAL_LEFT ? 3 : 1; }
     __device__ static int vert_off(int kind, int vi) { return (kind >= EK_MIXED_OBJ) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? W - 1 : S) : kind == EK_INTEGRAL_LEFT ? (vi == 0 ? 0 : vi == 1 ? NX : W - 1) : (kind == EK_DEFECT || kind == EK_INTEGRAL_TRAP) ? (vi == 0 ? 0 : vi == 1 ? NX : vi == 2 ? S : W - 1) : (kind == EK_CONTROL_COST || kind == EK_CONTROL_QCOST) ? NX : (kind == EK_DT_COST || kind == EK_DT_QCOST) ? W - 1 : 0; }
     __device__ static int vert_dim(int kind, int vi)

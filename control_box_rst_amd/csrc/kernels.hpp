@@ -39,6 +39,7 @@ struct SweepParams {
     int32_t inst0;      // first instance of this launch (sub-batch launches); grid = batch
     int32_t batch_total;  // instances of the handle (stride of the per-handle two-buffer arrays)
     int32_t eq_row0, ineq_row0;  // first residual row of the defect / stage-inequality edges (one edge per stage)
+    int32_t ineq_stride;         // rows between the stage inequalities of consecutive intervals: 1, or 1 + nu when every interval also has a control-deviation edge behind it
     const StageCols* stage_cols;  // N-1: Jacobian offsets of the defect columns of stage k
     const CompInfo* comp;         // nvs: cost-block offsets per component
     const int32_t* ineq_cols;     // (N-1)*nx or null

@@ -74,7 +74,7 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     if (d.final_eq && d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE) return "one final-stage constraint only (setFinalStageConstraint)";
     if (d.final_eq_mask) {
         if (!d.final_eq) return "final_eq_mask without final_eq";
-        if (d.nx > 4) return "partial terminal equality constraint: families with nx <= 4";
+        if (d.nx > 4 && !big_family_dims(d.nx, d.nu)) return "partial terminal equality constraint: families with nx <= 4, and the big-block family";
         if (d.final_eq_mask >> d.nx) return "final_eq_mask has bits beyond nx";
     }
     if (d.shooting_integrator < 0 || d.shooting_integrator > 7 || d.shooting_integrator == 4) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3), 5 / 6 / 7 (RK5 / RK6 / RK7)";
@@ -104,11 +104,16 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         if (d.stage_eq && !d.constraint_integration) return "stage_eq (integral form) needs a constraint_integration rule";
         if (d.ctrl_dev != CORBO_HIP_CTRL_DEV_NONE && d.ctrl_dev != CORBO_HIP_CTRL_DEV_RATE) return "unknown control-deviation term";
         if (any) {
-            if (d.grid != CORBO_HIP_GRID_FD && d.grid != CORBO_HIP_GRID_FD_VARIABLE) return "integral-form constraints / control-deviation term: FiniteDifferencesGrid and FiniteDifferencesVariableGrid";
+            // The integral-form edges are classes of the finite-differences grids (finite_differences_collocation_edges.h:149-459); on the shooting grids
+            // integral terms make the interval a MIXED edge (multiple_shooting_grid.cpp:70-77), which lives on the Hessian path (cost_integral).  The
+            // control-deviation term is a non-integral term: every grid creates it (multiple_shooting_grid.cpp:62, 193-197).
+            const bool fd_grid = (d.grid == CORBO_HIP_GRID_FD || d.grid == CORBO_HIP_GRID_FD_VARIABLE);
+            if (!fd_grid && (d.stage_ineq_integral || d.stage_eq)) return "integral-form constraint edges: FiniteDifferencesGrid and FiniteDifferencesVariableGrid (the shooting grids take the control-deviation term only)";
             if (d.cost_nonlsq || d.cost_integral) return "integral-form constraints / control-deviation term: Levenberg-Marquardt path (least-squares costs) only";
-            if (d.nx > 4) return "integral-form constraints / control-deviation term: families with nx <= 4";
-            if (d.N < 3 || d.N > 256) return "integral-form constraints / control-deviation term: 3 <= N <= 256";
+            if (d.nx > 4 && !big_family_dims(d.nx, d.nu)) return "integral-form constraints / control-deviation term: families with nx <= 4, and the big-block family";
+            if (d.N < 3 || d.N > 1024) return "integral-form constraints / control-deviation term: 3 <= N <= 1024";
             if (d.weights_dense) return "integral-form constraints / control-deviation term: diagonal weights";
+            if (d.shooting_integrator >= 5) return "integral-form constraints / control-deviation term: shooting integrators up to Runge-Kutta 4";
         }
     }
     return "";

@@ -659,7 +659,7 @@ static int validate(const corbo_hip_problem_desc* d)
     return 1;
 }
 
-/* integral-form constraints / control-deviation term: FiniteDifferencesGrid and FiniteDifferencesVariableGrid, least-squares problems */
+/* integral-form constraints (FiniteDifferencesGrid and FiniteDifferencesVariableGrid) / control-deviation term (every grid), least-squares problems */
 static int validate_extra(const corbo_hip_problem_desc* d)
 {
     const int any = d->stage_ineq_integral || d->stage_eq || d->ctrl_dev;
@@ -667,7 +667,10 @@ static int validate_extra(const corbo_hip_problem_desc* d)
     if (d->stage_ineq_integral && (d->stage_ineq != CORBO_HIP_INEQ_BALL || !d->constraint_integration)) return 0;
     if (d->stage_eq && (d->stage_eq != CORBO_HIP_STAGE_EQ_LINEAR || !d->constraint_integration)) return 0;
     if (d->ctrl_dev && d->ctrl_dev != CORBO_HIP_CTRL_DEV_RATE) return 0;
-    if (any && (d->grid == CORBO_HIP_GRID_MS || d->grid == CORBO_HIP_GRID_MS_VARIABLE || d->cost_nonlsq || d->cost_integral || d->N < 3)) return 0;
+    /* the integral-form edges are classes of the finite-differences grids; the control-deviation term is a non-integral term that every grid creates
+     * (multiple_shooting_grid.cpp:62, 193-197) */
+    if ((d->stage_ineq_integral || d->stage_eq) && (d->grid == CORBO_HIP_GRID_MS || d->grid == CORBO_HIP_GRID_MS_VARIABLE)) return 0;
+    if (any && (d->cost_nonlsq || d->cost_integral || d->N < 3)) return 0;
     return 1;
 }
 

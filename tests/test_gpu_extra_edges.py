@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import GOLDEN, desc_for
+from conftest import GOLDEN, desc_for, ledger_tolerances
 from control_box_rst_amd import capi
 from control_box_rst_amd.solver import BatchedLevenbergMarquardt, get_structure
 
@@ -61,7 +61,7 @@ def test_lm_iterates_vs_reference(name):
             s.solve(new_run=(i == 0))
         X, chi2, status = s.get_solution()
         ref = np.array(a["vertex"])[: s.dims.nv]
-        xt, ct = 5e-6, 2e-6
+        xt, ct = ledger_tolerances(name)   # (the defaults 5e-6 / 2e-6 unless tests/tolerances.json lists the fixture: the big-block models' soft directions)
         assert np.abs(X[0] - ref).max() <= xt * max(1.0, np.abs(ref).max()), (name, a["k"], np.abs(X[0] - ref).max())
         assert abs(chi2[0] - a["chi2"]) <= ct * max(1.0, abs(a["chi2"])), (name, a["k"])
 

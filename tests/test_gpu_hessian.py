@@ -26,7 +26,7 @@ HESS = ["hess_kcar", "hess_pquad_n5", "hess_pquad_fd_n5", "hess_unicycle_fullq",
         "hess_unicycle_ms_integral_teq", "hess_unicycle_ms_integral_tball",
         "hess_pquad_ms_integral", "hess_pquad_ms_integral_rk3",   # the mixed edge around a big-block model (nx = 6; the 12-state fixture hess_quad_ms_integral pins the oracle only: the device refuses nx > 8 here)
         # TerminalPartialEqualityConstraint on the Hessian path: rows / multipliers for the active components of x_f only
-        "hess_unicycle_pteq", "hess_cartpole_pteq", "hess_unicycle_ms_pteq", "hess_unicycle_ms_integral_pteq",   # (hess_pquad_pteq pins the oracle only: the descriptor gate admits the mask for nx <= 4)
+        "hess_unicycle_pteq", "hess_cartpole_pteq", "hess_unicycle_ms_pteq", "hess_unicycle_ms_integral_pteq", "hess_pquad_pteq",
         "hess_dint_mtq_integral_trap", "hess_dint_mtq_integral_left_last4"]   # MinTimeQuadratic in integral form (free dt)   # integral-form cost: one objective edge per interval   # *_nonlsq: plain (non-least-squares) objective edges
 KEYS = ("hobj", "heq", "hineq")
 REL = 2e-4   # of max(1, max |value| of the list): see the module docstring; checked against the reference's own spread below

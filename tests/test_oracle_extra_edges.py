@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import GOLDEN, desc_for
+from conftest import GOLDEN, LEDGER, desc_for, ledger_tolerances
 from control_box_rst_amd import capi
 
 FIXTURES = sorted(f[:-5] for f in os.listdir(GOLDEN) if f.startswith("xe_") and f.endswith(".json"))
@@ -50,9 +50,10 @@ def test_oracle_lm_iterates(oracle_mod, name):
         ref = np.array(a["vertex"])[: q.dims.nv]
         # first iteration: only the elimination order differs from Eigen's, amplified by the conditioning of H (penalty rows next to small cost
         # weights): 1e-13 .. 7e-8 on these fixtures; later iterations: the usual finite-difference level
-        tol = 2e-7 if a["k"] == 1 else 2e-6
+        tol = 2e-7 if a["k"] == 1 else (ledger_tolerances(name)[0] if name in LEDGER["fixtures"] else 2e-6)   # (ledger: the big-block models' soft directions)
         assert np.abs(q.x() - ref).max() <= tol * max(1.0, np.abs(ref).max()), (name, a["k"], np.abs(q.x() - ref).max())
-        assert abs(chi2 - a["chi2"]) <= 1e-6 * max(1.0, abs(a["chi2"])), (name, a["k"])
+        ctol = max(1e-6, ledger_tolerances(name)[1]) if name in LEDGER["fixtures"] else 1e-6
+        assert abs(chi2 - a["chi2"]) <= ctol * max(1.0, abs(a["chi2"])), (name, a["k"])
 
 
 @pytest.mark.parametrize("name", FIXTURES)

@@ -39,23 +39,26 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation on the device
         "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
-        "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq",
+        "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq", "pquad_n10_pteq", "pquad_fd_n10_pteq", "quad_n10_pteq",   # (... and around the big-block models)
         # a randomized-start case of tests/test_gpu_fuzz.py (seed 23091, the one whose device result once needed the 48-trial spread), all three
         # instances, solved by the reference itself from the same noisy start (ref_driver start=): N = 123 shooting intervals, keep-out ball,
         # TerminalBall, mixed bound patterns, random weights
         "fuzz_23091_b0", "fuzz_23091_b1", "fuzz_23091_b2"]
 
-# The reduced cfg-5 problem (quadrotor) has nearly flat directions (yaw, torques): rounding-level differences move the iterate
-# along them by ~1e-4 while chi2 agrees to 1e-9, so its trajectory tolerance is looser and chi2 carries the comparison.
-X_TOL = {"quad_n10": 3e-4, "quad_n10_tball": 3e-4, "quad_n10_tball_loose": 3e-4, "quad_n10_teq": 3e-4, "quad_n10_rk3": 3e-4, "quad_n10_euler": 3e-4,
-         # the planar quadrotor (user model, big-block family) has the same kind of soft directions (thrusts, cost weight 0.02): the first
-         # iteration agrees to 3e-13, later ones to 3e-5 .. 1e-4 while chi2 agrees to 1e-7 .. 1e-10
-         "pquad_n10": 3e-4, "pquad_n24": 3e-4, "pquad_n10_teq": 3e-4, "pquad_n10_tball": 3e-4, "pquad_n10_rk3": 3e-4,
-         # the same models on the collocation grid are stiffer in those directions: 3e-7 .. 4e-6 (chi2 to 1e-7)
-         "pquad_fd_n10": 1e-5, "pquad_fd_n24": 1e-5, "pquad_fd_n10_forward": 1e-5, "pquad_fd_n10_backward": 1e-5, "pquad_fd_n10_midpoint": 1e-5, "pquad_fd_n10_teq": 1e-5, "quad_fd_n10": 1e-5,
-         # ... and with a free dt: the same soft directions (1e-5 at the later iterations, chi2 to 1e-9)
-         "pquad_topt_n10": 3e-4, "pquad_topt_n30": 3e-4, "pquad_fd_topt_n12": 1e-5, "quad_topt_n8": 3e-4,
-         "cartpole_teq": 5e-6}   # 3.0e-6 at the fifth iteration (FD-noise level, different elimination order than Eigen's)
+# The big-block models (quadrotor, planar quadrotor) have nearly flat directions (yaw, torques, thrusts): rounding-level differences move the iterate
+# along them by ~1e-4 while chi2 agrees to 1e-9.  Their trajectory tolerances come from the ledger (tests/tolerances.json: the reference's own one-ulp
+# reproducibility on each fixture, oracle/gen_golden.py tolerances); every other fixture: 2e-6.
+from conftest import LEDGER, ledger_tolerances   # noqa: E402
+
+
+class _Tol(dict):
+    def get(self, name, default):
+        if name in LEDGER["fixtures"]:
+            return ledger_tolerances(name)[0]
+        return super().get(name, default)
+
+
+X_TOL = _Tol({"cartpole_teq": 5e-6})   # 3.0e-6 at the fifth iteration (FD-noise level, different elimination order than Eigen's)
 
 
 @pytest.mark.parametrize("name", FULL)
