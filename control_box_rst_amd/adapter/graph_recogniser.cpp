@@ -1374,8 +1374,9 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     }
     if (at != ins.size()) return fail(reason, "inequality edges the device cannot describe (kinds: keep-out ball on x_k or as integrand, input-rate limit, TerminalBall)");
     d.constraint_integration = integral_rule;
-    if ((d.stage_eq || d.stage_ineq_integral || d.ctrl_dev) && (g.kind != CORBO_HIP_GRID_FD && g.kind != CORBO_HIP_GRID_FD_VARIABLE))
-        return fail(reason, "integral-form constraints / control-deviation term on a grid other than the finite-differences grids");
+    // (the control-deviation term is a non-integral term: the shooting grids create its edges too, multiple_shooting_grid.cpp:62, 193-197)
+    if ((d.stage_eq || d.stage_ineq_integral) && (g.kind != CORBO_HIP_GRID_FD && g.kind != CORBO_HIP_GRID_FD_VARIABLE))
+        return fail(reason, "integral-form constraint edges on a grid other than the finite-differences grids");
     if (refs_vary)
     {   // rows 0 .. N-2: the stage references, row N-1: the reference of the final-stage terms
         model->xref_traj.resize(g.N, g.nx);

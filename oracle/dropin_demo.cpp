@@ -316,12 +316,12 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         xf[0] = 2; xf[1] = 1; xf[2] = 1;
         nu = 4;
     }
-    else if (scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq")
+    else if (scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate")
     {   // a user dynamics class with six states: matched against the models of csrc/models/, solved by the big-block family
         // (pquad_fd: on the FiniteDifferencesGrid, Crank-Nicolson collocation; pquad_topt: time-optimal on the MultipleShootingVariableGrid --
         // a free dt around a big-block model: the device's band factorisation)
         dyn = std::make_shared<PlanarQuadrotorRef>();
-        if (scenario == "pquad_fd") grid = std::make_shared<FiniteDifferencesGrid>();
+        if (scenario == "pquad_fd" || scenario == "pquad_fd_xe_ball") grid = std::make_shared<FiniteDifferencesGrid>();
         else if (scenario == "pquad_topt")
         {
             auto vg = std::make_shared<MultipleShootingVariableGrid>();
@@ -431,7 +431,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         if (scenario == "vdp_msint") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta3>());
         else ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
     }
-    const double dt = (scenario == "quad" || scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq") ? 0.05 : 0.1;
+    const double dt = (scenario == "quad" || scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
     if (mode == Mode::HipStatedWrong) d.r_diag[1] = 2.0 * d.r_diag[1];   // invisible at the reference's initial guess (u = 0)
     if (mode == Mode::Reference)
@@ -465,7 +465,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     {
         grid->setNRef(N);
         grid->setDtRef(dt);
-        grid->setCostIntegrationRule((itrap || scenario == "dint_mtq_itrap" || scenario == "unicycle_xe_ball" || scenario == "unicycle_xe_all") ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
+        grid->setCostIntegrationRule((itrap || scenario == "dint_mtq_itrap" || scenario == "unicycle_xe_ball" || scenario == "unicycle_xe_all" || scenario == "pquad_fd_xe_ball") ? FullDiscretizationGridBase::CostIntegrationRule::TrapezoidalRule : FullDiscretizationGridBase::CostIntegrationRule::LeftSum);
         any_grid = grid;
     }
     else
@@ -528,7 +528,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setControlBounds(ulb, uub);
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
-    else if (scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq")
+    else if (scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate")
     {
         Eigen::VectorXd q(6), rr(2);
         q << 1, 1, 0.5, 0.1, 0.1, 0.05;
@@ -541,6 +541,15 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
             ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         }
         ocp.setControlBounds(Eigen::Vector2d(0, 0), Eigen::Vector2d(12, 12));
+        if (scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate")
+        {   // round 5: the extra edge kinds around a six-state user model -- the keep-out ball as the stage inequalities' INTEGRAL term on the
+            // FiniteDifferencesGrid (TrapezoidalIntegralInequalityEdge), an input-rate limit (control-deviation edges) on the MultipleShootingGrid
+            auto c = std::make_shared<UserStageInequalities>();
+            if (scenario == "pquad_fd_xe_ball") { c->ball.resize(4); c->ball << 1.0, 0.5, 0.0, 0.3; }
+            else { c->rate.resize(2); c->rate << 40.0, 40.0; }
+            ocp.setStageInequalityConstraint(c);
+        }
+        else
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.0, 0.3));
         if (scenario == "pquad_pteq")
         {   // TerminalPartialEqualityConstraint around a six-state user model: position and attitude pinned at the goal, the velocities free
@@ -745,7 +754,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -753,7 +762,7 @@ int main(int argc, char** argv)
         double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
         printf("{\"scenario\": \"%s\", \"mode\": \"recognised\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
                sc, a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
-        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd" || std::string(sc) == "pquad_topt" || std::string(sc) == "pquad_pteq") ? 5e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
+        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd" || std::string(sc) == "pquad_topt" || std::string(sc) == "pquad_pteq" || std::string(sc) == "pquad_fd_xe_ball" || std::string(sc) == "pquad_xe_rate") ? 5e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
     for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft", "unicycle_plain_tvref", "unicycle_msint_tvref"})
