@@ -5943,52 +5943,94 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
     //      during phase j + 1 (wave 6), when nobody reads them any more; the pivot row is written out and its slot refilled by wave 7, and the next
     //      pivot's diagonal travels through a two-slot side buffer.  (LDS-only barriers: a full __syncthreads() waits for the wave's global operations
     //      too -- the write-out of row j and the request of the entering row would cost a memory round trip per pivot each.)
+    // Index arithmetic out of the pivot loop (round 5: the loop was 2.1 k cycles per pivot, most of it integer work -- a square root, two corrections and
+    // three modulo operations by the run-time window size per updated entry): entry q of the trailing triangle is (row j + 1 + a, column j + 1 + rem) for
+    // EVERY pivot j, so (a, rem) and the three column offsets inside the rows are per-lane constants; only the rows' ring slots move, by one per pivot.
+    constexpr int QMAX = 4;   // rounds of the trailing update: 63 * 64 / 2 entries at the largest half-bandwidth, 512 lanes
+    const int ntri_full = bw * (bw + 1) / 2;
+    int qa[QMAX], qoff_ij[QMAX], qoff_cj[QMAX], qoff_ic[QMAX], qsi[QMAX], qsc[QMAX];   // a, offsets of L(i,j) / L(c,j) / H(i,c) inside their rows, slot * W of rows i and c
+#pragma unroll
+    for (int r = 0; r < QMAX; ++r) {
+        const int q = tid + r * T;
+        int a = (int)((__builtin_sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);   // q = a (a + 1) / 2 + rem, rem <= a (single-precision estimate, corrected)
+        while (a * (a + 1) / 2 > q) --a;
+        while ((a + 1) * (a + 2) / 2 <= q) ++a;
+        const int rem = q - a * (a + 1) / 2;
+        qa[r] = (q < ntri_full) ? a : bw;   // (bw: never below any pivot's row count -- the entry does not exist)
+        qoff_ij[r] = bw - (1 + a); qoff_cj[r] = bw - (1 + rem); qoff_ic[r] = bw - (a - rem);
+        qsi[r] = ((1 + a) % W) * W; qsc[r] = ((1 + rem) % W) * W;
+    }
+    const int WW = W * W;
+    int s6 = ((1 + lane) % W) * W;          // wave 6: slot * W of row j + 1 + lane
+    int sj = 0;                             // slot * W of the pivot row j
     double inv_prev = 1.0;
-    for (int j = 0; j < nb; ++j) {
-        const int cnt = (nb - 1 - j < bw) ? nb - 1 - j : bw;   // rows below the pivot inside the band
-        double* rowj = win + (size_t)(j % W) * W;
+    // The entering rows are requested TWO pivots ahead into two registers that take turns (the loop body is instantiated twice per iteration): a pivot is
+    // ~ 600 cycles of LDS work, a row from HBM / L2 takes longer than that -- with one pivot of distance the loader wave was late at every barrier.  The
+    // request itself is BRANCH-FREE (every lane of every wave issues it, the non-loader lanes for row 0: one cache line): a load inside a conditional
+    // region makes the compiler wait for it at the join, i.e. at once.
+    const int lcol = loader ? lane : 0;
+    double preA = pre, preB = 0.0;
+    {
+        const int rb = (W + 1 < nb) ? W + 1 : 0;
+        preB = Hb[(size_t)(loader ? rb : 0) * W + lcol];
+        if (lcol == bw) preB += mu_eff;
+    }
+    auto pivot_step = [&](const int j, double& pre_now) {
+        const bool live = (j < nb);                                            // (uniform; false only for the odd step behind the last pivot)
+        const int cnt = live ? ((nb - 1 - j < bw) ? nb - 1 - j : bw) : 0;   // rows below the pivot inside the band
+        double* rowj = win + sj;
         const double dj  = dpiv[j & 1];
         const double inv = rsqrt(dj);              // (v_rsq_f64 + one Newton step: half the dependent instructions of sqrt and a division)
-        const double l   = dj * inv;
+        // the row that enters two pivots from now: requested first (see above; row index clamped, the value is only used when the row exists)
+        const int rreq = rnext + 2;
+        double pre_new = Hb[(size_t)((loader && rreq < nb) ? rreq : 0) * W + lcol];
+        if (lcol == bw) pre_new += mu_eff;
         // trailing update: H(i, c) -= L(i, j) L(c, j), j < c <= i <= j + cnt; rhs / border: g_i -= L(i, j) y_j
-        const int ntri = cnt * (cnt + 1) / 2;
-        for (int q = tid; q < ntri; q += T) {
-            int a = (int)((__builtin_sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);   // q = a (a + 1) / 2 + rem, rem <= a (single-precision estimate, corrected below)
-            while (a * (a + 1) / 2 > q) --a;
-            while ((a + 1) * (a + 2) / 2 <= q) ++a;
-            const int rem = q - a * (a + 1) / 2;
-            const int i = j + 1 + a, c = j + 1 + rem;
-            double* ri = win + (size_t)(i % W) * W;
-            const double lij = ri[bw - (i - j)] * inv, lcj = win[(size_t)(c % W) * W + bw - (c - j)] * inv;
-            const double v = ri[bw - (i - c)] - lij * lcj;
-            ri[bw - (i - c)] = v;
-            if (q == 0) dpiv[(j + 1) & 1] = v;     // (i = c = j + 1: the next pivot's diagonal)
+#pragma unroll
+        for (int r = 0; r < QMAX; ++r) {
+            if (r * T >= ntri_full) break;   // (uniform: rounds that hold no entry at this half-bandwidth cost nothing -- 27: one round)
+            if (qa[r] < cnt) {
+                double* ri = win + qsi[r];
+                const double lij = ri[qoff_ij[r]] * inv, lcj = win[qsc[r] + qoff_cj[r]] * inv;
+                const double v = ri[qoff_ic[r]] - lij * lcj;
+                ri[qoff_ic[r]] = v;
+                if (r == 0 && tid == 0) dpiv[(j + 1) & 1] = v;     // (i = c = j + 1: the next pivot's diagonal)
+            }
+            qsi[r] += W; if (qsi[r] == WW) qsi[r] = 0;
+            qsc[r] += W; if (qsc[r] == WW) qsc[r] = 0;
         }
         if (wave == 6) {
             if (lane < cnt) {   // rhs / border updates of the rows below the pivot
                 const int i = j + 1 + lane;
-                const double lij = win[(size_t)(i % W) * W + bw - (i - j)] * inv;
+                const double lij = win[s6 + bw - (1 + lane)] * inv;
                 g[i] -= lij * (g[j] * inv);
                 if (arrow) z[i] -= lij * (z[j] * inv);
             }
             // column j - 1, rows j + 1 .. : scaled in place now (phase j - 1 used it unscaled; row j's entry leaves with the row, see the loader)
-            if (j > 0 && lane < bw) {
+            if (live && j > 0 && lane < bw) {
                 const int i = j + 1 + lane;
-                if (i < nb && i - (j - 1) <= bw) win[(size_t)(i % W) * W + bw - (i - (j - 1))] *= inv_prev;
+                if (i < nb && lane + 2 <= bw) win[s6 + bw - (lane + 2)] *= inv_prev;
             }
-            if (lane == 63 && j > 0) { g[j - 1] *= inv_prev; if (arrow) z[j - 1] *= inv_prev; }   // y_{j-1}, (L^-1 border)_{j-1}
+            if (live && lane == 63 && j > 0) { g[j - 1] *= inv_prev; if (arrow) z[j - 1] *= inv_prev; }   // y_{j-1}, (L^-1 border)_{j-1}
+            s6 += W; if (s6 == WW) s6 = 0;
         }
-        if (loader) {
-            // row j is final: L(j, j - bw .. j) goes out (its entry in column j - 1 scaled on the way), the row that enters for the next pivot takes its
-            // slot, the one behind it is requested
+        if (loader && live) {
+            // row j is final: L(j, j - bw .. j) goes out (its entry in column j - 1 scaled on the way; the diagonal INVERTED: the back-substitution
+            // multiplies instead of dividing), the row that enters for the next pivot takes its slot.  (The write-out is issued BEHIND the request above:
+            // gfx9 returns vector-memory operations in order, a wait for a load issued behind a store waits for the store's acknowledgement too.)
             const double old = rowj[lane];
-            Hb[(size_t)j * W + lane] = (lane == bw) ? l : ((lane == bw - 1) ? old * inv_prev : old);
-            if (rnext < nb) rowj[lane] = pre;
-            ++rnext;
-            if (rnext < nb) { pre = Hb[(size_t)rnext * W + lane]; if (lane == bw) pre += mu_eff; }
+            Hb[(size_t)j * W + lane] = (lane == bw) ? inv : ((lane == bw - 1) ? old * inv_prev : old);
+            if (rnext < nb) rowj[lane] = pre_now;
         }
-        inv_prev = inv;
-        lds_barrier();   // (what crosses it lives in LDS: the row written out and the row requested stay in flight)
+        ++rnext;
+        pre_now = pre_new;
+        if (live) inv_prev = inv;
+        sj += W; if (sj == WW) sj = 0;
+        lds_barrier();   // (what crosses it lives in LDS: the row written out and the rows requested stay in flight)
+    };
+    for (int j = 0; j < nb; j += 2) {
+        pivot_step(j, preA);
+        pivot_step(j + 1, preB);
     }
     if (tid == 64 && nb > 0) g[nb - 1] *= inv_prev;
     if (tid == 65 && arrow && nb > 0) z[nb - 1] *= inv_prev;
@@ -6011,22 +6053,44 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
         for (int c = tid; c < nb; c += T) g[c] -= z[c] * ddt;
     }
     __syncthreads();
-    // ---- back-substitution L^T delta = y, row by row from the last one (wave 0; rows of L from HBM, two ahead)
+    // ---- back-substitution L^T delta = y, row by row from the last one (wave 0; rows of L from HBM, two ahead).  The part of the right-hand side a row can
+    //      touch -- the bw + 1 entries up to its own -- rides in REGISTERS, lane d = column i - bw + d of the current row i: one multiply for x_i, one
+    //      multiply-add for the others, then everything moves one lane up (a wave-wide DPP shift) and the next entry enters at lane 0.  (Round 5: with
+    //      the vector in LDS every row was a dependent LDS read-modify-write round trip and a division: 420 -> 350 -> ~ 100 cycles per row.)
     if (wave == 0) {
         __threadfence_block();
         const bool on = lane < W;
-        double r0 = 0.0, r1 = 0.0;
-        if (on && nb >= 1) r0 = Hb[(size_t)(nb - 1) * W + lane];
-        if (on && nb >= 2) r1 = Hb[(size_t)(nb - 2) * W + lane];
-        for (int i = nb - 1; i >= 0; --i) {
-            const double row = r0;
-            r0 = r1;
-            if (on && i >= 2) r1 = Hb[(size_t)(i - 2) * W + lane];
-            const double gi  = g[i];
-            const double xi  = gi / lane_bcast(row, bw);       // x_i = y_i / L(i, i)   (every lane the same number)
-            const int c = i - bw + lane;                        // lane d < bw: column c of row i
-            if (lane < bw && c >= 0) g[c] -= row * xi;
-            if (lane == bw) g[i] = xi;
+        // (the rows of L come from HBM / L2: eight of them in flight -- with two the loop waited ~ 350 cycles per row for its operand)
+        constexpr int PF = 8;
+        // (BRANCH-FREE loads: a load inside a divergent or conditional region makes the compiler wait for every outstanding memory operation at the join --
+        //  measured here: one s_waitcnt vmcnt(0) per row, the prefetch depth did not matter.  Indices are clamped instead, the duplicates are harmless.)
+        const int lc = on ? lane : 0;
+        double rr[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int ir = nb - 1 - u; rr[u] = Hb[(size_t)(ir >= 0 ? ir : 0) * W + lc]; }
+        const int c0 = nb - 1 - bw + lane;
+        double a   = (on && c0 >= 0 && nb >= 1) ? g[c0] : 0.0;
+        double gin = g[nb - 2 - bw >= 0 ? nb - 2 - bw : 0];   // the entry that enters with the next row (same address in every lane)
+        if (nb - 2 - bw < 0) gin = 0.0;
+        for (int i0 = nb - 1; i0 >= 0; i0 -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int i = i0 - u;
+                const bool act = (i >= 0);                              // (uniform; false only behind row 0 in the last chunk)
+                const double row = (on && act) ? rr[u] : 0.0;
+                rr[u] = Hb[(size_t)(i - PF >= 0 ? i - PF : 0) * W + lc];
+                const double xi = lane_bcast(a * row, bw);          // x_i = y_i / L(i, i): the row carries 1 / L(i, i) at its diagonal   (every lane the same number)
+                if (lane == bw && act) g[i] = xi;
+                const double upd = a - row * xi;                    // lane d < bw: y_c -= L(i, c) x_i
+                const double kept = (lane < bw) ? upd : 0.0;
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(kept), 0x138, 0xF, 0xF, false);   // wave_shr:1 -- lane d takes lane d - 1's value
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(kept), 0x138, 0xF, 0xF, false);
+                const double moved = (lane == 0) ? gin : __hiloint2double(hi, lo);
+                a = act ? moved : a;
+                const int ig = i - 2 - bw;
+                const double gl = g[ig >= 0 ? ig : 0];
+                gin = (ig >= 0) ? gl : 0.0;
+            }
         }
     }
     __syncthreads();

@@ -17,7 +17,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("CORBO_PROFILE_ROUND", "r04")   # file-name prefix of the round's summaries (<round> above)
+RND = os.environ.get("CORBO_PROFILE_ROUND", "r05")   # file-name prefix of the round's summaries (<round> above)
 
 
 def per_dispatch(path, kernel_substr):
