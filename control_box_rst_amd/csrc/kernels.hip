@@ -248,6 +248,28 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     const size_t xo = (size_t)inst * p.nvs;
     CORBO_HIP_DYN_OF(dynl, p, inst)
 
+    // Two-wave shape of the run-to-completion kernel (SC, below): the tables of this lane's stage -- component descriptors, bounds, the Jacobian offsets
+    // of its defect edge -- are requested FIRST, ahead of the state hand-over and its barriers: they depend on nothing but the lane, and their memory round
+    // trip (1.5 - 2 k cycles per pass when requested where they are used) rides under the phase's prologue.  Branch-free, indices clamped.
+    constexpr bool SC_EARLY = (THREADS <= 128) && !DENSE && !LONG;   // (= SC)
+    int4 pcA[SC_EARLY ? S : 1], pcB[SC_EARLY ? S : 1];
+    double plo[SC_EARLY ? S : 1], pup[SC_EARLY ? S : 1];
+    int scv_pre[W + 1];                  // StageCols of lane k's defect edge
+    if constexpr (SC_EARLY) {
+        const int4* comp4e = reinterpret_cast<const int4*>(p.comp);
+        const int kb = tid, js_ = kb - p.N;
+        const bool isfin = (kb == p.N - 1), reg = (kb < p.N - 1), spec = (js_ >= 0 && js_ <= NX);
+        const int vspec = (js_ < NX) ? (p.N - 1) * S + js_ : p.off_dt;
+#pragma unroll
+        for (int c = 0; c < W + 1; ++c) scv_pre[c] = p.stage_cols[reg ? kb : 0].col[c];
+#pragma unroll
+        for (int e = 0; e < S; ++e) {   // (an absent slot fetches component 0 and is ignored; slot 0 of a special lane: its component)
+            const bool on = reg || (isfin && e < NX);   // (the last block: x_f, no controls)
+            const int vc = on ? kb * S + e : ((spec && e == 0) ? vspec : 0);
+            pcA[e] = comp4e[2 * vc]; pcB[e] = comp4e[2 * vc + 1]; plo[e] = p.lb[xo + vc]; pup[e] = p.ub[xo + vc];
+        }
+    }
+
     const double* xsrc = p.x + xo;
     double* vout       = p.values0 + (size_t)inst * p.m_pad;
     int vsel           = 0;   // which half of the two-buffer arrays (values0 / values1, xe0) this evaluation writes
@@ -484,14 +506,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         const int js     = kb - p.N;
         const bool spec  = (js >= 0 && js <= NX);
         const int vspec  = (js < NX) ? (p.N - 1) * S + js : p.off_dt;
-        int4 cA[S], cB[S];
-        double lo[S], up[S], rv[NX];
-#pragma unroll
-        for (int e = 0; e < S; ++e) {   // (clamped, branch-free: an absent slot fetches component 0 and is ignored; slot 0 of a special lane: its component)
-            const bool on = reg || (isfin && e < NX);   // (the last block: x_f, no controls)
-            const int vc = on ? kb * S + e : ((spec && e == 0) ? vspec : 0);
-            cA[e] = comp4[2 * vc]; cB[e] = comp4[2 * vc + 1]; lo[e] = p.lb[xo + vc]; up[e] = p.ub[xo + vc];
-        }
+        // (descriptors, bounds and the defect edge's Jacobian offsets: requested at the top of the phase, see SC_EARLY -- also ahead of the accepted
+        //  iterate's copy to HBM: behind those stores the first use of a later load would wait for their acknowledgements as well)
+        int4 (&cA)[S] = pcA, (&cB)[S] = pcB;
+        double (&lo)[S] = plo, (&up)[S] = pup;
+        double rv[NX];
 #pragma unroll
         for (int e = 0; e < NX; ++e) rv[e] = xr[e];
         double rspec = 0.0;
@@ -847,7 +866,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         const bool cs_x1 = cset & 1u, cs_u0 = cset & 2u, cs_u1 = cset & 4u, cs_x2 = cset & 8u;
         for (int k = tid % JL; k < p.N - 1; k += JL) {
             const int base  = k * S;
-            const int* sc   = p.stage_cols[k].col;
+            const int* sc   = SC ? scv_pre : p.stage_cols[k].col;   // (SC: one lane per stage, k = tid: the offsets are in registers already)
             double x1[NX], u1[NU], x2[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { x1[i] = xs[base + i]; x2[i] = xs[base + S + i]; }
@@ -1400,6 +1419,9 @@ __device__ __forceinline__ double quad_bcast(double v)
 #ifndef CORBO_HIP_SOLO_LAST_LEVEL
 #define CORBO_HIP_SOLO_LAST_LEVEL 1  // (0: the last back-substitution level in two rounds of quads, for A/B)
 #endif
+#ifndef CORBO_HIP_RELOAD_UNR
+#define CORBO_HIP_RELOAD_UNR 10      // 16-byte loads in flight per lane when the Jacobian range is staged again after a rejected step (two-wave shape)
+#endif
 #ifndef CORBO_HIP_COMPACT_LEVELS
 #define CORBO_HIP_COMPACT_LEVELS 1   // (0: the two-round h = 2 level of round 4, for A/B)
 #endif
@@ -1658,7 +1680,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
         const int n2       = (RECOMP && p.jlean_hi2 > 0) ? p.jlean_hi2 : p.nnz_pad / 2;
         // loads in flight per lane (8 costs 3 % of a solve at the 128-VGPR budget) (branch-free: indices are clamped, the duplicates are harmless);
         // the two-wave shape of the run-to-completion kernel has the registers for the whole headline Jacobian in ONE round trip (17 x 128 x 16 bytes)
-        constexpr int UNR  = (THREADS <= 128) ? 8 : 4;   // (17 -- the whole headline Jacobian in one round trip of the two-wave shape -- was measured: 5.2 k -> 7.2 k cycles alone, 14 k+ under load)
+        constexpr int UNR  = (THREADS <= 128) ? CORBO_HIP_RELOAD_UNR : 4;   // (17 -- the whole headline Jacobian in one round trip of the two-wave shape -- was measured: 5.2 k -> 7.2 k cycles alone, 14 k+ under load)
         for (int i0 = lo2 + tid; i0 < n2; i0 += THREADS * UNR) {
             double2 v[UNR];
 #pragma unroll
