@@ -348,6 +348,26 @@ def band_leg(device):
     from control_box_rst_amd import problems
     from control_box_rst_amd.solver import BatchedLevenbergMarquardt, get_dims, get_structure
     out = {}
+    # the same workload through the stage / partitioned-chain kernels with the dt column as a second right-hand side (round 5; the default route of
+    # these descriptors for state blocks of 8 / 12 rows) -- the band route is kept for the A/B and for the structures only it covers
+    for B in (1, 64, 512):
+        d = problems.quad_desc(N=100, time_optimal=True)
+        x0 = np.zeros((B, d.nx)); xf = np.zeros((B, d.nx)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
+        s = BatchedLevenbergMarquardt(d, B, device=device)
+        s.setPenaltyWeights(100.0, 100.0, 100.0)
+        s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+        s.solve(new_run=True); s.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.restore_instance_data(); s.solve(new_run=True)
+        s.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        st = s.get_stats()
+        out[f"chain_route_batch{B}"] = {"ms_per_solve": ms, "passes": int(st["passes"]), "factorizations": int(st["factorizations"]),
+                                        "chi2_sum": float(np.sum(s.get_solution()[1]))}
+        del s
+    os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"   # (read by corbo_hip_create)
     for B in (1, 64):
         d = problems.quad_desc(N=100, time_optimal=True)
         x0 = np.zeros((B, d.nx)); xf = np.zeros((B, d.nx)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
@@ -378,8 +398,10 @@ def band_leg(device):
                             "us_per_pivot": 1e3 * f_ms / (n - 1), "cycles_per_pivot_at_2p4GHz": 2.4e6 * f_ms / (n - 1),
                             "flops_per_factorization_per_instance": flops,
                             "achieved_GFLOPs": B * flops / (f_ms * 1e-3) / 1e9, "frac_of_fp64_vector_peak": B * flops / (f_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
+        out[f"batch{B}"]["chi2_sum"] = float(np.sum(s.get_solution()[1]))
         del s
-    out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass"
+    del os.environ["CORBO_HIP_FREE_DT_BAND"]
+    out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass (batch1 / batch64: CORBO_HIP_FREE_DT_BAND=1); chain_route_*: the same solves through big_stage_kernel / big_chain3_kernel with the border column"
     out["bound"] = "latency: n sequential pivots per instance (one barrier each, eight waves on a sliding LDS window); the flop rate is quoted for completeness"
     return out
 

@@ -488,7 +488,11 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMalloc((void**)&h->d_state, BT * sizeof(LmState)));
     CREATE_TRY(hipMalloc((void**)&h->d_chi2, BT * sizeof(double)));
     // (the band route -- decided below -- reads the sweep's stored Jacobian: it needs neither the stage / chain workspace nor the first factorisation's cache)
-    const bool band_route_early = S.has_extra() || (S.dt_free && big_family_dims(S.nx, S.nu));
+    // A free dt around a big-block model: state blocks of 8 / 12 rows carry it through the partitioned chain as a second right-hand side (round 5);
+    // other block sizes -- and CORBO_HIP_FREE_DT_BAND=1, the A/B switch of bench.py's band leg -- take the band route.
+    const char* fdb_env = std::getenv("CORBO_HIP_FREE_DT_BAND");
+    const bool free_dt_band = S.dt_free && big_family_dims(S.nx, S.nu) && (S.nx % 4 != 0 || (fdb_env && fdb_env[0] == '1'));
+    const bool band_route_early = S.has_extra() || free_dt_band;
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
         if (!band_route_early || !big_family_dims(S.nx, S.nu)) CREATE_TRY(hipMalloc((void**)&h->d_work, BT * h->work_stride * sizeof(double)));
@@ -512,9 +516,9 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     }
     // The band factorisation (band_factor_kernel: H = J^T J from the stored Jacobian through static product lists, natural parameter order, a free dt
     // as a border) takes the structures the stage-parallel kernels do not cover: integral-form constraint edges / control-deviation edges, and a FREE dt
-    // with state blocks of 5 .. 12 rows (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid around a big-block model: the stage and chain
-    // kernels of that family carry no border column) -- the general, slower path: one wave per instance, n sequential pivots.
-    const bool band_route = S.has_extra() || (S.dt_free && big_family_dims(S.nx, S.nu));
+    // with state blocks of 5, 6, 7, 9, 10 or 11 rows (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid around a big-block model whose chain
+    // kernel is not the partitioned one) -- the general, slower path: one workgroup per instance, n sequential pivots.
+    const bool band_route = band_route_early;
     if (S.has_extra()) {
         // ---- the sweep's extra-edge table, the plug-in parameters, the previous control (zeros, dt_ref: structured_optimal_control_problem.cpp:67-71)
         std::vector<XEdge> xe = S.xedges;   // (Jacobian offsets: the device-internal layout is the public order for these handles)
@@ -918,7 +922,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     // (references per component, model parameters per instance) would have to follow the candidates
     // ... and when a pass is long against the one small launch per pass the bookkeeping costs (7 us: below 128 instances it is 4 - 7 % of a solve
     // and the laggers of a small batch hold back little); option reject_speculation: 0 = off, 1 = this rule, 2 = always, every streak (tests)
-    const bool spec = split && h->spare > 0 && h->reject_speculation && (h->batch >= 128 || h->reject_speculation == 2) && h->band.n == 0 &&
+    const bool spec = split && h->spare > 0 && h->reject_speculation && (h->batch >= 128 || h->reject_speculation == 2) && h->band.n == 0 && !h->S.dt_free &&
                       h->active == h->batch && !h->refvec_on && !h->d_dyn_inst && !h->profile && o->iterations > 0;
     auto spec_params = [&](int mode, int32_t* counter) {
         SpecParams q{};

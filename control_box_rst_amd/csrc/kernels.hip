@@ -2590,11 +2590,15 @@ __global__ __launch_bounds__(THREADS) void factor_kernel(const FactorParams p)
 //                       blocks (Schur complement Y Y^T on the matrix cores), backward sweep, controls, trial iterate, LM state.
 // Same LM bookkeeping as factor_body.
 // the two sizes of BigLds the host needs for a descriptor's (nx, nu) (checked against the structure in every unit that uses it)
-constexpr int big_ws_stage(int nx, int nu) { return (3 * nx * nx + nu * nu + 2 * nu * nx + 2 * nx + nu + 2) & ~1; }
+constexpr int big_ws_stage(int nx, int nu)
+{
+    const int base = (3 * nx * nx + nu * nu + 2 * nu * nx + 2 * nx + nu + 2) & ~1;
+    return (base + 3 * nx + nu + 4 + 1) & ~1;   // + the border (free dt) parts: BX, BN, ZU, four scalars, YV2
+}
 constexpr int big_lds_total(int nx, int nu)
 {
-    const int half = (4 * nx + 2 * (nx + nu) + nx * (nx + nu) + 8 + nx * nx + 1) & ~1, s = nx + nu;
-    return 2 * half + ((s * s + s + nu * nu + 2 * nu * nx + nu + 1) & ~1);
+    const int half = (5 * nx + 2 * (nx + nu) + nx * (nx + nu) + 8 + nx * nx + 1) & ~1, s = nx + nu;
+    return 2 * half + ((s * s + 2 * s + nu * nu + 2 * nu * nx + 2 * nu + 1) & ~1);
 }
 
 template <int NX, int NU>
@@ -2611,7 +2615,8 @@ struct BigLds {
     static constexpr int FIX = CIN + NX;               // [NX]     fixed flags (as doubles)
     static constexpr int RED = FIX + NX;               // [8]
     static constexpr int CM = RED + 8;                 // [NX][NX] the x_{k+1} block C when it is dense (collocation defects; shooting: diagonal, CD)
-    static constexpr int HALF = (CM + NX * NX + 1) & ~1;
+    static constexpr int DCV = CM + NX * NX;           // [NX]     the dt column of the defect edge (free-dt grids)
+    static constexpr int HALF = (DCV + NX + 1) & ~1;
     // shared by the two assemble turns of a wave:
     static constexpr int M = 0;                        // [S][S]   [A B]^T [A B]
     static constexpr int GM = M + (NX + NU) * (NX + NU);   // [S] -[A B]^T r
@@ -2619,7 +2624,9 @@ struct BigLds {
     static constexpr int ZX = LUU + NU * NU;           // [NU][NX]
     static constexpr int ZP = ZX + NU * NX;            // [NU][NX]
     static constexpr int YU = ZP + NU * NX;            // [NU]
-    static constexpr int SHARED = (YU + NU + 1) & ~1;
+    static constexpr int HB = YU + NU;                 // [S]  border (free dt): [A B]^T d,  d = the dt column
+    static constexpr int ZUB = HB + NX + NU;           // [NU] L_uu^{-1} (border's control part)
+    static constexpr int SHARED = (ZUB + NU + 1) & ~1;
     static constexpr int TOTAL = 2 * HALF + SHARED;    // doubles per wave (7.4 KB for nx = 12, nu = 4: the register budget, not LDS, bounds the occupancy)
     // HBM workspace per stage
     static constexpr int WS_L = 0;                    // [NX][NX] assemble: own parts of the diagonal block of x_k ; chain: L_k
@@ -2631,9 +2638,15 @@ struct BigLds {
     static constexpr int WS_GN = WS_YV + NX;          // [NX] rhs contribution to x_{k+1}
     static constexpr int WS_YU = WS_GN + NX;          // [NU]
     static constexpr int WS_Y2 = WS_YU + NU;          // [1]  |y_u|^2 of the stage
-    static constexpr int WS_STAGE = (WS_Y2 + 2) & ~1;
+    // border of a free dt (the arrowhead's last column, carried through the chain as a second right-hand side):
+    static constexpr int WS_BX = (WS_Y2 + 2) & ~1;    // [NX] border part of x_k (controls eliminated) ; chain: unchanged
+    static constexpr int WS_BN = WS_BX + NX;          // [NX] border contribution to x_{k+1}
+    static constexpr int WS_ZU = WS_BN + NX;          // [NU] L_uu^{-1} (border's control part)
+    static constexpr int WS_SC = WS_ZU + NU;          // [4]  the stage's parts of H(dt,dt), rhs(dt), |z_u|^2, z_u . y_u
+    static constexpr int WS_YV2 = WS_SC + 4;          // [NX] chain: W z (the second right-hand side's a_k)
+    static constexpr int WS_STAGE = (WS_YV2 + NX + 1) & ~1;
     static_assert(WS_STAGE == big_ws_stage(NX, NU) && TOTAL == big_lds_total(NX, NU), "host-side mirrors of the sizes");
-    static_assert(HALF == ((4 * NX + 2 * (NX + NU) + NX * (NX + NU) + 8 + NX * NX + 1) & ~1), "big_stage_cache_doubles mirrors HALF");
+    static_assert(HALF == ((5 * NX + 2 * (NX + NU) + NX * (NX + NU) + 8 + NX * NX + 1) & ~1), "big_stage_cache_doubles mirrors HALF");
 };
 
 // LDS pointers of one interval of the stage kernel (half = its per-interval area, shared = the wave's assemble scratch)
@@ -2641,10 +2654,11 @@ template <int NX, int NU>
 struct BigCtx {
     using BL = BigLds<NX, NU>;
     static constexpr int S = NX + NU;
-    double *Gm, *cd, *rv, *dg, *gd, *cin, *fx, *red, *cm, *Mm, *gm, *Luu, *Zx, *Zp, *yu;
+    double *Gm, *cd, *rv, *dg, *gd, *cin, *fx, *red, *cm, *dcv, *Mm, *gm, *Luu, *Zx, *Zp, *yu, *hb, *zub;
     __device__ __forceinline__ BigCtx(double* half, double* shared)
         : Gm(half + BL::G), cd(half + BL::CD), rv(half + BL::R), dg(half + BL::DIAG), gd(half + BL::GDIAG), cin(half + BL::CIN), fx(half + BL::FIX),
-          red(half + BL::RED), cm(half + BL::CM), Mm(shared + BL::M), gm(shared + BL::GM), Luu(shared + BL::LUU), Zx(shared + BL::ZX), Zp(shared + BL::ZP), yu(shared + BL::YU) {}
+          red(half + BL::RED), cm(half + BL::CM), dcv(half + BL::DCV), Mm(shared + BL::M), gm(shared + BL::GM), Luu(shared + BL::LUU), Zx(shared + BL::ZX), Zp(shared + BL::ZP),
+          yu(shared + BL::YU), hb(shared + BL::HB), zub(shared + BL::ZUB) {}
 };
 
 // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118), in two steps:
@@ -2653,9 +2667,17 @@ struct BigCtx {
 //                        [NX,2NX) same for rhs, [2NX,3NX) / [3NX,4NX) the C-parts this stage adds to x_{k+1}, [4NX], [4NX+1] the
 //                        maxima over the stage's controls;
 //      big_first_kernel  one wave per instance, lanes over the stages: adds the neighbouring parts, takes the maxima.
-template <int NX, int NU, bool DENSEC = false>
+template <int NX, int NU, bool DENSEC = false, bool ARROW = false>
 __device__ __forceinline__ void big_diag_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk)
 {
+    if constexpr (ARROW) {   // the stage's parts of H(dt,dt) and rhs(dt) (the dt vertex' own rows sit in stage 0's red[5], red[6])
+        if (lane == 63) {
+            double cdt = 0.0, gdt = 0.0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { cdt += c.dcv[r] * c.dcv[r]; gdt -= c.dcv[r] * c.rv[r]; }
+            wk[4 * NX + 2] = cdt + c.red[5]; wk[4 * NX + 3] = gdt + c.red[6];
+        }
+    }
     constexpr int S = NX + NU, W = 2 * NX + NU;
     double mu_d = -1e300, mu_g = 0.0;
     if (lane < W) {
@@ -2681,18 +2703,18 @@ __device__ __forceinline__ void big_diag_stage(const BigCtx<NX, NU>& c, const in
     if (lane == 0) { wk[4 * NX] = mu_d; wk[4 * NX + 1] = mu_g; }
 }
 
-template <int NX, int NU>
+template <int NX, int NU, bool ARROW = false>
 __global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
 {
     using BL = BigLds<NX, NU>;
     constexpr int S = NX + NU;
-    static_assert(4 * NX + 2 <= NX * NX, "the diag parts live in the factor slot of the stage");
+    static_assert(4 * NX + 4 <= NX * NX, "the diag parts live in the factor slot of the stage");
     const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
     LmState* st = p.st + inst;
     if (st->done || !st->first) return;
     const int N = p.N;
     const double* ws = p.work + (size_t)inst * p.work_stride + BL::WS_L;
-    double mx_d = -1e300, mx_g = 0.0;
+    double mx_d = -1e300, mx_g = 0.0, s_cdt = 0.0, s_gdt = 0.0;
     for (int k = lane; k < N; k += 64) {
         const double* wk = ws + (size_t)k * BL::WS_STAGE;
         const double* wp = wk - BL::WS_STAGE;   // stage k-1 (only read for k > 0)
@@ -2703,9 +2725,11 @@ __global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
             if (!p.comp[k * S + i].fixed) { mx_d = fmax(mx_d, dd); mx_g = fmax(mx_g, fabs(gg)); }
         }
         if (k < N - 1) { mx_d = fmax(mx_d, wk[4 * NX]); mx_g = fmax(mx_g, wk[4 * NX + 1]); }
+        if constexpr (ARROW) { s_cdt += wk[4 * NX + 2]; s_gdt += wk[4 * NX + 3]; }
     }
     mx_d = wave_max(mx_d);
     mx_g = wave_max(mx_g);
+    if constexpr (ARROW) { mx_d = fmax(mx_d, wave_sum(s_cdt)); mx_g = fmax(mx_g, fabs(wave_sum(s_gdt))); }   // (:115-118 incl. the dt vertex)
     if (lane == 0) {
         double mu = LM_TAU * mx_d;
         if (mu < 0) mu = 0;
@@ -2717,7 +2741,7 @@ __global__ __launch_bounds__(64) void big_first_kernel(const FactorParams p)
 // ---- per (stage, instance): everything of the factorisation that does not depend on the neighbouring stages.  The local Jacobian
 //      G = [A | B | C], the defect residual and the single-entry rows of the stage's components are in the LDS context c (written by
 //      the stage kernel straight from the finite differences: the Jacobian of this family never exists in HBM).
-template <int NX, int NU, bool USE_MFMA, bool DENSEC = false>
+template <int NX, int NU, bool USE_MFMA, bool DENSEC = false, bool ARROW = false>
 __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, const int N, const int k, const int lane, double* wk, const double mu_eff)
 {
     using BL = BigLds<NX, NU>;
@@ -2760,6 +2784,12 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
 #pragma unroll
             for (int r = 0; r < NX; ++r) v -= Gm[r * S + lane] * rv[r];
             gm[lane] = v;
+            if constexpr (ARROW) {   // border: [A B]^T d
+                double hv = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) hv += Gm[r * S + lane] * c.dcv[r];
+                c.hb[lane] = hv;
+            }
         }
         __syncthreads();
         // controls: Huu = M[uu] + diag + damping, Cholesky by one lane (NU x NU)
@@ -2777,7 +2807,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
         }
         __syncthreads();
         // Zx = L^{-1} H(u, x_k), Zp = L^{-1} H(u, x_{k+1}) = L^{-1} B^T C (column j of B^T scaled by c_j), yu = L^{-1} gu: one lane per column
-        if (lane < 2 * NX + 1) {
+        if (lane < 2 * NX + 1 + (ARROW ? 1 : 0)) {
             double col[NU];
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
@@ -2789,6 +2819,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
                 }
                 else
                 col[a] = (lane < NX) ? Mm[(NX + a) * S + lane] : (lane < 2 * NX) ? Gm[(lane - NX) * S + NX + a] * cd[lane - NX] : gm[NX + a] + gd[NX + a];
+                if constexpr (ARROW) { if (lane == 2 * NX + 1) col[a] = c.hb[NX + a]; }
             }
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
@@ -2801,7 +2832,8 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
             for (int a = 0; a < NU; ++a) {
                 if (lane < NX) Zx[a * NX + lane] = col[a];
                 else if (lane < 2 * NX) Zp[a * NX + lane - NX] = col[a];
-                else { yu[a] = col[a]; y2 += col[a] * col[a]; }
+                else if (lane == 2 * NX) { yu[a] = col[a]; y2 += col[a] * col[a]; }
+                else c.zub[a] = col[a];
             }
         }
         __syncthreads();
@@ -2841,6 +2873,30 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
             for (int a = 0; a < NU; ++a) { g -= Zx[a * NX + lane] * yu[a]; g2 -= Zp[a * NX + lane] * yu[a]; }
         }
         wk[BL::WS_YV + lane] = g; wk[BL::WS_GN + lane] = g2;
+        if constexpr (ARROW) {   // the border's parts of x_k and x_{k+1}, controls eliminated
+            double bx = 0.0, bn = 0.0;
+            if (stage) {
+                bx = c.hb[lane];
+                if constexpr (DENSEC) { for (int r = 0; r < NX; ++r) bn += cm[r * NX + lane] * c.dcv[r]; }
+                else bn = cd[lane] * c.dcv[lane];
+#pragma unroll
+                for (int a = 0; a < NU; ++a) { bx -= Zx[a * NX + lane] * c.zub[a]; bn -= Zp[a * NX + lane] * c.zub[a]; }
+            }
+            wk[BL::WS_BX + lane] = bx; wk[BL::WS_BN + lane] = bn;
+        }
+    }
+    if constexpr (ARROW) {
+        if (lane == 63) {   // the stage's parts of H(dt,dt), rhs(dt) (the dt vertex' own rows: red[5], red[6] of stage 0), |z_u|^2, z_u . y_u
+            double cdt = red[5], gdt = red[6], zzu = 0.0, zyu = 0.0;
+            if (stage) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) { cdt += c.dcv[r] * c.dcv[r]; gdt -= c.dcv[r] * rv[r]; }
+#pragma unroll
+                for (int a = 0; a < NU; ++a) { zzu += c.zub[a] * c.zub[a]; zyu += c.zub[a] * yu[a]; }
+            }
+            wk[BL::WS_SC] = cdt; wk[BL::WS_SC + 1] = gdt; wk[BL::WS_SC + 2] = zzu; wk[BL::WS_SC + 3] = zyu;
+        }
+        if (lane < NU) wk[BL::WS_ZU + lane] = stage ? c.zub[lane] : 0.0;
     }
     if (stage) {
         if (lane < NU * NU) wk[BL::WS_LUU + lane] = Luu[lane];
@@ -2863,7 +2919,7 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
 //      re-assembled from the (unchanged) accepted iterate with the larger damping -- same bits, no Jacobian traffic at all.
 //      jac_dump (parity hook, corbo_hip_eval): the Jacobian values this kernel works with, written in the public value order.
 #pragma clang fp contract(off)
-template <int DYN, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING>
+template <int DYN, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING, bool ARROW = false>
 __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const SweepParams& sp, const BigCtx<Dynamics<DYN>::NX, Dynamics<DYN>::NU>& c,
                                                 const int k, const int l32, const int inst, const int vsel, double* jac_dump)
 {
@@ -2890,7 +2946,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         CORBO_HIP_DYN_OF(dynl, sp, inst)
         const bool minus = (l32 & 1) != 0;
 #pragma unroll 1
-        for (int c0 = 0; c0 <= W; c0 += 16) {
+        for (int c0 = 0; c0 <= W + (ARROW ? 1 : 0); c0 += 16) {   // (free dt: column W + 1 is the dt column, every q of the formula changes)
             const int col = c0 + (l32 >> 1);
             double loc[W], e[NX];
             double pert = 0.0;
@@ -2900,10 +2956,17 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
             if (minus) pert += neg2delta;
 #pragma unroll
             for (int i = 0; i < W; ++i) loc[i] = (i == col) ? pert : loc[i];
-            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dt0, dynl, e);
+            double dtl = dt0;
+            if constexpr (ARROW) {
+                double da = dt0 + delta;
+                if (minus) da += neg2delta;
+                dtl = (col == W + 1) ? da : dt0;
+            }
+            defect_eval<DYN, DEFECT>(loc, loc + NX, loc + S, dtl, dynl, e);
             int jo = -1;
 #pragma unroll
             for (int i = 0; i < W; ++i) jo = (i == col) ? sc[i] : jo;
+            if constexpr (ARROW) jo = (col == W + 1) ? sc[W] : jo;
             const bool present = stage && col < W && jo >= 0;
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
@@ -2915,6 +2978,13 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
                     if (jac_dump && present) jac_dump[jo + r] = cv;
                 }
                 if (col == W && !minus) c.rv[r] = stage ? e[r] * sp.w_eq : 0.0;
+                if constexpr (ARROW) {
+                    if (col == W + 1 && !minus) {
+                        const bool pdt = stage && jo >= 0;
+                        c.dcv[r] = pdt ? cv : 0.0;
+                        if (jac_dump && pdt) jac_dump[jo + r] = cv;
+                    }
+                }
             }
         }
     }
@@ -2946,6 +3016,25 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
             if (!minus && col < S) {
                 c.Gm[r * S + col] = present ? cv : 0.0;
                 if (jac_dump && present) jac_dump[jo + r] = cv;
+            }
+        }
+        if constexpr (ARROW) {   // free dt: one more pair of integrations (lanes 0 / 1 of the interval matter), the step length perturbed
+#pragma unroll
+            for (int i = 0; i < S; ++i) loc[i] = X[kk * S + i];
+            double da = dt0 + delta;
+            if (minus) da += neg2delta;
+            rk4_end_state<DYN, false>(loc, loc + NX, da, dynl, ck, xe);
+            const int jd    = sc[S + NX];
+            const bool pdt  = stage && jd >= 0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                const double ev = xe[r] - X[kk * S + S + r];
+                const double eo = __shfl_xor(ev, 1);
+                const double cv = (scalar * (ev - eo)) * sp.w_eq;
+                if (l32 == 0) {
+                    c.dcv[r] = pdt ? cv : 0.0;
+                    if (jac_dump && pdt) jac_dump[jd + r] = cv;
+                }
             }
         }
     }
@@ -3063,10 +3152,36 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         c.dg[e] = dd;
         c.gd[e] = gg;
     }
+    if constexpr (ARROW) {   // the dt vertex' own rows (cost row, the duplicated MinimumTime row, bound row): once per instance, with stage 0
+        if (l32 == S) {
+            double dd = 0.0, gg = 0.0;
+            if (k == 0) {
+                const CompInfo ci = p.comp[sp.off_dt];
+                const double xv = dt0, w = sp.mp.dt_weight, ref = 0.0;
+                if (!ci.fixed && ci.cost_joff >= 0) {
+                    const double a = xv + delta, b = a + neg2delta;
+                    const double dv  = scalar * (w * (a - ref) - w * (b - ref));
+                    const double val = w * (xv - ref);
+                    dd += dv * dv; gg -= dv * val;
+                    if (jac_dump) jac_dump[ci.cost_joff] = dv;
+                    if (ci.cost2_joff >= 0) { dd += dv * dv; gg -= dv * val; if (jac_dump) jac_dump[ci.cost2_joff] = dv; }
+                }
+                if (ci.bnd_joff >= 0) {
+                    const double l = sp.lb[xo + sp.off_dt], u = sp.ub[xo + sp.off_dt];
+                    const double ab = (xv < l) ? -sp.w_b : ((xv > u) ? sp.w_b : 0.0);
+                    double vb = (xv < l) ? l - xv : ((xv > u) ? xv - u : 0.0);
+                    vb *= sp.w_b;
+                    dd += ab * ab; gg -= ab * vb;
+                    if (jac_dump) jac_dump[ci.bnd_joff] = ab;
+                }
+            }
+            c.red[5] = dd; c.red[6] = gg;
+        }
+    }
 }
 #pragma clang fp contract(fast)
 
-template <int DYN, bool USE_MFMA, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING>
+template <int DYN, bool USE_MFMA, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING, bool ARROW = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 registers: three waves per SIMD (170 without the cap, i.e. two; a cap of four spills 270 bytes and loses)
 void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
@@ -3098,7 +3213,7 @@ void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag
         for (int i = lane; i < BL::HALF; i += 64) reinterpret_cast<double2*>(sm)[i] = cache[i];
     }
     else
-    big_stage_edges<DYN, DEFECT>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
+    big_stage_edges<DYN, DEFECT, ARROW>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
     __syncthreads();
     if (jac_dump) return;
     if (cache && diag_only)
@@ -3107,8 +3222,8 @@ void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag
         const int k = 2 * pair + h;
         if (k >= p.N) break;
         double* wk = p.work + (size_t)inst * p.work_stride + (size_t)k * BL::WS_STAGE;
-        if (diag_only) big_diag_stage<NX, NU, DENSEC>(h ? c1 : c0, p.N, k, lane, wk + BL::WS_L);
-        else big_assemble_stage<NX, NU, USE_MFMA, DENSEC>(h ? c1 : c0, p.N, k, lane, wk, mu_eff);
+        if (diag_only) big_diag_stage<NX, NU, DENSEC, ARROW>(h ? c1 : c0, p.N, k, lane, wk + BL::WS_L);
+        else big_assemble_stage<NX, NU, USE_MFMA, DENSEC, ARROW>(h ? c1 : c0, p.N, k, lane, wk, mu_eff);
     }
 }
 
@@ -3776,7 +3891,7 @@ __global__ __launch_bounds__(256) void big_chain2_kernel(const FactorParams p)
 //      * reduced chain (NSEG - 1 blocks, one wave), then x_meeting, then both waves of every segment outwards.
 //      Same numbers as a Cholesky factorisation in the order [segment interiors, outside in | meeting blocks | separators]: the step
 //      differs from big_chain2_kernel's at rounding level (1e-13 relative), like that one's from Eigen's AMD order.
-template <int NX, int NU, int NSEG>
+template <int NX, int NU, int NSEG, bool ARROW = false>
 struct Chain3Lds {
     static constexpr int NN = NX * NX;
     static constexpr int DN = 0;                     // [NX][NX] Schur mailbox: -Y Y^T (+ the stage's contribution) for the next block of the sequence
@@ -3787,7 +3902,9 @@ struct Chain3Lds {
     static constexpr int WL = ZL + NN;               // [NX][NX] W rows
     static constexpr int GN = WL + NN;               // [16] right-hand-side mailbox
     static constexpr int GS = GN + 16;               // [16] what this wave adds to the right-hand side of its separator
-    static constexpr int PER_WAVE = GS + 16;
+    static constexpr int GN2 = GS + 16;              // (free dt) the same two mailboxes of the second right-hand side: the border column
+    static constexpr int GS2 = GN2 + 16;
+    static constexpr int PER_WAVE = ARROW ? GS2 + 16 : GS + 16;
     // Nothing else is shared but the state increments: what the phases after the elimination need lives in wave areas that are dead by then --
     //   the separator behind a downward wave is staged by that wave in its own YL (own parts of the diagonal block) and ZL ([0,12) right-hand side,
     //   [12] |y_u|^2 of the stage, [13] fixed mask), the coupling of a segment's two separators (-Z Y^T of its meeting block; rows: left
@@ -3795,17 +3912,18 @@ struct Chain3Lds {
     //   GN as its Schur / right-hand-side mailbox and keeps separator j's back-substitution operator / vector in ZL / GN of the upward wave 2 j.
     static constexpr int IDM = 2 * NSEG * PER_WAVE;  // [NX][NX] identity: the I rows of the stacked matrix read their start values like the other rows read their mailboxes
     static constexpr int DXS = IDM + NN;
-    __host__ __device__ static constexpr int total(int N) { return DXS + N * NX + 4 * NSEG + 8; }   // + state increments + sums (NSEG = 4, N = 200: 76.7 KB, two workgroups per CU)
+    static constexpr int BSUM = ARROW ? 12 * NSEG + 8 : 0;   // (free dt) per wave: z.y, |z|^2 and the four stage scalars; [12 NSEG] delta_dt, [12 NSEG + 1] y_dt^2
+    __host__ __device__ static constexpr int total(int N) { return DXS + N * NX + 4 * NSEG + 8 + BSUM; }   // + state increments + sums (NSEG = 4, N = 200: 76.7 KB, two workgroups per CU)
 };
 
 // (the body: `st` = the instance's LM state in LDS, `sm` = the chain's LDS area, `xs` = optional LDS copy of the trial iterate.  A residual sweep fused
 // behind the chain in the same launch -- sweep_body on that copy, 8 waves -- was built and measured: cfg 5 9.09 -> 9.36 ms, one OCP 1.83 -> 1.96 ms: the
 // sweep then runs at the chain's occupancy, one workgroup per CU, and its dependent descriptor loads are no longer hidden by co-resident workgroups; removed)
-template <int NX, int NU, int NSEG>
+template <int NX, int NU, int NSEG, bool ARROW = false>
 __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* const st, double* const sm, const int inst, double* const xs)
 {
     using BL = BigLds<NX, NU>;
-    using CL = Chain3Lds<NX, NU, NSEG>;
+    using CL = Chain3Lds<NX, NU, NSEG, ARROW>;
     constexpr int S = NX + NU, NN = NX * NX, NW = 2 * NSEG, THREADS = 128 * NSEG;
     static_assert(NX <= 12 && NX % 4 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, spike rows 32.., identity rows 48..");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -3818,6 +3936,8 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     double *Dn = wsm + CL::DN, *Tm = wsm + CL::TM, *Ds = wsm + CL::DS, *Yl = wsm + CL::YL, *Zl = wsm + CL::ZL, *Wl = wsm + CL::WL, *gnl = wsm + CL::GN, *gs = wsm + CL::GS;
     double* dxs  = sm + CL::DXS;                     // [N][NX] delta x of every block
     double* sums = dxs + N * NX;                     // [2 NW + ..] reductions across the waves
+    double* bsum = sums + 4 * NSEG + 8;              // (free dt) [6 NW] per wave: z.y, |z|^2, sums of the stage scalars; then delta_dt, y_dt^2
+    double *gnl2 = wsm + CL::GN2, *gs2 = wsm + CL::GS2;   // (only touched when ARROW)
     const double* xin = p.x + (size_t)inst * p.nvs;
     double* xt        = p.xt + (size_t)inst * p.nvs;
     double* ws        = p.work + (size_t)inst * p.work_stride;
@@ -3831,6 +3951,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     auto block_of = [&](int s) { return (side == 0) ? a + s : b - s; };
     // lane roles
     const bool isD = lane < NX, isC = lane >= 16 && lane < 16 + NX, isG = lane == 28, isS = lane >= 32 && lane < 32 + NX, isI = lane >= 48 && lane < 48 + NX;
+    const bool isG2 = ARROW && lane == 29;           // free dt: the border column rides along as a second right-hand-side row
     const int row = isD ? lane : (isC ? lane - 16 : (isS ? lane - 32 : (isI ? lane - 48 : 0)));
     // ---- mailboxes: empty, except next to a separator (the separator's stage contributes to the first block of an upward wave; the
     //      direct coupling of the first block to the separator is the spike the wave starts with)
@@ -3844,6 +3965,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
                 Tm[e] = wq[BL::WS_Y + c * NX + r];                    // H[sep, a] = H[a, sep]^T
             }
             if (lane < NX) gnl[lane] = wq[BL::WS_GN + lane];
+            if constexpr (ARROW) { if (lane < NX) gnl2[lane] = wq[BL::WS_BN + lane]; }
         }
         else {
             const double* wq = ws + (size_t)b * BL::WS_STAGE;         // stage b: couples block b to the separator b + 1
@@ -3852,28 +3974,41 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
                 Ds[e] = wq[BL::WS_DN + e];
             }
             if (lane < NX) gs[lane] = wq[BL::WS_GN + lane];
+            if constexpr (ARROW) { if (lane < NX) gs2[lane] = wq[BL::WS_BN + lane]; }
         }
+    }
+    if constexpr (ARROW) {   // the stage scalars of the border: every wave sums its share of the stages
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int k = tid; k < N; k += THREADS) {
+            const double* sc4 = ws + (size_t)k * BL::WS_STAGE + BL::WS_SC;
+            s0 += sc4[0]; s1 += sc4[1]; s2 += sc4[2]; s3 += sc4[3];
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+        if (lane == 0) { bsum[6 * wave + 2] = s0; bsum[6 * wave + 3] = s1; bsum[6 * wave + 4] = s2; bsum[6 * wave + 5] = s3; }
     }
     if (wave == 0)
         for (int e = lane; e < NN; e += 64) sm[CL::IDM + e] = (e / NX == e % NX) ? 1.0 : 0.0;
     // how a lane forms its row of the stacked matrix from what it prefetched (pm, pe) and its mailbox: coefficients instead of selects
     //   D: pm + mailbox (+ pe downward) | C: pm | S: mailbox | g: pm + mailbox (+ pe downward) | I: "mailbox" = a row of the identity
-    const double cpm   = (isD || isC || isG) ? 1.0 : 0.0;
-    const double cmail = (isD || isS || isG || isI) ? 1.0 : 0.0;
-    const double cpe   = (side == 1 && (isD || isG)) ? 1.0 : 0.0;
-    const double2* mailp = reinterpret_cast<const double2*>(isD ? Dn + row * NX : (isS ? Tm + row * NX : (isI ? sm + CL::IDM + row * NX : gnl)));
+    const double cpm   = (isD || isC || isG || isG2) ? 1.0 : 0.0;
+    const double cmail = (isD || isS || isG || isG2 || isI) ? 1.0 : 0.0;
+    const double cpe   = (side == 1 && (isD || isG || isG2)) ? 1.0 : 0.0;
+    const double2* mailp = reinterpret_cast<const double2*>(isD ? Dn + row * NX : (isS ? Tm + row * NX : (isI ? sm + CL::IDM + row * NX : (isG2 ? gnl2 : gnl))));
     // ---- prefetch of a block's assembled data, branch-free (see big_chain2_kernel)
     const int back = (side == 0) ? 0 : BL::WS_STAGE;   // downward waves take coupling / DN / GN from stage k-1
     int off_a = 0, str_a = 1, off_b = 0, off_g = 0;
     if (isD) { off_a = BL::WS_L + row * NX; off_b = BL::WS_DN + row * NX - back; }
     if (isC) { off_a = (side == 0) ? BL::WS_Y + row * NX : BL::WS_Y + row - back; str_a = (side == 0) ? 1 : NX; off_g = BL::WS_GN + row - back; }
     if (isG) { off_a = BL::WS_YV; off_b = BL::WS_GN - back; }
-    double pm[NX], pe[NX], pgn = 0.0, py2 = 0.0;
+    if (isG2) { off_a = BL::WS_BX; off_b = BL::WS_BN - back; }
+    const int off_g2 = isC ? BL::WS_BN + row - back : 0;
+    double pm[NX], pe[NX], pgn = 0.0, py2 = 0.0, pbn = 0.0;
     int pfix = 0;
     // (per-lane pointers and a per-lane byte stride, advanced load by load: indexing wk[off + cc * stride] cost 130 address instructions per block)
     const double* const pa0 = ws + off_a;
     const double* const pb0 = ws + off_b;
     const double* const pg0 = ws + off_g;
+    const double* const pg20 = ws + off_g2;
     const ptrdiff_t sa = str_a;
     const int32_t* const fx0 = &p.comp[row].fixed;
     auto fetch = [&](int k) {
@@ -3883,9 +4018,11 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
 #pragma unroll
         for (int cc = 0; cc < NX; ++cc) { pm[cc] = *pa; pa += sa; pe[cc] = pb[cc]; }
         pgn  = pg0[ko];
+        if constexpr (ARROW) pbn = pg20[ko];
         py2  = ws[ko + BL::WS_Y2];
         pfix = fx0[(size_t)k * S * (sizeof(CompInfo) / sizeof(int32_t))];
     };
+    double acc2 = 0.0;   // (free dt) second result of stacked_pass: the row's product with z
     auto stacked_pass = [&](double (&mrow)[NX]) -> double {   // (big_chain2_kernel: look-ahead order, v_rsq_f64 + the library's Newton step)
         double inv = rsqrt(lane_bcast(mrow[0], 0));
 #pragma unroll
@@ -3911,6 +4048,12 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         double acc = 0.0;
 #pragma unroll
         for (int t = 0; t < NX; ++t) acc += mrow[t] * lane_bcast(mrow[t], 28);
+        if constexpr (ARROW) {   // the same with the second right-hand-side row z^T (lane 29)
+            double a2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < NX; ++t) a2 += mrow[t] * lane_bcast(mrow[t], 29);
+            acc2 = a2;
+        }
         return acc;
     };
     typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -3947,6 +4090,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         }
     };
     double y2 = 0.0, zy = 0.0;            // zy: S lanes, (Z y)[row] summed over the wave's steps
+    double zy2 = 0.0, bsc = 0.0;          // (free dt) S lanes: (Z z)[row]; lane 28: z . y, lane 29: |z|^2 -- over the wave's pivots
     d4_t accZ = {0.0, 0.0, 0.0, 0.0};
     fetch(block_of(0));
     __syncthreads();   // the identity rows are in place
@@ -3970,7 +4114,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
                 const double unit  = (row == cc) ? 1.0 : 0.0;
                 double v = mrow[cc];
                 v = (isD && (fixed_r || fixed_c)) ? unit : v;
-                v = (isG && fixed_c) ? 0.0 : v;
+                v = ((isG || isG2) && fixed_c) ? 0.0 : v;
                 mrow[cc] = v;
             }
         }
@@ -3979,7 +4123,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
 #pragma unroll
             for (int c2 = 0; c2 < NX / 2; ++c2) dn2[c2] = (side == 0) ? double2{pe[2 * c2], pe[2 * c2 + 1]} : double2{0.0, 0.0};
         }
-        const double gn_base = (side == 0) ? pgn : 0.0;
+        const double gn_base = (side == 0) ? pgn : 0.0, gn2_base = (side == 0) ? pbn : 0.0;
         y2 += (lane == 0) ? py2 : 0.0;
         // next block of the wave; behind the last one: the segment's meeting block (its own parts: the upward wave takes it after the barrier)
         fetch((s + 1 < mysteps) ? block_of(s + 1) : m);
@@ -3989,6 +4133,12 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         zy += acc;                                        // (S lanes) the separator's right-hand side collects - Z y
         double* wk = ws + (size_t)k * BL::WS_STAGE;
         if (isI) wk[BL::WS_YV + row] = acc;               // a_k = W y
+        if constexpr (ARROW) {
+            bsc += acc2;                                  // lane 28: y . z ; lane 29: z . z
+            if (isC) gnl2[row] = gn2_base - acc2;
+            zy2 += acc2;
+            if (isI) wk[BL::WS_YV2 + row] = acc2;         // W z
+        }
         if (isC || isS || isI) {
             double2* dst = reinterpret_cast<double2*>((isC ? Yl : (isS ? Zl : Wl)) + row * NX);
 #pragma unroll
@@ -4003,6 +4153,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
             if (i < NX && j < NX) Ds[i * NX + j] -= accZ[r];
         }
         if (isS) gs[row] -= zy;
+        if constexpr (ARROW) { if (isS) gs2[row] -= zy2; }
     };
     if (side == 1) flush_sep();
     if (mysteps == 0 && side == 0) fetch(m);   // (a segment of one or two blocks)
@@ -4013,6 +4164,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         const double* wq = ws + (size_t)sj * BL::WS_STAGE;
         for (int e = lane; e < NN; e += 64) Yl[e] = wq[BL::WS_L + e];
         if (lane < NX) Zl[lane] = wq[BL::WS_YV + lane];
+        if constexpr (ARROW) { if (lane < NX) Zl[16 + lane] = wq[BL::WS_BX + lane]; }
         const unsigned long long fm = __ballot(lane < NX && p.comp[sj * S + (lane < NX ? lane : 0)].fixed != 0);
         if (lane == 0) { Zl[12] = wq[BL::WS_Y2]; Zl[13] = (double)(unsigned)fm; }
     }
@@ -4020,8 +4172,8 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     // ---- the meeting block of every segment (upward wave): own parts + both mailboxes, "next" = the right separator, spike = the left one
     if (side == 0) {
         double* wo = wsm + CL::PER_WAVE;                  // the downward wave's areas
-        const double *Dn1 = wo + CL::DN, *gn1 = wo + CL::GN, *Tm1 = wo + CL::TM;
-        double *Ds1 = wo + CL::DS, *gs1 = wo + CL::GS;
+        const double *Dn1 = wo + CL::DN, *gn1 = wo + CL::GN, *Tm1 = wo + CL::TM, *gn1b = wo + CL::GN2;
+        double *Ds1 = wo + CL::DS, *gs1 = wo + CL::GS, *gs1b = wo + CL::GS2;
         const unsigned long long fmask = __ballot(pfix != 0 && isD);
         const bool fixed_r = (fmask >> row) & 1ull;
         double mrow[NX];
@@ -4034,6 +4186,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
             else if (isC) v = Tm1[row * NX + cc];
             else if (isS) v = Tm[row * NX + cc];
             else if (isG) v = fixed_c ? 0.0 : pm[cc] + gnl[cc] + gn1[cc];
+            else if (isG2) v = fixed_c ? 0.0 : pm[cc] + gnl2[cc] + gn1b[cc];
             else if (isI) v = unit;
             mrow[cc] = v;
         }
@@ -4044,6 +4197,12 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         zy += acc;                                        // left separator:  - Z y
         double* wk = ws + (size_t)m * BL::WS_STAGE;
         if (isI) wk[BL::WS_YV + row] = acc;
+        if constexpr (ARROW) {
+            bsc += acc2;
+            if (isC) gs1b[row] -= acc2;
+            zy2 += acc2;
+            if (isI) wk[BL::WS_YV2 + row] = acc2;
+        }
         if (isC || isS || isI) {
             double* dst = (isC ? Yl : (isS ? Zl : Wl)) + row * NX;
 #pragma unroll
@@ -4052,15 +4211,20 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         products(Yl, Zl, Wl, Ds1, Tm, accZ, wk + BL::WS_L, wk + BL::WS_DN, true);   // (the spike mailbox has been read: it takes the separators' coupling)
         flush_sep();
     }
+    if constexpr (ARROW) {
+        if (wave != 1 && (isG || isG2)) bsum[6 * wave + (isG ? 0 : 1)] = bsc;
+    }
     __syncthreads();
     // ---- reduced chain over the separators (wave 1): D_j = own + what the two neighbouring waves collected, coupling to the next
     //      separator = (segment j's  -Z Y^T)^T, plain twisted-free elimination (NSEG - 1 blocks), then its back-substitution
     if (wave == 1) {
         double* w0 = sm;                                  // wave 0's areas (its meeting block is done)
-        double *Dr = w0 + CL::ZL, *gr = w0 + CL::GN, *yop = w0 + CL::YL, *wop = w0 + CL::WL;
+        double *Dr = w0 + CL::ZL, *gr = w0 + CL::GN, *yop = w0 + CL::YL, *wop = w0 + CL::WL, *gr2 = w0 + CL::GN2;
         auto area = [&](int w) { return sm + w * CL::PER_WAVE; };
         for (int e = lane; e < NN; e += 64) Dr[e] = 0.0;
         if (lane < 16) gr[lane] = 0.0;
+        if constexpr (ARROW) { if (lane < 16) gr2[lane] = 0.0; }
+        double last_a = 0.0, last_a2 = 0.0, ddt_r = 0.0;
         for (int j = 1; j < NSEG; ++j) {
             const double* DsL = area(2 * j - 1) + CL::DS;   // downward wave of the segment on the left
             const double* DsR = area(2 * j) + CL::DS;       // upward wave of the segment on the right
@@ -4068,6 +4232,8 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
             const double* gsR = area(2 * j) + CL::GS;
             const double* own = area(2 * j - 1) + CL::YL;   // staged by the downward wave on the left
             const double* og  = area(2 * j - 1) + CL::ZL;
+            const double* gsL2 = area(2 * j - 1) + CL::GS2;
+            const double* gsR2 = area(2 * j) + CL::GS2;
             const double* rc  = area(2 * j) + CL::TM;       // segment j lies between separator j and j + 1
             const unsigned long long fmask = (unsigned long long)(unsigned)og[13];
             const bool fixed_r = (fmask >> row) & 1ull;
@@ -4081,13 +4247,17 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
                 if (isD) v = (fixed_r || fixed_c) ? unit : own[row * NX + cc] + DsL[row * NX + cc] + DsR[row * NX + cc] + Dr[row * NX + cc];
                 else if (isC) v = last ? 0.0 : rc[cc * NX + row];   // H[sep j+1, sep j]
                 else if (isG) v = fixed_c ? 0.0 : og[cc] + gsL[cc] + gsR[cc] + gr[cc];
+                else if (isG2) v = fixed_c ? 0.0 : og[16 + cc] + gsL2[cc] + gsR2[cc] + gr2[cc];
                 else if (isI) v = unit;
                 mrow[cc] = v;
             }
             y2 += (lane == 0) ? og[12] : 0.0;
             const double acc = stacked_pass(mrow);
             if (isG) y2 += acc;
+            if constexpr (ARROW) bsc += acc2;
             if (last) {
+                if constexpr (ARROW) { last_a = acc; last_a2 = acc2; }   // (x = W y - delta_dt W z: behind the last pivot, below)
+                else
                 if (isI) dxs[sep_of(j) * NX + row] = acc;   // x = W y
             }
             else {
@@ -4095,6 +4265,10 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
                 double* ARj = area(2 * j) + CL::GN;
                 if (isC) gr[row] = -acc;
                 if (isI) ARj[row] = acc;
+                if constexpr (ARROW) {
+                    if (isC) gr2[row] = -acc2;
+                    if (isI) (area(2 * j) + CL::GN2)[row] = acc2;
+                }
                 if (isC || isI) {
                     double* dst = (isC ? yop : wop) + row * NX;
 #pragma unroll
@@ -4107,9 +4281,24 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
                 products(yop, yop, wop, Dr, nullptr, accZ, GRj, w0 + CL::DN, false);   // (gH: scratch)
             }
         }
+        if constexpr (ARROW) {
+            // the last pivot: H(dt,dt) + damping - |z|^2  (factor_body's arrowhead, same formulas);  every forward elimination is behind us
+            double zyt = lane_bcast(bsc, 28), zzt = lane_bcast(bsc, 29), cdt = 0.0, gdt = 0.0;
+            for (int w = 0; w < NW; ++w) {
+                if (w != 1) { zyt += bsum[6 * w]; zzt += bsum[6 * w + 1]; }
+                cdt += bsum[6 * w + 2]; gdt += bsum[6 * w + 3]; zzt += bsum[6 * w + 4]; zyt += bsum[6 * w + 5];
+            }
+            const double piv  = (cdt + mu_eff) - zzt;
+            const double linv = rsqrt(piv);
+            const double ydt  = (gdt - zyt) * linv;
+            ddt_r = ydt * linv;
+            if (lane == 0) { bsum[6 * NW] = ddt_r; bsum[6 * NW + 1] = ydt * ydt; }
+            if constexpr (NSEG > 1) { if (isI) dxs[sep_of(NSEG - 1) * NX + row] = last_a - ddt_r * last_a2; }
+        }
         for (int j = NSEG - 2; j >= 1; --j) {
             const double xn = isD ? dxs[sep_of(j + 1) * NX + lane] : 0.0;
             double v = isD ? (area(2 * j) + CL::GN)[lane] : 0.0;
+            if constexpr (ARROW) { if (isD) v -= ddt_r * (area(2 * j) + CL::GN2)[lane]; }
             const double* g = area(2 * j) + CL::ZL + (isD ? lane : 0) * NX;
 #pragma unroll
             for (int i = 0; i < NX; ++i) v -= g[i] * lane_bcast(xn, i);
@@ -4118,6 +4307,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     }
     __syncthreads();
     // ---- back-substitution.  Meeting block (upward wave):  x_m = a_m - G_m x_right - Gs_m x_left
+    const double ddt = ARROW ? bsum[6 * NW] : 0.0;   // (written by wave 1 before the barrier above)
     const int rr = isD ? lane : (isC ? lane - 16 : 0);
     const int off_back = isC ? BL::WS_DN + rr * NX : BL::WS_L + rr * NX;   // D lanes: rows of G_k, C lanes: rows of Gs_k
     if (side == 0) {
@@ -4125,7 +4315,8 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         double g[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) g[i] = wk[off_back + i];
-        const double am = wk[BL::WS_YV + rr];
+        double am = wk[BL::WS_YV + rr];
+        if constexpr (ARROW) am -= ddt * wk[BL::WS_YV2 + rr];
         const double xr = (isD && seg < NSEG - 1) ? dxs[(b + 1) * NX + lane] : 0.0;
         const double xl = (isD && seg > 0) ? dxs[(a - 1) * NX + lane] : 0.0;
         double v = 0.0;
@@ -4137,7 +4328,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     __syncthreads();
     // ---- outwards in every segment: x_k = a_k - G_k x_neighbour - Gs_k x_sep, data two steps ahead
     {
-        struct BackBuf { double g[NX], a; };
+        struct BackBuf { double g[NX], a, a2; };
         BackBuf b0{}, b1{};
         auto blk_of = [&](int s) { return (side == 0) ? m - 1 - s : m + 1 + s; };
         const int last_s = (mysteps > 0) ? mysteps - 1 : 0;
@@ -4146,6 +4337,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
 #pragma unroll
             for (int i = 0; i < NX; ++i) bb.g[i] = wk[off_back + i];
             bb.a = wk[BL::WS_YV + rr];
+            if constexpr (ARROW) bb.a2 = wk[BL::WS_YV2 + rr];
         };
         const double xsep = (isD && spike) ? dxs[((side == 0) ? a - 1 : b + 1) * NX + lane] : 0.0;
         double xn = isD ? dxs[m * NX + lane] : 0.0;
@@ -4155,6 +4347,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
 #pragma unroll
             for (int i = 0; i < NX; ++i) t += bb.g[i] * lane_bcast(xsep, i);
             double v = bb.a - __shfl(t, (lane + 16) & 63);
+            if constexpr (ARROW) v -= ddt * bb.a2;
 #pragma unroll
             for (int i = 0; i < NX; ++i) v -= bb.g[i] * lane_bcast(xn, i);
             fetch_b(bb, s + 2);
@@ -4187,6 +4380,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
             double v = wq[BL::WS_YU + c];
+            if constexpr (ARROW) v -= wq[BL::WS_ZU + c] * ddt;
 #pragma unroll
             for (int t = 0; t < NX; ++t) v -= wq[BL::WS_ZX + c * NX + t] * dxs[q * NX + t] + wq[BL::WS_ZP + c * NX + t] * dxs[(q + 1) * NX + t];
             w[c] = v;
@@ -4204,8 +4398,8 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         }
     }
     if (tid == 0) {
-        xt[p.off_dt] = xin[p.off_dt];
-        if (xs) xs[p.off_dt] = xin[p.off_dt];
+        xt[p.off_dt] = xin[p.off_dt] + ddt;
+        if (xs) xs[p.off_dt] = xin[p.off_dt] + ddt;
         if (p.off_dt + 1 < p.nvs) { xt[p.off_dt + 1] = 0.0; if (xs) xs[p.off_dt + 1] = 0.0; }
     }
     y2  = wave_sum(y2);
@@ -4215,6 +4409,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     if (tid == 0) {
         y2 = 0.0; dn2 = 0.0;
         for (int w = 0; w < NW; ++w) { y2 += sums[2 * w]; dn2 += sums[2 * w + 1]; }
+        if constexpr (ARROW) { y2 += bsum[6 * NW + 1]; dn2 += ddt * ddt; }
         st->mu_acc = mu_eff;
         st->first  = 0;
         st->fresh  = 0;
@@ -4230,7 +4425,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     }
 }
 
-template <int NX, int NU, int NSEG>
+template <int NX, int NU, int NSEG, bool ARROW = false>
 __global__ __launch_bounds__(128 * NSEG)
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 196 registers: two waves per SIMD (four segments: one workgroup per CU; two: two).  A 128-register build
                                              // (two 8-wave workgroups per CU) spills 290 - 340 bytes per lane into the dependent chain: 0.73 -> 0.88 ms per factor launch group at cfg 5, measured;
@@ -4238,12 +4433,12 @@ __attribute__((amdgpu_waves_per_eu(2, 2)))   // 196 registers: two waves per SIM
 void big_chain3_kernel(const FactorParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double sm3[];
-    LmState* sl = reinterpret_cast<LmState*>(sm3 + ((Chain3Lds<NX, NU, NSEG>::total(p.N) + 1) & ~1));
+    LmState* sl = reinterpret_cast<LmState*>(sm3 + ((Chain3Lds<NX, NU, NSEG, ARROW>::total(p.N) + 1) & ~1));
     const int inst = blockIdx.x + p.inst0;
     lm_state_in(sl, p.st + inst, threadIdx.x);
     __syncthreads();
     if (sl->done) return;
-    big_chain3_body<NX, NU, NSEG>(p, sl, sm3, inst, nullptr);
+    big_chain3_body<NX, NU, NSEG, ARROW>(p, sl, sm3, inst, nullptr);
     __syncthreads();
     lm_state_out(p.st + inst, sl, threadIdx.x);
 }
@@ -5280,6 +5475,20 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
     if (!sp.xe0 || (!fp.work && !jac_dump)) return false;
     const size_t lds = sizeof(double) * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
     const dim3 g((fp.N + 1) / 2, fp.batch), b(64);
+    if (fp.dt_free) {   // free dt: the dt column of every defect edge and the border parts (second right-hand side of the chain)
+        // (state blocks of 8 / 12 rows only -- the partitioned chain carries the border; the 6-state unit also trips a compiler defect on these instantiations,
+        //  "Operand has incorrect register class: V_CMP_NE_U32 0, $src_shared_base", docs/measurements/r05.md 3)
+        if constexpr (Dy::NX % 4 != 0) return false;
+        else
+        switch (fp.defect) {
+            case CORBO_HIP_DEFECT_RK4_SHOOTING: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_RK4_SHOOTING, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            case CORBO_HIP_DEFECT_BACKWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_BACKWARD, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            case CORBO_HIP_DEFECT_MIDPOINT: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_MIDPOINT, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            case CORBO_HIP_DEFECT_CRANK_NICOLSON: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_CRANK_NICOLSON, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            default: return false;
+        }
+    }
     switch (fp.defect) {   // shooting (Runge-Kutta 4 / 3 / 2, Euler), or a collocation formula on the FiniteDifferencesGrid
         case CORBO_HIP_DEFECT_RK4_SHOOTING: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
         case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
@@ -5297,13 +5506,31 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
     using Dy = Dynamics<CORBO_HIP_DYN_TU>;
     constexpr int NX = Dy::NX, NU = Dy::NU;
     static_assert(big_family_dims(NX, NU), "big-block family: 5 <= nx <= 12, nu <= 4, nx + nu <= 16");
-    if (p.dt_free || !p.work) return false;
+    if (!p.work) return false;
+    if (p.dt_free && NX % 4 != 0) return false;   // (a free dt rides through the partitioned chain only: block sizes 8 and 12; others take the band route)
     if (p.first_pass) {   // (the kernels themselves also check LmState::first)
         if (!CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(p, sp, 1, nullptr, stream)) return false;
-        hipLaunchKernelGGL((big_first_kernel<NX, NU>), dim3(p.batch), dim3(64), 0, stream, p);
+        if (p.dt_free) hipLaunchKernelGGL((big_first_kernel<NX, NU, true>), dim3(p.batch), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((big_first_kernel<NX, NU>), dim3(p.batch), dim3(64), 0, stream, p);
     }
     if (!CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(p, sp, 0, nullptr, stream)) return false;
     if constexpr (NX % 4 == 0) {
+        if (p.dt_free) {   // free dt: the partitioned chain with the border column as a second right-hand side; short horizons: one segment (two waves, from both ends)
+            int nseg = (p.N >= 64) ? 4 : 1;
+            if (p.chain_variant == 3) nseg = 4;
+            if (p.chain_variant == 4) nseg = 2;
+            if (p.chain_variant == 6) nseg = 1;
+            if (p.N < 4 * nseg) nseg = 1;
+            auto launch3a = [&](auto kernel, int nseg_, size_t lds3) {
+                static bool attr_set[9] = {};
+                if (!attr_set[nseg_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[nseg_] = true; }
+                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(128 * nseg_), ((lds3 + 15) & ~(size_t)15) + sizeof(LmState), stream, p);
+            };
+            if (nseg == 4) launch3a(big_chain3_kernel<NX, NU, 4, true>, 4, sizeof(double) * (size_t)Chain3Lds<NX, NU, 4, true>::total(p.N));
+            else if (nseg == 2) launch3a(big_chain3_kernel<NX, NU, 2, true>, 2, sizeof(double) * (size_t)Chain3Lds<NX, NU, 2, true>::total(p.N));
+            else launch3a(big_chain3_kernel<NX, NU, 1, true>, 1, sizeof(double) * (size_t)Chain3Lds<NX, NU, 1, true>::total(p.N));
+            return true;
+        }
         if (p.chain_variant == 1)   // (diagnostics: the first formulation)
             hipLaunchKernelGGL((big_chain_kernel<NX, NU, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);
         else {
@@ -6182,7 +6409,7 @@ bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_
 size_t big_stage_cache_doubles(const corbo_hip_problem_desc& d, int N)
 {
     if (!big_family_dims(d.nx, d.nu)) return 0;
-    const int half = (4 * d.nx + 2 * (d.nx + d.nu) + d.nx * (d.nx + d.nu) + 8 + d.nx * d.nx + 1) & ~1;   // BigLds::HALF (checked there)
+    const int half = (5 * d.nx + 2 * (d.nx + d.nu) + d.nx * (d.nx + d.nu) + 8 + d.nx * d.nx + 1) & ~1;   // BigLds::HALF (checked there)
     return (size_t)((N + 1) / 2) * 2 * (size_t)half;
 }
 

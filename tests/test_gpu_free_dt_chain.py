@@ -1,0 +1,164 @@
+"""GPU tests (-m gpu): a FREE dt around a big-block model through the stage / partitioned-chain kernels (round 5).
+
+MultipleShootingVariableGrid / FiniteDifferencesVariableGrid around the 12-state quadrotor: the dt column of every defect edge is formed by
+big_stage_kernel<..., ARROW> (one more pair of finite-difference evaluations per interval), its border parts ride through big_chain3_kernel<..., ARROW>
+as a second right-hand side and the last pivot H(dt,dt) + mu - |z|^2 closes the arrowhead (factor_body's formulas).  Checked
+
+  * against the genuine reference (tests/golden/quad_topt_n8.json: values, Jacobian, LM iterates -- tests/test_gpu_parity.py runs that fixture too),
+  * against the oracle at horizons the reference fixture does not cover, with one / two / four segments of the partitioned chain,
+  * against the band factorisation (the general path these descriptors took before: CORBO_HIP_FREE_DT_BAND=1) on the same device.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ledger_tolerances, load_golden, desc_for
+from control_box_rst_amd import capi, problems
+from control_box_rst_amd.problems import make_desc
+from control_box_rst_amd.solver import BatchedLevenbergMarquardt, get_structure
+
+pytestmark = pytest.mark.gpu
+W = (100.0, 100.0, 100.0)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+
+
+def _desc(N, fd=False):
+    if not fd:
+        return problems.quad_desc(N=N, time_optimal=True)
+    return make_desc(grid=capi.GRID_FD_VARIABLE, defect=capi.DEFECT_CRANK_NICOLSON, dynamics=capi.DYN_QUADROTOR, nx=12, nu=4, N=N, dt=0.05,
+                     stage_cost=capi.COST_MIN_TIME_LSQ, final_cost=0, u_lb=(0.0, -1.0, -1.0, -1.0), u_ub=(20.0, 1.0, 1.0, 1.0),
+                     xf_fixed_mask=0xFFF, dt_lb=0.01, dt_ub=10.0, stage_ineq=capi.INEQ_BALL, ineq_params=(1.0, 0.5, 0.6, 0.4),
+                     dyn_params=(9.81, 1.0, 0.01, 0.01, 0.02))
+
+
+def _instances(B, seed=5):
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 12)); xf = np.zeros((B, 12))
+    x0[:, :3] = rng.uniform(-0.2, 0.2, (B, 3))
+    xf[:, 0] = 2.0 + rng.uniform(-0.3, 0.3, B); xf[:, 1] = 1.0 + rng.uniform(-0.3, 0.3, B); xf[:, 2] = rng.uniform(-0.2, 0.4, B)
+    return x0, xf
+
+
+def _solve(d, x0, xf, iters, variant=0, band=False):
+    old = os.environ.get("CORBO_HIP_FREE_DT_BAND")
+    if band:
+        os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"
+    try:
+        s = BatchedLevenbergMarquardt(d, len(x0))
+    finally:
+        if band:
+            if old is None:
+                del os.environ["CORBO_HIP_FREE_DT_BAND"]
+            else:
+                os.environ["CORBO_HIP_FREE_DT_BAND"] = old
+    s.setIterations(iters)
+    s.setPenaltyWeights(*W)
+    if variant:
+        s.set_option("chain_variant", variant)
+    X0 = s.init_trajectory(x0, xf)
+    s.set_instance_data(X0, xref=xf)
+    s.solve()
+    X, chi2, status = s.get_solution()
+    return s, X0, X, chi2, status, s.get_stats()
+
+
+@pytest.mark.parametrize("fd", [False, True])
+@pytest.mark.parametrize("N", [8, 31])
+def test_values_and_jacobian_vs_oracle(oracle_mod, N, fd):
+    """corbo_hip_eval of these handles takes the Jacobian from the stage kernel (incl. the dt column and the dt vertex' own rows)."""
+    d = _desc(N, fd)
+    x0, xf = _instances(2)
+    s = BatchedLevenbergMarquardt(d, 2)
+    s.setPenaltyWeights(*W)
+    X0 = s.init_trajectory(x0, xf)
+    rng = np.random.default_rng(N)
+    X0 = X0 + 1e-2 * rng.standard_normal(X0.shape)     # (off the straight line: every column of the Jacobian carries information)
+    X0[:, -1] = 0.07                                   # dt
+    s.set_instance_data(X0, xref=xf)
+    values, jac = s.eval()
+    rows, cols = get_structure(d)
+    for b in range(2):
+        o = oracle_mod.OracleProblem(d)
+        o.set_data(X0[b], xref=xf[b])
+        vo, jo = o.eval(*W)
+        assert np.abs(values[b] - vo).max() <= 1e-12 * max(1.0, np.abs(vo).max())
+        Jd = sp.coo_matrix((jac[b], (rows, cols)), shape=(s.dims.m, s.dims.n)).tocsr()
+        Jo = sp.coo_matrix((jo, (rows, cols)), shape=(s.dims.m, s.dims.n)).tocsr()
+        assert abs(Jd - Jo).max() <= 1e-6 * max(1.0, abs(Jo).max()), (N, fd, abs(Jd - Jo).max())   # (central differences with delta = 1e-9 over two sin / cos libraries)
+    # the band route's handle evaluates the same descriptor with the sweep kernel: same finite differences, same operations -- the same bits
+    os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"
+    try:
+        sb = BatchedLevenbergMarquardt(d, 2)
+    finally:
+        del os.environ["CORBO_HIP_FREE_DT_BAND"]
+    sb.setPenaltyWeights(*W)
+    sb.set_instance_data(X0, xref=xf)
+    vb, jb = sb.eval()
+    assert np.array_equal(values, vb)
+    assert np.array_equal(jac, jb), np.abs(jac - jb).max()
+
+
+@pytest.mark.parametrize("N,variant,fd", [(8, 0, False), (30, 0, False), (30, 4, False), (30, 3, False), (100, 0, False), (100, 4, False), (70, 6, False),
+                                           (12, 0, True), (40, 4, True), (64, 0, True)])
+def test_lm_iterates_vs_oracle_and_band_route(oracle_mod, N, variant, fd):
+    d = _desc(N, fd)
+    B = 3
+    x0, xf = _instances(B, seed=N)
+    iters = 6
+    s, X0, X, chi2, status, st = _solve(d, x0, xf, iters, variant)
+    assert s.get_stats()["lm_iterations"] == B * iters
+    Xo, chi2o, statuso = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    # flat directions of the 12-state quadrotor: chi2 carries the comparison, the iterate to the drop-in scenarios' tolerance
+    assert np.allclose(chi2, chi2o, rtol=2e-6, atol=1e-9), (N, variant, chi2, chi2o)
+    assert np.abs(X - Xo).max() <= 3e-4, (N, variant, np.abs(X - Xo).max())
+    assert np.abs(X[:, -1] - Xo[:, -1]).max() <= 1e-6, "dt"
+    assert np.array_equal(status, statuso)
+    _, _, Xb, chi2b, statusb, stb = _solve(d, x0, xf, iters, band=True)
+    assert np.allclose(chi2, chi2b, rtol=2e-6, atol=1e-9)
+    assert np.abs(X - Xb).max() <= 3e-4
+    assert st["factorizations"] == stb["factorizations"] and st["accepted_steps"] == stb["accepted_steps"]
+
+
+def test_reference_fixture_with_every_segment_count():
+    """quad_topt_n8 (genuine reference) only exercises one segment by default; N = 8 admits two segments as well."""
+    g = load_golden("quad_topt_n8")
+    d = desc_for(g)
+    xtol, ctol = ledger_tolerances("quad_topt_n8")
+    for variant in (6, 4):
+        a = g["after_iter"][-1]
+        s = BatchedLevenbergMarquardt(d, 1)
+        s.setIterations(a["k"])
+        s.setPenaltyWeights(*g["weights"])
+        s.set_option("chain_variant", variant)
+        s.set_instance_data(s.init_trajectory(g["x0"], g["xf"]), xref=np.array(g["xf"])[None, :])
+        for i in range(g["solves"]):
+            s.solve(new_run=(i == 0))
+        x, chi2, status = s.get_solution()
+        assert np.abs(x[0] - np.array(a["vertex"])[: s.dims.nv]).max() <= xtol, variant
+        assert abs(chi2[0] - a["chi2"]) <= ctol * max(1.0, abs(a["chi2"])), variant
+
+
+def test_batch_beyond_one_cu_round_and_restore():
+    """300 instances (more than one workgroup per CU), solved twice from the same start: identical results (no state left behind by the border code)."""
+    d = _desc(64)
+    x0, xf = _instances(300, seed=9)
+    s = BatchedLevenbergMarquardt(d, 300)
+    s.setIterations(4)
+    s.setPenaltyWeights(*W)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    s.solve()
+    X1, c1, _ = s.get_solution()
+    s.restore_instance_data()
+    s.solve()
+    X2, c2, _ = s.get_solution()
+    assert np.array_equal(X1, X2) and np.array_equal(c1, c2)
+    assert np.isfinite(X1).all() and np.isfinite(c1).all()
