@@ -922,7 +922,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     // (references per component, model parameters per instance) would have to follow the candidates
     // ... and when a pass is long against the one small launch per pass the bookkeeping costs (7 us: below 128 instances it is 4 - 7 % of a solve
     // and the laggers of a small batch hold back little); option reject_speculation: 0 = off, 1 = this rule, 2 = always, every streak (tests)
-    const bool spec = split && h->spare > 0 && h->reject_speculation && (h->batch >= 128 || h->reject_speculation == 2) && h->band.n == 0 && !h->S.dt_free &&
+    const bool spec = split && h->spare > 0 && h->reject_speculation && (h->batch >= 128 || h->reject_speculation == 2) && h->band.n == 0 &&
                       h->active == h->batch && !h->refvec_on && !h->d_dyn_inst && !h->profile && o->iterations > 0;
     auto spec_params = [&](int mode, int32_t* counter) {
         SpecParams q{};

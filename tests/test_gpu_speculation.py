@@ -58,3 +58,16 @@ def test_cfg5_full_batch_identical_with_and_without():
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     for k in KEYS:
         assert got[3][k] == ref[3][k], k
+
+
+@pytest.mark.parametrize("B,N,weights,first", [(48, 40, problems.QUAD_WEIGHTS, 0), (32, 70, (100.0, 100.0, 100.0), 3)])
+def test_forced_speculation_with_a_free_dt_is_bit_identical(B, N, weights, first):
+    """... and with the dt column riding through the chain (time-optimal quadrotor): the candidates carry the instance's dt like every other parameter."""
+    d = problems.quad_desc(N=N, time_optimal=True)
+    x0, xf = problems.quad_instances(B, first=first)
+    ref = _run(d, weights, x0, xf, 0)
+    assert ref[3]["rejected_steps"] > 0, "the scenario is meant to reject steps"
+    got = _run(d, weights, x0, xf, 2)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    for k in KEYS:
+        assert got[3][k] == ref[3][k], k
