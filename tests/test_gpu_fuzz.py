@@ -241,6 +241,64 @@ def test_random_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
             assert ex <= widened(3e-4, 2.0, sx, xs_), (seed, ex, sx)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_free_dt_quadrotor_descriptor_vs_oracle(oracle_mod, seed):
+    """Big-block family with a FREE dt (time-optimal 12-state quadrotor; the border rides through the stage / partitioned-chain kernels):
+    random horizon, grid (shooting: Runge-Kutta 4 / 3 / 2, Euler; collocation: the four formulas), bound patterns, keep-out ball on / off, segment count."""
+    rng = np.random.default_rng(7000 + seed)
+    N = int(rng.integers(4, 72))
+    d = problems.quad_desc(N=N, dt=float(rng.uniform(0.03, 0.08)), time_optimal=True)
+    if rng.random() < 0.4:
+        d.grid = capi.GRID_FD_VARIABLE
+        d.defect = int(rng.choice([capi.DEFECT_FORWARD, capi.DEFECT_BACKWARD, capi.DEFECT_MIDPOINT, capi.DEFECT_CRANK_NICOLSON]))
+    else:
+        d.shooting_integrator = int(rng.choice([0, 0, 1, 2, 3]))
+    if rng.random() < 0.4:
+        d.stage_ineq = capi.INEQ_NONE
+    for i in range(12):
+        k = rng.integers(0, 4)
+        d.x_lb[i] = -INF if k in (0, 1, 2) else -4.0
+        d.x_ub[i] = INF if k in (0, 1) else 4.0
+    for i in range(4):
+        d.u_lb[i] = -INF if rng.random() < 0.3 else (0.0 if i == 0 else -1.0)
+        d.u_ub[i] = INF if rng.random() < 0.3 else (20.0 if i == 0 else 1.0)
+    B = 2
+    w = tuple(float(v) for v in rng.uniform(20.0, 150.0, 3))
+    x0, xf = problems.quad_instances(B, seed=int(rng.integers(0, 10 ** 6)))
+    variant = int(rng.choice([0, 6, 4, 3]))
+    s = BatchedLevenbergMarquardt(d, B)
+    s.setIterations(3)
+    s.setPenaltyWeights(*w)
+    s.set_option("chain_variant", variant)
+    X0 = s.init_trajectory(x0, xf)
+    X0[:, 12:-13] += 0.02 * rng.normal(size=X0[:, 12:-13].shape)   # (x_0 and the fixed x_f stay)
+    s.set_instance_data(X0, xref=xf)
+    po = oracle_mod.OracleProblem(d)
+    rows, cols = get_structure(d)
+    ro, co = po.structure()
+    assert np.array_equal(rows, ro) and np.array_equal(cols, co)
+    values, jac = s.eval()
+    for b in range(B):
+        p = oracle_mod.OracleProblem(d)
+        p.set_data(X0[b], xref=xf[b])
+        vo, jo = p.eval(*w)
+        assert np.abs(values[b] - vo).max() <= 1e-10 * max(1.0, np.abs(vo).max()), (seed, b)
+        assert np.abs(jac[b] - jo).max() <= 2e-6 * max(1.0, np.abs(jo).max()), (seed, b)
+    s.solve()
+    X, chi2, _ = s.get_solution()
+    Xo, chi2o, _ = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    if not np.allclose(chi2, chi2o, rtol=1e-6) or np.abs(X - Xo).max() > 3e-4:
+        ec, ex = np.abs(chi2 - chi2o).max() / np.abs(chi2o).max(), np.abs(X - Xo).max()
+        sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, 12)
+        xs_ = max(1.0, np.abs(Xo).max())
+        ESCALATIONS.append(dict(test="quadrotor_free_dt", seed=seed, stage=1, ex=float(ex), ec=float(ec), sx=sx, sc=sc))
+        if not (ec <= min(max(1e-6, 8.0 * sc), 1e-4) and ex <= widened(3e-4, 8.0, sx, xs_)):
+            sx, sc = oracle_own_spread(oracle_mod, d, X0, xf, s.opts, 12, trials=48)
+            ESCALATIONS[-1].update(stage=2, sx=sx, sc=sc)
+            assert ec <= min(max(1e-6, 2.0 * sc), 1e-4), (seed, chi2, chi2o, sc)
+            assert ex <= widened(3e-4, 2.0, sx, xs_), (seed, ex, sx)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_per_instance_bounds_and_weight_adaptation_vs_oracle(oracle_mod, seed):
     """Per-instance bound VALUES (the finiteness pattern of the descriptor is kept, corbo_hip_set_instance_data) and a second solve

@@ -20,6 +20,7 @@ O.load()
 bad = []
 for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range(first, first + count)),
                         ("quadrotor", F.test_random_quadrotor_descriptor_vs_oracle, range(first, first + count // 10)),
+                        ("quadrotor, free dt", F.test_random_free_dt_quadrotor_descriptor_vs_oracle, range(first, first + count // 10)),
                         ("bounds+weights", F.test_per_instance_bounds_and_weight_adaptation_vs_oracle, range(first, first + count // 5)),
                         ("closed loop", F.test_random_closed_loop_call_vs_stepwise_and_oracle_plant, range(first, first + count // 5)),
                         ("hessian operators", H.test_random_descriptor_hessians_vs_oracle, range(first, first + count)),
