@@ -571,6 +571,10 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
             upload(rent, &h->d_band_rent) || upload(S.param_voff, &h->d_band_voff))
             return CORBO_HIP_ERR_DEVICE;
         BandParams& bp = h->band;
+        if (S.desc.shooting_integrator >= 5 && big_family_dims(S.nx, S.nu)) {   // (only reachable through CORBO_HIP_FREE_DT_BAND=1: structure.cpp refuses the others)
+            g_last_error = "band factorisation around a big-block model: shooting integrators up to Runge-Kutta 4";
+            return CORBO_HIP_ERR_UNSUPPORTED;
+        }
         if (!band_route_supported(nb, bw)) {   // refused here, not at the first solve (include/corbo_hip.h: unsupported descriptors fail at create)
             g_last_error = "band factorisation: half-bandwidth " + std::to_string(bw) + " beyond 63, or window + vectors of " + std::to_string(nb) + " parameters beyond 160 KB of LDS";
             return CORBO_HIP_ERR_UNSUPPORTED;
@@ -1696,7 +1700,11 @@ try {
     ON_DEVICE_OF(h);
     DRAIN_ASYNC(h);
     h->sink_valid = false;   // the pinned result views are stale from here on
-    const SweepParams spe = h->sweep_params(jac_out ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
+    // (Runge-Kutta 5 - 7 around a big-block model: only the residual-only sweep exists; the Jacobian is the stage kernel's, below)
+    const bool high_big = big_family_dims(h->S.nx, h->S.nu) && h->S.desc.shooting_integrator >= 5;
+    if (jac_out && high_big && (h->band.n != 0 || h->S.desc.final_eq_mask))
+        return fail(CORBO_HIP_ERR_UNSUPPORTED, "corbo_hip_eval with a Jacobian: Runge-Kutta 5 - 7 around a big-block model with a partial terminal equality");
+    const SweepParams spe = h->sweep_params((jac_out && !high_big) ? 1 : 0, 0, w_eq, w_ineq, w_bounds, nullptr);
     int rc = launch_sweep_checked(h, spe);
     if (rc) return rc;
     // (a partial terminal equality: the stage kernel's dump writes the full constraint's block -- kernels.hip, big_stage_edges --, the sweep kernel's Jacobian is returned)

@@ -691,6 +691,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                 if (xeo) xeo[i] = xe[i];
             }
         }
+        else if constexpr (DEFECT == DEFECT_SHOOTING_HIGH && !STAGE && NX > 4) {
+            // (big-block family with Runge-Kutta 5 / 6 / 7: defect_eval's operations, the end state kept for the stage kernel like above)
+            double xe[NX];
+            rk_high_order_end_state<DYN>(xs + base, xs + base + NX, xs[p.off_dt], dynl, (int)dynl[7], xe);
+            double* xeo = p.xe0 ? p.xe0 + (((size_t)vsel * p.batch_total + inst) * p.N + k) * NX : nullptr;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                e[i] = xe[i]; e[i] -= xs[base + S + i];
+                if (xeo) xeo[i] = xe[i];
+            }
+        }
         else
             defect_eval<DYN, DEFECT>(xs + base, xs + base + NX, xs + base + S, xs[p.off_dt], dynl, e);
 #pragma unroll
@@ -2925,7 +2936,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 {
     using Dy = Dynamics<DYN>;
     constexpr int NX = Dy::NX, NU = Dy::NU, S = NX + NU, NC = Dy::NC;
-    constexpr bool SHOOT = (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING);
+    constexpr bool SHOOT = (DEFECT == CORBO_HIP_DEFECT_RK4_SHOOTING || DEFECT == DEFECT_SHOOTING_HIGH);
     constexpr double delta = 1e-9, neg2delta = -2 * delta, scalar = 1.0 / (2 * delta);
     const int N      = p.N;
     const bool stage = (k < N - 1), block = (k < N);
@@ -3003,6 +3014,8 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 #pragma unroll
         for (int i = 0; i < S; ++i) loc[i] = (i == col) ? pert : loc[i];
         CORBO_HIP_DYN_OF(dynl, sp, inst)
+        if constexpr (DEFECT == DEFECT_SHOOTING_HIGH) rk_high_order_end_state<DYN>(loc, loc + NX, dt0, dynl, (int)dynl[7], xe);   // Runge-Kutta 5 / 6 / 7
+        else
         rk4_end_state<DYN, false>(loc, loc + NX, dt0, dynl, ck, xe);
         int jo = 0;
 #pragma unroll
@@ -3023,6 +3036,8 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
             for (int i = 0; i < S; ++i) loc[i] = X[kk * S + i];
             double da = dt0 + delta;
             if (minus) da += neg2delta;
+            if constexpr (DEFECT == DEFECT_SHOOTING_HIGH) rk_high_order_end_state<DYN>(loc, loc + NX, da, dynl, (int)dynl[7], xe);
+            else
             rk4_end_state<DYN, false>(loc, loc + NX, da, dynl, ck, xe);
             const int jd    = sc[S + NX];
             const bool pdt  = stage && jd >= 0;
@@ -3186,7 +3201,7 @@ __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 registers: three waves per SIMD (170 without the cap, i.e. two; a cap of four spills 270 bytes and loses)
 void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
 {
-    constexpr bool DENSEC = (DEFECT != CORBO_HIP_DEFECT_RK4_SHOOTING);   // collocation: the x_{k+1} block of the local Jacobian is dense
+    constexpr bool DENSEC = (DEFECT != CORBO_HIP_DEFECT_RK4_SHOOTING && DEFECT != DEFECT_SHOOTING_HIGH);   // collocation: the x_{k+1} block of the local Jacobian is dense
     using Dy = Dynamics<DYN>;
     constexpr int NX = Dy::NX, NU = Dy::NU;
     using BL = BigLds<NX, NU>;
@@ -4721,7 +4736,12 @@ bool launch_sweep_d(int defect, const SweepParams& p, hipStream_t stream)
 #else
     if (defect == CORBO_HIP_DEFECT_RK4_SHOOTING && (int)p.mp.dyn[7] >= 5) {   // Runge-Kutta 5 / 6 / 7: a defect formula of its own (model.hpp)
         if constexpr (Dynamics<DYN>::NX <= 4) { launch_sweep_t<DYN, DEFECT_SHOOTING_HIGH>(p, stream); return true; }
-        else return false;
+        else {
+            // big-block family: the residual-only instantiation (the Jacobian of these handles is the stage kernel's; no band route with these integrators)
+            if (p.n_xedges > 0 || !(p.mode == 0 || (p.skip_jac && p.mode >= 2))) return false;
+            hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT_SHOOTING_HIGH, false, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+            return true;
+        }
     }
     switch (defect) {
         case CORBO_HIP_DEFECT_FORWARD: launch_sweep_t<DYN, CORBO_HIP_DEFECT_FORWARD>(p, stream); return true;
@@ -5481,7 +5501,11 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
         if constexpr (Dy::NX % 4 != 0) return false;
         else
         switch (fp.defect) {
-            case CORBO_HIP_DEFECT_RK4_SHOOTING: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_RK4_SHOOTING, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            case CORBO_HIP_DEFECT_RK4_SHOOTING:
+                if ((int)sp.mp.dyn[7] >= 5) hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, DEFECT_SHOOTING_HIGH, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump);   // Runge-Kutta 5 / 6 / 7
+                else
+                hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_RK4_SHOOTING, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump);
+                return true;
             case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
             case CORBO_HIP_DEFECT_BACKWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_BACKWARD, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
             case CORBO_HIP_DEFECT_MIDPOINT: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_MIDPOINT, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
@@ -5489,8 +5513,12 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
             default: return false;
         }
     }
-    switch (fp.defect) {   // shooting (Runge-Kutta 4 / 3 / 2, Euler), or a collocation formula on the FiniteDifferencesGrid
-        case CORBO_HIP_DEFECT_RK4_SHOOTING: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+    switch (fp.defect) {   // shooting (Runge-Kutta 4 / 3 / 2, Euler; 5 / 6 / 7: an instantiation of its own), or a collocation formula on the FiniteDifferencesGrid
+        case CORBO_HIP_DEFECT_RK4_SHOOTING:
+            if ((int)sp.mp.dyn[7] >= 5) hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, DEFECT_SHOOTING_HIGH>), g, b, lds, stream, fp, sp, diag_only, jac_dump);
+            else
+            hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump);
+            return true;
         case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
         case CORBO_HIP_DEFECT_BACKWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_BACKWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
         case CORBO_HIP_DEFECT_MIDPOINT: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_MIDPOINT>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;

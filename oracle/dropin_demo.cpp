@@ -306,7 +306,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         for (int i = 0; i < 3; ++i) { d.q_diag[i] = q[i]; d.qf_diag[i] = 10.0 * q[i]; }
         for (int i = 0; i < 2; ++i) d.r_diag[i] = rr[i];
     }
-    else if (scenario == "quad" || scenario == "quad_topt")
+    else if (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5")
     {
         dyn     = std::make_shared<QuadrotorRef>();
         if (scenario == "quad_topt")
@@ -325,6 +325,8 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         else
         {
         ms_grid = std::make_shared<MultipleShootingGrid>();
+        if (scenario == "quad_rk5") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta5>());   // six stages around the 12-state model (round 5)
+        else
         ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
         }
         x0 = Eigen::VectorXd::Zero(12);
@@ -447,7 +449,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         if (scenario == "vdp_msint") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta3>());
         else ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
     }
-    const double dt = (scenario == "quad" || scenario == "quad_topt" || scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate") ? 0.05 : 0.1;
+    const double dt = (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5" || scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
     if (mode == Mode::HipStatedWrong) d.r_diag[1] = 2.0 * d.r_diag[1];   // invisible at the reference's initial guess (u = 0)
     if (mode == Mode::Reference)
@@ -531,7 +533,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
             ocp.setFinalStageConstraint(c);
         }
     }
-    else if (scenario == "quad" || scenario == "quad_topt")
+    else if (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5")
     {
         Eigen::VectorXd q(12), rr(4), ulb(4), uub(4);
         q << 1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05;
@@ -774,7 +776,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate", "quad_topt"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate", "quad_topt", "quad_rk5"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -782,7 +784,7 @@ int main(int argc, char** argv)
         double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
         printf("{\"scenario\": \"%s\", \"mode\": \"recognised\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
                sc, a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
-        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "quad_topt" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd" || std::string(sc) == "pquad_topt" || std::string(sc) == "pquad_pteq" || std::string(sc) == "pquad_fd_xe_ball" || std::string(sc) == "pquad_xe_rate") ? 5e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
+        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "quad_topt" || std::string(sc) == "quad_rk5" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd" || std::string(sc) == "pquad_topt" || std::string(sc) == "pquad_pteq" || std::string(sc) == "pquad_fd_xe_ball" || std::string(sc) == "pquad_xe_rate") ? 5e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
     for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft", "unicycle_plain_tvref", "unicycle_msint_tvref"})

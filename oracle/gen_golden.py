@@ -450,6 +450,11 @@ BIGMODEL = [
     ("pquad_n10_pteq", dict(scenario="pquad", N=10, iters=5, teq=1, teq_mask=7), (1, 2, 3, 5)),
     ("pquad_fd_n10_pteq", dict(scenario="pquad", grid="fd", N=10, iters=5, teq=1, teq_mask=0b101011), (1, 2, 3, 5)),
     ("quad_n10_pteq", dict(scenario="quad", N=10, iters=5, teq=1, teq_mask=7), (1, 2, 3, 5)),
+    # Runge-Kutta 5 / 6 / 7 around the big-block models (VERDICT r4 "missing" 3: the cap nx <= 4 is gone), incl. a free dt around the 12-state quadrotor
+    ("quad_n10_rk5", dict(scenario="quad", N=10, iters=5, ms_integrator="rk5"), (1, 2, 3, 5)),
+    ("quad_n10_rk7", dict(scenario="quad", N=10, iters=5, ms_integrator="rk7"), (1, 3, 5)),
+    ("pquad_n10_rk6", dict(scenario="pquad", N=10, iters=6, ms_integrator="rk6"), (1, 2, 4, 6)),
+    ("quad_topt_n8_rk6", dict(scenario="quad", vargrid=1, N=8, iters=5, w="100,100,100", ms_integrator="rk6"), (1, 2, 5)),
 ]
 
 

@@ -56,6 +56,8 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
         # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation takes these
         "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
+        # Runge-Kutta 5 / 6 / 7 around the big-block models (incl. a free dt around the 12-state quadrotor: the dt column through the partitioned chain)
+        "quad_n10_rk5", "quad_n10_rk7", "pquad_n10_rk6", "quad_topt_n8_rk6",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq", "pquad_n10_pteq", "pquad_fd_n10_pteq", "quad_n10_pteq",   # (... and around the big-block models)
         # seed 23091 of the randomized suite (tests/test_gpu_fuzz.py), every instance, solved by the REFERENCE from the same noisy start

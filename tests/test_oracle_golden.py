@@ -38,6 +38,8 @@ FULL = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
         # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation on the device
         "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
+        # Runge-Kutta 5 / 6 / 7 around the big-block models (incl. a free dt around the 12-state quadrotor: the dt column through the partitioned chain)
+        "quad_n10_rk5", "quad_n10_rk7", "pquad_n10_rk6", "quad_topt_n8_rk6",
         # TerminalPartialEqualityConstraint: equality rows on a subset of the components of x_f
         "unicycle_n12_pteq", "vdp_pteq", "cartpole_pteq", "unicycle_n12_ms_pteq", "pquad_n10_pteq", "pquad_fd_n10_pteq", "quad_n10_pteq",   # (... and around the big-block models)
         # a randomized-start case of tests/test_gpu_fuzz.py (seed 23091, the one whose device result once needed the 48-trial spread), all three
