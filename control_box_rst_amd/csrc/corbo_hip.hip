@@ -488,10 +488,10 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMalloc((void**)&h->d_state, BT * sizeof(LmState)));
     CREATE_TRY(hipMalloc((void**)&h->d_chi2, BT * sizeof(double)));
     // (the band route -- decided below -- reads the sweep's stored Jacobian: it needs neither the stage / chain workspace nor the first factorisation's cache)
-    // A free dt around a big-block model: state blocks of 8 / 12 rows carry it through the partitioned chain as a second right-hand side (round 5);
-    // other block sizes -- and CORBO_HIP_FREE_DT_BAND=1, the A/B switch of bench.py's band leg -- take the band route.
+    // A free dt around a big-block model: even state-block sizes (6, 8, 10, 12 rows) carry it through the partitioned chain as a second right-hand side (round 5);
+    // odd block sizes -- and CORBO_HIP_FREE_DT_BAND=1, the A/B switch of bench.py's band leg -- take the band route.
     const char* fdb_env = std::getenv("CORBO_HIP_FREE_DT_BAND");
-    const bool free_dt_band = S.dt_free && big_family_dims(S.nx, S.nu) && (S.nx % 4 != 0 || (fdb_env && fdb_env[0] == '1'));
+    const bool free_dt_band = S.dt_free && big_family_dims(S.nx, S.nu) && (S.nx % 2 != 0 || (fdb_env && fdb_env[0] == '1'));
     const bool band_route_early = S.has_extra() || free_dt_band;
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
@@ -516,7 +516,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     }
     // The band factorisation (band_factor_kernel: H = J^T J from the stored Jacobian through static product lists, natural parameter order, a free dt
     // as a border) takes the structures the stage-parallel kernels do not cover: integral-form constraint edges / control-deviation edges, and a FREE dt
-    // with state blocks of 5, 6, 7, 9, 10 or 11 rows (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid around a big-block model whose chain
+    // with state blocks of 5, 7, 9 or 11 rows (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid around a big-block model whose chain
     // kernel is not the partitioned one) -- the general, slower path: one workgroup per instance, n sequential pivots.
     const bool band_route = band_route_early;
     if (S.has_extra()) {

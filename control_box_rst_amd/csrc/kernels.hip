@@ -2990,11 +2990,15 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
                 }
                 if (col == W && !minus) c.rv[r] = stage ? e[r] * sp.w_eq : 0.0;
                 if constexpr (ARROW) {
-                    if (col == W + 1 && !minus) {
-                        const bool pdt = stage && jo >= 0;
-                        c.dcv[r] = pdt ? cv : 0.0;
-                        if (jac_dump && pdt) jac_dump[jo + r] = cv;
-                    }
+                    if (col == W + 1 && !minus) c.dcv[r] = (stage && jo >= 0) ? cv : 0.0;
+                    e[r] = cv;
+                }
+            }
+            if constexpr (ARROW) {   // (the parity hook's copy of the dt column in a block of its own: see the shooting branch)
+                asm volatile("" ::: "memory");
+                if (jac_dump && col == W + 1 && !minus && stage && jo >= 0) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) jac_dump[jo + r] = e[r];
                 }
             }
         }
@@ -3046,10 +3050,15 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
                 const double ev = xe[r] - X[kk * S + S + r];
                 const double eo = __shfl_xor(ev, 1);
                 const double cv = (scalar * (ev - eo)) * sp.w_eq;
-                if (l32 == 0) {
-                    c.dcv[r] = pdt ? cv : 0.0;
-                    if (jac_dump && pdt) jac_dump[jd + r] = cv;
-                }
+                xe[r] = cv;
+                if (l32 == 0) c.dcv[r] = pdt ? cv : 0.0;
+            }
+            // (the parity hook's copy in a block of its own: with the LDS and the global store under one condition the 6-state unit's compile ends in
+            //  "Illegal instruction detected: Operand has incorrect register class" -- a flat store through a select of the two address spaces)
+            asm volatile("" ::: "memory");
+            if (jac_dump && pdt && l32 == 0) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) jac_dump[jd + r] = xe[r];
             }
         }
     }
@@ -3940,7 +3949,7 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
     using BL = BigLds<NX, NU>;
     using CL = Chain3Lds<NX, NU, NSEG, ARROW>;
     constexpr int S = NX + NU, NN = NX * NX, NW = 2 * NSEG, THREADS = 128 * NSEG;
-    static_assert(NX <= 12 && NX % 4 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, spike rows 32.., identity rows 48..");
+    static_assert(NX <= 12 && NX % 2 == 0 && NU <= NX, "lane roles of the stacked pass: D rows 0.., C rows 16.., rhs row 28, spike rows 32.., identity rows 48..; rows move as double2");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int seg = wave >> 1, side = wave & 1;
     int stop = st->stop;
@@ -4080,13 +4089,16 @@ __device__ __forceinline__ void big_chain3_body(const FactorParams& p, LmState* 
         d4_t accS = {0.0, 0.0, 0.0, 0.0}, accG = accS, accT = accS, accH = accS;
 #pragma unroll
         for (int k0 = 0; k0 < NX; k0 += 4) {
-            double yv = yop[ljc * NX + k0 + lk], wv = wop[ljc * NX + k0 + lk];
-            yv = ljin ? yv : 0.0; wv = ljin ? wv : 0.0;
+            // (block sizes that are not a multiple of the instruction's K = 4: the last step's surplus columns are zeros)
+            const bool kin = ljin && (NX % 4 == 0 || k0 + lk < NX);
+            const int kc   = (NX % 4 == 0 || k0 + lk < NX) ? k0 + lk : 0;
+            double yv = yop[ljc * NX + kc], wv = wop[ljc * NX + kc];
+            yv = kin ? yv : 0.0; wv = kin ? wv : 0.0;
             accS = __builtin_amdgcn_mfma_f64_16x16x4f64(yv, yv, accS, 0, 0, 0);
             accG = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, yv, accG, 0, 0, 0);
             if (with_spike) {
-                double zv = zop[ljc * NX + k0 + lk];
-                zv = ljin ? zv : 0.0;
+                double zv = zop[ljc * NX + kc];
+                zv = kin ? zv : 0.0;
                 accT = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, yv, accT, 0, 0, 0);
                 accZ = __builtin_amdgcn_mfma_f64_16x16x4f64(zv, zv, accZ, 0, 0, 0);
                 accH = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, zv, accH, 0, 0, 0);
@@ -5496,9 +5508,8 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
     const size_t lds = sizeof(double) * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
     const dim3 g((fp.N + 1) / 2, fp.batch), b(64);
     if (fp.dt_free) {   // free dt: the dt column of every defect edge and the border parts (second right-hand side of the chain)
-        // (state blocks of 8 / 12 rows only -- the partitioned chain carries the border; the 6-state unit also trips a compiler defect on these instantiations,
-        //  "Operand has incorrect register class: V_CMP_NE_U32 0, $src_shared_base", docs/measurements/r05.md 3)
-        if constexpr (Dy::NX % 4 != 0) return false;
+        // (even block sizes only -- the partitioned chain carries the border)
+        if constexpr (Dy::NX % 2 != 0) return false;
         else
         switch (fp.defect) {
             case CORBO_HIP_DEFECT_RK4_SHOOTING:
@@ -5535,14 +5546,14 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
     constexpr int NX = Dy::NX, NU = Dy::NU;
     static_assert(big_family_dims(NX, NU), "big-block family: 5 <= nx <= 12, nu <= 4, nx + nu <= 16");
     if (!p.work) return false;
-    if (p.dt_free && NX % 4 != 0) return false;   // (a free dt rides through the partitioned chain only: block sizes 8 and 12; others take the band route)
+    if (p.dt_free && NX % 2 != 0) return false;   // (a free dt rides through the partitioned chain only: even block sizes; others take the band route)
     if (p.first_pass) {   // (the kernels themselves also check LmState::first)
         if (!CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(p, sp, 1, nullptr, stream)) return false;
         if (p.dt_free) hipLaunchKernelGGL((big_first_kernel<NX, NU, true>), dim3(p.batch), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL((big_first_kernel<NX, NU>), dim3(p.batch), dim3(64), 0, stream, p);
     }
     if (!CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(p, sp, 0, nullptr, stream)) return false;
-    if constexpr (NX % 4 == 0) {
+    if constexpr (NX % 2 == 0) {
         if (p.dt_free) {   // free dt: the partitioned chain with the border column as a second right-hand side; short horizons: one segment (two waves, from both ends)
             int nseg = (p.N >= 64) ? 4 : 1;
             if (p.chain_variant == 3) nseg = 4;
@@ -5560,7 +5571,7 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
             return true;
         }
         if (p.chain_variant == 1)   // (diagnostics: the first formulation)
-            hipLaunchKernelGGL((big_chain_kernel<NX, NU, true>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);
+            hipLaunchKernelGGL((big_chain_kernel<NX, NU, NX % 4 == 0>), dim3(p.batch), dim3(128), sizeof(double) * (4 * NX * NX + 2 * NX + 8), stream, p);
         else {
             // partitioned chain (big_chain3_kernel): NSEG segments = 2 NSEG waves per instance.  chain_variant 0 = automatic (horizons of 64 grid points
             // and more: four segments), 2 = the twisted chain (big_chain2_kernel) whatever the horizon, 3 / 4 / 5 / 6 = 4 / 2 / 8 / 1 segments (tests, A/B)
@@ -5571,6 +5582,7 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
             if (p.chain_variant == 5) nseg = 8;
             if (p.chain_variant == 6) nseg = 1;
             if (nseg > 0 && p.N < 4 * nseg) nseg = 0;   // (every segment needs a block of its own next to its separators)
+            if (NX % 4 != 0 && nseg == 0) nseg = 1;     // (6- and 10-row blocks: the twisted chain's matrix-core tiling assumes multiples of four; one segment is the same elimination)
             auto launch3 = [&](auto kernel, int nseg_, size_t lds3) {
                 static bool attr_set[9] = {};
                 if (!attr_set[nseg_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[nseg_] = true; }
@@ -5580,7 +5592,7 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
             else if (nseg == 2) launch3(big_chain3_kernel<NX, NU, 2>, 2, sizeof(double) * (size_t)Chain3Lds<NX, NU, 2>::total(p.N));
             else if (nseg == 8) launch3(big_chain3_kernel<NX, NU, 8>, 8, sizeof(double) * (size_t)Chain3Lds<NX, NU, 8>::total(p.N));
             else if (nseg == 1) launch3(big_chain3_kernel<NX, NU, 1>, 1, sizeof(double) * (size_t)Chain3Lds<NX, NU, 1>::total(p.N));
-            else {
+            else if constexpr (NX % 4 == 0) {
                 const size_t lds2 = 2 * sizeof(double) * (size_t)Chain2Lds<NX, NU>::total(p.N);   // two instances per workgroup
                 hipLaunchKernelGGL((big_chain2_kernel<NX, NU>), dim3((p.batch + 1) / 2), dim3(256), lds2, stream, p);
             }

@@ -78,10 +78,10 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         if (d.final_eq_mask >> d.nx) return "final_eq_mask has bits beyond nx";
     }
     if (d.shooting_integrator < 0 || d.shooting_integrator > 7 || d.shooting_integrator == 4) return "shooting_integrator: 0 (RK4), 1 (Euler), 2 (RK2), 3 (RK3), 5 / 6 / 7 (RK5 / RK6 / RK7)";
-    // (Runge-Kutta 5 - 7 around a big-block model: LM path through the stage / chain kernels -- no band route, so no free dt for block sizes other than 8 / 12;
+    // (Runge-Kutta 5 - 7 around a big-block model: LM path through the stage / chain kernels -- no band route, so no free dt for odd block sizes;
     //  the Hessian-path operators refuse it at the call)
-    if (d.shooting_integrator >= 5 && d.nx > 4 && (d.grid == CORBO_HIP_GRID_MS_VARIABLE || d.grid == CORBO_HIP_GRID_FD_VARIABLE) && d.nx % 4 != 0)
-        return "shooting_integrator 5 .. 7 with a free dt: families with nx <= 4 or state blocks of 8 / 12 rows";
+    if (d.shooting_integrator >= 5 && d.nx > 4 && (d.grid == CORBO_HIP_GRID_MS_VARIABLE || d.grid == CORBO_HIP_GRID_FD_VARIABLE) && d.nx % 2 != 0)
+        return "shooting_integrator 5 .. 7 with a free dt: families with nx <= 4 or an even number of states";
     if (d.shooting_integrator != 0 && d.defect != CORBO_HIP_DEFECT_RK4_SHOOTING) return "shooting_integrator: shooting grids only";
     if (d.weights_dense < 0 || d.weights_dense > 7) return "weights_dense: bits 0..2";
     if (d.weights_dense) {

@@ -162,3 +162,25 @@ def test_batch_beyond_one_cu_round_and_restore():
     X2, c2, _ = s.get_solution()
     assert np.array_equal(X1, X2) and np.array_equal(c1, c2)
     assert np.isfinite(X1).all() and np.isfinite(c1).all()
+
+
+@pytest.mark.parametrize("N,variant,shooting", [(10, 0, True), (30, 0, True), (30, 4, True), (64, 0, True), (100, 3, True), (12, 0, False), (40, 4, False)])
+def test_six_state_model_free_dt_vs_oracle_and_band_route(oracle_mod, N, variant, shooting):
+    """The planar quadrotor (csrc/models/planar_quadrotor.hpp, nx = 6): block sizes that are not a multiple of the matrix-core instruction's K = 4 ride through
+    the same partitioned chain (the last K step's surplus columns are zeros)."""
+    d = problems.planar_quadrotor_desc(N=N, time_optimal=True, shooting=shooting)
+    B = 3
+    rng = np.random.default_rng(100 + N)
+    x0 = np.zeros((B, 6)); xf = np.zeros((B, 6))
+    x0[:, :2] = rng.uniform(-0.2, 0.2, (B, 2))
+    xf[:, 0] = 2.0 + rng.uniform(-0.3, 0.3, B); xf[:, 1] = 1.0 + rng.uniform(-0.3, 0.3, B)
+    iters = 6
+    s, X0, X, chi2, status, st = _solve(d, x0, xf, iters, variant)
+    Xo, chi2o, statuso = oracle_mod.solve_batch(d, X0, xf, s.opts)
+    assert np.allclose(chi2, chi2o, rtol=2e-6, atol=1e-9), (N, variant, chi2, chi2o)
+    assert np.abs(X - Xo).max() <= 3e-4, (N, variant, np.abs(X - Xo).max())
+    assert np.array_equal(status, statuso)
+    _, _, Xb, chi2b, statusb, stb = _solve(d, x0, xf, iters, band=True)
+    assert np.allclose(chi2, chi2b, rtol=2e-6, atol=1e-9)
+    assert np.abs(X - Xb).max() <= 3e-4
+    assert st["factorizations"] == stb["factorizations"] and st["accepted_steps"] == stb["accepted_steps"]
