@@ -187,7 +187,7 @@ typedef struct corbo_hip_problem_desc {
      * 0 = IntegratorExplicitRungeKutta4 (:244-295, what the reference's examples use), 1 = IntegratorExplicitEuler (:47-72),
      * 2 = IntegratorExplicitRungeKutta2 (:97-138), 3 = IntegratorExplicitRungeKutta3 (:167-213), 5 / 6 / 7 = IntegratorExplicitRungeKutta5 / 6 / 7
      * (:327-394, :429-503, :541-628; every family on the Levenberg-Marquardt path -- around a big-block model not together with extra edges or with a free
-     * dt on block sizes other than 8 / 12; the Hessian-path operators: families with nx <= 4).
+     * dt on odd block sizes; the Hessian-path operators: families with nx <= 4).
      * Travels to the kernels in slot 7 of the dynamics parameters (no model uses more than 5). */
     int32_t shooting_integrator;
     /* TerminalPartialEqualityConstraint (final_state_constraints.h:198-300): with final_eq = 1 and a non-zero mask the equality rows exist for the
