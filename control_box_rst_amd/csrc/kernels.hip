@@ -232,7 +232,7 @@ __device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc
 // generically (values before the chi2 reduction, central-difference blocks with the other Jacobian entries).  Stand-alone kernels only.
 template <int DYN, int DEFECT, bool FUSED, bool DENSE = false, bool LONG = false, int THREADS = SWEEP_THREADS, bool XE = false, bool NOJAC = false>
 __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode, int32_t* const active_count, LmState* const st, double* xs, double* red, double* cs, double* jst, const int inst, const int tid, const bool xs_ready = false,
-                                           StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr, const bool in_loop = false)
+                                           StageKeep<Dynamics<DYN>::NX, Dynamics<DYN>::NU>* const keep = nullptr, const bool in_loop = false, int* const sc_out = nullptr)
 {
     using Dy          = Dynamics<DYN>;
     constexpr int NX  = Dy::NX;
@@ -262,6 +262,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         const int vspec = (js_ < NX) ? (p.N - 1) * S + js_ : p.off_dt;
 #pragma unroll
         for (int c = 0; c < W + 1; ++c) scv_pre[c] = p.stage_cols[reg ? kb : 0].col[c];
+        if (sc_out) {   // (the factor phase of this pass gathers lane k's defect block through the same offsets: handed over in registers, not loaded a second time)
+#pragma unroll
+            for (int c = 0; c < W + 1; ++c) sc_out[c] = scv_pre[c];
+        }
 #pragma unroll
         for (int e = 0; e < S; ++e) {   // (an absent slot fetches component 0 and is ignored; slot 0 of a special lane: its component)
             const bool on = reg || (isfin && e < NX);   // (the last block: x_f, no controls)
@@ -1568,10 +1572,15 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // phase's own loads (gfx9 returns vector-memory operations in order: a load's wait includes every store and every slow load issued before it).
 template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false, bool RECOMP = false, class Hook = NoHook>
 __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr, const SweepParams* const sq = nullptr,
-                                            const StageKeep<NX, NU>* const keep = nullptr, const bool keep_valid = false, Hook&& after_gather = Hook{})
+                                            const StageKeep<NX, NU>* const keep = nullptr, const bool keep_valid = false, Hook&& after_gather = Hook{},
+                                            const int* const sc_in = nullptr, int* const smask = nullptr)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
+    // (two-wave run-to-completion shape) no table load at the start of the factor phase: the defect edge's Jacobian offsets come from the sweep phase of the
+    // same pass in registers (sc_in), and what the component tables say about this lane's stage is decoded once per solve into *smask -- bits [0, NX) fixed
+    // components, [8, 8 + S) cost rows present, [16, 16 + S) bound rows present, 24: the last block carries rows of a terminal equality, 31: valid
+    const bool SM = RECOMP && smask && (*smask < 0);
     constexpr int NT = NX * (NX + 1) / 2;
     const int N  = p.N;
     const int NP = NPC > 0 ? NPC : (N | 1);
@@ -1612,21 +1621,38 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     //      gathers from LDS.  Absent entries (offset -1: fixed component, no cost/bound row) are loaded from index 0 and zeroed.
     constexpr int WL = S + NX + 1;  // local columns of the defect edge: x_k, u_k, x_{k+1}, dt
     int sco[WL];
-    {
+    if (RECOMP && sc_in) {
+#pragma unroll
+        for (int c = 0; c < WL; ++c) sco[c] = has_stage ? sc_in[c] : -1;
+    }
+    else {
         const int ks = has_stage ? k : 0;
 #pragma unroll
         for (int c = 0; c < WL; ++c) { const int o = p.stage_cols[ks].col[c]; sco[c] = has_stage ? o : -1; }
     }
     int cj[S], cr[S], bj[S], br[S], xfixed[NX];   // cost / bound row (Jacobian offset, residual row) per component of stage k
-    {
+    if (SM) {   // (decoded: RECOMP takes the rows' values and entries from registers / recomputes them, only their presence matters here)
+        const int m = *smask;
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            cj[e] = ((m >> (8 + e)) & 1) ? 0 : -1; bj[e] = ((m >> (16 + e)) & 1) ? 0 : -1; cr[e] = 0; br[e] = 0;
+            if (e < NX) xfixed[e] = (m >> e) & 1;
+        }
+    }
+    else {
         const int kb = has_block ? k : 0;
+        int m = (int)0x80000000u;
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             const bool ok = (e < NX) ? has_block : has_stage;
             const CompInfo ci = p.comp[(ok ? kb : 0) * S + e];
             cj[e] = ok ? ci.cost_joff : -1; cr[e] = ci.cost_row; bj[e] = ok ? ci.bnd_joff : -1; br[e] = ci.bnd_row;
             if (e < NX) xfixed[e] = ok ? ci.fixed : 1;
+            m |= (cj[e] >= 0 ? 1 << (8 + e) : 0) | (bj[e] >= 0 ? 1 << (16 + e) : 0);
+            if (e < NX) m |= xfixed[e] ? 1 << e : 0;
+            if (e < NX && has_block && !has_stage && !ci.fixed && ci.cost2_joff >= 0 && ci.cost2_row >= 0) m |= 1 << 24;
         }
+        if (RECOMP && smask) *smask = m;
     }
     int iq_row = -1, iq[NX];
 #pragma unroll
@@ -1674,8 +1700,8 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 #pragma unroll
         for (int e = 0; e < S; ++e) { vc[e] = val[cj[e] >= 0 ? cr[e] : 0]; vb[e] = val[bj[e] >= 0 ? br[e] : 0]; }
     }
-    rin = val[iq_row >= 0 ? iq_row : 0];
-    if (iq_row < 0) rin = 0.0;
+    rin = 0.0;
+    if (iq_row >= 0) rin = val[iq_row];   // (a real branch: no load at all for a stage without an inequality row)
     if (!has_stage) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) r[i] = 0.0;
@@ -1744,7 +1770,7 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     constexpr int NUT = NU * (NU + 1) / 2;
     double dq[NT + NX + NUT + NU];
     if constexpr (DENSE) { if (wdm) dense_cost_terms<NX, NU>(p.stage_cols, p.comp, wdm, N, J, val, k, dq); }
-    if (has_block && !has_stage) {   // the last block: rows of a TerminalEqualityConstraint on x_f (second diagonal row of a component)
+    if (has_block && !has_stage && !(SM && !((*smask >> 24) & 1))) {   // the last block: rows of a TerminalEqualityConstraint on x_f (second diagonal row of a component)
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
             const CompInfo ci = p.comp[k * S + e];
@@ -4582,6 +4608,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
             int mode = ((const SweepParams&)ka->s).mode;
             const int max_passes = ((const FactorParams&)ka->f).loop_passes;
             StageKeep<Dy::NX, Dy::NU> keep;   // (two-wave shape) the residual rows paired with the resident Jacobian, in registers across the passes
+            int smask = 0;                    // (two-wave shape) what the component tables say about this lane's stage, decoded once per solve (factor_body)
 #pragma nounroll
             for (int pass = 0; pass <= max_passes; ++pass) {
                 asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");  // nothing derived from them is carried around the loop
@@ -4607,7 +4634,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                     }
                 }
                 constexpr bool TWOW = (THREADS <= 128);   // two-wave shape: Jacobian stream-out and bookkeeping ride inside the factor phase (factor_body, after_gather)
-                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep, TWOW && max_passes > 0);   // (active_count: per-pass launches only)
+                int scv[2 * Dy::NX + Dy::NU + 1];   // (two-wave shape) Jacobian offsets of lane k's defect edge: requested by the sweep phase, used by this pass's factor phase as well
+                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep, TWOW && max_passes > 0, TWOW ? scv : nullptr);   // (active_count: per-pass launches only)
                 __threadfence_block();
                 __syncthreads();
                 if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
@@ -4665,7 +4693,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 };
                 // (loop_passes = 0: ONE pass per launch -- the per-pass mode of corbo_hip_solve and the profiling mode; the trial iterate then
                 //  goes to HBM for the next launch instead of staying in the LDS array the next sweep phase evaluates it from)
-                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, false, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook);
+                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, false, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook, TWOW ? scv : nullptr, &smask);
                 if constexpr (BK_DEFER) { if (bk_slot >= 0) bk_rank(); }
                 __threadfence_block();
                 __syncthreads();
