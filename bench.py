@@ -382,6 +382,7 @@ def band_leg(device):
         s.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
         st = s.get_stats()
+        chi2_band = float(np.sum(s.get_solution()[1]))
         s.restore_instance_data()
         f_ms = s.time_factor(repeat=3)
         rows, cols = get_structure(d)
@@ -398,7 +399,7 @@ def band_leg(device):
                             "us_per_pivot": 1e3 * f_ms / (n - 1), "cycles_per_pivot_at_2p4GHz": 2.4e6 * f_ms / (n - 1),
                             "flops_per_factorization_per_instance": flops,
                             "achieved_GFLOPs": B * flops / (f_ms * 1e-3) / 1e9, "frac_of_fp64_vector_peak": B * flops / (f_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
-        out[f"batch{B}"]["chi2_sum"] = float(np.sum(s.get_solution()[1]))
+        out[f"batch{B}"]["chi2_sum"] = chi2_band
         del s
     del os.environ["CORBO_HIP_FREE_DT_BAND"]
     out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass (batch1 / batch64: CORBO_HIP_FREE_DT_BAND=1); chain_route_*: the same solves through big_stage_kernel / big_chain3_kernel with the border column"

@@ -1,5 +1,6 @@
 """Band factorisation path (free dt around a big-block model, integral-form constraints): time per solve (diagnostics).  python tools/band_time.py"""
 import os, sys, time
+os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"   # (the time-optimal big-block descriptors below take the stage / chain route by default since round 5: tools/free_dt_time.py)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
