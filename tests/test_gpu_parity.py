@@ -54,7 +54,7 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
         # ... and the same family on the FiniteDifferencesGrid (the four collocation formulas), incl. the 12-state quadrotor
         "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
-        # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the band factorisation takes these
+        # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the dt column rides through the stage / partitioned-chain kernels (the band route: tests/test_gpu_free_dt_chain.py)
         "pquad_topt_n10", "pquad_topt_n30", "pquad_fd_topt_n12", "quad_topt_n8",
         # Runge-Kutta 5 / 6 / 7 around the big-block models (incl. a free dt around the 12-state quadrotor: the dt column through the partitioned chain)
         "quad_n10_rk5", "quad_n10_rk7", "pquad_n10_rk6", "quad_topt_n8_rk6",

@@ -1,3 +1,5 @@
+"""Six-state planar quadrotor (user model of the big-block family): partitioned chain vs the first formulation (fixed dt), chain route vs band route (free dt);
+ms per 10-iteration solve (diagnostics).  python tools/pquad_time.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
