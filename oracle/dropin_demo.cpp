@@ -337,7 +337,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     else if (scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate")
     {   // a user dynamics class with six states: matched against the models of csrc/models/, solved by the big-block family
         // (pquad_fd: on the FiniteDifferencesGrid, Crank-Nicolson collocation; pquad_topt: time-optimal on the MultipleShootingVariableGrid --
-        // a free dt around a big-block model: the device's band factorisation)
+        // a free dt around a big-block model: the dt column through the device's stage / partitioned-chain kernels)
         dyn = std::make_shared<PlanarQuadrotorRef>();
         if (scenario == "pquad_fd" || scenario == "pquad_fd_xe_ball") grid = std::make_shared<FiniteDifferencesGrid>();
         else if (scenario == "pquad_topt")
