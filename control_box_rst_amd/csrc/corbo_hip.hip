@@ -212,6 +212,7 @@ struct corbo_hip_solver {
     size_t stage_cache_stride = 0;
     int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
+    int band_wide = 0;          // corbo_hip_set_option("band_wide"): FactorParams::band_wide
     int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, see FactorParams::chain_variant
     int pass_limit = 0;         // corbo_hip_set_option("pass_limit"): > 0 lowers the run-to-completion kernel's limit of 4096 LM passes
     int pass_timeline_inst = -1;   // corbo_hip_set_option("pass_timeline"): >= 0 prints that instance's per-pass shader-clock stamps
@@ -286,6 +287,7 @@ struct corbo_hip_solver {
         // instead of two rounds of single-instance latency (cfg 5: 8.33 -> 8.06 ms per solve; a single OCP: 1.76 against 2.03 ms, hence not always).
         // By the HANDLE's batch, not the launch's active count: every pass of a handle factorises the same way (the segment count changes the
         // elimination order, i.e. the iterates at rounding level -- tests/test_gpu_chain_variants.py).
+        p.band_wide = band_wide;
         p.chain_variant = (chain_variant == 0 && big_family_dims(S.nx, S.nu) && S.N >= 64 && num_cus > 0 && batch > num_cus) ? 4 : chain_variant;
         p.stage_cache = d_stage_cache; p.stage_cache_stride = (int64_t)stage_cache_stride;
         p.defect = S.desc.defect;
@@ -1549,6 +1551,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "pass_timeline") h->pass_timeline_inst = value;
     else if (n == "sweep_timeline") h->sweep_timeline = value != 0;
     else if (n == "chain_variant") h->chain_variant = value;
+    else if (n == "band_wide") h->band_wide = value;
     else if (n == "hess_split") h->hess_split = value;
     else if (n == "reject_speculation") h->reject_speculation = value;
     else if (n == "stagger") h->stagger = value;

@@ -6452,6 +6452,224 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
     lm_state_out(p.st + inst, st, tid);
 }
 
+// ---- (round 5) NARROW bands, half-bandwidth <= 7: ONE WAVE per instance, the 8 x 8 window of the elimination in REGISTERS (lane 8 i + j holds H'(p + i, p + j)
+//      at pivot p, both triangles), no barrier, no LDS traffic in the pivot loop.  The small-block families with integral-form constraint edges / the
+//      control-deviation term are exactly this case (unicycle: five parameters per stage, half-bandwidth 7; 495 pivots per factorisation): with the
+//      eight-wave kernel above a pivot is ~ 1.7 k cycles of barriers and LDS round trips whatever the bandwidth (the headline batch with a rate limit on
+//      the controls: 18.3 ms per solve against 0.48 ms without).  Per pivot here: the pivot and the right-hand side's entry by v_readlane, column 0 to
+//      the rows and columns by two lane permutations, one multiply-subtract, the window moved up its diagonal by a third permutation (lane + 9), the row
+//      that enters (requested eight pivots ahead, branch-free) taken by the window's last row and column.  Same products and the same order of operations
+//      per entry as band_factor_kernel; L leaves in the same row form (diagonal inverted), so the back-substitution is that kernel's, verbatim.
+__device__ __forceinline__ double lane_perm(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <bool ARROW>
+__global__ __launch_bounds__(64) void band_narrow_kernel(const FactorParams p, const BandParams bp)
+{
+    extern __shared__ __attribute__((aligned(16))) double nar_smem[];
+    __shared__ __attribute__((aligned(16))) LmState sl_;
+    const int inst = blockIdx.x + p.inst0, lane = threadIdx.x;
+    LmState* st = &sl_;
+    lm_state_in(st, p.st + inst, lane);
+    __syncthreads();
+    if (st->done) return;
+    const int n = bp.n, nb = bp.nb, bw = bp.bw, W = bw + 1;
+    constexpr bool arrow = ARROW;                             // (nb < n: a free dt as a border)
+    double* Hb  = bp.work + (size_t)inst * bp.work_stride;   // [nb][W]: column r - bw + d of row r at d; d = bw is the diagonal
+    const double* gz = Hb + (size_t)nb * W;                   // what band_assemble_kernel left: rhs, border, corner, rhs of dt
+    double* g = nar_smem;                                     // y -> delta
+    double* z = g + nb;                                       // L^-1 border (free dt)
+    const int fresh = st->fresh, first = st->first;
+    int stop = st->stop;
+    double mu = st->mu;
+    const double mu_acc_in = st->mu_acc;
+    const double corner = arrow ? gz[2 * nb] : 0.0, gdt = arrow ? gz[2 * nb + 1] : 0.0;
+    if (first) {   // mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
+        double mx_d = -1e300, mx_g = 0.0;
+        for (int c = lane; c < nb; c += 64) { mx_d = fmax(mx_d, Hb[(size_t)c * W + bw]); mx_g = fmax(mx_g, fabs(gz[c])); }
+        mx_d = wave_max(mx_d); mx_g = wave_max(mx_g);
+        if (arrow) { mx_d = fmax(mx_d, corner); mx_g = fmax(mx_g, fabs(gdt)); }
+        stop = (mx_g <= LM_EPS1) ? 1 : 0;
+        mu   = LM_TAU * mx_d;
+        if (mu < 0) mu = 0;
+    }
+    const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;   // H_ii += mu on every inner pass, never undone on reject (:135-138)
+#define NAR_STAMP(i) do { if (p.timeline && blockIdx.x == 0 && lane == 0) p.timeline[i] = clock64(); } while (0)
+    NAR_STAMP(0); NAR_STAMP(1);
+    // ---- the window: a RING -- row p + i of the band lives in row slot (p + i) & 7, column p + j in column slot (p + j) & 7; lane 8 a + b holds the
+    //      entry (row slot a, column slot b), both triangles.  Nothing moves between pivots: the finished pivot's row and column slots take the row that
+    //      enters.  (A window that is shifted up its diagonal every pivot puts a second lane permutation on the dependent chain: measured 950 cycles per
+    //      pivot incl. the back-substitution against ~ 1.7 k of the eight-wave kernel; the ring: one permutation round per pivot.)
+    const int wa = lane >> 3, wb = lane & 7;
+    const int whi = wa > wb ? wa : wb, wdd = wa > wb ? wa - wb : wb - wa;
+    double w = 0.0;
+    {
+        const bool in = (wdd <= bw) && (whi < nb);
+        const double v = Hb[(size_t)(in ? whi : 0) * W + (in ? bw - wdd : 0)];
+        w = in ? v : 0.0;
+        if (in && wdd == 0) w += mu_eff;
+    }
+    double gi = gz[wa < nb ? wa : 0], zi = arrow ? gz[nb + (wa < nb ? wa : 0)] : 0.0;   // lane (a, b): the right-hand side's / the border's entry of the row in slot a
+    if (wa >= nb) { gi = 0.0; zi = 0.0; }
+    // the row that enters behind pivot p is row p + 8: requested PD chunks of eight pivots ahead, element t of the band row by lane t (branch-free, clamped),
+    // already in the form the window takes it in: zero for a row behind the band's end and in the lanes beyond the row's length, the damping on its diagonal.
+    // (The band was written by another kernel on other compute units: it comes from the fabric-side cache or HBM, 1.5 - 2 us away.)
+    constexpr int PF = 8, PD = 3;
+    const int et = lane <= bw ? lane : 0;
+    const double emu = (lane == bw) ? mu_eff : 0.0;
+    // (the loaded values are NOT touched here: an operation on a value that is still in flight makes the wave wait for it at once -- measured: 585 -> 811
+    //  cycles per pivot with the masking done at the request; it is done where the row is used, PD chunks later)
+    auto fetch_row = [&](int r, double& vr, double& vg, double& vz) {
+        const int rc = r < nb ? r : 0;
+        vr = Hb[(size_t)rc * W + et]; vg = gz[rc];
+        if constexpr (arrow) vz = gz[nb + rc]; else vz = 0.0;
+    };
+    double pr[PD][PF], pg[PD][PF], pz[PD][PF];
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch_row(8 + q * PF + u, pr[q][u], pg[q][u], pz[q][u]);
+    // per-lane constants of the eight pivot slots: where column p of the window is (for this lane's row / column), whether the lane's entry belongs to the
+    // pivot's row / column slot (it takes the entering row then) and which element of that row it takes (lane 63 -- always zero -- for an entry outside the band)
+    int a_row[PF], a_col[PF], a_ent[PF], ia_[PF];
+    bool m_row[PF], m_any[PF], m_st[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int ia = (wa - u) & 7, ib = (wb - u) & 7;
+        const bool erow = (ia == 0), ecol = (ib == 0);
+        const int io = erow ? ib : ia;
+        const int eoff = (io == 0) ? 0 : 8 - io;
+        a_row[u] = ((lane & 56) | u) << 2; a_col[u] = ((u << 3) | wb) << 2;
+        a_ent[u] = ((eoff <= bw) ? bw - eoff : 63) << 2;
+        m_row[u] = erow; m_any[u] = erow || ecol; m_st[u] = ecol && ia <= bw; ia_[u] = ia;
+    }
+    auto perm = [](int addr, double v) {
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+        const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    };
+    double y2 = 0.0, zz = 0.0, zy = 0.0;
+    NAR_STAMP(2);
+    bool more = nb > 0;
+    for (int p0 = 0; more; p0 += PD * PF) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q)
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {   // (PF = 8: the pivot's slot is the compile-time constant u)
+            const int pv = p0 + q * PF + u;
+            if (pv >= nb) { more = false; break; }                  // (uniform)
+            double nr, ng, nz;
+            fetch_row(pv + 8 + PD * PF, nr, ng, nz);
+            const double d   = lane_bcast(w, 9 * u);
+            const double inv = rsqrt(d);                            // (v_rsq_f64 + one Newton step, like band_factor_kernel)
+            const double ci = perm(a_row[u], w), cj = perm(a_col[u], w);   // H'(row of slot a, p), H'(row of slot b, p)
+            const bool rin = pv + 8 < nb;                           // (uniform) the entering row exists
+            const double ev = perm(a_ent[u], (rin && lane <= bw) ? pr[q][u] + emu : 0.0);   // (off the dependent chain)
+            const double li = ci * inv, lj = cj * inv;
+            const double wu = w - li * lj;
+            const double y  = lane_bcast(gi, 8 * u) * inv;
+            const double gu = gi - li * y;
+            // column p of L leaves in ROW form: L(p + i, p) sits at offset bw - i of row p + i; the diagonal inverted (the back-substitution multiplies)
+            if (m_st[u] && pv + ia_[u] < nb) Hb[(size_t)(pv + ia_[u]) * W + bw - ia_[u]] = (ia_[u] == 0) ? inv : li;
+            if (lane == 0) g[pv] = y;
+            y2 += y * y;
+            if constexpr (arrow) {
+                const double zp = lane_bcast(zi, 8 * u) * inv, zu = zi - li * zp;
+                if (lane == 0) z[pv] = zp;
+                zz += zp * zp; zy += zp * y;
+                zi = m_row[u] ? (rin ? pz[q][u] : 0.0) : zu;
+            }
+            w  = m_any[u] ? ev : wu;
+            gi = m_row[u] ? (rin ? pg[q][u] : 0.0) : gu;
+            pr[q][u] = nr; pg[q][u] = ng; pz[q][u] = nz;   // (in place: the slot is due again PD chunks from now)
+        }
+    }
+    NAR_STAMP(3);
+    double ddt = 0.0;
+    __threadfence_block();
+    if (arrow) {   // the last pivot: H(dt, dt) + damping - |z|^2
+        const double piv  = (corner + mu_eff) - zz;
+        const double linv = 1.0 / sqrt(piv);
+        const double ydt  = (gdt - zy) * linv;
+        y2 += ydt * ydt;
+        ddt = ydt * linv;
+        for (int c = lane; c < nb; c += 64) g[c] -= z[c] * ddt;
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- back-substitution L^T delta = y: band_factor_kernel's (rows of L from HBM / L2, eight in flight, the touched part of the vector in registers)
+    {
+        const bool on = lane < W;
+        const int lc = on ? lane : 0;
+        double rr[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int ir = nb - 1 - u; rr[u] = Hb[(size_t)(ir >= 0 ? ir : 0) * W + lc]; }
+        const int c0 = nb - 1 - bw + lane;
+        double a   = (on && c0 >= 0 && nb >= 1) ? g[c0] : 0.0;
+        double gin = g[nb - 2 - bw >= 0 ? nb - 2 - bw : 0];
+        if (nb - 2 - bw < 0) gin = 0.0;
+        for (int i0 = nb - 1; i0 >= 0; i0 -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int i = i0 - u;
+                const bool act = (i >= 0);
+                const double row = (on && act) ? rr[u] : 0.0;
+                rr[u] = Hb[(size_t)(i - PF >= 0 ? i - PF : 0) * W + lc];
+                const double xi = lane_bcast(a * row, bw);
+                if (lane == bw && act) g[i] = xi;
+                const double upd = a - row * xi;
+                const double kept = (lane < bw) ? upd : 0.0;
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(kept), 0x138, 0xF, 0xF, false);   // wave_shr:1
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(kept), 0x138, 0xF, 0xF, false);
+                const double moved = (lane == 0) ? gin : __hiloint2double(hi, lo);
+                a = act ? moved : a;
+                const int ig = i - 2 - bw;
+                const double gl = g[ig >= 0 ? ig : 0];
+                gin = (ig >= 0) ? gl : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    NAR_STAMP(4);
+    // ---- trial iterate x + delta (applyIncrementNonFixed, vertex_set.cpp:357-367), step norms
+    const double* xin = p.x + (size_t)inst * p.nvs;
+    double* xt        = p.xt + (size_t)inst * p.nvs;
+    double* dl        = p.delta_out ? p.delta_out + (size_t)inst * p.nvs : nullptr;
+    for (int v = lane; v < p.nvs; v += 64) { xt[v] = xin[v]; if (dl) dl[v] = 0.0; }
+    __syncthreads();
+    double dn2 = 0.0;
+    for (int c = lane; c < n; c += 64) {
+        const double d = (c < nb) ? g[c] : ddt;
+        const int v    = bp.param_voff[c];
+        xt[v] = xin[v] + d;
+        if (dl) dl[v] = d;
+        dn2 += d * d;
+    }
+    dn2 = wave_sum(dn2);
+    if (lane == 0) {
+        st->mu     = mu;
+        st->mu_acc = mu_eff;
+        st->first  = 0;
+        st->fresh  = 0;
+        st->n_fact += 1;
+        st->inner += 1;
+        const double dnorm = sqrt(dn2);
+        st->dnorm = dnorm;
+        int no_trial;
+        if (dnorm <= LM_EPS2) { stop = 1; no_trial = 1; }                    // :151-154
+        else { no_trial = 0; st->den = mu * dn2 + y2; }                      // delta^T (mu delta + rhs), delta^T rhs = |y|^2
+        st->stop     = stop;
+        st->no_trial = no_trial;
+    }
+    NAR_STAMP(5);
+#undef NAR_STAMP
+    __syncthreads();
+    lm_state_out(p.st + inst, st, lane);
+}
+
 static constexpr size_t BAND_LDS_MAX = 160 * 1024 - 256;   // (the kernel also has 128 bytes of static LDS: the LM state)
 // what band_factor_kernel can take: one wave writes a finished row out / walks a row in the back-substitution (half-bandwidth <= 63), and the sliding
 // window + right-hand side + border live in LDS.  corbo_hip_create asks, so that an unsupported descriptor is refused THERE (include/corbo_hip.h).
@@ -6469,6 +6687,19 @@ bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_
         if (chunks > 64) chunks = 64;
         if (chunks < 1) chunks = 1;
         hipLaunchKernelGGL(band_assemble_kernel, dim3(chunks, fp.batch), dim3(256), 0, stream, fp, bp);
+    }
+    // half-bandwidth <= 7: one wave per instance, window in registers (band_narrow_kernel); option "band_wide" keeps the eight-wave kernel (A/B, tests)
+    const size_t lds_n = sizeof(double) * (2 * (size_t)bp.nb + 8);
+    if (bp.bw <= 7 && !fp.band_wide && lds_n <= BAND_LDS_MAX) {
+        static bool attr_n = false;
+        if (!attr_n) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_narrow_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError();
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_narrow_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError();
+            attr_n = true;
+        }
+        if (bp.nb < bp.n) hipLaunchKernelGGL(band_narrow_kernel<true>, dim3(fp.batch), dim3(64), lds_n, stream, fp, bp);
+        else hipLaunchKernelGGL(band_narrow_kernel<false>, dim3(fp.batch), dim3(64), lds_n, stream, fp, bp);
+        return true;
     }
     hipLaunchKernelGGL(band_factor_kernel, dim3(fp.batch), dim3(512), lds, stream, fp, bp);
     return true;

@@ -116,6 +116,7 @@ struct FactorParams {
     int64_t work_stride;          // doubles per instance
     long long* pass_timeline;     // optional [2 * 64 + 1] shader-clock stamps (pass start, sweep end) of one instance (diagnostics)
     int32_t pass_timeline_inst;
+    int32_t band_wide;            // band route: 1 = the eight-wave kernel whatever the half-bandwidth (option "band_wide": A/B, tests); 0 = one wave per instance for half-bandwidths <= 7
     int32_t chain_variant;        // big-block family: 0 = automatic (N >= 64: partitioned chain big_chain3_kernel, four segments; else the twisted chain big_chain2_kernel), 1 = the first formulation, 2 = twisted, 3 / 4 / 6 = 4 / 2 / 1 segments
     int32_t first_pass;           // big-block family: this may be the first factorisation of a solve (launches the mu / stop kernels)
     double* stage_cache;          // big-block family: [batch][pairs][2 x BigLds::HALF] the stage waves' local Jacobians of a solve's FIRST factorisation, written by its

@@ -130,3 +130,27 @@ def test_random_batches_vs_oracle(oracle_mod, seed):
     X, chi2, _ = s.get_solution()
     assert np.abs(X - Xo).max() <= 3e-5 * max(1.0, np.abs(Xo).max()), (seed, fam, np.abs(X - Xo).max())
     assert np.allclose(chi2, chi2o, rtol=5e-5, atol=1e-10), (seed, chi2, chi2o)
+
+
+@pytest.mark.parametrize("name", ["xe_unicycle_all_left_n100", "xe_unicycle_rate", "xe_vdp_eqlin_rate", "xe_int3_vargrid_trap", "xe_rocket_rate_eq", "xe_unicycle_all_n300"])
+def test_narrow_band_kernel_vs_eight_wave_kernel(name):
+    """Half-bandwidths up to 7 take band_narrow_kernel (one wave per instance, the 8 x 8 window in registers; incl. a free dt as a border); option band_wide
+    keeps band_factor_kernel.  Same products in the same order per entry of the factor: the LM decisions are the same, the iterates agree far inside the fixtures' tolerances."""
+    g = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    d = desc_for(g)
+    a = g["after_iter"][-1]
+    out = []
+    for wide in (0, 1):
+        s = _solver(g, d, a["k"], B=3)
+        s.set_option("band_wide", wide)
+        for i in range(g["solves"]):
+            s.solve(new_run=(i == 0))
+        x, chi2, status = s.get_solution()
+        out.append((x, chi2, status, s.get_stats()))
+    (x0, c0, s0, t0), (x1, c1, s1, t1) = out
+    assert np.array_equal(s0, s1)
+    assert t0["factorizations"] == t1["factorizations"] and t0["accepted_steps"] == t1["accepted_steps"]
+    # (|y|^2 is summed in another order: the damping after an accepted step differs in its last bits, the finite-difference Jacobians amplify that like any
+    #  other rounding difference -- both kernels stay inside the reference's own one-ulp spread of these fixtures, tests/tolerances.json)
+    assert np.allclose(c0, c1, rtol=2e-7, atol=1e-12), (name, c0, c1)
+    assert np.abs(x0 - x1).max() <= 2e-6, (name, np.abs(x0 - x1).max())
