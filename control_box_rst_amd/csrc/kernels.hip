@@ -6452,20 +6452,14 @@ __global__ __launch_bounds__(512) void band_factor_kernel(const FactorParams p, 
     lm_state_out(p.st + inst, st, tid);
 }
 
-// ---- (round 5) NARROW bands, half-bandwidth <= 7: ONE WAVE per instance, the 8 x 8 window of the elimination in REGISTERS (lane 8 i + j holds H'(p + i, p + j)
-//      at pivot p, both triangles), no barrier, no LDS traffic in the pivot loop.  The small-block families with integral-form constraint edges / the
-//      control-deviation term are exactly this case (unicycle: five parameters per stage, half-bandwidth 7; 495 pivots per factorisation): with the
-//      eight-wave kernel above a pivot is ~ 1.7 k cycles of barriers and LDS round trips whatever the bandwidth (the headline batch with a rate limit on
-//      the controls: 18.3 ms per solve against 0.48 ms without).  Per pivot here: the pivot and the right-hand side's entry by v_readlane, column 0 to
-//      the rows and columns by two lane permutations, one multiply-subtract, the window moved up its diagonal by a third permutation (lane + 9), the row
-//      that enters (requested eight pivots ahead, branch-free) taken by the window's last row and column.  Same products and the same order of operations
-//      per entry as band_factor_kernel; L leaves in the same row form (diagonal inverted), so the back-substitution is that kernel's, verbatim.
-__device__ __forceinline__ double lane_perm(double v, int src_lane)
-{
-    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
+// ---- (round 5) NARROW bands, half-bandwidth <= 7: ONE WAVE per instance, the 8 x 8 window of the elimination in REGISTERS (a ring of row / column slots,
+//      both triangles), no barrier, no LDS traffic in the pivot loop.  The small-block families with integral-form constraint edges / the control-deviation
+//      term are exactly this case (unicycle: five parameters per stage, half-bandwidth 7; 495 pivots per factorisation): with the eight-wave kernel above a
+//      pivot is ~ 1.7 k cycles of barriers and LDS round trips whatever the bandwidth (the headline batch with a rate limit on the controls: 18.3 ms per solve
+//      against 0.48 ms without).  Per pivot here: the pivot and the right-hand side's entry by v_readlane, column p to the rows and columns by one round of
+//      lane permutations, one multiply-subtract; the finished pivot's row and column slots take the row that enters (requested 24 pivots ahead, branch-free).
+//      Same products and the same order of operations per entry as band_factor_kernel; L leaves in the same row form (diagonal inverted), so the
+//      back-substitution is that kernel's, verbatim.  (docs/measurements/r05.md 9: the versions measured on the way.)
 template <bool ARROW>
 __global__ __launch_bounds__(64) void band_narrow_kernel(const FactorParams p, const BandParams bp)
 {
