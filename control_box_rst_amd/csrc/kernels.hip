@@ -6603,8 +6603,11 @@ __global__ __launch_bounds__(64) void band_narrow_kernel(const FactorParams p, c
         for (int u = 0; u < PF; ++u) { const int ir = nb - 1 - u; rr[u] = Hb[(size_t)(ir >= 0 ? ir : 0) * W + lc]; }
         const int c0 = nb - 1 - bw + lane;
         double a   = (on && c0 >= 0 && nb >= 1) ? g[c0] : 0.0;
-        double gin = g[nb - 2 - bw >= 0 ? nb - 2 - bw : 0];
-        if (nb - 2 - bw < 0) gin = 0.0;
+        // the entry that enters at lane 0 behind row i is y of column i - 1 - bw -- untouched by the rows above it: read eight rows ahead like the rows of L
+        // (one row ahead, its LDS round trip sat on every row's dependent chain)
+        double gq[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int ig = nb - 1 - u - 1 - bw; gq[u] = g[ig >= 0 ? ig : 0]; }
         for (int i0 = nb - 1; i0 >= 0; i0 -= PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -6618,11 +6621,11 @@ __global__ __launch_bounds__(64) void band_narrow_kernel(const FactorParams p, c
                 const double kept = (lane < bw) ? upd : 0.0;
                 const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(kept), 0x138, 0xF, 0xF, false);   // wave_shr:1
                 const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(kept), 0x138, 0xF, 0xF, false);
+                const double gin = (i - 1 - bw >= 0) ? gq[u] : 0.0;
                 const double moved = (lane == 0) ? gin : __hiloint2double(hi, lo);
                 a = act ? moved : a;
-                const int ig = i - 2 - bw;
-                const double gl = g[ig >= 0 ? ig : 0];
-                gin = (ig >= 0) ? gl : 0.0;
+                const int ig = i - PF - 1 - bw;
+                gq[u] = g[ig >= 0 ? ig : 0];
             }
         }
     }
