@@ -562,7 +562,9 @@ int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const dou
  *   "ff_converged"      0: compute the outer iterations that follow a converged step instead of counting them (A/B and tests)
  *   "lag_priority"      0: no lag-based issue priority in the run-to-completion kernel
  *   "phase_cycles"      1: per-instance phase totals of the run-to-completion kernel (corbo_hip_get_phase_cycles)
- *   "raw_stamps"        1: "pass_timeline" prints raw stamp offsets (development builds that re-purpose the stamp slots) */
+ *   "raw_stamps"        1: "pass_timeline" prints raw stamp offsets (development builds that re-purpose the stamp slots)
+ *   "band_wide"         1: the band route (integral-form constraint edges / control-deviation term) keeps the eight-wave factor kernel for every
+ *                       half-bandwidth; 0 (default): half-bandwidths up to 7 take the one-wave-per-instance kernel */
 int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value);
 
 /* Text of the last error on this thread. */
