@@ -402,6 +402,27 @@ def band_leg(device):
         out[f"batch{B}"]["chi2_sum"] = chi2_band
         del s
     del os.environ["CORBO_HIP_FREE_DT_BAND"]
+    # narrow bands (half-bandwidth 7: band_narrow_kernel, one wave per instance): the headline batch with the control-deviation term (a rate limit on the controls)
+    try:
+        from control_box_rst_amd import capi
+        wl = workload(3, 1024)
+        dx = wl["desc"]
+        dx.ctrl_dev = capi.CTRL_DEV_RATE
+        dx.ctrl_dev_params[0] = 1.0; dx.ctrl_dev_params[1] = 1.0
+        s = BatchedLevenbergMarquardt(dx, 1024, device=device)
+        s.setIterations(10); s.setPenaltyWeights(*wl["weights"])
+        s.set_instance_data(s.init_trajectory(wl["x0"], wl["xf"]), xref=wl["xf"])
+        s.solve(new_run=True); s.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            s.restore_instance_data(); s.solve(new_run=True)
+        s.synchronize()
+        st = s.get_stats()
+        out["headline_batch_with_rate_limit"] = {"ms_per_solve": (time.perf_counter() - t0) / 3 * 1e3, "factorizations": int(st["factorizations"]), "passes": int(st["passes"]),
+                                                 "chi2_sum": float(np.sum(s.get_solution()[1])), "what": "configs[2]'s 1024 unicycle OCPs + the control-deviation term: sweep (XE) + band_assemble_kernel + band_narrow_kernel per LM pass, host-launched"}
+        del s
+    except Exception as e:   # (a measurement row: never fatal for the line)
+        out["headline_batch_with_rate_limit"] = {"error": str(e)[:200]}
     out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass (batch1 / batch64: CORBO_HIP_FREE_DT_BAND=1); chain_route_*: the same solves through big_stage_kernel / big_chain3_kernel with the border column"
     out["bound"] = "latency: n sequential pivots per instance (one barrier each, eight waves on a sliding LDS window); the flop rate is quoted for completeness"
     return out
