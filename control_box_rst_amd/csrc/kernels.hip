@@ -6680,7 +6680,10 @@ bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_
     if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError(); attr_set = true; }
     if (!bp.work || !band_route_supported(bp.nb, bp.bw)) return false;
     {
-        int chunks = (bp.n_ent + 2047) / 2048;   // (eight list entries per thread)
+        // list entries per thread: an entry is a chain of dependent loads (index, pair, two values).  Small batches are latency-bound -- two per thread (one OCP:
+        // 5.09 -> 4.78 ms per extra-edge solve); from a few hundred instances on the chip is full either way and fewer, longer threads win (1024: 9.8 vs 10.2 ms)
+        const int per_wg = (fp.batch >= 256 || bp.bw > 7) ? 2048 : 512;   // (wide bands -- long product lists per entry -- lose with the finer split at every batch size)
+        int chunks = (bp.n_ent + per_wg - 1) / per_wg;
         if (chunks > 64) chunks = 64;
         if (chunks < 1) chunks = 1;
         hipLaunchKernelGGL(band_assemble_kernel, dim3(chunks, fp.batch), dim3(256), 0, stream, fp, bp);
