@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E (MI355X_MICROARCH.md)
 PEAK_F64_MFMA_TFLOPS = 78.6  # gfx950 dense fp64 matrix peak
-PROFILE_ROUND = "r05"         # prefix of the committed rocprofv3 summaries under profiles/ the line cross-checks itself against
+PROFILE_ROUND = "r06"         # prefix of the committed rocprofv3 summaries under profiles/ the line cross-checks itself against
 
 
 def workload(cfg: int, batch: int, first: int = 0):
@@ -282,10 +282,16 @@ def secondary_leg(cfg, iterations, device):
         rec = 3 * nxq * nxq + nuq * nuq + 2 * nuq * nxq + 2 * nxq + nuq + 2
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
-        alg = per_stage * desc.N * B
+        # SURVEY 8d's algorithmic bytes of one Jacobian sweep, 8 (n_vert + 2 n + m + nnz) per instance: what `frac` is priced on.  The kernels' OWN intermediate
+        # traffic (the stage records big_stage_kernel writes and big_chain3_kernel re-reads) is the model figure `traffic_model`; the counters' figure is `traffic`.
+        alg = 8 * (dims.nv + 2 * dims.n + dims.m + dims.nnz) * B
+        pmc5 = load_profile_json(PROFILE_ROUND + "_cfg5_pmc.json", B, desc.N)
         out["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain3_kernel (one factorisation of every instance)", "bytes_per_launch": alg,
+                           "bytes_per_instance": alg // B, "bytes_definition": "SURVEY 8d: 8 (n_vert + 2 n + m + nnz) per instance per Jacobian sweep",
                            "ms_per_launch": f_ms, "achieved": alg / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": alg / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                           "frac": alg / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                           "traffic_model": per_stage * desc.N * B, "traffic_model_note": "the pair's own reads + writes incl. the per-stage records handed from the stage kernel to the chain",
+                           "traffic": pmc5["hbm_bytes_per_launch"] if pmc5 else None, "traffic_source": pmc5["source"] if pmc5 else None}
     del solver
     return out
 
@@ -367,11 +373,11 @@ def band_leg(device):
         out[f"chain_route_batch{B}"] = {"ms_per_solve": ms, "passes": int(st["passes"]), "factorizations": int(st["factorizations"]),
                                         "chi2_sum": float(np.sum(s.get_solution()[1]))}
         del s
-    os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"   # (read by corbo_hip_create)
+    from control_box_rst_amd.capi import ROUTE_FREE_DT_BAND
     for B in (1, 64):
         d = problems.quad_desc(N=100, time_optimal=True)
         x0 = np.zeros((B, d.nx)); xf = np.zeros((B, d.nx)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
-        s = BatchedLevenbergMarquardt(d, B, device=device)
+        s = BatchedLevenbergMarquardt(d, B, device=device, route=ROUTE_FREE_DT_BAND)   # (corbo_hip_create_routed)
         s.setPenaltyWeights(100.0, 100.0, 100.0)
         s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
         s.solve(new_run=True); s.synchronize()
@@ -401,7 +407,6 @@ def band_leg(device):
                             "achieved_GFLOPs": B * flops / (f_ms * 1e-3) / 1e9, "frac_of_fp64_vector_peak": B * flops / (f_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
         out[f"batch{B}"]["chi2_sum"] = chi2_band
         del s
-    del os.environ["CORBO_HIP_FREE_DT_BAND"]
     # narrow bands (half-bandwidth 7: band_narrow_kernel, one wave per instance): the headline batch with the control-deviation term (a rate limit on the controls)
     try:
         from control_box_rst_amd import capi
@@ -423,7 +428,7 @@ def band_leg(device):
         del s
     except Exception as e:   # (a measurement row: never fatal for the line)
         out["headline_batch_with_rate_limit"] = {"error": str(e)[:200]}
-    out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass (batch1 / batch64: CORBO_HIP_FREE_DT_BAND=1); chain_route_*: the same solves through big_stage_kernel / big_chain3_kernel with the border column"
+    out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass (batch1 / batch64: corbo_hip_create_routed with CORBO_HIP_ROUTE_FREE_DT_BAND); chain_route_*: the same solves through big_stage_kernel / big_chain3_kernel with the border column"
     out["bound"] = "latency: n sequential pivots per instance (one barrier each, eight waves on a sliding LDS window); the flop rate is quoted for completeness"
     return out
 
@@ -447,15 +452,17 @@ def sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms):
     t_r = cyc_r / B / (clk_ghz * 1e9)
     ach_j = n_j * b_sweep / t_j / 1e9
     ach_all = (n_j * b_sweep + n_r * b_val) / (t_j + t_r) / 1e9
-    return {"bound": "hbm", "kernel": "lm_pass_kernel, sweep phases only (residual + Jacobian of accepted steps and of the prologue)",
-            "achieved": ach_j, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_j / PEAK_HBM_GBS,
-            "achieved_all_sweeps": ach_all, "frac_all_sweeps": ach_all / PEAK_HBM_GBS,
+    return {"kind": "time share, NOT an HBM bandwidth measurement", "kernel": "lm_pass_kernel, sweep phases only (residual + Jacobian of accepted steps and of the prologue)",
+            "time_share_equivalent_GBs": ach_j, "peak": PEAK_HBM_GBS, "unit": "GB/s", "time_share_equivalent": ach_j / PEAK_HBM_GBS,
+            "time_share_equivalent_all_sweeps_GBs": ach_all, "time_share_equivalent_all_sweeps": ach_all / PEAK_HBM_GBS,
             "bytes_per_jacobian_sweep": b_sweep, "jacobian_sweeps": int(n_j), "residual_sweeps": int(n_r), "factor_phases": int(n_f),
             "mean_cycles": {"jacobian_sweep_phase": cyc_j / max(1, n_j), "residual_sweep_phase": cyc_r / max(1, n_r), "factor_phase": cyc_f / max(1, n_f)},
             "share_of_workgroup_time": {"jacobian_sweeps": cyc_j / tot.sum(), "residual_sweeps": cyc_r / tot.sum(), "factor": cyc_f / tot.sum()},
             "slowest_instance_cycles": float(tot.max()), "mean_instance_cycles": float(tot.mean()), "shader_clock_ghz_estimate": clk_ghz, "kernel_ms": ms,
-            "note": "algorithmic bytes of SURVEY 8d over the time the sweep phases occupy their workgroups; inside the fused kernel most of these bytes never leave the chip "
-                    "(the Jacobian goes from the sweep phase to the factor phase through LDS), the HBM-side traffic of the whole launch is `roofline.traffic`"}
+            "note": "NOT HBM traffic and not a roofline fraction: algorithmic bytes of SURVEY 8d divided by (sum of the sweep phases' cycles / resident workgroups / clock), i.e. what the "
+                    "rate WOULD be if all resident workgroups ran nothing but their sweep phases side by side.  It restates the sweep phases' share of workgroup time (share_of_workgroup_time) "
+                    "in the roofline's unit; inside the fused kernel most of these bytes never leave the chip (the Jacobian goes from the sweep phase to the factor phase through LDS).  The "
+                    "measured bandwidth figures are `roofline` (whole launch, `traffic` from the counters) and `roofline_sweep` (the stand-alone sweep_kernel)"}
 
 
 def hessian_leg(desc, B, x0, xf, device):
@@ -724,9 +731,9 @@ def main():
                             "frac_from_profile": (alg_solve / (prof[0] * 1e-9) / 1e9 / PEAK_HBM_GBS) if (prof and B == 1024 and cfg == 3) else None,
                             "note": "a latency chain per instance (DESIGN.md 3.3), priced against HBM because its algorithmic work is the sweep traffic"}
         try:
-            line["roofline_sweep_phase"] = sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms)
+            line["sweep_phase_time_share"] = sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms)
         except Exception as e:
-            line["roofline_sweep_phase"] = {"error": repr(e)}
+            line["sweep_phase_time_share"] = {"error": repr(e)}
     # ---- the stand-alone edge/Jacobian sweep (north star: ">= 40 % of the HBM roofline on the Jacobian sweep")
     each = solver.time_sweep_each(with_jacobian=True, repeat=50)        # one event pair per launch (what a kernel trace reports)
     b2b_ms = solver.time_sweep(with_jacobian=True, repeat=50)            # back-to-back launches, one event pair around all of them

@@ -70,9 +70,12 @@ struct DeviceGuard {
 // Pending corbo_hip_solve_async launches are drained before any entry point touches iterates, flags, pinned result views or the shared
 // h_counter slots (a mutator between solve_async and fetch_solution must not leave the sink "valid" with stale rows).
 
+// A mutator drains and then DOES ITS OWN WORK: a failure of the drained solve ("pass limit reached") is remembered in the handle and reported by the
+// next call that hands out results or starts a synchronous solve (corbo_hip_solve / synchronize / fetch_solution / get_*), not by the mutator (ADVICE r5:
+// a caller that ignored the mutator's return code carried on with stale data).  Device errors of the drain itself are returned at once.
 #define DRAIN_ASYNC(h)                                   \
     do {                                                 \
-        const int rc_drain_ = finish_async(h);           \
+        const int rc_drain_ = finish_async(h, false);    \
         if (rc_drain_) return rc_drain_;                 \
     } while (0)
 #define ON_DEVICE_OF(h)                      \
@@ -93,7 +96,7 @@ struct EventList {
 
 }  // namespace
 
-static int finish_async(corbo_hip_handle h);   // (DRAIN_ASYNC)
+static int finish_async(corbo_hip_handle h, bool report = true);   // (DRAIN_ASYNC: report = false)
 
 static constexpr int PTL_LEN = 150 + 18 * 64;   // pass timeline buffer (diagnostics): stamps + per-pass phase log
 struct corbo_hip_solver {
@@ -210,7 +213,8 @@ struct corbo_hip_solver {
     int reject_speculation = 1; // corbo_hip_set_option("reject_speculation"): 0 = every rejected step is a pass of its own (A/B, tests)
     double* d_stage_cache = nullptr;   // big-block family: the stage waves' local Jacobians between the two passes of a solve's first factorisation (FactorParams::stage_cache)
     size_t stage_cache_stride = 0;
-    int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr;
+    bool async_error_deferred = false;   // an enqueued solve hit the pass limit and a mutator drained it: reported by the next result / solve call
+    int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr, *d_spec_adopted = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
     int band_wide = 0;          // corbo_hip_set_option("band_wide"): FactorParams::band_wide
     int chain_variant = 0;      // corbo_hip_set_option("chain_variant"): big-block family, see FactorParams::chain_variant
@@ -341,17 +345,25 @@ try {
 }
 ABI_CATCH
 
-static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out);
+static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device, uint32_t route, corbo_hip_handle* out);
 
 int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out)
 try {
     if (!desc || !out || batch < 1) return fail(CORBO_HIP_ERR_INVALID, "null argument or batch < 1");
     *out = nullptr;
-    return create_impl(desc, batch, device, out);
+    return create_impl(desc, batch, device, 0u, out);
 }
 ABI_CATCH
 
-static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out)
+int corbo_hip_create_routed(const corbo_hip_problem_desc* desc, int batch, int device, uint32_t route, corbo_hip_handle* out)
+try {
+    if (!desc || !out || batch < 1) return fail(CORBO_HIP_ERR_INVALID, "null argument or batch < 1");
+    *out = nullptr;
+    return create_impl(desc, batch, device, route, out);
+}
+ABI_CATCH
+
+static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device, uint32_t route, corbo_hip_handle* out)
 {
     // owns the half-built handle until it is handed to the caller (exceptions and early returns free everything created so far)
     struct Owner { corbo_hip_solver* p; ~Owner() { if (p) corbo_hip_destroy(p); } } owner{new corbo_hip_solver()};
@@ -442,7 +454,9 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     h->nnz_pad = (h->nnz_int + 1) & ~1;
     const size_t B = (size_t)batch;
     // big-block family on the stage / chain path: spare rows behind the batch for the candidates of the reject-streak speculation
-    h->spare = (big_family_dims(S.nx, S.nu) && !(S.dt_free) && !S.has_extra()) ? corbo_hip_solver::SPEC_GROUPS * corbo_hip_solver::SPEC_SLOTS : 0;
+    // (a free dt on the stage / chain route -- even block sizes -- carries its border through the candidates' rows like any parameter; the band route has no candidates)
+    const bool free_dt_band_route = S.dt_free && big_family_dims(S.nx, S.nu) && (S.nx % 2 != 0 || (route & CORBO_HIP_ROUTE_FREE_DT_BAND));
+    h->spare = (big_family_dims(S.nx, S.nu) && !free_dt_band_route && !S.has_extra()) ? corbo_hip_solver::SPEC_GROUPS * corbo_hip_solver::SPEC_SLOTS : 0;
     const size_t BT = B + (size_t)h->spare;
     CREATE_TRY(hipMalloc((void**)&h->d_x, BT * S.nvs * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->d_xt, BT * S.nvs * sizeof(double)));
@@ -491,9 +505,8 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
     CREATE_TRY(hipMalloc((void**)&h->d_chi2, BT * sizeof(double)));
     // (the band route -- decided below -- reads the sweep's stored Jacobian: it needs neither the stage / chain workspace nor the first factorisation's cache)
     // A free dt around a big-block model: even state-block sizes (6, 8, 10, 12 rows) carry it through the partitioned chain as a second right-hand side (round 5);
-    // odd block sizes -- and CORBO_HIP_FREE_DT_BAND=1, the A/B switch of bench.py's band leg -- take the band route.
-    const char* fdb_env = std::getenv("CORBO_HIP_FREE_DT_BAND");
-    const bool free_dt_band = S.dt_free && big_family_dims(S.nx, S.nu) && (S.nx % 2 != 0 || (fdb_env && fdb_env[0] == '1'));
+    // odd block sizes -- and corbo_hip_create_routed(.., CORBO_HIP_ROUTE_FREE_DT_BAND), the A/B switch of bench.py's band leg -- take the band route.
+    const bool free_dt_band = free_dt_band_route;
     const bool band_route_early = S.has_extra() || free_dt_band;
     h->work_stride = factor_work_doubles(*desc);
     if (h->work_stride) {
@@ -513,6 +526,8 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
             CREATE_TRY(hipMalloc((void**)&h->d_spec_seen, corbo_hip_solver::SPEC_GROUPS * sizeof(int32_t)));
             CREATE_TRY(hipMalloc((void**)&h->d_spec_slotrej, (size_t)h->spare * sizeof(int32_t)));
             CREATE_TRY(hipMalloc((void**)&h->d_spec_prev, B * sizeof(int32_t)));
+            CREATE_TRY(hipMalloc((void**)&h->d_spec_adopted, sizeof(int32_t)));
+            CREATE_TRY(hipMemset(h->d_spec_adopted, 0, sizeof(int32_t)));
         }
         h->force_split = true;  // no fused pass kernel for the big-block family / the long horizons: factor and sweep are separate launches
     }
@@ -573,7 +588,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
             upload(rent, &h->d_band_rent) || upload(S.param_voff, &h->d_band_voff))
             return CORBO_HIP_ERR_DEVICE;
         BandParams& bp = h->band;
-        if (S.desc.shooting_integrator >= 5 && big_family_dims(S.nx, S.nu)) {   // (only reachable through CORBO_HIP_FREE_DT_BAND=1: structure.cpp refuses the others)
+        if (S.desc.shooting_integrator >= 5 && big_family_dims(S.nx, S.nu)) {   // (only reachable through CORBO_HIP_ROUTE_FREE_DT_BAND: structure.cpp refuses the others)
             g_last_error = "band factorisation around a big-block model: shooting integrators up to Runge-Kutta 4";
             return CORBO_HIP_ERR_UNSUPPORTED;
         }
@@ -633,7 +648,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
                     h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
-                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_stage_cache, h->d_phase};
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
@@ -817,9 +832,14 @@ static int deliver_results(corbo_hip_handle h)
     return CORBO_HIP_OK;
 }
 
-static int finish_async(corbo_hip_handle h)
+static int finish_async(corbo_hip_handle h, bool report)
 {
-    if (h->async_pending == 0) return CORBO_HIP_OK;
+    auto deferred = [&]() -> int {
+        if (!report || !h->async_error_deferred) return CORBO_HIP_OK;
+        h->async_error_deferred = false;
+        return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    };
+    if (h->async_pending == 0) return deferred();
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto& pr : h->async_events) {
         float ms = 0;
@@ -830,10 +850,10 @@ static int finish_async(corbo_hip_handle h)
     h->async_pending = 0;
     const bool unfinished = h->h_counter[0] != 0 || h->h_counter[1] != 0;
     h->h_counter[0] = h->h_counter[1] = 0;
-    if (unfinished) return fail(CORBO_HIP_ERR_DEVICE, "pass limit reached with unfinished instances");
+    if (unfinished) { h->async_error_deferred = true; return deferred(); }
     h->sink_valid = h->result_sink && !h->sink_invalidated;
     h->sink_delivered = false;
-    return CORBO_HIP_OK;
+    return deferred();
 }
 
 static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_run, bool async);
@@ -935,7 +955,7 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
         q.mode = mode; q.batch = h->batch; q.groups = corbo_hip_solver::SPEC_GROUPS; q.spec = corbo_hip_solver::SPEC_SLOTS;
         q.nvs = h->S.nvs; q.m_pad = h->m_pad; q.xe_row = h->S.N * h->S.nx; q.batch_total = h->batch + h->spare;
         q.x = h->d_x; q.lb = h->d_lb; q.ub = h->d_ub; q.xref = h->d_xref; q.values0 = h->d_values0; q.values1 = h->d_values1; q.xe0 = h->d_xe0; q.chi2 = h->d_chi2;
-        q.st = h->d_state; q.parent_of = h->d_spec_parent; q.rej_seen = h->d_spec_seen; q.slot_rej = h->d_spec_slotrej; q.prev_reject = h->d_spec_prev;
+        q.st = h->d_state; q.parent_of = h->d_spec_parent; q.rej_seen = h->d_spec_seen; q.slot_rej = h->d_spec_slotrej; q.prev_reject = h->d_spec_prev; q.adopted = h->d_spec_adopted;
         q.counter = counter;
         q.max_parents = (h->reject_speculation == 2) ? corbo_hip_solver::SPEC_GROUPS : 3;
         return q;
@@ -994,7 +1014,8 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
             fp.unfinished_flag  = h->h_counter + 2 * i + flag_slot;
             if (h->phase_cycles) {
                 if (!h->d_phase) HIP_TRY(hipMalloc((void**)&h->d_phase, (size_t)h->batch * 8 * sizeof(long long)));
-                if (i == 0) HIP_TRY(hipMemsetAsync(h->d_phase, 0, (size_t)h->batch * 8 * sizeof(long long), st_of[i]));
+                // (each sub-batch clears ITS rows on ITS stream: the sub-streams are not ordered against each other)
+                HIP_TRY(hipMemsetAsync(h->d_phase + (size_t)first_of[i] * 8, 0, (size_t)count_of[i] * 8 * sizeof(long long), st_of[i]));
                 fp.phase_cycles = h->d_phase;
             }
             long long* d_ptl = nullptr;  // CORBO_HIP_PASS_TIMELINE=<instance>: per-pass shader-clock stamps of that instance on stderr
@@ -1690,6 +1711,8 @@ try {
         s.counted_iterations += a.pad[1];
     }
     s.passes = max_fact;  // inner passes of the slowest instance
+    s.speculative_takeovers = 0;
+    if (h->d_spec_adopted) { int32_t a = 0; HIP_TRY(hipMemcpy(&a, h->d_spec_adopted, sizeof(a), hipMemcpyDeviceToHost)); s.speculative_takeovers = a; }
     *stats = s;
     return CORBO_HIP_OK;
 }

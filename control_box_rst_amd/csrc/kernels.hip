@@ -25,6 +25,17 @@ constexpr int LONG_HORIZON_MAX = 1024;
 constexpr double LM_EPS1 = 1e-5, LM_EPS2 = 1e-5, LM_EPS3 = 1e-5, LM_EPS4 = 0.0, LM_TAU = 1e-5;  // levenberg_marquardt_sparse.cpp:103-110
 constexpr int LM_MAX_INNER = 64;  // guard against an endless reject loop (the reference would spin)
 
+// hipFuncSetAttribute is per DEVICE and handles may live on several: a launcher's "already set" flag is one bit per device.
+inline bool first_on_device(unsigned long long& mask)
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
 // Workgroup barrier for hand-overs through LDS only.  __syncthreads() is a workgroup-scope release/acquire fence + s_barrier: the
 // fence waits for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)), i.e. also for the write acknowledgements of
 // global stores that nobody in the workgroup is going to read (gfx9 counts stores in vmcnt) -- an HBM / L2 round trip at every
@@ -5589,8 +5600,8 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
             if (p.chain_variant == 6) nseg = 1;
             if (p.N < 4 * nseg) nseg = 1;
             auto launch3a = [&](auto kernel, int nseg_, size_t lds3) {
-                static bool attr_set[9] = {};
-                if (!attr_set[nseg_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[nseg_] = true; }
+                static unsigned long long attr_set[9] = {};   // (a kernel's attributes are per DEVICE: one bit per device, handles may live on several)
+                if (first_on_device(attr_set[nseg_])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(128 * nseg_), ((lds3 + 15) & ~(size_t)15) + sizeof(LmState), stream, p);
             };
             if (nseg == 4) launch3a(big_chain3_kernel<NX, NU, 4, true>, 4, sizeof(double) * (size_t)Chain3Lds<NX, NU, 4, true>::total(p.N));
@@ -5612,8 +5623,8 @@ bool CORBO_HIP_CAT(factor_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& p, 
             if (nseg > 0 && p.N < 4 * nseg) nseg = 0;   // (every segment needs a block of its own next to its separators)
             if (NX % 4 != 0 && nseg == 0) nseg = 1;     // (6- and 10-row blocks: the twisted chain's matrix-core tiling assumes multiples of four; one segment is the same elimination)
             auto launch3 = [&](auto kernel, int nseg_, size_t lds3) {
-                static bool attr_set[9] = {};
-                if (!attr_set[nseg_]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[nseg_] = true; }
+                static unsigned long long attr_set[9] = {};   // (a kernel's attributes are per DEVICE: one bit per device, handles may live on several)
+                if (first_on_device(attr_set[nseg_])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(128 * nseg_), ((lds3 + 15) & ~(size_t)15) + sizeof(LmState), stream, p);
             };
             if (nseg == 4) launch3(big_chain3_kernel<NX, NU, 4>, 4, sizeof(double) * (size_t)Chain3Lds<NX, NU, 4>::total(p.N));
@@ -6018,6 +6029,7 @@ __global__ __launch_bounds__(1024) void big_spec_kernel(const SpecParams p)
         for (int g = tid; g < G; g += 1024) { p.parent_of[g] = -1; p.rej_seen[g] = 0; }
         for (int i = tid; i < p.batch; i += 1024) p.prev_reject[i] = 0;
         for (int q = tid; q < G * SP; q += 1024) { p.st[slot0 + q].done = 1; p.slot_rej[q] = 0; }
+        if (tid == 0 && p.adopted) *p.adopted = 0;
         return;
     }
     if (tid < MAXG) { a_parent[tid] = -1; a_take[tid] = 0; a_fill[tid] = 0; }
@@ -6092,7 +6104,7 @@ __global__ __launch_bounds__(1024) void big_spec_kernel(const SpecParams p)
         copy_row(p.xe0, p.xe_row, P, src);
         copy_row(p.xe0, p.xe_row, p.batch_total + P, p.batch_total + src);
         copy_row(reinterpret_cast<double*>(p.st), sizeof(LmState) / sizeof(double), P, src);
-        if (tid == 0) p.chi2[P] = p.chi2[src];
+        if (tid == 0) { p.chi2[P] = p.chi2[src]; if (p.adopted) *p.adopted += 1; }   // (one workgroup, groups in sequence: no atomic needed)
     }
     __syncthreads();
     // ---- E: fill slots: copies of the parent with the LM state it would have after 1, 2, ... more rejected steps
@@ -6675,9 +6687,9 @@ bool band_route_supported(int nb, int bw) { return bw + 1 <= 64 && sizeof(double
 bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream)
 {
     const size_t lds = sizeof(double) * (band_lds_doubles(bp.nb, bp.bw) + 8);   // window + rhs + border + scratch (a horizon of 256 twelve-state intervals: 85 KB)
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0;   // (per device)
     constexpr size_t LDS_MAX = BAND_LDS_MAX;
-    if (!attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError(); attr_set = true; }
+    if (first_on_device(attr_set)) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError(); }
     if (!bp.work || !band_route_supported(bp.nb, bp.bw)) return false;
     {
         // list entries per thread: an entry is a chain of dependent loads (index, pair, two values).  Small batches are latency-bound -- two per thread (one OCP:
@@ -6691,11 +6703,10 @@ bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_
     // half-bandwidth <= 7: one wave per instance, window in registers (band_narrow_kernel); option "band_wide" keeps the eight-wave kernel (A/B, tests)
     const size_t lds_n = sizeof(double) * (2 * (size_t)bp.nb + 8);
     if (bp.bw <= 7 && !fp.band_wide && lds_n <= BAND_LDS_MAX) {
-        static bool attr_n = false;
-        if (!attr_n) {
+        static unsigned long long attr_n = 0;   // (per device)
+        if (first_on_device(attr_n)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_narrow_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError();
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(band_narrow_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) (void)hipGetLastError();
-            attr_n = true;
         }
         if (bp.nb < bp.n) hipLaunchKernelGGL(band_narrow_kernel<true>, dim3(fp.batch), dim3(64), lds_n, stream, fp, bp);
         else hipLaunchKernelGGL(band_narrow_kernel<false>, dim3(fp.batch), dim3(64), lds_n, stream, fp, bp);

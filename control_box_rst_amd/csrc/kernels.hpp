@@ -157,6 +157,7 @@ struct SpecParams {
     int32_t* prev_reject;    // [batch] n_reject of every instance at the last visit
     int32_t* counter;        // the pass's "unfinished instances" counter (slots that the sweep counted are taken out again) or null
     int32_t max_parents;     // streaks followed at a time (speculation pays when rejections are rare: see big_spec_kernel)
+    int32_t* adopted;        // statistics: times an instance took over a candidate's state in this solve (corbo_hip_stats.speculative_takeovers) or null
 };
 bool launch_big_spec(const SpecParams& p, hipStream_t stream);
 

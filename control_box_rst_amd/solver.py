@@ -64,7 +64,7 @@ def init_trajectory(desc: ProblemDesc, x0, xf) -> np.ndarray:
 class BatchedLevenbergMarquardt:
     """LevenbergMarquardtSparse for `batch` independent instances of one hypergraph structure, on one MI355X."""
 
-    def __init__(self, desc: ProblemDesc, batch: int, device: int = 0):
+    def __init__(self, desc: ProblemDesc, batch: int, device: int = 0, route: int = 0):
         self.lib = capi.load()
         self.desc = desc
         self.batch = int(batch)
@@ -72,7 +72,11 @@ class BatchedLevenbergMarquardt:
         self.opts: LmOpts = capi.default_lm_opts()
         self.dims = get_dims(desc)
         self._h = C.c_void_p()
-        rc = self.lib.corbo_hip_create(C.byref(desc), self.batch, self.device, C.byref(self._h))
+        # route: capi.ROUTE_* flags of corbo_hip_create_routed (A/B of two factorisation routes of one descriptor); 0 = the library's choice
+        if route:
+            rc = self.lib.corbo_hip_create_routed(C.byref(desc), self.batch, self.device, int(route), C.byref(self._h))
+        else:
+            rc = self.lib.corbo_hip_create(C.byref(desc), self.batch, self.device, C.byref(self._h))
         self._check(rc, "corbo_hip_create")
 
     # -- reference setters ------------------------------------------------------------------------------------------

@@ -267,6 +267,9 @@ typedef struct corbo_hip_stats {
                                  * (|delta| <= eps2 / 2) and were COUNTED, not executed (option "ff_converged", default on; the reference
                                  * executes them and changes nothing a caller sees, levenberg_marquardt_sparse.cpp:129-154).  Rates of
                                  * executed work: lm_iterations - counted_iterations, factorizations - counted_iterations. */
+    int64_t speculative_takeovers; /* big-block family, reject-streak speculation (option "reject_speculation"): how often an instance whose step was
+                                 * rejected took over the state of one of its damping candidates that had run alongside in spare rows.  The candidates ARE the
+                                 * instance's own next passes (same arithmetic, same numbers): every other field and every result is the same with or without. */
 } corbo_hip_stats;
 
 typedef struct corbo_hip_solver* corbo_hip_handle;
@@ -294,6 +297,15 @@ int corbo_hip_init_trajectory(const corbo_hip_problem_desc* desc, int batch, con
  * and restores the caller's current device before it returns.  No C++ exception leaves the library.  A handle is not thread-safe;
  * different handles (also on the same device) are independent. */
 int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, corbo_hip_handle* out);
+/* The same with an explicit choice of the factorisation ROUTE where a descriptor has two (A/B measurements and the cross-route parity tests;
+ * the library reads no environment variable).  `route` = OR of:
+ *   CORBO_HIP_ROUTE_FREE_DT_BAND  a free dt around a big-block model through the general band factorisation instead of the stage / chain kernels' border column
+ *   CORBO_HIP_ROUTE_XE_BAND       control-deviation edges of the small-block families through the general band factorisation instead of the structured
+ *                                 (x_k, u_k)-block elimination inside the run-to-completion kernel
+ * 0 = what corbo_hip_create chooses.  A flag that does not apply to the descriptor is ignored. */
+#define CORBO_HIP_ROUTE_FREE_DT_BAND 1u
+#define CORBO_HIP_ROUTE_XE_BAND      2u
+int corbo_hip_create_routed(const corbo_hip_problem_desc* desc, int batch, int device, uint32_t route, corbo_hip_handle* out);
 void corbo_hip_destroy(corbo_hip_handle h);
 
 /* Upload per-instance data (what the grid holds in its vertices when solve() is entered):
@@ -428,7 +440,9 @@ int corbo_hip_solve(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_r
  * a caller that streams batch after batch through one handle uses this).  Handles that solve in one launch (run to completion: the small-block families
  * up to 256 grid points); every other handle solves synchronously like corbo_hip_solve.  Results, statistics, the HIP-event times of corbo_hip_get_timing
  * and the pass-limit check of the enqueued solves become available with the next corbo_hip_synchronize / corbo_hip_solve / corbo_hip_get_* /
- * corbo_hip_fetch_solution call (an error of an enqueued solve is reported there). */
+ * corbo_hip_fetch_solution call (an error of an enqueued solve is reported there).  Entry points that CHANGE the handle's data (set_instance_data,
+ * warm_start, set_references ...) wait for the enqueued solves and then do their work; they never return an enqueued solve's error -- it stays pending
+ * for the next of the calls named above. */
 int corbo_hip_solve_async(corbo_hip_handle h, const corbo_hip_lm_opts* opts, int new_run);
 
 /* Block until the handle's stream is idle. */

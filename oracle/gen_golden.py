@@ -686,17 +686,17 @@ def tolerances():
     fixtures = {}
     with ProcessPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         for name, dx, dc, t in ex.map(_ledger_job, jobs):
-            def nice(v):   # tolerance = 4 x spread, rounded UP to one significant digit
+            def nice(v):   # tolerance = 4 x spread, rounded UP to two significant digits (4 x means <= 4.4 x)
                 if v <= 0:
                     return 0.0
-                e = 10.0 ** np.floor(np.log10(v))
+                e = 10.0 ** (np.floor(np.log10(v)) - 1)
                 return float(np.ceil(v / e - 1e-9) * e)
             x_tol = max(DEF_X, nice(4 * dx)) if 4 * dx > HARD_X else DEF_X
             c_tol = max(DEF_CHI2, nice(4 * dc)) if 4 * dc > HARD_CHI2 else DEF_CHI2
             fixtures[name] = {"x_tol": x_tol, "chi2_rtol": c_tol, "ref_spread_x": dx, "ref_spread_chi2": dc, "trials": t}
             if name in old and "note" in old[name]:
                 fixtures[name]["note"] = old[name]["note"]
-            print("%-24s spread x %.2e chi2 %.2e (%d trials) -> x_tol %.0e chi2_rtol %.0e" % (name, dx, dc, t, x_tol, c_tol))
+            print("%-24s spread x %.2e chi2 %.2e (%d trials) -> x_tol %.1e chi2_rtol %.1e" % (name, dx, dc, t, x_tol, c_tol))
     ledger = {
         "_rule": "x_tol <= max(hard_x, 4 * ref_spread_x) and chi2_rtol <= max(hard_chi2, 4 * ref_spread_chi2); fixtures not listed use the defaults. "
                  "ref_spread_* = the genuine reference against itself from inputs one ulp away (oracle/gen_golden.py tolerances).",

@@ -170,7 +170,7 @@ def ledger_rule_violations(ledger=None):
     L = ledger or LEDGER
     bad = []
     for name, e in L["fixtures"].items():
-        if e["x_tol"] > max(L["hard_x"], 4.0 * e["ref_spread_x"]) * (1 + 1e-12) and e["x_tol"] > max(L["hard_x"], _round_up(4.0 * e["ref_spread_x"])):
+        if e["x_tol"] > max(L["hard_x"], _round_up(4.0 * e["ref_spread_x"])):
             bad.append((name, "x_tol", e["x_tol"], e["ref_spread_x"]))
         if e["chi2_rtol"] > max(L["hard_chi2"], _round_up(4.0 * e["ref_spread_chi2"])):
             bad.append((name, "chi2_rtol", e["chi2_rtol"], e["ref_spread_chi2"]))
@@ -178,11 +178,11 @@ def ledger_rule_violations(ledger=None):
 
 
 def _round_up(v):
-    """one significant digit, upwards (how the generator rounds 4 x spread)"""
+    """two significant digits, upwards (how the generator rounds 4 x spread: a tolerance is at most 4.4 x the spread)"""
     import math
     if v <= 0:
         return 0.0
-    e = 10.0 ** math.floor(math.log10(v))
+    e = 10.0 ** (math.floor(math.log10(v)) - 1)
     return math.ceil(v / e - 1e-9) * e
 
 

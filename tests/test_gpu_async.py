@@ -68,6 +68,25 @@ def test_pass_limit_of_an_enqueued_solve_is_reported_by_the_next_wait():
     assert (s.get_solution()[2] <= 1).all()
 
 
+def test_mutator_behind_a_failed_enqueued_solve_still_mutates_and_the_error_stays_pending():
+    """set_instance_data / restore between a failing solve_async and the next wait do their work and return OK; the enqueued solve's
+    'pass limit' error is reported by the next result / solve call, once."""
+    s = _solver()
+    x0, xf = problems.unicycle_instances(48, seed=11)
+    X_new = s.init_trajectory(x0, xf)
+    s.set_option("pass_limit", 3)
+    s.solve_async()
+    s.set_instance_data(X_new, xref=xf)      # drains the failing solve; must upload and must not raise
+    with pytest.raises(CorboHipError, match="pass limit"):
+        s.synchronize()
+    s.synchronize()                          # reported once
+    X, _, _ = s.get_solution()
+    assert np.array_equal(X, X_new[:, : s.dims.nv]), "the mutator's upload was skipped"
+    s.set_option("pass_limit", 0)
+    s.solve()
+    assert (s.get_solution()[2] <= 1).all()
+
+
 def test_host_driven_handles_solve_synchronously():
     d = problems.quad_desc(N=24)
     x0, xf = problems.quad_instances(4)

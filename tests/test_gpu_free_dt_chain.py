@@ -6,7 +6,7 @@ as a second right-hand side and the last pivot H(dt,dt) + mu - |z|^2 closes the 
 
   * against the genuine reference (tests/golden/quad_topt_n8.json: values, Jacobian, LM iterates -- tests/test_gpu_parity.py runs that fixture too),
   * against the oracle at horizons the reference fixture does not cover, with one / two / four segments of the partitioned chain,
-  * against the band factorisation (the general path these descriptors took before: CORBO_HIP_FREE_DT_BAND=1) on the same device.
+  * against the band factorisation (the general path these descriptors took before: corbo_hip_create_routed, CORBO_HIP_ROUTE_FREE_DT_BAND) on the same device.
 """
 import os
 
@@ -49,17 +49,7 @@ def _instances(B, seed=5):
 
 
 def _solve(d, x0, xf, iters, variant=0, band=False):
-    old = os.environ.get("CORBO_HIP_FREE_DT_BAND")
-    if band:
-        os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"
-    try:
-        s = BatchedLevenbergMarquardt(d, len(x0))
-    finally:
-        if band:
-            if old is None:
-                del os.environ["CORBO_HIP_FREE_DT_BAND"]
-            else:
-                os.environ["CORBO_HIP_FREE_DT_BAND"] = old
+    s = BatchedLevenbergMarquardt(d, len(x0), route=capi.ROUTE_FREE_DT_BAND if band else 0)
     s.setIterations(iters)
     s.setPenaltyWeights(*W)
     if variant:
@@ -95,11 +85,7 @@ def test_values_and_jacobian_vs_oracle(oracle_mod, N, fd):
         Jo = sp.coo_matrix((jo, (rows, cols)), shape=(s.dims.m, s.dims.n)).tocsr()
         assert abs(Jd - Jo).max() <= 1e-6 * max(1.0, abs(Jo).max()), (N, fd, abs(Jd - Jo).max())   # (central differences with delta = 1e-9 over two sin / cos libraries)
     # the band route's handle evaluates the same descriptor with the sweep kernel: same finite differences, same operations -- the same bits
-    os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"
-    try:
-        sb = BatchedLevenbergMarquardt(d, 2)
-    finally:
-        del os.environ["CORBO_HIP_FREE_DT_BAND"]
+    sb = BatchedLevenbergMarquardt(d, 2, route=capi.ROUTE_FREE_DT_BAND)
     sb.setPenaltyWeights(*W)
     sb.set_instance_data(X0, xref=xf)
     vb, jb = sb.eval()

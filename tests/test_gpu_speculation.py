@@ -44,6 +44,7 @@ def test_forced_speculation_is_bit_identical(B, N, weights, first):
     ref = _run(d, weights, x0, xf, 0)
     assert ref[3]["rejected_steps"] > 0, "the scenario is meant to reject steps"
     got = _run(d, weights, x0, xf, 2)
+    assert ref[3]["speculative_takeovers"] == 0 and got[3]["speculative_takeovers"] > 0, "the comparison is vacuous unless candidates ran and were taken over"
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     for k in KEYS:
         assert got[3][k] == ref[3][k], k
@@ -68,6 +69,7 @@ def test_forced_speculation_with_a_free_dt_is_bit_identical(B, N, weights, first
     ref = _run(d, weights, x0, xf, 0)
     assert ref[3]["rejected_steps"] > 0, "the scenario is meant to reject steps"
     got = _run(d, weights, x0, xf, 2)
+    assert ref[3]["speculative_takeovers"] == 0 and got[3]["speculative_takeovers"] > 0, "the comparison is vacuous unless candidates ran and were taken over"
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     for k in KEYS:
         assert got[3][k] == ref[3][k], k

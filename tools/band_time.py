@@ -1,6 +1,6 @@
 """Band factorisation path (free dt around a big-block model, integral-form constraints): time per solve (diagnostics).  python tools/band_time.py"""
 import os, sys, time
-os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"   # (the time-optimal big-block descriptors below take the stage / chain route by default since round 5: tools/free_dt_time.py)
+ROUTE = 1   # CORBO_HIP_ROUTE_FREE_DT_BAND (the time-optimal big-block descriptors below take the stage / chain route by default since round 5: tools/free_dt_time.py)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ for name, d, B in (("pquad time-optimal N=30", problems.planar_quadrotor_desc(N=
                    ("quad time-optimal N=100", problems.quad_desc(N=100, time_optimal=True), 1), ("quad time-optimal N=100", problems.quad_desc(N=100, time_optimal=True), 64)):
     nx = d.nx
     x0 = np.zeros((B, nx)); xf = np.zeros((B, nx)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
-    s = BatchedLevenbergMarquardt(d, B); s.setPenaltyWeights(100.0, 100.0, 100.0)
+    s = BatchedLevenbergMarquardt(d, B, route=ROUTE); s.setPenaltyWeights(100.0, 100.0, 100.0)
     s.set_instance_data(s.init_trajectory(x0, xf), xref=xf); s.solve(new_run=True); s.synchronize()
     x, chi2, status = s.get_solution()
     t0 = time.perf_counter()

@@ -5,7 +5,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
-RND=${CORBO_PROFILE_ROUND:-r05}; export CORBO_PROFILE_ROUND=$RND
+RND=${CORBO_PROFILE_ROUND:-r06}; export CORBO_PROFILE_ROUND=$RND
 TAG="${1:-round ${RND#r0}}"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

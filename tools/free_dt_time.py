@@ -1,5 +1,5 @@
 """Free dt around the 12-state quadrotor (time-optimal, MultipleShootingVariableGrid): the stage / partitioned-chain route against the band route
-(CORBO_HIP_FREE_DT_BAND=1), same solves (diagnostics).  python tools/free_dt_time.py [N]"""
+(corbo_hip_create_routed, CORBO_HIP_ROUTE_FREE_DT_BAND), same solves (diagnostics).  python tools/free_dt_time.py [N]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,12 +10,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 for B in (1, 64, 256, 512):
     for band in (False, True):
         if band and B > 256: continue
-        if band: os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"
         d = problems.quad_desc(N=N, time_optimal=True)
         x0 = np.zeros((B, 12)); xf = np.zeros((B, 12)); xf[:, 0] = 2.0; xf[:, 1] = 1.0
         xf[:, 2] = np.linspace(-0.2, 0.4, B)
-        s = BatchedLevenbergMarquardt(d, B); s.setPenaltyWeights(100.0, 100.0, 100.0)
-        os.environ.pop("CORBO_HIP_FREE_DT_BAND", None)
+        s = BatchedLevenbergMarquardt(d, B, route=1 if band else 0); s.setPenaltyWeights(100.0, 100.0, 100.0)   # (1 = CORBO_HIP_ROUTE_FREE_DT_BAND)
         s.set_instance_data(s.init_trajectory(x0, xf), xref=xf); s.solve(new_run=True); s.synchronize()
         x, chi2, status = s.get_solution()
         t0 = time.perf_counter()

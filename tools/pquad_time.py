@@ -6,8 +6,7 @@ sys.path.insert(0, os.getcwd())
 from control_box_rst_amd import problems
 from control_box_rst_amd.solver import BatchedLevenbergMarquardt
 def run(d, B, label, variant=0, band=False, w=(10.0, 10.0, 10.0)):
-    if band: os.environ["CORBO_HIP_FREE_DT_BAND"] = "1"
-    s = BatchedLevenbergMarquardt(d, B); os.environ.pop("CORBO_HIP_FREE_DT_BAND", None)
+    s = BatchedLevenbergMarquardt(d, B, route=1 if band else 0)   # (1 = CORBO_HIP_ROUTE_FREE_DT_BAND)
     s.setPenaltyWeights(*w)
     if variant: s.set_option("chain_variant", variant)
     x0 = np.zeros((B, 6)); xf = np.zeros((B, 6)); xf[:, 0] = 2.0; xf[:, 1] = np.linspace(0.8, 1.2, B)
