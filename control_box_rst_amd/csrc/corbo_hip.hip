@@ -213,6 +213,9 @@ struct corbo_hip_solver {
     int reject_speculation = 1; // corbo_hip_set_option("reject_speculation"): 0 = every rejected step is a pass of its own (A/B, tests)
     double* d_stage_cache = nullptr;   // big-block family: the stage waves' local Jacobians between the two passes of a solve's first factorisation (FactorParams::stage_cache)
     size_t stage_cache_stride = 0;
+    uint32_t *d_bt_pairs = nullptr, *d_bt_target = nullptr;   // block-tridiagonal route (structure.hpp BtTables): the small-block families with extra edges, run to completion
+    int32_t* d_bt_off = nullptr;
+    int bt_rounds = 0;
     bool async_error_deferred = false;   // an enqueued solve hit the pass limit and a mutator drained it: reported by the next result / solve call
     int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr, *d_spec_adopted = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
@@ -296,6 +299,7 @@ struct corbo_hip_solver {
         p.stage_cache = d_stage_cache; p.stage_cache_stride = (int64_t)stage_cache_stride;
         p.defect = S.desc.defect;
         p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
+        p.bt_pairs = d_bt_pairs; p.bt_off = d_bt_off; p.bt_target = d_bt_target; p.bt_rounds = bt_rounds;
         return p;
     }
 };
@@ -551,8 +555,23 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         CREATE_TRY(hipMalloc((void**)&h->d_uprev, up.size() * sizeof(double)));
         CREATE_TRY(hipMemcpy(h->d_uprev, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // Small-block families with extra edges: H is block tridiagonal in the stage blocks (x_k, u_k) whatever the extra edges are (control deviation: u_k with
+    // u_{k-1}; integral forms: (x_k, u_k) with x_{k+1}) -- the run-to-completion kernel of the block-tridiagonal route (kernels.hip lm_bt_kernel)
+    // solves them in ONE launch.  The band tables are built all the same: the per-pass modes (option run_to_completion = 0, profiling, corbo_hip_time_factor)
+    // and corbo_hip_create_routed(.., CORBO_HIP_ROUTE_XE_BAND) -- the A/B switch -- run the band kernels.
+    bool bt_route = false;
+    if (S.has_extra() && !big_family_dims(S.nx, S.nu) && !(route & CORBO_HIP_ROUTE_XE_BAND) && S.desc.shooting_integrator < 5 && !S.desc.weights_dense) {
+        const int max_rounds = bt_route_max_rounds(S.nx, S.nu, S.dt_free, S.N, (int)h->nnz_pad, (int)h->m_pad, S.nvs);
+        BtTables bt;
+        std::string why;
+        if (max_rounds > 0 && build_bt_tables(S, h->jmap, (int)h->nnz_pad, (int)h->m_pad, BT_THREADS, bt, &why) && bt.rounds <= max_rounds) {
+            if (upload(bt.pairs, &h->d_bt_pairs) || upload(bt.off, &h->d_bt_off) || upload(bt.target, &h->d_bt_target)) return CORBO_HIP_ERR_DEVICE;
+            h->bt_rounds = bt.rounds;
+            bt_route = true;
+        }
+    }
     if (band_route) {
-        h->force_split = true;   // separate launches: sweep_kernel (residual + Jacobian in HBM) + band_factor_kernel
+        if (!bt_route) h->force_split = true;   // separate launches: sweep_kernel (residual + Jacobian in HBM) + band_factor_kernel
         // ---- band factorisation tables: H = J^T J entry by entry as sums of products of Jacobian values (natural parameter order; a free dt
         //      -- the last parameter -- as a border)
         const int n = S.dims.n, nb = S.dt_free ? n - 1 : n, m = S.dims.m, nnz = S.dims.nnz;
@@ -648,7 +667,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
                     h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
-                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase};
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase, h->d_bt_pairs, h->d_bt_target, h->d_bt_off};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }
@@ -899,7 +918,8 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
         (void)hipEventRecord(e, h->stream);
         evs.push_back(e);
     };
-    const bool split = h->split_passes || h->force_split;
+    // (handles of the block-tridiagonal route have a run-to-completion kernel only: every per-pass mode runs their passes as separate launches, band kernels)
+    const bool split = h->split_passes || h->force_split || (h->bt_rounds > 0 && !(h->loop_mode && o->iterations > 0));
     const bool run_to_completion = !split && h->loop_mode && o->iterations > 0;
     if (rearm && !run_to_completion) { launch_copy_rows(h->d_x0, h->d_x, nullptr, (size_t)h->batch * h->S.nvs, h->stream); HIP_TRY(hipGetLastError()); }
     if (async && !run_to_completion) { const int rc0 = finish_async(h); if (rc0) return rc0; async = false; }   // (host-driven passes: synchronous)

@@ -4738,6 +4738,147 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
     }
 }
 
+#include "bt_factor.hpp"
+#ifndef CORBO_HIP_BT_WAVES
+#define CORBO_HIP_BT_WAVES 2   // waves per SIMD lm_bt_kernel is compiled for: 2 = 256 VGPRs (two workgroups per CU), 3 = 168 (three, LDS permitting)
+#endif
+
+// Run-to-completion kernel of the block-tridiagonal route (small-block families with extra edges: DESIGN.md 3.5d): lm_pass_kernel's loop -- prologue
+// sweep, then [factor phase -> trial sweep phase] until the instance has finished its outer iterations -- with the sweep phase's XE instantiation (one
+// lane per extra edge) and bt_factor_body.  Four waves per instance; the LDS carve holds the operands [J | values] of the assembly and, overlaid, the
+// block storage of the cyclic reduction.  Queue mode, re-armed start, result sink and the pass limit as in lm_pass_kernel.
+// (the operands [J | values | 0] of the assembly may run on into the vertex array behind the carve: the trial iterate is dead while the factor phase
+//  assembles -- it is what that phase writes last -- so the carve only has to hold what does not fit there: three workgroups per CU for the headline structure)
+template <int NX, int NU, bool ARROW>
+__host__ __device__ constexpr int bt_carve_doubles(int N, int nnz_pad, int m_pad, int nc, int nvs)
+{
+    int c = BtLayout<NX + NU, ARROW>::carve(N);
+    if (c < nnz_pad + m_pad + 2 - nvs) c = nnz_pad + m_pad + 2 - nvs;
+    if (c < nnz_pad + N * nc) c = nnz_pad + N * nc;
+    return (c + 1) / 2 * 2;
+}
+
+template <int DYN, int DEFECT, bool ARROW>
+__global__ __launch_bounds__(BT_THREADS, CORBO_HIP_BT_WAVES) void lm_bt_kernel(const FactorParams fp, const SweepParams sp)
+{
+    using Dy = Dynamics<DYN>;
+    constexpr int THREADS = BT_THREADS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    int inst      = blockIdx.x + fp.inst0;
+    double* jst = smem;
+    double* cs  = smem + sp.nnz_pad;
+    double* xs  = smem + bt_carve_doubles<Dy::NX, Dy::NU, ARROW>(fp.N, sp.nnz_pad, sp.m_pad, Dy::NC, sp.nvs);
+    LmState* sl = reinterpret_cast<LmState*>(xs + sp.nvs);
+    double* red = reinterpret_cast<double*>(sl + 1);   // [12]: reductions [0, 8), the sweep phase's flag words behind them
+    int* flags  = reinterpret_cast<int*>(red + 8);
+    struct Args { FactorParams f; SweepParams s; };
+    typedef const __attribute__((address_space(4))) Args* ArgsPtr;
+    ArgsPtr ka = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    int tid_v = tid;
+#pragma nounroll
+    for (;;) {
+        const bool queue_mode = ((const FactorParams&)ka->f).queue != nullptr;
+        if (queue_mode) {
+            asm volatile("" : "+v"(tid_v), "+s"(ka) : : "memory");
+            const FactorParams& fq = (const FactorParams&)ka->f;
+            __syncthreads();
+            if (tid_v == 0) flags[2] = atomicAdd(fq.queue, 1);
+            __syncthreads();
+            const int ticket = __builtin_amdgcn_readfirstlane(flags[2]);
+            if (ticket >= fq.batch) break;
+            inst = ticket + fq.inst0;
+        }
+        int inst_v = inst;
+        {
+            const FactorParams& fq = (const FactorParams&)ka->f;
+            lm_state_in(sl, fq.st + inst_v, tid_v);
+        }
+        if (tid_v == 0) flags[0] = 0;
+        __syncthreads();
+        int mode = ((const SweepParams&)ka->s).mode;
+        const int max_passes = ((const FactorParams&)ka->f).loop_passes;
+#pragma nounroll
+        for (int pass = 0; pass <= max_passes; ++pass) {
+            asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");   // nothing derived from them is carried around the loop
+            const FactorParams& fpl = (const FactorParams&)ka->f;
+            const SweepParams& spl  = (const SweepParams&)ka->s;
+            const bool stamp = fpl.pass_timeline && inst_v == fpl.pass_timeline_inst && tid_v == 0 && pass < 64;   // (diagnostics: option pass_timeline)
+            if (stamp) fpl.pass_timeline[2 * pass] = clock64();
+            const bool pcyc = fpl.phase_cycles && tid_v == 0;
+            long long pc_t0 = 0;
+            if (pcyc) pc_t0 = clock64();
+            if (pass > 0 && tid_v == 0) flags[0] = 0;
+            sweep_body<DYN, DEFECT, true, false, false, THREADS, true>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0);
+            __threadfence_block();
+            __syncthreads();
+            if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
+            if (pcyc) {
+                const long long t1 = clock64();
+                long long* row = fpl.phase_cycles + (size_t)inst_v * 8;
+                const int w = flags[0] != 0 ? 0 : 1;
+                row[w] += t1 - pc_t0; row[3 + w] += 1;
+                pc_t0 = t1;
+            }
+            if (sl->done) break;
+            const bool j_fresh = flags[0] != 0;
+            bt_factor_body<Dy::NX + Dy::NU, Dy::NX, ARROW, THREADS>(fpl, sl, smem, xs, red, inst_v, tid_v, j_fresh);
+            __threadfence_block();
+            __syncthreads();
+            if (pcyc) { long long* row = fpl.phase_cycles + (size_t)inst_v * 8; row[2] += clock64() - pc_t0; row[5] += 1; }
+            if (stamp && fpl.timeline) {   // diagnostics: the phase stamps of this pass (factor [0,8), sweep [8,18)) into the per-pass log
+                long long* lg = fpl.pass_timeline + 150 + 18 * pass;
+                for (int q = 0; q < 18; ++q) { lg[q] = fpl.timeline[q]; fpl.timeline[q] = 0; }
+            }
+            mode = 3;
+        }
+        asm volatile("" : "+s"(inst_v), "+v"(tid_v), "+s"(ka) : : "memory");
+        const FactorParams& fe = (const FactorParams&)ka->f;
+        lm_state_out(fe.st + inst_v, sl, tid_v);
+        if (fe.x_host) {
+            const double2* src = reinterpret_cast<const double2*>(fe.x + (size_t)inst_v * fe.nvs);
+            double2* dst       = reinterpret_cast<double2*>(fe.x_host + (size_t)inst_v * fe.nvs);
+            for (int i = tid_v; i < fe.nvs / 2; i += THREADS) dst[i] = src[i];
+            lm_state_out(fe.st_host + inst_v, sl, tid_v);
+        }
+        if (tid_v == 0 && !sl->done && fe.unfinished_flag) *(volatile int32_t*)fe.unfinished_flag = 1;  // pass limit hit
+        asm volatile("" : "+s"(ka) : : "memory");
+        if (((const FactorParams&)ka->f).queue == nullptr) break;
+    }
+}
+
+template <int DYN, int DEFECT>
+bool launch_bt_t(const FactorParams& fp, const SweepParams& sp, hipStream_t stream)
+{
+    using Dy = Dynamics<DYN>;
+    if constexpr (DEFECT == DEFECT_SHOOTING_HIGH) return false;
+    else {
+        if (!fp.bt_pairs || fp.N > BtLayout<Dy::NX + Dy::NU, false>::NB_MAX || fp.loop_passes <= 0) return false;
+        const bool arrow = fp.dt_free != 0;
+        const size_t carve = arrow ? bt_carve_doubles<Dy::NX, Dy::NU, true>(fp.N, fp.nnz_pad, fp.m_pad, Dy::NC, fp.nvs) : bt_carve_doubles<Dy::NX, Dy::NU, false>(fp.N, fp.nnz_pad, fp.m_pad, Dy::NC, fp.nvs);
+        const size_t lds = sizeof(double) * (carve + fp.nvs + 12) + sizeof(LmState);
+        if (lds > (size_t)160 * 1024) return false;
+        int grid = fp.batch;
+        if (fp.queue) {
+            int per_cu = (int)((size_t)160 * 1024 / lds);
+            if (per_cu > CORBO_HIP_BT_WAVES) per_cu = CORBO_HIP_BT_WAVES;   // (four waves per workgroup: workgroups per CU = waves per SIMD)
+            if (per_cu < 1) per_cu = 1;
+            grid = fp.queue_grid * per_cu;
+            if (grid > fp.batch) grid = fp.batch;
+        }
+        static unsigned long long attr_set[2] = {0, 0};   // (per device)
+        if (arrow) {
+            if (first_on_device(attr_set[1])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lm_bt_kernel<DYN, DEFECT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((lm_bt_kernel<DYN, DEFECT, true>), dim3(grid), dim3(BT_THREADS), lds, stream, fp, sp);
+        }
+        else {
+            if (first_on_device(attr_set[0])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lm_bt_kernel<DYN, DEFECT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((lm_bt_kernel<DYN, DEFECT, false>), dim3(grid), dim3(BT_THREADS), lds, stream, fp, sp);
+        }
+        return true;
+    }
+}
+
 template <int DYN, int DEFECT>
 void launch_sweep_t(const SweepParams& p, hipStream_t stream)
 {
@@ -5328,6 +5469,7 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     using Dy = Dynamics<DYN>;
     if (fp.N > SWEEP_THREADS) return false;
     if (fp.wdense_mask) return false;   // non-diagonal weights: separate launches only (see sweep_body)
+    if (sp.n_xedges > 0) return launch_bt_t<DYN, DEFECT>(fp, sp, stream);   // extra edges: the block-tridiagonal route (bt_factor.hpp)
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
     const size_t lds = sizeof(double) * (((dbl + 1) & ~(size_t)1) + fp.nvs + 12) + sizeof(LmState);           // + vertex values + LM state + scratch
@@ -6077,7 +6219,8 @@ __global__ __launch_bounds__(1024) void big_spec_kernel(const SpecParams p)
         int busy = 0;
         for (int g = 0; g < G; ++g) busy += (p.parent_of[g] >= 0 || a_parent[g] >= 0) ? 1 : 0;
         int nn = n_new < MAXG ? n_new : MAXG;
-        if (busy + nn > SPEC_MAX_PARENTS) nn = 0;
+        // (option reject_speculation = 2 -- tests -- lifts the limit to the number of groups: whoever finds a free group gets it)
+        if (busy + nn > SPEC_MAX_PARENTS) nn = (SPEC_MAX_PARENTS >= G && busy < G) ? G - busy : 0;
         int g = 0;
         for (int q = 0; q < nn; ++q) {
             while (g < G && (p.parent_of[g] >= 0 || a_parent[g] >= 0)) ++g;
@@ -6682,6 +6825,22 @@ __global__ __launch_bounds__(64) void band_narrow_kernel(const FactorParams p, c
 static constexpr size_t BAND_LDS_MAX = 160 * 1024 - 256;   // (the kernel also has 128 bytes of static LDS: the LM state)
 // what band_factor_kernel can take: one wave writes a finished row out / walks a row in the back-substitution (half-bandwidth <= 63), and the sliding
 // window + right-hand side + border live in LDS.  corbo_hip_create asks, so that an unsupported descriptor is refused THERE (include/corbo_hip.h).
+// (host mirror of BtLayout / bt_carve_doubles / launch_bt_t for corbo_hip_create; nc: an upper bound of the dynamics' cache doubles per grid state)
+int bt_route_max_rounds(int nx, int nu, bool arrow, int N, int nnz_pad, int m_pad, int nvs)
+{
+    const int s = nx + nu;
+    if (nx < 1 || nx > 4 || nu < 1 || N > 128) return 0;
+    const int szp = (2 * s * s + s + (arrow ? s : 0)) | 1;
+    long carve = (long)N * szp + 3;
+    if (carve < (long)nnz_pad + m_pad + 2 - nvs) carve = (long)nnz_pad + m_pad + 2 - nvs;
+    if (carve < (long)nnz_pad + (long)N * 8) carve = (long)nnz_pad + (long)N * 8;
+    carve = (carve + 1) / 2 * 2;
+    const size_t lds = sizeof(double) * (size_t)(carve + nvs + 12) + sizeof(LmState);
+    if (lds > (size_t)160 * 1024) return 0;
+    const int epb = s * (s + 1) / 2 + s * s + s + (arrow ? s : 0);
+    return ((epb * 128 + 2 + BT_THREADS - 1) / BT_THREADS + 3) / 4;   // super-rounds (BtLayout::max_rounds, four rounds each)
+}
+
 bool band_route_supported(int nb, int bw) { return bw + 1 <= 64 && sizeof(double) * (band_lds_doubles(nb, bw) + 8) <= BAND_LDS_MAX; }
 
 bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream)

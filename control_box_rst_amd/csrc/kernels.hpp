@@ -134,6 +134,11 @@ struct FactorParams {
     int32_t defect;               // corbo_hip_problem_desc::defect (big-block family: which stage kernel)
     int32_t pass_threads;         // run-to-completion kernel: workgroup size 256 (default) / 192 / 128 (option "pass_threads"; headline shape only)
     int32_t* unfinished_flag;  // run-to-completion kernel: set to 1 by an instance that hits the pass limit (may be device-visible pinned host memory)
+    // block-tridiagonal route (small-block families with extra edges; bt_factor.hpp, structure.hpp BtTables) or null / 0
+    const uint32_t* bt_pairs;
+    const int32_t* bt_off;
+    const uint32_t* bt_target;
+    int32_t bt_rounds;
 };
 
 // Reject-streak speculation of the big-block family (big_spec_kernel; VERDICT r3 item 2 a).  An instance whose trial step was rejected re-factorises the
@@ -282,6 +287,10 @@ bool launch_stage_jacobian_dump(const corbo_hip_problem_desc& d, const FactorPar
 bool device_kernels_exist(const corbo_hip_problem_desc& d);   // host-only mirror of the dispatch (corbo_hip_create's gate)
 bool launch_pass(const corbo_hip_problem_desc& d, const FactorParams& fp, const SweepParams& sp, hipStream_t stream);
 bool launch_band_factor(const FactorParams& fp, const BandParams& bp, hipStream_t stream);
+// Block-tridiagonal route (lm_bt_kernel): what corbo_hip_create asks before it builds the tables -- block size s = nx + nu, free dt, grid points, the
+// padded Jacobian / residual lengths, the dynamics' cache doubles per grid state.  0 = no such kernel (horizon, LDS); else the rounds its assembly holds.
+int bt_route_max_rounds(int nx, int nu, bool arrow, int N, int nnz_pad, int m_pad, int nvs);
+constexpr int BT_THREADS = 256;
 size_t band_work_doubles(int nb, int bw);
 bool band_route_supported(int nb, int bw);   // half-bandwidth <= 63 and the sliding window + vectors within the LDS of a CU
 size_t sweep_lds_bytes(const SweepParams& p, int nc);

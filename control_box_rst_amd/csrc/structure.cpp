@@ -1,8 +1,10 @@
 // structure.cpp -- see structure.hpp.  Host only (no HIP).
 #include "structure.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 
 namespace corbo_hip {
 
@@ -557,6 +559,115 @@ void build_hessian_structure(const Structure& S, bool lower, HessianStructure& H
         H.lin_cols.push_back(S.comp[v].param);
     }
     H.lin_nnz = (int32_t)H.lin_rows.size();
+}
+
+// ---- block-tridiagonal tables (structure.hpp BtTables)
+bool build_bt_tables(const Structure& S, const std::vector<int32_t>& jmap, int nnz_pad, int m_pad, int threads, BtTables& out, std::string* why)
+{
+    auto no = [&](const std::string& w) { if (why) *why = w; return false; };
+    const int s = S.s, NB = S.N, n = S.dims.n, m = S.dims.m, nnz = S.dims.nnz;
+    const bool arrow = S.dt_free;
+    const int zero = nnz_pad + m_pad;
+    // parameter -> (block, component); the dt parameter: block -1
+    std::vector<int> pblk(n), pcmp(n);
+    std::vector<int> col_of((size_t)NB * s, -1);   // (block, component) -> parameter or -1 (fixed component / pad)
+    int dt_col = -1;
+    for (int c = 0; c < n; ++c) {
+        const int v = S.param_voff[c];
+        if (S.dt_free && v == S.off_dt) { pblk[c] = -1; pcmp[c] = 0; dt_col = c; continue; }
+        if (v >= S.off_xf) { pblk[c] = NB - 1; pcmp[c] = v - S.off_xf; }
+        else { pblk[c] = v / s; pcmp[c] = v % s; }
+        if (pblk[c] < 0 || pblk[c] >= NB || pcmp[c] >= s) return no("parameter outside the stage blocks");
+        col_of[(size_t)pblk[c] * s + pcmp[c]] = c;
+    }
+    if (arrow && dt_col < 0) return no("free dt without a dt parameter");
+    std::vector<std::vector<std::pair<int, int>>> rows(m);   // per residual row: (column, operand index of the Jacobian value)
+    for (int i = 0; i < nnz; ++i) rows[S.jac_rows[i]].push_back({S.jac_cols[i], jmap[i]});
+    // products per entry of the lower part of H, per column of the right-hand side
+    using Prod = std::pair<uint32_t, uint32_t>;   // byte offsets of the two operands in the LDS array [J | values | 0]
+    std::map<std::pair<int, int>, std::vector<Prod>> ent;
+    std::vector<std::vector<Prod>> rhs(n);
+    for (int r = 0; r < m; ++r)
+        for (const auto& a : rows[r]) {
+            rhs[a.first].push_back({(uint32_t)a.second * 8u, (uint32_t)(nnz_pad + r) * 8u});
+            for (const auto& b : rows[r]) {
+                // key: (row parameter, column parameter) with the row's block >= the column's block; the dt parameter is the last row
+                const int ba = pblk[a.first] < 0 ? NB : pblk[a.first], bb = pblk[b.first] < 0 ? NB : pblk[b.first];
+                if (ba < bb || (ba == bb && pcmp[a.first] < pcmp[b.first])) continue;
+                if (ba < NB && ba - bb > 1) return no("H = J^T J is not block tridiagonal in the stage blocks");
+                ent[{a.first, b.first}].push_back({(uint32_t)a.second * 8u, (uint32_t)b.second * 8u});
+            }
+        }
+    const int S2 = s * s, oA = 0, oB = S2, oG = 2 * S2, oZ = 2 * S2 + s;
+    const int szp = (2 * S2 + s + (arrow ? s : 0)) | 1;
+    struct Entry { uint32_t target; const std::vector<Prod>* list; };
+    static const std::vector<Prod> none;
+    std::vector<Entry> E;
+    auto list_of = [&](int ca, int cb) -> const std::vector<Prod>* {
+        if (ca < 0 || cb < 0) return &none;
+        auto it = ent.find({ca, cb});
+        return it == ent.end() ? &none : &it->second;
+    };
+    for (int k = 0; k < NB; ++k) {
+        const int base = k * szp;
+        for (int i = 0; i < s; ++i) {
+            const int ci = col_of[(size_t)k * s + i];
+            for (int j = 0; j <= i; ++j) {
+                const int cj = col_of[(size_t)k * s + j];
+                const uint32_t kind = (i == j) ? (ci >= 0 ? 1u : 2u) : 0u;   // bit 28: diagonal of a parameter (+ damping), bit 29: identity row
+                E.push_back({(uint32_t)(base + oA + i * s + j) | (kind << 28), list_of(ci, cj)});
+            }
+            E.push_back({(uint32_t)(base + oG + i) | ((ci >= 0 ? 4u : 0u) << 28), ci >= 0 ? &rhs[ci] : &none});   // bit 30: right-hand side (negated sum)
+            if (arrow) E.push_back({(uint32_t)(base + oZ + i), list_of(dt_col, ci)});
+            if (k + 1 < NB)
+                for (int c = 0; c < s; ++c)   // F_k[i][c] = H((k + 1, i), (k, c))
+                    E.push_back({(uint32_t)(base + oB + i * s + c), list_of(col_of[(size_t)(k + 1) * s + i], col_of[(size_t)k * s + c])});
+        }
+    }
+    if (arrow) {
+        E.push_back({(uint32_t)(NB * szp) | (8u << 28), list_of(dt_col, dt_col)});   // bit 31: the corner H(dt, dt)
+        E.push_back({(uint32_t)(NB * szp + 1) | (4u << 28), &rhs[dt_col]});
+    }
+    size_t used = 0;
+    for (const auto& e : E) used += e.list->size();
+    size_t all = 0;
+    for (const auto& kv : ent) all += kv.second.size();
+    for (const auto& r : rhs) all += r.size();
+    if (used != all) return no("an entry of H = J^T J falls outside the block-tridiagonal pattern");
+    std::stable_sort(E.begin(), E.end(), [](const Entry& a, const Entry& b) { return a.list->size() > b.list->size(); });
+    out = BtTables{};
+    out.S = s; out.NB = NB; out.szp = szp; out.threads = threads; out.arrow = arrow;
+    // super-rounds of four rounds (4 * threads entries): lane t of super-round sr holds the entries (4 sr + c) * threads + t, c = 0 .. 3; their lists are
+    // padded to the super-round's longest; step i of a super-round = the four operand pairs [i] of the lane's entries as one 16-byte word group
+    const size_t per_sr = 4 * (size_t)threads;
+    out.rounds = (int)((E.size() + per_sr - 1) / per_sr);
+    out.off.assign(1, 0);
+    out.target.assign((size_t)out.rounds * per_sr, (uint32_t)(NB * szp + 2));   // (no entry: the trash slot)
+    const uint32_t zoff = (uint32_t)zero * 8u;
+    for (int sr = 0; sr < out.rounds; ++sr) {
+        size_t L = 0;
+        for (size_t e = sr * per_sr; e < std::min(E.size(), (sr + 1) * per_sr); ++e) L = std::max(L, E[e].list->size());
+        L = (L + 3) / 4 * 4;   // (the kernel's loop body is four steps: its window of loads in flight has static registers)
+        const size_t o0 = (size_t)out.off.back();
+        out.pairs.resize((o0 + L) * per_sr * 2, zoff);
+        // Neighbours in the sorted list are the same entry of consecutive blocks: their operands sit a whole stage apart in the Jacobian -- 24 doubles for
+        // the unicycle's defect blocks, i.e. FOUR distinct LDS banks for the 64 lanes of a wave (measured: 345 cycles per step, all of it bank conflicts).
+        // The lanes of a super-round take its entries in a scattered order instead (a multiplicative permutation of the 4 * threads positions).
+        const size_t P = (per_sr % 2 == 0) ? (size_t)(0.618 * per_sr) | 1 : 1;
+        for (int c = 0; c < 4; ++c)
+            for (int t = 0; t < threads; ++t) {
+                const size_t e = sr * per_sr + (((size_t)c * threads + t) * P) % per_sr;
+                if (e >= E.size()) continue;
+                out.target[(sr * (size_t)threads + t) * 4 + c] = E[e].target;
+                for (size_t i = 0; i < E[e].list->size(); ++i) {
+                    out.pairs[((o0 + i) * threads + t) * 8 + 2 * c]     = (*E[e].list)[i].first;
+                    out.pairs[((o0 + i) * threads + t) * 8 + 2 * c + 1] = (*E[e].list)[i].second;
+                }
+            }
+        out.off.push_back((int32_t)(o0 + L));
+    }
+    out.pairs.resize(out.pairs.size() + 4 * per_sr * 2, zoff);     // (the kernel's window of loads runs four steps ahead of the last one)
+    return true;
 }
 
 }  // namespace corbo_hip

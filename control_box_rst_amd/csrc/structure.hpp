@@ -130,6 +130,23 @@ struct HessianStructure {
 };
 void build_hessian_structure(const Structure& S, bool lower_part_only, HessianStructure& out);
 
+// Block-tridiagonal route of the small-block families with extra edges (kernels.hip, bt_factor.hpp): H = J^T J in the stage
+// blocks z_k = (x_k, u_k) (S = nx + nu rows; the last block: x_f, padded), a free dt as a border.  Every assembled entry -- lower part of the
+// diagonal blocks D_k, the couplings F_k = H(block k + 1, block k), the right-hand side, the border -- is a sum of products of two operands of
+// the array [J (nnz_pad) | values (m_pad) | 0]; the entries are sorted by list length and dealt out in SUPER-ROUNDS of 4 * `threads` entries (four per
+// lane) whose lists are padded to the super-round's longest, a multiple of four (ELL layout: the two operands' BYTE OFFSETS of product i of the lane's entry c at
+// pairs[((off[sr] + i) * threads + lane) * 8 + 2 c + {0, 1}], padding = the zero operand; four more steps of padding behind the last one).
+struct BtTables {
+    int S = 0, NB = 0, szp = 0, threads = 0, rounds = 0;
+    bool arrow = false;
+    std::vector<uint32_t> pairs;     // operand byte offsets
+    std::vector<int32_t> off;        // [rounds + 1] steps (one step = one 16-byte group of four pairs per lane); rounds = super-rounds
+    std::vector<uint32_t> target;    // [rounds * threads * 4] (lane-major groups of four): LDS slot (bits 0..27) | flags -- bit 28 diagonal of a parameter (+ damping), 29 identity
+                                     // row (fixed component / pad: the value is 1), 30 right-hand side (negated sum), 31 corner H(dt, dt); no entry: the trash slot
+};
+// false (with a reason) when H is not block tridiagonal in the stage blocks
+bool build_bt_tables(const Structure& S, const std::vector<int32_t>& jmap, int nnz_pad, int m_pad, int threads, BtTables& out, std::string* why);
+
 // returns "" on success, otherwise an error text
 std::string validate_desc(const corbo_hip_problem_desc& d);
 std::string build_structure(const corbo_hip_problem_desc& d, Structure& out);

@@ -24,8 +24,8 @@ def _built():
     g.build()
 
 
-def _solver(g, d, iters, B=1):
-    s = BatchedLevenbergMarquardt(d, B)
+def _solver(g, d, iters, B=1, route=0):
+    s = BatchedLevenbergMarquardt(d, B, route=route)
     s.setIterations(iters)
     s.setPenaltyWeights(*g["weights"])
     X0 = np.tile(np.array(g["vertex_init"])[: s.dims.nv], (B, 1))
@@ -141,7 +141,7 @@ def test_narrow_band_kernel_vs_eight_wave_kernel(name):
     a = g["after_iter"][-1]
     out = []
     for wide in (0, 1):
-        s = _solver(g, d, a["k"], B=3)
+        s = _solver(g, d, a["k"], B=3, route=capi.ROUTE_XE_BAND)   # (the band route: these handles take the block-tridiagonal route by default since round 6)
         s.set_option("band_wide", wide)
         for i in range(g["solves"]):
             s.solve(new_run=(i == 0))
@@ -154,3 +154,65 @@ def test_narrow_band_kernel_vs_eight_wave_kernel(name):
     #  other rounding difference -- both kernels stay inside the reference's own one-ulp spread of these fixtures, tests/tolerances.json)
     assert np.allclose(c0, c1, rtol=2e-7, atol=1e-12), (name, c0, c1)
     assert np.abs(x0 - x1).max() <= 2e-6, (name, np.abs(x0 - x1).max())
+
+
+SMALL_BLOCK = [n for n in FIXTURES if "quad" not in n and "n300" not in n]   # (the big-block family and horizons beyond 128 grid points keep the band route)
+
+
+@pytest.mark.parametrize("name", SMALL_BLOCK)
+def test_block_tridiagonal_route_vs_band_route(name):
+    """Round 6: the small-block families with extra edges run to completion in ONE launch (lm_bt_kernel: block cyclic reduction on (x_k, u_k) blocks, a free dt
+    as a border); corbo_hip_create_routed(.., CORBO_HIP_ROUTE_XE_BAND) keeps the band route (host-launched passes).  Same LM decisions, iterates far inside the
+    fixtures' tolerances of each other -- and both inside them against the reference (test_lm_iterates_vs_reference runs the default route)."""
+    g = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    d = desc_for(g)
+    a = g["after_iter"][-1]
+    out = []
+    for route in (0, capi.ROUTE_XE_BAND):
+        s = _solver(g, d, a["k"], B=3, route=route)
+        for i in range(g["solves"]):
+            s.solve(new_run=(i == 0))
+        x, chi2, status = s.get_solution()
+        out.append((x, chi2, status, s.get_stats()))
+    (x0, c0, s0, t0), (x1, c1, s1, t1) = out
+    assert np.array_equal(s0, s1)
+    for k in ("factorizations", "accepted_steps", "rejected_steps", "jacobian_sweeps"):
+        assert t0[k] == t1[k], (name, k)
+    assert np.allclose(c0, c1, rtol=5e-7, atol=1e-12), (name, c0, c1)
+    assert np.abs(x0 - x1).max() <= 2e-6 * max(1.0, np.abs(x1).max()), (name, np.abs(x0 - x1).max())
+    ref = np.array(a["vertex"])[: x1.shape[1]]
+    xt, _ = ledger_tolerances(name)
+    assert np.abs(x1[0] - ref).max() <= xt * max(1.0, np.abs(ref).max()), name   # (the band route against the reference as well)
+
+
+def test_block_tridiagonal_route_batch_async_and_per_pass_mode():
+    """The headline structure with a rate limit on the controls: a batch through the run-to-completion kernel (synchronous, enqueued, re-armed) and through the
+    per-pass mode of the same handle (option run_to_completion = 0: band kernels) -- identical decisions, iterates within rounding-level amplification."""
+    import bench
+    w = bench.workload(3, 96)
+    d = w["desc"]
+    d.ctrl_dev = capi.CTRL_DEV_RATE
+    d.ctrl_dev_params[0] = 1.0
+    d.ctrl_dev_params[1] = 1.0
+    s = BatchedLevenbergMarquardt(d, 96)
+    s.setPenaltyWeights(*w["weights"])
+    s.set_instance_data(s.init_trajectory(w["x0"], w["xf"]), xref=w["xf"])
+    s.solve()
+    X, chi2, status = [a.copy() for a in s.get_solution()]
+    st = s.get_stats()
+    assert (status <= 1).all() and st["lm_iterations"] == 96 * 10
+    s.set_result_sink(True)
+    for _ in range(2):
+        s.solve_async(rearm=True)
+    s.synchronize()
+    Xa, ca, sa = s.fetch_solution()
+    assert np.array_equal(np.asarray(Xa)[:, : X.shape[1]], X) and np.array_equal(ca, chi2) and np.array_equal(sa, status)
+    s.set_result_sink(False)
+    s.set_option("run_to_completion", 0)
+    s.restore_instance_data()
+    s.solve()
+    Xp, cp, sp_ = s.get_solution()
+    stp = s.get_stats()
+    assert np.array_equal(sp_, status)
+    assert stp["factorizations"] == st["factorizations"] and stp["accepted_steps"] == st["accepted_steps"]
+    assert np.allclose(cp, chi2, rtol=5e-7) and np.abs(Xp - X).max() <= 2e-6
