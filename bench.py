@@ -407,25 +407,53 @@ def band_leg(device):
                             "achieved_GFLOPs": B * flops / (f_ms * 1e-3) / 1e9, "frac_of_fp64_vector_peak": B * flops / (f_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}
         out[f"batch{B}"]["chi2_sum"] = chi2_band
         del s
-    # narrow bands (half-bandwidth 7: band_narrow_kernel, one wave per instance): the headline batch with the control-deviation term (a rate limit on the controls)
+    # the headline batch with the control-deviation term (a rate limit on the controls): the block-tridiagonal route (round 6: lm_bt_kernel, run to completion,
+    # one launch per solve) and -- the A/B -- the band route it replaced (band_narrow_kernel per host-launched LM pass; corbo_hip_create_routed)
     try:
         from control_box_rst_amd import capi
-        wl = workload(3, 1024)
-        dx = wl["desc"]
-        dx.ctrl_dev = capi.CTRL_DEV_RATE
-        dx.ctrl_dev_params[0] = 1.0; dx.ctrl_dev_params[1] = 1.0
-        s = BatchedLevenbergMarquardt(dx, 1024, device=device)
-        s.setIterations(10); s.setPenaltyWeights(*wl["weights"])
-        s.set_instance_data(s.init_trajectory(wl["x0"], wl["xf"]), xref=wl["xf"])
-        s.solve(new_run=True); s.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            s.restore_instance_data(); s.solve(new_run=True)
-        s.synchronize()
+        def rate_limit_solver(B, route):
+            wl = workload(3, B)
+            dx = wl["desc"]
+            dx.ctrl_dev = capi.CTRL_DEV_RATE
+            dx.ctrl_dev_params[0] = 1.0; dx.ctrl_dev_params[1] = 1.0
+            s = BatchedLevenbergMarquardt(dx, B, device=device, route=route)
+            s.setIterations(10); s.setPenaltyWeights(*wl["weights"])
+            s.set_instance_data(s.init_trajectory(wl["x0"], wl["xf"]), xref=wl["xf"])
+            s.solve(new_run=True); s.synchronize()
+            return s
+        def timed(s, reps=3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                s.restore_instance_data(); s.solve(new_run=True)
+            s.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        s = rate_limit_solver(1024, 0)
+        ms = timed(s, 5)
         st = s.get_stats()
-        out["headline_batch_with_rate_limit"] = {"ms_per_solve": (time.perf_counter() - t0) / 3 * 1e3, "factorizations": int(st["factorizations"]), "passes": int(st["passes"]),
-                                                 "chi2_sum": float(np.sum(s.get_solution()[1])), "what": "configs[2]'s 1024 unicycle OCPs + the control-deviation term: sweep (XE) + band_assemble_kernel + band_narrow_kernel per LM pass, host-launched"}
+        row = {"ms_per_solve": ms, "factorizations": int(st["factorizations"]), "passes": int(st["passes"]), "chi2_sum": float(np.sum(s.get_solution()[1])),
+               "kernel_ms_hip_events": float(st["solve_ms"]),
+               "what": "configs[2]'s 1024 unicycle OCPs + the control-deviation term: ONE launch of lm_bt_kernel per solve (sweep phase with one lane per extra edge, H = J^T J in (x_k, u_k) "
+                       "blocks, block cyclic reduction; DESIGN.md 3.5d).  1024 instances = 768 resident workgroups (3 per CU: 52.6 KB of LDS each) + a second round of 256: the time per "
+                       "instance at 768 / 1536 / 2048 is what the route sustains (batch_sweep)"}
+        # HBM roofline of the solve on SURVEY 8d's algorithmic bytes (the same convention as the headline's `roofline`)
+        dims = s.dims
+        b_sweep = 8 * (dims.nv + 2 * dims.n + dims.m + dims.nnz); b_val = 8 * (dims.nv + 2 * dims.n + dims.m)
+        alg = st["jacobian_sweeps"] * b_sweep + max(0, st["residual_sweeps"] - st["jacobian_sweeps"]) * b_val
+        row["roofline"] = {"bound": "hbm", "bytes_per_launch": alg, "ms_per_launch": float(st["solve_ms"]), "achieved": alg / (st["solve_ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": alg / (st["solve_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "note": "a latency chain per instance like the headline's kernel; 22 factorisations per instance, 54 % of them rejected steps"}
         del s
+        sb = rate_limit_solver(1024, capi.ROUTE_XE_BAND)
+        row["band_route_ms_per_solve"] = timed(sb, 2)
+        row["band_route_chi2_sum"] = float(np.sum(sb.get_solution()[1]))
+        del sb
+        sweep = {}
+        for B in (1, 64, 768, 2048):
+            s = rate_limit_solver(B, 0)
+            sweep[str(B)] = {"ms_per_solve": timed(s, 3), "us_per_instance": None}
+            sweep[str(B)]["us_per_instance"] = 1e3 * sweep[str(B)]["ms_per_solve"] / B
+            del s
+        row["batch_sweep"] = sweep
+        out["headline_batch_with_rate_limit"] = row
     except Exception as e:   # (a measurement row: never fatal for the line)
         out["headline_batch_with_rate_limit"] = {"error": str(e)[:200]}
     out["workload"] = "time-optimal quadrotor nx=12 nu=4, MultipleShootingVariableGrid N=100, RK4, MinimumTime, x_f fixed: band_assemble_kernel + band_factor_kernel per LM pass (batch1 / batch64: corbo_hip_create_routed with CORBO_HIP_ROUTE_FREE_DT_BAND); chain_route_*: the same solves through big_stage_kernel / big_chain3_kernel with the border column"

@@ -5,9 +5,10 @@
 // (x_k, u_k, x_{k+1}) (finite_differences_collocation_edges.h:149-459) the controls of a stage no longer couple to x_k / x_{k+1} alone, so
 // factor_body's "controls first" elimination does not apply; but H = J^T J (levenberg_marquardt_sparse.cpp:97-100) is still BLOCK TRIDIAGONAL in the
 // stage blocks z_k = (x_k, u_k) of S = nx + nu rows (the last block: x_f, padded), plus a dense border for a free dt.  This phase
-//   (1) assembles the blocks from the Jacobian values the sweep phase left in LDS through static product lists (BtTables, structure.hpp:
-//       every entry of H and of rhs = -J^T r is a sum of products of two operands of the array [J | values | 0]; the lists are padded to
-//       equal length per round of THREADS entries -- ELL layout, coalesced, branch-free),
+//   (1) assembles the blocks from the Jacobian values the sweep phase left in LDS: the dynamics-defect edges (two thirds of the products) from
+//       their dense local Jacobians [A | B | C] by a lane pair per stage, every other row of J (cost, bound, inequality rows, the extra edges of
+//       whatever kind) through static product lists (BtTables, structure.hpp: an entry of H or of rhs = -J^T r is a sum of products of two
+//       operands of the array [J | values | 0]; the lists are padded to equal length per super-round -- ELL layout, coalesced, branch-free),
 //   (2) factors by block cyclic reduction on S x S blocks: level h eliminates the blocks k = h (2t + 1), S lanes per block (lane j: column j
 //       of the couplings), D_k^-1 applied through a Cholesky factor each lane computes redundantly,
 //   (3) back-substitutes down the tree, closes the arrowhead (free dt: the border rides as a second right-hand side) and writes the trial
@@ -25,7 +26,9 @@ struct BtLayout {
     static constexpr int SZP = SZ | 1;         // odd stride: consecutive blocks spread over the LDS banks
     static constexpr int EPB = S * (S + 1) / 2 + S * S + S + (ARROW ? S : 0);   // assembled entries per block
     static constexpr int NB_MAX = 128;         // blocks (= grid points) this route is instantiated for
-    __host__ __device__ static constexpr int max_rounds(int threads) { return (EPB * NB_MAX + 2 + threads - 1) / threads; }
+    // rounds of the product lists a lane holds in registers: the lists cover every row of J but the defect edges' (diagonals, right-hand sides, extra edges,
+    // inequality rows) -- sixteen entries per lane at most; a structure that needs more stays on the band route (corbo_hip_create asks bt_route_max_rounds)
+    __host__ __device__ static constexpr int max_rounds(int) { return 16; }
     __host__ __device__ static constexpr int carve(int nb) { return nb * SZP + 3; }   // + corner, rhs of dt, trash slot
 };
 
@@ -33,7 +36,8 @@ struct BtLayout {
 constexpr unsigned BT_DIAG = 1u << 28, BT_ONE = 1u << 29, BT_RHS = 1u << 30, BT_CORNER = 1u << 31, BT_SLOT = 0x0FFFFFFFu;
 
 template <int S, int NX, bool ARROW, int THREADS>
-__device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* const st, double* const smem, double* const xs, double* const red, const int inst, const int tid, const bool j_in_lds)
+__device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* const st, double* const smem, double* const xs, double* const red, const int inst, const int tid, const bool j_in_lds,
+                                               const int eq_stride, const int eq_defect_off)
 {
     using BL = BtLayout<S, ARROW>;
     constexpr int SZP = BL::SZP, MAXE = BL::max_rounds(THREADS), NW = THREADS / 64;
@@ -47,6 +51,20 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     if (done) return;
 #define BT_STAMP(id) do { if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); } while (0)
     BT_STAMP(0);
+    // the defect edge of stage ks is assembled by TWO lanes from its dense local Jacobian (below); its column offsets depend on nothing but the lane: requested first
+    constexpr int WL = S + NX, HALF = THREADS / 2;
+    static_assert(BL::NB_MAX <= HALF, "one lane pair per stage");
+    const int ks = tid & (HALF - 1), half = tid / HALF;
+    const bool st_on = ks < NB - 1;
+    int sco[WL + 1];
+#pragma unroll
+    for (int c = 0; c < WL + 1; ++c) sco[c] = p.stage_cols[st_on ? ks : 0].col[c];
+    // ... and so do the first steps of the product lists (a window of four 32-byte word groups per lane, kept in flight across the list loop below)
+    const uint4* const pw = reinterpret_cast<const uint4*>(p.bt_pairs);
+    const char* const Jb = reinterpret_cast<const char*>(smem);
+    auto fetch = [&](int step, uint4& lo, uint4& hi) { const uint4* q = pw + ((size_t)step * THREADS + tid) * 2; lo = q[0]; hi = q[1]; };   // (the table is four steps longer than its last step)
+    uint4 w0a, w0b, w1a, w1b, w2a, w2b, w3a, w3b;
+    fetch(0, w0a, w0b); fetch(1, w1a, w1b); fetch(2, w2a, w2b); fetch(3, w3a, w3b);
     // ---- (1) operands [J | values | 0] in LDS: the Jacobian is there after an accepted step (the sweep phase of this pass assembled it), after a
     //      rejected one it is staged again from HBM / L2; the residual paired with it always comes from HBM / L2 (10 KB, written by this workgroup)
     double* const Jv = smem;
@@ -76,26 +94,16 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     }
     lds_barrier();
     BT_STAMP(1);
-    // ---- (2) assembly into registers (the block storage overlays the operands).  Entry e = q * THREADS + tid of the table belongs to round q; FOUR rounds
-    //      form a super-round whose product lists are padded to one length: step i of a super-round is ONE 16-byte load per lane (the i-th operand pair of the
-    //      lane's four entries) and four independent multiply-adds.  The loads depend on nothing but the step: a window of four of them is kept in flight
-    //      across the super-rounds (the assembly was a chain of L2 round trips before: 23.5 k cycles for the headline structure, one trip per round).
+    // ---- (2a) the product lists into registers (the block storage overlays the operands: nothing is written before every lane is through with them).  Entry
+    //      e of the table = lane e % THREADS, round e / THREADS; FOUR rounds form a super-round whose lists are padded to one length, a multiple of four: step i
+    //      of a super-round is the i-th product of the lane's four entries -- eight operand BYTE OFFSETS into the LDS array (two 16-byte loads: no address
+    //      arithmetic between the table and the LDS reads) and four independent multiply-adds.  The loads depend on nothing but the step: a window of FOUR
+    //      steps is in flight with STATIC registers -- the loop body is four steps, each reloads the registers it has just consumed.  (A rotating window,
+    //      w0 = w1; w1 = w2; ..., does not pipeline: a register move of a value that is still in flight waits for it.)
     constexpr int MAXSR = (MAXE + 3) / 4;
     double acc[4 * MAXSR];
     unsigned tg[4 * MAXSR];
     const int R = p.bt_rounds;            // super-rounds of this handle
-    const uint4* const pw = reinterpret_cast<const uint4*>(p.bt_pairs);
-    const int ST = p.bt_off[R];           // steps in all
-    (void)ST;
-    // A step of a lane = four products = eight operand BYTE OFFSETS into the LDS array (two 16-byte loads): no address arithmetic between the table
-    // and the LDS reads (16-bit operand indices cost ten VALU operations per product, and a single wave per SIMD issues one every four cycles).
-    // A window of FOUR steps in flight with STATIC registers: the step count of every super-round is a multiple of four (BtTables pads), the loop body is
-    // four steps, each reloads the registers it has just consumed.  (A rotating window -- w0 = w1; w1 = w2; ... -- does not pipeline: a register move
-    // of a value that is still in flight waits for it.)
-    const char* const Jb = reinterpret_cast<const char*>(Jv);
-    auto fetch = [&](int step, uint4& lo, uint4& hi) { const uint4* q = pw + ((size_t)step * THREADS + tid) * 2; lo = q[0]; hi = q[1]; };   // (the table is four steps longer than ST)
-    uint4 w0a, w0b, w1a, w1b, w2a, w2b, w3a, w3b;
-    fetch(0, w0a, w0b); fetch(1, w1a, w1b); fetch(2, w2a, w2b); fetch(3, w3a, w3b);
     int step = 0;
 #pragma unroll
     for (int sr = 0; sr < MAXSR; ++sr) {
@@ -128,13 +136,137 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
         acc[4 * sr + 3] = (tg[4 * sr + 3] & BT_RHS) ? -a3 : a3;
     }
     BT_STAMP(2);
-    // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118)
+    // ---- (2b) the defect edges -- two thirds of the products of H = J^T J -- from their DENSE local Jacobians: the lane pair (ks, ks + HALF) of stage ks takes
+    //      G = [A | B | C] (NX x (S + NX): x_k, u_k, x_{k+1}) and the edge's residual out of the operand area into registers now, and forms its share of
+    //      G^T G once the operands are dead: half 0 the diagonal block of stage ks and its right-hand side, half 1 the coupling F_ks = H(x_{ks+1}, (x, u)_ks)
+    //      and, in a second write phase, what the edge adds to the NEXT block (C^T C, -C^T r).  (Through the product lists these were 2 x 132 scattered LDS
+    //      reads per stage, and the LDS pipe is what the three workgroups of a CU share.)
+    double G[NX][WL], rv[NX], dc[NX];
+#pragma unroll
+    for (int c = 0; c < WL; ++c) {
+        const int o = sco[c];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { const double v = Jv[(o >= 0 ? o : 0) + r]; G[r][c] = (st_on && o >= 0) ? v : 0.0; }
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        const double v = Jv[p.nnz_pad + p.eq_row0 + (st_on ? ks : 0) * eq_stride + eq_defect_off + r];
+        rv[r] = st_on ? v : 0.0;
+        const int o = sco[WL];
+        const double d = Jv[(ARROW && o >= 0 ? o : 0) + r];
+        dc[r] = (ARROW && st_on && o >= 0) ? d : 0.0;
+    }
+    // H_ii += mu on every inner pass, never undone on reject (:135-138 and the comment at :208); the first factorisation of a solve learns its mu below
+    double mu_eff = first ? 0.0 : (fresh ? 0.0 : mu_acc_in) + mu;
+    lds_barrier();   // every lane is through with the operands
+    double* const blk = smem;
+    // ---- write phase X: complete diagonal blocks (lower part), right-hand sides, borders and couplings of the stages, plain stores
+    if (st_on && half == 0) {
+        double* sk = blk + ks * SZP;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+#pragma unroll
+            for (int c = 0; c <= i; ++c) {
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v += G[r][i] * G[r][c];
+                sk[oA + i * S + c] = v;
+            }
+            double g = 0.0, z = 0.0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { g -= G[r][i] * rv[r]; z += G[r][i] * dc[r]; }
+            sk[oG + i] = g;
+            if constexpr (ARROW) sk[oZ + i] = z;
+        }
+    }
+    if (half == 0 && ks == NB - 1) {   // the last block (x_f): nothing but what its neighbour and the lists add
+        double* sk = blk + ks * SZP;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+#pragma unroll
+            for (int c = 0; c <= i; ++c) sk[oA + i * S + c] = 0.0;
+            sk[oG + i] = 0.0;
+            if constexpr (ARROW) sk[oZ + i] = 0.0;
+        }
+    }
+    if (st_on && half == 1) {
+        double* sk = blk + ks * SZP;
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                double v = 0.0;
+                if (i < NX) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) v += G[r][S + (i < NX ? i : 0)] * G[r][c];
+                }
+                sk[oB + i * S + c] = v;
+            }
+    }
+    if (ARROW && tid == THREADS - 1) { blk[NB * SZP] = 0.0; blk[NB * SZP + 1] = 0.0; }
+    lds_barrier();
+    // ---- write phase Y: what the edge of stage ks adds to block ks + 1
+    if (st_on && half == 1) {
+        double* sn = blk + (ks + 1) * SZP;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int c = 0; c <= i; ++c) {
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v += G[r][S + i] * G[r][S + c];
+                sn[oA + i * S + c] += v;
+            }
+            double g = 0.0, z = 0.0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { g -= G[r][S + i] * rv[r]; z += G[r][S + i] * dc[r]; }
+            sn[oG + i] += g;
+            if constexpr (ARROW) sn[oZ + i] += z;
+        }
+    }
+    double cdt = 0.0, gdtp = 0.0;   // (free dt) the edges' share of the corner H(dt, dt) and of rhs(dt)
+    if constexpr (ARROW) {
+        if (st_on && half == 0) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { cdt += dc[r] * dc[r]; gdtp -= dc[r] * rv[r]; }
+        }
+    }
+    lds_barrier();
+    // ---- write phase T: the sums of the product lists on top (every other row of J: cost, bound, inequality rows, the extra edges), the damping
+#pragma unroll
+    for (int q = 0; q < 4 * MAXSR; ++q) {
+        if (q < 4 * R) {   // (uniform)
+            const unsigned slot = tg[q] & BT_SLOT;
+            double v = blk[slot] + acc[q];
+            v += (tg[q] & BT_DIAG) ? mu_eff : 0.0;
+            v = (tg[q] & BT_ONE) ? 1.0 : v;       // a fixed component / a pad row of the last block: an identity row, its increment is zero
+            blk[slot] = v;
+        }
+    }
+    lds_barrier();
+    if constexpr (ARROW) {
+        const double s0 = wave_sum(cdt), s1 = wave_sum(gdtp);
+        if ((tid & 63) == 0) { red[2 * (tid >> 6)] = s0; red[2 * (tid >> 6) + 1] = s1; }
+        lds_barrier();
+        if (tid == 0) {
+            double c0 = 0.0, g0 = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { c0 += red[2 * w]; g0 += red[2 * w + 1]; }
+            blk[NB * SZP] += c0;
+            blk[NB * SZP + 1] += g0;
+        }
+        lds_barrier();
+    }
+    // ---- first factorisation of a solve: mu = tau * max diag(J^T J), stop = |rhs|_inf <= eps1 (:115-118) -- from the assembled entries; then the damping
     if (first) {
         double mx_d = -1e300, mx_g = 0.0;
 #pragma unroll
         for (int q = 0; q < 4 * MAXSR; ++q) {
-            if (tg[q] & (BT_DIAG | BT_CORNER)) mx_d = fmax(mx_d, acc[q]);
-            if (tg[q] & BT_RHS) mx_g = fmax(mx_g, fabs(acc[q]));
+            if (q < 4 * R) {   // (uniform)
+                const double v = blk[tg[q] & BT_SLOT];
+                if (tg[q] & (BT_DIAG | BT_CORNER)) mx_d = fmax(mx_d, v);
+                if (tg[q] & BT_RHS) mx_g = fmax(mx_g, fabs(v));
+            }
         }
         mx_d = wave_max(mx_d);
         mx_g = wave_max(mx_g);
@@ -146,19 +278,12 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
         stop = (mx_g <= LM_EPS1) ? 1 : 0;
         mu   = LM_TAU * mx_d;
         if (mu < 0) mu = 0;
-    }
-    // H_ii += mu on every inner pass, never undone on reject (:135-138 and the comment at :208)
-    const double mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;
-    lds_barrier();   // every lane is through with the operands (and with the reduction scratch)
-    double* const blk = smem;
+        mu_eff = (fresh ? 0.0 : mu_acc_in) + mu;
 #pragma unroll
-    for (int q = 0; q < 4 * MAXSR; ++q) {
-        double v = acc[q];
-        v += (tg[q] & BT_DIAG) ? mu_eff : 0.0;
-        v = (tg[q] & BT_ONE) ? 1.0 : v;       // a fixed component / a pad row of the last block: an identity row, its increment is zero
-        blk[tg[q] & BT_SLOT] = v;
+        for (int q = 0; q < 4 * MAXSR; ++q)
+            if (q < 4 * R && (tg[q] & BT_DIAG)) blk[tg[q] & BT_SLOT] += mu_eff;
+        lds_barrier();
     }
-    lds_barrier();
     BT_STAMP(3);
     // ---- (3) block cyclic reduction.  Level h: the blocks k = h (2 t + 1) are eliminated, neighbours a = k - h, b = k + h (remaining blocks).
     //      Lane (t, j): Cholesky of D_k (redundant in the S lanes), column j of W_a = D_k^-1 H(k, a) and W_b = D_k^-1 H(k, b), column j of the Schur
@@ -199,18 +324,23 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
                         wb[r] = has_b ? f : 0.0;
                     }
                     chol_inv<S>(L);
+                    double gk[S], bk[S];
+#pragma unroll
+                    for (int r = 0; r < S; ++r) { gk[r] = yh[r]; bk[r] = zh[r]; }
+                    // (the three / four solves back to back: independent dependent chains the scheduler interleaves)
+                    fwd_solve_vec<S>(L, wa); fwd_solve_vec<S>(L, wb); fwd_solve_vec<S>(L, yh);
+                    if constexpr (ARROW) fwd_solve_vec<S>(L, zh);
+                    bwd_solve_vec<S>(L, wa); bwd_solve_vec<S>(L, wb); bwd_solve_vec<S>(L, yh);
+                    if constexpr (ARROW) bwd_solve_vec<S>(L, zh);
+                    // (D_k^-1 is symmetric: H(k, a)[:, j] . (D_k^-1 g) = (D_k^-1 H(k, a)[:, j]) . g -- the updates of the neighbours' right-hand sides need W and the raw g)
                     double gkj = 0.0, bkj = 0.0;
 #pragma unroll
-                    for (int r = 0; r < S; ++r) { gkj = (r == j) ? yh[r] : gkj; bkj = (r == j) ? zh[r] : bkj; }
-                    // (D_k^-1 is symmetric: H(k, a)[:, j] . (D_k^-1 g) = (D_k^-1 H(k, a)[:, j]) . g -- the updates of the neighbours' right-hand sides need W, not D_k^-1 g)
-                    fwd_solve_vec<S>(L, wa); bwd_solve_vec<S>(L, wa);
-                    fwd_solve_vec<S>(L, wb); bwd_solve_vec<S>(L, wb);
-#pragma unroll
-                    for (int r = 0; r < S; ++r) { dga += wa[r] * yh[r]; dgb += wb[r] * yh[r]; if constexpr (ARROW) { dba += wa[r] * zh[r]; dbb += wb[r] * zh[r]; } }
-                    fwd_solve_vec<S>(L, yh); bwd_solve_vec<S>(L, yh);
-                    if constexpr (ARROW) { fwd_solve_vec<S>(L, zh); bwd_solve_vec<S>(L, zh); }
-#pragma unroll
-                    for (int r = 0; r < S; ++r) { yj = (r == j) ? yh[r] : yj; zj = (r == j) ? zh[r] : zj; }
+                    for (int r = 0; r < S; ++r) {
+                        dga += wa[r] * gk[r]; dgb += wb[r] * gk[r];
+                        if constexpr (ARROW) { dba += wa[r] * bk[r]; dbb += wb[r] * bk[r]; }
+                        gkj = (r == j) ? gk[r] : gkj; bkj = (r == j) ? bk[r] : bkj;
+                        yj = (r == j) ? yh[r] : yj; zj = (r == j) ? zh[r] : zj;
+                    }
                     gy += gkj * yj;
                     if constexpr (ARROW) { gz += gkj * zj; zz += bkj * zj; }
                 }

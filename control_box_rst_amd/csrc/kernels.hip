@@ -4740,7 +4740,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
 
 #include "bt_factor.hpp"
 #ifndef CORBO_HIP_BT_WAVES
-#define CORBO_HIP_BT_WAVES 2   // waves per SIMD lm_bt_kernel is compiled for: 2 = 256 VGPRs (two workgroups per CU), 3 = 168 (three, LDS permitting)
+#define CORBO_HIP_BT_WAVES 3   // waves per SIMD lm_bt_kernel is compiled for: 3 = 168 VGPRs, three workgroups per CU where the LDS permits (the headline structure with a rate
+                               // limit: 52.6 KB each); 2 = 256 VGPRs.  Measured, ms per solve at batch 512 / 768 / 1024 / 2048: 1.00 / 1.15 / 1.83 / 2.91 against 0.96 / 1.67 / 1.80 / 3.45
 #endif
 
 // Run-to-completion kernel of the block-tridiagonal route (small-block families with extra edges: DESIGN.md 3.5d): lm_pass_kernel's loop -- prologue
@@ -4822,7 +4823,7 @@ __global__ __launch_bounds__(BT_THREADS, CORBO_HIP_BT_WAVES) void lm_bt_kernel(c
             }
             if (sl->done) break;
             const bool j_fresh = flags[0] != 0;
-            bt_factor_body<Dy::NX + Dy::NU, Dy::NX, ARROW, THREADS>(fpl, sl, smem, xs, red, inst_v, tid_v, j_fresh);
+            bt_factor_body<Dy::NX + Dy::NU, Dy::NX, ARROW, THREADS>(fpl, sl, smem, xs, red, inst_v, tid_v, j_fresh, spl.eq_stride, spl.eq_defect_off);
             __threadfence_block();
             __syncthreads();
             if (pcyc) { long long* row = fpl.phase_cycles + (size_t)inst_v * 8; row[2] += clock64() - pc_t0; row[5] += 1; }
@@ -6838,7 +6839,8 @@ int bt_route_max_rounds(int nx, int nu, bool arrow, int N, int nnz_pad, int m_pa
     const size_t lds = sizeof(double) * (size_t)(carve + nvs + 12) + sizeof(LmState);
     if (lds > (size_t)160 * 1024) return 0;
     const int epb = s * (s + 1) / 2 + s * s + s + (arrow ? s : 0);
-    return ((epb * 128 + 2 + BT_THREADS - 1) / BT_THREADS + 3) / 4;   // super-rounds (BtLayout::max_rounds, four rounds each)
+    (void)epb;
+    return 4;   // super-rounds of the product lists (BtLayout::max_rounds: sixteen rounds, four each)
 }
 
 bool band_route_supported(int nb, int bw) { return bw + 1 <= 64 && sizeof(double) * (band_lds_doubles(nb, bw) + 8) <= BAND_LDS_MAX; }

@@ -587,7 +587,14 @@ bool build_bt_tables(const Structure& S, const std::vector<int32_t>& jmap, int n
     using Prod = std::pair<uint32_t, uint32_t>;   // byte offsets of the two operands in the LDS array [J | values | 0]
     std::map<std::pair<int, int>, std::vector<Prod>> ent;
     std::vector<std::vector<Prod>> rhs(n);
-    for (int r = 0; r < m; ++r)
+    // the rows of the dynamics-defect edges are NOT in the lists: the kernel assembles those edges from their dense local Jacobians (bt_factor.hpp, 2b)
+    auto defect_row = [&](int r) {
+        if (r < S.eq_row0 || S.eq_stride <= 0) return false;
+        const int q = (r - S.eq_row0) / S.eq_stride, o = (r - S.eq_row0) % S.eq_stride;
+        return q < NB - 1 && o >= S.eq_defect_off && o < S.eq_defect_off + S.nx;
+    };
+    for (int r = 0; r < m; ++r) {
+        if (defect_row(r)) continue;
         for (const auto& a : rows[r]) {
             rhs[a.first].push_back({(uint32_t)a.second * 8u, (uint32_t)(nnz_pad + r) * 8u});
             for (const auto& b : rows[r]) {
@@ -598,6 +605,7 @@ bool build_bt_tables(const Structure& S, const std::vector<int32_t>& jmap, int n
                 ent[{a.first, b.first}].push_back({(uint32_t)a.second * 8u, (uint32_t)b.second * 8u});
             }
         }
+    }
     const int S2 = s * s, oA = 0, oB = S2, oG = 2 * S2, oZ = 2 * S2 + s;
     const int szp = (2 * S2 + s + (arrow ? s : 0)) | 1;
     struct Entry { uint32_t target; const std::vector<Prod>* list; };
@@ -608,6 +616,8 @@ bool build_bt_tables(const Structure& S, const std::vector<int32_t>& jmap, int n
         auto it = ent.find({ca, cb});
         return it == ent.end() ? &none : &it->second;
     };
+    // entries: every diagonal entry (its flag carries the damping / the identity row) and every parameter's right-hand side (its flag: the first
+    // factorisation's |rhs|_inf); of the others those with products -- the kernel's stage lanes write every slot of every block before the lists are added
     for (int k = 0; k < NB; ++k) {
         const int base = k * szp;
         for (int i = 0; i < s; ++i) {
@@ -615,13 +625,16 @@ bool build_bt_tables(const Structure& S, const std::vector<int32_t>& jmap, int n
             for (int j = 0; j <= i; ++j) {
                 const int cj = col_of[(size_t)k * s + j];
                 const uint32_t kind = (i == j) ? (ci >= 0 ? 1u : 2u) : 0u;   // bit 28: diagonal of a parameter (+ damping), bit 29: identity row
-                E.push_back({(uint32_t)(base + oA + i * s + j) | (kind << 28), list_of(ci, cj)});
+                const auto* l = list_of(ci, cj);
+                if (i == j || !l->empty()) E.push_back({(uint32_t)(base + oA + i * s + j) | (kind << 28), l});
             }
-            E.push_back({(uint32_t)(base + oG + i) | ((ci >= 0 ? 4u : 0u) << 28), ci >= 0 ? &rhs[ci] : &none});   // bit 30: right-hand side (negated sum)
-            if (arrow) E.push_back({(uint32_t)(base + oZ + i), list_of(dt_col, ci)});
+            if (ci >= 0) E.push_back({(uint32_t)(base + oG + i) | (4u << 28), &rhs[ci]});   // bit 30: right-hand side (negated sum)
+            if (arrow && !list_of(dt_col, ci)->empty()) E.push_back({(uint32_t)(base + oZ + i), list_of(dt_col, ci)});
             if (k + 1 < NB)
-                for (int c = 0; c < s; ++c)   // F_k[i][c] = H((k + 1, i), (k, c))
-                    E.push_back({(uint32_t)(base + oB + i * s + c), list_of(col_of[(size_t)(k + 1) * s + i], col_of[(size_t)k * s + c])});
+                for (int c = 0; c < s; ++c) {   // F_k[i][c] = H((k + 1, i), (k, c))
+                    const auto* l = list_of(col_of[(size_t)(k + 1) * s + i], col_of[(size_t)k * s + c]);
+                    if (!l->empty()) E.push_back({(uint32_t)(base + oB + i * s + c), l});
+                }
         }
     }
     if (arrow) {

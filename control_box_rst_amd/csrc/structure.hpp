@@ -131,8 +131,9 @@ struct HessianStructure {
 void build_hessian_structure(const Structure& S, bool lower_part_only, HessianStructure& out);
 
 // Block-tridiagonal route of the small-block families with extra edges (kernels.hip, bt_factor.hpp): H = J^T J in the stage
-// blocks z_k = (x_k, u_k) (S = nx + nu rows; the last block: x_f, padded), a free dt as a border.  Every assembled entry -- lower part of the
-// diagonal blocks D_k, the couplings F_k = H(block k + 1, block k), the right-hand side, the border -- is a sum of products of two operands of
+// blocks z_k = (x_k, u_k) (S = nx + nu rows; the last block: x_f, padded), a free dt as a border.  The dynamics-defect edges are assembled by the kernel
+// from their dense local Jacobians; what every OTHER row of J adds to an entry -- lower part of the diagonal blocks D_k, the couplings
+// F_k = H(block k + 1, block k), the right-hand side, the border -- is a sum of products of two operands of
 // the array [J (nnz_pad) | values (m_pad) | 0]; the entries are sorted by list length and dealt out in SUPER-ROUNDS of 4 * `threads` entries (four per
 // lane) whose lists are padded to the super-round's longest, a multiple of four (ELL layout: the two operands' BYTE OFFSETS of product i of the lane's entry c at
 // pairs[((off[sr] + i) * threads + lane) * 8 + 2 c + {0, 1}], padding = the zero operand; four more steps of padding behind the last one).
