@@ -493,6 +493,42 @@ def sweep_phase_leg(solver, B, b_sweep, b_val, launch_ms):
                     "measured bandwidth figures are `roofline` (whole launch, `traffic` from the counters) and `roofline_sweep` (the stand-alone sweep_kernel)"}
 
 
+def dense_weights_leg(device):
+    """Non-diagonal Q / R / Qf (QuadraticFormCost::setWeightQ with a full matrix: dense cost blocks, quadratic_cost.cpp:36-55) on the headline structure: since
+    round 6 such handles run to completion in one launch (lm_pass_kernel<.., DENSE>); `separate_launches_ms` = the same solve with the phases of every LM pass as
+    two launches (corbo_hip_set_profiling: what these handles did until round 5)."""
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    B = 1024
+    w = workload(3, B)
+    d = w["desc"]
+    Q = np.array([[1.0, 0.2, 0.0], [0.2, 1.0, 0.05], [0.0, 0.05, 0.1]]); R = np.array([[0.1, 0.02], [0.02, 0.05]])
+    for name, M in (("q_sqrt", Q), ("r_sqrt", R), ("qf_sqrt", 10.0 * Q)):
+        U = np.linalg.cholesky(M).T
+        n = U.shape[0]
+        arr = getattr(d, name)
+        for i in range(n):
+            for j in range(n):
+                arr[i * n + j] = U[i, j]
+    d.weights_dense = 7
+    out = {"workload": "configs[2]'s structure, batch 1024, non-diagonal Q, R, Qf (upper Cholesky factors), 10 LM iterations"}
+    for tag, prof in (("ms_per_solve", False), ("separate_launches_ms", True)):
+        s = BatchedLevenbergMarquardt(d, B, device=device)
+        s.setIterations(10); s.setPenaltyWeights(*w["weights"])
+        s.set_instance_data(s.init_trajectory(w["x0"], w["xf"]), xref=w["xf"])
+        s.set_profiling(prof)
+        s.solve(new_run=True); s.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            s.restore_instance_data(); s.solve(new_run=True)
+        s.synchronize()
+        out[tag] = (time.perf_counter() - t0) / 3 * 1e3
+        st = s.get_stats()
+        out["factorizations"] = int(st["factorizations"]); out["passes"] = int(st["passes"])
+        out["chi2_sum" if not prof else "chi2_sum_separate_launches"] = float(np.sum(s.get_solution()[1]))
+        del s
+    return out
+
+
 def hessian_leg(desc, B, x0, xf, device):
     """Operators of the exact-Hessian path on the headline structure: corbo_hip_eval_hessians (lower part, values left in HBM) for the
     bench batch and for ONE OCP (what the drop-in adapter's Hessian-path entry points run).  Wall time per call around a device-resident call +
@@ -849,6 +885,10 @@ def main():
             line["secondary"]["band_path"] = band_leg(local_rank)
         except Exception as e:
             line["secondary"]["band_path"] = {"error": repr(e)}
+        try:
+            line["secondary"]["dense_weights"] = dense_weights_leg(local_rank)
+        except Exception as e:
+            line["secondary"]["dense_weights"] = {"error": repr(e)}
         try:
             lm_opts = solver.opts
             del solver

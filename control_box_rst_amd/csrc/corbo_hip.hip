@@ -625,7 +625,7 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         bp.work = h->d_band_work;
     }
     if (S.desc.shooting_integrator >= 5) h->force_split = true;   // Runge-Kutta 5 - 7: a defect formula of the stand-alone kernels only (model.hpp, DEFECT_SHOOTING_HIGH)
-    if (S.desc.weights_dense) h->force_split = true;   // non-diagonal weights: the DENSE instantiations exist for the stand-alone kernels only (kernels.hip, sweep_body)
+    if (S.desc.weights_dense && S.N > 256) h->force_split = true;   // non-diagonal weights beyond 256 grid points: the DENSE instantiations of the long-horizon (stand-alone) kernels; up to 256: lm_pass_kernel<.., DENSE> (round 6)
     CREATE_TRY(hipMemset(h->d_chi2, 0, B * sizeof(double)));
     {
         hipDeviceProp_t prop;
@@ -941,7 +941,8 @@ static int solve_impl(corbo_hip_handle h, const corbo_hip_lm_opts* o, int new_ru
     // prologue sweep (mode 2), the following ones the trial-step sweep (mode 3); an instance that finishes in its sweep phase
     // skips the factor phase.  Split (diagnostics / big-block family): the same phases as separate launches on one stream.
     // The batch is cut into `nsub` contiguous sub-batches, each driven on its own stream.
-    // (the big-block family's separate launches on 2 / 4 sub-batch streams were measured: 17.4 / 21.6 ms against 17.1 ms on one)
+    // (the big-block family's separate launches on 2 / 4 sub-batch streams were measured: 17.4 / 21.6 ms against 17.1 ms on one; round 6, cfg 5 without the
+    //  reject-streak speculation: 8.38 ms on two against 8.50 on one -- a stage kernel's 25 k waves leave the other half's chain nothing to overlap with)
     const int nsub = (split || run_to_completion) ? 1 : h->nsub;
     int pass_of[corbo_hip_solver::MAX_SUB] = {0, 0, 0, 0};
     int left_of[corbo_hip_solver::MAX_SUB] = {0, 0, 0, 0};

@@ -4536,9 +4536,12 @@ __device__ __forceinline__ int32_t* cu_row_of(int32_t* table)
 #endif                           // 168 VGPRs, no spills, three workgroups per CU (diagnostics: attribution of the scratch traffic, profiles/r03_spill_attribution.json)
 // THREADS: 256 (four waves, 128 VGPRs at four workgroups per CU), 192 (three waves: 168 VGPRs at the same four workgroups per CU, i.e. the
 // same 1024 resident instances without the register spills of the 128-VGPR build -- VERDICT r3 item 1a) or 128 (two waves, 256 VGPRs).
-template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, int THREADS = SWEEP_THREADS>
+// DENSE (round 6): the instantiation for non-diagonal weights (four-wave shape only; a separate instantiation, so the diagonal problems' kernels carry none of its
+// registers) -- such handles ran every LM pass as two launches before.
+template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, int THREADS = SWEEP_THREADS, bool DENSE = false>
 __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS_WAVES : THREADS / 64)) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
+    static_assert(!DENSE || THREADS == SWEEP_THREADS, "non-diagonal weights: four-wave shape");
     constexpr int BK_LANE = (THREADS > 128) ? 128 : THREADS - 1;   // the lane that keeps the CU's progress row (a spare lane of wave 2 / the last lane)
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
@@ -4561,11 +4564,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
         if (tid == 0) flags[0] = 0;
         __syncthreads();
         if (sp.mode == 3 && sl->done) return;
-        sweep_body<DYN, DEFECT, true, false, false, THREADS>(sp, sp.mode, sp.active_count, sl, xs, red, cs, jst, inst, tid);
+        sweep_body<DYN, DEFECT, true, DENSE, false, THREADS>(sp, sp.mode, sp.active_count, sl, xs, red, cs, jst, inst, tid);
         __threadfence_block();  // this workgroup's residual / iterate stores are visible to its factor phase
         __syncthreads();
         if (!sl->done) {
-            factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC>(fp, sl, smem, inst, tid, flags[0] != 0);
+            factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, DENSE>(fp, sl, smem, inst, tid, flags[0] != 0);
             __syncthreads();
         }
         lm_state_out(fp.st + inst, sl, tid);
@@ -4646,7 +4649,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 }
                 constexpr bool TWOW = (THREADS <= 128);   // two-wave shape: Jacobian stream-out and bookkeeping ride inside the factor phase (factor_body, after_gather)
                 int scv[2 * Dy::NX + Dy::NU + 1];   // (two-wave shape) Jacobian offsets of lane k's defect edge: requested by the sweep phase, used by this pass's factor phase as well
-                sweep_body<DYN, DEFECT, true, false, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep, TWOW && max_passes > 0, TWOW ? scv : nullptr);   // (active_count: per-pass launches only)
+                sweep_body<DYN, DEFECT, true, DENSE, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep, TWOW && max_passes > 0, TWOW ? scv : nullptr);   // (active_count: per-pass launches only)
                 __threadfence_block();
                 __syncthreads();
                 if (stamp) fpl.pass_timeline[2 * pass + 1] = clock64();
@@ -4704,7 +4707,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 };
                 // (loop_passes = 0: ONE pass per launch -- the per-pass mode of corbo_hip_solve and the profiling mode; the trial iterate then
                 //  goes to HBM for the next launch instead of staying in the LDS array the next sweep phase evaluates it from)
-                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, false, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook, TWOW ? scv : nullptr, &smask);
+                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, DENSE, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook, TWOW ? scv : nullptr, &smask);
                 if constexpr (BK_DEFER) { if (bk_slot >= 0) bk_rank(); }
                 __threadfence_block();
                 __syncthreads();
@@ -5469,7 +5472,6 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
 {
     using Dy = Dynamics<DYN>;
     if (fp.N > SWEEP_THREADS) return false;
-    if (fp.wdense_mask) return false;   // non-diagonal weights: separate launches only (see sweep_body)
     if (sp.n_xedges > 0) return launch_bt_t<DYN, DEFECT>(fp, sp, stream);   // extra edges: the block-tridiagonal route (bt_factor.hpp)
     size_t dbl = FactorLds<Dy::NX, Dy::NU>::total(fp.N | 1, fp.dt_free != 0);
     if (dbl < (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC) dbl = (size_t)fp.nnz_pad + (size_t)fp.N * Dy::NC;  // staging + caches
@@ -5489,6 +5491,15 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     // "pass_threads" (256 / 128) forces a shape (A/B measurements).
     const bool two_ok = fp.N + Dy::NX + 1 <= 128;
     const bool two    = two_ok && fp.pass_threads != 256;
+    if (fp.wdense_mask) {   // non-diagonal weights: the DENSE instantiation (four waves)
+        if constexpr (Dy::NX <= 4) {
+            const dim3 b(SWEEP_THREADS);
+            if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0, SWEEP_THREADS, true>), dim3(grid), b, lds, stream, fp, sp);
+            else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0, SWEEP_THREADS, true>), dim3(grid), b, lds, stream, fp, sp);
+            return true;
+        }
+        else return false;
+    }
     {
         if (two) {
             const dim3 b(128);

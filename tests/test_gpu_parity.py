@@ -621,3 +621,26 @@ def test_counted_converged_iterations_change_nothing(cfg):
     # (cfg 2, time-optimal with a free dt far from its optimum, still accepts a step in every iteration of its fourth solve: nothing to count there)
     if cfg != 2:
         assert out[0][-1][3]["accepted_steps"] < 10 * B
+
+
+@pytest.mark.parametrize("name", ["unicycle_n12_fullq", "cartpole_fullq", "vdp_fullq"])
+def test_dense_weights_run_to_completion_equals_separate_launches(name):
+    """Round 6: handles with non-diagonal weights (up to 256 grid points) solve in ONE launch (lm_pass_kernel<.., DENSE>); with corbo_hip_set_profiling the phases of
+    every LM pass are separate launches (the stand-alone DENSE kernels: what these handles ran until round 5).  Same arithmetic: identical results."""
+    g = load_golden(name)
+    d = desc_for(g)
+    out = []
+    for prof in (False, True):
+        s = BatchedLevenbergMarquardt(d, 5)
+        s.setIterations(g["after_iter"][-1]["k"])
+        s.setPenaltyWeights(*g["weights"])
+        rng = np.random.default_rng(7)
+        X0 = s.init_trajectory(np.tile(g["x0"], (5, 1)), np.tile(g["xf"], (5, 1))) + 0.01 * rng.standard_normal((5, s.dims.nv)) * (np.arange(5)[:, None] > 0)
+        X0[:, : d.nx] = np.array(g["x0"])
+        s.set_instance_data(X0, xref=np.tile(g["xf"], (5, 1)))
+        s.set_profiling(prof)
+        s.solve()
+        out.append([a.copy() for a in s.get_solution()] + [s.get_stats()])
+    assert np.array_equal(out[0][2], out[1][2])
+    assert out[0][3]["factorizations"] == out[1][3]["factorizations"] and out[0][3]["accepted_steps"] == out[1][3]["accepted_steps"]
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-9) and np.abs(out[0][0] - out[1][0]).max() <= 1e-8
