@@ -595,6 +595,36 @@ bool identifyBall(BaseEdge& e, VertexInterface* v, double* prm /*cx, cy, cz, r*/
     return true;
 }
 
+// A USER stage function of csrc/stage_functions/ (kind 0: the stage inequalities' state term on x_k, kind 1: their control term on u_k): the edge's value against
+// the device's own formula -- corbo_hip_eval_stage_function evaluates the very template the kernels compile -- at probe points.  Parameters: the shipped
+// examples have the form f(v) - prm[0]^2, so prm[0] = sqrt(-c(0)) (README.md there: a function with other parameters is matched with the registered defaults).
+bool identifyUserStageFunction(BaseEdge& e, VertexInterface* v, int kind, int32_t& id_out, double* prm /*[8]*/)
+{
+    const int n = v->getDimension();
+    if (e.getDimension() != 1) return false;
+    VertexGuard guard(v);
+    double* x = v->getDataRaw();
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    const double c0 = evalEdge(e)[0];
+    for (int slot = 0; slot < 16; ++slot)
+    {
+        const int id = CORBO_HIP_STAGE_FN_USER + slot;
+        if (corbo_hip_stage_function_kind(id) != kind) continue;
+        double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c0 < 0) p[0] = std::sqrt(-c0);
+        bool ok = true;
+        for (int q = 0; q < 5 && ok; ++q)
+        {
+            for (int i = 0; i < n; ++i) x[i] = (q == 0) ? 0.0 : 0.3 * std::sin(0.7 + 1.3 * i + 2.1 * q);
+            double mine = 0.0;
+            if (corbo_hip_eval_stage_function(id, n, 1, x, p, &mine) != CORBO_HIP_OK) { ok = false; break; }
+            ok = std::abs(evalEdge(e)[0] - mine) <= 1e-13 * (1.0 + std::abs(mine));
+        }
+        if (ok) { id_out = id; std::memcpy(prm, p, sizeof(p)); return true; }
+    }
+    return false;
+}
+
 // A scalar term  scale * sum_i q_i (x_i - ref_i)^2  (a cost in plain, non-least-squares form: quadratic_cost.cpp:133-138; the integrand of the
 // integral cost edges, finite_differences_collocation_edges.h:98-152, 323-368), diagonal and non-negative, evaluated through the edge itself.
 // The same term checked against a KNOWN model (the resident device model of the previous run): n + 1 evaluations instead of ~ 7 n.  The edge must
@@ -1304,18 +1334,38 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
     const std::vector<BaseEdge::Ptr>& ins = es->getInequalityEdges();
     size_t at = 0;
     {
-        double prm_k[4];
-        int n_ball = 0, n_dev = 0, n_int = 0;
+        double prm_k[8];
+        int n_ball = 0, n_dev = 0, n_int = 0, n_uctl = 0;
+        int32_t state_id = CORBO_HIP_INEQ_BALL;
         for (int k = 0; k < g.N - 1; ++k)
         {
             VertexInterface* x2 = (k + 1 < g.N - 1) ? g.xs[k + 1] : g.xf;
             if (at < ins.size() && ins[at]->getNumVertices() == 1 && ins[at]->getVertexRaw(0) == g.xs[k])
-            {
+            {   // the state term: the keep-out ball, or a user function dropped into csrc/stage_functions/ (kind state_ineq)
                 BaseEdge* e = ins[at].get();
-                if (!identifyBall(*e, g.xs[k], (n_ball == 0) ? d.ineq_params : prm_k))
-                    return fail(reason, "stage inequality " + std::to_string(k) + " is not a keep-out ball on the first three state components");
-                if (n_ball > 0 && std::memcmp(d.ineq_params, prm_k, sizeof(prm_k)) != 0) return fail(reason, "stage inequality varies along the horizon");
+                double* into = (n_ball == 0) ? d.ineq_params : prm_k;
+                for (int i = 0; i < 8; ++i) into[i] = 0.0;
+                int32_t id_k = CORBO_HIP_INEQ_BALL;
+                if (!identifyBall(*e, g.xs[k], into))
+                {
+                    for (int i = 0; i < 8; ++i) into[i] = 0.0;
+                    if (!identifyUserStageFunction(*e, g.xs[k], 0, id_k, into))
+                        return fail(reason, "stage inequality " + std::to_string(k) + " is neither a keep-out ball on the first three state components nor a registered user state function (csrc/stage_functions/)");
+                }
+                if (n_ball == 0) state_id = id_k;
+                else if (id_k != state_id || std::memcmp(d.ineq_params, prm_k, sizeof(prm_k)) != 0) return fail(reason, "stage inequality varies along the horizon");
                 ++n_ball; ++at;
+            }
+            if (at < ins.size() && ins[at]->getNumVertices() == 1 && ins[at]->getVertexRaw(0) == g.us[k])
+            {   // the control term (nlp_functions.cpp:82-89): a user function of kind control_ineq
+                BaseEdge* e = ins[at].get();
+                int32_t id_k = 0;
+                double* into = (n_uctl == 0) ? d.ineq_control_params : prm_k;
+                if (!identifyUserStageFunction(*e, g.us[k], 1, id_k, into))
+                    return fail(reason, "inequality edge on u_" + std::to_string(k) + " is not a registered user control function (csrc/stage_functions/, kind=control_ineq)");
+                if (n_uctl == 0) d.stage_ineq_control = id_k;
+                else if (id_k != d.stage_ineq_control || std::memcmp(d.ineq_control_params, prm_k, sizeof(prm_k)) != 0) return fail(reason, "the stage inequalities' control term varies along the horizon");
+                ++n_uctl; ++at;
             }
             if (at < ins.size() && dynamic_cast<ControlDeviationEdge*>(ins[at].get()))
             {
@@ -1345,9 +1395,10 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
                 ++n_int; ++at;
             }
         }
-        if ((n_ball && n_ball != g.N - 1) || (n_dev && n_dev != g.N - 1) || (n_int && n_int != g.N - 1) || (n_ball && n_int))
+        if ((n_ball && n_ball != g.N - 1) || (n_dev && n_dev != g.N - 1) || (n_int && n_int != g.N - 1) || (n_ball && n_int) || (n_uctl && n_uctl != g.N - 1))
             return fail(reason, "stage inequality terms that are not created on every interval (or both a non-integral and an integral state term)");
-        if (n_ball || n_int) d.stage_ineq = CORBO_HIP_INEQ_BALL;
+        if (n_ball) d.stage_ineq = state_id;
+        else if (n_int) d.stage_ineq = CORBO_HIP_INEQ_BALL;
         d.stage_ineq_integral = n_int ? 1 : 0;
         d.ctrl_dev = n_dev ? CORBO_HIP_CTRL_DEV_RATE : CORBO_HIP_CTRL_DEV_NONE;
     }
@@ -1372,7 +1423,7 @@ bool recogniseHyperGraphForHip(BaseHyperGraphOptimizationProblem& hg, HipRecogni
             return fail(reason, "final control-deviation edge is not the input-rate limit of the intervals");
         ++at;
     }
-    if (at != ins.size()) return fail(reason, "inequality edges the device cannot describe (kinds: keep-out ball on x_k or as integrand, input-rate limit, TerminalBall)");
+    if (at != ins.size()) return fail(reason, "inequality edges the device cannot describe (kinds: keep-out ball / a registered user function on x_k, a registered user function on u_k, the ball as integrand, input-rate limit, TerminalBall)");
     d.constraint_integration = integral_rule;
     // (the control-deviation term is a non-integral term: the shooting grids create its edges too, multiple_shooting_grid.cpp:62, 193-197)
     if ((d.stage_eq || d.stage_ineq_integral) && (g.kind != CORBO_HIP_GRID_FD && g.kind != CORBO_HIP_GRID_FD_VARIABLE))

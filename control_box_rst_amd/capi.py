@@ -48,6 +48,7 @@ class ProblemDesc(C.Structure):
         ("q_sqrt", C.c_double * 16), ("r_sqrt", C.c_double * 16), ("qf_sqrt", C.c_double * 16),
         ("constraint_integration", C.c_int32), ("stage_ineq_integral", C.c_int32), ("stage_eq", C.c_int32), ("ctrl_dev", C.c_int32),
         ("stage_eq_params", C.c_double * (MAX_NX + MAX_NU + 1)), ("ctrl_dev_params", C.c_double * MAX_NU),
+        ("stage_ineq_control", C.c_int32), ("reserved0", C.c_int32), ("ineq_control_params", C.c_double * 8),
     ]
 
 
@@ -87,6 +88,7 @@ def default_lm_opts(iterations=10, w_eq=2.0, w_ineq=2.0, w_bounds=2.0) -> LmOpts
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1   # corbo_hip_integrator
 
 ROUTE_FREE_DT_BAND, ROUTE_XE_BAND = 1, 2   # corbo_hip_create_routed
+STAGE_FN_USER = 1000                        # CORBO_HIP_STAGE_FN_USER: + slot of a user stage function (csrc/stage_functions/)
 
 # CORBO_HIP_LIB: A/B measurements of two builds of the same C-ABI in one GPU session (development only)
 _LIB_PATH = os.environ.get("CORBO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcorbo_hip.so")
@@ -103,7 +105,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
     "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_eval_hessians_views", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
-    "corbo_hip_sizeof", "corbo_hip_set_previous_control", "corbo_hip_get_phase_cycles", "corbo_hip_create_routed",
+    "corbo_hip_sizeof", "corbo_hip_set_previous_control", "corbo_hip_get_phase_cycles", "corbo_hip_create_routed", "corbo_hip_stage_function_kind", "corbo_hip_eval_stage_function",
 )
 
 
@@ -140,6 +142,8 @@ def load() -> C.CDLL:
     lib.corbo_hip_get_structure.argtypes = [C.POINTER(ProblemDesc), ip, ip]
     lib.corbo_hip_init_trajectory.argtypes = [C.POINTER(ProblemDesc), C.c_int, dp, dp, dp]
     lib.corbo_hip_create.argtypes = [C.POINTER(ProblemDesc), C.c_int, C.c_int, C.POINTER(H)]
+    lib.corbo_hip_stage_function_kind.argtypes = [C.c_int]
+    lib.corbo_hip_eval_stage_function.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp]
     lib.corbo_hip_create_routed.argtypes = [C.POINTER(ProblemDesc), C.c_int, C.c_int, C.c_uint32, C.POINTER(H)]
     lib.corbo_hip_destroy.argtypes = [H]
     lib.corbo_hip_destroy.restype = None

@@ -88,6 +88,14 @@ struct DeviceGuard {
     catch (const std::exception& e) { return fail(CORBO_HIP_ERR_DEVICE, std::string("exception: ") + e.what()); } \
     catch (...) { return fail(CORBO_HIP_ERR_DEVICE, "unknown exception"); }
 
+// corbo_hip_eval_stage_function: the user stage functions (model.hpp) on the host, by vertex dimension
+template <int DIM>
+void eval_stage_fn(int id, int kind, int n, const double* v, const double* prm, double* out)
+{
+    for (int p = 0; p < n; ++p)
+        out[p] = (kind == 1) ? stage_ineq_control<DIM>(id, v + (size_t)p * DIM, prm) : stage_ineq_state<DIM>(id, v + (size_t)p * DIM, prm);
+}
+
 // per-phase events of a profiled solve: destroyed on every exit path
 struct EventList {
     std::vector<hipEvent_t> v;
@@ -252,10 +260,11 @@ struct corbo_hip_solver {
         p.batch = active; p.nvs = S.nvs; p.m = S.dims.m; p.nnz = S.dims.nnz; p.N = S.N; p.s = S.s; p.nx = S.nx; p.off_dt = S.off_dt; p.dt_free = S.dt_free;
         p.batch_total = batch + spare; p.xe0 = d_xe0; p.skip_jac = (d_xe0 && mode >= 2 && band.n == 0) ? 1 : 0;   // (band route: the factorisation reads the stored Jacobian)
         p.eq_row0 = S.eq_row0; p.ineq_row0 = S.ineq_row0;
-        p.ineq_stride = 1 + ((S.desc.ctrl_dev && S.desc.stage_ineq != CORBO_HIP_INEQ_NONE && !S.desc.stage_ineq_integral) ? S.nu : 0);   // (creation order per interval: state term, control-deviation term)
+        p.ineq_stride = 1 + (S.desc.stage_ineq_control ? 1 : 0) + (S.desc.ctrl_dev ? S.nu : 0);   // (creation order per interval: state term, control term, control-deviation term)
         p.stage_cols = d_stage_cols; p.comp = d_comp; p.ineq_cols = d_ineq_cols;
         fill_dyn(p.mp.dyn);
         std::memcpy(p.mp.ineq, S.desc.ineq_params, sizeof(p.mp.ineq));
+        p.mp.ineq_id = S.desc.stage_ineq; p.mp.ineq_ctrl_id = S.desc.stage_ineq_control;
         std::memcpy(p.mp.sq, S.sq, sizeof(p.mp.sq));
         std::memcpy(p.mp.sr, S.sr, sizeof(p.mp.sr));
         std::memcpy(p.mp.sqf, S.sqf, sizeof(p.mp.sqf));
@@ -545,9 +554,10 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         std::vector<XEdge> xe = S.xedges;   // (Jacobian offsets: the device-internal layout is the public order for these handles)
         CREATE_TRY(hipMalloc((void**)&h->d_xedges, xe.size() * sizeof(XEdge)));
         CREATE_TRY(hipMemcpy(h->d_xedges, xe.data(), xe.size() * sizeof(XEdge), hipMemcpyHostToDevice));
-        std::vector<double> xp(CORBO_HIP_MAX_NX + 2 * CORBO_HIP_MAX_NU + 2, 0.0);
+        std::vector<double> xp(CORBO_HIP_MAX_NX + 2 * CORBO_HIP_MAX_NU + 2 + 8, 0.0);   // [stage_eq: a, b, c | ctrl_dev: r_max | control inequality: 8 parameters]
         for (int i = 0; i < S.nx + S.nu + 1; ++i) xp[i] = S.desc.stage_eq_params[i];
         for (int i = 0; i < S.nu; ++i) xp[S.nx + S.nu + 1 + i] = S.desc.ctrl_dev_params[i];
+        for (int i = 0; i < 8; ++i) xp[S.nx + 2 * S.nu + 1 + i] = S.desc.ineq_control_params[i];
         CREATE_TRY(hipMalloc((void**)&h->d_xparams, xp.size() * sizeof(double)));
         CREATE_TRY(hipMemcpy(h->d_xparams, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice));
         std::vector<double> up(B * (CORBO_HIP_MAX_NU + 1), 0.0);
@@ -2177,6 +2187,33 @@ int corbo_hip_time_factor(corbo_hip_handle h, int repeat, float* ms_per_launch, 
     }
     return CORBO_HIP_OK;
 }
+
+int corbo_hip_stage_function_kind(int id)
+{
+#if __has_include("stage_functions/_registry.inc")
+#define CORBO_HIP_USER_STAGE(NAME, SLOT, KIND_, NXMIN) if (id == CORBO_HIP_STAGE_FN_USER + SLOT) return KIND_;
+#include "stage_functions/_registry.inc"
+#undef CORBO_HIP_USER_STAGE
+#endif
+    (void)id;
+    return -1;
+}
+
+int corbo_hip_eval_stage_function(int id, int dim, int n, const double* v, const double* prm, double* out)
+try {
+    if (!v || !prm || !out || n < 1 || dim < 1 || dim > CORBO_HIP_MAX_NX) return fail(CORBO_HIP_ERR_INVALID, "bad argument");
+    const int kind = (id == CORBO_HIP_INEQ_BALL) ? 0 : corbo_hip_stage_function_kind(id);
+    if (kind < 0) return fail(CORBO_HIP_ERR_INVALID, "not a registered stage function");
+    switch (dim) {   // (the functions are templates on the vertex dimension, like the kernels instantiate them)
+#define CORBO_HIP_SF_DIM(D) case D: eval_stage_fn<D>(id, kind, n, v, prm, out); break;
+        CORBO_HIP_SF_DIM(1) CORBO_HIP_SF_DIM(2) CORBO_HIP_SF_DIM(3) CORBO_HIP_SF_DIM(4) CORBO_HIP_SF_DIM(5) CORBO_HIP_SF_DIM(6)
+        CORBO_HIP_SF_DIM(7) CORBO_HIP_SF_DIM(8) CORBO_HIP_SF_DIM(9) CORBO_HIP_SF_DIM(10) CORBO_HIP_SF_DIM(11) CORBO_HIP_SF_DIM(12)
+#undef CORBO_HIP_SF_DIM
+        default: return fail(CORBO_HIP_ERR_INVALID, "dimension out of range");
+    }
+    return CORBO_HIP_OK;
+}
+ABI_CATCH
 
 int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const double* x, const double* u, double* f)
 try {

@@ -204,7 +204,7 @@ __device__ __forceinline__ double dense_weight_row(const double* U, int c, int d
 // in the reference's operation order (finite_differences_collocation_edges.h:149-459: 0.5 * dt * (c1 + c2) resp. c1, then *= dt; the plug-in
 // stage functions as oracle/ref_driver.cpp states them).  loc[vi][c]: component c of attached vertex vi.
 template <int NX, int NU>
-__device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc)[4][(NX > NU ? NX : NU)], const double* xp, const double* ineqp, double (&out)[4])
+__device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc)[4][(NX > NU ? NX : NU)], const double* xp, const ModelParams& mp, double (&out)[4])
 {
     constexpr int MC = (NX > NU) ? NX : NU;   // components of the widest attached vertex
     auto lin = [&](const double (&x)[MC], const double (&u)[MC]) {   // a^T x + b^T u - c, summed left to right
@@ -215,9 +215,11 @@ __device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc
         for (int i = 0; i < NU; ++i) acc += xp[NX + i] * u[i];
         return acc - xp[NX + NU];
     };
-    auto ball = [&](const double (&x)[MC]) {
-        if constexpr (NX >= 3) { const double v[3] = {x[0], x[1], x[2]}; return ineq_ball(v, ineqp); }
-        else return 0.0;
+    auto ball = [&](const double (&x)[MC]) {   // the stage inequalities' integral term: the keep-out ball or a user state function (model.hpp stage_ineq_state)
+        double v[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) v[i] = x[i];
+        return stage_ineq_state<NX>(mp.ineq_id, v, mp.ineq);
     };
     out[0] = out[1] = out[2] = out[3] = 0.0;
     switch (xe.kind) {
@@ -229,6 +231,13 @@ __device__ __forceinline__ void xedge_values(const XEdge& xe, const double (&loc
         }
         case EK_XI_EQ_LEFT: out[0] = lin(loc[0], loc[1]); out[0] *= loc[2][0]; break;
         case EK_XI_EQ_ROW: { const double e1 = lin(loc[0], loc[1]), e2 = lin(loc[2], loc[1]); out[0] = 0.5 * loc[3][0] * (e1 + e2); break; }
+        case EK_U_INEQ: {   // the stage inequalities' non-integral control term c(u_k): a user function (csrc/stage_functions/), parameters behind the rate limits'
+            double v[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) v[i] = loc[0][i];
+            out[0] = stage_ineq_control<NU>(mp.ineq_ctrl_id, v, xp + NX + 2 * NU + 1);
+            break;
+        }
         default:   // EK_CTRL_DEV: ((u_k - u_prev) / dt_prev)^2 - r_max^2 per control
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
@@ -729,9 +738,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             sq_acc += val * val;
             if constexpr (LEAN) kt.r[i] = val;
         }
-        if constexpr (NX >= 3) {
+        {
             if (p.ineq_cols) {  // computeValuesActiveInequality (hyper_graph_optimization_problem_base.cpp:278-289)
-                double ci = ineq_ball(xs + base, p.mp.ineq);
+                double xl_[NX];   // (a private copy: the function sees one address space at every call site)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xl_[i] = xs[base + i];
+                double ci = stage_ineq_state<NX>(p.mp.ineq_id, xl_, p.mp.ineq);
                 ci        = (ci < 0) ? 0.0 : ci * p.w_ineq;
                 put_value(p.ineq_row0 + k * p.ineq_stride, ci);
                 sq_acc += ci * ci;
@@ -771,7 +783,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             const XEdge xe = p.xedges[i];
             double loc[4][XMC], out[4];
             xe_load(xe, loc);
-            xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, out);
+            xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, out);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (j < xe.dim) {
@@ -1116,13 +1128,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
         }
     }
     // (3) stage inequality rows (active rows only, explicit zero otherwise, :1568-1610)
-    if constexpr (NX >= 3) {
+    {
         if (p.ineq_cols) {
             for (int k = tid; k < p.N - 1; k += THREADS) {
                 double loc[NX];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) loc[i] = xs[k * S + i];
-                const double c0   = ineq_ball(loc, p.mp.ineq);
+                const double c0   = stage_ineq_state<NX>(p.mp.ineq_id, loc, p.mp.ineq);
                 const bool active = (((c0 < 0) ? 0.0 : c0 * p.w_ineq) > 0.0);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
@@ -1130,9 +1142,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     if (jo < 0) continue;
                     const double keep = loc[i];
                     loc[i] += delta;
-                    const double c2 = ineq_ball(loc, p.mp.ineq);
+                    const double c2 = stage_ineq_state<NX>(p.mp.ineq_id, loc, p.mp.ineq);
                     loc[i] += neg2delta;
-                    const double c1 = ineq_ball(loc, p.mp.ineq);
+                    const double c1 = stage_ineq_state<NX>(p.mp.ineq_id, loc, p.mp.ineq);
                     loc[i]  = keep;
                     jst[jo] = active ? (scalar * (c2 - c1)) * p.w_ineq : 0.0;
                 }
@@ -1167,7 +1179,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
             const XEdge xe = p.xedges[i];
             double loc[4][XMC], f0[4];
             xe_load(xe, loc);
-            xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, f0);
+            xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, f0);
 #pragma unroll
             for (int vi = 0; vi < 4; ++vi) {
                 if (vi >= xe.nverts || xe.joff[vi] < 0) continue;
@@ -1178,9 +1190,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
                     const double keep = loc[vi][c];
                     double v2[4], v1[4];
                     loc[vi][c] += delta;
-                    xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, v2);
+                    xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, v2);
                     loc[vi][c] += neg2delta;
-                    xedge_values<NX, NU>(xe, loc, p.xparams, p.mp.ineq, v1);
+                    xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, v1);
                     loc[vi][c] = keep;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -2967,7 +2979,9 @@ __device__ __forceinline__ void big_assemble_stage(const BigCtx<NX, NU>& c, cons
 //      re-assembled from the (unchanged) accepted iterate with the larger damping -- same bits, no Jacobian traffic at all.
 //      jac_dump (parity hook, corbo_hip_eval): the Jacobian values this kernel works with, written in the public value order.
 #pragma clang fp contract(off)
-template <int DYN, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING, bool ARROW = false>
+// USERINEQ: the stage inequality is a user state function (csrc/stage_functions/) -- an instantiation of its own, so that the keep-out ball's kernels (cfg 5)
+// are what they were: its three-component copies, no branch (an out-of-line helper behind a uniform branch cost cfg 5 8.05 -> 8.41 ms per solve: 192 bytes of scratch per lane)
+template <int DYN, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING, bool ARROW = false, bool USERINEQ = false>
 __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const SweepParams& sp, const BigCtx<Dynamics<DYN>::NX, Dynamics<DYN>::NU>& c,
                                                 const int k, const int l32, const int inst, const int vsel, double* jac_dump)
 {
@@ -3118,16 +3132,32 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
         }
         double cinv = 0.0, rin = 0.0;
         if (stage && p.ineq_cols) {   // computeValuesActiveInequality + its active-row Jacobian (sweep_body (b), (3))
-            double q[3];
+            double c0, c2, c1;
+            if constexpr (USERINEQ) {   // a user state function: all NX components in private copies, perturbed like BaseEdge::computeJacobian perturbs them
+                double q[NX];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) q[t] = X[kk * S + t];
-            const double c0 = ineq_ball(q, sp.mp.ineq);
+                for (int t = 0; t < NX; ++t) q[t] = X[kk * S + t];
+                c0 = stage_ineq_state<NX>(sp.mp.ineq_id, q, sp.mp.ineq);
+                const double up = X[kk * S + i] + delta;
+#pragma unroll
+                for (int t = 0; t < NX; ++t) q[t] = (t == i) ? up : X[kk * S + t];
+                c2 = stage_ineq_state<NX>(sp.mp.ineq_id, q, sp.mp.ineq);
+#pragma unroll
+                for (int t = 0; t < NX; ++t) q[t] = (t == i) ? up + neg2delta : X[kk * S + t];
+                c1 = stage_ineq_state<NX>(sp.mp.ineq_id, q, sp.mp.ineq);
+            }
+            else {   // the keep-out ball reads three components: three registers per copy (cfg 5's kernel)
+                double q[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) q[t] = X[kk * S + t];
+                c0 = ineq_ball(q, sp.mp.ineq);
+                double q2[3], q1[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { const double up = q[t] + delta; q2[t] = (t == i) ? up : q[t]; q1[t] = (t == i) ? up + neg2delta : q[t]; }
+                c2 = ineq_ball(q2, sp.mp.ineq); c1 = ineq_ball(q1, sp.mp.ineq);
+            }
             rin             = (c0 < 0) ? 0.0 : c0 * sp.w_ineq;
             const bool active = rin > 0.0;
-            double q2[3], q1[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) { const double up = q[t] + delta; q2[t] = (t == i) ? up : q[t]; q1[t] = (t == i) ? up + neg2delta : q[t]; }
-            const double c2 = ineq_ball(q2, sp.mp.ineq), c1 = ineq_ball(q1, sp.mp.ineq);
             const int jq = p.ineq_cols[kk * NX + i];
             cinv = (jq >= 0 && active) ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
             if (jac_dump && jq >= 0) jac_dump[jq] = active ? (scalar * (c2 - c1)) * sp.w_ineq : 0.0;
@@ -3242,7 +3272,7 @@ __device__ __forceinline__ void big_stage_edges(const FactorParams& p, const Swe
 }
 #pragma clang fp contract(fast)
 
-template <int DYN, bool USE_MFMA, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING, bool ARROW = false>
+template <int DYN, bool USE_MFMA, int DEFECT = CORBO_HIP_DEFECT_RK4_SHOOTING, bool ARROW = false, bool USERINEQ = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 registers: three waves per SIMD (170 without the cap, i.e. two; a cap of four spills 270 bytes and loses)
 void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag_only, double* jac_dump)
@@ -3274,7 +3304,7 @@ void big_stage_kernel(const FactorParams p, const SweepParams sp, const int diag
         for (int i = lane; i < BL::HALF; i += 64) reinterpret_cast<double2*>(sm)[i] = cache[i];
     }
     else
-    big_stage_edges<DYN, DEFECT, ARROW>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
+    big_stage_edges<DYN, DEFECT, ARROW, USERINEQ>(p, sp, half ? c1 : c0, 2 * pair + half, lane & 31, inst, vsel, jac_dump ? jac_dump + (size_t)inst * sp.nnz_pad : nullptr);
     __syncthreads();
     if (jac_dump) return;
     if (cache && diag_only)
@@ -5122,7 +5152,7 @@ struct HessEdge {
                 }
                 break;
             case EK_STAGE_INEQ:
-                if constexpr (NX >= 3) out[0] = ineq_ball(xl, mp.ineq);
+                out[0] = stage_ineq_state<NX>(mp.ineq_id, xl, mp.ineq);
                 break;
             case EK_FINAL_EQ:
                 if (mp.fin_eq_mask) {   // TerminalPartialEqualityConstraint (final_state_constraints.h:236-252): the active components only, in order
@@ -5700,35 +5730,43 @@ bool CORBO_HIP_CAT(stage_entry_, CORBO_HIP_DYN_TU_NAME)(const FactorParams& fp, 
     if (!sp.xe0 || (!fp.work && !jac_dump)) return false;
     const size_t lds = sizeof(double) * (size_t)BigLds<Dy::NX, Dy::NU>::TOTAL;
     const dim3 g((fp.N + 1) / 2, fp.batch), b(64);
+    // (a user state function as the stage inequality -- csrc/stage_functions/, only where one is registered for this state dimension -- : the USERINEQ instantiation)
+    const bool user_ineq = has_user_state_ineq<Dy::NX>() && sp.mp.ineq_id >= CORBO_HIP_STAGE_FN_USER;
+#define CORBO_HIP_STAGE_LAUNCH(DEFECT_, ARROW_)                                                                                                                             \
+    do {                                                                                                                                                                    \
+        if constexpr (has_user_state_ineq<Dy::NX>()) {                                                                                                                      \
+            if (user_ineq) { hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, DEFECT_, ARROW_, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true; } \
+        }                                                                                                                                                                   \
+        hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, DEFECT_, ARROW_, false>), g, b, lds, stream, fp, sp, diag_only, jac_dump);                             \
+        return true;                                                                                                                                                        \
+    } while (0)
+    (void)user_ineq;
     if (fp.dt_free) {   // free dt: the dt column of every defect edge and the border parts (second right-hand side of the chain)
         // (even block sizes only -- the partitioned chain carries the border)
         if constexpr (Dy::NX % 2 != 0) return false;
         else
         switch (fp.defect) {
             case CORBO_HIP_DEFECT_RK4_SHOOTING:
-                if ((int)sp.mp.dyn[7] >= 5) hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, DEFECT_SHOOTING_HIGH, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump);   // Runge-Kutta 5 / 6 / 7
-                else
-                hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_RK4_SHOOTING, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump);
-                return true;
-            case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
-            case CORBO_HIP_DEFECT_BACKWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_BACKWARD, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
-            case CORBO_HIP_DEFECT_MIDPOINT: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_MIDPOINT, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
-            case CORBO_HIP_DEFECT_CRANK_NICOLSON: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_CRANK_NICOLSON, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+                if ((int)sp.mp.dyn[7] >= 5) CORBO_HIP_STAGE_LAUNCH(DEFECT_SHOOTING_HIGH, true);   // Runge-Kutta 5 / 6 / 7
+                else CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_RK4_SHOOTING, true);
+            case CORBO_HIP_DEFECT_FORWARD: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_FORWARD, true);
+            case CORBO_HIP_DEFECT_BACKWARD: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_BACKWARD, true);
+            case CORBO_HIP_DEFECT_MIDPOINT: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_MIDPOINT, true);
+            case CORBO_HIP_DEFECT_CRANK_NICOLSON: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_CRANK_NICOLSON, true);
             default: return false;
         }
     }
     switch (fp.defect) {   // shooting (Runge-Kutta 4 / 3 / 2, Euler; 5 / 6 / 7: an instantiation of its own), or a collocation formula on the FiniteDifferencesGrid
         case CORBO_HIP_DEFECT_RK4_SHOOTING:
-            if ((int)sp.mp.dyn[7] >= 5) hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, DEFECT_SHOOTING_HIGH>), g, b, lds, stream, fp, sp, diag_only, jac_dump);
-            else
-            hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true>), g, b, lds, stream, fp, sp, diag_only, jac_dump);
-            return true;
-        case CORBO_HIP_DEFECT_FORWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_FORWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
-        case CORBO_HIP_DEFECT_BACKWARD: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_BACKWARD>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
-        case CORBO_HIP_DEFECT_MIDPOINT: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_MIDPOINT>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
-        case CORBO_HIP_DEFECT_CRANK_NICOLSON: hipLaunchKernelGGL((big_stage_kernel<CORBO_HIP_DYN_TU, true, CORBO_HIP_DEFECT_CRANK_NICOLSON>), g, b, lds, stream, fp, sp, diag_only, jac_dump); return true;
+            if ((int)sp.mp.dyn[7] >= 5) CORBO_HIP_STAGE_LAUNCH(DEFECT_SHOOTING_HIGH, false);
+            else CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_RK4_SHOOTING, false);
+        case CORBO_HIP_DEFECT_FORWARD: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_FORWARD, false);
+        case CORBO_HIP_DEFECT_BACKWARD: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_BACKWARD, false);
+        case CORBO_HIP_DEFECT_MIDPOINT: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_MIDPOINT, false);
+        case CORBO_HIP_DEFECT_CRANK_NICOLSON: CORBO_HIP_STAGE_LAUNCH(CORBO_HIP_DEFECT_CRANK_NICOLSON, false);
         default: return false;
     }
+#undef CORBO_HIP_STAGE_LAUNCH
 }
 // one factorisation of the big-block family: (first factorisation of a solve: diag pass + mu / stop) stage kernel, then the chain.  The
 // stacked chain kernel (big_chain2_kernel) is laid out for state blocks of 4, 8 or 12 rows; other sizes take the first formulation

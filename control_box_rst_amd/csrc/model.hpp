@@ -14,6 +14,8 @@ namespace corbo_hip {
 struct ModelParams {
     double dyn[8];
     double ineq[8];
+    int32_t ineq_id;               // corbo_hip_problem_desc::stage_ineq: CORBO_HIP_INEQ_BALL or a user stage function (stage_ineq_state below)
+    int32_t ineq_ctrl_id;          // corbo_hip_problem_desc::stage_ineq_control (stage_ineq_control below); its parameters travel with the extra edges' (SweepParams::xparams)
     double sq[CORBO_HIP_MAX_NX];   // sqrt(Q_ii)   (QuadraticFormCost::setWeightQ, quadratic_cost.cpp:59-67)
     double sr[CORBO_HIP_MAX_NU];   // sqrt(R_ii)
     double sqf[CORBO_HIP_MAX_NX];  // sqrt(Qf_ii)  (final_state_cost.cpp:60-68)
@@ -546,10 +548,64 @@ __device__ __forceinline__ double terminal_ball(const double* x, const double* x
 }
 
 // stage inequality on x_k (keep-out ball, cfg 5): c = r^2 - |pos - center|^2  (<= 0 feasible)
-__device__ __forceinline__ double ineq_ball(const double* x, const double* prm)
+__host__ __device__ __forceinline__ double ineq_ball(const double* x, const double* prm)
 {
     double dx = x[0] - prm[0], dy = x[1] - prm[1], dz = x[2] - prm[2];
     return prm[3] * prm[3] - (dx * dx + dy * dy + dz * dz);
+}
+
+// ---- user stage functions dropped into csrc/stage_functions/ (generated include list and registry: __graft_entry__.build(); README.md there):
+//      StageFunction<slot>::value<NV>(vertex, prm), public id CORBO_HIP_STAGE_FN_USER + slot
+constexpr int CORBO_HIP_STAGE_FN_STATE_INEQ = 0, CORBO_HIP_STAGE_FN_CONTROL_INEQ = 1;
+template <int SLOT> struct StageFunction;
+#if __has_include("stage_functions/_includes.inc")
+#include "stage_functions/_includes.inc"
+#endif
+// the stage inequalities' non-integral STATE term c(x_k) by descriptor id (corbo_hip_problem_desc::stage_ineq): the keep-out ball or a user function
+template <int NX>
+__host__ __device__ __forceinline__ double stage_ineq_state(int id, const double* x, const double* prm)
+{
+    if (id == CORBO_HIP_INEQ_BALL) {
+        if constexpr (NX >= 3) return ineq_ball(x, prm);
+        else return 0.0;
+    }
+#if __has_include("stage_functions/_registry.inc")
+    switch (id - CORBO_HIP_STAGE_FN_USER) {
+#define CORBO_HIP_USER_STAGE(NAME, SLOT, KIND_, NXMIN) \
+        case SLOT: if constexpr (KIND_ == CORBO_HIP_STAGE_FN_STATE_INEQ) return StageFunction<SLOT>::template value<NX>(x, prm); else break;
+#include "stage_functions/_registry.inc"
+#undef CORBO_HIP_USER_STAGE
+        default: break;
+    }
+#endif
+    return 0.0;
+}
+// is there a registered user state function this state dimension can carry?  (kernels that special-case the keep-out ball compile their general path only then)
+template <int NX>
+constexpr bool has_user_state_ineq()
+{
+    bool any = false;
+#if __has_include("stage_functions/_registry.inc")
+#define CORBO_HIP_USER_STAGE(NAME, SLOT, KIND_, NXMIN) any = any || (KIND_ == CORBO_HIP_STAGE_FN_STATE_INEQ && NX >= NXMIN);
+#include "stage_functions/_registry.inc"
+#undef CORBO_HIP_USER_STAGE
+#endif
+    return any;
+}
+// ... and their non-integral CONTROL term c(u_k) (corbo_hip_problem_desc::stage_ineq_control)
+template <int NU>
+__host__ __device__ __forceinline__ double stage_ineq_control(int id, const double* u, const double* prm)
+{
+#if __has_include("stage_functions/_registry.inc")
+    switch (id - CORBO_HIP_STAGE_FN_USER) {
+#define CORBO_HIP_USER_STAGE(NAME, SLOT, KIND_, NXMIN) \
+        case SLOT: if constexpr (KIND_ == CORBO_HIP_STAGE_FN_CONTROL_INEQ) return StageFunction<SLOT>::template value<NU>(u, prm); else break;
+#include "stage_functions/_registry.inc"
+#undef CORBO_HIP_USER_STAGE
+        default: break;
+    }
+#endif
+    return 0.0;
 }
 
 // ---- user models dropped into csrc/models/ (generated include list: __graft_entry__.build(); see models/README.md)

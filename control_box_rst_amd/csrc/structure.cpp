@@ -8,6 +8,19 @@
 
 namespace corbo_hip {
 
+// kind of a registered user stage function (csrc/stage_functions/_registry.inc): 0 state inequality, 1 control inequality; -1 = no such id (or nx below its nx_min)
+static int user_stage_kind(int id, int nx)
+{
+    (void)nx;
+#if __has_include("stage_functions/_registry.inc")
+#define CORBO_HIP_USER_STAGE(NAME, SLOT, KIND_, NXMIN) if (id == CORBO_HIP_STAGE_FN_USER + SLOT) return nx >= NXMIN ? KIND_ : -1;
+#include "stage_functions/_registry.inc"
+#undef CORBO_HIP_USER_STAGE
+#endif
+    (void)id;
+    return -1;
+}
+
 static bool finite_bound(double lb, double ub) { return lb > -CORBO_HIP_INF || ub < CORBO_HIP_INF; }  // vector_vertex.h:174-184
 
 std::string validate_desc(const corbo_hip_problem_desc& d)
@@ -67,7 +80,9 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
         return "cost_integral on the MultipleShootingGrid (MultipleShootingEdgeSingleControl): diagonal Q / R, no stage inequality, nx <= 8";
     if (d.quad_first_interval < 0 || d.quad_first_interval > d.N - 1) return "quad_first_interval out of range";
     if (d.quad_first_interval != 0 && d.stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return "quad_first_interval: MinTimeQuadratic only";
-    if (d.stage_ineq < CORBO_HIP_INEQ_NONE || d.stage_ineq > CORBO_HIP_INEQ_BALL) return "unknown stage inequality";
+    if (!(d.stage_ineq >= CORBO_HIP_INEQ_NONE && d.stage_ineq <= CORBO_HIP_INEQ_BALL) && user_stage_kind(d.stage_ineq, d.nx) != 0) return "unknown stage inequality (user state functions: csrc/stage_functions/, kind=state_ineq, nx >= its nx_min)";
+    if (d.stage_ineq_control != 0 && user_stage_kind(d.stage_ineq_control, d.nx) != 1) return "stage_ineq_control: not a registered control_ineq function (csrc/stage_functions/)";
+    if (d.stage_ineq_control != 0 && (d.cost_nonlsq || d.cost_integral)) return "stage_ineq_control: Levenberg-Marquardt path only";
     if (d.stage_ineq == CORBO_HIP_INEQ_BALL && d.nx < 3) return "ball inequality needs nx >= 3";
     if (d.final_ineq < CORBO_HIP_FINAL_INEQ_NONE || d.final_ineq > CORBO_HIP_FINAL_INEQ_TERMINAL_BALL) return "unknown final-stage inequality";
     if (d.final_ineq != CORBO_HIP_FINAL_INEQ_NONE && d.nx > 4 && !big_family_dims(d.nx, d.nu)) return "terminal ball: families with nx <= 4, and the big-block family";
@@ -101,7 +116,7 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
     }
     if (!(d.dt_ref > 0)) return "dt_ref must be > 0";
     {   // integral-form constraints / control-deviation term (user stage functions of the reference)
-        const bool any = d.stage_ineq_integral || d.stage_eq || d.ctrl_dev;
+        const bool any = d.stage_ineq_integral || d.stage_eq || d.ctrl_dev || d.stage_ineq_control;
         if (d.constraint_integration < 0 || d.constraint_integration > 2) return "constraint_integration: 0, 1 (trapezoidal rule) or 2 (left sum)";
         if (d.stage_ineq_integral != 0 && d.stage_ineq_integral != 1) return "stage_ineq_integral must be 0 or 1";
         if (d.stage_ineq_integral && (d.stage_ineq == CORBO_HIP_INEQ_NONE || !d.constraint_integration)) return "stage_ineq_integral needs a stage inequality and a constraint_integration rule";
@@ -186,6 +201,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
         // (creation order inside an interval, finite_differences_grid.cpp:49-125: the non-integral terms of the stage functions -- inequalities: state
         //  term, then control-deviation term, nlp_functions.cpp:70-131 --, then the integral equality / dynamics edges, then the integral inequality)
         if (d.stage_ineq != CORBO_HIP_INEQ_NONE && !d.stage_ineq_integral) ineq.push_back({EK_STAGE_INEQ, k, 1, 2});
+        if (d.stage_ineq_control) ineq.push_back({EK_U_INEQ, k, 1, 2});   // the control term's edge on u_k (nlp_functions.cpp:82-89)
         if (d.ctrl_dev) ineq.push_back({EK_CTRL_DEV, k, nu, 2});
         if (d.stage_eq && d.constraint_integration == 2) eq.push_back({EK_XI_EQ_LEFT, k, 1, 1});
         eq.push_back({EK_DEFECT, k, (d.stage_eq && d.constraint_integration == 1) ? nx + 1 : nx, 1});
@@ -241,6 +257,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
                 if (d.constraint_integration == 1) { v[2] = {(k + 1) * s, nx}; v[3] = {S.off_dt, 1}; return 4; }
                 v[2] = {S.off_dt, 1}; return 3;
             case EK_XI_EQ_LEFT: v[0] = {k * s, nx}; v[1] = {k * s + nx, nu}; v[2] = {S.off_dt, 1}; return 3;
+            case EK_U_INEQ: v[0] = {k * s + nx, nu}; return 1;
             case EK_CTRL_DEV:   // (u_k, u_prev, dt_prev): finite_differences_grid.cpp:51-53; the last one on (u_ref, u_{N-2}, dt), :149
                 if (k == N) { v[0] = {-2, nu}; v[1] = {(N - 2) * s + nx, nu}; v[2] = {S.off_dt, 1}; return 3; }
                 v[0] = {k * s + nx, nu};
@@ -271,7 +288,7 @@ std::string build_structure(const corbo_hip_problem_desc& d, Structure& S)
     };
     auto add_list = [&](const std::vector<E>& list) {
         for (const E& e : list) {
-            if (e.kind == EK_XI_INEQ || e.kind == EK_XI_EQ_LEFT || e.kind == EK_CTRL_DEV) { add_extra(e); continue; }
+            if (e.kind == EK_XI_INEQ || e.kind == EK_XI_EQ_LEFT || e.kind == EK_CTRL_DEV || e.kind == EK_U_INEQ) { add_extra(e); continue; }
             if (e.kind == EK_DEFECT && e.dim > nx) {   // TrapezoidalIntegralEqualityDynamicsEdge: the appended row as an XEdge over the dynamics edge's blocks
                 XEdge x{};
                 XV v[4];

@@ -49,7 +49,8 @@ enum EdgeKind : int32_t {
     EK_XI_INEQ    = 17,     // TrapezoidalIntegralInequalityEdge (x_k, u_k, x_{k+1}, dt) / LeftSumInequalityEdge (x_k, u_k, dt)
     EK_XI_EQ_LEFT = 18,     // LeftSumEqualityEdge (x_k, u_k, dt)
     EK_XI_EQ_ROW  = 19,     // the integral row the trapezoidal rule appends to the dynamics edge (TrapezoidalIntegralEqualityDynamicsEdge: dimension nx + 1)
-    EK_CTRL_DEV   = 20      // TernaryVectorScalarVertexEdge<computeNonIntegralControlDeviationTerm> (u_k, u_prev, dt_prev)
+    EK_CTRL_DEV   = 20,     // TernaryVectorScalarVertexEdge<computeNonIntegralControlDeviationTerm> (u_k, u_prev, dt_prev)
+    EK_U_INEQ     = 21      // UnaryVectorVertexEdge<computeNonIntegralControlTerm> on u_k: a user stage inequality's control term (csrc/stage_functions/)
 };
 
 // One "extra" edge (the kinds above), evaluated by a lane of the sweep kernel's generic loop (sweep_body, XE): attached vertices with their storage

@@ -111,6 +111,12 @@ typedef enum corbo_hip_stage_ineq {
     CORBO_HIP_INEQ_NONE = 0,
     CORBO_HIP_INEQ_BALL = 1 /* c(x) = r^2 - |x[0:3]-c|^2 <= 0 : spherical keep-out, params = cx,cy,cz,r (cfg 5) */
 } corbo_hip_stage_ineq;
+/* User stage functions: a `StageFunction<slot>` specialisation dropped into control_box_rst_amd/csrc/stage_functions/ (README.md there) is registered by
+ * the build under the id CORBO_HIP_STAGE_FN_USER + slot, slot = 0 .. 15 -- the device-side counterpart of a user's own corbo::StageInequalityConstraint
+ * subclass (stage_functions.h:276-310).  kind = state_ineq: its non-integral STATE term c(x_k) (dimension 1), named in `stage_ineq`, parameters
+ * `ineq_params`; kind = control_ineq: its non-integral CONTROL term c(u_k) (dimension 1), named in `stage_ineq_control`, parameters `ineq_control_params`.
+ * Shipped examples: slot 0 = tilt cone x[6]^2 + x[7]^2 - alpha^2 (state), slot 1 = input magnitude |u|^2 - r^2 (control). */
+#define CORBO_HIP_STAGE_FN_USER 1000
 
 typedef enum corbo_hip_final_ineq {
     CORBO_HIP_FINAL_INEQ_NONE = 0,
@@ -127,7 +133,7 @@ typedef struct corbo_hip_problem_desc {
     int32_t dynamics;      /* corbo_hip_dynamics */
     int32_t stage_cost;    /* corbo_hip_stage_cost */
     int32_t final_cost;    /* 0 = none, 1 = QuadraticFinalStateCost(Qf, lsq=true), diagonal (final_state_cost.cpp:72-112) */
-    int32_t stage_ineq;    /* corbo_hip_stage_ineq */
+    int32_t stage_ineq;    /* corbo_hip_stage_ineq, or CORBO_HIP_STAGE_FN_USER + slot: a user state function (csrc/stage_functions/) */
     int32_t nx, nu, N;     /* state dim, control dim, grid points (N-1 intervals) */
     uint32_t xf_fixed_mask; /* bit i set = component i of x_f is fixed (setXfFixed, full_discretization_grid_base.h:89-93) */
     double dt_ref;         /* dt (fixed grids) or initial dt (free-dt grid) */
@@ -219,6 +225,13 @@ typedef struct corbo_hip_problem_desc {
     int32_t ctrl_dev;
     double stage_eq_params[CORBO_HIP_MAX_NX + CORBO_HIP_MAX_NU + 1];   /* CORBO_HIP_STAGE_EQ_LINEAR: a_1 .. a_nx, b_1 .. b_nu, c */
     double ctrl_dev_params[CORBO_HIP_MAX_NU];                          /* CORBO_HIP_CTRL_DEV_RATE: r_max per control */
+    /* The stage inequalities' non-integral CONTROL term (getNonIntegralControlTermDimension = 1): 0 = none, else CORBO_HIP_STAGE_FN_USER + slot of a
+     * registered `control_ineq` function -- one UnaryVectorVertexEdge on u_k per interval, created behind the state term's edge and in front of the
+     * control-deviation edge (nlp_functions.cpp:82-89).  An edge on u_k alone; every family and grid on the Levenberg-Marquardt path (handles with it take
+     * the extra-edge routes like the control-deviation term does). */
+    int32_t stage_ineq_control;
+    int32_t reserved0;
+    double ineq_control_params[8];
 } corbo_hip_problem_desc;
 
 typedef enum corbo_hip_stage_eq {
@@ -565,6 +578,13 @@ int corbo_hip_set_profiling(corbo_hip_handle h, int enable);
  * the descriptor are read.  Runs on the current HIP device.  Lets a caller check that a dynamics object it holds is the model a
  * descriptor names (the adapter's recogniser matches user systems against the library's plug-in models with it). */
 int corbo_hip_eval_dynamics(const corbo_hip_problem_desc* desc, int n, const double* x, const double* u, double* f);
+
+/* User stage functions (csrc/stage_functions/): kind of a registered id -- 0 state inequality, 1 control inequality, -1 = not registered -- and the value
+ * c(v, prm) of such a function (or of CORBO_HIP_INEQ_BALL) at n points, evaluated on the HOST by the very template the kernels compile: v [n][dim], out [n].
+ * Lets a caller check that a stage-function object it holds is the function an id names (the adapter's recogniser matches a graph's inequality edges with it,
+ * like corbo_hip_eval_dynamics for a dynamics object).  Needs no GPU. */
+int corbo_hip_stage_function_kind(int id);
+int corbo_hip_eval_stage_function(int id, int dim, int n, const double* v, const double* prm, double* out);
 
 /* Diagnostics and test hooks of a handle (nothing here is read from the environment):
  *   "pass_limit"        value > 0: the run-to-completion kernel gives up after `value` LM passes per instance instead of 4096

@@ -32,7 +32,8 @@ enum { E_STATE_COST, E_CONTROL_COST, E_FINAL_COST, E_DT_COST, E_DEFECT, E_STAGE_
        E_MS_MIXED_OBJ, E_MS_MIXED_EQ, /* the objective part and the equality part of one MultipleShootingEdgeSingleControl (a BaseMixedEdge) */
        E_INT_INEQ,     /* TrapezoidalIntegralInequalityEdge (x1, u1, x2, dt) / LeftSumInequalityEdge (x1, u1, dt) */
        E_INT_EQ_LEFT,  /* LeftSumEqualityEdge (x1, u1, dt); the trapezoidal rule appends its row to the dynamics edge instead (E_DEFECT with dim = nx + 1) */
-       E_CTRL_DEV };   /* TernaryVectorScalarVertexEdge<computeNonIntegralControlDeviationTerm> (u_k, u_prev, dt_prev) */
+       E_CTRL_DEV,     /* TernaryVectorScalarVertexEdge<computeNonIntegralControlDeviationTerm> (u_k, u_prev, dt_prev) */
+       E_U_INEQ };     /* UnaryVectorVertexEdge<computeNonIntegralControlTerm> (u_k): a user stage inequality's control term */
 
 typedef struct {
     int type;
@@ -403,10 +404,28 @@ static void dense_weight_times(const double* U, int n, const double* xd, double*
 }
 
 /* the plug-in stage functions (user classes in the reference; oracle/ref_driver.cpp UserStageInequalities / LinearIntegralEquality) */
-static double stage_ineq_value(const corbo_hip_problem_desc* d, const double* xk) /* keep-out ball: r^2 - |pos - c|^2 */
+/* the stage inequalities' non-integral STATE term (a user StageInequalityConstraint of the reference, stage_functions.h:276-310; oracle/ref_driver.cpp
+ * UserStageInequalities): the keep-out ball r^2 - |pos - c|^2, or a user function by id -- CORBO_HIP_STAGE_FN_USER + 0: the tilt cone
+ * x[6]^2 + x[7]^2 - alpha^2 (restated from the host class like csrc/stage_functions/tilt_cone.hpp restates it) */
+static double stage_ineq_value(const corbo_hip_problem_desc* d, const double* xk)
 {
+    if (d->stage_ineq == CORBO_HIP_STAGE_FN_USER + 0) return (xk[6] * xk[6] + xk[7] * xk[7]) - d->ineq_params[0] * d->ineq_params[0];
     double dx = xk[0] - d->ineq_params[0], dy = xk[1] - d->ineq_params[1], dz = xk[2] - d->ineq_params[2];
     return d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
+}
+/* ... and their non-integral CONTROL term: CORBO_HIP_STAGE_FN_USER + 1 = the input-magnitude bound u[0]^2 + ... - r^2 (summed left to right) */
+static double stage_ineq_control_value(const corbo_hip_problem_desc* d, const double* uk)
+{
+    double acc = 0.0;
+    for (int i = 0; i < d->nu; ++i) acc += uk[i] * uk[i];
+    return acc - d->ineq_control_params[0] * d->ineq_control_params[0];
+}
+static int stage_ineq_known(const corbo_hip_problem_desc* d)
+{
+    if (d->stage_ineq == CORBO_HIP_INEQ_NONE) return 1;
+    if (d->stage_ineq == CORBO_HIP_INEQ_BALL) return d->nx >= 3;
+    if (d->stage_ineq == CORBO_HIP_STAGE_FN_USER + 0) return d->nx >= 8;
+    return 0;
 }
 static double stage_eq_value(const corbo_hip_problem_desc* d, const double* xk, const double* uk) /* a^T x + b^T u - c, summed left to right */
 {
@@ -529,10 +548,12 @@ static void edge_values_at(const oracle_problem* p, const o_edge* e, double* out
             }
             break;
         }
-        case E_STAGE_INEQ: { /* user StageInequalityConstraint (state term), keep-out ball: c = r^2 - |pos - c|^2 <= 0 */
-            const double* xk = x + p->v[e->vert[0]].off;
-            double dx = xk[0] - d->ineq_params[0], dy = xk[1] - d->ineq_params[1], dz = xk[2] - d->ineq_params[2];
-            out[0] = d->ineq_params[3] * d->ineq_params[3] - (dx * dx + dy * dy + dz * dz);
+        case E_STAGE_INEQ: { /* user StageInequalityConstraint (state term): keep-out ball c = r^2 - |pos - c|^2 <= 0, or a user function by id */
+            out[0] = stage_ineq_value(d, x + p->v[e->vert[0]].off);
+            break;
+        }
+        case E_U_INEQ: { /* user StageInequalityConstraint (control term): UnaryVectorVertexEdge on u_k (nlp_functions.cpp:82-89) */
+            out[0] = stage_ineq_control_value(d, x + p->v[e->vert[0]].off);
             break;
         }
         case E_INT_INEQ: { /* finite_differences_collocation_edges.h:271-321 (0.5 * dt * (c1 + c2), both ends with u1) / :412-459 (c1, then *= dt) */
@@ -653,8 +674,8 @@ static int validate(const corbo_hip_problem_desc* d)
     if (d->cost_integral && d->grid == CORBO_HIP_GRID_MS && (d->stage_ineq || (d->weights_dense & 3))) return 0; /* MultipleShootingEdgeSingleControl: diagonal Q / R, no stage inequality */
     if (d->quad_first_interval < 0 || d->quad_first_interval > d->N - 1) return 0;
     if (d->quad_first_interval != 0 && d->stage_cost != CORBO_HIP_COST_MIN_TIME_QUADRATIC_LSQ) return 0;
-    if (d->stage_ineq < 0 || d->stage_ineq > CORBO_HIP_INEQ_BALL) return 0;
-    if (d->stage_ineq == CORBO_HIP_INEQ_BALL && d->nx < 3) return 0;
+    if (!stage_ineq_known(d)) return 0;
+    if (d->stage_ineq_control != 0 && d->stage_ineq_control != CORBO_HIP_STAGE_FN_USER + 1) return 0;
     if (!(d->dt_ref > 0)) return 0;
     return 1;
 }
@@ -664,7 +685,7 @@ static int validate_extra(const corbo_hip_problem_desc* d)
 {
     const int any = d->stage_ineq_integral || d->stage_eq || d->ctrl_dev;
     if (d->constraint_integration < 0 || d->constraint_integration > 2) return 0;
-    if (d->stage_ineq_integral && (d->stage_ineq != CORBO_HIP_INEQ_BALL || !d->constraint_integration)) return 0;
+    if (d->stage_ineq_integral && (d->stage_ineq == CORBO_HIP_INEQ_NONE || !d->constraint_integration)) return 0;
     if (d->stage_eq && (d->stage_eq != CORBO_HIP_STAGE_EQ_LINEAR || !d->constraint_integration)) return 0;
     if (d->ctrl_dev && d->ctrl_dev != CORBO_HIP_CTRL_DEV_RATE) return 0;
     /* the integral-form edges are classes of the finite-differences grids; the control-deviation term is a non-integral term that every grid creates
@@ -824,8 +845,11 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
                 o_edge* e = &lsq[n_lsq++]; e->type = E_DT_COST; e->k = k; e->nverts = 1; e->vert[0] = dt_vertex; e->dim = 1; e->scale = 0; e->nonlsq = d->cost_nonlsq;
             }
         }
-        if (d->stage_ineq == CORBO_HIP_INEQ_BALL && !d->stage_ineq_integral) {
+        if (d->stage_ineq != CORBO_HIP_INEQ_NONE && !d->stage_ineq_integral) {
             o_edge* e = &ineq[n_ineq++]; e->type = E_STAGE_INEQ; e->k = k; e->nverts = 1; e->vert[0] = xk; e->dim = 1; e->scale = 2;
+        }
+        if (d->stage_ineq_control) { /* nlp_functions.cpp:82-89: the control term's edge behind the state term's */
+            o_edge* e = &ineq[n_ineq++]; e->type = E_U_INEQ; e->k = k; e->nverts = 1; e->vert[0] = uk; e->dim = 1; e->scale = 2;
         }
         if (d->ctrl_dev) { /* nlp_functions.cpp:117-123 (behind the state term of the same stage function): (u_k, u_prev, dt_prev);
                             * finite_differences_grid.cpp:51-53: u_prev = k > 0 ? u_seq[k-1] : _u_prev, dt_prev = k > 0 ? _dt : _u_prev_dt */
@@ -839,7 +863,7 @@ oracle_problem* oracle_create(const corbo_hip_problem_desc* desc)
         o_edge* e = &eq[n_eq++]; e->type = E_DEFECT; e->k = k; e->nverts = 4; e->dim = nx; e->scale = 1;
         e->vert[0] = xk; e->vert[1] = uk; e->vert[2] = xnext; e->vert[3] = dt_vertex;
         if (d->stage_eq && d->constraint_integration == 1) e->dim = nx + 1; /* :82-88: TrapezoidalIntegralEqualityDynamicsEdge */
-        if (d->stage_ineq == CORBO_HIP_INEQ_BALL && d->stage_ineq_integral) { /* :107-122 */
+        if (d->stage_ineq != CORBO_HIP_INEQ_NONE && d->stage_ineq_integral) { /* :107-122 */
             o_edge* ei = &ineq[n_ineq++]; ei->type = E_INT_INEQ; ei->k = k; ei->dim = 1; ei->scale = 2;
             ei->vert[0] = xk; ei->vert[1] = uk;
             if (d->constraint_integration == 1) { ei->nverts = 4; ei->vert[2] = xnext; ei->vert[3] = dt_vertex; }

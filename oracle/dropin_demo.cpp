@@ -143,7 +143,18 @@ class UserStageInequalities : public StageInequalityConstraint
 {
  public:
     Eigen::VectorXd ball, rate;   // cx, cy, cz, r (integral term) / r_max per control (control-deviation term); empty = absent
+    double tilt = 0, unorm = 0;   // > 0: the tilt cone x[6]^2 + x[7]^2 - tilt^2 as the non-integral STATE term / the input-magnitude bound |u|^2 - unorm^2 as the
+                                  // non-integral CONTROL term -- user functions the device knows from csrc/stage_functions/ (matched by evaluation, not by name)
     StageInequalityConstraint::Ptr getInstance() const override { return std::make_shared<UserStageInequalities>(*this); }
+    int getNonIntegralStateTermDimension(int k) const override { return tilt > 0 ? 1 : 0; }
+    void computeNonIntegralStateTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, Eigen::Ref<Eigen::VectorXd> cost) const override { cost[0] = (x[6] * x[6] + x[7] * x[7]) - tilt * tilt; }
+    int getNonIntegralControlTermDimension(int k) const override { return unorm > 0 ? 1 : 0; }
+    void computeNonIntegralControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& u, Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        double acc = 0.0;
+        for (int i = 0; i < u.size(); ++i) acc += u[i] * u[i];
+        cost[0] = acc - unorm * unorm;
+    }
     int getIntegralStateControlTermDimension(int k) const override { return ball.size() == 4 ? 1 : 0; }
     void computeIntegralStateControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, const Eigen::Ref<const Eigen::VectorXd>& u,
                                          Eigen::Ref<Eigen::VectorXd> cost) const override
@@ -290,7 +301,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     // integral-form constraints / control-deviation term (user stage functions above): the ball as integrand (trapezoidal rule), a linear integral
     // equality (left sum), an input-rate limit with a previously applied control, and all three together
     const bool xe_ball = (scenario == "unicycle_xe_ball" || scenario == "unicycle_xe_all"), xe_eq = (scenario == "unicycle_xe_eq" || scenario == "unicycle_xe_all"),
-               xe_rate = (scenario == "unicycle_xe_rate" || scenario == "unicycle_xe_all"), xe = xe_ball || xe_eq || xe_rate;
+               xe_rate = (scenario == "unicycle_xe_rate" || scenario == "unicycle_xe_all"), sf_unorm = (scenario == "unicycle_sf_unorm"), xe = xe_ball || xe_eq || xe_rate || sf_unorm;
     const bool uni = (scenario == "unicycle" || xe || moved || tball || tballc || fullq || tvref || urefnz || kcar || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
     {
@@ -306,7 +317,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         for (int i = 0; i < 3; ++i) { d.q_diag[i] = q[i]; d.qf_diag[i] = 10.0 * q[i]; }
         for (int i = 0; i < 2; ++i) d.r_diag[i] = rr[i];
     }
-    else if (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5")
+    else if (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5" || scenario == "quad_sf_tilt")
     {
         dyn     = std::make_shared<QuadrotorRef>();
         if (scenario == "quad_topt")
@@ -449,7 +460,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         if (scenario == "vdp_msint") ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta3>());
         else ms_grid->setNumericalIntegrator(std::make_shared<IntegratorExplicitRungeKutta4>());
     }
-    const double dt = (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5" || scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate") ? 0.05 : 0.1;
+    const double dt = (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5" || scenario == "quad_sf_tilt" || scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate") ? 0.05 : 0.1;
     d.N = N; d.dt_ref = dt;
     if (mode == Mode::HipStatedWrong) d.r_diag[1] = 2.0 * d.r_diag[1];   // invisible at the reference's initial guess (u = 0)
     if (mode == Mode::Reference)
@@ -507,9 +518,10 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setStageCost(std::make_shared<QuadraticFormCost>(Q, R, itrap || ileft, !hpath));
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, !hpath));
         ocp.setBounds(Eigen::Vector3d::Constant(-10), Eigen::Vector3d::Constant(10), Eigen::Vector2d::Constant(-1), Eigen::Vector2d::Constant(1));
-        if (xe_ball || xe_rate)
+        if (xe_ball || xe_rate || sf_unorm)
         {
             auto c = std::make_shared<UserStageInequalities>();
+            if (sf_unorm) c->unorm = 0.7;   // a user stage function of csrc/stage_functions/ (control_norm.hpp): an inequality edge on every u_k
             if (xe_ball) { c->ball.resize(4); c->ball << 1.0, 0.5, 0.2, 0.3; }
             if (xe_rate) { c->rate.resize(2); c->rate << 0.9, 0.6; }
             ocp.setStageInequalityConstraint(c);
@@ -533,7 +545,7 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
             ocp.setFinalStageConstraint(c);
         }
     }
-    else if (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5")
+    else if (scenario == "quad" || scenario == "quad_topt" || scenario == "quad_rk5" || scenario == "quad_sf_tilt")
     {
         Eigen::VectorXd q(12), rr(4), ulb(4), uub(4);
         q << 1, 1, 1, 0.1, 0.1, 0.1, 0.5, 0.5, 0.5, 0.05, 0.05, 0.05;
@@ -548,6 +560,13 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
         ocp.setFinalStageCost(std::make_shared<QuadraticFinalStateCost>(Qf, true));
         }
         ocp.setControlBounds(ulb, uub);
+        if (scenario == "quad_sf_tilt")
+        {   // a user stage function of csrc/stage_functions/ (tilt_cone.hpp) instead of the keep-out ball
+            auto c = std::make_shared<UserStageInequalities>();
+            c->tilt = 0.15;
+            ocp.setStageInequalityConstraint(c);
+        }
+        else
         ocp.setStageInequalityConstraint(std::make_shared<BallKeepOut>(1.0, 0.5, 0.6, 0.4));
     }
     else if (scenario == "pquad" || scenario == "pquad_fd" || scenario == "pquad_topt" || scenario == "pquad_pteq" || scenario == "pquad_fd_xe_ball" || scenario == "pquad_xe_rate")
@@ -776,7 +795,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate", "quad_topt", "quad_rk5"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate", "quad_topt", "quad_rk5", "unicycle_sf_unorm", "quad_sf_tilt"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);
@@ -784,7 +803,7 @@ int main(int argc, char** argv)
         double diff = (a.ok && b.ok && a.traj.size() == b.traj.size()) ? (a.traj - b.traj).cwiseAbs().maxCoeff() : 1e300;
         printf("{\"scenario\": \"%s\", \"mode\": \"recognised\", \"ok_reference\": %d, \"ok_hip\": %d, \"chi2_reference\": %.17g, \"chi2_hip\": %.17g, \"max_abs_diff\": %.6e}\n",
                sc, a.ok ? 1 : 0, b.ok ? 1 : 0, a.chi2, b.chi2, diff);
-        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "quad_topt" || std::string(sc) == "quad_rk5" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd" || std::string(sc) == "pquad_topt" || std::string(sc) == "pquad_pteq" || std::string(sc) == "pquad_fd_xe_ball" || std::string(sc) == "pquad_xe_rate") ? 5e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
+        if (!(diff < ((std::string(sc) == "quad" || std::string(sc) == "quad_topt" || std::string(sc) == "quad_rk5" || std::string(sc) == "quad_sf_tilt" || std::string(sc) == "pquad" || std::string(sc) == "pquad_fd" || std::string(sc) == "pquad_topt" || std::string(sc) == "pquad_pteq" || std::string(sc) == "pquad_fd_xe_ball" || std::string(sc) == "pquad_xe_rate") ? 5e-4 : std::string(sc) == "unicycle_tvref" ? 3e-5 : 1e-5))) rc = 1;
     }
     // the operators of the exact-Hessian path for the same graphs, through the adapter: device against the graph's own methods
     for (const char* sc : {"unicycle", "dint", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "dint_mtq8", "rocket", "toy", "cartpole", "par2", "unicycle_fullq", "unicycle_plain", "unicycle_itrap", "unicycle_ileft", "unicycle_plain_stated", "vdp_plain", "vdp_itrap", "dint_plain", "unicycle_msint", "vdp_msint", "dint_mtq_itrap", "dint_mtq8_ileft", "unicycle_plain_tvref", "unicycle_msint_tvref"})

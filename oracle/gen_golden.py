@@ -428,6 +428,9 @@ BIGMODEL = [
     # a USER dynamics model of the big-block family (csrc/models/planar_quadrotor.hpp <-> class PlanarQuadrotorRef of ref_driver.cpp; nx = 6, nu = 2):
     # multiple shooting + RK4, thrust bounds, keep-out ball; final-stage constraints; another integrator
     ("pquad_n10", dict(scenario="pquad", N=10, iters=6), (1, 2, 3, 4, 5, 6)),
+    # round 6: a USER stage inequality (state term) around the 12-state quadrotor -- the tilt cone of csrc/stage_functions/tilt_cone.hpp instead of the keep-out ball
+    ("sf_quad_tilt", dict(scenario="quad", N=10, iters=5, noball=1, tilt=0.15), (1, 2, 3, 5)),
+    ("sf_quad_fd_tilt", dict(scenario="quad", grid="fd", N=10, iters=5, noball=1, tilt=0.15), (1, 2, 3, 5)),
     ("pquad_n24", dict(scenario="pquad", N=24, iters=8), (1, 2, 4, 8)),
     ("pquad_n10_teq", dict(scenario="pquad", N=10, iters=5, teq=1), (1, 2, 3, 5)),
     ("pquad_n10_tball", dict(scenario="pquad", N=10, iters=5, tball=0.05, tball_s="1,1,0.5,0.2,0.2,0.1"), (1, 2, 3, 5)),
@@ -511,6 +514,12 @@ XE = [
                                   eq_lin="0.1,0.0,0.05,0.02,0.0,0.01,0.03,0.02,0.4", rate="3.0,3.0"), (1, 2, 3, 5)),
     ("xe_unicycle_ms_rate", dict(scenario="unicycle", grid="ms", N=12, iters=6, ball="1.0,0.5,0.2,0.3", rate="0.8,0.5", u_prev="0.2,-0.1", u_prev_dt=0.07), (1, 2, 3, 4, 6)),
     ("xe_int3_ms_vargrid_rate", dict(scenario="int3", grid="ms", N=20, iters=5, vargrid=1, xf="1.0,0.0,0.0", rate="3.0"), (1, 2, 3, 5)),
+    # round 6: USER stage functions (csrc/stage_functions/): the input-magnitude bound as the stage inequalities' control term (an edge on u_k), alone, next to the
+    # ball (state term) and the rate limit (control-deviation term: the three edges of an interval in the reference's order), around a big-block model
+    ("xe_sf_unicycle_unorm", dict(scenario="unicycle", N=12, iters=6, unorm=0.6), (1, 2, 3, 4, 6)),
+    ("xe_sf_unicycle_ball_unorm_rate", dict(scenario="unicycle", N=16, iters=6, ball="1.0,0.5,0.2,0.3", unorm=0.7, rate="0.8,0.5", u_prev="0.2,-0.1", u_prev_dt=0.07), (1, 2, 3, 4, 6)),
+    ("xe_sf_int3_unorm_vargrid", dict(scenario="int3", N=20, iters=5, vargrid=1, xf="1.0,0.0,0.0", unorm=1.5), (1, 2, 3, 5)),
+    ("xe_sf_quad_tilt_unorm", dict(scenario="quad", N=10, iters=5, noball=1, tilt=0.15, unorm=11.0), (1, 2, 3, 5)),
     ("xe_unicycle_all_n300", dict(scenario="unicycle", N=300, dt=0.04, iters=4, crule="trap", ball="1.0,0.5,0.2,0.3", ball_int=1, eq_lin="0.3,-0.2,0.1,0.05,0.02,0.1",
                                   rate="0.9,0.6"), (1, 2, 4)),
 ]

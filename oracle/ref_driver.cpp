@@ -179,9 +179,22 @@ class UserStageInequalities : public StageInequalityConstraint
     Eigen::VectorXd ball;        // cx, cy, cz, r or empty
     bool ball_integral = false;
     Eigen::VectorXd rate;        // r_max per control, or empty
+    double tilt  = 0;            // > 0: a tilt cone x[6]^2 + x[7]^2 - tilt^2 <= 0 as the non-integral state term (instead of the ball; csrc/stage_functions/tilt_cone.hpp)
+    double unorm = 0;            // > 0: an input-magnitude bound |u|^2 - unorm^2 <= 0 as the non-integral CONTROL term (csrc/stage_functions/control_norm.hpp)
     StageInequalityConstraint::Ptr getInstance() const override { return std::make_shared<UserStageInequalities>(*this); }
-    int getNonIntegralStateTermDimension(int k) const override { return (ball.size() == 4 && !ball_integral) ? 1 : 0; }
-    void computeNonIntegralStateTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, Eigen::Ref<Eigen::VectorXd> cost) const override { cost[0] = ballValue(x); }
+    int getNonIntegralStateTermDimension(int k) const override { return ((ball.size() == 4 && !ball_integral) || tilt > 0) ? 1 : 0; }
+    void computeNonIntegralStateTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        if (tilt > 0) cost[0] = (x[6] * x[6] + x[7] * x[7]) - tilt * tilt;
+        else cost[0] = ballValue(x);
+    }
+    int getNonIntegralControlTermDimension(int k) const override { return unorm > 0 ? 1 : 0; }
+    void computeNonIntegralControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& u, Eigen::Ref<Eigen::VectorXd> cost) const override
+    {
+        double acc = 0.0;
+        for (int i = 0; i < u.size(); ++i) acc += u[i] * u[i];
+        cost[0] = acc - unorm * unorm;
+    }
     int getIntegralStateControlTermDimension(int k) const override { return (ball.size() == 4 && ball_integral) ? 1 : 0; }
     void computeIntegralStateControlTerm(int k, const Eigen::Ref<const Eigen::VectorXd>& x, const Eigen::Ref<const Eigen::VectorXd>& u,
                                          Eigen::Ref<Eigen::VectorXd> cost) const override
@@ -248,6 +261,8 @@ struct Scenario
     std::string crule;          // crule=trap|left: the grid's integration rule for the integral constraint edges (setCostIntegrationRule)
     bool noball = false;        // noball=1 (pquad): without the keep-out ball the scenario carries by default
     bool ball_integral = false; // ball_int=1 (with ball=): the ball as the INTEGRAL state-control term of the stage inequalities
+    double tilt = 0;            // tilt=<alpha>: the tilt cone as the stage inequalities' state term (user stage function, slot 0)
+    double unorm = 0;           // unorm=<r>: the input-magnitude bound as their control term (user stage function, slot 1)
     Eigen::VectorXd eq_lin;     // eq_lin=a_1..a_nx,b_1..b_nu,c: LinearIntegralEquality
     Eigen::VectorXd rate;       // rate=r_1..r_nu: input-rate limit as the control-deviation term of the stage inequalities
     Eigen::VectorXd u_prev;     // u_prev=... (with rate=): the previously applied control (setPreviousControlInput), default zero
@@ -672,10 +687,10 @@ static Built build(const Scenario& s, int iterations)
     if (s.final_cost == 0) b.ocp->setFinalStageCost({});
     if (s.ball.size() == 4 && s.name != "quad" && s.name != "pquad" && !s.ball_integral && s.rate.size() == 0)
         b.ocp->setStageInequalityConstraint(std::make_shared<BallKeepOut>(s.ball[0], s.ball[1], s.ball[2], s.ball[3]));
-    else if (s.ball_integral || s.rate.size() > 0)
+    else if (s.ball_integral || s.rate.size() > 0 || s.tilt > 0 || s.unorm > 0)
     {
         auto c = std::make_shared<UserStageInequalities>();
-        c->ball = s.ball; c->ball_integral = s.ball_integral; c->rate = s.rate;
+        c->ball = s.ball; c->ball_integral = s.ball_integral; c->rate = s.rate; c->tilt = s.tilt; c->unorm = s.unorm;
         b.ocp->setStageInequalityConstraint(c);
     }
     if (s.eq_lin.size() > 0)
@@ -940,6 +955,8 @@ static Scenario parse(int argc, char** argv, std::map<std::string, std::string>&
     if (kv.count("noball")) s.noball = atoi(kv["noball"].c_str()) != 0;
     if (kv.count("eq_lin")) s.eq_lin = vec(kv["eq_lin"]);
     if (kv.count("rate")) s.rate = vec(kv["rate"]);
+    if (kv.count("tilt")) s.tilt = atof(kv["tilt"].c_str());
+    if (kv.count("unorm")) s.unorm = atof(kv["unorm"].c_str());
     if (kv.count("u_prev")) s.u_prev = vec(kv["u_prev"]);
     if (kv.count("u_prev_dt")) s.u_prev_dt = atof(kv["u_prev_dt"].c_str());
     if (kv.count("teq")) s.teq = atoi(kv["teq"].c_str()) != 0;
@@ -995,6 +1012,8 @@ static int dump(const Scenario& s)
     if (s.ball_integral) printf("\"ball_int\": 1,\n");
     if (s.eq_lin.size()) printVec("eq_lin", s.eq_lin);
     if (s.rate.size()) printVec("rate", s.rate);
+    if (s.tilt > 0) printf("\"tilt\": %.17g,\n", s.tilt);
+    if (s.unorm > 0) printf("\"unorm\": %.17g,\n", s.unorm);
     if (s.u_prev.size()) printVec("u_prev", s.u_prev);
     if (s.u_prev_dt > 0) printf("\"u_prev_dt\": %.17g,\n", s.u_prev_dt);
     if (s.noball) printf("\"noball\": 1,\n");

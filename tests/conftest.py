@@ -132,6 +132,14 @@ def desc_for(g):
         d.stage_eq = capi.STAGE_EQ_LINEAR
         for i, v in enumerate(g["eq_lin"]):
             d.stage_eq_params[i] = v
+    if "tilt" in g:             # user stage function, slot 0 (csrc/stage_functions/tilt_cone.hpp): the stage inequalities' state term
+        d.stage_ineq = capi.STAGE_FN_USER + 0
+        for i in range(8):
+            d.ineq_params[i] = 0.0
+        d.ineq_params[0] = g["tilt"]
+    if "unorm" in g:            # user stage function, slot 1 (control_norm.hpp): their control term
+        d.stage_ineq_control = capi.STAGE_FN_USER + 1
+        d.ineq_control_params[0] = g["unorm"]
     if "rate" in g:             # input-rate limit as the control-deviation term of the stage inequalities
         d.ctrl_dev = capi.CTRL_DEV_RATE
         for i, v in enumerate(g["rate"]):

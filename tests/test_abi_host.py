@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header(lib):
     # sizes implied by include/corbo_hip.h (packing check of the ctypes mirrors)
-    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8 + 28 * 8 + 4 * 4 + 2 * 4 + 3 * 16 * 8 + 4 * 4 + (25 + 8) * 8   # (+ shooting_integrator, final_eq_mask, q_sqrt, r_sqrt, qf_sqrt; + the integral-constraint / control-deviation fields)
+    assert C.sizeof(capi.ProblemDesc) == 10 * 4 + 3 * 8 + (2 * 16 + 2 * 8 + 16 + 8 + 16 + 8 + 8) * 8 + 2 * 4 + 17 * 8 + 28 * 8 + 4 * 4 + 2 * 4 + 3 * 16 * 8 + 4 * 4 + (25 + 8) * 8 + 2 * 4 + 8 * 8   # (+ shooting_integrator, final_eq_mask, q_sqrt, r_sqrt, qf_sqrt; + the integral-constraint / control-deviation fields; + stage_ineq_control and its parameters)
     assert C.sizeof(capi.Dims) == 8 * 4
     assert C.sizeof(capi.LmOpts) == 8 + 9 * 8
     o = capi.LmOpts()
@@ -37,7 +37,8 @@ def test_struct_sizes_match_header(lib):
     assert (o.iterations, o.weight_eq, o.adapt_factor_eq, o.adapt_max_bounds) == (10, 2.0, 1.0, 500.0)
 
 
-@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12", "quad_n10", "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal"])
+@pytest.mark.parametrize("name", ["unicycle", "vdp", "dint", "vdp_forward", "unicycle_n12", "quad_n10", "unicycle_n12_tball", "vdp_tball", "vdp_ms_rk4", "unicycle_n12_ms_rk4", "unicycle_n24_ball", "unicycle_n12_teq", "vdp_teq", "unicycle_n12_patterns", "vdp_patterns", "int3", "int3_ms_rk4", "int3_time_optimal",
+                                  "sf_quad_tilt", "xe_sf_unicycle_unorm", "xe_sf_unicycle_ball_unorm_rate", "xe_sf_int3_unorm_vargrid", "xe_sf_quad_tilt_unorm"])   # (user stage functions: the control term's edge between the state term's and the control-deviation edge)
 def test_dims_and_structure_match_reference(lib, oracle_mod, name):
     g = load_golden(name)
     d = desc_for(g)
@@ -194,4 +195,43 @@ def test_user_model_directory_is_registered(lib):
     d = problems.planar_quadrotor_desc(N=10)
     assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) == 0 and (dims.n, dims.m) == (72, 159)   # = the reference's own count (tests/golden/pquad_n10.json)
     d.nx = 5
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0
+
+
+def test_user_stage_function_directory_is_registered(lib):
+    """csrc/stage_functions/*.hpp (user stage inequalities): the build registers every header under CORBO_HIP_STAGE_FN_USER + slot with its kind; the shipped
+    examples -- tilt cone (state term, slot 0), input-magnitude bound (control term, slot 1) -- evaluate on the host through the very templates the kernels compile."""
+    import __graft_entry__ as g
+    fns = g.user_stage_functions()
+    assert ("tilt_cone", 0, 0, 8) in [f[:4] for f in fns] and ("control_norm", 1, 1, 1) in [f[:4] for f in fns]
+    reg = open(os.path.join(ROOT, "control_box_rst_amd", "csrc", "stage_functions", "_registry.inc")).read()
+    for name, slot, kind, nxmin, _ in fns:
+        assert f"CORBO_HIP_USER_STAGE({name}, {slot}, {kind}, {nxmin})" in reg
+    assert lib.corbo_hip_stage_function_kind(capi.STAGE_FN_USER + 0) == 0 and lib.corbo_hip_stage_function_kind(capi.STAGE_FN_USER + 1) == 1
+    assert lib.corbo_hip_stage_function_kind(capi.STAGE_FN_USER + 7) == -1
+    rng = np.random.default_rng(3)
+    dp = C.POINTER(C.c_double)
+    x = rng.standard_normal((5, 12)); u = rng.standard_normal((5, 4)); out = np.zeros(5)
+    prm = np.zeros(8); prm[0] = 0.4
+    assert lib.corbo_hip_eval_stage_function(capi.STAGE_FN_USER + 0, 12, 5, x.ctypes.data_as(dp), prm.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    assert np.array_equal(out, (x[:, 6] * x[:, 6] + x[:, 7] * x[:, 7]) - 0.4 * 0.4)
+    assert lib.corbo_hip_eval_stage_function(capi.STAGE_FN_USER + 1, 4, 5, u.ctypes.data_as(dp), prm.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    ref = np.zeros(5)
+    for i in range(4):
+        ref = ref + u[:, i] * u[:, i]
+    assert np.array_equal(out, ref - 0.4 * 0.4)
+    ball = np.array([1.0, 0.5, 0.2, 0.3, 0, 0, 0, 0.0])
+    assert lib.corbo_hip_eval_stage_function(capi.INEQ_BALL, 3, 5, np.ascontiguousarray(x[:, :3]).ctypes.data_as(dp), ball.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    d3 = x[:, :3] - ball[:3]
+    assert np.allclose(out, 0.09 - (d3 * d3).sum(axis=1), rtol=1e-14)
+    # descriptors: a state function below its nx_min, a control function named as the state term, an unregistered slot
+    from control_box_rst_amd import problems
+    dims = capi.Dims()
+    d = problems.unicycle_desc(N=12); d.stage_ineq = capi.STAGE_FN_USER + 0
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0
+    d = problems.unicycle_desc(N=12); d.stage_ineq = capi.STAGE_FN_USER + 1
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0
+    d = problems.unicycle_desc(N=12); d.stage_ineq_control = capi.STAGE_FN_USER + 1
+    assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) == 0 and dims.ineq == 11
+    d.stage_ineq_control = capi.STAGE_FN_USER + 5
     assert lib.corbo_hip_get_dims(C.byref(d), C.byref(dims)) != 0

@@ -36,14 +36,17 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
                                               # time-optimal transfer of the six-state user model on the MultipleShootingVariableGrid: a free dt around a big-block model
                                               "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate",
                                               # ... and of the 12-state quadrotor: the dt column rides through the stage / partitioned-chain kernels (round 5)
-                                              "quad_topt", "quad_rk5", "unicycle"], (p.stdout, p.stderr)   # (quad_rk5: Runge-Kutta 5 around the 12-state model)
-    assert [r["mode"] for r in solved] == ["recognised"] * 36 + ["stated"]   # (unicycle_moved: the setpoint moves between two runs without a structure change -- model tracking)   # (kcar, pquad: user dynamics classes matched against csrc/models/kinematic_car.hpp / planar_quadrotor.hpp -- the latter one of the big-block family)   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
+                                              "quad_topt", "quad_rk5",
+                                              # round 6: USER stage functions of csrc/stage_functions/ matched against the graph's inequality edges by evaluation -- an input-magnitude
+                                              # bound on every u_k (control term), a tilt cone on the quadrotor's roll / pitch (state term)
+                                              "unicycle_sf_unorm", "quad_sf_tilt", "unicycle"], (p.stdout, p.stderr)   # (quad_rk5: Runge-Kutta 5 around the 12-state model)
+    assert [r["mode"] for r in solved] == ["recognised"] * 38 + ["stated"]   # (unicycle_moved: the setpoint moves between two runs without a structure change -- model tracking)   # (kcar, pquad: user dynamics classes matched against csrc/models/kinematic_car.hpp / planar_quadrotor.hpp -- the latter one of the big-block family)   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
     # unicycle_tballc: TerminalBallInheritFromCost; dint_mtq8: MinTimeQuadratic with only_last_n)
     for r in solved:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, (r, p.stderr[-2000:])
         # cfg 3: 10 LM iterations; cfg 2: 5 x 10 iterations with warm start -- same tolerance as the golden parity tests;
         # cfg 5 family (quadrotor, multiple shooting, N=30): soft directions, chi2 carries the comparison (tests/test_oracle_fullsize.py)
-        assert r["max_abs_diff"] <= (5e-4 if r["scenario"] in ("pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate") else 3e-4 if r["scenario"] in ("quad", "pquad", "pquad_fd", "pquad_topt", "quad_topt", "quad_rk5") else 3e-5 if r["scenario"] == "unicycle_tvref" else 5e-6), r   # tvref: tests/test_references.py
+        assert r["max_abs_diff"] <= (5e-4 if r["scenario"] in ("pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate") else 3e-4 if r["scenario"] in ("quad", "pquad", "pquad_fd", "pquad_topt", "quad_topt", "quad_rk5", "quad_sf_tilt") else 3e-5 if r["scenario"] == "unicycle_tvref" else 5e-6), r   # tvref: tests/test_references.py
         assert abs(r["chi2_hip"] - r["chi2_reference"]) <= 2e-6 * max(1.0, abs(r["chi2_reference"])), r
     # the operators of the exact-Hessian path through the adapter (LevenbergMarquardtSparseHip::computeSparseHessians*), at a generic point
     # of the same graphs, against the graph's own computeSparseHessians{NNZ,Structure,Values}: identical lists, values within the

@@ -52,6 +52,8 @@ GOLD = ["unicycle", "vdp", "dint", "vdp_forward", "vdp_backward", "vdp_midpoint"
         "kcar_n16", "kcar_midpoint", "kcar_ms_rk4",
         # a user dynamics model of the big-block family dropped into csrc/models/ (planar quadrotor, nx = 6, nu = 2)
         "pquad_n10", "pquad_n24", "pquad_n10_teq", "pquad_n10_tball", "pquad_n10_rk3",
+        # a USER stage inequality dropped into csrc/stage_functions/ (tilt cone on roll / pitch: the state term, instead of the keep-out ball) around the 12-state quadrotor
+        "sf_quad_tilt", "sf_quad_fd_tilt",
         # ... and the same family on the FiniteDifferencesGrid (the four collocation formulas), incl. the 12-state quadrotor
         "pquad_fd_n10", "pquad_fd_n24", "pquad_fd_n10_forward", "pquad_fd_n10_backward", "pquad_fd_n10_midpoint", "pquad_fd_n10_teq", "quad_fd_n10",
         # ... with a FREE dt (MultipleShootingVariableGrid / FiniteDifferencesVariableGrid, MinimumTime, x_f fixed): the dt column rides through the stage / partitioned-chain kernels (the band route: tests/test_gpu_free_dt_chain.py)

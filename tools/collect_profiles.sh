@@ -47,7 +47,8 @@ cp "$(first sfetch '*counter_collection.csv')" "$P/${RND}_sweep_pmc_fetch_counte
 python tools/pass_timeline.py 900 > "$P/${RND}_pass_phases_instance900.txt" 2>&1
 python tools/ledger_check.py > "$P/${RND}_ledger_device_deviation.txt" 2>&1
 { python tools/free_dt_time.py 100; python tools/pquad_time.py; } 2>&1 | grep -v amdgpu.ids > "$P/${RND}_free_dt_routes.txt"
-{ python tools/xe_time.py; python tools/narrow_band_phases.py; } 2>&1 | grep -v amdgpu.ids > "$P/${RND}_extra_edge_routes.txt"
+{ python tools/xe_time.py; python tools/xe_batch_sweep.py; python tools/narrow_band_phases.py; } 2>&1 | grep -v amdgpu.ids > "$P/${RND}_extra_edge_routes.txt"
+{ python tools/bt_phases.py 0 1; python tools/bt_phases.py 900 1024; } 2>&1 | grep -v amdgpu.ids | cut -c1-400 > "$P/${RND}_xe_pass_phases.txt"
 # ---- the bench lines of the same build on the same box (the profile-derived fields now resolve against the files above)
 python bench.py > "$P/${RND}_bench_line.json" 2> "$OUT/benchline3.err"
 python bench.py --config 5 > "$P/${RND}_bench_line_cfg5.json" 2> "$OUT/benchline5.err"
