@@ -825,7 +825,9 @@ def main():
         rec = 3 * nxq * nxq + nuq * nuq + 2 * nuq * nxq + 2 * nxq + nuq + 2
         per_stage = 8 * ((nxq + nuq) + nxq + 2 * (nxq + nuq) + rec + rec + 2 * (nxq * nxq + nxq) + 2 * (nxq + nuq))
         f_ms = solver.time_factor(repeat=5)
-        alg_pair = per_stage * desc.N * B
+        model_pair = per_stage * desc.N * B    # the kernels' OWN reads + writes (stage records handed from the stage kernel to the chain): `traffic_model`
+        dq = solver.dims
+        alg_pair = 8 * (dq.nv + 2 * dq.n + dq.m + dq.nnz) * B   # the algorithmic bytes of one Jacobian sweep -- what `frac` is priced on
         # (the longest launches of a solve WITH the reject-streak speculation carry 32 candidate instances more than the batch -- a third round of the chain
         # kernel; the cross-check of a full launch over exactly `batch` instances reads the trace taken without it: tools/profile_cfg5.py .. nospec)
         pc = (profile_kernel_max_ns(PROFILE_ROUND + "_cfg5_nospec_kernel_stats.csv", ("big_stage_kernel", "big_chain3_kernel" if desc.N >= 64 else "big_chain2_kernel"))
@@ -834,7 +836,8 @@ def main():
         line["roofline"] = {"bound": "hbm", "kernel": "big_stage_kernel + big_chain3_kernel (one factorisation of every instance: FD Jacobian + assemble, then the partitioned block chain)",
                             "achieved": alg_pair / (f_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_pair / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                             "traffic": qpmc["hbm_bytes_per_launch"] if qpmc else None, "traffic_source": qpmc["source"] if qpmc else None,
-                            "bytes_per_launch": alg_pair, "bytes_per_interval": per_stage, "ms_per_launch": f_ms,
+                            "bytes_per_launch": alg_pair, "bytes_per_instance": alg_pair // B, "bytes_definition": "SURVEY 8d: 8 (n_vert + 2 n + m + nnz) per instance per Jacobian sweep",
+                            "traffic_model": model_pair, "traffic_model_bytes_per_interval": per_stage, "ms_per_launch": f_ms,
                             "timing": "HIP events around 5 back-to-back (stage, chain) launch pairs over all instances (corbo_hip_time_factor)",
                             "profile_full_launch_ms": pc[0] * 1e-6 if pc else None, "profile": pc[1] if pc else None,
                             "note": "the stage kernel is fp64-VALU-bound (RK4 finite differences), the chain a latency chain of 12 x 12 pivots; matrix-core view in `factorization`"}
