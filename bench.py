@@ -529,6 +529,32 @@ def dense_weights_leg(device):
     return out
 
 
+def long_horizon_leg(device):
+    """Horizons beyond 256 grid points (FiniteDifferencesVariableGrid's default n_max is 1000): the factor workspace lives in HBM, one 1024-thread workgroup per instance,
+    every LM pass is two launches (sweep_kernel<.., LONG>, factor_long_kernel) -- NOT fused into a run-to-completion launch yet (measured here so that
+    the cost is on record).  Unicycle, N = 512, batch 1024, 10 LM iterations; per pass per stage next to the headline's fused kernel."""
+    from control_box_rst_amd import problems
+    from control_box_rst_amd.solver import BatchedLevenbergMarquardt
+    B, N = 1024, 512
+    d = problems.unicycle_desc(N=N, dt=0.02)
+    x0, xf = problems.unicycle_instances(B)
+    s = BatchedLevenbergMarquardt(d, B, device=device)
+    s.setIterations(10); s.setPenaltyWeights(*problems.UNICYCLE_WEIGHTS)
+    s.set_instance_data(s.init_trajectory(x0, xf), xref=xf)
+    s.solve(new_run=True); s.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        s.restore_instance_data(); s.solve(new_run=True)
+    s.synchronize()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    st = s.get_stats()
+    out = {"workload": f"unicycle N={N}, batch {B}, 10 LM iterations (per-pass launches, workspace in HBM)", "ms_per_solve": ms, "passes": int(st["passes"]),
+           "factorizations": int(st["factorizations"]), "us_per_pass_per_1000_stages": 1e3 * ms / max(1, int(st["passes"])) / (N / 1000.0),
+           "chi2_sum": float(np.sum(s.get_solution()[1]))}
+    del s
+    return out
+
+
 def hessian_leg(desc, B, x0, xf, device):
     """Operators of the exact-Hessian path on the headline structure: corbo_hip_eval_hessians (lower part, values left in HBM) for the
     bench batch and for ONE OCP (what the drop-in adapter's Hessian-path entry points run).  Wall time per call around a device-resident call +
@@ -888,6 +914,10 @@ def main():
             line["secondary"]["band_path"] = band_leg(local_rank)
         except Exception as e:
             line["secondary"]["band_path"] = {"error": repr(e)}
+        try:
+            line["secondary"]["long_horizon"] = long_horizon_leg(local_rank)
+        except Exception as e:
+            line["secondary"]["long_horizon"] = {"error": repr(e)}
         try:
             line["secondary"]["dense_weights"] = dense_weights_leg(local_rank)
         except Exception as e:

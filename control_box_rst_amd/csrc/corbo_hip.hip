@@ -221,6 +221,8 @@ struct corbo_hip_solver {
     int reject_speculation = 1; // corbo_hip_set_option("reject_speculation"): 0 = every rejected step is a pass of its own (A/B, tests)
     double* d_stage_cache = nullptr;   // big-block family: the stage waves' local Jacobians between the two passes of a solve's first factorisation (FactorParams::stage_cache)
     size_t stage_cache_stride = 0;
+    int32_t* d_xtasks = nullptr;   // the extra edges' Jacobian columns, one per sweep lane (kernels.hpp SweepParams::xtasks)
+    int n_xtasks = 0;
     uint32_t *d_bt_pairs = nullptr, *d_bt_target = nullptr;   // block-tridiagonal route (structure.hpp BtTables): the small-block families with extra edges, run to completion
     int32_t* d_bt_off = nullptr;
     int bt_rounds = 0;
@@ -272,6 +274,7 @@ struct corbo_hip_solver {
         std::memcpy(p.mp.fin, S.desc.final_ineq_params, sizeof(p.mp.fin));
         p.fin_eq_row0 = S.fin_eq_row0; p.fin_eq_dim = S.fin_eq_dim;
         p.xedges = d_xedges; p.n_xedges = (int32_t)S.xedges.size(); p.eq_stride = S.eq_stride; p.eq_defect_off = S.eq_defect_off;
+        p.xtasks = reinterpret_cast<const int4*>(d_xtasks); p.n_xtasks = n_xtasks;
         p.xparams = d_xparams; p.uprev = d_uprev;
         p.mp.wdense = d_wdense; p.mp.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
         p.mp.fin_eq_mask = S.desc.final_eq ? (int32_t)S.desc.final_eq_mask : 0;
@@ -554,6 +557,21 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
         std::vector<XEdge> xe = S.xedges;   // (Jacobian offsets: the device-internal layout is the public order for these handles)
         CREATE_TRY(hipMalloc((void**)&h->d_xedges, xe.size() * sizeof(XEdge)));
         CREATE_TRY(hipMemcpy(h->d_xedges, xe.data(), xe.size() * sizeof(XEdge), hipMemcpyHostToDevice));
+        {   // one sweep lane per Jacobian column of these edges
+            std::vector<int32_t> tasks;
+            for (size_t e = 0; e < xe.size(); ++e)
+                for (int vi = 0; vi < xe[e].nverts; ++vi) {
+                    if (xe[e].joff[vi] < 0) continue;
+                    int col = 0;
+                    for (int c = 0; c < xe[e].vdim[vi]; ++c) {
+                        if ((xe[e].fixed[vi] >> c) & 1u) continue;
+                        tasks.push_back((int32_t)e); tasks.push_back(vi); tasks.push_back(c); tasks.push_back(xe[e].joff[vi] + col * xe[e].edim + xe[e].rie);
+                        ++col;
+                    }
+                }
+            h->n_xtasks = (int32_t)(tasks.size() / 4);
+            if (upload(tasks, &h->d_xtasks)) return CORBO_HIP_ERR_DEVICE;
+        }
         std::vector<double> xp(CORBO_HIP_MAX_NX + 2 * CORBO_HIP_MAX_NU + 2 + 8, 0.0);   // [stage_eq: a, b, c | ctrl_dev: r_max | control inequality: 8 parameters]
         for (int i = 0; i < S.nx + S.nu + 1; ++i) xp[i] = S.desc.stage_eq_params[i];
         for (int i = 0; i < S.nu; ++i) xp[S.nx + S.nu + 1 + i] = S.desc.ctrl_dev_params[i];
@@ -677,7 +695,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
                     h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
-                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase, h->d_bt_pairs, h->d_bt_target, h->d_bt_off};
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase, h->d_bt_pairs, h->d_bt_target, h->d_bt_off, h->d_xtasks};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }

@@ -1175,6 +1175,43 @@ __device__ __forceinline__ void sweep_body(const SweepParams& p, const int mode,
     // (4) extra edges: central differences of every unfixed component of every attached vertex (BaseEdge::computeJacobian, edge_interface.cpp:55-96);
     //     equality rows times w_eq (:1552), inequality rows times w_ineq where active, explicit zeros otherwise (:1568-1610)
     if constexpr (XE) {
+        // One lane per COLUMN of an extra edge (round 6; SweepParams::xtasks: edge, attached vertex, component, the column's first Jacobian value): its value, then
+        // the central-difference pair of that one component -- three evaluations per lane instead of 1 + 2 x (unfixed components) on one lane per edge (the
+        // control-deviation edges of the headline structure: 9 evaluations with two divisions each, 10.3 k cycles of a 30 k sweep phase).  The same
+        // operations on the same numbers per column: the values are bit-identical to the edge-per-lane loop below (kept for handles without the task table).
+        if (p.xtasks) {
+            for (int t = tid; t < p.n_xtasks; t += THREADS) {
+                const int4 tk = p.xtasks[t];
+                const XEdge xe = p.xedges[tk.x];
+                double loc[4][XMC], f0[4], v2[4], v1[4];
+                xe_load(xe, loc);
+                xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, f0);
+                double keep = 0.0;
+#pragma unroll
+                for (int vi = 0; vi < 4; ++vi)
+#pragma unroll
+                    for (int c = 0; c < XMC; ++c) keep = (vi == tk.y && c == tk.z) ? loc[vi][c] : keep;
+                const double a = keep + delta, b = a + neg2delta;   // x += delta; x += -2 delta (edge_interface.cpp:55-96)
+#pragma unroll
+                for (int vi = 0; vi < 4; ++vi)
+#pragma unroll
+                    for (int c = 0; c < XMC; ++c) loc[vi][c] = (vi == tk.y && c == tk.z) ? a : loc[vi][c];
+                xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, v2);
+#pragma unroll
+                for (int vi = 0; vi < 4; ++vi)
+#pragma unroll
+                    for (int c = 0; c < XMC; ++c) loc[vi][c] = (vi == tk.y && c == tk.z) ? b : loc[vi][c];
+                xedge_values<NX, NU>(xe, loc, p.xparams, p.mp, v1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < xe.dim) {
+                        const double dj = scalar * (v2[j] - v1[j]);
+                        const bool active = (((f0[j] < 0) ? 0.0 : f0[j] * p.w_ineq) > 0.0);
+                        jst[tk.w + j] = (xe.scale == 1) ? dj * p.w_eq : (active ? dj * p.w_ineq : 0.0);
+                    }
+            }
+        }
+        else
         for (int i = tid; i < p.n_xedges; i += THREADS) {
             const XEdge xe = p.xedges[i];
             double loc[4][XMC], f0[4];

@@ -52,6 +52,8 @@ struct SweepParams {
     // integral-form constraint edges / control-deviation edges (structure.hpp XEdge; sweep_body<..., XE>), or n_xedges = 0
     const XEdge* xedges;
     int32_t n_xedges;
+    const int4* xtasks;                 // or null: one entry per Jacobian COLUMN of the extra edges -- (edge, attached vertex, component, first Jacobian value of the column)
+    int32_t n_xtasks;
     int32_t eq_stride, eq_defect_off;   // equality rows per interval and the defect's row inside them (nx, 0 without integral equality rows)
     const double* xparams;              // [stage_eq: a (nx), b (nu), c | ctrl_dev: r_max (nu)]
     const double* uprev;                // [batch_total][CORBO_HIP_MAX_NU + 1]: previously applied control, its age (corbo_hip_set_previous_control)

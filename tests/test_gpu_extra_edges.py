@@ -91,6 +91,9 @@ def test_random_batches_vs_oracle(oracle_mod, seed):
         d.ctrl_dev = capi.CTRL_DEV_RATE
         d.ctrl_dev_params[0] = 1.0
         d.ctrl_dev_params[1] = 1.0
+    if seed >= 12 and rng.random() < 0.5:   # (campaign seeds -- tools/fuzz_campaign.py: a user control function, csrc/stage_functions/control_norm.hpp, on top)
+        d.stage_ineq_control = capi.STAGE_FN_USER + 1
+        d.ineq_control_params[0] = float(rng.uniform(0.3, 1.5))
     B = 3
     x0 = rng.uniform(-1, 1, (B, d.nx))
     xf = rng.uniform(-0.5, 0.5, (B, d.nx)) + (np.array([1.5, 0.5, 0.2])[: d.nx] if fam != "int3t" else 0.0)

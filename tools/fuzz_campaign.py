@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import test_gpu_fuzz as F   # noqa: E402
 import test_gpu_hessian as H   # noqa: E402
+import test_gpu_extra_edges as X   # noqa: E402
 from oracle import oracle as O   # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -26,7 +27,9 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
                         ("hessian operators", H.test_random_descriptor_hessians_vs_oracle, range(first, first + count)),
                         ("counted iterations on / off", lambda o, seed: F.test_counted_converged_iterations_random_descriptors(seed), range(first, first + count // 3)),
                         ("dense weights (incl. long horizons)", F.test_random_dense_weights_vs_oracle, range(first, first + count // 2)),
-                        ("hessian operators, partial terminal equality", H.test_random_descriptor_hessians_partial_terminal_equality, range(first, first + count // 2))):
+                        ("hessian operators, partial terminal equality", H.test_random_descriptor_hessians_partial_terminal_equality, range(first, first + count // 2)),
+                        # random combinations of the extra-edge kinds (incl. a user control function from seed 12 on) through the block-tridiagonal route (round 6)
+                        ("extra edges, block-tridiagonal route", X.test_random_batches_vs_oracle, range(first, first + count // 2))):
     n_bad = 0
     for seed in seeds:
         try:
