@@ -25,22 +25,23 @@ struct BtLayout {
     static constexpr int SZ  = 2 * S * S + S + (ARROW ? S : 0);
     static constexpr int SZP = SZ | 1;         // odd stride: consecutive blocks spread over the LDS banks
     static constexpr int EPB = S * (S + 1) / 2 + S * S + S + (ARROW ? S : 0);   // assembled entries per block
-    static constexpr int NB_MAX = 128;         // blocks (= grid points) this route is instantiated for
+    static constexpr int NB_MAX = 128;         // blocks (= grid points) of the regular instantiation (a lane PAIR per stage, sixteen list rounds); BIG: 256
     // rounds of the product lists a lane holds in registers: the lists cover every row of J but the defect edges' (diagonals, right-hand sides, extra edges,
     // inequality rows) -- sixteen entries per lane at most; a structure that needs more stays on the band route (corbo_hip_create asks bt_route_max_rounds)
-    __host__ __device__ static constexpr int max_rounds(int) { return 16; }
+    __host__ __device__ static constexpr int max_rounds(bool big) { return big ? 32 : 16; }
     __host__ __device__ static constexpr int carve(int nb) { return nb * SZP + 3; }   // + corner, rhs of dt, trash slot
 };
 
 // flags of BtTables::target (bits 28..31; bits 0..27: the LDS slot -- an entry of the padding points at the trash slot behind the two scalars)
 constexpr unsigned BT_DIAG = 1u << 28, BT_ONE = 1u << 29, BT_RHS = 1u << 30, BT_CORNER = 1u << 31, BT_SLOT = 0x0FFFFFFFu;
 
-template <int S, int NX, bool ARROW, int THREADS>
+// BIG: horizons of 129 .. 256 grid points -- one lane per stage does both halves of the defect edge's assembly, twice the list rounds; one workgroup per CU (LDS)
+template <int S, int NX, bool ARROW, int THREADS, bool BIG = false>
 __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* const st, double* const smem, double* const xs, double* const red, const int inst, const int tid, const bool j_in_lds,
                                                const int eq_stride, const int eq_defect_off)
 {
     using BL = BtLayout<S, ARROW>;
-    constexpr int SZP = BL::SZP, MAXE = BL::max_rounds(THREADS), NW = THREADS / 64;
+    constexpr int SZP = BL::SZP, MAXE = BL::max_rounds(BIG), NW = THREADS / 64;
     constexpr int oA = BL::A, oB = BL::B, oG = BL::G, oZ = BL::Z;
     const int NB = p.N;
     const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
@@ -52,9 +53,10 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
 #define BT_STAMP(id) do { if (p.timeline && inst == p.timeline_inst && tid == 0) p.timeline[id] = clock64(); } while (0)
     BT_STAMP(0);
     // the defect edge of stage ks is assembled by TWO lanes from its dense local Jacobian (below); its column offsets depend on nothing but the lane: requested first
-    constexpr int WL = S + NX, HALF = THREADS / 2;
-    static_assert(BL::NB_MAX <= HALF, "one lane pair per stage");
-    const int ks = tid & (HALF - 1), half = tid / HALF;
+    constexpr int WL = S + NX, HALF = BIG ? THREADS : THREADS / 2;
+    static_assert((BIG ? 2 : 1) * BL::NB_MAX <= HALF, "a lane (pair) per stage");
+    const int ks = tid & (HALF - 1), half = BIG ? 0 : tid / HALF;
+    constexpr bool BOTH = BIG;   // the lane of a stage does both halves
     const bool st_on = ks < NB - 1;
     int sco[WL + 1];
 #pragma unroll
@@ -189,7 +191,7 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
             if constexpr (ARROW) sk[oZ + i] = 0.0;
         }
     }
-    if (st_on && half == 1) {
+    if (st_on && (BOTH || half == 1)) {
         double* sk = blk + ks * SZP;
 #pragma unroll
         for (int i = 0; i < S; ++i)
@@ -206,7 +208,7 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     if (ARROW && tid == THREADS - 1) { blk[NB * SZP] = 0.0; blk[NB * SZP + 1] = 0.0; }
     lds_barrier();
     // ---- write phase Y: what the edge of stage ks adds to block ks + 1
-    if (st_on && half == 1) {
+    if (st_on && (BOTH || half == 1)) {
         double* sn = blk + (ks + 1) * SZP;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {

@@ -4829,8 +4829,9 @@ __host__ __device__ constexpr int bt_carve_doubles(int N, int nnz_pad, int m_pad
     return (c + 1) / 2 * 2;
 }
 
-template <int DYN, int DEFECT, bool ARROW>
-__global__ __launch_bounds__(BT_THREADS, CORBO_HIP_BT_WAVES) void lm_bt_kernel(const FactorParams fp, const SweepParams sp)
+// BIG: horizons of 129 .. 256 grid points (bt_factor_body<.., BIG>): the block storage alone is 113 KB for the unicycle at N = 256 -- one workgroup per CU, all its registers
+template <int DYN, int DEFECT, bool ARROW, bool BIG = false>
+__global__ __launch_bounds__(BT_THREADS, (BIG ? 1 : CORBO_HIP_BT_WAVES)) void lm_bt_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
     constexpr int THREADS = BT_THREADS;
@@ -4893,7 +4894,7 @@ __global__ __launch_bounds__(BT_THREADS, CORBO_HIP_BT_WAVES) void lm_bt_kernel(c
             }
             if (sl->done) break;
             const bool j_fresh = flags[0] != 0;
-            bt_factor_body<Dy::NX + Dy::NU, Dy::NX, ARROW, THREADS>(fpl, sl, smem, xs, red, inst_v, tid_v, j_fresh, spl.eq_stride, spl.eq_defect_off);
+            bt_factor_body<Dy::NX + Dy::NU, Dy::NX, ARROW, THREADS, BIG>(fpl, sl, smem, xs, red, inst_v, tid_v, j_fresh, spl.eq_stride, spl.eq_defect_off);
             __threadfence_block();
             __syncthreads();
             if (pcyc) { long long* row = fpl.phase_cycles + (size_t)inst_v * 8; row[2] += clock64() - pc_t0; row[5] += 1; }
@@ -4924,28 +4925,28 @@ bool launch_bt_t(const FactorParams& fp, const SweepParams& sp, hipStream_t stre
     using Dy = Dynamics<DYN>;
     if constexpr (DEFECT == DEFECT_SHOOTING_HIGH) return false;
     else {
-        if (!fp.bt_pairs || fp.N > BtLayout<Dy::NX + Dy::NU, false>::NB_MAX || fp.loop_passes <= 0) return false;
-        const bool arrow = fp.dt_free != 0;
+        constexpr int NBM = BtLayout<Dy::NX + Dy::NU, false>::NB_MAX;
+        if (!fp.bt_pairs || fp.N > 2 * NBM || fp.loop_passes <= 0) return false;
+        const bool arrow = fp.dt_free != 0, big = fp.N > NBM;
         const size_t carve = arrow ? bt_carve_doubles<Dy::NX, Dy::NU, true>(fp.N, fp.nnz_pad, fp.m_pad, Dy::NC, fp.nvs) : bt_carve_doubles<Dy::NX, Dy::NU, false>(fp.N, fp.nnz_pad, fp.m_pad, Dy::NC, fp.nvs);
         const size_t lds = sizeof(double) * (carve + fp.nvs + 12) + sizeof(LmState);
         if (lds > (size_t)160 * 1024) return false;
         int grid = fp.batch;
         if (fp.queue) {
             int per_cu = (int)((size_t)160 * 1024 / lds);
-            if (per_cu > CORBO_HIP_BT_WAVES) per_cu = CORBO_HIP_BT_WAVES;   // (four waves per workgroup: workgroups per CU = waves per SIMD)
+            const int cap = big ? 1 : CORBO_HIP_BT_WAVES;   // (four waves per workgroup: workgroups per CU = waves per SIMD the kernel is compiled for)
+            if (per_cu > cap) per_cu = cap;
             if (per_cu < 1) per_cu = 1;
             grid = fp.queue_grid * per_cu;
             if (grid > fp.batch) grid = fp.batch;
         }
-        static unsigned long long attr_set[2] = {0, 0};   // (per device)
-        if (arrow) {
-            if (first_on_device(attr_set[1])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lm_bt_kernel<DYN, DEFECT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((lm_bt_kernel<DYN, DEFECT, true>), dim3(grid), dim3(BT_THREADS), lds, stream, fp, sp);
-        }
-        else {
-            if (first_on_device(attr_set[0])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lm_bt_kernel<DYN, DEFECT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL((lm_bt_kernel<DYN, DEFECT, false>), dim3(grid), dim3(BT_THREADS), lds, stream, fp, sp);
-        }
+        static unsigned long long attr_set[4] = {0, 0, 0, 0};   // (per device)
+        auto go = [&](auto kernel, int slot) {
+            if (first_on_device(attr_set[slot])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(BT_THREADS), lds, stream, fp, sp);
+        };
+        if (big) { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, true>, 3); else go(lm_bt_kernel<DYN, DEFECT, false, true>, 2); }
+        else { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, false>, 1); else go(lm_bt_kernel<DYN, DEFECT, false, false>, 0); }
         return true;
     }
 }
@@ -6916,7 +6917,7 @@ static constexpr size_t BAND_LDS_MAX = 160 * 1024 - 256;   // (the kernel also h
 int bt_route_max_rounds(int nx, int nu, bool arrow, int N, int nnz_pad, int m_pad, int nvs)
 {
     const int s = nx + nu;
-    if (nx < 1 || nx > 4 || nu < 1 || N > 128) return 0;
+    if (nx < 1 || nx > 4 || nu < 1 || N > 256) return 0;
     const int szp = (2 * s * s + s + (arrow ? s : 0)) | 1;
     long carve = (long)N * szp + 3;
     if (carve < (long)nnz_pad + m_pad + 2 - nvs) carve = (long)nnz_pad + m_pad + 2 - nvs;
@@ -6926,7 +6927,7 @@ int bt_route_max_rounds(int nx, int nu, bool arrow, int N, int nnz_pad, int m_pa
     if (lds > (size_t)160 * 1024) return 0;
     const int epb = s * (s + 1) / 2 + s * s + s + (arrow ? s : 0);
     (void)epb;
-    return 4;   // super-rounds of the product lists (BtLayout::max_rounds: sixteen rounds, four each)
+    return N > 128 ? 8 : 4;   // super-rounds of the product lists (BtLayout::max_rounds: sixteen rounds -- the BIG instantiation: thirty-two --, four each)
 }
 
 bool band_route_supported(int nb, int bw) { return bw + 1 <= 64 && sizeof(double) * (band_lds_doubles(nb, bw) + 8) <= BAND_LDS_MAX; }

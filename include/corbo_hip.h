@@ -313,8 +313,8 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
 /* The same with an explicit choice of the factorisation ROUTE where a descriptor has two (A/B measurements and the cross-route parity tests;
  * the library reads no environment variable).  `route` = OR of:
  *   CORBO_HIP_ROUTE_FREE_DT_BAND  a free dt around a big-block model through the general band factorisation instead of the stage / chain kernels' border column
- *   CORBO_HIP_ROUTE_XE_BAND       control-deviation edges of the small-block families through the general band factorisation instead of the structured
- *                                 (x_k, u_k)-block elimination inside the run-to-completion kernel
+ *   CORBO_HIP_ROUTE_XE_BAND       extra edges (control-deviation term, integral-form constraint edges, a user control inequality) of the small-block families
+ *                                 up to 256 grid points through the general band factorisation instead of the block-tridiagonal route (one launch per solve)
  * 0 = what corbo_hip_create chooses.  A flag that does not apply to the descriptor is ignored. */
 #define CORBO_HIP_ROUTE_FREE_DT_BAND 1u
 #define CORBO_HIP_ROUTE_XE_BAND      2u

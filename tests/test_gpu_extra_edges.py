@@ -159,7 +159,7 @@ def test_narrow_band_kernel_vs_eight_wave_kernel(name):
     assert np.abs(x0 - x1).max() <= 2e-6, (name, np.abs(x0 - x1).max())
 
 
-SMALL_BLOCK = [n for n in FIXTURES if "quad" not in n and "n300" not in n]   # (the big-block family and horizons beyond 128 grid points keep the band route)
+SMALL_BLOCK = [n for n in FIXTURES if "quad" not in n and "n300" not in n]   # (the big-block family and horizons beyond 256 grid points keep the band route; n200: the BIG instantiation)
 
 
 @pytest.mark.parametrize("name", SMALL_BLOCK)
