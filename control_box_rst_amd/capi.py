@@ -88,6 +88,7 @@ def default_lm_opts(iterations=10, w_eq=2.0, w_ineq=2.0, w_bounds=2.0) -> LmOpts
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1   # corbo_hip_integrator
 
 ROUTE_FREE_DT_BAND, ROUTE_XE_BAND = 1, 2   # corbo_hip_create_routed
+FACTOR_STAGE_CR, FACTOR_STAGE_CHAIN, FACTOR_BAND, FACTOR_BLOCK_TRI = 0, 1, 2, 3   # corbo_hip_factor_route
 STAGE_FN_USER = 1000                        # CORBO_HIP_STAGE_FN_USER: + slot of a user stage function (csrc/stage_functions/)
 
 # CORBO_HIP_LIB: A/B measurements of two builds of the same C-ABI in one GPU session (development only)
@@ -105,7 +106,7 @@ EXPORTED_SYMBOLS = (
     "corbo_hip_closed_loop", "corbo_hip_fetch_solution", "corbo_hip_get_timing", "corbo_hip_time_sweep_each", "corbo_hip_set_result_sink", "corbo_hip_eval_dynamics", "corbo_hip_set_option", "corbo_hip_prepare_slots", "corbo_hip_get_dt", "corbo_hip_resample_into",
     "corbo_hip_device_count", "corbo_hip_shard_bounds", "corbo_hip_device_row_stride",
     "corbo_hip_set_references", "corbo_hip_set_reference_trajectory", "corbo_hip_hessian_nnz", "corbo_hip_hessian_structure", "corbo_hip_eval_hessians", "corbo_hip_eval_hessians_views", "corbo_hip_linear_form_structure", "corbo_hip_eval_linear_form", "corbo_hip_eval_objective_gradient",
-    "corbo_hip_sizeof", "corbo_hip_set_previous_control", "corbo_hip_get_phase_cycles", "corbo_hip_create_routed", "corbo_hip_stage_function_kind", "corbo_hip_eval_stage_function",
+    "corbo_hip_sizeof", "corbo_hip_set_previous_control", "corbo_hip_get_phase_cycles", "corbo_hip_create_routed", "corbo_hip_factor_route", "corbo_hip_stage_function_kind", "corbo_hip_eval_stage_function",
 )
 
 
@@ -145,6 +146,8 @@ def load() -> C.CDLL:
     lib.corbo_hip_stage_function_kind.argtypes = [C.c_int]
     lib.corbo_hip_eval_stage_function.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp]
     lib.corbo_hip_create_routed.argtypes = [C.POINTER(ProblemDesc), C.c_int, C.c_int, C.c_uint32, C.POINTER(H)]
+    lib.corbo_hip_factor_route.argtypes = [H]
+    lib.corbo_hip_factor_route.restype = C.c_int
     lib.corbo_hip_destroy.argtypes = [H]
     lib.corbo_hip_destroy.restype = None
     lib.corbo_hip_set_instance_data.argtypes = [H, dp, dp, dp, dp]

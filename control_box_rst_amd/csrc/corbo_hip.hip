@@ -1733,6 +1733,14 @@ int corbo_hip_get_timing(corbo_hip_handle h, double* solve_ms_sum, int64_t* solv
     return CORBO_HIP_OK;
 }
 
+int corbo_hip_factor_route(corbo_hip_handle h)
+{
+    if (!h) return fail(CORBO_HIP_ERR_INVALID, "null handle");
+    if (h->bt_rounds > 0) return CORBO_HIP_FACTOR_BLOCK_TRI;
+    if (h->band.n > 0) return CORBO_HIP_FACTOR_BAND;
+    return big_family_dims(h->S.nx, h->S.nu) ? CORBO_HIP_FACTOR_STAGE_CHAIN : CORBO_HIP_FACTOR_STAGE_CR;
+}
+
 int corbo_hip_get_stats(corbo_hip_handle h, corbo_hip_stats* stats)
 try {
     if (!h || !stats) return fail(CORBO_HIP_ERR_INVALID, "null argument");

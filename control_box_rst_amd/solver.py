@@ -271,6 +271,10 @@ class BatchedLevenbergMarquardt:
         self._check(self.lib.corbo_hip_get_timing(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "corbo_hip_get_timing")
         return float(ms.value), int(n.value)
 
+    def factor_route(self) -> int:
+        """capi.FACTOR_*: the factorisation this handle's solves run through (corbo_hip_factor_route)."""
+        return int(self.lib.corbo_hip_factor_route(self._h))
+
     def get_stats(self) -> dict:
         s = Stats()
         self._check(self.lib.corbo_hip_get_stats(self._h, C.byref(s)), "corbo_hip_get_stats")

@@ -320,6 +320,18 @@ int corbo_hip_create(const corbo_hip_problem_desc* desc, int batch, int device, 
 #define CORBO_HIP_ROUTE_XE_BAND      2u
 int corbo_hip_create_routed(const corbo_hip_problem_desc* desc, int batch, int device, uint32_t route, corbo_hip_handle* out);
 void corbo_hip_destroy(corbo_hip_handle h);
+/* Which factorisation a handle's solves run through (decided in corbo_hip_create from the descriptor's structure; for logs, A/B scripts and the route tests):
+ *   CORBO_HIP_FACTOR_STAGE_CR     small-block families (nx <= 4): controls first, block cyclic reduction on the state blocks; one launch per solve up to 256 grid
+ *                                 points, host-launched passes with the workspace in HBM beyond
+ *   CORBO_HIP_FACTOR_STAGE_CHAIN  big-block family (5 <= nx <= 12): stage kernel + partitioned chain (a free dt as a second right-hand side)
+ *   CORBO_HIP_FACTOR_BAND         general band factorisation of J^T J (host-launched passes)
+ *   CORBO_HIP_FACTOR_BLOCK_TRI    small-block families with extra edges: block cyclic reduction on the (x_k, u_k) blocks, one launch per solve
+ * Returns the value, or a negative CORBO_HIP_ERR_* for a null handle. */
+#define CORBO_HIP_FACTOR_STAGE_CR    0
+#define CORBO_HIP_FACTOR_STAGE_CHAIN 1
+#define CORBO_HIP_FACTOR_BAND        2
+#define CORBO_HIP_FACTOR_BLOCK_TRI   3
+int corbo_hip_factor_route(corbo_hip_handle h);
 
 /* Upload per-instance data (what the grid holds in its vertices when solve() is entered):
  *   x  [batch][nv] vertex values, lb/ub [batch][nv] bounds (+-CORBO_HIP_INF = unbounded; entries of fixed

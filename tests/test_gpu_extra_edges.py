@@ -69,10 +69,21 @@ def test_lm_iterates_vs_reference(name):
 @pytest.mark.parametrize("seed", range(12))
 def test_random_batches_vs_oracle(oracle_mod, seed):
     """Random combinations of the new edge kinds on the unicycle / Van der Pol / time-optimal integrator families, batches of perturbed starts."""
+    _random_batch(oracle_mod, seed, 4, 40)
+
+
+@pytest.mark.parametrize("seed", range(100, 106))
+def test_random_batches_129_to_256_grid_points_vs_oracle(oracle_mod, seed):
+    """The same on horizons of 129 .. 256 grid points: the BIG instantiation of the block-tridiagonal route (bt_factor_body<.., BIG>: one lane per stage,
+    thirty-two list rounds), with and without a free dt."""
+    assert _random_batch(oracle_mod, seed, 129, 257) == capi.FACTOR_BLOCK_TRI
+
+
+def _random_batch(oracle_mod, seed, n_lo, n_hi):
     from control_box_rst_amd import problems
     rng = np.random.default_rng(8800 + seed)
     fam = ["unicycle", "vdp", "int3t"][seed % 3]
-    N = int(rng.integers(4, 40))
+    N = int(rng.integers(n_lo, n_hi))
     d = {"unicycle": problems.unicycle_desc, "vdp": problems.vdp_desc}[fam](N=N) if fam != "int3t" else problems.int3_desc(N=N, dt=0.1, time_optimal=True)
     d.constraint_integration = int(rng.integers(1, 3))
     if rng.random() < 0.7:
@@ -133,6 +144,7 @@ def test_random_batches_vs_oracle(oracle_mod, seed):
     X, chi2, _ = s.get_solution()
     assert np.abs(X - Xo).max() <= 3e-5 * max(1.0, np.abs(Xo).max()), (seed, fam, np.abs(X - Xo).max())
     assert np.allclose(chi2, chi2o, rtol=5e-5, atol=1e-10), (seed, chi2, chi2o)
+    return s.factor_route()
 
 
 @pytest.mark.parametrize("name", ["xe_unicycle_all_left_n100", "xe_unicycle_rate", "xe_vdp_eqlin_rate", "xe_int3_vargrid_trap", "xe_rocket_rate_eq", "xe_unicycle_all_n300"])
@@ -150,6 +162,7 @@ def test_narrow_band_kernel_vs_eight_wave_kernel(name):
             s.solve(new_run=(i == 0))
         x, chi2, status = s.get_solution()
         out.append((x, chi2, status, s.get_stats()))
+        assert s.factor_route() == capi.FACTOR_BAND, name
     (x0, c0, s0, t0), (x1, c1, s1, t1) = out
     assert np.array_equal(s0, s1)
     assert t0["factorizations"] == t1["factorizations"] and t0["accepted_steps"] == t1["accepted_steps"]
@@ -177,6 +190,7 @@ def test_block_tridiagonal_route_vs_band_route(name):
             s.solve(new_run=(i == 0))
         x, chi2, status = s.get_solution()
         out.append((x, chi2, status, s.get_stats()))
+        assert s.factor_route() == (capi.FACTOR_BAND if route else capi.FACTOR_BLOCK_TRI), (name, route)
     (x0, c0, s0, t0), (x1, c1, s1, t1) = out
     assert np.array_equal(s0, s1)
     for k in ("factorizations", "accepted_steps", "rejected_steps", "jacobian_sweeps"):
@@ -221,3 +235,23 @@ def test_block_tridiagonal_route_batch_async_and_per_pass_mode():
     # (two elimination orders of the same H: rounding-level differences amplified by ten iterations of finite-difference Jacobians -- measured 1.2e-6 / 1.8e-6,
     #  inside the default tolerances of the reference fixtures, 2e-6 relative on chi2 and 5e-6 on the iterates)
     assert np.allclose(cp, chi2, rtol=2e-6) and np.abs(Xp - X).max() <= 5e-6
+
+
+def test_factor_route_of_the_families():
+    """corbo_hip_factor_route: the headline structure -> stage-parallel cyclic reduction; the quadrotor -> stage + chain kernels; a rate limit on top -> the
+    block-tridiagonal route resp. (big-block family, horizons beyond 256 grid points) the band route."""
+    from control_box_rst_amd import problems
+    d = problems.unicycle_desc(N=100)
+    assert BatchedLevenbergMarquardt(d, 2).factor_route() == capi.FACTOR_STAGE_CR
+    for N, want in ((100, capi.FACTOR_BLOCK_TRI), (128, capi.FACTOR_BLOCK_TRI), (129, capi.FACTOR_BLOCK_TRI), (256, capi.FACTOR_BLOCK_TRI), (257, capi.FACTOR_BAND)):
+        d = problems.unicycle_desc(N=N)
+        d.ctrl_dev = capi.CTRL_DEV_RATE
+        d.ctrl_dev_params[0] = d.ctrl_dev_params[1] = 1.0
+        assert BatchedLevenbergMarquardt(d, 2).factor_route() == want, N
+        assert BatchedLevenbergMarquardt(d, 2, route=capi.ROUTE_XE_BAND).factor_route() == capi.FACTOR_BAND, N
+    q = problems.quad_desc(N=20)
+    assert BatchedLevenbergMarquardt(q, 2).factor_route() == capi.FACTOR_STAGE_CHAIN
+    q.ctrl_dev = capi.CTRL_DEV_RATE
+    for i in range(q.nu):
+        q.ctrl_dev_params[i] = 5.0
+    assert BatchedLevenbergMarquardt(q, 2).factor_route() == capi.FACTOR_BAND

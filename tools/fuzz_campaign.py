@@ -29,7 +29,8 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
                         ("dense weights (incl. long horizons)", F.test_random_dense_weights_vs_oracle, range(first, first + count // 2)),
                         ("hessian operators, partial terminal equality", H.test_random_descriptor_hessians_partial_terminal_equality, range(first, first + count // 2)),
                         # random combinations of the extra-edge kinds (incl. a user control function from seed 12 on) through the block-tridiagonal route (round 6)
-                        ("extra edges, block-tridiagonal route", X.test_random_batches_vs_oracle, range(first, first + count // 2))):
+                        ("extra edges, block-tridiagonal route", X.test_random_batches_vs_oracle, range(first, first + count // 2)),
+                        ("extra edges, 129 .. 256 grid points (BIG instantiation)", X.test_random_batches_129_to_256_grid_points_vs_oracle, range(first, first + count // 5))):
     n_bad = 0
     for seed in seeds:
         try:
