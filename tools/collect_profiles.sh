@@ -46,6 +46,8 @@ cp "$(first sfetch '*counter_collection.csv')" "$P/${RND}_sweep_pmc_fetch_counte
 # ---- per-pass phase table of the slowest headline instance, the device's deviation per ledger fixture
 python tools/pass_timeline.py 900 > "$P/${RND}_pass_phases_instance900.txt" 2>&1
 python tools/ledger_check.py > "$P/${RND}_ledger_device_deviation.txt" 2>&1
+bash tools/fetch_calibration.sh > "$P/${RND}_fetch_size_calibration.txt" 2>&1   # FETCH_SIZE / WRITE_SIZE against known byte counts per access pattern
+cd "$ROOT"
 { python tools/free_dt_time.py 100; python tools/pquad_time.py; } 2>&1 | grep -v amdgpu.ids > "$P/${RND}_free_dt_routes.txt"
 { python tools/xe_time.py; python tools/xe_batch_sweep.py; python tools/narrow_band_phases.py; } 2>&1 | grep -v amdgpu.ids > "$P/${RND}_extra_edge_routes.txt"
 { python tools/bt_phases.py 0 1; python tools/bt_phases.py 900 1024; } 2>&1 | grep -v amdgpu.ids | cut -c1-400 > "$P/${RND}_xe_pass_phases.txt"
