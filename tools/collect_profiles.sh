@@ -20,6 +20,7 @@ run loop   --kernel-trace --stats -d "$OUT/loop" -o loop --output-format csv -- 
 run band   --kernel-trace --stats -d "$OUT/band" -o band --output-format csv -- python "$ROOT/tools/band_time.py"
 run freedt --kernel-trace --stats -d "$OUT/freedt" -o freedt --output-format csv -- python "$ROOT/tools/free_dt_time.py" 100
 run xe     --kernel-trace --stats -d "$OUT/xe" -o xe --output-format csv -- python "$ROOT/tools/xe_time.py"
+run long   --kernel-trace --stats -d "$OUT/long" -o long --output-format csv -- python "$ROOT/tools/long_horizon_time.py"
 BATCH=8192 run b8192  --kernel-trace --stats -d "$OUT/b8192" -o b8192 --output-format csv -- python "$ROOT/tools/opt_probe.py" ""
 # ---- HBM traffic counters (separate passes): the stand-alone sweep, and the run-to-completion solve kernel
 run sfetch --pmc FETCH_SIZE -d "$OUT/sfetch" -o q --output-format csv -- python "$ROOT/tools/profile_sweep.py" 1024 10
@@ -36,7 +37,7 @@ run qfetch --pmc FETCH_SIZE -d "$OUT/qfetch" -o q --output-format csv -- python 
 run qwrite --pmc WRITE_SIZE -d "$OUT/qwrite" -o q --output-format csv -- python "$ROOT/tools/profile_cfg5.py" 512 3
 cd "$ROOT"
 P=$ROOT/profiles
-for n in bench sweep cfg5 cfg5ns loop band freedt xe b8192 hess hess1; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done; [ -f "$P/${RND}_hess_kernel_stats.csv" ] && mv "$P/${RND}_hess_kernel_stats.csv" "$P/${RND}_hessian_kernel_stats.csv"; [ -f "$P/${RND}_hess1_kernel_stats.csv" ] && mv "$P/${RND}_hess1_kernel_stats.csv" "$P/${RND}_hessian_single_kernel_stats.csv"; [ -f "$P/${RND}_cfg5ns_kernel_stats.csv" ] && mv "$P/${RND}_cfg5ns_kernel_stats.csv" "$P/${RND}_cfg5_nospec_kernel_stats.csv"
+for n in bench sweep cfg5 cfg5ns loop band freedt xe long b8192 hess hess1; do s=$(first $n "*kernel_stats.csv"); [ -n "$s" ] && cp "$s" "$P/${RND}_${n}_kernel_stats.csv"; done; [ -f "$P/${RND}_hess_kernel_stats.csv" ] && mv "$P/${RND}_hess_kernel_stats.csv" "$P/${RND}_hessian_kernel_stats.csv"; [ -f "$P/${RND}_hess1_kernel_stats.csv" ] && mv "$P/${RND}_hess1_kernel_stats.csv" "$P/${RND}_hessian_single_kernel_stats.csv"; [ -f "$P/${RND}_cfg5ns_kernel_stats.csv" ] && mv "$P/${RND}_cfg5ns_kernel_stats.csv" "$P/${RND}_cfg5_nospec_kernel_stats.csv"
 python tools/summarize_pmc.py sweep "$(first sfetch '*counter_collection.csv')" "$(first swrite '*counter_collection.csv')" 1024 100 "$TAG, tools/profile_sweep.py 1024 10" | cut -c1-300
 python tools/summarize_pmc.py solve "$(first lfetch '*counter_collection.csv')" "$(first lwrite '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 10 --warmup 2" | cut -c1-300
 python tools/summarize_pmc.py sq "$(first sq1 '*counter_collection.csv')" "$(first sq2 '*counter_collection.csv')" 1024 100 "$TAG, bench.py --solve-only --steps 5 --warmup 1" | cut -c1-600
