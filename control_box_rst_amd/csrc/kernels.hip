@@ -4608,7 +4608,7 @@ __device__ __forceinline__ int32_t* cu_row_of(int32_t* table)
 template <int DYN, int DEFECT, bool ARROW, bool LOOP, int NPC, int THREADS = SWEEP_THREADS, bool DENSE = false>
 __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS_WAVES : THREADS / 64)) void lm_pass_kernel(const FactorParams fp, const SweepParams sp)
 {
-    static_assert(!DENSE || THREADS == SWEEP_THREADS, "non-diagonal weights: four-wave shape");
+    static_assert(!DENSE || THREADS == SWEEP_THREADS || THREADS == 128, "non-diagonal weights: the four-wave shape, or two waves WITHOUT the stage-centric component pass (its lean staging and re-evaluated rows are the diagonal problem's)");
     constexpr int BK_LANE = (THREADS > 128) ? 128 : THREADS - 1;   // the lane that keeps the CU's progress row (a spare lane of wave 2 / the last lane)
     using Dy = Dynamics<DYN>;
     using FL = FactorLds<Dy::NX, Dy::NU>;
@@ -4714,7 +4714,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                         }
                     }
                 }
-                constexpr bool TWOW = (THREADS <= 128);   // two-wave shape: Jacobian stream-out and bookkeeping ride inside the factor phase (factor_body, after_gather)
+                constexpr bool TWOW = (THREADS <= 128) && !DENSE;   // two-wave shape: Jacobian stream-out and bookkeeping ride inside the factor phase (factor_body, after_gather); non-diagonal weights: the sweep phase stores and streams everything itself
                 int scv[2 * Dy::NX + Dy::NU + 1];   // (two-wave shape) Jacobian offsets of lane k's defect edge: requested by the sweep phase, used by this pass's factor phase as well
                 sweep_body<DYN, DEFECT, true, DENSE, false, THREADS>(spl, mode, spl.active_count, sl, xs, red, cs, jst, inst_v, tid_v, pass > 0, &keep, TWOW && max_passes > 0, TWOW ? scv : nullptr);   // (active_count: per-pass launches only)
                 __threadfence_block();
@@ -4774,7 +4774,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == SWEEP_THREADS ? CORBO_HIP_PASS
                 };
                 // (loop_passes = 0: ONE pass per launch -- the per-pass mode of corbo_hip_solve and the profiling mode; the trial iterate then
                 //  goes to HBM for the next launch instead of staying in the LDS array the next sweep phase evaluates it from)
-                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, DENSE, false, (THREADS <= 128)>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook, TWOW ? scv : nullptr, &smask);
+                factor_body<Dy::NX, Dy::NU, THREADS, ARROW, NPC, DENSE, false, TWOW>(fpl, sl, smem, inst_v, tid_v, j_fresh, max_passes > 0 ? xs : nullptr, &spl, &keep, max_passes > 0 || j_fresh, hook, TWOW ? scv : nullptr, &smask);
                 if constexpr (BK_DEFER) { if (bk_slot >= 0) bk_rank(); }
                 __threadfence_block();
                 __syncthreads();
@@ -5561,6 +5561,12 @@ bool launch_pass_t(const FactorParams& fp, const SweepParams& sp, hipStream_t st
     const bool two    = two_ok && fp.pass_threads != 256;
     if (fp.wdense_mask) {   // non-diagonal weights: the DENSE instantiation (four waves)
         if constexpr (Dy::NX <= 4) {
+            if (two) {   // two waves, 256 VGPRs (the four-wave instantiation spills 130 registers at its 128)
+                const dim3 b(128);
+                if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0, 128, true>), dim3(grid), b, lds, stream, fp, sp);
+                else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0, 128, true>), dim3(grid), b, lds, stream, fp, sp);
+                return true;
+            }
             const dim3 b(SWEEP_THREADS);
             if (fp.dt_free) hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, true, true, 0, SWEEP_THREADS, true>), dim3(grid), b, lds, stream, fp, sp);
             else hipLaunchKernelGGL((lm_pass_kernel<DYN, DEFECT, false, true, 0, SWEEP_THREADS, true>), dim3(grid), b, lds, stream, fp, sp);
