@@ -19,6 +19,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 O.build()
 O.load()
 bad = []
+ROUTES = []   # corbo_hip_factor_route of the 129 .. 256-grid-point cases (3 = block-tridiagonal route, 2 = band route: more list rounds than the BIG instantiation holds)
 for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range(first, first + count)),
                         ("quadrotor", F.test_random_quadrotor_descriptor_vs_oracle, range(first, first + count // 10)),
                         ("quadrotor, free dt", F.test_random_free_dt_quadrotor_descriptor_vs_oracle, range(first, first + count // 10)),
@@ -30,7 +31,7 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
                         ("hessian operators, partial terminal equality", H.test_random_descriptor_hessians_partial_terminal_equality, range(first, first + count // 2)),
                         # random combinations of the extra-edge kinds (incl. a user control function from seed 12 on) through the block-tridiagonal route (round 6)
                         ("extra edges, block-tridiagonal route", X.test_random_batches_vs_oracle, range(first, first + count // 2)),
-                        ("extra edges, 129 .. 256 grid points (BIG instantiation)", X.test_random_batches_129_to_256_grid_points_vs_oracle, range(first, first + count // 5))):
+                        ("extra edges, 129 .. 256 grid points (BIG instantiation)", lambda o, seed: ROUTES.append(X.random_batch_129_to_256(o, seed)), range(first, first + count // 5))):
     n_bad = 0
     for seed in seeds:
         try:
@@ -39,6 +40,7 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
             n_bad += 1
             bad.append((name, seed, type(e).__name__, str(e)[:300]))
     print(f"{name}: {len(seeds)} seeds, {n_bad} failed", flush=True)
+print(f"129 .. 256 grid points: {sum(1 for r in ROUTES if r == 3)} of {len(ROUTES)} cases through the block-tridiagonal route, {sum(1 for r in ROUTES if r == 2)} through the band route")
 for b in bad:
     print("FAILED", b)
 esc = F.ESCALATIONS
