@@ -58,19 +58,26 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     const int ks = tid & (HALF - 1), half = BIG ? 0 : tid / HALF;
     constexpr bool BOTH = BIG;   // the lane of a stage does both halves
     const bool st_on = ks < NB - 1;
+    // The factorisation after a REJECTED step (the Jacobian was not refreshed: j_in_lds is false) has the same J and the same right-hand side as the one before it:
+    // the assembled blocks of that one -- damping included -- come back from HBM / L2 (FactorParams::bt_snap: written below by every factorisation that assembles)
+    // and take this pass's mu on top of their diagonal, the reference's own H_ii += mu (levenberg_marquardt_sparse.cpp:135-138; never undone, :208).
+    const bool reuse = !j_in_lds && !first && p.bt_snap != nullptr;
+    double* const snap = p.bt_snap ? p.bt_snap + (size_t)inst * p.bt_snap_stride : nullptr;
+    const int snap2 = (NB * SZP + 3 + 1) / 2;   // double2 words of the block storage (the carve is even)
     int sco[WL + 1];
 #pragma unroll
-    for (int c = 0; c < WL + 1; ++c) sco[c] = p.stage_cols[st_on ? ks : 0].col[c];
+    for (int c = 0; c < WL + 1; ++c) sco[c] = reuse ? 0 : p.stage_cols[st_on ? ks : 0].col[c];
     // ... and so do the first steps of the product lists (a window of four 32-byte word groups per lane, kept in flight across the list loop below)
     const uint4* const pw = reinterpret_cast<const uint4*>(p.bt_pairs);
     const char* const Jb = reinterpret_cast<const char*>(smem);
     auto fetch = [&](int step, uint4& lo, uint4& hi) { const uint4* q = pw + ((size_t)step * THREADS + tid) * 2; lo = q[0]; hi = q[1]; };   // (the table is four steps longer than its last step)
     uint4 w0a, w0b, w1a, w1b, w2a, w2b, w3a, w3b;
-    fetch(0, w0a, w0b); fetch(1, w1a, w1b); fetch(2, w2a, w2b); fetch(3, w3a, w3b);
+    if (!reuse) { fetch(0, w0a, w0b); fetch(1, w1a, w1b); fetch(2, w2a, w2b); fetch(3, w3a, w3b); }
+    else w0a = w0b = w1a = w1b = w2a = w2b = w3a = w3b = uint4{0u, 0u, 0u, 0u};
     // ---- (1) operands [J | values | 0] in LDS: the Jacobian is there after an accepted step (the sweep phase of this pass assembled it), after a
     //      rejected one it is staged again from HBM / L2; the residual paired with it always comes from HBM / L2 (10 KB, written by this workgroup)
     double* const Jv = smem;
-    if (!j_in_lds) {
+    if (!j_in_lds && !reuse) {
         const double2* src = reinterpret_cast<const double2*>(p.jac + (size_t)inst * p.nnz_pad);
         double2* dst       = reinterpret_cast<double2*>(Jv);
         const int n2       = p.nnz_pad / 2;
@@ -82,7 +89,7 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
             for (int u = 0; u < 4; ++u) { const int i = i0 + u * THREADS; dst[i < n2 ? i : n2 - 1] = v[u]; }
         }
     }
-    {
+    if (!reuse) {
         const double* val = (vbuf ? p.values1 : p.values0) + (size_t)inst * p.m_pad;
         double* dst       = Jv + p.nnz_pad;
         for (int i0 = tid; i0 < p.m; i0 += THREADS * 4) {
@@ -115,7 +122,7 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
         if (sr < R) {
             const uint4 t4 = reinterpret_cast<const uint4*>(p.bt_target)[(size_t)sr * THREADS + tid];
             tg[4 * sr] = t4.x; tg[4 * sr + 1] = t4.y; tg[4 * sr + 2] = t4.z; tg[4 * sr + 3] = t4.w;
-            const int s1 = p.bt_off[sr + 1];
+            const int s1 = reuse ? 0 : p.bt_off[sr + 1];
             // (per step: eight LDS operands in ONE batch -- the empty asm takes all of them, so all eight reads are issued before the first product)
             auto products = [&](const uint4& lo, const uint4& hi) {
                 auto ld = [&](unsigned off) { return *reinterpret_cast<const double*>(Jb + off); };
@@ -143,6 +150,10 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     //      G^T G once the operands are dead: half 0 the diagonal block of stage ks and its right-hand side, half 1 the coupling F_ks = H(x_{ks+1}, (x, u)_ks)
     //      and, in a second write phase, what the edge adds to the NEXT block (C^T C, -C^T r).  (Through the product lists these were 2 x 132 scattered LDS
     //      reads per stage, and the LDS pipe is what the three workgroups of a CU share.)
+    // H_ii += mu on every inner pass, never undone on reject (:135-138 and the comment at :208); the first factorisation of a solve learns its mu below
+    double mu_eff = first ? 0.0 : (fresh ? 0.0 : mu_acc_in) + mu;
+    double* const blk = smem;
+    if (!reuse) {
     double G[NX][WL], rv[NX], dc[NX];
 #pragma unroll
     for (int c = 0; c < WL; ++c) {
@@ -158,10 +169,7 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
         const double d = Jv[(ARROW && o >= 0 ? o : 0) + r];
         dc[r] = (ARROW && st_on && o >= 0) ? d : 0.0;
     }
-    // H_ii += mu on every inner pass, never undone on reject (:135-138 and the comment at :208); the first factorisation of a solve learns its mu below
-    double mu_eff = first ? 0.0 : (fresh ? 0.0 : mu_acc_in) + mu;
     lds_barrier();   // every lane is through with the operands
-    double* const blk = smem;
     // ---- write phase X: complete diagonal blocks (lower part), right-hand sides, borders and couplings of the stages, plain stores
     if (st_on && half == 0) {
         double* sk = blk + ks * SZP;
@@ -284,6 +292,47 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
 #pragma unroll
         for (int q = 0; q < 4 * MAXSR; ++q)
             if (q < 4 * R && (tg[q] & BT_DIAG)) blk[tg[q] & BT_SLOT] += mu_eff;
+        lds_barrier();
+    }
+    if (snap) {   // the assembled blocks, for the factorisation that follows a rejected step (stores nothing waits for; the reads precede the elimination's first writes)
+        const double2* b2 = reinterpret_cast<const double2*>(blk);
+        double2* s2       = reinterpret_cast<double2*>(snap);
+        for (int i0 = tid; i0 < snap2; i0 += THREADS * 4) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * THREADS; v[u] = b2[i < snap2 ? i : snap2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * THREADS; if (i < snap2) s2[i] = v[u]; }
+        }
+        lds_barrier();
+    }
+    }
+    else {
+        // ---- after a rejected step: the blocks of the previous factorisation, this pass's mu on top of their diagonal (the identity rows of fixed components stay)
+        {
+            const double2* s2 = reinterpret_cast<const double2*>(snap);
+            double2* b2       = reinterpret_cast<double2*>(blk);
+            constexpr int UN = 12;   // (the headline horizon's 44 KB in ONE round trip: eleven 16-byte loads per lane in flight)
+            for (int i0 = tid; i0 < snap2; i0 += THREADS * UN) {
+                double2 v[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; v[u] = s2[i < snap2 ? i : snap2 - 1]; }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; if (i < snap2) b2[i] = v[u]; }
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < 4 * MAXSR; ++q) {
+            if (q < 4 * R) {   // (uniform; branch-free inside: every other entry goes through the trash slot)
+                const unsigned t = tg[q];
+                const bool d = (t & BT_DIAG) && !(t & BT_ONE);
+                const unsigned slot = d ? (t & BT_SLOT) : (unsigned)(NB * SZP + 2);
+                const double v = blk[slot] + (d ? mu : 0.0);
+                blk[slot]  = v;
+                snap[slot] = v;   // (a streak of rejected steps: the next one adds its mu to this)
+            }
+        }
         lds_barrier();
     }
     BT_STAMP(3);

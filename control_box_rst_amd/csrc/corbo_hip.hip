@@ -226,6 +226,8 @@ struct corbo_hip_solver {
     uint32_t *d_bt_pairs = nullptr, *d_bt_target = nullptr;   // block-tridiagonal route (structure.hpp BtTables): the small-block families with extra edges, run to completion
     int32_t* d_bt_off = nullptr;
     int bt_rounds = 0;
+    double* d_bt_snap = nullptr;       // FactorParams::bt_snap
+    int bt_snap_stride = 0;
     bool async_error_deferred = false;   // an enqueued solve hit the pass limit and a mutator drained it: reported by the next result / solve call
     int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr, *d_spec_adopted = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
@@ -311,7 +313,7 @@ struct corbo_hip_solver {
         p.stage_cache = d_stage_cache; p.stage_cache_stride = (int64_t)stage_cache_stride;
         p.defect = S.desc.defect;
         p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
-        p.bt_pairs = d_bt_pairs; p.bt_off = d_bt_off; p.bt_target = d_bt_target; p.bt_rounds = bt_rounds;
+        p.bt_pairs = d_bt_pairs; p.bt_off = d_bt_off; p.bt_target = d_bt_target; p.bt_rounds = bt_rounds; p.bt_snap = d_bt_snap; p.bt_snap_stride = bt_snap_stride;
         return p;
     }
 };
@@ -596,6 +598,11 @@ static int create_impl(const corbo_hip_problem_desc* desc, int batch, int device
             if (upload(bt.pairs, &h->d_bt_pairs) || upload(bt.off, &h->d_bt_off) || upload(bt.target, &h->d_bt_target)) return CORBO_HIP_ERR_DEVICE;
             h->bt_rounds = bt.rounds;
             bt_route = true;
+            {   // the assembled blocks of an instance's last factorisation (re-used after a rejected step): N blocks of 2 s^2 + s (+ s: free dt) doubles, odd stride, + 3
+                const int s_ = S.nx + S.nu, szp = (2 * s_ * s_ + s_ + (S.dt_free ? s_ : 0)) | 1;
+                h->bt_snap_stride = (S.N * szp + 3 + 1) / 2 * 2;
+                CREATE_TRY(hipMalloc((void**)&h->d_bt_snap, B * (size_t)h->bt_snap_stride * sizeof(double)));
+            }
         }
     }
     if (band_route) {
@@ -695,7 +702,7 @@ void corbo_hip_destroy(corbo_hip_handle h)
     void* ptrs[] = {h->d_stage_cols, h->d_comp, h->d_ineq_cols, h->d_ineq_rows,
                     h->d_x0, h->d_x, h->d_xt, h->d_lb, h->d_ub, h->d_xref, h->d_values0, h->d_values1, h->d_jac, h->d_state, h->d_chi2, h->d_work, h->d_xe0, h->d_counters, h->d_queue, h->d_bound_rows, h->d_xplant, h->d_loop, h->d_lin, h->d_wdense, h->d_refvec, h->d_reftraj, h->d_plant_prm, h->d_dyn_inst,
                     h->d_xedges, h->d_xparams, h->d_uprev, h->d_band_work, h->d_band_target, h->d_band_ptr, h->d_band_pairs, h->d_band_rptr, h->d_band_rent, h->d_band_voff,
-                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase, h->d_bt_pairs, h->d_bt_target, h->d_bt_off, h->d_xtasks};
+                    h->d_spec_parent, h->d_spec_seen, h->d_spec_slotrej, h->d_spec_prev, h->d_spec_adopted, h->d_stage_cache, h->d_phase, h->d_bt_pairs, h->d_bt_target, h->d_bt_off, h->d_xtasks, h->d_bt_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& c : h->hess_cache) { c.d_so.release(); c.d_lo.release(); }

@@ -141,6 +141,10 @@ struct FactorParams {
     const int32_t* bt_off;
     const uint32_t* bt_target;
     int32_t bt_rounds;
+    // ... the assembled, damped blocks of an instance's last factorisation [batch][bt_snap_stride]: the factorisation after a REJECTED step has the same J and the
+    // same right-hand side, it reloads them and adds its mu to the diagonal (levenberg_marquardt_sparse.cpp:135-138: H_ii += mu, never undone) instead of assembling again
+    double* bt_snap;
+    int32_t bt_snap_stride;
 };
 
 // Reject-streak speculation of the big-block family (big_spec_kernel; VERDICT r3 item 2 a).  An instance whose trial step was rejected re-factorises the
