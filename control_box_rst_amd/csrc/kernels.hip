@@ -4957,8 +4957,9 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
     if constexpr (Dynamics<DYN>::NX <= 4) {
         if (p.N > LONG_HORIZON) {   // long horizon: Jacobian straight to HBM
             if constexpr (DEFECT != DEFECT_SHOOTING_HIGH) {
-                if (p.n_xedges > 0) {   // ... with integral-form constraint edges / control-deviation edges
-                    hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+                if (p.n_xedges > 0) {   // ... with integral-form constraint edges / control-deviation edges (and non-diagonal weights: the band route reads any pattern)
+                    if (p.mp.wdense) hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true, true, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+                    else hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, true, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
                     return;
                 }
             }
@@ -4968,7 +4969,8 @@ void launch_sweep_t(const SweepParams& p, hipStream_t stream)
         }
         if constexpr (DEFECT != DEFECT_SHOOTING_HIGH) {
             if (p.n_xedges > 0) {   // integral-form constraint edges (finite-differences grids) / control-deviation edges (every grid): the XE instantiation
-                hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+                if (p.mp.wdense) hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, true, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
+                else hipLaunchKernelGGL((sweep_kernel<DYN, DEFECT, false, false, true>), dim3(p.batch), dim3(SWEEP_THREADS), sweep_lds_bytes(p, Dynamics<DYN>::NC), stream, p);
                 return;
             }
         }

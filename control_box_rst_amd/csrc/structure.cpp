@@ -132,7 +132,7 @@ std::string validate_desc(const corbo_hip_problem_desc& d)
             if (d.cost_nonlsq || d.cost_integral) return "integral-form constraints / control-deviation term: Levenberg-Marquardt path (least-squares costs) only";
             if (d.nx > 4 && !big_family_dims(d.nx, d.nu)) return "integral-form constraints / control-deviation term: families with nx <= 4, and the big-block family";
             if (d.N < 3 || d.N > 1024) return "integral-form constraints / control-deviation term: 3 <= N <= 1024";
-            if (d.weights_dense) return "integral-form constraints / control-deviation term: diagonal weights";
+            if (d.weights_dense && d.nx > 4) return "integral-form constraints / control-deviation term with non-diagonal weights: families with nx <= 4";   // (band route: the DENSE x XE sweep instantiation)
             if (d.shooting_integrator >= 5) return "integral-form constraints / control-deviation term: shooting integrators up to Runge-Kutta 4";
         }
     }

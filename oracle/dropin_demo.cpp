@@ -265,7 +265,7 @@ static bool g_track_model = true;   // LevenbergMarquardtSparseHip::setTrackMode
 
 // scenarios: "unicycle" cfg 3 single instance; "dint" cfg 2 (free dt, 5 consecutive solves, new_run only first); "quad" reduced cfg 5;
 // "vdp" cfg 1; "unicycle_tball" TerminalBall; "duffing" / "pendulum" / "lin32": reference benchmark classes with NON-default parameters
-// (their private members are what the recogniser has to get right); "unicycle_fullq": non-diagonal Q, R, Qf (dense cost blocks); "unicycle_uref": a non-zero control reference (must be refused)
+// (their private members are what the recogniser has to get right); "unicycle_fullq": non-diagonal Q, R, Qf (dense cost blocks); "unicycle_fullq_xe_rate": the same with a rate limit on the controls (band route); "unicycle_uref": a non-zero control reference (must be refused)
 static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* describe_out = nullptr)
 {
     Run r;
@@ -296,12 +296,12 @@ static Run run(const std::string& scenario, Mode mode, int N, RecogniseOnly* des
     const bool plain = (scenario == "unicycle_plain" || stated || scenario == "vdp_plain" || scenario == "unicycle_plain_tvref"), itrap = (scenario == "unicycle_itrap" || scenario == "vdp_itrap" || msint),
                ileft = (scenario == "unicycle_ileft");
     const bool hpath = plain || itrap || ileft;
-    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq"), tvref = (scenario == "unicycle_tvref" || scenario == "unicycle_plain_tvref" || scenario == "unicycle_msint_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
+    const bool tball = (scenario == "unicycle_tball"), fullq = (scenario == "unicycle_fullq" || scenario == "unicycle_fullq_xe_rate"), tvref = (scenario == "unicycle_tvref" || scenario == "unicycle_plain_tvref" || scenario == "unicycle_msint_tvref"), urefnz = (scenario == "unicycle_uref"), kcar = (scenario == "kcar");
     const bool moved = (scenario == "unicycle_moved");   // the setpoint moves between two runs WITHOUT a structure change (model tracking)
     // integral-form constraints / control-deviation term (user stage functions above): the ball as integrand (trapezoidal rule), a linear integral
     // equality (left sum), an input-rate limit with a previously applied control, and all three together
     const bool xe_ball = (scenario == "unicycle_xe_ball" || scenario == "unicycle_xe_all"), xe_eq = (scenario == "unicycle_xe_eq" || scenario == "unicycle_xe_all"),
-               xe_rate = (scenario == "unicycle_xe_rate" || scenario == "unicycle_xe_all"), sf_unorm = (scenario == "unicycle_sf_unorm"), xe = xe_ball || xe_eq || xe_rate || sf_unorm;
+               xe_rate = (scenario == "unicycle_xe_rate" || scenario == "unicycle_xe_all" || scenario == "unicycle_fullq_xe_rate"), sf_unorm = (scenario == "unicycle_sf_unorm"), xe = xe_ball || xe_eq || xe_rate || sf_unorm;
     const bool uni = (scenario == "unicycle" || xe || moved || tball || tballc || fullq || tvref || urefnz || kcar || (hpath && scenario.compare(0, 3, "vdp") != 0));
     if (uni)
     {
@@ -795,7 +795,7 @@ int main(int argc, char** argv)
         return 0;
     }
     // the HIP solver configured with the reference solver's own setters only: the device model comes from the graph
-    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate", "quad_topt", "quad_rk5", "unicycle_sf_unorm", "quad_sf_tilt"})
+    for (const char* sc : {"unicycle", "dint", "quad", "unicycle_tball", "vdp", "duffing", "pendulum", "lin32", "unicycle_tvref", "dint_ms", "dint_mtq", "unicycle_tballc", "dint_mtq8", "rocket", "mpendulum", "toy", "artstein", "cartpole", "par2", "unicycle_fullq", "lin32_rk3", "kcar", "pquad", "lin32_rk7", "pquad_fd", "unicycle_moved", "unicycle_xe_ball", "unicycle_xe_eq", "unicycle_xe_rate", "unicycle_xe_all", "pquad_topt", "pquad_pteq", "pquad_fd_xe_ball", "pquad_xe_rate", "quad_topt", "quad_rk5", "unicycle_sf_unorm", "quad_sf_tilt", "unicycle_fullq_xe_rate"})
     {
         const int N = horizon(sc);
         Run a = run(sc, Mode::Reference, N);

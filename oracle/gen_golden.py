@@ -521,6 +521,10 @@ XE = [
     ("xe_sf_int3_unorm_vargrid", dict(scenario="int3", N=20, iters=5, vargrid=1, xf="1.0,0.0,0.0", unorm=1.5), (1, 2, 3, 5)),
     ("xe_sf_quad_tilt_unorm", dict(scenario="quad", N=10, iters=5, noball=1, tilt=0.15, unorm=11.0), (1, 2, 3, 5)),
     # ... and a horizon of 200 grid points: the BIG instantiation of the block-tridiagonal route (129 .. 256 grid points)
+    # non-diagonal weights TOGETHER with extra edges (band route: the DENSE x XE sweep instantiation)
+    ("xe_unicycle_rate_fullq", dict(scenario="unicycle", N=12, iters=6, fullq=1, rate="0.8,0.5", u_prev="0.2,-0.1", u_prev_dt=0.07), (1, 2, 3, 4, 6)),
+    ("xe_vdp_eqlin_rate_fullq", dict(scenario="vdp", N=20, iters=6, fullq=1, xf="0.4,0.1", crule="trap", eq_lin="0.3,-0.2,0.05,0.1", rate="0.7"), (1, 2, 3, 6)),   # (xf: a ZERO state reference is the reference's 1 x 1-into-vector branch, see vdp_fullq)
+    ("xe_unicycle_rate_fullq_n300", dict(scenario="unicycle", N=300, dt=0.04, iters=3, fullq=1, rate="0.9,0.6", u_prev="0.1,0.1"), (1, 3)),
     ("xe_unicycle_rate_n200", dict(scenario="unicycle", N=200, dt=0.05, iters=4, rate="0.9,0.6", u_prev="0.1,0.1"), (1, 2, 4)),
     ("xe_unicycle_all_n300", dict(scenario="unicycle", N=300, dt=0.04, iters=4, crule="trap", ball="1.0,0.5,0.2,0.3", ball_int=1, eq_lin="0.3,-0.2,0.1,0.05,0.02,0.1",
                                   rate="0.9,0.6"), (1, 2, 4)),

@@ -39,8 +39,10 @@ def test_reference_ocp_with_hip_solver_matches_reference_solver():
                                               "quad_topt", "quad_rk5",
                                               # round 6: USER stage functions of csrc/stage_functions/ matched against the graph's inequality edges by evaluation -- an input-magnitude
                                               # bound on every u_k (control term), a tilt cone on the quadrotor's roll / pitch (state term)
-                                              "unicycle_sf_unorm", "quad_sf_tilt", "unicycle"], (p.stdout, p.stderr)   # (quad_rk5: Runge-Kutta 5 around the 12-state model)
-    assert [r["mode"] for r in solved] == ["recognised"] * 38 + ["stated"]   # (unicycle_moved: the setpoint moves between two runs without a structure change -- model tracking)   # (kcar, pquad: user dynamics classes matched against csrc/models/kinematic_car.hpp / planar_quadrotor.hpp -- the latter one of the big-block family)   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
+                                              "unicycle_sf_unorm", "quad_sf_tilt",
+                                              # ... non-diagonal weights TOGETHER with a rate limit on the controls (band route: the DENSE x XE sweep instantiation)
+                                              "unicycle_fullq_xe_rate", "unicycle"], (p.stdout, p.stderr)   # (quad_rk5: Runge-Kutta 5 around the 12-state model)
+    assert [r["mode"] for r in solved] == ["recognised"] * 39 + ["stated"]   # (unicycle_moved: the setpoint moves between two runs without a structure change -- model tracking)   # (kcar, pquad: user dynamics classes matched against csrc/models/kinematic_car.hpp / planar_quadrotor.hpp -- the latter one of the big-block family)   # (dint_ms: cfg 2 on the MultipleShootingVariableGrid; dint_mtq: MinTimeQuadratic;
     # unicycle_tballc: TerminalBallInheritFromCost; dint_mtq8: MinTimeQuadratic with only_last_n)
     for r in solved:
         assert r["ok_reference"] == 1 and r["ok_hip"] == 1, (r, p.stderr[-2000:])

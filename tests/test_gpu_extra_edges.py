@@ -84,10 +84,19 @@ def random_batch_129_to_256(oracle_mod, seed):
     return _random_batch(oracle_mod, seed, 129, 257)
 
 
-def _random_batch(oracle_mod, seed, n_lo, n_hi):
+@pytest.mark.parametrize("seed", range(200, 208))
+def test_random_batches_with_dense_weights_vs_oracle(oracle_mod, seed):
+    """Non-diagonal Q / R / Qf TOGETHER with extra edges (band route: sweep_kernel<.., DENSE, .., XE>), short horizons and -- every other seed -- beyond 256 grid points."""
+    lo, hi = ((257, 300) if seed % 2 else (4, 40))
+    assert _random_batch(oracle_mod, seed, lo, hi, dense=True) == capi.FACTOR_BAND
+
+
+def _random_batch(oracle_mod, seed, n_lo, n_hi, dense=False):
     from control_box_rst_amd import problems
     rng = np.random.default_rng(8800 + seed)
     fam = ["unicycle", "vdp", "int3t"][seed % 3]
+    if dense and fam == "int3t":
+        fam = "vdp"   # (the time-optimal family has no quadratic cost to make dense)
     N = int(rng.integers(n_lo, n_hi))
     d = {"unicycle": problems.unicycle_desc, "vdp": problems.vdp_desc}[fam](N=N) if fam != "int3t" else problems.int3_desc(N=N, dt=0.1, time_optimal=True)
     d.constraint_integration = int(rng.integers(1, 3))
@@ -110,6 +119,13 @@ def _random_batch(oracle_mod, seed, n_lo, n_hi):
     if seed >= 12 and rng.random() < 0.5:   # (campaign seeds -- tools/fuzz_campaign.py: a user control function, csrc/stage_functions/control_norm.hpp, on top)
         d.stage_ineq_control = capi.STAGE_FN_USER + 1
         d.ineq_control_params[0] = float(rng.uniform(0.3, 1.5))
+    if dense:   # random symmetric positive definite weights, handed over as upper Cholesky factors (U^T U = the weight)
+        rd = np.random.default_rng(99000 + seed)
+        d.weights_dense = 1 | (2 if d.nu > 1 else 0) | (4 if d.final_cost else 0)
+        for dst, n in ((d.q_sqrt, d.nx), (d.r_sqrt, d.nu), (d.qf_sqrt, d.nx)):
+            a = rd.uniform(-1, 1, (n, n))
+            for i, v in enumerate(np.linalg.cholesky(a.T @ a + 0.5 * np.eye(n)).T.ravel()):
+                dst[i] = float(v)
     B = 3
     x0 = rng.uniform(-1, 1, (B, d.nx))
     xf = rng.uniform(-0.5, 0.5, (B, d.nx)) + (np.array([1.5, 0.5, 0.2])[: d.nx] if fam != "int3t" else 0.0)
@@ -177,7 +193,7 @@ def test_narrow_band_kernel_vs_eight_wave_kernel(name):
     assert np.abs(x0 - x1).max() <= 2e-6, (name, np.abs(x0 - x1).max())
 
 
-SMALL_BLOCK = [n for n in FIXTURES if "quad" not in n and "n300" not in n]   # (the big-block family and horizons beyond 256 grid points keep the band route; n200: the BIG instantiation)
+SMALL_BLOCK = [n for n in FIXTURES if "quad" not in n and "n300" not in n and "fullq" not in n]   # (the big-block family and horizons beyond 256 grid points keep the band route; n200: the BIG instantiation)
 
 
 @pytest.mark.parametrize("name", SMALL_BLOCK)
