@@ -31,6 +31,7 @@ for name, fn, seeds in (("descriptor", F.test_random_descriptor_vs_oracle, range
                         ("hessian operators, partial terminal equality", H.test_random_descriptor_hessians_partial_terminal_equality, range(first, first + count // 2)),
                         # random combinations of the extra-edge kinds (incl. a user control function from seed 12 on) through the block-tridiagonal route (round 6)
                         ("extra edges, block-tridiagonal route", X.test_random_batches_vs_oracle, range(first, first + count // 2)),
+                        ("extra edges + non-diagonal weights (band route)", X.test_random_batches_with_dense_weights_vs_oracle, range(first, first + count // 5)),
                         ("extra edges, 129 .. 256 grid points (BIG instantiation)", lambda o, seed: ROUTES.append(X.random_batch_129_to_256(o, seed)), range(first, first + count // 5))):
     n_bad = 0
     for seed in seeds:
