@@ -258,6 +258,33 @@ def test_block_tridiagonal_route_batch_async_and_per_pass_mode():
     assert np.allclose(cp, chi2, rtol=2e-6) and np.abs(Xp - X).max() <= 5e-6
 
 
+def test_block_tridiagonal_route_instance_queue_bit_equal_to_slices():
+    """More instances than the chip holds workgroups of lm_bt_kernel (1200 > 4 x 256: the instance queue -- a workgroup pulls instance after instance, its
+    LDS and the instance's row of the re-used blocks in HBM change hands): every instance bit for bit what it is in a batch of 600 that is resident at once."""
+    import bench
+    B = 1200
+    w = bench.workload(3, B)
+    d = w["desc"]
+    d.ctrl_dev = capi.CTRL_DEV_RATE
+    d.ctrl_dev_params[0] = 0.9
+    d.ctrl_dev_params[1] = 0.7
+
+    def run(lo, hi):
+        s = BatchedLevenbergMarquardt(d, hi - lo)
+        assert s.factor_route() == capi.FACTOR_BLOCK_TRI
+        s.setPenaltyWeights(*w["weights"])
+        s.set_instance_data(s.init_trajectory(w["x0"][lo:hi], w["xf"][lo:hi]), xref=w["xf"][lo:hi])
+        s.solve()
+        X, chi2, status = [a.copy() for a in s.get_solution()]
+        return X, chi2, status, s.get_stats()
+
+    X, chi2, status, st = run(0, B)
+    assert st["rejected_steps"] > B   # (the rate-limited problem rejects every other step: the re-used blocks are exercised)
+    for lo, hi in ((0, 600), (600, 1200)):
+        Xs, cs, ss, _ = run(lo, hi)
+        assert np.array_equal(Xs, X[lo:hi]) and np.array_equal(cs, chi2[lo:hi]) and np.array_equal(ss, status[lo:hi]), (lo, hi)
+
+
 def test_factor_route_of_the_families():
     """corbo_hip_factor_route: the headline structure -> stage-parallel cyclic reduction; the quadrotor -> stage + chain kernels; a rate limit on top -> the
     block-tridiagonal route resp. (big-block family, horizons beyond 256 grid points) the band route."""
