@@ -228,6 +228,7 @@ struct corbo_hip_solver {
     int bt_rounds = 0;
     double* d_bt_snap = nullptr;       // FactorParams::bt_snap
     int bt_snap_stride = 0;
+    int bt_waves = 0;                  // option "bt_waves": 0 = by batch size, 2 / 3 = that instantiation of lm_bt_kernel (A/B)
     bool async_error_deferred = false;   // an enqueued solve hit the pass limit and a mutator drained it: reported by the next result / solve call
     int32_t *d_spec_parent = nullptr, *d_spec_seen = nullptr, *d_spec_slotrej = nullptr, *d_spec_prev = nullptr, *d_spec_adopted = nullptr;
     int hess_split = -1;        // corbo_hip_set_option("hess_split"): -1 = automatic, 0 / 1 / 2 (HessParams::split; tests, A/B)
@@ -313,7 +314,7 @@ struct corbo_hip_solver {
         p.stage_cache = d_stage_cache; p.stage_cache_stride = (int64_t)stage_cache_stride;
         p.defect = S.desc.defect;
         p.wdense_mask = d_wdense ? S.desc.weights_dense : 0;
-        p.bt_pairs = d_bt_pairs; p.bt_off = d_bt_off; p.bt_target = d_bt_target; p.bt_rounds = bt_rounds; p.bt_snap = d_bt_snap; p.bt_snap_stride = bt_snap_stride;
+        p.bt_pairs = d_bt_pairs; p.bt_off = d_bt_off; p.bt_target = d_bt_target; p.bt_rounds = bt_rounds; p.bt_snap = d_bt_snap; p.bt_snap_stride = bt_snap_stride; p.bt_waves = bt_waves; p.num_cus = num_cus;
         return p;
     }
 };
@@ -1630,6 +1631,7 @@ int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value)
     else if (n == "chain_variant") h->chain_variant = value;
     else if (n == "band_wide") h->band_wide = value;
     else if (n == "hess_split") h->hess_split = value;
+    else if (n == "bt_waves") h->bt_waves = (value == 2 || value == 3) ? value : 0;
     else if (n == "reject_speculation") h->reject_speculation = value;
     else if (n == "stagger") h->stagger = value;
     else if (n == "pass_threads") h->pass_threads = value;

@@ -4830,8 +4830,10 @@ __host__ __device__ constexpr int bt_carve_doubles(int N, int nnz_pad, int m_pad
 }
 
 // BIG: horizons of 129 .. 256 grid points (bt_factor_body<.., BIG>): the block storage alone is 113 KB for the unicycle at N = 256 -- one workgroup per CU, all its registers
-template <int DYN, int DEFECT, bool ARROW, bool BIG = false>
-__global__ __launch_bounds__(BT_THREADS, (BIG ? 1 : CORBO_HIP_BT_WAVES)) void lm_bt_kernel(const FactorParams fp, const SweepParams sp)
+// WAVES: waves per SIMD = workgroups per CU the instantiation is compiled for -- 3: 168 VGPRs (46 spilled), 768 resident instances; 2: 256 VGPRs, no spills, 512 resident
+// instances, 6 - 9 % fewer cycles per instance.  launch_bt_t picks by the number of ROUNDS the batch needs (1024 = 2 x 512: two; 768, 1536, the instance queue: three).
+template <int DYN, int DEFECT, bool ARROW, bool BIG = false, int WAVES = CORBO_HIP_BT_WAVES>
+__global__ __launch_bounds__(BT_THREADS, (BIG ? 1 : WAVES)) void lm_bt_kernel(const FactorParams fp, const SweepParams sp)
 {
     using Dy = Dynamics<DYN>;
     constexpr int THREADS = BT_THREADS;
@@ -4931,22 +4933,31 @@ bool launch_bt_t(const FactorParams& fp, const SweepParams& sp, hipStream_t stre
         const size_t carve = arrow ? bt_carve_doubles<Dy::NX, Dy::NU, true>(fp.N, fp.nnz_pad, fp.m_pad, Dy::NC, fp.nvs) : bt_carve_doubles<Dy::NX, Dy::NU, false>(fp.N, fp.nnz_pad, fp.m_pad, Dy::NC, fp.nvs);
         const size_t lds = sizeof(double) * (carve + fp.nvs + 12) + sizeof(LmState);
         if (lds > (size_t)160 * 1024) return false;
+        // (four waves per workgroup: workgroups per CU = waves per SIMD the kernel is compiled for, if the LDS holds as many)
+        const int lds_per_cu = (int)((size_t)160 * 1024 / lds) < 1 ? 1 : (int)((size_t)160 * 1024 / lds);
+        const int cus = fp.num_cus > 0 ? fp.num_cus : 256;
+        const int res3 = (lds_per_cu < 3 ? lds_per_cu : 3) * cus, res2 = (lds_per_cu < 2 ? lds_per_cu : 2) * cus;   // resident instances of the two instantiations
+        // two workgroups per CU whenever the batch needs no more rounds that way (<= 512, 769 .. 1024 on 256 CUs; whenever the LDS holds two at most) -- the register-rich
+        // instantiation is 6 - 9 % faster per instance; three for the batches in between and for the instance queue (1.39 against 1.68 us per instance sustained)
+        bool two = !fp.queue && ((fp.batch + res2 - 1) / res2 <= (fp.batch + res3 - 1) / res3);
+        if (fp.bt_waves == 2) two = true;
+        if (fp.bt_waves == 3) two = false;
         int grid = fp.batch;
         if (fp.queue) {
-            int per_cu = (int)((size_t)160 * 1024 / lds);
-            const int cap = big ? 1 : CORBO_HIP_BT_WAVES;   // (four waves per workgroup: workgroups per CU = waves per SIMD the kernel is compiled for)
+            int per_cu = lds_per_cu;
+            const int cap = big ? 1 : (two ? 2 : 3);
             if (per_cu > cap) per_cu = cap;
-            if (per_cu < 1) per_cu = 1;
             grid = fp.queue_grid * per_cu;
             if (grid > fp.batch) grid = fp.batch;
         }
-        static unsigned long long attr_set[4] = {0, 0, 0, 0};   // (per device)
+        static unsigned long long attr_set[6] = {0, 0, 0, 0, 0, 0};   // (per device)
         auto go = [&](auto kernel, int slot) {
             if (first_on_device(attr_set[slot])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(BT_THREADS), lds, stream, fp, sp);
         };
-        if (big) { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, true>, 3); else go(lm_bt_kernel<DYN, DEFECT, false, true>, 2); }
-        else { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, false>, 1); else go(lm_bt_kernel<DYN, DEFECT, false, false>, 0); }
+        if (big) { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, true, 1>, 3); else go(lm_bt_kernel<DYN, DEFECT, false, true, 1>, 2); }
+        else if (two) { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, false, 2>, 5); else go(lm_bt_kernel<DYN, DEFECT, false, false, 2>, 4); }
+        else { if (arrow) go(lm_bt_kernel<DYN, DEFECT, true, false, 3>, 1); else go(lm_bt_kernel<DYN, DEFECT, false, false, 3>, 0); }
         return true;
     }
 }

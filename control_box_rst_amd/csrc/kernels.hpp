@@ -145,6 +145,8 @@ struct FactorParams {
     // same right-hand side, it reloads them and adds its mu to the diagonal (levenberg_marquardt_sparse.cpp:135-138: H_ii += mu, never undone) instead of assembling again
     double* bt_snap;
     int32_t bt_snap_stride;
+    int32_t bt_waves;             // handle option "bt_waves": 0 = launch_bt_t chooses by batch size, 2 / 3 = the instantiation for that many workgroups per CU (A/B)
+    int32_t num_cus;              // compute units of the device (launch_bt_t: how many instances are resident at once)
 };
 
 // Reject-streak speculation of the big-block family (big_spec_kernel; VERDICT r3 item 2 a).  An instance whose trial step was rejected re-factorises the

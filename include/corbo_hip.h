@@ -610,7 +610,9 @@ int corbo_hip_eval_stage_function(int id, int dim, int n, const double* v, const
  *   "phase_cycles"      1: per-instance phase totals of the run-to-completion kernel (corbo_hip_get_phase_cycles)
  *   "raw_stamps"        1: "pass_timeline" prints raw stamp offsets (development builds that re-purpose the stamp slots)
  *   "band_wide"         1: the band route (integral-form constraint edges / control-deviation term) keeps the eight-wave factor kernel for every
- *                       half-bandwidth; 0 (default): half-bandwidths up to 7 take the one-wave-per-instance kernel */
+ *                       half-bandwidth; 0 (default): half-bandwidths up to 7 take the one-wave-per-instance kernel
+ *   "bt_waves"          2 / 3: the block-tridiagonal route's kernel for two / three workgroups per CU whatever the batch size; 0 (default): chosen by the
+ *                       number of rounds the batch needs (A/B) */
 int corbo_hip_set_option(corbo_hip_handle h, const char* name, int value);
 
 /* Text of the last error on this thread. */

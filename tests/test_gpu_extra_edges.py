@@ -258,6 +258,28 @@ def test_block_tridiagonal_route_batch_async_and_per_pass_mode():
     assert np.allclose(cp, chi2, rtol=2e-6) and np.abs(Xp - X).max() <= 5e-6
 
 
+def test_block_tridiagonal_route_two_and_three_workgroups_per_cu():
+    """lm_bt_kernel's two instantiations (option bt_waves: 256 VGPRs / two workgroups per CU, 168 VGPRs / three; launch_bt_t picks by the rounds a batch needs): the
+    same source, the same arithmetic -- bit-identical results; and the automatic choice is one of them."""
+    import bench
+    B = 160
+    w = bench.workload(3, B)
+    d = w["desc"]
+    d.ctrl_dev = capi.CTRL_DEV_RATE
+    d.ctrl_dev_params[0] = 1.0
+    d.ctrl_dev_params[1] = 0.8
+    out = []
+    for waves in (0, 2, 3):
+        s = BatchedLevenbergMarquardt(d, B)
+        s.set_option("bt_waves", waves)
+        s.setPenaltyWeights(*w["weights"])
+        s.set_instance_data(s.init_trajectory(w["x0"], w["xf"]), xref=w["xf"])
+        s.solve()
+        out.append([a.copy() for a in s.get_solution()])
+    for X, chi2, status in out[1:]:
+        assert np.array_equal(X, out[0][0]) and np.array_equal(chi2, out[0][1]) and np.array_equal(status, out[0][2])
+
+
 def test_block_tridiagonal_route_instance_queue_bit_equal_to_slices():
     """More instances than the chip holds workgroups of lm_bt_kernel (1200 > 4 x 256: the instance queue -- a workgroup pulls instance after instance, its
     LDS and the instance's row of the re-used blocks in HBM change hands): every instance bit for bit what it is in a batch of 600 that is resident at once."""
