@@ -73,7 +73,21 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     auto fetch = [&](int step, uint4& lo, uint4& hi) { const uint4* q = pw + ((size_t)step * THREADS + tid) * 2; lo = q[0]; hi = q[1]; };   // (the table is four steps longer than its last step)
     uint4 w0a, w0b, w1a, w1b, w2a, w2b, w3a, w3b;
     if (!reuse) { fetch(0, w0a, w0b); fetch(1, w1a, w1b); fetch(2, w2a, w2b); fetch(3, w3a, w3b); }
-    else w0a = w0b = w1a = w1b = w2a = w2b = w3a = w3b = uint4{0u, 0u, 0u, 0u};
+    else {
+        w0a = w0b = w1a = w1b = w2a = w2b = w3a = w3b = uint4{0u, 0u, 0u, 0u};
+        // the blocks of the previous factorisation straight into the block storage (nothing of the sweep phase lives there any more; no operands are staged on this path):
+        // the headline horizon's 44 KB in ONE round trip, eleven 16-byte loads per lane, in flight next to the table loads below
+        const double2* s2 = reinterpret_cast<const double2*>(snap);
+        double2* b2       = reinterpret_cast<double2*>(smem);
+        constexpr int UN = 12;
+        for (int i0 = tid; i0 < snap2; i0 += THREADS * UN) {
+            double2 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; v[u] = s2[i < snap2 ? i : snap2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; if (i < snap2) b2[i] = v[u]; }
+        }
+    }
     // ---- (1) operands [J | values | 0] in LDS: the Jacobian is there after an accepted step (the sweep phase of this pass assembled it), after a
     //      rejected one it is staged again from HBM / L2; the residual paired with it always comes from HBM / L2 (10 KB, written by this workgroup)
     double* const Jv = smem;
@@ -243,14 +257,19 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     }
     lds_barrier();
     // ---- write phase T: the sums of the product lists on top (every other row of J: cost, bound, inequality rows, the extra edges), the damping
+    // (every entry of H / rhs is the target of exactly one list, the padding's targets are the trash slot: all reads first -- one LDS round trip --, then the writes)
+    {
+        double cur[4 * MAXSR];
 #pragma unroll
-    for (int q = 0; q < 4 * MAXSR; ++q) {
-        if (q < 4 * R) {   // (uniform)
-            const unsigned slot = tg[q] & BT_SLOT;
-            double v = blk[slot] + acc[q];
-            v += (tg[q] & BT_DIAG) ? mu_eff : 0.0;
-            v = (tg[q] & BT_ONE) ? 1.0 : v;       // a fixed component / a pad row of the last block: an identity row, its increment is zero
-            blk[slot] = v;
+        for (int q = 0; q < 4 * MAXSR; ++q) cur[q] = (q < 4 * R) ? blk[tg[q] & BT_SLOT] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4 * MAXSR; ++q) {
+            if (q < 4 * R) {   // (uniform)
+                double v = cur[q] + acc[q];
+                v += (tg[q] & BT_DIAG) ? mu_eff : 0.0;
+                v = (tg[q] & BT_ONE) ? 1.0 : v;       // a fixed component / a pad row of the last block: an identity row, its increment is zero
+                blk[tg[q] & BT_SLOT] = v;
+            }
         }
     }
     lds_barrier();
@@ -308,29 +327,25 @@ __device__ __forceinline__ void bt_factor_body(const FactorParams& p, LmState* c
     }
     }
     else {
-        // ---- after a rejected step: the blocks of the previous factorisation, this pass's mu on top of their diagonal (the identity rows of fixed components stay)
-        {
-            const double2* s2 = reinterpret_cast<const double2*>(snap);
-            double2* b2       = reinterpret_cast<double2*>(blk);
-            constexpr int UN = 12;   // (the headline horizon's 44 KB in ONE round trip: eleven 16-byte loads per lane in flight)
-            for (int i0 = tid; i0 < snap2; i0 += THREADS * UN) {
-                double2 v[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; v[u] = s2[i < snap2 ? i : snap2 - 1]; }
-#pragma unroll
-                for (int u = 0; u < UN; ++u) { const int i = i0 + u * THREADS; if (i < snap2) b2[i] = v[u]; }
-            }
-        }
+        // ---- after a rejected step: the blocks of the previous factorisation (requested at the top of the phase), this pass's mu on top of their diagonal (the
+        //      identity rows of fixed components stay)
         lds_barrier();
+        {   // (reads first, then the writes: the diagonal slots are distinct, every other entry goes through the trash slot)
+            double cur[4 * MAXSR];
 #pragma unroll
-        for (int q = 0; q < 4 * MAXSR; ++q) {
-            if (q < 4 * R) {   // (uniform; branch-free inside: every other entry goes through the trash slot)
-                const unsigned t = tg[q];
-                const bool d = (t & BT_DIAG) && !(t & BT_ONE);
-                const unsigned slot = d ? (t & BT_SLOT) : (unsigned)(NB * SZP + 2);
-                const double v = blk[slot] + (d ? mu : 0.0);
-                blk[slot]  = v;
-                snap[slot] = v;   // (a streak of rejected steps: the next one adds its mu to this)
+            for (int q = 0; q < 4 * MAXSR; ++q) {
+                const bool d = (q < 4 * R) && (tg[q] & BT_DIAG) && !(tg[q] & BT_ONE);
+                cur[q] = blk[d ? (tg[q] & BT_SLOT) : (unsigned)(NB * SZP + 2)];
+            }
+#pragma unroll
+            for (int q = 0; q < 4 * MAXSR; ++q) {
+                const bool d = (q < 4 * R) && (tg[q] & BT_DIAG) && !(tg[q] & BT_ONE);
+                if (d) {
+                    const unsigned slot = tg[q] & BT_SLOT;
+                    const double v = cur[q] + mu;
+                    blk[slot]  = v;
+                    snap[slot] = v;   // (a streak of rejected steps: the next one adds its mu to this)
+                }
             }
         }
         lds_barrier();
