@@ -1630,10 +1630,13 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // after_gather: called once every lane holds its Jacobian entries and before the staging area is released -- the run-to-completion kernel streams the
 // freshly evaluated Jacobian out there and does its per-CU bookkeeping: memory operations that nothing in the factor phase waits for, issued BEHIND the
 // phase's own loads (gfx9 returns vector-memory operations in order: a load's wait includes every store and every slow load issued before it).
-template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, bool GWS = false, bool RECOMP = false, class Hook = NoHook>
+// GWS = 2 (round 6; horizons beyond 256 grid points whose state-block arrays fit the CU's LDS: up to ~ 700 grid points for nx = 3): only the arrays of the eliminated
+// CONTROLS -- written and read by the lane of their own stage, nothing crosses lanes -- live in the HBM workspace (`ctrl_ws`); D, W_a, W_b, the right-hand sides and the
+// reduction scratch, everything the levels of the cyclic reduction exchange between lanes, are in LDS (`smem`).  The Jacobian is read from HBM in place as for GWS = 1.
+template <int NX, int NU, int THREADS, bool ARROW, int NPC = 0, bool DENSE = false, int GWS = 0, bool RECOMP = false, class Hook = NoHook>
 __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* const st, double* smem, const int inst, const int tid, const bool j_in_lds, double* const xt_lds = nullptr, const SweepParams* const sq = nullptr,
                                             const StageKeep<NX, NU>* const keep = nullptr, const bool keep_valid = false, Hook&& after_gather = Hook{},
-                                            const int* const sc_in = nullptr, int* const smask = nullptr)
+                                            const int* const sc_in = nullptr, int* const smask = nullptr, double* const ctrl_ws = nullptr)
 {
     constexpr int S  = NX + NU;
     constexpr int NW = THREADS / 64;
@@ -1645,23 +1648,23 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
     const int N  = p.N;
     const int NP = NPC > 0 ? NPC : (N | 1);
     auto fb_barrier = [] {
-        if constexpr (GWS) __syncthreads();   // workspace in HBM: the stores of every wave are visible behind the barrier
-        else lds_barrier();
+        if constexpr (GWS == 1) __syncthreads();   // workspace in HBM: the stores of every wave are visible behind the barrier
+        else lds_barrier();                          // (GWS = 2: what crosses lanes is in LDS)
     };
     constexpr int REDN = GWS ? 8 * (THREADS / 64) : FactorLds<NX, NU>::RED;   // reduction scratch: 5 doubles per wave
     // SoA arrays, element-major: arr[e][block].  Per state block: D/L (packed lower), W_a, W_b, rhs/y/x; per stage: the
     // eliminated controls.  Slots of block k+1 double as the mailbox for what stage k contributes to it.
-    double* Luu = smem;                    // NU*NU   L_uu (diag inverted)
+    double* Luu = (GWS == 2) ? ctrl_ws : smem;   // NU*NU   L_uu (diag inverted)
     double* Zx  = Luu + NU * NU * NP;      // NU*NX   L_uu^{-1} H(u_k, x_k)
     double* Zp  = Zx + NU * NX * NP;       // NU*NX   L_uu^{-1} H(u_k, x_{k+1})
     double* yu  = Zp + NU * NX * NP;       // NU
-    double* Dm  = yu + NU * NP;            // NT      D_i (packed lower) -> L_i
+    double* Dm  = (GWS == 2) ? smem : yu + NU * NP;   // NT      D_i (packed lower) -> L_i
     double* Wam = Dm + NT * NP;            // NX*NX   W_a = L_i^{-1} H(i, i-h)   (before: mailbox for H(k, k-1))
     double* Wbm = Wam + NX * NX * NP;      // NX*NX   W_b = L_i^{-1} H(i, i+h)
     double* gv  = Wbm + NX * NX * NP;      // NX      rhs -> y -> delta x
     double* red = gv + NX * NP;            // 24
-    double* zu  = red + REDN;  // NU  (arrowhead only from here on)
-    double* bv  = zu + NU * NP;            // NX      border column -> z
+    double* zu  = (GWS == 2) ? yu + NU * NP : red + REDN;  // NU  (arrowhead only from here on; a stage's own like the other arrays of the controls)
+    double* bv  = (GWS == 2) ? red + REDN : zu + NU * NP;  // NX      border column -> z
     const int done = st->done, fresh = st->fresh, first = st->first, vbuf = st->vbuf;
     const int stop_in = st->stop;
     double mu = st->mu;
@@ -2642,16 +2645,27 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 }
 
 // long horizons: the same phases with the workspace in HBM (FactorParams::work), one lane per stage in a 1024-thread workgroup
-template <int NX, int NU, bool ARROW, bool DENSE = false>
+// HYB (round 6): the state-block arrays in LDS, only the eliminated controls' arrays in the HBM workspace (factor_body, GWS = 2) -- wherever they fit
+template <int NX, int NU, bool ARROW, bool DENSE = false, bool HYB = false>
 __global__ __launch_bounds__(1024) void factor_long_kernel(const FactorParams p)
 {
     __shared__ __attribute__((aligned(16))) LmState sl_;
+    extern __shared__ __attribute__((aligned(16))) double long_lds[];   // (HYB)
     const int inst = blockIdx.x + p.inst0;
     lm_state_in(&sl_, p.st + inst, threadIdx.x);
     __syncthreads();
-    factor_body<NX, NU, 1024, ARROW, 0, DENSE, true>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
+    if constexpr (HYB)
+        factor_body<NX, NU, 1024, ARROW, 0, DENSE, 2>(p, &sl_, long_lds, inst, threadIdx.x, false, nullptr, nullptr, nullptr, false, NoHook{}, nullptr, nullptr, p.work + (size_t)inst * p.work_stride);
+    else
+        factor_body<NX, NU, 1024, ARROW, 0, DENSE, 1>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
     __syncthreads();
     lm_state_out(p.st + inst, &sl_, threadIdx.x);
+}
+// LDS of the HYB variant: D (packed), W_a, W_b, rhs per block, the reduction scratch of sixteen waves, the border column (free dt)
+template <int NX, int NU>
+__host__ __device__ constexpr size_t factor_long_hyb_lds_doubles(int N, bool arrow)
+{
+    return (size_t)(NX * (NX + 1) / 2 + 2 * NX * NX + NX) * (N | 1) + 8 * 16 + (arrow ? (size_t)NX * (N | 1) : 0) + 2;
 }
 template <int NX, int NU>
 __host__ __device__ constexpr size_t factor_long_work_doubles(int N, bool arrow)
@@ -5630,6 +5644,17 @@ bool launch_factor_a(const FactorParams& p, hipStream_t stream)
     lds = ((lds + 15) & ~(size_t)15) + sizeof(LmState);                                      // + LM state
     if (p.N > LONG_HORIZON) {   // long horizon: workspace in HBM
         if (p.N > LONG_HORIZON_MAX || !p.work) return false;
+        const size_t hyb = sizeof(double) * factor_long_hyb_lds_doubles<NX, NU>(p.N, ARROW);
+        if (hyb + sizeof(LmState) + 64 <= (size_t)160 * 1024) {   // the state-block arrays fit the LDS of a CU: only the controls' arrays stay in the HBM workspace
+            static unsigned long long attr_set[2] = {0, 0};   // (per device)
+            auto go = [&](auto kernel, int slot) {
+                if (first_on_device(attr_set[slot])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(LmState) - 64);
+                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(1024), hyb, stream, p);
+            };
+            if (p.wdense_mask) go(factor_long_kernel<NX, NU, ARROW, true, true>, 1);
+            else go(factor_long_kernel<NX, NU, ARROW, false, true>, 0);
+            return true;
+        }
         if (p.wdense_mask) hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW, true>), dim3(p.batch), dim3(1024), 0, stream, p);   // non-diagonal weights
         else hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW>), dim3(p.batch), dim3(1024), 0, stream, p);
         return true;
