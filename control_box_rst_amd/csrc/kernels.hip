@@ -2646,8 +2646,10 @@ __device__ __forceinline__ void factor_body(const FactorParams& p, LmState* cons
 
 // long horizons: the same phases with the workspace in HBM (FactorParams::work), one lane per stage in a 1024-thread workgroup
 // HYB (round 6): the state-block arrays in LDS, only the eliminated controls' arrays in the HBM workspace (factor_body, GWS = 2) -- wherever they fit
-template <int NX, int NU, bool ARROW, bool DENSE = false, bool HYB = false>
-__global__ __launch_bounds__(1024) void factor_long_kernel(const FactorParams p)
+// THREADS / MINW: up to 512 grid points eight waves do (one lane per stage) -- with 128 VGPRs where the LDS holds TWO such workgroups per CU (up to ~ 370 grid points
+// for nx = 3: 3.77 -> 2.93 ms per solve of 1024 unicycle OCPs at N = 300), with all the registers of two waves per SIMD where it holds one (N = 512: 4.9 -> 4.7)
+template <int NX, int NU, bool ARROW, bool DENSE = false, bool HYB = false, int THREADS = 1024, int MINW = 4>
+__global__ __launch_bounds__(THREADS, MINW) void factor_long_kernel(const FactorParams p)
 {
     __shared__ __attribute__((aligned(16))) LmState sl_;
     extern __shared__ __attribute__((aligned(16))) double long_lds[];   // (HYB)
@@ -2655,9 +2657,9 @@ __global__ __launch_bounds__(1024) void factor_long_kernel(const FactorParams p)
     lm_state_in(&sl_, p.st + inst, threadIdx.x);
     __syncthreads();
     if constexpr (HYB)
-        factor_body<NX, NU, 1024, ARROW, 0, DENSE, 2>(p, &sl_, long_lds, inst, threadIdx.x, false, nullptr, nullptr, nullptr, false, NoHook{}, nullptr, nullptr, p.work + (size_t)inst * p.work_stride);
+        factor_body<NX, NU, THREADS, ARROW, 0, DENSE, 2>(p, &sl_, long_lds, inst, threadIdx.x, false, nullptr, nullptr, nullptr, false, NoHook{}, nullptr, nullptr, p.work + (size_t)inst * p.work_stride);
     else
-        factor_body<NX, NU, 1024, ARROW, 0, DENSE, 1>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
+        factor_body<NX, NU, THREADS, ARROW, 0, DENSE, 1>(p, &sl_, p.work + (size_t)inst * p.work_stride, inst, threadIdx.x, false);
     __syncthreads();
     lm_state_out(p.st + inst, &sl_, threadIdx.x);
 }
@@ -5646,13 +5648,18 @@ bool launch_factor_a(const FactorParams& p, hipStream_t stream)
         if (p.N > LONG_HORIZON_MAX || !p.work) return false;
         const size_t hyb = sizeof(double) * factor_long_hyb_lds_doubles<NX, NU>(p.N, ARROW);
         if (hyb + sizeof(LmState) + 64 <= (size_t)160 * 1024) {   // the state-block arrays fit the LDS of a CU: only the controls' arrays stay in the HBM workspace
-            static unsigned long long attr_set[2] = {0, 0};   // (per device)
-            auto go = [&](auto kernel, int slot) {
+            static unsigned long long attr_set[4] = {0, 0, 0, 0};   // (per device)
+            auto go = [&](auto kernel, int slot, int threads) {
                 if (first_on_device(attr_set[slot])) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(LmState) - 64);
-                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(1024), hyb, stream, p);
+                hipLaunchKernelGGL(kernel, dim3(p.batch), dim3(threads), hyb, stream, p);
             };
-            if (p.wdense_mask) go(factor_long_kernel<NX, NU, ARROW, true, true>, 1);
-            else go(factor_long_kernel<NX, NU, ARROW, false, true>, 0);
+            const bool two_per_cu = 2 * (hyb + sizeof(LmState) + 64) <= (size_t)160 * 1024;
+            if (p.wdense_mask) go(factor_long_kernel<NX, NU, ARROW, true, true>, 1, 1024);
+            else if (p.N <= 512 && p.pass_threads != 1024) {   // (option pass_threads = 1024: the sixteen-wave shape, A/B)
+                if (two_per_cu) go(factor_long_kernel<NX, NU, ARROW, false, true, 512, 4>, 2, 512);
+                else go(factor_long_kernel<NX, NU, ARROW, false, true, 512, 2>, 3, 512);
+            }
+            else go(factor_long_kernel<NX, NU, ARROW, false, true>, 0, 1024);
             return true;
         }
         if (p.wdense_mask) hipLaunchKernelGGL((factor_long_kernel<NX, NU, ARROW, true>), dim3(p.batch), dim3(1024), 0, stream, p);   // non-diagonal weights
